@@ -1,0 +1,93 @@
+/*
+ * ORACLE (test infrastructure, NOT product code).
+ *
+ * Counter-based RNG contract for the Euler sampling hot path.  The reference
+ * has exactly one RNG entry point, `double euler::common::ThreadLocalRandom()`
+ * (euler/common/random.h:24, random.cc:22-27), backed by a time(0)-seeded
+ * thread_local minstd engine, so it cannot be seeded.  The seam replaces that
+ * single function with the stateless mapping defined here; the HIP kernels
+ * implement the same mapping independently (euler_amd/csrc/philox.h).
+ *
+ * Contract
+ *   key  = (seed_lo, seed_hi ^ SALT[domain])
+ *   ctr  = (call_id, stream_lo, stream_hi, draw_idx >> 1)
+ *   w[4] = Philox4x32-10(ctr, key)              (Salmon et al., SC'11)
+ *   draw `d` uses the word pair (w[2*(d&1)], w[2*(d&1)+1]) = (a, b)
+ *   u    = ((a >> 5) * 2^26 + (b >> 6)) * 2^-53          in [0, 1), 53 bits
+ *
+ *   domain 0  neighbor sampling : stream = root node id, draw_idx counts the
+ *             ThreadLocalRandom() calls made inside ONE Node::SampleNeighbor
+ *   domain 1  global node sampling : stream = 0, draw_idx counts calls inside
+ *             ONE Graph::SampleNode(type(s), count)
+ *   domain 2  node2vec biased step : stream = walker index, draw 0
+ *   domain 3  SAMPLE_NODE_SPLIT remainder draws : stream = 0
+ */
+#ifndef EULER_ORACLE_EO_RNG_H_
+#define EULER_ORACLE_EO_RNG_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  EO_DOMAIN_NEIGHBOR = 0,
+  EO_DOMAIN_NODE = 1,
+  EO_DOMAIN_WALK = 2,
+  EO_DOMAIN_SPLIT = 3
+};
+
+static const uint32_t EO_DOMAIN_SALT[4] = {0x00000000u, 0x9E3779B9u,
+                                           0x7F4A7C15u, 0xF39CC060u};
+
+static inline void eo_philox4x32_10(const uint32_t ctr[4],
+                                    const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+  uint32_t k0 = key[0], k1 = key[1];
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+typedef struct {
+  uint64_t seed;
+  uint32_t call_id;
+  uint32_t domain;
+  uint64_t stream;
+  uint64_t draw_idx;
+} eo_rng_ctx;
+
+static inline double eo_words_to_unit(uint32_t a, uint32_t b) {
+  return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) *
+         (1.0 / 9007199254740992.0);
+}
+
+/* Draw number ctx->draw_idx of the stream, then advance. */
+static inline double eo_next_uniform(eo_rng_ctx* c) {
+  uint32_t ctr[4], key[2], w[4];
+  ctr[0] = c->call_id;
+  ctr[1] = (uint32_t)c->stream;
+  ctr[2] = (uint32_t)(c->stream >> 32);
+  ctr[3] = (uint32_t)(c->draw_idx >> 1);
+  key[0] = (uint32_t)c->seed;
+  key[1] = (uint32_t)(c->seed >> 32) ^ EO_DOMAIN_SALT[c->domain & 3];
+  eo_philox4x32_10(ctr, key, w);
+  int h = (int)(c->draw_idx & 1);
+  c->draw_idx++;
+  return eo_words_to_unit(w[2 * h], w[2 * h + 1]);
+}
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* EULER_ORACLE_EO_RNG_H_ */

@@ -1,0 +1,667 @@
+"""ORACLE python bindings (test infrastructure, NOT product code).
+
+ctypes wrappers over
+  * oracle/libeuler_oracle.so   - the plain-C restatement (euler_oracle.c)
+  * oracle/_ref/libeuler_ref.so - the reference sampler compiled from
+    /root/reference with the RNG seam (ref_harness.cc), when it has been built
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
+this module.  The product package (euler_amd) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "libeuler_oracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libeuler_ref.so")
+
+DOMAIN_NEIGHBOR, DOMAIN_NODE, DOMAIN_WALK, DOMAIN_SPLIT = 0, 1, 2, 3
+
+_u64p = C.POINTER(C.c_uint64)
+_i64p = C.POINTER(C.c_int64)
+_i32p = C.POINTER(C.c_int32)
+_f32p = C.POINTER(C.c_float)
+
+
+def build(ref=True):
+    """Compile the C restatement (and oracle/_ref when /root/reference exists)."""
+    subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
+    if ref:
+        subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+
+
+def _p(a, typ):
+    if a is None:
+        return None
+    return a.ctypes.data_as(typ)
+
+
+def _arr(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_SO):
+            build(ref=False)
+        _lib = C.CDLL(ORACLE_SO)
+        L = _lib
+        L.eo_graph_create.restype = C.c_void_p
+        L.eo_graph_create.argtypes = [C.c_int64, C.c_int32, _u64p, _i64p, _i32p,
+                                      _u64p, _f32p, _f32p]
+        L.eo_graph_destroy.argtypes = [C.c_void_p]
+        L.eo_graph_find_row.restype = C.c_int64
+        L.eo_graph_find_row.argtypes = [C.c_void_p, C.c_uint64]
+        L.eo_uniform_at.restype = C.c_double
+        L.eo_uniform_at.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32,
+                                    C.c_uint64, C.c_uint64]
+        L.eo_random_select.restype = C.c_int64
+        L.eo_random_select.argtypes = [_f32p, C.c_uint64, C.c_uint64, C.c_double]
+        L.eo_sample_neighbor_core.restype = C.c_int64
+        L.eo_sample_neighbor_core.argtypes = [
+            C.c_void_p, C.c_uint64, C.c_uint32, _u64p, C.c_int64, _i32p,
+            C.c_int32, C.c_int32, _i32p, _u64p, _f32p, _i32p]
+        L.eo_sample_neighbor_tf.argtypes = [
+            C.c_void_p, C.c_uint64, C.c_uint32, _i64p, C.c_int64, _i32p,
+            C.c_int32, C.c_int32, C.c_int64, _i64p, _f32p, _i32p]
+        L.eo_sample_fanout_tf.argtypes = [
+            C.c_void_p, C.c_uint64, C.c_uint32, _i64p, C.c_int64, _i32p,
+            C.c_int32, _i32p, C.c_int32, C.c_int64, C.POINTER(_i64p),
+            C.POINTER(_f32p), C.POINTER(_i32p)]
+        L.eo_get_full_neighbor.restype = C.c_int64
+        L.eo_get_full_neighbor.argtypes = [C.c_void_p, _u64p, C.c_int64, _i32p,
+                                           C.c_int32, _i32p, _u64p, _f32p, _i32p]
+        L.eo_id_unique.restype = C.c_int64
+        L.eo_id_unique.argtypes = [_u64p, C.c_int64, _u64p, _i32p]
+        L.eo_idx_gather.argtypes = [_i32p, _i32p, C.c_int64, _i32p]
+        L.eo_data_gather.restype = C.c_int64
+        L.eo_data_gather.argtypes = [C.c_void_p, C.c_int32, _i32p, _i32p,
+                                     C.c_int64, C.c_void_p]
+        L.eo_alias_init.argtypes = [_f32p, C.c_int64, _f32p, _i64p]
+        L.eo_node_sampler_create.restype = C.c_void_p
+        L.eo_node_sampler_create.argtypes = [C.c_int64, _u64p, _i32p, _f32p,
+                                             C.c_int32]
+        L.eo_node_sampler_destroy.argtypes = [C.c_void_p]
+        L.eo_sample_node.restype = C.c_int64
+        L.eo_sample_node.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, _i32p,
+                                     C.c_int32, C.c_int32, _u64p]
+        L.eo_random_walk.argtypes = [
+            C.c_void_p, C.c_uint64, C.c_uint32, _i64p, C.c_int64, _i32p,
+            C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int64, _i64p]
+        L.eo_gen_pair_count.restype = C.c_int64
+        L.eo_gen_pair_count.argtypes = [C.c_int64, C.c_int32, C.c_int32]
+        L.eo_gen_pair.argtypes = [_i64p, C.c_int64, C.c_int64, C.c_int32,
+                                  C.c_int32, _i64p]
+        for f in (L.eo_scatter_add, L.eo_scatter_max):
+            f.argtypes = [_f32p, _i32p, C.c_int64, C.c_int64, C.c_int32, _f32p]
+        L.eo_gather.argtypes = [_f32p, _i32p, C.c_int64, C.c_int64, _f32p]
+        L.eo_shard_of.restype = C.c_int32
+        L.eo_shard_of.argtypes = [C.c_uint64, C.c_int32, C.c_int32]
+        L.eo_id_split.argtypes = [_u64p, C.c_int64, C.c_int32, C.c_int32, _i64p,
+                                  _u64p, _i32p]
+        L.eo_sample_node_split.argtypes = [C.c_uint64, C.c_uint32, C.c_int32,
+                                           _f32p, C.c_int32, _i32p]
+        L.eo_build_prefix.argtypes = [C.c_int64, C.c_int32, _i64p, _f32p, _i64p,
+                                      _i32p, _f32p, _f32p]
+        L.eo_bench_fanout.restype = C.c_double
+        L.eo_bench_fanout.argtypes = [C.c_void_p, C.c_uint64, _u64p, C.c_int64,
+                                      C.c_int32, _i32p, C.c_int32, C.c_int32,
+                                      _i64p]
+        L.eo_synth_fill_table.argtypes = [C.c_void_p]
+        L.eo_synth_degree.restype = C.c_int64
+        L.eo_synth_degree.argtypes = [C.c_void_p, C.c_uint64]
+        L.eo_synth_neighbor.restype = C.c_uint64
+        L.eo_synth_neighbor.argtypes = [C.c_void_p, C.c_uint64, C.c_int64]
+        L.eo_synth_weight.restype = C.c_float
+        L.eo_synth_weight.argtypes = [C.c_void_p, C.c_uint64, C.c_int64]
+        L.eo_synth_build.restype = C.c_int64
+        L.eo_synth_build.argtypes = [C.c_void_p, C.c_int64, C.c_int64, _i64p,
+                                     _i32p, _u64p, _f32p, _f32p]
+        L.eo_philox_kat.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                    C.POINTER(C.c_uint32)]
+    return _lib
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        _ref = C.CDLL(REF_SO)
+        R = _ref
+        R.euler_ref_graph_build.argtypes = [C.c_int64, _u64p, _i32p, _f32p,
+                                            C.c_int32, C.c_int32, _i64p, _u64p,
+                                            _f32p]
+        R.euler_ref_graph_load.argtypes = [C.c_char_p]
+        R.euler_ref_num_nodes.restype = C.c_int64
+        R.euler_ref_node_order.restype = C.c_int64
+        R.euler_ref_node_order.argtypes = [_u64p]
+        R.euler_ref_node_info.argtypes = [_u64p, C.c_int64, _i32p, _f32p]
+        R.euler_ref_row_shape.argtypes = [C.c_uint64, _i32p, _i64p]
+        R.euler_ref_export_rows.restype = C.c_int64
+        R.euler_ref_export_rows.argtypes = [_u64p, C.c_int64, C.c_int32, _i64p,
+                                            _i32p, _u64p, _f32p, _f32p]
+        R.euler_ref_sample_neighbor.restype = C.c_int64
+        R.euler_ref_sample_neighbor.argtypes = [
+            C.c_uint64, C.c_uint32, _u64p, C.c_int64, _i32p, C.c_int32,
+            C.c_int32, _i32p, _u64p, _f32p, _i32p]
+        R.euler_ref_sample_node.restype = C.c_int64
+        R.euler_ref_sample_node.argtypes = [C.c_uint64, C.c_uint32, _i32p,
+                                            C.c_int32, C.c_int32, _u64p]
+        R.euler_ref_alias_size.restype = C.c_int64
+        R.euler_ref_alias_size.argtypes = [C.c_int32]
+        R.euler_ref_alias_table.argtypes = [C.c_int32, _u64p, _f32p, _f32p, _i64p,
+                                            _f32p]
+        R.euler_ref_get_full_neighbor.restype = C.c_int64
+        R.euler_ref_get_full_neighbor.argtypes = [_u64p, C.c_int64, _i32p,
+                                                  C.c_int32, _i32p, _u64p, _f32p,
+                                                  _i32p]
+        R.euler_ref_random_walk.argtypes = [
+            C.c_uint64, C.c_uint32, _i64p, C.c_int64, _i32p, C.c_int32,
+            C.c_int32, C.c_float, C.c_float, C.c_int64, _i64p]
+        R.euler_ref_bench_fanout.restype = C.c_double
+        R.euler_ref_bench_fanout.argtypes = [C.c_uint64, _u64p, C.c_int64,
+                                             C.c_int32, _i32p, C.c_int32,
+                                             C.c_int32, _i64p]
+        R.euler_ref_set_rng.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32,
+                                        C.c_uint64]
+    return _ref
+
+
+# --------------------------------------------------------------------------
+# Graph containers
+# --------------------------------------------------------------------------
+class CSR:
+    """Reference-format adjacency (node.h:49-57) concatenated over rows."""
+
+    def __init__(self, row_id, row_ptr, type_end, nbr, prefix_w, type_prefix,
+                 n_types, node_type=None, node_weight=None):
+        self.row_id = _arr(row_id, np.uint64)
+        self.row_ptr = _arr(row_ptr, np.int64)
+        self.type_end = _arr(type_end, np.int32).reshape(-1)
+        self.nbr = _arr(nbr, np.uint64)
+        self.prefix_w = _arr(prefix_w, np.float32)
+        self.type_prefix = _arr(type_prefix, np.float32).reshape(-1)
+        self.n_types = int(n_types)
+        self.n_rows = len(self.row_id)
+        self.node_type = (_arr(node_type, np.int32) if node_type is not None
+                          else np.zeros(self.n_rows, np.int32))
+        self.node_weight = (_arr(node_weight, np.float32)
+                            if node_weight is not None
+                            else np.ones(self.n_rows, np.float32))
+
+
+def csr_from_raw(row_id, seg_ptr, nbr, w, n_types, node_type=None,
+                 node_weight=None):
+    """RAW weights per (node,type) segment -> reference-format CSR via the
+    restated Node::Init running sums."""
+    row_id = _arr(row_id, np.uint64)
+    seg_ptr = _arr(seg_ptr, np.int64)
+    nbr = _arr(nbr, np.uint64)
+    w = _arr(w, np.float32)
+    n = len(row_id)
+    row_ptr = np.zeros(n + 1, np.int64)
+    type_end = np.zeros(n * n_types, np.int32)
+    prefix = np.zeros(len(w), np.float32)
+    tpre = np.zeros(n * n_types, np.float32)
+    lib().eo_build_prefix(n, n_types, _p(seg_ptr, _i64p), _p(w, _f32p),
+                          _p(row_ptr, _i64p), _p(type_end, _i32p),
+                          _p(prefix, _f32p), _p(tpre, _f32p))
+    return CSR(row_id, row_ptr, type_end, nbr, prefix, tpre, n_types,
+               node_type, node_weight)
+
+
+class OracleGraph:
+    """The C restatement bound to one CSR."""
+
+    def __init__(self, csr):
+        self.csr = csr
+        c = csr
+        self.h = lib().eo_graph_create(
+            c.n_rows, c.n_types, _p(c.row_id, _u64p), _p(c.row_ptr, _i64p),
+            _p(c.type_end, _i32p), _p(c.nbr, _u64p), _p(c.prefix_w, _f32p),
+            _p(c.type_prefix, _f32p))
+        self._sampler = None
+
+    def __del__(self):
+        try:
+            if self._sampler:
+                lib().eo_node_sampler_destroy(self._sampler)
+            lib().eo_graph_destroy(self.h)
+        except Exception:
+            pass
+
+    def sample_neighbor_core(self, seed, call_id, ids, edge_types, count):
+        ids = _arr(ids, np.uint64)
+        et = _arr(edge_types, np.int32)
+        n = len(ids)
+        idx = np.zeros((n, 2), np.int32)
+        oid = np.zeros(n * count, np.uint64)
+        ow = np.zeros(n * count, np.float32)
+        ot = np.zeros(n * count, np.int32)
+        lib().eo_sample_neighbor_core(self.h, seed, call_id, _p(ids, _u64p), n,
+                                      _p(et, _i32p), len(et), count,
+                                      _p(idx, _i32p), _p(oid, _u64p),
+                                      _p(ow, _f32p), _p(ot, _i32p))
+        return idx, oid, ow, ot
+
+    def sample_neighbor(self, seed, call_id, nodes, edge_types, count,
+                        default_node=-1):
+        nodes = _arr(nodes, np.int64)
+        et = _arr(edge_types, np.int32)
+        n = len(nodes)
+        on = np.zeros((n, count), np.int64)
+        ow = np.zeros((n, count), np.float32)
+        ot = np.zeros((n, count), np.int32)
+        lib().eo_sample_neighbor_tf(self.h, seed, call_id, _p(nodes, _i64p), n,
+                                    _p(et, _i32p), len(et), count, default_node,
+                                    _p(on, _i64p), _p(ow, _f32p), _p(ot, _i32p))
+        return on, ow, ot
+
+    def sample_fanout(self, seed, call_id, nodes, edge_types, counts,
+                      default_node=-1):
+        nodes = _arr(nodes, np.int64).reshape(-1)
+        et = _arr(edge_types, np.int32)
+        layers = len(counts)
+        et = et.reshape(layers, -1)
+        cnt = _arr(counts, np.int32)
+        n = len(nodes)
+        outs_n, outs_w, outs_t = [], [], []
+        m = n
+        for c in counts:
+            m *= c
+            outs_n.append(np.zeros(m, np.int64))
+            outs_w.append(np.zeros(m, np.float32))
+            outs_t.append(np.zeros(m, np.int32))
+        pn = (_i64p * layers)(*[_p(a, _i64p) for a in outs_n])
+        pw = (_f32p * layers)(*[_p(a, _f32p) for a in outs_w])
+        pt = (_i32p * layers)(*[_p(a, _i32p) for a in outs_t])
+        lib().eo_sample_fanout_tf(self.h, seed, call_id, _p(nodes, _i64p), n,
+                                  _p(et, _i32p), et.shape[1], _p(cnt, _i32p),
+                                  layers, default_node, pn, pw, pt)
+        return outs_n, outs_w, outs_t
+
+    def get_full_neighbor(self, ids, edge_types):
+        ids = _arr(ids, np.uint64)
+        et = _arr(edge_types, np.int32)
+        n = len(ids)
+        tot = lib().eo_get_full_neighbor(self.h, _p(ids, _u64p), n,
+                                         _p(et, _i32p), len(et), None, None,
+                                         None, None)
+        idx = np.zeros((n, 2), np.int32)
+        oid = np.zeros(tot, np.uint64)
+        ow = np.zeros(tot, np.float32)
+        ot = np.zeros(tot, np.int32)
+        lib().eo_get_full_neighbor(self.h, _p(ids, _u64p), n, _p(et, _i32p),
+                                   len(et), _p(idx, _i32p), _p(oid, _u64p),
+                                   _p(ow, _f32p), _p(ot, _i32p))
+        return idx, oid, ow, ot
+
+    def random_walk(self, seed, call_id, nodes, edge_types, walk_len, p=1.0,
+                    q=1.0, default_node=-1):
+        nodes = _arr(nodes, np.int64)
+        et = _arr(edge_types, np.int32).reshape(walk_len, -1)
+        n = len(nodes)
+        out = np.zeros((n, walk_len + 1), np.int64)
+        lib().eo_random_walk(self.h, seed, call_id, _p(nodes, _i64p), n,
+                             _p(et, _i32p), et.shape[1], walk_len, p, q,
+                             default_node, _p(out, _i64p))
+        return out
+
+    def build_node_sampler(self, order=None):
+        """order: node ids in the order the reference iterates node_map_
+        (defaults to row order)."""
+        c = self.csr
+        if order is None:
+            ids, types, weights = c.row_id, c.node_type, c.node_weight
+        else:
+            order = _arr(order, np.uint64)
+            pos = {int(v): i for i, v in enumerate(c.row_id)}
+            sel = np.array([pos[int(v)] for v in order], np.int64)
+            ids = order
+            types = _arr(c.node_type[sel], np.int32)
+            weights = _arr(c.node_weight[sel], np.float32)
+        n_types = int(types.max()) + 1 if len(types) else 1
+        if self._sampler:
+            lib().eo_node_sampler_destroy(self._sampler)
+        self._keep = (ids, types, weights)
+        self._sampler = lib().eo_node_sampler_create(
+            len(ids), _p(ids, _u64p), _p(types, _i32p), _p(weights, _f32p),
+            n_types)
+        self.n_node_types = n_types
+
+    def sample_node(self, seed, call_id, node_types, count):
+        nt = _arr(np.atleast_1d(node_types), np.int32)
+        out = np.zeros(max(count, 1), np.uint64)
+        got = lib().eo_sample_node(self._sampler, seed, call_id, _p(nt, _i32p),
+                                   len(nt), count, _p(out, _u64p))
+        return out[:max(got, 0)]
+
+    def bench_fanout(self, seed, roots, batch, iters, counts, threads):
+        roots = _arr(roots, np.uint64)
+        cnt = _arr(counts, np.int32)
+        edges = C.c_int64(0)
+        secs = lib().eo_bench_fanout(self.h, seed, _p(roots, _u64p), batch,
+                                     iters, _p(cnt, _i32p), len(cnt), threads,
+                                     C.byref(edges))
+        return secs, edges.value
+
+
+# --------------------------------------------------------------------------
+# Stateless helpers of the restatement
+# --------------------------------------------------------------------------
+def uniform_at(seed, call_id, domain, stream, draw_idx):
+    return lib().eo_uniform_at(seed, call_id, domain, stream, draw_idx)
+
+
+def philox(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().eo_philox_kat(c, k, o)
+    return list(o)
+
+
+def random_select(sum_weights, begin, end, u):
+    sw = _arr(sum_weights, np.float32)
+    return lib().eo_random_select(_p(sw, _f32p), begin, end, u)
+
+
+def id_unique(ids):
+    ids = _arr(ids, np.uint64)
+    uq = np.zeros(len(ids), np.uint64)
+    gi = np.zeros(len(ids), np.int32)
+    n = lib().eo_id_unique(_p(ids, _u64p), len(ids), _p(uq, _u64p),
+                           _p(gi, _i32p))
+    return uq[:n], gi
+
+
+def idx_gather(idx, gather_idx):
+    idx = _arr(idx, np.int32)
+    gi = _arr(gather_idx, np.int32)
+    out = np.zeros((len(gi), 2), np.int32)
+    lib().eo_idx_gather(_p(idx, _i32p), _p(gi, _i32p), len(gi), _p(out, _i32p))
+    return out
+
+
+def data_gather(data, idx, gather_idx):
+    data = np.ascontiguousarray(data)
+    idx = _arr(idx, np.int32)
+    gi = _arr(gather_idx, np.int32)
+    tot = lib().eo_data_gather(data.ctypes.data, data.itemsize, _p(idx, _i32p),
+                               _p(gi, _i32p), len(gi), None)
+    out = np.zeros(tot, data.dtype)
+    lib().eo_data_gather(data.ctypes.data, data.itemsize, _p(idx, _i32p),
+                         _p(gi, _i32p), len(gi), out.ctypes.data)
+    return out
+
+
+def alias_init(weights):
+    w = _arr(weights, np.float32)
+    prob = np.zeros(len(w), np.float32)
+    alias = np.zeros(len(w), np.int64)
+    lib().eo_alias_init(_p(w, _f32p), len(w), _p(prob, _f32p), _p(alias, _i64p))
+    return prob, alias
+
+
+def gen_pair(paths, left, right):
+    paths = _arr(paths, np.int64)
+    b, l = paths.shape
+    pc = lib().eo_gen_pair_count(l, left, right)
+    out = np.zeros((b, pc, 2), np.int64)
+    lib().eo_gen_pair(_p(paths, _i64p), b, l, left, right, _p(out, _i64p))
+    return out
+
+
+def scatter_add(updates, indices, size):
+    u = _arr(updates, np.float32)
+    i = _arr(indices, np.int32)
+    out = np.zeros((size, u.shape[1]), np.float32)
+    lib().eo_scatter_add(_p(u, _f32p), _p(i, _i32p), u.shape[0], u.shape[1],
+                         size, _p(out, _f32p))
+    return out
+
+
+def scatter_max(updates, indices, size):
+    u = _arr(updates, np.float32)
+    i = _arr(indices, np.int32)
+    out = np.zeros((size, u.shape[1]), np.float32)
+    lib().eo_scatter_max(_p(u, _f32p), _p(i, _i32p), u.shape[0], u.shape[1],
+                         size, _p(out, _f32p))
+    return out
+
+
+def gather(params, indices):
+    p = _arr(params, np.float32)
+    i = _arr(indices, np.int32)
+    out = np.zeros((len(i), p.shape[1]), np.float32)
+    lib().eo_gather(_p(p, _f32p), _p(i, _i32p), len(i), p.shape[1],
+                    _p(out, _f32p))
+    return out
+
+
+def scatter_mean(updates, indices, size):
+    """mp_ops.py:65-69: add / (count + 1e-7), all fp32."""
+    u = _arr(updates, np.float32)
+    out = scatter_add(u, indices, size)
+    cnt = scatter_add(np.ones((u.shape[0], 1), np.float32), indices, size)
+    return out / (cnt + np.float32(1e-7))
+
+
+def scatter_softmax(updates, indices, size):
+    """mp_ops.py:76-79."""
+    u = _arr(updates, np.float32)
+    u = u - gather(scatter_max(u, indices, size), indices)
+    u = np.exp(u)
+    return u / gather(scatter_add(u, indices, size), indices)
+
+
+def shard_of(ids, partitions, shards):
+    ids = _arr(ids, np.uint64)
+    return ((ids % np.uint64(partitions)) % np.uint64(shards)).astype(np.int32)
+
+
+def id_split(ids, partitions, shards):
+    ids = _arr(ids, np.uint64)
+    off = np.zeros(shards + 1, np.int64)
+    sid = np.zeros(len(ids), np.uint64)
+    mi = np.zeros(len(ids), np.int32)
+    lib().eo_id_split(_p(ids, _u64p), len(ids), partitions, shards,
+                      _p(off, _i64p), _p(sid, _u64p), _p(mi, _i32p))
+    return off, sid, mi
+
+
+def sample_node_split(seed, call_id, count, shard_weight):
+    sw = _arr(shard_weight, np.float32)
+    shards = len(sw) - 1
+    out = np.zeros(shards, np.int32)
+    lib().eo_sample_node_split(seed, call_id, count, _p(sw, _f32p), shards,
+                               _p(out, _i32p))
+    return out
+
+
+# --------------------------------------------------------------------------
+# Synthetic graph (eo_synth.c)
+# --------------------------------------------------------------------------
+class SynthParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("n_nodes", C.c_int64),
+                ("n_edges_target", C.c_int64), ("scale", C.c_int32),
+                ("n_types", C.c_int32), ("weighted", C.c_int32),
+                ("pad", C.c_int32), ("deg_table", C.c_double * 64)]
+
+
+def synth_params(seed, n_nodes, n_edges, n_types=1, weighted=True, scale=None):
+    p = SynthParams()
+    p.seed = seed
+    p.n_nodes = n_nodes
+    p.n_edges_target = n_edges
+    if scale is None:
+        scale = max(1, int(np.ceil(np.log2(max(n_nodes, 2)))))
+    p.scale = scale
+    p.n_types = n_types
+    p.weighted = 1 if weighted else 0
+    lib().eo_synth_fill_table(C.byref(p))
+    return p
+
+
+def synth_csr(p, row_begin=0, row_end=None):
+    """Rows [row_begin,row_end) of the synthetic graph as a CSR (ids row+1)."""
+    if row_end is None:
+        row_end = p.n_nodes
+    n = row_end - row_begin
+    tot = lib().eo_synth_build(C.byref(p), row_begin, row_end, None, None, None,
+                               None, None)
+    row_ptr = np.zeros(n + 1, np.int64)
+    type_end = np.zeros(n * p.n_types, np.int32)
+    nbr = np.zeros(tot, np.uint64)
+    prefix = np.zeros(tot, np.float32)
+    tpre = np.zeros(n * p.n_types, np.float32)
+    lib().eo_synth_build(C.byref(p), row_begin, row_end, _p(row_ptr, _i64p),
+                         _p(type_end, _i32p), _p(nbr, _u64p), _p(prefix, _f32p),
+                         _p(tpre, _f32p))
+    row_id = np.arange(row_begin + 1, row_end + 1, dtype=np.uint64)
+    return CSR(row_id, row_ptr, type_end, nbr, prefix, tpre, p.n_types)
+
+
+# --------------------------------------------------------------------------
+# Reference library (oracle/_ref)
+# --------------------------------------------------------------------------
+class RefGraph:
+    """The REFERENCE graph singleton, loaded through the harness."""
+
+    @staticmethod
+    def build_raw(row_id, seg_ptr, nbr, w, n_types, node_type=None,
+                  node_weight=None):
+        row_id = _arr(row_id, np.uint64)
+        n = len(row_id)
+        nt = (_arr(node_type, np.int32) if node_type is not None
+              else np.zeros(n, np.int32))
+        nw = (_arr(node_weight, np.float32) if node_weight is not None
+              else np.ones(n, np.float32))
+        seg_ptr = _arr(seg_ptr, np.int64)
+        nbr = _arr(nbr, np.uint64)
+        w = _arr(w, np.float32)
+        n_node_types = int(nt.max()) + 1 if n else 1
+        rc = ref().euler_ref_graph_build(n, _p(row_id, _u64p), _p(nt, _i32p),
+                                         _p(nw, _f32p), n_types, n_node_types,
+                                         _p(seg_ptr, _i64p), _p(nbr, _u64p),
+                                         _p(w, _f32p))
+        assert rc == 0
+        return RefGraph(n_types)
+
+    @staticmethod
+    def load(path, n_types):
+        rc = ref().euler_ref_graph_load(path.encode())
+        assert rc == 0
+        return RefGraph(n_types)
+
+    def __init__(self, n_types):
+        self.n_types = n_types
+
+    def node_order(self):
+        n = ref().euler_ref_num_nodes()
+        out = np.zeros(n, np.uint64)
+        ref().euler_ref_node_order(_p(out, _u64p))
+        return out
+
+    def export_csr(self, ids=None):
+        if ids is None:
+            ids = np.sort(self.node_order())
+        ids = _arr(ids, np.uint64)
+        n = len(ids)
+        T = self.n_types
+        tot = ref().euler_ref_export_rows(_p(ids, _u64p), n, T, None, None, None,
+                                          None, None)
+        assert tot >= 0, tot
+        row_ptr = np.zeros(n + 1, np.int64)
+        type_end = np.zeros(n * T, np.int32)
+        nbr = np.zeros(tot, np.uint64)
+        prefix = np.zeros(tot, np.float32)
+        tpre = np.zeros(n * T, np.float32)
+        rc = ref().euler_ref_export_rows(_p(ids, _u64p), n, T, _p(row_ptr, _i64p),
+                                         _p(type_end, _i32p), _p(nbr, _u64p),
+                                         _p(prefix, _f32p), _p(tpre, _f32p))
+        assert rc >= 0, rc
+        ntype = np.zeros(n, np.int32)
+        nweight = np.zeros(n, np.float32)
+        ref().euler_ref_node_info(_p(ids, _u64p), n, _p(ntype, _i32p),
+                                  _p(nweight, _f32p))
+        return CSR(ids, row_ptr, type_end, nbr, prefix, tpre, T, ntype, nweight)
+
+    def sample_neighbor_core(self, seed, call_id, ids, edge_types, count):
+        ids = _arr(ids, np.uint64)
+        et = _arr(edge_types, np.int32)
+        n = len(ids)
+        idx = np.zeros((n, 2), np.int32)
+        oid = np.zeros(n * count, np.uint64)
+        ow = np.zeros(n * count, np.float32)
+        ot = np.zeros(n * count, np.int32)
+        ref().euler_ref_sample_neighbor(seed, call_id, _p(ids, _u64p), n,
+                                        _p(et, _i32p), len(et), count,
+                                        _p(idx, _i32p), _p(oid, _u64p),
+                                        _p(ow, _f32p), _p(ot, _i32p))
+        return idx, oid, ow, ot
+
+    def sample_node(self, seed, call_id, node_types, count):
+        nt = _arr(np.atleast_1d(node_types), np.int32)
+        out = np.zeros(max(count, 1), np.uint64)
+        got = ref().euler_ref_sample_node(seed, call_id, _p(nt, _i32p), len(nt),
+                                          count, _p(out, _u64p))
+        return out[:got]
+
+    def alias_table(self, node_type):
+        n = ref().euler_ref_alias_size(node_type)
+        ids = np.zeros(n, np.uint64)
+        w = np.zeros(n, np.float32)
+        prob = np.zeros(n, np.float32)
+        alias = np.zeros(n, np.int64)
+        s = C.c_float(0)
+        ref().euler_ref_alias_table(node_type, _p(ids, _u64p), _p(w, _f32p),
+                                    _p(prob, _f32p), _p(alias, _i64p),
+                                    C.byref(s))
+        return ids, w, prob, alias, s.value
+
+    def get_full_neighbor(self, ids, edge_types):
+        ids = _arr(ids, np.uint64)
+        et = _arr(edge_types, np.int32)
+        n = len(ids)
+        tot = ref().euler_ref_get_full_neighbor(_p(ids, _u64p), n, _p(et, _i32p),
+                                                len(et), None, None, None, None)
+        idx = np.zeros((n, 2), np.int32)
+        oid = np.zeros(tot, np.uint64)
+        ow = np.zeros(tot, np.float32)
+        ot = np.zeros(tot, np.int32)
+        ref().euler_ref_get_full_neighbor(_p(ids, _u64p), n, _p(et, _i32p),
+                                          len(et), _p(idx, _i32p),
+                                          _p(oid, _u64p), _p(ow, _f32p),
+                                          _p(ot, _i32p))
+        return idx, oid, ow, ot
+
+    def random_walk(self, seed, call_id, nodes, edge_types, walk_len, p=1.0,
+                    q=1.0, default_node=-1):
+        nodes = _arr(nodes, np.int64)
+        et = _arr(edge_types, np.int32).reshape(walk_len, -1)
+        out = np.zeros((len(nodes), walk_len + 1), np.int64)
+        ref().euler_ref_random_walk(seed, call_id, _p(nodes, _i64p), len(nodes),
+                                    _p(et, _i32p), et.shape[1], walk_len, p, q,
+                                    default_node, _p(out, _i64p))
+        return out
+
+    def bench_fanout(self, seed, roots, batch, iters, counts, threads):
+        roots = _arr(roots, np.uint64)
+        cnt = _arr(counts, np.int32)
+        edges = C.c_int64(0)
+        secs = ref().euler_ref_bench_fanout(seed, _p(roots, _u64p), batch, iters,
+                                            _p(cnt, _i32p), len(cnt), threads,
+                                            C.byref(edges))
+        return secs, edges.value

@@ -1,0 +1,432 @@
+// ORACLE (test infrastructure, NOT product code).
+//
+// C-ABI harness around the REFERENCE sampler, compiled unmodified from
+// /root/reference by oracle/Makefile into oracle/_ref/libeuler_ref.so.  The
+// only reference file replaced is euler/common/random.cc (see
+// ref_seam_random.cc).  Compiled with -fno-access-control so that the harness
+// can read the reference's private storage (Node::neighbor_info_,
+// Graph::node_map_, AliasMethod::prob_/alias_) without touching its sources.
+//
+// What is REFERENCE code here : Node::Init / Node::SampleNeighbor /
+//   Node::GetFullNeighbor (core/graph/node.cc), Graph::SampleNode /
+//   BuildGlobalSampler / Graph::Init + GraphBuilder (core/graph/graph.cc,
+//   graph_builder.cc), CompactWeightedCollection, AliasMethod,
+//   FastWeightedCollection (euler/common).
+// What is RESTATED here (their sources need protobuf / TensorFlow and cannot
+//   be compiled): the batch loop of api.cc:223-236 (so the RNG context can be
+//   set per root), the empty-row fill of core/kernels/sample_neighbor_op.cc:
+//   134-143, FillNeighbor (core/kernels/common.cc:275-334) and the TF
+//   RandomWalk kernel (tf_euler/kernels/random_walk_op.cc:83-168,207-247).
+#include <stdint.h>
+#include <string.h>
+
+#include <chrono>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "euler/common/compact_weighted_collection.h"
+#include "euler/common/data_types.h"
+#include "euler/common/server_register.h"
+#include "euler/core/api/api.h"
+#include "euler/core/graph/graph.h"
+#include "euler/core/graph/node.h"
+
+#include "eo_rng.h"
+
+extern "C" void euler_ref_set_rng(uint64_t seed, uint32_t call_id,
+                                  uint32_t domain, uint64_t stream);
+
+namespace euler {
+// graph.cc references the ZooKeeper register only in Deregister paths; the
+// zk sources are not part of the hot path and are not linked.
+std::shared_ptr<ServerRegister> GetServerRegister(const std::string&,
+                                                  const std::string&) {
+  return nullptr;
+}
+}  // namespace euler
+
+namespace {
+
+euler::Graph& G() { return euler::Graph::Instance(); }
+
+void SetTypeMaps(int n_node_types, int n_edge_types) {
+  auto& meta = G().meta_;
+  meta.node_type_map_.clear();
+  meta.edge_type_map_.clear();
+  for (int i = 0; i < n_node_types; ++i)
+    meta.node_type_map_[std::to_string(i)] = i;
+  for (int i = 0; i < n_edge_types; ++i)
+    meta.edge_type_map_[std::to_string(i)] = i;
+  meta.partitions_num_ = 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int euler_ref_graph_clear() {
+  auto& g = G();
+  for (auto& kv : g.node_map_) delete kv.second;
+  g.node_map_.clear();
+  g.node_samplers_.clear();
+  g.node_weight_sums_.clear();
+  g.node_type_collection_ = euler::common::FastWeightedCollection<int32_t>();
+  g.global_sampler_ok_ = false;
+  g.initialized_ = false;
+  return 0;
+}
+
+// Typed adjacency in (node, type)-major CSR: segment (i, t) is
+// [seg_ptr[i*T+t], seg_ptr[i*T+t+1]) of nbr/w (RAW weights).  Prefix sums are
+// produced by the reference's own Node::Init (node.cc:37-96).
+int euler_ref_graph_build(int64_t n, const uint64_t* ids,
+                          const int32_t* node_type, const float* node_weight,
+                          int32_t T, int32_t n_node_types,
+                          const int64_t* seg_ptr, const uint64_t* nbr,
+                          const float* w) {
+  euler_ref_graph_clear();
+  auto& g = G();
+  g.reserveNodeMap(n);
+  std::vector<std::vector<uint64_t>> nb(T);
+  std::vector<std::vector<float>> nw(T);
+  std::vector<std::vector<uint64_t>> f_u64;
+  std::vector<std::vector<float>> f_f32;
+  std::vector<std::string> f_bin;
+  for (int64_t i = 0; i < n; ++i) {
+    for (int t = 0; t < T; ++t) {
+      int64_t b = seg_ptr[i * T + t], e = seg_ptr[i * T + t + 1];
+      nb[t].assign(nbr + b, nbr + e);
+      nw[t].assign(w + b, w + e);
+    }
+    auto* node = new euler::Node(ids[i], node_weight[i], node_type[i]);
+    if (!node->Init(nb, nw, f_u64, f_f32, f_bin)) return -1;
+    g.AddNode(node);
+  }
+  SetTypeMaps(n_node_types, T);
+  g.BuildGlobalSampler();
+  return 0;
+}
+
+// Load a directory of .dat partitions written by the reference's own
+// euler/tools (Graph::Init, graph.cc:72-120, local mode = shard 0 of 1).
+int euler_ref_graph_load(const char* dir) {
+  euler_ref_graph_clear();
+  auto s = G().Init(0, 1, "node", dir, "node");
+  return s.ok() ? 0 : -1;
+}
+
+int64_t euler_ref_num_nodes() { return (int64_t)G().node_map_.size(); }
+
+int32_t euler_ref_num_node_types() {
+  return (int32_t)G().meta_.node_type_map_.size();
+}
+
+// node_map_ iteration order (graph.cc:349 builds the alias tables in it, Q7).
+int64_t euler_ref_node_order(uint64_t* ids_out) {
+  int64_t k = 0;
+  for (auto& kv : G().node_map_) ids_out[k++] = kv.first;
+  return k;
+}
+
+int euler_ref_node_info(const uint64_t* ids, int64_t n, int32_t* type,
+                        float* weight) {
+  for (int64_t i = 0; i < n; ++i) {
+    auto* node = G().GetNodeByID(ids[i]);
+    type[i] = node ? node->GetType() : -1;
+    weight[i] = node ? node->GetWeight() : 0.f;
+  }
+  return 0;
+}
+
+// Number of edge-type groups of a node (-1 if unknown) and its out degree.
+int euler_ref_row_shape(uint64_t id, int32_t* n_groups, int64_t* degree) {
+  auto* node = G().GetNodeByID(id);
+  if (!node) { *n_groups = -1; *degree = 0; return -1; }
+  *n_groups = (int32_t)node->neighbor_info_.neighbor_groups_idx.size();
+  *degree = (int64_t)node->neighbor_info_.neighbors.size();
+  return 0;
+}
+
+// Export the reference's stored adjacency (node.h:49-57) verbatim for the
+// listed ids: row_ptr[n+1], type_end[n*T] (cumulative, row-relative),
+// nbr[E], prefix_w[E] (running float sums ACROSS types), type_prefix[n*T]
+// (edge_group_collection running sums).  Unknown ids export an empty row.
+int64_t euler_ref_export_rows(const uint64_t* ids, int64_t n, int32_t T,
+                              int64_t* row_ptr, int32_t* type_end,
+                              uint64_t* nbr, float* prefix_w,
+                              float* type_prefix) {
+  int64_t off = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    if (row_ptr) row_ptr[i] = off;
+    auto* node = G().GetNodeByID(ids[i]);
+    if (!node) {
+      if (type_end) for (int t = 0; t < T; ++t) {
+        type_end[i * T + t] = 0; type_prefix[i * T + t] = 0.f;
+      }
+      continue;
+    }
+    const auto& ni = node->neighbor_info_;
+    if ((int32_t)ni.neighbor_groups_idx.size() != T) return -2;
+    if (type_end) {
+      for (int t = 0; t < T; ++t) {
+        type_end[i * T + t] = ni.neighbor_groups_idx[t];
+        type_prefix[i * T + t] = ni.edge_group_collection.sum_weights_[t];
+        if (ni.edge_group_collection.ids_[t] != t) return -3;
+      }
+      memcpy(nbr + off, ni.neighbors.data(), ni.neighbors.size() * 8);
+      memcpy(prefix_w + off, ni.neighbors_weight.data(),
+             ni.neighbors_weight.size() * 4);
+    }
+    off += (int64_t)ni.neighbors.size();
+  }
+  if (row_ptr) row_ptr[n] = off;
+  return off;
+}
+
+// API_SAMPLE_NB core result (GQL layout): idx[n,2], ids/w/t[n*count].
+// Loop = api.cc:223-236 with the RNG stream set per root; empty rows filled
+// with count x (0, 0.0, 0) (sample_neighbor_op.cc:134-143); flattened as
+// FillNeighbor does (common.cc:275-334).  Returns total element count.
+int64_t euler_ref_sample_neighbor(uint64_t seed, uint32_t call_id,
+                                  const uint64_t* ids, int64_t n,
+                                  const int32_t* edge_types, int32_t k,
+                                  int32_t count, int32_t* idx,
+                                  uint64_t* out_id, float* out_w,
+                                  int32_t* out_t) {
+  std::vector<int32_t> et(edge_types, edge_types + k);
+  int64_t off = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    std::vector<euler::common::IDWeightPair> res;
+    auto* node = G().GetNodeByID(ids[i]);
+    if (node != nullptr) {
+      euler_ref_set_rng(seed, call_id, EO_DOMAIN_NEIGHBOR, ids[i]);
+      res = node->SampleNeighbor(et, count);
+    }
+    if (res.empty()) {
+      for (int32_t j = 0; j < count; ++j)
+        res.push_back(euler::common::IDWeightPair(
+            euler::common::DEFAULT_UINT64, 0, 0));
+    }
+    idx[2 * i] = (int32_t)off;
+    idx[2 * i + 1] = (int32_t)(off + res.size());
+    for (auto& iw : res) {
+      out_id[off] = std::get<0>(iw);
+      out_w[off] = std::get<1>(iw);
+      out_t[off] = std::get<2>(iw);
+      ++off;
+    }
+  }
+  return off;
+}
+
+// API_SAMPLE_NODE core path without conditions: euler::SampleNode
+// (api.cc:32-37 -> graph.cc:221-275).  Returns the number of ids produced
+// (0 when the type weight sum is 0; the op then logs and emits nothing,
+// sample_node_op.cc:118-122).
+int64_t euler_ref_sample_node(uint64_t seed, uint32_t call_id,
+                              const int32_t* node_types, int32_t k,
+                              int32_t count, uint64_t* out) {
+  std::vector<int> types(node_types, node_types + k);
+  euler_ref_set_rng(seed, call_id, EO_DOMAIN_NODE, 0);
+  auto vec = euler::SampleNode(types, count);
+  for (size_t i = 0; i < vec.size(); ++i) out[i] = vec[i];
+  return (int64_t)vec.size();
+}
+
+int64_t euler_ref_alias_size(int32_t type) {
+  auto& g = G();
+  if (type < 0) return (int64_t)g.node_type_collection_.ids_.size();
+  if (type >= (int32_t)g.node_samplers_.size()) return -1;
+  return (int64_t)g.node_samplers_[type].ids_.size();
+}
+
+// Export an alias table built by the reference (type < 0: the node-type
+// collection; ids are then the type ids).
+int euler_ref_alias_table(int32_t type, uint64_t* ids, float* weights,
+                          float* prob, int64_t* alias, float* sum_weight) {
+  auto& g = G();
+  if (type < 0) {
+    auto& c = g.node_type_collection_;
+    for (size_t i = 0; i < c.ids_.size(); ++i) {
+      ids[i] = (uint64_t)c.ids_[i];
+      weights[i] = c.weights_[i];
+      prob[i] = c.alias_.prob_[i];
+      alias[i] = c.alias_.alias_[i];
+    }
+    *sum_weight = c.sum_weight_;
+    return 0;
+  }
+  auto& c = g.node_samplers_[type];
+  for (size_t i = 0; i < c.ids_.size(); ++i) {
+    ids[i] = c.ids_[i];
+    weights[i] = c.weights_[i];
+    prob[i] = c.alias_.prob_[i];
+    alias[i] = c.alias_.alias_[i];
+  }
+  *sum_weight = c.sum_weight_;
+  return 0;
+}
+
+// euler::GetFullNeighbor (api.cc:208-221) flattened like FillNeighbor.
+// Pass out_id == NULL to size the result.
+int64_t euler_ref_get_full_neighbor(const uint64_t* ids, int64_t n,
+                                    const int32_t* edge_types, int32_t k,
+                                    int32_t* idx, uint64_t* out_id,
+                                    float* out_w, int32_t* out_t) {
+  std::vector<uint64_t> v(ids, ids + n);
+  std::vector<int> et(edge_types, edge_types + k);
+  auto res = euler::GetFullNeighbor(v, et);
+  int64_t off = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    if (idx) { idx[2 * i] = (int32_t)off; }
+    for (auto& iw : res[i]) {
+      if (out_id) {
+        out_id[off] = std::get<0>(iw);
+        out_w[off] = std::get<1>(iw);
+        out_t[off] = std::get<2>(iw);
+      }
+      ++off;
+    }
+    if (idx) { idx[2 * i + 1] = (int32_t)off; }
+  }
+  return off;
+}
+
+// TF RandomWalk (tf_euler/kernels/random_walk_op.cc).  edge_types is
+// [walk_len, k].  |p-1|,|q-1| <= 1e-6 -> TraditionalRandomWalk (:207-247): a
+// chain of count=1 sampleNB hops on the CORE id tensor (sentinel 0 rows walk
+// on from node id 0), output 0 -> default_node.  Otherwise node2vec
+// (RWCallback :83-168) with the reference CompactWeightedCollection.
+int euler_ref_random_walk(uint64_t seed, uint32_t call_id,
+                          const int64_t* nodes, int64_t n,
+                          const int32_t* edge_types, int32_t k,
+                          int32_t walk_len, float p, float q,
+                          int64_t default_node, int64_t* out) {
+  const int64_t L = walk_len + 1;
+  for (int64_t i = 0; i < n; ++i) out[i * L] = nodes[i];
+  const float kEps = 1.0e-6;
+  if (fabs(p - 1.0) <= kEps && fabs(q - 1.0) <= kEps) {
+    for (int64_t i = 0; i < n; ++i) {
+      uint64_t cur = (uint64_t)nodes[i];
+      for (int32_t s = 0; s < walk_len; ++s) {
+        std::vector<int32_t> et(edge_types + s * k, edge_types + (s + 1) * k);
+        std::vector<euler::common::IDWeightPair> res;
+        auto* node = G().GetNodeByID(cur);
+        if (node != nullptr) {
+          euler_ref_set_rng(seed, call_id + s, EO_DOMAIN_NEIGHBOR, cur);
+          res = node->SampleNeighbor(et, 1);
+        }
+        uint64_t nb = res.empty() ? euler::common::DEFAULT_UINT64
+                                  : std::get<0>(res[0]);
+        out[i * L + s + 1] = nb == euler::common::DEFAULT_UINT64
+                                 ? (int64_t)(uint64_t)default_node
+                                 : (int64_t)nb;
+        cur = nb;
+      }
+    }
+    return 0;
+  }
+  std::vector<std::vector<int64_t>> parent_neighbors(n);
+  std::vector<int64_t> parent_ids(nodes, nodes + n);
+  std::vector<int64_t> cur(nodes, nodes + n);
+  for (int32_t s = 0; s < walk_len; ++s) {
+    std::vector<int> et(edge_types + s * k, edge_types + (s + 1) * k);
+    std::vector<uint64_t> cur_u(cur.begin(), cur.end());
+    auto full = euler::GetFullNeighbor(cur_u, et);
+    std::vector<std::vector<int64_t>> neighbors(n);
+    std::vector<int64_t> next(n);
+    for (int64_t i = 0; i < n; ++i) {
+      std::vector<float> w;
+      for (auto& iw : full[i]) {
+        neighbors[i].push_back((int64_t)std::get<0>(iw));
+        w.push_back(std::get<1>(iw));
+      }
+      auto& cn = neighbors[i];
+      int64_t sample_id = default_node;
+      if (!cn.empty()) {
+        auto parent_id = parent_ids[i];
+        auto& pn = parent_neighbors[i];
+        // BuildWeights (:140-168)
+        size_t j = 0, kk = 0;
+        while (j < cn.size() && kk < pn.size()) {
+          if (cn[j] < pn[kk]) {
+            if (cn[j] != parent_id) w[j] /= q; else w[j] /= p;
+            ++j;
+          } else if (cn[j] == pn[kk]) {
+            ++kk; ++j;
+          } else {
+            ++kk;
+          }
+        }
+        while (j < cn.size()) {
+          if (cn[j] != parent_id) w[j] /= q; else w[j] /= p;
+          ++j;
+        }
+        euler::common::CompactWeightedCollection<int64_t> sampler;
+        sampler.Init(cn, w);
+        euler_ref_set_rng(seed, call_id + s, EO_DOMAIN_WALK, (uint64_t)i);
+        sample_id = sampler.Sample().first;
+      }
+      out[i * L + s + 1] = sample_id;
+      next[i] = sample_id;
+    }
+    parent_neighbors = neighbors;
+    parent_ids = cur;
+    cur = next;
+  }
+  return 0;
+}
+
+// CPU baseline timing: `iters` minibatches of 2-hop (or L-hop) fanout through
+// the reference Node::SampleNeighbor, batch loop as api.cc:223-236, split over
+// `threads` query threads (the reference client pool has 8,
+// client/query_proxy.cc:205-210).  Roots of hop h+1 are the ids sampled at hop
+// h.  Returns seconds; *edges receives the number of sampled edges.
+double euler_ref_bench_fanout(uint64_t seed, const uint64_t* roots,
+                              int64_t batch, int32_t iters,
+                              const int32_t* counts, int32_t hops,
+                              int32_t threads, int64_t* edges) {
+  std::vector<int64_t> per_thread(threads, 0);
+  auto t0 = std::chrono::steady_clock::now();
+  auto work = [&](int tid) {
+    std::vector<int32_t> et(1, 0);
+    int64_t produced = 0;
+    for (int32_t it = tid; it < iters; it += threads) {
+      std::vector<uint64_t> frontier(roots + (int64_t)it * batch,
+                                     roots + (int64_t)(it + 1) * batch);
+      for (int32_t h = 0; h < hops; ++h) {
+        std::vector<uint64_t> next;
+        next.reserve(frontier.size() * counts[h]);
+        for (size_t i = 0; i < frontier.size(); ++i) {
+          auto* node = G().GetNodeByID(frontier[i]);
+          std::vector<euler::common::IDWeightPair> res;
+          if (node != nullptr) {
+            euler_ref_set_rng(seed, (uint32_t)(it * hops + h),
+                              EO_DOMAIN_NEIGHBOR, frontier[i]);
+            res = node->SampleNeighbor(et, counts[h]);
+          }
+          if (res.empty()) {
+            next.insert(next.end(), counts[h], 0);
+          } else {
+            for (auto& iw : res) next.push_back(std::get<0>(iw));
+          }
+        }
+        produced += (int64_t)next.size();
+        frontier.swap(next);
+      }
+    }
+    per_thread[tid] = produced;
+  };
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; ++t) pool.emplace_back(work, t);
+  for (auto& th : pool) th.join();
+  auto t1 = std::chrono::steady_clock::now();
+  int64_t total = 0;
+  for (auto v : per_thread) total += v;
+  *edges = total;
+  return std::chrono::duration<double>(t1 - t0).count();
+}
+
+}  // extern "C"

@@ -1,0 +1,78 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def O():
+    """The oracle bindings (builds oracle/libeuler_oracle.so on first use)."""
+    from oracle import oracle
+    oracle.lib()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def ref_available(O):
+    return O.have_ref()
+
+
+def load_csr(O, path):
+    g = np.load(path)
+    return O.CSR(g["row_id"], g["row_ptr"], g["type_end"], g["nbr"],
+                 g["prefix_w"], g["type_prefix"], int(g["n_types"]),
+                 g["node_type"], g["node_weight"])
+
+
+@pytest.fixture(scope="session")
+def fixture_csr(O):
+    return load_csr(O, os.path.join(GOLDEN, "fixture_graph.npz"))
+
+
+@pytest.fixture(scope="session")
+def random_csr(O):
+    return load_csr(O, os.path.join(GOLDEN, "random_graph.npz"))
+
+
+@pytest.fixture(scope="session")
+def fixture_samples():
+    return np.load(os.path.join(GOLDEN, "fixture_samples.npz"))
+
+
+@pytest.fixture(scope="session")
+def random_samples():
+    return np.load(os.path.join(GOLDEN, "random_graph.npz"))
+
+
+@pytest.fixture(scope="session")
+def ref_tests():
+    return np.load(os.path.join(GOLDEN, "ref_tests.npz"))
+
+
+def make_random_graph(rng, n, T, max_deg=12, id_space=None, zero_frac=0.1,
+                      empty_frac=0.3):
+    """Raw heterogeneous adjacency: (ids, seg_ptr, nbr, w, node_type, node_w)."""
+    id_space = id_space or 10 * n
+    ids = np.sort(rng.choice(np.arange(1, id_space), n, replace=False)).astype(np.uint64)
+    deg = rng.integers(0, max_deg, size=(n, T))
+    deg[rng.random((n, T)) < empty_frac] = 0
+    seg = np.zeros(n * T + 1, np.int64)
+    seg[1:] = np.cumsum(deg.reshape(-1))
+    E = int(seg[-1])
+    nbr = rng.choice(ids, E).astype(np.uint64)
+    w = (rng.random(E) * 7.5 + 0.5).astype(np.float32)
+    w[rng.random(E) < zero_frac] = 0
+    nt = rng.integers(0, 2, n).astype(np.int32)
+    nw = (rng.random(n) * 3 + 0.1).astype(np.float32)
+    return ids, seg, nbr, w, nt, nw

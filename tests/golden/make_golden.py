@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors under tests/golden/.
+
+Runs ONLY where /root/reference exists (the build container); the GPU box and
+the CPU test-suite consume the committed .npz files.  Everything written here
+comes out of REFERENCE code:
+
+  fixture_graph.npz   the reference's 6-node test graph
+                      (tools/test_data/graph.json) converted by the reference's
+                      own euler/tools (json2partdat) to .dat partitions, loaded
+                      by the reference's own GraphBuilder/Node::DeSerialize
+                      (through oracle/_ref) and exported from its Node storage.
+  fixture_samples.npz sampled ids / weights / types, SampleNode ids, random
+                      walks and full neighbors produced by the reference
+                      sampler (oracle/_ref = reference sources + RNG seam) on
+                      that fixture for fixed (seed, call_id).
+  random_graph.npz    a 300-node heterogeneous random graph (raw adjacency) +
+                      the same kinds of reference outputs.
+  ref_tests.npz       exact expectations copied from the reference's own tests
+                      (mp_ops_test.py:30-86, walk_ops_test.py:49-58,
+                      unique_gather_test.cc:28-160, neighbor_ops_test.py:46-75).
+"""
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O  # noqa: E402
+
+REF = os.environ.get("EULER_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+SEED = 20240521
+
+
+def convert_fixture(scratch):
+    """graph.json -> .dat with the reference's python tools (py3-compatible
+    part: meta + Node/Edge partitions; the index converter is py2-only)."""
+    pkg = os.path.join(scratch, "euler")
+    os.makedirs(pkg)
+    shutil.copytree(os.path.join(REF, "euler", "tools"), os.path.join(pkg, "tools"))
+    open(os.path.join(pkg, "__init__.py"), "w").close()
+    tools = os.path.join(pkg, "tools")
+    if not os.path.exists(os.path.join(tools, "__init__.py")):
+        open(os.path.join(tools, "__init__.py"), "w").close()
+    subprocess.check_call(
+        ["g++", "-std=c++11", "-O2", "-fPIC", "-shared", "-I" + REF,
+         os.path.join(REF, "euler/util/python_api.cc"),
+         os.path.join(REF, "euler/common/hash.cc"),
+         "-o", os.path.join(tools, "libeuler_util.so")])
+    empty = os.path.join(scratch, "empty.cc")
+    open(empty, "w").close()
+    subprocess.check_call(["g++", "-shared", "-fPIC", empty, "-o",
+                           os.path.join(tools, "libcommon.so")])
+    data = os.path.join(scratch, "data")
+    os.makedirs(data)
+    subprocess.check_call(
+        [sys.executable, os.path.join(tools, "generate_euler_data.py"),
+         os.path.join(REF, "tools/test_data/graph.json"), data, "2"],
+        cwd=scratch, env=dict(os.environ, PYTHONPATH=scratch))
+    return data
+
+
+def sample_pack(R, ids, T, prefix):
+    """Reference outputs on the loaded graph for a battery of queries."""
+    out = {}
+    q = np.concatenate([ids, ids[::-1], np.array([0, 987654321], np.uint64)])
+    out[prefix + "query_ids"] = q
+    etl = [[0], [1], [0, 1], [1, 0], [], [T + 3], [0, 0]]
+    if T > 2:
+        etl += [[2], [0, 2], [2, 1], list(range(T))]
+    for n, et in enumerate(etl):
+        for count in (1, 5):
+            idx, oid, ow, ot = R.sample_neighbor_core(SEED, 11 + n, q, et, count)
+            key = "%snb_%d_%d_" % (prefix, n, count)
+            out[key + "et"] = np.array(et, np.int32)
+            out[key + "idx"] = idx
+            out[key + "id"] = oid
+            out[key + "w"] = ow
+            out[key + "t"] = ot
+    for n, et in enumerate([[0], [1], [0, 1], list(range(T))]):
+        idx, oid, ow, ot = R.get_full_neighbor(q, et)
+        key = "%sfull_%d_" % (prefix, n)
+        out[key + "et"] = np.array(et, np.int32)
+        out[key + "idx"] = idx
+        out[key + "id"] = oid
+        out[key + "w"] = ow
+        out[key + "t"] = ot
+    out[prefix + "node_order"] = R.node_order()
+    for n, nt in enumerate([[-1], [0], [1], [0, 1]]):
+        out["%ssn_%d_types" % (prefix, n)] = np.array(nt, np.int32)
+        out["%ssn_%d" % (prefix, n)] = R.sample_node(SEED, 100 + n, nt, 64)
+    for t in (-1, 0, 1):
+        i, w, p, a, s = R.alias_table(t)
+        out["%salias_%d_ids" % (prefix, t + 1)] = i
+        out["%salias_%d_w" % (prefix, t + 1)] = w
+        out["%salias_%d_prob" % (prefix, t + 1)] = p
+        out["%salias_%d_alias" % (prefix, t + 1)] = a
+    starts = q.astype(np.int64)
+    L = 6
+    et_all = np.tile(np.arange(T, dtype=np.int32), (L, 1))
+    out[prefix + "walk_et"] = et_all
+    out[prefix + "walk_11"] = R.random_walk(SEED, 200, starts, et_all, L, 1.0, 1.0, -1)
+    out[prefix + "walk_n2v"] = R.random_walk(SEED, 300, starts, et_all, L, 0.25, 4.0, -1)
+    out[prefix + "walk_n2v_b"] = R.random_walk(SEED, 400, starts, et_all, L, 2.0, 0.5, 777)
+    return out
+
+
+def main():
+    O.build(ref=True)
+    assert O.have_ref(), "oracle/_ref must be built from " + REF
+    scratch = tempfile.mkdtemp(prefix="euler_golden_")
+    try:
+        data = convert_fixture(scratch)
+        T = 2
+        R = O.RefGraph.load(data, T)
+        ids = np.sort(R.node_order())
+        csr = R.export_csr(ids)
+        np.savez(os.path.join(OUT, "fixture_graph.npz"),
+                 row_id=csr.row_id, row_ptr=csr.row_ptr, type_end=csr.type_end,
+                 nbr=csr.nbr, prefix_w=csr.prefix_w, type_prefix=csr.type_prefix,
+                 node_type=csr.node_type, node_weight=csr.node_weight,
+                 n_types=np.int32(T))
+        pack = sample_pack(R, ids, T, "")
+        np.savez(os.path.join(OUT, "fixture_samples.npz"), seed=np.uint64(SEED),
+                 **pack)
+    finally:
+        shutil.rmtree(scratch, ignore_errors=True)
+
+    # ---- random heterogeneous graph built through the reference Node::Init
+    rng = np.random.default_rng(7)
+    n, T = 300, 3
+    ids = np.sort(rng.choice(np.arange(1, 5000), n, replace=False)).astype(np.uint64)
+    deg = rng.integers(0, 9, size=(n, T))
+    deg[rng.random((n, T)) < 0.25] = 0
+    deg[0, :] = [40, 0, 300]          # one hub row
+    seg = np.zeros(n * T + 1, np.int64)
+    seg[1:] = np.cumsum(deg.reshape(-1))
+    E = int(seg[-1])
+    nbr = rng.choice(ids, E).astype(np.uint64)
+    w = (rng.random(E) * 7.5 + 0.5).astype(np.float32)
+    w[rng.random(E) < 0.05] = 0
+    nt = rng.integers(0, 2, n).astype(np.int32)
+    nw = (rng.random(n) * 3 + 0.1).astype(np.float32)
+    R = O.RefGraph.build_raw(ids, seg, nbr, w, T, nt, nw)
+    csr = R.export_csr(ids)
+    pack = sample_pack(R, ids[:40], T, "")
+    np.savez_compressed(
+        os.path.join(OUT, "random_graph.npz"), seed=np.uint64(SEED),
+        raw_seg_ptr=seg, raw_nbr=nbr, raw_w=w,
+        row_id=csr.row_id, row_ptr=csr.row_ptr, type_end=csr.type_end,
+        nbr=csr.nbr, prefix_w=csr.prefix_w, type_prefix=csr.type_prefix,
+        node_type=csr.node_type, node_weight=csr.node_weight,
+        n_types=np.int32(T), **pack)
+
+    # ---- exact expectations stated in the reference's own tests
+    ref_tests = dict(
+        # tf_euler/python/euler_ops/mp_ops_test.py:30-36
+        scatter_add_x=np.array([[1., 2.], [3., 4.], [5., 6.]], np.float32),
+        scatter_idx=np.array([1, 0, 1], np.int32),
+        scatter_add_out=np.array([[3., 4.], [6., 8.]], np.float32),
+        # :46-54
+        scatter_mean_out=np.array([[3., 4.], [3., 4.]], np.float32),
+        # :64-70
+        scatter_max_x=np.array([[1., 6.], [3., 4.], [5., 2.]], np.float32),
+        scatter_max_out=np.array([[3., 4.], [5., 6.]], np.float32),
+        # :80-86
+        gather_x=np.array([[1., 2.], [3., 4.], [5., 6.]], np.float32),
+        gather_idx=np.array([1, 0, 1, 2], np.int32),
+        gather_out=np.array([[3., 4.], [1., 2.], [3., 4.], [5., 6.]], np.float32),
+        # tf_euler/python/euler_ops/walk_ops_test.py:49-58
+        gen_pair_in=np.array([[1, 2, 3, 4, 5, 6, 7, 8, 9]], np.int64),
+        gen_pair_out=np.array(
+            [[[1, 2], [1, 3], [2, 1], [2, 3], [2, 4], [3, 2], [3, 1],
+              [3, 4], [3, 5], [4, 3], [4, 2], [4, 5], [4, 6], [5, 4],
+              [5, 3], [5, 6], [5, 7], [6, 5], [6, 4], [6, 7], [6, 8],
+              [7, 6], [7, 5], [7, 8], [7, 9], [8, 7], [8, 6], [8, 9],
+              [9, 8], [9, 7]]], np.int64),
+    )
+    np.savez(os.path.join(OUT, "ref_tests.npz"), **ref_tests)
+    print("golden vectors written to", OUT)
+
+
+if __name__ == "__main__":
+    main()

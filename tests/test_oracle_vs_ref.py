@@ -1,0 +1,82 @@
+"""The C restatement against the REFERENCE sampler itself (oracle/_ref =
+reference sources + RNG seam), on fresh random graphs.  Skipped when the
+prebuilt oracle/_ref/libeuler_ref.so is absent.  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import make_random_graph
+
+
+@pytest.fixture(scope="module")
+def pair(O):
+    if not O.have_ref():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    rng = np.random.default_rng(2024)
+    ids, seg, nbr, w, nt, nw = make_random_graph(rng, 3000, 4, max_deg=20)
+    # a hub row and an id-0 node exercise deep searches and the sentinel quirk
+    R = O.RefGraph.build_raw(ids, seg, nbr, w, 4, nt, nw)
+    csr = O.csr_from_raw(ids, seg, nbr, w, 4, nt, nw)
+    ref_csr = R.export_csr(ids)
+    for a in ("row_ptr", "type_end", "nbr", "prefix_w", "type_prefix"):
+        assert np.array_equal(getattr(csr, a), getattr(ref_csr, a)), a
+    return R, O.OracleGraph(csr), ids, rng
+
+
+@pytest.mark.parametrize("et", [[0], [3], [1, 2], [3, 0, 1], [0, 1, 2, 3], [],
+                                [2, 2], [9], [1, 9], [0, 1, 2, 3, 0]])
+@pytest.mark.parametrize("count", [1, 10])
+def test_sample_neighbor_matches_reference(pair, et, count):
+    R, G, ids, rng = pair
+    q = np.concatenate([rng.choice(ids, 800), [0, 2 ** 63 + 5]]).astype(np.uint64)
+    for call in (0, 77):
+        a = R.sample_neighbor_core(99, call, q, et, count)
+        b = G.sample_neighbor_core(99, call, q, et, count)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+
+
+def test_sample_node_matches_reference(pair):
+    R, G, ids, rng = pair
+    G.build_node_sampler(order=R.node_order())
+    for call, types in enumerate([[-1], [0], [1], [0, 1], [1, 0, 1]]):
+        a = R.sample_node(5, call, types, 500)
+        b = G.sample_node(5, call, types, 500)
+        assert len(a) == 500 and np.array_equal(a, b)
+
+
+def test_full_neighbor_and_walks_match_reference(pair):
+    R, G, ids, rng = pair
+    q = np.concatenate([rng.choice(ids, 300), [0]]).astype(np.uint64)
+    for et in ([0], [1, 3], [3, 1], [0, 1, 2, 3]):
+        for x, y in zip(R.get_full_neighbor(q, et), G.get_full_neighbor(q, et)):
+            assert np.array_equal(x, y)
+    L = 8
+    et = np.tile(np.array([0, 1, 2, 3], np.int32), (L, 1))
+    starts = q.astype(np.int64)
+    for p, qq, dn in ((1.0, 1.0, -1), (1.0, 1.0 + 5e-7, 12345), (0.5, 2.0, -1),
+                      (4.0, 0.25, 4242)):
+        a = R.random_walk(3, 1000, starts, et, L, p, qq, dn)
+        b = G.random_walk(3, 1000, starts, et, L, p, qq, dn)
+        assert np.array_equal(a, b), (p, qq)
+
+
+def test_graph_with_node_id_zero(O):
+    """Q1: a real node 0 is indistinguishable from the sentinel."""
+    if not O.have_ref():
+        pytest.skip("oracle/_ref not built")
+    ids = np.array([0, 1, 2, 3], np.uint64)
+    seg = np.array([0, 2, 4, 6, 7], np.int64)
+    nbr = np.array([1, 2, 0, 2, 0, 3, 0], np.uint64)
+    w = np.array([1, 1, 5, 1, 1, 1, 2], np.float32)
+    R = O.RefGraph.build_raw(ids, seg, nbr, w, 1)
+    G = O.OracleGraph(O.csr_from_raw(ids, seg, nbr, w, 1))
+    q = np.array([0, 1, 2, 3, 9], np.uint64)
+    for call in range(20):
+        a = R.sample_neighbor_core(1, call, q, [0], 3)
+        b = G.sample_neighbor_core(1, call, q, [0], 3)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    starts = q.astype(np.int64)
+    et = np.zeros((5, 1), np.int32)
+    assert np.array_equal(R.random_walk(1, 0, starts, et, 5, 1.0, 1.0, -1),
+                          G.random_walk(1, 0, starts, et, 5, 1.0, 1.0, -1))
