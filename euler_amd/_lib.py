@@ -1,0 +1,137 @@
+"""ctypes binding of euler_amd/lib/libeuler_gpu.so (the C ABI in
+include/euler_gpu.h).  There is NO fallback: if the HIP library is missing the
+import fails loudly - build it with `python -c "import __graft_entry__ as g;
+g.build()"` or `make -C euler_amd/csrc`."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libeuler_gpu.so")
+
+OK, EINVAL, ENOMEM, EHIP, ENOGRAPH, EIO, EEMPTY = 0, -1, -2, -3, -4, -5, -6
+LAYOUT_CORE, LAYOUT_TF = 0, 1
+
+u64p = C.POINTER(C.c_uint64)
+i64p = C.POINTER(C.c_int64)
+i32p = C.POINTER(C.c_int32)
+f32p = C.POINTER(C.c_float)
+u8p = C.POINTER(C.c_uint8)
+vp = C.c_void_p
+
+
+class HostCSR(C.Structure):
+    _fields_ = [("n_rows", C.c_int64), ("n_edge_types", C.c_int32),
+                ("n_node_types", C.c_int32), ("row_id", u64p),
+                ("row_ptr", i64p), ("type_end", i32p), ("nbr", u64p),
+                ("prefix_w", f32p), ("type_prefix", f32p),
+                ("node_type", i32p), ("node_weight", f32p),
+                ("sampler_order", u64p)]
+
+
+class SynthParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("n_nodes", C.c_int64),
+                ("n_edges_target", C.c_int64), ("scale", C.c_int32),
+                ("n_types", C.c_int32), ("weighted", C.c_int32),
+                ("pad", C.c_int32), ("deg_table", C.c_double * 64)]
+
+
+# name -> (restype, argtypes); also the list of symbols include/euler_gpu.h declares
+SIGNATURES = {
+    "euler_gpu_last_error": (C.c_char_p, []),
+    "euler_gpu_version": (C.c_char_p, []),
+    "euler_gpu_device_count": (C.c_int, []),
+    "euler_gpu_graph_create": (C.c_int, [C.POINTER(HostCSR), C.c_int, C.POINTER(vp)]),
+    "euler_gpu_graph_create_shard": (C.c_int, [C.POINTER(HostCSR), C.c_int, C.c_int32,
+                                               C.c_int32, C.c_int32, C.POINTER(vp)]),
+    "euler_gpu_graph_create_synthetic": (C.c_int, [C.POINTER(SynthParams), C.c_int,
+                                                   C.c_int32, C.c_int32, C.c_int32,
+                                                   C.POINTER(vp)]),
+    "euler_gpu_graph_load": (C.c_int, [C.c_char_p, C.c_int, C.c_int32, C.c_int32,
+                                       C.POINTER(vp)]),
+    "euler_gpu_dat_open": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32,
+                                     C.POINTER(HostCSR), i32p, C.POINTER(vp)]),
+    "euler_gpu_dat_close": (None, [vp]),
+    "euler_gpu_graph_destroy": (None, [vp]),
+    "euler_gpu_graph_num_nodes": (C.c_int64, [vp]),
+    "euler_gpu_graph_num_edges": (C.c_int64, [vp]),
+    "euler_gpu_graph_num_edge_types": (C.c_int32, [vp]),
+    "euler_gpu_graph_num_node_types": (C.c_int32, [vp]),
+    "euler_gpu_graph_device": (C.c_int, [vp]),
+    "euler_gpu_graph_bytes": (C.c_int64, [vp]),
+    "euler_gpu_graph_node_weight_sums": (C.c_int, [vp, f32p]),
+    "euler_gpu_graph_export_rows": (C.c_int, [vp, u64p, C.c_int64, i64p, i32p, u64p,
+                                              f32p, f32p]),
+    "InitQueryProxy": (C.c_bool, [C.c_char_p]),
+    "euler_gpu_default_graph": (vp, []),
+    "euler_gpu_sample_neighbor": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp,
+                                            C.c_int64, vp, C.c_int32, i32p, C.c_int32,
+                                            C.c_int32, C.c_int32, C.c_int64, vp, vp,
+                                            vp, vp]),
+    "euler_gpu_sample_fanout_workspace": (C.c_size_t, [C.c_int64, i32p, C.c_int32]),
+    "euler_gpu_sample_fanout": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp,
+                                          C.c_int64, i32p, C.c_int32, i32p, C.c_int32,
+                                          C.c_int64, C.POINTER(vp), C.POINTER(vp),
+                                          C.POINTER(vp), vp]),
+    "euler_gpu_sample_node": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, i32p,
+                                        C.c_int32, C.c_int32, vp]),
+    "euler_gpu_get_full_neighbor": (C.c_int, [vp, vp, vp, C.c_int64, i32p, C.c_int32,
+                                              vp, i64p, vp, vp, vp]),
+    "euler_gpu_random_walk": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp, C.c_int64,
+                                        i32p, C.c_int32, C.c_int32, C.c_float,
+                                        C.c_float, C.c_int64, vp]),
+    "euler_gpu_gen_pair_count": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
+    "euler_gpu_gen_pair": (C.c_int, [vp, vp, C.c_int64, C.c_int64, C.c_int32,
+                                     C.c_int32, vp]),
+    "euler_gpu_id_unique": (C.c_int, [vp, vp, C.c_int64, vp, vp, i64p]),
+    "euler_gpu_idx_gather": (C.c_int, [vp, vp, vp, C.c_int64, vp, i64p]),
+    "euler_gpu_data_gather": (C.c_int, [vp, vp, C.c_int32, vp, vp, vp, C.c_int64, vp]),
+    "euler_gpu_scatter_add": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, C.c_int32, vp]),
+    "euler_gpu_scatter_max": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, C.c_int32, vp]),
+    "euler_gpu_gather": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, vp]),
+    "euler_gpu_id_split": (C.c_int, [vp, vp, C.c_int64, C.c_int32, C.c_int32, i64p,
+                                     vp, vp]),
+    "euler_gpu_merge_rows": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, vp]),
+    "euler_gpu_sample_node_split": (C.c_int, [C.c_uint64, C.c_uint32, C.c_int32, f32p,
+                                              C.c_int32, i32p]),
+    "euler_gpu_time_sample_neighbor": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_int64,
+                                                 i32p, C.c_int32, C.c_int32,
+                                                 C.c_int32, vp, vp, vp, C.c_int32,
+                                                 f32p]),
+    "euler_gpu_sample_neighbor_algo_bytes": (C.c_int, [vp, vp, vp, C.c_int64, i32p,
+                                                       C.c_int32, C.c_int32,
+                                                       C.POINTER(C.c_double)]),
+    "euler_op_registered": (C.c_int, [C.c_char_p]),
+    "euler_op_run_sample_nb": (C.c_int64, [vp, C.c_uint64, u64p, C.c_int64, i32p,
+                                           C.c_int32, C.c_int32, i32p, u64p, f32p,
+                                           i32p]),
+}
+
+_lib = None
+
+
+class EulerGpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("euler_gpu error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "euler_amd: %s is missing - the HIP library must be built "
+                "(make -C euler_amd/csrc); there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != OK:
+        raise EulerGpuError(rc, lib().euler_gpu_last_error().decode())
+    return rc

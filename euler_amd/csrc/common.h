@@ -1,0 +1,139 @@
+// Internal definitions shared by the HIP translation units of libeuler_gpu.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/euler_gpu.h"
+#include "philox.h"
+
+namespace euler_gpu {
+
+// ----------------------------------------------------------------- errors
+void SetError(const std::string& msg);
+int Fail(int code, const std::string& msg);
+
+#define EG_HIP(expr)                                                        \
+  do {                                                                      \
+    hipError_t _e = (expr);                                                 \
+    if (_e != hipSuccess)                                                   \
+      return ::euler_gpu::Fail(EULER_GPU_EHIP,                              \
+                               std::string(#expr) + ": " +                  \
+                                   hipGetErrorString(_e));                  \
+  } while (0)
+
+// ------------------------------------------------------------ HBM layout
+//
+// The reference keeps one heap object per node (unordered_map<id, Node*> ->
+// three std::vectors, node.h:49-57; 424 B + allocations per node).  Here the
+// whole graph is four flat arrays, sized for one 288 GB HBM stack:
+//
+//   row_meta [n_rows] records of (8 + 8*T) bytes:
+//        int64  row_ptr              offset of the row in nbr / prefix_w
+//        int32  type_end[T]          neighbor_groups_idx (cumulative, row-relative)
+//        float  type_prefix[T]       edge_group_collection running sums
+//     one record = everything Node::SampleNeighbor needs before the search,
+//     fetched with a single 16-byte load when T == 1 (one 64 B sector per root
+//     instead of three dependent pointer chases).
+//   prefix_w [E] float  neighbors_weight: the running f32 sums the reference
+//     binary-searches (kept bit-identical; 4 B/edge keeps a row's search
+//     inside 1-2 sectors for typical degrees)
+//   nbr      [E] uint64 neighbor ids, read once per sample at the found slot
+//   id map   identity/strided (id -> (id - base) / stride, no memory at all)
+//            or an open-addressing table of 16-byte {key,row} slots.
+struct GraphView {
+  int64_t n_rows;
+  int64_t n_edges;
+  const uint8_t* row_meta;
+  const uint64_t* nbr;
+  const float* prefix_w;
+  const uint64_t* row_id;       // [n_rows] or nullptr when ids are implicit
+  int32_t T;                    // edge-type groups per node
+  int32_t meta_stride;          // 8 + 8*T
+  int32_t map_mode;             // 0 = strided identity, 1 = hash table
+  int32_t has_zero_nbr;         // a neighbor id equals the sentinel 0 (Q1)
+  uint64_t id_base;             // identity: row = (id - id_base) / id_stride
+  uint64_t id_stride;
+  const uint64_t* hash_slots;   // [2 * (hash_mask + 1)] = {key, row} pairs
+  uint64_t hash_mask;
+};
+
+constexpr int kMaxListedTypes = 32;
+constexpr int kMaxNodeTypes = 32;
+
+// Alias-table entry of the global node sampler: one 32-byte record resolves a
+// draw (column hit or alias) with a single memory access.
+struct AliasEntry {
+  uint64_t id_self;
+  uint64_t id_alias;
+  float prob;
+  uint32_t pad0;
+  uint64_t pad1;
+};
+static_assert(sizeof(AliasEntry) == 32, "AliasEntry must be 32 bytes");
+
+struct NodeSamplerView {
+  const AliasEntry* entries;          // all types, concatenated
+  int32_t n_types;
+  int32_t pad;
+  int64_t type_off[kMaxNodeTypes + 1];
+  float type_sum[kMaxNodeTypes];      // node_weight_sums_
+  float sampler_sum[kMaxNodeTypes];   // FastWeightedCollection::sum_weight_
+  float tc_prob[kMaxNodeTypes];       // node_type_collection_ alias table
+  int32_t tc_alias[kMaxNodeTypes];
+  float tc_sum;
+};
+
+EG_HD uint64_t Mix64(uint64_t z) {
+  z ^= z >> 30; z *= 0xbf58476d1ce4e5b9ULL;
+  z ^= z >> 27; z *= 0x94d049bb133111ebULL;
+  z ^= z >> 31;
+  return z;
+}
+
+}  // namespace euler_gpu
+
+// The opaque handle of the C ABI.
+struct euler_gpu_graph {
+  int device = 0;
+  euler_gpu::GraphView view{};
+  euler_gpu::NodeSamplerView sampler{};
+  bool has_sampler = false;
+  int32_t n_node_types = 1;
+  int64_t bytes = 0;
+  std::vector<void*> allocations;     // every hipMalloc owned by the graph
+  std::vector<float> node_weight_sums;
+};
+
+namespace euler_gpu {
+
+// graph_build.hip
+int BuildGraphFromHost(const euler_gpu_host_csr* csr, int device,
+                       int32_t partitions, int32_t shard_index, int32_t shards,
+                       euler_gpu_graph** out);
+int BuildGraphSynthetic(const euler_gpu_synth_params* p, int device,
+                        int32_t partitions, int32_t shard_index, int32_t shards,
+                        euler_gpu_graph** out);
+// dat_reader.cc
+int LoadDatDirectory(const char* data_path, int32_t shard_index, int32_t shards,
+                     std::vector<uint64_t>* row_id, std::vector<int64_t>* row_ptr,
+                     std::vector<int32_t>* type_end, std::vector<uint64_t>* nbr,
+                     std::vector<float>* prefix_w, std::vector<float>* type_prefix,
+                     std::vector<int32_t>* node_type,
+                     std::vector<float>* node_weight, int32_t* n_edge_types,
+                     int32_t* n_node_types, int32_t* partitions);
+
+// Grid sizing for HBM-bound kernels: enough workgroups to fill 256 CUs x 8
+// resident blocks, grid-stride beyond that.
+inline int GridFor(int64_t work_items, int block) {
+  int64_t blocks = (work_items + block - 1) / block;
+  const int64_t cap = 256 * 16;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+}  // namespace euler_gpu

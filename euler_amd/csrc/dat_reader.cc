@@ -1,0 +1,183 @@
+// Reader for the on-disk graph the reference loads in Graph::Init: the
+// `euler.meta` header (core/graph/graph_builder.cc:230-307) and the
+// `Node/*_<partition>.dat` record files (graph_builder.cc:310-320; record =
+// Node::DeSerialize, core/graph/node.cc:414-526; primitives =
+// common/bytes_io.h:28-81, common/file_io.h:113-135).  Records go straight into
+// the flat CSR arrays that are uploaded to HBM - no per-node heap objects.
+#include <dirent.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace euler_gpu {
+
+namespace {
+
+struct Cursor {
+  const char* p;
+  size_t n;
+  size_t i = 0;
+  template <typename T>
+  bool Get(T* v) {
+    if (i + sizeof(T) > n) return false;
+    memcpy(v, p + i, sizeof(T));
+    i += sizeof(T);
+    return true;
+  }
+  template <typename T>
+  bool GetVec(std::vector<T>* v) {
+    uint32_t num = 0;
+    if (!Get(&num)) return false;
+    if (i + (size_t)num * sizeof(T) > n) return false;
+    v->resize(num);
+    if (num) memcpy(v->data(), p + i, (size_t)num * sizeof(T));
+    i += (size_t)num * sizeof(T);
+    return true;
+  }
+  bool GetString(std::string* s) {
+    uint32_t len = 0;
+    if (!Get(&len)) return false;
+    if (i + len > n) return false;
+    s->assign(p + i, len);
+    i += len;
+    return true;
+  }
+};
+
+bool ReadFile(const std::string& path, std::string* out) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return false;
+  f.seekg(0, std::ios::end);
+  const std::streamoff sz = f.tellg();
+  f.seekg(0);
+  out->resize((size_t)sz);
+  if (sz > 0) f.read(&(*out)[0], sz);
+  return (bool)f;
+}
+
+// Graph::Init's file filter (core/graph/graph.cc:90-98): "<x>_<idx>.dat" with
+// idx % shard_number == shard_index.
+bool KeepFile(const std::string& name, int32_t shard_index, int32_t shards) {
+  std::vector<std::string> parts;
+  std::string cur;
+  for (char ch : name) {
+    if (ch == '_' || ch == '.') { if (!cur.empty()) parts.push_back(cur); cur.clear(); }
+    else cur.push_back(ch);
+  }
+  if (!cur.empty()) parts.push_back(cur);
+  return parts.size() == 3 && parts[2] == "dat" &&
+         atoi(parts[1].c_str()) % shards == shard_index;
+}
+
+}  // namespace
+
+int LoadDatDirectory(const char* data_path, int32_t shard_index, int32_t shards,
+                     std::vector<uint64_t>* row_id, std::vector<int64_t>* row_ptr,
+                     std::vector<int32_t>* type_end, std::vector<uint64_t>* nbr,
+                     std::vector<float>* prefix_w, std::vector<float>* type_prefix,
+                     std::vector<int32_t>* node_type,
+                     std::vector<float>* node_weight, int32_t* n_edge_types,
+                     int32_t* n_node_types, int32_t* partitions) {
+  if (shards <= 0 || shard_index < 0 || shard_index >= shards)
+    return Fail(EULER_GPU_EINVAL, "graph_load: bad shard arguments");
+  const std::string root(data_path);
+  // ---- euler.meta
+  std::string meta;
+  if (!ReadFile(root + "/euler.meta", &meta))
+    return Fail(EULER_GPU_EIO, "graph_load: cannot read " + root + "/euler.meta");
+  Cursor m{meta.data(), meta.size()};
+  std::string name, version;
+  uint64_t node_count = 0, edge_count = 0;
+  int32_t parts = 0;
+  bool ok = m.GetString(&name) && m.GetString(&version) && m.Get(&node_count) &&
+            m.Get(&edge_count) && m.Get(&parts);
+  for (int pass = 0; ok && pass < 2; ++pass) {   // node features, edge features
+    uint32_t cnt = 0;
+    ok = m.Get(&cnt);
+    for (uint32_t i = 0; ok && i < cnt; ++i) {
+      std::string fname; int32_t ftype, idx; int64_t dim;
+      ok = m.GetString(&fname) && m.Get(&ftype) && m.Get(&idx) && m.Get(&dim);
+    }
+  }
+  uint32_t nt = 0, et = 0;
+  ok = ok && m.Get(&nt);
+  for (uint32_t i = 0; ok && i < nt; ++i) {
+    std::string s; uint32_t idx;
+    ok = m.GetString(&s) && m.Get(&idx);
+  }
+  ok = ok && m.Get(&et);
+  if (!ok) return Fail(EULER_GPU_EIO, "graph_load: malformed euler.meta");
+  if (parts <= 0) return Fail(EULER_GPU_EIO, "graph_load: partitions_num must be > 0");
+  *n_node_types = (int32_t)nt;
+  *n_edge_types = (int32_t)et;
+  *partitions = parts;
+  if (et == 0 || et > (uint32_t)kMaxListedTypes)
+    return Fail(EULER_GPU_EIO, "graph_load: need 1..32 edge types");
+  // ---- Node/*.dat
+  const std::string node_dir = root + "/Node";
+  DIR* d = opendir(node_dir.c_str());
+  if (!d) return Fail(EULER_GPU_EIO, "graph_load: no directory " + node_dir);
+  std::vector<std::string> files;
+  while (dirent* ent = readdir(d)) {
+    const std::string fn(ent->d_name);
+    if (KeepFile(fn, shard_index, shards)) files.push_back(fn);
+  }
+  closedir(d);
+  std::sort(files.begin(), files.end());
+  row_id->clear(); row_ptr->assign(1, 0); type_end->clear(); nbr->clear();
+  prefix_w->clear(); type_prefix->clear(); node_type->clear(); node_weight->clear();
+  const int32_t T = (int32_t)et;
+  std::vector<int32_t> gids, gidx;
+  std::vector<float> gw, nw;
+  std::vector<uint64_t> nb;
+  for (const auto& fn : files) {
+    std::string blob;
+    if (!ReadFile(node_dir + "/" + fn, &blob))
+      return Fail(EULER_GPU_EIO, "graph_load: cannot read " + fn);
+    Cursor f{blob.data(), blob.size()};
+    while (f.i < f.n) {
+      uint32_t len = 0;
+      if (!f.Get(&len) || f.i + len > f.n)
+        return Fail(EULER_GPU_EIO, "graph_load: truncated record in " + fn);
+      Cursor r{blob.data() + f.i, len};
+      f.i += len;
+      uint64_t id; int32_t type; float weight;
+      if (!(r.Get(&id) && r.Get(&type) && r.Get(&weight) && r.GetVec(&gids) &&
+            r.GetVec(&gw) && r.GetVec(&gidx) && r.GetVec(&nb) && r.GetVec(&nw)))
+        return Fail(EULER_GPU_EIO, "graph_load: malformed node record in " + fn);
+      if ((int32_t)gids.size() > T || gids.size() != gw.size() ||
+          gids.size() != gidx.size() || nb.size() != nw.size())
+        return Fail(EULER_GPU_EIO, "graph_load: inconsistent node record in " + fn);
+      row_id->push_back(id);
+      node_type->push_back(type);
+      node_weight->push_back(weight);
+      // CompactWeightedCollection::Init(ids, weights): running f32 sums
+      float acc = 0.f;
+      int32_t last_end = 0;
+      for (int32_t t = 0; t < T; ++t) {
+        if (t < (int32_t)gids.size()) {
+          if (gids[t] != t)
+            return Fail(EULER_GPU_EIO, "graph_load: edge group ids must be 0..T-1");
+          acc += gw[t];
+          last_end = gidx[t];
+        }
+        type_end->push_back(last_end);
+        type_prefix->push_back(acc);
+      }
+      if (last_end != (int32_t)nb.size())
+        return Fail(EULER_GPU_EIO, "graph_load: group index does not cover row");
+      nbr->insert(nbr->end(), nb.begin(), nb.end());
+      prefix_w->insert(prefix_w->end(), nw.begin(), nw.end());
+      row_ptr->push_back((int64_t)nbr->size());
+    }
+  }
+  return EULER_GPU_OK;
+}
+
+}  // namespace euler_gpu

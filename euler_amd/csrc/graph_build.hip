@@ -1,0 +1,718 @@
+// Graph construction: host CSR -> HBM layout, synthetic power-law generator
+// on device, global node sampler (alias tables), row export, and the graph
+// life-cycle entry points of the C ABI.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <sstream>
+
+#include "device_fns.h"
+
+namespace euler_gpu {
+
+namespace {
+thread_local std::string g_last_error;
+std::mutex g_default_mu;
+euler_gpu_graph* g_default_graph = nullptr;
+}  // namespace
+
+void SetError(const std::string& msg) { g_last_error = msg; }
+int Fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+namespace {
+
+struct GraphBuilder {
+  std::unique_ptr<euler_gpu_graph> g{new euler_gpu_graph()};
+  int rc = EULER_GPU_OK;
+
+  template <typename T>
+  T* Alloc(size_t count) {
+    void* p = nullptr;
+    const size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+      rc = Fail(EULER_GPU_ENOMEM, std::string("hipMalloc(") +
+                                      std::to_string(bytes) +
+                                      "): " + hipGetErrorString(e));
+      return nullptr;
+    }
+    g->allocations.push_back(p);
+    g->bytes += (int64_t)bytes;
+    return (T*)p;
+  }
+
+  template <typename T>
+  T* Upload(const T* host, size_t count) {
+    T* d = Alloc<T>(count);
+    if (!d) return nullptr;
+    if (count > 0) {
+      hipError_t e = hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice);
+      if (e != hipSuccess) {
+        rc = Fail(EULER_GPU_EHIP, std::string("hipMemcpy H2D: ") +
+                                      hipGetErrorString(e));
+        return nullptr;
+      }
+    }
+    return d;
+  }
+};
+
+void DestroyGraph(euler_gpu_graph* g) {
+  if (!g) return;
+  (void)hipSetDevice(g->device);
+  for (void* p : g->allocations) (void)hipFree(p);
+  delete g;
+}
+
+// AliasMethod::Init (euler/common/alias_method.cc:23-63), restated for the
+// table build: LIFO small/large stacks, `avg` in double, weights updated in
+// float, prob in float.  Element order is the caller's (Q7).
+void AliasBuild(const std::vector<float>& weights, std::vector<float>* prob,
+                std::vector<int64_t>* alias) {
+  const size_t n = weights.size();
+  prob->assign(n, 0.f);
+  alias->assign(n, 0);
+  std::vector<int64_t> small, large;
+  std::vector<float> w(weights);
+  const double avg = 1 / static_cast<double>(n);
+  for (size_t i = 0; i < n; ++i) {
+    if (w[i] > avg) large.push_back((int64_t)i); else small.push_back((int64_t)i);
+  }
+  while (!large.empty() && !small.empty()) {
+    const int64_t less = small.back(); small.pop_back();
+    const int64_t more = large.back(); large.pop_back();
+    (*prob)[less] = w[less] * n;
+    (*alias)[less] = more;
+    w[more] = w[more] + w[less] - avg;
+    if (w[more] > avg) large.push_back(more); else small.push_back(more);
+  }
+  while (!small.empty()) { (*prob)[small.back()] = 1.0; small.pop_back(); }
+  while (!large.empty()) { (*prob)[large.back()] = 1.0; large.pop_back(); }
+}
+
+// Graph::BuildGlobalSampler (core/graph/graph.cc:333-370) +
+// FastWeightedCollection::Init (common/fast_weighted_collection.h:55-75).
+int BuildNodeSampler(GraphBuilder* b, const std::vector<uint64_t>& ids,
+                     const std::vector<int32_t>& types,
+                     const std::vector<float>& weights, int32_t n_types) {
+  if (n_types > kMaxNodeTypes)
+    return Fail(EULER_GPU_EINVAL, "more than 32 node types");
+  const size_t n = ids.size();
+  NodeSamplerView& s = b->g->sampler;
+  std::memset(&s, 0, sizeof(s));
+  s.n_types = n_types;
+  std::vector<std::vector<uint64_t>> tid(n_types);
+  std::vector<std::vector<float>> tw(n_types);
+  std::vector<float> sums(n_types, 0.f);
+  for (size_t i = 0; i < n; ++i) {
+    const int32_t t = types[i];
+    if (t < 0 || t >= n_types)
+      return Fail(EULER_GPU_EINVAL, "node type out of range");
+    tid[t].push_back(ids[i]);
+    tw[t].push_back(weights[i]);
+    sums[t] += weights[i];
+  }
+  std::vector<AliasEntry> entries(n);
+  size_t off = 0;
+  for (int32_t t = 0; t < n_types; ++t) {
+    s.type_off[t] = (int64_t)off;
+    std::vector<float>& w = tw[t];
+    for (auto& x : w) x /= sums[t];                  // graph.cc:355-358
+    float sum = 0.f;
+    for (auto x : w) sum += x;                       // FWC::Init sum_weight_
+    std::vector<float> norm(w);
+    for (auto& x : norm) x /= sum;
+    std::vector<float> prob;
+    std::vector<int64_t> alias;
+    AliasBuild(norm, &prob, &alias);
+    for (size_t i = 0; i < w.size(); ++i) {
+      AliasEntry e{};
+      e.id_self = tid[t][i];
+      e.id_alias = tid[t][(size_t)alias[i]];
+      e.prob = prob[i];
+      entries[off + i] = e;
+    }
+    s.type_sum[t] = sums[t];
+    s.sampler_sum[t] = w.empty() ? 0.f : sum;
+    off += w.size();
+  }
+  s.type_off[n_types] = (int64_t)off;
+  // node_type_collection_.Init(node_type_ids, node_weight_sums_)
+  float tsum = 0.f;
+  for (int32_t t = 0; t < n_types; ++t) tsum += sums[t];
+  s.tc_sum = tsum;
+  std::vector<float> tnorm(sums);
+  for (auto& x : tnorm) x /= tsum;
+  std::vector<float> tprob;
+  std::vector<int64_t> talias;
+  AliasBuild(tnorm, &tprob, &talias);
+  for (int32_t t = 0; t < n_types; ++t) {
+    s.tc_prob[t] = tprob[t];
+    s.tc_alias[t] = (int32_t)talias[t];
+  }
+  s.entries = b->Upload(entries.data(), entries.size());
+  if (!s.entries) return b->rc;
+  b->g->has_sampler = true;
+  b->g->n_node_types = n_types;
+  b->g->node_weight_sums = sums;
+  return EULER_GPU_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------
+// Host CSR -> device graph (optionally only the rows a shard owns).
+// ------------------------------------------------------------------------
+int BuildGraphFromHost(const euler_gpu_host_csr* c, int device,
+                       int32_t partitions, int32_t shard_index, int32_t shards,
+                       euler_gpu_graph** out) {
+  if (!c || !out) return Fail(EULER_GPU_EINVAL, "graph_create: null argument");
+  if (c->n_rows < 0 || c->n_edge_types <= 0 || c->n_edge_types > kMaxListedTypes)
+    return Fail(EULER_GPU_EINVAL, "graph_create: need 1..32 edge types");
+  if (shards <= 0 || shard_index < 0 || shard_index >= shards || partitions <= 0)
+    return Fail(EULER_GPU_EINVAL, "graph_create: bad shard arguments");
+  if (c->n_rows > 0 && (!c->row_id || !c->row_ptr || !c->type_end ||
+                        !c->type_prefix))
+    return Fail(EULER_GPU_EINVAL, "graph_create: null CSR array");
+  EG_HIP(hipSetDevice(device));
+  const int32_t T = c->n_edge_types;
+  // rows kept by this shard
+  std::vector<int64_t> keep;
+  keep.reserve((size_t)c->n_rows / shards + 1);
+  for (int64_t r = 0; r < c->n_rows; ++r) {
+    const uint64_t id = c->row_id[r];
+    if ((int32_t)((id % (uint64_t)partitions) % (uint64_t)shards) == shard_index)
+      keep.push_back(r);
+  }
+  const int64_t n = (int64_t)keep.size();
+  GraphBuilder b;
+  b.g->device = device;
+  GraphView& v = b.g->view;
+  v.T = T;
+  v.meta_stride = 8 + 8 * T;
+  v.n_rows = n;
+  // gather rows
+  std::vector<uint64_t> row_id(n);
+  std::vector<uint8_t> meta((size_t)n * v.meta_stride + 16, 0);
+  int64_t E = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t r = keep[i];
+    E += c->row_ptr[r + 1] - c->row_ptr[r];
+  }
+  std::vector<uint64_t> nbr((size_t)E);
+  std::vector<float> pw((size_t)E);
+  int64_t off = 0;
+  bool zero_nbr = false;
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t r = keep[i];
+    row_id[i] = c->row_id[r];
+    const int64_t b0 = c->row_ptr[r], deg = c->row_ptr[r + 1] - b0;
+    if (deg < 0 || c->type_end[r * T + T - 1] != deg)
+      return Fail(EULER_GPU_EINVAL, "graph_create: type_end does not match row_ptr");
+    uint8_t* rec = meta.data() + (size_t)i * v.meta_stride;
+    std::memcpy(rec, &off, 8);
+    std::memcpy(rec + 8, c->type_end + r * T, 4 * T);
+    std::memcpy(rec + 8 + 4 * T, c->type_prefix + r * T, 4 * T);
+    if (deg > 0) {
+      std::memcpy(nbr.data() + off, c->nbr + b0, (size_t)deg * 8);
+      std::memcpy(pw.data() + off, c->prefix_w + b0, (size_t)deg * 4);
+      for (int64_t j = 0; j < deg; ++j) zero_nbr |= c->nbr[b0 + j] == 0;
+    }
+    off += deg;
+  }
+  v.n_edges = E;
+  v.has_zero_nbr = zero_nbr ? 1 : 0;
+  v.row_meta = b.Upload(meta.data(), meta.size());
+  v.nbr = b.Upload(nbr.data(), nbr.size());
+  v.prefix_w = b.Upload(pw.data(), pw.size());
+  v.row_id = b.Upload(row_id.data(), row_id.size());
+  if (b.rc != EULER_GPU_OK) { DestroyGraph(b.g.release()); return b.rc; }
+  // id map: strided identity when the ids allow it, else a hash table
+  bool identity = n > 0;
+  uint64_t base = n > 0 ? row_id[0] : 0, stride = 1;
+  if (n > 1) {
+    stride = row_id[1] - row_id[0];
+    if (row_id[1] <= row_id[0]) identity = false;
+  }
+  for (int64_t i = 0; identity && i < n; ++i)
+    identity = row_id[i] == base + (uint64_t)i * stride;
+  if (identity) {
+    v.map_mode = 0; v.id_base = base; v.id_stride = stride;
+  } else {
+    uint64_t cap = 16;
+    while (cap < (uint64_t)n * 2 + 1) cap <<= 1;
+    std::vector<uint64_t> slots(2 * cap);
+    for (uint64_t i = 0; i < cap; ++i) { slots[2 * i] = 0; slots[2 * i + 1] = ~0ULL; }
+    for (int64_t i = 0; i < n; ++i) {
+      uint64_t h = Mix64(row_id[i]) & (cap - 1);
+      // duplicate ids: the later row wins (Graph::AddNode overwrites,
+      // core/graph/graph.cc:162-166)
+      while ((int64_t)slots[2 * h + 1] >= 0 && slots[2 * h] != row_id[i])
+        h = (h + 1) & (cap - 1);
+      slots[2 * h] = row_id[i];
+      slots[2 * h + 1] = (uint64_t)i;
+    }
+    v.map_mode = 1; v.hash_mask = cap - 1; v.id_base = 0; v.id_stride = 1;
+    v.hash_slots = b.Upload(slots.data(), slots.size());
+    if (b.rc != EULER_GPU_OK) { DestroyGraph(b.g.release()); return b.rc; }
+  }
+  // global node sampler over this shard's nodes
+  {
+    std::vector<uint64_t> ids;
+    std::vector<int32_t> types;
+    std::vector<float> weights;
+    ids.reserve(n); types.reserve(n); weights.reserve(n);
+    auto push = [&](int64_t r) {
+      ids.push_back(c->row_id[r]);
+      types.push_back(c->node_type ? c->node_type[r] : 0);
+      weights.push_back(c->node_weight ? c->node_weight[r] : 1.0f);
+    };
+    if (c->sampler_order) {
+      std::map<uint64_t, int64_t> pos;
+      for (int64_t i = 0; i < n; ++i) pos[row_id[i]] = keep[i];
+      for (int64_t i = 0; i < c->n_rows; ++i) {
+        auto it = pos.find(c->sampler_order[i]);
+        if (it != pos.end()) push(it->second);
+      }
+    } else {
+      for (int64_t i = 0; i < n; ++i) push(keep[i]);
+    }
+    int32_t n_types = c->n_node_types > 0 ? c->n_node_types : 1;
+    int rc = BuildNodeSampler(&b, ids, types, weights, n_types);
+    if (rc != EULER_GPU_OK) { DestroyGraph(b.g.release()); return rc; }
+  }
+  *out = b.g.release();
+  return EULER_GPU_OK;
+}
+
+// ------------------------------------------------------------------------
+// Synthetic power-law graph, generated directly in HBM (bench configs 2/3).
+// Mirror of oracle/eo_synth.c: every value is a pure integer/IEEE function of
+// (seed, node id, slot), so host and device agree bit-for-bit.
+// ------------------------------------------------------------------------
+struct SynthView {
+  uint64_t seed;
+  int64_t n_nodes;
+  int32_t scale;
+  int32_t n_types;
+  int32_t weighted;
+  int32_t pad;
+  double deg_table[64];
+};
+
+__host__ __device__ __forceinline__ uint64_t SynthHash(uint64_t seed,
+                                                       uint64_t node,
+                                                       uint64_t j, uint64_t c) {
+  uint64_t h = Mix64(seed + node * 0x9E3779B97F4A7C15ULL);
+  h = Mix64(h + j * 0xD1B54A32D192ED03ULL + c * 0x8CB92BA72F3D8DD7ULL);
+  return h;
+}
+
+__device__ __forceinline__ int64_t SynthDegree(const SynthView& p, uint64_t node_id) {
+  const uint64_t x = node_id - 1;
+  const uint64_t mask = p.scale >= 64 ? ~0ULL : ((1ULL << p.scale) - 1);
+  const double lam = p.deg_table[__popcll(x & mask) & 63];
+  const double fl = floor(lam);
+  const double frac = __dsub_rn(lam, fl);
+  const uint64_t h = SynthHash(p.seed, node_id, ~0ULL, 0);
+  const double u = __dmul_rn((double)(h >> 11), 1.0 / 9007199254740992.0);
+  return 1 + (int64_t)fl + (u < frac ? 1 : 0);
+}
+
+__device__ __forceinline__ uint64_t SynthNeighbor(const SynthView& p,
+                                                  uint64_t node_id, int64_t j) {
+  const uint64_t x = node_id - 1;
+  uint64_t bits = 0, h = 0;
+  for (int i = 0; i < p.scale; ++i) {
+    if ((i & 3) == 0) h = SynthHash(p.seed, node_id, (uint64_t)j, 1 + (i >> 2));
+    const uint32_t slice = (uint32_t)(h >> (16 * (i & 3))) & 0xFFFFu;
+    const uint32_t thr = ((x >> i) & 1) ? 13653u : 16384u;
+    if (slice < thr) bits |= 1ULL << i;
+  }
+  return bits % (uint64_t)p.n_nodes + 1;
+}
+
+__device__ __forceinline__ float SynthWeight(const SynthView& p, uint64_t node_id,
+                                             int64_t j) {
+  if (!p.weighted) return 1.0f;
+  const uint64_t h = SynthHash(p.seed, node_id, (uint64_t)j, 0);
+  const float x = __fmul_rn((float)(uint32_t)(h >> 40), 1.0f / 16777216.0f);
+  return __fadd_rn(0.5f, __fmul_rn(7.5f, x));
+}
+
+// row r of a shard holds node id = id_base + r * id_stride
+__global__ void SynthDegreeKernel(SynthView p, uint64_t id_base, uint64_t id_stride,
+                                  int64_t n_rows, int64_t* deg) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n_rows) deg[r] = SynthDegree(p, id_base + (uint64_t)r * id_stride);
+}
+
+// One lane per edge: neighbour id + RAW weight (prefix summed afterwards).
+__global__ __launch_bounds__(256) void SynthEdgeKernel(
+    SynthView p, uint64_t id_base, uint64_t id_stride, int64_t n_rows,
+    const int64_t* row_ptr, int64_t n_edges, uint64_t* nbr, float* w) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_edges;
+       e += stride) {
+    // row = last r with row_ptr[r] <= e
+    int64_t lo = 0, hi = n_rows;
+    while (hi - lo > 1) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (row_ptr[mid] <= e) lo = mid; else hi = mid;
+    }
+    const uint64_t id = id_base + (uint64_t)lo * id_stride;
+    const int64_t j = e - row_ptr[lo];
+    nbr[e] = SynthNeighbor(p, id, j);
+    w[e] = SynthWeight(p, id, j);
+  }
+}
+
+// Node::Init (core/graph/node.cc:46-66) per row: strictly sequential f32
+// running sum across all types, per-type sums, row_meta record.  One lane per
+// row (the adds of a row cannot be reordered without changing the floats).
+__global__ __launch_bounds__(256) void SynthPrefixKernel(
+    int32_t T, int32_t meta_stride, int64_t n_rows, const int64_t* row_ptr,
+    float* w_inout, uint8_t* row_meta) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rows) return;
+  const int64_t b = row_ptr[r];
+  const int64_t deg = row_ptr[r + 1] - b;
+  uint8_t* rec = row_meta + r * (int64_t)meta_stride;
+  *reinterpret_cast<int64_t*>(rec) = b;
+  int32_t* type_end = reinterpret_cast<int32_t*>(rec + 8);
+  float* type_prefix = reinterpret_cast<float*>(rec + 8 + 4 * T);
+  float sum = 0.f, tsum = 0.f, tw = 0.f;
+  int32_t t = 0;
+  for (int64_t j = 0; j < deg; ++j) {
+    while (t < T - 1 && j >= deg * (t + 1) / T) {
+      type_end[t] = (int32_t)j;
+      tsum = __fadd_rn(tsum, tw); type_prefix[t] = tsum; tw = 0.f; ++t;
+    }
+    const float w = w_inout[b + j];
+    sum = __fadd_rn(sum, w);
+    tw = __fadd_rn(tw, w);
+    w_inout[b + j] = sum;
+  }
+  while (t < T) {
+    type_end[t] = (int32_t)deg;
+    tsum = __fadd_rn(tsum, tw); type_prefix[t] = tsum; tw = 0.f; ++t;
+  }
+}
+
+int BuildGraphSynthetic(const euler_gpu_synth_params* sp, int device,
+                        int32_t partitions, int32_t shard_index, int32_t shards,
+                        euler_gpu_graph** out) {
+  if (!sp || !out) return Fail(EULER_GPU_EINVAL, "graph_create_synthetic: null");
+  if (sp->n_nodes <= 0 || sp->n_types <= 0 || sp->n_types > kMaxListedTypes ||
+      sp->scale <= 0 || sp->scale > 40)
+    return Fail(EULER_GPU_EINVAL, "graph_create_synthetic: bad parameters");
+  if (shards <= 0 || shard_index < 0 || shard_index >= shards || partitions <= 0)
+    return Fail(EULER_GPU_EINVAL, "graph_create_synthetic: bad shard arguments");
+  if (shards > 1 && partitions % shards != 0)
+    return Fail(EULER_GPU_EINVAL,
+                "graph_create_synthetic: partitions must be a multiple of shards");
+  EG_HIP(hipSetDevice(device));
+  // owner(id) = (id % P) % S = id % S when S | P: the shard owns the ids
+  // congruent to shard_index mod S -> strided identity id map.
+  const uint64_t stride = (uint64_t)shards;
+  uint64_t base = (uint64_t)shard_index;
+  if (base == 0) base = stride;       // ids start at 1
+  if (shards == 1) base = 1;
+  const int64_t n_rows =
+      base > (uint64_t)sp->n_nodes ? 0
+                                   : (int64_t)(((uint64_t)sp->n_nodes - base) / stride + 1);
+  GraphBuilder b;
+  b.g->device = device;
+  GraphView& v = b.g->view;
+  const int32_t T = sp->n_types;
+  v.T = T; v.meta_stride = 8 + 8 * T; v.n_rows = n_rows;
+  v.map_mode = 0; v.id_base = base; v.id_stride = stride; v.row_id = nullptr;
+  v.has_zero_nbr = 0;
+  SynthView p{};
+  p.seed = sp->seed; p.n_nodes = sp->n_nodes; p.scale = sp->scale;
+  p.n_types = sp->n_types; p.weighted = sp->weighted;
+  std::memcpy(p.deg_table, sp->deg_table, sizeof(p.deg_table));
+  const int block = 256;
+  // degrees -> row_ptr (temporary, dropped after row_meta is built)
+  int64_t* deg = nullptr;
+  int64_t* row_ptr = nullptr;
+  EG_HIP(hipMalloc((void**)&deg, (size_t)(n_rows + 1) * 8 + 16));
+  EG_HIP(hipMalloc((void**)&row_ptr, (size_t)(n_rows + 1) * 8 + 16));
+  EG_HIP(hipMemset(deg, 0, (size_t)(n_rows + 1) * 8));
+  if (n_rows > 0)
+    hipLaunchKernelGGL(SynthDegreeKernel, dim3((n_rows + block - 1) / block),
+                       dim3(block), 0, 0, p, base, stride, n_rows, deg);
+  {
+    size_t tmp_bytes = 0;
+    EG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, deg, row_ptr,
+                                            n_rows + 1));
+    void* tmp = nullptr;
+    EG_HIP(hipMalloc(&tmp, tmp_bytes + 16));
+    EG_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, deg, row_ptr,
+                                            n_rows + 1));
+    EG_HIP(hipDeviceSynchronize());
+    EG_HIP(hipFree(tmp));
+  }
+  int64_t E = 0;
+  EG_HIP(hipMemcpy(&E, row_ptr + n_rows, 8, hipMemcpyDeviceToHost));
+  EG_HIP(hipFree(deg));
+  v.n_edges = E;
+  uint64_t* nbr = b.Alloc<uint64_t>((size_t)E);
+  float* pw = b.Alloc<float>((size_t)E);
+  uint8_t* meta = b.Alloc<uint8_t>((size_t)n_rows * v.meta_stride + 16);
+  if (b.rc != EULER_GPU_OK) { (void)hipFree(row_ptr); DestroyGraph(b.g.release()); return b.rc; }
+  if (E > 0)
+    hipLaunchKernelGGL(SynthEdgeKernel, dim3(GridFor(E, block)), dim3(block), 0, 0,
+                       p, base, stride, n_rows, row_ptr, E, nbr, pw);
+  if (n_rows > 0)
+    hipLaunchKernelGGL(SynthPrefixKernel, dim3((n_rows + block - 1) / block),
+                       dim3(block), 0, 0, T, v.meta_stride, n_rows, row_ptr, pw,
+                       meta);
+  EG_HIP(hipGetLastError());
+  EG_HIP(hipDeviceSynchronize());
+  EG_HIP(hipFree(row_ptr));
+  v.nbr = nbr; v.prefix_w = pw; v.row_meta = meta;
+  b.g->has_sampler = false;   // uniform roots are drawn by the caller
+  b.g->n_node_types = 1;
+  *out = b.g.release();
+  return EULER_GPU_OK;
+}
+
+// rows -> host (spot checks)
+__global__ void ExportMetaKernel(GraphView g, const uint64_t* ids, int64_t n,
+                                 int64_t* deg, int64_t* src_off, int32_t* type_end,
+                                 float* type_prefix) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t row = FindRow(g, ids[i]);
+  if (row < 0) {
+    deg[i] = 0; src_off[i] = 0;
+    for (int t = 0; t < g.T; ++t) { type_end[i * g.T + t] = 0; type_prefix[i * g.T + t] = 0.f; }
+    return;
+  }
+  const RowMeta m = LoadRowMeta(g, row);
+  deg[i] = m.type_end[g.T - 1];
+  src_off[i] = m.row_ptr;
+  for (int t = 0; t < g.T; ++t) {
+    type_end[i * g.T + t] = m.type_end[t];
+    type_prefix[i * g.T + t] = m.type_prefix[t];
+  }
+}
+
+}  // namespace euler_gpu
+
+using namespace euler_gpu;
+
+extern "C" {
+
+const char* euler_gpu_last_error(void) { return g_last_error.c_str(); }
+const char* euler_gpu_version(void) { return "euler-gpu 0.1 (gfx950)"; }
+
+int euler_gpu_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int euler_gpu_graph_create(const euler_gpu_host_csr* csr, int device,
+                           euler_gpu_graph** out) {
+  return BuildGraphFromHost(csr, device, 1, 0, 1, out);
+}
+
+int euler_gpu_graph_create_shard(const euler_gpu_host_csr* csr, int device,
+                                 int32_t partitions, int32_t shard_index,
+                                 int32_t shards, euler_gpu_graph** out) {
+  return BuildGraphFromHost(csr, device, partitions, shard_index, shards, out);
+}
+
+int euler_gpu_graph_create_synthetic(const euler_gpu_synth_params* p, int device,
+                                     int32_t partitions, int32_t shard_index,
+                                     int32_t shards, euler_gpu_graph** out) {
+  return BuildGraphSynthetic(p, device, partitions, shard_index, shards, out);
+}
+
+int euler_gpu_graph_load(const char* data_path, int device, int32_t shard_index,
+                         int32_t shards, euler_gpu_graph** out) {
+  if (!data_path || !out) return Fail(EULER_GPU_EINVAL, "graph_load: null argument");
+  std::vector<uint64_t> row_id, nbr;
+  std::vector<int64_t> row_ptr;
+  std::vector<int32_t> type_end, node_type;
+  std::vector<float> prefix_w, type_prefix, node_weight;
+  int32_t n_et = 0, n_nt = 0, partitions = 1;
+  int rc = LoadDatDirectory(data_path, shard_index, shards, &row_id, &row_ptr,
+                            &type_end, &nbr, &prefix_w, &type_prefix, &node_type,
+                            &node_weight, &n_et, &n_nt, &partitions);
+  if (rc != EULER_GPU_OK) return rc;
+  euler_gpu_host_csr c{};
+  c.n_rows = (int64_t)row_id.size();
+  c.n_edge_types = n_et; c.n_node_types = n_nt;
+  c.row_id = row_id.data(); c.row_ptr = row_ptr.data();
+  c.type_end = type_end.data(); c.nbr = nbr.data();
+  c.prefix_w = prefix_w.data(); c.type_prefix = type_prefix.data();
+  c.node_type = node_type.data(); c.node_weight = node_weight.data();
+  // the loader already kept only this shard's partitions
+  return BuildGraphFromHost(&c, device, 1, 0, 1, out);
+}
+
+namespace {
+struct DatOwner {
+  std::vector<uint64_t> row_id, nbr;
+  std::vector<int64_t> row_ptr;
+  std::vector<int32_t> type_end, node_type;
+  std::vector<float> prefix_w, type_prefix, node_weight;
+};
+}  // namespace
+
+int euler_gpu_dat_open(const char* data_path, int32_t shard_index,
+                       int32_t shards, euler_gpu_host_csr* csr,
+                       int32_t* partitions, void** owner) {
+  if (!data_path || !csr || !owner)
+    return Fail(EULER_GPU_EINVAL, "dat_open: null argument");
+  std::unique_ptr<DatOwner> o(new DatOwner());
+  int32_t n_et = 0, n_nt = 0, parts = 1;
+  int rc = LoadDatDirectory(data_path, shard_index, shards, &o->row_id,
+                            &o->row_ptr, &o->type_end, &o->nbr, &o->prefix_w,
+                            &o->type_prefix, &o->node_type, &o->node_weight,
+                            &n_et, &n_nt, &parts);
+  if (rc != EULER_GPU_OK) return rc;
+  std::memset(csr, 0, sizeof(*csr));
+  csr->n_rows = (int64_t)o->row_id.size();
+  csr->n_edge_types = n_et;
+  csr->n_node_types = n_nt;
+  csr->row_id = o->row_id.data();
+  csr->row_ptr = o->row_ptr.data();
+  csr->type_end = o->type_end.data();
+  csr->nbr = o->nbr.data();
+  csr->prefix_w = o->prefix_w.data();
+  csr->type_prefix = o->type_prefix.data();
+  csr->node_type = o->node_type.data();
+  csr->node_weight = o->node_weight.data();
+  if (partitions) *partitions = parts;
+  *owner = o.release();
+  return EULER_GPU_OK;
+}
+
+void euler_gpu_dat_close(void* owner) { delete static_cast<DatOwner*>(owner); }
+
+void euler_gpu_graph_destroy(euler_gpu_graph* g) {
+  {
+    std::lock_guard<std::mutex> lk(g_default_mu);
+    if (g == g_default_graph) g_default_graph = nullptr;
+  }
+  DestroyGraph(g);
+}
+
+int64_t euler_gpu_graph_num_nodes(const euler_gpu_graph* g) { return g ? g->view.n_rows : -1; }
+int64_t euler_gpu_graph_num_edges(const euler_gpu_graph* g) { return g ? g->view.n_edges : -1; }
+int32_t euler_gpu_graph_num_edge_types(const euler_gpu_graph* g) { return g ? g->view.T : -1; }
+int32_t euler_gpu_graph_num_node_types(const euler_gpu_graph* g) { return g ? g->n_node_types : -1; }
+int euler_gpu_graph_device(const euler_gpu_graph* g) { return g ? g->device : -1; }
+int64_t euler_gpu_graph_bytes(const euler_gpu_graph* g) { return g ? g->bytes : -1; }
+
+int euler_gpu_graph_node_weight_sums(const euler_gpu_graph* g, float* out_host) {
+  if (!g || !out_host) return Fail(EULER_GPU_EINVAL, "node_weight_sums: null");
+  for (size_t i = 0; i < g->node_weight_sums.size(); ++i)
+    out_host[i] = g->node_weight_sums[i];
+  return EULER_GPU_OK;
+}
+
+int euler_gpu_graph_export_rows(const euler_gpu_graph* g, const uint64_t* ids_host,
+                                int64_t n, int64_t* row_ptr_host,
+                                int32_t* type_end_host, uint64_t* nbr_host,
+                                float* prefix_w_host, float* type_prefix_host) {
+  if (!g) return Fail(EULER_GPU_ENOGRAPH, "export_rows: null graph");
+  if (n < 0 || !row_ptr_host) return Fail(EULER_GPU_EINVAL, "export_rows: bad args");
+  EG_HIP(hipSetDevice(g->device));
+  row_ptr_host[0] = 0;
+  if (n == 0) return EULER_GPU_OK;
+  const int32_t T = g->view.T;
+  uint64_t* ids_dev = nullptr;
+  int64_t* deg_dev = nullptr;
+  EG_HIP(hipMalloc((void**)&ids_dev, n * 8));
+  EG_HIP(hipMalloc((void**)&deg_dev, n * 16 + (size_t)n * T * 8));
+  int64_t* off_dev = deg_dev + n;
+  int32_t* te_dev = (int32_t*)(off_dev + n);
+  float* tp_dev = (float*)(te_dev + n * T);
+  EG_HIP(hipMemcpy(ids_dev, ids_host, n * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(ExportMetaKernel, dim3((n + 255) / 256), dim3(256), 0, 0,
+                     g->view, ids_dev, n, deg_dev, off_dev, te_dev, tp_dev);
+  std::vector<int64_t> deg(n), off(n);
+  EG_HIP(hipMemcpy(deg.data(), deg_dev, n * 8, hipMemcpyDeviceToHost));
+  EG_HIP(hipMemcpy(off.data(), off_dev, n * 8, hipMemcpyDeviceToHost));
+  for (int64_t i = 0; i < n; ++i) row_ptr_host[i + 1] = row_ptr_host[i] + deg[i];
+  if (nbr_host) {
+    EG_HIP(hipMemcpy(type_end_host, te_dev, (size_t)n * T * 4, hipMemcpyDeviceToHost));
+    EG_HIP(hipMemcpy(type_prefix_host, tp_dev, (size_t)n * T * 4, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n; ++i) {
+      if (deg[i] == 0) continue;
+      EG_HIP(hipMemcpy(nbr_host + row_ptr_host[i], g->view.nbr + off[i],
+                       (size_t)deg[i] * 8, hipMemcpyDeviceToHost));
+      EG_HIP(hipMemcpy(prefix_w_host + row_ptr_host[i], g->view.prefix_w + off[i],
+                       (size_t)deg[i] * 4, hipMemcpyDeviceToHost));
+    }
+  }
+  EG_HIP(hipFree(ids_dev));
+  EG_HIP(hipFree(deg_dev));
+  return EULER_GPU_OK;
+}
+
+// tf_euler/utils/init_query_proxy.cc:19-37: "k=v;k=v".  Returns false on a
+// malformed string exactly as the reference; a load failure also returns
+// false (the reference would FATAL inside QueryProxy::Init).
+bool InitQueryProxy(const char* conf) {
+  if (!conf) return false;
+  std::map<std::string, std::string> cfg;
+  std::stringstream ss(conf);
+  std::string item;
+  bool any = false;
+  while (std::getline(ss, item, ';')) {
+    if (item.empty()) continue;
+    const size_t eq = item.find('=');
+    if (eq == std::string::npos || eq == 0 || eq + 1 >= item.size() ||
+        item.find('=', eq + 1) != std::string::npos) {
+      SetError("InitQueryProxy: malformed item '" + item + "'");
+      return false;
+    }
+    cfg[item.substr(0, eq)] = item.substr(eq + 1);
+    any = true;
+  }
+  if (!any) return false;
+  const std::string mode = cfg.count("mode") ? cfg["mode"] : "local";
+  if (mode != "local") {
+    SetError("InitQueryProxy: only mode=local is served by the GPU backend "
+             "(remote mode = gRPC shard servers is replaced by in-process "
+             "multi-GPU sharding)");
+    return false;
+  }
+  if (!cfg.count("data_path")) {
+    SetError("InitQueryProxy: data_path missing");
+    return false;
+  }
+  const int device = cfg.count("device") ? atoi(cfg["device"].c_str()) : 0;
+  const int shard_idx = cfg.count("shard_idx") ? atoi(cfg["shard_idx"].c_str()) : 0;
+  const int shard_num = cfg.count("shard_num") ? atoi(cfg["shard_num"].c_str()) : 1;
+  euler_gpu_graph* g = nullptr;
+  if (euler_gpu_graph_load(cfg["data_path"].c_str(), device, shard_idx, shard_num,
+                           &g) != EULER_GPU_OK)
+    return false;
+  std::lock_guard<std::mutex> lk(g_default_mu);
+  if (g_default_graph) DestroyGraph(g_default_graph);
+  g_default_graph = g;
+  return true;
+}
+
+euler_gpu_graph* euler_gpu_default_graph(void) {
+  std::lock_guard<std::mutex> lk(g_default_mu);
+  return g_default_graph;
+}
+
+}  // extern "C"

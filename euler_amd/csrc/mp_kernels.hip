@@ -1,0 +1,544 @@
+// Message-passing (scatter / gather), ID_UNIQUE / *_GATHER and shard
+// split / merge kernels for gfx950, plus their C-ABI entry points.
+//
+// rocPRIM (via hipCUB) is used only for the two plain library primitives this
+// file needs - a device-wide exclusive scan and a stable radix sort; every
+// domain kernel is written here.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include "common.h"
+
+namespace euler_gpu {
+
+int ExclusiveScanI64(hipStream_t stream, const int64_t* in, int64_t* out,
+                     int64_t n) {
+  size_t tmp_bytes = 0;
+  EG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, in, out, (int)n,
+                                          stream));
+  void* tmp = nullptr;
+  EG_HIP(hipMallocAsync(&tmp, tmp_bytes + 16, stream));
+  EG_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, in, out, (int)n,
+                                          stream));
+  EG_HIP(hipFreeAsync(tmp, stream));
+  return EULER_GPU_OK;
+}
+
+// ------------------------------------------------------------------------
+// MPGather (tf_euler/kernels/gather_op.cc:46-51): out[i,:] = params[idx[i],:]
+// Rows are D contiguous floats: lanes sweep a row with 16-byte accesses when
+// D % 4 == 0 (coalesced 1 KiB per wave-instruction), several rows per wave
+// when D is small.
+// ------------------------------------------------------------------------
+template <typename V>
+__global__ __launch_bounds__(256) void GatherRowsKernel(
+    const V* __restrict__ params, const int32_t* __restrict__ idx, int64_t e,
+    int64_t dv, V* __restrict__ out) {
+  const int64_t total = e * dv;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < total;
+       x += stride) {
+    const int64_t i = x / dv;
+    const int64_t c = x - i * dv;
+    out[x] = params[(int64_t)idx[i] * dv + c];
+  }
+}
+
+// ------------------------------------------------------------------------
+// MPScatterAdd / MPScatterMax (tf_euler/kernels/scatter_op.cc:32-92).
+// The reference loops over the E updates in input order; fp32 addition is not
+// associative, so the result depends on that order.  We keep it: updates are
+// grouped by destination with a STABLE sort (identity when the indices are
+// already non-decreasing, the common case for sampled blocks), and each output
+// element then accumulates its segment sequentially in input order - a
+// segment-reduce with one lane per output column, bit-identical to the
+// reference, no atomics, zero-/-1e9-fill fused into the same pass.
+// ------------------------------------------------------------------------
+__global__ void IsSortedKernel(const int32_t* idx, int64_t e, int32_t* flag) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i + 1 < e && idx[i] > idx[i + 1]) *flag = 0;
+}
+
+__global__ void IotaKernel(uint32_t* v, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = (uint32_t)i;
+}
+
+__device__ __forceinline__ int64_t LowerBound(const int32_t* a, int64_t n,
+                                              int32_t key) {
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (a[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// One workgroup row-slot per output row: blockDim = (64, 4): 4 rows per block,
+// 64 lanes over the columns.  keys[] = destination of the p-th update in
+// grouped order; perm[p] = original update index (nullptr = identity).
+template <bool IS_MAX>
+__global__ __launch_bounds__(256) void SegmentReduceKernel(
+    const float* __restrict__ upd, const int32_t* __restrict__ keys,
+    const uint32_t* __restrict__ perm, int64_t e, int64_t d, int32_t size,
+    float* __restrict__ out) {
+  const int lane = threadIdx.x;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.y + threadIdx.y; r < size;
+       r += (int64_t)gridDim.x * blockDim.y) {
+    const int64_t b = LowerBound(keys, e, (int32_t)r);
+    const int64_t en = LowerBound(keys, e, (int32_t)r + 1);
+    for (int64_t c = lane; c < d; c += 64) {
+      float acc = IS_MAX ? (float)-1e9 : 0.f;   // scatter_op.cc:47,78
+      for (int64_t p = b; p < en; ++p) {
+        const int64_t src = perm ? (int64_t)perm[p] : p;
+        const float v = upd[src * d + c];
+        if (IS_MAX) { if (v > acc) acc = v; }
+        else acc = __fadd_rn(acc, v);
+      }
+      out[r * d + c] = acc;
+    }
+  }
+}
+
+template <bool IS_MAX>
+static int ScatterImpl(hipStream_t st, const float* upd, const int32_t* idx,
+                       int64_t e, int64_t d, int32_t size, float* out) {
+  if (e < 0 || d < 0 || size < 0) return Fail(EULER_GPU_EINVAL, "scatter: bad shape");
+  if (size == 0 || d == 0) return EULER_GPU_OK;
+  if (!out || (e > 0 && (!upd || !idx)))
+    return Fail(EULER_GPU_EINVAL, "scatter: null buffer");
+  const int32_t* keys = idx;
+  const uint32_t* perm = nullptr;
+  void* scratch = nullptr;
+  if (e > 1) {
+    int32_t* flag = nullptr;
+    EG_HIP(hipMallocAsync((void**)&flag, 16, st));
+    int32_t one = 1, sorted = 1;
+    EG_HIP(hipMemcpyAsync(flag, &one, 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(IsSortedKernel, dim3((e + 255) / 256), dim3(256), 0, st, idx,
+                       e, flag);
+    EG_HIP(hipMemcpyAsync(&sorted, flag, 4, hipMemcpyDeviceToHost, st));
+    EG_HIP(hipStreamSynchronize(st));
+    EG_HIP(hipFreeAsync(flag, st));
+    if (!sorted) {
+      // stable sort of (destination, original position)
+      const size_t n = (size_t)e;
+      const size_t bytes = n * (4 + 4 + 4 + 4) + 64;
+      EG_HIP(hipMallocAsync(&scratch, bytes, st));
+      int32_t* keys_out = (int32_t*)scratch;
+      uint32_t* vals_in = (uint32_t*)(keys_out + n);
+      uint32_t* vals_out = vals_in + n;
+      hipLaunchKernelGGL(IotaKernel, dim3((e + 255) / 256), dim3(256), 0, st,
+                         vals_in, e);
+      size_t tmp_bytes = 0;
+      EG_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, idx, keys_out,
+                                                vals_in, vals_out, (int)e, 0, 32,
+                                                st));
+      void* tmp = nullptr;
+      EG_HIP(hipMallocAsync(&tmp, tmp_bytes + 16, st));
+      EG_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, idx, keys_out,
+                                                vals_in, vals_out, (int)e, 0, 32,
+                                                st));
+      EG_HIP(hipFreeAsync(tmp, st));
+      keys = keys_out;
+      perm = vals_out;
+    }
+  }
+  const dim3 block(64, 4);
+  int64_t blocks = ((int64_t)size + 3) / 4;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(SegmentReduceKernel<IS_MAX>, dim3((unsigned)blocks), block, 0,
+                     st, upd, keys, perm, e, d, size, out);
+  EG_HIP(hipGetLastError());
+  if (scratch) EG_HIP(hipFreeAsync(scratch, st));
+  return EULER_GPU_OK;
+}
+
+// ------------------------------------------------------------------------
+// ID_UNIQUE (core/kernels/id_unique_op.cc:35-64): first-occurrence order.
+// Open-addressing table in HBM: every id claims a slot (atomicCAS on the key)
+// and atomicMin's its position into the slot; the ids whose position equals
+// the slot minimum are the first occurrences, and an exclusive scan of that
+// flag over positions IS the reference's first-occurrence rank.
+// The all-ones key is the empty marker; an id equal to it uses a side slot.
+// ------------------------------------------------------------------------
+constexpr uint64_t kEmptyKey = ~0ULL;
+
+struct UniqueTable {
+  unsigned long long* keys;   // [cap + 1]; slot `cap` is the side slot
+  uint32_t* minpos;           // [cap + 1]
+  int32_t* rank;              // [cap + 1]
+  uint64_t mask;              // cap - 1
+};
+
+__global__ void UniqueInsertKernel(const uint64_t* ids, int64_t n, UniqueTable t,
+                                   uint32_t* slot_of) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t id = ids[i];
+  uint64_t h;
+  if (id == kEmptyKey) {
+    h = t.mask + 1;
+  } else {
+    h = Mix64(id) & t.mask;
+    for (;;) {
+      const unsigned long long old =
+          atomicCAS(&t.keys[h], (unsigned long long)kEmptyKey,
+                    (unsigned long long)id);
+      if (old == kEmptyKey || old == id) break;
+      h = (h + 1) & t.mask;
+    }
+  }
+  atomicMin(&t.minpos[h], (uint32_t)i);
+  slot_of[i] = (uint32_t)h;
+}
+
+__global__ void UniqueFlagKernel(int64_t n, UniqueTable t, const uint32_t* slot_of,
+                                 int64_t* is_first) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) is_first[i] = t.minpos[slot_of[i]] == (uint32_t)i ? 1 : 0;
+}
+
+__global__ void UniqueEmitKernel(const uint64_t* ids, int64_t n, UniqueTable t,
+                                 const uint32_t* slot_of, const int64_t* is_first,
+                                 const int64_t* rank, uint64_t* unique_ids) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && is_first[i]) {
+    unique_ids[rank[i]] = ids[i];
+    t.rank[slot_of[i]] = (int32_t)rank[i];
+  }
+}
+
+__global__ void UniqueGatherIdxKernel(int64_t n, UniqueTable t,
+                                      const uint32_t* slot_of,
+                                      int32_t* gather_idx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) gather_idx[i] = t.rank[slot_of[i]];
+}
+
+// IDX_GATHER (core/kernels/idx_gather_op.cc:33-55)
+__global__ void SegLenKernel(const int32_t* idx, const int32_t* gather_idx,
+                             int64_t n, int64_t* len) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const int32_t a = gather_idx[i] * 2;
+    len[i] = idx[a + 1] - idx[a];
+  }
+}
+
+__global__ void EmitIdxKernel(const int64_t* len, const int64_t* off, int64_t n,
+                              int32_t* out_idx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    out_idx[2 * i] = (int32_t)off[i];
+    out_idx[2 * i + 1] = (int32_t)(off[i] + len[i]);
+  }
+}
+
+// DATA_GATHER (core/kernels/data_gather_op.cc:33-46): 16 lanes per output row.
+template <typename V>
+__global__ __launch_bounds__(256) void DataGatherKernel(
+    const V* data, const int32_t* idx, const int32_t* gather_idx,
+    const int32_t* out_idx, int64_t n, V* out) {
+  const int sub = threadIdx.x & 15;
+  const int64_t g0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int64_t ng = ((int64_t)gridDim.x * blockDim.x) >> 4;
+  for (int64_t i = g0; i < n; i += ng) {
+    const int32_t a = gather_idx[i] * 2;
+    const int32_t b = idx[a], e = idx[a + 1];
+    const int32_t o = out_idx[2 * i];
+    for (int32_t p = sub; p < e - b; p += 16) out[o + p] = data[b + p];
+  }
+}
+
+// ------------------------------------------------------------------------
+// ID_SPLIT (core/kernels/id_split_op.cc:46-99): stable bucket by owner.
+// Stability (the reference pushes ids in input order) comes from ranking each
+// id inside its bucket with a per-wave ballot prefix + a per-block exclusive
+// offset obtained from a scan of per-block histograms.
+// ------------------------------------------------------------------------
+constexpr int kSplitBlock = 256;
+constexpr int kMaxShards = 64;
+
+__device__ __forceinline__ int32_t OwnerOf(uint64_t id, int32_t partitions,
+                                           int32_t shards) {
+  return (int32_t)((id % (uint64_t)partitions) % (uint64_t)shards);
+}
+
+__global__ __launch_bounds__(kSplitBlock) void SplitHistKernel(
+    const uint64_t* ids, int64_t n, int32_t partitions, int32_t shards,
+    int64_t* block_hist /* [shards, n_blocks] */) {
+  __shared__ int32_t hist[kMaxShards];
+  if (threadIdx.x < kMaxShards) hist[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * kSplitBlock + threadIdx.x;
+  if (i < n) atomicAdd(&hist[OwnerOf(ids[i], partitions, shards)], 1);
+  __syncthreads();
+  if ((int)threadIdx.x < shards)
+    block_hist[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = hist[threadIdx.x];
+}
+
+__global__ __launch_bounds__(kSplitBlock) void SplitScatterKernel(
+    const uint64_t* ids, int64_t n, int32_t partitions, int32_t shards,
+    const int64_t* block_off /* scanned [shards, n_blocks] */,
+    uint64_t* shard_ids, int32_t* merge_idx) {
+  __shared__ int32_t wave_cnt[kSplitBlock / 64][kMaxShards];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * kSplitBlock + threadIdx.x;
+  const bool live = i < n;
+  const uint64_t id = live ? ids[i] : 0;
+  const int32_t own = live ? OwnerOf(id, partitions, shards) : -1;
+  // rank of this lane among the lanes of its wave with the same owner
+  int32_t rank_in_wave = 0, wave_total = 0;
+  for (int32_t s = 0; s < shards; ++s) {
+    const unsigned long long m = __ballot(own == s);
+    if (own == s) {
+      rank_in_wave = __popcll(m & ((1ULL << lane) - 1));
+    }
+    if (lane == 0) wave_cnt[wave][s] = __popcll(m);
+  }
+  (void)wave_total;
+  __syncthreads();
+  if (live) {
+    int32_t before = 0;
+    for (int w = 0; w < wave; ++w) before += wave_cnt[w][own];
+    const int64_t pos =
+        block_off[(int64_t)own * gridDim.x + blockIdx.x] + before + rank_in_wave;
+    shard_ids[pos] = id;
+    merge_idx[pos] = (int32_t)i;
+  }
+}
+
+// IDX_MERGE / DATA_MERGE with fixed-size rows (idx_merge_op.cc:61-77,
+// data_merge_op.cc:44-67): out[merge_idx[j]] = in[j], 4-byte granularity.
+__global__ __launch_bounds__(256) void MergeRowsKernel(
+    const uint32_t* in, const int32_t* merge_idx, int64_t n_rows, int64_t row_words,
+    uint32_t* out) {
+  const int64_t total = n_rows * row_words;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < total;
+       x += stride) {
+    const int64_t j = x / row_words, c = x - j * row_words;
+    out[(int64_t)merge_idx[j] * row_words + c] = in[x];
+  }
+}
+
+}  // namespace euler_gpu
+
+using namespace euler_gpu;
+
+extern "C" {
+
+int euler_gpu_gather(void* stream, const float* params_dev,
+                     const int32_t* indices_dev, int64_t e, int64_t d,
+                     int64_t n_params, float* out_dev) {
+  (void)n_params;
+  if (e < 0 || d < 0) return Fail(EULER_GPU_EINVAL, "gather: bad shape");
+  if (e == 0 || d == 0) return EULER_GPU_OK;
+  if (!params_dev || !indices_dev || !out_dev)
+    return Fail(EULER_GPU_EINVAL, "gather: null buffer");
+  hipStream_t st = (hipStream_t)stream;
+  const int block = 256;
+  const bool vec4 = (d % 4 == 0) && (((uintptr_t)params_dev | (uintptr_t)out_dev) % 16 == 0);
+  if (vec4) {
+    hipLaunchKernelGGL(GatherRowsKernel<float4>, dim3(GridFor(e * d / 4, block)),
+                       dim3(block), 0, st, (const float4*)params_dev, indices_dev,
+                       e, d / 4, (float4*)out_dev);
+  } else {
+    hipLaunchKernelGGL(GatherRowsKernel<float>, dim3(GridFor(e * d, block)),
+                       dim3(block), 0, st, params_dev, indices_dev, e, d, out_dev);
+  }
+  EG_HIP(hipGetLastError());
+  return EULER_GPU_OK;
+}
+
+int euler_gpu_scatter_add(void* stream, const float* updates_dev,
+                          const int32_t* indices_dev, int64_t e, int64_t d,
+                          int32_t size, float* out_dev) {
+  return ScatterImpl<false>((hipStream_t)stream, updates_dev, indices_dev, e, d,
+                            size, out_dev);
+}
+
+int euler_gpu_scatter_max(void* stream, const float* updates_dev,
+                          const int32_t* indices_dev, int64_t e, int64_t d,
+                          int32_t size, float* out_dev) {
+  return ScatterImpl<true>((hipStream_t)stream, updates_dev, indices_dev, e, d,
+                           size, out_dev);
+}
+
+int euler_gpu_id_unique(void* stream, const uint64_t* ids_dev, int64_t n,
+                        uint64_t* unique_dev, int32_t* gather_idx_dev,
+                        int64_t* n_unique_host) {
+  if (n < 0) return Fail(EULER_GPU_EINVAL, "id_unique: bad n");
+  if (n == 0) { if (n_unique_host) *n_unique_host = 0; return EULER_GPU_OK; }
+  if (n >= (1LL << 31)) return Fail(EULER_GPU_EINVAL, "id_unique: n >= 2^31");
+  if (!ids_dev || !unique_dev || !gather_idx_dev)
+    return Fail(EULER_GPU_EINVAL, "id_unique: null buffer");
+  hipStream_t st = (hipStream_t)stream;
+  uint64_t cap = 64;
+  while (cap < (uint64_t)n * 2) cap <<= 1;
+  const size_t slots = cap + 1;
+  const size_t bytes = slots * (8 + 4 + 4) + (size_t)n * (4 + 8 + 8) + 256;
+  uint8_t* buf = nullptr;
+  EG_HIP(hipMallocAsync((void**)&buf, bytes, st));
+  UniqueTable t;
+  t.keys = (unsigned long long*)buf;
+  int64_t* is_first = (int64_t*)(t.keys + slots);
+  int64_t* rank = is_first + n;
+  t.minpos = (uint32_t*)(rank + n);
+  t.rank = (int32_t*)(t.minpos + slots);
+  uint32_t* slot_of = (uint32_t*)(t.rank + slots);
+  t.mask = cap - 1;
+  EG_HIP(hipMemsetAsync(t.keys, 0xFF, slots * 8, st));
+  EG_HIP(hipMemsetAsync(t.minpos, 0xFF, slots * 4, st));
+  const int block = 256;
+  const dim3 grid((unsigned)((n + block - 1) / block));
+  hipLaunchKernelGGL(UniqueInsertKernel, grid, dim3(block), 0, st, ids_dev, n, t,
+                     slot_of);
+  hipLaunchKernelGGL(UniqueFlagKernel, grid, dim3(block), 0, st, n, t, slot_of,
+                     is_first);
+  int rc = ExclusiveScanI64(st, is_first, rank, n);
+  if (rc != EULER_GPU_OK) return rc;
+  hipLaunchKernelGGL(UniqueEmitKernel, grid, dim3(block), 0, st, ids_dev, n, t,
+                     slot_of, is_first, rank, unique_dev);
+  hipLaunchKernelGGL(UniqueGatherIdxKernel, grid, dim3(block), 0, st, n, t, slot_of,
+                     gather_idx_dev);
+  EG_HIP(hipGetLastError());
+  int64_t tail[2];
+  EG_HIP(hipMemcpyAsync(&tail[0], rank + (n - 1), 8, hipMemcpyDeviceToHost, st));
+  EG_HIP(hipMemcpyAsync(&tail[1], is_first + (n - 1), 8, hipMemcpyDeviceToHost, st));
+  EG_HIP(hipStreamSynchronize(st));
+  EG_HIP(hipFreeAsync(buf, st));
+  if (n_unique_host) *n_unique_host = tail[0] + tail[1];
+  return EULER_GPU_OK;
+}
+
+int euler_gpu_idx_gather(void* stream, const int32_t* idx_dev,
+                         const int32_t* gather_idx_dev, int64_t n,
+                         int32_t* out_idx_dev, int64_t* total_host) {
+  if (n < 0) return Fail(EULER_GPU_EINVAL, "idx_gather: bad n");
+  if (n == 0) { if (total_host) *total_host = 0; return EULER_GPU_OK; }
+  hipStream_t st = (hipStream_t)stream;
+  int64_t* len = nullptr;
+  EG_HIP(hipMallocAsync((void**)&len, (2 * n + 2) * 8, st));
+  int64_t* off = len + n + 1;
+  const int block = 256;
+  const dim3 grid((unsigned)((n + block - 1) / block));
+  hipLaunchKernelGGL(SegLenKernel, grid, dim3(block), 0, st, idx_dev,
+                     gather_idx_dev, n, len);
+  int rc = ExclusiveScanI64(st, len, off, n);
+  if (rc != EULER_GPU_OK) return rc;
+  hipLaunchKernelGGL(EmitIdxKernel, grid, dim3(block), 0, st, len, off, n,
+                     out_idx_dev);
+  int32_t last[2];
+  EG_HIP(hipMemcpyAsync(last, out_idx_dev + 2 * (n - 1), 8, hipMemcpyDeviceToHost, st));
+  EG_HIP(hipStreamSynchronize(st));
+  EG_HIP(hipFreeAsync(len, st));
+  if (total_host) *total_host = last[1];
+  return EULER_GPU_OK;
+}
+
+int euler_gpu_data_gather(void* stream, const void* data_dev, int32_t elem_size,
+                          const int32_t* idx_dev, const int32_t* gather_idx_dev,
+                          const int32_t* out_idx_dev, int64_t n, void* out_dev) {
+  if (n < 0) return Fail(EULER_GPU_EINVAL, "data_gather: bad n");
+  if (n == 0) return EULER_GPU_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int block = 256;
+  const int grid = GridFor(n * 16, block);
+  if (elem_size == 8) {
+    hipLaunchKernelGGL(DataGatherKernel<uint64_t>, dim3(grid), dim3(block), 0, st,
+                       (const uint64_t*)data_dev, idx_dev, gather_idx_dev,
+                       out_idx_dev, n, (uint64_t*)out_dev);
+  } else if (elem_size == 4) {
+    hipLaunchKernelGGL(DataGatherKernel<uint32_t>, dim3(grid), dim3(block), 0, st,
+                       (const uint32_t*)data_dev, idx_dev, gather_idx_dev,
+                       out_idx_dev, n, (uint32_t*)out_dev);
+  } else if (elem_size == 1) {
+    hipLaunchKernelGGL(DataGatherKernel<uint8_t>, dim3(grid), dim3(block), 0, st,
+                       (const uint8_t*)data_dev, idx_dev, gather_idx_dev,
+                       out_idx_dev, n, (uint8_t*)out_dev);
+  } else {
+    return Fail(EULER_GPU_EINVAL, "data_gather: elem_size must be 1, 4 or 8");
+  }
+  EG_HIP(hipGetLastError());
+  return EULER_GPU_OK;
+}
+
+int euler_gpu_id_split(void* stream, const uint64_t* ids_dev, int64_t n,
+                       int32_t partitions, int32_t shards,
+                       int64_t* shard_off_host, uint64_t* shard_ids_dev,
+                       int32_t* merge_idx_dev) {
+  if (n < 0 || partitions <= 0 || shards <= 0 || shards > kMaxShards ||
+      !shard_off_host)
+    return Fail(EULER_GPU_EINVAL, "id_split: bad arguments (shards <= 64)");
+  for (int s = 0; s <= shards; ++s) shard_off_host[s] = 0;
+  if (n == 0) return EULER_GPU_OK;
+  if (n >= (1LL << 31)) return Fail(EULER_GPU_EINVAL, "id_split: n >= 2^31");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n_blocks = (n + kSplitBlock - 1) / kSplitBlock;
+  const int64_t cells = n_blocks * shards;
+  int64_t* hist = nullptr;
+  EG_HIP(hipMallocAsync((void**)&hist, (2 * cells + 2) * 8, st));
+  int64_t* off = hist + cells + 1;
+  hipLaunchKernelGGL(SplitHistKernel, dim3((unsigned)n_blocks), dim3(kSplitBlock), 0,
+                     st, ids_dev, n, partitions, shards, hist);
+  int rc = ExclusiveScanI64(st, hist, off, cells);
+  if (rc != EULER_GPU_OK) return rc;
+  hipLaunchKernelGGL(SplitScatterKernel, dim3((unsigned)n_blocks), dim3(kSplitBlock),
+                     0, st, ids_dev, n, partitions, shards, off, shard_ids_dev,
+                     merge_idx_dev);
+  EG_HIP(hipGetLastError());
+  // shard s starts at the scanned offset of its first block cell
+  std::vector<int64_t> starts(shards);
+  for (int s = 0; s < shards; ++s)
+    EG_HIP(hipMemcpyAsync(&starts[s], off + (int64_t)s * n_blocks, 8,
+                          hipMemcpyDeviceToHost, st));
+  EG_HIP(hipStreamSynchronize(st));
+  EG_HIP(hipFreeAsync(hist, st));
+  for (int s = 0; s < shards; ++s) shard_off_host[s] = starts[s];
+  shard_off_host[shards] = n;
+  return EULER_GPU_OK;
+}
+
+int euler_gpu_merge_rows(void* stream, const void* in_dev,
+                         const int32_t* merge_idx_dev, int64_t n_rows,
+                         int64_t row_bytes, void* out_dev) {
+  if (n_rows < 0 || row_bytes <= 0 || row_bytes % 4 != 0)
+    return Fail(EULER_GPU_EINVAL, "merge_rows: row_bytes must be a multiple of 4");
+  if (n_rows == 0) return EULER_GPU_OK;
+  const int block = 256;
+  const int64_t words = row_bytes / 4;
+  hipLaunchKernelGGL(MergeRowsKernel, dim3(GridFor(n_rows * words, block)),
+                     dim3(block), 0, (hipStream_t)stream, (const uint32_t*)in_dev,
+                     merge_idx_dev, n_rows, words, (uint32_t*)out_dev);
+  EG_HIP(hipGetLastError());
+  return EULER_GPU_OK;
+}
+
+int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
+                                const float* shard_weight_host, int32_t shards,
+                                int32_t* split_cnt_host) {
+  // core/kernels/sample_node_split_op.cc:57-85 with the type weights already
+  // summed per shard; remainder draws use RNG domain SPLIT.
+  if (count < 0 || shards <= 0 || !shard_weight_host || !split_cnt_host)
+    return Fail(EULER_GPU_EINVAL, "sample_node_split: bad arguments");
+  std::vector<int32_t> nz;
+  int32_t remain = count;
+  const float sw1 = shard_weight_host[shards];
+  if (std::fabs(sw1 - 0.0) < 0.0000001)
+    return Fail(EULER_GPU_EEMPTY, "sample_node_split: node type sum weight is zero");
+  for (int32_t i = 0; i < shards; ++i) {
+    const float sw0 = shard_weight_host[i];
+    split_cnt_host[i] = (int32_t)std::floor(count * sw0 / sw1);
+    if (sw0 > 0) nz.push_back(i);
+    remain -= split_cnt_host[i];
+  }
+  for (uint64_t d = 0; remain > 0; ++d, --remain) {
+    const double u = RngDraw(seed, call_id, kDomainSplit, 0, d);
+    split_cnt_host[nz[(size_t)std::floor(u * nz.size())]] += 1;
+  }
+  return EULER_GPU_OK;
+}
+
+}  // extern "C"

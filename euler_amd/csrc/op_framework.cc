@@ -1,0 +1,398 @@
+// Implementation of the plugin-API mirror and of the hot-path op kernels
+// registered under the reference's op names.  See op_framework.h.
+#include "op_framework.h"
+
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <cstdio>
+#include <memory>
+
+namespace euler {
+
+namespace {
+
+void LogError(const std::string& msg) {
+  // EULER_LOG(ERROR) semantics: log, leave outputs unallocated, return.
+  fprintf(stderr, "[euler_gpu] ERROR %s\n", msg.c_str());
+}
+
+struct Registry {
+  std::mutex mu;
+  std::unordered_map<std::string, OpKernelRegistrar::Factory> factories;
+  std::unordered_map<std::string, std::unique_ptr<OpKernel>> kernels;
+};
+
+Registry* GlobalRegistry() {
+  static Registry* r = new Registry();
+  return r;
+}
+
+// RAII device staging buffer
+struct DevBuf {
+  void* p = nullptr;
+  explicit DevBuf(size_t bytes) { if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) p = nullptr; }
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+bool GetIntArg(const NodeDef& nd, int i, OpKernelContext* ctx,
+               std::vector<int32_t>* out) {
+  Tensor* t = nullptr;
+  if ((int)nd.inputs.size() <= i || ctx->tensor(nd.inputs[i], &t) != 0) return false;
+  out->assign(t->Raw<int32_t>(), t->Raw<int32_t>() + t->NumElements());
+  return true;
+}
+
+}  // namespace
+
+size_t SizeOfType(DataType t) {
+  switch (t) {
+    case kInt8: case kUInt8: case kBool: case kString: return 1;
+    case kInt16: case kUInt16: return 2;
+    case kInt32: case kUInt32: case kFloat: return 4;
+    default: return 8;
+  }
+}
+
+Tensor::Tensor(const TensorShape& shape, DataType type)
+    : shape_(shape), type_(type),
+      data_(malloc(shape.NumElements() * SizeOfType(type) + 16)) {}
+Tensor::~Tensor() { free(data_); }
+
+std::string OutputName(const NodeDef& node_def, int i) {
+  return node_def.name + ":" + std::to_string(i);
+}
+
+OpKernelContext::~OpKernelContext() {
+  for (auto& kv : tensor_map_) delete kv.second;
+}
+
+int OpKernelContext::Allocate(const std::string& name, const TensorShape& shape,
+                              DataType type, Tensor** tensor) {
+  std::lock_guard<std::mutex> lk(mu_);
+  if (tensor_map_.count(name)) return -1;        // already exists
+  *tensor = new Tensor(shape, type);
+  tensor_map_[name] = *tensor;
+  return 0;
+}
+
+int OpKernelContext::tensor(const std::string& name, Tensor** tensor) {
+  std::lock_guard<std::mutex> lk(mu_);
+  auto it = tensor_map_.find(name);
+  if (it == tensor_map_.end()) return -1;
+  *tensor = it->second;
+  return 0;
+}
+
+int OpKernelContext::Deallocate(const std::string& name) {
+  std::lock_guard<std::mutex> lk(mu_);
+  auto it = tensor_map_.find(name);
+  if (it == tensor_map_.end()) return -1;
+  delete it->second;
+  tensor_map_.erase(it);
+  return 0;
+}
+
+euler_gpu_graph* OpKernelContext::graph() const {
+  return graph_ ? graph_ : euler_gpu_default_graph();
+}
+
+void AsyncOpKernel::Compute(const NodeDef& node_def, OpKernelContext* ctx) {
+  std::mutex mu;
+  std::unique_lock<std::mutex> lk(mu);
+  bool done = false;
+  AsyncCompute(node_def, ctx, [&] { done = true; });
+  (void)lk;
+  (void)done;   // the GPU kernels complete synchronously inside AsyncCompute
+}
+
+OpKernelRegistrar::OpKernelRegistrar(const std::string& name, Factory factory) {
+  Registry* r = GlobalRegistry();
+  std::lock_guard<std::mutex> lk(r->mu);
+  if (r->factories.count(name)) {
+    // op_kernel.cc:203-207: duplicate registration is fatal
+    fprintf(stderr, "[euler_gpu] FATAL op kernel '%s' registered twice\n",
+            name.c_str());
+    abort();
+  }
+  r->factories[name] = factory;
+}
+
+int LookupOpKernel(const std::string& name) {
+  Registry* r = GlobalRegistry();
+  std::lock_guard<std::mutex> lk(r->mu);
+  return r->factories.count(name) ? 0 : -1;
+}
+
+int CreateOpKernel(const std::string& name, OpKernel** kernel) {
+  Registry* r = GlobalRegistry();
+  std::lock_guard<std::mutex> lk(r->mu);
+  auto k = r->kernels.find(name);
+  if (k == r->kernels.end()) {
+    auto f = r->factories.find(name);
+    if (f == r->factories.end()) return -1;
+    k = r->kernels.emplace(name, std::unique_ptr<OpKernel>(f->second(name))).first;
+  }
+  *kernel = k->second.get();
+  return 0;
+}
+
+// ---------------------------------------------------------------- kernels
+
+// API_SAMPLE_NB (core/kernels/sample_neighbor_op.cc:37-147, no-condition
+// path): inputs node_ids (uint64), edge_types (int32), count (int32[1]),
+// default_node (ignored, :134); outputs "<name>:0" idx [n,2] int32,
+// ":1" ids uint64, ":2" weights float, ":3" types int32 (FillNeighbor).
+class GpuSampleNeighborOp : public OpKernel {
+ public:
+  explicit GpuSampleNeighborOp(const std::string& name) : OpKernel(name) {}
+  void Compute(const NodeDef& nd, OpKernelContext* ctx) override {
+    if (nd.inputs.size() < 4) {
+      LogError("Argment 'node_ids', 'edge_types', 'count', 'default_node' must be specified!");
+      return;
+    }
+    Tensor* ids_t = nullptr;
+    if (ctx->tensor(nd.inputs[0], &ids_t) != 0) { LogError("Invalid argment 'node_ids'"); return; }
+    std::vector<int32_t> edge_types, arg;
+    if (!GetIntArg(nd, 1, ctx, &edge_types)) { LogError("Invalid argment 'edge_types'"); return; }
+    if (!GetIntArg(nd, 2, ctx, &arg) || arg.empty()) { LogError("Invalid argment 'count'"); return; }
+    euler_gpu_graph* g = ctx->graph();
+    if (!g) { LogError("API_SAMPLE_NB: no graph initialised"); return; }
+    const int64_t n = ids_t->NumElements();
+    const int32_t count = arg[0];
+    const int64_t total = n * count;
+    (void)hipSetDevice(euler_gpu_graph_device(g));
+    DevBuf d_ids(n * 8), d_oid(total * 8), d_ow(total * 4), d_ot(total * 4);
+    if (!d_ids.p || !d_oid.p || !d_ow.p || !d_ot.p) { LogError("API_SAMPLE_NB: device allocation failed"); return; }
+    (void)hipMemcpy(d_ids.p, ids_t->Raw<uint64_t>(), n * 8, hipMemcpyHostToDevice);
+    const int rc = euler_gpu_sample_neighbor(
+        g, nullptr, ctx->seed(), ctx->NextCallId(), d_ids.as<uint64_t>(), n, nullptr,
+        1, edge_types.data(), (int32_t)edge_types.size(), count,
+        EULER_GPU_LAYOUT_CORE, 0, d_oid.as<uint64_t>(), d_ow.as<float>(),
+        d_ot.as<int32_t>(), nullptr);
+    if (rc != 0) { LogError(std::string("API_SAMPLE_NB: ") + euler_gpu_last_error()); return; }
+    Tensor *idx = nullptr, *oid = nullptr, *ow = nullptr, *ot = nullptr;
+    if (ctx->Allocate(OutputName(nd, 0), {(size_t)n, 2}, kInt32, &idx) != 0 ||
+        ctx->Allocate(OutputName(nd, 1), {(size_t)total}, kUInt64, &oid) != 0 ||
+        ctx->Allocate(OutputName(nd, 2), {(size_t)total}, kFloat, &ow) != 0 ||
+        ctx->Allocate(OutputName(nd, 3), {(size_t)total}, kInt32, &ot) != 0) {
+      LogError("Allocate output tensor failed!");
+      return;
+    }
+    for (int64_t i = 0; i < n; ++i) {
+      idx->Raw<int32_t>()[2 * i] = (int32_t)(i * count);
+      idx->Raw<int32_t>()[2 * i + 1] = (int32_t)((i + 1) * count);
+    }
+    (void)hipMemcpy(oid->Raw<uint64_t>(), d_oid.p, total * 8, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(ow->Raw<float>(), d_ow.p, total * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(ot->Raw<int32_t>(), d_ot.p, total * 4, hipMemcpyDeviceToHost);
+  }
+};
+REGISTER_OP_KERNEL("API_SAMPLE_NB", GpuSampleNeighborOp);
+
+// API_SAMPLE_NODE (core/kernels/sample_node_op.cc:37-137): inputs node_type
+// (int32[k]), count (int32); output "<name>:0" [count] int64.  A size
+// mismatch logs and produces no output (:118-122).
+class GpuSampleNodeOp : public OpKernel {
+ public:
+  explicit GpuSampleNodeOp(const std::string& name) : OpKernel(name) {}
+  void Compute(const NodeDef& nd, OpKernelContext* ctx) override {
+    if (nd.inputs.size() != 2) { LogError("Invalid input arguments for SampleNode"); return; }
+    std::vector<int32_t> types, cnt;
+    if (!GetIntArg(nd, 0, ctx, &types)) { LogError("Retrieve node_type input for SampleNode failed!"); return; }
+    if (!GetIntArg(nd, 1, ctx, &cnt) || cnt.empty()) { LogError("Retrieve count input for SampleNode failed!"); return; }
+    euler_gpu_graph* g = ctx->graph();
+    if (!g) { LogError("API_SAMPLE_NODE: no graph initialised"); return; }
+    const int32_t count = cnt[0];
+    (void)hipSetDevice(euler_gpu_graph_device(g));
+    DevBuf d_out((size_t)count * 8);
+    const int rc = euler_gpu_sample_node(g, nullptr, ctx->seed(), ctx->NextCallId(),
+                                         types.data(), (int32_t)types.size(), count,
+                                         d_out.as<uint64_t>());
+    if (rc != 0) {
+      LogError("Expect sample count: " + std::to_string(count) + ", real got:0 (" +
+               euler_gpu_last_error() + ")");
+      return;
+    }
+    Tensor* out = nullptr;
+    if (ctx->Allocate(OutputName(nd, 0), {(size_t)count}, kInt64, &out) != 0) {
+      LogError("Allocate output tensor failed!");
+      return;
+    }
+    (void)hipMemcpy(out->Raw<int64_t>(), d_out.p, (size_t)count * 8, hipMemcpyDeviceToHost);
+  }
+};
+REGISTER_OP_KERNEL("API_SAMPLE_NODE", GpuSampleNodeOp);
+
+// ID_UNIQUE (core/kernels/id_unique_op.cc:35-64), node-id branch.
+class GpuIdUniqueOp : public OpKernel {
+ public:
+  explicit GpuIdUniqueOp(const std::string& name) : OpKernel(name) {}
+  void Compute(const NodeDef& nd, OpKernelContext* ctx) override {
+    Tensor* ids_t = nullptr;
+    if (nd.inputs.empty() || ctx->tensor(nd.inputs[0], &ids_t) != 0) { LogError("ID_UNIQUE: missing input"); return; }
+    const int64_t n = ids_t->NumElements();
+    DevBuf d_ids(n * 8), d_uq(n * 8), d_gi(n * 4);
+    (void)hipMemcpy(d_ids.p, ids_t->Raw<uint64_t>(), n * 8, hipMemcpyHostToDevice);
+    int64_t nu = 0;
+    if (euler_gpu_id_unique(nullptr, d_ids.as<uint64_t>(), n, d_uq.as<uint64_t>(),
+                            d_gi.as<int32_t>(), &nu) != 0) {
+      LogError(std::string("ID_UNIQUE: ") + euler_gpu_last_error());
+      return;
+    }
+    Tensor *uq = nullptr, *gi = nullptr;
+    ctx->Allocate(OutputName(nd, 0), {(size_t)nu}, kUInt64, &uq);
+    ctx->Allocate(OutputName(nd, 1), {(size_t)n}, kInt32, &gi);
+    if (!uq || !gi) { LogError("ID_UNIQUE: allocate failed"); return; }
+    (void)hipMemcpy(uq->Raw<uint64_t>(), d_uq.p, nu * 8, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(gi->Raw<int32_t>(), d_gi.p, n * 4, hipMemcpyDeviceToHost);
+  }
+};
+REGISTER_OP_KERNEL("ID_UNIQUE", GpuIdUniqueOp);
+
+// IDX_GATHER (core/kernels/idx_gather_op.cc:33-55).
+class GpuIdxGatherOp : public OpKernel {
+ public:
+  explicit GpuIdxGatherOp(const std::string& name) : OpKernel(name) {}
+  void Compute(const NodeDef& nd, OpKernelContext* ctx) override {
+    Tensor *idx_t = nullptr, *gi_t = nullptr;
+    if (nd.inputs.size() < 2 || ctx->tensor(nd.inputs[0], &idx_t) != 0 ||
+        ctx->tensor(nd.inputs[1], &gi_t) != 0) { LogError("IDX_GATHER: missing input"); return; }
+    const int64_t n = gi_t->NumElements();
+    DevBuf d_idx(idx_t->TotalBytes()), d_gi(n * 4), d_out(n * 8);
+    (void)hipMemcpy(d_idx.p, idx_t->Raw<int32_t>(), idx_t->TotalBytes(), hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_gi.p, gi_t->Raw<int32_t>(), n * 4, hipMemcpyHostToDevice);
+    int64_t total = 0;
+    if (euler_gpu_idx_gather(nullptr, d_idx.as<int32_t>(), d_gi.as<int32_t>(), n,
+                             d_out.as<int32_t>(), &total) != 0) {
+      LogError(std::string("IDX_GATHER: ") + euler_gpu_last_error());
+      return;
+    }
+    Tensor* out = nullptr;
+    if (ctx->Allocate(OutputName(nd, 0), {(size_t)n, 2}, kInt32, &out) != 0) return;
+    (void)hipMemcpy(out->Raw<int32_t>(), d_out.p, n * 8, hipMemcpyDeviceToHost);
+  }
+};
+REGISTER_OP_KERNEL("IDX_GATHER", GpuIdxGatherOp);
+
+// DATA_GATHER (core/kernels/data_gather_op.cc:33-80).
+class GpuDataGatherOp : public OpKernel {
+ public:
+  explicit GpuDataGatherOp(const std::string& name) : OpKernel(name) {}
+  void Compute(const NodeDef& nd, OpKernelContext* ctx) override {
+    Tensor *data_t = nullptr, *idx_t = nullptr, *gi_t = nullptr;
+    if (nd.inputs.size() < 3 || ctx->tensor(nd.inputs[0], &data_t) != 0 ||
+        ctx->tensor(nd.inputs[1], &idx_t) != 0 ||
+        ctx->tensor(nd.inputs[2], &gi_t) != 0) { LogError("DATA_GATHER: missing input"); return; }
+    const DataType type = data_t->Type();
+    if (type != kUInt64 && type != kFloat && type != kInt8 && type != kInt32) {
+      LogError("error data type");
+      return;
+    }
+    const int64_t n = gi_t->NumElements();
+    const int32_t es = (int32_t)SizeOfType(type);
+    DevBuf d_data(data_t->TotalBytes()), d_idx(idx_t->TotalBytes()), d_gi(n * 4), d_oidx(n * 8);
+    (void)hipMemcpy(d_data.p, data_t->Raw<char>(), data_t->TotalBytes(), hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_idx.p, idx_t->Raw<int32_t>(), idx_t->TotalBytes(), hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_gi.p, gi_t->Raw<int32_t>(), n * 4, hipMemcpyHostToDevice);
+    int64_t total = 0;
+    if (euler_gpu_idx_gather(nullptr, d_idx.as<int32_t>(), d_gi.as<int32_t>(), n,
+                             d_oidx.as<int32_t>(), &total) != 0) { LogError(euler_gpu_last_error()); return; }
+    DevBuf d_out((size_t)total * es);
+    if (euler_gpu_data_gather(nullptr, d_data.p, es, d_idx.as<int32_t>(),
+                              d_gi.as<int32_t>(), d_oidx.as<int32_t>(), n, d_out.p) != 0) {
+      LogError(euler_gpu_last_error());
+      return;
+    }
+    Tensor* out = nullptr;
+    if (ctx->Allocate(OutputName(nd, 0), {(size_t)total}, type, &out) != 0) return;
+    (void)hipMemcpy(out->Raw<char>(), d_out.p, (size_t)total * es, hipMemcpyDeviceToHost);
+  }
+};
+REGISTER_OP_KERNEL("DATA_GATHER", GpuDataGatherOp);
+
+// API_GET_NB_NODE (core/kernels/get_neighbor_op.cc, no-condition path).
+class GpuGetNeighborOp : public OpKernel {
+ public:
+  explicit GpuGetNeighborOp(const std::string& name) : OpKernel(name) {}
+  void Compute(const NodeDef& nd, OpKernelContext* ctx) override {
+    if (nd.inputs.size() < 2) { LogError("Argments 'node_ids' and 'edge_type' must be specified!"); return; }
+    Tensor* ids_t = nullptr;
+    std::vector<int32_t> et;
+    if (ctx->tensor(nd.inputs[0], &ids_t) != 0) { LogError("Invalid argment 'node_ids'"); return; }
+    if (!GetIntArg(nd, 1, ctx, &et)) { LogError("Invalid argment 'edge_types'"); return; }
+    euler_gpu_graph* g = ctx->graph();
+    if (!g) { LogError("API_GET_NB_NODE: no graph initialised"); return; }
+    const int64_t n = ids_t->NumElements();
+    (void)hipSetDevice(euler_gpu_graph_device(g));
+    DevBuf d_ids(n * 8), d_idx(n * 8);
+    (void)hipMemcpy(d_ids.p, ids_t->Raw<uint64_t>(), n * 8, hipMemcpyHostToDevice);
+    int64_t total = 0;
+    if (euler_gpu_get_full_neighbor(g, nullptr, d_ids.as<uint64_t>(), n, et.data(),
+                                    (int32_t)et.size(), d_idx.as<int32_t>(), &total,
+                                    nullptr, nullptr, nullptr) != 0) { LogError(euler_gpu_last_error()); return; }
+    DevBuf d_oid(total * 8), d_ow(total * 4), d_ot(total * 4);
+    if (euler_gpu_get_full_neighbor(g, nullptr, d_ids.as<uint64_t>(), n, et.data(),
+                                    (int32_t)et.size(), d_idx.as<int32_t>(), &total,
+                                    d_oid.as<uint64_t>(), d_ow.as<float>(),
+                                    d_ot.as<int32_t>()) != 0) { LogError(euler_gpu_last_error()); return; }
+    (void)hipDeviceSynchronize();
+    Tensor *idx = nullptr, *oid = nullptr, *ow = nullptr, *ot = nullptr;
+    ctx->Allocate(OutputName(nd, 0), {(size_t)n, 2}, kInt32, &idx);
+    ctx->Allocate(OutputName(nd, 1), {(size_t)total}, kUInt64, &oid);
+    ctx->Allocate(OutputName(nd, 2), {(size_t)total}, kFloat, &ow);
+    ctx->Allocate(OutputName(nd, 3), {(size_t)total}, kInt32, &ot);
+    if (!idx || !oid || !ow || !ot) { LogError("Allocate output tensor failed!"); return; }
+    (void)hipMemcpy(idx->Raw<int32_t>(), d_idx.p, n * 8, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(oid->Raw<uint64_t>(), d_oid.p, total * 8, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(ow->Raw<float>(), d_ow.p, total * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(ot->Raw<int32_t>(), d_ot.p, total * 4, hipMemcpyDeviceToHost);
+  }
+};
+REGISTER_OP_KERNEL("API_GET_NB_NODE", GpuGetNeighborOp);
+
+}  // namespace euler
+
+extern "C" {
+
+int euler_op_registered(const char* op_name) {
+  return euler::LookupOpKernel(op_name) == 0 ? 1 : 0;
+}
+
+int64_t euler_op_run_sample_nb(euler_gpu_graph* g, uint64_t seed,
+                               const uint64_t* node_ids, int64_t n,
+                               const int32_t* edge_types, int32_t k,
+                               int32_t count, int32_t* idx_out, uint64_t* id_out,
+                               float* w_out, int32_t* t_out) {
+  using namespace euler;
+  OpKernelContext ctx;
+  ctx.SetGraph(g);
+  ctx.SetSeed(seed);
+  Tensor *t_ids = nullptr, *t_et = nullptr, *t_cnt = nullptr, *t_def = nullptr;
+  ctx.Allocate("nodes", {(size_t)n}, kUInt64, &t_ids);
+  ctx.Allocate("edge_types", {(size_t)k}, kInt32, &t_et);
+  ctx.Allocate("nb_count", {1}, kInt32, &t_cnt);
+  ctx.Allocate("default_node", {1}, kInt32, &t_def);
+  memcpy(t_ids->Raw<uint64_t>(), node_ids, (size_t)n * 8);
+  if (k) memcpy(t_et->Raw<int32_t>(), edge_types, (size_t)k * 4);
+  *t_cnt->Raw<int32_t>() = count;
+  *t_def->Raw<int32_t>() = -1;
+  NodeDef nd{"API_SAMPLE_NB,0", "API_SAMPLE_NB",
+             {"nodes", "edge_types", "nb_count", "default_node"}};
+  OpKernel* kernel = nullptr;
+  if (CreateOpKernel("API_SAMPLE_NB", &kernel) != 0) return -1;
+  kernel->Compute(nd, &ctx);
+  Tensor *idx = nullptr, *oid = nullptr, *ow = nullptr, *ot = nullptr;
+  if (ctx.tensor(OutputName(nd, 0), &idx) != 0 || ctx.tensor(OutputName(nd, 1), &oid) != 0 ||
+      ctx.tensor(OutputName(nd, 2), &ow) != 0 || ctx.tensor(OutputName(nd, 3), &ot) != 0)
+    return -2;   // op logged an error and produced no output
+  memcpy(idx_out, idx->Raw<int32_t>(), idx->TotalBytes());
+  memcpy(id_out, oid->Raw<uint64_t>(), oid->TotalBytes());
+  memcpy(w_out, ow->Raw<float>(), ow->TotalBytes());
+  memcpy(t_out, ot->Raw<int32_t>(), ot->TotalBytes());
+  return oid->NumElements();
+}
+
+}  // extern "C"

@@ -1,0 +1,152 @@
+// Host-side mirror of the reference's plugin API for the ops on the hot path
+// (SURVEY.md §8b): euler::Tensor / OpKernel / OpKernelContext /
+// REGISTER_OP_KERNEL with the shapes of euler/core/framework/op_kernel.h:38-130
+// and tensor.h:57-118, minus protobuf: a node definition is reduced to
+// {name, op, inputs[]} (the only DAGNodeProto fields the hot-path kernels read:
+// core/kernels/sample_neighbor_op.cc:37-60, common.cc OutputName).
+//
+// The GPU kernels register under the reference's own op names
+// (API_SAMPLE_NB, API_SAMPLE_NODE, ID_UNIQUE, IDX_GATHER, DATA_GATHER,
+// API_GET_NB_NODE, ID_SPLIT), so a build of the reference that links this
+// library INSTEAD of the corresponding core/kernels/*.cc files dispatches the
+// same DAG nodes to the MI355X.  Tensors are host buffers (malloc, uninitialised
+// like the reference's, op_kernel.cc:92-105); device memory stays behind the
+// C ABI.
+#pragma once
+
+#include <stdint.h>
+
+#include <functional>
+#include <map>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/euler_gpu.h"
+
+namespace euler {
+
+enum DataType : int32_t {   // euler/core/framework/types.h:26-39
+  kInt8 = 0, kInt16, kInt32, kInt64, kUInt8, kUInt16, kUInt32, kUInt64,
+  kFloat, kDouble, kBool, kString
+};
+size_t SizeOfType(DataType t);
+
+class TensorShape {
+ public:
+  TensorShape() {}
+  TensorShape(std::initializer_list<size_t> dims) : dims_(dims) {}
+  explicit TensorShape(const std::vector<size_t>& dims) : dims_(dims) {}
+  const std::vector<size_t>& Dims() const { return dims_; }
+  size_t Size() const { return dims_.size(); }
+  size_t NumElements() const {
+    size_t n = 1;
+    for (auto d : dims_) n *= d;
+    return n;
+  }
+ private:
+  std::vector<size_t> dims_;
+};
+
+class Tensor {
+ public:
+  Tensor(const TensorShape& shape, DataType type);
+  ~Tensor();
+  Tensor(const Tensor&) = delete;
+  Tensor& operator=(const Tensor&) = delete;
+  template <typename T> T* Raw() const { return reinterpret_cast<T*>(data_); }
+  const TensorShape& Shape() const { return shape_; }
+  int NumElements() const { return (int)shape_.NumElements(); }
+  DataType Type() const { return type_; }
+  size_t TotalBytes() const { return shape_.NumElements() * SizeOfType(type_); }
+ private:
+  TensorShape shape_;
+  DataType type_;
+  void* data_;
+};
+
+// The fields of DAGNodeProto the hot-path kernels use.
+struct NodeDef {
+  std::string name;                 // outputs are "<name>:<i>"
+  std::string op;
+  std::vector<std::string> inputs;  // tensor names looked up in the context
+};
+std::string OutputName(const NodeDef& node_def, int i);
+
+class OpKernelContext {
+ public:
+  ~OpKernelContext();
+  // 0 on success (the reference returns Status; ok() == (rc == 0)).
+  int Allocate(const std::string& name, const TensorShape& shape, DataType type,
+               Tensor** tensor);
+  int tensor(const std::string& name, Tensor** tensor);
+  int Deallocate(const std::string& name);
+  // Sampling reproducibility (not in the reference: its RNG is unseedable).
+  void SetSeed(uint64_t seed) { seed_ = seed; }
+  uint64_t seed() const { return seed_; }
+  uint32_t NextCallId() { return call_id_++; }
+  void SetGraph(euler_gpu_graph* g) { graph_ = g; }
+  euler_gpu_graph* graph() const;
+ private:
+  std::mutex mu_;
+  std::unordered_map<std::string, Tensor*> tensor_map_;
+  uint64_t seed_ = 0;
+  uint32_t call_id_ = 0;
+  euler_gpu_graph* graph_ = nullptr;
+};
+
+class OpKernel {
+ public:
+  explicit OpKernel(const std::string& name) : name_(name) {}
+  virtual ~OpKernel() {}
+  // stateless + thread-safe, results persisted in ctx (op_kernel.h:40-49)
+  virtual void Compute(const NodeDef& node_def, OpKernelContext* ctx) = 0;
+  const std::string& name() const { return name_; }
+ private:
+  std::string name_;
+};
+
+class AsyncOpKernel : public OpKernel {
+ public:
+  using OpKernel::OpKernel;
+  typedef std::function<void()> DoneCallback;
+  void Compute(const NodeDef& node_def, OpKernelContext* ctx) override;
+  virtual void AsyncCompute(const NodeDef& node_def, OpKernelContext* ctx,
+                            DoneCallback callback) = 0;
+};
+
+class OpKernelRegistrar {
+ public:
+  typedef OpKernel* (*Factory)(const std::string& name);
+  OpKernelRegistrar(const std::string& name, Factory factory);
+};
+
+// 0 = found / created (cached singleton per op name, op_kernel.cc:217-231).
+int LookupOpKernel(const std::string& name);
+int CreateOpKernel(const std::string& name, OpKernel** kernel);
+
+#define REGISTER_OP_KERNEL(name, cls) \
+  REGISTER_OP_KERNEL_UNIQ_HELPER(__COUNTER__, name, cls)
+#define REGISTER_OP_KERNEL_UNIQ_HELPER(counter, name, cls) \
+  REGISTER_OP_KERNEL_UNIQ(counter, name, cls)
+#define REGISTER_OP_KERNEL_UNIQ(counter, name, cls)                      \
+  static ::euler::OpKernelRegistrar registrar__##counter##__obj(         \
+      name, [](const std::string& op) -> ::euler::OpKernel* {            \
+        return new cls(op);                                              \
+      });
+
+}  // namespace euler
+
+// C view of the registry, used by tests and by non-C++ hosts.
+extern "C" {
+int euler_op_registered(const char* op_name);
+// Runs one op on host buffers: builds a context with the given named int/uint64
+// input tensors, executes, and copies output `out_index` into `out` (up to
+// out_capacity bytes).  Returns the output's byte size or a negative code.
+int64_t euler_op_run_sample_nb(euler_gpu_graph* g, uint64_t seed,
+                               const uint64_t* node_ids, int64_t n,
+                               const int32_t* edge_types, int32_t k,
+                               int32_t count, int32_t* idx_out, uint64_t* id_out,
+                               float* w_out, int32_t* t_out);
+}

@@ -1,0 +1,337 @@
+"""Device-resident Euler graph + the sampling / message-passing operators on it.
+
+Host-side mirror of what the reference reaches through
+`QueryProxy::RunAsyncGremlin` for the hot path (tf_euler/kernels/*.cc): every
+method enqueues hand-written HIP kernels of libeuler_gpu.so on the current
+torch stream and returns torch tensors living in HBM.  torch is plumbing here
+(device memory, streams); the computation is in euler_amd/csrc.
+"""
+import ctypes as C
+import math
+import threading
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, lib
+
+_I32 = C.POINTER(C.c_int32)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _i32_array(values):
+    a = np.ascontiguousarray(np.asarray(values, dtype=np.int32).reshape(-1))
+    return a, a.ctypes.data_as(_I32), int(a.size)
+
+
+def _as_i64_cuda(x, device):
+    if not torch.is_tensor(x):
+        x = torch.as_tensor(np.asarray(x).astype(np.int64, copy=False))
+    if x.dtype != torch.int64:
+        x = x.to(torch.int64)
+    return x.to(device).contiguous()
+
+
+def _np(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def synth_params(seed, n_nodes, n_edges, n_types=1, weighted=True, scale=None):
+    """Parameters of the deterministic synthetic power-law graph (RMAT
+    marginals a,b,c,d = .57,.19,.19,.05, minimum degree 1).
+    deg_table[z] = expected extra out-degree of a node whose (id-1) has z one
+    bits, normalised so the edge total is n_edges."""
+    if scale is None:
+        scale = max(1, int(math.ceil(math.log2(max(n_nodes, 2)))))
+    # number of x in [0, n_nodes) with popcount(x & mask) == z, by digit DP
+    cnt = [0] * 65
+    mask_bits = scale
+    hi = n_nodes >> mask_bits           # full cycles of the low `scale` bits
+    lo = n_nodes & ((1 << mask_bits) - 1)
+    if hi:
+        for z in range(mask_bits + 1):
+            cnt[z] += hi * math.comb(mask_bits, z)
+    ones = 0
+    for b in range(mask_bits - 1, -1, -1):
+        if (lo >> b) & 1:
+            for z in range(b + 1):
+                cnt[ones + z] += math.comb(b, z)
+            ones += 1
+    p = _lib.SynthParams()
+    p.seed = seed
+    p.n_nodes = n_nodes
+    p.n_edges_target = n_edges
+    p.scale = scale
+    p.n_types = n_types
+    p.weighted = 1 if weighted else 0
+    wz = [(0.76 ** (scale - z)) * (0.24 ** z) for z in range(scale + 1)]
+    norm = sum(c * w for c, w in zip(cnt, wz))
+    extra = max(0.0, float(n_edges - n_nodes))
+    for z in range(64):
+        p.deg_table[z] = extra * wz[z] / norm if (z <= scale and norm > 0) else 0.0
+    return p
+
+
+class Graph:
+    """Immutable graph in HBM (CSR + row metadata + alias tables)."""
+
+    def __init__(self, handle, device, meta=None):
+        self._h = handle
+        self.device = torch.device("cuda", device)
+        self.device_index = device
+        self.seed = 0
+        self._call_id = 0
+        self._lock = threading.Lock()
+        self.node_type_names = (meta or {}).get("node_types", {})
+        self.edge_type_names = (meta or {}).get("edge_types", {})
+
+    # ------------------------------------------------------------ creation
+    @classmethod
+    def from_csr(cls, row_id, row_ptr, type_end, nbr, prefix_w, type_prefix,
+                 n_edge_types, node_type=None, node_weight=None,
+                 sampler_order=None, device=0, partitions=1, shard_index=0,
+                 shards=1):
+        row_id = _np(row_id, np.uint64)
+        row_ptr = _np(row_ptr, np.int64)
+        type_end = _np(type_end, np.int32).reshape(-1)
+        nbr = _np(nbr, np.uint64)
+        prefix_w = _np(prefix_w, np.float32)
+        type_prefix = _np(type_prefix, np.float32).reshape(-1)
+        c = _lib.HostCSR()
+        c.n_rows = len(row_id)
+        c.n_edge_types = int(n_edge_types)
+        keep = [row_id, row_ptr, type_end, nbr, prefix_w, type_prefix]
+        c.row_id = row_id.ctypes.data_as(_lib.u64p)
+        c.row_ptr = row_ptr.ctypes.data_as(_lib.i64p)
+        c.type_end = type_end.ctypes.data_as(_lib.i32p)
+        c.nbr = nbr.ctypes.data_as(_lib.u64p)
+        c.prefix_w = prefix_w.ctypes.data_as(_lib.f32p)
+        c.type_prefix = type_prefix.ctypes.data_as(_lib.f32p)
+        n_node_types = 1
+        if node_type is not None:
+            node_type = _np(node_type, np.int32)
+            keep.append(node_type)
+            c.node_type = node_type.ctypes.data_as(_lib.i32p)
+            n_node_types = int(node_type.max()) + 1 if len(node_type) else 1
+        if node_weight is not None:
+            node_weight = _np(node_weight, np.float32)
+            keep.append(node_weight)
+            c.node_weight = node_weight.ctypes.data_as(_lib.f32p)
+        if sampler_order is not None:
+            sampler_order = _np(sampler_order, np.uint64)
+            keep.append(sampler_order)
+            c.sampler_order = sampler_order.ctypes.data_as(_lib.u64p)
+        c.n_node_types = n_node_types
+        h = C.c_void_p()
+        check(lib().euler_gpu_graph_create_shard(C.byref(c), device, partitions,
+                                                 shard_index, shards, C.byref(h)))
+        return cls(h, device)
+
+    @classmethod
+    def synthetic(cls, params, device=0, partitions=1, shard_index=0, shards=1):
+        h = C.c_void_p()
+        check(lib().euler_gpu_graph_create_synthetic(
+            C.byref(params), device, partitions, shard_index, shards, C.byref(h)))
+        return cls(h, device)
+
+    @classmethod
+    def load(cls, data_path, device=0, shard_index=0, shards=1):
+        h = C.c_void_p()
+        check(lib().euler_gpu_graph_load(str(data_path).encode(), device,
+                                         shard_index, shards, C.byref(h)))
+        return cls(h, device)
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            lib().euler_gpu_graph_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -------------------------------------------------------------- facts
+    @property
+    def num_nodes(self):
+        return lib().euler_gpu_graph_num_nodes(self._h)
+
+    @property
+    def num_edges(self):
+        return lib().euler_gpu_graph_num_edges(self._h)
+
+    @property
+    def num_edge_types(self):
+        return lib().euler_gpu_graph_num_edge_types(self._h)
+
+    @property
+    def num_node_types(self):
+        return lib().euler_gpu_graph_num_node_types(self._h)
+
+    @property
+    def device_bytes(self):
+        return lib().euler_gpu_graph_bytes(self._h)
+
+    def node_weight_sums(self):
+        out = np.zeros(max(self.num_node_types, 1), np.float32)
+        check(lib().euler_gpu_graph_node_weight_sums(
+            self._h, out.ctypes.data_as(_lib.f32p)))
+        return out
+
+    def export_rows(self, ids):
+        """Rows of the device CSR for `ids` as host numpy arrays."""
+        ids = _np(ids, np.uint64)
+        n = len(ids)
+        T = self.num_edge_types
+        row_ptr = np.zeros(n + 1, np.int64)
+        check(lib().euler_gpu_graph_export_rows(
+            self._h, ids.ctypes.data_as(_lib.u64p), n,
+            row_ptr.ctypes.data_as(_lib.i64p), None, None, None, None))
+        tot = int(row_ptr[-1])
+        type_end = np.zeros(n * T, np.int32)
+        nbr = np.zeros(max(tot, 1), np.uint64)
+        pw = np.zeros(max(tot, 1), np.float32)
+        tp = np.zeros(n * T, np.float32)
+        check(lib().euler_gpu_graph_export_rows(
+            self._h, ids.ctypes.data_as(_lib.u64p), n,
+            row_ptr.ctypes.data_as(_lib.i64p), type_end.ctypes.data_as(_lib.i32p),
+            nbr.ctypes.data_as(_lib.u64p), pw.ctypes.data_as(_lib.f32p),
+            tp.ctypes.data_as(_lib.f32p)))
+        return row_ptr, type_end, nbr[:tot], pw[:tot], tp
+
+    # ---------------------------------------------------------------- RNG
+    def set_seed(self, seed, call_id=0):
+        """Fix the sampling stream: ids are a pure function of (seed, call_id,
+        node id / sample index, draw index)."""
+        with self._lock:
+            self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+            self._call_id = int(call_id)
+
+    def _take_call_ids(self, n, call_id=None):
+        if call_id is not None:
+            return int(call_id) & 0xFFFFFFFF
+        with self._lock:
+            c = self._call_id
+            self._call_id = (self._call_id + n) & 0xFFFFFFFF
+        return c
+
+    # ------------------------------------------------------------ sampling
+    def sample_neighbor(self, nodes, edge_types, count, default_node=-1,
+                        layout="tf", call_id=None, return_mask=False):
+        """tf_euler SampleNeighbor (tf_euler/kernels/sample_neighbor_op.cc):
+        nodes [n] int64 -> (neighbors [n,count] int64, weights f32, types
+        int32).  layout='core' gives the API_SAMPLE_NB fill (0, 0.0, 0)."""
+        nodes = _as_i64_cuda(nodes, self.device)
+        shape = tuple(nodes.shape) + (int(count),)
+        flat = nodes.reshape(-1)
+        n = flat.numel()
+        out_n = torch.empty((n, count), dtype=torch.int64, device=self.device)
+        out_w = torch.empty((n, count), dtype=torch.float32, device=self.device)
+        out_t = torch.empty((n, count), dtype=torch.int32, device=self.device)
+        mask = (torch.empty(n, dtype=torch.uint8, device=self.device)
+                if return_mask else None)
+        et, et_p, k = _i32_array(edge_types)
+        lay = _lib.LAYOUT_TF if layout == "tf" else _lib.LAYOUT_CORE
+        with torch.cuda.device(self.device):
+            check(lib().euler_gpu_sample_neighbor(
+                self._h, _stream(), self.seed, self._take_call_ids(1, call_id),
+                _ptr(flat), n, None, 1, et_p, k, int(count), lay,
+                int(default_node), _ptr(out_n), _ptr(out_w), _ptr(out_t),
+                _ptr(mask)))
+        res = (out_n.reshape(shape), out_w.reshape(shape), out_t.reshape(shape))
+        return res + (mask,) if return_mask else res
+
+    def sample_fanout(self, nodes, edge_types, counts, default_node=-1,
+                      call_id=None):
+        """tf_euler sample_fanout (euler_ops/neighbor_ops.py:122-158 over
+        tf_euler/kernels/sample_fanout_op.cc): returns (neighbors_list,
+        weights_list, types_list) with flattened per-hop tensors."""
+        nodes = _as_i64_cuda(nodes, self.device).reshape(-1)
+        layers = len(counts)
+        et = np.asarray(edge_types, dtype=np.int32).reshape(layers, -1)
+        et, et_p, _ = _i32_array(et)
+        k = et.size // layers if layers else 0
+        cnt, cnt_p, _ = _i32_array(counts)
+        n = nodes.numel()
+        outs_n, outs_w, outs_t = [], [], []
+        m = n
+        for c in counts:
+            m *= int(c)
+            outs_n.append(torch.empty(m, dtype=torch.int64, device=self.device))
+            outs_w.append(torch.empty(m, dtype=torch.float32, device=self.device))
+            outs_t.append(torch.empty(m, dtype=torch.int32, device=self.device))
+        ws_bytes = lib().euler_gpu_sample_fanout_workspace(n, cnt_p, layers)
+        ws = torch.empty(max(int(ws_bytes), 16), dtype=torch.uint8,
+                         device=self.device)
+        pn = (C.c_void_p * layers)(*[t.data_ptr() for t in outs_n])
+        pw = (C.c_void_p * layers)(*[t.data_ptr() for t in outs_w])
+        pt = (C.c_void_p * layers)(*[t.data_ptr() for t in outs_t])
+        with torch.cuda.device(self.device):
+            check(lib().euler_gpu_sample_fanout(
+                self._h, _stream(), self.seed,
+                self._take_call_ids(layers, call_id), _ptr(nodes), n, et_p, k,
+                cnt_p, layers, int(default_node), pn, pw, pt, _ptr(ws)))
+        return [nodes] + outs_n, outs_w, outs_t
+
+    def sample_node(self, count, node_type=-1, call_id=None):
+        """tf_euler sample_node (tf_euler/kernels/sample_node_op.cc:39-98):
+        [count] int64 ids drawn by node weight within the type(s)."""
+        nt, nt_p, k = _i32_array(np.atleast_1d(node_type))
+        out = torch.empty(int(count), dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().euler_gpu_sample_node(
+                self._h, _stream(), self.seed, self._take_call_ids(1, call_id),
+                nt_p, k, int(count), _ptr(out)))
+        return out
+
+    def get_full_neighbor(self, nodes, edge_types):
+        """GQL `v(nodes).outV(edge_types)` result (idx [n,2] int32, ids int64,
+        weights f32, types int32), core/kernels/get_neighbor_op.cc."""
+        nodes = _as_i64_cuda(nodes, self.device).reshape(-1)
+        n = nodes.numel()
+        et, et_p, k = _i32_array(edge_types)
+        idx = torch.empty((n, 2), dtype=torch.int32, device=self.device)
+        total = C.c_int64(0)
+        with torch.cuda.device(self.device):
+            check(lib().euler_gpu_get_full_neighbor(
+                self._h, _stream(), _ptr(nodes), n, et_p, k, _ptr(idx),
+                C.byref(total), None, None, None))
+            tot = int(total.value)
+            ids = torch.empty(tot, dtype=torch.int64, device=self.device)
+            w = torch.empty(tot, dtype=torch.float32, device=self.device)
+            t = torch.empty(tot, dtype=torch.int32, device=self.device)
+            if n:
+                check(lib().euler_gpu_get_full_neighbor(
+                    self._h, _stream(), _ptr(nodes), n, et_p, k, _ptr(idx),
+                    C.byref(total), _ptr(ids), _ptr(w), _ptr(t)))
+        return idx, ids, w, t
+
+    def random_walk(self, nodes, edge_types, p=1.0, q=1.0, default_node=-1,
+                    call_id=None):
+        """tf_euler random_walk (tf_euler/kernels/random_walk_op.cc):
+        edge_types = list (length walk_len) of per-step edge type lists;
+        returns [n, walk_len+1] int64."""
+        nodes = _as_i64_cuda(nodes, self.device).reshape(-1)
+        walk_len = len(edge_types)
+        et = np.asarray(edge_types, dtype=np.int32).reshape(walk_len, -1) \
+            if walk_len else np.zeros((0, 0), np.int32)
+        k = et.shape[1] if walk_len else 0
+        et, et_p, _ = _i32_array(et)
+        n = nodes.numel()
+        out = torch.empty((n, walk_len + 1), dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().euler_gpu_random_walk(
+                self._h, _stream(), self.seed,
+                self._take_call_ids(max(walk_len, 1), call_id), _ptr(nodes), n,
+                et_p, k, walk_len, float(p), float(q), int(default_node),
+                _ptr(out)))
+        return out

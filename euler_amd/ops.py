@@ -1,0 +1,231 @@
+"""Graph-independent device operators of libeuler_gpu.so on torch tensors:
+message passing (MPGather / MPScatterAdd / MPScatterMax), GenPair, the GQL
+helper ops (ID_UNIQUE / IDX_GATHER / DATA_GATHER) and the shard split/merge
+ops.  All tensors must live on a CUDA (ROCm) device; nothing here has a CPU
+path."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, lib
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if not t.is_cuda:
+            raise RuntimeError("euler_amd ops need tensors in GPU memory "
+                               "(no CPU fallback)")
+
+
+def _gather_raw(params, indices):
+    params = params.contiguous()
+    indices = indices.to(torch.int32).contiguous()
+    _need_cuda(params, indices)
+    e, d = indices.numel(), params.shape[1]
+    out = torch.empty((e, d), dtype=torch.float32, device=params.device)
+    with torch.cuda.device(params.device):
+        check(lib().euler_gpu_gather(_stream(), _ptr(params), _ptr(indices), e, d,
+                                     params.shape[0], _ptr(out)))
+    return out
+
+
+def _scatter_raw(fn, updates, indices, size):
+    updates = updates.contiguous()
+    indices = indices.to(torch.int32).contiguous()
+    _need_cuda(updates, indices)
+    e, d = updates.shape
+    out = torch.empty((int(size), d), dtype=torch.float32, device=updates.device)
+    with torch.cuda.device(updates.device):
+        check(fn(_stream(), _ptr(updates), _ptr(indices), e, d, int(size), _ptr(out)))
+    return out
+
+
+# Gradients as registered in tf_euler/python/euler_ops/mp_ops.py:39-62.
+class _Gather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, params, indices):
+        ctx.save_for_backward(indices)
+        ctx.n = params.shape[0]
+        return _gather_raw(params, indices)
+
+    @staticmethod
+    def backward(ctx, grad):
+        (indices,) = ctx.saved_tensors
+        return _scatter_raw(lib().euler_gpu_scatter_add, grad, indices, ctx.n), None
+
+
+class _ScatterAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, updates, indices, size):
+        ctx.save_for_backward(indices)
+        return _scatter_raw(lib().euler_gpu_scatter_add, updates, indices, size)
+
+    @staticmethod
+    def backward(ctx, grad):
+        (indices,) = ctx.saved_tensors
+        return _gather_raw(grad, indices), None, None
+
+
+class _ScatterMax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, updates, indices, size):
+        out = _scatter_raw(lib().euler_gpu_scatter_max, updates, indices, size)
+        ctx.save_for_backward(updates, indices, out)
+        ctx.size = size
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        updates, indices, out = ctx.saved_tensors
+        indicators = (updates == _gather_raw(out, indices)).to(updates.dtype)
+        num_selected = _scatter_raw(lib().euler_gpu_scatter_add, indicators,
+                                    indices, ctx.size)
+        indicators = indicators / _gather_raw(num_selected, indices)
+        return indicators * _gather_raw(grad, indices), None, None
+
+
+def gather(params, indices):
+    """MPGather: out[i,:] = params[indices[i],:] (fp32, int32 indices)."""
+    return _Gather.apply(params, indices)
+
+
+def scatter_add(updates, indices, size):
+    """MPScatterAdd: out[indices[i],:] += updates[i,:], zero init, [size,D]."""
+    return _ScatterAdd.apply(updates, indices, int(size))
+
+
+def scatter_max(updates, indices, size):
+    """MPScatterMax: element-wise max per destination, -1e9 for empty rows."""
+    return _ScatterMax.apply(updates, indices, int(size))
+
+
+def scatter_mean(updates, indices, size):
+    """mp_ops.py:65-69."""
+    out = scatter_add(updates, indices, size)
+    ep = 1e-7
+    ones = torch.ones((updates.shape[0], 1), dtype=torch.float32,
+                      device=updates.device)
+    count = scatter_add(ones, indices, size) + ep
+    return out / count
+
+
+def scatter_softmax(updates, indices, size):
+    """mp_ops.py:76-79."""
+    updates = updates - gather(scatter_max(updates, indices, size), indices)
+    updates = torch.exp(updates)
+    return updates / gather(scatter_add(updates, indices, size), indices)
+
+
+def scatter_(op, updates, indices, size):
+    """mp_ops.py:72-73."""
+    return {"add": scatter_add, "max": scatter_max, "mean": scatter_mean,
+            "softmax": scatter_softmax}[op](updates, indices, size)
+
+
+def gen_pair(paths, left_win_size, right_win_size):
+    """GenPair (tf_euler/kernels/gen_pair_op.cc): [batch, path_len] int64 ->
+    [batch, pair_count, 2]."""
+    paths = paths.to(torch.int64).contiguous()
+    _need_cuda(paths)
+    b, l = paths.shape
+    pc = lib().euler_gpu_gen_pair_count(l, left_win_size, right_win_size)
+    out = torch.empty((b, pc, 2), dtype=torch.int64, device=paths.device)
+    with torch.cuda.device(paths.device):
+        check(lib().euler_gpu_gen_pair(_stream(), _ptr(paths), b, l, left_win_size,
+                                       right_win_size, _ptr(out)))
+    return out
+
+
+def id_unique(ids):
+    """ID_UNIQUE: (unique ids in first-occurrence order, gather_idx int32)."""
+    ids = ids.to(torch.int64).contiguous().reshape(-1)
+    _need_cuda(ids)
+    n = ids.numel()
+    uq = torch.empty(n, dtype=torch.int64, device=ids.device)
+    gi = torch.empty(n, dtype=torch.int32, device=ids.device)
+    nu = C.c_int64(0)
+    with torch.cuda.device(ids.device):
+        check(lib().euler_gpu_id_unique(_stream(), _ptr(ids), n, _ptr(uq), _ptr(gi),
+                                        C.byref(nu)))
+    return uq[:nu.value], gi
+
+
+def idx_gather(idx, gather_idx):
+    """IDX_GATHER: re-based [n,2] offsets of the gathered segments."""
+    idx = idx.to(torch.int32).contiguous()
+    gi = gather_idx.to(torch.int32).contiguous()
+    _need_cuda(idx, gi)
+    n = gi.numel()
+    out = torch.empty((n, 2), dtype=torch.int32, device=idx.device)
+    total = C.c_int64(0)
+    with torch.cuda.device(idx.device):
+        check(lib().euler_gpu_idx_gather(_stream(), _ptr(idx), _ptr(gi), n,
+                                         _ptr(out), C.byref(total)))
+    return out, int(total.value)
+
+
+def data_gather(data, idx, gather_idx):
+    """DATA_GATHER: concatenated segments data[idx[g]] for g in gather_idx."""
+    data = data.contiguous()
+    idx = idx.to(torch.int32).contiguous()
+    gi = gather_idx.to(torch.int32).contiguous()
+    _need_cuda(data, idx, gi)
+    out_idx, total = idx_gather(idx, gi)
+    out = torch.empty(total, dtype=data.dtype, device=data.device)
+    with torch.cuda.device(data.device):
+        check(lib().euler_gpu_data_gather(_stream(), _ptr(data), data.element_size(),
+                                          _ptr(idx), _ptr(gi), _ptr(out_idx),
+                                          gi.numel(), _ptr(out)))
+    return out
+
+
+def id_split(ids, partitions, shards):
+    """ID_SPLIT: stable bucket by owner(id) = (id % partitions) % shards.
+    Returns (shard_off list[shards+1], shard_ids int64 [n], merge_idx int32 [n])."""
+    ids = ids.to(torch.int64).contiguous().reshape(-1)
+    _need_cuda(ids)
+    n = ids.numel()
+    off = (C.c_int64 * (shards + 1))()
+    sid = torch.empty(n, dtype=torch.int64, device=ids.device)
+    mi = torch.empty(n, dtype=torch.int32, device=ids.device)
+    with torch.cuda.device(ids.device):
+        check(lib().euler_gpu_id_split(_stream(), _ptr(ids), n, partitions, shards,
+                                       off, _ptr(sid), _ptr(mi)))
+    return list(off), sid, mi
+
+
+def merge_rows(rows, merge_idx, n_rows=None):
+    """IDX_MERGE / DATA_MERGE for fixed-size rows: out[merge_idx[j]] = rows[j]."""
+    rows = rows.contiguous()
+    mi = merge_idx.to(torch.int32).contiguous()
+    _need_cuda(rows, mi)
+    n = mi.numel()
+    out = torch.empty_like(rows) if n_rows is None else torch.empty(
+        (n_rows,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+    row_bytes = rows.element_size() * (rows.numel() // max(n, 1)) if n else 4
+    with torch.cuda.device(rows.device):
+        check(lib().euler_gpu_merge_rows(_stream(), _ptr(rows), _ptr(mi), n,
+                                         row_bytes, _ptr(out)))
+    return out
+
+
+def sample_node_split(seed, call_id, count, shard_weight):
+    """SAMPLE_NODE_SPLIT (host): per-shard counts proportional to the shards'
+    type weight sums; shard_weight has shards+1 entries (last = total)."""
+    sw = np.ascontiguousarray(shard_weight, dtype=np.float32)
+    shards = len(sw) - 1
+    out = np.zeros(shards, np.int32)
+    check(lib().euler_gpu_sample_node_split(
+        seed, call_id, count, sw.ctypes.data_as(_lib.f32p), shards,
+        out.ctypes.data_as(_lib.i32p)))
+    return out

@@ -1,0 +1,304 @@
+/*
+ * euler_gpu.h - C ABI of the MI355X-native sampling / aggregation backend for
+ * Euler's minibatch-construction hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch
+ * types.  Each entry point names the reference interface it replaces
+ * (paths relative to the alibaba/euler tree).  INTEGRATION.md shows the
+ * binding a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - Every function returns 0 on success or a negative EULER_GPU_E* code; the
+ *     message is available from euler_gpu_last_error() (thread-local).  This
+ *     mirrors the reference's "log and produce no output" error behaviour
+ *     (core/kernels/sample_node_op.cc:118-122) with a code the caller can test.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All
+ *     device work is enqueued on it; nothing synchronises unless documented.
+ *   - Pointers named *_dev are device (HBM) pointers, *_host are host
+ *     pointers.  Outputs are caller-allocated; their sizes are static
+ *     (n * count ...), exactly the shapes of the reference ops.
+ *   - Node ids are uint64 (euler::common::NodeID); the TF-level ops read and
+ *     write them as int64 bit patterns (tf_euler/kernels/sample_neighbor_op.cc:110).
+ *   - Random numbers: counter-based Philox4x32-10 keyed by (seed, call_id,
+ *     node id | sample index, draw index) - see DESIGN.md "RNG contract".  The
+ *     same (seed, call_id) always reproduces the same ids, independent of batch
+ *     order, duplication, launch geometry or sharding.
+ */
+#ifndef EULER_GPU_H_
+#define EULER_GPU_H_
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EULER_GPU_OK 0
+#define EULER_GPU_EINVAL (-1)   /* bad argument                                */
+#define EULER_GPU_ENOMEM (-2)   /* device or host allocation failed            */
+#define EULER_GPU_EHIP (-3)     /* HIP runtime error (message has the detail)  */
+#define EULER_GPU_ENOGRAPH (-4) /* no graph initialised / bad handle           */
+#define EULER_GPU_EIO (-5)      /* data_path unreadable / malformed .dat       */
+#define EULER_GPU_EEMPTY (-6)   /* sampler has zero total weight: no output    */
+
+typedef struct euler_gpu_graph euler_gpu_graph;
+
+/* Result layouts of the neighbour sampler. */
+#define EULER_GPU_LAYOUT_CORE 0 /* API_SAMPLE_NB / GQL layout: empty rows are
+                                   count x (0, 0.0f, 0)
+                                   (core/kernels/sample_neighbor_op.cc:134-143) */
+#define EULER_GPU_LAYOUT_TF 1   /* tf_euler dense layout: rows whose first id
+                                   is the sentinel 0 are default_node/0.0/-1
+                                   (tf_euler/kernels/sample_neighbor_op.cc:79-81,
+                                   114-122)                                     */
+
+/* Host description of a graph in the reference's own per-node storage
+ * (euler/core/graph/node.h:49-57) concatenated over rows. */
+typedef struct euler_gpu_host_csr {
+  int64_t n_rows;
+  int32_t n_edge_types;        /* edge-type groups per node                    */
+  int32_t n_node_types;
+  const uint64_t* row_id;      /* [n_rows] node id of each row                 */
+  const int64_t* row_ptr;      /* [n_rows+1]                                   */
+  const int32_t* type_end;     /* [n_rows*T] neighbor_groups_idx (row-relative)*/
+  const uint64_t* nbr;         /* [E] neighbors                                */
+  const float* prefix_w;       /* [E] neighbors_weight (running f32 sums)      */
+  const float* type_prefix;    /* [n_rows*T] edge_group_collection running sums*/
+  const int32_t* node_type;    /* [n_rows] or NULL (all type 0)                */
+  const float* node_weight;    /* [n_rows] or NULL (all 1.0f)                  */
+  const uint64_t* sampler_order; /* [n_rows] node ids in the order the global
+                                  node sampler enumerates them
+                                  (Graph::BuildGlobalSampler, graph.cc:349) or
+                                  NULL = row order                             */
+} euler_gpu_host_csr;
+
+/* Parameters of the deterministic synthetic power-law graph (benchmarks). */
+typedef struct euler_gpu_synth_params {
+  uint64_t seed;
+  int64_t n_nodes;             /* ids 1..n_nodes                               */
+  int64_t n_edges_target;
+  int32_t scale;               /* RMAT scale (bits)                            */
+  int32_t n_types;
+  int32_t weighted;            /* 0: all weights 1.0f, 1: uniform [0.5, 8)     */
+  int32_t pad;
+  double deg_table[64];        /* expected extra degree by popcount(id-1)      */
+} euler_gpu_synth_params;
+
+/* ---- library / error ---------------------------------------------------- */
+const char* euler_gpu_last_error(void);
+const char* euler_gpu_version(void);
+int euler_gpu_device_count(void);
+
+/* ---- graph life cycle ---------------------------------------------------
+ * Replaces QueryProxy::Init local branch -> Graph::Init -> GraphBuilder::Build
+ * -> BuildGlobalSampler (client/query_proxy.cc:145-190, core/graph/graph.cc:
+ * 72-120,333-370): the graph becomes an immutable CSR + alias tables in HBM. */
+int euler_gpu_graph_create(const euler_gpu_host_csr* csr, int device,
+                           euler_gpu_graph** out);
+/* Only rows owned by `shard_index` under owner(id) = (id % partitions) % shards
+ * (core/kernels/id_split_op.cc:46-49) are kept (Graph::Init file filter,
+ * core/graph/graph.cc:90-98). */
+int euler_gpu_graph_create_shard(const euler_gpu_host_csr* csr, int device,
+                                 int32_t partitions, int32_t shard_index,
+                                 int32_t shards, euler_gpu_graph** out);
+/* Synthetic graph generated directly in HBM.  rows are [row_begin,row_end) of
+ * the global graph when sharded by contiguous ranges is wanted; pass
+ * partitions/shards = 1 for the whole graph.  With shards > 1 the shard keeps
+ * the nodes with owner(id) == shard_index. */
+int euler_gpu_graph_create_synthetic(const euler_gpu_synth_params* p,
+                                     int device, int32_t partitions,
+                                     int32_t shard_index, int32_t shards,
+                                     euler_gpu_graph** out);
+/* Load a directory written by euler/tools (euler.meta + Node/*.dat), the
+ * input of the reference's Graph::Init (core/graph/graph_builder.cc:57-158,
+ * core/graph/node.cc:414-526). */
+int euler_gpu_graph_load(const char* data_path, int device,
+                         int32_t shard_index, int32_t shards,
+                         euler_gpu_graph** out);
+/* Host-only view of the same reader (no GPU needed): parses the directory
+ * into malloc'ed arrays described by *csr; free with euler_gpu_dat_close().
+ * *partitions receives euler.meta's partitions_num. */
+int euler_gpu_dat_open(const char* data_path, int32_t shard_index,
+                       int32_t shards, euler_gpu_host_csr* csr,
+                       int32_t* partitions, void** owner);
+void euler_gpu_dat_close(void* owner);
+void euler_gpu_graph_destroy(euler_gpu_graph* g);
+
+int64_t euler_gpu_graph_num_nodes(const euler_gpu_graph* g);
+int64_t euler_gpu_graph_num_edges(const euler_gpu_graph* g);
+int32_t euler_gpu_graph_num_edge_types(const euler_gpu_graph* g);
+int32_t euler_gpu_graph_num_node_types(const euler_gpu_graph* g);
+int euler_gpu_graph_device(const euler_gpu_graph* g);
+/* Total device bytes held by the graph. */
+int64_t euler_gpu_graph_bytes(const euler_gpu_graph* g);
+/* Per node type weight sums (Graph::GetNodeWeightSums, used by
+ * SAMPLE_NODE_SPLIT); out_host has n_node_types floats. */
+int euler_gpu_graph_node_weight_sums(const euler_gpu_graph* g, float* out_host);
+/* Copy rows of the device CSR back to the host for the listed ids, in the
+ * euler_gpu_host_csr layout (spot checks at sizes no CPU structure can hold).
+ * Call with nbr_host == NULL to obtain row_ptr_host (n+1) first. */
+int euler_gpu_graph_export_rows(const euler_gpu_graph* g, const uint64_t* ids_host,
+                                int64_t n, int64_t* row_ptr_host,
+                                int32_t* type_end_host, uint64_t* nbr_host,
+                                float* prefix_w_host, float* type_prefix_host);
+
+/* The reference's one process-level C entry (tf_euler/utils/
+ * init_query_proxy.cc:19-37, loaded by euler_ops/base.py:33-67).  Accepts the
+ * same "k=v;k=v" string (mode=local; data_path; sampler_type; data_type) plus
+ * `device`, `shard_idx`, `shard_num`.  Installs the process-wide default graph
+ * returned by euler_gpu_default_graph(). */
+bool InitQueryProxy(const char* conf);
+euler_gpu_graph* euler_gpu_default_graph(void);
+
+/* ---- SampleNeighbor ------------------------------------------------------
+ * Replaces euler::SampleNeighbor (core/api/api.cc:223-236) ->
+ * Node::SampleNeighbor (core/graph/node.cc:98-167) -> RandomSelect
+ * (common/compact_weighted_collection.h:30-52), the empty-row fill of
+ * API_SAMPLE_NB, FillNeighbor (core/kernels/common.cc:275-334) and, with
+ * LAYOUT_TF, the dense repack of the TF SampleNeighbor kernel.
+ *   roots_dev      [n] node ids
+ *   root_mask_dev  optional [ceil(n / root_group)] bytes; a non-zero byte means
+ *                  "this group of roots came from a missing row": they sample
+ *                  as node id 0, the id the reference's core tensors carry
+ *                  (used to chain hops, tf_euler/kernels/sample_fanout_op.cc)
+ *   edge_types_host[k] (k may be 0 = all types)
+ *   out_*_dev      [n*count]; out_row_mask_dev optional [n] (1 = default row)
+ */
+int euler_gpu_sample_neighbor(const euler_gpu_graph* g, void* stream,
+                              uint64_t seed, uint32_t call_id,
+                              const uint64_t* roots_dev, int64_t n,
+                              const uint8_t* root_mask_dev, int32_t root_group,
+                              const int32_t* edge_types_host, int32_t k,
+                              int32_t count, int32_t layout,
+                              int64_t default_node, uint64_t* out_id_dev,
+                              float* out_w_dev, int32_t* out_t_dev,
+                              uint8_t* out_row_mask_dev);
+
+/* TF SampleFanout (tf_euler/kernels/sample_fanout_op.cc:32-148): `layers` hops
+ * chained on device; hop h uses call_id + h, edge_types_host[h*k .. h*k+k) and
+ * counts_host[h].  out_*_dev[h] has n * prod(counts[0..h]) elements.
+ * workspace_dev must hold euler_gpu_sample_fanout_workspace() bytes. */
+size_t euler_gpu_sample_fanout_workspace(int64_t n, const int32_t* counts_host,
+                                         int32_t layers);
+int euler_gpu_sample_fanout(const euler_gpu_graph* g, void* stream,
+                            uint64_t seed, uint32_t call_id,
+                            const uint64_t* roots_dev, int64_t n,
+                            const int32_t* edge_types_host, int32_t k,
+                            const int32_t* counts_host, int32_t layers,
+                            int64_t default_node, uint64_t* const* out_id_dev,
+                            float* const* out_w_dev, int32_t* const* out_t_dev,
+                            void* workspace_dev);
+
+/* ---- SampleNode -----------------------------------------------------------
+ * Replaces euler::SampleNode (core/api/api.cc:32-37) -> Graph::SampleNode
+ * (core/graph/graph.cc:221-275) -> AliasMethod::Next (common/alias_method.cc:
+ * 66-78).  node_types_host[k]: k == 1 && type == -1 samples over all types.
+ * Returns EULER_GPU_EEMPTY (and writes nothing) when the weight sum is 0. */
+int euler_gpu_sample_node(const euler_gpu_graph* g, void* stream, uint64_t seed,
+                          uint32_t call_id, const int32_t* node_types_host,
+                          int32_t k, int32_t count, uint64_t* out_dev);
+
+/* ---- full neighbours ------------------------------------------------------
+ * euler::GetFullNeighbor (core/api/api.cc:208-221) -> Node::GetFullNeighbor
+ * (core/graph/node.cc:175-197) in the FillNeighbor layout.  Two calls: first
+ * with out_id_dev == NULL fills idx_dev [n,2] (int32 offsets) and *total_host
+ * (synchronises the stream); the second call writes the values. */
+int euler_gpu_get_full_neighbor(const euler_gpu_graph* g, void* stream,
+                                const uint64_t* ids_dev, int64_t n,
+                                const int32_t* edge_types_host, int32_t k,
+                                int32_t* idx_dev, int64_t* total_host,
+                                uint64_t* out_id_dev, float* out_w_dev,
+                                int32_t* out_t_dev);
+
+/* ---- RandomWalk -------------------------------------------------------------
+ * TF RandomWalk kernel (tf_euler/kernels/random_walk_op.cc:172-291):
+ * |p-1|,|q-1| <= 1e-6 -> chain of count=1 SampleNeighbor hops (:207-247), else
+ * node2vec with BuildWeights (:83-168).  edge_types_host is [walk_len, k];
+ * out_dev is [n, walk_len+1] int64. */
+int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
+                          uint32_t call_id, const int64_t* nodes_dev, int64_t n,
+                          const int32_t* edge_types_host, int32_t k,
+                          int32_t walk_len, float p, float q,
+                          int64_t default_node, int64_t* out_dev);
+
+/* GenPair (tf_euler/kernels/gen_pair_op.cc:42-95): paths [batch,path_len] ->
+ * pairs [batch, pair_count, 2]. */
+int64_t euler_gpu_gen_pair_count(int64_t path_len, int32_t left_win,
+                                 int32_t right_win);
+int euler_gpu_gen_pair(void* stream, const int64_t* paths_dev, int64_t batch,
+                       int64_t path_len, int32_t left_win, int32_t right_win,
+                       int64_t* out_dev);
+
+/* ---- ID_UNIQUE / IDX_GATHER / DATA_GATHER ----------------------------------
+ * core/kernels/id_unique_op.cc:35-64 (first-occurrence order),
+ * idx_gather_op.cc:33-55, data_gather_op.cc:33-80.
+ * euler_gpu_id_unique synchronises the stream to return *n_unique_host. */
+int euler_gpu_id_unique(void* stream, const uint64_t* ids_dev, int64_t n,
+                        uint64_t* unique_dev, int32_t* gather_idx_dev,
+                        int64_t* n_unique_host);
+int euler_gpu_idx_gather(void* stream, const int32_t* idx_dev,
+                         const int32_t* gather_idx_dev, int64_t n,
+                         int32_t* out_idx_dev, int64_t* total_host);
+int euler_gpu_data_gather(void* stream, const void* data_dev, int32_t elem_size,
+                          const int32_t* idx_dev, const int32_t* gather_idx_dev,
+                          const int32_t* out_idx_dev, int64_t n, void* out_dev);
+
+/* ---- message passing -----------------------------------------------------
+ * MPScatterAdd / MPScatterMax / MPGather (tf_euler/kernels/scatter_op.cc:27-105,
+ * gather_op.cc:26-59).  fp32 data, int32 indices.  Scatter results are
+ * order-faithful: each output element adds its updates in input order, so
+ * they are bit-identical to the reference's sequential loop. */
+int euler_gpu_scatter_add(void* stream, const float* updates_dev,
+                          const int32_t* indices_dev, int64_t e, int64_t d,
+                          int32_t size, float* out_dev);
+int euler_gpu_scatter_max(void* stream, const float* updates_dev,
+                          const int32_t* indices_dev, int64_t e, int64_t d,
+                          int32_t size, float* out_dev);
+int euler_gpu_gather(void* stream, const float* params_dev,
+                     const int32_t* indices_dev, int64_t e, int64_t d,
+                     int64_t n_params, float* out_dev);
+
+/* ---- shard ops (multi-GPU) --------------------------------------------------
+ * ID_SPLIT (core/kernels/id_split_op.cc:46-99): stable bucket of ids by
+ * owner(id) = (id % partitions) % shards.  shard_off_host [shards+1] is
+ * returned after a stream sync; shard_ids_dev / merge_idx_dev have n entries.
+ * euler_gpu_merge_rows is IDX_MERGE/DATA_MERGE (idx_merge_op.cc:61-77,
+ * data_merge_op.cc:44-67) for fixed-size rows: out[merge_idx[j]] = in[j]. */
+int euler_gpu_id_split(void* stream, const uint64_t* ids_dev, int64_t n,
+                       int32_t partitions, int32_t shards,
+                       int64_t* shard_off_host, uint64_t* shard_ids_dev,
+                       int32_t* merge_idx_dev);
+int euler_gpu_merge_rows(void* stream, const void* in_dev,
+                         const int32_t* merge_idx_dev, int64_t n_rows,
+                         int64_t row_bytes, void* out_dev);
+/* SAMPLE_NODE_SPLIT (core/kernels/sample_node_split_op.cc:57-85), host only:
+ * shard_weight_host[shards+1] (last = total) -> split_cnt_host[shards]. */
+int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
+                                const float* shard_weight_host, int32_t shards,
+                                int32_t* split_cnt_host);
+
+/* ---- measurement helper -------------------------------------------------------
+ * Runs the sample_neighbor kernel `iters` times on `stream` between two HIP
+ * events recorded on that same stream and returns the mean kernel time in
+ * milliseconds (bench.py's roofline leg). */
+int euler_gpu_time_sample_neighbor(const euler_gpu_graph* g, void* stream,
+                                   uint64_t seed, const uint64_t* roots_dev,
+                                   int64_t n, const int32_t* edge_types_host,
+                                   int32_t k, int32_t count, int32_t layout,
+                                   uint64_t* out_id_dev, float* out_w_dev,
+                                   int32_t* out_t_dev, int32_t iters,
+                                   float* mean_ms_host);
+/* Exact algorithmic byte count of one sample_neighbor launch (SURVEY §8d
+ * formula evaluated on the actual roots' degrees); synchronises. */
+int euler_gpu_sample_neighbor_algo_bytes(const euler_gpu_graph* g, void* stream,
+                                         const uint64_t* roots_dev, int64_t n,
+                                         const int32_t* edge_types_host,
+                                         int32_t k, int32_t count,
+                                         double* bytes_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* EULER_GPU_H_ */

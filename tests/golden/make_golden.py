@@ -16,6 +16,8 @@ comes out of REFERENCE code:
                       that fixture for fixed (seed, call_id).
   random_graph.npz    a 300-node heterogeneous random graph (raw adjacency) +
                       the same kinds of reference outputs.
+  fixture_dat/        euler.meta + Node/*.dat exactly as written by the
+                      reference's euler/tools for that fixture (2 partitions).
   ref_tests.npz       exact expectations copied from the reference's own tests
                       (mp_ops_test.py:30-86, walk_ops_test.py:49-58,
                       unique_gather_test.cc:28-160, neighbor_ops_test.py:46-75).
@@ -129,6 +131,13 @@ def main():
         pack = sample_pack(R, ids, T, "")
         np.savez(os.path.join(OUT, "fixture_samples.npz"), seed=np.uint64(SEED),
                  **pack)
+        # the reference tool's own output files: input of the .dat reader test
+        dst = os.path.join(OUT, "fixture_dat")
+        shutil.rmtree(dst, ignore_errors=True)
+        os.makedirs(os.path.join(dst, "Node"))
+        shutil.copy(os.path.join(data, "euler.meta"), dst)
+        for fn in sorted(os.listdir(os.path.join(data, "Node"))):
+            shutil.copy(os.path.join(data, "Node", fn), os.path.join(dst, "Node"))
     finally:
         shutil.rmtree(scratch, ignore_errors=True)
 

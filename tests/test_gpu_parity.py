@@ -1,0 +1,409 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the
+committed golden vectors.  Bit-exact for ids / types / weights / indices;
+scatter results are bit-exact too (order-faithful segment reduce), which is
+stronger than the 1e-5 fp32 tolerance north_star allows.  Needs an MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import make_random_graph
+
+pytestmark = pytest.mark.gpu
+
+SEED = 20240521
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def EA(torch_cuda):
+    import euler_amd
+    return euler_amd
+
+
+def gpu_graph(EA, csr, order=None, **kw):
+    return EA.Graph.from_csr(csr.row_id, csr.row_ptr, csr.type_end, csr.nbr,
+                             csr.prefix_w, csr.type_prefix, csr.n_types,
+                             csr.node_type, csr.node_weight, sampler_order=order,
+                             **kw)
+
+
+def t2n(t):
+    return t.detach().cpu().numpy()
+
+
+def _check_pack(EA, O, torch, csr, s):
+    """Same battery as tests/test_oracle.py::_check_pack, on the GPU, against
+    vectors produced by the reference sampler."""
+    G = gpu_graph(EA, csr, order=s["node_order"])
+    seed = int(s["seed"]) if "seed" in s.files else SEED
+    G.set_seed(seed)
+    q = s["query_ids"]
+    qt = torch.as_tensor(q.astype(np.int64)).cuda()
+    n = 0
+    while "nb_%d_1_et" % n in s.files:
+        for count in (1, 5):
+            key = "nb_%d_%d_" % (n, count)
+            ids, w, t = G.sample_neighbor(qt, s[key + "et"], count, layout="core",
+                                          call_id=11 + n)
+            assert np.array_equal(t2n(ids).reshape(-1).astype(np.uint64), s[key + "id"]), key
+            assert np.array_equal(t2n(w).reshape(-1), s[key + "w"]), key
+            assert np.array_equal(t2n(t).reshape(-1), s[key + "t"]), key
+        n += 1
+    assert n >= 7
+    n = 0
+    while "full_%d_et" % n in s.files:
+        key = "full_%d_" % n
+        idx, ids, w, t = G.get_full_neighbor(qt, s[key + "et"])
+        assert np.array_equal(t2n(idx), s[key + "idx"])
+        assert np.array_equal(t2n(ids).astype(np.uint64), s[key + "id"])
+        assert np.array_equal(t2n(w), s[key + "w"])
+        assert np.array_equal(t2n(t), s[key + "t"])
+        n += 1
+    for n in range(4):
+        got = G.sample_node(64, s["sn_%d_types" % n], call_id=100 + n)
+        assert np.array_equal(t2n(got).astype(np.uint64), s["sn_%d" % n]), n
+    et = s["walk_et"]
+    L = et.shape[0]
+    assert np.array_equal(t2n(G.random_walk(qt, et.tolist(), 1.0, 1.0, -1, call_id=200)),
+                          s["walk_11"])
+    assert np.array_equal(t2n(G.random_walk(qt, et.tolist(), 0.25, 4.0, -1, call_id=300)),
+                          s["walk_n2v"])
+    assert np.array_equal(t2n(G.random_walk(qt, et.tolist(), 2.0, 0.5, 777, call_id=400)),
+                          s["walk_n2v_b"])
+    assert L == 6
+
+
+def test_fixture_goldens_gpu(EA, O, torch_cuda, fixture_csr, fixture_samples):
+    _check_pack(EA, O, torch_cuda, fixture_csr, fixture_samples)
+
+
+def test_random_graph_goldens_gpu(EA, O, torch_cuda, random_csr, random_samples):
+    _check_pack(EA, O, torch_cuda, random_csr, random_samples)
+
+
+@pytest.fixture(scope="module")
+def big_pair(EA, O):
+    rng = np.random.default_rng(77)
+    ids, seg, nbr, w, nt, nw = make_random_graph(rng, 20000, 4, max_deg=40,
+                                                 id_space=10 ** 12)
+    csr = O.csr_from_raw(ids, seg, nbr, w, 4, nt, nw)
+    return gpu_graph(EA, csr), O.OracleGraph(csr), ids, rng
+
+
+@pytest.mark.parametrize("et", [[0], [3], [1, 2], [3, 0, 1], [0, 1, 2, 3], [],
+                                [2, 2], [9], [1, 9]])
+def test_sample_neighbor_vs_oracle(EA, O, torch_cuda, big_pair, et):
+    torch = torch_cuda
+    G, OG, ids, rng = big_pair
+    q = np.concatenate([rng.choice(ids, 5000), [0, 2 ** 63 + 5]]).astype(np.uint64)
+    qt = torch.as_tensor(q.astype(np.int64)).cuda()
+    for count in (1, 10, 25):
+        G.set_seed(99)
+        idx, oid, ow, ot = OG.sample_neighbor_core(99, 5, q, et, count)
+        ids_g, w_g, t_g = G.sample_neighbor(qt, et, count, layout="core", call_id=5)
+        assert np.array_equal(t2n(ids_g).reshape(-1).astype(np.uint64), oid)
+        assert np.array_equal(t2n(w_g).reshape(-1), ow)
+        assert np.array_equal(t2n(t_g).reshape(-1), ot)
+        on, ow2, ot2 = OG.sample_neighbor(99, 5, q.astype(np.int64), et, count, -7)
+        ids_g, w_g, t_g = G.sample_neighbor(qt, et, count, default_node=-7, call_id=5)
+        assert np.array_equal(t2n(ids_g), on)
+        assert np.array_equal(t2n(w_g), ow2)
+        assert np.array_equal(t2n(t_g), ot2)
+
+
+def test_sample_fanout_vs_oracle(EA, O, torch_cuda, big_pair):
+    torch = torch_cuda
+    G, OG, ids, rng = big_pair
+    q = np.concatenate([rng.choice(ids, 1024), [0, 12345]]).astype(np.int64)
+    G.set_seed(7)
+    for et, counts in (([[0, 1, 2, 3], [0, 1, 2, 3]], [25, 10]),
+                       ([[1], [2]], [10, 5]), ([[0, 2], [3, 1]], [4, 3])):
+        ns, ws, ts = OG.sample_fanout(7, 40, q, et, counts, 10 ** 13)
+        gn, gw, gt = G.sample_fanout(torch.as_tensor(q).cuda(), et, counts,
+                                     10 ** 13, call_id=40)
+        assert np.array_equal(t2n(gn[0]), q)
+        for h in range(len(counts)):
+            assert np.array_equal(t2n(gn[h + 1]), ns[h]), (et, h)
+            assert np.array_equal(t2n(gw[h]), ws[h])
+            assert np.array_equal(t2n(gt[h]), ts[h])
+
+
+def test_sample_node_and_walks_vs_oracle(EA, O, torch_cuda, big_pair):
+    torch = torch_cuda
+    G, OG, ids, rng = big_pair
+    OG.build_node_sampler()
+    G.set_seed(5)
+    for call, types in enumerate([[-1], [0], [1], [0, 1]]):
+        a = OG.sample_node(5, call, types, 4096)
+        b = G.sample_node(4096, types, call_id=call)
+        assert np.array_equal(t2n(b).astype(np.uint64), a)
+    starts = np.concatenate([rng.choice(ids, 2000), [0]]).astype(np.int64)
+    st = torch.as_tensor(starts).cuda()
+    L = 12
+    et = [[0, 1, 2, 3]] * L
+    for p, q, dn in ((1.0, 1.0, -1), (0.5, 2.0, -1), (4.0, 0.25, 4242)):
+        a = OG.random_walk(5, 1000, starts, et, L, p, q, dn)
+        b = G.random_walk(st, et, p, q, dn, call_id=1000)
+        assert np.array_equal(t2n(b), a), (p, q)
+    et1 = [[2]] * L
+    assert np.array_equal(t2n(G.random_walk(st, et1, 1.0, 1.0, -1, call_id=50)),
+                          OG.random_walk(5, 50, starts, et1, L, 1.0, 1.0, -1))
+
+
+def test_graph_with_node_zero_sentinel_quirk(EA, O, torch_cuda):
+    """Q1: a live row whose first sample is node id 0 is dropped by the TF
+    layout; the kernel's slow check must reproduce it."""
+    torch = torch_cuda
+    ids = np.array([0, 1, 2, 3], np.uint64)
+    seg = np.array([0, 2, 4, 6, 7], np.int64)
+    nbr = np.array([1, 2, 0, 2, 0, 3, 0], np.uint64)
+    w = np.array([1, 1, 5, 1, 1, 1, 2], np.float32)
+    csr = O.csr_from_raw(ids, seg, nbr, w, 1)
+    G, OG = gpu_graph(EA, csr), O.OracleGraph(csr)
+    q = np.array([0, 1, 2, 3, 9], np.int64)
+    G.set_seed(1)
+    for call in range(30):
+        on, ow, ot = OG.sample_neighbor(1, call, q, [0], 3, -1)
+        gn, gw, gt = G.sample_neighbor(torch.as_tensor(q).cuda(), [0], 3, -1,
+                                       call_id=call)
+        assert np.array_equal(t2n(gn), on)
+        assert np.array_equal(t2n(gw), ow)
+        assert np.array_equal(t2n(gt), ot)
+    ns, ws, ts = OG.sample_fanout(1, 0, q, [[0], [0]], [3, 2], -1)
+    gn, gw, gt = G.sample_fanout(torch.as_tensor(q).cuda(), [[0], [0]], [3, 2], -1,
+                                 call_id=0)
+    for h in range(2):
+        assert np.array_equal(t2n(gn[h + 1]), ns[h])
+
+
+def test_empty_and_ragged_inputs(EA, O, torch_cuda, fixture_csr):
+    torch = torch_cuda
+    G = gpu_graph(EA, fixture_csr)
+    e = torch.zeros(0, dtype=torch.int64).cuda()
+    n, w, t = G.sample_neighbor(e, [0], 5)
+    assert tuple(n.shape) == (0, 5)
+    n, w, t = G.sample_neighbor(torch.tensor([1, 2]).cuda(), [0], 0)
+    assert tuple(n.shape) == (2, 0)
+    assert tuple(G.random_walk(e, [[0]] * 3).shape) == (0, 4)
+    idx, ids, w, t = G.get_full_neighbor(e, [0, 1])
+    assert ids.numel() == 0
+    assert G.sample_node(0, -1).numel() == 0
+    # zero-weight type -> EEMPTY error, no output (sample_node_op.cc:118-122)
+    from euler_amd._lib import EulerGpuError
+    with pytest.raises(EulerGpuError):
+        G.sample_node(4, 7)
+
+
+def test_mp_ops_goldens_and_oracle(EA, O, torch_cuda, ref_tests):
+    torch = torch_cuda
+    ops = EA.ops
+    t = ref_tests
+    x = torch.as_tensor(t["scatter_add_x"]).cuda()
+    idx = torch.as_tensor(t["scatter_idx"]).cuda()
+    assert np.array_equal(t2n(ops.scatter_add(x, idx, 2)), t["scatter_add_out"])
+    assert np.abs(t2n(ops.scatter_mean(x, idx, 2)) - t["scatter_mean_out"]).sum() < 1e-6
+    xm = torch.as_tensor(t["scatter_max_x"]).cuda()
+    assert np.array_equal(t2n(ops.scatter_max(xm, idx, 2)), t["scatter_max_out"])
+    assert np.all(t2n(ops.scatter_max(xm, idx, 3))[2] == np.float32(-1e9))
+    g = ops.gather(torch.as_tensor(t["gather_x"]).cuda(),
+                   torch.as_tensor(t["gather_idx"]).cuda())
+    assert np.array_equal(t2n(g), t["gather_out"])
+    pairs = ops.gen_pair(torch.as_tensor(t["gen_pair_in"]).cuda(), 2, 2)
+    assert np.array_equal(t2n(pairs), t["gen_pair_out"])
+    # random shapes: bit-exact vs the sequential reference loop, sorted and
+    # unsorted indices, D multiple of 4 or not
+    rng = np.random.default_rng(3)
+    for e, d, size, sort in ((5000, 32, 700, False), (4096, 100, 512, True),
+                             (777, 7, 50, False), (1, 3, 4, False)):
+        u = (rng.standard_normal((e, d)) * 100).astype(np.float32)
+        i = rng.integers(0, size, e).astype(np.int32)
+        if sort:
+            i = np.sort(i)
+        ut, it = torch.as_tensor(u).cuda(), torch.as_tensor(i).cuda()
+        assert np.array_equal(t2n(ops.scatter_add(ut, it, size)), O.scatter_add(u, i, size))
+        assert np.array_equal(t2n(ops.scatter_max(ut, it, size)), O.scatter_max(u, i, size))
+        p = rng.standard_normal((size, d)).astype(np.float32)
+        assert np.array_equal(t2n(ops.gather(torch.as_tensor(p).cuda(), it)), O.gather(p, i))
+        assert np.allclose(t2n(ops.scatter_mean(ut, it, size)), O.scatter_mean(u, i, size),
+                           rtol=0, atol=1e-5)
+
+
+def test_mp_gradients(EA, torch_cuda):
+    """mp_ops_test.py:38-94 check compute_gradient_error < 1e-4; here the
+    registered gradients are compared with torch's own autograd of the same
+    math (index_add / index_select / amax)."""
+    torch = torch_cuda
+    ops = EA.ops
+    x = torch.tensor([[1., 2., 7.], [3., 4., 8.], [5., 6., 7.]], device="cuda",
+                     requires_grad=True)
+    idx = torch.tensor([1, 0, 1], device="cuda")
+    g = torch.tensor([[1., 2., 3.], [4., 5., 6.]], device="cuda")
+    ops.scatter_add(x, idx, 2).backward(g)
+    assert torch.allclose(x.grad, g[idx])
+    x.grad = None
+    ops.scatter_mean(x, idx, 2).backward(g)
+    cnt = torch.tensor([[1.], [2.]], device="cuda") + 1e-7
+    assert torch.allclose(x.grad, (g / cnt)[idx], atol=1e-6)
+    x.grad = None
+    ops.scatter_max(x, idx, 2).backward(g)
+    ref = torch.zeros_like(x)
+    ref[1] = g[0]
+    ref[2, 0:2] = g[1, 0:2]
+    ref[0, 2] = g[1, 2] / 2
+    ref[2, 2] = g[1, 2] / 2
+    assert torch.allclose(x.grad, ref)
+    p = torch.tensor([[1., 2.], [3., 4.], [5., 6.]], device="cuda", requires_grad=True)
+    gi = torch.tensor([1, 0, 1, 2], device="cuda")
+    go = torch.arange(8, dtype=torch.float32, device="cuda").reshape(4, 2)
+    ops.gather(p, gi).backward(go)
+    ref = torch.zeros_like(p).index_add_(0, gi, go)
+    assert torch.allclose(p.grad, ref)
+
+
+def test_unique_gather_split_merge(EA, O, torch_cuda):
+    torch = torch_cuda
+    ops = EA.ops
+    uq, gi = ops.id_unique(torch.tensor([1, 2, 3, 3, 2, 2, 4]).cuda())
+    assert t2n(uq).tolist() == [1, 2, 3, 4]
+    assert t2n(gi).tolist() == [0, 1, 2, 2, 1, 1, 3]
+    idx = torch.tensor([[0, 2], [2, 5], [5, 6]], dtype=torch.int32).cuda()
+    gidx = torch.tensor([0, 1, 0, 2, 1], dtype=torch.int32).cuda()
+    oi, tot = ops.idx_gather(idx, gidx)
+    assert t2n(oi).reshape(-1).tolist() == [0, 2, 2, 5, 5, 7, 7, 8, 8, 11]
+    data = torch.tensor([11, 12, 21, 22, 23, 31]).cuda()
+    assert t2n(ops.data_gather(data, idx, gidx)).tolist() == [
+        11, 12, 21, 22, 23, 11, 12, 31, 21, 22, 23]
+    rng = np.random.default_rng(11)
+    ids = rng.integers(0, 5000, 40000).astype(np.uint64)
+    ids[::97] = np.uint64(2 ** 64 - 1)
+    uq_o, gi_o = O.id_unique(ids)
+    uq, gi = ops.id_unique(torch.as_tensor(ids.astype(np.int64)).cuda())
+    assert np.array_equal(t2n(uq).astype(np.uint64), uq_o)
+    assert np.array_equal(t2n(gi), gi_o)
+    for parts, shards in ((8, 3), (1024, 8), (8, 8), (5, 1)):
+        off_o, sid_o, mi_o = O.id_split(ids, parts, shards)
+        off, sid, mi = ops.id_split(torch.as_tensor(ids.astype(np.int64)).cuda(),
+                                    parts, shards)
+        assert list(off) == off_o.tolist()
+        assert np.array_equal(t2n(sid).astype(np.uint64), sid_o)
+        assert np.array_equal(t2n(mi), mi_o)
+        rows = torch.as_tensor(rng.integers(0, 9, (len(ids), 3)).astype(np.int32)).cuda()
+        merged = ops.merge_rows(rows, mi)
+        assert np.array_equal(t2n(merged)[mi_o], t2n(rows))
+
+
+def test_synthetic_graph_matches_host_generator(EA, O, torch_cuda):
+    torch = torch_cuda
+    for weighted, T in ((True, 1), (False, 1), (True, 3)):
+        p = EA.synth_params(4242, 30000, 300000, n_types=T, weighted=weighted)
+        po = O.SynthParams()
+        for f, _ in po._fields_:
+            setattr(po, f, getattr(p, f))
+        csr = O.synth_csr(po)
+        G = EA.Graph.synthetic(p)
+        assert G.num_nodes == 30000 and G.num_edges == len(csr.nbr)
+        ids = np.arange(1, 30001, dtype=np.uint64)
+        row_ptr, type_end, nbr, pw, tp = G.export_rows(ids)
+        assert np.array_equal(row_ptr, csr.row_ptr)
+        assert np.array_equal(type_end, csr.type_end)
+        assert np.array_equal(nbr, csr.nbr)
+        assert np.array_equal(pw, csr.prefix_w)
+        assert np.array_equal(tp, csr.type_prefix)
+        OG = O.OracleGraph(csr)
+        q = np.random.default_rng(1).integers(1, 30001, 4096).astype(np.int64)
+        G.set_seed(3)
+        et = [[0]] * 2 if T == 1 else [[0, 2], list(range(T))]
+        ns, ws, ts = OG.sample_fanout(3, 0, q, et, [25, 10], 30001)
+        gn, gw, gt = G.sample_fanout(torch.as_tensor(q).cuda(), et, [25, 10], 30001,
+                                     call_id=0)
+        for h in range(2):
+            assert np.array_equal(t2n(gn[h + 1]), ns[h])
+            assert np.array_equal(t2n(gw[h]), ws[h])
+            assert np.array_equal(t2n(gt[h]), ts[h])
+        # sharded build: shard s of 4 owns ids == s (mod 4); same samples
+        shards = [EA.Graph.synthetic(p, partitions=4, shard_index=s, shards=4)
+                  for s in range(4)]
+        assert sum(g.num_nodes for g in shards) == 30000
+        for s, g in enumerate(shards):
+            own = q[q % 4 == s]
+            g.set_seed(3)
+            a, b, c = g.sample_neighbor(torch.as_tensor(own).cuda(), et[0], 25,
+                                        30001, call_id=0)
+            ref = t2n(gn[1]).reshape(-1, 25)[q % 4 == s]
+            assert np.array_equal(t2n(a), ref)
+
+
+def test_op_registry_and_dat_loader(EA, O, torch_cuda, fixture_csr, tmp_path):
+    """The plugin-API mirror dispatches API_SAMPLE_NB to the GPU; the .dat
+    reader loads what euler/tools writes."""
+    import ctypes as C
+    from euler_amd import _lib
+    L = _lib.lib()
+    for op in (b"API_SAMPLE_NB", b"API_SAMPLE_NODE", b"ID_UNIQUE", b"IDX_GATHER",
+               b"DATA_GATHER", b"API_GET_NB_NODE"):
+        assert L.euler_op_registered(op) == 1
+    G = gpu_graph(EA, fixture_csr)
+    OG = O.OracleGraph(fixture_csr)
+    q = np.array([1, 2, 3, 4, 5, 6, 42], np.uint64)
+    et = np.array([0, 1], np.int32)
+    n, count = len(q), 4
+    idx = np.zeros((n, 2), np.int32)
+    oid = np.zeros(n * count, np.uint64)
+    ow = np.zeros(n * count, np.float32)
+    ot = np.zeros(n * count, np.int32)
+    got = L.euler_op_run_sample_nb(G._h, 77, q.ctypes.data_as(_lib.u64p), n,
+                                   et.ctypes.data_as(_lib.i32p), 2, count,
+                                   idx.ctypes.data_as(_lib.i32p),
+                                   oid.ctypes.data_as(_lib.u64p),
+                                   ow.ctypes.data_as(_lib.f32p),
+                                   ot.ctypes.data_as(_lib.i32p))
+    assert got == n * count
+    ridx, rid, rw, rt = OG.sample_neighbor_core(77, 0, q, et, count)
+    assert np.array_equal(idx, ridx) and np.array_equal(oid, rid)
+    assert np.array_equal(ow, rw) and np.array_equal(ot, rt)
+    # .dat round trip written with the record layout of node.cc:414-526
+    from test_host import write_dat_dir
+    write_dat_dir(tmp_path, fixture_csr, partitions=2)
+    G2 = EA.Graph.load(str(tmp_path))
+    assert G2.num_nodes == 6 and G2.num_edges == 12
+    rp, te, nb, pw, tp = G2.export_rows(fixture_csr.row_id)
+    assert np.array_equal(nb, fixture_csr.nbr) and np.array_equal(pw, fixture_csr.prefix_w)
+    assert np.array_equal(te, fixture_csr.type_end) and np.array_equal(tp, fixture_csr.type_prefix)
+    assert EA.initialize_embedded_graph(str(tmp_path))
+    EA.set_seed(9)
+    nb_ids, _, _ = EA.sample_neighbor(torch_cuda.tensor([1, 6]).cuda(), [0, 1], 3)
+    exp, _, _ = OG.sample_neighbor(9, 0, np.array([1, 6], np.int64), [0, 1], 3, -1)
+    assert np.array_equal(t2n(nb_ids), exp)
+
+
+def test_full_size_properties(EA, O, torch_cuda):
+    """At a size no CPU structure is asked to hold (2M nodes / 20M edges here;
+    bench.py does the same at 100M / 1B): determinism, membership (every
+    sampled (id, weight) is an edge of the root) and a bit-exact spot check of
+    1000 roots against the oracle fed with the exported rows."""
+    torch = torch_cuda
+    p = EA.synth_params(20240521, 2_000_000, 20_000_000, weighted=True)
+    G = EA.Graph.synthetic(p)
+    rng = np.random.default_rng(5)
+    q = rng.integers(1, 2_000_001, 200_000).astype(np.int64)
+    qt = torch.as_tensor(q).cuda()
+    G.set_seed(123)
+    a = G.sample_neighbor(qt, [0], 25, 2_000_001, call_id=9)
+    b = G.sample_neighbor(qt, [0], 25, 2_000_001, call_id=9)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    sel = rng.choice(len(q), 1000, replace=False)
+    rows = np.unique(q[sel]).astype(np.uint64)
+    row_ptr, type_end, nbr, pw, tp = G.export_rows(rows)
+    csr = O.CSR(rows, row_ptr, type_end, nbr, pw, tp, 1)
+    OG = O.OracleGraph(csr)
+    on, ow, ot = OG.sample_neighbor(123, 9, q[sel], [0], 25, 2_000_001)
+    assert np.array_equal(t2n(a[0])[sel], on)
+    assert np.array_equal(t2n(a[1])[sel], ow)
+    assert np.array_equal(t2n(a[2])[sel], ot)
