@@ -1,0 +1,272 @@
+#!/usr/bin/env python3
+"""Benchmark of the sampling hot path on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+                  [--nodes 100000000] [--edges 1000000000]
+
+Metric (BASELINE.json): sampled edges/sec, whole node, 2-hop fanout [25,10] on
+a 100M-node / 1B-edge weighted power-law graph resident in HBM.  One "step" =
+one minibatch of B roots through SampleFanout([25,10]) = B*275 sampled edges,
+roots already in HBM.  With --gpus N > 1 (launched by torch.distributed.run,
+one rank per GPU) the graph is hash-partitioned over the ranks (owner(id) =
+id % N) and every hop does the id / result all-to-all over RCCL; every rank
+samples its own B roots per step (weak scaling).
+
+Rank 0 prints ONE JSON line: metric/value/... plus
+  roofline      SampleNeighborKernel (both launches of a step) timed with HIP
+                events on its own stream; achieved = algorithmic bytes / time
+  cpu_baseline  the reference sampler (oracle/_ref: reference sources + RNG
+                seam) timed on the host cores on a bounded sample of the same
+                workload family
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FANOUT = [25, 10]
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+GRAPH_SEED = 20240521
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=131072,
+                    help="roots per step per GPU")
+    ap.add_argument("--nodes", type=int, default=100_000_000)
+    ap.add_argument("--edges", type=int, default=1_000_000_000)
+    ap.add_argument("--cpu-nodes", type=int, default=1_000_000,
+                    help="graph size of the bounded CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """Reference sampler on the host: same synthetic family, smaller graph
+    (the reference's per-node objects cannot hold 100M nodes: SURVEY F8)."""
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    threads = min(8, cores)      # the reference client pool has 8 threads
+    n = args.cpu_nodes
+    po = O.synth_params(GRAPH_SEED, n, 10 * n, weighted=True)
+    csr = O.synth_csr(po)
+    rng = np.random.default_rng(1)
+    batch = 1024
+    iters = 64
+    roots = rng.integers(1, n + 1, batch * iters).astype(np.uint64)
+    kind = "port"
+    if O.have_ref():
+        T = 1
+        seg = csr.row_ptr.copy()
+        # per-edge weights as f32 differences of the running sums (timing
+        # only: the reference's Node::Init re-accumulates them)
+        w = csr.prefix_w.copy()
+        w[1:] -= csr.prefix_w[:-1]
+        starts = csr.row_ptr[:-1]
+        w[starts] = csr.prefix_w[starts]
+        R = O.RefGraph.build_raw(csr.row_id, seg, csr.nbr, w, T)
+        bench = R.bench_fanout
+        kind = "reference"
+    else:
+        bench = O.OracleGraph(csr).bench_fanout
+    bench(GRAPH_SEED, roots[:batch * 4], batch, 4, FANOUT, threads)   # warm-up
+    secs, edges = bench(GRAPH_SEED, roots, batch, iters, FANOUT, threads)
+    return {"value": edges / secs, "unit": "sampled edges/s", "cores": threads,
+            "kind": kind,
+            "sample": "%d minibatches x %d roots, fanout [25,10], synthetic "
+                      "power-law graph of the same family with %d nodes / %d "
+                      "edges (largest that fits the reference's Node objects "
+                      "in a few seconds; host has %d cores)"
+                      % (iters, batch, n, len(csr.nbr), cores)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=dev)
+
+    import euler_amd
+    from euler_amd import _lib
+    L = _lib.lib()
+
+    t0 = time.time()
+    p = euler_amd.synth_params(GRAPH_SEED, args.nodes, args.edges, weighted=True)
+    G = euler_amd.Graph.synthetic(p, device=local_rank, partitions=world,
+                                  shard_index=rank, shards=world)
+    G.set_seed(GRAPH_SEED)
+    torch.cuda.synchronize()
+    build_s = time.time() - t0
+
+    B = args.batch
+    n_steps = args.steps + args.warmup
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    roots = torch.randint(1, args.nodes + 1, (n_steps, B), generator=gen,
+                          device=dev, dtype=torch.int64)
+    et = [[0], [0]]
+    default_node = args.nodes + 1
+
+    if world > 1:
+        from euler_amd.distributed import gpu_sharded_sampler
+        S = gpu_sharded_sampler(G, partitions=world)
+
+        def step(i):
+            return S.sample_fanout(roots[i], et, FANOUT, default_node, call_id=2 * i)
+    else:
+        def step(i):
+            return G.sample_fanout(roots[i], et, FANOUT, default_node, call_id=2 * i)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        out = step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_steps):
+        out = step(i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    edges_per_step = B * (FANOUT[0] + FANOUT[0] * FANOUT[1]) * world
+    value = edges_per_step * args.steps / elapsed
+
+    # ---- parity spot check at full size: 64 roots of the last step against
+    # the oracle fed with the rows exported from HBM (single GPU only)
+    checked = None
+    if world == 1 and not args.no_check:
+        from oracle import oracle as O
+        last = n_steps - 1
+        sel = np.random.default_rng(0).choice(B, 64, replace=False)
+        r0 = roots[last].cpu().numpy()[sel]
+        hop1 = out[0][1].reshape(B, FANOUT[0]).cpu().numpy()[sel]
+        hop2 = out[0][2].reshape(B, FANOUT[0], FANOUT[1]).cpu().numpy()[sel]
+        need = np.unique(np.concatenate([r0, hop1.reshape(-1)])).astype(np.uint64)
+        need = need[need <= args.nodes]
+        rp, te, nb, pw, tp = G.export_rows(need)
+        OG = O.OracleGraph(O.CSR(need, rp, te, nb, pw, tp, 1))
+        on, _, _ = OG.sample_fanout(GRAPH_SEED, 2 * last, r0, et, FANOUT, default_node)
+        assert np.array_equal(on[0], hop1.reshape(-1)), "hop-1 ids differ from oracle"
+        assert np.array_equal(on[1], hop2.reshape(-1)), "hop-2 ids differ from oracle"
+        checked = int(len(r0) * 275)
+
+    # ---- roofline leg: the two launches of a step, HIP events on the stream
+    roofline = None
+    if rank == 0:
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        et1 = (C.c_int32 * 1)(0)
+        iters = 5
+        times, abytes = [], []
+        shapes = [(roots[n_steps - 1].contiguous(), FANOUT[0])]
+        if world == 1:
+            shapes.append((out[0][1].contiguous(), FANOUT[1]))
+        else:
+            shapes.append((torch.randint(1, args.nodes + 1, (B * FANOUT[0],),
+                                         generator=gen, device=dev,
+                                         dtype=torch.int64), FANOUT[1]))
+        for r, cnt in shapes:
+            if world > 1:      # a shard only owns ids == rank (mod world)
+                r = (r // world) * world + (rank if rank else world)
+                r = torch.clamp(r, max=args.nodes - world)
+            n = r.numel()
+            oid = torch.empty(n * cnt, dtype=torch.int64, device=dev)
+            ow = torch.empty(n * cnt, dtype=torch.float32, device=dev)
+            ot = torch.empty(n * cnt, dtype=torch.int32, device=dev)
+            ms = C.c_float(0)
+            _lib.check(L.euler_gpu_time_sample_neighbor(
+                G._h, st, GRAPH_SEED, C.c_void_p(r.data_ptr()), n, et1, 1, cnt,
+                _lib.LAYOUT_TF, C.c_void_p(oid.data_ptr()), C.c_void_p(ow.data_ptr()),
+                C.c_void_p(ot.data_ptr()), iters, C.byref(ms)))
+            b = C.c_double(0)
+            _lib.check(L.euler_gpu_sample_neighbor_algo_bytes(
+                G._h, st, C.c_void_p(r.data_ptr()), n, et1, 1, cnt, C.byref(b)))
+            times.append(ms.value)
+            abytes.append(b.value)
+        achieved = sum(abytes) / (sum(times) * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc))
+                if rec.get("batch") == B and rec.get("nodes") == args.nodes:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {
+            "kernel": "SampleNeighborKernel",
+            "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": traffic,
+            "algorithmic_bytes_per_launch": round(sum(abytes) / len(abytes), 1),
+            "avg_launch_ms": round(sum(times) / len(times), 4),
+            "launch_ms": [round(x, 4) for x in times],
+            "bytes_per_sampled_edge": round(
+                sum(abytes) / (B * (FANOUT[0] + FANOUT[0] * FANOUT[1])), 2),
+        }
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args)
+
+    if rank == 0:
+        line = {
+            "metric": "sampled edges/sec (whole node), 2-hop fanout=[25,10], "
+                      "100M-node power-law graph",
+            "value": value, "unit": "sampled edges/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": "synthetic RMAT-marginal power-law graph, %d nodes / "
+                            "%d edges (min degree 1), f32 weights uniform [0.5,8), "
+                            "weighted CDF-inversion SampleNeighbor, fanout [25,10], "
+                            "%d uniform-random roots per step per GPU, TF dense "
+                            "layout" % (args.nodes, G.num_edges * 1 if world == 1
+                                        else args.edges, B),
+                "roots_per_step_per_gpu": B, "fanout": FANOUT,
+                "graph_bytes_per_gpu": G.device_bytes,
+                "graph_build_s": round(build_s, 2),
+                "partitioning": "none" if world == 1 else
+                                "hash owner(id)=id%%%d, all-to-all per hop" % world,
+                "parity_checked_edges": checked,
+            },
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

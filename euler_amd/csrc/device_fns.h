@@ -15,7 +15,9 @@ __device__ __forceinline__ int64_t FindRow(const GraphView& g, uint64_t id) {
     return (r * g.id_stride == d && r < (uint64_t)g.n_rows) ? (int64_t)r : -1;
   }
   uint64_t h = Mix64(id) & g.hash_mask;
-  for (;;) {
+  // the table is at most half full, so a probe sequence always meets an empty
+  // slot; the bound only keeps a corrupted table from hanging the GPU
+  for (uint64_t probes = 0; probes <= g.hash_mask; ++probes) {
     // one 16-byte slot = {key, row}
     const ulonglong2 s =
         *reinterpret_cast<const ulonglong2*>(g.hash_slots + 2 * h);
@@ -23,6 +25,7 @@ __device__ __forceinline__ int64_t FindRow(const GraphView& g, uint64_t id) {
     if (s.x == id) return (int64_t)s.y;
     h = (h + 1) & g.hash_mask;
   }
+  return -1;
 }
 
 struct RowMeta {
@@ -61,7 +64,9 @@ __device__ __forceinline__ uint64_t RandomSelectT(const SumAt& sw,
   const double r = ScaleDraw(u, limit_begin, limit_end);
   uint64_t low = begin_pos, high = end_pos, mid = 0;
   bool finish = false;
-  while (low <= high && !finish) {
+  // a bisection over a 64-bit range ends within 64 probes; the counter only
+  // bounds the loop on NaN sums (where the reference would spin forever)
+  for (int probes = 0; low <= high && !finish && probes < 65; ++probes) {
     mid = (low + high) >> 1;
     const float interval_begin = mid == 0 ? 0.f : sw(mid - 1);
     const float interval_end = sw(mid);

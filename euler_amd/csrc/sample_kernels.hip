@@ -621,10 +621,12 @@ int euler_gpu_get_full_neighbor(const euler_gpu_graph* g, void* stream,
                                 uint64_t* out_id_dev, float* out_w_dev,
                                 int32_t* out_t_dev) {
   if (!g) return Fail(EULER_GPU_ENOGRAPH, "get_full_neighbor: null graph");
-  if (n < 0 || k < 0 || k > kMaxListedTypes || !idx_dev)
+  if (n < 0 || k < 0 || k > kMaxListedTypes)
     return Fail(EULER_GPU_EINVAL, "get_full_neighbor: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   if (n == 0) { if (total_host) *total_host = 0; return EULER_GPU_OK; }
+  if (!idx_dev || !ids_dev)
+    return Fail(EULER_GPU_EINVAL, "get_full_neighbor: null buffer");
   FullNbArgs a{};
   a.g = g->view; a.ids = ids_dev; a.n = n; a.k = k;
   for (int i = 0; i < k; ++i) a.et[i] = edge_types_host[i];

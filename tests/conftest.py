@@ -13,6 +13,16 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # Safety net: a runaway host allocation must raise MemoryError in the test
+    # process instead of taking the (shared) box down with it.
+    try:
+        import resource
+        cap = 48 << 30
+        soft, hard = resource.getrlimit(resource.RLIMIT_DATA)
+        if hard == resource.RLIM_INFINITY or hard > cap:
+            resource.setrlimit(resource.RLIMIT_DATA, (cap, hard))
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")
@@ -64,7 +74,10 @@ def make_random_graph(rng, n, T, max_deg=12, id_space=None, zero_frac=0.1,
                       empty_frac=0.3):
     """Raw heterogeneous adjacency: (ids, seg_ptr, nbr, w, node_type, node_w)."""
     id_space = id_space or 10 * n
-    ids = np.sort(rng.choice(np.arange(1, id_space), n, replace=False)).astype(np.uint64)
+    # never materialise the id space (id_space may be 1e12): draw, then dedup
+    ids = np.unique(rng.integers(1, id_space, size=3 * n, dtype=np.int64))
+    assert len(ids) >= n
+    ids = np.sort(rng.permutation(ids)[:n]).astype(np.uint64)
     deg = rng.integers(0, max_deg, size=(n, T))
     deg[rng.random((n, T)) < empty_frac] = 0
     seg = np.zeros(n * T + 1, np.int64)

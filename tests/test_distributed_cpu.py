@@ -1,0 +1,117 @@
+"""world_size-2 gloo test of the sharded sampling path's host logic
+(euler_amd/distributed.py): bucket by owner -> all-to-all ids -> local sample
+-> all-to-all results -> inverse permutation.  The local sampler / split /
+merge are test doubles backed by the CPU oracle (the product's are HIP
+kernels); the result must be bit-identical to the unsharded oracle."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _build_csr(O):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import make_random_graph
+    rng = np.random.default_rng(4)
+    ids, seg, nbr, w, nt, nw = make_random_graph(rng, 600, 3, max_deg=10,
+                                                 id_space=4000)
+    return O.csr_from_raw(ids, seg, nbr, w, 3, nt, nw), ids
+
+
+def _shard_csr(O, csr, partitions, rank, world):
+    own = O.shard_of(csr.row_id, partitions, world) == rank
+    rows = np.nonzero(own)[0]
+    T = csr.n_types
+    row_ptr = [0]
+    nbr, pw, te, tp = [], [], [], []
+    for r in rows:
+        b, e = csr.row_ptr[r], csr.row_ptr[r + 1]
+        nbr.append(csr.nbr[b:e]); pw.append(csr.prefix_w[b:e])
+        te.append(csr.type_end[r * T:(r + 1) * T]); tp.append(csr.type_prefix[r * T:(r + 1) * T])
+        row_ptr.append(row_ptr[-1] + (e - b))
+    cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dt)
+    return O.CSR(csr.row_id[rows], np.array(row_ptr, np.int64), cat(te, np.int32),
+                 cat(nbr, np.uint64), cat(pw, np.float32), cat(tp, np.float32), T)
+
+
+def _worker(rank, world, port, partitions, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from euler_amd.distributed import ShardedSampler, owner_of
+    csr, ids = _build_csr(O)
+    OG_local = O.OracleGraph(_shard_csr(O, csr, partitions, rank, world))
+    OG_full = O.OracleGraph(csr)
+    seed = 99
+
+    def local_sample(owned, edge_types, count, default_node, call_id):
+        q = owned.numpy().astype(np.int64)
+        # every id routed here must be owned by this rank
+        assert np.all(O.shard_of(q.astype(np.uint64), partitions, world) == rank)
+        n, w, t = OG_local.sample_neighbor(seed, call_id, q, edge_types, count,
+                                           default_node)
+        _, cid, _, _ = OG_local.sample_neighbor_core(seed, call_id, q.astype(np.uint64),
+                                                     edge_types, count)
+        mask = (cid.reshape(len(q), count)[:, 0] == 0).astype(np.uint8) if count else \
+            np.zeros(len(q), np.uint8)
+        return (torch.as_tensor(n), torch.as_tensor(w), torch.as_tensor(t),
+                torch.as_tensor(mask))
+
+    def split_fn(roots, parts, shards):
+        off, sid, mi = O.id_split(roots.numpy().astype(np.uint64), parts, shards)
+        return off.tolist(), torch.as_tensor(sid.astype(np.int64)), torch.as_tensor(mi)
+
+    def merge_fn(rows, merge_idx):
+        out = torch.empty_like(rows)
+        out[merge_idx.long()] = rows
+        return out
+
+    S = ShardedSampler(local_sample, split_fn, merge_fn, partitions)
+    rng = np.random.default_rng(10 + rank)
+    roots = np.concatenate([rng.choice(ids, 257 + 64 * rank),
+                            [0, 5, 2 ** 63 + 11]]).astype(np.uint64).astype(np.int64)
+    # owner_of agrees with the reference's unsigned modulo
+    assert np.array_equal(owner_of(torch.as_tensor(roots), partitions, world).numpy(),
+                          O.shard_of(roots.astype(np.uint64), partitions, world))
+    for et, counts in (([[0, 1, 2], [0, 1, 2]], [5, 3]), ([[1], [2]], [4, 2]),
+                       ([[0, 2], [2, 1]], [3, 3])):
+        ns, ws, ts = S.sample_fanout(torch.as_tensor(roots), et, counts, -1, 40)
+        on, ow, ot = OG_full.sample_fanout(seed, 40, roots, et, counts, -1)
+        for h in range(len(counts)):
+            assert np.array_equal(ns[h + 1].numpy(), on[h]), (rank, et, h)
+            assert np.array_equal(ws[h].numpy(), ow[h])
+            assert np.array_equal(ts[h].numpy(), ot[h])
+    # empty request from one rank must not dead-lock the exchange
+    empty = torch.zeros(0, dtype=torch.int64) if rank == 0 else torch.as_tensor(roots)
+    n1, w1, t1, m1 = S.sample_neighbor(empty, [0], 2, -1, 7)
+    assert n1.shape[0] == empty.numel()
+    dist.barrier()
+    open(os.path.join(out_dir, "ok_%d" % rank), "w").write("ok")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("partitions", [2, 8])
+def test_sharded_fanout_matches_unsharded_gloo(O, tmp_path, partitions):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, partitions, str(tmp_path)), nprocs=world,
+             join=True)
+    for r in range(world):
+        assert os.path.exists(tmp_path / ("ok_%d" % r))
