@@ -319,7 +319,7 @@ def test_synthetic_graph_matches_host_generator(EA, O, torch_cuda):
         OG = O.OracleGraph(csr)
         q = np.random.default_rng(1).integers(1, 30001, 4096).astype(np.int64)
         G.set_seed(3)
-        et = [[0]] * 2 if T == 1 else [[0, 2], list(range(T))]
+        et = [[0]] * 2 if T == 1 else [[0, 2], [2, 1]]
         ns, ws, ts = OG.sample_fanout(3, 0, q, et, [25, 10], 30001)
         gn, gw, gt = G.sample_fanout(torch.as_tensor(q).cuda(), et, [25, 10], 30001,
                                      call_id=0)
