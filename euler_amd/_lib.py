@@ -100,6 +100,7 @@ SIGNATURES = {
     "euler_gpu_sample_neighbor_algo_bytes": (C.c_int, [vp, vp, vp, C.c_int64, i32p,
                                                        C.c_int32, C.c_int32,
                                                        C.POINTER(C.c_double)]),
+    "euler_gpu_set_tuning": (C.c_int, [C.c_int32, C.c_int32]),
     "euler_op_registered": (C.c_int, [C.c_char_p]),
     "euler_op_run_sample_nb": (C.c_int64, [vp, C.c_uint64, u64p, C.c_int64, i32p,
                                            C.c_int32, C.c_int32, i32p, u64p, f32p,

@@ -55,6 +55,10 @@ struct GraphView {
   int32_t meta_stride;          // 8 + 8*T
   int32_t map_mode;             // 0 = strided identity, 1 = hash table
   int32_t has_zero_nbr;         // a neighbor id equals the sentinel 0 (Q1)
+  int32_t monotone;             // every row's prefix_w is non-decreasing, >= 0
+                                // and NaN-free (true for non-negative weights):
+                                // licence for the single-load search of K1
+  int32_t pad0;
   uint64_t id_base;             // identity: row = (id - id_base) / id_stride
   uint64_t id_stride;
   const uint64_t* hash_slots;   // [2 * (hash_mask + 1)] = {key, row} pairs

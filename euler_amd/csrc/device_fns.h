@@ -73,6 +73,11 @@ __device__ __forceinline__ uint64_t RandomSelectT(const SumAt& sw,
     if ((double)interval_begin <= r && r < (double)interval_end) {
       finish = true;
     } else if ((double)interval_begin > r) {
+      // r >= limit_begin = sw(begin_pos - 1) in every valid call, so this branch
+      // is never taken at mid == begin_pos (Q4); the guard keeps a row with
+      // decreasing sums (negative weights: out-of-range reads in the reference)
+      // from walking outside [begin_pos, end_pos].
+      if (mid == begin_pos) break;
       high = mid - 1;
     } else if ((double)interval_end <= r) {
       low = mid + 1;

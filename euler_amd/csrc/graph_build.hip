@@ -212,6 +212,7 @@ int BuildGraphFromHost(const euler_gpu_host_csr* c, int device,
   std::vector<float> pw((size_t)E);
   int64_t off = 0;
   bool zero_nbr = false;
+  bool monotone = true;
   for (int64_t i = 0; i < n; ++i) {
     const int64_t r = keep[i];
     row_id[i] = c->row_id[r];
@@ -225,12 +226,19 @@ int BuildGraphFromHost(const euler_gpu_host_csr* c, int device,
     if (deg > 0) {
       std::memcpy(nbr.data() + off, c->nbr + b0, (size_t)deg * 8);
       std::memcpy(pw.data() + off, c->prefix_w + b0, (size_t)deg * 4);
-      for (int64_t j = 0; j < deg; ++j) zero_nbr |= c->nbr[b0 + j] == 0;
+      float prev = 0.f;
+      for (int64_t j = 0; j < deg; ++j) {
+        zero_nbr |= c->nbr[b0 + j] == 0;
+        const float cur = c->prefix_w[b0 + j];
+        monotone &= cur >= prev;           // false for NaN too
+        prev = cur;
+      }
     }
     off += deg;
   }
   v.n_edges = E;
   v.has_zero_nbr = zero_nbr ? 1 : 0;
+  v.monotone = monotone ? 1 : 0;
   v.row_meta = b.Upload(meta.data(), meta.size());
   v.nbr = b.Upload(nbr.data(), nbr.size());
   v.prefix_w = b.Upload(pw.data(), pw.size());
@@ -437,6 +445,7 @@ int BuildGraphSynthetic(const euler_gpu_synth_params* sp, int device,
   v.T = T; v.meta_stride = 8 + 8 * T; v.n_rows = n_rows;
   v.map_mode = 0; v.id_base = base; v.id_stride = stride; v.row_id = nullptr;
   v.has_zero_nbr = 0;
+  v.monotone = 1;     // weights are >= 0.5: f32 running sums never decrease
   SynthView p{};
   p.seed = sp->seed; p.n_nodes = sp->n_nodes; p.scale = sp->scale;
   p.n_types = sp->n_types; p.weighted = sp->weighted;

@@ -85,6 +85,125 @@ __global__ __launch_bounds__(256) void SampleNeighborKernel(const SampleNbArgs a
   }
 }
 
+// ------------------------------------------------------------------------
+// K1 fast path: single listed edge type (the GraphSAGE / DeepWalk case) on a
+// graph whose prefix sums are monotone (GraphView::monotone).
+//
+// Same lane-per-sample mapping, but the per-sample instruction stream is cut
+// to what the hardware needs:
+//   * (root, slot) advance incrementally through the grid-stride loop - one
+//     64-bit division per lane per launch instead of one per sample;
+//   * 32-bit row-relative indices;
+//   * the search is a single-load upper bound (first m with sw[m] > r).  With
+//     non-decreasing sums the interval that holds r is unique, so this is the
+//     index the reference's bisection returns (compact_weighted_collection.h:
+//     37-50); when NO interval holds r (r rounded up to the segment's end, Q3)
+//     the lane replays the reference's exact probe sequence instead.
+// ------------------------------------------------------------------------
+template <bool TF_LAYOUT, bool ZERO_CHECK>
+__device__ __forceinline__ void FastSampleOne(const GraphView& g,
+                                              const float* __restrict__ nw,
+                                              const uint64_t* __restrict__ nbr,
+                                              int32_t b, int32_t e, double u,
+                                              uint64_t* out_id, float* out_w) {
+  const float limit_begin = b == 0 ? 0.f : nw[b - 1];
+  const float limit_end = nw[e];
+  const double r = ScaleDraw(u, limit_begin, limit_end);
+  int32_t lo = b, hi = e + 1;
+  while (lo < hi) {
+    const int32_t mid = (int32_t)(((uint32_t)lo + (uint32_t)hi) >> 1);
+    if ((double)nw[mid] > r) hi = mid; else lo = mid + 1;
+  }
+  int32_t m = lo;
+  float pre;
+  if (m <= e) {
+    pre = m == 0 ? 0.f : nw[m - 1];
+  } else {
+    // fall-through of RandomSelect: replay the reference probe sequence
+    m = (int32_t)RandomSelect(nw, (uint64_t)b, (uint64_t)e, u);
+    pre = m == 0 ? 0.f : nw[m - 1];
+  }
+  *out_id = nbr[m];
+  *out_w = __fsub_rn(nw[m], pre);
+}
+
+template <bool TF_LAYOUT, bool ZERO_CHECK>
+__global__ __launch_bounds__(256) void SampleNeighborFastKernel(
+    const SampleNbArgs a, const int64_t stride_rows, const int32_t stride_slots) {
+  const int64_t total = a.n * (int64_t)a.count;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= total) return;
+  int64_t r = s / a.count;
+  int32_t j = (int32_t)(s - r * a.count);
+  const int32_t t = a.et[0];
+  const int32_t T = a.g.T;
+  for (; s < total; s += stride) {
+    uint64_t node = a.roots[r];
+    if (a.root_mask != nullptr && a.root_mask[r / a.root_group]) node = 0;
+    const int64_t row = FindRow(a.g, node);
+    uint64_t id = 0;
+    float w = 0.f;
+    bool valid = false;
+    if (row >= 0 && t >= 0 && t < T) {
+      const uint8_t* rec = a.g.row_meta + row * (int64_t)a.g.meta_stride;
+      int64_t row_ptr;
+      int32_t b, e;
+      if (T == 1) {
+        // {row_ptr, type_end[0], type_prefix[0]} in one 16-byte load
+        const uint4 q = *reinterpret_cast<const uint4*>(rec);
+        row_ptr = (int64_t)(((uint64_t)q.y << 32) | q.x);
+        b = 0;
+        e = (int32_t)q.z - 1;
+      } else {
+        row_ptr = *reinterpret_cast<const int64_t*>(rec);
+        const int32_t* te = reinterpret_cast<const int32_t*>(rec + 8);
+        b = t == 0 ? 0 : te[t - 1];
+        e = te[t] - 1;
+      }
+      if (e >= b) {                                       // node.cc:133-135
+        valid = true;
+        const Philox4 blk = RngBlock(a.seed, a.call_id, kDomainNeighbor, node,
+                                     ((uint32_t)j) >> 1);
+        const double u = (j & 1) ? UnitFromWords(blk.w[2], blk.w[3])
+                                 : UnitFromWords(blk.w[0], blk.w[1]);
+        const float* nw = a.g.prefix_w + row_ptr;
+        const uint64_t* nbr = a.g.nbr + row_ptr;
+        FastSampleOne<TF_LAYOUT, ZERO_CHECK>(a.g, nw, nbr, b, e, u, &id, &w);
+        if (TF_LAYOUT && ZERO_CHECK) {
+          // Q1: the row is dropped when its FIRST sample is the sentinel id 0
+          uint64_t id0 = id;
+          if (j != 0) {
+            const Philox4 b0 = RngBlock(a.seed, a.call_id, kDomainNeighbor, node, 0);
+            float w0;
+            FastSampleOne<TF_LAYOUT, ZERO_CHECK>(a.g, nw, nbr, b, e,
+                                                 UnitFromWords(b0.w[0], b0.w[1]),
+                                                 &id0, &w0);
+          }
+          valid = id0 != 0;
+        }
+      }
+    }
+    int32_t ot = t;
+    if (!valid) {
+      if (TF_LAYOUT) { id = (uint64_t)a.default_node; w = 0.f; ot = -1; }
+      else { id = 0; w = 0.f; ot = 0; }
+    }
+    a.out_id[s] = id;
+    a.out_w[s] = w;
+    a.out_t[s] = ot;
+    if (j == 0 && a.out_row_mask != nullptr) a.out_row_mask[r] = valid ? 0 : 1;
+    // advance (root, slot) by the grid stride without dividing
+    r += stride_rows;
+    j += stride_slots;
+    if (j >= a.count) { j -= a.count; ++r; }
+  }
+}
+
+namespace {
+int g_k1_variant = 1;   // 1 = fast path when applicable, 0 = always generic
+}
+
 static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
                                 uint64_t seed, uint32_t call_id,
                                 const uint64_t* roots, int64_t n,
@@ -116,7 +235,20 @@ static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
   for (int i = 0; i < k; ++i) a.et[i] = edge_types[i];
   const int block = 256;
   const int grid = GridFor(n * (int64_t)count, block);
-  hipLaunchKernelGGL(SampleNeighborKernel, dim3(grid), dim3(block), 0, stream, a);
+  if (g_k1_variant == 1 && k == 1 && g->view.monotone) {
+    const int64_t stride = (int64_t)grid * block;
+    const int64_t stride_rows = stride / count;
+    const int32_t stride_slots = (int32_t)(stride - stride_rows * count);
+    const bool tf = layout == EULER_GPU_LAYOUT_TF;
+    const bool zc = g->view.has_zero_nbr != 0;
+    auto kern = tf ? (zc ? SampleNeighborFastKernel<true, true>
+                         : SampleNeighborFastKernel<true, false>)
+                   : SampleNeighborFastKernel<false, false>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, stream, a, stride_rows,
+                       stride_slots);
+  } else {
+    hipLaunchKernelGGL(SampleNeighborKernel, dim3(grid), dim3(block), 0, stream, a);
+  }
   EG_HIP(hipGetLastError());
   return EULER_GPU_OK;
 }
@@ -486,6 +618,11 @@ __global__ void AlgoBytesKernel(const FullNbArgs a, int32_t count, double* acc) 
 using namespace euler_gpu;
 
 extern "C" {
+
+int euler_gpu_set_tuning(int32_t key, int32_t value) {
+  if (key == 0) { g_k1_variant = value; return EULER_GPU_OK; }
+  return Fail(EULER_GPU_EINVAL, "set_tuning: unknown key");
+}
 
 int euler_gpu_sample_neighbor(const euler_gpu_graph* g, void* stream,
                               uint64_t seed, uint32_t call_id,

@@ -279,6 +279,12 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
                                 const float* shard_weight_host, int32_t shards,
                                 int32_t* split_cnt_host);
 
+/* ---- tuning ---------------------------------------------------------------
+ * key 0: sample_neighbor kernel variant (1 = specialised single-type kernel when
+ * applicable [default], 0 = always the generic reference-loop kernel).  Both
+ * produce identical results; the knob exists for A/B measurements and tests. */
+int euler_gpu_set_tuning(int32_t key, int32_t value);
+
 /* ---- measurement helper -------------------------------------------------------
  * Runs the sample_neighbor kernel `iters` times on `stream` between two HIP
  * events recorded on that same stream and returns the mean kernel time in

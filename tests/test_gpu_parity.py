@@ -27,6 +27,16 @@ def EA(torch_cuda):
     return euler_amd
 
 
+@pytest.fixture(params=[1, 0], ids=["k1fast", "k1generic"])
+def k1_variant(request, EA):
+    """Run with the specialised single-type K1 kernel and with the generic
+    reference-loop kernel: both must match the oracle bit for bit."""
+    from euler_amd import _lib
+    _lib.lib().euler_gpu_set_tuning(0, request.param)
+    yield request.param
+    _lib.lib().euler_gpu_set_tuning(0, 1)
+
+
 def gpu_graph(EA, csr, order=None, **kw):
     return EA.Graph.from_csr(csr.row_id, csr.row_ptr, csr.type_end, csr.nbr,
                              csr.prefix_w, csr.type_prefix, csr.n_types,
@@ -99,7 +109,7 @@ def big_pair(EA, O):
 
 @pytest.mark.parametrize("et", [[0], [3], [1, 2], [3, 0, 1], [0, 1, 2, 3], [],
                                 [2, 2], [9], [1, 9]])
-def test_sample_neighbor_vs_oracle(EA, O, torch_cuda, big_pair, et):
+def test_sample_neighbor_vs_oracle(EA, O, torch_cuda, big_pair, et, k1_variant):
     torch = torch_cuda
     G, OG, ids, rng = big_pair
     q = np.concatenate([rng.choice(ids, 5000), [0, 2 ** 63 + 5]]).astype(np.uint64)
@@ -118,7 +128,7 @@ def test_sample_neighbor_vs_oracle(EA, O, torch_cuda, big_pair, et):
         assert np.array_equal(t2n(t_g), ot2)
 
 
-def test_sample_fanout_vs_oracle(EA, O, torch_cuda, big_pair):
+def test_sample_fanout_vs_oracle(EA, O, torch_cuda, big_pair, k1_variant):
     torch = torch_cuda
     G, OG, ids, rng = big_pair
     q = np.concatenate([rng.choice(ids, 1024), [0, 12345]]).astype(np.int64)
@@ -157,7 +167,7 @@ def test_sample_node_and_walks_vs_oracle(EA, O, torch_cuda, big_pair):
                           OG.random_walk(5, 50, starts, et1, L, 1.0, 1.0, -1))
 
 
-def test_graph_with_node_zero_sentinel_quirk(EA, O, torch_cuda):
+def test_graph_with_node_zero_sentinel_quirk(EA, O, torch_cuda, k1_variant):
     """Q1: a live row whose first sample is node id 0 is dropped by the TF
     layout; the kernel's slow check must reproduce it."""
     torch = torch_cuda
@@ -299,7 +309,7 @@ def test_unique_gather_split_merge(EA, O, torch_cuda):
         assert np.array_equal(t2n(merged)[mi_o], t2n(rows))
 
 
-def test_synthetic_graph_matches_host_generator(EA, O, torch_cuda):
+def test_synthetic_graph_matches_host_generator(EA, O, torch_cuda, k1_variant):
     torch = torch_cuda
     for weighted, T in ((True, 1), (False, 1), (True, 3)):
         p = EA.synth_params(4242, 30000, 300000, n_types=T, weighted=weighted)
@@ -407,3 +417,33 @@ def test_full_size_properties(EA, O, torch_cuda):
     assert np.array_equal(t2n(a[0])[sel], on)
     assert np.array_equal(t2n(a[1])[sel], ow)
     assert np.array_equal(t2n(a[2])[sel], ot)
+
+
+def test_non_monotone_rows_use_reference_loop(EA, O, torch_cuda):
+    """Negative weights make the running sums non-monotone; the reference's
+    RandomSelect then reads outside the row (size_t underflow of `mid - 1`,
+    compact_weighted_collection.h:45), so there is no oracle answer to compare
+    with.  The builder detects such rows (GraphView::monotone = 0), K1 stays on
+    the bounded reference loop, and the call must stay memory-safe and
+    deterministic and return neighbours of the right row."""
+    torch = torch_cuda
+    rng = np.random.default_rng(8)
+    n = 400
+    ids = np.arange(1, n + 1).astype(np.uint64)
+    deg = rng.integers(1, 30, n)
+    seg = np.zeros(n + 1, np.int64)
+    seg[1:] = np.cumsum(deg)
+    nbr = rng.choice(ids, int(seg[-1])).astype(np.uint64)
+    w = (rng.random(int(seg[-1])) * 4 - 1).astype(np.float32)   # some negative
+    csr = O.csr_from_raw(ids, seg, nbr, w, 1)
+    G = gpu_graph(EA, csr)
+    G.set_seed(2)
+    q = rng.choice(ids, 3000).astype(np.int64)
+    a = G.sample_neighbor(torch.as_tensor(q).cuda(), [0], 8, -1, call_id=1)
+    b = G.sample_neighbor(torch.as_tensor(q).cuda(), [0], 8, -1, call_id=1)
+    assert np.array_equal(t2n(a[0]), t2n(b[0]))
+    got = t2n(a[0]).astype(np.uint64)
+    for i in range(0, 3000, 97):
+        r = int(q[i]) - 1
+        row = set(nbr[seg[r]:seg[r + 1]].tolist()) | {2 ** 64 - 1}
+        assert set(got[i].tolist()) <= row
