@@ -44,6 +44,8 @@ int Fail(int code, const std::string& msg);
 //   nbr      [E] uint64 neighbor ids, read once per sample at the found slot
 //   id map   identity/strided (id -> (id - base) / stride, no memory at all)
 //            or an open-addressing table of 16-byte {key,row} slots.
+constexpr int kPivotLevels = 10;   // levels 1..10: rows of up to 4*5^9*4 edges
+
 struct GraphView {
   int64_t n_rows;
   int64_t n_edges;
@@ -63,7 +65,40 @@ struct GraphView {
   uint64_t id_stride;
   const uint64_t* hash_slots;   // [2 * (hash_mask + 1)] = {key, row} pairs
   uint64_t hash_mask;
+  // sampling index over the flat edge arrays (built on device at graph
+  // creation): blk[i] = edges [10 i, 10 i + 10); skip1[i] = running sum of the
+  // last edge of block i; skip2[j] = skip1[32 j + 31]; skip3[k] = skip2[32 k +
+  // 31] (indices clamped to the array end).  A search descends skip3 -> skip2
+  // -> skip1 -> block; each level is one 128-byte line.
+  // pivot levels (K1 default search): level 1 entry q = prefix_w[4 q + 3],
+  // level k+1 entry q = level k entry 5 q + 4 (indices clamped to the level's
+  // end).  One unaligned 16-byte load reads the <= 4 candidate entries a
+  // search step needs, so a sample costs ~log5(deg) loads instead of
+  // ~log2(deg).  All levels live in one allocation, level k at pivots +
+  // piv_off[k] (floats); +1.25 B per edge.
+  const float* pivots;
+  int64_t piv_off[kPivotLevels + 1];
+  const struct EdgeBlock* blk;
+  const float* skip1;
+  const float* skip2;
+  const float* skip3;
+  int64_t n_blk, n_skip2, n_skip3;
 };
+
+// Edge block of the sampling index: 10 consecutive edges of the flat arrays
+// (global edge indices [10 i, 10 i + 10)) with their running sums AND their
+// neighbour ids inside ONE 128-byte line - the fetch unit of the L2 / fabric
+// on gfx950.  The last search steps and the id read of a sample therefore cost
+// one line instead of two (measured: random 128 B lines beyond the L2 are the
+// scarce resource of K1, ~54 G lines/s for the whole chip).
+constexpr int kEdgesPerBlock = 10;
+struct alignas(128) EdgeBlock {
+  float pw[kEdgesPerBlock];        // prefix_w of the 10 edges
+  uint32_t pad[2];
+  uint64_t nbr[kEdgesPerBlock];    // their neighbour ids
+};
+static_assert(sizeof(EdgeBlock) == 128, "EdgeBlock must be one 128-byte line");
+constexpr int kSkipFanout = 32;    // 32 floats = one 128-byte line per skip node
 
 constexpr int kMaxListedTypes = 32;
 constexpr int kMaxNodeTypes = 32;

@@ -66,6 +66,110 @@ struct GraphBuilder {
   }
 };
 
+// ---- sampling index (EdgeBlock + skip levels), built from the flat arrays --
+__global__ void BuildBlocksKernel(const float* __restrict__ pw,
+                                  const uint64_t* __restrict__ nbr, int64_t E,
+                                  int64_t n_blk, EdgeBlock* __restrict__ blk,
+                                  float* __restrict__ skip1) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_blk) return;
+  EdgeBlock b;
+  const int64_t base = i * kEdgesPerBlock;
+#pragma unroll
+  for (int x = 0; x < kEdgesPerBlock; ++x) {
+    const int64_t m = base + x < E ? base + x : E - 1;   // tail: repeat the last edge
+    b.pw[x] = pw[m];
+    b.nbr[x] = nbr[m];
+  }
+  b.pad[0] = 0; b.pad[1] = 0;
+  blk[i] = b;
+  skip1[i] = b.pw[kEdgesPerBlock - 1];
+}
+
+__global__ void BuildSkipKernel(const float* __restrict__ lower, int64_t n_lower,
+                                int64_t n_upper, float* __restrict__ upper) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_upper) return;
+  int64_t x = j * kSkipFanout + (kSkipFanout - 1);
+  if (x > n_lower - 1) x = n_lower - 1;
+  upper[j] = lower[x];
+}
+
+// upper[q] = lower[min(fan * q + fan - 1, n_lower - 1)]
+__global__ void BuildPivotKernel(const float* __restrict__ lower, int64_t n_lower,
+                                 int32_t fan, int64_t n_upper,
+                                 float* __restrict__ upper) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n_upper) return;
+  int64_t x = q * fan + (fan - 1);
+  if (x > n_lower - 1) x = n_lower - 1;
+  upper[q] = lower[x];
+}
+
+int BuildPivotLevels(GraphBuilder* b) {
+  GraphView& v = b->g->view;
+  const int64_t E = v.n_edges;
+  if (E >= (int64_t)0x7fffffff * 4 - 64)
+    return Fail(EULER_GPU_EINVAL, "graph too large for 32-bit pivot indices");
+  int64_t n[kPivotLevels + 1];
+  int64_t total = 0;
+  n[0] = E;
+  for (int k = 1; k <= kPivotLevels; ++k) {
+    const int fan = k == 1 ? 4 : 5;
+    n[k] = (n[k - 1] + fan - 1) / fan;
+    v.piv_off[k] = total;
+    total += n[k] + 4;          // a 4-float window may run past the level's end
+  }
+  v.piv_off[0] = 0;
+  float* piv = b->Alloc<float>((size_t)total + 8);
+  if (b->rc != EULER_GPU_OK) return b->rc;
+  EG_HIP(hipMemset(piv, 0, ((size_t)total + 8) * sizeof(float)));
+  const int block = 256;
+  const float* lower = v.prefix_w;
+  for (int k = 1; k <= kPivotLevels && E > 0; ++k) {
+    const int fan = k == 1 ? 4 : 5;
+    hipLaunchKernelGGL(BuildPivotKernel, dim3((n[k] + block - 1) / block), dim3(block),
+                       0, 0, lower, n[k - 1], fan, n[k], piv + v.piv_off[k]);
+    lower = piv + v.piv_off[k];
+  }
+  EG_HIP(hipGetLastError());
+  EG_HIP(hipDeviceSynchronize());
+  v.pivots = piv;
+  return EULER_GPU_OK;
+}
+
+int BuildSearchIndex(GraphBuilder* b) {
+  {
+    const int rc = BuildPivotLevels(b);
+    if (rc != EULER_GPU_OK) return rc;
+  }
+  GraphView& v = b->g->view;
+  const int64_t E = v.n_edges;
+  v.n_blk = (E + kEdgesPerBlock - 1) / kEdgesPerBlock;
+  v.n_skip2 = (v.n_blk + kSkipFanout - 1) / kSkipFanout;
+  v.n_skip3 = (v.n_skip2 + kSkipFanout - 1) / kSkipFanout;
+  if (E >= (int64_t)kEdgesPerBlock * 0x7fffff00LL)
+    return Fail(EULER_GPU_EINVAL, "graph too large for 32-bit block indices");
+  EdgeBlock* blk = b->Alloc<EdgeBlock>((size_t)v.n_blk);
+  float* s1 = b->Alloc<float>((size_t)v.n_blk);
+  float* s2 = b->Alloc<float>((size_t)v.n_skip2);
+  float* s3 = b->Alloc<float>((size_t)v.n_skip3);
+  if (b->rc != EULER_GPU_OK) return b->rc;
+  const int block = 256;
+  if (E > 0) {
+    hipLaunchKernelGGL(BuildBlocksKernel, dim3((v.n_blk + block - 1) / block),
+                       dim3(block), 0, 0, v.prefix_w, v.nbr, E, v.n_blk, blk, s1);
+    hipLaunchKernelGGL(BuildSkipKernel, dim3((v.n_skip2 + block - 1) / block),
+                       dim3(block), 0, 0, s1, v.n_blk, v.n_skip2, s2);
+    hipLaunchKernelGGL(BuildSkipKernel, dim3((v.n_skip3 + block - 1) / block),
+                       dim3(block), 0, 0, s2, v.n_skip2, v.n_skip3, s3);
+    EG_HIP(hipGetLastError());
+    EG_HIP(hipDeviceSynchronize());
+  }
+  v.blk = blk; v.skip1 = s1; v.skip2 = s2; v.skip3 = s3;
+  return EULER_GPU_OK;
+}
+
 void DestroyGraph(euler_gpu_graph* g) {
   if (!g) return;
   (void)hipSetDevice(g->device);
@@ -272,6 +376,10 @@ int BuildGraphFromHost(const euler_gpu_host_csr* c, int device,
     v.map_mode = 1; v.hash_mask = cap - 1; v.id_base = 0; v.id_stride = 1;
     v.hash_slots = b.Upload(slots.data(), slots.size());
     if (b.rc != EULER_GPU_OK) { DestroyGraph(b.g.release()); return b.rc; }
+  }
+  {
+    int rc = BuildSearchIndex(&b);
+    if (rc != EULER_GPU_OK) { DestroyGraph(b.g.release()); return rc; }
   }
   // global node sampler over this shard's nodes
   {
@@ -490,6 +598,10 @@ int BuildGraphSynthetic(const euler_gpu_synth_params* sp, int device,
   EG_HIP(hipDeviceSynchronize());
   EG_HIP(hipFree(row_ptr));
   v.nbr = nbr; v.prefix_w = pw; v.row_meta = meta;
+  {
+    int rc = BuildSearchIndex(&b);
+    if (rc != EULER_GPU_OK) { DestroyGraph(b.g.release()); return rc; }
+  }
   b.g->has_sampler = false;   // uniform roots are drawn by the caller
   b.g->n_node_types = 1;
   *out = b.g.release();

@@ -280,9 +280,13 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
                                 int32_t* split_cnt_host);
 
 /* ---- tuning ---------------------------------------------------------------
- * key 0: sample_neighbor kernel variant (1 = specialised single-type kernel when
- * applicable [default], 0 = always the generic reference-loop kernel).  Both
- * produce identical results; the knob exists for A/B measurements and tests. */
+ * key 0: sample_neighbor kernel variant for single-type calls on graphs with
+ *        non-decreasing running sums: 3 = blocked sampling index [default],
+ *        2 = flat arrays, several samples per lane, 1 = flat arrays, one
+ *        sample per lane, 0 = always the generic reference-loop kernel.
+ * key 1: samples per lane of variant 2 (1, 2, 4 or 8).
+ * All variants produce identical results; the knobs exist for A/B measurements
+ * and tests. */
 int euler_gpu_set_tuning(int32_t key, int32_t value);
 
 /* ---- measurement helper -------------------------------------------------------

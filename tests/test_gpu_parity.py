@@ -27,14 +27,19 @@ def EA(torch_cuda):
     return euler_amd
 
 
-@pytest.fixture(params=[1, 0], ids=["k1fast", "k1generic"])
+@pytest.fixture(params=[(5, 4), (4, 4), (3, 4), (2, 4), (2, 2), (2, 8), (1, 4), (0, 4)],
+                ids=["k1pivot", "k1wave", "k1blocked", "k1ilp4", "k1ilp2", "k1ilp8", "k1fast",
+                     "k1generic"])
 def k1_variant(request, EA):
-    """Run with the specialised single-type K1 kernel and with the generic
-    reference-loop kernel: both must match the oracle bit for bit."""
+    """Run with every variant of the K1 kernel (blocked sampling index, ILP with
+    2/4/8 samples per lane, the single-sample fast path, the generic reference-loop kernel): all
+    must match the oracle bit for bit."""
     from euler_amd import _lib
-    _lib.lib().euler_gpu_set_tuning(0, request.param)
+    _lib.lib().euler_gpu_set_tuning(0, request.param[0])
+    _lib.lib().euler_gpu_set_tuning(1, request.param[1])
     yield request.param
-    _lib.lib().euler_gpu_set_tuning(0, 1)
+    _lib.lib().euler_gpu_set_tuning(0, 5)
+    _lib.lib().euler_gpu_set_tuning(1, 4)
 
 
 def gpu_graph(EA, csr, order=None, **kw):
