@@ -13,7 +13,7 @@ id % N) and every hop does the id / result all-to-all over RCCL; every rank
 samples its own B roots per step (weak scaling).
 
 Rank 0 prints ONE JSON line: metric/value/... plus
-  roofline      SampleNeighborKernel (both launches of a step) timed with HIP
+  roofline      SampleNeighborPivotKernel (both launches of a step) timed with HIP
                 events on its own stream; achieved = algorithmic bytes / time
   cpu_baseline  the reference sampler (oracle/_ref: reference sources + RNG
                 seam) timed on the host cores on a bounded sample of the same
@@ -222,7 +222,7 @@ def main():
             except Exception:
                 traffic = None
         roofline = {
-            "kernel": "SampleNeighborKernel",
+            "kernel": "SampleNeighborPivotKernel",
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": traffic,

@@ -156,6 +156,7 @@ int BuildGraphFromHost(const euler_gpu_host_csr* csr, int device,
 int BuildGraphSynthetic(const euler_gpu_synth_params* p, int device,
                         int32_t partitions, int32_t shard_index, int32_t shards,
                         euler_gpu_graph** out);
+int EnsureBlockedIndex(const euler_gpu_graph* g);   // K1 variants 3 / 4 only
 // dat_reader.cc
 int LoadDatDirectory(const char* data_path, int32_t shard_index, int32_t shards,
                      std::vector<uint64_t>* row_id, std::vector<int64_t>* row_ptr,

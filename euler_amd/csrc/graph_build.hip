@@ -138,11 +138,11 @@ int BuildPivotLevels(GraphBuilder* b) {
   return EULER_GPU_OK;
 }
 
-int BuildSearchIndex(GraphBuilder* b) {
-  {
-    const int rc = BuildPivotLevels(b);
-    if (rc != EULER_GPU_OK) return rc;
-  }
+int BuildSearchIndex(GraphBuilder* b) { return BuildPivotLevels(b); }
+
+// EdgeBlock + skip levels: only the A/B variants 3 and 4 of K1 use them, so
+// they are built on first use (EnsureBlockedIndex), not at graph creation.
+int BuildBlockedIndex(GraphBuilder* b) {
   GraphView& v = b->g->view;
   const int64_t E = v.n_edges;
   v.n_blk = (E + kEdgesPerBlock - 1) / kEdgesPerBlock;
@@ -169,6 +169,8 @@ int BuildSearchIndex(GraphBuilder* b) {
   v.blk = blk; v.skip1 = s1; v.skip2 = s2; v.skip3 = s3;
   return EULER_GPU_OK;
 }
+
+std::mutex g_blocked_mu;
 
 void DestroyGraph(euler_gpu_graph* g) {
   if (!g) return;
@@ -606,6 +608,21 @@ int BuildGraphSynthetic(const euler_gpu_synth_params* sp, int device,
   b.g->n_node_types = 1;
   *out = b.g.release();
   return EULER_GPU_OK;
+}
+
+int EnsureBlockedIndex(const euler_gpu_graph* cg) {
+  euler_gpu_graph* g = const_cast<euler_gpu_graph*>(cg);
+  std::lock_guard<std::mutex> lk(g_blocked_mu);
+  if (g->view.blk != nullptr) return EULER_GPU_OK;
+  int prev = 0;
+  EG_HIP(hipGetDevice(&prev));
+  EG_HIP(hipSetDevice(g->device));
+  GraphBuilder b;
+  b.g.reset(g);                 // borrow the graph: allocations land in its list
+  const int rc = BuildBlockedIndex(&b);
+  b.g.release();
+  (void)hipSetDevice(prev);
+  return rc;
 }
 
 // rows -> host (spot checks)

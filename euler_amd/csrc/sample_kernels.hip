@@ -346,6 +346,8 @@ __global__ __launch_bounds__(256) void SampleNeighborIlpKernel(const SampleNbArg
 }
 
 namespace {
+constexpr int64_t kK1GridCap = 32768;
+int g_k1_pair = 1;      // pivot kernel: two adjacent samples per lane when count is even
 int g_k1_grid_cap = 0;  // measurement only: override the workgroup cap of K1
 int g_k1_ablate = 0;   // measurement only: skip parts of the blocked kernel
 int g_k1_ilp = 4;      // samples per lane of the ILP kernel (1, 2, 4, 8)
@@ -844,138 +846,173 @@ __device__ __forceinline__ float Pick4(const float4u& v, int32_t i) {
   return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w;
 }
 
-template <bool TF_LAYOUT>
+struct Segment {
+  int64_t row_ptr;      // first edge of the row
+  int64_t lo, hi;       // searched edges [lo, hi] (global indices)
+  float limit_begin, limit_end;
+  int32_t b, e;         // the same segment, row-relative
+};
+
+// One draw u on a segment: the neighbour RandomSelect picks and its weight.
+__device__ __forceinline__ void PivotSample(const GraphView& g, const Segment& sg,
+                                            double u, uint64_t* id, float* w) {
+  const float* __restrict__ A0 = g.prefix_w;
+  const int64_t lo = sg.lo, hi = sg.hi;
+  const double rr = ScaleDraw(u, sg.limit_begin, sg.limit_end);
+  if (!((double)sg.limit_end > rr)) {
+    // Q3: r rounded up to the end of the segment - replay the reference
+    const float* nw = A0 + sg.row_ptr;
+    const int32_t m = (int32_t)RandomSelect(nw, (uint64_t)sg.b, (uint64_t)sg.e, u);
+    *id = g.nbr[sg.row_ptr + m];
+    *w = __fsub_rn(nw[m], m == 0 ? 0.f : nw[m - 1]);
+    return;
+  }
+  // candidate ranges of every level; K = first level with <= 4 of them
+  uint32_t l[kPivotLevels + 1], h[kPivotLevels + 1];
+  l[1] = (uint32_t)(lo >> 2);
+  h[1] = (uint32_t)(hi >> 2);
+#pragma unroll
+  for (int k = 2; k <= kPivotLevels; ++k) { l[k] = l[k - 1] / 5u; h[k] = h[k - 1] / 5u; }
+  int32_t K = 0;
+  if (hi - lo > 3) {
+    K = kPivotLevels + 1;
+#pragma unroll
+    for (int k = kPivotLevels; k >= 1; --k)
+      if (h[k] - l[k] <= 4u) K = k;
+  }
+  if (K > kPivotLevels) {
+    // rows beyond the pivot levels' reach: plain upper-bound search
+    int64_t lo2 = lo, hi2 = hi;
+    while (lo2 < hi2) {
+      const int64_t mid = (lo2 + hi2) >> 1;
+      if ((double)A0[mid] > rr) hi2 = mid; else lo2 = mid + 1;
+    }
+    *id = g.nbr[lo2];
+    *w = __fsub_rn(A0[lo2], lo2 == sg.row_ptr ? 0.f : A0[lo2 - 1]);
+    return;
+  }
+  uint32_t x = 0;        // chosen entry of the level above
+  bool found = false;    // its key was compared (> r): it bounds its children
+  float kv = 0.f;        // that key
+#pragma unroll
+  for (int k = kPivotLevels; k >= 1; --k) {
+    if (k <= K) {
+      uint32_t c_lo, c_hi;
+      if (k == K) { c_lo = l[k]; c_hi = h[k]; }
+      else {
+        c_lo = max(l[k], 5u * x);
+        c_hi = found ? 5u * x + 4u : h[k];
+      }
+      const int32_t cnt = (int32_t)(c_hi - c_lo);
+      const float4u kw =
+          *reinterpret_cast<const float4u*>(g.pivots + g.piv_off[k] + c_lo);
+      int32_t pos = 0;
+      pos += (0 < cnt && !((double)kw.x > rr)) ? 1 : 0;
+      pos += (1 < cnt && !((double)kw.y > rr)) ? 1 : 0;
+      pos += (2 < cnt && !((double)kw.z > rr)) ? 1 : 0;
+      pos += (3 < cnt && !((double)kw.w > rr)) ? 1 : 0;
+      x = c_lo + (uint32_t)pos;
+      if (pos < cnt) { found = true; kv = Pick4(kw, pos); }
+    }
+  }
+  // leaf: candidates among the flat elements below level-1 entry x
+  int64_t c_lo = lo, c_hi = hi;
+  if (K >= 1) {
+    c_lo = max(lo, (int64_t)x * 4);
+    c_hi = found ? (int64_t)x * 4 + 3 : hi;
+  }
+  const int32_t cnt = (int32_t)(c_hi - c_lo);       // <= 3
+  int64_t ws = c_lo - 1;                            // window start
+  if (ws > g.n_edges - 4) ws = g.n_edges - 4;
+  if (ws < 0) ws = 0;
+  const int32_t sh = (int32_t)(c_lo - ws);          // key i sits at sh + i
+  const float4u wv = *reinterpret_cast<const float4u*>(A0 + ws);
+  int32_t pos = 0;
+  pos += (0 < cnt && !((double)Pick4(wv, sh) > rr)) ? 1 : 0;
+  pos += (1 < cnt && !((double)Pick4(wv, sh + 1) > rr)) ? 1 : 0;
+  pos += (2 < cnt && !((double)Pick4(wv, sh + 2) > rr)) ? 1 : 0;
+  const int64_t m = c_lo + pos;
+  const float nw_m = pos < cnt ? Pick4(wv, sh + pos) : (found ? kv : sg.limit_end);
+  // `mid ? nw[mid-1] : 0` is row-relative
+  const float prev = m == sg.row_ptr ? 0.f : Pick4(wv, sh + pos - 1);
+  *id = g.nbr[m];
+  *w = __fsub_rn(nw_m, prev);
+}
+
+// Row record -> searched segment of the listed type; false = empty / invalid
+// (node.cc:127-136).
+__device__ __forceinline__ bool LoadSegment(const GraphView& g, int64_t row,
+                                            int32_t t, Segment* sg) {
+  if (row < 0 || t < 0 || t >= g.T) return false;
+  const uint8_t* rec = g.row_meta + row * (int64_t)g.meta_stride;
+  if (g.T == 1) {
+    const uint4 q = *reinterpret_cast<const uint4*>(rec);
+    sg->row_ptr = (int64_t)(((uint64_t)q.y << 32) | q.x);
+    sg->b = 0;
+    sg->e = (int32_t)q.z - 1;
+  } else {
+    sg->row_ptr = *reinterpret_cast<const int64_t*>(rec);
+    const int32_t* te = reinterpret_cast<const int32_t*>(rec + 8);
+    sg->b = t == 0 ? 0 : te[t - 1];
+    sg->e = te[t] - 1;
+  }
+  if (sg->e < sg->b) return false;
+  sg->lo = sg->row_ptr + sg->b;
+  sg->hi = sg->row_ptr + sg->e;
+  sg->limit_end = g.prefix_w[sg->hi];
+  sg->limit_begin = sg->b == 0 ? 0.f : g.prefix_w[sg->lo - 1];
+  return true;
+}
+
+// U = 1: one sample per lane.  U = 2 (even `count`): a lane draws the two
+// adjacent samples (j, j+1) of one root - one root id / row record / limit
+// load, one Philox block and one 16-byte id store per PAIR.
+template <bool TF_LAYOUT, int U>
 __global__ __launch_bounds__(256) void SampleNeighborPivotKernel(
     const SampleNbArgs a, const int64_t stride_rows, const int32_t stride_slots) {
   const int64_t total = a.n * (int64_t)a.count;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * U;
+  int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * U;
   if (s >= total) return;
   int64_t r = s / a.count;
   int32_t j = (int32_t)(s - r * a.count);
   const int32_t t = a.et[0];
-  const int32_t T = a.g.T;
-  const float* __restrict__ A0 = a.g.prefix_w;
   for (; s < total; s += stride) {
     uint64_t node = a.roots[r];
     if (a.root_mask != nullptr && a.root_mask[r / a.root_group]) node = 0;
-    const int64_t row = FindRow(a.g, node);
-    uint64_t id = 0;
-    float w = 0.f;
-    bool valid = false;
-    if (row >= 0 && t >= 0 && t < T) {
-      const uint8_t* rec = a.g.row_meta + row * (int64_t)a.g.meta_stride;
-      int64_t row_ptr;
-      int32_t b, e;
-      if (T == 1) {
-        const uint4 q = *reinterpret_cast<const uint4*>(rec);
-        row_ptr = (int64_t)(((uint64_t)q.y << 32) | q.x);
-        b = 0;
-        e = (int32_t)q.z - 1;
-      } else {
-        row_ptr = *reinterpret_cast<const int64_t*>(rec);
-        const int32_t* te = reinterpret_cast<const int32_t*>(rec + 8);
-        b = t == 0 ? 0 : te[t - 1];
-        e = te[t] - 1;
-      }
-      if (e >= b) {                                       // node.cc:133-135
-        valid = true;
-        const int64_t lo = row_ptr + b, hi = row_ptr + e;
-        const float limit_end = A0[hi];
-        const float limit_begin = b == 0 ? 0.f : A0[lo - 1];
-        const Philox4 blk = RngBlock(a.seed, a.call_id, kDomainNeighbor, node,
-                                     ((uint32_t)j) >> 1);
+    Segment sg;
+    const bool valid = LoadSegment(a.g, FindRow(a.g, node), t, &sg);
+    uint64_t id[U];
+    float w[U];
+    int32_t ot = t;
+    if (valid) {
+      const Philox4 blk = RngBlock(a.seed, a.call_id, kDomainNeighbor, node,
+                                   ((uint32_t)j) >> 1);
+      if (U == 1) {
         const double u = (j & 1) ? UnitFromWords(blk.w[2], blk.w[3])
                                  : UnitFromWords(blk.w[0], blk.w[1]);
-        const double rr = ScaleDraw(u, limit_begin, limit_end);
-        if ((double)limit_end > rr) {
-          // candidate ranges of every level; K = first level with <= 4 of them
-          uint32_t l[kPivotLevels + 1], h[kPivotLevels + 1];
-          l[1] = (uint32_t)(lo >> 2);
-          h[1] = (uint32_t)(hi >> 2);
-#pragma unroll
-          for (int k = 2; k <= kPivotLevels; ++k) { l[k] = l[k - 1] / 5u; h[k] = h[k - 1] / 5u; }
-          int32_t K = 0;
-          if (hi - lo > 3) {
-            K = kPivotLevels + 1;
-#pragma unroll
-            for (int k = kPivotLevels; k >= 1; --k)
-              if (h[k] - l[k] <= 4u) K = k;
-          }
-          uint32_t x = 0;        // chosen entry of the level above
-          bool found = false;    // its key was compared (> r): it bounds its children
-          float kv = 0.f;        // that key
-          if (K <= kPivotLevels) {
-#pragma unroll
-            for (int k = kPivotLevels; k >= 1; --k) {
-              if (k <= K) {
-                uint32_t c_lo, c_hi;
-                if (k == K) { c_lo = l[k]; c_hi = h[k]; }
-                else {
-                  c_lo = max(l[k], 5u * x);
-                  c_hi = found ? 5u * x + 4u : h[k];
-                }
-                const int32_t cnt = (int32_t)(c_hi - c_lo);
-                const float4u kw = *reinterpret_cast<const float4u*>(
-                    a.g.pivots + a.g.piv_off[k] + c_lo);
-                int32_t pos = 0;
-                pos += (0 < cnt && !((double)kw.x > rr)) ? 1 : 0;
-                pos += (1 < cnt && !((double)kw.y > rr)) ? 1 : 0;
-                pos += (2 < cnt && !((double)kw.z > rr)) ? 1 : 0;
-                pos += (3 < cnt && !((double)kw.w > rr)) ? 1 : 0;
-                x = c_lo + (uint32_t)pos;
-                if (pos < cnt) { found = true; kv = Pick4(kw, pos); }
-              }
-            }
-            // leaf: candidates of flat elements below level-1 entry x
-            int64_t c_lo = lo, c_hi = hi;
-            if (K >= 1) {
-              c_lo = max(lo, (int64_t)x * 4);
-              c_hi = found ? (int64_t)x * 4 + 3 : hi;
-            }
-            const int32_t cnt = (int32_t)(c_hi - c_lo);       // <= 3
-            int64_t ws = c_lo - 1;                            // window start
-            if (ws > a.g.n_edges - 4) ws = a.g.n_edges - 4;
-            if (ws < 0) ws = 0;
-            const int32_t sh = (int32_t)(c_lo - ws);          // key i sits at sh + i
-            const float4u wv = *reinterpret_cast<const float4u*>(A0 + ws);
-            int32_t pos = 0;
-            pos += (0 < cnt && !((double)Pick4(wv, sh) > rr)) ? 1 : 0;
-            pos += (1 < cnt && !((double)Pick4(wv, sh + 1) > rr)) ? 1 : 0;
-            pos += (2 < cnt && !((double)Pick4(wv, sh + 2) > rr)) ? 1 : 0;
-            const int64_t m = c_lo + pos;
-            const float nw_m = pos < cnt ? Pick4(wv, sh + pos) : (found ? kv : limit_end);
-            // `mid ? nw[mid-1] : 0` is row-relative
-            const float prev = m == row_ptr ? 0.f : Pick4(wv, sh + pos - 1);
-            id = a.g.nbr[m];
-            w = __fsub_rn(nw_m, prev);
-          } else {
-            // rows beyond the pivot levels' reach: plain upper-bound search
-            int64_t lo2 = lo, hi2 = hi;
-            while (lo2 < hi2) {
-              const int64_t mid = (lo2 + hi2) >> 1;
-              if ((double)A0[mid] > rr) hi2 = mid; else lo2 = mid + 1;
-            }
-            id = a.g.nbr[lo2];
-            w = __fsub_rn(A0[lo2], lo2 == row_ptr ? 0.f : A0[lo2 - 1]);
-          }
-        } else {
-          // Q3: r rounded up to the end of the segment - replay the reference
-          const float* nw = A0 + row_ptr;
-          const int32_t m = (int32_t)RandomSelect(nw, (uint64_t)b, (uint64_t)e, u);
-          id = a.g.nbr[row_ptr + m];
-          w = __fsub_rn(nw[m], m == 0 ? 0.f : nw[m - 1]);
-        }
+        PivotSample(a.g, sg, u, &id[0], &w[0]);
+      } else {
+        PivotSample(a.g, sg, UnitFromWords(blk.w[0], blk.w[1]), &id[0], &w[0]);
+        PivotSample(a.g, sg, UnitFromWords(blk.w[2], blk.w[3]), &id[U - 1], &w[U - 1]);
       }
+    } else {
+#pragma unroll
+      for (int x = 0; x < U; ++x) {
+        id[x] = TF_LAYOUT ? (uint64_t)a.default_node : 0;
+        w[x] = 0.f;
+      }
+      ot = TF_LAYOUT ? -1 : 0;
     }
-    int32_t ot = t;
-    if (!valid) {
-      if (TF_LAYOUT) { id = (uint64_t)a.default_node; w = 0.f; ot = -1; }
-      else { id = 0; w = 0.f; ot = 0; }
+    if (U == 1) {
+      a.out_id[s] = id[0];
+      a.out_w[s] = w[0];
+      a.out_t[s] = ot;
+    } else {
+      *reinterpret_cast<ulonglong2*>(a.out_id + s) = make_ulonglong2(id[0], id[U - 1]);
+      *reinterpret_cast<float2*>(a.out_w + s) = make_float2(w[0], w[U - 1]);
+      *reinterpret_cast<int2*>(a.out_t + s) = make_int2(ot, ot);
     }
-    a.out_id[s] = id;
-    a.out_w[s] = w;
-    a.out_t[s] = ot;
     if (j == 0 && a.out_row_mask != nullptr) a.out_row_mask[r] = valid ? 0 : 1;
     r += stride_rows;
     j += stride_slots;
@@ -1014,6 +1051,10 @@ static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
     return Fail(EULER_GPU_EINVAL, "sample_neighbor: null buffer");
   if (k > 0 && !edge_types)
     return Fail(EULER_GPU_EINVAL, "sample_neighbor: null edge_types");
+  if ((g_k1_variant == 3 || g_k1_variant == 4) && g->view.blk == nullptr) {
+    const int rc = EnsureBlockedIndex(g);     // A/B variants only: built on first use
+    if (rc != EULER_GPU_OK) return rc;
+  }
   SampleNbArgs a{};
   a.g = g->view;
   a.seed = seed; a.call_id = call_id;
@@ -1025,25 +1066,40 @@ static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
   a.k = k; a.count = count; a.layout = layout;
   for (int i = 0; i < k; ++i) a.et[i] = edge_types[i];
   const int block = 256;
-  int grid = GridFor(n * (int64_t)count, block);
-  if (g_k1_grid_cap > 0) {
+  // K1 launches up to 32768 workgroups (128 per CU) rather than GridFor's 16 per
+  // CU: hub-heavy and leaf-heavy workgroups finish at very different times and
+  // the finer grain lets the dispatcher even that out (measured -7 %).
+  int grid;
+  {
     int64_t blocks = (n * (int64_t)count + block - 1) / block;
-    if (blocks > g_k1_grid_cap) blocks = g_k1_grid_cap;
+    const int64_t cap = g_k1_grid_cap > 0 ? g_k1_grid_cap : kK1GridCap;
+    if (blocks > cap) blocks = cap;
     grid = (int)(blocks < 1 ? 1 : blocks);
   }
   const bool single = k == 1 && g->view.monotone;
   const bool tf_zero = layout == EULER_GPU_LAYOUT_TF && g->view.has_zero_nbr != 0;
   if (g_k1_variant == 5 && single && !tf_zero) {
-    const int64_t stride = (int64_t)grid * block;
+    const bool pair = g_k1_pair != 0 && count % 2 == 0 &&
+                      ((uintptr_t)out_id % 16 == 0) && ((uintptr_t)out_w % 8 == 0) &&
+                      ((uintptr_t)out_t % 8 == 0);
+    const int U = pair ? 2 : 1;
+    int gridp = grid;
+    if (pair) {
+      int64_t blocks = (n * (int64_t)count / 2 + block - 1) / block;
+      const int64_t cap = g_k1_grid_cap > 0 ? g_k1_grid_cap : kK1GridCap;
+      if (blocks > cap) blocks = cap;
+      gridp = (int)(blocks < 1 ? 1 : blocks);
+    }
+    const int64_t stride = (int64_t)gridp * block * U;
     const int64_t stride_rows = stride / count;
     const int32_t stride_slots = (int32_t)(stride - stride_rows * count);
-    if (layout == EULER_GPU_LAYOUT_TF) {
-      hipLaunchKernelGGL(SampleNeighborPivotKernel<true>, dim3(grid), dim3(block), 0,
-                         stream, a, stride_rows, stride_slots);
-    } else {
-      hipLaunchKernelGGL(SampleNeighborPivotKernel<false>, dim3(grid), dim3(block), 0,
-                         stream, a, stride_rows, stride_slots);
-    }
+    const bool tf = layout == EULER_GPU_LAYOUT_TF;
+    auto kern = pair ? (tf ? SampleNeighborPivotKernel<true, 2>
+                           : SampleNeighborPivotKernel<false, 2>)
+                     : (tf ? SampleNeighborPivotKernel<true, 1>
+                           : SampleNeighborPivotKernel<false, 1>);
+    hipLaunchKernelGGL(kern, dim3(gridp), dim3(block), 0, stream, a, stride_rows,
+                       stride_slots);
   } else if (g_k1_variant == 4 && single && !tf_zero && count >= 8) {
     const int64_t chunks = (n * (int64_t)count + 63) / 64;
     int64_t blocks = (chunks + 3) / 4;
@@ -1463,6 +1519,7 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 0) { g_k1_variant = value; return EULER_GPU_OK; }
   if (key == 2) { g_k1_ablate = value; return EULER_GPU_OK; }
   if (key == 3) { g_k1_grid_cap = value; return EULER_GPU_OK; }
+  if (key == 4) { g_k1_pair = value; return EULER_GPU_OK; }
   if (key == 1 && (value == 1 || value == 2 || value == 4 || value == 8)) {
     g_k1_ilp = value;
     return EULER_GPU_OK;

@@ -14,12 +14,14 @@ hop2_roots = out[0][1].contiguous()
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 et1 = (C.c_int32*1)(0)
 res = {}
-for variant in ((1,0), (5,0), (5,8192), (5,32768), (1,32768)):
+for variant in ((5,0), (5,8192), (5,32768)):
     L.euler_gpu_set_tuning(0, variant[0]); L.euler_gpu_set_tuning(3, variant[1])
-    for name, r, cnt in (('hop1', roots, 25), ('hop2', hop2_roots, 10)):
+    for pair in (0, 1):
+     L.euler_gpu_set_tuning(4, pair)
+     for name, r, cnt in (('hop1', roots, 25), ('hop2', hop2_roots, 10)):
         n = r.numel()
         oid = torch.empty(n*cnt, dtype=torch.int64, device='cuda'); ow = torch.empty(n*cnt, dtype=torch.float32, device='cuda'); ot = torch.empty(n*cnt, dtype=torch.int32, device='cuda')
         ms = C.c_float(0)
         _lib.check(L.euler_gpu_time_sample_neighbor(G._h, st, 20240521, C.c_void_p(r.data_ptr()), n, et1, 1, cnt, 1, C.c_void_p(oid.data_ptr()), C.c_void_p(ow.data_ptr()), C.c_void_p(ot.data_ptr()), 10, C.byref(ms)))
-        res.setdefault((variant,name), []).append(round(ms.value,4))
+        res.setdefault((variant,pair,name), []).append(round(ms.value,4))
 print({str(k): v for k, v in res.items()})
