@@ -179,21 +179,33 @@ def main():
         assert np.array_equal(on[1], hop2.reshape(-1)), "hop-2 ids differ from oracle"
         checked = int(len(r0) * 275)
 
-    # ---- roofline leg: the two launches of a step, HIP events on the stream
+    # ---- roofline leg: the launches of a step, phase by phase, HIP events on
+    # the stream the kernels run on.  Hop 1 samples the caller's roots directly;
+    # hop 2 counts duplicate roots on device and (when they repeat) samples the
+    # distinct ones once and expands.  The dominant kernel is K1
+    # (SampleNeighborPivotKernel): its algorithmic bytes are SURVEY 8(d)'s
+    # per-root / per-edge figure summed over the roots it actually processes.
     roofline = None
     if rank == 0:
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         et1 = (C.c_int32 * 1)(0)
         iters = 5
-        times, abytes = [], []
-        shapes = [(roots[n_steps - 1].contiguous(), FANOUT[0])]
+        shapes = [(roots[n_steps - 1].contiguous(), FANOUT[0], 0)]
         if world == 1:
-            shapes.append((out[0][1].contiguous(), FANOUT[1]))
+            shapes.append((out[0][1].contiguous(), FANOUT[1], 1))
         else:
             shapes.append((torch.randint(1, args.nodes + 1, (B * FANOUT[0],),
                                          generator=gen, device=dev,
-                                         dtype=torch.int64), FANOUT[1]))
-        for r, cnt in shapes:
+                                         dtype=torch.int64), FANOUT[1], 1))
+
+        def algo_bytes(r, cnt):
+            b = C.c_double(0)
+            _lib.check(L.euler_gpu_sample_neighbor_algo_bytes(
+                G._h, st, C.c_void_p(r.data_ptr()), r.numel(), et1, 1, cnt, C.byref(b)))
+            return b.value
+
+        k1_ms, k1_bytes, phases = [], [], []
+        for r, cnt, dedup in shapes:
             if world > 1:      # a shard only owns ids == rank (mod world)
                 r = (r // world) * world + (rank if rank else world)
                 r = torch.clamp(r, max=args.nodes - world)
@@ -201,17 +213,29 @@ def main():
             oid = torch.empty(n * cnt, dtype=torch.int64, device=dev)
             ow = torch.empty(n * cnt, dtype=torch.float32, device=dev)
             ot = torch.empty(n * cnt, dtype=torch.int32, device=dev)
-            ms = C.c_float(0)
-            _lib.check(L.euler_gpu_time_sample_neighbor(
+            ms3 = (C.c_float * 3)()
+            nu = C.c_int64(-1)
+            _lib.check(L.euler_gpu_time_sample_neighbor_phases(
                 G._h, st, GRAPH_SEED, C.c_void_p(r.data_ptr()), n, et1, 1, cnt,
-                _lib.LAYOUT_TF, C.c_void_p(oid.data_ptr()), C.c_void_p(ow.data_ptr()),
-                C.c_void_p(ot.data_ptr()), iters, C.byref(ms)))
-            b = C.c_double(0)
-            _lib.check(L.euler_gpu_sample_neighbor_algo_bytes(
-                G._h, st, C.c_void_p(r.data_ptr()), n, et1, 1, cnt, C.byref(b)))
-            times.append(ms.value)
-            abytes.append(b.value)
-        achieved = sum(abytes) / (sum(times) * 1e-3) / 1e9
+                _lib.LAYOUT_TF, dedup, C.c_void_p(oid.data_ptr()),
+                C.c_void_p(ow.data_ptr()), C.c_void_p(ot.data_ptr()), iters, ms3,
+                C.byref(nu)))
+            unique_path = dedup == 1 and nu.value >= 0 and nu.value * 4 <= n * 3
+            sampled = torch.unique(r) if unique_path else r
+            kb = algo_bytes(sampled.contiguous(), cnt)
+            k1_ms.append(ms3[1])
+            k1_bytes.append(kb)
+            ph = {"roots": n, "count": cnt, "roots_sampled": int(sampled.numel()),
+                  "k1_ms": round(ms3[1], 4), "k1_algorithmic_bytes": kb}
+            if unique_path:
+                # dedup adds 8 + 4 bytes per input id, the gather 16
+                # per expanded output edge (+ the unique rows it reads once)
+                eb = 16.0 * n * cnt + 16.0 * nu.value * cnt + 4.0 * n
+                ph.update({"dedup_ms": round(ms3[0], 4), "dedup_algorithmic_bytes": 12.0 * n,
+                           "expand_ms": round(ms3[2], 4), "expand_algorithmic_bytes": eb,
+                           "expand_GBps": round(eb / (ms3[2] * 1e-3) / 1e9, 1)})
+            phases.append(ph)
+        achieved = sum(k1_bytes) / (sum(k1_ms) * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
@@ -226,11 +250,14 @@ def main():
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": traffic,
-            "algorithmic_bytes_per_launch": round(sum(abytes) / len(abytes), 1),
-            "avg_launch_ms": round(sum(times) / len(times), 4),
-            "launch_ms": [round(x, 4) for x in times],
-            "bytes_per_sampled_edge": round(
-                sum(abytes) / (B * (FANOUT[0] + FANOUT[0] * FANOUT[1])), 2),
+            "algorithmic_bytes_per_launch": round(sum(k1_bytes) / len(k1_bytes), 1),
+            "avg_launch_ms": round(sum(k1_ms) / len(k1_ms), 4),
+            "launch_ms": [round(x, 4) for x in k1_ms],
+            "launches_per_step": phases,
+            "note": "K1 launches that do work in one step: hop 1 over the batch, hop 2 "
+                    "over the distinct hop-2 roots (duplicates are counted on device and "
+                    "their rows expanded by DedupExpandKernel); bytes = SURVEY 8(d) formula "
+                    "over the roots each launch processes",
         }
 
     cpu = None

@@ -101,6 +101,11 @@ SIGNATURES = {
                                                        C.c_int32, C.c_int32,
                                                        C.POINTER(C.c_double)]),
     "euler_gpu_set_tuning": (C.c_int, [C.c_int32, C.c_int32]),
+    "euler_gpu_time_sample_neighbor_phases": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_int64,
+                                                        i32p, C.c_int32, C.c_int32,
+                                                        C.c_int32, C.c_int32, vp, vp, vp,
+                                                        C.c_int32, f32p,
+                                                        C.POINTER(C.c_int64)]),
     "euler_op_registered": (C.c_int, [C.c_char_p]),
     "euler_op_run_sample_nb": (C.c_int64, [vp, C.c_uint64, u64p, C.c_int64, i32p,
                                            C.c_int32, C.c_int32, i32p, u64p, f32p,

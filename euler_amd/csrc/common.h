@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -145,6 +147,11 @@ struct euler_gpu_graph {
   int64_t bytes = 0;
   std::vector<void*> allocations;     // every hipMalloc owned by the graph
   std::vector<float> node_weight_sums;
+  // scratch of the sampling launcher (dedup table, unique rows), one buffer
+  // per stream: calls on one stream are ordered, calls on different streams
+  // never share a buffer
+  mutable std::mutex ws_mu;
+  mutable std::map<void*, std::pair<void*, size_t>> ws;
 };
 
 namespace euler_gpu {

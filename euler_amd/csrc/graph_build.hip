@@ -176,6 +176,7 @@ void DestroyGraph(euler_gpu_graph* g) {
   if (!g) return;
   (void)hipSetDevice(g->device);
   for (void* p : g->allocations) (void)hipFree(p);
+  for (auto& kv : g->ws) (void)hipFree(kv.second.first);
   delete g;
 }
 

@@ -1,6 +1,7 @@
 // Sampling kernels: SampleNeighbor / SampleFanout / SampleNode /
 // GetFullNeighbor / RandomWalk for gfx950, plus their C-ABI entry points.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <cmath>
 #include <vector>
@@ -39,12 +40,156 @@ struct SampleNbArgs {
   int32_t k;
   int32_t count;
   int32_t layout;
-  int32_t pad;
+  int32_t dd_role;              // 0 no gate, 1 pass over the given roots, 2 pass
+                                // over the unique roots (see DedupGate)
+  const uint32_t* dd_counter;   // [0] = number of unique roots (device)
+  int64_t dd_n_in;              // roots of the call
   int32_t et[kMaxListedTypes];
 };
 
-__global__ __launch_bounds__(256) void SampleNeighborKernel(const SampleNbArgs a) {
+// ------------------------------------------------------------------------
+// Duplicate roots.  Rows are a pure function of (seed, call_id, node id), so
+// sampling a node once and copying its row to every position that asked for it
+// is exactly the reference's ID_UNIQUE -> sample -> GATHER rewrite
+// (parser/compiler.cc:76-90, core/kernels/id_unique_op.cc, data_gather_op.cc).
+// The second hop of a fanout is where it pays: on the metric workload 3.28 M
+// hop-2 roots are 286 K distinct nodes (8.7 %).  Nothing returns to the host:
+// the insert kernel counts the unique roots on device and every later kernel
+// of the call reads that count and either runs or exits:
+//   unique * 4 <= roots * 3   -> sample the unique roots, then expand;
+//   otherwise                 -> sample the given roots directly.
+// ------------------------------------------------------------------------
+__device__ __forceinline__ bool DedupActive(const uint32_t* counter, int64_t n_in) {
+  return (int64_t)(*counter) * 4 <= n_in * 3;
+}
+
+// false = this launch has nothing to do; *n = number of roots it processes
+__device__ __forceinline__ bool DedupGate(const SampleNbArgs& a, int64_t* n) {
+  *n = a.n;
+  if (a.dd_role == 0) return true;
+  const bool dedup = DedupActive(a.dd_counter, a.dd_n_in);
+  if (a.dd_role == 1) return !dedup;
+  *n = (int64_t)(*a.dd_counter);
+  return dedup;
+}
+
+// Finding the duplicates without atomics.  A hash table filled with
+// compare-and-swap was measured at 0.6 ms for the 3.28 M hop-2 roots of the
+// metric workload (device-scope atomics execute at the memory side on this
+// multi-die part: ~0.45 ns per CAS, ~9 ns per same-address add).  Rows give a
+// dense key instead: every position stores its own index into owner[row] with a
+// plain 4-byte store (a benign race: one of the positions naming the row
+// survives, and every referenced row is written by this call, so the table
+// never needs clearing); a second kernel reads it back - the survivor is the
+// row's representative; an exclusive scan of the representative flags numbers
+// the unique roots and counts them.  All unknown ids share the slot n_rows:
+// their rows are the same default fill.
+struct DedupArgs {
+  GraphView g;
+  const uint64_t* roots;
+  const uint8_t* root_mask;
+  int64_t n;
+  int32_t root_group;
+  int32_t pad;
+  uint32_t* owner;           // [n_rows + 1] row -> a position that names it
+  uint32_t* row_slot;        // [n] row of every position (n_rows = no such node)
+  uint32_t* flag;            // [n + 1] 1 = representative; flag[n] = 0
+  uint32_t* pos;             // [n + 1] exclusive scan of flag; pos[n] = unique count
+  uint64_t* uniq;            // [<= n] unique roots (node ids), by first representative
+  uint32_t* uidx_of;         // [n] index into uniq of every position
+  uint32_t* counter;         // [0] unique count
+};
+
+__device__ __forceinline__ uint64_t DedupKey(const DedupArgs& a, int64_t i) {
+  uint64_t key = a.roots[i];
+  if (a.root_mask != nullptr && a.root_mask[i / a.root_group]) key = 0;
+  return key;
+}
+
+__global__ __launch_bounds__(256) void DedupMarkKernel(const DedupArgs a) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n;
+       i += stride) {
+    const int64_t row = FindRow(a.g, DedupKey(a, i));
+    const uint32_t slot = row < 0 ? (uint32_t)a.g.n_rows : (uint32_t)row;
+    a.row_slot[i] = slot;
+    a.owner[slot] = (uint32_t)i;
+  }
+}
+
+__global__ __launch_bounds__(256) void DedupFlagKernel(const DedupArgs a) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= a.n;
+       i += stride)
+    a.flag[i] = (i < a.n && a.owner[a.row_slot[i]] == (uint32_t)i) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void DedupIndexKernel(const DedupArgs a) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (first == 0) a.counter[0] = a.pos[a.n];
+  for (int64_t i = first; i < a.n; i += stride) {
+    const uint32_t rep = a.owner[a.row_slot[i]];
+    a.uidx_of[i] = a.pos[rep];
+    if (rep == (uint32_t)i) a.uniq[a.pos[i]] = DedupKey(a, i);
+  }
+}
+
+struct ExpandArgs {
+  const uint32_t* counter;
+  const uint32_t* uidx_of;
+  const uint64_t* t_id;
+  const float* t_w;
+  const int32_t* t_t;
+  const uint8_t* t_mask;
+  uint64_t* out_id;
+  float* out_w;
+  int32_t* out_t;
+  uint8_t* out_mask;
+  int64_t n;
+  int32_t count;
+};
+
+// out row i = sampled row of unique root uidx_of[i]; U adjacent samples
+// per lane (U = 2: 16-byte id stores, needs an even count).
+template <int U>
+__global__ __launch_bounds__(256) void DedupExpandKernel(const ExpandArgs a,
+                                                         const int64_t stride_rows,
+                                                         const int32_t stride_slots) {
+  if (!DedupActive(a.counter, a.n)) return;
   const int64_t total = a.n * (int64_t)a.count;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * U;
+  int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * U;
+  if (s >= total) return;
+  int64_t i = s / a.count;
+  int32_t j = (int32_t)(s - i * a.count);
+  for (; s < total; s += stride) {
+    const int64_t u = (int64_t)a.uidx_of[i];
+    const int64_t src = u * a.count + j;
+    if (U == 1) {
+      a.out_id[s] = a.t_id[src];
+      a.out_w[s] = a.t_w[src];
+      a.out_t[s] = a.t_t[src];
+    } else {
+      // src is even whenever count is even
+      *reinterpret_cast<ulonglong2*>(a.out_id + s) =
+          *reinterpret_cast<const ulonglong2*>(a.t_id + src);
+      *reinterpret_cast<float2*>(a.out_w + s) =
+          *reinterpret_cast<const float2*>(a.t_w + src);
+      *reinterpret_cast<int2*>(a.out_t + s) =
+          *reinterpret_cast<const int2*>(a.t_t + src);
+    }
+    if (j == 0 && a.out_mask != nullptr) a.out_mask[i] = a.t_mask[u];
+    i += stride_rows;
+    j += stride_slots;
+    if (j >= a.count) { j -= a.count; ++i; }
+  }
+}
+
+__global__ __launch_bounds__(256) void SampleNeighborKernel(const SampleNbArgs a) {
+  int64_t n_roots;
+  if (!DedupGate(a, &n_roots)) return;
+  const int64_t total = n_roots * (int64_t)a.count;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total;
        s += stride) {
@@ -130,7 +275,9 @@ __device__ __forceinline__ void FastSampleOne(const GraphView& g,
 template <bool TF_LAYOUT, bool ZERO_CHECK>
 __global__ __launch_bounds__(256) void SampleNeighborFastKernel(
     const SampleNbArgs a, const int64_t stride_rows, const int32_t stride_slots) {
-  const int64_t total = a.n * (int64_t)a.count;
+  int64_t n_roots;
+  if (!DedupGate(a, &n_roots)) return;
+  const int64_t total = n_roots * (int64_t)a.count;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= total) return;
@@ -347,6 +494,7 @@ __global__ __launch_bounds__(256) void SampleNeighborIlpKernel(const SampleNbArg
 
 namespace {
 constexpr int64_t kK1GridCap = 32768;
+int g_k1_dedup = 1;     // 0 = never, 1 = automatic for >= 16384 roots, 2 = always try
 int g_k1_pair = 1;      // pivot kernel: two adjacent samples per lane when count is even
 int g_k1_grid_cap = 0;  // measurement only: override the workgroup cap of K1
 int g_k1_ablate = 0;   // measurement only: skip parts of the blocked kernel
@@ -970,7 +1118,9 @@ __device__ __forceinline__ bool LoadSegment(const GraphView& g, int64_t row,
 template <bool TF_LAYOUT, int U>
 __global__ __launch_bounds__(256) void SampleNeighborPivotKernel(
     const SampleNbArgs a, const int64_t stride_rows, const int32_t stride_slots) {
-  const int64_t total = a.n * (int64_t)a.count;
+  int64_t n_roots;
+  if (!DedupGate(a, &n_roots)) return;
+  const int64_t total = n_roots * (int64_t)a.count;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x * U;
   int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * U;
   if (s >= total) return;
@@ -1032,39 +1182,14 @@ static void LaunchIlp(bool tf, int grid, int block, hipStream_t stream,
   }
 }
 
-static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
-                                uint64_t seed, uint32_t call_id,
-                                const uint64_t* roots, int64_t n,
-                                const uint8_t* root_mask, int32_t root_group,
-                                const int32_t* edge_types, int32_t k,
-                                int32_t count, int32_t layout,
-                                int64_t default_node, uint64_t* out_id,
-                                float* out_w, int32_t* out_t,
-                                uint8_t* out_row_mask) {
-  if (g == nullptr) return Fail(EULER_GPU_ENOGRAPH, "sample_neighbor: null graph");
-  if (n < 0 || count < 0 || k < 0 || k > kMaxListedTypes)
-    return Fail(EULER_GPU_EINVAL, "sample_neighbor: bad n/count/k (k <= 32)");
-  if (layout != EULER_GPU_LAYOUT_CORE && layout != EULER_GPU_LAYOUT_TF)
-    return Fail(EULER_GPU_EINVAL, "sample_neighbor: bad layout");
-  if (n == 0 || count == 0) return EULER_GPU_OK;
-  if (!roots || !out_id || !out_w || !out_t)
-    return Fail(EULER_GPU_EINVAL, "sample_neighbor: null buffer");
-  if (k > 0 && !edge_types)
-    return Fail(EULER_GPU_EINVAL, "sample_neighbor: null edge_types");
-  if ((g_k1_variant == 3 || g_k1_variant == 4) && g->view.blk == nullptr) {
-    const int rc = EnsureBlockedIndex(g);     // A/B variants only: built on first use
-    if (rc != EULER_GPU_OK) return rc;
-  }
-  SampleNbArgs a{};
-  a.g = g->view;
-  a.seed = seed; a.call_id = call_id;
-  a.roots = roots; a.root_mask = root_mask;
-  a.root_group = root_group > 0 ? root_group : 1;
-  a.out_id = out_id; a.out_w = out_w; a.out_t = out_t;
-  a.out_row_mask = out_row_mask;
-  a.n = n; a.default_node = default_node;
-  a.k = k; a.count = count; a.layout = layout;
-  for (int i = 0; i < k; ++i) a.et[i] = edge_types[i];
+// Kernel selection for one pass over a.n roots (a.dd_role says which pass).
+static int LaunchK1(const euler_gpu_graph* g, hipStream_t stream,
+                    const SampleNbArgs& a) {
+  const int64_t n = a.n;
+  const int32_t count = a.count, layout = a.layout, k = a.k;
+  uint64_t* out_id = a.out_id;
+  float* out_w = a.out_w;
+  int32_t* out_t = a.out_t;
   const int block = 256;
   // K1 launches up to 32768 workgroups (128 per CU) rather than GridFor's 16 per
   // CU: hub-heavy and leaf-heavy workgroups finish at very different times and
@@ -1145,6 +1270,187 @@ static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
   } else {
     hipLaunchKernelGGL(SampleNeighborKernel, dim3(grid), dim3(block), 0, stream, a);
   }
+  EG_HIP(hipGetLastError());
+  return EULER_GPU_OK;
+}
+
+// Per-(graph, stream) scratch, grown on demand.
+static int GetWorkspace(const euler_gpu_graph* g, hipStream_t stream, size_t bytes,
+                        void** out) {
+  std::lock_guard<std::mutex> lk(g->ws_mu);
+  auto& slot = g->ws[(void*)stream];
+  if (slot.second < bytes) {
+    if (slot.first != nullptr) {
+      EG_HIP(hipStreamSynchronize(stream));   // earlier calls may still use it
+      EG_HIP(hipFree(slot.first));
+      slot.first = nullptr; slot.second = 0;
+    }
+    const size_t want = bytes + bytes / 4;
+    hipError_t e = hipMalloc(&slot.first, want);
+    if (e != hipSuccess) {
+      slot.first = nullptr;
+      return Fail(EULER_GPU_ENOMEM, std::string("sample_neighbor workspace: ") +
+                                        hipGetErrorString(e));
+    }
+    slot.second = want;
+  }
+  *out = slot.first;
+  return EULER_GPU_OK;
+}
+
+constexpr int64_t kDedupMinRoots = 16384;
+
+// Measurement hook (euler_gpu_time_sample_neighbor_phases): when set, the
+// launcher records these 4 events on its stream at the phase boundaries
+// [0] start, [1] duplicate detection done, [2] sampling done, [3] expand done.
+thread_local hipEvent_t* t_phase_events = nullptr;
+thread_local int64_t g_last_unique_offset = -1;   // of the unique count in the workspace
+static int64_t ReadU32(const uint8_t* dev) {
+  uint32_t v = 0;
+  if (hipMemcpy(&v, dev, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (int64_t)v;
+}
+static void PhaseMark(hipStream_t stream, int i) {
+  if (t_phase_events != nullptr) (void)hipEventRecord(t_phase_events[i], stream);
+}
+
+// dedup: 0 = never, 1 = automatic (count duplicates on device, decide there).
+static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
+                                uint64_t seed, uint32_t call_id,
+                                const uint64_t* roots, int64_t n,
+                                const uint8_t* root_mask, int32_t root_group,
+                                const int32_t* edge_types, int32_t k,
+                                int32_t count, int32_t layout,
+                                int64_t default_node, uint64_t* out_id,
+                                float* out_w, int32_t* out_t,
+                                uint8_t* out_row_mask, int dedup = 1) {
+  if (g == nullptr) return Fail(EULER_GPU_ENOGRAPH, "sample_neighbor: null graph");
+  if (n < 0 || count < 0 || k < 0 || k > kMaxListedTypes)
+    return Fail(EULER_GPU_EINVAL, "sample_neighbor: bad n/count/k (k <= 32)");
+  if (layout != EULER_GPU_LAYOUT_CORE && layout != EULER_GPU_LAYOUT_TF)
+    return Fail(EULER_GPU_EINVAL, "sample_neighbor: bad layout");
+  if (n == 0 || count == 0) return EULER_GPU_OK;
+  if (!roots || !out_id || !out_w || !out_t)
+    return Fail(EULER_GPU_EINVAL, "sample_neighbor: null buffer");
+  if (k > 0 && !edge_types)
+    return Fail(EULER_GPU_EINVAL, "sample_neighbor: null edge_types");
+  if ((g_k1_variant == 3 || g_k1_variant == 4) && g->view.blk == nullptr) {
+    const int rc = EnsureBlockedIndex(g);     // A/B variants only: built on first use
+    if (rc != EULER_GPU_OK) return rc;
+  }
+  SampleNbArgs a{};
+  a.g = g->view;
+  a.seed = seed; a.call_id = call_id;
+  a.roots = roots; a.root_mask = root_mask;
+  a.root_group = root_group > 0 ? root_group : 1;
+  a.out_id = out_id; a.out_w = out_w; a.out_t = out_t;
+  a.out_row_mask = out_row_mask;
+  a.n = n; a.default_node = default_node;
+  a.k = k; a.count = count; a.layout = layout;
+  for (int i = 0; i < k; ++i) a.et[i] = edge_types[i];
+  const bool try_dedup = dedup != 0 && g_k1_dedup != 0 && g_k1_variant == 5 &&
+                         (n >= kDedupMinRoots || g_k1_dedup == 2) &&
+                         n < (int64_t)0x3fffffff &&
+                         g->view.n_rows < (int64_t)0xfffffff0;
+  if (!try_dedup) {
+    PhaseMark(stream, 0);
+    PhaseMark(stream, 1);
+    const int rc = LaunchK1(g, stream, a);
+    PhaseMark(stream, 2);
+    PhaseMark(stream, 3);
+    return rc;
+  }
+
+  // ---- workspace -----------------------------------------------------------
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t total_out = (size_t)n * (size_t)count;
+  size_t scan_bytes = 0;
+  EG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t*)nullptr,
+                                          (uint32_t*)nullptr, (int)(n + 1), stream));
+  const size_t o_owner = 0;
+  const size_t o_slot = o_owner + al(((size_t)g->view.n_rows + 1) * 4);
+  const size_t o_flag = o_slot + al((size_t)n * 4);
+  const size_t o_pos = o_flag + al(((size_t)n + 1) * 4);
+  const size_t o_uidx = o_pos + al(((size_t)n + 1) * 4);
+  const size_t o_uniq = o_uidx + al((size_t)n * 4);
+  const size_t o_cnt = o_uniq + al((size_t)n * 8);
+  const size_t o_scan = o_cnt + 256;
+  const size_t o_mask = o_scan + al(scan_bytes);
+  const size_t o_tid = o_mask + al((size_t)n);
+  const size_t o_tw = o_tid + al(total_out * 8);
+  const size_t o_tt = o_tw + al(total_out * 4);
+  const size_t ws_bytes = o_tt + al(total_out * 4);
+  void* wsp = nullptr;
+  {
+    const int rc = GetWorkspace(g, stream, ws_bytes, &wsp);
+    if (rc != EULER_GPU_OK) return rc;
+  }
+  uint8_t* ws = (uint8_t*)wsp;
+  DedupArgs d{};
+  d.g = g->view;
+  d.roots = roots; d.root_mask = root_mask; d.n = n; d.root_group = a.root_group;
+  d.owner = (uint32_t*)(ws + o_owner);
+  d.row_slot = (uint32_t*)(ws + o_slot);
+  d.flag = (uint32_t*)(ws + o_flag);
+  d.pos = (uint32_t*)(ws + o_pos);
+  d.uidx_of = (uint32_t*)(ws + o_uidx);
+  d.uniq = (uint64_t*)(ws + o_uniq);
+  d.counter = (uint32_t*)(ws + o_cnt);
+  g_last_unique_offset = (int64_t)o_cnt;
+  const int block = 256;
+  const int dgrid = GridFor(n + 1, block);
+  PhaseMark(stream, 0);
+  hipLaunchKernelGGL(DedupMarkKernel, dim3(dgrid), dim3(block), 0, stream, d);
+  hipLaunchKernelGGL(DedupFlagKernel, dim3(dgrid), dim3(block), 0, stream, d);
+  EG_HIP(hipcub::DeviceScan::ExclusiveSum(ws + o_scan, scan_bytes, d.flag, d.pos,
+                                          (int)(n + 1), stream));
+  hipLaunchKernelGGL(DedupIndexKernel, dim3(dgrid), dim3(block), 0, stream, d);
+  PhaseMark(stream, 1);
+  // ---- pass 1: the given roots, straight to the outputs (few duplicates) -----
+  a.dd_counter = d.counter;
+  a.dd_n_in = n;
+  a.dd_role = 1;
+  {
+    const int rc = LaunchK1(g, stream, a);
+    if (rc != EULER_GPU_OK) return rc;
+  }
+  // ---- pass 2: the unique roots into scratch rows, then expand ---------------
+  SampleNbArgs b = a;
+  b.dd_role = 2;
+  b.roots = d.uniq;
+  b.root_mask = nullptr;          // masked roots were entered as node id 0
+  b.root_group = 1;
+  b.out_id = (uint64_t*)(ws + o_tid);
+  b.out_w = (float*)(ws + o_tw);
+  b.out_t = (int32_t*)(ws + o_tt);
+  b.out_row_mask = ws + o_mask;
+  {
+    const int rc = LaunchK1(g, stream, b);
+    if (rc != EULER_GPU_OK) return rc;
+  }
+  PhaseMark(stream, 2);
+  ExpandArgs x{};
+  x.counter = d.counter; x.uidx_of = d.uidx_of;
+  x.t_id = b.out_id; x.t_w = b.out_w; x.t_t = b.out_t; x.t_mask = b.out_row_mask;
+  x.out_id = out_id; x.out_w = out_w; x.out_t = out_t; x.out_mask = out_row_mask;
+  x.n = n; x.count = count;
+  const bool pair = count % 2 == 0 && ((uintptr_t)out_id % 16 == 0) &&
+                    ((uintptr_t)out_w % 8 == 0) && ((uintptr_t)out_t % 8 == 0);
+  const int U = pair ? 2 : 1;
+  int64_t blocks = ((int64_t)total_out / U + block - 1) / block;
+  if (blocks > kK1GridCap) blocks = kK1GridCap;
+  if (blocks < 1) blocks = 1;
+  const int64_t stride = blocks * block * U;
+  const int64_t stride_rows = stride / count;
+  const int32_t stride_slots = (int32_t)(stride - stride_rows * count);
+  if (pair) {
+    hipLaunchKernelGGL(DedupExpandKernel<2>, dim3((int)blocks), dim3(block), 0, stream,
+                       x, stride_rows, stride_slots);
+  } else {
+    hipLaunchKernelGGL(DedupExpandKernel<1>, dim3((int)blocks), dim3(block), 0, stream,
+                       x, stride_rows, stride_slots);
+  }
+  PhaseMark(stream, 3);
   EG_HIP(hipGetLastError());
   return EULER_GPU_OK;
 }
@@ -1520,6 +1826,7 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 2) { g_k1_ablate = value; return EULER_GPU_OK; }
   if (key == 3) { g_k1_grid_cap = value; return EULER_GPU_OK; }
   if (key == 4) { g_k1_pair = value; return EULER_GPU_OK; }
+  if (key == 5) { g_k1_dedup = value; return EULER_GPU_OK; }
   if (key == 1 && (value == 1 || value == 2 || value == 4 || value == 8)) {
     g_k1_ilp = value;
     return EULER_GPU_OK;
@@ -1583,7 +1890,10 @@ int euler_gpu_sample_fanout(const euler_gpu_graph* g, void* stream,
                                   edge_types_host + (size_t)h * k, k,
                                   counts_host[h], EULER_GPU_LAYOUT_TF,
                                   default_node, out_id_dev[h], out_w_dev[h],
-                                  out_t_dev[h], row_mask);
+                                  out_t_dev[h], row_mask,
+                                  // hop 0 samples the caller's batch; later hops
+                                  // sample sampled neighbours, which repeat
+                                  h == 0 ? 0 : 1);
     if (rc != EULER_GPU_OK) return rc;
     roots = out_id_dev[h];
     mask = row_mask;
@@ -1789,6 +2099,52 @@ int euler_gpu_time_sample_neighbor(const euler_gpu_graph* g, void* stream,
   EG_HIP(hipEventDestroy(e1));
   *mean_ms_host = ms / (float)iters;
   return EULER_GPU_OK;
+}
+
+int euler_gpu_time_sample_neighbor_phases(const euler_gpu_graph* g, void* stream,
+                                          uint64_t seed, const uint64_t* roots_dev,
+                                          int64_t n, const int32_t* edge_types_host,
+                                          int32_t k, int32_t count, int32_t layout,
+                                          int32_t dedup, uint64_t* out_id_dev,
+                                          float* out_w_dev, int32_t* out_t_dev,
+                                          int32_t iters, float* mean_ms3_host,
+                                          int64_t* n_unique_host) {
+  if (iters <= 0 || iters > 64 || !mean_ms3_host)
+    return Fail(EULER_GPU_EINVAL, "time_sample_neighbor_phases: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  std::vector<hipEvent_t> ev((size_t)iters * 4);
+  for (auto& e : ev) EG_HIP(hipEventCreate(&e));
+  int rc = EULER_GPU_OK;
+  for (int32_t it = 0; it < iters && rc == EULER_GPU_OK; ++it) {
+    t_phase_events = ev.data() + (size_t)it * 4;
+    rc = LaunchSampleNeighbor(g, st, seed, (uint32_t)it, roots_dev, n, nullptr, 1,
+                              edge_types_host, k, count, layout, -1, out_id_dev,
+                              out_w_dev, out_t_dev, nullptr, dedup);
+  }
+  t_phase_events = nullptr;
+  if (rc == EULER_GPU_OK) {
+    EG_HIP(hipStreamSynchronize(st));
+    float sum[3] = {0.f, 0.f, 0.f};
+    for (int32_t it = 0; it < iters; ++it)
+      for (int p = 0; p < 3; ++p) {
+        float ms = 0.f;
+        EG_HIP(hipEventElapsedTime(&ms, ev[(size_t)it * 4 + p], ev[(size_t)it * 4 + p + 1]));
+        sum[p] += ms;
+      }
+    for (int p = 0; p < 3; ++p) mean_ms3_host[p] = sum[p] / (float)iters;
+    if (n_unique_host != nullptr) {
+      *n_unique_host = -1;
+      std::lock_guard<std::mutex> lk(g->ws_mu);
+      auto it = g->ws.find((void*)st);
+      // the unique count of the last launch sits at a fixed offset only the
+      // launcher knows; report it through the side channel it left behind
+      *n_unique_host = g_last_unique_offset >= 0 && it != g->ws.end()
+                           ? ReadU32((const uint8_t*)it->second.first + g_last_unique_offset)
+                           : -1;
+    }
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return rc;
 }
 
 int euler_gpu_sample_neighbor_algo_bytes(const euler_gpu_graph* g, void* stream,

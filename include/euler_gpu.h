@@ -280,12 +280,17 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
                                 int32_t* split_cnt_host);
 
 /* ---- tuning ---------------------------------------------------------------
- * key 0: sample_neighbor kernel variant for single-type calls on graphs with
- *        non-decreasing running sums: 3 = blocked sampling index [default],
- *        2 = flat arrays, several samples per lane, 1 = flat arrays, one
- *        sample per lane, 0 = always the generic reference-loop kernel.
+ * key 0: sample_neighbor kernel for single-type calls on graphs with
+ *        non-decreasing running sums: 5 = pivot levels [default], 4 = wave-staged
+ *        LDS search, 3 = blocked index, 2 = flat arrays / several samples per
+ *        lane, 1 = flat arrays / one sample per lane, 0 = always the generic
+ *        reference-loop kernel.
  * key 1: samples per lane of variant 2 (1, 2, 4 or 8).
- * All variants produce identical results; the knobs exist for A/B measurements
+ * key 2, 3: measurement only (ablation mask, workgroup cap).
+ * key 4: variant 5 draws two adjacent samples per lane when count is even (1).
+ * key 5: duplicate roots: 0 = never look, 1 = look when a call has >= 16384
+ *        roots [default], 2 = always look.
+ * All settings produce identical results; the knobs exist for A/B measurements
  * and tests. */
 int euler_gpu_set_tuning(int32_t key, int32_t value);
 
@@ -300,6 +305,19 @@ int euler_gpu_time_sample_neighbor(const euler_gpu_graph* g, void* stream,
                                    uint64_t* out_id_dev, float* out_w_dev,
                                    int32_t* out_t_dev, int32_t iters,
                                    float* mean_ms_host);
+/* Same, split by phase: mean_ms3_host[0] duplicate detection, [1] sampling
+ * kernel(s), [2] expansion of the unique rows (0 when the call did not take
+ * the unique path).  dedup: 0 = sample the given roots directly, 1 = the
+ * launcher's automatic policy.  *n_unique_host (optional) receives the number
+ * of distinct roots the last launch counted (-1 if it did not count). */
+int euler_gpu_time_sample_neighbor_phases(const euler_gpu_graph* g, void* stream,
+                                          uint64_t seed, const uint64_t* roots_dev,
+                                          int64_t n, const int32_t* edge_types_host,
+                                          int32_t k, int32_t count, int32_t layout,
+                                          int32_t dedup, uint64_t* out_id_dev,
+                                          float* out_w_dev, int32_t* out_t_dev,
+                                          int32_t iters, float* mean_ms3_host,
+                                          int64_t* n_unique_host);
 /* Exact algorithmic byte count of one sample_neighbor launch (SURVEY §8d
  * formula evaluated on the actual roots' degrees); synchronises. */
 int euler_gpu_sample_neighbor_algo_bytes(const euler_gpu_graph* g, void* stream,

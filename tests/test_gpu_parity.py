@@ -27,8 +27,8 @@ def EA(torch_cuda):
     return euler_amd
 
 
-@pytest.fixture(params=[(5, 4), (5, 1), (4, 4), (3, 4), (2, 4), (2, 2), (2, 8), (1, 4), (0, 4)],
-                ids=["k1pivot", "k1pivot1", "k1wave", "k1blocked", "k1ilp4", "k1ilp2", "k1ilp8", "k1fast",
+@pytest.fixture(params=[(5, 4), (5, 2), (5, 1), (4, 4), (3, 4), (2, 4), (2, 2), (2, 8), (1, 4), (0, 4)],
+                ids=["k1pivot", "k1dedup", "k1pivot1", "k1wave", "k1blocked", "k1ilp4", "k1ilp2", "k1ilp8", "k1fast",
                      "k1generic"])
 def k1_variant(request, EA):
     """Run with every variant of the K1 kernel (blocked sampling index, ILP with
@@ -39,8 +39,11 @@ def k1_variant(request, EA):
     _lib.lib().euler_gpu_set_tuning(1, request.param[1])
     # pivot kernel: param[1] == 1 forces one sample per lane
     _lib.lib().euler_gpu_set_tuning(4, 0 if request.param == (5, 1) else 1)
+    # (5, 2): always run the duplicate-root machinery, whatever the batch size
+    _lib.lib().euler_gpu_set_tuning(5, 2 if request.param == (5, 2) else 1)
     yield request.param
     _lib.lib().euler_gpu_set_tuning(4, 1)
+    _lib.lib().euler_gpu_set_tuning(5, 1)
     _lib.lib().euler_gpu_set_tuning(0, 5)
     _lib.lib().euler_gpu_set_tuning(1, 4)
 
@@ -455,3 +458,47 @@ def test_non_monotone_rows_use_reference_loop(EA, O, torch_cuda):
         r = int(q[i]) - 1
         row = set(nbr[seg[r]:seg[r + 1]].tolist()) | {2 ** 64 - 1}
         assert set(got[i].tolist()) <= row
+
+
+@pytest.mark.parametrize("et", [[0], [1, 2], []])
+@pytest.mark.parametrize("count", [10, 7])
+def test_duplicate_roots_take_the_unique_path(EA, O, torch_cuda, big_pair, et, count):
+    """40 000 roots drawn from 300 nodes (plus unknown ids and the sentinel):
+    the launcher counts duplicates on device, samples each distinct node once
+    and expands - ID_UNIQUE -> sample -> GATHER of the reference
+    (parser/compiler.cc:76-90).  Results must equal the oracle's row by row, in
+    both layouts, with the row mask."""
+    torch = torch_cuda
+    G, OG, ids, rng = big_pair
+    pool = np.concatenate([rng.choice(ids, 300), [0, 2 ** 63 + 5, 12345]]).astype(np.uint64)
+    q = rng.choice(pool, 40000).astype(np.uint64)
+    qt = torch.as_tensor(q.astype(np.int64)).cuda()
+    G.set_seed(4)
+    idx, oid, ow, ot = OG.sample_neighbor_core(4, 9, q, et, count)
+    ids_g, w_g, t_g = G.sample_neighbor(qt, et, count, layout="core", call_id=9)
+    assert np.array_equal(t2n(ids_g).reshape(-1).astype(np.uint64), oid)
+    assert np.array_equal(t2n(w_g).reshape(-1), ow)
+    assert np.array_equal(t2n(t_g).reshape(-1), ot)
+    on, ow2, ot2 = OG.sample_neighbor(4, 9, q.astype(np.int64), et, count, -7)
+    ids_g, w_g, t_g, m_g = G.sample_neighbor(qt, et, count, default_node=-7, call_id=9,
+                                             return_mask=True)
+    assert np.array_equal(t2n(ids_g), on)
+    assert np.array_equal(t2n(w_g), ow2)
+    assert np.array_equal(t2n(t_g), ot2)
+    assert np.array_equal(t2n(m_g) != 0, (on[:, 0] == -7) & (ot2[:, 0] == -1))
+
+
+def test_fanout_second_hop_dedup(EA, O, torch_cuda, big_pair):
+    """2048 roots, fanout [8, 6]: hop 2 has 16 384 roots with many repeats and
+    goes through the duplicate-root path automatically."""
+    torch = torch_cuda
+    G, OG, ids, rng = big_pair
+    q = np.concatenate([rng.choice(ids, 2046), [0, 777]]).astype(np.int64)
+    G.set_seed(12)
+    gn, gw, gt = G.sample_fanout(torch.as_tensor(q).cuda(), [[0], [1]], [8, 6], -1,
+                                 call_id=3)
+    on, ow, ot = OG.sample_fanout(12, 3, q, [[0], [1]], [8, 6], -1)
+    for h in range(2):
+        assert np.array_equal(t2n(gn[h + 1]), on[h])
+        assert np.array_equal(t2n(gw[h]), ow[h])
+        assert np.array_equal(t2n(gt[h]), ot[h])

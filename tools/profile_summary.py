@@ -27,17 +27,38 @@ def passes(name, kernel="SampleNeighbor"):
 
 summary = {"note": "rocprofv3 --pmc passes (one counter set per pass, --kernel-trace only) over "
                    "`bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-check`; per-launch "
-                   "means of the K1 kernel split into the hop-1 shape (short launches) and the "
-                   "hop-2 shape (long launches). FETCH_SIZE / WRITE_SIZE are reported in KiB."}
+                   "means of the K1 kernel: hop1 = SampleNeighborPivotKernel<true,1> over the batch, "
+                   "hop2 = SampleNeighborPivotKernel<true,2> over the distinct hop-2 roots (gated "
+                   "no-op launches excluded); expand = DedupExpandKernel. FETCH_SIZE / WRITE_SIZE "
+                   "are reported in KiB."}
+# K1 launches of a step that do work: <true, 1> = hop 1 (odd count, one sample
+# per lane), <true, 2> = hop 2 over the distinct roots; the <true, 2> launches
+# that last a few microseconds are the gated no-op pass (see DedupGate).
+def split(v):
+    h1 = [x for x in v if "<true, 1>" in x[3]]
+    h2 = [x for x in v if "<true, 2>" in x[3] and x[2] > 30000]
+    return h1, h2
+
+def passes_named(name):
+    rows = collections.defaultdict(list)
+    for f in glob.glob(g + "_pmc_%s/**/*counter_collection.csv" % name, recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "SampleNeighborPivotKernel" in r["Kernel_Name"] or "DedupExpand" in r["Kernel_Name"]:
+                rows[r["Counter_Name"]].append(
+                    (int(r["Dispatch_Id"]), float(r["Counter_Value"]),
+                     int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r["Kernel_Name"]))
+    return rows
+
 for name in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum"):
-    for ctr, v in passes(name).items():
-        durs = sorted(x[2] for x in v)
-        cut = (durs[0] + durs[-1]) / 2
-        h1 = [x[1] for x in v if x[2] < cut]
-        h2 = [x[1] for x in v if x[2] >= cut]
-        summary[ctr] = {"hop1_mean": sum(h1) / max(len(h1), 1), "hop2_mean": sum(h2) / max(len(h2), 1),
+    for ctr, v in passes_named(name).items():
+        h1, h2 = split(v)
+        ex = [x for x in v if "DedupExpand" in x[3] and x[2] > 30000]
+        mean = lambda xs, i: sum(x[i] for x in xs) / max(len(xs), 1)
+        summary[ctr] = {"hop1_mean": mean(h1, 1), "hop2_mean": mean(h2, 1),
                         "hop1_n": len(h1), "hop2_n": len(h2),
-                        "hop2_mean_ns": sum(x[2] for x in v if x[2] >= cut) / max(len(h2), 1)}
+                        "hop1_mean_ns": mean(h1, 2), "hop2_mean_ns": mean(h2, 2),
+                        "expand_mean": mean(ex, 1), "expand_n": len(ex),
+                        "expand_mean_ns": mean(ex, 2)}
 # calibration: tools/ubench_tcp "divergent dword" on the 4 GiB working set reads
 # 256*8*256 lanes * 32 iters * 8 loads = 134 217 728 random 4-byte words, one per
 # 64-byte sector (collisions negligible) -> at least 8.59e9 bytes by sector count
