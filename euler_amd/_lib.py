@@ -25,7 +25,9 @@ class HostCSR(C.Structure):
                 ("row_ptr", i64p), ("type_end", i32p), ("nbr", u64p),
                 ("prefix_w", f32p), ("type_prefix", f32p),
                 ("node_type", i32p), ("node_weight", f32p),
-                ("sampler_order", u64p)]
+                ("sampler_order", u64p),
+                ("n_float_features", C.c_int32), ("pad0", C.c_int32),
+                ("feat_ptr", i64p), ("feat_idx", i32p), ("feat_val", f32p)]
 
 
 class SynthParams(C.Structure):
@@ -101,6 +103,9 @@ SIGNATURES = {
                                                        C.c_int32, C.c_int32,
                                                        C.POINTER(C.c_double)]),
     "euler_gpu_set_tuning": (C.c_int, [C.c_int32, C.c_int32]),
+    "euler_gpu_graph_num_float_features": (C.c_int32, [vp]),
+    "euler_gpu_get_dense_feature": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int32,
+                                              C.c_int32, vp]),
     "euler_gpu_time_sample_neighbor_phases": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_int64,
                                                         i32p, C.c_int32, C.c_int32,
                                                         C.c_int32, C.c_int32, vp, vp, vp,

@@ -72,6 +72,17 @@ struct GraphView {
   // last edge of block i; skip2[j] = skip1[32 j + 31]; skip3[k] = skip2[32 k +
   // 31] (indices clamped to the array end).  A search descends skip3 -> skip2
   // -> skip1 -> block; each level is one 128-byte line.
+  // dense float features (node.h float_features_idx_ / float_features_):
+  // values of row r live at feat_val[feat_ptr[r] ...], slot f ends at
+  // feat_idx[r * n_float + f] (row-relative).  When every row has the same
+  // slot layout (the usual fixed-dimension table) feat_uniform = 1 and
+  // feat_ptr[r] = r * feat_stride with the ends of row 0 valid for all rows.
+  const int64_t* feat_ptr;
+  const int32_t* feat_idx;
+  const float* feat_val;
+  int32_t n_float;
+  int32_t feat_uniform;
+  int64_t feat_stride;
   // pivot levels (K1 default search): level 1 entry q = prefix_w[4 q + 3],
   // level k+1 entry q = level k entry 5 q + 4 (indices clamped to the level's
   // end).  One unaligned 16-byte load reads the <= 4 candidate entries a
@@ -165,13 +176,16 @@ int BuildGraphSynthetic(const euler_gpu_synth_params* p, int device,
                         euler_gpu_graph** out);
 int EnsureBlockedIndex(const euler_gpu_graph* g);   // K1 variants 3 / 4 only
 // dat_reader.cc
+struct DatGraph {
+  std::vector<uint64_t> row_id, nbr;
+  std::vector<int64_t> row_ptr, feat_ptr;
+  std::vector<int32_t> type_end, node_type, feat_idx;
+  std::vector<float> prefix_w, type_prefix, node_weight, feat_val;
+  int32_t n_edge_types = 0, n_node_types = 0, partitions = 1, n_float = 0;
+  void Describe(euler_gpu_host_csr* c) const;
+};
 int LoadDatDirectory(const char* data_path, int32_t shard_index, int32_t shards,
-                     std::vector<uint64_t>* row_id, std::vector<int64_t>* row_ptr,
-                     std::vector<int32_t>* type_end, std::vector<uint64_t>* nbr,
-                     std::vector<float>* prefix_w, std::vector<float>* type_prefix,
-                     std::vector<int32_t>* node_type,
-                     std::vector<float>* node_weight, int32_t* n_edge_types,
-                     int32_t* n_node_types, int32_t* partitions);
+                     DatGraph* out);
 
 // Grid sizing for HBM-bound kernels: enough workgroups to fill 256 CUs x 8
 // resident blocks, grid-stride beyond that.

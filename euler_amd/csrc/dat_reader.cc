@@ -77,13 +77,34 @@ bool KeepFile(const std::string& name, int32_t shard_index, int32_t shards) {
 
 }  // namespace
 
+void DatGraph::Describe(euler_gpu_host_csr* c) const {
+  *c = euler_gpu_host_csr{};
+  c->n_rows = (int64_t)row_id.size();
+  c->n_edge_types = n_edge_types; c->n_node_types = n_node_types;
+  c->row_id = row_id.data(); c->row_ptr = row_ptr.data();
+  c->type_end = type_end.data(); c->nbr = nbr.data();
+  c->prefix_w = prefix_w.data(); c->type_prefix = type_prefix.data();
+  c->node_type = node_type.data(); c->node_weight = node_weight.data();
+  c->n_float_features = n_float;
+  if (n_float > 0) {
+    c->feat_ptr = feat_ptr.data(); c->feat_idx = feat_idx.data();
+    c->feat_val = feat_val.data();
+  }
+}
+
 int LoadDatDirectory(const char* data_path, int32_t shard_index, int32_t shards,
-                     std::vector<uint64_t>* row_id, std::vector<int64_t>* row_ptr,
-                     std::vector<int32_t>* type_end, std::vector<uint64_t>* nbr,
-                     std::vector<float>* prefix_w, std::vector<float>* type_prefix,
-                     std::vector<int32_t>* node_type,
-                     std::vector<float>* node_weight, int32_t* n_edge_types,
-                     int32_t* n_node_types, int32_t* partitions) {
+                     DatGraph* out) {
+  std::vector<uint64_t>* row_id = &out->row_id;
+  std::vector<int64_t>* row_ptr = &out->row_ptr;
+  std::vector<int32_t>* type_end = &out->type_end;
+  std::vector<uint64_t>* nbr = &out->nbr;
+  std::vector<float>* prefix_w = &out->prefix_w;
+  std::vector<float>* type_prefix = &out->type_prefix;
+  std::vector<int32_t>* node_type = &out->node_type;
+  std::vector<float>* node_weight = &out->node_weight;
+  int32_t* n_edge_types = &out->n_edge_types;
+  int32_t* n_node_types = &out->n_node_types;
+  int32_t* partitions = &out->partitions;
   if (shards <= 0 || shard_index < 0 || shard_index >= shards)
     return Fail(EULER_GPU_EINVAL, "graph_load: bad shard arguments");
   const std::string root(data_path);
@@ -136,6 +157,14 @@ int LoadDatDirectory(const char* data_path, int32_t shard_index, int32_t shards,
   std::vector<int32_t> gids, gidx;
   std::vector<float> gw, nw;
   std::vector<uint64_t> nb;
+  // per-node float features: slot counts differ between nodes in principle, so
+  // collect ragged and square up after the scan
+  std::vector<std::vector<int32_t>> f_idx_rows;
+  out->feat_ptr.assign(1, 0);
+  out->feat_val.clear();
+  std::vector<int32_t> in_gids, in_gidx, u64_idx, f32_idx;
+  std::vector<float> in_gw, in_nw, f32_val;
+  std::vector<uint64_t> in_nb, u64_val;
   for (const auto& fn : files) {
     std::string blob;
     if (!ReadFile(node_dir + "/" + fn, &blob))
@@ -175,6 +204,28 @@ int LoadDatDirectory(const char* data_path, int32_t shard_index, int32_t shards,
       nbr->insert(nbr->end(), nb.begin(), nb.end());
       prefix_w->insert(prefix_w->end(), nw.begin(), nw.end());
       row_ptr->push_back((int64_t)nbr->size());
+      // in-neighbour block (same five vectors), then uint64 / float / binary
+      // features (node.cc:462-523); only the float features are kept
+      if (!(r.GetVec(&in_gids) && r.GetVec(&in_gw) && r.GetVec(&in_gidx) &&
+            r.GetVec(&in_nb) && r.GetVec(&in_nw) && r.GetVec(&u64_idx) &&
+            r.GetVec(&u64_val) && r.GetVec(&f32_idx) && r.GetVec(&f32_val)))
+        return Fail(EULER_GPU_EIO, "graph_load: malformed feature block in " + fn);
+      if (!f32_idx.empty() && f32_idx.back() != (int32_t)f32_val.size())
+        return Fail(EULER_GPU_EIO, "graph_load: float feature index does not cover values");
+      f_idx_rows.push_back(f32_idx);
+      out->feat_val.insert(out->feat_val.end(), f32_val.begin(), f32_val.end());
+      out->feat_ptr.push_back((int64_t)out->feat_val.size());
+    }
+  }
+  int32_t F = 0;
+  for (const auto& v : f_idx_rows) F = std::max(F, (int32_t)v.size());
+  out->n_float = F;
+  out->feat_idx.assign((size_t)F * f_idx_rows.size(), 0);
+  for (size_t i = 0; i < f_idx_rows.size(); ++i) {
+    int32_t last = 0;
+    for (int32_t f = 0; f < F; ++f) {
+      if (f < (int32_t)f_idx_rows[i].size()) last = f_idx_rows[i][f];
+      out->feat_idx[i * F + f] = last;       // a missing slot has length 0
     }
   }
   return EULER_GPU_OK;

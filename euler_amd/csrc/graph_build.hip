@@ -384,6 +384,47 @@ int BuildGraphFromHost(const euler_gpu_host_csr* c, int device,
     int rc = BuildSearchIndex(&b);
     if (rc != EULER_GPU_OK) { DestroyGraph(b.g.release()); return rc; }
   }
+  // dense float features of the kept rows
+  if (c->n_float_features > 0) {
+    if (!c->feat_ptr || !c->feat_idx || (c->feat_ptr[c->n_rows] > 0 && !c->feat_val)) {
+      DestroyGraph(b.g.release());
+      return Fail(EULER_GPU_EINVAL, "graph_create: null feature array");
+    }
+    const int32_t F = c->n_float_features;
+    std::vector<int64_t> fptr((size_t)n + 1, 0);
+    std::vector<int32_t> fidx((size_t)n * F);
+    int64_t tot = 0;
+    bool uniform = n > 0;
+    for (int64_t i = 0; i < n; ++i) {
+      const int64_t r = keep[i];
+      const int64_t len = c->feat_ptr[r + 1] - c->feat_ptr[r];
+      if (len < 0 || c->feat_idx[r * F + F - 1] != len) {
+        DestroyGraph(b.g.release());
+        return Fail(EULER_GPU_EINVAL, "graph_create: feature index does not cover values");
+      }
+      tot += len;
+    }
+    std::vector<float> fval((size_t)tot);
+    int64_t foff = 0;
+    for (int64_t i = 0; i < n; ++i) {
+      const int64_t r = keep[i];
+      const int64_t len = c->feat_ptr[r + 1] - c->feat_ptr[r];
+      fptr[i] = foff;
+      std::memcpy(fidx.data() + i * F, c->feat_idx + r * F, (size_t)F * 4);
+      if (len > 0)
+        std::memcpy(fval.data() + foff, c->feat_val + c->feat_ptr[r], (size_t)len * 4);
+      uniform &= std::memcmp(fidx.data() + i * F, fidx.data(), (size_t)F * 4) == 0;
+      foff += len;
+    }
+    fptr[n] = foff;
+    v.n_float = F;
+    v.feat_uniform = uniform ? 1 : 0;
+    v.feat_stride = uniform ? (int64_t)fidx[F - 1] : 0;
+    v.feat_ptr = b.Upload(fptr.data(), fptr.size());
+    v.feat_idx = b.Upload(fidx.data(), fidx.size());
+    v.feat_val = b.Upload(fval.data(), fval.size());
+    if (b.rc != EULER_GPU_OK) { DestroyGraph(b.g.release()); return b.rc; }
+  }
   // global node sampler over this shard's nodes
   {
     std::vector<uint64_t> ids;
@@ -682,65 +723,30 @@ int euler_gpu_graph_create_synthetic(const euler_gpu_synth_params* p, int device
 int euler_gpu_graph_load(const char* data_path, int device, int32_t shard_index,
                          int32_t shards, euler_gpu_graph** out) {
   if (!data_path || !out) return Fail(EULER_GPU_EINVAL, "graph_load: null argument");
-  std::vector<uint64_t> row_id, nbr;
-  std::vector<int64_t> row_ptr;
-  std::vector<int32_t> type_end, node_type;
-  std::vector<float> prefix_w, type_prefix, node_weight;
-  int32_t n_et = 0, n_nt = 0, partitions = 1;
-  int rc = LoadDatDirectory(data_path, shard_index, shards, &row_id, &row_ptr,
-                            &type_end, &nbr, &prefix_w, &type_prefix, &node_type,
-                            &node_weight, &n_et, &n_nt, &partitions);
+  DatGraph d;
+  int rc = LoadDatDirectory(data_path, shard_index, shards, &d);
   if (rc != EULER_GPU_OK) return rc;
   euler_gpu_host_csr c{};
-  c.n_rows = (int64_t)row_id.size();
-  c.n_edge_types = n_et; c.n_node_types = n_nt;
-  c.row_id = row_id.data(); c.row_ptr = row_ptr.data();
-  c.type_end = type_end.data(); c.nbr = nbr.data();
-  c.prefix_w = prefix_w.data(); c.type_prefix = type_prefix.data();
-  c.node_type = node_type.data(); c.node_weight = node_weight.data();
+  d.Describe(&c);
   // the loader already kept only this shard's partitions
   return BuildGraphFromHost(&c, device, 1, 0, 1, out);
 }
-
-namespace {
-struct DatOwner {
-  std::vector<uint64_t> row_id, nbr;
-  std::vector<int64_t> row_ptr;
-  std::vector<int32_t> type_end, node_type;
-  std::vector<float> prefix_w, type_prefix, node_weight;
-};
-}  // namespace
 
 int euler_gpu_dat_open(const char* data_path, int32_t shard_index,
                        int32_t shards, euler_gpu_host_csr* csr,
                        int32_t* partitions, void** owner) {
   if (!data_path || !csr || !owner)
     return Fail(EULER_GPU_EINVAL, "dat_open: null argument");
-  std::unique_ptr<DatOwner> o(new DatOwner());
-  int32_t n_et = 0, n_nt = 0, parts = 1;
-  int rc = LoadDatDirectory(data_path, shard_index, shards, &o->row_id,
-                            &o->row_ptr, &o->type_end, &o->nbr, &o->prefix_w,
-                            &o->type_prefix, &o->node_type, &o->node_weight,
-                            &n_et, &n_nt, &parts);
+  std::unique_ptr<DatGraph> o(new DatGraph());
+  int rc = LoadDatDirectory(data_path, shard_index, shards, o.get());
   if (rc != EULER_GPU_OK) return rc;
-  std::memset(csr, 0, sizeof(*csr));
-  csr->n_rows = (int64_t)o->row_id.size();
-  csr->n_edge_types = n_et;
-  csr->n_node_types = n_nt;
-  csr->row_id = o->row_id.data();
-  csr->row_ptr = o->row_ptr.data();
-  csr->type_end = o->type_end.data();
-  csr->nbr = o->nbr.data();
-  csr->prefix_w = o->prefix_w.data();
-  csr->type_prefix = o->type_prefix.data();
-  csr->node_type = o->node_type.data();
-  csr->node_weight = o->node_weight.data();
-  if (partitions) *partitions = parts;
+  o->Describe(csr);
+  if (partitions) *partitions = o->partitions;
   *owner = o.release();
   return EULER_GPU_OK;
 }
 
-void euler_gpu_dat_close(void* owner) { delete static_cast<DatOwner*>(owner); }
+void euler_gpu_dat_close(void* owner) { delete static_cast<DatGraph*>(owner); }
 
 void euler_gpu_graph_destroy(euler_gpu_graph* g) {
   {
@@ -755,6 +761,9 @@ int64_t euler_gpu_graph_num_edges(const euler_gpu_graph* g) { return g ? g->view
 int32_t euler_gpu_graph_num_edge_types(const euler_gpu_graph* g) { return g ? g->view.T : -1; }
 int32_t euler_gpu_graph_num_node_types(const euler_gpu_graph* g) { return g ? g->n_node_types : -1; }
 int euler_gpu_graph_device(const euler_gpu_graph* g) { return g ? g->device : -1; }
+int32_t euler_gpu_graph_num_float_features(const euler_gpu_graph* g) {
+  return g ? g->view.n_float : 0;
+}
 int64_t euler_gpu_graph_bytes(const euler_gpu_graph* g) { return g ? g->bytes : -1; }
 
 int euler_gpu_graph_node_weight_sums(const euler_gpu_graph* g, float* out_host) {

@@ -7,7 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
-#include "common.h"
+#include "device_fns.h"
 
 namespace euler_gpu {
 
@@ -155,6 +155,39 @@ static int ScatterImpl(hipStream_t st, const float* upd, const int32_t* idx,
 }
 
 // ------------------------------------------------------------------------
+// GetDenseFeature (tf_euler/kernels/get_dense_feature_op.cc:63-125 over
+// Node::GetFloat32Feature, core/graph/node.cc:330-394).  One lane per output
+// element: the dim lanes of a row read consecutive floats of the node's value
+// block (one or two 128-byte lines for typical dims) and write consecutive
+// floats of the output - a row gather, HBM-streaming bound; the row lookup and
+// the two slot ends are the same address for the whole row (one request).
+// Bytes: 4*dim in + 4*dim out per node (+ 8 id + 16 row metadata).
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void DenseFeatureKernel(
+    const GraphView g, const uint64_t* __restrict__ nodes, int64_t n, int32_t fid,
+    int32_t dim, float* __restrict__ out) {
+  const int64_t total = n * (int64_t)dim;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total;
+       s += stride) {
+    const int64_t j = s / dim;
+    const int32_t c = (int32_t)(s - j * dim);
+    float v = 0.f;
+    const int64_t row = FindRow(g, nodes[j]);
+    if (row >= 0 && fid >= 0 && fid < g.n_float) {
+      const int32_t* idx = g.feat_idx + (g.feat_uniform ? 0 : row * g.n_float);
+      const int32_t pre = fid == 0 ? 0 : idx[fid - 1];
+      const int32_t now = idx[fid];
+      if (c < now - pre) {
+        const int64_t base = g.feat_uniform ? row * g.feat_stride : g.feat_ptr[row];
+        v = g.feat_val[base + pre + c];
+      }
+    }
+    out[s] = v;
+  }
+}
+
+// ------------------------------------------------------------------------
 // ID_UNIQUE (core/kernels/id_unique_op.cc:35-64): first-occurrence order.
 // Open-addressing table in HBM: every id claims a slot (atomicCAS on the key)
 // and atomicMin's its position into the slot; the ids whose position equals
@@ -182,14 +215,23 @@ __global__ void UniqueInsertKernel(const uint64_t* ids, int64_t n, UniqueTable t
   } else {
     h = Mix64(id) & t.mask;
     for (;;) {
-      const unsigned long long old =
-          atomicCAS(&t.keys[h], (unsigned long long)kEmptyKey,
-                    (unsigned long long)id);
+      // look before the atomic (agent scope: never from this CU's stale L1):
+      // device-scope atomics execute at the memory side on this multi-die part
+      // (~0.5 ns each, serialised per address), a repeated id only needs a load
+      unsigned long long old =
+          __hip_atomic_load(&t.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old == kEmptyKey)
+        old = atomicCAS(&t.keys[h], (unsigned long long)kEmptyKey,
+                        (unsigned long long)id);
       if (old == kEmptyKey || old == id) break;
       h = (h + 1) & t.mask;
     }
   }
-  atomicMin(&t.minpos[h], (uint32_t)i);
+  // positions are handed out in launch order, so the slot usually already holds
+  // a smaller one: only then skip the atomicMin
+  if (__hip_atomic_load(&t.minpos[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >
+      (uint32_t)i)
+    atomicMin(&t.minpos[h], (uint32_t)i);
   slot_of[i] = (uint32_t)h;
 }
 
@@ -364,6 +406,22 @@ int euler_gpu_scatter_max(void* stream, const float* updates_dev,
                           int32_t size, float* out_dev) {
   return ScatterImpl<true>((hipStream_t)stream, updates_dev, indices_dev, e, d,
                            size, out_dev);
+}
+
+int euler_gpu_get_dense_feature(const euler_gpu_graph* g, void* stream,
+                                const uint64_t* nodes_dev, int64_t n, int32_t fid,
+                                int32_t dim, float* out_dev) {
+  if (!g) return Fail(EULER_GPU_ENOGRAPH, "get_dense_feature: null graph");
+  if (n < 0 || dim < 0) return Fail(EULER_GPU_EINVAL, "get_dense_feature: bad n/dim");
+  if (n == 0 || dim == 0) return EULER_GPU_OK;
+  if (!nodes_dev || !out_dev)
+    return Fail(EULER_GPU_EINVAL, "get_dense_feature: null buffer");
+  const int block = 256;
+  hipLaunchKernelGGL(DenseFeatureKernel, dim3(GridFor(n * (int64_t)dim, block)),
+                     dim3(block), 0, (hipStream_t)stream, g->view, nodes_dev, n, fid,
+                     dim, out_dev);
+  EG_HIP(hipGetLastError());
+  return EULER_GPU_OK;
 }
 
 int euler_gpu_id_unique(void* stream, const uint64_t* ids_dev, int64_t n,

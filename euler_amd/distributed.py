@@ -34,17 +34,21 @@ def owner_of(ids, partitions, shards):
 class ShardedSampler:
     """Neighbor sampling over a graph sharded across the ranks of `group`.
 
-    local_sample(roots, root_is_zero_mask, edge_types, count, default_node,
-                 call_id) -> (ids [m,count] int64, weights f32, types i32,
-                              row_mask [m] uint8)
-    must return the TF-layout rows for the roots this rank owns.
+    local_sample(roots, edge_types, count, default_node, call_id)
+        -> (ids [m,count] int64, weights f32, types i32, row_mask [m] uint8)
+        TF-layout rows for roots this rank owns;
     split_fn(ids, partitions, shards) -> (shard_off list, shard_ids, merge_idx)
-    and merge_fn(rows, merge_idx) are the bucket / inverse-permutation ops
-    (HIP kernels on GPUs).
+        stable bucket by owner (ID_SPLIT);
+    merge_fn(rows, merge_idx) -> out with out[merge_idx[j]] = rows[j]
+        (IDX_MERGE / DATA_MERGE for fixed-size rows, int32 rows);
+    unique_fn(ids) -> (unique ids, gather_idx) (ID_UNIQUE);
+    gather_fn(rows, gather_idx) -> rows[gather_idx] (DATA_GATHER, int32 rows).
+    On GPUs all five are HIP kernels (gpu_sharded_sampler); the CPU tests inject
+    oracle-backed doubles.
     """
 
     def __init__(self, local_sample, split_fn, merge_fn, partitions=None,
-                 group=None):
+                 group=None, unique_fn=None, gather_fn=None):
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
@@ -52,9 +56,11 @@ class ShardedSampler:
         self.local_sample = local_sample
         self.split_fn = split_fn
         self.merge_fn = merge_fn
+        self.unique_fn = unique_fn
+        self.gather_fn = gather_fn
 
     # -------------------------------------------------------------- helpers
-    def _exchange(self, send, send_counts, recv_counts, row_elems=1):
+    def _exchange(self, send, send_counts, recv_counts):
         """all-to-all(v) of rows; counts are in rows."""
         out_rows = int(sum(recv_counts))
         shape = (out_rows,) + tuple(send.shape[1:])
@@ -65,18 +71,50 @@ class ShardedSampler:
                                group=self.group)
         return recv
 
+    @staticmethod
+    def _pack(ids, w, t, mask, count):
+        """One int32 row per root: ids (2 words per id), weights, types, mask -
+        one exchange and one merge instead of four."""
+        m = ids.shape[0]
+        buf = torch.empty((m, 4 * count + 1), dtype=torch.int32, device=ids.device)
+        buf[:, :2 * count] = ids.reshape(m, count).contiguous().view(torch.int32)
+        buf[:, 2 * count:3 * count] = w.reshape(m, count).contiguous().view(torch.int32)
+        buf[:, 3 * count:4 * count] = t.reshape(m, count)
+        buf[:, 4 * count] = mask.reshape(m).to(torch.int32)
+        return buf
+
+    @staticmethod
+    def _unpack(buf, count):
+        if buf.shape[0] == 0:
+            e = lambda dt: torch.empty((0, count), dtype=dt, device=buf.device)
+            return (e(torch.int64), e(torch.float32), e(torch.int32),
+                    torch.empty(0, dtype=torch.uint8, device=buf.device))
+        ids = buf[:, :2 * count].contiguous().view(torch.int64)
+        w = buf[:, 2 * count:3 * count].contiguous().view(torch.float32)
+        t = buf[:, 3 * count:4 * count].contiguous()
+        mask = buf[:, 4 * count].to(torch.uint8)
+        return ids, w, t, mask
+
     def sample_neighbor(self, roots, edge_types, count, default_node=-1,
                         call_id=0, root_mask=None, root_group=1):
         """One hop for this rank's `roots` ([n] int64).  root_mask ([n /
         root_group] uint8) marks roots that stand for a missing row of the
         previous hop: they sample as node id 0 (the reference chains hops on
         its core tensors, whose empty rows hold the sentinel 0).
-        Returns (ids [n,count], weights, types, row_mask [n])."""
+        Returns (ids [n,count], weights, types, row_mask [n]).
+
+        Duplicate roots are removed BEFORE the exchange (the reference's
+        ID_UNIQUE precedes ID_SPLIT, parser/compiler.cc:76-90): rows depend only
+        on the node id, and on a fanout's second hop >90 % of the roots repeat,
+        so the wire carries the distinct ones only."""
         roots = roots.reshape(-1).to(torch.int64)
         n = roots.numel()
         if root_mask is not None:
             expand = root_mask.to(torch.bool).repeat_interleave(root_group)[:n]
             roots = torch.where(expand, torch.zeros_like(roots), roots)
+        gather_idx = None
+        if self.unique_fn is not None and n > 0:
+            roots, gather_idx = self.unique_fn(roots)
         # C1: bucket by owner, tell every peer how many ids it gets
         shard_off, shard_ids, merge_idx = self.split_fn(roots, self.partitions,
                                                         self.world)
@@ -89,15 +127,15 @@ class ShardedSampler:
         # local sampling on the rows this rank owns
         ids, w, t, mask = self.local_sample(owned, edge_types, count, default_node,
                                             call_id)
-        # C2: results travel back along the reversed split
-        ids_b = self._exchange(ids.reshape(-1, count), recv_counts, send_counts)
-        w_b = self._exchange(w.reshape(-1, count), recv_counts, send_counts)
-        t_b = self._exchange(t.reshape(-1, count), recv_counts, send_counts)
-        m_b = self._exchange(mask.reshape(-1, 1), recv_counts, send_counts)
+        # C2: results travel back along the reversed split, one packed row each
+        back = self._exchange(self._pack(ids, w, t, mask, count), recv_counts,
+                              send_counts)
         # IDX_MERGE / DATA_MERGE: out[merge_idx[j]] = back[j]
-        return (self.merge_fn(ids_b, merge_idx), self.merge_fn(w_b, merge_idx),
-                self.merge_fn(t_b, merge_idx),
-                self.merge_fn(m_b, merge_idx).reshape(-1))
+        rows = self.merge_fn(back, merge_idx)
+        if gather_idx is not None:                 # DATA_GATHER back to positions
+            rows = self.gather_fn(rows, gather_idx)
+        ids, w, t, mask = self._unpack(rows, count)
+        return ids, w, t, mask
 
     def sample_fanout(self, roots, edge_types, counts, default_node=-1, call_id=0):
         """Multi-hop fanout (tf_euler sample_fanout): returns (neighbors_list,
@@ -116,8 +154,24 @@ class ShardedSampler:
             cur, mask, group = ids.reshape(-1), m, count
         return neighbors, weights, types
 
+    def random_walk(self, nodes, edge_types, default_node=-1, call_id=0):
+        """tf_euler random_walk with p = q = 1 (TraditionalRandomWalk,
+        tf_euler/kernels/random_walk_op.cc:207-247) over the sharded graph: one
+        id / result exchange per step; edge_types is a list (walk_len) of
+        per-step edge type lists.  Returns [n, walk_len + 1] int64, identical
+        to the single-GPU kernel (step s uses call_id + s)."""
+        nodes = nodes.reshape(-1).to(torch.int64)
+        cols = [nodes]
+        cur, mask = nodes, None
+        for s, et in enumerate(edge_types):
+            ids, _, _, mask = self.sample_neighbor(cur, et, 1, default_node,
+                                                   call_id + s, mask, 1)
+            cur = ids.reshape(-1)
+            cols.append(cur)
+        return torch.stack(cols, dim=1)
 
-def gpu_sharded_sampler(graph, partitions=None, group=None):
+
+def gpu_sharded_sampler(graph, partitions=None, group=None, dedup=True):
     """ShardedSampler over an euler_amd.Graph shard living on this rank's GPU."""
     from . import ops
 
@@ -127,10 +181,9 @@ def gpu_sharded_sampler(graph, partitions=None, group=None):
                                                 call_id=call_id, return_mask=True)
         return ids, w, t, mask
 
-    def merge(rows, merge_idx):
-        if rows.element_size() * (rows.numel() // max(rows.shape[0], 1)) % 4 != 0:
-            # 1-byte mask rows: widen to int32 for the 4-byte merge kernel
-            return ops.merge_rows(rows.to(torch.int32), merge_idx).to(rows.dtype)
-        return ops.merge_rows(rows, merge_idx)
+    def gather_rows(rows, gather_idx):
+        # MPGather kernel on the int32 rows viewed as f32 words (a bit copy)
+        return ops.gather(rows.view(torch.float32), gather_idx).view(torch.int32)
 
-    return ShardedSampler(local_sample, ops.id_split, merge, partitions, group)
+    return ShardedSampler(local_sample, ops.id_split, ops.merge_rows, partitions,
+                          group, ops.id_unique if dedup else None, gather_rows)

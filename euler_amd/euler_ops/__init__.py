@@ -5,3 +5,4 @@ from .sample_ops import *    # noqa: F401,F403
 from .neighbor_ops import *  # noqa: F401,F403
 from .walk_ops import *      # noqa: F401,F403
 from .mp_ops import *        # noqa: F401,F403
+from .feature_ops import *   # noqa: F401,F403

@@ -98,7 +98,10 @@ class Graph:
     def from_csr(cls, row_id, row_ptr, type_end, nbr, prefix_w, type_prefix,
                  n_edge_types, node_type=None, node_weight=None,
                  sampler_order=None, device=0, partitions=1, shard_index=0,
-                 shards=1):
+                 shards=1, features=None):
+        """features = (n_float, feat_ptr [n+1], feat_idx [n*F], feat_val): the
+        reference's per-node float_features_idx_ / float_features_
+        (core/graph/node.h) concatenated over rows."""
         row_id = _np(row_id, np.uint64)
         row_ptr = _np(row_ptr, np.int64)
         type_end = _np(type_end, np.int32).reshape(-1)
@@ -130,6 +133,16 @@ class Graph:
             keep.append(sampler_order)
             c.sampler_order = sampler_order.ctypes.data_as(_lib.u64p)
         c.n_node_types = n_node_types
+        if features is not None:
+            nf, fptr, fidx, fval = features
+            fptr = _np(fptr, np.int64)
+            fidx = _np(fidx, np.int32).reshape(-1)
+            fval = _np(fval, np.float32)
+            keep += [fptr, fidx, fval]
+            c.n_float_features = int(nf)
+            c.feat_ptr = fptr.ctypes.data_as(_lib.i64p)
+            c.feat_idx = fidx.ctypes.data_as(_lib.i32p)
+            c.feat_val = fval.ctypes.data_as(_lib.f32p)
         h = C.c_void_p()
         check(lib().euler_gpu_graph_create_shard(C.byref(c), device, partitions,
                                                  shard_index, shards, C.byref(h)))
@@ -292,6 +305,26 @@ class Graph:
                 self._h, _stream(), self.seed, self._take_call_ids(1, call_id),
                 nt_p, k, int(count), _ptr(out)))
         return out
+
+    @property
+    def num_float_features(self):
+        return lib().euler_gpu_graph_num_float_features(self._h)
+
+    def get_dense_feature(self, nodes, feature_ids, dimensions):
+        """tf_euler get_dense_feature (euler_ops/feature_ops.py:108-122 over
+        tf_euler/kernels/get_dense_feature_op.cc): nodes [n] int64 -> list of
+        [n, dim] float32 tensors, one per feature id; unknown nodes and missing
+        features are zero rows."""
+        nodes = _as_i64_cuda(nodes, self.device).reshape(-1)
+        n = nodes.numel()
+        outs = []
+        with torch.cuda.device(self.device):
+            for fid, dim in zip(feature_ids, dimensions):
+                out = torch.empty((n, int(dim)), dtype=torch.float32, device=self.device)
+                check(lib().euler_gpu_get_dense_feature(
+                    self._h, _stream(), _ptr(nodes), n, int(fid), int(dim), _ptr(out)))
+                outs.append(out)
+        return outs
 
     def get_full_neighbor(self, nodes, edge_types):
         """GQL `v(nodes).outV(edge_types)` result (idx [n,2] int32, ids int64,

@@ -72,6 +72,15 @@ typedef struct euler_gpu_host_csr {
                                   node sampler enumerates them
                                   (Graph::BuildGlobalSampler, graph.cc:349) or
                                   NULL = row order                             */
+  /* dense float features, the reference's per-node float_features_idx_ /
+   * float_features_ (core/graph/node.h): optional (n_float_features = 0) */
+  int32_t n_float_features;    /* feature slots per node                       */
+  int32_t pad0;
+  const int64_t* feat_ptr;     /* [n_rows+1] offset of each row's values        */
+  const int32_t* feat_idx;     /* [n_rows*F] cumulative ends per slot,
+                                  row-relative; a missing slot repeats the
+                                  previous end                                 */
+  const float* feat_val;       /* [feat_ptr[n_rows]]                            */
 } euler_gpu_host_csr;
 
 /* Parameters of the deterministic synthetic power-law graph (benchmarks). */
@@ -211,6 +220,18 @@ int euler_gpu_get_full_neighbor(const euler_gpu_graph* g, void* stream,
                                 int32_t* idx_dev, int64_t* total_host,
                                 uint64_t* out_id_dev, float* out_w_dev,
                                 int32_t* out_t_dev);
+
+/* ---- dense features --------------------------------------------------------
+ * TF GetDenseFeature (tf_euler/kernels/get_dense_feature_op.cc:63-125) over
+ * Node::GetFloat32Feature (core/graph/node.cc:330-394): out_dev is [n, dim]
+ * float32, zero filled; row j receives the stored values of feature slot `fid`
+ * of node nodes_dev[j] (unknown node / slot: zeros).  A node that stores more
+ * than `dim` values would overrun the reference's output row; here the row is
+ * truncated to dim. */
+int32_t euler_gpu_graph_num_float_features(const euler_gpu_graph* g);
+int euler_gpu_get_dense_feature(const euler_gpu_graph* g, void* stream,
+                                const uint64_t* nodes_dev, int64_t n, int32_t fid,
+                                int32_t dim, float* out_dev);
 
 /* ---- RandomWalk -------------------------------------------------------------
  * TF RandomWalk kernel (tf_euler/kernels/random_walk_op.cc:172-291):

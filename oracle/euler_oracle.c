@@ -759,3 +759,27 @@ double eo_bench_fanout(const eo_graph* g, uint64_t seed,
   *edges = total;
   return t1 - t0;
 }
+
+
+/* tf_euler/kernels/get_dense_feature_op.cc:63-125: outputs are zero filled
+ * (:70-72); the GQL values() step returns, per node, the (begin, end) offsets
+ * of feature `fid` in the node's float_features_ (GET_NODE_FEATURE,
+ * core/graph/node.cc:330-352: fid out of range -> length 0; unknown node ->
+ * empty); the callback copies end - begin values to row j (:113-120). */
+int eo_get_dense_feature(const eo_graph* g, const eo_features* f,
+                         const uint64_t* ids, int64_t n, int32_t fid,
+                         int32_t dim, float* out) {
+  for (int64_t i = 0; i < n * (int64_t)dim; ++i) out[i] = 0.0f;
+  for (int64_t j = 0; j < n; ++j) {
+    int64_t row = eo_graph_find_row(g, ids[j]);
+    if (row < 0) continue;
+    if (fid < 0 || fid >= f->n_float) continue;
+    const int32_t* idx = f->feat_idx + row * f->n_float;
+    int32_t pre = fid == 0 ? 0 : idx[fid - 1];
+    int32_t now = idx[fid];
+    if (now - pre > dim) return -2;
+    const float* src = f->feat_val + f->feat_ptr[row] + pre;
+    for (int32_t c = 0; c < now - pre; ++c) out[j * (int64_t)dim + c] = src[c];
+  }
+  return 0;
+}

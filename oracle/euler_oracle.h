@@ -84,6 +84,22 @@ void eo_sample_fanout_tf(const eo_graph* g, uint64_t seed, uint32_t call_id,
                          int64_t default_node, int64_t** out_n,
                          float** out_w, int32_t** out_t);
 
+/* Dense float features in the reference's per-node form (node.h
+ * float_features_ / float_features_idx_), concatenated over rows. */
+typedef struct eo_features {
+  int32_t n_float;            /* feature slots per node                       */
+  const int64_t* feat_ptr;    /* [n_rows+1] offset of each row's values        */
+  const int32_t* feat_idx;    /* [n_rows*F] cumulative ends, row-relative      */
+  const float* feat_val;
+} eo_features;
+
+/* TF GetDenseFeature (tf_euler/kernels/get_dense_feature_op.cc:63-125):
+ * out [n, dim] zero filled, then the stored values of feature fid. Returns -2
+ * if a node stores more than dim values (the reference would overrun). */
+int eo_get_dense_feature(const eo_graph* g, const eo_features* f,
+                         const uint64_t* ids, int64_t n, int32_t fid,
+                         int32_t dim, float* out);
+
 int64_t eo_get_full_neighbor(const eo_graph* g, const uint64_t* ids,
                              int64_t n, const int32_t* edge_types, int32_t k,
                              int32_t* idx, uint64_t* out_id, float* out_w,

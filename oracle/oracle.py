@@ -76,6 +76,9 @@ def lib():
             C.c_void_p, C.c_uint64, C.c_uint32, _i64p, C.c_int64, _i32p,
             C.c_int32, _i32p, C.c_int32, C.c_int64, C.POINTER(_i64p),
             C.POINTER(_f32p), C.POINTER(_i32p)]
+        L.eo_get_dense_feature.restype = C.c_int
+        L.eo_get_dense_feature.argtypes = [C.c_void_p, C.c_void_p, _u64p, C.c_int64,
+                                           C.c_int32, C.c_int32, _f32p]
         L.eo_get_full_neighbor.restype = C.c_int64
         L.eo_get_full_neighbor.argtypes = [C.c_void_p, _u64p, C.c_int64, _i32p,
                                            C.c_int32, _i32p, _u64p, _f32p, _i32p]
@@ -175,6 +178,14 @@ def ref():
                                              C.c_int32, _i64p]
         R.euler_ref_set_rng.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32,
                                         C.c_uint64]
+        R.euler_ref_set_float_features.argtypes = [_u64p, C.c_int64, C.c_int32,
+                                                   _i64p, _i32p, _f32p]
+        R.euler_ref_export_float_features.restype = C.c_int64
+        R.euler_ref_export_float_features.argtypes = [_u64p, C.c_int64, C.c_int32,
+                                                      _i64p, _i32p, _f32p]
+        R.euler_ref_num_float_features.restype = C.c_int32
+        R.euler_ref_get_dense_feature.argtypes = [_u64p, C.c_int64, C.c_int32,
+                                                  C.c_int32, _f32p]
     return _ref
 
 
@@ -199,6 +210,40 @@ class CSR:
         self.node_weight = (_arr(node_weight, np.float32)
                             if node_weight is not None
                             else np.ones(self.n_rows, np.float32))
+
+
+class Features(C.Structure):
+    _fields_ = [("n_float", C.c_int32), ("feat_ptr", _i64p), ("feat_idx", _i32p),
+                ("feat_val", _f32p)]
+
+
+class DenseFeatures:
+    """Per-node float features in the reference's storage form
+    (float_features_idx_ = cumulative ends per slot, float_features_)."""
+
+    def __init__(self, n_float, feat_ptr, feat_idx, feat_val):
+        self.n_float = int(n_float)
+        self.feat_ptr = _arr(feat_ptr, np.int64)
+        self.feat_idx = _arr(feat_idx, np.int32).reshape(-1)
+        self.feat_val = _arr(feat_val, np.float32)
+
+    @staticmethod
+    def from_lists(per_node):
+        """per_node[i] = list (one entry per slot) of value lists."""
+        F = max((len(x) for x in per_node), default=0)
+        ptr, idx, val = [0], [], []
+        for slots in per_node:
+            end = 0
+            for f in range(F):
+                if f < len(slots):
+                    val.extend(slots[f]); end += len(slots[f])
+                idx.append(end)
+            ptr.append(len(val))
+        return DenseFeatures(F, ptr, idx, val)
+
+    def c_struct(self):
+        return Features(self.n_float, _p(self.feat_ptr, _i64p),
+                        _p(self.feat_idx, _i32p), _p(self.feat_val, _f32p))
 
 
 def csr_from_raw(row_id, seg_ptr, nbr, w, n_types, node_type=None,
@@ -240,6 +285,20 @@ class OracleGraph:
             lib().eo_graph_destroy(self.h)
         except Exception:
             pass
+
+    def get_dense_feature(self, feats, nodes, feature_ids, dimensions):
+        """tf_euler get_dense_feature: list of [n, dim] f32 arrays; `feats` is
+        a DenseFeatures aligned with the CSR rows."""
+        ids = _arr(nodes, np.int64).astype(np.uint64)
+        fs = feats.c_struct()
+        outs = []
+        for fid, dim in zip(feature_ids, dimensions):
+            out = np.zeros((len(ids), dim), np.float32)
+            rc = lib().eo_get_dense_feature(self.h, C.byref(fs), _p(ids, _u64p), len(ids),
+                                            int(fid), int(dim), _p(out, _f32p))
+            assert rc == 0, rc
+            outs.append(out)
+        return outs
 
     def sample_neighbor_core(self, seed, call_id, ids, edge_types, count):
         ids = _arr(ids, np.uint64)
@@ -567,6 +626,36 @@ class RefGraph:
 
     def __init__(self, n_types):
         self.n_types = n_types
+
+    def set_float_features(self, row_id, feats):
+        ids = _arr(row_id, np.uint64)
+        rc = ref().euler_ref_set_float_features(
+            _p(ids, _u64p), len(ids), feats.n_float, _p(feats.feat_ptr, _i64p),
+            _p(feats.feat_idx, _i32p), _p(feats.feat_val, _f32p))
+        assert rc == 0
+
+    def export_float_features(self, ids):
+        ids = _arr(ids, np.uint64)
+        F = ref().euler_ref_num_float_features()
+        n = len(ids)
+        tot = ref().euler_ref_export_float_features(_p(ids, _u64p), n, F, None, None, None)
+        ptr = np.zeros(n + 1, np.int64)
+        idx = np.zeros(n * max(F, 1), np.int32)
+        val = np.zeros(max(tot, 1), np.float32)
+        ref().euler_ref_export_float_features(_p(ids, _u64p), n, F, _p(ptr, _i64p),
+                                              _p(idx, _i32p), _p(val, _f32p))
+        return DenseFeatures(F, ptr, idx[:n * F], val[:tot])
+
+    def get_dense_feature(self, nodes, feature_ids, dimensions):
+        ids = _arr(nodes, np.int64).astype(np.uint64)
+        outs = []
+        for fid, dim in zip(feature_ids, dimensions):
+            out = np.zeros((len(ids), dim), np.float32)
+            rc = ref().euler_ref_get_dense_feature(_p(ids, _u64p), len(ids), int(fid),
+                                                   int(dim), _p(out, _f32p))
+            assert rc == 0, rc
+            outs.append(out)
+        return outs
 
     def node_order(self):
         n = ref().euler_ref_num_nodes()

@@ -117,6 +117,76 @@ int euler_ref_graph_load(const char* dir) {
   return s.ok() ? 0 : -1;
 }
 
+// Dense (float32) node features: written straight into the reference Node's
+// own storage (float_features_ / float_features_idx_, node.h) so that the
+// reference's Node::GetFloat32Feature (node.cc:330-394) serves them.
+// feat_idx is [n, F] cumulative ends (row-relative), feat_ptr [n+1].
+int euler_ref_set_float_features(const uint64_t* ids, int64_t n, int32_t F,
+                                 const int64_t* feat_ptr, const int32_t* feat_idx,
+                                 const float* feat_val) {
+  for (int64_t i = 0; i < n; ++i) {
+    auto it = G().node_map_.find(ids[i]);
+    if (it == G().node_map_.end()) return -1;
+    euler::Node* node = it->second;
+    node->float_features_idx_.assign(feat_idx + i * F, feat_idx + (i + 1) * F);
+    node->float_features_.assign(feat_val + feat_ptr[i], feat_val + feat_ptr[i + 1]);
+  }
+  return 0;
+}
+
+// What the reference holds for these nodes (loaded .dat files included):
+// first call with feat_val == NULL sizes it.  Slots a node does not have
+// repeat its last end (length 0), which is how GET_NODE_FEATURE treats them.
+int64_t euler_ref_export_float_features(const uint64_t* ids, int64_t n, int32_t F,
+                                        int64_t* feat_ptr, int32_t* feat_idx,
+                                        float* feat_val) {
+  int64_t off = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    auto it = G().node_map_.find(ids[i]);
+    if (feat_ptr) feat_ptr[i] = off;
+    int32_t last = 0;
+    for (int32_t f = 0; f < F; ++f) {
+      if (it != G().node_map_.end() &&
+          f < (int32_t)it->second->float_features_idx_.size())
+        last = it->second->float_features_idx_[f];
+      if (feat_idx) feat_idx[i * F + f] = last;
+    }
+    if (it != G().node_map_.end()) {
+      const auto& v = it->second->float_features_;
+      if (feat_val) std::copy(v.begin(), v.end(), feat_val + off);
+      off += (int64_t)v.size();
+    }
+  }
+  if (feat_ptr) feat_ptr[n] = off;
+  return off;
+}
+
+int32_t euler_ref_num_float_features() {
+  int32_t m = 0;
+  for (auto& kv : G().node_map_)
+    m = std::max(m, (int32_t)kv.second->float_features_idx_.size());
+  return m;
+}
+
+// TF GetDenseFeature (tf_euler/kernels/get_dense_feature_op.cc:63-125) over
+// the reference's Node::GetFloat32Feature: out is [n, dim], zero filled, row j
+// receives the node's stored values of feature `fid`.
+int euler_ref_get_dense_feature(const uint64_t* ids, int64_t n, int32_t fid,
+                                int32_t dim, float* out) {
+  std::fill(out, out + n * (int64_t)dim, 0.0f);
+  std::vector<int32_t> fids(1, fid);
+  for (int64_t j = 0; j < n; ++j) {
+    auto it = G().node_map_.find(ids[j]);
+    if (it == G().node_map_.end()) continue;
+    std::vector<uint32_t> nums;
+    std::vector<float> vals;
+    it->second->GetFloat32Feature(fids, &nums, &vals);
+    if ((int64_t)vals.size() > dim) return -2;   // the TF kernel would overrun
+    std::copy(vals.begin(), vals.end(), out + j * (int64_t)dim);
+  }
+  return 0;
+}
+
 int64_t euler_ref_num_nodes() { return (int64_t)G().node_map_.size(); }
 
 int32_t euler_ref_num_node_types() {

@@ -34,6 +34,19 @@ def O():
 
 
 @pytest.fixture(scope="session")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+@pytest.fixture(scope="session")
+def EA(torch_cuda):
+    import euler_amd
+    return euler_amd
+
+
+@pytest.fixture(scope="session")
 def ref_available(O):
     return O.have_ref()
 

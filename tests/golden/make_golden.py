@@ -18,6 +18,9 @@ comes out of REFERENCE code:
                       the same kinds of reference outputs.
   fixture_dat/        euler.meta + Node/*.dat exactly as written by the
                       reference's euler/tools for that fixture (2 partitions).
+  features.npz        dense float features of both graphs as the reference holds
+                      them + the rows GetFloat32Feature / TF GetDenseFeature
+                      produce for a battery of (node, feature id, dim) queries.
   ref_tests.npz       exact expectations copied from the reference's own tests
                       (mp_ops_test.py:30-86, walk_ops_test.py:49-58,
                       unique_gather_test.cc:28-160, neighbor_ops_test.py:46-75).
@@ -195,5 +198,68 @@ def main():
     print("golden vectors written to", OUT)
 
 
+def feature_goldens():
+    """features.npz: dense float features.  Fixture: what the reference's own
+    loader (Node::DeSerialize) holds for tools/test_data/graph.json, exported
+    from its Node storage, and the rows the reference's GetFloat32Feature +
+    the TF GetDenseFeature copy loop produce.  Random graph: random ragged
+    features pushed into the reference nodes, same outputs."""
+    O.build(ref=True)
+    assert O.have_ref(), "oracle/_ref must be built from " + REF
+    out = {}
+    scratch = tempfile.mkdtemp(prefix="euler_golden_")
+    try:
+        data = convert_fixture(scratch)
+        R = O.RefGraph.load(data, 2)
+        ids = np.sort(R.node_order())
+        F = R.export_float_features(ids)
+        out.update(fx_ids=ids, fx_n_float=np.int32(F.n_float), fx_feat_ptr=F.feat_ptr,
+                   fx_feat_idx=F.feat_idx, fx_feat_val=F.feat_val)
+        q = np.concatenate([ids, ids[::-1], [0, 987654321]]).astype(np.int64)
+        out["fx_query"] = q
+        fids = list(range(F.n_float)) + [F.n_float + 2]
+        dims = [int(max(F.feat_idx.reshape(len(ids), -1)[:, f] -
+                        (F.feat_idx.reshape(len(ids), -1)[:, f - 1] if f else 0)).max()
+                    if False else 0) for f in range(F.n_float)]
+        idx2 = F.feat_idx.reshape(len(ids), -1)
+        dims = [int((idx2[:, f] - (idx2[:, f - 1] if f else 0)).max()) + (f % 2)
+                for f in range(F.n_float)] + [3]
+        out["fx_fids"] = np.array(fids, np.int32)
+        out["fx_dims"] = np.array(dims, np.int32)
+        for k, o in enumerate(R.get_dense_feature(q, fids, dims)):
+            out["fx_dense_%d" % k] = o
+    finally:
+        shutil.rmtree(scratch, ignore_errors=True)
+    g = np.load(os.path.join(OUT, "random_graph.npz"))
+    ids = g["row_id"]
+    n = len(ids)
+    R = O.RefGraph.build_raw(ids, g["raw_seg_ptr"], g["raw_nbr"], g["raw_w"], 3,
+                             g["node_type"], g["node_weight"])
+    rng = np.random.default_rng(11)
+    per = []
+    for i in range(n):
+        slots = [list(rng.standard_normal(16).astype(np.float32)),
+                 list(rng.standard_normal(int(rng.integers(0, 6))).astype(np.float32)),
+                 list(rng.standard_normal(100).astype(np.float32))]
+        per.append(slots[:int(rng.integers(1, 4))] if i % 5 == 0 else slots)
+    F = O.DenseFeatures.from_lists(per)
+    R.set_float_features(ids, F)
+    out.update(rg_n_float=np.int32(F.n_float), rg_feat_ptr=F.feat_ptr,
+               rg_feat_idx=F.feat_idx, rg_feat_val=F.feat_val)
+    q = np.concatenate([rng.choice(ids, 200), [0, 4999999]]).astype(np.int64)
+    out["rg_query"] = q
+    fids, dims = [0, 1, 2, 5], [16, 5, 100, 4]
+    out["rg_fids"] = np.array(fids, np.int32)
+    out["rg_dims"] = np.array(dims, np.int32)
+    for k, o in enumerate(R.get_dense_feature(q, fids, dims)):
+        out["rg_dense_%d" % k] = o
+    np.savez_compressed(os.path.join(OUT, "features.npz"), **out)
+    print("feature goldens written")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "features":
+        feature_goldens()
+    else:
+        main()
+        feature_goldens()

@@ -1,0 +1,180 @@
+"""BASELINE.json `configs` as parity cases.  configs[2] (the
+metric: 100M / 1B weighted, fanout [25,10]) is bench.py's workload and is
+property-checked at 2M nodes in test_gpu_parity.py::test_full_size_properties;
+the others are covered here, each against the CPU oracle (and the reference
+sampler build where it is present).
+
+  config 1  Cora-shaped graph, GraphSAGE 2-hop fanout [10,5], batch 32 - the
+            whole minibatch construction on the CPU oracle (plumbing, no GPU)
+  config 2  ogbn-products-shaped CSR, uniform weights, fanout [25,10], 1 GPU
+  config 4  DeepWalk: p = q = 1 random walk of length 40 (sharded N > 1 host
+            logic: tests/test_distributed_cpu.py with gloo)
+  config 5  heterogeneous typed graph: per-type sampling (k = 1, 3-of-8, all)
+            + 128-d features + scatter_mean aggregation
+"""
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def t2n(t):
+    return t.detach().cpu().numpy()
+
+
+def cora_shaped(O):
+    """tf_euler/python/dataset/cora.py:36-52 counts: 2 708 nodes, 5 429 cites
+    edges (directed), 1 433-dim row-normalised bag-of-words features, node
+    weight 1, edge weight 1, edge types train / train_removed.  The real files
+    need a download, so the shape is synthetic with a fixed seed."""
+    rng = np.random.default_rng(20240521)
+    n, e, d = 2708, 5429, 1433
+    ids = np.arange(1, n + 1).astype(np.uint64)
+    src = rng.integers(0, n, e)
+    dst = rng.integers(0, n, e)
+    et = (rng.random(e) < 0.1).astype(np.int64)      # ~10 % train_removed
+    order = np.lexsort((et, src))
+    src, dst, et = src[order], dst[order], et[order]
+    T = 2
+    seg = np.zeros(n * T + 1, np.int64)
+    np.add.at(seg, src * T + et + 1, 1)
+    seg = np.cumsum(seg)
+    nbr = ids[dst]
+    w = np.ones(e, np.float32)
+    feat = (rng.random((n, d)) < 0.012).astype(np.float32)
+    feat /= np.maximum(feat.sum(1, keepdims=True), 1)
+    F = O.DenseFeatures(1, np.arange(n + 1) * d, np.full(n, d), feat.reshape(-1))
+    return ids, seg, nbr, w, T, F, feat
+
+
+def test_config1_cora_graphsage_minibatch_on_cpu_oracle(O):
+    """configs[0]: roots -> fanout [10,5] -> feature fetch -> mean aggregation
+    of the sampled block, all on the oracle; the sampled ids are additionally
+    compared with the reference sampler build when it is present."""
+    ids, seg, nbr, w, T, F, feat = cora_shaped(O)
+    csr = O.csr_from_raw(ids, seg, nbr, w, T)
+    OG = O.OracleGraph(csr)
+    rng = np.random.default_rng(1)
+    roots = rng.choice(ids, 32).astype(np.int64)
+    fan = [10, 5]
+    et = [[0], [0]]
+    nbrs, ws, ts = OG.sample_fanout(7, 0, roots, et, fan, -1)
+    assert nbrs[0].shape == (32 * 10,) and nbrs[1].shape == (32 * 10 * 5,)
+    if O.have_ref():
+        R = O.RefGraph.build_raw(ids, seg, nbr, w, T)
+        cur = roots.astype(np.uint64)
+        for h in range(2):       # hop by hop on the reference's core tensors
+            _, oid, ow, _ = OG.sample_neighbor_core(7, h, cur, et[h], fan[h])
+            _, rid, rw, _ = R.sample_neighbor_core(7, h, cur, et[h], fan[h])
+            assert np.array_equal(oid, rid) and np.array_equal(ow, rw)
+            cur = oid
+    # layer-2 block: neighbours' features averaged into their hop-1 parents
+    x2 = OG.get_dense_feature(F, nbrs[1], [0], [1433])[0]
+    valid = nbrs[1] > 0
+    assert np.array_equal(x2[valid], feat[nbrs[1][valid] - 1])
+    assert not x2[~valid].any()
+    dst = np.repeat(np.arange(32 * 10, dtype=np.int32), 5)
+    agg = O.scatter_mean(x2, dst, 32 * 10)
+    want = x2.reshape(320, 5, -1).astype(np.float64).mean(1)
+    assert np.allclose(agg, want, rtol=0, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_config2_products_shaped_uniform_fanout(EA, O, torch_cuda):
+    """configs[1]: ogbn-products-shaped CSR (2 449 029 nodes, ~123.7 M directed
+    edges, all weights 1.0), uniform SampleNeighbor fanout [25,10].  The GPU
+    graph is built at full size; 512 roots are checked bit for bit against the
+    oracle fed with the rows exported from HBM, the rest through determinism
+    and membership."""
+    torch = torch_cuda
+    N, E = 2_449_029, 123_718_280
+    p = EA.synth_params(42, N, E, weighted=False)
+    G = EA.Graph.synthetic(p)
+    assert G.num_nodes == N and abs(G.num_edges - E) < 0.02 * E
+    rng = np.random.default_rng(2)
+    roots = rng.integers(1, N + 1, 4096).astype(np.int64)
+    G.set_seed(42)
+    a = G.sample_fanout(torch.as_tensor(roots).cuda(), [[0], [0]], [25, 10], N + 1,
+                        call_id=4)
+    b = G.sample_fanout(torch.as_tensor(roots).cuda(), [[0], [0]], [25, 10], N + 1,
+                        call_id=4)
+    for x, y in zip(a[0], b[0]):
+        assert torch.equal(x, y)
+    assert bool((a[1][1] == 1.0).all())           # uniform weights come back as 1.0
+    sel = np.arange(512)
+    hop1 = t2n(a[0][1]).reshape(4096, 25)[sel]
+    need = np.unique(np.concatenate([roots[sel], hop1.reshape(-1)])).astype(np.uint64)
+    need = need[(need >= 1) & (need <= N)]
+    rp, te, nb, pw, tp = G.export_rows(need)
+    OG = O.OracleGraph(O.CSR(need, rp, te, nb, pw, tp, 1))
+    on, ow, ot = OG.sample_fanout(42, 4, roots[sel], [[0], [0]], [25, 10], N + 1)
+    assert np.array_equal(on[0], hop1.reshape(-1))
+    assert np.array_equal(on[1], t2n(a[0][2]).reshape(4096, 250)[sel].reshape(-1))
+    assert np.array_equal(ow[1], t2n(a[1][1]).reshape(4096, 250)[sel].reshape(-1))
+
+
+@pytest.mark.gpu
+def test_config4_deepwalk_walk_length_40(EA, O, torch_cuda):
+    """configs[3] on one GPU: 100 000 walkers, p = q = 1, 40 steps on a 1M-node
+    power-law graph; 256 walkers bit-exact against the oracle (rows exported
+    from HBM), all walkers: every step follows an edge of the graph's CSR."""
+    torch = torch_cuda
+    N = 1_000_000
+    p = EA.synth_params(9, N, 10 * N, weighted=True)
+    G = EA.Graph.synthetic(p)
+    rng = np.random.default_rng(3)
+    starts = rng.integers(1, N + 1, 100_000).astype(np.int64)
+    L = 40
+    et = [[0]] * L
+    G.set_seed(5)
+    walks = t2n(G.random_walk(torch.as_tensor(starts).cuda(), et, 1.0, 1.0, N + 1,
+                              call_id=100))
+    assert walks.shape == (100_000, L + 1) and np.array_equal(walks[:, 0], starts)
+    assert walks.min() >= 1 and walks.max() <= N       # min degree 1: no dead ends
+    sel = np.arange(256)
+    need = np.unique(walks[sel].reshape(-1)).astype(np.uint64)
+    rp, te, nb, pw, tp = G.export_rows(need)
+    OG = O.OracleGraph(O.CSR(need, rp, te, nb, pw, tp, 1))
+    want = OG.random_walk(5, 100, starts[sel], et, L, 1.0, 1.0, N + 1)
+    assert np.array_equal(walks[sel], want)
+
+
+@pytest.mark.gpu
+def test_config5_typed_sampling_and_aggregation(EA, O, torch_cuda):
+    """configs[4] on one GPU: 8 edge types; per-type sampling with one listed
+    type, 3 of 8 (sub-collection draw) and all 8 (type draw over all groups),
+    128-d features gathered for the sampled block and scatter_mean into the
+    roots - ids / weights / types bit-exact, aggregate within 1e-5 (it is
+    bit-exact: the segment reduce keeps the reference's order of additions)."""
+    torch = torch_cuda
+    N, T, D = 60_000, 8, 128
+    po = O.synth_params(77, N, 40 * N, n_types=T, weighted=True)
+    csr = O.synth_csr(po)
+    p = EA.synth_params(77, N, 40 * N, n_types=T, weighted=True)
+    G = EA.Graph.synthetic(p)
+    OG = O.OracleGraph(csr)
+    rng = np.random.default_rng(4)
+    roots = rng.integers(1, N + 1, 20_000).astype(np.int64)
+    rt = torch.as_tensor(roots).cuda()
+    G.set_seed(8)
+    for call, et in enumerate(([3], [1, 4, 6], list(range(T)), [])):
+        on, ow, ot = OG.sample_neighbor(8, call, roots, et, 10, N + 1)
+        gn, gw, gt = G.sample_neighbor(rt, et, 10, N + 1, call_id=call)
+        assert np.array_equal(t2n(gn), on), et
+        assert np.array_equal(t2n(gw), ow)
+        assert np.array_equal(t2n(gt), ot)
+        if len(et) == 1:
+            assert set(np.unique(ot).tolist()) <= {3, -1}
+    # features of the sampled block -> mean per root (RGCN-style aggregation)
+    feat = torch.randn(N + 2, D, device="cuda")
+    idx = gn.reshape(-1).to(torch.int32)
+    x = EA.ops.gather(feat, idx)
+    want_x = O.gather(t2n(feat), t2n(idx))
+    assert np.array_equal(t2n(x), want_x)
+    dst = torch.arange(len(roots), device="cuda", dtype=torch.int32).repeat_interleave(10)
+    agg = EA.ops.scatter_mean(x, dst, len(roots))
+    want = O.scatter_mean(want_x, t2n(dst), len(roots))
+    assert np.allclose(t2n(agg), want, rtol=0, atol=1e-5)
+    assert np.array_equal(t2n(agg), want)

@@ -83,7 +83,18 @@ def _worker(rank, world, port, partitions, out_dir):
         out[merge_idx.long()] = rows
         return out
 
-    S = ShardedSampler(local_sample, split_fn, merge_fn, partitions)
+    def unique_fn(ids):
+        uq, gi = O.id_unique(ids.numpy().astype(np.uint64))
+        return torch.as_tensor(uq.astype(np.int64)), torch.as_tensor(gi)
+
+    def gather_fn(rows, gather_idx):
+        return rows[gather_idx.long()]
+
+    # with and without the duplicate-root removal: both must equal the
+    # unsharded oracle
+    S_plain = ShardedSampler(local_sample, split_fn, merge_fn, partitions)
+    S = ShardedSampler(local_sample, split_fn, merge_fn, partitions,
+                       unique_fn=unique_fn, gather_fn=gather_fn)
     rng = np.random.default_rng(10 + rank)
     roots = np.concatenate([rng.choice(ids, 257 + 64 * rank),
                             [0, 5, 2 ** 63 + 11]]).astype(np.uint64).astype(np.int64)
@@ -92,12 +103,20 @@ def _worker(rank, world, port, partitions, out_dir):
                           O.shard_of(roots.astype(np.uint64), partitions, world))
     for et, counts in (([[0, 1, 2], [0, 1, 2]], [5, 3]), ([[1], [2]], [4, 2]),
                        ([[0, 2], [2, 1]], [3, 3])):
-        ns, ws, ts = S.sample_fanout(torch.as_tensor(roots), et, counts, -1, 40)
         on, ow, ot = OG_full.sample_fanout(seed, 40, roots, et, counts, -1)
-        for h in range(len(counts)):
-            assert np.array_equal(ns[h + 1].numpy(), on[h]), (rank, et, h)
-            assert np.array_equal(ws[h].numpy(), ow[h])
-            assert np.array_equal(ts[h].numpy(), ot[h])
+        for sampler in (S, S_plain):
+            ns, ws, ts = sampler.sample_fanout(torch.as_tensor(roots), et, counts, -1, 40)
+            for h in range(len(counts)):
+                assert np.array_equal(ns[h + 1].numpy(), on[h]), (rank, et, h)
+                assert np.array_equal(ws[h].numpy(), ow[h])
+                assert np.array_equal(ts[h].numpy(), ot[h])
+    # DeepWalk (config 4): p = q = 1 random walk over the sharded graph, one
+    # exchange per step, identical to the unsharded walk
+    L = 6
+    et_walk = [[0, 1, 2]] * L
+    walk = S.random_walk(torch.as_tensor(roots), et_walk, default_node=-1, call_id=70)
+    ref = OG_full.random_walk(seed, 70, roots, et_walk, L, 1.0, 1.0, -1)
+    assert np.array_equal(walk.numpy(), ref), rank
     # empty request from one rank must not dead-lock the exchange
     empty = torch.zeros(0, dtype=torch.int64) if rank == 0 else torch.as_tensor(roots)
     n1, w1, t1, m1 = S.sample_neighbor(empty, [0], 2, -1, 7)

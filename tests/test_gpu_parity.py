@@ -8,23 +8,11 @@ import numpy as np
 import pytest
 
 from conftest import make_random_graph
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
 SEED = 20240521
-
-
-@pytest.fixture(scope="module")
-def torch_cuda():
-    import torch
-    assert torch.cuda.is_available(), "GPU tests need a GPU"
-    return torch
-
-
-@pytest.fixture(scope="module")
-def EA(torch_cuda):
-    import euler_amd
-    return euler_amd
 
 
 @pytest.fixture(params=[(5, 4), (5, 2), (5, 1), (4, 4), (3, 4), (2, 4), (2, 2), (2, 8), (1, 4), (0, 4)],
@@ -502,3 +490,80 @@ def test_fanout_second_hop_dedup(EA, O, torch_cuda, big_pair):
         assert np.array_equal(t2n(gn[h + 1]), on[h])
         assert np.array_equal(t2n(gw[h]), ow[h])
         assert np.array_equal(t2n(gt[h]), ot[h])
+
+
+def test_gpu_sharded_sampler_single_rank(EA, O, torch_cuda, big_pair):
+    """The multi-GPU sampler with its real HIP pieces (id_unique, id_split,
+    merge_rows, gather) and RCCL, on a one-rank group: ids and rows go through
+    unique -> split -> all-to-all -> sample -> all-to-all -> merge -> gather and
+    must come back equal to the oracle's fanout and walk (the N > 1 host logic
+    is covered with gloo in test_distributed_cpu.py)."""
+    torch = torch_cuda
+    import torch.distributed as dist
+    from euler_amd.distributed import gpu_sharded_sampler
+    G, OG, ids, rng = big_pair
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        G.set_seed(31)
+        q = np.concatenate([rng.choice(ids, 3000), rng.choice(ids[:50], 3000),
+                            [0, 999]]).astype(np.int64)
+        on, ow, ot = OG.sample_fanout(31, 8, q, [[0, 1], [2, 3]], [6, 4], -1)
+        for dedup in (True, False):
+            S = gpu_sharded_sampler(G, partitions=1, dedup=dedup)
+            gn, gw, gt = S.sample_fanout(torch.as_tensor(q).cuda(), [[0, 1], [2, 3]], [6, 4],
+                                         -1, call_id=8)
+            for h in range(2):
+                assert np.array_equal(t2n(gn[h + 1]), on[h])
+                assert np.array_equal(t2n(gw[h]), ow[h])
+                assert np.array_equal(t2n(gt[h]), ot[h])
+        S = gpu_sharded_sampler(G, partitions=1)
+        L = 5
+        et = [[0, 1, 2, 3]] * L
+        walk = S.random_walk(torch.as_tensor(q).cuda(), et, default_node=-1, call_id=20)
+        assert np.array_equal(t2n(walk), OG.random_walk(31, 20, q, et, L, 1.0, 1.0, -1))
+        assert np.array_equal(
+            t2n(walk), t2n(G.random_walk(torch.as_tensor(q).cuda(), et, 1.0, 1.0, -1,
+                                         call_id=20)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dense_feature_vs_goldens_and_oracle(EA, O, torch_cuda, fixture_csr, random_csr):
+    """get_dense_feature on device == the reference's rows (features.npz) for
+    the fixture and the random graph, through from_csr and through the .dat
+    loader; plus a 100-dimension uniform table (the fixed-stride fast path)."""
+    torch = torch_cuda
+    fg = np.load(os.path.join(ROOT, "tests", "golden", "features.npz"))
+    for prefix, csr in (("fx_", fixture_csr), ("rg_", random_csr)):
+        feats = (int(fg[prefix + "n_float"]), fg[prefix + "feat_ptr"],
+                 fg[prefix + "feat_idx"], fg[prefix + "feat_val"])
+        G = EA.Graph.from_csr(csr.row_id, csr.row_ptr, csr.type_end, csr.nbr,
+                              csr.prefix_w, csr.type_prefix, csr.n_types,
+                              csr.node_type, csr.node_weight, features=feats)
+        assert G.num_float_features == feats[0]
+        got = G.get_dense_feature(torch.as_tensor(fg[prefix + "query"]).cuda(),
+                                  fg[prefix + "fids"].tolist(), fg[prefix + "dims"].tolist())
+        for k, o in enumerate(got):
+            assert np.array_equal(t2n(o), fg[prefix + "dense_%d" % k]), (prefix, k)
+    G = EA.Graph.load(os.path.join(ROOT, "tests", "golden", "fixture_dat"))
+    got = G.get_dense_feature(torch.as_tensor(fg["fx_query"]).cuda(),
+                              fg["fx_fids"].tolist(), fg["fx_dims"].tolist())
+    for k, o in enumerate(got):
+        assert np.array_equal(t2n(o), fg["fx_dense_%d" % k])
+    # uniform table: 5000 nodes x (100 + 28) floats
+    rng = np.random.default_rng(3)
+    n = 5000
+    ids = np.arange(10, 10 + n).astype(np.uint64)
+    seg = np.arange(n + 1, dtype=np.int64)
+    csr = O.csr_from_raw(ids, seg, rng.choice(ids, n), np.ones(n, np.float32), 1)
+    val = rng.standard_normal((n, 128)).astype(np.float32)
+    F = O.DenseFeatures(2, np.arange(n + 1) * 128, np.tile([100, 128], n), val.reshape(-1))
+    G = gpu_graph(EA, csr, features=(2, F.feat_ptr, F.feat_idx, F.feat_val))
+    q = np.concatenate([rng.choice(ids, 20000), [0, 3]]).astype(np.int64)
+    want = O.OracleGraph(csr).get_dense_feature(F, q, [0, 1], [100, 32])
+    got = G.get_dense_feature(torch.as_tensor(q).cuda(), [0, 1], [100, 32])
+    assert np.array_equal(t2n(got[0]), want[0]) and np.array_equal(t2n(got[1]), want[1])
+    assert np.array_equal(want[0][:-2], val[(q[:-2] - 10), :100])

@@ -61,6 +61,13 @@ def read_dat(path, shard_index=0, shards=1):
     E = int(out["row_ptr"][-1])
     out["nbr"] = np.ctypeslib.as_array(csr.nbr, (max(E, 1),))[:E].copy()
     out["prefix_w"] = np.ctypeslib.as_array(csr.prefix_w, (max(E, 1),))[:E].copy()
+    F = csr.n_float_features
+    out["n_float"] = F
+    if F > 0:
+        out["feat_ptr"] = np.ctypeslib.as_array(csr.feat_ptr, (n + 1,)).copy()
+        out["feat_idx"] = np.ctypeslib.as_array(csr.feat_idx, (n * F,)).copy()
+        tot = int(out["feat_ptr"][-1])
+        out["feat_val"] = np.ctypeslib.as_array(csr.feat_val, (max(tot, 1),))[:tot].copy()
     L.euler_gpu_dat_close(owner)
     return out
 
@@ -84,6 +91,15 @@ def test_dat_reader_on_reference_tool_output(fixture_csr):
                               fixture_csr.type_end[old * T:old * T + T])
         assert np.array_equal(d["type_prefix"][new * T:new * T + T],
                               fixture_csr.type_prefix[old * T:old * T + T])
+    # float features of the records == what the reference's DeSerialize holds
+    fg = np.load(os.path.join(ROOT, "tests", "golden", "features.npz"))
+    F = int(fg["fx_n_float"])
+    assert d["n_float"] == F
+    for new, old in zip(order, range(6)):
+        assert np.array_equal(d["feat_idx"][new * F:new * F + F],
+                              fg["fx_feat_idx"][old * F:old * F + F])
+        assert np.array_equal(d["feat_val"][d["feat_ptr"][new]:d["feat_ptr"][new + 1]],
+                              fg["fx_feat_val"][fg["fx_feat_ptr"][old]:fg["fx_feat_ptr"][old + 1]])
     # shard filter of Graph::Init: file idx % shards == shard_index
     s0 = read_dat(os.path.join(ROOT, "tests", "golden", "fixture_dat"), 0, 2)
     s1 = read_dat(os.path.join(ROOT, "tests", "golden", "fixture_dat"), 1, 2)

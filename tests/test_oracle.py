@@ -1,6 +1,8 @@
 """Pin the CPU oracle (oracle/euler_oracle.c): known-answer tests, the exact
 expectations of the reference's own tests, and the golden vectors produced by
 the reference sampler (tests/golden/make_golden.py).  CPU only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -247,3 +249,26 @@ def test_synth_graph_properties(O):
     assert np.array_equal(sub.prefix_w, csr.prefix_w[b:e])
     w0 = csr.prefix_w[csr.row_ptr[:-1]]
     assert w0.min() >= 0.5 and w0.max() < 8.0
+
+
+def _golden_features(O, prefix):
+    fg = np.load(os.path.join(os.path.dirname(__file__), "golden", "features.npz"))
+    F = O.DenseFeatures(int(fg[prefix + "n_float"]), fg[prefix + "feat_ptr"],
+                        fg[prefix + "feat_idx"], fg[prefix + "feat_val"])
+    return fg, F
+
+
+def test_dense_feature_goldens(O, fixture_csr, random_csr):
+    """Restated GetDenseFeature == rows produced by the reference's
+    GetFloat32Feature + the TF kernel's copy loop (tests/golden/features.npz):
+    the fixture's own features as loaded by Node::DeSerialize, and ragged random
+    features (missing slots, short rows, unknown nodes, slot out of range)."""
+    for prefix, csr in (("fx_", fixture_csr), ("rg_", random_csr)):
+        fg, F = _golden_features(O, prefix)
+        got = O.OracleGraph(csr).get_dense_feature(F, fg[prefix + "query"],
+                                                   fg[prefix + "fids"], fg[prefix + "dims"])
+        for k, o in enumerate(got):
+            assert np.array_equal(o, fg[prefix + "dense_%d" % k]), (prefix, k)
+    # the fixture's values are the ones of tools/test_data/graph.json
+    fg, F = _golden_features(O, "fx_")
+    assert np.allclose(fg["fx_dense_0"][0], [1.1, 1.2])

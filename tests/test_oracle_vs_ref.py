@@ -80,3 +80,27 @@ def test_graph_with_node_id_zero(O):
     et = np.zeros((5, 1), np.int32)
     assert np.array_equal(R.random_walk(1, 0, starts, et, 5, 1.0, 1.0, -1),
                           G.random_walk(1, 0, starts, et, 5, 1.0, 1.0, -1))
+
+
+def test_dense_features_match_reference(O):
+    """Random ragged float features pushed into the reference's Node storage:
+    Node::GetFloat32Feature + TF copy loop == restatement."""
+    rng = np.random.default_rng(21)
+    n = 200
+    ids = np.sort(rng.choice(np.arange(1, 10 ** 6), n, replace=False)).astype(np.uint64)
+    seg = np.arange(n + 1, dtype=np.int64)
+    nbr = rng.choice(ids, n).astype(np.uint64)
+    w = np.ones(n, np.float32)
+    csr = O.csr_from_raw(ids, seg, nbr, w, 1)
+    per = [[list(rng.standard_normal(int(rng.integers(0, 9))).astype(np.float32))
+            for _ in range(int(rng.integers(0, 4)))] for _ in range(n)]
+    per[0] = [[1.0] * 8, [2.0] * 8, [3.0] * 8]
+    F = O.DenseFeatures.from_lists(per)
+    R = O.RefGraph.build_raw(ids, seg, nbr, w, 1)
+    R.set_float_features(ids, F)
+    q = np.concatenate([rng.choice(ids, 500), [0, 7]]).astype(np.int64)
+    fids, dims = [0, 1, 2, 3, -1], [8, 8, 9, 4, 2]
+    a = O.OracleGraph(csr).get_dense_feature(F, q, fids, dims)
+    b = R.get_dense_feature(q, fids, dims)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
