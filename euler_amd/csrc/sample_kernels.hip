@@ -80,9 +80,9 @@ __device__ __forceinline__ bool DedupGate(const SampleNbArgs& a, int64_t* n) {
 // dense key instead: every position stores its own index into owner[row] with a
 // plain 4-byte store (a benign race: one of the positions naming the row
 // survives, and every referenced row is written by this call, so the table
-// never needs clearing); a second kernel reads it back - the survivor is the
-// row's representative; an exclusive scan of the representative flags numbers
-// the unique roots and counts them.  All unknown ids share the slot n_rows:
+// never needs clearing); reading it back tells who survived - the row's
+// representative; an exclusive scan of the representative flags (evaluated
+// inside the scan's loads) numbers the unique roots and counts them.  All unknown ids share the slot n_rows:
 // their rows are the same default fill.
 struct DedupArgs {
   GraphView g;
@@ -93,7 +93,6 @@ struct DedupArgs {
   int32_t pad;
   uint32_t* owner;           // [n_rows + 1] row -> a position that names it
   uint32_t* row_slot;        // [n] row of every position (n_rows = no such node)
-  uint32_t* flag;            // [n + 1] 1 = representative; flag[n] = 0
   uint32_t* pos;             // [n + 1] exclusive scan of flag; pos[n] = unique count
   uint64_t* uniq;            // [<= n] unique roots (node ids), by first representative
   uint32_t* uidx_of;         // [n] index into uniq of every position
@@ -117,12 +116,16 @@ __global__ __launch_bounds__(256) void DedupMarkKernel(const DedupArgs a) {
   }
 }
 
-__global__ __launch_bounds__(256) void DedupFlagKernel(const DedupArgs a) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= a.n;
-       i += stride)
-    a.flag[i] = (i < a.n && a.owner[a.row_slot[i]] == (uint32_t)i) ? 1u : 0u;
-}
+// flag[i] = 1 when position i is its row's representative; evaluated inside
+// the scan's loads (no flag array, no separate pass)
+struct DedupFlagOp {
+  const uint32_t* owner;
+  const uint32_t* row_slot;
+  int64_t n;
+  __host__ __device__ __forceinline__ uint32_t operator()(const uint32_t& i) const {
+    return ((int64_t)i < n && owner[row_slot[i]] == i) ? 1u : 0u;
+  }
+};
 
 __global__ __launch_bounds__(256) void DedupIndexKernel(const DedupArgs a) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -166,18 +169,23 @@ __global__ __launch_bounds__(256) void DedupExpandKernel(const ExpandArgs a,
   for (; s < total; s += stride) {
     const int64_t u = (int64_t)a.uidx_of[i];
     const int64_t src = u * a.count + j;
+    // the outputs are written once and not read by this call: non-temporal
+    // stores keep the rows of the distinct roots (re-read ~11x) in the L2
     if (U == 1) {
-      a.out_id[s] = a.t_id[src];
-      a.out_w[s] = a.t_w[src];
-      a.out_t[s] = a.t_t[src];
+      __builtin_nontemporal_store(a.t_id[src], a.out_id + s);
+      __builtin_nontemporal_store(a.t_w[src], a.out_w + s);
+      __builtin_nontemporal_store(a.t_t[src], a.out_t + s);
     } else {
       // src is even whenever count is even
-      *reinterpret_cast<ulonglong2*>(a.out_id + s) =
-          *reinterpret_cast<const ulonglong2*>(a.t_id + src);
-      *reinterpret_cast<float2*>(a.out_w + s) =
-          *reinterpret_cast<const float2*>(a.t_w + src);
-      *reinterpret_cast<int2*>(a.out_t + s) =
-          *reinterpret_cast<const int2*>(a.t_t + src);
+      typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      typedef int i32x2 __attribute__((ext_vector_type(2)));
+      __builtin_nontemporal_store(*reinterpret_cast<const u64x2*>(a.t_id + src),
+                                  reinterpret_cast<u64x2*>(a.out_id + s));
+      __builtin_nontemporal_store(*reinterpret_cast<const f32x2*>(a.t_w + src),
+                                  reinterpret_cast<f32x2*>(a.out_w + s));
+      __builtin_nontemporal_store(*reinterpret_cast<const i32x2*>(a.t_t + src),
+                                  reinterpret_cast<i32x2*>(a.out_t + s));
     }
     if (j == 0 && a.out_mask != nullptr) a.out_mask[i] = a.t_mask[u];
     i += stride_rows;
@@ -1204,7 +1212,11 @@ static int LaunchK1(const euler_gpu_graph* g, hipStream_t stream,
   const bool single = k == 1 && g->view.monotone;
   const bool tf_zero = layout == EULER_GPU_LAYOUT_TF && g->view.has_zero_nbr != 0;
   if (g_k1_variant == 5 && single && !tf_zero) {
-    const bool pair = g_k1_pair != 0 && count % 2 == 0 &&
+    // two samples per lane pay when the launch is bound by memory-instruction
+    // throughput (millions of roots with hot rows); the pass over the distinct
+    // roots (dd_role 2) is small and cold - there the shorter dependent chain of
+    // one sample per lane wins (0.139 vs 0.149 ms on the metric workload)
+    const bool pair = g_k1_pair != 0 && a.dd_role != 2 && count % 2 == 0 &&
                       ((uintptr_t)out_id % 16 == 0) && ((uintptr_t)out_w % 8 == 0) &&
                       ((uintptr_t)out_t % 8 == 0);
     const int U = pair ? 2 : 1;
@@ -1365,8 +1377,14 @@ static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t total_out = (size_t)n * (size_t)count;
   size_t scan_bytes = 0;
-  EG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t*)nullptr,
-                                          (uint32_t*)nullptr, (int)(n + 1), stream));
+  {
+    hipcub::CountingInputIterator<uint32_t> pos_it(0u);
+    hipcub::TransformInputIterator<uint32_t, DedupFlagOp,
+                                   hipcub::CountingInputIterator<uint32_t>>
+        flag_it(pos_it, DedupFlagOp{nullptr, nullptr, n});
+    EG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, flag_it,
+                                            (uint32_t*)nullptr, (int)(n + 1), stream));
+  }
   const size_t o_owner = 0;
   const size_t o_slot = o_owner + al(((size_t)g->view.n_rows + 1) * 4);
   const size_t o_flag = o_slot + al((size_t)n * 4);
@@ -1391,7 +1409,6 @@ static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
   d.roots = roots; d.root_mask = root_mask; d.n = n; d.root_group = a.root_group;
   d.owner = (uint32_t*)(ws + o_owner);
   d.row_slot = (uint32_t*)(ws + o_slot);
-  d.flag = (uint32_t*)(ws + o_flag);
   d.pos = (uint32_t*)(ws + o_pos);
   d.uidx_of = (uint32_t*)(ws + o_uidx);
   d.uniq = (uint64_t*)(ws + o_uniq);
@@ -1401,9 +1418,14 @@ static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
   const int dgrid = GridFor(n + 1, block);
   PhaseMark(stream, 0);
   hipLaunchKernelGGL(DedupMarkKernel, dim3(dgrid), dim3(block), 0, stream, d);
-  hipLaunchKernelGGL(DedupFlagKernel, dim3(dgrid), dim3(block), 0, stream, d);
-  EG_HIP(hipcub::DeviceScan::ExclusiveSum(ws + o_scan, scan_bytes, d.flag, d.pos,
-                                          (int)(n + 1), stream));
+  {
+    hipcub::CountingInputIterator<uint32_t> pos_it(0u);
+    hipcub::TransformInputIterator<uint32_t, DedupFlagOp,
+                                   hipcub::CountingInputIterator<uint32_t>>
+        flag_it(pos_it, DedupFlagOp{d.owner, d.row_slot, n});
+    EG_HIP(hipcub::DeviceScan::ExclusiveSum(ws + o_scan, scan_bytes, flag_it, d.pos,
+                                            (int)(n + 1), stream));
+  }
   hipLaunchKernelGGL(DedupIndexKernel, dim3(dgrid), dim3(block), 0, stream, d);
   PhaseMark(stream, 1);
   // ---- pass 1: the given roots, straight to the outputs (few duplicates) -----
