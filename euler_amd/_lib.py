@@ -104,6 +104,11 @@ SIGNATURES = {
                                                        C.POINTER(C.c_double)]),
     "euler_gpu_set_tuning": (C.c_int, [C.c_int32, C.c_int32]),
     "euler_gpu_graph_num_float_features": (C.c_int32, [vp]),
+    "euler_gpu_neighbor_post_process": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, vp, vp,
+                                                  C.c_int32, C.c_int32, C.c_int64,
+                                                  C.POINTER(C.c_int64)]),
+    "euler_gpu_neighbor_to_dense": (C.c_int, [vp, C.c_int64, vp, vp, vp, vp, C.c_int32,
+                                              C.c_int64, vp, vp, vp]),
     "euler_gpu_get_dense_feature": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int32,
                                               C.c_int32, vp]),
     "euler_gpu_time_sample_neighbor_phases": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_int64,

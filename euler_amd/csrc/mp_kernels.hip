@@ -155,6 +155,89 @@ static int ScatterImpl(hipStream_t st, const float* upd, const int32_t* idx,
 }
 
 // ------------------------------------------------------------------------
+// Post-process of API_GET_NB_NODE (core/kernels/get_neighbor_op.cc:117-168):
+// `order_by id|weight [desc]` sorts every row of a FillNeighbor-layout result,
+// `limit k` keeps its first k entries.  Rows are segments of one flat array,
+// so the sort is one segmented radix sort of (key, position) pairs (rocPRIM,
+// stable: equal keys keep storage order - the reference sorts with a
+// non-strict comparator, so its order of equal keys is undefined), then one
+// wave per row moves the surviving entries to their packed place.
+// ------------------------------------------------------------------------
+struct IdxEdge {
+  const int32_t* idx;
+  int32_t which;
+  __host__ __device__ __forceinline__ int32_t operator()(const int32_t& i) const {
+    return idx[2 * i + which];
+  }
+};
+
+__global__ void IotaKernel(int32_t* p, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = (int32_t)i;
+}
+
+__global__ void LimitLenKernel(const int32_t* idx, int64_t n, int64_t limit,
+                               int64_t* len) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    int64_t l = idx[2 * i + 1] - idx[2 * i];
+    if (limit >= 0 && l > limit) l = limit;
+    len[i] = l;
+  }
+}
+
+// one wave per row: dst[new_off[i] + p] = src[perm ? perm[b + p] : b + p]
+__global__ __launch_bounds__(256) void RepackRowsKernel(
+    const int32_t* __restrict__ old_idx, const int64_t* __restrict__ new_len,
+    const int64_t* __restrict__ new_off, const int32_t* __restrict__ perm, int64_t n,
+    const uint64_t* __restrict__ s_id, const float* __restrict__ s_w,
+    const int32_t* __restrict__ s_t, uint64_t* __restrict__ d_id,
+    float* __restrict__ d_w, int32_t* __restrict__ d_t) {
+  const int lane = threadIdx.x & 63;
+  const int64_t waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < n;
+       i += waves) {
+    const int64_t b = old_idx[2 * i], len = new_len[i], o = new_off[i];
+    for (int64_t p = lane; p < len; p += 64) {
+      const int64_t src = perm ? (int64_t)perm[b + p] : b + p;
+      d_id[o + p] = s_id[src];
+      d_w[o + p] = s_w[src];
+      d_t[o + p] = s_t[src];
+    }
+  }
+}
+
+__global__ void LenOffToIdxKernel(const int64_t* len, const int64_t* off, int64_t n,
+                                  int32_t* idx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    idx[2 * i] = (int32_t)off[i];
+    idx[2 * i + 1] = (int32_t)(off[i] + len[i]);
+  }
+}
+
+// TF GetTopKNeighbor dense fill (tf_euler/kernels/get_top_k_neighbor_op.cc:
+// 70-75 prefill default_node / 0.0 / -1, :101-109 copy the row's entries).
+__global__ __launch_bounds__(256) void NeighborToDenseKernel(
+    const int32_t* __restrict__ idx, const uint64_t* __restrict__ ids,
+    const float* __restrict__ w, const int32_t* __restrict__ t, int64_t n, int32_t k,
+    int64_t default_node, int64_t* __restrict__ out_id, float* __restrict__ out_w,
+    int32_t* __restrict__ out_t) {
+  const int64_t total = n * (int64_t)k;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total;
+       s += stride) {
+    const int64_t i = s / k;
+    const int32_t p = (int32_t)(s - i * k);
+    const int32_t b = idx[2 * i], e = idx[2 * i + 1];
+    const bool have = b + p < e;
+    out_id[s] = have ? (int64_t)ids[b + p] : default_node;
+    out_w[s] = have ? w[b + p] : 0.f;
+    out_t[s] = have ? t[b + p] : -1;
+  }
+}
+
+// ------------------------------------------------------------------------
 // GetDenseFeature (tf_euler/kernels/get_dense_feature_op.cc:63-125 over
 // Node::GetFloat32Feature, core/graph/node.cc:330-394).  One lane per output
 // element: the dim lanes of a row read consecutive floats of the node's value
@@ -406,6 +489,107 @@ int euler_gpu_scatter_max(void* stream, const float* updates_dev,
                           int32_t size, float* out_dev) {
   return ScatterImpl<true>((hipStream_t)stream, updates_dev, indices_dev, e, d,
                            size, out_dev);
+}
+
+int euler_gpu_neighbor_post_process(void* stream, int64_t n, int32_t* idx_dev,
+                                    int64_t total, uint64_t* id_dev, float* w_dev,
+                                    int32_t* t_dev, int32_t order_by, int32_t desc,
+                                    int64_t limit, int64_t* total_host) {
+  if (n < 0 || total < 0 || order_by < 0 || order_by > 2)
+    return Fail(EULER_GPU_EINVAL, "neighbor_post_process: bad arguments");
+  if (total_host) *total_host = total;
+  if (n == 0 || total == 0 || (order_by == 0 && limit < 0)) return EULER_GPU_OK;
+  if (!idx_dev || !id_dev || !w_dev || !t_dev)
+    return Fail(EULER_GPU_EINVAL, "neighbor_post_process: null buffer");
+  if (total >= (1LL << 31)) return Fail(EULER_GPU_EINVAL, "neighbor_post_process: total >= 2^31");
+  hipStream_t st = (hipStream_t)stream;
+  const int block = 256;
+  // scratch: copies of the three value arrays, the permutation, lengths/offsets
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t o_id = 0, o_w = o_id + al((size_t)total * 8), o_t = o_w + al((size_t)total * 4);
+  const size_t o_pin = o_t + al((size_t)total * 4), o_pout = o_pin + al((size_t)total * 4);
+  const size_t o_key = o_pout + al((size_t)total * 4);
+  const size_t o_len = o_key + al((size_t)total * 8), o_off = o_len + al((size_t)(n + 1) * 8);
+  const size_t bytes = o_off + al((size_t)(n + 1) * 8);
+  uint8_t* buf = nullptr;
+  EG_HIP(hipMallocAsync((void**)&buf, bytes, st));
+  uint64_t* c_id = (uint64_t*)(buf + o_id);
+  float* c_w = (float*)(buf + o_w);
+  int32_t* c_t = (int32_t*)(buf + o_t);
+  int32_t* p_in = (int32_t*)(buf + o_pin);
+  int32_t* p_out = (int32_t*)(buf + o_pout);
+  int64_t* len = (int64_t*)(buf + o_len);
+  int64_t* off = (int64_t*)(buf + o_off);
+  EG_HIP(hipMemcpyAsync(c_id, id_dev, (size_t)total * 8, hipMemcpyDeviceToDevice, st));
+  EG_HIP(hipMemcpyAsync(c_w, w_dev, (size_t)total * 4, hipMemcpyDeviceToDevice, st));
+  EG_HIP(hipMemcpyAsync(c_t, t_dev, (size_t)total * 4, hipMemcpyDeviceToDevice, st));
+  const int32_t* perm = nullptr;
+  if (order_by != 0) {
+    hipLaunchKernelGGL(IotaKernel, dim3((total + block - 1) / block), dim3(block), 0, st,
+                       p_in, total);
+    hipcub::CountingInputIterator<int32_t> row_it(0);
+    hipcub::TransformInputIterator<int32_t, IdxEdge, hipcub::CountingInputIterator<int32_t>>
+        seg_b(row_it, IdxEdge{idx_dev, 0}), seg_e(row_it, IdxEdge{idx_dev, 1});
+    size_t tmp_bytes = 0;
+    void* tmp = nullptr;
+#define EG_SEGSORT(KEY_T, KEYS_IN, FN)                                               \
+    {                                                                                \
+      KEY_T* keys_out = (KEY_T*)(buf + o_key);                                       \
+      EG_HIP(hipcub::DeviceSegmentedRadixSort::FN(nullptr, tmp_bytes, KEYS_IN,       \
+                                                  keys_out, p_in, p_out, (int)total, \
+                                                  (int)n, seg_b, seg_e, 0,           \
+                                                  (int)sizeof(KEY_T) * 8, st));      \
+      EG_HIP(hipMallocAsync(&tmp, tmp_bytes + 16, st));                              \
+      EG_HIP(hipcub::DeviceSegmentedRadixSort::FN(tmp, tmp_bytes, KEYS_IN, keys_out, \
+                                                  p_in, p_out, (int)total, (int)n,   \
+                                                  seg_b, seg_e, 0,                   \
+                                                  (int)sizeof(KEY_T) * 8, st));      \
+    }
+    if (order_by == 1) {
+      if (desc) EG_SEGSORT(uint64_t, c_id, SortPairsDescending)
+      else EG_SEGSORT(uint64_t, c_id, SortPairs)
+    } else {
+      if (desc) EG_SEGSORT(float, c_w, SortPairsDescending)
+      else EG_SEGSORT(float, c_w, SortPairs)
+    }
+#undef EG_SEGSORT
+    EG_HIP(hipFreeAsync(tmp, st));
+    perm = p_out;
+  }
+  hipLaunchKernelGGL(LimitLenKernel, dim3((n + block - 1) / block), dim3(block), 0, st,
+                     idx_dev, n, limit, len);
+  {
+    const int rc = ExclusiveScanI64(st, len, off, n);
+    if (rc != EULER_GPU_OK) return rc;
+  }
+  hipLaunchKernelGGL(RepackRowsKernel, dim3(GridFor(n * 64, block)), dim3(block), 0, st,
+                     idx_dev, len, off, perm, n, c_id, c_w, c_t, id_dev, w_dev, t_dev);
+  hipLaunchKernelGGL(LenOffToIdxKernel, dim3((n + block - 1) / block), dim3(block), 0,
+                     st, len, off, n, idx_dev);
+  EG_HIP(hipGetLastError());
+  int32_t last[2];
+  EG_HIP(hipMemcpyAsync(last, idx_dev + 2 * (n - 1), 8, hipMemcpyDeviceToHost, st));
+  EG_HIP(hipStreamSynchronize(st));
+  EG_HIP(hipFreeAsync(buf, st));
+  if (total_host) *total_host = last[1];
+  return EULER_GPU_OK;
+}
+
+int euler_gpu_neighbor_to_dense(void* stream, int64_t n, const int32_t* idx_dev,
+                                const uint64_t* id_dev, const float* w_dev,
+                                const int32_t* t_dev, int32_t k, int64_t default_node,
+                                int64_t* out_id_dev, float* out_w_dev,
+                                int32_t* out_t_dev) {
+  if (n < 0 || k < 0) return Fail(EULER_GPU_EINVAL, "neighbor_to_dense: bad n/k");
+  if (n == 0 || k == 0) return EULER_GPU_OK;
+  if (!idx_dev || !out_id_dev || !out_w_dev || !out_t_dev)
+    return Fail(EULER_GPU_EINVAL, "neighbor_to_dense: null buffer");
+  const int block = 256;
+  hipLaunchKernelGGL(NeighborToDenseKernel, dim3(GridFor(n * (int64_t)k, block)),
+                     dim3(block), 0, (hipStream_t)stream, idx_dev, id_dev, w_dev, t_dev, n,
+                     k, default_node, out_id_dev, out_w_dev, out_t_dev);
+  EG_HIP(hipGetLastError());
+  return EULER_GPU_OK;
 }
 
 int euler_gpu_get_dense_feature(const euler_gpu_graph* g, void* stream,

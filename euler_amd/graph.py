@@ -326,9 +326,13 @@ class Graph:
                 outs.append(out)
         return outs
 
-    def get_full_neighbor(self, nodes, edge_types):
-        """GQL `v(nodes).outV(edge_types)` result (idx [n,2] int32, ids int64,
-        weights f32, types int32), core/kernels/get_neighbor_op.cc."""
+    _ORDER = {None: 0, "": 0, "id": 1, "weight": 2}
+
+    def get_full_neighbor(self, nodes, edge_types, order_by=None, desc=False,
+                          limit=None):
+        """GQL `v(nodes).outV(edge_types)[.order_by(f, asc|desc)][.limit(k)]`
+        result (idx [n,2] int32, ids int64, weights f32, types int32),
+        core/kernels/get_neighbor_op.cc (post-process :117-168)."""
         nodes = _as_i64_cuda(nodes, self.device).reshape(-1)
         n = nodes.numel()
         et, et_p, k = _i32_array(edge_types)
@@ -346,7 +350,38 @@ class Graph:
                 check(lib().euler_gpu_get_full_neighbor(
                     self._h, _stream(), _ptr(nodes), n, et_p, k, _ptr(idx),
                     C.byref(total), _ptr(ids), _ptr(w), _ptr(t)))
+            if n and (self._ORDER[order_by] or limit is not None):
+                new_total = C.c_int64(0)
+                check(lib().euler_gpu_neighbor_post_process(
+                    _stream(), n, _ptr(idx), tot, _ptr(ids), _ptr(w), _ptr(t),
+                    self._ORDER[order_by], 1 if desc else 0,
+                    -1 if limit is None else int(limit), C.byref(new_total)))
+                m = int(new_total.value)
+                ids, w, t = ids[:m], w[:m], t[:m]
         return idx, ids, w, t
+
+    def get_sorted_full_neighbor(self, nodes, edge_types):
+        """tf_euler get_sorted_full_neighbor: rows ordered by neighbour id
+        (tf_euler/kernels/get_sorted_full_neighbor_op.cc:43-46)."""
+        return self.get_full_neighbor(nodes, edge_types, order_by="id")
+
+    def get_top_k_neighbor(self, nodes, edge_types, k, default_node=-1):
+        """tf_euler get_top_k_neighbor (tf_euler/kernels/get_top_k_neighbor_op.cc):
+        the k heaviest neighbours per node as dense [n, k] tensors (ids int64,
+        weights f32, types int32), default_node / 0.0 / -1 where a node has
+        fewer."""
+        nodes = _as_i64_cuda(nodes, self.device).reshape(-1)
+        n = nodes.numel()
+        idx, ids, w, t = self.get_full_neighbor(nodes, edge_types, order_by="weight",
+                                                desc=True, limit=k)
+        out_n = torch.empty((n, k), dtype=torch.int64, device=self.device)
+        out_w = torch.empty((n, k), dtype=torch.float32, device=self.device)
+        out_t = torch.empty((n, k), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().euler_gpu_neighbor_to_dense(
+                _stream(), n, _ptr(idx), _ptr(ids), _ptr(w), _ptr(t), int(k),
+                int(default_node), _ptr(out_n), _ptr(out_w), _ptr(out_t)))
+        return out_n, out_w, out_t
 
     def random_walk(self, nodes, edge_types, p=1.0, q=1.0, default_node=-1,
                     call_id=None):

@@ -221,6 +221,28 @@ int euler_gpu_get_full_neighbor(const euler_gpu_graph* g, void* stream,
                                 uint64_t* out_id_dev, float* out_w_dev,
                                 int32_t* out_t_dev);
 
+/* Post-process of API_GET_NB_NODE (core/kernels/get_neighbor_op.cc:117-168) on
+ * the result of euler_gpu_get_full_neighbor, in place: order_by (0 none, 1 id,
+ * 2 weight; desc != 0 = descending) then limit (< 0 = none).  Rows are
+ * re-packed, idx_dev rewritten, *total_host receives the new total (stream
+ * sync).  This is what the TF ops GetSortedFullNeighbor (`order_by(id, asc)`,
+ * tf_euler/kernels/get_sorted_full_neighbor_op.cc:43-46) and GetTopKNeighbor
+ * (`order_by(weight, desc).limit(k)`, get_top_k_neighbor_op.cc:36-44) run.
+ * Equal keys keep storage order (undefined in the reference: std::sort with a
+ * non-strict comparator). */
+int euler_gpu_neighbor_post_process(void* stream, int64_t n, int32_t* idx_dev,
+                                    int64_t total, uint64_t* id_dev, float* w_dev,
+                                    int32_t* t_dev, int32_t order_by, int32_t desc,
+                                    int64_t limit, int64_t* total_host);
+/* Dense [n, k] fill of the TF GetTopKNeighbor kernel
+ * (tf_euler/kernels/get_top_k_neighbor_op.cc:70-75,101-109): default_node /
+ * 0.0 / -1 where a row has fewer than k entries. */
+int euler_gpu_neighbor_to_dense(void* stream, int64_t n, const int32_t* idx_dev,
+                                const uint64_t* id_dev, const float* w_dev,
+                                const int32_t* t_dev, int32_t k, int64_t default_node,
+                                int64_t* out_id_dev, float* out_w_dev,
+                                int32_t* out_t_dev);
+
 /* ---- dense features --------------------------------------------------------
  * TF GetDenseFeature (tf_euler/kernels/get_dense_feature_op.cc:63-125) over
  * Node::GetFloat32Feature (core/graph/node.cc:330-394): out_dev is [n, dim]

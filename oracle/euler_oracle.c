@@ -783,3 +783,59 @@ int eo_get_dense_feature(const eo_graph* g, const eo_features* f,
   }
   return 0;
 }
+
+
+/* core/kernels/get_neighbor_op.cc:117-168.  order_by sorts every row with
+ * std::sort and `a <= b` (asc) / `!(a <= b)` (desc) on the key: for distinct
+ * keys that is ascending / descending order; equal keys have no defined order
+ * there (non-strict comparator), here they keep storage order (insertion sort,
+ * stable).  limit k truncates every row to its first k entries. */
+int64_t eo_neighbor_post_process(int64_t n, int32_t* idx, uint64_t* ids, float* w,
+                                 int32_t* t, int32_t order_by, int32_t desc,
+                                 int64_t limit) {
+  int64_t out = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t b = idx[2 * i], e = idx[2 * i + 1];
+    if (order_by == 1 || order_by == 2) {
+      for (int64_t x = b + 1; x < e; ++x) {
+        uint64_t ki = ids[x]; float kw = w[x]; int32_t kt = t[x];
+        int64_t y = x - 1;
+        while (y >= b) {
+          int before;   /* does element y stay before the moving element? */
+          if (order_by == 1) before = desc ? ids[y] >= ki : ids[y] <= ki;
+          else before = desc ? w[y] >= kw : w[y] <= kw;
+          if (before) break;
+          ids[y + 1] = ids[y]; w[y + 1] = w[y]; t[y + 1] = t[y];
+          --y;
+        }
+        ids[y + 1] = ki; w[y + 1] = kw; t[y + 1] = kt;
+      }
+    }
+    int64_t len = e - b;
+    if (limit >= 0 && len > limit) len = limit;
+    for (int64_t x = 0; x < len; ++x) {
+      ids[out + x] = ids[b + x]; w[out + x] = w[b + x]; t[out + x] = t[b + x];
+    }
+    idx[2 * i] = (int32_t)out;
+    idx[2 * i + 1] = (int32_t)(out + len);
+    out += len;
+  }
+  return out;
+}
+
+void eo_neighbor_to_dense(int64_t n, const int32_t* idx, const uint64_t* ids,
+                          const float* w, const int32_t* t, int32_t k,
+                          int64_t default_node, int64_t* out_id, float* out_w,
+                          int32_t* out_t) {
+  for (int64_t i = 0; i < n * (int64_t)k; ++i) {
+    out_id[i] = default_node; out_w[i] = 0.0f; out_t[i] = -1;
+  }
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t b = idx[2 * i], e = idx[2 * i + 1];
+    for (int64_t j = b; j < e && j - b < k; ++j) {
+      out_id[i * k + j - b] = (int64_t)ids[j];
+      out_w[i * k + j - b] = w[j];
+      out_t[i * k + j - b] = t[j];
+    }
+  }
+}

@@ -105,6 +105,21 @@ int64_t eo_get_full_neighbor(const eo_graph* g, const uint64_t* ids,
                              int32_t* idx, uint64_t* out_id, float* out_w,
                              int32_t* out_t);
 
+/* Post-process of API_GET_NB_NODE (core/kernels/get_neighbor_op.cc:117-168) on
+ * a FillNeighbor-layout result, in place: order_by (0 none, 1 id, 2 weight;
+ * desc != 0 reverses) then limit (< 0 none).  Rows are re-packed, idx
+ * rewritten; returns the new total.  Ties keep storage order (the reference
+ * sorts with a non-strict comparator, so its order of equal keys is undefined). */
+int64_t eo_neighbor_post_process(int64_t n, int32_t* idx, uint64_t* ids, float* w,
+                                 int32_t* t, int32_t order_by, int32_t desc,
+                                 int64_t limit);
+/* TF GetTopKNeighbor dense fill (tf_euler/kernels/get_top_k_neighbor_op.cc:
+ * 70-75,101-109). */
+void eo_neighbor_to_dense(int64_t n, const int32_t* idx, const uint64_t* ids,
+                          const float* w, const int32_t* t, int32_t k,
+                          int64_t default_node, int64_t* out_id, float* out_w,
+                          int32_t* out_t);
+
 int64_t eo_id_unique(const uint64_t* ids, int64_t n, uint64_t* unique_ids,
                      int32_t* gather_idx);
 void eo_idx_gather(const int32_t* idx, const int32_t* gather_idx, int64_t n,

@@ -76,6 +76,11 @@ def lib():
             C.c_void_p, C.c_uint64, C.c_uint32, _i64p, C.c_int64, _i32p,
             C.c_int32, _i32p, C.c_int32, C.c_int64, C.POINTER(_i64p),
             C.POINTER(_f32p), C.POINTER(_i32p)]
+        L.eo_neighbor_post_process.restype = C.c_int64
+        L.eo_neighbor_post_process.argtypes = [C.c_int64, _i32p, _u64p, _f32p, _i32p,
+                                               C.c_int32, C.c_int32, C.c_int64]
+        L.eo_neighbor_to_dense.argtypes = [C.c_int64, _i32p, _u64p, _f32p, _i32p,
+                                           C.c_int32, C.c_int64, _i64p, _f32p, _i32p]
         L.eo_get_dense_feature.restype = C.c_int
         L.eo_get_dense_feature.argtypes = [C.c_void_p, C.c_void_p, _u64p, C.c_int64,
                                            C.c_int32, C.c_int32, _f32p]
@@ -178,6 +183,10 @@ def ref():
                                              C.c_int32, _i64p]
         R.euler_ref_set_rng.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32,
                                         C.c_uint64]
+        R.euler_ref_get_neighbor.restype = C.c_int64
+        R.euler_ref_get_neighbor.argtypes = [_u64p, C.c_int64, _i32p, C.c_int32,
+                                             C.c_int32, C.c_int32, C.c_int64, _i32p,
+                                             _u64p, _f32p, _i32p]
         R.euler_ref_set_float_features.argtypes = [_u64p, C.c_int64, C.c_int32,
                                                    _i64p, _i32p, _f32p]
         R.euler_ref_export_float_features.restype = C.c_int64
@@ -210,6 +219,34 @@ class CSR:
         self.node_weight = (_arr(node_weight, np.float32)
                             if node_weight is not None
                             else np.ones(self.n_rows, np.float32))
+
+
+ORDER = {None: 0, "": 0, "id": 1, "weight": 2}
+
+
+def neighbor_post_process(idx, ids, w, t, order_by=None, desc=False, limit=None):
+    """API_GET_NB_NODE post-process on a GQL-layout result (copies)."""
+    idx = _arr(idx, np.int32).copy()
+    ids = _arr(ids, np.uint64).copy()
+    w = _arr(w, np.float32).copy()
+    t = _arr(t, np.int32).copy()
+    tot = lib().eo_neighbor_post_process(len(idx), _p(idx, _i32p), _p(ids, _u64p),
+                                         _p(w, _f32p), _p(t, _i32p), ORDER[order_by],
+                                         1 if desc else 0,
+                                         -1 if limit is None else int(limit))
+    return idx, ids[:tot], w[:tot], t[:tot]
+
+
+def neighbor_to_dense(idx, ids, w, t, k, default_node=-1):
+    idx = _arr(idx, np.int32)
+    n = len(idx)
+    ids = _arr(ids, np.uint64); w = _arr(w, np.float32); t = _arr(t, np.int32)
+    oi = np.zeros((n, k), np.int64); ow = np.zeros((n, k), np.float32)
+    ot = np.zeros((n, k), np.int32)
+    lib().eo_neighbor_to_dense(n, _p(idx, _i32p), _p(ids, _u64p), _p(w, _f32p),
+                               _p(t, _i32p), k, default_node, _p(oi, _i64p),
+                               _p(ow, _f32p), _p(ot, _i32p))
+    return oi, ow, ot
 
 
 class Features(C.Structure):
@@ -626,6 +663,23 @@ class RefGraph:
 
     def __init__(self, n_types):
         self.n_types = n_types
+
+    def get_neighbor(self, ids, edge_types, order_by=None, desc=False, limit=None):
+        """The reference's GetFullNeighbor + the post-process of
+        API_GET_NB_NODE with the reference's comparators and std::sort."""
+        ids = _arr(ids, np.uint64)
+        et = _arr(edge_types, np.int32)
+        n = len(ids)
+        a = (_p(ids, _u64p), n, _p(et, _i32p), len(et), ORDER[order_by],
+             1 if desc else 0, -1 if limit is None else int(limit))
+        tot = ref().euler_ref_get_neighbor(*a, None, None, None, None)
+        idx = np.zeros((n, 2), np.int32)
+        oid = np.zeros(max(tot, 1), np.uint64)
+        ow = np.zeros(max(tot, 1), np.float32)
+        ot = np.zeros(max(tot, 1), np.int32)
+        ref().euler_ref_get_neighbor(*a, _p(idx, _i32p), _p(oid, _u64p), _p(ow, _f32p),
+                                     _p(ot, _i32p))
+        return idx, oid[:tot], ow[:tot], ot[:tot]
 
     def set_float_features(self, row_id, feats):
         ids = _arr(row_id, np.uint64)

@@ -364,6 +364,48 @@ int64_t euler_ref_get_full_neighbor(const uint64_t* ids, int64_t n,
   return off;
 }
 
+// API_GET_NB_NODE with its post-process (core/kernels/get_neighbor_op.cc:
+// 117-168; the op itself needs protobuf, so the loop is restated around the
+// reference's GetFullNeighbor with the reference's comparators and std::sort).
+int64_t euler_ref_get_neighbor(const uint64_t* ids, int64_t n,
+                               const int32_t* edge_types, int32_t k,
+                               int32_t order_by, int32_t desc, int64_t limit,
+                               int32_t* idx, uint64_t* out_id, float* out_w,
+                               int32_t* out_t) {
+  typedef euler::common::IDWeightPair IdWeightPair;
+  std::vector<uint64_t> v(ids, ids + n);
+  std::vector<int> et(edge_types, edge_types + k);
+  auto res = euler::GetFullNeighbor(v, et);
+  const int sign = desc ? -1 : 1;
+  if (order_by == 1) {
+    auto cmp = [sign] (IdWeightPair a, IdWeightPair b) {
+      return (std::get<0>(a) <= std::get<0>(b) ? 1 : -1) * sign > 0;
+    };
+    for (auto& item : res) std::sort(item.begin(), item.end(), cmp);
+  } else if (order_by == 2) {
+    auto cmp = [sign] (IdWeightPair a, IdWeightPair b) {
+      return (std::get<1>(a) <= std::get<1>(b) ? 1 : -1) * sign > 0;
+    };
+    for (auto& item : res) std::sort(item.begin(), item.end(), cmp);
+  }
+  if (limit >= 0)
+    for (auto& item : res) if ((int64_t)item.size() > limit) item.resize(limit);
+  int64_t off = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    if (idx) idx[2 * i] = (int32_t)off;
+    for (auto& iw : res[i]) {
+      if (out_id) {
+        out_id[off] = std::get<0>(iw);
+        out_w[off] = std::get<1>(iw);
+        out_t[off] = std::get<2>(iw);
+      }
+      ++off;
+    }
+    if (idx) idx[2 * i + 1] = (int32_t)off;
+  }
+  return off;
+}
+
 // TF RandomWalk (tf_euler/kernels/random_walk_op.cc).  edge_types is
 // [walk_len, k].  |p-1|,|q-1| <= 1e-6 -> TraditionalRandomWalk (:207-247): a
 // chain of count=1 sampleNB hops on the CORE id tensor (sentinel 0 rows walk

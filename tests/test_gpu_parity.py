@@ -567,3 +567,36 @@ def test_dense_feature_vs_goldens_and_oracle(EA, O, torch_cuda, fixture_csr, ran
     got = G.get_dense_feature(torch.as_tensor(q).cuda(), [0, 1], [100, 32])
     assert np.array_equal(t2n(got[0]), want[0]) and np.array_equal(t2n(got[1]), want[1])
     assert np.array_equal(want[0][:-2], val[(q[:-2] - 10), :100])
+
+
+def test_sorted_and_top_k_neighbors(EA, O, torch_cuda, fixture_csr, big_pair):
+    """get_sorted_full_neighbor / get_top_k_neighbor / order_by+limit on device
+    == the reference tests' expectations on the fixture and == the oracle on a
+    20 000-node heterogeneous graph (ties included: both keep storage order)."""
+    torch = torch_cuda
+    G = gpu_graph(EA, fixture_csr)
+    idx, ids, w, t = G.get_sorted_full_neighbor(torch.tensor([1, 2]).cuda(), [0, 1])
+    assert t2n(idx).tolist() == [[0, 3], [3, 5]] and t2n(ids).tolist() == [2, 3, 4, 3, 5]
+    assert t2n(t).tolist() == [0, 1, 0, 1, 1]
+    di, dw, dt = G.get_top_k_neighbor(torch.tensor([1, 2]).cuda(), [0, 1], 2)
+    assert t2n(di).tolist() == [[4, 3], [5, 3]] and t2n(dt).tolist() == [[0, 1], [1, 1]]
+    assert t2n(dw).tolist() == [[4.0, 3.0], [5.0, 3.0]]
+    G, OG, node_ids, rng = big_pair
+    q = np.concatenate([rng.choice(node_ids, 3000), [0, 11]]).astype(np.uint64)
+    qt = torch.as_tensor(q.astype(np.int64)).cuda()
+    for et in ([0, 1, 2, 3], [2], [3, 1]):
+        full = OG.get_full_neighbor(q, et)
+        for order_by, desc, limit in (("id", False, None), ("weight", True, 4),
+                                      ("id", True, 2), ("weight", False, None),
+                                      (None, False, 3)):
+            want = O.neighbor_post_process(*full, order_by=order_by, desc=desc, limit=limit)
+            got = G.get_full_neighbor(qt, et, order_by=order_by, desc=desc, limit=limit)
+            assert np.array_equal(t2n(got[0]), want[0]), (et, order_by, desc, limit)
+            assert np.array_equal(t2n(got[1]).astype(np.uint64), want[1])
+            assert np.array_equal(t2n(got[2]), want[2])
+            assert np.array_equal(t2n(got[3]), want[3])
+        want = O.neighbor_to_dense(*O.neighbor_post_process(*full, order_by="weight",
+                                                            desc=True, limit=6), 6, -9)
+        got = G.get_top_k_neighbor(qt, et, 6, default_node=-9)
+        for x, y in zip(got, want):
+            assert np.array_equal(t2n(x), y)

@@ -272,3 +272,22 @@ def test_dense_feature_goldens(O, fixture_csr, random_csr):
     # the fixture's values are the ones of tools/test_data/graph.json
     fg, F = _golden_features(O, "fx_")
     assert np.allclose(fg["fx_dense_0"][0], [1.1, 1.2])
+
+
+def test_sorted_and_top_k_neighbor_reference_goldens(O, fixture_csr):
+    """tf_euler/python/euler_ops/neighbor_ops_test.py:75-86 (sorted) and
+    :101-109 (top-k) on the reference's fixture graph."""
+    OG = O.OracleGraph(fixture_csr)
+    full = OG.get_full_neighbor(np.array([1, 2], np.uint64), [0, 1])
+    idx, ids, w, t = O.neighbor_post_process(*full, order_by="id")
+    assert idx.tolist() == [[0, 3], [3, 5]]
+    assert ids.tolist() == [2, 3, 4, 3, 5] and t.tolist() == [0, 1, 0, 1, 1]
+    assert w.tolist() == [2.0, 3.0, 4.0, 3.0, 5.0]
+    top = O.neighbor_post_process(*full, order_by="weight", desc=True, limit=2)
+    di, dw, dt = O.neighbor_to_dense(*top, 2, -1)
+    assert di.tolist() == [[4, 3], [5, 3]] and dt.tolist() == [[0, 1], [1, 1]]
+    assert dw.tolist() == [[4.0, 3.0], [5.0, 3.0]]
+    # fewer than k neighbours: default_node / 0.0 / -1 fill (:70-75)
+    top = O.neighbor_post_process(*full, order_by="weight", desc=True, limit=4)
+    di, dw, dt = O.neighbor_to_dense(*top, 4, -1)
+    assert di[1].tolist() == [5, 3, -1, -1] and dt[1].tolist() == [1, 1, -1, -1]

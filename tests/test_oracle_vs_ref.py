@@ -104,3 +104,35 @@ def test_dense_features_match_reference(O):
     b = R.get_dense_feature(q, fids, dims)
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
+
+
+def test_neighbor_post_process_matches_reference_sort(O):
+    """order_by id / weight, asc / desc, limit: restatement == the reference's
+    comparators under std::sort, on rows whose keys are distinct (equal keys
+    have no defined order in the reference: its comparator is `<=`)."""
+    rng = np.random.default_rng(33)
+    n, T = 300, 3
+    ids = np.sort(rng.choice(np.arange(1, 10 ** 6), n, replace=False)).astype(np.uint64)
+    deg = rng.integers(0, 30, size=(n, T))
+    seg = np.zeros(n * T + 1, np.int64)
+    seg[1:] = np.cumsum(deg.reshape(-1))
+    E = int(seg[-1])
+    nbr = np.zeros(E, np.uint64)
+    w = np.zeros(E, np.float32)
+    for i in range(n):          # distinct ids and distinct weights within a row
+        b, e = seg[i * T], seg[(i + 1) * T]
+        nbr[b:e] = rng.choice(ids, e - b, replace=False)
+        w[b:e] = rng.permutation(e - b).astype(np.float32) * 0.37 + 0.5
+    csr = O.csr_from_raw(ids, seg, nbr, w, T)
+    OG = O.OracleGraph(csr)
+    R = O.RefGraph.build_raw(ids, seg, nbr, w, T)
+    q = np.concatenate([rng.choice(ids, 400), [0, 5]]).astype(np.uint64)
+    for et in ([0, 1, 2], [2, 0], [1]):
+        full = OG.get_full_neighbor(q, et)
+        for order_by, desc, limit in (("id", False, None), ("id", True, 3),
+                                      ("weight", True, 5), ("weight", False, None),
+                                      (None, False, 2)):
+            a = O.neighbor_post_process(*full, order_by=order_by, desc=desc, limit=limit)
+            b = R.get_neighbor(q, et, order_by, desc, limit)
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y), (et, order_by, desc, limit)
