@@ -6,4 +6,5 @@ are torch tensors in HBM; the work is done by hand-written HIP kernels behind
 the C ABI of include/euler_gpu.h.  There is no CPU fallback."""
 from .graph import Graph, synth_params            # noqa: F401
 from . import ops                                 # noqa: F401
+from . import dataflow                            # noqa: F401
 from .euler_ops import *                          # noqa: F401,F403

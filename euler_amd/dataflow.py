@@ -1,0 +1,116 @@
+"""Minibatch block construction on the GPU: tf_euler/python/dataflow
+(`base_dataflow.py:22-51`, `neighbor_dataflow.py:22-110`, `sage_dataflow.py:
+20-50`) with the sampler and `tf.unique` replaced by the HIP kernels of this
+package (sample_neighbor, ID_UNIQUE in first-occurrence order).  Everything
+stays in HBM; the only host round trip per hop is the unique count (the shape of
+the next hop), exactly where TensorFlow has a dynamic shape.
+
+    flow = SageDataFlow(graph, fanouts=[10, 5], metapath=[[0], [0]], max_id=N)
+    df = flow(roots)            # DataFlow: blocks from the outermost hop inwards
+    for block in df: block.n_id, block.res_n_id, block.edge_index, block.size
+"""
+import torch
+
+from . import ops
+
+
+class Block(object):
+    """base_dataflow.py:22-28."""
+
+    def __init__(self, n_id, res_n_id, e_id, edge_index, size):
+        self.n_id = n_id
+        self.res_n_id = res_n_id
+        self.e_id = e_id
+        self.edge_index = edge_index
+        self.size = size
+
+
+class DataFlow(object):
+    """base_dataflow.py:31-51."""
+
+    def __init__(self, n_id):
+        self.n_id = n_id
+        self.__last_n_id__ = n_id
+        self.blocks = []
+
+    def append(self, n_id, res_n_id, e_id, edge_index):
+        size = [int(self.__last_n_id__.shape[0]), int(n_id.shape[0])]
+        self.blocks.append(Block(n_id, res_n_id, e_id, edge_index, size))
+        self.__last_n_id__ = n_id
+
+    def __len__(self):
+        return len(self.blocks)
+
+    def __getitem__(self, idx):
+        return self.blocks[::-1][idx]
+
+    def __iter__(self):
+        for block in self.blocks[::-1]:
+            yield block
+
+
+def _unique(ids):
+    """tf.unique: (values in first-occurrence order, index of every input)."""
+    uq, inv = ops.id_unique(ids)
+    return uq, inv.to(torch.int64)
+
+
+class UniqueDataFlow(object):
+    """neighbor_dataflow.py:78-110 (UniqueDataFlow.produce_subgraph)."""
+
+    def __init__(self, num_hops, add_self_loops=True):
+        self.num_hops = num_hops
+        self.add_self_loops = add_self_loops
+
+    def get_neighbors(self, n_id):
+        raise NotImplementedError()
+
+    def produce_subgraph(self, n_id):
+        n_id = n_id.reshape(-1)
+        dev = n_id.device
+        last_idx = torch.arange(n_id.numel(), device=dev)
+        data_flow = DataFlow(n_id)
+        n_neighbors, n_edge_src = self.get_neighbors(n_id)
+        for i in range(self.num_hops):
+            edge_src = n_edge_src[i]
+            n_prev = n_id.numel()
+            new_n_id, new_inv = _unique(torch.cat([n_neighbors[i], n_id]))
+            res_n_id = new_inv[new_inv.numel() - n_prev:]
+            if self.add_self_loops:
+                edge_src = torch.cat([edge_src, last_idx])
+                last_idx = torch.arange(new_n_id.numel(), device=dev)
+            else:
+                new_inv = new_inv[:new_inv.numel() - n_prev]
+                last_idx = new_inv
+            n_id = new_n_id
+            edge_index = torch.stack([edge_src, new_inv], 0)
+            data_flow.append(new_n_id, res_n_id, None, edge_index)
+        return data_flow
+
+    def __call__(self, n_id):
+        return self.produce_subgraph(n_id)
+
+
+class SageDataFlow(UniqueDataFlow):
+    """sage_dataflow.py:20-50: every hop samples `count` neighbours of the
+    nodes seen so far (a unique set), default_node = max_id + 1."""
+
+    def __init__(self, graph, fanouts, metapath, add_self_loops=True, max_id=-1):
+        super(SageDataFlow, self).__init__(len(metapath), add_self_loops)
+        self.graph = graph
+        self.fanouts = fanouts
+        self.metapath = metapath
+        self.max_id = max_id
+
+    def get_neighbors(self, n_id):
+        neighbors, neighbor_src = [], []
+        for hop_edge_types, count in zip(self.metapath, self.fanouts):
+            n_id = n_id.reshape(-1)
+            one_neighbor, _w, _t = self.graph.sample_neighbor(
+                n_id, hop_edge_types, count, default_node=self.max_id + 1)
+            new_n_id = one_neighbor.reshape(-1)
+            neighbors.append(new_n_id)
+            neighbor_src.append(torch.arange(n_id.numel(), device=n_id.device)
+                                .repeat_interleave(count))
+            n_id, _ = _unique(torch.cat([new_n_id, n_id]))
+        return neighbors, neighbor_src

@@ -2,7 +2,8 @@
 from . import base, type_ops
 
 __all__ = ["sample_neighbor", "sample_fanout", "get_full_neighbor",
-           "get_sorted_full_neighbor", "get_top_k_neighbor", "to_sparse"]
+           "get_sorted_full_neighbor", "get_top_k_neighbor", "to_sparse",
+           "sample_fanout_with_feature"]
 
 
 def sample_neighbor(nodes, edge_types, count, default_node=-1, condition=''):
@@ -66,3 +67,24 @@ def to_sparse(idx, values):
     width = int(lens.max().item()) if n else 0
     return (torch.stack([rows, cols], dim=1), values,
             torch.tensor([n, width], dtype=torch.int64))
+
+
+def sample_fanout_with_feature(nodes, edge_types, count, default_node,
+                               dense_feature_names, dense_dimensions,
+                               sparse_feature_names=(), sparse_default_values=()):
+    """sample_fanout + the dense features of every layer's nodes in one call
+    (neighbor_ops.py:49-70 over tf_euler/kernels/sample_fanout_with_feature_op.cc):
+    returns (neighbors, weights, types, dense_features, sparse_features) with
+    dense_features[layer * len(names) + j] = feature j of layer `layer`'s nodes
+    (layer 0 = the roots), as the op lays its outputs out (:135-178,233).
+    Sparse (uint64) features are out of scope: the list must be empty."""
+    if len(sparse_feature_names):
+        raise NotImplementedError("sparse features are out of scope (SURVEY §8f)")
+    g = base.get_default_graph()
+    ets = [type_ops.get_edge_type_id(et) for et in edge_types]
+    neighbors, weights, types = g.sample_fanout(nodes, ets, count, default_node)
+    fids = [int(str(f)) for f in dense_feature_names]
+    dense = []
+    for layer_nodes in neighbors:
+        dense.extend(g.get_dense_feature(layer_nodes, fids, list(dense_dimensions)))
+    return neighbors, weights, types, dense, []

@@ -600,3 +600,46 @@ def test_sorted_and_top_k_neighbors(EA, O, torch_cuda, fixture_csr, big_pair):
         got = G.get_top_k_neighbor(qt, et, 6, default_node=-9)
         for x, y in zip(got, want):
             assert np.array_equal(t2n(x), y)
+
+
+def test_sage_dataflow_blocks(EA, O, torch_cuda, big_pair):
+    """SageDataFlow on device == the same composition on the oracle
+    (sample_neighbor of the unique frontier, tf.unique = first-occurrence
+    ID_UNIQUE, edge_index / res_n_id arithmetic of neighbor_dataflow.py:84-110)."""
+    torch = torch_cuda
+    G, OG, ids, rng = big_pair
+    roots = rng.choice(ids, 64).astype(np.int64)
+    fanouts, metapath, max_id = [4, 3], [[0, 1], [2]], 10 ** 13
+    G.set_seed(77, call_id=500)
+    flow = EA.dataflow.SageDataFlow(G, fanouts, metapath, add_self_loops=True, max_id=max_id)
+    df = flow(torch.as_tensor(roots).cuda())
+
+    def uniq(a):
+        uq, gi = O.id_unique(a.astype(np.uint64))
+        return uq.astype(np.int64), gi.astype(np.int64)
+
+    # oracle composition (call ids 500, 501 in get_neighbors)
+    n_id = roots.copy()
+    nbrs, srcs = [], []
+    for h, (et, c) in enumerate(zip(metapath, fanouts)):
+        nb, _, _ = OG.sample_neighbor(77, 500 + h, n_id, et, c, max_id + 1)
+        nbrs.append(nb.reshape(-1))
+        srcs.append(np.repeat(np.arange(len(n_id)), c))
+        n_id, _ = uniq(np.concatenate([nb.reshape(-1), n_id]))
+    n_id = roots.copy()
+    last_idx = np.arange(len(n_id))
+    want = []
+    for i in range(2):
+        new_n_id, inv = uniq(np.concatenate([nbrs[i], n_id]))
+        res = inv[-len(n_id):]
+        src = np.concatenate([srcs[i], last_idx])
+        last_idx = np.arange(len(new_n_id))
+        want.append((new_n_id, res, np.stack([src, inv]), [len(n_id), len(new_n_id)]))
+        n_id = new_n_id
+    assert len(df) == 2
+    for blk, (wn, wr, we, ws) in zip(df.blocks, want):
+        assert np.array_equal(t2n(blk.n_id), wn)
+        assert np.array_equal(t2n(blk.res_n_id), wr)
+        assert np.array_equal(t2n(blk.edge_index), we)
+        assert blk.size == ws
+    assert [b.size for b in df] == [w[3] for w in want][::-1]
