@@ -52,6 +52,9 @@ def parse():
                     help="graph size of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the multi-GPU sampler (unique / split / all-to-all / "
+                         "merge / gather) even on one rank: measures its overhead")
     return ap.parse_args()
 
 
@@ -104,8 +107,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=dev)
 
@@ -130,7 +135,7 @@ def main():
     et = [[0], [0]]
     default_node = args.nodes + 1
 
-    if world > 1:
+    if sharded:
         from euler_amd.distributed import gpu_sharded_sampler
         S = gpu_sharded_sampler(G, partitions=world)
 
@@ -141,7 +146,7 @@ def main():
             return G.sample_fanout(roots[i], et, FANOUT, default_node, call_id=2 * i)
 
     def sync():
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -283,14 +288,15 @@ def main():
                 "roots_per_step_per_gpu": B, "fanout": FANOUT,
                 "graph_bytes_per_gpu": G.device_bytes,
                 "graph_build_s": round(build_s, 2),
-                "partitioning": "none" if world == 1 else
+                "partitioning": ("none" if not sharded else "sharded sampler on 1 rank")
+                                if world == 1 else
                                 "hash owner(id)=id%%%d, all-to-all per hop" % world,
                 "parity_checked_edges": checked,
             },
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
 

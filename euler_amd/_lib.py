@@ -104,6 +104,17 @@ SIGNATURES = {
                                                        C.POINTER(C.c_double)]),
     "euler_gpu_set_tuning": (C.c_int, [C.c_int32, C.c_int32]),
     "euler_gpu_graph_num_float_features": (C.c_int32, [vp]),
+    "euler_gpu_sample_neighbor_distinct": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp,
+                                                     C.c_int64, i32p, C.c_int32,
+                                                     C.c_int32, C.c_int32, C.c_int64, vp,
+                                                     vp, vp, vp]),
+    "euler_gpu_dedup_split": (C.c_int, [vp, vp, C.c_int64, vp, C.c_int32, C.c_int32,
+                                        C.c_int32, C.POINTER(C.c_int64), vp, vp]),
+    "euler_gpu_pack_rows": (C.c_int, [vp, vp, vp, vp, vp, C.c_int64, C.c_int32, vp]),
+    "euler_gpu_expand_packed": (C.c_int, [vp, vp, C.c_int64, C.c_int32, vp, vp, vp, vp,
+                                          vp]),
+    "euler_gpu_expand_rows": (C.c_int, [vp, vp, C.c_int64, C.c_int32, vp, vp, vp, vp,
+                                        vp, vp, vp, vp]),
     "euler_gpu_neighbor_post_process": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, vp, vp,
                                                   C.c_int32, C.c_int32, C.c_int64,
                                                   C.POINTER(C.c_int64)]),

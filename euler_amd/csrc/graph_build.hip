@@ -172,6 +172,17 @@ int BuildBlockedIndex(GraphBuilder* b) {
 
 std::mutex g_blocked_mu;
 
+// Stream-ordered scratch (hipMallocAsync) is used per call by several entry
+// points; keep freed blocks in the pool instead of returning them to the
+// driver at every synchronisation (the default threshold is 0).
+void KeepPoolMemory(int device) {
+  hipMemPool_t pool;
+  if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
+    uint64_t keep = ~0ULL;
+    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+  }
+}
+
 void DestroyGraph(euler_gpu_graph* g) {
   if (!g) return;
   (void)hipSetDevice(g->device);
@@ -301,6 +312,7 @@ int BuildGraphFromHost(const euler_gpu_host_csr* c, int device,
       keep.push_back(r);
   }
   const int64_t n = (int64_t)keep.size();
+  KeepPoolMemory(device);
   GraphBuilder b;
   b.g->device = device;
   GraphView& v = b.g->view;
@@ -590,6 +602,7 @@ int BuildGraphSynthetic(const euler_gpu_synth_params* sp, int device,
   const int64_t n_rows =
       base > (uint64_t)sp->n_nodes ? 0
                                    : (int64_t)(((uint64_t)sp->n_nodes - base) / stride + 1);
+  KeepPoolMemory(device);
   GraphBuilder b;
   b.g->device = device;
   GraphView& v = b.g->view;

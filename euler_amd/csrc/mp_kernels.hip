@@ -743,6 +743,169 @@ int euler_gpu_id_split(void* stream, const uint64_t* ids_dev, int64_t n,
   return EULER_GPU_OK;
 }
 
+// ------------------------------------------------------------------------
+// Front end of a multi-GPU hop: the distinct ids of a batch, bucketed by owner
+// (ID_UNIQUE then ID_SPLIT, parser/compiler.cc:76-90 + core/kernels/
+// id_split_op.cc), plus for every input position the index of its id in the
+// bucketed array - so the rows that come back from the shards (in the order the
+// ids were sent) expand straight to positions, without a merge pass.
+// Duplicates are found without atomics (see sample_kernels.hip, DedupArgs):
+// owner[hash(id)] = position by plain stores, the survivor of a slot represents
+// every position whose id equals its own; a position that lost its slot to a
+// DIFFERENT id simply represents itself (its duplicates are then not merged:
+// more rows on the wire, same result).  Two rounds (two tables of 4x the batch,
+// two hashes) leave ~0.01 % of the distinct ids in that state.
+// ------------------------------------------------------------------------
+struct DedupIdsArgs {
+  const uint64_t* ids;
+  const uint8_t* root_mask;   // optional: a set byte makes its group sample as id 0
+  int32_t root_group;
+  int32_t pad;
+  int64_t n;
+  uint32_t mask;
+  uint32_t* owner;     // [mask + 1]
+  uint32_t* owner2;    // [mask + 1] second round (stale entries are checked by id)
+  uint32_t* pos;       // [n + 1] exclusive scan of the representative flags
+  uint64_t* uniq;      // [<= n]
+  uint32_t* u_of;      // [n] index into uniq of every position
+};
+
+__device__ __forceinline__ uint64_t DedupIdAt(const DedupIdsArgs& a, int64_t i) {
+  if (a.root_mask != nullptr && a.root_mask[i / a.root_group]) return 0;
+  return a.ids[i];
+}
+
+__device__ __forceinline__ uint32_t DedupSlot2(uint64_t id, uint32_t mask) {
+  return (uint32_t)(Mix64(id ^ 0x9E3779B97F4A7C15ULL) >> 20) & mask;
+}
+
+// Representative of position i: the survivor of its first-round slot if that
+// is the same id, else the survivor of its second-round slot (a second table,
+// a second hash, written only by first-round losers), else i itself.
+__device__ __forceinline__ uint32_t DedupRep(const DedupIdsArgs& a, uint32_t i) {
+  const uint64_t id = DedupIdAt(a, i);
+  const uint32_t o = a.owner[(uint32_t)Mix64(id) & a.mask];
+  if (DedupIdAt(a, o) == id) return o;
+  const uint32_t o2 = a.owner2[DedupSlot2(id, a.mask)];
+  return (o2 < (uint32_t)a.n && DedupIdAt(a, o2) == id) ? o2 : i;
+}
+
+__global__ __launch_bounds__(256) void DedupIdsMarkKernel(const DedupIdsArgs a) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride)
+    a.owner[(uint32_t)Mix64(DedupIdAt(a, i)) & a.mask] = (uint32_t)i;
+}
+
+// second round: positions whose slot went to a different id try another slot
+__global__ __launch_bounds__(256) void DedupIdsMark2Kernel(const DedupIdsArgs a) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+    const uint64_t id = DedupIdAt(a, i);
+    const uint32_t o = a.owner[(uint32_t)Mix64(id) & a.mask];
+    if (DedupIdAt(a, o) != id) a.owner2[DedupSlot2(id, a.mask)] = (uint32_t)i;
+  }
+}
+
+struct DedupIdsFlagOp {
+  DedupIdsArgs a;
+  __device__ __forceinline__ uint32_t operator()(const uint32_t& i) const {
+    return ((int64_t)i < a.n && DedupRep(a, i) == i) ? 1u : 0u;
+  }
+};
+
+__global__ __launch_bounds__(256) void DedupIdsIndexKernel(const DedupIdsArgs a) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+    const uint32_t rep = DedupRep(a, (uint32_t)i);
+    a.u_of[i] = a.pos[rep];
+    if (rep == (uint32_t)i) a.uniq[a.pos[i]] = DedupIdAt(a, i);
+  }
+}
+
+__global__ void InvertIdxKernel(const int32_t* merge_idx, int64_t m, int32_t* inv) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < m) inv[merge_idx[j]] = (int32_t)j;
+}
+
+__global__ void ComposeIdxKernel(const uint32_t* u_of, const int32_t* inv, int64_t n,
+                                 int32_t* pos_out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    pos_out[i] = inv[u_of[i]];
+}
+
+int euler_gpu_dedup_split(void* stream, const uint64_t* ids_dev, int64_t n,
+                          const uint8_t* root_mask_dev, int32_t root_group,
+                          int32_t partitions, int32_t shards, int64_t* shard_off_host,
+                          uint64_t* shard_ids_dev, int32_t* pos_dev) {
+  if (n < 0 || partitions <= 0 || shards <= 0 || shards > kMaxShards || !shard_off_host)
+    return Fail(EULER_GPU_EINVAL, "dedup_split: bad arguments (shards <= 64)");
+  for (int s = 0; s <= shards; ++s) shard_off_host[s] = 0;
+  if (n == 0) return EULER_GPU_OK;
+  if (n >= (1LL << 30)) return Fail(EULER_GPU_EINVAL, "dedup_split: n >= 2^30");
+  if (!ids_dev || !shard_ids_dev || !pos_dev)
+    return Fail(EULER_GPU_EINVAL, "dedup_split: null buffer");
+  hipStream_t st = (hipStream_t)stream;
+  uint64_t cap = 1024;
+  while (cap < (uint64_t)n * 4) cap <<= 1;
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  DedupIdsArgs a{};
+  a.ids = ids_dev; a.n = n; a.mask = (uint32_t)(cap - 1);
+  a.root_mask = root_mask_dev; a.root_group = root_group > 0 ? root_group : 1;
+  hipcub::CountingInputIterator<uint32_t> pos_it(0u);
+  size_t scan_bytes = 0;
+  {
+    hipcub::TransformInputIterator<uint32_t, DedupIdsFlagOp,
+                                   hipcub::CountingInputIterator<uint32_t>>
+        flag_it(pos_it, DedupIdsFlagOp{a});
+    EG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, flag_it,
+                                            (uint32_t*)nullptr, (int)(n + 1), st));
+  }
+  const size_t o_owner = 0, o_owner2 = o_owner + al(cap * 4);
+  const size_t o_pos = o_owner2 + al(cap * 4);
+  const size_t o_uniq = o_pos + al((size_t)(n + 1) * 4);
+  const size_t o_uof = o_uniq + al((size_t)n * 8);
+  const size_t o_midx = o_uof + al((size_t)n * 4);
+  const size_t o_inv = o_midx + al((size_t)n * 4);
+  const size_t o_scan = o_inv + al((size_t)n * 4);
+  const size_t bytes = o_scan + al(scan_bytes);
+  uint8_t* buf = nullptr;
+  EG_HIP(hipMallocAsync((void**)&buf, bytes, st));
+  a.owner = (uint32_t*)(buf + o_owner);
+  a.owner2 = (uint32_t*)(buf + o_owner2);
+  a.pos = (uint32_t*)(buf + o_pos);
+  a.uniq = (uint64_t*)(buf + o_uniq);
+  a.u_of = (uint32_t*)(buf + o_uof);
+  int32_t* merge_idx = (int32_t*)(buf + o_midx);
+  int32_t* inv = (int32_t*)(buf + o_inv);
+  const int block = 256;
+  const int grid = GridFor(n, block);
+  hipLaunchKernelGGL(DedupIdsMarkKernel, dim3(grid), dim3(block), 0, st, a);
+  hipLaunchKernelGGL(DedupIdsMark2Kernel, dim3(grid), dim3(block), 0, st, a);
+  {
+    hipcub::TransformInputIterator<uint32_t, DedupIdsFlagOp,
+                                   hipcub::CountingInputIterator<uint32_t>>
+        flag_it(pos_it, DedupIdsFlagOp{a});
+    EG_HIP(hipcub::DeviceScan::ExclusiveSum(buf + o_scan, scan_bytes, flag_it, a.pos,
+                                            (int)(n + 1), st));
+  }
+  hipLaunchKernelGGL(DedupIdsIndexKernel, dim3(grid), dim3(block), 0, st, a);
+  uint32_t n_unique = 0;
+  EG_HIP(hipMemcpyAsync(&n_unique, a.pos + n, 4, hipMemcpyDeviceToHost, st));
+  EG_HIP(hipStreamSynchronize(st));
+  int rc = euler_gpu_id_split(stream, a.uniq, (int64_t)n_unique, partitions, shards,
+                              shard_off_host, shard_ids_dev, merge_idx);
+  if (rc == EULER_GPU_OK) {
+    hipLaunchKernelGGL(InvertIdxKernel, dim3((n_unique + block - 1) / block), dim3(block),
+                       0, st, merge_idx, (int64_t)n_unique, inv);
+    hipLaunchKernelGGL(ComposeIdxKernel, dim3(grid), dim3(block), 0, st, a.u_of, inv, n,
+                       pos_dev);
+    if (hipGetLastError() != hipSuccess) rc = Fail(EULER_GPU_EHIP, "dedup_split: launch failed");
+  }
+  (void)hipFreeAsync(buf, st);
+  return rc;
+}
+
 int euler_gpu_merge_rows(void* stream, const void* in_dev,
                          const int32_t* merge_idx_dev, int64_t n_rows,
                          int64_t row_bytes, void* out_dev) {

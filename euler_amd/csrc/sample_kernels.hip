@@ -1871,6 +1871,20 @@ int euler_gpu_sample_neighbor(const euler_gpu_graph* g, void* stream,
                               out_t_dev, out_row_mask_dev);
 }
 
+int euler_gpu_sample_neighbor_distinct(const euler_gpu_graph* g, void* stream,
+                                       uint64_t seed, uint32_t call_id,
+                                       const uint64_t* roots_dev, int64_t n,
+                                       const int32_t* edge_types_host, int32_t k,
+                                       int32_t count, int32_t layout,
+                                       int64_t default_node, uint64_t* out_id_dev,
+                                       float* out_w_dev, int32_t* out_t_dev,
+                                       uint8_t* out_row_mask_dev) {
+  return LaunchSampleNeighbor(g, (hipStream_t)stream, seed, call_id, roots_dev, n,
+                              nullptr, 1, edge_types_host, k, count, layout,
+                              default_node, out_id_dev, out_w_dev, out_t_dev,
+                              out_row_mask_dev, /*dedup=*/0);
+}
+
 size_t euler_gpu_sample_fanout_workspace(int64_t n, const int32_t* counts_host,
                                          int32_t layers) {
   // one mask byte per root of every hop (16-byte aligned slices)
@@ -2120,6 +2134,142 @@ int euler_gpu_time_sample_neighbor(const euler_gpu_graph* g, void* stream,
   EG_HIP(hipEventDestroy(e0));
   EG_HIP(hipEventDestroy(e1));
   *mean_ms_host = ms / (float)iters;
+  return EULER_GPU_OK;
+}
+
+// ------------------------------------------------------------------------
+// Wire format of the multi-GPU result exchange: one row of 4*count + 2 int32
+// words per root = [count ids (2 words each) | count weights | count types |
+// mask | pad], so that one all-to-all moves everything a hop returns and every
+// row starts 8-byte aligned.  PackRows writes it from the sampler's outputs;
+// ExpandPacked reads it back per POSITION through `pos` (merge + gather +
+// unpack in one pass).
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void PackRowsKernel(
+    const uint64_t* __restrict__ ids, const float* __restrict__ w,
+    const int32_t* __restrict__ t, const uint8_t* __restrict__ mask, int64_t m,
+    int32_t count, int32_t* __restrict__ packed) {
+  const int32_t words = 4 * count + 2;
+  const int64_t total = m * (int64_t)words;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total;
+       s += stride) {
+    const int64_t r = s / words;
+    const int32_t c = (int32_t)(s - r * words);
+    int32_t v;
+    if (c < 2 * count) v = reinterpret_cast<const int32_t*>(ids)[r * 2 * count + c];
+    else if (c < 3 * count) v = __float_as_int(w[r * count + (c - 2 * count)]);
+    else if (c < 4 * count) v = t[r * count + (c - 3 * count)];
+    else v = c == 4 * count ? (int32_t)mask[r] : 0;
+    packed[s] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void ExpandPackedKernel(
+    const int32_t* __restrict__ pos, const int32_t* __restrict__ packed, int64_t n,
+    int32_t count, uint64_t* __restrict__ out_id, float* __restrict__ out_w,
+    int32_t* __restrict__ out_t, uint8_t* __restrict__ out_mask,
+    const int64_t stride_rows, const int32_t stride_slots) {
+  const int32_t words = 4 * count + 2;
+  const int64_t total = n * (int64_t)count;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= total) return;
+  int64_t i = s / count;
+  int32_t j = (int32_t)(s - i * count);
+  for (; s < total; s += stride) {
+    const int32_t* row = packed + (int64_t)pos[i] * words;
+    const uint64_t id = *reinterpret_cast<const uint64_t*>(row + 2 * j);
+    __builtin_nontemporal_store(id, out_id + s);
+    __builtin_nontemporal_store(__int_as_float(row[2 * count + j]), out_w + s);
+    __builtin_nontemporal_store(row[3 * count + j], out_t + s);
+    if (j == 0 && out_mask != nullptr) out_mask[i] = (uint8_t)row[4 * count];
+    i += stride_rows;
+    j += stride_slots;
+    if (j >= count) { j -= count; ++i; }
+  }
+}
+
+int euler_gpu_pack_rows(void* stream, const uint64_t* id_dev, const float* w_dev,
+                        const int32_t* t_dev, const uint8_t* mask_dev, int64_t m,
+                        int32_t count, int32_t* packed_dev) {
+  if (m < 0 || count <= 0) return Fail(EULER_GPU_EINVAL, "pack_rows: bad m/count");
+  if (m == 0) return EULER_GPU_OK;
+  if (!id_dev || !w_dev || !t_dev || !mask_dev || !packed_dev)
+    return Fail(EULER_GPU_EINVAL, "pack_rows: null buffer");
+  const int block = 256;
+  hipLaunchKernelGGL(PackRowsKernel, dim3(GridFor(m * (4LL * count + 2), block)),
+                     dim3(block), 0, (hipStream_t)stream, id_dev, w_dev, t_dev, mask_dev,
+                     m, count, packed_dev);
+  EG_HIP(hipGetLastError());
+  return EULER_GPU_OK;
+}
+
+int euler_gpu_expand_packed(void* stream, const int32_t* pos_dev, int64_t n,
+                            int32_t count, const int32_t* packed_dev,
+                            uint64_t* out_id_dev, float* out_w_dev, int32_t* out_t_dev,
+                            uint8_t* out_mask_dev) {
+  if (n < 0 || count <= 0) return Fail(EULER_GPU_EINVAL, "expand_packed: bad n/count");
+  if (n == 0) return EULER_GPU_OK;
+  if (!pos_dev || !packed_dev || !out_id_dev || !out_w_dev || !out_t_dev)
+    return Fail(EULER_GPU_EINVAL, "expand_packed: null buffer");
+  const int block = 256;
+  int64_t blocks = ((int64_t)n * count + block - 1) / block;
+  if (blocks > kK1GridCap) blocks = kK1GridCap;
+  const int64_t stride = blocks * block;
+  const int64_t stride_rows = stride / count;
+  const int32_t stride_slots = (int32_t)(stride - stride_rows * count);
+  hipLaunchKernelGGL(ExpandPackedKernel, dim3((int)blocks), dim3(block), 0,
+                     (hipStream_t)stream, pos_dev, packed_dev, n, count, out_id_dev,
+                     out_w_dev, out_t_dev, out_mask_dev, stride_rows, stride_slots);
+  EG_HIP(hipGetLastError());
+  return EULER_GPU_OK;
+}
+
+int euler_gpu_expand_rows(void* stream, const int32_t* pos_dev, int64_t n,
+                          int32_t count, const uint64_t* row_id_dev,
+                          const float* row_w_dev, const int32_t* row_t_dev,
+                          const uint8_t* row_mask_dev, uint64_t* out_id_dev,
+                          float* out_w_dev, int32_t* out_t_dev, uint8_t* out_mask_dev) {
+  if (n < 0 || count < 0) return Fail(EULER_GPU_EINVAL, "expand_rows: bad n/count");
+  if (n == 0 || count == 0) return EULER_GPU_OK;
+  if (!pos_dev || !row_id_dev || !row_w_dev || !row_t_dev || !out_id_dev ||
+      !out_w_dev || !out_t_dev || (out_mask_dev && !row_mask_dev))
+    return Fail(EULER_GPU_EINVAL, "expand_rows: null buffer");
+  hipStream_t st = (hipStream_t)stream;
+  // DedupExpandKernel gates on a device-side counter: give it one that says
+  // "expand" (0 distinct roots * 4 <= n * 3)
+  uint32_t* zero = nullptr;
+  EG_HIP(hipMallocAsync((void**)&zero, 16, st));
+  EG_HIP(hipMemsetAsync(zero, 0, 16, st));
+  ExpandArgs x{};
+  x.counter = zero;
+  x.uidx_of = reinterpret_cast<const uint32_t*>(pos_dev);
+  x.t_id = row_id_dev; x.t_w = row_w_dev; x.t_t = row_t_dev; x.t_mask = row_mask_dev;
+  x.out_id = out_id_dev; x.out_w = out_w_dev; x.out_t = out_t_dev;
+  x.out_mask = out_mask_dev;
+  x.n = n; x.count = count;
+  const int block = 256;
+  const bool pair = count % 2 == 0 && ((uintptr_t)out_id_dev % 16 == 0) &&
+                    ((uintptr_t)out_w_dev % 8 == 0) && ((uintptr_t)out_t_dev % 8 == 0) &&
+                    ((uintptr_t)row_id_dev % 16 == 0) && ((uintptr_t)row_w_dev % 8 == 0) &&
+                    ((uintptr_t)row_t_dev % 8 == 0);
+  const int U = pair ? 2 : 1;
+  int64_t blocks = ((int64_t)n * count / U + block - 1) / block;
+  if (blocks > kK1GridCap) blocks = kK1GridCap;
+  if (blocks < 1) blocks = 1;
+  const int64_t stride = blocks * block * U;
+  const int64_t stride_rows = stride / count;
+  const int32_t stride_slots = (int32_t)(stride - stride_rows * count);
+  if (pair) {
+    hipLaunchKernelGGL(DedupExpandKernel<2>, dim3((int)blocks), dim3(block), 0, st, x,
+                       stride_rows, stride_slots);
+  } else {
+    hipLaunchKernelGGL(DedupExpandKernel<1>, dim3((int)blocks), dim3(block), 0, st, x,
+                       stride_rows, stride_slots);
+  }
+  EG_HIP(hipGetLastError());
+  EG_HIP(hipFreeAsync(zero, st));
   return EULER_GPU_OK;
 }
 

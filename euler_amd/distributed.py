@@ -48,7 +48,8 @@ class ShardedSampler:
     """
 
     def __init__(self, local_sample, split_fn, merge_fn, partitions=None,
-                 group=None, unique_fn=None, gather_fn=None):
+                 group=None, unique_fn=None, gather_fn=None, dedup_split_fn=None,
+                 expand_fn=None):
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
@@ -58,6 +59,14 @@ class ShardedSampler:
         self.merge_fn = merge_fn
         self.unique_fn = unique_fn
         self.gather_fn = gather_fn
+        # fused front end / back end (one call each): dedup_split_fn(ids,
+        # partitions, shards) -> (shard_off, distinct ids bucketed by owner,
+        # pos [n]); expand_fn(pos, ids, w, t, mask, count) -> rows per position
+        self.dedup_split_fn = dedup_split_fn
+        self.expand_fn = expand_fn
+        # wire format hooks of the fused path (HIP kernels on GPUs): pack_fn(ids,
+        # w, t, mask, count) -> int32 rows; expand_fn(pos, rows, count) -> outputs
+        self.pack_fn = None
 
     # -------------------------------------------------------------- helpers
     def _exchange(self, send, send_counts, recv_counts):
@@ -109,15 +118,23 @@ class ShardedSampler:
         so the wire carries the distinct ones only."""
         roots = roots.reshape(-1).to(torch.int64)
         n = roots.numel()
-        if root_mask is not None:
-            expand = root_mask.to(torch.bool).repeat_interleave(root_group)[:n]
-            roots = torch.where(expand, torch.zeros_like(roots), roots)
         gather_idx = None
-        if self.unique_fn is not None and n > 0:
-            roots, gather_idx = self.unique_fn(roots)
-        # C1: bucket by owner, tell every peer how many ids it gets
-        shard_off, shard_ids, merge_idx = self.split_fn(roots, self.partitions,
-                                                        self.world)
+        fused = self.dedup_split_fn is not None and self.expand_fn is not None and n > 0
+        if fused:
+            # C1 (fused): distinct ids bucketed by owner + where each position's
+            # row will sit among the answers (the root mask is applied inside)
+            shard_off, shard_ids, pos = self.dedup_split_fn(
+                roots, self.partitions, self.world, root_mask, root_group)
+            merge_idx = None
+        else:
+            if root_mask is not None:
+                expand = root_mask.to(torch.bool).repeat_interleave(root_group)[:n]
+                roots = torch.where(expand, torch.zeros_like(roots), roots)
+            if self.unique_fn is not None and n > 0:
+                roots, gather_idx = self.unique_fn(roots)
+            # C1: bucket by owner, tell every peer how many ids it gets
+            shard_off, shard_ids, merge_idx = self.split_fn(roots, self.partitions,
+                                                            self.world)
         send_counts = [int(shard_off[s + 1] - shard_off[s]) for s in range(self.world)]
         sc = torch.tensor(send_counts, dtype=torch.int64, device=roots.device)
         rc = torch.empty_like(sc)
@@ -128,8 +145,17 @@ class ShardedSampler:
         ids, w, t, mask = self.local_sample(owned, edge_types, count, default_node,
                                             call_id)
         # C2: results travel back along the reversed split, one packed row each
+        if fused and self.pack_fn is not None:
+            back = self._exchange(self.pack_fn(ids, w, t, mask, count), recv_counts,
+                                  send_counts)
+            # the shards answered in the order they were asked: row pos[i] of
+            # `back` is position i's row (merge + gather + unpack in one pass)
+            return self.expand_fn(pos, back, count)
         back = self._exchange(self._pack(ids, w, t, mask, count), recv_counts,
                               send_counts)
+        if fused:
+            b_ids, b_w, b_t, b_mask = self._unpack(back, count)
+            return self.expand_fn(pos, b_ids, b_w, b_t, b_mask, count)
         # IDX_MERGE / DATA_MERGE: out[merge_idx[j]] = back[j]
         rows = self.merge_fn(back, merge_idx)
         if gather_idx is not None:                 # DATA_GATHER back to positions
@@ -172,18 +198,28 @@ class ShardedSampler:
 
 
 def gpu_sharded_sampler(graph, partitions=None, group=None, dedup=True):
-    """ShardedSampler over an euler_amd.Graph shard living on this rank's GPU."""
+    """ShardedSampler over an euler_amd.Graph shard living on this rank's GPU.
+    dedup: True / "fused" = one-call front end (euler_gpu_dedup_split) and back end
+    (euler_gpu_expand_rows); "ops" = ID_UNIQUE / ID_SPLIT / merge / gather as separate
+    kernels; False = no duplicate removal."""
     from . import ops
 
     def local_sample(owned, edge_types, count, default_node, call_id):
         ids, w, t, mask = graph.sample_neighbor(owned, edge_types, count,
                                                 default_node, layout="tf",
-                                                call_id=call_id, return_mask=True)
+                                                call_id=call_id, return_mask=True,
+                                                dedup=not bool(dedup))
         return ids, w, t, mask
 
     def gather_rows(rows, gather_idx):
         # MPGather kernel on the int32 rows viewed as f32 words (a bit copy)
         return ops.gather(rows.view(torch.float32), gather_idx).view(torch.int32)
 
-    return ShardedSampler(local_sample, ops.id_split, ops.merge_rows, partitions,
-                          group, ops.id_unique if dedup else None, gather_rows)
+    fused = dedup == "fused" or dedup is True
+    S = ShardedSampler(local_sample, ops.id_split, ops.merge_rows, partitions,
+                       group, ops.id_unique if dedup else None, gather_rows,
+                       ops.dedup_split if fused else None,
+                       ops.expand_packed if fused else None)
+    if fused:
+        S.pack_fn = ops.pack_rows
+    return S

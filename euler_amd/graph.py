@@ -239,7 +239,7 @@ class Graph:
 
     # ------------------------------------------------------------ sampling
     def sample_neighbor(self, nodes, edge_types, count, default_node=-1,
-                        layout="tf", call_id=None, return_mask=False):
+                        layout="tf", call_id=None, return_mask=False, dedup=True):
         """tf_euler SampleNeighbor (tf_euler/kernels/sample_neighbor_op.cc):
         nodes [n] int64 -> (neighbors [n,count] int64, weights f32, types
         int32).  layout='core' gives the API_SAMPLE_NB fill (0, 0.0, 0)."""
@@ -255,11 +255,17 @@ class Graph:
         et, et_p, k = _i32_array(edge_types)
         lay = _lib.LAYOUT_TF if layout == "tf" else _lib.LAYOUT_CORE
         with torch.cuda.device(self.device):
-            check(lib().euler_gpu_sample_neighbor(
-                self._h, _stream(), self.seed, self._take_call_ids(1, call_id),
-                _ptr(flat), n, None, 1, et_p, k, int(count), lay,
-                int(default_node), _ptr(out_n), _ptr(out_w), _ptr(out_t),
-                _ptr(mask)))
+            if dedup:
+                check(lib().euler_gpu_sample_neighbor(
+                    self._h, _stream(), self.seed, self._take_call_ids(1, call_id),
+                    _ptr(flat), n, None, 1, et_p, k, int(count), lay,
+                    int(default_node), _ptr(out_n), _ptr(out_w), _ptr(out_t),
+                    _ptr(mask)))
+            else:       # roots known to be distinct (sharded sampler)
+                check(lib().euler_gpu_sample_neighbor_distinct(
+                    self._h, _stream(), self.seed, self._take_call_ids(1, call_id),
+                    _ptr(flat), n, et_p, k, int(count), lay, int(default_node),
+                    _ptr(out_n), _ptr(out_w), _ptr(out_t), _ptr(mask)))
         res = (out_n.reshape(shape), out_w.reshape(shape), out_t.reshape(shape))
         return res + (mask,) if return_mask else res
 

@@ -204,6 +204,79 @@ def id_split(ids, partitions, shards):
     return list(off), sid, mi
 
 
+def dedup_split(ids, partitions, shards, root_mask=None, root_group=1):
+    """Distinct ids bucketed by owner + the bucketed index of every position
+    (ID_UNIQUE + ID_SPLIT in one call).  Returns (shard_off list[shards+1],
+    shard_ids int64 [m], pos int32 [n]) with m = shard_off[-1] <= n.
+    root_mask ([ceil(n / root_group)] uint8): marked groups count as id 0."""
+    ids = ids.to(torch.int64).contiguous().reshape(-1)
+    _need_cuda(ids)
+    n = ids.numel()
+    if root_mask is not None:
+        root_mask = root_mask.to(torch.uint8).contiguous()
+    off = (C.c_int64 * (shards + 1))()
+    sid = torch.empty(n, dtype=torch.int64, device=ids.device)
+    pos = torch.empty(n, dtype=torch.int32, device=ids.device)
+    with torch.cuda.device(ids.device):
+        check(lib().euler_gpu_dedup_split(_stream(), _ptr(ids), n, _ptr(root_mask),
+                                          int(root_group), partitions, shards, off,
+                                          _ptr(sid), _ptr(pos)))
+    off = list(off)
+    return off, sid[:off[-1]], pos
+
+
+def expand_rows(pos, ids, w, t, mask, count):
+    """Row pos[i] of the sampled rows of the distinct roots -> position i:
+    (ids [n,count] int64, w f32, t int32, mask [n] uint8)."""
+    pos = pos.to(torch.int32).contiguous()
+    ids = ids.contiguous(); w = w.contiguous(); t = t.contiguous()
+    mask = mask.to(torch.uint8).contiguous()
+    _need_cuda(pos, ids, w, t, mask)
+    n = pos.numel()
+    dev = pos.device
+    o_id = torch.empty((n, count), dtype=torch.int64, device=dev)
+    o_w = torch.empty((n, count), dtype=torch.float32, device=dev)
+    o_t = torch.empty((n, count), dtype=torch.int32, device=dev)
+    o_m = torch.empty(n, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib().euler_gpu_expand_rows(_stream(), _ptr(pos), n, int(count), _ptr(ids),
+                                          _ptr(w), _ptr(t), _ptr(mask), _ptr(o_id),
+                                          _ptr(o_w), _ptr(o_t), _ptr(o_m)))
+    return o_id, o_w, o_t, o_m
+
+
+def pack_rows(ids, w, t, mask, count):
+    """Sampler outputs [m, count] (+ mask [m]) -> wire rows [m, 4*count + 2] int32."""
+    ids = ids.contiguous(); w = w.contiguous(); t = t.contiguous()
+    mask = mask.to(torch.uint8).contiguous()
+    _need_cuda(ids, w, t, mask)
+    m = mask.numel()
+    out = torch.empty((m, 4 * count + 2), dtype=torch.int32, device=ids.device)
+    with torch.cuda.device(ids.device):
+        check(lib().euler_gpu_pack_rows(_stream(), _ptr(ids), _ptr(w), _ptr(t),
+                                        _ptr(mask), m, int(count), _ptr(out)))
+    return out
+
+
+def expand_packed(pos, packed, count):
+    """Wire rows -> (ids [n,count] int64, w f32, t int32, mask [n] uint8) per
+    position: row pos[i] of `packed` is position i's row."""
+    pos = pos.to(torch.int32).contiguous()
+    packed = packed.contiguous()
+    _need_cuda(pos, packed)
+    n = pos.numel()
+    dev = pos.device
+    o_id = torch.empty((n, count), dtype=torch.int64, device=dev)
+    o_w = torch.empty((n, count), dtype=torch.float32, device=dev)
+    o_t = torch.empty((n, count), dtype=torch.int32, device=dev)
+    o_m = torch.empty(n, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib().euler_gpu_expand_packed(_stream(), _ptr(pos), n, int(count),
+                                            _ptr(packed), _ptr(o_id), _ptr(o_w),
+                                            _ptr(o_t), _ptr(o_m)))
+    return o_id, o_w, o_t, o_m
+
+
 def merge_rows(rows, merge_idx, n_rows=None):
     """IDX_MERGE / DATA_MERGE for fixed-size rows: out[merge_idx[j]] = rows[j]."""
     rows = rows.contiguous()

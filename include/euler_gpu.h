@@ -185,6 +185,18 @@ int euler_gpu_sample_neighbor(const euler_gpu_graph* g, void* stream,
                               float* out_w_dev, int32_t* out_t_dev,
                               uint8_t* out_row_mask_dev);
 
+/* Same call for roots the caller knows to be (mostly) distinct - e.g. the ids a
+ * shard receives after euler_gpu_dedup_split: skips the on-device duplicate
+ * detection of euler_gpu_sample_neighbor.  Results are identical. */
+int euler_gpu_sample_neighbor_distinct(const euler_gpu_graph* g, void* stream,
+                                       uint64_t seed, uint32_t call_id,
+                                       const uint64_t* roots_dev, int64_t n,
+                                       const int32_t* edge_types_host, int32_t k,
+                                       int32_t count, int32_t layout,
+                                       int64_t default_node, uint64_t* out_id_dev,
+                                       float* out_w_dev, int32_t* out_t_dev,
+                                       uint8_t* out_row_mask_dev);
+
 /* TF SampleFanout (tf_euler/kernels/sample_fanout_op.cc:32-148): `layers` hops
  * chained on device; hop h uses call_id + h, edge_types_host[h*k .. h*k+k) and
  * counts_host[h].  out_*_dev[h] has n * prod(counts[0..h]) elements.
@@ -313,6 +325,39 @@ int euler_gpu_id_split(void* stream, const uint64_t* ids_dev, int64_t n,
                        int32_t partitions, int32_t shards,
                        int64_t* shard_off_host, uint64_t* shard_ids_dev,
                        int32_t* merge_idx_dev);
+/* Front end of a multi-GPU hop in one call: the DISTINCT ids of the batch
+ * (ID_UNIQUE, which the reference's optimizer puts before ID_SPLIT:
+ * parser/compiler.cc:76-90) bucketed by owner into shard_ids_dev (<= n entries,
+ * shard s at [shard_off_host[s], shard_off_host[s+1])), and pos_dev[i] = index
+ * in shard_ids_dev of ids_dev[i].  The shards answer in the order they were
+ * asked, so row pos_dev[i] of the concatenated answers is position i's row:
+ * euler_gpu_expand_rows finishes the hop (IDX_MERGE / DATA_MERGE / DATA_GATHER
+ * in one pass).  An id may occur more than once in shard_ids_dev (hash-slot
+ * collisions are not resolved); results are unaffected.  Synchronises.
+ * root_mask_dev (optional, [ceil(n / root_group)] bytes) has the meaning it has
+ * in euler_gpu_sample_neighbor: marked groups sample as node id 0. */
+int euler_gpu_dedup_split(void* stream, const uint64_t* ids_dev, int64_t n,
+                          const uint8_t* root_mask_dev, int32_t root_group,
+                          int32_t partitions, int32_t shards, int64_t* shard_off_host,
+                          uint64_t* shard_ids_dev, int32_t* pos_dev);
+/* Wire format of the result exchange: one row of 4*count + 2 int32 words per
+ * root = [ids (2 words each) | weights | types | mask | pad].  pack_rows writes
+ * it from the sampler's outputs [m, count] (+ row mask [m]); expand_packed reads
+ * the concatenated answers back per position through pos_dev (merge + gather +
+ * unpack in one pass). */
+int euler_gpu_pack_rows(void* stream, const uint64_t* id_dev, const float* w_dev,
+                        const int32_t* t_dev, const uint8_t* mask_dev, int64_t m,
+                        int32_t count, int32_t* packed_dev);
+int euler_gpu_expand_packed(void* stream, const int32_t* pos_dev, int64_t n,
+                            int32_t count, const int32_t* packed_dev,
+                            uint64_t* out_id_dev, float* out_w_dev, int32_t* out_t_dev,
+                            uint8_t* out_mask_dev);
+/* out row i = row pos_dev[i] of (row_id, row_w, row_t [m, count], row_mask [m]). */
+int euler_gpu_expand_rows(void* stream, const int32_t* pos_dev, int64_t n,
+                          int32_t count, const uint64_t* row_id_dev,
+                          const float* row_w_dev, const int32_t* row_t_dev,
+                          const uint8_t* row_mask_dev, uint64_t* out_id_dev,
+                          float* out_w_dev, int32_t* out_t_dev, uint8_t* out_mask_dev);
 int euler_gpu_merge_rows(void* stream, const void* in_dev,
                          const int32_t* merge_idx_dev, int64_t n_rows,
                          int64_t row_bytes, void* out_dev);

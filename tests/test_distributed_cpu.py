@@ -90,6 +90,22 @@ def _worker(rank, world, port, partitions, out_dir):
     def gather_fn(rows, gather_idx):
         return rows[gather_idx.long()]
 
+    def dedup_split_fn(ids, parts, shards, root_mask=None, root_group=1):
+        if root_mask is not None:
+            m = root_mask.numpy().astype(bool).repeat(root_group)[:ids.numel()]
+            ids = torch.where(torch.as_tensor(m), torch.zeros_like(ids), ids)
+        uq, gi = O.id_unique(ids.numpy().astype(np.uint64))
+        off, sid, mi = O.id_split(uq, parts, shards)
+        inv = np.empty(len(uq), np.int64)
+        inv[mi] = np.arange(len(uq))
+        return off.tolist(), torch.as_tensor(sid.astype(np.int64)), torch.as_tensor(inv[gi])
+
+    def expand_fn(pos, ids, w, t, mask, count):
+        p = pos.long()
+        return ids[p], w[p], t[p], mask[p]
+
+    S_fused = ShardedSampler(local_sample, split_fn, merge_fn, partitions,
+                             dedup_split_fn=dedup_split_fn, expand_fn=expand_fn)
     # with and without the duplicate-root removal: both must equal the
     # unsharded oracle
     S_plain = ShardedSampler(local_sample, split_fn, merge_fn, partitions)
@@ -104,7 +120,7 @@ def _worker(rank, world, port, partitions, out_dir):
     for et, counts in (([[0, 1, 2], [0, 1, 2]], [5, 3]), ([[1], [2]], [4, 2]),
                        ([[0, 2], [2, 1]], [3, 3])):
         on, ow, ot = OG_full.sample_fanout(seed, 40, roots, et, counts, -1)
-        for sampler in (S, S_plain):
+        for sampler in (S, S_plain, S_fused):
             ns, ws, ts = sampler.sample_fanout(torch.as_tensor(roots), et, counts, -1, 40)
             for h in range(len(counts)):
                 assert np.array_equal(ns[h + 1].numpy(), on[h]), (rank, et, h)
@@ -114,7 +130,7 @@ def _worker(rank, world, port, partitions, out_dir):
     # exchange per step, identical to the unsharded walk
     L = 6
     et_walk = [[0, 1, 2]] * L
-    walk = S.random_walk(torch.as_tensor(roots), et_walk, default_node=-1, call_id=70)
+    walk = S_fused.random_walk(torch.as_tensor(roots), et_walk, default_node=-1, call_id=70)
     ref = OG_full.random_walk(seed, 70, roots, et_walk, L, 1.0, 1.0, -1)
     assert np.array_equal(walk.numpy(), ref), rank
     # empty request from one rank must not dead-lock the exchange

@@ -511,7 +511,7 @@ def test_gpu_sharded_sampler_single_rank(EA, O, torch_cuda, big_pair):
         q = np.concatenate([rng.choice(ids, 3000), rng.choice(ids[:50], 3000),
                             [0, 999]]).astype(np.int64)
         on, ow, ot = OG.sample_fanout(31, 8, q, [[0, 1], [2, 3]], [6, 4], -1)
-        for dedup in (True, False):
+        for dedup in (True, "ops", False):
             S = gpu_sharded_sampler(G, partitions=1, dedup=dedup)
             gn, gw, gt = S.sample_fanout(torch.as_tensor(q).cuda(), [[0, 1], [2, 3]], [6, 4],
                                          -1, call_id=8)
@@ -643,3 +643,44 @@ def test_sage_dataflow_blocks(EA, O, torch_cuda, big_pair):
         assert np.array_equal(t2n(blk.edge_index), we)
         assert blk.size == ws
     assert [b.size for b in df] == [w[3] for w in want][::-1]
+
+
+def test_dedup_split_pack_expand(EA, O, torch_cuda):
+    """Fused front / back end of a multi-GPU hop: every position finds its id in
+    the bucketed distinct list, buckets hold the ids their shard owns
+    (id_split_op.cc:46-49), duplicates collapse (almost all: unresolved hash
+    collisions may leave a few), and pack -> expand_packed returns each
+    position its row."""
+    torch = torch_cuda
+    rng = np.random.default_rng(12)
+    pool = np.concatenate([rng.integers(1, 2 ** 62, 5000), [0, 2 ** 63 + 9]]).astype(np.uint64)
+    ids = rng.choice(pool, 200_000)
+    mask = (rng.random(200_000 // 10) < 0.05).astype(np.uint8)
+    eff = ids.copy()
+    eff[np.repeat(mask, 10).astype(bool)] = 0
+    it = torch.as_tensor(ids.astype(np.int64)).cuda()
+    for parts, shards in ((8, 8), (1024, 3), (5, 1)):
+        off, sid, pos = EA.ops.dedup_split(it, parts, shards, torch.as_tensor(mask).cuda(), 10)
+        sid_n, pos_n = t2n(sid).astype(np.uint64), t2n(pos)
+        assert off[0] == 0 and off[-1] == len(sid_n) <= len(ids)
+        assert np.array_equal(sid_n[pos_n], eff)
+        assert set(sid_n.tolist()) == set(eff.tolist())
+        assert len(sid_n) < 1.05 * len(set(eff.tolist()))
+        own = O.shard_of(sid_n, parts, shards)
+        for s in range(shards):
+            assert np.all(own[off[s]:off[s + 1]] == s)
+    # wire format round trip
+    m, count = len(sid_n), 6
+    r_id = torch.as_tensor(rng.integers(-2 ** 62, 2 ** 62, (m, count))).cuda()
+    r_w = torch.as_tensor(rng.random((m, count)).astype(np.float32)).cuda()
+    r_t = torch.as_tensor(rng.integers(-1, 9, (m, count)).astype(np.int32)).cuda()
+    r_m = torch.as_tensor((rng.random(m) < 0.3).astype(np.uint8)).cuda()
+    packed = EA.ops.pack_rows(r_id, r_w, r_t, r_m, count)
+    assert tuple(packed.shape) == (m, 4 * count + 2)
+    o_id, o_w, o_t, o_m = EA.ops.expand_packed(pos, packed, count)
+    assert np.array_equal(t2n(o_id), t2n(r_id)[pos_n])
+    assert np.array_equal(t2n(o_w), t2n(r_w)[pos_n])
+    assert np.array_equal(t2n(o_t), t2n(r_t)[pos_n])
+    assert np.array_equal(t2n(o_m), t2n(r_m)[pos_n])
+    e_id, e_w, e_t, e_m = EA.ops.expand_rows(pos, r_id, r_w, r_t, r_m, count)
+    assert np.array_equal(t2n(e_id), t2n(o_id)) and np.array_equal(t2n(e_m), t2n(o_m))
