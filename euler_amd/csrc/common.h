@@ -91,6 +91,10 @@ struct GraphView {
   // piv_off[k] (floats); +1.25 B per edge.
   const float* pivots;
   int64_t piv_off[kPivotLevels + 1];
+  // block pivot levels (K1 variant 6): level 1 = skip1 (one entry per EdgeBlock),
+  // level k+1 entry q = level k entry 5q+4; bpiv + bpiv_off[k] for k >= 2
+  const float* bpiv;
+  int64_t bpiv_off[kPivotLevels + 1];
   const struct EdgeBlock* blk;
   const float* skip1;
   const float* skip2;
@@ -107,7 +111,8 @@ struct GraphView {
 constexpr int kEdgesPerBlock = 10;
 struct alignas(128) EdgeBlock {
   float pw[kEdgesPerBlock];        // prefix_w of the 10 edges
-  uint32_t pad[2];
+  float prev_last;                 // prefix_w of the edge before the block (0 for block 0)
+  uint32_t pad;
   uint64_t nbr[kEdgesPerBlock];    // their neighbour ids
 };
 static_assert(sizeof(EdgeBlock) == 128, "EdgeBlock must be one 128-byte line");

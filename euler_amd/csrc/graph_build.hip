@@ -81,7 +81,8 @@ __global__ void BuildBlocksKernel(const float* __restrict__ pw,
     b.pw[x] = pw[m];
     b.nbr[x] = nbr[m];
   }
-  b.pad[0] = 0; b.pad[1] = 0;
+  b.prev_last = base > 0 ? pw[base - 1] : 0.f;
+  b.pad = 0;
   blk[i] = b;
   skip1[i] = b.pw[kEdgesPerBlock - 1];
 }
@@ -138,10 +139,15 @@ int BuildPivotLevels(GraphBuilder* b) {
   return EULER_GPU_OK;
 }
 
-int BuildSearchIndex(GraphBuilder* b) { return BuildPivotLevels(b); }
+int BuildBlockedIndex(GraphBuilder* b);
 
-// EdgeBlock + skip levels: only the A/B variants 3 and 4 of K1 use them, so
-// they are built on first use (EnsureBlockedIndex), not at graph creation.
+// Pivot levels over the flat arrays (variant 5) and the EdgeBlock copy with its
+// block pivots (variant 6, the default sampler) are both built at creation.
+int BuildSearchIndex(GraphBuilder* b) {
+  const int rc = BuildPivotLevels(b);
+  return rc != EULER_GPU_OK ? rc : BuildBlockedIndex(b);
+}
+
 int BuildBlockedIndex(GraphBuilder* b) {
   GraphView& v = b->g->view;
   const int64_t E = v.n_edges;
@@ -151,7 +157,7 @@ int BuildBlockedIndex(GraphBuilder* b) {
   if (E >= (int64_t)kEdgesPerBlock * 0x7fffff00LL)
     return Fail(EULER_GPU_EINVAL, "graph too large for 32-bit block indices");
   EdgeBlock* blk = b->Alloc<EdgeBlock>((size_t)v.n_blk);
-  float* s1 = b->Alloc<float>((size_t)v.n_blk);
+  float* s1 = b->Alloc<float>((size_t)v.n_blk + 8);   // windows may run 3 past the end
   float* s2 = b->Alloc<float>((size_t)v.n_skip2);
   float* s3 = b->Alloc<float>((size_t)v.n_skip3);
   if (b->rc != EULER_GPU_OK) return b->rc;
@@ -165,6 +171,30 @@ int BuildBlockedIndex(GraphBuilder* b) {
                        dim3(block), 0, 0, s2, v.n_skip2, v.n_skip3, s3);
     EG_HIP(hipGetLastError());
     EG_HIP(hipDeviceSynchronize());
+  }
+  // block pivot levels over skip1 (fanout 5)
+  {
+    int64_t n[kPivotLevels + 1];
+    int64_t total = 0;
+    n[1] = v.n_blk;
+    v.bpiv_off[0] = v.bpiv_off[1] = 0;
+    for (int k = 2; k <= kPivotLevels; ++k) {
+      n[k] = (n[k - 1] + 4) / 5;
+      v.bpiv_off[k] = total;
+      total += n[k] + 4;
+    }
+    float* bp = b->Alloc<float>((size_t)total + 8);
+    if (b->rc != EULER_GPU_OK) return b->rc;
+    EG_HIP(hipMemset(bp, 0, ((size_t)total + 8) * sizeof(float)));
+    const float* lower = s1;
+    for (int k = 2; k <= kPivotLevels && E > 0; ++k) {
+      hipLaunchKernelGGL(BuildPivotKernel, dim3((n[k] + block - 1) / block), dim3(block),
+                         0, 0, lower, n[k - 1], 5, n[k], bp + v.bpiv_off[k]);
+      lower = bp + v.bpiv_off[k];
+    }
+    EG_HIP(hipGetLastError());
+    EG_HIP(hipDeviceSynchronize());
+    v.bpiv = bp;
   }
   v.blk = blk; v.skip1 = s1; v.skip2 = s2; v.skip3 = s3;
   return EULER_GPU_OK;

@@ -507,7 +507,7 @@ int g_k1_pair = 1;      // pivot kernel: two adjacent samples per lane when coun
 int g_k1_grid_cap = 0;  // measurement only: override the workgroup cap of K1
 int g_k1_ablate = 0;   // measurement only: skip parts of the blocked kernel
 int g_k1_ilp = 4;      // samples per lane of the ILP kernel (1, 2, 4, 8)
-int g_k1_variant = 5;   // 5 = pivot levels, 4 = wave-staged (count >= 8) else blocked,
+int g_k1_variant = 6;   // 6 = block pivots, 5 = pivot levels, 4 = wave-staged (count >= 8) else blocked,
                         // 3 = blocked index,
                         // 2 = ILP, 1 = fast path, 0 = generic
 }
@@ -1095,8 +1095,104 @@ __device__ __forceinline__ void PivotSample(const GraphView& g, const Segment& s
   *w = __fsub_rn(nw_m, prev);
 }
 
+// ------------------------------------------------------------------------
+// Block-pivot search (K1 variant 6).  Over the distinct roots of a dedup'ed
+// hop every row is cold and the launch runs at the chip's random-line rate
+// (46 of ~54 G L2 misses/s), touching ~3 cold lines per sample: a level-1
+// pivot window, the leaf window of prefix_w, and the id in nbr.  Here the
+// pivots index 128-byte EdgeBlocks (10 edges: sums + ids + the previous block's
+// last sum in ONE line) instead of 4-element groups of the flat array: level 1
+// = one entry per block (skip1), level k+1 entry q = level k entry 5q+4.  A
+// sample then touches a level-1 window (a row of degree d has d/320 lines of
+// them, shared by its samples) and one block line.
+// Same contract as PivotSample: first m in [lo, hi] with nw[m] > r.
+// ------------------------------------------------------------------------
+__device__ __forceinline__ void BlockPivotSample(const GraphView& g, const Segment& sg,
+                                                 double u, uint64_t* id, float* w) {
+  const int64_t lo = sg.lo, hi = sg.hi;
+  const double rr = ScaleDraw(u, sg.limit_begin, sg.limit_end);
+  if (!((double)sg.limit_end > rr)) {
+    // Q3: r rounded up to the end of the segment - replay the reference
+    const float* nw = g.prefix_w + sg.row_ptr;
+    const int32_t m = (int32_t)RandomSelect(nw, (uint64_t)sg.b, (uint64_t)sg.e, u);
+    *id = g.nbr[sg.row_ptr + m];
+    *w = __fsub_rn(nw[m], m == 0 ? 0.f : nw[m - 1]);
+    return;
+  }
+  uint32_t l[kPivotLevels + 1], h[kPivotLevels + 1];
+  l[1] = (uint32_t)(lo / kEdgesPerBlock);
+  h[1] = (uint32_t)(hi / kEdgesPerBlock);
+#pragma unroll
+  for (int k = 2; k <= kPivotLevels; ++k) { l[k] = l[k - 1] / 5u; h[k] = h[k - 1] / 5u; }
+  int32_t K = 0;                     // 0: the segment lies inside one block
+  if (h[1] != l[1]) {
+    K = kPivotLevels + 1;
+#pragma unroll
+    for (int k = kPivotLevels; k >= 1; --k)
+      if (h[k] - l[k] <= 4u) K = k;
+  }
+  uint32_t x = l[1];
+  bool found = false;
+  if (K > kPivotLevels) {
+    // beyond the levels' reach: bisect the block entries
+    uint32_t a = l[1], b = h[1];
+    while (a < b) {
+      const uint32_t mid = (a + b) >> 1;
+      if ((double)g.skip1[mid] > rr) b = mid; else a = mid + 1;
+    }
+    x = a;
+    found = a < h[1];
+  } else {
+#pragma unroll
+    for (int k = kPivotLevels; k >= 1; --k) {
+      if (k <= K) {
+        uint32_t c_lo, c_hi;
+        if (k == K) { c_lo = l[k]; c_hi = h[k]; }
+        else {
+          c_lo = max(l[k], 5u * x);
+          c_hi = found ? 5u * x + 4u : h[k];
+        }
+        const int32_t cnt = (int32_t)(c_hi - c_lo);
+        const float* lvl = k == 1 ? g.skip1 : g.bpiv + g.bpiv_off[k];
+        const float4u kw = *reinterpret_cast<const float4u*>(lvl + c_lo);
+        int32_t pos = 0;
+        pos += (0 < cnt && !((double)kw.x > rr)) ? 1 : 0;
+        pos += (1 < cnt && !((double)kw.y > rr)) ? 1 : 0;
+        pos += (2 < cnt && !((double)kw.z > rr)) ? 1 : 0;
+        pos += (3 < cnt && !((double)kw.w > rr)) ? 1 : 0;
+        x = c_lo + (uint32_t)pos;
+        if (pos < cnt) found = true;
+      }
+    }
+  }
+  // leaf: block x holds the answer (its last sum exceeds r when `found`,
+  // otherwise it is the block of hi, whose sum exceeds r)
+  const EdgeBlock* bk = g.blk + x;
+  const int64_t base = (int64_t)x * kEdgesPerBlock;
+  const int32_t i_lo = lo > base ? (int32_t)(lo - base) : 0;
+  const int32_t i_hi = found ? kEdgesPerBlock - 1 : (int32_t)(hi - base);   // inclusive
+  const float4 a0 = *reinterpret_cast<const float4*>(bk->pw);
+  const float4 a1 = *reinterpret_cast<const float4*>(bk->pw + 4);
+  const float4 a2 = *reinterpret_cast<const float4*>(bk->pw + 8);   // pw[8], pw[9], prev_last, pad
+  const float v[10] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y};
+  int32_t i = i_lo;
+#pragma unroll
+  for (int j = 0; j < kEdgesPerBlock - 1; ++j)
+    i += (j >= i_lo && j < i_hi && !((double)v[j] > rr)) ? 1 : 0;
+  float nw_m = v[0], prev = a2.z;
+#pragma unroll
+  for (int j = 0; j < kEdgesPerBlock; ++j) {
+    if (j == i) nw_m = v[j];
+    if (j + 1 == i) prev = v[j];
+  }
+  if (base + i == sg.row_ptr) prev = 0.f;          // `mid ? nw[mid-1] : 0`, row-relative
+  *id = bk->nbr[i];
+  *w = __fsub_rn(nw_m, prev);
+}
+
 // Row record -> searched segment of the listed type; false = empty / invalid
 // (node.cc:127-136).
+template <bool BLOCKED = false>
 __device__ __forceinline__ bool LoadSegment(const GraphView& g, int64_t row,
                                             int32_t t, Segment* sg) {
   if (row < 0 || t < 0 || t >= g.T) return false;
@@ -1115,15 +1211,20 @@ __device__ __forceinline__ bool LoadSegment(const GraphView& g, int64_t row,
   if (sg->e < sg->b) return false;
   sg->lo = sg->row_ptr + sg->b;
   sg->hi = sg->row_ptr + sg->e;
-  sg->limit_end = g.prefix_w[sg->hi];
-  sg->limit_begin = sg->b == 0 ? 0.f : g.prefix_w[sg->lo - 1];
+  if (BLOCKED) {     // same values, read from the block lines the search will touch
+    sg->limit_end = BlockedPw(g, sg->hi);
+    sg->limit_begin = sg->b == 0 ? 0.f : BlockedPw(g, sg->lo - 1);
+  } else {
+    sg->limit_end = g.prefix_w[sg->hi];
+    sg->limit_begin = sg->b == 0 ? 0.f : g.prefix_w[sg->lo - 1];
+  }
   return true;
 }
 
 // U = 1: one sample per lane.  U = 2 (even `count`): a lane draws the two
 // adjacent samples (j, j+1) of one root - one root id / row record / limit
 // load, one Philox block and one 16-byte id store per PAIR.
-template <bool TF_LAYOUT, int U>
+template <bool TF_LAYOUT, int U, bool BLOCKED = false>
 __global__ __launch_bounds__(256) void SampleNeighborPivotKernel(
     const SampleNbArgs a, const int64_t stride_rows, const int32_t stride_slots) {
   int64_t n_roots;
@@ -1139,7 +1240,7 @@ __global__ __launch_bounds__(256) void SampleNeighborPivotKernel(
     uint64_t node = a.roots[r];
     if (a.root_mask != nullptr && a.root_mask[r / a.root_group]) node = 0;
     Segment sg;
-    const bool valid = LoadSegment(a.g, FindRow(a.g, node), t, &sg);
+    const bool valid = LoadSegment<BLOCKED>(a.g, FindRow(a.g, node), t, &sg);
     uint64_t id[U];
     float w[U];
     int32_t ot = t;
@@ -1149,7 +1250,11 @@ __global__ __launch_bounds__(256) void SampleNeighborPivotKernel(
       if (U == 1) {
         const double u = (j & 1) ? UnitFromWords(blk.w[2], blk.w[3])
                                  : UnitFromWords(blk.w[0], blk.w[1]);
-        PivotSample(a.g, sg, u, &id[0], &w[0]);
+        if (BLOCKED) BlockPivotSample(a.g, sg, u, &id[0], &w[0]);
+        else PivotSample(a.g, sg, u, &id[0], &w[0]);
+      } else if (BLOCKED) {
+        BlockPivotSample(a.g, sg, UnitFromWords(blk.w[0], blk.w[1]), &id[0], &w[0]);
+        BlockPivotSample(a.g, sg, UnitFromWords(blk.w[2], blk.w[3]), &id[U - 1], &w[U - 1]);
       } else {
         PivotSample(a.g, sg, UnitFromWords(blk.w[0], blk.w[1]), &id[0], &w[0]);
         PivotSample(a.g, sg, UnitFromWords(blk.w[2], blk.w[3]), &id[U - 1], &w[U - 1]);
@@ -1211,7 +1316,8 @@ static int LaunchK1(const euler_gpu_graph* g, hipStream_t stream,
   }
   const bool single = k == 1 && g->view.monotone;
   const bool tf_zero = layout == EULER_GPU_LAYOUT_TF && g->view.has_zero_nbr != 0;
-  if (g_k1_variant == 5 && single && !tf_zero) {
+  if ((g_k1_variant == 5 || g_k1_variant == 6) && single && !tf_zero) {
+    const bool blocked = g_k1_variant == 6;
     // two samples per lane pay when the launch is bound by memory-instruction
     // throughput (millions of roots with hot rows); the pass over the distinct
     // roots (dd_role 2) is small and cold - there the shorter dependent chain of
@@ -1231,10 +1337,15 @@ static int LaunchK1(const euler_gpu_graph* g, hipStream_t stream,
     const int64_t stride_rows = stride / count;
     const int32_t stride_slots = (int32_t)(stride - stride_rows * count);
     const bool tf = layout == EULER_GPU_LAYOUT_TF;
-    auto kern = pair ? (tf ? SampleNeighborPivotKernel<true, 2>
-                           : SampleNeighborPivotKernel<false, 2>)
-                     : (tf ? SampleNeighborPivotKernel<true, 1>
-                           : SampleNeighborPivotKernel<false, 1>);
+    auto kern = blocked
+        ? (pair ? (tf ? SampleNeighborPivotKernel<true, 2, true>
+                      : SampleNeighborPivotKernel<false, 2, true>)
+                : (tf ? SampleNeighborPivotKernel<true, 1, true>
+                      : SampleNeighborPivotKernel<false, 1, true>))
+        : (pair ? (tf ? SampleNeighborPivotKernel<true, 2>
+                      : SampleNeighborPivotKernel<false, 2>)
+                : (tf ? SampleNeighborPivotKernel<true, 1>
+                      : SampleNeighborPivotKernel<false, 1>));
     hipLaunchKernelGGL(kern, dim3(gridp), dim3(block), 0, stream, a, stride_rows,
                        stride_slots);
   } else if (g_k1_variant == 4 && single && !tf_zero && count >= 8) {
@@ -1346,7 +1457,8 @@ static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
     return Fail(EULER_GPU_EINVAL, "sample_neighbor: null buffer");
   if (k > 0 && !edge_types)
     return Fail(EULER_GPU_EINVAL, "sample_neighbor: null edge_types");
-  if ((g_k1_variant == 3 || g_k1_variant == 4) && g->view.blk == nullptr) {
+  if ((g_k1_variant == 3 || g_k1_variant == 4 || g_k1_variant == 6) &&
+      g->view.blk == nullptr) {
     const int rc = EnsureBlockedIndex(g);     // A/B variants only: built on first use
     if (rc != EULER_GPU_OK) return rc;
   }
@@ -1360,7 +1472,8 @@ static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
   a.n = n; a.default_node = default_node;
   a.k = k; a.count = count; a.layout = layout;
   for (int i = 0; i < k; ++i) a.et[i] = edge_types[i];
-  const bool try_dedup = dedup != 0 && g_k1_dedup != 0 && g_k1_variant == 5 &&
+  const bool try_dedup = dedup != 0 && g_k1_dedup != 0 &&
+                         (g_k1_variant == 5 || g_k1_variant == 6) &&
                          (n >= kDedupMinRoots || g_k1_dedup == 2) &&
                          n < (int64_t)0x3fffffff &&
                          g->view.n_rows < (int64_t)0xfffffff0;

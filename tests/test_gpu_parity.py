@@ -15,8 +15,8 @@ pytestmark = pytest.mark.gpu
 SEED = 20240521
 
 
-@pytest.fixture(params=[(5, 4), (5, 2), (5, 1), (4, 4), (3, 4), (2, 4), (2, 2), (2, 8), (1, 4), (0, 4)],
-                ids=["k1pivot", "k1dedup", "k1pivot1", "k1wave", "k1blocked", "k1ilp4", "k1ilp2", "k1ilp8", "k1fast",
+@pytest.fixture(params=[(6, 4), (5, 4), (6, 2), (6, 1), (4, 4), (3, 4), (2, 4), (2, 2), (2, 8), (1, 4), (0, 4)],
+                ids=["k1blockpivot", "k1pivot", "k1dedup", "k1blockpivot1", "k1wave", "k1blocked", "k1ilp4", "k1ilp2", "k1ilp8", "k1fast",
                      "k1generic"])
 def k1_variant(request, EA):
     """Run with every variant of the K1 kernel (blocked sampling index, ILP with
@@ -25,14 +25,14 @@ def k1_variant(request, EA):
     from euler_amd import _lib
     _lib.lib().euler_gpu_set_tuning(0, request.param[0])
     _lib.lib().euler_gpu_set_tuning(1, request.param[1])
-    # pivot kernel: param[1] == 1 forces one sample per lane
-    _lib.lib().euler_gpu_set_tuning(4, 0 if request.param == (5, 1) else 1)
-    # (5, 2): always run the duplicate-root machinery, whatever the batch size
-    _lib.lib().euler_gpu_set_tuning(5, 2 if request.param == (5, 2) else 1)
+    # (6, 1) forces one sample per lane
+    _lib.lib().euler_gpu_set_tuning(4, 0 if request.param == (6, 1) else 1)
+    # (6, 2): always run the duplicate-root machinery, whatever the batch size
+    _lib.lib().euler_gpu_set_tuning(5, 2 if request.param == (6, 2) else 1)
     yield request.param
     _lib.lib().euler_gpu_set_tuning(4, 1)
     _lib.lib().euler_gpu_set_tuning(5, 1)
-    _lib.lib().euler_gpu_set_tuning(0, 5)
+    _lib.lib().euler_gpu_set_tuning(0, 6)
     _lib.lib().euler_gpu_set_tuning(1, 4)
 
 

@@ -18,7 +18,7 @@ st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 et1 = (C.c_int32*1)(0)
 res = {}
 L.euler_gpu_set_tuning(5, 0)
-for variant, pair in ((5, 1), (5, 0), (1, 0), (5, 1), (5, 0)):
+for variant, pair in ((6, 0), (5, 0), (6, 0), (5, 0), (6, 1), (5, 1)):
     L.euler_gpu_set_tuning(0, variant); L.euler_gpu_set_tuning(4, pair)
     for name, r in (('sorted', uq), ('shuffled', uq_shuf)):
         n = r.numel(); cnt = 10
