@@ -52,6 +52,10 @@ def parse():
                     help="graph size of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--pipeline", type=int, default=3,
+                    help="sharded path: minibatches in flight (each on its own host "
+                         "thread, HIP stream and RCCL communicator, so one batch's "
+                         "host synchronisations overlap another batch's kernels)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU sampler (unique / split / all-to-all / "
                          "merge / gather) even on one rank: measures its overhead")
@@ -135,29 +139,59 @@ def main():
     et = [[0], [0]]
     default_node = args.nodes + 1
 
-    if sharded:
-        from euler_amd.distributed import gpu_sharded_sampler
-        S = gpu_sharded_sampler(G, partitions=world)
-
-        def step(i):
-            return S.sample_fanout(roots[i], et, FANOUT, default_node, call_id=2 * i)
-    else:
-        def step(i):
-            return G.sample_fanout(roots[i], et, FANOUT, default_node, call_id=2 * i)
-
     def sync():
         if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        out = step(i)
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.warmup, n_steps):
-        out = step(i)
-    sync()
-    elapsed = time.perf_counter() - t0
+    if sharded:
+        # A sharded hop needs the host three times (distinct count, split
+        # offsets, peer counts).  K minibatches are kept in flight, each on its
+        # own thread / stream / communicator: while one waits, the GPU runs the
+        # others.  Every rank runs the same slot -> step schedule, and a slot's
+        # collectives are ordered on its own communicator.
+        import threading
+        from euler_amd.distributed import gpu_sharded_sampler
+        K = max(1, min(args.pipeline, args.steps))
+        groups = [dist.new_group(list(range(world))) if K > 1 else None for _ in range(K)]
+        samplers = [gpu_sharded_sampler(G, partitions=world, group=g) for g in groups]
+        streams = [torch.cuda.Stream(device=dev) for _ in range(K)]
+        last_out = [None] * K
+
+        def run_slot(k, first, last):
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(streams[k]):
+                for i in range(first + k, last, K):
+                    last_out[k] = samplers[k].sample_fanout(roots[i], et, FANOUT,
+                                                            default_node, call_id=2 * i)
+                streams[k].synchronize()
+
+        def run(first, last):
+            ts = [threading.Thread(target=run_slot, args=(k, first, last)) for k in range(K)]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+
+        run(0, args.warmup)
+        sync()
+        t0 = time.perf_counter()
+        run(args.warmup, n_steps)
+        sync()
+        elapsed = time.perf_counter() - t0
+        out = last_out[(n_steps - 1 - args.warmup) % K]
+    else:
+        def step(i):
+            return G.sample_fanout(roots[i], et, FANOUT, default_node, call_id=2 * i)
+
+        for i in range(args.warmup):
+            out = step(i)
+        sync()
+        t0 = time.perf_counter()
+        for i in range(args.warmup, n_steps):
+            out = step(i)
+        sync()
+        elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -288,9 +322,11 @@ def main():
                 "roots_per_step_per_gpu": B, "fanout": FANOUT,
                 "graph_bytes_per_gpu": G.device_bytes,
                 "graph_build_s": round(build_s, 2),
-                "partitioning": ("none" if not sharded else "sharded sampler on 1 rank")
+                "partitioning": ("none" if not sharded else
+                                 "sharded sampler on 1 rank, %d minibatches in flight" % args.pipeline)
                                 if world == 1 else
-                                "hash owner(id)=id%%%d, all-to-all per hop" % world,
+                                "hash owner(id)=id%%%d, all-to-all per hop, %d minibatches "
+                                "in flight" % (world, args.pipeline),
                 "parity_checked_edges": checked,
             },
             "roofline": roofline, "cpu_baseline": cpu,

@@ -338,6 +338,35 @@ class GpuGetNeighborOp : public OpKernel {
                                     (int32_t)et.size(), d_idx.as<int32_t>(), &total,
                                     d_oid.as<uint64_t>(), d_ow.as<float>(),
                                     d_ot.as<int32_t>()) != 0) { LogError(euler_gpu_last_error()); return; }
+    // Post process (get_neighbor_op.cc:117-168): applied in order
+    for (const std::string& post : nd.post_process) {
+      std::vector<std::string> vec;
+      std::string cur;
+      for (char ch : post) {
+        if (ch == ' ') { if (!cur.empty()) vec.push_back(cur); cur.clear(); }
+        else cur.push_back(ch);
+      }
+      if (!cur.empty()) vec.push_back(cur);
+      if (vec.empty()) continue;
+      int32_t order_by = 0, desc = 0;
+      int64_t limit = -1;
+      if (vec[0] == "order_by") {
+        if (vec.size() < 2 || vec.size() > 3) { LogError("Invalid post process: " + post); continue; }
+        desc = vec.size() == 3 && vec[2] == "desc" ? 1 : 0;
+        if (vec[1] == "id") order_by = 1;
+        else if (vec[1] == "weight") order_by = 2;
+        else { LogError("Invalid order_by field: " + vec[1]); continue; }
+      } else if (vec[0] == "limit") {
+        if (vec.size() != 2) { LogError("Invalid post process: " + post); continue; }
+        limit = atoll(vec[1].c_str());
+      } else {
+        continue;
+      }
+      if (euler_gpu_neighbor_post_process(nullptr, n, d_idx.as<int32_t>(), total,
+                                          d_oid.as<uint64_t>(), d_ow.as<float>(),
+                                          d_ot.as<int32_t>(), order_by, desc, limit,
+                                          &total) != 0) { LogError(euler_gpu_last_error()); return; }
+    }
     (void)hipDeviceSynchronize();
     Tensor *idx = nullptr, *oid = nullptr, *ow = nullptr, *ot = nullptr;
     ctx->Allocate(OutputName(nd, 0), {(size_t)n, 2}, kInt32, &idx);
@@ -388,6 +417,48 @@ int64_t euler_op_run_sample_nb(euler_gpu_graph* g, uint64_t seed,
   if (ctx.tensor(OutputName(nd, 0), &idx) != 0 || ctx.tensor(OutputName(nd, 1), &oid) != 0 ||
       ctx.tensor(OutputName(nd, 2), &ow) != 0 || ctx.tensor(OutputName(nd, 3), &ot) != 0)
     return -2;   // op logged an error and produced no output
+  memcpy(idx_out, idx->Raw<int32_t>(), idx->TotalBytes());
+  memcpy(id_out, oid->Raw<uint64_t>(), oid->TotalBytes());
+  memcpy(w_out, ow->Raw<float>(), ow->TotalBytes());
+  memcpy(t_out, ot->Raw<int32_t>(), ot->TotalBytes());
+  return oid->NumElements();
+}
+
+// Runs the registered API_GET_NB_NODE kernel (with its post-process strings,
+// ';'-separated) through the plugin API on host tensors; returns the number of
+// neighbours or < 0.
+int64_t euler_op_run_get_nb(euler_gpu_graph* g, const uint64_t* node_ids, int64_t n,
+                            const int32_t* edge_types, int32_t k,
+                            const char* post_process, int64_t capacity,
+                            int32_t* idx_out, uint64_t* id_out, float* w_out,
+                            int32_t* t_out) {
+  using namespace euler;
+  OpKernelContext ctx;
+  ctx.SetGraph(g);
+  Tensor *t_ids = nullptr, *t_et = nullptr;
+  ctx.Allocate("nodes", {(size_t)n}, kUInt64, &t_ids);
+  ctx.Allocate("edge_types", {(size_t)k}, kInt32, &t_et);
+  memcpy(t_ids->Raw<uint64_t>(), node_ids, (size_t)n * 8);
+  if (k) memcpy(t_et->Raw<int32_t>(), edge_types, (size_t)k * 4);
+  NodeDef nd{"API_GET_NB_NODE,0", "API_GET_NB_NODE", {"nodes", "edge_types"}, {}};
+  std::string cur;
+  for (const char* p = post_process ? post_process : ""; ; ++p) {
+    if (*p == ';' || *p == 0) {
+      if (!cur.empty()) nd.post_process.push_back(cur);
+      cur.clear();
+      if (*p == 0) break;
+    } else {
+      cur.push_back(*p);
+    }
+  }
+  OpKernel* kernel = nullptr;
+  if (CreateOpKernel("API_GET_NB_NODE", &kernel) != 0) return -1;
+  kernel->Compute(nd, &ctx);
+  Tensor *idx = nullptr, *oid = nullptr, *ow = nullptr, *ot = nullptr;
+  if (ctx.tensor(OutputName(nd, 0), &idx) != 0 || ctx.tensor(OutputName(nd, 1), &oid) != 0 ||
+      ctx.tensor(OutputName(nd, 2), &ow) != 0 || ctx.tensor(OutputName(nd, 3), &ot) != 0)
+    return -2;
+  if (oid->NumElements() > capacity) return -3;
   memcpy(idx_out, idx->Raw<int32_t>(), idx->TotalBytes());
   memcpy(id_out, oid->Raw<uint64_t>(), oid->TotalBytes());
   memcpy(w_out, ow->Raw<float>(), ow->TotalBytes());

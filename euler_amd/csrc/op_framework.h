@@ -71,6 +71,9 @@ struct NodeDef {
   std::string name;                 // outputs are "<name>:<i>"
   std::string op;
   std::vector<std::string> inputs;  // tensor names looked up in the context
+  // DAGNodeProto.post_process of API_GET_NB_NODE: "order_by id|weight [desc]",
+  // "limit k" (core/kernels/get_neighbor_op.cc:117-168)
+  std::vector<std::string> post_process;
 };
 std::string OutputName(const NodeDef& node_def, int i);
 
@@ -149,4 +152,11 @@ int64_t euler_op_run_sample_nb(euler_gpu_graph* g, uint64_t seed,
                                const int32_t* edge_types, int32_t k,
                                int32_t count, int32_t* idx_out, uint64_t* id_out,
                                float* w_out, int32_t* t_out);
+// API_GET_NB_NODE with ';'-separated post-process strings ("order_by weight
+// desc;limit 4"); outputs have room for `capacity` neighbours.
+int64_t euler_op_run_get_nb(euler_gpu_graph* g, const uint64_t* node_ids, int64_t n,
+                            const int32_t* edge_types, int32_t k,
+                            const char* post_process, int64_t capacity,
+                            int32_t* idx_out, uint64_t* id_out, float* w_out,
+                            int32_t* t_out);
 }

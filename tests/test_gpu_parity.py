@@ -377,6 +377,21 @@ def test_op_registry_and_dat_loader(EA, O, torch_cuda, fixture_csr, tmp_path):
     ridx, rid, rw, rt = OG.sample_neighbor_core(77, 0, q, et, count)
     assert np.array_equal(idx, ridx) and np.array_equal(oid, rid)
     assert np.array_equal(ow, rw) and np.array_equal(ot, rt)
+    # API_GET_NB_NODE through the plugin API, with the post-process strings the
+    # TF top-k op compiles to (get_top_k_neighbor_op.cc:36-44)
+    cap = 64
+    idx = np.zeros((n, 2), np.int32); oid = np.zeros(cap, np.uint64)
+    ow = np.zeros(cap, np.float32); ot = np.zeros(cap, np.int32)
+    got = L.euler_op_run_get_nb(G._h, q.ctypes.data_as(_lib.u64p), n,
+                                et.ctypes.data_as(_lib.i32p), 2,
+                                b"order_by weight desc;limit 2", cap,
+                                idx.ctypes.data_as(_lib.i32p), oid.ctypes.data_as(_lib.u64p),
+                                ow.ctypes.data_as(_lib.f32p), ot.ctypes.data_as(_lib.i32p))
+    want = O.neighbor_post_process(*OG.get_full_neighbor(q, et), order_by="weight",
+                                   desc=True, limit=2)
+    assert got == len(want[1])
+    assert np.array_equal(idx, want[0]) and np.array_equal(oid[:got], want[1])
+    assert np.array_equal(ow[:got], want[2]) and np.array_equal(ot[:got], want[3])
     # .dat round trip written with the record layout of node.cc:414-526
     from test_host import write_dat_dir
     write_dat_dir(tmp_path, fixture_csr, partitions=2)
