@@ -27,16 +27,20 @@ def passes(name, kernel="SampleNeighbor"):
 
 summary = {"note": "rocprofv3 --pmc passes (one counter set per pass, --kernel-trace only) over "
                    "`bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-check`; per-launch "
-                   "means of the K1 kernel: hop1 = SampleNeighborPivotKernel<true,1> over the batch, "
-                   "hop2 = SampleNeighborPivotKernel<true,2> over the distinct hop-2 roots (gated "
-                   "no-op launches excluded); expand = DedupExpandKernel. FETCH_SIZE / WRITE_SIZE "
-                   "are reported in KiB."}
+                   "means of the K1 kernel (SampleNeighborPivotKernel<true,1,true>): hop1 = over the "
+                   "batch, hop2 = over the distinct hop-2 roots (gated no-op launches excluded); "
+                   "expand = DedupExpandKernel. FETCH_SIZE / WRITE_SIZE are reported in KiB."}
 # K1 launches of a step that do work: <true, 1> = hop 1 (odd count, one sample
 # per lane), <true, 2> = hop 2 over the distinct roots; the <true, 2> launches
 # that last a few microseconds are the gated no-op pass (see DedupGate).
 def split(v):
-    h1 = [x for x in v if "<true, 1>" in x[3]]
-    h2 = [x for x in v if "<true, 2>" in x[3] and x[2] > 30000]
+    # hop 1 and the distinct-root pass of hop 2 are the same kernel (one sample
+    # per lane); the launcher sizes their grids from 131072 * 25 and 3276800 * 10
+    # samples, which tells them apart; launches of a few microseconds are the
+    # gated no-op pass (DedupGate)
+    work = [x for x in v if x[2] > 30000]
+    h1 = [x for x in work if x[4] < 4_000_000]
+    h2 = [x for x in work if x[4] >= 4_000_000]
     return h1, h2
 
 def passes_named(name):
@@ -46,12 +50,13 @@ def passes_named(name):
             if "SampleNeighborPivotKernel" in r["Kernel_Name"] or "DedupExpand" in r["Kernel_Name"]:
                 rows[r["Counter_Name"]].append(
                     (int(r["Dispatch_Id"]), float(r["Counter_Value"]),
-                     int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r["Kernel_Name"]))
+                     int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r["Kernel_Name"],
+                     int(r["Grid_Size"])))
     return rows
 
 for name in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum"):
     for ctr, v in passes_named(name).items():
-        h1, h2 = split(v)
+        h1, h2 = split([x for x in v if "SampleNeighborPivotKernel" in x[3]])
         ex = [x for x in v if "DedupExpand" in x[3] and x[2] > 30000]
         mean = lambda xs, i: sum(x[i] for x in xs) / max(len(xs), 1)
         summary[ctr] = {"hop1_mean": mean(h1, 1), "hop2_mean": mean(h2, 1),
