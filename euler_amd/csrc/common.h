@@ -62,7 +62,10 @@ struct GraphView {
   int32_t monotone;             // every row's prefix_w is non-decreasing, >= 0
                                 // and NaN-free (true for non-negative weights):
                                 // licence for the single-load search of K1
-  int32_t pad0;
+  int32_t total_in_meta;        // T == 1 and every row's type_prefix[0] has the
+                                // bits of its last running sum (checked on device
+                                // at build): the segment limit comes with the row
+                                // record, no separate load
   uint64_t id_base;             // identity: row = (id - id_base) / id_stride
   uint64_t id_stride;
   const uint64_t* hash_slots;   // [2 * (hash_mask + 1)] = {key, row} pairs

@@ -139,12 +139,40 @@ int BuildPivotLevels(GraphBuilder* b) {
   return EULER_GPU_OK;
 }
 
+// flag[0] stays 1 iff every non-empty row's type_prefix[0] == its last sum (T == 1)
+__global__ void VerifyTotalsKernel(GraphView g, int32_t* flag) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= g.n_rows) return;
+  const uint4 q = *reinterpret_cast<const uint4*>(g.row_meta + row * 16);
+  const int64_t row_ptr = (int64_t)(((uint64_t)q.y << 32) | q.x);
+  const int32_t deg = (int32_t)q.z;
+  if (deg > 0 && __float_as_uint(g.prefix_w[row_ptr + deg - 1]) != q.w) flag[0] = 0;
+}
+
+int VerifyTotals(GraphBuilder* b) {
+  GraphView& v = b->g->view;
+  v.total_in_meta = 0;
+  if (v.T != 1 || v.n_rows == 0) return EULER_GPU_OK;
+  int32_t* flag = nullptr;
+  EG_HIP(hipMalloc((void**)&flag, 16));
+  const int32_t one = 1;
+  EG_HIP(hipMemcpy(flag, &one, 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(VerifyTotalsKernel, dim3((v.n_rows + 255) / 256), dim3(256), 0, 0, v,
+                     flag);
+  int32_t res = 0;
+  EG_HIP(hipMemcpy(&res, flag, 4, hipMemcpyDeviceToHost));
+  EG_HIP(hipFree(flag));
+  v.total_in_meta = res;
+  return EULER_GPU_OK;
+}
+
 int BuildBlockedIndex(GraphBuilder* b);
 
 // Pivot levels over the flat arrays (variant 5) and the EdgeBlock copy with its
 // block pivots (variant 6, the default sampler) are both built at creation.
 int BuildSearchIndex(GraphBuilder* b) {
-  const int rc = BuildPivotLevels(b);
+  int rc = VerifyTotals(b);
+  if (rc == EULER_GPU_OK) rc = BuildPivotLevels(b);
   return rc != EULER_GPU_OK ? rc : BuildBlockedIndex(b);
 }
 

@@ -503,6 +503,10 @@ __global__ __launch_bounds__(256) void SampleNeighborIlpKernel(const SampleNbArg
 namespace {
 constexpr int64_t kK1GridCap = 32768;
 int g_k1_dedup = 1;     // 0 = never, 1 = automatic for >= 16384 roots, 2 = always try
+int g_k1_group = 0;     // block-pivot kernel: five adjacent samples per lane for odd counts
+                        // that are a multiple of 5 - measured 8 % SLOWER on the metric's
+                        // first hop (it is bound by the dependent-load chain per lane, not
+                        // by instruction count), kept selectable
 int g_k1_pair = 1;      // pivot kernel: two adjacent samples per lane when count is even
 int g_k1_grid_cap = 0;  // measurement only: override the workgroup cap of K1
 int g_k1_ablate = 0;   // measurement only: skip parts of the blocked kernel
@@ -1202,6 +1206,16 @@ __device__ __forceinline__ bool LoadSegment(const GraphView& g, int64_t row,
     sg->row_ptr = (int64_t)(((uint64_t)q.y << 32) | q.x);
     sg->b = 0;
     sg->e = (int32_t)q.z - 1;
+    if (g.total_in_meta) {
+      // the record's type sum IS the row's last running sum (verified at build):
+      // one dependent load less per root
+      if (sg->e < 0) return false;
+      sg->lo = sg->row_ptr;
+      sg->hi = sg->row_ptr + sg->e;
+      sg->limit_begin = 0.f;
+      sg->limit_end = __uint_as_float(q.w);
+      return true;
+    }
   } else {
     sg->row_ptr = *reinterpret_cast<const int64_t*>(rec);
     const int32_t* te = reinterpret_cast<const int32_t*>(rec + 8);
@@ -1283,6 +1297,113 @@ __global__ __launch_bounds__(256) void SampleNeighborPivotKernel(
   }
 }
 
+// ------------------------------------------------------------------------
+// Group mode of the block-pivot kernel: a lane draws U adjacent samples of one
+// root (count % U == 0).  The root id, row record and limits are loaded once per
+// U samples, and when the searched segment lies inside ONE EdgeBlock (the usual
+// case for the uniformly drawn roots of a first hop: average degree 10) so are
+// the three leaf loads - every sample then costs one id load.  Used for odd
+// counts that are a multiple of 5 (fanout 25), where the two-sample mode with
+// its 16-byte stores does not apply.
+// ------------------------------------------------------------------------
+template <bool TF_LAYOUT, int U>
+__global__ __launch_bounds__(256) void SampleNeighborGroupKernel(
+    const SampleNbArgs a, const int64_t stride_rows, const int32_t stride_slots) {
+  int64_t n_roots;
+  if (!DedupGate(a, &n_roots)) return;
+  const int64_t total = n_roots * (int64_t)a.count;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * U;
+  int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * U;
+  if (s >= total) return;
+  int64_t r = s / a.count;
+  int32_t j = (int32_t)(s - r * a.count);
+  const int32_t t = a.et[0];
+  for (; s < total; s += stride) {
+    uint64_t node = a.roots[r];
+    if (a.root_mask != nullptr && a.root_mask[r / a.root_group]) node = 0;
+    Segment sg;
+    const bool valid = LoadSegment<true>(a.g, FindRow(a.g, node), t, &sg);
+    uint64_t id[U];
+    float w[U];
+    int32_t ot = t;
+    if (valid) {
+      double u[U];
+#pragma unroll
+      for (int x = 0; x < U; x += 2) {
+        // draws j+x, j+x+1 (j is a multiple of U; U odd -> the parity of j varies)
+        const uint32_t d = (uint32_t)(j + x);
+        const Philox4 b0 = RngBlock(a.seed, a.call_id, kDomainNeighbor, node, d >> 1);
+        if ((d & 1) == 0) {
+          u[x] = UnitFromWords(b0.w[0], b0.w[1]);
+          if (x + 1 < U) u[x + 1] = UnitFromWords(b0.w[2], b0.w[3]);
+        } else {
+          u[x] = UnitFromWords(b0.w[2], b0.w[3]);
+          if (x + 1 < U) {
+            const Philox4 b1 = RngBlock(a.seed, a.call_id, kDomainNeighbor, node,
+                                        (d + 1) >> 1);
+            u[x + 1] = UnitFromWords(b1.w[0], b1.w[1]);
+          }
+        }
+      }
+      const int64_t blk_lo = sg.lo / kEdgesPerBlock;
+      if (blk_lo == sg.hi / kEdgesPerBlock) {
+        // the whole segment sits in one block: one set of leaf loads for U draws
+        const EdgeBlock* bk = a.g.blk + blk_lo;
+        const int64_t base = blk_lo * kEdgesPerBlock;
+        const int32_t i_lo = (int32_t)(sg.lo - base), i_hi = (int32_t)(sg.hi - base);
+        const float4 a0 = *reinterpret_cast<const float4*>(bk->pw);
+        const float4 a1 = *reinterpret_cast<const float4*>(bk->pw + 4);
+        const float4 a2 = *reinterpret_cast<const float4*>(bk->pw + 8);
+        const float v[10] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y};
+#pragma unroll
+        for (int x = 0; x < U; ++x) {
+          const double rr = ScaleDraw(u[x], sg.limit_begin, sg.limit_end);
+          if (!((double)sg.limit_end > rr)) {          // Q3: replay the reference
+            const float* nw = a.g.prefix_w + sg.row_ptr;
+            const int32_t m = (int32_t)RandomSelect(nw, (uint64_t)sg.b, (uint64_t)sg.e, u[x]);
+            id[x] = a.g.nbr[sg.row_ptr + m];
+            w[x] = __fsub_rn(nw[m], m == 0 ? 0.f : nw[m - 1]);
+            continue;
+          }
+          int32_t i = i_lo;
+#pragma unroll
+          for (int q = 0; q < kEdgesPerBlock - 1; ++q)
+            i += (q >= i_lo && q < i_hi && !((double)v[q] > rr)) ? 1 : 0;
+          float nw_m = v[0], prev = a2.z;
+#pragma unroll
+          for (int q = 0; q < kEdgesPerBlock; ++q) {
+            if (q == i) nw_m = v[q];
+            if (q + 1 == i) prev = v[q];
+          }
+          if (base + i == sg.row_ptr) prev = 0.f;
+          id[x] = bk->nbr[i];
+          w[x] = __fsub_rn(nw_m, prev);
+        }
+      } else {
+#pragma unroll
+        for (int x = 0; x < U; ++x) BlockPivotSample(a.g, sg, u[x], &id[x], &w[x]);
+      }
+    } else {
+#pragma unroll
+      for (int x = 0; x < U; ++x) {
+        id[x] = TF_LAYOUT ? (uint64_t)a.default_node : 0;
+        w[x] = 0.f;
+      }
+      ot = TF_LAYOUT ? -1 : 0;
+    }
+#pragma unroll
+    for (int x = 0; x < U; ++x) {
+      a.out_id[s + x] = id[x];
+      a.out_w[s + x] = w[x];
+      a.out_t[s + x] = ot;
+    }
+    if (j == 0 && a.out_row_mask != nullptr) a.out_row_mask[r] = valid ? 0 : 1;
+    r += stride_rows;
+    j += stride_slots;
+    if (j >= a.count) { j -= a.count; ++r; }
+  }
+}
+
 template <int U>
 static void LaunchIlp(bool tf, int grid, int block, hipStream_t stream,
                       const SampleNbArgs& a) {
@@ -1337,6 +1458,25 @@ static int LaunchK1(const euler_gpu_graph* g, hipStream_t stream,
     const int64_t stride_rows = stride / count;
     const int32_t stride_slots = (int32_t)(stride - stride_rows * count);
     const bool tf = layout == EULER_GPU_LAYOUT_TF;
+    if (blocked && !pair && g_k1_group != 0 && count % 5 == 0 && a.dd_role != 2) {
+      // odd multiple of 5 (fanout 25): five adjacent samples per lane
+      int64_t blocks = (n * (int64_t)count / 5 + block - 1) / block;
+      const int64_t cap = g_k1_grid_cap > 0 ? g_k1_grid_cap : kK1GridCap;
+      if (blocks > cap) blocks = cap;
+      const int gridg = (int)(blocks < 1 ? 1 : blocks);
+      const int64_t gstride = (int64_t)gridg * block * 5;
+      const int64_t g_rows = gstride / count;
+      const int32_t g_slots = (int32_t)(gstride - g_rows * count);
+      if (tf) {
+        hipLaunchKernelGGL((SampleNeighborGroupKernel<true, 5>), dim3(gridg), dim3(block),
+                           0, stream, a, g_rows, g_slots);
+      } else {
+        hipLaunchKernelGGL((SampleNeighborGroupKernel<false, 5>), dim3(gridg), dim3(block),
+                           0, stream, a, g_rows, g_slots);
+      }
+      EG_HIP(hipGetLastError());
+      return EULER_GPU_OK;
+    }
     auto kern = blocked
         ? (pair ? (tf ? SampleNeighborPivotKernel<true, 2, true>
                       : SampleNeighborPivotKernel<false, 2, true>)
@@ -1962,6 +2102,7 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 3) { g_k1_grid_cap = value; return EULER_GPU_OK; }
   if (key == 4) { g_k1_pair = value; return EULER_GPU_OK; }
   if (key == 5) { g_k1_dedup = value; return EULER_GPU_OK; }
+  if (key == 6) { g_k1_group = value; return EULER_GPU_OK; }
   if (key == 1 && (value == 1 || value == 2 || value == 4 || value == 8)) {
     g_k1_ilp = value;
     return EULER_GPU_OK;

@@ -27,11 +27,14 @@ def k1_variant(request, EA):
     _lib.lib().euler_gpu_set_tuning(1, request.param[1])
     # (6, 1) forces one sample per lane
     _lib.lib().euler_gpu_set_tuning(4, 0 if request.param == (6, 1) else 1)
+    # ... and (6, 2) also turns on five samples per lane for odd multiples of 5
+    _lib.lib().euler_gpu_set_tuning(6, 1 if request.param == (6, 2) else 0)
     # (6, 2): always run the duplicate-root machinery, whatever the batch size
     _lib.lib().euler_gpu_set_tuning(5, 2 if request.param == (6, 2) else 1)
     yield request.param
     _lib.lib().euler_gpu_set_tuning(4, 1)
     _lib.lib().euler_gpu_set_tuning(5, 1)
+    _lib.lib().euler_gpu_set_tuning(6, 0)
     _lib.lib().euler_gpu_set_tuning(0, 6)
     _lib.lib().euler_gpu_set_tuning(1, 4)
 

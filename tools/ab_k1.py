@@ -14,10 +14,11 @@ hop2_roots = out[0][1].contiguous()
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 et1 = (C.c_int32*1)(0)
 res = {}
-for variant in ((5,0),):
+for variant in ((6,0),):
     L.euler_gpu_set_tuning(0, variant[0]); L.euler_gpu_set_tuning(3, variant[1])
-    for pair in (0, 1, 2):
-     L.euler_gpu_set_tuning(5, pair)
+    L.euler_gpu_set_tuning(5, 0)
+    for pair in (0, 1, 0, 1):
+     L.euler_gpu_set_tuning(6, pair)
      for name, r, cnt in (('hop1', roots, 25), ('hop2', hop2_roots, 10)):
         n = r.numel()
         oid = torch.empty(n*cnt, dtype=torch.int64, device='cuda'); ow = torch.empty(n*cnt, dtype=torch.float32, device='cuda'); ot = torch.empty(n*cnt, dtype=torch.int32, device='cuda')
