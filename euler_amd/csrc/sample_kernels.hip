@@ -1876,6 +1876,11 @@ struct WalkArgs {
   float q;
 };
 
+// FAST: one listed edge type per step on a graph with non-decreasing running
+// sums - every step is the block-pivot search of K1 (draw 0 of the current
+// node, call_id + step), i.e. ~log5(deg / 10) + 4 dependent loads instead of
+// the reference loop's 2 * ceil(log2 deg).
+template <bool FAST>
 __global__ __launch_bounds__(256) void RandomWalkKernel(const WalkArgs a) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t L = a.walk_len + 1;
@@ -1884,10 +1889,19 @@ __global__ __launch_bounds__(256) void RandomWalkKernel(const WalkArgs a) {
     uint64_t cur = (uint64_t)a.nodes[i];
     a.out[i * L] = (int64_t)cur;
     for (int32_t s = 0; s < a.walk_len; ++s) {
-      RowSampler rs;
-      InitRowSampler(rs, a.g, FindRow(a.g, cur), a.edge_types + s * a.k, a.k);
       uint64_t id = 0; float w; int32_t t;
-      if (rs.valid) SampleAt(rs, a.seed, a.call_id + (uint32_t)s, cur, 0, &id, &w, &t);
+      if (FAST) {
+        Segment sg;
+        if (LoadSegment<true>(a.g, FindRow(a.g, cur), a.edge_types[s], &sg)) {
+          const Philox4 blk = RngBlock(a.seed, a.call_id + (uint32_t)s, kDomainNeighbor,
+                                       cur, 0);
+          BlockPivotSample(a.g, sg, UnitFromWords(blk.w[0], blk.w[1]), &id, &w);
+        }
+      } else {
+        RowSampler rs;
+        InitRowSampler(rs, a.g, FindRow(a.g, cur), a.edge_types + s * a.k, a.k);
+        if (rs.valid) SampleAt(rs, a.seed, a.call_id + (uint32_t)s, cur, 0, &id, &w, &t);
+      }
       a.out[i * L + s + 1] = id == 0 ? a.default_node : (int64_t)id;
       cur = id;
     }
@@ -2323,8 +2337,13 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
   const float kEps = 1.0e-6;
   // random_walk_op.cc:281: fabs(p_ - 1.0) <= kEps && fabs(q_ - 1.0) <= kEps
   if (std::fabs((double)p - 1.0) <= kEps && std::fabs((double)q - 1.0) <= kEps) {
-    hipLaunchKernelGGL(RandomWalkKernel, dim3(GridFor(n, block)), dim3(block), 0,
-                       st, a);
+    if (k == 1 && g->view.monotone && g->view.blk != nullptr && g_k1_variant >= 5) {
+      hipLaunchKernelGGL(RandomWalkKernel<true>, dim3(GridFor(n, block)), dim3(block), 0,
+                         st, a);
+    } else {
+      hipLaunchKernelGGL(RandomWalkKernel<false>, dim3(GridFor(n, block)), dim3(block), 0,
+                         st, a);
+    }
   } else {
     hipLaunchKernelGGL(Node2VecKernel, dim3(GridFor(n, block)), dim3(block), 0,
                        st, a);
