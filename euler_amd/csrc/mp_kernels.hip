@@ -89,7 +89,23 @@ __global__ __launch_bounds__(256) void SegmentReduceKernel(
     const int64_t en = LowerBound(keys, e, (int32_t)r + 1);
     for (int64_t c = lane; c < d; c += 64) {
       float acc = IS_MAX ? (float)-1e9 : 0.f;   // scatter_op.cc:47,78
-      for (int64_t p = b; p < en; ++p) {
+      int64_t p = b;
+      // the additions stay in input order (fp32 is not associative); only the
+      // loads are issued eight at a time so that their latencies overlap
+      for (; p + 8 <= en; p += 8) {
+        float v[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+          const int64_t src = perm ? (int64_t)perm[p + x] : p + x;
+          v[x] = upd[src * d + c];
+        }
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+          if (IS_MAX) { if (v[x] > acc) acc = v[x]; }
+          else acc = __fadd_rn(acc, v[x]);
+        }
+      }
+      for (; p < en; ++p) {
         const int64_t src = perm ? (int64_t)perm[p] : p;
         const float v = upd[src * d + c];
         if (IS_MAX) { if (v > acc) acc = v; }
@@ -170,6 +186,69 @@ struct IdxEdge {
     return idx[2 * i + which];
   }
 };
+
+// Rows of up to kWaveSortMax entries (most rows of a batch) are ranked inside one
+// wave: every entry counts the entries that sort before it - smaller key, or
+// equal key and earlier position (stable, as the radix sort used for longer
+// rows).  perm[b + rank] = b + j.  Longer rows are left to the segmented radix
+// sort, which sees the short rows as empty segments.
+constexpr int32_t kWaveSortMax = 64;     // rows up to this length are ranked by one wave (longer
+                                         // ones cost len^2 / 64 steps there: measured slower at 1024)
+
+struct IdxEdgeLong {
+  const int32_t* idx;
+  int32_t which;
+  __host__ __device__ __forceinline__ int32_t operator()(const int32_t& i) const {
+    const int32_t b = idx[2 * i], e = idx[2 * i + 1];
+    if (e - b <= kWaveSortMax) return b;   // empty segment: handled by WaveRankKernel
+    return which ? e : b;
+  }
+};
+
+// One wave per row: lane j holds entries j, j + 64, ... and counts, for each,
+// the entries that sort before it (the keys of a row are read by all lanes at
+// the same address: one request each, then the L1).
+template <typename K, bool DESC>
+__global__ __launch_bounds__(256) void SmallRowRankKernel(
+    const int32_t* __restrict__ idx, int64_t n, const K* __restrict__ keys,
+    int32_t* __restrict__ perm) {
+  const int lane = threadIdx.x & 63;
+  const int64_t waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < n;
+       i += waves) {
+    const int32_t b = idx[2 * i], len = idx[2 * i + 1] - b;
+    if (len <= 0 || len > kWaveSortMax) continue;
+    if (len <= 64) {
+      const bool live = lane < len;
+      const K mine = live ? keys[b + lane] : K();
+      int32_t rank = 0;
+      for (int32_t o = 0; o < len; ++o) {
+        const K other = __shfl(mine, o);
+        const bool before = DESC ? (other > mine) : (other < mine);
+        rank += (before || (other == mine && o < lane)) ? 1 : 0;
+      }
+      if (live) perm[b + rank] = b + lane;
+    } else {
+      for (int32_t j = lane; j < len; j += 64) {
+        const K mine = keys[b + j];
+        int32_t rank = 0;
+        for (int32_t o = 0; o < len; ++o) {
+          const K other = keys[b + o];
+          const bool before = DESC ? (other > mine) : (other < mine);
+          rank += (before || (other == mine && o < j)) ? 1 : 0;
+        }
+        perm[b + rank] = b + j;
+      }
+    }
+  }
+}
+
+__global__ void MaxRowLenKernel(const int32_t* idx, int64_t n, int32_t* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int32_t l = i < n ? idx[2 * i + 1] - idx[2 * i] : 0;
+  for (int off = 32; off > 0; off >>= 1) l = max(l, __shfl_xor(l, off));
+  if ((threadIdx.x & 63) == 0 && l > kWaveSortMax) atomicMax(out, l);   // only long rows report
+}
 
 __global__ void IotaKernel(int32_t* p, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -528,11 +607,23 @@ int euler_gpu_neighbor_post_process(void* stream, int64_t n, int32_t* idx_dev,
     hipLaunchKernelGGL(IotaKernel, dim3((total + block - 1) / block), dim3(block), 0, st,
                        p_in, total);
     hipcub::CountingInputIterator<int32_t> row_it(0);
-    hipcub::TransformInputIterator<int32_t, IdxEdge, hipcub::CountingInputIterator<int32_t>>
-        seg_b(row_it, IdxEdge{idx_dev, 0}), seg_e(row_it, IdxEdge{idx_dev, 1});
+    hipcub::TransformInputIterator<int32_t, IdxEdgeLong,
+                                   hipcub::CountingInputIterator<int32_t>>
+        seg_b(row_it, IdxEdgeLong{idx_dev, 0}), seg_e(row_it, IdxEdgeLong{idx_dev, 1});
     size_t tmp_bytes = 0;
     void* tmp = nullptr;
+    // the library pass is only needed when some row is longer than a wave ranks
+    int32_t max_len = 0;
+    {
+      int32_t* d_max = (int32_t*)(buf + o_len);      // free until LimitLenKernel
+      EG_HIP(hipMemsetAsync(d_max, 0, 4, st));
+      hipLaunchKernelGGL(MaxRowLenKernel, dim3((n + block - 1) / block), dim3(block), 0,
+                         st, idx_dev, n, d_max);
+      EG_HIP(hipMemcpyAsync(&max_len, d_max, 4, hipMemcpyDeviceToHost, st));
+      EG_HIP(hipStreamSynchronize(st));
+    }
 #define EG_SEGSORT(KEY_T, KEYS_IN, FN)                                               \
+    { if (max_len > kWaveSortMax)                                                    \
     {                                                                                \
       KEY_T* keys_out = (KEY_T*)(buf + o_key);                                       \
       EG_HIP(hipcub::DeviceSegmentedRadixSort::FN(nullptr, tmp_bytes, KEYS_IN,       \
@@ -544,7 +635,7 @@ int euler_gpu_neighbor_post_process(void* stream, int64_t n, int32_t* idx_dev,
                                                   p_in, p_out, (int)total, (int)n,   \
                                                   seg_b, seg_e, 0,                   \
                                                   (int)sizeof(KEY_T) * 8, st));      \
-    }
+    } }
     if (order_by == 1) {
       if (desc) EG_SEGSORT(uint64_t, c_id, SortPairsDescending)
       else EG_SEGSORT(uint64_t, c_id, SortPairs)
@@ -553,7 +644,22 @@ int euler_gpu_neighbor_post_process(void* stream, int64_t n, int32_t* idx_dev,
       else EG_SEGSORT(float, c_w, SortPairs)
     }
 #undef EG_SEGSORT
-    EG_HIP(hipFreeAsync(tmp, st));
+    if (tmp) EG_HIP(hipFreeAsync(tmp, st));
+    // short rows: ranked in a wave, written into the same permutation array
+    {
+      const int gridw = GridFor(n * 64, block);
+      if (order_by == 1) {
+        if (desc) hipLaunchKernelGGL((SmallRowRankKernel<uint64_t, true>), dim3(gridw),
+                                     dim3(block), 0, st, idx_dev, n, c_id, p_out);
+        else hipLaunchKernelGGL((SmallRowRankKernel<uint64_t, false>), dim3(gridw),
+                                dim3(block), 0, st, idx_dev, n, c_id, p_out);
+      } else {
+        if (desc) hipLaunchKernelGGL((SmallRowRankKernel<float, true>), dim3(gridw),
+                                     dim3(block), 0, st, idx_dev, n, c_w, p_out);
+        else hipLaunchKernelGGL((SmallRowRankKernel<float, false>), dim3(gridw),
+                                dim3(block), 0, st, idx_dev, n, c_w, p_out);
+      }
+    }
     perm = p_out;
   }
   hipLaunchKernelGGL(LimitLenKernel, dim3((n + block - 1) / block), dim3(block), 0, st,
