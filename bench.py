@@ -52,10 +52,14 @@ def parse():
                     help="graph size of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
-    ap.add_argument("--pipeline", type=int, default=3,
+    ap.add_argument("--pipeline", type=int, default=0,
                     help="sharded path: minibatches in flight (each on its own host "
                          "thread, HIP stream and RCCL communicator, so one batch's "
-                         "host synchronisations overlap another batch's kernels)")
+                         "host synchronisations overlap another batch's kernels).  "
+                         "0 = automatic: 1 when several ranks exchange data (several "
+                         "communicators driven from several threads are only safe "
+                         "if their kernels can always co-run; not verified on 8 GPUs "
+                         "yet), 3 for the one-rank --force-sharded measurement")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU sampler (unique / split / all-to-all / "
                          "merge / gather) even on one rank: measures its overhead")
@@ -152,6 +156,8 @@ def main():
         # collectives are ordered on its own communicator.
         import threading
         from euler_amd.distributed import gpu_sharded_sampler
+        if args.pipeline <= 0:
+            args.pipeline = 1 if world > 1 else 3
         K = max(1, min(args.pipeline, args.steps))
         groups = [dist.new_group(list(range(world))) if K > 1 else None for _ in range(K)]
         samplers = [gpu_sharded_sampler(G, partitions=world, group=g) for g in groups]
