@@ -503,6 +503,7 @@ __global__ __launch_bounds__(256) void SampleNeighborIlpKernel(const SampleNbArg
 namespace {
 constexpr int64_t kK1GridCap = 32768;
 int g_k1_dedup = 1;     // 0 = never, 1 = automatic for >= 16384 roots, 2 = always try
+int g_n2v_wave = 1;     // node2vec: 1 = one wave per walker (LDS-staged lists), 0 = one lane
 int g_k1_group = 0;     // block-pivot kernel: five adjacent samples per lane for odd counts
                         // that are a multiple of 5 - measured 8 % SLOWER on the metric's
                         // first hop (it is bound by the dependent-load chain per lane, not
@@ -2040,6 +2041,177 @@ __global__ __launch_bounds__(256) void Node2VecKernel(const WalkArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------
+// node2vec, one WAVE per walker (default).  The step's weights come out of a
+// two-cursor walk over the child's and the parent's neighbour lists in storage
+// order (BuildWeights, random_walk_op.cc:140-168) - a sequential recurrence
+// that cannot be split across lanes without changing which parent entry each
+// child is compared with.  What can be shared is the memory traffic: the 64
+// lanes copy both lists into LDS in coalesced chunks (ids, and the weights as
+// differences of the running sums), and lane 0 runs the recurrence out of LDS
+// (tens of cycles per step instead of a dependent HBM round trip per lane and
+// step, and no lane waits for a neighbour's hub row).  Pass 1 accumulates the
+// total with the reference's sequential f32 adds, pass 2 stops at the first
+// running sum > r - the same index the reference's bisection of those sums
+// returns (and its last element when the total is 0).  Measured on the metric
+// graph (100 K walkers x 10 steps, walkers sit on hubs of 1e5+ neighbours):
+// 1.69 s -> 1.15 s; prefetching the next entries by hand made it slower (1.34 s).
+// ------------------------------------------------------------------------
+constexpr int kN2vChunk = 256;
+constexpr int kN2vMaxSeg = kMaxListedTypes;
+
+struct N2vList {           // one neighbour list = listed type segments of a row
+  int64_t row_ptr;         // row start in nbr / prefix_w
+  int32_t n_seg;
+  int32_t total;           // entries
+  int32_t seg_b[kN2vMaxSeg];
+  int32_t seg_len[kN2vMaxSeg];
+};
+
+struct alignas(16) N2vLds {
+  uint64_t c_id[kN2vChunk];
+  uint64_t p_id[kN2vChunk];
+  float c_w[kN2vChunk];
+  N2vList child, parent;
+};
+
+// Built by lane 0, read by all lanes after a wave sync.
+__device__ __forceinline__ void N2vBuildList(N2vList* L, const GraphView& g, int64_t row,
+                                             const int32_t* et, int32_t k) {
+  L->n_seg = 0; L->total = 0; L->row_ptr = 0;
+  if (row < 0) return;
+  const RowMeta m = LoadRowMeta(g, row);
+  L->row_ptr = m.row_ptr;
+  for (int32_t x = 0; x < k; ++x) {
+    const int32_t t = et[x];
+    if (t < 0 || t >= g.T) continue;
+    const int32_t b = t == 0 ? 0 : m.type_end[t - 1];
+    const int32_t len = m.type_end[t] - b;
+    if (len <= 0) continue;
+    L->seg_b[L->n_seg] = b;
+    L->seg_len[L->n_seg] = len;
+    ++L->n_seg;
+    L->total += len;
+  }
+}
+
+// row-relative position of logical entry j
+__device__ __forceinline__ int32_t N2vPhys(const N2vList& L, int32_t j) {
+  for (int32_t x = 0; x < L.n_seg; ++x) {
+    if (j < L.seg_len[x]) return L.seg_b[x] + j;
+    j -= L.seg_len[x];
+  }
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void Node2VecWaveKernel(const WalkArgs a) {
+  __shared__ N2vLds lds_all[4];
+  N2vLds& S = lds_all[threadIdx.x >> 6];
+  const int lane = threadIdx.x & 63;
+  const int64_t waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int64_t L = a.walk_len + 1;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < a.n;
+       i += waves) {
+    int64_t cur = a.nodes[i];
+    int64_t parent = cur;          // parent_ids_ starts as the start nodes
+    bool have_parent_nb = false;   // parent_neighbors_ starts empty
+    if (lane == 0) a.out[i * L] = cur;
+    for (int32_t s = 0; s < a.walk_len; ++s) {
+      const int32_t* et = a.edge_types + s * a.k;
+      const int32_t* pet = s > 0 ? a.edge_types + (s - 1) * a.k : et;
+      WaveSync();
+      if (lane == 0) {
+        N2vBuildList(&S.child, a.g, FindRow(a.g, (uint64_t)cur), et, a.k);
+        N2vBuildList(&S.parent, a.g,
+                     have_parent_nb ? FindRow(a.g, (uint64_t)parent) : -1, pet, a.k);
+      }
+      WaveSync();
+      const int32_t nc = S.child.total, np = S.parent.total;
+      int64_t sample_id = a.default_node;
+      if (nc > 0) {
+        const float* c_nw = a.g.prefix_w + S.child.row_ptr;
+        const uint64_t* c_nbr = a.g.nbr + S.child.row_ptr;
+        const uint64_t* p_nbr = a.g.nbr + S.parent.row_ptr;
+        float total = 0.f;
+        double r = 0.0;
+        uint64_t last_id = 0;
+        for (int pass = 0; pass < 2; ++pass) {
+          int32_t j = 0, k = 0;           // cursors (logical entries)
+          int32_t cj0 = 0, pk0 = 0;       // chunk bases
+          int32_t c_have = 0, p_have = 0; // entries loaded in each chunk
+          float acc = 0.f;
+          bool found = false;
+          bool need_c = true, need_p = np > 0;
+          while (j < nc && !found) {
+            if (need_c) {
+              WaveSync();
+              cj0 = j;
+              c_have = min(kN2vChunk, nc - cj0);
+              for (int32_t t = lane; t < c_have; t += 64) {
+                const int32_t ph = N2vPhys(S.child, cj0 + t);
+                S.c_id[t] = c_nbr[ph];
+                S.c_w[t] = __fsub_rn(c_nw[ph], ph == 0 ? 0.f : c_nw[ph - 1]);
+              }
+              need_c = false;
+            }
+            if (need_p) {
+              WaveSync();
+              pk0 = k;
+              p_have = min(kN2vChunk, np - pk0);
+              for (int32_t t = lane; t < p_have; t += 64)
+                S.p_id[t] = p_nbr[N2vPhys(S.parent, pk0 + t)];
+              need_p = false;
+            }
+            WaveSync();
+            if (lane == 0) {
+              const int32_t c_end = cj0 + c_have;
+              const int32_t p_end = pk0 + p_have;
+              while (j < c_end) {
+                const int64_t cid = (int64_t)S.c_id[j - cj0];
+                float w = S.c_w[j - cj0];
+                if (k < np) {
+                  if (k >= p_end) break;               // next parent chunk
+                  const int64_t pid = (int64_t)S.p_id[k - pk0];
+                  if (cid > pid) { ++k; continue; }    // parent cursor only
+                  if (cid == pid) ++k;                 // common neighbour: weight kept
+                  else w = cid != parent ? __fdiv_rn(w, a.q) : __fdiv_rn(w, a.p);
+                } else {
+                  w = cid != parent ? __fdiv_rn(w, a.q) : __fdiv_rn(w, a.p);
+                }
+                const float prev = acc;
+                acc = __fadd_rn(acc, w);
+                last_id = (uint64_t)cid;
+                ++j;
+                if (pass == 1 && (double)prev <= r && r < (double)acc) { found = true; break; }
+              }
+            }
+            j = __shfl(j, 0);
+            k = __shfl(k, 0);
+            found = __shfl((int)found, 0) != 0;
+            need_c = j >= cj0 + c_have;
+            need_p = k < np && k >= pk0 + p_have;
+          }
+          if (pass == 0) {
+            total = __shfl(acc, 0);
+            const double u = RngDraw(a.seed, a.call_id + (uint32_t)s, kDomainWalk,
+                                     (uint64_t)i, 0);
+            r = ScaleDraw(u, 0.f, total);
+          }
+        }
+        // found: last_id is the hit; not found (total == 0): RandomSelect's
+        // fall-through ends on the last element, which is last_id as well
+        const uint32_t lo32 = __shfl((uint32_t)last_id, 0);
+        const uint32_t hi32 = __shfl((uint32_t)(last_id >> 32), 0);
+        sample_id = (int64_t)(((uint64_t)hi32 << 32) | lo32);
+      }
+      if (lane == 0) a.out[i * L + s + 1] = sample_id;
+      parent = cur;
+      have_parent_nb = true;
+      cur = sample_id;
+    }
+  }
+}
+
 struct GenPairArgs {
   const int64_t* paths;
   int64_t* out;
@@ -2117,6 +2289,7 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 4) { g_k1_pair = value; return EULER_GPU_OK; }
   if (key == 5) { g_k1_dedup = value; return EULER_GPU_OK; }
   if (key == 6) { g_k1_group = value; return EULER_GPU_OK; }
+  if (key == 7) { g_n2v_wave = value; return EULER_GPU_OK; }
   if (key == 1 && (value == 1 || value == 2 || value == 4 || value == 8)) {
     g_k1_ilp = value;
     return EULER_GPU_OK;
@@ -2345,8 +2518,12 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
                          st, a);
     }
   } else {
-    hipLaunchKernelGGL(Node2VecKernel, dim3(GridFor(n, block)), dim3(block), 0,
-                       st, a);
+    if (g_n2v_wave != 0) {
+      hipLaunchKernelGGL(Node2VecWaveKernel, dim3(GridFor(n * 64, block)), dim3(block), 0,
+                         st, a);
+    } else {
+      hipLaunchKernelGGL(Node2VecKernel, dim3(GridFor(n, block)), dim3(block), 0, st, a);
+    }
   }
   EG_HIP(hipGetLastError());
   // the edge-type table must outlive the kernel: stream-ordered free

@@ -378,6 +378,8 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  * key 4: variant 5 draws two adjacent samples per lane when count is even (1).
  * key 6: five adjacent samples per lane for odd counts that are a multiple of 5
  *        (default 0: measured slower on the metric's first hop).
+ * key 7: node2vec kernel: 1 = one wave per walker, lists staged in LDS [default],
+ *        0 = one lane per walker.
  * key 5: duplicate roots: 0 = never look, 1 = look when a call has >= 16384
  *        roots [default], 2 = always look.
  * All settings produce identical results; the knobs exist for A/B measurements

@@ -702,3 +702,47 @@ def test_dedup_split_pack_expand(EA, O, torch_cuda):
     assert np.array_equal(t2n(o_m), t2n(r_m)[pos_n])
     e_id, e_w, e_t, e_m = EA.ops.expand_rows(pos, r_id, r_w, r_t, r_m, count)
     assert np.array_equal(t2n(e_id), t2n(o_id)) and np.array_equal(t2n(e_m), t2n(o_m))
+
+
+@pytest.mark.parametrize("wave", [1, 0], ids=["n2v_wave", "n2v_lane"])
+def test_node2vec_long_lists_both_kernels(EA, O, torch_cuda, wave):
+    """node2vec steps whose child AND parent lists span several 256-entry LDS
+    chunks (hubs of 700-900 neighbours that point at each other), with two
+    listed edge types: the wave-per-walker kernel and the lane-per-walker kernel
+    must both reproduce the oracle's two-cursor BuildWeights walk."""
+    torch = torch_cuda
+    from euler_amd import _lib
+    rng = np.random.default_rng(41)
+    n, T = 400, 2
+    ids = np.arange(1, n + 1).astype(np.uint64)
+    deg = rng.integers(1, 12, size=(n, T))
+    hubs = np.arange(0, 12)
+    deg[hubs, :] = rng.integers(350, 450, size=(len(hubs), T))
+    seg = np.zeros(n * T + 1, np.int64)
+    seg[1:] = np.cumsum(deg.reshape(-1))
+    E = int(seg[-1])
+    nbr = rng.choice(ids, E).astype(np.uint64)
+    # hubs mostly point at hubs, so walks keep meeting long parent lists
+    for h in hubs:
+        for t in range(T):
+            b, e = seg[h * T + t], seg[h * T + t + 1]
+            nbr[b:e] = np.where(rng.random(e - b) < 0.7, rng.choice(ids[hubs], e - b),
+                                nbr[b:e])
+    w = (rng.random(E) * 3 + 0.1).astype(np.float32)
+    w[rng.random(E) < 0.05] = 0
+    csr = O.csr_from_raw(ids, seg, nbr, w, T)
+    G, OG = gpu_graph(EA, csr), O.OracleGraph(csr)
+    starts = np.concatenate([rng.choice(ids, 300), ids[hubs], [0, 999]]).astype(np.int64)
+    L = 7
+    et = [[0, 1], [1], [0, 1], [1, 0], [0], [0, 1], [1, 0]]
+    et_arr = [e + [e[-1]] * (2 - len(e)) for e in et]      # pad to k = 2 (repeats a type)
+    _lib.lib().euler_gpu_set_tuning(7, wave)
+    try:
+        G.set_seed(6)
+        for p, q in ((0.25, 4.0), (2.0, 0.5)):
+            got = t2n(G.random_walk(torch.as_tensor(starts).cuda(), et_arr, p, q, -1,
+                                    call_id=50))
+            want = OG.random_walk(6, 50, starts, et_arr, L, p, q, -1)
+            assert np.array_equal(got, want), (p, q)
+    finally:
+        _lib.lib().euler_gpu_set_tuning(7, 1)
