@@ -67,6 +67,13 @@ class ShardedSampler:
         # wire format hooks of the fused path (HIP kernels on GPUs): pack_fn(ids,
         # w, t, mask, count) -> int32 rows; expand_fn(pos, rows, count) -> outputs
         self.pack_fn = None
+        # optional hooks for get_dense_feature / sample_node (see those methods)
+        self.local_feature = None
+        self.row_gather_fn = None
+        self.local_sample_node = None
+        self.node_weight_sum = None
+        self.node_split_fn = None
+        self.device = torch.device("cpu")
 
     # -------------------------------------------------------------- helpers
     def _exchange(self, send, send_counts, recv_counts):
@@ -180,6 +187,69 @@ class ShardedSampler:
             cur, mask, group = ids.reshape(-1), m, count
         return neighbors, weights, types
 
+    # ------------------------------------------------------------ features
+    def get_dense_feature(self, nodes, feature_ids, dimensions):
+        """tf_euler get_dense_feature over the sharded graph: the distinct ids
+        travel to their owners (same front end as a sampling hop), each owner
+        gathers its rows, the rows come back and are expanded to positions.
+        Needs local_feature(owned ids, feature_ids, dimensions) -> list of
+        [m, dim] float32 tensors and row_gather_fn(rows f32 [m, D], pos) -> rows."""
+        nodes = nodes.reshape(-1).to(torch.int64)
+        n = nodes.numel()
+        dims = [int(d) for d in dimensions]
+        if self.dedup_split_fn is not None:
+            shard_off, shard_ids, pos = self.dedup_split_fn(nodes, self.partitions,
+                                                            self.world, None, 1)
+        else:
+            shard_off, shard_ids, merge_idx = self.split_fn(nodes, self.partitions,
+                                                            self.world)
+            pos = torch.empty_like(merge_idx)
+            pos[merge_idx.long()] = torch.arange(n, dtype=merge_idx.dtype,
+                                                 device=merge_idx.device)
+        send_counts = [int(shard_off[s + 1] - shard_off[s]) for s in range(self.world)]
+        sc = torch.tensor(send_counts, dtype=torch.int64, device=nodes.device)
+        rc = torch.empty_like(sc)
+        dist.all_to_all_single(rc, sc, group=self.group)
+        recv_counts = [int(x) for x in rc.tolist()]
+        owned = self._exchange(shard_ids, send_counts, recv_counts)
+        feats = self.local_feature(owned, list(feature_ids), dims)
+        rows = torch.cat([f.reshape(owned.numel(), d) for f, d in zip(feats, dims)], dim=1) \
+            if dims else torch.empty((owned.numel(), 0), dtype=torch.float32,
+                                     device=nodes.device)
+        back = self._exchange(rows.contiguous(), recv_counts, send_counts)
+        out = self.row_gather_fn(back, pos)
+        return list(torch.split(out, dims, dim=1)) if dims else []
+
+    # ---------------------------------------------------------- sample_node
+    def sample_node(self, count, node_type=-1, call_id=0):
+        """SampleNode over the shards: SAMPLE_NODE_SPLIT divides
+        `count` in proportion to the shards' weight sums of the type (remainder
+        by RNG domain SPLIT, core/kernels/sample_node_split_op.cc:57-85), every
+        shard draws its share from its own alias tables, APPEND_MERGE
+        concatenates in shard order (append_merge_op.cc:67-93).  Every rank
+        gets the same [count] tensor.  Needs local_sample_node(count, node_type,
+        call_id), node_weight_sum(node_type) and node_split_fn(call_id, count,
+        weights[world + 1]) -> counts[world]."""
+        dev = self.device
+        mine = torch.tensor([float(self.node_weight_sum(node_type))], dtype=torch.float32,
+                            device=dev)
+        allw = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(allw, mine, group=self.group)
+        w = torch.cat(allw).cpu().numpy().astype("float32")
+        total = w[0].copy()
+        for x in w[1:]:
+            total = (total + x).astype("float32")          # f32 adds in shard order
+        split = [int(c) for c in self.node_split_fn(call_id, int(count),
+                                                   list(w) + [float(total)])]
+        own = self.local_sample_node(split[self.rank], node_type, call_id) \
+            if split[self.rank] > 0 else torch.empty(0, dtype=torch.int64, device=dev)
+        width = max(max(split), 1)
+        pad = torch.zeros(width, dtype=torch.int64, device=dev)
+        pad[:own.numel()] = own
+        parts = [torch.empty_like(pad) for _ in range(self.world)]
+        dist.all_gather(parts, pad, group=self.group)
+        return torch.cat([parts[s][:split[s]] for s in range(self.world)])
+
     def random_walk(self, nodes, edge_types, default_node=-1, call_id=0):
         """tf_euler random_walk with p = q = 1 (TraditionalRandomWalk,
         tf_euler/kernels/random_walk_op.cc:207-247) over the sharded graph: one
@@ -222,4 +292,17 @@ def gpu_sharded_sampler(graph, partitions=None, group=None, dedup=True):
                        ops.expand_packed if fused else None)
     if fused:
         S.pack_fn = ops.pack_rows
+    S.device = graph.device
+    S.local_feature = graph.get_dense_feature
+    S.row_gather_fn = lambda rows, pos: ops.gather(rows, pos.to(torch.int32))
+    S.local_sample_node = lambda count, node_type, call_id: graph.sample_node(
+        count, node_type, call_id=call_id)
+
+    def weight_sum(node_type):
+        sums = graph.node_weight_sums()
+        return float(sums.sum(dtype="float32")) if node_type == -1 else float(sums[node_type])
+
+    S.node_weight_sum = weight_sum
+    S.node_split_fn = lambda call_id, count, weights: ops.sample_node_split(
+        graph.seed, call_id, count, weights)
     return S

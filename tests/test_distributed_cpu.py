@@ -46,7 +46,8 @@ def _shard_csr(O, csr, partitions, rank, world):
         row_ptr.append(row_ptr[-1] + (e - b))
     cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dt)
     return O.CSR(csr.row_id[rows], np.array(row_ptr, np.int64), cat(te, np.int32),
-                 cat(nbr, np.uint64), cat(pw, np.float32), cat(tp, np.float32), T)
+                 cat(nbr, np.uint64), cat(pw, np.float32), cat(tp, np.float32), T,
+                 csr.node_type[rows], csr.node_weight[rows])
 
 
 def _worker(rank, world, port, partitions, out_dir):
@@ -133,6 +134,53 @@ def _worker(rank, world, port, partitions, out_dir):
     walk = S_fused.random_walk(torch.as_tensor(roots), et_walk, default_node=-1, call_id=70)
     ref = OG_full.random_walk(seed, 70, roots, et_walk, L, 1.0, 1.0, -1)
     assert np.array_equal(walk.numpy(), ref), rank
+    # ---- dense features of remote nodes: same exchange, rows of floats
+    per = [[list(np.float32([i, i + 0.5, -i])), list(np.float32([2 * i]))] for i in
+           range(csr.n_rows)]
+    F_full = O.DenseFeatures.from_lists(per)
+    own_rows = np.nonzero(O.shard_of(csr.row_id, partitions, world) == rank)[0]
+    F_local = O.DenseFeatures.from_lists([per[i] for i in own_rows])
+
+    def local_feature(owned, fids, dims):
+        return [torch.as_tensor(x) for x in
+                OG_local.get_dense_feature(F_local, owned.numpy(), fids, dims)]
+
+    S_fused.local_feature = local_feature
+    S_fused.row_gather_fn = lambda rows, pos: rows[pos.long()]
+    S_plain.local_feature = local_feature
+    S_plain.row_gather_fn = lambda rows, pos: rows[pos.long()]
+    want_f = OG_full.get_dense_feature(F_full, roots, [0, 1, 3], [3, 2, 2])
+    for sampler in (S_fused, S_plain):
+        got_f = sampler.get_dense_feature(torch.as_tensor(roots), [0, 1, 3], [3, 2, 2])
+        for g_, w_ in zip(got_f, want_f):
+            assert np.array_equal(g_.numpy(), w_)
+    # ---- SampleNode over the shards: SAMPLE_NODE_SPLIT + local draws + APPEND_MERGE
+    OG_local.build_node_sampler()
+    shard_graphs = [O.OracleGraph(_shard_csr(O, csr, partitions, r, world)) for r in range(world)]
+    for g_ in shard_graphs:
+        g_.build_node_sampler()
+
+    def type_sum(g_, node_type):
+        tot = np.float32(0)
+        for t_, w_ in zip(g_.csr.node_type, g_.csr.node_weight):
+            if node_type == -1 or t_ == node_type:
+                tot = np.float32(tot + w_)
+        return float(tot)
+
+    S_fused.local_sample_node = lambda count, nt, call_id: torch.as_tensor(
+        OG_local.sample_node(seed, call_id, [nt], count).astype(np.int64))
+    S_fused.node_weight_sum = lambda nt: type_sum(OG_local, nt)
+    S_fused.node_split_fn = lambda call_id, count, w: O.sample_node_split(seed, call_id, count, w)
+    for nt, count in ((-1, 37), (0, 20), (1, 5)):
+        got_n = S_fused.sample_node(count, nt, call_id=90).numpy()
+        w = np.array([type_sum(g_, nt) for g_ in shard_graphs], np.float32)
+        tot = w[0]
+        for x in w[1:]:
+            tot = np.float32(tot + x)
+        split = O.sample_node_split(seed, 90, count, list(w) + [tot])
+        want_n = np.concatenate([g_.sample_node(seed, 90, [nt], int(c)).astype(np.int64)
+                                 for g_, c in zip(shard_graphs, split)])
+        assert int(split.sum()) == count and np.array_equal(got_n, want_n), (nt, count)
     # empty request from one rank must not dead-lock the exchange
     empty = torch.zeros(0, dtype=torch.int64) if rank == 0 else torch.as_tensor(roots)
     n1, w1, t1, m1 = S.sample_neighbor(empty, [0], 2, -1, 7)

@@ -538,6 +538,26 @@ def test_gpu_sharded_sampler_single_rank(EA, O, torch_cuda, big_pair):
                 assert np.array_equal(t2n(gw[h]), ow[h])
                 assert np.array_equal(t2n(gt[h]), ot[h])
         S = gpu_sharded_sampler(G, partitions=1)
+        # SampleNode over the (single) shard: split + local draw + append
+        G.set_seed(31)
+        for nt, cnt in ((-1, 300), (0, 40), (1, 7)):
+            assert torch.equal(S.sample_node(cnt, nt, call_id=60),
+                               G.sample_node(cnt, nt, call_id=60))
+        # dense features through the exchange
+        n_f = 3000
+        f_ids = np.arange(5, 5 + n_f).astype(np.uint64)
+        f_csr = O.csr_from_raw(f_ids, np.arange(n_f + 1, dtype=np.int64),
+                               rng.choice(f_ids, n_f), np.ones(n_f, np.float32), 1)
+        f_val = rng.standard_normal((n_f, 48)).astype(np.float32)
+        Ff = O.DenseFeatures(2, np.arange(n_f + 1) * 48, np.tile([32, 48], n_f),
+                             f_val.reshape(-1))
+        Gf = gpu_graph(EA, f_csr, features=(2, Ff.feat_ptr, Ff.feat_idx, Ff.feat_val))
+        Sf = gpu_sharded_sampler(Gf, partitions=1)
+        fq = np.concatenate([rng.choice(f_ids, 20000), [0, 1]]).astype(np.int64)
+        got_f = Sf.get_dense_feature(torch.as_tensor(fq).cuda(), [0, 1], [32, 16])
+        want_f = O.OracleGraph(f_csr).get_dense_feature(Ff, fq, [0, 1], [32, 16])
+        assert np.array_equal(t2n(got_f[0]), want_f[0])
+        assert np.array_equal(t2n(got_f[1]), want_f[1])
         L = 5
         et = [[0, 1, 2, 3]] * L
         walk = S.random_walk(torch.as_tensor(q).cuda(), et, default_node=-1, call_id=20)
