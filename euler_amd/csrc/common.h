@@ -170,6 +170,11 @@ struct euler_gpu_graph {
   // per stream: calls on one stream are ordered, calls on different streams
   // never share a buffer
   mutable std::mutex ws_mu;
+  // held while one call ENQUEUES its kernels on a stream's scratch: two host
+  // threads sharing a stream then cannot interleave their launches (the stream
+  // runs one call's kernels to completion before the next call's touch the
+  // scratch)
+  mutable std::mutex launch_mu;
   mutable std::map<void*, std::pair<void*, size_t>> ws;
 };
 

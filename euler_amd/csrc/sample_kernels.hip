@@ -1627,6 +1627,7 @@ static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
     return rc;
   }
 
+  std::lock_guard<std::mutex> launch_lk(g->launch_mu);
   // ---- workspace -----------------------------------------------------------
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t total_out = (size_t)n * (size_t)count;

@@ -766,3 +766,32 @@ def test_node2vec_long_lists_both_kernels(EA, O, torch_cuda, wave):
             assert np.array_equal(got, want), (p, q)
     finally:
         _lib.lib().euler_gpu_set_tuning(7, 1)
+
+
+def test_concurrent_callers_share_a_stream(EA, O, torch_cuda, big_pair):
+    """The reference runs ops from an 8-thread pool (query_proxy.cc:209).  Four
+    host threads call the fanout (second hop through the duplicate-root path and
+    its per-stream scratch) on the same stream at once: every thread must get
+    what it gets alone."""
+    import threading
+    torch = torch_cuda
+    G, OG, ids, rng = big_pair
+    G.set_seed(3)
+    qs = [torch.as_tensor(rng.choice(ids[:3000], 2048).astype(np.int64)).cuda()
+          for _ in range(4)]
+    alone = [G.sample_fanout(q, [[0], [1]], [8, 6], -1, call_id=10 * i)
+             for i, q in enumerate(qs)]
+    torch.cuda.synchronize()
+    got = [None] * 4
+    for _ in range(3):
+        def work(i):
+            for _rep in range(5):
+                got[i] = G.sample_fanout(qs[i], [[0], [1]], [8, 6], -1, call_id=10 * i)
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        torch.cuda.synchronize()
+        for i in range(4):
+            for h in range(2):
+                assert torch.equal(got[i][0][h + 1], alone[i][0][h + 1])
+                assert torch.equal(got[i][1][h], alone[i][1][h])
