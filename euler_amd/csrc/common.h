@@ -166,6 +166,8 @@ struct euler_gpu_graph {
   int64_t bytes = 0;
   std::vector<void*> allocations;     // every hipMalloc owned by the graph
   std::vector<float> node_weight_sums;
+  bool feat_slot_aligned = false;     // uniform feature table: every slot begins at a
+                                      // multiple of 4 floats (16-byte lanes allowed)
   // scratch of the sampling launcher (dedup table, unique rows), one buffer
   // per stream: calls on one stream are ordered, calls on different streams
   // never share a buffer

@@ -490,6 +490,9 @@ int BuildGraphFromHost(const euler_gpu_host_csr* c, int device,
     v.n_float = F;
     v.feat_uniform = uniform ? 1 : 0;
     v.feat_stride = uniform ? (int64_t)fidx[F - 1] : 0;
+    bool aligned = uniform;
+    for (int32_t f = 0; aligned && f + 1 < F; ++f) aligned = fidx[f] % 4 == 0;
+    b.g->feat_slot_aligned = aligned;
     v.feat_ptr = b.Upload(fptr.data(), fptr.size());
     v.feat_idx = b.Upload(fidx.data(), fidx.size());
     v.feat_val = b.Upload(fval.data(), fval.size());

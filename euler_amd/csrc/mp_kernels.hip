@@ -698,6 +698,36 @@ int euler_gpu_neighbor_to_dense(void* stream, int64_t n, const int32_t* idx_dev,
   return EULER_GPU_OK;
 }
 
+int g_feature_vec4 = 1;   // euler_gpu_set_tuning key 8
+
+// 16-byte lanes: dim % 4 == 0, fixed-stride table whose rows and slots start on
+// 16-byte boundaries (feat_uniform, stride % 4 == 0, slot begin % 4 == 0).
+__global__ __launch_bounds__(256) void DenseFeatureVec4Kernel(
+    const GraphView g, const uint64_t* __restrict__ nodes, int64_t n, int32_t fid,
+    int32_t dv /* dim / 4 */, float4* __restrict__ out) {
+  const int32_t pre = fid == 0 ? 0 : g.feat_idx[fid - 1];
+  const int32_t len = g.feat_idx[fid] - pre;
+  const uint32_t total = (uint32_t)(n * dv);
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < total; s += stride) {
+    const uint32_t j = s / (uint32_t)dv;
+    const int32_t c = (int32_t)(s - j * (uint32_t)dv) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t row = FindRow(g, nodes[j]);
+    if (row >= 0 && c < len) {
+      const float* src = g.feat_val + row * g.feat_stride + pre + c;
+      if (c + 3 < len) {
+        v = *reinterpret_cast<const float4*>(src);
+      } else {
+        v.x = src[0];
+        if (c + 1 < len) v.y = src[1];
+        if (c + 2 < len) v.z = src[2];
+      }
+    }
+    out[s] = v;
+  }
+}
+
 int euler_gpu_get_dense_feature(const euler_gpu_graph* g, void* stream,
                                 const uint64_t* nodes_dev, int64_t n, int32_t fid,
                                 int32_t dim, float* out_dev) {
@@ -707,9 +737,19 @@ int euler_gpu_get_dense_feature(const euler_gpu_graph* g, void* stream,
   if (!nodes_dev || !out_dev)
     return Fail(EULER_GPU_EINVAL, "get_dense_feature: null buffer");
   const int block = 256;
-  hipLaunchKernelGGL(DenseFeatureKernel, dim3(GridFor(n * (int64_t)dim, block)),
-                     dim3(block), 0, (hipStream_t)stream, g->view, nodes_dev, n, fid,
-                     dim, out_dev);
+  const GraphView& v = g->view;
+  const bool vec4 = g_feature_vec4 != 0 && v.feat_uniform && fid >= 0 && fid < v.n_float && dim % 4 == 0 &&
+                    v.feat_stride % 4 == 0 && g->feat_slot_aligned &&
+                    ((uintptr_t)out_dev % 16 == 0) && n * (int64_t)(dim / 4) < 0xffffffffLL;
+  if (vec4) {
+    hipLaunchKernelGGL(DenseFeatureVec4Kernel, dim3(GridFor(n * (int64_t)(dim / 4), block)),
+                       dim3(block), 0, (hipStream_t)stream, v, nodes_dev, n, fid, dim / 4,
+                       reinterpret_cast<float4*>(out_dev));
+  } else {
+    hipLaunchKernelGGL(DenseFeatureKernel, dim3(GridFor(n * (int64_t)dim, block)),
+                       dim3(block), 0, (hipStream_t)stream, v, nodes_dev, n, fid, dim,
+                       out_dev);
+  }
   EG_HIP(hipGetLastError());
   return EULER_GPU_OK;
 }

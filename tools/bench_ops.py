@@ -70,4 +70,21 @@ ms, d = timed(lambda: ops.dedup_split(hop2, 8, 8), iters=5)
 res['dedup_split_3.28M_8shards'] = {'ms': round(ms, 3), 'distinct_sent': int(d[1].numel())}
 ms, _ = timed(lambda: ops.id_split(hop2, 8, 8), iters=5)
 res['id_split_3.28M_8shards'] = {'ms': round(ms, 3)}
+# dense feature fetch: 2M-node table of 128 floats (1 GB), 3.28M random + repeated nodes
+import numpy as np
+nf, D = 2_000_000, 128
+ids = np.arange(1, nf + 1).astype(np.uint64)
+rp = np.arange(nf + 1, dtype=np.int64)
+Gf = euler_amd.Graph.from_csr(ids, rp, np.ones(nf, np.int32), ids[::-1].copy(),
+                              np.ones(nf, np.float32), np.ones(nf, np.float32), 1,
+                              features=(1, np.arange(nf + 1, dtype=np.int64) * D,
+                                        np.full(nf, D, np.int32),
+                                        np.random.default_rng(0).standard_normal(nf * D).astype(np.float32)))
+q = torch.randint(1, nf + 1, (Eb,), generator=gen, device='cuda')
+from euler_amd import _lib
+for vec4 in (1, 0, 1):
+    _lib.lib().euler_gpu_set_tuning(8, vec4)
+    ms, _ = timed(lambda: Gf.get_dense_feature(q, [0], [D]))
+    res['get_dense_feature_3.28M_D128_vec4=%d' % vec4] = {
+        'ms': round(ms, 3), 'GBps': round((8 * Eb * D + 8 * Eb + 16 * Eb) / ms / 1e6, 1)}
 print(json.dumps(res, indent=1))
