@@ -120,7 +120,7 @@ int euler_gpu_graph_create_synthetic(const euler_gpu_synth_params* p,
                                      int device, int32_t partitions,
                                      int32_t shard_index, int32_t shards,
                                      euler_gpu_graph** out);
-/* Load a directory written by euler/tools (euler.meta + Node/*.dat), the
+/* Load a directory written by euler/tools (euler.meta + Node/<x>_<partition>.dat), the
  * input of the reference's Graph::Init (core/graph/graph_builder.cc:57-158,
  * core/graph/node.cc:414-526). */
 int euler_gpu_graph_load(const char* data_path, int device,
