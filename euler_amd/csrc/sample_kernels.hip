@@ -1126,17 +1126,24 @@ __device__ __forceinline__ void BlockPivotSample(const GraphView& g, const Segme
     *w = __fsub_rn(nw[m], m == 0 ? 0.f : nw[m - 1]);
     return;
   }
+  // ranges of the levels, bottom up, only as far as needed: K = first level
+  // with <= 4 candidates (most rows stop at level 1 or 2, and a wave whose
+  // lanes have all stopped skips the remaining divisions)
   uint32_t l[kPivotLevels + 1], h[kPivotLevels + 1];
   l[1] = (uint32_t)(lo / kEdgesPerBlock);
   h[1] = (uint32_t)(hi / kEdgesPerBlock);
-#pragma unroll
-  for (int k = 2; k <= kPivotLevels; ++k) { l[k] = l[k - 1] / 5u; h[k] = h[k - 1] / 5u; }
   int32_t K = 0;                     // 0: the segment lies inside one block
   if (h[1] != l[1]) {
-    K = kPivotLevels + 1;
+    K = h[1] - l[1] <= 4u ? 1 : kPivotLevels + 1;
 #pragma unroll
-    for (int k = kPivotLevels; k >= 1; --k)
-      if (h[k] - l[k] <= 4u) K = k;
+    for (int k = 2; k <= kPivotLevels; ++k) {
+      l[k] = 0; h[k] = 0;
+      if (K > kPivotLevels) {
+        l[k] = l[k - 1] / 5u;
+        h[k] = h[k - 1] / 5u;
+        if (h[k] - l[k] <= 4u) K = k;
+      }
+    }
   }
   uint32_t x = l[1];
   bool found = false;
