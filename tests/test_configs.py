@@ -178,3 +178,34 @@ def test_config5_typed_sampling_and_aggregation(EA, O, torch_cuda):
     want = O.scatter_mean(want_x, t2n(dst), len(roots))
     assert np.allclose(t2n(agg), want, rtol=0, atol=1e-5)
     assert np.array_equal(t2n(agg), want)
+
+
+@pytest.mark.gpu
+def test_three_hop_fanout_through_the_duplicate_path(EA, O, torch_cuda):
+    """Fanout [25, 10, 5] of 4096 roots on a 2M-node graph: hops 2 and 3
+    (102 400 and 1 024 000 roots) go through the on-device duplicate-root path;
+    64 roots are checked bit for bit against the oracle fed with the rows
+    exported from HBM."""
+    torch = torch_cuda
+    N = 2_000_000
+    p = EA.synth_params(11, N, 10 * N, weighted=True)
+    G = EA.Graph.synthetic(p)
+    rng = np.random.default_rng(6)
+    roots = rng.integers(1, N + 1, 4096).astype(np.int64)
+    fan = [25, 10, 5]
+    et = [[0], [0], [0]]
+    G.set_seed(13)
+    nb, ws, ts = G.sample_fanout(torch.as_tensor(roots).cuda(), et, fan, N + 1, call_id=30)
+    assert [x.numel() for x in nb] == [4096, 102400, 1024000, 5120000]
+    sel = np.arange(64)
+    h1 = t2n(nb[1]).reshape(4096, 25)[sel]
+    h2 = t2n(nb[2]).reshape(4096, 250)[sel]
+    need = np.unique(np.concatenate([roots[sel], h1.reshape(-1), h2.reshape(-1)])).astype(np.uint64)
+    need = need[(need >= 1) & (need <= N)]
+    rp, te, nbr, pw, tp = G.export_rows(need)
+    OG = O.OracleGraph(O.CSR(need, rp, te, nbr, pw, tp, 1))
+    on, ow, ot = OG.sample_fanout(13, 30, roots[sel], et, fan, N + 1)
+    assert np.array_equal(on[0], h1.reshape(-1))
+    assert np.array_equal(on[1], h2.reshape(-1))
+    assert np.array_equal(on[2], t2n(nb[3]).reshape(4096, 1250)[sel].reshape(-1))
+    assert np.array_equal(ow[2], t2n(ws[2]).reshape(4096, 1250)[sel].reshape(-1))
