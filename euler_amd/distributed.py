@@ -73,6 +73,9 @@ class ShardedSampler:
         self.local_sample_node = None
         self.node_weight_sum = None
         self.node_split_fn = None
+        self.local_full_neighbor = None
+        self.idx_gather_fn = None
+        self.data_gather_fn = None
         self.device = torch.device("cpu")
 
     # -------------------------------------------------------------- helpers
@@ -220,6 +223,64 @@ class ShardedSampler:
         out = self.row_gather_fn(back, pos)
         return list(torch.split(out, dims, dim=1)) if dims else []
 
+    # ------------------------------------------------------- full neighbours
+    def get_full_neighbor(self, nodes, edge_types):
+        """`v(nodes).outV(edge_types)` over the sharded graph, GQL layout (idx
+        [n,2] int32, ids int64, weights f32, types int32).  Rows have different
+        lengths, so the answers travel as (row lengths) + (packed values) and
+        are put back with the variable-length IDX_MERGE / DATA_MERGE
+        (core/kernels/idx_merge_op.cc:32-78, data_merge_op.cc:44-110), here
+        IDX_GATHER + DATA_GATHER through the position map.  Needs
+        local_full_neighbor(owned, edge_types) -> (idx, ids, w, t),
+        idx_gather_fn(idx, gather_idx) -> (idx_out, total) and
+        data_gather_fn(data, idx, gather_idx) -> data_out."""
+        nodes = nodes.reshape(-1).to(torch.int64)
+        dev = nodes.device
+        if self.dedup_split_fn is not None:
+            shard_off, shard_ids, pos = self.dedup_split_fn(nodes, self.partitions,
+                                                            self.world, None, 1)
+        else:
+            shard_off, shard_ids, merge_idx = self.split_fn(nodes, self.partitions,
+                                                            self.world)
+            pos = torch.empty_like(merge_idx)
+            pos[merge_idx.long()] = torch.arange(nodes.numel(), dtype=merge_idx.dtype,
+                                                 device=dev)
+        send_counts = [int(shard_off[s + 1] - shard_off[s]) for s in range(self.world)]
+        sc = torch.tensor(send_counts, dtype=torch.int64, device=dev)
+        rc = torch.empty_like(sc)
+        dist.all_to_all_single(rc, sc, group=self.group)
+        recv_counts = [int(x) for x in rc.tolist()]
+        owned = self._exchange(shard_ids, send_counts, recv_counts)
+        idx, ids, w, t = self.local_full_neighbor(owned, edge_types)
+        idx = idx.reshape(-1, 2).to(torch.int64)
+        lens = (idx[:, 1] - idx[:, 0]).to(torch.int32)
+        # values per requester: sum of the lengths of its rows
+        bounds = [0]
+        for c in recv_counts:
+            bounds.append(bounds[-1] + c)
+        csum = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev),
+                          torch.cumsum(lens.to(torch.int64), 0)])
+        val_send = [int(csum[bounds[s + 1]] - csum[bounds[s]]) for s in range(self.world)]
+        vs = torch.tensor(val_send, dtype=torch.int64, device=dev)
+        vr = torch.empty_like(vs)
+        dist.all_to_all_single(vr, vs, group=self.group)
+        val_recv = [int(x) for x in vr.tolist()]
+        lens_back = self._exchange(lens.reshape(-1, 1), recv_counts, send_counts).reshape(-1)
+        vals = torch.empty((ids.numel(), 4), dtype=torch.int32, device=dev)
+        vals[:, :2] = ids.reshape(-1, 1).contiguous().view(torch.int32).reshape(-1, 2)
+        vals[:, 2] = w.contiguous().view(torch.int32)
+        vals[:, 3] = t
+        vals_back = self._exchange(vals, val_send, val_recv)
+        end = torch.cumsum(lens_back.to(torch.int64), 0)
+        idx_cat = torch.stack([end - lens_back, end], dim=1).to(torch.int32)
+        out_idx, _total = self.idx_gather_fn(idx_cat, pos)
+        out_ids = self.data_gather_fn(vals_back[:, :2].contiguous().view(torch.int64)
+                                      .reshape(-1), idx_cat, pos)
+        out_w = self.data_gather_fn(vals_back[:, 2].contiguous().view(torch.float32),
+                                    idx_cat, pos)
+        out_t = self.data_gather_fn(vals_back[:, 3].contiguous(), idx_cat, pos)
+        return out_idx, out_ids, out_w, out_t
+
     # ---------------------------------------------------------- sample_node
     def sample_node(self, count, node_type=-1, call_id=0):
         """SampleNode over the shards: SAMPLE_NODE_SPLIT divides
@@ -302,6 +363,9 @@ def gpu_sharded_sampler(graph, partitions=None, group=None, dedup=True):
         sums = graph.node_weight_sums()
         return float(sums.sum(dtype="float32")) if node_type == -1 else float(sums[node_type])
 
+    S.local_full_neighbor = graph.get_full_neighbor
+    S.idx_gather_fn = ops.idx_gather
+    S.data_gather_fn = ops.data_gather
     S.node_weight_sum = weight_sum
     S.node_split_fn = lambda call_id, count, weights: ops.sample_node_split(
         graph.seed, call_id, count, weights)

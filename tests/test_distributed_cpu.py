@@ -154,6 +154,29 @@ def _worker(rank, world, port, partitions, out_dir):
         got_f = sampler.get_dense_feature(torch.as_tensor(roots), [0, 1, 3], [3, 2, 2])
         for g_, w_ in zip(got_f, want_f):
             assert np.array_equal(g_.numpy(), w_)
+    # ---- full neighbours: variable-length rows, IDX_MERGE / DATA_MERGE semantics
+    def local_full_neighbor(owned, et):
+        i_, d_, w_, t_ = OG_local.get_full_neighbor(owned.numpy().astype(np.uint64), et)
+        return (torch.as_tensor(i_), torch.as_tensor(d_.astype(np.int64)), torch.as_tensor(w_),
+                torch.as_tensor(t_))
+
+    def idx_gather_fn(idx, gi):
+        o = O.idx_gather(idx.numpy(), gi.numpy())
+        return torch.as_tensor(o), int(o[-1, 1]) if len(o) else 0
+
+    def data_gather_fn(data, idx, gi):
+        return torch.as_tensor(O.data_gather(data.numpy(), idx.numpy(), gi.numpy()))
+
+    for sampler in (S_fused, S_plain):
+        sampler.local_full_neighbor = local_full_neighbor
+        sampler.idx_gather_fn = idx_gather_fn
+        sampler.data_gather_fn = data_gather_fn
+        for et_ in ([0, 1, 2], [2, 0], [1]):
+            gi_, gd_, gw_, gt_ = sampler.get_full_neighbor(torch.as_tensor(roots), et_)
+            wi_, wd_, ww_, wt_ = OG_full.get_full_neighbor(roots.astype(np.uint64), et_)
+            assert np.array_equal(gi_.numpy(), wi_), (rank, et_)
+            assert np.array_equal(gd_.numpy().astype(np.uint64), wd_)
+            assert np.array_equal(gw_.numpy(), ww_) and np.array_equal(gt_.numpy(), wt_)
     # ---- SampleNode over the shards: SAMPLE_NODE_SPLIT + local draws + APPEND_MERGE
     OG_local.build_node_sampler()
     shard_graphs = [O.OracleGraph(_shard_csr(O, csr, partitions, r, world)) for r in range(world)]

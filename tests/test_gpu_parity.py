@@ -538,6 +538,13 @@ def test_gpu_sharded_sampler_single_rank(EA, O, torch_cuda, big_pair):
                 assert np.array_equal(t2n(gw[h]), ow[h])
                 assert np.array_equal(t2n(gt[h]), ot[h])
         S = gpu_sharded_sampler(G, partitions=1)
+        # full neighbours through the exchange (variable-length merge)
+        qf = torch.as_tensor(q).cuda()
+        for et_ in ([0, 1, 2, 3], [2], [3, 1]):
+            gi_, gd_, gw_, gt_ = S.get_full_neighbor(qf, et_)
+            wi_, wd_, ww_, wt_ = OG.get_full_neighbor(q.astype(np.uint64), et_)
+            assert np.array_equal(t2n(gi_), wi_) and np.array_equal(t2n(gd_).astype(np.uint64), wd_)
+            assert np.array_equal(t2n(gw_), ww_) and np.array_equal(t2n(gt_), wt_)
         # SampleNode over the (single) shard: split + local draw + append
         G.set_seed(31)
         for nt, cnt in ((-1, 300), (0, 40), (1, 7)):
