@@ -261,33 +261,75 @@ def main():
             return b.value
 
         k1_ms, k1_bytes, phases = [], [], []
-        for r, cnt, dedup in shapes:
+        in_place = None
+        if world == 1:
+            # the fanout timed in place (hop 1's kernel also enters its ids into
+            # hop 2's owner table, so the hops are not independent launches)
+            layers = len(FANOUT)
+            cnt_a = (C.c_int32 * layers)(*FANOUT)
+            et_a = (C.c_int32 * layers)(*([0] * layers))
+            r = shapes[0][0]
+            o_n, o_w, o_t, m = [], [], [], r.numel()
+            for c in FANOUT:
+                m *= c
+                o_n.append(torch.empty(m, dtype=torch.int64, device=dev))
+                o_w.append(torch.empty(m, dtype=torch.float32, device=dev))
+                o_t.append(torch.empty(m, dtype=torch.int32, device=dev))
+            wsz = int(L.euler_gpu_sample_fanout_workspace(r.numel(), cnt_a, layers))
+            fws = torch.empty(max(wsz, 16), dtype=torch.uint8, device=dev)
+            pn = (C.c_void_p * layers)(*[t.data_ptr() for t in o_n])
+            pw_ = (C.c_void_p * layers)(*[t.data_ptr() for t in o_w])
+            pt = (C.c_void_p * layers)(*[t.data_ptr() for t in o_t])
+            ms_all = (C.c_float * (3 * layers))()
+            nu_all = (C.c_int64 * layers)()
+            _lib.check(L.euler_gpu_time_sample_fanout_phases(
+                G._h, st, GRAPH_SEED, C.c_void_p(r.data_ptr()), r.numel(), et_a, 1, cnt_a,
+                layers, default_node, pn, pw_, pt, C.c_void_p(fws.data_ptr()), iters,
+                ms_all, nu_all))
+            in_place = ([list(ms_all[3 * h:3 * h + 3]) for h in range(layers)],
+                        list(nu_all), [r] + o_n)
+        for h, (r, cnt, dedup) in enumerate(shapes):
             if world > 1:      # a shard only owns ids == rank (mod world)
                 r = (r // world) * world + (rank if rank else world)
                 r = torch.clamp(r, max=args.nodes - world)
             n = r.numel()
-            oid = torch.empty(n * cnt, dtype=torch.int64, device=dev)
-            ow = torch.empty(n * cnt, dtype=torch.float32, device=dev)
-            ot = torch.empty(n * cnt, dtype=torch.int32, device=dev)
             ms3 = (C.c_float * 3)()
             nu = C.c_int64(-1)
-            _lib.check(L.euler_gpu_time_sample_neighbor_phases(
-                G._h, st, GRAPH_SEED, C.c_void_p(r.data_ptr()), n, et1, 1, cnt,
-                _lib.LAYOUT_TF, dedup, C.c_void_p(oid.data_ptr()),
-                C.c_void_p(ow.data_ptr()), C.c_void_p(ot.data_ptr()), iters, ms3,
-                C.byref(nu)))
+            if in_place is None:
+                oid = torch.empty(n * cnt, dtype=torch.int64, device=dev)
+                ow = torch.empty(n * cnt, dtype=torch.float32, device=dev)
+                ot = torch.empty(n * cnt, dtype=torch.int32, device=dev)
+            if in_place is not None:
+                r = in_place[2][h].contiguous()     # this hop's roots in the timed fanout
+                ms3[0], ms3[1], ms3[2] = in_place[0][h]
+                nu = C.c_int64(in_place[1][h])
+            else:
+                _lib.check(L.euler_gpu_time_sample_neighbor_phases(
+                    G._h, st, GRAPH_SEED, C.c_void_p(r.data_ptr()), n, et1, 1, cnt,
+                    _lib.LAYOUT_TF, dedup, C.c_void_p(oid.data_ptr()),
+                    C.c_void_p(ow.data_ptr()), C.c_void_p(ot.data_ptr()), iters, ms3,
+                    C.byref(nu)))
             unique_path = dedup == 1 and nu.value >= 0 and nu.value * 4 <= n * 3
             sampled = torch.unique(r) if unique_path else r
             kb = algo_bytes(sampled.contiguous(), cnt)
+            # hop chaining: this hop's kernel also does the next hop's 4-byte
+            # owner store per id (SURVEY 8(d)'s "dedup: 8 + 4 per input id" -
+            # the 4 move here, the next hop's dedup keeps the 8)
+            marks_next = in_place is not None and h + 1 < len(shapes) and not unique_path
+            premarked = in_place is not None and h > 0
+            if marks_next:
+                kb += 4.0 * n * cnt
             k1_ms.append(ms3[1])
             k1_bytes.append(kb)
             ph = {"roots": n, "count": cnt, "roots_sampled": int(sampled.numel()),
-                  "k1_ms": round(ms3[1], 4), "k1_algorithmic_bytes": kb}
+                  "k1_ms": round(ms3[1], 4), "k1_algorithmic_bytes": kb,
+                  "marks_next_hop": bool(marks_next)}
             if unique_path:
                 # dedup adds 8 + 4 bytes per input id, the gather 16
                 # per expanded output edge (+ the unique rows it reads once)
                 eb = 16.0 * n * cnt + 16.0 * nu.value * cnt + 4.0 * n
-                ph.update({"dedup_ms": round(ms3[0], 4), "dedup_algorithmic_bytes": 12.0 * n,
+                ph.update({"dedup_ms": round(ms3[0], 4),
+                           "dedup_algorithmic_bytes": (8.0 if premarked else 12.0) * n,
                            "expand_ms": round(ms3[2], 4), "expand_algorithmic_bytes": eb,
                            "expand_GBps": round(eb / (ms3[2] * 1e-3) / 1e9, 1)})
             phases.append(ph)

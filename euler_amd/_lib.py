@@ -127,6 +127,12 @@ SIGNATURES = {
                                                         C.c_int32, C.c_int32, vp, vp, vp,
                                                         C.c_int32, f32p,
                                                         C.POINTER(C.c_int64)]),
+    "euler_gpu_time_sample_fanout_phases": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_int64,
+                                                      i32p, C.c_int32, i32p, C.c_int32,
+                                                      C.c_int64, C.POINTER(vp),
+                                                      C.POINTER(vp), C.POINTER(vp), vp,
+                                                      C.c_int32, f32p,
+                                                      C.POINTER(C.c_int64)]),
     "euler_op_registered": (C.c_int, [C.c_char_p]),
     "euler_op_run_get_nb": (C.c_int64, [vp, u64p, C.c_int64, i32p, C.c_int32, C.c_char_p,
                                         C.c_int64, i32p, u64p, f32p, i32p]),

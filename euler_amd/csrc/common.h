@@ -176,7 +176,7 @@ struct euler_gpu_graph {
   // threads sharing a stream then cannot interleave their launches (the stream
   // runs one call's kernels to completion before the next call's touch the
   // scratch)
-  mutable std::mutex launch_mu;
+  mutable std::recursive_mutex launch_mu;   // a fanout holds it across its hops
   mutable std::map<void*, std::pair<void*, size_t>> ws;
 };
 

@@ -46,6 +46,8 @@ struct SampleNbArgs {
                                 // over the unique roots (see DedupGate)
   const uint32_t* dd_counter;   // [0] = number of unique roots (device)
   int64_t dd_n_in;              // roots of the call
+  uint32_t* mark_owner;         // not null: the outputs are the next hop's roots -
+                                // enter them into its owner table (MarkNextHop)
   int32_t et[kMaxListedTypes];
 };
 
@@ -73,6 +75,20 @@ __device__ __forceinline__ bool DedupGate(const SampleNbArgs& a, int64_t* n) {
   if (a.dd_role == 1) return !dedup;
   *n = (int64_t)(*a.dd_counter);
   return dedup;
+}
+
+// owner-table slot of a root key: its row, or n_rows for "no such node"
+__device__ __forceinline__ uint32_t OwnerSlot(const GraphView& g, uint64_t key) {
+  const int64_t row = FindRow(g, key);
+  return row < 0 ? (uint32_t)g.n_rows : (uint32_t)row;
+}
+
+// DedupMarkKernel of the NEXT hop, done by the kernel that writes this hop's
+// ids (fanout only, identity id map): output position s will be root s of the
+// next hop, and a masked row stands for node id 0 there.
+__device__ __forceinline__ void MarkNextHop(const GraphView& g, uint32_t* owner,
+                                            uint64_t id, bool row_valid, int64_t s) {
+  owner[OwnerSlot(g, row_valid ? id : 0)] = (uint32_t)s;
 }
 
 // Finding the duplicates without atomics.  A hash table filled with
@@ -140,6 +156,47 @@ __global__ __launch_bounds__(256) void DedupIndexKernel(const DedupArgs a) {
   }
 }
 
+// Premarked form (the previous hop of a fanout filled `owner`, identity id
+// map): the slot is arithmetic on the key, so there is no row_slot array.
+struct IdentityMap {
+  uint64_t id_base, id_stride;
+  int64_t n_rows;
+  __host__ __device__ __forceinline__ uint32_t Slot(uint64_t id) const {
+    if (id < id_base) return (uint32_t)n_rows;
+    const uint64_t d = id - id_base;
+    const uint64_t r = id_stride == 1 ? d : d / id_stride;
+    return (r * id_stride == d && r < (uint64_t)n_rows) ? (uint32_t)r : (uint32_t)n_rows;
+  }
+};
+
+struct DedupFlagPremarkedOp {
+  const uint32_t* owner;
+  const uint64_t* roots;
+  const uint8_t* root_mask;
+  IdentityMap map;
+  int64_t n;
+  int32_t root_group;
+  __host__ __device__ __forceinline__ uint32_t operator()(const uint32_t& i) const {
+    if ((int64_t)i >= n) return 0u;
+    uint64_t key = roots[i];
+    if (root_mask != nullptr && root_mask[i / root_group]) key = 0;
+    return owner[map.Slot(key)] == i ? 1u : 0u;
+  }
+};
+
+__global__ __launch_bounds__(256) void DedupIndexPremarkedKernel(const DedupArgs a,
+                                                                 const IdentityMap map) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (first == 0) a.counter[0] = a.pos[a.n];
+  for (int64_t i = first; i < a.n; i += stride) {
+    const uint64_t key = DedupKey(a, i);
+    const uint32_t rep = a.owner[map.Slot(key)];
+    a.uidx_of[i] = a.pos[rep];
+    if (rep == (uint32_t)i) a.uniq[a.pos[i]] = key;
+  }
+}
+
 struct ExpandArgs {
   const uint32_t* counter;
   const uint32_t* uidx_of;
@@ -153,14 +210,29 @@ struct ExpandArgs {
   uint8_t* out_mask;
   int64_t n;
   int32_t count;
+  uint32_t* mark_owner;      // see SampleNbArgs::mark_owner
+  IdentityMap map;
+  int32_t type0;             // CT kernels: type of every valid sample ...
+  int32_t masked_type;       // ... and of the samples of a masked row
 };
 
-// out row i = sampled row of unique root uidx_of[i]; U adjacent samples
-// per lane (U = 2: 16-byte id stores, needs an even count).
-template <int U>
+// out row i = sampled row of unique root uidx_of[i].  U adjacent samples per
+// lane (U = 2: 16-byte id stores, needs an even count); V grid-stride steps of
+// a lane are in flight together.  The kernel is a gather-copy: on the metric's
+// hop 2 it reads 0.39 GB of rows (L2 / infinity cache; the 34 MB of distinct
+// rows do not fit one XCD's L2) and writes 0.52 GB - 6.9 TB/s of fabric
+// traffic at 0.134 ms, where writing the same three arrays alone takes 0.087 ms
+// (tools/ubench_fill.hip).  Measured (tools/ab_expand.py): V = 2 is the best
+// (V = 4 is slower: not a latency-bound kernel), and so is CT - every sample of
+// a single-type call has the same type, so the type column is not gathered but
+// rebuilt from the row mask (-5 %).
+template <int U, int V, bool CT>
 __global__ __launch_bounds__(256) void DedupExpandKernel(const ExpandArgs a,
                                                          const int64_t stride_rows,
                                                          const int32_t stride_slots) {
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
   if (!DedupActive(a.counter, a.n)) return;
   const int64_t total = a.n * (int64_t)a.count;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x * U;
@@ -168,31 +240,77 @@ __global__ __launch_bounds__(256) void DedupExpandKernel(const ExpandArgs a,
   if (s >= total) return;
   int64_t i = s / a.count;
   int32_t j = (int32_t)(s - i * a.count);
-  for (; s < total; s += stride) {
-    const int64_t u = (int64_t)a.uidx_of[i];
-    const int64_t src = u * a.count + j;
-    // the outputs are written once and not read by this call: non-temporal
-    // stores keep the rows of the distinct roots (re-read ~11x) in the L2
-    if (U == 1) {
-      __builtin_nontemporal_store(a.t_id[src], a.out_id + s);
-      __builtin_nontemporal_store(a.t_w[src], a.out_w + s);
-      __builtin_nontemporal_store(a.t_t[src], a.out_t + s);
-    } else {
-      // src is even whenever count is even
-      typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-      typedef float f32x2 __attribute__((ext_vector_type(2)));
-      typedef int i32x2 __attribute__((ext_vector_type(2)));
-      __builtin_nontemporal_store(*reinterpret_cast<const u64x2*>(a.t_id + src),
-                                  reinterpret_cast<u64x2*>(a.out_id + s));
-      __builtin_nontemporal_store(*reinterpret_cast<const f32x2*>(a.t_w + src),
-                                  reinterpret_cast<f32x2*>(a.out_w + s));
-      __builtin_nontemporal_store(*reinterpret_cast<const i32x2*>(a.t_t + src),
-                                  reinterpret_cast<i32x2*>(a.out_t + s));
+  const bool need_mask = CT || a.mark_owner != nullptr;
+  while (s < total) {
+    int64_t sv[V], iv[V];
+    int32_t jv[V];
+    bool live[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      sv[v] = s; iv[v] = i; jv[v] = j;
+      live[v] = s < total;
+      s += stride;
+      i += stride_rows;
+      j += stride_slots;
+      if (j >= a.count) { j -= a.count; ++i; }
     }
-    if (j == 0 && a.out_mask != nullptr) a.out_mask[i] = a.t_mask[u];
-    i += stride_rows;
-    j += stride_slots;
-    if (j >= a.count) { j -= a.count; ++i; }
+    // all index loads, then all row loads, then the stores: steps past the end
+    // load element 0 (harmless) so that the loads stay unconditional
+    int64_t uv[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) uv[v] = (int64_t)a.uidx_of[live[v] ? iv[v] : 0];
+    uint64_t id[V][U];
+    float w[V][U];
+    int32_t t[V][U];
+    uint8_t m[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const int64_t src = live[v] ? uv[v] * a.count + jv[v] : 0;   // even when count is
+      if (U == 1) {
+        id[v][0] = a.t_id[src];
+        w[v][0] = a.t_w[src];
+        if (!CT) t[v][0] = a.t_t[src];
+      } else {
+        const u64x2 i2 = *reinterpret_cast<const u64x2*>(a.t_id + src);
+        const f32x2 w2 = *reinterpret_cast<const f32x2*>(a.t_w + src);
+        id[v][0] = i2.x; id[v][U - 1] = i2.y;
+        w[v][0] = w2.x; w[v][U - 1] = w2.y;
+        if (!CT) {
+          const i32x2 t2 = *reinterpret_cast<const i32x2*>(a.t_t + src);
+          t[v][0] = t2.x; t[v][U - 1] = t2.y;
+        }
+      }
+      m[v] = (need_mask || (jv[v] == 0 && a.out_mask != nullptr)) ? a.t_mask[uv[v]] : 0;
+      if (CT) {
+#pragma unroll
+        for (int x = 0; x < U; ++x) t[v][x] = m[v] ? a.masked_type : a.type0;
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      if (!live[v]) continue;
+      const int64_t d = sv[v];
+      // the outputs are written once and not read by this call: non-temporal
+      // stores keep the rows of the distinct roots (re-read ~11x) in the caches
+      if (U == 1) {
+        __builtin_nontemporal_store(id[v][0], a.out_id + d);
+        __builtin_nontemporal_store(w[v][0], a.out_w + d);
+        __builtin_nontemporal_store(t[v][0], a.out_t + d);
+      } else {
+        const u64x2 i2 = {id[v][0], id[v][U - 1]};
+        const f32x2 w2 = {w[v][0], w[v][U - 1]};
+        const i32x2 t2 = {t[v][0], t[v][U - 1]};
+        __builtin_nontemporal_store(i2, reinterpret_cast<u64x2*>(a.out_id + d));
+        __builtin_nontemporal_store(w2, reinterpret_cast<f32x2*>(a.out_w + d));
+        __builtin_nontemporal_store(t2, reinterpret_cast<i32x2*>(a.out_t + d));
+      }
+      if (a.mark_owner != nullptr) {
+#pragma unroll
+        for (int x = 0; x < U; ++x)
+          a.mark_owner[a.map.Slot(m[v] ? 0 : id[v][x])] = (uint32_t)(d + x);
+      }
+      if (jv[v] == 0 && a.out_mask != nullptr) a.out_mask[iv[v]] = m[v];
+    }
   }
 }
 
@@ -512,6 +630,11 @@ int g_k1_group = 0;     // block-pivot kernel: five adjacent samples per lane fo
                         // by instruction count), kept selectable
 int g_k1_pair = 1;      // pivot kernel: two adjacent samples per lane when count is even
 int g_k1_grid_cap = 0;  // measurement only: override the workgroup cap of K1
+int g_k1_fuse_mark = 1; // fanout: a hop's kernels fill the next hop's owner table
+int g_k1_dual = 1;      // duplicate-root call: both gated passes in one launch
+int g_expand_steps = 2;        // DedupExpandKernel: grid-stride steps in flight per lane (1, 2, 4)
+int g_expand_const_type = 1;   // ... rebuild the type column of single-type calls from the mask
+int g_expand_grid_cap = 0;     // ... workgroup cap (0 = kK1GridCap)
 int g_k1_ablate = 0;   // measurement only: skip parts of the blocked kernel
 int g_k1_ilp = 4;      // samples per lane of the ILP kernel (1, 2, 4, 8)
 int g_k1_variant = 6;   // 6 = block pivots, 5 = pivot levels, 4 = wave-staged (count >= 8) else blocked,
@@ -1248,11 +1371,10 @@ __device__ __forceinline__ bool LoadSegment(const GraphView& g, int64_t row,
 // U = 1: one sample per lane.  U = 2 (even `count`): a lane draws the two
 // adjacent samples (j, j+1) of one root - one root id / row record / limit
 // load, one Philox block and one 16-byte id store per PAIR.
-template <bool TF_LAYOUT, int U, bool BLOCKED = false>
-__global__ __launch_bounds__(256) void SampleNeighborPivotKernel(
-    const SampleNbArgs a, const int64_t stride_rows, const int32_t stride_slots) {
-  int64_t n_roots;
-  if (!DedupGate(a, &n_roots)) return;
+template <bool TF_LAYOUT, int U, bool BLOCKED>
+__device__ __forceinline__ void PivotPass(const SampleNbArgs& a, const int64_t n_roots,
+                                          const int64_t stride_rows,
+                                          const int32_t stride_slots) {
   const int64_t total = n_roots * (int64_t)a.count;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x * U;
   int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * U;
@@ -1301,9 +1423,36 @@ __global__ __launch_bounds__(256) void SampleNeighborPivotKernel(
       *reinterpret_cast<int2*>(a.out_t + s) = make_int2(ot, ot);
     }
     if (j == 0 && a.out_row_mask != nullptr) a.out_row_mask[r] = valid ? 0 : 1;
+    if (a.mark_owner != nullptr) {
+#pragma unroll
+      for (int x = 0; x < U; ++x) MarkNextHop(a.g, a.mark_owner, id[x], valid, s + x);
+    }
     r += stride_rows;
     j += stride_slots;
     if (j >= a.count) { j -= a.count; ++r; }
+  }
+}
+
+template <bool TF_LAYOUT, int U, bool BLOCKED = false>
+__global__ __launch_bounds__(256) void SampleNeighborPivotKernel(
+    const SampleNbArgs a, const int64_t stride_rows, const int32_t stride_slots) {
+  int64_t n_roots;
+  if (!DedupGate(a, &n_roots)) return;
+  PivotPass<TF_LAYOUT, U, BLOCKED>(a, n_roots, stride_rows, stride_slots);
+}
+
+// Both passes of a duplicate-root call in one launch: the device-side count
+// picks which one runs - `a` (the given roots, U samples per lane) or `b` (the
+// distinct roots into scratch rows, one sample per lane).  A gated launch that
+// only exits still costs ~8 us for its 32 768 workgroups.
+template <bool TF_LAYOUT, int U, bool BLOCKED>
+__global__ __launch_bounds__(256) void SampleNeighborPivotDualKernel(
+    const SampleNbArgs a, const int64_t a_rows, const int32_t a_slots,
+    const SampleNbArgs b, const int64_t b_rows, const int32_t b_slots) {
+  if (DedupActive(a.dd_counter, a.dd_n_in)) {
+    PivotPass<TF_LAYOUT, 1, BLOCKED>(b, (int64_t)(*a.dd_counter), b_rows, b_slots);
+  } else {
+    PivotPass<TF_LAYOUT, U, BLOCKED>(a, a.n, a_rows, a_slots);
   }
 }
 
@@ -1426,6 +1575,31 @@ static void LaunchIlp(bool tf, int grid, int block, hipStream_t stream,
   }
 }
 
+template <int U, int V>
+static void LaunchExpandUV(bool ct, int grid, int block, hipStream_t stream,
+                           const ExpandArgs& x, int64_t stride_rows, int32_t stride_slots) {
+  if (ct) {
+    hipLaunchKernelGGL((DedupExpandKernel<U, V, true>), dim3(grid), dim3(block), 0, stream,
+                       x, stride_rows, stride_slots);
+  } else {
+    hipLaunchKernelGGL((DedupExpandKernel<U, V, false>), dim3(grid), dim3(block), 0, stream,
+                       x, stride_rows, stride_slots);
+  }
+}
+
+static void LaunchExpand(int U, int V, bool ct, int grid, int block, hipStream_t stream,
+                         const ExpandArgs& x, int64_t stride_rows, int32_t stride_slots) {
+  if (U == 2) {
+    if (V >= 4) LaunchExpandUV<2, 4>(ct, grid, block, stream, x, stride_rows, stride_slots);
+    else if (V >= 2) LaunchExpandUV<2, 2>(ct, grid, block, stream, x, stride_rows, stride_slots);
+    else LaunchExpandUV<2, 1>(ct, grid, block, stream, x, stride_rows, stride_slots);
+  } else {
+    if (V >= 4) LaunchExpandUV<1, 4>(ct, grid, block, stream, x, stride_rows, stride_slots);
+    else if (V >= 2) LaunchExpandUV<1, 2>(ct, grid, block, stream, x, stride_rows, stride_slots);
+    else LaunchExpandUV<1, 1>(ct, grid, block, stream, x, stride_rows, stride_slots);
+  }
+}
+
 // Kernel selection for one pass over a.n roots (a.dd_role says which pass).
 static int LaunchK1(const euler_gpu_graph* g, hipStream_t stream,
                     const SampleNbArgs& a) {
@@ -1468,7 +1642,8 @@ static int LaunchK1(const euler_gpu_graph* g, hipStream_t stream,
     const int64_t stride_rows = stride / count;
     const int32_t stride_slots = (int32_t)(stride - stride_rows * count);
     const bool tf = layout == EULER_GPU_LAYOUT_TF;
-    if (blocked && !pair && g_k1_group != 0 && count % 5 == 0 && a.dd_role != 2) {
+    if (blocked && !pair && g_k1_group != 0 && count % 5 == 0 && a.dd_role != 2 &&
+        a.mark_owner == nullptr) {
       // odd multiple of 5 (fanout 25): five adjacent samples per lane
       int64_t blocks = (n * (int64_t)count / 5 + block - 1) / block;
       const int64_t cap = g_k1_grid_cap > 0 ? g_k1_grid_cap : kK1GridCap;
@@ -1587,6 +1762,116 @@ static void PhaseMark(hipStream_t stream, int i) {
   if (t_phase_events != nullptr) (void)hipEventRecord(t_phase_events[i], stream);
 }
 
+// The two gated passes of a duplicate-root call as one launch, when both would
+// run the pivot kernel (see LaunchK1's selection); false = not applicable.
+static bool LaunchK1Dual(const euler_gpu_graph* g, hipStream_t stream,
+                         const SampleNbArgs& a, const SampleNbArgs& b) {
+  const bool single = a.k == 1 && g->view.monotone;
+  const bool tf_zero = a.layout == EULER_GPU_LAYOUT_TF && g->view.has_zero_nbr != 0;
+  if (g_k1_dual == 0 || !(g_k1_variant == 5 || g_k1_variant == 6) || !single || tf_zero)
+    return false;
+  const bool blocked = g_k1_variant == 6;
+  const int32_t count = a.count;
+  const bool pair = g_k1_pair != 0 && count % 2 == 0 &&
+                    ((uintptr_t)a.out_id % 16 == 0) && ((uintptr_t)a.out_w % 8 == 0) &&
+                    ((uintptr_t)a.out_t % 8 == 0);
+  if (blocked && !pair && g_k1_group != 0 && count % 5 == 0 && a.mark_owner == nullptr)
+    return false;                              // pass 1 would take the group kernel
+  const int block = 256;
+  const int U = pair ? 2 : 1;
+  int64_t blocks = (a.n * (int64_t)count / U + block - 1) / block;
+  const int64_t cap = g_k1_grid_cap > 0 ? g_k1_grid_cap : kK1GridCap;
+  if (blocks > cap) blocks = cap;
+  const int grid = (int)(blocks < 1 ? 1 : blocks);
+  const int64_t a_stride = (int64_t)grid * block * U;
+  const int64_t a_rows = a_stride / count;
+  const int32_t a_slots = (int32_t)(a_stride - a_rows * count);
+  const int64_t b_stride = (int64_t)grid * block;
+  const int64_t b_rows = b_stride / count;
+  const int32_t b_slots = (int32_t)(b_stride - b_rows * count);
+  const bool tf = a.layout == EULER_GPU_LAYOUT_TF;
+#define EG_DUAL(TF, UU, BL)                                                            \
+  hipLaunchKernelGGL((SampleNeighborPivotDualKernel<TF, UU, BL>), dim3(grid), dim3(block), \
+                     0, stream, a, a_rows, a_slots, b, b_rows, b_slots)
+  if (tf) {
+    if (pair) { if (blocked) EG_DUAL(true, 2, true); else EG_DUAL(true, 2, false); }
+    else { if (blocked) EG_DUAL(true, 1, true); else EG_DUAL(true, 1, false); }
+  } else {
+    if (pair) { if (blocked) EG_DUAL(false, 2, true); else EG_DUAL(false, 2, false); }
+    else { if (blocked) EG_DUAL(false, 1, true); else EG_DUAL(false, 1, false); }
+  }
+#undef EG_DUAL
+  return true;
+}
+
+// Scratch of one duplicate-root call, carved out of the per-stream workspace.
+// `owner` sits at offset 0 whatever n is: the previous hop of a fanout fills it
+// for the next one before that hop's layout exists.
+struct DedupLayout {
+  size_t scan_bytes, o_owner, o_slot, o_pos, o_uidx, o_uniq, o_cnt, o_scan, o_mask, o_tid,
+      o_tw, o_tt, bytes;
+};
+
+static int MakeDedupLayout(const euler_gpu_graph* g, hipStream_t stream, int64_t n,
+                           int32_t count, DedupLayout* L) {
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t total_out = (size_t)n * (size_t)count;
+  L->scan_bytes = 0;
+  {
+    hipcub::CountingInputIterator<uint32_t> pos_it(0u);
+    hipcub::TransformInputIterator<uint32_t, DedupFlagOp,
+                                   hipcub::CountingInputIterator<uint32_t>>
+        flag_it(pos_it, DedupFlagOp{nullptr, nullptr, n});
+    EG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, L->scan_bytes, flag_it,
+                                            (uint32_t*)nullptr, (int)(n + 1), stream));
+    size_t pre = 0;
+    hipcub::TransformInputIterator<uint32_t, DedupFlagPremarkedOp,
+                                   hipcub::CountingInputIterator<uint32_t>>
+        pre_it(pos_it, DedupFlagPremarkedOp{});
+    EG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, pre, pre_it, (uint32_t*)nullptr,
+                                            (int)(n + 1), stream));
+    if (pre > L->scan_bytes) L->scan_bytes = pre;
+  }
+  L->o_owner = 0;
+  L->o_slot = L->o_owner + al(((size_t)g->view.n_rows + 1) * 4);
+  L->o_pos = L->o_slot + al((size_t)n * 4);
+  L->o_uidx = L->o_pos + al(((size_t)n + 1) * 4);
+  L->o_uniq = L->o_uidx + al((size_t)n * 4);
+  L->o_cnt = L->o_uniq + al((size_t)n * 8);
+  L->o_scan = L->o_cnt + 256;
+  L->o_mask = L->o_scan + al(L->scan_bytes);
+  L->o_tid = L->o_mask + al((size_t)n);
+  L->o_tw = L->o_tid + al(total_out * 8);
+  L->o_tt = L->o_tw + al(total_out * 4);
+  L->bytes = L->o_tt + al(total_out * 4);
+  return EULER_GPU_OK;
+}
+
+// will a call with n roots go through the duplicate-root path?
+static bool WantsDedup(const euler_gpu_graph* g, int64_t n, int dedup) {
+  return dedup != 0 && g_k1_dedup != 0 && (g_k1_variant == 5 || g_k1_variant == 6) &&
+         (n >= kDedupMinRoots || g_k1_dedup == 2) && n < (int64_t)0x3fffffff &&
+         g->view.n_rows < (int64_t)0xfffffff0;
+}
+
+// can LaunchK1 mark the next hop's owner table for this call (pivot kernels,
+// one sample or a pair per lane)?
+static bool K1CanMark(const euler_gpu_graph* g, int32_t k, int32_t count, int32_t layout) {
+  const bool single = k == 1 && g->view.monotone;
+  const bool tf_zero = layout == EULER_GPU_LAYOUT_TF && g->view.has_zero_nbr != 0;
+  (void)count;
+  return g_k1_fuse_mark != 0 && (g_k1_variant == 5 || g_k1_variant == 6) && single &&
+         !tf_zero && layout == EULER_GPU_LAYOUT_TF && g->view.map_mode == 0;
+}
+
+// Hop chaining of a fanout (euler_gpu_sample_fanout holds launch_mu and has
+// sized the stream's workspace for its largest hop, so `owner` does not move).
+struct HopFusion {
+  bool premarked = false;   // in: the previous hop entered these roots into `owner`
+  bool mark_next = false;   // in: the outputs are the next hop's roots, mark them if
+                            // the kernels of this call can; out: whether they did
+};
+
 // dedup: 0 = never, 1 = automatic (count duplicates on device, decide there).
 static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
                                 uint64_t seed, uint32_t call_id,
@@ -1596,7 +1881,11 @@ static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
                                 int32_t count, int32_t layout,
                                 int64_t default_node, uint64_t* out_id,
                                 float* out_w, int32_t* out_t,
-                                uint8_t* out_row_mask, int dedup = 1) {
+                                uint8_t* out_row_mask, int dedup = 1,
+                                HopFusion* hop = nullptr) {
+  const bool premarked = hop != nullptr && hop->premarked;
+  const bool want_mark = hop != nullptr && hop->mark_next;
+  if (hop != nullptr) hop->mark_next = false;
   if (g == nullptr) return Fail(EULER_GPU_ENOGRAPH, "sample_neighbor: null graph");
   if (n < 0 || count < 0 || k < 0 || k > kMaxListedTypes)
     return Fail(EULER_GPU_EINVAL, "sample_neighbor: bad n/count/k (k <= 32)");
@@ -1622,96 +1911,97 @@ static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
   a.n = n; a.default_node = default_node;
   a.k = k; a.count = count; a.layout = layout;
   for (int i = 0; i < k; ++i) a.et[i] = edge_types[i];
-  const bool try_dedup = dedup != 0 && g_k1_dedup != 0 &&
-                         (g_k1_variant == 5 || g_k1_variant == 6) &&
-                         (n >= kDedupMinRoots || g_k1_dedup == 2) &&
-                         n < (int64_t)0x3fffffff &&
-                         g->view.n_rows < (int64_t)0xfffffff0;
+  const bool try_dedup = WantsDedup(g, n, dedup);
+  if (premarked && !try_dedup)
+    return Fail(EULER_GPU_EINVAL, "sample_neighbor: premarked roots without dedup");
+  const bool do_mark = want_mark && K1CanMark(g, k, count, layout);
+  void* wsp = nullptr;
+  if (do_mark && !try_dedup) {
+    // owner table only (the fanout sized the workspace; this is a lookup)
+    const int rc = GetWorkspace(g, stream, ((size_t)g->view.n_rows + 1) * 4, &wsp);
+    if (rc != EULER_GPU_OK) return rc;
+    a.mark_owner = (uint32_t*)wsp;
+  }
   if (!try_dedup) {
     PhaseMark(stream, 0);
     PhaseMark(stream, 1);
     const int rc = LaunchK1(g, stream, a);
     PhaseMark(stream, 2);
     PhaseMark(stream, 3);
+    if (rc == EULER_GPU_OK && hop != nullptr) hop->mark_next = do_mark;
     return rc;
   }
 
-  std::lock_guard<std::mutex> launch_lk(g->launch_mu);
+  std::lock_guard<std::recursive_mutex> launch_lk(g->launch_mu);
   // ---- workspace -----------------------------------------------------------
-  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  const size_t total_out = (size_t)n * (size_t)count;
-  size_t scan_bytes = 0;
+  DedupLayout L;
   {
-    hipcub::CountingInputIterator<uint32_t> pos_it(0u);
-    hipcub::TransformInputIterator<uint32_t, DedupFlagOp,
-                                   hipcub::CountingInputIterator<uint32_t>>
-        flag_it(pos_it, DedupFlagOp{nullptr, nullptr, n});
-    EG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, flag_it,
-                                            (uint32_t*)nullptr, (int)(n + 1), stream));
+    const int rc = MakeDedupLayout(g, stream, n, count, &L);
+    if (rc != EULER_GPU_OK) return rc;
   }
-  const size_t o_owner = 0;
-  const size_t o_slot = o_owner + al(((size_t)g->view.n_rows + 1) * 4);
-  const size_t o_flag = o_slot + al((size_t)n * 4);
-  const size_t o_pos = o_flag + al(((size_t)n + 1) * 4);
-  const size_t o_uidx = o_pos + al(((size_t)n + 1) * 4);
-  const size_t o_uniq = o_uidx + al((size_t)n * 4);
-  const size_t o_cnt = o_uniq + al((size_t)n * 8);
-  const size_t o_scan = o_cnt + 256;
-  const size_t o_mask = o_scan + al(scan_bytes);
-  const size_t o_tid = o_mask + al((size_t)n);
-  const size_t o_tw = o_tid + al(total_out * 8);
-  const size_t o_tt = o_tw + al(total_out * 4);
-  const size_t ws_bytes = o_tt + al(total_out * 4);
-  void* wsp = nullptr;
   {
-    const int rc = GetWorkspace(g, stream, ws_bytes, &wsp);
+    const int rc = GetWorkspace(g, stream, L.bytes, &wsp);
     if (rc != EULER_GPU_OK) return rc;
   }
   uint8_t* ws = (uint8_t*)wsp;
   DedupArgs d{};
   d.g = g->view;
   d.roots = roots; d.root_mask = root_mask; d.n = n; d.root_group = a.root_group;
-  d.owner = (uint32_t*)(ws + o_owner);
-  d.row_slot = (uint32_t*)(ws + o_slot);
-  d.pos = (uint32_t*)(ws + o_pos);
-  d.uidx_of = (uint32_t*)(ws + o_uidx);
-  d.uniq = (uint64_t*)(ws + o_uniq);
-  d.counter = (uint32_t*)(ws + o_cnt);
-  g_last_unique_offset = (int64_t)o_cnt;
+  d.owner = (uint32_t*)(ws + L.o_owner);
+  d.row_slot = (uint32_t*)(ws + L.o_slot);
+  d.pos = (uint32_t*)(ws + L.o_pos);
+  d.uidx_of = (uint32_t*)(ws + L.o_uidx);
+  d.uniq = (uint64_t*)(ws + L.o_uniq);
+  d.counter = (uint32_t*)(ws + L.o_cnt);
+  g_last_unique_offset = (int64_t)L.o_cnt;
+  const IdentityMap idmap{g->view.id_base, g->view.id_stride, g->view.n_rows};
   const int block = 256;
   const int dgrid = GridFor(n + 1, block);
   PhaseMark(stream, 0);
-  hipLaunchKernelGGL(DedupMarkKernel, dim3(dgrid), dim3(block), 0, stream, d);
-  {
-    hipcub::CountingInputIterator<uint32_t> pos_it(0u);
+  hipcub::CountingInputIterator<uint32_t> pos_it(0u);
+  if (premarked) {
+    // the previous hop's kernels stored every position into owner[slot(key)]
+    hipcub::TransformInputIterator<uint32_t, DedupFlagPremarkedOp,
+                                   hipcub::CountingInputIterator<uint32_t>>
+        flag_it(pos_it, DedupFlagPremarkedOp{d.owner, roots, root_mask, idmap, n,
+                                             a.root_group});
+    size_t sb = L.scan_bytes;
+    EG_HIP(hipcub::DeviceScan::ExclusiveSum(ws + L.o_scan, sb, flag_it, d.pos,
+                                            (int)(n + 1), stream));
+    hipLaunchKernelGGL(DedupIndexPremarkedKernel, dim3(dgrid), dim3(block), 0, stream, d,
+                       idmap);
+  } else {
+    hipLaunchKernelGGL(DedupMarkKernel, dim3(dgrid), dim3(block), 0, stream, d);
     hipcub::TransformInputIterator<uint32_t, DedupFlagOp,
                                    hipcub::CountingInputIterator<uint32_t>>
         flag_it(pos_it, DedupFlagOp{d.owner, d.row_slot, n});
-    EG_HIP(hipcub::DeviceScan::ExclusiveSum(ws + o_scan, scan_bytes, flag_it, d.pos,
+    size_t sb = L.scan_bytes;
+    EG_HIP(hipcub::DeviceScan::ExclusiveSum(ws + L.o_scan, sb, flag_it, d.pos,
                                             (int)(n + 1), stream));
+    hipLaunchKernelGGL(DedupIndexKernel, dim3(dgrid), dim3(block), 0, stream, d);
   }
-  hipLaunchKernelGGL(DedupIndexKernel, dim3(dgrid), dim3(block), 0, stream, d);
   PhaseMark(stream, 1);
   // ---- pass 1: the given roots, straight to the outputs (few duplicates) -----
+  // (the owner table is free again: Flag and Index are done with it, so the
+  // kernels that write the final ids may fill it for the next hop)
   a.dd_counter = d.counter;
   a.dd_n_in = n;
   a.dd_role = 1;
-  {
-    const int rc = LaunchK1(g, stream, a);
-    if (rc != EULER_GPU_OK) return rc;
-  }
+  a.mark_owner = do_mark ? d.owner : nullptr;
   // ---- pass 2: the unique roots into scratch rows, then expand ---------------
   SampleNbArgs b = a;
   b.dd_role = 2;
+  b.mark_owner = nullptr;
   b.roots = d.uniq;
   b.root_mask = nullptr;          // masked roots were entered as node id 0
   b.root_group = 1;
-  b.out_id = (uint64_t*)(ws + o_tid);
-  b.out_w = (float*)(ws + o_tw);
-  b.out_t = (int32_t*)(ws + o_tt);
-  b.out_row_mask = ws + o_mask;
-  {
-    const int rc = LaunchK1(g, stream, b);
+  b.out_id = (uint64_t*)(ws + L.o_tid);
+  b.out_w = (float*)(ws + L.o_tw);
+  b.out_t = (int32_t*)(ws + L.o_tt);
+  b.out_row_mask = ws + L.o_mask;
+  if (!LaunchK1Dual(g, stream, a, b)) {
+    int rc = LaunchK1(g, stream, a);
+    if (rc == EULER_GPU_OK) rc = LaunchK1(g, stream, b);
     if (rc != EULER_GPU_OK) return rc;
   }
   PhaseMark(stream, 2);
@@ -1720,24 +2010,30 @@ static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
   x.t_id = b.out_id; x.t_w = b.out_w; x.t_t = b.out_t; x.t_mask = b.out_row_mask;
   x.out_id = out_id; x.out_w = out_w; x.out_t = out_t; x.out_mask = out_row_mask;
   x.n = n; x.count = count;
+  x.mark_owner = do_mark ? d.owner : nullptr;
+  x.map = idmap;
+  const size_t total_out = (size_t)n * (size_t)count;
   const bool pair = count % 2 == 0 && ((uintptr_t)out_id % 16 == 0) &&
                     ((uintptr_t)out_w % 8 == 0) && ((uintptr_t)out_t % 8 == 0);
   const int U = pair ? 2 : 1;
   int64_t blocks = ((int64_t)total_out / U + block - 1) / block;
-  if (blocks > kK1GridCap) blocks = kK1GridCap;
+  const int64_t xcap = g_expand_grid_cap > 0 ? g_expand_grid_cap : kK1GridCap;
+  if (blocks > xcap) blocks = xcap;
   if (blocks < 1) blocks = 1;
   const int64_t stride = blocks * block * U;
   const int64_t stride_rows = stride / count;
   const int32_t stride_slots = (int32_t)(stride - stride_rows * count);
-  if (pair) {
-    hipLaunchKernelGGL(DedupExpandKernel<2>, dim3((int)blocks), dim3(block), 0, stream,
-                       x, stride_rows, stride_slots);
-  } else {
-    hipLaunchKernelGGL(DedupExpandKernel<1>, dim3((int)blocks), dim3(block), 0, stream,
-                       x, stride_rows, stride_slots);
-  }
+  // single-type calls served by the pivot kernels: the type column is a
+  // function of the row mask (SampleNeighborPivotKernel: t or -1 / 0)
+  const bool ct = g_expand_const_type != 0 && k == 1 && g->view.monotone &&
+                  !(layout == EULER_GPU_LAYOUT_TF && g->view.has_zero_nbr != 0);
+  x.type0 = k == 1 ? edge_types[0] : 0;
+  x.masked_type = layout == EULER_GPU_LAYOUT_TF ? -1 : 0;
+  LaunchExpand(pair ? 2 : 1, g_expand_steps, ct, (int)blocks, block, stream, x,
+               stride_rows, stride_slots);
   PhaseMark(stream, 3);
   EG_HIP(hipGetLastError());
+  if (hop != nullptr) hop->mark_next = do_mark;
   return EULER_GPU_OK;
 }
 
@@ -2290,12 +2586,87 @@ __global__ void AlgoBytesKernel(const FullNbArgs a, int32_t count, double* acc) 
 
 using namespace euler_gpu;
 
+// The hops of a fanout under one lock: hop h's kernels that write the final ids
+// also enter them into hop h+1's owner table (MarkNextHop), so the duplicate
+// detection of hop h+1 starts at its scan.  events: 4 per hop (PhaseMark) or
+// null; uniq_off: per hop, the workspace offset of the hop's unique count (-1
+// when the hop did not look for duplicates) or null.
+static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed,
+                     uint32_t call_id, const uint64_t* roots_dev, int64_t n,
+                     const int32_t* edge_types_host, int32_t k,
+                     const int32_t* counts_host, int32_t layers, int64_t default_node,
+                     uint64_t* const* out_id_dev, float* const* out_w_dev,
+                     int32_t* const* out_t_dev, void* workspace_dev, hipEvent_t* events,
+                     int64_t* uniq_off) {
+  std::lock_guard<std::recursive_mutex> launch_lk(g->launch_mu);
+  // size the stream's scratch for the largest hop up front: the owner table a
+  // hop fills for its successor must not move in between
+  {
+    size_t need = 0;
+    int64_t m = n;
+    for (int32_t h = 0; h < layers; ++h) {
+      if (m > 0 && counts_host[h] > 0 && WantsDedup(g, m, h == 0 ? 0 : 1)) {
+        DedupLayout L;
+        const int rc = MakeDedupLayout(g, stream, m, counts_host[h], &L);
+        if (rc != EULER_GPU_OK) return rc;
+        if (L.bytes > need) need = L.bytes;
+      }
+      m *= counts_host[h];
+    }
+    if (need > 0) {
+      void* p = nullptr;
+      const int rc = GetWorkspace(g, stream, need, &p);
+      if (rc != EULER_GPU_OK) return rc;
+    }
+  }
+  const uint64_t* roots = roots_dev;
+  const uint8_t* mask = nullptr;
+  int32_t group = 1;
+  int64_t m = n;
+  uint8_t* ws = (uint8_t*)workspace_dev;
+  HopFusion hop;
+  int rc = EULER_GPU_OK;
+  for (int32_t h = 0; h < layers && rc == EULER_GPU_OK; ++h) {
+    // hop h: roots are the previous hop's TF-layout ids; rows the previous hop
+    // marked as missing sample as the sentinel id 0, which is what the
+    // reference's chained GQL feeds on (sample_fanout_op.cc:37-42).
+    uint8_t* row_mask = ws;
+    ws += ((size_t)m + 15) & ~(size_t)15;
+    const int64_t m_next = m * counts_host[h];
+    // hop 0 samples the caller's batch; later hops sample sampled neighbours,
+    // which repeat
+    const int dedup = h == 0 ? 0 : 1;
+    hop.mark_next = h + 1 < layers && m_next > 0 && WantsDedup(g, m_next, 1);
+    if (events != nullptr) t_phase_events = events + (size_t)h * 4;
+    g_last_unique_offset = -1;
+    rc = LaunchSampleNeighbor(g, stream, seed, call_id + (uint32_t)h, roots, m, mask,
+                              group, edge_types_host + (size_t)h * k, k, counts_host[h],
+                              EULER_GPU_LAYOUT_TF, default_node, out_id_dev[h],
+                              out_w_dev[h], out_t_dev[h], row_mask, dedup, &hop);
+    if (uniq_off != nullptr) uniq_off[h] = g_last_unique_offset;
+    hop.premarked = hop.mark_next;     // what this hop did is the next hop's input
+    roots = out_id_dev[h];
+    mask = row_mask;
+    group = counts_host[h];
+    m = m_next;
+  }
+  t_phase_events = nullptr;
+  return rc;
+}
+
 extern "C" {
 
 int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 0) { g_k1_variant = value; return EULER_GPU_OK; }
   if (key == 2) { g_k1_ablate = value; return EULER_GPU_OK; }
   if (key == 3) { g_k1_grid_cap = value; return EULER_GPU_OK; }
+  if (key == 9) { g_k1_fuse_mark = value != 0; return EULER_GPU_OK; }
+  if (key == 10 && (value == 1 || value == 2 || value == 4)) {
+    g_expand_steps = value; return EULER_GPU_OK;
+  }
+  if (key == 11) { g_expand_const_type = value != 0; return EULER_GPU_OK; }
+  if (key == 13) { g_k1_dual = value != 0; return EULER_GPU_OK; }
+  if (key == 12 && value >= 0) { g_expand_grid_cap = value; return EULER_GPU_OK; }
   if (key == 4) { g_k1_pair = value; return EULER_GPU_OK; }
   if (key == 5) { g_k1_dedup = value; return EULER_GPU_OK; }
   if (key == 6) { g_k1_group = value; return EULER_GPU_OK; }
@@ -2362,33 +2733,10 @@ int euler_gpu_sample_fanout(const euler_gpu_graph* g, void* stream,
     return Fail(EULER_GPU_EINVAL, "sample_fanout: bad arguments");
   if (layers > 0 && n > 0 && !workspace_dev)
     return Fail(EULER_GPU_EINVAL, "sample_fanout: workspace required");
-  const uint64_t* roots = roots_dev;
-  const uint8_t* mask = nullptr;
-  int32_t group = 1;
-  int64_t m = n;
-  uint8_t* ws = (uint8_t*)workspace_dev;
-  for (int32_t h = 0; h < layers; ++h) {
-    // hop h: roots are the previous hop's TF-layout ids; rows the previous hop
-    // marked as missing sample as the sentinel id 0, which is what the
-    // reference's chained GQL feeds on (sample_fanout_op.cc:37-42).
-    uint8_t* row_mask = ws;
-    ws += ((size_t)m + 15) & ~(size_t)15;
-    int rc = LaunchSampleNeighbor(g, (hipStream_t)stream, seed,
-                                  call_id + (uint32_t)h, roots, m, mask, group,
-                                  edge_types_host + (size_t)h * k, k,
-                                  counts_host[h], EULER_GPU_LAYOUT_TF,
-                                  default_node, out_id_dev[h], out_w_dev[h],
-                                  out_t_dev[h], row_mask,
-                                  // hop 0 samples the caller's batch; later hops
-                                  // sample sampled neighbours, which repeat
-                                  h == 0 ? 0 : 1);
-    if (rc != EULER_GPU_OK) return rc;
-    roots = out_id_dev[h];
-    mask = row_mask;
-    group = counts_host[h];
-    m *= counts_host[h];
-  }
-  return EULER_GPU_OK;
+  if (g == nullptr) return Fail(EULER_GPU_ENOGRAPH, "sample_fanout: null graph");
+  return RunFanout(g, (hipStream_t)stream, seed, call_id, roots_dev, n, edge_types_host, k,
+                   counts_host, layers, default_node, out_id_dev, out_w_dev, out_t_dev,
+                   workspace_dev, nullptr, nullptr);
 }
 
 int euler_gpu_sample_node(const euler_gpu_graph* g, void* stream, uint64_t seed,
@@ -2722,13 +3070,8 @@ int euler_gpu_expand_rows(void* stream, const int32_t* pos_dev, int64_t n,
   const int64_t stride = blocks * block * U;
   const int64_t stride_rows = stride / count;
   const int32_t stride_slots = (int32_t)(stride - stride_rows * count);
-  if (pair) {
-    hipLaunchKernelGGL(DedupExpandKernel<2>, dim3((int)blocks), dim3(block), 0, st, x,
-                       stride_rows, stride_slots);
-  } else {
-    hipLaunchKernelGGL(DedupExpandKernel<1>, dim3((int)blocks), dim3(block), 0, st, x,
-                       stride_rows, stride_slots);
-  }
+  LaunchExpand(U, g_expand_steps, false, (int)blocks, block, st, x, stride_rows,
+               stride_slots);
   EG_HIP(hipGetLastError());
   EG_HIP(hipFreeAsync(zero, st));
   return EULER_GPU_OK;
@@ -2774,6 +3117,58 @@ int euler_gpu_time_sample_neighbor_phases(const euler_gpu_graph* g, void* stream
       *n_unique_host = g_last_unique_offset >= 0 && it != g->ws.end()
                            ? ReadU32((const uint8_t*)it->second.first + g_last_unique_offset)
                            : -1;
+    }
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return rc;
+}
+
+int euler_gpu_time_sample_fanout_phases(const euler_gpu_graph* g, void* stream,
+                                        uint64_t seed, const uint64_t* roots_dev,
+                                        int64_t n, const int32_t* edge_types_host,
+                                        int32_t k, const int32_t* counts_host,
+                                        int32_t layers, int64_t default_node,
+                                        uint64_t* const* out_id_dev,
+                                        float* const* out_w_dev,
+                                        int32_t* const* out_t_dev, void* workspace_dev,
+                                        int32_t iters, float* mean_ms_host,
+                                        int64_t* n_unique_host) {
+  if (!g) return Fail(EULER_GPU_ENOGRAPH, "time_sample_fanout_phases: null graph");
+  if (iters <= 0 || iters > 64 || layers <= 0 || layers > 8 || !mean_ms_host ||
+      !counts_host || !out_id_dev || !out_w_dev || !out_t_dev || !workspace_dev)
+    return Fail(EULER_GPU_EINVAL, "time_sample_fanout_phases: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t per_it = (size_t)layers * 4;
+  std::vector<hipEvent_t> ev((size_t)iters * per_it);
+  for (auto& e : ev) EG_HIP(hipEventCreate(&e));
+  std::vector<int64_t> off((size_t)layers, -1);
+  int rc = EULER_GPU_OK;
+  for (int32_t it = 0; it < iters && rc == EULER_GPU_OK; ++it)
+    rc = RunFanout(g, st, seed, (uint32_t)(it * layers), roots_dev, n, edge_types_host, k,
+                   counts_host, layers, default_node, out_id_dev, out_w_dev, out_t_dev,
+                   workspace_dev, ev.data() + (size_t)it * per_it, off.data());
+  if (rc == EULER_GPU_OK) {
+    EG_HIP(hipStreamSynchronize(st));
+    for (int32_t h = 0; h < layers; ++h)
+      for (int p = 0; p < 3; ++p) {
+        float sum = 0.f;
+        for (int32_t it = 0; it < iters; ++it) {
+          float ms = 0.f;
+          const size_t b = (size_t)it * per_it + (size_t)h * 4 + p;
+          EG_HIP(hipEventElapsedTime(&ms, ev[b], ev[b + 1]));
+          sum += ms;
+        }
+        mean_ms_host[h * 3 + p] = sum / (float)iters;
+      }
+    if (n_unique_host != nullptr) {
+      // a later hop reuses the scratch of an earlier one, so only the last
+      // hop's count is still there after the call; earlier hops report -1
+      std::lock_guard<std::mutex> lk(g->ws_mu);
+      auto it = g->ws.find((void*)st);
+      for (int32_t h = 0; h < layers; ++h) n_unique_host[h] = -1;
+      const int32_t last = layers - 1;
+      if (off[last] >= 0 && it != g->ws.end())
+        n_unique_host[last] = ReadU32((const uint8_t*)it->second.first + off[last]);
     }
   }
   for (auto& e : ev) (void)hipEventDestroy(e);

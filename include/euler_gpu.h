@@ -382,6 +382,13 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  *        0 = one lane per walker.
  * key 5: duplicate roots: 0 = never look, 1 = look when a call has >= 16384
  *        roots [default], 2 = always look.
+ * key 8: dense-feature kernel: 16-byte loads when the slots allow it (1).
+ * key 9: fanout: a hop's kernels enter their ids into the next hop's owner
+ *        table, 1 [default]; 0 = every hop runs its own mark pass.
+ * key 10: expansion of the distinct roots' rows: grid-stride steps in flight per
+ *        lane (1, 2 [default], 4).  key 11: rebuild the type column of
+ *        single-type calls from the row mask instead of gathering it (1).
+ *        key 12: measurement only (workgroup cap of the expansion).
  * All settings produce identical results; the knobs exist for A/B measurements
  * and tests. */
 int euler_gpu_set_tuning(int32_t key, int32_t value);
@@ -410,6 +417,21 @@ int euler_gpu_time_sample_neighbor_phases(const euler_gpu_graph* g, void* stream
                                           float* out_w_dev, int32_t* out_t_dev,
                                           int32_t iters, float* mean_ms3_host,
                                           int64_t* n_unique_host);
+/* The whole fanout (euler_gpu_sample_fanout's arguments), timed in place:
+ * mean_ms_host[3*h + {0,1,2}] = hop h's duplicate detection / sampling
+ * kernel(s) / expansion, with the hop chaining the product uses (hop h's
+ * kernels enter their ids into hop h+1's owner table).  n_unique_host
+ * (optional, [layers]): distinct roots the LAST hop counted, -1 elsewhere. */
+int euler_gpu_time_sample_fanout_phases(const euler_gpu_graph* g, void* stream,
+                                        uint64_t seed, const uint64_t* roots_dev,
+                                        int64_t n, const int32_t* edge_types_host,
+                                        int32_t k, const int32_t* counts_host,
+                                        int32_t layers, int64_t default_node,
+                                        uint64_t* const* out_id_dev,
+                                        float* const* out_w_dev,
+                                        int32_t* const* out_t_dev, void* workspace_dev,
+                                        int32_t iters, float* mean_ms_host,
+                                        int64_t* n_unique_host);
 /* Exact algorithmic byte count of one sample_neighbor launch (SURVEY §8d
  * formula evaluated on the actual roots' degrees); synchronises. */
 int euler_gpu_sample_neighbor_algo_bytes(const euler_gpu_graph* g, void* stream,

@@ -802,3 +802,54 @@ def test_concurrent_callers_share_a_stream(EA, O, torch_cuda, big_pair):
             for h in range(2):
                 assert torch.equal(got[i][0][h + 1], alone[i][0][h + 1])
                 assert torch.equal(got[i][1][h], alone[i][1][h])
+
+
+@pytest.mark.parametrize("base,stride", [(1, 1), (1000, 3)])
+def test_fanout_hop_chaining_on_identity_id_maps(EA, O, torch_cuda, base, stride):
+    """Fanout on graphs whose ids are base + stride * row (identity id map): hop
+    h's kernels enter their ids into hop h+1's owner table (tuning key 9), so
+    hop h+1's duplicate detection starts at its scan.  Rows without neighbours
+    (masked -> node id 0 in the next hop), ids off the stride grid and ids
+    beyond the last row all go through it; results must equal the oracle's and
+    be the same with the chaining switched off.  Even counts take the
+    pair-per-lane kernels, odd counts the single ones; the forced mode (key 5 =
+    2) makes the small first hops use the duplicate path too, so the expand
+    kernel is the one that marks."""
+    torch = torch_cuda
+    rng = np.random.default_rng(5150 + stride)
+    n, T = 30000, 2
+    ids = (base + stride * np.arange(n)).astype(np.uint64)
+    deg = rng.integers(0, 30, size=(n, T))
+    deg[rng.random((n, T)) < 0.3] = 0
+    seg = np.zeros(n * T + 1, np.int64)
+    seg[1:] = np.cumsum(deg.reshape(-1))
+    E = int(seg[-1])
+    nbr = rng.choice(ids, E).astype(np.uint64)
+    dangling = rng.random(E) < 0.03
+    nbr[dangling] = nbr[dangling] + (1 if stride > 1 else stride * n + 7)   # no such node
+    w = (rng.random(E) * 7.5 + 0.5).astype(np.float32)
+    nt = np.zeros(n, np.int32)
+    nw = np.ones(n, np.float32)
+    csr = O.csr_from_raw(ids, seg, nbr, w, T, nt, nw)
+    G, OG = gpu_graph(EA, csr), O.OracleGraph(csr)
+    q = np.concatenate([rng.choice(ids, 4094), [0, base + stride * n + 1]]).astype(np.int64)
+    qt = torch.as_tensor(q).cuda()
+    from euler_amd import _lib
+    L = _lib.lib()
+    try:
+        for forced in (1, 2):
+            L.euler_gpu_set_tuning(5, forced)
+            for et, counts in (([[0], [1], [0]], [8, 6, 4]), ([[1], [0]], [25, 10]),
+                               ([[0], [0], [1]], [5, 3, 3])):
+                on, ow, ot = OG.sample_fanout(21, 60, q, et, counts, -1)
+                for fuse in (1, 0):
+                    L.euler_gpu_set_tuning(9, fuse)
+                    G.set_seed(21)
+                    gn, gw, gt = G.sample_fanout(qt, et, counts, -1, call_id=60)
+                    for h in range(len(counts)):
+                        assert np.array_equal(t2n(gn[h + 1]), on[h]), (forced, counts, fuse, h)
+                        assert np.array_equal(t2n(gw[h]), ow[h]), (forced, counts, fuse, h)
+                        assert np.array_equal(t2n(gt[h]), ot[h]), (forced, counts, fuse, h)
+    finally:
+        L.euler_gpu_set_tuning(5, 1)
+        L.euler_gpu_set_tuning(9, 1)

@@ -1,0 +1,68 @@
+"""A/B of one tuning key on the metric's fanout, timed in place
+(euler_gpu_time_sample_fanout_phases) and by wall clock.
+
+  python tools/ab_key.py KEY V0 V1 [V2 ...]      e.g.  tools/ab_key.py 13 1 0"""
+import sys, json, time, ctypes as C
+sys.path.insert(0, '.')
+import torch, euler_amd
+from euler_amd import _lib
+L = _lib.lib()
+key = int(sys.argv[1])
+values = [int(x) for x in sys.argv[2:]]
+fan = [25, 10]
+layers = 2
+N = 100_000_000
+p = euler_amd.synth_params(20240521, N, 1_000_000_000, weighted=True)
+G = euler_amd.Graph.synthetic(p)
+G.set_seed(20240521)
+B = 131072
+gen = torch.Generator(device='cuda'); gen.manual_seed(1234)
+roots = torch.randint(1, N + 1, (B,), generator=gen, device='cuda')
+st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+et = (C.c_int32 * layers)(*([0] * layers))
+cnt = (C.c_int32 * layers)(*fan)
+outs_n, outs_w, outs_t = [], [], []
+m = B
+for c in fan:
+    m *= c
+    outs_n.append(torch.empty(m, dtype=torch.int64, device='cuda'))
+    outs_w.append(torch.empty(m, dtype=torch.float32, device='cuda'))
+    outs_t.append(torch.empty(m, dtype=torch.int32, device='cuda'))
+ws = torch.empty(max(int(L.euler_gpu_sample_fanout_workspace(B, cnt, layers)), 16),
+                 dtype=torch.uint8, device='cuda')
+pn = (C.c_void_p * layers)(*[t.data_ptr() for t in outs_n])
+pw = (C.c_void_p * layers)(*[t.data_ptr() for t in outs_w])
+pt = (C.c_void_p * layers)(*[t.data_ptr() for t in outs_t])
+
+
+def sig():
+    out = G.sample_fanout(roots, [[0]] * layers, fan, N + 1, call_id=0)
+    return ([int(x.sum().item()) for x in out[0]] + [float(x.double().sum().item()) for x in out[1]]
+            + [int(x.sum().item()) for x in out[2]])
+
+
+res = {}
+ref = None
+for rep in range(2):
+    for v in values:
+        _lib.check(L.euler_gpu_set_tuning(key, v))
+        ms = (C.c_float * (3 * layers))()
+        nu = (C.c_int64 * layers)()
+        _lib.check(L.euler_gpu_time_sample_fanout_phases(
+            G._h, st, 20240521, C.c_void_p(roots.data_ptr()), B, et, 1, cnt, layers, N + 1,
+            pn, pw, pt, C.c_void_p(ws.data_ptr()), 20, ms, nu))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(50):
+            G.sample_fanout(roots, [[0]] * layers, fan, N + 1, call_id=0)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / 50 * 1e3
+        s = sig()
+        if ref is None:
+            ref = s
+        assert s == ref, (key, v)
+        res.setdefault('key %d = %d' % (key, v), []).append(
+            {'phases_ms': [round(x, 4) for x in ms], 'sum_ms': round(sum(ms), 4),
+             'wall_ms': round(wall, 4)})
+for k, v in res.items():
+    print(k, json.dumps(v))

@@ -27,8 +27,8 @@ def passes(name, kernel="SampleNeighbor"):
 
 summary = {"note": "rocprofv3 --pmc passes (one counter set per pass, --kernel-trace only) over "
                    "`bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-check`; per-launch "
-                   "means of the K1 kernel (SampleNeighborPivotKernel<true,1,true>): hop1 = over the "
-                   "batch, hop2 = over the distinct hop-2 roots (gated no-op launches excluded); "
+                   "means of the K1 kernel: hop1 = SampleNeighborPivotKernel<true,1,true> over the batch, "
+                   "hop2 = SampleNeighborPivotDualKernel over the distinct hop-2 roots; "
                    "expand = DedupExpandKernel. FETCH_SIZE / WRITE_SIZE are reported in KiB."}
 # K1 launches of a step that do work: <true, 1> = hop 1 (odd count, one sample
 # per lane), <true, 2> = hop 2 over the distinct roots; the <true, 2> launches
@@ -47,7 +47,7 @@ def passes_named(name):
     rows = collections.defaultdict(list)
     for f in glob.glob(g + "_pmc_%s/**/*counter_collection.csv" % name, recursive=True):
         for r in csv.DictReader(open(f)):
-            if "SampleNeighborPivotKernel" in r["Kernel_Name"] or "DedupExpand" in r["Kernel_Name"]:
+            if "SampleNeighborPivot" in r["Kernel_Name"] or "DedupExpand" in r["Kernel_Name"]:
                 rows[r["Counter_Name"]].append(
                     (int(r["Dispatch_Id"]), float(r["Counter_Value"]),
                      int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r["Kernel_Name"],
@@ -56,7 +56,7 @@ def passes_named(name):
 
 for name in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum"):
     for ctr, v in passes_named(name).items():
-        h1, h2 = split([x for x in v if "SampleNeighborPivotKernel" in x[3]])
+        h1, h2 = split([x for x in v if "SampleNeighborPivot" in x[3]])
         ex = [x for x in v if "DedupExpand" in x[3] and x[2] > 30000]
         mean = lambda xs, i: sum(x[i] for x in xs) / max(len(xs), 1)
         summary[ctr] = {"hop1_mean": mean(h1, 1), "hop2_mean": mean(h2, 1),
