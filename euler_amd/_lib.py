@@ -109,7 +109,9 @@ SIGNATURES = {
                                                      C.c_int32, C.c_int32, C.c_int64, vp,
                                                      vp, vp, vp]),
     "euler_gpu_dedup_split": (C.c_int, [vp, vp, C.c_int64, vp, C.c_int32, C.c_int32,
-                                        C.c_int32, C.POINTER(C.c_int64), vp, vp]),
+                                        C.c_int32, vp, C.c_int64, C.POINTER(C.c_int64),
+                                        vp, vp]),
+    "euler_gpu_graph_id_range": (C.c_int, [vp, u64p, i32p]),
     "euler_gpu_pack_rows": (C.c_int, [vp, vp, vp, vp, vp, C.c_int64, C.c_int32, vp]),
     "euler_gpu_expand_packed": (C.c_int, [vp, vp, C.c_int64, C.c_int32, vp, vp, vp, vp,
                                           vp]),

@@ -164,6 +164,7 @@ struct euler_gpu_graph {
   bool has_sampler = false;
   int32_t n_node_types = 1;
   int64_t bytes = 0;
+  uint64_t max_id = 0;          // largest node id of this graph (shard)
   std::vector<void*> allocations;     // every hipMalloc owned by the graph
   std::vector<float> node_weight_sums;
   bool feat_slot_aligned = false;     // uniform feature table: every slot begins at a

@@ -430,6 +430,8 @@ int BuildGraphFromHost(const euler_gpu_host_csr* c, int device,
   }
   for (int64_t i = 0; identity && i < n; ++i)
     identity = row_id[i] == base + (uint64_t)i * stride;
+  for (int64_t i = 0; i < n; ++i)
+    if (row_id[i] > b.g->max_id) b.g->max_id = row_id[i];
   if (identity) {
     v.map_mode = 0; v.id_base = base; v.id_stride = stride;
   } else {
@@ -670,6 +672,7 @@ int BuildGraphSynthetic(const euler_gpu_synth_params* sp, int device,
   const int32_t T = sp->n_types;
   v.T = T; v.meta_stride = 8 + 8 * T; v.n_rows = n_rows;
   v.map_mode = 0; v.id_base = base; v.id_stride = stride; v.row_id = nullptr;
+  b.g->max_id = n_rows > 0 ? base + (uint64_t)(n_rows - 1) * stride : 0;
   v.has_zero_nbr = 0;
   v.monotone = 1;     // weights are >= 0.5: f32 running sums never decrease
   SynthView p{};
@@ -839,6 +842,15 @@ int32_t euler_gpu_graph_num_float_features(const euler_gpu_graph* g) {
   return g ? g->view.n_float : 0;
 }
 int64_t euler_gpu_graph_bytes(const euler_gpu_graph* g) { return g ? g->bytes : -1; }
+
+int euler_gpu_graph_id_range(const euler_gpu_graph* g, uint64_t* max_id_host,
+                             int32_t* identity_host) {
+  if (!g || !max_id_host || !identity_host)
+    return Fail(EULER_GPU_EINVAL, "graph_id_range: null");
+  *max_id_host = g->max_id;
+  *identity_host = g->view.map_mode == 0 ? 1 : 0;
+  return EULER_GPU_OK;
+}
 
 int euler_gpu_graph_node_weight_sums(const euler_gpu_graph* g, float* out_host) {
   if (!g || !out_host) return Fail(EULER_GPU_EINVAL, "node_weight_sums: null");

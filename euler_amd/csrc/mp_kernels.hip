@@ -6,6 +6,9 @@
 // domain kernel is written here.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "device_fns.h"
 
@@ -911,9 +914,6 @@ struct DedupIdsArgs {
   uint32_t mask;
   uint32_t* owner;     // [mask + 1]
   uint32_t* owner2;    // [mask + 1] second round (stale entries are checked by id)
-  uint32_t* pos;       // [n + 1] exclusive scan of the representative flags
-  uint64_t* uniq;      // [<= n]
-  uint32_t* u_of;      // [n] index into uniq of every position
 };
 
 __device__ __forceinline__ uint64_t DedupIdAt(const DedupIdsArgs& a, int64_t i) {
@@ -952,37 +952,150 @@ __global__ __launch_bounds__(256) void DedupIdsMark2Kernel(const DedupIdsArgs a)
   }
 }
 
-struct DedupIdsFlagOp {
-  DedupIdsArgs a;
-  __device__ __forceinline__ uint32_t operator()(const uint32_t& i) const {
-    return ((int64_t)i < a.n && DedupRep(a, i) == i) ? 1u : 0u;
-  }
+// ---- v2 front end: representatives -> per-(shard, block) counts -> scan ->
+// bucketed index, one host sync.  (The first version numbered the distinct ids
+// with a scan, copied the count to the host, ran ID_SPLIT on them with a second
+// sync and `shards` more 8-byte device-to-host copies at ~40 us each, then
+// inverted and composed two index maps: 0.61 ms for the metric's hop 2 on 8
+// shards, most of it host time.)
+struct FrontArgs {
+  DedupIdsArgs d;            // ids / mask / hash tables (hash mode)
+  uint32_t* dense_owner;     // dense mode: [dense_limit + 1], slot = id (or the limit)
+  uint64_t dense_limit;
+  uint32_t* rep;             // [n] representative of every position
+  int32_t* bidx;             // [n] bucketed index, valid at representatives
+  int64_t* block_hist;       // [shards, n_blocks]
+  int32_t partitions, shards;
 };
 
-__global__ __launch_bounds__(256) void DedupIdsIndexKernel(const DedupIdsArgs a) {
+__device__ __forceinline__ uint32_t DenseSlot(const FrontArgs& a, uint64_t id) {
+  return id < a.dense_limit ? (uint32_t)id : (uint32_t)a.dense_limit;
+}
+
+// dense ids: owner[id] = position by plain stores (see sample_kernels.hip,
+// DedupMarkKernel); every id >= the limit is "no such node" and shares a slot -
+// whichever owner answers for its representative answers the default row
+__global__ __launch_bounds__(256) void FrontMarkDenseKernel(const FrontArgs a) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
-    const uint32_t rep = DedupRep(a, (uint32_t)i);
-    a.u_of[i] = a.pos[rep];
-    if (rep == (uint32_t)i) a.uniq[a.pos[i]] = DedupIdAt(a, i);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.d.n; i += stride)
+    a.dense_owner[DenseSlot(a, DedupIdAt(a.d, i))] = (uint32_t)i;
+}
+
+// one position per thread: its representative, and the block's count of
+// representatives per owner shard
+__global__ __launch_bounds__(kSplitBlock) void FrontRepHistKernel(const FrontArgs a) {
+  const bool DENSE = a.dense_owner != nullptr;
+  __shared__ int32_t hist[kMaxShards];
+  if (threadIdx.x < kMaxShards) hist[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * kSplitBlock + threadIdx.x;
+  if (i < a.d.n) {
+    const uint64_t id = DedupIdAt(a.d, i);
+    const uint32_t r = DENSE ? a.dense_owner[DenseSlot(a, id)] : DedupRep(a.d, (uint32_t)i);
+    a.rep[i] = r;
+    if (r == (uint32_t)i) atomicAdd(&hist[OwnerOf(id, a.partitions, a.shards)], 1);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < a.shards)
+    a.block_hist[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = hist[threadIdx.x];
+}
+
+// representatives take their place in their shard's bucket
+__global__ __launch_bounds__(kSplitBlock) void FrontScatterKernel(
+    const FrontArgs a, const int64_t* block_off, uint64_t* shard_ids) {
+  __shared__ int32_t wave_cnt[kSplitBlock / 64][kMaxShards];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * kSplitBlock + threadIdx.x;
+  const bool is_rep = i < a.d.n && a.rep[i] == (uint32_t)i;
+  const uint64_t id = is_rep ? DedupIdAt(a.d, i) : 0;
+  const int32_t own = is_rep ? OwnerOf(id, a.partitions, a.shards) : -1;
+  int32_t rank_in_wave = 0;
+  for (int32_t s = 0; s < a.shards; ++s) {
+    const unsigned long long m = __ballot(own == s);
+    if (own == s) rank_in_wave = __popcll(m & ((1ULL << lane) - 1));
+    if (lane == 0) wave_cnt[wave][s] = __popcll(m);
+  }
+  __syncthreads();
+  if (is_rep) {
+    int32_t before = 0;
+    for (int w = 0; w < wave; ++w) before += wave_cnt[w][own];
+    const int64_t q = block_off[(int64_t)own * gridDim.x + blockIdx.x] + before + rank_in_wave;
+    shard_ids[q] = id;
+    a.bidx[i] = (int32_t)q;
   }
 }
 
-__global__ void InvertIdxKernel(const int32_t* merge_idx, int64_t m, int32_t* inv) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < m) inv[merge_idx[j]] = (int32_t)j;
+// pos[i] = bucketed index of position i's id; block 0 also collects the shard
+// starts (and the total) into one contiguous array for a single copy
+__global__ __launch_bounds__(256) void FrontComposeKernel(const FrontArgs a,
+                                                          const int64_t* block_off,
+                                                          int64_t n_blocks, int32_t* pos_out,
+                                                          int64_t* starts /* [shards + 1] */) {
+  if (blockIdx.x == 0 && (int)threadIdx.x <= a.shards) {
+    const int s = threadIdx.x;
+    starts[s] = s < a.shards
+                    ? block_off[(int64_t)s * n_blocks]
+                    : block_off[(int64_t)a.shards * n_blocks - 1] +
+                          a.block_hist[(int64_t)a.shards * n_blocks - 1];
+  }
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.d.n; i += stride)
+    pos_out[i] = a.bidx[a.rep[i]];
 }
 
-__global__ void ComposeIdxKernel(const uint32_t* u_of, const int32_t* inv, int64_t n,
-                                 int32_t* pos_out) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-    pos_out[i] = inv[u_of[i]];
+// Grow-only device scratch per (device, stream) for the front end: it runs
+// twice per hop with very different sizes, and alternating stream-ordered
+// allocations of 1 MB and 60 MB cost ~0.2 ms per call in the allocator.  The
+// entry is locked for the whole call (which ends with a stream sync, so the
+// scratch is idle again when the lock drops).
+struct StreamScratch {
+  std::mutex mu;
+  void* ptr = nullptr;
+  size_t bytes = 0;
+};
+static StreamScratch* ScratchEntry(hipStream_t stream) {
+  static std::mutex map_mu;
+  static std::map<std::pair<int, void*>, StreamScratch*> entries;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(map_mu);
+  auto& e = entries[std::make_pair(dev, (void*)stream)];
+  if (e == nullptr) e = new StreamScratch();
+  return e;
+}
+// caller holds e->mu
+static int ScratchReserve(StreamScratch* e, hipStream_t stream, size_t bytes, void** out) {
+  if (e->bytes < bytes) {
+    if (e->ptr != nullptr) {
+      EG_HIP(hipStreamSynchronize(stream));
+      EG_HIP(hipFree(e->ptr));
+      e->ptr = nullptr; e->bytes = 0;
+    }
+    const size_t want = bytes + bytes / 4;
+    hipError_t err = hipMalloc(&e->ptr, want);
+    if (err != hipSuccess) {
+      e->ptr = nullptr;
+      return Fail(EULER_GPU_ENOMEM, std::string("dedup_split scratch: ") + hipGetErrorString(err));
+    }
+    e->bytes = want;
+  }
+  *out = e->ptr;
+  return EULER_GPU_OK;
+}
+
+// small pinned staging buffer per host thread (a pageable device-to-host copy
+// costs ~40 us; this one is written by the copy engine directly)
+static int64_t* PinnedStage() {
+  static thread_local int64_t* p = nullptr;
+  if (p == nullptr && hipHostMalloc((void**)&p, (kMaxShards + 1) * sizeof(int64_t)) != hipSuccess)
+    p = nullptr;
+  return p;
 }
 
 int euler_gpu_dedup_split(void* stream, const uint64_t* ids_dev, int64_t n,
                           const uint8_t* root_mask_dev, int32_t root_group,
-                          int32_t partitions, int32_t shards, int64_t* shard_off_host,
+                          int32_t partitions, int32_t shards, uint32_t* dense_owner_dev,
+                          int64_t dense_limit, int64_t* shard_off_host,
                           uint64_t* shard_ids_dev, int32_t* pos_dev) {
   if (n < 0 || partitions <= 0 || shards <= 0 || shards > kMaxShards || !shard_off_host)
     return Fail(EULER_GPU_EINVAL, "dedup_split: bad arguments (shards <= 64)");
@@ -991,64 +1104,82 @@ int euler_gpu_dedup_split(void* stream, const uint64_t* ids_dev, int64_t n,
   if (n >= (1LL << 30)) return Fail(EULER_GPU_EINVAL, "dedup_split: n >= 2^30");
   if (!ids_dev || !shard_ids_dev || !pos_dev)
     return Fail(EULER_GPU_EINVAL, "dedup_split: null buffer");
+  const bool dense = dense_owner_dev != nullptr;
+  if (dense && (dense_limit <= 0 || dense_limit >= (1LL << 32) - 1))
+    return Fail(EULER_GPU_EINVAL, "dedup_split: dense_limit out of range");
+  int64_t* stage = PinnedStage();
+  if (stage == nullptr) return Fail(EULER_GPU_ENOMEM, "dedup_split: pinned staging buffer");
   hipStream_t st = (hipStream_t)stream;
   uint64_t cap = 1024;
-  while (cap < (uint64_t)n * 4) cap <<= 1;
+  while (!dense && cap < (uint64_t)n * 4) cap <<= 1;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  DedupIdsArgs a{};
-  a.ids = ids_dev; a.n = n; a.mask = (uint32_t)(cap - 1);
-  a.root_mask = root_mask_dev; a.root_group = root_group > 0 ? root_group : 1;
-  hipcub::CountingInputIterator<uint32_t> pos_it(0u);
+  const int64_t n_blocks = (n + kSplitBlock - 1) / kSplitBlock;
+  const int64_t cells = n_blocks * shards;
+  const size_t o_owner = 0, o_owner2 = o_owner + (dense ? 0 : al(cap * 4));
+  const size_t o_rep = o_owner2 + (dense ? 0 : al(cap * 4));
+  const size_t o_bidx = o_rep + al((size_t)n * 4);
+  const size_t o_hist = o_bidx + al((size_t)n * 4);
+  const size_t o_off = o_hist + al((size_t)(cells + 1) * 8);
+  const size_t o_starts = o_off + al((size_t)(cells + 1) * 8);
   size_t scan_bytes = 0;
-  {
-    hipcub::TransformInputIterator<uint32_t, DedupIdsFlagOp,
-                                   hipcub::CountingInputIterator<uint32_t>>
-        flag_it(pos_it, DedupIdsFlagOp{a});
-    EG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, flag_it,
-                                            (uint32_t*)nullptr, (int)(n + 1), st));
-  }
-  const size_t o_owner = 0, o_owner2 = o_owner + al(cap * 4);
-  const size_t o_pos = o_owner2 + al(cap * 4);
-  const size_t o_uniq = o_pos + al((size_t)(n + 1) * 4);
-  const size_t o_uof = o_uniq + al((size_t)n * 8);
-  const size_t o_midx = o_uof + al((size_t)n * 4);
-  const size_t o_inv = o_midx + al((size_t)n * 4);
-  const size_t o_scan = o_inv + al((size_t)n * 4);
-  const size_t bytes = o_scan + al(scan_bytes);
+  EG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (const int64_t*)nullptr,
+                                          (int64_t*)nullptr, (int)cells, st));
+  const size_t o_scan = o_starts + al((size_t)(shards + 1) * 8);
+  const size_t bytes = o_scan + al(scan_bytes + 16);
+  StreamScratch* scratch = ScratchEntry(st);
+  std::lock_guard<std::mutex> scratch_lk(scratch->mu);
   uint8_t* buf = nullptr;
-  EG_HIP(hipMallocAsync((void**)&buf, bytes, st));
-  a.owner = (uint32_t*)(buf + o_owner);
-  a.owner2 = (uint32_t*)(buf + o_owner2);
-  a.pos = (uint32_t*)(buf + o_pos);
-  a.uniq = (uint64_t*)(buf + o_uniq);
-  a.u_of = (uint32_t*)(buf + o_uof);
-  int32_t* merge_idx = (int32_t*)(buf + o_midx);
-  int32_t* inv = (int32_t*)(buf + o_inv);
+  {
+    void* p = nullptr;
+    const int src = ScratchReserve(scratch, st, bytes, &p);
+    if (src != EULER_GPU_OK) return src;
+    buf = (uint8_t*)p;
+  }
+  FrontArgs a{};
+  a.d.ids = ids_dev; a.d.n = n; a.d.mask = (uint32_t)(cap - 1);
+  a.d.root_mask = root_mask_dev; a.d.root_group = root_group > 0 ? root_group : 1;
+  a.d.owner = (uint32_t*)(buf + o_owner);
+  a.d.owner2 = (uint32_t*)(buf + o_owner2);
+  a.dense_owner = dense_owner_dev;
+  a.dense_limit = (uint64_t)dense_limit;
+  a.rep = (uint32_t*)(buf + o_rep);
+  a.bidx = (int32_t*)(buf + o_bidx);
+  a.block_hist = (int64_t*)(buf + o_hist);
+  a.partitions = partitions; a.shards = shards;
+  int64_t* off = (int64_t*)(buf + o_off);
+  int64_t* starts = (int64_t*)(buf + o_starts);
   const int block = 256;
   const int grid = GridFor(n, block);
-  hipLaunchKernelGGL(DedupIdsMarkKernel, dim3(grid), dim3(block), 0, st, a);
-  hipLaunchKernelGGL(DedupIdsMark2Kernel, dim3(grid), dim3(block), 0, st, a);
-  {
-    hipcub::TransformInputIterator<uint32_t, DedupIdsFlagOp,
-                                   hipcub::CountingInputIterator<uint32_t>>
-        flag_it(pos_it, DedupIdsFlagOp{a});
-    EG_HIP(hipcub::DeviceScan::ExclusiveSum(buf + o_scan, scan_bytes, flag_it, a.pos,
-                                            (int)(n + 1), st));
+  int rc = EULER_GPU_OK;
+  if (dense) {
+    hipLaunchKernelGGL(FrontMarkDenseKernel, dim3(grid), dim3(block), 0, st, a);
+    hipLaunchKernelGGL(FrontRepHistKernel, dim3((unsigned)n_blocks), dim3(kSplitBlock),
+                       0, st, a);
+  } else {
+    hipLaunchKernelGGL(DedupIdsMarkKernel, dim3(grid), dim3(block), 0, st, a.d);
+    hipLaunchKernelGGL(DedupIdsMark2Kernel, dim3(grid), dim3(block), 0, st, a.d);
+    hipLaunchKernelGGL(FrontRepHistKernel, dim3((unsigned)n_blocks), dim3(kSplitBlock),
+                       0, st, a);
   }
-  hipLaunchKernelGGL(DedupIdsIndexKernel, dim3(grid), dim3(block), 0, st, a);
-  uint32_t n_unique = 0;
-  EG_HIP(hipMemcpyAsync(&n_unique, a.pos + n, 4, hipMemcpyDeviceToHost, st));
-  EG_HIP(hipStreamSynchronize(st));
-  int rc = euler_gpu_id_split(stream, a.uniq, (int64_t)n_unique, partitions, shards,
-                              shard_off_host, shard_ids_dev, merge_idx);
+  if (hipcub::DeviceScan::ExclusiveSum(buf + o_scan, scan_bytes, (const int64_t*)a.block_hist,
+                                       off, (int)cells, st) != hipSuccess)
+    rc = Fail(EULER_GPU_EHIP, "dedup_split: scan failed");
   if (rc == EULER_GPU_OK) {
-    hipLaunchKernelGGL(InvertIdxKernel, dim3((n_unique + block - 1) / block), dim3(block),
-                       0, st, merge_idx, (int64_t)n_unique, inv);
-    hipLaunchKernelGGL(ComposeIdxKernel, dim3(grid), dim3(block), 0, st, a.u_of, inv, n,
-                       pos_dev);
+    hipLaunchKernelGGL(FrontScatterKernel, dim3((unsigned)n_blocks), dim3(kSplitBlock), 0, st,
+                       a, off, shard_ids_dev);
+    hipLaunchKernelGGL(FrontComposeKernel, dim3(grid), dim3(block), 0, st, a, off, n_blocks,
+                       pos_dev, starts);
     if (hipGetLastError() != hipSuccess) rc = Fail(EULER_GPU_EHIP, "dedup_split: launch failed");
   }
-  (void)hipFreeAsync(buf, st);
+  if (rc == EULER_GPU_OK) {
+    hipError_t e = hipMemcpyAsync(stage, starts, (size_t)(shards + 1) * 8,
+                                  hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) rc = Fail(EULER_GPU_EHIP, std::string("dedup_split: ") + hipGetErrorString(e));
+    else for (int s = 0; s <= shards; ++s) shard_off_host[s] = stage[s];
+  } else {
+    (void)hipStreamSynchronize(st);        // the scratch must be idle when the lock drops
+  }
   return rc;
 }
 

@@ -314,6 +314,50 @@ __global__ __launch_bounds__(256) void DedupExpandKernel(const ExpandArgs a,
   }
 }
 
+// Back end of a multi-GPU hop: position i takes row pos[i] of the packed
+// answers (4 * count + 2 int32 words per row: ids, weights, types, mask, pad).
+// U = 2 (even count, aligned outputs): a lane moves two adjacent samples -
+// rows are 8-byte aligned, so the ids are two 8-byte loads and one 16-byte
+// store; weights and types one 8-byte load and store each.
+template <int U>
+__global__ __launch_bounds__(256) void ExpandPackedKernel(
+    const int32_t* __restrict__ pos, const int32_t* __restrict__ packed, int64_t n,
+    int32_t count, uint64_t* __restrict__ out_id, float* __restrict__ out_w,
+    int32_t* __restrict__ out_t, uint8_t* __restrict__ out_mask,
+    const int64_t stride_rows, const int32_t stride_slots) {
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
+  const int32_t words = 4 * count + 2;
+  const int64_t total = n * (int64_t)count;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * U;
+  int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * U;
+  if (s >= total) return;
+  int64_t i = s / count;
+  int32_t j = (int32_t)(s - i * count);
+  for (; s < total; s += stride) {
+    const int32_t* row = packed + (int64_t)pos[i] * words;
+    if (U == 1) {
+      const uint64_t id = *reinterpret_cast<const uint64_t*>(row + 2 * j);
+      __builtin_nontemporal_store(id, out_id + s);
+      __builtin_nontemporal_store(__int_as_float(row[2 * count + j]), out_w + s);
+      __builtin_nontemporal_store(row[3 * count + j], out_t + s);
+    } else {
+      const uint64_t* idp = reinterpret_cast<const uint64_t*>(row + 2 * j);
+      const u64x2 id2 = {idp[0], idp[1]};
+      const f32x2 w2 = *reinterpret_cast<const f32x2*>(row + 2 * count + j);
+      const i32x2 t2 = *reinterpret_cast<const i32x2*>(row + 3 * count + j);
+      __builtin_nontemporal_store(id2, reinterpret_cast<u64x2*>(out_id + s));
+      __builtin_nontemporal_store(w2, reinterpret_cast<f32x2*>(out_w + s));
+      __builtin_nontemporal_store(t2, reinterpret_cast<i32x2*>(out_t + s));
+    }
+    if (j == 0 && out_mask != nullptr) out_mask[i] = (uint8_t)row[4 * count];
+    i += stride_rows;
+    j += stride_slots;
+    if (j >= count) { j -= count; ++i; }
+  }
+}
+
 __global__ __launch_bounds__(256) void SampleNeighborKernel(const SampleNbArgs a) {
   int64_t n_roots;
   if (!DedupGate(a, &n_roots)) return;
@@ -2974,31 +3018,6 @@ __global__ __launch_bounds__(256) void PackRowsKernel(
   }
 }
 
-__global__ __launch_bounds__(256) void ExpandPackedKernel(
-    const int32_t* __restrict__ pos, const int32_t* __restrict__ packed, int64_t n,
-    int32_t count, uint64_t* __restrict__ out_id, float* __restrict__ out_w,
-    int32_t* __restrict__ out_t, uint8_t* __restrict__ out_mask,
-    const int64_t stride_rows, const int32_t stride_slots) {
-  const int32_t words = 4 * count + 2;
-  const int64_t total = n * (int64_t)count;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= total) return;
-  int64_t i = s / count;
-  int32_t j = (int32_t)(s - i * count);
-  for (; s < total; s += stride) {
-    const int32_t* row = packed + (int64_t)pos[i] * words;
-    const uint64_t id = *reinterpret_cast<const uint64_t*>(row + 2 * j);
-    __builtin_nontemporal_store(id, out_id + s);
-    __builtin_nontemporal_store(__int_as_float(row[2 * count + j]), out_w + s);
-    __builtin_nontemporal_store(row[3 * count + j], out_t + s);
-    if (j == 0 && out_mask != nullptr) out_mask[i] = (uint8_t)row[4 * count];
-    i += stride_rows;
-    j += stride_slots;
-    if (j >= count) { j -= count; ++i; }
-  }
-}
-
 int euler_gpu_pack_rows(void* stream, const uint64_t* id_dev, const float* w_dev,
                         const int32_t* t_dev, const uint8_t* mask_dev, int64_t m,
                         int32_t count, int32_t* packed_dev) {
@@ -3023,14 +3042,25 @@ int euler_gpu_expand_packed(void* stream, const int32_t* pos_dev, int64_t n,
   if (!pos_dev || !packed_dev || !out_id_dev || !out_w_dev || !out_t_dev)
     return Fail(EULER_GPU_EINVAL, "expand_packed: null buffer");
   const int block = 256;
-  int64_t blocks = ((int64_t)n * count + block - 1) / block;
+  const bool pair = count % 2 == 0 && ((uintptr_t)out_id_dev % 16 == 0) &&
+                    ((uintptr_t)out_w_dev % 8 == 0) && ((uintptr_t)out_t_dev % 8 == 0) &&
+                    ((uintptr_t)packed_dev % 8 == 0);
+  const int U = pair ? 2 : 1;
+  int64_t blocks = ((int64_t)n * count / U + block - 1) / block;
   if (blocks > kK1GridCap) blocks = kK1GridCap;
-  const int64_t stride = blocks * block;
+  if (blocks < 1) blocks = 1;
+  const int64_t stride = blocks * block * U;
   const int64_t stride_rows = stride / count;
   const int32_t stride_slots = (int32_t)(stride - stride_rows * count);
-  hipLaunchKernelGGL(ExpandPackedKernel, dim3((int)blocks), dim3(block), 0,
-                     (hipStream_t)stream, pos_dev, packed_dev, n, count, out_id_dev,
-                     out_w_dev, out_t_dev, out_mask_dev, stride_rows, stride_slots);
+  if (pair) {
+    hipLaunchKernelGGL(ExpandPackedKernel<2>, dim3((int)blocks), dim3(block), 0,
+                       (hipStream_t)stream, pos_dev, packed_dev, n, count, out_id_dev,
+                       out_w_dev, out_t_dev, out_mask_dev, stride_rows, stride_slots);
+  } else {
+    hipLaunchKernelGGL(ExpandPackedKernel<1>, dim3((int)blocks), dim3(block), 0,
+                       (hipStream_t)stream, pos_dev, packed_dev, n, count, out_id_dev,
+                       out_w_dev, out_t_dev, out_mask_dev, stride_rows, stride_slots);
+  }
   EG_HIP(hipGetLastError());
   return EULER_GPU_OK;
 }

@@ -328,11 +328,15 @@ class ShardedSampler:
         return torch.stack(cols, dim=1)
 
 
-def gpu_sharded_sampler(graph, partitions=None, group=None, dedup=True):
+DENSE_ID_LIMIT = 1 << 30      # ids: a 4 GB table at most
+
+
+def gpu_sharded_sampler(graph, partitions=None, group=None, dedup=True, dense_ids=None):
     """ShardedSampler over an euler_amd.Graph shard living on this rank's GPU.
     dedup: True / "fused" = one-call front end (euler_gpu_dedup_split) and back end
     (euler_gpu_expand_rows); "ops" = ID_UNIQUE / ID_SPLIT / merge / gather as separate
-    kernels; False = no duplicate removal."""
+    kernels; False = no duplicate removal.  dense_ids: False = always find
+    duplicates by hashing (None = by id-indexed table when the ids allow it)."""
     from . import ops
 
     def local_sample(owned, edge_types, count, default_node, call_id):
@@ -347,10 +351,32 @@ def gpu_sharded_sampler(graph, partitions=None, group=None, dedup=True):
         return ops.gather(rows.view(torch.float32), gather_idx).view(torch.int32)
 
     fused = dedup == "fused" or dedup is True
+    # duplicate detection of the front end: when every shard's ids are base +
+    # stride * row and the largest id of the whole graph is small enough for a
+    # table indexed by the id itself (4 bytes per id, kept by this sampler),
+    # one store + one load per id replaces two rounds of hashing.  All ranks
+    # agree on the choice (two small all-reduces at construction).
+    dense_table = None
+    if fused and dense_ids is not False:
+        max_id, identity = graph.id_range()
+        if dist.is_available() and dist.is_initialized():
+            on_gpu = dist.get_backend(group) == "nccl"
+            v = torch.tensor([max_id, 0 if identity else 1], dtype=torch.int64,
+                             device=graph.device if on_gpu else "cpu")
+            dist.all_reduce(v, op=dist.ReduceOp.MAX, group=group)
+            max_id, identity = int(v[0]), int(v[1]) == 0
+        if identity and 0 < max_id + 2 <= DENSE_ID_LIMIT:
+            dense_table = torch.empty(max_id + 2, dtype=torch.int32, device=graph.device)
+
+    def front(ids, parts, shards, root_mask, root_group):
+        return ops.dedup_split(ids, parts, shards, root_mask, root_group,
+                               dense_table=dense_table)
+
     S = ShardedSampler(local_sample, ops.id_split, ops.merge_rows, partitions,
                        group, ops.id_unique if dedup else None, gather_rows,
-                       ops.dedup_split if fused else None,
+                       front if fused else None,
                        ops.expand_packed if fused else None)
+    S.dense_table = dense_table
     if fused:
         S.pack_fn = ops.pack_rows
     S.device = graph.device

@@ -312,6 +312,13 @@ class Graph:
                 nt_p, k, int(count), _ptr(out)))
         return out
 
+    def id_range(self):
+        """(largest node id of this graph / shard, ids are base + stride * row)."""
+        mx = C.c_uint64(0)
+        ident = C.c_int32(0)
+        check(lib().euler_gpu_graph_id_range(self._h, C.byref(mx), C.byref(ident)))
+        return int(mx.value), bool(ident.value)
+
     @property
     def num_float_features(self):
         return lib().euler_gpu_graph_num_float_features(self._h)

@@ -204,23 +204,32 @@ def id_split(ids, partitions, shards):
     return list(off), sid, mi
 
 
-def dedup_split(ids, partitions, shards, root_mask=None, root_group=1):
+def dedup_split(ids, partitions, shards, root_mask=None, root_group=1, dense_table=None):
     """Distinct ids bucketed by owner + the bucketed index of every position
-    (ID_UNIQUE + ID_SPLIT in one call).  Returns (shard_off list[shards+1],
-    shard_ids int64 [m], pos int32 [n]) with m = shard_off[-1] <= n.
-    root_mask ([ceil(n / root_group)] uint8): marked groups count as id 0."""
+    (ID_UNIQUE + ID_SPLIT in one call, one host sync).  Returns (shard_off
+    list[shards+1], shard_ids int64 [m], pos int32 [n]) with m = shard_off[-1] <= n.
+    root_mask ([ceil(n / root_group)] uint8): marked groups count as id 0.
+    dense_table (optional int32 [limit + 1] scratch kept by the caller, contents
+    irrelevant): every id of the graph is < limit, so duplicates are found in a
+    table indexed by the id itself instead of by hashing."""
     ids = ids.to(torch.int64).contiguous().reshape(-1)
     _need_cuda(ids)
     n = ids.numel()
     if root_mask is not None:
         root_mask = root_mask.to(torch.uint8).contiguous()
+    limit = 0
+    if dense_table is not None:
+        _need_cuda(dense_table)
+        assert dense_table.dtype == torch.int32 and dense_table.is_contiguous()
+        limit = dense_table.numel() - 1
     off = (C.c_int64 * (shards + 1))()
     sid = torch.empty(n, dtype=torch.int64, device=ids.device)
     pos = torch.empty(n, dtype=torch.int32, device=ids.device)
     with torch.cuda.device(ids.device):
         check(lib().euler_gpu_dedup_split(_stream(), _ptr(ids), n, _ptr(root_mask),
-                                          int(root_group), partitions, shards, off,
-                                          _ptr(sid), _ptr(pos)))
+                                          int(root_group), partitions, shards,
+                                          _ptr(dense_table), limit, off, _ptr(sid),
+                                          _ptr(pos)))
     off = list(off)
     return off, sid[:off[-1]], pos
 

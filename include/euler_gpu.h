@@ -161,6 +161,12 @@ int euler_gpu_graph_export_rows(const euler_gpu_graph* g, const uint64_t* ids_ho
 bool InitQueryProxy(const char* conf);
 euler_gpu_graph* euler_gpu_default_graph(void);
 
+/* Largest node id of the graph (shard) and whether its id -> row map is the
+ * strided identity (ids = base + stride * row).  A multi-GPU sampler reduces
+ * max_id over the shards to size euler_gpu_dedup_split's dense table. */
+int euler_gpu_graph_id_range(const euler_gpu_graph* g, uint64_t* max_id_host,
+                             int32_t* identity_host);
+
 /* ---- SampleNeighbor ------------------------------------------------------
  * Replaces euler::SampleNeighbor (core/api/api.cc:223-236) ->
  * Node::SampleNeighbor (core/graph/node.cc:98-167) -> RandomSelect
@@ -333,12 +339,19 @@ int euler_gpu_id_split(void* stream, const uint64_t* ids_dev, int64_t n,
  * asked, so row pos_dev[i] of the concatenated answers is position i's row:
  * euler_gpu_expand_rows finishes the hop (IDX_MERGE / DATA_MERGE / DATA_GATHER
  * in one pass).  An id may occur more than once in shard_ids_dev (hash-slot
- * collisions are not resolved); results are unaffected.  Synchronises.
+ * collisions are not resolved); results are unaffected.  Synchronises once.
+ * dense_owner_dev (optional): scratch of dense_limit + 1 uint32 the caller keeps
+ * between calls (contents irrelevant) when every id of the graph is below
+ * dense_limit (euler_gpu_graph_id_range): duplicates are then found with one
+ * store and one load per id in a table indexed by the id itself instead of two
+ * rounds of hashing; ids >= dense_limit are "no such node" and share one
+ * representative (every owner answers the default row for them).
  * root_mask_dev (optional, [ceil(n / root_group)] bytes) has the meaning it has
  * in euler_gpu_sample_neighbor: marked groups sample as node id 0. */
 int euler_gpu_dedup_split(void* stream, const uint64_t* ids_dev, int64_t n,
                           const uint8_t* root_mask_dev, int32_t root_group,
-                          int32_t partitions, int32_t shards, int64_t* shard_off_host,
+                          int32_t partitions, int32_t shards, uint32_t* dense_owner_dev,
+                          int64_t dense_limit, int64_t* shard_off_host,
                           uint64_t* shard_ids_dev, int32_t* pos_dev);
 /* Wire format of the result exchange: one row of 4*count + 2 int32 words per
  * root = [ids (2 words each) | weights | types | mask | pad].  pack_rows writes

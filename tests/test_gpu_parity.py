@@ -565,6 +565,29 @@ def test_gpu_sharded_sampler_single_rank(EA, O, torch_cuda, big_pair):
         want_f = O.OracleGraph(f_csr).get_dense_feature(Ff, fq, [0, 1], [32, 16])
         assert np.array_equal(t2n(got_f[0]), want_f[0])
         assert np.array_equal(t2n(got_f[1]), want_f[1])
+        assert Sf.dense_table is not None and S.dense_table is None
+        # a fanout through the id-indexed front end (ids base + stride * row)
+        n_i = 20000
+        i_ids = (7 + 3 * np.arange(n_i)).astype(np.uint64)
+        i_deg = rng.integers(0, 25, n_i)
+        i_seg = np.zeros(n_i + 1, np.int64)
+        i_seg[1:] = np.cumsum(i_deg)
+        i_nbr = rng.choice(i_ids, int(i_seg[-1])).astype(np.uint64)
+        i_nbr[rng.random(len(i_nbr)) < 0.02] += 1          # no such node
+        i_csr = O.csr_from_raw(i_ids, i_seg, i_nbr,
+                               (rng.random(len(i_nbr)) * 5 + 0.5).astype(np.float32), 1)
+        Gi = gpu_graph(EA, i_csr)
+        Gi.set_seed(31)
+        Si = gpu_sharded_sampler(Gi, partitions=1)
+        assert Si.dense_table is not None
+        qi = np.concatenate([rng.choice(i_ids, 4000), [0, 8, 7 + 3 * n_i, 2 ** 40]]).astype(np.int64)
+        on_i, ow_i, ot_i = O.OracleGraph(i_csr).sample_fanout(31, 70, qi, [[0], [0]], [8, 5], -1)
+        gn_i, gw_i, gt_i = Si.sample_fanout(torch.as_tensor(qi).cuda(), [[0], [0]], [8, 5], -1,
+                                            call_id=70)
+        for h in range(2):
+            assert np.array_equal(t2n(gn_i[h + 1]), on_i[h])
+            assert np.array_equal(t2n(gw_i[h]), ow_i[h])
+            assert np.array_equal(t2n(gt_i[h]), ot_i[h])
         L = 5
         et = [[0, 1, 2, 3]] * L
         walk = S.random_walk(torch.as_tensor(q).cuda(), et, default_node=-1, call_id=20)
@@ -729,6 +752,41 @@ def test_dedup_split_pack_expand(EA, O, torch_cuda):
     assert np.array_equal(t2n(o_m), t2n(r_m)[pos_n])
     e_id, e_w, e_t, e_m = EA.ops.expand_rows(pos, r_id, r_w, r_t, r_m, count)
     assert np.array_equal(t2n(e_id), t2n(o_id)) and np.array_equal(t2n(e_m), t2n(o_m))
+
+
+def test_dedup_split_dense_id_table(EA, O, torch_cuda):
+    """Front end with the id-indexed table (graphs whose ids are all below a known
+    limit): exactly one copy of every distinct id below the limit; ids at or
+    above it (no such node) may share a representative - every position still
+    finds an id of its own class; the table is reused dirty across calls."""
+    torch = torch_cuda
+    rng = np.random.default_rng(13)
+    limit = 1_000_000
+    table = torch.randint(-2 ** 31, 2 ** 31 - 1, (limit + 1,), dtype=torch.int32, device="cuda")
+    for n, n_pool in ((200_000, 7000), (1, 1), (70_001, 70_001)):
+        pool = np.concatenate([rng.integers(0, limit, n_pool),
+                               [0, limit - 1, limit, limit + 5, 2 ** 63 + 9]]).astype(np.uint64)
+        ids = rng.choice(pool, n)
+        group = 10
+        mask = (rng.random((n + group - 1) // group) < 0.05).astype(np.uint8)
+        eff = ids.copy()
+        eff[np.repeat(mask, group)[:n].astype(bool)] = 0
+        it = torch.as_tensor(ids.astype(np.int64)).cuda()
+        for parts, shards in ((8, 8), (1024, 3), (5, 1)):
+            off, sid, pos = EA.ops.dedup_split(it, parts, shards, torch.as_tensor(mask).cuda(),
+                                               group, dense_table=table)
+            sid_n, pos_n = t2n(sid).astype(np.uint64), t2n(pos)
+            assert off[0] == 0 and off[-1] == len(sid_n) <= n
+            got = sid_n[pos_n]
+            known = eff < limit
+            assert np.array_equal(got[known], eff[known])
+            assert np.all(got[~known] >= limit)
+            below = sid_n[sid_n < limit]
+            assert len(below) == len(set(below.tolist())) == len(set(eff[known].tolist()))
+            assert (sid_n >= limit).sum() == (1 if (~known).any() else 0)
+            own = O.shard_of(sid_n, parts, shards)
+            for s in range(shards):
+                assert np.all(own[off[s]:off[s + 1]] == s)
 
 
 @pytest.mark.parametrize("wave", [1, 0], ids=["n2v_wave", "n2v_lane"])
