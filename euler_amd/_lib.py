@@ -108,10 +108,18 @@ SIGNATURES = {
                                                      C.c_int64, i32p, C.c_int32,
                                                      C.c_int32, C.c_int32, C.c_int64, vp,
                                                      vp, vp, vp]),
+    "euler_gpu_sample_neighbor_packed": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp,
+                                                   C.c_int64, i32p, C.c_int32, C.c_int32,
+                                                   C.c_int64, vp]),
     "euler_gpu_dedup_split": (C.c_int, [vp, vp, C.c_int64, vp, C.c_int32, C.c_int32,
                                         C.c_int32, vp, C.c_int64, C.POINTER(C.c_int64),
                                         vp, vp]),
     "euler_gpu_graph_id_range": (C.c_int, [vp, u64p, i32p]),
+    "euler_shm_open": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]),
+    "euler_shm_alltoall_i64": (C.c_int, [vp, i64p, i64p, C.c_int32, C.c_int64]),
+    "euler_shm_attached": (C.c_int32, [vp]),
+    "euler_shm_unlink": (C.c_int, [vp]),
+    "euler_shm_close": (None, [vp]),
     "euler_gpu_pack_rows": (C.c_int, [vp, vp, vp, vp, vp, C.c_int64, C.c_int32, vp]),
     "euler_gpu_expand_packed": (C.c_int, [vp, vp, C.c_int64, C.c_int32, vp, vp, vp, vp,
                                           vp]),

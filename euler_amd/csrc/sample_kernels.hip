@@ -48,6 +48,10 @@ struct SampleNbArgs {
   int64_t dd_n_in;              // roots of the call
   uint32_t* mark_owner;         // not null: the outputs are the next hop's roots -
                                 // enter them into its owner table (MarkNextHop)
+  int32_t* packed;              // not null (pivot kernels): write wire rows of
+                                // 4 * count + 2 words instead of out_id / out_w /
+                                // out_t / out_row_mask (see PackRowsKernel)
+  int32_t cold_roots;           // hint: the roots are distinct (one sample per lane)
   int32_t et[kMaxListedTypes];
 };
 
@@ -1457,7 +1461,17 @@ __device__ __forceinline__ void PivotPass(const SampleNbArgs& a, const int64_t n
       }
       ot = TF_LAYOUT ? -1 : 0;
     }
-    if (U == 1) {
+    if (a.packed != nullptr) {
+      // wire row of root r: ids (2 words each) | weights | types | mask, pad
+      int32_t* row = a.packed + r * (int64_t)(4 * a.count + 2);
+#pragma unroll
+      for (int x = 0; x < U; ++x) {
+        *reinterpret_cast<uint64_t*>(row + 2 * (j + x)) = id[x];
+        row[2 * a.count + j + x] = __float_as_int(w[x]);
+        row[3 * a.count + j + x] = ot;
+      }
+      if (j == 0) *reinterpret_cast<int2*>(row + 4 * a.count) = make_int2(valid ? 0 : 1, 0);
+    } else if (U == 1) {
       a.out_id[s] = id[0];
       a.out_w[s] = w[0];
       a.out_t[s] = ot;
@@ -1671,7 +1685,8 @@ static int LaunchK1(const euler_gpu_graph* g, hipStream_t stream,
     // throughput (millions of roots with hot rows); the pass over the distinct
     // roots (dd_role 2) is small and cold - there the shorter dependent chain of
     // one sample per lane wins (0.139 vs 0.149 ms on the metric workload)
-    const bool pair = g_k1_pair != 0 && a.dd_role != 2 && count % 2 == 0 &&
+    const bool pair = g_k1_pair != 0 && a.dd_role != 2 && a.cold_roots == 0 &&
+                      a.packed == nullptr && count % 2 == 0 &&
                       ((uintptr_t)out_id % 16 == 0) && ((uintptr_t)out_w % 8 == 0) &&
                       ((uintptr_t)out_t % 8 == 0);
     const int U = pair ? 2 : 1;
@@ -1687,7 +1702,7 @@ static int LaunchK1(const euler_gpu_graph* g, hipStream_t stream,
     const int32_t stride_slots = (int32_t)(stride - stride_rows * count);
     const bool tf = layout == EULER_GPU_LAYOUT_TF;
     if (blocked && !pair && g_k1_group != 0 && count % 5 == 0 && a.dd_role != 2 &&
-        a.mark_owner == nullptr) {
+        a.mark_owner == nullptr && a.packed == nullptr) {
       // odd multiple of 5 (fanout 25): five adjacent samples per lane
       int64_t blocks = (n * (int64_t)count / 5 + block - 1) / block;
       const int64_t cap = g_k1_grid_cap > 0 ? g_k1_grid_cap : kK1GridCap;
@@ -1893,7 +1908,7 @@ static int MakeDedupLayout(const euler_gpu_graph* g, hipStream_t stream, int64_t
 
 // will a call with n roots go through the duplicate-root path?
 static bool WantsDedup(const euler_gpu_graph* g, int64_t n, int dedup) {
-  return dedup != 0 && g_k1_dedup != 0 && (g_k1_variant == 5 || g_k1_variant == 6) &&
+  return dedup > 0 && g_k1_dedup != 0 && (g_k1_variant == 5 || g_k1_variant == 6) &&
          (n >= kDedupMinRoots || g_k1_dedup == 2) && n < (int64_t)0x3fffffff &&
          g->view.n_rows < (int64_t)0xfffffff0;
 }
@@ -1908,6 +1923,13 @@ static bool K1CanMark(const euler_gpu_graph* g, int32_t k, int32_t count, int32_
          !tf_zero && layout == EULER_GPU_LAYOUT_TF && g->view.map_mode == 0;
 }
 
+// will LaunchK1 pick a pivot kernel (the only ones that write wire rows)?
+static bool K1WritesPacked(const euler_gpu_graph* g, int32_t k, int32_t layout) {
+  const bool single = k == 1 && g->view.monotone;
+  const bool tf_zero = layout == EULER_GPU_LAYOUT_TF && g->view.has_zero_nbr != 0;
+  return (g_k1_variant == 5 || g_k1_variant == 6) && single && !tf_zero;
+}
+
 // Hop chaining of a fanout (euler_gpu_sample_fanout holds launch_mu and has
 // sized the stream's workspace for its largest hop, so `owner` does not move).
 struct HopFusion {
@@ -1916,7 +1938,9 @@ struct HopFusion {
                             // the kernels of this call can; out: whether they did
 };
 
-// dedup: 0 = never, 1 = automatic (count duplicates on device, decide there).
+// dedup: 0 = never, 1 = automatic (count duplicates on device, decide there),
+// -1 = never and the caller knows the roots to be distinct (cold rows: one sample
+// per lane).  packed_out: wire rows instead of the four output arrays.
 static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
                                 uint64_t seed, uint32_t call_id,
                                 const uint64_t* roots, int64_t n,
@@ -1926,7 +1950,7 @@ static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
                                 int64_t default_node, uint64_t* out_id,
                                 float* out_w, int32_t* out_t,
                                 uint8_t* out_row_mask, int dedup = 1,
-                                HopFusion* hop = nullptr) {
+                                HopFusion* hop = nullptr, int32_t* packed_out = nullptr) {
   const bool premarked = hop != nullptr && hop->premarked;
   const bool want_mark = hop != nullptr && hop->mark_next;
   if (hop != nullptr) hop->mark_next = false;
@@ -1936,10 +1960,12 @@ static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
   if (layout != EULER_GPU_LAYOUT_CORE && layout != EULER_GPU_LAYOUT_TF)
     return Fail(EULER_GPU_EINVAL, "sample_neighbor: bad layout");
   if (n == 0 || count == 0) return EULER_GPU_OK;
-  if (!roots || !out_id || !out_w || !out_t)
+  if (!roots || (packed_out == nullptr && (!out_id || !out_w || !out_t)))
     return Fail(EULER_GPU_EINVAL, "sample_neighbor: null buffer");
   if (k > 0 && !edge_types)
     return Fail(EULER_GPU_EINVAL, "sample_neighbor: null edge_types");
+  if (packed_out != nullptr && (dedup > 0 || !K1WritesPacked(g, k, layout)))
+    return Fail(EULER_GPU_EINVAL, "sample_neighbor: packed output needs the pivot kernels");
   if ((g_k1_variant == 3 || g_k1_variant == 4 || g_k1_variant == 6) &&
       g->view.blk == nullptr) {
     const int rc = EnsureBlockedIndex(g);     // A/B variants only: built on first use
@@ -1954,6 +1980,8 @@ static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
   a.out_row_mask = out_row_mask;
   a.n = n; a.default_node = default_node;
   a.k = k; a.count = count; a.layout = layout;
+  a.packed = packed_out;
+  a.cold_roots = dedup < 0 ? 1 : 0;
   for (int i = 0; i < k; ++i) a.et[i] = edge_types[i];
   const bool try_dedup = WantsDedup(g, n, dedup);
   if (premarked && !try_dedup)
@@ -2749,7 +2777,41 @@ int euler_gpu_sample_neighbor_distinct(const euler_gpu_graph* g, void* stream,
   return LaunchSampleNeighbor(g, (hipStream_t)stream, seed, call_id, roots_dev, n,
                               nullptr, 1, edge_types_host, k, count, layout,
                               default_node, out_id_dev, out_w_dev, out_t_dev,
-                              out_row_mask_dev, /*dedup=*/0);
+                              out_row_mask_dev, /*dedup=*/-1);
+}
+
+int euler_gpu_sample_neighbor_packed(const euler_gpu_graph* g, void* stream,
+                                     uint64_t seed, uint32_t call_id,
+                                     const uint64_t* roots_dev, int64_t n,
+                                     const int32_t* edge_types_host, int32_t k,
+                                     int32_t count, int64_t default_node,
+                                     int32_t* packed_dev) {
+  if (g == nullptr) return Fail(EULER_GPU_ENOGRAPH, "sample_neighbor_packed: null graph");
+  if (n < 0 || count <= 0) return Fail(EULER_GPU_EINVAL, "sample_neighbor_packed: bad n/count");
+  if (n == 0) return EULER_GPU_OK;
+  if (!packed_dev) return Fail(EULER_GPU_EINVAL, "sample_neighbor_packed: null buffer");
+  hipStream_t st = (hipStream_t)stream;
+  if (K1WritesPacked(g, k, EULER_GPU_LAYOUT_TF))
+    return LaunchSampleNeighbor(g, st, seed, call_id, roots_dev, n, nullptr, 1,
+                                edge_types_host, k, count, EULER_GPU_LAYOUT_TF, default_node,
+                                nullptr, nullptr, nullptr, nullptr, /*dedup=*/-1, nullptr,
+                                packed_dev);
+  // type draws, non-monotone rows, the id-0 sentinel rule: the reference loop
+  // into scratch arrays, then the pack kernel
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t total = (size_t)n * (size_t)count;
+  const size_t o_w = al(total * 8), o_t = o_w + al(total * 4), o_m = o_t + al(total * 4);
+  uint8_t* buf = nullptr;
+  EG_HIP(hipMallocAsync((void**)&buf, o_m + al((size_t)n), st));
+  int rc = LaunchSampleNeighbor(g, st, seed, call_id, roots_dev, n, nullptr, 1,
+                                edge_types_host, k, count, EULER_GPU_LAYOUT_TF, default_node,
+                                (uint64_t*)buf, (float*)(buf + o_w), (int32_t*)(buf + o_t),
+                                buf + o_m, /*dedup=*/-1);
+  if (rc == EULER_GPU_OK)
+    rc = euler_gpu_pack_rows(stream, (const uint64_t*)buf, (const float*)(buf + o_w),
+                             (const int32_t*)(buf + o_t), buf + o_m, n, count, packed_dev);
+  (void)hipFreeAsync(buf, st);
+  return rc;
 }
 
 size_t euler_gpu_sample_fanout_workspace(int64_t n, const int32_t* counts_host,

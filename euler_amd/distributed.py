@@ -14,6 +14,8 @@ The local sampler is injected (`local_sample`), so the host logic - bucketing,
 split sizes, the two exchanges, the inverse permutation - is exercised on CPU
 with the gloo backend and a test double; on GPUs it is the HIP kernel path.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -67,6 +69,11 @@ class ShardedSampler:
         # wire format hooks of the fused path (HIP kernels on GPUs): pack_fn(ids,
         # w, t, mask, count) -> int32 rows; expand_fn(pos, rows, count) -> outputs
         self.pack_fn = None
+        # local_sample_packed(owned, edge_types, count, default_node, call_id) ->
+        # wire rows (sampling and packing in one kernel)
+        self.local_sample_packed = None
+        # counts_fn(send_counts list[world]) -> recv_counts list[world]
+        self.counts_fn = None
         # optional hooks for get_dense_feature / sample_node (see those methods)
         self.local_feature = None
         self.row_gather_fn = None
@@ -79,6 +86,20 @@ class ShardedSampler:
         self.device = torch.device("cpu")
 
     # -------------------------------------------------------------- helpers
+    def _exchange_counts(self, send_counts, device):
+        """Every peer learns how many rows it gets from this rank: counts_fn (a
+        host-side mailbox between the ranks of one node, see ShmCounts) when the
+        sampler has one, else an all-to-all of the counts on the GPU followed by
+        a device sync."""
+        if self.world == 1:
+            return [int(c) for c in send_counts]
+        if self.counts_fn is not None:
+            return self.counts_fn(send_counts)
+        sc = torch.tensor(send_counts, dtype=torch.int64, device=device)
+        rc = torch.empty_like(sc)
+        dist.all_to_all_single(rc, sc, group=self.group)
+        return [int(x) for x in rc.tolist()]
+
     def _exchange(self, send, send_counts, recv_counts):
         """all-to-all(v) of rows; counts are in rows."""
         out_rows = int(sum(recv_counts))
@@ -146,11 +167,14 @@ class ShardedSampler:
             shard_off, shard_ids, merge_idx = self.split_fn(roots, self.partitions,
                                                             self.world)
         send_counts = [int(shard_off[s + 1] - shard_off[s]) for s in range(self.world)]
-        sc = torch.tensor(send_counts, dtype=torch.int64, device=roots.device)
-        rc = torch.empty_like(sc)
-        dist.all_to_all_single(rc, sc, group=self.group)
-        recv_counts = [int(x) for x in rc.tolist()]
+        recv_counts = self._exchange_counts(send_counts, roots.device)
         owned = self._exchange(shard_ids, send_counts, recv_counts)
+        if fused and self.local_sample_packed is not None:
+            # local sampling straight into wire rows, back along the reversed
+            # split; the shards answered in the order they were asked: row pos[i]
+            # of `back` is position i's row
+            rows = self.local_sample_packed(owned, edge_types, count, default_node, call_id)
+            return self.expand_fn(pos, self._exchange(rows, recv_counts, send_counts), count)
         # local sampling on the rows this rank owns
         ids, w, t, mask = self.local_sample(owned, edge_types, count, default_node,
                                             call_id)
@@ -210,10 +234,7 @@ class ShardedSampler:
             pos[merge_idx.long()] = torch.arange(n, dtype=merge_idx.dtype,
                                                  device=merge_idx.device)
         send_counts = [int(shard_off[s + 1] - shard_off[s]) for s in range(self.world)]
-        sc = torch.tensor(send_counts, dtype=torch.int64, device=nodes.device)
-        rc = torch.empty_like(sc)
-        dist.all_to_all_single(rc, sc, group=self.group)
-        recv_counts = [int(x) for x in rc.tolist()]
+        recv_counts = self._exchange_counts(send_counts, nodes.device)
         owned = self._exchange(shard_ids, send_counts, recv_counts)
         feats = self.local_feature(owned, list(feature_ids), dims)
         rows = torch.cat([f.reshape(owned.numel(), d) for f, d in zip(feats, dims)], dim=1) \
@@ -246,10 +267,7 @@ class ShardedSampler:
             pos[merge_idx.long()] = torch.arange(nodes.numel(), dtype=merge_idx.dtype,
                                                  device=dev)
         send_counts = [int(shard_off[s + 1] - shard_off[s]) for s in range(self.world)]
-        sc = torch.tensor(send_counts, dtype=torch.int64, device=dev)
-        rc = torch.empty_like(sc)
-        dist.all_to_all_single(rc, sc, group=self.group)
-        recv_counts = [int(x) for x in rc.tolist()]
+        recv_counts = self._exchange_counts(send_counts, dev)
         owned = self._exchange(shard_ids, send_counts, recv_counts)
         idx, ids, w, t = self.local_full_neighbor(owned, edge_types)
         idx = idx.reshape(-1, 2).to(torch.int64)
@@ -261,10 +279,7 @@ class ShardedSampler:
         csum = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev),
                           torch.cumsum(lens.to(torch.int64), 0)])
         val_send = [int(csum[bounds[s + 1]] - csum[bounds[s]]) for s in range(self.world)]
-        vs = torch.tensor(val_send, dtype=torch.int64, device=dev)
-        vr = torch.empty_like(vs)
-        dist.all_to_all_single(vr, vs, group=self.group)
-        val_recv = [int(x) for x in vr.tolist()]
+        val_recv = self._exchange_counts(val_send, dev)
         lens_back = self._exchange(lens.reshape(-1, 1), recv_counts, send_counts).reshape(-1)
         vals = torch.empty((ids.numel(), 4), dtype=torch.int32, device=dev)
         vals[:, :2] = ids.reshape(-1, 1).contiguous().view(torch.int32).reshape(-1, 2)
@@ -328,15 +343,88 @@ class ShardedSampler:
         return torch.stack(cols, dim=1)
 
 
+class ShmCounts:
+    """All-to-all of the per-peer row counts of a hop through a shared-memory
+    mailbox (euler_shm_* in include/euler_gpu.h) - the ranks are processes of one
+    node, so the counts need neither a GPU collective nor a device sync.
+    Construction is collective over `group`; `ok` is the same on every rank (any
+    rank that cannot attach or fails the self-test makes all ranks fall back to
+    the GPU exchange)."""
+
+    def __init__(self, group=None, device=None):
+        from . import _lib
+        import ctypes as C
+        import uuid
+        self._lib, self._C = _lib, C
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self._h = None
+        on_gpu = dist.get_backend(group) == "nccl"
+        dev = device if on_gpu else "cpu"
+        name = ["/euler_amd_%d_%s" % (os.getpid(), uuid.uuid4().hex[:12])]
+        dist.broadcast_object_list(name, src=dist.get_global_rank(group, 0) if group is not None else 0,
+                                   group=group, **({"device": dev} if on_gpu else {}))
+        self.name = name[0]
+        ok = 1
+
+        def agree(flag):
+            v = torch.tensor([flag], dtype=torch.int32, device=dev)
+            dist.all_reduce(v, op=dist.ReduceOp.MIN, group=group)
+            return int(v.item())
+
+        L = _lib.lib()
+        h = C.c_void_p()
+        if self.rank == 0:
+            ok = 1 if L.euler_shm_open(self.name.encode(), 0, self.world, 1, C.byref(h)) == 0 else 0
+        ok = agree(ok)                       # the region exists (or nobody goes on)
+        if ok and self.rank != 0:
+            ok = 1 if L.euler_shm_open(self.name.encode(), self.rank, self.world, 0, C.byref(h)) == 0 else 0
+        if h.value:
+            self._h = h
+        ok = agree(ok)                       # everybody is attached
+        if self.rank == 0 and self._h is not None:
+            L.euler_shm_unlink(self._h)       # the mappings stay; the name cannot leak
+        if ok:
+            try:
+                got = self(list(range(self.rank * 1000, self.rank * 1000 + self.world)))
+                ok = 1 if got == [p * 1000 + self.rank for p in range(self.world)] else 0
+            except Exception:
+                ok = 0
+        self.ok = bool(agree(ok))
+        if not self.ok:
+            self.close()
+
+    def __call__(self, send_counts):
+        C = self._C
+        n = self.world
+        send = (C.c_int64 * n)(*[int(c) for c in send_counts])
+        recv = (C.c_int64 * n)()
+        self._lib.check(self._lib.lib().euler_shm_alltoall_i64(self._h, send, recv, 1, 60000))
+        return list(recv)
+
+    def close(self):
+        if self._h is not None:
+            self._lib.lib().euler_shm_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 DENSE_ID_LIMIT = 1 << 30      # ids: a 4 GB table at most
 
 
-def gpu_sharded_sampler(graph, partitions=None, group=None, dedup=True, dense_ids=None):
+def gpu_sharded_sampler(graph, partitions=None, group=None, dedup=True, dense_ids=None,
+                        packed=True):
     """ShardedSampler over an euler_amd.Graph shard living on this rank's GPU.
     dedup: True / "fused" = one-call front end (euler_gpu_dedup_split) and back end
     (euler_gpu_expand_rows); "ops" = ID_UNIQUE / ID_SPLIT / merge / gather as separate
     kernels; False = no duplicate removal.  dense_ids: False = always find
-    duplicates by hashing (None = by id-indexed table when the ids allow it)."""
+    duplicates by hashing (None = by id-indexed table when the ids allow it).
+    packed: the shard samples straight into wire rows (False = sample, then pack)."""
     from . import ops
 
     def local_sample(owned, edge_types, count, default_node, call_id):
@@ -377,8 +465,16 @@ def gpu_sharded_sampler(graph, partitions=None, group=None, dedup=True, dense_id
                        front if fused else None,
                        ops.expand_packed if fused else None)
     S.dense_table = dense_table
+    # peer counts through a shared-memory mailbox instead of a GPU collective
+    # plus device sync per hop (all ranks agree on whether it came up)
+    if S.world > 1 and os.environ.get("EULER_AMD_SHM_COUNTS", "1") != "0":
+        shm = ShmCounts(group, graph.device)
+        if shm.ok:
+            S.counts_fn = shm
     if fused:
         S.pack_fn = ops.pack_rows
+        if packed:
+            S.local_sample_packed = graph.sample_neighbor_packed
     S.device = graph.device
     S.local_feature = graph.get_dense_feature
     S.row_gather_fn = lambda rows, pos: ops.gather(rows, pos.to(torch.int32))

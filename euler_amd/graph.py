@@ -269,6 +269,21 @@ class Graph:
         res = (out_n.reshape(shape), out_w.reshape(shape), out_t.reshape(shape))
         return res + (mask,) if return_mask else res
 
+    def sample_neighbor_packed(self, nodes, edge_types, count, default_node=-1,
+                               call_id=None):
+        """The shard side of a multi-GPU hop: TF-layout SampleNeighbor of the
+        (distinct) ids this shard owns, returned as wire rows [n, 4 * count + 2]
+        int32 (ids | weights | types | mask, pad) for ops.expand_packed."""
+        flat = _as_i64_cuda(nodes, self.device).reshape(-1)
+        n = flat.numel()
+        rows = torch.empty((n, 4 * int(count) + 2), dtype=torch.int32, device=self.device)
+        et, et_p, k = _i32_array(edge_types)
+        with torch.cuda.device(self.device):
+            check(lib().euler_gpu_sample_neighbor_packed(
+                self._h, _stream(), self.seed, self._take_call_ids(1, call_id),
+                _ptr(flat), n, et_p, k, int(count), int(default_node), _ptr(rows)))
+        return rows
+
     def sample_fanout(self, nodes, edge_types, counts, default_node=-1,
                       call_id=None):
         """tf_euler sample_fanout (euler_ops/neighbor_ops.py:122-158 over

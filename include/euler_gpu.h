@@ -202,6 +202,18 @@ int euler_gpu_sample_neighbor_distinct(const euler_gpu_graph* g, void* stream,
                                        int64_t default_node, uint64_t* out_id_dev,
                                        float* out_w_dev, int32_t* out_t_dev,
                                        uint8_t* out_row_mask_dev);
+/* The shard side of a multi-GPU hop in one call: sample the (distinct) ids this
+ * shard received, TF layout, and write the wire rows euler_gpu_expand_packed
+ * consumes - 4 * count + 2 int32 words per root: ids (2 words each) | weights |
+ * types | row mask, pad (euler_gpu_pack_rows' format).  Single-type calls on
+ * graphs the pivot kernels serve write the rows straight from the sampling
+ * kernel; every other call samples into scratch arrays and packs. */
+int euler_gpu_sample_neighbor_packed(const euler_gpu_graph* g, void* stream,
+                                     uint64_t seed, uint32_t call_id,
+                                     const uint64_t* roots_dev, int64_t n,
+                                     const int32_t* edge_types_host, int32_t k,
+                                     int32_t count, int64_t default_node,
+                                     int32_t* packed_dev);
 
 /* TF SampleFanout (tf_euler/kernels/sample_fanout_op.cc:32-148): `layers` hops
  * chained on device; hop h uses call_id + h, edge_types_host[h*k .. h*k+k) and
@@ -331,6 +343,23 @@ int euler_gpu_id_split(void* stream, const uint64_t* ids_dev, int64_t n,
                        int32_t partitions, int32_t shards,
                        int64_t* shard_off_host, uint64_t* shard_ids_dev,
                        int32_t* merge_idx_dev);
+/* Split sizes between the ranks of one node without the GPU: an all-to-all of
+ * up to 8 int64 per peer through a POSIX shared-memory mailbox.  Replaces what
+ * the reference carries inside its per-shard gRPC requests / replies
+ * (core/kernels/remote_op.cc:62-142); RCCL needs both sides' counts on the host
+ * before the data moves.  One rank creates the region (create = 1, the name is
+ * new), the others open it afterwards; every rank then calls
+ * euler_shm_alltoall_i64 in the same order (send / recv: [world * width], peer
+ * p's message at p * width).  timeout_ms <= 0 means 60 s. */
+typedef struct euler_shm euler_shm;
+int euler_shm_open(const char* name, int32_t rank, int32_t world, int32_t create,
+                   euler_shm** out);
+int euler_shm_alltoall_i64(euler_shm* s, const int64_t* send, int64_t* recv,
+                           int32_t width, int64_t timeout_ms);
+int32_t euler_shm_attached(const euler_shm* s);
+int euler_shm_unlink(euler_shm* s);
+void euler_shm_close(euler_shm* s);
+
 /* Front end of a multi-GPU hop in one call: the DISTINCT ids of the batch
  * (ID_UNIQUE, which the reference's optimizer puts before ID_SPLIT:
  * parser/compiler.cc:76-90) bucketed by owner into shard_ids_dev (<= n entries,

@@ -107,6 +107,16 @@ def _worker(rank, world, port, partitions, out_dir):
 
     S_fused = ShardedSampler(local_sample, split_fn, merge_fn, partitions,
                              dedup_split_fn=dedup_split_fn, expand_fn=expand_fn)
+    # the fused sampler gets its peer counts through the shared-memory mailbox
+    # (the ranks are processes of one node), the other two through the collective
+    from euler_amd.distributed import ShmCounts
+    shm = ShmCounts()
+    assert shm.ok, "shared-memory mailbox did not come up"
+    assert not os.path.exists("/dev/shm" + shm.name), "the region's name must not outlive setup"
+    for rnd in range(200):          # many rounds back to back, uneven pace
+        msg = [rank * 100000 + rnd * 10 + p for p in range(world)]
+        assert shm(msg) == [p * 100000 + rnd * 10 + rank for p in range(world)]
+    S_fused.counts_fn = shm
     # with and without the duplicate-root removal: both must equal the
     # unsharded oracle
     S_plain = ShardedSampler(local_sample, split_fn, merge_fn, partitions)
@@ -219,5 +229,37 @@ def test_sharded_fanout_matches_unsharded_gloo(O, tmp_path, partitions):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, partitions, str(tmp_path)), nprocs=world,
              join=True)
+    for r in range(world):
+        assert os.path.exists(tmp_path / ("ok_%d" % r))
+
+
+def _mailbox_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from euler_amd.distributed import ShmCounts
+    import time
+    shm = ShmCounts()
+    assert shm.ok
+    rng = np.random.default_rng(rank)
+    for rnd in range(3000):
+        if rng.random() < 0.01:
+            time.sleep(0.001 * rng.random())         # ranks drift apart by whole rounds' worth
+        msg = [(rank << 40) | (rnd << 8) | p for p in range(world)]
+        assert shm(msg) == [(p << 40) | (rnd << 8) | rank for p in range(world)], (rank, rnd)
+    shm.close()
+    dist.barrier()
+    open(os.path.join(out_dir, "ok_%d" % rank), "w").write("ok")
+    dist.destroy_process_group()
+
+
+def test_shared_memory_counts_mailbox_world8(tmp_path):
+    """euler_shm_* (the per-hop peer counts of the multi-GPU sampler) with 8
+    processes: 3000 all-to-all rounds back to back with ranks drifting apart,
+    every message arrives once, in order, from the right peer."""
+    world = 8
+    port = _free_port()
+    mp.spawn(_mailbox_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert os.path.exists(tmp_path / ("ok_%d" % r))

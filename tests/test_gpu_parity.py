@@ -528,15 +528,17 @@ def test_gpu_sharded_sampler_single_rank(EA, O, torch_cuda, big_pair):
         G.set_seed(31)
         q = np.concatenate([rng.choice(ids, 3000), rng.choice(ids[:50], 3000),
                             [0, 999]]).astype(np.int64)
-        on, ow, ot = OG.sample_fanout(31, 8, q, [[0, 1], [2, 3]], [6, 4], -1)
-        for dedup in (True, "ops", False):
-            S = gpu_sharded_sampler(G, partitions=1, dedup=dedup)
-            gn, gw, gt = S.sample_fanout(torch.as_tensor(q).cuda(), [[0, 1], [2, 3]], [6, 4],
-                                         -1, call_id=8)
-            for h in range(2):
-                assert np.array_equal(t2n(gn[h + 1]), on[h])
-                assert np.array_equal(t2n(gw[h]), ow[h])
-                assert np.array_equal(t2n(gt[h]), ot[h])
+        # type draws take the reference loop (sample, then pack); single-type
+        # hops are written as wire rows by the sampling kernel itself
+        for ets, cnts in (([[0, 1], [2, 3]], [6, 4]), ([[0], [1]], [6, 5]), ([[2], [2]], [3, 4])):
+            on, ow, ot = OG.sample_fanout(31, 8, q, ets, cnts, -1)
+            for dedup, packed in ((True, True), (True, False), ("ops", True), (False, True)):
+                S = gpu_sharded_sampler(G, partitions=1, dedup=dedup, packed=packed)
+                gn, gw, gt = S.sample_fanout(torch.as_tensor(q).cuda(), ets, cnts, -1, call_id=8)
+                for h in range(2):
+                    assert np.array_equal(t2n(gn[h + 1]), on[h]), (ets, dedup, packed, h)
+                    assert np.array_equal(t2n(gw[h]), ow[h])
+                    assert np.array_equal(t2n(gt[h]), ot[h])
         S = gpu_sharded_sampler(G, partitions=1)
         # full neighbours through the exchange (variable-length merge)
         qf = torch.as_tensor(q).cuda()
