@@ -1,6 +1,6 @@
 // Implementation of the plugin-API mirror and of the hot-path op kernels
-// registered under the reference's op names.  See op_framework.h.
-#include "op_framework.h"
+// registered under the reference's op names.  See include/euler_op_framework.h.
+#include "euler_op_framework.h"
 
 #include <hip/hip_runtime.h>
 #include <stdlib.h>

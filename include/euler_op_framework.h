@@ -23,7 +23,7 @@
 #include <unordered_map>
 #include <vector>
 
-#include "../../include/euler_gpu.h"
+#include "euler_gpu.h"
 
 namespace euler {
 
