@@ -1,0 +1,767 @@
+// SampleNode, GetFullNeighbor, RandomWalk / node2vec and gen_pair kernels for
+// gfx950 with their C-ABI entry points.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <cmath>
+#include <vector>
+
+#include "k1_args.h"
+#include "k1_search.h"
+
+namespace euler_gpu {
+
+// ------------------------------------------------------------------------
+// K2  sample_node: Graph::SampleNode (graph.cc:221-275) over alias tables.
+// One lane per sample; draw indices follow the reference's program order
+// inside one call (domain NODE, stream 0).
+// ------------------------------------------------------------------------
+struct SampleNodeArgs {
+  NodeSamplerView s;
+  uint64_t seed;
+  uint64_t* out;
+  uint32_t call_id;
+  int32_t count;
+  int32_t mode;          // 0 fixed type, 1 all types (-1), 2 type list
+  int32_t type;          // mode 0
+  int32_t n_sub;         // mode 2
+  int32_t sub_type[kMaxNodeTypes];
+  float sub_sum[kMaxNodeTypes];
+};
+
+__device__ __forceinline__ uint64_t AliasNext(const AliasEntry* tab, int64_t n,
+                                              double u_col, double u_coin) {
+  // AliasMethod::Next (alias_method.cc:66-78)
+  const int64_t column = (int64_t)floor(__dmul_rn((double)n, u_col));
+  const AliasEntry e = tab[column];
+  return u_coin < (double)e.prob ? e.id_self : e.id_alias;
+}
+
+__global__ __launch_bounds__(256) void SampleNodeKernel(const SampleNodeArgs a) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.count;
+       i += stride) {
+    int32_t t = a.type;
+    uint64_t d = 0;   // index of the next draw of this sample
+    if (a.mode == 0) {
+      d = 2 * (uint64_t)i;
+    } else if (a.mode == 1) {
+      d = 4 * (uint64_t)i;
+      const Philox4 b = RngBlock(a.seed, a.call_id, kDomainNode, 0,
+                                 (uint32_t)(d >> 1));
+      const int64_t col = (int64_t)floor(__dmul_rn(
+          (double)a.s.n_types, UnitFromWords(b.w[0], b.w[1])));
+      t = UnitFromWords(b.w[2], b.w[3]) < (double)a.s.tc_prob[col]
+              ? (int32_t)col : a.s.tc_alias[col];
+      d += 2;
+    } else {
+      d = 3 * (uint64_t)i;
+      const double u = RngDraw(a.seed, a.call_id, kDomainNode, 0, d);
+      t = a.sub_type[RandomSelect(a.sub_sum, 0, (uint64_t)(a.n_sub - 1), u)];
+      d += 1;
+    }
+    const double u_col = RngDraw(a.seed, a.call_id, kDomainNode, 0, d);
+    const double u_coin = RngDraw(a.seed, a.call_id, kDomainNode, 0, d + 1);
+    const int64_t b = a.s.type_off[t];
+    a.out[i] = AliasNext(a.s.entries + b, a.s.type_off[t + 1] - b, u_col, u_coin);
+  }
+}
+
+// ------------------------------------------------------------------------
+// GetFullNeighbor (node.cc:175-197): count pass + fill pass.
+// ------------------------------------------------------------------------
+struct FullNbArgs {
+  GraphView g;
+  const uint64_t* ids;
+  int64_t n;
+  int32_t k;
+  int32_t pad;
+  int32_t et[kMaxListedTypes];
+};
+
+__device__ __forceinline__ int64_t FullNbCount(const FullNbArgs& a, int64_t row) {
+  if (row < 0) return 0;
+  const RowMeta m = LoadRowMeta(a.g, row);
+  int64_t c = 0;
+  for (int32_t x = 0; x < a.k; ++x) {
+    const int32_t t = a.et[x];
+    if (t >= 0 && t < a.g.T)
+      c += m.type_end[t] - (t == 0 ? 0 : m.type_end[t - 1]);
+  }
+  return c;
+}
+
+__global__ void FullNbCountKernel(const FullNbArgs a, int64_t* counts) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < a.n) counts[i] = FullNbCount(a, FindRow(a.g, a.ids[i]));
+}
+
+// idx[i] = (offset[i], offset[i+1]) as int32 pairs (FillNeighbor layout).
+__global__ void OffsetsToIdxKernel(const int64_t* counts, const int64_t* offsets,
+                                   int64_t n, int32_t* idx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    idx[2 * i] = (int32_t)offsets[i];
+    idx[2 * i + 1] = (int32_t)(offsets[i] + counts[i]);
+  }
+}
+
+// One wave per queried node: lanes stride over the row's listed segments.
+__global__ __launch_bounds__(256) void FullNbFillKernel(
+    const FullNbArgs a, const int32_t* idx, uint64_t* out_id, float* out_w,
+    int32_t* out_t) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t i = wave; i < a.n; i += n_waves) {
+    const int64_t row = FindRow(a.g, a.ids[i]);
+    if (row < 0) continue;
+    const RowMeta m = LoadRowMeta(a.g, row);
+    const float* nw = a.g.prefix_w + m.row_ptr;
+    const uint64_t* nbr = a.g.nbr + m.row_ptr;
+    int64_t o = idx[2 * i];
+    for (int32_t x = 0; x < a.k; ++x) {
+      const int32_t t = a.et[x];
+      if (t < 0 || t >= a.g.T) continue;
+      const int32_t b = t == 0 ? 0 : m.type_end[t - 1];
+      const int32_t e = m.type_end[t];
+      for (int32_t p = b + lane; p < e; p += 64) {
+        const float pre = p == 0 ? 0.f : nw[p - 1];
+        out_id[o + (p - b)] = nbr[p];
+        out_w[o + (p - b)] = __fsub_rn(nw[p], pre);
+        out_t[o + (p - b)] = t;
+      }
+      o += e - b;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------
+// K4  random walk.
+// p = q = 1 (tf_euler/kernels/random_walk_op.cc:207-247): walk_len dependent
+// count=1 hops per walker, chained on the CORE id (a missing row continues
+// from the sentinel id 0); output 0 -> default_node.
+// ------------------------------------------------------------------------
+struct WalkArgs {
+  GraphView g;
+  uint64_t seed;
+  const int64_t* nodes;
+  const int32_t* edge_types;   // device [walk_len, k]
+  int64_t* out;
+  int64_t n;
+  int64_t default_node;
+  uint32_t call_id;
+  int32_t k;
+  int32_t walk_len;
+  float p;
+  float q;
+};
+
+// FAST: one listed edge type per step on a graph with non-decreasing running
+// sums - every step is the block-pivot search of K1 (draw 0 of the current
+// node, call_id + step), i.e. ~log5(deg / 10) + 4 dependent loads instead of
+// the reference loop's 2 * ceil(log2 deg).
+template <bool FAST>
+__global__ __launch_bounds__(256) void RandomWalkKernel(const WalkArgs a) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t L = a.walk_len + 1;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n;
+       i += stride) {
+    uint64_t cur = (uint64_t)a.nodes[i];
+    a.out[i * L] = (int64_t)cur;
+    for (int32_t s = 0; s < a.walk_len; ++s) {
+      uint64_t id = 0; float w; int32_t t;
+      if (FAST) {
+        Segment sg;
+        if (LoadSegment<true>(a.g, FindRow(a.g, cur), a.edge_types[s], &sg)) {
+          const Philox4 blk = RngBlock(a.seed, a.call_id + (uint32_t)s, kDomainNeighbor,
+                                       cur, 0);
+          BlockPivotSample(a.g, sg, UnitFromWords(blk.w[0], blk.w[1]), &id, &w);
+        }
+      } else {
+        RowSampler rs;
+        InitRowSampler(rs, a.g, FindRow(a.g, cur), a.edge_types + s * a.k, a.k);
+        if (rs.valid) SampleAt(rs, a.seed, a.call_id + (uint32_t)s, cur, 0, &id, &w, &t);
+      }
+      a.out[i * L + s + 1] = id == 0 ? a.default_node : (int64_t)id;
+      cur = id;
+    }
+  }
+}
+
+// Iterator over GetFullNeighbor(node, listed types) in the reference order
+// (listed-type order, storage order inside a type) without materialising it.
+struct NbIter {
+  const uint64_t* nbr;
+  const float* nw;
+  const int32_t* type_end;
+  const int32_t* et;
+  int32_t k, T;
+  int32_t x;       // current listed-type slot
+  int32_t p, e;    // current position / end inside the row
+  __device__ __forceinline__ void Seek() {
+    while (x < k) {
+      const int32_t t = et[x];
+      if (t >= 0 && t < T) {
+        p = t == 0 ? 0 : type_end[t - 1];
+        e = type_end[t];
+        if (p < e) return;
+      }
+      ++x;
+    }
+  }
+  __device__ __forceinline__ void Init(const GraphView& g, int64_t row,
+                                       const int32_t* et_, int32_t k_) {
+    et = et_; k = k_; T = g.T; x = 0; p = 0; e = 0;
+    if (row < 0) { x = k; return; }
+    const RowMeta m = LoadRowMeta(g, row);
+    nbr = g.nbr + m.row_ptr; nw = g.prefix_w + m.row_ptr; type_end = m.type_end;
+    Seek();
+  }
+  __device__ __forceinline__ bool Done() const { return x >= k; }
+  __device__ __forceinline__ int64_t Id() const { return (int64_t)nbr[p]; }
+  __device__ __forceinline__ float Weight() const {
+    return __fsub_rn(nw[p], p == 0 ? 0.f : nw[p - 1]);
+  }
+  __device__ __forceinline__ void Next() {
+    if (++p >= e) { ++x; Seek(); }
+  }
+};
+
+// node2vec step weights (BuildWeights, random_walk_op.cc:140-168) streamed:
+// the child list is merged against the parent's list with two cursors and the
+// biased weight of each child is produced in order.
+struct BiasedStream {
+  NbIter c, pn;
+  int64_t parent_id;
+  float p, q;
+  __device__ __forceinline__ bool Done() const { return c.Done(); }
+  // weight of the current child (advances the parent cursor as the reference)
+  __device__ __forceinline__ float Take(int64_t* id) {
+    const int64_t cid = c.Id();
+    float w = c.Weight();
+    for (;;) {
+      if (pn.Done()) {
+        w = cid != parent_id ? __fdiv_rn(w, q) : __fdiv_rn(w, p);
+        break;
+      }
+      const int64_t pid = pn.Id();
+      if (cid < pid) {
+        w = cid != parent_id ? __fdiv_rn(w, q) : __fdiv_rn(w, p);
+        break;
+      } else if (cid == pid) {
+        pn.Next();
+        break;
+      } else {
+        pn.Next();
+      }
+    }
+    *id = cid;
+    c.Next();
+    return w;
+  }
+};
+
+// node2vec (RWCallback, random_walk_op.cc:83-138).  One lane per walker.  The
+// reference materialises w[], builds f32 running sums and binary-searches
+// them; with non-negative weights the hit interval is unique, so the same
+// index is found by one sequential pass for the total and a second pass that
+// stops at the first running sum > r.  The running sums are the same
+// sequential f32 adds, hence bit-identical.  (All-zero totals follow the
+// reference's fall-through: every probe moves `low` up, ending on the last
+// element.)
+__global__ __launch_bounds__(256) void Node2VecKernel(const WalkArgs a) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t L = a.walk_len + 1;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n;
+       i += stride) {
+    int64_t cur = a.nodes[i];
+    int64_t parent = cur;         // parent_ids_ starts as the start nodes
+    bool have_parent_nb = false;  // parent_neighbors_ starts empty
+    a.out[i * L] = cur;
+    for (int32_t s = 0; s < a.walk_len; ++s) {
+      const int32_t* et = a.edge_types + s * a.k;
+      const int64_t row = FindRow(a.g, (uint64_t)cur);
+      const int64_t prow = have_parent_nb ? FindRow(a.g, (uint64_t)parent) : -1;
+      const int32_t* pet = s > 0 ? a.edge_types + (s - 1) * a.k : et;
+      BiasedStream bs;
+      bs.parent_id = parent; bs.p = a.p; bs.q = a.q;
+      bs.c.Init(a.g, row, et, a.k);
+      bs.pn.Init(a.g, prow, pet, a.k);
+      int64_t sample_id = a.default_node;
+      if (!bs.Done()) {
+        float total = 0.f;
+        int64_t nc = 0, id;
+        while (!bs.Done()) { total = __fadd_rn(total, bs.Take(&id)); ++nc; }
+        const double u = RngDraw(a.seed, a.call_id + (uint32_t)s, kDomainWalk,
+                                 (uint64_t)i, 0);
+        const double r = ScaleDraw(u, 0.f, total);
+        bs.c.Init(a.g, row, et, a.k);
+        bs.pn.Init(a.g, prow, pet, a.k);
+        float acc = 0.f;
+        bool found = false;
+        while (!bs.Done()) {
+          const float w = bs.Take(&id);
+          const float prev = acc;
+          acc = __fadd_rn(acc, w);
+          if ((double)prev <= r && r < (double)acc) { found = true; break; }
+        }
+        if (!found) {
+          // fall-through of RandomSelect: no interval holds r (total == 0).
+          // Every probe then takes `interval_end <= r`: low = mid + 1, so the
+          // search ends on mid = nc - 1; `id` already is that last element.
+        }
+        sample_id = id;
+      }
+      a.out[i * L + s + 1] = sample_id;
+      parent = cur;
+      have_parent_nb = true;
+      cur = sample_id;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------
+// node2vec, one WAVE per walker (default).  The step's weights come out of a
+// two-cursor walk over the child's and the parent's neighbour lists in storage
+// order (BuildWeights, random_walk_op.cc:140-168) - a sequential recurrence
+// that cannot be split across lanes without changing which parent entry each
+// child is compared with.  What can be shared is the memory traffic: the 64
+// lanes copy both lists into LDS in coalesced chunks (ids, and the weights as
+// differences of the running sums), and lane 0 runs the recurrence out of LDS
+// (tens of cycles per step instead of a dependent HBM round trip per lane and
+// step, and no lane waits for a neighbour's hub row).  Pass 1 accumulates the
+// total with the reference's sequential f32 adds, pass 2 stops at the first
+// running sum > r - the same index the reference's bisection of those sums
+// returns (and its last element when the total is 0).  Measured on the metric
+// graph (100 K walkers x 10 steps, walkers sit on hubs of 1e5+ neighbours):
+// 1.69 s -> 1.15 s; prefetching the next entries by hand made it slower (1.34 s).
+// ------------------------------------------------------------------------
+constexpr int kN2vChunk = 256;
+constexpr int kN2vMaxSeg = kMaxListedTypes;
+
+struct N2vList {           // one neighbour list = listed type segments of a row
+  int64_t row_ptr;         // row start in nbr / prefix_w
+  int32_t n_seg;
+  int32_t total;           // entries
+  int32_t seg_b[kN2vMaxSeg];
+  int32_t seg_len[kN2vMaxSeg];
+};
+
+struct alignas(16) N2vLds {
+  uint64_t c_id[kN2vChunk];
+  uint64_t p_id[kN2vChunk];
+  float c_w[kN2vChunk];
+  N2vList child, parent;
+};
+
+// Built by lane 0, read by all lanes after a wave sync.
+__device__ __forceinline__ void N2vBuildList(N2vList* L, const GraphView& g, int64_t row,
+                                             const int32_t* et, int32_t k) {
+  L->n_seg = 0; L->total = 0; L->row_ptr = 0;
+  if (row < 0) return;
+  const RowMeta m = LoadRowMeta(g, row);
+  L->row_ptr = m.row_ptr;
+  for (int32_t x = 0; x < k; ++x) {
+    const int32_t t = et[x];
+    if (t < 0 || t >= g.T) continue;
+    const int32_t b = t == 0 ? 0 : m.type_end[t - 1];
+    const int32_t len = m.type_end[t] - b;
+    if (len <= 0) continue;
+    L->seg_b[L->n_seg] = b;
+    L->seg_len[L->n_seg] = len;
+    ++L->n_seg;
+    L->total += len;
+  }
+}
+
+// row-relative position of logical entry j
+__device__ __forceinline__ int32_t N2vPhys(const N2vList& L, int32_t j) {
+  for (int32_t x = 0; x < L.n_seg; ++x) {
+    if (j < L.seg_len[x]) return L.seg_b[x] + j;
+    j -= L.seg_len[x];
+  }
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void Node2VecWaveKernel(const WalkArgs a) {
+  __shared__ N2vLds lds_all[4];
+  N2vLds& S = lds_all[threadIdx.x >> 6];
+  const int lane = threadIdx.x & 63;
+  const int64_t waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int64_t L = a.walk_len + 1;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < a.n;
+       i += waves) {
+    int64_t cur = a.nodes[i];
+    int64_t parent = cur;          // parent_ids_ starts as the start nodes
+    bool have_parent_nb = false;   // parent_neighbors_ starts empty
+    if (lane == 0) a.out[i * L] = cur;
+    for (int32_t s = 0; s < a.walk_len; ++s) {
+      const int32_t* et = a.edge_types + s * a.k;
+      const int32_t* pet = s > 0 ? a.edge_types + (s - 1) * a.k : et;
+      WaveSync();
+      if (lane == 0) {
+        N2vBuildList(&S.child, a.g, FindRow(a.g, (uint64_t)cur), et, a.k);
+        N2vBuildList(&S.parent, a.g,
+                     have_parent_nb ? FindRow(a.g, (uint64_t)parent) : -1, pet, a.k);
+      }
+      WaveSync();
+      const int32_t nc = S.child.total, np = S.parent.total;
+      int64_t sample_id = a.default_node;
+      if (nc > 0) {
+        const float* c_nw = a.g.prefix_w + S.child.row_ptr;
+        const uint64_t* c_nbr = a.g.nbr + S.child.row_ptr;
+        const uint64_t* p_nbr = a.g.nbr + S.parent.row_ptr;
+        float total = 0.f;
+        double r = 0.0;
+        uint64_t last_id = 0;
+        for (int pass = 0; pass < 2; ++pass) {
+          int32_t j = 0, k = 0;           // cursors (logical entries)
+          int32_t cj0 = 0, pk0 = 0;       // chunk bases
+          int32_t c_have = 0, p_have = 0; // entries loaded in each chunk
+          float acc = 0.f;
+          bool found = false;
+          bool need_c = true, need_p = np > 0;
+          while (j < nc && !found) {
+            if (need_c) {
+              WaveSync();
+              cj0 = j;
+              c_have = min(kN2vChunk, nc - cj0);
+              for (int32_t t = lane; t < c_have; t += 64) {
+                const int32_t ph = N2vPhys(S.child, cj0 + t);
+                S.c_id[t] = c_nbr[ph];
+                S.c_w[t] = __fsub_rn(c_nw[ph], ph == 0 ? 0.f : c_nw[ph - 1]);
+              }
+              need_c = false;
+            }
+            if (need_p) {
+              WaveSync();
+              pk0 = k;
+              p_have = min(kN2vChunk, np - pk0);
+              for (int32_t t = lane; t < p_have; t += 64)
+                S.p_id[t] = p_nbr[N2vPhys(S.parent, pk0 + t)];
+              need_p = false;
+            }
+            WaveSync();
+            if (lane == 0) {
+              const int32_t c_end = cj0 + c_have;
+              const int32_t p_end = pk0 + p_have;
+              while (j < c_end) {
+                const int64_t cid = (int64_t)S.c_id[j - cj0];
+                float w = S.c_w[j - cj0];
+                if (k < np) {
+                  if (k >= p_end) break;               // next parent chunk
+                  const int64_t pid = (int64_t)S.p_id[k - pk0];
+                  if (cid > pid) { ++k; continue; }    // parent cursor only
+                  if (cid == pid) ++k;                 // common neighbour: weight kept
+                  else w = cid != parent ? __fdiv_rn(w, a.q) : __fdiv_rn(w, a.p);
+                } else {
+                  w = cid != parent ? __fdiv_rn(w, a.q) : __fdiv_rn(w, a.p);
+                }
+                const float prev = acc;
+                acc = __fadd_rn(acc, w);
+                last_id = (uint64_t)cid;
+                ++j;
+                if (pass == 1 && (double)prev <= r && r < (double)acc) { found = true; break; }
+              }
+            }
+            j = __shfl(j, 0);
+            k = __shfl(k, 0);
+            found = __shfl((int)found, 0) != 0;
+            need_c = j >= cj0 + c_have;
+            need_p = k < np && k >= pk0 + p_have;
+          }
+          if (pass == 0) {
+            total = __shfl(acc, 0);
+            const double u = RngDraw(a.seed, a.call_id + (uint32_t)s, kDomainWalk,
+                                     (uint64_t)i, 0);
+            r = ScaleDraw(u, 0.f, total);
+          }
+        }
+        // found: last_id is the hit; not found (total == 0): RandomSelect's
+        // fall-through ends on the last element, which is last_id as well
+        const uint32_t lo32 = __shfl((uint32_t)last_id, 0);
+        const uint32_t hi32 = __shfl((uint32_t)(last_id >> 32), 0);
+        sample_id = (int64_t)(((uint64_t)hi32 << 32) | lo32);
+      }
+      if (lane == 0) a.out[i * L + s + 1] = sample_id;
+      parent = cur;
+      have_parent_nb = true;
+      cur = sample_id;
+    }
+  }
+}
+
+struct GenPairArgs {
+  const int64_t* paths;
+  int64_t* out;
+  int64_t batch, path_len, pair_count;
+  int32_t left, right;
+};
+
+// GenPair (tf_euler/kernels/gen_pair_op.cc:66-84): one lane per (path, j).
+__global__ void GenPairKernel(const GenPairArgs a) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.batch * a.path_len) return;
+  const int64_t i = idx / a.path_len, j = idx - i * a.path_len;
+  // pairs emitted before position j: sum over j' < j of (min(j',L) + min(len-1-j',R))
+  int64_t before = 0;
+  for (int64_t x = 0; x < j; ++x) {
+    const int64_t l = x < a.left ? x : a.left;
+    const int64_t r0 = a.path_len - 1 - x;
+    before += l + (r0 < a.right ? r0 : a.right);
+  }
+  const int64_t* path = a.paths + i * a.path_len;
+  int64_t* o = a.out + (i * a.pair_count + before) * 2;
+  int k = 0;
+  while ((j - k - 1) >= 0 && k < a.left) { *o++ = path[j]; *o++ = path[j - k - 1]; ++k; }
+  k = 0;
+  while ((j + k + 1) < a.path_len && k < a.right) { *o++ = path[j]; *o++ = path[j + k + 1]; ++k; }
+}
+
+// Algorithmic bytes of one sample_neighbor launch: summed per
+// root from its actual degree.
+__global__ void AlgoBytesKernel(const FullNbArgs a, int32_t count, double* acc) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double b = 0.0;
+  if (i < a.n) {
+    const int64_t row = FindRow(a.g, a.ids[i]);
+    const int32_t mode = TypeModeOf(a.k, a.g.T);
+    // per root: id in (8) + row_ptr pair (16) + type offsets (4k') + idx out (8)
+    b = 8.0 + 16.0 + 4.0 * (mode == kTypeSingle ? 1 : a.g.T) + 8.0;
+    double per = 16.0;  // id + weight + type out
+    if (row >= 0) {
+      const RowMeta m = LoadRowMeta(a.g, row);
+      int32_t deg;
+      if (mode == kTypeSingle) {
+        const int32_t t = a.et[0];
+        deg = (t >= 0 && t < a.g.T)
+                  ? m.type_end[t] - (t == 0 ? 0 : m.type_end[t - 1]) : 0;
+      } else {
+        deg = m.type_end[a.g.T - 1];
+      }
+      if (deg > 0) {
+        const int32_t d2 = deg < 2 ? 2 : deg;
+        per += 8.0 + 8.0 + 4.0 * (double)(32 - __clz(d2 - 1));
+        if (mode != kTypeSingle) {
+          const int32_t t2 = a.g.T < 2 ? 2 : a.g.T;
+          per += 4.0 * (double)(32 - __clz(t2 - 1)) + 8.0;
+        }
+      }
+    }
+    b += per * count;
+  }
+  // wave reduction then one atomic per wave
+  for (int off = 32; off > 0; off >>= 1) b += __shfl_down(b, off, 64);
+  if ((threadIdx.x & 63) == 0 && b != 0.0) atomicAdd(acc, b);
+}
+
+}  // namespace euler_gpu
+
+using namespace euler_gpu;
+
+extern "C" {
+
+int euler_gpu_sample_node(const euler_gpu_graph* g, void* stream, uint64_t seed,
+                          uint32_t call_id, const int32_t* node_types_host,
+                          int32_t k, int32_t count, uint64_t* out_dev) {
+  if (!g) return Fail(EULER_GPU_ENOGRAPH, "sample_node: null graph");
+  if (!g->has_sampler)
+    return Fail(EULER_GPU_ENOGRAPH, "sample_node: graph has no global sampler");
+  if (count < 0 || k < 0 || (k > 0 && !node_types_host))
+    return Fail(EULER_GPU_EINVAL, "sample_node: bad arguments");
+  if (count == 0) return EULER_GPU_OK;
+  if (!out_dev) return Fail(EULER_GPU_EINVAL, "sample_node: null output");
+  SampleNodeArgs a{};
+  a.s = g->sampler;
+  a.seed = seed; a.call_id = call_id; a.count = count; a.out = out_dev;
+  const int32_t T = g->sampler.n_types;
+  if (k == 1) {                                     // api.cc:33-35
+    const int32_t type = node_types_host[0];
+    if (type == -1) {                               // graph.cc:229-236
+      if (g->sampler.tc_sum == 0.f)
+        return Fail(EULER_GPU_EEMPTY, "sample_node: total node weight is 0");
+      a.mode = 1;
+    } else {
+      if (type < 0 || type >= T)
+        return Fail(EULER_GPU_EINVAL, "sample_node: node type out of range");
+      if (g->sampler.sampler_sum[type] == 0.f ||
+          g->sampler.type_off[type + 1] == g->sampler.type_off[type])
+        return Fail(EULER_GPU_EEMPTY, "sample_node: type weight is 0");
+      a.mode = 0; a.type = type;
+    }
+  } else {                                          // graph.cc:247-275
+    a.mode = 2;
+    float acc = 0.f;
+    int32_t m = 0;
+    for (int32_t t = 0; t < T; ++t) {
+      bool in = false;
+      for (int32_t j = 0; j < k; ++j) in |= node_types_host[j] == t;
+      if (in) {
+        acc += g->sampler.type_sum[t];
+        a.sub_type[m] = t; a.sub_sum[m] = acc; ++m;
+      }
+    }
+    a.n_sub = m;
+    if (m == 0 || !(a.sub_sum[m - 1] > 0.f))
+      return Fail(EULER_GPU_EEMPTY, "sample_node: listed types have zero weight");
+  }
+  const int block = 256;
+  hipLaunchKernelGGL(SampleNodeKernel, dim3(GridFor(count, block)), dim3(block),
+                     0, (hipStream_t)stream, a);
+  EG_HIP(hipGetLastError());
+  return EULER_GPU_OK;
+}
+
+}  // extern "C"
+
+// exclusive scan helper (mp_kernels.hip)
+namespace euler_gpu {
+int ExclusiveScanI64(hipStream_t stream, const int64_t* in, int64_t* out,
+                     int64_t n);
+}
+
+extern "C" {
+
+int euler_gpu_get_full_neighbor(const euler_gpu_graph* g, void* stream,
+                                const uint64_t* ids_dev, int64_t n,
+                                const int32_t* edge_types_host, int32_t k,
+                                int32_t* idx_dev, int64_t* total_host,
+                                uint64_t* out_id_dev, float* out_w_dev,
+                                int32_t* out_t_dev) {
+  if (!g) return Fail(EULER_GPU_ENOGRAPH, "get_full_neighbor: null graph");
+  if (n < 0 || k < 0 || k > kMaxListedTypes)
+    return Fail(EULER_GPU_EINVAL, "get_full_neighbor: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) { if (total_host) *total_host = 0; return EULER_GPU_OK; }
+  if (!idx_dev || !ids_dev)
+    return Fail(EULER_GPU_EINVAL, "get_full_neighbor: null buffer");
+  FullNbArgs a{};
+  a.g = g->view; a.ids = ids_dev; a.n = n; a.k = k;
+  for (int i = 0; i < k; ++i) a.et[i] = edge_types_host[i];
+  const int block = 256;
+  if (out_id_dev == nullptr) {
+    int64_t* counts = nullptr;
+    EG_HIP(hipMallocAsync((void**)&counts, (2 * n + 2) * sizeof(int64_t), st));
+    int64_t* offsets = counts + n + 1;
+    hipLaunchKernelGGL(FullNbCountKernel, dim3((n + block - 1) / block),
+                       dim3(block), 0, st, a, counts);
+    int rc = ExclusiveScanI64(st, counts, offsets, n);
+    if (rc != EULER_GPU_OK) return rc;
+    hipLaunchKernelGGL(OffsetsToIdxKernel, dim3((n + block - 1) / block),
+                       dim3(block), 0, st, counts, offsets, n, idx_dev);
+    int32_t last[2];
+    EG_HIP(hipMemcpyAsync(last, idx_dev + 2 * (n - 1), 8, hipMemcpyDeviceToHost, st));
+    EG_HIP(hipStreamSynchronize(st));
+    EG_HIP(hipFreeAsync(counts, st));
+    if (total_host) *total_host = last[1];
+    return EULER_GPU_OK;
+  }
+  const int64_t waves_needed = n;
+  const int grid = GridFor(waves_needed * 64, block);
+  hipLaunchKernelGGL(FullNbFillKernel, dim3(grid), dim3(block), 0, st, a, idx_dev,
+                     out_id_dev, out_w_dev, out_t_dev);
+  EG_HIP(hipGetLastError());
+  return EULER_GPU_OK;
+}
+
+int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
+                          uint32_t call_id, const int64_t* nodes_dev, int64_t n,
+                          const int32_t* edge_types_host, int32_t k,
+                          int32_t walk_len, float p, float q,
+                          int64_t default_node, int64_t* out_dev) {
+  if (!g) return Fail(EULER_GPU_ENOGRAPH, "random_walk: null graph");
+  if (n < 0 || walk_len < 0 || k < 0 || k > kMaxListedTypes)
+    return Fail(EULER_GPU_EINVAL, "random_walk: bad arguments");
+  if (n == 0) return EULER_GPU_OK;
+  if (!nodes_dev || !out_dev || (k > 0 && walk_len > 0 && !edge_types_host))
+    return Fail(EULER_GPU_EINVAL, "random_walk: null buffer");
+  hipStream_t st = (hipStream_t)stream;
+  int32_t* et_dev = nullptr;
+  const size_t et_bytes = (size_t)walk_len * (k > 0 ? k : 1) * sizeof(int32_t) + 16;
+  EG_HIP(hipMallocAsync((void**)&et_dev, et_bytes, st));
+  if (k > 0 && walk_len > 0)
+    EG_HIP(hipMemcpyAsync(et_dev, edge_types_host,
+                          (size_t)walk_len * k * sizeof(int32_t),
+                          hipMemcpyHostToDevice, st));
+  WalkArgs a{};
+  a.g = g->view; a.seed = seed; a.call_id = call_id; a.nodes = nodes_dev;
+  a.edge_types = et_dev; a.out = out_dev; a.n = n; a.default_node = default_node;
+  a.k = k; a.walk_len = walk_len; a.p = p; a.q = q;
+  const int block = 256;
+  const float kEps = 1.0e-6;
+  // random_walk_op.cc:281: fabs(p_ - 1.0) <= kEps && fabs(q_ - 1.0) <= kEps
+  if (std::fabs((double)p - 1.0) <= kEps && std::fabs((double)q - 1.0) <= kEps) {
+    if (k == 1 && g->view.monotone && g->view.blk != nullptr && g_k1_variant >= 5) {
+      hipLaunchKernelGGL(RandomWalkKernel<true>, dim3(GridFor(n, block)), dim3(block), 0,
+                         st, a);
+    } else {
+      hipLaunchKernelGGL(RandomWalkKernel<false>, dim3(GridFor(n, block)), dim3(block), 0,
+                         st, a);
+    }
+  } else {
+    if (g_n2v_wave != 0) {
+      hipLaunchKernelGGL(Node2VecWaveKernel, dim3(GridFor(n * 64, block)), dim3(block), 0,
+                         st, a);
+    } else {
+      hipLaunchKernelGGL(Node2VecKernel, dim3(GridFor(n, block)), dim3(block), 0, st, a);
+    }
+  }
+  EG_HIP(hipGetLastError());
+  // the edge-type table must outlive the kernel: stream-ordered free
+  EG_HIP(hipFreeAsync(et_dev, st));
+  return EULER_GPU_OK;
+}
+
+int64_t euler_gpu_gen_pair_count(int64_t path_len, int32_t left_win,
+                                 int32_t right_win) {
+  // gen_pair_op.cc:48-54
+  int64_t pair_count = path_len * (left_win + right_win);
+  for (int i = left_win, j = 0; i > 0 && j < path_len; --i, ++j) pair_count -= i;
+  for (int i = right_win, j = 0; i > 0 && j < path_len; --i, ++j) pair_count -= i;
+  return pair_count;
+}
+
+int euler_gpu_gen_pair(void* stream, const int64_t* paths_dev, int64_t batch,
+                       int64_t path_len, int32_t left_win, int32_t right_win,
+                       int64_t* out_dev) {
+  if (batch < 0 || path_len < 0 || left_win < 0 || right_win < 0)
+    return Fail(EULER_GPU_EINVAL, "gen_pair: bad arguments");
+  if (batch == 0 || path_len == 0) return EULER_GPU_OK;
+  GenPairArgs a{paths_dev, out_dev, batch, path_len,
+                euler_gpu_gen_pair_count(path_len, left_win, right_win),
+                left_win, right_win};
+  const int block = 256;
+  const int64_t items = batch * path_len;
+  hipLaunchKernelGGL(GenPairKernel, dim3((items + block - 1) / block), dim3(block),
+                     0, (hipStream_t)stream, a);
+  EG_HIP(hipGetLastError());
+  return EULER_GPU_OK;
+}
+
+int euler_gpu_sample_neighbor_algo_bytes(const euler_gpu_graph* g, void* stream,
+                                         const uint64_t* roots_dev, int64_t n,
+                                         const int32_t* edge_types_host,
+                                         int32_t k, int32_t count,
+                                         double* bytes_host) {
+  if (!g) return Fail(EULER_GPU_ENOGRAPH, "algo_bytes: null graph");
+  if (n < 0 || k < 0 || k > kMaxListedTypes || !bytes_host)
+    return Fail(EULER_GPU_EINVAL, "algo_bytes: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  double* acc = nullptr;
+  EG_HIP(hipMallocAsync((void**)&acc, sizeof(double), st));
+  EG_HIP(hipMemsetAsync(acc, 0, sizeof(double), st));
+  FullNbArgs a{};
+  a.g = g->view; a.ids = roots_dev; a.n = n; a.k = k;
+  for (int i = 0; i < k; ++i) a.et[i] = edge_types_host[i];
+  const int block = 256;
+  if (n > 0)
+    hipLaunchKernelGGL(AlgoBytesKernel, dim3((n + block - 1) / block), dim3(block),
+                       0, st, a, count, acc);
+  EG_HIP(hipMemcpyAsync(bytes_host, acc, sizeof(double), hipMemcpyDeviceToHost, st));
+  EG_HIP(hipStreamSynchronize(st));
+  EG_HIP(hipFreeAsync(acc, st));
+  return EULER_GPU_OK;
+}
+
+}  // extern "C"
