@@ -121,6 +121,17 @@ struct alignas(128) EdgeBlock {
 static_assert(sizeof(EdgeBlock) == 128, "EdgeBlock must be one 128-byte line");
 constexpr int kSkipFanout = 32;    // 32 floats = one 128-byte line per skip node
 
+// A 256-thread workgroup is one wave per SIMD, and a SIMD admits
+// min(8, 800 / (ceil(sgpr / 16) * 16 + 16)) of them (MI355X_MICROARCH.md,
+// "Residency").  Kernels that take a GraphView by value have their arguments
+// hoisted into SGPRs and, at the compiler's default budget, use 106: SIX waves.
+// The sampling kernels wait on dependent loads most of the time, so they are
+// declared __launch_bounds__(256, kWavesPerSimd): the compiler then keeps the
+// SGPR count at <= 80 (the rest is spilled to VGPR lanes) and all eight waves
+// fit (measured on the metric workload: hop-1 kernel -7 %, distinct-root pass
+// -4 %).
+constexpr int kWavesPerSimd = 8;
+
 constexpr int kMaxListedTypes = 32;
 constexpr int kMaxNodeTypes = 32;
 

@@ -12,7 +12,7 @@
 
 namespace euler_gpu {
 
-__global__ __launch_bounds__(256) void SampleNeighborKernel(const SampleNbArgs a) {
+__global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborKernel(const SampleNbArgs a) {
   int64_t n_roots;
   if (!DedupGate(a, &n_roots)) return;
   const int64_t total = n_roots * (int64_t)a.count;
@@ -99,7 +99,7 @@ __device__ __forceinline__ void FastSampleOne(const GraphView& g,
 }
 
 template <bool TF_LAYOUT, bool ZERO_CHECK>
-__global__ __launch_bounds__(256) void SampleNeighborFastKernel(
+__global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborFastKernel(
     const SampleNbArgs a, const int64_t stride_rows, const int32_t stride_slots) {
   int64_t n_roots;
   if (!DedupGate(a, &n_roots)) return;
@@ -405,7 +405,7 @@ __device__ __forceinline__ int64_t BlockedSearch(const GraphView& g,
 }
 
 template <bool TF_LAYOUT>
-__global__ __launch_bounds__(256) void SampleNeighborBlockedKernel(
+__global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborBlockedKernel(
     const SampleNbArgs a, const int64_t stride_rows, const int32_t stride_slots,
     const int32_t ablate) {
   const int64_t total = a.n * (int64_t)a.count;

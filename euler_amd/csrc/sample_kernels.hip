@@ -153,7 +153,7 @@ struct ExpandArgs {
 // a single-type call has the same type, so the type column is not gathered but
 // rebuilt from the row mask (-5 %).
 template <int U, int V, bool CT>
-__global__ __launch_bounds__(256) void DedupExpandKernel(const ExpandArgs a,
+__global__ __launch_bounds__(256, kWavesPerSimd) void DedupExpandKernel(const ExpandArgs a,
                                                          const int64_t stride_rows,
                                                          const int32_t stride_slots) {
   typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void DedupExpandKernel(const ExpandArgs a,
 // rows are 8-byte aligned, so the ids are two 8-byte loads and one 16-byte
 // store; weights and types one 8-byte load and store each.
 template <int U>
-__global__ __launch_bounds__(256) void ExpandPackedKernel(
+__global__ __launch_bounds__(256, kWavesPerSimd) void ExpandPackedKernel(
     const int32_t* __restrict__ pos, const int32_t* __restrict__ packed, int64_t n,
     int32_t count, uint64_t* __restrict__ out_id, float* __restrict__ out_w,
     int32_t* __restrict__ out_t, uint8_t* __restrict__ out_mask,
@@ -379,7 +379,7 @@ __device__ __forceinline__ void PivotPass(const SampleNbArgs& a, const int64_t n
 }
 
 template <bool TF_LAYOUT, int U, bool BLOCKED = false>
-__global__ __launch_bounds__(256) void SampleNeighborPivotKernel(
+__global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborPivotKernel(
     const SampleNbArgs a, const int64_t stride_rows, const int32_t stride_slots) {
   int64_t n_roots;
   if (!DedupGate(a, &n_roots)) return;
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void SampleNeighborPivotKernel(
 // distinct roots into scratch rows, one sample per lane).  A gated launch that
 // only exits still costs ~8 us for its 32 768 workgroups.
 template <bool TF_LAYOUT, int U, bool BLOCKED>
-__global__ __launch_bounds__(256) void SampleNeighborPivotDualKernel(
+__global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborPivotDualKernel(
     const SampleNbArgs a, const int64_t a_rows, const int32_t a_slots,
     const SampleNbArgs b, const int64_t b_rows, const int32_t b_slots) {
   if (DedupActive(a.dd_counter, a.dd_n_in)) {

@@ -162,7 +162,7 @@ struct WalkArgs {
 // node, call_id + step), i.e. ~log5(deg / 10) + 4 dependent loads instead of
 // the reference loop's 2 * ceil(log2 deg).
 template <bool FAST>
-__global__ __launch_bounds__(256) void RandomWalkKernel(const WalkArgs a) {
+__global__ __launch_bounds__(256, kWavesPerSimd) void RandomWalkKernel(const WalkArgs a) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t L = a.walk_len + 1;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n;
@@ -270,7 +270,7 @@ struct BiasedStream {
 // sequential f32 adds, hence bit-identical.  (All-zero totals follow the
 // reference's fall-through: every probe moves `low` up, ending on the last
 // element.)
-__global__ __launch_bounds__(256) void Node2VecKernel(const WalkArgs a) {
+__global__ __launch_bounds__(256, kWavesPerSimd) void Node2VecKernel(const WalkArgs a) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t L = a.walk_len + 1;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n;
