@@ -123,6 +123,85 @@ __global__ __launch_bounds__(256) void DedupIndexPremarkedKernel(const DedupArgs
   }
 }
 
+// Numbering the representatives without a device-wide scan over the positions
+// (tuning key 14).  The rocPRIM scan evaluated the flags - a random read of
+// `owner` each - inside its load phase and took 39 + 5 us for the metric's 3.28 M
+// hop-2 roots, the index kernel another 19.  Here: one position per thread reads
+// its representative once (full occupancy, nothing else in flight) and the
+// workgroup counts its representatives; ONE workgroup scans the 3 200 counts;
+// the representatives take block offset + rank among the block's
+// representatives; every position then looks up its representative's number.
+struct DedupBlockArgs {
+  DedupArgs d;
+  IdentityMap map;
+  int32_t premarked;
+  int32_t pad;
+  uint32_t* rep;      // [n] representative of every position
+  uint32_t* posrep;   // [n] index into uniq, valid at representatives
+  uint32_t* bcnt;     // [n_blocks] representatives per workgroup
+  uint32_t* boff;     // [n_blocks] exclusive scan of bcnt
+};
+
+constexpr int kDedupBlock = 1024;   // positions per workgroup: 3 200 counts to scan for 3.28 M roots
+
+__global__ __launch_bounds__(kDedupBlock) void DedupRepCountKernel(const DedupBlockArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * kDedupBlock + threadIdx.x;
+  bool is_rep = false;
+  if (i < a.d.n) {
+    const uint32_t slot = a.premarked ? a.map.Slot(DedupKey(a.d, i)) : a.d.row_slot[i];
+    const uint32_t r = a.d.owner[slot];
+    a.rep[i] = r;
+    is_rep = r == (uint32_t)i;
+  }
+  const int c = __syncthreads_count(is_rep ? 1 : 0);
+  if (threadIdx.x == 0) a.bcnt[blockIdx.x] = (uint32_t)c;
+}
+
+__global__ __launch_bounds__(1024) void DedupBlockScanKernel(const uint32_t* cnt, int64_t m,
+                                                             uint32_t* off, uint32_t* counter) {
+  __shared__ uint32_t part[1024];
+  const int tid = threadIdx.x;
+  const int64_t per = (m + 1023) / 1024;
+  const int64_t b = (int64_t)tid * per;
+  const int64_t e = b + per < m ? b + per : m;
+  uint32_t sum = 0;
+  for (int64_t x = b; x < e; ++x) sum += cnt[x];
+  part[tid] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const uint32_t v = tid >= d ? part[tid - d] : 0u;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[tid] - sum;
+  for (int64_t x = b; x < e; ++x) { off[x] = run; run += cnt[x]; }
+  if (tid == 1023) counter[0] = part[1023];
+}
+
+__global__ __launch_bounds__(kDedupBlock) void DedupAssignKernel(const DedupBlockArgs a) {
+  __shared__ uint32_t wave_cnt[kDedupBlock / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * kDedupBlock + threadIdx.x;
+  const bool is_rep = i < a.d.n && a.rep[i] == (uint32_t)i;
+  const unsigned long long m = __ballot(is_rep);
+  if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (is_rep) {
+    uint32_t before = 0;
+    for (int w = 0; w < wave; ++w) before += wave_cnt[w];
+    const uint32_t q = a.boff[blockIdx.x] + before + (uint32_t)__popcll(m & ((1ULL << lane) - 1));
+    a.d.uniq[q] = DedupKey(a.d, i);
+    a.posrep[i] = q;
+  }
+}
+
+__global__ __launch_bounds__(256) void DedupResolveKernel(const DedupBlockArgs a) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.d.n; i += stride)
+    a.d.uidx_of[i] = a.posrep[a.rep[i]];
+}
+
 struct ExpandArgs {
   const uint32_t* counter;
   const uint32_t* uidx_of;
@@ -294,6 +373,7 @@ int g_k1_pair = 1;      // pivot kernel: two adjacent samples per lane when coun
 int g_k1_grid_cap = 0;  // measurement only: override the workgroup cap of K1
 int g_k1_fuse_mark = 1; // fanout: a hop's kernels fill the next hop's owner table
 int g_k1_dual = 1;      // duplicate-root call: both gated passes in one launch
+int g_dedup_block_numbering = 1;   // representatives numbered per workgroup (no scan over positions)
 int g_expand_steps = 2;        // DedupExpandKernel: grid-stride steps in flight per lane (1, 2, 4)
 int g_expand_const_type = 1;   // ... rebuild the type column of single-type calls from the mask
 int g_expand_grid_cap = 0;     // ... workgroup cap (0 = kK1GridCap)
@@ -698,8 +778,8 @@ static bool LaunchK1Dual(const euler_gpu_graph* g, hipStream_t stream,
 // `owner` sits at offset 0 whatever n is: the previous hop of a fanout fills it
 // for the next one before that hop's layout exists.
 struct DedupLayout {
-  size_t scan_bytes, o_owner, o_slot, o_pos, o_uidx, o_uniq, o_cnt, o_scan, o_mask, o_tid,
-      o_tw, o_tt, bytes;
+  size_t scan_bytes, o_owner, o_slot, o_pos, o_uidx, o_uniq, o_cnt, o_scan, o_bcnt, o_boff,
+      o_mask, o_tid, o_tw, o_tt, bytes;
 };
 
 static int MakeDedupLayout(const euler_gpu_graph* g, hipStream_t stream, int64_t n,
@@ -729,7 +809,10 @@ static int MakeDedupLayout(const euler_gpu_graph* g, hipStream_t stream, int64_t
   L->o_uniq = L->o_uidx + al((size_t)n * 4);
   L->o_cnt = L->o_uniq + al((size_t)n * 8);
   L->o_scan = L->o_cnt + 256;
-  L->o_mask = L->o_scan + al(L->scan_bytes);
+  const size_t n_blocks = ((size_t)n + 255) / 256 + 1;
+  L->o_bcnt = L->o_scan + al(L->scan_bytes);
+  L->o_boff = L->o_bcnt + al(n_blocks * 4);
+  L->o_mask = L->o_boff + al(n_blocks * 4);
   L->o_tid = L->o_mask + al((size_t)n);
   L->o_tw = L->o_tid + al(total_out * 8);
   L->o_tt = L->o_tw + al(total_out * 4);
@@ -862,7 +945,24 @@ static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
   const int dgrid = GridFor(n + 1, block);
   PhaseMark(stream, 0);
   hipcub::CountingInputIterator<uint32_t> pos_it(0u);
-  if (premarked) {
+  if (g_dedup_block_numbering != 0) {
+    if (!premarked) hipLaunchKernelGGL(DedupMarkKernel, dim3(dgrid), dim3(block), 0, stream, d);
+    DedupBlockArgs ba{};
+    ba.d = d; ba.map = idmap; ba.premarked = premarked ? 1 : 0;
+    ba.rep = d.pos;                      // the scan's output array is free in this mode
+    // scratch-row ids: >= 4 n bytes, idle until the sampling pass (after Resolve)
+    ba.posrep = (uint32_t*)(ws + L.o_tid);
+    ba.bcnt = (uint32_t*)(ws + L.o_bcnt);
+    ba.boff = (uint32_t*)(ws + L.o_boff);
+    const int64_t nb = (n + kDedupBlock - 1) / kDedupBlock;
+    hipLaunchKernelGGL(DedupRepCountKernel, dim3((unsigned)nb), dim3(kDedupBlock), 0, stream, ba);
+    hipLaunchKernelGGL(DedupBlockScanKernel, dim3(1), dim3(1024), 0, stream, ba.bcnt, nb,
+                       ba.boff, d.counter);
+    hipLaunchKernelGGL(DedupAssignKernel, dim3((unsigned)nb), dim3(kDedupBlock), 0, stream, ba);
+    // (letting the expand look posrep[rep[i]] up itself saves this kernel's 8 us
+    // and costs the expand 10: measured, not kept)
+    hipLaunchKernelGGL(DedupResolveKernel, dim3(dgrid), dim3(block), 0, stream, ba);
+  } else if (premarked) {
     // the previous hop's kernels stored every position into owner[slot(key)]
     hipcub::TransformInputIterator<uint32_t, DedupFlagPremarkedOp,
                                    hipcub::CountingInputIterator<uint32_t>>
@@ -1024,6 +1124,7 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   }
   if (key == 11) { g_expand_const_type = value != 0; return EULER_GPU_OK; }
   if (key == 13) { g_k1_dual = value != 0; return EULER_GPU_OK; }
+  if (key == 14) { g_dedup_block_numbering = value != 0; return EULER_GPU_OK; }
   if (key == 12 && value >= 0) { g_expand_grid_cap = value; return EULER_GPU_OK; }
   if (key == 4) { g_k1_pair = value; return EULER_GPU_OK; }
   if (key == 5) { g_k1_dedup = value; return EULER_GPU_OK; }

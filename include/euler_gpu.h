@@ -431,6 +431,10 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  *        lane (1, 2 [default], 4).  key 11: rebuild the type column of
  *        single-type calls from the row mask instead of gathering it (1).
  *        key 12: measurement only (workgroup cap of the expansion).
+ * key 13: both gated passes of a duplicate-root call in one launch (1).
+ * key 14: duplicate roots: representatives numbered per workgroup + one small
+ *        scan of the workgroup counts (1 [default]); 0 = device-wide scan over the
+ *        positions with the flags evaluated in its loads.
  * All settings produce identical results; the knobs exist for A/B measurements
  * and tests. */
 int euler_gpu_set_tuning(int32_t key, int32_t value);

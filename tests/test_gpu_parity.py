@@ -466,9 +466,20 @@ def test_non_monotone_rows_use_reference_loop(EA, O, torch_cuda):
         assert set(got[i].tolist()) <= row
 
 
+@pytest.fixture(params=[1, 0], ids=["blocknum", "scan"])
+def dedup_numbering(request):
+    """Both ways of numbering the distinct roots (tuning key 14): per-workgroup
+    counts + one small scan, and the device-wide scan over the positions."""
+    from euler_amd import _lib
+    _lib.lib().euler_gpu_set_tuning(14, request.param)
+    yield request.param
+    _lib.lib().euler_gpu_set_tuning(14, 1)
+
+
 @pytest.mark.parametrize("et", [[0], [1, 2], []])
 @pytest.mark.parametrize("count", [10, 7])
-def test_duplicate_roots_take_the_unique_path(EA, O, torch_cuda, big_pair, et, count):
+def test_duplicate_roots_take_the_unique_path(EA, O, torch_cuda, big_pair, et, count,
+                                              dedup_numbering):
     """40 000 roots drawn from 300 nodes (plus unknown ids and the sentinel):
     the launcher counts duplicates on device, samples each distinct node once
     and expands - ID_UNIQUE -> sample -> GATHER of the reference
@@ -865,7 +876,8 @@ def test_concurrent_callers_share_a_stream(EA, O, torch_cuda, big_pair):
 
 
 @pytest.mark.parametrize("base,stride", [(1, 1), (1000, 3)])
-def test_fanout_hop_chaining_on_identity_id_maps(EA, O, torch_cuda, base, stride):
+def test_fanout_hop_chaining_on_identity_id_maps(EA, O, torch_cuda, base, stride,
+                                                 dedup_numbering):
     """Fanout on graphs whose ids are base + stride * row (identity id map): hop
     h's kernels enter their ids into hop h+1's owner table (tuning key 9), so
     hop h+1's duplicate detection starts at its scan.  Rows without neighbours
