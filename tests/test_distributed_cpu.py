@@ -117,6 +117,30 @@ def _worker(rank, world, port, partitions, out_dir):
         msg = [rank * 100000 + rnd * 10 + p for p in range(world)]
         assert shm(msg) == [p * 100000 + rnd * 10 + rank for p in range(world)]
     S_fused.counts_fn = shm
+
+    # the branch the GPU sampler takes: the shard samples straight into wire rows
+    # (4 * count + 2 int32 words: ids | weights | types | mask, pad) and the
+    # requester expands them by position
+    def local_sample_packed(owned, edge_types, count, default_node, call_id):
+        ids_, w_, t_, m_ = local_sample(owned, edge_types, count, default_node, call_id)
+        m = ids_.shape[0]
+        rows = torch.zeros((m, 4 * count + 2), dtype=torch.int32)
+        rows[:, :2 * count] = ids_.reshape(m, count).contiguous().view(torch.int32)
+        rows[:, 2 * count:3 * count] = w_.reshape(m, count).contiguous().view(torch.int32)
+        rows[:, 3 * count:4 * count] = t_.reshape(m, count)
+        rows[:, 4 * count] = m_.reshape(m).to(torch.int32)
+        return rows
+
+    def expand_packed(pos, rows, count):
+        r = rows[pos.long()]
+        return (r[:, :2 * count].contiguous().view(torch.int64),
+                r[:, 2 * count:3 * count].contiguous().view(torch.float32),
+                r[:, 3 * count:4 * count].contiguous(), r[:, 4 * count].to(torch.uint8))
+
+    S_packed = ShardedSampler(local_sample, split_fn, merge_fn, partitions,
+                              dedup_split_fn=dedup_split_fn, expand_fn=expand_packed)
+    S_packed.local_sample_packed = local_sample_packed
+    S_packed.counts_fn = shm
     # with and without the duplicate-root removal: both must equal the
     # unsharded oracle
     S_plain = ShardedSampler(local_sample, split_fn, merge_fn, partitions)
@@ -131,7 +155,7 @@ def _worker(rank, world, port, partitions, out_dir):
     for et, counts in (([[0, 1, 2], [0, 1, 2]], [5, 3]), ([[1], [2]], [4, 2]),
                        ([[0, 2], [2, 1]], [3, 3])):
         on, ow, ot = OG_full.sample_fanout(seed, 40, roots, et, counts, -1)
-        for sampler in (S, S_plain, S_fused):
+        for sampler in (S, S_plain, S_fused, S_packed):
             ns, ws, ts = sampler.sample_fanout(torch.as_tensor(roots), et, counts, -1, 40)
             for h in range(len(counts)):
                 assert np.array_equal(ns[h + 1].numpy(), on[h]), (rank, et, h)
