@@ -1,7 +1,8 @@
 """Minibatch block construction on the GPU: tf_euler/python/dataflow
 (`base_dataflow.py:22-51`, `neighbor_dataflow.py:22-110`, `sage_dataflow.py:
-20-50`) with the sampler and `tf.unique` replaced by the HIP kernels of this
-package (sample_neighbor, ID_UNIQUE in first-occurrence order).  Everything
+20-50`, `gcn_dataflow.py:24-47`, `relation_dataflow.py:24-75`) with the sampler,
+the full-neighbour query and `tf.unique` replaced by the HIP kernels of this
+package (sample_neighbor, get_full_neighbor, ID_UNIQUE in first-occurrence order).  Everything
 stays in HBM; the only host round trip per hop is the unique count (the shape of
 the next hop), exactly where TensorFlow has a dynamic shape.
 
@@ -114,3 +115,70 @@ class SageDataFlow(UniqueDataFlow):
                                 .repeat_interleave(count))
             n_id, _ = _unique(torch.cat([new_n_id, n_id]))
         return neighbors, neighbor_src
+
+
+def _full_neighbor_coo(graph, n_id, edge_types):
+    """tf_euler.get_full_neighbor as the dataflows read it: the neighbour ids in
+    row order (`SparseTensor.values`), their row index (`indices[:, 0]`) and
+    their edge types."""
+    idx, ids, _w, t = graph.get_full_neighbor(n_id, edge_types)
+    lens = (idx[:, 1] - idx[:, 0]).to(torch.int64)
+    src = torch.repeat_interleave(torch.arange(n_id.numel(), device=n_id.device), lens)
+    return ids.reshape(-1), src, t.reshape(-1)
+
+
+class GCNDataFlow(UniqueDataFlow):
+    """gcn_dataflow.py:24-47: every hop takes ALL neighbours (of the listed edge
+    types) of the nodes seen so far."""
+
+    def __init__(self, graph, metapath, add_self_loops=True):
+        super(GCNDataFlow, self).__init__(len(metapath), add_self_loops)
+        self.graph = graph
+        self.metapath = metapath
+
+    def get_neighbors(self, n_id):
+        neighbors, neighbor_src = [], []
+        for hop_edge_types in self.metapath:
+            n_id = n_id.reshape(-1)
+            new_n_id, src, _t = _full_neighbor_coo(self.graph, n_id, hop_edge_types)
+            neighbors.append(new_n_id)
+            neighbor_src.append(src)
+            n_id, _ = _unique(torch.cat([new_n_id, n_id]))
+        return neighbors, neighbor_src
+
+
+class RelationDataFlow(object):
+    """relation_dataflow.py:24-75 (RGCN): full neighbours per hop, the edge TYPE
+    of every edge as the block's e_id, no self loops."""
+
+    def __init__(self, graph, metapath):
+        self.graph = graph
+        self.metapath = metapath
+
+    def get_neighbors(self, n_id):
+        neighbors, types, neighbor_src = [], [], []
+        for hop_edge_types in self.metapath:
+            n_id = n_id.reshape(-1)
+            new_n_id, src, t = _full_neighbor_coo(self.graph, n_id, hop_edge_types)
+            neighbors.append(new_n_id)
+            types.append(t)
+            neighbor_src.append(src)
+            n_id, _ = _unique(torch.cat([new_n_id, n_id]))
+        return neighbors, types, neighbor_src
+
+    def produce_subgraph(self, n_id):
+        n_id = n_id.reshape(-1)
+        data_flow = DataFlow(n_id)
+        n_neighbors, types, n_edge_src = self.get_neighbors(n_id)
+        for i in range(len(self.metapath)):
+            n_prev = n_id.numel()
+            new_n_id, new_inv = _unique(torch.cat([n_neighbors[i], n_id]))
+            res_n_id = new_inv[new_inv.numel() - n_prev:]
+            edge_dst = new_inv[:new_inv.numel() - n_prev]
+            n_id = new_n_id
+            edge_index = torch.stack([n_edge_src[i], edge_dst], 0)
+            data_flow.append(new_n_id, res_n_id, types[i], edge_index)
+        return data_flow
+
+    def __call__(self, n_id):
+        return self.produce_subgraph(n_id)

@@ -726,6 +726,54 @@ def test_sage_dataflow_blocks(EA, O, torch_cuda, big_pair):
     assert [b.size for b in df] == [w[3] for w in want][::-1]
 
 
+def test_gcn_and_relation_dataflow_blocks(EA, O, torch_cuda, big_pair):
+    """GCNDataFlow / RelationDataFlow (RGCN, config 5) on device == the same
+    composition on the oracle: full neighbours of the unique frontier per hop
+    (gcn_dataflow.py:33-47, relation_dataflow.py:30-72), tf.unique =
+    first-occurrence ID_UNIQUE, edge types as e_id."""
+    torch = torch_cuda
+    G, OG, ids, rng = big_pair
+    roots = np.concatenate([rng.choice(ids, 48), [0, 4242]]).astype(np.int64)
+    metapath = [[0, 1], [2, 3]]
+
+    def uniq(a):
+        uq, gi = O.id_unique(a.astype(np.uint64))
+        return uq.astype(np.int64), gi.astype(np.int64)
+
+    n_id = roots.copy()
+    nbrs, srcs, typs = [], [], []
+    for et in metapath:
+        idx, nb, _w, t = OG.get_full_neighbor(n_id.astype(np.uint64), et)
+        lens = idx[:, 1] - idx[:, 0]
+        nbrs.append(nb.astype(np.int64)); typs.append(t)
+        srcs.append(np.repeat(np.arange(len(n_id)), lens))
+        n_id, _ = uniq(np.concatenate([nb.astype(np.int64), n_id]))
+    rt = torch.as_tensor(roots).cuda()
+    # RelationDataFlow: no self loops, e_id = edge types
+    df = EA.dataflow.RelationDataFlow(G, metapath)(rt)
+    n_id = roots.copy()
+    for i, blk in enumerate(df.blocks):
+        new_n_id, inv = uniq(np.concatenate([nbrs[i], n_id]))
+        assert np.array_equal(t2n(blk.n_id), new_n_id)
+        assert np.array_equal(t2n(blk.res_n_id), inv[len(inv) - len(n_id):])
+        assert np.array_equal(t2n(blk.edge_index), np.stack([srcs[i], inv[:len(inv) - len(n_id)]]))
+        assert np.array_equal(t2n(blk.e_id), typs[i])
+        assert blk.size == [len(n_id), len(new_n_id)]
+        n_id = new_n_id
+    # GCNDataFlow: the UniqueDataFlow arithmetic with self loops
+    df = EA.dataflow.GCNDataFlow(G, metapath, add_self_loops=True)(rt)
+    n_id = roots.copy()
+    last_idx = np.arange(len(n_id))
+    for i, blk in enumerate(df.blocks):
+        new_n_id, inv = uniq(np.concatenate([nbrs[i], n_id]))
+        src = np.concatenate([srcs[i], last_idx])
+        last_idx = np.arange(len(new_n_id))
+        assert np.array_equal(t2n(blk.n_id), new_n_id)
+        assert np.array_equal(t2n(blk.res_n_id), inv[len(inv) - len(n_id):])
+        assert np.array_equal(t2n(blk.edge_index), np.stack([src, inv]))
+        n_id = new_n_id
+
+
 def test_dedup_split_pack_expand(EA, O, torch_cuda):
     """Fused front / back end of a multi-GPU hop: every position finds its id in
     the bucketed distinct list, buckets hold the ids their shard owns
