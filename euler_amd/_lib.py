@@ -78,6 +78,8 @@ SIGNATURES = {
                                         C.c_int32, C.c_int32, vp]),
     "euler_gpu_get_full_neighbor": (C.c_int, [vp, vp, vp, C.c_int64, i32p, C.c_int32,
                                               vp, i64p, vp, vp, vp]),
+    "euler_gpu_get_top_k_neighbor": (C.c_int, [vp, vp, vp, C.c_int64, i32p, C.c_int32,
+                                               C.c_int32, C.c_int64, vp, vp, vp]),
     "euler_gpu_random_walk": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp, C.c_int64,
                                         i32p, C.c_int32, C.c_int32, C.c_float,
                                         C.c_float, C.c_int64, vp]),

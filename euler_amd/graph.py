@@ -400,14 +400,13 @@ class Graph:
         fewer."""
         nodes = _as_i64_cuda(nodes, self.device).reshape(-1)
         n = nodes.numel()
-        idx, ids, w, t = self.get_full_neighbor(nodes, edge_types, order_by="weight",
-                                                desc=True, limit=k)
+        et, et_p, k_types = _i32_array(edge_types)
         out_n = torch.empty((n, k), dtype=torch.int64, device=self.device)
         out_w = torch.empty((n, k), dtype=torch.float32, device=self.device)
         out_t = torch.empty((n, k), dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
-            check(lib().euler_gpu_neighbor_to_dense(
-                _stream(), n, _ptr(idx), _ptr(ids), _ptr(w), _ptr(t), int(k),
+            check(lib().euler_gpu_get_top_k_neighbor(
+                self._h, _stream(), _ptr(nodes), n, et_p, k_types, int(k),
                 int(default_node), _ptr(out_n), _ptr(out_w), _ptr(out_t)))
         return out_n, out_w, out_t
 

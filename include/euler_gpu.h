@@ -264,6 +264,19 @@ int euler_gpu_neighbor_post_process(void* stream, int64_t n, int32_t* idx_dev,
                                     int64_t total, uint64_t* id_dev, float* w_dev,
                                     int32_t* t_dev, int32_t order_by, int32_t desc,
                                     int64_t limit, int64_t* total_host);
+/* tf_euler get_top_k_neighbor (tf_euler/kernels/get_top_k_neighbor_op.cc: GQL
+ * `v(nodes).outV(edge_types).order_by(weight, desc).limit(k)`, dense fill) in
+ * one kernel: out_*_dev [n, k] = the k heaviest neighbours of every node over
+ * the listed edge types (ties keep the order of Node::GetFullNeighbor,
+ * core/graph/node.cc:175-197), default_node / 0.0 / -1 where a node has fewer.
+ * Same result as euler_gpu_get_full_neighbor + euler_gpu_neighbor_post_process
+ * (weight, descending, limit k) + euler_gpu_neighbor_to_dense. */
+int euler_gpu_get_top_k_neighbor(const euler_gpu_graph* g, void* stream,
+                                 const uint64_t* ids_dev, int64_t n,
+                                 const int32_t* edge_types_host, int32_t k_types,
+                                 int32_t k, int64_t default_node, uint64_t* out_id_dev,
+                                 float* out_w_dev, int32_t* out_t_dev);
+
 /* Dense [n, k] fill of the TF GetTopKNeighbor kernel
  * (tf_euler/kernels/get_top_k_neighbor_op.cc:70-75,101-109): default_node /
  * 0.0 / -1 where a row has fewer than k entries. */

@@ -207,6 +207,19 @@ def test_empty_and_ragged_inputs(EA, O, torch_cuda, fixture_csr):
     idx, ids, w, t = G.get_full_neighbor(e, [0, 1])
     assert ids.numel() == 0
     assert G.sample_node(0, -1).numel() == 0
+    # the multi-GPU pieces on empty inputs (a rank may own none of a batch's ids)
+    assert tuple(G.sample_neighbor_packed(e, [0], 5).shape) == (0, 22)
+    off, sid, pos = EA.ops.dedup_split(e, 4, 4)
+    assert off == [0] * 5 and sid.numel() == 0 and pos.numel() == 0
+    table = torch.zeros(9, dtype=torch.int32, device="cuda")
+    off, sid, pos = EA.ops.dedup_split(e, 4, 4, dense_table=table)
+    assert off == [0] * 5 and sid.numel() == 0
+    rows = torch.zeros((0, 22), dtype=torch.int32, device="cuda")
+    o = EA.ops.expand_packed(torch.zeros(0, dtype=torch.int32, device="cuda"), rows, 5)
+    assert tuple(o[0].shape) == (0, 5)
+    # one id, one shard
+    off, sid, pos = EA.ops.dedup_split(torch.tensor([7]).cuda(), 1, 1, dense_table=table)
+    assert off == [0, 1] and t2n(sid).tolist() == [7] and t2n(pos).tolist() == [0]
     # zero-weight type -> EEMPTY error, no output (sample_node_op.cc:118-122)
     from euler_amd._lib import EulerGpuError
     with pytest.raises(EulerGpuError):
@@ -681,6 +694,26 @@ def test_sorted_and_top_k_neighbors(EA, O, torch_cuda, fixture_csr, big_pair):
         got = G.get_top_k_neighbor(qt, et, 6, default_node=-9)
         for x, y in zip(got, want):
             assert np.array_equal(t2n(x), y)
+    # rows longer than a wave (k rounds of selection), heavy ties, k > row length
+    n_l = 400
+    l_ids = np.arange(1, n_l + 1).astype(np.uint64)
+    l_deg = rng.integers(0, 700, size=(n_l, 2))
+    l_deg[rng.random((n_l, 2)) < 0.2] = 0
+    l_seg = np.zeros(2 * n_l + 1, np.int64)
+    l_seg[1:] = np.cumsum(l_deg.reshape(-1))
+    l_nbr = rng.choice(l_ids, int(l_seg[-1])).astype(np.uint64)
+    l_w = rng.integers(1, 6, int(l_seg[-1])).astype(np.float32)      # 5 distinct weights: ties
+    l_csr = O.csr_from_raw(l_ids, l_seg, l_nbr, l_w, 2)
+    GL, OL = gpu_graph(EA, l_csr), O.OracleGraph(l_csr)
+    ql = np.concatenate([l_ids, [0, 999]]).astype(np.uint64)
+    for et, k in (([0, 1], 7), ([1], 3), ([1, 0], 70), ([0], 1)):
+        full = OL.get_full_neighbor(ql, et)
+        want = O.neighbor_to_dense(*O.neighbor_post_process(*full, order_by="weight",
+                                                            desc=True, limit=k), k, -3)
+        got = GL.get_top_k_neighbor(torch.as_tensor(ql.astype(np.int64)).cuda(), et, k,
+                                    default_node=-3)
+        for x, y in zip(got, want):
+            assert np.array_equal(t2n(x), y), (et, k)
 
 
 def test_sage_dataflow_blocks(EA, O, torch_cuda, big_pair):
