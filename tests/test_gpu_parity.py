@@ -1006,3 +1006,65 @@ def test_fanout_hop_chaining_on_identity_id_maps(EA, O, torch_cuda, base, stride
     finally:
         L.euler_gpu_set_tuning(5, 1)
         L.euler_gpu_set_tuning(9, 1)
+
+
+def test_fanout_paths_agree_fuzz(EA, O, torch_cuda):
+    """Differential fuzz: sample_fanout (duplicate-root path, hop chaining, both
+    gated passes in one launch, expansion) against the plain per-hop kernel
+    (sample_neighbor on the given roots, no duplicate detection) chained by hand,
+    over random graphs (identity and hashed id maps, 1-3 edge types, empty rows,
+    dangling and zero ids), batch sizes and fanouts.  Rows are a function of
+    (seed, call id, node id) only, so both must agree bit for bit."""
+    torch = torch_cuda
+    rng = np.random.default_rng(20240927)
+    for trial in range(24):
+        n = int(rng.integers(200, 40000))
+        T = int(rng.integers(1, 4))
+        identity = trial % 3 != 0
+        if identity:
+            base, stride = int(rng.integers(0, 50)), int(rng.integers(1, 4))
+            ids = (base + stride * np.arange(n)).astype(np.uint64)
+        else:
+            ids = np.unique(rng.integers(1, 10 ** 9, 2 * n)).astype(np.uint64)[:n]
+            n = len(ids)
+        deg = rng.integers(0, int(rng.integers(2, 60)), size=(n, T))
+        deg[rng.random((n, T)) < 0.25] = 0
+        seg = np.zeros(n * T + 1, np.int64)
+        seg[1:] = np.cumsum(deg.reshape(-1))
+        E = int(seg[-1])
+        nbr = rng.choice(ids, E).astype(np.uint64)
+        nbr[rng.random(E) < 0.02] = 10 ** 12 + 7            # no such node
+        w = (rng.random(E) * 4 + 0.25).astype(np.float32)
+        csr = O.csr_from_raw(ids, seg, nbr, w, T)
+        G = gpu_graph(EA, csr)
+        layers = int(rng.integers(2, 4))
+        counts = [int(c) for c in rng.integers(1, 9, layers)]
+        # the op takes a rectangular [layers, k] tensor: one listed type per hop
+        # (pivot kernels, hop chaining) or all of them (type draws, reference loop)
+        if rng.random() < 0.7:
+            et = [[int(rng.integers(0, T))] for _ in range(layers)]
+        else:
+            et = [list(range(T)) for _ in range(layers)]
+        B = int(rng.integers(1, 6000))
+        q = np.concatenate([rng.choice(ids, B), [0]]).astype(np.int64)
+        qt = torch.as_tensor(q).cuda()
+        G.set_seed(1000 + trial)
+        from euler_amd import _lib
+        # every other trial: the duplicate path for every hop past the first,
+        # whatever its size
+        _lib.lib().euler_gpu_set_tuning(5, 2 if trial % 2 else 1)
+        try:
+            gn, gw, gt = G.sample_fanout(qt, et, counts, -1, call_id=5)
+        finally:
+            _lib.lib().euler_gpu_set_tuning(5, 1)
+        cur, mask, group = qt, None, 1
+        for h in range(layers):
+            # hop h by hand: masked rows of the previous hop sample as node id 0
+            roots_h = cur.clone()
+            if mask is not None:
+                roots_h[mask.to(torch.bool).repeat_interleave(group)] = 0
+            ids_h, w_h, t_h, m_h = G.sample_neighbor(roots_h, et[h], counts[h], -1, call_id=5 + h,
+                                                     return_mask=True, dedup=False)
+            assert torch.equal(gn[h + 1], ids_h.reshape(-1)), (trial, h, counts, et)
+            assert torch.equal(gw[h], w_h.reshape(-1)) and torch.equal(gt[h], t_h.reshape(-1))
+            cur, mask, group = ids_h.reshape(-1), m_h, counts[h]
