@@ -614,6 +614,36 @@ def test_gpu_sharded_sampler_single_rank(EA, O, torch_cuda, big_pair):
             assert np.array_equal(t2n(gn_i[h + 1]), on_i[h])
             assert np.array_equal(t2n(gw_i[h]), ow_i[h])
             assert np.array_equal(t2n(gt_i[h]), ot_i[h])
+        # differential fuzz: the sharded hop (front end, wire rows, expansion) against
+        # the single-GPU fanout on random graphs with both kinds of id map
+        for trial in range(10):
+            n_z = int(rng.integers(300, 30000))
+            if trial % 2:
+                z_ids = (int(rng.integers(0, 9)) + int(rng.integers(1, 4)) * np.arange(n_z)).astype(np.uint64)
+            else:
+                z_ids = np.unique(rng.integers(1, 10 ** 10, 2 * n_z)).astype(np.uint64)[:n_z]
+                n_z = len(z_ids)
+            z_deg = rng.integers(0, 40, size=(n_z, 2))
+            z_deg[rng.random((n_z, 2)) < 0.3] = 0
+            z_seg = np.zeros(2 * n_z + 1, np.int64)
+            z_seg[1:] = np.cumsum(z_deg.reshape(-1))
+            z_nbr = rng.choice(z_ids, int(z_seg[-1])).astype(np.uint64)
+            z_nbr[rng.random(len(z_nbr)) < 0.02] = 10 ** 12 + 3
+            z_csr = O.csr_from_raw(z_ids, z_seg, z_nbr,
+                                   (rng.random(len(z_nbr)) * 3 + 0.5).astype(np.float32), 2)
+            Gz = gpu_graph(EA, z_csr)
+            Gz.set_seed(500 + trial)
+            Sz = gpu_sharded_sampler(Gz, partitions=int(rng.integers(1, 9)), packed=bool(trial % 3))
+            assert (Sz.dense_table is not None) == bool(trial % 2)
+            cnts = [int(c) for c in rng.integers(1, 8, 2)]
+            ets = [[int(rng.integers(0, 2))], [int(rng.integers(0, 2))]] if trial % 4 else [[0, 1], [0, 1]]
+            qz = torch.as_tensor(np.concatenate([rng.choice(z_ids, int(rng.integers(1, 5000))), [0]])
+                                 .astype(np.int64)).cuda()
+            want = Gz.sample_fanout(qz, ets, cnts, -1, call_id=9)
+            got = Sz.sample_fanout(qz, ets, cnts, -1, call_id=9)
+            for h in range(2):
+                assert torch.equal(got[0][h + 1], want[0][h + 1]), (trial, h)
+                assert torch.equal(got[1][h], want[1][h]) and torch.equal(got[2][h], want[2][h])
         L = 5
         et = [[0, 1, 2, 3]] * L
         walk = S.random_walk(torch.as_tensor(q).cuda(), et, default_node=-1, call_id=20)
