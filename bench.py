@@ -52,12 +52,11 @@ def parse():
                     help="graph size of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
-    ap.add_argument("--pipeline", type=int, default=1,
-                    help="sharded path: minibatches in flight (each on its own host "
-                         "thread, HIP stream and RCCL communicator).  1 [default]: "
-                         "since the front end needs the host once per hop instead of "
-                         "three times, more batches in flight only add contention "
-                         "(one rank: 0.92 ms / step with 1, 1.28 ms with 3)")
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="sharded path: minibatches in flight, interleaved hop by hop "
+                         "from one host thread (each on its own sampler and HIP "
+                         "stream): while the host waits for one batch's bucket sizes "
+                         "the GPU runs the other's kernels and exchanges")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU sampler (unique / split / all-to-all / "
                          "merge / gather) even on one rank: measures its overhead")
@@ -158,43 +157,33 @@ def main():
         torch.cuda.synchronize()
 
     if sharded:
-        # A sharded hop needs the host twice (split offsets, peer counts).  K
-        # minibatches can be kept in flight, each on its own thread / stream /
-        # communicator (every rank runs the same slot -> step schedule, and a
-        # slot's collectives are ordered on its own communicator); K = 1 is the
-        # default and the fastest since the front end became one call.
-        import threading
-        from euler_amd.distributed import gpu_sharded_sampler
-        if args.pipeline <= 0:
-            args.pipeline = 1
+        # A sharded hop makes the host wait once (the bucket sizes of its front
+        # end).  K minibatches are kept in flight from ONE host thread
+        # (euler_amd.distributed.run_interleaved): each has its own sampler
+        # (front-end handle, id-indexed table, counts mailbox) and HIP stream, the
+        # hops of the batches alternate, and every rank issues the same sequence
+        # of collectives because the schedule does not depend on the data.
+        from euler_amd.distributed import gpu_sharded_sampler, run_interleaved
         K = max(1, min(args.pipeline, args.steps))
-        groups = [dist.new_group(list(range(world))) if K > 1 else None for _ in range(K)]
-        samplers = [gpu_sharded_sampler(G, partitions=world, group=g) for g in groups]
+        samplers = [gpu_sharded_sampler(G, partitions=world) for _ in range(K)]
         streams = [torch.cuda.Stream(device=dev) for _ in range(K)]
-        last_out = [None] * K
-
-        def run_slot(k, first, last):
-            torch.cuda.set_device(dev)
-            with torch.cuda.stream(streams[k]):
-                for i in range(first + k, last, K):
-                    last_out[k] = samplers[k].sample_fanout(roots[i], et, FANOUT,
-                                                            default_node, call_id=2 * i)
-                streams[k].synchronize()
 
         def run(first, last):
-            ts = [threading.Thread(target=run_slot, args=(k, first, last)) for k in range(K)]
-            for t in ts:
-                t.start()
-            for t in ts:
-                t.join()
+            res = run_interleaved(
+                lambda j: samplers[j % K].sample_fanout_steps(
+                    roots[first + j], et, FANOUT, default_node, call_id=2 * (first + j)),
+                last - first, K, enter=lambda k: torch.cuda.stream(streams[k]))
+            for st_ in streams:
+                st_.synchronize()
+            return res[-1] if res else None
 
+        torch.cuda.synchronize()          # roots were produced on the default stream
         run(0, args.warmup)
         sync()
         t0 = time.perf_counter()
-        run(args.warmup, n_steps)
+        out = run(args.warmup, n_steps)
         sync()
         elapsed = time.perf_counter() - t0
-        out = last_out[(n_steps - 1 - args.warmup) % K]
     else:
         def step(i):
             return G.sample_fanout(roots[i], et, FANOUT, default_node, call_id=2 * i)

@@ -116,6 +116,11 @@ SIGNATURES = {
     "euler_gpu_dedup_split": (C.c_int, [vp, vp, C.c_int64, vp, C.c_int32, C.c_int32,
                                         C.c_int32, vp, C.c_int64, C.POINTER(C.c_int64),
                                         vp, vp]),
+    "euler_gpu_front_create": (C.c_int, [C.POINTER(vp)]),
+    "euler_gpu_front_destroy": (None, [vp]),
+    "euler_gpu_dedup_split_begin": (C.c_int, [vp, vp, vp, C.c_int64, vp, C.c_int32, C.c_int32,
+                                              C.c_int32, vp, C.c_int64, vp, vp]),
+    "euler_gpu_dedup_split_end": (C.c_int, [vp, C.POINTER(C.c_int64)]),
     "euler_gpu_graph_id_range": (C.c_int, [vp, u64p, i32p]),
     "euler_shm_open": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]),
     "euler_shm_alltoall_i64": (C.c_int, [vp, i64p, i64p, C.c_int32, C.c_int64]),

@@ -7,10 +7,18 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <map>
+#include <new>
 #include <mutex>
 #include <utility>
 
 #include "device_fns.h"
+
+struct euler_gpu_front {
+  int64_t* stage = nullptr;      // pinned, kMaxShards + 1
+  hipEvent_t done = nullptr;
+  int32_t shards = 0;
+  int32_t pending = 0;           // a begin without its end
+};
 
 namespace euler_gpu {
 
@@ -1083,23 +1091,42 @@ static int ScratchReserve(StreamScratch* e, hipStream_t stream, size_t bytes, vo
   return EULER_GPU_OK;
 }
 
-// small pinned staging buffer per host thread (a pageable device-to-host copy
-// costs ~40 us; this one is written by the copy engine directly)
-static int64_t* PinnedStage() {
-  static thread_local int64_t* p = nullptr;
-  if (p == nullptr && hipHostMalloc((void**)&p, (kMaxShards + 1) * sizeof(int64_t)) != hipSuccess)
-    p = nullptr;
-  return p;
+// One front-end call in flight: the bucket sizes travel through a small pinned
+// buffer (a pageable device-to-host copy costs ~40 us; this one is written by the
+// copy engine directly) and an event marks their arrival, so that a caller can
+// enqueue the front ends of several minibatches before it waits for the first.
+int euler_gpu_front_create(euler_gpu_front** out) {
+  if (!out) return Fail(EULER_GPU_EINVAL, "front_create: null");
+  euler_gpu_front* f = new (std::nothrow) euler_gpu_front();
+  if (!f) return Fail(EULER_GPU_ENOMEM, "front_create: out of memory");
+  if (hipHostMalloc((void**)&f->stage, (kMaxShards + 1) * sizeof(int64_t)) != hipSuccess ||
+      hipEventCreateWithFlags(&f->done, hipEventDisableTiming) != hipSuccess) {
+    if (f->stage) (void)hipHostFree(f->stage);
+    delete f;
+    return Fail(EULER_GPU_ENOMEM, "front_create: pinned buffer / event");
+  }
+  *out = f;
+  return EULER_GPU_OK;
 }
 
-int euler_gpu_dedup_split(void* stream, const uint64_t* ids_dev, int64_t n,
-                          const uint8_t* root_mask_dev, int32_t root_group,
-                          int32_t partitions, int32_t shards, uint32_t* dense_owner_dev,
-                          int64_t dense_limit, int64_t* shard_off_host,
-                          uint64_t* shard_ids_dev, int32_t* pos_dev) {
-  if (n < 0 || partitions <= 0 || shards <= 0 || shards > kMaxShards || !shard_off_host)
+void euler_gpu_front_destroy(euler_gpu_front* f) {
+  if (!f) return;
+  if (f->pending) (void)hipEventSynchronize(f->done);
+  (void)hipEventDestroy(f->done);
+  (void)hipHostFree(f->stage);
+  delete f;
+}
+
+int euler_gpu_dedup_split_begin(euler_gpu_front* f, void* stream, const uint64_t* ids_dev,
+                                int64_t n, const uint8_t* root_mask_dev, int32_t root_group,
+                                int32_t partitions, int32_t shards,
+                                uint32_t* dense_owner_dev, int64_t dense_limit,
+                                uint64_t* shard_ids_dev, int32_t* pos_dev) {
+  if (!f || n < 0 || partitions <= 0 || shards <= 0 || shards > kMaxShards)
     return Fail(EULER_GPU_EINVAL, "dedup_split: bad arguments (shards <= 64)");
-  for (int s = 0; s <= shards; ++s) shard_off_host[s] = 0;
+  if (f->pending) return Fail(EULER_GPU_EINVAL, "dedup_split: the handle has a call in flight");
+  f->shards = shards;
+  for (int s = 0; s <= shards; ++s) f->stage[s] = 0;
   if (n == 0) return EULER_GPU_OK;
   if (n >= (1LL << 30)) return Fail(EULER_GPU_EINVAL, "dedup_split: n >= 2^30");
   if (!ids_dev || !shard_ids_dev || !pos_dev)
@@ -1107,8 +1134,6 @@ int euler_gpu_dedup_split(void* stream, const uint64_t* ids_dev, int64_t n,
   const bool dense = dense_owner_dev != nullptr;
   if (dense && (dense_limit <= 0 || dense_limit >= (1LL << 32) - 1))
     return Fail(EULER_GPU_EINVAL, "dedup_split: dense_limit out of range");
-  int64_t* stage = PinnedStage();
-  if (stage == nullptr) return Fail(EULER_GPU_ENOMEM, "dedup_split: pinned staging buffer");
   hipStream_t st = (hipStream_t)stream;
   uint64_t cap = 1024;
   while (!dense && cap < (uint64_t)n * 4) cap <<= 1;
@@ -1172,14 +1197,44 @@ int euler_gpu_dedup_split(void* stream, const uint64_t* ids_dev, int64_t n,
     if (hipGetLastError() != hipSuccess) rc = Fail(EULER_GPU_EHIP, "dedup_split: launch failed");
   }
   if (rc == EULER_GPU_OK) {
-    hipError_t e = hipMemcpyAsync(stage, starts, (size_t)(shards + 1) * 8,
+    hipError_t e = hipMemcpyAsync(f->stage, starts, (size_t)(shards + 1) * 8,
                                   hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipEventRecord(f->done, st);
     if (e != hipSuccess) rc = Fail(EULER_GPU_EHIP, std::string("dedup_split: ") + hipGetErrorString(e));
-    else for (int s = 0; s <= shards; ++s) shard_off_host[s] = stage[s];
-  } else {
-    (void)hipStreamSynchronize(st);        // the scratch must be idle when the lock drops
+    else f->pending = 1;
   }
+  // the scratch stays in use until the stream has run these kernels; whoever
+  // takes the lock next enqueues on the same stream, i.e. after them
+  return rc;
+}
+
+int euler_gpu_dedup_split_end(euler_gpu_front* f, int64_t* shard_off_host) {
+  if (!f || !shard_off_host) return Fail(EULER_GPU_EINVAL, "dedup_split_end: null");
+  if (f->pending) {
+    const hipError_t e = hipEventSynchronize(f->done);
+    f->pending = 0;
+    if (e != hipSuccess)
+      return Fail(EULER_GPU_EHIP, std::string("dedup_split_end: ") + hipGetErrorString(e));
+  }
+  for (int s = 0; s <= f->shards; ++s) shard_off_host[s] = f->stage[s];
+  return EULER_GPU_OK;
+}
+
+int euler_gpu_dedup_split(void* stream, const uint64_t* ids_dev, int64_t n,
+                          const uint8_t* root_mask_dev, int32_t root_group,
+                          int32_t partitions, int32_t shards, uint32_t* dense_owner_dev,
+                          int64_t dense_limit, int64_t* shard_off_host,
+                          uint64_t* shard_ids_dev, int32_t* pos_dev) {
+  if (!shard_off_host) return Fail(EULER_GPU_EINVAL, "dedup_split: null shard_off_host");
+  static thread_local euler_gpu_front* f = nullptr;      // one per host thread, kept
+  if (f == nullptr) {
+    const int rc = euler_gpu_front_create(&f);
+    if (rc != EULER_GPU_OK) return rc;
+  }
+  int rc = euler_gpu_dedup_split_begin(f, stream, ids_dev, n, root_mask_dev, root_group,
+                                       partitions, shards, dense_owner_dev, dense_limit,
+                                       shard_ids_dev, pos_dev);
+  if (rc == EULER_GPU_OK) rc = euler_gpu_dedup_split_end(f, shard_off_host);
   return rc;
 }
 

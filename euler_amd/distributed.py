@@ -72,6 +72,11 @@ class ShardedSampler:
         # local_sample_packed(owned, edge_types, count, default_node, call_id) ->
         # wire rows (sampling and packing in one kernel)
         self.local_sample_packed = None
+        # two-phase front end: front_begin_fn(ids, partitions, shards, root_mask,
+        # root_group) enqueues it and returns a token, front_end_fn(token) waits
+        # for the bucket sizes -> (shard_off, shard_ids, pos)
+        self.front_begin_fn = None
+        self.front_end_fn = None
         # counts_fn(send_counts list[world]) -> recv_counts list[world]
         self.counts_fn = None
         # optional hooks for get_dense_feature / sample_node (see those methods)
@@ -135,6 +140,15 @@ class ShardedSampler:
         mask = buf[:, 4 * count].to(torch.uint8)
         return ids, w, t, mask
 
+    @staticmethod
+    def _run(gen):
+        """Drive a *_steps generator to its result."""
+        try:
+            while True:
+                next(gen)
+        except StopIteration as stop:
+            return stop.value
+
     def sample_neighbor(self, roots, edge_types, count, default_node=-1,
                         call_id=0, root_mask=None, root_group=1):
         """One hop for this rank's `roots` ([n] int64).  root_mask ([n /
@@ -147,15 +161,37 @@ class ShardedSampler:
         ID_UNIQUE precedes ID_SPLIT, parser/compiler.cc:76-90): rows depend only
         on the node id, and on a fanout's second hop >90 % of the roots repeat,
         so the wire carries the distinct ones only."""
+        return self._run(self.sample_neighbor_steps(roots, edge_types, count, default_node,
+                                                    call_id, root_mask, root_group))
+
+    def sample_neighbor_steps(self, roots, edge_types, count, default_node=-1,
+                              call_id=0, root_mask=None, root_group=1):
+        """The hop as a generator that yields ONCE, at the only place the host
+        has to wait (the bucket sizes of the front end) - after enqueueing the
+        front end when the sampler has a two-phase one (front_begin_fn /
+        front_end_fn).  A caller that interleaves several minibatches advances
+        the other generators there.  The yield is unconditional (also for an
+        empty batch or a sampler without a two-phase front end): every rank must
+        issue its collectives in the same order."""
         roots = roots.reshape(-1).to(torch.int64)
         n = roots.numel()
         gather_idx = None
-        fused = self.dedup_split_fn is not None and self.expand_fn is not None and n > 0
+        # (not `and n > 0`: a rank whose own batch is empty still answers its peers,
+        # and must do so in the wire format they expect)
+        fused = self.dedup_split_fn is not None and self.expand_fn is not None
+        token = None
+        if fused and self.front_begin_fn is not None:
+            token = self.front_begin_fn(roots, self.partitions, self.world, root_mask,
+                                        root_group)
+        yield
         if fused:
             # C1 (fused): distinct ids bucketed by owner + where each position's
             # row will sit among the answers (the root mask is applied inside)
-            shard_off, shard_ids, pos = self.dedup_split_fn(
-                roots, self.partitions, self.world, root_mask, root_group)
+            if token is not None:
+                shard_off, shard_ids, pos = self.front_end_fn(token)
+            else:
+                shard_off, shard_ids, pos = self.dedup_split_fn(
+                    roots, self.partitions, self.world, root_mask, root_group)
             merge_idx = None
         else:
             if root_mask is not None:
@@ -200,14 +236,18 @@ class ShardedSampler:
     def sample_fanout(self, roots, edge_types, counts, default_node=-1, call_id=0):
         """Multi-hop fanout (tf_euler sample_fanout): returns (neighbors_list,
         weights_list, types_list) flattened like euler_ops.sample_fanout."""
+        return self._run(self.sample_fanout_steps(roots, edge_types, counts, default_node,
+                                                  call_id))
+
+    def sample_fanout_steps(self, roots, edge_types, counts, default_node=-1, call_id=0):
+        """sample_fanout as a generator: one yield per hop (sample_neighbor_steps)."""
         roots = roots.reshape(-1).to(torch.int64)
         neighbors, weights, types = [roots], [], []
         mask, group = None, 1
         cur = roots
         for h, count in enumerate(counts):
-            ids, w, t, m = self.sample_neighbor(cur, edge_types[h], count,
-                                                default_node, call_id + h, mask,
-                                                group)
+            ids, w, t, m = yield from self.sample_neighbor_steps(
+                cur, edge_types[h], count, default_node, call_id + h, mask, group)
             neighbors.append(ids.reshape(-1))
             weights.append(w.reshape(-1))
             types.append(t.reshape(-1))
@@ -343,6 +383,43 @@ class ShardedSampler:
         return torch.stack(cols, dim=1)
 
 
+def run_interleaved(make_steps, n_jobs, in_flight=2, enter=None):
+    """Drive n_jobs *_steps generators from one host thread with `in_flight` of
+    them active: job j runs in slot j % in_flight and is advanced one step at a
+    time, slot by slot, so that while the host waits for one minibatch's bucket
+    sizes the GPU has the other minibatches' kernels and exchanges queued.  The
+    schedule depends on nothing but (n_jobs, in_flight) and the number of yields
+    per job, which the *_steps generators keep independent of the data - every
+    rank therefore issues its collectives in the same order.
+      make_steps(j) -> generator for job j (called when its slot becomes free);
+      enter(slot)   -> optional context manager entered around every advance of
+                       that slot (e.g. its HIP stream).
+    Returns the results in job order."""
+    import contextlib
+    results = [None] * n_jobs
+    slots = [None] * in_flight           # (job, generator)
+    next_job = 0
+    live = 0
+    while next_job < n_jobs or live:
+        for k in range(in_flight):
+            ctx = enter(k) if enter is not None else contextlib.nullcontext()
+            with ctx:
+                if slots[k] is None and next_job < n_jobs and next_job % in_flight == k:
+                    slots[k] = (next_job, make_steps(next_job))
+                    next_job += 1
+                    live += 1
+                if slots[k] is None:
+                    continue
+                job, gen = slots[k]
+                try:
+                    next(gen)
+                except StopIteration as stop:
+                    results[job] = stop.value
+                    slots[k] = None
+                    live -= 1
+    return results
+
+
 class ShmCounts:
     """All-to-all of the per-peer row counts of a hop through a shared-memory
     mailbox (euler_shm_* in include/euler_gpu.h) - the ranks are processes of one
@@ -465,6 +542,11 @@ def gpu_sharded_sampler(graph, partitions=None, group=None, dedup=True, dense_id
                        front if fused else None,
                        ops.expand_packed if fused else None)
     S.dense_table = dense_table
+    if fused:
+        handle = ops.FrontHandle()          # one front end in flight per sampler
+        S.front_begin_fn = lambda ids, parts, shards, root_mask, root_group: handle.begin(
+            ids, parts, shards, root_mask, root_group, dense_table=dense_table)
+        S.front_end_fn = lambda token: token.end()
     # peer counts through a shared-memory mailbox instead of a GPU collective
     # plus device sync per hop (all ranks agree on whether it came up)
     if S.world > 1 and os.environ.get("EULER_AMD_SHM_COUNTS", "1") != "0":

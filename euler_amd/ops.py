@@ -234,6 +234,50 @@ def dedup_split(ids, partitions, shards, root_mask=None, root_group=1, dense_tab
     return off, sid[:off[-1]], pos
 
 
+class FrontHandle(object):
+    """One dedup_split call in flight (euler_gpu_front): begin() enqueues the
+    front end and returns, end() waits for the bucket sizes only."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        check(lib().euler_gpu_front_create(C.byref(h)))
+        self._h = h
+        self._token = None
+
+    def begin(self, ids, partitions, shards, root_mask=None, root_group=1, dense_table=None):
+        ids = ids.to(torch.int64).contiguous().reshape(-1)
+        _need_cuda(ids)
+        n = ids.numel()
+        if root_mask is not None:
+            root_mask = root_mask.to(torch.uint8).contiguous()
+        limit = dense_table.numel() - 1 if dense_table is not None else 0
+        sid = torch.empty(n, dtype=torch.int64, device=ids.device)
+        pos = torch.empty(n, dtype=torch.int32, device=ids.device)
+        with torch.cuda.device(ids.device):
+            check(lib().euler_gpu_dedup_split_begin(
+                self._h, _stream(), _ptr(ids), n, _ptr(root_mask), int(root_group), partitions,
+                shards, _ptr(dense_table), limit, _ptr(sid), _ptr(pos)))
+        # the inputs must outlive the enqueued kernels: keep them with the token
+        self._token = (shards, sid, pos, ids, root_mask)
+        return self
+
+    def end(self):
+        shards, sid, pos, _ids, _mask = self._token
+        self._token = None
+        off = (C.c_int64 * (shards + 1))()
+        check(lib().euler_gpu_dedup_split_end(self._h, off))
+        off = list(off)
+        return off, sid[:off[-1]], pos
+
+    def __del__(self):
+        try:
+            if self._h is not None and self._h.value:
+                lib().euler_gpu_front_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
 def expand_rows(pos, ids, w, t, mask, count):
     """Row pos[i] of the sampled rows of the distinct roots -> position i:
     (ids [n,count] int64, w f32, t int32, mask [n] uint8)."""

@@ -395,6 +395,21 @@ int euler_gpu_dedup_split(void* stream, const uint64_t* ids_dev, int64_t n,
                           int32_t partitions, int32_t shards, uint32_t* dense_owner_dev,
                           int64_t dense_limit, int64_t* shard_off_host,
                           uint64_t* shard_ids_dev, int32_t* pos_dev);
+/* The same call in two halves, for callers that keep several minibatches in
+ * flight from one host thread: _begin enqueues everything (the bucket sizes end
+ * in a pinned buffer of the handle, an event marks their arrival) and returns;
+ * _end waits for that event only and hands out shard_off_host [shards + 1].  One
+ * call in flight per handle; shard_ids_dev / pos_dev are valid in stream order
+ * after _begin. */
+typedef struct euler_gpu_front euler_gpu_front;
+int euler_gpu_front_create(euler_gpu_front** out);
+void euler_gpu_front_destroy(euler_gpu_front* f);
+int euler_gpu_dedup_split_begin(euler_gpu_front* f, void* stream, const uint64_t* ids_dev,
+                                int64_t n, const uint8_t* root_mask_dev, int32_t root_group,
+                                int32_t partitions, int32_t shards,
+                                uint32_t* dense_owner_dev, int64_t dense_limit,
+                                uint64_t* shard_ids_dev, int32_t* pos_dev);
+int euler_gpu_dedup_split_end(euler_gpu_front* f, int64_t* shard_off_host);
 /* Wire format of the result exchange: one row of 4*count + 2 int32 words per
  * root = [ids (2 words each) | weights | types | mask | pad].  pack_rows writes
  * it from the sampler's outputs [m, count] (+ row mask [m]); expand_packed reads

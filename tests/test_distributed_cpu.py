@@ -161,6 +161,29 @@ def _worker(rank, world, port, partitions, out_dir):
                 assert np.array_equal(ns[h + 1].numpy(), on[h]), (rank, et, h)
                 assert np.array_equal(ws[h].numpy(), ow[h])
                 assert np.array_equal(ts[h].numpy(), ot[h])
+    # several minibatches in flight from one thread (run_interleaved): a two-phase
+    # front end (begin = enqueue, end = wait) lets the hops of different batches
+    # alternate; every rank must still issue the same sequence of collectives -
+    # also when one rank's batch is empty
+    from euler_amd.distributed import run_interleaved
+    S_two = ShardedSampler(local_sample, split_fn, merge_fn, partitions,
+                           dedup_split_fn=dedup_split_fn, expand_fn=expand_packed)
+    S_two.local_sample_packed = local_sample_packed
+    S_two.counts_fn = shm
+    S_two.front_begin_fn = lambda ids_, parts, shards, rm, rg: dedup_split_fn(ids_, parts, shards,
+                                                                            rm, rg)
+    S_two.front_end_fn = lambda token: token
+    batches = [roots, roots[::2], roots[:0] if rank == 0 else roots[:7], roots[5:90], roots[::3]]
+    et_i, cnt_i = [[0, 1, 2], [0, 1, 2]], [4, 3]
+    for in_flight in (2, 3):
+        got = run_interleaved(lambda j: S_two.sample_fanout_steps(
+            torch.as_tensor(batches[j]), et_i, cnt_i, -1, 100 + 2 * j), len(batches), in_flight)
+        for j, b in enumerate(batches):
+            on, ow, ot = OG_full.sample_fanout(seed, 100 + 2 * j, b, et_i, cnt_i, -1)
+            for h in range(2):
+                assert np.array_equal(got[j][0][h + 1].numpy(), on[h]), (rank, j, h)
+                assert np.array_equal(got[j][1][h].numpy(), ow[h])
+                assert np.array_equal(got[j][2][h].numpy(), ot[h])
     # DeepWalk (config 4): p = q = 1 random walk over the sharded graph, one
     # exchange per step, identical to the unsharded walk
     L = 6
@@ -240,8 +263,11 @@ def _worker(rank, world, port, partitions, out_dir):
         assert int(split.sum()) == count and np.array_equal(got_n, want_n), (nt, count)
     # empty request from one rank must not dead-lock the exchange
     empty = torch.zeros(0, dtype=torch.int64) if rank == 0 else torch.as_tensor(roots)
-    n1, w1, t1, m1 = S.sample_neighbor(empty, [0], 2, -1, 7)
-    assert n1.shape[0] == empty.numel()
+    want_e = OG_full.sample_neighbor(seed, 7, empty.numpy(), [0], 2, -1)
+    for sampler in (S, S_fused, S_packed):
+        n1, w1, t1, m1 = sampler.sample_neighbor(empty, [0], 2, -1, 7)
+        assert n1.shape[0] == empty.numel()
+        assert np.array_equal(n1.numpy().reshape(-1), want_e[0].reshape(-1))
     dist.barrier()
     open(os.path.join(out_dir, "ok_%d" % rank), "w").write("ok")
     dist.destroy_process_group()
