@@ -127,9 +127,10 @@ SIGNATURES = {
     "euler_shm_attached": (C.c_int32, [vp]),
     "euler_shm_unlink": (C.c_int, [vp]),
     "euler_shm_close": (None, [vp]),
-    "euler_gpu_pack_rows": (C.c_int, [vp, vp, vp, vp, vp, C.c_int64, C.c_int32, vp]),
-    "euler_gpu_expand_packed": (C.c_int, [vp, vp, C.c_int64, C.c_int32, vp, vp, vp, vp,
-                                          vp]),
+    "euler_gpu_pack_rows": (C.c_int, [vp, vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_int32,
+                                      vp]),
+    "euler_gpu_expand_packed": (C.c_int, [vp, vp, C.c_int64, C.c_int32, C.c_int32, vp, vp, vp,
+                                          vp, vp]),
     "euler_gpu_expand_rows": (C.c_int, [vp, vp, C.c_int64, C.c_int32, vp, vp, vp, vp,
                                         vp, vp, vp, vp]),
     "euler_gpu_neighbor_post_process": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, vp, vp,

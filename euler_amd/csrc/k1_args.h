@@ -50,6 +50,7 @@ struct SampleNbArgs {
   int32_t* packed;              // not null (pivot kernels): write wire rows of
                                 // 4 * count + 2 words instead of out_id / out_w /
                                 // out_t / out_row_mask (see PackRowsKernel)
+  int32_t packed_tcol;          // ... with (1) or without (0: single-type call) the types
   int32_t cold_roots;           // hint: the roots are distinct (one sample per lane)
   int32_t et[kMaxListedTypes];
 };
@@ -92,6 +93,14 @@ __device__ __forceinline__ uint32_t OwnerSlot(const GraphView& g, uint64_t key) 
 __device__ __forceinline__ void MarkNextHop(const GraphView& g, uint32_t* owner,
                                             uint64_t id, bool row_valid, int64_t s) {
   owner[OwnerSlot(g, row_valid ? id : 0)] = (uint32_t)s;
+}
+
+// int32 words of one wire row (multi-GPU result exchange, see PackRowsKernel):
+// ids (2 each) | weights | [types] | mask | pad to an even count, so that every
+// row starts 8-byte aligned (RCCL moves odd-sized rows an order of magnitude
+// slower, and the ids are read and written as 8-byte words).
+__host__ __device__ __forceinline__ int32_t PackedWords(int32_t count, int32_t tcol) {
+  return ((3 + tcol) * count + 2 + 1) & ~1;
 }
 
 // ---- tuning switches (euler_gpu_set_tuning; defined in sample_kernels.hip) ----

@@ -320,20 +320,22 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void DedupExpandKernel(const Ex
 }
 
 // Back end of a multi-GPU hop: position i takes row pos[i] of the packed
-// answers (4 * count + 2 int32 words per row: ids, weights, types, mask, pad).
+// answers ((3 + TCOL) * count + 2 int32 words per row: ids, weights, [types],
+// mask, pad; without the type column the types are rebuilt from the mask).
 // U = 2 (even count, aligned outputs): a lane moves two adjacent samples -
 // rows are 8-byte aligned, so the ids are two 8-byte loads and one 16-byte
 // store; weights and types one 8-byte load and store each.
-template <int U>
+template <int U, bool TCOL>
 __global__ __launch_bounds__(256, kWavesPerSimd) void ExpandPackedKernel(
     const int32_t* __restrict__ pos, const int32_t* __restrict__ packed, int64_t n,
-    int32_t count, uint64_t* __restrict__ out_id, float* __restrict__ out_w,
-    int32_t* __restrict__ out_t, uint8_t* __restrict__ out_mask,
+    int32_t count, int32_t single_type, uint64_t* __restrict__ out_id,
+    float* __restrict__ out_w, int32_t* __restrict__ out_t, uint8_t* __restrict__ out_mask,
     const int64_t stride_rows, const int32_t stride_slots) {
   typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   typedef int i32x2 __attribute__((ext_vector_type(2)));
-  const int32_t words = 4 * count + 2;
+  const int32_t cols = TCOL ? 4 : 3;
+  const int32_t words = PackedWords(count, TCOL ? 1 : 0);
   const int64_t total = n * (int64_t)count;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x * U;
   int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * U;
@@ -342,21 +344,24 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void ExpandPackedKernel(
   int32_t j = (int32_t)(s - i * count);
   for (; s < total; s += stride) {
     const int32_t* row = packed + (int64_t)pos[i] * words;
+    const int32_t masked = (!TCOL || (j == 0 && out_mask != nullptr)) ? row[cols * count] : 0;
+    const int32_t ct = masked ? -1 : single_type;       // used when !TCOL
     if (U == 1) {
       const uint64_t id = *reinterpret_cast<const uint64_t*>(row + 2 * j);
       __builtin_nontemporal_store(id, out_id + s);
       __builtin_nontemporal_store(__int_as_float(row[2 * count + j]), out_w + s);
-      __builtin_nontemporal_store(row[3 * count + j], out_t + s);
+      __builtin_nontemporal_store(TCOL ? row[3 * count + j] : ct, out_t + s);
     } else {
       const uint64_t* idp = reinterpret_cast<const uint64_t*>(row + 2 * j);
       const u64x2 id2 = {idp[0], idp[1]};
       const f32x2 w2 = *reinterpret_cast<const f32x2*>(row + 2 * count + j);
-      const i32x2 t2 = *reinterpret_cast<const i32x2*>(row + 3 * count + j);
+      i32x2 t2 = {ct, ct};
+      if (TCOL) t2 = *reinterpret_cast<const i32x2*>(row + 3 * count + j);
       __builtin_nontemporal_store(id2, reinterpret_cast<u64x2*>(out_id + s));
       __builtin_nontemporal_store(w2, reinterpret_cast<f32x2*>(out_w + s));
       __builtin_nontemporal_store(t2, reinterpret_cast<i32x2*>(out_t + s));
     }
-    if (j == 0 && out_mask != nullptr) out_mask[i] = (uint8_t)row[4 * count];
+    if (j == 0 && out_mask != nullptr) out_mask[i] = (uint8_t)masked;
     i += stride_rows;
     j += stride_slots;
     if (j >= count) { j -= count; ++i; }
@@ -429,15 +434,16 @@ __device__ __forceinline__ void PivotPass(const SampleNbArgs& a, const int64_t n
       ot = TF_LAYOUT ? -1 : 0;
     }
     if (a.packed != nullptr) {
-      // wire row of root r: ids (2 words each) | weights | types | mask, pad
-      int32_t* row = a.packed + r * (int64_t)(4 * a.count + 2);
+      // wire row of root r: ids (2 words each) | weights | [types] | mask, pad
+      const int32_t cols = 3 + a.packed_tcol;
+      int32_t* row = a.packed + r * (int64_t)PackedWords(a.count, a.packed_tcol);
 #pragma unroll
       for (int x = 0; x < U; ++x) {
         *reinterpret_cast<uint64_t*>(row + 2 * (j + x)) = id[x];
         row[2 * a.count + j + x] = __float_as_int(w[x]);
-        row[3 * a.count + j + x] = ot;
+        if (a.packed_tcol) row[3 * a.count + j + x] = ot;
       }
-      if (j == 0) *reinterpret_cast<int2*>(row + 4 * a.count) = make_int2(valid ? 0 : 1, 0);
+      if (j == 0) *reinterpret_cast<int2*>(row + cols * a.count) = make_int2(valid ? 0 : 1, 0);
     } else if (U == 1) {
       a.out_id[s] = id[0];
       a.out_w[s] = w[0];
@@ -895,6 +901,7 @@ static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
   a.n = n; a.default_node = default_node;
   a.k = k; a.count = count; a.layout = layout;
   a.packed = packed_out;
+  a.packed_tcol = k == 1 ? 0 : 1;
   a.cold_roots = dedup < 0 ? 1 : 0;
   for (int i = 0; i < k; ++i) a.et[i] = edge_types[i];
   const bool try_dedup = WantsDedup(g, n, dedup);
@@ -1178,6 +1185,10 @@ int euler_gpu_sample_neighbor_packed(const euler_gpu_graph* g, void* stream,
   if (n == 0) return EULER_GPU_OK;
   if (!packed_dev) return Fail(EULER_GPU_EINVAL, "sample_neighbor_packed: null buffer");
   hipStream_t st = (hipStream_t)stream;
+  // one listed type: the type column stays off the wire (see PackRowsKernel)
+  const int32_t single_type = k == 1 ? edge_types_host[0] : -1;
+  if (k == 1 && (single_type < 0 || !edge_types_host))
+    return Fail(EULER_GPU_EINVAL, "sample_neighbor_packed: bad edge type");
   if (K1WritesPacked(g, k, EULER_GPU_LAYOUT_TF))
     return LaunchSampleNeighbor(g, st, seed, call_id, roots_dev, n, nullptr, 1,
                                 edge_types_host, k, count, EULER_GPU_LAYOUT_TF, default_node,
@@ -1196,7 +1207,8 @@ int euler_gpu_sample_neighbor_packed(const euler_gpu_graph* g, void* stream,
                                 buf + o_m, /*dedup=*/-1);
   if (rc == EULER_GPU_OK)
     rc = euler_gpu_pack_rows(stream, (const uint64_t*)buf, (const float*)(buf + o_w),
-                             (const int32_t*)(buf + o_t), buf + o_m, n, count, packed_dev);
+                             (const int32_t*)(buf + o_t), buf + o_m, n, count, single_type,
+                             packed_dev);
   (void)hipFreeAsync(buf, st);
   return rc;
 }
@@ -1262,18 +1274,21 @@ int euler_gpu_time_sample_neighbor(const euler_gpu_graph* g, void* stream,
 }
 
 // ------------------------------------------------------------------------
-// Wire format of the multi-GPU result exchange: one row of 4*count + 2 int32
-// words per root = [count ids (2 words each) | count weights | count types |
-// mask | pad], so that one all-to-all moves everything a hop returns and every
-// row starts 8-byte aligned.  PackRows writes it from the sampler's outputs;
-// ExpandPacked reads it back per POSITION through `pos` (merge + gather +
-// unpack in one pass).
+// Wire format of the multi-GPU result exchange: one int32 row per root =
+// [count ids (2 words each) | count weights | count types | mask | pad] -
+// 4 * count + 2 words - so that one all-to-all moves everything a hop returns and
+// every row starts 8-byte aligned.  A call with ONE listed edge type leaves the
+// type column out (3 * count + 2 words, padded to even: a quarter less on the wire): every
+// sample of a valid row has that type, a masked row -1 (TF layout).  PackRows
+// writes the rows from the sampler's outputs (the pivot kernels write them
+// directly); ExpandPacked reads them back per POSITION through `pos` (merge +
+// gather + unpack in one pass).
 // ------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void PackRowsKernel(
     const uint64_t* __restrict__ ids, const float* __restrict__ w,
     const int32_t* __restrict__ t, const uint8_t* __restrict__ mask, int64_t m,
-    int32_t count, int32_t* __restrict__ packed) {
-  const int32_t words = 4 * count + 2;
+    int32_t count, int32_t tcol, int32_t* __restrict__ packed) {
+  const int32_t words = PackedWords(count, tcol);
   const int64_t total = m * (int64_t)words;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total;
@@ -1283,29 +1298,30 @@ __global__ __launch_bounds__(256) void PackRowsKernel(
     int32_t v;
     if (c < 2 * count) v = reinterpret_cast<const int32_t*>(ids)[r * 2 * count + c];
     else if (c < 3 * count) v = __float_as_int(w[r * count + (c - 2 * count)]);
-    else if (c < 4 * count) v = t[r * count + (c - 3 * count)];
-    else v = c == 4 * count ? (int32_t)mask[r] : 0;
+    else if (c < (3 + tcol) * count) v = t[r * count + (c - 3 * count)];
+    else v = c == (3 + tcol) * count ? (int32_t)mask[r] : 0;
     packed[s] = v;
   }
 }
 
 int euler_gpu_pack_rows(void* stream, const uint64_t* id_dev, const float* w_dev,
                         const int32_t* t_dev, const uint8_t* mask_dev, int64_t m,
-                        int32_t count, int32_t* packed_dev) {
+                        int32_t count, int32_t single_type, int32_t* packed_dev) {
   if (m < 0 || count <= 0) return Fail(EULER_GPU_EINVAL, "pack_rows: bad m/count");
   if (m == 0) return EULER_GPU_OK;
   if (!id_dev || !w_dev || !t_dev || !mask_dev || !packed_dev)
     return Fail(EULER_GPU_EINVAL, "pack_rows: null buffer");
   const int block = 256;
-  hipLaunchKernelGGL(PackRowsKernel, dim3(GridFor(m * (4LL * count + 2), block)),
+  const int32_t tcol = single_type >= 0 ? 0 : 1;
+  hipLaunchKernelGGL(PackRowsKernel, dim3(GridFor(m * (int64_t)PackedWords(count, tcol), block)),
                      dim3(block), 0, (hipStream_t)stream, id_dev, w_dev, t_dev, mask_dev,
-                     m, count, packed_dev);
+                     m, count, tcol, packed_dev);
   EG_HIP(hipGetLastError());
   return EULER_GPU_OK;
 }
 
 int euler_gpu_expand_packed(void* stream, const int32_t* pos_dev, int64_t n,
-                            int32_t count, const int32_t* packed_dev,
+                            int32_t count, int32_t single_type, const int32_t* packed_dev,
                             uint64_t* out_id_dev, float* out_w_dev, int32_t* out_t_dev,
                             uint8_t* out_mask_dev) {
   if (n < 0 || count <= 0) return Fail(EULER_GPU_EINVAL, "expand_packed: bad n/count");
@@ -1323,15 +1339,14 @@ int euler_gpu_expand_packed(void* stream, const int32_t* pos_dev, int64_t n,
   const int64_t stride = blocks * block * U;
   const int64_t stride_rows = stride / count;
   const int32_t stride_slots = (int32_t)(stride - stride_rows * count);
-  if (pair) {
-    hipLaunchKernelGGL(ExpandPackedKernel<2>, dim3((int)blocks), dim3(block), 0,
-                       (hipStream_t)stream, pos_dev, packed_dev, n, count, out_id_dev,
-                       out_w_dev, out_t_dev, out_mask_dev, stride_rows, stride_slots);
-  } else {
-    hipLaunchKernelGGL(ExpandPackedKernel<1>, dim3((int)blocks), dim3(block), 0,
-                       (hipStream_t)stream, pos_dev, packed_dev, n, count, out_id_dev,
-                       out_w_dev, out_t_dev, out_mask_dev, stride_rows, stride_slots);
-  }
+#define EG_XP(UU, TC)                                                                     \
+  hipLaunchKernelGGL((ExpandPackedKernel<UU, TC>), dim3((int)blocks), dim3(block), 0,      \
+                     (hipStream_t)stream, pos_dev, packed_dev, n, count, single_type,      \
+                     out_id_dev, out_w_dev, out_t_dev, out_mask_dev, stride_rows,          \
+                     stride_slots)
+  if (single_type >= 0) { if (pair) EG_XP(2, false); else EG_XP(1, false); }
+  else { if (pair) EG_XP(2, true); else EG_XP(1, true); }
+#undef EG_XP
   EG_HIP(hipGetLastError());
   return EULER_GPU_OK;
 }

@@ -67,7 +67,8 @@ class ShardedSampler:
         self.dedup_split_fn = dedup_split_fn
         self.expand_fn = expand_fn
         # wire format hooks of the fused path (HIP kernels on GPUs): pack_fn(ids,
-        # w, t, mask, count) -> int32 rows; expand_fn(pos, rows, count) -> outputs
+        # w, t, mask, count, single_type) -> int32 rows; expand_fn(pos, rows,
+        # count, single_type) -> outputs
         self.pack_fn = None
         # local_sample_packed(owned, edge_types, count, default_node, call_id) ->
         # wire rows (sampling and packing in one kernel)
@@ -121,7 +122,9 @@ class ShardedSampler:
         """One int32 row per root: ids (2 words per id), weights, types, mask -
         one exchange and one merge instead of four."""
         m = ids.shape[0]
-        buf = torch.empty((m, 4 * count + 1), dtype=torch.int32, device=ids.device)
+        # 4 * count + 2 words: an even width keeps the rows 8-byte aligned (RCCL moves
+        # odd-sized rows an order of magnitude slower)
+        buf = torch.zeros((m, 4 * count + 2), dtype=torch.int32, device=ids.device)
         buf[:, :2 * count] = ids.reshape(m, count).contiguous().view(torch.int32)
         buf[:, 2 * count:3 * count] = w.reshape(m, count).contiguous().view(torch.int32)
         buf[:, 3 * count:4 * count] = t.reshape(m, count)
@@ -176,6 +179,9 @@ class ShardedSampler:
         roots = roots.reshape(-1).to(torch.int64)
         n = roots.numel()
         gather_idx = None
+        # one listed edge type: the wire rows of the fused path carry no type column
+        et_list = [int(x) for x in (edge_types if hasattr(edge_types, "__len__") else [edge_types])]
+        single_type = et_list[0] if len(et_list) == 1 else None
         # (not `and n > 0`: a rank whose own batch is empty still answers its peers,
         # and must do so in the wire format they expect)
         fused = self.dedup_split_fn is not None and self.expand_fn is not None
@@ -210,17 +216,18 @@ class ShardedSampler:
             # split; the shards answered in the order they were asked: row pos[i]
             # of `back` is position i's row
             rows = self.local_sample_packed(owned, edge_types, count, default_node, call_id)
-            return self.expand_fn(pos, self._exchange(rows, recv_counts, send_counts), count)
+            return self.expand_fn(pos, self._exchange(rows, recv_counts, send_counts), count,
+                                  single_type)
         # local sampling on the rows this rank owns
         ids, w, t, mask = self.local_sample(owned, edge_types, count, default_node,
                                             call_id)
         # C2: results travel back along the reversed split, one packed row each
         if fused and self.pack_fn is not None:
-            back = self._exchange(self.pack_fn(ids, w, t, mask, count), recv_counts,
-                                  send_counts)
+            back = self._exchange(self.pack_fn(ids, w, t, mask, count, single_type),
+                                  recv_counts, send_counts)
             # the shards answered in the order they were asked: row pos[i] of
             # `back` is position i's row (merge + gather + unpack in one pass)
-            return self.expand_fn(pos, back, count)
+            return self.expand_fn(pos, back, count, single_type)
         back = self._exchange(self._pack(ids, w, t, mask, count), recv_counts,
                               send_counts)
         if fused:

@@ -272,12 +272,15 @@ class Graph:
     def sample_neighbor_packed(self, nodes, edge_types, count, default_node=-1,
                                call_id=None):
         """The shard side of a multi-GPU hop: TF-layout SampleNeighbor of the
-        (distinct) ids this shard owns, returned as wire rows [n, 4 * count + 2]
-        int32 (ids | weights | types | mask, pad) for ops.expand_packed."""
+        (distinct) ids this shard owns, returned as wire rows for ops.expand_packed:
+        [n, 4 * count + 2] int32 (ids | weights | types | mask, pad), or
+        [n, 3 * count + 2 (padded to even)] without the types when one edge type is listed."""
         flat = _as_i64_cuda(nodes, self.device).reshape(-1)
         n = flat.numel()
-        rows = torch.empty((n, 4 * int(count) + 2), dtype=torch.int32, device=self.device)
         et, et_p, k = _i32_array(edge_types)
+        # one listed type: the type column stays off the wire
+        words = ((3 if k == 1 else 4) * int(count) + 2 + 1) & ~1
+        rows = torch.empty((n, words), dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
             check(lib().euler_gpu_sample_neighbor_packed(
                 self._h, _stream(), self.seed, self._take_call_ids(1, call_id),

@@ -298,25 +298,36 @@ def expand_rows(pos, ids, w, t, mask, count):
     return o_id, o_w, o_t, o_m
 
 
-def pack_rows(ids, w, t, mask, count):
-    """Sampler outputs [m, count] (+ mask [m]) -> wire rows [m, 4*count + 2] int32."""
+def packed_words(count, single_type=None):
+    """int32 words per wire row: ids (2 each) | weights | [types] | mask, pad."""
+    return ((3 if single_type is not None else 4) * int(count) + 2 + 1) & ~1     # even: 8-byte rows
+
+
+def pack_rows(ids, w, t, mask, count, single_type=None):
+    """Sampler outputs [m, count] (+ mask [m]) -> wire rows [m, packed_words] int32.
+    single_type (the one listed edge type of the call): the type column is left
+    off the wire."""
     ids = ids.contiguous(); w = w.contiguous(); t = t.contiguous()
     mask = mask.to(torch.uint8).contiguous()
     _need_cuda(ids, w, t, mask)
     m = mask.numel()
-    out = torch.empty((m, 4 * count + 2), dtype=torch.int32, device=ids.device)
+    out = torch.empty((m, packed_words(count, single_type)), dtype=torch.int32,
+                      device=ids.device)
     with torch.cuda.device(ids.device):
         check(lib().euler_gpu_pack_rows(_stream(), _ptr(ids), _ptr(w), _ptr(t),
-                                        _ptr(mask), m, int(count), _ptr(out)))
+                                        _ptr(mask), m, int(count),
+                                        -1 if single_type is None else int(single_type),
+                                        _ptr(out)))
     return out
 
 
-def expand_packed(pos, packed, count):
+def expand_packed(pos, packed, count, single_type=None):
     """Wire rows -> (ids [n,count] int64, w f32, t int32, mask [n] uint8) per
     position: row pos[i] of `packed` is position i's row."""
     pos = pos.to(torch.int32).contiguous()
     packed = packed.contiguous()
     _need_cuda(pos, packed)
+    assert packed.shape[-1] == packed_words(count, single_type), "wire row width"
     n = pos.numel()
     dev = pos.device
     o_id = torch.empty((n, count), dtype=torch.int64, device=dev)
@@ -325,6 +336,7 @@ def expand_packed(pos, packed, count):
     o_m = torch.empty(n, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         check(lib().euler_gpu_expand_packed(_stream(), _ptr(pos), n, int(count),
+                                            -1 if single_type is None else int(single_type),
                                             _ptr(packed), _ptr(o_id), _ptr(o_w),
                                             _ptr(o_t), _ptr(o_m)))
     return o_id, o_w, o_t, o_m

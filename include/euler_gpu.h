@@ -204,8 +204,9 @@ int euler_gpu_sample_neighbor_distinct(const euler_gpu_graph* g, void* stream,
                                        uint8_t* out_row_mask_dev);
 /* The shard side of a multi-GPU hop in one call: sample the (distinct) ids this
  * shard received, TF layout, and write the wire rows euler_gpu_expand_packed
- * consumes - 4 * count + 2 int32 words per root: ids (2 words each) | weights |
- * types | row mask, pad (euler_gpu_pack_rows' format).  Single-type calls on
+ * consumes - euler_gpu_pack_rows' format: 4 * count + 2 int32 words per root
+ * (ids | weights | types | row mask, pad), 3 * count + 2 (padded to even) without
+ * the type column when k == 1.  Single-type calls on
  * graphs the pivot kernels serve write the rows straight from the sampling
  * kernel; every other call samples into scratch arrays and packs. */
 int euler_gpu_sample_neighbor_packed(const euler_gpu_graph* g, void* stream,
@@ -410,16 +411,18 @@ int euler_gpu_dedup_split_begin(euler_gpu_front* f, void* stream, const uint64_t
                                 uint32_t* dense_owner_dev, int64_t dense_limit,
                                 uint64_t* shard_ids_dev, int32_t* pos_dev);
 int euler_gpu_dedup_split_end(euler_gpu_front* f, int64_t* shard_off_host);
-/* Wire format of the result exchange: one row of 4*count + 2 int32 words per
- * root = [ids (2 words each) | weights | types | mask | pad].  pack_rows writes
- * it from the sampler's outputs [m, count] (+ row mask [m]); expand_packed reads
- * the concatenated answers back per position through pos_dev (merge + gather +
- * unpack in one pass). */
+/* Wire format of the result exchange: one int32 row per root = [ids (2 words
+ * each) | weights | types | mask | pad], 4 * count + 2 words; with ONE listed
+ * edge type (single_type >= 0) the type column stays off the wire - 3 * count +
+ * 2 words, padded to an even number (rows stay 8-byte aligned) - and is rebuilt on arrival (single_type, or -1 for a masked row).
+ * pack_rows writes the rows from the sampler's outputs [m, count] (+ row mask
+ * [m]); expand_packed reads the concatenated answers back per position through
+ * pos_dev (merge + gather + unpack in one pass).  single_type = -1: full rows. */
 int euler_gpu_pack_rows(void* stream, const uint64_t* id_dev, const float* w_dev,
                         const int32_t* t_dev, const uint8_t* mask_dev, int64_t m,
-                        int32_t count, int32_t* packed_dev);
+                        int32_t count, int32_t single_type, int32_t* packed_dev);
 int euler_gpu_expand_packed(void* stream, const int32_t* pos_dev, int64_t n,
-                            int32_t count, const int32_t* packed_dev,
+                            int32_t count, int32_t single_type, const int32_t* packed_dev,
                             uint64_t* out_id_dev, float* out_w_dev, int32_t* out_t_dev,
                             uint8_t* out_mask_dev);
 /* out row i = row pos_dev[i] of (row_id, row_w, row_t [m, count], row_mask [m]). */

@@ -124,18 +124,28 @@ def _worker(rank, world, port, partitions, out_dir):
     def local_sample_packed(owned, edge_types, count, default_node, call_id):
         ids_, w_, t_, m_ = local_sample(owned, edge_types, count, default_node, call_id)
         m = ids_.shape[0]
-        rows = torch.zeros((m, 4 * count + 2), dtype=torch.int32)
+        cols = 3 if len(edge_types) == 1 else 4        # one listed type: no type column
+        rows = torch.zeros((m, (cols * count + 3) & ~1), dtype=torch.int32)
         rows[:, :2 * count] = ids_.reshape(m, count).contiguous().view(torch.int32)
         rows[:, 2 * count:3 * count] = w_.reshape(m, count).contiguous().view(torch.int32)
-        rows[:, 3 * count:4 * count] = t_.reshape(m, count)
-        rows[:, 4 * count] = m_.reshape(m).to(torch.int32)
+        if cols == 4:
+            rows[:, 3 * count:4 * count] = t_.reshape(m, count)
+        rows[:, cols * count] = m_.reshape(m).to(torch.int32)
         return rows
 
-    def expand_packed(pos, rows, count):
+    def expand_packed(pos, rows, count, single_type=None):
+        cols = 3 if single_type is not None else 4
+        assert rows.shape[1] == (cols * count + 3) & ~1
         r = rows[pos.long()]
+        mask_ = r[:, cols * count].to(torch.uint8)
+        if cols == 4:
+            types_ = r[:, 3 * count:4 * count].contiguous()
+        else:
+            types_ = torch.where(mask_.to(torch.bool)[:, None],
+                                 torch.full((len(r), count), -1, dtype=torch.int32),
+                                 torch.full((len(r), count), int(single_type), dtype=torch.int32))
         return (r[:, :2 * count].contiguous().view(torch.int64),
-                r[:, 2 * count:3 * count].contiguous().view(torch.float32),
-                r[:, 3 * count:4 * count].contiguous(), r[:, 4 * count].to(torch.uint8))
+                r[:, 2 * count:3 * count].contiguous().view(torch.float32), types_, mask_)
 
     S_packed = ShardedSampler(local_sample, split_fn, merge_fn, partitions,
                               dedup_split_fn=dedup_split_fn, expand_fn=expand_packed)

@@ -208,7 +208,8 @@ def test_empty_and_ragged_inputs(EA, O, torch_cuda, fixture_csr):
     assert ids.numel() == 0
     assert G.sample_node(0, -1).numel() == 0
     # the multi-GPU pieces on empty inputs (a rank may own none of a batch's ids)
-    assert tuple(G.sample_neighbor_packed(e, [0], 5).shape) == (0, 22)
+    assert tuple(G.sample_neighbor_packed(e, [0], 5).shape) == (0, 18)
+    assert tuple(G.sample_neighbor_packed(e, [0, 1], 5).shape) == (0, 22)
     off, sid, pos = EA.ops.dedup_split(e, 4, 4)
     assert off == [0] * 5 and sid.numel() == 0 and pos.numel() == 0
     table = torch.zeros(9, dtype=torch.int32, device="cuda")
@@ -874,6 +875,17 @@ def test_dedup_split_pack_expand(EA, O, torch_cuda):
     assert np.array_equal(t2n(o_w), t2n(r_w)[pos_n])
     assert np.array_equal(t2n(o_t), t2n(r_t)[pos_n])
     assert np.array_equal(t2n(o_m), t2n(r_m)[pos_n])
+    # single-type calls: no type column on the wire, types rebuilt from the mask
+    for cnt1 in (6, 5):
+        r_id1 = r_id[:, :cnt1].contiguous(); r_w1 = r_w[:, :cnt1].contiguous()
+        packed1 = EA.ops.pack_rows(r_id1, r_w1, r_t[:, :cnt1].contiguous(), r_m, cnt1, single_type=3)
+        assert tuple(packed1.shape) == (m, (3 * cnt1 + 3) & ~1)
+        s_id, s_w, s_t, s_m = EA.ops.expand_packed(pos, packed1, cnt1, single_type=3)
+        assert np.array_equal(t2n(s_id), t2n(r_id1)[pos_n])
+        assert np.array_equal(t2n(s_w), t2n(r_w1)[pos_n])
+        assert np.array_equal(t2n(s_m), t2n(r_m)[pos_n])
+        assert np.array_equal(t2n(s_t), np.where(t2n(r_m)[pos_n][:, None] != 0, -1, 3)
+                              * np.ones((1, cnt1), np.int32))
     e_id, e_w, e_t, e_m = EA.ops.expand_rows(pos, r_id, r_w, r_t, r_m, count)
     assert np.array_equal(t2n(e_id), t2n(o_id)) and np.array_equal(t2n(e_m), t2n(o_m))
 

@@ -44,11 +44,11 @@ def hop(tag, r, count, call_id, mask, group):
     t = tick(tag + ' ids exchange', t)
     ids, w, ty, m = S.local_sample(owned, [0], count, N + 1, call_id)
     t = tick(tag + ' local sample', t)
-    packed = S.pack_fn(ids, w, ty, m, count)
+    packed = S.pack_fn(ids, w, ty, m, count, 0)
     t = tick(tag + ' pack', t)
     back = S._exchange(packed, recv_counts, send_counts)
     t = tick(tag + ' rows exchange', t)
-    out = S.expand_fn(pos, back, count)
+    out = S.expand_fn(pos, back, count, 0)
     t = tick(tag + ' expand_packed', t)
     return out
 
