@@ -327,7 +327,9 @@ class ShardedSampler:
                           torch.cumsum(lens.to(torch.int64), 0)])
         val_send = [int(csum[bounds[s + 1]] - csum[bounds[s]]) for s in range(self.world)]
         val_recv = self._exchange_counts(val_send, dev)
-        lens_back = self._exchange(lens.reshape(-1, 1), recv_counts, send_counts).reshape(-1)
+        # (8-byte rows: RCCL moves rows of an odd number of 4-byte words far slower)
+        lens_back = self._exchange(lens.to(torch.int64).reshape(-1, 1), recv_counts,
+                                   send_counts).reshape(-1)
         vals = torch.empty((ids.numel(), 4), dtype=torch.int32, device=dev)
         vals[:, :2] = ids.reshape(-1, 1).contiguous().view(torch.int32).reshape(-1, 2)
         vals[:, 2] = w.contiguous().view(torch.int32)
