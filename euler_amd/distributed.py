@@ -392,7 +392,7 @@ class ShardedSampler:
         return torch.stack(cols, dim=1)
 
 
-def run_interleaved(make_steps, n_jobs, in_flight=2, enter=None):
+def run_interleaved(make_steps, n_jobs, in_flight=2, enter=None, on_result=None):
     """Drive n_jobs *_steps generators from one host thread with `in_flight` of
     them active: job j runs in slot j % in_flight and is advanced one step at a
     time, slot by slot, so that while the host waits for one minibatch's bucket
@@ -403,7 +403,11 @@ def run_interleaved(make_steps, n_jobs, in_flight=2, enter=None):
       make_steps(j) -> generator for job j (called when its slot becomes free);
       enter(slot)   -> optional context manager entered around every advance of
                        that slot (e.g. its HIP stream).
-    Returns the results in job order."""
+      on_result(job, value) -> optional consumer; the results are then NOT kept
+                       (a fanout's outputs are ~0.6 GB per minibatch of the metric:
+                       holding every step's tensors makes the caching allocator go
+                       back to the driver for each new step).
+    Returns the results in job order (None entries when on_result consumes them)."""
     import contextlib
     results = [None] * n_jobs
     slots = [None] * in_flight           # (job, generator)
@@ -423,7 +427,10 @@ def run_interleaved(make_steps, n_jobs, in_flight=2, enter=None):
                 try:
                     next(gen)
                 except StopIteration as stop:
-                    results[job] = stop.value
+                    if on_result is not None:
+                        on_result(job, stop.value)
+                    else:
+                        results[job] = stop.value
                     slots[k] = None
                     live -= 1
     return results
