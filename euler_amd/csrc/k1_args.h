@@ -97,8 +97,7 @@ __device__ __forceinline__ void MarkNextHop(const GraphView& g, uint32_t* owner,
 
 // int32 words of one wire row (multi-GPU result exchange, see PackRowsKernel):
 // ids (2 each) | weights | [types] | mask | pad to an even count, so that every
-// row starts 8-byte aligned: the ids are read and written as 8-byte words (with
-// 77-word rows - count 25, no type column - the sharded step took 30x longer).
+// row starts 8-byte aligned: the ids are read and written as 8-byte words.
 __host__ __device__ __forceinline__ int32_t PackedWords(int32_t count, int32_t tcol) {
   return ((3 + tcol) * count + 2 + 1) & ~1;
 }

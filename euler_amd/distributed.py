@@ -122,8 +122,7 @@ class ShardedSampler:
         """One int32 row per root: ids (2 words per id), weights, types, mask -
         one exchange and one merge instead of four."""
         m = ids.shape[0]
-        # 4 * count + 2 words: an even width keeps the rows 8-byte aligned (with rows
-        # of an odd number of words the sharded step was measured 30x slower)
+        # 4 * count + 2 words: an even width keeps the rows 8-byte aligned
         buf = torch.zeros((m, 4 * count + 2), dtype=torch.int32, device=ids.device)
         buf[:, :2 * count] = ids.reshape(m, count).contiguous().view(torch.int32)
         buf[:, 2 * count:3 * count] = w.reshape(m, count).contiguous().view(torch.int32)
