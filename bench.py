@@ -54,11 +54,12 @@ def parse():
                     help="graph size of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
-    ap.add_argument("--pipeline", type=int, default=2,
+    ap.add_argument("--pipeline", type=int, default=3,
                     help="sharded path: minibatches in flight, interleaved hop by hop "
                          "from one host thread (each on its own sampler and HIP "
                          "stream): while the host waits for one batch's bucket sizes "
-                         "the GPU runs the other's kernels and exchanges")
+                         "the GPU runs the others' kernels and exchanges (one rank: 0.61 ms "
+                         "/ step with 1, 0.47 with 2, 0.46 with 3 or 4)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU sampler (unique / split / all-to-all / "
                          "merge / gather) even on one rank: measures its overhead")
