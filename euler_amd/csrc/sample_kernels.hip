@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void ExpandPackedKernel(
   }
 }
 // ---- tuning switches (euler_gpu_set_tuning; declared in k1_args.h) ----
-int g_k1_dedup = 1;     // 0 = never, 1 = automatic for >= 16384 roots, 2 = always try
+int g_k1_dedup = 1;     // 0 = never, 1 = automatic for >= 100 000 roots, 2 = always try
 int g_n2v_wave = 1;     // node2vec: 1 = one wave per walker (LDS-staged lists), 0 = one lane
 int g_k1_group = 0;     // block-pivot kernel: five adjacent samples per lane for odd counts
                         // that are a multiple of 5 - measured 8 % SLOWER on the metric's
@@ -722,7 +722,11 @@ static int GetWorkspace(const euler_gpu_graph* g, hipStream_t stream, size_t byt
   return EULER_GPU_OK;
 }
 
-constexpr int64_t kDedupMinRoots = 16384;
+// Below ~100 K roots the six dependent kernels of the duplicate path (~38 us end to
+// end, whatever the size) lose to sampling the given roots directly, even with 90 %
+// duplicates (tools/ab_dedup_threshold.py on the metric graph: 25 600 roots 26 vs
+// 38 us, 102 400: 42 vs 42, 204 800: 57 vs 48, 819 200: 157 vs 92).
+constexpr int64_t kDedupMinRoots = 100000;
 
 // Measurement hook (euler_gpu_time_sample_neighbor_phases): when set, the
 // launcher records these 4 events on its stream at the phase boundaries

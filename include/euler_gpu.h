@@ -453,7 +453,7 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  *        (default 0: measured slower on the metric's first hop).
  * key 7: node2vec kernel: 1 = one wave per walker, lists staged in LDS [default],
  *        0 = one lane per walker.
- * key 5: duplicate roots: 0 = never look, 1 = look when a call has >= 16384
+ * key 5: duplicate roots: 0 = never look, 1 = look when a call has >= 100 000
  *        roots [default], 2 = always look.
  * key 8: dense-feature kernel: 16-byte loads when the slots allow it (1).
  * key 9: fanout: a hop's kernels enter their ids into the next hop's owner
