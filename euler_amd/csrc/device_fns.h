@@ -3,10 +3,31 @@
 
 #include "common.h"
 
+// Correctly rounded, never-contracted f32 / f64 operations.  On the device
+// these are the HIP intrinsics; the host spelling exists only so that
+// tests/csrc/host_check.hip can run the SAME per-item functions on the CPU
+// (the library is built -ffp-contract=off, so the plain operators round the
+// same way).  No product path runs them on the host.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define EG_FSUB(a, b) __fsub_rn((a), (b))
+#define EG_FADD(a, b) __fadd_rn((a), (b))
+#define EG_FMUL(a, b) __fmul_rn((a), (b))
+#define EG_FDIV(a, b) __fdiv_rn((a), (b))
+#define EG_DADD(a, b) __dadd_rn((a), (b))
+#define EG_DMUL(a, b) __dmul_rn((a), (b))
+#else
+#define EG_FSUB(a, b) ((float)(a) - (float)(b))
+#define EG_FADD(a, b) ((float)(a) + (float)(b))
+#define EG_FMUL(a, b) ((float)(a) * (float)(b))
+#define EG_FDIV(a, b) ((float)(a) / (float)(b))
+#define EG_DADD(a, b) ((double)(a) + (double)(b))
+#define EG_DMUL(a, b) ((double)(a) * (double)(b))
+#endif
+
 namespace euler_gpu {
 
 // Graph::GetNodeByID (core/graph/graph.h:87-92): id -> row, -1 on a miss.
-__device__ __forceinline__ int64_t FindRow(const GraphView& g, uint64_t id) {
+EG_HD int64_t FindRow(const GraphView& g, uint64_t id) {
   if (g.map_mode == 0) {
     const uint64_t d = id - g.id_base;
     if (id < g.id_base) return -1;
@@ -34,7 +55,7 @@ struct RowMeta {
   const float* type_prefix;    // [T]
 };
 
-__device__ __forceinline__ RowMeta LoadRowMeta(const GraphView& g, int64_t row) {
+EG_HD RowMeta LoadRowMeta(const GraphView& g, int64_t row) {
   const uint8_t* rec = g.row_meta + row * (int64_t)g.meta_stride;
   RowMeta m;
   m.row_ptr = *reinterpret_cast<const int64_t*>(rec);
@@ -46,17 +67,17 @@ __device__ __forceinline__ RowMeta LoadRowMeta(const GraphView& g, int64_t row) 
 // r = u * (limit_end - limit_begin) + limit_begin exactly as the reference
 // evaluates it on baseline x86-64 (no FMA): an f32 subtraction, then an fp64
 // multiply and an fp64 add, each rounded (compact_weighted_collection.h:32-36).
-__device__ __forceinline__ double ScaleDraw(double u, float limit_begin,
+EG_HD double ScaleDraw(double u, float limit_begin,
                                             float limit_end) {
-  const float span = __fsub_rn(limit_end, limit_begin);
-  return __dadd_rn(__dmul_rn(u, (double)span), (double)limit_begin);
+  const float span = EG_FSUB(limit_end, limit_begin);
+  return EG_DADD(EG_DMUL(u, (double)span), (double)limit_begin);
 }
 
 // RandomSelect<T> (common/compact_weighted_collection.h:30-52) over the
 // running sums sw(i): same probe sequence, same unsigned index arithmetic,
 // same fall-through (returns the last probed mid when no interval holds r).
 template <typename SumAt>
-__device__ __forceinline__ uint64_t RandomSelectT(const SumAt& sw,
+EG_HD uint64_t RandomSelectT(const SumAt& sw,
                                                   uint64_t begin_pos,
                                                   uint64_t end_pos, double u) {
   const float limit_begin = begin_pos == 0 ? 0.f : sw(begin_pos - 1);
@@ -88,10 +109,10 @@ __device__ __forceinline__ uint64_t RandomSelectT(const SumAt& sw,
 
 struct ArraySum {
   const float* __restrict__ p;
-  __device__ __forceinline__ float operator()(uint64_t i) const { return p[i]; }
+  EG_HD float operator()(uint64_t i) const { return p[i]; }
 };
 
-__device__ __forceinline__ uint64_t RandomSelect(const float* sw,
+EG_HD uint64_t RandomSelect(const float* sw,
                                                  uint64_t begin_pos,
                                                  uint64_t end_pos, double u) {
   return RandomSelectT(ArraySum{sw}, begin_pos, end_pos, u);
@@ -103,11 +124,11 @@ __device__ __forceinline__ uint64_t RandomSelect(const float* sw,
 struct SubTypeSum {
   const float* type_prefix;
   const int32_t* edge_types;
-  __device__ __forceinline__ float operator()(uint64_t i) const {
+  EG_HD float operator()(uint64_t i) const {
     float s = 0.f;
     for (uint64_t x = 0; x <= i; ++x) {
       const int32_t t = edge_types[x];
-      s = __fadd_rn(s, __fsub_rn(type_prefix[t], t > 0 ? type_prefix[t - 1] : 0.f));
+      s = EG_FADD(s, EG_FSUB(type_prefix[t], t > 0 ? type_prefix[t - 1] : 0.f));
     }
     return s;
   }
@@ -120,7 +141,7 @@ enum TypeMode : int32_t {
   kTypeAll = 2      // size == 0 or >= T : CDF over all groups (list ignored, Q5)
 };
 
-__device__ __forceinline__ int32_t TypeModeOf(int32_t k, int32_t T) {
+EG_HD int32_t TypeModeOf(int32_t k, int32_t T) {
   return k == 1 ? kTypeSingle : (k > 1 && k < T) ? kTypeSub : kTypeAll;
 }
 
@@ -139,7 +160,7 @@ struct RowSampler {
   const uint64_t* nbr;    // nbr + row_ptr
 };
 
-__device__ __forceinline__ void InitRowSampler(RowSampler& rs, const GraphView& g,
+EG_HD void InitRowSampler(RowSampler& rs, const GraphView& g,
                                                int64_t row,
                                                const int32_t* edge_types,
                                                int32_t k) {
@@ -180,20 +201,21 @@ __device__ __forceinline__ void InitRowSampler(RowSampler& rs, const GraphView& 
 // Sample number j of the row (node.cc:123-159).  Draw order per row is
 // i-major, within i: [type draw,] neighbour draw; draw_idx therefore is j for
 // the single-type mode and (2j, 2j+1) otherwise - one Philox block per sample.
-__device__ __forceinline__ void SampleAt(const RowSampler& rs, uint64_t seed,
+EG_HD void SampleAt(const RowSampler& rs, uint64_t seed,
                                          uint32_t call_id, uint64_t node_id,
                                          int32_t j, uint64_t* out_id,
-                                         float* out_w, int32_t* out_t) {
+                                         float* out_w, int32_t* out_t,
+                                         uint32_t domain = kDomainNeighbor) {
   int32_t t;
   double u_nb;
   if (rs.mode == kTypeSingle) {
     t = rs.single_type;
-    const Philox4 b = RngBlock(seed, call_id, kDomainNeighbor, node_id,
+    const Philox4 b = RngBlock(seed, call_id, domain, node_id,
                                ((uint32_t)j) >> 1);
     const int h = j & 1;
     u_nb = h ? UnitFromWords(b.w[2], b.w[3]) : UnitFromWords(b.w[0], b.w[1]);
   } else {
-    const Philox4 b = RngBlock(seed, call_id, kDomainNeighbor, node_id,
+    const Philox4 b = RngBlock(seed, call_id, domain, node_id,
                                (uint32_t)j);
     const double u_type = UnitFromWords(b.w[0], b.w[1]);
     u_nb = UnitFromWords(b.w[2], b.w[3]);
@@ -216,7 +238,7 @@ __device__ __forceinline__ void SampleAt(const RowSampler& rs, uint64_t seed,
   const uint64_t mid = RandomSelect(rs.nw, (uint64_t)b_idx, (uint64_t)e_idx, u_nb);
   const float pre = mid == 0 ? 0.f : rs.nw[mid - 1];
   *out_id = rs.nbr[mid];
-  *out_w = __fsub_rn(rs.nw[mid], pre);
+  *out_w = EG_FSUB(rs.nw[mid], pre);
   *out_t = t;
 }
 

@@ -30,14 +30,20 @@ enum RngDomain : uint32_t {
   kDomainNeighbor = 0,  // stream = root node id
   kDomainNode = 1,      // stream = 0, draws in Graph::SampleNode program order
   kDomainWalk = 2,      // stream = walker index (node2vec step)
-  kDomainSplit = 3      // SAMPLE_NODE_SPLIT remainder
+  kDomainSplit = 3,     // SAMPLE_NODE_SPLIT remainder
+  kDomainRoot = 4,      // API_SAMPLE_ROOT: stream = batch row, 2 draws per sample
+  kDomainLayer = 5      // API_SAMPLE_L: stream = POSITION in the root list (the
+                        // same node drawn twice samples twice), draws of one
+                        // Node::SampleNeighbor(count = 1)
 };
 
 EG_HD uint32_t DomainSalt(uint32_t domain) {
   return domain == 0 ? 0x00000000u
        : domain == 1 ? 0x9E3779B9u
        : domain == 2 ? 0x7F4A7C15u
-                     : 0xF39CC060u;
+       : domain == 3 ? 0xF39CC060u
+       : domain == 4 ? 0x6A09E667u
+                     : 0xB5C0FBCFu;
 }
 
 struct Philox4 {

@@ -287,6 +287,88 @@ int euler_gpu_neighbor_to_dense(void* stream, int64_t n, const int32_t* idx_dev,
                                 int64_t* out_id_dev, float* out_w_dev,
                                 int32_t* out_t_dev);
 
+/* ---- layerwise sampling (GQL sampleLNB without a weight function) -----------
+ * The DAG euler/parser/translator.cc:338-386,489-527 builds for
+ * `v(nodes).sampleLNB(edge_types, n, m, default_node)`:
+ * API_GET_EDGE_SUM_WEIGHT -> API_SAMPLE_ROOT -> API_SAMPLE_L ->
+ * API_SPARSE_GEN_ADJ -> API_SPARSE_GET_ADJ -> API_GATHER_RESULT.
+ * (The `sqrt` weight function runs API_LOCAL_SAMPLE_L, whose candidate order is
+ * the iteration order of a std::unordered_map<std::string, ...>: not built.) */
+
+/* API_GET_EDGE_SUM_WEIGHT (core/kernels/get_edge_sum_weight_op.cc:33-66):
+ * out_w_dev[i] = f32 sum, in Node::GetFullNeighbor order (core/graph/node.cc:
+ * 175-197), of the weights of ids_dev[i]'s out-edges of the listed types; 0 for
+ * an unknown node. */
+int euler_gpu_get_edge_sum_weight(const euler_gpu_graph* g, void* stream,
+                                  const uint64_t* ids_dev, int64_t n,
+                                  const int32_t* edge_types_host, int32_t k,
+                                  float* out_w_dev);
+
+/* API_SAMPLE_ROOT (core/kernels/sample_root_op.cc:33-88): for every batch row b,
+ * a FastWeightedCollection (common/fast_weighted_collection.h:55-75 over
+ * AliasMethod::Init, common/alias_method.cc:23-63) of roots_dev[b*n .. b*n+n)
+ * with weights_dev[b*n ..]; m draws per row -> out_dev [batch * m]; rows whose
+ * f32 weight sum is 0 give default_node.  RNG: domain 4, stream = b, draws 2j
+ * (column) and 2j+1 (coin) for draw j. */
+int euler_gpu_sample_root(void* stream, uint64_t seed, uint32_t call_id,
+                          const uint64_t* roots_dev, const float* weights_dev,
+                          int64_t batch, int32_t n, int32_t m, int64_t default_node,
+                          uint64_t* out_dev);
+
+/* API_SAMPLE_L (core/kernels/sample_layer_op.cc:32-72): position i receives ONE
+ * neighbour of roots_dev[i] (euler::SampleNeighbor({root}, edge_types, 1)) or
+ * (default_node, 0.0, 0) when that yields nothing.  RNG: domain 5, stream = the
+ * position i (a root listed twice is sampled twice, as in the reference).
+ * out_w_dev / out_t_dev may be NULL. */
+int euler_gpu_sample_layer(const euler_gpu_graph* g, void* stream, uint64_t seed,
+                           uint32_t call_id, const uint64_t* roots_dev, int64_t n,
+                           const int32_t* edge_types_host, int32_t k,
+                           int64_t default_node, uint64_t* out_id_dev,
+                           float* out_w_dev, int32_t* out_t_dev);
+
+/* The three ops above chained on the stream = output 0 of the TF kernel
+ * SampleNeighborLayerwiseWithAdj (tf_euler/kernels/
+ * sample_neighbor_layerwise_with_adj_op.cc:56-150, weight_func == ""):
+ * nodes_dev [batch, n] -> out_dev [batch, count].  Its sparse adjacency outputs
+ * are euler_gpu_sparse_get_adj_tf(nodes_dev, out_dev, batch, n, count, ...). */
+int euler_gpu_sample_neighbor_layerwise(const euler_gpu_graph* g, void* stream,
+                                        uint64_t seed, uint32_t call_id,
+                                        const uint64_t* nodes_dev, int64_t batch,
+                                        int32_t n, const int32_t* edge_types_host,
+                                        int32_t k, int32_t count,
+                                        int64_t default_node, uint64_t* out_dev);
+
+/* API_SPARSE_GET_ADJ (core/kernels/sparse_get_adj_op.cc:35-92) with the
+ * root_batch tensor API_SPARSE_GEN_ADJ builds (sparse_gen_adj_op.cc:52-61:
+ * root r belongs to batch row r / n): for every root the candidates
+ * l_nb_dev[b*m .. b*m+m) it has an edge of a listed type to, in candidate
+ * order.  FillNeighbor-style result: idx_dev [batch*n, 2] int32 offsets +
+ * out_id_dev [total].  Two calls like euler_gpu_get_full_neighbor: with
+ * out_id_dev == NULL it fills idx_dev and *total_host (stream sync), then it
+ * writes the ids.  EdgeExist (core/api/api.cc:46-48) is answered from the
+ * adjacency rows: the Edge records the reference would consult hold the same
+ * (src, dst, type) triples in data written by its converter. */
+int euler_gpu_sparse_get_adj(const euler_gpu_graph* g, void* stream,
+                             const uint64_t* roots_dev, const uint64_t* l_nb_dev,
+                             int64_t batch, int32_t n, int32_t m,
+                             const int32_t* edge_types_host, int32_t k,
+                             int32_t* idx_dev, int64_t* total_host,
+                             uint64_t* out_id_dev);
+
+/* TF SparseGetAdj (tf_euler/kernels/sparse_get_adj_op.cc:43-134) and the
+ * adjacency outputs of SampleNeighborLayerwiseWithAdj: COO triples (b, j, c) in
+ * row-major order with value 1 where nodes[b, j] has a listed-type edge to
+ * nb_nodes[b, c], plus the kernel's explicit 0 at (b, n-1, m-1) when that pair
+ * is no edge (so dense_shape = [batch, n, m]).  Two calls: indices_dev == NULL
+ * fills row_off_dev [batch*n + 1] (int64 scratch the second call reads) and
+ * *nnz_host (stream sync); then indices_dev [nnz, 3] / values_dev [nnz] int64. */
+int euler_gpu_sparse_get_adj_tf(const euler_gpu_graph* g, void* stream,
+                                const uint64_t* nodes_dev, const uint64_t* nb_nodes_dev,
+                                int64_t batch, int32_t n, int32_t m,
+                                const int32_t* edge_types_host, int32_t k,
+                                int64_t* row_off_dev, int64_t* nnz_host,
+                                int64_t* indices_dev, int64_t* values_dev);
+
 /* ---- dense features --------------------------------------------------------
  * TF GetDenseFeature (tf_euler/kernels/get_dense_feature_op.cc:63-125) over
  * Node::GetFloat32Feature (core/graph/node.cc:330-394): out_dev is [n, dim]

@@ -21,6 +21,11 @@
  *             ONE Graph::SampleNode(type(s), count)
  *   domain 2  node2vec biased step : stream = walker index, draw 0
  *   domain 3  SAMPLE_NODE_SPLIT remainder draws : stream = 0
+ *   domain 4  API_SAMPLE_ROOT (core/kernels/sample_root_op.cc) : stream =
+ *             batch row, draw_idx counts calls inside the row's sampling loop
+ *   domain 5  API_SAMPLE_L (core/kernels/sample_layer_op.cc) : stream =
+ *             POSITION of the root in the op's input (each position is its own
+ *             SampleNeighbor(count = 1) call), draw_idx counts calls inside it
  */
 #ifndef EULER_ORACLE_EO_RNG_H_
 #define EULER_ORACLE_EO_RNG_H_
@@ -35,11 +40,15 @@ enum {
   EO_DOMAIN_NEIGHBOR = 0,
   EO_DOMAIN_NODE = 1,
   EO_DOMAIN_WALK = 2,
-  EO_DOMAIN_SPLIT = 3
+  EO_DOMAIN_SPLIT = 3,
+  EO_DOMAIN_ROOT = 4,
+  EO_DOMAIN_LAYER = 5
 };
 
-static const uint32_t EO_DOMAIN_SALT[4] = {0x00000000u, 0x9E3779B9u,
-                                           0x7F4A7C15u, 0xF39CC060u};
+static const uint32_t EO_DOMAIN_SALT[8] = {0x00000000u, 0x9E3779B9u,
+                                           0x7F4A7C15u, 0xF39CC060u,
+                                           0x6A09E667u, 0xB5C0FBCFu,
+                                           0xB5C0FBCFu, 0xB5C0FBCFu};
 
 static inline void eo_philox4x32_10(const uint32_t ctr[4],
                                     const uint32_t key[2], uint32_t out[4]) {
@@ -80,7 +89,7 @@ static inline double eo_next_uniform(eo_rng_ctx* c) {
   ctr[2] = (uint32_t)(c->stream >> 32);
   ctr[3] = (uint32_t)(c->draw_idx >> 1);
   key[0] = (uint32_t)c->seed;
-  key[1] = (uint32_t)(c->seed >> 32) ^ EO_DOMAIN_SALT[c->domain & 3];
+  key[1] = (uint32_t)(c->seed >> 32) ^ EO_DOMAIN_SALT[c->domain & 7];
   eo_philox4x32_10(ctr, key, w);
   int h = (int)(c->draw_idx & 1);
   c->draw_idx++;

@@ -839,3 +839,173 @@ void eo_neighbor_to_dense(int64_t n, const int32_t* idx, const uint64_t* ids,
     }
   }
 }
+
+/* ------------------------------------------------ layerwise sampling ops
+ * The DAG of `sampleLNB(edge_types, n, m, default_node)` (parser/translator.cc:
+ * 338-386,489-527).  The `sqrt` variant (API_LOCAL_SAMPLE_L) is not restated:
+ * its candidate order is std::unordered_map<std::string,...> iteration order. */
+
+/* API_GET_EDGE_SUM_WEIGHT (core/kernels/get_edge_sum_weight_op.cc:51-62):
+ * `float sum_weight = 0; for (iw : GetFullNeighbor({root}, edge_types)[0])
+ * sum_weight += weight`. */
+void eo_get_edge_sum_weight(const eo_graph* g, const uint64_t* ids, int64_t n,
+                            const int32_t* edge_types, int32_t k, float* out_w) {
+  const int32_t T = g->n_types;
+  for (int64_t i = 0; i < n; ++i) {
+    float sum = 0;
+    int64_t row = eo_graph_find_row(g, ids[i]);
+    if (row >= 0) {
+      const int32_t* gi = g->type_end + row * T;
+      const float* nw = g->prefix_w + g->row_ptr[row];
+      for (int32_t a = 0; a < k; ++a) {
+        int32_t et = edge_types[a];
+        if (et >= 0 && et < T) {
+          int32_t b = et == 0 ? 0 : gi[et - 1];
+          for (int32_t j = b; j < gi[et]; ++j) {
+            float pre = j == 0 ? 0 : nw[j - 1];
+            float w = nw[j] - pre;
+            sum += w;
+          }
+        }
+      }
+    }
+    out_w[i] = sum;
+  }
+}
+
+/* API_SAMPLE_ROOT (core/kernels/sample_root_op.cc:42-86): per batch row a
+ * FastWeightedCollection (fast_weighted_collection.h:55-75: f32 sum, weights
+ * divided by it, AliasMethod::Init) over the row's n roots; m draws
+ * (AliasMethod::Next: 2 uniforms each); zero sum -> default_node.
+ * RNG: domain ROOT, stream = batch row. */
+void eo_sample_root(uint64_t seed, uint32_t call_id, const uint64_t* roots,
+                    const float* weights, int64_t batch, int32_t n, int32_t m,
+                    int64_t default_node, uint64_t* out) {
+  float* norm = (float*)malloc((size_t)(n + 1) * 4);
+  float* prob = (float*)malloc((size_t)(n + 1) * 4);
+  int64_t* alias = (int64_t*)malloc((size_t)(n + 1) * 8);
+  for (int64_t b = 0; b < batch; ++b) {
+    const float* w = weights + b * n;
+    float sum = 0.0f;
+    for (int32_t i = 0; i < n; ++i) sum += w[i];
+    if (sum == 0) {
+      for (int32_t j = 0; j < m; ++j) out[b * m + j] = (uint64_t)default_node;
+      continue;
+    }
+    for (int32_t i = 0; i < n; ++i) norm[i] = w[i] / sum;
+    eo_alias_init(norm, n, prob, alias);
+    eo_rng_ctx rng = {seed, call_id, EO_DOMAIN_ROOT, (uint64_t)b, 0};
+    for (int32_t j = 0; j < m; ++j)
+      out[b * m + j] = roots[b * n + eo_alias_next(prob, alias, n, &rng)];
+  }
+  free(norm); free(prob); free(alias);
+}
+
+/* API_SAMPLE_L (core/kernels/sample_layer_op.cc:54-70): one
+ * SampleNeighbor({root}, edge_types, 1) per position; empty -> (default_node,
+ * 0, 0).  RNG: domain LAYER, stream = position. */
+void eo_sample_layer(const eo_graph* g, uint64_t seed, uint32_t call_id,
+                     const uint64_t* roots, int64_t n, const int32_t* edge_types,
+                     int32_t k, int64_t default_node, uint64_t* out_id,
+                     float* out_w, int32_t* out_t) {
+  for (int64_t i = 0; i < n; ++i) {
+    int32_t got = 0;
+    int64_t row = eo_graph_find_row(g, roots[i]);
+    if (row >= 0) {
+      eo_rng_ctx rng = {seed, call_id, EO_DOMAIN_LAYER, (uint64_t)i, 0};
+      got = eo_sample_row(g, row, edge_types, k, 1, &rng, out_id + i, out_w + i,
+                          out_t + i);
+    }
+    if (got == 0) {
+      out_id[i] = (uint64_t)default_node; out_w[i] = 0; out_t[i] = 0;
+    }
+  }
+}
+
+/* EdgeExist(EdgeId(src, dst, type)) (core/api/api.cc:46-48) answered from the
+ * adjacency rows (the Edge map holds the same triples; checked against the
+ * reference's loaded Edge records in tests/test_oracle_vs_ref.py). */
+static int eo_edge_exist(const eo_graph* g, uint64_t src, uint64_t dst,
+                         int32_t type) {
+  const int32_t T = g->n_types;
+  if (type < 0 || type >= T) return 0;
+  int64_t row = eo_graph_find_row(g, src);
+  if (row < 0) return 0;
+  const int32_t* gi = g->type_end + row * T;
+  const uint64_t* nbr = g->nbr + g->row_ptr[row];
+  for (int32_t j = type == 0 ? 0 : gi[type - 1]; j < gi[type]; ++j)
+    if (nbr[j] == dst) return 1;
+  return 0;
+}
+
+/* API_SPARSE_GEN_ADJ + API_SPARSE_GET_ADJ (core/kernels/sparse_gen_adj_op.cc:
+ * 52-61, sparse_get_adj_op.cc:55-91): root r of batch row r / n keeps the
+ * candidates l_nb[b*m .. b*m+m) it has an edge of a listed type to.  Pass
+ * out_id == NULL to size.  Returns the total. */
+int64_t eo_sparse_get_adj(const eo_graph* g, const uint64_t* roots,
+                          const uint64_t* l_nb, int64_t batch, int32_t n,
+                          int32_t m, const int32_t* edge_types, int32_t k,
+                          int32_t* idx, uint64_t* out_id) {
+  int64_t off = 0;
+  for (int64_t r = 0; r < batch * n; ++r) {
+    int64_t b = r / n;
+    if (idx) idx[2 * r] = (int32_t)off;
+    for (int32_t j = 0; j < m; ++j) {
+      uint64_t nb = l_nb[b * m + j];
+      int exist = 0;
+      for (int32_t a = 0; a < k; ++a)
+        exist = exist || eo_edge_exist(g, roots[r], nb, edge_types[a]);
+      if (exist) {
+        if (out_id) out_id[off] = nb;
+        ++off;
+      }
+    }
+    if (idx) idx[2 * r + 1] = (int32_t)off;
+  }
+  return off;
+}
+
+/* The sparse-tensor assembly shared by the TF kernels SparseGetAdj
+ * (tf_euler/kernels/sparse_get_adj_op.cc:92-124) and
+ * SampleNeighborLayerwiseWithAdj (sample_neighbor_layerwise_with_adj_op.cc:
+ * 112-140), from the API_SPARSE_GET_ADJ result (idx, vals): per batch row a
+ * std::set of (src id, nb id) pairs, then for every (j, c) a 1 where the pair
+ * is in the set, and a 0 at (j, c) = (n-1, m-1) otherwise.  indices [nnz,3],
+ * values [nnz], shape[3] (= max index + 1 per dimension, SparseTensorBuilder).
+ * Pass indices == NULL to size. */
+int64_t eo_adj_to_sparse(const uint64_t* nodes, const uint64_t* nb_nodes,
+                         int64_t batch, int32_t n, int32_t m, const int32_t* idx,
+                         const uint64_t* vals, int64_t* indices, int64_t* values,
+                         int64_t* shape) {
+  int64_t nnz = 0;
+  if (shape) shape[0] = shape[1] = shape[2] = 0;
+  for (int64_t i = 0; i < batch; ++i) {
+    for (int32_t j = 0; j < n; ++j) {
+      uint64_t src = nodes[j + (int64_t)n * i];
+      for (int32_t c = 0; c < m; ++c) {
+        uint64_t dst = nb_nodes[c + (int64_t)m * i];
+        /* relation_set.find((src, dst)): the set holds (nodes[j'], v) for every
+         * j' of this batch row and every v in its result slice */
+        int found = 0;
+        for (int64_t jj = (int64_t)n * i; jj < (int64_t)n * (i + 1) && !found; ++jj) {
+          if (nodes[jj] != src) continue;
+          for (int32_t p = idx[2 * jj]; p < idx[2 * jj + 1]; ++p)
+            if (vals[p] == dst) { found = 1; break; }
+        }
+        int emit = found || (j == n - 1 && c == m - 1);
+        if (!emit) continue;
+        if (indices) {
+          indices[3 * nnz] = i; indices[3 * nnz + 1] = j; indices[3 * nnz + 2] = c;
+          values[nnz] = found ? 1 : 0;
+        }
+        if (shape) {
+          if (i + 1 > shape[0]) shape[0] = i + 1;
+          if (j + 1 > shape[1]) shape[1] = j + 1;
+          if (c + 1 > shape[2]) shape[2] = c + 1;
+        }
+        ++nnz;
+      }
+    }
+  }
+  return nnz;
+}

@@ -120,6 +120,25 @@ void eo_neighbor_to_dense(int64_t n, const int32_t* idx, const uint64_t* ids,
                           int64_t default_node, int64_t* out_id, float* out_w,
                           int32_t* out_t);
 
+/* layerwise sampling (sampleLNB without a weight function) */
+void eo_get_edge_sum_weight(const eo_graph* g, const uint64_t* ids, int64_t n,
+                            const int32_t* edge_types, int32_t k, float* out_w);
+void eo_sample_root(uint64_t seed, uint32_t call_id, const uint64_t* roots,
+                    const float* weights, int64_t batch, int32_t n, int32_t m,
+                    int64_t default_node, uint64_t* out);
+void eo_sample_layer(const eo_graph* g, uint64_t seed, uint32_t call_id,
+                     const uint64_t* roots, int64_t n, const int32_t* edge_types,
+                     int32_t k, int64_t default_node, uint64_t* out_id,
+                     float* out_w, int32_t* out_t);
+int64_t eo_sparse_get_adj(const eo_graph* g, const uint64_t* roots,
+                          const uint64_t* l_nb, int64_t batch, int32_t n,
+                          int32_t m, const int32_t* edge_types, int32_t k,
+                          int32_t* idx, uint64_t* out_id);
+int64_t eo_adj_to_sparse(const uint64_t* nodes, const uint64_t* nb_nodes,
+                         int64_t batch, int32_t n, int32_t m, const int32_t* idx,
+                         const uint64_t* vals, int64_t* indices, int64_t* values,
+                         int64_t* shape);
+
 int64_t eo_id_unique(const uint64_t* ids, int64_t n, uint64_t* unique_ids,
                      int32_t* gather_idx);
 void eo_idx_gather(const int32_t* idx, const int32_t* gather_idx, int64_t n,

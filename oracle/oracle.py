@@ -135,6 +135,19 @@ def lib():
                                      _i32p, _u64p, _f32p, _f32p]
         L.eo_philox_kat.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                     C.POINTER(C.c_uint32)]
+        L.eo_get_edge_sum_weight.argtypes = [C.c_void_p, _u64p, C.c_int64, _i32p,
+                                             C.c_int32, _f32p]
+        L.eo_sample_root.argtypes = [C.c_uint64, C.c_uint32, _u64p, _f32p, C.c_int64,
+                                     C.c_int32, C.c_int32, C.c_int64, _u64p]
+        L.eo_sample_layer.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, _u64p,
+                                      C.c_int64, _i32p, C.c_int32, C.c_int64, _u64p,
+                                      _f32p, _i32p]
+        L.eo_sparse_get_adj.restype = C.c_int64
+        L.eo_sparse_get_adj.argtypes = [C.c_void_p, _u64p, _u64p, C.c_int64, C.c_int32,
+                                        C.c_int32, _i32p, C.c_int32, _i32p, _u64p]
+        L.eo_adj_to_sparse.restype = C.c_int64
+        L.eo_adj_to_sparse.argtypes = [_u64p, _u64p, C.c_int64, C.c_int32, C.c_int32,
+                                       _i32p, _u64p, _i64p, _i64p, _i64p]
     return _lib
 
 
@@ -195,6 +208,25 @@ def ref():
         R.euler_ref_num_float_features.restype = C.c_int32
         R.euler_ref_get_dense_feature.argtypes = [_u64p, C.c_int64, C.c_int32,
                                                   C.c_int32, _f32p]
+        R.euler_ref_graph_load_all.argtypes = [C.c_char_p]
+        R.euler_ref_add_edges_from_adjacency.restype = C.c_int64
+        R.euler_ref_num_edges.restype = C.c_int64
+        R.euler_ref_edge_exist.argtypes = [C.c_uint64, C.c_uint64, C.c_int32]
+        R.euler_ref_get_edge_sum_weight.argtypes = [_u64p, C.c_int64, _i32p, C.c_int32,
+                                                    _f32p]
+        R.euler_ref_sample_root.argtypes = [C.c_uint64, C.c_uint32, _u64p, _f32p,
+                                            C.c_int64, C.c_int32, C.c_int32, C.c_int64,
+                                            _u64p]
+        R.euler_ref_sample_layer.argtypes = [C.c_uint64, C.c_uint32, _u64p, C.c_int64,
+                                             _i32p, C.c_int32, C.c_int64, _u64p, _f32p,
+                                             _i32p]
+        R.euler_ref_sparse_get_adj.restype = C.c_int64
+        R.euler_ref_sparse_get_adj.argtypes = [_u64p, _u64p, C.c_int64, C.c_int32,
+                                               C.c_int32, _i32p, C.c_int32, _i32p, _u64p]
+        R.euler_ref_adj_to_sparse.restype = C.c_int64
+        R.euler_ref_adj_to_sparse.argtypes = [_u64p, _u64p, C.c_int64, C.c_int32,
+                                              C.c_int32, _i32p, _u64p, _i64p, _i64p,
+                                              _i64p]
     return _ref
 
 
@@ -303,7 +335,74 @@ def csr_from_raw(row_id, seg_ptr, nbr, w, n_types, node_type=None,
                node_type, node_weight)
 
 
-class OracleGraph:
+
+# --------------------------------------------------------------------------
+# Layerwise sampling (sampleLNB without a weight function): the op chain
+# API_GET_EDGE_SUM_WEIGHT -> API_SAMPLE_ROOT -> API_SAMPLE_L ->
+# API_SPARSE_GET_ADJ + the TF kernel's sparse assembly.  `_LayerwiseMixin`
+# composes the chain from the four primitives of whichever backend (C
+# restatement / compiled reference) the class provides.
+# --------------------------------------------------------------------------
+def _adj_to_sparse_with(fn, nodes, nb_nodes, batch, n, m, idx, vals):
+    nodes = _arr(np.asarray(nodes).reshape(-1), np.uint64)
+    nb_nodes = _arr(np.asarray(nb_nodes).reshape(-1), np.uint64)
+    idx = _arr(idx, np.int32)
+    vals = _arr(vals, np.uint64)
+    shape = np.zeros(3, np.int64)
+    nnz = fn(_p(nodes, _u64p), _p(nb_nodes, _u64p), batch, n, m, _p(idx, _i32p),
+             _p(vals, _u64p), None, None, _p(shape, _i64p))
+    indices = np.zeros((nnz, 3), np.int64)
+    values = np.zeros(nnz, np.int64)
+    fn(_p(nodes, _u64p), _p(nb_nodes, _u64p), batch, n, m, _p(idx, _i32p),
+       _p(vals, _u64p), _p(indices, _i64p), _p(values, _i64p), _p(shape, _i64p))
+    return indices, values, shape
+
+
+def adj_to_sparse(nodes, nb_nodes, batch, n, m, idx, vals):
+    return _adj_to_sparse_with(lib().eo_adj_to_sparse, nodes, nb_nodes, batch, n, m,
+                               idx, vals)
+
+
+def sample_root(seed, call_id, roots, weights, n, m, default_node=-1):
+    roots = _arr(np.asarray(roots).reshape(-1), np.uint64)
+    weights = _arr(np.asarray(weights).reshape(-1), np.float32)
+    batch = len(roots) // n
+    out = np.zeros(batch * m, np.uint64)
+    lib().eo_sample_root(seed, call_id, _p(roots, _u64p), _p(weights, _f32p), batch,
+                         n, m, default_node, _p(out, _u64p))
+    return out
+
+
+class _LayerwiseMixin:
+    def sparse_get_adj_tf(self, nodes, nb_nodes, edge_types, n=-1, m=-1):
+        """TF SparseGetAdj (tf_euler/kernels/sparse_get_adj_op.cc:43-134):
+        (indices [nnz,3], values [nnz], dense_shape [3])."""
+        nodes = np.asarray(nodes).reshape(-1)
+        nb_nodes = np.asarray(nb_nodes).reshape(-1)
+        if n == -1:
+            n = len(nodes)
+        if m == -1:
+            m = len(nb_nodes)
+        batch = len(nodes) // n if n else 0
+        idx, vals = self.sparse_get_adj(nodes, nb_nodes, batch, n, m, edge_types)
+        return self._adj_to_sparse(nodes, nb_nodes, batch, n, m, idx, vals)
+
+    def sample_neighbor_layerwise(self, seed, call_id, nodes, edge_types, count,
+                                  default_node=-1):
+        """TF SampleNeighborLayerwiseWithAdj with weight_func == '':
+        nodes [batch, n] -> (neighbors [batch, count] int64, indices, values,
+        dense_shape)."""
+        nodes = np.asarray(nodes)
+        batch, n = nodes.shape
+        flat = _arr(nodes.reshape(-1), np.uint64)
+        w = self.get_edge_sum_weight(flat, edge_types)
+        l_root = self._sample_root(seed, call_id, flat, w, n, count, default_node)
+        l_nb, _, _ = self.sample_layer(seed, call_id, l_root, edge_types, default_node)
+        idx, vals = self.sparse_get_adj(flat, l_nb, batch, n, count, edge_types)
+        ind, val, shape = self._adj_to_sparse(flat, l_nb, batch, n, count, idx, vals)
+        return l_nb.view(np.int64).reshape(batch, count), ind, val, shape
+
+class OracleGraph(_LayerwiseMixin):
     """The C restatement bound to one CSR."""
 
     def __init__(self, csr):
@@ -402,6 +501,44 @@ class OracleGraph:
                                    len(et), _p(idx, _i32p), _p(oid, _u64p),
                                    _p(ow, _f32p), _p(ot, _i32p))
         return idx, oid, ow, ot
+
+    # ---- layerwise primitives (C restatement)
+    _adj_to_sparse = staticmethod(adj_to_sparse)
+    _sample_root = staticmethod(sample_root)
+
+    def get_edge_sum_weight(self, ids, edge_types):
+        ids = _arr(ids, np.uint64)
+        et = _arr(edge_types, np.int32)
+        out = np.zeros(len(ids), np.float32)
+        lib().eo_get_edge_sum_weight(self.h, _p(ids, _u64p), len(ids), _p(et, _i32p),
+                                     len(et), _p(out, _f32p))
+        return out
+
+    def sample_layer(self, seed, call_id, roots, edge_types, default_node=-1):
+        roots = _arr(roots, np.uint64)
+        et = _arr(edge_types, np.int32)
+        n = len(roots)
+        oid = np.zeros(n, np.uint64)
+        ow = np.zeros(n, np.float32)
+        ot = np.zeros(n, np.int32)
+        lib().eo_sample_layer(self.h, seed, call_id, _p(roots, _u64p), n,
+                              _p(et, _i32p), len(et), default_node, _p(oid, _u64p),
+                              _p(ow, _f32p), _p(ot, _i32p))
+        return oid, ow, ot
+
+    def sparse_get_adj(self, roots, l_nb, batch, n, m, edge_types):
+        roots = _arr(np.asarray(roots).reshape(-1), np.uint64)
+        l_nb = _arr(np.asarray(l_nb).reshape(-1), np.uint64)
+        et = _arr(edge_types, np.int32)
+        idx = np.zeros((batch * n, 2), np.int32)
+        tot = lib().eo_sparse_get_adj(self.h, _p(roots, _u64p), _p(l_nb, _u64p), batch,
+                                      n, m, _p(et, _i32p), len(et), _p(idx, _i32p),
+                                      None)
+        vals = np.zeros(tot, np.uint64)
+        lib().eo_sparse_get_adj(self.h, _p(roots, _u64p), _p(l_nb, _u64p), batch, n, m,
+                                _p(et, _i32p), len(et), _p(idx, _i32p),
+                                _p(vals, _u64p))
+        return idx, vals
 
     def random_walk(self, seed, call_id, nodes, edge_types, walk_len, p=1.0,
                     q=1.0, default_node=-1):
@@ -632,7 +769,7 @@ def synth_csr(p, row_begin=0, row_end=None):
 # --------------------------------------------------------------------------
 # Reference library (oracle/_ref)
 # --------------------------------------------------------------------------
-class RefGraph:
+class RefGraph(_LayerwiseMixin):
     """The REFERENCE graph singleton, loaded through the harness."""
 
     @staticmethod
@@ -663,6 +800,72 @@ class RefGraph:
 
     def __init__(self, n_types):
         self.n_types = n_types
+
+    # ---- layerwise primitives (reference code through the harness)
+    @staticmethod
+    def load_all(path, n_types):
+        """Node/ and Edge/ partitions through the reference's own loader."""
+        rc = ref().euler_ref_graph_load_all(path.encode())
+        assert rc == 0
+        return RefGraph(n_types)
+
+    def add_edges_from_adjacency(self):
+        return ref().euler_ref_add_edges_from_adjacency()
+
+    def num_edges(self):
+        return ref().euler_ref_num_edges()
+
+    def edge_exist(self, src, dst, etype):
+        return bool(ref().euler_ref_edge_exist(int(src), int(dst), int(etype)))
+
+    @staticmethod
+    def _adj_to_sparse(nodes, nb_nodes, batch, n, m, idx, vals):
+        return _adj_to_sparse_with(ref().euler_ref_adj_to_sparse, nodes, nb_nodes,
+                                   batch, n, m, idx, vals)
+
+    @staticmethod
+    def _sample_root(seed, call_id, roots, weights, n, m, default_node=-1):
+        roots = _arr(np.asarray(roots).reshape(-1), np.uint64)
+        weights = _arr(np.asarray(weights).reshape(-1), np.float32)
+        batch = len(roots) // n
+        out = np.zeros(batch * m, np.uint64)
+        ref().euler_ref_sample_root(seed, call_id, _p(roots, _u64p), _p(weights, _f32p),
+                                    batch, n, m, default_node, _p(out, _u64p))
+        return out
+
+    def get_edge_sum_weight(self, ids, edge_types):
+        ids = _arr(ids, np.uint64)
+        et = _arr(edge_types, np.int32)
+        out = np.zeros(len(ids), np.float32)
+        ref().euler_ref_get_edge_sum_weight(_p(ids, _u64p), len(ids), _p(et, _i32p),
+                                            len(et), _p(out, _f32p))
+        return out
+
+    def sample_layer(self, seed, call_id, roots, edge_types, default_node=-1):
+        roots = _arr(roots, np.uint64)
+        et = _arr(edge_types, np.int32)
+        n = len(roots)
+        oid = np.zeros(n, np.uint64)
+        ow = np.zeros(n, np.float32)
+        ot = np.zeros(n, np.int32)
+        ref().euler_ref_sample_layer(seed, call_id, _p(roots, _u64p), n, _p(et, _i32p),
+                                     len(et), default_node, _p(oid, _u64p),
+                                     _p(ow, _f32p), _p(ot, _i32p))
+        return oid, ow, ot
+
+    def sparse_get_adj(self, roots, l_nb, batch, n, m, edge_types):
+        roots = _arr(np.asarray(roots).reshape(-1), np.uint64)
+        l_nb = _arr(np.asarray(l_nb).reshape(-1), np.uint64)
+        et = _arr(edge_types, np.int32)
+        idx = np.zeros((batch * n, 2), np.int32)
+        tot = ref().euler_ref_sparse_get_adj(_p(roots, _u64p), _p(l_nb, _u64p), batch,
+                                             n, m, _p(et, _i32p), len(et),
+                                             _p(idx, _i32p), None)
+        vals = np.zeros(tot, np.uint64)
+        ref().euler_ref_sparse_get_adj(_p(roots, _u64p), _p(l_nb, _u64p), batch, n, m,
+                                       _p(et, _i32p), len(et), _p(idx, _i32p),
+                                       _p(vals, _u64p))
+        return idx, vals
 
     def get_neighbor(self, ids, edge_types, order_by=None, desc=False, limit=None):
         """The reference's GetFullNeighbor + the post-process of

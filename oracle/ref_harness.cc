@@ -16,11 +16,17 @@
 //   be compiled): the batch loop of api.cc:223-236 (so the RNG context can be
 //   set per root), the empty-row fill of core/kernels/sample_neighbor_op.cc:
 //   134-143, FillNeighbor (core/kernels/common.cc:275-334) and the TF
-//   RandomWalk kernel (tf_euler/kernels/random_walk_op.cc:83-168,207-247).
+//   RandomWalk kernel (tf_euler/kernels/random_walk_op.cc:83-168,207-247);
+//   the bodies of the layerwise ops (core/kernels/get_edge_sum_weight_op.cc,
+//   sample_root_op.cc, sample_layer_op.cc, sparse_get_adj_op.cc) and the
+//   sparse assembly of tf_euler/kernels/sparse_get_adj_op.cc:92-124, each
+//   around the reference's own euler::GetFullNeighbor / SampleNeighbor /
+//   EdgeExist, FastWeightedCollection and std::set.
 #include <stdint.h>
 #include <string.h>
 
 #include <chrono>
+#include <set>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -28,8 +34,10 @@
 
 #include "euler/common/compact_weighted_collection.h"
 #include "euler/common/data_types.h"
+#include "euler/common/fast_weighted_collection.h"
 #include "euler/common/server_register.h"
 #include "euler/core/api/api.h"
+#include "euler/core/graph/edge.h"
 #include "euler/core/graph/graph.h"
 #include "euler/core/graph/node.h"
 
@@ -70,6 +78,9 @@ int euler_ref_graph_clear() {
   auto& g = G();
   for (auto& kv : g.node_map_) delete kv.second;
   g.node_map_.clear();
+  for (auto& kv : g.edge_map_) delete kv.second;
+  g.edge_map_.clear();
+  g.edge_id_map_.clear();
   g.node_samplers_.clear();
   g.node_weight_sums_.clear();
   g.node_type_collection_ = euler::common::FastWeightedCollection<int32_t>();
@@ -539,6 +550,178 @@ double euler_ref_bench_fanout(uint64_t seed, const uint64_t* roots,
   for (auto v : per_thread) total += v;
   *edges = total;
   return std::chrono::duration<double>(t1 - t0).count();
+}
+
+// ---------------------------------------------------------------- layerwise
+// Load Node/ AND Edge/ partitions with the reference's own loader
+// (data type "all"): EdgeExist then consults the Edge records.
+int euler_ref_graph_load_all(const char* dir) {
+  euler_ref_graph_clear();
+  auto s = G().Init(0, 1, "node", dir, "all");
+  return s.ok() ? 0 : -1;
+}
+
+// For graphs built from raw adjacency: one Edge record per (src, dst, type)
+// entry of the node rows - what euler/tools writes for consistent input.
+int64_t euler_ref_add_edges_from_adjacency() {
+  auto& g = G();
+  int64_t added = 0;
+  for (auto& kv : g.node_map_) {
+    euler::Node* node = kv.second;
+    auto& ni = node->neighbor_info_;
+    const int32_t T = (int32_t)ni.neighbor_groups_idx.size();
+    for (int32_t t = 0; t < T; ++t) {
+      int32_t b = t == 0 ? 0 : ni.neighbor_groups_idx[t - 1];
+      for (int32_t j = b; j < ni.neighbor_groups_idx[t]; ++j) {
+        float pre = j == 0 ? 0 : ni.neighbors_weight[j - 1];
+        euler::common::EdgeID eid(kv.first, ni.neighbors[j], t);
+        if (g.edge_map_.find(eid) != g.edge_map_.end()) continue;
+        g.AddEdge(new euler::Edge(kv.first, ni.neighbors[j], t,
+                                  ni.neighbors_weight[j] - pre));
+        ++added;
+      }
+    }
+  }
+  return added;
+}
+
+int64_t euler_ref_num_edges() { return (int64_t)G().edge_map_.size(); }
+
+int euler_ref_edge_exist(uint64_t src, uint64_t dst, int32_t type) {
+  return euler::EdgeExist(euler::EdgeId(src, dst, type)) ? 1 : 0;
+}
+
+// API_GET_EDGE_SUM_WEIGHT body (get_edge_sum_weight_op.cc:51-62).
+void euler_ref_get_edge_sum_weight(const uint64_t* ids, int64_t n,
+                                   const int32_t* edge_types, int32_t k,
+                                   float* out_w) {
+  std::vector<int32_t> et(edge_types, edge_types + k);
+  for (int64_t i = 0; i < n; ++i) {
+    std::vector<uint64_t> roots = {ids[i]};
+    euler::IdWeightPairVec nb = euler::GetFullNeighbor(roots, et);
+    float sum_weight = 0;
+    for (auto& iw : nb[0]) sum_weight += std::get<1>(iw);
+    out_w[i] = sum_weight;
+  }
+}
+
+// API_SAMPLE_ROOT body (sample_root_op.cc:48-86) over the reference's
+// FastWeightedCollection; RNG stream = batch row.
+void euler_ref_sample_root(uint64_t seed, uint32_t call_id, const uint64_t* roots_in,
+                           const float* weights_in, int64_t batch, int32_t n,
+                           int32_t m, int64_t default_node_in, uint64_t* out) {
+  uint64_t default_node = (uint64_t)default_node_in;
+  for (int64_t i = 0; i < batch; ++i) {
+    std::vector<uint64_t> roots(roots_in + i * n, roots_in + (i + 1) * n);
+    std::vector<float> weights(weights_in + i * n, weights_in + (i + 1) * n);
+    euler::common::FastWeightedCollection<uint64_t> fwc;
+    fwc.Init(roots, weights);
+    std::vector<uint64_t> result(m);
+    if (fwc.GetSumWeight() == 0) {
+      for (int32_t j = 0; j < m; ++j) result[j] = default_node;
+    } else {
+      euler_ref_set_rng(seed, call_id, EO_DOMAIN_ROOT, (uint64_t)i);
+      for (int32_t j = 0; j < m; ++j) result[j] = fwc.Sample().first;
+    }
+    std::copy(result.begin(), result.end(), out + i * m);
+  }
+}
+
+// API_SAMPLE_L body (sample_layer_op.cc:54-70); RNG stream = position.
+void euler_ref_sample_layer(uint64_t seed, uint32_t call_id, const uint64_t* l_root,
+                            int64_t n, const int32_t* edge_types, int32_t k,
+                            int64_t default_node, uint64_t* out_id, float* out_w,
+                            int32_t* out_t) {
+  std::vector<int32_t> et(edge_types, edge_types + k);
+  for (int64_t i = 0; i < n; ++i) {
+    std::vector<uint64_t> roots = {l_root[i]};
+    euler_ref_set_rng(seed, call_id, EO_DOMAIN_LAYER, (uint64_t)i);
+    euler::IdWeightPairVec nb = euler::SampleNeighbor(roots, et, 1);
+    if (nb[0].empty()) {
+      out_id[i] = (uint64_t)default_node; out_w[i] = 0; out_t[i] = 0;
+    } else {
+      out_id[i] = std::get<0>(nb[0][0]);
+      out_w[i] = std::get<1>(nb[0][0]);
+      out_t[i] = std::get<2>(nb[0][0]);
+    }
+  }
+}
+
+// API_SPARSE_GEN_ADJ + API_SPARSE_GET_ADJ bodies (sparse_gen_adj_op.cc:52-61,
+// sparse_get_adj_op.cc:55-91) over the reference's EdgeExist.  out_id == NULL
+// sizes the result.
+int64_t euler_ref_sparse_get_adj(const uint64_t* roots, const uint64_t* l_nb,
+                                 int64_t batch, int32_t n, int32_t m,
+                                 const int32_t* edge_types, int32_t k,
+                                 int32_t* idx, uint64_t* out_id) {
+  std::vector<int32_t> et(edge_types, edge_types + k);
+  size_t root_num = (size_t)(batch * n);
+  std::vector<std::vector<uint64_t>> adj(root_num);
+  for (size_t i = 0; i < root_num; ++i) {
+    uint64_t root_id = roots[i];
+    int32_t batch_num = (int32_t)(i / n);
+    int32_t l_nb_batch_begin = batch_num * m;
+    for (int32_t j = 0; j < m; ++j) {
+      uint64_t nb_id = l_nb[l_nb_batch_begin + j];
+      bool exist = false;
+      for (int32_t e_type : et) {
+        euler::EdgeId eid(root_id, nb_id, e_type);
+        exist = exist || euler::EdgeExist(eid);
+      }
+      if (exist) adj[i].push_back(nb_id);
+    }
+  }
+  int32_t offset = 0;
+  for (size_t i = 0; i < root_num; ++i) {
+    if (idx) { idx[i * 2] = offset; idx[i * 2 + 1] = offset + (int32_t)adj[i].size(); }
+    if (out_id) std::copy(adj[i].begin(), adj[i].end(), out_id + offset);
+    offset += (int32_t)adj[i].size();
+  }
+  return offset;
+}
+
+// Sparse assembly of the TF kernels (tf_euler/kernels/sparse_get_adj_op.cc:
+// 92-124 = sample_neighbor_layerwise_with_adj_op.cc:112-140) with the same
+// std::set and the SparseTensorBuilder shape rule (tf_euler/utils/
+// sparse_tensor_builder.h:30-40).  indices == NULL sizes the result.
+int64_t euler_ref_adj_to_sparse(const uint64_t* nodes, const uint64_t* nb_nodes,
+                                int64_t batch_size, int32_t N, int32_t M,
+                                const int32_t* idx_data, const uint64_t* val_data,
+                                int64_t* indices, int64_t* values, int64_t* shape) {
+  std::set<std::pair<int64_t, int64_t>> relation_set;
+  int64_t nnz = 0;
+  int64_t dense_shape[3] = {0, 0, 0};
+  auto emplace = [&](int64_t a, int64_t b, int64_t c, int64_t v) {
+    const int64_t ix[3] = {a, b, c};
+    for (int d = 0; d < 3; ++d) {
+      if (indices) indices[3 * nnz + d] = ix[d];
+      if (ix[d] + 1 > dense_shape[d]) dense_shape[d] = ix[d] + 1;
+    }
+    if (values) values[nnz] = v;
+    ++nnz;
+  };
+  for (int64_t i = 0; i < batch_size; ++i) {
+    relation_set.clear();
+    for (int64_t j = N * i; j < N * (i + 1); ++j) {
+      int32_t begin = idx_data[j * 2];
+      int32_t end = idx_data[j * 2 + 1];
+      for (int32_t k = begin; k < end; ++k)
+        relation_set.insert(std::make_pair((int64_t)nodes[j], (int64_t)val_data[k]));
+    }
+    for (int64_t j = 0; j < N; ++j) {
+      int64_t src_id = (int64_t)nodes[j + N * i];
+      for (int64_t k = 0; k < M; ++k) {
+        int64_t dst_id = (int64_t)nb_nodes[k + M * i];
+        if (relation_set.find(std::make_pair(src_id, dst_id)) != relation_set.end()) {
+          emplace(i, j, k, 1);
+        } else if (j == N - 1 && k == M - 1) {
+          emplace(i, j, k, 0);
+        }
+      }
+    }
+  }
+  if (shape) { shape[0] = dense_shape[0]; shape[1] = dense_shape[1]; shape[2] = dense_shape[2]; }
+  return nnz;
 }
 
 }  // extern "C"

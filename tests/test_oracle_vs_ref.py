@@ -136,3 +136,107 @@ def test_neighbor_post_process_matches_reference_sort(O):
             b = R.get_neighbor(q, et, order_by, desc, limit)
             for x, y in zip(a, b):
                 assert np.array_equal(x, y), (et, order_by, desc, limit)
+
+
+# ------------------------------------------------------------------ layerwise
+@pytest.fixture(scope="module")
+def lpair(O):
+    """Own graph pair: the reference graph is a process-wide singleton and the
+    tests above rebuild it, so it is (re)built here, with Edge records."""
+    if not O.have_ref():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    rng = np.random.default_rng(4048)
+    ids, seg, nbr, w, nt, nw = make_random_graph(rng, 3000, 4, max_deg=20)
+    R = O.RefGraph.build_raw(ids, seg, nbr, w, 4, nt, nw)
+    assert R.add_edges_from_adjacency() > 0
+    return R, O.OracleGraph(O.csr_from_raw(ids, seg, nbr, w, 4, nt, nw)), ids, rng
+
+
+def _layer_batches(rng, ids, batch, n, dup=True):
+    nodes = rng.choice(ids, (batch, n)).astype(np.uint64)
+    if dup:                       # duplicates inside a row, an unknown id, a 0
+        nodes[0, 1] = nodes[0, 0]
+        nodes[1, 0] = 2 ** 62 + 3
+        nodes[-1, -1] = 0
+    return nodes
+
+
+@pytest.mark.parametrize("et", [[0], [3], [1, 2], [3, 0, 1], [0, 1, 2, 3], [],
+                                [9], [1, 9]])
+def test_layerwise_primitives_match_reference(lpair, et):
+    R, G, ids, rng = lpair
+    q = np.concatenate([rng.choice(ids, 500), [0, 2 ** 63 + 5]]).astype(np.uint64)
+    a, b = R.get_edge_sum_weight(q, et), G.get_edge_sum_weight(q, et)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    for call, dn in ((0, -1), (5, 424242)):
+        x = R.sample_layer(7, call, q, et, dn)
+        y = G.sample_layer(7, call, q, et, dn)
+        for u, v in zip(x, y):
+            assert np.array_equal(u, v)
+    # a position-keyed stream: the same root at two positions draws twice
+    rep = np.repeat(q[:1], 64)
+    ids_rep = G.sample_layer(7, 1, rep, [0, 1, 2, 3], -1)[0]
+    if G.get_edge_sum_weight(q[:1], [0, 1, 2, 3])[0] > 0 and \
+            len(set(G.get_full_neighbor(q[:1], [0, 1, 2, 3])[1].tolist())) > 1:
+        assert len(set(ids_rep.tolist())) > 1
+
+
+def test_sample_root_matches_reference(lpair, O):
+    R, G, ids, rng = lpair
+    for n, m in ((1, 3), (2, 5), (7, 16), (64, 10), (301, 33)):
+        batch = 9
+        roots = rng.choice(ids, (batch, n)).astype(np.uint64)
+        w = (rng.random((batch, n)) * 5).astype(np.float32)
+        w[rng.random((batch, n)) < 0.3] = 0
+        w[2] = 0                                     # zero-sum row -> default node
+        if n > 2:
+            w[3] = 0; w[3, 1] = 2.5                  # a single heavy entry
+            w[4] = 1.0                               # uniform weights
+        for call, dn in ((0, -1), (3, 77)):
+            a = R._sample_root(11, call, roots, w, n, m, dn)
+            b = O.sample_root(11, call, roots, w, n, m, dn)
+            assert np.array_equal(a, b), (n, m)
+            assert np.all(b.reshape(batch, m)[2] == np.uint64(dn & (2 ** 64 - 1)))
+
+
+def test_sparse_get_adj_matches_reference(lpair):
+    R, G, ids, rng = lpair
+    assert R.num_edges() > 0
+    # EdgeExist from the reference's Edge map == membership in the adjacency rows
+    csr = G.csr
+    for r in rng.choice(len(csr.row_id), 50):
+        src = int(csr.row_id[r])
+        full = G.get_full_neighbor(np.array([src], np.uint64), [0, 1, 2, 3])
+        for dst, t in zip(full[1][:6], full[3][:6]):
+            assert R.edge_exist(src, int(dst), int(t))
+        assert not R.edge_exist(src, 2 ** 61 + 1, 0)
+    for batch, n, m in ((1, 5, 7), (3, 4, 70), (2, 1, 1), (4, 9, 130)):
+        nodes = _layer_batches(rng, ids, batch, n, dup=n > 1 and batch > 1)
+        # candidates: real neighbours of the row's nodes mixed with random ids
+        cand = rng.choice(ids, (batch, m)).astype(np.uint64)
+        for b in range(batch):
+            nb = G.get_full_neighbor(nodes[b], [0, 1, 2, 3])[1]
+            if len(nb):
+                take = rng.choice(nb, m // 2 + 1)
+                cand[b, :len(take)] = take
+        for et in ([0], [1, 3], [0, 1, 2, 3], [], [9]):
+            x = R.sparse_get_adj(nodes, cand, batch, n, m, et)
+            y = G.sparse_get_adj(nodes, cand, batch, n, m, et)
+            assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
+            sx = R._adj_to_sparse(nodes, cand, batch, n, m, *x)
+            sy = G._adj_to_sparse(nodes, cand, batch, n, m, *y)
+            for u, v in zip(sx, sy):
+                assert np.array_equal(u, v)
+            assert list(sy[2]) == [batch, n, m]
+
+
+def test_sample_neighbor_layerwise_matches_reference(lpair):
+    R, G, ids, rng = lpair
+    for batch, n, count in ((4, 3, 10), (2, 16, 5), (6, 1, 4)):
+        nodes = _layer_batches(rng, ids, batch, n, dup=n > 1)
+        for et in ([0], [0, 1], [0, 1, 2, 3]):
+            for call, dn in ((0, -1), (9, 31337)):
+                x = R.sample_neighbor_layerwise(21, call, nodes, et, count, dn)
+                y = G.sample_neighbor_layerwise(21, call, nodes, et, count, dn)
+                for u, v in zip(x, y):
+                    assert np.array_equal(u, v)
