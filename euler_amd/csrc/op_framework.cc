@@ -66,7 +66,20 @@ std::string OutputName(const NodeDef& node_def, int i) {
 }
 
 OpKernelContext::~OpKernelContext() {
-  for (auto& kv : tensor_map_) delete kv.second;
+  // aliases share a tensor: free every distinct pointer once
+  std::vector<Tensor*> seen;
+  for (auto& kv : tensor_map_) {
+    bool dup = false;
+    for (Tensor* t : seen) dup = dup || t == kv.second;
+    if (!dup) { seen.push_back(kv.second); delete kv.second; }
+  }
+}
+
+int OpKernelContext::AddAlias(const std::string& name, Tensor* tensor) {
+  std::lock_guard<std::mutex> lk(mu_);
+  if (tensor_map_.count(name)) return -1;
+  tensor_map_[name] = tensor;
+  return 0;
 }
 
 int OpKernelContext::Allocate(const std::string& name, const TensorShape& shape,
@@ -90,8 +103,11 @@ int OpKernelContext::Deallocate(const std::string& name) {
   std::lock_guard<std::mutex> lk(mu_);
   auto it = tensor_map_.find(name);
   if (it == tensor_map_.end()) return -1;
-  delete it->second;
+  Tensor* t = it->second;
   tensor_map_.erase(it);
+  for (auto& kv : tensor_map_)
+    if (kv.second == t) return 0;      // still reachable through an alias
+  delete t;
   return 0;
 }
 
@@ -382,6 +398,247 @@ class GpuGetNeighborOp : public OpKernel {
 };
 REGISTER_OP_KERNEL("API_GET_NB_NODE", GpuGetNeighborOp);
 
+// ------------------------------------------------------- layerwise chain
+// The DAG of `v(nodes).sampleLNB(edge_types, n, m, default_node)`
+// (euler/parser/translator.cc:338-386,489-527).  Literal attributes
+// (default_node) arrive as the input STRING itself, as in the reference
+// (`atol(node_def.inputs(i).c_str())`).
+
+// API_GET_EDGE_SUM_WEIGHT (core/kernels/get_edge_sum_weight_op.cc:33-66):
+// inputs roots (uint64), edge_types; outputs ":0" roots [n,1], ":1" sums [n,1].
+class GpuGetEdgeSumWeightOp : public OpKernel {
+ public:
+  explicit GpuGetEdgeSumWeightOp(const std::string& name) : OpKernel(name) {}
+  void Compute(const NodeDef& nd, OpKernelContext* ctx) override {
+    Tensor* root_t = nullptr;
+    std::vector<int32_t> et;
+    if (nd.inputs.size() < 2 || ctx->tensor(nd.inputs[0], &root_t) != 0 ||
+        !GetIntArg(nd, 1, ctx, &et)) { LogError("API_GET_EDGE_SUM_WEIGHT: bad inputs"); return; }
+    euler_gpu_graph* g = ctx->graph();
+    if (!g) { LogError("API_GET_EDGE_SUM_WEIGHT: no graph initialised"); return; }
+    const int64_t n = root_t->NumElements();
+    (void)hipSetDevice(euler_gpu_graph_device(g));
+    DevBuf d_ids(n * 8), d_w(n * 4);
+    if (!d_ids.p || !d_w.p) { LogError("API_GET_EDGE_SUM_WEIGHT: device allocation failed"); return; }
+    (void)hipMemcpy(d_ids.p, root_t->Raw<uint64_t>(), n * 8, hipMemcpyHostToDevice);
+    if (euler_gpu_get_edge_sum_weight(g, nullptr, d_ids.as<uint64_t>(), n, et.data(),
+                                      (int32_t)et.size(), d_w.as<float>()) != 0) {
+      LogError(std::string("API_GET_EDGE_SUM_WEIGHT: ") + euler_gpu_last_error());
+      return;
+    }
+    Tensor *o_root = nullptr, *o_w = nullptr;
+    if (ctx->Allocate(OutputName(nd, 0), {(size_t)n, 1}, kUInt64, &o_root) != 0 ||
+        ctx->Allocate(OutputName(nd, 1), {(size_t)n, 1}, kFloat, &o_w) != 0) {
+      LogError("Allocate output tensor failed!");
+      return;
+    }
+    memcpy(o_root->Raw<uint64_t>(), root_t->Raw<uint64_t>(), (size_t)n * 8);
+    (void)hipMemcpy(o_w->Raw<float>(), d_w.p, n * 4, hipMemcpyDeviceToHost);
+  }
+};
+REGISTER_OP_KERNEL("API_GET_EDGE_SUM_WEIGHT", GpuGetEdgeSumWeightOp);
+
+// API_SAMPLE_ROOT (core/kernels/sample_root_op.cc:33-88): inputs roots,
+// weights, n, m, default_node (literal); output ":0" [batch * m] uint64.
+class GpuSampleRootOp : public OpKernel {
+ public:
+  explicit GpuSampleRootOp(const std::string& name) : OpKernel(name) {}
+  void Compute(const NodeDef& nd, OpKernelContext* ctx) override {
+    Tensor *roots_t = nullptr, *w_t = nullptr;
+    std::vector<int32_t> n_v, m_v;
+    if (nd.inputs.size() < 5 || ctx->tensor(nd.inputs[0], &roots_t) != 0 ||
+        ctx->tensor(nd.inputs[1], &w_t) != 0 || !GetIntArg(nd, 2, ctx, &n_v) ||
+        !GetIntArg(nd, 3, ctx, &m_v) || n_v.empty() || m_v.empty() || n_v[0] <= 0) {
+      LogError("API_SAMPLE_ROOT: bad inputs");
+      return;
+    }
+    const int64_t default_node = atol(nd.inputs[4].c_str());
+    const int32_t n = n_v[0], m = m_v[0];
+    const int64_t batch = roots_t->NumElements() / n;
+    if (batch == 0) { LogError("batch size is zero!"); abort(); }   // EULER_LOG(FATAL)
+    const int64_t cells = batch * n, draws = batch * m;
+    euler_gpu_graph* g = ctx->graph();
+    if (g) (void)hipSetDevice(euler_gpu_graph_device(g));
+    DevBuf d_r(cells * 8), d_w(cells * 4), d_o(draws * 8);
+    if (!d_r.p || !d_w.p || !d_o.p) { LogError("API_SAMPLE_ROOT: device allocation failed"); return; }
+    (void)hipMemcpy(d_r.p, roots_t->Raw<uint64_t>(), cells * 8, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_w.p, w_t->Raw<float>(), cells * 4, hipMemcpyHostToDevice);
+    if (euler_gpu_sample_root(nullptr, ctx->seed(), ctx->NextCallId(), d_r.as<uint64_t>(),
+                              d_w.as<float>(), batch, n, m, default_node,
+                              d_o.as<uint64_t>()) != 0) {
+      LogError(std::string("API_SAMPLE_ROOT: ") + euler_gpu_last_error());
+      return;
+    }
+    Tensor* out = nullptr;
+    if (ctx->Allocate(OutputName(nd, 0), {(size_t)draws}, kUInt64, &out) != 0) {
+      LogError("Allocate output tensor failed!");
+      return;
+    }
+    (void)hipMemcpy(out->Raw<uint64_t>(), d_o.p, draws * 8, hipMemcpyDeviceToHost);
+  }
+};
+REGISTER_OP_KERNEL("API_SAMPLE_ROOT", GpuSampleRootOp);
+
+// API_SAMPLE_L (core/kernels/sample_layer_op.cc:32-72): inputs l_root,
+// edge_types, default_node (literal); outputs ":0" ids, ":1" weights,
+// ":2" types, each [n, 1].
+class GpuSampleLayerOp : public OpKernel {
+ public:
+  explicit GpuSampleLayerOp(const std::string& name) : OpKernel(name) {}
+  void Compute(const NodeDef& nd, OpKernelContext* ctx) override {
+    Tensor* root_t = nullptr;
+    std::vector<int32_t> et;
+    if (nd.inputs.size() < 3 || ctx->tensor(nd.inputs[0], &root_t) != 0 ||
+        !GetIntArg(nd, 1, ctx, &et)) { LogError("API_SAMPLE_L: bad inputs"); return; }
+    const int64_t default_node = atol(nd.inputs[2].c_str());
+    euler_gpu_graph* g = ctx->graph();
+    if (!g) { LogError("API_SAMPLE_L: no graph initialised"); return; }
+    const int64_t n = root_t->NumElements();
+    (void)hipSetDevice(euler_gpu_graph_device(g));
+    DevBuf d_r(n * 8), d_id(n * 8), d_w(n * 4), d_t(n * 4);
+    if (!d_r.p || !d_id.p || !d_w.p || !d_t.p) { LogError("API_SAMPLE_L: device allocation failed"); return; }
+    (void)hipMemcpy(d_r.p, root_t->Raw<uint64_t>(), n * 8, hipMemcpyHostToDevice);
+    if (euler_gpu_sample_layer(g, nullptr, ctx->seed(), ctx->NextCallId(),
+                               d_r.as<uint64_t>(), n, et.data(), (int32_t)et.size(),
+                               default_node, d_id.as<uint64_t>(), d_w.as<float>(),
+                               d_t.as<int32_t>()) != 0) {
+      LogError(std::string("API_SAMPLE_L: ") + euler_gpu_last_error());
+      return;
+    }
+    Tensor *o_nb = nullptr, *o_w = nullptr, *o_t = nullptr;
+    if (ctx->Allocate(OutputName(nd, 0), {(size_t)n, 1}, kUInt64, &o_nb) != 0 ||
+        ctx->Allocate(OutputName(nd, 1), {(size_t)n, 1}, kFloat, &o_w) != 0 ||
+        ctx->Allocate(OutputName(nd, 2), {(size_t)n, 1}, kInt32, &o_t) != 0) {
+      LogError("Allocate output tensor failed!");
+      return;
+    }
+    (void)hipMemcpy(o_nb->Raw<uint64_t>(), d_id.p, n * 8, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(o_w->Raw<float>(), d_w.p, n * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(o_t->Raw<int32_t>(), d_t.p, n * 4, hipMemcpyDeviceToHost);
+  }
+};
+REGISTER_OP_KERNEL("API_SAMPLE_L", GpuSampleLayerOp);
+
+// API_SPARSE_GEN_ADJ (core/kernels/sparse_gen_adj_op.cc:35-64): host-only
+// reshaping - (root id, batch row) pairs + an alias of l_nb.
+class SparseGenAdjOp : public OpKernel {
+ public:
+  explicit SparseGenAdjOp(const std::string& name) : OpKernel(name) {}
+  void Compute(const NodeDef& nd, OpKernelContext* ctx) override {
+    Tensor *roots_t = nullptr, *l_nb_t = nullptr;
+    std::vector<int32_t> n_v;
+    if (nd.inputs.size() < 3 || ctx->tensor(nd.inputs[0], &roots_t) != 0 ||
+        ctx->tensor(nd.inputs[1], &l_nb_t) != 0 || !GetIntArg(nd, 2, ctx, &n_v) ||
+        n_v.empty() || n_v[0] <= 0) { LogError("API_SPARSE_GEN_ADJ: bad inputs"); return; }
+    const int32_t n = n_v[0];
+    const int32_t batch = roots_t->NumElements() / n;
+    if (batch == 0) { LogError("batch size is zero!"); abort(); }
+    Tensor* rb = nullptr;
+    if (ctx->Allocate(OutputName(nd, 0), {(size_t)roots_t->NumElements(), 2}, kUInt64, &rb) != 0) {
+      LogError("Allocate output tensor failed!");
+      return;
+    }
+    for (int32_t i = 0; i < batch; ++i)
+      for (int32_t j = 0; j < n; ++j) {
+        const int32_t cnt = i * n + j;
+        rb->Raw<uint64_t>()[cnt * 2] = roots_t->Raw<uint64_t>()[cnt];
+        rb->Raw<uint64_t>()[cnt * 2 + 1] = (uint64_t)i;
+      }
+    ctx->AddAlias(OutputName(nd, 1), l_nb_t);
+  }
+};
+REGISTER_OP_KERNEL("API_SPARSE_GEN_ADJ", SparseGenAdjOp);
+
+// API_SPARSE_GET_ADJ (core/kernels/sparse_get_adj_op.cc:35-92): inputs
+// root_batch [R,2] (id, batch row), l_nb, edge_types, m; outputs ":0" idx
+// [R,2] int32, ":1" ids.  The device entry point takes the batch row as
+// r / n, which is what API_SPARSE_GEN_ADJ writes; any other root_batch is
+// rejected.
+class GpuSparseGetAdjOp : public OpKernel {
+ public:
+  explicit GpuSparseGetAdjOp(const std::string& name) : OpKernel(name) {}
+  void Compute(const NodeDef& nd, OpKernelContext* ctx) override {
+    Tensor *rb_t = nullptr, *l_nb_t = nullptr;
+    std::vector<int32_t> et, m_v;
+    if (nd.inputs.size() < 4 || ctx->tensor(nd.inputs[0], &rb_t) != 0 ||
+        ctx->tensor(nd.inputs[1], &l_nb_t) != 0 || !GetIntArg(nd, 2, ctx, &et) ||
+        !GetIntArg(nd, 3, ctx, &m_v) || m_v.empty() || m_v[0] < 0) {
+      LogError("API_SPARSE_GET_ADJ: bad inputs");
+      return;
+    }
+    euler_gpu_graph* g = ctx->graph();
+    if (!g) { LogError("API_SPARSE_GET_ADJ: no graph initialised"); return; }
+    const int32_t m = m_v[0];
+    const int64_t R = rb_t->NumElements() / 2;
+    const uint64_t* rb = rb_t->Raw<uint64_t>();
+    const int64_t batch = R ? (int64_t)rb[2 * (R - 1) + 1] + 1 : 0;
+    const int64_t n = batch ? R / batch : 0;
+    bool regular = batch > 0 && n * batch == R &&
+                   (int64_t)l_nb_t->NumElements() >= batch * m;
+    std::vector<uint64_t> roots((size_t)R);
+    for (int64_t r = 0; r < R && regular; ++r) {
+      roots[r] = rb[2 * r];
+      regular = (int64_t)rb[2 * r + 1] == r / n;
+    }
+    if (R > 0 && !regular) { LogError("API_SPARSE_GET_ADJ: root_batch is not API_SPARSE_GEN_ADJ's"); return; }
+    int64_t total = 0;
+    std::vector<int32_t> idx((size_t)R * 2);
+    std::vector<uint64_t> vals;
+    if (R > 0) {
+      (void)hipSetDevice(euler_gpu_graph_device(g));
+      DevBuf d_r(R * 8), d_nb((size_t)batch * m * 8), d_idx(R * 8);
+      if (!d_r.p || !d_nb.p || !d_idx.p) { LogError("API_SPARSE_GET_ADJ: device allocation failed"); return; }
+      (void)hipMemcpy(d_r.p, roots.data(), R * 8, hipMemcpyHostToDevice);
+      (void)hipMemcpy(d_nb.p, l_nb_t->Raw<uint64_t>(), (size_t)batch * m * 8, hipMemcpyHostToDevice);
+      if (euler_gpu_sparse_get_adj(g, nullptr, d_r.as<uint64_t>(), d_nb.as<uint64_t>(), batch,
+                                   (int32_t)n, m, et.data(), (int32_t)et.size(),
+                                   d_idx.as<int32_t>(), &total, nullptr) != 0) {
+        LogError(std::string("API_SPARSE_GET_ADJ: ") + euler_gpu_last_error());
+        return;
+      }
+      DevBuf d_v((size_t)total * 8);
+      if (!d_v.p) { LogError("API_SPARSE_GET_ADJ: device allocation failed"); return; }
+      if (total > 0 &&
+          euler_gpu_sparse_get_adj(g, nullptr, d_r.as<uint64_t>(), d_nb.as<uint64_t>(), batch,
+                                   (int32_t)n, m, et.data(), (int32_t)et.size(),
+                                   d_idx.as<int32_t>(), &total, d_v.as<uint64_t>()) != 0) {
+        LogError(std::string("API_SPARSE_GET_ADJ: ") + euler_gpu_last_error());
+        return;
+      }
+      (void)hipDeviceSynchronize();
+      vals.resize((size_t)total);
+      (void)hipMemcpy(idx.data(), d_idx.p, R * 8, hipMemcpyDeviceToHost);
+      if (total) (void)hipMemcpy(vals.data(), d_v.p, (size_t)total * 8, hipMemcpyDeviceToHost);
+    }
+    Tensor *o_idx = nullptr, *o_data = nullptr;
+    if (ctx->Allocate(OutputName(nd, 0), {(size_t)R, 2}, kInt32, &o_idx) != 0 ||
+        ctx->Allocate(OutputName(nd, 1), {(size_t)total}, kUInt64, &o_data) != 0) {
+      LogError("Allocate output tensor failed!");
+      return;
+    }
+    if (R) memcpy(o_idx->Raw<int32_t>(), idx.data(), (size_t)R * 8);
+    if (total) memcpy(o_data->Raw<uint64_t>(), vals.data(), (size_t)total * 8);
+  }
+};
+REGISTER_OP_KERNEL("API_SPARSE_GET_ADJ", GpuSparseGetAdjOp);
+
+// API_GATHER_RESULT (core/kernels/gather_result_op.cc:25-47): three aliases.
+class GatherResultOp : public OpKernel {
+ public:
+  explicit GatherResultOp(const std::string& name) : OpKernel(name) {}
+  void Compute(const NodeDef& nd, OpKernelContext* ctx) override {
+    for (int i = 0; i < 3; ++i) {
+      Tensor* t = nullptr;
+      if ((int)nd.inputs.size() <= i || ctx->tensor(nd.inputs[i], &t) != 0) {
+        LogError("API_GATHER_RESULT: missing input");
+        return;
+      }
+      ctx->AddAlias(OutputName(nd, i), t);
+    }
+  }
+};
+REGISTER_OP_KERNEL("API_GATHER_RESULT", GatherResultOp);
+
 }  // namespace euler
 
 extern "C" {
@@ -464,6 +721,64 @@ int64_t euler_op_run_get_nb(euler_gpu_graph* g, const uint64_t* node_ids, int64_
   memcpy(w_out, ow->Raw<float>(), ow->TotalBytes());
   memcpy(t_out, ot->Raw<int32_t>(), ot->TotalBytes());
   return oid->NumElements();
+}
+
+// Runs the DAG the reference's translator builds for
+// `v(nodes).sampleLNB(edge_types, n, m, default_node).as(nb)` (euler/parser/
+// translator.cc:338-386,489-527) through the plugin API on host tensors:
+// nb:0 = adjacency idx [batch*n, 2], nb:1 = adjacency ids (<= capacity),
+// nb:2 = the sampled layer [batch*m].  Returns the number of adjacency ids or
+// < 0.  call ids: API_SAMPLE_ROOT takes the context's next one, API_SAMPLE_L
+// the one after.
+int64_t euler_op_run_sample_lnb(euler_gpu_graph* g, uint64_t seed, uint32_t first_call_id,
+                                const uint64_t* node_ids, int64_t batch, int32_t n,
+                                const int32_t* edge_types, int32_t k, int32_t m,
+                                int64_t default_node, int64_t capacity,
+                                int32_t* adj_idx_out, uint64_t* adj_id_out,
+                                uint64_t* l_nb_out) {
+  using namespace euler;
+  OpKernelContext ctx;
+  ctx.SetGraph(g);
+  ctx.SetSeed(seed);
+  for (uint32_t i = 0; i < first_call_id; ++i) ctx.NextCallId();
+  const int64_t R = batch * n;
+  Tensor *t_ids = nullptr, *t_et = nullptr, *t_n = nullptr, *t_m = nullptr;
+  ctx.Allocate("nodes", {(size_t)R}, kUInt64, &t_ids);
+  ctx.Allocate("edge_types", {(size_t)k}, kInt32, &t_et);
+  ctx.Allocate("n", {1}, kInt32, &t_n);
+  ctx.Allocate("m", {1}, kInt32, &t_m);
+  memcpy(t_ids->Raw<uint64_t>(), node_ids, (size_t)R * 8);
+  if (k) memcpy(t_et->Raw<int32_t>(), edge_types, (size_t)k * 4);
+  *t_n->Raw<int32_t>() = n;
+  *t_m->Raw<int32_t>() = m;
+  const std::string dn = std::to_string(default_node);
+  const NodeDef dag[] = {
+      {"API_GET_EDGE_SUM_WEIGHT,0", "API_GET_EDGE_SUM_WEIGHT", {"nodes", "edge_types"}, {}},
+      {"API_SAMPLE_ROOT,1", "API_SAMPLE_ROOT",
+       {"API_GET_EDGE_SUM_WEIGHT,0:0", "API_GET_EDGE_SUM_WEIGHT,0:1", "n", "m", dn}, {}},
+      {"API_SAMPLE_L,2", "API_SAMPLE_L", {"API_SAMPLE_ROOT,1:0", "edge_types", dn}, {}},
+      {"API_SPARSE_GEN_ADJ,3", "API_SPARSE_GEN_ADJ",
+       {"API_GET_EDGE_SUM_WEIGHT,0:0", "API_SAMPLE_L,2:0", "n"}, {}},
+      {"API_SPARSE_GET_ADJ,4", "API_SPARSE_GET_ADJ",
+       {"API_SPARSE_GEN_ADJ,3:0", "API_SPARSE_GEN_ADJ,3:1", "edge_types", "m"}, {}},
+      {"API_GATHER_RESULT,5", "API_GATHER_RESULT",
+       {"API_SPARSE_GET_ADJ,4:0", "API_SPARSE_GET_ADJ,4:1", "API_SAMPLE_L,2:0"}, {}},
+  };
+  for (const NodeDef& nd : dag) {
+    OpKernel* kernel = nullptr;
+    if (CreateOpKernel(nd.op, &kernel) != 0) return -1;
+    kernel->Compute(nd, &ctx);
+  }
+  Tensor *idx = nullptr, *ids = nullptr, *l_nb = nullptr;
+  if (ctx.tensor("API_GATHER_RESULT,5:0", &idx) != 0 ||
+      ctx.tensor("API_GATHER_RESULT,5:1", &ids) != 0 ||
+      ctx.tensor("API_GATHER_RESULT,5:2", &l_nb) != 0)
+    return -2;   // an op logged an error and produced no output
+  if (ids->NumElements() > capacity) return -3;
+  memcpy(adj_idx_out, idx->Raw<int32_t>(), idx->TotalBytes());
+  memcpy(adj_id_out, ids->Raw<uint64_t>(), ids->TotalBytes());
+  memcpy(l_nb_out, l_nb->Raw<uint64_t>(), l_nb->TotalBytes());
+  return ids->NumElements();
 }
 
 }  // extern "C"

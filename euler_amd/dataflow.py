@@ -182,3 +182,108 @@ class RelationDataFlow(object):
 
     def __call__(self, n_id):
         return self.produce_subgraph(n_id)
+
+
+class NeighborDataFlow(object):
+    """neighbor_dataflow.py:24-75: blocks over the hop results as they are (no
+    dedup between hops)."""
+
+    def __init__(self, num_hops, add_self_loops=True):
+        self.num_hops = num_hops
+        self.add_self_loops = add_self_loops
+
+    def get_neighbors(self, n_id):
+        raise NotImplementedError()
+
+    def produce_subgraph(self, n_id):
+        n_id = n_id.reshape(-1)
+        dev = n_id.device
+        last_idx = torch.arange(n_id.numel(), device=dev)
+        data_flow = DataFlow(n_id)
+        n_neighbors, n_edge_src = self.get_neighbors(n_id)
+        for i in range(self.num_hops):
+            edge_src = n_edge_src[i].to(torch.int64)
+            n_prev = n_id.numel()
+            new_n_id = torch.cat([n_neighbors[i], n_id])
+            new_inv = torch.arange(new_n_id.numel(), device=dev)
+            res_n_id = new_inv[new_inv.numel() - n_prev:]
+            if self.add_self_loops:
+                edge_src = torch.cat([edge_src, last_idx])
+                last_idx = new_inv
+            else:
+                new_inv = new_inv[:new_inv.numel() - n_prev]
+                last_idx = new_inv
+            n_id = new_n_id
+            edge_index = torch.stack([edge_src, new_inv], 0)
+            data_flow.append(new_n_id, res_n_id, None, edge_index)
+        return data_flow
+
+    def __call__(self, n_id):
+        return self.produce_subgraph(n_id)
+
+
+class LayerwiseDataFlow(UniqueDataFlow):
+    """layerwise_dataflow.py:26-62: every hop but the last draws
+    sum(fanouts[:i+1]) nodes for the whole current node set with
+    sample_neighbor_layerwise (one batch row) and keeps the (source, sampled
+    node) pairs that are edges; the last hop takes full neighbours."""
+
+    def __init__(self, graph, fanouts, metapath, add_self_loops=True):
+        super(LayerwiseDataFlow, self).__init__(len(metapath), add_self_loops)
+        self.graph = graph
+        self.fanouts = fanouts
+        self.metapath = metapath
+
+    def get_neighbors(self, n_id):
+        neighbors, neighbor_src = [], []
+        total_fanout = 0
+        for i in range(len(self.metapath)):
+            if i == len(self.metapath) - 1:
+                one_neighbor, one_indices, _t = _full_neighbor_coo(
+                    self.graph, n_id.reshape(-1), self.metapath[i])
+            else:
+                total_fanout += self.fanouts[i]
+                unique_neighbor, (ind, _val, _shape) = \
+                    self.graph.sample_neighbor_layerwise(
+                        n_id.reshape(1, -1), self.metapath[i], total_fanout)
+                # the reference gathers through EVERY stored entry, the explicit
+                # zero at (0, n-1, m-1) included (layerwise_dataflow.py:48-51)
+                one_neighbor = unique_neighbor.reshape(-1)[ind[:, 2]]
+                one_indices = ind[:, 1]
+            neighbors.append(one_neighbor.reshape(-1))
+            neighbor_src.append(one_indices)
+            n_id, _ = _unique(torch.cat([one_neighbor.reshape(-1), n_id.reshape(-1)]))
+        return neighbors, neighbor_src
+
+
+class WholeDataFlow(NeighborDataFlow):
+    """whole_dataflow.py:25-60: one adjacency among the batch's own nodes
+    (sparse_get_adj(n_id, n_id)), reused by every hop.  Like the reference it
+    reads columns 0 and 1 of the [1, n, n] sparse indices as (src, dst)."""
+
+    def __init__(self, graph, metapath, add_self_loops=True):
+        super(WholeDataFlow, self).__init__(len(metapath), add_self_loops)
+        self.graph = graph
+        self.neighbor_type = metapath[0]
+        for n_type in metapath:
+            if not n_type == self.neighbor_type:
+                raise ValueError('Metapath should be the same in whole graph sampler.')
+
+    def get_self_neighbors(self, n_id):
+        n_id = n_id.reshape(-1)
+        ind, _val, _shape = self.graph.sparse_get_adj(n_id, n_id, self.neighbor_type,
+                                                      -1, -1)
+        return ind[:, 0], ind[:, 1]
+
+    def produce_subgraph(self, n_id):
+        n_id = n_id.reshape(-1)
+        inv = torch.arange(n_id.numel(), device=n_id.device)
+        data_flow = DataFlow(n_id)
+        edge_src, edge_dst = self.get_self_neighbors(n_id)
+        if self.add_self_loops:
+            edge_dst = torch.cat([edge_dst, inv])
+            edge_src = torch.cat([edge_src, inv])
+        edge_index = torch.stack([edge_src, edge_dst], 0)
+        for _ in range(self.num_hops):
+            data_flow.append(n_id, inv, None, edge_index)
+        return data_flow

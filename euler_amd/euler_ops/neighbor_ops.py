@@ -3,7 +3,9 @@ from . import base, type_ops
 
 __all__ = ["sample_neighbor", "sample_fanout", "get_full_neighbor",
            "get_sorted_full_neighbor", "get_top_k_neighbor", "to_sparse",
-           "sample_fanout_with_feature"]
+           "sample_fanout_with_feature", "sparse_get_adj",
+           "sample_neighbor_layerwise", "sample_fanout_layerwise_each_node",
+           "sample_fanout_layerwise", "get_multi_hop_neighbor"]
 
 
 def sample_neighbor(nodes, edge_types, count, default_node=-1, condition=''):
@@ -88,3 +90,94 @@ def sample_fanout_with_feature(nodes, edge_types, count, default_node,
     for layer_nodes in neighbors:
         dense.extend(g.get_dense_feature(layer_nodes, fids, list(dense_dimensions)))
     return neighbors, weights, types, dense, []
+
+
+def sparse_get_adj(nodes, nb_nodes, edge_types, n=-1, m=-1):
+    """The SparseTensor triple (indices [nnz,3] int64, values int64,
+    dense_shape) of the [batch, n, m] 0/1 adjacency between `nodes` and
+    `nb_nodes` over the listed edge types (neighbor_ops.py:33-36 over
+    tf_euler/kernels/sparse_get_adj_op.cc; n / m = -1: one batch row)."""
+    edge_types = type_ops.get_edge_type_id(edge_types)
+    return base.get_default_graph().sparse_get_adj(nodes, nb_nodes, edge_types, n, m)
+
+
+def sample_neighbor_layerwise(nodes, edge_types, count, default_node=-1,
+                              weight_func=''):
+    """nodes [batch, n] -> (neighbors [batch, count] int64, (indices, values,
+    dense_shape) of the [batch, n, count] adjacency) (neighbor_ops.py:72-77).
+    Only weight_func == '' (the sampleLNB form without a weight function)."""
+    edge_types = type_ops.get_edge_type_id(edge_types)
+    return base.get_default_graph().sample_neighbor_layerwise(
+        nodes, edge_types, count, default_node, weight_func)
+
+
+def sample_fanout_layerwise_each_node(nodes, edge_types, counts, default_node=-1):
+    """neighbor_ops.py:161-186: hop 1 = sample_neighbor, later hops =
+    sample_neighbor_layerwise over each root's own previous layer."""
+    import torch
+    g = base.get_default_graph()
+    ets = [type_ops.get_edge_type_id(et) for et in edge_types]
+    neighbors_list = [torch.as_tensor(nodes).reshape(-1)]
+    adj_list = []
+    last_count = None
+    for hop_edge_types, count in zip(ets, counts):
+        if len(neighbors_list) == 1:
+            neighbors, _, _ = g.sample_neighbor(neighbors_list[-1], hop_edge_types,
+                                                count, default_node)
+        else:
+            neighbors, adj = g.sample_neighbor_layerwise(
+                neighbors_list[-1].reshape(-1, last_count), hop_edge_types, count,
+                default_node)
+            adj_list.append(adj)
+        neighbors_list.append(neighbors.reshape(-1))
+        last_count = count
+    return neighbors_list, adj_list
+
+
+def sample_fanout_layerwise(nodes, edge_types, counts, default_node=-1,
+                            weight_func=''):
+    """neighbor_ops.py:189-206: every hop samples `count` nodes for the whole
+    previous layer (one batch row)."""
+    import torch
+    g = base.get_default_graph()
+    ets = [type_ops.get_edge_type_id(et) for et in edge_types]
+    neighbors_list = [torch.as_tensor(nodes).reshape(-1)]
+    adj_list = []
+    last_count = neighbors_list[0].numel()
+    for hop_edge_types, count in zip(ets, counts):
+        neighbors, adj = g.sample_neighbor_layerwise(
+            neighbors_list[-1].reshape(-1, last_count), hop_edge_types, count,
+            default_node, weight_func)
+        neighbors_list.append(neighbors.reshape(-1))
+        adj_list.append(adj)
+        last_count = count
+    return neighbors_list, adj_list
+
+
+def get_multi_hop_neighbor(nodes, edge_types):
+    """neighbor_ops.py:209-243: per hop the distinct full neighbours of the
+    previous node set (first-occurrence order, tf.unique) and the weighted
+    adjacency between the two sets as (indices [nnz,2] int64 sorted row-major,
+    values f32, dense_shape) - tf.sparse_reorder'ed like the reference."""
+    import torch
+    from .. import ops
+    g = base.get_default_graph()
+    ets = [type_ops.get_edge_type_id(et) for et in edge_types]
+    nodes = torch.as_tensor(nodes).reshape(-1).to(g.device)
+    nodes_list, adj_list = [nodes], []
+    for hop_edge_types in ets:
+        idx, ids, w, _t = g.get_full_neighbor(nodes, hop_edge_types)
+        lens = (idx[:, 1] - idx[:, 0]).to(torch.int64)
+        rows = torch.repeat_interleave(
+            torch.arange(nodes.numel(), device=nodes.device), lens)
+        next_nodes, next_idx = ops.id_unique(ids)
+        next_idx = next_idx.to(torch.int64)
+        # tf.sparse_reorder: canonical row-major order (stable for equal cells)
+        order = torch.argsort(rows * max(int(next_nodes.numel()), 1) + next_idx,
+                              stable=True)
+        indices = torch.stack([rows[order], next_idx[order]], 1)
+        adj_list.append((indices, w[order],
+                         [int(nodes.numel()), int(next_nodes.numel())]))
+        nodes_list.append(next_nodes)
+        nodes = next_nodes
+    return nodes_list, adj_list

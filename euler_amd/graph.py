@@ -413,6 +413,122 @@ class Graph:
                 int(default_node), _ptr(out_n), _ptr(out_w), _ptr(out_t)))
         return out_n, out_w, out_t
 
+    # ------------------------------------------------- layerwise sampling
+    def get_edge_sum_weight(self, nodes, edge_types):
+        """API_GET_EDGE_SUM_WEIGHT (core/kernels/get_edge_sum_weight_op.cc):
+        f32 sum of each node's out-edge weights over the listed types."""
+        nodes = _as_i64_cuda(nodes, self.device).reshape(-1)
+        n = nodes.numel()
+        et, et_p, k = _i32_array(edge_types)
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().euler_gpu_get_edge_sum_weight(
+                self._h, _stream(), _ptr(nodes), n, et_p, k, _ptr(out)))
+        return out
+
+    def sample_root(self, roots, weights, m, default_node=-1, call_id=None):
+        """API_SAMPLE_ROOT (core/kernels/sample_root_op.cc): roots / weights
+        [batch, n] -> [batch, m] draws (alias method per batch row)."""
+        roots = _as_i64_cuda(roots, self.device)
+        batch, n = roots.shape
+        weights = torch.as_tensor(weights, dtype=torch.float32,
+                                  device=self.device).reshape(batch, n).contiguous()
+        out = torch.empty((batch, int(m)), dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().euler_gpu_sample_root(
+                _stream(), self.seed, self._take_call_ids(1, call_id), _ptr(roots),
+                _ptr(weights), batch, n, int(m), int(default_node), _ptr(out)))
+        return out
+
+    def sample_layer(self, roots, edge_types, default_node=-1, call_id=None):
+        """API_SAMPLE_L (core/kernels/sample_layer_op.cc): one neighbour per
+        listed root (position-keyed RNG) or (default_node, 0.0, 0)."""
+        roots = _as_i64_cuda(roots, self.device).reshape(-1)
+        n = roots.numel()
+        et, et_p, k = _i32_array(edge_types)
+        oid = torch.empty(n, dtype=torch.int64, device=self.device)
+        ow = torch.empty(n, dtype=torch.float32, device=self.device)
+        ot = torch.empty(n, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().euler_gpu_sample_layer(
+                self._h, _stream(), self.seed, self._take_call_ids(1, call_id),
+                _ptr(roots), n, et_p, k, int(default_node), _ptr(oid), _ptr(ow),
+                _ptr(ot)))
+        return oid, ow, ot
+
+    def sparse_get_adj_core(self, roots, l_nb, n, m, edge_types):
+        """API_SPARSE_GEN_ADJ + API_SPARSE_GET_ADJ (core/kernels/
+        sparse_get_adj_op.cc): (idx [batch*n, 2] int32, ids int64)."""
+        roots = _as_i64_cuda(roots, self.device).reshape(-1)
+        l_nb = _as_i64_cuda(l_nb, self.device).reshape(-1)
+        n, m = int(n), int(m)
+        batch = roots.numel() // n if n else 0
+        assert roots.numel() == batch * n and l_nb.numel() == batch * m
+        et, et_p, k = _i32_array(edge_types)
+        idx = torch.empty((batch * n, 2), dtype=torch.int32, device=self.device)
+        total = C.c_int64(0)
+        with torch.cuda.device(self.device):
+            check(lib().euler_gpu_sparse_get_adj(
+                self._h, _stream(), _ptr(roots), _ptr(l_nb), batch, n, m, et_p, k,
+                _ptr(idx), C.byref(total), None))
+            vals = torch.empty(int(total.value), dtype=torch.int64, device=self.device)
+            if total.value:
+                check(lib().euler_gpu_sparse_get_adj(
+                    self._h, _stream(), _ptr(roots), _ptr(l_nb), batch, n, m, et_p, k,
+                    _ptr(idx), C.byref(total), _ptr(vals)))
+        return idx, vals
+
+    def sparse_get_adj(self, nodes, nb_nodes, edge_types, n=-1, m=-1):
+        """tf_euler sparse_get_adj (tf_euler/kernels/sparse_get_adj_op.cc):
+        COO (indices [nnz, 3] int64, values [nnz] int64, dense_shape) of the
+        [batch, n, m] adjacency between nodes [batch*n] and nb_nodes
+        [batch*m]; n / m = -1 take the whole input as one batch row."""
+        nodes = _as_i64_cuda(nodes, self.device).reshape(-1)
+        nb_nodes = _as_i64_cuda(nb_nodes, self.device).reshape(-1)
+        n = nodes.numel() if n == -1 else int(n)
+        m = nb_nodes.numel() if m == -1 else int(m)
+        batch = nodes.numel() // n if n else 0
+        if nodes.numel() != batch * n or nb_nodes.numel() < batch * m:
+            raise ValueError("sparse_get_adj: nodes / nb_nodes do not match n, m")
+        et, et_p, k = _i32_array(edge_types)
+        row_off = torch.empty(batch * n + 1, dtype=torch.int64, device=self.device)
+        nnz = C.c_int64(0)
+        with torch.cuda.device(self.device):
+            check(lib().euler_gpu_sparse_get_adj_tf(
+                self._h, _stream(), _ptr(nodes), _ptr(nb_nodes), batch, n, m, et_p, k,
+                _ptr(row_off), C.byref(nnz), None, None))
+            ind = torch.empty((int(nnz.value), 3), dtype=torch.int64, device=self.device)
+            val = torch.empty(int(nnz.value), dtype=torch.int64, device=self.device)
+            if nnz.value:
+                check(lib().euler_gpu_sparse_get_adj_tf(
+                    self._h, _stream(), _ptr(nodes), _ptr(nb_nodes), batch, n, m, et_p,
+                    k, _ptr(row_off), C.byref(nnz), _ptr(ind), _ptr(val)))
+        shape = [batch, n, m] if nnz.value else [0, 0, 0]
+        return ind, val, shape
+
+    def sample_neighbor_layerwise(self, nodes, edge_types, count, default_node=-1,
+                                  weight_func='', call_id=None):
+        """tf_euler sample_neighbor_layerwise (euler_ops/neighbor_ops.py:72-77
+        over tf_euler/kernels/sample_neighbor_layerwise_with_adj_op.cc):
+        nodes [batch, n] -> (neighbors [batch, count] int64, (indices, values,
+        dense_shape) of the [batch, n, count] adjacency)."""
+        if weight_func:
+            raise NotImplementedError(
+                "sampleLNB weight functions run API_LOCAL_SAMPLE_L, whose order is "
+                "std::unordered_map<std::string> iteration order (DESIGN.md §8)")
+        nodes = _as_i64_cuda(nodes, self.device)
+        if nodes.dim() != 2:
+            raise ValueError("sample_neighbor_layerwise: nodes must be [batch, n]")
+        batch, n = nodes.shape
+        et, et_p, k = _i32_array(edge_types)
+        out = torch.empty((batch, int(count)), dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().euler_gpu_sample_neighbor_layerwise(
+                self._h, _stream(), self.seed, self._take_call_ids(1, call_id),
+                _ptr(nodes), batch, n, et_p, k, int(count), int(default_node),
+                _ptr(out)))
+        return out, self.sparse_get_adj(nodes, out, et, n, int(count))
+
     def random_walk(self, nodes, edge_types, p=1.0, q=1.0, default_node=-1,
                     call_id=None):
         """tf_euler random_walk (tf_euler/kernels/random_walk_op.cc):

@@ -7,7 +7,9 @@
 //
 // The GPU kernels register under the reference's own op names
 // (API_SAMPLE_NB, API_SAMPLE_NODE, ID_UNIQUE, IDX_GATHER, DATA_GATHER,
-// API_GET_NB_NODE, ID_SPLIT), so a build of the reference that links this
+// API_GET_NB_NODE and the layerwise chain API_GET_EDGE_SUM_WEIGHT,
+// API_SAMPLE_ROOT, API_SAMPLE_L, API_SPARSE_GEN_ADJ, API_SPARSE_GET_ADJ,
+// API_GATHER_RESULT), so a build of the reference that links this
 // library INSTEAD of the corresponding core/kernels/*.cc files dispatches the
 // same DAG nodes to the MI355X.  Tensors are host buffers (malloc, uninitialised
 // like the reference's, op_kernel.cc:92-105); device memory stays behind the
@@ -85,6 +87,9 @@ class OpKernelContext {
                Tensor** tensor);
   int tensor(const std::string& name, Tensor** tensor);
   int Deallocate(const std::string& name);
+  // A second name for an existing tensor (op_kernel.cc AddAlias; the context
+  // frees every distinct tensor once, op_kernel.cc:80-90).
+  int AddAlias(const std::string& name, Tensor* tensor);
   // Sampling reproducibility (not in the reference: its RNG is unseedable).
   void SetSeed(uint64_t seed) { seed_ = seed; }
   uint64_t seed() const { return seed_; }
@@ -159,4 +164,14 @@ int64_t euler_op_run_get_nb(euler_gpu_graph* g, const uint64_t* node_ids, int64_
                             const char* post_process, int64_t capacity,
                             int32_t* idx_out, uint64_t* id_out, float* w_out,
                             int32_t* t_out);
+// The six-node DAG of `v(nodes).sampleLNB(edge_types, n, m, default_node)`
+// (euler/parser/translator.cc:338-386,489-527) executed node by node through
+// the registry: adjacency idx [batch*n, 2], adjacency ids (room for `capacity`),
+// sampled layer [batch*m].  Returns the number of adjacency ids or < 0.
+int64_t euler_op_run_sample_lnb(euler_gpu_graph* g, uint64_t seed, uint32_t first_call_id,
+                                const uint64_t* node_ids, int64_t batch, int32_t n,
+                                const int32_t* edge_types, int32_t k, int32_t m,
+                                int64_t default_node, int64_t capacity,
+                                int32_t* adj_idx_out, uint64_t* adj_id_out,
+                                uint64_t* l_nb_out);
 }

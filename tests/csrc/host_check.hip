@@ -1,0 +1,133 @@
+// TEST INFRASTRUCTURE (not product code): runs the per-item functions of
+// euler_amd/csrc/layer_fns.h - the very source the HIP kernels of
+// layer_kernels.hip call one item per lane - in plain host loops over host
+// arrays, so that `pytest -m "not gpu"` can compare their LOGIC with the
+// oracle where no GPU exists.  What this cannot cover is the kernels' lane /
+// wave mapping (that is the -m gpu tests' job).  Nothing in euler_amd/ links or
+// loads this file; it is compiled on demand by tests/test_host_check.py with
+// `hipcc -ffp-contract=off` (host pass only is used).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <vector>
+
+#include "layer_fns.h"
+
+using namespace euler_gpu;
+
+namespace {
+
+struct HostGraph {
+  GraphView v{};
+  std::vector<uint8_t> meta;
+  std::vector<uint64_t> slots;
+};
+
+}  // namespace
+
+extern "C" {
+
+// CSR in the oracle's layout (row_ptr [n+1], type_end / type_prefix [n*T]).
+void* hc_graph_create(int64_t n, int32_t T, const uint64_t* row_id,
+                      const int64_t* row_ptr, const int32_t* type_end,
+                      const uint64_t* nbr, const float* prefix_w,
+                      const float* type_prefix, int32_t force_hash) {
+  HostGraph* g = new HostGraph();
+  GraphView& v = g->v;
+  v.n_rows = n; v.T = T; v.meta_stride = 8 + 8 * T;
+  v.n_edges = n ? row_ptr[n] : 0;
+  g->meta.resize((size_t)n * v.meta_stride);
+  for (int64_t i = 0; i < n; ++i) {
+    uint8_t* rec = g->meta.data() + (size_t)i * v.meta_stride;
+    std::memcpy(rec, &row_ptr[i], 8);
+    std::memcpy(rec + 8, type_end + i * T, 4 * T);
+    std::memcpy(rec + 8 + 4 * T, type_prefix + i * T, 4 * T);
+  }
+  v.row_meta = g->meta.data();
+  v.nbr = nbr;
+  v.prefix_w = prefix_w;
+  v.row_id = row_id;
+  bool identity = n > 0 && !force_hash;
+  uint64_t base = n > 0 ? row_id[0] : 0, stride = 1;
+  if (n > 1) {
+    stride = row_id[1] - row_id[0];
+    if (row_id[1] <= row_id[0]) identity = false;
+  }
+  for (int64_t i = 0; identity && i < n; ++i)
+    identity = row_id[i] == base + (uint64_t)i * stride;
+  if (identity) {
+    v.map_mode = 0; v.id_base = base; v.id_stride = stride;
+  } else {
+    uint64_t cap = 16;
+    while (cap < (uint64_t)n * 2 + 1) cap <<= 1;
+    g->slots.assign(2 * cap, 0);
+    for (uint64_t i = 0; i < cap; ++i) g->slots[2 * i + 1] = ~0ULL;
+    for (int64_t i = 0; i < n; ++i) {
+      uint64_t h = Mix64(row_id[i]) & (cap - 1);
+      while ((int64_t)g->slots[2 * h + 1] >= 0 && g->slots[2 * h] != row_id[i])
+        h = (h + 1) & (cap - 1);
+      g->slots[2 * h] = row_id[i];
+      g->slots[2 * h + 1] = (uint64_t)i;
+    }
+    v.map_mode = 1; v.hash_mask = cap - 1; v.id_base = 0; v.id_stride = 1;
+    v.hash_slots = g->slots.data();
+  }
+  return g;
+}
+
+void hc_graph_destroy(void* h) { delete static_cast<HostGraph*>(h); }
+
+void hc_edge_sum_weight(void* h, const uint64_t* ids, int64_t n, const int32_t* et,
+                        int32_t k, float* out) {
+  const GraphView& g = static_cast<HostGraph*>(h)->v;
+  for (int64_t i = 0; i < n; ++i) out[i] = EdgeSumWeight(g, ids[i], et, k);
+}
+
+// The two kernels of euler_gpu_sample_root with the same interleaved scratch
+// layout (slot j of batch row b at j * batch + b).
+void hc_sample_root(uint64_t seed, uint32_t call_id, const uint64_t* roots,
+                    const float* weights, int64_t batch, int32_t n, int32_t m,
+                    int64_t default_node, uint64_t* out) {
+  const int64_t cells = batch * n;
+  std::vector<float> wn(cells), prob(cells), sum(batch);
+  std::vector<int32_t> alias(cells), stack(cells);
+  for (int64_t b = 0; b < batch; ++b)
+    sum[b] = AliasBuildRow(weights + b * n, n, batch, wn.data() + b, prob.data() + b,
+                           alias.data() + b, stack.data() + b);
+  for (int64_t i = 0; i < batch * m; ++i) {
+    const int64_t b = i / m;
+    const int32_t j = (int32_t)(i - b * m);
+    if (sum[b] == 0.f) {
+      out[i] = (uint64_t)default_node;
+    } else {
+      const int32_t slot = SampleRootSlot(seed, call_id, b, j, n, batch,
+                                          prob.data() + b, alias.data() + b);
+      out[i] = roots[b * n + slot];
+    }
+  }
+}
+
+void hc_sample_layer(void* h, uint64_t seed, uint32_t call_id, const uint64_t* roots,
+                     int64_t n, const int32_t* et, int32_t k, int64_t default_node,
+                     uint64_t* out_id, float* out_w, int32_t* out_t) {
+  const GraphView& g = static_cast<HostGraph*>(h)->v;
+  int32_t types[kMaxListedTypes] = {0};
+  for (int32_t i = 0; i < k && i < kMaxListedTypes; ++i) types[i] = et[i];
+  for (int64_t i = 0; i < n; ++i)
+    SampleLayerAt(g, seed, call_id, i, roots[i], types, k, default_node, out_id + i,
+                  out_w + i, out_t + i);
+}
+
+// mask[r * m + j] = EdgeExistAny(roots[r], l_nb[(r / n) * m + j])
+void hc_edge_exist_mask(void* h, const uint64_t* roots, const uint64_t* l_nb,
+                        int64_t batch, int32_t n, int32_t m, const int32_t* et,
+                        int32_t k, uint8_t* mask) {
+  const GraphView& g = static_cast<HostGraph*>(h)->v;
+  for (int64_t r = 0; r < batch * n; ++r) {
+    const int64_t row = FindRow(g, roots[r]);
+    for (int32_t j = 0; j < m; ++j)
+      mask[r * m + j] = EdgeExistAny(g, row, l_nb[(r / n) * m + j], et, k) ? 1 : 0;
+  }
+}
+
+}  // extern "C"

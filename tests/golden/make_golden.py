@@ -21,6 +21,15 @@ comes out of REFERENCE code:
   features.npz        dense float features of both graphs as the reference holds
                       them + the rows GetFloat32Feature / TF GetDenseFeature
                       produce for a battery of (node, feature id, dim) queries.
+  layerwise.npz       layerwise sampling (sampleLNB without a weight function) and
+                      SparseGetAdj on the fixture - loaded WITH its Edge/*.dat
+                      partitions by the reference's own loader, so EdgeExist
+                      consults the reference's Edge records - and on the random
+                      graph: per-op outputs (edge weight sums, API_SAMPLE_ROOT,
+                      API_SAMPLE_L, API_SPARSE_GET_ADJ) and the TF kernels'
+                      results (neighbors + sparse adjacency), including the
+                      batches of neighbor_ops_test.py:142-175.
+                      `python make_golden.py layerwise` writes only this file.
   ref_tests.npz       exact expectations copied from the reference's own tests
                       (mp_ops_test.py:30-86, walk_ops_test.py:49-58,
                       unique_gather_test.cc:28-160, neighbor_ops_test.py:46-75).
@@ -116,6 +125,88 @@ def sample_pack(R, ids, T, prefix):
     return out
 
 
+def layer_pack(R, ids, T, prefix, rng):
+    """Reference outputs of the layerwise op chain for a battery of queries."""
+    out = {}
+    etl = [[0], [1], [0, 1], [], [T + 3]] + ([[2, 0], list(range(T))] if T > 2 else [])
+    q = np.concatenate([ids, ids[::-1], np.array([0, 987654321], np.uint64)])
+    out[prefix + "q"] = q
+    for e, et in enumerate(etl):
+        out["%set_%d" % (prefix, e)] = np.array(et, np.int32)
+        out["%ssumw_%d" % (prefix, e)] = R.get_edge_sum_weight(q, et)
+        for c, (call, dn) in enumerate(((3, -1), (4, 4242))):
+            lid, lw, lt = R.sample_layer(SEED, call, q, et, dn)
+            key = "%slayer_%d_%d_" % (prefix, e, c)
+            out[key + "id"], out[key + "w"], out[key + "t"] = lid, lw, lt
+    # API_SAMPLE_ROOT on explicit weights (zero rows, single entries, ties)
+    for c, (n, m) in enumerate(((1, 4), (3, 10), (17, 9))):
+        batch = 6
+        roots = rng.choice(ids, (batch, n)).astype(np.uint64)
+        w = (rng.random((batch, n)) * 4).astype(np.float32)
+        w[rng.random((batch, n)) < 0.3] = 0
+        w[1] = 0
+        w[2] = 1.0
+        key = "%sroot_%d_" % (prefix, c)
+        out[key + "roots"], out[key + "w"] = roots, w
+        out[key + "m"] = np.int32(m)
+        out[key + "out"] = R._sample_root(SEED, 50 + c, roots, w, n, m, -1)
+    # the whole TF op + SparseGetAdj on batches of graph nodes
+    shapes = ((4, 3, 10), (2, 5, 4), (3, 1, 6))
+    for c, (batch, n, count) in enumerate(shapes):
+        nodes = rng.choice(ids, (batch, n)).astype(np.uint64)
+        if n > 1:
+            nodes[0, 1] = nodes[0, 0]
+        nodes[-1, -1] = 987654321
+        for e, et in enumerate(etl[:3] + etl[-1:]):
+            key = "%slw_%d_%d_" % (prefix, c, e)
+            nb, ind, val, shape = R.sample_neighbor_layerwise(SEED, 70 + c, nodes, et,
+                                                              count, -1)
+            out[key + "nodes"], out[key + "et"] = nodes, np.array(et, np.int32)
+            out[key + "nb"], out[key + "ind"], out[key + "val"] = nb, ind, val
+            out[key + "shape"] = shape
+            idx, vals = R.sparse_get_adj(nodes, nb.view(np.uint64), batch, n, count, et)
+            out[key + "adj_idx"], out[key + "adj_val"] = idx, vals
+    return out
+
+
+def main_layerwise():
+    O.build(ref=True)
+    assert O.have_ref(), "oracle/_ref must be built from " + REF
+    out = {"seed": np.uint64(SEED)}
+    scratch = tempfile.mkdtemp(prefix="euler_golden_")
+    try:
+        data = convert_fixture(scratch)
+        R = O.RefGraph.load_all(data, 2)
+        assert R.num_edges() > 0
+        ids = np.sort(R.node_order())
+        out.update(layer_pack(R, ids, 2, "fx_", np.random.default_rng(11)))
+        # the batches of the reference's own test (neighbor_ops_test.py:142-175)
+        src = np.array([[1, 2, 3], [1, 2, 3], [2, 3, 4], [2, 2, 4]], np.uint64)
+        nb, ind, val, shape = R.sample_neighbor_layerwise(SEED, 90, src, [0, 1], 10, -1)
+        out.update(fx_t_nodes=src, fx_t_nb=nb, fx_t_ind=ind, fx_t_val=val,
+                   fx_t_shape=shape)
+        # every (src, dst, type) the reference holds an Edge record for
+        g = np.load(os.path.join(OUT, "fixture_graph.npz"))
+        trip = []
+        for s_ in ids:
+            for d_ in np.concatenate([ids, [0, 99]]):
+                for t_ in (0, 1, 2):
+                    if R.edge_exist(s_, d_, t_):
+                        trip.append((int(s_), int(d_), t_))
+        out["fx_edges"] = np.array(trip, np.int64)
+    finally:
+        shutil.rmtree(scratch, ignore_errors=True)
+    g = np.load(os.path.join(OUT, "random_graph.npz"))
+    n = len(g["row_id"])
+    T = int(g["n_types"])
+    R = O.RefGraph.build_raw(g["row_id"], g["raw_seg_ptr"], g["raw_nbr"], g["raw_w"], T,
+                             g["node_type"], g["node_weight"])
+    R.add_edges_from_adjacency()
+    out.update(layer_pack(R, g["row_id"][:40], T, "rg_", np.random.default_rng(12)))
+    np.savez_compressed(os.path.join(OUT, "layerwise.npz"), **out)
+    print("layerwise golden vectors written")
+
+
 def main():
     O.build(ref=True)
     assert O.have_ref(), "oracle/_ref must be built from " + REF
@@ -196,6 +287,7 @@ def main():
     )
     np.savez(os.path.join(OUT, "ref_tests.npz"), **ref_tests)
     print("golden vectors written to", OUT)
+    main_layerwise()
 
 
 def feature_goldens():
@@ -260,6 +352,8 @@ def feature_goldens():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "features":
         feature_goldens()
+    elif len(sys.argv) > 1 and sys.argv[1] == "layerwise":
+        main_layerwise()
     else:
         main()
         feature_goldens()

@@ -1,0 +1,191 @@
+"""The per-item functions of euler_amd/csrc/layer_fns.h - the source the HIP
+kernels call one item per lane - compiled for the HOST by tests/csrc/
+host_check.hip and compared with the oracle / the reference's golden vectors.
+CPU only: a check of the kernel logic where no GPU exists (the lane mapping is
+covered by the -m gpu tests).  Skipped when hipcc is absent."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, make_random_graph
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+u64p, i64p, i32p = C.POINTER(C.c_uint64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)
+f32p, u8p = C.POINTER(C.c_float), C.POINTER(C.c_uint8)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+@pytest.fixture(scope="module")
+def HC():
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out_dir = os.path.join(HERE, "csrc", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "libhost_check.so")
+    src = os.path.join(HERE, "csrc", "host_check.hip")
+    deps = [src] + [os.path.join(ROOT, "euler_amd", "csrc", f)
+                    for f in ("layer_fns.h", "device_fns.h", "common.h", "philox.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so)
+                                     for d in deps):
+        subprocess.check_call(
+            [hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared",
+             "-ffp-contract=off", "-I" + os.path.join(ROOT, "euler_amd", "csrc"),
+             "-I" + os.path.join(ROOT, "include"), src, "-o", so])
+    L = C.CDLL(so)
+    L.hc_graph_create.restype = C.c_void_p
+    L.hc_graph_create.argtypes = [C.c_int64, C.c_int32, u64p, i64p, i32p, u64p, f32p,
+                                  f32p, C.c_int32]
+    L.hc_graph_destroy.argtypes = [C.c_void_p]
+    L.hc_edge_sum_weight.argtypes = [C.c_void_p, u64p, C.c_int64, i32p, C.c_int32, f32p]
+    L.hc_sample_root.argtypes = [C.c_uint64, C.c_uint32, u64p, f32p, C.c_int64,
+                                 C.c_int32, C.c_int32, C.c_int64, u64p]
+    L.hc_sample_layer.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, u64p, C.c_int64,
+                                  i32p, C.c_int32, C.c_int64, u64p, f32p, i32p]
+    L.hc_edge_exist_mask.argtypes = [C.c_void_p, u64p, u64p, C.c_int64, C.c_int32,
+                                     C.c_int32, i32p, C.c_int32, u8p]
+    return L
+
+
+class HostBackend:
+    """layer_cases backend over the host build of layer_fns.h.  The adjacency
+    results are assembled from EdgeExistAny masks the way AdjCount/AdjFill do
+    (hits in candidate order, the TF corner zero)."""
+
+    def __init__(self, L, csr, force_hash=False):
+        self.L, self.csr = L, csr
+        self.keep = [np.ascontiguousarray(a) for a in (
+            csr.row_id.astype(np.uint64), csr.row_ptr.astype(np.int64),
+            csr.type_end.astype(np.int32), csr.nbr.astype(np.uint64),
+            csr.prefix_w.astype(np.float32), csr.type_prefix.astype(np.float32))]
+        k = self.keep
+        self.h = L.hc_graph_create(len(k[0]), csr.n_types, _p(k[0], u64p), _p(k[1], i64p),
+                                   _p(k[2], i32p), _p(k[3], u64p), _p(k[4], f32p),
+                                   _p(k[5], f32p), 1 if force_hash else 0)
+
+    def __del__(self):
+        self.L.hc_graph_destroy(self.h)
+
+    @staticmethod
+    def _u64(a):
+        a = np.ascontiguousarray(np.asarray(a).reshape(-1))
+        return a.view(np.uint64) if a.dtype == np.int64 else a.astype(np.uint64)
+
+    def get_edge_sum_weight(self, q, et):
+        q = self._u64(q)
+        et = np.ascontiguousarray(et, np.int32)
+        out = np.zeros(len(q), np.float32)
+        self.L.hc_edge_sum_weight(self.h, _p(q, u64p), len(q), _p(et, i32p), len(et),
+                                  _p(out, f32p))
+        return out
+
+    def sample_layer(self, seed, call, q, et, dn):
+        q = self._u64(q)
+        et = np.ascontiguousarray(et, np.int32)
+        oid = np.zeros(len(q), np.uint64)
+        ow = np.zeros(len(q), np.float32)
+        ot = np.zeros(len(q), np.int32)
+        self.L.hc_sample_layer(self.h, seed, call, _p(q, u64p), len(q), _p(et, i32p),
+                               len(et), dn, _p(oid, u64p), _p(ow, f32p), _p(ot, i32p))
+        return oid, ow, ot
+
+    def sample_root(self, seed, call, roots, w, n, m, dn):
+        roots = self._u64(roots)
+        w = np.ascontiguousarray(np.asarray(w, np.float32).reshape(-1))
+        batch = len(roots) // n
+        out = np.zeros(batch * m, np.uint64)
+        self.L.hc_sample_root(seed, call, _p(roots, u64p), _p(w, f32p), batch, n, m, dn,
+                              _p(out, u64p))
+        return out
+
+    def _mask(self, nodes, nb, batch, n, m, et):
+        nodes, nb = self._u64(nodes), self._u64(nb)
+        et = np.ascontiguousarray(et, np.int32)
+        mask = np.zeros(batch * n * m, np.uint8)
+        self.L.hc_edge_exist_mask(self.h, _p(nodes, u64p), _p(nb, u64p), batch, n, m,
+                                  _p(et, i32p), len(et), _p(mask, u8p))
+        return mask.reshape(batch * n, m).astype(bool), nb.reshape(batch, m)
+
+    def sparse_get_adj(self, nodes, nb, batch, n, m, et):
+        mask, nb = self._mask(nodes, nb, batch, n, m, et)
+        counts = mask.sum(1)
+        idx = np.zeros((batch * n, 2), np.int32)
+        idx[:, 1] = np.cumsum(counts)
+        idx[1:, 0] = idx[:-1, 1]
+        vals = np.concatenate([nb[r // n][mask[r]] for r in range(batch * n)]
+                              + [np.zeros(0, np.uint64)])
+        return idx, vals
+
+    def sample_neighbor_layerwise(self, seed, call, nodes, et, count, dn):
+        nodes = np.asarray(nodes)
+        batch, n = nodes.shape
+        w = self.get_edge_sum_weight(nodes, et)
+        l_root = self.sample_root(seed, call, nodes, w, n, count, dn)
+        l_nb = self.sample_layer(seed, call, l_root, et, dn)[0]
+        mask, _ = self._mask(nodes, l_nb, batch, n, count, et)
+        mask = mask.reshape(batch, n, count)
+        emit = mask.copy()
+        emit[:, n - 1, count - 1] = True
+        ind = np.argwhere(emit).astype(np.int64)
+        val = mask[emit].astype(np.int64)
+        return (l_nb.view(np.int64).reshape(batch, count), ind, val,
+                np.array([batch, n, count], np.int64))
+
+
+def test_layer_fns_host_vs_goldens(HC, O, fixture_csr, random_csr):
+    from layer_cases import check_layer_pack
+    L = np.load(os.path.join(GOLDEN, "layerwise.npz"))
+    check_layer_pack(HostBackend(HC, fixture_csr), L, "fx_", 2)
+    check_layer_pack(HostBackend(HC, fixture_csr, force_hash=True), L, "fx_", 2)
+    check_layer_pack(HostBackend(HC, random_csr), L, "rg_", 3)
+
+
+@pytest.mark.parametrize("T,n_nodes,id_space", [(1, 400, "identity"), (4, 1500, None),
+                                                (3, 300, 10 ** 12)])
+def test_layer_fns_host_vs_oracle_random(HC, O, T, n_nodes, id_space):
+    from layer_cases import OracleBackend
+    rng = np.random.default_rng(100 + T)
+    ids, seg, nbr, w, nt, nw = make_random_graph(
+        rng, n_nodes, T, max_deg=25, id_space=None if id_space == "identity" else id_space)
+    if id_space == "identity":        # contiguous ids: the identity id map
+        ids = np.arange(1, n_nodes + 1, dtype=np.uint64)
+        nbr = rng.choice(ids, len(nbr)).astype(np.uint64)
+    csr = O.csr_from_raw(ids, seg, nbr, w, T, nt, nw)
+    H, G = HostBackend(HC, csr), OracleBackend(O, O.OracleGraph(csr))
+    q = np.concatenate([rng.choice(ids, 700), [0, 2 ** 63 + 9]]).astype(np.uint64)
+    for et in ([0], [T - 1], list(range(T)), [], [T + 2], [0, T - 1, 0][:max(2, T - 1)]):
+        a, b = H.get_edge_sum_weight(q, et), G.get_edge_sum_weight(q, et)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), et
+        for call, dn in ((1, -1), (2, 99)):
+            for x, y in zip(H.sample_layer(5, call, q, et, dn),
+                            G.sample_layer(5, call, q, et, dn)):
+                assert np.array_equal(x, y), et
+    for n, m in ((1, 2), (2, 7), (5, 64), (33, 65), (257, 20), (1000, 3)):
+        batch = 11
+        roots = rng.choice(ids, (batch, n)).astype(np.uint64)
+        wts = (rng.random((batch, n)) * 3).astype(np.float32)
+        wts[rng.random((batch, n)) < 0.4] = 0
+        wts[0] = 0
+        wts[1] = 0.125
+        if n > 1:
+            wts[2] = 0; wts[2, n - 1] = 1e-30
+        assert np.array_equal(H.sample_root(9, 4, roots, wts, n, m, 5),
+                              G.sample_root(9, 4, roots, wts, n, m, 5)), (n, m)
+    for batch, n, count in ((3, 4, 9), (1, 70, 130), (5, 1, 1)):
+        nodes = rng.choice(ids, (batch, n)).astype(np.uint64)
+        for et in ([0], list(range(T))):
+            x = H.sample_neighbor_layerwise(3, 8, nodes, et, count, -1)
+            y = G.sample_neighbor_layerwise(3, 8, nodes, et, count, -1)
+            for u, v in zip(x, y):
+                assert np.array_equal(u, v)
+            nbq = y[0].reshape(-1).view(np.uint64)
+            for u, v in zip(H.sparse_get_adj(nodes, nbq, batch, n, count, et),
+                            G.sparse_get_adj(nodes, nbq, batch, n, count, et)):
+                assert np.array_equal(u, v)

@@ -1,0 +1,271 @@
+"""GPU parity of the layerwise-sampling ops (sampleLNB without a weight
+function) and SparseGetAdj, through the C ABI: the reference's golden vectors
+(tests/golden/layerwise.npz), random graphs against the oracle, empty / ragged
+inputs, the euler_ops surface and the dataflows built on it.  Bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, make_random_graph
+from layer_cases import GpuBackend, OracleBackend, check_layer_pack
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_graph(EA, csr, **kw):
+    return EA.Graph.from_csr(csr.row_id, csr.row_ptr, csr.type_end, csr.nbr,
+                             csr.prefix_w, csr.type_prefix, csr.n_types,
+                             csr.node_type, csr.node_weight, **kw)
+
+
+def t2n(t):
+    return t.detach().cpu().numpy()
+
+
+def test_layerwise_goldens_gpu(EA, O, torch_cuda, fixture_csr, random_csr):
+    L = np.load(os.path.join(GOLDEN, "layerwise.npz"))
+    G = gpu_graph(EA, fixture_csr)
+    B = GpuBackend(torch_cuda, G)
+    check_layer_pack(B, L, "fx_", 2)
+    nb, ind, val, shape = B.sample_neighbor_layerwise(int(L["seed"]), 90, L["fx_t_nodes"],
+                                                      [0, 1], 10, -1)
+    assert np.array_equal(nb, L["fx_t_nb"]) and np.array_equal(ind, L["fx_t_ind"])
+    assert np.array_equal(val, L["fx_t_val"]) and list(shape) == [4, 3, 10]
+    # EdgeExist from the rows == the reference's Edge records, pair by pair
+    have = {tuple(x) for x in L["fx_edges"].tolist()}
+    ids = [int(x) for x in fixture_csr.row_id]
+    for t in (0, 1, 2):
+        src = np.repeat(ids, len(ids) + 2)
+        dst = np.tile(ids + [0, 99], len(ids))
+        idx, vals = B.sparse_get_adj(src, dst, len(src), 1, 1, [t])
+        got = (idx[:, 1] - idx[:, 0]) == 1
+        want = np.array([(s, d, t) in have for s, d in zip(src, dst)])
+        assert np.array_equal(got, want), t
+    check_layer_pack(GpuBackend(torch_cuda, gpu_graph(EA, random_csr)), L, "rg_", 3)
+
+
+@pytest.fixture(scope="module")
+def lw_pair(EA, O):
+    rng = np.random.default_rng(4711)
+    ids, seg, nbr, w, nt, nw = make_random_graph(rng, 20000, 4, max_deg=40,
+                                                 id_space=10 ** 12)
+    # one hub row: a long sequential weight sum and a long EdgeExist scan
+    csr = O.csr_from_raw(ids, seg, nbr, w, 4, nt, nw)
+    return gpu_graph(EA, csr), O.OracleGraph(csr), ids, rng
+
+
+@pytest.mark.parametrize("et", [[0], [3], [1, 2], [0, 1, 2, 3], [], [9], [1, 9]])
+def test_layerwise_primitives_vs_oracle(EA, O, torch_cuda, lw_pair, et):
+    G, OG, ids, rng = lw_pair
+    B, OB = GpuBackend(torch_cuda, G), OracleBackend(O, OG)
+    q = np.concatenate([rng.choice(ids, 70000), [0, 2 ** 63 + 5]]).astype(np.uint64)
+    a, b = B.get_edge_sum_weight(q, et), OB.get_edge_sum_weight(q, et)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    for call, dn in ((0, -1), (6, 31337)):
+        for x, y in zip(B.sample_layer(17, call, q, et, dn),
+                        OB.sample_layer(17, call, q, et, dn)):
+            assert np.array_equal(x, y)
+
+
+def test_sample_root_vs_oracle(EA, O, torch_cuda, lw_pair):
+    G, OG, ids, rng = lw_pair
+    B, OB = GpuBackend(torch_cuda, G), OracleBackend(O, OG)
+    for batch, n, m in ((1, 1, 1), (7, 2, 5), (300, 25, 10), (1000, 3, 64),
+                        (5, 1000, 200), (64, 257, 33)):
+        roots = rng.choice(ids, (batch, n)).astype(np.uint64)
+        w = (rng.random((batch, n)) * 5).astype(np.float32)
+        w[rng.random((batch, n)) < 0.3] = 0
+        w[0] = 0
+        if batch > 2:
+            w[1] = 1.0
+            w[2] = 0
+            w[2, n - 1] = 1e-30
+        for call, dn in ((0, -1), (3, 77)):
+            assert np.array_equal(B.sample_root(11, call, roots, w, n, m, dn),
+                                  OB.sample_root(11, call, roots, w, n, m, dn)), (n, m)
+
+
+def test_sparse_get_adj_and_layerwise_vs_oracle(EA, O, torch_cuda, lw_pair):
+    torch = torch_cuda
+    G, OG, ids, rng = lw_pair
+    B, OB = GpuBackend(torch, G), OracleBackend(O, OG)
+    for batch, n, m in ((1, 5, 7), (3, 4, 70), (2, 1, 1), (4, 9, 130), (40, 25, 10),
+                        (1, 300, 300)):
+        nodes = rng.choice(ids, (batch, n)).astype(np.uint64)
+        if n > 1:
+            nodes[0, 1] = nodes[0, 0]
+        nodes[-1, -1] = 2 ** 62 + 3
+        cand = rng.choice(ids, (batch, m)).astype(np.uint64)
+        for b in range(batch):
+            nb = OG.get_full_neighbor(nodes[b], [0, 1, 2, 3])[1]
+            if len(nb):
+                take = rng.choice(nb, m // 2 + 1)
+                cand[b, :len(take)] = take[:m]
+        for et in ([0], [1, 3], [0, 1, 2, 3], [], [9]):
+            x = B.sparse_get_adj(nodes, cand, batch, n, m, et)
+            y = OB.sparse_get_adj(nodes, cand, batch, n, m, et)
+            assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
+            ind, val, shape = G.sparse_get_adj(
+                torch.as_tensor(nodes.view(np.int64)).cuda(),
+                torch.as_tensor(cand.view(np.int64)).cuda(), et, n, m)
+            wi, wv, ws = OG._adj_to_sparse(nodes, cand, batch, n, m, *y)
+            assert np.array_equal(t2n(ind), wi) and np.array_equal(t2n(val), wv)
+            assert list(shape) == list(ws)
+    for batch, n, count in ((4, 3, 10), (2, 16, 5), (6, 1, 4), (128, 25, 10), (1, 500, 64)):
+        nodes = rng.choice(ids, (batch, n)).astype(np.uint64)
+        nodes[-1, -1] = 0
+        for et in ([0], [0, 1], [0, 1, 2, 3]):
+            for call, dn in ((0, -1), (9, 31337)):
+                x = B.sample_neighbor_layerwise(21, call, nodes, et, count, dn)
+                y = OB.sample_neighbor_layerwise(21, call, nodes, et, count, dn)
+                for u, v in zip(x, y):
+                    assert np.array_equal(u, v)
+
+
+def test_layerwise_empty_and_errors(EA, O, torch_cuda, fixture_csr):
+    torch = torch_cuda
+    G = gpu_graph(EA, fixture_csr)
+    e = torch.zeros(0, dtype=torch.int64, device="cuda")
+    assert G.get_edge_sum_weight(e, [0]).numel() == 0
+    assert G.sample_layer(e, [0])[0].numel() == 0
+    idx, vals = G.sparse_get_adj_core(e, e, 3, 4, [0])
+    assert idx.shape == (0, 2) and vals.numel() == 0
+    ind, val, shape = G.sparse_get_adj(e, e, [0], 3, 4)
+    assert ind.shape == (0, 3) and shape == [0, 0, 0]
+    nodes = torch.as_tensor(fixture_csr.row_id.astype(np.int64)).cuda()
+    # no candidates: every root has an empty slice, the TF form has no entries
+    idx, vals = G.sparse_get_adj_core(nodes, e, 1, 0, [0])
+    assert t2n(idx).sum() == 0 and vals.numel() == 0
+    nb, (ind, val, shape) = G.sample_neighbor_layerwise(nodes.reshape(1, -1), [0, 1], 0)
+    assert nb.shape == (1, 0) and ind.shape[0] == 0
+    with pytest.raises(NotImplementedError):
+        G.sample_neighbor_layerwise(nodes.reshape(1, -1), [0], 4, weight_func="sqrt")
+    with pytest.raises(ValueError):
+        G.sample_neighbor_layerwise(nodes, [0], 4)
+    from euler_amd._lib import EulerGpuError
+    with pytest.raises(EulerGpuError):
+        G.get_edge_sum_weight(nodes, list(range(40)))
+
+
+def test_layerwise_ops_surface_and_dataflows(EA, O, torch_cuda, lw_pair):
+    """euler_ops.sample_fanout_layerwise(_each_node) / get_multi_hop_neighbor
+    and Layerwise / Whole dataflows == the same compositions on the oracle."""
+    torch = torch_cuda
+    from euler_amd import euler_ops as ops
+    from euler_amd.euler_ops import base
+    G, OG, ids, rng = lw_pair
+    OB = OracleBackend(O, OG)
+    base.set_default_graph(G)
+    roots = rng.choice(ids, 32).astype(np.int64)
+    rt = torch.as_tensor(roots).cuda()
+
+    # sample_fanout_layerwise: one batch row per hop (call ids 700, 701)
+    G.set_seed(5, call_id=700)
+    nl, al = ops.sample_fanout_layerwise(rt, [[0, 1], [2, 3]], [20, 10], default_node=-1)
+    cur, last = roots.reshape(1, -1), len(roots)
+    for h, (et, c) in enumerate((([0, 1], 20), ([2, 3], 10))):
+        nb, ind, val, shape = OB.sample_neighbor_layerwise(5, 700 + h,
+                                                           cur.view(np.uint64), et, c, -1)
+        assert np.array_equal(t2n(nl[h + 1]), nb.reshape(-1))
+        assert np.array_equal(t2n(al[h][0]), ind) and np.array_equal(t2n(al[h][1]), val)
+        assert list(al[h][2]) == list(shape)
+        cur = nb.reshape(1, -1)
+
+    # sample_fanout_layerwise_each_node: hop 1 sample_neighbor (call 710), hop 2
+    # layerwise over each root's own 6 neighbours (call 711)
+    G.set_seed(5, call_id=710)
+    nl, al = ops.sample_fanout_layerwise_each_node(rt, [[0], [0, 1, 2, 3]], [6, 4])
+    n1 = OG.sample_neighbor(5, 710, roots, [0], 6, -1)[0]
+    assert np.array_equal(t2n(nl[1]), n1.reshape(-1))
+    nb, ind, val, shape = OB.sample_neighbor_layerwise(
+        5, 711, n1.reshape(-1, 6).view(np.uint64), [0, 1, 2, 3], 4, -1)
+    assert np.array_equal(t2n(nl[2]), nb.reshape(-1)) and np.array_equal(t2n(al[0][0]), ind)
+
+    # get_multi_hop_neighbor: distinct full neighbours + weighted adjacency
+    nodes_list, adj_list = ops.get_multi_hop_neighbor(rt, [[0, 1], [3]])
+    cur = roots.astype(np.uint64)
+    for h, et in enumerate(([0, 1], [3])):
+        idx, fid, fw, _ = OG.get_full_neighbor(cur, et)
+        rows = np.repeat(np.arange(len(cur)), idx[:, 1] - idx[:, 0])
+        uq, gi = O.id_unique(fid)
+        order = np.argsort(rows * max(len(uq), 1) + gi.astype(np.int64), kind="stable")
+        assert np.array_equal(t2n(nodes_list[h + 1]).view(np.uint64), uq)
+        gi_, gv_, gs_ = adj_list[h]
+        assert np.array_equal(t2n(gi_), np.stack([rows[order], gi.astype(np.int64)[order]], 1))
+        assert np.array_equal(t2n(gv_), fw[order]) and gs_ == [len(cur), len(uq)]
+        cur = uq
+
+    # WholeDataFlow: sparse_get_adj(n_id, n_id) read as the reference reads it
+    flow = EA.dataflow.WholeDataFlow(G, [[0, 1], [0, 1]], add_self_loops=True)
+    df = flow(rt)
+    idx, vals = OB.sparse_get_adj(roots.view(np.uint64), roots.view(np.uint64), 1,
+                                  len(roots), len(roots), [0, 1])
+    wi, wv, ws = OG._adj_to_sparse(roots.view(np.uint64), roots.view(np.uint64), 1,
+                                   len(roots), len(roots), idx, vals)
+    inv = np.arange(len(roots))
+    want = np.stack([np.concatenate([wi[:, 0], inv]), np.concatenate([wi[:, 1], inv])])
+    assert len(df) == 2
+    for blk in df:
+        assert np.array_equal(t2n(blk.edge_index), want)
+        assert np.array_equal(t2n(blk.n_id), roots) and blk.size == [32, 32]
+
+    # LayerwiseDataFlow: hop 1 layerwise over the batch (call 720), last hop full
+    G.set_seed(5, call_id=720)
+    flow = EA.dataflow.LayerwiseDataFlow(G, [8, 8], [[0, 1, 2, 3], [0]],
+                                         add_self_loops=False)
+    df = flow(rt)
+
+    def uniq(a):
+        uq, gi = O.id_unique(np.asarray(a).astype(np.uint64))
+        return uq.astype(np.int64), gi.astype(np.int64)
+
+    nb, ind, val, shape = OB.sample_neighbor_layerwise(
+        5, 720, roots.reshape(1, -1).view(np.uint64), [0, 1, 2, 3], 8, -1)
+    nbrs = [nb.reshape(-1)[ind[:, 2]]]
+    srcs = [ind[:, 1]]
+    n_id, _ = uniq(np.concatenate([nbrs[0], roots]))
+    idx, fid, _, _ = OG.get_full_neighbor(n_id.astype(np.uint64), [0])
+    nbrs.append(fid.astype(np.int64))
+    srcs.append(np.repeat(np.arange(len(n_id)), idx[:, 1] - idx[:, 0]))
+    n_id = roots.copy()
+    for i, blk in enumerate(df.blocks):
+        new_n_id, inv = uniq(np.concatenate([nbrs[i], n_id]))
+        res = inv[-len(n_id):]
+        inv = inv[:-len(n_id)]
+        assert np.array_equal(t2n(blk.n_id), new_n_id)
+        assert np.array_equal(t2n(blk.res_n_id), res)
+        assert np.array_equal(t2n(blk.edge_index), np.stack([srcs[i], inv]))
+        n_id = new_n_id
+
+
+def test_layerwise_plugin_dag(EA, O, torch_cuda, lw_pair):
+    """The six registered op kernels executed as the reference's translator
+    chains them (euler_op_run_sample_lnb) == the oracle's op-by-op chain."""
+    import ctypes as C
+    from euler_amd import _lib
+    L = _lib.lib()
+    G, OG, ids, rng = lw_pair
+    for batch, n, m in ((3, 4, 6), (1, 20, 50), (16, 1, 3)):
+        nodes = rng.choice(ids, (batch, n)).astype(np.uint64)
+        nodes[0, 0] = 12345678901234            # unknown node: weight 0
+        for et in ([0], [1, 2, 3]):
+            eta = np.asarray(et, np.int32)
+            cap = batch * n * m
+            adj_idx = np.zeros((batch * n, 2), np.int32)
+            adj_id = np.zeros(cap, np.uint64)
+            l_nb = np.zeros(batch * m, np.uint64)
+            flat = np.ascontiguousarray(nodes.reshape(-1))
+            got = L.euler_op_run_sample_lnb(
+                G._h, 31, 7, flat.ctypes.data_as(_lib.u64p), batch, n,
+                eta.ctypes.data_as(_lib.i32p), len(eta), m, -1, cap,
+                adj_idx.ctypes.data_as(_lib.i32p), adj_id.ctypes.data_as(_lib.u64p),
+                l_nb.ctypes.data_as(_lib.u64p))
+            assert got >= 0, got
+            w = OG.get_edge_sum_weight(flat, et)
+            l_root = O.sample_root(31, 7, flat, w, n, m, -1)
+            want_nb = OG.sample_layer(31, 8, l_root, et, -1)[0]
+            widx, wvals = OG.sparse_get_adj(flat, want_nb, batch, n, m, et)
+            assert np.array_equal(l_nb, want_nb)
+            assert np.array_equal(adj_idx, widx) and got == len(wvals)
+            assert np.array_equal(adj_id[:got], wvals)

@@ -292,3 +292,31 @@ def test_sorted_and_top_k_neighbor_reference_goldens(O, fixture_csr):
     top = O.neighbor_post_process(*full, order_by="weight", desc=True, limit=4)
     di, dw, dt = O.neighbor_to_dense(*top, 4, -1)
     assert di[1].tolist() == [5, 3, -1, -1] and dt[1].tolist() == [1, 1, -1, -1]
+
+
+# ------------------------------------------------------------------ layerwise
+def test_layerwise_goldens(O, fixture_csr, random_csr):
+    """sampleLNB op chain + SparseGetAdj against vectors produced by the
+    reference (fixture loaded with its Edge records; random graph)."""
+    import os
+    from conftest import GOLDEN
+    from layer_cases import OracleBackend, check_layer_pack
+    L = np.load(os.path.join(GOLDEN, "layerwise.npz"))
+    G = O.OracleGraph(fixture_csr)
+    check_layer_pack(OracleBackend(O, G), L, "fx_", 2)
+    # EdgeExist answered from the rows == the reference's Edge records
+    have = {tuple(x) for x in L["fx_edges"].tolist()}
+    ids = fixture_csr.row_id
+    for s in ids:
+        for d in list(ids) + [0, 99]:
+            for t in (0, 1, 2):
+                idx, vals = G.sparse_get_adj([s], [d], 1, 1, 1, [t])
+                assert (len(vals) == 1) == ((int(s), int(d), t) in have)
+    # the reference's own test batches (neighbor_ops_test.py:142-175)
+    nb, ind, val, shape = G.sample_neighbor_layerwise(int(L["seed"]), 90, L["fx_t_nodes"],
+                                                      [0, 1], 10, -1)
+    assert np.array_equal(nb, L["fx_t_nb"]) and np.array_equal(ind, L["fx_t_ind"])
+    assert np.array_equal(val, L["fx_t_val"]) and list(shape) == [4, 3, 10]
+    assert set(nb[0].tolist()) <= {2, 3, 4, 5} and set(nb[2].tolist()) <= {3, 4, 5}
+    assert set(nb[3].tolist()) <= {3, 5}
+    check_layer_pack(OracleBackend(O, O.OracleGraph(random_csr)), L, "rg_", 3)
