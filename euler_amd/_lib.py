@@ -78,6 +78,9 @@ SIGNATURES = {
                                         C.c_int32, C.c_int32, vp]),
     "euler_gpu_get_full_neighbor": (C.c_int, [vp, vp, vp, C.c_int64, i32p, C.c_int32,
                                               vp, i64p, vp, vp, vp]),
+    "euler_gpu_get_node_type": (C.c_int, [vp, vp, vp, C.c_int64, vp]),
+    "euler_gpu_sample_n_with_types": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp,
+                                                C.c_int64, C.c_int32, vp]),
     "euler_gpu_get_edge_sum_weight": (C.c_int, [vp, vp, vp, C.c_int64, i32p, C.c_int32, vp]),
     "euler_gpu_sample_root": (C.c_int, [vp, C.c_uint64, C.c_uint32, vp, vp, C.c_int64,
                                         C.c_int32, C.c_int32, C.c_int64, vp]),

@@ -178,6 +178,7 @@ struct euler_gpu_graph {
   uint64_t max_id = 0;          // largest node id of this graph (shard)
   std::vector<void*> allocations;     // every hipMalloc owned by the graph
   std::vector<float> node_weight_sums;
+  const int32_t* node_type_dev = nullptr;   // [n_rows] node types; nullptr = all 0
   bool feat_slot_aligned = false;     // uniform feature table: every slot begins at a
                                       // multiple of 4 floats (16-byte lanes allowed)
   // scratch of the sampling launcher (dedup table, unique rows), one buffer

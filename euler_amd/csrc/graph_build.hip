@@ -525,6 +525,13 @@ int BuildGraphFromHost(const euler_gpu_host_csr* c, int device,
     int rc = BuildNodeSampler(&b, ids, types, weights, n_types);
     if (rc != EULER_GPU_OK) { DestroyGraph(b.g.release()); return rc; }
   }
+  // node types in row order (API_GET_NODE_T); graphs without types keep nullptr
+  if (c->node_type && n > 0) {
+    std::vector<int32_t> row_type((size_t)n);
+    for (int64_t i = 0; i < n; ++i) row_type[i] = c->node_type[keep[i]];
+    b.g->node_type_dev = b.Upload(row_type.data(), row_type.size());
+    if (b.rc != EULER_GPU_OK) { DestroyGraph(b.g.release()); return b.rc; }
+  }
   *out = b.g.release();
   return EULER_GPU_OK;
 }

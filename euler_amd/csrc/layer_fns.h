@@ -136,4 +136,47 @@ EG_HD bool EdgeExistAny(const GraphView& g, int64_t row, uint64_t dst,
   return false;
 }
 
+// Graph::GetNodeByID(id)->GetType() (core/api/api.cc:50-61, GetNodeType):
+// DEFAULT_INT32 = numeric_limits<int32_t>::lowest() for an unknown node
+// (common/data_types.cc:23).  node_type == nullptr: every node has type 0.
+EG_HD int32_t NodeTypeOf(const GraphView& g, const int32_t* node_type, uint64_t id) {
+  const int64_t row = FindRow(g, id);
+  if (row < 0) return (int32_t)0x80000000;
+  return node_type ? node_type[row] : 0;
+}
+
+// Sample j of ONE Graph::SampleNode(type, count) call (core/graph/graph.cc:
+// 221-245), the call API_SAMPLE_N_WITH_TYPES makes per listed type
+// (core/kernels/sample_n_with_types_op.cc:44-52).  RNG: domain NODE, stream =
+// the index of the call inside the op, draws in the call's program order (2 per
+// sample for a fixed type, 4 for type -1).  *ok = false where the reference
+// returns an empty vector (zero weight) or indexes node_samplers_ out of range.
+EG_HD uint64_t SampleNodeOfType(const NodeSamplerView& s, uint64_t seed,
+                                uint32_t call_id, uint64_t stream, int32_t type,
+                                int32_t j, bool* ok) {
+  *ok = false;
+  int32_t t = type;
+  uint32_t block = (uint32_t)j;
+  if (type == -1) {
+    if (s.tc_sum == 0.f) return 0;
+    const Philox4 b = RngBlock(seed, call_id, kDomainNode, stream, 2u * (uint32_t)j);
+    const int64_t col = (int64_t)floor(EG_DMUL((double)s.n_types,
+                                               UnitFromWords(b.w[0], b.w[1])));
+    t = UnitFromWords(b.w[2], b.w[3]) < (double)s.tc_prob[col] ? (int32_t)col
+                                                                : s.tc_alias[col];
+    block = 2u * (uint32_t)j + 1u;
+  } else {
+    if (type < 0 || type >= s.n_types) return 0;
+    if (s.sampler_sum[type] == 0.f || s.type_off[type + 1] == s.type_off[type]) return 0;
+  }
+  const Philox4 b = RngBlock(seed, call_id, kDomainNode, stream, block);
+  const int64_t base = s.type_off[t];
+  const int64_t n = s.type_off[t + 1] - base;
+  // AliasMethod::Next (alias_method.cc:66-78)
+  const int64_t column = (int64_t)floor(EG_DMUL((double)n, UnitFromWords(b.w[0], b.w[1])));
+  const AliasEntry e = s.entries[base + column];
+  *ok = true;
+  return UnitFromWords(b.w[2], b.w[3]) < (double)e.prob ? e.id_self : e.id_alias;
+}
+
 }  // namespace euler_gpu

@@ -176,6 +176,31 @@ __global__ void AdjOffsetsToIdxKernel(const int64_t* __restrict__ off, int64_t n
   }
 }
 
+// ---------------------------------------------------------------- node types
+__global__ __launch_bounds__(256) void NodeTypeKernel(
+    const GraphView g, const int32_t* __restrict__ node_type,
+    const uint64_t* __restrict__ ids, int64_t n, int32_t* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = NodeTypeOf(g, node_type, ids[i]);
+}
+
+// one lane per (row i, sample j) of API_SAMPLE_N_WITH_TYPES
+__global__ __launch_bounds__(256) void SampleNWithTypesKernel(
+    const NodeSamplerView s, const int32_t* __restrict__ types, int64_t n,
+    int32_t count, uint64_t seed, uint32_t call_id, uint64_t* __restrict__ out,
+    int32_t* __restrict__ bad) {
+  const int64_t total = n * count;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < total; x += stride) {
+    const int64_t i = x / count;
+    const int32_t j = (int32_t)(x - i * count);
+    bool ok;
+    out[x] = SampleNodeOfType(s, seed, call_id, (uint64_t)i, types[i], j, &ok);
+    if (!ok && j == 0) *bad = 1;
+  }
+}
+
 int FillTypes(const int32_t* edge_types_host, int32_t k, TypeList* tl, const char* who) {
   if (k < 0 || k > kMaxListedTypes || (k > 0 && !edge_types_host))
     return Fail(EULER_GPU_EINVAL, std::string(who) + ": bad edge type list (<= 32)");
@@ -307,6 +332,48 @@ int euler_gpu_sample_neighbor_layerwise(const euler_gpu_graph* g, void* stream,
   hipError_t f = hipFreeAsync(buf, st);
   if (rc != EULER_GPU_OK) return rc;
   EG_HIP(f);
+  return EULER_GPU_OK;
+}
+
+int euler_gpu_get_node_type(const euler_gpu_graph* g, void* stream,
+                            const uint64_t* ids_dev, int64_t n, int32_t* out_dev) {
+  if (!g) return Fail(EULER_GPU_ENOGRAPH, "get_node_type: null graph");
+  if (n < 0) return Fail(EULER_GPU_EINVAL, "get_node_type: n < 0");
+  if (n == 0) return EULER_GPU_OK;
+  if (!ids_dev || !out_dev) return Fail(EULER_GPU_EINVAL, "get_node_type: null buffer");
+  const int block = 256;
+  hipLaunchKernelGGL(NodeTypeKernel, dim3(GridFor(n, block)), dim3(block), 0,
+                     (hipStream_t)stream, g->view, g->node_type_dev, ids_dev, n, out_dev);
+  EG_HIP(hipGetLastError());
+  return EULER_GPU_OK;
+}
+
+int euler_gpu_sample_n_with_types(const euler_gpu_graph* g, void* stream, uint64_t seed,
+                                  uint32_t call_id, const int32_t* types_dev, int64_t n,
+                                  int32_t count, uint64_t* out_dev) {
+  if (!g) return Fail(EULER_GPU_ENOGRAPH, "sample_n_with_types: null graph");
+  if (!g->has_sampler)
+    return Fail(EULER_GPU_ENOGRAPH, "sample_n_with_types: graph has no global sampler");
+  if (n < 0 || count < 0) return Fail(EULER_GPU_EINVAL, "sample_n_with_types: bad sizes");
+  if (n == 0 || count == 0) return EULER_GPU_OK;
+  if (!types_dev || !out_dev)
+    return Fail(EULER_GPU_EINVAL, "sample_n_with_types: null buffer");
+  hipStream_t st = (hipStream_t)stream;
+  int32_t* bad = nullptr;
+  EG_HIP(hipMallocAsync((void**)&bad, sizeof(int32_t), st));
+  EG_HIP(hipMemsetAsync(bad, 0, sizeof(int32_t), st));
+  const int block = 256;
+  hipLaunchKernelGGL(SampleNWithTypesKernel, dim3(GridFor(n * count, block)), dim3(block),
+                     0, st, g->sampler, types_dev, n, count, seed, call_id, out_dev, bad);
+  hipError_t e = hipGetLastError();
+  int32_t bad_host = 0;
+  hipError_t c = hipMemcpyAsync(&bad_host, bad, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+  hipError_t y = hipStreamSynchronize(st);
+  hipError_t f = hipFreeAsync(bad, st);
+  EG_HIP(e); EG_HIP(c); EG_HIP(y); EG_HIP(f);
+  if (bad_host)
+    return Fail(EULER_GPU_EEMPTY,
+                "sample_n_with_types: a listed type is unknown or has zero weight");
   return EULER_GPU_OK;
 }
 

@@ -413,6 +413,32 @@ class Graph:
                 int(default_node), _ptr(out_n), _ptr(out_w), _ptr(out_t)))
         return out_n, out_w, out_t
 
+    def get_node_type(self, nodes):
+        """tf_euler get_node_type (tf_euler/kernels/get_node_type_op.cc): int32
+        type of every node, INT32_MIN for an unknown id."""
+        nodes = _as_i64_cuda(nodes, self.device).reshape(-1)
+        n = nodes.numel()
+        out = torch.empty(n, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().euler_gpu_get_node_type(self._h, _stream(), _ptr(nodes), n,
+                                                _ptr(out)))
+        return out
+
+    def sample_n_with_types(self, count, types, call_id=None):
+        """tf_euler sample_n_with_types (tf_euler/kernels/
+        sample_n_with_types_op.cc): [len(types), count] int64, row i drawn from
+        the global sampler of node type types[i] (-1: all types).  Raises where
+        the reference aborts (unknown / zero-weight type)."""
+        types = torch.as_tensor(types, dtype=torch.int32, device=self.device) \
+            .reshape(-1).contiguous()
+        n = types.numel()
+        out = torch.empty((n, int(count)), dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().euler_gpu_sample_n_with_types(
+                self._h, _stream(), self.seed, self._take_call_ids(1, call_id),
+                _ptr(types), n, int(count), _ptr(out)))
+        return out
+
     # ------------------------------------------------- layerwise sampling
     def get_edge_sum_weight(self, nodes, edge_types):
         """API_GET_EDGE_SUM_WEIGHT (core/kernels/get_edge_sum_weight_op.cc):

@@ -240,6 +240,23 @@ int euler_gpu_sample_node(const euler_gpu_graph* g, void* stream, uint64_t seed,
                           uint32_t call_id, const int32_t* node_types_host,
                           int32_t k, int32_t count, uint64_t* out_dev);
 
+/* API_GET_NODE_T / TF GetNodeType (core/kernels/get_node_type_op.cc:35-62,
+ * tf_euler/kernels/get_node_type_op.cc:33-57): the node type of every id;
+ * INT32_MIN (euler::common::DEFAULT_INT32) for an unknown node. */
+int euler_gpu_get_node_type(const euler_gpu_graph* g, void* stream,
+                            const uint64_t* ids_dev, int64_t n, int32_t* out_dev);
+
+/* API_SAMPLE_N_WITH_TYPES / TF SampleNWithTypes (core/kernels/
+ * sample_n_with_types_op.cc:33-75, tf_euler/kernels/sample_n_with_types_op.cc:
+ * 38-84; euler_ops sample_node_with_src): row i of out_dev [n, count] = one
+ * Graph::SampleNode(types_dev[i], count) call (type -1 = all types).  RNG:
+ * domain 1, stream = i.  A type that is out of range or has zero weight makes
+ * the reference's TF kernel abort ("samples size error, invalid node types!");
+ * here the call returns EULER_GPU_EEMPTY.  Synchronises the stream. */
+int euler_gpu_sample_n_with_types(const euler_gpu_graph* g, void* stream, uint64_t seed,
+                                  uint32_t call_id, const int32_t* types_dev, int64_t n,
+                                  int32_t count, uint64_t* out_dev);
+
 /* ---- full neighbours ------------------------------------------------------
  * euler::GetFullNeighbor (core/api/api.cc:208-221) -> Node::GetFullNeighbor
  * (core/graph/node.cc:175-197) in the FillNeighbor layout.  Two calls: first

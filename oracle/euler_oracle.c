@@ -471,10 +471,38 @@ void eo_node_sampler_destroy(eo_node_sampler* s) {
 
 /* euler::SampleNode (api.cc:32-37) -> Graph::SampleNode (graph.cc:221-275).
  * One RNG stream per call (domain NODE, stream 0), draws in program order. */
+static int64_t eo_sample_node_stream(const eo_node_sampler* s, uint64_t seed,
+                                     uint32_t call_id, uint64_t stream,
+                                     const int32_t* node_types, int32_t k,
+                                     int32_t count, uint64_t* out);
+
 int64_t eo_sample_node(const eo_node_sampler* s, uint64_t seed,
                        uint32_t call_id, const int32_t* node_types, int32_t k,
                        int32_t count, uint64_t* out) {
-  eo_rng_ctx rng = {seed, call_id, EO_DOMAIN_NODE, 0, 0};
+  return eo_sample_node_stream(s, seed, call_id, 0, node_types, k, count, out);
+}
+
+/* API_SAMPLE_N_WITH_TYPES (core/kernels/sample_n_with_types_op.cc:44-52) as the
+ * TF kernel calls it (tf_euler/kernels/sample_n_with_types_op.cc:50-57: the same
+ * count for every type): one SampleNode({type}, count) per listed type, its RNG
+ * stream = the index of the call.  Returns 0, or -1 where the TF kernel would
+ * abort ("samples size error, invalid node types!"). */
+int eo_sample_n_with_types(const eo_node_sampler* s, uint64_t seed,
+                           uint32_t call_id, const int32_t* types, int64_t n,
+                           int32_t count, uint64_t* out) {
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t got = eo_sample_node_stream(s, seed, call_id, (uint64_t)i, types + i, 1,
+                                        count, out + i * count);
+    if (got != count) return -1;
+  }
+  return 0;
+}
+
+static int64_t eo_sample_node_stream(const eo_node_sampler* s, uint64_t seed,
+                                     uint32_t call_id, uint64_t stream,
+                                     const int32_t* node_types, int32_t k,
+                                     int32_t count, uint64_t* out) {
+  eo_rng_ctx rng = {seed, call_id, EO_DOMAIN_NODE, stream, 0};
   const int32_t T = s->n_types;
   if (k == 1) {
     int32_t type = node_types[0];

@@ -172,6 +172,9 @@ void eo_node_sampler_destroy(eo_node_sampler* s);
 int64_t eo_sample_node(const eo_node_sampler* s, uint64_t seed,
                        uint32_t call_id, const int32_t* node_types, int32_t k,
                        int32_t count, uint64_t* out);
+int eo_sample_n_with_types(const eo_node_sampler* s, uint64_t seed,
+                           uint32_t call_id, const int32_t* types, int64_t n,
+                           int32_t count, uint64_t* out);
 
 int eo_random_walk(const eo_graph* g, uint64_t seed, uint32_t call_id,
                    const int64_t* nodes, int64_t n, const int32_t* edge_types,

@@ -135,6 +135,8 @@ def lib():
                                      _i32p, _u64p, _f32p, _f32p]
         L.eo_philox_kat.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                     C.POINTER(C.c_uint32)]
+        L.eo_sample_n_with_types.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, _i32p,
+                                             C.c_int64, C.c_int32, _u64p]
         L.eo_get_edge_sum_weight.argtypes = [C.c_void_p, _u64p, C.c_int64, _i32p,
                                              C.c_int32, _f32p]
         L.eo_sample_root.argtypes = [C.c_uint64, C.c_uint32, _u64p, _f32p, C.c_int64,
@@ -208,6 +210,9 @@ def ref():
         R.euler_ref_num_float_features.restype = C.c_int32
         R.euler_ref_get_dense_feature.argtypes = [_u64p, C.c_int64, C.c_int32,
                                                   C.c_int32, _f32p]
+        R.euler_ref_sample_n_with_types.argtypes = [C.c_uint64, C.c_uint32, _i32p,
+                                                    C.c_int64, C.c_int32, _u64p]
+        R.euler_ref_get_node_type.argtypes = [_u64p, C.c_int64, _i32p]
         R.euler_ref_graph_load_all.argtypes = [C.c_char_p]
         R.euler_ref_add_edges_from_adjacency.restype = C.c_int64
         R.euler_ref_num_edges.restype = C.c_int64
@@ -501,6 +506,25 @@ class OracleGraph(_LayerwiseMixin):
                                    len(et), _p(idx, _i32p), _p(oid, _u64p),
                                    _p(ow, _f32p), _p(ot, _i32p))
         return idx, oid, ow, ot
+
+    def get_node_type(self, ids):
+        """euler::GetNodeType (api.cc:50-61): DEFAULT_INT32 for unknown ids."""
+        ids = _arr(ids, np.uint64)
+        out = np.full(len(ids), -2 ** 31, np.int32)
+        for i, v in enumerate(ids):
+            r = lib().eo_graph_find_row(self.h, int(v))
+            if r >= 0:
+                out[i] = self.csr.node_type[r]
+        return out
+
+    def sample_n_with_types(self, seed, call_id, types, count):
+        """[len(types), count] ids, or None where the TF kernel aborts."""
+        types = _arr(types, np.int32)
+        out = np.zeros((len(types), count), np.uint64)
+        rc = lib().eo_sample_n_with_types(self._sampler, seed, call_id,
+                                          _p(types, _i32p), len(types), count,
+                                          _p(out, _u64p))
+        return out if rc == 0 else None
 
     # ---- layerwise primitives (C restatement)
     _adj_to_sparse = staticmethod(adj_to_sparse)
@@ -800,6 +824,19 @@ class RefGraph(_LayerwiseMixin):
 
     def __init__(self, n_types):
         self.n_types = n_types
+
+    def get_node_type(self, ids):
+        ids = _arr(ids, np.uint64)
+        out = np.zeros(len(ids), np.int32)
+        ref().euler_ref_get_node_type(_p(ids, _u64p), len(ids), _p(out, _i32p))
+        return out
+
+    def sample_n_with_types(self, seed, call_id, types, count):
+        types = _arr(types, np.int32)
+        out = np.zeros((len(types), count), np.uint64)
+        rc = ref().euler_ref_sample_n_with_types(seed, call_id, _p(types, _i32p),
+                                                 len(types), count, _p(out, _u64p))
+        return out if rc == 0 else None
 
     # ---- layerwise primitives (reference code through the harness)
     @staticmethod

@@ -724,4 +724,29 @@ int64_t euler_ref_adj_to_sparse(const uint64_t* nodes, const uint64_t* nb_nodes,
   return nnz;
 }
 
+// API_SAMPLE_N_WITH_TYPES body (sample_n_with_types_op.cc:44-52) with the TF
+// kernel's inputs (one count for all types); RNG stream = index of the call.
+// Returns 0, or -1 where the TF kernel aborts on a size mismatch.
+int euler_ref_sample_n_with_types(uint64_t seed, uint32_t call_id, const int32_t* types,
+                                  int64_t n, int32_t count, uint64_t* out) {
+  for (int64_t i = 0; i < n; ++i) {
+    // Graph::SampleNode indexes node_samplers_[type] unchecked (graph.cc:238)
+    if (types[i] != -1 &&
+        (types[i] < 0 || types[i] >= (int32_t)G().node_samplers_.size()))
+      return -1;
+    euler_ref_set_rng(seed, call_id, EO_DOMAIN_NODE, (uint64_t)i);
+    auto vec = euler::SampleNode({types[i]}, count);
+    if ((int32_t)vec.size() != count) return -1;
+    std::copy(vec.begin(), vec.end(), out + i * count);
+  }
+  return 0;
+}
+
+// euler::GetNodeType (api.cc:50-61).
+void euler_ref_get_node_type(const uint64_t* ids, int64_t n, int32_t* out) {
+  std::vector<uint64_t> v(ids, ids + n);
+  auto t = euler::GetNodeType(v);
+  std::copy(t.begin(), t.end(), out);
+}
+
 }  // extern "C"

@@ -269,3 +269,34 @@ def test_layerwise_plugin_dag(EA, O, torch_cuda, lw_pair):
             assert np.array_equal(l_nb, want_nb)
             assert np.array_equal(adj_idx, widx) and got == len(wvals)
             assert np.array_equal(adj_id[:got], wvals)
+
+
+def test_node_type_and_sample_node_with_src(EA, O, torch_cuda, random_csr):
+    """get_node_type / sample_n_with_types (sample_node_with_src) == oracle."""
+    torch = torch_cuda
+    from euler_amd._lib import EulerGpuError
+    from euler_amd import euler_ops as ops
+    from euler_amd.euler_ops import base
+    G = gpu_graph(EA, random_csr)
+    OG = O.OracleGraph(random_csr)
+    OG.build_node_sampler()
+    rng = np.random.default_rng(3)
+    q = np.concatenate([rng.choice(random_csr.row_id, 5000), [0, 2 ** 63 + 5]]).astype(np.uint64)
+    qt = torch.as_tensor(q.view(np.int64)).cuda()
+    assert np.array_equal(t2n(G.get_node_type(qt)), OG.get_node_type(q))
+    types = np.concatenate([OG.get_node_type(q[:5000]), [-1, -1, 0, 1]]).astype(np.int32)
+    for call, count in ((0, 1), (1, 5), (2, 16)):
+        G.set_seed(13)
+        got = G.sample_n_with_types(count, types, call_id=call)
+        want = OG.sample_n_with_types(13, call, types, count)
+        assert np.array_equal(t2n(got).view(np.uint64), want)
+    base.set_default_graph(G)
+    G.set_seed(13, call_id=40)
+    got = ops.sample_node_with_src(qt[:100], 7)
+    want = OG.sample_n_with_types(13, 40, OG.get_node_type(q[:100]), 7)
+    assert np.array_equal(t2n(got).view(np.uint64), want)
+    with pytest.raises(EulerGpuError):          # the TF kernel aborts here
+        G.sample_n_with_types(3, [0, 7])
+    with pytest.raises(EulerGpuError):          # unknown src node: type INT32_MIN
+        ops.sample_node_with_src(qt[-1:], 2)
+    assert G.sample_n_with_types(0, [0]).shape == (1, 0)

@@ -240,3 +240,19 @@ def test_sample_neighbor_layerwise_matches_reference(lpair):
                 y = G.sample_neighbor_layerwise(21, call, nodes, et, count, dn)
                 for u, v in zip(x, y):
                     assert np.array_equal(u, v)
+
+
+def test_node_type_and_sample_n_with_types_match_reference(lpair):
+    R, G, ids, rng = lpair
+    q = np.concatenate([rng.choice(ids, 300), [0, 2 ** 63 + 5]]).astype(np.uint64)
+    assert np.array_equal(R.get_node_type(q), G.get_node_type(q))
+    assert G.get_node_type(q)[-1] == -2 ** 31
+    G.build_node_sampler(order=R.node_order())
+    types = np.concatenate([G.get_node_type(q[:300]), [-1, -1, 0, 1]]).astype(np.int32)
+    for call, count in ((0, 1), (1, 5), (2, 16)):
+        a = R.sample_n_with_types(13, call, types, count)
+        b = G.sample_n_with_types(13, call, types, count)
+        assert a is not None and np.array_equal(a, b)
+    # rows are independent SampleNode calls: row i == SampleNode with stream i
+    assert R.sample_n_with_types(13, 0, [0, 7], 3) is None
+    assert G.sample_n_with_types(13, 0, [0, 7], 3) is None
