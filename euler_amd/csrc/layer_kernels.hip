@@ -11,11 +11,24 @@
 //                            tf_euler/kernels/sample_neighbor_layerwise_with_adj_op.cc:56-150
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <thread>
 #include <vector>
 
 #include "layer_fns.h"
 
 namespace euler_gpu {
+
+// euler_gpu_set_tuning key 15.  API_SAMPLE_ROOT's table build (Vose's alias
+// method with LIFO stacks, common/alias_method.cc:23-63) is one dependency
+// chain per batch row: with many rows they run one per lane, but a call with
+// FEW rows - the layerwise dataflow passes the whole frontier as ONE row
+// (tf_euler/python/dataflow/layerwise_dataflow.py:44-47) - would leave a
+// single lane walking n elements through HBM latency.  Calls with fewer rows
+// than this build their tables with the host's cores (the same AliasBuildRow
+// source, compiled for the host) between two copies; the draws stay on the
+// device.  0 = always on the device.
+int g_root_host_batch = 64;
 
 int ExclusiveScanI64(hipStream_t stream, const int64_t* in, int64_t* out,
                      int64_t n);   // mp_kernels.hip
@@ -268,14 +281,52 @@ int euler_gpu_sample_root(void* stream, uint64_t seed, uint32_t call_id,
   s.stack = s.alias + cells;
   s.sum = reinterpret_cast<float*>(s.stack + cells);
   const int block = 256;
-  hipLaunchKernelGGL(SampleRootBuildKernel, dim3(GridFor(batch, block)), dim3(block), 0,
-                     st, weights_dev, batch, n, s);
+  const bool on_host = batch < g_root_host_batch;
+  std::vector<float> h_w, h_wn, h_prob, h_sum;
+  std::vector<int32_t> h_alias, h_stack;
+  if (on_host) {
+    h_w.resize(cells); h_wn.resize(cells); h_prob.assign(cells, 0.f); h_sum.resize(batch);
+    h_alias.assign(cells, 0); h_stack.resize(cells);
+    hipError_t c = hipMemcpyAsync(h_w.data(), weights_dev, (size_t)cells * 4,
+                                  hipMemcpyDeviceToHost, st);
+    if (c == hipSuccess) c = hipStreamSynchronize(st);
+    if (c != hipSuccess) { (void)hipFreeAsync(buf, st); EG_HIP(c); }
+    auto build = [&](int64_t b0, int64_t b1) {
+      for (int64_t b = b0; b < b1; ++b)
+        h_sum[b] = AliasBuildRow(h_w.data() + b * n, n, batch, h_wn.data() + b,
+                                 h_prob.data() + b, h_alias.data() + b,
+                                 h_stack.data() + b);
+    };
+    const int64_t hw = (int64_t)std::thread::hardware_concurrency();
+    const int64_t n_thr = std::min<int64_t>(std::min<int64_t>(batch, 8),
+                                            std::max<int64_t>(1, std::min<int64_t>(hw, cells >> 14)));
+    if (n_thr <= 1) {
+      build(0, batch);
+    } else {
+      std::vector<std::thread> pool;
+      for (int64_t t = 0; t < n_thr; ++t)
+        pool.emplace_back(build, batch * t / n_thr, batch * (t + 1) / n_thr);
+      for (auto& th : pool) th.join();
+    }
+    c = hipMemcpyAsync(s.prob, h_prob.data(), (size_t)cells * 4, hipMemcpyHostToDevice, st);
+    if (c == hipSuccess)
+      c = hipMemcpyAsync(s.alias, h_alias.data(), (size_t)cells * 4, hipMemcpyHostToDevice, st);
+    if (c == hipSuccess)
+      c = hipMemcpyAsync(s.sum, h_sum.data(), (size_t)batch * 4, hipMemcpyHostToDevice, st);
+    if (c != hipSuccess) { (void)hipFreeAsync(buf, st); EG_HIP(c); }
+  } else {
+    hipLaunchKernelGGL(SampleRootBuildKernel, dim3(GridFor(batch, block)), dim3(block), 0,
+                       st, weights_dev, batch, n, s);
+  }
   hipLaunchKernelGGL(SampleRootDrawKernel, dim3(GridFor(batch * m, block)), dim3(block),
                      0, st, roots_dev, batch, n, m, seed, call_id, default_node, s,
                      out_dev);
   hipError_t e = hipGetLastError();
+  // the host vectors feed asynchronous copies: they must outlive them
+  hipError_t y = on_host ? hipStreamSynchronize(st) : hipSuccess;
   hipError_t f = hipFreeAsync(buf, st);
   EG_HIP(e);
+  EG_HIP(y);
   EG_HIP(f);
   return EULER_GPU_OK;
 }

@@ -565,6 +565,10 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  * key 14: duplicate roots: representatives numbered per workgroup + one small
  *        scan of the workgroup counts (1 [default]); 0 = device-wide scan over the
  *        positions with the flags evaluated in its loads.
+ * key 15: euler_gpu_sample_root: calls with fewer batch rows than this (default
+ *        64) build their alias tables with the host's cores between two copies
+ *        (the build is one sequential chain per row; the draws stay on the
+ *        device); 0 = always one lane per row on the device.
  * All settings produce identical results; the knobs exist for A/B measurements
  * and tests. */
 int euler_gpu_set_tuning(int32_t key, int32_t value);

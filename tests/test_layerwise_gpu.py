@@ -68,7 +68,21 @@ def test_layerwise_primitives_vs_oracle(EA, O, torch_cuda, lw_pair, et):
             assert np.array_equal(x, y)
 
 
-def test_sample_root_vs_oracle(EA, O, torch_cuda, lw_pair):
+@pytest.mark.parametrize("host_rows", [64, 0, 10 ** 9],
+                         ids=["root_auto", "root_device", "root_host"])
+def test_sample_root_vs_oracle(EA, O, torch_cuda, lw_pair, host_rows):
+    """Both builders of the alias tables (one lane per batch row on the device /
+    the host's cores for calls with few rows, tuning key 15) give the
+    reference's draws."""
+    from euler_amd import _lib
+    _lib.lib().euler_gpu_set_tuning(15, host_rows)
+    try:
+        _sample_root_cases(EA, O, torch_cuda, lw_pair)
+    finally:
+        _lib.lib().euler_gpu_set_tuning(15, 64)
+
+
+def _sample_root_cases(EA, O, torch_cuda, lw_pair):
     G, OG, ids, rng = lw_pair
     B, OB = GpuBackend(torch_cuda, G), OracleBackend(O, OG)
     for batch, n, m in ((1, 1, 1), (7, 2, 5), (300, 25, 10), (1000, 3, 64),
