@@ -22,13 +22,24 @@ namespace euler_gpu {
 // euler_gpu_set_tuning key 15.  API_SAMPLE_ROOT's table build (Vose's alias
 // method with LIFO stacks, common/alias_method.cc:23-63) is one dependency
 // chain per batch row: with many rows they run one per lane, but a call with
-// FEW rows - the layerwise dataflow passes the whole frontier as ONE row
-// (tf_euler/python/dataflow/layerwise_dataflow.py:44-47) - would leave a
-// single lane walking n elements through HBM latency.  Calls with fewer rows
-// than this build their tables with the host's cores (the same AliasBuildRow
-// source, compiled for the host) between two copies; the draws stay on the
-// device.  0 = always on the device.
-int g_root_host_batch = 64;
+// FEW LONG rows - the layerwise dataflow passes the whole frontier as ONE row
+// (tf_euler/python/dataflow/layerwise_dataflow.py:44-47) - leaves a single
+// lane walking n elements through HBM latency (measured: 0.6 - 0.85 us per
+// element whatever the batch; 60 ms for one row of 100 000).  Such calls build
+// their tables with the host's cores (the same AliasBuildRow source, compiled
+// for the host: ~8 ns per element + ~0.35 ms for two copies and a sync; 0.8 ms
+// for that row) and keep the draws on the device.
+// 1 = choose by that cost model [default], 0 = always the device, 2 = always the host.
+int g_root_host_batch = 1;
+
+static bool RootTablesOnHost(int64_t batch, int32_t n) {
+  if (g_root_host_batch != 1) return g_root_host_batch == 2;
+  const double dev_us = 0.85 * n + 20.0;
+  const double host_us = 350.0 + 0.008 * (double)batch * n;
+  return host_us < dev_us;
+}
+// key 16: SparseGetAdj mask by the direct scan (1) instead of the LDS hash (0).
+int g_adj_scan = 0;
 
 int ExclusiveScanI64(hipStream_t stream, const int64_t* in, int64_t* out,
                      int64_t n);   // mp_kernels.hip
@@ -41,12 +52,137 @@ struct TypeList {
 };
 
 // ---------------------------------------------------------------- sum weight
+// The sum must add the edge weights in storage order (f32 addition does not
+// associate), so a row is one dependency chain.  Short rows: one lane per node
+// (EdgeSumWeight).  Rows with more than kLongRow listed edges - a power-law
+// graph's hubs, which made one lane of the 1M-node call run 100 000+ dependent
+// iterations - are then added by the whole wave: 64 lanes fetch 64 consecutive
+// weights (coalesced, four chunks in flight) and the wave adds them in order
+// with a lane-shifting chain (ChunkChain): a few clocks per edge instead of a
+// memory round trip.
+constexpr int kLongRow = 128;
+
+// carry + d[0] + d[1] + ... + d[cnt-1] in exactly that order, d[k] held by lane
+// k.  Lane k's running sum is lane k-1's plus d[k]; instead of broadcasting one
+// lane per step (v_readlane -> SGPR -> v_add: the SGPR hazard made it ~29
+// clocks per edge) every lane repeats  s = shift_right_by_one_lane(s) + d  64
+// times as ONE v_add_f32 with a DPP wave_shr:1 operand: after step t lane t is
+// final, and re-evaluating a final lane reproduces the same bits, so nothing
+// needs masking.  Lane 0 takes the carry through d (carry + d[0] is the
+// reference's first addition; the sums start at +0 and can never be -0, so the
+// later `0 + x` of lane 0 is exact).
+__device__ __forceinline__ float ChunkChain(float carry, float d, int lane, int cnt) {
+  const float dp = lane == 0 ? __fadd_rn(carry, d) : d;
+  float s = dp;
+#pragma unroll
+  for (int t = 1; t < 64; ++t)
+    s = __fadd_rn(__int_as_float(__builtin_amdgcn_update_dpp(
+                      0, __float_as_int(s), 0x138 /* wave_shr:1 */, 0xf, 0xf, true)),
+                  dp);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), cnt - 1));
+}
+
+// One row, added by a whole wave.  The weights of the NEXT group of
+// kSumGroup x 64 edges are fetched while the chain of the current group runs
+// (a group's chain takes about as long as one HBM round trip; without the
+// overlap the wave sat idle for a round trip per group).
+constexpr int kSumGroup = 8;
+
+__device__ __forceinline__ void LoadWeightGroup(const float* nw, int32_t p0, int32_t e,
+                                                int lane, int (&di)[kSumGroup]) {
+#pragma unroll
+  for (int u = 0; u < kSumGroup; ++u) {
+    const int32_t p = p0 + 64 * u + lane;
+    float d = 0.f;
+    if (p < e) d = __fsub_rn(nw[p], p == 0 ? 0.f : nw[p - 1]);
+    di[u] = __float_as_int(d);
+  }
+}
+
+__device__ __forceinline__ float WaveRowSum(const GraphView& g, const TypeList& tl,
+                                            int64_t row, int lane) {
+  const RowMeta m = LoadRowMeta(g, row);
+  const float* nw = g.prefix_w + m.row_ptr;
+  float sum = 0.f;
+  for (int32_t x = 0; x < tl.k; ++x) {
+    const int32_t t = tl.et[x];
+    if (t < 0 || t >= g.T) continue;
+    const int32_t b = t == 0 ? 0 : m.type_end[t - 1];
+    const int32_t e = m.type_end[t];
+    if (b >= e) continue;
+    int cur[kSumGroup], nxt[kSumGroup];
+    LoadWeightGroup(nw, b, e, lane, cur);
+    for (int32_t p0 = b; p0 < e; p0 += 64 * kSumGroup) {
+      LoadWeightGroup(nw, p0 + 64 * kSumGroup, e, lane, nxt);   // all zero past the end
+#pragma unroll
+      for (int u = 0; u < kSumGroup; ++u) {
+        const int32_t cnt = e - (p0 + 64 * u);
+        if (cnt > 0) sum = ChunkChain(sum, __int_as_float(cur[u]), lane, cnt < 64 ? cnt : 64);
+      }
+#pragma unroll
+      for (int u = 0; u < kSumGroup; ++u) cur[u] = nxt[u];
+    }
+  }
+  return sum;
+}
+
 __global__ __launch_bounds__(256) void EdgeSumWeightKernel(
     const GraphView g, const TypeList tl, const uint64_t* __restrict__ ids,
-    int64_t n, float* __restrict__ out) {
+    int64_t n, float* __restrict__ out, int64_t* __restrict__ long_rows,
+    int32_t* __restrict__ long_pos, unsigned long long* __restrict__ n_long) {
+  const int lane = threadIdx.x & 63;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-    out[i] = EdgeSumWeight(g, ids[i], tl.et, tl.k);
+  // whole waves iterate together: the bound is rounded up to a multiple of 64
+  const int64_t n_up = (n + 63) & ~(int64_t)63;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_up; i += stride) {
+    int64_t row = -1;
+    int64_t listed = 0;
+    if (i < n) {
+      row = FindRow(g, ids[i]);
+      if (row >= 0) {
+        const RowMeta m = LoadRowMeta(g, row);
+        for (int32_t x = 0; x < tl.k; ++x) {
+          const int32_t t = tl.et[x];
+          if (t >= 0 && t < g.T) listed += m.type_end[t] - (t == 0 ? 0 : m.type_end[t - 1]);
+        }
+      }
+    }
+    const bool is_long = listed > kLongRow;
+    if (i < n && !is_long) out[i] = EdgeSumWeight(g, ids[i], tl.et, tl.k);
+    // long rows go to a queue (one atomic per wave) for EdgeSumLongRowsKernel
+    const uint64_t pending = __ballot(is_long);
+    if (pending) {
+      unsigned long long base = 0;
+      if (lane == 0) base = atomicAdd(n_long, (unsigned long long)__popcll(pending));
+      base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+      if (is_long) {
+        const unsigned long long q = base + __popcll(pending & ((1ull << lane) - 1ull));
+        long_rows[q] = row;
+        long_pos[q] = (int32_t)i;
+      }
+    }
+  }
+}
+
+// One wave per queued row, whatever wave met it: the hubs of a batch spread
+// over the chip instead of queueing up inside the waves that found them.
+__global__ __launch_bounds__(256) void EdgeSumLongRowsKernel(
+    const GraphView g, const TypeList tl, const int64_t* __restrict__ long_rows,
+    const int32_t* __restrict__ long_pos, const unsigned long long* __restrict__ n_long,
+    float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int64_t total = (int64_t)*n_long;
+  for (int64_t q = wave; q < total; q += n_waves) {
+    // wave-uniform row index (scalar loop bounds in WaveRowSum)
+    const int64_t rv = long_rows[q];
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rv);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)rv >> 32));
+    const float sum = WaveRowSum(g, tl, (int64_t)(((uint64_t)hi << 32) | lo), lane);
+    if (lane == 0) out[long_pos[q]] = sum;
+  }
 }
 
 // ---------------------------------------------------------------- root draw
@@ -102,80 +238,238 @@ __global__ __launch_bounds__(256) void SampleLayerKernel(
 }
 
 // ---------------------------------------------------------------- adjacency
-// One wave per source node r = (batch row b, slot r % n); lanes take the m
-// candidate neighbours of batch row b, 64 at a time, and ballot the hits, so
-// the hits of a source keep candidate order (the push_back order of
-// sparse_get_adj_op.cc:60-72).  tf != 0 adds the TF kernel's explicit zero at
-// (b, n-1, m-1) when that pair is no edge (tf_euler/kernels/
-// sparse_get_adj_op.cc:112-118).
+// SparseGetAdj asks, for every source node r of batch row b, which of the m
+// candidates of that row it has a listed-type edge to.  The answers go into a
+// bit mask (one bit per (source, candidate), words of 64) from which the
+// count / scan / fill passes build either result layout without touching the
+// graph again.
+//
+// AdjHashMaskKernel (default): O(deg + m) per source instead of O(deg * m).
+// A workgroup takes a chunk of sources of one batch row and puts the row's
+// candidates (<= kAdjChunk at a time) into an LDS hash table - slots hold the
+// index of the first candidate with a key, duplicates resolve to it - then
+// each wave streams the adjacency row of one source (lanes over edges,
+// coalesced), probes the table with every neighbour id and sets the hit bit of
+// the matching candidate in its LDS bitmap; finally lane j looks its own
+// candidate up and the ballot of the hit bits is one mask word.  Degree skew
+// no longer multiplies with m: the 4096 x 4096 WholeDataFlow query on the
+// metric graph went from 77 ms (one wave per source comparing every candidate
+// with the whole row, AdjScanMaskKernel, kept selectable: tuning key 16) to
+// the time of streaming the rows once.
+constexpr int kAdjChunk = 2048;          // candidates per table build
+constexpr uint32_t kAdjEmpty = 0xFFFFFFFFu;
+
 struct AdjArgs {
   GraphView g;
   TypeList tl;
   const uint64_t* roots;    // [batch * n]
   const uint64_t* l_nb;     // [batch * m]
+  uint64_t* mask;           // [batch * n * words]
   int64_t batch;
   int32_t n, m;
-  int32_t tf;
+  int32_t words;            // ceil(m / 64)
+  int32_t roots_per_wg;     // sources of one workgroup (its 4 waves take every 4th)
+  int32_t wgs_per_row;      // workgroups per batch row
+  int32_t cap;              // hash slots (power of two >= 2 * min(m, kAdjChunk))
 };
 
-__device__ __forceinline__ bool AdjEmit(const AdjArgs& a, int64_t row, int64_t b,
-                                        int32_t slot, int32_t j, bool* exists) {
-  *exists = false;
-  if (j >= a.m) return false;
-  *exists = EdgeExistAny(a.g, row, a.l_nb[b * a.m + j], a.tl.et, a.tl.k);
-  return *exists || (a.tf && slot == a.n - 1 && j == a.m - 1);
-}
+constexpr int kAdjGroup = 8;
 
-__global__ __launch_bounds__(256) void AdjCountKernel(const AdjArgs a,
-                                                      int64_t* __restrict__ counts) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  const int64_t total = a.batch * a.n;
-  for (int64_t r = wave; r < total; r += n_waves) {
-    const int64_t b = r / a.n;
-    const int32_t slot = (int32_t)(r - b * a.n);
-    const int64_t row = FindRow(a.g, a.roots[r]);
-    int64_t c = 0;
-    for (int32_t base = 0; base < a.m; base += 64) {
-      bool exists;
-      const bool emit = AdjEmit(a, row, b, slot, base + lane, &exists);
-      c += __popcll(__ballot(emit));
-    }
-    if (lane == 0) counts[r] = c;
+__device__ __forceinline__ void LoadNbrGroup(const uint64_t* nbr, int32_t p0, int32_t ee,
+                                             int lane, uint64_t (&d)[kAdjGroup]) {
+#pragma unroll
+  for (int u = 0; u < kAdjGroup; ++u) {
+    const int32_t p = p0 + 64 * u + lane;
+    d[u] = p < ee ? nbr[p] : 0;
   }
 }
 
-__global__ __launch_bounds__(256) void AdjFillKernel(
-    const AdjArgs a, const int64_t* __restrict__ off64,
-    const int32_t* __restrict__ idx32, uint64_t* __restrict__ out_id,
-    int64_t* __restrict__ indices, int64_t* __restrict__ values) {
+__device__ __forceinline__ void AdjWaveSync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(256) void AdjHashMaskKernel(const AdjArgs a) {
+  extern __shared__ uint64_t adj_lds[];
+  const int mc_max = a.m < kAdjChunk ? a.m : kAdjChunk;
+  uint64_t* cand = adj_lds;                                        // [mc_max]
+  uint32_t* table = reinterpret_cast<uint32_t*>(cand + mc_max);    // [cap]
+  uint32_t* bits = table + a.cap;                                  // [4][bw]
+  const int bw = (mc_max + 31) >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t* my_bits = bits + wave * bw;
+  const uint32_t cmask = (uint32_t)a.cap - 1u;
+  const int64_t total_wgs = a.batch * a.wgs_per_row;
+  for (int64_t wg = blockIdx.x; wg < total_wgs; wg += gridDim.x) {
+    const int64_t b = wg / a.wgs_per_row;
+    const int32_t r_begin = (int32_t)(wg - b * a.wgs_per_row) * a.roots_per_wg;
+    const int32_t r_end = min(a.n, r_begin + a.roots_per_wg);
+    for (int32_t c0 = 0; c0 < a.m; c0 += kAdjChunk) {
+      const int mc = min(kAdjChunk, a.m - c0);
+      __syncthreads();                       // previous chunk / group done with the LDS
+      for (int i = tid; i < a.cap; i += 256) table[i] = kAdjEmpty;
+      for (int j = tid; j < mc; j += 256) cand[j] = a.l_nb[b * a.m + c0 + j];
+      __syncthreads();
+      for (int j = tid; j < mc; j += 256) {
+        const uint64_t key = cand[j];
+        uint32_t slot = (uint32_t)Mix64(key) & cmask;
+        for (int probes = 0; probes < a.cap; ++probes) {
+          const uint32_t prev = atomicCAS(&table[slot], kAdjEmpty, (uint32_t)j);
+          if (prev == kAdjEmpty || cand[prev] == key) break;   // inserted / duplicate
+          slot = (slot + 1u) & cmask;
+        }
+      }
+      __syncthreads();
+      // The waves walk their sources independently (a hub row delays only its own
+      // wave): the bitmap is private to the wave, whose LDS operations execute in
+      // program order, so a wave-scope fence (no reordering by the compiler) is
+      // all the clear / mark / read-back phases need between them.
+      for (int32_t slot_r = r_begin + wave; slot_r < r_end; slot_r += 4) {
+        for (int i = lane; i < bw; i += 64) my_bits[i] = 0u;
+        AdjWaveSync();
+        {
+          const int64_t row = FindRow(a.g, a.roots[b * a.n + slot_r]);
+          if (row >= 0) {
+            const RowMeta rm = LoadRowMeta(a.g, row);
+            const uint64_t* nbr = a.g.nbr + rm.row_ptr;
+            for (int32_t x = 0; x < a.tl.k; ++x) {
+              const int32_t t = a.tl.et[x];
+              if (t < 0 || t >= a.g.T) continue;
+              const int32_t eb = t == 0 ? 0 : rm.type_end[t - 1];
+              const int32_t ee = rm.type_end[t];
+              // the NEXT 8 x 64 neighbour ids are fetched while the current ones
+              // probe the table (a long row was paying an HBM round trip per group)
+              if (eb >= ee) continue;
+              uint64_t cur[kAdjGroup], nxt[kAdjGroup];
+              LoadNbrGroup(nbr, eb, ee, lane, cur);
+              for (int32_t p0 = eb; p0 < ee; p0 += 64 * kAdjGroup) {
+                LoadNbrGroup(nbr, p0 + 64 * kAdjGroup, ee, lane, nxt);
+#pragma unroll
+                for (int u = 0; u < kAdjGroup; ++u) {
+                  if (p0 + 64 * u + lane >= ee) continue;
+                  uint32_t slot = (uint32_t)Mix64(cur[u]) & cmask;
+                  for (int probes = 0; probes < a.cap; ++probes) {
+                    const uint32_t jv = table[slot];
+                    if (jv == kAdjEmpty) break;
+                    if (cand[jv] == cur[u]) {
+                      // a hub among the candidates is hit by most lanes of most
+                      // steps: only the first hit pays for the (same-address,
+                      // serialised) LDS atomic
+                      const uint32_t bit = 1u << (jv & 31);
+                      if (!(my_bits[jv >> 5] & bit)) atomicOr(&my_bits[jv >> 5], bit);
+                      break;
+                    }
+                    slot = (slot + 1u) & cmask;
+                  }
+                }
+#pragma unroll
+                for (int u = 0; u < kAdjGroup; ++u) cur[u] = nxt[u];
+              }
+            }
+          }
+        }
+        AdjWaveSync();
+        {
+          uint64_t* out = a.mask + (b * a.n + slot_r) * (int64_t)a.words + (c0 >> 6);
+          for (int j0 = 0; j0 < mc; j0 += 64) {
+            const int j = j0 + lane;
+            bool hit = false;
+            if (j < mc) {
+              const uint64_t key = cand[j];
+              uint32_t slot = (uint32_t)Mix64(key) & cmask;
+              for (int probes = 0; probes < a.cap; ++probes) {
+                const uint32_t jv = table[slot];
+                if (jv == kAdjEmpty) break;            // cannot happen: j was inserted
+                if (cand[jv] == key) { hit = (my_bits[jv >> 5] >> (jv & 31)) & 1u; break; }
+                slot = (slot + 1u) & cmask;
+              }
+            }
+            const uint64_t word = __ballot(hit);
+            if (lane == 0) out[j0 >> 6] = word;
+          }
+        }
+        AdjWaveSync();
+      }
+    }
+  }
+}
+
+// The direct form (tuning key 16 = 1): one wave per source, lanes over the
+// candidates, every lane compares its candidate with the whole row
+// (EdgeExistAny).  Same mask.
+__global__ __launch_bounds__(256) void AdjScanMaskKernel(const AdjArgs a) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int64_t total = a.batch * a.n;
   for (int64_t r = wave; r < total; r += n_waves) {
     const int64_t b = r / a.n;
-    const int32_t slot = (int32_t)(r - b * a.n);
     const int64_t row = FindRow(a.g, a.roots[r]);
-    int64_t o = off64 ? off64[r] : (int64_t)idx32[2 * r];
     for (int32_t base = 0; base < a.m; base += 64) {
       const int32_t j = base + lane;
-      bool exists;
-      const bool emit = AdjEmit(a, row, b, slot, j, &exists);
-      const uint64_t ballot = __ballot(emit);
-      if (emit) {
-        const int64_t p = o + __popcll(ballot & ((1ull << lane) - 1ull));
-        if (a.tf) {
-          indices[3 * p] = b;
-          indices[3 * p + 1] = slot;
-          indices[3 * p + 2] = j;
-          values[p] = exists ? 1 : 0;
-        } else {
-          out_id[p] = a.l_nb[b * a.m + j];
-        }
+      const bool hit = j < a.m &&
+                       EdgeExistAny(a.g, row, a.l_nb[b * a.m + j], a.tl.et, a.tl.k);
+      const uint64_t word = __ballot(hit);
+      if (lane == 0) a.mask[r * (int64_t)a.words + (base >> 6)] = word;
+    }
+  }
+}
+
+// The TF kernels add an explicit zero at (b, n-1, m-1) when that pair is no
+// edge (tf_euler/kernels/sparse_get_adj_op.cc:112-118): the word an entry list
+// is built from is the mask word plus that corner bit.
+__device__ __forceinline__ uint64_t AdjEmitWord(const uint64_t* mask, int64_t r,
+                                                int32_t w, int32_t n, int32_t m,
+                                                int32_t words, int32_t tf) {
+  uint64_t word = mask[r * (int64_t)words + w];
+  if (tf && w == words - 1 && (int32_t)(r % n) == n - 1) word |= 1ull << ((m - 1) & 63);
+  return word;
+}
+
+__global__ __launch_bounds__(256) void AdjCountKernel(const uint64_t* __restrict__ mask,
+                                                      int64_t R, int32_t n, int32_t m,
+                                                      int32_t words, int32_t tf,
+                                                      int64_t* __restrict__ counts) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += stride) {
+    int64_t c = 0;
+    for (int32_t w = 0; w < words; ++w) c += __popcll(AdjEmitWord(mask, r, w, n, m, words, tf));
+    counts[r] = c;
+  }
+}
+
+// One lane per (source, mask word): entries of a source keep candidate order
+// (the push_back order of core/kernels/sparse_get_adj_op.cc:60-72).
+__global__ __launch_bounds__(256) void AdjFillKernel(
+    const uint64_t* __restrict__ mask, const uint64_t* __restrict__ l_nb, int64_t R,
+    int32_t n, int32_t m, int32_t words, int32_t tf, const int64_t* __restrict__ off,
+    uint64_t* __restrict__ out_id, int64_t* __restrict__ indices,
+    int64_t* __restrict__ values) {
+  const int64_t total = R * words;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < total; x += stride) {
+    const int64_t r = x / words;
+    const int32_t w = (int32_t)(x - r * words);
+    uint64_t word = AdjEmitWord(mask, r, w, n, m, words, tf);
+    if (word == 0) continue;
+    int64_t p = off[r];
+    for (int32_t v = 0; v < w; ++v) p += __popcll(AdjEmitWord(mask, r, v, n, m, words, tf));
+    const uint64_t hits = mask[x];
+    const int64_t b = r / n;
+    while (word) {
+      const int bit = __ffsll((unsigned long long)word) - 1;
+      word &= word - 1;
+      const int32_t j = w * 64 + bit;
+      if (tf) {
+        indices[3 * p] = b;
+        indices[3 * p + 1] = r - b * n;
+        indices[3 * p + 2] = j;
+        values[p] = (hits >> bit) & 1ull;
+      } else {
+        out_id[p] = l_nb[b * m + j];
       }
-      o += __popcll(ballot);
+      ++p;
     }
   }
 }
@@ -223,16 +517,61 @@ int FillTypes(const int32_t* edge_types_host, int32_t k, TypeList* tl, const cha
   return EULER_GPU_OK;
 }
 
-// counts -> offsets [R + 1] (off[R] = total) on the stream
-int CountAndScan(const AdjArgs& a, hipStream_t st, int64_t* counts /* [R+1] */,
-                 int64_t* off /* [R+1] */) {
+// Workspace of a SparseGetAdj query: offsets [R + 1] int64, then the mask.
+struct AdjWorkspace {
+  int64_t* off;
+  uint64_t* mask;
+  int32_t words;
+};
+
+AdjWorkspace SplitAdjWorkspace(void* ws, int64_t R, int32_t m) {
+  AdjWorkspace w;
+  w.off = static_cast<int64_t*>(ws);
+  w.mask = reinterpret_cast<uint64_t*>(w.off + R + 1);
+  w.words = (m + 63) / 64;
+  return w;
+}
+
+// mask -> counts -> offsets [R + 1] (off[R] = total), all on the stream
+int BuildAdjMask(const euler_gpu_graph* g, hipStream_t st, AdjArgs a, int32_t tf,
+                 const AdjWorkspace& w) {
   const int64_t R = a.batch * a.n;
   const int block = 256;
+  a.g = g->view;
+  a.mask = w.mask;
+  a.words = w.words;
+  if (a.m > 0) {
+    if (g_adj_scan) {
+      hipLaunchKernelGGL(AdjScanMaskKernel, dim3(GridFor(R * 64, block)), dim3(block), 0,
+                         st, a);
+    } else {
+      const int32_t mc = a.m < kAdjChunk ? a.m : kAdjChunk;
+      int32_t cap = 64;
+      while (cap < 2 * mc) cap <<= 1;
+      a.cap = cap;
+      // ~4096 workgroups over the whole query, >= 4 sources (one per wave) each
+      const int64_t want = std::max<int64_t>(1, 4096 / std::max<int64_t>(a.batch, 1));
+      int32_t rpw = (int32_t)((a.n + want - 1) / want);
+      rpw = std::max(4, (rpw + 3) & ~3);
+      a.roots_per_wg = rpw;
+      a.wgs_per_row = (a.n + rpw - 1) / rpw;
+      const int64_t wgs = a.batch * (int64_t)a.wgs_per_row;
+      const size_t lds = (size_t)mc * 8 + (size_t)cap * 4 + (size_t)4 * ((mc + 31) / 32) * 4;
+      hipLaunchKernelGGL(AdjHashMaskKernel, dim3((unsigned)std::min<int64_t>(wgs, 1 << 16)),
+                         dim3(block), lds, st, a);
+    }
+    EG_HIP(hipGetLastError());
+  }
+  int64_t* counts = nullptr;
+  EG_HIP(hipMallocAsync((void**)&counts, (size_t)(R + 1) * sizeof(int64_t), st));
   EG_HIP(hipMemsetAsync(counts + R, 0, sizeof(int64_t), st));
-  hipLaunchKernelGGL(AdjCountKernel, dim3(GridFor(R * 64, block)), dim3(block), 0, st,
-                     a, counts);
-  EG_HIP(hipGetLastError());
-  return ExclusiveScanI64(st, counts, off, R + 1);
+  hipLaunchKernelGGL(AdjCountKernel, dim3(GridFor(R, block)), dim3(block), 0, st, w.mask, R,
+                     a.n, a.m, w.words, tf, counts);
+  int rc = ExclusiveScanI64(st, counts, w.off, R + 1);
+  hipError_t f = hipFreeAsync(counts, st);
+  if (rc != EULER_GPU_OK) return rc;
+  EG_HIP(f);
+  return EULER_GPU_OK;
 }
 
 }  // namespace
@@ -254,10 +593,24 @@ int euler_gpu_get_edge_sum_weight(const euler_gpu_graph* g, void* stream,
   if (n == 0) return EULER_GPU_OK;
   if (!ids_dev || !out_w_dev)
     return Fail(EULER_GPU_EINVAL, "get_edge_sum_weight: null buffer");
+  if (n > 0x7fffffffLL) return Fail(EULER_GPU_EINVAL, "get_edge_sum_weight: n exceeds int32");
   const int block = 256;
-  hipLaunchKernelGGL(EdgeSumWeightKernel, dim3(GridFor(n, block)), dim3(block), 0,
-                     (hipStream_t)stream, g->view, tl, ids_dev, n, out_w_dev);
-  EG_HIP(hipGetLastError());
+  hipStream_t st = (hipStream_t)stream;
+  // queue of the long rows: [n] rows, [n] positions, one counter
+  uint8_t* q = nullptr;
+  EG_HIP(hipMallocAsync((void**)&q, (size_t)n * 12 + 16, st));
+  int64_t* long_rows = reinterpret_cast<int64_t*>(q);
+  int32_t* long_pos = reinterpret_cast<int32_t*>(long_rows + n);
+  unsigned long long* n_long =
+      reinterpret_cast<unsigned long long*>(q + (((size_t)n * 12 + 7) & ~(size_t)7));
+  hipError_t e = hipMemsetAsync(n_long, 0, 8, st);
+  hipLaunchKernelGGL(EdgeSumWeightKernel, dim3(GridFor(n, block)), dim3(block), 0, st,
+                     g->view, tl, ids_dev, n, out_w_dev, long_rows, long_pos, n_long);
+  hipLaunchKernelGGL(EdgeSumLongRowsKernel, dim3(GridFor(n * 64, block)), dim3(block), 0, st,
+                     g->view, tl, long_rows, long_pos, n_long, out_w_dev);
+  hipError_t l = hipGetLastError();
+  hipError_t f = hipFreeAsync(q, st);
+  EG_HIP(e); EG_HIP(l); EG_HIP(f);
   return EULER_GPU_OK;
 }
 
@@ -281,7 +634,7 @@ int euler_gpu_sample_root(void* stream, uint64_t seed, uint32_t call_id,
   s.stack = s.alias + cells;
   s.sum = reinterpret_cast<float*>(s.stack + cells);
   const int block = 256;
-  const bool on_host = batch < g_root_host_batch;
+  const bool on_host = RootTablesOnHost(batch, n);
   std::vector<float> h_w, h_wn, h_prob, h_sum;
   std::vector<int32_t> h_alias, h_stack;
   if (on_host) {
@@ -428,12 +781,18 @@ int euler_gpu_sample_n_with_types(const euler_gpu_graph* g, void* stream, uint64
   return EULER_GPU_OK;
 }
 
+size_t euler_gpu_sparse_get_adj_workspace(int64_t batch, int32_t n, int32_t m) {
+  if (batch < 0 || n < 0 || m < 0) return 0;
+  const int64_t R = batch * n;
+  return (size_t)(R + 1) * 8 + (size_t)R * (size_t)((m + 63) / 64) * 8;
+}
+
 int euler_gpu_sparse_get_adj(const euler_gpu_graph* g, void* stream,
                              const uint64_t* roots_dev, const uint64_t* l_nb_dev,
                              int64_t batch, int32_t n, int32_t m,
                              const int32_t* edge_types_host, int32_t k,
-                             int32_t* idx_dev, int64_t* total_host,
-                             uint64_t* out_id_dev) {
+                             void* workspace_dev, int32_t* idx_dev,
+                             int64_t* total_host, uint64_t* out_id_dev) {
   if (!g) return Fail(EULER_GPU_ENOGRAPH, "sparse_get_adj: null graph");
   if (batch < 0 || n < 0 || m < 0)
     return Fail(EULER_GPU_EINVAL, "sparse_get_adj: negative size");
@@ -442,31 +801,28 @@ int euler_gpu_sparse_get_adj(const euler_gpu_graph* g, void* stream,
   if (rc != EULER_GPU_OK) return rc;
   const int64_t R = batch * n;
   if (R == 0) { if (total_host) *total_host = 0; return EULER_GPU_OK; }
-  if (!roots_dev || !idx_dev || (m > 0 && !l_nb_dev))
+  if (!roots_dev || !idx_dev || !workspace_dev || (m > 0 && !l_nb_dev))
     return Fail(EULER_GPU_EINVAL, "sparse_get_adj: null buffer");
   if ((int64_t)m * n * batch > 0x7fffffffLL)
     return Fail(EULER_GPU_EINVAL, "sparse_get_adj: result offsets exceed int32");
   hipStream_t st = (hipStream_t)stream;
-  a.g = g->view; a.roots = roots_dev; a.l_nb = l_nb_dev;
-  a.batch = batch; a.n = n; a.m = m; a.tf = 0;
+  a.roots = roots_dev; a.l_nb = l_nb_dev; a.batch = batch; a.n = n; a.m = m;
+  const AdjWorkspace w = SplitAdjWorkspace(workspace_dev, R, m);
   const int block = 256;
   if (out_id_dev == nullptr) {
-    int64_t* counts = nullptr;
-    EG_HIP(hipMallocAsync((void**)&counts, (size_t)(2 * (R + 1)) * sizeof(int64_t), st));
-    int64_t* off = counts + R + 1;
-    rc = CountAndScan(a, st, counts, off);
-    if (rc != EULER_GPU_OK) { (void)hipFreeAsync(counts, st); return rc; }
+    rc = BuildAdjMask(g, st, a, 0, w);
+    if (rc != EULER_GPU_OK) return rc;
     hipLaunchKernelGGL(AdjOffsetsToIdxKernel, dim3((unsigned)((R + block - 1) / block)),
-                       dim3(block), 0, st, off, R, idx_dev);
+                       dim3(block), 0, st, w.off, R, idx_dev);
     int64_t total = 0;
-    EG_HIP(hipMemcpyAsync(&total, off + R, 8, hipMemcpyDeviceToHost, st));
+    EG_HIP(hipMemcpyAsync(&total, w.off + R, 8, hipMemcpyDeviceToHost, st));
     EG_HIP(hipStreamSynchronize(st));
-    EG_HIP(hipFreeAsync(counts, st));
     if (total_host) *total_host = total;
     return EULER_GPU_OK;
   }
-  hipLaunchKernelGGL(AdjFillKernel, dim3(GridFor(R * 64, block)), dim3(block), 0, st, a,
-                     (const int64_t*)nullptr, (const int32_t*)idx_dev, out_id_dev,
+  if (m == 0) return EULER_GPU_OK;
+  hipLaunchKernelGGL(AdjFillKernel, dim3(GridFor(R * w.words, block)), dim3(block), 0, st,
+                     w.mask, l_nb_dev, R, n, m, w.words, 0, w.off, out_id_dev,
                      (int64_t*)nullptr, (int64_t*)nullptr);
   EG_HIP(hipGetLastError());
   return EULER_GPU_OK;
@@ -476,7 +832,7 @@ int euler_gpu_sparse_get_adj_tf(const euler_gpu_graph* g, void* stream,
                                 const uint64_t* nodes_dev, const uint64_t* nb_nodes_dev,
                                 int64_t batch, int32_t n, int32_t m,
                                 const int32_t* edge_types_host, int32_t k,
-                                int64_t* row_off_dev, int64_t* nnz_host,
+                                void* workspace_dev, int64_t* nnz_host,
                                 int64_t* indices_dev, int64_t* values_dev) {
   if (!g) return Fail(EULER_GPU_ENOGRAPH, "sparse_get_adj_tf: null graph");
   if (batch < 0 || n < 0 || m < 0)
@@ -486,28 +842,25 @@ int euler_gpu_sparse_get_adj_tf(const euler_gpu_graph* g, void* stream,
   if (rc != EULER_GPU_OK) return rc;
   const int64_t R = batch * n;
   if (R == 0 || m == 0) { if (nnz_host) *nnz_host = 0; return EULER_GPU_OK; }
-  if (!nodes_dev || !nb_nodes_dev || !row_off_dev)
+  if (!nodes_dev || !nb_nodes_dev || !workspace_dev)
     return Fail(EULER_GPU_EINVAL, "sparse_get_adj_tf: null buffer");
   hipStream_t st = (hipStream_t)stream;
-  a.g = g->view; a.roots = nodes_dev; a.l_nb = nb_nodes_dev;
-  a.batch = batch; a.n = n; a.m = m; a.tf = 1;
+  a.roots = nodes_dev; a.l_nb = nb_nodes_dev; a.batch = batch; a.n = n; a.m = m;
+  const AdjWorkspace w = SplitAdjWorkspace(workspace_dev, R, m);
   const int block = 256;
   if (indices_dev == nullptr) {
-    int64_t* counts = nullptr;
-    EG_HIP(hipMallocAsync((void**)&counts, (size_t)(R + 1) * sizeof(int64_t), st));
-    rc = CountAndScan(a, st, counts, row_off_dev);
-    if (rc != EULER_GPU_OK) { (void)hipFreeAsync(counts, st); return rc; }
+    rc = BuildAdjMask(g, st, a, 1, w);
+    if (rc != EULER_GPU_OK) return rc;
     int64_t total = 0;
-    EG_HIP(hipMemcpyAsync(&total, row_off_dev + R, 8, hipMemcpyDeviceToHost, st));
+    EG_HIP(hipMemcpyAsync(&total, w.off + R, 8, hipMemcpyDeviceToHost, st));
     EG_HIP(hipStreamSynchronize(st));
-    EG_HIP(hipFreeAsync(counts, st));
     if (nnz_host) *nnz_host = total;
     return EULER_GPU_OK;
   }
   if (!values_dev) return Fail(EULER_GPU_EINVAL, "sparse_get_adj_tf: null values");
-  hipLaunchKernelGGL(AdjFillKernel, dim3(GridFor(R * 64, block)), dim3(block), 0, st, a,
-                     (const int64_t*)row_off_dev, (const int32_t*)nullptr,
-                     (uint64_t*)nullptr, indices_dev, values_dev);
+  hipLaunchKernelGGL(AdjFillKernel, dim3(GridFor(R * w.words, block)), dim3(block), 0, st,
+                     w.mask, nb_nodes_dev, R, n, m, w.words, 1, w.off, (uint64_t*)nullptr,
+                     indices_dev, values_dev);
   EG_HIP(hipGetLastError());
   return EULER_GPU_OK;
 }

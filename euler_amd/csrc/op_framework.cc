@@ -586,12 +586,13 @@ class GpuSparseGetAdjOp : public OpKernel {
     std::vector<uint64_t> vals;
     if (R > 0) {
       (void)hipSetDevice(euler_gpu_graph_device(g));
-      DevBuf d_r(R * 8), d_nb((size_t)batch * m * 8), d_idx(R * 8);
-      if (!d_r.p || !d_nb.p || !d_idx.p) { LogError("API_SPARSE_GET_ADJ: device allocation failed"); return; }
+      DevBuf d_r(R * 8), d_nb((size_t)batch * m * 8), d_idx(R * 8),
+          d_ws(euler_gpu_sparse_get_adj_workspace(batch, (int32_t)n, m));
+      if (!d_r.p || !d_nb.p || !d_idx.p || !d_ws.p) { LogError("API_SPARSE_GET_ADJ: device allocation failed"); return; }
       (void)hipMemcpy(d_r.p, roots.data(), R * 8, hipMemcpyHostToDevice);
       (void)hipMemcpy(d_nb.p, l_nb_t->Raw<uint64_t>(), (size_t)batch * m * 8, hipMemcpyHostToDevice);
       if (euler_gpu_sparse_get_adj(g, nullptr, d_r.as<uint64_t>(), d_nb.as<uint64_t>(), batch,
-                                   (int32_t)n, m, et.data(), (int32_t)et.size(),
+                                   (int32_t)n, m, et.data(), (int32_t)et.size(), d_ws.p,
                                    d_idx.as<int32_t>(), &total, nullptr) != 0) {
         LogError(std::string("API_SPARSE_GET_ADJ: ") + euler_gpu_last_error());
         return;
@@ -600,7 +601,7 @@ class GpuSparseGetAdjOp : public OpKernel {
       if (!d_v.p) { LogError("API_SPARSE_GET_ADJ: device allocation failed"); return; }
       if (total > 0 &&
           euler_gpu_sparse_get_adj(g, nullptr, d_r.as<uint64_t>(), d_nb.as<uint64_t>(), batch,
-                                   (int32_t)n, m, et.data(), (int32_t)et.size(),
+                                   (int32_t)n, m, et.data(), (int32_t)et.size(), d_ws.p,
                                    d_idx.as<int32_t>(), &total, d_v.as<uint64_t>()) != 0) {
         LogError(std::string("API_SPARSE_GET_ADJ: ") + euler_gpu_last_error());
         return;

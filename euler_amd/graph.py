@@ -492,17 +492,24 @@ class Graph:
         assert roots.numel() == batch * n and l_nb.numel() == batch * m
         et, et_p, k = _i32_array(edge_types)
         idx = torch.empty((batch * n, 2), dtype=torch.int32, device=self.device)
+        ws = self._adj_workspace(batch, n, m)
         total = C.c_int64(0)
         with torch.cuda.device(self.device):
             check(lib().euler_gpu_sparse_get_adj(
                 self._h, _stream(), _ptr(roots), _ptr(l_nb), batch, n, m, et_p, k,
-                _ptr(idx), C.byref(total), None))
+                _ptr(ws), _ptr(idx), C.byref(total), None))
             vals = torch.empty(int(total.value), dtype=torch.int64, device=self.device)
             if total.value:
                 check(lib().euler_gpu_sparse_get_adj(
                     self._h, _stream(), _ptr(roots), _ptr(l_nb), batch, n, m, et_p, k,
-                    _ptr(idx), C.byref(total), _ptr(vals)))
+                    _ptr(ws), _ptr(idx), C.byref(total), _ptr(vals)))
         return idx, vals
+
+    def _adj_workspace(self, batch, n, m):
+        """Scratch of a SparseGetAdj query (offsets + one bit per pair), kept
+        between its two calls."""
+        nbytes = int(lib().euler_gpu_sparse_get_adj_workspace(batch, n, m))
+        return torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=self.device)
 
     def sparse_get_adj(self, nodes, nb_nodes, edge_types, n=-1, m=-1):
         """tf_euler sparse_get_adj (tf_euler/kernels/sparse_get_adj_op.cc):
@@ -517,7 +524,7 @@ class Graph:
         if nodes.numel() != batch * n or nb_nodes.numel() < batch * m:
             raise ValueError("sparse_get_adj: nodes / nb_nodes do not match n, m")
         et, et_p, k = _i32_array(edge_types)
-        row_off = torch.empty(batch * n + 1, dtype=torch.int64, device=self.device)
+        row_off = self._adj_workspace(batch, n, m)
         nnz = C.c_int64(0)
         with torch.cuda.device(self.device):
             check(lib().euler_gpu_sparse_get_adj_tf(

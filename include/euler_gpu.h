@@ -361,29 +361,34 @@ int euler_gpu_sample_neighbor_layerwise(const euler_gpu_graph* g, void* stream,
  * l_nb_dev[b*m .. b*m+m) it has an edge of a listed type to, in candidate
  * order.  FillNeighbor-style result: idx_dev [batch*n, 2] int32 offsets +
  * out_id_dev [total].  Two calls like euler_gpu_get_full_neighbor: with
- * out_id_dev == NULL it fills idx_dev and *total_host (stream sync), then it
- * writes the ids.  EdgeExist (core/api/api.cc:46-48) is answered from the
- * adjacency rows: the Edge records the reference would consult hold the same
- * (src, dst, type) triples in data written by its converter. */
+ * out_id_dev == NULL it answers the query (one bit per (root, candidate) kept
+ * in workspace_dev), fills idx_dev and *total_host (stream sync); the second
+ * call writes the ids from the workspace.  workspace_dev:
+ * euler_gpu_sparse_get_adj_workspace(batch, n, m) bytes, 8-byte aligned, kept
+ * by the caller between the two calls.  EdgeExist (core/api/api.cc:46-48) is
+ * answered from the adjacency rows: the Edge records the reference would
+ * consult hold the same (src, dst, type) triples in data written by its
+ * converter. */
+size_t euler_gpu_sparse_get_adj_workspace(int64_t batch, int32_t n, int32_t m);
 int euler_gpu_sparse_get_adj(const euler_gpu_graph* g, void* stream,
                              const uint64_t* roots_dev, const uint64_t* l_nb_dev,
                              int64_t batch, int32_t n, int32_t m,
                              const int32_t* edge_types_host, int32_t k,
-                             int32_t* idx_dev, int64_t* total_host,
-                             uint64_t* out_id_dev);
+                             void* workspace_dev, int32_t* idx_dev,
+                             int64_t* total_host, uint64_t* out_id_dev);
 
 /* TF SparseGetAdj (tf_euler/kernels/sparse_get_adj_op.cc:43-134) and the
  * adjacency outputs of SampleNeighborLayerwiseWithAdj: COO triples (b, j, c) in
  * row-major order with value 1 where nodes[b, j] has a listed-type edge to
  * nb_nodes[b, c], plus the kernel's explicit 0 at (b, n-1, m-1) when that pair
- * is no edge (so dense_shape = [batch, n, m]).  Two calls: indices_dev == NULL
- * fills row_off_dev [batch*n + 1] (int64 scratch the second call reads) and
+ * is no edge (so dense_shape = [batch, n, m]).  Two calls over the same
+ * workspace (see above): indices_dev == NULL answers the query and returns
  * *nnz_host (stream sync); then indices_dev [nnz, 3] / values_dev [nnz] int64. */
 int euler_gpu_sparse_get_adj_tf(const euler_gpu_graph* g, void* stream,
                                 const uint64_t* nodes_dev, const uint64_t* nb_nodes_dev,
                                 int64_t batch, int32_t n, int32_t m,
                                 const int32_t* edge_types_host, int32_t k,
-                                int64_t* row_off_dev, int64_t* nnz_host,
+                                void* workspace_dev, int64_t* nnz_host,
                                 int64_t* indices_dev, int64_t* values_dev);
 
 /* ---- dense features --------------------------------------------------------
@@ -565,10 +570,12 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  * key 14: duplicate roots: representatives numbered per workgroup + one small
  *        scan of the workgroup counts (1 [default]); 0 = device-wide scan over the
  *        positions with the flags evaluated in its loads.
- * key 15: euler_gpu_sample_root: calls with fewer batch rows than this (default
- *        64) build their alias tables with the host's cores between two copies
- *        (the build is one sequential chain per row; the draws stay on the
- *        device); 0 = always one lane per row on the device.
+ * key 15: euler_gpu_sample_root: who builds the alias tables (one sequential
+ *        chain per batch row): 0 = one lane per row on the device, 2 = the host's
+ *        cores between two copies, 1 = by a measured cost model [default] (few
+ *        long rows go to the host); the draws always run on the device.
+ * key 16: SparseGetAdj: 0 = candidates in an LDS hash table, sources stream
+ *        their rows once [default]; 1 = every candidate compared with the row.
  * All settings produce identical results; the knobs exist for A/B measurements
  * and tests. */
 int euler_gpu_set_tuning(int32_t key, int32_t value);

@@ -68,7 +68,7 @@ def test_layerwise_primitives_vs_oracle(EA, O, torch_cuda, lw_pair, et):
             assert np.array_equal(x, y)
 
 
-@pytest.mark.parametrize("host_rows", [64, 0, 10 ** 9],
+@pytest.mark.parametrize("host_rows", [1, 0, 2],
                          ids=["root_auto", "root_device", "root_host"])
 def test_sample_root_vs_oracle(EA, O, torch_cuda, lw_pair, host_rows):
     """Both builders of the alias tables (one lane per batch row on the device /
@@ -79,7 +79,7 @@ def test_sample_root_vs_oracle(EA, O, torch_cuda, lw_pair, host_rows):
     try:
         _sample_root_cases(EA, O, torch_cuda, lw_pair)
     finally:
-        _lib.lib().euler_gpu_set_tuning(15, 64)
+        _lib.lib().euler_gpu_set_tuning(15, 1)
 
 
 def _sample_root_cases(EA, O, torch_cuda, lw_pair):
@@ -100,12 +100,24 @@ def _sample_root_cases(EA, O, torch_cuda, lw_pair):
                                   OB.sample_root(11, call, roots, w, n, m, dn)), (n, m)
 
 
-def test_sparse_get_adj_and_layerwise_vs_oracle(EA, O, torch_cuda, lw_pair):
+@pytest.mark.parametrize("adj_scan", [0, 1], ids=["adj_hash", "adj_scan"])
+def test_sparse_get_adj_and_layerwise_vs_oracle(EA, O, torch_cuda, lw_pair, adj_scan):
+    """Both mask builders (LDS hash table of the candidates / direct scan,
+    tuning key 16), incl. more candidates than one table chunk holds."""
+    from euler_amd import _lib
+    _lib.lib().euler_gpu_set_tuning(16, adj_scan)
+    try:
+        _adj_cases(EA, O, torch_cuda, lw_pair)
+    finally:
+        _lib.lib().euler_gpu_set_tuning(16, 0)
+
+
+def _adj_cases(EA, O, torch_cuda, lw_pair):
     torch = torch_cuda
     G, OG, ids, rng = lw_pair
     B, OB = GpuBackend(torch, G), OracleBackend(O, OG)
     for batch, n, m in ((1, 5, 7), (3, 4, 70), (2, 1, 1), (4, 9, 130), (40, 25, 10),
-                        (1, 300, 300)):
+                        (1, 300, 300), (2, 37, 4500), (1, 6, 2048), (1, 3, 2049)):
         nodes = rng.choice(ids, (batch, n)).astype(np.uint64)
         if n > 1:
             nodes[0, 1] = nodes[0, 0]
@@ -116,6 +128,8 @@ def test_sparse_get_adj_and_layerwise_vs_oracle(EA, O, torch_cuda, lw_pair):
             if len(nb):
                 take = rng.choice(nb, m // 2 + 1)
                 cand[b, :len(take)] = take[:m]
+        cand[0, m - 1] = 2 ** 64 - 1           # default_node = -1 among the candidates
+        cand[-1, 0] = cand[-1, m // 2]           # duplicate candidates
         for et in ([0], [1, 3], [0, 1, 2, 3], [], [9]):
             x = B.sparse_get_adj(nodes, cand, batch, n, m, et)
             y = OB.sparse_get_adj(nodes, cand, batch, n, m, et)
@@ -314,3 +328,35 @@ def test_node_type_and_sample_node_with_src(EA, O, torch_cuda, random_csr):
     with pytest.raises(EulerGpuError):          # unknown src node: type INT32_MIN
         ops.sample_node_with_src(qt[-1:], 2)
     assert G.sample_n_with_types(0, [0]).shape == (1, 0)
+
+
+def test_long_rows(EA, O, torch_cuda):
+    """Rows longer than the lane-per-node limit: the wave-cooperative weight sum
+    (chunks of 64 / groups of 256 edges, every boundary) and the row streaming
+    of the adjacency kernel."""
+    torch = torch_cuda
+    rng = np.random.default_rng(99)
+    degs = [0, 1, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 320, 511, 512,
+            513, 1000, 3000]
+    n, T = 64, 2
+    ids = np.arange(10, 10 + n, dtype=np.uint64) * 7
+    deg = np.zeros((n, T), np.int64)
+    for i, d in enumerate(degs):
+        deg[i, 0] = d
+        deg[i, 1] = degs[-1 - i]
+        deg[i + len(degs), 1] = d          # type 1 only
+    seg = np.zeros(n * T + 1, np.int64)
+    seg[1:] = np.cumsum(deg.reshape(-1))
+    E = int(seg[-1])
+    nbr = rng.choice(ids, E).astype(np.uint64)
+    w = (rng.random(E) * 7.5 + 0.01).astype(np.float32)
+    csr = O.csr_from_raw(ids, seg, nbr, w, T)
+    G, OG = gpu_graph(EA, csr), O.OracleGraph(csr)
+    B, OB = GpuBackend(torch, G), OracleBackend(O, OG)
+    q = np.concatenate([ids, ids[::-1], [5]]).astype(np.uint64)
+    for et in ([0], [1], [0, 1], [1, 0], [1, 1]):
+        a, b = B.get_edge_sum_weight(q, et), OB.get_edge_sum_weight(q, et)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), et
+        x = B.sparse_get_adj(ids, ids, 1, n, n, et)
+        y = OB.sparse_get_adj(ids, ids, 1, n, n, et)
+        assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]), et

@@ -46,7 +46,7 @@ res['get_edge_sum_weight_1M'] = {'ms': round(ms, 4)}
 ms, _ = timed(lambda: G.sample_layer(ids, [0], -1, call_id=3))
 res['sample_layer_1M'] = {'ms': round(ms, 4), 'samples_per_s': ids.numel() / ms * 1e3}
 from euler_amd import _lib
-for mode, host_rows in (('device', 0), ('host', 10 ** 9)):      # tuning key 15 A/B
+for mode, host_rows in (('device', 0), ('host', 2), ('auto', 1)):      # tuning key 15 A/B
     _lib.lib().euler_gpu_set_tuning(15, host_rows)
     for batch, n, m in ((1024, 25, 10), (1024, 256, 256), (256, 256, 256), (64, 1000, 100),
                         (8, 10000, 1000), (1, 100000, 1000)):
@@ -56,7 +56,7 @@ for mode, host_rows in (('device', 0), ('host', 10 ** 9)):      # tuning key 15 
         ms, _ = timed(lambda: G.sample_root(r, wr, m, -1, call_id=4),
                       iters=1 if slow else 5, warm=0 if slow else 1)
         res['sample_root_%s_b%d_n%d_m%d' % (mode, batch, n, m)] = {'ms': round(ms, 4)}
-_lib.lib().euler_gpu_set_tuning(15, 64)
+_lib.lib().euler_gpu_set_tuning(15, 1)
 for batch, n, m in ((1024, 25, 10), (128, 250, 100), (1, 10000, 1000)):
     r = ids[:batch * n].reshape(batch, n)
     ms, out = timed(lambda: G.sample_neighbor_layerwise(r, [0], m, -1, call_id=5), iters=3)
@@ -68,9 +68,21 @@ for batch, n, m in ((1024, 25, 10), (128, 250, 100), (1, 10000, 1000)):
     res['sparse_get_adj_b%d_n%d_m%d' % (batch, n, m)] = {
         'ms': round(ms, 4), 'pairs_per_s': batch * n * m / ms * 1e3}
 sub = ids[:4096]
-ms, out = timed(lambda: G.sparse_get_adj(sub, sub, [0], -1, -1), iters=3)
-res['sparse_get_adj_whole_4096x4096'] = {'ms': round(ms, 4), 'nnz': int(out[0].shape[0]),
-                                         'pairs_per_s': 4096 * 4096 / ms * 1e3}
+for mode, key in (('hash', 0), ('scan', 1)):
+    _lib.lib().euler_gpu_set_tuning(16, key)
+    ms, out = timed(lambda: G.sparse_get_adj(sub, sub, [0], -1, -1), iters=3)
+    res['sparse_get_adj_whole_4096x4096_' + mode] = {
+        'ms': round(ms, 4), 'nnz': int(out[0].shape[0]), 'pairs_per_s': 4096 * 4096 / ms * 1e3}
+    r = ids[:1024 * 25].reshape(1024, 25)
+    nb = ids[30000:30000 + 1024 * 10].reshape(1024, 10)
+    ms, out = timed(lambda: G.sparse_get_adj(r, nb, [0], 25, 10), iters=3)
+    res['sparse_get_adj_b1024_n25_m10_' + mode] = {'ms': round(ms, 4)}
+_lib.lib().euler_gpu_set_tuning(16, 0)
+hub = torch.arange(1, 4097, device='cuda')           # the heaviest rows of the graph
+ms, out = timed(lambda: G.sparse_get_adj(hub, hub, [0], -1, -1), iters=2)
+res['sparse_get_adj_hubs_4096x4096_hash'] = {'ms': round(ms, 4), 'nnz': int(out[0].shape[0])}
+ms, _ = timed(lambda: G.get_edge_sum_weight(hub, [0]), iters=2)
+res['get_edge_sum_weight_hubs_4096'] = {'ms': round(ms, 4)}
 ms, t = timed(lambda: G.get_node_type(ids))
 res['get_node_type_1M'] = {'ms': round(ms, 4)}
 print(json.dumps(res, indent=1))
