@@ -27,7 +27,9 @@ class HostCSR(C.Structure):
                 ("node_type", i32p), ("node_weight", f32p),
                 ("sampler_order", u64p),
                 ("n_float_features", C.c_int32), ("pad0", C.c_int32),
-                ("feat_ptr", i64p), ("feat_idx", i32p), ("feat_val", f32p)]
+                ("feat_ptr", i64p), ("feat_idx", i32p), ("feat_val", f32p),
+                ("n_u64_features", C.c_int32), ("pad1", C.c_int32),
+                ("ufeat_ptr", i64p), ("ufeat_idx", i32p), ("ufeat_val", u64p)]
 
 
 class SynthParams(C.Structure):
@@ -78,6 +80,9 @@ SIGNATURES = {
                                         C.c_int32, C.c_int32, vp]),
     "euler_gpu_get_full_neighbor": (C.c_int, [vp, vp, vp, C.c_int64, i32p, C.c_int32,
                                               vp, i64p, vp, vp, vp]),
+    "euler_gpu_graph_num_u64_features": (C.c_int32, [vp]),
+    "euler_gpu_get_sparse_feature": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int32, C.c_int64,
+                                               vp, i64p, i64p, vp, vp]),
     "euler_gpu_get_node_type": (C.c_int, [vp, vp, vp, C.c_int64, vp]),
     "euler_gpu_sample_n_with_types": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp,
                                                 C.c_int64, C.c_int32, vp]),

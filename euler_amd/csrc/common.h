@@ -179,6 +179,12 @@ struct euler_gpu_graph {
   std::vector<void*> allocations;     // every hipMalloc owned by the graph
   std::vector<float> node_weight_sums;
   const int32_t* node_type_dev = nullptr;   // [n_rows] node types; nullptr = all 0
+  // sparse (uint64) features in the layout of the float ones: values of row r at
+  // ufeat_val[ufeat_ptr[r] ...], slot f ends at ufeat_idx[r * n_u64 + f]
+  const int64_t* ufeat_ptr = nullptr;
+  const int32_t* ufeat_idx = nullptr;
+  const uint64_t* ufeat_val = nullptr;
+  int32_t n_u64 = 0;
   bool feat_slot_aligned = false;     // uniform feature table: every slot begins at a
                                       // multiple of 4 floats (16-byte lanes allowed)
   // scratch of the sampling launcher (dedup table, unique rows), one buffer
@@ -209,7 +215,10 @@ struct DatGraph {
   std::vector<int64_t> row_ptr, feat_ptr;
   std::vector<int32_t> type_end, node_type, feat_idx;
   std::vector<float> prefix_w, type_prefix, node_weight, feat_val;
-  int32_t n_edge_types = 0, n_node_types = 0, partitions = 1, n_float = 0;
+  std::vector<int64_t> ufeat_ptr;
+  std::vector<int32_t> ufeat_idx;
+  std::vector<uint64_t> ufeat_val;
+  int32_t n_edge_types = 0, n_node_types = 0, partitions = 1, n_float = 0, n_u64 = 0;
   void Describe(euler_gpu_host_csr* c) const;
 };
 int LoadDatDirectory(const char* data_path, int32_t shard_index, int32_t shards,

@@ -90,6 +90,11 @@ void DatGraph::Describe(euler_gpu_host_csr* c) const {
     c->feat_ptr = feat_ptr.data(); c->feat_idx = feat_idx.data();
     c->feat_val = feat_val.data();
   }
+  c->n_u64_features = n_u64;
+  if (n_u64 > 0) {
+    c->ufeat_ptr = ufeat_ptr.data(); c->ufeat_idx = ufeat_idx.data();
+    c->ufeat_val = ufeat_val.data();
+  }
 }
 
 int LoadDatDirectory(const char* data_path, int32_t shard_index, int32_t shards,
@@ -159,9 +164,11 @@ int LoadDatDirectory(const char* data_path, int32_t shard_index, int32_t shards,
   std::vector<uint64_t> nb;
   // per-node float features: slot counts differ between nodes in principle, so
   // collect ragged and square up after the scan
-  std::vector<std::vector<int32_t>> f_idx_rows;
+  std::vector<std::vector<int32_t>> f_idx_rows, u_idx_rows;
   out->feat_ptr.assign(1, 0);
   out->feat_val.clear();
+  out->ufeat_ptr.assign(1, 0);
+  out->ufeat_val.clear();
   std::vector<int32_t> in_gids, in_gidx, u64_idx, f32_idx;
   std::vector<float> in_gw, in_nw, f32_val;
   std::vector<uint64_t> in_nb, u64_val;
@@ -205,16 +212,21 @@ int LoadDatDirectory(const char* data_path, int32_t shard_index, int32_t shards,
       prefix_w->insert(prefix_w->end(), nw.begin(), nw.end());
       row_ptr->push_back((int64_t)nbr->size());
       // in-neighbour block (same five vectors), then uint64 / float / binary
-      // features (node.cc:462-523); only the float features are kept
+      // features (node.cc:462-523); the uint64 and float features are kept
       if (!(r.GetVec(&in_gids) && r.GetVec(&in_gw) && r.GetVec(&in_gidx) &&
             r.GetVec(&in_nb) && r.GetVec(&in_nw) && r.GetVec(&u64_idx) &&
             r.GetVec(&u64_val) && r.GetVec(&f32_idx) && r.GetVec(&f32_val)))
         return Fail(EULER_GPU_EIO, "graph_load: malformed feature block in " + fn);
       if (!f32_idx.empty() && f32_idx.back() != (int32_t)f32_val.size())
         return Fail(EULER_GPU_EIO, "graph_load: float feature index does not cover values");
+      if (!u64_idx.empty() && u64_idx.back() != (int32_t)u64_val.size())
+        return Fail(EULER_GPU_EIO, "graph_load: uint64 feature index does not cover values");
       f_idx_rows.push_back(f32_idx);
       out->feat_val.insert(out->feat_val.end(), f32_val.begin(), f32_val.end());
       out->feat_ptr.push_back((int64_t)out->feat_val.size());
+      u_idx_rows.push_back(u64_idx);
+      out->ufeat_val.insert(out->ufeat_val.end(), u64_val.begin(), u64_val.end());
+      out->ufeat_ptr.push_back((int64_t)out->ufeat_val.size());
     }
   }
   int32_t F = 0;
@@ -226,6 +238,17 @@ int LoadDatDirectory(const char* data_path, int32_t shard_index, int32_t shards,
     for (int32_t f = 0; f < F; ++f) {
       if (f < (int32_t)f_idx_rows[i].size()) last = f_idx_rows[i][f];
       out->feat_idx[i * F + f] = last;       // a missing slot has length 0
+    }
+  }
+  int32_t U = 0;
+  for (const auto& v : u_idx_rows) U = std::max(U, (int32_t)v.size());
+  out->n_u64 = U;
+  out->ufeat_idx.assign((size_t)U * u_idx_rows.size(), 0);
+  for (size_t i = 0; i < u_idx_rows.size(); ++i) {
+    int32_t last = 0;
+    for (int32_t f = 0; f < U; ++f) {
+      if (f < (int32_t)u_idx_rows[i].size()) last = u_idx_rows[i][f];
+      out->ufeat_idx[i * U + f] = last;
     }
   }
   return EULER_GPU_OK;

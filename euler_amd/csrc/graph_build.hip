@@ -525,6 +525,35 @@ int BuildGraphFromHost(const euler_gpu_host_csr* c, int device,
     int rc = BuildNodeSampler(&b, ids, types, weights, n_types);
     if (rc != EULER_GPU_OK) { DestroyGraph(b.g.release()); return rc; }
   }
+  // sparse (uint64) features of the kept rows
+  if (c->n_u64_features > 0) {
+    if (!c->ufeat_ptr || !c->ufeat_idx || (c->ufeat_ptr[c->n_rows] > 0 && !c->ufeat_val)) {
+      DestroyGraph(b.g.release());
+      return Fail(EULER_GPU_EINVAL, "graph_create: null uint64 feature array");
+    }
+    const int32_t U = c->n_u64_features;
+    std::vector<int64_t> uptr((size_t)n + 1, 0);
+    std::vector<int32_t> uidx((size_t)n * U);
+    std::vector<uint64_t> uval;
+    for (int64_t i = 0; i < n; ++i) {
+      const int64_t r = keep[i];
+      const int64_t len = c->ufeat_ptr[r + 1] - c->ufeat_ptr[r];
+      if (len < 0 || c->ufeat_idx[r * U + U - 1] != len) {
+        DestroyGraph(b.g.release());
+        return Fail(EULER_GPU_EINVAL, "graph_create: uint64 feature index does not cover values");
+      }
+      uptr[i] = (int64_t)uval.size();
+      std::memcpy(uidx.data() + i * U, c->ufeat_idx + r * U, (size_t)U * 4);
+      uval.insert(uval.end(), c->ufeat_val + c->ufeat_ptr[r], c->ufeat_val + c->ufeat_ptr[r] + len);
+    }
+    uptr[n] = (int64_t)uval.size();
+    b.g->n_u64 = U;
+    b.g->ufeat_ptr = b.Upload(uptr.data(), uptr.size());
+    b.g->ufeat_idx = b.Upload(uidx.data(), uidx.size());
+    if (uval.empty()) uval.push_back(0);      // keep the pointer valid
+    b.g->ufeat_val = b.Upload(uval.data(), uval.size());
+    if (b.rc != EULER_GPU_OK) { DestroyGraph(b.g.release()); return b.rc; }
+  }
   // node types in row order (API_GET_NODE_T); graphs without types keep nullptr
   if (c->node_type && n > 0) {
     std::vector<int32_t> row_type((size_t)n);

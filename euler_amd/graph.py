@@ -98,10 +98,11 @@ class Graph:
     def from_csr(cls, row_id, row_ptr, type_end, nbr, prefix_w, type_prefix,
                  n_edge_types, node_type=None, node_weight=None,
                  sampler_order=None, device=0, partitions=1, shard_index=0,
-                 shards=1, features=None):
+                 shards=1, features=None, sparse_features=None):
         """features = (n_float, feat_ptr [n+1], feat_idx [n*F], feat_val): the
         reference's per-node float_features_idx_ / float_features_
-        (core/graph/node.h) concatenated over rows."""
+        (core/graph/node.h) concatenated over rows; sparse_features = the same
+        four for uint64_features_idx_ / uint64_features_."""
         row_id = _np(row_id, np.uint64)
         row_ptr = _np(row_ptr, np.int64)
         type_end = _np(type_end, np.int32).reshape(-1)
@@ -143,6 +144,16 @@ class Graph:
             c.feat_ptr = fptr.ctypes.data_as(_lib.i64p)
             c.feat_idx = fidx.ctypes.data_as(_lib.i32p)
             c.feat_val = fval.ctypes.data_as(_lib.f32p)
+        if sparse_features is not None:
+            nu, uptr, uidx, uval = sparse_features
+            uptr = _np(uptr, np.int64)
+            uidx = _np(uidx, np.int32).reshape(-1)
+            uval = _np(uval, np.uint64)
+            keep += [uptr, uidx, uval]
+            c.n_u64_features = int(nu)
+            c.ufeat_ptr = uptr.ctypes.data_as(_lib.i64p)
+            c.ufeat_idx = uidx.ctypes.data_as(_lib.i32p)
+            c.ufeat_val = uval.ctypes.data_as(_lib.u64p)
         h = C.c_void_p()
         check(lib().euler_gpu_graph_create_shard(C.byref(c), device, partitions,
                                                  shard_index, shards, C.byref(h)))
@@ -355,6 +366,37 @@ class Graph:
                 check(lib().euler_gpu_get_dense_feature(
                     self._h, _stream(), _ptr(nodes), n, int(fid), int(dim), _ptr(out)))
                 outs.append(out)
+        return outs
+
+    def num_u64_features(self):
+        return lib().euler_gpu_graph_num_u64_features(self._h)
+
+    def get_sparse_feature(self, nodes, feature_ids, default_values=None):
+        """tf_euler get_sparse_feature (euler_ops/feature_ops.py:57-73 over
+        tf_euler/kernels/get_sparse_feature_op.cc): nodes [n] int64 -> one
+        SparseTensor triple (indices [nnz, 2] int64, values [nnz] int64,
+        dense_shape [n, max_len]) per uint64 feature id; a node without values
+        contributes the single entry (row, 0) = default value."""
+        nodes = _as_i64_cuda(nodes, self.device).reshape(-1)
+        n = nodes.numel()
+        if default_values is None:
+            default_values = [0] * len(feature_ids)
+        outs = []
+        with torch.cuda.device(self.device):
+            for fid, dv in zip(feature_ids, default_values):
+                row_off = torch.empty(n + 1, dtype=torch.int64, device=self.device)
+                nnz, max_len = C.c_int64(0), C.c_int64(0)
+                check(lib().euler_gpu_get_sparse_feature(
+                    self._h, _stream(), _ptr(nodes), n, int(fid), int(dv), _ptr(row_off),
+                    C.byref(nnz), C.byref(max_len), None, None))
+                ind = torch.empty((int(nnz.value), 2), dtype=torch.int64, device=self.device)
+                val = torch.empty(int(nnz.value), dtype=torch.int64, device=self.device)
+                if nnz.value:
+                    check(lib().euler_gpu_get_sparse_feature(
+                        self._h, _stream(), _ptr(nodes), n, int(fid), int(dv),
+                        _ptr(row_off), C.byref(nnz), C.byref(max_len), _ptr(ind),
+                        _ptr(val)))
+                outs.append((ind, val, [n, int(max_len.value)] if n else [0, 0]))
         return outs
 
     _ORDER = {None: 0, "": 0, "id": 1, "weight": 2}

@@ -81,6 +81,13 @@ typedef struct euler_gpu_host_csr {
                                   row-relative; a missing slot repeats the
                                   previous end                                 */
   const float* feat_val;       /* [feat_ptr[n_rows]]                            */
+  /* sparse (uint64) features, the reference's uint64_features_idx_ /
+   * uint64_features_ (core/graph/node.h), same layout: optional */
+  int32_t n_u64_features;
+  int32_t pad1;
+  const int64_t* ufeat_ptr;    /* [n_rows+1]                                    */
+  const int32_t* ufeat_idx;    /* [n_rows*U] cumulative ends per slot           */
+  const uint64_t* ufeat_val;   /* [ufeat_ptr[n_rows]]                           */
 } euler_gpu_host_csr;
 
 /* Parameters of the deterministic synthetic power-law graph (benchmarks). */
@@ -402,6 +409,22 @@ int32_t euler_gpu_graph_num_float_features(const euler_gpu_graph* g);
 int euler_gpu_get_dense_feature(const euler_gpu_graph* g, void* stream,
                                 const uint64_t* nodes_dev, int64_t n, int32_t fid,
                                 int32_t dim, float* out_dev);
+
+/* ---- sparse (uint64) features ----------------------------------------------
+ * TF GetSparseFeature (tf_euler/kernels/get_sparse_feature_op.cc:52-131) over
+ * Node::GetUint64Feature (core/graph/node.cc:330-372), one feature slot per
+ * call: the COO triple of the [n, max_len] SparseTensor - for node j the
+ * entries (j, 0..len-1) = its stored values, or ONE entry (j, 0) =
+ * default_value when it stores none (unknown node / slot included).
+ * Two calls: with indices_dev == NULL it fills row_off_dev [n + 1] (int64
+ * scratch the second call reads), *nnz_host and *max_len_host (dense_shape =
+ * [n, max_len]; stream sync); then indices_dev [nnz, 2] / values_dev [nnz]. */
+int32_t euler_gpu_graph_num_u64_features(const euler_gpu_graph* g);
+int euler_gpu_get_sparse_feature(const euler_gpu_graph* g, void* stream,
+                                 const uint64_t* nodes_dev, int64_t n, int32_t fid,
+                                 int64_t default_value, int64_t* row_off_dev,
+                                 int64_t* nnz_host, int64_t* max_len_host,
+                                 int64_t* indices_dev, int64_t* values_dev);
 
 /* ---- RandomWalk -------------------------------------------------------------
  * TF RandomWalk kernel (tf_euler/kernels/random_walk_op.cc:172-291):

@@ -1037,3 +1037,40 @@ int64_t eo_adj_to_sparse(const uint64_t* nodes, const uint64_t* nb_nodes,
   }
   return nnz;
 }
+
+/* TF GetSparseFeature for one feature (tf_euler/kernels/get_sparse_feature_op.cc:
+ * 84-113): the GQL result "fea:2i" / "fea:2i+1" (idx pairs + values of slot fid,
+ * GET_NODE_FEATURE, core/graph/node.cc:330-351) turned into SparseTensorBuilder
+ * entries: node j with no value -> ((j, 0), default); else ((j, k), value k).
+ * Pass indices == NULL to size.  shape[2] = max index + 1 per dimension. */
+int64_t eo_get_sparse_feature(const eo_graph* g, const eo_u64_features* f,
+                              const uint64_t* ids, int64_t n, int32_t fid,
+                              int64_t default_value, int64_t* indices,
+                              int64_t* values, int64_t* shape) {
+  int64_t nnz = 0;
+  if (shape) shape[0] = shape[1] = 0;
+  for (int64_t j = 0; j < n; ++j) {
+    int32_t len = 0;
+    const uint64_t* src = 0;
+    int64_t row = eo_graph_find_row(g, ids[j]);
+    if (row >= 0 && fid >= 0 && fid < f->n_u64) {
+      const int32_t* idx = f->feat_idx + row * f->n_u64;
+      int32_t pre = fid == 0 ? 0 : idx[fid - 1];
+      len = idx[fid] - pre;
+      src = f->feat_val + f->feat_ptr[row] + pre;
+    }
+    int32_t emit = len > 0 ? len : 1;
+    for (int32_t k = 0; k < emit; ++k) {
+      if (indices) {
+        indices[2 * nnz] = j; indices[2 * nnz + 1] = k;
+        values[nnz] = len > 0 ? (int64_t)src[k] : default_value;
+      }
+      if (shape) {
+        if (j + 1 > shape[0]) shape[0] = j + 1;
+        if (k + 1 > shape[1]) shape[1] = k + 1;
+      }
+      ++nnz;
+    }
+  }
+  return nnz;
+}

@@ -100,6 +100,18 @@ int eo_get_dense_feature(const eo_graph* g, const eo_features* f,
                          const uint64_t* ids, int64_t n, int32_t fid,
                          int32_t dim, float* out);
 
+/* uint64 ("sparse") features, same layout as eo_features */
+typedef struct eo_u64_features {
+  int32_t n_u64;
+  const int64_t* feat_ptr;
+  const int32_t* feat_idx;
+  const uint64_t* feat_val;
+} eo_u64_features;
+int64_t eo_get_sparse_feature(const eo_graph* g, const eo_u64_features* f,
+                              const uint64_t* ids, int64_t n, int32_t fid,
+                              int64_t default_value, int64_t* indices,
+                              int64_t* values, int64_t* shape);
+
 int64_t eo_get_full_neighbor(const eo_graph* g, const uint64_t* ids,
                              int64_t n, const int32_t* edge_types, int32_t k,
                              int32_t* idx, uint64_t* out_id, float* out_w,

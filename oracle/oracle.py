@@ -135,6 +135,9 @@ def lib():
                                      _i32p, _u64p, _f32p, _f32p]
         L.eo_philox_kat.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                     C.POINTER(C.c_uint32)]
+        L.eo_get_sparse_feature.restype = C.c_int64
+        L.eo_get_sparse_feature.argtypes = [C.c_void_p, C.c_void_p, _u64p, C.c_int64,
+                                            C.c_int32, C.c_int64, _i64p, _i64p, _i64p]
         L.eo_sample_n_with_types.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, _i32p,
                                              C.c_int64, C.c_int32, _u64p]
         L.eo_get_edge_sum_weight.argtypes = [C.c_void_p, _u64p, C.c_int64, _i32p,
@@ -210,6 +213,15 @@ def ref():
         R.euler_ref_num_float_features.restype = C.c_int32
         R.euler_ref_get_dense_feature.argtypes = [_u64p, C.c_int64, C.c_int32,
                                                   C.c_int32, _f32p]
+        R.euler_ref_set_u64_features.argtypes = [_u64p, C.c_int64, C.c_int32, _i64p,
+                                                 _i32p, _u64p]
+        R.euler_ref_export_u64_features.restype = C.c_int64
+        R.euler_ref_export_u64_features.argtypes = [_u64p, C.c_int64, C.c_int32, _i64p,
+                                                    _i32p, _u64p]
+        R.euler_ref_num_u64_features.restype = C.c_int32
+        R.euler_ref_get_sparse_feature.restype = C.c_int64
+        R.euler_ref_get_sparse_feature.argtypes = [_u64p, C.c_int64, C.c_int32, C.c_int64,
+                                                   _i64p, _i64p, _i64p]
         R.euler_ref_sample_n_with_types.argtypes = [C.c_uint64, C.c_uint32, _i32p,
                                                     C.c_int64, C.c_int32, _u64p]
         R.euler_ref_get_node_type.argtypes = [_u64p, C.c_int64, _i32p]
@@ -318,6 +330,51 @@ class DenseFeatures:
     def c_struct(self):
         return Features(self.n_float, _p(self.feat_ptr, _i64p),
                         _p(self.feat_idx, _i32p), _p(self.feat_val, _f32p))
+
+
+class U64Features(C.Structure):
+    _fields_ = [("n_u64", C.c_int32), ("feat_ptr", _i64p), ("feat_idx", _i32p),
+                ("feat_val", _u64p)]
+
+
+class SparseFeatures:
+    """uint64 features of every row in the reference's per-node form
+    (uint64_features_idx_ / uint64_features_, node.h), concatenated."""
+
+    def __init__(self, n_u64, feat_ptr, feat_idx, feat_val):
+        self.n_u64 = int(n_u64)
+        self.feat_ptr = _arr(feat_ptr, np.int64)
+        self.feat_idx = _arr(feat_idx, np.int32).reshape(-1)
+        self.feat_val = _arr(feat_val, np.uint64)
+
+    @staticmethod
+    def from_lists(per_node):
+        U = max((len(x) for x in per_node), default=0)
+        ptr, idx, val = [0], [], []
+        for slots in per_node:
+            end = 0
+            for f in range(U):
+                if f < len(slots):
+                    val.extend(slots[f]); end += len(slots[f])
+                idx.append(end)
+            ptr.append(len(val))
+        return SparseFeatures(U, ptr, idx, np.array(val, np.uint64))
+
+    def c_struct(self):
+        return U64Features(self.n_u64, _p(self.feat_ptr, _i64p),
+                           _p(self.feat_idx, _i32p), _p(self.feat_val, _u64p))
+
+
+def _sparse_feature_with(fn, head, nodes, fid, default_value):
+    nodes = _arr(nodes, np.uint64)
+    shape = np.zeros(2, np.int64)
+    nnz = fn(*head, _p(nodes, _u64p), len(nodes), fid, default_value, None, None,
+             _p(shape, _i64p))
+    ind = np.zeros((nnz, 2), np.int64)
+    val = np.zeros(nnz, np.int64)
+    fn(*head, _p(nodes, _u64p), len(nodes), fid, default_value, _p(ind, _i64p),
+       _p(val, _i64p), _p(shape, _i64p))
+    return ind, val, shape
 
 
 def csr_from_raw(row_id, seg_ptr, nbr, w, n_types, node_type=None,
@@ -506,6 +563,14 @@ class OracleGraph(_LayerwiseMixin):
                                    len(et), _p(idx, _i32p), _p(oid, _u64p),
                                    _p(ow, _f32p), _p(ot, _i32p))
         return idx, oid, ow, ot
+
+    def get_sparse_feature(self, feats, nodes, feature_ids, default_values=None):
+        """[(indices, values, dense_shape)] per feature id (TF GetSparseFeature)."""
+        st = feats.c_struct()
+        dv = [0] * len(feature_ids) if default_values is None else default_values
+        return [_sparse_feature_with(lib().eo_get_sparse_feature, (self.h, C.byref(st)),
+                                     nodes, int(f), int(d))
+                for f, d in zip(feature_ids, dv)]
 
     def get_node_type(self, ids):
         """euler::GetNodeType (api.cc:50-61): DEFAULT_INT32 for unknown ids."""
@@ -824,6 +889,31 @@ class RefGraph(_LayerwiseMixin):
 
     def __init__(self, n_types):
         self.n_types = n_types
+
+    def set_u64_features(self, row_id, feats):
+        row_id = _arr(row_id, np.uint64)
+        rc = ref().euler_ref_set_u64_features(
+            _p(row_id, _u64p), len(row_id), feats.n_u64, _p(feats.feat_ptr, _i64p),
+            _p(feats.feat_idx, _i32p), _p(feats.feat_val, _u64p))
+        assert rc == 0
+
+    def export_u64_features(self, ids):
+        ids = _arr(ids, np.uint64)
+        U = ref().euler_ref_num_u64_features()
+        n = len(ids)
+        tot = ref().euler_ref_export_u64_features(_p(ids, _u64p), n, U, None, None, None)
+        ptr = np.zeros(n + 1, np.int64)
+        idx = np.zeros(n * max(U, 1), np.int32)
+        val = np.zeros(max(tot, 1), np.uint64)
+        ref().euler_ref_export_u64_features(_p(ids, _u64p), n, U, _p(ptr, _i64p),
+                                            _p(idx, _i32p), _p(val, _u64p))
+        return SparseFeatures(U, ptr, idx[:n * U], val[:tot])
+
+    def get_sparse_feature(self, nodes, feature_ids, default_values=None):
+        dv = [0] * len(feature_ids) if default_values is None else default_values
+        return [_sparse_feature_with(ref().euler_ref_get_sparse_feature, (), nodes,
+                                     int(f), int(d))
+                for f, d in zip(feature_ids, dv)]
 
     def get_node_type(self, ids):
         ids = _arr(ids, np.uint64)

@@ -749,4 +749,79 @@ void euler_ref_get_node_type(const uint64_t* ids, int64_t n, int32_t* out) {
   std::copy(t.begin(), t.end(), out);
 }
 
+// uint64 ("sparse") node features, the counterparts of the float helpers above.
+int euler_ref_set_u64_features(const uint64_t* ids, int64_t n, int32_t U,
+                               const int64_t* feat_ptr, const int32_t* feat_idx,
+                               const uint64_t* feat_val) {
+  for (int64_t i = 0; i < n; ++i) {
+    auto it = G().node_map_.find(ids[i]);
+    if (it == G().node_map_.end()) return -1;
+    euler::Node* node = it->second;
+    node->uint64_features_idx_.assign(feat_idx + i * U, feat_idx + (i + 1) * U);
+    node->uint64_features_.assign(feat_val + feat_ptr[i], feat_val + feat_ptr[i + 1]);
+  }
+  return 0;
+}
+
+int64_t euler_ref_export_u64_features(const uint64_t* ids, int64_t n, int32_t U,
+                                      int64_t* feat_ptr, int32_t* feat_idx,
+                                      uint64_t* feat_val) {
+  int64_t off = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    auto it = G().node_map_.find(ids[i]);
+    if (feat_ptr) feat_ptr[i] = off;
+    int32_t last = 0;
+    for (int32_t f = 0; f < U; ++f) {
+      if (it != G().node_map_.end() &&
+          f < (int32_t)it->second->uint64_features_idx_.size())
+        last = it->second->uint64_features_idx_[f];
+      if (feat_idx) feat_idx[i * U + f] = last;
+    }
+    if (it != G().node_map_.end()) {
+      const auto& v = it->second->uint64_features_;
+      if (feat_val) std::copy(v.begin(), v.end(), feat_val + off);
+      off += (int64_t)v.size();
+    }
+  }
+  if (feat_ptr) feat_ptr[n] = off;
+  return off;
+}
+
+int32_t euler_ref_num_u64_features() {
+  int32_t m = 0;
+  for (auto& kv : G().node_map_)
+    m = std::max(m, (int32_t)kv.second->uint64_features_idx_.size());
+  return m;
+}
+
+// TF GetSparseFeature for one feature (get_sparse_feature_op.cc:84-113) over the
+// reference's Node::GetUint64Feature + the SparseTensorBuilder rules.
+// indices == NULL sizes the result.
+int64_t euler_ref_get_sparse_feature(const uint64_t* ids, int64_t n, int32_t fid,
+                                     int64_t default_value, int64_t* indices,
+                                     int64_t* values, int64_t* shape) {
+  std::vector<int32_t> fids(1, fid);
+  int64_t nnz = 0;
+  int64_t dense_shape[2] = {0, 0};
+  auto emplace = [&](int64_t a, int64_t b, int64_t v) {
+    if (indices) { indices[2 * nnz] = a; indices[2 * nnz + 1] = b; values[nnz] = v; }
+    if (a + 1 > dense_shape[0]) dense_shape[0] = a + 1;
+    if (b + 1 > dense_shape[1]) dense_shape[1] = b + 1;
+    ++nnz;
+  };
+  for (int64_t j = 0; j < n; ++j) {
+    std::vector<uint32_t> nums;
+    std::vector<uint64_t> vals;
+    auto it = G().node_map_.find(ids[j]);
+    if (it != G().node_map_.end()) it->second->GetUint64Feature(fids, &nums, &vals);
+    if (vals.empty()) {
+      emplace(j, 0, default_value);
+    } else {
+      for (size_t k = 0; k < vals.size(); ++k) emplace(j, (int64_t)k, (int64_t)vals[k]);
+    }
+  }
+  if (shape) { shape[0] = dense_shape[0]; shape[1] = dense_shape[1]; }
+  return nnz;
+}
+
 }  // extern "C"

@@ -30,6 +30,11 @@ comes out of REFERENCE code:
                       results (neighbors + sparse adjacency), including the
                       batches of neighbor_ops_test.py:142-175.
                       `python make_golden.py layerwise` writes only this file.
+  sparse_features.npz uint64 ("sparse") features of both graphs as the reference
+                      holds them (fixture: parsed from the .dat files by its own
+                      Node::DeSerialize) + the SparseTensor triples its
+                      GetUint64Feature + the TF GetSparseFeature builder produce.
+                      `python make_golden.py sparse` writes only this file.
   ref_tests.npz       exact expectations copied from the reference's own tests
                       (mp_ops_test.py:30-86, walk_ops_test.py:49-58,
                       unique_gather_test.cc:28-160, neighbor_ops_test.py:46-75).
@@ -349,11 +354,63 @@ def feature_goldens():
     print("feature goldens written")
 
 
+def sparse_feature_goldens():
+    O.build(ref=True)
+    assert O.have_ref(), "oracle/_ref must be built from " + REF
+    out = {}
+    scratch = tempfile.mkdtemp(prefix="euler_golden_")
+    try:
+        data = convert_fixture(scratch)
+        R = O.RefGraph.load(data, 2)
+        ids = np.sort(R.node_order())
+        F = R.export_u64_features(ids)
+        out.update(fx_ids=ids, fx_n_u64=np.int32(F.n_u64), fx_feat_ptr=F.feat_ptr,
+                   fx_feat_idx=F.feat_idx, fx_feat_val=F.feat_val)
+        q = np.concatenate([ids, ids[::-1], [0, 987654321]]).astype(np.uint64)
+        out["fx_query"] = q
+        fids = list(range(F.n_u64)) + [F.n_u64 + 2, -1]
+        dvs = [0, 7, -1, 0, 5, 9][:len(fids)] + [0] * max(0, len(fids) - 6)
+        out["fx_fids"], out["fx_defaults"] = np.array(fids, np.int32), np.array(dvs, np.int64)
+        for k, (ind, val, shape) in enumerate(R.get_sparse_feature(q, fids, dvs)):
+            out["fx_sp_%d_ind" % k], out["fx_sp_%d_val" % k] = ind, val
+            out["fx_sp_%d_shape" % k] = shape
+    finally:
+        shutil.rmtree(scratch, ignore_errors=True)
+    g = np.load(os.path.join(OUT, "random_graph.npz"))
+    ids = g["row_id"]
+    n = len(ids)
+    R = O.RefGraph.build_raw(ids, g["raw_seg_ptr"], g["raw_nbr"], g["raw_w"], 3,
+                             g["node_type"], g["node_weight"])
+    rng = np.random.default_rng(21)
+    per = []
+    for i in range(n):
+        slots = [list(rng.integers(0, 2 ** 63, 3, dtype=np.uint64) * 2 + 1),
+                 list(rng.integers(0, 1000, int(rng.integers(0, 6)), dtype=np.uint64)),
+                 list(rng.integers(0, 2 ** 40, 70 if i % 17 == 0 else 1, dtype=np.uint64))]
+        per.append(slots[:int(rng.integers(1, 4))] if i % 5 == 0 else slots)
+    F = O.SparseFeatures.from_lists(per)
+    R.set_u64_features(ids, F)
+    out.update(rg_n_u64=np.int32(F.n_u64), rg_feat_ptr=F.feat_ptr, rg_feat_idx=F.feat_idx,
+               rg_feat_val=F.feat_val)
+    q = np.concatenate([rng.choice(ids, 200), [0, 4999999]]).astype(np.uint64)
+    out["rg_query"] = q
+    fids, dvs = [0, 1, 2, 5], [0, 0, 123, 4]
+    out["rg_fids"], out["rg_defaults"] = np.array(fids, np.int32), np.array(dvs, np.int64)
+    for k, (ind, val, shape) in enumerate(R.get_sparse_feature(q, fids, dvs)):
+        out["rg_sp_%d_ind" % k], out["rg_sp_%d_val" % k] = ind, val
+        out["rg_sp_%d_shape" % k] = shape
+    np.savez_compressed(os.path.join(OUT, "sparse_features.npz"), **out)
+    print("sparse feature goldens written")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "features":
         feature_goldens()
+    elif len(sys.argv) > 1 and sys.argv[1] == "sparse":
+        sparse_feature_goldens()
     elif len(sys.argv) > 1 and sys.argv[1] == "layerwise":
         main_layerwise()
     else:
         main()
         feature_goldens()
+        sparse_feature_goldens()

@@ -71,6 +71,13 @@ def read_dat(path, shard_index=0, shards=1):
         out["feat_idx"] = np.ctypeslib.as_array(csr.feat_idx, (n * F,)).copy()
         tot = int(out["feat_ptr"][-1])
         out["feat_val"] = np.ctypeslib.as_array(csr.feat_val, (max(tot, 1),))[:tot].copy()
+    U = csr.n_u64_features
+    out["n_u64"] = U
+    if U > 0:
+        out["ufeat_ptr"] = np.ctypeslib.as_array(csr.ufeat_ptr, (n + 1,)).copy()
+        out["ufeat_idx"] = np.ctypeslib.as_array(csr.ufeat_idx, (n * U,)).copy()
+        tot = int(out["ufeat_ptr"][-1])
+        out["ufeat_val"] = np.ctypeslib.as_array(csr.ufeat_val, (max(tot, 1),))[:tot].copy()
     L.euler_gpu_dat_close(owner)
     return out
 
@@ -103,6 +110,15 @@ def test_dat_reader_on_reference_tool_output(fixture_csr):
                               fg["fx_feat_idx"][old * F:old * F + F])
         assert np.array_equal(d["feat_val"][d["feat_ptr"][new]:d["feat_ptr"][new + 1]],
                               fg["fx_feat_val"][fg["fx_feat_ptr"][old]:fg["fx_feat_ptr"][old + 1]])
+    # ... and the uint64 ("sparse") features
+    sg = np.load(os.path.join(ROOT, "tests", "golden", "sparse_features.npz"))
+    U = int(sg["fx_n_u64"])
+    assert d["n_u64"] == U and U > 0
+    for new, old in zip(order, range(6)):
+        assert np.array_equal(d["ufeat_idx"][new * U:new * U + U],
+                              sg["fx_feat_idx"][old * U:old * U + U])
+        assert np.array_equal(d["ufeat_val"][d["ufeat_ptr"][new]:d["ufeat_ptr"][new + 1]],
+                              sg["fx_feat_val"][sg["fx_feat_ptr"][old]:sg["fx_feat_ptr"][old + 1]])
     # shard filter of Graph::Init: file idx % shards == shard_index
     s0 = read_dat(os.path.join(ROOT, "tests", "golden", "fixture_dat"), 0, 2)
     s1 = read_dat(os.path.join(ROOT, "tests", "golden", "fixture_dat"), 1, 2)

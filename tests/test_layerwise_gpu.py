@@ -360,3 +360,39 @@ def test_long_rows(EA, O, torch_cuda):
         x = B.sparse_get_adj(ids, ids, 1, n, n, et)
         y = OB.sparse_get_adj(ids, ids, 1, n, n, et)
         assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]), et
+
+
+def test_sparse_feature_vs_goldens_and_loader(EA, O, torch_cuda, fixture_csr, random_csr):
+    """get_sparse_feature on device == the reference's SparseTensor triples
+    (sparse_features.npz), from a CSR upload and from the .dat loader."""
+    torch = torch_cuda
+    from conftest import ROOT
+    sg = np.load(os.path.join(GOLDEN, "sparse_features.npz"))
+    for prefix, csr in (("fx_", fixture_csr), ("rg_", random_csr)):
+        feats = (int(sg[prefix + "n_u64"]), sg[prefix + "feat_ptr"], sg[prefix + "feat_idx"],
+                 sg[prefix + "feat_val"])
+        graphs = [gpu_graph(EA, csr, sparse_features=feats)]
+        if prefix == "fx_":
+            graphs.append(EA.Graph.load(os.path.join(GOLDEN, "fixture_dat")))
+        q = torch.as_tensor(sg[prefix + "query"].view(np.int64)).cuda()
+        for G in graphs:
+            assert G.num_u64_features() == feats[0]
+            got = G.get_sparse_feature(q, sg[prefix + "fids"].tolist(),
+                                       sg[prefix + "defaults"].tolist())
+            for k, (ind, val, shape) in enumerate(got):
+                assert np.array_equal(t2n(ind), sg[prefix + "sp_%d_ind" % k]), (prefix, k)
+                assert np.array_equal(t2n(val), sg[prefix + "sp_%d_val" % k]), (prefix, k)
+                assert list(shape) == sg[prefix + "sp_%d_shape" % k].tolist(), (prefix, k)
+    # a graph without uint64 features: every node yields the default entry
+    G = gpu_graph(EA, fixture_csr)
+    ind, val, shape = G.get_sparse_feature(q[:4], [0], [9])[0]
+    assert t2n(val).tolist() == [9, 9, 9, 9] and shape == [4, 1]
+    e = torch.zeros(0, dtype=torch.int64, device="cuda")
+    ind, val, shape = G.get_sparse_feature(e, [0])[0]
+    assert ind.shape == (0, 2) and shape == [0, 0]
+    # the ops surface
+    from euler_amd import euler_ops as ops
+    from euler_amd.euler_ops import base
+    base.set_default_graph(graphs[0])
+    got = ops.get_sparse_feature(q, ["0", 1])
+    assert np.array_equal(t2n(got[0][1]), sg["rg_sp_0_val"])

@@ -275,6 +275,27 @@ def test_dense_feature_goldens(O, fixture_csr, random_csr):
     assert np.allclose(fg["fx_dense_0"][0], [1.1, 1.2])
 
 
+def test_sparse_feature_goldens(O, fixture_csr, random_csr):
+    """Restated GetSparseFeature == the SparseTensor triples produced by the
+    reference's GetUint64Feature + the TF kernel's builder
+    (tests/golden/sparse_features.npz): default entries for empty slots, unknown
+    nodes, slots out of range (also negative)."""
+    sg = np.load(os.path.join(os.path.dirname(__file__), "golden", "sparse_features.npz"))
+    for prefix, csr in (("fx_", fixture_csr), ("rg_", random_csr)):
+        F = O.SparseFeatures(int(sg[prefix + "n_u64"]), sg[prefix + "feat_ptr"],
+                             sg[prefix + "feat_idx"], sg[prefix + "feat_val"])
+        got = O.OracleGraph(csr).get_sparse_feature(F, sg[prefix + "query"],
+                                                    sg[prefix + "fids"],
+                                                    sg[prefix + "defaults"])
+        assert len(got) == len(sg[prefix + "fids"])
+        for k, (ind, val, shape) in enumerate(got):
+            assert np.array_equal(ind, sg[prefix + "sp_%d_ind" % k]), (prefix, k)
+            assert np.array_equal(val, sg[prefix + "sp_%d_val" % k]), (prefix, k)
+            assert np.array_equal(shape, sg[prefix + "sp_%d_shape" % k]), (prefix, k)
+    # node 1 of tools/test_data/graph.json: f1 = [11, 12]
+    assert sg["fx_sp_0_val"][:2].tolist() == [11, 12]
+
+
 def test_sorted_and_top_k_neighbor_reference_goldens(O, fixture_csr):
     """tf_euler/python/euler_ops/neighbor_ops_test.py:75-86 (sorted) and
     :101-109 (top-k) on the reference's fixture graph."""

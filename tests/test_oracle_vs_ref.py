@@ -106,6 +106,35 @@ def test_dense_features_match_reference(O):
         assert np.array_equal(x, y)
 
 
+def test_sparse_features_match_reference(O):
+    """Random ragged uint64 features pushed into the reference's Node storage:
+    Node::GetUint64Feature + the TF SparseTensor builder == restatement."""
+    if not O.have_ref():
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(22)
+    n = 200
+    ids = np.sort(rng.choice(np.arange(1, 10 ** 6), n, replace=False)).astype(np.uint64)
+    seg = np.arange(n + 1, dtype=np.int64)
+    nbr = rng.choice(ids, n).astype(np.uint64)
+    w = np.ones(n, np.float32)
+    csr = O.csr_from_raw(ids, seg, nbr, w, 1)
+    per = [[list(rng.integers(0, 2 ** 64, int(rng.integers(0, 9)), dtype=np.uint64))
+            for _ in range(int(rng.integers(0, 4)))] for _ in range(n)]
+    per[0] = [[1] * 8, [], [3] * 90]
+    F = O.SparseFeatures.from_lists(per)
+    R = O.RefGraph.build_raw(ids, seg, nbr, w, 1)
+    R.set_u64_features(ids, F)
+    q = np.concatenate([rng.choice(ids, 500), [0, 7]]).astype(np.uint64)
+    fids, dvs = [0, 1, 2, 3, -1], [0, 5, -1, 4, 2]
+    a = O.OracleGraph(csr).get_sparse_feature(F, q, fids, dvs)
+    b = R.get_sparse_feature(q, fids, dvs)
+    for (ai, av, ash), (bi, bv, bsh) in zip(a, b):
+        assert np.array_equal(ai, bi) and np.array_equal(av, bv) and np.array_equal(ash, bsh)
+    # empty query
+    e = O.OracleGraph(csr).get_sparse_feature(F, np.zeros(0, np.uint64), [0])[0]
+    assert e[0].shape == (0, 2) and list(e[2]) == [0, 0]
+
+
 def test_neighbor_post_process_matches_reference_sort(O):
     """order_by id / weight, asc / desc, limit: restatement == the reference's
     comparators under std::sort, on rows whose keys are distinct (equal keys
