@@ -79,17 +79,21 @@ def sample_fanout_with_feature(nodes, edge_types, count, default_node,
     returns (neighbors, weights, types, dense_features, sparse_features) with
     dense_features[layer * len(names) + j] = feature j of layer `layer`'s nodes
     (layer 0 = the roots), as the op lays its outputs out (:135-178,233).
-    Sparse (uint64) features are out of scope: the list must be empty."""
-    if len(sparse_feature_names):
-        raise NotImplementedError("sparse features are out of scope (SURVEY §8f)")
+    sparse_features[layer * len(sparse names) + j] likewise, each a
+    SparseTensor triple (indices, values, dense_shape) with the per-feature
+    default values (tf_euler/kernels/sample_fanout_with_feature_op.cc:180-232)."""
     g = base.get_default_graph()
     ets = [type_ops.get_edge_type_id(et) for et in edge_types]
     neighbors, weights, types = g.sample_fanout(nodes, ets, count, default_node)
     fids = [int(str(f)) for f in dense_feature_names]
-    dense = []
+    sfids = [int(str(f)) for f in sparse_feature_names]
+    sdef = list(sparse_default_values) if len(sparse_default_values) else [0] * len(sfids)
+    dense, sparse = [], []
     for layer_nodes in neighbors:
         dense.extend(g.get_dense_feature(layer_nodes, fids, list(dense_dimensions)))
-    return neighbors, weights, types, dense, []
+        if sfids:
+            sparse.extend(g.get_sparse_feature(layer_nodes, sfids, sdef))
+    return neighbors, weights, types, dense, sparse
 
 
 def sparse_get_adj(nodes, nb_nodes, edge_types, n=-1, m=-1):
