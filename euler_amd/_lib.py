@@ -94,6 +94,9 @@ SIGNATURES = {
     "euler_gpu_sample_neighbor_layerwise": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp,
                                                       C.c_int64, C.c_int32, i32p, C.c_int32,
                                                       C.c_int32, C.c_int64, vp]),
+    "euler_gpu_local_sample_layer": (C.c_int, [vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp,
+                                               C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                               C.c_char_p, C.c_int64, vp, vp, vp]),
     "euler_gpu_sparse_get_adj_workspace": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "euler_gpu_sparse_get_adj": (C.c_int, [vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_int32,
                                            i32p, C.c_int32, vp, vp, i64p, vp]),

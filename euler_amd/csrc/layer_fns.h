@@ -136,6 +136,17 @@ EG_HD bool EdgeExistAny(const GraphView& g, int64_t row, uint64_t dst,
   return false;
 }
 
+// Draw j of batch row b of API_LOCAL_SAMPLE_L (local_sample_layer_op.cc:128-145):
+// CompactWeightedCollection::Sample = RandomSelect over the row's running sums
+// (cnt entries at sum_w), or -1 for the rows the op memsets (no candidates /
+// zero weight).  RNG: domain 6, stream = b, draw j.
+EG_HD int64_t LocalLayerPick(uint64_t seed, uint32_t call_id, int64_t b, int32_t j,
+                             const float* sum_w, int64_t cnt) {
+  if (cnt == 0 || sum_w[cnt - 1] == 0.f) return -1;
+  const double u = RngDraw(seed, call_id, kDomainLocalLayer, (uint64_t)b, (uint64_t)j);
+  return (int64_t)RandomSelect(sum_w, 0, (uint64_t)(cnt - 1), u);
+}
+
 // Graph::GetNodeByID(id)->GetType() (core/api/api.cc:50-61, GetNodeType):
 // DEFAULT_INT32 = numeric_limits<int32_t>::lowest() for an unknown node
 // (common/data_types.cc:23).  node_type == nullptr: every node has type 0.

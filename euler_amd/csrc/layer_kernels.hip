@@ -12,10 +12,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
+#include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "layer_fns.h"
+#include "local_layer_host.h"
 
 namespace euler_gpu {
 
@@ -483,6 +487,44 @@ __global__ void AdjOffsetsToIdxKernel(const int64_t* __restrict__ off, int64_t n
   }
 }
 
+// ---------------------------------------------------------------- local layer
+// API_LOCAL_SAMPLE_L draws (core/kernels/local_sample_layer_op.cc:128-145): one
+// lane per (batch row, sample): CompactWeightedCollection::Sample =
+// RandomSelect over the row's running sums, or the op's memset fill.
+struct LocalLayerArgs {
+  const int64_t* seg;       // [batch + 1] offsets of the rows' distinct entries
+  const uint64_t* u_id;
+  const float* u_w;         // accumulated (and sqrt'ed) weight of every entry
+  const int32_t* u_t;
+  const float* sum_w;       // running f32 sums inside every row
+  int64_t batch;
+  int32_t m;
+  uint64_t seed;
+  uint32_t call_id;
+  uint64_t fill_id;         // default_node's low byte repeated (the op memsets)
+  uint64_t* out_id;
+  float* out_w;
+  int32_t* out_t;
+};
+
+__global__ __launch_bounds__(256) void LocalSampleLayerKernel(const LocalLayerArgs a) {
+  const int64_t total = a.batch * a.m;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < total; x += stride) {
+    const int64_t b = x / a.m;
+    const int32_t j = (int32_t)(x - b * a.m);
+    const int64_t s0 = a.seg[b];
+    const int64_t mid = LocalLayerPick(a.seed, a.call_id, b, j, a.sum_w + s0, a.seg[b + 1] - s0);
+    if (mid < 0) {                                            // :129-134
+      a.out_id[x] = a.fill_id; a.out_w[x] = 0.f; a.out_t[x] = 0;
+      continue;
+    }
+    a.out_id[x] = a.u_id[s0 + mid];
+    a.out_w[x] = a.u_w[s0 + mid];
+    a.out_t[x] = a.u_t[s0 + mid];
+  }
+}
+
 // ---------------------------------------------------------------- node types
 __global__ __launch_bounds__(256) void NodeTypeKernel(
     const GraphView g, const int32_t* __restrict__ node_type,
@@ -736,6 +778,77 @@ int euler_gpu_sample_neighbor_layerwise(const euler_gpu_graph* g, void* stream,
   hipError_t f = hipFreeAsync(buf, st);
   if (rc != EULER_GPU_OK) return rc;
   EG_HIP(f);
+  return EULER_GPU_OK;
+}
+
+int euler_gpu_local_sample_layer(void* stream, uint64_t seed, uint32_t call_id,
+                                 const int32_t* idx_dev, const uint64_t* ids_dev,
+                                 const float* w_dev, const int32_t* t_dev, int64_t total,
+                                 int64_t batch, int32_t n, int32_t m,
+                                 const char* weight_func, int64_t default_node,
+                                 uint64_t* out_id_dev, float* out_w_dev,
+                                 int32_t* out_t_dev) {
+  if (batch < 0 || n <= 0 || m < 0 || total < 0)
+    return Fail(EULER_GPU_EINVAL, "local_sample_layer: bad sizes");
+  if (batch == 0 || m == 0) return EULER_GPU_OK;
+  if (!idx_dev || !out_id_dev || !out_w_dev || !out_t_dev ||
+      (total > 0 && (!ids_dev || !w_dev || !t_dev)))
+    return Fail(EULER_GPU_EINVAL, "local_sample_layer: null buffer");
+  hipStream_t st = (hipStream_t)stream;
+  // ---- the candidate tables are built where the reference builds them: on the
+  // host, in a std::unordered_map<std::string, ...> per batch row - the ORDER of
+  // the candidates is that container's iteration order (local_sample_layer_op.cc:
+  // 73-121), a property of libstdc++ this library shares with the reference.
+  const int64_t R = batch * n;
+  std::vector<int32_t> idx((size_t)R * 2), t((size_t)total);
+  std::vector<uint64_t> ids((size_t)total);
+  std::vector<float> w((size_t)total);
+  EG_HIP(hipMemcpyAsync(idx.data(), idx_dev, (size_t)R * 8, hipMemcpyDeviceToHost, st));
+  if (total > 0) {
+    EG_HIP(hipMemcpyAsync(ids.data(), ids_dev, (size_t)total * 8, hipMemcpyDeviceToHost, st));
+    EG_HIP(hipMemcpyAsync(w.data(), w_dev, (size_t)total * 4, hipMemcpyDeviceToHost, st));
+    EG_HIP(hipMemcpyAsync(t.data(), t_dev, (size_t)total * 4, hipMemcpyDeviceToHost, st));
+  }
+  EG_HIP(hipStreamSynchronize(st));
+  LocalLayerTables tb;
+  if (!BuildLocalLayerTables(idx.data(), ids.data(), w.data(), t.data(), total, batch, n,
+                             weight_func && std::string(weight_func) == "sqrt", &tb))
+    return Fail(EULER_GPU_EINVAL, "local_sample_layer: idx does not index the values");
+  std::vector<int64_t>& seg = tb.seg;
+  std::vector<uint64_t>& u_id = tb.u_id;
+  std::vector<float>&u_w = tb.u_w, &sum_w = tb.sum_w;
+  std::vector<int32_t>& u_t = tb.u_t;
+  const size_t U = u_id.size();
+  uint8_t* buf = nullptr;
+  const size_t bytes = (size_t)(batch + 1) * 8 + U * 8 + U * 12 + 64;
+  EG_HIP(hipMallocAsync((void**)&buf, bytes, st));
+  LocalLayerArgs a{};
+  int64_t* d_seg = reinterpret_cast<int64_t*>(buf);
+  uint64_t* d_id = reinterpret_cast<uint64_t*>(d_seg + batch + 1);
+  float* d_w = reinterpret_cast<float*>(d_id + U);
+  float* d_sum = d_w + U;
+  int32_t* d_t = reinterpret_cast<int32_t*>(d_sum + U);
+  hipError_t c = hipMemcpyAsync(d_seg, seg.data(), (size_t)(batch + 1) * 8, hipMemcpyHostToDevice, st);
+  if (U > 0) {
+    if (c == hipSuccess) c = hipMemcpyAsync(d_id, u_id.data(), U * 8, hipMemcpyHostToDevice, st);
+    if (c == hipSuccess) c = hipMemcpyAsync(d_w, u_w.data(), U * 4, hipMemcpyHostToDevice, st);
+    if (c == hipSuccess) c = hipMemcpyAsync(d_sum, sum_w.data(), U * 4, hipMemcpyHostToDevice, st);
+    if (c == hipSuccess) c = hipMemcpyAsync(d_t, u_t.data(), U * 4, hipMemcpyHostToDevice, st);
+  }
+  a.seg = d_seg; a.u_id = d_id; a.u_w = d_w; a.u_t = d_t; a.sum_w = d_sum;
+  a.batch = batch; a.m = m; a.seed = seed; a.call_id = call_id;
+  // memset(out, default_node, ...) fills BYTES with the value's low byte (:130)
+  a.fill_id = 0x0101010101010101ULL * (uint64_t)(uint8_t)default_node;
+  a.out_id = out_id_dev; a.out_w = out_w_dev; a.out_t = out_t_dev;
+  const int block = 256;
+  if (c == hipSuccess) {
+    hipLaunchKernelGGL(LocalSampleLayerKernel, dim3(GridFor(batch * m, block)), dim3(block), 0,
+                       st, a);
+    c = hipGetLastError();
+  }
+  hipError_t y = hipStreamSynchronize(st);      // the host vectors feed async copies
+  hipError_t f = hipFreeAsync(buf, st);
+  EG_HIP(c); EG_HIP(y); EG_HIP(f);
   return EULER_GPU_OK;
 }
 

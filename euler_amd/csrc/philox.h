@@ -32,9 +32,10 @@ enum RngDomain : uint32_t {
   kDomainWalk = 2,      // stream = walker index (node2vec step)
   kDomainSplit = 3,     // SAMPLE_NODE_SPLIT remainder
   kDomainRoot = 4,      // API_SAMPLE_ROOT: stream = batch row, 2 draws per sample
-  kDomainLayer = 5      // API_SAMPLE_L: stream = POSITION in the root list (the
+  kDomainLayer = 5,     // API_SAMPLE_L: stream = POSITION in the root list (the
                         // same node drawn twice samples twice), draws of one
                         // Node::SampleNeighbor(count = 1)
+  kDomainLocalLayer = 6 // API_LOCAL_SAMPLE_L: stream = batch row, draw j = sample j
 };
 
 EG_HD uint32_t DomainSalt(uint32_t domain) {
@@ -43,7 +44,8 @@ EG_HD uint32_t DomainSalt(uint32_t domain) {
        : domain == 2 ? 0x7F4A7C15u
        : domain == 3 ? 0xF39CC060u
        : domain == 4 ? 0x6A09E667u
-                     : 0xB5C0FBCFu;
+       : domain == 5 ? 0xB5C0FBCFu
+                     : 0x3C6EF372u;
 }
 
 struct Philox4 {

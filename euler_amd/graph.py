@@ -524,6 +524,28 @@ class Graph:
                 _ptr(ot)))
         return oid, ow, ot
 
+    def local_sample_layer(self, idx, ids, w, t, batch, n, m, weight_func="sqrt",
+                           default_node=-1, call_id=None):
+        """API_LOCAL_SAMPLE_L (core/kernels/local_sample_layer_op.cc): m draws
+        per batch row from the distinct (id, type) full neighbours of its n
+        nodes, weights of duplicates added and transformed by weight_func;
+        (ids, weights, types) each [batch * m]."""
+        idx = idx.to(torch.int32).contiguous()
+        ids = ids.to(torch.int64).contiguous()
+        w = w.to(torch.float32).contiguous()
+        t = t.to(torch.int32).contiguous()
+        total = ids.numel()
+        oid = torch.empty(batch * m, dtype=torch.int64, device=self.device)
+        ow = torch.empty(batch * m, dtype=torch.float32, device=self.device)
+        ot = torch.empty(batch * m, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().euler_gpu_local_sample_layer(
+                _stream(), self.seed, self._take_call_ids(1, call_id), _ptr(idx),
+                _ptr(ids), _ptr(w), _ptr(t), total, batch, n, m,
+                str(weight_func).encode(), int(default_node), _ptr(oid), _ptr(ow),
+                _ptr(ot)))
+        return oid, ow, ot
+
     def sparse_get_adj_core(self, roots, l_nb, n, m, edge_types):
         """API_SPARSE_GEN_ADJ + API_SPARSE_GET_ADJ (core/kernels/
         sparse_get_adj_op.cc): (idx [batch*n, 2] int32, ids int64)."""
@@ -586,16 +608,23 @@ class Graph:
         """tf_euler sample_neighbor_layerwise (euler_ops/neighbor_ops.py:72-77
         over tf_euler/kernels/sample_neighbor_layerwise_with_adj_op.cc):
         nodes [batch, n] -> (neighbors [batch, count] int64, (indices, values,
-        dense_shape) of the [batch, n, count] adjacency)."""
-        if weight_func:
-            raise NotImplementedError(
-                "sampleLNB weight functions run API_LOCAL_SAMPLE_L, whose order is "
-                "std::unordered_map<std::string> iteration order (DESIGN.md §8)")
+        dense_shape) of the [batch, n, count] adjacency).  weight_func == ''
+        draws a node of the layer by edge weight sum, then one of its
+        neighbours; 'sqrt' draws from the layer's distinct neighbours by the
+        square root of their accumulated weight."""
         nodes = _as_i64_cuda(nodes, self.device)
         if nodes.dim() != 2:
             raise ValueError("sample_neighbor_layerwise: nodes must be [batch, n]")
         batch, n = nodes.shape
         et, et_p, k = _i32_array(edge_types)
+        if weight_func:
+            # sampleLNB(edge_types, n, m, weight_func, default_node): API_GET_NB_NODE
+            # -> API_LOCAL_SAMPLE_L (parser/translator.cc:388-441)
+            idx, ids, w, t = self.get_full_neighbor(nodes.reshape(-1), et)
+            out, _w, _t = self.local_sample_layer(idx, ids, w, t, batch, n, int(count),
+                                                  weight_func, default_node, call_id)
+            out = out.reshape(batch, int(count))
+            return out, self.sparse_get_adj(nodes, out, et, n, int(count))
         out = torch.empty((batch, int(count)), dtype=torch.int64, device=self.device)
         with torch.cuda.device(self.device):
             check(lib().euler_gpu_sample_neighbor_layerwise(

@@ -316,8 +316,8 @@ int euler_gpu_neighbor_to_dense(void* stream, int64_t n, const int32_t* idx_dev,
  * `v(nodes).sampleLNB(edge_types, n, m, default_node)`:
  * API_GET_EDGE_SUM_WEIGHT -> API_SAMPLE_ROOT -> API_SAMPLE_L ->
  * API_SPARSE_GEN_ADJ -> API_SPARSE_GET_ADJ -> API_GATHER_RESULT.
- * (The `sqrt` weight function runs API_LOCAL_SAMPLE_L, whose candidate order is
- * the iteration order of a std::unordered_map<std::string, ...>: not built.) */
+ * With a weight function the first three are API_GET_NB_NODE ->
+ * API_LOCAL_SAMPLE_L (euler_gpu_local_sample_layer below). */
 
 /* API_GET_EDGE_SUM_WEIGHT (core/kernels/get_edge_sum_weight_op.cc:33-66):
  * out_w_dev[i] = f32 sum, in Node::GetFullNeighbor order (core/graph/node.cc:
@@ -361,6 +361,26 @@ int euler_gpu_sample_neighbor_layerwise(const euler_gpu_graph* g, void* stream,
                                         int32_t n, const int32_t* edge_types_host,
                                         int32_t k, int32_t count,
                                         int64_t default_node, uint64_t* out_dev);
+
+/* API_LOCAL_SAMPLE_L (core/kernels/local_sample_layer_op.cc:43-146), the
+ * sampler of `sampleLNB(edge_types, n, m, weight_func, default_node)`: per batch
+ * row the distinct (neighbour id, edge type) pairs among the full neighbours of
+ * its n nodes (idx_dev [batch*n, 2] / ids_dev / w_dev / t_dev [total]: the
+ * API_GET_NB_NODE result, e.g. euler_gpu_get_full_neighbor), weights of
+ * duplicates added, then `sqrt` when weight_func is "sqrt" (any other string
+ * leaves them as they are, :86-95), then m draws by CDF inversion -> out_*_dev
+ * [batch * m].  The candidate ORDER is the iteration order of the op's
+ * std::unordered_map<std::string, ...>; the tables are therefore built on the
+ * host with that very container (a stream sync each way), the draws run on the
+ * device.  Rows with no candidates or zero weight are memset like the op does:
+ * every BYTE of the ids = default_node's low byte.  RNG: domain 6, stream = b. */
+int euler_gpu_local_sample_layer(void* stream, uint64_t seed, uint32_t call_id,
+                                 const int32_t* idx_dev, const uint64_t* ids_dev,
+                                 const float* w_dev, const int32_t* t_dev, int64_t total,
+                                 int64_t batch, int32_t n, int32_t m,
+                                 const char* weight_func, int64_t default_node,
+                                 uint64_t* out_id_dev, float* out_w_dev,
+                                 int32_t* out_t_dev);
 
 /* API_SPARSE_GET_ADJ (core/kernels/sparse_get_adj_op.cc:35-92) with the
  * root_batch tensor API_SPARSE_GEN_ADJ builds (sparse_gen_adj_op.cc:52-61:

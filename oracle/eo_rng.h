@@ -26,6 +26,8 @@
  *   domain 5  API_SAMPLE_L (core/kernels/sample_layer_op.cc) : stream =
  *             POSITION of the root in the op's input (each position is its own
  *             SampleNeighbor(count = 1) call), draw_idx counts calls inside it
+ *   domain 6  API_LOCAL_SAMPLE_L (core/kernels/local_sample_layer_op.cc) :
+ *             stream = batch row, draw_idx counts the draws of the row's loop
  */
 #ifndef EULER_ORACLE_EO_RNG_H_
 #define EULER_ORACLE_EO_RNG_H_
@@ -42,13 +44,14 @@ enum {
   EO_DOMAIN_WALK = 2,
   EO_DOMAIN_SPLIT = 3,
   EO_DOMAIN_ROOT = 4,
-  EO_DOMAIN_LAYER = 5
+  EO_DOMAIN_LAYER = 5,
+  EO_DOMAIN_LOCAL_LAYER = 6
 };
 
 static const uint32_t EO_DOMAIN_SALT[8] = {0x00000000u, 0x9E3779B9u,
                                            0x7F4A7C15u, 0xF39CC060u,
                                            0x6A09E667u, 0xB5C0FBCFu,
-                                           0xB5C0FBCFu, 0xB5C0FBCFu};
+                                           0x3C6EF372u, 0x3C6EF372u};
 
 static inline void eo_philox4x32_10(const uint32_t ctr[4],
                                     const uint32_t key[2], uint32_t out[4]) {

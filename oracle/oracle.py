@@ -225,6 +225,9 @@ def ref():
         R.euler_ref_sample_n_with_types.argtypes = [C.c_uint64, C.c_uint32, _i32p,
                                                     C.c_int64, C.c_int32, _u64p]
         R.euler_ref_get_node_type.argtypes = [_u64p, C.c_int64, _i32p]
+        R.euler_ref_local_sample_layer.argtypes = [
+            C.c_uint64, C.c_uint32, _i32p, C.c_int64, _u64p, _f32p, _i32p, C.c_int32,
+            C.c_int32, C.c_char_p, C.c_int64, _u64p, _f32p, _i32p]
         R.euler_ref_graph_load_all.argtypes = [C.c_char_p]
         R.euler_ref_add_edges_from_adjacency.restype = C.c_int64
         R.euler_ref_num_edges.restype = C.c_int64
@@ -944,6 +947,36 @@ class RefGraph(_LayerwiseMixin):
 
     def edge_exist(self, src, dst, etype):
         return bool(ref().euler_ref_edge_exist(int(src), int(dst), int(etype)))
+
+    def local_sample_layer(self, seed, call_id, idx, ids, w, t, n, m, weight_func="sqrt",
+                           default_node=-1):
+        """API_LOCAL_SAMPLE_L over the reference's own containers."""
+        idx = _arr(idx, np.int32).reshape(-1)
+        ids, w, t = _arr(ids, np.uint64), _arr(w, np.float32), _arr(t, np.int32)
+        batch = len(idx) // (2 * n)
+        oid = np.zeros(batch * m, np.uint64)
+        ow = np.zeros(batch * m, np.float32)
+        ot = np.zeros(batch * m, np.int32)
+        ref().euler_ref_local_sample_layer(seed, call_id, _p(idx, _i32p), len(idx),
+                                           _p(ids, _u64p), _p(w, _f32p), _p(t, _i32p), n,
+                                           m, weight_func.encode(), default_node,
+                                           _p(oid, _u64p), _p(ow, _f32p), _p(ot, _i32p))
+        return oid, ow, ot
+
+    def sample_neighbor_layerwise_func(self, seed, call_id, nodes, edge_types, count,
+                                       weight_func, default_node=-1):
+        """sampleLNB with a weight function: API_GET_NB_NODE -> API_LOCAL_SAMPLE_L
+        -> adjacency (translator.cc:388-441,489-527)."""
+        nodes = np.asarray(nodes)
+        batch, n = nodes.shape
+        flat = _arr(nodes.reshape(-1), np.uint64)
+        idx, ids, w, t = self.get_full_neighbor(flat, edge_types)
+        l_nb, l_w, l_t = self.local_sample_layer(seed, call_id, idx, ids, w, t, n, count,
+                                                 weight_func, default_node)
+        aidx, avals = self.sparse_get_adj(flat, l_nb, batch, n, count, edge_types)
+        ind, val, shape = self._adj_to_sparse(flat, l_nb, batch, n, count, aidx, avals)
+        return (l_nb.view(np.int64).reshape(batch, count), l_w.reshape(batch, count),
+                l_t.reshape(batch, count), ind, val, shape)
 
     @staticmethod
     def _adj_to_sparse(nodes, nb_nodes, batch, n, m, idx, vals):

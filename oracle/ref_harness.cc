@@ -25,6 +25,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <cmath>
 #include <chrono>
 #include <set>
 #include <string>
@@ -822,6 +823,72 @@ int64_t euler_ref_get_sparse_feature(const uint64_t* ids, int64_t n, int32_t fid
   }
   if (shape) { shape[0] = dense_shape[0]; shape[1] = dense_shape[1]; }
   return nnz;
+}
+
+// API_LOCAL_SAMPLE_L body (local_sample_layer_op.cc:43-146) restated around the
+// same std::unordered_map<std::string, ...>, CompactWeightedCollection and
+// memset calls; RNG stream = batch row.
+void euler_ref_local_sample_layer(uint64_t seed, uint32_t call_id, const int32_t* idx_data,
+                                  int64_t idx_elems, const uint64_t* nb_id,
+                                  const float* nb_w, const int32_t* nb_type, int32_t n,
+                                  int32_t m, const char* weight_func_c,
+                                  int64_t default_node, uint64_t* o_nb, float* o_w,
+                                  int32_t* o_t) {
+  struct DstTypeWeight { uint64_t dst_id_; float edge_weight_; int32_t edge_type_; };
+  std::string weight_func(weight_func_c);
+  int32_t batch = idx_elems / (n * 2);
+  std::vector<int32_t> batch_nb_offset;
+  for (int32_t i = 0; i < idx_elems; i += n * 2) batch_nb_offset.push_back(idx_data[i]);
+  std::vector<std::unordered_map<std::string, DstTypeWeight>> batch_nb_unique_map(batch);
+  for (int32_t i = 0; i < batch; ++i) {
+    int32_t batch_begin = batch_nb_offset[i];
+    int32_t batch_end = 0;
+    if (i < batch - 1) batch_end = batch_nb_offset[i + 1];
+    else batch_end = idx_data[idx_elems - 1];
+    for (int32_t j = batch_begin; j < batch_end; ++j) {
+      uint64_t dst_id = nb_id[j];
+      float weight = nb_w[j];
+      int32_t type = nb_type[j];
+      std::string key = std::to_string(dst_id) + std::to_string(type);
+      if (batch_nb_unique_map[i].find(key) == batch_nb_unique_map[i].end()) {
+        batch_nb_unique_map[i][key] = {dst_id, weight, type};
+      } else {
+        batch_nb_unique_map[i][key].edge_weight_ += weight;
+      }
+    }
+  }
+  if (weight_func == "sqrt") {
+    for (int32_t i = 0; i < batch; ++i)
+      for (auto it = batch_nb_unique_map[i].begin(); it != batch_nb_unique_map[i].end(); ++it)
+        it->second.edge_weight_ = sqrt(it->second.edge_weight_);
+  }
+  std::vector<euler::common::CompactWeightedCollection<DstTypeWeight>> batch_sampler(batch);
+  for (int32_t i = 0; i < batch; ++i) {
+    if (!batch_nb_unique_map[i].empty()) {
+      std::vector<DstTypeWeight> values;
+      std::vector<float> weights;
+      for (auto it = batch_nb_unique_map[i].begin(); it != batch_nb_unique_map[i].end(); ++it) {
+        values.push_back(it->second);
+        weights.push_back(it->second.edge_weight_);
+      }
+      batch_sampler[i].Init(values, weights);
+    }
+  }
+  for (int32_t i = 0; i < batch; ++i) {
+    if (batch_sampler[i].GetSize() == 0 || batch_sampler[i].GetSumWeight() == 0) {
+      memset(o_nb + i * m, default_node, sizeof(uint64_t) * m);
+      memset(o_w + i * m, 0, sizeof(float) * m);
+      memset(o_t + i * m, 0, sizeof(int32_t) * m);
+    } else {
+      euler_ref_set_rng(seed, call_id, EO_DOMAIN_LOCAL_LAYER, (uint64_t)i);
+      for (int32_t j = 0; j < m; ++j) {
+        DstTypeWeight e = batch_sampler[i].Sample().first;
+        o_nb[i * m + j] = e.dst_id_;
+        o_w[i * m + j] = e.edge_weight_;
+        o_t[i * m + j] = e.edge_type_;
+      }
+    }
+  }
 }
 
 }  // extern "C"

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "layer_fns.h"
+#include "local_layer_host.h"
 
 using namespace euler_gpu;
 
@@ -116,6 +117,31 @@ void hc_sample_layer(void* h, uint64_t seed, uint32_t call_id, const uint64_t* r
   for (int64_t i = 0; i < n; ++i)
     SampleLayerAt(g, seed, call_id, i, roots[i], types, k, default_node, out_id + i,
                   out_w + i, out_t + i);
+}
+
+// euler_gpu_local_sample_layer with its kernel replaced by a host loop over the
+// same LocalLayerPick.
+int hc_local_sample_layer(uint64_t seed, uint32_t call_id, const int32_t* idx,
+                          const uint64_t* ids, const float* w, const int32_t* t,
+                          int64_t total, int64_t batch, int32_t n, int32_t m,
+                          const char* weight_func, int64_t default_node, uint64_t* out_id,
+                          float* out_w, int32_t* out_t) {
+  LocalLayerTables tb;
+  if (!BuildLocalLayerTables(idx, ids, w, t, total, batch, n,
+                             std::string(weight_func) == "sqrt", &tb))
+    return -1;
+  const uint64_t fill = 0x0101010101010101ULL * (uint64_t)(uint8_t)default_node;
+  for (int64_t x = 0; x < batch * m; ++x) {
+    const int64_t b = x / m;
+    const int64_t s0 = tb.seg[b];
+    const int64_t mid = LocalLayerPick(seed, call_id, b, (int32_t)(x - b * m),
+                                       tb.sum_w.data() + s0, tb.seg[b + 1] - s0);
+    if (mid < 0) { out_id[x] = fill; out_w[x] = 0.f; out_t[x] = 0; continue; }
+    out_id[x] = tb.u_id[s0 + mid];
+    out_w[x] = tb.u_w[s0 + mid];
+    out_t[x] = tb.u_t[s0 + mid];
+  }
+  return 0;
 }
 
 // mask[r * m + j] = EdgeExistAny(roots[r], l_nb[(r / n) * m + j])

@@ -190,6 +190,18 @@ def main_layerwise():
         nb, ind, val, shape = R.sample_neighbor_layerwise(SEED, 90, src, [0, 1], 10, -1)
         out.update(fx_t_nodes=src, fx_t_nb=nb, fx_t_ind=ind, fx_t_val=val,
                    fx_t_shape=shape)
+        # sampleLNB WITH a weight function (API_LOCAL_SAMPLE_L), the reference's own
+        # test batches (neighbor_ops_test.py:159-175) and a default_node whose low
+        # byte shows the op's memset fill
+        for c, (wf, dn) in enumerate((("sqrt", -1), ("sqrt", 261), ("none", -1))):
+            r = R.sample_neighbor_layerwise_func(SEED, 95 + c, src, [0, 1], 10, wf, dn)
+            for k, v in zip(("nb", "w", "t", "ind", "val", "shape"), r):
+                out["fx_lf_%d_%s" % (c, k)] = v
+        lone = np.array([[6, 6], [987654321, 6], [1, 5]], np.uint64)
+        out["fx_lf_lone_nodes"] = lone
+        r = R.sample_neighbor_layerwise_func(SEED, 99, lone, [0], 4, "sqrt", 261)
+        for k, v in zip(("nb", "w", "t", "ind", "val", "shape"), r):
+            out["fx_lf_lone_%s" % k] = v
         # every (src, dst, type) the reference holds an Edge record for
         g = np.load(os.path.join(OUT, "fixture_graph.npz"))
         trip = []
@@ -208,6 +220,15 @@ def main_layerwise():
                              g["node_type"], g["node_weight"])
     R.add_edges_from_adjacency()
     out.update(layer_pack(R, g["row_id"][:40], T, "rg_", np.random.default_rng(12)))
+    rng = np.random.default_rng(13)
+    for c, (batch, n, count, et) in enumerate(((3, 4, 12, [0, 1, 2]), (1, 40, 64, [2]),
+                                               (5, 1, 3, [0, 2]), (2, 60, 30, [0, 1, 2]))):
+        nodes = rng.choice(g["row_id"], (batch, n)).astype(np.uint64)
+        nodes[0, 0] = g["row_id"][0]                  # the hub row: many duplicates
+        out["rg_lf_%d_nodes" % c], out["rg_lf_%d_et" % c] = nodes, np.array(et, np.int32)
+        r = R.sample_neighbor_layerwise_func(SEED, 120 + c, nodes, et, count, "sqrt", -1)
+        for k, v in zip(("nb", "w", "t", "ind", "val", "shape"), r):
+            out["rg_lf_%d_%s" % (c, k)] = v
     np.savez_compressed(os.path.join(OUT, "layerwise.npz"), **out)
     print("layerwise golden vectors written")
 

@@ -58,6 +58,37 @@ def check_layer_pack(B, L, prefix, T):
     assert e > 0 and c > 0
 
 
+def check_layer_func_pack(fn, L, prefix):
+    """sampleLNB with a weight function against the reference harness' outputs:
+    fn(seed, call_id, nodes, edge_types, count, weight_func, default_node) ->
+    (nb [batch, count], w, t, indices, values, dense_shape)."""
+    seed = int(L["seed"])
+    keys = ("nb", "w", "t", "ind", "val", "shape")
+
+    def one(tag, call, nodes, et, count, wf, dn):
+        got = fn(seed, call, nodes, et, count, wf, dn)
+        for k, g in zip(keys, got):
+            _eq(L["%s%s_%s" % (prefix, tag, k)], g, (prefix, tag, k))
+
+    if prefix == "fx_":
+        src = L["fx_t_nodes"]
+        for c, (wf, dn) in enumerate((("sqrt", -1), ("sqrt", 261), ("none", -1))):
+            one("lf_%d" % c, 95 + c, src, [0, 1], 10, wf, dn)
+        one("lf_lone", 99, L["fx_lf_lone_nodes"], [0], 4, "sqrt", 261)
+        # the reference's own assertions (neighbor_ops_test.py:159-175)
+        nb = L["fx_lf_0_nb"]
+        assert set(nb[0].tolist()) <= {2, 3, 4, 5} and set(nb[2].tolist()) <= {3, 4, 5}
+        assert set(nb[3].tolist()) <= {3, 5}
+    else:
+        c = 0
+        while "%slf_%d_nodes" % (prefix, c) in L:
+            nodes, et = L["%slf_%d_nodes" % (prefix, c)], L["%slf_%d_et" % (prefix, c)]
+            one("lf_%d" % c, 120 + c, nodes, et, L["%slf_%d_nb" % (prefix, c)].shape[1],
+                "sqrt", -1)
+            c += 1
+        assert c >= 4
+
+
 class OracleBackend:
     def __init__(self, O, G):
         self.O, self.G = O, G
@@ -102,6 +133,22 @@ class GpuBackend:
             self._dev(nodes), et, count, dn, call_id=call)
         return (nb.cpu().numpy(), ind.cpu().numpy(), val.cpu().numpy(),
                 np.asarray(shape, np.int64))
+
+    def sample_neighbor_layerwise_func(self, seed, call, nodes, et, count, wf, dn):
+        """Graph.sample_neighbor_layerwise(weight_func=wf) + the sampled weights and
+        types of its API_LOCAL_SAMPLE_L step."""
+        self.G.set_seed(seed)
+        nd = self._dev(nodes)
+        batch, n = nd.shape
+        nb, (ind, val, shape) = self.G.sample_neighbor_layerwise(nd, et, count, dn, wf,
+                                                                 call_id=call)
+        idx, ids, w, t = self.G.get_full_neighbor(nd.reshape(-1), et)
+        nb2, lw, lt = self.G.local_sample_layer(idx, ids, w, t, batch, n, count, wf, dn,
+                                                call_id=call)
+        assert bool((nb2.reshape(batch, count) == nb).all())
+        return (nb.cpu().numpy(), lw.cpu().numpy().reshape(batch, count),
+                lt.cpu().numpy().reshape(batch, count), ind.cpu().numpy(),
+                val.cpu().numpy(), np.asarray(shape, np.int64))
 
     def sparse_get_adj(self, nodes, nb, batch, n, m, et):
         idx, vals = self.G.sparse_get_adj_core(self._dev(nodes), self._dev(nb), n, m, et)

@@ -32,7 +32,8 @@ def HC():
     so = os.path.join(out_dir, "libhost_check.so")
     src = os.path.join(HERE, "csrc", "host_check.hip")
     deps = [src] + [os.path.join(ROOT, "euler_amd", "csrc", f)
-                    for f in ("layer_fns.h", "device_fns.h", "common.h", "philox.h")]
+                    for f in ("layer_fns.h", "device_fns.h", "common.h", "philox.h",
+                              "local_layer_host.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so)
                                      for d in deps):
         subprocess.check_call(
@@ -49,6 +50,9 @@ def HC():
                                  C.c_int32, C.c_int32, C.c_int64, u64p]
     L.hc_sample_layer.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, u64p, C.c_int64,
                                   i32p, C.c_int32, C.c_int64, u64p, f32p, i32p]
+    L.hc_local_sample_layer.argtypes = [C.c_uint64, C.c_uint32, i32p, u64p, f32p, i32p,
+                                        C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                        C.c_char_p, C.c_int64, u64p, f32p, i32p]
     L.hc_edge_exist_mask.argtypes = [C.c_void_p, u64p, u64p, C.c_int64, C.c_int32,
                                      C.c_int32, i32p, C.c_int32, u8p]
     return L
@@ -123,6 +127,33 @@ class HostBackend:
                               + [np.zeros(0, np.uint64)])
         return idx, vals
 
+    def _sparse(self, nodes, l_nb, batch, n, count, et):
+        mask, _ = self._mask(nodes, l_nb, batch, n, count, et)
+        mask = mask.reshape(batch, n, count)
+        emit = mask.copy()
+        emit[:, n - 1, count - 1] = True
+        return (np.argwhere(emit).astype(np.int64), mask[emit].astype(np.int64),
+                np.array([batch, n, count], np.int64))
+
+    def sample_neighbor_layerwise_func(self, OG, seed, call, nodes, et, count, wf, dn):
+        """sampleLNB with a weight function: the library's host table builder +
+        LocalLayerPick (full neighbours supplied by the oracle)."""
+        nodes = np.asarray(nodes)
+        batch, n = nodes.shape
+        flat = self._u64(nodes)
+        idx, ids, w, t = OG.get_full_neighbor(flat, et)
+        idx = np.ascontiguousarray(idx.reshape(-1), np.int32)
+        oid = np.zeros(batch * count, np.uint64)
+        ow = np.zeros(batch * count, np.float32)
+        ot = np.zeros(batch * count, np.int32)
+        rc = self.L.hc_local_sample_layer(seed, call, _p(idx, i32p), _p(ids, u64p),
+                                          _p(w, f32p), _p(t, i32p), len(ids), batch, n,
+                                          count, wf.encode(), dn, _p(oid, u64p),
+                                          _p(ow, f32p), _p(ot, i32p))
+        assert rc == 0
+        return (oid.view(np.int64).reshape(batch, count), ow.reshape(batch, count),
+                ot.reshape(batch, count)) + self._sparse(nodes, oid, batch, n, count, et)
+
     def sample_neighbor_layerwise(self, seed, call, nodes, et, count, dn):
         nodes = np.asarray(nodes)
         batch, n = nodes.shape
@@ -137,6 +168,18 @@ class HostBackend:
         val = mask[emit].astype(np.int64)
         return (l_nb.view(np.int64).reshape(batch, count), ind, val,
                 np.array([batch, n, count], np.int64))
+
+
+def test_local_sample_layer_host_vs_goldens(HC, O, fixture_csr, random_csr):
+    """sampleLNB with a weight function: the library's host table builder (the
+    real std::unordered_map<std::string, ...>) + LocalLayerPick == the reference
+    harness (accumulated weights, sqrt, iteration order, memset fill)."""
+    from layer_cases import check_layer_func_pack
+    L = np.load(os.path.join(GOLDEN, "layerwise.npz"))
+    for prefix, csr in (("fx_", fixture_csr), ("rg_", random_csr)):
+        H, OG = HostBackend(HC, csr), O.OracleGraph(csr)
+        check_layer_func_pack(
+            lambda *a: H.sample_neighbor_layerwise_func(OG, *a), L, prefix)
 
 
 def test_layer_fns_host_vs_goldens(HC, O, fixture_csr, random_csr):

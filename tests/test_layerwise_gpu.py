@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN, make_random_graph
-from layer_cases import GpuBackend, OracleBackend, check_layer_pack
+from layer_cases import GpuBackend, OracleBackend, check_layer_func_pack, check_layer_pack
 
 pytestmark = pytest.mark.gpu
 
@@ -43,6 +43,16 @@ def test_layerwise_goldens_gpu(EA, O, torch_cuda, fixture_csr, random_csr):
         want = np.array([(s, d, t) in have for s, d in zip(src, dst)])
         assert np.array_equal(got, want), t
     check_layer_pack(GpuBackend(torch_cuda, gpu_graph(EA, random_csr)), L, "rg_", 3)
+
+
+def test_layerwise_weight_func_goldens_gpu(EA, O, torch_cuda, fixture_csr, random_csr):
+    """sampleLNB with a weight function (API_GET_NB_NODE -> API_LOCAL_SAMPLE_L ->
+    adjacency) == the reference harness: candidate order of the op's
+    std::unordered_map, accumulated / sqrt'ed weights, the memset fill."""
+    L = np.load(os.path.join(GOLDEN, "layerwise.npz"))
+    for prefix, csr in (("fx_", fixture_csr), ("rg_", random_csr)):
+        B = GpuBackend(torch_cuda, gpu_graph(EA, csr))
+        check_layer_func_pack(B.sample_neighbor_layerwise_func, L, prefix)
 
 
 @pytest.fixture(scope="module")
@@ -167,8 +177,6 @@ def test_layerwise_empty_and_errors(EA, O, torch_cuda, fixture_csr):
     assert t2n(idx).sum() == 0 and vals.numel() == 0
     nb, (ind, val, shape) = G.sample_neighbor_layerwise(nodes.reshape(1, -1), [0, 1], 0)
     assert nb.shape == (1, 0) and ind.shape[0] == 0
-    with pytest.raises(NotImplementedError):
-        G.sample_neighbor_layerwise(nodes.reshape(1, -1), [0], 4, weight_func="sqrt")
     with pytest.raises(ValueError):
         G.sample_neighbor_layerwise(nodes, [0], 4)
     from euler_amd._lib import EulerGpuError
