@@ -180,7 +180,8 @@ SIGNATURES = {
                                         C.c_int64, i32p, u64p, f32p, i32p]),
     "euler_op_run_sample_lnb": (C.c_int64, [vp, C.c_uint64, C.c_uint32, u64p, C.c_int64,
                                             C.c_int32, i32p, C.c_int32, C.c_int32,
-                                            C.c_int64, C.c_int64, i32p, u64p, u64p]),
+                                            C.c_char_p, C.c_int64, C.c_int64, i32p, u64p,
+                                            u64p]),
     "euler_op_run_sample_nb": (C.c_int64, [vp, C.c_uint64, u64p, C.c_int64, i32p,
                                            C.c_int32, C.c_int32, i32p, u64p, f32p,
                                            i32p]),

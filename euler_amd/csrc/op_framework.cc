@@ -519,6 +519,63 @@ class GpuSampleLayerOp : public OpKernel {
 };
 REGISTER_OP_KERNEL("API_SAMPLE_L", GpuSampleLayerOp);
 
+// API_LOCAL_SAMPLE_L (core/kernels/local_sample_layer_op.cc:43-146): inputs the
+// four API_GET_NB_NODE outputs (idx, ids, weights, types), n, m, weight_func and
+// default_node (literals); outputs ":0" ids, ":1" weights, ":2" types [batch*m, 1].
+class GpuLocalSampleLayerOp : public OpKernel {
+ public:
+  explicit GpuLocalSampleLayerOp(const std::string& name) : OpKernel(name) {}
+  void Compute(const NodeDef& nd, OpKernelContext* ctx) override {
+    Tensor *idx_t = nullptr, *id_t = nullptr, *w_t = nullptr, *t_t = nullptr;
+    std::vector<int32_t> n_v, m_v;
+    if (nd.inputs.size() < 8 || ctx->tensor(nd.inputs[0], &idx_t) != 0 ||
+        ctx->tensor(nd.inputs[1], &id_t) != 0 || ctx->tensor(nd.inputs[2], &w_t) != 0 ||
+        ctx->tensor(nd.inputs[3], &t_t) != 0 || !GetIntArg(nd, 4, ctx, &n_v) ||
+        !GetIntArg(nd, 5, ctx, &m_v) || n_v.empty() || m_v.empty() || n_v[0] <= 0) {
+      LogError("API_LOCAL_SAMPLE_L: bad inputs");
+      return;
+    }
+    const std::string weight_func = nd.inputs[6];
+    const int64_t default_node = atol(nd.inputs[7].c_str());
+    if (weight_func != "sqrt") LogError("weight function: " + weight_func + " not support");
+    const int32_t n = n_v[0], m = m_v[0];
+    const int64_t batch = idx_t->NumElements() / (n * 2);
+    const int64_t total = id_t->NumElements(), draws = batch * m;
+    euler_gpu_graph* g = ctx->graph();
+    if (g) (void)hipSetDevice(euler_gpu_graph_device(g));
+    DevBuf d_idx((size_t)idx_t->NumElements() * 4), d_id(total * 8), d_w(total * 4),
+        d_t(total * 4), o_id(draws * 8), o_w(draws * 4), o_t(draws * 4);
+    if (!d_idx.p || !d_id.p || !d_w.p || !d_t.p || !o_id.p || !o_w.p || !o_t.p) {
+      LogError("API_LOCAL_SAMPLE_L: device allocation failed");
+      return;
+    }
+    (void)hipMemcpy(d_idx.p, idx_t->Raw<int32_t>(), (size_t)idx_t->NumElements() * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_id.p, id_t->Raw<uint64_t>(), total * 8, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_w.p, w_t->Raw<float>(), total * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_t.p, t_t->Raw<int32_t>(), total * 4, hipMemcpyHostToDevice);
+    if (euler_gpu_local_sample_layer(nullptr, ctx->seed(), ctx->NextCallId(),
+                                     d_idx.as<int32_t>(), d_id.as<uint64_t>(), d_w.as<float>(),
+                                     d_t.as<int32_t>(), total, batch, n, m, weight_func.c_str(),
+                                     default_node, o_id.as<uint64_t>(), o_w.as<float>(),
+                                     o_t.as<int32_t>()) != 0) {
+      LogError(std::string("API_LOCAL_SAMPLE_L: ") + euler_gpu_last_error());
+      return;
+    }
+    Tensor *r_id = nullptr, *r_w = nullptr, *r_t = nullptr;
+    if (ctx->Allocate(OutputName(nd, 0), {(size_t)draws, 1}, kUInt64, &r_id) != 0 ||
+        ctx->Allocate(OutputName(nd, 1), {(size_t)draws, 1}, kFloat, &r_w) != 0 ||
+        ctx->Allocate(OutputName(nd, 2), {(size_t)draws, 1}, kInt32, &r_t) != 0) {
+      LogError("Allocate output tensor failed!");
+      return;
+    }
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(r_id->Raw<uint64_t>(), o_id.p, draws * 8, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(r_w->Raw<float>(), o_w.p, draws * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(r_t->Raw<int32_t>(), o_t.p, draws * 4, hipMemcpyDeviceToHost);
+  }
+};
+REGISTER_OP_KERNEL("API_LOCAL_SAMPLE_L", GpuLocalSampleLayerOp);
+
 // API_SPARSE_GEN_ADJ (core/kernels/sparse_gen_adj_op.cc:35-64): host-only
 // reshaping - (root id, batch row) pairs + an alias of l_nb.
 class SparseGenAdjOp : public OpKernel {
@@ -734,7 +791,8 @@ int64_t euler_op_run_get_nb(euler_gpu_graph* g, const uint64_t* node_ids, int64_
 int64_t euler_op_run_sample_lnb(euler_gpu_graph* g, uint64_t seed, uint32_t first_call_id,
                                 const uint64_t* node_ids, int64_t batch, int32_t n,
                                 const int32_t* edge_types, int32_t k, int32_t m,
-                                int64_t default_node, int64_t capacity,
+                                const char* weight_func, int64_t default_node,
+                                int64_t capacity,
                                 int32_t* adj_idx_out, uint64_t* adj_id_out,
                                 uint64_t* l_nb_out) {
   using namespace euler;
@@ -753,18 +811,30 @@ int64_t euler_op_run_sample_lnb(euler_gpu_graph* g, uint64_t seed, uint32_t firs
   *t_n->Raw<int32_t>() = n;
   *t_m->Raw<int32_t>() = m;
   const std::string dn = std::to_string(default_node);
-  const NodeDef dag[] = {
-      {"API_GET_EDGE_SUM_WEIGHT,0", "API_GET_EDGE_SUM_WEIGHT", {"nodes", "edge_types"}, {}},
-      {"API_SAMPLE_ROOT,1", "API_SAMPLE_ROOT",
-       {"API_GET_EDGE_SUM_WEIGHT,0:0", "API_GET_EDGE_SUM_WEIGHT,0:1", "n", "m", dn}, {}},
-      {"API_SAMPLE_L,2", "API_SAMPLE_L", {"API_SAMPLE_ROOT,1:0", "edge_types", dn}, {}},
-      {"API_SPARSE_GEN_ADJ,3", "API_SPARSE_GEN_ADJ",
-       {"API_GET_EDGE_SUM_WEIGHT,0:0", "API_SAMPLE_L,2:0", "n"}, {}},
-      {"API_SPARSE_GET_ADJ,4", "API_SPARSE_GET_ADJ",
-       {"API_SPARSE_GEN_ADJ,3:0", "API_SPARSE_GEN_ADJ,3:1", "edge_types", "m"}, {}},
-      {"API_GATHER_RESULT,5", "API_GATHER_RESULT",
-       {"API_SPARSE_GET_ADJ,4:0", "API_SPARSE_GET_ADJ,4:1", "API_SAMPLE_L,2:0"}, {}},
-  };
+  const std::string wf = weight_func ? weight_func : "";
+  std::vector<NodeDef> dag;
+  std::string roots_name, l_nb_name;
+  if (wf.empty()) {           // Translator::TrivialSampleLayer
+    dag.push_back({"API_GET_EDGE_SUM_WEIGHT,0", "API_GET_EDGE_SUM_WEIGHT", {"nodes", "edge_types"}, {}});
+    dag.push_back({"API_SAMPLE_ROOT,1", "API_SAMPLE_ROOT",
+                   {"API_GET_EDGE_SUM_WEIGHT,0:0", "API_GET_EDGE_SUM_WEIGHT,0:1", "n", "m", dn}, {}});
+    dag.push_back({"API_SAMPLE_L,2", "API_SAMPLE_L", {"API_SAMPLE_ROOT,1:0", "edge_types", dn}, {}});
+    roots_name = "API_GET_EDGE_SUM_WEIGHT,0:0";
+    l_nb_name = "API_SAMPLE_L,2:0";
+  } else {                    // Translator::GeneralSampleLayer (API_RESHAPE of the roots
+                              // is host plumbing: the roots are fed as they are)
+    dag.push_back({"API_GET_NB_NODE,1", "API_GET_NB_NODE", {"nodes", "edge_types"}, {}});
+    dag.push_back({"API_LOCAL_SAMPLE_L,2", "API_LOCAL_SAMPLE_L",
+                   {"API_GET_NB_NODE,1:0", "API_GET_NB_NODE,1:1", "API_GET_NB_NODE,1:2",
+                    "API_GET_NB_NODE,1:3", "n", "m", wf, dn}, {}});
+    roots_name = "nodes";
+    l_nb_name = "API_LOCAL_SAMPLE_L,2:0";
+  }
+  dag.push_back({"API_SPARSE_GEN_ADJ,3", "API_SPARSE_GEN_ADJ", {roots_name, l_nb_name, "n"}, {}});
+  dag.push_back({"API_SPARSE_GET_ADJ,4", "API_SPARSE_GET_ADJ",
+                 {"API_SPARSE_GEN_ADJ,3:0", "API_SPARSE_GEN_ADJ,3:1", "edge_types", "m"}, {}});
+  dag.push_back({"API_GATHER_RESULT,5", "API_GATHER_RESULT",
+                 {"API_SPARSE_GET_ADJ,4:0", "API_SPARSE_GET_ADJ,4:1", l_nb_name}, {}});
   for (const NodeDef& nd : dag) {
     OpKernel* kernel = nullptr;
     if (CreateOpKernel(nd.op, &kernel) != 0) return -1;

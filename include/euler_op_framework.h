@@ -165,13 +165,15 @@ int64_t euler_op_run_get_nb(euler_gpu_graph* g, const uint64_t* node_ids, int64_
                             int32_t* idx_out, uint64_t* id_out, float* w_out,
                             int32_t* t_out);
 // The six-node DAG of `v(nodes).sampleLNB(edge_types, n, m, default_node)`
-// (euler/parser/translator.cc:338-386,489-527) executed node by node through
+// (euler/parser/translator.cc:338-386,489-527; with a non-empty weight_func the
+// API_GET_NB_NODE -> API_LOCAL_SAMPLE_L form, :388-441) executed node by node through
 // the registry: adjacency idx [batch*n, 2], adjacency ids (room for `capacity`),
 // sampled layer [batch*m].  Returns the number of adjacency ids or < 0.
 int64_t euler_op_run_sample_lnb(euler_gpu_graph* g, uint64_t seed, uint32_t first_call_id,
                                 const uint64_t* node_ids, int64_t batch, int32_t n,
                                 const int32_t* edge_types, int32_t k, int32_t m,
-                                int64_t default_node, int64_t capacity,
+                                const char* weight_func, int64_t default_node,
+                                int64_t capacity,
                                 int32_t* adj_idx_out, uint64_t* adj_id_out,
                                 uint64_t* l_nb_out);
 }

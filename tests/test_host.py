@@ -36,7 +36,7 @@ def test_version_and_registry(L):
     assert b"gfx950" in L.euler_gpu_version()
     for op in (b"API_SAMPLE_NB", b"API_SAMPLE_NODE", b"ID_UNIQUE", b"IDX_GATHER",
                b"DATA_GATHER", b"API_GET_NB_NODE", b"API_GET_EDGE_SUM_WEIGHT",
-               b"API_SAMPLE_ROOT", b"API_SAMPLE_L", b"API_SPARSE_GEN_ADJ",
+               b"API_SAMPLE_ROOT", b"API_SAMPLE_L", b"API_LOCAL_SAMPLE_L", b"API_SPARSE_GEN_ADJ",
                b"API_SPARSE_GET_ADJ", b"API_GATHER_RESULT"):
         assert L.euler_op_registered(op) == 1
     assert L.euler_op_registered(b"API_NOT_THERE") == 0

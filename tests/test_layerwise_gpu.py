@@ -294,7 +294,7 @@ def test_layerwise_plugin_dag(EA, O, torch_cuda, lw_pair):
             flat = np.ascontiguousarray(nodes.reshape(-1))
             got = L.euler_op_run_sample_lnb(
                 G._h, 31, 7, flat.ctypes.data_as(_lib.u64p), batch, n,
-                eta.ctypes.data_as(_lib.i32p), len(eta), m, -1, cap,
+                eta.ctypes.data_as(_lib.i32p), len(eta), m, b"", -1, cap,
                 adj_idx.ctypes.data_as(_lib.i32p), adj_id.ctypes.data_as(_lib.u64p),
                 l_nb.ctypes.data_as(_lib.u64p))
             assert got >= 0, got
@@ -305,6 +305,20 @@ def test_layerwise_plugin_dag(EA, O, torch_cuda, lw_pair):
             assert np.array_equal(l_nb, want_nb)
             assert np.array_equal(adj_idx, widx) and got == len(wvals)
             assert np.array_equal(adj_id[:got], wvals)
+            # the weight-function form of the DAG == the direct C-ABI composition
+            got = L.euler_op_run_sample_lnb(
+                G._h, 31, 7, flat.ctypes.data_as(_lib.u64p), batch, n,
+                eta.ctypes.data_as(_lib.i32p), len(eta), m, b"sqrt", -1, cap,
+                adj_idx.ctypes.data_as(_lib.i32p), adj_id.ctypes.data_as(_lib.u64p),
+                l_nb.ctypes.data_as(_lib.u64p))
+            assert got >= 0, got
+            G.set_seed(31)
+            import torch
+            nb, _adj = G.sample_neighbor_layerwise(
+                torch.as_tensor(nodes.view(np.int64)).cuda(), et, m, -1, "sqrt", call_id=7)
+            assert np.array_equal(l_nb.view(np.int64), t2n(nb).reshape(-1))
+            widx, wvals = OG.sparse_get_adj(flat, l_nb, batch, n, m, et)
+            assert np.array_equal(adj_idx, widx) and np.array_equal(adj_id[:got], wvals)
 
 
 def test_node_type_and_sample_node_with_src(EA, O, torch_cuda, random_csr):
