@@ -103,6 +103,16 @@ __device__ __forceinline__ void LoadWeightGroup(const float* nw, int32_t p0, int
   }
 }
 
+__device__ __forceinline__ float ChainGroup(float sum, const int (&di)[kSumGroup], int32_t p0,
+                                            int32_t e, int lane) {
+#pragma unroll
+  for (int u = 0; u < kSumGroup; ++u) {
+    const int32_t cnt = e - (p0 + 64 * u);
+    if (cnt > 0) sum = ChunkChain(sum, __int_as_float(di[u]), lane, cnt < 64 ? cnt : 64);
+  }
+  return sum;
+}
+
 __device__ __forceinline__ float WaveRowSum(const GraphView& g, const TypeList& tl,
                                             int64_t row, int lane) {
   const RowMeta m = LoadRowMeta(g, row);
@@ -114,17 +124,15 @@ __device__ __forceinline__ float WaveRowSum(const GraphView& g, const TypeList& 
     const int32_t b = t == 0 ? 0 : m.type_end[t - 1];
     const int32_t e = m.type_end[t];
     if (b >= e) continue;
-    int cur[kSumGroup], nxt[kSumGroup];
-    LoadWeightGroup(nw, b, e, lane, cur);
-    for (int32_t p0 = b; p0 < e; p0 += 64 * kSumGroup) {
-      LoadWeightGroup(nw, p0 + 64 * kSumGroup, e, lane, nxt);   // all zero past the end
-#pragma unroll
-      for (int u = 0; u < kSumGroup; ++u) {
-        const int32_t cnt = e - (p0 + 64 * u);
-        if (cnt > 0) sum = ChunkChain(sum, __int_as_float(cur[u]), lane, cnt < 64 ? cnt : 64);
-      }
-#pragma unroll
-      for (int u = 0; u < kSumGroup; ++u) cur[u] = nxt[u];
+    // two register groups alternate (no copies between them, so the loads of one
+    // stay in flight while the chain of the other runs)
+    int ga[kSumGroup], gb[kSumGroup];
+    LoadWeightGroup(nw, b, e, lane, ga);
+    for (int32_t p0 = b; p0 < e; p0 += 2 * 64 * kSumGroup) {
+      LoadWeightGroup(nw, p0 + 64 * kSumGroup, e, lane, gb);     // all zero past the end
+      sum = ChainGroup(sum, ga, p0, e, lane);
+      LoadWeightGroup(nw, p0 + 2 * 64 * kSumGroup, e, lane, ga);
+      sum = ChainGroup(sum, gb, p0 + 64 * kSumGroup, e, lane);
     }
   }
   return sum;
@@ -260,8 +268,19 @@ __global__ __launch_bounds__(256) void SampleLayerKernel(
 // metric graph went from 77 ms (one wave per source comparing every candidate
 // with the whole row, AdjScanMaskKernel, kept selectable: tuning key 16) to
 // the time of streaming the rows once.
-constexpr int kAdjChunk = 2048;          // candidates per table build
+constexpr int kAdjChunk = 2048;          // candidates per table build (11 index bits)
 constexpr uint32_t kAdjEmpty = 0xFFFFFFFFu;
+// A table slot = (21-bit tag of the key's hash << 11) | candidate index: a probe
+// compares tags with ONE LDS read and touches the 8-byte key only on a tag match
+// (v1 read slot -> key for every probe, two dependent LDS round trips).  The
+// table has 4 slots per candidate: the lanes of a wave probe in lockstep, so a
+// step costs the LONGEST probe chain among 64 lanes - at half load that was ~10
+// slots per step and a hub row went at 64 edges per 2 us.
+constexpr int kAdjIdxBits = 11;
+__device__ __forceinline__ uint32_t AdjTag(uint64_t h) {
+  const uint32_t tag = (uint32_t)(h >> 43);            // 21 bits
+  return tag == 0x1FFFFFu ? 0u : tag;                   // never the empty pattern
+}
 
 struct AdjArgs {
   GraphView g;
@@ -274,7 +293,7 @@ struct AdjArgs {
   int32_t words;            // ceil(m / 64)
   int32_t roots_per_wg;     // sources of one workgroup (its 4 waves take every 4th)
   int32_t wgs_per_row;      // workgroups per batch row
-  int32_t cap;              // hash slots (power of two >= 2 * min(m, kAdjChunk))
+  int32_t cap;              // hash slots (power of two >= 4 * min(m, kAdjChunk))
 };
 
 constexpr int kAdjGroup = 8;
@@ -285,6 +304,39 @@ __device__ __forceinline__ void LoadNbrGroup(const uint64_t* nbr, int32_t p0, in
   for (int u = 0; u < kAdjGroup; ++u) {
     const int32_t p = p0 + 64 * u + lane;
     d[u] = p < ee ? nbr[p] : 0;
+  }
+}
+
+// index of the candidate with this key, or -1
+__device__ __forceinline__ int AdjFind(uint64_t key, const uint32_t* table,
+                                       const uint64_t* cand, uint32_t cmask, int cap) {
+  const uint64_t h = Mix64(key);
+  const uint32_t tag = AdjTag(h);
+  uint32_t slot = (uint32_t)h & cmask;
+  for (int probes = 0; probes < cap; ++probes) {
+    const uint32_t e = table[slot];
+    if (e == kAdjEmpty) return -1;
+    if ((e >> kAdjIdxBits) == tag && cand[e & (kAdjChunk - 1)] == key)
+      return (int)(e & (kAdjChunk - 1));
+    slot = (slot + 1u) & cmask;
+  }
+  return -1;
+}
+
+__device__ __forceinline__ void AdjProbeGroup(const uint64_t (&d)[kAdjGroup], int32_t p0,
+                                              int32_t ee, int lane, const uint32_t* table,
+                                              const uint64_t* cand, uint32_t cmask, int cap,
+                                              uint32_t* my_bits) {
+#pragma unroll
+  for (int u = 0; u < kAdjGroup; ++u) {
+    if (p0 + 64 * u + lane >= ee) continue;
+    const int jv = AdjFind(d[u], table, cand, cmask, cap);
+    if (jv >= 0) {
+      // a hub among the candidates is hit by most lanes of most steps: only the
+      // first hit pays for the (same-address, serialised) LDS atomic
+      const uint32_t bit = 1u << (jv & 31);
+      if (!(my_bits[jv >> 5] & bit)) atomicOr(&my_bits[jv >> 5], bit);
+    }
   }
 }
 
@@ -317,10 +369,14 @@ __global__ __launch_bounds__(256) void AdjHashMaskKernel(const AdjArgs a) {
       __syncthreads();
       for (int j = tid; j < mc; j += 256) {
         const uint64_t key = cand[j];
-        uint32_t slot = (uint32_t)Mix64(key) & cmask;
+        const uint64_t h = Mix64(key);
+        const uint32_t tag = AdjTag(h);
+        const uint32_t entry = (tag << kAdjIdxBits) | (uint32_t)j;
+        uint32_t slot = (uint32_t)h & cmask;
         for (int probes = 0; probes < a.cap; ++probes) {
-          const uint32_t prev = atomicCAS(&table[slot], kAdjEmpty, (uint32_t)j);
-          if (prev == kAdjEmpty || cand[prev] == key) break;   // inserted / duplicate
+          const uint32_t prev = atomicCAS(&table[slot], kAdjEmpty, entry);
+          if (prev == kAdjEmpty) break;                                    // inserted
+          if ((prev >> kAdjIdxBits) == tag && cand[prev & (kAdjChunk - 1)] == key) break;  // duplicate
           slot = (slot + 1u) & cmask;
         }
       }
@@ -342,33 +398,17 @@ __global__ __launch_bounds__(256) void AdjHashMaskKernel(const AdjArgs a) {
               if (t < 0 || t >= a.g.T) continue;
               const int32_t eb = t == 0 ? 0 : rm.type_end[t - 1];
               const int32_t ee = rm.type_end[t];
-              // the NEXT 8 x 64 neighbour ids are fetched while the current ones
-              // probe the table (a long row was paying an HBM round trip per group)
+              // two register groups of 8 x 64 neighbour ids alternate: one loads
+              // while the other probes the table
               if (eb >= ee) continue;
-              uint64_t cur[kAdjGroup], nxt[kAdjGroup];
-              LoadNbrGroup(nbr, eb, ee, lane, cur);
-              for (int32_t p0 = eb; p0 < ee; p0 += 64 * kAdjGroup) {
-                LoadNbrGroup(nbr, p0 + 64 * kAdjGroup, ee, lane, nxt);
-#pragma unroll
-                for (int u = 0; u < kAdjGroup; ++u) {
-                  if (p0 + 64 * u + lane >= ee) continue;
-                  uint32_t slot = (uint32_t)Mix64(cur[u]) & cmask;
-                  for (int probes = 0; probes < a.cap; ++probes) {
-                    const uint32_t jv = table[slot];
-                    if (jv == kAdjEmpty) break;
-                    if (cand[jv] == cur[u]) {
-                      // a hub among the candidates is hit by most lanes of most
-                      // steps: only the first hit pays for the (same-address,
-                      // serialised) LDS atomic
-                      const uint32_t bit = 1u << (jv & 31);
-                      if (!(my_bits[jv >> 5] & bit)) atomicOr(&my_bits[jv >> 5], bit);
-                      break;
-                    }
-                    slot = (slot + 1u) & cmask;
-                  }
-                }
-#pragma unroll
-                for (int u = 0; u < kAdjGroup; ++u) cur[u] = nxt[u];
+              uint64_t ga[kAdjGroup], gb[kAdjGroup];
+              LoadNbrGroup(nbr, eb, ee, lane, ga);
+              for (int32_t p0 = eb; p0 < ee; p0 += 2 * 64 * kAdjGroup) {
+                LoadNbrGroup(nbr, p0 + 64 * kAdjGroup, ee, lane, gb);
+                AdjProbeGroup(ga, p0, ee, lane, table, cand, cmask, a.cap, my_bits);
+                LoadNbrGroup(nbr, p0 + 2 * 64 * kAdjGroup, ee, lane, ga);
+                AdjProbeGroup(gb, p0 + 64 * kAdjGroup, ee, lane, table, cand, cmask, a.cap,
+                              my_bits);
               }
             }
           }
@@ -380,14 +420,8 @@ __global__ __launch_bounds__(256) void AdjHashMaskKernel(const AdjArgs a) {
             const int j = j0 + lane;
             bool hit = false;
             if (j < mc) {
-              const uint64_t key = cand[j];
-              uint32_t slot = (uint32_t)Mix64(key) & cmask;
-              for (int probes = 0; probes < a.cap; ++probes) {
-                const uint32_t jv = table[slot];
-                if (jv == kAdjEmpty) break;            // cannot happen: j was inserted
-                if (cand[jv] == key) { hit = (my_bits[jv >> 5] >> (jv & 31)) & 1u; break; }
-                slot = (slot + 1u) & cmask;
-              }
+              const int jv = AdjFind(cand[j], table, cand, cmask, a.cap);   // >= 0: j was inserted
+              if (jv >= 0) hit = (my_bits[jv >> 5] >> (jv & 31)) & 1u;
             }
             const uint64_t word = __ballot(hit);
             if (lane == 0) out[j0 >> 6] = word;
@@ -589,7 +623,7 @@ int BuildAdjMask(const euler_gpu_graph* g, hipStream_t st, AdjArgs a, int32_t tf
     } else {
       const int32_t mc = a.m < kAdjChunk ? a.m : kAdjChunk;
       int32_t cap = 64;
-      while (cap < 2 * mc) cap <<= 1;
+      while (cap < 4 * mc) cap <<= 1;
       a.cap = cap;
       // ~4096 workgroups over the whole query, >= 4 sources (one per wave) each
       const int64_t want = std::max<int64_t>(1, 4096 / std::max<int64_t>(a.batch, 1));
