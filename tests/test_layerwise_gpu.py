@@ -418,3 +418,45 @@ def test_sparse_feature_vs_goldens_and_loader(EA, O, torch_cuda, fixture_csr, ra
     base.set_default_graph(graphs[0])
     got = ops.get_sparse_feature(q, ["0", 1])
     assert np.array_equal(t2n(got[0][1]), sg["rg_sp_0_val"])
+
+
+def test_cpp_host_example(EA, O, torch_cuda, fixture_csr):
+    """examples/cpp/sage_minibatch: a C++ host driving the C ABI with nothing but
+    the HIP runtime (InitQueryProxy -> SampleNode -> SampleFanout ->
+    GetDenseFeature -> MPScatterAdd) prints the same bits as the Python surface,
+    and the sampled block matches the oracle."""
+    import subprocess
+    from conftest import ROOT
+    torch = torch_cuda
+    exe = os.path.join(ROOT, "examples", "cpp", "sage_minibatch")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(exe)])
+    dat = os.path.join(GOLDEN, "fixture_dat")
+    seed, batch, c1, c2, fid, dim = 42, 8, 3, 2, 0, 2
+    out = subprocess.run([exe, dat, str(seed), str(batch), str(c1), str(c2), str(fid), str(dim)],
+                         check=True, capture_output=True, text=True, timeout=120).stdout
+    got = {}
+    for line in out.strip().splitlines():
+        name, *vals = line.split()
+        got[name] = vals
+    ids = lambda k: np.array([int(v) for v in got[k]], np.uint64)
+    bits = lambda k: np.array([int(v, 16) for v in got[k]], np.uint32)
+    G = EA.Graph.load(dat)
+    G.set_seed(seed)
+    roots = G.sample_node(batch, -1, call_id=0)
+    nb, w, t = G.sample_fanout(roots, [[0, 1], [0, 1]], [c1, c2], -1, call_id=1)
+    feat = G.get_dense_feature(nb[2], [fid], [dim])[0]
+    parent = torch.arange(batch * c1, device="cuda", dtype=torch.int32).repeat_interleave(c2)
+    agg = EA.ops.scatter_add(feat, parent, batch * c1)
+    assert np.array_equal(ids("roots"), t2n(roots).view(np.uint64))
+    assert np.array_equal(ids("hop1"), t2n(nb[1]).view(np.uint64))
+    assert np.array_equal(ids("hop2"), t2n(nb[2]).view(np.uint64))
+    assert np.array_equal(bits("w2"), t2n(w[1]).reshape(-1).view(np.uint32))
+    assert np.array_equal(bits("agg"), t2n(agg).reshape(-1).view(np.uint32))
+    # ... and against the oracle, given the roots
+    OG = O.OracleGraph(fixture_csr)
+    on, ow, ot = OG.sample_fanout(seed, 1, ids("roots").view(np.int64), [[0, 1], [0, 1]],
+                                  [c1, c2], -1)
+    assert np.array_equal(ids("hop1").view(np.int64), on[0].reshape(-1))
+    assert np.array_equal(ids("hop2").view(np.int64), on[1].reshape(-1))
+    assert np.array_equal(bits("w2"), ow[1].reshape(-1).view(np.uint32))
