@@ -44,6 +44,9 @@ static bool RootTablesOnHost(int64_t batch, int32_t n) {
 }
 // key 16: SparseGetAdj mask by the direct scan (1) instead of the LDS hash (0).
 int g_adj_scan = 0;
+// key 17: SparseGetAdj: sources with more listed edges than this are split over
+// workgroups by AdjLongRowsKernel (tests lower it to reach that path on small graphs).
+int g_adj_long_row = 16384;
 
 int ExclusiveScanI64(hipStream_t stream, const int64_t* in, int64_t* out,
                      int64_t n);   // mp_kernels.hip
@@ -294,6 +297,9 @@ struct AdjArgs {
   int32_t roots_per_wg;     // sources of one workgroup (its 4 waves take every 4th)
   int32_t wgs_per_row;      // workgroups per batch row
   int32_t cap;              // hash slots (power of two >= 4 * min(m, kAdjChunk))
+  int32_t long_row;         // rows with more listed edges go to AdjLongRowsKernel
+  int64_t* long_src;        // [batch * n] queue of such sources (index b * n + slot)
+  unsigned long long* n_long;
 };
 
 constexpr int kAdjGroup = 8;
@@ -346,6 +352,40 @@ __device__ __forceinline__ void AdjWaveSync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// All 256 threads: the candidates [c0, c0 + mc) of batch row b into the LDS table.
+__device__ __forceinline__ void AdjBuildTable(const AdjArgs& a, int64_t b, int32_t c0, int mc,
+                                              int tid, uint64_t* cand, uint32_t* table,
+                                              uint32_t cmask) {
+  __syncthreads();                       // everybody is done with the previous table
+  for (int i = tid; i < a.cap; i += 256) table[i] = kAdjEmpty;
+  for (int j = tid; j < mc; j += 256) cand[j] = a.l_nb[b * a.m + c0 + j];
+  __syncthreads();
+  for (int j = tid; j < mc; j += 256) {
+    const uint64_t key = cand[j];
+    const uint64_t h = Mix64(key);
+    const uint32_t tag = AdjTag(h);
+    const uint32_t entry = (tag << kAdjIdxBits) | (uint32_t)j;
+    uint32_t slot = (uint32_t)h & cmask;
+    for (int probes = 0; probes < a.cap; ++probes) {
+      const uint32_t prev = atomicCAS(&table[slot], kAdjEmpty, entry);
+      if (prev == kAdjEmpty) break;                                    // inserted
+      if ((prev >> kAdjIdxBits) == tag && cand[prev & (kAdjChunk - 1)] == key) break;  // duplicate
+      slot = (slot + 1u) & cmask;
+    }
+  }
+  __syncthreads();
+}
+
+// Listed edges of a row (what a source streams): sum over the valid listed types.
+__device__ __forceinline__ int64_t AdjListedDegree(const AdjArgs& a, const RowMeta& rm) {
+  int64_t d = 0;
+  for (int32_t x = 0; x < a.tl.k; ++x) {
+    const int32_t t = a.tl.et[x];
+    if (t >= 0 && t < a.g.T) d += rm.type_end[t] - (t == 0 ? 0 : rm.type_end[t - 1]);
+  }
+  return d;
+}
+
 __global__ __launch_bounds__(256) void AdjHashMaskKernel(const AdjArgs a) {
   extern __shared__ uint64_t adj_lds[];
   const int mc_max = a.m < kAdjChunk ? a.m : kAdjChunk;
@@ -363,24 +403,7 @@ __global__ __launch_bounds__(256) void AdjHashMaskKernel(const AdjArgs a) {
     const int32_t r_end = min(a.n, r_begin + a.roots_per_wg);
     for (int32_t c0 = 0; c0 < a.m; c0 += kAdjChunk) {
       const int mc = min(kAdjChunk, a.m - c0);
-      __syncthreads();                       // previous chunk / group done with the LDS
-      for (int i = tid; i < a.cap; i += 256) table[i] = kAdjEmpty;
-      for (int j = tid; j < mc; j += 256) cand[j] = a.l_nb[b * a.m + c0 + j];
-      __syncthreads();
-      for (int j = tid; j < mc; j += 256) {
-        const uint64_t key = cand[j];
-        const uint64_t h = Mix64(key);
-        const uint32_t tag = AdjTag(h);
-        const uint32_t entry = (tag << kAdjIdxBits) | (uint32_t)j;
-        uint32_t slot = (uint32_t)h & cmask;
-        for (int probes = 0; probes < a.cap; ++probes) {
-          const uint32_t prev = atomicCAS(&table[slot], kAdjEmpty, entry);
-          if (prev == kAdjEmpty) break;                                    // inserted
-          if ((prev >> kAdjIdxBits) == tag && cand[prev & (kAdjChunk - 1)] == key) break;  // duplicate
-          slot = (slot + 1u) & cmask;
-        }
-      }
-      __syncthreads();
+      AdjBuildTable(a, b, c0, mc, tid, cand, table, cmask);
       // The waves walk their sources independently (a hub row delays only its own
       // wave): the bitmap is private to the wave, whose LDS operations execute in
       // program order, so a wave-scope fence (no reordering by the compiler) is
@@ -390,7 +413,17 @@ __global__ __launch_bounds__(256) void AdjHashMaskKernel(const AdjArgs a) {
         AdjWaveSync();
         {
           const int64_t row = FindRow(a.g, a.roots[b * a.n + slot_r]);
-          if (row >= 0) {
+          bool here = row >= 0;
+          if (here) {
+            const RowMeta rm0 = LoadRowMeta(a.g, row);
+            if (AdjListedDegree(a, rm0) > a.long_row) {
+              // a hub: queued once (first candidate pass) for AdjLongRowsKernel, which
+              // splits the row over many workgroups; its mask words stay zero here
+              here = false;
+              if (c0 == 0 && lane == 0) a.long_src[atomicAdd(a.n_long, 1ull)] = b * a.n + slot_r;
+            }
+          }
+          if (here) {
             const RowMeta rm = LoadRowMeta(a.g, row);
             const uint64_t* nbr = a.g.nbr + rm.row_ptr;
             for (int32_t x = 0; x < a.tl.k; ++x) {
@@ -430,6 +463,76 @@ __global__ __launch_bounds__(256) void AdjHashMaskKernel(const AdjArgs a) {
         AdjWaveSync();
       }
     }
+  }
+}
+
+// Hub rows.  One wave streams 64 edges per ~0.8 us through the table, so the
+// 545 K-edge row of the metric graph alone took 7 ms per candidate pass.  The
+// sources the main kernel queued are cut into segments of kAdjSegment listed
+// edges; a workgroup takes one (source, segment) unit at a time, its four waves
+// share the segment and ONE LDS bitmap, and the hits leave through 64-bit
+// atomicOr on the (zeroed) mask words - few, because adjacency is sparse.
+constexpr int kAdjSegment = 8192;
+
+__global__ __launch_bounds__(256) void AdjLongRowsKernel(const AdjArgs a) {
+  extern __shared__ uint64_t adj_lds[];
+  const int mc_max = a.m < kAdjChunk ? a.m : kAdjChunk;
+  uint64_t* cand = adj_lds;
+  uint32_t* table = reinterpret_cast<uint32_t*>(cand + mc_max);
+  uint32_t* bits = table + a.cap;                                  // [bw] shared by the 4 waves
+  const int bw = (mc_max + 31) >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t cmask = (uint32_t)a.cap - 1u;
+  const int64_t n_long = (int64_t)*a.n_long;
+  // units are numbered source by source; every thread walks the queue the same way
+  int64_t unit0 = 0;            // first unit of queue entry q
+  for (int64_t q = 0; q < n_long; ++q) {
+    const int64_t r = a.long_src[q];
+    const int64_t b = r / a.n;
+    const int64_t row = FindRow(a.g, a.roots[r]);
+    const RowMeta rm = LoadRowMeta(a.g, row);
+    const int64_t D = AdjListedDegree(a, rm);
+    const int64_t nseg = (D + kAdjSegment - 1) / kAdjSegment;
+    // this workgroup's units inside [unit0, unit0 + nseg)
+    int64_t u = unit0 + ((int64_t)blockIdx.x - unit0 % gridDim.x + gridDim.x) % gridDim.x;
+    for (; u < unit0 + nseg; u += gridDim.x) {
+      const int64_t s_begin = (u - unit0) * kAdjSegment;
+      const int64_t s_end = min(D, s_begin + (int64_t)kAdjSegment);
+      for (int32_t c0 = 0; c0 < a.m; c0 += kAdjChunk) {
+        const int mc = min(kAdjChunk, a.m - c0);
+        AdjBuildTable(a, b, c0, mc, tid, cand, table, cmask);
+        for (int i = tid; i < bw; i += 256) bits[i] = 0u;
+        __syncthreads();
+        // the segment's positions in the concatenation of the listed ranges
+        const uint64_t* nbr = a.g.nbr + rm.row_ptr;
+        int64_t base = 0;
+        for (int32_t x = 0; x < a.tl.k; ++x) {
+          const int32_t t = a.tl.et[x];
+          if (t < 0 || t >= a.g.T) continue;
+          const int32_t eb = t == 0 ? 0 : rm.type_end[t - 1];
+          const int32_t ee = rm.type_end[t];
+          const int64_t lo = max(s_begin, base), hi = min(s_end, base + (ee - eb));
+          base += ee - eb;
+          if (lo >= hi) continue;
+          const int32_t pb = eb + (int32_t)(lo - (base - (ee - eb)));
+          const int32_t pe = eb + (int32_t)(hi - (base - (ee - eb)));
+          // wave w takes the groups w, w + 4, ... of [pb, pe)
+          for (int32_t p0 = pb + wave * 64 * kAdjGroup; p0 < pe; p0 += 4 * 64 * kAdjGroup) {
+            uint64_t gr[kAdjGroup];
+            LoadNbrGroup(nbr, p0, pe, lane, gr);
+            AdjProbeGroup(gr, p0, pe, lane, table, cand, cmask, a.cap, bits);
+          }
+        }
+        __syncthreads();
+        uint64_t* out = a.mask + r * (int64_t)a.words + (c0 >> 6);
+        for (int j = tid; j < mc; j += 256) {
+          const int jv = AdjFind(cand[j], table, cand, cmask, a.cap);
+          if (jv >= 0 && ((bits[jv >> 5] >> (jv & 31)) & 1u))
+            atomicOr(reinterpret_cast<unsigned long long*>(out + (j >> 6)), 1ull << (j & 63));
+        }
+      }
+    }
+    unit0 += nseg;
   }
 }
 
@@ -633,8 +736,19 @@ int BuildAdjMask(const euler_gpu_graph* g, hipStream_t st, AdjArgs a, int32_t tf
       a.wgs_per_row = (a.n + rpw - 1) / rpw;
       const int64_t wgs = a.batch * (int64_t)a.wgs_per_row;
       const size_t lds = (size_t)mc * 8 + (size_t)cap * 4 + (size_t)4 * ((mc + 31) / 32) * 4;
+      // queue of the hub sources: [R] indices + a counter
+      uint8_t* q = nullptr;
+      EG_HIP(hipMallocAsync((void**)&q, (size_t)R * 8 + 8, st));
+      a.long_src = reinterpret_cast<int64_t*>(q);
+      a.n_long = reinterpret_cast<unsigned long long*>(q + (size_t)R * 8);
+      a.long_row = g_adj_long_row;
+      hipError_t e0 = hipMemsetAsync(a.n_long, 0, 8, st);
       hipLaunchKernelGGL(AdjHashMaskKernel, dim3((unsigned)std::min<int64_t>(wgs, 1 << 16)),
                          dim3(block), lds, st, a);
+      hipLaunchKernelGGL(AdjLongRowsKernel, dim3(2048), dim3(block), lds, st, a);
+      hipError_t e1 = hipGetLastError();
+      hipError_t e2 = hipFreeAsync(q, st);
+      EG_HIP(e0); EG_HIP(e1); EG_HIP(e2);
     }
     EG_HIP(hipGetLastError());
   }

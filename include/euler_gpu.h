@@ -619,6 +619,8 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  *        long rows go to the host); the draws always run on the device.
  * key 16: SparseGetAdj: 0 = candidates in an LDS hash table, sources stream
  *        their rows once [default]; 1 = every candidate compared with the row.
+ * key 17: SparseGetAdj: sources with more listed edges than this (default
+ *        16384) are cut into segments handled by separate workgroups.
  * All settings produce identical results; the knobs exist for A/B measurements
  * and tests. */
 int euler_gpu_set_tuning(int32_t key, int32_t value);

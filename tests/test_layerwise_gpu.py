@@ -110,16 +110,21 @@ def _sample_root_cases(EA, O, torch_cuda, lw_pair):
                                   OB.sample_root(11, call, roots, w, n, m, dn)), (n, m)
 
 
-@pytest.mark.parametrize("adj_scan", [0, 1], ids=["adj_hash", "adj_scan"])
-def test_sparse_get_adj_and_layerwise_vs_oracle(EA, O, torch_cuda, lw_pair, adj_scan):
-    """Both mask builders (LDS hash table of the candidates / direct scan,
-    tuning key 16), incl. more candidates than one table chunk holds."""
+@pytest.mark.parametrize("adj_scan,long_row", [(0, 16384), (0, 20), (1, 16384)],
+                         ids=["adj_hash", "adj_hash_split", "adj_scan"])
+def test_sparse_get_adj_and_layerwise_vs_oracle(EA, O, torch_cuda, lw_pair, adj_scan,
+                                                long_row):
+    """The mask builders: LDS hash table of the candidates (rows streamed by one
+    wave / rows above tuning key 17 split over workgroups) and the direct scan
+    (key 16), incl. more candidates than one table chunk holds."""
     from euler_amd import _lib
     _lib.lib().euler_gpu_set_tuning(16, adj_scan)
+    _lib.lib().euler_gpu_set_tuning(17, long_row)
     try:
         _adj_cases(EA, O, torch_cuda, lw_pair)
     finally:
         _lib.lib().euler_gpu_set_tuning(16, 0)
+        _lib.lib().euler_gpu_set_tuning(17, 16384)
 
 
 def _adj_cases(EA, O, torch_cuda, lw_pair):
@@ -359,7 +364,7 @@ def test_long_rows(EA, O, torch_cuda):
     torch = torch_cuda
     rng = np.random.default_rng(99)
     degs = [0, 1, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 320, 511, 512,
-            513, 1000, 3000]
+            513, 1000, 3000, 8191, 8193, 20000]
     n, T = 64, 2
     ids = np.arange(10, 10 + n, dtype=np.uint64) * 7
     deg = np.zeros((n, T), np.int64)
@@ -376,12 +381,19 @@ def test_long_rows(EA, O, torch_cuda):
     G, OG = gpu_graph(EA, csr), O.OracleGraph(csr)
     B, OB = GpuBackend(torch, G), OracleBackend(O, OG)
     q = np.concatenate([ids, ids[::-1], [5]]).astype(np.uint64)
+    from euler_amd import _lib
     for et in ([0], [1], [0, 1], [1, 0], [1, 1]):
         a, b = B.get_edge_sum_weight(q, et), OB.get_edge_sum_weight(q, et)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), et
-        x = B.sparse_get_adj(ids, ids, 1, n, n, et)
         y = OB.sparse_get_adj(ids, ids, 1, n, n, et)
-        assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]), et
+        # rows of one wave / rows split into segments of 8192 edges over workgroups
+        for long_row in (16384, 1000, 50):
+            _lib.lib().euler_gpu_set_tuning(17, long_row)
+            try:
+                x = B.sparse_get_adj(ids, ids, 1, n, n, et)
+            finally:
+                _lib.lib().euler_gpu_set_tuning(17, 16384)
+            assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]), (et, long_row)
 
 
 def test_sparse_feature_vs_goldens_and_loader(EA, O, torch_cuda, fixture_csr, random_csr):
