@@ -47,6 +47,10 @@ int g_adj_scan = 0;
 // key 17: SparseGetAdj: sources with more listed edges than this are split over
 // workgroups by AdjLongRowsKernel (tests lower it to reach that path on small graphs).
 int g_adj_long_row = 16384;
+// key 18: long-row weight sums: 0 = 64 lanes load, lane-shifting DPP chain [default];
+// 1 = scalar loads + a wave-uniform add chain (measured 2x slower: 11.9 vs 5.6 ms on
+// the 4096 heaviest rows - the s_loads are not overlapped with the chain).
+int g_sum_scalar = 0;
 
 int ExclusiveScanI64(hipStream_t stream, const int64_t* in, int64_t* out,
                      int64_t n);   // mp_kernels.hip
@@ -72,20 +76,31 @@ constexpr int kLongRow = 128;
 // carry + d[0] + d[1] + ... + d[cnt-1] in exactly that order, d[k] held by lane
 // k.  Lane k's running sum is lane k-1's plus d[k]; instead of broadcasting one
 // lane per step (v_readlane -> SGPR -> v_add: the SGPR hazard made it ~29
-// clocks per edge) every lane repeats  s = shift_right_by_one_lane(s) + d  64
-// times as ONE v_add_f32 with a DPP wave_shr:1 operand: after step t lane t is
-// final, and re-evaluating a final lane reproduces the same bits, so nothing
-// needs masking.  Lane 0 takes the carry through d (carry + d[0] is the
-// reference's first addition; the sums start at +0 and can never be -0, so the
-// later `0 + x` of lane 0 is exact).
+// clocks per edge) every lane repeats  s = shift_right_by_one_lane(s) + d  as
+// ONE v_add_f32 with a DPP operand: after step t lane t is final, and
+// re-evaluating a final lane reproduces the same bits, so nothing needs masking.
+// The shift is row_shr:1 (inside the 16-lane DPP rows, a full-rate operand; the
+// whole-wave wave_shr:1 measured ~24 clocks per step): the four rows take turns,
+// 16 steps each, and between turns the next row's first lane takes the previous
+// row's total through d (v_readlane).  A row's first lane shifts in 0, and its d
+// carries the incoming sum: carry + d[0] is the reference's own addition, and
+// since the sums start at +0 and can never be -0 the later `0 + x` is exact.
 __device__ __forceinline__ float ChunkChain(float carry, float d, int lane, int cnt) {
-  const float dp = lane == 0 ? __fadd_rn(carry, d) : d;
+  float dp = lane == 0 ? __fadd_rn(carry, d) : d;
   float s = dp;
 #pragma unroll
-  for (int t = 1; t < 64; ++t)
-    s = __fadd_rn(__int_as_float(__builtin_amdgcn_update_dpp(
-                      0, __float_as_int(s), 0x138 /* wave_shr:1 */, 0xf, 0xf, true)),
-                  dp);
+  for (int row = 0; row < 4; ++row) {
+    if (row > 0) {
+      const float prev = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 16 * row - 1));
+      if (lane == 16 * row) dp = __fadd_rn(prev, d);
+      s = dp;           // first lane of the row: its final value; the others are redone below
+    }
+#pragma unroll
+    for (int t = 1; t < 16; ++t)
+      s = __fadd_rn(__int_as_float(__builtin_amdgcn_update_dpp(
+                        0, __float_as_int(s), 0x111 /* row_shr:1 */, 0xf, 0xf, true)),
+                    dp);
+  }
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), cnt - 1));
 }
 
@@ -112,6 +127,42 @@ __device__ __forceinline__ float ChainGroup(float sum, const int (&di)[kSumGroup
   for (int u = 0; u < kSumGroup; ++u) {
     const int32_t cnt = e - (p0 + 64 * u);
     if (cnt > 0) sum = ChunkChain(sum, __int_as_float(di[u]), lane, cnt < 64 ? cnt : 64);
+  }
+  return sum;
+}
+
+// Variant of the long-row sum with no cross-lane traffic at all (tuning key 18 = 1;
+// measured slower than the DPP chain, kept for A/B):
+// the row index is wave-uniform, so the weights can come through SCALAR loads
+// (16 floats per s_load) and every lane runs the same v_sub / v_add chain over
+// SGPR operands.
+__device__ __forceinline__ float UniformRowSum(const GraphView& g, const TypeList& tl,
+                                               int64_t row) {
+  const RowMeta m = LoadRowMeta(g, row);
+  const float* nw = g.prefix_w + m.row_ptr;
+  float sum = 0.f;
+  for (int32_t x = 0; x < tl.k; ++x) {
+    const int32_t t = tl.et[x];
+    if (t < 0 || t >= g.T) continue;
+    int32_t p = t == 0 ? 0 : m.type_end[t - 1];
+    const int32_t e = m.type_end[t];
+    if (p >= e) continue;
+    float prev = p == 0 ? 0.f : nw[p - 1];
+    for (; p + 16 <= e; p += 16) {
+      float v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = nw[p + i];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        sum = __fadd_rn(sum, __fsub_rn(v[i], prev));
+        prev = v[i];
+      }
+    }
+    for (; p < e; ++p) {
+      const float c = nw[p];
+      sum = __fadd_rn(sum, __fsub_rn(c, prev));
+      prev = c;
+    }
   }
   return sum;
 }
@@ -185,7 +236,7 @@ __global__ __launch_bounds__(256) void EdgeSumWeightKernel(
 __global__ __launch_bounds__(256) void EdgeSumLongRowsKernel(
     const GraphView g, const TypeList tl, const int64_t* __restrict__ long_rows,
     const int32_t* __restrict__ long_pos, const unsigned long long* __restrict__ n_long,
-    float* __restrict__ out) {
+    float* __restrict__ out, int scalar_loads) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -195,7 +246,8 @@ __global__ __launch_bounds__(256) void EdgeSumLongRowsKernel(
     const int64_t rv = long_rows[q];
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rv);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)rv >> 32));
-    const float sum = WaveRowSum(g, tl, (int64_t)(((uint64_t)hi << 32) | lo), lane);
+    const int64_t row = (int64_t)(((uint64_t)hi << 32) | lo);
+    const float sum = scalar_loads ? UniformRowSum(g, tl, row) : WaveRowSum(g, tl, row, lane);
     if (lane == 0) out[long_pos[q]] = sum;
   }
 }
@@ -797,7 +849,7 @@ int euler_gpu_get_edge_sum_weight(const euler_gpu_graph* g, void* stream,
   hipLaunchKernelGGL(EdgeSumWeightKernel, dim3(GridFor(n, block)), dim3(block), 0, st,
                      g->view, tl, ids_dev, n, out_w_dev, long_rows, long_pos, n_long);
   hipLaunchKernelGGL(EdgeSumLongRowsKernel, dim3(GridFor(n * 64, block)), dim3(block), 0, st,
-                     g->view, tl, long_rows, long_pos, n_long, out_w_dev);
+                     g->view, tl, long_rows, long_pos, n_long, out_w_dev, g_sum_scalar);
   hipError_t l = hipGetLastError();
   hipError_t f = hipFreeAsync(q, st);
   EG_HIP(e); EG_HIP(l); EG_HIP(f);

@@ -14,7 +14,7 @@
 #include "k1_search.h"
 
 extern "C" int g_feature_vec4;   // mp_kernels.hip
-namespace euler_gpu { extern int g_root_host_batch, g_adj_scan, g_adj_long_row; }   // layer_kernels.hip
+namespace euler_gpu { extern int g_root_host_batch, g_adj_scan, g_adj_long_row, g_sum_scalar; }   // layer_kernels.hip
 
 namespace euler_gpu {
 
@@ -1146,6 +1146,7 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 15 && value >= 0 && value <= 2) { g_root_host_batch = value; return EULER_GPU_OK; }
   if (key == 16) { g_adj_scan = value != 0; return EULER_GPU_OK; }
   if (key == 17 && value >= 0) { g_adj_long_row = value; return EULER_GPU_OK; }
+  if (key == 18) { g_sum_scalar = value != 0; return EULER_GPU_OK; }
   if (key == 1 && (value == 1 || value == 2 || value == 4 || value == 8)) {
     g_k1_ilp = value;
     return EULER_GPU_OK;

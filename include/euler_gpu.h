@@ -621,6 +621,8 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  *        their rows once [default]; 1 = every candidate compared with the row.
  * key 17: SparseGetAdj: sources with more listed edges than this (default
  *        16384) are cut into segments handled by separate workgroups.
+ * key 18: edge weight sums of long rows: 0 = lane-shifting DPP chain [default],
+ *        1 = scalar loads and a wave-uniform chain (measured 2x slower).
  * All settings produce identical results; the knobs exist for A/B measurements
  * and tests. */
 int euler_gpu_set_tuning(int32_t key, int32_t value);

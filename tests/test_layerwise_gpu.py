@@ -383,8 +383,14 @@ def test_long_rows(EA, O, torch_cuda):
     q = np.concatenate([ids, ids[::-1], [5]]).astype(np.uint64)
     from euler_amd import _lib
     for et in ([0], [1], [0, 1], [1, 0], [1, 1]):
-        a, b = B.get_edge_sum_weight(q, et), OB.get_edge_sum_weight(q, et)
-        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), et
+        b = OB.get_edge_sum_weight(q, et)
+        for scalar in (1, 0):        # both long-row chains (tuning key 18)
+            _lib.lib().euler_gpu_set_tuning(18, scalar)
+            try:
+                a = B.get_edge_sum_weight(q, et)
+            finally:
+                _lib.lib().euler_gpu_set_tuning(18, 0)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (et, scalar)
         y = OB.sparse_get_adj(ids, ids, 1, n, n, et)
         # rows of one wave / rows split into segments of 8192 edges over workgroups
         for long_row in (16384, 1000, 50):

@@ -81,8 +81,13 @@ _lib.lib().euler_gpu_set_tuning(16, 0)
 hub = torch.arange(1, 4097, device='cuda')           # the heaviest rows of the graph
 ms, out = timed(lambda: G.sparse_get_adj(hub, hub, [0], -1, -1), iters=2)
 res['sparse_get_adj_hubs_4096x4096_hash'] = {'ms': round(ms, 4), 'nnz': int(out[0].shape[0])}
-ms, _ = timed(lambda: G.get_edge_sum_weight(hub, [0]), iters=2)
-res['get_edge_sum_weight_hubs_4096'] = {'ms': round(ms, 4)}
+for mode, key in (('scalar', 1), ('dpp', 0)):
+    _lib.lib().euler_gpu_set_tuning(18, key)
+    ms, _ = timed(lambda: G.get_edge_sum_weight(hub, [0]), iters=2)
+    res['get_edge_sum_weight_hubs_4096_' + mode] = {'ms': round(ms, 4)}
+    ms, _ = timed(lambda: G.get_edge_sum_weight(ids, [0]))
+    res['get_edge_sum_weight_1M_' + mode] = {'ms': round(ms, 4)}
+_lib.lib().euler_gpu_set_tuning(18, 0)
 ms, t = timed(lambda: G.get_node_type(ids))
 res['get_node_type_1M'] = {'ms': round(ms, 4)}
 print(json.dumps(res, indent=1))
