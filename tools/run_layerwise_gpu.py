@@ -7,16 +7,20 @@ sys.path.insert(0, '.')
 os.makedirs('gpurun_out', exist_ok=True)
 import pytest
 
+BENCH_ONLY = '--bench-only' in sys.argv
+if BENCH_ONLY:
+    sys.argv.remove('--bench-only')
 buf = io.StringIO()
 with contextlib.redirect_stdout(buf):
-    rc = pytest.main(['-q', '-m', 'gpu', '-p', 'no:cacheprovider',
+    rc = 0 if BENCH_ONLY else pytest.main(['-q', '-m', 'gpu', '-p', 'no:cacheprovider',
                       'tests/test_layerwise_gpu.py',
                       'tests/test_gpu_parity.py::test_fixture_goldens_gpu',
                       'tests/test_gpu_parity.py::test_random_graph_goldens_gpu',
                       'tests/test_gpu_parity.py::test_op_registry_and_dat_loader',
                       'tests/test_gpu_parity.py::test_sample_node_and_walks_vs_oracle'])
 out = buf.getvalue()
-open('gpurun_out/r1_layerwise_pytest.txt', 'w').write(out)
+if not BENCH_ONLY:
+    open('gpurun_out/r1_layerwise_pytest.txt', 'w').write(out)
 print(out[-3000:])
 print('pytest rc', int(rc))
 
@@ -90,5 +94,9 @@ for mode, key in (('scalar', 1), ('dpp', 0)):
 _lib.lib().euler_gpu_set_tuning(18, 0)
 ms, t = timed(lambda: G.get_node_type(ids))
 res['get_node_type_1M'] = {'ms': round(ms, 4)}
+ms, out = timed(lambda: G.sample_neighbor_layerwise(ids[:25600].reshape(1024, 25), [0], 10, -1,
+                                                    'sqrt', call_id=6), iters=3)
+res['sample_neighbor_layerwise_sqrt_b1024_n25_m10'] = {
+    'ms': round(ms, 4), 'note': 'full neighbours -> host tables (unordered_map order) -> draws'}
 print(json.dumps(res, indent=1))
 json.dump(res, open('gpurun_out/r1_layerwise_bench.json', 'w'), indent=1)
