@@ -232,3 +232,26 @@ def test_layer_fns_host_vs_oracle_random(HC, O, T, n_nodes, id_space):
             for u, v in zip(H.sparse_get_adj(nodes, nbq, batch, n, count, et),
                             G.sparse_get_adj(nodes, nbq, batch, n, count, et)):
                 assert np.array_equal(u, v)
+
+
+def test_local_sample_layer_threaded_vs_reference(HC, O):
+    """Batches large enough for the multi-threaded host table build == the
+    reference harness (one container per batch row there too)."""
+    if not O.have_ref():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    rng = np.random.default_rng(808)
+    ids, seg, nbr, w, nt, nw = make_random_graph(rng, 2000, 3, max_deg=20)
+    csr = O.csr_from_raw(ids, seg, nbr, w, 3, nt, nw)
+    R = O.RefGraph.build_raw(ids, seg, nbr, w, 3, nt, nw)
+    R.add_edges_from_adjacency()
+    H, OG = HostBackend(HC, csr), O.OracleGraph(csr)
+    for batch, n, count in ((64, 60, 8), (9, 400, 16)):
+        nodes = rng.choice(ids, (batch, n)).astype(np.uint64)
+        assert len(OG.get_full_neighbor(nodes.reshape(-1), [0, 1, 2])[1]) > (1 << 14)
+        for wf, dn in (("sqrt", -1), ("id", 7)):
+            a = R.sample_neighbor_layerwise_func(5, 3, nodes, [0, 1, 2], count, wf, dn)
+            b = H.sample_neighbor_layerwise_func(OG, 5, 3, nodes, [0, 1, 2], count, wf, dn)
+            for x, y in zip(a, b):
+                if x.dtype == np.float32:
+                    x, y = x.view(np.uint32), np.asarray(y, np.float32).view(np.uint32)
+                assert np.array_equal(x, y)
