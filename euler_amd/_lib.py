@@ -83,6 +83,8 @@ SIGNATURES = {
     "euler_gpu_graph_num_u64_features": (C.c_int32, [vp]),
     "euler_gpu_get_sparse_feature": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int32, C.c_int64,
                                                vp, i64p, i64p, vp, vp]),
+    "euler_gpu_get_sparse_feature_core": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int32, vp,
+                                                    i64p, vp]),
     "euler_gpu_get_node_type": (C.c_int, [vp, vp, vp, C.c_int64, vp]),
     "euler_gpu_sample_n_with_types": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp,
                                                 C.c_int64, C.c_int32, vp]),

@@ -57,6 +57,39 @@ __global__ __launch_bounds__(256) void SparseFeatCountKernel(
   if ((threadIdx.x & 63) == 0 && local_max > 0) atomicMax(max_len, (unsigned long long)local_max);
 }
 
+// The GQL `values(...)` form (core/kernels/get_feature_op.cc:34-70, "fea:2i" /
+// "fea:2i+1"): counts without the default entry, idx pairs, packed values.
+__global__ __launch_bounds__(256) void SparseFeatCoreCountKernel(
+    const SparseFeatArgs a, int64_t* __restrict__ counts) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+    const uint64_t* first;
+    counts[i] = SlotRange(a, a.nodes[i], &first);
+  }
+}
+
+__global__ __launch_bounds__(256) void SparseFeatCoreFillKernel(
+    const SparseFeatArgs a, const int32_t* __restrict__ idx, uint64_t* __restrict__ values) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t i = wave; i < a.n; i += n_waves) {
+    const uint64_t* first;
+    const int32_t len = SlotRange(a, a.nodes[i], &first);
+    const int64_t o = idx[2 * i];
+    for (int32_t k = lane; k < len; k += 64) values[o + k] = first[k];
+  }
+}
+
+__global__ void SparseFeatOffsetsToIdxKernel(const int64_t* __restrict__ off, int64_t n,
+                                             int32_t* __restrict__ idx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    idx[2 * i] = (int32_t)off[i];
+    idx[2 * i + 1] = (int32_t)off[i + 1];
+  }
+}
+
 // One wave per node: lanes over its values (lists are short; the row offsets
 // make the writes of consecutive nodes contiguous).
 __global__ __launch_bounds__(256) void SparseFeatFillKernel(
@@ -138,6 +171,45 @@ int euler_gpu_get_sparse_feature(const euler_gpu_graph* g, void* stream,
   if (!values_dev) return Fail(EULER_GPU_EINVAL, "get_sparse_feature: null values");
   hipLaunchKernelGGL(SparseFeatFillKernel, dim3(GridFor(n * 64, block)), dim3(block), 0, st,
                      a, row_off_dev, default_value, indices_dev, values_dev);
+  EG_HIP(hipGetLastError());
+  return EULER_GPU_OK;
+}
+
+int euler_gpu_get_sparse_feature_core(const euler_gpu_graph* g, void* stream,
+                                      const uint64_t* nodes_dev, int64_t n, int32_t fid,
+                                      int32_t* idx_dev, int64_t* total_host,
+                                      uint64_t* values_dev) {
+  if (!g) return Fail(EULER_GPU_ENOGRAPH, "get_sparse_feature_core: null graph");
+  if (n < 0) return Fail(EULER_GPU_EINVAL, "get_sparse_feature_core: n < 0");
+  if (n == 0) { if (total_host) *total_host = 0; return EULER_GPU_OK; }
+  if (!nodes_dev || !idx_dev)
+    return Fail(EULER_GPU_EINVAL, "get_sparse_feature_core: null buffer");
+  hipStream_t st = (hipStream_t)stream;
+  SparseFeatArgs a{};
+  a.g = g->view;
+  a.ufeat_ptr = g->ufeat_ptr; a.ufeat_idx = g->ufeat_idx; a.ufeat_val = g->ufeat_val;
+  a.nodes = nodes_dev; a.n = n; a.n_u64 = g->n_u64; a.fid = fid;
+  const int block = 256;
+  if (values_dev == nullptr) {
+    int64_t* counts = nullptr;
+    EG_HIP(hipMallocAsync((void**)&counts, (size_t)(2 * n + 2) * sizeof(int64_t), st));
+    int64_t* off = counts + n + 1;
+    EG_HIP(hipMemsetAsync(counts + n, 0, sizeof(int64_t), st));
+    hipLaunchKernelGGL(SparseFeatCoreCountKernel, dim3(GridFor(n, block)), dim3(block), 0, st,
+                       a, counts);
+    int rc = ExclusiveScanI64(st, counts, off, n + 1);
+    if (rc != EULER_GPU_OK) { (void)hipFreeAsync(counts, st); return rc; }
+    hipLaunchKernelGGL(SparseFeatOffsetsToIdxKernel, dim3((unsigned)((n + block - 1) / block)),
+                       dim3(block), 0, st, off, n, idx_dev);
+    int64_t total = 0;
+    EG_HIP(hipMemcpyAsync(&total, off + n, 8, hipMemcpyDeviceToHost, st));
+    EG_HIP(hipStreamSynchronize(st));
+    EG_HIP(hipFreeAsync(counts, st));
+    if (total_host) *total_host = total;
+    return EULER_GPU_OK;
+  }
+  hipLaunchKernelGGL(SparseFeatCoreFillKernel, dim3(GridFor(n * 64, block)), dim3(block), 0, st,
+                     a, idx_dev, values_dev);
   EG_HIP(hipGetLastError());
   return EULER_GPU_OK;
 }

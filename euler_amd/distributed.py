@@ -33,6 +33,31 @@ def owner_of(ids, partitions, shards):
     return torch.remainder(m, shards)
 
 
+def sparse_from_core(idx, vals, default_value):
+    """The SparseTensorBuilder rules of the TF GetSparseFeature kernel
+    (tf_euler/kernels/get_sparse_feature_op.cc:96-107) over a GQL `values()`
+    result (idx [n, 2] offsets, packed values): node j with no value gives the
+    single entry (j, 0) = default, else (j, k) = value k.  Returns (indices
+    [nnz, 2] int64, values [nnz] int64, dense_shape)."""
+    idx = idx.reshape(-1, 2).to(torch.int64)
+    dev = idx.device
+    n = idx.shape[0]
+    if n == 0:
+        return (torch.zeros((0, 2), dtype=torch.int64, device=dev),
+                torch.zeros(0, dtype=torch.int64, device=dev), [0, 0])
+    lens = idx[:, 1] - idx[:, 0]
+    emit = torch.clamp(lens, min=1)
+    start = torch.cumsum(emit, 0) - emit
+    rows = torch.repeat_interleave(torch.arange(n, device=dev), emit)
+    col = torch.arange(int(emit.sum()), device=dev) - start[rows]
+    has = lens[rows] > 0
+    values = torch.full((rows.numel(),), int(default_value), dtype=torch.int64, device=dev)
+    if vals.numel():
+        src = (idx[rows, 0] + col).clamp(max=vals.numel() - 1)
+        values = torch.where(has, vals.to(torch.int64)[src], values)
+    return torch.stack([rows, col], 1), values, [n, int(emit.max())]
+
+
 class ShardedSampler:
     """Neighbor sampling over a graph sharded across the ranks of `group`.
 
@@ -87,6 +112,7 @@ class ShardedSampler:
         self.node_weight_sum = None
         self.node_split_fn = None
         self.local_full_neighbor = None
+        self.local_sparse_feature = None
         self.idx_gather_fn = None
         self.data_gather_fn = None
         self.device = torch.device("cpu")
@@ -344,6 +370,57 @@ class ShardedSampler:
         out_t = self.data_gather_fn(vals_back[:, 3].contiguous(), idx_cat, pos)
         return out_idx, out_ids, out_w, out_t
 
+    # ------------------------------------------------------ sparse features
+    def get_sparse_feature(self, nodes, feature_ids, default_values=None):
+        """tf_euler get_sparse_feature over the sharded graph: per uint64 feature
+        id the SparseTensor triple (indices [nnz, 2] int64, values [nnz] int64,
+        dense_shape [n, max_len]).  The distinct ids travel to their owners, each
+        owner answers in the GQL `values()` layout (row lengths + packed values,
+        no default entries), the answers come back like the rows of
+        get_full_neighbor (IDX_GATHER / DATA_GATHER through the position map) and
+        the requester inserts the default entry of nodes without values, as the
+        TF kernel does (tf_euler/kernels/get_sparse_feature_op.cc:96-107).  Needs
+        local_sparse_feature(owned ids, fid) -> (idx [m, 2] int32, values int64)
+        and the idx_gather_fn / data_gather_fn of get_full_neighbor."""
+        nodes = nodes.reshape(-1).to(torch.int64)
+        dev = nodes.device
+        n = nodes.numel()
+        if default_values is None:
+            default_values = [0] * len(feature_ids)
+        if self.dedup_split_fn is not None:
+            shard_off, shard_ids, pos = self.dedup_split_fn(nodes, self.partitions,
+                                                            self.world, None, 1)
+        else:
+            shard_off, shard_ids, merge_idx = self.split_fn(nodes, self.partitions,
+                                                            self.world)
+            pos = torch.empty_like(merge_idx)
+            pos[merge_idx.long()] = torch.arange(n, dtype=merge_idx.dtype, device=dev)
+        send_counts = [int(shard_off[s + 1] - shard_off[s]) for s in range(self.world)]
+        recv_counts = self._exchange_counts(send_counts, dev)
+        owned = self._exchange(shard_ids, send_counts, recv_counts)
+        bounds = [0]
+        for c in recv_counts:
+            bounds.append(bounds[-1] + c)
+        outs = []
+        for fid, dv in zip(feature_ids, default_values):
+            idx, vals = self.local_sparse_feature(owned, int(fid))
+            idx = idx.reshape(-1, 2).to(torch.int64)
+            lens = idx[:, 1] - idx[:, 0]
+            csum = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev),
+                              torch.cumsum(lens, 0)])
+            val_send = [int(csum[bounds[s + 1]] - csum[bounds[s]]) for s in range(self.world)]
+            val_recv = self._exchange_counts(val_send, dev)
+            lens_back = self._exchange(lens.reshape(-1, 1).contiguous(), recv_counts,
+                                       send_counts).reshape(-1)
+            vals_back = self._exchange(vals.to(torch.int64).reshape(-1, 1).contiguous(),
+                                       val_send, val_recv).reshape(-1)
+            end = torch.cumsum(lens_back, 0)
+            idx_cat = torch.stack([end - lens_back, end], dim=1).to(torch.int32)
+            out_idx, _total = self.idx_gather_fn(idx_cat, pos)
+            out_vals = self.data_gather_fn(vals_back.contiguous(), idx_cat, pos)
+            outs.append(sparse_from_core(out_idx, out_vals, int(dv)))
+        return outs
+
     # ---------------------------------------------------------- sample_node
     def sample_node(self, count, node_type=-1, call_id=0):
         """SampleNode over the shards: SAMPLE_NODE_SPLIT divides
@@ -583,6 +660,7 @@ def gpu_sharded_sampler(graph, partitions=None, group=None, dedup=True, dense_id
         return float(sums.sum(dtype="float32")) if node_type == -1 else float(sums[node_type])
 
     S.local_full_neighbor = graph.get_full_neighbor
+    S.local_sparse_feature = graph.get_sparse_feature_core
     S.idx_gather_fn = ops.idx_gather
     S.data_gather_fn = ops.data_gather
     S.node_weight_sum = weight_sum

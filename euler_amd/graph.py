@@ -399,6 +399,24 @@ class Graph:
                 outs.append((ind, val, [n, int(max_len.value)] if n else [0, 0]))
         return outs
 
+    def get_sparse_feature_core(self, nodes, fid):
+        """One uint64 feature slot in the GQL `values()` layout: (idx [n, 2]
+        int32 offsets, values int64), no default entries."""
+        nodes = _as_i64_cuda(nodes, self.device).reshape(-1)
+        n = nodes.numel()
+        idx = torch.empty((n, 2), dtype=torch.int32, device=self.device)
+        total = C.c_int64(0)
+        with torch.cuda.device(self.device):
+            check(lib().euler_gpu_get_sparse_feature_core(
+                self._h, _stream(), _ptr(nodes), n, int(fid), _ptr(idx), C.byref(total),
+                None))
+            vals = torch.empty(int(total.value), dtype=torch.int64, device=self.device)
+            if total.value:
+                check(lib().euler_gpu_get_sparse_feature_core(
+                    self._h, _stream(), _ptr(nodes), n, int(fid), _ptr(idx),
+                    C.byref(total), _ptr(vals)))
+        return idx, vals
+
     _ORDER = {None: 0, "": 0, "id": 1, "weight": 2}
 
     def get_full_neighbor(self, nodes, edge_types, order_by=None, desc=False,

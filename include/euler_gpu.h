@@ -446,6 +446,15 @@ int euler_gpu_get_sparse_feature(const euler_gpu_graph* g, void* stream,
                                  int64_t* nnz_host, int64_t* max_len_host,
                                  int64_t* indices_dev, int64_t* values_dev);
 
+/* The same feature slot in the GQL `values(...)` layout of API_GET_P
+ * (core/kernels/get_feature_op.cc:34-70): idx_dev [n, 2] int32 offsets + the
+ * packed values, no default entries - what a shard returns to the requester in
+ * the multi-GPU path.  Two calls like euler_gpu_get_full_neighbor. */
+int euler_gpu_get_sparse_feature_core(const euler_gpu_graph* g, void* stream,
+                                      const uint64_t* nodes_dev, int64_t n, int32_t fid,
+                                      int32_t* idx_dev, int64_t* total_host,
+                                      uint64_t* values_dev);
+
 /* ---- RandomWalk -------------------------------------------------------------
  * TF RandomWalk kernel (tf_euler/kernels/random_walk_op.cc:172-291):
  * |p-1|,|q-1| <= 1e-6 -> chain of count=1 SampleNeighbor hops (:207-247), else

@@ -244,6 +244,37 @@ def _worker(rank, world, port, partitions, out_dir):
             assert np.array_equal(gi_.numpy(), wi_), (rank, et_)
             assert np.array_equal(gd_.numpy().astype(np.uint64), wd_)
             assert np.array_equal(gw_.numpy(), ww_) and np.array_equal(gt_.numpy(), wt_)
+    # ---- sparse (uint64) features: variable-length rows again, then the TF
+    # kernel's default entries on the requester
+    sper = [[[int(v)] * (i % 4), [int(v) + 7, 3][: (i % 3)], [2 ** 63 + i]] if i % 5 else [[]]
+            for i, v in enumerate(csr.row_id)]
+    SF_full = O.SparseFeatures.from_lists(sper)
+    SF_local = O.SparseFeatures.from_lists([sper[i] for i in own_rows])
+    local_rows = {int(v): k for k, v in enumerate(csr.row_id[own_rows])}
+
+    def local_sparse_feature(owned, fid):
+        idx = np.zeros((owned.numel(), 2), np.int32)
+        vals = []
+        U = SF_local.n_u64
+        for j, v in enumerate(owned.numpy().astype(np.uint64)):
+            idx[j, 0] = len(vals)
+            r = local_rows.get(int(v))
+            if r is not None and 0 <= fid < U:
+                fi = SF_local.feat_idx[r * U:(r + 1) * U]
+                pre = 0 if fid == 0 else fi[fid - 1]
+                b0 = SF_local.feat_ptr[r]
+                vals.extend(SF_local.feat_val[b0 + pre:b0 + fi[fid]].view(np.int64).tolist())
+            idx[j, 1] = len(vals)
+        return torch.as_tensor(idx), torch.as_tensor(np.array(vals, np.int64))
+
+    q_sp = np.concatenate([roots, [0, 123456789]]).astype(np.int64)
+    want_s = OG_full.get_sparse_feature(SF_full, q_sp.astype(np.uint64), [0, 1, 2, 5], [0, 9, -1, 4])
+    for sampler in (S_fused, S_plain):
+        sampler.local_sparse_feature = local_sparse_feature
+        got_s = sampler.get_sparse_feature(torch.as_tensor(q_sp), [0, 1, 2, 5], [0, 9, -1, 4])
+        for (gi_, gv_, gs_), (wi_, wv_, ws_) in zip(got_s, want_s):
+            assert np.array_equal(gi_.numpy(), wi_) and np.array_equal(gv_.numpy(), wv_)
+            assert list(gs_) == list(ws_)
     # ---- SampleNode over the shards: SAMPLE_NODE_SPLIT + local draws + APPEND_MERGE
     OG_local.build_node_sampler()
     shard_graphs = [O.OracleGraph(_shard_csr(O, csr, partitions, r, world)) for r in range(world)]

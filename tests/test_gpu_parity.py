@@ -593,6 +593,22 @@ def test_gpu_sharded_sampler_single_rank(EA, O, torch_cuda, big_pair):
         assert np.array_equal(t2n(got_f[0]), want_f[0])
         assert np.array_equal(t2n(got_f[1]), want_f[1])
         assert Sf.dense_table is not None and S.dense_table is None
+        # sparse (uint64) features through the exchange: variable-length answers +
+        # the TF kernel's default entries on the requester
+        sper = [[list(rng.integers(0, 2 ** 63, int(rng.integers(0, 5)), dtype=np.uint64)),
+                 [int(v)] * (i % 3)] if i % 7 else [[]] for i, v in enumerate(f_ids)]
+        SF = O.SparseFeatures.from_lists(sper)
+        Gs = gpu_graph(EA, f_csr, sparse_features=(SF.n_u64, SF.feat_ptr, SF.feat_idx,
+                                                    SF.feat_val))
+        Ss = gpu_sharded_sampler(Gs, partitions=1)
+        got_s = Ss.get_sparse_feature(torch.as_tensor(fq).cuda(), [0, 1, 4], [0, 11, -1])
+        want_s = O.OracleGraph(f_csr).get_sparse_feature(SF, fq.astype(np.uint64), [0, 1, 4],
+                                                         [0, 11, -1])
+        direct = Gs.get_sparse_feature(torch.as_tensor(fq).cuda(), [0, 1, 4], [0, 11, -1])
+        for (gi_, gv_, gs_), (wi_, wv_, ws_), (di_, dv_, ds_) in zip(got_s, want_s, direct):
+            assert np.array_equal(t2n(gi_), wi_) and np.array_equal(t2n(gv_), wv_)
+            assert list(gs_) == list(ws_) == list(ds_)
+            assert np.array_equal(t2n(di_), wi_) and np.array_equal(t2n(dv_), wv_)
         # a fanout through the id-indexed front end (ids base + stride * row)
         n_i = 20000
         i_ids = (7 + 3 * np.arange(n_i)).astype(np.uint64)
