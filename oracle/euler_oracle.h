@@ -11,6 +11,9 @@
  * unique_gather_test.cc, *_merge_op_test.cc) committed under tests/golden/.
  * Sampled ids have no golden in the reference (its sampling tests are
  * statistical); they are pinned by (1).
+ * Third-party arithmetic: API_LOCAL_SAMPLE_L depends on the iteration order of
+ * libstdc++'s std::unordered_map<std::string, ...> (GCC 11.4.0, GLIBCXX_3.4.30);
+ * eo_umap.c restates it and is pinned against the real container in oracle/_ref.
  */
 #ifndef EULER_ORACLE_H_
 #define EULER_ORACLE_H_
@@ -131,6 +134,14 @@ void eo_neighbor_to_dense(int64_t n, const int32_t* idx, const uint64_t* ids,
                           const float* w, const int32_t* t, int32_t k,
                           int64_t default_node, int64_t* out_id, float* out_w,
                           int32_t* out_t);
+
+/* libstdc++ internals restated for API_LOCAL_SAMPLE_L (oracle/eo_umap.c) */
+uint64_t eo_std_hash_bytes(const void* ptr, uint64_t len);
+void eo_umap_iteration_order(const uint64_t* hash, int64_t n, int64_t* order);
+void eo_local_sample_layer(uint64_t seed, uint32_t call_id, const int32_t* idx,
+                           int64_t idx_elems, const uint64_t* ids, const float* w,
+                           const int32_t* t, int32_t n, int32_t m, int32_t take_sqrt,
+                           int64_t default_node, uint64_t* o_nb, float* o_w, int32_t* o_t);
 
 /* layerwise sampling (sampleLNB without a weight function) */
 void eo_get_edge_sum_weight(const eo_graph* g, const uint64_t* ids, int64_t n,

@@ -135,6 +135,12 @@ def lib():
                                      _i32p, _u64p, _f32p, _f32p]
         L.eo_philox_kat.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                     C.POINTER(C.c_uint32)]
+        L.eo_std_hash_bytes.restype = C.c_uint64
+        L.eo_std_hash_bytes.argtypes = [C.c_char_p, C.c_uint64]
+        L.eo_umap_iteration_order.argtypes = [_u64p, C.c_int64, _i64p]
+        L.eo_local_sample_layer.argtypes = [
+            C.c_uint64, C.c_uint32, _i32p, C.c_int64, _u64p, _f32p, _i32p, C.c_int32,
+            C.c_int32, C.c_int32, C.c_int64, _u64p, _f32p, _i32p]
         L.eo_get_sparse_feature.restype = C.c_int64
         L.eo_get_sparse_feature.argtypes = [C.c_void_p, C.c_void_p, _u64p, C.c_int64,
                                             C.c_int32, C.c_int64, _i64p, _i64p, _i64p]
@@ -225,6 +231,8 @@ def ref():
         R.euler_ref_sample_n_with_types.argtypes = [C.c_uint64, C.c_uint32, _i32p,
                                                     C.c_int64, C.c_int32, _u64p]
         R.euler_ref_get_node_type.argtypes = [_u64p, C.c_int64, _i32p]
+        R.euler_ref_umap_order.restype = C.c_int64
+        R.euler_ref_umap_order.argtypes = [C.c_char_p, _i32p, C.c_int64, _i64p, _u64p]
         R.euler_ref_local_sample_layer.argtypes = [
             C.c_uint64, C.c_uint32, _i32p, C.c_int64, _u64p, _f32p, _i32p, C.c_int32,
             C.c_int32, C.c_char_p, C.c_int64, _u64p, _f32p, _i32p]
@@ -438,6 +446,33 @@ def sample_root(seed, call_id, roots, weights, n, m, default_node=-1):
     return out
 
 
+def std_hash(key):
+    """libstdc++ std::hash<std::string> restated (oracle/eo_umap.c)."""
+    key = key if isinstance(key, bytes) else key.encode()
+    return int(lib().eo_std_hash_bytes(key, len(key)))
+
+
+def umap_iteration_order(keys):
+    """Restated iteration order of std::unordered_map<std::string, ...> after
+    inserting the DISTINCT keys in order."""
+    h = np.array([std_hash(k) for k in keys], np.uint64)
+    order = np.zeros(len(keys), np.int64)
+    lib().eo_umap_iteration_order(_p(h, _u64p), len(keys), _p(order, _i64p))
+    return order
+
+
+def ref_umap_iteration_order(keys):
+    """The real container inside oracle/_ref: (order over the distinct keys,
+    std::hash of every key)."""
+    bs = [k if isinstance(k, bytes) else k.encode() for k in keys]
+    lens = np.array([len(b) for b in bs], np.int32)
+    order = np.zeros(len(bs), np.int64)
+    hashes = np.zeros(len(bs), np.uint64)
+    d = ref().euler_ref_umap_order(b"".join(bs), _p(lens, _i32p), len(bs), _p(order, _i64p),
+                                   _p(hashes, _u64p))
+    return order[:d], hashes
+
+
 class _LayerwiseMixin:
     def sparse_get_adj_tf(self, nodes, nb_nodes, edge_types, n=-1, m=-1):
         """TF SparseGetAdj (tf_euler/kernels/sparse_get_adj_op.cc:43-134):
@@ -451,6 +486,21 @@ class _LayerwiseMixin:
         batch = len(nodes) // n if n else 0
         idx, vals = self.sparse_get_adj(nodes, nb_nodes, batch, n, m, edge_types)
         return self._adj_to_sparse(nodes, nb_nodes, batch, n, m, idx, vals)
+
+    def sample_neighbor_layerwise_func(self, seed, call_id, nodes, edge_types, count,
+                                       weight_func, default_node=-1):
+        """sampleLNB with a weight function: API_GET_NB_NODE -> API_LOCAL_SAMPLE_L
+        -> adjacency (translator.cc:388-441,489-527)."""
+        nodes = np.asarray(nodes)
+        batch, n = nodes.shape
+        flat = _arr(nodes.reshape(-1), np.uint64)
+        idx, ids, w, t = self.get_full_neighbor(flat, edge_types)
+        l_nb, l_w, l_t = self.local_sample_layer(seed, call_id, idx, ids, w, t, n, count,
+                                                 weight_func, default_node)
+        aidx, avals = self.sparse_get_adj(flat, l_nb, batch, n, count, edge_types)
+        ind, val, shape = self._adj_to_sparse(flat, l_nb, batch, n, count, aidx, avals)
+        return (l_nb.view(np.int64).reshape(batch, count), l_w.reshape(batch, count),
+                l_t.reshape(batch, count), ind, val, shape)
 
     def sample_neighbor_layerwise(self, seed, call_id, nodes, edge_types, count,
                                   default_node=-1):
@@ -593,6 +643,21 @@ class OracleGraph(_LayerwiseMixin):
                                           _p(types, _i32p), len(types), count,
                                           _p(out, _u64p))
         return out if rc == 0 else None
+
+    def local_sample_layer(self, seed, call_id, idx, ids, w, t, n, m, weight_func="sqrt",
+                           default_node=-1):
+        """API_LOCAL_SAMPLE_L with libstdc++'s container order restated in C."""
+        idx = _arr(idx, np.int32).reshape(-1)
+        ids, w, t = _arr(ids, np.uint64), _arr(w, np.float32), _arr(t, np.int32)
+        batch = len(idx) // (2 * n)
+        oid = np.zeros(batch * m, np.uint64)
+        ow = np.zeros(batch * m, np.float32)
+        ot = np.zeros(batch * m, np.int32)
+        lib().eo_local_sample_layer(seed, call_id, _p(idx, _i32p), len(idx), _p(ids, _u64p),
+                                    _p(w, _f32p), _p(t, _i32p), n, m,
+                                    1 if weight_func == "sqrt" else 0, default_node,
+                                    _p(oid, _u64p), _p(ow, _f32p), _p(ot, _i32p))
+        return oid, ow, ot
 
     # ---- layerwise primitives (C restatement)
     _adj_to_sparse = staticmethod(adj_to_sparse)
@@ -962,21 +1027,6 @@ class RefGraph(_LayerwiseMixin):
                                            m, weight_func.encode(), default_node,
                                            _p(oid, _u64p), _p(ow, _f32p), _p(ot, _i32p))
         return oid, ow, ot
-
-    def sample_neighbor_layerwise_func(self, seed, call_id, nodes, edge_types, count,
-                                       weight_func, default_node=-1):
-        """sampleLNB with a weight function: API_GET_NB_NODE -> API_LOCAL_SAMPLE_L
-        -> adjacency (translator.cc:388-441,489-527)."""
-        nodes = np.asarray(nodes)
-        batch, n = nodes.shape
-        flat = _arr(nodes.reshape(-1), np.uint64)
-        idx, ids, w, t = self.get_full_neighbor(flat, edge_types)
-        l_nb, l_w, l_t = self.local_sample_layer(seed, call_id, idx, ids, w, t, n, count,
-                                                 weight_func, default_node)
-        aidx, avals = self.sparse_get_adj(flat, l_nb, batch, n, count, edge_types)
-        ind, val, shape = self._adj_to_sparse(flat, l_nb, batch, n, count, aidx, avals)
-        return (l_nb.view(np.int64).reshape(batch, count), l_w.reshape(batch, count),
-                l_t.reshape(batch, count), ind, val, shape)
 
     @staticmethod
     def _adj_to_sparse(nodes, nb_nodes, batch, n, m, idx, vals):

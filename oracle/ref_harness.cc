@@ -891,4 +891,24 @@ void euler_ref_local_sample_layer(uint64_t seed, uint32_t call_id, const int32_t
   }
 }
 
+// Iteration order of a REAL std::unordered_map<std::string, int> after inserting
+// the given keys (concatenated bytes, lengths) in order; duplicate keys are
+// skipped like operator[] on an existing key.  order[k] = index (among the
+// distinct keys, in first-occurrence order) of the k-th element.  Returns the
+// number of distinct keys.  Also returns std::hash<std::string> of every key.
+int64_t euler_ref_umap_order(const char* bytes, const int32_t* lens, int64_t n,
+                             int64_t* order, uint64_t* hashes) {
+  std::unordered_map<std::string, int64_t> m;
+  int64_t off = 0, distinct = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    std::string key(bytes + off, (size_t)lens[i]);
+    off += lens[i];
+    if (hashes) hashes[i] = std::hash<std::string>()(key);
+    if (m.find(key) == m.end()) m[key] = distinct++;
+  }
+  int64_t k = 0;
+  for (auto it = m.begin(); it != m.end(); ++it) order[k++] = it->second;
+  return distinct;
+}
+
 }  // extern "C"

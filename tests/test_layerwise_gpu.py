@@ -478,3 +478,24 @@ def test_cpp_host_example(EA, O, torch_cuda, fixture_csr):
     assert np.array_equal(ids("hop1").view(np.int64), on[0].reshape(-1))
     assert np.array_equal(ids("hop2").view(np.int64), on[1].reshape(-1))
     assert np.array_equal(bits("w2"), ow[1].reshape(-1).view(np.uint32))
+
+
+def test_layerwise_weight_func_vs_oracle(EA, O, torch_cuda, lw_pair):
+    """sampleLNB with a weight function on a 20 000-node graph: the library (host
+    tables in the real std::unordered_map, draws on the device) == the C oracle
+    (libstdc++'s container order restated, oracle/eo_umap.c), incl. batches
+    large enough for the multi-threaded host build."""
+    G, OG, ids, rng = lw_pair
+    B = GpuBackend(torch_cuda, G)
+    for batch, n, count in ((8, 25, 10), (1, 2000, 256), (64, 60, 8), (3, 1, 4)):
+        nodes = rng.choice(ids, (batch, n)).astype(np.uint64)
+        nodes[-1, -1] = 2 ** 62 + 9
+        for et in ([0], [1, 3], [0, 1, 2, 3]):
+            for wf, dn in (("sqrt", -1), ("sqrt", 261), ("other", 0)):
+                x = B.sample_neighbor_layerwise_func(23, 4, nodes, et, count, wf, dn)
+                y = OG.sample_neighbor_layerwise_func(23, 4, nodes, et, count, wf, dn)
+                for u, v in zip(x, y):
+                    u, v = np.asarray(u), np.asarray(v)
+                    if u.dtype == np.float32:
+                        u, v = u.view(np.uint32), v.view(np.uint32)
+                    assert np.array_equal(u, v), (batch, n, et, wf)

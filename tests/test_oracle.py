@@ -341,3 +341,22 @@ def test_layerwise_goldens(O, fixture_csr, random_csr):
     assert set(nb[0].tolist()) <= {2, 3, 4, 5} and set(nb[2].tolist()) <= {3, 4, 5}
     assert set(nb[3].tolist()) <= {3, 5}
     check_layer_pack(OracleBackend(O, O.OracleGraph(random_csr)), L, "rg_", 3)
+
+
+def test_layerwise_weight_func_goldens(O, fixture_csr, random_csr):
+    """sampleLNB with a weight function (API_LOCAL_SAMPLE_L): the C restatement -
+    libstdc++'s std::hash<std::string>, prime bucket policy and list insertion
+    restated in oracle/eo_umap.c - against the reference harness' vectors."""
+    import os
+    from conftest import GOLDEN
+    from layer_cases import check_layer_func_pack
+    L = np.load(os.path.join(GOLDEN, "layerwise.npz"))
+    for prefix, csr in (("fx_", fixture_csr), ("rg_", random_csr)):
+        check_layer_func_pack(O.OracleGraph(csr).sample_neighbor_layerwise_func, L, prefix)
+    # known answers of the restated hash (std::hash<std::string> of libstdc++,
+    # GLIBCXX_3.4.30): values produced by the real library
+    assert O.std_hash("") == 6142509188972423790
+    assert O.std_hash("a") == 4993892634952068459
+    assert O.std_hash("euler") == 6969579379935283931
+    assert O.std_hash("12345678901234567890") == 3825371124932007023
+    assert O.umap_iteration_order([]).shape == (0,)

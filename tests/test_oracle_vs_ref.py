@@ -285,3 +285,38 @@ def test_node_type_and_sample_n_with_types_match_reference(lpair):
     # rows are independent SampleNode calls: row i == SampleNode with stream i
     assert R.sample_n_with_types(13, 0, [0, 7], 3) is None
     assert G.sample_n_with_types(13, 0, [0, 7], 3) is None
+
+
+def test_unordered_map_order_and_local_sample_layer_match_reference(lpair, O):
+    """oracle/eo_umap.c (libstdc++'s string hash, prime rehash policy, list
+    insertion) == the real std::unordered_map inside oracle/_ref: iteration order
+    on random key sets across many rehashes, then the whole API_LOCAL_SAMPLE_L."""
+    R, G, ids, rng = lpair
+    for trial in range(60):
+        n = int(rng.integers(0, 50 if trial < 20 else 3000 if trial < 55 else 40000))
+        keys = list({"%d%d" % (rng.integers(0, 2 ** 63), rng.integers(0, 5)) for _ in range(n)})
+        want, hashes = O.ref_umap_iteration_order(keys)
+        assert np.array_equal(hashes, np.array([O.std_hash(k) for k in keys], np.uint64))
+        assert np.array_equal(want, O.umap_iteration_order(keys)), len(keys)
+    # to_string(id) + to_string(type) can run two pairs together (id 12 / type 3,
+    # id 1 / type 23): the reference merges them, so does the restatement
+    idx = np.array([[0, 4]], np.int32)
+    ids4 = np.array([12, 1, 12, 7], np.uint64)
+    w4 = np.array([1.0, 2.0, 4.0, 8.0], np.float32)
+    t4 = np.array([3, 23, 3, 0], np.int32)
+    a = R.local_sample_layer(3, 1, idx, ids4, w4, t4, 1, 32, "sqrt", -1)
+    b = G.local_sample_layer(3, 1, idx, ids4, w4, t4, 1, 32, "sqrt", -1)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    assert set(np.round(a[1] ** 2).astype(int).tolist()) <= {7, 8}
+    for batch, n, count in ((4, 3, 10), (2, 50, 40), (7, 1, 5), (1, 300, 64)):
+        nodes = rng.choice(ids, (batch, n)).astype(np.uint64)
+        nodes[-1, -1] = 2 ** 62 + 1
+        for et in ([0], [1, 2], [0, 1, 2, 3]):
+            for wf, dn in (("sqrt", -1), ("sqrt", 261), ("id", 0)):
+                x = R.sample_neighbor_layerwise_func(9, 2, nodes, et, count, wf, dn)
+                y = G.sample_neighbor_layerwise_func(9, 2, nodes, et, count, wf, dn)
+                for u, v in zip(x, y):
+                    if u.dtype == np.float32:
+                        u, v = u.view(np.uint32), v.view(np.uint32)
+                    assert np.array_equal(u, v), (batch, n, et, wf)
