@@ -93,6 +93,8 @@ SIGNATURES = {
                                         C.c_int32, C.c_int32, C.c_int64, vp]),
     "euler_gpu_sample_layer": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp, C.c_int64,
                                          i32p, C.c_int32, C.c_int64, vp, vp, vp]),
+    "euler_gpu_sample_layer_at": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp, vp, C.c_int64,
+                                            i32p, C.c_int32, C.c_int64, vp, vp, vp]),
     "euler_gpu_sample_neighbor_layerwise": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp,
                                                       C.c_int64, C.c_int32, i32p, C.c_int32,
                                                       C.c_int32, C.c_int64, vp]),

@@ -291,13 +291,16 @@ __global__ __launch_bounds__(256) void SampleRootDrawKernel(
 // ---------------------------------------------------------------- layer draw
 __global__ __launch_bounds__(256) void SampleLayerKernel(
     const GraphView g, const TypeList tl, const uint64_t* __restrict__ roots,
-    int64_t n, uint64_t seed, uint32_t call_id, int64_t default_node,
-    uint64_t* __restrict__ out_id, float* __restrict__ out_w,
+    const int64_t* __restrict__ pos, int64_t n, uint64_t seed, uint32_t call_id,
+    int64_t default_node, uint64_t* __restrict__ out_id, float* __restrict__ out_w,
     int32_t* __restrict__ out_t) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     uint64_t id; float w; int32_t t;
-    SampleLayerAt(g, seed, call_id, i, roots[i], tl.et, tl.k, default_node, &id, &w, &t);
+    // the RNG stream is the position in the op's root list: i, or the position the
+    // requester of a multi-GPU hop gave this root
+    SampleLayerAt(g, seed, call_id, pos ? pos[i] : i, roots[i], tl.et, tl.k, default_node,
+                  &id, &w, &t);
     out_id[i] = id;
     if (out_w) out_w[i] = w;
     if (out_t) out_t[i] = t;
@@ -931,6 +934,17 @@ int euler_gpu_sample_layer(const euler_gpu_graph* g, void* stream, uint64_t seed
                            const int32_t* edge_types_host, int32_t k,
                            int64_t default_node, uint64_t* out_id_dev,
                            float* out_w_dev, int32_t* out_t_dev) {
+  return euler_gpu_sample_layer_at(g, stream, seed, call_id, roots_dev, nullptr, n,
+                                   edge_types_host, k, default_node, out_id_dev, out_w_dev,
+                                   out_t_dev);
+}
+
+int euler_gpu_sample_layer_at(const euler_gpu_graph* g, void* stream, uint64_t seed,
+                              uint32_t call_id, const uint64_t* roots_dev,
+                              const int64_t* pos_dev, int64_t n,
+                              const int32_t* edge_types_host, int32_t k,
+                              int64_t default_node, uint64_t* out_id_dev,
+                              float* out_w_dev, int32_t* out_t_dev) {
   if (!g) return Fail(EULER_GPU_ENOGRAPH, "sample_layer: null graph");
   if (n < 0) return Fail(EULER_GPU_EINVAL, "sample_layer: n < 0");
   TypeList tl;
@@ -941,7 +955,7 @@ int euler_gpu_sample_layer(const euler_gpu_graph* g, void* stream, uint64_t seed
     return Fail(EULER_GPU_EINVAL, "sample_layer: null buffer");
   const int block = 256;
   hipLaunchKernelGGL(SampleLayerKernel, dim3(GridFor(n, block)), dim3(block), 0,
-                     (hipStream_t)stream, g->view, tl, roots_dev, n, seed, call_id,
+                     (hipStream_t)stream, g->view, tl, roots_dev, pos_dev, n, seed, call_id,
                      default_node, out_id_dev, out_w_dev, out_t_dev);
   EG_HIP(hipGetLastError());
   return EULER_GPU_OK;

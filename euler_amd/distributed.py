@@ -113,6 +113,10 @@ class ShardedSampler:
         self.node_split_fn = None
         self.local_full_neighbor = None
         self.local_sparse_feature = None
+        # layerwise sampling (see sample_neighbor_layerwise)
+        self.local_edge_sum_weight = None
+        self.sample_root_fn = None
+        self.local_sample_layer = None
         self.idx_gather_fn = None
         self.data_gather_fn = None
         self.device = torch.device("cpu")
@@ -421,6 +425,107 @@ class ShardedSampler:
             outs.append(sparse_from_core(out_idx, out_vals, int(dv)))
         return outs
 
+    # ---------------------------------------------------- layerwise sampling
+    def get_edge_sum_weight(self, nodes, edge_types):
+        """API_GET_EDGE_SUM_WEIGHT over the sharded graph: one f32 per node, by
+        the id exchange of get_dense_feature.  Needs
+        local_edge_sum_weight(owned ids, edge_types) -> f32 [m] and row_gather_fn."""
+        nodes = nodes.reshape(-1).to(torch.int64)
+        n = nodes.numel()
+        if self.dedup_split_fn is not None:
+            shard_off, shard_ids, pos = self.dedup_split_fn(nodes, self.partitions,
+                                                            self.world, None, 1)
+        else:
+            shard_off, shard_ids, merge_idx = self.split_fn(nodes, self.partitions,
+                                                            self.world)
+            pos = torch.empty_like(merge_idx)
+            pos[merge_idx.long()] = torch.arange(n, dtype=merge_idx.dtype,
+                                                 device=merge_idx.device)
+        send_counts = [int(shard_off[s + 1] - shard_off[s]) for s in range(self.world)]
+        recv_counts = self._exchange_counts(send_counts, nodes.device)
+        owned = self._exchange(shard_ids, send_counts, recv_counts)
+        sums = self.local_edge_sum_weight(owned, edge_types).reshape(-1, 1)
+        # (8-byte rows on the wire, like every other exchange of the sampler)
+        rows = torch.zeros((owned.numel(), 2), dtype=torch.float32, device=nodes.device)
+        rows[:, :1] = sums
+        back = self._exchange(rows.contiguous(), recv_counts, send_counts)
+        return self.row_gather_fn(back, pos)[:, 0].contiguous()
+
+    def sample_layer(self, roots, edge_types, default_node=-1, call_id=0):
+        """API_SAMPLE_L over the sharded graph.  The draw of a root depends on its
+        POSITION in the list (a root listed twice is sampled twice), so nothing is
+        deduplicated: ID_SPLIT buckets (id, position) by owner, the owner draws
+        with the requester's positions as RNG streams
+        (euler_gpu_sample_layer_at), IDX_MERGE / DATA_MERGE put the rows back.
+        Needs local_sample_layer(ids, positions, edge_types, default_node,
+        call_id) -> (ids, w, t)."""
+        roots = roots.reshape(-1).to(torch.int64)
+        dev = roots.device
+        shard_off, shard_ids, merge_idx = self.split_fn(roots, self.partitions, self.world)
+        send_counts = [int(shard_off[s + 1] - shard_off[s]) for s in range(self.world)]
+        recv_counts = self._exchange_counts(send_counts, dev)
+        ask = torch.stack([shard_ids.to(torch.int64), merge_idx.to(torch.int64)], dim=1)
+        got = self._exchange(ask.contiguous(), send_counts, recv_counts)
+        ids, w, t = self.local_sample_layer(got[:, 0].contiguous(), got[:, 1].contiguous(),
+                                            edge_types, default_node, call_id)
+        rows = torch.empty((ids.numel(), 4), dtype=torch.int32, device=dev)
+        rows[:, :2] = ids.to(torch.int64).reshape(-1, 1).contiguous().view(torch.int32).reshape(-1, 2)
+        rows[:, 2] = w.to(torch.float32).contiguous().view(torch.int32)
+        rows[:, 3] = t.to(torch.int32)
+        back = self._exchange(rows, recv_counts, send_counts)
+        out = self.merge_fn(back, merge_idx)
+        return (out[:, :2].contiguous().view(torch.int64).reshape(-1),
+                out[:, 2].contiguous().view(torch.float32), out[:, 3].contiguous())
+
+    def sparse_get_adj(self, nodes, nb_nodes, edge_types, n=-1, m=-1):
+        """tf_euler sparse_get_adj over the sharded graph: the SparseTensor
+        triple of the [batch, n, m] adjacency.  The rows of `nodes` come to the
+        requester through get_full_neighbor (EdgeExist is membership in the row,
+        DESIGN.md), the membership test is a join on (source, compact id) keys
+        and the TF kernel's explicit zero at (b, n-1, m-1) is added here."""
+        nodes = nodes.reshape(-1).to(torch.int64)
+        nb_nodes = nb_nodes.reshape(-1).to(torch.int64)
+        dev = nodes.device
+        n = nodes.numel() if n == -1 else int(n)
+        m = nb_nodes.numel() if m == -1 else int(m)
+        batch = nodes.numel() // n if n else 0
+        idx, ids, _w, _t = self.get_full_neighbor(nodes, edge_types)
+        R = batch * n
+        if R == 0 or m == 0:
+            z = torch.zeros
+            return z((0, 3), dtype=torch.int64, device=dev), z(0, dtype=torch.int64,
+                                                                device=dev), [0, 0, 0]
+        idx = idx.reshape(-1, 2).to(torch.int64)
+        lens = idx[:, 1] - idx[:, 0]
+        src = torch.repeat_interleave(torch.arange(R, device=dev), lens)
+        cand = nb_nodes[:batch * m]
+        _uq, inv = torch.unique(torch.cat([ids.to(torch.int64), cand]), return_inverse=True)
+        U = int(_uq.numel())
+        ent_key = src * U + inv[:ids.numel()]
+        cand_c = inv[ids.numel():].reshape(batch, m)
+        r = torch.arange(R, device=dev)
+        pair_key = r[:, None] * U + cand_c[r // n]
+        mask = torch.isin(pair_key, ent_key).reshape(batch, n, m)
+        emit = mask.clone()
+        emit[:, n - 1, m - 1] = True
+        return torch.nonzero(emit), mask[emit].to(torch.int64), [batch, n, m]
+
+    def sample_neighbor_layerwise(self, nodes, edge_types, count, default_node=-1,
+                                  call_id=0):
+        """tf_euler sample_neighbor_layerwise (weight_func == '') over the sharded
+        graph: nodes [batch, n] -> (neighbors [batch, count], adjacency triple),
+        equal to the single-GPU result: edge weight sums by id exchange, the root
+        draw locally (it needs no graph; sample_root_fn(roots, weights, m,
+        default_node, call_id)), the layer draw on the owners with the requester's
+        positions, the adjacency from the rows fetched by get_full_neighbor."""
+        nodes = nodes.to(torch.int64)
+        batch, n = nodes.shape
+        w = self.get_edge_sum_weight(nodes.reshape(-1), edge_types).reshape(batch, n)
+        l_root = self.sample_root_fn(nodes, w, int(count), default_node, call_id)
+        l_nb, _lw, _lt = self.sample_layer(l_root.reshape(-1), edge_types, default_node, call_id)
+        l_nb = l_nb.reshape(batch, int(count))
+        return l_nb, self.sparse_get_adj(nodes, l_nb, edge_types, n, int(count))
+
     # ---------------------------------------------------------- sample_node
     def sample_node(self, count, node_type=-1, call_id=0):
         """SampleNode over the shards: SAMPLE_NODE_SPLIT divides
@@ -661,6 +766,11 @@ def gpu_sharded_sampler(graph, partitions=None, group=None, dedup=True, dense_id
 
     S.local_full_neighbor = graph.get_full_neighbor
     S.local_sparse_feature = graph.get_sparse_feature_core
+    S.local_edge_sum_weight = graph.get_edge_sum_weight
+    S.sample_root_fn = lambda roots, w, m, default_node, call_id: graph.sample_root(
+        roots, w, m, default_node, call_id=call_id)
+    S.local_sample_layer = lambda ids, positions, et, default_node, call_id: graph.sample_layer(
+        ids, et, default_node, call_id=call_id, positions=positions)
     S.idx_gather_fn = ops.idx_gather
     S.data_gather_fn = ops.data_gather
     S.node_weight_sum = weight_sum

@@ -526,20 +526,25 @@ class Graph:
                 _ptr(weights), batch, n, int(m), int(default_node), _ptr(out)))
         return out
 
-    def sample_layer(self, roots, edge_types, default_node=-1, call_id=None):
+    def sample_layer(self, roots, edge_types, default_node=-1, call_id=None, positions=None):
         """API_SAMPLE_L (core/kernels/sample_layer_op.cc): one neighbour per
-        listed root (position-keyed RNG) or (default_node, 0.0, 0)."""
+        listed root (position-keyed RNG) or (default_node, 0.0, 0).  positions:
+        the RNG stream of every root (default: its index) - what the shard of a
+        multi-GPU hop receives from the requester."""
         roots = _as_i64_cuda(roots, self.device).reshape(-1)
         n = roots.numel()
+        if positions is not None:
+            positions = _as_i64_cuda(positions, self.device).reshape(-1)
+            assert positions.numel() == n
         et, et_p, k = _i32_array(edge_types)
         oid = torch.empty(n, dtype=torch.int64, device=self.device)
         ow = torch.empty(n, dtype=torch.float32, device=self.device)
         ot = torch.empty(n, dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
-            check(lib().euler_gpu_sample_layer(
+            check(lib().euler_gpu_sample_layer_at(
                 self._h, _stream(), self.seed, self._take_call_ids(1, call_id),
-                _ptr(roots), n, et_p, k, int(default_node), _ptr(oid), _ptr(ow),
-                _ptr(ot)))
+                _ptr(roots), _ptr(positions), n, et_p, k, int(default_node), _ptr(oid),
+                _ptr(ow), _ptr(ot)))
         return oid, ow, ot
 
     def local_sample_layer(self, idx, ids, w, t, batch, n, m, weight_func="sqrt",

@@ -350,6 +350,16 @@ int euler_gpu_sample_layer(const euler_gpu_graph* g, void* stream, uint64_t seed
                            int64_t default_node, uint64_t* out_id_dev,
                            float* out_w_dev, int32_t* out_t_dev);
 
+/* The same draw with explicit RNG streams: root i samples as position
+ * pos_dev[i].  A shard of a multi-GPU hop answers the requester's positions, so
+ * the sharded result equals the single-GPU one. */
+int euler_gpu_sample_layer_at(const euler_gpu_graph* g, void* stream, uint64_t seed,
+                              uint32_t call_id, const uint64_t* roots_dev,
+                              const int64_t* pos_dev, int64_t n,
+                              const int32_t* edge_types_host, int32_t k,
+                              int64_t default_node, uint64_t* out_id_dev,
+                              float* out_w_dev, int32_t* out_t_dev);
+
 /* The three ops above chained on the stream = output 0 of the TF kernel
  * SampleNeighborLayerwiseWithAdj (tf_euler/kernels/
  * sample_neighbor_layerwise_with_adj_op.cc:56-150, weight_func == ""):

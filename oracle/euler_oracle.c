@@ -936,11 +936,21 @@ void eo_sample_layer(const eo_graph* g, uint64_t seed, uint32_t call_id,
                      const uint64_t* roots, int64_t n, const int32_t* edge_types,
                      int32_t k, int64_t default_node, uint64_t* out_id,
                      float* out_w, int32_t* out_t) {
+  eo_sample_layer_at(g, seed, call_id, roots, 0, n, edge_types, k, default_node, out_id,
+                     out_w, out_t);
+}
+
+/* ... with explicit RNG streams (pos == NULL: the index): what a shard of the
+ * multi-GPU path computes for the positions its requester sent along. */
+void eo_sample_layer_at(const eo_graph* g, uint64_t seed, uint32_t call_id,
+                        const uint64_t* roots, const int64_t* pos, int64_t n,
+                        const int32_t* edge_types, int32_t k, int64_t default_node,
+                        uint64_t* out_id, float* out_w, int32_t* out_t) {
   for (int64_t i = 0; i < n; ++i) {
     int32_t got = 0;
     int64_t row = eo_graph_find_row(g, roots[i]);
     if (row >= 0) {
-      eo_rng_ctx rng = {seed, call_id, EO_DOMAIN_LAYER, (uint64_t)i, 0};
+      eo_rng_ctx rng = {seed, call_id, EO_DOMAIN_LAYER, (uint64_t)(pos ? pos[i] : i), 0};
       got = eo_sample_row(g, row, edge_types, k, 1, &rng, out_id + i, out_w + i,
                           out_t + i);
     }

@@ -153,6 +153,10 @@ void eo_sample_layer(const eo_graph* g, uint64_t seed, uint32_t call_id,
                      const uint64_t* roots, int64_t n, const int32_t* edge_types,
                      int32_t k, int64_t default_node, uint64_t* out_id,
                      float* out_w, int32_t* out_t);
+void eo_sample_layer_at(const eo_graph* g, uint64_t seed, uint32_t call_id,
+                        const uint64_t* roots, const int64_t* pos, int64_t n,
+                        const int32_t* edge_types, int32_t k, int64_t default_node,
+                        uint64_t* out_id, float* out_w, int32_t* out_t);
 int64_t eo_sparse_get_adj(const eo_graph* g, const uint64_t* roots,
                           const uint64_t* l_nb, int64_t batch, int32_t n,
                           int32_t m, const int32_t* edge_types, int32_t k,

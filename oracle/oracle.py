@@ -153,6 +153,9 @@ def lib():
         L.eo_sample_layer.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, _u64p,
                                       C.c_int64, _i32p, C.c_int32, C.c_int64, _u64p,
                                       _f32p, _i32p]
+        L.eo_sample_layer_at.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, _u64p, _i64p,
+                                         C.c_int64, _i32p, C.c_int32, C.c_int64, _u64p,
+                                         _f32p, _i32p]
         L.eo_sparse_get_adj.restype = C.c_int64
         L.eo_sparse_get_adj.argtypes = [C.c_void_p, _u64p, _u64p, C.c_int64, C.c_int32,
                                         C.c_int32, _i32p, C.c_int32, _i32p, _u64p]
@@ -671,16 +674,19 @@ class OracleGraph(_LayerwiseMixin):
                                      len(et), _p(out, _f32p))
         return out
 
-    def sample_layer(self, seed, call_id, roots, edge_types, default_node=-1):
+    def sample_layer(self, seed, call_id, roots, edge_types, default_node=-1,
+                     positions=None):
         roots = _arr(roots, np.uint64)
         et = _arr(edge_types, np.int32)
         n = len(roots)
+        pos = None if positions is None else _arr(positions, np.int64)
         oid = np.zeros(n, np.uint64)
         ow = np.zeros(n, np.float32)
         ot = np.zeros(n, np.int32)
-        lib().eo_sample_layer(self.h, seed, call_id, _p(roots, _u64p), n,
-                              _p(et, _i32p), len(et), default_node, _p(oid, _u64p),
-                              _p(ow, _f32p), _p(ot, _i32p))
+        lib().eo_sample_layer_at(self.h, seed, call_id, _p(roots, _u64p),
+                                 None if pos is None else _p(pos, _i64p), n,
+                                 _p(et, _i32p), len(et), default_node, _p(oid, _u64p),
+                                 _p(ow, _f32p), _p(ot, _i32p))
         return oid, ow, ot
 
     def sparse_get_adj(self, roots, l_nb, batch, n, m, edge_types):

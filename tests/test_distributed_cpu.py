@@ -275,6 +275,37 @@ def _worker(rank, world, port, partitions, out_dir):
         for (gi_, gv_, gs_), (wi_, wv_, ws_) in zip(got_s, want_s):
             assert np.array_equal(gi_.numpy(), wi_) and np.array_equal(gv_.numpy(), wv_)
             assert list(gs_) == list(ws_)
+    # ---- layerwise sampling: sums by id exchange, local root draw, position-keyed
+    # layer draw on the owners, adjacency from the fetched rows
+    def local_edge_sum_weight(owned, et):
+        return torch.as_tensor(OG_local.get_edge_sum_weight(owned.numpy().astype(np.uint64), et))
+
+    def sample_root_fn(r_, w_, m_, dn_, call_id):
+        out = O.sample_root(seed, call_id, r_.numpy().astype(np.uint64), w_.numpy(), r_.shape[1],
+                            m_, dn_)
+        return torch.as_tensor(out.view(np.int64).reshape(r_.shape[0], m_))
+
+    def local_sample_layer(ids_, pos_, et, dn_, call_id):
+        q_ = ids_.numpy().astype(np.uint64)
+        assert np.all(O.shard_of(q_, partitions, world) == rank)
+        a_, b_, c_ = OG_local.sample_layer(seed, call_id, q_, et, dn_, positions=pos_.numpy())
+        return torch.as_tensor(a_.view(np.int64)), torch.as_tensor(b_), torch.as_tensor(c_)
+
+    rng_l = np.random.default_rng(50 + rank)       # every rank asks for its own minibatch
+    for sampler in (S_fused, S_plain):
+        sampler.local_edge_sum_weight = local_edge_sum_weight
+        sampler.sample_root_fn = sample_root_fn
+        sampler.local_sample_layer = local_sample_layer
+        for batch_l, n_l, cnt_l, et_l in ((3, 4, 6, [0, 1, 2]), (1, 30, 12, [1]), (5, 1, 2, [2, 0])):
+            nodes_l = rng_l.choice(ids, (batch_l, n_l)).astype(np.uint64)
+            nodes_l[0, 0] = nodes_l[0, -1]
+            got_nb, (gi_, gv_, gs_) = sampler.sample_neighbor_layerwise(
+                torch.as_tensor(nodes_l.view(np.int64)), et_l, cnt_l, -1, call_id=33)
+            wnb, wi_, wv_, ws_ = OG_full.sample_neighbor_layerwise(seed, 33, nodes_l, et_l,
+                                                                   cnt_l, -1)
+            assert np.array_equal(got_nb.numpy(), wnb), (rank, batch_l, n_l)
+            assert np.array_equal(gi_.numpy(), wi_) and np.array_equal(gv_.numpy(), wv_)
+            assert list(gs_) == list(ws_)
     # ---- SampleNode over the shards: SAMPLE_NODE_SPLIT + local draws + APPEND_MERGE
     OG_local.build_node_sampler()
     shard_graphs = [O.OracleGraph(_shard_csr(O, csr, partitions, r, world)) for r in range(world)]

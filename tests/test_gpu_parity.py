@@ -593,6 +593,17 @@ def test_gpu_sharded_sampler_single_rank(EA, O, torch_cuda, big_pair):
         assert np.array_equal(t2n(got_f[0]), want_f[0])
         assert np.array_equal(t2n(got_f[1]), want_f[1])
         assert Sf.dense_table is not None and S.dense_table is None
+        # layerwise sampling through the exchange == the single-GPU op == the oracle
+        for batch_l, n_l, cnt_l, et_l in ((8, 25, 10, [0, 1]), (1, 400, 64, [2]), (5, 1, 3, [0, 1, 2, 3])):
+            nodes_l = rng.choice(ids, (batch_l, n_l)).astype(np.uint64)
+            nodes_l[0, 0] = nodes_l[0, -1]
+            nt_l = torch.as_tensor(nodes_l.view(np.int64)).cuda()
+            got_nb, (gi_, gv_, gs_) = S.sample_neighbor_layerwise(nt_l, et_l, cnt_l, -1, call_id=71)
+            one_nb, (oi_, ov_, os_) = G.sample_neighbor_layerwise(nt_l, et_l, cnt_l, -1, call_id=71)
+            wnb, wi_, wv_, ws_ = OG.sample_neighbor_layerwise(31, 71, nodes_l, et_l, cnt_l, -1)
+            assert np.array_equal(t2n(got_nb), wnb) and np.array_equal(t2n(one_nb), wnb)
+            assert np.array_equal(t2n(gi_), wi_) and np.array_equal(t2n(gv_), wv_)
+            assert np.array_equal(t2n(oi_), wi_) and list(gs_) == list(ws_) == list(os_)
         # sparse (uint64) features through the exchange: variable-length answers +
         # the TF kernel's default entries on the requester
         sper = [[list(rng.integers(0, 2 ** 63, int(rng.integers(0, 5)), dtype=np.uint64)),
