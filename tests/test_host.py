@@ -262,3 +262,19 @@ def test_product_never_imports_oracle():
                 text = open(os.path.join(dirpath, fn)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", text, re.M), fn
                 assert "libeuler_oracle" not in text and "_ref/" not in text, fn
+
+
+def test_cpp_host_example_builds():
+    """examples/cpp/sage_minibatch.cc - a C++ host over include/euler_gpu.h and the
+    HIP runtime only - compiles and links against the in-tree library (running it
+    needs a GPU: tests/test_layerwise_gpu.py::test_cpp_host_example)."""
+    import shutil
+    import subprocess
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    d = os.path.join(ROOT, "examples", "cpp")
+    subprocess.check_call(["make", "-s", "-C", d])
+    exe = os.path.join(d, "sage_minibatch")
+    assert os.path.exists(exe)
+    deps = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+    assert "libeuler_gpu.so" in deps and "torch" not in deps and "python" not in deps.lower()
