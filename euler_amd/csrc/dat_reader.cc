@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <fstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -73,6 +74,78 @@ bool KeepFile(const std::string& name, int32_t shard_index, int32_t shards) {
   if (!cur.empty()) parts.push_back(cur);
   return parts.size() == 3 && parts[2] == "dat" &&
          atoi(parts[1].c_str()) % shards == shard_index;
+}
+
+// One partition file parsed on its own (row offsets relative to the file).
+struct FilePart {
+  std::vector<uint64_t> row_id, nbr, ufeat_val;
+  std::vector<int32_t> type_end, node_type;
+  std::vector<float> prefix_w, type_prefix, node_weight, feat_val;
+  std::vector<int64_t> row_end, feat_end, ufeat_end;     // cumulative, per row
+  std::vector<std::vector<int32_t>> f_idx_rows, u_idx_rows;
+  std::string error;
+};
+
+void ParseNodeFile(const std::string& path, const std::string& fn, int32_t T, FilePart* out) {
+  std::string blob;
+  if (!ReadFile(path, &blob)) { out->error = "graph_load: cannot read " + fn; return; }
+  std::vector<int32_t> gids, gidx, in_gids, in_gidx, u64_idx, f32_idx;
+  std::vector<float> gw, nw, in_gw, in_nw, f32_val;
+  std::vector<uint64_t> nb, in_nb, u64_val;
+  Cursor f{blob.data(), blob.size()};
+  while (f.i < f.n) {
+    uint32_t len = 0;
+    if (!f.Get(&len) || f.i + len > f.n) { out->error = "graph_load: truncated record in " + fn; return; }
+    Cursor r{blob.data() + f.i, len};
+    f.i += len;
+    uint64_t id; int32_t type; float weight;
+    if (!(r.Get(&id) && r.Get(&type) && r.Get(&weight) && r.GetVec(&gids) &&
+          r.GetVec(&gw) && r.GetVec(&gidx) && r.GetVec(&nb) && r.GetVec(&nw))) {
+      out->error = "graph_load: malformed node record in " + fn; return;
+    }
+    if ((int32_t)gids.size() > T || gids.size() != gw.size() ||
+        gids.size() != gidx.size() || nb.size() != nw.size()) {
+      out->error = "graph_load: inconsistent node record in " + fn; return;
+    }
+    out->row_id.push_back(id);
+    out->node_type.push_back(type);
+    out->node_weight.push_back(weight);
+    // CompactWeightedCollection::Init(ids, weights): running f32 sums
+    float acc = 0.f;
+    int32_t last_end = 0;
+    for (int32_t t = 0; t < T; ++t) {
+      if (t < (int32_t)gids.size()) {
+        if (gids[t] != t) { out->error = "graph_load: edge group ids must be 0..T-1"; return; }
+        acc += gw[t];
+        last_end = gidx[t];
+      }
+      out->type_end.push_back(last_end);
+      out->type_prefix.push_back(acc);
+    }
+    if (last_end != (int32_t)nb.size()) { out->error = "graph_load: group index does not cover row"; return; }
+    out->nbr.insert(out->nbr.end(), nb.begin(), nb.end());
+    out->prefix_w.insert(out->prefix_w.end(), nw.begin(), nw.end());
+    out->row_end.push_back((int64_t)out->nbr.size());
+    // in-neighbour block (same five vectors), then uint64 / float / binary
+    // features (node.cc:462-523); the uint64 and float features are kept
+    if (!(r.GetVec(&in_gids) && r.GetVec(&in_gw) && r.GetVec(&in_gidx) &&
+          r.GetVec(&in_nb) && r.GetVec(&in_nw) && r.GetVec(&u64_idx) &&
+          r.GetVec(&u64_val) && r.GetVec(&f32_idx) && r.GetVec(&f32_val))) {
+      out->error = "graph_load: malformed feature block in " + fn; return;
+    }
+    if (!f32_idx.empty() && f32_idx.back() != (int32_t)f32_val.size()) {
+      out->error = "graph_load: float feature index does not cover values"; return;
+    }
+    if (!u64_idx.empty() && u64_idx.back() != (int32_t)u64_val.size()) {
+      out->error = "graph_load: uint64 feature index does not cover values"; return;
+    }
+    out->f_idx_rows.push_back(f32_idx);
+    out->feat_val.insert(out->feat_val.end(), f32_val.begin(), f32_val.end());
+    out->feat_end.push_back((int64_t)out->feat_val.size());
+    out->u_idx_rows.push_back(u64_idx);
+    out->ufeat_val.insert(out->ufeat_val.end(), u64_val.begin(), u64_val.end());
+    out->ufeat_end.push_back((int64_t)out->ufeat_val.size());
+  }
 }
 
 }  // namespace
@@ -156,78 +229,55 @@ int LoadDatDirectory(const char* data_path, int32_t shard_index, int32_t shards,
   }
   closedir(d);
   std::sort(files.begin(), files.end());
+  // The partition files are independent: up to 8 host threads parse them into
+  // per-file parts, which are then appended in file order (the order a single
+  // reader would produce).
+  const int32_t T = (int32_t)et;
+  std::vector<FilePart> parts_(files.size());
+  {
+    const size_t hw = std::max<size_t>(1, std::thread::hardware_concurrency());
+    const size_t n_thr = std::min<size_t>(std::min<size_t>(8, hw), files.size());
+    auto work = [&](size_t first) {
+      for (size_t f = first; f < files.size(); f += std::max<size_t>(n_thr, 1))
+        ParseNodeFile(node_dir + "/" + files[f], files[f], T, &parts_[f]);
+    };
+    if (n_thr <= 1) {
+      if (!files.empty()) work(0);
+    } else {
+      std::vector<std::thread> pool;
+      for (size_t t = 0; t < n_thr; ++t) pool.emplace_back(work, t);
+      for (auto& th : pool) th.join();
+    }
+  }
+  for (const FilePart& fp : parts_)
+    if (!fp.error.empty()) return Fail(EULER_GPU_EIO, fp.error);
   row_id->clear(); row_ptr->assign(1, 0); type_end->clear(); nbr->clear();
   prefix_w->clear(); type_prefix->clear(); node_type->clear(); node_weight->clear();
-  const int32_t T = (int32_t)et;
-  std::vector<int32_t> gids, gidx;
-  std::vector<float> gw, nw;
-  std::vector<uint64_t> nb;
-  // per-node float features: slot counts differ between nodes in principle, so
-  // collect ragged and square up after the scan
   std::vector<std::vector<int32_t>> f_idx_rows, u_idx_rows;
   out->feat_ptr.assign(1, 0);
   out->feat_val.clear();
   out->ufeat_ptr.assign(1, 0);
   out->ufeat_val.clear();
-  std::vector<int32_t> in_gids, in_gidx, u64_idx, f32_idx;
-  std::vector<float> in_gw, in_nw, f32_val;
-  std::vector<uint64_t> in_nb, u64_val;
-  for (const auto& fn : files) {
-    std::string blob;
-    if (!ReadFile(node_dir + "/" + fn, &blob))
-      return Fail(EULER_GPU_EIO, "graph_load: cannot read " + fn);
-    Cursor f{blob.data(), blob.size()};
-    while (f.i < f.n) {
-      uint32_t len = 0;
-      if (!f.Get(&len) || f.i + len > f.n)
-        return Fail(EULER_GPU_EIO, "graph_load: truncated record in " + fn);
-      Cursor r{blob.data() + f.i, len};
-      f.i += len;
-      uint64_t id; int32_t type; float weight;
-      if (!(r.Get(&id) && r.Get(&type) && r.Get(&weight) && r.GetVec(&gids) &&
-            r.GetVec(&gw) && r.GetVec(&gidx) && r.GetVec(&nb) && r.GetVec(&nw)))
-        return Fail(EULER_GPU_EIO, "graph_load: malformed node record in " + fn);
-      if ((int32_t)gids.size() > T || gids.size() != gw.size() ||
-          gids.size() != gidx.size() || nb.size() != nw.size())
-        return Fail(EULER_GPU_EIO, "graph_load: inconsistent node record in " + fn);
-      row_id->push_back(id);
-      node_type->push_back(type);
-      node_weight->push_back(weight);
-      // CompactWeightedCollection::Init(ids, weights): running f32 sums
-      float acc = 0.f;
-      int32_t last_end = 0;
-      for (int32_t t = 0; t < T; ++t) {
-        if (t < (int32_t)gids.size()) {
-          if (gids[t] != t)
-            return Fail(EULER_GPU_EIO, "graph_load: edge group ids must be 0..T-1");
-          acc += gw[t];
-          last_end = gidx[t];
-        }
-        type_end->push_back(last_end);
-        type_prefix->push_back(acc);
-      }
-      if (last_end != (int32_t)nb.size())
-        return Fail(EULER_GPU_EIO, "graph_load: group index does not cover row");
-      nbr->insert(nbr->end(), nb.begin(), nb.end());
-      prefix_w->insert(prefix_w->end(), nw.begin(), nw.end());
-      row_ptr->push_back((int64_t)nbr->size());
-      // in-neighbour block (same five vectors), then uint64 / float / binary
-      // features (node.cc:462-523); the uint64 and float features are kept
-      if (!(r.GetVec(&in_gids) && r.GetVec(&in_gw) && r.GetVec(&in_gidx) &&
-            r.GetVec(&in_nb) && r.GetVec(&in_nw) && r.GetVec(&u64_idx) &&
-            r.GetVec(&u64_val) && r.GetVec(&f32_idx) && r.GetVec(&f32_val)))
-        return Fail(EULER_GPU_EIO, "graph_load: malformed feature block in " + fn);
-      if (!f32_idx.empty() && f32_idx.back() != (int32_t)f32_val.size())
-        return Fail(EULER_GPU_EIO, "graph_load: float feature index does not cover values");
-      if (!u64_idx.empty() && u64_idx.back() != (int32_t)u64_val.size())
-        return Fail(EULER_GPU_EIO, "graph_load: uint64 feature index does not cover values");
-      f_idx_rows.push_back(f32_idx);
-      out->feat_val.insert(out->feat_val.end(), f32_val.begin(), f32_val.end());
-      out->feat_ptr.push_back((int64_t)out->feat_val.size());
-      u_idx_rows.push_back(u64_idx);
-      out->ufeat_val.insert(out->ufeat_val.end(), u64_val.begin(), u64_val.end());
-      out->ufeat_ptr.push_back((int64_t)out->ufeat_val.size());
+  for (FilePart& fp : parts_) {
+    const int64_t e0 = (int64_t)nbr->size();
+    const int64_t f0 = (int64_t)out->feat_val.size(), u0 = (int64_t)out->ufeat_val.size();
+    row_id->insert(row_id->end(), fp.row_id.begin(), fp.row_id.end());
+    node_type->insert(node_type->end(), fp.node_type.begin(), fp.node_type.end());
+    node_weight->insert(node_weight->end(), fp.node_weight.begin(), fp.node_weight.end());
+    type_end->insert(type_end->end(), fp.type_end.begin(), fp.type_end.end());
+    type_prefix->insert(type_prefix->end(), fp.type_prefix.begin(), fp.type_prefix.end());
+    nbr->insert(nbr->end(), fp.nbr.begin(), fp.nbr.end());
+    prefix_w->insert(prefix_w->end(), fp.prefix_w.begin(), fp.prefix_w.end());
+    out->feat_val.insert(out->feat_val.end(), fp.feat_val.begin(), fp.feat_val.end());
+    out->ufeat_val.insert(out->ufeat_val.end(), fp.ufeat_val.begin(), fp.ufeat_val.end());
+    for (size_t r = 0; r < fp.row_id.size(); ++r) {
+      row_ptr->push_back(e0 + fp.row_end[r]);
+      out->feat_ptr.push_back(f0 + fp.feat_end[r]);
+      out->ufeat_ptr.push_back(u0 + fp.ufeat_end[r]);
     }
+    for (auto& v : fp.f_idx_rows) f_idx_rows.push_back(std::move(v));
+    for (auto& v : fp.u_idx_rows) u_idx_rows.push_back(std::move(v));
+    fp = FilePart();                       // release the part's memory as we go
   }
   int32_t F = 0;
   for (const auto& v : f_idx_rows) F = std::max(F, (int32_t)v.size());

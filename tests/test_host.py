@@ -278,3 +278,40 @@ def test_cpp_host_example_builds():
     assert os.path.exists(exe)
     deps = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
     assert "libeuler_gpu.so" in deps and "torch" not in deps and "python" not in deps.lower()
+
+
+def test_dat_reader_many_partitions_keeps_file_order(O, tmp_path):
+    """The partition files are parsed by several host threads; rows must still
+    come out in file order (names sorted), every row intact, and a corrupt file
+    must be reported whichever thread meets it."""
+    rng = np.random.default_rng(5)
+    n, T, parts = 3000, 2, 24
+    ids = np.arange(1, n + 1).astype(np.uint64) * 3
+    deg = rng.integers(0, 9, (n, T))
+    seg = np.zeros(n * T + 1, np.int64)
+    seg[1:] = np.cumsum(deg.reshape(-1))
+    nbr = rng.choice(ids, int(seg[-1])).astype(np.uint64)
+    w = rng.integers(1, 9, int(seg[-1])).astype(np.float32)
+    csr = O.csr_from_raw(ids, seg, nbr, w, T, rng.integers(0, 2, n), np.ones(n))
+    write_dat_dir(tmp_path, csr, partitions=parts)
+    d = read_dat(tmp_path)
+    want = []
+    for name in sorted("data_%d.dat" % p for p in range(parts)):
+        p = int(name.split("_")[1].split(".")[0])
+        want.extend(int(v) for v in ids if int(v) % parts == p)
+    assert d["row_id"].tolist() == want
+    pos = {int(v): i for i, v in enumerate(csr.row_id)}
+    for new in rng.choice(n, 200, replace=False):
+        old = pos[int(d["row_id"][new])]
+        b, e = d["row_ptr"][new], d["row_ptr"][new + 1]
+        assert np.array_equal(d["nbr"][b:e], csr.nbr[csr.row_ptr[old]:csr.row_ptr[old + 1]])
+        assert np.array_equal(d["prefix_w"][b:e],
+                              csr.prefix_w[csr.row_ptr[old]:csr.row_ptr[old + 1]])
+        assert np.array_equal(d["type_end"][new * T:new * T + T], csr.type_end[old * T:old * T + T])
+    # shards still select whole files
+    s1 = read_dat(tmp_path, 1, 3)
+    assert all(int(v) % parts % 3 == 1 for v in s1["row_id"])
+    with open(os.path.join(str(tmp_path), "Node", "data_17.dat"), "r+b") as f:
+        f.truncate(os.path.getsize(f.name) - 3)
+    with pytest.raises(RuntimeError, match="data_17"):
+        read_dat(tmp_path)
