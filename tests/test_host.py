@@ -286,7 +286,7 @@ def test_dat_reader_many_partitions_keeps_file_order(O, tmp_path):
     must be reported whichever thread meets it."""
     rng = np.random.default_rng(5)
     n, T, parts = 3000, 2, 24
-    ids = np.arange(1, n + 1).astype(np.uint64) * 3
+    ids = np.arange(1, n + 1).astype(np.uint64) * 5
     deg = rng.integers(0, 9, (n, T))
     seg = np.zeros(n * T + 1, np.int64)
     seg[1:] = np.cumsum(deg.reshape(-1))
