@@ -55,6 +55,8 @@ SIGNATURES = {
     "euler_gpu_dat_open": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32,
                                      C.POINTER(HostCSR), i32p, C.POINTER(vp)]),
     "euler_gpu_dat_close": (None, [vp]),
+    "euler_gpu_dat_verify_edges": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, i64p, i64p,
+                                             i64p]),
     "euler_gpu_graph_destroy": (None, [vp]),
     "euler_gpu_graph_num_nodes": (C.c_int64, [vp]),
     "euler_gpu_graph_num_edges": (C.c_int64, [vp]),

@@ -223,6 +223,9 @@ struct DatGraph {
 };
 int LoadDatDirectory(const char* data_path, int32_t shard_index, int32_t shards,
                      DatGraph* out);
+int VerifyEdgeFiles(const char* data_path, int32_t shard_index, int32_t shards,
+                    const DatGraph& g, int64_t* edge_records, int64_t* not_in_rows,
+                    int64_t* row_triples);
 
 // Grid sizing for HBM-bound kernels: enough workgroups to fill 256 CUs x 8
 // resident blocks, grid-stride beyond that.

@@ -12,6 +12,7 @@
 #include <fstream>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "common.h"
@@ -301,6 +302,72 @@ int LoadDatDirectory(const char* data_path, int32_t shard_index, int32_t shards,
       out->ufeat_idx[i * U + f] = last;
     }
   }
+  return EULER_GPU_OK;
+}
+
+// Edge/*.dat against the node rows: the reference answers EdgeExist from its Edge
+// records (core/api/api.cc:46-48), this backend from the adjacency rows; the two
+// agree exactly when every Edge record (src, dst, type - the first 20 bytes of a
+// record, core/graph/edge.cc:136-153) is an entry of src's row and the rows hold
+// no further (src, dst, type) triples.
+int VerifyEdgeFiles(const char* data_path, int32_t shard_index, int32_t shards,
+                    const DatGraph& g, int64_t* edge_records, int64_t* not_in_rows,
+                    int64_t* row_triples) {
+  const std::string edge_dir = std::string(data_path) + "/Edge";
+  DIR* d = opendir(edge_dir.c_str());
+  if (!d) return Fail(EULER_GPU_EIO, "dat_verify_edges: no directory " + edge_dir);
+  std::vector<std::string> files;
+  while (dirent* ent = readdir(d)) {
+    const std::string fn(ent->d_name);
+    if (KeepFile(fn, shard_index, shards)) files.push_back(fn);
+  }
+  closedir(d);
+  std::sort(files.begin(), files.end());
+  const int32_t T = g.n_edge_types;
+  const int64_t n = (int64_t)g.row_id.size();
+  std::unordered_map<uint64_t, int64_t> row_of;
+  row_of.reserve((size_t)n * 2);
+  for (int64_t r = 0; r < n; ++r) row_of[g.row_id[r]] = r;
+  // distinct (dst) per (row, type) segment = the triples the rows hold
+  int64_t triples = 0;
+  for (int64_t r = 0; r < n; ++r) {
+    for (int32_t t = 0; t < T; ++t) {
+      const int64_t b = g.row_ptr[r] + (t == 0 ? 0 : g.type_end[r * T + t - 1]);
+      const int64_t e = g.row_ptr[r] + g.type_end[r * T + t];
+      std::vector<uint64_t> seg(g.nbr.begin() + b, g.nbr.begin() + e);
+      std::sort(seg.begin(), seg.end());
+      triples += std::unique(seg.begin(), seg.end()) - seg.begin();
+    }
+  }
+  int64_t records = 0, missing = 0;
+  for (const auto& fn : files) {
+    std::string blob;
+    if (!ReadFile(edge_dir + "/" + fn, &blob))
+      return Fail(EULER_GPU_EIO, "dat_verify_edges: cannot read " + fn);
+    Cursor f{blob.data(), blob.size()};
+    while (f.i < f.n) {
+      uint32_t len = 0;
+      if (!f.Get(&len) || f.i + len > f.n || len < 20)
+        return Fail(EULER_GPU_EIO, "dat_verify_edges: truncated record in " + fn);
+      Cursor r{blob.data() + f.i, len};
+      f.i += len;
+      uint64_t src, dst; int32_t type;
+      r.Get(&src); r.Get(&dst); r.Get(&type);
+      ++records;
+      bool found = false;
+      auto it = row_of.find(src);
+      if (it != row_of.end() && type >= 0 && type < T) {
+        const int64_t row = it->second;
+        const int64_t b = g.row_ptr[row] + (type == 0 ? 0 : g.type_end[row * T + type - 1]);
+        const int64_t e = g.row_ptr[row] + g.type_end[row * T + type];
+        for (int64_t p = b; p < e && !found; ++p) found = g.nbr[p] == dst;
+      }
+      if (!found) ++missing;
+    }
+  }
+  if (edge_records) *edge_records = records;
+  if (not_in_rows) *not_in_rows = missing;
+  if (row_triples) *row_triples = triples;
   return EULER_GPU_OK;
 }
 

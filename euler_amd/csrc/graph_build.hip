@@ -861,6 +861,17 @@ int euler_gpu_dat_open(const char* data_path, int32_t shard_index,
 
 void euler_gpu_dat_close(void* owner) { delete static_cast<DatGraph*>(owner); }
 
+int euler_gpu_dat_verify_edges(const char* data_path, int32_t shard_index, int32_t shards,
+                               int64_t* edge_records, int64_t* not_in_rows,
+                               int64_t* row_triples) {
+  if (!data_path) return Fail(EULER_GPU_EINVAL, "dat_verify_edges: null path");
+  DatGraph d;
+  int rc = LoadDatDirectory(data_path, shard_index, shards, &d);
+  if (rc != EULER_GPU_OK) return rc;
+  return VerifyEdgeFiles(data_path, shard_index, shards, d, edge_records, not_in_rows,
+                         row_triples);
+}
+
 void euler_gpu_graph_destroy(euler_gpu_graph* g) {
   {
     std::lock_guard<std::mutex> lk(g_default_mu);

@@ -140,6 +140,14 @@ int euler_gpu_dat_open(const char* data_path, int32_t shard_index,
                        int32_t shards, euler_gpu_host_csr* csr,
                        int32_t* partitions, void** owner);
 void euler_gpu_dat_close(void* owner);
+/* Host-only check of a dataset (no GPU needed): every record of the Edge partition files (the
+ * (src, dst, type) the reference's EdgeExist consults, core/api/api.cc:46-48,
+ * core/graph/edge.cc:136-153) against the node rows this backend answers
+ * SparseGetAdj from.  The two agree exactly when *not_in_rows == 0 and
+ * *edge_records == *row_triples (distinct (src, dst, type) entries of the rows). */
+int euler_gpu_dat_verify_edges(const char* data_path, int32_t shard_index, int32_t shards,
+                               int64_t* edge_records, int64_t* not_in_rows,
+                               int64_t* row_triples);
 void euler_gpu_graph_destroy(euler_gpu_graph* g);
 
 int64_t euler_gpu_graph_num_nodes(const euler_gpu_graph* g);

@@ -16,7 +16,7 @@ comes out of REFERENCE code:
                       that fixture for fixed (seed, call_id).
   random_graph.npz    a 300-node heterogeneous random graph (raw adjacency) +
                       the same kinds of reference outputs.
-  fixture_dat/        euler.meta + Node/*.dat exactly as written by the
+  fixture_dat/        euler.meta + Node/*.dat + Edge/*.dat exactly as written by the
                       reference's euler/tools for that fixture (2 partitions).
   features.npz        dense float features of both graphs as the reference holds
                       them + the rows GetFloat32Feature / TF GetDenseFeature
@@ -258,6 +258,10 @@ def main():
         shutil.copy(os.path.join(data, "euler.meta"), dst)
         for fn in sorted(os.listdir(os.path.join(data, "Node"))):
             shutil.copy(os.path.join(data, "Node", fn), os.path.join(dst, "Node"))
+        # ... and its Edge partitions (input of euler_gpu_dat_verify_edges)
+        os.makedirs(os.path.join(dst, "Edge"))
+        for fn in sorted(os.listdir(os.path.join(data, "Edge"))):
+            shutil.copy(os.path.join(data, "Edge", fn), os.path.join(dst, "Edge"))
     finally:
         shutil.rmtree(scratch, ignore_errors=True)
 

@@ -315,3 +315,29 @@ def test_dat_reader_many_partitions_keeps_file_order(O, tmp_path):
         f.truncate(os.path.getsize(f.name) - 3)
     with pytest.raises(RuntimeError, match="data_17"):
         read_dat(tmp_path)
+
+
+def test_edge_records_match_node_rows(L, tmp_path):
+    """euler_gpu_dat_verify_edges on the reference tool's own output: every Edge
+    record is an entry of its source's row and the rows hold nothing else - the
+    condition under which EdgeExist-from-rows equals the reference's EdgeExist."""
+    import shutil
+    dat = os.path.join(ROOT, "tests", "golden", "fixture_dat")
+    rec, miss, trip = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    assert L.euler_gpu_dat_verify_edges(dat.encode(), 0, 1, C.byref(rec), C.byref(miss),
+                                        C.byref(trip)) == 0
+    assert rec.value > 0 and miss.value == 0 and rec.value == trip.value
+    for shard in (0, 1):          # per shard the same holds (files split by partition)
+        assert L.euler_gpu_dat_verify_edges(dat.encode(), shard, 2, C.byref(rec), C.byref(miss),
+                                            C.byref(trip)) == 0
+        assert miss.value == 0 and rec.value == trip.value
+    # an inconsistent dataset is reported: drop one Edge partition
+    bad = str(tmp_path / "bad")
+    shutil.copytree(dat, bad)
+    open(os.path.join(bad, "Edge", "data_1.dat"), "wb").close()
+    assert L.euler_gpu_dat_verify_edges(bad.encode(), 0, 1, C.byref(rec), C.byref(miss),
+                                        C.byref(trip)) == 0
+    assert rec.value < trip.value
+    shutil.rmtree(os.path.join(bad, "Edge"))
+    assert L.euler_gpu_dat_verify_edges(bad.encode(), 0, 1, C.byref(rec), C.byref(miss),
+                                        C.byref(trip)) != 0
