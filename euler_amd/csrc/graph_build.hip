@@ -981,6 +981,21 @@ bool InitQueryProxy(const char* conf) {
   const int device = cfg.count("device") ? atoi(cfg["device"].c_str()) : 0;
   const int shard_idx = cfg.count("shard_idx") ? atoi(cfg["shard_idx"].c_str()) : 0;
   const int shard_num = cfg.count("shard_num") ? atoi(cfg["shard_num"].c_str()) : 1;
+  // verify_edges=1: refuse a dataset whose Edge records are not exactly the
+  // (src, dst, type) entries of its node rows (SparseGetAdj answers EdgeExist
+  // from the rows; see euler_gpu_dat_verify_edges)
+  if (cfg.count("verify_edges") && atoi(cfg["verify_edges"].c_str()) != 0) {
+    int64_t records = 0, missing = 0, triples = 0;
+    if (euler_gpu_dat_verify_edges(cfg["data_path"].c_str(), shard_idx, shard_num, &records,
+                                   &missing, &triples) != EULER_GPU_OK)
+      return false;
+    if (missing != 0 || records != triples) {
+      SetError("InitQueryProxy: Edge records and node rows disagree (" +
+               std::to_string(records) + " records, " + std::to_string(missing) +
+               " not in the rows, " + std::to_string(triples) + " row entries)");
+      return false;
+    }
+  }
   euler_gpu_graph* g = nullptr;
   if (euler_gpu_graph_load(cfg["data_path"].c_str(), device, shard_idx, shard_num,
                            &g) != EULER_GPU_OK)

@@ -171,8 +171,10 @@ int euler_gpu_graph_export_rows(const euler_gpu_graph* g, const uint64_t* ids_ho
 /* The reference's one process-level C entry (tf_euler/utils/
  * init_query_proxy.cc:19-37, loaded by euler_ops/base.py:33-67).  Accepts the
  * same "k=v;k=v" string (mode=local; data_path; sampler_type; data_type) plus
- * `device`, `shard_idx`, `shard_num`.  Installs the process-wide default graph
- * returned by euler_gpu_default_graph(). */
+ * `device`, `shard_idx`, `shard_num` and `verify_edges` (1: refuse a dataset whose
+ * Edge records are not exactly the entries of its node rows, see
+ * euler_gpu_dat_verify_edges).  Installs the process-wide default graph returned
+ * by euler_gpu_default_graph(). */
 bool InitQueryProxy(const char* conf);
 euler_gpu_graph* euler_gpu_default_graph(void);
 

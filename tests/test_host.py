@@ -338,6 +338,9 @@ def test_edge_records_match_node_rows(L, tmp_path):
     assert L.euler_gpu_dat_verify_edges(bad.encode(), 0, 1, C.byref(rec), C.byref(miss),
                                         C.byref(trip)) == 0
     assert rec.value < trip.value
+    # ... and InitQueryProxy(verify_edges=1) refuses it before touching the GPU
+    assert L.InitQueryProxy(("mode=local;data_path=%s;verify_edges=1" % bad).encode()) is False
+    assert b"disagree" in L.euler_gpu_last_error()
     shutil.rmtree(os.path.join(bad, "Edge"))
     assert L.euler_gpu_dat_verify_edges(bad.encode(), 0, 1, C.byref(rec), C.byref(miss),
                                         C.byref(trip)) != 0
