@@ -117,6 +117,7 @@ class ShardedSampler:
         self.local_edge_sum_weight = None
         self.sample_root_fn = None
         self.local_sample_layer = None
+        self.local_layer_fn = None
         self.idx_gather_fn = None
         self.data_gather_fn = None
         self.device = torch.device("cpu")
@@ -511,8 +512,12 @@ class ShardedSampler:
         return torch.nonzero(emit), mask[emit].to(torch.int64), [batch, n, m]
 
     def sample_neighbor_layerwise(self, nodes, edge_types, count, default_node=-1,
-                                  call_id=0):
-        """tf_euler sample_neighbor_layerwise (weight_func == '') over the sharded
+                                  call_id=0, weight_func=''):
+        """With a weight function: the rows of `nodes` are fetched
+        (get_full_neighbor) and API_LOCAL_SAMPLE_L - which needs no graph, only
+        those lists - runs on the requester (local_layer_fn(idx, ids, w, t, batch,
+        n, m, weight_func, default_node, call_id) -> (ids, w, t)).  Otherwise:
+        tf_euler sample_neighbor_layerwise (weight_func == '') over the sharded
         graph: nodes [batch, n] -> (neighbors [batch, count], adjacency triple),
         equal to the single-GPU result: edge weight sums by id exchange, the root
         draw locally (it needs no graph; sample_root_fn(roots, weights, m,
@@ -520,6 +525,12 @@ class ShardedSampler:
         positions, the adjacency from the rows fetched by get_full_neighbor."""
         nodes = nodes.to(torch.int64)
         batch, n = nodes.shape
+        if weight_func:
+            idx, ids, w_, t_ = self.get_full_neighbor(nodes.reshape(-1), edge_types)
+            l_nb, _lw, _lt = self.local_layer_fn(idx, ids, w_, t_, batch, n, int(count),
+                                                 weight_func, default_node, call_id)
+            l_nb = l_nb.reshape(batch, int(count))
+            return l_nb, self.sparse_get_adj(nodes, l_nb, edge_types, n, int(count))
         w = self.get_edge_sum_weight(nodes.reshape(-1), edge_types).reshape(batch, n)
         l_root = self.sample_root_fn(nodes, w, int(count), default_node, call_id)
         l_nb, _lw, _lt = self.sample_layer(l_root.reshape(-1), edge_types, default_node, call_id)
@@ -771,6 +782,8 @@ def gpu_sharded_sampler(graph, partitions=None, group=None, dedup=True, dense_id
         roots, w, m, default_node, call_id=call_id)
     S.local_sample_layer = lambda ids, positions, et, default_node, call_id: graph.sample_layer(
         ids, et, default_node, call_id=call_id, positions=positions)
+    S.local_layer_fn = lambda idx, ids, w, t, batch, n, m, wf, default_node, call_id: \
+        graph.local_sample_layer(idx, ids, w, t, batch, n, m, wf, default_node, call_id=call_id)
     S.idx_gather_fn = ops.idx_gather
     S.data_gather_fn = ops.data_gather
     S.node_weight_sum = weight_sum

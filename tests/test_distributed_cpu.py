@@ -306,6 +306,20 @@ def _worker(rank, world, port, partitions, out_dir):
             assert np.array_equal(got_nb.numpy(), wnb), (rank, batch_l, n_l)
             assert np.array_equal(gi_.numpy(), wi_) and np.array_equal(gv_.numpy(), wv_)
             assert list(gs_) == list(ws_)
+            # ... and with a weight function: rows fetched, API_LOCAL_SAMPLE_L on the requester
+            def local_layer_fn(idx_, ids_, w_, t_, b_, n_, m_, wf_, dn_, call_id):
+                a_, bw_, c_ = OG_full.local_sample_layer(
+                    seed, call_id, idx_.numpy(), ids_.numpy().astype(np.uint64), w_.numpy(),
+                    t_.numpy(), n_, m_, wf_, dn_)
+                return torch.as_tensor(a_.view(np.int64)), torch.as_tensor(bw_), torch.as_tensor(c_)
+            sampler.local_layer_fn = local_layer_fn
+            got_nb, (gi_, gv_, gs_) = sampler.sample_neighbor_layerwise(
+                torch.as_tensor(nodes_l.view(np.int64)), et_l, cnt_l, -1, call_id=34,
+                weight_func="sqrt")
+            wf_want = OG_full.sample_neighbor_layerwise_func(seed, 34, nodes_l, et_l, cnt_l,
+                                                             "sqrt", -1)
+            assert np.array_equal(got_nb.numpy(), wf_want[0])
+            assert np.array_equal(gi_.numpy(), wf_want[3]) and np.array_equal(gv_.numpy(), wf_want[4])
     # ---- SampleNode over the shards: SAMPLE_NODE_SPLIT + local draws + APPEND_MERGE
     OG_local.build_node_sampler()
     shard_graphs = [O.OracleGraph(_shard_csr(O, csr, partitions, r, world)) for r in range(world)]

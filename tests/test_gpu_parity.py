@@ -604,6 +604,11 @@ def test_gpu_sharded_sampler_single_rank(EA, O, torch_cuda, big_pair):
             assert np.array_equal(t2n(got_nb), wnb) and np.array_equal(t2n(one_nb), wnb)
             assert np.array_equal(t2n(gi_), wi_) and np.array_equal(t2n(gv_), wv_)
             assert np.array_equal(t2n(oi_), wi_) and list(gs_) == list(ws_) == list(os_)
+            got_nb, (gi_, gv_, gs_) = S.sample_neighbor_layerwise(nt_l, et_l, cnt_l, -1, call_id=72,
+                                                                  weight_func="sqrt")
+            wf_ = OG.sample_neighbor_layerwise_func(31, 72, nodes_l, et_l, cnt_l, "sqrt", -1)
+            assert np.array_equal(t2n(got_nb), wf_[0]) and np.array_equal(t2n(gi_), wf_[3])
+            assert np.array_equal(t2n(gv_), wf_[4])
         # sparse (uint64) features through the exchange: variable-length answers +
         # the TF kernel's default entries on the requester
         sper = [[list(rng.integers(0, 2 ** 63, int(rng.integers(0, 5)), dtype=np.uint64)),
