@@ -359,9 +359,8 @@ def _worker(rank, world, port, partitions, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("partitions", [2, 8])
-def test_sharded_fanout_matches_unsharded_gloo(O, tmp_path, partitions):
-    world = 2
+@pytest.mark.parametrize("world,partitions", [(2, 2), (2, 8), (3, 6)])
+def test_sharded_fanout_matches_unsharded_gloo(O, tmp_path, world, partitions):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, partitions, str(tmp_path)), nprocs=world,
              join=True)
