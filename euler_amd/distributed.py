@@ -58,6 +58,35 @@ def sparse_from_core(idx, vals, default_value):
     return torch.stack([rows, col], 1), values, [n, int(emit.max())]
 
 
+def adj_from_rows(idx, ids, nb_nodes, batch, n, m):
+    """The TF SparseGetAdj triple (tf_euler/kernels/sparse_get_adj_op.cc:92-124)
+    from the full-neighbour rows of the batch*n sources (idx [batch*n, 2], ids) and
+    the candidates nb_nodes [batch*m]: (b, j, c) = 1 where candidate c of batch row
+    b is in the row of source (b, j), plus the explicit 0 at (b, n-1, m-1).  The
+    membership test is an exact join: ids and candidates are renumbered together
+    (torch.unique), a pair is the key source * U + compact id."""
+    dev = idx.device
+    R = batch * n
+    if R == 0 or m == 0:
+        return (torch.zeros((0, 3), dtype=torch.int64, device=dev),
+                torch.zeros(0, dtype=torch.int64, device=dev), [0, 0, 0])
+    idx = idx.reshape(-1, 2).to(torch.int64)
+    ids = ids.reshape(-1).to(torch.int64)
+    lens = idx[:, 1] - idx[:, 0]
+    src = torch.repeat_interleave(torch.arange(R, device=dev), lens)
+    cand = nb_nodes.reshape(-1).to(torch.int64)[:batch * m]
+    uq, inv = torch.unique(torch.cat([ids, cand]), return_inverse=True)
+    U = int(uq.numel())
+    ent_key = src * U + inv[:ids.numel()]
+    cand_c = inv[ids.numel():].reshape(batch, m)
+    r = torch.arange(R, device=dev)
+    pair_key = r[:, None] * U + cand_c[r // n]
+    mask = torch.isin(pair_key, ent_key).reshape(batch, n, m)
+    emit = mask.clone()
+    emit[:, n - 1, m - 1] = True
+    return torch.nonzero(emit), mask[emit].to(torch.int64), [batch, n, m]
+
+
 class ShardedSampler:
     """Neighbor sampling over a graph sharded across the ranks of `group`.
 
@@ -491,25 +520,7 @@ class ShardedSampler:
         m = nb_nodes.numel() if m == -1 else int(m)
         batch = nodes.numel() // n if n else 0
         idx, ids, _w, _t = self.get_full_neighbor(nodes, edge_types)
-        R = batch * n
-        if R == 0 or m == 0:
-            z = torch.zeros
-            return z((0, 3), dtype=torch.int64, device=dev), z(0, dtype=torch.int64,
-                                                                device=dev), [0, 0, 0]
-        idx = idx.reshape(-1, 2).to(torch.int64)
-        lens = idx[:, 1] - idx[:, 0]
-        src = torch.repeat_interleave(torch.arange(R, device=dev), lens)
-        cand = nb_nodes[:batch * m]
-        _uq, inv = torch.unique(torch.cat([ids.to(torch.int64), cand]), return_inverse=True)
-        U = int(_uq.numel())
-        ent_key = src * U + inv[:ids.numel()]
-        cand_c = inv[ids.numel():].reshape(batch, m)
-        r = torch.arange(R, device=dev)
-        pair_key = r[:, None] * U + cand_c[r // n]
-        mask = torch.isin(pair_key, ent_key).reshape(batch, n, m)
-        emit = mask.clone()
-        emit[:, n - 1, m - 1] = True
-        return torch.nonzero(emit), mask[emit].to(torch.int64), [batch, n, m]
+        return adj_from_rows(idx, ids, nb_nodes, batch, n, m)
 
     def sample_neighbor_layerwise(self, nodes, edge_types, count, default_node=-1,
                                   call_id=0, weight_func=''):

@@ -398,3 +398,54 @@ def test_shared_memory_counts_mailbox_world8(tmp_path):
     mp.spawn(_mailbox_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert os.path.exists(tmp_path / ("ok_%d" % r))
+
+
+def test_adj_from_rows_and_sparse_from_core_vs_oracle(O):
+    """The requester-side assembly of the sharded path (pure torch, runs on the
+    CPU here): adjacency triple from fetched rows, sparse-feature triple from the
+    GQL values() layout - against the oracle on random inputs."""
+    sys.path.insert(0, ROOT)
+    from euler_amd.distributed import adj_from_rows, sparse_from_core
+    csr, ids = _build_csr(O)
+    OG = O.OracleGraph(csr)
+    rng = np.random.default_rng(12)
+    for batch, n, m in ((1, 1, 1), (3, 4, 9), (2, 17, 70), (5, 1, 3), (1, 40, 200)):
+        nodes = rng.choice(ids, (batch, n)).astype(np.uint64)
+        nodes[0, 0] = 2 ** 62 + 5
+        cand = rng.choice(ids, (batch, m)).astype(np.uint64)
+        for b in range(batch):
+            nb = OG.get_full_neighbor(nodes[b], [0, 1, 2])[1]
+            if len(nb):
+                take = rng.choice(nb, m // 2 + 1)
+                cand[b, :len(take)] = take[:m]
+        cand[-1, 0] = cand[-1, m - 1]
+        for et in ([0], [2, 1], [0, 1, 2], []):
+            idx, fid, _, _ = OG.get_full_neighbor(nodes.reshape(-1), et)
+            got = adj_from_rows(torch.as_tensor(idx), torch.as_tensor(fid.view(np.int64)),
+                                torch.as_tensor(cand.view(np.int64)), batch, n, m)
+            want = OG.sparse_get_adj_tf(nodes, cand, et, n, m)
+            assert np.array_equal(got[0].numpy(), want[0]) and np.array_equal(got[1].numpy(), want[1])
+            assert list(got[2]) == list(want[2])
+    assert adj_from_rows(torch.zeros((0, 2), dtype=torch.int32), torch.zeros(0, dtype=torch.int64),
+                         torch.zeros(0, dtype=torch.int64), 0, 3, 4)[2] == [0, 0, 0]
+    per = [[list(rng.integers(0, 2 ** 63, int(rng.integers(0, 4)), dtype=np.uint64)), [int(v)] * (i % 3)]
+           if i % 4 else [[]] for i, v in enumerate(csr.row_id)]
+    SF = O.SparseFeatures.from_lists(per)
+    q = np.concatenate([rng.choice(ids, 300), [0, 77777777]]).astype(np.uint64)
+    U = SF.n_u64
+    pos = {int(v): i for i, v in enumerate(csr.row_id)}
+    for fid, dv in ((0, 0), (1, 9), (3, -1)):
+        idx = np.zeros((len(q), 2), np.int32)
+        vals = []
+        for j, v in enumerate(q):
+            idx[j, 0] = len(vals)
+            r = pos.get(int(v))
+            if r is not None and 0 <= fid < U:
+                fi = SF.feat_idx[r * U:(r + 1) * U]
+                pre = 0 if fid == 0 else fi[fid - 1]
+                vals.extend(SF.feat_val[SF.feat_ptr[r] + pre:SF.feat_ptr[r] + fi[fid]].view(np.int64).tolist())
+            idx[j, 1] = len(vals)
+        got = sparse_from_core(torch.as_tensor(idx), torch.as_tensor(np.array(vals, np.int64)), dv)
+        want = OG.get_sparse_feature(SF, q, [fid], [dv])[0]
+        assert np.array_equal(got[0].numpy(), want[0]) and np.array_equal(got[1].numpy(), want[1])
+        assert list(got[2]) == list(want[2])
