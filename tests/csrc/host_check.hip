@@ -144,6 +144,26 @@ int hc_local_sample_layer(uint64_t seed, uint32_t call_id, const int32_t* idx,
   return 0;
 }
 
+// The per-sample logic of the generic K1 kernel (k1_variants.hip:
+// SampleNeighborKernel = InitRowSampler + SampleAt per (root, slot)) with the
+// API_SAMPLE_NB fill for empty rows (count x (0, 0.0, 0)).
+void hc_sample_neighbor_core(void* h, uint64_t seed, uint32_t call_id, const uint64_t* ids,
+                             int64_t n, const int32_t* et, int32_t k, int32_t count,
+                             uint64_t* out_id, float* out_w, int32_t* out_t) {
+  const GraphView& g = static_cast<HostGraph*>(h)->v;
+  int32_t types[kMaxListedTypes] = {0};
+  for (int32_t i = 0; i < k && i < kMaxListedTypes; ++i) types[i] = et[i];
+  for (int64_t i = 0; i < n; ++i) {
+    RowSampler rs;
+    InitRowSampler(rs, g, FindRow(g, ids[i]), types, k);
+    for (int32_t j = 0; j < count; ++j) {
+      const int64_t o = i * count + j;
+      if (!rs.valid) { out_id[o] = 0; out_w[o] = 0.f; out_t[o] = 0; continue; }
+      SampleAt(rs, seed, call_id, ids[i], j, out_id + o, out_w + o, out_t + o);
+    }
+  }
+}
+
 // mask[r * m + j] = EdgeExistAny(roots[r], l_nb[(r / n) * m + j])
 void hc_edge_exist_mask(void* h, const uint64_t* roots, const uint64_t* l_nb,
                         int64_t batch, int32_t n, int32_t m, const int32_t* et,

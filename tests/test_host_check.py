@@ -53,6 +53,8 @@ def HC():
     L.hc_local_sample_layer.argtypes = [C.c_uint64, C.c_uint32, i32p, u64p, f32p, i32p,
                                         C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                         C.c_char_p, C.c_int64, u64p, f32p, i32p]
+    L.hc_sample_neighbor_core.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, u64p, C.c_int64,
+                                          i32p, C.c_int32, C.c_int32, u64p, f32p, i32p]
     L.hc_edge_exist_mask.argtypes = [C.c_void_p, u64p, u64p, C.c_int64, C.c_int32,
                                      C.c_int32, i32p, C.c_int32, u8p]
     return L
@@ -255,3 +257,46 @@ def test_local_sample_layer_threaded_vs_reference(HC, O):
                 if x.dtype == np.float32:
                     x, y = x.view(np.uint32), np.asarray(y, np.float32).view(np.uint32)
                 assert np.array_equal(x, y)
+
+
+def test_generic_sampler_logic_host_vs_goldens_and_oracle(HC, O, fixture_csr, random_csr,
+                                                          fixture_samples, random_samples):
+    """InitRowSampler + SampleAt (device_fns.h: the per-sample logic of the generic
+    K1 kernel, every edge-type mode) compiled for the host == the reference
+    sampler's golden vectors and the oracle on a random graph."""
+    def run(H, seed, call, q, et, count):
+        q = np.ascontiguousarray(q, np.uint64)
+        et = np.ascontiguousarray(et, np.int32)
+        oid = np.zeros(len(q) * count, np.uint64)
+        ow = np.zeros(len(q) * count, np.float32)
+        ot = np.zeros(len(q) * count, np.int32)
+        HC.hc_sample_neighbor_core(H.h, seed, call, _p(q, u64p), len(q), _p(et, i32p), len(et),
+                                   count, _p(oid, u64p), _p(ow, f32p), _p(ot, i32p))
+        return oid, ow, ot
+
+    for csr, s in ((fixture_csr, fixture_samples), (random_csr, random_samples)):
+        for force_hash in (False, True):
+            H = HostBackend(HC, csr, force_hash=force_hash)
+            seed = int(s["seed"])
+            q = s["query_ids"]
+            n = 0
+            while "nb_%d_1_et" % n in s.files:
+                for count in (1, 5):
+                    key = "nb_%d_%d_" % (n, count)
+                    oid, ow, ot = run(H, seed, 11 + n, q, s[key + "et"], count)
+                    assert np.array_equal(oid, s[key + "id"]), key
+                    assert np.array_equal(ow.view(np.uint32), s[key + "w"].view(np.uint32)), key
+                    assert np.array_equal(ot, s[key + "t"]), key
+                n += 1
+            assert n >= 7
+    rng = np.random.default_rng(31)
+    ids, seg, nbr, w, nt, nw = make_random_graph(rng, 2500, 4, max_deg=30, id_space=10 ** 12)
+    csr = O.csr_from_raw(ids, seg, nbr, w, 4, nt, nw)
+    H, OG = HostBackend(HC, csr), O.OracleGraph(csr)
+    q = np.concatenate([rng.choice(ids, 1500), [0, 2 ** 63 + 5]]).astype(np.uint64)
+    for et in ([0], [3], [1, 2], [3, 0, 1], [0, 1, 2, 3], [], [2, 2], [9], [1, 9]):
+        for count in (1, 10):
+            _, oid, ow, ot = OG.sample_neighbor_core(99, 5, q, et, count)
+            hid, hw, ht = run(H, 99, 5, q, et, count)
+            assert np.array_equal(hid, oid) and np.array_equal(ht, ot), et
+            assert np.array_equal(hw.view(np.uint32), ow.view(np.uint32)), et
