@@ -344,3 +344,41 @@ def test_edge_records_match_node_rows(L, tmp_path):
     shutil.rmtree(os.path.join(bad, "Edge"))
     assert L.euler_gpu_dat_verify_edges(bad.encode(), 0, 1, C.byref(rec), C.byref(miss),
                                         C.byref(trip)) != 0
+
+
+def test_neighbor_dataflow_block_arithmetic():
+    """NeighborDataFlow.produce_subgraph (tf_euler/python/dataflow/
+    neighbor_dataflow.py:45-75: no dedup between hops) is index arithmetic only:
+    checked on the CPU against the reference's formulas written out by hand."""
+    import torch
+    from euler_amd.dataflow import NeighborDataFlow
+
+    class Fixed(NeighborDataFlow):
+        def get_neighbors(self, n_id):
+            return ([torch.tensor([7, 8, 9, 7]), torch.tensor([1, 2, 3, 4, 5, 6, 7, 8, 9])],
+                    [torch.tensor([0, 0, 1, 1]), torch.tensor([0, 1, 2, 3, 0, 1, 2, 3, 4])])
+
+    roots = torch.tensor([10, 11])
+    for loops in (True, False):
+        df = Fixed(2, add_self_loops=loops)(roots)
+        n_id = roots.numpy()
+        last_idx = np.arange(2)
+        nbrs = [np.array([7, 8, 9, 7]), np.array([1, 2, 3, 4, 5, 6, 7, 8, 9])]
+        srcs = [np.array([0, 0, 1, 1]), np.array([0, 1, 2, 3, 0, 1, 2, 3, 4])]
+        for i, blk in enumerate(df.blocks):
+            new_n_id = np.concatenate([nbrs[i], n_id])
+            new_inv = np.arange(len(new_n_id))
+            res = new_inv[-len(n_id):]
+            src = srcs[i]
+            if loops:
+                src = np.concatenate([src, last_idx])
+                last_idx = new_inv
+            else:
+                new_inv = new_inv[:-len(n_id)]
+                last_idx = new_inv
+            assert np.array_equal(blk.n_id.numpy(), new_n_id)
+            assert np.array_equal(blk.res_n_id.numpy(), res)
+            assert np.array_equal(blk.edge_index.numpy(), np.stack([src, new_inv]))
+            assert blk.size == [len(n_id), len(new_n_id)]
+            n_id = new_n_id
+        assert len(df) == 2 and [b.size for b in df] == [b.size for b in df.blocks[::-1]]
