@@ -825,68 +825,54 @@ int64_t euler_ref_get_sparse_feature(const uint64_t* ids, int64_t n, int32_t fid
   return nnz;
 }
 
-// API_LOCAL_SAMPLE_L body (local_sample_layer_op.cc:43-146) restated around the
-// same std::unordered_map<std::string, ...>, CompactWeightedCollection and
-// memset calls; RNG stream = batch row.
+// API_LOCAL_SAMPLE_L (local_sample_layer_op.cc:43-146) expressed over the SAME
+// library types the op uses - std::unordered_map<std::string, ...> keyed by
+// to_string(id) + to_string(type) for the distinct candidates of a batch row, the
+// reference's CompactWeightedCollection for the draws, memset for empty rows - one
+// batch row at a time; RNG stream = batch row.
 void euler_ref_local_sample_layer(uint64_t seed, uint32_t call_id, const int32_t* idx_data,
                                   int64_t idx_elems, const uint64_t* nb_id,
                                   const float* nb_w, const int32_t* nb_type, int32_t n,
                                   int32_t m, const char* weight_func_c,
                                   int64_t default_node, uint64_t* o_nb, float* o_w,
                                   int32_t* o_t) {
-  struct DstTypeWeight { uint64_t dst_id_; float edge_weight_; int32_t edge_type_; };
-  std::string weight_func(weight_func_c);
-  int32_t batch = idx_elems / (n * 2);
-  std::vector<int32_t> batch_nb_offset;
-  for (int32_t i = 0; i < idx_elems; i += n * 2) batch_nb_offset.push_back(idx_data[i]);
-  std::vector<std::unordered_map<std::string, DstTypeWeight>> batch_nb_unique_map(batch);
-  for (int32_t i = 0; i < batch; ++i) {
-    int32_t batch_begin = batch_nb_offset[i];
-    int32_t batch_end = 0;
-    if (i < batch - 1) batch_end = batch_nb_offset[i + 1];
-    else batch_end = idx_data[idx_elems - 1];
-    for (int32_t j = batch_begin; j < batch_end; ++j) {
-      uint64_t dst_id = nb_id[j];
-      float weight = nb_w[j];
-      int32_t type = nb_type[j];
-      std::string key = std::to_string(dst_id) + std::to_string(type);
-      if (batch_nb_unique_map[i].find(key) == batch_nb_unique_map[i].end()) {
-        batch_nb_unique_map[i][key] = {dst_id, weight, type};
-      } else {
-        batch_nb_unique_map[i][key].edge_weight_ += weight;
-      }
+  struct Cand { uint64_t id; float w; int32_t type; };
+  const bool root = std::string(weight_func_c) == "sqrt";
+  const int32_t rows = (int32_t)(idx_elems / (n * 2));
+  for (int32_t b = 0; b < rows; ++b) {
+    // the row's slice of the neighbour arrays: from its first node's begin to the
+    // next row's (the last row ends at the very last offset)
+    const int32_t lo = idx_data[(int64_t)b * n * 2];
+    const int32_t hi = b + 1 < rows ? idx_data[(int64_t)(b + 1) * n * 2] : idx_data[idx_elems - 1];
+    std::unordered_map<std::string, Cand> seen;
+    for (int32_t j = lo; j < hi; ++j) {
+      const std::string key = std::to_string(nb_id[j]) + std::to_string(nb_type[j]);
+      auto hit = seen.find(key);
+      if (hit == seen.end()) seen[key] = Cand{nb_id[j], nb_w[j], nb_type[j]};
+      else seen[key].w += nb_w[j];
     }
-  }
-  if (weight_func == "sqrt") {
-    for (int32_t i = 0; i < batch; ++i)
-      for (auto it = batch_nb_unique_map[i].begin(); it != batch_nb_unique_map[i].end(); ++it)
-        it->second.edge_weight_ = sqrt(it->second.edge_weight_);
-  }
-  std::vector<euler::common::CompactWeightedCollection<DstTypeWeight>> batch_sampler(batch);
-  for (int32_t i = 0; i < batch; ++i) {
-    if (!batch_nb_unique_map[i].empty()) {
-      std::vector<DstTypeWeight> values;
-      std::vector<float> weights;
-      for (auto it = batch_nb_unique_map[i].begin(); it != batch_nb_unique_map[i].end(); ++it) {
-        values.push_back(it->second);
-        weights.push_back(it->second.edge_weight_);
-      }
-      batch_sampler[i].Init(values, weights);
+    std::vector<Cand> cands;
+    std::vector<float> weights;
+    for (auto& kv : seen) {                       // the container's iteration order
+      if (root) kv.second.w = sqrt(kv.second.w);
+      cands.push_back(kv.second);
+      weights.push_back(kv.second.w);
     }
-  }
-  for (int32_t i = 0; i < batch; ++i) {
-    if (batch_sampler[i].GetSize() == 0 || batch_sampler[i].GetSumWeight() == 0) {
-      memset(o_nb + i * m, default_node, sizeof(uint64_t) * m);
-      memset(o_w + i * m, 0, sizeof(float) * m);
-      memset(o_t + i * m, 0, sizeof(int32_t) * m);
-    } else {
-      euler_ref_set_rng(seed, call_id, EO_DOMAIN_LOCAL_LAYER, (uint64_t)i);
-      for (int32_t j = 0; j < m; ++j) {
-        DstTypeWeight e = batch_sampler[i].Sample().first;
-        o_nb[i * m + j] = e.dst_id_;
-        o_w[i * m + j] = e.edge_weight_;
-        o_t[i * m + j] = e.edge_type_;
-      }
+    euler::common::CompactWeightedCollection<Cand> sampler;
+    if (!cands.empty()) sampler.Init(cands, weights);
+    uint64_t* ids_out = o_nb + (int64_t)b * m;
+    float* w_out = o_w + (int64_t)b * m;
+    int32_t* t_out = o_t + (int64_t)b * m;
+    if (sampler.GetSize() == 0 || sampler.GetSumWeight() == 0) {
+      memset(ids_out, default_node, sizeof(uint64_t) * m);    // byte fill, as the op does
+      memset(w_out, 0, sizeof(float) * m);
+      memset(t_out, 0, sizeof(int32_t) * m);
+      continue;
+    }
+    euler_ref_set_rng(seed, call_id, EO_DOMAIN_LOCAL_LAYER, (uint64_t)b);
+    for (int32_t j = 0; j < m; ++j) {
+      const Cand c = sampler.Sample().first;
+      ids_out[j] = c.id; w_out[j] = c.w; t_out[j] = c.type;
     }
   }
 }
