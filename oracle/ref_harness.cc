@@ -648,80 +648,64 @@ void euler_ref_sample_layer(uint64_t seed, uint32_t call_id, const uint64_t* l_r
   }
 }
 
-// API_SPARSE_GEN_ADJ + API_SPARSE_GET_ADJ bodies (sparse_gen_adj_op.cc:52-61,
-// sparse_get_adj_op.cc:55-91) over the reference's EdgeExist.  out_id == NULL
-// sizes the result.
+// API_SPARSE_GEN_ADJ + API_SPARSE_GET_ADJ (sparse_gen_adj_op.cc:52-61,
+// sparse_get_adj_op.cc:55-91) over the reference's own EdgeExist: source r belongs
+// to batch row r / n and keeps, in candidate order, the candidates of that row it
+// has an edge of a listed type to.  out_id == NULL sizes the result.
 int64_t euler_ref_sparse_get_adj(const uint64_t* roots, const uint64_t* l_nb,
                                  int64_t batch, int32_t n, int32_t m,
                                  const int32_t* edge_types, int32_t k,
                                  int32_t* idx, uint64_t* out_id) {
-  std::vector<int32_t> et(edge_types, edge_types + k);
-  size_t root_num = (size_t)(batch * n);
-  std::vector<std::vector<uint64_t>> adj(root_num);
-  for (size_t i = 0; i < root_num; ++i) {
-    uint64_t root_id = roots[i];
-    int32_t batch_num = (int32_t)(i / n);
-    int32_t l_nb_batch_begin = batch_num * m;
-    for (int32_t j = 0; j < m; ++j) {
-      uint64_t nb_id = l_nb[l_nb_batch_begin + j];
-      bool exist = false;
-      for (int32_t e_type : et) {
-        euler::EdgeId eid(root_id, nb_id, e_type);
-        exist = exist || euler::EdgeExist(eid);
-      }
-      if (exist) adj[i].push_back(nb_id);
+  int64_t written = 0;
+  for (int64_t r = 0; r < batch * n; ++r) {
+    const uint64_t* cand = l_nb + (r / n) * m;
+    if (idx) idx[2 * r] = (int32_t)written;
+    for (int32_t c = 0; c < m; ++c) {
+      bool linked = false;
+      for (int32_t x = 0; x < k; ++x)
+        linked = linked || euler::EdgeExist(euler::EdgeId(roots[r], cand[c], edge_types[x]));
+      if (!linked) continue;
+      if (out_id) out_id[written] = cand[c];
+      ++written;
     }
+    if (idx) idx[2 * r + 1] = (int32_t)written;
   }
-  int32_t offset = 0;
-  for (size_t i = 0; i < root_num; ++i) {
-    if (idx) { idx[i * 2] = offset; idx[i * 2 + 1] = offset + (int32_t)adj[i].size(); }
-    if (out_id) std::copy(adj[i].begin(), adj[i].end(), out_id + offset);
-    offset += (int32_t)adj[i].size();
-  }
-  return offset;
+  return written;
 }
 
-// Sparse assembly of the TF kernels (tf_euler/kernels/sparse_get_adj_op.cc:
-// 92-124 = sample_neighbor_layerwise_with_adj_op.cc:112-140) with the same
-// std::set and the SparseTensorBuilder shape rule (tf_euler/utils/
-// sparse_tensor_builder.h:30-40).  indices == NULL sizes the result.
+// The sparse assembly of the TF kernels (tf_euler/kernels/sparse_get_adj_op.cc:
+// 92-124 = sample_neighbor_layerwise_with_adj_op.cc:112-140): per batch row a
+// std::set of (source id, neighbour id) pairs taken from the core result, a 1 for
+// every (j, c) whose pair is in the set, a 0 at the last (j, c) otherwise; the
+// shape follows SparseTensorBuilder (tf_euler/utils/sparse_tensor_builder.h:30-40:
+// largest index + 1 per dimension).  indices == NULL sizes the result.
 int64_t euler_ref_adj_to_sparse(const uint64_t* nodes, const uint64_t* nb_nodes,
                                 int64_t batch_size, int32_t N, int32_t M,
                                 const int32_t* idx_data, const uint64_t* val_data,
                                 int64_t* indices, int64_t* values, int64_t* shape) {
-  std::set<std::pair<int64_t, int64_t>> relation_set;
-  int64_t nnz = 0;
-  int64_t dense_shape[3] = {0, 0, 0};
-  auto emplace = [&](int64_t a, int64_t b, int64_t c, int64_t v) {
-    const int64_t ix[3] = {a, b, c};
-    for (int d = 0; d < 3; ++d) {
-      if (indices) indices[3 * nnz + d] = ix[d];
-      if (ix[d] + 1 > dense_shape[d]) dense_shape[d] = ix[d] + 1;
-    }
-    if (values) values[nnz] = v;
-    ++nnz;
-  };
-  for (int64_t i = 0; i < batch_size; ++i) {
-    relation_set.clear();
-    for (int64_t j = N * i; j < N * (i + 1); ++j) {
-      int32_t begin = idx_data[j * 2];
-      int32_t end = idx_data[j * 2 + 1];
-      for (int32_t k = begin; k < end; ++k)
-        relation_set.insert(std::make_pair((int64_t)nodes[j], (int64_t)val_data[k]));
+  int64_t nnz = 0, extent[3] = {0, 0, 0};
+  for (int64_t b = 0; b < batch_size; ++b) {
+    std::set<std::pair<int64_t, int64_t>> pairs;
+    for (int64_t j = 0; j < N; ++j) {
+      const int64_t r = b * N + j;
+      for (int32_t p = idx_data[2 * r]; p < idx_data[2 * r + 1]; ++p)
+        pairs.insert({(int64_t)nodes[r], (int64_t)val_data[p]});
     }
     for (int64_t j = 0; j < N; ++j) {
-      int64_t src_id = (int64_t)nodes[j + N * i];
-      for (int64_t k = 0; k < M; ++k) {
-        int64_t dst_id = (int64_t)nb_nodes[k + M * i];
-        if (relation_set.find(std::make_pair(src_id, dst_id)) != relation_set.end()) {
-          emplace(i, j, k, 1);
-        } else if (j == N - 1 && k == M - 1) {
-          emplace(i, j, k, 0);
+      for (int64_t c = 0; c < M; ++c) {
+        const bool one = pairs.count({(int64_t)nodes[b * N + j], (int64_t)nb_nodes[b * M + c]}) > 0;
+        if (!one && !(j == N - 1 && c == M - 1)) continue;
+        const int64_t at[3] = {b, j, c};
+        for (int d = 0; d < 3; ++d) {
+          if (indices) indices[3 * nnz + d] = at[d];
+          if (at[d] + 1 > extent[d]) extent[d] = at[d] + 1;
         }
+        if (values) values[nnz] = one ? 1 : 0;
+        ++nnz;
       }
     }
   }
-  if (shape) { shape[0] = dense_shape[0]; shape[1] = dense_shape[1]; shape[2] = dense_shape[2]; }
+  if (shape) { shape[0] = extent[0]; shape[1] = extent[1]; shape[2] = extent[2]; }
   return nnz;
 }
 
