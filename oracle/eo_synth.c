@@ -5,7 +5,7 @@
  * (SURVEY.md §8d configs 2/3): every quantity is a pure function of
  * (seed, node id, edge slot), so the CPU baseline and the GPU run sample the
  * SAME graph and any row can be regenerated on the host for a spot check.
- * The device mirror is euler_amd/csrc/synth_graph.hip; tests compare the two
+ * The device mirror is euler_amd/csrc/graph_build.hip; tests compare the two
  * bit-for-bit.
  *
  * Model: RMAT(a,b,c,d = 0.57,0.19,0.19,0.05) marginals.  In RMAT the source

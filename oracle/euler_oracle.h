@@ -235,7 +235,7 @@ double eo_bench_fanout(const eo_graph* g, uint64_t seed,
                        int64_t* edges);
 
 /* Deterministic synthetic power-law graph (eo_synth.c), mirrored bit-for-bit
- * by the device generator in euler_amd/csrc/synth_graph.hip. */
+ * by the device generator in euler_amd/csrc/graph_build.hip. */
 typedef struct eo_synth_params {
   uint64_t seed;
   int64_t n_nodes;        /* ids are 1..n_nodes */
