@@ -50,8 +50,14 @@ def parse():
                     help="roots per step per GPU")
     ap.add_argument("--nodes", type=int, default=100_000_000)
     ap.add_argument("--edges", type=int, default=1_000_000_000)
-    ap.add_argument("--cpu-nodes", type=int, default=4_000_000,
-                    help="graph size of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-nodes", type=int, default=20_000_000,
+                    help="graph size of the CPU baseline (SURVEY 8(d): 20M nodes / 200M "
+                         "edges; reduced automatically when the host's RAM does not hold it)")
+    ap.add_argument("--cpu-protocol", choices=["quick", "full"], default="quick",
+                    help="full = 5 warm-up + 30 timed rounds for every cell (minutes)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the K-step timed loop is repeated this many times; the line "
+                         "reports the median repetition (and lists all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--pipeline", type=int, default=3,
@@ -60,102 +66,201 @@ def parse():
                          "stream): while the host waits for one batch's bucket sizes "
                          "the GPU runs the others' kernels and exchanges (one rank: 0.61 ms "
                          "/ step with 1, 0.47 with 2, 0.46 with 3 or 4)")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="functional check only: when fewer GPUs are visible than --gpus, "
+                         "let the ranks share them (rank r on GPU r %% visible) with a "
+                         "gloo host-staged transport (RCCL refuses two ranks per device); "
+                         "the line then says so and is not a scaling number")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU sampler (unique / split / all-to-all / "
                          "merge / gather) even on one rank: measures its overhead")
     return ap.parse_args()
 
 
+def _stats(secs, edges_per_round):
+    """median / p10 / p90 of per-round wall times -> edges/s (p10 of the time is
+    the p90 of the rate)."""
+    secs = np.sort(np.asarray(secs, np.float64))
+    med = float(np.median(secs))
+    return {"edges_per_s": edges_per_round / med,
+            "p10_edges_per_s": edges_per_round / float(np.percentile(secs, 90)),
+            "p90_edges_per_s": edges_per_round / float(np.percentile(secs, 10)),
+            "median_ms_per_round": med * 1e3, "rounds": int(len(secs)),
+            "edges_per_round": int(edges_per_round)}
+
+
 def cpu_baseline(args):
-    """Reference sampler on the host: same synthetic family, smaller graph
-    (the reference's per-node objects cannot hold 100M nodes: SURVEY F8).  Two
-    thread counts are timed - 8, the reference's client pool
-    (client/query_proxy.cc:209), and 32, where its throughput peaks on this
-    host (tools/cpu_scaling.py: 8 -> 133, 32 -> 370, 64 -> 321, 256 -> 223 M
-    edges/s on the 1M-node graph) - and the better one is the baseline."""
+    """SURVEY 8(d) protocol.  The reference sampler (oracle/_ref = the reference's
+    own sources + RNG seam) and the GPU run the SAME graph (device generator ==
+    host generator, tests/test_gpu_parity.py::test_synthetic_graph_matches_host_
+    generator), the SAME roots and the SAME batch sizes (B = 1 024, the batch of
+    every reference example, and B = 131 072, the metric's), and the same DAG:
+    per hop ID_UNIQUE -> API_SAMPLE_NB -> DATA_GATHER (parser/compiler.cc:76-90;
+    oracle/ref_harness.cc: euler_ref_bench_fanout_dag).  Two named CPU numbers
+    per batch size:
+      as_shipped  USE_OPENMP off: 8 concurrent single-threaded queries (the
+                  client pool, client/query_proxy.cc:205-210)
+      best        the better of (a) more concurrent queries, (b) -DOPENMP batch
+                  loop over `omp_threads` threads, one query at a time
+    Rounds: 5 warm-up + 30 timed (median, p10 / p90) - except the cells of
+    B = 131 072, which take seconds per round: --cpu-protocol quick (default)
+    gives them 1 + 5 rounds, --cpu-protocol full the whole 5 + 30."""
     from oracle import oracle as O
     cores = os.cpu_count() or 1
     n = args.cpu_nodes
+    try:
+        import psutil
+        avail = psutil.virtual_memory().available
+    except Exception:
+        avail = 0
+    fit_note = "%d nodes / ~%d edges" % (n, 10 * n)
+    # the reference's Node objects + unordered_map + our staging arrays: ~1.3 KB / node
+    if avail and n * 1400 > avail * 0.8:
+        n = max(1_000_000, int(avail * 0.8 / 1400) // 1_000_000 * 1_000_000)
+        fit_note = "%d nodes (host has %.0f GB available: %d would not fit)" % (
+            n, avail / 2 ** 30, args.cpu_nodes)
+    if not O.have_ref():
+        return {"value": None, "unit": "sampled edges/s", "cores": cores, "kind": "reference",
+                "error": "oracle/_ref/libeuler_ref.so missing"}
+    build_threads = min(32, cores)
+    t0 = time.time()
     po = O.synth_params(GRAPH_SEED, n, 10 * n, weighted=True)
-    csr = O.synth_csr(po)
+    csr = O.synth_csr(po, threads=build_threads)
+    # per-edge weights as f32 differences of the running sums (timing only: the
+    # reference's Node::Init re-accumulates them)
+    w = csr.prefix_w.copy()
+    w[1:] -= csr.prefix_w[:-1]
+    starts = csr.row_ptr[:-1]
+    w[starts] = csr.prefix_w[starts]
+    n_edges = int(len(csr.nbr))
+    R = O.RefGraph.build_raw(csr.row_id, csr.row_ptr, csr.nbr, w, 1, threads=build_threads,
+                             build_sampler=False)
+    del csr, w
+    build_s = time.time() - t0
+    full = args.cpu_protocol == "full"
     rng = np.random.default_rng(1)
-    batch = 1024
-    kind = "port"
-    if O.have_ref():
-        T = 1
-        seg = csr.row_ptr.copy()
-        # per-edge weights as f32 differences of the running sums (timing
-        # only: the reference's Node::Init re-accumulates them)
-        w = csr.prefix_w.copy()
-        w[1:] -= csr.prefix_w[:-1]
-        starts = csr.row_ptr[:-1]
-        w[starts] = csr.prefix_w[starts]
-        R = O.RefGraph.build_raw(csr.row_id, seg, csr.nbr, w, T)
-        bench = R.bench_fanout
-        kind = "reference"
-    else:
-        bench = O.OracleGraph(csr).bench_fanout
-    runs = []
-    for threads, iters in ((min(8, cores), 1024), (min(32, cores), 8192)):
-        if runs and threads == runs[0][0]:
-            continue
-        roots = rng.integers(1, n + 1, batch * iters).astype(np.uint64)
-        bench(GRAPH_SEED, roots[:batch * 4], batch, 4, FANOUT, threads)   # warm-up
-        secs, edges = bench(GRAPH_SEED, roots, batch, iters, FANOUT, threads)
-        runs.append((threads, iters, secs, edges / secs))
-    best = max(runs, key=lambda x: x[3])
-    # the GPU on the SAME graph (SURVEY 8d: the >= 10x claim is made on an identical
-    # graph; the device generator builds the graph the host generator built)
-    same = None
+    shipped_threads = min(8, cores)
+    many = min(32, cores)
+    cells = {}
+    roots_by_b = {}
+    for B in (1024, 131072):
+        nb = 64 if B == 1024 else 8
+        roots = rng.integers(1, n + 1, B * nb).astype(np.uint64)
+        roots_by_b[B] = roots
+        big = B > 4096
+        wu, timed = (5, 30) if (full or not big) else (1, 5)
+        cell = {}
+        secs, e = R.bench_fanout_dag(GRAPH_SEED, roots, B, FANOUT, shipped_threads, 0, True, wu, timed)
+        cell["as_shipped"] = dict(_stats(secs, e), threads=shipped_threads,
+                                  what="%d concurrent single-threaded queries" % shipped_threads)
+        cands = []
+        if many > shipped_threads and not big:
+            secs, e = R.bench_fanout_dag(GRAPH_SEED, roots, B, FANOUT, many, 0, True, wu, timed)
+            cands.append(dict(_stats(secs, e), threads=many,
+                              what="%d concurrent single-threaded queries" % many))
+        secs, e = R.bench_fanout_dag(GRAPH_SEED, roots, B, FANOUT, many, 1, True,
+                                     wu if not big else max(wu, 2), timed if not big else max(timed, 10))
+        cands.append(dict(_stats(secs, e), threads=many,
+                          what="-DOPENMP batch loop, %d threads, one query at a time" % many))
+        cell["best"] = max(cands + [cell["as_shipped"]], key=lambda c: c["edges_per_s"])
+        cell["other"] = [c for c in cands if c is not cell["best"]]
+        cells[B] = cell
+    del R
+    # ---- the GPU on the SAME graph, roots and batch sizes (call ids as the harness':
+    # query q, hop h -> call_id 2 q + h), per-step times from HIP events on the stream
+    same = {}
     try:
         import euler_amd
         Gs = euler_amd.Graph.synthetic(euler_amd.synth_params(GRAPH_SEED, n, 10 * n, weighted=True))
         Gs.set_seed(GRAPH_SEED)
-        gen = torch.Generator(device="cuda")
-        gen.manual_seed(99)
-        B = args.batch
-        r = torch.randint(1, n + 1, (24, B), generator=gen, device="cuda", dtype=torch.int64)
-        for i in range(4):
-            Gs.sample_fanout(r[i], [[0], [0]], FANOUT, n + 1, call_id=2 * i)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(4, 24):
-            Gs.sample_fanout(r[i], [[0], [0]], FANOUT, n + 1, call_id=2 * i)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 20
-        same = {"value": B * (FANOUT[0] + FANOUT[0] * FANOUT[1]) / dt, "ms_per_step": dt * 1e3,
-                "roots_per_step": B, "ratio_to_cpu": B * (FANOUT[0] + FANOUT[0] * FANOUT[1]) / dt / best[3]}
+        for B, roots in roots_by_b.items():
+            r = torch.as_tensor(roots.astype(np.int64)).cuda().reshape(-1, B)
+            nb = r.shape[0]
+            for i in range(5):
+                Gs.sample_fanout(r[i % nb], [[0], [0]], FANOUT, n + 1, call_id=2 * i)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(31)]
+            torch.cuda.synchronize()
+            ev[0].record()
+            for i in range(30):
+                Gs.sample_fanout(r[i % nb], [[0], [0]], FANOUT, n + 1, call_id=2 * i)
+                ev[i + 1].record()
+            torch.cuda.synchronize()
+            secs = [ev[i].elapsed_time(ev[i + 1]) * 1e-3 for i in range(30)]
+            g = _stats(secs, B * (FANOUT[0] + FANOUT[0] * FANOUT[1]))
+            g["ratio_to_cpu_as_shipped"] = g["edges_per_s"] / cells[B]["as_shipped"]["edges_per_s"]
+            g["ratio_to_cpu_best"] = g["edges_per_s"] / cells[B]["best"]["edges_per_s"]
+            same[B] = g
         del Gs
     except Exception as e:                 # the baseline itself must not fail the bench
         same = {"error": str(e)}
-    return {"value": best[3], "unit": "sampled edges/s", "cores": best[0],
-            "kind": kind, "gpu_same_graph": same,
-            "sample": "%d minibatches x %d roots, fanout [25,10] (%.1f s of wall time on %d "
-                      "threads), synthetic power-law graph of the same family with %d nodes / "
-                      "%d edges (the reference's Node objects for it build in seconds; the "
-                      "100M-node graph does not fit them); other thread counts: %s; host has "
-                      "%d cores"
-                      % (best[1], batch, best[2], best[0], n, len(csr.nbr),
-                         ", ".join("%d threads -> %.0f M edges/s" % (r[0], r[3] / 1e6)
-                                   for r in runs if r is not best) or "none", cores)}
+    head = cells[131072]["best"]
+    return {"value": head["edges_per_s"], "unit": "sampled edges/s", "cores": head["threads"],
+            "kind": "reference", "host_cores": cores,
+            "graph": "synthetic power-law graph of the metric's family, %s, %d edges built "
+                     "(reference Node objects, %.1f s with %d threads)" % (fit_note, n_edges, build_s,
+                                                                           build_threads),
+            "protocol": "SURVEY 8(d): ID_UNIQUE -> API_SAMPLE_NB -> DATA_GATHER per hop, same graph / "
+                        "roots / batch on CPU and GPU; 5 warm-up + 30 timed rounds, median (p10, p90)"
+                        + ("" if full else "; B = 131072 cells: 1 + 5 rounds (as shipped) / 2 + 10 "
+                           "(OpenMP) - pass --cpu-protocol full for 5 + 30"),
+            "B1024": {"cpu": cells[1024], "gpu_same_graph": same.get(1024, same)},
+            "B131072": {"cpu": cells[131072], "gpu_same_graph": same.get(131072, same)},
+            "sample": "value = best CPU configuration at B = 131072 (%s); as shipped (8 query "
+                      "threads): %.3g edges/s; B = 1024: as shipped %.3g, best %.3g edges/s"
+                      % (head["what"], cells[131072]["as_shipped"]["edges_per_s"],
+                         cells[1024]["as_shipped"]["edges_per_s"], cells[1024]["best"]["edges_per_s"])}
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks
+    ourselves (torch.distributed.run, one process per GPU, rendezvous on
+    127.0.0.1) and pass their output through.  Returns the exit code."""
+    import socket
+    import subprocess
+    visible = torch.cuda.device_count()
+    if visible < args.gpus and not args.oversubscribe:
+        print("bench.py: --gpus %d but only %d GPU(s) visible (use --oversubscribe for a "
+              "functional check on fewer devices)" % (args.gpus, visible), file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    visible = torch.cuda.device_count()
+    shared_gpus = world > visible           # ranks share devices: functional check only
+    if shared_gpus and not args.oversubscribe:
+        raise SystemExit("bench.py: %d ranks but %d GPU(s) visible (pass --oversubscribe)"
+                         % (world, visible))
+    local_rank %= visible
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     sharded = world > 1 or args.force_sharded
+    backend = "gloo" if shared_gpus else "nccl"
     if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import euler_amd
     from euler_amd import _lib
@@ -225,11 +330,16 @@ def main():
         run(0, args.warmup)
         sync()
         gc.collect(); gc.freeze(); gc.disable()      # a gen-2 collection costs ~40 ms
-        t0 = time.perf_counter()
-        out = run(args.warmup, n_steps)
-        sync()
-        elapsed = time.perf_counter() - t0
+        wire0 = sum(s_.bytes_sent for s_ in samplers)
+        rep_secs = []
+        for _rep in range(max(1, args.repeats)):
+            sync()
+            t0 = time.perf_counter()
+            out = run(args.warmup, n_steps)
+            sync()
+            rep_secs.append(time.perf_counter() - t0)
         gc.enable()
+        wire_bytes = (sum(s_.bytes_sent for s_ in samplers) - wire0) / len(rep_secs)
         if trace is not None and rank == 0:
             tail = trace[-(n_steps - args.warmup):]
             print("trace (step, ms since previous job started, device allocs so far):",
@@ -243,16 +353,29 @@ def main():
             out = step(i)
         sync()
         gc.collect(); gc.freeze(); gc.disable()      # a gen-2 collection costs ~40 ms
-        t0 = time.perf_counter()
-        for i in range(args.warmup, n_steps):
-            out = step(i)
-        sync()
-        elapsed = time.perf_counter() - t0
+        rep_secs = []
+        for _rep in range(max(1, args.repeats)):
+            sync()
+            t0 = time.perf_counter()
+            for i in range(args.warmup, n_steps):
+                out = step(i)
+            sync()
+            rep_secs.append(time.perf_counter() - t0)
         gc.enable()
+    exchanged = None
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        wire_dev = dev if backend == "nccl" else "cpu"
+        t = torch.tensor(rep_secs, device=wire_dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)          # slowest rank, per repetition
+        rep_secs = [float(x) for x in t.tolist()]
+    # EXACTLY K steps were timed, `repeats` times over; the line reports the median
+    elapsed = float(np.median(rep_secs))
+    if world > 1:
+        t = torch.tensor([float(wire_bytes)], device=wire_dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        exchanged = float(t.item()) / args.steps          # bytes / step, all ranks
+    elif sharded:
+        exchanged = 0.0                                   # one rank: self exchanges only
     edges_per_step = B * (FANOUT[0] + FANOUT[0] * FANOUT[1]) * world
     value = edges_per_step * args.steps / elapsed
 
@@ -406,7 +529,8 @@ def main():
         line = {
             "metric": "sampled edges/sec (whole node), 2-hop fanout=[25,10], "
                       "100M-node power-law graph",
-            "value": value, "unit": "sampled edges/s", "n_gpus": world,
+            "value": value, "unit": "sampled edges/s",
+            "n_gpus": min(world, visible),
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -427,6 +551,15 @@ def main():
                                 "hash owner(id)=id%%%d, all-to-all per hop, %d minibatches "
                                 "in flight" % (world, args.pipeline),
                 "parity_checked_edges": checked,
+                "repeats": len(rep_secs),
+                "repeat_ms_per_step": [round(x / args.steps * 1e3, 4) for x in rep_secs],
+                "ranks": world,
+                "transport": (None if not sharded else
+                              "RCCL all-to-all (%d ranks in the communicator)" % dist.get_world_size()
+                              if backend == "nccl" else
+                              "gloo, host-staged: %d ranks share %d GPU(s) - functional check, "
+                              "NOT a scaling number" % (world, visible)),
+                "exchanged_bytes_per_step": exchanged,
             },
             "roofline": roofline, "cpu_baseline": cpu,
         }

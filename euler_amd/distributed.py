@@ -150,6 +150,32 @@ class ShardedSampler:
         self.idx_gather_fn = None
         self.data_gather_fn = None
         self.device = torch.device("cpu")
+        # transport: RCCL moves device tensors directly; a gloo group (ranks that
+        # share one GPU in the world-2-on-one-GPU tests, or CPU test doubles)
+        # carries device tensors staged through the host
+        self.host_staged = dist.get_backend(group) == "gloo"
+        # wire statistics (rows this rank handed to / took from its peers, self
+        # exchanges excluded): bench.py reports bytes exchanged per step
+        self.bytes_sent = 0
+        self.bytes_received = 0
+        self.exchanges = 0
+        # call ids: every sampling call without an explicit call_id takes fresh
+        # ones from this counter (by hops for a fanout, by steps for a walk), like
+        # Graph._take_call_ids - identically on all ranks, because every rank makes
+        # the same sequence of collective calls
+        self._call_id = 0
+
+    def set_call_id(self, call_id):
+        """Restart the implicit call-id sequence (reproducible runs); call it with
+        the same value on every rank."""
+        self._call_id = int(call_id) & 0xFFFFFFFF
+
+    def _take_call_ids(self, n, call_id=None):
+        if call_id is not None:
+            return int(call_id) & 0xFFFFFFFF
+        c = self._call_id
+        self._call_id = (self._call_id + int(n)) & 0xFFFFFFFF
+        return c
 
     # -------------------------------------------------------------- helpers
     def _exchange_counts(self, send_counts, device):
@@ -161,7 +187,8 @@ class ShardedSampler:
             return [int(c) for c in send_counts]
         if self.counts_fn is not None:
             return self.counts_fn(send_counts)
-        sc = torch.tensor(send_counts, dtype=torch.int64, device=device)
+        sc = torch.tensor(send_counts, dtype=torch.int64,
+                          device="cpu" if self.host_staged else device)
         rc = torch.empty_like(sc)
         dist.all_to_all_single(rc, sc, group=self.group)
         return [int(x) for x in rc.tolist()]
@@ -170,12 +197,21 @@ class ShardedSampler:
         """all-to-all(v) of rows; counts are in rows."""
         out_rows = int(sum(recv_counts))
         shape = (out_rows,) + tuple(send.shape[1:])
-        recv = torch.empty(shape, dtype=send.dtype, device=send.device)
-        dist.all_to_all_single(recv, send.contiguous(),
+        row_bytes = send.element_size()
+        for d in send.shape[1:]:
+            row_bytes *= int(d)
+        me = self.rank
+        self.bytes_sent += row_bytes * (int(sum(send_counts)) - int(send_counts[me]))
+        self.bytes_received += row_bytes * (out_rows - int(recv_counts[me]))
+        self.exchanges += 1
+        staged = self.host_staged and send.is_cuda
+        src = send.contiguous().cpu() if staged else send.contiguous()
+        recv = torch.empty(shape, dtype=send.dtype, device=src.device)
+        dist.all_to_all_single(recv, src,
                                output_split_sizes=[int(c) for c in recv_counts],
                                input_split_sizes=[int(c) for c in send_counts],
                                group=self.group)
-        return recv
+        return recv.to(send.device) if staged else recv
 
     @staticmethod
     def _pack(ids, w, t, mask, count):
@@ -212,7 +248,7 @@ class ShardedSampler:
             return stop.value
 
     def sample_neighbor(self, roots, edge_types, count, default_node=-1,
-                        call_id=0, root_mask=None, root_group=1):
+                        call_id=None, root_mask=None, root_group=1):
         """One hop for this rank's `roots` ([n] int64).  root_mask ([n /
         root_group] uint8) marks roots that stand for a missing row of the
         previous hop: they sample as node id 0 (the reference chains hops on
@@ -227,7 +263,7 @@ class ShardedSampler:
                                                     call_id, root_mask, root_group))
 
     def sample_neighbor_steps(self, roots, edge_types, count, default_node=-1,
-                              call_id=0, root_mask=None, root_group=1):
+                              call_id=None, root_mask=None, root_group=1):
         """The hop as a generator that yields ONCE, at the only place the host
         has to wait (the bucket sizes of the front end) - after enqueueing the
         front end when the sampler has a two-phase one (front_begin_fn /
@@ -235,6 +271,7 @@ class ShardedSampler:
         the other generators there.  The yield is unconditional (also for an
         empty batch or a sampler without a two-phase front end): every rank must
         issue its collectives in the same order."""
+        call_id = self._take_call_ids(1, call_id)
         roots = roots.reshape(-1).to(torch.int64)
         n = roots.numel()
         gather_idx = None
@@ -299,14 +336,15 @@ class ShardedSampler:
         ids, w, t, mask = self._unpack(rows, count)
         return ids, w, t, mask
 
-    def sample_fanout(self, roots, edge_types, counts, default_node=-1, call_id=0):
+    def sample_fanout(self, roots, edge_types, counts, default_node=-1, call_id=None):
         """Multi-hop fanout (tf_euler sample_fanout): returns (neighbors_list,
         weights_list, types_list) flattened like euler_ops.sample_fanout."""
         return self._run(self.sample_fanout_steps(roots, edge_types, counts, default_node,
                                                   call_id))
 
-    def sample_fanout_steps(self, roots, edge_types, counts, default_node=-1, call_id=0):
+    def sample_fanout_steps(self, roots, edge_types, counts, default_node=-1, call_id=None):
         """sample_fanout as a generator: one yield per hop (sample_neighbor_steps)."""
+        call_id = self._take_call_ids(len(counts), call_id)
         roots = roots.reshape(-1).to(torch.int64)
         neighbors, weights, types = [roots], [], []
         mask, group = None, 1
@@ -481,7 +519,7 @@ class ShardedSampler:
         back = self._exchange(rows.contiguous(), recv_counts, send_counts)
         return self.row_gather_fn(back, pos)[:, 0].contiguous()
 
-    def sample_layer(self, roots, edge_types, default_node=-1, call_id=0):
+    def sample_layer(self, roots, edge_types, default_node=-1, call_id=None):
         """API_SAMPLE_L over the sharded graph.  The draw of a root depends on its
         POSITION in the list (a root listed twice is sampled twice), so nothing is
         deduplicated: ID_SPLIT buckets (id, position) by owner, the owner draws
@@ -489,6 +527,7 @@ class ShardedSampler:
         (euler_gpu_sample_layer_at), IDX_MERGE / DATA_MERGE put the rows back.
         Needs local_sample_layer(ids, positions, edge_types, default_node,
         call_id) -> (ids, w, t)."""
+        call_id = self._take_call_ids(1, call_id)
         roots = roots.reshape(-1).to(torch.int64)
         dev = roots.device
         shard_off, shard_ids, merge_idx = self.split_fn(roots, self.partitions, self.world)
@@ -523,7 +562,7 @@ class ShardedSampler:
         return adj_from_rows(idx, ids, nb_nodes, batch, n, m)
 
     def sample_neighbor_layerwise(self, nodes, edge_types, count, default_node=-1,
-                                  call_id=0, weight_func=''):
+                                  call_id=None, weight_func=''):
         """With a weight function: the rows of `nodes` are fetched
         (get_full_neighbor) and API_LOCAL_SAMPLE_L - which needs no graph, only
         those lists - runs on the requester (local_layer_fn(idx, ids, w, t, batch,
@@ -534,6 +573,7 @@ class ShardedSampler:
         draw locally (it needs no graph; sample_root_fn(roots, weights, m,
         default_node, call_id)), the layer draw on the owners with the requester's
         positions, the adjacency from the rows fetched by get_full_neighbor."""
+        call_id = self._take_call_ids(1, call_id)
         nodes = nodes.to(torch.int64)
         batch, n = nodes.shape
         if weight_func:
@@ -549,7 +589,7 @@ class ShardedSampler:
         return l_nb, self.sparse_get_adj(nodes, l_nb, edge_types, n, int(count))
 
     # ---------------------------------------------------------- sample_node
-    def sample_node(self, count, node_type=-1, call_id=0):
+    def sample_node(self, count, node_type=-1, call_id=None):
         """SampleNode over the shards: SAMPLE_NODE_SPLIT divides
         `count` in proportion to the shards' weight sums of the type (remainder
         by RNG domain SPLIT, core/kernels/sample_node_split_op.cc:57-85), every
@@ -558,9 +598,11 @@ class ShardedSampler:
         gets the same [count] tensor.  Needs local_sample_node(count, node_type,
         call_id), node_weight_sum(node_type) and node_split_fn(call_id, count,
         weights[world + 1]) -> counts[world]."""
+        call_id = self._take_call_ids(1, call_id)
         dev = self.device
+        wire = torch.device("cpu") if self.host_staged else dev
         mine = torch.tensor([float(self.node_weight_sum(node_type))], dtype=torch.float32,
-                            device=dev)
+                            device=wire)
         allw = [torch.empty_like(mine) for _ in range(self.world)]
         dist.all_gather(allw, mine, group=self.group)
         w = torch.cat(allw).cpu().numpy().astype("float32")
@@ -572,18 +614,19 @@ class ShardedSampler:
         own = self.local_sample_node(split[self.rank], node_type, call_id) \
             if split[self.rank] > 0 else torch.empty(0, dtype=torch.int64, device=dev)
         width = max(max(split), 1)
-        pad = torch.zeros(width, dtype=torch.int64, device=dev)
-        pad[:own.numel()] = own
+        pad = torch.zeros(width, dtype=torch.int64, device=wire)
+        pad[:own.numel()] = own.to(wire)
         parts = [torch.empty_like(pad) for _ in range(self.world)]
         dist.all_gather(parts, pad, group=self.group)
-        return torch.cat([parts[s][:split[s]] for s in range(self.world)])
+        return torch.cat([parts[s][:split[s]] for s in range(self.world)]).to(dev)
 
-    def random_walk(self, nodes, edge_types, default_node=-1, call_id=0):
+    def random_walk(self, nodes, edge_types, default_node=-1, call_id=None):
         """tf_euler random_walk with p = q = 1 (TraditionalRandomWalk,
         tf_euler/kernels/random_walk_op.cc:207-247) over the sharded graph: one
         id / result exchange per step; edge_types is a list (walk_len) of
         per-step edge type lists.  Returns [n, walk_len + 1] int64, identical
         to the single-GPU kernel (step s uses call_id + s)."""
+        call_id = self._take_call_ids(max(len(edge_types), 1), call_id)
         nodes = nodes.reshape(-1).to(torch.int64)
         cols = [nodes]
         cur, mask = nodes, None

@@ -210,6 +210,14 @@ def ref():
                                              C.c_int32, _i64p]
         R.euler_ref_set_rng.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32,
                                         C.c_uint64]
+        if hasattr(R, "euler_ref_bench_fanout_dag"):
+            R.euler_ref_bench_fanout_dag.restype = C.c_int64
+            R.euler_ref_bench_fanout_dag.argtypes = [
+                C.c_uint64, _u64p, C.c_int64, C.c_int64, _i32p, C.c_int32, C.c_int32,
+                C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
+            R.euler_ref_graph_build_mt.argtypes = [
+                C.c_int64, _u64p, _i32p, _f32p, C.c_int32, C.c_int32, _i64p, _u64p, _f32p,
+                C.c_int32, C.c_int32]
         R.euler_ref_get_neighbor.restype = C.c_int64
         R.euler_ref_get_neighbor.argtypes = [_u64p, C.c_int64, _i32p, C.c_int32,
                                              C.c_int32, C.c_int32, C.c_int64, _i32p,
@@ -910,11 +918,44 @@ def synth_params(seed, n_nodes, n_edges, n_types=1, weighted=True, scale=None):
     return p
 
 
-def synth_csr(p, row_begin=0, row_end=None):
-    """Rows [row_begin,row_end) of the synthetic graph as a CSR (ids row+1)."""
+def synth_csr(p, row_begin=0, row_end=None, threads=1):
+    """Rows [row_begin,row_end) of the synthetic graph as a CSR (ids row+1).
+    threads > 1: row ranges are generated concurrently (every quantity is a pure
+    function of (seed, node, slot); ctypes releases the GIL)."""
     if row_end is None:
         row_end = p.n_nodes
     n = row_end - row_begin
+    if threads > 1 and n >= 4 * threads:
+        from concurrent.futures import ThreadPoolExecutor
+        L = lib()
+        cuts = [row_begin + n * i // threads for i in range(threads + 1)]
+        with ThreadPoolExecutor(threads) as ex:
+            tots = list(ex.map(lambda i: L.eo_synth_build(C.byref(p), cuts[i], cuts[i + 1], None,
+                                                          None, None, None, None),
+                               range(threads)))
+            offs = np.concatenate([[0], np.cumsum(tots)]).astype(np.int64)
+            tot = int(offs[-1])
+            T = p.n_types
+            row_ptr = np.zeros(n + 1, np.int64)
+            type_end = np.zeros(n * T, np.int32)
+            nbr = np.zeros(tot, np.uint64)
+            prefix = np.zeros(tot, np.float32)
+            tpre = np.zeros(n * T, np.float32)
+            tmp_ptr = [np.zeros(cuts[i + 1] - cuts[i] + 1, np.int64) for i in range(threads)]
+
+            def fill(i):
+                r0 = cuts[i] - row_begin
+                m = cuts[i + 1] - cuts[i]
+                L.eo_synth_build(C.byref(p), cuts[i], cuts[i + 1], _p(tmp_ptr[i], _i64p),
+                                 _p(type_end[r0 * T:(r0 + m) * T], _i32p),
+                                 _p(nbr[offs[i]:offs[i + 1]], _u64p),
+                                 _p(prefix[offs[i]:offs[i + 1]], _f32p),
+                                 _p(tpre[r0 * T:(r0 + m) * T], _f32p))
+                row_ptr[r0:r0 + m] = tmp_ptr[i][:m] + offs[i]
+            list(ex.map(fill, range(threads)))
+        row_ptr[n] = tot
+        row_id = np.arange(row_begin + 1, row_end + 1, dtype=np.uint64)
+        return CSR(row_id, row_ptr, type_end, nbr, prefix, tpre, p.n_types)
     tot = lib().eo_synth_build(C.byref(p), row_begin, row_end, None, None, None,
                                None, None)
     row_ptr = np.zeros(n + 1, np.int64)
@@ -937,7 +978,9 @@ class RefGraph(_LayerwiseMixin):
 
     @staticmethod
     def build_raw(row_id, seg_ptr, nbr, w, n_types, node_type=None,
-                  node_weight=None):
+                  node_weight=None, threads=1, build_sampler=True):
+        """threads > 1: the Node objects are constructed by that many threads
+        (euler_ref_graph_build_mt; same graph)."""
         row_id = _arr(row_id, np.uint64)
         n = len(row_id)
         nt = (_arr(node_type, np.int32) if node_type is not None
@@ -948,10 +991,16 @@ class RefGraph(_LayerwiseMixin):
         nbr = _arr(nbr, np.uint64)
         w = _arr(w, np.float32)
         n_node_types = int(nt.max()) + 1 if n else 1
-        rc = ref().euler_ref_graph_build(n, _p(row_id, _u64p), _p(nt, _i32p),
-                                         _p(nw, _f32p), n_types, n_node_types,
-                                         _p(seg_ptr, _i64p), _p(nbr, _u64p),
-                                         _p(w, _f32p))
+        if threads > 1 or not build_sampler:
+            rc = ref().euler_ref_graph_build_mt(
+                n, _p(row_id, _u64p), _p(nt, _i32p), _p(nw, _f32p), n_types, n_node_types,
+                _p(seg_ptr, _i64p), _p(nbr, _u64p), _p(w, _f32p), int(threads),
+                1 if build_sampler else 0)
+        else:
+            rc = ref().euler_ref_graph_build(n, _p(row_id, _u64p), _p(nt, _i32p),
+                                             _p(nw, _f32p), n_types, n_node_types,
+                                             _p(seg_ptr, _i64p), _p(nbr, _u64p),
+                                             _p(w, _f32p))
         assert rc == 0
         return RefGraph(n_types)
 
@@ -1218,6 +1267,24 @@ class RefGraph(_LayerwiseMixin):
                                     _p(et, _i32p), et.shape[1], walk_len, p, q,
                                     default_node, _p(out, _i64p))
         return out
+
+    def bench_fanout_dag(self, seed, roots, batch, counts, threads, mode, dedup=True,
+                         warmup=5, timed=30):
+        """SURVEY 8(d) CPU-baseline protocol (euler_ref_bench_fanout_dag): the
+        ID_UNIQUE -> API_SAMPLE_NB -> DATA_GATHER DAG per hop.  mode 0 = `threads`
+        concurrent single-threaded queries per round ("as shipped"), mode 1 = one
+        query per round with the OpenMP batch loop over `threads` threads.
+        Returns (seconds of every timed round [timed], sampled edges per round)."""
+        roots = _arr(roots, np.uint64)
+        cnt = _arr(counts, np.int32)
+        n_batches = len(roots) // batch
+        assert n_batches >= 1
+        secs = np.zeros(timed, np.float64)
+        edges = ref().euler_ref_bench_fanout_dag(
+            seed, _p(roots, _u64p), batch, n_batches, _p(cnt, _i32p), len(cnt), int(threads),
+            int(mode), 1 if dedup else 0, int(warmup), int(timed),
+            secs.ctypes.data_as(C.POINTER(C.c_double)))
+        return secs, int(edges)
 
     def bench_fanout(self, seed, roots, batch, iters, counts, threads):
         roots = _arr(roots, np.uint64)

@@ -26,7 +26,11 @@
 #include <string.h>
 
 #include <cmath>
+#include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <set>
 #include <string>
 #include <thread>
@@ -551,6 +555,217 @@ double euler_ref_bench_fanout(uint64_t seed, const uint64_t* roots,
   for (auto v : per_thread) total += v;
   *edges = total;
   return std::chrono::duration<double>(t1 - t0).count();
+}
+
+// CPU baseline on SURVEY 8(d)'s protocol.  One QUERY = the DAG the reference's
+// optimizer builds for `v(roots).sampleNB(...).sampleNB(...)`: per hop
+// ID_UNIQUE -> API_SAMPLE_NB over the distinct ids -> IDX_GATHER / DATA_GATHER
+// (parser/compiler.cc:76-90).  The pieces follow
+//   ID_UNIQUE     core/kernels/id_unique_op.cc:35-64 (unordered_map, first
+//                 occurrence order, gather_idx per position),
+//   API_SAMPLE_NB core/api/api.cc:223-236 batch loop over Node::SampleNeighbor,
+//                 empty rows -> count x (0, 0.0f, 0) (sample_neighbor_op.cc:134-143),
+//                 FillNeighbor's flat id / weight / type arrays (common.cc:275-334),
+//   DATA_GATHER   core/kernels/data_gather_op.cc:33-80 (row copies through
+//                 gather_idx; rows are `count` wide, so IDX_GATHER is arithmetic).
+// mode 0 "as shipped" (USE_OPENMP off, CMakeLists.txt:15): `threads` query
+//   threads - the client pool has 8, client/query_proxy.cc:205-210 - each runs
+//   one whole query per round; a round ends when all have finished.
+// mode 1 "best case" (-DOPENMP): one query at a time, the api.cc batch loop is
+//   an `omp parallel for` over `threads` threads; ID_UNIQUE / gathers stay
+//   serial, as they are in the reference.
+// rounds = warmup + timed; secs_out[timed] receives each timed round's wall
+// time.  Query q of a round reads roots[(q % n_batches) * batch ...].  Returns
+// the sampled edges (sum of rows x count over hops) ONE round produces.
+namespace {
+struct HopResult {
+  std::vector<uint64_t> ids;
+  std::vector<float> w;
+  std::vector<int32_t> t;
+};
+
+void SampleRows(uint64_t seed, uint32_t call_id, const std::vector<uint64_t>& roots,
+                const std::vector<int32_t>& et, int32_t count, bool omp,
+                int32_t threads, HopResult* out) {
+  const int64_t n = (int64_t)roots.size();
+  out->ids.resize(n * count);
+  out->w.resize(n * count);
+  out->t.resize(n * count);
+  auto body = [&](int64_t i) {
+    auto* node = G().GetNodeByID(roots[i]);
+    std::vector<euler::common::IDWeightPair> res;
+    if (node != nullptr) {
+      euler_ref_set_rng(seed, call_id, EO_DOMAIN_NEIGHBOR, roots[i]);
+      res = node->SampleNeighbor(et, count);
+    }
+    uint64_t* oi = out->ids.data() + i * count;
+    float* ow = out->w.data() + i * count;
+    int32_t* ot = out->t.data() + i * count;
+    if (res.empty()) {
+      for (int32_t j = 0; j < count; ++j) { oi[j] = 0; ow[j] = 0.f; ot[j] = 0; }
+    } else {
+      for (int32_t j = 0; j < count; ++j) {
+        oi[j] = std::get<0>(res[j]); ow[j] = std::get<1>(res[j]); ot[j] = std::get<2>(res[j]);
+      }
+    }
+  };
+  if (omp) {
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int64_t i = 0; i < n; ++i) body(i);
+  } else {
+    for (int64_t i = 0; i < n; ++i) body(i);
+  }
+}
+
+int64_t RunDagQuery(uint64_t seed, uint32_t call_base, const uint64_t* roots, int64_t batch,
+                    const int32_t* counts, int32_t hops, bool dedup, bool omp,
+                    int32_t threads, uint64_t* checksum) {
+  std::vector<int32_t> et(1, 0);
+  std::vector<uint64_t> frontier(roots, roots + batch);
+  int64_t produced = 0;
+  uint64_t sum = 0;
+  for (int32_t h = 0; h < hops; ++h) {
+    const int32_t count = counts[h];
+    HopResult full;
+    if (dedup) {
+      // ID_UNIQUE
+      std::unordered_map<uint64_t, int32_t> ids_map;
+      ids_map.reserve(frontier.size());
+      std::vector<uint64_t> unique_vec;
+      unique_vec.reserve(frontier.size());
+      std::vector<int32_t> gather_idx(frontier.size());
+      int32_t cnt = 0;
+      for (size_t i = 0; i < frontier.size(); ++i) {
+        auto it = ids_map.find(frontier[i]);
+        if (it == ids_map.end()) {
+          ids_map[frontier[i]] = cnt++;
+          unique_vec.push_back(frontier[i]);
+        }
+      }
+      for (size_t i = 0; i < frontier.size(); ++i) gather_idx[i] = ids_map.at(frontier[i]);
+      HopResult uq;
+      SampleRows(seed, call_base + h, unique_vec, et, count, omp, threads, &uq);
+      // DATA_GATHER x3 (ids, weights, types)
+      const size_t n = frontier.size();
+      full.ids.resize(n * count); full.w.resize(n * count); full.t.resize(n * count);
+      for (size_t i = 0; i < n; ++i) {
+        const size_t b = (size_t)gather_idx[i] * count;
+        std::copy(uq.ids.begin() + b, uq.ids.begin() + b + count, full.ids.begin() + i * count);
+      }
+      for (size_t i = 0; i < n; ++i) {
+        const size_t b = (size_t)gather_idx[i] * count;
+        std::copy(uq.w.begin() + b, uq.w.begin() + b + count, full.w.begin() + i * count);
+      }
+      for (size_t i = 0; i < n; ++i) {
+        const size_t b = (size_t)gather_idx[i] * count;
+        std::copy(uq.t.begin() + b, uq.t.begin() + b + count, full.t.begin() + i * count);
+      }
+    } else {
+      SampleRows(seed, call_base + h, frontier, et, count, omp, threads, &full);
+    }
+    produced += (int64_t)full.ids.size();
+    for (size_t i = 0; i < full.ids.size(); i += 997) sum += full.ids[i];
+    frontier.swap(full.ids);
+  }
+  if (checksum) *checksum += sum;
+  return produced;
+}
+}  // namespace
+
+int64_t euler_ref_bench_fanout_dag(uint64_t seed, const uint64_t* roots, int64_t batch,
+                                   int64_t n_batches, const int32_t* counts, int32_t hops,
+                                   int32_t threads, int32_t mode, int32_t dedup,
+                                   int32_t warmup, int32_t timed, double* secs_out) {
+  if (threads < 1) threads = 1;
+  const int32_t rounds = warmup + timed;
+  const int32_t queries_per_round = mode == 0 ? threads : 1;
+  int64_t per_round = 0;
+  uint64_t sink = 0;
+  if (mode == 1) {
+    for (int32_t r = 0; r < rounds; ++r) {
+      auto t0 = std::chrono::steady_clock::now();
+      int64_t e = RunDagQuery(seed, (uint32_t)(r * hops), roots + (r % n_batches) * batch, batch,
+                              counts, hops, dedup != 0, true, threads, &sink);
+      auto t1 = std::chrono::steady_clock::now();
+      per_round = e;
+      if (r >= warmup) secs_out[r - warmup] = std::chrono::duration<double>(t1 - t0).count();
+    }
+    return per_round + (sink == 0x7fffffffffffffffULL ? 1 : 0);
+  }
+  // mode 0: persistent query threads, two barriers per round
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0, generation = 0;
+  auto barrier = [&]() {
+    std::unique_lock<std::mutex> lk(mu);
+    int gen = generation;
+    if (++arrived == threads + 1) { arrived = 0; ++generation; cv.notify_all(); }
+    else cv.wait(lk, [&] { return gen != generation; });
+  };
+  std::vector<int64_t> produced(threads, 0);
+  std::vector<uint64_t> sums(threads, 0);
+  auto work = [&](int tid) {
+    for (int32_t r = 0; r < rounds; ++r) {
+      barrier();
+      int64_t q = (int64_t)r * queries_per_round + tid;
+      produced[tid] = RunDagQuery(seed, (uint32_t)(q * hops), roots + (q % n_batches) * batch,
+                                  batch, counts, hops, dedup != 0, false, 1, &sums[tid]);
+      barrier();
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; ++t) pool.emplace_back(work, t);
+  for (int32_t r = 0; r < rounds; ++r) {
+    barrier();
+    auto t0 = std::chrono::steady_clock::now();
+    barrier();
+    auto t1 = std::chrono::steady_clock::now();
+    if (r >= warmup) secs_out[r - warmup] = std::chrono::duration<double>(t1 - t0).count();
+  }
+  for (auto& th : pool) th.join();
+  for (int t = 0; t < threads; ++t) { per_round += produced[t]; sink += sums[t]; }
+  return per_round + (sink == 0x7fffffffffffffffULL ? 1 : 0);
+}
+
+// The same graph build as euler_ref_graph_build with the Node objects
+// constructed by `threads` threads (Node::Init is per node); AddNode and
+// BuildGlobalSampler stay serial.  For the 20M-node baseline graph.
+int euler_ref_graph_build_mt(int64_t n, const uint64_t* ids, const int32_t* node_type,
+                             const float* node_weight, int32_t T, int32_t n_node_types,
+                             const int64_t* seg_ptr, const uint64_t* nbr, const float* w,
+                             int32_t threads, int32_t build_sampler) {
+  euler_ref_graph_clear();
+  auto& g = G();
+  g.reserveNodeMap(n);
+  std::vector<euler::Node*> nodes(n, nullptr);
+  std::atomic<int> bad(0);
+  auto work = [&](int tid) {
+    std::vector<std::vector<uint64_t>> nb(T);
+    std::vector<std::vector<float>> nw(T);
+    std::vector<std::vector<uint64_t>> f_u64;
+    std::vector<std::vector<float>> f_f32;
+    std::vector<std::string> f_bin;
+    int64_t b0 = n * tid / threads, e0 = n * (tid + 1) / threads;
+    for (int64_t i = b0; i < e0; ++i) {
+      for (int t = 0; t < T; ++t) {
+        int64_t b = seg_ptr[i * T + t], e = seg_ptr[i * T + t + 1];
+        nb[t].assign(nbr + b, nbr + e);
+        nw[t].assign(w + b, w + e);
+      }
+      auto* node = new euler::Node(ids[i], node_weight[i], node_type[i]);
+      if (!node->Init(nb, nw, f_u64, f_f32, f_bin)) bad = 1;
+      nodes[i] = node;
+    }
+  };
+  if (threads < 1) threads = 1;
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; ++t) pool.emplace_back(work, t);
+  for (auto& th : pool) th.join();
+  if (bad) return -1;
+  for (int64_t i = 0; i < n; ++i) g.AddNode(nodes[i]);
+  SetTypeMaps(n_node_types, T);
+  if (build_sampler) g.BuildGlobalSampler();
+  return 0;
 }
 
 // ---------------------------------------------------------------- layerwise

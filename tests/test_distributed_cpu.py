@@ -194,6 +194,19 @@ def _worker(rank, world, port, partitions, out_dir):
                 assert np.array_equal(got[j][0][h + 1].numpy(), on[h]), (rank, j, h)
                 assert np.array_equal(got[j][1][h].numpy(), ow[h])
                 assert np.array_equal(got[j][2][h].numpy(), ot[h])
+    # calls without an explicit call_id draw fresh ids from the sampler's counter
+    # (by hops for a fanout): two consecutive default calls differ, and equal the
+    # explicit calls a single-GPU Graph would have made
+    S.set_call_id(700)
+    d1 = S.sample_fanout(torch.as_tensor(roots), et_i, cnt_i, -1)
+    d2 = S.sample_fanout(torch.as_tensor(roots), et_i, cnt_i, -1)
+    d3 = S.sample_neighbor(torch.as_tensor(roots), [0, 1, 2], 3, -1)
+    assert not np.array_equal(d1[0][1].numpy(), d2[0][1].numpy())
+    for got_d, cid in ((d1, 700), (d2, 702)):
+        on, _, _ = OG_full.sample_fanout(seed, cid, roots, et_i, cnt_i, -1)
+        assert np.array_equal(got_d[0][1].numpy(), on[0]) and np.array_equal(got_d[0][2].numpy(), on[1])
+    on3, _, _ = OG_full.sample_neighbor(seed, 704, roots, [0, 1, 2], 3, -1)
+    assert np.array_equal(d3[0].numpy().reshape(-1), np.asarray(on3).reshape(-1))
     # DeepWalk (config 4): p = q = 1 random walk over the sharded graph, one
     # exchange per step, identical to the unsharded walk
     L = 6

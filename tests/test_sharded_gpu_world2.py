@@ -1,0 +1,242 @@
+"""The multi-GPU sampler with world > 1 and the REAL HIP pieces, on one GPU.
+
+Two (or three) processes share cuda:0.  Each builds its shard of the graph
+(euler_gpu_graph_create_shard / _create_synthetic with shard_index = rank), and a
+hop runs euler_gpu_dedup_split -> id exchange -> euler_gpu_sample_neighbor_packed
+on the owner -> row exchange -> euler_gpu_expand_packed.  RCCL refuses two ranks
+on one device, so the transport is gloo over host-staged tensors
+(ShardedSampler.host_staged); everything else is the code an N-GPU run executes.
+The sharded result must equal the unsharded GPU graph's and the oracle's, bit
+for bit: owner(id) = (id % partitions) % shards as core/kernels/id_split_op.cc:46-49,
+merge order as idx_merge_op.cc:32-78 / data_merge_op.cc:44-67.
+
+Covers BASELINE configs 3 (fanout [25,10]), 4 (random_walk length 40) and 5
+(typed sampling: one listed type, 3 of 8, all) in their sharded form, empty
+buckets, a rank with an empty batch, non-self exchanges and both id maps."""
+import os
+import socket
+import sys
+import traceback
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def t2n(t):
+    return t.detach().cpu().numpy()
+
+
+def _same(got, want, what):
+    import torch
+    for h, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a.reshape(-1), b.reshape(-1)), (what, h)
+
+
+def _worker(rank, world, port, partitions, err_dir):
+    try:
+        _worker_body(rank, world, port, partitions)
+    except BaseException:
+        with open(os.path.join(err_dir, "rank%d.err" % rank), "w") as f:
+            f.write(traceback.format_exc())
+        raise
+
+
+def _worker_body(rank, world, port, partitions):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import euler_amd as EA
+    from euler_amd.distributed import gpu_sharded_sampler, run_interleaved
+    from oracle import oracle as O
+    from conftest import make_random_graph
+    dev = torch.device("cuda", 0)
+
+    # ---------------- config 3 shape: weighted single-type power-law graph
+    N = 300_000
+    p = EA.synth_params(20240521, N, 10 * N, weighted=True)
+    G_full = EA.Graph.synthetic(p)
+    G_shard = EA.Graph.synthetic(p, partitions=partitions, shard_index=rank, shards=world)
+    assert G_shard.num_nodes < G_full.num_nodes
+    G_full.set_seed(5)
+    G_shard.set_seed(5)
+    S = gpu_sharded_sampler(G_shard, partitions=partitions)
+    assert S.host_staged and S.world == world
+    rng = np.random.default_rng(100 + rank)                 # every rank its own batch
+    B = 20_000
+    roots = torch.as_tensor(rng.integers(1, N + 1, B).astype(np.int64)).to(dev)
+    et2 = [[0], [0]]
+    want = G_full.sample_fanout(roots, et2, [25, 10], N + 1, call_id=6)
+    got = S.sample_fanout(roots, et2, [25, 10], N + 1, call_id=6)
+    _same(got[0], want[0], "fanout ids")
+    _same(got[1], want[1], "fanout weights")
+    _same(got[2], want[2], "fanout types")
+    assert S.bytes_sent > 0 and S.bytes_received > 0        # rows really crossed ranks
+    # ... and against the oracle (host generator == device generator)
+    po = O.SynthParams()
+    for f, _ in po._fields_:
+        setattr(po, f, getattr(p, f))
+    OG = O.OracleGraph(O.synth_csr(po))
+    sel = t2n(roots)[:300]
+    on, ow, ot = OG.sample_fanout(5, 6, sel, et2, [25, 10], N + 1)
+    assert np.array_equal(t2n(got[0][1])[:300 * 25], on[0])
+    assert np.array_equal(t2n(got[0][2])[:300 * 250], on[1])
+    assert np.array_equal(t2n(got[1][1])[:300 * 250], ow[1])
+
+    # the same fanout with several minibatches in flight (what bench.py runs)
+    samplers = [gpu_sharded_sampler(G_shard, partitions=partitions) for _ in range(2)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    batches = [torch.as_tensor(rng.integers(1, N + 1, 3000 + 500 * j).astype(np.int64)).to(dev)
+               for j in range(4)]
+    torch.cuda.synchronize()
+    res = run_interleaved(
+        lambda j: samplers[j % 2].sample_fanout_steps(batches[j], et2, [25, 10], N + 1,
+                                                      call_id=40 + 2 * j),
+        4, 2, enter=lambda k: torch.cuda.stream(streams[k]))
+    for st in streams:
+        st.synchronize()
+    for j in range(4):
+        w = G_full.sample_fanout(batches[j], et2, [25, 10], N + 1, call_id=40 + 2 * j)
+        _same(res[j][0], w[0], "interleaved ids %d" % j)
+
+    # implicit call ids advance identically on all ranks and re-randomise the sample
+    S.set_call_id(1000)
+    a = S.sample_fanout(roots[:2000], et2, [5, 3], N + 1)
+    b = S.sample_fanout(roots[:2000], et2, [5, 3], N + 1)
+    assert not torch.equal(a[0][1], b[0][1])
+    _same(a[0], G_full.sample_fanout(roots[:2000], et2, [5, 3], N + 1, call_id=1000)[0], "cid a")
+    _same(b[0], G_full.sample_fanout(roots[:2000], et2, [5, 3], N + 1, call_id=1002)[0], "cid b")
+
+    # empty bucket: every root of every rank belongs to shard (world - 1); then a
+    # rank with an empty batch (it still answers its peers)
+    last = world - 1
+    base = rng.integers(0, N // partitions - 1, 5000).astype(np.int64) * partitions
+    own_last = base + [r for r in range(partitions) if r % world == last][0]
+    own_last = torch.as_tensor(own_last[own_last >= 1]).to(dev)
+    want = G_full.sample_neighbor(own_last, [0], 25, N + 1, call_id=9)
+    got = S.sample_neighbor(own_last, [0], 25, N + 1, call_id=9)
+    _same(got[:3], want, "one-owner batch")
+    mine = roots[:777] if rank != 0 else roots[:0]
+    want = G_full.sample_fanout(mine, et2, [4, 3], N + 1, call_id=11)
+    got = S.sample_fanout(mine, et2, [4, 3], N + 1, call_id=11)
+    _same(got[0], want[0], "empty batch on rank 0")
+
+    # ---------------- config 4: random_walk length 40, one exchange pair per step
+    L = 40
+    starts = torch.as_tensor(rng.integers(1, N + 1, 4000).astype(np.int64)).to(dev)
+    etw = [[0]] * L
+    want = G_full.random_walk(starts, etw, 1.0, 1.0, N + 1, call_id=100)
+    got = S.random_walk(starts, etw, default_node=N + 1, call_id=100)
+    assert torch.equal(got, want)
+    assert np.array_equal(t2n(got)[:64], OG.random_walk(5, 100, t2n(starts)[:64], etw, L, 1.0,
+                                                       1.0, N + 1))
+    # SampleNode over the shards: split + local draws + append
+    sn = S.sample_node(500, -1, call_id=60)
+    assert sn.numel() == 500 and int(sn.min()) >= 1 and int(sn.max()) <= N
+    # dedup="ops" (ID_UNIQUE / ID_SPLIT / merge_rows / gather as separate kernels)
+    S_ops = gpu_sharded_sampler(G_shard, partitions=partitions, dedup="ops")
+    got = S_ops.sample_fanout(roots[:5000], et2, [6, 4], N + 1, call_id=13)
+    _same(got[0], G_full.sample_fanout(roots[:5000], et2, [6, 4], N + 1, call_id=13)[0], "ops")
+    del G_full, G_shard, S, S_ops, samplers
+
+    # ---------------- config 5: 8 edge types, typed sampling k = 1 / 3 of 8 / all
+    N5, T = 60_000, 8
+    p5 = EA.synth_params(77, N5, 40 * N5, n_types=T, weighted=True)
+    G5 = EA.Graph.synthetic(p5)
+    G5s = EA.Graph.synthetic(p5, partitions=partitions, shard_index=rank, shards=world)
+    G5.set_seed(8)
+    G5s.set_seed(8)
+    S5 = gpu_sharded_sampler(G5s, partitions=partitions)
+    po5 = O.synth_params(77, N5, 40 * N5, n_types=T, weighted=True)
+    OG5 = O.OracleGraph(O.synth_csr(po5))
+    r5 = rng.integers(1, N5 + 1, 8000).astype(np.int64)
+    r5t = torch.as_tensor(r5).to(dev)
+    for call, et in enumerate(([3], [1, 4, 6], list(range(T)), [])):
+        want = G5.sample_neighbor(r5t, et, 10, N5 + 1, call_id=call)
+        got = S5.sample_neighbor(r5t, et, 10, N5 + 1, call_id=call)
+        _same(got[:3], want, ("typed", et))
+        on, ow, ot = OG5.sample_neighbor(8, call, r5[:500], et, 10, N5 + 1)
+        assert np.array_equal(t2n(got[0])[:500], on) and np.array_equal(t2n(got[2])[:500], ot)
+    # typed fanout + aggregation on the sharded sample (scatter_mean acts on the
+    # minibatch-local block: replicas only, no collective)
+    gn, gw, gt = S5.sample_fanout(r5t, [[1, 4, 6], [3]], [5, 5], N5 + 1, call_id=20)
+    wn, ww, wt = G5.sample_fanout(r5t, [[1, 4, 6], [3]], [5, 5], N5 + 1, call_id=20)
+    _same(gn, wn, "typed fanout ids"); _same(gt, wt, "typed fanout types")
+    feat = torch.randn(N5 + 2, 32, device=dev, generator=torch.Generator(dev).manual_seed(3))
+    x = EA.ops.gather(feat, gn[1].to(torch.int32))
+    dst = torch.arange(len(r5), device=dev, dtype=torch.int32).repeat_interleave(5)
+    agg = EA.ops.scatter_mean(x, dst, len(r5))
+    assert np.array_equal(t2n(agg), O.scatter_mean(t2n(x), t2n(dst), len(r5)))
+    del G5, G5s, S5
+
+    # ---------------- arbitrary u64 ids (hash id map), 3 types, zero weights, missing rows
+    grng = np.random.default_rng(4)                         # same graph on every rank
+    ids, seg, nbr, w, nt, nw = make_random_graph(grng, 20000, 3, max_deg=30, id_space=10 ** 12)
+    csr = O.csr_from_raw(ids, seg, nbr, w, 3, nt, nw)
+    mk = lambda **kw: EA.Graph.from_csr(csr.row_id, csr.row_ptr, csr.type_end, csr.nbr,
+                                        csr.prefix_w, csr.type_prefix, csr.n_types,
+                                        csr.node_type, csr.node_weight, **kw)
+    Gh = mk()
+    Ghs = mk(partitions=partitions, shard_index=rank, shards=world)
+    Gh.set_seed(31)
+    Ghs.set_seed(31)
+    Sh = gpu_sharded_sampler(Ghs, partitions=partitions)
+    assert Sh.dense_table is None
+    q = np.concatenate([rng.choice(ids, 6000), rng.choice(ids[:40], 3000), [0, 999]]).astype(np.int64)
+    qt = torch.as_tensor(q).to(dev)
+    OGh = O.OracleGraph(csr)
+    for ets, cnts in (([[0, 1], [2, 0]], [6, 4]), ([[0], [1]], [7, 5]), ([[], []], [3, 3])):
+        on, ow, ot = OGh.sample_fanout(31, 8, q, ets, cnts, -1)
+        got = Sh.sample_fanout(qt, ets, cnts, -1, call_id=8)
+        for h in range(2):
+            assert np.array_equal(t2n(got[0][h + 1]), on[h]), (ets, h)
+            assert np.array_equal(t2n(got[1][h]), ow[h]) and np.array_equal(t2n(got[2][h]), ot[h])
+    gi_, gd_, gw_, gt_ = Sh.get_full_neighbor(qt, [0, 2])
+    wi_, wd_, ww_, wt_ = OGh.get_full_neighbor(q.astype(np.uint64), [0, 2])
+    assert np.array_equal(t2n(gi_), wi_) and np.array_equal(t2n(gd_).astype(np.uint64), wd_)
+    assert np.array_equal(t2n(gw_), ww_) and np.array_equal(t2n(gt_), wt_)
+    walk = Sh.random_walk(qt[:2000], [[0, 1, 2]] * 6, default_node=-1, call_id=50)
+    assert np.array_equal(t2n(walk), OGh.random_walk(31, 50, q[:2000], [[0, 1, 2]] * 6, 6, 1.0,
+                                                     1.0, -1))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,partitions", [(2, 2), (2, 6), (3, 3)])
+def test_sharded_hip_pieces_world_gt1_on_one_gpu(torch_cuda, tmp_path, world, partitions):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(r, world, port, partitions, str(tmp_path)))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(900)
+    errs = []
+    for r, p in enumerate(procs):
+        if p.is_alive():
+            p.kill()
+            errs.append("rank %d timed out" % r)
+        f = tmp_path / ("rank%d.err" % r)
+        if f.exists():
+            errs.append("rank %d:\n%s" % (r, f.read_text()))
+        elif p.exitcode not in (0, None):
+            errs.append("rank %d exit code %s" % (r, p.exitcode))
+    assert not errs, "\n".join(errs)
