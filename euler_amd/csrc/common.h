@@ -197,6 +197,9 @@ struct euler_gpu_graph {
   // scratch)
   mutable std::recursive_mutex launch_mu;   // a fanout holds it across its hops
   mutable std::map<void*, std::pair<void*, size_t>> ws;
+  // which counter of the stream's pair the next duplicate-root call uses
+  // (DedupNumberKernel clears the other one); reset when the scratch is reallocated
+  mutable std::map<void*, int> ws_parity;
 };
 
 namespace euler_gpu {

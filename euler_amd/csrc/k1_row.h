@@ -1,0 +1,243 @@
+// K1 "row" kernel (gfx950): ONE LANE PER ROOT.
+//
+// Round 1's kernels give every SAMPLE a lane: the `count` lanes of a root repeat
+// the root's dependent chain (root id -> row record -> pivot window -> block
+// line -> id) and a wave of 64 samples carries ~9 vector-memory instructions.
+// On the metric's first hop (131 072 uniformly drawn roots x 25) that chain,
+// not bytes or lines, is the cost: 67 us against ~25 us of traffic.
+//
+// Here a lane owns a root.  Most rows are short (94 % of uniformly drawn roots
+// of the metric graph have <= 10 edges) and lie inside ONE or TWO consecutive
+// 128-byte EdgeBlocks: the lane fetches the row record, then the <= 20 running
+// sums of those blocks (six independent 16-byte loads), and draws all `count`
+// samples from registers - no further memory instruction in the search.  Every
+// draw is the index Node::SampleNeighbor's RandomSelect returns
+// (core/graph/node.cc:150-158, common/compact_weighted_collection.h:30-52): the
+// first m of the segment with nw[m] > r (non-decreasing rows; Q3 draws replay
+// the reference loop).  The samples of the 64 roots of a wave are staged in LDS
+// (slot index + weight) and written by the whole wave in OUTPUT order: ids are
+// fetched from the block lines (L1 / L2 hits: the lines were just read) and
+// leave as 16-byte stores, weights and types as 8-byte stores.
+//
+// Rows that span more than two blocks ("slow" roots: 6 % of the first hop) are
+// handed to the wave after the register pass: their count x S samples become
+// lane-per-sample tasks running the block-pivot search of k1_search.h.
+#ifndef EULER_AMD_CSRC_K1_ROW_H_
+#define EULER_AMD_CSRC_K1_ROW_H_
+
+#include <hip/hip_runtime.h>
+
+#include "k1_args.h"
+#include "k1_search.h"
+
+namespace euler_gpu {
+
+constexpr int kRowTile = 64;                        // roots per wave (= workgroup)
+constexpr int kRowMaxCount = 64;
+constexpr int kRowSlots = 2 * kEdgesPerBlock;       // sums a lane keeps in registers
+
+// dynamic LDS of one wave:
+//   sums [kRowSlots + 1][64] f32   (slot-major: lane l reads bank l % 32 whatever
+//                                   its slot - conflict-free dynamic indexing)
+//   w    [64 * count]        f32   output order
+//   blk  [64]                i64   first block of every root
+//   m    [64 * count]        u8    slot of every sample, 0xFF = id already written
+//   slow [64]                u8    lanes of the slow roots
+//   flag [64]                u8    0 = valid, 1 = no samples (default row)
+__host__ __device__ inline size_t RowKernelLdsBytes(int32_t count) {
+  const size_t b = (size_t)(kRowSlots + 1) * 64 * 4 + (size_t)64 * count * 4 + 64 * 8 +
+                   (size_t)64 * count + 64 + 64;
+  return (b + 15) & ~(size_t)15;
+}
+
+template <bool TF_LAYOUT>
+__global__ __launch_bounds__(64) void SampleNeighborRowKernel(const SampleNbArgs a) {
+  extern __shared__ __align__(16) uint8_t row_smem[];
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  int64_t n_roots;
+  if (!DedupGate(a, &n_roots)) return;
+  const int lane = threadIdx.x;
+  const int32_t count = a.count;
+  float* s_sum = reinterpret_cast<float*>(row_smem);
+  float* s_w = s_sum + (kRowSlots + 1) * 64;
+  int64_t* s_blk = reinterpret_cast<int64_t*>(s_w + 64 * count);
+  uint8_t* s_m = reinterpret_cast<uint8_t*>(s_blk + 64);
+  uint8_t* s_slow = s_m + 64 * count;
+  uint8_t* s_flag = s_slow + 64;
+  const int32_t t = a.et[0];
+  const bool mark = a.mark_owner != nullptr;
+  const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  const double kInf = __builtin_huge_val();
+  const int64_t tiles = (n_roots + kRowTile - 1) / kRowTile;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    // ---- P1: root id -> row record -> the sums of the row's (<= 2) blocks
+    const int64_t r = tile * kRowTile + lane;
+    const bool live = r < n_roots;
+    uint64_t node = 0;
+    Segment sg;
+    bool valid = false;
+    if (live) {
+      node = a.roots[r];
+      if (a.root_mask != nullptr && a.root_mask[r / a.root_group]) node = 0;
+      valid = LoadSegment<true>(a.g, FindRow(a.g, node), t, &sg);
+    }
+    int64_t blk_lo = 0;
+    int32_t i_lo = 0, i_hi = 0;
+    if (valid) {
+      blk_lo = sg.lo / kEdgesPerBlock;
+      i_lo = (int32_t)(sg.lo - blk_lo * kEdgesPerBlock);
+      i_hi = (int32_t)(sg.hi - blk_lo * kEdgesPerBlock);
+    }
+    const bool fast = valid && i_hi < kRowSlots;
+    const bool slow = valid && !fast;
+    double vd[kRowSlots - 1];          // compare keys of slots 0 .. 18, padded
+    if (fast) {
+      const EdgeBlock* bk = a.g.blk + blk_lo;
+      const float4 a0 = *reinterpret_cast<const float4*>(bk->pw);
+      const float4 a1 = *reinterpret_cast<const float4*>(bk->pw + 4);
+      const float4 a2 = *reinterpret_cast<const float4*>(bk->pw + 8);   // pw[8], pw[9], prev_last
+      float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0, b2 = b0;
+      if (i_hi >= kEdgesPerBlock) {
+        b0 = *reinterpret_cast<const float4*>(bk[1].pw);
+        b1 = *reinterpret_cast<const float4*>(bk[1].pw + 4);
+        b2 = *reinterpret_cast<const float4*>(bk[1].pw + 8);
+      }
+      const float v[kRowSlots] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y,
+                                  b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y};
+      s_sum[lane] = a2.z;                                  // the sum before slot 0
+#pragma unroll
+      for (int q = 0; q < kRowSlots; ++q) s_sum[(q + 1) * 64 + lane] = v[q];
+      // slots before the segment always count (-inf is never > r), slots from the
+      // segment's last one on never do: pos = first slot of [i_lo, i_hi] whose sum > r
+#pragma unroll
+      for (int q = 0; q < kRowSlots - 1; ++q)
+        vd[q] = q < i_lo ? -kInf : (q >= i_hi ? kInf : (double)v[q]);
+      s_blk[lane] = blk_lo;
+    }
+    s_flag[lane] = valid ? 0 : 1;
+    // ---- P2: all `count` draws of a fast root from registers
+    if (fast) {
+      const float lb = sg.limit_begin, le = sg.limit_end;
+      const bool first_block_is_row_start = blk_lo * kEdgesPerBlock <= sg.row_ptr;
+      const int32_t row_start_slot = (int32_t)(sg.row_ptr - blk_lo * kEdgesPerBlock);
+      for (int32_t j = 0; j < count; j += 2) {
+        const Philox4 pb = RngBlock(a.seed, a.call_id, kDomainNeighbor, node, ((uint32_t)j) >> 1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (j + h >= count) break;
+          const double u = h ? UnitFromWords(pb.w[2], pb.w[3]) : UnitFromWords(pb.w[0], pb.w[1]);
+          const double rr = ScaleDraw(u, lb, le);
+          float wv;
+          uint8_t mm;
+          if (!((double)le > rr)) {
+            // Q3: r rounded up to the end of the segment - replay the reference
+            const float* nw = a.g.prefix_w + sg.row_ptr;
+            const int32_t m = (int32_t)RandomSelect(nw, (uint64_t)sg.b, (uint64_t)sg.e, u);
+            const uint64_t id = a.g.nbr[sg.row_ptr + m];
+            wv = __fsub_rn(nw[m], m == 0 ? 0.f : nw[m - 1]);
+            const int64_t s = r * (int64_t)count + j + h;
+            a.out_id[s] = id;
+            if (mark) MarkNextHop(a.g, a.mark_owner, id, true, s);
+            mm = 0xFF;
+          } else {
+            int32_t pos = 0;
+#pragma unroll
+            for (int q = 0; q < kRowSlots - 1; ++q) pos += (vd[q] > rr) ? 0 : 1;
+            const float nw_m = s_sum[(pos + 1) * 64 + lane];
+            // `mid ? nw[mid-1] : 0` is row-relative
+            const float prev = (first_block_is_row_start && pos == row_start_slot)
+                                   ? 0.f : s_sum[pos * 64 + lane];
+            wv = __fsub_rn(nw_m, prev);
+            mm = (uint8_t)pos;
+          }
+          s_w[lane * count + j + h] = wv;
+          s_m[lane * count + j + h] = mm;
+        }
+      }
+    }
+    // ---- slow roots (more than two blocks): lane-per-sample tasks
+    const uint64_t slow_mask = __ballot(slow);
+    if (slow_mask != 0) {
+      if (slow) s_slow[__popcll(slow_mask & lt_mask)] = (uint8_t)lane;
+      WaveSync();
+      const int32_t n_tasks = (int32_t)__popcll(slow_mask) * count;
+      for (int32_t tk = lane; tk < n_tasks; tk += 64) {
+        const int32_t q = tk / count;
+        const int32_t j = tk - q * count;
+        const int32_t sl = s_slow[q];
+        const int64_t r2 = tile * kRowTile + sl;
+        uint64_t nd = a.roots[r2];
+        if (a.root_mask != nullptr && a.root_mask[r2 / a.root_group]) nd = 0;
+        Segment s2;
+        (void)LoadSegment<true>(a.g, FindRow(a.g, nd), t, &s2);
+        const Philox4 pb = RngBlock(a.seed, a.call_id, kDomainNeighbor, nd, ((uint32_t)j) >> 1);
+        const double u = (j & 1) ? UnitFromWords(pb.w[2], pb.w[3])
+                                 : UnitFromWords(pb.w[0], pb.w[1]);
+        uint64_t id;
+        float wv;
+        BlockPivotSample(a.g, s2, u, &id, &wv);
+        const int64_t s = r2 * (int64_t)count + j;
+        a.out_id[s] = id;
+        if (mark) MarkNextHop(a.g, a.mark_owner, id, true, s);
+        s_w[sl * count + j] = wv;
+        s_m[sl * count + j] = 0xFF;
+      }
+    }
+    if (live && a.out_row_mask != nullptr) a.out_row_mask[r] = valid ? 0 : 1;
+    WaveSync();
+    // ---- P3: the tile's samples in output order, two per lane
+    const int64_t left = n_roots - tile * kRowTile;
+    const int32_t nt = (int32_t)(left < kRowTile ? left : kRowTile) * count;
+    const int64_t base = tile * kRowTile * (int64_t)count;
+    for (int32_t e = lane * 2; e < nt; e += 128) {
+      uint64_t id[2] = {0, 0};
+      float wv[2] = {0.f, 0.f};
+      int32_t ot[2] = {t, t};
+      bool have[2] = {false, false}, rv[2] = {true, true};
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        if (e + x >= nt) continue;
+        const int32_t rl = (e + x) / count;
+        if (s_flag[rl] != 0) {
+          id[x] = TF_LAYOUT ? (uint64_t)a.default_node : 0;
+          ot[x] = TF_LAYOUT ? -1 : 0;
+          have[x] = true;
+          rv[x] = false;
+          continue;
+        }
+        wv[x] = s_w[e + x];
+        const int32_t mm = s_m[e + x];
+        if (mm == 0xFF) continue;                     // id written by its sampler
+        const EdgeBlock* bk = a.g.blk + s_blk[rl] + (mm >= kEdgesPerBlock ? 1 : 0);
+        id[x] = bk->nbr[mm >= kEdgesPerBlock ? mm - kEdgesPerBlock : mm];
+        have[x] = true;
+      }
+      const int64_t d = base + e;
+      if (e + 1 < nt) {
+        if (have[0] && have[1]) {
+          const u64x2 i2 = {id[0], id[1]};
+          *reinterpret_cast<u64x2*>(a.out_id + d) = i2;
+        } else {
+          if (have[0]) a.out_id[d] = id[0];
+          if (have[1]) a.out_id[d + 1] = id[1];
+        }
+        *reinterpret_cast<float2*>(a.out_w + d) = make_float2(wv[0], wv[1]);
+        *reinterpret_cast<int2*>(a.out_t + d) = make_int2(ot[0], ot[1]);
+      } else {
+        if (have[0]) a.out_id[d] = id[0];
+        a.out_w[d] = wv[0];
+        a.out_t[d] = ot[0];
+      }
+      if (mark) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+          if (e + x < nt && have[x]) MarkNextHop(a.g, a.mark_owner, id[x], rv[x], d + x);
+      }
+    }
+    WaveSync();        // the next tile reuses the staging area
+  }
+}
+
+}  // namespace euler_gpu
+
+#endif  // EULER_AMD_CSRC_K1_ROW_H_

@@ -12,6 +12,7 @@
 
 #include "k1_args.h"
 #include "k1_search.h"
+#include "k1_row.h"
 
 extern "C" int g_feature_vec4;   // mp_kernels.hip
 namespace euler_gpu { extern int g_root_host_batch, g_adj_scan, g_adj_long_row, g_sum_scalar; }   // layer_kernels.hip
@@ -203,6 +204,86 @@ __global__ __launch_bounds__(256) void DedupResolveKernel(const DedupBlockArgs a
     a.d.uidx_of[i] = a.posrep[a.rep[i]];
 }
 
+// Numbering in ONE pass (tuning key 14 = 2, default).  The three kernels above
+// exist to give the representatives consecutive numbers in position order - an
+// order nothing depends on: a number only names the scratch row the distinct
+// root is sampled into.  So a workgroup counts the representatives among its
+// 4 096 positions and takes that many numbers from the call's counter with ONE
+// returning atomic (800 atomics for the metric's 3.28 M hop-2 roots; a single
+// word sustains ~88 of them per microsecond, spread over the kernel's run).  The
+// representative then leaves its number IN the owner table, flagged with bit 31
+// (positions are < 2^30): a reader of owner[slot] sees either the representative's
+// position or a flagged number - both say "not me" to everybody else - and
+// DedupResolveKernel (or the expansion itself, last hop) finds every position's
+// number with one lookup.  The counter ends up holding the number of distinct
+// roots; `next_counter` (the other counter of the stream's pair) is cleared for
+// the stream's next call.
+constexpr uint32_t kOwnerNumbered = 0x80000000u;
+constexpr int kNumberTile = 4096, kNumberThreads = 1024;
+
+__global__ __launch_bounds__(kNumberThreads) void DedupNumberKernel(const DedupBlockArgs a,
+                                                                    uint32_t* next_counter) {
+  __shared__ uint32_t wave_cnt[kNumberThreads / 64];
+  __shared__ uint32_t base_s;
+  constexpr int kPer = kNumberTile / kNumberThreads;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t tile0 = (int64_t)blockIdx.x * kNumberTile;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && next_counter != nullptr) next_counter[0] = 0;
+  uint64_t key[kPer];
+  uint32_t slot[kPer];
+  bool is_rep[kPer];
+#pragma unroll
+  for (int x = 0; x < kPer; ++x) {
+    const int64_t i = tile0 + (int64_t)x * kNumberThreads + threadIdx.x;
+    is_rep[x] = false;
+    key[x] = 0; slot[x] = 0;
+    if (i < a.d.n) {
+      key[x] = DedupKey(a.d, i);
+      slot[x] = a.premarked ? a.map.Slot(key[x]) : a.d.row_slot[i];
+    }
+  }
+#pragma unroll
+  for (int x = 0; x < kPer; ++x) {
+    const int64_t i = tile0 + (int64_t)x * kNumberThreads + threadIdx.x;
+    if (i < a.d.n) is_rep[x] = a.d.owner[slot[x]] == (uint32_t)i;
+  }
+  const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  uint32_t rank[kPer];
+  uint32_t mine = 0;
+#pragma unroll
+  for (int x = 0; x < kPer; ++x) {
+    const unsigned long long m = __ballot(is_rep[x]);
+    rank[x] = mine + (uint32_t)__popcll(m & lt);
+    mine += (uint32_t)__popcll(m);
+  }
+  if (lane == 0) wave_cnt[wave] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t total = 0;
+    for (int w = 0; w < kNumberThreads / 64; ++w) { const uint32_t c = wave_cnt[w]; wave_cnt[w] = total; total += c; }
+    base_s = total != 0 ? atomicAdd(a.d.counter, total) : 0u;
+  }
+  __syncthreads();
+  const uint32_t base = base_s + wave_cnt[wave];
+#pragma unroll
+  for (int x = 0; x < kPer; ++x) {
+    if (is_rep[x]) {
+      const uint32_t q = base + rank[x];
+      a.d.uniq[q] = key[x];
+      a.d.owner[slot[x]] = q | kOwnerNumbered;
+    }
+  }
+}
+
+// uidx_of[i] = the number DedupNumberKernel left at position i's slot
+__global__ __launch_bounds__(256) void DedupResolveNumberedKernel(const DedupBlockArgs a) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.d.n; i += stride) {
+    const uint32_t slot = a.premarked ? a.map.Slot(DedupKey(a.d, i)) : a.d.row_slot[i];
+    a.d.uidx_of[i] = a.d.owner[slot] & ~kOwnerNumbered;
+  }
+}
+
 struct ExpandArgs {
   const uint32_t* counter;
   const uint32_t* uidx_of;
@@ -220,6 +301,15 @@ struct ExpandArgs {
   IdentityMap map;
   int32_t type0;             // CT kernels: type of every valid sample ...
   int32_t masked_type;       // ... and of the samples of a masked row
+  // resolve_owner != null (last hop of a numbered call, nothing marks `owner`
+  // any more): the row number of position i is owner[slot(i)] & ~kOwnerNumbered -
+  // no DedupResolve kernel, no uidx array
+  const uint32_t* resolve_owner;
+  const uint32_t* resolve_row_slot;   // slot of every position, or null = map.Slot(key)
+  const uint64_t* roots;
+  const uint8_t* root_mask;
+  int32_t root_group;
+  int32_t pad;
 };
 
 // out row i = sampled row of unique root uidx_of[i].  U adjacent samples per
@@ -263,8 +353,25 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void DedupExpandKernel(const Ex
     // all index loads, then all row loads, then the stores: steps past the end
     // load element 0 (harmless) so that the loads stay unconditional
     int64_t uv[V];
+    if (a.resolve_owner != nullptr) {
+      uint32_t sl[V];
 #pragma unroll
-    for (int v = 0; v < V; ++v) uv[v] = (int64_t)a.uidx_of[live[v] ? iv[v] : 0];
+      for (int v = 0; v < V; ++v) {
+        const int64_t p = live[v] ? iv[v] : 0;
+        if (a.resolve_row_slot != nullptr) {
+          sl[v] = a.resolve_row_slot[p];
+        } else {
+          uint64_t key = a.roots[p];
+          if (a.root_mask != nullptr && a.root_mask[p / a.root_group]) key = 0;
+          sl[v] = a.map.Slot(key);
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < V; ++v) uv[v] = (int64_t)(a.resolve_owner[sl[v]] & 0x7fffffffu);
+    } else {
+#pragma unroll
+      for (int v = 0; v < V; ++v) uv[v] = (int64_t)a.uidx_of[live[v] ? iv[v] : 0];
+    }
     uint64_t id[V][U];
     float w[V][U];
     int32_t t[V][U];
@@ -379,12 +486,17 @@ int g_k1_pair = 1;      // pivot kernel: two adjacent samples per lane when coun
 int g_k1_grid_cap = 0;  // measurement only: override the workgroup cap of K1
 int g_k1_fuse_mark = 1; // fanout: a hop's kernels fill the next hop's owner table
 int g_k1_dual = 1;      // duplicate-root call: both gated passes in one launch
-int g_dedup_block_numbering = 1;   // representatives numbered per workgroup (no scan over positions)
+int g_dedup_block_numbering = 2;   // 2 = one pass (workgroups take numbers from the call's counter),
+                                   // 1 = per-workgroup counts + one small scan, 0 = device-wide scan
 int g_expand_steps = 2;        // DedupExpandKernel: grid-stride steps in flight per lane (1, 2, 4)
 int g_expand_const_type = 1;   // ... rebuild the type column of single-type calls from the mask
 int g_expand_grid_cap = 0;     // ... workgroup cap (0 = kK1GridCap)
 int g_k1_ablate = 0;   // measurement only: skip parts of the blocked kernel
 int g_k1_ilp = 4;      // samples per lane of the ILP kernel (1, 2, 4, 8)
+int g_k1_row = 1;       // block-pivot calls without the duplicate path: one lane per ROOT
+                        // (k1_row.h) for 4 <= count <= 64; 0 = one lane per sample
+int g_dedup_resolve_in_expand = 1;   // last hop: the expansion reads its row number from the
+                                     // owner table itself (no DedupResolveKernel, no uidx array)
 int g_k1_variant = 6;   // 6 = block pivots, 5 = pivot levels, 4 = wave-staged (count >= 8) else blocked,
                         // 3 = blocked index,
                         // 2 = ILP, 1 = fast path, 0 = generic
@@ -661,6 +773,25 @@ static int LaunchK1(const euler_gpu_graph* g, hipStream_t stream,
     const int64_t stride_rows = stride / count;
     const int32_t stride_slots = (int32_t)(stride - stride_rows * count);
     const bool tf = layout == EULER_GPU_LAYOUT_TF;
+    if (blocked && g_k1_row != 0 && a.dd_role == 0 && a.packed == nullptr && count >= 4 &&
+        count <= kRowMaxCount && ((uintptr_t)out_id % 16 == 0) && ((uintptr_t)out_w % 8 == 0) &&
+        ((uintptr_t)out_t % 8 == 0)) {
+      // one lane per root, one wave per workgroup; the LDS staging area bounds the
+      // waves a CU holds (count 25: 14 KB -> 11), the grid-stride loop does the rest
+      const size_t lds = RowKernelLdsBytes(count);
+      int64_t tiles = (n + kRowTile - 1) / kRowTile;
+      const int64_t cap = g_k1_grid_cap > 0 ? g_k1_grid_cap : 256 * 16;
+      if (tiles > cap) tiles = cap;
+      if (tf) {
+        hipLaunchKernelGGL((SampleNeighborRowKernel<true>), dim3((unsigned)tiles), dim3(64), lds,
+                           stream, a);
+      } else {
+        hipLaunchKernelGGL((SampleNeighborRowKernel<false>), dim3((unsigned)tiles), dim3(64), lds,
+                           stream, a);
+      }
+      EG_HIP(hipGetLastError());
+      return EULER_GPU_OK;
+    }
     if (blocked && !pair && g_k1_group != 0 && count % 5 == 0 && a.dd_role != 2 &&
         a.mark_owner == nullptr && a.packed == nullptr) {
       // odd multiple of 5 (fanout 25): five adjacent samples per lane
@@ -699,6 +830,10 @@ static int LaunchK1(const euler_gpu_graph* g, hipStream_t stream,
   return EULER_GPU_OK;
 }
 
+static size_t CounterOffset(const euler_gpu_graph* g) {
+  return (((size_t)g->view.n_rows + 1) * 4 + 255) & ~(size_t)255;
+}
+
 // Per-(graph, stream) scratch, grown on demand.
 static int GetWorkspace(const euler_gpu_graph* g, hipStream_t stream, size_t bytes,
                         void** out) {
@@ -718,6 +853,11 @@ static int GetWorkspace(const euler_gpu_graph* g, hipStream_t stream, size_t byt
                                         hipGetErrorString(e));
     }
     slot.second = want;
+    // fresh scratch: both counters of the one-pass numbering start at zero
+    if (want >= CounterOffset(g) + 256) {
+      EG_HIP(hipMemsetAsync((uint8_t*)slot.first + CounterOffset(g), 0, 256, stream));
+    }
+    g->ws_parity[(void*)stream] = 0;
   }
   *out = slot.first;
   return EULER_GPU_OK;
@@ -813,13 +953,16 @@ static int MakeDedupLayout(const euler_gpu_graph* g, hipStream_t stream, int64_t
                                             (int)(n + 1), stream));
     if (pre > L->scan_bytes) L->scan_bytes = pre;
   }
+  // owner table, then the stream's counters at an offset that depends on the graph
+  // only (DedupNumberKernel of one call clears the counter of the next): words 0
+  // and 32 = the pair of the one-pass numbering, word 16 = the other modes' counter
   L->o_owner = 0;
-  L->o_slot = L->o_owner + al(((size_t)g->view.n_rows + 1) * 4);
+  L->o_cnt = CounterOffset(g);
+  L->o_slot = L->o_cnt + 256;
   L->o_pos = L->o_slot + al((size_t)n * 4);
   L->o_uidx = L->o_pos + al(((size_t)n + 1) * 4);
   L->o_uniq = L->o_uidx + al((size_t)n * 4);
-  L->o_cnt = L->o_uniq + al((size_t)n * 8);
-  L->o_scan = L->o_cnt + 256;
+  L->o_scan = L->o_uniq + al((size_t)n * 8);
   const size_t n_blocks = ((size_t)n + 255) / 256 + 1;
   L->o_bcnt = L->o_scan + al(L->scan_bytes);
   L->o_boff = L->o_bcnt + al(n_blocks * 4);
@@ -950,14 +1093,38 @@ static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
   d.pos = (uint32_t*)(ws + L.o_pos);
   d.uidx_of = (uint32_t*)(ws + L.o_uidx);
   d.uniq = (uint64_t*)(ws + L.o_uniq);
-  d.counter = (uint32_t*)(ws + L.o_cnt);
-  g_last_unique_offset = (int64_t)L.o_cnt;
+  d.counter = (uint32_t*)(ws + L.o_cnt) + 16;
+  g_last_unique_offset = (int64_t)L.o_cnt + 64;
   const IdentityMap idmap{g->view.id_base, g->view.id_stride, g->view.n_rows};
   const int block = 256;
   const int dgrid = GridFor(n + 1, block);
   PhaseMark(stream, 0);
   hipcub::CountingInputIterator<uint32_t> pos_it(0u);
-  if (g_dedup_block_numbering != 0) {
+  bool resolve_in_expand = false;
+  if (g_dedup_block_numbering == 2) {
+    // one pass: workgroups take their numbers from the call's counter; the stream
+    // owns a PAIR of counters - this call's was cleared by the previous call's
+    // numbering kernel (or at allocation), and clears the other one
+    uint32_t* pair = (uint32_t*)(ws + L.o_cnt);
+    int* parity = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(g->ws_mu);
+      parity = &g->ws_parity[(void*)stream];
+    }
+    d.counter = pair + (*parity ? 32 : 0);
+    uint32_t* next_counter = pair + (*parity ? 0 : 32);
+    *parity ^= 1;
+    g_last_unique_offset = (int64_t)((uint8_t*)d.counter - ws);
+    if (!premarked) hipLaunchKernelGGL(DedupMarkKernel, dim3(dgrid), dim3(block), 0, stream, d);
+    DedupBlockArgs ba{};
+    ba.d = d; ba.map = idmap; ba.premarked = premarked ? 1 : 0;
+    const int64_t nb = (n + kNumberTile - 1) / kNumberTile;
+    hipLaunchKernelGGL(DedupNumberKernel, dim3((unsigned)nb), dim3(kNumberThreads), 0, stream, ba,
+                       next_counter);
+    resolve_in_expand = g_dedup_resolve_in_expand != 0 && !do_mark;
+    if (!resolve_in_expand)
+      hipLaunchKernelGGL(DedupResolveNumberedKernel, dim3(dgrid), dim3(block), 0, stream, ba);
+  } else if (g_dedup_block_numbering != 0) {
     if (!premarked) hipLaunchKernelGGL(DedupMarkKernel, dim3(dgrid), dim3(block), 0, stream, d);
     DedupBlockArgs ba{};
     ba.d = d; ba.map = idmap; ba.premarked = premarked ? 1 : 0;
@@ -1027,6 +1194,11 @@ static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
   x.n = n; x.count = count;
   x.mark_owner = do_mark ? d.owner : nullptr;
   x.map = idmap;
+  if (resolve_in_expand) {
+    x.resolve_owner = d.owner;
+    x.resolve_row_slot = premarked ? nullptr : d.row_slot;
+    x.roots = roots; x.root_mask = root_mask; x.root_group = a.root_group;
+  }
   const size_t total_out = (size_t)n * (size_t)count;
   const bool pair = count % 2 == 0 && ((uintptr_t)out_id % 16 == 0) &&
                     ((uintptr_t)out_w % 8 == 0) && ((uintptr_t)out_t % 8 == 0);
@@ -1136,7 +1308,7 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   }
   if (key == 11) { g_expand_const_type = value != 0; return EULER_GPU_OK; }
   if (key == 13) { g_k1_dual = value != 0; return EULER_GPU_OK; }
-  if (key == 14) { g_dedup_block_numbering = value != 0; return EULER_GPU_OK; }
+  if (key == 14 && value >= 0 && value <= 2) { g_dedup_block_numbering = value; return EULER_GPU_OK; }
   if (key == 12 && value >= 0) { g_expand_grid_cap = value; return EULER_GPU_OK; }
   if (key == 4) { g_k1_pair = value; return EULER_GPU_OK; }
   if (key == 5) { g_k1_dedup = value; return EULER_GPU_OK; }
@@ -1147,6 +1319,8 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 16) { g_adj_scan = value != 0; return EULER_GPU_OK; }
   if (key == 17 && value >= 0) { g_adj_long_row = value; return EULER_GPU_OK; }
   if (key == 18) { g_sum_scalar = value != 0; return EULER_GPU_OK; }
+  if (key == 19) { g_k1_row = value != 0; return EULER_GPU_OK; }
+  if (key == 20) { g_dedup_resolve_in_expand = value != 0; return EULER_GPU_OK; }
   if (key == 1 && (value == 1 || value == 2 || value == 4 || value == 8)) {
     g_k1_ilp = value;
     return EULER_GPU_OK;

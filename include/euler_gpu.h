@@ -639,9 +639,11 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  *        single-type calls from the row mask instead of gathering it (1).
  *        key 12: measurement only (workgroup cap of the expansion).
  * key 13: both gated passes of a duplicate-root call in one launch (1).
- * key 14: duplicate roots: representatives numbered per workgroup + one small
- *        scan of the workgroup counts (1 [default]); 0 = device-wide scan over the
- *        positions with the flags evaluated in its loads.
+ * key 14: duplicate roots, numbering of the distinct ones: 2 = ONE pass, every
+ *        workgroup takes its numbers from the call's counter with one atomic and the
+ *        representative leaves its number in the owner table [default]; 1 =
+ *        per-workgroup counts + one small scan + assign + resolve; 0 = device-wide
+ *        scan over the positions with the flags evaluated in its loads.
  * key 15: euler_gpu_sample_root: who builds the alias tables (one sequential
  *        chain per batch row): 0 = one lane per row on the device, 2 = the host's
  *        cores between two copies, 1 = by a measured cost model [default] (few
@@ -652,6 +654,14 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  *        16384) are cut into segments handled by separate workgroups.
  * key 18: edge weight sums of long rows: 0 = lane-shifting DPP chain [default],
  *        1 = scalar loads and a wave-uniform chain (measured 2x slower).
+ * key 19: sample_neighbor calls that do not take the duplicate-root path (first
+ *        hop of a fanout, calls below 100 000 roots), single listed type,
+ *        4 <= count <= 64: 1 = one lane per ROOT, the row's running sums in
+ *        registers, samples staged in LDS and written in output order [default];
+ *        0 = one lane per sample.
+ * key 20: last hop of a fanout with key 14 = 2: the expansion reads every
+ *        position's row number from the owner table itself (1 [default]); 0 = a
+ *        separate resolve kernel fills an index array first.
  * All settings produce identical results; the knobs exist for A/B measurements
  * and tests. */
 int euler_gpu_set_tuning(int32_t key, int32_t value);

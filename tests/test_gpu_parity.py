@@ -15,8 +15,8 @@ pytestmark = pytest.mark.gpu
 SEED = 20240521
 
 
-@pytest.fixture(params=[(6, 4), (5, 4), (6, 2), (6, 1), (4, 4), (3, 4), (2, 4), (2, 2), (2, 8), (1, 4), (0, 4)],
-                ids=["k1blockpivot", "k1pivot", "k1dedup", "k1blockpivot1", "k1wave", "k1blocked", "k1ilp4", "k1ilp2", "k1ilp8", "k1fast",
+@pytest.fixture(params=[(6, 4), (6, 3), (5, 4), (6, 2), (6, 1), (4, 4), (3, 4), (2, 4), (2, 2), (2, 8), (1, 4), (0, 4)],
+                ids=["k1row", "k1blockpivot", "k1pivot", "k1dedup", "k1blockpivot1", "k1wave", "k1blocked", "k1ilp4", "k1ilp2", "k1ilp8", "k1fast",
                      "k1generic"])
 def k1_variant(request, EA):
     """Run with every variant of the K1 kernel (blocked sampling index, ILP with
@@ -24,7 +24,10 @@ def k1_variant(request, EA):
     must match the oracle bit for bit."""
     from euler_amd import _lib
     _lib.lib().euler_gpu_set_tuning(0, request.param[0])
-    _lib.lib().euler_gpu_set_tuning(1, request.param[1])
+    _lib.lib().euler_gpu_set_tuning(1, request.param[1] if request.param[1] != 3 else 4)
+    # (6, 4) = the default: one lane per ROOT (k1_row.h) wherever it applies;
+    # every other parameter runs the lane-per-sample kernels
+    _lib.lib().euler_gpu_set_tuning(19, 1 if request.param == (6, 4) else 0)
     # (6, 1) forces one sample per lane
     _lib.lib().euler_gpu_set_tuning(4, 0 if request.param == (6, 1) else 1)
     # ... and (6, 2) also turns on five samples per lane for odd multiples of 5
@@ -32,6 +35,7 @@ def k1_variant(request, EA):
     # (6, 2): always run the duplicate-root machinery, whatever the batch size
     _lib.lib().euler_gpu_set_tuning(5, 2 if request.param == (6, 2) else 1)
     yield request.param
+    _lib.lib().euler_gpu_set_tuning(19, 1)
     _lib.lib().euler_gpu_set_tuning(4, 1)
     _lib.lib().euler_gpu_set_tuning(5, 1)
     _lib.lib().euler_gpu_set_tuning(6, 0)
@@ -480,14 +484,19 @@ def test_non_monotone_rows_use_reference_loop(EA, O, torch_cuda):
         assert set(got[i].tolist()) <= row
 
 
-@pytest.fixture(params=[1, 0], ids=["blocknum", "scan"])
+@pytest.fixture(params=[(2, 1), (2, 0), (1, 1), (0, 1)],
+                ids=["onepass", "onepass_resolve_kernel", "blocknum", "scan"])
 def dedup_numbering(request):
-    """Both ways of numbering the distinct roots (tuning key 14): per-workgroup
-    counts + one small scan, and the device-wide scan over the positions."""
+    """Every way of numbering the distinct roots (tuning key 14): one pass with
+    workgroup-level atomics (the default; with the expansion reading the owner table
+    itself, or with the separate resolve kernel: key 20), per-workgroup counts + one
+    small scan, and the device-wide scan over the positions."""
     from euler_amd import _lib
-    _lib.lib().euler_gpu_set_tuning(14, request.param)
+    _lib.lib().euler_gpu_set_tuning(14, request.param[0])
+    _lib.lib().euler_gpu_set_tuning(20, request.param[1])
     yield request.param
-    _lib.lib().euler_gpu_set_tuning(14, 1)
+    _lib.lib().euler_gpu_set_tuning(14, 2)
+    _lib.lib().euler_gpu_set_tuning(20, 1)
 
 
 @pytest.mark.parametrize("et", [[0], [1, 2], []])
