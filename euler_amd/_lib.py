@@ -191,6 +191,15 @@ SIGNATURES = {
     "euler_op_run_sample_nb": (C.c_int64, [vp, C.c_uint64, u64p, C.c_int64, i32p,
                                            C.c_int32, C.c_int32, i32p, u64p, f32p,
                                            i32p]),
+    "euler_op_run_sample_nb_post": (C.c_int64, [vp, C.c_uint64, C.c_uint32, u64p, C.c_int64,
+                                                i32p, C.c_int32, C.c_int32, C.c_char_p, i32p,
+                                                u64p, f32p, i32p]),
+    # include/euler_query.h
+    "euler_query_run": (C.c_int64, [C.c_char_p, C.c_int32, C.POINTER(C.c_char_p), i32p,
+                                    C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.c_char_p,
+                                    C.c_void_p, C.c_int64]),
+    "euler_query_set_seed": (None, [C.c_uint64]),
+    "euler_query_set_graph": (None, [vp]),
 }
 
 _lib = None

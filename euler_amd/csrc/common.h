@@ -200,6 +200,9 @@ struct euler_gpu_graph {
   // which counter of the stream's pair the next duplicate-root call uses
   // (DedupNumberKernel clears the other one); reset when the scratch is reallocated
   mutable std::map<void*, int> ws_parity;
+  // row kernel (k1_row.h): per stream, 256 bytes of counters + the queue of the
+  // roots left to SampleNeighborSlowKernel
+  mutable std::map<void*, std::pair<void*, size_t>> row_ws;
 };
 
 namespace euler_gpu {

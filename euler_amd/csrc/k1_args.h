@@ -52,6 +52,8 @@ struct SampleNbArgs {
                                 // out_t / out_row_mask (see PackRowsKernel)
   int32_t packed_tcol;          // ... with (1) or without (0: single-type call) the types
   int32_t cold_roots;           // hint: the roots are distinct (one sample per lane)
+  uint32_t* slow_list;          // row kernel (k1_row.h): queue of the roots it leaves to
+  uint32_t* slow_count;         // SampleNeighborSlowKernel; [0] = length, [1] = workgroups done
   int32_t et[kMaxListedTypes];
 };
 

@@ -19,9 +19,13 @@
 // fetched from the block lines (L1 / L2 hits: the lines were just read) and
 // leave as 16-byte stores, weights and types as 8-byte stores.
 //
-// Rows that span more than two blocks ("slow" roots: 6 % of the first hop) are
-// handed to the wave after the register pass: their count x S samples become
-// lane-per-sample tasks running the block-pivot search of k1_search.h.
+// Rows that span more than two blocks ("slow" roots: 6 % of the first hop, nearly
+// all roots of a later hop) are not sampled here: the wave appends them to a
+// device-side list (one atomic per tile) and SampleNeighborSlowKernel, launched
+// right behind, gives each of their samples a lane and the block-pivot search of
+// k1_search.h - perfectly balanced over the chip, where doing them inside their
+// tile made the tile with the most hubs the kernel's critical path (measured:
+// 69 us for the metric's first hop, no better than one lane per sample).
 #ifndef EULER_AMD_CSRC_K1_ROW_H_
 #define EULER_AMD_CSRC_K1_ROW_H_
 
@@ -42,11 +46,11 @@ constexpr int kRowSlots = 2 * kEdgesPerBlock;       // sums a lane keeps in regi
 //   w    [64 * count]        f32   output order
 //   blk  [64]                i64   first block of every root
 //   m    [64 * count]        u8    slot of every sample, 0xFF = id already written
-//   slow [64]                u8    lanes of the slow roots
-//   flag [64]                u8    0 = valid, 1 = no samples (default row)
+//   flag [64]                u8    0 = sampled here, 1 = no samples (default row),
+//                                  2 = slow root (SampleNeighborSlowKernel writes it)
 __host__ __device__ inline size_t RowKernelLdsBytes(int32_t count) {
   const size_t b = (size_t)(kRowSlots + 1) * 64 * 4 + (size_t)64 * count * 4 + 64 * 8 +
-                   (size_t)64 * count + 64 + 64;
+                   (size_t)64 * count + 64;
   return (b + 15) & ~(size_t)15;
 }
 
@@ -62,8 +66,7 @@ __global__ __launch_bounds__(64) void SampleNeighborRowKernel(const SampleNbArgs
   float* s_w = s_sum + (kRowSlots + 1) * 64;
   int64_t* s_blk = reinterpret_cast<int64_t*>(s_w + 64 * count);
   uint8_t* s_m = reinterpret_cast<uint8_t*>(s_blk + 64);
-  uint8_t* s_slow = s_m + 64 * count;
-  uint8_t* s_flag = s_slow + 64;
+  uint8_t* s_flag = s_m + 64 * count;
   const int32_t t = a.et[0];
   const bool mark = a.mark_owner != nullptr;
   const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(64) void SampleNeighborRowKernel(const SampleNbArgs
         vd[q] = q < i_lo ? -kInf : (q >= i_hi ? kInf : (double)v[q]);
       s_blk[lane] = blk_lo;
     }
-    s_flag[lane] = valid ? 0 : 1;
+    s_flag[lane] = !valid ? 1 : (slow ? 2 : 0);
     // ---- P2: all `count` draws of a fast root from registers
     if (fast) {
       const float lb = sg.limit_begin, le = sg.limit_end;
@@ -155,33 +158,13 @@ __global__ __launch_bounds__(64) void SampleNeighborRowKernel(const SampleNbArgs
         }
       }
     }
-    // ---- slow roots (more than two blocks): lane-per-sample tasks
+    // ---- slow roots (more than two blocks): queued for SampleNeighborSlowKernel
     const uint64_t slow_mask = __ballot(slow);
     if (slow_mask != 0) {
-      if (slow) s_slow[__popcll(slow_mask & lt_mask)] = (uint8_t)lane;
-      WaveSync();
-      const int32_t n_tasks = (int32_t)__popcll(slow_mask) * count;
-      for (int32_t tk = lane; tk < n_tasks; tk += 64) {
-        const int32_t q = tk / count;
-        const int32_t j = tk - q * count;
-        const int32_t sl = s_slow[q];
-        const int64_t r2 = tile * kRowTile + sl;
-        uint64_t nd = a.roots[r2];
-        if (a.root_mask != nullptr && a.root_mask[r2 / a.root_group]) nd = 0;
-        Segment s2;
-        (void)LoadSegment<true>(a.g, FindRow(a.g, nd), t, &s2);
-        const Philox4 pb = RngBlock(a.seed, a.call_id, kDomainNeighbor, nd, ((uint32_t)j) >> 1);
-        const double u = (j & 1) ? UnitFromWords(pb.w[2], pb.w[3])
-                                 : UnitFromWords(pb.w[0], pb.w[1]);
-        uint64_t id;
-        float wv;
-        BlockPivotSample(a.g, s2, u, &id, &wv);
-        const int64_t s = r2 * (int64_t)count + j;
-        a.out_id[s] = id;
-        if (mark) MarkNextHop(a.g, a.mark_owner, id, true, s);
-        s_w[sl * count + j] = wv;
-        s_m[sl * count + j] = 0xFF;
-      }
+      uint32_t base_q = 0;
+      if (lane == 0) base_q = atomicAdd(a.slow_count, (uint32_t)__popcll(slow_mask));
+      base_q = __shfl(base_q, 0);
+      if (slow) a.slow_list[base_q + (uint32_t)__popcll(slow_mask & lt_mask)] = (uint32_t)r;
     }
     if (live && a.out_row_mask != nullptr) a.out_row_mask[r] = valid ? 0 : 1;
     WaveSync();
@@ -193,12 +176,16 @@ __global__ __launch_bounds__(64) void SampleNeighborRowKernel(const SampleNbArgs
       uint64_t id[2] = {0, 0};
       float wv[2] = {0.f, 0.f};
       int32_t ot[2] = {t, t};
-      bool have[2] = {false, false}, rv[2] = {true, true};
+      // have: the id is written here; skip: the whole sample belongs to the slow kernel
+      bool have[2] = {false, false}, skip[2] = {true, true}, rv[2] = {true, true};
 #pragma unroll
       for (int x = 0; x < 2; ++x) {
         if (e + x >= nt) continue;
         const int32_t rl = (e + x) / count;
-        if (s_flag[rl] != 0) {
+        const int32_t fl = s_flag[rl];
+        if (fl == 2) continue;
+        skip[x] = false;
+        if (fl == 1) {
           id[x] = TF_LAYOUT ? (uint64_t)a.default_node : 0;
           ot[x] = TF_LAYOUT ? -1 : 0;
           have[x] = true;
@@ -207,34 +194,69 @@ __global__ __launch_bounds__(64) void SampleNeighborRowKernel(const SampleNbArgs
         }
         wv[x] = s_w[e + x];
         const int32_t mm = s_m[e + x];
-        if (mm == 0xFF) continue;                     // id written by its sampler
+        if (mm == 0xFF) continue;                     // id written by the Q3 replay
         const EdgeBlock* bk = a.g.blk + s_blk[rl] + (mm >= kEdgesPerBlock ? 1 : 0);
         id[x] = bk->nbr[mm >= kEdgesPerBlock ? mm - kEdgesPerBlock : mm];
         have[x] = true;
       }
       const int64_t d = base + e;
-      if (e + 1 < nt) {
-        if (have[0] && have[1]) {
-          const u64x2 i2 = {id[0], id[1]};
-          *reinterpret_cast<u64x2*>(a.out_id + d) = i2;
-        } else {
-          if (have[0]) a.out_id[d] = id[0];
-          if (have[1]) a.out_id[d + 1] = id[1];
-        }
+      if (have[0] && have[1]) {
+        const u64x2 i2 = {id[0], id[1]};
+        *reinterpret_cast<u64x2*>(a.out_id + d) = i2;
+      } else {
+        if (have[0]) a.out_id[d] = id[0];
+        if (have[1]) a.out_id[d + 1] = id[1];
+      }
+      if (!skip[0] && !skip[1]) {
         *reinterpret_cast<float2*>(a.out_w + d) = make_float2(wv[0], wv[1]);
         *reinterpret_cast<int2*>(a.out_t + d) = make_int2(ot[0], ot[1]);
       } else {
-        if (have[0]) a.out_id[d] = id[0];
-        a.out_w[d] = wv[0];
-        a.out_t[d] = ot[0];
+        if (!skip[0]) { a.out_w[d] = wv[0]; a.out_t[d] = ot[0]; }
+        if (!skip[1]) { a.out_w[d + 1] = wv[1]; a.out_t[d + 1] = ot[1]; }
       }
       if (mark) {
 #pragma unroll
         for (int x = 0; x < 2; ++x)
-          if (e + x < nt && have[x]) MarkNextHop(a.g, a.mark_owner, id[x], rv[x], d + x);
+          if (have[x]) MarkNextHop(a.g, a.mark_owner, id[x], rv[x], d + x);
       }
     }
     WaveSync();        // the next tile reuses the staging area
+  }
+}
+
+// The queued slow roots, one lane per sample (see the head of this file).  The
+// last workgroup to finish clears the queue's counters for the stream's next call.
+template <bool TF_LAYOUT>
+__global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborSlowKernel(
+    const SampleNbArgs a) {
+  const uint32_t n_slow = *a.slow_count;
+  const int32_t count = a.count;
+  const int32_t t = a.et[0];
+  const int64_t total = (int64_t)n_slow * count;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total; s += stride) {
+    const int64_t q = s / count;
+    const int32_t j = (int32_t)(s - q * count);
+    const int64_t r = (int64_t)a.slow_list[q];
+    uint64_t node = a.roots[r];
+    if (a.root_mask != nullptr && a.root_mask[r / a.root_group]) node = 0;
+    Segment sg;
+    (void)LoadSegment<true>(a.g, FindRow(a.g, node), t, &sg);     // valid: it was queued
+    const Philox4 pb = RngBlock(a.seed, a.call_id, kDomainNeighbor, node, ((uint32_t)j) >> 1);
+    const double u = (j & 1) ? UnitFromWords(pb.w[2], pb.w[3]) : UnitFromWords(pb.w[0], pb.w[1]);
+    uint64_t id;
+    float wv;
+    BlockPivotSample(a.g, sg, u, &id, &wv);
+    const int64_t d = r * (int64_t)count + j;
+    a.out_id[d] = id;
+    a.out_w[d] = wv;
+    a.out_t[d] = t;
+    if (a.mark_owner != nullptr) MarkNextHop(a.g, a.mark_owner, id, true, d);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t done = atomicAdd(a.slow_count + 1, 1u);
+    if (done == gridDim.x - 1) { a.slow_count[0] = 0; a.slow_count[1] = 0; }
   }
 }
 

@@ -6,10 +6,14 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <cstdio>
+#include <map>
 #include <memory>
+#include <random>
 
 namespace euler {
+inline namespace gpu_abi {
 
 namespace {
 
@@ -29,12 +33,113 @@ Registry* GlobalRegistry() {
   return r;
 }
 
-// RAII device staging buffer
-struct DevBuf {
-  void* p = nullptr;
-  explicit DevBuf(size_t bytes) { if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) p = nullptr; }
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+// ---- process-wide sampling state (OpKernelContext::seed / NextCallId)
+std::atomic<uint32_t> g_call_seq{0};
+std::atomic<uint64_t> g_process_seed{0};
+std::once_flag g_seed_once;
+uint64_t ProcessSeed() {
+  std::call_once(g_seed_once, [] {
+    if (g_process_seed.load() == 0) {
+      std::random_device rd;
+      g_process_seed.store(((uint64_t)rd() << 32) ^ (uint64_t)rd() ^ 0x9E3779B97F4A7C15ULL);
+    }
+  });
+  return g_process_seed.load();
+}
+
+// ---- device staging of one op invocation.  Every host thread (the reference's
+// client pool runs 8 of them, client/query_proxy.cc:205-210) owns, per device, a
+// non-blocking HIP stream and a grow-only arena: an op bump-allocates its
+// staging buffers from the arena, enqueues copies and kernels on the stream and
+// synchronises once (twice when a size has to come back first).  No hipMalloc /
+// hipFree in steady state, nothing on the null stream, every HIP call checked:
+// a failure marks the scope and the op logs and returns WITHOUT allocating its
+// outputs.
+struct Arena {
+  hipStream_t stream = nullptr;
+  struct Chunk { void* p; size_t cap; size_t used; };
+  std::vector<Chunk> chunks;
+};
+
+Arena* ThreadArena(int device) {
+  // leaked on purpose: freeing device memory from thread_local destructors races
+  // with the HIP runtime's own teardown at process exit
+  thread_local std::map<int, Arena*>* arenas = new std::map<int, Arena*>();
+  Arena*& a = (*arenas)[device];
+  if (a == nullptr) a = new Arena();
+  return a;
+}
+
+class OpScope {
+ public:
+  explicit OpScope(euler_gpu_graph* g) {
+    int dev = 0;
+    if (g != nullptr) dev = euler_gpu_graph_device(g);
+    else (void)hipGetDevice(&dev);
+    Check(hipSetDevice(dev), "hipSetDevice");
+    arena_ = ThreadArena(dev);
+    if (ok_ && arena_->stream == nullptr)
+      Check(hipStreamCreateWithFlags(&arena_->stream, hipStreamNonBlocking), "hipStreamCreate");
+  }
+  ~OpScope() {
+    if (arena_ == nullptr) return;
+    if (arena_->chunks.size() > 1) {
+      // the op outgrew the arena: one chunk of the total size for the next call
+      size_t total = 0;
+      (void)hipStreamSynchronize(arena_->stream);
+      for (auto& c : arena_->chunks) { total += c.cap; (void)hipFree(c.p); }
+      arena_->chunks.clear();
+      void* p = nullptr;
+      if (hipMalloc(&p, total) == hipSuccess) arena_->chunks.push_back({p, total, 0});
+    }
+    for (auto& c : arena_->chunks) c.used = 0;
+  }
+  bool ok() const { return ok_; }
+  const std::string& error() const { return err_; }
+  void* stream() const { return (void*)arena_->stream; }
+  void* AllocBytes(size_t bytes) {
+    if (!ok_) return nullptr;
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    if (!arena_->chunks.empty()) {
+      auto& c = arena_->chunks.back();
+      if (c.cap - c.used >= bytes) { void* p = (uint8_t*)c.p + c.used; c.used += bytes; return p; }
+    }
+    size_t have = 0;
+    for (auto& c : arena_->chunks) have += c.cap;
+    size_t want = bytes > 2 * have ? bytes : 2 * have;
+    if (want < ((size_t)1 << 20)) want = (size_t)1 << 20;
+    void* p = nullptr;
+    if (!Check(hipMalloc(&p, want), "hipMalloc")) return nullptr;
+    arena_->chunks.push_back({p, want, bytes});
+    return p;
+  }
+  template <typename T> T* Alloc(size_t n) { return reinterpret_cast<T*>(AllocBytes(n * sizeof(T))); }
+  bool Upload(void* dst, const void* src, size_t bytes) {
+    if (!ok_ || dst == nullptr) return ok_ = false;
+    if (bytes == 0) return true;
+    return Check(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, arena_->stream), "copy to device");
+  }
+  bool Download(void* dst, const void* src, size_t bytes) {
+    if (!ok_ || src == nullptr) return ok_ = false;
+    if (bytes == 0) return true;
+    return Check(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, arena_->stream), "copy to host");
+  }
+  bool Sync() { return ok_ && Check(hipStreamSynchronize(arena_->stream), "stream sync"); }
+  // the C ABI's return code
+  bool Call(int rc) {
+    if (rc != 0) { ok_ = false; err_ = euler_gpu_last_error(); }
+    return ok_;
+  }
+
+ private:
+  bool Check(hipError_t e, const char* what) {
+    if (e != hipSuccess) { ok_ = false; err_ = std::string(what) + ": " + hipGetErrorString(e); }
+    return ok_;
+  }
+  Arena* arena_ = nullptr;
+  bool ok_ = true;
+  std::string err_;
 };
 
 bool GetIntArg(const NodeDef& nd, int i, OpKernelContext* ctx,
@@ -45,7 +150,45 @@ bool GetIntArg(const NodeDef& nd, int i, OpKernelContext* ctx,
   return true;
 }
 
+// DAGNodeProto.post_process entry -> (order_by, desc, limit); false = skip it
+// (get_neighbor_op.cc:117-168, sample_neighbor_op.cc:86-132: same grammar)
+bool ParsePostProcess(const std::string& post, int32_t* order_by, int32_t* desc, int64_t* limit) {
+  std::vector<std::string> vec;
+  std::string cur;
+  for (char ch : post) {
+    if (ch == ' ') { if (!cur.empty()) vec.push_back(cur); cur.clear(); }
+    else cur.push_back(ch);
+  }
+  if (!cur.empty()) vec.push_back(cur);
+  *order_by = 0; *desc = 0; *limit = -1;
+  if (vec.empty()) return false;
+  if (vec[0] == "order_by") {
+    if (vec.size() < 2 || vec.size() > 3) { LogError("Invalid post process: " + post); return false; }
+    *desc = vec.size() == 3 && vec[2] == "desc" ? 1 : 0;
+    if (vec[1] == "id") *order_by = 1;
+    else if (vec[1] == "weight") *order_by = 2;
+    else { LogError("Invalid order_by field: " + vec[1]); return false; }
+    return true;
+  }
+  if (vec[0] == "limit") {
+    if (vec.size() != 2) { LogError("Invalid post process: " + post); return false; }
+    *limit = atoll(vec[1].c_str());
+    return true;
+  }
+  return false;
+}
+
 }  // namespace
+
+uint64_t OpKernelContext::seed() const { return seed_set_ ? seed_ : ProcessSeed(); }
+uint32_t OpKernelContext::NextCallId() {
+  return call_id_set_ ? call_id_++ : g_call_seq.fetch_add(1, std::memory_order_relaxed);
+}
+void OpKernelContext::SetProcessSeed(uint64_t seed) {
+  (void)ProcessSeed();                 // consume the once-flag first
+  g_process_seed.store(seed);
+  g_call_seq.store(0);
+}
 
 size_t SizeOfType(DataType t) {
   switch (t) {
@@ -156,11 +299,16 @@ int CreateOpKernel(const std::string& name, OpKernel** kernel) {
 }
 
 // ---------------------------------------------------------------- kernels
+#define OP_FAIL(scope, what)                                                   \
+  do { LogError(std::string(what) + ": " + (scope).error()); return; } while (0)
 
 // API_SAMPLE_NB (core/kernels/sample_neighbor_op.cc:37-147, no-condition
 // path): inputs node_ids (uint64), edge_types (int32), count (int32[1]),
 // default_node (ignored, :134); outputs "<name>:0" idx [n,2] int32,
 // ":1" ids uint64, ":2" weights float, ":3" types int32 (FillNeighbor).
+// Post process (:86-132): `order_by id|weight [desc]` and `limit k` act on the
+// rows that HAVE samples; rows without are filled with count x (0, 0.0, 0)
+// afterwards (:134-143), so they keep `count` entries whatever the limit.
 class GpuSampleNeighborOp : public OpKernel {
  public:
   explicit GpuSampleNeighborOp(const std::string& name) : OpKernel(name) {}
@@ -179,18 +327,101 @@ class GpuSampleNeighborOp : public OpKernel {
     const int64_t n = ids_t->NumElements();
     const int32_t count = arg[0];
     const int64_t total = n * count;
-    (void)hipSetDevice(euler_gpu_graph_device(g));
-    DevBuf d_ids(n * 8), d_oid(total * 8), d_ow(total * 4), d_ot(total * 4);
-    if (!d_ids.p || !d_oid.p || !d_ow.p || !d_ot.p) { LogError("API_SAMPLE_NB: device allocation failed"); return; }
-    (void)hipMemcpy(d_ids.p, ids_t->Raw<uint64_t>(), n * 8, hipMemcpyHostToDevice);
-    const int rc = euler_gpu_sample_neighbor(
-        g, nullptr, ctx->seed(), ctx->NextCallId(), d_ids.as<uint64_t>(), n, nullptr,
-        1, edge_types.data(), (int32_t)edge_types.size(), count,
-        EULER_GPU_LAYOUT_CORE, 0, d_oid.as<uint64_t>(), d_ow.as<float>(),
-        d_ot.as<int32_t>(), nullptr);
-    if (rc != 0) { LogError(std::string("API_SAMPLE_NB: ") + euler_gpu_last_error()); return; }
-    Tensor *idx = nullptr, *oid = nullptr, *ow = nullptr, *ot = nullptr;
-    if (ctx->Allocate(OutputName(nd, 0), {(size_t)n, 2}, kInt32, &idx) != 0 ||
+    bool post = false;
+    for (const std::string& pp : nd.post_process) {
+      int32_t ob, de; int64_t li;
+      post = post || ParsePostProcess(pp, &ob, &de, &li);
+    }
+    OpScope sc(g);
+    uint64_t* d_ids = sc.Alloc<uint64_t>(n);
+    uint64_t* d_oid = sc.Alloc<uint64_t>(total);
+    float* d_ow = sc.Alloc<float>(total);
+    int32_t* d_ot = sc.Alloc<int32_t>(total);
+    uint8_t* d_mask = sc.Alloc<uint8_t>(n);
+    if (!sc.Upload(d_ids, ids_t->Raw<uint64_t>(), n * 8)) OP_FAIL(sc, "API_SAMPLE_NB");
+    if (!sc.Call(euler_gpu_sample_neighbor(
+            g, sc.stream(), ctx->seed(), ctx->NextCallId(), d_ids, n, nullptr, 1,
+            edge_types.data(), (int32_t)edge_types.size(), count, EULER_GPU_LAYOUT_CORE, 0,
+            d_oid, d_ow, d_ot, d_mask)))
+      OP_FAIL(sc, "API_SAMPLE_NB");
+    std::vector<int32_t> idx((size_t)n * 2);
+    std::vector<uint8_t> mask((size_t)n, 0);
+    int64_t out_total = total;
+    if (post && n > 0) {
+      // rows with samples: [i * count, (i + 1) * count); rows without: empty, so that
+      // order_by / limit leave them alone; the device post-process repacks in place
+      if (!sc.Download(mask.data(), d_mask, (size_t)n) || !sc.Sync()) OP_FAIL(sc, "API_SAMPLE_NB");
+      // compact the valid rows to the front (the post-process expects packed rows)
+      int64_t w = 0;
+      for (int64_t i = 0; i < n; ++i) {
+        idx[2 * i] = (int32_t)w;
+        if (!mask[i]) w += count;
+        idx[2 * i + 1] = (int32_t)w;
+      }
+      uint64_t* p_id = sc.Alloc<uint64_t>(w);
+      float* p_w = sc.Alloc<float>(w);
+      int32_t* p_t = sc.Alloc<int32_t>(w);
+      int32_t* d_idx = sc.Alloc<int32_t>(n * 2);
+      if (!sc.ok()) OP_FAIL(sc, "API_SAMPLE_NB");
+      // runs of consecutive valid rows move with one copy each
+      for (int64_t i = 0; i < n;) {
+        if (mask[i]) { ++i; continue; }
+        int64_t j = i;
+        while (j < n && !mask[j]) ++j;
+        const size_t src = (size_t)i * count, dst = (size_t)idx[2 * i], len = (size_t)(j - i) * count;
+        if (hipMemcpyAsync(p_id + dst, d_oid + src, len * 8, hipMemcpyDeviceToDevice, (hipStream_t)sc.stream()) != hipSuccess ||
+            hipMemcpyAsync(p_w + dst, d_ow + src, len * 4, hipMemcpyDeviceToDevice, (hipStream_t)sc.stream()) != hipSuccess ||
+            hipMemcpyAsync(p_t + dst, d_ot + src, len * 4, hipMemcpyDeviceToDevice, (hipStream_t)sc.stream()) != hipSuccess) {
+          LogError("API_SAMPLE_NB: device copy failed");
+          return;
+        }
+        i = j;
+      }
+      if (!sc.Upload(d_idx, idx.data(), (size_t)n * 8)) OP_FAIL(sc, "API_SAMPLE_NB");
+      int64_t cur = w;
+      for (const std::string& pp : nd.post_process) {
+        int32_t order_by, desc; int64_t limit;
+        if (!ParsePostProcess(pp, &order_by, &desc, &limit)) continue;
+        if (!sc.Call(euler_gpu_neighbor_post_process(sc.stream(), n, d_idx, cur, p_id, p_w, p_t,
+                                                     order_by, desc, limit, &cur)))
+          OP_FAIL(sc, "API_SAMPLE_NB post process");
+      }
+      std::vector<int32_t> pidx((size_t)n * 2);
+      std::vector<uint64_t> hid((size_t)cur);
+      std::vector<float> hw((size_t)cur);
+      std::vector<int32_t> ht((size_t)cur);
+      if (!sc.Download(pidx.data(), d_idx, (size_t)n * 8) || !sc.Download(hid.data(), p_id, (size_t)cur * 8) ||
+          !sc.Download(hw.data(), p_w, (size_t)cur * 4) || !sc.Download(ht.data(), p_t, (size_t)cur * 4) ||
+          !sc.Sync())
+        OP_FAIL(sc, "API_SAMPLE_NB");
+      out_total = 0;
+      for (int64_t i = 0; i < n; ++i) out_total += mask[i] ? count : pidx[2 * i + 1] - pidx[2 * i];
+      Tensor *t_idx = nullptr, *oid = nullptr, *ow = nullptr, *ot = nullptr;
+      if (ctx->Allocate(OutputName(nd, 0), {(size_t)n, 2}, kInt32, &t_idx) != 0 ||
+          ctx->Allocate(OutputName(nd, 1), {(size_t)out_total}, kUInt64, &oid) != 0 ||
+          ctx->Allocate(OutputName(nd, 2), {(size_t)out_total}, kFloat, &ow) != 0 ||
+          ctx->Allocate(OutputName(nd, 3), {(size_t)out_total}, kInt32, &ot) != 0) {
+        LogError("Allocate output tensor failed!");
+        return;
+      }
+      int64_t o = 0;
+      for (int64_t i = 0; i < n; ++i) {
+        t_idx->Raw<int32_t>()[2 * i] = (int32_t)o;
+        if (mask[i]) {
+          for (int32_t j = 0; j < count; ++j, ++o) {
+            oid->Raw<uint64_t>()[o] = 0; ow->Raw<float>()[o] = 0.f; ot->Raw<int32_t>()[o] = 0;
+          }
+        } else {
+          for (int32_t s2 = pidx[2 * i]; s2 < pidx[2 * i + 1]; ++s2, ++o) {
+            oid->Raw<uint64_t>()[o] = hid[s2]; ow->Raw<float>()[o] = hw[s2]; ot->Raw<int32_t>()[o] = ht[s2];
+          }
+        }
+        t_idx->Raw<int32_t>()[2 * i + 1] = (int32_t)o;
+      }
+      return;
+    }
+    Tensor *t_idx = nullptr, *oid = nullptr, *ow = nullptr, *ot = nullptr;
+    if (ctx->Allocate(OutputName(nd, 0), {(size_t)n, 2}, kInt32, &t_idx) != 0 ||
         ctx->Allocate(OutputName(nd, 1), {(size_t)total}, kUInt64, &oid) != 0 ||
         ctx->Allocate(OutputName(nd, 2), {(size_t)total}, kFloat, &ow) != 0 ||
         ctx->Allocate(OutputName(nd, 3), {(size_t)total}, kInt32, &ot) != 0) {
@@ -198,12 +429,15 @@ class GpuSampleNeighborOp : public OpKernel {
       return;
     }
     for (int64_t i = 0; i < n; ++i) {
-      idx->Raw<int32_t>()[2 * i] = (int32_t)(i * count);
-      idx->Raw<int32_t>()[2 * i + 1] = (int32_t)((i + 1) * count);
+      t_idx->Raw<int32_t>()[2 * i] = (int32_t)(i * count);
+      t_idx->Raw<int32_t>()[2 * i + 1] = (int32_t)((i + 1) * count);
     }
-    (void)hipMemcpy(oid->Raw<uint64_t>(), d_oid.p, total * 8, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(ow->Raw<float>(), d_ow.p, total * 4, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(ot->Raw<int32_t>(), d_ot.p, total * 4, hipMemcpyDeviceToHost);
+    if (!sc.Download(oid->Raw<uint64_t>(), d_oid, (size_t)total * 8) ||
+        !sc.Download(ow->Raw<float>(), d_ow, (size_t)total * 4) ||
+        !sc.Download(ot->Raw<int32_t>(), d_ot, (size_t)total * 4) || !sc.Sync()) {
+      for (int i = 0; i < 4; ++i) ctx->Deallocate(OutputName(nd, i));
+      OP_FAIL(sc, "API_SAMPLE_NB");
+    }
   }
 };
 REGISTER_OP_KERNEL("API_SAMPLE_NB", GpuSampleNeighborOp);
@@ -222,14 +456,12 @@ class GpuSampleNodeOp : public OpKernel {
     euler_gpu_graph* g = ctx->graph();
     if (!g) { LogError("API_SAMPLE_NODE: no graph initialised"); return; }
     const int32_t count = cnt[0];
-    (void)hipSetDevice(euler_gpu_graph_device(g));
-    DevBuf d_out((size_t)count * 8);
-    const int rc = euler_gpu_sample_node(g, nullptr, ctx->seed(), ctx->NextCallId(),
-                                         types.data(), (int32_t)types.size(), count,
-                                         d_out.as<uint64_t>());
-    if (rc != 0) {
-      LogError("Expect sample count: " + std::to_string(count) + ", real got:0 (" +
-               euler_gpu_last_error() + ")");
+    OpScope sc(g);
+    uint64_t* d_out = sc.Alloc<uint64_t>((size_t)(count > 0 ? count : 0));
+    if (!sc.ok()) OP_FAIL(sc, "API_SAMPLE_NODE");
+    if (!sc.Call(euler_gpu_sample_node(g, sc.stream(), ctx->seed(), ctx->NextCallId(), types.data(),
+                                       (int32_t)types.size(), count, d_out))) {
+      LogError("Expect sample count: " + std::to_string(count) + ", real got:0 (" + sc.error() + ")");
       return;
     }
     Tensor* out = nullptr;
@@ -237,7 +469,10 @@ class GpuSampleNodeOp : public OpKernel {
       LogError("Allocate output tensor failed!");
       return;
     }
-    (void)hipMemcpy(out->Raw<int64_t>(), d_out.p, (size_t)count * 8, hipMemcpyDeviceToHost);
+    if (!sc.Download(out->Raw<int64_t>(), d_out, (size_t)count * 8) || !sc.Sync()) {
+      ctx->Deallocate(OutputName(nd, 0));
+      OP_FAIL(sc, "API_SAMPLE_NODE");
+    }
   }
 };
 REGISTER_OP_KERNEL("API_SAMPLE_NODE", GpuSampleNodeOp);
@@ -250,20 +485,24 @@ class GpuIdUniqueOp : public OpKernel {
     Tensor* ids_t = nullptr;
     if (nd.inputs.empty() || ctx->tensor(nd.inputs[0], &ids_t) != 0) { LogError("ID_UNIQUE: missing input"); return; }
     const int64_t n = ids_t->NumElements();
-    DevBuf d_ids(n * 8), d_uq(n * 8), d_gi(n * 4);
-    (void)hipMemcpy(d_ids.p, ids_t->Raw<uint64_t>(), n * 8, hipMemcpyHostToDevice);
+    OpScope sc(ctx->graph());
+    uint64_t* d_ids = sc.Alloc<uint64_t>(n);
+    uint64_t* d_uq = sc.Alloc<uint64_t>(n);
+    int32_t* d_gi = sc.Alloc<int32_t>(n);
+    if (!sc.Upload(d_ids, ids_t->Raw<uint64_t>(), (size_t)n * 8)) OP_FAIL(sc, "ID_UNIQUE");
     int64_t nu = 0;
-    if (euler_gpu_id_unique(nullptr, d_ids.as<uint64_t>(), n, d_uq.as<uint64_t>(),
-                            d_gi.as<int32_t>(), &nu) != 0) {
-      LogError(std::string("ID_UNIQUE: ") + euler_gpu_last_error());
+    if (!sc.Call(euler_gpu_id_unique(sc.stream(), d_ids, n, d_uq, d_gi, &nu))) OP_FAIL(sc, "ID_UNIQUE");
+    Tensor *uq = nullptr, *gi = nullptr;
+    if (ctx->Allocate(OutputName(nd, 0), {(size_t)nu}, kUInt64, &uq) != 0 ||
+        ctx->Allocate(OutputName(nd, 1), {(size_t)n}, kInt32, &gi) != 0) {
+      LogError("ID_UNIQUE: allocate failed");
       return;
     }
-    Tensor *uq = nullptr, *gi = nullptr;
-    ctx->Allocate(OutputName(nd, 0), {(size_t)nu}, kUInt64, &uq);
-    ctx->Allocate(OutputName(nd, 1), {(size_t)n}, kInt32, &gi);
-    if (!uq || !gi) { LogError("ID_UNIQUE: allocate failed"); return; }
-    (void)hipMemcpy(uq->Raw<uint64_t>(), d_uq.p, nu * 8, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(gi->Raw<int32_t>(), d_gi.p, n * 4, hipMemcpyDeviceToHost);
+    if (!sc.Download(uq->Raw<uint64_t>(), d_uq, (size_t)nu * 8) ||
+        !sc.Download(gi->Raw<int32_t>(), d_gi, (size_t)n * 4) || !sc.Sync()) {
+      ctx->Deallocate(OutputName(nd, 0)); ctx->Deallocate(OutputName(nd, 1));
+      OP_FAIL(sc, "ID_UNIQUE");
+    }
   }
 };
 REGISTER_OP_KERNEL("ID_UNIQUE", GpuIdUniqueOp);
@@ -277,18 +516,20 @@ class GpuIdxGatherOp : public OpKernel {
     if (nd.inputs.size() < 2 || ctx->tensor(nd.inputs[0], &idx_t) != 0 ||
         ctx->tensor(nd.inputs[1], &gi_t) != 0) { LogError("IDX_GATHER: missing input"); return; }
     const int64_t n = gi_t->NumElements();
-    DevBuf d_idx(idx_t->TotalBytes()), d_gi(n * 4), d_out(n * 8);
-    (void)hipMemcpy(d_idx.p, idx_t->Raw<int32_t>(), idx_t->TotalBytes(), hipMemcpyHostToDevice);
-    (void)hipMemcpy(d_gi.p, gi_t->Raw<int32_t>(), n * 4, hipMemcpyHostToDevice);
+    OpScope sc(ctx->graph());
+    int32_t* d_idx = (int32_t*)sc.AllocBytes(idx_t->TotalBytes());
+    int32_t* d_gi = sc.Alloc<int32_t>(n);
+    int32_t* d_out = sc.Alloc<int32_t>(n * 2);
+    if (!sc.Upload(d_idx, idx_t->Raw<int32_t>(), idx_t->TotalBytes()) ||
+        !sc.Upload(d_gi, gi_t->Raw<int32_t>(), (size_t)n * 4)) OP_FAIL(sc, "IDX_GATHER");
     int64_t total = 0;
-    if (euler_gpu_idx_gather(nullptr, d_idx.as<int32_t>(), d_gi.as<int32_t>(), n,
-                             d_out.as<int32_t>(), &total) != 0) {
-      LogError(std::string("IDX_GATHER: ") + euler_gpu_last_error());
-      return;
-    }
+    if (!sc.Call(euler_gpu_idx_gather(sc.stream(), d_idx, d_gi, n, d_out, &total))) OP_FAIL(sc, "IDX_GATHER");
     Tensor* out = nullptr;
     if (ctx->Allocate(OutputName(nd, 0), {(size_t)n, 2}, kInt32, &out) != 0) return;
-    (void)hipMemcpy(out->Raw<int32_t>(), d_out.p, n * 8, hipMemcpyDeviceToHost);
+    if (!sc.Download(out->Raw<int32_t>(), d_out, (size_t)n * 8) || !sc.Sync()) {
+      ctx->Deallocate(OutputName(nd, 0));
+      OP_FAIL(sc, "IDX_GATHER");
+    }
   }
 };
 REGISTER_OP_KERNEL("IDX_GATHER", GpuIdxGatherOp);
@@ -309,22 +550,26 @@ class GpuDataGatherOp : public OpKernel {
     }
     const int64_t n = gi_t->NumElements();
     const int32_t es = (int32_t)SizeOfType(type);
-    DevBuf d_data(data_t->TotalBytes()), d_idx(idx_t->TotalBytes()), d_gi(n * 4), d_oidx(n * 8);
-    (void)hipMemcpy(d_data.p, data_t->Raw<char>(), data_t->TotalBytes(), hipMemcpyHostToDevice);
-    (void)hipMemcpy(d_idx.p, idx_t->Raw<int32_t>(), idx_t->TotalBytes(), hipMemcpyHostToDevice);
-    (void)hipMemcpy(d_gi.p, gi_t->Raw<int32_t>(), n * 4, hipMemcpyHostToDevice);
+    OpScope sc(ctx->graph());
+    void* d_data = sc.AllocBytes(data_t->TotalBytes());
+    int32_t* d_idx = (int32_t*)sc.AllocBytes(idx_t->TotalBytes());
+    int32_t* d_gi = sc.Alloc<int32_t>(n);
+    int32_t* d_oidx = sc.Alloc<int32_t>(n * 2);
+    if (!sc.Upload(d_data, data_t->Raw<char>(), data_t->TotalBytes()) ||
+        !sc.Upload(d_idx, idx_t->Raw<int32_t>(), idx_t->TotalBytes()) ||
+        !sc.Upload(d_gi, gi_t->Raw<int32_t>(), (size_t)n * 4)) OP_FAIL(sc, "DATA_GATHER");
     int64_t total = 0;
-    if (euler_gpu_idx_gather(nullptr, d_idx.as<int32_t>(), d_gi.as<int32_t>(), n,
-                             d_oidx.as<int32_t>(), &total) != 0) { LogError(euler_gpu_last_error()); return; }
-    DevBuf d_out((size_t)total * es);
-    if (euler_gpu_data_gather(nullptr, d_data.p, es, d_idx.as<int32_t>(),
-                              d_gi.as<int32_t>(), d_oidx.as<int32_t>(), n, d_out.p) != 0) {
-      LogError(euler_gpu_last_error());
-      return;
-    }
+    if (!sc.Call(euler_gpu_idx_gather(sc.stream(), d_idx, d_gi, n, d_oidx, &total))) OP_FAIL(sc, "DATA_GATHER");
+    void* d_out = sc.AllocBytes((size_t)total * es);
+    if (!sc.ok()) OP_FAIL(sc, "DATA_GATHER");
+    if (!sc.Call(euler_gpu_data_gather(sc.stream(), d_data, es, d_idx, d_gi, d_oidx, n, d_out)))
+      OP_FAIL(sc, "DATA_GATHER");
     Tensor* out = nullptr;
     if (ctx->Allocate(OutputName(nd, 0), {(size_t)total}, type, &out) != 0) return;
-    (void)hipMemcpy(out->Raw<char>(), d_out.p, (size_t)total * es, hipMemcpyDeviceToHost);
+    if (!sc.Download(out->Raw<char>(), d_out, (size_t)total * es) || !sc.Sync()) {
+      ctx->Deallocate(OutputName(nd, 0));
+      OP_FAIL(sc, "DATA_GATHER");
+    }
   }
 };
 REGISTER_OP_KERNEL("DATA_GATHER", GpuDataGatherOp);
@@ -342,58 +587,44 @@ class GpuGetNeighborOp : public OpKernel {
     euler_gpu_graph* g = ctx->graph();
     if (!g) { LogError("API_GET_NB_NODE: no graph initialised"); return; }
     const int64_t n = ids_t->NumElements();
-    (void)hipSetDevice(euler_gpu_graph_device(g));
-    DevBuf d_ids(n * 8), d_idx(n * 8);
-    (void)hipMemcpy(d_ids.p, ids_t->Raw<uint64_t>(), n * 8, hipMemcpyHostToDevice);
+    OpScope sc(g);
+    uint64_t* d_ids = sc.Alloc<uint64_t>(n);
+    int32_t* d_idx = sc.Alloc<int32_t>(n * 2);
+    if (!sc.Upload(d_ids, ids_t->Raw<uint64_t>(), (size_t)n * 8)) OP_FAIL(sc, "API_GET_NB_NODE");
     int64_t total = 0;
-    if (euler_gpu_get_full_neighbor(g, nullptr, d_ids.as<uint64_t>(), n, et.data(),
-                                    (int32_t)et.size(), d_idx.as<int32_t>(), &total,
-                                    nullptr, nullptr, nullptr) != 0) { LogError(euler_gpu_last_error()); return; }
-    DevBuf d_oid(total * 8), d_ow(total * 4), d_ot(total * 4);
-    if (euler_gpu_get_full_neighbor(g, nullptr, d_ids.as<uint64_t>(), n, et.data(),
-                                    (int32_t)et.size(), d_idx.as<int32_t>(), &total,
-                                    d_oid.as<uint64_t>(), d_ow.as<float>(),
-                                    d_ot.as<int32_t>()) != 0) { LogError(euler_gpu_last_error()); return; }
+    if (!sc.Call(euler_gpu_get_full_neighbor(g, sc.stream(), d_ids, n, et.data(), (int32_t)et.size(),
+                                             d_idx, &total, nullptr, nullptr, nullptr)))
+      OP_FAIL(sc, "API_GET_NB_NODE");
+    uint64_t* d_oid = sc.Alloc<uint64_t>(total);
+    float* d_ow = sc.Alloc<float>(total);
+    int32_t* d_ot = sc.Alloc<int32_t>(total);
+    if (!sc.ok()) OP_FAIL(sc, "API_GET_NB_NODE");
+    if (!sc.Call(euler_gpu_get_full_neighbor(g, sc.stream(), d_ids, n, et.data(), (int32_t)et.size(),
+                                             d_idx, &total, d_oid, d_ow, d_ot)))
+      OP_FAIL(sc, "API_GET_NB_NODE");
     // Post process (get_neighbor_op.cc:117-168): applied in order
     for (const std::string& post : nd.post_process) {
-      std::vector<std::string> vec;
-      std::string cur;
-      for (char ch : post) {
-        if (ch == ' ') { if (!cur.empty()) vec.push_back(cur); cur.clear(); }
-        else cur.push_back(ch);
-      }
-      if (!cur.empty()) vec.push_back(cur);
-      if (vec.empty()) continue;
-      int32_t order_by = 0, desc = 0;
-      int64_t limit = -1;
-      if (vec[0] == "order_by") {
-        if (vec.size() < 2 || vec.size() > 3) { LogError("Invalid post process: " + post); continue; }
-        desc = vec.size() == 3 && vec[2] == "desc" ? 1 : 0;
-        if (vec[1] == "id") order_by = 1;
-        else if (vec[1] == "weight") order_by = 2;
-        else { LogError("Invalid order_by field: " + vec[1]); continue; }
-      } else if (vec[0] == "limit") {
-        if (vec.size() != 2) { LogError("Invalid post process: " + post); continue; }
-        limit = atoll(vec[1].c_str());
-      } else {
-        continue;
-      }
-      if (euler_gpu_neighbor_post_process(nullptr, n, d_idx.as<int32_t>(), total,
-                                          d_oid.as<uint64_t>(), d_ow.as<float>(),
-                                          d_ot.as<int32_t>(), order_by, desc, limit,
-                                          &total) != 0) { LogError(euler_gpu_last_error()); return; }
+      int32_t order_by, desc; int64_t limit;
+      if (!ParsePostProcess(post, &order_by, &desc, &limit)) continue;
+      if (!sc.Call(euler_gpu_neighbor_post_process(sc.stream(), n, d_idx, total, d_oid, d_ow, d_ot,
+                                                   order_by, desc, limit, &total)))
+        OP_FAIL(sc, "API_GET_NB_NODE post process");
     }
-    (void)hipDeviceSynchronize();
     Tensor *idx = nullptr, *oid = nullptr, *ow = nullptr, *ot = nullptr;
-    ctx->Allocate(OutputName(nd, 0), {(size_t)n, 2}, kInt32, &idx);
-    ctx->Allocate(OutputName(nd, 1), {(size_t)total}, kUInt64, &oid);
-    ctx->Allocate(OutputName(nd, 2), {(size_t)total}, kFloat, &ow);
-    ctx->Allocate(OutputName(nd, 3), {(size_t)total}, kInt32, &ot);
-    if (!idx || !oid || !ow || !ot) { LogError("Allocate output tensor failed!"); return; }
-    (void)hipMemcpy(idx->Raw<int32_t>(), d_idx.p, n * 8, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(oid->Raw<uint64_t>(), d_oid.p, total * 8, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(ow->Raw<float>(), d_ow.p, total * 4, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(ot->Raw<int32_t>(), d_ot.p, total * 4, hipMemcpyDeviceToHost);
+    if (ctx->Allocate(OutputName(nd, 0), {(size_t)n, 2}, kInt32, &idx) != 0 ||
+        ctx->Allocate(OutputName(nd, 1), {(size_t)total}, kUInt64, &oid) != 0 ||
+        ctx->Allocate(OutputName(nd, 2), {(size_t)total}, kFloat, &ow) != 0 ||
+        ctx->Allocate(OutputName(nd, 3), {(size_t)total}, kInt32, &ot) != 0) {
+      LogError("Allocate output tensor failed!");
+      return;
+    }
+    if (!sc.Download(idx->Raw<int32_t>(), d_idx, (size_t)n * 8) ||
+        !sc.Download(oid->Raw<uint64_t>(), d_oid, (size_t)total * 8) ||
+        !sc.Download(ow->Raw<float>(), d_ow, (size_t)total * 4) ||
+        !sc.Download(ot->Raw<int32_t>(), d_ot, (size_t)total * 4) || !sc.Sync()) {
+      for (int i = 0; i < 4; ++i) ctx->Deallocate(OutputName(nd, i));
+      OP_FAIL(sc, "API_GET_NB_NODE");
+    }
   }
 };
 REGISTER_OP_KERNEL("API_GET_NB_NODE", GpuGetNeighborOp);
@@ -417,15 +648,12 @@ class GpuGetEdgeSumWeightOp : public OpKernel {
     euler_gpu_graph* g = ctx->graph();
     if (!g) { LogError("API_GET_EDGE_SUM_WEIGHT: no graph initialised"); return; }
     const int64_t n = root_t->NumElements();
-    (void)hipSetDevice(euler_gpu_graph_device(g));
-    DevBuf d_ids(n * 8), d_w(n * 4);
-    if (!d_ids.p || !d_w.p) { LogError("API_GET_EDGE_SUM_WEIGHT: device allocation failed"); return; }
-    (void)hipMemcpy(d_ids.p, root_t->Raw<uint64_t>(), n * 8, hipMemcpyHostToDevice);
-    if (euler_gpu_get_edge_sum_weight(g, nullptr, d_ids.as<uint64_t>(), n, et.data(),
-                                      (int32_t)et.size(), d_w.as<float>()) != 0) {
-      LogError(std::string("API_GET_EDGE_SUM_WEIGHT: ") + euler_gpu_last_error());
-      return;
-    }
+    OpScope sc(g);
+    uint64_t* d_ids = sc.Alloc<uint64_t>(n);
+    float* d_w = sc.Alloc<float>(n);
+    if (!sc.Upload(d_ids, root_t->Raw<uint64_t>(), (size_t)n * 8)) OP_FAIL(sc, "API_GET_EDGE_SUM_WEIGHT");
+    if (!sc.Call(euler_gpu_get_edge_sum_weight(g, sc.stream(), d_ids, n, et.data(), (int32_t)et.size(), d_w)))
+      OP_FAIL(sc, "API_GET_EDGE_SUM_WEIGHT");
     Tensor *o_root = nullptr, *o_w = nullptr;
     if (ctx->Allocate(OutputName(nd, 0), {(size_t)n, 1}, kUInt64, &o_root) != 0 ||
         ctx->Allocate(OutputName(nd, 1), {(size_t)n, 1}, kFloat, &o_w) != 0) {
@@ -433,7 +661,10 @@ class GpuGetEdgeSumWeightOp : public OpKernel {
       return;
     }
     memcpy(o_root->Raw<uint64_t>(), root_t->Raw<uint64_t>(), (size_t)n * 8);
-    (void)hipMemcpy(o_w->Raw<float>(), d_w.p, n * 4, hipMemcpyDeviceToHost);
+    if (!sc.Download(o_w->Raw<float>(), d_w, (size_t)n * 4) || !sc.Sync()) {
+      ctx->Deallocate(OutputName(nd, 0)); ctx->Deallocate(OutputName(nd, 1));
+      OP_FAIL(sc, "API_GET_EDGE_SUM_WEIGHT");
+    }
   }
 };
 REGISTER_OP_KERNEL("API_GET_EDGE_SUM_WEIGHT", GpuGetEdgeSumWeightOp);
@@ -457,24 +688,24 @@ class GpuSampleRootOp : public OpKernel {
     const int64_t batch = roots_t->NumElements() / n;
     if (batch == 0) { LogError("batch size is zero!"); abort(); }   // EULER_LOG(FATAL)
     const int64_t cells = batch * n, draws = batch * m;
-    euler_gpu_graph* g = ctx->graph();
-    if (g) (void)hipSetDevice(euler_gpu_graph_device(g));
-    DevBuf d_r(cells * 8), d_w(cells * 4), d_o(draws * 8);
-    if (!d_r.p || !d_w.p || !d_o.p) { LogError("API_SAMPLE_ROOT: device allocation failed"); return; }
-    (void)hipMemcpy(d_r.p, roots_t->Raw<uint64_t>(), cells * 8, hipMemcpyHostToDevice);
-    (void)hipMemcpy(d_w.p, w_t->Raw<float>(), cells * 4, hipMemcpyHostToDevice);
-    if (euler_gpu_sample_root(nullptr, ctx->seed(), ctx->NextCallId(), d_r.as<uint64_t>(),
-                              d_w.as<float>(), batch, n, m, default_node,
-                              d_o.as<uint64_t>()) != 0) {
-      LogError(std::string("API_SAMPLE_ROOT: ") + euler_gpu_last_error());
-      return;
-    }
+    OpScope sc(ctx->graph());
+    uint64_t* d_r = sc.Alloc<uint64_t>(cells);
+    float* d_w = sc.Alloc<float>(cells);
+    uint64_t* d_o = sc.Alloc<uint64_t>(draws);
+    if (!sc.Upload(d_r, roots_t->Raw<uint64_t>(), (size_t)cells * 8) ||
+        !sc.Upload(d_w, w_t->Raw<float>(), (size_t)cells * 4)) OP_FAIL(sc, "API_SAMPLE_ROOT");
+    if (!sc.Call(euler_gpu_sample_root(sc.stream(), ctx->seed(), ctx->NextCallId(), d_r, d_w, batch, n, m,
+                                       default_node, d_o)))
+      OP_FAIL(sc, "API_SAMPLE_ROOT");
     Tensor* out = nullptr;
     if (ctx->Allocate(OutputName(nd, 0), {(size_t)draws}, kUInt64, &out) != 0) {
       LogError("Allocate output tensor failed!");
       return;
     }
-    (void)hipMemcpy(out->Raw<uint64_t>(), d_o.p, draws * 8, hipMemcpyDeviceToHost);
+    if (!sc.Download(out->Raw<uint64_t>(), d_o, (size_t)draws * 8) || !sc.Sync()) {
+      ctx->Deallocate(OutputName(nd, 0));
+      OP_FAIL(sc, "API_SAMPLE_ROOT");
+    }
   }
 };
 REGISTER_OP_KERNEL("API_SAMPLE_ROOT", GpuSampleRootOp);
@@ -494,17 +725,15 @@ class GpuSampleLayerOp : public OpKernel {
     euler_gpu_graph* g = ctx->graph();
     if (!g) { LogError("API_SAMPLE_L: no graph initialised"); return; }
     const int64_t n = root_t->NumElements();
-    (void)hipSetDevice(euler_gpu_graph_device(g));
-    DevBuf d_r(n * 8), d_id(n * 8), d_w(n * 4), d_t(n * 4);
-    if (!d_r.p || !d_id.p || !d_w.p || !d_t.p) { LogError("API_SAMPLE_L: device allocation failed"); return; }
-    (void)hipMemcpy(d_r.p, root_t->Raw<uint64_t>(), n * 8, hipMemcpyHostToDevice);
-    if (euler_gpu_sample_layer(g, nullptr, ctx->seed(), ctx->NextCallId(),
-                               d_r.as<uint64_t>(), n, et.data(), (int32_t)et.size(),
-                               default_node, d_id.as<uint64_t>(), d_w.as<float>(),
-                               d_t.as<int32_t>()) != 0) {
-      LogError(std::string("API_SAMPLE_L: ") + euler_gpu_last_error());
-      return;
-    }
+    OpScope sc(g);
+    uint64_t* d_r = sc.Alloc<uint64_t>(n);
+    uint64_t* d_id = sc.Alloc<uint64_t>(n);
+    float* d_w = sc.Alloc<float>(n);
+    int32_t* d_t = sc.Alloc<int32_t>(n);
+    if (!sc.Upload(d_r, root_t->Raw<uint64_t>(), (size_t)n * 8)) OP_FAIL(sc, "API_SAMPLE_L");
+    if (!sc.Call(euler_gpu_sample_layer(g, sc.stream(), ctx->seed(), ctx->NextCallId(), d_r, n, et.data(),
+                                        (int32_t)et.size(), default_node, d_id, d_w, d_t)))
+      OP_FAIL(sc, "API_SAMPLE_L");
     Tensor *o_nb = nullptr, *o_w = nullptr, *o_t = nullptr;
     if (ctx->Allocate(OutputName(nd, 0), {(size_t)n, 1}, kUInt64, &o_nb) != 0 ||
         ctx->Allocate(OutputName(nd, 1), {(size_t)n, 1}, kFloat, &o_w) != 0 ||
@@ -512,9 +741,12 @@ class GpuSampleLayerOp : public OpKernel {
       LogError("Allocate output tensor failed!");
       return;
     }
-    (void)hipMemcpy(o_nb->Raw<uint64_t>(), d_id.p, n * 8, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(o_w->Raw<float>(), d_w.p, n * 4, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(o_t->Raw<int32_t>(), d_t.p, n * 4, hipMemcpyDeviceToHost);
+    if (!sc.Download(o_nb->Raw<uint64_t>(), d_id, (size_t)n * 8) ||
+        !sc.Download(o_w->Raw<float>(), d_w, (size_t)n * 4) ||
+        !sc.Download(o_t->Raw<int32_t>(), d_t, (size_t)n * 4) || !sc.Sync()) {
+      for (int i = 0; i < 3; ++i) ctx->Deallocate(OutputName(nd, i));
+      OP_FAIL(sc, "API_SAMPLE_L");
+    }
   }
 };
 REGISTER_OP_KERNEL("API_SAMPLE_L", GpuSampleLayerOp);
@@ -541,26 +773,22 @@ class GpuLocalSampleLayerOp : public OpKernel {
     const int32_t n = n_v[0], m = m_v[0];
     const int64_t batch = idx_t->NumElements() / (n * 2);
     const int64_t total = id_t->NumElements(), draws = batch * m;
-    euler_gpu_graph* g = ctx->graph();
-    if (g) (void)hipSetDevice(euler_gpu_graph_device(g));
-    DevBuf d_idx((size_t)idx_t->NumElements() * 4), d_id(total * 8), d_w(total * 4),
-        d_t(total * 4), o_id(draws * 8), o_w(draws * 4), o_t(draws * 4);
-    if (!d_idx.p || !d_id.p || !d_w.p || !d_t.p || !o_id.p || !o_w.p || !o_t.p) {
-      LogError("API_LOCAL_SAMPLE_L: device allocation failed");
-      return;
-    }
-    (void)hipMemcpy(d_idx.p, idx_t->Raw<int32_t>(), (size_t)idx_t->NumElements() * 4, hipMemcpyHostToDevice);
-    (void)hipMemcpy(d_id.p, id_t->Raw<uint64_t>(), total * 8, hipMemcpyHostToDevice);
-    (void)hipMemcpy(d_w.p, w_t->Raw<float>(), total * 4, hipMemcpyHostToDevice);
-    (void)hipMemcpy(d_t.p, t_t->Raw<int32_t>(), total * 4, hipMemcpyHostToDevice);
-    if (euler_gpu_local_sample_layer(nullptr, ctx->seed(), ctx->NextCallId(),
-                                     d_idx.as<int32_t>(), d_id.as<uint64_t>(), d_w.as<float>(),
-                                     d_t.as<int32_t>(), total, batch, n, m, weight_func.c_str(),
-                                     default_node, o_id.as<uint64_t>(), o_w.as<float>(),
-                                     o_t.as<int32_t>()) != 0) {
-      LogError(std::string("API_LOCAL_SAMPLE_L: ") + euler_gpu_last_error());
-      return;
-    }
+    OpScope sc(ctx->graph());
+    int32_t* d_idx = sc.Alloc<int32_t>(idx_t->NumElements());
+    uint64_t* d_id = sc.Alloc<uint64_t>(total);
+    float* d_w = sc.Alloc<float>(total);
+    int32_t* d_t = sc.Alloc<int32_t>(total);
+    uint64_t* o_id = sc.Alloc<uint64_t>(draws);
+    float* o_w = sc.Alloc<float>(draws);
+    int32_t* o_t = sc.Alloc<int32_t>(draws);
+    if (!sc.Upload(d_idx, idx_t->Raw<int32_t>(), (size_t)idx_t->NumElements() * 4) ||
+        !sc.Upload(d_id, id_t->Raw<uint64_t>(), (size_t)total * 8) ||
+        !sc.Upload(d_w, w_t->Raw<float>(), (size_t)total * 4) ||
+        !sc.Upload(d_t, t_t->Raw<int32_t>(), (size_t)total * 4)) OP_FAIL(sc, "API_LOCAL_SAMPLE_L");
+    if (!sc.Call(euler_gpu_local_sample_layer(sc.stream(), ctx->seed(), ctx->NextCallId(), d_idx, d_id, d_w,
+                                              d_t, total, batch, n, m, weight_func.c_str(),
+                                              default_node, o_id, o_w, o_t)))
+      OP_FAIL(sc, "API_LOCAL_SAMPLE_L");
     Tensor *r_id = nullptr, *r_w = nullptr, *r_t = nullptr;
     if (ctx->Allocate(OutputName(nd, 0), {(size_t)draws, 1}, kUInt64, &r_id) != 0 ||
         ctx->Allocate(OutputName(nd, 1), {(size_t)draws, 1}, kFloat, &r_w) != 0 ||
@@ -568,10 +796,12 @@ class GpuLocalSampleLayerOp : public OpKernel {
       LogError("Allocate output tensor failed!");
       return;
     }
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpy(r_id->Raw<uint64_t>(), o_id.p, draws * 8, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(r_w->Raw<float>(), o_w.p, draws * 4, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(r_t->Raw<int32_t>(), o_t.p, draws * 4, hipMemcpyDeviceToHost);
+    if (!sc.Download(r_id->Raw<uint64_t>(), o_id, (size_t)draws * 8) ||
+        !sc.Download(r_w->Raw<float>(), o_w, (size_t)draws * 4) ||
+        !sc.Download(r_t->Raw<int32_t>(), o_t, (size_t)draws * 4) || !sc.Sync()) {
+      for (int i = 0; i < 3; ++i) ctx->Deallocate(OutputName(nd, i));
+      OP_FAIL(sc, "API_LOCAL_SAMPLE_L");
+    }
   }
 };
 REGISTER_OP_KERNEL("API_LOCAL_SAMPLE_L", GpuLocalSampleLayerOp);
@@ -642,31 +872,26 @@ class GpuSparseGetAdjOp : public OpKernel {
     std::vector<int32_t> idx((size_t)R * 2);
     std::vector<uint64_t> vals;
     if (R > 0) {
-      (void)hipSetDevice(euler_gpu_graph_device(g));
-      DevBuf d_r(R * 8), d_nb((size_t)batch * m * 8), d_idx(R * 8),
-          d_ws(euler_gpu_sparse_get_adj_workspace(batch, (int32_t)n, m));
-      if (!d_r.p || !d_nb.p || !d_idx.p || !d_ws.p) { LogError("API_SPARSE_GET_ADJ: device allocation failed"); return; }
-      (void)hipMemcpy(d_r.p, roots.data(), R * 8, hipMemcpyHostToDevice);
-      (void)hipMemcpy(d_nb.p, l_nb_t->Raw<uint64_t>(), (size_t)batch * m * 8, hipMemcpyHostToDevice);
-      if (euler_gpu_sparse_get_adj(g, nullptr, d_r.as<uint64_t>(), d_nb.as<uint64_t>(), batch,
-                                   (int32_t)n, m, et.data(), (int32_t)et.size(), d_ws.p,
-                                   d_idx.as<int32_t>(), &total, nullptr) != 0) {
-        LogError(std::string("API_SPARSE_GET_ADJ: ") + euler_gpu_last_error());
-        return;
-      }
-      DevBuf d_v((size_t)total * 8);
-      if (!d_v.p) { LogError("API_SPARSE_GET_ADJ: device allocation failed"); return; }
+      OpScope sc(g);
+      uint64_t* d_r = sc.Alloc<uint64_t>(R);
+      uint64_t* d_nb = sc.Alloc<uint64_t>((size_t)batch * m);
+      int32_t* d_idx = sc.Alloc<int32_t>(R * 2);
+      void* d_ws = sc.AllocBytes(euler_gpu_sparse_get_adj_workspace(batch, (int32_t)n, m));
+      if (!sc.Upload(d_r, roots.data(), (size_t)R * 8) ||
+          !sc.Upload(d_nb, l_nb_t->Raw<uint64_t>(), (size_t)batch * m * 8)) OP_FAIL(sc, "API_SPARSE_GET_ADJ");
+      if (!sc.Call(euler_gpu_sparse_get_adj(g, sc.stream(), d_r, d_nb, batch, (int32_t)n, m, et.data(),
+                                            (int32_t)et.size(), d_ws, d_idx, &total, nullptr)))
+        OP_FAIL(sc, "API_SPARSE_GET_ADJ");
+      uint64_t* d_v = sc.Alloc<uint64_t>((size_t)total);
+      if (!sc.ok()) OP_FAIL(sc, "API_SPARSE_GET_ADJ");
       if (total > 0 &&
-          euler_gpu_sparse_get_adj(g, nullptr, d_r.as<uint64_t>(), d_nb.as<uint64_t>(), batch,
-                                   (int32_t)n, m, et.data(), (int32_t)et.size(), d_ws.p,
-                                   d_idx.as<int32_t>(), &total, d_v.as<uint64_t>()) != 0) {
-        LogError(std::string("API_SPARSE_GET_ADJ: ") + euler_gpu_last_error());
-        return;
-      }
-      (void)hipDeviceSynchronize();
+          !sc.Call(euler_gpu_sparse_get_adj(g, sc.stream(), d_r, d_nb, batch, (int32_t)n, m, et.data(),
+                                            (int32_t)et.size(), d_ws, d_idx, &total, d_v)))
+        OP_FAIL(sc, "API_SPARSE_GET_ADJ");
       vals.resize((size_t)total);
-      (void)hipMemcpy(idx.data(), d_idx.p, R * 8, hipMemcpyDeviceToHost);
-      if (total) (void)hipMemcpy(vals.data(), d_v.p, (size_t)total * 8, hipMemcpyDeviceToHost);
+      if (!sc.Download(idx.data(), d_idx, (size_t)R * 8) ||
+          (total && !sc.Download(vals.data(), d_v, (size_t)total * 8)) || !sc.Sync())
+        OP_FAIL(sc, "API_SPARSE_GET_ADJ");
     }
     Tensor *o_idx = nullptr, *o_data = nullptr;
     if (ctx->Allocate(OutputName(nd, 0), {(size_t)R, 2}, kInt32, &o_idx) != 0 ||
@@ -697,6 +922,7 @@ class GatherResultOp : public OpKernel {
 };
 REGISTER_OP_KERNEL("API_GATHER_RESULT", GatherResultOp);
 
+}  // namespace gpu_abi
 }  // namespace euler
 
 extern "C" {
@@ -711,9 +937,20 @@ int64_t euler_op_run_sample_nb(euler_gpu_graph* g, uint64_t seed,
                                int32_t count, int32_t* idx_out, uint64_t* id_out,
                                float* w_out, int32_t* t_out) {
   using namespace euler;
+  return euler_op_run_sample_nb_post(g, seed, 0, node_ids, n, edge_types, k, count, nullptr,
+                                     idx_out, id_out, w_out, t_out);
+}
+
+int64_t euler_op_run_sample_nb_post(euler_gpu_graph* g, uint64_t seed, uint32_t call_id,
+                                    const uint64_t* node_ids, int64_t n,
+                                    const int32_t* edge_types, int32_t k, int32_t count,
+                                    const char* post_process, int32_t* idx_out,
+                                    uint64_t* id_out, float* w_out, int32_t* t_out) {
+  using namespace euler;
   OpKernelContext ctx;
   ctx.SetGraph(g);
   ctx.SetSeed(seed);
+  ctx.SetCallId(call_id);
   Tensor *t_ids = nullptr, *t_et = nullptr, *t_cnt = nullptr, *t_def = nullptr;
   ctx.Allocate("nodes", {(size_t)n}, kUInt64, &t_ids);
   ctx.Allocate("edge_types", {(size_t)k}, kInt32, &t_et);
@@ -724,7 +961,19 @@ int64_t euler_op_run_sample_nb(euler_gpu_graph* g, uint64_t seed,
   *t_cnt->Raw<int32_t>() = count;
   *t_def->Raw<int32_t>() = -1;
   NodeDef nd{"API_SAMPLE_NB,0", "API_SAMPLE_NB",
-             {"nodes", "edge_types", "nb_count", "default_node"}};
+             {"nodes", "edge_types", "nb_count", "default_node"}, {}};
+  {
+    std::string cur;
+    for (const char* p = post_process ? post_process : ""; ; ++p) {
+      if (*p == ';' || *p == 0) {
+        if (!cur.empty()) nd.post_process.push_back(cur);
+        cur.clear();
+        if (*p == 0) break;
+      } else {
+        cur.push_back(*p);
+      }
+    }
+  }
   OpKernel* kernel = nullptr;
   if (CreateOpKernel("API_SAMPLE_NB", &kernel) != 0) return -1;
   kernel->Compute(nd, &ctx);
@@ -799,7 +1048,7 @@ int64_t euler_op_run_sample_lnb(euler_gpu_graph* g, uint64_t seed, uint32_t firs
   OpKernelContext ctx;
   ctx.SetGraph(g);
   ctx.SetSeed(seed);
-  for (uint32_t i = 0; i < first_call_id; ++i) ctx.NextCallId();
+  ctx.SetCallId(first_call_id);
   const int64_t R = batch * n;
   Tensor *t_ids = nullptr, *t_et = nullptr, *t_n = nullptr, *t_m = nullptr;
   ctx.Allocate("nodes", {(size_t)R}, kUInt64, &t_ids);

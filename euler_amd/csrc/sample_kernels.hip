@@ -730,6 +730,32 @@ static void LaunchExpand(int U, int V, bool ct, int grid, int block, hipStream_t
     else LaunchExpandUV<1, 1>(ct, grid, block, stream, x, stride_rows, stride_slots);
   }
 }
+// Queue of the row kernel (k1_row.h), per (graph, stream), grown on demand: 256
+// bytes of counters (zero between calls: the slow kernel's last workgroup clears
+// them) + one uint32 per root.
+static int GetRowScratch(const euler_gpu_graph* g, hipStream_t stream, int64_t n, void** out) {
+  std::lock_guard<std::mutex> lk(g->ws_mu);
+  auto& slot = g->row_ws[(void*)stream];
+  const size_t bytes = 256 + (size_t)n * 4;
+  if (slot.second < bytes) {
+    if (slot.first != nullptr) {
+      EG_HIP(hipStreamSynchronize(stream));
+      EG_HIP(hipFree(slot.first));
+      slot.first = nullptr; slot.second = 0;
+    }
+    const size_t want = bytes + bytes / 4;
+    hipError_t e = hipMalloc(&slot.first, want);
+    if (e != hipSuccess) {
+      slot.first = nullptr;
+      return Fail(EULER_GPU_ENOMEM, std::string("sample_neighbor queue: ") + hipGetErrorString(e));
+    }
+    slot.second = want;
+    EG_HIP(hipMemsetAsync(slot.first, 0, 256, stream));
+  }
+  *out = slot.first;
+  return EULER_GPU_OK;
+}
+
 // Kernel selection for one pass over a.n roots (a.dd_role says which pass).
 static int LaunchK1(const euler_gpu_graph* g, hipStream_t stream,
                     const SampleNbArgs& a) {
@@ -782,12 +808,26 @@ static int LaunchK1(const euler_gpu_graph* g, hipStream_t stream,
       int64_t tiles = (n + kRowTile - 1) / kRowTile;
       const int64_t cap = g_k1_grid_cap > 0 ? g_k1_grid_cap : 256 * 16;
       if (tiles > cap) tiles = cap;
+      void* q = nullptr;
+      const int rc = GetRowScratch(g, stream, n, &q);
+      if (rc != EULER_GPU_OK) return rc;
+      SampleNbArgs ra = a;
+      ra.slow_count = (uint32_t*)q;
+      ra.slow_list = (uint32_t*)q + 64;
+      // the queued (long-row) roots, one lane per sample; the grid loops over the
+      // device-side queue length
+      int64_t sblocks = (n * (int64_t)count + 255) / 256;
+      if (sblocks > 256 * 8) sblocks = 256 * 8;
       if (tf) {
         hipLaunchKernelGGL((SampleNeighborRowKernel<true>), dim3((unsigned)tiles), dim3(64), lds,
-                           stream, a);
+                           stream, ra);
+        hipLaunchKernelGGL((SampleNeighborSlowKernel<true>), dim3((unsigned)sblocks), dim3(256), 0,
+                           stream, ra);
       } else {
         hipLaunchKernelGGL((SampleNeighborRowKernel<false>), dim3((unsigned)tiles), dim3(64), lds,
-                           stream, a);
+                           stream, ra);
+        hipLaunchKernelGGL((SampleNeighborSlowKernel<false>), dim3((unsigned)sblocks), dim3(256), 0,
+                           stream, ra);
       }
       EG_HIP(hipGetLastError());
       return EULER_GPU_OK;

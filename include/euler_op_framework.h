@@ -14,6 +14,14 @@
 // same DAG nodes to the MI355X.  Tensors are host buffers (malloc, uninitialised
 // like the reference's, op_kernel.cc:92-105); device memory stays behind the
 // C ABI.
+//
+// Coexistence with the real euler:: classes: everything here lives in the INLINE
+// namespace euler::gpu_abi.  Source written against the reference's names
+// (`euler::OpKernel`, `euler::Tensor`, REGISTER_OP_KERNEL) compiles unchanged
+// against this header, while the symbols are `euler::gpu_abi::...` - a binary may
+// link libeuler_gpu.so next to the reference's libeuler_core without an ODR
+// clash, and a translation unit that includes BOTH headers fails to compile
+// (ambiguous names) instead of silently mixing the two class layouts.
 #pragma once
 
 #include <stdint.h>
@@ -28,6 +36,7 @@
 #include "euler_gpu.h"
 
 namespace euler {
+inline namespace gpu_abi {
 
 enum DataType : int32_t {   // euler/core/framework/types.h:26-39
   kInt8 = 0, kInt16, kInt32, kInt64, kUInt8, kUInt16, kUInt32, kUInt64,
@@ -90,10 +99,18 @@ class OpKernelContext {
   // A second name for an existing tensor (op_kernel.cc AddAlias; the context
   // frees every distinct tensor once, op_kernel.cc:80-90).
   int AddAlias(const std::string& name, Tensor* tensor);
-  // Sampling reproducibility (not in the reference: its RNG is unseedable).
-  void SetSeed(uint64_t seed) { seed_ = seed; }
-  uint64_t seed() const { return seed_; }
-  uint32_t NextCallId() { return call_id_++; }
+  // Sampling randomness (not in the reference, whose RNG is time(0)-seeded and
+  // cannot be fixed).  A context the host did not touch - what a DAG executor
+  // creates per query - samples with the PROCESS seed (std::random_device once
+  // per process, or SetProcessSeed) and takes every op invocation's call id from
+  // a process-wide atomic sequence, so two queries never repeat each other's
+  // draws.  SetSeed / SetCallId pin this context for reproducible runs: its ops
+  // then use seed, call_id, call_id + 1, ...
+  void SetSeed(uint64_t seed) { seed_ = seed; seed_set_ = true; }
+  void SetCallId(uint32_t first) { call_id_ = first; call_id_set_ = true; }
+  uint64_t seed() const;
+  uint32_t NextCallId();
+  static void SetProcessSeed(uint64_t seed);   // also restarts the call-id sequence
   void SetGraph(euler_gpu_graph* g) { graph_ = g; }
   euler_gpu_graph* graph() const;
  private:
@@ -101,6 +118,7 @@ class OpKernelContext {
   std::unordered_map<std::string, Tensor*> tensor_map_;
   uint64_t seed_ = 0;
   uint32_t call_id_ = 0;
+  bool seed_set_ = false, call_id_set_ = false;
   euler_gpu_graph* graph_ = nullptr;
 };
 
@@ -144,6 +162,7 @@ int CreateOpKernel(const std::string& name, OpKernel** kernel);
         return new cls(op);                                              \
       });
 
+}  // namespace gpu_abi
 }  // namespace euler
 
 // C view of the registry, used by tests and by non-C++ hosts.
@@ -157,6 +176,15 @@ int64_t euler_op_run_sample_nb(euler_gpu_graph* g, uint64_t seed,
                                const int32_t* edge_types, int32_t k,
                                int32_t count, int32_t* idx_out, uint64_t* id_out,
                                float* w_out, int32_t* t_out);
+// The same op with DAGNodeProto.post_process strings (';'-separated: "order_by id|weight
+// [desc]", "limit k"; core/kernels/sample_neighbor_op.cc:86-132) and an explicit call
+// id; rows then have different lengths: outputs have room for n * count entries,
+// idx_out [n, 2] delimits them.  Returns the number of entries or < 0.
+int64_t euler_op_run_sample_nb_post(euler_gpu_graph* g, uint64_t seed, uint32_t call_id,
+                                    const uint64_t* node_ids, int64_t n,
+                                    const int32_t* edge_types, int32_t k, int32_t count,
+                                    const char* post_process, int32_t* idx_out,
+                                    uint64_t* id_out, float* w_out, int32_t* t_out);
 // API_GET_NB_NODE with ';'-separated post-process strings ("order_by weight
 // desc;limit 4"); outputs have room for `capacity` neighbours.
 int64_t euler_op_run_get_nb(euler_gpu_graph* g, const uint64_t* node_ids, int64_t n,

@@ -22,9 +22,9 @@ def L():
 def test_library_exports_every_declared_symbol(L):
     from euler_amd import _lib
     hdr = "".join(open(os.path.join(ROOT, "include", f)).read()
-                  for f in ("euler_gpu.h", "euler_op_framework.h"))
+                  for f in ("euler_gpu.h", "euler_op_framework.h", "euler_query.h"))
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b((?:euler_(?:gpu|shm|op)_\w+)|InitQueryProxy)\s*\(", hdr))
+    declared = set(re.findall(r"\b((?:euler_(?:gpu|shm|op|query)_\w+)|InitQueryProxy)\s*\(", hdr))
     declared -= {"euler_gpu_graph", "euler_gpu_host_csr", "euler_gpu_synth_params"}
     assert len(declared) >= 55 and "euler_shm_alltoall_i64" in declared
     for name in sorted(declared):

@@ -146,9 +146,6 @@ def _worker_body(rank, world, port, partitions):
     assert torch.equal(got, want)
     assert np.array_equal(t2n(got)[:64], OG.random_walk(5, 100, t2n(starts)[:64], etw, L, 1.0,
                                                        1.0, N + 1))
-    # SampleNode over the shards: split + local draws + append
-    sn = S.sample_node(500, -1, call_id=60)
-    assert sn.numel() == 500 and int(sn.min()) >= 1 and int(sn.max()) <= N
     # dedup="ops" (ID_UNIQUE / ID_SPLIT / merge_rows / gather as separate kernels)
     S_ops = gpu_sharded_sampler(G_shard, partitions=partitions, dedup="ops")
     got = S_ops.sample_fanout(roots[:5000], et2, [6, 4], N + 1, call_id=13)
@@ -211,6 +208,13 @@ def _worker_body(rank, world, port, partitions):
     wi_, wd_, ww_, wt_ = OGh.get_full_neighbor(q.astype(np.uint64), [0, 2])
     assert np.array_equal(t2n(gi_), wi_) and np.array_equal(t2n(gd_).astype(np.uint64), wd_)
     assert np.array_equal(t2n(gw_), ww_) and np.array_equal(t2n(gt_), wt_)
+    # SampleNode over the shards: SAMPLE_NODE_SPLIT + local draws + APPEND_MERGE; every
+    # rank gets the same ids, all of the asked type
+    sn = t2n(Sh.sample_node(500, 1, call_id=60))
+    assert len(sn) == 500 and np.all(np.isin(sn.astype(np.uint64), ids[nt == 1]))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, sn.tolist())
+    assert all(g == gathered[0] for g in gathered)
     walk = Sh.random_walk(qt[:2000], [[0, 1, 2]] * 6, default_node=-1, call_id=50)
     assert np.array_equal(t2n(walk), OGh.random_walk(31, 50, q[:2000], [[0, 1, 2]] * 6, 6, 1.0,
                                                      1.0, -1))
