@@ -55,6 +55,13 @@ def parse():
                          "edges; reduced automatically when the host's RAM does not hold it)")
     ap.add_argument("--cpu-protocol", choices=["quick", "full"], default="quick",
                     help="full = 5 warm-up + 30 timed rounds for every cell (minutes)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="unsharded path: consecutive minibatches alternate between this many "
+                         "HIP streams (each with its own scratch): the latency-bound phases of "
+                         "one minibatch (first hop, duplicate detection, sampling of the "
+                         "distinct roots) overlap the bandwidth-bound expansion of the other - "
+                         "the reference likewise keeps 8 queries in flight "
+                         "(client/query_proxy.cc:205-210)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the K-step timed loop is repeated this many times; the line "
                          "reports the median repetition (and lists all)")
@@ -154,8 +161,9 @@ def cpu_baseline(args):
         cell["as_shipped"] = dict(_stats(secs, e), threads=shipped_threads,
                                   what="%d concurrent single-threaded queries" % shipped_threads)
         cands = []
-        if many > shipped_threads and not big:
-            secs, e = R.bench_fanout_dag(GRAPH_SEED, roots, B, FANOUT, many, 0, True, wu, timed)
+        if many > shipped_threads:
+            secs, e = R.bench_fanout_dag(GRAPH_SEED, roots, B, FANOUT, many, 0, True,
+                                         wu if not big else 1, timed if (not big or full) else 3)
             cands.append(dict(_stats(secs, e), threads=many,
                               what="%d concurrent single-threaded queries" % many))
         secs, e = R.bench_fanout_dag(GRAPH_SEED, roots, B, FANOUT, many, 1, True,
@@ -349,16 +357,39 @@ def main():
         def step(i):
             return G.sample_fanout(roots[i], et, FANOUT, default_node, call_id=2 * i)
 
-        for i in range(args.warmup):
-            out = step(i)
+        n_streams = max(1, args.streams)
+        side = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else None
+
+        def loop(first, last, streams):
+            res = None
+            if streams is None:
+                for i in range(first, last):
+                    res = step(i)
+            else:
+                for i in range(first, last):
+                    with torch.cuda.stream(streams[i % len(streams)]):
+                        res = step(i)
+            return res
+
+        torch.cuda.synchronize()              # roots were produced on the default stream
+        out = loop(0, max(args.warmup, 2 * n_streams), side)
         sync()
         gc.collect(); gc.freeze(); gc.disable()      # a gen-2 collection costs ~40 ms
+        one_stream = []
+        if side is not None:                  # the same K steps on ONE stream, for the record
+            loop(0, args.warmup, None)
+            for _rep in range(3):
+                sync()
+                t0 = time.perf_counter()
+                loop(args.warmup, n_steps, None)
+                sync()
+                one_stream.append(time.perf_counter() - t0)
+            loop(0, 2 * n_streams, side)
         rep_secs = []
         for _rep in range(max(1, args.repeats)):
             sync()
             t0 = time.perf_counter()
-            for i in range(args.warmup, n_steps):
-                out = step(i)
+            out = loop(args.warmup, n_steps, side)
             sync()
             rep_secs.append(time.perf_counter() - t0)
         gc.enable()
@@ -551,6 +582,9 @@ def main():
                                 "hash owner(id)=id%%%d, all-to-all per hop, %d minibatches "
                                 "in flight" % (world, args.pipeline),
                 "parity_checked_edges": checked,
+                "streams": 1 if sharded else max(1, args.streams),
+                "one_stream_ms_per_step": (round(float(np.median(one_stream)) / args.steps * 1e3, 4)
+                                           if (not sharded and one_stream) else None),
                 "repeats": len(rep_secs),
                 "repeat_ms_per_step": [round(x / args.steps * 1e3, 4) for x in rep_secs],
                 "ranks": world,
