@@ -43,14 +43,18 @@ constexpr int kRowSlots = 2 * kEdgesPerBlock;       // sums a lane keeps in regi
 // dynamic LDS of one wave:
 //   sums [kRowSlots + 1][64] f32   (slot-major: lane l reads bank l % 32 whatever
 //                                   its slot - conflict-free dynamic indexing)
-//   w    [64 * count]        f32   output order
-//   blk  [64]                i64   first block of every root
-//   m    [64 * count]        u8    slot of every sample, 0xFF = id already written
+//   ids  [64][kRowSlots]     u64   the neighbour ids of every root's (<= 2) blocks
+//   m    [64 * count]        u8    slot of every sample, 0xFF = written by the Q3 replay
+//   rs   [64]                u8    slot of the row's first edge (0xFF: in an earlier block)
 //   flag [64]                u8    0 = sampled here, 1 = no samples (default row),
 //                                  2 = slow root (SampleNeighborSlowKernel writes it)
+// The write phase needs NO global load: a first version fetched the ids from the
+// block lines again, 25 dependent load -> store iterations per wave (vector-memory
+// operations retire in order on gfx950, so every iteration also waited for the
+// previous iteration's stores): 95 us for the metric's first hop.
 __host__ __device__ inline size_t RowKernelLdsBytes(int32_t count) {
-  const size_t b = (size_t)(kRowSlots + 1) * 64 * 4 + (size_t)64 * count * 4 + 64 * 8 +
-                   (size_t)64 * count + 64;
+  const size_t b = (size_t)(kRowSlots + 1) * 64 * 4 + (size_t)64 * kRowSlots * 8 +
+                   (size_t)64 * count + 64 + 64;
   return (b + 15) & ~(size_t)15;
 }
 
@@ -63,17 +67,17 @@ __global__ __launch_bounds__(64) void SampleNeighborRowKernel(const SampleNbArgs
   const int lane = threadIdx.x;
   const int32_t count = a.count;
   float* s_sum = reinterpret_cast<float*>(row_smem);
-  float* s_w = s_sum + (kRowSlots + 1) * 64;
-  int64_t* s_blk = reinterpret_cast<int64_t*>(s_w + 64 * count);
-  uint8_t* s_m = reinterpret_cast<uint8_t*>(s_blk + 64);
-  uint8_t* s_flag = s_m + 64 * count;
+  uint64_t* s_id = reinterpret_cast<uint64_t*>(s_sum + (kRowSlots + 1) * 64);
+  uint8_t* s_m = reinterpret_cast<uint8_t*>(s_id + 64 * kRowSlots);
+  uint8_t* s_rs = s_m + 64 * count;
+  uint8_t* s_flag = s_rs + 64;
   const int32_t t = a.et[0];
   const bool mark = a.mark_owner != nullptr;
   const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   const double kInf = __builtin_huge_val();
   const int64_t tiles = (n_roots + kRowTile - 1) / kRowTile;
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    // ---- P1: root id -> row record -> the sums of the row's (<= 2) blocks
+    // ---- P1: root id -> row record -> the sums and ids of the row's (<= 2) blocks
     const int64_t r = tile * kRowTile + lane;
     const bool live = r < n_roots;
     uint64_t node = 0;
@@ -96,33 +100,49 @@ __global__ __launch_bounds__(64) void SampleNeighborRowKernel(const SampleNbArgs
     double vd[kRowSlots - 1];          // compare keys of slots 0 .. 18, padded
     if (fast) {
       const EdgeBlock* bk = a.g.blk + blk_lo;
+      const bool two = i_hi >= kEdgesPerBlock;
       const float4 a0 = *reinterpret_cast<const float4*>(bk->pw);
       const float4 a1 = *reinterpret_cast<const float4*>(bk->pw + 4);
       const float4 a2 = *reinterpret_cast<const float4*>(bk->pw + 8);   // pw[8], pw[9], prev_last
+      u64x2 ia[kEdgesPerBlock / 2], ib[kEdgesPerBlock / 2];
+#pragma unroll
+      for (int q = 0; q < kEdgesPerBlock / 2; ++q)
+        ia[q] = *reinterpret_cast<const u64x2*>(bk->nbr + 2 * q);
       float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0, b2 = b0;
-      if (i_hi >= kEdgesPerBlock) {
+#pragma unroll
+      for (int q = 0; q < kEdgesPerBlock / 2; ++q) ib[q] = u64x2{0, 0};
+      if (two) {
         b0 = *reinterpret_cast<const float4*>(bk[1].pw);
         b1 = *reinterpret_cast<const float4*>(bk[1].pw + 4);
         b2 = *reinterpret_cast<const float4*>(bk[1].pw + 8);
+#pragma unroll
+        for (int q = 0; q < kEdgesPerBlock / 2; ++q)
+          ib[q] = *reinterpret_cast<const u64x2*>(bk[1].nbr + 2 * q);
       }
       const float v[kRowSlots] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y,
                                   b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y};
       s_sum[lane] = a2.z;                                  // the sum before slot 0
 #pragma unroll
       for (int q = 0; q < kRowSlots; ++q) s_sum[(q + 1) * 64 + lane] = v[q];
+      u64x2* my_ids = reinterpret_cast<u64x2*>(s_id + lane * kRowSlots);
+#pragma unroll
+      for (int q = 0; q < kEdgesPerBlock / 2; ++q) {
+        my_ids[q] = ia[q];
+        my_ids[kEdgesPerBlock / 2 + q] = ib[q];
+      }
       // slots before the segment always count (-inf is never > r), slots from the
       // segment's last one on never do: pos = first slot of [i_lo, i_hi] whose sum > r
 #pragma unroll
       for (int q = 0; q < kRowSlots - 1; ++q)
         vd[q] = q < i_lo ? -kInf : (q >= i_hi ? kInf : (double)v[q]);
-      s_blk[lane] = blk_lo;
+      // `mid ? nw[mid-1] : 0` is row-relative: the slot whose predecessor sum is 0
+      const int64_t rs = sg.row_ptr - blk_lo * kEdgesPerBlock;
+      s_rs[lane] = rs >= 0 ? (uint8_t)rs : (uint8_t)0xFF;
     }
     s_flag[lane] = !valid ? 1 : (slow ? 2 : 0);
     // ---- P2: all `count` draws of a fast root from registers
     if (fast) {
       const float lb = sg.limit_begin, le = sg.limit_end;
-      const bool first_block_is_row_start = blk_lo * kEdgesPerBlock <= sg.row_ptr;
-      const int32_t row_start_slot = (int32_t)(sg.row_ptr - blk_lo * kEdgesPerBlock);
       for (int32_t j = 0; j < count; j += 2) {
         const Philox4 pb = RngBlock(a.seed, a.call_id, kDomainNeighbor, node, ((uint32_t)j) >> 1);
 #pragma unroll
@@ -130,30 +150,23 @@ __global__ __launch_bounds__(64) void SampleNeighborRowKernel(const SampleNbArgs
           if (j + h >= count) break;
           const double u = h ? UnitFromWords(pb.w[2], pb.w[3]) : UnitFromWords(pb.w[0], pb.w[1]);
           const double rr = ScaleDraw(u, lb, le);
-          float wv;
           uint8_t mm;
           if (!((double)le > rr)) {
             // Q3: r rounded up to the end of the segment - replay the reference
             const float* nw = a.g.prefix_w + sg.row_ptr;
             const int32_t m = (int32_t)RandomSelect(nw, (uint64_t)sg.b, (uint64_t)sg.e, u);
             const uint64_t id = a.g.nbr[sg.row_ptr + m];
-            wv = __fsub_rn(nw[m], m == 0 ? 0.f : nw[m - 1]);
             const int64_t s = r * (int64_t)count + j + h;
             a.out_id[s] = id;
+            a.out_w[s] = __fsub_rn(nw[m], m == 0 ? 0.f : nw[m - 1]);
             if (mark) MarkNextHop(a.g, a.mark_owner, id, true, s);
             mm = 0xFF;
           } else {
             int32_t pos = 0;
 #pragma unroll
             for (int q = 0; q < kRowSlots - 1; ++q) pos += (vd[q] > rr) ? 0 : 1;
-            const float nw_m = s_sum[(pos + 1) * 64 + lane];
-            // `mid ? nw[mid-1] : 0` is row-relative
-            const float prev = (first_block_is_row_start && pos == row_start_slot)
-                                   ? 0.f : s_sum[pos * 64 + lane];
-            wv = __fsub_rn(nw_m, prev);
             mm = (uint8_t)pos;
           }
-          s_w[lane * count + j + h] = wv;
           s_m[lane * count + j + h] = mm;
         }
       }
@@ -168,7 +181,8 @@ __global__ __launch_bounds__(64) void SampleNeighborRowKernel(const SampleNbArgs
     }
     if (live && a.out_row_mask != nullptr) a.out_row_mask[r] = valid ? 0 : 1;
     WaveSync();
-    // ---- P3: the tile's samples in output order, two per lane
+    // ---- P3: the tile's samples in output order, two per lane; everything comes
+    // from LDS, the loop is stores only
     const int64_t left = n_roots - tile * kRowTile;
     const int32_t nt = (int32_t)(left < kRowTile ? left : kRowTile) * count;
     const int64_t base = tile * kRowTile * (int64_t)count;
@@ -176,7 +190,8 @@ __global__ __launch_bounds__(64) void SampleNeighborRowKernel(const SampleNbArgs
       uint64_t id[2] = {0, 0};
       float wv[2] = {0.f, 0.f};
       int32_t ot[2] = {t, t};
-      // have: the id is written here; skip: the whole sample belongs to the slow kernel
+      // have: id and weight are written here; skip: the whole sample belongs to the
+      // slow kernel
       bool have[2] = {false, false}, skip[2] = {true, true}, rv[2] = {true, true};
 #pragma unroll
       for (int x = 0; x < 2; ++x) {
@@ -192,27 +207,28 @@ __global__ __launch_bounds__(64) void SampleNeighborRowKernel(const SampleNbArgs
           rv[x] = false;
           continue;
         }
-        wv[x] = s_w[e + x];
         const int32_t mm = s_m[e + x];
-        if (mm == 0xFF) continue;                     // id written by the Q3 replay
-        const EdgeBlock* bk = a.g.blk + s_blk[rl] + (mm >= kEdgesPerBlock ? 1 : 0);
-        id[x] = bk->nbr[mm >= kEdgesPerBlock ? mm - kEdgesPerBlock : mm];
+        if (mm == 0xFF) continue;                     // id and weight written by the Q3 replay
+        id[x] = s_id[rl * kRowSlots + mm];
+        const float nw_m = s_sum[(mm + 1) * 64 + rl];
+        const float prev = mm == (int32_t)s_rs[rl] ? 0.f : s_sum[mm * 64 + rl];
+        wv[x] = __fsub_rn(nw_m, prev);
         have[x] = true;
       }
       const int64_t d = base + e;
       if (have[0] && have[1]) {
         const u64x2 i2 = {id[0], id[1]};
         *reinterpret_cast<u64x2*>(a.out_id + d) = i2;
+        *reinterpret_cast<float2*>(a.out_w + d) = make_float2(wv[0], wv[1]);
       } else {
-        if (have[0]) a.out_id[d] = id[0];
-        if (have[1]) a.out_id[d + 1] = id[1];
+        if (have[0]) { a.out_id[d] = id[0]; a.out_w[d] = wv[0]; }
+        if (have[1]) { a.out_id[d + 1] = id[1]; a.out_w[d + 1] = wv[1]; }
       }
       if (!skip[0] && !skip[1]) {
-        *reinterpret_cast<float2*>(a.out_w + d) = make_float2(wv[0], wv[1]);
         *reinterpret_cast<int2*>(a.out_t + d) = make_int2(ot[0], ot[1]);
       } else {
-        if (!skip[0]) { a.out_w[d] = wv[0]; a.out_t[d] = ot[0]; }
-        if (!skip[1]) { a.out_w[d + 1] = wv[1]; a.out_t[d + 1] = ot[1]; }
+        if (!skip[0]) a.out_t[d] = ot[0];
+        if (!skip[1]) a.out_t[d + 1] = ot[1];
       }
       if (mark) {
 #pragma unroll

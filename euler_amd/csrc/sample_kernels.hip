@@ -495,8 +495,9 @@ int g_k1_ablate = 0;   // measurement only: skip parts of the blocked kernel
 int g_k1_ilp = 4;      // samples per lane of the ILP kernel (1, 2, 4, 8)
 int g_k1_row = 1;       // block-pivot calls without the duplicate path: one lane per ROOT
                         // (k1_row.h) for 4 <= count <= 64; 0 = one lane per sample
-int g_dedup_resolve_in_expand = 1;   // last hop: the expansion reads its row number from the
-                                     // owner table itself (no DedupResolveKernel, no uidx array)
+int g_dedup_resolve_in_expand = 0;   // 1 = last hop: the expansion reads its row number from the
+                                     // owner table itself (no resolve kernel, no uidx array) -
+                                     // measured: dedup 43 -> 28 us, expansion 134 -> 157 us; off
 int g_k1_variant = 6;   // 6 = block pivots, 5 = pivot levels, 4 = wave-staged (count >= 8) else blocked,
                         // 3 = blocked index,
                         // 2 = ILP, 1 = fast path, 0 = generic

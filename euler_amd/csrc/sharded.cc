@@ -1,0 +1,263 @@
+// Multi-GPU sampling for C / C++ hosts: one hop = front end (distinct ids bucketed
+// by owner) -> id exchange -> owner-side sampling into wire rows -> row exchange ->
+// expansion, all behind one C entry point (include/euler_gpu.h,
+// euler_gpu_sharded_sample_fanout).  This is what the reference's
+// ID_SPLIT -> REMOTE -> IDX_MERGE / DATA_MERGE sub-DAG does over gRPC
+// (core/kernels/id_split_op.cc:46-99, remote_op.cc:60-142, idx_merge_op.cc:32-78,
+// data_merge_op.cc:44-67); here the exchange is an all-to-all(v) between the GPUs
+// of one node through a caller-supplied transport: RCCL (ncclSend / ncclRecv
+// groups over xGMI, euler_gpu_transport_rccl) in production, anything else - the
+// tests use a host-staged one so that several ranks can share one GPU - through
+// the two callbacks of euler_gpu_transport.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+using euler_gpu::Fail;
+
+namespace {
+
+// ---- RCCL, resolved at run time: the library never links librccl itself (the
+// host process - a C++ trainer linked with -lrccl, or torch, which brings its own
+// copy - already has one loaded, and two RCCL copies in one process do not mix).
+typedef int (*nccl_send_t)(const void*, size_t, int, int, void*, hipStream_t);
+typedef int (*nccl_recv_t)(void*, size_t, int, int, void*, hipStream_t);
+typedef int (*nccl_group_t)(void);
+struct Rccl {
+  nccl_send_t send = nullptr;
+  nccl_recv_t recv = nullptr;
+  nccl_group_t group_start = nullptr, group_end = nullptr;
+  bool ok = false;
+};
+
+const Rccl& GetRccl() {
+  static Rccl r = [] {
+    Rccl x;
+    // the global scope first, then copies that were loaded RTLD_LOCAL (torch's)
+    void* handles[3] = {RTLD_DEFAULT, dlopen("librccl.so.1", RTLD_NOLOAD | RTLD_LAZY),
+                        dlopen("librccl.so", RTLD_NOLOAD | RTLD_LAZY)};
+    for (void* h : handles) {
+      x.send = (nccl_send_t)dlsym(h, "ncclSend");
+      x.recv = (nccl_recv_t)dlsym(h, "ncclRecv");
+      x.group_start = (nccl_group_t)dlsym(h, "ncclGroupStart");
+      x.group_end = (nccl_group_t)dlsym(h, "ncclGroupEnd");
+      if (x.send && x.recv && x.group_start && x.group_end) { x.ok = true; break; }
+    }
+    if (!x.ok) {
+      // nothing loaded yet: load the system copy
+      void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+      if (h == nullptr) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+      if (h != nullptr) {
+        x.send = (nccl_send_t)dlsym(h, "ncclSend");
+        x.recv = (nccl_recv_t)dlsym(h, "ncclRecv");
+        x.group_start = (nccl_group_t)dlsym(h, "ncclGroupStart");
+        x.group_end = (nccl_group_t)dlsym(h, "ncclGroupEnd");
+        x.ok = x.send && x.recv && x.group_start && x.group_end;
+      }
+    }
+    return x;
+  }();
+  return r;
+}
+
+struct RcclUser {
+  void* comm;
+  int32_t rank, world;
+  euler_shm* shm;           // host-side counts mailbox, or null
+  int64_t* pinned;          // [2 * world] when the counts travel through RCCL
+  int64_t* dev_counts;      // [2 * world]
+};
+
+int RcclCounts(void* user, const int64_t* send, int64_t* recv) {
+  RcclUser* u = (RcclUser*)user;
+  if (u->world == 1) { recv[0] = send[0]; return EULER_GPU_OK; }
+  if (u->shm != nullptr) return euler_shm_alltoall_i64(u->shm, send, recv, 1, 60000);
+  // no mailbox: the counts make a round trip through the GPUs (one sync per hop)
+  const Rccl& r = GetRccl();
+  for (int p = 0; p < u->world; ++p) u->pinned[p] = send[p];
+  EG_HIP(hipMemcpy(u->dev_counts, u->pinned, sizeof(int64_t) * u->world, hipMemcpyHostToDevice));
+  if (r.group_start() != 0) return Fail(EULER_GPU_EHIP, "ncclGroupStart failed");
+  for (int p = 0; p < u->world; ++p) {
+    if (r.send(u->dev_counts + p, 8, 0, p, u->comm, nullptr) != 0 ||
+        r.recv(u->dev_counts + u->world + p, 8, 0, p, u->comm, nullptr) != 0)
+      return Fail(EULER_GPU_EHIP, "ncclSend / ncclRecv (counts) failed");
+  }
+  if (r.group_end() != 0) return Fail(EULER_GPU_EHIP, "ncclGroupEnd failed");
+  EG_HIP(hipMemcpy(u->pinned + u->world, u->dev_counts + u->world, sizeof(int64_t) * u->world,
+                   hipMemcpyDeviceToHost));
+  for (int p = 0; p < u->world; ++p) recv[p] = u->pinned[u->world + p];
+  return EULER_GPU_OK;
+}
+
+int RcclAllToAllV(void* user, const void* send_dev, const int64_t* send_rows, void* recv_dev,
+                  const int64_t* recv_rows, int64_t row_bytes, void* stream) {
+  RcclUser* u = (RcclUser*)user;
+  const Rccl& r = GetRccl();
+  hipStream_t st = (hipStream_t)stream;
+  if (r.group_start() != 0) return Fail(EULER_GPU_EHIP, "ncclGroupStart failed");
+  int64_t so = 0, ro = 0;
+  for (int p = 0; p < u->world; ++p) {
+    const size_t sb = (size_t)(send_rows[p] * row_bytes), rb = (size_t)(recv_rows[p] * row_bytes);
+    if (sb && r.send((const uint8_t*)send_dev + so, sb, 0 /* ncclInt8 */, p, u->comm, st) != 0)
+      return Fail(EULER_GPU_EHIP, "ncclSend failed");
+    if (rb && r.recv((uint8_t*)recv_dev + ro, rb, 0, p, u->comm, st) != 0)
+      return Fail(EULER_GPU_EHIP, "ncclRecv failed");
+    so += (int64_t)sb; ro += (int64_t)rb;
+  }
+  if (r.group_end() != 0) return Fail(EULER_GPU_EHIP, "ncclGroupEnd failed");
+  return EULER_GPU_OK;
+}
+
+// device scratch of one call, stream-ordered
+struct Scratch {
+  hipStream_t st;
+  std::vector<void*> ptrs;
+  explicit Scratch(hipStream_t s) : st(s) {}
+  ~Scratch() { for (void* p : ptrs) (void)hipFreeAsync(p, st); }
+  void* Get(size_t bytes) {
+    void* p = nullptr;
+    if (hipMallocAsync(&p, bytes ? bytes : 16, st) != hipSuccess) return nullptr;
+    ptrs.push_back(p);
+    return p;
+  }
+};
+
+int32_t PackedWordsHost(int32_t count, int32_t tcol) { return ((3 + tcol) * count + 2 + 1) & ~1; }
+
+}  // namespace
+
+extern "C" {
+
+int euler_gpu_transport_rccl(void* nccl_comm, int32_t rank, int32_t world, euler_shm* counts,
+                             euler_gpu_transport* out) {
+  if (!out || !nccl_comm || world < 1 || rank < 0 || rank >= world)
+    return Fail(EULER_GPU_EINVAL, "transport_rccl: bad arguments");
+  if (!GetRccl().ok)
+    return Fail(EULER_GPU_EHIP, "transport_rccl: no RCCL (ncclSend / ncclRecv) in this process");
+  RcclUser* u = new RcclUser();
+  u->comm = nccl_comm; u->rank = rank; u->world = world; u->shm = counts;
+  u->pinned = nullptr; u->dev_counts = nullptr;
+  if (counts == nullptr && world > 1) {
+    EG_HIP(hipHostMalloc((void**)&u->pinned, sizeof(int64_t) * 2 * world));
+    EG_HIP(hipMalloc((void**)&u->dev_counts, sizeof(int64_t) * 2 * world));
+  }
+  out->rank = rank; out->world = world; out->user = u;
+  out->alltoall_counts = RcclCounts;
+  out->alltoallv = RcclAllToAllV;
+  return EULER_GPU_OK;
+}
+
+void euler_gpu_transport_rccl_release(euler_gpu_transport* t) {
+  if (t == nullptr || t->user == nullptr) return;
+  RcclUser* u = (RcclUser*)t->user;
+  if (u->pinned) (void)hipHostFree(u->pinned);
+  if (u->dev_counts) (void)hipFree(u->dev_counts);
+  delete u;
+  t->user = nullptr;
+}
+
+int euler_gpu_sharded_sample_neighbor(const euler_gpu_graph* shard, const euler_gpu_transport* tr,
+                                      void* stream, uint64_t seed, uint32_t call_id,
+                                      const uint64_t* roots_dev, int64_t n,
+                                      const uint8_t* root_mask_dev, int32_t root_group,
+                                      const int32_t* edge_types_host, int32_t k, int32_t count,
+                                      int64_t default_node, int32_t partitions,
+                                      uint64_t* out_id_dev, float* out_w_dev, int32_t* out_t_dev,
+                                      uint8_t* out_mask_dev) {
+  if (!shard) return Fail(EULER_GPU_ENOGRAPH, "sharded_sample_neighbor: null graph");
+  if (!tr || !tr->alltoall_counts || !tr->alltoallv || tr->world < 1 || n < 0 || count <= 0 ||
+      partitions < tr->world)
+    return Fail(EULER_GPU_EINVAL, "sharded_sample_neighbor: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int32_t W = tr->world;
+  Scratch sc(st);
+  // 1. the DISTINCT ids of the batch bucketed by owner + every position's place
+  //    among the answers (ID_UNIQUE precedes ID_SPLIT: parser/compiler.cc:76-90)
+  uint64_t* shard_ids = (uint64_t*)sc.Get((size_t)(n > 0 ? n : 1) * 8);
+  int32_t* pos = (int32_t*)sc.Get((size_t)(n > 0 ? n : 1) * 4);
+  if (!shard_ids || !pos) return Fail(EULER_GPU_ENOMEM, "sharded_sample_neighbor: scratch");
+  std::vector<int64_t> off((size_t)W + 1, 0);
+  if (n > 0) {
+    const int rc = euler_gpu_dedup_split(stream, roots_dev, n, root_mask_dev, root_group, partitions,
+                                         W, nullptr, 0, off.data(), shard_ids, pos);
+    if (rc != EULER_GPU_OK) return rc;
+  }
+  std::vector<int64_t> send_rows((size_t)W), recv_rows((size_t)W);
+  for (int32_t s = 0; s < W; ++s) send_rows[s] = off[s + 1] - off[s];
+  // 2. who gets how many ids from whom
+  int rc = tr->alltoall_counts(tr->user, send_rows.data(), recv_rows.data());
+  if (rc != EULER_GPU_OK) return rc;
+  int64_t m = 0;
+  for (int32_t s = 0; s < W; ++s) m += recv_rows[s];
+  // 3. ids to their owners
+  uint64_t* owned = (uint64_t*)sc.Get((size_t)(m > 0 ? m : 1) * 8);
+  if (!owned) return Fail(EULER_GPU_ENOMEM, "sharded_sample_neighbor: scratch");
+  rc = tr->alltoallv(tr->user, shard_ids, send_rows.data(), owned, recv_rows.data(), 8, stream);
+  if (rc != EULER_GPU_OK) return rc;
+  // 4. the owner samples its rows straight into wire rows
+  const int32_t single_type = k == 1 ? edge_types_host[0] : -1;
+  const int32_t words = PackedWordsHost(count, single_type >= 0 ? 0 : 1);
+  int32_t* rows = (int32_t*)sc.Get((size_t)(m > 0 ? m : 1) * words * 4);
+  int64_t asked = 0;
+  for (int32_t s = 0; s < W; ++s) asked += send_rows[s];
+  int32_t* back = (int32_t*)sc.Get((size_t)(asked > 0 ? asked : 1) * words * 4);
+  if (!rows || !back) return Fail(EULER_GPU_ENOMEM, "sharded_sample_neighbor: scratch");
+  if (m > 0) {
+    rc = euler_gpu_sample_neighbor_packed(shard, stream, seed, call_id, owned, m, edge_types_host, k,
+                                          count, default_node, rows);
+    if (rc != EULER_GPU_OK) return rc;
+  }
+  // 5. rows back along the reversed split; the shards answered in the order they
+  //    were asked, so row pos[i] of `back` is position i's row
+  rc = tr->alltoallv(tr->user, rows, recv_rows.data(), back, send_rows.data(), (int64_t)words * 4,
+                     stream);
+  if (rc != EULER_GPU_OK) return rc;
+  // 6. IDX_MERGE / DATA_MERGE / DATA_GATHER / unpack in one pass
+  if (n > 0) {
+    rc = euler_gpu_expand_packed(stream, pos, n, count, single_type, back, out_id_dev, out_w_dev,
+                                 out_t_dev, out_mask_dev);
+    if (rc != EULER_GPU_OK) return rc;
+  }
+  return EULER_GPU_OK;
+}
+
+int euler_gpu_sharded_sample_fanout(const euler_gpu_graph* shard, const euler_gpu_transport* tr,
+                                    void* stream, uint64_t seed, uint32_t call_id,
+                                    const uint64_t* roots_dev, int64_t n,
+                                    const int32_t* edge_types_host, int32_t k,
+                                    const int32_t* counts_host, int32_t layers,
+                                    int64_t default_node, int32_t partitions,
+                                    uint64_t* const* out_id_dev, float* const* out_w_dev,
+                                    int32_t* const* out_t_dev, void* workspace_dev) {
+  if (layers < 0 || (layers > 0 && (!counts_host || !out_id_dev || !out_w_dev || !out_t_dev)))
+    return Fail(EULER_GPU_EINVAL, "sharded_sample_fanout: bad arguments");
+  if (layers > 0 && n > 0 && !workspace_dev)
+    return Fail(EULER_GPU_EINVAL, "sharded_sample_fanout: workspace required");
+  const uint64_t* roots = roots_dev;
+  const uint8_t* mask = nullptr;
+  int32_t group = 1;
+  int64_t m = n;
+  uint8_t* ws = (uint8_t*)workspace_dev;
+  for (int32_t h = 0; h < layers; ++h) {
+    uint8_t* row_mask = ws;
+    ws += ((size_t)m + 15) & ~(size_t)15;
+    // every rank makes every hop's exchanges, also with an empty batch
+    const int rc = euler_gpu_sharded_sample_neighbor(
+        shard, tr, stream, seed, call_id + (uint32_t)h, roots, m, mask, group,
+        edge_types_host + (size_t)h * k, k, counts_host[h], default_node, partitions,
+        out_id_dev[h], out_w_dev[h], out_t_dev[h], row_mask);
+    if (rc != EULER_GPU_OK) return rc;
+    roots = out_id_dev[h];
+    mask = row_mask;
+    group = counts_host[h];
+    m *= counts_host[h];
+  }
+  return EULER_GPU_OK;
+}
+
+}  // extern "C"

@@ -844,3 +844,113 @@ def gpu_sharded_sampler(graph, partitions=None, group=None, dedup=True, dense_id
     S.node_split_fn = lambda call_id, count, weights: ops.sample_node_split(
         graph.seed, call_id, count, weights)
     return S
+
+
+# --------------------------------------------------------------------------
+# The C-level multi-GPU path (include/euler_gpu.h: euler_gpu_sharded_sample_fanout)
+# driven from Python: the hop's orchestration runs inside libeuler_gpu.so, the
+# exchange goes through an euler_gpu_transport.
+# --------------------------------------------------------------------------
+class CTransport:
+    """euler_gpu_transport over a torch.distributed group whose backend cannot move
+    device memory between ranks that share a GPU (gloo): the two callbacks stage the
+    rows through the host (hipMemcpy of libamdhip64) and exchange them with
+    all_to_all_single.  A production C++ host uses euler_gpu_transport_rccl with its
+    ncclComm_t instead; this class exists so that world > 1 runs of the C entry
+    points can be verified on one GPU."""
+
+    def __init__(self, group=None):
+        import ctypes as C
+        from . import _lib
+        self._C = C
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.bytes_sent = 0
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        self._hip = hip
+
+        COUNTS = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64))
+        A2AV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p,
+                           C.POINTER(C.c_int64), C.c_int64, C.c_void_p)
+
+        class Transport(C.Structure):
+            _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("user", C.c_void_p),
+                        ("alltoall_counts", COUNTS), ("alltoallv", A2AV)]
+
+        def counts(_user, send, recv):
+            try:
+                sc = torch.tensor([send[p] for p in range(self.world)], dtype=torch.int64)
+                rc = torch.empty_like(sc)
+                dist.all_to_all_single(rc, sc, group=self.group)
+                for p in range(self.world):
+                    recv[p] = int(rc[p])
+                return 0
+            except Exception:                     # a callback must not raise into C
+                return -3
+
+        def a2av(_user, send_dev, send_rows, recv_dev, recv_rows, row_bytes, stream):
+            try:
+                s_rows = [int(send_rows[p]) for p in range(self.world)]
+                r_rows = [int(recv_rows[p]) for p in range(self.world)]
+                hip.hipStreamSynchronize(stream)          # the rows to send are ready
+                sb = torch.empty(sum(s_rows) * row_bytes, dtype=torch.uint8)
+                rb = torch.empty(sum(r_rows) * row_bytes, dtype=torch.uint8)
+                if sb.numel():
+                    if hip.hipMemcpy(sb.data_ptr(), send_dev, sb.numel(), 2) != 0:
+                        return -3
+                dist.all_to_all_single(rb, sb, output_split_sizes=[r * row_bytes for r in r_rows],
+                                       input_split_sizes=[s * row_bytes for s in s_rows],
+                                       group=self.group)
+                if rb.numel():
+                    if hip.hipMemcpy(recv_dev, rb.data_ptr(), rb.numel(), 1) != 0:
+                        return -3
+                self.bytes_sent += (sum(s_rows) - s_rows[self.rank]) * row_bytes
+                return 0
+            except Exception:
+                return -3
+
+        self._keep = (COUNTS(counts), A2AV(a2av))
+        self.struct = Transport(self.rank, self.world, None, self._keep[0], self._keep[1])
+
+    def ptr(self):
+        return self._C.byref(self.struct)
+
+
+def c_sharded_sample_fanout(graph, transport, roots, edge_types, counts, default_node=-1,
+                            call_id=0, partitions=None):
+    """tf_euler sample_fanout through euler_gpu_sharded_sample_fanout (the C entry a
+    C++ host calls): same result as Graph.sample_fanout on the unsharded graph."""
+    import ctypes as C
+    import numpy as np
+    from . import _lib
+    L = _lib.lib()
+    dev = graph.device
+    roots = roots.reshape(-1).to(torch.int64).to(dev).contiguous()
+    layers = len(counts)
+    et = np.ascontiguousarray(np.asarray(edge_types, dtype=np.int32).reshape(layers, -1))
+    k = et.shape[1] if layers else 0
+    cnt = np.ascontiguousarray(np.asarray(counts, dtype=np.int32))
+    n = roots.numel()
+    outs_n, outs_w, outs_t, m = [], [], [], n
+    for c in counts:
+        m *= int(c)
+        outs_n.append(torch.empty(m, dtype=torch.int64, device=dev))
+        outs_w.append(torch.empty(m, dtype=torch.float32, device=dev))
+        outs_t.append(torch.empty(m, dtype=torch.int32, device=dev))
+    ws = torch.empty(max(int(L.euler_gpu_sample_fanout_workspace(
+        n, cnt.ctypes.data_as(_lib.i32p), layers)), 16), dtype=torch.uint8, device=dev)
+    pn = (C.c_void_p * layers)(*[t.data_ptr() for t in outs_n])
+    pw = (C.c_void_p * layers)(*[t.data_ptr() for t in outs_w])
+    pt = (C.c_void_p * layers)(*[t.data_ptr() for t in outs_t])
+    with torch.cuda.device(dev):
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(L.euler_gpu_sharded_sample_fanout(
+            graph._h, transport.ptr() if hasattr(transport, "ptr") else transport, st, graph.seed,
+            int(call_id) & 0xFFFFFFFF, C.c_void_p(roots.data_ptr()), n,
+            et.ctypes.data_as(_lib.i32p), k, cnt.ctypes.data_as(_lib.i32p), layers,
+            int(default_node), int(partitions or transport.world), pn, pw, pt,
+            C.c_void_p(ws.data_ptr())))
+    return [roots] + outs_n, outs_w, outs_t

@@ -610,6 +610,61 @@ int euler_gpu_expand_rows(void* stream, const int32_t* pos_dev, int64_t n,
 int euler_gpu_merge_rows(void* stream, const void* in_dev,
                          const int32_t* merge_idx_dev, int64_t n_rows,
                          int64_t row_bytes, void* out_dev);
+/* ---- multi-GPU hop for C / C++ hosts ------------------------------------------
+ * What ID_SPLIT -> REMOTE -> IDX_MERGE / DATA_MERGE does over gRPC in the
+ * reference (core/kernels/id_split_op.cc:46-99, remote_op.cc:60-142,
+ * idx_merge_op.cc:32-78, data_merge_op.cc:44-67), as ONE call per rank: every
+ * rank (one process per GPU, holding the shard owner(id) = (id % partitions) %
+ * world == rank) calls it with its own batch, and the calls exchange ids and wire
+ * rows through `tr`.  The result equals the unsharded euler_gpu_sample_neighbor /
+ * euler_gpu_sample_fanout (TF layout) bit for bit.  All ranks must make the same
+ * sequence of calls (also a rank whose batch is empty: n = 0).
+ *
+ * The transport is two callbacks over one opaque pointer:
+ *   alltoall_counts  host-side all-to-all of one int64 per peer (send[p] = rows this
+ *                    rank will send to p -> recv[p] = rows it gets from p);
+ *   alltoallv        all-to-all(v) of DEVICE rows of row_bytes each, enqueued on
+ *                    `stream` (send_rows / recv_rows per peer, buffers packed in
+ *                    peer order).
+ * euler_gpu_transport_rccl fills it for an ncclComm_t (ncclSend / ncclRecv groups
+ * over xGMI; the RCCL the host process already loaded is resolved at run time, this
+ * library does not link it); `counts` = an euler_shm mailbox the ranks opened, or
+ * NULL = the counts travel through the communicator (a device sync per hop). */
+typedef struct euler_gpu_transport {
+  int32_t rank, world;
+  void* user;
+  int (*alltoall_counts)(void* user, const int64_t* send, int64_t* recv);
+  int (*alltoallv)(void* user, const void* send_dev, const int64_t* send_rows,
+                   void* recv_dev, const int64_t* recv_rows, int64_t row_bytes,
+                   void* stream);
+} euler_gpu_transport;
+int euler_gpu_transport_rccl(void* nccl_comm, int32_t rank, int32_t world,
+                             euler_shm* counts, euler_gpu_transport* out);
+void euler_gpu_transport_rccl_release(euler_gpu_transport* t);
+/* One hop; arguments as euler_gpu_sample_neighbor (TF layout), out_mask_dev [n]
+ * optional. */
+int euler_gpu_sharded_sample_neighbor(const euler_gpu_graph* shard,
+                                      const euler_gpu_transport* tr, void* stream,
+                                      uint64_t seed, uint32_t call_id,
+                                      const uint64_t* roots_dev, int64_t n,
+                                      const uint8_t* root_mask_dev, int32_t root_group,
+                                      const int32_t* edge_types_host, int32_t k,
+                                      int32_t count, int64_t default_node,
+                                      int32_t partitions, uint64_t* out_id_dev,
+                                      float* out_w_dev, int32_t* out_t_dev,
+                                      uint8_t* out_mask_dev);
+/* The fanout; arguments as euler_gpu_sample_fanout (workspace_dev:
+ * euler_gpu_sample_fanout_workspace bytes). */
+int euler_gpu_sharded_sample_fanout(const euler_gpu_graph* shard,
+                                    const euler_gpu_transport* tr, void* stream,
+                                    uint64_t seed, uint32_t call_id,
+                                    const uint64_t* roots_dev, int64_t n,
+                                    const int32_t* edge_types_host, int32_t k,
+                                    const int32_t* counts_host, int32_t layers,
+                                    int64_t default_node, int32_t partitions,
+                                    uint64_t* const* out_id_dev, float* const* out_w_dev,
+                                    int32_t* const* out_t_dev, void* workspace_dev);
+
 /* SAMPLE_NODE_SPLIT (core/kernels/sample_node_split_op.cc:57-85), host only:
  * shard_weight_host[shards+1] (last = total) -> split_cnt_host[shards]. */
 int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
@@ -659,9 +714,9 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  *        4 <= count <= 64: 1 = one lane per ROOT, the row's running sums in
  *        registers, samples staged in LDS and written in output order [default];
  *        0 = one lane per sample.
- * key 20: last hop of a fanout with key 14 = 2: the expansion reads every
- *        position's row number from the owner table itself (1 [default]); 0 = a
- *        separate resolve kernel fills an index array first.
+ * key 20: last hop of a fanout with key 14 = 2: 1 = the expansion reads every
+ *        position's row number from the owner table itself; 0 = a separate resolve
+ *        kernel fills an index array first [default: measured 9 us faster].
  * All settings produce identical results; the knobs exist for A/B measurements
  * and tests. */
 int euler_gpu_set_tuning(int32_t key, int32_t value);

@@ -484,8 +484,8 @@ def test_non_monotone_rows_use_reference_loop(EA, O, torch_cuda):
         assert set(got[i].tolist()) <= row
 
 
-@pytest.fixture(params=[(2, 1), (2, 0), (1, 1), (0, 1)],
-                ids=["onepass", "onepass_resolve_kernel", "blocknum", "scan"])
+@pytest.fixture(params=[(2, 0), (2, 1), (1, 0), (0, 0)],
+                ids=["onepass", "onepass_resolve_in_expand", "blocknum", "scan"])
 def dedup_numbering(request):
     """Every way of numbering the distinct roots (tuning key 14): one pass with
     workgroup-level atomics (the default; with the expansion reading the owner table
@@ -496,7 +496,7 @@ def dedup_numbering(request):
     _lib.lib().euler_gpu_set_tuning(20, request.param[1])
     yield request.param
     _lib.lib().euler_gpu_set_tuning(14, 2)
-    _lib.lib().euler_gpu_set_tuning(20, 1)
+    _lib.lib().euler_gpu_set_tuning(20, 0)
 
 
 @pytest.mark.parametrize("et", [[0], [1, 2], []])

@@ -63,7 +63,8 @@ def _worker_body(rank, world, port, partitions):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import euler_amd as EA
-    from euler_amd.distributed import gpu_sharded_sampler, run_interleaved
+    from euler_amd.distributed import (gpu_sharded_sampler, run_interleaved, CTransport,
+                                       c_sharded_sample_fanout)
     from oracle import oracle as O
     from conftest import make_random_graph
     dev = torch.device("cuda", 0)
@@ -98,6 +99,21 @@ def _worker_body(rank, world, port, partitions):
     assert np.array_equal(t2n(got[0][1])[:300 * 25], on[0])
     assert np.array_equal(t2n(got[0][2])[:300 * 250], on[1])
     assert np.array_equal(t2n(got[1][1])[:300 * 250], ow[1])
+
+    # the C-level path a C++ host calls (euler_gpu_sharded_sample_fanout): the hop is
+    # orchestrated inside libeuler_gpu.so, the exchange goes through the transport's
+    # two callbacks (host-staged here; euler_gpu_transport_rccl in production)
+    tr = CTransport()
+    got_c = c_sharded_sample_fanout(G_shard, tr, roots, et2, [25, 10], N + 1, call_id=6,
+                                    partitions=partitions)
+    _same(got_c[0], want[0], "C fanout ids")
+    _same(got_c[1], want[1], "C fanout weights")
+    _same(got_c[2], want[2], "C fanout types")
+    assert tr.bytes_sent > 0
+    mine_c = roots[:500] if rank != world - 1 else roots[:0]          # one rank with no batch
+    got_c = c_sharded_sample_fanout(G_shard, tr, mine_c, et2, [3, 2], N + 1, call_id=15,
+                                    partitions=partitions)
+    _same(got_c[0], G_full.sample_fanout(mine_c, et2, [3, 2], N + 1, call_id=15)[0], "C empty batch")
 
     # the same fanout with several minibatches in flight (what bench.py runs)
     samplers = [gpu_sharded_sampler(G_shard, partitions=partitions) for _ in range(2)]
@@ -172,8 +188,8 @@ def _worker_body(rank, world, port, partitions):
         assert np.array_equal(t2n(got[0])[:500], on) and np.array_equal(t2n(got[2])[:500], ot)
     # typed fanout + aggregation on the sharded sample (scatter_mean acts on the
     # minibatch-local block: replicas only, no collective)
-    gn, gw, gt = S5.sample_fanout(r5t, [[1, 4, 6], [3]], [5, 5], N5 + 1, call_id=20)
-    wn, ww, wt = G5.sample_fanout(r5t, [[1, 4, 6], [3]], [5, 5], N5 + 1, call_id=20)
+    gn, gw, gt = S5.sample_fanout(r5t, [[1, 4, 6], [0, 2, 5]], [5, 5], N5 + 1, call_id=20)
+    wn, ww, wt = G5.sample_fanout(r5t, [[1, 4, 6], [0, 2, 5]], [5, 5], N5 + 1, call_id=20)
     _same(gn, wn, "typed fanout ids"); _same(gt, wt, "typed fanout types")
     feat = torch.randn(N5 + 2, 32, device=dev, generator=torch.Generator(dev).manual_seed(3))
     x = EA.ops.gather(feat, gn[1].to(torch.int32))
@@ -203,6 +219,14 @@ def _worker_body(rank, world, port, partitions):
         got = Sh.sample_fanout(qt, ets, cnts, -1, call_id=8)
         for h in range(2):
             assert np.array_equal(t2n(got[0][h + 1]), on[h]), (ets, h)
+            assert np.array_equal(t2n(got[1][h]), ow[h]) and np.array_equal(t2n(got[2][h]), ot[h])
+    # typed / multi-type hops through the C entry (type draws: sample + pack on the owner)
+    trh = CTransport()
+    for ets, cnts in (([[0, 1], [2, 0]], [6, 4]), ([[1], [1]], [5, 5])):
+        on, ow, ot = OGh.sample_fanout(31, 8, q, ets, cnts, -1)
+        got = c_sharded_sample_fanout(Ghs, trh, qt, ets, cnts, -1, call_id=8, partitions=partitions)
+        for h in range(2):
+            assert np.array_equal(t2n(got[0][h + 1]), on[h]), ("C", ets, h)
             assert np.array_equal(t2n(got[1][h]), ow[h]) and np.array_equal(t2n(got[2][h]), ot[h])
     gi_, gd_, gw_, gt_ = Sh.get_full_neighbor(qt, [0, 2])
     wi_, wd_, ww_, wt_ = OGh.get_full_neighbor(q.astype(np.uint64), [0, 2])

@@ -82,7 +82,7 @@ for row in (1, 0):
             key = "row=%d numbering=%d resolve_in_expand=%d" % (row, num, rix)
             res[key] = {"phases_ms": phases(), "ms_per_step": whole()}
             print(key, json.dumps(res[key]), flush=True)
-L.euler_gpu_set_tuning(19, 1); L.euler_gpu_set_tuning(14, 2); L.euler_gpu_set_tuning(20, 1)
+L.euler_gpu_set_tuning(19, 1); L.euler_gpu_set_tuning(14, 2); L.euler_gpu_set_tuning(20, 0)
 # B = 1024 latency (the batch of the reference's examples)
 small = roots[:1024].contiguous()
 for row in (1, 0):
