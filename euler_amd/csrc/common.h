@@ -215,6 +215,13 @@ int BuildGraphSynthetic(const euler_gpu_synth_params* p, int device,
                         int32_t partitions, int32_t shard_index, int32_t shards,
                         euler_gpu_graph** out);
 int EnsureBlockedIndex(const euler_gpu_graph* g);   // K1 variants 3 / 4 only
+// sample_kernels.hip: TF-layout SampleNeighbor over the first *n_dev roots of a list
+// sized for `cap` (dataflow_kernels.hip)
+int LaunchSampleNeighborCounted(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed,
+                                uint32_t call_id, const uint64_t* roots, int64_t cap,
+                                const uint32_t* n_dev, const int32_t* edge_types, int32_t k,
+                                int32_t count, int64_t default_node, uint64_t* out_id,
+                                float* out_w, int32_t* out_t);
 // dat_reader.cc
 struct DatGraph {
   std::vector<uint64_t> row_id, nbr;

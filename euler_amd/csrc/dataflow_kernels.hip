@@ -1,0 +1,247 @@
+// Block construction on the device: the whole
+// SageDataFlow of the reference - tf_euler/python/dataflow/sage_dataflow.py:35-50
+// (get_neighbors: sample, then tf.unique of [neighbours | nodes]) followed by
+// neighbor_dataflow.py:84-110 (UniqueDataFlow.produce_subgraph: tf.unique of
+// [neighbours | nodes] again, res_n_id, edge_index, self loops) - enqueued on one
+// stream WITHOUT a host round trip between the hops.
+//
+// TensorFlow gives every hop a dynamic shape (the number of distinct nodes); a
+// host that wants that shape has to wait for the device.  Here every array is
+// sized for the worst case (cap_0 = n, cap_{h+1} = cap_h * (count_h + 1)) and the
+// true sizes stay in a device-side counts array: hop h+1's sampler and unique
+// kernels are launched for cap_{h+1} items and their lanes beyond counts[h+1]
+// exit.  The host reads the counts once, after the last hop (or never: padded
+// tensors + counts are a valid result for a consumer that masks).
+//
+// Per hop (`cnt` = counts[h], all on device):
+//   1. SampleNeighbor(count) of n_id[0 .. cnt)                 -> nb [cnt * count]
+//   2. tf.unique of the virtual concatenation V = [nb | n_id], first-occurrence
+//      order (id_unique_op.cc:35-64 semantics): open-addressing claim + atomicMin
+//      of the position, first-occurrence flags, ONE exclusive scan = the rank
+//      -> n_id' [cnt'], inv [cnt * (count + 1)]
+//   3. res_n_id = inv[cnt * count ..], edge_dst = inv (or its first cnt * count
+//      entries without self loops), edge_src[e] = e / count for the sampled
+//      edges and e - cnt * count for the self loops.
+// The reference runs tf.unique twice per hop on the same input (once inside
+// get_neighbors, once in produce_subgraph): one pass serves both.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include "common.h"
+#include "device_fns.h"
+
+namespace euler_gpu {
+
+namespace {
+
+constexpr uint64_t kFlowEmptyKey = ~0ULL;
+
+struct FlowTable {
+  unsigned long long* keys;   // [cap + 1]; slot `cap` is the side slot of the all-ones id
+  uint32_t* minpos;           // [cap + 1]
+  int32_t* rank;              // [cap + 1]
+  uint64_t mask;              // cap - 1
+};
+
+struct FlowHop {
+  const uint64_t* nb;         // [cap_n * count] sampled neighbours (valid: cnt * count)
+  const uint64_t* n_id;       // [cap_n] nodes of the previous layer (valid: cnt)
+  const uint32_t* cnt;        // device-side count of n_id
+  uint32_t* cnt_out;          // device-side count of the new layer
+  int32_t count;
+  int32_t self_loops;
+  int64_t cap_m;              // cap_n * (count + 1): worst-case length of V
+  FlowTable t;
+  uint32_t* slot_of;          // [cap_m]
+  uint32_t* is_first;         // [cap_m + 1] (entry cap_m stays 0: the scan's total lands there)
+  uint32_t* rank;             // [cap_m + 1]
+  uint64_t* new_n_id;         // [cap_m]
+  int64_t* inv;               // [cap_m] edge_dst: index of every element of V in new_n_id
+  int64_t* edge_src;          // [cap_m]
+  int64_t* res_n_id;          // [cap_n]
+};
+
+__device__ __forceinline__ uint64_t FlowElem(const FlowHop& h, int64_t i, int64_t m_nb) {
+  return i < m_nb ? h.nb[i] : h.n_id[i - m_nb];
+}
+
+__global__ __launch_bounds__(256) void FlowInsertKernel(const FlowHop h) {
+  const int64_t cnt = (int64_t)(*h.cnt);
+  const int64_t m_nb = cnt * h.count, m = m_nb + cnt;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
+    const uint64_t id = FlowElem(h, i, m_nb);
+    uint64_t s;
+    if (id == kFlowEmptyKey) {
+      s = h.t.mask + 1;
+    } else {
+      s = Mix64(id) & h.t.mask;
+      for (;;) {
+        unsigned long long old =
+            __hip_atomic_load(&h.t.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == kFlowEmptyKey)
+          old = atomicCAS(&h.t.keys[s], (unsigned long long)kFlowEmptyKey, (unsigned long long)id);
+        if (old == kFlowEmptyKey || old == id) break;
+        s = (s + 1) & h.t.mask;
+      }
+    }
+    if (__hip_atomic_load(&h.t.minpos[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (uint32_t)i)
+      atomicMin(&h.t.minpos[s], (uint32_t)i);
+    h.slot_of[i] = (uint32_t)s;
+  }
+}
+
+// is_first over the WORST-CASE length (zeros beyond the valid prefix), so that the
+// scan needs no device-side length
+__global__ __launch_bounds__(256) void FlowFlagKernel(const FlowHop h) {
+  const int64_t cnt = (int64_t)(*h.cnt);
+  const int64_t m = cnt * (h.count + 1);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= h.cap_m; i += stride)
+    h.is_first[i] = (i < m && h.t.minpos[h.slot_of[i]] == (uint32_t)i) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void FlowEmitKernel(const FlowHop h) {
+  const int64_t cnt = (int64_t)(*h.cnt);
+  const int64_t m_nb = cnt * h.count, m = m_nb + cnt;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (first == 0) *h.cnt_out = h.rank[h.cap_m];          // exclusive scan: the total
+  for (int64_t i = first; i < m; i += stride) {
+    if (h.is_first[i]) {
+      h.new_n_id[h.rank[i]] = FlowElem(h, i, m_nb);
+      h.t.rank[h.slot_of[i]] = (int32_t)h.rank[i];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void FlowIndexKernel(const FlowHop h) {
+  const int64_t cnt = (int64_t)(*h.cnt);
+  const int64_t m_nb = cnt * h.count, m = m_nb + cnt;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
+    const int64_t dst = (int64_t)h.t.rank[h.slot_of[i]];
+    if (i < m_nb) {
+      h.inv[i] = dst;
+      h.edge_src[i] = i / h.count;
+    } else {
+      h.res_n_id[i - m_nb] = dst;
+      if (h.self_loops) {
+        h.inv[i] = dst;
+        h.edge_src[i] = i - m_nb;        // last_idx = arange: node j keeps an edge to itself
+      }
+    }
+  }
+}
+
+__global__ void FlowInitKernel(uint32_t* counts, uint32_t n) { counts[0] = n; }
+
+size_t Al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace
+}  // namespace euler_gpu
+
+using namespace euler_gpu;
+
+extern "C" {
+
+// capacities of layer h (nodes) and of hop h's edge arrays
+static int64_t FlowCap(int64_t n, const int32_t* fanouts, int32_t h) {
+  int64_t c = n;
+  for (int32_t i = 0; i < h; ++i) c *= (int64_t)fanouts[i] + 1;
+  return c;
+}
+
+size_t euler_gpu_sage_blocks_workspace(int64_t n, const int32_t* fanouts_host, int32_t layers) {
+  size_t best = 0;
+  for (int32_t h = 0; h < layers; ++h) {
+    const int64_t cap_n = FlowCap(n, fanouts_host, h);
+    const int64_t cap_m = cap_n * ((int64_t)fanouts_host[h] + 1);
+    uint64_t tcap = 64;
+    while (tcap < (uint64_t)cap_m * 2) tcap <<= 1;
+    size_t scan_bytes = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t*)nullptr,
+                                           (uint32_t*)nullptr, (int)(cap_m + 1), nullptr);
+    const size_t b = Al((size_t)cap_n * fanouts_host[h] * 8)      // nb ids
+                     + Al((size_t)cap_n * fanouts_host[h] * 4) * 2   // weights, types (unused outputs)
+                     + Al((tcap + 1) * 8) + Al((tcap + 1) * 4) * 2  // table
+                     + Al((size_t)cap_m * 4)                        // slot_of
+                     + Al(((size_t)cap_m + 1) * 4) * 2              // is_first, rank
+                     + Al(scan_bytes) + 256;
+    if (b > best) best = b;
+  }
+  return best + 256;
+}
+
+int euler_gpu_sage_blocks(const euler_gpu_graph* g, void* stream, uint64_t seed, uint32_t call_id,
+                          const uint64_t* roots_dev, int64_t n, const int32_t* edge_types_host,
+                          int32_t k, const int32_t* fanouts_host, int32_t layers,
+                          int64_t default_node, int32_t add_self_loops, void* workspace_dev,
+                          uint64_t* const* n_id_dev, int64_t* const* res_n_id_dev,
+                          int64_t* const* edge_src_dev, int64_t* const* edge_dst_dev,
+                          uint32_t* counts_dev) {
+  if (!g) return Fail(EULER_GPU_ENOGRAPH, "sage_blocks: null graph");
+  if (n < 0 || layers <= 0 || layers > 8 || k < 0 || !fanouts_host || !n_id_dev || !res_n_id_dev ||
+      !edge_src_dev || !edge_dst_dev || !counts_dev || (n > 0 && (!roots_dev || !workspace_dev)))
+    return Fail(EULER_GPU_EINVAL, "sage_blocks: bad arguments");
+  for (int32_t h = 0; h < layers; ++h)
+    if (fanouts_host[h] <= 0) return Fail(EULER_GPU_EINVAL, "sage_blocks: fanouts must be > 0");
+  if (FlowCap(n, fanouts_host, layers) >= ((int64_t)1 << 31))
+    return Fail(EULER_GPU_EINVAL, "sage_blocks: worst-case layer size >= 2^31");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(FlowInitKernel, dim3(1), dim3(1), 0, st, counts_dev, (uint32_t)n);
+  if (n == 0) {
+    EG_HIP(hipMemsetAsync(counts_dev, 0, sizeof(uint32_t) * (layers + 1), st));
+    return EULER_GPU_OK;
+  }
+  const uint64_t* n_id = roots_dev;
+  for (int32_t h = 0; h < layers; ++h) {
+    const int32_t count = fanouts_host[h];
+    const int64_t cap_n = FlowCap(n, fanouts_host, h);
+    const int64_t cap_m = cap_n * ((int64_t)count + 1);
+    uint64_t tcap = 64;
+    while (tcap < (uint64_t)cap_m * 2) tcap <<= 1;
+    uint8_t* p = (uint8_t*)workspace_dev;
+    uint64_t* nb = (uint64_t*)p;        p += Al((size_t)cap_n * count * 8);
+    float* nb_w = (float*)p;            p += Al((size_t)cap_n * count * 4);
+    int32_t* nb_t = (int32_t*)p;        p += Al((size_t)cap_n * count * 4);
+    FlowHop f{};
+    f.t.keys = (unsigned long long*)p;  p += Al((tcap + 1) * 8);
+    f.t.minpos = (uint32_t*)p;          p += Al((tcap + 1) * 4);
+    f.t.rank = (int32_t*)p;             p += Al((tcap + 1) * 4);
+    f.t.mask = tcap - 1;
+    f.slot_of = (uint32_t*)p;           p += Al((size_t)cap_m * 4);
+    f.is_first = (uint32_t*)p;          p += Al(((size_t)cap_m + 1) * 4);
+    f.rank = (uint32_t*)p;              p += Al(((size_t)cap_m + 1) * 4);
+    void* scan_tmp = p;
+    size_t scan_bytes = 0;
+    EG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, f.is_first, f.rank,
+                                            (int)(cap_m + 1), st));
+    // 1. the hop's sampler over the first counts[h] nodes of the layer
+    int rc = LaunchSampleNeighborCounted(g, st, seed, call_id + (uint32_t)h, n_id, cap_n,
+                                         counts_dev + h, edge_types_host + (size_t)h * k, k, count,
+                                         default_node, nb, nb_w, nb_t);
+    if (rc != EULER_GPU_OK) return rc;
+    // 2. first-occurrence unique of [nb | n_id]
+    EG_HIP(hipMemsetAsync(f.t.keys, 0xFF, (tcap + 1) * 8, st));
+    EG_HIP(hipMemsetAsync(f.t.minpos, 0xFF, (tcap + 1) * 4, st));
+    f.nb = nb; f.n_id = n_id; f.cnt = counts_dev + h; f.cnt_out = counts_dev + h + 1;
+    f.count = count; f.self_loops = add_self_loops ? 1 : 0; f.cap_m = cap_m;
+    f.new_n_id = n_id_dev[h]; f.inv = edge_dst_dev[h]; f.edge_src = edge_src_dev[h];
+    f.res_n_id = res_n_id_dev[h];
+    const int block = 256;
+    const int grid = GridFor(cap_m + 1, block);
+    hipLaunchKernelGGL(FlowInsertKernel, dim3(grid), dim3(block), 0, st, f);
+    hipLaunchKernelGGL(FlowFlagKernel, dim3(grid), dim3(block), 0, st, f);
+    EG_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, f.is_first, f.rank,
+                                            (int)(cap_m + 1), st));
+    hipLaunchKernelGGL(FlowEmitKernel, dim3(grid), dim3(block), 0, st, f);
+    // 3. res_n_id, edge_index
+    hipLaunchKernelGGL(FlowIndexKernel, dim3(grid), dim3(block), 0, st, f);
+    EG_HIP(hipGetLastError());
+    n_id = n_id_dev[h];
+  }
+  return EULER_GPU_OK;
+}
+
+}  // extern "C"

@@ -54,6 +54,8 @@ struct SampleNbArgs {
   int32_t cold_roots;           // hint: the roots are distinct (one sample per lane)
   uint32_t* slow_list;          // row kernel (k1_row.h): queue of the roots it leaves to
   uint32_t* slow_count;         // SampleNeighborSlowKernel; [0] = length, [1] = workgroups done
+  int32_t ablate;               // measurement only (tuning key 2): row kernel 1 = no draws,
+                                // 2 = no write phase, 4 = no Philox (u = 0.5)
   int32_t et[kMaxListedTypes];
 };
 

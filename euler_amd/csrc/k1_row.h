@@ -141,10 +141,14 @@ __global__ __launch_bounds__(64) void SampleNeighborRowKernel(const SampleNbArgs
     }
     s_flag[lane] = !valid ? 1 : (slow ? 2 : 0);
     // ---- P2: all `count` draws of a fast root from registers
-    if (fast) {
+    if (fast && (a.ablate & 1)) {
+      for (int32_t j = 0; j < count; ++j) s_m[lane * count + j] = (uint8_t)i_lo;
+    } else if (fast) {
       const float lb = sg.limit_begin, le = sg.limit_end;
       for (int32_t j = 0; j < count; j += 2) {
-        const Philox4 pb = RngBlock(a.seed, a.call_id, kDomainNeighbor, node, ((uint32_t)j) >> 1);
+        Philox4 pb;
+        if (a.ablate & 4) { pb.w[0] = pb.w[2] = 0x80000000u + (uint32_t)j; pb.w[1] = pb.w[3] = 0; }
+        else pb = RngBlock(a.seed, a.call_id, kDomainNeighbor, node, ((uint32_t)j) >> 1);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           if (j + h >= count) break;
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(64) void SampleNeighborRowKernel(const SampleNbArgs
     const int64_t left = n_roots - tile * kRowTile;
     const int32_t nt = (int32_t)(left < kRowTile ? left : kRowTile) * count;
     const int64_t base = tile * kRowTile * (int64_t)count;
-    for (int32_t e = lane * 2; e < nt; e += 128) {
+    for (int32_t e = lane * 2; e < nt && !(a.ablate & 2); e += 128) {
       uint64_t id[2] = {0, 0};
       float wv[2] = {0.f, 0.f};
       int32_t ot[2] = {t, t};

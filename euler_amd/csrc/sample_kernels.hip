@@ -813,6 +813,7 @@ static int LaunchK1(const euler_gpu_graph* g, hipStream_t stream,
       const int rc = GetRowScratch(g, stream, n, &q);
       if (rc != EULER_GPU_OK) return rc;
       SampleNbArgs ra = a;
+      ra.ablate = g_k1_ablate;
       ra.slow_count = (uint32_t*)q;
       ra.slow_list = (uint32_t*)q + 64;
       // the queued (long-row) roots, one lane per sample; the grid loops over the
@@ -1263,6 +1264,41 @@ static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
   EG_HIP(hipGetLastError());
   if (hop != nullptr) hop->mark_next = do_mark;
   return EULER_GPU_OK;
+}
+
+// TF-layout sampling of the first *n_dev roots of a worst-case-sized list (the
+// count lives on the device: block construction chains hops without telling the
+// host how many distinct nodes a hop produced).  The pass-2 gate of the
+// duplicate-root path does exactly this: a launch sized for `cap` roots whose
+// lanes beyond the device-side count exit.
+int LaunchSampleNeighborCounted(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed,
+                                uint32_t call_id, const uint64_t* roots, int64_t cap,
+                                const uint32_t* n_dev, const int32_t* edge_types, int32_t k,
+                                int32_t count, int64_t default_node, uint64_t* out_id,
+                                float* out_w, int32_t* out_t) {
+  if (g == nullptr) return Fail(EULER_GPU_ENOGRAPH, "sample_neighbor: null graph");
+  if (cap < 0 || count <= 0 || k < 0 || k > kMaxListedTypes)
+    return Fail(EULER_GPU_EINVAL, "sample_neighbor (counted): bad cap/count/k");
+  if (cap == 0) return EULER_GPU_OK;
+  if (!(g_k1_variant == 5 || g_k1_variant == 6 || g_k1_variant == 0))
+    return Fail(EULER_GPU_EINVAL, "sample_neighbor (counted): needs the default kernels");
+  if (g_k1_variant == 6 && g->view.blk == nullptr) {
+    const int rc = EnsureBlockedIndex(g);
+    if (rc != EULER_GPU_OK) return rc;
+  }
+  SampleNbArgs a{};
+  a.g = g->view;
+  a.seed = seed; a.call_id = call_id;
+  a.roots = roots; a.root_mask = nullptr; a.root_group = 1;
+  a.out_id = out_id; a.out_w = out_w; a.out_t = out_t; a.out_row_mask = nullptr;
+  a.n = cap; a.default_node = default_node;
+  a.k = k; a.count = count; a.layout = EULER_GPU_LAYOUT_TF;
+  a.cold_roots = 1;
+  a.dd_role = 2;
+  a.dd_counter = n_dev;
+  a.dd_n_in = (int64_t)1 << 60;          // the gate's "duplicates pay" test always holds
+  for (int i = 0; i < k; ++i) a.et[i] = edge_types[i];
+  return LaunchK1(g, stream, a);
 }
 
 }  // namespace euler_gpu

@@ -103,6 +103,24 @@ class SageDataFlow(UniqueDataFlow):
         self.metapath = metapath
         self.max_id = max_id
 
+    def produce_subgraph(self, n_id):
+        """One enqueue for all hops (Graph.sage_blocks -> euler_gpu_sage_blocks):
+        sampler, first-occurrence unique, res_n_id and edge_index of every hop run
+        back to back on the stream; the host reads the layer sizes once at the end.
+        `fused = False` (or hops whose edge-type lists differ in length) takes the
+        op-by-op composition of the base class, one host round trip per hop."""
+        lens = {len(m) for m in self.metapath}
+        if not getattr(self, "fused", True) or len(lens) != 1:
+            return super(SageDataFlow, self).produce_subgraph(n_id)
+        n_id = n_id.reshape(-1)
+        blocks, _cnt = self.graph.sage_blocks(n_id, self.metapath, self.fanouts,
+                                              default_node=self.max_id + 1,
+                                              add_self_loops=self.add_self_loops)
+        data_flow = DataFlow(n_id)
+        for new_n_id, res_n_id, edge_src, edge_dst in blocks:
+            data_flow.append(new_n_id, res_n_id, None, torch.stack([edge_src, edge_dst], 0))
+        return data_flow
+
     def get_neighbors(self, n_id):
         neighbors, neighbor_src = [], []
         for hop_edge_types, count in zip(self.metapath, self.fanouts):

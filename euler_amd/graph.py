@@ -330,6 +330,47 @@ class Graph:
                 cnt_p, layers, int(default_node), pn, pw, pt, _ptr(ws)))
         return [nodes] + outs_n, outs_w, outs_t
 
+    def sage_blocks(self, nodes, edge_types, fanouts, default_node=-1, add_self_loops=True,
+                    call_id=None, sync=True):
+        """The whole SageDataFlow (tf_euler/python/dataflow/sage_dataflow.py +
+        UniqueDataFlow.produce_subgraph) as ONE enqueue, no host round trip between
+        the hops (euler_gpu_sage_blocks).  Returns (blocks, counts): blocks[h] =
+        (n_id, res_n_id, edge_src, edge_dst) and counts = the layer sizes - sliced to
+        their true sizes after one read of the counts when sync is True, else padded
+        to the worst case with `counts` left on the device (uint32 [layers + 1])."""
+        nodes = _as_i64_cuda(nodes, self.device).reshape(-1)
+        layers = len(fanouts)
+        et = np.asarray(edge_types, dtype=np.int32).reshape(layers, -1)
+        et, et_p, _ = _i32_array(et)
+        k = et.size // layers if layers else 0
+        fan, fan_p, _ = _i32_array(fanouts)
+        n = nodes.numel()
+        caps = [n]
+        for c in fanouts:
+            caps.append(caps[-1] * (int(c) + 1))
+        dev = self.device
+        n_ids = [torch.empty(max(caps[h + 1], 1), dtype=torch.int64, device=dev) for h in range(layers)]
+        res = [torch.empty(max(caps[h], 1), dtype=torch.int64, device=dev) for h in range(layers)]
+        esrc = [torch.empty(max(caps[h + 1], 1), dtype=torch.int64, device=dev) for h in range(layers)]
+        edst = [torch.empty(max(caps[h + 1], 1), dtype=torch.int64, device=dev) for h in range(layers)]
+        counts = torch.zeros(layers + 1, dtype=torch.int32, device=dev)
+        ws = torch.empty(max(int(lib().euler_gpu_sage_blocks_workspace(n, fan_p, layers)), 16),
+                         dtype=torch.uint8, device=dev)
+        arr = lambda ts: (C.c_void_p * layers)(*[t.data_ptr() for t in ts])
+        with torch.cuda.device(dev):
+            check(lib().euler_gpu_sage_blocks(
+                self._h, _stream(), self.seed, self._take_call_ids(layers, call_id), _ptr(nodes), n,
+                et_p, k, fan_p, layers, int(default_node), 1 if add_self_loops else 0, _ptr(ws),
+                arr(n_ids), arr(res), arr(esrc), arr(edst), _ptr(counts)))
+        if not sync:
+            return list(zip(n_ids, res, esrc, edst)), counts
+        cnt = [int(c) for c in counts.cpu().tolist()]          # the one host read
+        blocks = []
+        for h in range(layers):
+            e = cnt[h] * int(fanouts[h]) + (cnt[h] if add_self_loops else 0)
+            blocks.append((n_ids[h][:cnt[h + 1]], res[h][:cnt[h]], esrc[h][:e], edst[h][:e]))
+        return blocks, cnt
+
     def sample_node(self, count, node_type=-1, call_id=None):
         """tf_euler sample_node (tf_euler/kernels/sample_node_op.cc:39-98):
         [count] int64 ids drawn by node weight within the type(s)."""

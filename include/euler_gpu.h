@@ -475,6 +475,33 @@ int euler_gpu_get_sparse_feature_core(const euler_gpu_graph* g, void* stream,
                                       int32_t* idx_dev, int64_t* total_host,
                                       uint64_t* values_dev);
 
+/* ---- block construction (SageDataFlow) on the device ---------------------------
+ * tf_euler/python/dataflow/sage_dataflow.py:35-50 + neighbor_dataflow.py:84-110
+ * (UniqueDataFlow.produce_subgraph) for `layers` hops, enqueued on `stream` with NO
+ * host round trip in between: hop h samples fanouts_host[h] neighbours
+ * (edge_types_host[h*k .. h*k+k), call id call_id + h, default_node) of the layer's
+ * nodes, takes the first-occurrence unique (tf.unique) of [neighbours | nodes] as
+ * the next layer and emits the block.  Arrays are sized for the worst case
+ * cap_0 = n, cap_{h+1} = cap_h * (fanouts[h] + 1); the true sizes are
+ * counts_dev [layers + 1] (uint32: counts[0] = n, counts[h+1] = nodes of layer
+ * h + 1), which the host may read after the call or never.  Block h:
+ *   n_id_dev[h]      [cap_{h+1}]                 new_n_id (valid: counts[h+1])
+ *   res_n_id_dev[h]  [cap_h]                     index of every node of layer h in
+ *                                                new_n_id (valid: counts[h])
+ *   edge_src_dev[h], edge_dst_dev[h]  [cap_h * (fanouts[h] + 1)]   edge_index rows;
+ *                    valid: counts[h] * fanouts[h] (+ counts[h] self loops when
+ *                    add_self_loops != 0)
+ * workspace_dev: euler_gpu_sage_blocks_workspace(n, fanouts_host, layers) bytes. */
+size_t euler_gpu_sage_blocks_workspace(int64_t n, const int32_t* fanouts_host, int32_t layers);
+int euler_gpu_sage_blocks(const euler_gpu_graph* g, void* stream, uint64_t seed,
+                          uint32_t call_id, const uint64_t* roots_dev, int64_t n,
+                          const int32_t* edge_types_host, int32_t k,
+                          const int32_t* fanouts_host, int32_t layers, int64_t default_node,
+                          int32_t add_self_loops, void* workspace_dev,
+                          uint64_t* const* n_id_dev, int64_t* const* res_n_id_dev,
+                          int64_t* const* edge_src_dev, int64_t* const* edge_dst_dev,
+                          uint32_t* counts_dev);
+
 /* ---- RandomWalk -------------------------------------------------------------
  * TF RandomWalk kernel (tf_euler/kernels/random_walk_op.cc:172-291):
  * |p-1|,|q-1| <= 1e-6 -> chain of count=1 SampleNeighbor hops (:207-247), else
