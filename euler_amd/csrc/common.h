@@ -203,6 +203,7 @@ struct euler_gpu_graph {
   // row kernel (k1_row.h): per stream, 256 bytes of counters + the queue of the
   // roots left to SampleNeighborSlowKernel
   mutable std::map<void*, std::pair<void*, size_t>> row_ws;
+  mutable std::map<void*, int> row_parity;
 };
 
 namespace euler_gpu {

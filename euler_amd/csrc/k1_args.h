@@ -53,7 +53,9 @@ struct SampleNbArgs {
   int32_t packed_tcol;          // ... with (1) or without (0: single-type call) the types
   int32_t cold_roots;           // hint: the roots are distinct (one sample per lane)
   uint32_t* slow_list;          // row kernel (k1_row.h): queue of the roots it leaves to
-  uint32_t* slow_count;         // SampleNeighborSlowKernel; [0] = length, [1] = workgroups done
+  uint32_t* slow_count;         // SampleNeighborSlowKernel: [kSlowShards] queue lengths of this
+  uint32_t* slow_count_next;    // call; the set the stream's next call uses (cleared here)
+  int64_t slow_cap;             // entries per queue
   int32_t ablate;               // measurement only (tuning key 2): row kernel 1 = no draws,
                                 // 2 = no write phase, 4 = no Philox (u = 0.5)
   int32_t et[kMaxListedTypes];

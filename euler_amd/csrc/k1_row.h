@@ -20,12 +20,15 @@
 // leave as 16-byte stores, weights and types as 8-byte stores.
 //
 // Rows that span more than two blocks ("slow" roots: 6 % of the first hop, nearly
-// all roots of a later hop) are not sampled here: the wave appends them to a
-// device-side list (one atomic per tile) and SampleNeighborSlowKernel, launched
-// right behind, gives each of their samples a lane and the block-pivot search of
-// k1_search.h - perfectly balanced over the chip, where doing them inside their
-// tile made the tile with the most hubs the kernel's critical path (measured:
-// 69 us for the metric's first hop, no better than one lane per sample).
+// all roots of a later hop) are not sampled here: the wave appends them to one of
+// kSlowShards device-side queues and SampleNeighborSlowKernel, launched right
+// behind, gives each of their samples a lane and the block-pivot search of
+// k1_search.h - balanced over the chip, where doing them inside their tile made
+// the tile with the most hubs the kernel's critical path.  The queues are sharded
+// and their counters come in two sets used alternately (a call clears the set the
+// NEXT call will use): a single counter made 2 048 waves queue behind one another
+// on a same-address atomic (~9 ns each, returned value awaited: +18 us), and a
+// "last workgroup clears" counter in the slow kernel did it a second time.
 #ifndef EULER_AMD_CSRC_K1_ROW_H_
 #define EULER_AMD_CSRC_K1_ROW_H_
 
@@ -39,6 +42,11 @@ namespace euler_gpu {
 constexpr int kRowTile = 64;                        // roots per wave (= workgroup)
 constexpr int kRowMaxCount = 64;
 constexpr int kRowSlots = 2 * kEdgesPerBlock;       // sums a lane keeps in registers
+constexpr int kSlowShards = 64;                     // queues of the slow roots (tile % 64)
+// scratch: counters [2 sets][kSlowShards] u32, then kSlowShards queues of
+// `slow_cap` root indices each (slow_cap >= 64 * tiles per shard)
+constexpr int kSlowCounterWords = 2 * kSlowShards;
+constexpr int64_t kRowMinSamples = 1 << 20;         // below: one lane per sample
 
 // dynamic LDS of one wave:
 //   sums [kRowSlots + 1][64] f32   (slot-major: lane l reads bank l % 32 whatever
@@ -76,6 +84,8 @@ __global__ __launch_bounds__(64) void SampleNeighborRowKernel(const SampleNbArgs
   const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   const double kInf = __builtin_huge_val();
   const int64_t tiles = (n_roots + kRowTile - 1) / kRowTile;
+  // the counters of the stream's NEXT call
+  if (blockIdx.x == 0 && lane < kSlowShards) a.slow_count_next[lane] = 0;
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     // ---- P1: root id -> row record -> the sums and ids of the row's (<= 2) blocks
     const int64_t r = tile * kRowTile + lane;
@@ -178,10 +188,13 @@ __global__ __launch_bounds__(64) void SampleNeighborRowKernel(const SampleNbArgs
     // ---- slow roots (more than two blocks): queued for SampleNeighborSlowKernel
     const uint64_t slow_mask = __ballot(slow);
     if (slow_mask != 0) {
+      const int32_t shard = (int32_t)(tile % kSlowShards);
       uint32_t base_q = 0;
-      if (lane == 0) base_q = atomicAdd(a.slow_count, (uint32_t)__popcll(slow_mask));
+      if (lane == 0) base_q = atomicAdd(a.slow_count + shard, (uint32_t)__popcll(slow_mask));
       base_q = __shfl(base_q, 0);
-      if (slow) a.slow_list[base_q + (uint32_t)__popcll(slow_mask & lt_mask)] = (uint32_t)r;
+      if (slow)
+        a.slow_list[(int64_t)shard * a.slow_cap + base_q + (uint32_t)__popcll(slow_mask & lt_mask)] =
+            (uint32_t)r;
     }
     if (live && a.out_row_mask != nullptr) a.out_row_mask[r] = valid ? 0 : 1;
     WaveSync();
@@ -244,20 +257,32 @@ __global__ __launch_bounds__(64) void SampleNeighborRowKernel(const SampleNbArgs
   }
 }
 
-// The queued slow roots, one lane per sample (see the head of this file).  The
-// last workgroup to finish clears the queue's counters for the stream's next call.
+// The queued slow roots, one lane per sample (see the head of this file).
 template <bool TF_LAYOUT>
 __global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborSlowKernel(
     const SampleNbArgs a) {
-  const uint32_t n_slow = *a.slow_count;
+  __shared__ uint32_t s_off[kSlowShards + 1];
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int x = 0; x < kSlowShards; ++x) { s_off[x] = run; run += a.slow_count[x]; }
+    s_off[kSlowShards] = run;
+  }
+  __syncthreads();
+  const uint32_t n_slow = s_off[kSlowShards];
   const int32_t count = a.count;
   const int32_t t = a.et[0];
   const int64_t total = (int64_t)n_slow * count;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total; s += stride) {
-    const int64_t q = s / count;
-    const int32_t j = (int32_t)(s - q * count);
-    const int64_t r = (int64_t)a.slow_list[q];
+    const uint32_t q = (uint32_t)(s / count);
+    const int32_t j = (int32_t)(s - (int64_t)q * count);
+    // shard of queue entry q: the last offset <= q
+    int32_t lo = 0, hi = kSlowShards - 1;
+    while (lo < hi) {
+      const int32_t mid = (lo + hi + 1) >> 1;
+      if (s_off[mid] <= q) lo = mid; else hi = mid - 1;
+    }
+    const int64_t r = (int64_t)a.slow_list[(int64_t)lo * a.slow_cap + (q - s_off[lo])];
     uint64_t node = a.roots[r];
     if (a.root_mask != nullptr && a.root_mask[r / a.root_group]) node = 0;
     Segment sg;
@@ -272,11 +297,6 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborSlowKernel(
     a.out_w[d] = wv;
     a.out_t[d] = t;
     if (a.mark_owner != nullptr) MarkNextHop(a.g, a.mark_owner, id, true, d);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const uint32_t done = atomicAdd(a.slow_count + 1, 1u);
-    if (done == gridDim.x - 1) { a.slow_count[0] = 0; a.slow_count[1] = 0; }
   }
 }
 

@@ -731,13 +731,19 @@ static void LaunchExpand(int U, int V, bool ct, int grid, int block, hipStream_t
     else LaunchExpandUV<1, 1>(ct, grid, block, stream, x, stride_rows, stride_slots);
   }
 }
-// Queue of the row kernel (k1_row.h), per (graph, stream), grown on demand: 256
-// bytes of counters (zero between calls: the slow kernel's last workgroup clears
-// them) + one uint32 per root.
-static int GetRowScratch(const euler_gpu_graph* g, hipStream_t stream, int64_t n, void** out) {
+// Queues of the row kernel (k1_row.h), per (graph, stream), grown on demand: two
+// sets of kSlowShards counters (used alternately, each call clears the other set)
+// + kSlowShards queues of `cap` root indices.
+static int64_t RowQueueCap(int64_t n) {
+  const int64_t tiles = (n + kRowTile - 1) / kRowTile;
+  return ((tiles + kSlowShards - 1) / kSlowShards) * kRowTile;
+}
+
+static int GetRowScratch(const euler_gpu_graph* g, hipStream_t stream, int64_t n, void** out,
+                         int* parity) {
   std::lock_guard<std::mutex> lk(g->ws_mu);
   auto& slot = g->row_ws[(void*)stream];
-  const size_t bytes = 256 + (size_t)n * 4;
+  const size_t bytes = kSlowCounterWords * 4 + (size_t)RowQueueCap(n) * kSlowShards * 4;
   if (slot.second < bytes) {
     if (slot.first != nullptr) {
       EG_HIP(hipStreamSynchronize(stream));
@@ -751,9 +757,13 @@ static int GetRowScratch(const euler_gpu_graph* g, hipStream_t stream, int64_t n
       return Fail(EULER_GPU_ENOMEM, std::string("sample_neighbor queue: ") + hipGetErrorString(e));
     }
     slot.second = want;
-    EG_HIP(hipMemsetAsync(slot.first, 0, 256, stream));
+    EG_HIP(hipMemsetAsync(slot.first, 0, kSlowCounterWords * 4, stream));
+    g->row_parity[(void*)stream] = 0;
   }
   *out = slot.first;
+  int& par = g->row_parity[(void*)stream];
+  *parity = par;
+  par ^= 1;
   return EULER_GPU_OK;
 }
 
@@ -800,8 +810,11 @@ static int LaunchK1(const euler_gpu_graph* g, hipStream_t stream,
     const int64_t stride_rows = stride / count;
     const int32_t stride_slots = (int32_t)(stride - stride_rows * count);
     const bool tf = layout == EULER_GPU_LAYOUT_TF;
+    // (small launches stay with one lane per sample: a root's `count` draws are one
+    // lane's serial work here - 21 us for 1 024 x 25 against 8 - which only pays
+    // once the lane-per-sample kernel would need several rounds of waves)
     if (blocked && g_k1_row != 0 && a.dd_role == 0 && a.packed == nullptr && count >= 4 &&
-        count <= kRowMaxCount && ((uintptr_t)out_id % 16 == 0) && ((uintptr_t)out_w % 8 == 0) &&
+        count <= kRowMaxCount && (n * (int64_t)count >= kRowMinSamples || g_k1_row == 2) && ((uintptr_t)out_id % 16 == 0) && ((uintptr_t)out_w % 8 == 0) &&
         ((uintptr_t)out_t % 8 == 0)) {
       // one lane per root, one wave per workgroup; the LDS staging area bounds the
       // waves a CU holds (count 25: 14 KB -> 11), the grid-stride loop does the rest
@@ -810,12 +823,15 @@ static int LaunchK1(const euler_gpu_graph* g, hipStream_t stream,
       const int64_t cap = g_k1_grid_cap > 0 ? g_k1_grid_cap : 256 * 16;
       if (tiles > cap) tiles = cap;
       void* q = nullptr;
-      const int rc = GetRowScratch(g, stream, n, &q);
+      int parity = 0;
+      const int rc = GetRowScratch(g, stream, n, &q, &parity);
       if (rc != EULER_GPU_OK) return rc;
       SampleNbArgs ra = a;
       ra.ablate = g_k1_ablate;
-      ra.slow_count = (uint32_t*)q;
-      ra.slow_list = (uint32_t*)q + 64;
+      ra.slow_count = (uint32_t*)q + (parity ? kSlowShards : 0);
+      ra.slow_count_next = (uint32_t*)q + (parity ? 0 : kSlowShards);
+      ra.slow_list = (uint32_t*)q + kSlowCounterWords;
+      ra.slow_cap = RowQueueCap(n);
       // the queued (long-row) roots, one lane per sample; the grid loops over the
       // device-side queue length
       int64_t sblocks = (n * (int64_t)count + 255) / 256;
@@ -1396,7 +1412,7 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 16) { g_adj_scan = value != 0; return EULER_GPU_OK; }
   if (key == 17 && value >= 0) { g_adj_long_row = value; return EULER_GPU_OK; }
   if (key == 18) { g_sum_scalar = value != 0; return EULER_GPU_OK; }
-  if (key == 19) { g_k1_row = value != 0; return EULER_GPU_OK; }
+  if (key == 19 && value >= 0 && value <= 2) { g_k1_row = value; return EULER_GPU_OK; }
   if (key == 20) { g_dedup_resolve_in_expand = value != 0; return EULER_GPU_OK; }
   if (key == 1 && (value == 1 || value == 2 || value == 4 || value == 8)) {
     g_k1_ilp = value;

@@ -770,6 +770,68 @@ __global__ void AlgoBytesKernel(const FullNbArgs a, int32_t count, double* acc) 
   if ((threadIdx.x & 63) == 0 && b != 0.0) atomicAdd(acc, b);
 }
 
+// Algorithmic bytes of a finished walk: p = q = 1 - every step
+// is one SampleNeighbor(count = 1) of the walker's node: the K1 per-root and
+// per-edge terms; node2vec - (deg(cur) + deg(prev)) * (8 + 4) per step, the two
+// neighbour lists BuildWeights merges (random_walk_op.cc:140-168).  One lane
+// per (walker, step); degrees over the listed types of that step.
+struct WalkBytesArgs {
+  GraphView g;
+  const int64_t* walks;      // [n, walk_len + 1]
+  const int32_t* edge_types; // [walk_len, k]
+  int64_t n;
+  int32_t walk_len, k, node2vec;
+};
+
+__device__ __forceinline__ int32_t ListedDegree(const GraphView& g, int64_t row,
+                                                const int32_t* et, int32_t k) {
+  if (row < 0) return 0;
+  const RowMeta m = LoadRowMeta(g, row);
+  const int32_t mode = TypeModeOf(k, g.T);
+  if (mode == kTypeAll) return m.type_end[g.T - 1];
+  int32_t deg = 0;
+  for (int32_t x = 0; x < k; ++x) {
+    const int32_t t = et[x];
+    if (t >= 0 && t < g.T) deg += m.type_end[t] - (t == 0 ? 0 : m.type_end[t - 1]);
+  }
+  return deg;
+}
+
+__global__ void WalkAlgoBytesKernel(const WalkBytesArgs a, double* acc) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double b = 0.0;
+  if (idx < a.n * a.walk_len) {
+    const int64_t i = idx / a.walk_len;
+    const int32_t s = (int32_t)(idx - i * a.walk_len);
+    const int64_t L = a.walk_len + 1;
+    const uint64_t cur = (uint64_t)a.walks[i * L + s];
+    const int32_t* et = a.edge_types + (size_t)s * a.k;
+    const int32_t deg = ListedDegree(a.g, FindRow(a.g, cur), et, a.k);
+    if (a.node2vec) {
+      int32_t pdeg = 0;
+      if (s > 0)
+        pdeg = ListedDegree(a.g, FindRow(a.g, (uint64_t)a.walks[i * L + s - 1]),
+                            a.edge_types + (size_t)(s - 1) * a.k, a.k);
+      b = 12.0 * ((double)deg + (double)pdeg) + 8.0;       // + the step's output id
+    } else {
+      const int32_t mode = TypeModeOf(a.k, a.g.T);
+      b = 8.0 + 16.0 + 4.0 * (mode == kTypeSingle ? 1 : a.g.T) + 8.0;
+      double per = 16.0;
+      if (deg > 0) {
+        const int32_t d2 = deg < 2 ? 2 : deg;
+        per += 8.0 + 8.0 + 4.0 * (double)(32 - __clz(d2 - 1));
+        if (mode != kTypeSingle) {
+          const int32_t t2 = a.g.T < 2 ? 2 : a.g.T;
+          per += 4.0 * (double)(32 - __clz(t2 - 1)) + 8.0;
+        }
+      }
+      b += per;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) b += __shfl_down(b, off, 64);
+  if ((threadIdx.x & 63) == 0 && b != 0.0) atomicAdd(acc, b);
+}
+
 }  // namespace euler_gpu
 
 using namespace euler_gpu;
@@ -947,6 +1009,42 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
   EG_HIP(hipGetLastError());
   // the edge-type table must outlive the kernel: stream-ordered free
   EG_HIP(hipFreeAsync(et_dev, st));
+  return EULER_GPU_OK;
+}
+
+int euler_gpu_random_walk_algo_bytes(const euler_gpu_graph* g, void* stream,
+                                     const int64_t* walks_dev, int64_t n,
+                                     const int32_t* edge_types_host, int32_t k,
+                                     int32_t walk_len, float p, float q, double* bytes_host) {
+  if (!g) return Fail(EULER_GPU_ENOGRAPH, "random_walk_algo_bytes: null graph");
+  if (n < 0 || walk_len < 0 || k < 0 || k > kMaxListedTypes || !bytes_host)
+    return Fail(EULER_GPU_EINVAL, "random_walk_algo_bytes: bad arguments");
+  *bytes_host = 0.0;
+  if (n == 0 || walk_len == 0) return EULER_GPU_OK;
+  if (!walks_dev || (k > 0 && !edge_types_host))
+    return Fail(EULER_GPU_EINVAL, "random_walk_algo_bytes: null buffer");
+  hipStream_t st = (hipStream_t)stream;
+  uint8_t* buf = nullptr;
+  const size_t et_bytes = ((size_t)walk_len * (k > 0 ? k : 1) * sizeof(int32_t) + 15) & ~(size_t)15;
+  EG_HIP(hipMallocAsync((void**)&buf, et_bytes + 16, st));
+  double* acc = (double*)(buf + et_bytes);
+  EG_HIP(hipMemsetAsync(acc, 0, 8, st));
+  if (k > 0)
+    EG_HIP(hipMemcpyAsync(buf, edge_types_host, (size_t)walk_len * k * sizeof(int32_t),
+                          hipMemcpyHostToDevice, st));
+  WalkBytesArgs a{};
+  a.g = g->view; a.walks = walks_dev; a.edge_types = (const int32_t*)buf; a.n = n;
+  a.walk_len = walk_len; a.k = k;
+  const float kEps = 1.0e-6;
+  a.node2vec = (std::fabs((double)p - 1.0) <= kEps && std::fabs((double)q - 1.0) <= kEps) ? 0 : 1;
+  const int block = 256;
+  const int64_t items = n * walk_len;
+  hipLaunchKernelGGL(WalkAlgoBytesKernel, dim3((unsigned)((items + block - 1) / block)), dim3(block),
+                     0, st, a, acc);
+  EG_HIP(hipGetLastError());
+  EG_HIP(hipMemcpyAsync(bytes_host, acc, 8, hipMemcpyDeviceToHost, st));
+  EG_HIP(hipStreamSynchronize(st));
+  EG_HIP(hipFreeAsync(buf, st));
   return EULER_GPU_OK;
 }
 

@@ -513,6 +513,17 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
                           int32_t walk_len, float p, float q,
                           int64_t default_node, int64_t* out_dev);
 
+/* Exact algorithmic byte count of a finished walk (walks_dev = the
+ * [n, walk_len + 1] output of euler_gpu_random_walk): p = q = 1 - per step the
+ * SampleNeighbor(count = 1) terms of euler_gpu_sample_neighbor_algo_bytes over the
+ * degree of the node the walker stands on; node2vec - (deg(cur) + deg(prev)) * 12
+ * + 8 per step.  Synchronises. */
+int euler_gpu_random_walk_algo_bytes(const euler_gpu_graph* g, void* stream,
+                                     const int64_t* walks_dev, int64_t n,
+                                     const int32_t* edge_types_host, int32_t k,
+                                     int32_t walk_len, float p, float q,
+                                     double* bytes_host);
+
 /* GenPair (tf_euler/kernels/gen_pair_op.cc:42-95): paths [batch,path_len] ->
  * pairs [batch, pair_count, 2]. */
 int64_t euler_gpu_gen_pair_count(int64_t path_len, int32_t left_win,
@@ -738,9 +749,9 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  *        1 = scalar loads and a wave-uniform chain (measured 2x slower).
  * key 19: sample_neighbor calls that do not take the duplicate-root path (first
  *        hop of a fanout, calls below 100 000 roots), single listed type,
- *        4 <= count <= 64: 1 = one lane per ROOT, the row's running sums in
- *        registers, samples staged in LDS and written in output order [default];
- *        0 = one lane per sample.
+ *        4 <= count <= 64: 1 = one lane per ROOT (the row's running sums in
+ *        registers, samples staged in LDS and written in output order) for launches
+ *        of >= 2^20 samples [default]; 2 = for every launch; 0 = one lane per sample.
  * key 20: last hop of a fanout with key 14 = 2: 1 = the expansion reads every
  *        position's row number from the owner table itself; 0 = a separate resolve
  *        kernel fills an index array first [default: measured 9 us faster].

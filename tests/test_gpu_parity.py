@@ -25,9 +25,10 @@ def k1_variant(request, EA):
     from euler_amd import _lib
     _lib.lib().euler_gpu_set_tuning(0, request.param[0])
     _lib.lib().euler_gpu_set_tuning(1, request.param[1] if request.param[1] != 3 else 4)
-    # (6, 4) = the default: one lane per ROOT (k1_row.h) wherever it applies;
-    # every other parameter runs the lane-per-sample kernels
-    _lib.lib().euler_gpu_set_tuning(19, 1 if request.param == (6, 4) else 0)
+    # (6, 4): one lane per ROOT (k1_row.h) wherever it applies, whatever the launch
+    # size (2; the default, 1, keeps launches below 2^20 samples on the
+    # lane-per-sample kernels); every other parameter runs the lane-per-sample kernels
+    _lib.lib().euler_gpu_set_tuning(19, 2 if request.param == (6, 4) else 0)
     # (6, 1) forces one sample per lane
     _lib.lib().euler_gpu_set_tuning(4, 0 if request.param == (6, 1) else 1)
     # ... and (6, 2) also turns on five samples per lane for odd multiples of 5
