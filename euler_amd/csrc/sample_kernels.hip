@@ -427,6 +427,54 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void DedupExpandKernel(const Ex
   }
 }
 
+// The same gather-copy with as few instructions as it takes.  The kernel above
+// compiles to ~1 800 instructions (64-bit index arithmetic, a division by `count`,
+// the grid-stride bookkeeping of V steps, the mark / resolve options), and with
+// 16 M lane-iterations on the metric's second hop its ISSUE time - not the 0.9 GB
+// it moves - set its 125-135 us.  Here a workgroup owns 256 / P whole positions
+// (P = count / 2 pairs per row), a lane one pair: tid -> (position, pair) is one
+// multiply and a shift, all offsets are 32-bit, the body is 4 loads and 3 stores.
+// Even counts, no next-hop marking (the last hop of a fanout), n * count < 2^31.
+template <bool CT>
+__global__ __launch_bounds__(256, kWavesPerSimd) void DedupExpandLeanKernel(
+    const uint32_t* __restrict__ counter, const uint32_t* __restrict__ uidx_of,
+    const uint64_t* __restrict__ t_id, const float* __restrict__ t_w,
+    const int32_t* __restrict__ t_t, const uint8_t* __restrict__ t_mask,
+    uint64_t* __restrict__ out_id, float* __restrict__ out_w, int32_t* __restrict__ out_t,
+    uint8_t* __restrict__ out_mask, const uint32_t n, const uint32_t count, const uint32_t P,
+    const uint32_t inv_p, const uint32_t rows_per_block, const int32_t type0,
+    const int32_t masked_type) {
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
+  if (!DedupActive(counter, (int64_t)n)) return;
+  const uint32_t r_in_block = (threadIdx.x * inv_p) >> 16;          // tid / P
+  const uint32_t pr = threadIdx.x - r_in_block * P;                 // tid % P
+  if (r_in_block >= rows_per_block) return;
+  for (uint32_t i = blockIdx.x * rows_per_block + r_in_block; i < n;
+       i += gridDim.x * rows_per_block) {
+    const uint32_t u = uidx_of[i];
+    const uint32_t src = u * count + 2u * pr;
+    const uint32_t dst = i * count + 2u * pr;
+    const u64x2 i2 = *reinterpret_cast<const u64x2*>(t_id + src);
+    const f32x2 w2 = *reinterpret_cast<const f32x2*>(t_w + src);
+    i32x2 t2;
+    uint8_t m = 0;
+    if (CT) {
+      m = t_mask[u];
+      const int32_t tt = m ? masked_type : type0;
+      t2 = i32x2{tt, tt};
+    } else {
+      t2 = *reinterpret_cast<const i32x2*>(t_t + src);
+      if (pr == 0 && out_mask != nullptr) m = t_mask[u];
+    }
+    __builtin_nontemporal_store(i2, reinterpret_cast<u64x2*>(out_id + dst));
+    __builtin_nontemporal_store(w2, reinterpret_cast<f32x2*>(out_w + dst));
+    __builtin_nontemporal_store(t2, reinterpret_cast<i32x2*>(out_t + dst));
+    if (pr == 0 && out_mask != nullptr) out_mask[i] = m;
+  }
+}
+
 // Back end of a multi-GPU hop: position i takes row pos[i] of the packed
 // answers ((3 + TCOL) * count + 2 int32 words per row: ids, weights, [types],
 // mask, pad; without the type column the types are rebuilt from the mask).
@@ -493,6 +541,8 @@ int g_expand_const_type = 1;   // ... rebuild the type column of single-type cal
 int g_expand_grid_cap = 0;     // ... workgroup cap (0 = kK1GridCap)
 int g_k1_ablate = 0;   // measurement only: skip parts of the blocked kernel
 int g_k1_ilp = 4;      // samples per lane of the ILP kernel (1, 2, 4, 8)
+int g_k1_pair_distinct = 0;   // pass over the distinct roots: two samples per lane (key 22)
+int g_expand_lean = 1;  // last hop, even count: the lean gather-copy kernel (key 21)
 int g_k1_row = 1;       // block-pivot calls without the duplicate path: one lane per ROOT
                         // (k1_row.h) for 4 <= count <= 64; 0 = one lane per sample
 int g_dedup_resolve_in_expand = 0;   // 1 = last hop: the expansion reads its row number from the
@@ -590,12 +640,12 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborPivotKernel(
 // picks which one runs - `a` (the given roots, U samples per lane) or `b` (the
 // distinct roots into scratch rows, one sample per lane).  A gated launch that
 // only exits still costs ~8 us for its 32 768 workgroups.
-template <bool TF_LAYOUT, int U, bool BLOCKED>
+template <bool TF_LAYOUT, int U, bool BLOCKED, int U2 = 1>
 __global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborPivotDualKernel(
     const SampleNbArgs a, const int64_t a_rows, const int32_t a_slots,
     const SampleNbArgs b, const int64_t b_rows, const int32_t b_slots) {
   if (DedupActive(a.dd_counter, a.dd_n_in)) {
-    PivotPass<TF_LAYOUT, 1, BLOCKED>(b, (int64_t)(*a.dd_counter), b_rows, b_slots);
+    PivotPass<TF_LAYOUT, U2, BLOCKED>(b, (int64_t)(*a.dd_counter), b_rows, b_slots);
   } else {
     PivotPass<TF_LAYOUT, U, BLOCKED>(a, a.n, a_rows, a_slots);
   }
@@ -965,10 +1015,25 @@ static bool LaunchK1Dual(const euler_gpu_graph* g, hipStream_t stream,
   const int64_t a_stride = (int64_t)grid * block * U;
   const int64_t a_rows = a_stride / count;
   const int32_t a_slots = (int32_t)(a_stride - a_rows * count);
-  const int64_t b_stride = (int64_t)grid * block;
+  // the pass over the distinct roots: one sample per lane, or (key 22) the two
+  // adjacent samples of a root per lane - one Philox block, root id, row record
+  // and id store per pair; the K1 kernels are bound by instruction issue as much
+  // as by memory (tools/prof_tlb.py: the same roots in row order run no faster)
+  const bool pair2 = pair && g_k1_pair_distinct != 0;
+  const int64_t b_stride = (int64_t)grid * block * (pair2 ? 2 : 1);
   const int64_t b_rows = b_stride / count;
   const int32_t b_slots = (int32_t)(b_stride - b_rows * count);
   const bool tf = a.layout == EULER_GPU_LAYOUT_TF;
+  if (pair2 && blocked) {
+    if (tf) {
+      hipLaunchKernelGGL((SampleNeighborPivotDualKernel<true, 2, true, 2>), dim3(grid), dim3(block),
+                         0, stream, a, a_rows, a_slots, b, b_rows, b_slots);
+    } else {
+      hipLaunchKernelGGL((SampleNeighborPivotDualKernel<false, 2, true, 2>), dim3(grid), dim3(block),
+                         0, stream, a, a_rows, a_slots, b, b_rows, b_slots);
+    }
+    return true;
+  }
 #define EG_DUAL(TF, UU, BL)                                                            \
   hipLaunchKernelGGL((SampleNeighborPivotDualKernel<TF, UU, BL>), dim3(grid), dim3(block), \
                      0, stream, a, a_rows, a_slots, b, b_rows, b_slots)
@@ -1274,8 +1339,23 @@ static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
                   !(layout == EULER_GPU_LAYOUT_TF && g->view.has_zero_nbr != 0);
   x.type0 = k == 1 ? edge_types[0] : 0;
   x.masked_type = layout == EULER_GPU_LAYOUT_TF ? -1 : 0;
-  LaunchExpand(pair ? 2 : 1, g_expand_steps, ct, (int)blocks, block, stream, x,
-               stride_rows, stride_slots);
+  const bool lean = g_expand_lean != 0 && pair && !do_mark && !resolve_in_expand &&
+                    count / 2 <= 128 && (int64_t)n * count < ((int64_t)1 << 31);
+  if (lean) {
+    const uint32_t P = (uint32_t)count / 2;
+    const uint32_t rows_per_block = 256u / P;
+    int64_t lb = ((int64_t)n + rows_per_block - 1) / rows_per_block;
+    if (lb > xcap) lb = xcap;
+    if (lb < 1) lb = 1;
+    auto kern = ct ? DedupExpandLeanKernel<true> : DedupExpandLeanKernel<false>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)lb), dim3(256), 0, stream, x.counter, x.uidx_of, x.t_id,
+                       x.t_w, x.t_t, x.t_mask, out_id, out_w, out_t, out_row_mask, (uint32_t)n,
+                       (uint32_t)count, P, 65536u / P + 1u, rows_per_block, x.type0,
+                       x.masked_type);
+  } else {
+    LaunchExpand(pair ? 2 : 1, g_expand_steps, ct, (int)blocks, block, stream, x,
+                 stride_rows, stride_slots);
+  }
   PhaseMark(stream, 3);
   EG_HIP(hipGetLastError());
   if (hop != nullptr) hop->mark_next = do_mark;
@@ -1414,6 +1494,8 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 18) { g_sum_scalar = value != 0; return EULER_GPU_OK; }
   if (key == 19 && value >= 0 && value <= 2) { g_k1_row = value; return EULER_GPU_OK; }
   if (key == 20) { g_dedup_resolve_in_expand = value != 0; return EULER_GPU_OK; }
+  if (key == 21) { g_expand_lean = value != 0; return EULER_GPU_OK; }
+  if (key == 22) { g_k1_pair_distinct = value != 0; return EULER_GPU_OK; }
   if (key == 1 && (value == 1 || value == 2 || value == 4 || value == 8)) {
     g_k1_ilp = value;
     return EULER_GPU_OK;

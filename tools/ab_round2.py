@@ -67,25 +67,28 @@ def whole(steps=20):
 
 ref = None
 res = {}
-for row in (1, 0):
-    for num in (2, 1):
-        for rix in ((1, 0) if num == 2 else (1,)):
-            L.euler_gpu_set_tuning(19, row)
-            L.euler_gpu_set_tuning(14, num)
-            L.euler_gpu_set_tuning(20, rix)
-            out = G.sample_fanout(roots, [[0], [0]], FAN, N + 1, call_id=0)
-            sig = [int(x.sum().item()) for x in out[0][1:]] + [float(x.double().sum().item()) for x in out[1]]
-            if ref is None:
-                ref = sig
-            assert sig == ref, ("results differ between tunings", sig, ref)
-            phases(2)
-            key = "row=%d numbering=%d resolve_in_expand=%d" % (row, num, rix)
-            res[key] = {"phases_ms": phases(), "ms_per_step": whole()}
-            print(key, json.dumps(res[key]), flush=True)
+# (19 row kernel, 14 numbering, 21 lean expand, 22 pair mode over the distinct roots)
+for row, num, lean, pair2 in ((0, 2, 0, 0), (0, 2, 1, 0), (0, 2, 1, 1), (0, 2, 0, 1), (1, 2, 1, 0), (0, 1, 1, 0)):
+    L.euler_gpu_set_tuning(19, row)
+    L.euler_gpu_set_tuning(14, num)
+    L.euler_gpu_set_tuning(20, 0)
+    L.euler_gpu_set_tuning(21, lean)
+    L.euler_gpu_set_tuning(22, pair2)
+    out = G.sample_fanout(roots, [[0], [0]], FAN, N + 1, call_id=0)
+    sig = [int(x.sum().item()) for x in out[0][1:]] + [float(x.double().sum().item()) for x in out[1]] \
+        + [int(x.sum().item()) for x in out[2]]
+    if ref is None:
+        ref = sig
+    assert sig == ref, ("results differ between tunings", sig, ref)
+    phases(2)
+    key = "row=%d numbering=%d lean_expand=%d pair_distinct=%d" % (row, num, lean, pair2)
+    res[key] = {"phases_ms": phases(), "ms_per_step": whole()}
+    print(key, json.dumps(res[key]), flush=True)
+L.euler_gpu_set_tuning(21, 1); L.euler_gpu_set_tuning(22, 0)
 L.euler_gpu_set_tuning(19, 1); L.euler_gpu_set_tuning(14, 2); L.euler_gpu_set_tuning(20, 0)
 # B = 1024 latency (the batch of the reference's examples)
 small = roots[:1024].contiguous()
-for row in (1, 0):
+for row in (2, 0):
     L.euler_gpu_set_tuning(19, row)
     for _ in range(20):
         G.sample_fanout(small, [[0], [0]], FAN, N + 1, call_id=1)
