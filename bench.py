@@ -62,6 +62,8 @@ def parse():
                          "distinct roots) overlap the bandwidth-bound expansion of the other - "
                          "the reference likewise keeps 8 queries in flight "
                          "(client/query_proxy.cc:205-210)")
+    ap.add_argument("--tuning", default="",
+                    help="A/B only: comma-separated key=value pairs for euler_gpu_set_tuning")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the K-step timed loop is repeated this many times; the line "
                          "reports the median repetition (and lists all)")
@@ -273,6 +275,9 @@ def main():
     import euler_amd
     from euler_amd import _lib
     L = _lib.lib()
+    for kv in filter(None, args.tuning.split(",")):
+        k_, v_ = kv.split("=")
+        _lib.check(L.euler_gpu_set_tuning(int(k_), int(v_)))
 
     t0 = time.time()
     p = euler_amd.synth_params(GRAPH_SEED, args.nodes, args.edges, weighted=True)
@@ -583,6 +588,7 @@ def main():
                                 "in flight" % (world, args.pipeline),
                 "parity_checked_edges": checked,
                 "streams": 1 if sharded else max(1, args.streams),
+                "tuning": args.tuning or None,
                 "one_stream_ms_per_step": (round(float(np.median(one_stream)) / args.steps * 1e3, 4)
                                            if (not sharded and one_stream) else None),
                 "repeats": len(rep_secs),

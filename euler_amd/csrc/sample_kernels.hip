@@ -543,8 +543,10 @@ int g_k1_ablate = 0;   // measurement only: skip parts of the blocked kernel
 int g_k1_ilp = 4;      // samples per lane of the ILP kernel (1, 2, 4, 8)
 int g_k1_pair_distinct = 0;   // pass over the distinct roots: two samples per lane (key 22)
 int g_expand_lean = 1;  // last hop, even count: the lean gather-copy kernel (key 21)
-int g_k1_row = 1;       // block-pivot calls without the duplicate path: one lane per ROOT
-                        // (k1_row.h) for 4 <= count <= 64; 0 = one lane per sample
+int g_k1_row = 0;       // 1 / 2 = block-pivot calls without the duplicate path sample with one
+                        // lane per ROOT (k1_row.h; 1: launches of >= 2^20 samples, 2: all) -
+                        // measured a tie with one lane per sample (56 vs 50 us on the metric's
+                        // first hop), so off by default; parity-tested
 int g_dedup_resolve_in_expand = 0;   // 1 = last hop: the expansion reads its row number from the
                                      // owner table itself (no resolve kernel, no uidx array) -
                                      // measured: dedup 43 -> 28 us, expansion 134 -> 157 us; off

@@ -36,7 +36,7 @@ def k1_variant(request, EA):
     # (6, 2): always run the duplicate-root machinery, whatever the batch size
     _lib.lib().euler_gpu_set_tuning(5, 2 if request.param == (6, 2) else 1)
     yield request.param
-    _lib.lib().euler_gpu_set_tuning(19, 1)
+    _lib.lib().euler_gpu_set_tuning(19, 0)
     _lib.lib().euler_gpu_set_tuning(4, 1)
     _lib.lib().euler_gpu_set_tuning(5, 1)
     _lib.lib().euler_gpu_set_tuning(6, 0)

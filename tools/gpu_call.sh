@@ -1,3 +1,5 @@
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp; mkdir -p gpurun_out
-timeout 400 python tools/ab_round2.py > gpurun_out/c8_ab.log 2>&1; echo "ab rc=$?"; grep -E "^row=|^B1024|Error|error" gpurun_out/c8_ab.log | cut -c1-400
-timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/c8_pytest.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/c8_pytest.log | cut -c1-200
+B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-check"
+for cfg in "--streams 1" "--streams 2" "--streams 3" "--streams 4" "--streams 2 --tuning 3=4096,12=4096" "--streams 3 --tuning 3=4096,12=4096" "--streams 2 --tuning 3=8192,12=8192" "--streams 4 --tuning 3=2048,12=2048" "--streams 2 --tuning 19=1"; do
+  echo "== $cfg"; timeout 200 $B $cfg 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['config']['repeat_ms_per_step'], d['config']['one_stream_ms_per_step'])"
+done
