@@ -62,6 +62,10 @@ struct GraphView {
   int32_t monotone;             // every row's prefix_w is non-decreasing, >= 0
                                 // and NaN-free (true for non-negative weights):
                                 // licence for the single-load search of K1
+  int32_t uniform_w;            // every edge weight is exactly 1.0f (running sums 1, 2, 3, ...
+                                // per row, degrees < 2^24): the draw r = u * span + begin
+                                // lands on edge floor(r) - no search, no sums read
+  int32_t pad_flags;
   int32_t total_in_meta;        // T == 1 and every row's type_prefix[0] has the
                                 // bits of its last running sum (checked on device
                                 // at build): the segment limit comes with the row

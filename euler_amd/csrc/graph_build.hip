@@ -390,6 +390,7 @@ int BuildGraphFromHost(const euler_gpu_host_csr* c, int device,
   int64_t off = 0;
   bool zero_nbr = false;
   bool monotone = true;
+  bool uniform = true;
   for (int64_t i = 0; i < n; ++i) {
     const int64_t r = keep[i];
     row_id[i] = c->row_id[r];
@@ -408,6 +409,7 @@ int BuildGraphFromHost(const euler_gpu_host_csr* c, int device,
         zero_nbr |= c->nbr[b0 + j] == 0;
         const float cur = c->prefix_w[b0 + j];
         monotone &= cur >= prev;           // false for NaN too
+        uniform &= cur == (float)(j + 1) && j + 1 < (1 << 24);
         prev = cur;
       }
     }
@@ -416,6 +418,7 @@ int BuildGraphFromHost(const euler_gpu_host_csr* c, int device,
   v.n_edges = E;
   v.has_zero_nbr = zero_nbr ? 1 : 0;
   v.monotone = monotone ? 1 : 0;
+  v.uniform_w = (uniform && monotone && E > 0) ? 1 : 0;   // (j + 1 is exact in f32 below 2^24)
   v.row_meta = b.Upload(meta.data(), meta.size());
   v.nbr = b.Upload(nbr.data(), nbr.size());
   v.prefix_w = b.Upload(pw.data(), pw.size());
@@ -711,6 +714,7 @@ int BuildGraphSynthetic(const euler_gpu_synth_params* sp, int device,
   b.g->max_id = n_rows > 0 ? base + (uint64_t)(n_rows - 1) * stride : 0;
   v.has_zero_nbr = 0;
   v.monotone = 1;     // weights are >= 0.5: f32 running sums never decrease
+  v.uniform_w = sp->weighted ? 0 : 1;   // unweighted: every weight is 1.0f, sums 1, 2, 3, ...
   SynthView p{};
   p.seed = sp->seed; p.n_nodes = sp->n_nodes; p.scale = sp->scale;
   p.n_types = sp->n_types; p.weighted = sp->weighted;

@@ -74,6 +74,14 @@ __device__ __forceinline__ void PivotSample(const GraphView& g, const Segment& s
     *w = __fsub_rn(nw[m], m == 0 ? 0.f : nw[m - 1]);
     return;
   }
+  if (g.uniform_w) {
+    // H1 (uniform weights, configs[1]): nw[m] = m + 1 exactly, so the first m with
+    // nw[m] > r is floor(r) (r < limit_end was just checked; r >= limit_begin = b)
+    // and the weight nw[m] - nw[m-1] is 1.0f
+    *id = g.nbr[sg.row_ptr + (int64_t)rr];
+    *w = 1.0f;
+    return;
+  }
   // candidate ranges of every level; K = first level with <= 4 of them
   uint32_t l[kPivotLevels + 1], h[kPivotLevels + 1];
   l[1] = (uint32_t)(lo >> 2);
@@ -168,6 +176,14 @@ __device__ __forceinline__ void BlockPivotSample(const GraphView& g, const Segme
     const int32_t m = (int32_t)RandomSelect(nw, (uint64_t)sg.b, (uint64_t)sg.e, u);
     *id = g.nbr[sg.row_ptr + m];
     *w = __fsub_rn(nw[m], m == 0 ? 0.f : nw[m - 1]);
+    return;
+  }
+  if (g.uniform_w) {
+    // H1 (uniform weights, configs[1]): nw[m] = m + 1 exactly, so the first m with
+    // nw[m] > r is floor(r) (r < limit_end was just checked; r >= limit_begin = b)
+    // and the weight nw[m] - nw[m-1] is 1.0f
+    *id = g.nbr[sg.row_ptr + (int64_t)rr];
+    *w = 1.0f;
     return;
   }
   // ranges of the levels, bottom up, only as far as needed: K = first level

@@ -1152,3 +1152,28 @@ def test_fanout_paths_agree_fuzz(EA, O, torch_cuda):
             assert torch.equal(gn[h + 1], ids_h.reshape(-1)), (trial, h, counts, et)
             assert torch.equal(gw[h], w_h.reshape(-1)) and torch.equal(gt[h], t_h.reshape(-1))
             cur, mask, group = ids_h.reshape(-1), m_h, counts[h]
+
+
+def test_uniform_weight_fast_path(EA, O, torch_cuda, k1_variant):
+    """H1: a graph whose weights are all 1.0 (configs[1], ogbn-products-shaped) is
+    sampled without a search - edge floor(u * deg) - and must still equal the
+    reference's CDF inversion bit for bit, for one listed type of a two-type graph
+    and for type draws (which take the reference loop)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(31)
+    ids, seg, nbr, w, nt, nw = make_random_graph(rng, 5000, 2, max_deg=60, id_space=10 ** 9,
+                                                 zero_frac=0.0)
+    w[:] = 1.0
+    csr = O.csr_from_raw(ids, seg, nbr, w, 2, nt, nw)
+    G = gpu_graph(EA, csr)
+    OG = O.OracleGraph(csr)
+    q = np.concatenate([rng.choice(ids, 4000), [0, 77]]).astype(np.int64)
+    qt = torch.as_tensor(q).cuda()
+    G.set_seed(3)
+    for call, (et, count) in enumerate((([0], 25), ([1], 10), ([0, 1], 7), ([], 4))):
+        on, ow, ot = OG.sample_neighbor(3, call, q, et, count, -1)
+        gn, gw, gt = G.sample_neighbor(qt, et, count, -1, call_id=call)
+        assert np.array_equal(t2n(gn), on), et
+        assert np.array_equal(t2n(gw), ow) and np.array_equal(t2n(gt), ot)
+    walk = G.random_walk(qt[:500], [[0]] * 8, 1.0, 1.0, -1, call_id=40)
+    assert np.array_equal(t2n(walk), OG.random_walk(3, 40, q[:500], [[0]] * 8, 8, 1.0, 1.0, -1))
