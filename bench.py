@@ -62,12 +62,20 @@ def parse():
                          "distinct roots) overlap the bandwidth-bound expansion of the other - "
                          "the reference likewise keeps 8 queries in flight "
                          "(client/query_proxy.cc:205-210)")
+    ap.add_argument("--workload", choices=["metric", "products", "hetero", "deepwalk"],
+                    default="metric",
+                    help="metric = BASELINE.json's headline (configs[2]); products = configs[1] "
+                         "(ogbn-products-shaped CSR, uniform SampleNeighbor fanout [25,10]); "
+                         "hetero = configs[4] on one GPU (8 edge types: typed sampling k = 1 / "
+                         "3 of 8 / all + 128-d feature gather + scatter_mean); deepwalk = "
+                         "configs[3] on one GPU (random_walk length 40)")
     ap.add_argument("--tuning", default="",
                     help="A/B only: comma-separated key=value pairs for euler_gpu_set_tuning")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the K-step timed loop is repeated this many times; the line "
                          "reports the median repetition (and lists all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--n2v", action="store_true", help="deepwalk workload: also time node2vec")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--pipeline", type=int, default=3,
                     help="sharded path: minibatches in flight, interleaved hop by hop "
@@ -221,6 +229,235 @@ def cpu_baseline(args):
                          cells[1024]["as_shipped"]["edges_per_s"], cells[1024]["best"]["edges_per_s"])}
 
 
+def latency_small_batch(G, L, _lib, n_nodes, default_node, batch=1024, iters=300, streams=8):
+    """B = 1 024 (the batch of every reference example): microseconds per minibatch of
+    the 2-hop fanout, euler_gpu_sample_fanout called back to back on ONE stream with
+    preallocated outputs (no Python allocation in the loop), and the throughput with
+    `streams` minibatches in flight (the reference keeps 8 queries in flight,
+    client/query_proxy.cc:205-210)."""
+    dev = G.device
+    layers = len(FANOUT)
+    cnt_a = (C.c_int32 * layers)(*FANOUT)
+    et_a = (C.c_int32 * layers)(*([0] * layers))
+    gen = torch.Generator(device=dev); gen.manual_seed(77)
+    roots = torch.randint(1, n_nodes + 1, (64, batch), generator=gen, device=dev, dtype=torch.int64)
+    wsz = int(L.euler_gpu_sample_fanout_workspace(batch, cnt_a, layers))
+
+    def buffers():
+        o_n, o_w, o_t, m = [], [], [], batch
+        for c in FANOUT:
+            m *= c
+            o_n.append(torch.empty(m, dtype=torch.int64, device=dev))
+            o_w.append(torch.empty(m, dtype=torch.float32, device=dev))
+            o_t.append(torch.empty(m, dtype=torch.int32, device=dev))
+        ws = torch.empty(max(wsz, 16), dtype=torch.uint8, device=dev)
+        return (o_n, o_w, o_t, ws, (C.c_void_p * layers)(*[t.data_ptr() for t in o_n]),
+                (C.c_void_p * layers)(*[t.data_ptr() for t in o_w]),
+                (C.c_void_p * layers)(*[t.data_ptr() for t in o_t]))
+
+    def call(bufs, st, i):
+        _lib.check(L.euler_gpu_sample_fanout(
+            G._h, st, GRAPH_SEED, 2 * i, C.c_void_p(roots[i % 64].data_ptr()), batch, et_a, 1,
+            cnt_a, layers, default_node, bufs[4], bufs[5], bufs[6], C.c_void_p(bufs[3].data_ptr())))
+
+    b0 = buffers()
+    st0 = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for i in range(50):
+        call(b0, st0, i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(iters):
+        call(b0, st0, i)
+    torch.cuda.synchronize()
+    one = (time.perf_counter() - t0) / iters
+    side = [torch.cuda.Stream(device=dev) for _ in range(streams)]
+    bufs = [buffers() for _ in range(streams)]
+    sts = [C.c_void_p(s_.cuda_stream) for s_ in side]
+    torch.cuda.synchronize()
+    for i in range(4 * streams):
+        call(bufs[i % streams], sts[i % streams], i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(iters * 2):
+        call(bufs[i % streams], sts[i % streams], i)
+    torch.cuda.synchronize()
+    many = (time.perf_counter() - t0) / (iters * 2)
+    e = batch * (FANOUT[0] + FANOUT[0] * FANOUT[1])
+    return {"latency_B1024_us": round(one * 1e6, 2), "edges_per_s_one_stream": e / one,
+            "us_per_minibatch_%d_streams" % streams: round(many * 1e6, 2),
+            "edges_per_s_%d_streams" % streams: e / many}
+
+
+def _events(fn, iters):
+    """mean milliseconds of fn() over `iters` runs, HIP events on the current stream"""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def run_hetero(args):
+    """configs[4] on one GPU: heterogeneous graph (8 edge types), per-type neighbour
+    sampling with one listed type, 3 of 8 (sub-collection draw) and all 8 (type draw
+    over all groups), each followed by the 128-d feature gather of the sampled block
+    and scatter_mean into the roots (segment reduce, fp32, order-faithful)."""
+    import euler_amd
+    from euler_amd import ops
+    N, T, D, CNT = 20_000_000, 8, 128, 10
+    B = args.batch
+    t0 = time.time()
+    G = euler_amd.Graph.synthetic(euler_amd.synth_params(GRAPH_SEED, N, 20 * N, n_types=T,
+                                                         weighted=True))
+    G.set_seed(GRAPH_SEED)
+    feat = torch.randn(N + 2, D, device="cuda", generator=torch.Generator("cuda").manual_seed(7))
+    torch.cuda.synchronize()
+    build_s = time.time() - t0
+    n_steps = args.steps + args.warmup
+    gen = torch.Generator(device="cuda"); gen.manual_seed(1234)
+    roots = torch.randint(1, N + 1, (n_steps, B), generator=gen, device="cuda", dtype=torch.int64)
+    dst = torch.arange(B, device="cuda", dtype=torch.int32).repeat_interleave(CNT)
+    type_sets = ([3], [1, 4, 6], list(range(T)))
+
+    def step(i):
+        aggs = []
+        for c, et in enumerate(type_sets):
+            nb, _w, _t = G.sample_neighbor(roots[i], et, CNT, N + 1, call_id=3 * i + c)
+            x = ops.gather(feat, nb.reshape(-1).to(torch.int32))
+            aggs.append(ops.scatter_mean(x, dst, B))
+        return aggs
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    reps = []
+    for _rep in range(max(1, args.repeats)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.warmup, n_steps):
+            step(i)
+        torch.cuda.synchronize()
+        reps.append(time.perf_counter() - t0)
+    elapsed = float(np.median(reps))
+    edges = B * CNT * len(type_sets)
+    # phase split of one step + the dominant kernel's roofline (the gather: E rows of
+    # D floats read at random and written in order: 8 E D + 4 E bytes, SURVEY 8(d))
+    r = roots[n_steps - 1]
+    ph = {}
+    for c, et in enumerate(type_sets):
+        ph["sample k=%d" % len(et)] = _events(lambda: G.sample_neighbor(r, et, CNT, N + 1, call_id=c), 10)
+    nb = G.sample_neighbor(r, [3], CNT, N + 1, call_id=0)[0].reshape(-1).to(torch.int32)
+    g_ms = _events(lambda: ops.gather(feat, nb), 10)
+    x = ops.gather(feat, nb)
+    s_ms = _events(lambda: ops.scatter_mean(x, dst, B), 10)
+    E = B * CNT
+    g_bytes = 8.0 * E * D + 4.0 * E
+    s_bytes = 4.0 * E * D + 4.0 * E + 4.0 * B * D
+    line = {
+        "metric": "sampled + aggregated edges/sec, typed SampleNeighbor (k = 1, 3 of 8, all) + 128-d "
+                  "gather + scatter_mean, heterogeneous graph (BASELINE configs[4], 1 GPU)",
+        "value": edges * args.steps / elapsed, "unit": "sampled edges/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 / f32",
+        "data": "synthetic",
+        "config": {"workload": "hetero: %d nodes / %d edges, %d edge types, weighted; %d roots per step, "
+                               "3 typed hops of %d neighbours, features [%d, %d] f32"
+                               % (N, G.num_edges, T, B, CNT, N + 2, D),
+                   "graph_build_s": round(build_s, 2), "repeats": len(reps),
+                   "repeat_ms_per_step": [round(x_ / args.steps * 1e3, 4) for x_ in reps],
+                   "phases_ms": dict({k_: round(v_, 4) for k_, v_ in ph.items()},
+                                     gather=round(g_ms, 4), scatter_mean=round(s_ms, 4))},
+        "roofline": {"kernel": "GatherRowsKernel (MPGather, 16-B lanes)", "bound": "hbm",
+                     "achieved": round(g_bytes / (g_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(g_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "traffic": None, "algorithmic_bytes_per_launch": g_bytes,
+                     "avg_launch_ms": round(g_ms, 4),
+                     "scatter_mean": {"GBps": round(s_bytes / (s_ms * 1e-3) / 1e9, 1),
+                                      "frac": round(s_bytes / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                      "algorithmic_bytes": s_bytes, "ms": round(s_ms, 4)}},
+        "cpu_baseline": None,
+    }
+    print(json.dumps(line), flush=True)
+
+
+def run_deepwalk(args):
+    """configs[3] on one GPU: DeepWalk, random_walk length 40 (p = q = 1) from 1M
+    start nodes of the metric graph; value = walker steps / s.  --n2v also times
+    node2vec (p = 0.25, q = 4) on 100 000 walkers x 10 steps."""
+    import euler_amd
+    from euler_amd import _lib
+    L = _lib.lib()
+    N = args.nodes
+    t0 = time.time()
+    G = euler_amd.Graph.synthetic(euler_amd.synth_params(GRAPH_SEED, N, args.edges, weighted=True))
+    G.set_seed(GRAPH_SEED)
+    torch.cuda.synchronize()
+    build_s = time.time() - t0
+    W, LEN = 1_000_000, 40
+    gen = torch.Generator(device="cuda"); gen.manual_seed(1234)
+    n_steps = args.steps + args.warmup
+    starts = torch.randint(1, N + 1, (n_steps, W), generator=gen, device="cuda", dtype=torch.int64)
+    et = [[0]] * LEN
+    for i in range(args.warmup):
+        G.random_walk(starts[i], et, 1.0, 1.0, N + 1, call_id=LEN * i)
+    torch.cuda.synchronize()
+    reps = []
+    for _rep in range(max(1, args.repeats)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.warmup, n_steps):
+            walks = G.random_walk(starts[i], et, 1.0, 1.0, N + 1, call_id=LEN * i)
+        torch.cuda.synchronize()
+        reps.append(time.perf_counter() - t0)
+    elapsed = float(np.median(reps))
+
+    def walk_bytes(walks_, n, L_, p, q):
+        b = C.c_double(0)
+        et_a = (C.c_int32 * L_)(*([0] * L_))
+        _lib.check(L.euler_gpu_random_walk_algo_bytes(
+            G._h, C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(walks_.data_ptr()),
+            n, et_a, 1, L_, p, q, C.byref(b)))
+        return b.value
+
+    ms = _events(lambda: G.random_walk(starts[n_steps - 1], et, 1.0, 1.0, N + 1, call_id=7), 5)
+    wb = walk_bytes(walks, W, LEN, 1.0, 1.0)
+    n2v = None
+    if args.n2v:
+        W2, L2 = 100_000, 10
+        s2 = starts[0][:W2].contiguous()
+        et2 = [[0]] * L2
+        w2 = G.random_walk(s2, et2, 0.25, 4.0, N + 1, call_id=3)
+        ms2 = _events(lambda: G.random_walk(s2, et2, 0.25, 4.0, N + 1, call_id=3), 2)
+        b2 = walk_bytes(w2, W2, L2, 0.25, 4.0)
+        n2v = {"walkers": W2, "walk_len": L2, "p": 0.25, "q": 4.0, "ms": round(ms2, 3),
+               "steps_per_s": W2 * L2 / (ms2 * 1e-3), "algorithmic_bytes": b2,
+               "GBps": round(b2 / (ms2 * 1e-3) / 1e9, 1),
+               "frac": round(b2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+    line = {
+        "metric": "walker steps/sec, DeepWalk random_walk length 40 (p = q = 1) on the 100M-node "
+                  "power-law graph (BASELINE configs[3], 1 GPU)",
+        "value": W * LEN * args.steps / elapsed, "unit": "walker steps/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "deepwalk: %d walkers x %d steps per step of the bench, graph %d nodes / "
+                               "%d edges, weighted" % (W, LEN, N, G.num_edges),
+                   "graph_build_s": round(build_s, 2), "repeats": len(reps),
+                   "repeat_ms_per_step": [round(x_ / args.steps * 1e3, 4) for x_ in reps],
+                   "node2vec": n2v},
+        "roofline": {"kernel": "RandomWalkKernel", "bound": "hbm",
+                     "achieved": round(wb / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(wb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                     "traffic": None, "algorithmic_bytes_per_launch": wb, "avg_launch_ms": round(ms, 4)},
+        "cpu_baseline": None,
+    }
+    print(json.dumps(line), flush=True)
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` with no launcher around it: start the N ranks
     ourselves (torch.distributed.run, one process per GPU, rendezvous on
@@ -278,9 +515,20 @@ def main():
     for kv in filter(None, args.tuning.split(",")):
         k_, v_ = kv.split("=")
         _lib.check(L.euler_gpu_set_tuning(int(k_), int(v_)))
+    if args.workload in ("hetero", "deepwalk"):
+        assert world == 1, "the secondary workloads are single-GPU lines"
+        (run_hetero if args.workload == "hetero" else run_deepwalk)(args)
+        return
+    weighted = args.workload != "products"
+    if args.workload == "products":
+        # configs[1]: ogbn-products' public shape (2 449 029 nodes, 61 859 140 undirected =
+        # 123 718 280 directed edges), all weights 1.0; `ogb` is not installed and there is
+        # no network: a degree-sequence-matched synthetic graph of that size
+        args.nodes, args.edges = 2_449_029, 123_718_280
+        args.no_cpu_baseline = True
 
     t0 = time.time()
-    p = euler_amd.synth_params(GRAPH_SEED, args.nodes, args.edges, weighted=True)
+    p = euler_amd.synth_params(GRAPH_SEED, args.nodes, args.edges, weighted=weighted)
     G = euler_amd.Graph.synthetic(p, device=local_rank, partitions=world,
                                   shard_index=rank, shards=world)
     G.set_seed(GRAPH_SEED)
@@ -557,14 +805,22 @@ def main():
                     "over the roots each launch processes",
         }
 
+    small = None
+    if rank == 0 and world == 1 and not sharded:
+        try:
+            small = latency_small_batch(G, L, _lib, args.nodes, default_node)
+        except Exception as e:              # a side measurement must not fail the bench
+            small = {"error": str(e)}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
 
     if rank == 0:
         line = {
-            "metric": "sampled edges/sec (whole node), 2-hop fanout=[25,10], "
-                      "100M-node power-law graph",
+            "metric": ("sampled edges/sec (whole node), 2-hop fanout=[25,10], "
+                       "100M-node power-law graph") if args.workload == "metric" else
+                      "sampled edges/sec, uniform SampleNeighbor fanout=[25,10], ogbn-products-shaped "
+                      "CSR in one MI355X's HBM (BASELINE configs[1])",
             "value": value, "unit": "sampled edges/s",
             "n_gpus": min(world, visible),
             "steps": args.steps, "warmup": args.warmup,
@@ -572,12 +828,16 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": "synthetic RMAT-marginal power-law graph, %d nodes / "
-                            "%d edges (min degree 1), f32 weights uniform [0.5,8), "
-                            "weighted CDF-inversion SampleNeighbor, fanout [25,10], "
-                            "%d uniform-random roots per step per GPU, TF dense "
-                            "layout" % (args.nodes, G.num_edges * 1 if world == 1
-                                        else args.edges, B),
+                "workload": ("synthetic RMAT-marginal power-law graph, %d nodes / "
+                             "%d edges (min degree 1), f32 weights uniform [0.5,8), "
+                             "weighted CDF-inversion SampleNeighbor, fanout [25,10], "
+                             "%d uniform-random roots per step per GPU, TF dense "
+                             "layout" if weighted else
+                             "products: synthetic power-law graph with ogbn-products' node / edge "
+                             "counts, %d nodes / %d edges, all weights 1.0 (the draw is edge "
+                             "floor(u * deg): no search), fanout [25,10], %d uniform-random roots "
+                             "per step, TF dense layout") % (args.nodes, G.num_edges * 1 if world == 1
+                                                            else args.edges, B),
                 "roots_per_step_per_gpu": B, "fanout": FANOUT,
                 "graph_bytes_per_gpu": G.device_bytes,
                 "graph_build_s": round(build_s, 2),
@@ -587,6 +847,8 @@ def main():
                                 "hash owner(id)=id%%%d, all-to-all per hop, %d minibatches "
                                 "in flight" % (world, args.pipeline),
                 "parity_checked_edges": checked,
+                "small_batch": small,
+                "latency_B1024_us": (small or {}).get("latency_B1024_us"),
                 "streams": 1 if sharded else max(1, args.streams),
                 "tuning": args.tuning or None,
                 "one_stream_ms_per_step": (round(float(np.median(one_stream)) / args.steps * 1e3, 4)
