@@ -121,6 +121,7 @@ SIGNATURES = {
     "euler_gpu_data_gather": (C.c_int, [vp, vp, C.c_int32, vp, vp, vp, C.c_int64, vp]),
     "euler_gpu_scatter_add": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, C.c_int32, vp]),
     "euler_gpu_scatter_max": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, C.c_int32, vp]),
+    "euler_gpu_scatter_mean": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, C.c_int32, vp]),
     "euler_gpu_gather": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, vp]),
     "euler_gpu_id_split": (C.c_int, [vp, vp, C.c_int64, C.c_int32, C.c_int32, i64p,
                                      vp, vp]),

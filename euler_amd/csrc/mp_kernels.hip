@@ -88,7 +88,11 @@ __device__ __forceinline__ int64_t LowerBound(const int32_t* a, int64_t n,
 // One workgroup row-slot per output row: blockDim = (64, 4): 4 rows per block,
 // 64 lanes over the columns.  keys[] = destination of the p-th update in
 // grouped order; perm[p] = original update index (nullptr = identity).
-template <bool IS_MAX>
+// MODE 0 = add, 1 = max, 2 = mean: the reference's scatter_mean is
+// scatter_add(x) / (scatter_add(ones) + 1e-7) (euler_ops/mp_ops.py:65-69); the
+// count of a destination is its segment length (an exact f32 below 2^24), so the
+// same correctly rounded f32 add and divide give the same bits in one pass.
+template <int MODE>
 __global__ __launch_bounds__(256) void SegmentReduceKernel(
     const float* __restrict__ upd, const int32_t* __restrict__ keys,
     const uint32_t* __restrict__ perm, int64_t e, int64_t d, int32_t size,
@@ -98,6 +102,8 @@ __global__ __launch_bounds__(256) void SegmentReduceKernel(
        r += (int64_t)gridDim.x * blockDim.y) {
     const int64_t b = LowerBound(keys, e, (int32_t)r);
     const int64_t en = LowerBound(keys, e, (int32_t)r + 1);
+    constexpr bool IS_MAX = MODE == 1;
+    const float denom = __fadd_rn((float)(en - b), 1e-7f);
     for (int64_t c = lane; c < d; c += 64) {
       float acc = IS_MAX ? (float)-1e9 : 0.f;   // scatter_op.cc:47,78
       int64_t p = b;
@@ -122,12 +128,12 @@ __global__ __launch_bounds__(256) void SegmentReduceKernel(
         if (IS_MAX) { if (v > acc) acc = v; }
         else acc = __fadd_rn(acc, v);
       }
-      out[r * d + c] = acc;
+      out[r * d + c] = MODE == 2 ? __fdiv_rn(acc, denom) : acc;
     }
   }
 }
 
-template <bool IS_MAX>
+template <int MODE>
 static int ScatterImpl(hipStream_t st, const float* upd, const int32_t* idx,
                        int64_t e, int64_t d, int32_t size, float* out) {
   if (e < 0 || d < 0 || size < 0) return Fail(EULER_GPU_EINVAL, "scatter: bad shape");
@@ -174,7 +180,7 @@ static int ScatterImpl(hipStream_t st, const float* upd, const int32_t* idx,
   const dim3 block(64, 4);
   int64_t blocks = ((int64_t)size + 3) / 4;
   if (blocks > 256 * 32) blocks = 256 * 32;
-  hipLaunchKernelGGL(SegmentReduceKernel<IS_MAX>, dim3((unsigned)blocks), block, 0,
+  hipLaunchKernelGGL(SegmentReduceKernel<MODE>, dim3((unsigned)blocks), block, 0,
                      st, upd, keys, perm, e, d, size, out);
   EG_HIP(hipGetLastError());
   if (scratch) EG_HIP(hipFreeAsync(scratch, st));
@@ -570,15 +576,26 @@ int euler_gpu_gather(void* stream, const float* params_dev,
 int euler_gpu_scatter_add(void* stream, const float* updates_dev,
                           const int32_t* indices_dev, int64_t e, int64_t d,
                           int32_t size, float* out_dev) {
-  return ScatterImpl<false>((hipStream_t)stream, updates_dev, indices_dev, e, d,
-                            size, out_dev);
+  return ScatterImpl<0>((hipStream_t)stream, updates_dev, indices_dev, e, d,
+                        size, out_dev);
+}
+
+int euler_gpu_scatter_mean(void* stream, const float* updates_dev,
+                           const int32_t* indices_dev, int64_t e, int64_t d,
+                           int32_t size, float* out_dev) {
+  if (e >= (1LL << 24)) {
+    // a destination could collect 2^24 or more updates: its f32 count would no longer
+    // be its length - callers compose scatter_add as the reference does
+    return Fail(EULER_GPU_EINVAL, "scatter_mean: e >= 2^24, compose scatter_add instead");
+  }
+  return ScatterImpl<2>((hipStream_t)stream, updates_dev, indices_dev, e, d, size, out_dev);
 }
 
 int euler_gpu_scatter_max(void* stream, const float* updates_dev,
                           const int32_t* indices_dev, int64_t e, int64_t d,
                           int32_t size, float* out_dev) {
-  return ScatterImpl<true>((hipStream_t)stream, updates_dev, indices_dev, e, d,
-                           size, out_dev);
+  return ScatterImpl<1>((hipStream_t)stream, updates_dev, indices_dev, e, d,
+                        size, out_dev);
 }
 
 int euler_gpu_neighbor_post_process(void* stream, int64_t n, int32_t* idx_dev,

@@ -109,8 +109,28 @@ def scatter_max(updates, indices, size):
     return _ScatterMax.apply(updates, indices, int(size))
 
 
+class _ScatterMean(torch.autograd.Function):
+    """scatter_add(x) / (scatter_add(ones) + 1e-7) in one pass (euler_gpu_scatter_mean);
+    the gradient of the composition: grad / (count + 1e-7) gathered back."""
+
+    @staticmethod
+    def forward(ctx, updates, indices, size):
+        ctx.save_for_backward(indices)
+        ctx.size = size
+        return _scatter_raw(lib().euler_gpu_scatter_mean, updates, indices, size)
+
+    @staticmethod
+    def backward(ctx, grad):
+        (indices,) = ctx.saved_tensors
+        ones = torch.ones((indices.numel(), 1), dtype=torch.float32, device=grad.device)
+        count = _scatter_raw(lib().euler_gpu_scatter_add, ones, indices, ctx.size) + 1e-7
+        return _gather_raw(grad / count, indices), None, None
+
+
 def scatter_mean(updates, indices, size):
     """mp_ops.py:65-69."""
+    if updates.shape[0] < (1 << 24):
+        return _ScatterMean.apply(updates, indices, int(size))
     out = scatter_add(updates, indices, size)
     ep = 1e-7
     ones = torch.ones((updates.shape[0], 1), dtype=torch.float32,

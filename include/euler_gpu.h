@@ -557,6 +557,12 @@ int euler_gpu_scatter_add(void* stream, const float* updates_dev,
 int euler_gpu_scatter_max(void* stream, const float* updates_dev,
                           const int32_t* indices_dev, int64_t e, int64_t d,
                           int32_t size, float* out_dev);
+/* scatter_mean of euler_ops/mp_ops.py:65-69 - scatter_add(x) / (scatter_add(ones) +
+ * 1e-7) - in ONE pass over the segments (a destination's count is its segment
+ * length); same bits as the composition.  e < 2^24. */
+int euler_gpu_scatter_mean(void* stream, const float* updates_dev,
+                           const int32_t* indices_dev, int64_t e, int64_t d,
+                           int32_t size, float* out_dev);
 int euler_gpu_gather(void* stream, const float* params_dev,
                      const int32_t* indices_dev, int64_t e, int64_t d,
                      int64_t n_params, float* out_dev);
