@@ -77,6 +77,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--n2v", action="store_true", help="deepwalk workload: also time node2vec")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-small-batch", action="store_true",
+                    help="skip the B = 1 024 latency leg (profiling runs: its 1 000 small "
+                         "launches would share kernel names with the step's)")
     ap.add_argument("--pipeline", type=int, default=3,
                     help="sharded path: minibatches in flight, interleaved hop by hop "
                          "from one host thread (each on its own sampler and HIP "
@@ -782,12 +785,14 @@ def main():
             phases.append(ph)
         achieved = sum(k1_bytes) / (sum(k1_ms) * 1e-3) / 1e9
         traffic = None
+        traffic_hops = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
                 if rec.get("batch") == B and rec.get("nodes") == args.nodes:
                     traffic = rec.get("hbm_bytes_per_launch")
+                    traffic_hops = [rec.get("hbm_bytes_hop1_launch"), rec.get("hbm_bytes_hop2_launch")]
             except Exception:
                 traffic = None
         roofline = {
@@ -795,6 +800,11 @@ def main():
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": traffic,
+            "traffic_per_launch": traffic_hops,
+            "traffic_note": "profiles/pmc_latest.json: (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 per launch "
+                            "of hop 1 / hop 2 (separate rocprofv3 --pmc passes); x2 because every L2 read "
+                            "request is one 128-B line tallied at 64 B - calibrated on known request shapes "
+                            "(tools/ubench_fetch.hip, profiles/r2_pmc_summary.json)",
             "algorithmic_bytes_per_launch": round(sum(k1_bytes) / len(k1_bytes), 1),
             "avg_launch_ms": round(sum(k1_ms) / len(k1_ms), 4),
             "launch_ms": [round(x, 4) for x in k1_ms],
@@ -806,7 +816,7 @@ def main():
         }
 
     small = None
-    if rank == 0 and world == 1 and not sharded:
+    if rank == 0 and world == 1 and not sharded and not args.no_small_batch:
         try:
             small = latency_small_batch(G, L, _lib, args.nodes, default_node)
         except Exception as e:              # a side measurement must not fail the bench

@@ -6,7 +6,7 @@
 tag=${1:-r2}
 R="${GRAFT_REPO_ROOT:-$(pwd)}"
 cd "$R"; export TMPDIR=/tmp; mkdir -p gpurun_out
-CMD="python $R/bench.py --steps 4 --warmup 1 --streams 1 --repeats 1 --no-cpu-baseline --no-check"
+CMD="python $R/bench.py --steps 4 --warmup 1 --streams 1 --repeats 1 --no-cpu-baseline --no-check --no-small-batch"
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_stats -o bench -- $CMD > $R/gpurun_out/${tag}_stats.log 2>&1; echo "stats rc=$?"
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_RDREQ_32B_sum"; do
