@@ -525,13 +525,16 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void ExpandPackedKernel(
 }
 // ---- tuning switches (euler_gpu_set_tuning; declared in k1_args.h) ----
 int g_k1_dedup = 1;     // 0 = never, 1 = automatic for >= 100 000 roots, 2 = always try
-int g_n2v_wave = 1;     // node2vec: 1 = one wave per walker (LDS-staged lists), 0 = one lane
+int g_n2v_wave = 2;     // node2vec: 2 = one wave per walker, the two-cursor walk by the whole wave,
+                        // 1 = one wave per walker, lane 0 walks LDS-staged lists, 0 = one lane
 int g_k1_group = 0;     // block-pivot kernel: five adjacent samples per lane for odd counts
                         // that are a multiple of 5 - measured 8 % SLOWER on the metric's
                         // first hop (it is bound by the dependent-load chain per lane, not
                         // by instruction count), kept selectable
 int g_k1_pair = 1;      // pivot kernel: two adjacent samples per lane when count is even
-int g_k1_grid_cap = 0;  // measurement only: override the workgroup cap of K1
+int g_k1_grid_cap = 4096;   // workgroup cap of the K1 launches (0 = kK1GridCap = 32 768): 16 waves per
+                        // CU leave room for the kernels of another minibatch's stream (two
+                        // streams: -5 % per step; one stream: +2 %)
 int g_k1_fuse_mark = 1; // fanout: a hop's kernels fill the next hop's owner table
 int g_k1_dual = 1;      // duplicate-root call: both gated passes in one launch
 int g_dedup_block_numbering = 2;   // 2 = one pass (workgroups take numbers from the call's counter),
@@ -543,10 +546,11 @@ int g_k1_ablate = 0;   // measurement only: skip parts of the blocked kernel
 int g_k1_ilp = 4;      // samples per lane of the ILP kernel (1, 2, 4, 8)
 int g_k1_pair_distinct = 0;   // pass over the distinct roots: two samples per lane (key 22)
 int g_expand_lean = 1;  // last hop, even count: the lean gather-copy kernel (key 21)
-int g_k1_row = 0;       // 1 / 2 = block-pivot calls without the duplicate path sample with one
-                        // lane per ROOT (k1_row.h; 1: launches of >= 2^20 samples, 2: all) -
-                        // measured a tie with one lane per sample (56 vs 50 us on the metric's
-                        // first hop), so off by default; parity-tested
+int g_k1_row = 1;       // 1 / 2 = block-pivot calls without the duplicate path sample with one
+                        // lane per ROOT (k1_row.h; 1: launches of >= 2^20 samples, 2: all).
+                        // Alone it ties with one lane per sample (56 vs 50 us on the metric's
+                        // first hop); it holds a quarter of the wave slots, though, and with
+                        // two minibatches in flight the step is 3-9 % faster with it
 int g_dedup_resolve_in_expand = 0;   // 1 = last hop: the expansion reads its row number from the
                                      // owner table itself (no resolve kernel, no uidx array) -
                                      // measured: dedup 43 -> 28 us, expansion 134 -> 157 us; off

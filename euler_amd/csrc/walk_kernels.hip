@@ -598,6 +598,142 @@ __device__ __forceinline__ int32_t N2vPhys(const N2vList& L, int32_t j) {
   return 0;
 }
 
+// ------------------------------------------------------------------------
+// node2vec, one wave per walker, the two-cursor walk done by the WHOLE wave
+// (tuning key 7 = 2, default).  BuildWeights (random_walk_op.cc:140-168) moves a
+// parent cursor k forward only: child j is resolved against pn[k] -
+//   cn[j] <  pn[k] : "not a common neighbour", weight / q (or / p), j++
+//   cn[j] == pn[k] : common neighbour, weight kept,            j++, k++
+//   cn[j] >  pn[k] : k++ and look again
+// - so between two moves of k every child compares with the SAME pn[k], and a run
+// of children below it is resolved by all lanes at once (one ballot).  Only a
+// child that is >= pn[k] is an event: the wave then scans pn from k in 64-entry
+// steps for the first entry >= that child (another ballot) and goes on.  On lists
+// in storage order - what the reference's `outV` returns and what this backend's
+// synthetic graphs hold - pn[k] soon sits on a large id and events are rare: the
+// step costs (children + parents) / 64 loads instead of one LDS round trip per
+// entry on lane 0.  Lists that ARE ascending make every child an event; a step
+// whose first chunk resolves fewer than 4 children per event is handed to the
+// lane-0 automaton below (same results, different speed).
+// The running sums stay the reference's sequential f32 adds: a lane-shifting DPP
+// chain (one v_add per entry, see layer_kernels.hip: ChunkChain) that leaves every
+// lane its inclusive sum; pass 1 yields the total, pass 2 stops at the first
+// interval holding r - the index RandomSelect's bisection of those sums returns
+// (its last element when the total is 0).
+// ------------------------------------------------------------------------
+__device__ __forceinline__ float ChunkScan(float carry, float d, int lane) {
+  float dp = lane == 0 ? __fadd_rn(carry, d) : d;
+  float s = dp;
+#pragma unroll
+  for (int row = 0; row < 4; ++row) {
+    if (row > 0) {
+      const float prev = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 16 * row - 1));
+      if (lane == 16 * row) dp = __fadd_rn(prev, d);
+      s = dp;
+    }
+#pragma unroll
+    for (int t = 1; t < 16; ++t)
+      s = __fadd_rn(__int_as_float(__builtin_amdgcn_update_dpp(
+                        0, __float_as_int(s), 0x111 /* row_shr:1 */, 0xf, 0xf, true)),
+                    dp);
+  }
+  return s;          // lane t: carry + d[0] + ... + d[t], added in that order
+}
+
+__device__ __forceinline__ int64_t ReadLane64(int64_t v, int src) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), src);
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+// One step of one walker by the whole wave; returns false when the lists look
+// ascending (the caller then runs the sequential automaton).  *out = sampled id.
+__device__ __forceinline__ bool N2vStepParallel(const WalkArgs& a, const N2vLds& S, int lane,
+                                                int64_t parent, int64_t walker, int32_t step,
+                                                int64_t* out) {
+  const int32_t nc = S.child.total, np = S.parent.total;
+  const float* c_nw = a.g.prefix_w + S.child.row_ptr;
+  const uint64_t* c_nbr = a.g.nbr + S.child.row_ptr;
+  const uint64_t* p_nbr = a.g.nbr + S.parent.row_ptr;
+  float total = 0.f;
+  double r = 0.0;
+  int64_t result = a.default_node;
+  for (int pass = 0; pass < 2; ++pass) {
+    int32_t k = 0;
+    float acc = 0.f;
+    bool found = false;
+    int64_t last_id = 0;
+    for (int32_t j0 = 0; j0 < nc && !found; j0 += 64) {
+      const int32_t j = j0 + lane;
+      const bool live = j < nc;
+      int64_t cid = 0;
+      float w = 0.f;
+      if (live) {
+        const int32_t ph = N2vPhys(S.child, j);
+        cid = (int64_t)c_nbr[ph];
+        w = __fsub_rn(c_nw[ph], ph == 0 ? 0.f : c_nw[ph - 1]);
+      }
+      bool keep = false;
+      unsigned long long todo = __ballot(live);
+      int32_t events = 0;
+      while (todo != 0 && k < np) {
+        const int64_t M = (int64_t)p_nbr[N2vPhys(S.parent, k)];
+        const unsigned long long below = __ballot(live && cid < M);
+        const unsigned long long ev = todo & ~below;
+        if (ev == 0) break;                       // every remaining child is below pn[k]
+        const int f = __ffsll((long long)ev) - 1;
+        const int64_t cf = ReadLane64(cid, f);
+        // first k' >= k with pn[k'] >= cf (the cursor skips the smaller entries)
+        bool eq = false;
+        for (;;) {
+          const int32_t kk = k + lane;
+          int64_t pv = 0;
+          if (kk < np) pv = (int64_t)p_nbr[N2vPhys(S.parent, kk)];
+          const unsigned long long ge = __ballot(kk < np && pv >= cf);
+          if (ge != 0) {
+            const int g = __ffsll((long long)ge) - 1;
+            k += g;
+            eq = ReadLane64(pv, g) == cf;
+            break;
+          }
+          k += 64;
+          if (k >= np) { k = np; break; }
+        }
+        if (eq) { if (lane == f) keep = true; ++k; }
+        // lanes up to and including f are resolved
+        todo &= f == 63 ? 0ull : (~0ull << (f + 1));
+        ++events;
+      }
+      if (pass == 0 && j0 == 0 && nc >= 64 && events > 16) return false;   // ascending lists
+      const float wq = !live ? 0.f
+                             : keep ? w : (cid != parent ? __fdiv_rn(w, a.q) : __fdiv_rn(w, a.p));
+      const float sum = ChunkScan(acc, wq, lane);
+      const int32_t cnt = nc - j0 < 64 ? nc - j0 : 64;
+      if (pass == 1) {
+        float prev = __shfl_up(sum, 1);
+        if (lane == 0) prev = acc;
+        const unsigned long long hit = __ballot(live && (double)prev <= r && r < (double)sum);
+        if (hit != 0) {
+          found = true;
+          result = ReadLane64(cid, __ffsll((long long)hit) - 1);
+        }
+      }
+      acc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sum), cnt - 1));
+      last_id = ReadLane64(cid, cnt - 1);
+    }
+    if (pass == 0) {
+      total = acc;
+      const double u = RngDraw(a.seed, a.call_id + (uint32_t)step, kDomainWalk, (uint64_t)walker, 0);
+      r = ScaleDraw(u, 0.f, total);
+    } else if (!found) {
+      result = last_id;      // total == 0: RandomSelect's fall-through ends on the last element
+    }
+  }
+  *out = result;
+  return true;
+}
+
+template <bool PAR>
 __global__ __launch_bounds__(256) void Node2VecWaveKernel(const WalkArgs a) {
   __shared__ N2vLds lds_all[4];
   N2vLds& S = lds_all[threadIdx.x >> 6];
@@ -622,7 +758,9 @@ __global__ __launch_bounds__(256) void Node2VecWaveKernel(const WalkArgs a) {
       WaveSync();
       const int32_t nc = S.child.total, np = S.parent.total;
       int64_t sample_id = a.default_node;
-      if (nc > 0) {
+      bool done = false;
+      if (PAR && nc > 0) done = N2vStepParallel(a, S, lane, parent, i, s, &sample_id);
+      if (nc > 0 && !done) {
         const float* c_nw = a.g.prefix_w + S.child.row_ptr;
         const uint64_t* c_nbr = a.g.nbr + S.child.row_ptr;
         const uint64_t* p_nbr = a.g.nbr + S.parent.row_ptr;
@@ -999,8 +1137,11 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
                          st, a);
     }
   } else {
-    if (g_n2v_wave != 0) {
-      hipLaunchKernelGGL(Node2VecWaveKernel, dim3(GridFor(n * 64, block)), dim3(block), 0,
+    if (g_n2v_wave == 2) {
+      hipLaunchKernelGGL(Node2VecWaveKernel<true>, dim3(GridFor(n * 64, block)), dim3(block), 0,
+                         st, a);
+    } else if (g_n2v_wave != 0) {
+      hipLaunchKernelGGL(Node2VecWaveKernel<false>, dim3(GridFor(n * 64, block)), dim3(block), 0,
                          st, a);
     } else {
       hipLaunchKernelGGL(Node2VecKernel, dim3(GridFor(n, block)), dim3(block), 0, st, a);

@@ -722,12 +722,16 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  *        lane, 1 = flat arrays / one sample per lane, 0 = always the generic
  *        reference-loop kernel.
  * key 1: samples per lane of variant 2 (1, 2, 4 or 8).
- * key 2, 3: measurement only (ablation mask, workgroup cap).
+ * key 2: measurement only (ablation mask).
+ * key 3: workgroup cap of the sample_neighbor launches (default 4096 = 16 waves per CU:
+ *        the kernels of a second minibatch's stream fit beside them; 0 = 32 768).
  * key 4: variant 5 draws two adjacent samples per lane when count is even (1).
  * key 6: five adjacent samples per lane for odd counts that are a multiple of 5
  *        (default 0: measured slower on the metric's first hop).
- * key 7: node2vec kernel: 1 = one wave per walker, lists staged in LDS [default],
- *        0 = one lane per walker.
+ * key 7: node2vec kernel: 2 = one wave per walker, runs of children below the
+ *        parent cursor resolved by all lanes at once + lane-shifting running sums
+ *        [default]; 1 = one wave per walker, lane 0 walks LDS-staged lists; 0 = one
+ *        lane per walker.
  * key 5: duplicate roots: 0 = never look, 1 = look when a call has >= 100 000
  *        roots [default], 2 = always look.
  * key 8: dense-feature kernel: 16-byte loads when the slots allow it (1).
@@ -757,8 +761,9 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  *        hop of a fanout, calls below 100 000 roots), single listed type,
  *        4 <= count <= 64: 1 = one lane per ROOT (the row's running sums in
  *        registers, samples staged in LDS and written in output order) for launches
- *        of >= 2^20 samples; 2 = for every launch; 0 = one lane per sample [default:
- *        the two designs measure within 10 % of each other on the metric's first hop].
+ *        of >= 2^20 samples [default]; 2 = for every launch; 0 = one lane per sample
+ *        (alone the two designs measure within 10 % of each other on the metric's
+ *        first hop; with two minibatches in flight the row kernel wins).
  * key 21: last hop, even count: the lean expansion kernel (1 [default]).
  * key 22: the pass over the distinct roots draws two samples per lane (default 0:
  *        measured 16 % slower).

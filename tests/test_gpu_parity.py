@@ -36,7 +36,7 @@ def k1_variant(request, EA):
     # (6, 2): always run the duplicate-root machinery, whatever the batch size
     _lib.lib().euler_gpu_set_tuning(5, 2 if request.param == (6, 2) else 1)
     yield request.param
-    _lib.lib().euler_gpu_set_tuning(19, 0)
+    _lib.lib().euler_gpu_set_tuning(19, 1)
     _lib.lib().euler_gpu_set_tuning(4, 1)
     _lib.lib().euler_gpu_set_tuning(5, 1)
     _lib.lib().euler_gpu_set_tuning(6, 0)
@@ -967,8 +967,9 @@ def test_dedup_split_dense_id_table(EA, O, torch_cuda):
                 assert np.all(own[off[s]:off[s + 1]] == s)
 
 
-@pytest.mark.parametrize("wave", [1, 0], ids=["n2v_wave", "n2v_lane"])
-def test_node2vec_long_lists_both_kernels(EA, O, torch_cuda, wave):
+@pytest.mark.parametrize("ascending", [False, True], ids=["storage_order", "ascending_lists"])
+@pytest.mark.parametrize("wave", [2, 1, 0], ids=["n2v_parallel", "n2v_wave", "n2v_lane"])
+def test_node2vec_long_lists_both_kernels(EA, O, torch_cuda, wave, ascending):
     """node2vec steps whose child AND parent lists span several 256-entry LDS
     chunks (hubs of 700-900 neighbours that point at each other), with two
     listed edge types: the wave-per-walker kernel and the lane-per-walker kernel
@@ -993,6 +994,13 @@ def test_node2vec_long_lists_both_kernels(EA, O, torch_cuda, wave):
                                 nbr[b:e])
     w = (rng.random(E) * 3 + 0.1).astype(np.float32)
     w[rng.random(E) < 0.05] = 0
+    if ascending:
+        # neighbour lists sorted by id inside every (node, type) segment: every child is
+        # an event for the parallel kernel, which hands such steps to the lane-0 automaton
+        for x in range(n * T):
+            b, e = seg[x], seg[x + 1]
+            o = np.argsort(nbr[b:e], kind="stable")
+            nbr[b:e], w[b:e] = nbr[b:e][o], w[b:e][o]
     csr = O.csr_from_raw(ids, seg, nbr, w, T)
     G, OG = gpu_graph(EA, csr), O.OracleGraph(csr)
     starts = np.concatenate([rng.choice(ids, 300), ids[hubs], [0, 999]]).astype(np.int64)
@@ -1008,7 +1016,7 @@ def test_node2vec_long_lists_both_kernels(EA, O, torch_cuda, wave):
             want = OG.random_walk(6, 50, starts, et_arr, L, p, q, -1)
             assert np.array_equal(got, want), (p, q)
     finally:
-        _lib.lib().euler_gpu_set_tuning(7, 1)
+        _lib.lib().euler_gpu_set_tuning(7, 2)
 
 
 def test_concurrent_callers_share_a_stream(EA, O, torch_cuda, big_pair):
