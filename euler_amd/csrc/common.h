@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -208,6 +209,10 @@ struct euler_gpu_graph {
   // roots left to SampleNeighborSlowKernel
   mutable std::map<void*, std::pair<void*, size_t>> row_ws;
   mutable std::map<void*, int> row_parity;
+  // the stream of the previous sampling call: a caller that alternates streams keeps
+  // several minibatches in flight, and the launcher then sizes its K1 grids so that the
+  // kernels of two streams fit on the chip together (sample_kernels.hip: ConcurrentCall)
+  mutable std::atomic<void*> last_stream{nullptr};
 };
 
 namespace euler_gpu {

@@ -532,9 +532,10 @@ int g_k1_group = 0;     // block-pivot kernel: five adjacent samples per lane fo
                         // first hop (it is bound by the dependent-load chain per lane, not
                         // by instruction count), kept selectable
 int g_k1_pair = 1;      // pivot kernel: two adjacent samples per lane when count is even
-int g_k1_grid_cap = 4096;   // workgroup cap of the K1 launches (0 = kK1GridCap = 32 768): 16 waves per
-                        // CU leave room for the kernels of another minibatch's stream (two
-                        // streams: -5 % per step; one stream: +2 %)
+int g_k1_grid_cap = -1;  // workgroup cap of the K1 launches: -1 = by concurrency (see ConcurrentCall:
+                        // 4096 = 16 waves per CU when the caller alternates streams, so that the
+                        // kernels of another minibatch fit beside them: two streams -5 % per
+                        // step; else kK1GridCap = 32 768), 0 = always 32 768, > 0 = that many
 int g_k1_fuse_mark = 1; // fanout: a hop's kernels fill the next hop's owner table
 int g_k1_dual = 1;      // duplicate-root call: both gated passes in one launch
 int g_dedup_block_numbering = 2;   // 2 = one pass (workgroups take numbers from the call's counter),
@@ -547,7 +548,8 @@ int g_k1_ilp = 4;      // samples per lane of the ILP kernel (1, 2, 4, 8)
 int g_k1_pair_distinct = 0;   // pass over the distinct roots: two samples per lane (key 22)
 int g_expand_lean = 1;  // last hop, even count: the lean gather-copy kernel (key 21)
 int g_k1_row = 1;       // 1 / 2 = block-pivot calls without the duplicate path sample with one
-                        // lane per ROOT (k1_row.h; 1: launches of >= 2^20 samples, 2: all).
+                        // lane per ROOT (k1_row.h; 1: launches of >= 2^20 samples of a caller
+                        // that alternates streams, 2: all).
                         // Alone it ties with one lane per sample (56 vs 50 us on the metric's
                         // first hop); it holds a quarter of the wave slots, though, and with
                         // two minibatches in flight the step is 3-9 % faster with it
@@ -823,6 +825,22 @@ static int GetRowScratch(const euler_gpu_graph* g, hipStream_t stream, int64_t n
   return EULER_GPU_OK;
 }
 
+// A caller that alternates streams between calls keeps several minibatches in
+// flight (bench.py --streams, the reference's 8 query threads): the K1 launches of
+// such a call take 16 waves per CU instead of all 32 and its first hop uses the row
+// kernel (a quarter of the wave slots), which overlaps the latency-bound phases of one
+// minibatch with the bandwidth-bound expansion of the other.  One stream: full grids.
+thread_local int t_concurrent = -1;      // -1 = not inside a call
+static bool ConcurrentCall(const euler_gpu_graph* g, hipStream_t stream) {
+  void* prev = g->last_stream.exchange((void*)stream);
+  return prev != nullptr && prev != (void*)stream;
+}
+static int64_t K1GridCap() {
+  if (g_k1_grid_cap > 0) return g_k1_grid_cap;
+  if (g_k1_grid_cap == 0) return kK1GridCap;
+  return t_concurrent == 1 ? 4096 : kK1GridCap;
+}
+
 // Kernel selection for one pass over a.n roots (a.dd_role says which pass).
 static int LaunchK1(const euler_gpu_graph* g, hipStream_t stream,
                     const SampleNbArgs& a) {
@@ -838,7 +856,7 @@ static int LaunchK1(const euler_gpu_graph* g, hipStream_t stream,
   int grid;
   {
     int64_t blocks = (n * (int64_t)count + block - 1) / block;
-    const int64_t cap = g_k1_grid_cap > 0 ? g_k1_grid_cap : kK1GridCap;
+    const int64_t cap = K1GridCap();
     if (blocks > cap) blocks = cap;
     grid = (int)(blocks < 1 ? 1 : blocks);
   }
@@ -858,7 +876,7 @@ static int LaunchK1(const euler_gpu_graph* g, hipStream_t stream,
     int gridp = grid;
     if (pair) {
       int64_t blocks = (n * (int64_t)count / 2 + block - 1) / block;
-      const int64_t cap = g_k1_grid_cap > 0 ? g_k1_grid_cap : kK1GridCap;
+      const int64_t cap = K1GridCap();
       if (blocks > cap) blocks = cap;
       gridp = (int)(blocks < 1 ? 1 : blocks);
     }
@@ -870,7 +888,8 @@ static int LaunchK1(const euler_gpu_graph* g, hipStream_t stream,
     // lane's serial work here - 21 us for 1 024 x 25 against 8 - which only pays
     // once the lane-per-sample kernel would need several rounds of waves)
     if (blocked && g_k1_row != 0 && a.dd_role == 0 && a.packed == nullptr && count >= 4 &&
-        count <= kRowMaxCount && (n * (int64_t)count >= kRowMinSamples || g_k1_row == 2) && ((uintptr_t)out_id % 16 == 0) && ((uintptr_t)out_w % 8 == 0) &&
+        count <= kRowMaxCount &&
+        ((n * (int64_t)count >= kRowMinSamples && t_concurrent == 1) || g_k1_row == 2) && ((uintptr_t)out_id % 16 == 0) && ((uintptr_t)out_w % 8 == 0) &&
         ((uintptr_t)out_t % 8 == 0)) {
       // one lane per root, one wave per workgroup; the LDS staging area bounds the
       // waves a CU holds (count 25: 14 KB -> 11), the grid-stride loop does the rest
@@ -910,7 +929,7 @@ static int LaunchK1(const euler_gpu_graph* g, hipStream_t stream,
         a.mark_owner == nullptr && a.packed == nullptr) {
       // odd multiple of 5 (fanout 25): five adjacent samples per lane
       int64_t blocks = (n * (int64_t)count / 5 + block - 1) / block;
-      const int64_t cap = g_k1_grid_cap > 0 ? g_k1_grid_cap : kK1GridCap;
+      const int64_t cap = K1GridCap();
       if (blocks > cap) blocks = cap;
       const int gridg = (int)(blocks < 1 ? 1 : blocks);
       const int64_t gstride = (int64_t)gridg * block * 5;
@@ -1015,7 +1034,7 @@ static bool LaunchK1Dual(const euler_gpu_graph* g, hipStream_t stream,
   const int block = 256;
   const int U = pair ? 2 : 1;
   int64_t blocks = (a.n * (int64_t)count / U + block - 1) / block;
-  const int64_t cap = g_k1_grid_cap > 0 ? g_k1_grid_cap : kK1GridCap;
+  const int64_t cap = K1GridCap();
   if (blocks > cap) blocks = cap;
   const int grid = (int)(blocks < 1 ? 1 : blocks);
   const int64_t a_stride = (int64_t)grid * block * U;
@@ -1148,6 +1167,13 @@ static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
                                 float* out_w, int32_t* out_t,
                                 uint8_t* out_row_mask, int dedup = 1,
                                 HopFusion* hop = nullptr, int32_t* packed_out = nullptr) {
+  struct ConcurrencyScope {      // the outermost call of this thread decides
+    bool own;
+    ConcurrencyScope(const euler_gpu_graph* g_, hipStream_t st_) : own(t_concurrent < 0) {
+      if (own) t_concurrent = (g_ != nullptr && ConcurrentCall(g_, st_)) ? 1 : 0;
+    }
+    ~ConcurrencyScope() { if (own) t_concurrent = -1; }
+  } concurrency_scope(g, stream);
   const bool premarked = hop != nullptr && hop->premarked;
   const bool want_mark = hop != nullptr && hop->mark_next;
   if (hop != nullptr) hop->mark_next = false;
@@ -1419,6 +1445,13 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
                      uint64_t* const* out_id_dev, float* const* out_w_dev,
                      int32_t* const* out_t_dev, void* workspace_dev, hipEvent_t* events,
                      int64_t* uniq_off) {
+  struct FanoutConcurrency {
+    bool own;
+    FanoutConcurrency(const euler_gpu_graph* g_, hipStream_t st_) : own(t_concurrent < 0) {
+      if (own) t_concurrent = ConcurrentCall(g_, st_) ? 1 : 0;
+    }
+    ~FanoutConcurrency() { if (own) t_concurrent = -1; }
+  } fanout_concurrency(g, stream);
   std::lock_guard<std::recursive_mutex> launch_lk(g->launch_mu);
   // size the stream's scratch for the largest hop up front: the owner table a
   // hop fills for its successor must not move in between

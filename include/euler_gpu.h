@@ -723,8 +723,10 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  *        reference-loop kernel.
  * key 1: samples per lane of variant 2 (1, 2, 4 or 8).
  * key 2: measurement only (ablation mask).
- * key 3: workgroup cap of the sample_neighbor launches (default 4096 = 16 waves per CU:
- *        the kernels of a second minibatch's stream fit beside them; 0 = 32 768).
+ * key 3: workgroup cap of the sample_neighbor launches: -1 = by concurrency [default]: a
+ *        caller that alternates streams between calls (several minibatches in flight)
+ *        gets 4096 = 16 waves per CU, so that the kernels of two streams fit on the
+ *        chip together, every other call 32 768; 0 = always 32 768; > 0 = that many.
  * key 4: variant 5 draws two adjacent samples per lane when count is even (1).
  * key 6: five adjacent samples per lane for odd counts that are a multiple of 5
  *        (default 0: measured slower on the metric's first hop).
@@ -761,7 +763,8 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  *        hop of a fanout, calls below 100 000 roots), single listed type,
  *        4 <= count <= 64: 1 = one lane per ROOT (the row's running sums in
  *        registers, samples staged in LDS and written in output order) for launches
- *        of >= 2^20 samples [default]; 2 = for every launch; 0 = one lane per sample
+ *        of >= 2^20 samples of a caller that alternates streams [default]; 2 = for
+ *        every launch; 0 = one lane per sample
  *        (alone the two designs measure within 10 % of each other on the metric's
  *        first hop; with two minibatches in flight the row kernel wins).
  * key 21: last hop, even count: the lean expansion kernel (1 [default]).
