@@ -69,6 +69,7 @@ SIGNATURES = {
                                               f32p, f32p]),
     "InitQueryProxy": (C.c_bool, [C.c_char_p]),
     "euler_gpu_default_graph": (vp, []),
+    "euler_gpu_graph_partitions": (C.c_int32, [vp]),
     "euler_gpu_sample_neighbor": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp,
                                             C.c_int64, vp, C.c_int32, i32p, C.c_int32,
                                             C.c_int32, C.c_int32, C.c_int64, vp, vp,

@@ -181,6 +181,7 @@ struct euler_gpu_graph {
   int32_t n_node_types = 1;
   int64_t bytes = 0;
   uint64_t max_id = 0;          // largest node id of this graph (shard)
+  int32_t partitions = 0;       // euler.meta's partitions_num for a loaded dataset, else 0
   std::vector<void*> allocations;     // every hipMalloc owned by the graph
   std::vector<float> node_weight_sums;
   const int32_t* node_type_dev = nullptr;   // [n_rows] node types; nullptr = all 0

@@ -846,7 +846,9 @@ int euler_gpu_graph_load(const char* data_path, int device, int32_t shard_index,
   euler_gpu_host_csr c{};
   d.Describe(&c);
   // the loader already kept only this shard's partitions
-  return BuildGraphFromHost(&c, device, 1, 0, 1, out);
+  rc = BuildGraphFromHost(&c, device, 1, 0, 1, out);
+  if (rc == EULER_GPU_OK) (*out)->partitions = d.partitions;
+  return rc;
 }
 
 int euler_gpu_dat_open(const char* data_path, int32_t shard_index,
@@ -893,6 +895,7 @@ int32_t euler_gpu_graph_num_float_features(const euler_gpu_graph* g) {
   return g ? g->view.n_float : 0;
 }
 int64_t euler_gpu_graph_bytes(const euler_gpu_graph* g) { return g ? g->bytes : -1; }
+int32_t euler_gpu_graph_partitions(const euler_gpu_graph* g) { return g ? g->partitions : 0; }
 
 int euler_gpu_graph_id_range(const euler_gpu_graph* g, uint64_t* max_id_host,
                              int32_t* identity_host) {

@@ -766,6 +766,17 @@ def gpu_sharded_sampler(graph, partitions=None, group=None, dedup=True, dense_id
     packed: the shard samples straight into wire rows (False = sample, then pack)."""
     from . import ops
 
+    # a dataset's files are kept by file_idx % shards while ids are routed by
+    # (id % partitions) % shards: both must use euler.meta's partitions_num
+    meta_parts = getattr(graph, "partitions", 0)
+    if meta_parts:
+        if partitions is None:
+            partitions = meta_parts
+        elif int(partitions) != int(meta_parts):
+            raise ValueError("gpu_sharded_sampler: partitions = %d but the dataset was written with "
+                             "partitions_num = %d (ids would be routed to ranks that do not hold "
+                             "their rows)" % (int(partitions), meta_parts))
+
     def local_sample(owned, edge_types, count, default_node, call_id):
         ids, w, t, mask = graph.sample_neighbor(owned, edge_types, count,
                                                 default_node, layout="tf",

@@ -202,6 +202,12 @@ class Graph:
         return lib().euler_gpu_graph_num_node_types(self._h)
 
     @property
+    def partitions(self):
+        """euler.meta's partitions_num for a graph loaded from a data directory (0
+        otherwise): the `partitions` a sharded sampler must route ids with."""
+        return int(lib().euler_gpu_graph_partitions(self._h))
+
+    @property
     def device_bytes(self):
         return lib().euler_gpu_graph_bytes(self._h)
 

@@ -157,6 +157,12 @@ int32_t euler_gpu_graph_num_node_types(const euler_gpu_graph* g);
 int euler_gpu_graph_device(const euler_gpu_graph* g);
 /* Total device bytes held by the graph. */
 int64_t euler_gpu_graph_bytes(const euler_gpu_graph* g);
+/* euler.meta's partitions_num of a graph loaded with euler_gpu_graph_load (0 for a
+ * graph built from arrays): a multi-GPU sampler must route ids with
+ * owner(id) = (id % partitions) % shards using THIS value, because the loader kept
+ * the partition files with file_idx % shards == shard_index
+ * (core/graph/graph.cc:90-98). */
+int32_t euler_gpu_graph_partitions(const euler_gpu_graph* g);
 /* Per node type weight sums (Graph::GetNodeWeightSums, used by
  * SAMPLE_NODE_SPLIT); out_host has n_node_types floats. */
 int euler_gpu_graph_node_weight_sums(const euler_gpu_graph* g, float* out_host);

@@ -419,6 +419,7 @@ def test_op_registry_and_dat_loader(EA, O, torch_cuda, fixture_csr, tmp_path):
     write_dat_dir(tmp_path, fixture_csr, partitions=2)
     G2 = EA.Graph.load(str(tmp_path))
     assert G2.num_nodes == 6 and G2.num_edges == 12
+    assert G2.partitions == 2 and G.partitions == 0       # euler.meta's partitions_num
     rp, te, nb, pw, tp = G2.export_rows(fixture_csr.row_id)
     assert np.array_equal(nb, fixture_csr.nbr) and np.array_equal(pw, fixture_csr.prefix_w)
     assert np.array_equal(te, fixture_csr.type_end) and np.array_equal(tp, fixture_csr.type_prefix)
