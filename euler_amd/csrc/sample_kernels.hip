@@ -545,6 +545,7 @@ int g_expand_const_type = 1;   // ... rebuild the type column of single-type cal
 int g_expand_grid_cap = 0;     // ... workgroup cap (0 = kK1GridCap)
 int g_k1_ablate = 0;   // measurement only: skip parts of the blocked kernel
 int g_k1_ilp = 4;      // samples per lane of the ILP kernel (1, 2, 4, 8)
+int g_fanout_fused = 1;       // small 2-hop single-type fanouts as one launch (key 23)
 int g_k1_pair_distinct = 0;   // pass over the distinct roots: two samples per lane (key 22)
 int g_expand_lean = 1;  // last hop, even count: the lean gather-copy kernel (key 21)
 int g_k1_row = 1;       // 1 / 2 = block-pivot calls without the duplicate path sample with one
@@ -1394,6 +1395,79 @@ static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
   return EULER_GPU_OK;
 }
 
+// ------------------------------------------------------------------------
+// Small 2-hop fanouts in ONE launch (tuning key 23).  The batch of every reference
+// example is 1 024 roots: hop 1 is 25 600 samples, hop 2 256 000 - too few for
+// the duplicate-root path, so the step was two latency-bound launches and a
+// boundary, 26 us.  Hop 2's roots of batch root r are r's own hop-1 samples, so a
+// workgroup that owns root r needs nothing from any other workgroup: it draws
+// r's c1 samples (lanes 0 .. c1-1), keeps them in LDS, and its 256 lanes then
+// draw the c1 * c2 second-hop samples - one launch, no global round trip between
+// the hops.  Same draws as the chained kernels: hop h uses call_id + h, a hop-1
+// row without samples hands node id 0 to hop 2 (sample_fanout_op.cc:37-42 over
+// the core tensors' sentinel).  Single listed type per hop, block-pivot graphs.
+// ------------------------------------------------------------------------
+struct Fanout2Args {
+  GraphView g;
+  uint64_t seed;
+  uint32_t call_id;
+  const uint64_t* roots;
+  int64_t n;
+  int64_t default_node;
+  int32_t c1, c2, t1, t2;
+  uint64_t* id1; float* w1; int32_t* ty1; uint8_t* mask0;
+  uint64_t* id2; float* w2; int32_t* ty2; uint8_t* mask1;
+};
+
+__global__ __launch_bounds__(256) void SampleFanout2Kernel(const Fanout2Args a) {
+  __shared__ uint64_t s_id[256];
+  __shared__ int32_t s_valid;
+  for (int64_t r = blockIdx.x; r < a.n; r += gridDim.x) {
+    const int32_t j = threadIdx.x;
+    if (j < a.c1) {
+      const uint64_t node = a.roots[r];
+      Segment sg;
+      const bool valid = LoadSegment<true>(a.g, FindRow(a.g, node), a.t1, &sg);
+      uint64_t id = (uint64_t)a.default_node;
+      float w = 0.f;
+      if (valid) {
+        const Philox4 pb = RngBlock(a.seed, a.call_id, kDomainNeighbor, node, ((uint32_t)j) >> 1);
+        const double u = (j & 1) ? UnitFromWords(pb.w[2], pb.w[3]) : UnitFromWords(pb.w[0], pb.w[1]);
+        BlockPivotSample(a.g, sg, u, &id, &w);
+      }
+      const int64_t d = r * a.c1 + j;
+      a.id1[d] = id;
+      a.w1[d] = w;
+      a.ty1[d] = valid ? a.t1 : -1;
+      s_id[j] = valid ? id : 0;             // a missing row samples as node id 0 downstream
+      if (j == 0) { s_valid = valid ? 1 : 0; a.mask0[r] = valid ? 0 : 1; }
+    }
+    __syncthreads();
+    const int32_t tasks = a.c1 * a.c2;
+    for (int32_t tk = threadIdx.x; tk < tasks; tk += 256) {
+      const int32_t q = tk / a.c2;
+      const int32_t x = tk - q * a.c2;
+      const uint64_t node = s_id[q];
+      Segment sg;
+      const bool valid = LoadSegment<true>(a.g, FindRow(a.g, node), a.t2, &sg);
+      uint64_t id = (uint64_t)a.default_node;
+      float w = 0.f;
+      if (valid) {
+        const Philox4 pb = RngBlock(a.seed, a.call_id + 1u, kDomainNeighbor, node, ((uint32_t)x) >> 1);
+        const double u = (x & 1) ? UnitFromWords(pb.w[2], pb.w[3]) : UnitFromWords(pb.w[0], pb.w[1]);
+        BlockPivotSample(a.g, sg, u, &id, &w);
+      }
+      const int64_t row = r * a.c1 + q;
+      const int64_t d = row * a.c2 + x;
+      a.id2[d] = id;
+      a.w2[d] = w;
+      a.ty2[d] = valid ? a.t2 : -1;
+      if (x == 0) a.mask1[row] = valid ? 0 : 1;
+    }
+    __syncthreads();            // s_id is rewritten by the next root
+  }
+}
+
 // TF-layout sampling of the first *n_dev roots of a worst-case-sized list (the
 // count lives on the device: block construction chains hops without telling the
 // host how many distinct nodes a hop produced).  The pass-2 gate of the
@@ -1473,6 +1547,30 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
       if (rc != EULER_GPU_OK) return rc;
     }
   }
+  // a small 2-hop fanout of single listed types: one launch (SampleFanout2Kernel)
+  if (g_fanout_fused != 0 && events == nullptr && layers == 2 && k == 1 && n > 0 &&
+      g_k1_variant == 6 && g->view.monotone && g->view.has_zero_nbr == 0 &&
+      counts_host[0] > 0 && counts_host[0] <= 256 && counts_host[1] > 0 &&
+      !WantsDedup(g, n * counts_host[0], 1) && !WantsDedup(g, n, 1)) {
+    if (g->view.blk == nullptr) {
+      const int rc0 = EnsureBlockedIndex(g);
+      if (rc0 != EULER_GPU_OK) return rc0;
+    }
+    Fanout2Args f{};
+    f.g = g->view; f.seed = seed; f.call_id = call_id; f.roots = roots_dev; f.n = n;
+    f.default_node = default_node;
+    f.c1 = counts_host[0]; f.c2 = counts_host[1];
+    f.t1 = edge_types_host[0]; f.t2 = edge_types_host[1];
+    uint8_t* wsb = (uint8_t*)workspace_dev;
+    f.id1 = out_id_dev[0]; f.w1 = out_w_dev[0]; f.ty1 = out_t_dev[0]; f.mask0 = wsb;
+    f.id2 = out_id_dev[1]; f.w2 = out_w_dev[1]; f.ty2 = out_t_dev[1];
+    f.mask1 = wsb + (((size_t)n + 15) & ~(size_t)15);
+    int64_t blocks = n < 256 * 16 ? n : 256 * 16;
+    hipLaunchKernelGGL(SampleFanout2Kernel, dim3((unsigned)blocks), dim3(256), 0, stream, f);
+    EG_HIP(hipGetLastError());
+    if (uniq_off != nullptr) { uniq_off[0] = -1; uniq_off[1] = -1; }
+    return EULER_GPU_OK;
+  }
   const uint64_t* roots = roots_dev;
   const uint8_t* mask = nullptr;
   int32_t group = 1;
@@ -1535,6 +1633,7 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 20) { g_dedup_resolve_in_expand = value != 0; return EULER_GPU_OK; }
   if (key == 21) { g_expand_lean = value != 0; return EULER_GPU_OK; }
   if (key == 22) { g_k1_pair_distinct = value != 0; return EULER_GPU_OK; }
+  if (key == 23) { g_fanout_fused = value != 0; return EULER_GPU_OK; }
   if (key == 1 && (value == 1 || value == 2 || value == 4 || value == 8)) {
     g_k1_ilp = value;
     return EULER_GPU_OK;

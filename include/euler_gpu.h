@@ -776,6 +776,10 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  * key 21: last hop, even count: the lean expansion kernel (1 [default]).
  * key 22: the pass over the distinct roots draws two samples per lane (default 0:
  *        measured 16 % slower).
+ * key 23: a 2-hop fanout of single listed types below the duplicate-root threshold
+ *        (the reference examples' batch of 1 024) runs as ONE launch: a workgroup
+ *        draws a root's first-hop samples and, from LDS, their second-hop samples
+ *        (1 [default]); 0 = one launch per hop.
  * key 20: last hop of a fanout with key 14 = 2: 1 = the expansion reads every
  *        position's row number from the owner table itself; 0 = a separate resolve
  *        kernel fills an index array first [default: measured 9 us faster].

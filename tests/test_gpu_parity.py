@@ -1186,3 +1186,32 @@ def test_uniform_weight_fast_path(EA, O, torch_cuda, k1_variant):
         assert np.array_equal(t2n(gw), ow) and np.array_equal(t2n(gt), ot)
     walk = G.random_walk(qt[:500], [[0]] * 8, 1.0, 1.0, -1, call_id=40)
     assert np.array_equal(t2n(walk), OG.random_walk(3, 40, q[:500], [[0]] * 8, 8, 1.0, 1.0, -1))
+
+
+def test_small_fanout_in_one_launch(EA, O, torch_cuda, big_pair):
+    """Tuning key 23: a 2-hop fanout of single listed types below the duplicate-root
+    threshold runs as ONE launch (a workgroup draws a root's first-hop samples and,
+    from LDS, their second-hop samples).  Same ids / weights / types as one launch
+    per hop and as the oracle - including unknown roots, rows without the listed
+    type, counts that are odd, larger than the block and equal to 1."""
+    torch = torch_cuda
+    from euler_amd import _lib
+    G, OG, ids, rng = big_pair
+    q = np.concatenate([rng.choice(ids, 700), [0, 4242, 2 ** 62]]).astype(np.int64)
+    qt = torch.as_tensor(q).cuda()
+    G.set_seed(19)
+    try:
+        for et, counts in (([[0], [1]], [25, 10]), ([[3], [3]], [7, 40]), ([[2], [0]], [1, 1]),
+                           ([[1], [9]], [5, 3]), ([[0], [2]], [256, 2])):
+            on, ow, ot = OG.sample_fanout(19, 77, q, et, counts, -5)
+            res = []
+            for fused in (1, 0):
+                _lib.lib().euler_gpu_set_tuning(23, fused)
+                res.append(G.sample_fanout(qt, et, counts, -5, call_id=77))
+            for h in range(2):
+                assert np.array_equal(t2n(res[0][0][h + 1]), on[h]), (et, counts, h)
+                assert np.array_equal(t2n(res[0][1][h]), ow[h]) and np.array_equal(t2n(res[0][2][h]), ot[h])
+                assert torch.equal(res[0][0][h + 1], res[1][0][h + 1])
+                assert torch.equal(res[0][1][h], res[1][1][h]) and torch.equal(res[0][2][h], res[1][2][h])
+    finally:
+        _lib.lib().euler_gpu_set_tuning(23, 1)
