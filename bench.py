@@ -881,6 +881,13 @@ def main():
             },
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        # RCCL prints its version banner through C stdio (fully buffered when stdout is
+        # not a terminal, i.e. flushed at exit - AFTER this line): flush it first so that
+        # the JSON stays the last line of the output
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(line), flush=True)
     if sharded:
         dist.barrier()
