@@ -211,9 +211,17 @@ static int ScatterImpl(hipStream_t st, const float* upd, const int32_t* idx,
   if (size == 0 || d == 0) return EULER_GPU_OK;
   if (!out || (e > 0 && (!upd || !idx)))
     return Fail(EULER_GPU_EINVAL, "scatter: null buffer");
+  if (e >= (1LL << 31)) return Fail(EULER_GPU_EINVAL, "scatter: e >= 2^31");
   const int32_t* keys = idx;
   const uint32_t* perm = nullptr;
-  void* scratch = nullptr;
+  // stream-ordered scratch of the unsorted path, released on every exit
+  struct Scratch {
+    hipStream_t st;
+    void* p = nullptr;
+    explicit Scratch(hipStream_t s) : st(s) {}
+    ~Scratch() { if (p) (void)hipFreeAsync(p, st); }
+  } sc(st);
+  void*& scratch = sc.p;
   if (e > 1) {
     int32_t* flag = nullptr;
     EG_HIP(hipMallocAsync((void**)&flag, 16, st));
@@ -264,7 +272,6 @@ static int ScatterImpl(hipStream_t st, const float* upd, const int32_t* idx,
                        st, upd, keys, perm, e, d, size, out);
   }
   EG_HIP(hipGetLastError());
-  if (scratch) EG_HIP(hipFreeAsync(scratch, st));
   return EULER_GPU_OK;
 }
 
