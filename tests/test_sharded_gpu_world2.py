@@ -268,3 +268,21 @@ def test_sharded_hip_pieces_world_gt1_on_one_gpu(torch_cuda, tmp_path, world, pa
         elif p.exitcode not in (0, None):
             errs.append("rank %d exit code %s" % (r, p.exitcode))
     assert not errs, "\n".join(errs)
+
+
+def test_cpp_multi_gpu_host_over_rccl(torch_cuda):
+    """examples/cpp/sharded_fanout: a C++ host (no Python, no torch) with one thread per
+    GPU, euler_gpu_transport_rccl (ncclSend / ncclRecv groups, resolved at run time) and
+    euler_gpu_sharded_sample_fanout; it compares every rank's result with the unsharded
+    graph itself.  One GPU here, so one rank: the exchanges are self sends through RCCL -
+    the code path an 8-GPU node runs with N = 8."""
+    import subprocess
+    exe = os.path.join(ROOT, "examples", "cpp", "sharded_fanout")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "examples", "cpp")])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run([exe, "1", "300000", "2048"], capture_output=True, text=True, timeout=600,
+                         env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "sharded_fanout OK: 1 rank(s)" in out.stdout, out.stdout + out.stderr
