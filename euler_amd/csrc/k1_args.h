@@ -109,8 +109,11 @@ __host__ __device__ __forceinline__ int32_t PackedWords(int32_t count, int32_t t
 }
 
 // ---- tuning switches (euler_gpu_set_tuning; defined in sample_kernels.hip) ----
+// thread_local: a knob set by one host thread changes the launches THAT thread
+// enqueues and nobody else's (the reference's client pool runs 8 query threads
+// side by side; tests toggle variants in-process)
 constexpr int64_t kK1GridCap = 32768;
-extern int g_k1_variant, g_k1_ilp, g_k1_ablate, g_k1_grid_cap, g_k1_pair, g_k1_group,
+extern thread_local int g_k1_variant, g_k1_ilp, g_k1_ablate, g_k1_grid_cap, g_k1_pair, g_k1_group,
     g_k1_dedup, g_k1_fuse_mark, g_k1_dual, g_expand_steps, g_expand_const_type,
     g_expand_grid_cap, g_n2v_wave, g_dedup_block_numbering, g_k1_row,
     g_dedup_resolve_in_expand, g_expand_lean, g_k1_pair_distinct, g_fanout_fused;

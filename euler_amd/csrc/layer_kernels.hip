@@ -34,7 +34,7 @@ namespace euler_gpu {
 // for the host: ~8 ns per element + ~0.35 ms for two copies and a sync; 0.8 ms
 // for that row) and keep the draws on the device.
 // 1 = choose by that cost model [default], 0 = always the device, 2 = always the host.
-int g_root_host_batch = 1;
+thread_local int g_root_host_batch = 1;
 
 static bool RootTablesOnHost(int64_t batch, int32_t n) {
   if (g_root_host_batch != 1) return g_root_host_batch == 2;
@@ -43,14 +43,14 @@ static bool RootTablesOnHost(int64_t batch, int32_t n) {
   return host_us < dev_us;
 }
 // key 16: SparseGetAdj mask by the direct scan (1) instead of the LDS hash (0).
-int g_adj_scan = 0;
+thread_local int g_adj_scan = 0;
 // key 17: SparseGetAdj: sources with more listed edges than this are split over
 // workgroups by AdjLongRowsKernel (tests lower it to reach that path on small graphs).
-int g_adj_long_row = 16384;
+thread_local int g_adj_long_row = 16384;
 // key 18: long-row weight sums: 0 = 64 lanes load, lane-shifting DPP chain [default];
 // 1 = scalar loads + a wave-uniform add chain (measured 2x slower: 11.9 vs 5.6 ms on
 // the 4096 heaviest rows - the s_loads are not overlapped with the chain).
-int g_sum_scalar = 0;
+thread_local int g_sum_scalar = 0;
 
 int ExclusiveScanI64(hipStream_t stream, const int64_t* in, int64_t* out,
                      int64_t n);   // mp_kernels.hip

@@ -814,7 +814,7 @@ int euler_gpu_neighbor_to_dense(void* stream, int64_t n, const int32_t* idx_dev,
   return EULER_GPU_OK;
 }
 
-int g_feature_vec4 = 1;   // euler_gpu_set_tuning key 8
+thread_local int g_feature_vec4 = 1;   // euler_gpu_set_tuning key 8
 
 // 16-byte lanes: dim % 4 == 0, fixed-stride table whose rows and slots start on
 // 16-byte boundaries (feat_uniform, stride % 4 == 0, slot begin % 4 == 0).

@@ -14,8 +14,8 @@
 #include "k1_search.h"
 #include "k1_row.h"
 
-extern "C" int g_feature_vec4;   // mp_kernels.hip
-namespace euler_gpu { extern int g_root_host_batch, g_adj_scan, g_adj_long_row, g_sum_scalar; }   // layer_kernels.hip
+extern thread_local int g_feature_vec4;   // mp_kernels.hip
+namespace euler_gpu { extern thread_local int g_root_host_batch, g_adj_scan, g_adj_long_row, g_sum_scalar; }   // layer_kernels.hip
 
 namespace euler_gpu {
 
@@ -524,40 +524,40 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void ExpandPackedKernel(
   }
 }
 // ---- tuning switches (euler_gpu_set_tuning; declared in k1_args.h) ----
-int g_k1_dedup = 1;     // 0 = never, 1 = automatic for >= 100 000 roots, 2 = always try
-int g_n2v_wave = 2;     // node2vec: 2 = one wave per walker, the two-cursor walk by the whole wave,
+thread_local int g_k1_dedup = 1;     // 0 = never, 1 = automatic for >= 100 000 roots, 2 = always try
+thread_local int g_n2v_wave = 2;     // node2vec: 2 = one wave per walker, the two-cursor walk by the whole wave,
                         // 1 = one wave per walker, lane 0 walks LDS-staged lists, 0 = one lane
-int g_k1_group = 0;     // block-pivot kernel: five adjacent samples per lane for odd counts
+thread_local int g_k1_group = 0;     // block-pivot kernel: five adjacent samples per lane for odd counts
                         // that are a multiple of 5 - measured 8 % SLOWER on the metric's
                         // first hop (it is bound by the dependent-load chain per lane, not
                         // by instruction count), kept selectable
-int g_k1_pair = 1;      // pivot kernel: two adjacent samples per lane when count is even
-int g_k1_grid_cap = -1;  // workgroup cap of the K1 launches: -1 = by concurrency (see ConcurrentCall:
+thread_local int g_k1_pair = 1;      // pivot kernel: two adjacent samples per lane when count is even
+thread_local int g_k1_grid_cap = -1;  // workgroup cap of the K1 launches: -1 = by concurrency (see ConcurrentCall:
                         // 4096 = 16 waves per CU when the caller alternates streams, so that the
                         // kernels of another minibatch fit beside them: two streams -5 % per
                         // step; else kK1GridCap = 32 768), 0 = always 32 768, > 0 = that many
-int g_k1_fuse_mark = 1; // fanout: a hop's kernels fill the next hop's owner table
-int g_k1_dual = 1;      // duplicate-root call: both gated passes in one launch
-int g_dedup_block_numbering = 2;   // 2 = one pass (workgroups take numbers from the call's counter),
+thread_local int g_k1_fuse_mark = 1; // fanout: a hop's kernels fill the next hop's owner table
+thread_local int g_k1_dual = 1;      // duplicate-root call: both gated passes in one launch
+thread_local int g_dedup_block_numbering = 2;   // 2 = one pass (workgroups take numbers from the call's counter),
                                    // 1 = per-workgroup counts + one small scan, 0 = device-wide scan
-int g_expand_steps = 2;        // DedupExpandKernel: grid-stride steps in flight per lane (1, 2, 4)
-int g_expand_const_type = 1;   // ... rebuild the type column of single-type calls from the mask
-int g_expand_grid_cap = 0;     // ... workgroup cap (0 = kK1GridCap)
-int g_k1_ablate = 0;   // measurement only: skip parts of the blocked kernel
-int g_k1_ilp = 4;      // samples per lane of the ILP kernel (1, 2, 4, 8)
-int g_fanout_fused = 1;       // small 2-hop single-type fanouts as one launch (key 23)
-int g_k1_pair_distinct = 0;   // pass over the distinct roots: two samples per lane (key 22)
-int g_expand_lean = 1;  // last hop, even count: the lean gather-copy kernel (key 21)
-int g_k1_row = 1;       // 1 / 2 = block-pivot calls without the duplicate path sample with one
+thread_local int g_expand_steps = 2;        // DedupExpandKernel: grid-stride steps in flight per lane (1, 2, 4)
+thread_local int g_expand_const_type = 1;   // ... rebuild the type column of single-type calls from the mask
+thread_local int g_expand_grid_cap = 0;     // ... workgroup cap (0 = kK1GridCap)
+thread_local int g_k1_ablate = 0;   // measurement only: skip parts of the blocked kernel
+thread_local int g_k1_ilp = 4;      // samples per lane of the ILP kernel (1, 2, 4, 8)
+thread_local int g_fanout_fused = 1;       // small 2-hop single-type fanouts as one launch (key 23)
+thread_local int g_k1_pair_distinct = 0;   // pass over the distinct roots: two samples per lane (key 22)
+thread_local int g_expand_lean = 1;  // last hop, even count: the lean gather-copy kernel (key 21)
+thread_local int g_k1_row = 1;       // 1 / 2 = block-pivot calls without the duplicate path sample with one
                         // lane per ROOT (k1_row.h; 1: launches of >= 2^20 samples of a caller
                         // that alternates streams, 2: all).
                         // Alone it ties with one lane per sample (56 vs 50 us on the metric's
                         // first hop); it holds a quarter of the wave slots, though, and with
                         // two minibatches in flight the step is 3-9 % faster with it
-int g_dedup_resolve_in_expand = 0;   // 1 = last hop: the expansion reads its row number from the
+thread_local int g_dedup_resolve_in_expand = 0;   // 1 = last hop: the expansion reads its row number from the
                                      // owner table itself (no resolve kernel, no uidx array) -
                                      // measured: dedup 43 -> 28 us, expansion 134 -> 157 us; off
-int g_k1_variant = 6;   // 6 = block pivots, 5 = pivot levels, 4 = wave-staged (count >= 8) else blocked,
+thread_local int g_k1_variant = 6;   // 6 = block pivots, 5 = pivot levels, 4 = wave-staged (count >= 8) else blocked,
                         // 3 = blocked index,
                         // 2 = ILP, 1 = fast path, 0 = generic
 

@@ -784,7 +784,9 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  *        position's row number from the owner table itself; 0 = a separate resolve
  *        kernel fills an index array first [default: measured 9 us faster].
  * All settings produce identical results; the knobs exist for A/B measurements
- * and tests. */
+ * and tests.  They are THREAD-LOCAL: a call changes the launches the calling host
+ * thread enqueues afterwards and nobody else's (new threads start from the
+ * defaults), so concurrent query threads cannot disturb one another. */
 int euler_gpu_set_tuning(int32_t key, int32_t value);
 
 /* ---- measurement helper -------------------------------------------------------
