@@ -679,6 +679,17 @@ def main():
         need = np.unique(np.concatenate([r0, hop1.reshape(-1)])).astype(np.uint64)
         need = need[need <= args.nodes]
         rp, te, nb, pw, tp = G.export_rows(need)
+        # the rows in HBM are the rows the HOST generator (oracle/eo_synth.c) produces for
+        # these ids - a generator fault at full size cannot hide behind "oracle fed with
+        # exported rows"
+        po = O.SynthParams()
+        for f_, _t in po._fields_:
+            setattr(po, f_, getattr(p, f_))
+        for j_ in np.random.default_rng(1).choice(len(need), min(256, len(need)), replace=False):
+            h_ = O.synth_csr(po, int(need[j_]) - 1, int(need[j_]))
+            b_, e_ = int(rp[j_]), int(rp[j_ + 1])
+            assert np.array_equal(h_.nbr, nb[b_:e_]) and np.array_equal(h_.prefix_w, pw[b_:e_]), \
+                "device generator differs from the host generator at node %d" % int(need[j_])
         OG = O.OracleGraph(O.CSR(need, rp, te, nb, pw, tp, 1))
         on, _, _ = OG.sample_fanout(GRAPH_SEED, 2 * last, r0, et, FANOUT, default_node)
         assert np.array_equal(on[0], hop1.reshape(-1)), "hop-1 ids differ from oracle"
