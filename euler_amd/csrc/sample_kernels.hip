@@ -545,6 +545,7 @@ thread_local int g_expand_const_type = 1;   // ... rebuild the type column of si
 thread_local int g_expand_grid_cap = 0;     // ... workgroup cap (0 = kK1GridCap)
 thread_local int g_k1_ablate = 0;   // measurement only: skip parts of the blocked kernel
 thread_local int g_k1_ilp = 4;      // samples per lane of the ILP kernel (1, 2, 4, 8)
+thread_local int g_full_nb_balanced = 1;   // get_full_neighbor fill: a lane owns 4 output entries (key 24)
 thread_local int g_fanout_fused = 1;       // small 2-hop single-type fanouts as one launch (key 23)
 thread_local int g_k1_pair_distinct = 0;   // pass over the distinct roots: two samples per lane (key 22)
 thread_local int g_expand_lean = 1;  // last hop, even count: the lean gather-copy kernel (key 21)
@@ -1634,6 +1635,7 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 21) { g_expand_lean = value != 0; return EULER_GPU_OK; }
   if (key == 22) { g_k1_pair_distinct = value != 0; return EULER_GPU_OK; }
   if (key == 23) { g_fanout_fused = value != 0; return EULER_GPU_OK; }
+  if (key == 24) { g_full_nb_balanced = value != 0; return EULER_GPU_OK; }
   if (key == 1 && (value == 1 || value == 2 || value == 4 || value == 8)) {
     g_k1_ilp = value;
     return EULER_GPU_OK;

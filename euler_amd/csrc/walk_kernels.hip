@@ -136,6 +136,54 @@ __global__ __launch_bounds__(256) void FullNbFillKernel(
   }
 }
 
+// Balanced fill: a lane owns 4 consecutive OUTPUT entries, whatever rows they
+// belong to (the wave-per-node kernel above left 60 lanes idle on the 2-edge rows
+// most nodes have and one wave alone on a hub's 10^5 edges).  The row of an entry
+// e is the first i with idx[2i+1] > e (row ends are non-decreasing; rows without
+// neighbours have begin == end and are skipped by the search).
+constexpr int kFullNbPerLane = 4;
+__global__ __launch_bounds__(256) void FullNbFillBalancedKernel(
+    const FullNbArgs a, const int32_t* __restrict__ idx, uint64_t* __restrict__ out_id,
+    float* __restrict__ out_w, int32_t* __restrict__ out_t) {
+  const int64_t total = (int64_t)idx[2 * (a.n - 1) + 1];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * kFullNbPerLane;
+  for (int64_t e0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * kFullNbPerLane; e0 < total;
+       e0 += stride) {
+    int64_t lo = 0, hi = a.n - 1;                 // first row whose end exceeds e0
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((int64_t)idx[2 * mid + 1] > e0) hi = mid; else lo = mid + 1;
+    }
+    int64_t i = lo;
+    int64_t row = FindRow(a.g, a.ids[i]);
+    RowMeta m = LoadRowMeta(a.g, row < 0 ? 0 : row);
+    int64_t begin = idx[2 * i], end = idx[2 * i + 1];
+    const int64_t e1 = e0 + kFullNbPerLane < total ? e0 + kFullNbPerLane : total;
+    for (int64_t e = e0; e < e1; ++e) {
+      while (e >= end) {                           // next row that has entries
+        ++i;
+        begin = idx[2 * i]; end = idx[2 * i + 1];
+        if (end > begin) { row = FindRow(a.g, a.ids[i]); m = LoadRowMeta(a.g, row); }
+      }
+      // entry q of the row's listed segments, in listed order
+      int32_t q = (int32_t)(e - begin);
+      int32_t t = 0, p = 0;
+      for (int32_t x = 0; x < a.k; ++x) {
+        t = a.et[x];
+        if (t < 0 || t >= a.g.T) continue;
+        const int32_t b = t == 0 ? 0 : m.type_end[t - 1];
+        const int32_t len = m.type_end[t] - b;
+        if (q < len) { p = b + q; break; }
+        q -= len;
+      }
+      const float* nw = a.g.prefix_w + m.row_ptr;
+      out_id[e] = a.g.nbr[m.row_ptr + p];
+      out_w[e] = __fsub_rn(nw[p], p == 0 ? 0.f : nw[p - 1]);
+      out_t[e] = t;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------
 // get_top_k_neighbor in one kernel (tf_euler/kernels/get_top_k_neighbor_op.cc:
 // `v(nodes).outV(edge_types).order_by(weight, desc).limit(k)` filled into dense
@@ -1071,10 +1119,18 @@ int euler_gpu_get_full_neighbor(const euler_gpu_graph* g, void* stream,
     if (total_host) *total_host = last[1];
     return EULER_GPU_OK;
   }
-  const int64_t waves_needed = n;
-  const int grid = GridFor(waves_needed * 64, block);
-  hipLaunchKernelGGL(FullNbFillKernel, dim3(grid), dim3(block), 0, st, a, idx_dev,
-                     out_id_dev, out_w_dev, out_t_dev);
+  if (g_full_nb_balanced != 0) {
+    // the grid covers the worst case the caller's arrays can hold is unknown here: size it
+    // for 16 entries per queried node and let the grid-stride loop do the rest
+    const int grid = GridFor((n * 16 + kFullNbPerLane - 1) / kFullNbPerLane, block);
+    hipLaunchKernelGGL(FullNbFillBalancedKernel, dim3(grid), dim3(block), 0, st, a, idx_dev,
+                       out_id_dev, out_w_dev, out_t_dev);
+  } else {
+    const int64_t waves_needed = n;
+    const int grid = GridFor(waves_needed * 64, block);
+    hipLaunchKernelGGL(FullNbFillKernel, dim3(grid), dim3(block), 0, st, a, idx_dev,
+                       out_id_dev, out_w_dev, out_t_dev);
+  }
   EG_HIP(hipGetLastError());
   return EULER_GPU_OK;
 }

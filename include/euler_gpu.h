@@ -780,6 +780,8 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  *        (the reference examples' batch of 1 024) runs as ONE launch: a workgroup
  *        draws a root's first-hop samples and, from LDS, their second-hop samples
  *        (1 [default]); 0 = one launch per hop.
+ * key 24: get_full_neighbor fill pass: a lane owns 4 consecutive output entries,
+ *        whatever rows they belong to (1 [default]); 0 = one wave per queried node.
  * key 20: last hop of a fanout with key 14 = 2: 1 = the expansion reads every
  *        position's row number from the owner table itself; 0 = a separate resolve
  *        kernel fills an index array first [default: measured 9 us faster].

@@ -1215,3 +1215,25 @@ def test_small_fanout_in_one_launch(EA, O, torch_cuda, big_pair):
                 assert torch.equal(res[0][1][h], res[1][1][h]) and torch.equal(res[0][2][h], res[1][2][h])
     finally:
         _lib.lib().euler_gpu_set_tuning(23, 1)
+
+
+def test_full_neighbor_fill_kernels_agree(EA, O, torch_cuda, big_pair):
+    """Both fill passes of get_full_neighbor (tuning key 24: a lane owns 4 output entries /
+    one wave per queried node) against the oracle: unknown ids, rows without the listed
+    types, repeated ids, all type subsets."""
+    torch = torch_cuda
+    from euler_amd import _lib
+    G, OG, ids, rng = big_pair
+    q = np.concatenate([rng.choice(ids, 5000), rng.choice(ids[:20], 2000), [0, 31337]]).astype(np.uint64)
+    qt = torch.as_tensor(q.astype(np.int64)).cuda()
+    try:
+        for et in ([0, 1, 2, 3], [2], [3, 0], [1, 1], []):
+            wi, wd, ww, wt = OG.get_full_neighbor(q, et)
+            for mode in (1, 0):
+                _lib.lib().euler_gpu_set_tuning(24, mode)
+                gi, gd, gw, gt = G.get_full_neighbor(qt, et)
+                assert np.array_equal(t2n(gi), wi), (et, mode)
+                assert np.array_equal(t2n(gd).astype(np.uint64), wd)
+                assert np.array_equal(t2n(gw), ww) and np.array_equal(t2n(gt), wt)
+    finally:
+        _lib.lib().euler_gpu_set_tuning(24, 1)
