@@ -382,3 +382,16 @@ def test_neighbor_dataflow_block_arithmetic():
             assert blk.size == [len(n_id), len(new_n_id)]
             n_id = new_n_id
         assert len(df) == 2 and [b.size for b in df] == [b.size for b in df.blocks[::-1]]
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus N` with no launcher around it starts its own N ranks
+    (torch.distributed.run); with fewer GPUs visible than ranks it must refuse loudly
+    instead of running one rank and printing n_gpus: 1 (here: no GPU at all)."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 2, (out.returncode, out.stderr[-500:])
+    assert "--gpus 2 but only" in out.stderr and "{" not in out.stdout

@@ -2,7 +2,7 @@
 events via torch on the current stream), algorithmic bytes and
 GB/s.  Writes one JSON object; the committed copy lives in profiles/."""
 import json, sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, euler_amd
 from euler_amd import ops
 

@@ -3,7 +3,7 @@ all-to-all with itself), phase by phase with a device sync after each phase.
 
   python tools/prof_sharded.py"""
 import os, sys, json, time
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.distributed as dist
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29533")
