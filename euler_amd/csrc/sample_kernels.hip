@@ -525,8 +525,10 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void ExpandPackedKernel(
 }
 // ---- tuning switches (euler_gpu_set_tuning; declared in k1_args.h) ----
 thread_local int g_k1_dedup = 1;     // 0 = never, 1 = automatic for >= 100 000 roots, 2 = always try
-thread_local int g_n2v_wave = 2;     // node2vec: 2 = one wave per walker, the two-cursor walk by the whole wave,
-                        // 1 = one wave per walker, lane 0 walks LDS-staged lists, 0 = one lane
+thread_local int g_n2v_wave = 2;     // node2vec: 3 = launched per step, long lists by a workgroup (walk_kernels.hip:
+                        // N2vBigStepKernel), 2 = one launch, one wave per walker, the two-cursor walk by
+                        // the whole wave, 1 = lane 0 walks LDS-staged lists, 0 = one lane per walker
+thread_local int g_n2v_big = 8192;   // key 25: child lists of this many entries go to the workgroup kernel (0 = none)
 thread_local int g_k1_group = 0;     // block-pivot kernel: five adjacent samples per lane for odd counts
                         // that are a multiple of 5 - measured 8 % SLOWER on the metric's
                         // first hop (it is bound by the dependent-load chain per lane, not
@@ -1636,6 +1638,7 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 22) { g_k1_pair_distinct = value != 0; return EULER_GPU_OK; }
   if (key == 23) { g_fanout_fused = value != 0; return EULER_GPU_OK; }
   if (key == 24) { g_full_nb_balanced = value != 0; return EULER_GPU_OK; }
+  if (key == 25 && value >= 0) { g_n2v_big = value; return EULER_GPU_OK; }
   if (key == 1 && (value == 1 || value == 2 || value == 4 || value == 8)) {
     g_k1_ilp = value;
     return EULER_GPU_OK;

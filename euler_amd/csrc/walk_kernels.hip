@@ -417,6 +417,19 @@ struct WalkArgs {
   int32_t walk_len;
   float p;
   float q;
+  // node2vec launched step by step (tuning key 7 = 3): this launch does steps
+  // [step_begin, step_end) from the paths written so far; a step whose child list
+  // has big_threshold entries or more is left to N2vBigStepKernel (queued by
+  // N2vClassifyKernel).  step_end == 0: all steps, nothing queued.
+  int32_t step_begin;
+  int32_t step_end;
+  int32_t big_threshold;
+  int32_t* big_queue;     // walker indices
+  int32_t* big_count;     // [0] entries queued, [1] next entry to hand out
+  // p (q) a power of two: w / p == w * inv_p in every bit (both are the correctly
+  // rounded w / p); 0 = divide
+  float inv_p;
+  float inv_q;
 };
 
 // FAST: one listed edge type per step on a graph with non-decreasing running
@@ -610,9 +623,11 @@ struct N2vList {           // one neighbour list = listed type segments of a row
   int32_t seg_len[kN2vMaxSeg];
 };
 
+constexpr int kN2vCk = 2 * kN2vChunk;   // checkpoints of the whole-wave path (they reuse the staging arrays)
+
 struct alignas(16) N2vLds {
-  uint64_t c_id[kN2vChunk];
-  uint64_t p_id[kN2vChunk];
+  union { uint64_t c_id[kN2vChunk]; float ck_acc[kN2vCk]; };
+  union { uint64_t p_id[kN2vChunk]; int32_t ck_k[kN2vCk]; };
   float c_w[kN2vChunk];
   N2vList child, parent;
 };
@@ -635,6 +650,16 @@ __device__ __forceinline__ void N2vBuildList(N2vList* L, const GraphView& g, int
     ++L->n_seg;
     L->total += len;
   }
+}
+
+// The child list IS the parent list (the walker took a self loop and the steps list the
+// same types): the two cursors then move in lockstep and every child is common.
+__device__ __forceinline__ bool N2vSameLists(const N2vList& c, const N2vList& p) {
+  if (c.total == 0 || c.total != p.total || c.row_ptr != p.row_ptr || c.n_seg != p.n_seg)
+    return false;
+  for (int32_t x = 0; x < c.n_seg; ++x)
+    if (c.seg_b[x] != p.seg_b[x] || c.seg_len[x] != p.seg_len[x]) return false;
+  return true;
 }
 
 // row-relative position of logical entry j
@@ -694,91 +719,313 @@ __device__ __forceinline__ int64_t ReadLane64(int64_t v, int src) {
   return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
+// Inclusive integer sum over the wave: four row_shr steps inside each row of 16
+// lanes, then the three row totals added to the rows above them.
+__device__ __forceinline__ int32_t WaveInclusiveAdd(int32_t v, int lane) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112 /* row_shr:2 */, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114 /* row_shr:4 */, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118 /* row_shr:8 */, 0xf, 0xf, true);
+  const int32_t t0 = __builtin_amdgcn_readlane(v, 15);
+  const int32_t t1 = __builtin_amdgcn_readlane(v, 31);
+  const int32_t t2 = __builtin_amdgcn_readlane(v, 47);
+  return v + (lane >= 16 ? t0 : 0) + (lane >= 32 ? t1 : 0) + (lane >= 48 ? t2 : 0);
+}
+
+// The sequential f32 running sums of a chunk WITHOUT the 63-deep add chain, when
+// the chunk stays inside the binade of its carry.  For carry = m * ulp in
+// [2^e, 2^(e+1)) and carry + d below 2^(e+1), fl(carry + d) = (m + n) * ulp with
+// n = d / ulp rounded to nearest - the same n for every m unless d / ulp ends in
+// exactly .5 (then the tie goes to the even m + n and depends on m).  So with no
+// such tie in the chunk and no sum reaching 2^(e+1), the f32 chain IS an integer
+// running sum of the n's over the mantissa, which a wave does in ten instructions.
+// n comes out of the adder itself: fl(2^e + d) has mantissa offset n (2^e is an
+// even m, and without a tie the parity does not matter); d - (fl(2^e + d) - 2^e) is
+// exact and equals +-ulp/2 exactly on a tie.  Returns false - the caller runs the
+// add chain - on a tie, a negative / NaN entry, a sum that leaves the binade, or a
+// carry that is zero / tiny / huge.  On the metric graph's hub rows 92 % of the
+// chunks take this path (tools/n2v_binade_model.py restates it in numpy against
+// the sequential sums).
+__device__ __forceinline__ bool ChunkScanBinade(float carry, float d, int lane, float* sum) {
+  // A lane the integer sum cannot pass - the sum leaves the binade there, a tie, a
+  // negative entry, a carry of 0 - gets its sum from one real f32 add of its
+  // predecessor's; the lanes after it start over from that sum.  A few such lanes
+  // per chunk (binade crossings: ~20 per list), else the caller's add chain.
+  float out = 0.f;
+  int start = 0;
+  for (int iter = 0; iter < 4; ++iter) {
+    const uint32_t cb = __float_as_uint(carry);
+    const uint32_t e = cb >> 23;                     // sign bit set => e >= 256
+    const bool range_ok = e >= 30u && e < 254u;
+    const uint32_t bb = cb & 0xFF800000u;
+    const float B = __uint_as_float(bb);
+    const float t = __fadd_rn(B, d);
+    const float err = __fsub_rn(d, __fsub_rn(t, B));
+    const float half_ulp = __uint_as_float(bb - (24u << 23));
+    const bool active = lane >= start;
+    const bool ok = d >= 0.f && fabsf(err) != half_ulp && t < __fadd_rn(B, B);
+    const int32_t n = active && ok ? (int32_t)(__float_as_uint(t) - bb) : 0;   // < 2^23
+    const int32_t off = (int32_t)(cb - bb) + WaveInclusiveAdd(n, lane);        // < 2^30
+    const unsigned long long prob =
+        __ballot(active && (!range_ok || !ok || off >= (1 << 23)));
+    const int c = prob != 0 ? __ffsll((long long)prob) - 1 : 64;
+    if (active && lane < c) out = __uint_as_float(bb + (uint32_t)off);
+    if (c == 64) { *sum = out; return true; }
+    const float before = c == start
+                             ? carry
+                             : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(out), c - 1));
+    const float dc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), c));
+    carry = __fadd_rn(before, dc);
+    if (lane == c) out = carry;
+    start = c + 1;
+    if (start == 64) { *sum = out; return true; }
+  }
+  return false;
+}
+
+// BuildWeights' weight of a child that is not a common neighbour (random_walk_op.cc:
+// 152-160): w / p for the parent itself, w / q otherwise.
+__device__ __forceinline__ float N2vScaled(const WalkArgs& a, float w, bool is_parent) {
+  const float inv = is_parent ? a.inv_p : a.inv_q;
+  if (a.inv_p != 0.f && a.inv_q != 0.f) return __fmul_rn(w, inv);
+  return is_parent ? __fdiv_rn(w, a.p) : __fdiv_rn(w, a.q);
+}
+
+// One lane's entry of a 64-entry chunk of the child list (ids, and the weight as the
+// difference of the row's running sums - what `outV` hands the reference).
+struct N2vEntry {
+  int64_t cid;
+  float w;
+  bool live;
+};
+
+__device__ __forceinline__ N2vEntry N2vLoad(const WalkArgs& a, const N2vLds& S, int lane,
+                                            int32_t nc, int32_t j0) {
+  N2vEntry e;
+  const int32_t j = j0 + lane;
+  e.live = j < nc;
+  e.cid = 0;
+  e.w = 0.f;
+  if (e.live) {
+    const float* c_nw = a.g.prefix_w + S.child.row_ptr;
+    const int32_t ph = N2vPhys(S.child, j);
+    e.cid = (int64_t)(a.g.nbr + S.child.row_ptr)[ph];
+    e.w = __fsub_rn(c_nw[ph], ph == 0 ? 0.f : c_nw[ph - 1]);
+  }
+  return e;
+}
+
+// The parent cursor: k, and pn[k] once it has been read (a run of chunks whose
+// children all sit below pn[k] reads it once).
+struct N2vCursor {
+  int32_t k;
+  int32_t m_k;      // the k that M belongs to, -1 = none
+  int64_t M;
+};
+
+// One chunk with the parent cursor at *c: every lane's weight after BuildWeights'
+// comparison and the running sums (lane t: acc + w[0] + ... + w[t] in that order).
+// *events = moves of the parent cursor that needed a scan.
+__device__ __forceinline__ float N2vChunk(const WalkArgs& a, const N2vLds& S, int lane,
+                                          int64_t parent, int32_t np, bool same_lists,
+                                          const N2vEntry& e, float acc, N2vCursor* c,
+                                          int32_t* events_out) {
+  const uint64_t* p_nbr = a.g.nbr + S.parent.row_ptr;
+  int32_t k = c->k;
+  bool keep = same_lists;            // cn == pn entry by entry: every child is a common neighbour
+  unsigned long long todo = same_lists ? 0ull : __ballot(e.live);
+  int32_t events = 0;
+  while (todo != 0 && k < np) {
+    if (c->m_k != k) { c->M = (int64_t)p_nbr[N2vPhys(S.parent, k)]; c->m_k = k; }
+    const unsigned long long below = __ballot(e.live && e.cid < c->M);
+    const unsigned long long ev = todo & ~below;
+    if (ev == 0) break;                       // every remaining child is below pn[k]
+    const int f = __ffsll((long long)ev) - 1;
+    const int64_t cf = ReadLane64(e.cid, f);
+    // first k' >= k with pn[k'] >= cf (the cursor skips the smaller entries)
+    bool eq = false;
+    for (;;) {
+      const int32_t kk = k + lane;
+      int64_t pv = 0;
+      if (kk < np) pv = (int64_t)p_nbr[N2vPhys(S.parent, kk)];
+      const unsigned long long ge = __ballot(kk < np && pv >= cf);
+      if (ge != 0) {
+        const int g = __ffsll((long long)ge) - 1;
+        k += g;
+        c->M = ReadLane64(pv, g);
+        c->m_k = k;
+        eq = c->M == cf;
+        break;
+      }
+      k += 64;
+      if (k >= np) { k = np; break; }
+    }
+    if (eq) { if (lane == f) keep = true; ++k; }
+    // lanes up to and including f are resolved
+    todo &= f == 63 ? 0ull : (~0ull << (f + 1));
+    ++events;
+  }
+  const float wq = !e.live ? 0.f : keep ? e.w : N2vScaled(a, e.w, e.cid == parent);
+  float sum;
+  if (!ChunkScanBinade(acc, wq, lane, &sum)) sum = ChunkScan(acc, wq, lane);
+  c->k = k;
+  *events_out = events;
+  return sum;
+}
+
 // One step of one walker by the whole wave; returns false when the lists look
 // ascending (the caller then runs the sequential automaton).  *out = sampled id.
-__device__ __forceinline__ bool N2vStepParallel(const WalkArgs& a, const N2vLds& S, int lane,
+// Pass 1 runs the chunks once for the total and leaves (running sum, parent cursor)
+// checkpoints in LDS - one per 2^sh chunks, at most kN2vCk of them; the draw r
+// then names the first checkpoint whose sum exceeds it, and only the chunks after
+// the previous checkpoint are run again to find the entry (the sums never
+// decrease when the weights, p and q are non-negative; otherwise the second pass
+// starts from the first entry as the reference's scan would).
+__device__ __forceinline__ bool N2vStepParallel(const WalkArgs& a, N2vLds& S, int lane,
                                                 int64_t parent, int64_t walker, int32_t step,
                                                 int64_t* out) {
+  const int32_t nc = S.child.total, np = S.parent.total;
+  const int32_t nchunks = (nc + 63) >> 6;
+  int32_t sh = 0;
+  while ((nchunks >> sh) > kN2vCk) ++sh;
+  const int32_t n_slots = nchunks >> sh;
+  int32_t events;
+  float acc = 0.f;
+  N2vCursor cur{0, -1, 0};
+  const bool same = N2vSameLists(S.child, S.parent);
+  // the next chunk's entries are requested before this chunk is worked on: a wave
+  // has one dependent round trip per chunk, not two
+  N2vEntry e = N2vLoad(a, S, lane, nc, 0), nx = e;
+  for (int32_t ci = 0; ci < nchunks; ++ci) {
+    if (ci + 1 < nchunks) nx = N2vLoad(a, S, lane, nc, (ci + 1) << 6);
+    const float sum = N2vChunk(a, S, lane, parent, np, same, e, acc, &cur, &events);
+    if (ci == 0 && nc >= 64 && events > 16) return false;   // ascending lists
+    const int32_t cnt = nc - (ci << 6) < 64 ? nc - (ci << 6) : 64;
+    acc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sum), cnt - 1));
+    if (((ci + 1) & ((1 << sh) - 1)) == 0 && lane == 0) {
+      S.ck_acc[((ci + 1) >> sh) - 1] = acc;
+      S.ck_k[((ci + 1) >> sh) - 1] = cur.k;
+    }
+    e = nx;
+  }
+  const float total = acc;
+  const double u = RngDraw(a.seed, a.call_id + (uint32_t)step, kDomainWalk, (uint64_t)walker, 0);
+  const double r = ScaleDraw(u, 0.f, total);
+  WaveSync();
+  int32_t first = 0;
+  if (a.g.monotone && a.p > 0.f && a.q > 0.f) {
+    first = n_slots;
+    for (int32_t base = 0; base < n_slots; base += 64) {
+      const int32_t idx = base + lane;
+      const unsigned long long gt = __ballot(idx < n_slots && (double)S.ck_acc[idx] > r);
+      if (gt != 0) { first = base + __ffsll((long long)gt) - 1; break; }
+    }
+  }
+  acc = first == 0 ? 0.f : S.ck_acc[first - 1];
+  cur.k = first == 0 ? 0 : S.ck_k[first - 1];
+  cur.m_k = -1;
+  bool found = false;
+  int64_t result = a.default_node;
+  for (int32_t ci = first << sh; ci < nchunks && !found; ++ci) {
+    e = N2vLoad(a, S, lane, nc, ci << 6);
+    const float sum = N2vChunk(a, S, lane, parent, np, same, e, acc, &cur, &events);
+    float prev = __shfl_up(sum, 1);
+    if (lane == 0) prev = acc;
+    const unsigned long long hit = __ballot(e.live && (double)prev <= r && r < (double)sum);
+    if (hit != 0) {
+      found = true;
+      result = ReadLane64(e.cid, __ffsll((long long)hit) - 1);
+    }
+    const int32_t cnt = nc - (ci << 6) < 64 ? nc - (ci << 6) : 64;
+    acc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sum), cnt - 1));
+  }
+  // no interval holds r (total == 0): RandomSelect's fall-through ends on the last element
+  if (!found) result = (int64_t)(a.g.nbr + S.child.row_ptr)[N2vPhys(S.child, nc - 1)];
+  WaveSync();          // the checkpoints share LDS with the next step's lists
+  *out = result;
+  return true;
+}
+
+// One step of one walker, lists in LDS chunk by chunk, lane 0 runs the two-cursor
+// recurrence (see the header comment above); every lane returns the sampled id.
+__device__ __forceinline__ int64_t N2vStepSequential(const WalkArgs& a, N2vLds& S, int lane,
+                                                     int64_t parent, int64_t walker,
+                                                     int32_t step) {
   const int32_t nc = S.child.total, np = S.parent.total;
   const float* c_nw = a.g.prefix_w + S.child.row_ptr;
   const uint64_t* c_nbr = a.g.nbr + S.child.row_ptr;
   const uint64_t* p_nbr = a.g.nbr + S.parent.row_ptr;
   float total = 0.f;
   double r = 0.0;
-  int64_t result = a.default_node;
+  uint64_t last_id = 0;
   for (int pass = 0; pass < 2; ++pass) {
-    int32_t k = 0;
+    int32_t j = 0, k = 0;           // cursors (logical entries)
+    int32_t cj0 = 0, pk0 = 0;       // chunk bases
+    int32_t c_have = 0, p_have = 0; // entries loaded in each chunk
     float acc = 0.f;
     bool found = false;
-    int64_t last_id = 0;
-    for (int32_t j0 = 0; j0 < nc && !found; j0 += 64) {
-      const int32_t j = j0 + lane;
-      const bool live = j < nc;
-      int64_t cid = 0;
-      float w = 0.f;
-      if (live) {
-        const int32_t ph = N2vPhys(S.child, j);
-        cid = (int64_t)c_nbr[ph];
-        w = __fsub_rn(c_nw[ph], ph == 0 ? 0.f : c_nw[ph - 1]);
+    bool need_c = true, need_p = np > 0;
+    while (j < nc && !found) {
+      if (need_c) {
+        WaveSync();
+        cj0 = j;
+        c_have = min(kN2vChunk, nc - cj0);
+        for (int32_t t = lane; t < c_have; t += 64) {
+          const int32_t ph = N2vPhys(S.child, cj0 + t);
+          S.c_id[t] = c_nbr[ph];
+          S.c_w[t] = __fsub_rn(c_nw[ph], ph == 0 ? 0.f : c_nw[ph - 1]);
+        }
+        need_c = false;
       }
-      bool keep = false;
-      unsigned long long todo = __ballot(live);
-      int32_t events = 0;
-      while (todo != 0 && k < np) {
-        const int64_t M = (int64_t)p_nbr[N2vPhys(S.parent, k)];
-        const unsigned long long below = __ballot(live && cid < M);
-        const unsigned long long ev = todo & ~below;
-        if (ev == 0) break;                       // every remaining child is below pn[k]
-        const int f = __ffsll((long long)ev) - 1;
-        const int64_t cf = ReadLane64(cid, f);
-        // first k' >= k with pn[k'] >= cf (the cursor skips the smaller entries)
-        bool eq = false;
-        for (;;) {
-          const int32_t kk = k + lane;
-          int64_t pv = 0;
-          if (kk < np) pv = (int64_t)p_nbr[N2vPhys(S.parent, kk)];
-          const unsigned long long ge = __ballot(kk < np && pv >= cf);
-          if (ge != 0) {
-            const int g = __ffsll((long long)ge) - 1;
-            k += g;
-            eq = ReadLane64(pv, g) == cf;
-            break;
+      if (need_p) {
+        WaveSync();
+        pk0 = k;
+        p_have = min(kN2vChunk, np - pk0);
+        for (int32_t t = lane; t < p_have; t += 64)
+          S.p_id[t] = p_nbr[N2vPhys(S.parent, pk0 + t)];
+        need_p = false;
+      }
+      WaveSync();
+      if (lane == 0) {
+        const int32_t c_end = cj0 + c_have;
+        const int32_t p_end = pk0 + p_have;
+        while (j < c_end) {
+          const int64_t cid = (int64_t)S.c_id[j - cj0];
+          float w = S.c_w[j - cj0];
+          if (k < np) {
+            if (k >= p_end) break;               // next parent chunk
+            const int64_t pid = (int64_t)S.p_id[k - pk0];
+            if (cid > pid) { ++k; continue; }    // parent cursor only
+            if (cid == pid) ++k;                 // common neighbour: weight kept
+            else w = cid != parent ? __fdiv_rn(w, a.q) : __fdiv_rn(w, a.p);
+          } else {
+            w = cid != parent ? __fdiv_rn(w, a.q) : __fdiv_rn(w, a.p);
           }
-          k += 64;
-          if (k >= np) { k = np; break; }
-        }
-        if (eq) { if (lane == f) keep = true; ++k; }
-        // lanes up to and including f are resolved
-        todo &= f == 63 ? 0ull : (~0ull << (f + 1));
-        ++events;
-      }
-      if (pass == 0 && j0 == 0 && nc >= 64 && events > 16) return false;   // ascending lists
-      const float wq = !live ? 0.f
-                             : keep ? w : (cid != parent ? __fdiv_rn(w, a.q) : __fdiv_rn(w, a.p));
-      const float sum = ChunkScan(acc, wq, lane);
-      const int32_t cnt = nc - j0 < 64 ? nc - j0 : 64;
-      if (pass == 1) {
-        float prev = __shfl_up(sum, 1);
-        if (lane == 0) prev = acc;
-        const unsigned long long hit = __ballot(live && (double)prev <= r && r < (double)sum);
-        if (hit != 0) {
-          found = true;
-          result = ReadLane64(cid, __ffsll((long long)hit) - 1);
+          const float prev = acc;
+          acc = __fadd_rn(acc, w);
+          last_id = (uint64_t)cid;
+          ++j;
+          if (pass == 1 && (double)prev <= r && r < (double)acc) { found = true; break; }
         }
       }
-      acc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sum), cnt - 1));
-      last_id = ReadLane64(cid, cnt - 1);
+      j = __shfl(j, 0);
+      k = __shfl(k, 0);
+      found = __shfl((int)found, 0) != 0;
+      need_c = j >= cj0 + c_have;
+      need_p = k < np && k >= pk0 + p_have;
     }
     if (pass == 0) {
-      total = acc;
-      const double u = RngDraw(a.seed, a.call_id + (uint32_t)step, kDomainWalk, (uint64_t)walker, 0);
+      total = __shfl(acc, 0);
+      const double u = RngDraw(a.seed, a.call_id + (uint32_t)step, kDomainWalk,
+                               (uint64_t)walker, 0);
       r = ScaleDraw(u, 0.f, total);
-    } else if (!found) {
-      result = last_id;      // total == 0: RandomSelect's fall-through ends on the last element
     }
   }
-  *out = result;
-  return true;
+  // found: last_id is the hit; not found (total == 0): RandomSelect's
+  // fall-through ends on the last element, which is last_id as well
+  const uint32_t lo32 = __shfl((uint32_t)last_id, 0);
+  const uint32_t hi32 = __shfl((uint32_t)(last_id >> 32), 0);
+  return (int64_t)(((uint64_t)hi32 << 32) | lo32);
 }
 
 template <bool PAR>
@@ -788,13 +1035,22 @@ __global__ __launch_bounds__(256) void Node2VecWaveKernel(const WalkArgs a) {
   const int lane = threadIdx.x & 63;
   const int64_t waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int64_t L = a.walk_len + 1;
+  const int32_t s_end = a.step_end > 0 ? a.step_end : a.walk_len;
   for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < a.n;
        i += waves) {
-    int64_t cur = a.nodes[i];
-    int64_t parent = cur;          // parent_ids_ starts as the start nodes
-    bool have_parent_nb = false;   // parent_neighbors_ starts empty
-    if (lane == 0) a.out[i * L] = cur;
-    for (int32_t s = 0; s < a.walk_len; ++s) {
+    int64_t cur, parent;
+    bool have_parent_nb;
+    if (a.step_begin == 0) {
+      cur = a.nodes[i];
+      parent = cur;                // parent_ids_ starts as the start nodes
+      have_parent_nb = false;      // parent_neighbors_ starts empty
+      if (lane == 0) a.out[i * L] = cur;
+    } else {
+      cur = a.out[i * L + a.step_begin];
+      parent = a.out[i * L + a.step_begin - 1];
+      have_parent_nb = true;
+    }
+    for (int32_t s = a.step_begin; s < s_end; ++s) {
       const int32_t* et = a.edge_types + s * a.k;
       const int32_t* pet = s > 0 ? a.edge_types + (s - 1) * a.k : et;
       WaveSync();
@@ -804,91 +1060,293 @@ __global__ __launch_bounds__(256) void Node2VecWaveKernel(const WalkArgs a) {
                      have_parent_nb ? FindRow(a.g, (uint64_t)parent) : -1, pet, a.k);
       }
       WaveSync();
-      const int32_t nc = S.child.total, np = S.parent.total;
+      const int32_t nc = S.child.total;
+      if (a.big_threshold > 0 && nc >= a.big_threshold) break;   // N2vBigStepKernel's
       int64_t sample_id = a.default_node;
       bool done = false;
       if (PAR && nc > 0) done = N2vStepParallel(a, S, lane, parent, i, s, &sample_id);
-      if (nc > 0 && !done) {
-        const float* c_nw = a.g.prefix_w + S.child.row_ptr;
-        const uint64_t* c_nbr = a.g.nbr + S.child.row_ptr;
-        const uint64_t* p_nbr = a.g.nbr + S.parent.row_ptr;
-        float total = 0.f;
-        double r = 0.0;
-        uint64_t last_id = 0;
-        for (int pass = 0; pass < 2; ++pass) {
-          int32_t j = 0, k = 0;           // cursors (logical entries)
-          int32_t cj0 = 0, pk0 = 0;       // chunk bases
-          int32_t c_have = 0, p_have = 0; // entries loaded in each chunk
-          float acc = 0.f;
-          bool found = false;
-          bool need_c = true, need_p = np > 0;
-          while (j < nc && !found) {
-            if (need_c) {
-              WaveSync();
-              cj0 = j;
-              c_have = min(kN2vChunk, nc - cj0);
-              for (int32_t t = lane; t < c_have; t += 64) {
-                const int32_t ph = N2vPhys(S.child, cj0 + t);
-                S.c_id[t] = c_nbr[ph];
-                S.c_w[t] = __fsub_rn(c_nw[ph], ph == 0 ? 0.f : c_nw[ph - 1]);
-              }
-              need_c = false;
-            }
-            if (need_p) {
-              WaveSync();
-              pk0 = k;
-              p_have = min(kN2vChunk, np - pk0);
-              for (int32_t t = lane; t < p_have; t += 64)
-                S.p_id[t] = p_nbr[N2vPhys(S.parent, pk0 + t)];
-              need_p = false;
-            }
-            WaveSync();
-            if (lane == 0) {
-              const int32_t c_end = cj0 + c_have;
-              const int32_t p_end = pk0 + p_have;
-              while (j < c_end) {
-                const int64_t cid = (int64_t)S.c_id[j - cj0];
-                float w = S.c_w[j - cj0];
-                if (k < np) {
-                  if (k >= p_end) break;               // next parent chunk
-                  const int64_t pid = (int64_t)S.p_id[k - pk0];
-                  if (cid > pid) { ++k; continue; }    // parent cursor only
-                  if (cid == pid) ++k;                 // common neighbour: weight kept
-                  else w = cid != parent ? __fdiv_rn(w, a.q) : __fdiv_rn(w, a.p);
-                } else {
-                  w = cid != parent ? __fdiv_rn(w, a.q) : __fdiv_rn(w, a.p);
-                }
-                const float prev = acc;
-                acc = __fadd_rn(acc, w);
-                last_id = (uint64_t)cid;
-                ++j;
-                if (pass == 1 && (double)prev <= r && r < (double)acc) { found = true; break; }
-              }
-            }
-            j = __shfl(j, 0);
-            k = __shfl(k, 0);
-            found = __shfl((int)found, 0) != 0;
-            need_c = j >= cj0 + c_have;
-            need_p = k < np && k >= pk0 + p_have;
-          }
-          if (pass == 0) {
-            total = __shfl(acc, 0);
-            const double u = RngDraw(a.seed, a.call_id + (uint32_t)s, kDomainWalk,
-                                     (uint64_t)i, 0);
-            r = ScaleDraw(u, 0.f, total);
-          }
-        }
-        // found: last_id is the hit; not found (total == 0): RandomSelect's
-        // fall-through ends on the last element, which is last_id as well
-        const uint32_t lo32 = __shfl((uint32_t)last_id, 0);
-        const uint32_t hi32 = __shfl((uint32_t)(last_id >> 32), 0);
-        sample_id = (int64_t)(((uint64_t)hi32 << 32) | lo32);
-      }
+      if (nc > 0 && !done) sample_id = N2vStepSequential(a, S, lane, parent, i, s);
       if (lane == 0) a.out[i * L + s + 1] = sample_id;
       parent = cur;
       have_parent_nb = true;
       cur = sample_id;
     }
+  }
+}
+
+// ------------------------------------------------------------------------
+// node2vec step by step (tuning key 7 = 3, default).  A walker's step is one wave's
+// serial work - 0.6 us per 64-entry chunk - and the metric graph has rows of 5e5
+// neighbours: one walker in 10^5 spends 12 ms on its ten steps while the rest of
+// the chip has long finished (tools/prof_n2v.py: 1 000 walkers take 12.6 ms,
+// 100 000 take 37 ms).  So the walk is launched per step, and a step whose child
+// list is long goes to a WORKGROUP of 16 waves: 1 024 entries per round, the parent
+// cursor and the running sum carried across the waves through LDS.
+//   * Parent cursor: all lanes compare with the same pn[k]; the first lane that is
+//     not below it is found with one ballot per wave and one LDS exchange, the
+//     cursor scan runs 1 024 parent entries per round.  (3 such events per step on
+//     the metric graph; lists that look ascending go to the sequential automaton.)
+//   * Running sums: inside one binade and without a rounding tie the f32 chain is an
+//     integer sum (ChunkScanBinade), so every wave sums its 64 entries, the 16
+//     totals are exchanged and each wave adds what lies before it.  A round with a
+//     tie, a negative entry or a sum that leaves the binade is redone wave after
+//     wave, each taking the previous wave's last sum (its own 64 entries by the
+//     integer scan when that now fits, by the add chain otherwise).
+// ------------------------------------------------------------------------
+constexpr int kN2vBigWaves = 16;
+constexpr int kN2vBigCk = 1024;
+
+struct alignas(16) N2vBigLds {
+  N2vLds seq;                                   // lists + staging of the sequential automaton
+  unsigned long long x_mask[2][kN2vBigWaves];   // exchange slots, alternating
+  int64_t x_val[2][kN2vBigWaves];
+  float hand;                                   // wave-after-wave sums: the previous wave's last
+  int64_t next;                                 // queue entry of this workgroup
+  float ck_acc[kN2vBigCk];
+  int32_t ck_k[kN2vBigCk];
+};
+
+// Every wave contributes a lane mask and the value of its first set lane; returns the
+// workgroup-wide index (wave * 64 + lane) of the first set lane, -1 if none, and that
+// lane's value.  One barrier; consecutive calls use alternate slots, so a wave that
+// runs ahead writes the slots nobody reads any more.
+__device__ __forceinline__ int32_t N2vBigFirst(N2vBigLds& S, int* phase, int wv, int lane,
+                                               unsigned long long mask, int64_t v,
+                                               int64_t* v_out) {
+  const int b = *phase & 1;
+  ++*phase;
+  if (lane == 0) S.x_mask[b][wv] = mask;
+  if (mask != 0 && lane == __ffsll((long long)mask) - 1) S.x_val[b][wv] = v;
+  __syncthreads();
+  const unsigned long long mine = lane < kN2vBigWaves ? S.x_mask[b][lane] : 0ull;
+  const unsigned long long nz = __ballot(mine != 0);
+  if (nz == 0) return -1;
+  const int w = __ffsll((long long)nz) - 1;
+  const unsigned long long m = S.x_mask[b][w];
+  *v_out = S.x_val[b][w];
+  return w * 64 + __ffsll((long long)m) - 1;
+}
+
+struct N2vBigState {
+  int32_t k;        // parent cursor
+  int32_t m_k;      // the k that M belongs to, -1 = none
+  int64_t M;
+  float acc;        // running sum before this round
+};
+
+// One round (64 * kN2vBigWaves child entries, `e` = this lane's): *sum = this lane's
+// running sum, *before = the running sum before this wave's first lane.
+// Workgroup-uniform control flow throughout.
+__device__ __forceinline__ void N2vBigRound(const WalkArgs& a, N2vBigLds& S, int* phase, int wv,
+                                            int lane, int64_t parent, int32_t np,
+                                            bool same_lists, const N2vEntry& e, N2vBigState* st,
+                                            float* sum_out, float* before_out,
+                                            int32_t* events_out) {
+  const int tid = wv * 64 + lane;
+  const uint64_t* p_nbr = a.g.nbr + S.seq.parent.row_ptr;
+  bool keep = same_lists;
+  int32_t resolved = -1, events = 0;
+  int32_t k = st->k;
+  while (!same_lists && k < np) {
+    if (st->m_k != k) { st->M = (int64_t)p_nbr[N2vPhys(S.seq.parent, k)]; st->m_k = k; }
+    const unsigned long long ev = __ballot(e.live && tid > resolved && e.cid >= st->M);
+    int64_t cf = 0;
+    const int32_t f = N2vBigFirst(S, phase, wv, lane, ev, e.cid, &cf);
+    if (f < 0) break;                          // every remaining child is below pn[k]
+    // first k' >= k with pn[k'] >= cf (the cursor skips the smaller entries)
+    bool hit = false;
+    for (;;) {
+      const int32_t kk = k + tid;
+      int64_t pv = 0;
+      if (kk < np) pv = (int64_t)p_nbr[N2vPhys(S.seq.parent, kk)];
+      const unsigned long long ge = __ballot(kk < np && pv >= cf);
+      int64_t mv = 0;
+      const int32_t g = N2vBigFirst(S, phase, wv, lane, ge, pv, &mv);
+      if (g >= 0) { k += g; st->M = mv; st->m_k = k; hit = true; break; }
+      k += 64 * kN2vBigWaves;
+      if (k >= np) { k = np; break; }
+    }
+    if (hit && st->M == cf) { if (tid == f) keep = true; ++k; }
+    resolved = f;                              // lanes up to and including f are resolved
+    ++events;
+  }
+  st->k = k;
+  *events_out = events;
+  const float wq = !e.live ? 0.f : keep ? e.w : N2vScaled(a, e.w, e.cid == parent);
+  // ---- running sums.  Every wave from w0 on sums its entries in the binade of
+  // `carry`; the totals are exchanged; the waves before the first one that cannot do
+  // that (a tie, a negative entry, the sum leaving the binade inside it) are final,
+  // that wave runs its 64 entries from its real carry, and the rest start over from
+  // its last sum.
+  float carry = st->acc;
+  int w0 = 0;
+  float sum = 0.f, before = 0.f;
+  for (;;) {
+    const uint32_t cb = __float_as_uint(carry);
+    const uint32_t ex = cb >> 23;
+    const uint32_t bb = cb & 0xFF800000u;
+    const float B = __uint_as_float(bb);
+    const float t = __fadd_rn(B, wq);
+    const float err = __fsub_rn(wq, __fsub_rn(t, B));
+    const float half_ulp = __uint_as_float(bb - (24u << 23));
+    const bool range_ok = ex >= 30u && ex < 254u;
+    const bool active = wv >= w0;
+    const bool ok = wq >= 0.f && fabsf(err) != half_ulp && t < __fadd_rn(B, B);
+    const int32_t n = active && ok ? (int32_t)(__float_as_uint(t) - bb) : 0;
+    const int32_t incl = WaveInclusiveAdd(n, lane);                 // < 2^29
+    const bool bad = active && (!range_ok || __ballot(!ok) != 0);
+    const int b = *phase & 1;
+    ++*phase;
+    if (lane == 63) S.x_val[b][wv] = ((int64_t)(bad ? 1 : 0) << 32) | (uint32_t)incl;
+    __syncthreads();
+    const int64_t mine = lane < kN2vBigWaves ? S.x_val[b][lane] : 0;
+    int64_t pre = (int64_t)(uint32_t)mine;                          // inclusive over the waves
+#pragma unroll
+    for (int d = 1; d < kN2vBigWaves; d <<= 1) {
+      const int64_t up = __shfl_up(pre, d);
+      if (lane >= d) pre += up;
+    }
+    const int64_t off0 = (int64_t)(cb - bb);
+    const unsigned long long probw =
+        __ballot(lane < kN2vBigWaves && lane >= w0 &&
+                 ((mine >> 32) != 0 || off0 + pre >= (1 << 23)));
+    const int pw = probw != 0 ? __ffsll((long long)probw) - 1 : kN2vBigWaves;
+    const int64_t my_before = (wv == 0 ? 0 : __shfl(pre, wv - 1)) + off0;
+    if (active && wv < pw) {
+      before = __uint_as_float(bb + (uint32_t)my_before);
+      sum = __uint_as_float(bb + (uint32_t)(my_before + incl));
+    }
+    if (pw == kN2vBigWaves) {
+      st->acc = __uint_as_float(bb + (uint32_t)(__shfl(pre, kN2vBigWaves - 1) + off0));
+      break;
+    }
+    const int64_t pw_before = (pw == 0 ? 0 : __shfl(pre, pw - 1)) + off0;
+    if (wv == pw) {
+      before = pw == w0 ? carry : __uint_as_float(bb + (uint32_t)pw_before);
+      if (!ChunkScanBinade(before, wq, lane, &sum)) sum = ChunkScan(before, wq, lane);
+      if (lane == 63) S.hand = sum;            // dead lanes add 0: lane 63 has the wave's last sum
+    }
+    __syncthreads();
+    carry = S.hand;
+    w0 = pw + 1;
+    if (w0 == kN2vBigWaves) { st->acc = carry; break; }
+  }
+  *before_out = before;
+  *sum_out = sum;
+}
+
+// Lane per walker: queue the walkers whose step `s` has a long child list.
+__global__ __launch_bounds__(256) void N2vClassifyKernel(const WalkArgs a) {
+  __shared__ int32_t base;
+  __shared__ int32_t wave_cnt[4];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int32_t s = a.step_begin;
+  const int64_t L = a.walk_len + 1;
+  bool big = false;
+  if (i < a.n) {
+    const int64_t cur = s == 0 ? a.nodes[i] : a.out[i * L + s];
+    N2vList l;
+    N2vBuildList(&l, a.g, FindRow(a.g, (uint64_t)cur), a.edge_types + s * a.k, a.k);
+    big = l.total >= a.big_threshold;
+  }
+  const unsigned long long m = __ballot(big);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) wave_cnt[wv] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int32_t tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    base = tot > 0 ? atomicAdd(a.big_count, tot) : 0;
+  }
+  __syncthreads();
+  if (big) {
+    int32_t off = base;
+    for (int w = 0; w < wv; ++w) off += wave_cnt[w];
+    off += __popcll(m & ((1ull << lane) - 1));
+    a.big_queue[off] = (int32_t)i;
+  }
+}
+
+__global__ __launch_bounds__(64 * kN2vBigWaves) void N2vBigStepKernel(const WalkArgs a) {
+  __shared__ N2vBigLds S;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int32_t s = a.step_begin;
+  const int64_t L = a.walk_len + 1;
+  const int32_t queued = a.big_count[0];
+  int phase = 0;
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) S.next = atomicAdd(a.big_count + 1, 1);
+    __syncthreads();
+    const int64_t qe = S.next;
+    if (qe >= queued) break;
+    const int64_t i = a.big_queue[qe];
+    const int64_t cur = s == 0 ? a.nodes[i] : a.out[i * L + s];
+    const int64_t parent = s == 0 ? cur : a.out[i * L + s - 1];
+    if (threadIdx.x == 0) {
+      const int32_t* et = a.edge_types + s * a.k;
+      const int32_t* pet = s > 0 ? a.edge_types + (s - 1) * a.k : et;
+      N2vBuildList(&S.seq.child, a.g, FindRow(a.g, (uint64_t)cur), et, a.k);
+      N2vBuildList(&S.seq.parent, a.g, s > 0 ? FindRow(a.g, (uint64_t)parent) : -1, pet, a.k);
+    }
+    __syncthreads();
+    const int32_t nc = S.seq.child.total, np = S.seq.parent.total;
+    constexpr int32_t kRound = 64 * kN2vBigWaves;
+    const int32_t rounds = (nc + kRound - 1) / kRound;
+    int32_t sh = 0;
+    while ((rounds >> sh) > kN2vBigCk) ++sh;
+    const int32_t n_slots = rounds >> sh;
+    N2vBigState st{0, -1, 0, 0.f};
+    const bool same = N2vSameLists(S.seq.child, S.seq.parent);
+    float sum, before;
+    int32_t events;
+    bool ascending = false;
+    // the next round's entries are requested before this round is worked on
+    N2vEntry e = N2vLoad(a, S.seq, lane, nc, wv * 64), nx = e;
+    for (int32_t ri = 0; ri < rounds; ++ri) {
+      if (ri + 1 < rounds) nx = N2vLoad(a, S.seq, lane, nc, (ri + 1) * kRound + wv * 64);
+      N2vBigRound(a, S, &phase, wv, lane, parent, np, same, e, &st, &sum, &before, &events);
+      e = nx;
+      if (ri == 0 && events > 16 * kN2vBigWaves) { ascending = true; break; }
+      if (((ri + 1) & ((1 << sh) - 1)) == 0 && threadIdx.x == 0) {
+        S.ck_acc[((ri + 1) >> sh) - 1] = st.acc;
+        S.ck_k[((ri + 1) >> sh) - 1] = st.k;
+      }
+    }
+    int64_t result = a.default_node;
+    if (ascending) {
+      // every child moves the parent cursor: the lane-0 automaton of one wave does it
+      if (wv == 0) result = N2vStepSequential(a, S.seq, lane, parent, i, s);
+    } else {
+      const float total = st.acc;
+      const double u = RngDraw(a.seed, a.call_id + (uint32_t)s, kDomainWalk, (uint64_t)i, 0);
+      const double r = ScaleDraw(u, 0.f, total);
+      __syncthreads();
+      int32_t first = 0;
+      if (a.g.monotone && a.p > 0.f && a.q > 0.f) {
+        first = n_slots;
+        for (int32_t base = 0; base < n_slots; base += 64) {
+          const int32_t idx = base + lane;
+          const unsigned long long gt = __ballot(idx < n_slots && (double)S.ck_acc[idx] > r);
+          if (gt != 0) { first = base + __ffsll((long long)gt) - 1; break; }
+        }
+      }
+      st.acc = first == 0 ? 0.f : S.ck_acc[first - 1];
+      st.k = first == 0 ? 0 : S.ck_k[first - 1];
+      st.m_k = -1;
+      bool found = false;
+      for (int32_t ri = first << sh; ri < rounds && !found; ++ri) {
+        e = N2vLoad(a, S.seq, lane, nc, ri * kRound + wv * 64);
+        N2vBigRound(a, S, &phase, wv, lane, parent, np, same, e, &st, &sum, &before, &events);
+        float prev = __shfl_up(sum, 1);
+        if (lane == 0) prev = before;
+        const unsigned long long hit = __ballot(e.live && (double)prev <= r && r < (double)sum);
+        int64_t hv = 0;
+        if (N2vBigFirst(S, &phase, wv, lane, hit, e.cid, &hv) >= 0) { found = true; result = hv; }
+      }
+      // no interval holds r (total == 0): RandomSelect's fall-through ends on the last element
+      if (!found) result = (int64_t)(a.g.nbr + S.seq.child.row_ptr)[N2vPhys(S.seq.child, nc - 1)];
+    }
+    if (threadIdx.x == 0) a.out[i * L + s + 1] = result;
   }
 }
 
@@ -1181,6 +1639,15 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
   a.g = g->view; a.seed = seed; a.call_id = call_id; a.nodes = nodes_dev;
   a.edge_types = et_dev; a.out = out_dev; a.n = n; a.default_node = default_node;
   a.k = k; a.walk_len = walk_len; a.p = p; a.q = q;
+  {
+    // w / p by an exact reciprocal when p and q are powers of two (both then are the
+    // correctly rounded quotient)
+    int ep = 0, eq = 0;
+    const bool p2 = p > 0.f && std::isfinite(p) && std::frexp(p, &ep) == 0.5f && ep > -100 && ep < 100;
+    const bool q2 = q > 0.f && std::isfinite(q) && std::frexp(q, &eq) == 0.5f && eq > -100 && eq < 100;
+    a.inv_p = p2 && q2 ? 1.0f / p : 0.f;
+    a.inv_q = p2 && q2 ? 1.0f / q : 0.f;
+  }
   const int block = 256;
   const float kEps = 1.0e-6;
   // random_walk_op.cc:281: fabs(p_ - 1.0) <= kEps && fabs(q_ - 1.0) <= kEps
@@ -1193,7 +1660,30 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
                          st, a);
     }
   } else {
-    if (g_n2v_wave == 2) {
+    if (g_n2v_wave >= 3 && walk_len > 0 && n < (1ll << 31)) {
+      // step by step: classify, the short lists one wave per walker, the long ones one
+      // workgroup per walker from a queue handed out by an atomic counter
+      int32_t* q = nullptr;
+      const size_t q_bytes = ((size_t)n * 4 + 15) & ~(size_t)15;
+      EG_HIP(hipMallocAsync((void**)&q, q_bytes + (size_t)walk_len * 8, st));
+      int32_t* counters = (int32_t*)((uint8_t*)q + q_bytes);
+      EG_HIP(hipMemsetAsync(counters, 0, (size_t)walk_len * 8, st));
+      a.big_threshold = g_n2v_big > 0 ? g_n2v_big : (1 << 30);
+      a.big_queue = q;
+      for (int32_t s = 0; s < walk_len; ++s) {
+        a.step_begin = s; a.step_end = s + 1;
+        a.big_count = counters + 2 * s;
+        if (g_n2v_big > 0)
+          hipLaunchKernelGGL(N2vClassifyKernel, dim3((unsigned)((n + block - 1) / block)), dim3(block),
+                             0, st, a);
+        hipLaunchKernelGGL(Node2VecWaveKernel<true>, dim3(GridFor(n * 64, block)), dim3(block), 0,
+                           st, a);
+        if (g_n2v_big > 0)
+          hipLaunchKernelGGL(N2vBigStepKernel, dim3(512), dim3(64 * kN2vBigWaves), 0, st, a);
+      }
+      EG_HIP(hipGetLastError());
+      EG_HIP(hipFreeAsync(q, st));
+    } else if (g_n2v_wave >= 2) {
       hipLaunchKernelGGL(Node2VecWaveKernel<true>, dim3(GridFor(n * 64, block)), dim3(block), 0,
                          st, a);
     } else if (g_n2v_wave != 0) {

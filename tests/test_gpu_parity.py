@@ -969,7 +969,7 @@ def test_dedup_split_dense_id_table(EA, O, torch_cuda):
 
 
 @pytest.mark.parametrize("ascending", [False, True], ids=["storage_order", "ascending_lists"])
-@pytest.mark.parametrize("wave", [2, 1, 0], ids=["n2v_parallel", "n2v_wave", "n2v_lane"])
+@pytest.mark.parametrize("wave", [3, 2, 1, 0], ids=["n2v_stepwise", "n2v_parallel", "n2v_wave", "n2v_lane"])
 def test_node2vec_long_lists_both_kernels(EA, O, torch_cuda, wave, ascending):
     """node2vec steps whose child AND parent lists span several 256-entry LDS
     chunks (hubs of 700-900 neighbours that point at each other), with two
@@ -1009,6 +1009,7 @@ def test_node2vec_long_lists_both_kernels(EA, O, torch_cuda, wave, ascending):
     et = [[0, 1], [1], [0, 1], [1, 0], [0], [0, 1], [1, 0]]
     et_arr = [e + [e[-1]] * (2 - len(e)) for e in et]      # pad to k = 2 (repeats a type)
     _lib.lib().euler_gpu_set_tuning(7, wave)
+    _lib.lib().euler_gpu_set_tuning(25, 256)      # stepwise: these hubs go to the workgroup kernel
     try:
         G.set_seed(6)
         for p, q in ((0.25, 4.0), (2.0, 0.5)):
@@ -1018,6 +1019,70 @@ def test_node2vec_long_lists_both_kernels(EA, O, torch_cuda, wave, ascending):
             assert np.array_equal(got, want), (p, q)
     finally:
         _lib.lib().euler_gpu_set_tuning(7, 2)
+        _lib.lib().euler_gpu_set_tuning(25, 8192)
+
+
+@pytest.mark.parametrize("mode", ["stepwise", "stepwise_all_big", "one_launch"])
+@pytest.mark.parametrize("weights", ["random", "dyadic", "zeros", "ascending"])
+def test_node2vec_hub_rows_checkpointed_sums(EA, O, torch_cuda, weights, mode):
+    """node2vec on hubs of 33 000 - 70 000 neighbours.  Default (key 7 = 3): the walk
+    is launched per step and these rows go to the workgroup kernel (1 024 entries per
+    round, parent cursor and running sum carried across 16 waves); "stepwise_all_big"
+    sends every row of 2+ entries there, "one_launch" (key 7 = 2) is one wave per
+    walker.  Both keep a (running sum, parent cursor) checkpoint per 2^sh rounds and
+    replay only the rounds the draw lands in; inside a round the f32 running sums come
+    from the integer scan over the mantissa when the round stays in one binade without
+    a rounding tie (walk_kernels.hip: ChunkScanBinade) and from the add chain
+    otherwise.  Dyadic weights (multiples of 1/8) make ties and exact sums common,
+    random weights make them rare, all-zero rows take RandomSelect's fall-through
+    (random_walk_op.cc:83-138), ascending lists make every child move the parent
+    cursor (handed to the sequential automaton)."""
+    torch = torch_cuda
+    from euler_amd import _lib
+    rng = np.random.default_rng(77)
+    n = 3000
+    ids = np.arange(1, n + 1).astype(np.uint64)
+    deg = rng.integers(1, 9, size=n)
+    hubs = np.arange(0, 5)
+    deg[hubs] = [41000, 70000, 33000, 52000, 36000]
+    seg = np.zeros(n + 1, np.int64)
+    seg[1:] = np.cumsum(deg)
+    E = int(seg[-1])
+    nbr = rng.choice(ids, E).astype(np.uint64)
+    for h in hubs:
+        b, e = seg[h], seg[h + 1]
+        nbr[b:e] = np.where(rng.random(e - b) < 0.5, rng.choice(ids[hubs], e - b), nbr[b:e])
+    # every small row points at a hub first
+    nbr[seg[5:-1]] = rng.choice(ids[hubs], n - 5)
+    if weights in ("random", "ascending"):
+        w = (rng.random(E) * 7.5 + 0.5).astype(np.float32)
+    elif weights == "dyadic":
+        w = (rng.integers(1, 64, E) / 8.0).astype(np.float32)
+    else:
+        w = (rng.random(E) * 2).astype(np.float32)
+        w[seg[1]:seg[2]] = 0            # one hub row of zero weights
+        w[rng.random(E) < 0.3] = 0
+    if weights == "ascending":
+        for x in range(n):
+            b, e = seg[x], seg[x + 1]
+            o = np.argsort(nbr[b:e], kind="stable")
+            nbr[b:e], w[b:e] = nbr[b:e][o], w[b:e][o]
+    csr = O.csr_from_raw(ids, seg, nbr, w, 1)
+    G, OG = gpu_graph(EA, csr), O.OracleGraph(csr)
+    starts = np.concatenate([ids[hubs], rng.choice(ids, 200), [2, 2, 0]]).astype(np.int64)
+    L = 5
+    et = [[0]] * L
+    G.set_seed(9)
+    _lib.lib().euler_gpu_set_tuning(7, 2 if mode == "one_launch" else 3)
+    _lib.lib().euler_gpu_set_tuning(25, 2 if mode == "stepwise_all_big" else 8192)
+    try:
+        for p_, q_ in ((0.25, 4.0), (2.0, 0.5), (3.0, 0.7), (1.0, 1.0)):
+            got = t2n(G.random_walk(torch.as_tensor(starts).cuda(), et, p_, q_, -1, call_id=60))
+            want = OG.random_walk(9, 60, starts, et, L, p_, q_, -1)
+            assert np.array_equal(got, want), (weights, mode, p_, q_)
+    finally:
+        _lib.lib().euler_gpu_set_tuning(7, 2)
+        _lib.lib().euler_gpu_set_tuning(25, 8192)
 
 
 def test_concurrent_callers_share_a_stream(EA, O, torch_cuda, big_pair):
