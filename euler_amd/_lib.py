@@ -196,6 +196,7 @@ SIGNATURES = {
     "euler_op_run_sample_nb_post": (C.c_int64, [vp, C.c_uint64, C.c_uint32, u64p, C.c_int64,
                                                 i32p, C.c_int32, C.c_int32, C.c_char_p, i32p,
                                                 u64p, f32p, i32p]),
+    "euler_gpu_random_walk_stats": (C.c_int, [C.POINTER(C.c_uint64), C.c_int32]),
     "euler_gpu_random_walk_algo_bytes": (C.c_int, [vp, vp, vp, C.c_int64, i32p, C.c_int32, C.c_int32,
                                                    C.c_float, C.c_float, C.POINTER(C.c_double)]),
     "euler_gpu_sage_blocks_workspace": (C.c_size_t, [C.c_int64, i32p, C.c_int32]),

@@ -672,9 +672,9 @@ __device__ __forceinline__ int32_t N2vPhys(const N2vList& L, int32_t j) {
 }
 
 // ------------------------------------------------------------------------
-// node2vec, one wave per walker, the two-cursor walk done by the WHOLE wave
-// (tuning key 7 = 2, default).  BuildWeights (random_walk_op.cc:140-168) moves a
-// parent cursor k forward only: child j is resolved against pn[k] -
+// node2vec, the two-cursor walk done by the WHOLE wave (tuning key 7 >= 2).
+// BuildWeights (random_walk_op.cc:140-168) moves a parent cursor k forward only:
+// child j is resolved against pn[k] -
 //   cn[j] <  pn[k] : "not a common neighbour", weight / q (or / p), j++
 //   cn[j] == pn[k] : common neighbour, weight kept,            j++, k++
 //   cn[j] >  pn[k] : k++ and look again
@@ -683,34 +683,53 @@ __device__ __forceinline__ int32_t N2vPhys(const N2vList& L, int32_t j) {
 // child that is >= pn[k] is an event: the wave then scans pn from k in 64-entry
 // steps for the first entry >= that child (another ballot) and goes on.  On lists
 // in storage order - what the reference's `outV` returns and what this backend's
-// synthetic graphs hold - pn[k] soon sits on a large id and events are rare: the
-// step costs (children + parents) / 64 loads instead of one LDS round trip per
-// entry on lane 0.  Lists that ARE ascending make every child an event; a step
-// whose first chunk resolves fewer than 4 children per event is handed to the
-// lane-0 automaton below (same results, different speed).
-// The running sums stay the reference's sequential f32 adds: a lane-shifting DPP
-// chain (one v_add per entry, see layer_kernels.hip: ChunkChain) that leaves every
-// lane its inclusive sum; pass 1 yields the total, pass 2 stops at the first
-// interval holding r - the index RandomSelect's bisection of those sums returns
-// (its last element when the total is 0).
+// synthetic graphs hold - pn[k] soon sits on a large id and events are rare (3 per
+// step on the metric graph, after which the parent list is used up).  Lists that
+// ARE ascending make every child an event; a step whose first chunk has many is
+// handed to the lane-0 automaton (same results, different speed).
+//
+// A lane holds kN2vR CONSECUTIVE child entries (a chunk is 64 * kN2vR entries): the
+// per-chunk work - ballots, the scan across lanes, the loop - is paid once per
+// four entries, and the kernel is bound by instruction issue (a 64-entry chunk
+// cost ~200 wave instructions).
+//
+// The running sums stay the reference's sequential f32 adds, mostly without doing
+// them one by one.  For a carry m * ulp in [2^e, 2^(e+1)) and carry + d below
+// 2^(e+1), fl(carry + d) = (m + n) * ulp with n = d / ulp rounded to nearest - the
+// same n for every m unless d / ulp ends in exactly .5 (then the tie goes to the
+// even m + n and depends on m).  So with no such tie and no sum reaching 2^(e+1),
+// the f32 chain IS an integer running sum of the n's over the mantissa.  n comes
+// out of the adder itself: fl(2^e + d) has mantissa offset n (2^e is an even m, and
+// without a tie the parity does not matter); d - (fl(2^e + d) - 2^e) is exact and
+// equals +-ulp/2 exactly on a tie.  A lane the integer sum cannot pass - the sum
+// leaves the binade there, a tie, a negative entry, a carry of 0 - does its entries
+// by real f32 adds from its predecessor's sum and the lanes after it start over
+// from there (binade crossings: ~20 per list); a chunk with more than four such
+// lanes runs the add chain lane after lane (a row_shr DPP chain).  On the metric
+// graph's hub rows 92 % of the 64-entry chunks need no real add at all
+// (tools/n2v_binade_model.py restates the scheme in numpy against the sequential
+// sums).
+//
+// Pass 1 runs the chunks once for the total and leaves (running sum, parent cursor)
+// checkpoints in LDS - one per 2^sh chunks; the draw r then names the first
+// checkpoint whose sum exceeds it, and only the chunks after the previous
+// checkpoint are run again to find the entry (the sums never decrease when the
+// weights, p and q are non-negative; otherwise the second pass starts from the
+// first entry as the reference's scan would).  That entry is the index
+// RandomSelect's bisection of the sums returns (its last element when the total
+// is 0).
 // ------------------------------------------------------------------------
-__device__ __forceinline__ float ChunkScan(float carry, float d, int lane) {
-  float dp = lane == 0 ? __fadd_rn(carry, d) : d;
-  float s = dp;
-#pragma unroll
-  for (int row = 0; row < 4; ++row) {
-    if (row > 0) {
-      const float prev = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 16 * row - 1));
-      if (lane == 16 * row) dp = __fadd_rn(prev, d);
-      s = dp;
-    }
-#pragma unroll
-    for (int t = 1; t < 16; ++t)
-      s = __fadd_rn(__int_as_float(__builtin_amdgcn_update_dpp(
-                        0, __float_as_int(s), 0x111 /* row_shr:1 */, 0xf, 0xf, true)),
-                    dp);
-  }
-  return s;          // lane t: carry + d[0] + ... + d[t], added in that order
+constexpr int kN2vR = 4;
+constexpr int kN2vChunkR = 64 * kN2vR;
+
+// Diagnostic counters of the node2vec kernels (euler_gpu_random_walk_stats): 0 steps by
+// the whole-wave path, 1 their child entries, 2 steps handed to the sequential
+// automaton, 3 their child entries, 4 moves of the parent cursor, 5 chunks / wave-chunks
+// whose running sums needed the add chain, 6 steps by the workgroup kernel, 7 their entries.
+__device__ unsigned long long g_n2v_stats[8];
+__device__ int g_n2v_stats_on;          // set by euler_gpu_random_walk_stats(.., reset = 2)
+__device__ __forceinline__ void N2vCount(int slot, unsigned long long v) {
+  if (g_n2v_stats_on) atomicAdd(&g_n2v_stats[slot], v);
 }
 
 __device__ __forceinline__ int64_t ReadLane64(int64_t v, int src) {
@@ -719,9 +738,14 @@ __device__ __forceinline__ int64_t ReadLane64(int64_t v, int src) {
   return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
-// Inclusive integer sum over the wave: four row_shr steps inside each row of 16
-// lanes, then the three row totals added to the rows above them.
-__device__ __forceinline__ int32_t WaveInclusiveAdd(int32_t v, int lane) {
+__device__ __forceinline__ float ReadLaneF(float v, int src) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
+// Inclusive integer sum over the wave (mod 2^32): four row_shr steps inside each
+// row of 16 lanes, then the three row totals added to the rows above them.
+__device__ __forceinline__ uint32_t WaveInclusiveAdd(uint32_t x, int lane) {
+  int32_t v = (int32_t)x;
   v += __builtin_amdgcn_update_dpp(0, v, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
   v += __builtin_amdgcn_update_dpp(0, v, 0x112 /* row_shr:2 */, 0xf, 0xf, true);
   v += __builtin_amdgcn_update_dpp(0, v, 0x114 /* row_shr:4 */, 0xf, 0xf, true);
@@ -729,29 +753,42 @@ __device__ __forceinline__ int32_t WaveInclusiveAdd(int32_t v, int lane) {
   const int32_t t0 = __builtin_amdgcn_readlane(v, 15);
   const int32_t t1 = __builtin_amdgcn_readlane(v, 31);
   const int32_t t2 = __builtin_amdgcn_readlane(v, 47);
-  return v + (lane >= 16 ? t0 : 0) + (lane >= 32 ? t1 : 0) + (lane >= 48 ? t2 : 0);
+  return (uint32_t)(v + (lane >= 16 ? t0 : 0) + (lane >= 32 ? t1 : 0) + (lane >= 48 ? t2 : 0));
 }
 
-// The sequential f32 running sums of a chunk WITHOUT the 63-deep add chain, when
-// the chunk stays inside the binade of its carry.  For carry = m * ulp in
-// [2^e, 2^(e+1)) and carry + d below 2^(e+1), fl(carry + d) = (m + n) * ulp with
-// n = d / ulp rounded to nearest - the same n for every m unless d / ulp ends in
-// exactly .5 (then the tie goes to the even m + n and depends on m).  So with no
-// such tie in the chunk and no sum reaching 2^(e+1), the f32 chain IS an integer
-// running sum of the n's over the mantissa, which a wave does in ten instructions.
-// n comes out of the adder itself: fl(2^e + d) has mantissa offset n (2^e is an
-// even m, and without a tie the parity does not matter); d - (fl(2^e + d) - 2^e) is
-// exact and equals +-ulp/2 exactly on a tie.  Returns false - the caller runs the
-// add chain - on a tie, a negative / NaN entry, a sum that leaves the binade, or a
-// carry that is zero / tiny / huge.  On the metric graph's hub rows 92 % of the
-// chunks take this path (tools/n2v_binade_model.py restates it in numpy against
-// the sequential sums).
-__device__ __forceinline__ bool ChunkScanBinade(float carry, float d, int lane, float* sum) {
-  // A lane the integer sum cannot pass - the sum leaves the binade there, a tie, a
-  // negative entry, a carry of 0 - gets its sum from one real f32 add of its
-  // predecessor's; the lanes after it start over from that sum.  A few such lanes
-  // per chunk (binade crossings: ~20 per list), else the caller's add chain.
-  float out = 0.f;
+// The add chain: lane after lane, a lane's kN2vR entries one after the other.
+// *cin = the sum before this lane's first entry; returns the sum after the last lane.
+__device__ __forceinline__ float ChunkChainVec(float carry, const float (&d)[kN2vR], int lane,
+                                               float* cin_out) {
+  float s = 0.f, cin = 0.f, my_rin = 0.f;
+#pragma unroll
+  for (int row = 0; row < 4; ++row) {
+    const float rin = row == 0 ? carry : ReadLaneF(s, 16 * row - 1);
+    if ((lane >> 4) == row) my_rin = rin;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      // after iteration t the first t + 1 lanes of this row hold their sums; the
+      // rows before it recompute theirs unchanged
+      float in = __int_as_float(__builtin_amdgcn_update_dpp(
+          0, __float_as_int(s), 0x111 /* row_shr:1 */, 0xf, 0xf, true));
+      if ((lane & 15) == 0) in = my_rin;
+      cin = in;
+      float x = in;
+#pragma unroll
+      for (int r = 0; r < kN2vR; ++r) x = __fadd_rn(x, d[r]);
+      s = x;
+    }
+  }
+  *cin_out = cin;
+  return ReadLaneF(s, 63);
+}
+
+// Running sums of one chunk: *cin = the sum before this lane's first entry (its
+// entries' sums follow by kN2vR adds); returns the sum after the chunk.
+__device__ __forceinline__ float WaveSumsVec(float carry, const float (&d)[kN2vR], int lane,
+                                             float* cin_out) {
+  const float carry0 = carry;
+  float cin = 0.f, lout = 0.f;
   int start = 0;
   for (int iter = 0; iter < 4; ++iter) {
     const uint32_t cb = __float_as_uint(carry);
@@ -759,28 +796,41 @@ __device__ __forceinline__ bool ChunkScanBinade(float carry, float d, int lane, 
     const bool range_ok = e >= 30u && e < 254u;
     const uint32_t bb = cb & 0xFF800000u;
     const float B = __uint_as_float(bb);
-    const float t = __fadd_rn(B, d);
-    const float err = __fsub_rn(d, __fsub_rn(t, B));
+    const float twoB = __fadd_rn(B, B);
     const float half_ulp = __uint_as_float(bb - (24u << 23));
+    uint32_t N = 0;
+    bool okl = true;
+#pragma unroll
+    for (int r = 0; r < kN2vR; ++r) {
+      const float t = __fadd_rn(B, d[r]);
+      const float err = __fsub_rn(d[r], __fsub_rn(t, B));
+      const bool ok = d[r] >= 0.f && fabsf(err) != half_ulp && t < twoB;
+      okl = okl && ok;
+      N += ok ? __float_as_uint(t) - bb : 0u;        // each < 2^23
+    }
     const bool active = lane >= start;
-    const bool ok = d >= 0.f && fabsf(err) != half_ulp && t < __fadd_rn(B, B);
-    const int32_t n = active && ok ? (int32_t)(__float_as_uint(t) - bb) : 0;   // < 2^23
-    const int32_t off = (int32_t)(cb - bb) + WaveInclusiveAdd(n, lane);        // < 2^30
+    if (!active) N = 0;
+    // <= (2^23 - 1) * (64 * 4 + 1): fits 32 bits unsigned
+    const uint32_t off_out = (cb - bb) + WaveInclusiveAdd(N, lane);
     const unsigned long long prob =
-        __ballot(active && (!range_ok || !ok || off >= (1 << 23)));
+        __ballot(active && (!range_ok || !okl || off_out >= (1u << 23)));
     const int c = prob != 0 ? __ffsll((long long)prob) - 1 : 64;
-    if (active && lane < c) out = __uint_as_float(bb + (uint32_t)off);
-    if (c == 64) { *sum = out; return true; }
-    const float before = c == start
-                             ? carry
-                             : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(out), c - 1));
-    const float dc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), c));
-    carry = __fadd_rn(before, dc);
-    if (lane == c) out = carry;
+    if (active && lane < c) {
+      cin = __uint_as_float(bb + off_out - N);
+      lout = __uint_as_float(bb + off_out);
+    }
+    if (c == 64) { *cin_out = cin; return ReadLaneF(lout, 63); }
+    const float cin_c = c == start ? carry : ReadLaneF(lout, c - 1);
+    float x = cin_c;
+#pragma unroll
+    for (int r = 0; r < kN2vR; ++r) x = __fadd_rn(x, ReadLaneF(d[r], c));
+    if (lane == c) { cin = cin_c; lout = x; }
+    carry = x;
     start = c + 1;
-    if (start == 64) { *sum = out; return true; }
+    if (start == 64) { *cin_out = cin; return carry; }
   }
-  return false;
+  if (lane == 0) N2vCount(5, 1);
+  return ChunkChainVec(carry0, d, lane, cin_out);
 }
 
 // BuildWeights' weight of a child that is not a common neighbour (random_walk_op.cc:
@@ -791,28 +841,57 @@ __device__ __forceinline__ float N2vScaled(const WalkArgs& a, float w, bool is_p
   return is_parent ? __fdiv_rn(w, a.p) : __fdiv_rn(w, a.q);
 }
 
-// One lane's entry of a 64-entry chunk of the child list (ids, and the weight as the
-// difference of the row's running sums - what `outV` hands the reference).
-struct N2vEntry {
-  int64_t cid;
-  float w;
-  bool live;
+// A lane's kN2vR consecutive entries of the child list from logical entry jl (ids,
+// and the weights as differences of the row's running sums - what `outV` hands the
+// reference).
+struct N2vVec {
+  int64_t cid[kN2vR];
+  float w[kN2vR];
+  uint32_t live;                  // bit r: the entry exists
 };
 
-__device__ __forceinline__ N2vEntry N2vLoad(const WalkArgs& a, const N2vLds& S, int lane,
-                                            int32_t nc, int32_t j0) {
-  N2vEntry e;
-  const int32_t j = j0 + lane;
-  e.live = j < nc;
-  e.cid = 0;
-  e.w = 0.f;
-  if (e.live) {
-    const float* c_nw = a.g.prefix_w + S.child.row_ptr;
-    const int32_t ph = N2vPhys(S.child, j);
-    e.cid = (int64_t)(a.g.nbr + S.child.row_ptr)[ph];
-    e.w = __fsub_rn(c_nw[ph], ph == 0 ? 0.f : c_nw[ph - 1]);
+__device__ __forceinline__ N2vVec N2vLoadVec(const WalkArgs& a, const N2vList& L, int32_t nc,
+                                             int32_t jl) {
+  N2vVec v;
+  v.live = 0;
+  const float* c_nw = a.g.prefix_w + L.row_ptr;
+  const uint64_t* c_nbr = a.g.nbr + L.row_ptr;
+  if (L.n_seg == 1 && jl + kN2vR <= nc) {
+    // one listed type (or one non-empty): the entries are adjacent in the row
+    const int32_t ph = L.seg_b[0] + jl;
+    float prev = ph == 0 ? 0.f : c_nw[ph - 1];
+#pragma unroll
+    for (int r = 0; r < kN2vR; ++r) {
+      v.cid[r] = (int64_t)c_nbr[ph + r];
+      const float x = c_nw[ph + r];
+      v.w[r] = __fsub_rn(x, prev);
+      prev = x;
+    }
+    v.live = (1u << kN2vR) - 1;
+  } else {
+#pragma unroll
+    for (int r = 0; r < kN2vR; ++r) {
+      v.cid[r] = 0;
+      v.w[r] = 0.f;
+      if (jl + r < nc) {
+        const int32_t ph = N2vPhys(L, jl + r);
+        v.cid[r] = (int64_t)c_nbr[ph];
+        v.w[r] = __fsub_rn(c_nw[ph], ph == 0 ? 0.f : c_nw[ph - 1]);
+        v.live |= 1u << r;
+      }
+    }
   }
-  return e;
+  return v;
+}
+
+// lane-local pick of entry r.  Written as a masked OR so that it stays a select
+// network: an if-chain over e.cid[q] is folded into a dynamically indexed load,
+// which puts the whole struct into scratch / LDS.
+__device__ __forceinline__ int64_t N2vPick(const N2vVec& e, int r) {
+  uint64_t x = 0;
+#pragma unroll
+  for (int q = 0; q < kN2vR; ++q) x |= (uint64_t)e.cid[q] & (r == q ? ~0ull : 0ull);
+  return (int64_t)x;
 }
 
 // The parent cursor: k, and pn[k] once it has been read (a run of chunks whose
@@ -823,31 +902,35 @@ struct N2vCursor {
   int64_t M;
 };
 
-// One chunk with the parent cursor at *c: every lane's weight after BuildWeights'
-// comparison and the running sums (lane t: acc + w[0] + ... + w[t] in that order).
-// *events = moves of the parent cursor that needed a scan.
-__device__ __forceinline__ float N2vChunk(const WalkArgs& a, const N2vLds& S, int lane,
-                                          int64_t parent, int32_t np, bool same_lists,
-                                          const N2vEntry& e, float acc, N2vCursor* c,
-                                          int32_t* events_out) {
-  const uint64_t* p_nbr = a.g.nbr + S.parent.row_ptr;
+// BuildWeights' comparisons for one chunk: returns the mask of this lane's entries
+// that are common neighbours; *events = moves of the parent cursor.
+__device__ __forceinline__ uint32_t N2vEventsWave(const WalkArgs& a, const N2vList& P, int lane,
+                                                  int32_t np, const N2vVec& e, N2vCursor* c,
+                                                  int32_t* events_out) {
+  const uint64_t* p_nbr = a.g.nbr + P.row_ptr;
   int32_t k = c->k;
-  bool keep = same_lists;            // cn == pn entry by entry: every child is a common neighbour
-  unsigned long long todo = same_lists ? 0ull : __ballot(e.live);
+  uint32_t keep = 0;
+  int res_lane = -1, res_r = -1;    // entries up to (res_lane, res_r) are resolved
   int32_t events = 0;
-  while (todo != 0 && k < np) {
-    if (c->m_k != k) { c->M = (int64_t)p_nbr[N2vPhys(S.parent, k)]; c->m_k = k; }
-    const unsigned long long below = __ballot(e.live && e.cid < c->M);
-    const unsigned long long ev = todo & ~below;
+  while (k < np) {
+    if (c->m_k != k) { c->M = (int64_t)p_nbr[N2vPhys(P, k)]; c->m_k = k; }
+    uint32_t evm = 0;
+#pragma unroll
+    for (int r = 0; r < kN2vR; ++r)
+      if (((e.live >> r) & 1u) && (lane > res_lane || (lane == res_lane && r > res_r)) &&
+          e.cid[r] >= c->M)
+        evm |= 1u << r;
+    const unsigned long long ev = __ballot(evm != 0);
     if (ev == 0) break;                       // every remaining child is below pn[k]
     const int f = __ffsll((long long)ev) - 1;
-    const int64_t cf = ReadLane64(e.cid, f);
+    const int rsel = evm != 0 ? __ffs((int)evm) - 1 : 0;
+    const int64_t cf = ReadLane64(N2vPick(e, rsel), f);
     // first k' >= k with pn[k'] >= cf (the cursor skips the smaller entries)
     bool eq = false;
     for (;;) {
       const int32_t kk = k + lane;
       int64_t pv = 0;
-      if (kk < np) pv = (int64_t)p_nbr[N2vPhys(S.parent, kk)];
+      if (kk < np) pv = (int64_t)p_nbr[N2vPhys(P, kk)];
       const unsigned long long ge = __ballot(kk < np && pv >= cf);
       if (ge != 0) {
         const int g = __ffsll((long long)ge) - 1;
@@ -860,48 +943,65 @@ __device__ __forceinline__ float N2vChunk(const WalkArgs& a, const N2vLds& S, in
       k += 64;
       if (k >= np) { k = np; break; }
     }
-    if (eq) { if (lane == f) keep = true; ++k; }
-    // lanes up to and including f are resolved
-    todo &= f == 63 ? 0ull : (~0ull << (f + 1));
+    if (eq) { if (lane == f) keep |= 1u << rsel; ++k; }
+    res_lane = f;
+    if (lane == f) res_r = rsel;
     ++events;
   }
-  const float wq = !e.live ? 0.f : keep ? e.w : N2vScaled(a, e.w, e.cid == parent);
-  float sum;
-  if (!ChunkScanBinade(acc, wq, lane, &sum)) sum = ChunkScan(acc, wq, lane);
   c->k = k;
   *events_out = events;
-  return sum;
+  if (lane == 0 && events > 0) N2vCount(4, (unsigned long long)events);
+  return keep;
+}
+
+__device__ __forceinline__ void N2vWeights(const WalkArgs& a, const N2vVec& e, uint32_t keep,
+                                           int64_t parent, float (&d)[kN2vR]) {
+#pragma unroll
+  for (int r = 0; r < kN2vR; ++r)
+    d[r] = !((e.live >> r) & 1u) ? 0.f
+           : ((keep >> r) & 1u)  ? e.w[r]
+                                 : N2vScaled(a, e.w[r], e.cid[r] == parent);
+}
+
+// The entry whose interval [sum before, sum after) holds r, if this lane has one:
+// bit r of the result.
+__device__ __forceinline__ uint32_t N2vHits(const N2vVec& e, const float (&d)[kN2vR], float cin,
+                                            double r) {
+  uint32_t hit = 0;
+  float x = cin;
+#pragma unroll
+  for (int q = 0; q < kN2vR; ++q) {
+    const float prev = x;
+    x = __fadd_rn(x, d[q]);
+    if (((e.live >> q) & 1u) && (double)prev <= r && r < (double)x) hit |= 1u << q;
+  }
+  return hit;
 }
 
 // One step of one walker by the whole wave; returns false when the lists look
 // ascending (the caller then runs the sequential automaton).  *out = sampled id.
-// Pass 1 runs the chunks once for the total and leaves (running sum, parent cursor)
-// checkpoints in LDS - one per 2^sh chunks, at most kN2vCk of them; the draw r
-// then names the first checkpoint whose sum exceeds it, and only the chunks after
-// the previous checkpoint are run again to find the entry (the sums never
-// decrease when the weights, p and q are non-negative; otherwise the second pass
-// starts from the first entry as the reference's scan would).
 __device__ __forceinline__ bool N2vStepParallel(const WalkArgs& a, N2vLds& S, int lane,
                                                 int64_t parent, int64_t walker, int32_t step,
                                                 int64_t* out) {
   const int32_t nc = S.child.total, np = S.parent.total;
-  const int32_t nchunks = (nc + 63) >> 6;
+  const int32_t nchunks = (nc + kN2vChunkR - 1) / kN2vChunkR;
   int32_t sh = 0;
   while ((nchunks >> sh) > kN2vCk) ++sh;
   const int32_t n_slots = nchunks >> sh;
-  int32_t events;
-  float acc = 0.f;
-  N2vCursor cur{0, -1, 0};
   const bool same = N2vSameLists(S.child, S.parent);
+  int32_t events = 0;
+  float acc = 0.f, cin;
+  float d[kN2vR];
+  N2vCursor cur{0, -1, 0};
   // the next chunk's entries are requested before this chunk is worked on: a wave
   // has one dependent round trip per chunk, not two
-  N2vEntry e = N2vLoad(a, S, lane, nc, 0), nx = e;
+  N2vVec e = N2vLoadVec(a, S.child, nc, lane * kN2vR), nx = e;
   for (int32_t ci = 0; ci < nchunks; ++ci) {
-    if (ci + 1 < nchunks) nx = N2vLoad(a, S, lane, nc, (ci + 1) << 6);
-    const float sum = N2vChunk(a, S, lane, parent, np, same, e, acc, &cur, &events);
+    if (ci + 1 < nchunks) nx = N2vLoadVec(a, S.child, nc, (ci + 1) * kN2vChunkR + lane * kN2vR);
+    const uint32_t keep = same ? e.live : N2vEventsWave(a, S.parent, lane, np, e, &cur, &events);
     if (ci == 0 && nc >= 64 && events > 16) return false;   // ascending lists
-    const int32_t cnt = nc - (ci << 6) < 64 ? nc - (ci << 6) : 64;
-    acc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sum), cnt - 1));
+    N2vWeights(a, e, keep, parent, d);
+    acc = WaveSumsVec(acc, d, lane, &cin);
     if (((ci + 1) & ((1 << sh) - 1)) == 0 && lane == 0) {
       S.ck_acc[((ci + 1) >> sh) - 1] = acc;
       S.ck_k[((ci + 1) >> sh) - 1] = cur.k;
@@ -927,17 +1027,16 @@ __device__ __forceinline__ bool N2vStepParallel(const WalkArgs& a, N2vLds& S, in
   bool found = false;
   int64_t result = a.default_node;
   for (int32_t ci = first << sh; ci < nchunks && !found; ++ci) {
-    e = N2vLoad(a, S, lane, nc, ci << 6);
-    const float sum = N2vChunk(a, S, lane, parent, np, same, e, acc, &cur, &events);
-    float prev = __shfl_up(sum, 1);
-    if (lane == 0) prev = acc;
-    const unsigned long long hit = __ballot(e.live && (double)prev <= r && r < (double)sum);
+    e = N2vLoadVec(a, S.child, nc, ci * kN2vChunkR + lane * kN2vR);
+    const uint32_t keep = same ? e.live : N2vEventsWave(a, S.parent, lane, np, e, &cur, &events);
+    N2vWeights(a, e, keep, parent, d);
+    acc = WaveSumsVec(acc, d, lane, &cin);
+    const uint32_t hm = N2vHits(e, d, cin, r);
+    const unsigned long long hit = __ballot(hm != 0);
     if (hit != 0) {
       found = true;
-      result = ReadLane64(e.cid, __ffsll((long long)hit) - 1);
+      result = ReadLane64(N2vPick(e, hm != 0 ? __ffs((int)hm) - 1 : 0), __ffsll((long long)hit) - 1);
     }
-    const int32_t cnt = nc - (ci << 6) < 64 ? nc - (ci << 6) : 64;
-    acc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sum), cnt - 1));
   }
   // no interval holds r (total == 0): RandomSelect's fall-through ends on the last element
   if (!found) result = (int64_t)(a.g.nbr + S.child.row_ptr)[N2vPhys(S.child, nc - 1)];
@@ -1065,6 +1164,7 @@ __global__ __launch_bounds__(256) void Node2VecWaveKernel(const WalkArgs a) {
       int64_t sample_id = a.default_node;
       bool done = false;
       if (PAR && nc > 0) done = N2vStepParallel(a, S, lane, parent, i, s, &sample_id);
+      if (lane == 0 && nc > 0) { N2vCount(done ? 0 : 2, 1); N2vCount(done ? 1 : 3, (unsigned long long)nc); }
       if (nc > 0 && !done) sample_id = N2vStepSequential(a, S, lane, parent, i, s);
       if (lane == 0) a.out[i * L + s + 1] = sample_id;
       parent = cur;
@@ -1075,32 +1175,32 @@ __global__ __launch_bounds__(256) void Node2VecWaveKernel(const WalkArgs a) {
 }
 
 // ------------------------------------------------------------------------
-// node2vec step by step (tuning key 7 = 3, default).  A walker's step is one wave's
-// serial work - 0.6 us per 64-entry chunk - and the metric graph has rows of 5e5
-// neighbours: one walker in 10^5 spends 12 ms on its ten steps while the rest of
-// the chip has long finished (tools/prof_n2v.py: 1 000 walkers take 12.6 ms,
-// 100 000 take 37 ms).  So the walk is launched per step, and a step whose child
-// list is long goes to a WORKGROUP of 16 waves: 1 024 entries per round, the parent
-// cursor and the running sum carried across the waves through LDS.
-//   * Parent cursor: all lanes compare with the same pn[k]; the first lane that is
+// node2vec step by step (tuning key 7 = 3).  A walker's step is one wave's serial
+// work and the metric graph has rows of 5e5 neighbours: one walker in 10^5 spends
+// 12 ms on its ten steps while the rest of the chip has long finished
+// (tools/prof_n2v.py: 1 000 walkers take 12.6 ms, 100 000 take 37 ms).  So the walk
+// is launched per step, and a step whose child list is long goes to a WORKGROUP of
+// 16 waves: 4 096 entries per round, the parent cursor and the running sum carried
+// across the waves through LDS.
+//   * Parent cursor: all lanes compare with the same pn[k]; the first entry that is
 //     not below it is found with one ballot per wave and one LDS exchange, the
-//     cursor scan runs 1 024 parent entries per round.  (3 such events per step on
-//     the metric graph; lists that look ascending go to the sequential automaton.)
-//   * Running sums: inside one binade and without a rounding tie the f32 chain is an
-//     integer sum (ChunkScanBinade), so every wave sums its 64 entries, the 16
-//     totals are exchanged and each wave adds what lies before it.  A round with a
-//     tie, a negative entry or a sum that leaves the binade is redone wave after
-//     wave, each taking the previous wave's last sum (its own 64 entries by the
-//     integer scan when that now fits, by the add chain otherwise).
+//     cursor scan runs 1 024 parent entries per round.
+//   * Running sums: every wave sums its 256 entries in the binade of the round's
+//     carry (WaveSumsVec's integer path), the 16 totals are exchanged and each wave
+//     adds what lies before it.  The waves before the first one that cannot do that
+//     (a tie, a negative entry, the sum leaving the binade inside it) are final;
+//     that wave runs its entries from its real carry and the rest start over from
+//     its last sum.
 // ------------------------------------------------------------------------
 constexpr int kN2vBigWaves = 16;
 constexpr int kN2vBigCk = 1024;
+constexpr int kN2vBigRound = kN2vBigWaves * kN2vChunkR;
 
 struct alignas(16) N2vBigLds {
   N2vLds seq;                                   // lists + staging of the sequential automaton
   unsigned long long x_mask[2][kN2vBigWaves];   // exchange slots, alternating
   int64_t x_val[2][kN2vBigWaves];
-  float hand;                                   // wave-after-wave sums: the previous wave's last
+  float hand;                                   // the restarting wave's last sum
   int64_t next;                                 // queue entry of this workgroup
   float ck_acc[kN2vBigCk];
   int32_t ck_k[kN2vBigCk];
@@ -1128,30 +1228,37 @@ __device__ __forceinline__ int32_t N2vBigFirst(N2vBigLds& S, int* phase, int wv,
 }
 
 struct N2vBigState {
-  int32_t k;        // parent cursor
-  int32_t m_k;      // the k that M belongs to, -1 = none
-  int64_t M;
+  N2vCursor cur;
   float acc;        // running sum before this round
 };
 
-// One round (64 * kN2vBigWaves child entries, `e` = this lane's): *sum = this lane's
-// running sum, *before = the running sum before this wave's first lane.
-// Workgroup-uniform control flow throughout.
+// One round: d[] = this lane's weights after BuildWeights' comparisons, *cin = the
+// running sum before this lane's first entry.  Workgroup-uniform control flow.
 __device__ __forceinline__ void N2vBigRound(const WalkArgs& a, N2vBigLds& S, int* phase, int wv,
                                             int lane, int64_t parent, int32_t np,
-                                            bool same_lists, const N2vEntry& e, N2vBigState* st,
-                                            float* sum_out, float* before_out,
+                                            bool same_lists, const N2vVec& e, N2vBigState* st,
+                                            float (&d)[kN2vR], float* cin_out,
                                             int32_t* events_out) {
   const int tid = wv * 64 + lane;
   const uint64_t* p_nbr = a.g.nbr + S.seq.parent.row_ptr;
-  bool keep = same_lists;
-  int32_t resolved = -1, events = 0;
-  int32_t k = st->k;
+  uint32_t keep = same_lists ? e.live : 0u;
+  int res_tid = -1, res_r = -1;
+  int32_t events = 0;
+  int32_t k = st->cur.k;
   while (!same_lists && k < np) {
-    if (st->m_k != k) { st->M = (int64_t)p_nbr[N2vPhys(S.seq.parent, k)]; st->m_k = k; }
-    const unsigned long long ev = __ballot(e.live && tid > resolved && e.cid >= st->M);
+    if (st->cur.m_k != k) {
+      st->cur.M = (int64_t)p_nbr[N2vPhys(S.seq.parent, k)];
+      st->cur.m_k = k;
+    }
+    uint32_t evm = 0;
+#pragma unroll
+    for (int r = 0; r < kN2vR; ++r)
+      if (((e.live >> r) & 1u) && (tid > res_tid || (tid == res_tid && r > res_r)) &&
+          e.cid[r] >= st->cur.M)
+        evm |= 1u << r;
+    const int rsel = evm != 0 ? __ffs((int)evm) - 1 : 0;
     int64_t cf = 0;
-    const int32_t f = N2vBigFirst(S, phase, wv, lane, ev, e.cid, &cf);
+    const int32_t f = N2vBigFirst(S, phase, wv, lane, __ballot(evm != 0), N2vPick(e, rsel), &cf);
     if (f < 0) break;                          // every remaining child is below pn[k]
     // first k' >= k with pn[k'] >= cf (the cursor skips the smaller entries)
     bool hit = false;
@@ -1159,52 +1266,57 @@ __device__ __forceinline__ void N2vBigRound(const WalkArgs& a, N2vBigLds& S, int
       const int32_t kk = k + tid;
       int64_t pv = 0;
       if (kk < np) pv = (int64_t)p_nbr[N2vPhys(S.seq.parent, kk)];
-      const unsigned long long ge = __ballot(kk < np && pv >= cf);
       int64_t mv = 0;
-      const int32_t g = N2vBigFirst(S, phase, wv, lane, ge, pv, &mv);
-      if (g >= 0) { k += g; st->M = mv; st->m_k = k; hit = true; break; }
+      const int32_t g = N2vBigFirst(S, phase, wv, lane, __ballot(kk < np && pv >= cf), pv, &mv);
+      if (g >= 0) { k += g; st->cur.M = mv; st->cur.m_k = k; hit = true; break; }
       k += 64 * kN2vBigWaves;
       if (k >= np) { k = np; break; }
     }
-    if (hit && st->M == cf) { if (tid == f) keep = true; ++k; }
-    resolved = f;                              // lanes up to and including f are resolved
+    if (hit && st->cur.M == cf) { if (tid == f) keep |= 1u << rsel; ++k; }
+    res_tid = f;
+    if (tid == f) res_r = rsel;
     ++events;
   }
-  st->k = k;
+  st->cur.k = k;
   *events_out = events;
-  const float wq = !e.live ? 0.f : keep ? e.w : N2vScaled(a, e.w, e.cid == parent);
-  // ---- running sums.  Every wave from w0 on sums its entries in the binade of
-  // `carry`; the totals are exchanged; the waves before the first one that cannot do
-  // that (a tie, a negative entry, the sum leaving the binade inside it) are final,
-  // that wave runs its 64 entries from its real carry, and the rest start over from
-  // its last sum.
+  if (tid == 0 && events > 0) N2vCount(4, (unsigned long long)events);
+  N2vWeights(a, e, keep, parent, d);
+  // ---- running sums
   float carry = st->acc;
   int w0 = 0;
-  float sum = 0.f, before = 0.f;
+  float cin = 0.f;
   for (;;) {
     const uint32_t cb = __float_as_uint(carry);
     const uint32_t ex = cb >> 23;
     const uint32_t bb = cb & 0xFF800000u;
     const float B = __uint_as_float(bb);
-    const float t = __fadd_rn(B, wq);
-    const float err = __fsub_rn(wq, __fsub_rn(t, B));
+    const float twoB = __fadd_rn(B, B);
     const float half_ulp = __uint_as_float(bb - (24u << 23));
     const bool range_ok = ex >= 30u && ex < 254u;
     const bool active = wv >= w0;
-    const bool ok = wq >= 0.f && fabsf(err) != half_ulp && t < __fadd_rn(B, B);
-    const int32_t n = active && ok ? (int32_t)(__float_as_uint(t) - bb) : 0;
-    const int32_t incl = WaveInclusiveAdd(n, lane);                 // < 2^29
-    const bool bad = active && (!range_ok || __ballot(!ok) != 0);
+    uint32_t N = 0;
+    bool okl = true;
+#pragma unroll
+    for (int r = 0; r < kN2vR; ++r) {
+      const float t = __fadd_rn(B, d[r]);
+      const float err = __fsub_rn(d[r], __fsub_rn(t, B));
+      const bool ok = d[r] >= 0.f && fabsf(err) != half_ulp && t < twoB;
+      okl = okl && ok;
+      N += ok ? __float_as_uint(t) - bb : 0u;
+    }
+    if (!active) N = 0;
+    const uint32_t incl = WaveInclusiveAdd(N, lane);                // < 2^31
+    const bool bad = active && (!range_ok || __ballot(!okl) != 0);
     const int b = *phase & 1;
     ++*phase;
-    if (lane == 63) S.x_val[b][wv] = ((int64_t)(bad ? 1 : 0) << 32) | (uint32_t)incl;
+    if (lane == 63) S.x_val[b][wv] = ((int64_t)(bad ? 1 : 0) << 32) | incl;
     __syncthreads();
     const int64_t mine = lane < kN2vBigWaves ? S.x_val[b][lane] : 0;
     int64_t pre = (int64_t)(uint32_t)mine;                          // inclusive over the waves
 #pragma unroll
-    for (int d = 1; d < kN2vBigWaves; d <<= 1) {
-      const int64_t up = __shfl_up(pre, d);
-      if (lane >= d) pre += up;
+    for (int dd = 1; dd < kN2vBigWaves; dd <<= 1) {
+      const int64_t up = __shfl_up(pre, dd);
+      if (lane >= dd) pre += up;
     }
     const int64_t off0 = (int64_t)(cb - bb);
     const unsigned long long probw =
@@ -1212,27 +1324,23 @@ __device__ __forceinline__ void N2vBigRound(const WalkArgs& a, N2vBigLds& S, int
                  ((mine >> 32) != 0 || off0 + pre >= (1 << 23)));
     const int pw = probw != 0 ? __ffsll((long long)probw) - 1 : kN2vBigWaves;
     const int64_t my_before = (wv == 0 ? 0 : __shfl(pre, wv - 1)) + off0;
-    if (active && wv < pw) {
-      before = __uint_as_float(bb + (uint32_t)my_before);
-      sum = __uint_as_float(bb + (uint32_t)(my_before + incl));
-    }
+    if (active && wv < pw) cin = __uint_as_float(bb + (uint32_t)(my_before + incl - N));
     if (pw == kN2vBigWaves) {
       st->acc = __uint_as_float(bb + (uint32_t)(__shfl(pre, kN2vBigWaves - 1) + off0));
       break;
     }
     const int64_t pw_before = (pw == 0 ? 0 : __shfl(pre, pw - 1)) + off0;
     if (wv == pw) {
-      before = pw == w0 ? carry : __uint_as_float(bb + (uint32_t)pw_before);
-      if (!ChunkScanBinade(before, wq, lane, &sum)) sum = ChunkScan(before, wq, lane);
-      if (lane == 63) S.hand = sum;            // dead lanes add 0: lane 63 has the wave's last sum
+      const float before = pw == w0 ? carry : __uint_as_float(bb + (uint32_t)pw_before);
+      const float last = WaveSumsVec(before, d, lane, &cin);
+      if (lane == 0) S.hand = last;
     }
     __syncthreads();
     carry = S.hand;
     w0 = pw + 1;
     if (w0 == kN2vBigWaves) { st->acc = carry; break; }
   }
-  *before_out = before;
-  *sum_out = sum;
+  *cin_out = cin;
 }
 
 // Lane per walker: queue the walkers whose step `s` has a long child list.
@@ -1290,29 +1398,33 @@ __global__ __launch_bounds__(64 * kN2vBigWaves) void N2vBigStepKernel(const Walk
     }
     __syncthreads();
     const int32_t nc = S.seq.child.total, np = S.seq.parent.total;
-    constexpr int32_t kRound = 64 * kN2vBigWaves;
-    const int32_t rounds = (nc + kRound - 1) / kRound;
+    const int32_t rounds = (nc + kN2vBigRound - 1) / kN2vBigRound;
     int32_t sh = 0;
     while ((rounds >> sh) > kN2vBigCk) ++sh;
     const int32_t n_slots = rounds >> sh;
-    N2vBigState st{0, -1, 0, 0.f};
+    N2vBigState st{{0, -1, 0}, 0.f};
     const bool same = N2vSameLists(S.seq.child, S.seq.parent);
-    float sum, before;
+    const int32_t jl = threadIdx.x * kN2vR;
+    float d[kN2vR], cin;
     int32_t events;
     bool ascending = false;
     // the next round's entries are requested before this round is worked on
-    N2vEntry e = N2vLoad(a, S.seq, lane, nc, wv * 64), nx = e;
+    N2vVec e = N2vLoadVec(a, S.seq.child, nc, jl), nx = e;
     for (int32_t ri = 0; ri < rounds; ++ri) {
-      if (ri + 1 < rounds) nx = N2vLoad(a, S.seq, lane, nc, (ri + 1) * kRound + wv * 64);
-      N2vBigRound(a, S, &phase, wv, lane, parent, np, same, e, &st, &sum, &before, &events);
+      if (ri + 1 < rounds) nx = N2vLoadVec(a, S.seq.child, nc, (ri + 1) * kN2vBigRound + jl);
+      N2vBigRound(a, S, &phase, wv, lane, parent, np, same, e, &st, d, &cin, &events);
       e = nx;
-      if (ri == 0 && events > 16 * kN2vBigWaves) { ascending = true; break; }
+      if (ri == 0 && events > 64) { ascending = true; break; }
       if (((ri + 1) & ((1 << sh) - 1)) == 0 && threadIdx.x == 0) {
         S.ck_acc[((ri + 1) >> sh) - 1] = st.acc;
-        S.ck_k[((ri + 1) >> sh) - 1] = st.k;
+        S.ck_k[((ri + 1) >> sh) - 1] = st.cur.k;
       }
     }
     int64_t result = a.default_node;
+    if (threadIdx.x == 0) {
+      N2vCount(ascending ? 2 : 6, 1);
+      N2vCount(ascending ? 3 : 7, (unsigned long long)nc);
+    }
     if (ascending) {
       // every child moves the parent cursor: the lane-0 automaton of one wave does it
       if (wv == 0) result = N2vStepSequential(a, S.seq, lane, parent, i, s);
@@ -1331,17 +1443,19 @@ __global__ __launch_bounds__(64 * kN2vBigWaves) void N2vBigStepKernel(const Walk
         }
       }
       st.acc = first == 0 ? 0.f : S.ck_acc[first - 1];
-      st.k = first == 0 ? 0 : S.ck_k[first - 1];
-      st.m_k = -1;
+      st.cur.k = first == 0 ? 0 : S.ck_k[first - 1];
+      st.cur.m_k = -1;
       bool found = false;
       for (int32_t ri = first << sh; ri < rounds && !found; ++ri) {
-        e = N2vLoad(a, S.seq, lane, nc, ri * kRound + wv * 64);
-        N2vBigRound(a, S, &phase, wv, lane, parent, np, same, e, &st, &sum, &before, &events);
-        float prev = __shfl_up(sum, 1);
-        if (lane == 0) prev = before;
-        const unsigned long long hit = __ballot(e.live && (double)prev <= r && r < (double)sum);
+        e = N2vLoadVec(a, S.seq.child, nc, ri * kN2vBigRound + jl);
+        N2vBigRound(a, S, &phase, wv, lane, parent, np, same, e, &st, d, &cin, &events);
+        const uint32_t hm = N2vHits(e, d, cin, r);
         int64_t hv = 0;
-        if (N2vBigFirst(S, &phase, wv, lane, hit, e.cid, &hv) >= 0) { found = true; result = hv; }
+        if (N2vBigFirst(S, &phase, wv, lane, __ballot(hm != 0),
+                        N2vPick(e, hm != 0 ? __ffs((int)hm) - 1 : 0), &hv) >= 0) {
+          found = true;
+          result = hv;
+        }
       }
       // no interval holds r (total == 0): RandomSelect's fall-through ends on the last element
       if (!found) result = (int64_t)(a.g.nbr + S.seq.child.row_ptr)[N2vPhys(S.seq.child, nc - 1)];
@@ -1696,6 +1810,20 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
   EG_HIP(hipGetLastError());
   // the edge-type table must outlive the kernel: stream-ordered free
   EG_HIP(hipFreeAsync(et_dev, st));
+  return EULER_GPU_OK;
+}
+
+int euler_gpu_random_walk_stats(uint64_t* out8_host, int32_t reset) {
+  if (out8_host) {
+    EG_HIP(hipDeviceSynchronize());
+    EG_HIP(hipMemcpyFromSymbol(out8_host, HIP_SYMBOL(g_n2v_stats), 8 * sizeof(uint64_t)));
+  }
+  if (reset) {
+    const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    EG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_n2v_stats), z, sizeof(z)));
+    const int on = reset == 2 ? 1 : 0;      // 2 = clear and count from now on, 1 = clear and stop
+    EG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_n2v_stats_on), &on, sizeof(on)));
+  }
   return EULER_GPU_OK;
 }
 

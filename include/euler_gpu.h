@@ -519,6 +519,16 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
                           int32_t walk_len, float p, float q,
                           int64_t default_node, int64_t* out_dev);
 
+/* Diagnostic counters of the node2vec kernels on the current device since the last
+ * reset (synchronises the device): out8_host[0] steps done by the whole-wave path,
+ * [1] their child-list entries, [2] steps handed to the sequential automaton, [3]
+ * their entries, [4] moves of the parent cursor, [5] chunks whose running sums fell
+ * back to the add chain, [6] steps done by the workgroup kernel, [7] their entries.
+ * reset: 2 = clear the counters and count from now on (the kernels then pay an atomic
+ * per counted event), 1 = clear and stop counting (the default state), 0 = read only.
+ * out8_host may be NULL. */
+int euler_gpu_random_walk_stats(uint64_t* out8_host, int32_t reset);
+
 /* Exact algorithmic byte count of a finished walk (walks_dev = the
  * [n, walk_len + 1] output of euler_gpu_random_walk): p = q = 1 - per step the
  * SampleNeighbor(count = 1) terms of euler_gpu_sample_neighbor_algo_bytes over the

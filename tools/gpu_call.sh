@@ -1,3 +1,2 @@
-cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp; mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "node2vec or walk" 2>&1 < /dev/null | tail -12
-timeout 300 python tools/prof_n2v.py 2>&1 < /dev/null | tail -16 | cut -c1-1500 | tee gpurun_out/r2g_prof_n2v.txt
+cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp; mkdir -p gpurun_out; R=$PWD
+for cfg in "2 0 100000" "3 16384 100000" "3 16384 1000"; do timeout 120 python tools/n2v_one.py $cfg 2>&1 < /dev/null | grep stats; done

@@ -7,8 +7,17 @@ G = euler_amd.Graph.synthetic(euler_amd.synth_params(20240521, N, 10*N, weighted
 G.set_seed(20240521)
 gen = torch.Generator(device='cuda'); gen.manual_seed(1234)
 starts = torch.randint(1, N + 1, (100_000,), generator=gen, device='cuda', dtype=torch.int64)
-big = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+mode = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+big = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
+W = int(sys.argv[3]) if len(sys.argv) > 3 else 100_000
+_lib.lib().euler_gpu_set_tuning(7, mode)
 _lib.lib().euler_gpu_set_tuning(25, big)
-for _ in range(2):
-    G.random_walk(starts, [[0]]*10, 0.25, 4.0, N+1, call_id=3)
+s = starts[:W].contiguous()
+import ctypes as C
+st = (C.c_uint64 * 8)()
+G.random_walk(s, [[0]]*10, 0.25, 4.0, N+1, call_id=3)
+_lib.lib().euler_gpu_random_walk_stats(None, 2)
+w = G.random_walk(s, [[0]]*10, 0.25, 4.0, N+1, call_id=3)
+_lib.lib().euler_gpu_random_walk_stats(st, 1)
+print("mode", mode, "big", big, "walkers", W, "stats", list(st))
 torch.cuda.synchronize()

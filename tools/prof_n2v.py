@@ -36,7 +36,7 @@ from euler_amd import _lib
 Lb = _lib.lib()
 res = {}
 ref = None
-for mode, big in ((2, 0), (3, 0), (3, 2048), (3, 8192), (3, 32768), (3, 131072)):
+for mode, big in ((2, 0), (3, 4096), (3, 16384), (3, 65536)):
     Lb.euler_gpu_set_tuning(7, mode)
     Lb.euler_gpu_set_tuning(25, big)
     for W in (1000, 100_000):
