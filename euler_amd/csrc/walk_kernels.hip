@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void Node2VecKernel(const WalkA
 // graph (100 K walkers x 10 steps, walkers sit on hubs of 1e5+ neighbours):
 // 1.69 s -> 1.15 s; prefetching the next entries by hand made it slower (1.34 s).
 // ------------------------------------------------------------------------
-constexpr int kN2vChunk = 256;
+constexpr int kN2vChunk = 128;
 constexpr int kN2vMaxSeg = kMaxListedTypes;
 
 struct N2vList {           // one neighbour list = listed type segments of a row
@@ -994,7 +994,9 @@ __device__ __forceinline__ bool N2vStepParallel(const WalkArgs& a, N2vLds& S, in
   float d[kN2vR];
   N2vCursor cur{0, -1, 0};
   // the next chunk's entries are requested before this chunk is worked on: a wave
-  // has one dependent round trip per chunk, not two
+  // has one dependent round trip per chunk, not two.  (Two chunks ahead costs 20
+  // more registers: 23.7 ms against 18.8 on the hub workload, and the slowest
+  // walker is no faster.)
   N2vVec e = N2vLoadVec(a, S.child, nc, lane * kN2vR), nx = e;
   for (int32_t ci = 0; ci < nchunks; ++ci) {
     if (ci + 1 < nchunks) nx = N2vLoadVec(a, S.child, nc, (ci + 1) * kN2vChunkR + lane * kN2vR);
@@ -1127,8 +1129,10 @@ __device__ __forceinline__ int64_t N2vStepSequential(const WalkArgs& a, N2vLds& 
   return (int64_t)(((uint64_t)hi32 << 32) | lo32);
 }
 
+// 64 registers (8 waves per SIMD) and 12 KB of LDS per workgroup: 18.8 ms against
+// 20.4 with 82 registers on the hub workload.
 template <bool PAR>
-__global__ __launch_bounds__(256) void Node2VecWaveKernel(const WalkArgs a) {
+__global__ __launch_bounds__(256, kWavesPerSimd) void Node2VecWaveKernel(const WalkArgs a) {
   __shared__ N2vLds lds_all[4];
   N2vLds& S = lds_all[threadIdx.x >> 6];
   const int lane = threadIdx.x & 63;

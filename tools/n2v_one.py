@@ -19,5 +19,10 @@ G.random_walk(s, [[0]]*10, 0.25, 4.0, N+1, call_id=3)
 _lib.lib().euler_gpu_random_walk_stats(None, 2)
 w = G.random_walk(s, [[0]]*10, 0.25, 4.0, N+1, call_id=3)
 _lib.lib().euler_gpu_random_walk_stats(st, 1)
-print("mode", mode, "big", big, "walkers", W, "stats", list(st))
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+torch.cuda.synchronize(); e0.record()
+for _ in range(3):
+    G.random_walk(s, [[0]]*10, 0.25, 4.0, N+1, call_id=3)
+e1.record(); torch.cuda.synchronize()
+print("mode", mode, "big", big, "walkers", W, "ms", round(e0.elapsed_time(e1) / 3, 3), "stats", list(st))
 torch.cuda.synchronize()
