@@ -747,9 +747,11 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  * key 6: five adjacent samples per lane for odd counts that are a multiple of 5
  *        (default 0: measured slower on the metric's first hop).
  * key 7: node2vec kernel: 2 = one wave per walker, runs of children below the
- *        parent cursor resolved by all lanes at once + lane-shifting running sums
- *        [default]; 1 = one wave per walker, lane 0 walks LDS-staged lists; 0 = one
- *        lane per walker.
+ *        parent cursor resolved by all lanes at once, running sums as integer sums
+ *        inside a binade [default]; 3 = the same launched per step, child lists of
+ *        key 25 entries or more (default 8192, 0 = none) by a 16-wave workgroup;
+ *        1 = one wave per walker, lane 0 walks LDS-staged lists; 0 = one lane per
+ *        walker.
  * key 5: duplicate roots: 0 = never look, 1 = look when a call has >= 100 000
  *        roots [default], 2 = always look.
  * key 8: dense-feature kernel: 16-byte loads when the slots allow it (1).
@@ -792,6 +794,8 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  *        (1 [default]); 0 = one launch per hop.
  * key 24: get_full_neighbor fill pass: a lane owns 4 consecutive output entries,
  *        whatever rows they belong to (1 [default]); 0 = one wave per queried node.
+ * key 25: node2vec with key 7 = 3: child lists of this many entries or more go to the
+ *        workgroup kernel (default 8192; 0 = none).
  * key 20: last hop of a fanout with key 14 = 2: 1 = the expansion reads every
  *        position's row number from the owner table itself; 0 = a separate resolve
  *        kernel fills an index array first [default: measured 9 us faster].
