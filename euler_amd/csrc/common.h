@@ -48,6 +48,7 @@ int Fail(int code, const std::string& msg);
 //   id map   identity/strided (id -> (id - base) / stride, no memory at all)
 //            or an open-addressing table of 16-byte {key,row} slots.
 constexpr int kPivotLevels = 10;   // levels 1..10: rows of up to 4*5^9*4 edges
+constexpr int kInlineEdges = 9;    // edges of a row kept in its 128-byte row_inline line
 
 struct GraphView {
   int64_t n_rows;
@@ -66,11 +67,20 @@ struct GraphView {
   int32_t uniform_w;            // every edge weight is exactly 1.0f (running sums 1, 2, 3, ...
                                 // per row, degrees < 2^24): the draw r = u * span + begin
                                 // lands on edge floor(r) - no search, no sums read
-  int32_t pad_flags;
+  int32_t inline_k;             // > 0: row_inline holds the first inline_k edges of every row
   int32_t total_in_meta;        // T == 1 and every row's type_prefix[0] has the
                                 // bits of its last running sum (checked on device
                                 // at build): the segment limit comes with the row
                                 // record, no separate load
+  // T == 1, total_in_meta, monotone: one 128-byte line per row = the 16-byte row record
+  // followed by the running sums (bytes 16..51) and the neighbour ids (bytes 56..127)
+  // of the row's first kInlineEdges edges.  A row of <= kInlineEdges edges is sampled
+  // from that ONE line (row record, sums and ids used to be 2-3 dependent cold lines:
+  // record -> [block pivots ->] EdgeBlock); longer rows read the record from it and
+  // go on as before.  +112 B per row of HBM (12.8 GB for the metric graph).  An A/B
+  // layout (tuning key 26, off by default): it removes a cold line per short row and
+  // the step is no faster for it.
+  const uint8_t* row_inline;
   uint64_t id_base;             // identity: row = (id - id_base) / id_stride
   uint64_t id_stride;
   const uint64_t* hash_slots;   // [2 * (hash_mask + 1)] = {key, row} pairs

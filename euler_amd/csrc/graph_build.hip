@@ -16,6 +16,8 @@
 
 namespace euler_gpu {
 
+extern thread_local int g_k1_inline;      // sample_kernels.hip (tuning key 26)
+
 namespace {
 thread_local std::string g_last_error;
 std::mutex g_default_mu;
@@ -168,10 +170,46 @@ int VerifyTotals(GraphBuilder* b) {
 
 int BuildBlockedIndex(GraphBuilder* b);
 
+// row_inline (common.h): record + first kInlineEdges sums and ids of every row
+__global__ __launch_bounds__(256) void InlineRowsKernel(GraphView g, uint8_t* out) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= g.n_rows) return;
+  const uint4 q = *reinterpret_cast<const uint4*>(g.row_meta + row * 16);
+  const int64_t row_ptr = (int64_t)(((uint64_t)q.y << 32) | q.x);
+  const int32_t deg = (int32_t)q.z;
+  uint8_t* rec = out + row * 128;
+  *reinterpret_cast<uint4*>(rec) = q;
+  float* pw = reinterpret_cast<float*>(rec + 16);
+  uint64_t* nb = reinterpret_cast<uint64_t*>(rec + 56);
+  for (int32_t j = 0; j < kInlineEdges; ++j) {
+    pw[j] = j < deg ? g.prefix_w[row_ptr + j] : 0.f;
+    nb[j] = j < deg ? g.nbr[row_ptr + j] : 0;
+  }
+  pw[kInlineEdges] = 0.f;       // bytes 52..55
+}
+
+int BuildInlineRows(GraphBuilder* b) {
+  GraphView& v = b->g->view;
+  v.inline_k = 0;
+  v.row_inline = nullptr;
+  if (!g_k1_inline) return EULER_GPU_OK;   // an A/B layout (see the key's comment): built on request
+  if (v.T != 1 || !v.total_in_meta || !v.monotone || v.n_rows == 0) return EULER_GPU_OK;
+  uint8_t* buf = b->Alloc<uint8_t>((size_t)v.n_rows * 128);
+  if (b->rc != EULER_GPU_OK) return b->rc;
+  if (((uintptr_t)buf & 127) != 0) return Fail(EULER_GPU_EHIP, "row_inline: unaligned allocation");
+  hipLaunchKernelGGL(InlineRowsKernel, dim3((v.n_rows + 255) / 256), dim3(256), 0, 0, v, buf);
+  EG_HIP(hipGetLastError());
+  EG_HIP(hipDeviceSynchronize());
+  v.row_inline = buf;
+  v.inline_k = kInlineEdges;
+  return EULER_GPU_OK;
+}
+
 // Pivot levels over the flat arrays (variant 5) and the EdgeBlock copy with its
 // block pivots (variant 6, the default sampler) are both built at creation.
 int BuildSearchIndex(GraphBuilder* b) {
   int rc = VerifyTotals(b);
+  if (rc == EULER_GPU_OK) rc = BuildInlineRows(b);
   if (rc == EULER_GPU_OK) rc = BuildPivotLevels(b);
   return rc != EULER_GPU_OK ? rc : BuildBlockedIndex(b);
 }

@@ -98,9 +98,14 @@ __global__ __launch_bounds__(64) void SampleNeighborRowKernel(const SampleNbArgs
       if (a.root_mask != nullptr && a.root_mask[r / a.root_group]) node = 0;
       valid = LoadSegment<true>(a.g, FindRow(a.g, node), t, &sg);
     }
+    // a row of <= kInlineEdges edges comes whole with its record (row_inline): slots
+    // 0 .. e of a virtual block that starts at the row
+    const bool inl = valid && sg.inl != nullptr;
     int64_t blk_lo = 0;
     int32_t i_lo = 0, i_hi = 0;
-    if (valid) {
+    if (inl) {
+      i_hi = sg.e;
+    } else if (valid) {
       blk_lo = sg.lo / kEdgesPerBlock;
       i_lo = (int32_t)(sg.lo - blk_lo * kEdgesPerBlock);
       i_hi = (int32_t)(sg.hi - blk_lo * kEdgesPerBlock);
@@ -110,14 +115,30 @@ __global__ __launch_bounds__(64) void SampleNeighborRowKernel(const SampleNbArgs
     double vd[kRowSlots - 1];          // compare keys of slots 0 .. 18, padded
     if (fast) {
       const EdgeBlock* bk = a.g.blk + blk_lo;
-      const bool two = i_hi >= kEdgesPerBlock;
-      const float4 a0 = *reinterpret_cast<const float4*>(bk->pw);
-      const float4 a1 = *reinterpret_cast<const float4*>(bk->pw + 4);
-      const float4 a2 = *reinterpret_cast<const float4*>(bk->pw + 8);   // pw[8], pw[9], prev_last
+      const bool two = !inl && i_hi >= kEdgesPerBlock;
+      float4 a0, a1, a2;
       u64x2 ia[kEdgesPerBlock / 2], ib[kEdgesPerBlock / 2];
+      if (inl) {
+        const float* ipw = reinterpret_cast<const float*>(sg.inl + 16);
+        const uint64_t* inb = reinterpret_cast<const uint64_t*>(sg.inl + 56);
+        a0 = *reinterpret_cast<const float4*>(ipw);
+        a1 = *reinterpret_cast<const float4*>(ipw + 4);
+        a2 = make_float4(ipw[8], 0.f, 0.f, 0.f);          // slot 8; slot 9 unused; sum before slot 0 = 0
 #pragma unroll
-      for (int q = 0; q < kEdgesPerBlock / 2; ++q)
-        ia[q] = *reinterpret_cast<const u64x2*>(bk->nbr + 2 * q);
+        for (int q = 0; q < kEdgesPerBlock / 2 - 1; ++q) {
+          ia[q].x = inb[2 * q];
+          ia[q].y = inb[2 * q + 1];
+        }
+        ia[kEdgesPerBlock / 2 - 1].x = inb[kInlineEdges - 1];
+        ia[kEdgesPerBlock / 2 - 1].y = 0;
+      } else {
+        a0 = *reinterpret_cast<const float4*>(bk->pw);
+        a1 = *reinterpret_cast<const float4*>(bk->pw + 4);
+        a2 = *reinterpret_cast<const float4*>(bk->pw + 8);   // pw[8], pw[9], prev_last
+#pragma unroll
+        for (int q = 0; q < kEdgesPerBlock / 2; ++q)
+          ia[q] = *reinterpret_cast<const u64x2*>(bk->nbr + 2 * q);
+      }
       float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0, b2 = b0;
 #pragma unroll
       for (int q = 0; q < kEdgesPerBlock / 2; ++q) ib[q] = u64x2{0, 0};
@@ -146,7 +167,7 @@ __global__ __launch_bounds__(64) void SampleNeighborRowKernel(const SampleNbArgs
       for (int q = 0; q < kRowSlots - 1; ++q)
         vd[q] = q < i_lo ? -kInf : (q >= i_hi ? kInf : (double)v[q]);
       // `mid ? nw[mid-1] : 0` is row-relative: the slot whose predecessor sum is 0
-      const int64_t rs = sg.row_ptr - blk_lo * kEdgesPerBlock;
+      const int64_t rs = inl ? 0 : sg.row_ptr - blk_lo * kEdgesPerBlock;
       s_rs[lane] = rs >= 0 ? (uint8_t)rs : (uint8_t)0xFF;
     }
     s_flag[lane] = !valid ? 1 : (slow ? 2 : 0);

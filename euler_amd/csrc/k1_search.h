@@ -58,7 +58,39 @@ struct Segment {
   int64_t lo, hi;       // searched edges [lo, hi] (global indices)
   float limit_begin, limit_end;
   int32_t b, e;         // the same segment, row-relative
+  const uint8_t* inl;   // the row's row_inline line when it holds the WHOLE row, else nullptr
 };
+
+// A draw on a row that lives in its row_inline line (<= kInlineEdges edges, the whole
+// row is the segment): the first m of [0, e] with nw[m] > r, from the line the row
+// record came in.  Same contract as the searches below; the caller has checked
+// r < limit_end.
+__device__ __forceinline__ void InlineSample(const GraphView& g, const Segment& sg, double rr,
+                                             uint64_t* id, float* w) {
+  const float* ipw = reinterpret_cast<const float*>(sg.inl + 16);
+  const uint64_t* inb = reinterpret_cast<const uint64_t*>(sg.inl + 56);
+  int32_t i = 0;
+  if (g.uniform_w) {
+    i = (int32_t)rr;                 // nw[m] = m + 1: the first m with nw[m] > r is floor(r)
+    *w = 1.0f;
+  } else {
+    const float4 a0 = *reinterpret_cast<const float4*>(ipw);
+    const float4 a1 = *reinterpret_cast<const float4*>(ipw + 4);
+    const float a8 = ipw[8];
+    const float v[kInlineEdges] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a8};
+#pragma unroll
+    for (int j = 0; j < kInlineEdges - 1; ++j)
+      i += (j < sg.e && !((double)v[j] > rr)) ? 1 : 0;
+    float nw_m = v[0], prev = 0.f;    // `mid ? nw[mid-1] : 0`
+#pragma unroll
+    for (int j = 0; j < kInlineEdges; ++j) {
+      if (j == i) nw_m = v[j];
+      if (j + 1 == i) prev = v[j];
+    }
+    *w = __fsub_rn(nw_m, prev);
+  }
+  *id = inb[i];
+}
 
 // One draw u on a segment: the neighbour RandomSelect picks and its weight.
 __device__ __forceinline__ void PivotSample(const GraphView& g, const Segment& sg,
@@ -74,6 +106,7 @@ __device__ __forceinline__ void PivotSample(const GraphView& g, const Segment& s
     *w = __fsub_rn(nw[m], m == 0 ? 0.f : nw[m - 1]);
     return;
   }
+  if (sg.inl != nullptr) { InlineSample(g, sg, rr, id, w); return; }
   if (g.uniform_w) {
     // H1 (uniform weights, configs[1]): nw[m] = m + 1 exactly, so the first m with
     // nw[m] > r is floor(r) (r < limit_end was just checked; r >= limit_begin = b)
@@ -178,6 +211,7 @@ __device__ __forceinline__ void BlockPivotSample(const GraphView& g, const Segme
     *w = __fsub_rn(nw[m], m == 0 ? 0.f : nw[m - 1]);
     return;
   }
+  if (sg.inl != nullptr) { InlineSample(g, sg, rr, id, w); return; }
   if (g.uniform_w) {
     // H1 (uniform weights, configs[1]): nw[m] = m + 1 exactly, so the first m with
     // nw[m] > r is floor(r) (r < limit_end was just checked; r >= limit_begin = b)
@@ -270,7 +304,10 @@ template <bool BLOCKED = false>
 __device__ __forceinline__ bool LoadSegment(const GraphView& g, int64_t row,
                                             int32_t t, Segment* sg) {
   if (row < 0 || t < 0 || t >= g.T) return false;
-  const uint8_t* rec = g.row_meta + row * (int64_t)g.meta_stride;
+  sg->inl = nullptr;
+  // inline_k > 0 implies T == 1 and total_in_meta; the line starts with the row record
+  const uint8_t* rec = g.inline_k > 0 ? g.row_inline + row * 128
+                                      : g.row_meta + row * (int64_t)g.meta_stride;
   if (g.T == 1) {
     const uint4 q = *reinterpret_cast<const uint4*>(rec);
     sg->row_ptr = (int64_t)(((uint64_t)q.y << 32) | q.x);
@@ -284,6 +321,7 @@ __device__ __forceinline__ bool LoadSegment(const GraphView& g, int64_t row,
       sg->hi = sg->row_ptr + sg->e;
       sg->limit_begin = 0.f;
       sg->limit_end = __uint_as_float(q.w);
+      if (g.inline_k > 0 && sg->e < g.inline_k) sg->inl = rec;
       return true;
     }
   } else {

@@ -528,6 +528,11 @@ thread_local int g_k1_dedup = 1;     // 0 = never, 1 = automatic for >= 100 000 
 thread_local int g_n2v_wave = 2;     // node2vec: 3 = launched per step, long lists by a workgroup (walk_kernels.hip:
                         // N2vBigStepKernel), 2 = one launch, one wave per walker, the two-cursor walk by
                         // the whole wave, 1 = lane 0 walks LDS-staged lists, 0 = one lane per walker
+thread_local int g_k1_inline = 0;    // key 26: rows of <= 9 edges sampled from their row_inline line (common.h);
+                        // the lines are built for graphs created while it is 1.  Measured on the metric
+                        // (profiles/r2_inline_ab.txt): first hop alone 51.3 -> 48.2 us lane per sample,
+                        // 62.4 -> 66 us lane per root, the step and the B = 1 024 latency unchanged or
+                        // 1-3 % worse, for 12.8 GB more HBM - off
 thread_local int g_n2v_big = 8192;   // key 25: child lists of this many entries go to the workgroup kernel (0 = none)
 thread_local int g_k1_group = 0;     // block-pivot kernel: five adjacent samples per lane for odd counts
                         // that are a multiple of 5 - measured 8 % SLOWER on the metric's
@@ -1199,7 +1204,7 @@ static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
     if (rc != EULER_GPU_OK) return rc;
   }
   SampleNbArgs a{};
-  a.g = g->view;
+  a.g = SamplingView(g);
   a.seed = seed; a.call_id = call_id;
   a.roots = roots; a.root_mask = root_mask;
   a.root_group = root_group > 0 ? root_group : 1;
@@ -1492,7 +1497,7 @@ int LaunchSampleNeighborCounted(const euler_gpu_graph* g, hipStream_t stream, ui
     if (rc != EULER_GPU_OK) return rc;
   }
   SampleNbArgs a{};
-  a.g = g->view;
+  a.g = SamplingView(g);
   a.seed = seed; a.call_id = call_id;
   a.roots = roots; a.root_mask = nullptr; a.root_group = 1;
   a.out_id = out_id; a.out_w = out_w; a.out_t = out_t; a.out_row_mask = nullptr;
@@ -1560,7 +1565,7 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
       if (rc0 != EULER_GPU_OK) return rc0;
     }
     Fanout2Args f{};
-    f.g = g->view; f.seed = seed; f.call_id = call_id; f.roots = roots_dev; f.n = n;
+    f.g = SamplingView(g); f.seed = seed; f.call_id = call_id; f.roots = roots_dev; f.n = n;
     f.default_node = default_node;
     f.c1 = counts_host[0]; f.c2 = counts_host[1];
     f.t1 = edge_types_host[0]; f.t2 = edge_types_host[1];
@@ -1639,6 +1644,7 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 23) { g_fanout_fused = value != 0; return EULER_GPU_OK; }
   if (key == 24) { g_full_nb_balanced = value != 0; return EULER_GPU_OK; }
   if (key == 25 && value >= 0) { g_n2v_big = value; return EULER_GPU_OK; }
+  if (key == 26) { g_k1_inline = value != 0; return EULER_GPU_OK; }
   if (key == 1 && (value == 1 || value == 2 || value == 4 || value == 8)) {
     g_k1_ilp = value;
     return EULER_GPU_OK;

@@ -1754,7 +1754,7 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
                           (size_t)walk_len * k * sizeof(int32_t),
                           hipMemcpyHostToDevice, st));
   WalkArgs a{};
-  a.g = g->view; a.seed = seed; a.call_id = call_id; a.nodes = nodes_dev;
+  a.g = SamplingView(g); a.seed = seed; a.call_id = call_id; a.nodes = nodes_dev;
   a.edge_types = et_dev; a.out = out_dev; a.n = n; a.default_node = default_node;
   a.k = k; a.walk_len = walk_len; a.p = p; a.q = q;
   {

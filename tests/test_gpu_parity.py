@@ -1253,6 +1253,69 @@ def test_uniform_weight_fast_path(EA, O, torch_cuda, k1_variant):
     assert np.array_equal(t2n(walk), OG.random_walk(3, 40, q[:500], [[0]] * 8, 8, 1.0, 1.0, -1))
 
 
+@pytest.mark.parametrize("weights", ["random", "uniform", "zeros"])
+@pytest.mark.parametrize("ids_kind", ["hash_ids", "identity_ids"])
+def test_short_rows_sampled_from_their_inline_line(EA, O, torch_cuda, k1_variant, weights, ids_kind):
+    """Single-type graphs keep a 128-byte line per row: the row record, then the running
+    sums and ids of its first 9 edges (common.h: row_inline).  Rows of <= 9 edges are
+    sampled from that line (tuning key 26 = 1; an A/B layout, off by default), longer rows
+    read their record from it and search as before.  Degrees 0 .. 13 straddle the boundary; results with
+    key 26 = 1, key 26 = 0 and the oracle agree bit for bit - sample_neighbor (odd, even,
+    large counts; duplicate roots; the lane-per-root kernel, key 19 = 2), the 2-hop
+    fanout (one launch and per hop) and random_walk (p = q = 1), on hash and identity
+    id maps, with uniform weights (no search) and zero weights (Q3 replays)."""
+    torch = torch_cuda
+    from euler_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(97)
+    n = 6000
+    ids = (np.arange(1, n + 1) if ids_kind == "identity_ids"
+           else rng.choice(10 ** 12, n, replace=False) + 1).astype(np.uint64)
+    deg = rng.integers(0, 14, size=n)
+    deg[:40] = rng.integers(25, 400, size=40)          # some long rows among them
+    seg = np.zeros(n + 1, np.int64)
+    seg[1:] = np.cumsum(deg)
+    E = int(seg[-1])
+    nbr = rng.choice(ids, E).astype(np.uint64)
+    if weights == "uniform":
+        w = np.ones(E, np.float32)
+    else:
+        w = (rng.random(E) * 4 + 0.05).astype(np.float32)
+        if weights == "zeros":
+            w[rng.random(E) < 0.3] = 0
+    csr = O.csr_from_raw(ids, seg, nbr, w, 1)
+    L.euler_gpu_set_tuning(26, 1)          # the lines are built for graphs created while the key is 1
+    G, OG = gpu_graph(EA, csr), O.OracleGraph(csr)
+    q = np.concatenate([rng.choice(ids, 3000), ids[:40], [0, 5, 2 ** 61]]).astype(np.int64)
+    qt = torch.as_tensor(q).cuda()
+    G.set_seed(23)
+    try:
+        for inline in (1, 0):
+            L.euler_gpu_set_tuning(26, inline)
+            for call, count in enumerate((25, 10, 1, 64)):
+                on, ow, ot = OG.sample_neighbor(23, call, q, [0], count, -1)
+                for row_kernel in (1, 2):
+                    L.euler_gpu_set_tuning(19, row_kernel)
+                    gn, gw, gt = G.sample_neighbor(qt, [0], count, -1, call_id=call)
+                    assert np.array_equal(t2n(gn), on), (inline, count, row_kernel)
+                    assert np.array_equal(t2n(gw), ow) and np.array_equal(t2n(gt), ot)
+                L.euler_gpu_set_tuning(19, 1)
+            on, ow, ot = OG.sample_fanout(23, 30, q[:900], [[0], [0]], [5, 4], -1)
+            for fused in (1, 0):
+                L.euler_gpu_set_tuning(23, fused)
+                gn, gw, gt = G.sample_fanout(qt[:900], [[0], [0]], [5, 4], -1, call_id=30)
+                for h in range(2):
+                    assert np.array_equal(t2n(gn[h + 1]), on[h]), (inline, fused, h)
+                    assert np.array_equal(t2n(gw[h]), ow[h]) and np.array_equal(t2n(gt[h]), ot[h])
+            L.euler_gpu_set_tuning(23, 1)
+            walk = G.random_walk(qt[:800], [[0]] * 6, 1.0, 1.0, -1, call_id=50)
+            assert np.array_equal(t2n(walk), OG.random_walk(23, 50, q[:800], [[0]] * 6, 6, 1.0, 1.0, -1))
+    finally:
+        L.euler_gpu_set_tuning(26, 0)
+        L.euler_gpu_set_tuning(19, 1)
+        L.euler_gpu_set_tuning(23, 1)
+
+
 def test_small_fanout_in_one_launch(EA, O, torch_cuda, big_pair):
     """Tuning key 23: a 2-hop fanout of single listed types below the duplicate-root
     threshold runs as ONE launch (a workgroup draws a root's first-hop samples and,
