@@ -76,6 +76,8 @@ def parse():
                          "reports the median repetition (and lists all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--n2v", action="store_true", help="deepwalk workload: also time node2vec")
+    ap.add_argument("--unfused-aggregation", action="store_true",
+                    help="hetero workload: gather, then scatter_mean (two passes over the E x D block)")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-small-batch", action="store_true",
                     help="skip the B = 1 024 latency leg (profiling runs: its 1 000 small "
@@ -326,12 +328,17 @@ def run_hetero(args):
     dst = torch.arange(B, device="cuda", dtype=torch.int32).repeat_interleave(CNT)
     type_sets = ([3], [1, 4, 6], list(range(T)))
 
+    fused = not args.unfused_aggregation
+
     def step(i):
         aggs = []
         for c, et in enumerate(type_sets):
             nb, _w, _t = G.sample_neighbor(roots[i], et, CNT, N + 1, call_id=3 * i + c)
-            x = ops.gather(feat, nb.reshape(-1).to(torch.int32))
-            aggs.append(ops.scatter_mean(x, dst, B))
+            src = nb.reshape(-1).to(torch.int32)
+            if fused:      # the rows are reduced as they are read, CNT per root
+                aggs.append(ops.gather_segment_reduce("mean", feat, src, B, count=CNT))
+            else:
+                aggs.append(ops.scatter_mean(ops.gather(feat, src), dst, B))
         return aggs
 
     for i in range(args.warmup):
@@ -357,9 +364,13 @@ def run_hetero(args):
     g_ms = _events(lambda: ops.gather(feat, nb), 10)
     x = ops.gather(feat, nb)
     s_ms = _events(lambda: ops.scatter_mean(x, dst, B), 10)
+    f_ms = _events(lambda: ops.gather_segment_reduce("mean", feat, nb, B, count=CNT), 10)
+    assert torch.equal(ops.gather_segment_reduce("mean", feat, nb, B, count=CNT), ops.scatter_mean(x, dst, B))
+    assert torch.equal(ops.gather_scatter("mean", feat, nb, dst, B), ops.scatter_mean(x, dst, B))
     E = B * CNT
     g_bytes = 8.0 * E * D + 4.0 * E
     s_bytes = 4.0 * E * D + 4.0 * E + 4.0 * B * D
+    f_bytes = 4.0 * E * D + 4.0 * E + 4.0 * B * D      # rows read once, their numbers, means written
     line = {
         "metric": "sampled + aggregated edges/sec, typed SampleNeighbor (k = 1, 3 of 8, all) + 128-d "
                   "gather + scatter_mean, heterogeneous graph (BASELINE configs[4], 1 GPU)",
@@ -372,13 +383,23 @@ def run_hetero(args):
                                % (N, G.num_edges, T, B, CNT, N + 2, D),
                    "graph_build_s": round(build_s, 2), "repeats": len(reps),
                    "repeat_ms_per_step": [round(x_ / args.steps * 1e3, 4) for x_ in reps],
+                   "aggregation": ("ops.gather_segment_reduce (one pass, %d rows per root)" % CNT if fused
+                                   else "ops.gather + ops.scatter_mean"),
                    "phases_ms": dict({k_: round(v_, 4) for k_, v_ in ph.items()},
-                                     gather=round(g_ms, 4), scatter_mean=round(s_ms, 4))},
-        "roofline": {"kernel": "GatherRowsKernel (MPGather, 16-B lanes)", "bound": "hbm",
-                     "achieved": round(g_bytes / (g_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(g_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                     "traffic": None, "algorithmic_bytes_per_launch": g_bytes,
-                     "avg_launch_ms": round(g_ms, 4),
+                                     gather=round(g_ms, 4), scatter_mean=round(s_ms, 4),
+                                     gather_scatter_mean=round(f_ms, 4))},
+        "roofline": {"kernel": ("SegmentReduceVec4Kernel<mean> over gathered rows (ops.gather_segment_reduce)"
+                                if fused else "GatherRowsKernel (MPGather, 16-B lanes)"),
+                     "bound": "hbm",
+                     "achieved": round((f_bytes / f_ms if fused else g_bytes / g_ms) / 1e6, 1),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round((f_bytes / f_ms if fused else g_bytes / g_ms) / 1e6 / HBM_PEAK_GBS, 4),
+                     "traffic": None,
+                     "algorithmic_bytes_per_launch": f_bytes if fused else g_bytes,
+                     "avg_launch_ms": round(f_ms if fused else g_ms, 4),
+                     "gather": {"GBps": round(g_bytes / (g_ms * 1e-3) / 1e9, 1),
+                                "frac": round(g_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                "algorithmic_bytes": g_bytes, "ms": round(g_ms, 4)},
                      "scatter_mean": {"GBps": round(s_bytes / (s_ms * 1e-3) / 1e9, 1),
                                       "frac": round(s_bytes / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                       "algorithmic_bytes": s_bytes, "ms": round(s_ms, 4)}},

@@ -97,6 +97,29 @@ __device__ __forceinline__ int64_t SegStart(const int32_t* keys, int64_t e, int3
   return LowerBound(keys, e, (int32_t)r);
 }
 
+// Where destination r's updates are: a grouped key array (scatter: bisected / guessed),
+// explicit offsets (segment reduce), or `count` updates per destination.
+struct SegSpec {
+  const int32_t* keys;
+  const int64_t* ptr;      // [size + 1] when keys == nullptr (nullptr: uniform `count`)
+  int64_t count;
+  int64_t e;
+  int32_t size;
+};
+
+__device__ __forceinline__ void SegBounds(const SegSpec& s, int64_t r, int64_t* b, int64_t* en) {
+  if (s.keys != nullptr) {
+    *b = SegStart(s.keys, s.e, s.size, r);
+    *en = SegStart(s.keys, s.e, s.size, r + 1);
+  } else if (s.ptr != nullptr) {
+    *b = s.ptr[r];
+    *en = s.ptr[r + 1];
+  } else {
+    *b = r * s.count;
+    *en = *b + s.count;
+  }
+}
+
 // One wave-slot per output row: blockDim = (64, 4): 4 rows per block,
 // 64 lanes over the columns.  keys[] = destination of the p-th update in
 // grouped order; perm[p] = original update index (nullptr = identity).
@@ -104,16 +127,19 @@ __device__ __forceinline__ int64_t SegStart(const int32_t* keys, int64_t e, int3
 // scatter_add(x) / (scatter_add(ones) + 1e-7) (euler_ops/mp_ops.py:65-69); the
 // count of a destination is its segment length (an exact f32 below 2^24), so the
 // same correctly rounded f32 add and divide give the same bits in one pass.
+// gsrc != nullptr: update p is row gsrc[p] of `upd` (the gather of the message passing
+// step folded into the reduce: the E x d block of gathered rows is never written).
 template <int MODE>
 __global__ __launch_bounds__(256) void SegmentReduceKernel(
-    const float* __restrict__ upd, const int32_t* __restrict__ keys,
-    const uint32_t* __restrict__ perm, int64_t e, int64_t d, int32_t size,
+    const float* __restrict__ upd, const SegSpec seg,
+    const uint32_t* __restrict__ perm, const int32_t* __restrict__ gsrc, int64_t d,
     float* __restrict__ out) {
   const int lane = threadIdx.x;
+  const int32_t size = seg.size;
   for (int64_t r = (int64_t)blockIdx.x * blockDim.y + threadIdx.y; r < size;
        r += (int64_t)gridDim.x * blockDim.y) {
-    const int64_t b = SegStart(keys, e, size, r);
-    const int64_t en = SegStart(keys, e, size, r + 1);
+    int64_t b, en;
+    SegBounds(seg, r, &b, &en);
     constexpr bool IS_MAX = MODE == 1;
     const float denom = __fadd_rn((float)(en - b), 1e-7f);
     for (int64_t c = lane; c < d; c += 64) {
@@ -125,7 +151,8 @@ __global__ __launch_bounds__(256) void SegmentReduceKernel(
         float v[8];
 #pragma unroll
         for (int x = 0; x < 8; ++x) {
-          const int64_t src = perm ? (int64_t)perm[p + x] : p + x;
+          int64_t src = perm ? (int64_t)perm[p + x] : p + x;
+          if (gsrc) src = gsrc[src];
           v[x] = upd[src * d + c];
         }
 #pragma unroll
@@ -135,7 +162,8 @@ __global__ __launch_bounds__(256) void SegmentReduceKernel(
         }
       }
       for (; p < en; ++p) {
-        const int64_t src = perm ? (int64_t)perm[p] : p;
+        int64_t src = perm ? (int64_t)perm[p] : p;
+        if (gsrc) src = gsrc[src];
         const float v = upd[src * d + c];
         if (IS_MAX) { if (v > acc) acc = v; }
         else acc = __fadd_rn(acc, v);
@@ -151,27 +179,53 @@ __global__ __launch_bounds__(256) void SegmentReduceKernel(
 // order - identical bits, a quarter of the memory instructions.
 template <int MODE>
 __global__ __launch_bounds__(256) void SegmentReduceVec4Kernel(
-    const float* __restrict__ upd, const int32_t* __restrict__ keys,
-    const uint32_t* __restrict__ perm, int64_t e, int32_t d4, int32_t size,
+    const float* __restrict__ upd, const SegSpec seg,
+    const uint32_t* __restrict__ perm, const int32_t* __restrict__ gsrc, int32_t d4,
     float* __restrict__ out) {
   constexpr bool IS_MAX = MODE == 1;
+  const int32_t size = seg.size;
   const int32_t rows_per_wave = 64 / d4;
   const int32_t sub = threadIdx.x / d4, cl = threadIdx.x - sub * d4;
   const int64_t rows_per_block = (int64_t)blockDim.y * rows_per_wave;
   for (int64_t r = (int64_t)blockIdx.x * rows_per_block + threadIdx.y * rows_per_wave + sub;
        r < size; r += (int64_t)gridDim.x * rows_per_block) {
-    const int64_t b = SegStart(keys, e, size, r);
-    const int64_t en = SegStart(keys, e, size, r + 1);
+    int64_t b, en;
+    SegBounds(seg, r, &b, &en);
     const float denom = __fadd_rn((float)(en - b), 1e-7f);
     const float init = IS_MAX ? (float)-1e9 : 0.f;
     float4 acc = make_float4(init, init, init, init);
     const float4* u4 = reinterpret_cast<const float4*>(upd);
     int64_t p = b;
+    // the additions stay in input order; the loads (for gathered rows: the row numbers
+    // first, then the rows) are issued eight at a time so that their latencies overlap
+    for (; p + 8 <= en; p += 8) {
+      int64_t src[8];
+#pragma unroll
+      for (int x = 0; x < 8; ++x) src[x] = perm ? (int64_t)perm[p + x] : p + x;
+      if (gsrc) {
+#pragma unroll
+        for (int x = 0; x < 8; ++x) src[x] = gsrc[src[x]];
+      }
+      float4 v[8];
+#pragma unroll
+      for (int x = 0; x < 8; ++x) v[x] = u4[src[x] * d4 + cl];
+#pragma unroll
+      for (int x = 0; x < 8; ++x) {
+        if (IS_MAX) {
+          acc.x = v[x].x > acc.x ? v[x].x : acc.x; acc.y = v[x].y > acc.y ? v[x].y : acc.y;
+          acc.z = v[x].z > acc.z ? v[x].z : acc.z; acc.w = v[x].w > acc.w ? v[x].w : acc.w;
+        } else {
+          acc.x = __fadd_rn(acc.x, v[x].x); acc.y = __fadd_rn(acc.y, v[x].y);
+          acc.z = __fadd_rn(acc.z, v[x].z); acc.w = __fadd_rn(acc.w, v[x].w);
+        }
+      }
+    }
     for (; p + 4 <= en; p += 4) {
       float4 v[4];
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
-        const int64_t src = perm ? (int64_t)perm[p + x] : p + x;
+        int64_t src = perm ? (int64_t)perm[p + x] : p + x;
+        if (gsrc) src = gsrc[src];
         v[x] = u4[src * d4 + cl];
       }
 #pragma unroll
@@ -186,7 +240,8 @@ __global__ __launch_bounds__(256) void SegmentReduceVec4Kernel(
       }
     }
     for (; p < en; ++p) {
-      const int64_t src = perm ? (int64_t)perm[p] : p;
+      int64_t src = perm ? (int64_t)perm[p] : p;
+      if (gsrc) src = gsrc[src];
       const float4 v = u4[src * d4 + cl];
       if (IS_MAX) {
         acc.x = v.x > acc.x ? v.x : acc.x; acc.y = v.y > acc.y ? v.y : acc.y;
@@ -206,7 +261,8 @@ __global__ __launch_bounds__(256) void SegmentReduceVec4Kernel(
 
 template <int MODE>
 static int ScatterImpl(hipStream_t st, const float* upd, const int32_t* idx,
-                       int64_t e, int64_t d, int32_t size, float* out) {
+                       int64_t e, int64_t d, int32_t size, float* out,
+                       const int32_t* gsrc = nullptr) {
   if (e < 0 || d < 0 || size < 0) return Fail(EULER_GPU_EINVAL, "scatter: bad shape");
   if (size == 0 || d == 0) return EULER_GPU_OK;
   if (!out || (e > 0 && (!upd || !idx)))
@@ -264,12 +320,36 @@ static int ScatterImpl(hipStream_t st, const float* upd, const int32_t* idx,
     int64_t blocks = ((int64_t)size + rows_per_block - 1) / rows_per_block;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(SegmentReduceVec4Kernel<MODE>, dim3((unsigned)blocks), block, 0, st, upd,
-                       keys, perm, e, (int32_t)d4, size, out);
+                       SegSpec{keys, nullptr, 0, e, size}, perm, gsrc, (int32_t)d4, out);
   } else {
     int64_t blocks = ((int64_t)size + 3) / 4;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(SegmentReduceKernel<MODE>, dim3((unsigned)blocks), block, 0,
-                       st, upd, keys, perm, e, d, size, out);
+                       st, upd, SegSpec{keys, nullptr, 0, e, size}, perm, gsrc, d, out);
+  }
+  EG_HIP(hipGetLastError());
+  return EULER_GPU_OK;
+}
+
+template <int MODE>
+static int SegmentReduceImpl(hipStream_t st, const float* params, const int32_t* gsrc,
+                             const int64_t* seg_ptr, int64_t count, int64_t d, int32_t size,
+                             float* out) {
+  const dim3 block(64, 4);
+  const int64_t d4 = d / 4;
+  const SegSpec seg{nullptr, seg_ptr, count, 0, size};
+  if (d % 4 == 0 && d4 <= 64 && 64 % d4 == 0 && ((uintptr_t)params % 16 == 0) &&
+      ((uintptr_t)out % 16 == 0)) {
+    const int64_t rows_per_block = 4 * (64 / d4);
+    int64_t blocks = ((int64_t)size + rows_per_block - 1) / rows_per_block;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(SegmentReduceVec4Kernel<MODE>, dim3((unsigned)blocks), block, 0, st, params,
+                       seg, nullptr, gsrc, (int32_t)d4, out);
+  } else {
+    int64_t blocks = ((int64_t)size + 3) / 4;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(SegmentReduceKernel<MODE>, dim3((unsigned)blocks), block, 0, st, params, seg,
+                       nullptr, gsrc, d, out);
   }
   EG_HIP(hipGetLastError());
   return EULER_GPU_OK;
@@ -684,6 +764,42 @@ int euler_gpu_scatter_max(void* stream, const float* updates_dev,
                           int32_t size, float* out_dev) {
   return ScatterImpl<1>((hipStream_t)stream, updates_dev, indices_dev, e, d,
                         size, out_dev);
+}
+
+int euler_gpu_gather_segment_reduce(void* stream, int32_t mode, const float* params_dev,
+                                    const int32_t* gather_indices_dev,
+                                    const int64_t* seg_ptr_dev, int64_t count, int64_t d,
+                                    int32_t size, float* out_dev) {
+  if (mode < 0 || mode > 2)
+    return Fail(EULER_GPU_EINVAL, "gather_segment_reduce: mode is 0 add, 1 max, 2 mean");
+  if (d < 0 || size < 0 || (!seg_ptr_dev && count < 0))
+    return Fail(EULER_GPU_EINVAL, "gather_segment_reduce: bad shape");
+  if (size == 0 || d == 0) return EULER_GPU_OK;
+  if (!out_dev || !params_dev) return Fail(EULER_GPU_EINVAL, "gather_segment_reduce: null buffer");
+  if (!seg_ptr_dev && mode == 2 && count >= (1LL << 24))
+    return Fail(EULER_GPU_EINVAL, "gather_segment_reduce: mean needs segments shorter than 2^24");
+  hipStream_t st = (hipStream_t)stream;
+  if (mode == 0)
+    return SegmentReduceImpl<0>(st, params_dev, gather_indices_dev, seg_ptr_dev, count, d, size, out_dev);
+  if (mode == 1)
+    return SegmentReduceImpl<1>(st, params_dev, gather_indices_dev, seg_ptr_dev, count, d, size, out_dev);
+  return SegmentReduceImpl<2>(st, params_dev, gather_indices_dev, seg_ptr_dev, count, d, size, out_dev);
+}
+
+int euler_gpu_gather_scatter(void* stream, int32_t mode, const float* params_dev,
+                             const int32_t* gather_indices_dev,
+                             const int32_t* scatter_indices_dev, int64_t e, int64_t d,
+                             int32_t size, float* out_dev) {
+  if (mode < 0 || mode > 2) return Fail(EULER_GPU_EINVAL, "gather_scatter: mode is 0 add, 1 max, 2 mean");
+  if (e > 0 && !gather_indices_dev) return Fail(EULER_GPU_EINVAL, "gather_scatter: null buffer");
+  if (mode == 2 && e >= (1LL << 24))
+    return Fail(EULER_GPU_EINVAL, "gather_scatter: mean needs e < 2^24");
+  hipStream_t st = (hipStream_t)stream;
+  if (mode == 0)
+    return ScatterImpl<0>(st, params_dev, scatter_indices_dev, e, d, size, out_dev, gather_indices_dev);
+  if (mode == 1)
+    return ScatterImpl<1>(st, params_dev, scatter_indices_dev, e, d, size, out_dev, gather_indices_dev);
+  return ScatterImpl<2>(st, params_dev, scatter_indices_dev, e, d, size, out_dev, gather_indices_dev);
 }
 
 int euler_gpu_neighbor_post_process(void* stream, int64_t n, int32_t* idx_dev,

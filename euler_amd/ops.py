@@ -139,6 +139,136 @@ def scatter_mean(updates, indices, size):
     return out / count
 
 
+_GS_MODE = {"add": 0, "max": 1, "mean": 2}
+
+
+def _gather_scatter_raw(mode, params, gather_indices, scatter_indices, size):
+    params = params.contiguous()
+    gi = gather_indices.to(torch.int32).contiguous()
+    si = scatter_indices.to(torch.int32).contiguous()
+    _need_cuda(params, gi)
+    _need_cuda(params, si)
+    if gi.numel() != si.numel():
+        raise ValueError("gather_scatter: one gather index and one scatter index per edge")
+    if gi.numel() and (int(gi.min()) < 0 or int(gi.max()) >= params.shape[0]):
+        raise IndexError("gather_scatter: gather index out of range")
+    e, d = gi.numel(), params.shape[1]
+    out = torch.empty((int(size), d), dtype=torch.float32, device=params.device)
+    with torch.cuda.device(params.device):
+        check(lib().euler_gpu_gather_scatter(_stream(), mode, _ptr(params), _ptr(gi), _ptr(si), e, d,
+                                             int(size), _ptr(out)))
+    return out
+
+
+class _GatherScatter(torch.autograd.Function):
+    """scatter_(op, gather(params, gi), si, size) in one pass (euler_gpu_gather_scatter);
+    the gradient is the composition's: the scatter's gradient (mp_ops.py:39-62) per edge,
+    scatter-added into the rows of params the edges read."""
+
+    @staticmethod
+    def forward(ctx, params, gather_indices, scatter_indices, size, op):
+        out = _gather_scatter_raw(_GS_MODE[op], params, gather_indices, scatter_indices, size)
+        ctx.save_for_backward(params, gather_indices, scatter_indices, out)
+        ctx.size, ctx.op = size, op
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        params, gi, si, out = ctx.saved_tensors
+        if ctx.op == "add":
+            per_edge = _gather_raw(grad, si)
+        elif ctx.op == "mean":
+            ones = torch.ones((si.numel(), 1), dtype=torch.float32, device=grad.device)
+            count = _scatter_raw(lib().euler_gpu_scatter_add, ones, si, ctx.size) + 1e-7
+            per_edge = _gather_raw(grad / count, si)
+        else:
+            updates = _gather_raw(params, gi)
+            indicators = (updates == _gather_raw(out, si)).to(updates.dtype)
+            num_selected = _scatter_raw(lib().euler_gpu_scatter_add, indicators, si, ctx.size)
+            per_edge = indicators / _gather_raw(num_selected, si) * _gather_raw(grad, si)
+        return (_scatter_raw(lib().euler_gpu_scatter_add, per_edge, gi, params.shape[0]),
+                None, None, None, None)
+
+
+def gather_scatter(op, params, gather_indices, scatter_indices, size):
+    """scatter_(op, gather(params, gather_indices), scatter_indices, size) for op in
+    "add" / "max" / "mean" - the aggregation of a message-passing step whose message is
+    the neighbour's row (SAGE mean / max, GCN after its normalisation) - without
+    materialising the gathered [E, D] block: same bits, a third of the HBM traffic."""
+    if op not in _GS_MODE:
+        raise ValueError("gather_scatter: op is add, max or mean")
+    if op == "mean" and gather_indices.numel() >= (1 << 24):
+        return scatter_mean(gather(params, gather_indices), scatter_indices, size)
+    return _GatherScatter.apply(params, gather_indices, scatter_indices, int(size), op)
+
+
+def _segment_dst(seg_ptr, count, size, device):
+    """destination of every update of a segmented block (for the gradient)"""
+    if seg_ptr is None:
+        return torch.arange(size, device=device, dtype=torch.int32).repeat_interleave(int(count))
+    lens = (seg_ptr[1:] - seg_ptr[:-1]).to(torch.int64)
+    return torch.repeat_interleave(torch.arange(size, device=device, dtype=torch.int32), lens)
+
+
+class _GatherSegmentReduce(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, params, gather_indices, seg_ptr, count, size, op):
+        params = params.contiguous()
+        gi = gather_indices.to(torch.int32).contiguous()
+        _need_cuda(params, gi)
+        sp = None
+        if seg_ptr is not None:
+            sp = seg_ptr.to(torch.int64).contiguous()
+            _need_cuda(params, sp)
+            if sp.numel() != size + 1:
+                raise ValueError("gather_segment_reduce: seg_ptr has size + 1 entries")
+        elif gi.numel() != size * count:
+            raise ValueError("gather_segment_reduce: size * count gather indices")
+        if gi.numel() and (int(gi.min()) < 0 or int(gi.max()) >= params.shape[0]):
+            raise IndexError("gather_segment_reduce: gather index out of range")
+        out = torch.empty((int(size), params.shape[1]), dtype=torch.float32, device=params.device)
+        with torch.cuda.device(params.device):
+            check(lib().euler_gpu_gather_segment_reduce(
+                _stream(), _GS_MODE[op], _ptr(params), _ptr(gi), _ptr(sp) if sp is not None else None,
+                int(count), params.shape[1], int(size), _ptr(out)))
+        ctx.save_for_backward(params, gi, sp if sp is not None else torch.empty(0), out)
+        ctx.has_ptr, ctx.count, ctx.size, ctx.op = sp is not None, int(count), int(size), op
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        params, gi, sp, out = ctx.saved_tensors
+        si = _segment_dst(sp if ctx.has_ptr else None, ctx.count, ctx.size, grad.device)
+        if ctx.op == "add":
+            per_edge = _gather_raw(grad, si)
+        elif ctx.op == "mean":
+            ones = torch.ones((si.numel(), 1), dtype=torch.float32, device=grad.device)
+            cnt = _scatter_raw(lib().euler_gpu_scatter_add, ones, si, ctx.size) + 1e-7
+            per_edge = _gather_raw(grad / cnt, si)
+        else:
+            updates = _gather_raw(params, gi)
+            indicators = (updates == _gather_raw(out, si)).to(updates.dtype)
+            num_selected = _scatter_raw(lib().euler_gpu_scatter_add, indicators, si, ctx.size)
+            per_edge = indicators / _gather_raw(num_selected, si) * _gather_raw(grad, si)
+        return (_scatter_raw(lib().euler_gpu_scatter_add, per_edge, gi, params.shape[0]),
+                None, None, None, None, None)
+
+
+def gather_segment_reduce(op, params, gather_indices, size, seg_ptr=None, count=None):
+    """The aggregation of a sampled block: destination r reduces (op = "add" / "max" /
+    "mean") the rows params[gather_indices[p]] for p in [seg_ptr[r], seg_ptr[r + 1]) - or
+    its `count` consecutive indices when seg_ptr is None (SampleNeighbor's fixed fan-out)
+    - in that order.  The bits of scatter_(op, gather(params, gather_indices), dst, size)
+    with dst = the destination of every index, in one pass and without the scatter's
+    look at its key column (no host wait)."""
+    if op not in _GS_MODE:
+        raise ValueError("gather_segment_reduce: op is add, max or mean")
+    if (seg_ptr is None) == (count is None):
+        raise ValueError("gather_segment_reduce: pass seg_ptr or count")
+    return _GatherSegmentReduce.apply(params, gather_indices, seg_ptr, 0 if count is None else int(count),
+                                      int(size), op)
+
+
 def scatter_softmax(updates, indices, size):
     """mp_ops.py:76-79."""
     updates = updates - gather(scatter_max(updates, indices, size), indices)

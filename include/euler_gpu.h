@@ -579,6 +579,27 @@ int euler_gpu_scatter_max(void* stream, const float* updates_dev,
 int euler_gpu_scatter_mean(void* stream, const float* updates_dev,
                            const int32_t* indices_dev, int64_t e, int64_t d,
                            int32_t size, float* out_dev);
+/* scatter_{add,max,mean}(gather(params, gather_indices), scatter_indices, size) of a
+ * message-passing step (tf_euler/python/convolution: x_j = gather(x, edge_index[1]);
+ * scatter_(aggr, x_j, edge_index[0])) in ONE pass: a destination's updates are read
+ * straight from the rows of `params` they name, in input order - the bits of the
+ * composition, without writing and re-reading the e x d block of gathered rows (a third
+ * of the composition's HBM traffic).  mode: 0 add, 1 max, 2 mean.  Indices are int32,
+ * gather indices must be valid rows of params. */
+int euler_gpu_gather_scatter(void* stream, int32_t mode, const float* params_dev,
+                             const int32_t* gather_indices_dev,
+                             const int32_t* scatter_indices_dev, int64_t e, int64_t d,
+                             int32_t size, float* out_dev);
+/* The same reduction when the caller knows the segments (a sampled block: `count`
+ * neighbours per destination, or CSR offsets): out[r] = reduce over p in
+ * [seg_ptr[r], seg_ptr[r+1]) - or [r * count, (r+1) * count) when seg_ptr_dev is NULL -
+ * of params[gather_indices[p]] (gather_indices_dev NULL: of params[p]), in that order.
+ * No sortedness check of a key column, no host wait.  mean divides by (length + 1e-7)
+ * as scatter_mean does. */
+int euler_gpu_gather_segment_reduce(void* stream, int32_t mode, const float* params_dev,
+                                    const int32_t* gather_indices_dev,
+                                    const int64_t* seg_ptr_dev, int64_t count, int64_t d,
+                                    int32_t size, float* out_dev);
 int euler_gpu_gather(void* stream, const float* params_dev,
                      const int32_t* indices_dev, int64_t e, int64_t d,
                      int64_t n_params, float* out_dev);

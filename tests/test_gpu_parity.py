@@ -266,6 +266,67 @@ def test_mp_ops_goldens_and_oracle(EA, O, torch_cuda, ref_tests):
                            rtol=0, atol=1e-5)
 
 
+def test_gather_scatter_fused_equals_composition(EA, O, torch_cuda):
+    """ops.gather_scatter(op, x, gi, si, size) - the aggregation of a message-passing step
+    in one pass (euler_gpu_gather_scatter) - has the bits of scatter_(op, gather(x, gi),
+    si, size) and of the oracle's sequential loops, forward, and the composition's
+    gradient; sorted (sampled blocks) and unsorted destinations, D a multiple of 4 or
+    not, empty destinations, repeated sources."""
+    torch = torch_cuda
+    ops = EA.ops
+    rng = np.random.default_rng(8)
+    for e, d, n, size, sort in ((6000, 128, 900, 600, True), (5000, 32, 300, 700, False),
+                                (777, 7, 40, 50, False), (1, 3, 2, 4, True), (0, 8, 5, 3, True)):
+        x = (rng.standard_normal((n, d)) * 50).astype(np.float32)
+        gi = rng.integers(0, n, e).astype(np.int32)
+        si = rng.integers(0, size, e).astype(np.int32)
+        if sort:
+            si = np.sort(si)
+        xt = torch.as_tensor(x).cuda()
+        git, sit = torch.as_tensor(gi).cuda(), torch.as_tensor(si).cuda()
+        for op, oracle in (("add", O.scatter_add), ("max", O.scatter_max), ("mean", None)):
+            fused = ops.gather_scatter(op, xt, git, sit, size)
+            comp = ops.scatter_(op, ops.gather(xt, git), sit, size)
+            assert np.array_equal(t2n(fused), t2n(comp)), (op, e, d)
+            if oracle is not None and e > 0:
+                assert np.array_equal(t2n(fused), oracle(O.gather(x, gi), si, size)), (op, e, d)
+        if e > 1:
+            for op in ("add", "mean", "max"):
+                g = torch.as_tensor(rng.standard_normal((size, d)).astype(np.float32)).cuda()
+                a = xt.clone().requires_grad_(True)
+                b = xt.clone().requires_grad_(True)
+                (ops.gather_scatter(op, a, git, sit, size) * g).sum().backward()
+                (ops.scatter_(op, ops.gather(b, git), sit, size) * g).sum().backward()
+                assert np.array_equal(t2n(a.grad), t2n(b.grad)), (op, e, d)
+    with pytest.raises(IndexError):
+        ops.gather_scatter("add", xt, torch.as_tensor([7], dtype=torch.int32).cuda(),
+                           torch.as_tensor([0], dtype=torch.int32).cuda(), 2)
+    # the segmented form (a sampled block): fixed fan-out and CSR offsets, no key column
+    for d, n, size, count in ((128, 5000, 700, 10), (64, 300, 90, 25), (6, 50, 33, 3), (128, 40, 5, 1)):
+        x = (rng.standard_normal((n, d)) * 50).astype(np.float32)
+        xt = torch.as_tensor(x).cuda()
+        gi = rng.integers(0, n, size * count).astype(np.int32)
+        git = torch.as_tensor(gi).cuda()
+        dst = torch.arange(size, dtype=torch.int32).repeat_interleave(count).cuda()
+        lens = rng.integers(0, 2 * count + 1, size)
+        lens[-1] = 0
+        ptr = np.zeros(size + 1, np.int64); ptr[1:] = np.cumsum(lens)
+        gi2 = rng.integers(0, n, int(ptr[-1])).astype(np.int32)
+        gi2t, ptrt = torch.as_tensor(gi2).cuda(), torch.as_tensor(ptr).cuda()
+        dst2 = torch.as_tensor(np.repeat(np.arange(size, dtype=np.int32), lens)).cuda()
+        for op in ("add", "max", "mean"):
+            a = ops.gather_segment_reduce(op, xt, git, size, count=count)
+            assert np.array_equal(t2n(a), t2n(ops.scatter_(op, ops.gather(xt, git), dst, size))), (op, d)
+            b = ops.gather_segment_reduce(op, xt, gi2t, size, seg_ptr=ptrt)
+            assert np.array_equal(t2n(b), t2n(ops.scatter_(op, ops.gather(xt, gi2t), dst2, size))), (op, d)
+            g = torch.as_tensor(rng.standard_normal((size, d)).astype(np.float32)).cuda()
+            p1 = xt.clone().requires_grad_(True)
+            p2 = xt.clone().requires_grad_(True)
+            (ops.gather_segment_reduce(op, p1, gi2t, size, seg_ptr=ptrt) * g).sum().backward()
+            (ops.scatter_(op, ops.gather(p2, gi2t), dst2, size) * g).sum().backward()
+            assert np.array_equal(t2n(p1.grad), t2n(p2.grad)), (op, d)
+
+
 def test_mp_gradients(EA, torch_cuda):
     """mp_ops_test.py:38-94 check compute_gradient_error < 1e-4; here the
     registered gradients are compared with torch's own autograd of the same
