@@ -430,36 +430,62 @@ struct WalkArgs {
   // rounded w / p); 0 = divide
   float inv_p;
   float inv_q;
+  int32_t ablate;         // measurement only (tuning key 2): 8 = random_walk keeps its path to itself
 };
 
 // FAST: one listed edge type per step on a graph with non-decreasing running
 // sums - every step is the block-pivot search of K1 (draw 0 of the current
 // node, call_id + step), i.e. ~log5(deg / 10) + 4 dependent loads instead of
 // the reference loop's 2 * ceil(log2 deg).
-template <bool FAST>
+// The path of a walker is walk_len + 1 consecutive int64: a lane that stored every step
+// itself issued 8-byte writes 8 * (walk_len + 1) bytes apart - a partial sector each, 14 %
+// of the kernel (profiles/r2_walk_ab.txt).  The steps are staged in LDS instead
+// (kWalkStage per walker, one padded row per lane) and written by the whole workgroup,
+// eight lanes per walker: 64 contiguous bytes.
+constexpr int kWalkStage = 8;
+
+template <bool FAST, bool BLOCKED = false>
 __global__ __launch_bounds__(256, kWavesPerSimd) void RandomWalkKernel(const WalkArgs a) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  __shared__ int64_t stage[256 * (kWalkStage + 1)];
   const int64_t L = a.walk_len + 1;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n;
-       i += stride) {
-    uint64_t cur = (uint64_t)a.nodes[i];
-    a.out[i * L] = (int64_t)cur;
-    for (int32_t s = 0; s < a.walk_len; ++s) {
-      uint64_t id = 0; float w; int32_t t;
-      if (FAST) {
-        Segment sg;
-        if (LoadSegment<true>(a.g, FindRow(a.g, cur), a.edge_types[s], &sg)) {
-          const Philox4 blk = RngBlock(a.seed, a.call_id + (uint32_t)s, kDomainNeighbor,
-                                       cur, 0);
-          BlockPivotSample(a.g, sg, UnitFromWords(blk.w[0], blk.w[1]), &id, &w);
+  const int64_t tiles = (a.n + 255) / 256;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t i = tile * 256 + threadIdx.x;
+    const bool live = i < a.n;
+    uint64_t cur = live ? (uint64_t)a.nodes[i] : 0;
+    if (live) a.out[i * L] = (int64_t)cur;
+    for (int32_t s0 = 0; s0 < a.walk_len; s0 += kWalkStage) {
+      const int32_t ns = min(kWalkStage, a.walk_len - s0);
+      for (int32_t k = 0; k < ns; ++k) {
+        const int32_t s = s0 + k;
+        uint64_t id = 0; float w; int32_t t;
+        if (live) {
+          if (FAST) {
+            Segment sg;
+            if (LoadSegment<true>(a.g, FindRow(a.g, cur), a.edge_types[s], &sg)) {
+              const Philox4 blk = RngBlock(a.seed, a.call_id + (uint32_t)s, kDomainNeighbor,
+                                           cur, 0);
+              if (BLOCKED) BlockedSample(a.g, sg, UnitFromWords(blk.w[0], blk.w[1]), &id, &w);
+              else BlockPivotSample(a.g, sg, UnitFromWords(blk.w[0], blk.w[1]), &id, &w);
+            }
+          } else {
+            RowSampler rs;
+            InitRowSampler(rs, a.g, FindRow(a.g, cur), a.edge_types + s * a.k, a.k);
+            if (rs.valid) SampleAt(rs, a.seed, a.call_id + (uint32_t)s, cur, 0, &id, &w, &t);
+          }
         }
-      } else {
-        RowSampler rs;
-        InitRowSampler(rs, a.g, FindRow(a.g, cur), a.edge_types + s * a.k, a.k);
-        if (rs.valid) SampleAt(rs, a.seed, a.call_id + (uint32_t)s, cur, 0, &id, &w, &t);
+        stage[threadIdx.x * (kWalkStage + 1) + k] = id == 0 ? a.default_node : (int64_t)id;
+        cur = id;
       }
-      a.out[i * L + s + 1] = id == 0 ? a.default_node : (int64_t)id;
-      cur = id;
+      __syncthreads();
+      // entry e = (walker e / ns of the tile, step e % ns): consecutive lanes, consecutive words
+      for (int32_t e = threadIdx.x; e < 256 * ns; e += 256) {
+        const int32_t wl = e / ns, k = e - wl * ns;
+        const int64_t wi = tile * 256 + wl;
+        if (wi < a.n && !(a.ablate & 8))
+          a.out[wi * L + s0 + k + 1] = stage[wl * (kWalkStage + 1) + k];
+      }
+      __syncthreads();
     }
   }
 }
@@ -1757,6 +1783,7 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
   a.g = SamplingView(g); a.seed = seed; a.call_id = call_id; a.nodes = nodes_dev;
   a.edge_types = et_dev; a.out = out_dev; a.n = n; a.default_node = default_node;
   a.k = k; a.walk_len = walk_len; a.p = p; a.q = q;
+  a.ablate = g_k1_ablate;
   {
     // w / p by an exact reciprocal when p and q are powers of two (both then are the
     // correctly rounded quotient)
@@ -1770,7 +1797,11 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
   const float kEps = 1.0e-6;
   // random_walk_op.cc:281: fabs(p_ - 1.0) <= kEps && fabs(q_ - 1.0) <= kEps
   if (std::fabs((double)p - 1.0) <= kEps && std::fabs((double)q - 1.0) <= kEps) {
-    if (k == 1 && g->view.monotone && g->view.blk != nullptr && g_k1_variant >= 5) {
+    if (k == 1 && g->view.monotone && g->view.blk != nullptr && g_k1_variant == 3) {
+      // A/B: the 32-ary skip levels (one line per level) instead of the fanout-5 block pivots
+      hipLaunchKernelGGL((RandomWalkKernel<true, true>), dim3(GridFor(n, block)), dim3(block), 0,
+                         st, a);
+    } else if (k == 1 && g->view.monotone && g->view.blk != nullptr && g_k1_variant >= 5) {
       hipLaunchKernelGGL(RandomWalkKernel<true>, dim3(GridFor(n, block)), dim3(block), 0,
                          st, a);
     } else {
