@@ -20,6 +20,7 @@
 
 #include "layer_fns.h"
 #include "local_layer_host.h"
+#include "wave_sums.h"
 
 namespace euler_gpu {
 
@@ -126,7 +127,12 @@ __device__ __forceinline__ float ChainGroup(float sum, const int (&di)[kSumGroup
 #pragma unroll
   for (int u = 0; u < kSumGroup; ++u) {
     const int32_t cnt = e - (p0 + 64 * u);
-    if (cnt > 0) sum = ChunkChain(sum, __int_as_float(di[u]), lane, cnt < 64 ? cnt : 64);
+    if (cnt > 0) {
+      // the integer form of the same sums first (wave_sums.h); the chain where it does not apply
+      float total;
+      if (BinadeChunkTotal(sum, __int_as_float(di[u]), lane, &total)) sum = total;
+      else sum = ChunkChain(sum, __int_as_float(di[u]), lane, cnt < 64 ? cnt : 64);
+    }
   }
   return sum;
 }

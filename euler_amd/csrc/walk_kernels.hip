@@ -8,6 +8,7 @@
 
 #include "k1_args.h"
 #include "k1_search.h"
+#include "wave_sums.h"
 
 namespace euler_gpu {
 
@@ -762,24 +763,6 @@ __device__ __forceinline__ int64_t ReadLane64(int64_t v, int src) {
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
   const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), src);
   return (int64_t)(((uint64_t)hi << 32) | lo);
-}
-
-__device__ __forceinline__ float ReadLaneF(float v, int src) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
-}
-
-// Inclusive integer sum over the wave (mod 2^32): four row_shr steps inside each
-// row of 16 lanes, then the three row totals added to the rows above them.
-__device__ __forceinline__ uint32_t WaveInclusiveAdd(uint32_t x, int lane) {
-  int32_t v = (int32_t)x;
-  v += __builtin_amdgcn_update_dpp(0, v, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x112 /* row_shr:2 */, 0xf, 0xf, true);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x114 /* row_shr:4 */, 0xf, 0xf, true);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x118 /* row_shr:8 */, 0xf, 0xf, true);
-  const int32_t t0 = __builtin_amdgcn_readlane(v, 15);
-  const int32_t t1 = __builtin_amdgcn_readlane(v, 31);
-  const int32_t t2 = __builtin_amdgcn_readlane(v, 47);
-  return (uint32_t)(v + (lane >= 16 ? t0 : 0) + (lane >= 32 ? t1 : 0) + (lane >= 48 ? t2 : 0));
 }
 
 // The add chain: lane after lane, a lane's kN2vR entries one after the other.
