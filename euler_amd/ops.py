@@ -142,7 +142,13 @@ def scatter_mean(updates, indices, size):
 _GS_MODE = {"add": 0, "max": 1, "mean": 2}
 
 
-def _gather_scatter_raw(mode, params, gather_indices, scatter_indices, size):
+def _check_rows(name, gi, n_rows):
+    """opt-in (a device round trip): the kernels index params with these as they are"""
+    if gi.numel() and (int(gi.min()) < 0 or int(gi.max()) >= n_rows):
+        raise IndexError("%s: gather index out of range" % name)
+
+
+def _gather_scatter_raw(mode, params, gather_indices, scatter_indices, size, validate=False):
     params = params.contiguous()
     gi = gather_indices.to(torch.int32).contiguous()
     si = scatter_indices.to(torch.int32).contiguous()
@@ -150,8 +156,8 @@ def _gather_scatter_raw(mode, params, gather_indices, scatter_indices, size):
     _need_cuda(params, si)
     if gi.numel() != si.numel():
         raise ValueError("gather_scatter: one gather index and one scatter index per edge")
-    if gi.numel() and (int(gi.min()) < 0 or int(gi.max()) >= params.shape[0]):
-        raise IndexError("gather_scatter: gather index out of range")
+    if validate:
+        _check_rows("gather_scatter", gi, params.shape[0])
     e, d = gi.numel(), params.shape[1]
     out = torch.empty((int(size), d), dtype=torch.float32, device=params.device)
     with torch.cuda.device(params.device):
@@ -166,8 +172,9 @@ class _GatherScatter(torch.autograd.Function):
     scatter-added into the rows of params the edges read."""
 
     @staticmethod
-    def forward(ctx, params, gather_indices, scatter_indices, size, op):
-        out = _gather_scatter_raw(_GS_MODE[op], params, gather_indices, scatter_indices, size)
+    def forward(ctx, params, gather_indices, scatter_indices, size, op, validate):
+        out = _gather_scatter_raw(_GS_MODE[op], params, gather_indices, scatter_indices, size,
+                                  validate)
         ctx.save_for_backward(params, gather_indices, scatter_indices, out)
         ctx.size, ctx.op = size, op
         return out
@@ -187,19 +194,21 @@ class _GatherScatter(torch.autograd.Function):
             num_selected = _scatter_raw(lib().euler_gpu_scatter_add, indicators, si, ctx.size)
             per_edge = indicators / _gather_raw(num_selected, si) * _gather_raw(grad, si)
         return (_scatter_raw(lib().euler_gpu_scatter_add, per_edge, gi, params.shape[0]),
-                None, None, None, None)
+                None, None, None, None, None)
 
 
-def gather_scatter(op, params, gather_indices, scatter_indices, size):
+def gather_scatter(op, params, gather_indices, scatter_indices, size, validate=False):
     """scatter_(op, gather(params, gather_indices), scatter_indices, size) for op in
     "add" / "max" / "mean" - the aggregation of a message-passing step whose message is
     the neighbour's row (SAGE mean / max, GCN after its normalisation) - without
-    materialising the gathered [E, D] block: same bits, a third of the HBM traffic."""
+    materialising the gathered [E, D] block: same bits, a third of the HBM traffic.
+    Like `gather`, the kernel trusts the gather indices; validate=True checks them first
+    (one device round trip)."""
     if op not in _GS_MODE:
         raise ValueError("gather_scatter: op is add, max or mean")
     if op == "mean" and gather_indices.numel() >= (1 << 24):
         return scatter_mean(gather(params, gather_indices), scatter_indices, size)
-    return _GatherScatter.apply(params, gather_indices, scatter_indices, int(size), op)
+    return _GatherScatter.apply(params, gather_indices, scatter_indices, int(size), op, bool(validate))
 
 
 def _segment_dst(seg_ptr, count, size, device):
@@ -212,7 +221,7 @@ def _segment_dst(seg_ptr, count, size, device):
 
 class _GatherSegmentReduce(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, params, gather_indices, seg_ptr, count, size, op):
+    def forward(ctx, params, gather_indices, seg_ptr, count, size, op, validate):
         params = params.contiguous()
         gi = gather_indices.to(torch.int32).contiguous()
         _need_cuda(params, gi)
@@ -224,8 +233,8 @@ class _GatherSegmentReduce(torch.autograd.Function):
                 raise ValueError("gather_segment_reduce: seg_ptr has size + 1 entries")
         elif gi.numel() != size * count:
             raise ValueError("gather_segment_reduce: size * count gather indices")
-        if gi.numel() and (int(gi.min()) < 0 or int(gi.max()) >= params.shape[0]):
-            raise IndexError("gather_segment_reduce: gather index out of range")
+        if validate:
+            _check_rows("gather_segment_reduce", gi, params.shape[0])
         out = torch.empty((int(size), params.shape[1]), dtype=torch.float32, device=params.device)
         with torch.cuda.device(params.device):
             check(lib().euler_gpu_gather_segment_reduce(
@@ -251,22 +260,23 @@ class _GatherSegmentReduce(torch.autograd.Function):
             num_selected = _scatter_raw(lib().euler_gpu_scatter_add, indicators, si, ctx.size)
             per_edge = indicators / _gather_raw(num_selected, si) * _gather_raw(grad, si)
         return (_scatter_raw(lib().euler_gpu_scatter_add, per_edge, gi, params.shape[0]),
-                None, None, None, None, None)
+                None, None, None, None, None, None)
 
 
-def gather_segment_reduce(op, params, gather_indices, size, seg_ptr=None, count=None):
+def gather_segment_reduce(op, params, gather_indices, size, seg_ptr=None, count=None, validate=False):
     """The aggregation of a sampled block: destination r reduces (op = "add" / "max" /
     "mean") the rows params[gather_indices[p]] for p in [seg_ptr[r], seg_ptr[r + 1]) - or
     its `count` consecutive indices when seg_ptr is None (SampleNeighbor's fixed fan-out)
     - in that order.  The bits of scatter_(op, gather(params, gather_indices), dst, size)
     with dst = the destination of every index, in one pass and without the scatter's
-    look at its key column (no host wait)."""
+    look at its key column (no host wait; validate=True checks the gather indices first,
+    which is one)."""
     if op not in _GS_MODE:
         raise ValueError("gather_segment_reduce: op is add, max or mean")
     if (seg_ptr is None) == (count is None):
         raise ValueError("gather_segment_reduce: pass seg_ptr or count")
     return _GatherSegmentReduce.apply(params, gather_indices, seg_ptr, 0 if count is None else int(count),
-                                      int(size), op)
+                                      int(size), op, bool(validate))
 
 
 def scatter_softmax(updates, indices, size):

@@ -300,7 +300,7 @@ def test_gather_scatter_fused_equals_composition(EA, O, torch_cuda):
                 assert np.array_equal(t2n(a.grad), t2n(b.grad)), (op, e, d)
     with pytest.raises(IndexError):
         ops.gather_scatter("add", xt, torch.as_tensor([7], dtype=torch.int32).cuda(),
-                           torch.as_tensor([0], dtype=torch.int32).cuda(), 2)
+                           torch.as_tensor([0], dtype=torch.int32).cuda(), 2, validate=True)
     # the segmented form (a sampled block): fixed fan-out and CSR offsets, no key column
     for d, n, size, count in ((128, 5000, 700, 10), (64, 300, 90, 25), (6, 50, 33, 3), (128, 40, 5, 1)):
         x = (rng.standard_normal((n, d)) * 50).astype(np.float32)
