@@ -7,7 +7,8 @@
 //   SampleNode     -> euler_gpu_sample_node      tf_euler/kernels/sample_node_op.cc
 //   SampleFanout   -> euler_gpu_sample_fanout    tf_euler/kernels/sample_fanout_op.cc
 //   GetDenseFeature-> euler_gpu_get_dense_feature  tf_euler/kernels/get_dense_feature_op.cc
-//   MPScatterAdd   -> euler_gpu_scatter_add      tf_euler/kernels/scatter_op.cc
+//   MPScatterAdd   -> euler_gpu_gather_segment_reduce (euler_gpu_scatter_add for arbitrary indices)
+//                                               tf_euler/kernels/scatter_op.cc
 //
 // usage: sage_minibatch <data_path> <seed> <batch> <fanout1> <fanout2> <feature id> <dim>
 // Prints one line per result array (ids in decimal, floats as hex bit patterns)
@@ -109,14 +110,12 @@ int main(int argc, char** argv) {
 
   // features of the second hop's nodes, summed into their first-hop parents
   float *feat, *agg;
-  int32_t* parent;
-  if (DeviceAlloc(&feat, n2 * dim) || DeviceAlloc(&agg, n1 * dim) || DeviceAlloc(&parent, n2))
-    return 2;
+  if (DeviceAlloc(&feat, n2 * dim) || DeviceAlloc(&agg, n1 * dim)) return 2;
   EULER_OK(euler_gpu_get_dense_feature(g, stream, ids[1], n2, fid, dim, feat));
-  std::vector<int32_t> parent_h(n2);
-  for (int64_t i = 0; i < n2; ++i) parent_h[i] = (int32_t)(i / counts[1]);
-  HIP_OK(hipMemcpyAsync(parent, parent_h.data(), n2 * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-  EULER_OK(euler_gpu_scatter_add(stream, feat, parent, n2, dim, (int32_t)n1, agg));
+  // the counts[1] second-hop rows of a first-hop node are consecutive: MPScatterAdd with the
+  // index i / counts[1] is a segment reduce with a fixed segment length (same adds, same order)
+  EULER_OK(euler_gpu_gather_segment_reduce(stream, /*mode=add*/ 0, feat, /*gather_indices=*/nullptr,
+                                           /*seg_ptr=*/nullptr, counts[1], dim, (int32_t)n1, agg));
   HIP_OK(hipStreamSynchronize(stream));
 
   PrintIds("roots", ToHost(roots, batch));
