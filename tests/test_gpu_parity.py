@@ -517,6 +517,46 @@ def test_full_size_properties(EA, O, torch_cuda):
     assert np.array_equal(t2n(a[2])[sel], ot)
 
 
+def test_node2vec_on_the_metric_graph_hub_rows(EA, O, torch_cuda):
+    """node2vec (p = 0.25, q = 4) on the 100M-node / 1B-edge graph of the headline metric,
+    walkers started on its largest rows (578 088 and 182 555 neighbours: 2 259 chunks of
+    256, checkpoints 8 chunks apart, long runs of integer running sums): the one-launch
+    kernel and the per-step launch agree, and both equal the oracle fed with the rows
+    exported from HBM for every node the walks visit."""
+    torch = torch_cuda
+    from euler_amd import _lib
+    L = _lib.lib()
+    N = 100_000_000
+    G = EA.Graph.synthetic(EA.synth_params(20240521, N, 10 * N, weighted=True))
+    G.set_seed(99)
+    rng = np.random.default_rng(12)
+    starts = np.concatenate([[1, 2, 3, 5, 9, 17, 33, 1, 2], rng.integers(1, N + 1, 23)]).astype(np.int64)
+    st = torch.as_tensor(starts).cuda()
+    steps = 4
+    et = [[0]] * steps
+    try:
+        L.euler_gpu_set_tuning(7, 2)
+        a = G.random_walk(st, et, 0.25, 4.0, N + 1, call_id=7)
+        L.euler_gpu_set_tuning(7, 3)
+        b = G.random_walk(st, et, 0.25, 4.0, N + 1, call_id=7)
+    finally:
+        L.euler_gpu_set_tuning(7, 2)
+    assert torch.equal(a, b)
+    walks = t2n(a)
+    rows = np.unique(walks[walks <= N]).astype(np.uint64)
+    row_ptr, type_end, nbr, pw, tp = G.export_rows(rows)
+    assert int(np.diff(row_ptr).max()) == 578088
+    OG = O.OracleGraph(O.CSR(rows, row_ptr, type_end, nbr, pw, tp, 1))
+    want = OG.random_walk(99, 7, starts, et, steps, 0.25, 4.0, N + 1)
+    assert np.array_equal(walks, want)
+    # DeepWalk (configs[3]: length 40, p = q = 1) from the same graph, same check
+    dw = t2n(G.random_walk(st[:16], [[0]] * 40, 1.0, 1.0, N + 1, call_id=100))
+    rows = np.unique(dw[dw <= N]).astype(np.uint64)
+    row_ptr, type_end, nbr, pw, tp = G.export_rows(rows)
+    OG = O.OracleGraph(O.CSR(rows, row_ptr, type_end, nbr, pw, tp, 1))
+    assert np.array_equal(dw, OG.random_walk(99, 100, starts[:16], [[0]] * 40, 40, 1.0, 1.0, N + 1))
+
+
 def test_non_monotone_rows_use_reference_loop(EA, O, torch_cuda):
     """Negative weights make the running sums non-monotone; the reference's
     RandomSelect then reads outside the row (size_t underflow of `mid - 1`,
@@ -1086,7 +1126,7 @@ def test_node2vec_long_lists_both_kernels(EA, O, torch_cuda, wave, ascending):
 @pytest.mark.parametrize("mode", ["stepwise", "stepwise_all_big", "one_launch"])
 @pytest.mark.parametrize("weights", ["random", "dyadic", "zeros", "ascending"])
 def test_node2vec_hub_rows_checkpointed_sums(EA, O, torch_cuda, weights, mode):
-    """node2vec on hubs of 33 000 - 70 000 neighbours.  Default (key 7 = 3): the walk
+    """node2vec on hubs of 33 000 - 300 000 neighbours.  Default (key 7 = 3): the walk
     is launched per step and these rows go to the workgroup kernel (1 024 entries per
     round, parent cursor and running sum carried across 16 waves); "stepwise_all_big"
     sends every row of 2+ entries there, "one_launch" (key 7 = 2) is one wave per
@@ -1105,7 +1145,9 @@ def test_node2vec_hub_rows_checkpointed_sums(EA, O, torch_cuda, weights, mode):
     ids = np.arange(1, n + 1).astype(np.uint64)
     deg = rng.integers(1, 9, size=n)
     hubs = np.arange(0, 5)
-    deg[hubs] = [41000, 70000, 33000, 52000, 36000]
+    # 300 000 entries = 1 172 chunks of 256: more than the 512 checkpoint slots of the wave
+    # kernel, so its checkpoints are 4 chunks apart and the second pass replays up to 4
+    deg[hubs] = [41000, 300000, 33000, 52000, 36000]
     seg = np.zeros(n + 1, np.int64)
     seg[1:] = np.cumsum(deg)
     E = int(seg[-1])
