@@ -1,4 +1,7 @@
-cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp; mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 < /dev/null | grep -E "passed|failed|error" | tail -3 | tee gpurun_out/r2_gpu_pytest_summary.txt
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 < /dev/null | grep -i smoke
-timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r2_final_bench.json 2>/dev/null < /dev/null; tail -1 gpurun_out/r2_final_bench.json | cut -c1-260
+cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp; mkdir -p gpurun_out; R=$PWD
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/dw_stats -o dw -- python $R/bench.py --workload deepwalk --n2v --steps 3 --warmup 1 --repeats 1 > /dev/null 2>&1 < /dev/null; echo "deepwalk rc=$?"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/he_stats -o he -- python $R/bench.py --workload hetero --steps 6 --warmup 2 --repeats 1 > /dev/null 2>&1 < /dev/null; echo "hetero rc=$?"
+cd $R
+for d in dw he; do f=$(find gpurun_out/${d}_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f gpurun_out/r2_${d}_kernel_stats.csv && head -8 gpurun_out/r2_${d}_kernel_stats.csv | cut -c1-150; done
+rm -rf gpurun_out/dw_stats gpurun_out/he_stats
