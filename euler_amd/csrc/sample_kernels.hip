@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void ExpandPackedKernel(
 }
 // ---- tuning switches (euler_gpu_set_tuning; declared in k1_args.h) ----
 thread_local int g_k1_dedup = 1;     // 0 = never, 1 = automatic for >= 100 000 roots, 2 = always try
-thread_local int g_n2v_wave = 2;     // node2vec: 3 = launched per step, long lists by a workgroup (walk_kernels.hip:
+thread_local int g_n2v_wave = 2;     // node2vec: 3 = launched per step, long lists by a workgroup (n2v_kernels.h:
                         // N2vBigStepKernel), 2 = one launch, one wave per walker, the two-cursor walk by
                         // the whole wave, 1 = lane 0 walks LDS-staged lists, 0 = one lane per walker
 thread_local int g_k1_inline = 0;    // key 26: rows of <= 9 edges sampled from their row_inline line (common.h);

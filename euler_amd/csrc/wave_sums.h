@@ -28,7 +28,7 @@ __device__ __forceinline__ uint32_t WaveInclusiveAdd(uint32_t x, int lane) {
 // reference's sequential f32 adds would give it, WITHOUT adding one by one when the
 // sums stay inside the binade of the carry and no add is a rounding tie: then
 // fl(carry + d) = (m + n) * ulp with n = d / ulp rounded to nearest, and the chain is an
-// integer sum over the mantissa (walk_kernels.hip has the full account and the
+// integer sum over the mantissa (n2v_kernels.h has the full account and the
 // four-entries-per-lane form; tools/n2v_binade_model.py restates it in numpy).  A lane
 // the integer sum cannot pass (the sum leaves the binade there, a tie, a negative
 // entry, a zero carry) is done by one real add and the lanes after it start over;

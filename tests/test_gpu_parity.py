@@ -1133,7 +1133,7 @@ def test_node2vec_hub_rows_checkpointed_sums(EA, O, torch_cuda, weights, mode):
     walker.  Both keep a (running sum, parent cursor) checkpoint per 2^sh rounds and
     replay only the rounds the draw lands in; inside a round the f32 running sums come
     from the integer scan over the mantissa when the round stays in one binade without
-    a rounding tie (walk_kernels.hip: ChunkScanBinade) and from the add chain
+    a rounding tie (n2v_kernels.h: WaveSumsVec) and from the add chain
     otherwise.  Dyadic weights (multiples of 1/8) make ties and exact sums common,
     random weights make them rare, all-zero rows take RandomSelect's fall-through
     (random_walk_op.cc:83-138), ascending lists make every child move the parent

@@ -1,4 +1,4 @@
-"""The arithmetic behind node2vec's running sums (walk_kernels.hip: WaveSumsVec) restated
+"""The arithmetic behind node2vec's running sums (n2v_kernels.h: WaveSumsVec) restated
 in numpy (tools/n2v_binade_model.py) equals the sequential f32 adds of the reference's
 BuildWeights / RandomSelect pair (tf_euler/kernels/random_walk_op.cc:83-168) on every
 input class the kernel meets: random and dyadic weights (ties), zeros, binade crossings,

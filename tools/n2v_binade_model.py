@@ -1,4 +1,4 @@
-"""numpy restatement of the node2vec running-sum scheme (walk_kernels.hip: WaveSumsVec)
+"""numpy restatement of the node2vec running-sum scheme (n2v_kernels.h: WaveSumsVec)
 against the sequential f32 adds it replaces.
 
 For a carry m * ulp in [2^e, 2^(e+1)) and carry + d below 2^(e+1), fl(carry + d) =
