@@ -13,6 +13,7 @@
 #include "k1_args.h"
 #include "k1_search.h"
 #include "k1_row.h"
+#include "fanout_local.h"
 
 extern thread_local int g_feature_vec4;   // mp_kernels.hip
 namespace euler_gpu { extern thread_local int g_root_host_batch, g_adj_scan, g_adj_long_row, g_sum_scalar; }   // layer_kernels.hip
@@ -554,6 +555,17 @@ thread_local int g_k1_ablate = 0;   // measurement only: skip parts of the block
 thread_local int g_k1_ilp = 4;      // samples per lane of the ILP kernel (1, 2, 4, 8)
 thread_local int g_full_nb_balanced = 1;   // get_full_neighbor fill: a lane owns 4 output entries (key 24)
 thread_local int g_fanout_fused = 1;       // small 2-hop single-type fanouts as one launch (key 23)
+// 2-hop single-type fanouts as ONE kernel with the duplicate children found inside the wave
+// (fanout_local.h).  key 27: 0 = off (hop by hop, global duplicate path), 1 = on.
+thread_local int g_fanout_local = 1;
+thread_local int g_fl_roots = 4;      // key 28: roots per wave (1 .. 16)
+thread_local int g_fl_cap = 0;        // key 29: hop-2 slots per pass, 0 = 8 x roots per wave
+thread_local int g_fl_block = 256;    // key 30: threads per workgroup (64, 128, 256)
+thread_local int g_fl_wide = 1;       // key 31: weights / types as 16-byte stores
+thread_local int g_fl_grid_cap = 0;   // key 32: workgroups (0 = one tile per wave, no loop)
+thread_local int g_fl_wps = 8;        // key 35: register budget, waves per SIMD (8 or 5)
+thread_local int g_fl_plain = 1;      // key 34: the constant-folded kernel for plain graphs
+thread_local int g_fl_min_roots = 4096;   // key 33: smaller batches keep the workgroup-per-root kernel
 thread_local int g_k1_pair_distinct = 0;   // pass over the distinct roots: two samples per lane (key 22)
 thread_local int g_expand_lean = 1;  // last hop, even count: the lean gather-copy kernel (key 21)
 thread_local int g_k1_row = 1;       // 1 / 2 = block-pivot calls without the duplicate path sample with one
@@ -1534,6 +1546,63 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
     }
     ~FanoutConcurrency() { if (own) t_concurrent = -1; }
   } fanout_concurrency(g, stream);
+  // a 2-hop fanout of single listed types: ONE kernel, duplicates found inside the wave
+  if (g_fanout_local != 0 && events == nullptr && layers == 2 && k == 1 && n >= g_fl_min_roots &&
+      g_k1_variant == 6 && g->view.monotone && counts_host[0] > 0 && counts_host[1] > 0) {
+    const int32_t c1 = counts_host[0], c2 = counts_host[1];
+    int32_t gr = g_fl_roots < 1 ? 1 : g_fl_roots > 16 ? 16 : g_fl_roots;
+    while (gr > 1 && (int64_t)gr * c1 > 0x7FFF) gr >>= 1;
+    int32_t cap = g_fl_cap > 0 ? g_fl_cap : 8 * gr;
+    if (cap > gr * c1) cap = gr * c1;
+    const int block = (g_fl_block == 64 || g_fl_block == 128) ? g_fl_block : 256;
+    FanoutLocalLds lay = FanoutLocalLayout(gr, c1, c2, cap);
+    // shrink the pass until a workgroup's LDS fits
+    while (cap > 1 && (size_t)lay.bytes * (block / 64) > 64 * 1024) {
+      cap >>= 1;
+      lay = FanoutLocalLayout(gr, c1, c2, cap);
+    }
+    const uint64_t tile_pos = (uint64_t)gr * c1 * c2;
+    const bool fits = (size_t)lay.bytes * (block / 64) <= 64 * 1024 && (int64_t)gr * c1 <= 0x7FFF &&
+                      tile_pos * (uint64_t)(c1 > c2 ? c1 : c2) < 0xFFFFFFFFull;
+    if (fits) {
+      if (g->view.blk == nullptr) {
+        const int rc0 = EnsureBlockedIndex(g);
+        if (rc0 != EULER_GPU_OK) return rc0;
+      }
+      FanoutLocalArgs f{};
+      f.g = SamplingView(g); f.seed = seed; f.call_id = call_id; f.roots = roots_dev; f.n = n;
+      f.default_node = default_node;
+      f.c1 = c1; f.c2 = c2;
+      f.t1 = edge_types_host[0]; f.t2 = edge_types_host[1];
+      f.gr = gr; f.cap = cap; f.wave_lds = (int32_t)lay.bytes;
+      f.div_c1.Set((uint32_t)c1); f.div_c2.Set((uint32_t)c2);
+      uint8_t* wsb = (uint8_t*)workspace_dev;
+      f.id1 = out_id_dev[0]; f.w1 = out_w_dev[0]; f.ty1 = out_t_dev[0]; f.mask0 = wsb;
+      f.id2 = out_id_dev[1]; f.w2 = out_w_dev[1]; f.ty2 = out_t_dev[1];
+      f.mask1 = wsb + (((size_t)n + 15) & ~(size_t)15);
+      f.vec = (c2 % 2 == 0 && (uintptr_t)f.id2 % 16 == 0 && (uintptr_t)f.w2 % 16 == 0 &&
+               (uintptr_t)f.ty2 % 16 == 0) ? 1 : 0;
+      f.wide = (f.vec && g_fl_wide != 0 && tile_pos % 4 == 0) ? 1 : 0;
+      const int64_t tiles = (n + gr - 1) / gr;
+      const int wpb = block / 64;
+      int64_t blocks = (tiles + wpb - 1) / wpb;
+      if (g_fl_grid_cap > 0 && blocks > g_fl_grid_cap) blocks = g_fl_grid_cap;
+      const size_t lds = (size_t)lay.bytes * wpb;
+      const GraphView& v = f.g;
+      const bool plain = g_fl_plain != 0 && v.T == 1 && v.total_in_meta != 0 && v.uniform_w == 0 &&
+                         v.inline_k == 0 && v.map_mode == 0 && v.has_zero_nbr == 0 &&
+                         f.t1 == 0 && f.t2 == 0;
+      void (*kern)(const FanoutLocalArgs) = nullptr;
+#define EG_FL(W, P) (g_fl_wps == 5 ? SampleFanoutLocalKernel<W, P, 5> : SampleFanoutLocalKernel<W, P, 8>)
+      kern = f.wide ? (plain ? EG_FL(true, true) : EG_FL(true, false))
+                    : (plain ? EG_FL(false, true) : EG_FL(false, false));
+#undef EG_FL
+      hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(block), lds, stream, f);
+      EG_HIP(hipGetLastError());
+      if (uniq_off != nullptr) { uniq_off[0] = -1; uniq_off[1] = -1; }
+      return EULER_GPU_OK;
+    }
+  }
   std::lock_guard<std::recursive_mutex> launch_lk(g->launch_mu);
   // size the stream's scratch for the largest hop up front: the owner table a
   // hop fills for its successor must not move in between
@@ -1645,6 +1714,15 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 24) { g_full_nb_balanced = value != 0; return EULER_GPU_OK; }
   if (key == 25 && value >= 0) { g_n2v_big = value; return EULER_GPU_OK; }
   if (key == 26) { g_k1_inline = value != 0; return EULER_GPU_OK; }
+  if (key == 27) { g_fanout_local = value != 0; return EULER_GPU_OK; }
+  if (key == 28 && value >= 1 && value <= 16) { g_fl_roots = value; return EULER_GPU_OK; }
+  if (key == 29 && value >= 0) { g_fl_cap = value; return EULER_GPU_OK; }
+  if (key == 30 && (value == 64 || value == 128 || value == 256)) { g_fl_block = value; return EULER_GPU_OK; }
+  if (key == 31) { g_fl_wide = value != 0; return EULER_GPU_OK; }
+  if (key == 32 && value >= 0) { g_fl_grid_cap = value; return EULER_GPU_OK; }
+  if (key == 33 && value >= 0) { g_fl_min_roots = value; return EULER_GPU_OK; }
+  if (key == 34) { g_fl_plain = value != 0; return EULER_GPU_OK; }
+  if (key == 35 && (value == 5 || value == 8)) { g_fl_wps = value; return EULER_GPU_OK; }
   if (key == 1 && (value == 1 || value == 2 || value == 4 || value == 8)) {
     g_k1_ilp = value;
     return EULER_GPU_OK;

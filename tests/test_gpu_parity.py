@@ -1468,3 +1468,79 @@ def test_full_neighbor_fill_kernels_agree(EA, O, torch_cuda, big_pair):
                 assert np.array_equal(t2n(gw), ww) and np.array_equal(t2n(gt), wt)
     finally:
         _lib.lib().euler_gpu_set_tuning(24, 1)
+
+
+_FL_DEFAULTS = {27: 1, 28: 4, 29: 0, 30: 256, 31: 1, 32: 0, 33: 4096, 34: 1, 35: 8}
+
+
+@pytest.mark.parametrize("geom", [(4, 0, 256, 1, 8, 1, 0), (1, 1, 64, 0, 5, 0, 0), (2, 3, 128, 1, 8, 0, 0),
+                                  (8, 5, 256, 0, 8, 1, 3), (16, 64, 64, 1, 5, 1, 0), (3, 2, 256, 1, 8, 1, 1)],
+                         ids=["default", "gr1cap1", "gr2cap3", "gr8cap5grid3", "gr16cap64", "gr3cap2grid1"])
+def test_fanout_local_dedup_kernel(EA, O, torch_cuda, big_pair, geom):
+    """fanout_local.h: the 2-hop fanout of single listed types as ONE kernel - a wave owns
+    `gr` roots, finds the distinct children among its own hop-1 samples and samples each
+    once (`cap` of them per pass).  Every geometry (roots per wave, slots per pass, block
+    size, 8- / 16-byte weight stores, register budget, constant-folded or general build,
+    grid-stride loop) must give the oracle's ids / weights / types - including unknown
+    roots, id 0, rows without the listed type, odd counts (scalar stores), count 1, ragged
+    last tiles, duplicate roots, hashed and identity id maps, uniform weights and the
+    id-0 sentinel rule - and what the hop-by-hop kernels write."""
+    torch = torch_cuda
+    from euler_amd import _lib
+    L = _lib.lib()
+    gr, cap, block, wide, wps, plain, grid = geom
+    keys = {27: 1, 28: gr, 29: cap, 30: block, 31: wide, 32: grid, 33: 0, 34: plain, 35: wps}
+
+    def check(G, OG, q, et, counts, default, seed, call):
+        qt = torch.as_tensor(q).cuda()
+        G.set_seed(seed)
+        on, ow, ot = OG.sample_fanout(seed, call, q, et, counts, default)
+        L.euler_gpu_set_tuning(27, 1)
+        gn, gw, gt = G.sample_fanout(qt, et, counts, default, call_id=call)
+        for h in range(2):
+            assert np.array_equal(t2n(gn[h + 1]), on[h]), (geom, len(q), et, counts, h)
+            assert np.array_equal(t2n(gw[h]), ow[h]), (geom, len(q), et, counts, h)
+            assert np.array_equal(t2n(gt[h]), ot[h]), (geom, len(q), et, counts, h)
+        L.euler_gpu_set_tuning(27, 0)           # hop by hop
+        rn, rw, rt = G.sample_fanout(qt, et, counts, default, call_id=call)
+        for h in range(2):
+            assert torch.equal(gn[h + 1], rn[h + 1]) and torch.equal(gw[h], rw[h])
+            assert torch.equal(gt[h], rt[h])
+
+    try:
+        for k_, v_ in keys.items():
+            _lib.check(L.euler_gpu_set_tuning(k_, v_))
+        # 4 edge types, arbitrary (hashed) ids
+        G, OG, ids, rng = big_pair
+        for B in (1, 7, 333, 2050):
+            q = np.concatenate([rng.choice(ids, B), [0, 4242, 2 ** 62]]).astype(np.int64)
+            if B == 1:
+                q = q[:1]
+            for et, counts in (([[0], [1]], [25, 10]), ([[3], [3]], [7, 40]), ([[2], [0]], [1, 1]),
+                               ([[1], [9]], [5, 3]), ([[0], [2]], [70, 2]), ([[1], [1]], [10, 5])):
+                check(G, OG, q, et, counts, -5, 23, 91)
+        # one edge type, identity ids: weighted (the constant-folded build) and uniform
+        for weighted in (True, False):
+            p = EA.synth_params(977, 20000, 260000, n_types=1, weighted=weighted)
+            po = O.SynthParams()
+            for f, _ in po._fields_:
+                setattr(po, f, getattr(p, f))
+            G1, OG1 = EA.Graph.synthetic(p), O.OracleGraph(O.synth_csr(po))
+            r1 = np.random.default_rng(5)
+            q = np.concatenate([r1.integers(1, 20001, 3001), [0, 20001, 1, 1, 2]]).astype(np.int64)
+            for counts in ([25, 10], [3, 4], [10, 5]):
+                check(G1, OG1, q, [[0], [0]], counts, 20001, 3, 6)
+        # Q1: a row whose FIRST sample is node id 0 is dropped (both hops)
+        ids0 = np.array([0, 1, 2, 3], np.uint64)
+        seg = np.array([0, 2, 4, 6, 7], np.int64)
+        nbr = np.array([1, 2, 0, 2, 0, 3, 0], np.uint64)
+        w = np.array([1, 1, 5, 1, 1, 1, 2], np.float32)
+        csr = O.csr_from_raw(ids0, seg, nbr, w, 1)
+        G0, OG0 = gpu_graph(EA, csr), O.OracleGraph(csr)
+        q = np.array([0, 1, 2, 3, 9, 2, 2, 1], np.int64)
+        for call in range(12):
+            check(G0, OG0, q, [[0], [0]], [3, 2], -1, 1, call)
+            check(G0, OG0, q, [[0], [0]], [4, 6], -1, 1, 100 + call)
+    finally:
+        for k_, v_ in _FL_DEFAULTS.items():
+            L.euler_gpu_set_tuning(k_, v_)
