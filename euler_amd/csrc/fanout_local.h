@@ -31,8 +31,9 @@
 //
 // Same draws as the chained kernels: hop h uses call_id + h, stream = node id,
 // draw x of a row = Philox block x >> 1, half x & 1.  A hop-1 row without samples
-// (unknown root, empty type group, or - TF sentinel rule, Q1 - a first sample with
-// id 0) is default-filled and hands node id 0 to hop 2.
+// (unknown root, empty type group) is default-filled and hands node id 0 to hop 2; a row
+// the TF repack drops because its first sample is id 0 (Q1) is default-filled too, but
+// hop 2 samples its real ids: the reference chains the hops on the core tensors.
 #ifndef EULER_AMD_CSRC_FANOUT_LOCAL_H_
 #define EULER_AMD_CSRC_FANOUT_LOCAL_H_
 
@@ -172,12 +173,11 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLocalKernel(
           if (x == 0) (phase == 0 ? s_rvalid : s_svalid)[q] = (valid && !(zero_rule && id == 0)) ? 1 : 0;
         }
         if (phase == 0) {
-          if (zero_rule) {
-            WaveSync();
-            if (live) valid = s_rvalid[q] != 0;
-          }
           if (live) {
-            s_c1[tk] = valid ? id : 0;       // a missing row samples as node id 0 downstream
+            // hop 2 is chained on the CORE ids (sample_fanout_op.cc:37-42: one GQL): a row
+            // WITH samples hands them on even when the TF repack drops it for starting
+            // with id 0; a row without samples hands on the core fill, node id 0
+            s_c1[tk] = valid ? id : 0;
             s_w1[tk] = valid ? w : 0.f;
           }
         } else if (live) {
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLocalKernel(
         // s_rvalid was written by the root's j == 0 lane in phase 0
         const bool ok = s_rvalid[g] != 0;
         a.id1[out1 + tk] = ok ? s_c1[tk] : (uint64_t)a.default_node;
-        a.w1[out1 + tk] = s_w1[tk];
+        a.w1[out1 + tk] = ok ? s_w1[tk] : 0.f;
         a.ty1[out1 + tk] = ok ? a.t1 : -1;
         if (j == 0) a.mask0[r0 + g] = ok ? 0 : 1;
       }

@@ -1527,6 +1527,36 @@ int LaunchSampleNeighborCounted(const euler_gpu_graph* g, hipStream_t stream, ui
 
 using namespace euler_gpu;
 
+// TF dense repack of a hop sampled in the CORE layout (tf_euler/kernels/
+// sample_fanout_op.cc:124-137, sample_neighbor_op.cc:110-122): a row whose FIRST id is the
+// sentinel 0 - a row without samples, or a row with samples that happens to start with
+// node id 0 (Q1) - becomes default_node / 0.0 / -1.  Only graphs that contain the id 0
+// as a neighbour take this path: their fanouts are chained on the core ids, as the
+// reference's single GQL does, and repacked afterwards.
+__global__ __launch_bounds__(256) void TfRepackKernel(uint64_t* id, float* w, int32_t* t,
+                                                      int64_t n_rows, int32_t count,
+                                                      int64_t default_node, uint8_t* row_mask) {
+  const int64_t total = n_rows * (int64_t)count;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total; s += stride) {
+    const int64_t r = s / count;
+    const bool drop = id[r * count] == 0;
+    // the row's first id is what every lane of the row tests, so it is not rewritten
+    // here (no ordering between the lanes of a row): TfRepackFirstKernel does it
+    if (drop && s != r * count) { id[s] = (uint64_t)default_node; w[s] = 0.f; t[s] = -1; }
+    if (s == r * count && row_mask != nullptr) row_mask[r] = drop ? 1 : 0;
+  }
+}
+__global__ __launch_bounds__(256) void TfRepackFirstKernel(uint64_t* id, float* w, int32_t* t,
+                                                           int64_t n_rows, int32_t count,
+                                                           int64_t default_node) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride) {
+    const int64_t s = r * count;
+    if (id[s] == 0) { id[s] = (uint64_t)default_node; w[s] = 0.f; t[s] = -1; }
+  }
+}
+
 // The hops of a fanout under one lock: hop h's kernels that write the final ids
 // also enter them into hop h+1's owner table (MarkNextHop), so the duplicate
 // detection of hop h+1 starts at its scan.  events: 4 per hop (PhaseMark) or
@@ -1655,6 +1685,44 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
   uint8_t* ws = (uint8_t*)workspace_dev;
   HopFusion hop;
   int rc = EULER_GPU_OK;
+  // A graph with a neighbour id 0: the reference chains the hops on the CORE tensors
+  // (one GQL, sample_fanout_op.cc:37-42) - a row the TF repack drops because it starts
+  // with id 0 still hands its real samples to the next hop.  Sample in the core layout,
+  // let the next hop read it, repack afterwards.
+  const bool core_chain = g->view.has_zero_nbr != 0;
+  auto repack = [&](int32_t h, int64_t rows, uint8_t* row_mask) {
+    const int64_t total = rows * counts_host[h];
+    if (total <= 0) return;
+    hipLaunchKernelGGL(TfRepackKernel, dim3(GridFor(total, 256)), dim3(256), 0, stream,
+                       out_id_dev[h], out_w_dev[h], out_t_dev[h], rows, counts_host[h],
+                       default_node, row_mask);
+    hipLaunchKernelGGL(TfRepackFirstKernel, dim3(GridFor(rows, 256)), dim3(256), 0, stream,
+                       out_id_dev[h], out_w_dev[h], out_t_dev[h], rows, counts_host[h],
+                       default_node);
+  };
+  if (core_chain) {
+    int64_t rows_prev = 0;
+    uint8_t* mask_prev = nullptr;
+    for (int32_t h = 0; h < layers && rc == EULER_GPU_OK; ++h) {
+      uint8_t* row_mask = ws;
+      ws += ((size_t)m + 15) & ~(size_t)15;
+      if (events != nullptr) t_phase_events = events + (size_t)h * 4;
+      g_last_unique_offset = -1;
+      rc = LaunchSampleNeighbor(g, stream, seed, call_id + (uint32_t)h, roots, m, nullptr, 1,
+                                edge_types_host + (size_t)h * k, k, counts_host[h],
+                                EULER_GPU_LAYOUT_CORE, default_node, out_id_dev[h],
+                                out_w_dev[h], out_t_dev[h], nullptr, h == 0 ? 0 : 1, nullptr);
+      if (uniq_off != nullptr) uniq_off[h] = g_last_unique_offset;
+      if (h > 0) repack(h - 1, rows_prev, mask_prev);     // its ids have been read
+      rows_prev = m; mask_prev = row_mask;
+      roots = out_id_dev[h];
+      m *= counts_host[h];
+    }
+    if (rc == EULER_GPU_OK && layers > 0) repack(layers - 1, rows_prev, mask_prev);
+    t_phase_events = nullptr;
+    if (rc == EULER_GPU_OK) EG_HIP(hipGetLastError());
+    return rc;
+  }
   for (int32_t h = 0; h < layers && rc == EULER_GPU_OK; ++h) {
     // hop h: roots are the previous hop's TF-layout ids; rows the previous hop
     // marked as missing sample as the sentinel id 0, which is what the
