@@ -66,6 +66,7 @@ struct FanoutLocalArgs {
   int32_t vec;              // 1: c2 even and the outputs 16-byte aligned (two ids per lane)
   int32_t wave_lds;         // bytes of LDS per wave
   SmallDiv div_c1, div_c2;
+  SmallDiv div_h1, div_h2;  // by the pairs per row, (c1 + 1) / 2 and c2 / 2 (lean kernel)
   uint64_t* id1; float* w1; int32_t* ty1; uint8_t* mask0;
   uint64_t* id2; float* w2; int32_t* ty2; uint8_t* mask1;
 };
@@ -324,6 +325,427 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLocalKernel(
         a.w1[out1 + tk] = ok ? s_w1[tk] : 0.f;
         a.ty1[out1 + tk] = ok ? a.t1 : -1;
         if (j == 0) a.mask0[r0 + g] = ok ? 0 : 1;
+      }
+    }
+    WaveSync();
+  }
+}
+
+
+// ------------------------------------------------------------------------
+// The lean build of the same kernel for PLAIN graphs: one edge-type group per node with
+// the row total in its record, weighted, identity id map, no neighbour id 0, fewer than
+// 2^31 edges.  rocprofv3 on the general kernel above (profiles/r3_fl_v1_pmc.json): 3 400
+// VALU instructions per wave and tile, every one of them a quad-cycle - 185 us of the
+// step's 350 are VALU issue, the memory pipes idle half the time.  The search is the
+// cost, so here it is rewritten for instruction count (same contract: the first m of
+// the row with nw[m] > r, i.e. RandomSelect's index on a non-decreasing row):
+//   * a lane draws the PAIR of samples one Philox block yields (x, x + 1): root id, row
+//     record, the level ranges and the Philox block are per pair, and the two searches
+//     run in lockstep (two loads in flight);
+//   * compares are f32: for a float v and the f64 draw r, v > r  <=>  v > f with
+//     f = the largest float <= r (round-down of r) - one conversion per draw instead of
+//     one per key, full-rate compares;
+//   * the candidate range of level k is carried as base-5 DIGITS of the first / last
+//     block index (l[k] = 5 l[k+1] + digit), 3 bits each in one register, instead of
+//     twenty registers of quotients; levels are walked in a scalar loop from the
+//     wave's deepest level down, so the level's array offset is an SGPR;
+//   * the leaf counts with a bit mask (v_cmp + v_addc per key, one v_bcnt) and fetches
+//     nw[m-1], nw[m] and the id by index from the block line it just read;
+//   * duplicate children by EDGE: a root of <= 64 edges ORs its drawn edge offsets into
+//     one 64-bit LDS word; the slot of a sample is the rank of its bit (two distinct
+//     edges with the same neighbour are two slots - the rows are equal anyway);
+//   * hop 2 writes finished rows (default-filled when the child has none) into LDS
+//     and the write phase is a copy.
+// Draws whose r rounds up to the row total (Q3) and rows beyond the pivot levels' reach
+// replay the reference's bisection over the flat arrays (cold).
+// ------------------------------------------------------------------------
+// FindRow for the strided identity map
+__device__ __forceinline__ int64_t LeanFindRow(const GraphView& g, uint64_t id) {
+  const uint64_t d = id - g.id_base;
+  if (id < g.id_base) return -1;
+  if (g.id_stride == 1) return d < (uint64_t)g.n_rows ? (int64_t)d : -1;
+  const uint64_t r = d / g.id_stride;
+  return (r * g.id_stride == d && r < (uint64_t)g.n_rows) ? (int64_t)r : -1;
+}
+
+// largest float <= r (r >= 0)
+__device__ __forceinline__ float FloorToFloat(double r) {
+  float f = (float)r;
+  if ((double)f > r) f = __uint_as_float(__float_as_uint(f) - 1u);
+  return f;
+}
+
+// Both draws of one Philox block on one row.  lo = first edge, deg > 0, total = the row's
+// last running sum.  m[] = the edge drawn (global index).
+__device__ __forceinline__ void LeanSamplePair(const GraphView& g, const uint32_t lo,
+                                               const int32_t deg, const float total,
+                                               const bool live, const double u0, const double u1,
+                                               uint64_t id[2], float w[2], uint32_t m[2]) {
+  const uint32_t hi = lo + (uint32_t)deg - 1u;
+  const uint32_t l1 = lo / 10u, h1 = hi / 10u;
+  const uint32_t lo_off = lo - 10u * l1, hi_off = hi - 10u * h1;
+  // r = u * (total - 0) + 0: the subtraction and the addition of zero are exact
+  const double r0 = __dmul_rn(u0, (double)total), r1 = __dmul_rn(u1, (double)total);
+  const float f[2] = {FloorToFloat(r0), FloorToFloat(r1)};
+  // level ranges as base-5 digits; K = first level with <= 4 candidates
+  uint32_t lt = l1, ht = h1, ldig = 0, hdig = 0;
+  int32_t K = 0;
+  if (live && h1 != l1) {
+    K = 1;
+    while (ht - lt > 4u && K <= kPivotLevels) {
+      const uint32_t l5 = lt / 5u, h5 = ht / 5u;
+      ldig = (ldig << 3) | (lt - 5u * l5);
+      hdig = (hdig << 3) | (ht - 5u * h5);
+      lt = l5; ht = h5; ++K;
+    }
+  }
+  // cold: Q3 (r rounded up to the row's end) or a row beyond the levels' reach
+  const bool cold0 = live && (!((double)total > r0) || K > kPivotLevels);
+  const bool cold1 = live && (!((double)total > r1) || K > kPivotLevels);
+  if (K > kPivotLevels) K = 0;
+  uint32_t x[2] = {l1, l1};
+  bool found[2] = {false, false}, onl[2] = {true, true};
+  int32_t kmax = 0;
+#pragma unroll
+  for (int k = 1; k <= kPivotLevels; ++k) kmax = __ballot(K >= k) != 0ull ? k : kmax;
+  for (int k = kmax; k >= 1; --k) {
+    const float* lvl = k == 1 ? g.skip1 : g.bpiv + g.bpiv_off[k];
+    if (k <= K) {
+      uint32_t dl = 0, dh = 0;
+      if (k < K) { dl = ldig & 7u; dh = hdig & 7u; ldig >>= 3; hdig >>= 3; }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        uint32_t c_lo, c_hi;
+        if (k == K) { c_lo = lt; c_hi = ht; }
+        else {
+          c_lo = 5u * x[s] + (onl[s] ? dl : 0u);
+          c_hi = 5u * x[s] + (found[s] ? 4u : dh);
+        }
+        const int32_t cnt = (int32_t)(c_hi - c_lo);
+        const float4u kw = *reinterpret_cast<const float4u*>(lvl + c_lo);
+        int32_t pos = 0;
+        pos += (0 < cnt && !(kw.x > f[s])) ? 1 : 0;
+        pos += (1 < cnt && !(kw.y > f[s])) ? 1 : 0;
+        pos += (2 < cnt && !(kw.z > f[s])) ? 1 : 0;
+        pos += (3 < cnt && !(kw.w > f[s])) ? 1 : 0;
+        x[s] = c_lo + (uint32_t)pos;
+        onl[s] = onl[s] && pos == 0;
+        if (pos < cnt) found[s] = true;
+      }
+    }
+  }
+  // leaf: block x[s] holds the answer
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const EdgeBlock* bk = g.blk + x[s];
+    const uint32_t i_lo = x[s] == l1 ? lo_off : 0u;
+    const uint32_t i_hi = found[s] ? (uint32_t)(kEdgesPerBlock - 1) : hi_off;   // inclusive
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
+    if (live) {
+      a0 = *reinterpret_cast<const float4*>(bk->pw);
+      a1 = *reinterpret_cast<const float4*>(bk->pw + 4);
+      a2 = *reinterpret_cast<const float4*>(bk->pw + 8);   // pw[8], pw[9], prev_last, pad
+    }
+    // bit j = [pw[j] <= r] for j = 0 .. 8, built from the top: mask = 2 mask + bit
+    uint32_t le = 0;
+    le = 2u * le + (!(a2.x > f[s]) ? 1u : 0u);
+    le = 2u * le + (!(a1.w > f[s]) ? 1u : 0u);
+    le = 2u * le + (!(a1.z > f[s]) ? 1u : 0u);
+    le = 2u * le + (!(a1.y > f[s]) ? 1u : 0u);
+    le = 2u * le + (!(a1.x > f[s]) ? 1u : 0u);
+    le = 2u * le + (!(a0.w > f[s]) ? 1u : 0u);
+    le = 2u * le + (!(a0.z > f[s]) ? 1u : 0u);
+    le = 2u * le + (!(a0.y > f[s]) ? 1u : 0u);
+    le = 2u * le + (!(a0.x > f[s]) ? 1u : 0u);
+    const uint32_t range = ((1u << i_hi) - 1u) & ~((1u << i_lo) - 1u);     // bits [i_lo, i_hi)
+    const uint32_t i = i_lo + (uint32_t)__popc(le & range);
+    m[s] = 10u * x[s] + i;
+    id[s] = 0; w[s] = 0.f;
+    if (live) {
+      const uint32_t i1 = i == 0u ? 0u : i - 1u;
+      const float2 pv = *reinterpret_cast<const float2*>(
+          reinterpret_cast<const uint8_t*>(bk->pw) + 4u * i1);   // 4-byte aligned pair
+      id[s] = bk->nbr[i];
+      const float nw_m = i == 0u ? pv.x : pv.y;
+      float prev = i == 0u ? a2.z : pv.x;
+      if (m[s] == lo) prev = 0.f;                  // `mid ? nw[mid-1] : 0` is row-relative
+      w[s] = __fsub_rn(nw_m, prev);
+    }
+  }
+  if (__ballot(cold0 || cold1) != 0ull) {
+    // the reference's own bisection over the flat running sums (RandomSelect,
+    // compact_weighted_collection.h:30-52) - right on every row, slow, rare; once in
+    // the code for both draws
+#pragma nounroll
+    for (int s = 0; s < 2; ++s) {
+      if (s == 0 ? cold0 : cold1) {
+        const float* nw = g.prefix_w + lo;
+        const uint32_t mid = (uint32_t)RandomSelect(nw, 0, (uint64_t)(deg - 1), s == 0 ? u0 : u1);
+        const uint64_t ci = g.nbr[lo + mid];
+        const float cw = __fsub_rn(nw[mid], mid == 0u ? 0.f : nw[mid - 1]);
+        if (s == 0) { id[0] = ci; w[0] = cw; m[0] = lo + mid; }
+        else { id[1] = ci; w[1] = cw; m[1] = lo + mid; }
+      }
+    }
+  }
+}
+
+struct FanoutLeanLds {
+  uint32_t o_sid, o_c1, o_slotid, o_mask, o_sw, o_w1, o_st, o_slot, o_rvalid, bytes;
+};
+__host__ __device__ inline FanoutLeanLds FanoutLeanLayout(int32_t gr, int32_t c1, int32_t c2,
+                                                          int32_t cap) {
+  FanoutLeanLds L;
+  const uint32_t p = (uint32_t)gr * (uint32_t)c1;
+  const uint32_t s = (uint32_t)cap * (uint32_t)c2;
+  uint32_t o = 0;
+  L.o_sid = o; o += s * 8;                  // u64 [cap][c2]  finished hop-2 rows: ids
+  L.o_c1 = o; o += (p + (p & 1)) * 8;       // u64 [gr][c1]   hop-1 ids (0 for a row without samples)
+  L.o_slotid = o; o += p * 8;               // u64 [slots]    the child of a slot
+  L.o_mask = o; o += (uint32_t)gr * 8;      // u64 [gr]       drawn edge offsets of a root
+  L.o_sw = o; o += s * 4;                   // f32 [cap][c2]  ... weights
+  L.o_w1 = o; o += p * 4;                   // f32 [gr][c1]
+  L.o_st = o; o += (uint32_t)cap * 4;       // i32 [cap]      ... type (or -1)
+  L.o_slot = o; o += (p * 2 + 3) & ~3u;     // u16 [gr][c1]   slot of the sample's child
+  L.o_rvalid = o; o += ((uint32_t)gr + 3) & ~3u;
+  L.bytes = (o + 15) & ~15u;
+  return L;
+}
+
+template <bool WIDE>
+__global__ __launch_bounds__(256, kWavesPerSimd) void SampleFanoutLeanKernel(
+    const FanoutLocalArgs a) {
+  extern __shared__ __align__(16) uint8_t fl_smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int waves_per_block = blockDim.x >> 6;
+  const FanoutLeanLds L = FanoutLeanLayout(a.gr, a.c1, a.c2, a.cap);
+  uint8_t* base = fl_smem + (size_t)wave_in_block * a.wave_lds;
+  uint64_t* s_sid = reinterpret_cast<uint64_t*>(base + L.o_sid);
+  uint64_t* s_c1 = reinterpret_cast<uint64_t*>(base + L.o_c1);
+  uint64_t* s_slotid = reinterpret_cast<uint64_t*>(base + L.o_slotid);
+  unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(base + L.o_mask);
+  float* s_sw = reinterpret_cast<float*>(base + L.o_sw);
+  float* s_w1 = reinterpret_cast<float*>(base + L.o_w1);
+  int32_t* s_st = reinterpret_cast<int32_t*>(base + L.o_st);
+  uint16_t* s_slot = reinterpret_cast<uint16_t*>(base + L.o_slot);
+  uint8_t* s_rvalid = base + L.o_rvalid;
+  // (no local copy of the view: its level offsets are indexed by a runtime level, and a
+  // private copy indexed that way lives in scratch memory)
+  const GraphView& g = a.g;
+  const uint32_t c1 = (uint32_t)a.c1, c2 = (uint32_t)a.c2, c12 = c1 * c2;
+  const uint32_t hp1 = (c1 + 1u) >> 1, hp2 = c2 >> 1;     // pairs per row (c2 is even)
+  const uint32_t gr = (uint32_t)a.gr, cap = (uint32_t)a.cap;
+  const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  const int64_t n_tiles = (a.n + gr - 1) / gr;
+  const int64_t wave0 = (int64_t)blockIdx.x * waves_per_block + wave_in_block;
+  const int64_t wave_stride = (int64_t)gridDim.x * waves_per_block;
+  for (int64_t tile = wave0; tile < n_tiles; tile += wave_stride) {
+    const int64_t r0 = tile * gr;
+    const uint32_t nr = (uint32_t)(a.n - r0 < (int64_t)gr ? a.n - r0 : (int64_t)gr);
+    const uint32_t p1 = nr * c1, p2 = nr * c12;
+    const int64_t out1 = r0 * (int64_t)c1, out2 = out1 * (int64_t)c2;
+    if ((uint32_t)lane < gr) s_mask[lane] = 0ull;
+    WaveSync();
+    // ---- P1: hop 1, a lane per pair of samples -----------------------------------
+    bool by_edge = true;                  // every root of the tile has <= 64 edges
+    const uint32_t t1n = nr * hp1;
+    for (uint32_t b = 0; b < t1n; b += 64) {
+      const uint32_t tk = b + lane;
+      const bool in = tk < t1n;
+      const uint32_t q = a.div_h1(tk);
+      const uint32_t jp = tk - q * hp1;
+      uint32_t lo = 0;
+      int32_t deg = 0;
+      float total = 0.f;
+      uint64_t node = 0;
+      if (in) {
+        node = a.roots[r0 + q];
+        const int64_t row = LeanFindRow(g, node);
+        if (row >= 0) {
+          const uint4 rec = *reinterpret_cast<const uint4*>(g.row_meta + row * 16);
+          lo = rec.x; deg = (int32_t)rec.z; total = __uint_as_float(rec.w);
+        }
+      }
+      const bool live = in && deg > 0;
+      const Philox4 pb = RngBlock(a.seed, a.call_id, kDomainNeighbor, node, jp);
+      uint64_t id[2]; float w[2]; uint32_t m[2];
+      LeanSamplePair(g, lo, deg, total, live, UnitFromWords(pb.w[0], pb.w[1]),
+                     UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
+      by_edge = by_edge && __ballot(in && deg > 64) == 0ull;
+      if (in) {
+        const uint32_t j0 = 2u * jp;
+        const uint32_t e0 = q * c1 + j0;
+        s_c1[e0] = live ? id[0] : 0;        // a row without samples hands node id 0 on
+        s_w1[e0] = live ? w[0] : 0.f;
+        unsigned long long bits = live ? 1ull << ((m[0] - lo) & 63u) : 1ull;
+        if (j0 + 1u < c1) {
+          s_c1[e0 + 1] = live ? id[1] : 0;
+          s_w1[e0 + 1] = live ? w[1] : 0.f;
+          if (live) bits |= 1ull << ((m[1] - lo) & 63u);
+          // the slot pass below needs the edge of every sample: park it in s_slot
+          s_slot[e0 + 1] = (uint16_t)(live ? (m[1] - lo) & 63u : 0u);
+        }
+        s_slot[e0] = (uint16_t)(live ? (m[0] - lo) & 63u : 0u);
+        atomicOr(&s_mask[q], bits);
+        if (jp == 0) s_rvalid[q] = live ? 1 : 0;
+      }
+    }
+    WaveSync();
+    // ---- P2: slots of the distinct children -----------------------------------------
+    uint32_t n_slots = 0;
+    if (by_edge) {
+      for (uint32_t b = 0; b < p1; b += 64) {
+        const uint32_t tk = b + lane;
+        if (tk < p1) {
+          const uint32_t q = a.div_c1(tk);
+          uint32_t sbase = 0;
+          for (uint32_t x = 0; x < q; ++x) sbase += (uint32_t)__popcll(s_mask[x]);
+          const uint32_t off = s_slot[tk];
+          const uint32_t slot = sbase + (uint32_t)__popcll(s_mask[q] & ((1ull << off) - 1ull));
+          s_slot[tk] = (uint16_t)slot;        // own entry only: nobody else reads it
+          s_slotid[slot] = s_c1[tk];          // every sample of the slot writes the same id
+        }
+      }
+      for (uint32_t x = 0; x < nr; ++x) n_slots += (uint32_t)__popcll(s_mask[x]);
+    } else {
+      // some root has more than 64 edges: first occurrence by id among the root's samples
+      for (uint32_t b = 0; b < p1; b += 64) {
+        const uint32_t tk = b + lane;
+        const bool in = tk < p1;
+        const uint32_t q = a.div_c1(tk);
+        const uint32_t j = tk - q * c1;
+        const uint64_t mine = in ? s_c1[tk] : 0;
+        uint32_t first = j;
+        const uint64_t* row = s_c1 + q * c1;
+        for (uint32_t i = 0; i + 1 < c1; ++i) {          // wave-uniform trip count
+          const uint64_t v = in ? row[i] : 0;
+          if (in && i < j && first == j && v == mine) first = i;
+        }
+        const bool rep = in && first == j;
+        const uint64_t bal = __ballot(rep);
+        if (rep) {
+          const uint32_t slot = n_slots + (uint32_t)__popcll(bal & lt_mask);
+          s_slot[tk] = (uint16_t)slot;
+          s_slotid[slot] = mine;
+        } else if (in) {
+          s_slot[tk] = (uint16_t)(0x8000u | first);
+        }
+        n_slots += (uint32_t)__popcll(bal);
+      }
+      WaveSync();
+      for (uint32_t b = 0; b < p1; b += 64) {
+        const uint32_t tk = b + lane;
+        if (tk < p1) {
+          const uint32_t v = s_slot[tk];
+          if (v & 0x8000u) {
+            const uint32_t q = a.div_c1(tk);
+            s_slot[tk] = s_slot[q * c1 + (v & 0x7FFFu)];
+          }
+        }
+      }
+    }
+    WaveSync();
+    // ---- P3 / P4 per chunk of `cap` slots -------------------------------------------
+    for (uint32_t s0 = 0; s0 < n_slots; s0 += cap) {
+      const uint32_t ns = n_slots - s0 < cap ? n_slots - s0 : cap;
+      const uint32_t t2n = ns * hp2;
+      for (uint32_t b = 0; b < t2n; b += 64) {
+        const uint32_t tk = b + lane;
+        const bool in = tk < t2n;
+        const uint32_t sl = a.div_h2(tk);
+        const uint32_t xp = tk - sl * hp2;
+        uint32_t lo = 0;
+        int32_t deg = 0;
+        float total = 0.f;
+        uint64_t node = 0;
+        if (in) {
+          node = s_slotid[s0 + sl];
+          const int64_t row = LeanFindRow(g, node);
+          if (row >= 0) {
+            const uint4 rec = *reinterpret_cast<const uint4*>(g.row_meta + row * 16);
+            lo = rec.x; deg = (int32_t)rec.z; total = __uint_as_float(rec.w);
+          }
+        }
+        const bool live = in && deg > 0;
+        const Philox4 pb = RngBlock(a.seed, a.call_id + 1u, kDomainNeighbor, node, xp);
+        uint64_t id[2]; float w[2]; uint32_t m[2];
+        LeanSamplePair(g, lo, deg, total, live, UnitFromWords(pb.w[0], pb.w[1]),
+                       UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
+        if (in) {
+          fl_u64x2 iv;
+          iv.x = live ? id[0] : (uint64_t)a.default_node;
+          iv.y = live ? id[1] : (uint64_t)a.default_node;
+          *reinterpret_cast<fl_u64x2*>(s_sid + sl * c2 + 2u * xp) = iv;
+          *reinterpret_cast<float2*>(s_sw + sl * c2 + 2u * xp) =
+              make_float2(live ? w[0] : 0.f, live ? w[1] : 0.f);
+          if (xp == 0) s_st[sl] = live ? 0 : -1;
+        }
+      }
+      WaveSync();
+      // -- P4: copy the finished rows to the positions that asked for them ------------
+      for (uint32_t b = 0; b < p2; b += 128) {
+        const uint32_t p = b + 2 * lane;
+        if (p < p2) {
+          const uint32_t gj = a.div_c2(p);
+          const uint32_t x = p - gj * c2;
+          const uint32_t sl = (uint32_t)s_slot[gj] - s0;
+          if (sl < ns) {
+            *reinterpret_cast<fl_u64x2*>(a.id2 + out2 + p) =
+                *reinterpret_cast<const fl_u64x2*>(s_sid + sl * c2 + x);
+            if (!WIDE) {
+              *reinterpret_cast<float2*>(a.w2 + out2 + p) =
+                  *reinterpret_cast<const float2*>(s_sw + sl * c2 + x);
+              const int32_t tv = s_st[sl];
+              *reinterpret_cast<int2*>(a.ty2 + out2 + p) = make_int2(tv, tv);
+            }
+          }
+        }
+      }
+      if (WIDE) {
+        for (uint32_t b = 0; b < p2; b += 256) {
+          const uint32_t p = b + 4 * lane;
+          if (p < p2) {
+            const uint32_t gja = a.div_c2(p);
+            const uint32_t xa = p - gja * c2;
+            const uint32_t sla = (uint32_t)s_slot[gja] - s0;
+            const bool ina = sla < ns;
+            const bool hasb = p + 2 < p2;
+            uint32_t gjb = gja, xb = xa + 2;
+            if (xb >= c2) { xb -= c2; ++gjb; }
+            const uint32_t slb = hasb ? (uint32_t)s_slot[gjb] - s0 : 0xFFFFFFFFu;
+            const bool inb = hasb && slb < ns;
+            float2 wa = make_float2(0.f, 0.f), wb = wa;
+            int32_t ta = -1, tb = -1;
+            if (ina) { wa = *reinterpret_cast<const float2*>(s_sw + sla * c2 + xa); ta = s_st[sla]; }
+            if (inb) { wb = *reinterpret_cast<const float2*>(s_sw + slb * c2 + xb); tb = s_st[slb]; }
+            float* wp = a.w2 + out2 + p;
+            int32_t* tp = a.ty2 + out2 + p;
+            if (ina && inb) {
+              *reinterpret_cast<float4*>(wp) = make_float4(wa.x, wa.y, wb.x, wb.y);
+              *reinterpret_cast<int4*>(tp) = make_int4(ta, ta, tb, tb);
+            } else if (ina) {
+              *reinterpret_cast<float2*>(wp) = wa;
+              *reinterpret_cast<int2*>(tp) = make_int2(ta, ta);
+            } else if (inb) {
+              *reinterpret_cast<float2*>(wp + 2) = wb;
+              *reinterpret_cast<int2*>(tp + 2) = make_int2(tb, tb);
+            }
+          }
+        }
+      }
+      WaveSync();              // the next chunk rewrites the slot rows
+    }
+    // ---- hop-1 outputs (contiguous over the tile) -----------------------------------
+    for (uint32_t b = 0; b < p1; b += 64) {
+      const uint32_t tk = b + lane;
+      if (tk < p1) {
+        const uint32_t q = a.div_c1(tk);
+        const bool ok = s_rvalid[q] != 0;
+        a.id1[out1 + tk] = ok ? s_c1[tk] : (uint64_t)a.default_node;
+        a.w1[out1 + tk] = s_w1[tk];
+        a.ty1[out1 + tk] = ok ? 0 : -1;
       }
     }
     WaveSync();

@@ -564,7 +564,8 @@ thread_local int g_fl_block = 256;    // key 30: threads per workgroup (64, 128,
 thread_local int g_fl_wide = 1;       // key 31: weights / types as 16-byte stores
 thread_local int g_fl_grid_cap = 0;   // key 32: workgroups (0 = one tile per wave, no loop)
 thread_local int g_fl_wps = 8;        // key 35: register budget, waves per SIMD (8 or 5)
-thread_local int g_fl_plain = 1;      // key 34: the constant-folded kernel for plain graphs
+thread_local int g_fl_plain = 2;      // key 34: plain graphs: 2 = the lean kernel, 1 = the general kernel
+                                      // constant-folded, 0 = the general kernel
 thread_local int g_fl_min_roots = 4096;   // key 33: smaller batches keep the workgroup-per-root kernel
 thread_local int g_k1_pair_distinct = 0;   // pass over the distinct roots: two samples per lane (key 22)
 thread_local int g_expand_lean = 1;  // last hop, even count: the lean gather-copy kernel (key 21)
@@ -1622,6 +1623,30 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
       const bool plain = g_fl_plain != 0 && v.T == 1 && v.total_in_meta != 0 && v.uniform_w == 0 &&
                          v.inline_k == 0 && v.map_mode == 0 && v.has_zero_nbr == 0 &&
                          f.t1 == 0 && f.t2 == 0;
+      if (plain && g_fl_plain == 2 && f.vec && v.n_edges < ((int64_t)1 << 31)) {
+        // the lean build (pairs of samples per lane, f32 compares, duplicates by edge)
+        int32_t lcap = cap;
+        FanoutLeanLds ll = FanoutLeanLayout(gr, c1, c2, lcap);
+        while (lcap > 1 && (size_t)ll.bytes * (block / 64) > 64 * 1024) {
+          lcap >>= 1;
+          ll = FanoutLeanLayout(gr, c1, c2, lcap);
+        }
+        if ((size_t)ll.bytes * (block / 64) <= 64 * 1024) {
+          f.cap = lcap; f.wave_lds = (int32_t)ll.bytes;
+          f.div_h1.Set((uint32_t)(c1 + 1) / 2); f.div_h2.Set((uint32_t)c2 / 2);
+          const size_t llds = (size_t)ll.bytes * wpb;
+          if (f.wide) {
+            hipLaunchKernelGGL((SampleFanoutLeanKernel<true>), dim3((unsigned)blocks), dim3(block),
+                               llds, stream, f);
+          } else {
+            hipLaunchKernelGGL((SampleFanoutLeanKernel<false>), dim3((unsigned)blocks), dim3(block),
+                               llds, stream, f);
+          }
+          EG_HIP(hipGetLastError());
+          if (uniq_off != nullptr) { uniq_off[0] = -1; uniq_off[1] = -1; }
+          return EULER_GPU_OK;
+        }
+      }
       void (*kern)(const FanoutLocalArgs) = nullptr;
 #define EG_FL(W, P) (g_fl_wps == 5 ? SampleFanoutLocalKernel<W, P, 5> : SampleFanoutLocalKernel<W, P, 8>)
       kern = f.wide ? (plain ? EG_FL(true, true) : EG_FL(true, false))
@@ -1789,7 +1814,7 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 31) { g_fl_wide = value != 0; return EULER_GPU_OK; }
   if (key == 32 && value >= 0) { g_fl_grid_cap = value; return EULER_GPU_OK; }
   if (key == 33 && value >= 0) { g_fl_min_roots = value; return EULER_GPU_OK; }
-  if (key == 34) { g_fl_plain = value != 0; return EULER_GPU_OK; }
+  if (key == 34 && value >= 0 && value <= 2) { g_fl_plain = value; return EULER_GPU_OK; }
   if (key == 35 && (value == 5 || value == 8)) { g_fl_wps = value; return EULER_GPU_OK; }
   if (key == 1 && (value == 1 || value == 2 || value == 4 || value == 8)) {
     g_k1_ilp = value;

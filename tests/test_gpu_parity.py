@@ -1470,12 +1470,15 @@ def test_full_neighbor_fill_kernels_agree(EA, O, torch_cuda, big_pair):
         _lib.lib().euler_gpu_set_tuning(24, 1)
 
 
-_FL_DEFAULTS = {27: 1, 28: 4, 29: 0, 30: 256, 31: 1, 32: 0, 33: 4096, 34: 1, 35: 8}
+_FL_DEFAULTS = {27: 1, 28: 4, 29: 0, 30: 256, 31: 1, 32: 0, 33: 4096, 34: 2, 35: 8}
 
 
-@pytest.mark.parametrize("geom", [(4, 0, 256, 1, 8, 1, 0), (1, 1, 64, 0, 5, 0, 0), (2, 3, 128, 1, 8, 0, 0),
-                                  (8, 5, 256, 0, 8, 1, 3), (16, 64, 64, 1, 5, 1, 0), (3, 2, 256, 1, 8, 1, 1)],
-                         ids=["default", "gr1cap1", "gr2cap3", "gr8cap5grid3", "gr16cap64", "gr3cap2grid1"])
+@pytest.mark.parametrize("geom", [(4, 0, 256, 1, 8, 2, 0), (1, 1, 64, 0, 5, 0, 0), (2, 3, 128, 1, 8, 0, 0),
+                                  (8, 5, 256, 0, 8, 1, 3), (16, 64, 64, 1, 5, 1, 0), (3, 2, 256, 1, 8, 1, 1),
+                                  (1, 1, 64, 0, 8, 2, 0), (8, 5, 128, 1, 8, 2, 3), (16, 0, 256, 0, 8, 2, 1),
+                                  (5, 2, 256, 1, 8, 2, 0)],
+                         ids=["default", "gr1cap1", "gr2cap3", "gr8cap5grid3", "gr16cap64", "gr3cap2grid1",
+                              "lean_gr1cap1", "lean_gr8cap5grid3", "lean_gr16grid1", "lean_gr5cap2"])
 def test_fanout_local_dedup_kernel(EA, O, torch_cuda, big_pair, geom):
     """fanout_local.h: the 2-hop fanout of single listed types as ONE kernel - a wave owns
     `gr` roots, finds the distinct children among its own hop-1 samples and samples each
@@ -1528,8 +1531,17 @@ def test_fanout_local_dedup_kernel(EA, O, torch_cuda, big_pair, geom):
             G1, OG1 = EA.Graph.synthetic(p), O.OracleGraph(O.synth_csr(po))
             r1 = np.random.default_rng(5)
             q = np.concatenate([r1.integers(1, 20001, 3001), [0, 20001, 1, 1, 2]]).astype(np.int64)
-            for counts in ([25, 10], [3, 4], [10, 5]):
+            for counts in ([25, 10], [3, 4], [10, 5], [1, 2], [80, 6]):
                 check(G1, OG1, q, [[0], [0]], counts, 20001, 3, 6)
+        # hubs: rows of thousands of edges (several pivot levels, > 64 edges: duplicates by id)
+        ph = EA.synth_params(31, 3000, 900000, n_types=1, weighted=True)
+        po = O.SynthParams()
+        for f, _ in po._fields_:
+            setattr(po, f, getattr(ph, f))
+        G2, OG2 = EA.Graph.synthetic(ph), O.OracleGraph(O.synth_csr(po))
+        q = np.random.default_rng(6).integers(1, 3001, 700).astype(np.int64)
+        for counts in ([25, 10], [6, 4]):
+            check(G2, OG2, q, [[0], [0]], counts, 3001, 9, 40)
         # Q1: a row whose FIRST sample is node id 0 is dropped (both hops)
         ids0 = np.array([0, 1, 2, 3], np.uint64)
         seg = np.array([0, 2, 4, 6, 7], np.int64)

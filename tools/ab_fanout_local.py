@@ -30,7 +30,7 @@ fan = [25, 10]
 gen = torch.Generator(device='cuda'); gen.manual_seed(1234)
 n_sets = 8
 roots = torch.randint(1, N + 1, (n_sets, B), generator=gen, device='cuda')
-DEFAULTS = {27: 1, 28: 4, 29: 0, 30: 256, 31: 1, 32: 0, 33: 4096, 34: 1, 35: 8}
+DEFAULTS = {27: 1, 28: 4, 29: 0, 30: 256, 31: 1, 32: 0, 33: 4096, 34: 2, 35: 8}
 
 
 def apply(cfg):
@@ -77,14 +77,13 @@ if args.configs:
     configs = [dict((int(kv.split('=')[0]), int(kv.split('=')[1])) for kv in c.split(',') if kv)
                for c in args.configs.split(';')]
 else:
-    configs = [{}]
-    for gr in (1, 2, 4, 8):
-        for capm in (4, 8, 16):
+    configs = [{}, {34: 1}]
+    for gr in (2, 4, 8, 9, 12, 16):
+        for capm in (4, 8):
             configs.append({28: gr, 29: gr * capm})
     configs += [{28: 4, 29: 32, 30: 64}, {28: 4, 29: 32, 30: 128}, {28: 4, 29: 32, 31: 0},
-                {28: 4, 29: 32, 35: 5}, {28: 4, 29: 32, 34: 0}, {28: 4, 29: 32, 32: 2048},
-                {28: 4, 29: 32, 32: 4096}, {28: 2, 29: 16, 35: 5}, {28: 2, 29: 16, 30: 64},
-                {28: 8, 29: 64, 35: 5}, {28: 8, 29: 64, 30: 64}]
+                {28: 4, 29: 32, 32: 2048}, {28: 4, 29: 32, 32: 4096}, {28: 8, 29: 64, 30: 64},
+                {28: 4, 29: 16, 30: 64}, {28: 4, 29: 24, 30: 64}, {28: 9, 29: 72, 30: 64}]
     if args.quick:
         configs = configs[:6]
 
