@@ -69,6 +69,7 @@ struct FanoutLocalArgs {
   SmallDiv div_h1, div_h2;  // by the pairs per row, (c1 + 1) / 2 and c2 / 2 (lean kernel)
   uint64_t* id1; float* w1; int32_t* ty1; uint8_t* mask0;
   uint64_t* id2; float* w2; int32_t* ty2; uint8_t* mask1;
+  unsigned long long* dbg;  // measurement only (tuning key 36): [tiles][8] phase stamps
 };
 
 // LDS of one wave (bytes), and the offsets of its arrays
@@ -513,8 +514,12 @@ __host__ __device__ inline FanoutLeanLds FanoutLeanLayout(int32_t gr, int32_t c1
   return L;
 }
 
-template <bool WIDE>
-__global__ __launch_bounds__(256, kWavesPerSimd) void SampleFanoutLeanKernel(
+// WPS: waves per SIMD the register allocation targets (6: 80 VGPRs, nothing spilled; 8: 64
+// with ~17 registers spilled - 140 MB of scratch stores and as much again re-read per
+// step, profiles/r3_fl_v2_pmc.json).  a.dbg (measurement only): per tile, s_memtime at
+// the phase boundaries.
+template <bool WIDE, int WPS>
+__global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
     const FanoutLocalArgs a) {
   extern __shared__ __align__(16) uint8_t fl_smem[];
   const int lane = threadIdx.x & 63;
@@ -548,6 +553,8 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void SampleFanoutLeanKernel(
     const int64_t out1 = r0 * (int64_t)c1, out2 = out1 * (int64_t)c2;
     if ((uint32_t)lane < gr) s_mask[lane] = 0ull;
     WaveSync();
+    unsigned long long t_s[6] = {0, 0, 0, 0, 0, 0};
+    if (a.dbg != nullptr) t_s[0] = __builtin_readcyclecounter();
     // ---- P1: hop 1, a lane per pair of samples -----------------------------------
     bool by_edge = true;                  // every root of the tile has <= 64 edges
     const uint32_t t1n = nr * hp1;
@@ -593,6 +600,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void SampleFanoutLeanKernel(
       }
     }
     WaveSync();
+    if (a.dbg != nullptr) t_s[1] = __builtin_readcyclecounter();
     // ---- P2: slots of the distinct children -----------------------------------------
     uint32_t n_slots = 0;
     if (by_edge) {
@@ -647,6 +655,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void SampleFanoutLeanKernel(
       }
     }
     WaveSync();
+    if (a.dbg != nullptr) t_s[2] = __builtin_readcyclecounter();
     // ---- P3 / P4 per chunk of `cap` slots -------------------------------------------
     for (uint32_t s0 = 0; s0 < n_slots; s0 += cap) {
       const uint32_t ns = n_slots - s0 < cap ? n_slots - s0 : cap;
@@ -684,6 +693,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void SampleFanoutLeanKernel(
         }
       }
       WaveSync();
+      if (a.dbg != nullptr && s0 == 0) t_s[3] = __builtin_readcyclecounter();
       // -- P4: copy the finished rows to the positions that asked for them ------------
       for (uint32_t b = 0; b < p2; b += 128) {
         const uint32_t p = b + 2 * lane;
@@ -737,6 +747,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void SampleFanoutLeanKernel(
       }
       WaveSync();              // the next chunk rewrites the slot rows
     }
+    if (a.dbg != nullptr) t_s[4] = __builtin_readcyclecounter();
     // ---- hop-1 outputs (contiguous over the tile) -----------------------------------
     for (uint32_t b = 0; b < p1; b += 64) {
       const uint32_t tk = b + lane;
@@ -749,6 +760,16 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void SampleFanoutLeanKernel(
       }
     }
     WaveSync();
+    if (a.dbg != nullptr) {
+      __builtin_amdgcn_s_waitcnt(0);          // the stores have left the wave's queue
+      t_s[5] = __builtin_readcyclecounter();
+      if (lane == 0) {
+        unsigned long long* d = a.dbg + tile * 8;
+        for (int x = 0; x < 6; ++x) d[x] = t_s[x];
+        d[6] = n_slots;
+        d[7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
+      }
+    }
   }
 }
 

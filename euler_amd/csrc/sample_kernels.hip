@@ -563,7 +563,8 @@ thread_local int g_fl_cap = 0;        // key 29: hop-2 slots per pass, 0 = 8 x r
 thread_local int g_fl_block = 256;    // key 30: threads per workgroup (64, 128, 256)
 thread_local int g_fl_wide = 1;       // key 31: weights / types as 16-byte stores
 thread_local int g_fl_grid_cap = 0;   // key 32: workgroups (0 = one tile per wave, no loop)
-thread_local int g_fl_wps = 8;        // key 35: register budget, waves per SIMD (8 or 5)
+thread_local int g_fl_wps = 6;        // key 35: register budget, waves per SIMD (8, or 6 lean / 5 general)
+thread_local void* g_fl_debug = nullptr;   // euler_gpu_set_debug_buffer: phase stamps of the lean kernel
 thread_local int g_fl_plain = 2;      // key 34: plain graphs: 2 = the lean kernel, 1 = the general kernel
                                       // constant-folded, 0 = the general kernel
 thread_local int g_fl_min_roots = 4096;   // key 33: smaller batches keep the workgroup-per-root kernel
@@ -1635,20 +1636,18 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
           f.cap = lcap; f.wave_lds = (int32_t)ll.bytes;
           f.div_h1.Set((uint32_t)(c1 + 1) / 2); f.div_h2.Set((uint32_t)c2 / 2);
           const size_t llds = (size_t)ll.bytes * wpb;
-          if (f.wide) {
-            hipLaunchKernelGGL((SampleFanoutLeanKernel<true>), dim3((unsigned)blocks), dim3(block),
-                               llds, stream, f);
-          } else {
-            hipLaunchKernelGGL((SampleFanoutLeanKernel<false>), dim3((unsigned)blocks), dim3(block),
-                               llds, stream, f);
-          }
+          f.dbg = (unsigned long long*)g_fl_debug;
+          void (*lk)(const FanoutLocalArgs) =
+              f.wide ? (g_fl_wps == 8 ? SampleFanoutLeanKernel<true, 8> : SampleFanoutLeanKernel<true, 6>)
+                     : (g_fl_wps == 8 ? SampleFanoutLeanKernel<false, 8> : SampleFanoutLeanKernel<false, 6>);
+          hipLaunchKernelGGL(lk, dim3((unsigned)blocks), dim3(block), llds, stream, f);
           EG_HIP(hipGetLastError());
           if (uniq_off != nullptr) { uniq_off[0] = -1; uniq_off[1] = -1; }
           return EULER_GPU_OK;
         }
       }
       void (*kern)(const FanoutLocalArgs) = nullptr;
-#define EG_FL(W, P) (g_fl_wps == 5 ? SampleFanoutLocalKernel<W, P, 5> : SampleFanoutLocalKernel<W, P, 8>)
+#define EG_FL(W, P) (g_fl_wps != 8 ? SampleFanoutLocalKernel<W, P, 5> : SampleFanoutLocalKernel<W, P, 8>)
       kern = f.wide ? (plain ? EG_FL(true, true) : EG_FL(true, false))
                     : (plain ? EG_FL(false, true) : EG_FL(false, false));
 #undef EG_FL
@@ -1778,6 +1777,8 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
 
 extern "C" {
 
+int euler_gpu_set_debug_buffer(void* dev) { g_fl_debug = dev; return EULER_GPU_OK; }
+
 int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 0) { g_k1_variant = value; return EULER_GPU_OK; }
   if (key == 2) { g_k1_ablate = value; return EULER_GPU_OK; }
@@ -1815,7 +1816,7 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 32 && value >= 0) { g_fl_grid_cap = value; return EULER_GPU_OK; }
   if (key == 33 && value >= 0) { g_fl_min_roots = value; return EULER_GPU_OK; }
   if (key == 34 && value >= 0 && value <= 2) { g_fl_plain = value; return EULER_GPU_OK; }
-  if (key == 35 && (value == 5 || value == 8)) { g_fl_wps = value; return EULER_GPU_OK; }
+  if (key == 35 && (value == 5 || value == 6 || value == 8)) { g_fl_wps = value; return EULER_GPU_OK; }
   if (key == 1 && (value == 1 || value == 2 || value == 4 || value == 8)) {
     g_k1_ilp = value;
     return EULER_GPU_OK;

@@ -829,6 +829,10 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  * thread enqueues afterwards and nobody else's (new threads start from the
  * defaults), so concurrent query threads cannot disturb one another. */
 int euler_gpu_set_tuning(int32_t key, int32_t value);
+/* Measurement only: a device buffer of 8 x uint64 per wave tile in which the one-kernel
+ * fanout (fanout_local.h, lean build) leaves its phase time stamps; NULL = off.
+ * Thread-local like the tuning keys. */
+int euler_gpu_set_debug_buffer(void* dev);
 
 /* ---- measurement helper -------------------------------------------------------
  * Runs the sample_neighbor kernel `iters` times on `stream` between two HIP
