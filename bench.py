@@ -765,7 +765,83 @@ def main():
     # (SampleNeighborPivotKernel): its algorithmic bytes are SURVEY 8(d)'s
     # per-root / per-edge figure summed over the roots it actually processes.
     roofline = None
-    if rank == 0:
+    fused = world == 1 and not sharded and "27=0" not in args.tuning.split(",")
+    if rank == 0 and fused:
+        # The step is ONE kernel (fanout_local.h: hop 1, the duplicate children found inside
+        # the wave, hop 2 once per distinct child, the rows streamed out): the roofline object
+        # is that launch.  Algorithmic bytes = SURVEY 8(d), evaluated on the roots the step
+        # really has: K1 over the batch (hop 1) + K1 over the DISTINCT hop-2 roots (counted
+        # globally, as the reference's ID_UNIQUE would - the kernel itself samples ~1.3x as
+        # many, duplicates across waves) + 8 + 4 per hop-2 input id (dedup) + 16 per
+        # expanded output edge (gather).
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        et1 = (C.c_int32 * 1)(0)
+        layers = len(FANOUT)
+        cnt_a = (C.c_int32 * layers)(*FANOUT)
+        et_a = (C.c_int32 * layers)(*([0] * layers))
+        r = roots[n_steps - 1].contiguous()
+        o_n, o_w, o_t, m = [], [], [], r.numel()
+        for c in FANOUT:
+            m *= c
+            o_n.append(torch.empty(m, dtype=torch.int64, device=dev))
+            o_w.append(torch.empty(m, dtype=torch.float32, device=dev))
+            o_t.append(torch.empty(m, dtype=torch.int32, device=dev))
+        wsz = int(L.euler_gpu_sample_fanout_workspace(r.numel(), cnt_a, layers))
+        fws = torch.empty(max(wsz, 16), dtype=torch.uint8, device=dev)
+        pn = (C.c_void_p * layers)(*[t.data_ptr() for t in o_n])
+        pw_ = (C.c_void_p * layers)(*[t.data_ptr() for t in o_w])
+        pt = (C.c_void_p * layers)(*[t.data_ptr() for t in o_t])
+        torch.cuda.synchronize()
+        ms = C.c_float(0)
+        _lib.check(L.euler_gpu_time_sample_fanout(
+            G._h, st, GRAPH_SEED, C.c_void_p(r.data_ptr()), r.numel(), et_a, 1, cnt_a, layers,
+            default_node, pn, pw_, pt, C.c_void_p(fws.data_ptr()), 20, C.byref(ms)))
+
+        def algo_bytes(x, cnt):
+            b = C.c_double(0)
+            _lib.check(L.euler_gpu_sample_neighbor_algo_bytes(
+                G._h, st, C.c_void_p(x.data_ptr()), x.numel(), et1, 1, cnt, C.byref(b)))
+            return b.value
+        hop2_roots = o_n[0]
+        uniq2 = torch.unique(hop2_roots).contiguous()
+        b1 = algo_bytes(r, FANOUT[0])
+        b2 = algo_bytes(uniq2, FANOUT[1])
+        n2 = hop2_roots.numel()
+        b_dedup = 12.0 * n2
+        b_gather = 16.0 * n2 * FANOUT[1]
+        total_b = b1 + b2 + b_dedup + b_gather
+        achieved = total_b / (ms.value * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        pmc_rec = {}
+        if os.path.exists(pmc):
+            try:
+                pmc_rec = json.load(open(pmc))
+                if pmc_rec.get("batch") == B and pmc_rec.get("nodes") == args.nodes and \
+                        pmc_rec.get("kernel") == "SampleFanoutLeanKernel":
+                    traffic = pmc_rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {
+            "kernel": "SampleFanoutLeanKernel", "bound": "hbm",
+            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "traffic_note": "profiles/pmc_latest.json: TCC_EA0_RDREQ x 128 B + TCC_EA0_WRREQ x 64 B per "
+                            "launch (separate rocprofv3 --pmc pass; a read request moves a 128-byte line, "
+                            "FETCH_SIZE tallies it at 64 B - calibration in profiles/r2_pmc_summary.json)",
+            "algorithmic_bytes_per_launch": round(total_b, 1),
+            "avg_launch_ms": round(ms.value, 4),
+            "launches_per_step": [{
+                "roots": int(r.numel()), "fanout": FANOUT, "hop2_roots": int(n2),
+                "hop2_distinct_roots": int(uniq2.numel()),
+                "k1_hop1_algorithmic_bytes": b1, "k1_hop2_distinct_algorithmic_bytes": b2,
+                "dedup_algorithmic_bytes": b_dedup, "gather_algorithmic_bytes": b_gather}],
+            "note": "the whole step is this one launch, timed alone on one stream with HIP events "
+                    "(euler_gpu_time_sample_fanout, 20 calls); bytes = SURVEY 8(d) summed over the "
+                    "step: K1 of hop 1 over the batch, K1 of hop 2 over the globally distinct hop-2 "
+                    "roots, 8 + 4 per hop-2 input id, 16 per expanded output edge",
+        }
+    if rank == 0 and not fused:
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         et1 = (C.c_int32 * 1)(0)
         iters = 5

@@ -182,6 +182,11 @@ SIGNATURES = {
                                                         C.c_int32, C.c_int32, vp, vp, vp,
                                                         C.c_int32, f32p,
                                                         C.POINTER(C.c_int64)]),
+    "euler_gpu_time_sample_fanout": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_int64,
+                                               i32p, C.c_int32, i32p, C.c_int32,
+                                               C.c_int64, C.POINTER(vp),
+                                               C.POINTER(vp), C.POINTER(vp), vp,
+                                               C.c_int32, C.POINTER(C.c_float)]),
     "euler_gpu_time_sample_fanout_phases": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_int64,
                                                       i32p, C.c_int32, i32p, C.c_int32,
                                                       C.c_int64, C.POINTER(vp),

@@ -69,7 +69,9 @@ struct FanoutLocalArgs {
   SmallDiv div_h1, div_h2;  // by the pairs per row, (c1 + 1) / 2 and c2 / 2 (lean kernel)
   uint64_t* id1; float* w1; int32_t* ty1; uint8_t* mask0;
   uint64_t* id2; float* w2; int32_t* ty2; uint8_t* mask1;
-  unsigned long long* dbg;  // measurement only (tuning key 36): [tiles][8] phase stamps
+  unsigned long long* dbg;  // measurement only (euler_gpu_set_debug_buffer): [tiles][8] phase stamps
+  int32_t ablate;           // measurement only (tuning key 36), lean kernel: 1 = no hop-2 stores,
+                            // 2 = no hop-2 sampling, 4 = no hop-1 stores, 8 = no hop-1 sampling
 };
 
 // LDS of one wave (bytes), and the offsets of its arrays
@@ -382,7 +384,8 @@ __device__ __forceinline__ float FloorToFloat(double r) {
 __device__ __forceinline__ void LeanSamplePair(const GraphView& g, const uint32_t lo,
                                                const int32_t deg, const float total,
                                                const bool live, const double u0, const double u1,
-                                               uint64_t id[2], float w[2], uint32_t m[2]) {
+                                               uint64_t id[2], float w[2], uint32_t m[2],
+                                               const int32_t ablate = 0) {
   const uint32_t hi = lo + (uint32_t)deg - 1u;
   const uint32_t l1 = lo / 10u, h1 = hi / 10u;
   const uint32_t lo_off = lo - 10u * l1, hi_off = hi - 10u * h1;
@@ -392,6 +395,14 @@ __device__ __forceinline__ void LeanSamplePair(const GraphView& g, const uint32_
   // level ranges as base-5 digits; K = first level with <= 4 candidates
   uint32_t lt = l1, ht = h1, ldig = 0, hdig = 0;
   int32_t K = 0;
+  // Interpolation start.  A row of i.i.d. weights has nearly linear running sums: the
+  // entry that holds r is within a fraction of sqrt(deg) edges of (r / total) * deg.
+  // Level kg is the lowest whose entries span more than that; ONE window of four keys
+  // around the guessed entry there either brackets r (then the walk continues below
+  // kg, having skipped the levels above it) or it does not, and the walk starts at
+  // the top as if nothing had been tried.  Same answer either way: the keys decide.
+  const int32_t kg = deg <= 1600 ? 1 : deg <= 40000 ? 2 : deg <= 1000000 ? 3 : 4;
+  uint32_t lg = l1, hg = h1;
   if (live && h1 != l1) {
     K = 1;
     while (ht - lt > 4u && K <= kPivotLevels) {
@@ -399,6 +410,7 @@ __device__ __forceinline__ void LeanSamplePair(const GraphView& g, const uint32_
       ldig = (ldig << 3) | (lt - 5u * l5);
       hdig = (hdig << 3) | (ht - 5u * h5);
       lt = l5; ht = h5; ++K;
+      if (K == kg) { lg = lt; hg = ht; }
     }
   }
   // cold: Q3 (r rounded up to the row's end) or a row beyond the levels' reach
@@ -407,9 +419,49 @@ __device__ __forceinline__ void LeanSamplePair(const GraphView& g, const uint32_
   if (K > kPivotLevels) K = 0;
   uint32_t x[2] = {l1, l1};
   bool found[2] = {false, false}, onl[2] = {true, true};
+  int32_t ks[2] = {K, K};               // the level a draw's walk starts at
+  const bool guess = K > kg && !(ablate & 128);
+  if (__ballot(guess) != 0ull) {
+    const float* gl = kg == 1 ? g.skip1 : g.bpiv + (kg == 2 ? g.bpiv_off[2] : kg == 3 ? g.bpiv_off[3]
+                                                                                   : g.bpiv_off[4]);
+    const float inv = __frcp_rn(total) * (float)(hg - lg + 1u);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (guess) {
+        uint32_t e = lg + (uint32_t)(f[s] * inv);
+        // window of entries wq .. wq + 3 (all inside the row: hg - lg >= 5 here),
+        // candidates wq .. wq + 4
+        uint32_t wq = (e > lg + 2u ? e : lg + 2u) - 2u;
+        wq = wq < hg - 4u ? wq : hg - 4u;
+        const float4u kw = *reinterpret_cast<const float4u*>(gl + wq);
+        int32_t pos = 0;
+        pos += !(kw.x > f[s]) ? 1 : 0;
+        pos += !(kw.y > f[s]) ? 1 : 0;
+        pos += !(kw.z > f[s]) ? 1 : 0;
+        pos += !(kw.w > f[s]) ? 1 : 0;
+        const bool ok = (pos > 0 || wq == lg) && (pos < 4 || wq + 4u == hg);
+        if (ok) {
+          x[s] = wq + (uint32_t)pos;
+          found[s] = pos < 4;
+          onl[s] = x[s] == lg;
+          ks[s] = kg - 1;
+        }
+      }
+    }
+  }
   int32_t kmax = 0;
 #pragma unroll
-  for (int k = 1; k <= kPivotLevels; ++k) kmax = __ballot(K >= k) != 0ull ? k : kmax;
+  for (int k = 1; k <= kPivotLevels; ++k)
+    kmax = __ballot(ks[0] >= k || ks[1] >= k) != 0ull ? k : kmax;
+  if (ablate & 32) {          // measurement only: no level walk, some block of the row
+    kmax = 0;
+    x[0] = l1 + (__float_as_uint(f[0]) * 2654435761u >> 8) % (h1 - l1 + 1u);
+    x[1] = l1 + (__float_as_uint(f[1]) * 2654435761u >> 8) % (h1 - l1 + 1u);
+  }
+  if (K - 1 > kmax) {         // the digits of the levels nobody of this wave walks
+    const uint32_t sh = 3u * (uint32_t)(K - 1 - kmax);
+    ldig >>= sh; hdig >>= sh;
+  }
   for (int k = kmax; k >= 1; --k) {
     const float* lvl = k == 1 ? g.skip1 : g.bpiv + g.bpiv_off[k];
     if (k <= K) {
@@ -417,22 +469,24 @@ __device__ __forceinline__ void LeanSamplePair(const GraphView& g, const uint32_
       if (k < K) { dl = ldig & 7u; dh = hdig & 7u; ldig >>= 3; hdig >>= 3; }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        uint32_t c_lo, c_hi;
-        if (k == K) { c_lo = lt; c_hi = ht; }
-        else {
-          c_lo = 5u * x[s] + (onl[s] ? dl : 0u);
-          c_hi = 5u * x[s] + (found[s] ? 4u : dh);
+        if (k <= ks[s]) {
+          uint32_t c_lo, c_hi;
+          if (k == K) { c_lo = lt; c_hi = ht; }
+          else {
+            c_lo = 5u * x[s] + (onl[s] ? dl : 0u);
+            c_hi = 5u * x[s] + (found[s] ? 4u : dh);
+          }
+          const int32_t cnt = (int32_t)(c_hi - c_lo);
+          const float4u kw = *reinterpret_cast<const float4u*>(lvl + c_lo);
+          int32_t pos = 0;
+          pos += (0 < cnt && !(kw.x > f[s])) ? 1 : 0;
+          pos += (1 < cnt && !(kw.y > f[s])) ? 1 : 0;
+          pos += (2 < cnt && !(kw.z > f[s])) ? 1 : 0;
+          pos += (3 < cnt && !(kw.w > f[s])) ? 1 : 0;
+          x[s] = c_lo + (uint32_t)pos;
+          onl[s] = onl[s] && pos == 0;
+          if (pos < cnt) found[s] = true;
         }
-        const int32_t cnt = (int32_t)(c_hi - c_lo);
-        const float4u kw = *reinterpret_cast<const float4u*>(lvl + c_lo);
-        int32_t pos = 0;
-        pos += (0 < cnt && !(kw.x > f[s])) ? 1 : 0;
-        pos += (1 < cnt && !(kw.y > f[s])) ? 1 : 0;
-        pos += (2 < cnt && !(kw.z > f[s])) ? 1 : 0;
-        pos += (3 < cnt && !(kw.w > f[s])) ? 1 : 0;
-        x[s] = c_lo + (uint32_t)pos;
-        onl[s] = onl[s] && pos == 0;
-        if (pos < cnt) found[s] = true;
       }
     }
   }
@@ -443,7 +497,7 @@ __device__ __forceinline__ void LeanSamplePair(const GraphView& g, const uint32_
     const uint32_t i_lo = x[s] == l1 ? lo_off : 0u;
     const uint32_t i_hi = found[s] ? (uint32_t)(kEdgesPerBlock - 1) : hi_off;   // inclusive
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
-    if (live) {
+    if (live && !(ablate & 64)) {
       a0 = *reinterpret_cast<const float4*>(bk->pw);
       a1 = *reinterpret_cast<const float4*>(bk->pw + 4);
       a2 = *reinterpret_cast<const float4*>(bk->pw + 8);   // pw[8], pw[9], prev_last, pad
@@ -462,14 +516,27 @@ __device__ __forceinline__ void LeanSamplePair(const GraphView& g, const uint32_
     const uint32_t range = ((1u << i_hi) - 1u) & ~((1u << i_lo) - 1u);     // bits [i_lo, i_hi)
     const uint32_t i = i_lo + (uint32_t)__popc(le & range);
     m[s] = 10u * x[s] + i;
-    id[s] = 0; w[s] = 0.f;
-    if (live) {
-      const uint32_t i1 = i == 0u ? 0u : i - 1u;
-      const float2 pv = *reinterpret_cast<const float2*>(
-          reinterpret_cast<const uint8_t*>(bk->pw) + 4u * i1);   // 4-byte aligned pair
+    id[s] = m[s]; w[s] = 0.f;
+    if (live && !(ablate & 16)) {
       id[s] = bk->nbr[i];
-      const float nw_m = i == 0u ? pv.x : pv.y;
-      float prev = i == 0u ? a2.z : pv.x;
+      // nw[m] and nw[m-1] out of the registers the leaf was read into (a second load of
+      // the line costs the CU's memory pipe more than a dozen selects cost a SIMD)
+      const float v0 = a0.x, v1 = a0.y, v2 = a0.z, v3 = a0.w, v4 = a1.x, v5 = a1.y, v6 = a1.z,
+                  v7 = a1.w, v8 = a2.x, v9 = a2.y;
+      const bool b0 = (i & 1u) != 0, b1 = (i & 2u) != 0, b2 = (i & 4u) != 0, b3 = (i & 8u) != 0;
+      // v[i]
+      const float s01 = b0 ? v1 : v0, s23 = b0 ? v3 : v2, s45 = b0 ? v5 : v4, s67 = b0 ? v7 : v6,
+                  s89 = b0 ? v9 : v8;
+      const float q03 = b1 ? s23 : s01, q47 = b1 ? s67 : s45;
+      const float nw_m = b3 ? s89 : (b2 ? q47 : q03);
+      // v[i - 1] (i >= 1), prev_last for i == 0: index i - 1 = (i + 15) & 15 over
+      // {v0 .. v8}, with slot 15 = prev_last
+      const uint32_t ip = (i + 15u) & 15u;
+      const bool c0 = (ip & 1u) != 0, c1b = (ip & 2u) != 0, c2b = (ip & 4u) != 0, c3 = (ip & 8u) != 0;
+      const float r01 = c0 ? v1 : v0, r23 = c0 ? v3 : v2, r45 = c0 ? v5 : v4, r67 = c0 ? v7 : v6;
+      const float u03 = c1b ? r23 : r01, u47 = c1b ? r67 : r45;
+      const float lowp = c2b ? u47 : u03;                    // ip in 0 .. 7
+      float prev = c3 ? (ip == 8u ? v8 : a2.z) : lowp;       // 8, or 15 = prev_last
       if (m[s] == lo) prev = 0.f;                  // `mid ? nw[mid-1] : 0` is row-relative
       w[s] = __fsub_rn(nw_m, prev);
     }
@@ -575,7 +642,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
           lo = rec.x; deg = (int32_t)rec.z; total = __uint_as_float(rec.w);
         }
       }
-      const bool live = in && deg > 0;
+      const bool live = in && deg > 0 && !(a.ablate & 8);
       const Philox4 pb = RngBlock(a.seed, a.call_id, kDomainNeighbor, node, jp);
       uint64_t id[2]; float w[2]; uint32_t m[2];
       LeanSamplePair(g, lo, deg, total, live, UnitFromWords(pb.w[0], pb.w[1]),
@@ -677,11 +744,11 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
             lo = rec.x; deg = (int32_t)rec.z; total = __uint_as_float(rec.w);
           }
         }
-        const bool live = in && deg > 0;
+        const bool live = in && deg > 0 && !(a.ablate & 2);
         const Philox4 pb = RngBlock(a.seed, a.call_id + 1u, kDomainNeighbor, node, xp);
         uint64_t id[2]; float w[2]; uint32_t m[2];
         LeanSamplePair(g, lo, deg, total, live, UnitFromWords(pb.w[0], pb.w[1]),
-                       UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
+                       UnitFromWords(pb.w[2], pb.w[3]), id, w, m, a.ablate);
         if (in) {
           fl_u64x2 iv;
           iv.x = live ? id[0] : (uint64_t)a.default_node;
@@ -695,6 +762,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
       WaveSync();
       if (a.dbg != nullptr && s0 == 0) t_s[3] = __builtin_readcyclecounter();
       // -- P4: copy the finished rows to the positions that asked for them ------------
+      if (!(a.ablate & 1)) {
       for (uint32_t b = 0; b < p2; b += 128) {
         const uint32_t p = b + 2 * lane;
         if (p < p2) {
@@ -745,11 +813,12 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
           }
         }
       }
+      }
       WaveSync();              // the next chunk rewrites the slot rows
     }
     if (a.dbg != nullptr) t_s[4] = __builtin_readcyclecounter();
     // ---- hop-1 outputs (contiguous over the tile) -----------------------------------
-    for (uint32_t b = 0; b < p1; b += 64) {
+    for (uint32_t b = 0; b < p1 && !(a.ablate & 4); b += 64) {
       const uint32_t tk = b + lane;
       if (tk < p1) {
         const uint32_t q = a.div_c1(tk);

@@ -560,10 +560,13 @@ thread_local int g_fanout_fused = 1;       // small 2-hop single-type fanouts as
 thread_local int g_fanout_local = 1;
 thread_local int g_fl_roots = 4;      // key 28: roots per wave (1 .. 16)
 thread_local int g_fl_cap = 0;        // key 29: hop-2 slots per pass, 0 = 8 x roots per wave
-thread_local int g_fl_block = 256;    // key 30: threads per workgroup (64, 128, 256)
+thread_local int g_fl_block = 64;     // key 30: threads per workgroup (64, 128, 256)
 thread_local int g_fl_wide = 1;       // key 31: weights / types as 16-byte stores
-thread_local int g_fl_grid_cap = 0;   // key 32: workgroups (0 = one tile per wave, no loop)
-thread_local int g_fl_wps = 6;        // key 35: register budget, waves per SIMD (8, or 6 lean / 5 general)
+thread_local int g_fl_grid_cap = -1;  // key 32: waves of the launch: 0 = one tile per wave (no loop), -1 = that for a
+                                      // caller on one stream and 16 384 looping waves for one that alternates
+                                      // streams (two launches share the chip), > 0 = that many
+thread_local int g_fl_wps = 5;        // key 35: register budget, waves per SIMD (8, 6 or 5; 5: nothing spilled)
+thread_local int g_fl_ablate = 0;     // key 36: measurement only (FanoutLocalArgs::ablate)
 thread_local void* g_fl_debug = nullptr;   // euler_gpu_set_debug_buffer: phase stamps of the lean kernel
 thread_local int g_fl_plain = 2;      // key 34: plain graphs: 2 = the lean kernel, 1 = the general kernel
                                       // constant-folded, 0 = the general kernel
@@ -1618,7 +1621,9 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
       const int64_t tiles = (n + gr - 1) / gr;
       const int wpb = block / 64;
       int64_t blocks = (tiles + wpb - 1) / wpb;
-      if (g_fl_grid_cap > 0 && blocks > g_fl_grid_cap) blocks = g_fl_grid_cap;
+      const int64_t wave_cap = g_fl_grid_cap > 0 ? g_fl_grid_cap
+                               : (g_fl_grid_cap < 0 && t_concurrent == 1) ? 16384 : 0;
+      if (wave_cap > 0 && blocks > (wave_cap + wpb - 1) / wpb) blocks = (wave_cap + wpb - 1) / wpb;
       const size_t lds = (size_t)lay.bytes * wpb;
       const GraphView& v = f.g;
       const bool plain = g_fl_plain != 0 && v.T == 1 && v.total_in_meta != 0 && v.uniform_w == 0 &&
@@ -1637,9 +1642,14 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
           f.div_h1.Set((uint32_t)(c1 + 1) / 2); f.div_h2.Set((uint32_t)c2 / 2);
           const size_t llds = (size_t)ll.bytes * wpb;
           f.dbg = (unsigned long long*)g_fl_debug;
+          f.ablate = g_fl_ablate;
           void (*lk)(const FanoutLocalArgs) =
-              f.wide ? (g_fl_wps == 8 ? SampleFanoutLeanKernel<true, 8> : SampleFanoutLeanKernel<true, 6>)
-                     : (g_fl_wps == 8 ? SampleFanoutLeanKernel<false, 8> : SampleFanoutLeanKernel<false, 6>);
+              f.wide ? (g_fl_wps == 8 ? SampleFanoutLeanKernel<true, 8>
+                                      : g_fl_wps == 5 ? SampleFanoutLeanKernel<true, 5>
+                                                      : SampleFanoutLeanKernel<true, 6>)
+                     : (g_fl_wps == 8 ? SampleFanoutLeanKernel<false, 8>
+                                      : g_fl_wps == 5 ? SampleFanoutLeanKernel<false, 5>
+                                                      : SampleFanoutLeanKernel<false, 6>);
           hipLaunchKernelGGL(lk, dim3((unsigned)blocks), dim3(block), llds, stream, f);
           EG_HIP(hipGetLastError());
           if (uniq_off != nullptr) { uniq_off[0] = -1; uniq_off[1] = -1; }
@@ -1813,9 +1823,10 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 29 && value >= 0) { g_fl_cap = value; return EULER_GPU_OK; }
   if (key == 30 && (value == 64 || value == 128 || value == 256)) { g_fl_block = value; return EULER_GPU_OK; }
   if (key == 31) { g_fl_wide = value != 0; return EULER_GPU_OK; }
-  if (key == 32 && value >= 0) { g_fl_grid_cap = value; return EULER_GPU_OK; }
+  if (key == 32 && value >= -1) { g_fl_grid_cap = value; return EULER_GPU_OK; }
   if (key == 33 && value >= 0) { g_fl_min_roots = value; return EULER_GPU_OK; }
   if (key == 34 && value >= 0 && value <= 2) { g_fl_plain = value; return EULER_GPU_OK; }
+  if (key == 36) { g_fl_ablate = value; return EULER_GPU_OK; }
   if (key == 35 && (value == 5 || value == 6 || value == 8)) { g_fl_wps = value; return EULER_GPU_OK; }
   if (key == 1 && (value == 1 || value == 2 || value == 4 || value == 8)) {
     g_k1_ilp = value;
@@ -2115,6 +2126,37 @@ int euler_gpu_time_sample_neighbor_phases(const euler_gpu_graph* g, void* stream
     }
   }
   for (auto& e : ev) (void)hipEventDestroy(e);
+  return rc;
+}
+
+int euler_gpu_time_sample_fanout(const euler_gpu_graph* g, void* stream, uint64_t seed,
+                                 const uint64_t* roots_dev, int64_t n,
+                                 const int32_t* edge_types_host, int32_t k,
+                                 const int32_t* counts_host, int32_t layers,
+                                 int64_t default_node, uint64_t* const* out_id_dev,
+                                 float* const* out_w_dev, int32_t* const* out_t_dev,
+                                 void* workspace_dev, int32_t iters, float* mean_ms_host) {
+  if (!g) return Fail(EULER_GPU_ENOGRAPH, "time_sample_fanout: null graph");
+  if (iters <= 0 || !mean_ms_host) return Fail(EULER_GPU_EINVAL, "time_sample_fanout: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipEvent_t e0, e1;
+  EG_HIP(hipEventCreate(&e0));
+  EG_HIP(hipEventCreate(&e1));
+  int rc = euler_gpu_sample_fanout(g, stream, seed, 0, roots_dev, n, edge_types_host, k,
+                                   counts_host, layers, default_node, out_id_dev, out_w_dev,
+                                   out_t_dev, workspace_dev);       // untimed: first-use work
+  EG_HIP(hipEventRecord(e0, st));
+  for (int32_t it = 0; it < iters && rc == EULER_GPU_OK; ++it)
+    rc = euler_gpu_sample_fanout(g, stream, seed, (uint32_t)(it * layers), roots_dev, n,
+                                 edge_types_host, k, counts_host, layers, default_node,
+                                 out_id_dev, out_w_dev, out_t_dev, workspace_dev);
+  EG_HIP(hipEventRecord(e1, st));
+  EG_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  EG_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *mean_ms_host = ms / (float)iters;
   return rc;
 }
 

@@ -858,6 +858,16 @@ int euler_gpu_time_sample_neighbor_phases(const euler_gpu_graph* g, void* stream
                                           float* out_w_dev, int32_t* out_t_dev,
                                           int32_t iters, float* mean_ms3_host,
                                           int64_t* n_unique_host);
+/* euler_gpu_sample_fanout's arguments, the call repeated `iters` times between two HIP
+ * events recorded on `stream` (after one untimed call): the mean time of one call in
+ * milliseconds.  What bench.py quotes for the one-kernel 2-hop fanout. */
+int euler_gpu_time_sample_fanout(const euler_gpu_graph* g, void* stream, uint64_t seed,
+                                 const uint64_t* roots_dev, int64_t n,
+                                 const int32_t* edge_types_host, int32_t k,
+                                 const int32_t* counts_host, int32_t layers,
+                                 int64_t default_node, uint64_t* const* out_id_dev,
+                                 float* const* out_w_dev, int32_t* const* out_t_dev,
+                                 void* workspace_dev, int32_t iters, float* mean_ms_host);
 /* The whole fanout (euler_gpu_sample_fanout's arguments), timed in place:
  * mean_ms_host[3*h + {0,1,2}] = hop h's duplicate detection / sampling
  * kernel(s) / expansion, with the hop chaining the product uses (hop h's
