@@ -57,6 +57,83 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborKernel(const
 }
 
 // ------------------------------------------------------------------------
+// Type draws on the block-pivot search.  A call that lists several edge types (or none:
+// all of them) makes Node::__SampleNeighbor (core/graph/node.cc:98-161) draw the type
+// first - a CDF over the row's per-type sums, in the LISTED order for 1 < k < T, over all
+// groups otherwise - and then the neighbour inside that type's segment.  The reference
+// loop above does the second draw with a bisection over the flat running sums
+// (~log2(deg) dependent loads); here the type draw is the same code (a handful of
+// entries out of the row record) and the neighbour draw is BlockPivotSample on the
+// type's segment [lo, hi] of the row - the search of the single-type kernels, which
+// takes any sub-range of a row.  Monotone graphs without the id-0 sentinel rule; same
+// draws: one Philox block per sample, words 0-1 the type, words 2-3 the neighbour.
+// ------------------------------------------------------------------------
+template <bool TF_LAYOUT>
+__global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborTypedPivotKernel(
+    const SampleNbArgs a) {
+  int64_t n_roots;
+  if (!DedupGate(a, &n_roots)) return;
+  const int64_t total = n_roots * (int64_t)a.count;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int32_t mode = TypeModeOf(a.k, a.g.T);
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total; s += stride) {
+    const int64_t r = s / a.count;
+    const int32_t j = (int32_t)(s - r * a.count);
+    uint64_t node = a.roots[r];
+    if (a.root_mask != nullptr && a.root_mask[r / a.root_group]) node = 0;
+    const int64_t row = FindRow(a.g, node);
+    uint64_t id = TF_LAYOUT ? (uint64_t)a.default_node : 0;
+    float w = 0.f;
+    int32_t t = TF_LAYOUT ? -1 : 0;
+    bool valid = false;
+    if (row >= 0) {
+      const RowMeta m = LoadRowMeta(a.g, row);
+      // node.cc:106-121,137-148: which rows have nothing to draw from
+      if (mode == kTypeSub) {
+        valid = true;
+        for (int32_t i = 0; i < a.k; ++i) valid = valid && a.et[i] >= 0 && a.et[i] < a.g.T;
+        if (valid) {
+          const SubTypeSum sub{m.type_prefix, a.et};
+          valid = sub((uint64_t)(a.k - 1)) != 0.f;
+        }
+      } else {
+        valid = m.type_prefix[a.g.T - 1] != 0.f;
+      }
+      if (valid) {
+        const Philox4 b = RngBlock(a.seed, a.call_id, kDomainNeighbor, node, (uint32_t)j);
+        const double u_type = UnitFromWords(b.w[0], b.w[1]);
+        const double u_nb = UnitFromWords(b.w[2], b.w[3]);
+        if (mode == kTypeSub) {
+          const SubTypeSum sub{m.type_prefix, a.et};
+          t = a.et[RandomSelectT(sub, 0, (uint64_t)(a.k - 1), u_type)];
+        } else {
+          t = (int32_t)RandomSelect(m.type_prefix, 0, (uint64_t)(a.g.T - 1), u_type);
+        }
+        const int32_t b_idx = t == 0 ? 0 : m.type_end[t - 1];
+        const int32_t e_idx = m.type_end[t] - 1;
+        if (e_idx < b_idx) {
+          // an empty group is only reachable through an out-of-range read in the
+          // reference: the sentinel, as SampleAt (device_fns.h)
+          id = 0; w = 0.f; t = 0;
+        } else {
+          Segment sg;
+          sg.row_ptr = m.row_ptr; sg.b = b_idx; sg.e = e_idx;
+          sg.lo = m.row_ptr + b_idx; sg.hi = m.row_ptr + e_idx;
+          sg.limit_end = BlockedPw(a.g, sg.hi);
+          sg.limit_begin = b_idx == 0 ? 0.f : BlockedPw(a.g, sg.lo - 1);
+          sg.inl = nullptr;
+          BlockPivotSample(a.g, sg, u_nb, &id, &w);
+        }
+      }
+    }
+    a.out_id[s] = id;
+    a.out_w[s] = w;
+    a.out_t[s] = t;
+    if (j == 0 && a.out_row_mask != nullptr) a.out_row_mask[r] = valid ? 0 : 1;
+  }
+}
+
+// ------------------------------------------------------------------------
 // K1 fast path: single listed edge type (the GraphSAGE / DeepWalk case) on a
 // graph whose prefix sums are monotone (GraphView::monotone).
 //
@@ -762,6 +839,13 @@ int LaunchK1Variant(const euler_gpu_graph* g, hipStream_t stream, const SampleNb
                    : SampleNeighborFastKernel<false, false>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, stream, a, stride_rows,
                        stride_slots);
+  } else if (g_k1_variant == 6 && g_k1_typed_pivot != 0 && k != 1 && g->view.monotone &&
+             !tf_zero && g->view.blk != nullptr) {
+    if (layout == EULER_GPU_LAYOUT_TF) {
+      hipLaunchKernelGGL(SampleNeighborTypedPivotKernel<true>, dim3(grid), dim3(block), 0, stream, a);
+    } else {
+      hipLaunchKernelGGL(SampleNeighborTypedPivotKernel<false>, dim3(grid), dim3(block), 0, stream, a);
+    }
   } else {
     hipLaunchKernelGGL(SampleNeighborKernel, dim3(grid), dim3(block), 0, stream, a);
   }

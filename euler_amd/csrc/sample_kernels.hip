@@ -557,6 +557,7 @@ thread_local int g_full_nb_balanced = 1;   // get_full_neighbor fill: a lane own
 thread_local int g_fanout_fused = 1;       // small 2-hop single-type fanouts as one launch (key 23)
 // 2-hop single-type fanouts as ONE kernel with the duplicate children found inside the wave
 // (fanout_local.h).  key 27: 0 = off (hop by hop, global duplicate path), 1 = on.
+thread_local int g_k1_typed_pivot = 1;   // key 37: calls with type draws search with the block pivots (0 = reference loop)
 thread_local int g_fanout_local = 1;
 thread_local int g_fl_roots = 4;      // key 28: roots per wave (1 .. 16)
 thread_local int g_fl_cap = 0;        // key 29: hop-2 slots per pass, 0 = 8 x roots per wave
@@ -1827,6 +1828,7 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 33 && value >= 0) { g_fl_min_roots = value; return EULER_GPU_OK; }
   if (key == 34 && value >= 0 && value <= 2) { g_fl_plain = value; return EULER_GPU_OK; }
   if (key == 36) { g_fl_ablate = value; return EULER_GPU_OK; }
+  if (key == 37) { g_k1_typed_pivot = value != 0; return EULER_GPU_OK; }
   if (key == 35 && (value == 5 || value == 6 || value == 8)) { g_fl_wps = value; return EULER_GPU_OK; }
   if (key == 1 && (value == 1 || value == 2 || value == 4 || value == 8)) {
     g_k1_ilp = value;
