@@ -48,7 +48,6 @@ int Fail(int code, const std::string& msg);
 //   id map   identity/strided (id -> (id - base) / stride, no memory at all)
 //            or an open-addressing table of 16-byte {key,row} slots.
 constexpr int kPivotLevels = 10;   // levels 1..10: rows of up to 4*5^9*4 edges
-constexpr int kInlineEdges = 9;    // edges of a row kept in its 128-byte row_inline line
 
 struct GraphView {
   int64_t n_rows;
@@ -67,29 +66,14 @@ struct GraphView {
   int32_t uniform_w;            // every edge weight is exactly 1.0f (running sums 1, 2, 3, ...
                                 // per row, degrees < 2^24): the draw r = u * span + begin
                                 // lands on edge floor(r) - no search, no sums read
-  int32_t inline_k;             // > 0: row_inline holds the first inline_k edges of every row
   int32_t total_in_meta;        // T == 1 and every row's type_prefix[0] has the
                                 // bits of its last running sum (checked on device
                                 // at build): the segment limit comes with the row
                                 // record, no separate load
-  // T == 1, total_in_meta, monotone: one 128-byte line per row = the 16-byte row record
-  // followed by the running sums (bytes 16..51) and the neighbour ids (bytes 56..127)
-  // of the row's first kInlineEdges edges.  A row of <= kInlineEdges edges is sampled
-  // from that ONE line (row record, sums and ids used to be 2-3 dependent cold lines:
-  // record -> [block pivots ->] EdgeBlock); longer rows read the record from it and
-  // go on as before.  +112 B per row of HBM (12.8 GB for the metric graph).  An A/B
-  // layout (tuning key 26, off by default): it removes a cold line per short row and
-  // the step is no faster for it.
-  const uint8_t* row_inline;
   uint64_t id_base;             // identity: row = (id - id_base) / id_stride
   uint64_t id_stride;
   const uint64_t* hash_slots;   // [2 * (hash_mask + 1)] = {key, row} pairs
   uint64_t hash_mask;
-  // sampling index over the flat edge arrays (built on device at graph
-  // creation): blk[i] = edges [10 i, 10 i + 10); skip1[i] = running sum of the
-  // last edge of block i; skip2[j] = skip1[32 j + 31]; skip3[k] = skip2[32 k +
-  // 31] (indices clamped to the array end).  A search descends skip3 -> skip2
-  // -> skip1 -> block; each level is one 128-byte line.
   // dense float features (node.h float_features_idx_ / float_features_):
   // values of row r live at feat_val[feat_ptr[r] ...], slot f ends at
   // feat_idx[r * n_float + f] (row-relative).  When every row has the same
@@ -114,10 +98,8 @@ struct GraphView {
   const float* bpiv;
   int64_t bpiv_off[kPivotLevels + 1];
   const struct EdgeBlock* blk;
-  const float* skip1;
-  const float* skip2;
-  const float* skip3;
-  int64_t n_blk, n_skip2, n_skip3;
+  const float* skip1;           // [n_blk] running sum of the last edge of every EdgeBlock
+  int64_t n_blk;
 };
 
 // Edge block of the sampling index: 10 consecutive edges of the flat arrays
@@ -134,7 +116,6 @@ struct alignas(128) EdgeBlock {
   uint64_t nbr[kEdgesPerBlock];    // their neighbour ids
 };
 static_assert(sizeof(EdgeBlock) == 128, "EdgeBlock must be one 128-byte line");
-constexpr int kSkipFanout = 32;    // 32 floats = one 128-byte line per skip node
 
 // A 256-thread workgroup is one wave per SIMD, and a SIMD admits
 // min(8, 800 / (ceil(sgpr / 16) * 16 + 16)) of them (MI355X_MICROARCH.md,
@@ -216,10 +197,6 @@ struct euler_gpu_graph {
   // which counter of the stream's pair the next duplicate-root call uses
   // (DedupNumberKernel clears the other one); reset when the scratch is reallocated
   mutable std::map<void*, int> ws_parity;
-  // row kernel (k1_row.h): per stream, 256 bytes of counters + the queue of the
-  // roots left to SampleNeighborSlowKernel
-  mutable std::map<void*, std::pair<void*, size_t>> row_ws;
-  mutable std::map<void*, int> row_parity;
   // the stream of the previous sampling call: a caller that alternates streams keeps
   // several minibatches in flight, and the launcher then sizes its K1 grids so that the
   // kernels of two streams fit on the chip together (sample_kernels.hip: ConcurrentCall)
@@ -235,7 +212,7 @@ int BuildGraphFromHost(const euler_gpu_host_csr* csr, int device,
 int BuildGraphSynthetic(const euler_gpu_synth_params* p, int device,
                         int32_t partitions, int32_t shard_index, int32_t shards,
                         euler_gpu_graph** out);
-int EnsureBlockedIndex(const euler_gpu_graph* g);   // K1 variants 3 / 4 only
+int EnsureBlockedIndex(const euler_gpu_graph* g);   // EdgeBlocks + block pivots, on first use
 // sample_kernels.hip: TF-layout SampleNeighbor over the first *n_dev roots of a list
 // sized for `cap` (dataflow_kernels.hip)
 int LaunchSampleNeighborCounted(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed,

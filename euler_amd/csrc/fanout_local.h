@@ -99,7 +99,7 @@ __host__ __device__ inline FanoutLocalLds FanoutLocalLayout(int32_t gr, int32_t 
 typedef unsigned long long fl_u64x2 __attribute__((ext_vector_type(2)));
 
 // PLAIN: the graph is the common case - one edge-type group per node with the row's total
-// in its record, weighted, identity id map, no neighbour id 0, no row_inline lines - and the
+// in its record, weighted, identity id map, no neighbour id 0 - and the
 // kernel is compiled with those as constants (fewer live registers: 8 waves per SIMD).
 // WPS: waves per SIMD the register allocation targets (8: 64 VGPRs with a few cold spills
 // at the phase boundaries; 5: 96, none).
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLocalKernel(
   FanoutLocalArgs a = a_in;
   if (PLAIN) {
     a.g.T = 1; a.g.meta_stride = 16; a.g.total_in_meta = 1; a.g.uniform_w = 0;
-    a.g.inline_k = 0; a.g.map_mode = 0; a.g.has_zero_nbr = 0; a.g.monotone = 1;
+    a.g.map_mode = 0; a.g.has_zero_nbr = 0; a.g.monotone = 1;
   }
   extern __shared__ __align__(16) uint8_t fl_smem[];
   const int lane = threadIdx.x & 63;

@@ -16,7 +16,6 @@
 
 namespace euler_gpu {
 
-extern thread_local int g_k1_inline;      // sample_kernels.hip (tuning key 26)
 
 namespace {
 thread_local std::string g_last_error;
@@ -87,15 +86,6 @@ __global__ void BuildBlocksKernel(const float* __restrict__ pw,
   b.pad = 0;
   blk[i] = b;
   skip1[i] = b.pw[kEdgesPerBlock - 1];
-}
-
-__global__ void BuildSkipKernel(const float* __restrict__ lower, int64_t n_lower,
-                                int64_t n_upper, float* __restrict__ upper) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n_upper) return;
-  int64_t x = j * kSkipFanout + (kSkipFanout - 1);
-  if (x > n_lower - 1) x = n_lower - 1;
-  upper[j] = lower[x];
 }
 
 // upper[q] = lower[min(fan * q + fan - 1, n_lower - 1)]
@@ -170,46 +160,10 @@ int VerifyTotals(GraphBuilder* b) {
 
 int BuildBlockedIndex(GraphBuilder* b);
 
-// row_inline (common.h): record + first kInlineEdges sums and ids of every row
-__global__ __launch_bounds__(256) void InlineRowsKernel(GraphView g, uint8_t* out) {
-  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= g.n_rows) return;
-  const uint4 q = *reinterpret_cast<const uint4*>(g.row_meta + row * 16);
-  const int64_t row_ptr = (int64_t)(((uint64_t)q.y << 32) | q.x);
-  const int32_t deg = (int32_t)q.z;
-  uint8_t* rec = out + row * 128;
-  *reinterpret_cast<uint4*>(rec) = q;
-  float* pw = reinterpret_cast<float*>(rec + 16);
-  uint64_t* nb = reinterpret_cast<uint64_t*>(rec + 56);
-  for (int32_t j = 0; j < kInlineEdges; ++j) {
-    pw[j] = j < deg ? g.prefix_w[row_ptr + j] : 0.f;
-    nb[j] = j < deg ? g.nbr[row_ptr + j] : 0;
-  }
-  pw[kInlineEdges] = 0.f;       // bytes 52..55
-}
-
-int BuildInlineRows(GraphBuilder* b) {
-  GraphView& v = b->g->view;
-  v.inline_k = 0;
-  v.row_inline = nullptr;
-  if (!g_k1_inline) return EULER_GPU_OK;   // an A/B layout (see the key's comment): built on request
-  if (v.T != 1 || !v.total_in_meta || !v.monotone || v.n_rows == 0) return EULER_GPU_OK;
-  uint8_t* buf = b->Alloc<uint8_t>((size_t)v.n_rows * 128);
-  if (b->rc != EULER_GPU_OK) return b->rc;
-  if (((uintptr_t)buf & 127) != 0) return Fail(EULER_GPU_EHIP, "row_inline: unaligned allocation");
-  hipLaunchKernelGGL(InlineRowsKernel, dim3((v.n_rows + 255) / 256), dim3(256), 0, 0, v, buf);
-  EG_HIP(hipGetLastError());
-  EG_HIP(hipDeviceSynchronize());
-  v.row_inline = buf;
-  v.inline_k = kInlineEdges;
-  return EULER_GPU_OK;
-}
-
 // Pivot levels over the flat arrays (variant 5) and the EdgeBlock copy with its
 // block pivots (variant 6, the default sampler) are both built at creation.
 int BuildSearchIndex(GraphBuilder* b) {
   int rc = VerifyTotals(b);
-  if (rc == EULER_GPU_OK) rc = BuildInlineRows(b);
   if (rc == EULER_GPU_OK) rc = BuildPivotLevels(b);
   return rc != EULER_GPU_OK ? rc : BuildBlockedIndex(b);
 }
@@ -218,23 +172,15 @@ int BuildBlockedIndex(GraphBuilder* b) {
   GraphView& v = b->g->view;
   const int64_t E = v.n_edges;
   v.n_blk = (E + kEdgesPerBlock - 1) / kEdgesPerBlock;
-  v.n_skip2 = (v.n_blk + kSkipFanout - 1) / kSkipFanout;
-  v.n_skip3 = (v.n_skip2 + kSkipFanout - 1) / kSkipFanout;
   if (E >= (int64_t)kEdgesPerBlock * 0x7fffff00LL)
     return Fail(EULER_GPU_EINVAL, "graph too large for 32-bit block indices");
   EdgeBlock* blk = b->Alloc<EdgeBlock>((size_t)v.n_blk);
   float* s1 = b->Alloc<float>((size_t)v.n_blk + 8);   // windows may run 3 past the end
-  float* s2 = b->Alloc<float>((size_t)v.n_skip2);
-  float* s3 = b->Alloc<float>((size_t)v.n_skip3);
   if (b->rc != EULER_GPU_OK) return b->rc;
   const int block = 256;
   if (E > 0) {
     hipLaunchKernelGGL(BuildBlocksKernel, dim3((v.n_blk + block - 1) / block),
                        dim3(block), 0, 0, v.prefix_w, v.nbr, E, v.n_blk, blk, s1);
-    hipLaunchKernelGGL(BuildSkipKernel, dim3((v.n_skip2 + block - 1) / block),
-                       dim3(block), 0, 0, s1, v.n_blk, v.n_skip2, s2);
-    hipLaunchKernelGGL(BuildSkipKernel, dim3((v.n_skip3 + block - 1) / block),
-                       dim3(block), 0, 0, s2, v.n_skip2, v.n_skip3, s3);
     EG_HIP(hipGetLastError());
     EG_HIP(hipDeviceSynchronize());
   }
@@ -262,7 +208,7 @@ int BuildBlockedIndex(GraphBuilder* b) {
     EG_HIP(hipDeviceSynchronize());
     v.bpiv = bp;
   }
-  v.blk = blk; v.skip1 = s1; v.skip2 = s2; v.skip3 = s3;
+  v.blk = blk; v.skip1 = s1;
   return EULER_GPU_OK;
 }
 

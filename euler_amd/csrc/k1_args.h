@@ -1,7 +1,7 @@
 // Arguments and device-side gates shared by the sample_neighbor kernels
-// (sample_kernels.hip: the default pivot kernels and the duplicate-root path;
-// k1_variants.hip: the reference loop and the earlier search variants) and the
-// tuning switches of euler_gpu_set_tuning.
+// (sample_kernels.hip: the single-type pivot kernels and the duplicate-root path;
+// k1_variants.hip: the reference loop and the type-draw kernel) and the tuning
+// switches of euler_gpu_set_tuning.
 #ifndef EULER_AMD_CSRC_K1_ARGS_H_
 #define EULER_AMD_CSRC_K1_ARGS_H_
 
@@ -52,12 +52,6 @@ struct SampleNbArgs {
                                 // out_t / out_row_mask (see PackRowsKernel)
   int32_t packed_tcol;          // ... with (1) or without (0: single-type call) the types
   int32_t cold_roots;           // hint: the roots are distinct (one sample per lane)
-  uint32_t* slow_list;          // row kernel (k1_row.h): queue of the roots it leaves to
-  uint32_t* slow_count;         // SampleNeighborSlowKernel: [kSlowShards] queue lengths of this
-  uint32_t* slow_count_next;    // call; the set the stream's next call uses (cleared here)
-  int64_t slow_cap;             // entries per queue
-  int32_t ablate;               // measurement only (tuning key 2): row kernel 1 = no draws,
-                                // 2 = no write phase, 4 = no Philox (u = 0.5)
   int32_t et[kMaxListedTypes];
 };
 
@@ -113,17 +107,10 @@ __host__ __device__ __forceinline__ int32_t PackedWords(int32_t count, int32_t t
 // enqueues and nobody else's (the reference's client pool runs 8 query threads
 // side by side; tests toggle variants in-process)
 constexpr int64_t kK1GridCap = 32768;
-extern thread_local int g_k1_variant, g_k1_ilp, g_k1_ablate, g_k1_grid_cap, g_k1_pair, g_k1_group,
-    g_k1_dedup, g_k1_fuse_mark, g_k1_dual, g_expand_steps, g_expand_const_type,
-    g_expand_grid_cap, g_n2v_wave, g_dedup_block_numbering, g_k1_row,
-    g_dedup_resolve_in_expand, g_expand_lean, g_k1_pair_distinct, g_fanout_fused, g_full_nb_balanced, g_n2v_big, g_k1_inline, g_k1_typed_pivot;
-
-// the graph as the sampling launches of this host thread see it (tuning key 26)
-inline GraphView SamplingView(const euler_gpu_graph* g) {
-  GraphView v = g->view;
-  if (!g_k1_inline) { v.inline_k = 0; v.row_inline = nullptr; }
-  return v;
-}
+extern thread_local int g_k1_variant, g_k1_ablate, g_k1_grid_cap, g_k1_pair, g_k1_dedup,
+    g_k1_fuse_mark, g_k1_dual, g_expand_steps, g_expand_const_type, g_expand_grid_cap,
+    g_n2v_wave, g_dedup_block_numbering, g_dedup_resolve_in_expand, g_fanout_fused,
+    g_full_nb_balanced, g_n2v_big, g_k1_typed_pivot;
 
 // k1_variants.hip: launches the kernel variant `g_k1_variant` selects for calls
 // the pivot kernels do not serve (grid = workgroups for one sample per lane)

@@ -58,39 +58,7 @@ struct Segment {
   int64_t lo, hi;       // searched edges [lo, hi] (global indices)
   float limit_begin, limit_end;
   int32_t b, e;         // the same segment, row-relative
-  const uint8_t* inl;   // the row's row_inline line when it holds the WHOLE row, else nullptr
 };
-
-// A draw on a row that lives in its row_inline line (<= kInlineEdges edges, the whole
-// row is the segment): the first m of [0, e] with nw[m] > r, from the line the row
-// record came in.  Same contract as the searches below; the caller has checked
-// r < limit_end.
-__device__ __forceinline__ void InlineSample(const GraphView& g, const Segment& sg, double rr,
-                                             uint64_t* id, float* w) {
-  const float* ipw = reinterpret_cast<const float*>(sg.inl + 16);
-  const uint64_t* inb = reinterpret_cast<const uint64_t*>(sg.inl + 56);
-  int32_t i = 0;
-  if (g.uniform_w) {
-    i = (int32_t)rr;                 // nw[m] = m + 1: the first m with nw[m] > r is floor(r)
-    *w = 1.0f;
-  } else {
-    const float4 a0 = *reinterpret_cast<const float4*>(ipw);
-    const float4 a1 = *reinterpret_cast<const float4*>(ipw + 4);
-    const float a8 = ipw[8];
-    const float v[kInlineEdges] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a8};
-#pragma unroll
-    for (int j = 0; j < kInlineEdges - 1; ++j)
-      i += (j < sg.e && !((double)v[j] > rr)) ? 1 : 0;
-    float nw_m = v[0], prev = 0.f;    // `mid ? nw[mid-1] : 0`
-#pragma unroll
-    for (int j = 0; j < kInlineEdges; ++j) {
-      if (j == i) nw_m = v[j];
-      if (j + 1 == i) prev = v[j];
-    }
-    *w = __fsub_rn(nw_m, prev);
-  }
-  *id = inb[i];
-}
 
 // One draw u on a segment: the neighbour RandomSelect picks and its weight.
 __device__ __forceinline__ void PivotSample(const GraphView& g, const Segment& sg,
@@ -106,7 +74,6 @@ __device__ __forceinline__ void PivotSample(const GraphView& g, const Segment& s
     *w = __fsub_rn(nw[m], m == 0 ? 0.f : nw[m - 1]);
     return;
   }
-  if (sg.inl != nullptr) { InlineSample(g, sg, rr, id, w); return; }
   if (g.uniform_w) {
     // H1 (uniform weights, configs[1]): nw[m] = m + 1 exactly, so the first m with
     // nw[m] > r is floor(r) (r < limit_end was just checked; r >= limit_begin = b)
@@ -211,7 +178,6 @@ __device__ __forceinline__ void BlockPivotSample(const GraphView& g, const Segme
     *w = __fsub_rn(nw[m], m == 0 ? 0.f : nw[m - 1]);
     return;
   }
-  if (sg.inl != nullptr) { InlineSample(g, sg, rr, id, w); return; }
   if (g.uniform_w) {
     // H1 (uniform weights, configs[1]): nw[m] = m + 1 exactly, so the first m with
     // nw[m] > r is floor(r) (r < limit_end was just checked; r >= limit_begin = b)
@@ -298,102 +264,13 @@ __device__ __forceinline__ void BlockPivotSample(const GraphView& g, const Segme
   *w = __fsub_rn(nw_m, prev);
 }
 
-// first x in [lo, hi) with a[x] > r, else hi
-__device__ __forceinline__ int32_t UpperBound32(const float* __restrict__ a,
-                                                int32_t lo, int32_t hi, double r) {
-  while (lo < hi) {
-    const int32_t mid = (int32_t)(((uint32_t)lo + (uint32_t)hi) >> 1);
-    if ((double)a[mid] > r) hi = mid; else lo = mid + 1;
-  }
-  return lo;
-}
-
-// Global edge index of the first edge in [lo, hi] whose running sum exceeds r
-// (the caller guarantees sum(hi) > r).  *pw_m / *nbr_m receive that edge.
-__device__ __forceinline__ int64_t BlockedSearch(const GraphView& g,
-                                                 int64_t row_start, int64_t lo,
-                                                 int64_t hi, double r,
-                                                 float* pw_m, float* pw_prev,
-                                                 uint64_t* nbr_m, int mode = 0) {
-  const int32_t b_lo = (int32_t)(lo / kEdgesPerBlock);
-  const int32_t b_hi = (int32_t)(hi / kEdgesPerBlock);
-  // answer block = first B in [x_lo, x_hi) with skip1[B] > r, else x_hi
-  int32_t x_lo = b_lo, x_hi = b_hi;
-  if (mode == 10) {          // measurement only: no skip search, random block
-    x_lo = b_lo + (int32_t)((uint32_t)(r * 7919.0) % (uint32_t)(b_hi - b_lo + 1));
-    x_hi = x_lo;
-  } else
-  if (x_hi - x_lo > kSkipFanout) {
-    int32_t y_lo = x_lo / kSkipFanout, y_hi = (x_hi - 1) / kSkipFanout;
-    if (y_hi - y_lo > kSkipFanout) {
-      const int32_t z_lo = y_lo / kSkipFanout, z_hi = (y_hi - 1) / kSkipFanout;
-      const int32_t zm = UpperBound32(g.skip3, z_lo, z_hi, r);
-      y_lo = max(y_lo, zm * kSkipFanout);
-      y_hi = min(y_hi, zm * kSkipFanout + kSkipFanout);
-    }
-    const int32_t ym = UpperBound32(g.skip2, y_lo, y_hi, r);
-    x_lo = max(x_lo, ym * kSkipFanout);
-    x_hi = min(x_hi, ym * kSkipFanout + kSkipFanout);
-  }
-  int32_t bm;
-  const bool short_row = x_hi - x_lo <= 2;
-  if (short_row) {
-    // short rows: probe the candidate blocks themselves (one of them is the
-    // answer's line anyway) instead of touching a skip1 line
-    bm = x_lo;
-    while (bm < x_hi && !((double)g.blk[bm].pw[kEdgesPerBlock - 1] > r)) ++bm;
-  } else {
-    bm = UpperBound32(g.skip1, x_lo, x_hi, r);
-  }
-  if (mode == 11) {          // measurement only: no leaf
-    *pw_m = (float)bm; *pw_prev = 0.f; *nbr_m = (uint64_t)bm;
-    return bm;
-  }
-  const EdgeBlock* bk = g.blk + bm;
-  const int64_t base = (int64_t)bm * kEdgesPerBlock;
-  const int32_t i_lo = lo > base ? (int32_t)(lo - base) : 0;
-  const int32_t i_hi = hi - base < kEdgesPerBlock - 1 ? (int32_t)(hi - base)
-                                                      : kEdgesPerBlock - 1;
-  const int32_t i = UpperBound32(bk->pw, i_lo, i_hi, r);
-  *pw_m = bk->pw[i];
-  *nbr_m = bk->nbr[i];
-  // `mid ? nw[mid-1] : 0` is row-relative: the first edge of a row subtracts
-  // 0, not the previous row's last sum.  The previous block's last sum is read
-  // from whichever line the search has already touched.
-  if (base + i == row_start) *pw_prev = 0.f;
-  else if (i > 0) *pw_prev = bk->pw[i - 1];
-  else *pw_prev = short_row ? g.blk[bm - 1].pw[kEdgesPerBlock - 1] : g.skip1[bm - 1];
-  return base + i;
-}
-
-// One draw u on a segment through the 32-ary skip levels (K1 variant 3's search): the
-// contract of PivotSample / BlockPivotSample.
-__device__ __forceinline__ void BlockedSample(const GraphView& g, const Segment& sg, double u,
-                                              uint64_t* id, float* w) {
-  const double rr = ScaleDraw(u, sg.limit_begin, sg.limit_end);
-  if (!((double)sg.limit_end > rr)) {
-    // Q3: r rounded up to the end of the segment - replay the reference
-    const float* nw = g.prefix_w + sg.row_ptr;
-    const int32_t m = (int32_t)RandomSelect(nw, (uint64_t)sg.b, (uint64_t)sg.e, u);
-    *id = g.nbr[sg.row_ptr + m];
-    *w = __fsub_rn(nw[m], m == 0 ? 0.f : nw[m - 1]);
-    return;
-  }
-  float pw_m, pw_prev;
-  BlockedSearch(g, sg.row_ptr, sg.lo, sg.hi, rr, &pw_m, &pw_prev, id);
-  *w = __fsub_rn(pw_m, pw_prev);
-}
-
 // Row record -> searched segment of the listed type; false = empty / invalid
 // (node.cc:127-136).
 template <bool BLOCKED = false>
 __device__ __forceinline__ bool LoadSegment(const GraphView& g, int64_t row,
                                             int32_t t, Segment* sg) {
   if (row < 0 || t < 0 || t >= g.T) return false;
-  sg->inl = nullptr;
-  // inline_k > 0 implies T == 1 and total_in_meta; the line starts with the row record
-  const uint8_t* rec = g.inline_k > 0 ? g.row_inline + row * 128
-                                      : g.row_meta + row * (int64_t)g.meta_stride;
+  const uint8_t* rec = g.row_meta + row * (int64_t)g.meta_stride;
   if (g.T == 1) {
     const uint4 q = *reinterpret_cast<const uint4*>(rec);
     sg->row_ptr = (int64_t)(((uint64_t)q.y << 32) | q.x);
@@ -407,7 +284,6 @@ __device__ __forceinline__ bool LoadSegment(const GraphView& g, int64_t row,
       sg->hi = sg->row_ptr + sg->e;
       sg->limit_begin = 0.f;
       sg->limit_end = __uint_as_float(q.w);
-      if (g.inline_k > 0 && sg->e < g.inline_k) sg->inl = rec;
       return true;
     }
   } else {

@@ -91,7 +91,11 @@ __device__ __forceinline__ int64_t LowerBound(const int32_t* a, int64_t n,
 // falls back to the bisection.
 __device__ __forceinline__ int64_t SegStart(const int32_t* keys, int64_t e, int32_t size,
                                             int64_t r) {
-  if (r >= size) return e;
+  // r == size: the end of the LAST destination's segment - the first key >= size, not e:
+  // out-of-range scatter indices (undefined behaviour in the reference,
+  // tf_euler/kernels/scatter_op.cc:27-105) are left out instead of being folded into
+  // row size - 1
+  if (r >= size) return (e > 0 && keys[e - 1] >= size) ? LowerBound(keys, e, size) : e;
   const int64_t g = r * e / size;
   if ((g == 0 || keys[g - 1] < (int32_t)r) && (g == e || keys[g] >= (int32_t)r)) return g;
   return LowerBound(keys, e, (int32_t)r);

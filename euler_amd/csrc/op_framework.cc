@@ -83,6 +83,10 @@ class OpScope {
   }
   ~OpScope() {
     if (arena_ == nullptr) return;
+    // an op that leaves early (a failed call, a bad argument) may have copies and kernels
+    // queued that read or write its locals, its just-freed outputs or this arena: wait
+    // for them before any of that memory is reused
+    if (arena_->stream != nullptr && dirty_) (void)hipStreamSynchronize(arena_->stream);
     if (arena_->chunks.size() > 1) {
       // the op outgrew the arena: one chunk of the total size for the next call
       size_t total = 0;
@@ -118,16 +122,25 @@ class OpScope {
   bool Upload(void* dst, const void* src, size_t bytes) {
     if (!ok_ || dst == nullptr) return ok_ = false;
     if (bytes == 0) return true;
+    dirty_ = true;
     return Check(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, arena_->stream), "copy to device");
   }
   bool Download(void* dst, const void* src, size_t bytes) {
     if (!ok_ || src == nullptr) return ok_ = false;
     if (bytes == 0) return true;
+    dirty_ = true;
     return Check(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, arena_->stream), "copy to host");
   }
-  bool Sync() { return ok_ && Check(hipStreamSynchronize(arena_->stream), "stream sync"); }
+  bool Sync() {
+    if (!ok_) return false;
+    const bool r = Check(hipStreamSynchronize(arena_->stream), "stream sync");
+    if (r) dirty_ = false;
+    return r;
+  }
+  void MarkDirty() { dirty_ = true; }     // the caller enqueues on stream() itself
   // the C ABI's return code
   bool Call(int rc) {
+    dirty_ = true;              // the call may have enqueued kernels on the stream
     if (rc != 0) { ok_ = false; err_ = euler_gpu_last_error(); }
     return ok_;
   }
@@ -139,6 +152,7 @@ class OpScope {
   }
   Arena* arena_ = nullptr;
   bool ok_ = true;
+  bool dirty_ = false;        // work was enqueued on the stream since the last Sync()
   std::string err_;
 };
 
@@ -364,6 +378,7 @@ class GpuSampleNeighborOp : public OpKernel {
       int32_t* d_idx = sc.Alloc<int32_t>(n * 2);
       if (!sc.ok()) OP_FAIL(sc, "API_SAMPLE_NB");
       // runs of consecutive valid rows move with one copy each
+      sc.MarkDirty();
       for (int64_t i = 0; i < n;) {
         if (mask[i]) { ++i; continue; }
         int64_t j = i;
@@ -394,6 +409,11 @@ class GpuSampleNeighborOp : public OpKernel {
           !sc.Download(hw.data(), p_w, (size_t)cur * 4) || !sc.Download(ht.data(), p_t, (size_t)cur * 4) ||
           !sc.Sync())
         OP_FAIL(sc, "API_SAMPLE_NB");
+      // a row the post-process emptied (`limit 0`) is an empty row like one without
+      // samples: the reference refills EVERY empty row with count x (0, 0.0, 0)
+      // (core/kernels/sample_neighbor_op.cc:134-143)
+      for (int64_t i = 0; i < n; ++i)
+        if (pidx[2 * i + 1] == pidx[2 * i]) mask[i] = 1;
       out_total = 0;
       for (int64_t i = 0; i < n; ++i) out_total += mask[i] ? count : pidx[2 * i + 1] - pidx[2 * i];
       Tensor *t_idx = nullptr, *oid = nullptr, *ow = nullptr, *ot = nullptr;

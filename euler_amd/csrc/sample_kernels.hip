@@ -12,7 +12,6 @@
 
 #include "k1_args.h"
 #include "k1_search.h"
-#include "k1_row.h"
 #include "fanout_local.h"
 
 extern thread_local int g_feature_vec4;   // mp_kernels.hip
@@ -525,39 +524,34 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void ExpandPackedKernel(
   }
 }
 // ---- tuning switches (euler_gpu_set_tuning; declared in k1_args.h) ----
-thread_local int g_k1_dedup = 1;     // 0 = never, 1 = automatic for >= 100 000 roots, 2 = always try
-thread_local int g_n2v_wave = 2;     // node2vec: 3 = launched per step, long lists by a workgroup (n2v_kernels.h:
-                        // N2vBigStepKernel), 2 = one launch, one wave per walker, the two-cursor walk by
-                        // the whole wave, 1 = lane 0 walks LDS-staged lists, 0 = one lane per walker
-thread_local int g_k1_inline = 0;    // key 26: rows of <= 9 edges sampled from their row_inline line (common.h);
-                        // the lines are built for graphs created while it is 1.  Measured on the metric
-                        // (profiles/r2_inline_ab.txt): first hop alone 51.3 -> 48.2 us lane per sample,
-                        // 62.4 -> 66 us lane per root, the step and the B = 1 024 latency unchanged or
-                        // 1-3 % worse, for 12.8 GB more HBM - off
+thread_local int g_k1_variant = 6;   // key 0: 6 = block pivots, 5 = pivot levels over the flat arrays,
+                                     // 0 = the reference loop for every call
+thread_local int g_k1_ablate = 0;    // key 2: measurement only (walk kernels)
+thread_local int g_k1_grid_cap = -1; // key 3: workgroup cap of the K1 launches: -1 = by concurrency (see
+                        // ConcurrentCall: 4096 = 16 waves per CU when the caller alternates streams, so
+                        // that the kernels of another minibatch fit beside them; else kK1GridCap =
+                        // 32 768), 0 = always 32 768, > 0 = that many
+thread_local int g_k1_pair = 1;      // key 4: pivot kernel: two adjacent samples per lane when count is even
+thread_local int g_k1_dedup = 1;     // key 5: 0 = never, 1 = automatic for >= 100 000 roots, 2 = always try
+thread_local int g_n2v_wave = 2;     // key 7: node2vec: 3 = launched per step, long lists by a workgroup
+                        // (n2v_kernels.h: N2vBigStepKernel), 2 = one launch, one wave per walker, the
+                        // two-cursor walk by the whole wave, 1 = lane 0 walks LDS-staged lists, 0 = one
+                        // lane per walker
+thread_local int g_k1_fuse_mark = 1; // key 9: fanout: a hop's kernels fill the next hop's owner table
+thread_local int g_expand_steps = 2;        // key 10: DedupExpandKernel: grid-stride steps in flight per lane (1, 2, 4)
+thread_local int g_expand_const_type = 1;   // key 11: ... rebuild the type column of single-type calls from the mask
+thread_local int g_expand_grid_cap = 0;     // key 12: ... workgroup cap (0 = kK1GridCap)
+thread_local int g_k1_dual = 1;      // key 13: duplicate-root call: both gated passes in one launch
+thread_local int g_dedup_block_numbering = 2;   // key 14: 2 = one pass (workgroups take numbers from the call's
+                                   // counter), 1 = per-workgroup counts + one small scan, 0 = device-wide scan
+thread_local int g_dedup_resolve_in_expand = 0;   // key 20: 1 = last hop: the expansion reads its row number from
+                                     // the owner table itself (no resolve kernel, no uidx array) -
+                                     // measured: dedup 43 -> 28 us, expansion 134 -> 157 us; off
+thread_local int g_fanout_fused = 1;       // key 23: small 2-hop single-type fanouts as one launch, a workgroup per root
+thread_local int g_full_nb_balanced = 1;   // key 24: get_full_neighbor fill: a lane owns 4 output entries
 thread_local int g_n2v_big = 8192;   // key 25: child lists of this many entries go to the workgroup kernel (0 = none)
-thread_local int g_k1_group = 0;     // block-pivot kernel: five adjacent samples per lane for odd counts
-                        // that are a multiple of 5 - measured 8 % SLOWER on the metric's
-                        // first hop (it is bound by the dependent-load chain per lane, not
-                        // by instruction count), kept selectable
-thread_local int g_k1_pair = 1;      // pivot kernel: two adjacent samples per lane when count is even
-thread_local int g_k1_grid_cap = -1;  // workgroup cap of the K1 launches: -1 = by concurrency (see ConcurrentCall:
-                        // 4096 = 16 waves per CU when the caller alternates streams, so that the
-                        // kernels of another minibatch fit beside them: two streams -5 % per
-                        // step; else kK1GridCap = 32 768), 0 = always 32 768, > 0 = that many
-thread_local int g_k1_fuse_mark = 1; // fanout: a hop's kernels fill the next hop's owner table
-thread_local int g_k1_dual = 1;      // duplicate-root call: both gated passes in one launch
-thread_local int g_dedup_block_numbering = 2;   // 2 = one pass (workgroups take numbers from the call's counter),
-                                   // 1 = per-workgroup counts + one small scan, 0 = device-wide scan
-thread_local int g_expand_steps = 2;        // DedupExpandKernel: grid-stride steps in flight per lane (1, 2, 4)
-thread_local int g_expand_const_type = 1;   // ... rebuild the type column of single-type calls from the mask
-thread_local int g_expand_grid_cap = 0;     // ... workgroup cap (0 = kK1GridCap)
-thread_local int g_k1_ablate = 0;   // measurement only: skip parts of the blocked kernel
-thread_local int g_k1_ilp = 4;      // samples per lane of the ILP kernel (1, 2, 4, 8)
-thread_local int g_full_nb_balanced = 1;   // get_full_neighbor fill: a lane owns 4 output entries (key 24)
-thread_local int g_fanout_fused = 1;       // small 2-hop single-type fanouts as one launch (key 23)
 // 2-hop single-type fanouts as ONE kernel with the duplicate children found inside the wave
 // (fanout_local.h).  key 27: 0 = off (hop by hop, global duplicate path), 1 = on.
-thread_local int g_k1_typed_pivot = 1;   // key 37: calls with type draws search with the block pivots (0 = reference loop)
 thread_local int g_fanout_local = 1;
 thread_local int g_fl_roots = 4;      // key 28: roots per wave (1 .. 16)
 thread_local int g_fl_cap = 0;        // key 29: hop-2 slots per pass, 0 = 8 x roots per wave
@@ -566,26 +560,13 @@ thread_local int g_fl_wide = 1;       // key 31: weights / types as 16-byte stor
 thread_local int g_fl_grid_cap = -1;  // key 32: waves of the launch: 0 = one tile per wave (no loop), -1 = that for a
                                       // caller on one stream and 16 384 looping waves for one that alternates
                                       // streams (two launches share the chip), > 0 = that many
-thread_local int g_fl_wps = 5;        // key 35: register budget, waves per SIMD (8, 6 or 5; 5: nothing spilled)
-thread_local int g_fl_ablate = 0;     // key 36: measurement only (FanoutLocalArgs::ablate)
-thread_local void* g_fl_debug = nullptr;   // euler_gpu_set_debug_buffer: phase stamps of the lean kernel
+thread_local int g_fl_min_roots = 4096;   // key 33: smaller batches keep the workgroup-per-root kernel
 thread_local int g_fl_plain = 2;      // key 34: plain graphs: 2 = the lean kernel, 1 = the general kernel
                                       // constant-folded, 0 = the general kernel
-thread_local int g_fl_min_roots = 4096;   // key 33: smaller batches keep the workgroup-per-root kernel
-thread_local int g_k1_pair_distinct = 0;   // pass over the distinct roots: two samples per lane (key 22)
-thread_local int g_expand_lean = 1;  // last hop, even count: the lean gather-copy kernel (key 21)
-thread_local int g_k1_row = 1;       // 1 / 2 = block-pivot calls without the duplicate path sample with one
-                        // lane per ROOT (k1_row.h; 1: launches of >= 2^20 samples of a caller
-                        // that alternates streams, 2: all).
-                        // Alone it ties with one lane per sample (56 vs 50 us on the metric's
-                        // first hop); it holds a quarter of the wave slots, though, and with
-                        // two minibatches in flight the step is 3-9 % faster with it
-thread_local int g_dedup_resolve_in_expand = 0;   // 1 = last hop: the expansion reads its row number from the
-                                     // owner table itself (no resolve kernel, no uidx array) -
-                                     // measured: dedup 43 -> 28 us, expansion 134 -> 157 us; off
-thread_local int g_k1_variant = 6;   // 6 = block pivots, 5 = pivot levels, 4 = wave-staged (count >= 8) else blocked,
-                        // 3 = blocked index,
-                        // 2 = ILP, 1 = fast path, 0 = generic
+thread_local int g_fl_wps = 5;        // key 35: register budget, waves per SIMD (8, 6 or 5; 5: nothing spilled)
+thread_local int g_fl_ablate = 0;     // key 36: measurement only (FanoutLocalArgs::ablate)
+thread_local int g_k1_typed_pivot = 1;   // key 37: calls with type draws search with the block pivots (0 = reference loop)
+thread_local void* g_fl_debug = nullptr;   // euler_gpu_set_debug_buffer: phase stamps of the lean kernel
 
 // U = 1: one sample per lane.  U = 2 (even `count`): a lane draws the two
 // adjacent samples (j, j+1) of one root - one root id / row record / limit
@@ -675,123 +656,17 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborPivotKernel(
 // picks which one runs - `a` (the given roots, U samples per lane) or `b` (the
 // distinct roots into scratch rows, one sample per lane).  A gated launch that
 // only exits still costs ~8 us for its 32 768 workgroups.
-template <bool TF_LAYOUT, int U, bool BLOCKED, int U2 = 1>
+template <bool TF_LAYOUT, int U, bool BLOCKED>
 __global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborPivotDualKernel(
     const SampleNbArgs a, const int64_t a_rows, const int32_t a_slots,
     const SampleNbArgs b, const int64_t b_rows, const int32_t b_slots) {
   if (DedupActive(a.dd_counter, a.dd_n_in)) {
-    PivotPass<TF_LAYOUT, U2, BLOCKED>(b, (int64_t)(*a.dd_counter), b_rows, b_slots);
+    PivotPass<TF_LAYOUT, 1, BLOCKED>(b, (int64_t)(*a.dd_counter), b_rows, b_slots);
   } else {
     PivotPass<TF_LAYOUT, U, BLOCKED>(a, a.n, a_rows, a_slots);
   }
 }
 
-// ------------------------------------------------------------------------
-// Group mode of the block-pivot kernel: a lane draws U adjacent samples of one
-// root (count % U == 0).  The root id, row record and limits are loaded once per
-// U samples, and when the searched segment lies inside ONE EdgeBlock (the usual
-// case for the uniformly drawn roots of a first hop: average degree 10) so are
-// the three leaf loads - every sample then costs one id load.  Used for odd
-// counts that are a multiple of 5 (fanout 25), where the two-sample mode with
-// its 16-byte stores does not apply.
-// ------------------------------------------------------------------------
-template <bool TF_LAYOUT, int U>
-__global__ __launch_bounds__(256) void SampleNeighborGroupKernel(
-    const SampleNbArgs a, const int64_t stride_rows, const int32_t stride_slots) {
-  int64_t n_roots;
-  if (!DedupGate(a, &n_roots)) return;
-  const int64_t total = n_roots * (int64_t)a.count;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x * U;
-  int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * U;
-  if (s >= total) return;
-  int64_t r = s / a.count;
-  int32_t j = (int32_t)(s - r * a.count);
-  const int32_t t = a.et[0];
-  for (; s < total; s += stride) {
-    uint64_t node = a.roots[r];
-    if (a.root_mask != nullptr && a.root_mask[r / a.root_group]) node = 0;
-    Segment sg;
-    const bool valid = LoadSegment<true>(a.g, FindRow(a.g, node), t, &sg);
-    uint64_t id[U];
-    float w[U];
-    int32_t ot = t;
-    if (valid) {
-      double u[U];
-#pragma unroll
-      for (int x = 0; x < U; x += 2) {
-        // draws j+x, j+x+1 (j is a multiple of U; U odd -> the parity of j varies)
-        const uint32_t d = (uint32_t)(j + x);
-        const Philox4 b0 = RngBlock(a.seed, a.call_id, kDomainNeighbor, node, d >> 1);
-        if ((d & 1) == 0) {
-          u[x] = UnitFromWords(b0.w[0], b0.w[1]);
-          if (x + 1 < U) u[x + 1] = UnitFromWords(b0.w[2], b0.w[3]);
-        } else {
-          u[x] = UnitFromWords(b0.w[2], b0.w[3]);
-          if (x + 1 < U) {
-            const Philox4 b1 = RngBlock(a.seed, a.call_id, kDomainNeighbor, node,
-                                        (d + 1) >> 1);
-            u[x + 1] = UnitFromWords(b1.w[0], b1.w[1]);
-          }
-        }
-      }
-      const int64_t blk_lo = sg.lo / kEdgesPerBlock;
-      if (blk_lo == sg.hi / kEdgesPerBlock) {
-        // the whole segment sits in one block: one set of leaf loads for U draws
-        const EdgeBlock* bk = a.g.blk + blk_lo;
-        const int64_t base = blk_lo * kEdgesPerBlock;
-        const int32_t i_lo = (int32_t)(sg.lo - base), i_hi = (int32_t)(sg.hi - base);
-        const float4 a0 = *reinterpret_cast<const float4*>(bk->pw);
-        const float4 a1 = *reinterpret_cast<const float4*>(bk->pw + 4);
-        const float4 a2 = *reinterpret_cast<const float4*>(bk->pw + 8);
-        const float v[10] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y};
-#pragma unroll
-        for (int x = 0; x < U; ++x) {
-          const double rr = ScaleDraw(u[x], sg.limit_begin, sg.limit_end);
-          if (!((double)sg.limit_end > rr)) {          // Q3: replay the reference
-            const float* nw = a.g.prefix_w + sg.row_ptr;
-            const int32_t m = (int32_t)RandomSelect(nw, (uint64_t)sg.b, (uint64_t)sg.e, u[x]);
-            id[x] = a.g.nbr[sg.row_ptr + m];
-            w[x] = __fsub_rn(nw[m], m == 0 ? 0.f : nw[m - 1]);
-            continue;
-          }
-          int32_t i = i_lo;
-#pragma unroll
-          for (int q = 0; q < kEdgesPerBlock - 1; ++q)
-            i += (q >= i_lo && q < i_hi && !((double)v[q] > rr)) ? 1 : 0;
-          float nw_m = v[0], prev = a2.z;
-#pragma unroll
-          for (int q = 0; q < kEdgesPerBlock; ++q) {
-            if (q == i) nw_m = v[q];
-            if (q + 1 == i) prev = v[q];
-          }
-          if (base + i == sg.row_ptr) prev = 0.f;
-          id[x] = bk->nbr[i];
-          w[x] = __fsub_rn(nw_m, prev);
-        }
-      } else {
-#pragma unroll
-        for (int x = 0; x < U; ++x) BlockPivotSample(a.g, sg, u[x], &id[x], &w[x]);
-      }
-    } else {
-#pragma unroll
-      for (int x = 0; x < U; ++x) {
-        id[x] = TF_LAYOUT ? (uint64_t)a.default_node : 0;
-        w[x] = 0.f;
-      }
-      ot = TF_LAYOUT ? -1 : 0;
-    }
-#pragma unroll
-    for (int x = 0; x < U; ++x) {
-      a.out_id[s + x] = id[x];
-      a.out_w[s + x] = w[x];
-      a.out_t[s + x] = ot;
-    }
-    if (j == 0 && a.out_row_mask != nullptr) a.out_row_mask[r] = valid ? 0 : 1;
-    r += stride_rows;
-    j += stride_slots;
-    if (j >= a.count) { j -= a.count; ++r; }
-  }
-}
 template <int U, int V>
 static void LaunchExpandUV(bool ct, int grid, int block, hipStream_t stream,
                            const ExpandArgs& x, int64_t stride_rows, int32_t stride_slots) {
@@ -816,47 +691,11 @@ static void LaunchExpand(int U, int V, bool ct, int grid, int block, hipStream_t
     else LaunchExpandUV<1, 1>(ct, grid, block, stream, x, stride_rows, stride_slots);
   }
 }
-// Queues of the row kernel (k1_row.h), per (graph, stream), grown on demand: two
-// sets of kSlowShards counters (used alternately, each call clears the other set)
-// + kSlowShards queues of `cap` root indices.
-static int64_t RowQueueCap(int64_t n) {
-  const int64_t tiles = (n + kRowTile - 1) / kRowTile;
-  return ((tiles + kSlowShards - 1) / kSlowShards) * kRowTile;
-}
-
-static int GetRowScratch(const euler_gpu_graph* g, hipStream_t stream, int64_t n, void** out,
-                         int* parity) {
-  std::lock_guard<std::mutex> lk(g->ws_mu);
-  auto& slot = g->row_ws[(void*)stream];
-  const size_t bytes = kSlowCounterWords * 4 + (size_t)RowQueueCap(n) * kSlowShards * 4;
-  if (slot.second < bytes) {
-    if (slot.first != nullptr) {
-      EG_HIP(hipStreamSynchronize(stream));
-      EG_HIP(hipFree(slot.first));
-      slot.first = nullptr; slot.second = 0;
-    }
-    const size_t want = bytes + bytes / 4;
-    hipError_t e = hipMalloc(&slot.first, want);
-    if (e != hipSuccess) {
-      slot.first = nullptr;
-      return Fail(EULER_GPU_ENOMEM, std::string("sample_neighbor queue: ") + hipGetErrorString(e));
-    }
-    slot.second = want;
-    EG_HIP(hipMemsetAsync(slot.first, 0, kSlowCounterWords * 4, stream));
-    g->row_parity[(void*)stream] = 0;
-  }
-  *out = slot.first;
-  int& par = g->row_parity[(void*)stream];
-  *parity = par;
-  par ^= 1;
-  return EULER_GPU_OK;
-}
-
 // A caller that alternates streams between calls keeps several minibatches in
 // flight (bench.py --streams, the reference's 8 query threads): the K1 launches of
-// such a call take 16 waves per CU instead of all 32 and its first hop uses the row
-// kernel (a quarter of the wave slots), which overlaps the latency-bound phases of one
-// minibatch with the bandwidth-bound expansion of the other.  One stream: full grids.
+// such a call take 16 waves per CU instead of all 32, which overlaps the latency-bound
+// phases of one minibatch with the bandwidth-bound expansion of the other.  One stream:
+// full grids.
 thread_local int t_concurrent = -1;      // -1 = not inside a call
 static bool ConcurrentCall(const euler_gpu_graph* g, hipStream_t stream) {
   void* prev = g->last_stream.exchange((void*)stream);
@@ -911,67 +750,6 @@ static int LaunchK1(const euler_gpu_graph* g, hipStream_t stream,
     const int64_t stride_rows = stride / count;
     const int32_t stride_slots = (int32_t)(stride - stride_rows * count);
     const bool tf = layout == EULER_GPU_LAYOUT_TF;
-    // (small launches stay with one lane per sample: a root's `count` draws are one
-    // lane's serial work here - 21 us for 1 024 x 25 against 8 - which only pays
-    // once the lane-per-sample kernel would need several rounds of waves)
-    if (blocked && g_k1_row != 0 && a.dd_role == 0 && a.packed == nullptr && count >= 4 &&
-        count <= kRowMaxCount &&
-        ((n * (int64_t)count >= kRowMinSamples && t_concurrent == 1) || g_k1_row == 2) && ((uintptr_t)out_id % 16 == 0) && ((uintptr_t)out_w % 8 == 0) &&
-        ((uintptr_t)out_t % 8 == 0)) {
-      // one lane per root, one wave per workgroup; the LDS staging area bounds the
-      // waves a CU holds (count 25: 14 KB -> 11), the grid-stride loop does the rest
-      const size_t lds = RowKernelLdsBytes(count);
-      int64_t tiles = (n + kRowTile - 1) / kRowTile;
-      const int64_t cap = g_k1_grid_cap > 0 ? g_k1_grid_cap : 256 * 16;
-      if (tiles > cap) tiles = cap;
-      void* q = nullptr;
-      int parity = 0;
-      const int rc = GetRowScratch(g, stream, n, &q, &parity);
-      if (rc != EULER_GPU_OK) return rc;
-      SampleNbArgs ra = a;
-      ra.ablate = g_k1_ablate;
-      ra.slow_count = (uint32_t*)q + (parity ? kSlowShards : 0);
-      ra.slow_count_next = (uint32_t*)q + (parity ? 0 : kSlowShards);
-      ra.slow_list = (uint32_t*)q + kSlowCounterWords;
-      ra.slow_cap = RowQueueCap(n);
-      // the queued (long-row) roots, one lane per sample; the grid loops over the
-      // device-side queue length
-      int64_t sblocks = (n * (int64_t)count + 255) / 256;
-      if (sblocks > 256 * 8) sblocks = 256 * 8;
-      if (tf) {
-        hipLaunchKernelGGL((SampleNeighborRowKernel<true>), dim3((unsigned)tiles), dim3(64), lds,
-                           stream, ra);
-        hipLaunchKernelGGL((SampleNeighborSlowKernel<true>), dim3((unsigned)sblocks), dim3(256), 0,
-                           stream, ra);
-      } else {
-        hipLaunchKernelGGL((SampleNeighborRowKernel<false>), dim3((unsigned)tiles), dim3(64), lds,
-                           stream, ra);
-        hipLaunchKernelGGL((SampleNeighborSlowKernel<false>), dim3((unsigned)sblocks), dim3(256), 0,
-                           stream, ra);
-      }
-      EG_HIP(hipGetLastError());
-      return EULER_GPU_OK;
-    }
-    if (blocked && !pair && g_k1_group != 0 && count % 5 == 0 && a.dd_role != 2 &&
-        a.mark_owner == nullptr && a.packed == nullptr) {
-      // odd multiple of 5 (fanout 25): five adjacent samples per lane
-      int64_t blocks = (n * (int64_t)count / 5 + block - 1) / block;
-      const int64_t cap = K1GridCap();
-      if (blocks > cap) blocks = cap;
-      const int gridg = (int)(blocks < 1 ? 1 : blocks);
-      const int64_t gstride = (int64_t)gridg * block * 5;
-      const int64_t g_rows = gstride / count;
-      const int32_t g_slots = (int32_t)(gstride - g_rows * count);
-      if (tf) {
-        hipLaunchKernelGGL((SampleNeighborGroupKernel<true, 5>), dim3(gridg), dim3(block),
-                           0, stream, a, g_rows, g_slots);
-      } else {
-        hipLaunchKernelGGL((SampleNeighborGroupKernel<false, 5>), dim3(gridg), dim3(block),
-                           0, stream, a, g_rows, g_slots);
-      }
-      EG_HIP(hipGetLastError());
-      return EULER_GPU_OK;
-    }
     auto kern = blocked
         ? (pair ? (tf ? SampleNeighborPivotKernel<true, 2, true>
                       : SampleNeighborPivotKernel<false, 2, true>)
@@ -1056,8 +834,6 @@ static bool LaunchK1Dual(const euler_gpu_graph* g, hipStream_t stream,
   const bool pair = g_k1_pair != 0 && count % 2 == 0 &&
                     ((uintptr_t)a.out_id % 16 == 0) && ((uintptr_t)a.out_w % 8 == 0) &&
                     ((uintptr_t)a.out_t % 8 == 0);
-  if (blocked && !pair && g_k1_group != 0 && count % 5 == 0 && a.mark_owner == nullptr)
-    return false;                              // pass 1 would take the group kernel
   const int block = 256;
   const int U = pair ? 2 : 1;
   int64_t blocks = (a.n * (int64_t)count / U + block - 1) / block;
@@ -1067,25 +843,12 @@ static bool LaunchK1Dual(const euler_gpu_graph* g, hipStream_t stream,
   const int64_t a_stride = (int64_t)grid * block * U;
   const int64_t a_rows = a_stride / count;
   const int32_t a_slots = (int32_t)(a_stride - a_rows * count);
-  // the pass over the distinct roots: one sample per lane, or (key 22) the two
-  // adjacent samples of a root per lane - one Philox block, root id, row record
-  // and id store per pair; the K1 kernels are bound by instruction issue as much
-  // as by memory (tools/prof_tlb.py: the same roots in row order run no faster)
-  const bool pair2 = pair && g_k1_pair_distinct != 0;
-  const int64_t b_stride = (int64_t)grid * block * (pair2 ? 2 : 1);
+  // the pass over the distinct roots: one sample per lane (the shorter dependent chain
+  // wins on cold rows: 0.139 vs 0.149 ms with two per lane on the metric workload)
+  const int64_t b_stride = (int64_t)grid * block;
   const int64_t b_rows = b_stride / count;
   const int32_t b_slots = (int32_t)(b_stride - b_rows * count);
   const bool tf = a.layout == EULER_GPU_LAYOUT_TF;
-  if (pair2 && blocked) {
-    if (tf) {
-      hipLaunchKernelGGL((SampleNeighborPivotDualKernel<true, 2, true, 2>), dim3(grid), dim3(block),
-                         0, stream, a, a_rows, a_slots, b, b_rows, b_slots);
-    } else {
-      hipLaunchKernelGGL((SampleNeighborPivotDualKernel<false, 2, true, 2>), dim3(grid), dim3(block),
-                         0, stream, a, a_rows, a_slots, b, b_rows, b_slots);
-    }
-    return true;
-  }
 #define EG_DUAL(TF, UU, BL)                                                            \
   hipLaunchKernelGGL((SampleNeighborPivotDualKernel<TF, UU, BL>), dim3(grid), dim3(block), \
                      0, stream, a, a_rows, a_slots, b, b_rows, b_slots)
@@ -1216,13 +979,12 @@ static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
     return Fail(EULER_GPU_EINVAL, "sample_neighbor: null edge_types");
   if (packed_out != nullptr && (dedup > 0 || !K1WritesPacked(g, k, layout)))
     return Fail(EULER_GPU_EINVAL, "sample_neighbor: packed output needs the pivot kernels");
-  if ((g_k1_variant == 3 || g_k1_variant == 4 || g_k1_variant == 6) &&
-      g->view.blk == nullptr) {
-    const int rc = EnsureBlockedIndex(g);     // A/B variants only: built on first use
+  if (g_k1_variant == 6 && g->view.blk == nullptr) {
+    const int rc = EnsureBlockedIndex(g);     // built on first use
     if (rc != EULER_GPU_OK) return rc;
   }
   SampleNbArgs a{};
-  a.g = SamplingView(g);
+  a.g = g->view;
   a.seed = seed; a.call_id = call_id;
   a.roots = roots; a.root_mask = root_mask;
   a.root_group = root_group > 0 ? root_group : 1;
@@ -1398,7 +1160,7 @@ static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
                   !(layout == EULER_GPU_LAYOUT_TF && g->view.has_zero_nbr != 0);
   x.type0 = k == 1 ? edge_types[0] : 0;
   x.masked_type = layout == EULER_GPU_LAYOUT_TF ? -1 : 0;
-  const bool lean = g_expand_lean != 0 && pair && !do_mark && !resolve_in_expand &&
+  const bool lean = pair && !do_mark && !resolve_in_expand &&
                     count / 2 <= 128 && (int64_t)n * count < ((int64_t)1 << 31);
   if (lean) {
     const uint32_t P = (uint32_t)count / 2;
@@ -1515,7 +1277,7 @@ int LaunchSampleNeighborCounted(const euler_gpu_graph* g, hipStream_t stream, ui
     if (rc != EULER_GPU_OK) return rc;
   }
   SampleNbArgs a{};
-  a.g = SamplingView(g);
+  a.g = g->view;
   a.seed = seed; a.call_id = call_id;
   a.roots = roots; a.root_mask = nullptr; a.root_group = 1;
   a.out_id = out_id; a.out_w = out_w; a.out_t = out_t; a.out_row_mask = nullptr;
@@ -1606,7 +1368,7 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
         if (rc0 != EULER_GPU_OK) return rc0;
       }
       FanoutLocalArgs f{};
-      f.g = SamplingView(g); f.seed = seed; f.call_id = call_id; f.roots = roots_dev; f.n = n;
+      f.g = g->view; f.seed = seed; f.call_id = call_id; f.roots = roots_dev; f.n = n;
       f.default_node = default_node;
       f.c1 = c1; f.c2 = c2;
       f.t1 = edge_types_host[0]; f.t2 = edge_types_host[1];
@@ -1628,7 +1390,7 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
       const size_t lds = (size_t)lay.bytes * wpb;
       const GraphView& v = f.g;
       const bool plain = g_fl_plain != 0 && v.T == 1 && v.total_in_meta != 0 && v.uniform_w == 0 &&
-                         v.inline_k == 0 && v.map_mode == 0 && v.has_zero_nbr == 0 &&
+                         v.map_mode == 0 && v.has_zero_nbr == 0 &&
                          f.t1 == 0 && f.t2 == 0;
       if (plain && g_fl_plain == 2 && f.vec && v.n_edges < ((int64_t)1 << 31)) {
         // the lean build (pairs of samples per lane, f32 compares, duplicates by edge)
@@ -1699,7 +1461,7 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
       if (rc0 != EULER_GPU_OK) return rc0;
     }
     Fanout2Args f{};
-    f.g = SamplingView(g); f.seed = seed; f.call_id = call_id; f.roots = roots_dev; f.n = n;
+    f.g = g->view; f.seed = seed; f.call_id = call_id; f.roots = roots_dev; f.n = n;
     f.default_node = default_node;
     f.c1 = counts_host[0]; f.c2 = counts_host[1];
     f.t1 = edge_types_host[0]; f.t2 = edge_types_host[1];
@@ -1791,7 +1553,7 @@ extern "C" {
 int euler_gpu_set_debug_buffer(void* dev) { g_fl_debug = dev; return EULER_GPU_OK; }
 
 int euler_gpu_set_tuning(int32_t key, int32_t value) {
-  if (key == 0) { g_k1_variant = value; return EULER_GPU_OK; }
+  if (key == 0 && (value == 0 || value == 5 || value == 6)) { g_k1_variant = value; return EULER_GPU_OK; }
   if (key == 2) { g_k1_ablate = value; return EULER_GPU_OK; }
   if (key == 3) { g_k1_grid_cap = value; return EULER_GPU_OK; }
   if (key == 9) { g_k1_fuse_mark = value != 0; return EULER_GPU_OK; }
@@ -1804,21 +1566,16 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 12 && value >= 0) { g_expand_grid_cap = value; return EULER_GPU_OK; }
   if (key == 4) { g_k1_pair = value; return EULER_GPU_OK; }
   if (key == 5) { g_k1_dedup = value; return EULER_GPU_OK; }
-  if (key == 6) { g_k1_group = value; return EULER_GPU_OK; }
   if (key == 7) { g_n2v_wave = value; return EULER_GPU_OK; }
   if (key == 8) { g_feature_vec4 = value; return EULER_GPU_OK; }
   if (key == 15 && value >= 0 && value <= 2) { g_root_host_batch = value; return EULER_GPU_OK; }
   if (key == 16) { g_adj_scan = value != 0; return EULER_GPU_OK; }
   if (key == 17 && value >= 0) { g_adj_long_row = value; return EULER_GPU_OK; }
   if (key == 18) { g_sum_scalar = value != 0; return EULER_GPU_OK; }
-  if (key == 19 && value >= 0 && value <= 2) { g_k1_row = value; return EULER_GPU_OK; }
   if (key == 20) { g_dedup_resolve_in_expand = value != 0; return EULER_GPU_OK; }
-  if (key == 21) { g_expand_lean = value != 0; return EULER_GPU_OK; }
-  if (key == 22) { g_k1_pair_distinct = value != 0; return EULER_GPU_OK; }
   if (key == 23) { g_fanout_fused = value != 0; return EULER_GPU_OK; }
   if (key == 24) { g_full_nb_balanced = value != 0; return EULER_GPU_OK; }
   if (key == 25 && value >= 0) { g_n2v_big = value; return EULER_GPU_OK; }
-  if (key == 26) { g_k1_inline = value != 0; return EULER_GPU_OK; }
   if (key == 27) { g_fanout_local = value != 0; return EULER_GPU_OK; }
   if (key == 28 && value >= 1 && value <= 16) { g_fl_roots = value; return EULER_GPU_OK; }
   if (key == 29 && value >= 0) { g_fl_cap = value; return EULER_GPU_OK; }
@@ -1830,10 +1587,6 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 36) { g_fl_ablate = value; return EULER_GPU_OK; }
   if (key == 37) { g_k1_typed_pivot = value != 0; return EULER_GPU_OK; }
   if (key == 35 && (value == 5 || value == 6 || value == 8)) { g_fl_wps = value; return EULER_GPU_OK; }
-  if (key == 1 && (value == 1 || value == 2 || value == 4 || value == 8)) {
-    g_k1_ilp = value;
-    return EULER_GPU_OK;
-  }
   return Fail(EULER_GPU_EINVAL, "set_tuning: unknown key");
 }
 

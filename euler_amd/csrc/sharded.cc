@@ -82,12 +82,16 @@ int RcclCounts(void* user, const int64_t* send, int64_t* recv) {
   for (int p = 0; p < u->world; ++p) u->pinned[p] = send[p];
   EG_HIP(hipMemcpy(u->dev_counts, u->pinned, sizeof(int64_t) * u->world, hipMemcpyHostToDevice));
   if (r.group_start() != 0) return Fail(EULER_GPU_EHIP, "ncclGroupStart failed");
-  for (int p = 0; p < u->world; ++p) {
-    if (r.send(u->dev_counts + p, 8, 0, p, u->comm, nullptr) != 0 ||
-        r.recv(u->dev_counts + u->world + p, 8, 0, p, u->comm, nullptr) != 0)
-      return Fail(EULER_GPU_EHIP, "ncclSend / ncclRecv (counts) failed");
+  // a group left open defers or hangs every later collective of this rank while the peers
+  // block: remember the first failure, always close the group
+  bool failed = false;
+  for (int p = 0; p < u->world && !failed; ++p) {
+    failed = r.send(u->dev_counts + p, 8, 0, p, u->comm, nullptr) != 0 ||
+             r.recv(u->dev_counts + u->world + p, 8, 0, p, u->comm, nullptr) != 0;
   }
-  if (r.group_end() != 0) return Fail(EULER_GPU_EHIP, "ncclGroupEnd failed");
+  const bool end_failed = r.group_end() != 0;
+  if (failed) return Fail(EULER_GPU_EHIP, "ncclSend / ncclRecv (counts) failed");
+  if (end_failed) return Fail(EULER_GPU_EHIP, "ncclGroupEnd failed");
   EG_HIP(hipMemcpy(u->pinned + u->world, u->dev_counts + u->world, sizeof(int64_t) * u->world,
                    hipMemcpyDeviceToHost));
   for (int p = 0; p < u->world; ++p) recv[p] = u->pinned[u->world + p];
@@ -101,15 +105,18 @@ int RcclAllToAllV(void* user, const void* send_dev, const int64_t* send_rows, vo
   hipStream_t st = (hipStream_t)stream;
   if (r.group_start() != 0) return Fail(EULER_GPU_EHIP, "ncclGroupStart failed");
   int64_t so = 0, ro = 0;
-  for (int p = 0; p < u->world; ++p) {
+  const char* failed = nullptr;          // first failure; the group is closed regardless
+  for (int p = 0; p < u->world && failed == nullptr; ++p) {
     const size_t sb = (size_t)(send_rows[p] * row_bytes), rb = (size_t)(recv_rows[p] * row_bytes);
     if (sb && r.send((const uint8_t*)send_dev + so, sb, 0 /* ncclInt8 */, p, u->comm, st) != 0)
-      return Fail(EULER_GPU_EHIP, "ncclSend failed");
-    if (rb && r.recv((uint8_t*)recv_dev + ro, rb, 0, p, u->comm, st) != 0)
-      return Fail(EULER_GPU_EHIP, "ncclRecv failed");
+      failed = "ncclSend failed";
+    else if (rb && r.recv((uint8_t*)recv_dev + ro, rb, 0, p, u->comm, st) != 0)
+      failed = "ncclRecv failed";
     so += (int64_t)sb; ro += (int64_t)rb;
   }
-  if (r.group_end() != 0) return Fail(EULER_GPU_EHIP, "ncclGroupEnd failed");
+  const bool end_failed = r.group_end() != 0;
+  if (failed != nullptr) return Fail(EULER_GPU_EHIP, failed);
+  if (end_failed) return Fail(EULER_GPU_EHIP, "ncclGroupEnd failed");
   return EULER_GPU_OK;
 }
 
@@ -143,8 +150,13 @@ int euler_gpu_transport_rccl(void* nccl_comm, int32_t rank, int32_t world, euler
   u->comm = nccl_comm; u->rank = rank; u->world = world; u->shm = counts;
   u->pinned = nullptr; u->dev_counts = nullptr;
   if (counts == nullptr && world > 1) {
-    EG_HIP(hipHostMalloc((void**)&u->pinned, sizeof(int64_t) * 2 * world));
-    EG_HIP(hipMalloc((void**)&u->dev_counts, sizeof(int64_t) * 2 * world));
+    hipError_t e = hipHostMalloc((void**)&u->pinned, sizeof(int64_t) * 2 * world);
+    if (e == hipSuccess) e = hipMalloc((void**)&u->dev_counts, sizeof(int64_t) * 2 * world);
+    if (e != hipSuccess) {
+      if (u->pinned) (void)hipHostFree(u->pinned);
+      delete u;
+      return Fail(EULER_GPU_ENOMEM, std::string("transport_rccl: ") + hipGetErrorString(e));
+    }
   }
   out->rank = rank; out->world = world; out->user = u;
   out->alltoall_counts = RcclCounts;

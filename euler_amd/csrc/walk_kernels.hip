@@ -445,7 +445,7 @@ struct WalkArgs {
 // eight lanes per walker: 64 contiguous bytes.
 constexpr int kWalkStage = 8;
 
-template <bool FAST, bool BLOCKED = false>
+template <bool FAST>
 __global__ __launch_bounds__(256, kWavesPerSimd) void RandomWalkKernel(const WalkArgs a) {
   __shared__ int64_t stage[256 * (kWalkStage + 1)];
   const int64_t L = a.walk_len + 1;
@@ -466,8 +466,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void RandomWalkKernel(const Wal
             if (LoadSegment<true>(a.g, FindRow(a.g, cur), a.edge_types[s], &sg)) {
               const Philox4 blk = RngBlock(a.seed, a.call_id + (uint32_t)s, kDomainNeighbor,
                                            cur, 0);
-              if (BLOCKED) BlockedSample(a.g, sg, UnitFromWords(blk.w[0], blk.w[1]), &id, &w);
-              else BlockPivotSample(a.g, sg, UnitFromWords(blk.w[0], blk.w[1]), &id, &w);
+              BlockPivotSample(a.g, sg, UnitFromWords(blk.w[0], blk.w[1]), &id, &w);
             }
           } else {
             RowSampler rs;
@@ -779,7 +778,7 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
                           (size_t)walk_len * k * sizeof(int32_t),
                           hipMemcpyHostToDevice, st));
   WalkArgs a{};
-  a.g = SamplingView(g); a.seed = seed; a.call_id = call_id; a.nodes = nodes_dev;
+  a.g = g->view; a.seed = seed; a.call_id = call_id; a.nodes = nodes_dev;
   a.edge_types = et_dev; a.out = out_dev; a.n = n; a.default_node = default_node;
   a.k = k; a.walk_len = walk_len; a.p = p; a.q = q;
   a.ablate = g_k1_ablate;
@@ -796,11 +795,7 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
   const float kEps = 1.0e-6;
   // random_walk_op.cc:281: fabs(p_ - 1.0) <= kEps && fabs(q_ - 1.0) <= kEps
   if (std::fabs((double)p - 1.0) <= kEps && std::fabs((double)q - 1.0) <= kEps) {
-    if (k == 1 && g->view.monotone && g->view.blk != nullptr && g_k1_variant == 3) {
-      // A/B: the 32-ary skip levels (one line per level) instead of the fanout-5 block pivots
-      hipLaunchKernelGGL((RandomWalkKernel<true, true>), dim3(GridFor(n, block)), dim3(block), 0,
-                         st, a);
-    } else if (k == 1 && g->view.monotone && g->view.blk != nullptr && g_k1_variant >= 5) {
+    if (k == 1 && g->view.monotone && g->view.blk != nullptr && g_k1_variant >= 5) {
       hipLaunchKernelGGL(RandomWalkKernel<true>, dim3(GridFor(n, block)), dim3(block), 0,
                          st, a);
     } else {

@@ -13,6 +13,7 @@ the next hop), exactly where TensorFlow has a dynamic shape.
 import torch
 
 from . import ops
+from ._lib import EINVAL, EulerGpuError
 
 
 class Block(object):
@@ -113,9 +114,16 @@ class SageDataFlow(UniqueDataFlow):
         if not getattr(self, "fused", True) or len(lens) != 1:
             return super(SageDataFlow, self).produce_subgraph(n_id)
         n_id = n_id.reshape(-1)
-        blocks, _cnt = self.graph.sage_blocks(n_id, self.metapath, self.fanouts,
-                                              default_node=self.max_id + 1,
-                                              add_self_loops=self.add_self_loops)
+        try:
+            blocks, _cnt = self.graph.sage_blocks(n_id, self.metapath, self.fanouts,
+                                                  default_node=self.max_id + 1,
+                                                  add_self_loops=self.add_self_loops)
+        except EulerGpuError as e:
+            # the one-enqueue form has preconditions (worst-case layer sizes below 2^31, a
+            # sampler the counted launch supports): EINVAL there means "not this way"
+            if e.code != EINVAL:
+                raise
+            return super(SageDataFlow, self).produce_subgraph(n_id)
         data_flow = DataFlow(n_id)
         for new_n_id, res_n_id, edge_src, edge_dst in blocks:
             data_flow.append(new_n_id, res_n_id, None, torch.stack([edge_src, edge_dst], 0))

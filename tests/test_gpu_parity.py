@@ -15,33 +15,27 @@ pytestmark = pytest.mark.gpu
 SEED = 20240521
 
 
-@pytest.fixture(params=[(6, 4), (6, 3), (5, 4), (6, 2), (6, 1), (4, 4), (3, 4), (2, 4), (2, 2), (2, 8), (1, 4), (0, 4)],
-                ids=["k1row", "k1blockpivot", "k1pivot", "k1dedup", "k1blockpivot1", "k1wave", "k1blocked", "k1ilp4", "k1ilp2", "k1ilp8", "k1fast",
-                     "k1generic"])
+@pytest.fixture(params=["blockpivot", "blockpivot1", "pivot", "dedup", "typedloop", "generic"])
 def k1_variant(request, EA):
-    """Run with every variant of the K1 kernel (blocked sampling index, ILP with
-    2/4/8 samples per lane, the single-sample fast path, the generic reference-loop kernel): all
-    must match the oracle bit for bit."""
+    """The sample_neighbor kernels a call can be served by - block pivots (the default:
+    pairs of samples per lane for even counts, the one-kernel fanout, type draws on the
+    pivots), the same with one sample per lane, pivot levels over the flat arrays, the
+    duplicate-root machinery forced for every batch size, type draws by the reference
+    loop, and the reference loop for everything: all must match the oracle bit for bit."""
     from euler_amd import _lib
-    _lib.lib().euler_gpu_set_tuning(0, request.param[0])
-    _lib.lib().euler_gpu_set_tuning(1, request.param[1] if request.param[1] != 3 else 4)
-    # (6, 4): one lane per ROOT (k1_row.h) wherever it applies, whatever the launch
-    # size (2; the default, 1, keeps launches below 2^20 samples on the
-    # lane-per-sample kernels); every other parameter runs the lane-per-sample kernels
-    _lib.lib().euler_gpu_set_tuning(19, 2 if request.param == (6, 4) else 0)
-    # (6, 1) forces one sample per lane
-    _lib.lib().euler_gpu_set_tuning(4, 0 if request.param == (6, 1) else 1)
-    # ... and (6, 2) also turns on five samples per lane for odd multiples of 5
-    _lib.lib().euler_gpu_set_tuning(6, 1 if request.param == (6, 2) else 0)
-    # (6, 2): always run the duplicate-root machinery, whatever the batch size
-    _lib.lib().euler_gpu_set_tuning(5, 2 if request.param == (6, 2) else 1)
-    yield request.param
-    _lib.lib().euler_gpu_set_tuning(19, 1)
-    _lib.lib().euler_gpu_set_tuning(4, 1)
-    _lib.lib().euler_gpu_set_tuning(5, 1)
-    _lib.lib().euler_gpu_set_tuning(6, 0)
-    _lib.lib().euler_gpu_set_tuning(0, 6)
-    _lib.lib().euler_gpu_set_tuning(1, 4)
+    L = _lib.lib()
+    v = request.param
+    L.euler_gpu_set_tuning(0, 0 if v == "generic" else 5 if v == "pivot" else 6)
+    L.euler_gpu_set_tuning(4, 0 if v == "blockpivot1" else 1)     # pairs per lane
+    L.euler_gpu_set_tuning(5, 2 if v == "dedup" else 1)           # duplicate path always
+    L.euler_gpu_set_tuning(27, 0 if v in ("dedup", "blockpivot1") else 1)   # one-kernel fanout
+    L.euler_gpu_set_tuning(37, 0 if v == "typedloop" else 1)
+    yield v
+    L.euler_gpu_set_tuning(0, 6)
+    L.euler_gpu_set_tuning(4, 1)
+    L.euler_gpu_set_tuning(5, 1)
+    L.euler_gpu_set_tuning(27, 1)
+    L.euler_gpu_set_tuning(37, 1)
 
 
 def gpu_graph(EA, csr, order=None, **kw):
@@ -1354,69 +1348,6 @@ def test_uniform_weight_fast_path(EA, O, torch_cuda, k1_variant):
         assert np.array_equal(t2n(gw), ow) and np.array_equal(t2n(gt), ot)
     walk = G.random_walk(qt[:500], [[0]] * 8, 1.0, 1.0, -1, call_id=40)
     assert np.array_equal(t2n(walk), OG.random_walk(3, 40, q[:500], [[0]] * 8, 8, 1.0, 1.0, -1))
-
-
-@pytest.mark.parametrize("weights", ["random", "uniform", "zeros"])
-@pytest.mark.parametrize("ids_kind", ["hash_ids", "identity_ids"])
-def test_short_rows_sampled_from_their_inline_line(EA, O, torch_cuda, k1_variant, weights, ids_kind):
-    """Single-type graphs keep a 128-byte line per row: the row record, then the running
-    sums and ids of its first 9 edges (common.h: row_inline).  Rows of <= 9 edges are
-    sampled from that line (tuning key 26 = 1; an A/B layout, off by default), longer rows
-    read their record from it and search as before.  Degrees 0 .. 13 straddle the boundary; results with
-    key 26 = 1, key 26 = 0 and the oracle agree bit for bit - sample_neighbor (odd, even,
-    large counts; duplicate roots; the lane-per-root kernel, key 19 = 2), the 2-hop
-    fanout (one launch and per hop) and random_walk (p = q = 1), on hash and identity
-    id maps, with uniform weights (no search) and zero weights (Q3 replays)."""
-    torch = torch_cuda
-    from euler_amd import _lib
-    L = _lib.lib()
-    rng = np.random.default_rng(97)
-    n = 6000
-    ids = (np.arange(1, n + 1) if ids_kind == "identity_ids"
-           else rng.choice(10 ** 12, n, replace=False) + 1).astype(np.uint64)
-    deg = rng.integers(0, 14, size=n)
-    deg[:40] = rng.integers(25, 400, size=40)          # some long rows among them
-    seg = np.zeros(n + 1, np.int64)
-    seg[1:] = np.cumsum(deg)
-    E = int(seg[-1])
-    nbr = rng.choice(ids, E).astype(np.uint64)
-    if weights == "uniform":
-        w = np.ones(E, np.float32)
-    else:
-        w = (rng.random(E) * 4 + 0.05).astype(np.float32)
-        if weights == "zeros":
-            w[rng.random(E) < 0.3] = 0
-    csr = O.csr_from_raw(ids, seg, nbr, w, 1)
-    L.euler_gpu_set_tuning(26, 1)          # the lines are built for graphs created while the key is 1
-    G, OG = gpu_graph(EA, csr), O.OracleGraph(csr)
-    q = np.concatenate([rng.choice(ids, 3000), ids[:40], [0, 5, 2 ** 61]]).astype(np.int64)
-    qt = torch.as_tensor(q).cuda()
-    G.set_seed(23)
-    try:
-        for inline in (1, 0):
-            L.euler_gpu_set_tuning(26, inline)
-            for call, count in enumerate((25, 10, 1, 64)):
-                on, ow, ot = OG.sample_neighbor(23, call, q, [0], count, -1)
-                for row_kernel in (1, 2):
-                    L.euler_gpu_set_tuning(19, row_kernel)
-                    gn, gw, gt = G.sample_neighbor(qt, [0], count, -1, call_id=call)
-                    assert np.array_equal(t2n(gn), on), (inline, count, row_kernel)
-                    assert np.array_equal(t2n(gw), ow) and np.array_equal(t2n(gt), ot)
-                L.euler_gpu_set_tuning(19, 1)
-            on, ow, ot = OG.sample_fanout(23, 30, q[:900], [[0], [0]], [5, 4], -1)
-            for fused in (1, 0):
-                L.euler_gpu_set_tuning(23, fused)
-                gn, gw, gt = G.sample_fanout(qt[:900], [[0], [0]], [5, 4], -1, call_id=30)
-                for h in range(2):
-                    assert np.array_equal(t2n(gn[h + 1]), on[h]), (inline, fused, h)
-                    assert np.array_equal(t2n(gw[h]), ow[h]) and np.array_equal(t2n(gt[h]), ot[h])
-            L.euler_gpu_set_tuning(23, 1)
-            walk = G.random_walk(qt[:800], [[0]] * 6, 1.0, 1.0, -1, call_id=50)
-            assert np.array_equal(t2n(walk), OG.random_walk(23, 50, q[:800], [[0]] * 6, 6, 1.0, 1.0, -1))
-    finally:
-        L.euler_gpu_set_tuning(26, 0)
-        L.euler_gpu_set_tuning(19, 1)
-        L.euler_gpu_set_tuning(23, 1)
 
 
 def test_small_fanout_in_one_launch(EA, O, torch_cuda, big_pair):

@@ -16,7 +16,7 @@ gen = torch.Generator(device='cuda'); gen.manual_seed(1234)
 roots = torch.randint(1, N + 1, (B,), generator=gen, device='cuda')
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 et1 = (C.c_int32 * 1)(0)
-L.euler_gpu_set_tuning(19, 0)
+pass
 
 
 def k1_us(r, cnt, iters=20):
