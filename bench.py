@@ -79,6 +79,9 @@ def parse():
     ap.add_argument("--unfused-aggregation", action="store_true",
                     help="hetero workload: gather, then scatter_mean (two passes over the E x D block)")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the short products / hetero / deepwalk (+ node2vec) legs the default "
+                         "single-GPU metric run appends under config.secondary")
     ap.add_argument("--no-small-batch", action="store_true",
                     help="skip the B = 1 024 latency leg (profiling runs: its 1 000 small "
                          "launches would share kernel names with the step's)")
@@ -306,7 +309,26 @@ def _events(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
-def run_hetero(args):
+def _oracle_rows(G, p, need, n_types, spot=64):
+    """OracleGraph over the rows of the ids `need`, exported from HBM; `spot` of them are
+    first compared with the HOST generator (oracle/eo_synth.c), so that a device generator
+    fault cannot hide behind "oracle fed with exported rows"."""
+    from oracle import oracle as O
+    need = np.unique(np.asarray(need, dtype=np.uint64))
+    rp, te, nb, pw, tp = G.export_rows(need)
+    po = O.SynthParams()
+    for f_, _t in po._fields_:
+        setattr(po, f_, getattr(p, f_))
+    T = n_types
+    for j_ in np.random.default_rng(1).choice(len(need), min(spot, len(need)), replace=False):
+        h_ = O.synth_csr(po, int(need[j_]) - 1, int(need[j_]))
+        b_, e_ = int(rp[j_]), int(rp[j_ + 1])
+        assert np.array_equal(h_.nbr, nb[b_:e_]) and np.array_equal(h_.prefix_w, pw[b_:e_]), \
+            "device generator differs from the host generator at node %d" % int(need[j_])
+    return O.OracleGraph(O.CSR(need, rp, te, nb, pw, tp, T))
+
+
+def run_hetero(args, quiet=False):
     """configs[4] on one GPU: heterogeneous graph (8 edge types), per-type neighbour
     sampling with one listed type, 3 of 8 (sub-collection draw) and all 8 (type draw
     over all groups), each followed by the 128-d feature gather of the sampled block
@@ -316,8 +338,8 @@ def run_hetero(args):
     N, T, D, CNT = 20_000_000, 8, 128, 10
     B = args.batch
     t0 = time.time()
-    G = euler_amd.Graph.synthetic(euler_amd.synth_params(GRAPH_SEED, N, 20 * N, n_types=T,
-                                                         weighted=True))
+    p_h = euler_amd.synth_params(GRAPH_SEED, N, 20 * N, n_types=T, weighted=True)
+    G = euler_amd.Graph.synthetic(p_h)
     G.set_seed(GRAPH_SEED)
     feat = torch.randn(N + 2, D, device="cuda", generator=torch.Generator("cuda").manual_seed(7))
     torch.cuda.synchronize()
@@ -386,6 +408,25 @@ def run_hetero(args):
     f_ms = _events(lambda: ops.gather_segment_reduce("mean", feat, nb, B, count=CNT), 10)
     assert torch.equal(ops.gather_segment_reduce("mean", feat, nb, B, count=CNT), ops.scatter_mean(x, dst, B))
     assert torch.equal(ops.gather_scatter("mean", feat, nb, dst, B), ops.scatter_mean(x, dst, B))
+    # parity at bench scale: 64 roots of the last step, every type set, against the oracle
+    # fed with the rows exported from HBM; their aggregated features against an fp64 mean
+    sel = np.random.default_rng(0).choice(B, 64, replace=False)
+    r_sel = r.cpu().numpy()[sel]
+    need_ids = r_sel[(r_sel >= 1) & (r_sel <= N)]
+    OGh = _oracle_rows(G, p_h, need_ids, T)
+    checked = 0
+    for c, et in enumerate(type_sets):
+        nb_b, w_b, t_b = G.sample_neighbor(r, et, CNT, N + 1, call_id=900 + c)
+        on, ow, ot = OGh.sample_neighbor(GRAPH_SEED, 900 + c, r_sel, et, CNT, N + 1)
+        got = nb_b.reshape(B, CNT).cpu().numpy()[sel]
+        assert np.array_equal(got, on.reshape(-1, CNT)), "hetero: sampled ids differ from the oracle"
+        assert np.array_equal(w_b.reshape(B, CNT).cpu().numpy()[sel], ow.reshape(-1, CNT))
+        assert np.array_equal(t_b.reshape(B, CNT).cpu().numpy()[sel], ot.reshape(-1, CNT))
+        agg = ops.gather_segment_reduce("mean", feat, nb_b.reshape(-1).to(torch.int32), B, count=CNT)
+        ref = feat[torch.as_tensor(got.reshape(-1)).cuda()].double().reshape(64, CNT, D).mean(1)
+        a_sel = agg[torch.as_tensor(sel).cuda()].double()
+        assert torch.all((a_sel - ref).abs() <= 1e-5 * (1.0 + ref.abs())), "hetero: aggregation off"
+        checked += int(got.size)
     E = B * CNT
     g_bytes = 8.0 * E * D + 4.0 * E
     s_bytes = 4.0 * E * D + 4.0 * E + 4.0 * B * D
@@ -437,6 +478,7 @@ def run_hetero(args):
                    "graph_build_s": round(build_s, 2), "repeats": len(reps),
                    "repeat_ms_per_step": [round(x_ / args.steps * 1e3, 4) for x_ in reps],
                    "streams": n_streams,
+                   "parity_checked_edges": checked,
                    "one_stream_ms_per_step": None if one_stream is None else round(one_stream, 4),
                    "aggregation": ("ops.gather_segment_reduce (one pass, %d rows per root)" % CNT if fused
                                    else "ops.gather + ops.scatter_mean"),
@@ -446,10 +488,14 @@ def run_hetero(args):
         "roofline": roof,
         "cpu_baseline": None,
     }
-    print(json.dumps(line), flush=True)
+    if not quiet:
+        print(json.dumps(line), flush=True)
+    del G, feat
+    torch.cuda.empty_cache()
+    return line
 
 
-def run_deepwalk(args):
+def run_deepwalk(args, G=None, p_g=None, quiet=False):
     """configs[3] on one GPU: DeepWalk, random_walk length 40 (p = q = 1) from 1M
     start nodes of the metric graph; value = walker steps / s.  --n2v also times
     node2vec (p = 0.25, q = 4) on 100 000 walkers x 10 steps."""
@@ -458,7 +504,9 @@ def run_deepwalk(args):
     L = _lib.lib()
     N = args.nodes
     t0 = time.time()
-    G = euler_amd.Graph.synthetic(euler_amd.synth_params(GRAPH_SEED, N, args.edges, weighted=True))
+    if G is None:
+        p_g = euler_amd.synth_params(GRAPH_SEED, N, args.edges, weighted=True)
+        G = euler_amd.Graph.synthetic(p_g)
     G.set_seed(GRAPH_SEED)
     torch.cuda.synchronize()
     build_s = time.time() - t0
@@ -490,6 +538,16 @@ def run_deepwalk(args):
 
     ms = _events(lambda: G.random_walk(starts[n_steps - 1], et, 1.0, 1.0, N + 1, call_id=7), 5)
     wb = walk_bytes(walks, W, LEN, 1.0, 1.0)
+    # parity at bench scale: 64 walkers of the last step against the oracle fed with the rows
+    # (exported from HBM) of every node they visit
+    last = n_steps - 1
+    sel = np.random.default_rng(0).choice(W, 64, replace=False)
+    w_sel = walks.cpu().numpy()[sel]
+    need_ids = w_sel[(w_sel >= 1) & (w_sel <= N)]
+    OGw = _oracle_rows(G, p_g, need_ids, 1)
+    ow_ = OGw.random_walk(GRAPH_SEED, LEN * last, starts[last].cpu().numpy()[sel], et, LEN, 1.0, 1.0, N + 1)
+    assert np.array_equal(ow_, w_sel), "deepwalk: walks differ from the oracle"
+    checked = int(w_sel.shape[0] * LEN)
     n2v = None
     if args.n2v:
         W2, L2 = 100_000, 10
@@ -498,10 +556,17 @@ def run_deepwalk(args):
         w2 = G.random_walk(s2, et2, 0.25, 4.0, N + 1, call_id=3)
         ms2 = _events(lambda: G.random_walk(s2, et2, 0.25, 4.0, N + 1, call_id=3), 2)
         b2 = walk_bytes(w2, W2, L2, 0.25, 4.0)
+        # the biased draw is keyed by the walker's INDEX: the first 16 walkers, as walkers 0..15
+        w2_sel = w2.cpu().numpy()[:16]
+        need2 = w2_sel[(w2_sel >= 1) & (w2_sel <= N)]
+        OG2 = _oracle_rows(G, p_g, need2, 1)
+        o2 = OG2.random_walk(GRAPH_SEED, 3, s2.cpu().numpy()[:16], et2, L2, 0.25, 4.0, N + 1)
+        assert np.array_equal(o2, w2_sel), "node2vec: walks differ from the oracle"
         n2v = {"walkers": W2, "walk_len": L2, "p": 0.25, "q": 4.0, "ms": round(ms2, 3),
                "steps_per_s": W2 * L2 / (ms2 * 1e-3), "algorithmic_bytes": b2,
                "GBps": round(b2 / (ms2 * 1e-3) / 1e9, 1),
-               "frac": round(b2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+               "frac": round(b2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+               "parity_checked_steps": int(16 * L2)}
     line = {
         "metric": "walker steps/sec, DeepWalk random_walk length 40 (p = q = 1) on the 100M-node "
                   "power-law graph (BASELINE configs[3], 1 GPU)",
@@ -513,6 +578,7 @@ def run_deepwalk(args):
                                "%d edges, weighted" % (W, LEN, N, G.num_edges),
                    "graph_build_s": round(build_s, 2), "repeats": len(reps),
                    "repeat_ms_per_step": [round(x_ / args.steps * 1e3, 4) for x_ in reps],
+                   "parity_checked_steps": checked,
                    "node2vec": n2v},
         "roofline": {"kernel": "RandomWalkKernel", "bound": "hbm",
                      "achieved": round(wb / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
@@ -520,7 +586,108 @@ def run_deepwalk(args):
                      "traffic": None, "algorithmic_bytes_per_launch": wb, "avg_launch_ms": round(ms, 4)},
         "cpu_baseline": None,
     }
-    print(json.dumps(line), flush=True)
+    if not quiet:
+        print(json.dumps(line), flush=True)
+    return line
+
+
+def run_products_leg(args):
+    """configs[1] as a short leg of the default run: the products-shaped uniform graph, the
+    2-hop fanout on two alternating streams, 64 roots checked against the oracle."""
+    import copy
+    import euler_amd
+    N, E = 2_449_029, 123_718_280
+    p = euler_amd.synth_params(GRAPH_SEED, N, E, weighted=False)
+    G = euler_amd.Graph.synthetic(p)
+    G.set_seed(GRAPH_SEED)
+    B = args.batch
+    steps, warm = 10, 3
+    gen = torch.Generator(device="cuda"); gen.manual_seed(4321)
+    roots = torch.randint(1, N + 1, (steps + warm, B), generator=gen, device="cuda", dtype=torch.int64)
+    et = [[0], [0]]
+    side = [torch.cuda.Stream(), torch.cuda.Stream()]
+
+    def loop(first, last):
+        res = None
+        for i in range(first, last):
+            with torch.cuda.stream(side[i % 2]):
+                res = G.sample_fanout(roots[i], et, FANOUT, N + 1, call_id=2 * i)
+        return res
+    torch.cuda.synchronize()
+    loop(0, warm + 1)
+    torch.cuda.synchronize()
+    reps = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = loop(warm, warm + steps)
+        torch.cuda.synchronize()
+        reps.append(time.perf_counter() - t0)
+    elapsed = float(np.median(reps))
+    last = warm + steps - 1
+    sel = np.random.default_rng(0).choice(B, 64, replace=False)
+    r0 = roots[last].cpu().numpy()[sel]
+    hop1 = out[0][1].reshape(B, FANOUT[0]).cpu().numpy()[sel]
+    hop2 = out[0][2].reshape(B, FANOUT[0], FANOUT[1]).cpu().numpy()[sel]
+    need = np.concatenate([r0, hop1.reshape(-1)])
+    OG = _oracle_rows(G, p, need[(need >= 1) & (need <= N)], 1)
+    on, _, _ = OG.sample_fanout(GRAPH_SEED, 2 * last, r0, et, FANOUT, N + 1)
+    assert np.array_equal(on[0], hop1.reshape(-1)) and np.array_equal(on[1], hop2.reshape(-1)), \
+        "products: sampled ids differ from the oracle"
+    ms_alone = _events(lambda: G.sample_fanout(roots[last], et, FANOUT, N + 1, call_id=5), 10)
+    edges = B * (FANOUT[0] + FANOUT[0] * FANOUT[1])
+    # uniform weights: no search, no sums read - per sampled edge 16 (out) + 8 (id), per root
+    # the record; the expansion's 16 per output edge is the out above
+    algo = 36.0 * B + 24.0 * edges + 36.0 * B * FANOUT[0]
+    res = {"value": edges * steps / elapsed, "unit": "sampled edges/s",
+           "ms_per_step": elapsed / steps * 1e3, "one_stream_ms_per_step": round(ms_alone, 4),
+           "roofline_frac": round(algo / (ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "parity_checked": int(64 * 275),
+           "workload": "ogbn-products-shaped uniform graph (%d nodes / %d edges), fanout [25,10], %d roots "
+                       "per step, two streams" % (N, G.num_edges, B)}
+    del G
+    torch.cuda.empty_cache()
+    return res
+
+
+def secondary_legs(args, G, p_g):
+    """BASELINE configs[1], [3], [4] as short legs of the default run (rank 0, one GPU), each
+    with a spot check against the oracle at bench scale: {value, ms_per_step, roofline_frac,
+    parity_checked}."""
+    import copy
+    sec = {}
+    t0 = time.time()
+    try:
+        a = copy.copy(args)
+        a.steps, a.warmup, a.repeats, a.n2v = 3, 1, 3, True
+        d = run_deepwalk(a, G, p_g, quiet=True)
+        sec["deepwalk"] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+                           "roofline_frac": d["roofline"]["frac"],
+                           "parity_checked": d["config"]["parity_checked_steps"],
+                           "workload": d["config"]["workload"]}
+        n2 = d["config"]["node2vec"]
+        sec["node2vec"] = {"value": n2["steps_per_s"], "unit": "walker steps/s", "ms_per_step": n2["ms"],
+                           "roofline_frac": n2["frac"], "parity_checked": n2["parity_checked_steps"],
+                           "workload": "p = 0.25, q = 4: %d walkers x %d steps on the metric graph"
+                                       % (n2["walkers"], n2["walk_len"])}
+    except Exception as e:          # a side measurement must not fail the bench
+        sec["deepwalk"] = {"error": repr(e)}
+    try:
+        sec["products"] = run_products_leg(args)
+    except Exception as e:
+        sec["products"] = {"error": repr(e)}
+    try:
+        a = copy.copy(args)
+        a.steps, a.warmup, a.repeats = 10, 3, 3
+        h = run_hetero(a, quiet=True)
+        sec["hetero"] = {"value": h["value"], "unit": h["unit"], "ms_per_step": h["ms_per_step"],
+                         "roofline_frac": h["roofline"]["frac"],
+                         "parity_checked": h["config"]["parity_checked_edges"],
+                         "workload": h["config"]["workload"]}
+    except Exception as e:
+        sec["hetero"] = {"error": repr(e)}
+    sec["seconds"] = round(time.time() - t0, 1)
+    return sec
 
 
 def launch_ranks(args):
@@ -976,6 +1143,9 @@ def main():
             small = latency_small_batch(G, L, _lib, args.nodes, default_node)
         except Exception as e:              # a side measurement must not fail the bench
             small = {"error": str(e)}
+    secondary = None
+    if rank == 0 and world == 1 and not sharded and args.workload == "metric" and not args.no_secondary:
+        secondary = secondary_legs(args, G, p)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
@@ -1013,6 +1183,7 @@ def main():
                                 "in flight" % (world, args.pipeline),
                 "parity_checked_edges": checked,
                 "small_batch": small,
+                "secondary": secondary,
                 "latency_B1024_us": (small or {}).get("latency_B1024_us"),
                 "streams": 1 if sharded else max(1, args.streams),
                 "tuning": args.tuning or None,
