@@ -1389,10 +1389,10 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
       if (wave_cap > 0 && blocks > (wave_cap + wpb - 1) / wpb) blocks = (wave_cap + wpb - 1) / wpb;
       const size_t lds = (size_t)lay.bytes * wpb;
       const GraphView& v = f.g;
-      const bool plain = g_fl_plain != 0 && v.T == 1 && v.total_in_meta != 0 && v.uniform_w == 0 &&
-                         v.map_mode == 0 && v.has_zero_nbr == 0 &&
-                         f.t1 == 0 && f.t2 == 0;
-      if (plain && g_fl_plain == 2 && f.vec && v.n_edges < ((int64_t)1 << 31)) {
+      const bool plain_u = g_fl_plain != 0 && v.T == 1 && v.total_in_meta != 0 &&
+                           v.map_mode == 0 && v.has_zero_nbr == 0 && f.t1 == 0 && f.t2 == 0;
+      const bool plain = plain_u && v.uniform_w == 0;
+      if (plain_u && g_fl_plain == 2 && f.vec && v.n_edges < ((int64_t)1 << 31)) {
         // the lean build (pairs of samples per lane, f32 compares, duplicates by edge)
         int32_t lcap = cap;
         FanoutLeanLds ll = FanoutLeanLayout(gr, c1, c2, lcap);
@@ -1406,13 +1406,17 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
           const size_t llds = (size_t)ll.bytes * wpb;
           f.dbg = (unsigned long long*)g_fl_debug;
           f.ablate = g_fl_ablate;
-          void (*lk)(const FanoutLocalArgs) =
-              f.wide ? (g_fl_wps == 8 ? SampleFanoutLeanKernel<true, 8>
-                                      : g_fl_wps == 5 ? SampleFanoutLeanKernel<true, 5>
-                                                      : SampleFanoutLeanKernel<true, 6>)
-                     : (g_fl_wps == 8 ? SampleFanoutLeanKernel<false, 8>
-                                      : g_fl_wps == 5 ? SampleFanoutLeanKernel<false, 5>
-                                                      : SampleFanoutLeanKernel<false, 6>);
+          void (*lk)(const FanoutLocalArgs) = nullptr;
+          if (v.uniform_w != 0) {
+            lk = f.wide ? SampleFanoutLeanKernel<true, 8, true> : SampleFanoutLeanKernel<false, 8, true>;
+          } else {
+            lk = f.wide ? (g_fl_wps == 8 ? SampleFanoutLeanKernel<true, 8>
+                                         : g_fl_wps == 5 ? SampleFanoutLeanKernel<true, 5>
+                                                         : SampleFanoutLeanKernel<true, 6>)
+                        : (g_fl_wps == 8 ? SampleFanoutLeanKernel<false, 8>
+                                         : g_fl_wps == 5 ? SampleFanoutLeanKernel<false, 5>
+                                                         : SampleFanoutLeanKernel<false, 6>);
+          }
           hipLaunchKernelGGL(lk, dim3((unsigned)blocks), dim3(block), llds, stream, f);
           EG_HIP(hipGetLastError());
           if (uniq_off != nullptr) { uniq_off[0] = -1; uniq_off[1] = -1; }
