@@ -551,7 +551,8 @@ thread_local int g_fanout_fused = 1;       // key 23: small 2-hop single-type fa
 thread_local int g_full_nb_balanced = 1;   // key 24: get_full_neighbor fill: a lane owns 4 output entries
 thread_local int g_n2v_big = 8192;   // key 25: child lists of this many entries go to the workgroup kernel (0 = none)
 // 2-hop single-type fanouts as ONE kernel with the duplicate children found inside the wave
-// (fanout_local.h).  key 27: 0 = off (hop by hop, global duplicate path), 1 = on.
+// (fanout_local.h).  key 27: 0 = off (hop by hop, global duplicate path), 1 = on for weighted
+// graphs, 2 = on for every graph.
 thread_local int g_fanout_local = 1;
 thread_local int g_fl_roots = 4;      // key 28: roots per wave (1 .. 16)
 thread_local int g_fl_cap = 0;        // key 29: hop-2 slots per pass, 0 = 8 x roots per wave
@@ -1345,7 +1346,11 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
     ~FanoutConcurrency() { if (own) t_concurrent = -1; }
   } fanout_concurrency(g, stream);
   // a 2-hop fanout of single listed types: ONE kernel, duplicates found inside the wave
-  if (g_fanout_local != 0 && events == nullptr && layers == 2 && k == 1 && n >= g_fl_min_roots &&
+  // (a graph of all-1.0 weights keeps the hop-by-hop path unless key 27 = 2: its draws cost
+  // one id load, and the global duplicate detection finds more to share on the small dense
+  // graphs of that kind - products-shaped: 135 vs 131 G edges/s)
+  if (g_fanout_local != 0 && (g->view.uniform_w == 0 || g_fanout_local == 2) && events == nullptr &&
+      layers == 2 && k == 1 && n >= g_fl_min_roots &&
       g_k1_variant == 6 && g->view.monotone && counts_host[0] > 0 && counts_host[1] > 0) {
     const int32_t c1 = counts_host[0], c2 = counts_host[1];
     int32_t gr = g_fl_roots < 1 ? 1 : g_fl_roots > 16 ? 16 : g_fl_roots;
@@ -1580,7 +1585,7 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 23) { g_fanout_fused = value != 0; return EULER_GPU_OK; }
   if (key == 24) { g_full_nb_balanced = value != 0; return EULER_GPU_OK; }
   if (key == 25 && value >= 0) { g_n2v_big = value; return EULER_GPU_OK; }
-  if (key == 27) { g_fanout_local = value != 0; return EULER_GPU_OK; }
+  if (key == 27 && value >= 0 && value <= 2) { g_fanout_local = value; return EULER_GPU_OK; }
   if (key == 28 && value >= 1 && value <= 16) { g_fl_roots = value; return EULER_GPU_OK; }
   if (key == 29 && value >= 0) { g_fl_cap = value; return EULER_GPU_OK; }
   if (key == 30 && (value == 64 || value == 128 || value == 256)) { g_fl_block = value; return EULER_GPU_OK; }

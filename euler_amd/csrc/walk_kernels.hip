@@ -492,6 +492,69 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void RandomWalkKernel(const Wal
 
 #include "n2v_kernels.h"      // NbIter ... N2vBigStepKernel
 
+// node2vec step over explicit lists (euler_gpu_node2vec_step): one lane per walker, the
+// reference's own two passes - BuildWeights while summing, then the first running sum > r
+// (Node2VecKernel above says why that is RandomSelect's index; same sequential f32 adds).
+struct N2vListArgs {
+  uint64_t seed;
+  uint32_t call_id;
+  int64_t n;
+  const int32_t* c_row; const int32_t* c_idx; const uint64_t* c_ids; const float* c_w;
+  const int32_t* p_row; const int32_t* p_idx; const uint64_t* p_ids;
+  const int64_t* parent_ids;
+  float p, q;
+  int64_t default_node;
+  int64_t* out;
+};
+
+// BuildWeights (random_walk_op.cc:140-168), one child at a time: the weight of child j
+// given where the parent cursor stands (advanced as the reference advances it)
+__device__ __forceinline__ float N2vListTake(const N2vListArgs& a, int32_t j, const float w,
+                                             const int64_t cid, int32_t* pk, const int32_t pe,
+                                             const int64_t parent_id) {
+  (void)j;
+  for (;;) {
+    if (*pk >= pe) return cid != parent_id ? __fdiv_rn(w, a.q) : __fdiv_rn(w, a.p);
+    const int64_t pid = (int64_t)a.p_ids[*pk];
+    if (cid < pid) return cid != parent_id ? __fdiv_rn(w, a.q) : __fdiv_rn(w, a.p);
+    ++*pk;
+    if (cid == pid) return w;
+  }
+}
+
+__global__ __launch_bounds__(256) void Node2VecListStepKernel(const N2vListArgs a) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+    const int32_t cr = a.c_row[i];
+    const int32_t cb = a.c_idx[2 * cr], ce = a.c_idx[2 * cr + 1];
+    int32_t pb = 0, pe = 0;
+    if (a.p_row != nullptr) { const int32_t pr = a.p_row[i]; pb = a.p_idx[2 * pr]; pe = a.p_idx[2 * pr + 1]; }
+    const int64_t parent_id = a.parent_ids[i];
+    int64_t sample_id = a.default_node;
+    if (ce > cb) {
+      float total = 0.f;
+      int32_t pk = pb;
+      for (int32_t j = cb; j < ce; ++j)
+        total = __fadd_rn(total, N2vListTake(a, j, a.c_w[j], (int64_t)a.c_ids[j], &pk, pe, parent_id));
+      const double u = RngDraw(a.seed, a.call_id, kDomainWalk, (uint64_t)i, 0);
+      const double r = ScaleDraw(u, 0.f, total);
+      float acc = 0.f;
+      pk = pb;
+      int64_t id = 0;
+      for (int32_t j = cb; j < ce; ++j) {
+        id = (int64_t)a.c_ids[j];
+        const float w = N2vListTake(a, j, a.c_w[j], id, &pk, pe, parent_id);
+        const float prev = acc;
+        acc = __fadd_rn(acc, w);
+        if ((double)prev <= r && r < (double)acc) break;
+        // no interval holds r (total == 0): RandomSelect ends on the last element - `id`
+      }
+      sample_id = id;
+    }
+    a.out[i] = sample_id;
+  }
+}
+
 struct GenPairArgs {
   const int64_t* paths;
   int64_t* out;
@@ -753,6 +816,39 @@ int euler_gpu_get_top_k_neighbor(const euler_gpu_graph* g, void* stream,
   for (int32_t i = 0; i < k_types; ++i) a.et[i] = edge_types_host[i];
   const int block = 256;
   hipLaunchKernelGGL(TopKNeighborKernel, dim3(GridFor(n * 64, block)), dim3(block), 0,
+                     (hipStream_t)stream, a);
+  EG_HIP(hipGetLastError());
+  return EULER_GPU_OK;
+}
+
+// One node2vec step over EXPLICIT neighbour lists - what the reference's client does
+// (tf_euler/kernels/random_walk_op.cc:83-138, RWCallback::operator()): the lists of the
+// walkers' current nodes came back from the (remote) `v(nodes).outV(edge_types)` query, the
+// parents' lists are those of the previous step; BuildWeights (:140-168) merges the two and
+// CompactWeightedCollection draws.  No graph argument: on a sharded graph the requester runs
+// this on the rows it fetched (euler_amd/distributed.py: ShardedSampler.random_walk).
+// Lists are rows of a packed set: walker i's child list is row c_row[i] of (c_idx, c_ids,
+// c_w), its parent's list row p_row[i] of (p_idx, p_ids) - several walkers on one node share
+// a row; p_row == NULL: no parent lists yet (the first step).  Draw: domain WALK, stream =
+// walker index, call_id - the single-GPU kernels' (Node2VecKernel above).
+int euler_gpu_node2vec_step(void* stream, uint64_t seed, uint32_t call_id, int64_t n,
+                            const int32_t* c_row_dev, const int32_t* c_idx_dev,
+                            const uint64_t* c_ids_dev, const float* c_w_dev,
+                            const int32_t* p_row_dev, const int32_t* p_idx_dev,
+                            const uint64_t* p_ids_dev, const int64_t* parent_ids_dev,
+                            float p, float q, int64_t default_node, int64_t* out_dev) {
+  if (n < 0) return Fail(EULER_GPU_EINVAL, "node2vec_step: bad n");
+  if (n == 0) return EULER_GPU_OK;
+  if (!c_row_dev || !c_idx_dev || !parent_ids_dev || !out_dev ||
+      (p_row_dev != nullptr && !p_idx_dev))
+    return Fail(EULER_GPU_EINVAL, "node2vec_step: null buffer");
+  N2vListArgs a{};
+  a.seed = seed; a.call_id = call_id; a.n = n;
+  a.c_row = c_row_dev; a.c_idx = c_idx_dev; a.c_ids = c_ids_dev; a.c_w = c_w_dev;
+  a.p_row = p_row_dev; a.p_idx = p_idx_dev; a.p_ids = p_ids_dev;
+  a.parent_ids = parent_ids_dev; a.p = p; a.q = q; a.default_node = default_node;
+  a.out = out_dev;
+  hipLaunchKernelGGL(Node2VecListStepKernel, dim3(GridFor(n, 256)), dim3(256), 0,
                      (hipStream_t)stream, a);
   EG_HIP(hipGetLastError());
   return EULER_GPU_OK;

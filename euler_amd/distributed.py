@@ -389,7 +389,7 @@ class ShardedSampler:
         return list(torch.split(out, dims, dim=1)) if dims else []
 
     # ------------------------------------------------------- full neighbours
-    def get_full_neighbor(self, nodes, edge_types):
+    def get_full_neighbor(self, nodes, edge_types, packed_rows=False):
         """`v(nodes).outV(edge_types)` over the sharded graph, GQL layout (idx
         [n,2] int32, ids int64, weights f32, types int32).  Rows have different
         lengths, so the answers travel as (row lengths) + (packed values) and
@@ -398,7 +398,9 @@ class ShardedSampler:
         IDX_GATHER + DATA_GATHER through the position map.  Needs
         local_full_neighbor(owned, edge_types) -> (idx, ids, w, t),
         idx_gather_fn(idx, gather_idx) -> (idx_out, total) and
-        data_gather_fn(data, idx, gather_idx) -> data_out."""
+        data_gather_fn(data, idx, gather_idx) -> data_out.
+        packed_rows: return (idx [rows, 2], ids, w, t, row [n]) - the distinct rows and
+        the row of every position - instead of one copy of the row per position."""
         nodes = nodes.reshape(-1).to(torch.int64)
         dev = nodes.device
         if self.dedup_split_fn is not None:
@@ -434,6 +436,13 @@ class ShardedSampler:
         vals_back = self._exchange(vals, val_send, val_recv)
         end = torch.cumsum(lens_back.to(torch.int64), 0)
         idx_cat = torch.stack([end - lens_back, end], dim=1).to(torch.int32)
+        if packed_rows:
+            # the rows as they came back (one per distinct id asked, bucketed by owner) and
+            # the row of every position: callers that can index rows do not need a copy of
+            # a hub's list per position that named it
+            return (idx_cat, vals_back[:, :2].contiguous().view(torch.int64).reshape(-1),
+                    vals_back[:, 2].contiguous().view(torch.float32),
+                    vals_back[:, 3].contiguous(), pos.to(torch.int32))
         out_idx, _total = self.idx_gather_fn(idx_cat, pos)
         out_ids = self.data_gather_fn(vals_back[:, :2].contiguous().view(torch.int64)
                                       .reshape(-1), idx_cat, pos)
@@ -620,20 +629,41 @@ class ShardedSampler:
         dist.all_gather(parts, pad, group=self.group)
         return torch.cat([parts[s][:split[s]] for s in range(self.world)]).to(dev)
 
-    def random_walk(self, nodes, edge_types, default_node=-1, call_id=None):
-        """tf_euler random_walk with p = q = 1 (TraditionalRandomWalk,
-        tf_euler/kernels/random_walk_op.cc:207-247) over the sharded graph: one
-        id / result exchange per step; edge_types is a list (walk_len) of
-        per-step edge type lists.  Returns [n, walk_len + 1] int64, identical
-        to the single-GPU kernel (step s uses call_id + s)."""
+    def random_walk(self, nodes, edge_types, p=1.0, q=1.0, default_node=-1, call_id=None):
+        """tf_euler random_walk over the sharded graph; edge_types is a list (walk_len)
+        of per-step edge type lists.  Returns [n, walk_len + 1] int64, identical to the
+        single-GPU kernel (step s uses call_id + s).
+        p = q = 1 (TraditionalRandomWalk, tf_euler/kernels/random_walk_op.cc:207-247):
+        one id / result exchange per step, sample_neighbor with count 1.
+        Otherwise node2vec as the reference's client runs it (random_walk_op.cc:83-168):
+        every step fetches the neighbour lists of the walkers' current nodes
+        (get_full_neighbor: `v(nodes).outV(edge_types)`, one row per DISTINCT node), keeps
+        the previous step's lists as the parents' and draws on the requester -
+        n2v_step_fn(call_id, c_row, c_idx, c_ids, c_w, p_row, p_idx, p_ids, parent_ids, p, q,
+        default_node) -> next nodes (euler_gpu_node2vec_step).  The draw is keyed by the
+        walker's index in `nodes`."""
         call_id = self._take_call_ids(max(len(edge_types), 1), call_id)
         nodes = nodes.reshape(-1).to(torch.int64)
         cols = [nodes]
-        cur, mask = nodes, None
+        # random_walk_op.cc:281: fabs(p_ - 1.0) <= kEps && fabs(q_ - 1.0) <= kEps, in f32
+        import numpy as _np
+        k_eps = 1.0e-6
+        if abs(float(_np.float32(p)) - 1.0) <= k_eps and abs(float(_np.float32(q)) - 1.0) <= k_eps:
+            cur, mask = nodes, None
+            for s, et in enumerate(edge_types):
+                ids, _, _, mask = self.sample_neighbor(cur, et, 1, default_node,
+                                                       call_id + s, mask, 1)
+                cur = ids.reshape(-1)
+                cols.append(cur)
+            return torch.stack(cols, dim=1)
+        cur, parent = nodes, nodes            # parent_ids_ starts as the start nodes
+        p_row = p_idx = p_ids = None          # parent_neighbors_ starts empty
         for s, et in enumerate(edge_types):
-            ids, _, _, mask = self.sample_neighbor(cur, et, 1, default_node,
-                                                   call_id + s, mask, 1)
-            cur = ids.reshape(-1)
+            c_idx, c_ids, c_w, _t, c_row = self.get_full_neighbor(cur, et, packed_rows=True)
+            nxt = self.n2v_step_fn(call_id + s, c_row, c_idx, c_ids, c_w, p_row, p_idx, p_ids,
+                                   parent, p, q, default_node)
+            parent, cur = cur, nxt
+            p_row, p_idx, p_ids = c_row, c_idx, c_ids
             cols.append(cur)
         return torch.stack(cols, dim=1)
 
@@ -854,6 +884,7 @@ def gpu_sharded_sampler(graph, partitions=None, group=None, dedup=True, dense_id
     S.node_weight_sum = weight_sum
     S.node_split_fn = lambda call_id, count, weights: ops.sample_node_split(
         graph.seed, call_id, count, weights)
+    S.n2v_step_fn = lambda call_id, *lists: ops.node2vec_step(graph.seed, call_id, *lists)
     return S
 
 

@@ -306,6 +306,36 @@ def gen_pair(paths, left_win_size, right_win_size):
     return out
 
 
+def node2vec_step(seed, call_id, c_row, c_idx, c_ids, c_w, p_row, p_idx, p_ids, parent_ids,
+                  p, q, default_node=-1):
+    """One node2vec step over explicit neighbour lists (euler_gpu_node2vec_step;
+    tf_euler/kernels/random_walk_op.cc:83-168): walker i's child list is row c_row[i] of
+    (c_idx [rows, 2], c_ids, c_w), its parent's list row p_row[i] of (p_idx, p_ids) -
+    p_row None on the first step.  Returns the next nodes [n] int64."""
+    c_row = c_row.to(torch.int32).contiguous()
+    c_idx = c_idx.to(torch.int32).contiguous()
+    c_ids = c_ids.to(torch.int64).contiguous()
+    c_w = c_w.to(torch.float32).contiguous()
+    parent_ids = parent_ids.to(torch.int64).contiguous()
+    _need_cuda(c_row, c_idx, c_ids, c_w, parent_ids)
+    if p_row is not None:
+        p_row = p_row.to(torch.int32).contiguous()
+        p_idx = p_idx.to(torch.int32).contiguous()
+        p_ids = p_ids.to(torch.int64).contiguous()
+        _need_cuda(p_row, p_idx, p_ids)
+    n = c_row.numel()
+    out = torch.empty(n, dtype=torch.int64, device=c_row.device)
+    null = C.c_void_p(0)
+    with torch.cuda.device(c_row.device):
+        check(lib().euler_gpu_node2vec_step(
+            _stream(), int(seed), int(call_id), n, _ptr(c_row), _ptr(c_idx), _ptr(c_ids), _ptr(c_w),
+            _ptr(p_row) if p_row is not None else null,
+            _ptr(p_idx) if p_row is not None else null,
+            _ptr(p_ids) if p_row is not None else null,
+            _ptr(parent_ids), float(p), float(q), int(default_node), _ptr(out)))
+    return out
+
+
 def id_unique(ids):
     """ID_UNIQUE: (unique ids in first-occurrence order, gather_idx int32)."""
     ids = ids.to(torch.int64).contiguous().reshape(-1)

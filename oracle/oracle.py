@@ -781,6 +781,58 @@ def random_select(sum_weights, begin, end, u):
     return lib().eo_random_select(_p(sw, _f32p), begin, end, u)
 
 
+def node2vec_step_lists(seed, call_id, c_row, c_idx, c_ids, c_w, p_row, p_idx, p_ids,
+                        parent_ids, p, q, default_node=-1):
+    """One node2vec step over explicit neighbour lists, the reference's client code restated
+    (tf_euler/kernels/random_walk_op.cc:83-138 RWCallback::operator(), :140-168
+    BuildWeights, euler/common/compact_weighted_collection.h:84-152 Init / Sample over
+    RandomSelect :30-52).  Pure Python: small cases.  Walker i's child list is row c_row[i]
+    of (c_idx, c_ids, c_w), its parent's list row p_row[i] of (p_idx, p_ids) (p_row None:
+    no parent lists, the first step); draw = eo_uniform_at(seed, call_id, WALK = 2,
+    stream i, draw 0), as the seam defines it for the walk."""
+    c_row = np.asarray(c_row).reshape(-1)
+    c_idx = np.asarray(c_idx).reshape(-1, 2)
+    c_ids = np.asarray(c_ids).astype(np.int64).reshape(-1)
+    c_w = np.asarray(c_w, dtype=np.float32).reshape(-1)
+    parent_ids = np.asarray(parent_ids).astype(np.int64).reshape(-1)
+    if p_row is not None:
+        p_row = np.asarray(p_row).reshape(-1)
+        p_idx = np.asarray(p_idx).reshape(-1, 2)
+        p_ids = np.asarray(p_ids).astype(np.int64).reshape(-1)
+    pf, qf = np.float32(p), np.float32(q)
+    out = np.full(len(c_row), default_node, np.int64)
+    for i in range(len(c_row)):
+        b, e = int(c_idx[c_row[i], 0]), int(c_idx[c_row[i], 1])
+        if e <= b:
+            continue
+        cn = c_ids[b:e]
+        w = c_w[b:e].copy()
+        pn = p_ids[int(p_idx[p_row[i], 0]):int(p_idx[p_row[i], 1])] if p_row is not None \
+            else np.zeros(0, np.int64)
+        parent = parent_ids[i]
+        j = k = 0                                   # BuildWeights, :140-168
+        while j < len(cn) and k < len(pn):
+            if cn[j] < pn[k]:
+                w[j] = w[j] / (qf if cn[j] != parent else pf)
+                j += 1
+            elif cn[j] == pn[k]:
+                k += 1
+                j += 1
+            else:
+                k += 1
+        while j < len(cn):
+            w[j] = w[j] / (qf if cn[j] != parent else pf)
+            j += 1
+        sums = np.zeros(len(cn), np.float32)        # CompactWeightedCollection::Init
+        acc = np.float32(0)
+        for x in range(len(cn)):
+            acc = np.float32(acc + w[x])
+            sums[x] = acc
+        u = uniform_at(seed, call_id, 2, i, 0)
+        out[i] = cn[random_select(sums, 0, len(cn) - 1, u)]
+    return out
+
+
 def id_unique(ids):
     ids = _arr(ids, np.uint64)
     uq = np.zeros(len(ids), np.uint64)

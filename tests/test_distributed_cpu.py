@@ -257,6 +257,23 @@ def _worker(rank, world, port, partitions, out_dir):
             assert np.array_equal(gi_.numpy(), wi_), (rank, et_)
             assert np.array_equal(gd_.numpy().astype(np.uint64), wd_)
             assert np.array_equal(gw_.numpy(), ww_) and np.array_equal(gt_.numpy(), wt_)
+    # ---- node2vec (config 4's biased walk) over the sharded graph: the requester fetches
+    # the rows of the walkers' nodes step by step and draws on them, as the reference's
+    # client does (random_walk_op.cc:83-168); equal to the unsharded walk
+    def n2v_step_fn(call_id, c_row, c_idx, c_ids, c_w, p_row, p_idx, p_ids, parent, p_, q_, dn):
+        f = lambda x: None if x is None else x.numpy()
+        return torch.as_tensor(O.node2vec_step_lists(seed, call_id, f(c_row), f(c_idx), f(c_ids),
+                                                     f(c_w), f(p_row), f(p_idx), f(p_ids),
+                                                     f(parent), p_, q_, dn))
+    starts = roots[:60 + 5 * rank]
+    for sampler in (S_fused, S_plain):
+        sampler.n2v_step_fn = n2v_step_fn
+        for (p_, q_, et_w) in ((0.25, 4.0, [[0, 1, 2]] * 4), (2.0, 0.5, [[1, 0], [0, 2], [2, 1]]),
+                               (1.0, 1.0 + 1e-7, [[0, 1, 2]] * 2)):
+            got_w = sampler.random_walk(torch.as_tensor(starts), et_w, p_, q_, default_node=-3,
+                                        call_id=300)
+            want_w = OG_full.random_walk(seed, 300, starts, et_w, len(et_w), p_, q_, -3)
+            assert np.array_equal(got_w.numpy(), want_w), (rank, p_, q_)
     # ---- sparse (uint64) features: variable-length rows again, then the TF
     # kernel's default entries on the requester
     sper = [[[int(v)] * (i % 4), [int(v) + 7, 3][: (i % 3)], [2 ** 63 + i]] if i % 5 else [[]]

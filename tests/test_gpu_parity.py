@@ -790,6 +790,12 @@ def test_gpu_sharded_sampler_single_rank(EA, O, torch_cuda, big_pair):
         assert np.array_equal(
             t2n(walk), t2n(G.random_walk(torch.as_tensor(q).cuda(), et, 1.0, 1.0, -1,
                                          call_id=20)))
+        # node2vec through the sampler: rows fetched step by step, the draw on explicit
+        # lists (euler_gpu_node2vec_step) == the single-GPU kernels == the oracle
+        for p_, q_ in ((0.25, 4.0), (2.0, 0.5)):
+            w2 = S.random_walk(torch.as_tensor(q).cuda(), et, p_, q_, default_node=-1, call_id=30)
+            assert np.array_equal(t2n(w2), OG.random_walk(31, 30, q, et, L, p_, q_, -1)), (p_, q_)
+            assert torch.equal(w2, G.random_walk(torch.as_tensor(q).cuda(), et, p_, q_, -1, call_id=30))
     finally:
         dist.destroy_process_group()
 
@@ -1423,13 +1429,13 @@ def test_fanout_local_dedup_kernel(EA, O, torch_cuda, big_pair, geom):
     from euler_amd import _lib
     L = _lib.lib()
     gr, cap, block, wide, wps, plain, grid = geom
-    keys = {27: 1, 28: gr, 29: cap, 30: block, 31: wide, 32: grid, 33: 0, 34: plain, 35: wps}
+    keys = {27: 2, 28: gr, 29: cap, 30: block, 31: wide, 32: grid, 33: 0, 34: plain, 35: wps}
 
     def check(G, OG, q, et, counts, default, seed, call):
         qt = torch.as_tensor(q).cuda()
         G.set_seed(seed)
         on, ow, ot = OG.sample_fanout(seed, call, q, et, counts, default)
-        L.euler_gpu_set_tuning(27, 1)
+        L.euler_gpu_set_tuning(27, 2)
         gn, gw, gt = G.sample_fanout(qt, et, counts, default, call_id=call)
         for h in range(2):
             assert np.array_equal(t2n(gn[h + 1]), on[h]), (geom, len(q), et, counts, h)

@@ -162,6 +162,14 @@ def _worker_body(rank, world, port, partitions):
     assert torch.equal(got, want)
     assert np.array_equal(t2n(got)[:64], OG.random_walk(5, 100, t2n(starts)[:64], etw, L, 1.0,
                                                        1.0, N + 1))
+    # ... and its node2vec run (p = 0.25, q = 4): every step fetches the rows of the walkers'
+    # nodes from their owners and draws on the requester (random_walk_op.cc:83-168)
+    etn = [[0]] * 8
+    want = G_full.random_walk(starts[:1500], etn, 0.25, 4.0, N + 1, call_id=200)
+    got = S.random_walk(starts[:1500], etn, 0.25, 4.0, default_node=N + 1, call_id=200)
+    assert torch.equal(got, want)
+    assert np.array_equal(t2n(got)[:32], OG.random_walk(5, 200, t2n(starts)[:32], etn, 8, 0.25,
+                                                       4.0, N + 1))
     # dedup="ops" (ID_UNIQUE / ID_SPLIT / merge_rows / gather as separate kernels)
     S_ops = gpu_sharded_sampler(G_shard, partitions=partitions, dedup="ops")
     got = S_ops.sample_fanout(roots[:5000], et2, [6, 4], N + 1, call_id=13)
@@ -242,6 +250,9 @@ def _worker_body(rank, world, port, partitions):
     walk = Sh.random_walk(qt[:2000], [[0, 1, 2]] * 6, default_node=-1, call_id=50)
     assert np.array_equal(t2n(walk), OGh.random_walk(31, 50, q[:2000], [[0, 1, 2]] * 6, 6, 1.0,
                                                      1.0, -1))
+    walk = Sh.random_walk(qt[:500], [[0, 1, 2]] * 4, 2.0, 0.5, default_node=-1, call_id=55)
+    assert np.array_equal(t2n(walk), OGh.random_walk(31, 55, q[:500], [[0, 1, 2]] * 4, 4, 2.0,
+                                                     0.5, -1))
     dist.barrier()
     dist.destroy_process_group()
 
