@@ -328,6 +328,29 @@ def _oracle_rows(G, p, need, n_types, spot=64):
     return O.OracleGraph(O.CSR(need, rp, te, nb, pw, tp, T))
 
 
+def _rank_ctx():
+    """(rank, world, wire device) of the sharded secondary workloads; one process: (0, 1, None)"""
+    if dist.is_available() and dist.is_initialized():
+        on_gpu = dist.get_backend() == "nccl"
+        return dist.get_rank(), dist.get_world_size(), (torch.device("cuda", torch.cuda.current_device())
+                                                        if on_gpu else torch.device("cpu"))
+    return 0, 1, None
+
+
+def _max_over_ranks(secs, wire):
+    if wire is None:
+        return secs
+    t = torch.tensor(secs, device=wire, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(x) for x in t.tolist()]
+
+
+def _sync_ranks(wire):
+    if wire is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
 def run_hetero(args, quiet=False):
     """configs[4] on one GPU: heterogeneous graph (8 edge types), per-type neighbour
     sampling with one listed type, 3 of 8 (sub-collection draw) and all 8 (type draw
@@ -335,17 +358,34 @@ def run_hetero(args, quiet=False):
     and scatter_mean into the roots (segment reduce, fp32, order-faithful)."""
     import euler_amd
     from euler_amd import ops
+    rank, world, wire = _rank_ctx()
     N, T, D, CNT = 20_000_000, 8, 128, 10
+    if args.nodes < 100_000_000:           # functional runs on small graphs (--nodes)
+        N = max(1000, args.nodes // 5)
     B = args.batch
     t0 = time.time()
     p_h = euler_amd.synth_params(GRAPH_SEED, N, 20 * N, n_types=T, weighted=True)
-    G = euler_amd.Graph.synthetic(p_h)
+    G = euler_amd.Graph.synthetic(p_h, device=torch.cuda.current_device(), partitions=world,
+                                  shard_index=rank, shards=world)
     G.set_seed(GRAPH_SEED)
+    # N ranks: the graph is hash-sharded (owner = id % world), every typed hop is one id /
+    # result exchange (ShardedSampler); the feature table is replicated and the aggregation
+    # local - it works on minibatch-local tensors (SURVEY 8(e): replicas only)
+    S = None
+    if wire is not None:
+        from euler_amd.distributed import gpu_sharded_sampler
+        S = gpu_sharded_sampler(G, partitions=world)
+
+    def sample(r_, et_, call_id):
+        if S is None:
+            return G.sample_neighbor(r_, et_, CNT, N + 1, call_id=call_id)
+        ids_, w_, t_, _m = S.sample_neighbor(r_, et_, CNT, N + 1, call_id)
+        return ids_, w_, t_
     feat = torch.randn(N + 2, D, device="cuda", generator=torch.Generator("cuda").manual_seed(7))
     torch.cuda.synchronize()
     build_s = time.time() - t0
     n_steps = args.steps + args.warmup
-    gen = torch.Generator(device="cuda"); gen.manual_seed(1234)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(1234 + rank)
     roots = torch.randint(1, N + 1, (n_steps, B), generator=gen, device="cuda", dtype=torch.int64)
     dst = torch.arange(B, device="cuda", dtype=torch.int32).repeat_interleave(CNT)
     type_sets = ([3], [1, 4, 6], list(range(T)))
@@ -355,7 +395,7 @@ def run_hetero(args, quiet=False):
     def step(i):
         aggs = []
         for c, et in enumerate(type_sets):
-            nb, _w, _t = G.sample_neighbor(roots[i], et, CNT, N + 1, call_id=3 * i + c)
+            nb, _w, _t = sample(roots[i], et, 3 * i + c)
             src = nb.reshape(-1).to(torch.int32)
             if fused:      # the rows are reduced as they are read, CNT per root
                 aggs.append(ops.gather_segment_reduce("mean", feat, src, B, count=CNT))
@@ -365,7 +405,7 @@ def run_hetero(args, quiet=False):
 
     # consecutive minibatches alternate between --streams HIP streams (default 2), as in the
     # headline workload: the latency-bound sampling of one overlaps the aggregation of another
-    n_streams = max(1, args.streams)
+    n_streams = max(1, args.streams) if S is None else 1     # a sharded hop waits on the host
     side = [torch.cuda.Stream() for _ in range(n_streams)] if n_streams > 1 else None
 
     def loop(first, last):
@@ -376,17 +416,40 @@ def run_hetero(args, quiet=False):
                 with torch.cuda.stream(side[i % n_streams]):
                     step(i)
 
-    torch.cuda.synchronize()
+    _sync_ranks(wire)
     loop(0, max(args.warmup, 2 * n_streams))
-    torch.cuda.synchronize()
+    _sync_ranks(wire)
     reps = []
     for _rep in range(max(1, args.repeats)):
-        torch.cuda.synchronize()
+        _sync_ranks(wire)
         t0 = time.perf_counter()
         loop(args.warmup, n_steps)
-        torch.cuda.synchronize()
+        _sync_ranks(wire)
         reps.append(time.perf_counter() - t0)
+    reps = _max_over_ranks(reps, wire)           # slowest rank, per repetition
     elapsed = float(np.median(reps))
+    if S is not None:
+        edges = B * CNT * len(type_sets) * world
+        line = {
+            "metric": "sampled + aggregated edges/sec, typed SampleNeighbor (k = 1, 3 of 8, all) + 128-d "
+                      "gather + scatter_mean, heterogeneous graph (BASELINE configs[4])",
+            "value": edges * args.steps / elapsed, "unit": "sampled edges/s",
+            "n_gpus": min(world, torch.cuda.device_count()),
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 / f32",
+            "data": "synthetic",
+            "config": {"workload": "hetero, sharded: %d nodes, %d edge types, hash owner(id) = id %% %d, one "
+                                   "exchange per typed hop (3 per step), %d roots per step per rank, "
+                                   "features [%d, %d] f32 replicated, aggregation local"
+                                   % (N, T, world, B, N + 2, D),
+                       "ranks": world, "graph_build_s": round(build_s, 2), "repeats": len(reps),
+                       "repeat_ms_per_step": [round(x_ / args.steps * 1e3, 4) for x_ in reps],
+                       "transport": dist.get_backend()},
+            "roofline": None, "cpu_baseline": None,
+        }
+        if rank == 0 and not quiet:
+            print(json.dumps(line), flush=True)
+        return line
     one_stream = None
     if side is not None:                       # the same steps on ONE stream, for the record
         t0 = time.perf_counter()
@@ -502,31 +565,79 @@ def run_deepwalk(args, G=None, p_g=None, quiet=False):
     import euler_amd
     from euler_amd import _lib
     L = _lib.lib()
+    rank, world, wire = _rank_ctx()
     N = args.nodes
     t0 = time.time()
     if G is None:
         p_g = euler_amd.synth_params(GRAPH_SEED, N, args.edges, weighted=True)
-        G = euler_amd.Graph.synthetic(p_g)
+        G = euler_amd.Graph.synthetic(p_g, device=torch.cuda.current_device(), partitions=world,
+                                      shard_index=rank, shards=world)
     G.set_seed(GRAPH_SEED)
     torch.cuda.synchronize()
     build_s = time.time() - t0
-    W, LEN = 1_000_000, 40
-    gen = torch.Generator(device="cuda"); gen.manual_seed(1234)
+    W, LEN = (1_000_000 if N >= 100_000_000 else max(1000, N // 100)), 40
+    gen = torch.Generator(device="cuda"); gen.manual_seed(1234 + rank)
     n_steps = args.steps + args.warmup
     starts = torch.randint(1, N + 1, (n_steps, W), generator=gen, device="cuda", dtype=torch.int64)
     et = [[0]] * LEN
+    # N ranks: the graph is hash-sharded (owner = id % world); every walk step is one id /
+    # result exchange (ShardedSampler.random_walk), the node2vec run fetches the rows of the
+    # walkers' nodes from their owners step by step (random_walk_op.cc:83-168)
+    S = None
+    if wire is not None:
+        from euler_amd.distributed import gpu_sharded_sampler
+        S = gpu_sharded_sampler(G, partitions=world)
+
+    def walk(st_, et_, p_, q_, call_id):
+        if S is None:
+            return G.random_walk(st_, et_, p_, q_, N + 1, call_id=call_id)
+        return S.random_walk(st_, et_, p_, q_, default_node=N + 1, call_id=call_id)
+
     for i in range(args.warmup):
-        G.random_walk(starts[i], et, 1.0, 1.0, N + 1, call_id=LEN * i)
-    torch.cuda.synchronize()
+        walk(starts[i], et, 1.0, 1.0, LEN * i)
+    _sync_ranks(wire)
     reps = []
     for _rep in range(max(1, args.repeats)):
-        torch.cuda.synchronize()
+        _sync_ranks(wire)
         t0 = time.perf_counter()
         for i in range(args.warmup, n_steps):
-            walks = G.random_walk(starts[i], et, 1.0, 1.0, N + 1, call_id=LEN * i)
-        torch.cuda.synchronize()
+            walks = walk(starts[i], et, 1.0, 1.0, LEN * i)
+        _sync_ranks(wire)
         reps.append(time.perf_counter() - t0)
+    reps = _max_over_ranks(reps, wire)           # slowest rank, per repetition
     elapsed = float(np.median(reps))
+    if S is not None:
+        n2v = None
+        if args.n2v:
+            W2, L2 = min(100_000, W), 10
+            s2 = starts[0][:W2].contiguous()
+            walk(s2, [[0]] * L2, 0.25, 4.0, 3)
+            _sync_ranks(wire)
+            t0 = time.perf_counter()
+            walk(s2, [[0]] * L2, 0.25, 4.0, 3)
+            _sync_ranks(wire)
+            sec2 = _max_over_ranks([time.perf_counter() - t0], wire)[0]
+            n2v = {"walkers_per_rank": W2, "walk_len": L2, "p": 0.25, "q": 4.0,
+                   "ms": round(sec2 * 1e3, 3), "steps_per_s": world * W2 * L2 / sec2}
+        line = {
+            "metric": "walker steps/sec, DeepWalk random_walk length 40 (p = q = 1) on the power-law "
+                      "graph hash-sharded over the ranks (BASELINE configs[3])",
+            "value": world * W * LEN * args.steps / elapsed, "unit": "walker steps/s",
+            "n_gpus": min(world, torch.cuda.device_count()),
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "deepwalk, sharded: %d walkers x %d steps per rank per step of the "
+                                   "bench, graph %d nodes / %d edges (all shards), owner(id) = id %% %d, "
+                                   "one exchange per walk step" % (W, LEN, N, args.edges, world),
+                       "ranks": world, "graph_build_s": round(build_s, 2), "repeats": len(reps),
+                       "repeat_ms_per_step": [round(x_ / args.steps * 1e3, 4) for x_ in reps],
+                       "transport": dist.get_backend(), "node2vec": n2v},
+            "roofline": None, "cpu_baseline": None,
+        }
+        if rank == 0 and not quiet:
+            print(json.dumps(line), flush=True)
+        return line
 
     def walk_bytes(walks_, n, L_, p, q):
         b = C.c_double(0)
@@ -748,8 +859,10 @@ def main():
         k_, v_ = kv.split("=")
         _lib.check(L.euler_gpu_set_tuning(int(k_), int(v_)))
     if args.workload in ("hetero", "deepwalk"):
-        assert world == 1, "the secondary workloads are single-GPU lines"
         (run_hetero if args.workload == "hetero" else run_deepwalk)(args)
+        if sharded:
+            dist.barrier()
+            dist.destroy_process_group()
         return
     weighted = args.workload != "products"
     if args.workload == "products":
