@@ -1697,6 +1697,36 @@ int euler_gpu_sample_fanout(const euler_gpu_graph* g, void* stream,
                    counts_host, layers, default_node, out_id_dev, out_w_dev, out_t_dev,
                    workspace_dev, nullptr, nullptr);
 }
+// TF SampleFanoutWithFeature (tf_euler/kernels/sample_fanout_with_feature_op.cc:135-233:
+// `v(nodes).as(nb_0).sampleNB(..).as(nb_1) ... .v_select(nb_i).values(..).as(fea_i)`): the
+// fanout and, for every layer's nodes (layer 0 = the roots), the dense features - one
+// enqueue, nothing returns to the host.  dense_out_dev[layer * n_dense + j] = [m_layer,
+// dims[j]] float32 (zero rows for default_node / unknown nodes / missing slots, :160-178).
+int euler_gpu_sample_fanout_with_feature(const euler_gpu_graph* g, void* stream, uint64_t seed,
+                                         uint32_t call_id, const uint64_t* roots_dev, int64_t n,
+                                         const int32_t* edge_types_host, int32_t k,
+                                         const int32_t* counts_host, int32_t layers,
+                                         int64_t default_node, uint64_t* const* out_id_dev,
+                                         float* const* out_w_dev, int32_t* const* out_t_dev,
+                                         void* workspace_dev, const int32_t* dense_fids_host,
+                                         const int32_t* dense_dims_host, int32_t n_dense,
+                                         float* const* dense_out_dev) {
+  if (n_dense < 0 || (n_dense > 0 && (!dense_fids_host || !dense_dims_host || !dense_out_dev)))
+    return Fail(EULER_GPU_EINVAL, "sample_fanout_with_feature: bad feature arguments");
+  int rc = euler_gpu_sample_fanout(g, stream, seed, call_id, roots_dev, n, edge_types_host, k,
+                                   counts_host, layers, default_node, out_id_dev, out_w_dev,
+                                   out_t_dev, workspace_dev);
+  int64_t m = n;
+  for (int32_t layer = 0; layer <= layers && rc == EULER_GPU_OK; ++layer) {
+    const uint64_t* nodes = layer == 0 ? roots_dev : out_id_dev[layer - 1];
+    for (int32_t j = 0; j < n_dense && rc == EULER_GPU_OK; ++j)
+      rc = euler_gpu_get_dense_feature(g, stream, nodes, m, dense_fids_host[j], dense_dims_host[j],
+                                       dense_out_dev[(size_t)layer * n_dense + j]);
+    if (layer < layers) m *= counts_host[layer];
+  }
+  return rc;
+}
+
 int euler_gpu_time_sample_neighbor(const euler_gpu_graph* g, void* stream,
                                    uint64_t seed, const uint64_t* roots_dev,
                                    int64_t n, const int32_t* edge_types_host,

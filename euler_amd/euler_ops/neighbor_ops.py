@@ -84,13 +84,16 @@ def sample_fanout_with_feature(nodes, edge_types, count, default_node,
     default values (tf_euler/kernels/sample_fanout_with_feature_op.cc:180-232)."""
     g = base.get_default_graph()
     ets = [type_ops.get_edge_type_id(et) for et in edge_types]
-    neighbors, weights, types = g.sample_fanout(nodes, ets, count, default_node)
     fids = [int(str(f)) for f in dense_feature_names]
     sfids = [int(str(f)) for f in sparse_feature_names]
     sdef = list(sparse_default_values) if len(sparse_default_values) else [0] * len(sfids)
-    dense, sparse = [], []
+    # the fanout and every layer's dense features: one enqueue, no host round trip
+    # (euler_gpu_sample_fanout_with_feature); the sparse features need their sizes on the
+    # host, one query per layer
+    neighbors, weights, types, dense = g.sample_fanout_with_feature(
+        nodes, ets, count, default_node, fids, list(dense_dimensions))
+    sparse = []
     for layer_nodes in neighbors:
-        dense.extend(g.get_dense_feature(layer_nodes, fids, list(dense_dimensions)))
         if sfids:
             sparse.extend(g.get_sparse_feature(layer_nodes, sfids, sdef))
     return neighbors, weights, types, dense, sparse

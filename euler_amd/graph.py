@@ -336,6 +336,48 @@ class Graph:
                 cnt_p, layers, int(default_node), pn, pw, pt, _ptr(ws)))
         return [nodes] + outs_n, outs_w, outs_t
 
+    def sample_fanout_with_feature(self, nodes, edge_types, counts, default_node,
+                                   feature_ids, dimensions, call_id=None):
+        """tf_euler sample_fanout_with_feature, dense part (euler_ops/neighbor_ops.py:49-70
+        over tf_euler/kernels/sample_fanout_with_feature_op.cc:135-233) as ONE enqueue
+        (euler_gpu_sample_fanout_with_feature): returns (neighbors_list, weights_list,
+        types_list, dense_features) with dense_features[layer * len(feature_ids) + j] =
+        [m_layer, dimensions[j]] float32, layer 0 = the roots."""
+        nodes = _as_i64_cuda(nodes, self.device).reshape(-1)
+        layers = len(counts)
+        et = np.asarray(edge_types, dtype=np.int32).reshape(layers, -1)
+        et, et_p, _ = _i32_array(et)
+        k = et.size // layers if layers else 0
+        cnt, cnt_p, _ = _i32_array(counts)
+        fid, fid_p, _ = _i32_array(feature_ids)
+        dim, dim_p, _ = _i32_array(dimensions)
+        nd = len(feature_ids)
+        n = nodes.numel()
+        outs_n, outs_w, outs_t, dense = [], [], [], []
+        m = n
+        sizes = [n]
+        for c in counts:
+            m *= int(c)
+            sizes.append(m)
+            outs_n.append(torch.empty(m, dtype=torch.int64, device=self.device))
+            outs_w.append(torch.empty(m, dtype=torch.float32, device=self.device))
+            outs_t.append(torch.empty(m, dtype=torch.int32, device=self.device))
+        for ml in sizes:
+            for d in dimensions:
+                dense.append(torch.empty((ml, int(d)), dtype=torch.float32, device=self.device))
+        ws_bytes = lib().euler_gpu_sample_fanout_workspace(n, cnt_p, layers)
+        ws = torch.empty(max(int(ws_bytes), 16), dtype=torch.uint8, device=self.device)
+        pn = (C.c_void_p * max(layers, 1))(*[t.data_ptr() for t in outs_n])
+        pw = (C.c_void_p * max(layers, 1))(*[t.data_ptr() for t in outs_w])
+        pt = (C.c_void_p * max(layers, 1))(*[t.data_ptr() for t in outs_t])
+        pd = (C.c_void_p * max(len(dense), 1))(*[t.data_ptr() for t in dense])
+        with torch.cuda.device(self.device):
+            check(lib().euler_gpu_sample_fanout_with_feature(
+                self._h, _stream(), self.seed, self._take_call_ids(layers, call_id),
+                _ptr(nodes), n, et_p, k, cnt_p, layers, int(default_node), pn, pw, pt, _ptr(ws),
+                fid_p, dim_p, nd, pd))
+        return [nodes] + outs_n, outs_w, outs_t, dense
+
     def sage_blocks(self, nodes, edge_types, fanouts, default_node=-1, add_self_loops=True,
                     call_id=None, sync=True):
         """The whole SageDataFlow (tf_euler/python/dataflow/sage_dataflow.py +

@@ -875,6 +875,22 @@ int euler_gpu_time_sample_neighbor_phases(const euler_gpu_graph* g, void* stream
                                           float* out_w_dev, int32_t* out_t_dev,
                                           int32_t iters, float* mean_ms3_host,
                                           int64_t* n_unique_host);
+/* TF SampleFanoutWithFeature (tf_euler/kernels/sample_fanout_with_feature_op.cc:135-233;
+ * op tf_euler/ops/neighbor_ops.cc:282-321): euler_gpu_sample_fanout plus the dense
+ * features of every layer's nodes (layer 0 = the roots), enqueued back to back on `stream`
+ * - no host round trip.  dense_out_dev[(layer) * n_dense + j] is a [m_layer, dims[j]]
+ * float32 buffer (m_0 = n, m_{l+1} = m_l * counts[l]); zero rows for default_node,
+ * unknown nodes and missing slots.  (The sparse features of the op need their sizes on
+ * the host: euler_gpu_get_sparse_feature per layer, euler_amd/euler_ops/neighbor_ops.py.) */
+int euler_gpu_sample_fanout_with_feature(const euler_gpu_graph* g, void* stream, uint64_t seed,
+                                         uint32_t call_id, const uint64_t* roots_dev, int64_t n,
+                                         const int32_t* edge_types_host, int32_t k,
+                                         const int32_t* counts_host, int32_t layers,
+                                         int64_t default_node, uint64_t* const* out_id_dev,
+                                         float* const* out_w_dev, int32_t* const* out_t_dev,
+                                         void* workspace_dev, const int32_t* dense_fids_host,
+                                         const int32_t* dense_dims_host, int32_t n_dense,
+                                         float* const* dense_out_dev);
 /* euler_gpu_sample_fanout's arguments, the call repeated `iters` times between two HIP
  * events recorded on `stream` (after one untimed call): the mean time of one call in
  * milliseconds.  What bench.py quotes for the one-kernel 2-hop fanout. */

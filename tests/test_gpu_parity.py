@@ -838,6 +838,71 @@ def test_dense_feature_vs_goldens_and_oracle(EA, O, torch_cuda, fixture_csr, ran
     assert np.array_equal(want[0][:-2], val[(q[:-2] - 10), :100])
 
 
+def test_sample_fanout_with_feature(EA, O, torch_cuda):
+    """TF SampleFanoutWithFeature (sample_fanout_with_feature_op.cc:135-233) as one
+    enqueue (euler_gpu_sample_fanout_with_feature): neighbours / weights / types == the
+    oracle's fanout, dense_features[layer * F + j] == the oracle's get_dense_feature of that
+    layer's nodes (roots first) - zero rows for default_node, unknown ids and missing
+    slots; the operator-surface wrapper (euler_ops.sample_fanout_with_feature) adds the
+    sparse features per layer."""
+    torch = torch_cuda
+    rng = np.random.default_rng(11)
+    n = 3000
+    ids = np.arange(5, 5 + n).astype(np.uint64)
+    deg = rng.integers(0, 12, n)
+    seg = np.zeros(n + 1, np.int64)
+    seg[1:] = np.cumsum(deg)
+    E = int(seg[-1])
+    nbr = rng.choice(ids, E).astype(np.uint64)
+    nbr[rng.random(E) < 0.03] = 10 ** 9          # no such node
+    w = (rng.random(E) * 3 + 0.5).astype(np.float32)
+    csr = O.csr_from_raw(ids, seg, nbr, w, 1)
+    # two float slots: 6 values, then 3 (some rows leave the second empty)
+    per = [[list(np.float32(rng.standard_normal(6))),
+            list(np.float32(rng.standard_normal(3))) if i % 4 else []] for i in range(n)]
+    F = O.DenseFeatures.from_lists(per)
+    G = gpu_graph(EA, csr, features=(F.n_float, F.feat_ptr, F.feat_idx, F.feat_val))
+    OG = O.OracleGraph(csr)
+    q = np.concatenate([rng.choice(ids, 700), [0, 3, 10 ** 9]]).astype(np.int64)
+    qt = torch.as_tensor(q).cuda()
+    G.set_seed(5)
+    for counts in ([4, 3], [5], [2, 2, 2]):
+        et = [[0]] * len(counts)
+        nb, ww, tt, dense = G.sample_fanout_with_feature(qt, et, counts, -1, [0, 1], [6, 3],
+                                                         call_id=17)
+        on, ow, ot = OG.sample_fanout(5, 17, q, et, counts, -1)
+        assert len(dense) == (len(counts) + 1) * 2
+        layer_nodes = [q] + [np.asarray(x) for x in on]
+        for h in range(len(counts)):
+            assert np.array_equal(t2n(nb[h + 1]), on[h]) and np.array_equal(t2n(ww[h]), ow[h])
+            assert np.array_equal(t2n(tt[h]), ot[h])
+        for layer, nodes_l in enumerate(layer_nodes):
+            want = OG.get_dense_feature(F, nodes_l, [0, 1], [6, 3])
+            for j in range(2):
+                got = t2n(dense[layer * 2 + j])
+                assert got.shape == (len(nodes_l), [6, 3][j])
+                assert np.array_equal(got, want[j]), (counts, layer, j)
+                # default_node / unknown ids: zero rows
+                bad = ~np.isin(nodes_l.astype(np.uint64), ids)
+                assert not got[bad].any()
+    # the operator surface (tf_euler/python/euler_ops/neighbor_ops.py:49-70)
+    from euler_amd import euler_ops
+    from euler_amd.euler_ops import base as _base
+    prev = _base._default
+    _base.set_default_graph(G)
+    try:
+        G.set_seed(5, 40)
+        nb, ww, tt, dense, sparse = euler_ops.sample_fanout_with_feature(
+            qt, [[0], [0]], [4, 3], -1, ["0", "1"], [6, 3])
+        on, _, _ = OG.sample_fanout(5, 40, q, [[0], [0]], [4, 3], -1)
+        assert np.array_equal(t2n(nb[1]), on[0]) and np.array_equal(t2n(nb[2]), on[1])
+        assert len(dense) == 6 and sparse == []
+        want = OG.get_dense_feature(F, np.asarray(on[1]), [0, 1], [6, 3])
+        assert np.array_equal(t2n(dense[4]), want[0]) and np.array_equal(t2n(dense[5]), want[1])
+    finally:
+        _base._default = prev
+
+
 def test_sorted_and_top_k_neighbors(EA, O, torch_cuda, fixture_csr, big_pair):
     """get_sorted_full_neighbor / get_top_k_neighbor / order_by+limit on device
     == the reference tests' expectations on the fixture and == the oracle on a
