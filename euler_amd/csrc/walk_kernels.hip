@@ -405,6 +405,10 @@ __global__ __launch_bounds__(256) void TopKNeighborKernel(const TopKArgs a) {
 // count=1 hops per walker, chained on the CORE id (a missing row continues
 // from the sentinel id 0); output 0 -> default_node.
 // ------------------------------------------------------------------------
+// key 38: DeepWalk (p = q = 1) of at least this many walkers runs over groups of merged
+// walkers (CwSampleKernel ...); 0 = never
+thread_local int g_walk_collapse = 131072;
+
 struct WalkArgs {
   GraphView g;
   uint64_t seed;
@@ -491,6 +495,152 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void RandomWalkKernel(const Wal
 }
 
 #include "n2v_kernels.h"      // NbIter ... N2vBigStepKernel
+// ------------------------------------------------------------------------
+// DeepWalk with the walkers that have MERGED walked once.
+//
+// The draw of a step is keyed by (seed, call_id + step, node id): two walkers standing on
+// the same node in the same step take the same next node - what the reference's ID_UNIQUE
+// -> sample -> GATHER rewrite gives (parser/compiler.cc:76-90) - and therefore stay
+// together for the rest of the walk.  On the metric graph 1M walkers are 63 % distinct
+// nodes after one step, 11 % after ten, 2 % after forty: a tenth of the walker-steps
+// of a walk are distinct (tools/walk_coincidence.py, profiles/r3_walk_coincidence.json).
+// So the walk is run over GROUPS of merged walkers:
+//   level s holds the nodes of the n[s] groups alive at step s (level 0 = the walkers);
+//   CwSampleKernel   draws every group's next node and enters the group into the owner
+//                    table at that node's row (plain stores, one survivor per row - the
+//                    trick of the duplicate-root path, sample_kernels.hip);
+//   CwNumberKernel   the survivor of a row is its representative: representatives take
+//                    the numbers of level s + 1 (one atomic per workgroup) and leave
+//                    them in the table;
+//   CwSampleKernel   (next step, same launch) first reads every group's number back:
+//                    map[s][g] = its group at level s + 1;
+//   CwExpandKernel   walker w follows map[0][w], map[1][..], ... and writes its path.
+// Counts stay on the device; every launch is sized for the walkers and exits past n[s].
+// ------------------------------------------------------------------------
+struct CwArgs {
+  GraphView g;
+  uint64_t seed;
+  const int32_t* edge_types;    // device [walk_len, k]
+  uint32_t* counts;             // [walk_len + 2] groups per level
+  uint64_t* level;              // [walk_len + 1][cap] nodes of the groups
+  uint32_t* map;                // [walk_len][cap] group of level s -> group of level s + 1
+  uint64_t* tmp_id[2];          // [cap] next node of every group (before numbering)
+  uint32_t* tmp_slot[2];        // [cap] its owner-table slot
+  uint32_t* owner[2];           // [n_rows + 1], alternating between steps
+  int64_t cap;                  // walkers
+  int64_t default_node;
+  uint32_t call_id;
+  int32_t k;
+  int32_t walk_len;
+  int32_t step;                 // the step this launch samples (walk_len: none)
+  int32_t fast;                 // one listed type per step on a monotone graph
+};
+
+constexpr uint32_t kCwFlag = 0x80000000u;
+
+__global__ __launch_bounds__(256, kWavesPerSimd) void CwSampleKernel(const CwArgs a) {
+  const int64_t gidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int32_t s = a.step;
+  // (1) the numbers the previous step's representatives left in its table
+  if (s > 0 && gidx < (int64_t)a.counts[s - 1]) {
+    const int par = (s - 1) & 1;
+    const uint32_t sl = a.tmp_slot[par][gidx];
+    // (a group whose next id has no row was numbered on its own: CwNumberKernel wrote its map)
+    if (sl != (uint32_t)a.g.n_rows) a.map[(int64_t)(s - 1) * a.cap + gidx] = a.owner[par][sl] & ~kCwFlag;
+  }
+  // (2) this step's draw
+  if (s >= a.walk_len || gidx >= (int64_t)a.counts[s]) return;
+  const uint64_t cur = a.level[(int64_t)s * a.cap + gidx];
+  uint64_t id = 0;
+  float w;
+  int32_t t;
+  const int64_t row = FindRow(a.g, cur);
+  if (a.fast) {
+    Segment sg;
+    if (LoadSegment<true>(a.g, row, a.edge_types[s], &sg)) {
+      const Philox4 blk = RngBlock(a.seed, a.call_id + (uint32_t)s, kDomainNeighbor, cur, 0);
+      BlockPivotSample(a.g, sg, UnitFromWords(blk.w[0], blk.w[1]), &id, &w);
+    }
+  } else {
+    RowSampler rs;
+    InitRowSampler(rs, a.g, row, a.edge_types + s * a.k, a.k);
+    if (rs.valid) SampleAt(rs, a.seed, a.call_id + (uint32_t)s, cur, 0, &id, &w, &t);
+  }
+  const int par = s & 1;
+  const int64_t nrow = FindRow(a.g, id);
+  const uint32_t slot = nrow < 0 ? (uint32_t)a.g.n_rows : (uint32_t)nrow;
+  a.tmp_id[par][gidx] = id;
+  a.tmp_slot[par][gidx] = slot;
+  a.owner[par][slot] = (uint32_t)gidx;       // benign race: one group naming the row survives
+}
+
+// (unknown ids share the slot n_rows: they are "no such node" for every later step, and a
+// walker there keeps returning default_node - but they may be DIFFERENT ids, which the path
+// must show for this step: the level keeps the id of the representative only.  Ids without
+// a row are therefore numbered one by one, never merged.)
+__global__ __launch_bounds__(256) void CwNumberKernel(const CwArgs a) {
+  __shared__ uint32_t s_base;
+  __shared__ uint32_t s_wave[4];
+  const int64_t gidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int32_t s = a.step;
+  const int par = s & 1;
+  const uint32_t n = a.counts[s];
+  if ((int64_t)blockIdx.x * blockDim.x >= (int64_t)n) return;
+  bool rep = false;
+  uint32_t slot = 0;
+  if (gidx < (int64_t)n) {
+    slot = a.tmp_slot[par][gidx];
+    rep = slot == (uint32_t)a.g.n_rows || a.owner[par][slot] == (uint32_t)gidx;
+  }
+  const uint64_t bal = __ballot(rep);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) s_wave[wv] = (uint32_t)__popcll(bal);
+  __syncthreads();
+  if (threadIdx.x == 0)
+    s_base = atomicAdd(&a.counts[s + 1], s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3]);
+  __syncthreads();
+  if (rep) {
+    uint32_t nid = s_base + (uint32_t)__popcll(bal & (lane == 0 ? 0ull : (~0ull >> (64 - lane))));
+    for (int x = 0; x < wv; ++x) nid += s_wave[x];
+    a.level[(int64_t)(s + 1) * a.cap + nid] = a.tmp_id[par][gidx];
+    if (slot != (uint32_t)a.g.n_rows) a.owner[par][slot] = nid | kCwFlag;
+    else a.map[(int64_t)s * a.cap + gidx] = nid;
+  }
+}
+
+__global__ __launch_bounds__(256, kWavesPerSimd) void CwExpandKernel(const CwArgs a,
+                                                                     const int64_t* starts,
+                                                                     int64_t* out) {
+  __shared__ int64_t stage[256 * (kWalkStage + 1)];
+  const int64_t L = a.walk_len + 1;
+  const int64_t tiles = (a.cap + 255) / 256;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t i = tile * 256 + threadIdx.x;
+    const bool live = i < a.cap;
+    if (live) out[i * L] = starts[i];
+    uint32_t grp = (uint32_t)i;
+    for (int32_t s0 = 0; s0 < a.walk_len; s0 += kWalkStage) {
+      const int32_t ns = min(kWalkStage, a.walk_len - s0);
+      for (int32_t x = 0; x < ns; ++x) {
+        const int32_t s = s0 + x;
+        uint64_t id = 0;
+        if (live) {
+          grp = a.map[(int64_t)s * a.cap + grp] & ~kCwFlag;
+          id = a.level[(int64_t)(s + 1) * a.cap + grp];
+        }
+        stage[threadIdx.x * (kWalkStage + 1) + x] = id == 0 ? a.default_node : (int64_t)id;
+      }
+      __syncthreads();
+      for (int32_t e = threadIdx.x; e < 256 * ns; e += 256) {
+        const int32_t wl = e / ns, x = e - wl * ns;
+        const int64_t wi = tile * 256 + wl;
+        if (wi < a.cap) out[wi * L + s0 + x + 1] = stage[wl * (kWalkStage + 1) + x];
+      }
+      __syncthreads();
+    }
+  }
+}
+
 
 // node2vec step over explicit lists (euler_gpu_node2vec_step): one lane per walker, the
 // reference's own two passes - BuildWeights while summing, then the first running sum > r
@@ -891,7 +1041,44 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
   const float kEps = 1.0e-6;
   // random_walk_op.cc:281: fabs(p_ - 1.0) <= kEps && fabs(q_ - 1.0) <= kEps
   if (std::fabs((double)p - 1.0) <= kEps && std::fabs((double)q - 1.0) <= kEps) {
-    if (k == 1 && g->view.monotone && g->view.blk != nullptr && g_k1_variant >= 5) {
+    const bool fast = k == 1 && g->view.monotone && g->view.blk != nullptr && g_k1_variant >= 5;
+    if (g_walk_collapse != 0 && walk_len >= 4 && n >= g_walk_collapse && n < ((int64_t)1 << 31) &&
+        g->view.n_rows < ((int64_t)1 << 31) - 2 && k > 0) {
+      // the walk over groups of merged walkers (CwSampleKernel ...)
+      CwArgs c{};
+      c.g = g->view; c.seed = seed; c.call_id = call_id; c.edge_types = et_dev; c.k = k;
+      c.walk_len = walk_len; c.cap = n; c.default_node = default_node; c.fast = fast ? 1 : 0;
+      const size_t cap = (size_t)n, rows = (size_t)g->view.n_rows + 1;
+      auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+      const size_t o_counts = 0, o_level = al(((size_t)walk_len + 2) * 4),
+                   o_map = o_level + al(((size_t)walk_len + 1) * cap * 8),
+                   o_tid = o_map + al((size_t)walk_len * cap * 4), o_tsl = o_tid + al(2 * cap * 8),
+                   o_own = o_tsl + al(2 * cap * 4), total = o_own + al(2 * rows * 4);
+      uint8_t* buf = nullptr;
+      EG_HIP(hipMallocAsync((void**)&buf, total, st));
+      c.counts = (uint32_t*)(buf + o_counts);
+      c.level = (uint64_t*)(buf + o_level);
+      c.map = (uint32_t*)(buf + o_map);
+      c.tmp_id[0] = (uint64_t*)(buf + o_tid); c.tmp_id[1] = c.tmp_id[0] + cap;
+      c.tmp_slot[0] = (uint32_t*)(buf + o_tsl); c.tmp_slot[1] = c.tmp_slot[0] + cap;
+      c.owner[0] = (uint32_t*)(buf + o_own); c.owner[1] = c.owner[0] + rows;
+      EG_HIP(hipMemsetAsync(c.counts, 0, ((size_t)walk_len + 2) * 4, st));
+      EG_HIP(hipMemsetD32Async((hipDeviceptr_t)c.counts, (int)n, 1, st));
+      EG_HIP(hipMemcpyAsync(c.level, nodes_dev, cap * 8, hipMemcpyDeviceToDevice, st));
+      const unsigned grid = (unsigned)((n + block - 1) / block);
+      c.step = 0;
+      hipLaunchKernelGGL(CwSampleKernel, dim3(grid), dim3(block), 0, st, c);
+      for (int32_t s2 = 0; s2 < walk_len; ++s2) {
+        c.step = s2;
+        hipLaunchKernelGGL(CwNumberKernel, dim3(grid), dim3(block), 0, st, c);
+        c.step = s2 + 1;
+        hipLaunchKernelGGL(CwSampleKernel, dim3(grid), dim3(block), 0, st, c);
+      }
+      hipLaunchKernelGGL(CwExpandKernel, dim3(GridFor(n, block)), dim3(block), 0, st, c, nodes_dev,
+                         out_dev);
+      EG_HIP(hipGetLastError());
+      (void)hipFreeAsync(buf, st);
+    } else if (fast) {
       hipLaunchKernelGGL(RandomWalkKernel<true>, dim3(GridFor(n, block)), dim3(block), 0,
                          st, a);
     } else {

@@ -1558,3 +1558,47 @@ def test_fanout_local_dedup_kernel(EA, O, torch_cuda, big_pair, geom):
     finally:
         for k_, v_ in _FL_DEFAULTS.items():
             L.euler_gpu_set_tuning(k_, v_)
+
+
+def test_random_walk_over_merged_walkers(EA, O, torch_cuda, big_pair):
+    """DeepWalk over groups of merged walkers (walk_kernels.hip: CwSampleKernel /
+    CwNumberKernel / CwExpandKernel, tuning key 38): walkers that meet on a node in a step
+    share every later draw (the draw is keyed by node id and step), so the walk is run once
+    per distinct node and expanded.  Same paths as the per-walker kernel and the oracle -
+    duplicate and unknown start nodes, dangling neighbour ids (never merged: they are
+    different ids), rows without the listed type, hashed and identity id maps, one listed
+    type (pivot search) and several (reference loop), walk lengths around the staging size."""
+    torch = torch_cuda
+    from euler_amd import _lib
+    L = _lib.lib()
+    G, OG, ids, rng = big_pair
+    try:
+        for n, walk_len, et in ((5000, 9, [[0, 1, 2, 3]]), (777, 4, [[2]]), (3000, 17, [[1, 3]]),
+                                (2500, 8, [[3]])):
+            et_w = et * walk_len
+            q = np.concatenate([rng.choice(ids, n), rng.choice(ids, 50).repeat(4),
+                                [0, 4242, 2 ** 62]]).astype(np.int64)
+            qt = torch.as_tensor(q).cuda()
+            G.set_seed(41)
+            want = OG.random_walk(41, 500, q, et_w, walk_len, 1.0, 1.0, -9)
+            L.euler_gpu_set_tuning(38, 1)
+            got = G.random_walk(qt, et_w, 1.0, 1.0, -9, call_id=500)
+            L.euler_gpu_set_tuning(38, 0)
+            ref = G.random_walk(qt, et_w, 1.0, 1.0, -9, call_id=500)
+            assert np.array_equal(t2n(got), want), (n, walk_len, et)
+            assert torch.equal(got, ref)
+        # identity ids, hubs: most walkers merge within a few steps
+        p = EA.synth_params(17, 30000, 600000, n_types=1, weighted=True)
+        po = O.SynthParams()
+        for f, _ in po._fields_:
+            setattr(po, f, getattr(p, f))
+        G1, OG1 = EA.Graph.synthetic(p), O.OracleGraph(O.synth_csr(po))
+        q = np.random.default_rng(3).integers(1, 30001, 40000).astype(np.int64)
+        G1.set_seed(8)
+        L.euler_gpu_set_tuning(38, 1)
+        got = G1.random_walk(torch.as_tensor(q).cuda(), [[0]] * 12, 1.0, 1.0, 30001, call_id=3)
+        assert np.array_equal(t2n(got), OG1.random_walk(8, 3, q, [[0]] * 12, 12, 1.0, 1.0, 30001))
+        frac = len(np.unique(t2n(got)[:, -1])) / len(q)
+        assert frac < 0.5, frac          # the premise: walkers do merge on a power-law graph
+    finally:
+        L.euler_gpu_set_tuning(38, 131072)
