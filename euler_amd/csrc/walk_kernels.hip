@@ -408,6 +408,7 @@ __global__ __launch_bounds__(256) void TopKNeighborKernel(const TopKArgs a) {
 // key 38: DeepWalk (p = q = 1) of at least this many walkers runs over groups of merged
 // walkers (CwSampleKernel ...); 0 = never
 thread_local int g_walk_collapse = 131072;
+thread_local int g_walk_grid = 1024;      // key 39: workgroups of its per-step launches (0 = one per 256 walkers)
 
 struct WalkArgs {
   GraphView g;
@@ -505,16 +506,18 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void RandomWalkKernel(const Wal
 // nodes after one step, 11 % after ten, 2 % after forty: a tenth of the walker-steps
 // of a walk are distinct (tools/walk_coincidence.py, profiles/r3_walk_coincidence.json).
 // So the walk is run over GROUPS of merged walkers:
-//   level s holds the nodes of the n[s] groups alive at step s (level 0 = the walkers);
+//   level s holds the nodes of the n[s] groups alive at step s (level 0 = the walkers) as
+//                    16-byte records {node, group at level s + 1};
 //   CwSampleKernel   draws every group's next node and enters the group into the owner
 //                    table at that node's row (plain stores, one survivor per row - the
 //                    trick of the duplicate-root path, sample_kernels.hip);
 //   CwNumberKernel   the survivor of a row is its representative: representatives take
 //                    the numbers of level s + 1 (one atomic per workgroup) and leave
 //                    them in the table;
-//   CwSampleKernel   (next step, same launch) first reads every group's number back:
-//                    map[s][g] = its group at level s + 1;
-//   CwExpandKernel   walker w follows map[0][w], map[1][..], ... and writes its path.
+//   CwSampleKernel   (next step, same launch) first reads every group's number back into
+//                    its record;
+//   CwExpandKernel   walker w follows the records, one 16-byte load per step, and writes its
+//                    path.
 // Counts stay on the device; every launch is sized for the walkers and exits past n[s].
 // ------------------------------------------------------------------------
 struct CwArgs {
@@ -522,8 +525,10 @@ struct CwArgs {
   uint64_t seed;
   const int32_t* edge_types;    // device [walk_len, k]
   uint32_t* counts;             // [walk_len + 2] groups per level
-  uint64_t* level;              // [walk_len + 1][cap] nodes of the groups
-  uint32_t* map;                // [walk_len][cap] group of level s -> group of level s + 1
+  struct Rec { uint64_t id; uint32_t next; uint32_t pad; };
+  Rec* rec;                     // [walk_len + 1][cap]: the node of group g of level s and its
+                                // group at level s + 1 - one 16-byte load per step for the
+                                // walker that follows the chain (CwExpandKernel)
   uint64_t* tmp_id[2];          // [cap] next node of every group (before numbering)
   uint32_t* tmp_slot[2];        // [cap] its owner-table slot
   uint32_t* owner[2];           // [n_rows + 1], alternating between steps
@@ -538,40 +543,54 @@ struct CwArgs {
 
 constexpr uint32_t kCwFlag = 0x80000000u;
 
+__global__ __launch_bounds__(256) void CwInitKernel(const CwArgs a, const int64_t* starts) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.cap; i += stride)
+    a.rec[i].id = (uint64_t)starts[i];
+}
+
 __global__ __launch_bounds__(256, kWavesPerSimd) void CwSampleKernel(const CwArgs a) {
-  const int64_t gidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int32_t s = a.step;
-  // (1) the numbers the previous step's representatives left in its table
-  if (s > 0 && gidx < (int64_t)a.counts[s - 1]) {
-    const int par = (s - 1) & 1;
-    const uint32_t sl = a.tmp_slot[par][gidx];
-    // (a group whose next id has no row was numbered on its own: CwNumberKernel wrote its map)
-    if (sl != (uint32_t)a.g.n_rows) a.map[(int64_t)(s - 1) * a.cap + gidx] = a.owner[par][sl] & ~kCwFlag;
-  }
-  // (2) this step's draw
-  if (s >= a.walk_len || gidx >= (int64_t)a.counts[s]) return;
-  const uint64_t cur = a.level[(int64_t)s * a.cap + gidx];
-  uint64_t id = 0;
-  float w;
-  int32_t t;
-  const int64_t row = FindRow(a.g, cur);
-  if (a.fast) {
-    Segment sg;
-    if (LoadSegment<true>(a.g, row, a.edge_types[s], &sg)) {
-      const Philox4 blk = RngBlock(a.seed, a.call_id + (uint32_t)s, kDomainNeighbor, cur, 0);
-      BlockPivotSample(a.g, sg, UnitFromWords(blk.w[0], blk.w[1]), &id, &w);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n_prev = s > 0 ? (int64_t)a.counts[s - 1] : 0;
+  const int64_t n_cur = s < a.walk_len ? (int64_t)a.counts[s] : 0;
+  // (the grid is a fraction of the walkers: the groups of the later steps are few, and a
+  // launch of 4 096 workgroups that mostly exit costs as much as the work)
+  for (int64_t gidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+       gidx < n_prev || gidx < n_cur; gidx += stride) {
+    // (1) the numbers the previous step's representatives left in its table
+    if (gidx < n_prev) {
+      const int par = (s - 1) & 1;
+      const uint32_t sl = a.tmp_slot[par][gidx];
+      // (a group whose next id has no row was numbered on its own: CwNumberKernel wrote its map)
+      if (sl != (uint32_t)a.g.n_rows)
+        a.rec[(int64_t)(s - 1) * a.cap + gidx].next = a.owner[par][sl] & ~kCwFlag;
     }
-  } else {
-    RowSampler rs;
-    InitRowSampler(rs, a.g, row, a.edge_types + s * a.k, a.k);
-    if (rs.valid) SampleAt(rs, a.seed, a.call_id + (uint32_t)s, cur, 0, &id, &w, &t);
+    // (2) this step's draw
+    if (gidx >= n_cur) continue;
+    const uint64_t cur = a.rec[(int64_t)s * a.cap + gidx].id;
+    uint64_t id = 0;
+    float w;
+    int32_t t;
+    const int64_t row = FindRow(a.g, cur);
+    if (a.fast) {
+      Segment sg;
+      if (LoadSegment<true>(a.g, row, a.edge_types[s], &sg)) {
+        const Philox4 blk = RngBlock(a.seed, a.call_id + (uint32_t)s, kDomainNeighbor, cur, 0);
+        BlockPivotSample(a.g, sg, UnitFromWords(blk.w[0], blk.w[1]), &id, &w);
+      }
+    } else {
+      RowSampler rs;
+      InitRowSampler(rs, a.g, row, a.edge_types + s * a.k, a.k);
+      if (rs.valid) SampleAt(rs, a.seed, a.call_id + (uint32_t)s, cur, 0, &id, &w, &t);
+    }
+    const int par = s & 1;
+    const int64_t nrow = FindRow(a.g, id);
+    const uint32_t slot = nrow < 0 ? (uint32_t)a.g.n_rows : (uint32_t)nrow;
+    a.tmp_id[par][gidx] = id;
+    a.tmp_slot[par][gidx] = slot;
+    a.owner[par][slot] = (uint32_t)gidx;       // benign race: one group naming the row survives
   }
-  const int par = s & 1;
-  const int64_t nrow = FindRow(a.g, id);
-  const uint32_t slot = nrow < 0 ? (uint32_t)a.g.n_rows : (uint32_t)nrow;
-  a.tmp_id[par][gidx] = id;
-  a.tmp_slot[par][gidx] = slot;
-  a.owner[par][slot] = (uint32_t)gidx;       // benign race: one group naming the row survives
 }
 
 // (unknown ids share the slot n_rows: they are "no such node" for every later step, and a
@@ -581,30 +600,33 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void CwSampleKernel(const CwArg
 __global__ __launch_bounds__(256) void CwNumberKernel(const CwArgs a) {
   __shared__ uint32_t s_base;
   __shared__ uint32_t s_wave[4];
-  const int64_t gidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int32_t s = a.step;
   const int par = s & 1;
-  const uint32_t n = a.counts[s];
-  if ((int64_t)blockIdx.x * blockDim.x >= (int64_t)n) return;
-  bool rep = false;
-  uint32_t slot = 0;
-  if (gidx < (int64_t)n) {
-    slot = a.tmp_slot[par][gidx];
-    rep = slot == (uint32_t)a.g.n_rows || a.owner[par][slot] == (uint32_t)gidx;
-  }
-  const uint64_t bal = __ballot(rep);
+  const int64_t n = (int64_t)a.counts[s];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  if (lane == 0) s_wave[wv] = (uint32_t)__popcll(bal);
-  __syncthreads();
-  if (threadIdx.x == 0)
-    s_base = atomicAdd(&a.counts[s + 1], s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3]);
-  __syncthreads();
-  if (rep) {
-    uint32_t nid = s_base + (uint32_t)__popcll(bal & (lane == 0 ? 0ull : (~0ull >> (64 - lane))));
-    for (int x = 0; x < wv; ++x) nid += s_wave[x];
-    a.level[(int64_t)(s + 1) * a.cap + nid] = a.tmp_id[par][gidx];
-    if (slot != (uint32_t)a.g.n_rows) a.owner[par][slot] = nid | kCwFlag;
-    else a.map[(int64_t)s * a.cap + gidx] = nid;
+  for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < n;
+       base += (int64_t)gridDim.x * blockDim.x) {        // block-uniform trip count
+    const int64_t gidx = base + threadIdx.x;
+    bool rep = false;
+    uint32_t slot = 0;
+    if (gidx < n) {
+      slot = a.tmp_slot[par][gidx];
+      rep = slot == (uint32_t)a.g.n_rows || a.owner[par][slot] == (uint32_t)gidx;
+    }
+    const uint64_t bal = __ballot(rep);
+    if (lane == 0) s_wave[wv] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0)
+      s_base = atomicAdd(&a.counts[s + 1], s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3]);
+    __syncthreads();
+    if (rep) {
+      uint32_t nid = s_base + (uint32_t)__popcll(bal & (lane == 0 ? 0ull : (~0ull >> (64 - lane))));
+      for (int x = 0; x < wv; ++x) nid += s_wave[x];
+      a.rec[(int64_t)(s + 1) * a.cap + nid].id = a.tmp_id[par][gidx];
+      if (slot != (uint32_t)a.g.n_rows) a.owner[par][slot] = nid | kCwFlag;
+      else a.rec[(int64_t)s * a.cap + gidx].next = nid;
+    }
+    __syncthreads();             // s_base / s_wave are rewritten by the next round
   }
 }
 
@@ -618,17 +640,21 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void CwExpandKernel(const CwArg
     const int64_t i = tile * 256 + threadIdx.x;
     const bool live = i < a.cap;
     if (live) out[i * L] = starts[i];
-    uint32_t grp = (uint32_t)i;
+    // the walker's group at level 1: level 0 is the walkers themselves
+    uint32_t grp = live ? a.rec[i].next : 0u, nxt_grp = 0;
     for (int32_t s0 = 0; s0 < a.walk_len; s0 += kWalkStage) {
       const int32_t ns = min(kWalkStage, a.walk_len - s0);
       for (int32_t x = 0; x < ns; ++x) {
         const int32_t s = s0 + x;
         uint64_t id = 0;
         if (live) {
-          grp = a.map[(int64_t)s * a.cap + grp] & ~kCwFlag;
-          id = a.level[(int64_t)(s + 1) * a.cap + grp];
+          // grp = this walker's group at level s + 1; its record gives the node and the way on
+          const uint4 q = *reinterpret_cast<const uint4*>(&a.rec[(int64_t)(s + 1) * a.cap + grp]);
+          id = ((uint64_t)q.y << 32) | q.x;
+          nxt_grp = q.z;
         }
         stage[threadIdx.x * (kWalkStage + 1) + x] = id == 0 ? a.default_node : (int64_t)id;
+        grp = nxt_grp;
       }
       __syncthreads();
       for (int32_t e = threadIdx.x; e < 256 * ns; e += 256) {
@@ -1050,22 +1076,21 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
       c.walk_len = walk_len; c.cap = n; c.default_node = default_node; c.fast = fast ? 1 : 0;
       const size_t cap = (size_t)n, rows = (size_t)g->view.n_rows + 1;
       auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-      const size_t o_counts = 0, o_level = al(((size_t)walk_len + 2) * 4),
-                   o_map = o_level + al(((size_t)walk_len + 1) * cap * 8),
-                   o_tid = o_map + al((size_t)walk_len * cap * 4), o_tsl = o_tid + al(2 * cap * 8),
+      const size_t o_counts = 0, o_rec = al(((size_t)walk_len + 2) * 4),
+                   o_tid = o_rec + al(((size_t)walk_len + 1) * cap * 16), o_tsl = o_tid + al(2 * cap * 8),
                    o_own = o_tsl + al(2 * cap * 4), total = o_own + al(2 * rows * 4);
       uint8_t* buf = nullptr;
       EG_HIP(hipMallocAsync((void**)&buf, total, st));
       c.counts = (uint32_t*)(buf + o_counts);
-      c.level = (uint64_t*)(buf + o_level);
-      c.map = (uint32_t*)(buf + o_map);
+      c.rec = (CwArgs::Rec*)(buf + o_rec);
       c.tmp_id[0] = (uint64_t*)(buf + o_tid); c.tmp_id[1] = c.tmp_id[0] + cap;
       c.tmp_slot[0] = (uint32_t*)(buf + o_tsl); c.tmp_slot[1] = c.tmp_slot[0] + cap;
       c.owner[0] = (uint32_t*)(buf + o_own); c.owner[1] = c.owner[0] + rows;
       EG_HIP(hipMemsetAsync(c.counts, 0, ((size_t)walk_len + 2) * 4, st));
       EG_HIP(hipMemsetD32Async((hipDeviceptr_t)c.counts, (int)n, 1, st));
-      EG_HIP(hipMemcpyAsync(c.level, nodes_dev, cap * 8, hipMemcpyDeviceToDevice, st));
-      const unsigned grid = (unsigned)((n + block - 1) / block);
+      hipLaunchKernelGGL(CwInitKernel, dim3(GridFor(n, block)), dim3(block), 0, st, c, nodes_dev);
+      unsigned grid = (unsigned)((n + block - 1) / block);
+      if (g_walk_grid > 0 && grid > (unsigned)g_walk_grid) grid = (unsigned)g_walk_grid;
       c.step = 0;
       hipLaunchKernelGGL(CwSampleKernel, dim3(grid), dim3(block), 0, st, c);
       for (int32_t s2 = 0; s2 < walk_len; ++s2) {
