@@ -70,6 +70,9 @@ struct FanoutLocalArgs {
   uint64_t* id1; float* w1; int32_t* ty1; uint8_t* mask0;
   uint64_t* id2; float* w2; int32_t* ty2; uint8_t* mask1;
   unsigned long long* dbg;  // measurement only (euler_gpu_set_debug_buffer): [tiles][8] phase stamps
+  uint32_t* row_index;      // lean kernel, not null: the (unique rows, index) form - id2 / w2 / ty2
+                            // receive each tile's DISTINCT hop-2 rows (row r0 * c1 + slot), row_index
+                            // the row of every hop-1 sample; nothing is expanded
   int32_t ablate;           // measurement only (tuning key 36), lean kernel: 1 = no hop-2 stores,
                             // 2 = no hop-2 sampling, 4 = no hop-1 stores, 8 = no hop-1 sampling
 };
@@ -753,6 +756,12 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
       }
     }
     WaveSync();
+    if (a.row_index != nullptr) {
+      for (uint32_t b = 0; b < p1; b += 64) {
+        const uint32_t tk = b + lane;
+        if (tk < p1) a.row_index[out1 + tk] = (uint32_t)(out1 + s_slot[tk]);
+      }
+    }
     if (a.dbg != nullptr) t_s[2] = __builtin_readcyclecounter();
     // ---- P3 / P4 per chunk of `cap` slots -------------------------------------------
     for (uint32_t s0 = 0; s0 < n_slots; s0 += cap) {
@@ -794,6 +803,19 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
       }
       WaveSync();
       if (a.dbg != nullptr && s0 == 0) t_s[3] = __builtin_readcyclecounter();
+      // -- P4, (unique rows, index) form: the chunk's rows as they are, once ------------
+      if (a.row_index != nullptr) {
+        const int64_t row0 = (out1 + (int64_t)s0) * (int64_t)c2;     // first sample of row r0 * c1 + s0
+        for (uint32_t b = 0; b < ns * c2; b += 128) {
+          const uint32_t e = b + 2 * lane;
+          if (e < ns * c2) {
+            *reinterpret_cast<fl_u64x2*>(a.id2 + row0 + e) = *reinterpret_cast<const fl_u64x2*>(s_sid + e);
+            *reinterpret_cast<float2*>(a.w2 + row0 + e) = *reinterpret_cast<const float2*>(s_sw + e);
+            const int32_t tv = s_st[a.div_c2(e)];
+            *reinterpret_cast<int2*>(a.ty2 + row0 + e) = make_int2(tv, tv);
+          }
+        }
+      } else
       // -- P4: copy the finished rows to the positions that asked for them ------------
       if (!(a.ablate & 1)) {
       for (uint32_t b = 0; b < p2; b += 128) {
@@ -803,8 +825,9 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
           const uint32_t x = p - gj * c2;
           const uint32_t sl = (uint32_t)s_slot[gj] - s0;
           if (sl < ns) {
-            *reinterpret_cast<fl_u64x2*>(a.id2 + out2 + p) =
-                *reinterpret_cast<const fl_u64x2*>(s_sid + sl * c2 + x);
+            const fl_u64x2 iv = *reinterpret_cast<const fl_u64x2*>(s_sid + sl * c2 + x);
+            if (a.ablate & 256) __builtin_nontemporal_store(iv, reinterpret_cast<fl_u64x2*>(a.id2 + out2 + p));
+            else *reinterpret_cast<fl_u64x2*>(a.id2 + out2 + p) = iv;
             if (!WIDE) {
               *reinterpret_cast<float2*>(a.w2 + out2 + p) =
                   *reinterpret_cast<const float2*>(s_sw + sl * c2 + x);
@@ -833,7 +856,14 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
             if (inb) { wb = *reinterpret_cast<const float2*>(s_sw + slb * c2 + xb); tb = s_st[slb]; }
             float* wp = a.w2 + out2 + p;
             int32_t* tp = a.ty2 + out2 + p;
-            if (ina && inb) {
+            if (ina && inb && (a.ablate & 256)) {
+              typedef float fl_f4 __attribute__((ext_vector_type(4)));
+              typedef int fl_i4 __attribute__((ext_vector_type(4)));
+              const fl_f4 wv4 = {wa.x, wa.y, wb.x, wb.y};
+              const fl_i4 tv4 = {ta, ta, tb, tb};
+              __builtin_nontemporal_store(wv4, reinterpret_cast<fl_f4*>(wp));
+              __builtin_nontemporal_store(tv4, reinterpret_cast<fl_i4*>(tp));
+            } else if (ina && inb) {
               *reinterpret_cast<float4*>(wp) = make_float4(wa.x, wa.y, wb.x, wb.y);
               *reinterpret_cast<int4*>(tp) = make_int4(ta, ta, tb, tb);
             } else if (ina) {

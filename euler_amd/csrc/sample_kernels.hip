@@ -568,6 +568,8 @@ thread_local int g_fl_plain = 2;      // key 34: plain graphs: 2 = the lean kern
 thread_local int g_fl_wps = 5;        // key 35: register budget, waves per SIMD (8, 6 or 5; 5: nothing spilled)
 thread_local int g_fl_ablate = 0;     // key 36: measurement only (FanoutLocalArgs::ablate)
 thread_local int g_k1_typed_pivot = 1;   // key 37: calls with type draws search with the block pivots (0 = reference loop)
+thread_local uint32_t* t_fl_row_index = nullptr;   // set by euler_gpu_sample_fanout_unique around its call
+thread_local int t_fl_took_lean = 0;                // ... and whether the lean kernel served it
 thread_local void* g_fl_debug = nullptr;   // euler_gpu_set_debug_buffer: phase stamps of the lean kernel
 
 // U = 1: one sample per lane.  U = 2 (even `count`): a lane draws the two
@@ -1411,6 +1413,8 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
           f.div_h1.Set((uint32_t)(c1 + 1) / 2); f.div_h2.Set((uint32_t)c2 / 2);
           const size_t llds = (size_t)ll.bytes * wpb;
           f.dbg = (unsigned long long*)g_fl_debug;
+          f.row_index = t_fl_row_index;
+          t_fl_took_lean = 1;
           f.ablate = g_fl_ablate;
           void (*lk)(const FanoutLocalArgs) = nullptr;
           if (v.uniform_w != 0) {
@@ -1728,6 +1732,49 @@ int euler_gpu_sample_fanout_with_feature(const euler_gpu_graph* g, void* stream,
     if (layer < layers) m *= counts_host[layer];
   }
   return rc;
+}
+
+// The 2-hop fanout in the (unique rows, index) form - what the reference's GQL holds before
+// DATA_GATHER expands it (core/kernels/data_gather_op.cc:33-80 over ID_UNIQUE's gather_idx,
+// id_unique_op.cc:35-64): hop 1 as euler_gpu_sample_fanout writes it, and for hop 2 the
+// DISTINCT rows only - rows_*_dev hold n * counts[0] row slots of counts[1] samples each, of
+// which a group of 4 roots fills the first few of ITS 4 * counts[0] (one per distinct child it
+// drew); row_index_dev[i] names the row of hop-1 sample i.  The expanded tensor is
+// rows[row_index] - 44 MB + 13 MB written per metric step instead of 524 MB.  Plain graphs
+// only (the lean kernel of fanout_local.h: one edge-type group, identity ids, no id 0, even
+// counts[1]); EULER_GPU_EINVAL otherwise - the caller falls back to euler_gpu_sample_fanout.
+int euler_gpu_sample_fanout_unique(const euler_gpu_graph* g, void* stream, uint64_t seed,
+                                   uint32_t call_id, const uint64_t* roots_dev, int64_t n,
+                                   const int32_t* edge_types_host, const int32_t* counts_host,
+                                   int64_t default_node, uint64_t* out_id1_dev, float* out_w1_dev,
+                                   int32_t* out_t1_dev, uint32_t* row_index_dev,
+                                   uint64_t* rows_id_dev, float* rows_w_dev, int32_t* rows_t_dev,
+                                   void* workspace_dev) {
+  if (!g) return Fail(EULER_GPU_ENOGRAPH, "sample_fanout_unique: null graph");
+  if (n < 0 || !counts_host || !edge_types_host || (n > 0 && (!roots_dev || !out_id1_dev ||
+      !out_w1_dev || !out_t1_dev || !row_index_dev || !rows_id_dev || !rows_w_dev || !rows_t_dev ||
+      !workspace_dev)))
+    return Fail(EULER_GPU_EINVAL, "sample_fanout_unique: bad arguments");
+  if (n == 0) return EULER_GPU_OK;
+  if (n * (int64_t)counts_host[0] >= ((int64_t)1 << 32))
+    return Fail(EULER_GPU_EINVAL, "sample_fanout_unique: more than 2^32 row slots");
+  uint64_t* ids[2] = {out_id1_dev, rows_id_dev};
+  float* ws[2] = {out_w1_dev, rows_w_dev};
+  int32_t* ts[2] = {out_t1_dev, rows_t_dev};
+  const int save_min = g_fl_min_roots, save_local = g_fanout_local;
+  g_fl_min_roots = 0; g_fanout_local = 2;          // this form exists in the one-kernel path only
+  t_fl_row_index = row_index_dev;
+  t_fl_took_lean = 0;
+  const int rc = RunFanout(g, (hipStream_t)stream, seed, call_id, roots_dev, n, edge_types_host, 1,
+                           counts_host, 2, default_node, ids, ws, ts, workspace_dev, nullptr,
+                           nullptr);
+  t_fl_row_index = nullptr;
+  g_fl_min_roots = save_min; g_fanout_local = save_local;
+  if (rc != EULER_GPU_OK) return rc;
+  if (!t_fl_took_lean)
+    return Fail(EULER_GPU_EINVAL, "sample_fanout_unique: this graph / fanout is not served by the "
+                                  "one-kernel path (the outputs hold the dense form's first rows)");
+  return EULER_GPU_OK;
 }
 
 int euler_gpu_time_sample_neighbor(const euler_gpu_graph* g, void* stream,

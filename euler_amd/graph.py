@@ -336,6 +336,37 @@ class Graph:
                 cnt_p, layers, int(default_node), pn, pw, pt, _ptr(ws)))
         return [nodes] + outs_n, outs_w, outs_t
 
+    def sample_fanout_unique(self, nodes, edge_types, counts, default_node=-1, call_id=None):
+        """The 2-hop fanout in the (unique rows, index) form (euler_gpu_sample_fanout_unique):
+        returns (hop-1 ids [n, c1], weights, types, row_index [n * c1] int64, rows_id
+        [n * c1, c2], rows_w, rows_t) with hop-2 tensor = rows[row_index]; only the rows
+        row_index names are written.  Raises EulerGpuError(EINVAL) for graphs / fanouts the
+        one-kernel path does not serve."""
+        nodes = _as_i64_cuda(nodes, self.device).reshape(-1)
+        assert len(counts) == 2
+        et = np.asarray(edge_types, dtype=np.int32).reshape(2, -1)
+        assert et.shape[1] == 1, "one listed edge type per hop"
+        et, et_p, _ = _i32_array(et)
+        cnt, cnt_p, _ = _i32_array(counts)
+        n, c1, c2 = nodes.numel(), int(counts[0]), int(counts[1])
+        dev = self.device
+        id1 = torch.empty((n, c1), dtype=torch.int64, device=dev)
+        w1 = torch.empty((n, c1), dtype=torch.float32, device=dev)
+        t1 = torch.empty((n, c1), dtype=torch.int32, device=dev)
+        idx = torch.empty(n * c1, dtype=torch.int32, device=dev)
+        rid = torch.empty((n * c1, c2), dtype=torch.int64, device=dev)
+        rw = torch.empty((n * c1, c2), dtype=torch.float32, device=dev)
+        rt = torch.empty((n * c1, c2), dtype=torch.int32, device=dev)
+        ws_bytes = lib().euler_gpu_sample_fanout_workspace(n, cnt_p, 2)
+        ws = torch.empty(max(int(ws_bytes), 16), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            check(lib().euler_gpu_sample_fanout_unique(
+                self._h, _stream(), self.seed, self._take_call_ids(2, call_id), _ptr(nodes), n,
+                et_p, cnt_p, int(default_node), _ptr(id1), _ptr(w1), _ptr(t1), _ptr(idx),
+                _ptr(rid), _ptr(rw), _ptr(rt), _ptr(ws)))
+        # uint32 row numbers read as int64 for indexing
+        return id1, w1, t1, idx.to(torch.int64) & 0xFFFFFFFF, rid, rw, rt
+
     def sample_fanout_with_feature(self, nodes, edge_types, counts, default_node,
                                    feature_ids, dimensions, call_id=None):
         """tf_euler sample_fanout_with_feature, dense part (euler_ops/neighbor_ops.py:49-70

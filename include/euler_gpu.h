@@ -875,6 +875,22 @@ int euler_gpu_time_sample_neighbor_phases(const euler_gpu_graph* g, void* stream
                                           float* out_w_dev, int32_t* out_t_dev,
                                           int32_t iters, float* mean_ms3_host,
                                           int64_t* n_unique_host);
+/* The 2-hop fanout of single listed types in the (unique rows, index) form - the GQL result
+ * before DATA_GATHER (core/kernels/data_gather_op.cc:33-80; ID_UNIQUE: id_unique_op.cc:35-64):
+ * hop 1 dense ([n, counts[0]] as euler_gpu_sample_fanout), hop 2 as DISTINCT rows:
+ * rows_{id,w,t}_dev are [n * counts[0], counts[1]] row slots, row_index_dev [n * counts[0]]
+ * (uint32) names the row of every hop-1 sample - the dense hop-2 tensors are
+ * rows[row_index].  Roots are processed in groups of 4 (tuning key 28); a group fills the
+ * first D of its 4 * counts[0] row slots, D = the distinct children it drew, the rest stay
+ * untouched.  Plain graphs only (one edge-type group per node, identity id map, no neighbour
+ * id 0, counts[1] even): EULER_GPU_EINVAL otherwise.  workspace: as euler_gpu_sample_fanout. */
+int euler_gpu_sample_fanout_unique(const euler_gpu_graph* g, void* stream, uint64_t seed,
+                                   uint32_t call_id, const uint64_t* roots_dev, int64_t n,
+                                   const int32_t* edge_types_host, const int32_t* counts_host,
+                                   int64_t default_node, uint64_t* out_id1_dev, float* out_w1_dev,
+                                   int32_t* out_t1_dev, uint32_t* row_index_dev,
+                                   uint64_t* rows_id_dev, float* rows_w_dev, int32_t* rows_t_dev,
+                                   void* workspace_dev);
 /* TF SampleFanoutWithFeature (tf_euler/kernels/sample_fanout_with_feature_op.cc:135-233;
  * op tf_euler/ops/neighbor_ops.cc:282-321): euler_gpu_sample_fanout plus the dense
  * features of every layer's nodes (layer 0 = the roots), enqueued back to back on `stream`

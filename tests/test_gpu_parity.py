@@ -1602,3 +1602,38 @@ def test_random_walk_over_merged_walkers(EA, O, torch_cuda, big_pair):
         assert frac < 0.5, frac          # the premise: walkers do merge on a power-law graph
     finally:
         L.euler_gpu_set_tuning(38, 131072)
+
+
+def test_fanout_unique_rows_and_index(EA, O, torch_cuda, big_pair):
+    """euler_gpu_sample_fanout_unique: the GQL result before DATA_GATHER - hop 2 as the
+    distinct rows of every group of roots plus the row of each hop-1 sample.  rows[row_index]
+    must be the dense hop-2 tensors of sample_fanout (== the oracle), weighted and uniform
+    plain graphs, odd batch sizes, hub roots (several passes of slots); other graphs
+    answer EINVAL (the caller uses the dense form)."""
+    torch = torch_cuda
+    from euler_amd import _lib
+    for weighted in (True, False):
+        p = EA.synth_params(977, 20000, 260000, n_types=1, weighted=weighted)
+        po = O.SynthParams()
+        for f, _ in po._fields_:
+            setattr(po, f, getattr(p, f))
+        G, OG = EA.Graph.synthetic(p), O.OracleGraph(O.synth_csr(po))
+        q = np.concatenate([np.random.default_rng(5).integers(1, 20001, 5003), [0, 20001, 1, 1]])
+        q = q.astype(np.int64)
+        qt = torch.as_tensor(q).cuda()
+        G.set_seed(3)
+        for counts in ([25, 10], [3, 4], [7, 2]):
+            on, ow, ot = OG.sample_fanout(3, 12, q, [[0], [0]], counts, 20001)
+            id1, w1, t1, idx, rid, rw, rt = G.sample_fanout_unique(qt, [[0], [0]], counts, 20001,
+                                                                   call_id=12)
+            assert np.array_equal(t2n(id1).reshape(-1), on[0]) and np.array_equal(t2n(w1).reshape(-1), ow[0])
+            assert np.array_equal(t2n(t1).reshape(-1), ot[0])
+            assert np.array_equal(t2n(rid[idx]).reshape(-1), on[1]), (weighted, counts)
+            assert np.array_equal(t2n(rw[idx]).reshape(-1), ow[1])
+            assert np.array_equal(t2n(rt[idx]).reshape(-1), ot[1])
+            # the point of the form: far fewer rows than positions
+            assert len(np.unique(t2n(idx))) < 0.8 * idx.numel()
+    G4, _OG4, ids4, rng = big_pair          # four edge-type groups: not served
+    with pytest.raises(_lib.EulerGpuError):
+        G4.sample_fanout_unique(torch.as_tensor(rng.choice(ids4, 100).astype(np.int64)).cuda(),
+                                [[0], [1]], [4, 2], -1, call_id=1)
