@@ -761,6 +761,58 @@ def run_products_leg(args):
     return res
 
 
+def run_unique_leg(args, G):
+    """The metric step in the (unique rows, index) form (euler_gpu_sample_fanout_unique): the
+    GQL result before DATA_GATHER - hop 2 as distinct rows + the row of every hop-1 sample;
+    the whole result is compared with the dense form on the device."""
+    N, B = args.nodes, args.batch
+    gen = torch.Generator(device="cuda"); gen.manual_seed(99)
+    r = torch.randint(1, N + 1, (B,), generator=gen, device="cuda", dtype=torch.int64)
+    et = [[0], [0]]
+    id1, w1, t1, idx, rid, rw, rt = G.sample_fanout_unique(r, et, FANOUT, N + 1, call_id=8)
+    dn, dw, dt = G.sample_fanout(r, et, FANOUT, N + 1, call_id=8)
+    assert torch.equal(id1.reshape(-1), dn[1]) and torch.equal(rid[idx].reshape(-1), dn[2])
+    assert torch.equal(rw[idx].reshape(-1), dw[1]) and torch.equal(rt[idx].reshape(-1), dt[1])
+    rows = int(torch.unique(idx).numel())
+    del dn, dw, dt
+    ms = _events(lambda: G.sample_fanout_unique(r, et, FANOUT, N + 1, call_id=8), 10)
+    edges = B * (FANOUT[0] + FANOUT[0] * FANOUT[1])
+    return {"value": edges / (ms * 1e-3), "unit": "sampled edges/s (as rows + index)",
+            "ms_per_step": round(ms, 4), "roofline_frac": None, "parity_checked": int(edges),
+            "distinct_rows": rows, "positions": int(idx.numel()),
+            "workload": "the metric step, hop 2 left as %d distinct rows + a row index per hop-1 sample "
+                        "(one stream, output buffers allocated per call)" % rows}
+
+
+def run_sage_leg(args, G):
+    """SageDataFlow block construction (euler_gpu_sage_blocks: sampler + first-occurrence
+    unique + res_n_id + edge_index per hop, one enqueue) on the metric graph: blocks/s; the
+    blocks are compared with the op-by-op composition of the base class."""
+    from euler_amd.dataflow import SageDataFlow
+    N = args.nodes
+    B = 16384
+    gen = torch.Generator(device="cuda"); gen.manual_seed(77)
+    r = torch.randint(1, N + 1, (B,), generator=gen, device="cuda", dtype=torch.int64)
+    flow = SageDataFlow(G, FANOUT, [[0], [0]], add_self_loops=True, max_id=N)
+    G.set_seed(GRAPH_SEED, 4000)
+    df = flow(r)
+    flow.fused = False
+    G.set_seed(GRAPH_SEED, 4000)
+    df2 = flow(r)
+    flow.fused = True
+    n_edges = 0
+    for b1, b2 in zip(df, df2):
+        assert torch.equal(b1.n_id, b2.n_id) and torch.equal(b1.res_n_id, b2.res_n_id)
+        assert torch.equal(b1.edge_index, b2.edge_index)
+        n_edges += int(b1.edge_index.shape[1])
+    ms = _events(lambda: flow(r), 10)
+    return {"value": 1e3 / ms, "unit": "minibatches (2 blocks each)/s", "ms_per_step": round(ms, 4),
+            "roofline_frac": None, "parity_checked": n_edges,
+            "block_edges_per_s": n_edges / (ms * 1e-3),
+            "workload": "SageDataFlow, %d roots, fanouts %s, self loops: %d block edges per minibatch; "
+                        "one host read (the layer sizes) per minibatch" % (B, FANOUT, n_edges)}
+
+
 def secondary_legs(args, G, p_g):
     """BASELINE configs[1], [3], [4] as short legs of the default run (rank 0, one GPU), each
     with a spot check against the oracle at bench scale: {value, ms_per_step, roofline_frac,
@@ -783,6 +835,11 @@ def secondary_legs(args, G, p_g):
                                        % (n2["walkers"], n2["walk_len"])}
     except Exception as e:          # a side measurement must not fail the bench
         sec["deepwalk"] = {"error": repr(e)}
+    for name_, fn_ in (("fanout_unique_rows", run_unique_leg), ("sage_blocks", run_sage_leg)):
+        try:
+            sec[name_] = fn_(args, G)
+        except Exception as e:
+            sec[name_] = {"error": repr(e)}
     try:
         sec["products"] = run_products_leg(args)
     except Exception as e:
