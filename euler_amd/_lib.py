@@ -190,6 +190,10 @@ SIGNATURES = {
                                                        i32p, i32p, C.c_int32, C.POINTER(vp)]),
     "euler_gpu_sample_fanout_unique": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp, C.c_int64, i32p, i32p,
                                                  C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "euler_gpu_full_blocks_workspace": (C.c_size_t, [C.c_int64, C.POINTER(C.c_int64), C.c_int32]),
+    "euler_gpu_full_blocks": (C.c_int, [vp, vp, vp, C.c_int64, i32p, C.c_int32, C.c_int32, C.c_int32,
+                                        C.POINTER(C.c_int64), vp, C.POINTER(vp), C.POINTER(vp),
+                                        C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp]),
     "euler_gpu_time_sample_fanout": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_int64,
                                                i32p, C.c_int32, i32p, C.c_int32,
                                                C.c_int64, C.POINTER(vp),

@@ -48,6 +48,9 @@ struct FlowHop {
   const uint64_t* n_id;       // [cap_n] nodes of the previous layer (valid: cnt)
   const uint32_t* cnt;        // device-side count of n_id
   uint32_t* cnt_out;          // device-side count of the new layer
+  const uint32_t* m_nb_dev;   // not null: the length of nb lives on the device (full-neighbour
+                              // flows: rows of different lengths) instead of being cnt * count
+  const int32_t* nb_src;      // ... and the source (index into n_id) of every entry of nb
   int32_t count;
   int32_t self_loops;
   int64_t cap_m;              // cap_n * (count + 1): worst-case length of V
@@ -61,13 +64,17 @@ struct FlowHop {
   int64_t* res_n_id;          // [cap_n]
 };
 
+__device__ __forceinline__ int64_t FlowNbLen(const FlowHop& h, int64_t cnt) {
+  return h.m_nb_dev != nullptr ? (int64_t)(*h.m_nb_dev) : cnt * h.count;
+}
+
 __device__ __forceinline__ uint64_t FlowElem(const FlowHop& h, int64_t i, int64_t m_nb) {
   return i < m_nb ? h.nb[i] : h.n_id[i - m_nb];
 }
 
 __global__ __launch_bounds__(256) void FlowInsertKernel(const FlowHop h) {
   const int64_t cnt = (int64_t)(*h.cnt);
-  const int64_t m_nb = cnt * h.count, m = m_nb + cnt;
+  const int64_t m_nb = FlowNbLen(h, cnt), m = m_nb + cnt;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
     const uint64_t id = FlowElem(h, i, m_nb);
@@ -95,7 +102,7 @@ __global__ __launch_bounds__(256) void FlowInsertKernel(const FlowHop h) {
 // scan needs no device-side length
 __global__ __launch_bounds__(256) void FlowFlagKernel(const FlowHop h) {
   const int64_t cnt = (int64_t)(*h.cnt);
-  const int64_t m = cnt * (h.count + 1);
+  const int64_t m = FlowNbLen(h, cnt) + cnt;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= h.cap_m; i += stride)
     h.is_first[i] = (i < m && h.t.minpos[h.slot_of[i]] == (uint32_t)i) ? 1u : 0u;
@@ -103,7 +110,7 @@ __global__ __launch_bounds__(256) void FlowFlagKernel(const FlowHop h) {
 
 __global__ __launch_bounds__(256) void FlowEmitKernel(const FlowHop h) {
   const int64_t cnt = (int64_t)(*h.cnt);
-  const int64_t m_nb = cnt * h.count, m = m_nb + cnt;
+  const int64_t m_nb = FlowNbLen(h, cnt), m = m_nb + cnt;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (first == 0) *h.cnt_out = h.rank[h.cap_m];          // exclusive scan: the total
@@ -117,13 +124,13 @@ __global__ __launch_bounds__(256) void FlowEmitKernel(const FlowHop h) {
 
 __global__ __launch_bounds__(256) void FlowIndexKernel(const FlowHop h) {
   const int64_t cnt = (int64_t)(*h.cnt);
-  const int64_t m_nb = cnt * h.count, m = m_nb + cnt;
+  const int64_t m_nb = FlowNbLen(h, cnt), m = m_nb + cnt;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
     const int64_t dst = (int64_t)h.t.rank[h.slot_of[i]];
     if (i < m_nb) {
       h.inv[i] = dst;
-      h.edge_src[i] = i / h.count;
+      h.edge_src[i] = h.nb_src != nullptr ? (int64_t)h.nb_src[i] : i / h.count;
     } else {
       h.res_n_id[i - m_nb] = dst;
       if (h.self_loops) {
@@ -131,6 +138,81 @@ __global__ __launch_bounds__(256) void FlowIndexKernel(const FlowHop h) {
         h.edge_src[i] = i - m_nb;        // last_idx = arange: node j keeps an edge to itself
       }
     }
+  }
+}
+
+// ---- full-neighbour flows (GCNDataFlow, RelationDataFlow) ------------------------------
+// tf_euler/python/dataflow/gcn_dataflow.py:33-47, relation_dataflow.py:30-72: every hop takes
+// ALL neighbours (of the listed edge types) of the nodes seen so far, then the same
+// tf.unique / res_n_id / edge_index as above.  Rows have different lengths, so the length of
+// the hop's neighbour list is a second device-side count; the caller gives the capacity of
+// the edge arrays (a hop that would overflow it sets the overflow word and produces no
+// edges: the host sees it in the one read of the counts and takes the op-by-op path).
+struct FlowFull {
+  GraphView g;
+  const uint64_t* n_id;       // [cap_n]
+  const uint32_t* cnt;
+  int32_t k;
+  int32_t et[kMaxListedTypes];
+  uint32_t* lens;             // [cap_n + 1] row lengths (zeros past cnt), then their exclusive scan
+  uint32_t* offs;             // [cap_n + 1]
+  uint32_t* m_nb;             // out: the hop's neighbour count
+  uint32_t* overflow;         // set to 1 when m_nb > cap_e
+  int64_t cap_n, cap_e;
+  uint64_t* nb; int32_t* nb_src; int32_t* nb_t;
+};
+
+__device__ __forceinline__ uint32_t FlowRowLen(const FlowFull& f, int64_t row) {
+  if (row < 0) return 0;
+  const RowMeta m = LoadRowMeta(f.g, row);
+  uint32_t len = 0;
+  for (int32_t x = 0; x < f.k; ++x) {
+    const int32_t t = f.et[x];
+    if (t < 0 || t >= f.g.T) continue;
+    len += (uint32_t)(m.type_end[t] - (t == 0 ? 0 : m.type_end[t - 1]));
+  }
+  return len;
+}
+
+__global__ __launch_bounds__(256) void FlowFullCountKernel(const FlowFull f) {
+  const int64_t cnt = (int64_t)(*f.cnt);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= f.cap_n; i += stride)
+    f.lens[i] = i < cnt ? FlowRowLen(f, FindRow(f.g, f.n_id[i])) : 0u;
+}
+
+__global__ void FlowFullTotalKernel(const FlowFull f) {
+  const uint32_t total = f.offs[f.cap_n];       // exclusive scan over cap_n + 1 entries
+  if ((int64_t)total > f.cap_e) { *f.overflow = 1u; *f.m_nb = 0u; }
+  else *f.m_nb = total;
+}
+
+// one lane per output entry: its row is the last i with offs[i] <= e
+__global__ __launch_bounds__(256) void FlowFullFillKernel(const FlowFull f) {
+  const int64_t total = (int64_t)(*f.m_nb);
+  const int64_t cnt = (int64_t)(*f.cnt);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    int64_t lo = 0, hi = cnt;                   // offs[lo] <= e < offs[hi]
+    while (hi - lo > 1) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((int64_t)f.offs[mid] <= e) lo = mid; else hi = mid;
+    }
+    int32_t p = (int32_t)(e - (int64_t)f.offs[lo]);      // position in the row's listed order
+    const RowMeta m = LoadRowMeta(f.g, FindRow(f.g, f.n_id[lo]));
+    uint64_t id = 0;
+    int32_t ty = 0;
+    for (int32_t x = 0; x < f.k; ++x) {
+      const int32_t t = f.et[x];
+      if (t < 0 || t >= f.g.T) continue;
+      const int32_t b = t == 0 ? 0 : m.type_end[t - 1];
+      const int32_t len = m.type_end[t] - b;
+      if (p < len) { id = f.g.nbr[m.row_ptr + b + p]; ty = t; break; }
+      p -= len;
+    }
+    f.nb[e] = id;
+    f.nb_src[e] = (int32_t)lo;
+    if (f.nb_t != nullptr) f.nb_t[e] = ty;
   }
 }
 
@@ -237,6 +319,118 @@ int euler_gpu_sage_blocks(const euler_gpu_graph* g, void* stream, uint64_t seed,
                                             (int)(cap_m + 1), st));
     hipLaunchKernelGGL(FlowEmitKernel, dim3(grid), dim3(block), 0, st, f);
     // 3. res_n_id, edge_index
+    hipLaunchKernelGGL(FlowIndexKernel, dim3(grid), dim3(block), 0, st, f);
+    EG_HIP(hipGetLastError());
+    n_id = n_id_dev[h];
+  }
+  return EULER_GPU_OK;
+}
+
+static void FullCaps(int64_t n, const int64_t* edge_caps, int32_t h, int64_t* cap_n, int64_t* cap_e) {
+  int64_t c = n;
+  for (int32_t i = 0; i < h; ++i) c += edge_caps[i];
+  *cap_n = c; *cap_e = edge_caps[h];
+}
+
+size_t euler_gpu_full_blocks_workspace(int64_t n, const int64_t* edge_caps_host, int32_t layers) {
+  size_t best = 0;
+  for (int32_t h = 0; h < layers; ++h) {
+    int64_t cap_n, cap_e;
+    FullCaps(n, edge_caps_host, h, &cap_n, &cap_e);
+    const int64_t cap_m = cap_e + cap_n;
+    uint64_t tcap = 64;
+    while (tcap < (uint64_t)cap_m * 2) tcap <<= 1;
+    size_t scan_bytes = 0, scan2 = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t*)nullptr,
+                                           (uint32_t*)nullptr, (int)(cap_m + 1), nullptr);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan2, (uint32_t*)nullptr,
+                                           (uint32_t*)nullptr, (int)(cap_n + 1), nullptr);
+    if (scan2 > scan_bytes) scan_bytes = scan2;
+    const size_t b = Al(((size_t)cap_n + 1) * 4) * 2 + Al((size_t)cap_e * 8) + Al((size_t)cap_e * 4)
+                     + Al((tcap + 1) * 8) + Al((tcap + 1) * 4) * 2 + Al((size_t)cap_m * 4)
+                     + Al(((size_t)cap_m + 1) * 4) * 2 + Al(scan_bytes) + 512;
+    if (b > best) best = b;
+  }
+  return best + 256;
+}
+
+// counts_dev: [layers + 1] nodes per layer, then [layers] edges per hop (without the self
+// loops), then one overflow word.  Layer h + 1 holds at most cap_n[h] + edge_caps[h] nodes.
+int euler_gpu_full_blocks(const euler_gpu_graph* g, void* stream, const uint64_t* roots_dev,
+                          int64_t n, const int32_t* edge_types_host, int32_t k, int32_t layers,
+                          int32_t add_self_loops, const int64_t* edge_caps_host,
+                          void* workspace_dev, uint64_t* const* n_id_dev,
+                          int64_t* const* res_n_id_dev, int64_t* const* edge_src_dev,
+                          int64_t* const* edge_dst_dev, int32_t* const* e_type_dev,
+                          uint32_t* counts_dev) {
+  if (!g) return Fail(EULER_GPU_ENOGRAPH, "full_blocks: null graph");
+  if (n < 0 || layers <= 0 || layers > 8 || k < 0 || k > kMaxListedTypes || !edge_caps_host ||
+      !n_id_dev || !res_n_id_dev || !edge_src_dev || !edge_dst_dev || !counts_dev ||
+      (k > 0 && !edge_types_host) || (n > 0 && (!roots_dev || !workspace_dev)))
+    return Fail(EULER_GPU_EINVAL, "full_blocks: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  EG_HIP(hipMemsetAsync(counts_dev, 0, sizeof(uint32_t) * (2 * layers + 2), st));
+  if (n == 0) return EULER_GPU_OK;
+  {
+    int64_t cap_n, cap_e;
+    FullCaps(n, edge_caps_host, layers - 1, &cap_n, &cap_e);
+    if (cap_n + cap_e >= ((int64_t)1 << 31))
+      return Fail(EULER_GPU_EINVAL, "full_blocks: capacities >= 2^31");
+  }
+  hipLaunchKernelGGL(FlowInitKernel, dim3(1), dim3(1), 0, st, counts_dev, (uint32_t)n);
+  const uint64_t* n_id = roots_dev;
+  uint32_t* overflow = counts_dev + 2 * layers + 1;
+  const int block = 256;
+  for (int32_t h = 0; h < layers; ++h) {
+    int64_t cap_n, cap_e;
+    FullCaps(n, edge_caps_host, h, &cap_n, &cap_e);
+    if (cap_e < 0) return Fail(EULER_GPU_EINVAL, "full_blocks: negative capacity");
+    const int64_t cap_m = cap_e + cap_n;
+    uint64_t tcap = 64;
+    while (tcap < (uint64_t)cap_m * 2) tcap <<= 1;
+    uint8_t* p = (uint8_t*)workspace_dev;
+    FlowFull ff{};
+    ff.g = g->view; ff.n_id = n_id; ff.cnt = counts_dev + h; ff.k = k;
+    for (int32_t x = 0; x < k; ++x) ff.et[x] = edge_types_host[(size_t)h * k + x];
+    ff.lens = (uint32_t*)p;             p += Al(((size_t)cap_n + 1) * 4);
+    ff.offs = (uint32_t*)p;             p += Al(((size_t)cap_n + 1) * 4);
+    ff.nb = (uint64_t*)p;               p += Al((size_t)cap_e * 8);
+    ff.nb_src = (int32_t*)p;            p += Al((size_t)cap_e * 4);
+    ff.nb_t = e_type_dev != nullptr ? e_type_dev[h] : nullptr;
+    ff.m_nb = counts_dev + layers + 1 + h; ff.overflow = overflow;
+    ff.cap_n = cap_n; ff.cap_e = cap_e;
+    FlowHop f{};
+    f.t.keys = (unsigned long long*)p;  p += Al((tcap + 1) * 8);
+    f.t.minpos = (uint32_t*)p;          p += Al((tcap + 1) * 4);
+    f.t.rank = (int32_t*)p;             p += Al((tcap + 1) * 4);
+    f.t.mask = tcap - 1;
+    f.slot_of = (uint32_t*)p;           p += Al((size_t)cap_m * 4);
+    f.is_first = (uint32_t*)p;          p += Al(((size_t)cap_m + 1) * 4);
+    f.rank = (uint32_t*)p;              p += Al(((size_t)cap_m + 1) * 4);
+    void* scan_tmp = p;
+    size_t scan_bytes = 0, scan2 = 0;
+    EG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, f.is_first, f.rank, (int)(cap_m + 1), st));
+    EG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan2, ff.lens, ff.offs, (int)(cap_n + 1), st));
+    // 1. the rows of the layer's nodes: lengths -> offsets -> the hop's neighbour list
+    hipLaunchKernelGGL(FlowFullCountKernel, dim3(GridFor(cap_n + 1, block)), dim3(block), 0, st, ff);
+    EG_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan2, ff.lens, ff.offs, (int)(cap_n + 1), st));
+    hipLaunchKernelGGL(FlowFullTotalKernel, dim3(1), dim3(1), 0, st, ff);
+    if (cap_e > 0)
+      hipLaunchKernelGGL(FlowFullFillKernel, dim3(GridFor(cap_e, block)), dim3(block), 0, st, ff);
+    // 2. first-occurrence unique of [nb | n_id], 3. res_n_id / edge_index - the kernels of
+    // the Sage flow with the list length and the edge sources read from the device
+    EG_HIP(hipMemsetAsync(f.t.keys, 0xFF, (tcap + 1) * 8, st));
+    EG_HIP(hipMemsetAsync(f.t.minpos, 0xFF, (tcap + 1) * 4, st));
+    f.nb = ff.nb; f.n_id = n_id; f.cnt = counts_dev + h; f.cnt_out = counts_dev + h + 1;
+    f.m_nb_dev = ff.m_nb; f.nb_src = ff.nb_src;
+    f.count = 0; f.self_loops = add_self_loops ? 1 : 0; f.cap_m = cap_m;
+    f.new_n_id = n_id_dev[h]; f.inv = edge_dst_dev[h]; f.edge_src = edge_src_dev[h];
+    f.res_n_id = res_n_id_dev[h];
+    const int grid = GridFor(cap_m + 1, block);
+    hipLaunchKernelGGL(FlowInsertKernel, dim3(grid), dim3(block), 0, st, f);
+    hipLaunchKernelGGL(FlowFlagKernel, dim3(grid), dim3(block), 0, st, f);
+    EG_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, f.is_first, f.rank, (int)(cap_m + 1), st));
+    hipLaunchKernelGGL(FlowEmitKernel, dim3(grid), dim3(block), 0, st, f);
     hipLaunchKernelGGL(FlowIndexKernel, dim3(grid), dim3(block), 0, st, f);
     EG_HIP(hipGetLastError());
     n_id = n_id_dev[h];

@@ -153,7 +153,49 @@ def _full_neighbor_coo(graph, n_id, edge_types):
     return ids.reshape(-1), src, t.reshape(-1)
 
 
-class GCNDataFlow(UniqueDataFlow):
+class _FullBlocksMixin(object):
+    """One enqueue for all hops of a full-neighbour flow (Graph.full_blocks ->
+    euler_gpu_full_blocks): the row lengths are data, so every hop's edge list gets a
+    capacity - an estimate from the graph's mean degree at first, then what the last
+    minibatches needed with headroom; a minibatch that overflows it is redone op by op
+    (one host round trip per hop, as TensorFlow's dynamic shapes) and raises the estimate."""
+
+    _growth = None
+
+    def _edge_caps(self, n):
+        g = self.graph
+        if self._growth is None:
+            mean_deg = max(1.0, g.num_edges / max(1, g.num_nodes))
+            self._growth = [4.0 * mean_deg] * len(self.metapath)
+        caps, nodes = [], float(n)
+        for gr in self._growth:
+            e = int(nodes * gr) + 1024
+            caps.append(e)
+            nodes += e
+        return caps
+
+    def _full_blocks(self, n_id, self_loops, with_types):
+        if not getattr(self, "fused", True) or len({len(m) for m in self.metapath}) != 1:
+            return None
+        n_id = n_id.reshape(-1)
+        caps = self._edge_caps(n_id.numel())
+        try:
+            blocks, cnt = self.graph.full_blocks(n_id, self.metapath, caps, self_loops, with_types)
+        except EulerGpuError as e:
+            if e.code != EINVAL:
+                raise
+            return None
+        L = len(self.metapath)
+        # edges per node of the layer, as seen: the next estimate (with headroom)
+        for h in range(L):
+            seen = cnt[L + 1 + h] / max(1, cnt[h])
+            if blocks is None and cnt[L + 1 + h] == 0 and cnt[h] > 0:
+                seen = 4.0 * self._growth[h]           # the hop that overflowed
+            self._growth[h] = max(1.0, 0.5 * self._growth[h], 2.0 * seen)
+        return blocks
+
+
+class GCNDataFlow(_FullBlocksMixin, UniqueDataFlow):
     """gcn_dataflow.py:24-47: every hop takes ALL neighbours (of the listed edge
     types) of the nodes seen so far."""
 
@@ -161,6 +203,15 @@ class GCNDataFlow(UniqueDataFlow):
         super(GCNDataFlow, self).__init__(len(metapath), add_self_loops)
         self.graph = graph
         self.metapath = metapath
+
+    def produce_subgraph(self, n_id):
+        blocks = self._full_blocks(n_id, self.add_self_loops, False)
+        if blocks is None:
+            return super(GCNDataFlow, self).produce_subgraph(n_id)
+        data_flow = DataFlow(n_id.reshape(-1))
+        for new_n_id, res_n_id, edge_src, edge_dst, _t in blocks:
+            data_flow.append(new_n_id, res_n_id, None, torch.stack([edge_src, edge_dst], 0))
+        return data_flow
 
     def get_neighbors(self, n_id):
         neighbors, neighbor_src = [], []
@@ -173,7 +224,7 @@ class GCNDataFlow(UniqueDataFlow):
         return neighbors, neighbor_src
 
 
-class RelationDataFlow(object):
+class RelationDataFlow(_FullBlocksMixin):
     """relation_dataflow.py:24-75 (RGCN): full neighbours per hop, the edge TYPE
     of every edge as the block's e_id, no self loops."""
 
@@ -194,6 +245,12 @@ class RelationDataFlow(object):
 
     def produce_subgraph(self, n_id):
         n_id = n_id.reshape(-1)
+        blocks = self._full_blocks(n_id, False, True)
+        if blocks is not None:
+            data_flow = DataFlow(n_id)
+            for new_n_id, res_n_id, edge_src, edge_dst, e_type in blocks:
+                data_flow.append(new_n_id, res_n_id, e_type, torch.stack([edge_src, edge_dst], 0))
+            return data_flow
         data_flow = DataFlow(n_id)
         n_neighbors, types, n_edge_src = self.get_neighbors(n_id)
         for i in range(len(self.metapath)):

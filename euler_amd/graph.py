@@ -450,6 +450,52 @@ class Graph:
             blocks.append((n_ids[h][:cnt[h + 1]], res[h][:cnt[h]], esrc[h][:e], edst[h][:e]))
         return blocks, cnt
 
+    def full_blocks(self, nodes, edge_types, edge_caps, add_self_loops=True, with_types=False):
+        """GCNDataFlow / RelationDataFlow block construction as ONE enqueue
+        (euler_gpu_full_blocks): every hop = full neighbours of the listed types of the
+        nodes so far + first-occurrence unique + res_n_id + edge_index.  edge_caps[h] =
+        capacity of hop h's edge list.  Returns (blocks, counts) with blocks[h] = (n_id,
+        res_n_id, edge_src, edge_dst, e_type or None) sliced to their true sizes after the
+        one host read of the counts, or None when a hop overflowed its capacity (counts then
+        tells the sizes that were reached)."""
+        nodes = _as_i64_cuda(nodes, self.device).reshape(-1)
+        layers = len(edge_types)
+        et = np.asarray(edge_types, dtype=np.int32).reshape(layers, -1)
+        et, et_p, _ = _i32_array(et)
+        k = et.size // layers if layers else 0
+        n = nodes.numel()
+        caps_e = [int(c) for c in edge_caps]
+        caps_n = [n]
+        for c in caps_e:
+            caps_n.append(caps_n[-1] + c)
+        dev = self.device
+        ecap = (C.c_int64 * layers)(*caps_e)
+        n_ids = [torch.empty(max(caps_n[h + 1], 1), dtype=torch.int64, device=dev) for h in range(layers)]
+        res = [torch.empty(max(caps_n[h], 1), dtype=torch.int64, device=dev) for h in range(layers)]
+        esrc = [torch.empty(max(caps_e[h] + caps_n[h], 1), dtype=torch.int64, device=dev) for h in range(layers)]
+        edst = [torch.empty(max(caps_e[h] + caps_n[h], 1), dtype=torch.int64, device=dev) for h in range(layers)]
+        etyp = [torch.empty(max(caps_e[h], 1), dtype=torch.int32, device=dev) for h in range(layers)] \
+            if with_types else None
+        counts = torch.zeros(2 * layers + 2, dtype=torch.int32, device=dev)
+        ws = torch.empty(max(int(lib().euler_gpu_full_blocks_workspace(n, ecap, layers)), 16),
+                         dtype=torch.uint8, device=dev)
+        arr = lambda ts: (C.c_void_p * layers)(*[t.data_ptr() for t in ts])
+        with torch.cuda.device(dev):
+            check(lib().euler_gpu_full_blocks(
+                self._h, _stream(), _ptr(nodes), n, et_p, k, layers, 1 if add_self_loops else 0, ecap,
+                _ptr(ws), arr(n_ids), arr(res), arr(esrc), arr(edst),
+                arr(etyp) if with_types else None, _ptr(counts)))
+        cnt = [int(c) for c in counts.cpu().tolist()]          # the one host read
+        if cnt[2 * layers + 1]:
+            return None, cnt
+        blocks = []
+        for h in range(layers):
+            m_nb = cnt[layers + 1 + h]
+            e = m_nb + (cnt[h] if add_self_loops else 0)
+            blocks.append((n_ids[h][:cnt[h + 1]], res[h][:cnt[h]], esrc[h][:e], edst[h][:e],
+                           etyp[h][:m_nb] if with_types else None))
+        return blocks, cnt
+
     def sample_node(self, count, node_type=-1, call_id=None):
         """tf_euler sample_node (tf_euler/kernels/sample_node_op.cc:39-98):
         [count] int64 ids drawn by node weight within the type(s)."""

@@ -508,6 +508,30 @@ int euler_gpu_sage_blocks(const euler_gpu_graph* g, void* stream, uint64_t seed,
                           int64_t* const* edge_src_dev, int64_t* const* edge_dst_dev,
                           uint32_t* counts_dev);
 
+/* The full-neighbour dataflows (tf_euler/python/dataflow/gcn_dataflow.py:33-47 GCNDataFlow,
+ * relation_dataflow.py:30-72 RelationDataFlow: every hop takes ALL neighbours of the listed
+ * edge types of the nodes seen so far, then tf.unique of [neighbours | nodes], res_n_id and
+ * edge_index) enqueued without a host round trip between the hops.  Row lengths are
+ * data: the caller gives the capacity of every hop's edge list, edge_caps_host[h]; layer
+ * h + 1 then holds at most cap_n[h] + edge_caps[h] nodes (cap_n[0] = n).  A hop whose rows
+ * do not fit sets the overflow word and contributes no edges - the host sees it in its one
+ * read of counts_dev and repeats the flow with larger capacities (or op by op).
+ *   n_id_dev[h]      [cap_n[h + 1]]              nodes of layer h + 1 (first-occurrence order)
+ *   res_n_id_dev[h]  [cap_n[h]]                  index of layer h's nodes in layer h + 1
+ *   edge_src_dev[h], edge_dst_dev[h]  [edge_caps[h] + cap_n[h]]   edges, then (add_self_loops) one
+ *                                                self loop per node of layer h
+ *   e_type_dev[h]    [edge_caps[h]] or e_type_dev == NULL   the edge type of every edge (RGCN's e_id)
+ *   counts_dev       uint32 [2 * layers + 2]: nodes per layer [layers + 1], edges per hop
+ *                    [layers] (self loops not counted), overflow [1] */
+size_t euler_gpu_full_blocks_workspace(int64_t n, const int64_t* edge_caps_host, int32_t layers);
+int euler_gpu_full_blocks(const euler_gpu_graph* g, void* stream, const uint64_t* roots_dev,
+                          int64_t n, const int32_t* edge_types_host, int32_t k, int32_t layers,
+                          int32_t add_self_loops, const int64_t* edge_caps_host,
+                          void* workspace_dev, uint64_t* const* n_id_dev,
+                          int64_t* const* res_n_id_dev, int64_t* const* edge_src_dev,
+                          int64_t* const* edge_dst_dev, int32_t* const* e_type_dev,
+                          uint32_t* counts_dev);
+
 /* ---- RandomWalk -------------------------------------------------------------
  * TF RandomWalk kernel (tf_euler/kernels/random_walk_op.cc:172-291):
  * |p-1|,|q-1| <= 1e-6 -> chain of count=1 SampleNeighbor hops (:207-247), else

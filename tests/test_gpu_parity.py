@@ -1047,6 +1047,50 @@ def test_gcn_and_relation_dataflow_blocks(EA, O, torch_cuda, big_pair):
         n_id = new_n_id
 
 
+def test_full_neighbour_flows_one_enqueue(EA, O, torch_cuda, big_pair):
+    """euler_gpu_full_blocks (GCNDataFlow / RelationDataFlow without a host round trip per
+    hop): the blocks equal the op-by-op composition of the base classes (itself checked
+    against the oracle above) - with and without self loops, three hops, duplicate and
+    unknown roots; a capacity that is too small is reported (no blocks), the flow then
+    falls back and raises its estimate so that the next minibatch fits."""
+    torch = torch_cuda
+    G, _OG, ids, rng = big_pair
+    roots = np.concatenate([rng.choice(ids, 300), rng.choice(ids, 20).repeat(3), [0, 4242]])
+    rt = torch.as_tensor(roots.astype(np.int64)).cuda()
+
+    def same(df_a, df_b, with_types):
+        assert len(df_a.blocks) == len(df_b.blocks)
+        for a, b in zip(df_a.blocks, df_b.blocks):
+            assert torch.equal(a.n_id, b.n_id) and torch.equal(a.res_n_id, b.res_n_id)
+            assert torch.equal(a.edge_index, b.edge_index) and a.size == b.size
+            if with_types:
+                assert torch.equal(a.e_id.to(torch.int64), b.e_id.to(torch.int64))
+
+    for metapath in ([[0, 1], [2, 3]], [[3], [0], [1]], [[0, 1, 2, 3]]):
+        for loops in (True, False):
+            f1 = EA.dataflow.GCNDataFlow(G, metapath, add_self_loops=loops)
+            f2 = EA.dataflow.GCNDataFlow(G, metapath, add_self_loops=loops)
+            f2.fused = False
+            same(f1(rt), f2(rt), False)
+        r1 = EA.dataflow.RelationDataFlow(G, metapath)
+        r2 = EA.dataflow.RelationDataFlow(G, metapath)
+        r2.fused = False
+        same(r1(rt), r2(rt), True)
+    # capacity too small: reported, the flow falls back and learns
+    blocks, cnt = G.full_blocks(rt, [[0, 1, 2, 3], [0, 1, 2, 3]], [10, 10], True, False)
+    assert blocks is None and cnt[-1] == 1
+    f = EA.dataflow.GCNDataFlow(G, [[0, 1, 2, 3], [0, 1, 2, 3]])
+    f._growth = [0.01, 0.01]
+    ref = EA.dataflow.GCNDataFlow(G, [[0, 1, 2, 3], [0, 1, 2, 3]])
+    ref.fused = False
+    same(f(rt), ref(rt), False)              # overflowed -> op by op
+    assert min(f._growth) > 0.01
+    same(f(rt), ref(rt), False)
+    same(f(rt), ref(rt), False)              # by now the capacities fit
+    blocks, cnt = G.full_blocks(rt, [[0, 1, 2, 3], [0, 1, 2, 3]], f._edge_caps(rt.numel()), True, False)
+    assert blocks is not None
+
+
 def test_dedup_split_pack_expand(EA, O, torch_cuda):
     """Fused front / back end of a multi-GPU hop: every position finds its id in
     the bucketed distinct list, buckets hold the ids their shard owns
