@@ -171,7 +171,9 @@ class _FullBlocksMixin(object):
         for gr in self._growth:
             e = int(nodes * gr) + 1024
             caps.append(e)
-            nodes += e
+            # a layer cannot hold more distinct nodes than the graph has (+ the unknown ids
+            # of the batch): estimates must not compound past that
+            nodes = min(nodes + e, float(g.num_nodes + n))
         return caps
 
     def _full_blocks(self, n_id, self_loops, with_types):
