@@ -194,6 +194,10 @@ SIGNATURES = {
     "euler_gpu_full_blocks": (C.c_int, [vp, vp, vp, C.c_int64, i32p, C.c_int32, C.c_int32, C.c_int32,
                                         C.POINTER(C.c_int64), vp, C.POINTER(vp), C.POINTER(vp),
                                         C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp]),
+    "euler_gpu_sparse_adj_mask": (C.c_int, [vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, i32p,
+                                            C.c_int32, vp]),
+    "euler_gpu_sparse_adj_from_mask_tf": (C.c_int, [vp, vp, C.c_int64, C.c_int32, C.c_int32, vp,
+                                                    C.POINTER(C.c_int64), vp, vp]),
     "euler_gpu_time_sample_fanout": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_int64,
                                                i32p, C.c_int32, i32p, C.c_int32,
                                                C.c_int64, C.POINTER(vp),

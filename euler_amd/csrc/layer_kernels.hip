@@ -772,14 +772,18 @@ AdjWorkspace SplitAdjWorkspace(void* ws, int64_t R, int32_t m) {
   return w;
 }
 
-// mask -> counts -> offsets [R + 1] (off[R] = total), all on the stream
-int BuildAdjMask(const euler_gpu_graph* g, hipStream_t st, AdjArgs a, int32_t tf,
-                 const AdjWorkspace& w) {
+int AdjMaskOffsets(hipStream_t st, const uint64_t* mask, int64_t R, int32_t n, int32_t m,
+                   int32_t words, int32_t tf, int64_t* off);
+
+// the hit mask of every source: [R][words] uint64, bit c of source r = candidate c of its
+// batch row is in the source's row
+int BuildAdjMaskOnly(const euler_gpu_graph* g, hipStream_t st, AdjArgs a, uint64_t* mask,
+                     int32_t words) {
   const int64_t R = a.batch * a.n;
   const int block = 256;
   a.g = g->view;
-  a.mask = w.mask;
-  a.words = w.words;
+  a.mask = mask;
+  a.words = words;
   if (a.m > 0) {
     if (g_adj_scan) {
       hipLaunchKernelGGL(AdjScanMaskKernel, dim3(GridFor(R * 64, block)), dim3(block), 0,
@@ -813,16 +817,31 @@ int BuildAdjMask(const euler_gpu_graph* g, hipStream_t st, AdjArgs a, int32_t tf
     }
     EG_HIP(hipGetLastError());
   }
+  return EULER_GPU_OK;
+}
+
+// mask -> counts -> offsets [R + 1] (off[R] = total)
+int AdjMaskOffsets(hipStream_t st, const uint64_t* mask, int64_t R, int32_t n, int32_t m,
+                   int32_t words, int32_t tf, int64_t* off) {
+  const int block = 256;
   int64_t* counts = nullptr;
   EG_HIP(hipMallocAsync((void**)&counts, (size_t)(R + 1) * sizeof(int64_t), st));
   EG_HIP(hipMemsetAsync(counts + R, 0, sizeof(int64_t), st));
-  hipLaunchKernelGGL(AdjCountKernel, dim3(GridFor(R, block)), dim3(block), 0, st, w.mask, R,
-                     a.n, a.m, w.words, tf, counts);
-  int rc = ExclusiveScanI64(st, counts, w.off, R + 1);
+  hipLaunchKernelGGL(AdjCountKernel, dim3(GridFor(R, block)), dim3(block), 0, st, mask, R, n, m,
+                     words, tf, counts);
+  int rc = ExclusiveScanI64(st, counts, off, R + 1);
   hipError_t f = hipFreeAsync(counts, st);
   if (rc != EULER_GPU_OK) return rc;
   EG_HIP(f);
   return EULER_GPU_OK;
+}
+
+// mask -> counts -> offsets, all on the stream
+int BuildAdjMask(const euler_gpu_graph* g, hipStream_t st, AdjArgs a, int32_t tf,
+                 const AdjWorkspace& w) {
+  const int rc = BuildAdjMaskOnly(g, st, a, w.mask, w.words);
+  if (rc != EULER_GPU_OK) return rc;
+  return AdjMaskOffsets(st, w.mask, a.batch * a.n, a.n, a.m, w.words, tf, w.off);
 }
 
 }  // namespace
@@ -1193,6 +1212,62 @@ int euler_gpu_sparse_get_adj_tf(const euler_gpu_graph* g, void* stream,
   if (!values_dev) return Fail(EULER_GPU_EINVAL, "sparse_get_adj_tf: null values");
   hipLaunchKernelGGL(AdjFillKernel, dim3(GridFor(R * w.words, block)), dim3(block), 0, st,
                      w.mask, nb_nodes_dev, R, n, m, w.words, 1, w.off, (uint64_t*)nullptr,
+                     indices_dev, values_dev);
+  EG_HIP(hipGetLastError());
+  return EULER_GPU_OK;
+}
+
+// The owner's half of SparseGetAdj on a sharded graph: the hit mask of the sources this
+// shard OWNS (a source without a row here contributes zeros), [batch * n][(m + 63) / 64]
+// uint64.  The masks of all shards OR together to the mask of the whole graph - an id has
+// one owner - so a requester needs 8 bytes per 64 candidates and source from every shard
+// instead of the sources' whole rows (core/kernels/sparse_get_adj_op.cc:35-92 is the
+// per-shard op the reference runs remotely).
+int euler_gpu_sparse_adj_mask(const euler_gpu_graph* g, void* stream, const uint64_t* nodes_dev,
+                              const uint64_t* nb_nodes_dev, int64_t batch, int32_t n, int32_t m,
+                              const int32_t* edge_types_host, int32_t k, uint64_t* mask_dev) {
+  if (!g) return Fail(EULER_GPU_ENOGRAPH, "sparse_adj_mask: null graph");
+  if (batch < 0 || n < 0 || m < 0) return Fail(EULER_GPU_EINVAL, "sparse_adj_mask: negative size");
+  AdjArgs a{};
+  int rc = FillTypes(edge_types_host, k, &a.tl, "sparse_adj_mask");
+  if (rc != EULER_GPU_OK) return rc;
+  const int64_t R = batch * n;
+  if (R == 0 || m == 0) return EULER_GPU_OK;
+  if (!nodes_dev || !nb_nodes_dev || !mask_dev)
+    return Fail(EULER_GPU_EINVAL, "sparse_adj_mask: null buffer");
+  a.roots = nodes_dev; a.l_nb = nb_nodes_dev; a.batch = batch; a.n = n; a.m = m;
+  return BuildAdjMaskOnly(g, (hipStream_t)stream, a, mask_dev, (m + 63) / 64);
+}
+
+// ... and the requester's: the TF SparseGetAdj triple (tf_euler/kernels/sparse_get_adj_op.cc:
+// 92-124, explicit zero at (b, n-1, m-1) included) from a hit mask.  Two calls as
+// euler_gpu_sparse_get_adj_tf: indices_dev == NULL sizes (nnz_host, stream sync; the offsets
+// stay in workspace_dev), the second fills.  workspace: 8 * (batch * n + 1) bytes.
+int euler_gpu_sparse_adj_from_mask_tf(void* stream, const uint64_t* mask_dev, int64_t batch,
+                                      int32_t n, int32_t m, void* workspace_dev,
+                                      int64_t* nnz_host, int64_t* indices_dev,
+                                      int64_t* values_dev) {
+  if (batch < 0 || n < 0 || m < 0)
+    return Fail(EULER_GPU_EINVAL, "sparse_adj_from_mask_tf: negative size");
+  const int64_t R = batch * n;
+  if (R == 0 || m == 0) { if (nnz_host) *nnz_host = 0; return EULER_GPU_OK; }
+  if (!mask_dev || !workspace_dev)
+    return Fail(EULER_GPU_EINVAL, "sparse_adj_from_mask_tf: null buffer");
+  hipStream_t st = (hipStream_t)stream;
+  int64_t* off = static_cast<int64_t*>(workspace_dev);
+  const int32_t words = (m + 63) / 64;
+  if (indices_dev == nullptr) {
+    const int rc = AdjMaskOffsets(st, mask_dev, R, n, m, words, 1, off);
+    if (rc != EULER_GPU_OK) return rc;
+    int64_t total = 0;
+    EG_HIP(hipMemcpyAsync(&total, off + R, 8, hipMemcpyDeviceToHost, st));
+    EG_HIP(hipStreamSynchronize(st));
+    if (nnz_host) *nnz_host = total;
+    return EULER_GPU_OK;
+  }
+  if (!values_dev) return Fail(EULER_GPU_EINVAL, "sparse_adj_from_mask_tf: null values");
+  hipLaunchKernelGGL(AdjFillKernel, dim3(GridFor(R * words, 256)), dim3(256), 0, st, mask_dev,
+                     (const uint64_t*)nullptr, R, n, m, words, 1, off, (uint64_t*)nullptr,
                      indices_dev, values_dev);
   EG_HIP(hipGetLastError());
   return EULER_GPU_OK;

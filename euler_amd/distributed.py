@@ -567,8 +567,50 @@ class ShardedSampler:
         n = nodes.numel() if n == -1 else int(n)
         m = nb_nodes.numel() if m == -1 else int(m)
         batch = nodes.numel() // n if n else 0
+        if getattr(self, "local_adj_mask", None) is not None:
+            return self._sparse_get_adj_owner_side(nodes, nb_nodes, edge_types, batch, n, m)
         idx, ids, _w, _t = self.get_full_neighbor(nodes, edge_types)
         return adj_from_rows(idx, ids, nb_nodes, batch, n, m)
+
+    def _sparse_get_adj_owner_side(self, nodes, nb_nodes, edge_types, batch, n, m):
+        """The adjacency answered on the OWNERS (core/kernels/sparse_get_adj_op.cc:35-92 is
+        the per-shard op the reference runs remotely): every rank learns every rank's
+        (sources, candidates) - a few KB -, computes the hit mask of the sources it owns
+        (local_adj_mask(nodes, nb_nodes, batch, n, m, edge_types) -> int64 [batch * n,
+        words]; a source it does not own gives zeros) and sends each requester its mask;
+        the requester ORs the masks - an id has one owner - and builds the TF triple
+        (adj_from_mask_fn(mask, batch, n, m)).  8 bytes per 64 candidates and source on the
+        wire instead of the sources' rows."""
+        dev = nodes.device
+        wire = torch.device("cpu") if self.host_staged else dev
+        W = self.world
+        shp = torch.tensor([batch, n, m], dtype=torch.int64, device=wire)
+        all_shp = [torch.empty_like(shp) for _ in range(W)]
+        dist.all_gather(all_shp, shp, group=self.group)
+        shapes = [[int(x) for x in t.tolist()] for t in all_shp]
+        max_nodes = max(b * n_ for b, n_, _ in shapes)
+        max_nb = max(b * m_ for b, _, m_ in shapes)
+        pad = torch.zeros(max_nodes + max_nb, dtype=torch.int64, device=wire)
+        pad[:batch * n] = nodes[:batch * n].to(wire)
+        pad[max_nodes:max_nodes + batch * m] = nb_nodes[:batch * m].to(wire)
+        allq = [torch.empty_like(pad) for _ in range(W)]
+        dist.all_gather(allq, pad, group=self.group)
+        parts, send_counts = [], []
+        for r in range(W):
+            b_, n_, m_ = shapes[r]
+            q_nodes = allq[r][:b_ * n_].to(dev)
+            q_nb = allq[r][max_nodes:max_nodes + b_ * m_].to(dev)
+            mk = self.local_adj_mask(q_nodes, q_nb, b_, n_, m_, edge_types).reshape(-1)
+            parts.append(mk)
+            send_counts.append(int(mk.numel()))
+        words = (m + 63) // 64
+        mine = batch * n * words
+        send = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int64, device=dev)
+        got = self._exchange(send.reshape(-1, 1), send_counts, [mine] * W).reshape(W, -1)
+        mask = got[0].clone()
+        for r in range(1, W):
+            mask |= got[r]
+        return self.adj_from_mask_fn(mask.reshape(batch * n, words), batch, n, m)
 
     def sample_neighbor_layerwise(self, nodes, edge_types, count, default_node=-1,
                                   call_id=None, weight_func=''):
@@ -885,6 +927,8 @@ def gpu_sharded_sampler(graph, partitions=None, group=None, dedup=True, dense_id
     S.node_split_fn = lambda call_id, count, weights: ops.sample_node_split(
         graph.seed, call_id, count, weights)
     S.n2v_step_fn = lambda call_id, *lists: ops.node2vec_step(graph.seed, call_id, *lists)
+    S.local_adj_mask = graph.sparse_adj_mask
+    S.adj_from_mask_fn = type(graph).adj_from_mask
     return S
 
 

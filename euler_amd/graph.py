@@ -792,6 +792,41 @@ class Graph:
         shape = [batch, n, m] if nnz.value else [0, 0, 0]
         return ind, val, shape
 
+    def sparse_adj_mask(self, nodes, nb_nodes, batch, n, m, edge_types):
+        """The hit mask of SparseGetAdj on THIS graph (shard): int64 [batch * n, (m + 63) // 64],
+        bit c of a source = candidate c of its batch row is in the source's row; sources
+        without a row here give zeros (euler_gpu_sparse_adj_mask)."""
+        nodes = _as_i64_cuda(nodes, self.device).reshape(-1)
+        nb_nodes = _as_i64_cuda(nb_nodes, self.device).reshape(-1)
+        words = (int(m) + 63) // 64
+        mask = torch.zeros((int(batch) * int(n), words), dtype=torch.int64, device=self.device)
+        et, et_p, k = _i32_array(edge_types)
+        if mask.numel():
+            with torch.cuda.device(self.device):
+                check(lib().euler_gpu_sparse_adj_mask(
+                    self._h, _stream(), _ptr(nodes), _ptr(nb_nodes), int(batch), int(n), int(m),
+                    et_p, k, _ptr(mask)))
+        return mask
+
+    @staticmethod
+    def adj_from_mask(mask, batch, n, m):
+        """TF SparseGetAdj triple (indices [nnz, 3], values, dense_shape) from a hit mask
+        (euler_gpu_sparse_adj_from_mask_tf) - needs no graph."""
+        dev = mask.device
+        batch, n, m = int(batch), int(n), int(m)
+        mask = mask.contiguous()
+        ws = torch.empty(8 * (batch * n + 1) + 16, dtype=torch.uint8, device=dev)
+        nnz = C.c_int64(0)
+        with torch.cuda.device(dev):
+            check(lib().euler_gpu_sparse_adj_from_mask_tf(
+                _stream(), _ptr(mask), batch, n, m, _ptr(ws), C.byref(nnz), None, None))
+            ind = torch.empty((int(nnz.value), 3), dtype=torch.int64, device=dev)
+            val = torch.empty(int(nnz.value), dtype=torch.int64, device=dev)
+            if nnz.value:
+                check(lib().euler_gpu_sparse_adj_from_mask_tf(
+                    _stream(), _ptr(mask), batch, n, m, _ptr(ws), C.byref(nnz), _ptr(ind), _ptr(val)))
+        return ind, val, ([batch, n, m] if nnz.value else [0, 0, 0])
+
     def sample_neighbor_layerwise(self, nodes, edge_types, count, default_node=-1,
                                   weight_func='', call_id=None):
         """tf_euler sample_neighbor_layerwise (euler_ops/neighbor_ops.py:72-77

@@ -444,6 +444,21 @@ int euler_gpu_sparse_get_adj_tf(const euler_gpu_graph* g, void* stream,
                                 void* workspace_dev, int64_t* nnz_host,
                                 int64_t* indices_dev, int64_t* values_dev);
 
+/* SparseGetAdj on a SHARDED graph, owner side and requester side.  Every shard computes the
+ * hit mask of the sources it owns - mask_dev [batch * n][(m + 63) / 64] uint64, bit c of a
+ * source = candidate c of its batch row is in the source's row; sources without a row on
+ * this shard give zeros - and the masks of all shards OR to the mask of the whole graph.  The
+ * requester turns the combined mask into the TF triple (two calls as
+ * euler_gpu_sparse_get_adj_tf; workspace 8 * (batch * n + 1) bytes).  Replaces shipping the
+ * sources' whole rows (core/kernels/sparse_get_adj_op.cc:35-92 is the per-shard op). */
+int euler_gpu_sparse_adj_mask(const euler_gpu_graph* g, void* stream, const uint64_t* nodes_dev,
+                              const uint64_t* nb_nodes_dev, int64_t batch, int32_t n, int32_t m,
+                              const int32_t* edge_types_host, int32_t k, uint64_t* mask_dev);
+int euler_gpu_sparse_adj_from_mask_tf(void* stream, const uint64_t* mask_dev, int64_t batch,
+                                      int32_t n, int32_t m, void* workspace_dev,
+                                      int64_t* nnz_host, int64_t* indices_dev,
+                                      int64_t* values_dev);
+
 /* ---- dense features --------------------------------------------------------
  * TF GetDenseFeature (tf_euler/kernels/get_dense_feature_op.cc:63-125) over
  * Node::GetFloat32Feature (core/graph/node.cc:330-394): out_dev is [n, dim]

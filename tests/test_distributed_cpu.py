@@ -321,6 +321,35 @@ def _worker(rank, world, port, partitions, out_dir):
         a_, b_, c_ = OG_local.sample_layer(seed, call_id, q_, et, dn_, positions=pos_.numpy())
         return torch.as_tensor(a_.view(np.int64)), torch.as_tensor(b_), torch.as_tensor(c_)
 
+    # SparseGetAdj answered by the owners (hit masks ORed on the requester) for one sampler,
+    # by fetched rows for the other: both must give the unsharded triple
+    def local_adj_mask(q_nodes, q_nb, b_, n_, m_, et):
+        words = (m_ + 63) // 64
+        mk = np.zeros((b_ * n_, words), np.uint64)
+        if b_ * n_ and m_:
+            idx_, ids_, _w, _t = OG_local.get_full_neighbor(q_nodes.numpy().astype(np.uint64), et)
+            nbv = q_nb.numpy().astype(np.uint64).reshape(b_, m_)
+            for r_ in range(b_ * n_):
+                row = set(ids_[idx_[r_, 0]:idx_[r_, 1]].tolist())
+                for c_ in range(m_):
+                    if int(nbv[r_ // n_, c_]) in row:
+                        mk[r_, c_ // 64] |= np.uint64(1) << np.uint64(c_ % 64)
+        return torch.as_tensor(mk.view(np.int64))
+
+    def adj_from_mask_fn(mask, b_, n_, m_):
+        mk = mask.numpy().view(np.uint64).reshape(b_ * n_, -1)
+        ind, val = [], []
+        for r_ in range(b_ * n_):
+            for c_ in range(m_):
+                hit = bool((mk[r_, c_ // 64] >> np.uint64(c_ % 64)) & np.uint64(1))
+                if hit or (r_ % n_ == n_ - 1 and c_ == m_ - 1):
+                    ind.append([r_ // n_, r_ % n_, c_]); val.append(1 if hit else 0)
+        if not ind:
+            return torch.zeros((0, 3), dtype=torch.int64), torch.zeros(0, dtype=torch.int64), [0, 0, 0]
+        return torch.as_tensor(np.array(ind, np.int64)), torch.as_tensor(np.array(val, np.int64)), [b_, n_, m_]
+
+    S_fused.local_adj_mask = local_adj_mask
+    S_fused.adj_from_mask_fn = adj_from_mask_fn
     rng_l = np.random.default_rng(50 + rank)       # every rank asks for its own minibatch
     for sampler in (S_fused, S_plain):
         sampler.local_edge_sum_weight = local_edge_sum_weight

@@ -1681,3 +1681,30 @@ def test_fanout_unique_rows_and_index(EA, O, torch_cuda, big_pair):
     with pytest.raises(_lib.EulerGpuError):
         G4.sample_fanout_unique(torch.as_tensor(rng.choice(ids4, 100).astype(np.int64)).cuda(),
                                 [[0], [1]], [4, 2], -1, call_id=1)
+
+
+def test_sparse_adj_mask_and_triple(EA, O, torch_cuda, big_pair):
+    """The two halves of SparseGetAdj on a sharded graph: euler_gpu_sparse_adj_mask (the hit
+    mask of the sources a graph holds) + euler_gpu_sparse_adj_from_mask_tf (the TF triple
+    from a mask) == euler_gpu_sparse_get_adj_tf == the oracle; masks of two disjoint shards
+    OR to the mask of the whole graph."""
+    torch = torch_cuda
+    G, OG, ids, rng = big_pair
+    for batch, n, m in ((1, 1, 1), (3, 4, 9), (2, 17, 70), (1, 40, 200), (4, 5, 130)):
+        nodes = rng.choice(ids, (batch, n)).astype(np.uint64)
+        nodes[0, 0] = 2 ** 62 + 5
+        cand = rng.choice(ids, (batch, m)).astype(np.uint64)
+        for b in range(batch):
+            nb = OG.get_full_neighbor(nodes[b], [0, 1, 2, 3])[1]
+            if len(nb):
+                take = rng.choice(nb, m // 2 + 1)
+                cand[b, :len(take)] = take[:m]
+        nt = torch.as_tensor(nodes.view(np.int64)).cuda()
+        ct = torch.as_tensor(cand.view(np.int64)).cuda()
+        for et in ([0], [2, 1], [0, 1, 2, 3]):
+            mask = G.sparse_adj_mask(nt, ct, batch, n, m, et)
+            ind, val, shape = EA.Graph.adj_from_mask(mask, batch, n, m)
+            wi, wv, ws = G.sparse_get_adj(nt, ct, et, n, m)
+            assert torch.equal(ind, wi) and torch.equal(val, wv) and list(shape) == list(ws)
+            want = OG.sparse_get_adj_tf(nodes, cand, et, n, m)
+            assert np.array_equal(t2n(ind), want[0]) and np.array_equal(t2n(val), want[1])
