@@ -58,8 +58,6 @@ struct Segment {
   int64_t lo, hi;       // searched edges [lo, hi] (global indices)
   float limit_begin, limit_end;
   int32_t b, e;         // the same segment, row-relative
-  bool one_block;       // BLOCKED LoadSegment: the segment lies inside one EdgeBlock and the limits
-                        // were NOT loaded - BlockPivotSample takes them from the block's sums
 };
 
 // One draw u on a segment: the neighbour RandomSelect picks and its weight.
@@ -156,45 +154,6 @@ __device__ __forceinline__ void PivotSample(const GraphView& g, const Segment& s
   *w = __fsub_rn(nw_m, prev);
 }
 
-// One draw on a segment [lo, hi] that lies inside one EdgeBlock; false = Q3 (r rounded up
-// to the segment's end): the caller takes the general search, which replays the reference.
-__device__ __forceinline__ bool OneBlockSample(const GraphView& g, int64_t row_ptr, int64_t lo,
-                                               int64_t hi, int32_t b_idx, double u, uint64_t* id,
-                                               float* w) {
-  const int64_t x = lo / kEdgesPerBlock;
-  const EdgeBlock* bk = g.blk + x;
-  const int64_t base = x * kEdgesPerBlock;
-  const int32_t i_lo = (int32_t)(lo - base), i_hi = (int32_t)(hi - base);      // inclusive
-  const float4 a0 = *reinterpret_cast<const float4*>(bk->pw);
-  const float4 a1 = *reinterpret_cast<const float4*>(bk->pw + 4);
-  const float4 a2 = *reinterpret_cast<const float4*>(bk->pw + 8);   // pw[8], pw[9], prev_last, pad
-  const float v[10] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y};
-  float limit_end = v[0], limit_begin = 0.f;
-#pragma unroll
-  for (int j = 0; j < kEdgesPerBlock; ++j) {
-    if (j == i_hi) limit_end = v[j];
-    if (j + 1 == i_lo) limit_begin = v[j];
-  }
-  if (i_lo == 0) limit_begin = a2.z;                 // the edge before the block
-  if (b_idx == 0) limit_begin = 0.f;                 // the segment starts the row
-  const double rr = ScaleDraw(u, limit_begin, limit_end);
-  if (!((double)limit_end > rr)) return false;
-  int32_t i = i_lo;
-#pragma unroll
-  for (int j = 0; j < kEdgesPerBlock - 1; ++j)
-    i += (j >= i_lo && j < i_hi && !((double)v[j] > rr)) ? 1 : 0;
-  float nw_m = v[0], prev = a2.z;
-#pragma unroll
-  for (int j = 0; j < kEdgesPerBlock; ++j) {
-    if (j == i) nw_m = v[j];
-    if (j + 1 == i) prev = v[j];
-  }
-  if (base + i == row_ptr) prev = 0.f;               // `mid ? nw[mid-1] : 0`, row-relative
-  *id = bk->nbr[i];
-  *w = __fsub_rn(nw_m, prev);
-  return true;
-}
-
 // ------------------------------------------------------------------------
 // Block-pivot search (K1 variant 6).  Over the distinct roots of a dedup'ed
 // hop every row is cold and the launch runs at the chip's random-line rate
@@ -207,15 +166,8 @@ __device__ __forceinline__ bool OneBlockSample(const GraphView& g, int64_t row_p
 // them, shared by its samples) and one block line.
 // Same contract as PivotSample: first m in [lo, hi] with nw[m] > r.
 // ------------------------------------------------------------------------
-__device__ __forceinline__ void BlockPivotSample(const GraphView& g, const Segment& sg_in,
+__device__ __forceinline__ void BlockPivotSample(const GraphView& g, const Segment& sg,
                                                  double u, uint64_t* id, float* w) {
-  Segment sg = sg_in;
-  if (sg.one_block) {
-    // limits and leaf are the same block line: block -> id instead of limits -> leaf -> id
-    if (OneBlockSample(g, sg.row_ptr, sg.lo, sg.hi, sg.b, u, id, w)) return;
-    sg.limit_end = BlockedPw(g, sg.hi);              // Q3: the general path replays the reference
-    sg.limit_begin = sg.b == 0 ? 0.f : BlockedPw(g, sg.lo - 1);
-  }
   const int64_t lo = sg.lo, hi = sg.hi;
   const double rr = ScaleDraw(u, sg.limit_begin, sg.limit_end);
   if (!((double)sg.limit_end > rr)) {
@@ -318,7 +270,6 @@ template <bool BLOCKED = false>
 __device__ __forceinline__ bool LoadSegment(const GraphView& g, int64_t row,
                                             int32_t t, Segment* sg) {
   if (row < 0 || t < 0 || t >= g.T) return false;
-  sg->one_block = false;
   const uint8_t* rec = g.row_meta + row * (int64_t)g.meta_stride;
   if (g.T == 1) {
     const uint4 q = *reinterpret_cast<const uint4*>(rec);
@@ -344,10 +295,7 @@ __device__ __forceinline__ bool LoadSegment(const GraphView& g, int64_t row,
   if (sg->e < sg->b) return false;
   sg->lo = sg->row_ptr + sg->b;
   sg->hi = sg->row_ptr + sg->e;
-  if (BLOCKED && g.uniform_w == 0 && sg->lo / kEdgesPerBlock == sg->hi / kEdgesPerBlock) {
-    sg->one_block = true;          // BlockPivotSample reads the limits with the leaf
-    sg->limit_begin = 0.f; sg->limit_end = 0.f;
-  } else if (BLOCKED) {     // same values, read from the block lines the search will touch
+  if (BLOCKED) {     // same values, read from the block lines the search will touch
     sg->limit_end = BlockedPw(g, sg->hi);
     sg->limit_begin = sg->b == 0 ? 0.f : BlockedPw(g, sg->lo - 1);
   } else {

@@ -108,6 +108,45 @@ struct RegSubTypeSum {           // SubTypeSum (device_fns.h) out of registers
   }
 };
 
+// One draw on a segment [lo, hi] that lies inside one EdgeBlock; false = Q3 (r rounded up
+// to the segment's end): the caller takes the general search, which replays the reference.
+__device__ __forceinline__ bool OneBlockSample(const GraphView& g, int64_t row_ptr, int64_t lo,
+                                               int64_t hi, int32_t b_idx, double u, uint64_t* id,
+                                               float* w) {
+  const int64_t x = lo / kEdgesPerBlock;
+  const EdgeBlock* bk = g.blk + x;
+  const int64_t base = x * kEdgesPerBlock;
+  const int32_t i_lo = (int32_t)(lo - base), i_hi = (int32_t)(hi - base);      // inclusive
+  const float4 a0 = *reinterpret_cast<const float4*>(bk->pw);
+  const float4 a1 = *reinterpret_cast<const float4*>(bk->pw + 4);
+  const float4 a2 = *reinterpret_cast<const float4*>(bk->pw + 8);   // pw[8], pw[9], prev_last, pad
+  const float v[10] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y};
+  float limit_end = v[0], limit_begin = 0.f;
+#pragma unroll
+  for (int j = 0; j < kEdgesPerBlock; ++j) {
+    if (j == i_hi) limit_end = v[j];
+    if (j + 1 == i_lo) limit_begin = v[j];
+  }
+  if (i_lo == 0) limit_begin = a2.z;                 // the edge before the block
+  if (b_idx == 0) limit_begin = 0.f;                 // the segment starts the row
+  const double rr = ScaleDraw(u, limit_begin, limit_end);
+  if (!((double)limit_end > rr)) return false;
+  int32_t i = i_lo;
+#pragma unroll
+  for (int j = 0; j < kEdgesPerBlock - 1; ++j)
+    i += (j >= i_lo && j < i_hi && !((double)v[j] > rr)) ? 1 : 0;
+  float nw_m = v[0], prev = a2.z;
+#pragma unroll
+  for (int j = 0; j < kEdgesPerBlock; ++j) {
+    if (j == i) nw_m = v[j];
+    if (j + 1 == i) prev = v[j];
+  }
+  if (base + i == row_ptr) prev = 0.f;               // `mid ? nw[mid-1] : 0`, row-relative
+  *id = bk->nbr[i];
+  *w = __fsub_rn(nw_m, prev);
+  return true;
+}
+
 template <bool TF_LAYOUT, bool REG8>
 __global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborTypedPivotKernel(
     const SampleNbArgs a) {
@@ -175,7 +214,6 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborTypedPivotKe
             sg.lo = lo; sg.hi = hi;
             sg.limit_end = BlockedPw(a.g, sg.hi);
             sg.limit_begin = b_idx == 0 ? 0.f : BlockedPw(a.g, sg.lo - 1);
-            sg.one_block = false;
             BlockPivotSample(a.g, sg, u_nb, &id, &w);
           }
         }

@@ -549,6 +549,7 @@ __global__ __launch_bounds__(256) void CwInitKernel(const CwArgs a, const int64_
     a.rec[i].id = (uint64_t)starts[i];
 }
 
+template <bool FAST>
 __global__ __launch_bounds__(256, kWavesPerSimd) void CwSampleKernel(const CwArgs a) {
   const int32_t s = a.step;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -573,7 +574,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void CwSampleKernel(const CwArg
     float w;
     int32_t t;
     const int64_t row = FindRow(a.g, cur);
-    if (a.fast) {
+    if (FAST) {
       Segment sg;
       if (LoadSegment<true>(a.g, row, a.edge_types[s], &sg)) {
         const Philox4 blk = RngBlock(a.seed, a.call_id + (uint32_t)s, kDomainNeighbor, cur, 0);
@@ -1092,12 +1093,13 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
       unsigned grid = (unsigned)((n + block - 1) / block);
       if (g_walk_grid > 0 && grid > (unsigned)g_walk_grid) grid = (unsigned)g_walk_grid;
       c.step = 0;
-      hipLaunchKernelGGL(CwSampleKernel, dim3(grid), dim3(block), 0, st, c);
+      auto sample_kernel = fast ? CwSampleKernel<true> : CwSampleKernel<false>;
+      hipLaunchKernelGGL(sample_kernel, dim3(grid), dim3(block), 0, st, c);
       for (int32_t s2 = 0; s2 < walk_len; ++s2) {
         c.step = s2;
         hipLaunchKernelGGL(CwNumberKernel, dim3(grid), dim3(block), 0, st, c);
         c.step = s2 + 1;
-        hipLaunchKernelGGL(CwSampleKernel, dim3(grid), dim3(block), 0, st, c);
+        hipLaunchKernelGGL(sample_kernel, dim3(grid), dim3(block), 0, st, c);
       }
       hipLaunchKernelGGL(CwExpandKernel, dim3(GridFor(n, block)), dim3(block), 0, st, c, nodes_dev,
                          out_dev);
