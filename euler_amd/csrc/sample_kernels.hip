@@ -568,7 +568,7 @@ thread_local int g_fl_plain = 2;      // key 34: plain graphs: 2 = the lean kern
 thread_local int g_fl_wps = 5;        // key 35: register budget, waves per SIMD (8, 6 or 5; 5: nothing spilled)
 thread_local int g_fl_ablate = 0;     // key 36: measurement only (FanoutLocalArgs::ablate)
 thread_local int g_k1_typed_pivot = 1;   // key 37: calls with type draws search with the block pivots (0 = reference
-                                         // loop, 2 = without the register copy of the row record)
+                                         // loop)
 thread_local uint32_t* t_fl_row_index = nullptr;   // set by euler_gpu_sample_fanout_unique around its call
 thread_local int t_fl_took_lean = 0;                // ... and whether the lean kernel served it
 thread_local void* g_fl_debug = nullptr;   // euler_gpu_set_debug_buffer: phase stamps of the lean kernel
@@ -1600,7 +1600,7 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 33 && value >= 0) { g_fl_min_roots = value; return EULER_GPU_OK; }
   if (key == 34 && value >= 0 && value <= 2) { g_fl_plain = value; return EULER_GPU_OK; }
   if (key == 36) { g_fl_ablate = value; return EULER_GPU_OK; }
-  if (key == 37 && value >= 0 && value <= 2) { g_k1_typed_pivot = value; return EULER_GPU_OK; }
+  if (key == 37 && value >= 0 && value <= 1) { g_k1_typed_pivot = value; return EULER_GPU_OK; }
   if (key == 38 && value >= 0) { g_walk_collapse = value; return EULER_GPU_OK; }
   if (key == 39 && value >= 0) { g_walk_grid = value; return EULER_GPU_OK; }
   if (key == 35 && (value == 5 || value == 6 || value == 8)) { g_fl_wps = value; return EULER_GPU_OK; }
