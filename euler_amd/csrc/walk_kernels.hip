@@ -516,8 +516,13 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void RandomWalkKernel(const Wal
 //                    them in the table;
 //   CwSampleKernel   (next step, same launch) first reads every group's number back into
 //                    its record;
-//   CwExpandKernel   walker w follows the records, one 16-byte load per step, and writes its
-//                    path.
+//   CwChainKernel    walker w follows the records, one 16-byte load per step (four walkers
+//                    per lane: four chains in flight), and leaves its path TRANSPOSED,
+//                    [step][walker] - every store a full run of 512 bytes;
+//   CwTransposeKernel  [step][walker] -> the op's [walker][step]: 64 walkers per workgroup
+//                    through LDS, their rows leave as one contiguous run.
+//   (One kernel that staged 8 steps per walker and wrote 64-byte pieces of rows 328 bytes
+//   apart took 0.65 ms for 1 M walkers x 40 steps - a third of the walk - at 0.5 TB/s.)
 // Counts stay on the device; every launch is sized for the walkers and exits past n[s].
 // ------------------------------------------------------------------------
 struct CwArgs {
@@ -528,7 +533,7 @@ struct CwArgs {
   struct Rec { uint64_t id; uint32_t next; uint32_t pad; };
   Rec* rec;                     // [walk_len + 1][cap]: the node of group g of level s and its
                                 // group at level s + 1 - one 16-byte load per step for the
-                                // walker that follows the chain (CwExpandKernel)
+                                // walker that follows the chain (CwChainKernel)
   uint64_t* tmp_id[2];          // [cap] next node of every group (before numbering)
   uint32_t* tmp_slot[2];        // [cap] its owner-table slot
   uint32_t* owner[2];           // [n_rows + 1], alternating between steps
@@ -631,37 +636,59 @@ __global__ __launch_bounds__(256) void CwNumberKernel(const CwArgs a) {
   }
 }
 
-__global__ __launch_bounds__(256, kWavesPerSimd) void CwExpandKernel(const CwArgs a,
-                                                                     const int64_t* starts,
-                                                                     int64_t* out) {
-  __shared__ int64_t stage[256 * (kWalkStage + 1)];
-  const int64_t L = a.walk_len + 1;
-  const int64_t tiles = (a.cap + 255) / 256;
-  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    const int64_t i = tile * 256 + threadIdx.x;
-    const bool live = i < a.cap;
-    if (live) out[i * L] = starts[i];
-    // the walker's group at level 1: level 0 is the walkers themselves
-    uint32_t grp = live ? a.rec[i].next : 0u, nxt_grp = 0;
-    for (int32_t s0 = 0; s0 < a.walk_len; s0 += kWalkStage) {
-      const int32_t ns = min(kWalkStage, a.walk_len - s0);
-      for (int32_t x = 0; x < ns; ++x) {
-        const int32_t s = s0 + x;
-        uint64_t id = 0;
-        if (live) {
-          // grp = this walker's group at level s + 1; its record gives the node and the way on
-          const uint4 q = *reinterpret_cast<const uint4*>(&a.rec[(int64_t)(s + 1) * a.cap + grp]);
-          id = ((uint64_t)q.y << 32) | q.x;
-          nxt_grp = q.z;
-        }
-        stage[threadIdx.x * (kWalkStage + 1) + x] = id == 0 ? a.default_node : (int64_t)id;
-        grp = nxt_grp;
+constexpr int kCwChains = 4;
+__global__ __launch_bounds__(256, kWavesPerSimd) void CwChainKernel(const CwArgs a,
+                                                                    const int64_t* starts,
+                                                                    int64_t* tr) {
+  const int64_t span = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < a.cap; i0 += span * kCwChains) {
+    uint32_t grp[kCwChains];
+    bool live[kCwChains];
+#pragma unroll
+    for (int u = 0; u < kCwChains; ++u) {
+      const int64_t i = i0 + u * span;
+      live[u] = i < a.cap;
+      // the walker's group at level 1: level 0 is the walkers themselves
+      grp[u] = live[u] ? a.rec[i].next : 0u;
+      if (live[u]) tr[i] = starts[i];
+    }
+    for (int32_t s = 0; s < a.walk_len; ++s) {
+      uint4 q[kCwChains];
+#pragma unroll
+      for (int u = 0; u < kCwChains; ++u) {
+        q[u] = make_uint4(0, 0, 0, 0);
+        // grp = this walker's group at level s + 1; its record gives the node and the way on
+        if (live[u]) q[u] = *reinterpret_cast<const uint4*>(&a.rec[(int64_t)(s + 1) * a.cap + grp[u]]);
       }
+#pragma unroll
+      for (int u = 0; u < kCwChains; ++u) {
+        const uint64_t id = ((uint64_t)q[u].y << 32) | q[u].x;
+        if (live[u]) tr[(int64_t)(s + 1) * a.cap + i0 + u * span] = id == 0 ? a.default_node : (int64_t)id;
+        grp[u] = q[u].z;
+      }
+    }
+  }
+}
+
+// tr [L][cap] -> out [cap][L].  A workgroup takes 64 walkers and `ch` steps at a time (all
+// of them when the rows fit in LDS: the 64 rows then leave as ONE contiguous run).
+__global__ __launch_bounds__(256) void CwTransposeKernel(const int64_t* tr, int64_t* out, int64_t cap,
+                                                         int32_t L, int32_t ch) {
+  extern __shared__ __align__(16) int64_t cw_stage[];       // [64][ch | 1]
+  const int32_t ls = ch | 1;
+  const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int64_t tiles = (cap + 63) / 64;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t w0 = tile * 64;
+    const int32_t nw = (int32_t)(cap - w0 < 64 ? cap - w0 : 64);
+    for (int32_t c0 = 0; c0 < L; c0 += ch) {
+      const int32_t ns = L - c0 < ch ? L - c0 : ch;
+      for (int32_t x = part; x < ns; x += 4)
+        if (lane < nw) cw_stage[lane * ls + x] = tr[(int64_t)(c0 + x) * cap + w0 + lane];
       __syncthreads();
-      for (int32_t e = threadIdx.x; e < 256 * ns; e += 256) {
+      for (int32_t e = threadIdx.x; e < nw * ns; e += 256) {
         const int32_t wl = e / ns, x = e - wl * ns;
-        const int64_t wi = tile * 256 + wl;
-        if (wi < a.cap) out[wi * L + s0 + x + 1] = stage[wl * (kWalkStage + 1) + x];
+        out[(w0 + wl) * L + c0 + x] = cw_stage[wl * ls + x];
       }
       __syncthreads();
     }
@@ -1079,7 +1106,8 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
       auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
       const size_t o_counts = 0, o_rec = al(((size_t)walk_len + 2) * 4),
                    o_tid = o_rec + al(((size_t)walk_len + 1) * cap * 16), o_tsl = o_tid + al(2 * cap * 8),
-                   o_own = o_tsl + al(2 * cap * 4), total = o_own + al(2 * rows * 4);
+                   o_own = o_tsl + al(2 * cap * 4), o_tr = o_own + al(2 * rows * 4),
+                   total = o_tr + al(((size_t)walk_len + 1) * cap * 8);
       uint8_t* buf = nullptr;
       EG_HIP(hipMallocAsync((void**)&buf, total, st));
       c.counts = (uint32_t*)(buf + o_counts);
@@ -1101,8 +1129,17 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
         c.step = s2 + 1;
         hipLaunchKernelGGL(sample_kernel, dim3(grid), dim3(block), 0, st, c);
       }
-      hipLaunchKernelGGL(CwExpandKernel, dim3(GridFor(n, block)), dim3(block), 0, st, c, nodes_dev,
-                         out_dev);
+      {
+        int64_t* tr = (int64_t*)(buf + o_tr);
+        const int64_t chain_blocks = (n + (int64_t)block * kCwChains - 1) / ((int64_t)block * kCwChains);
+        hipLaunchKernelGGL(CwChainKernel, dim3((unsigned)chain_blocks), dim3(block), 0, st, c, nodes_dev, tr);
+        const int32_t L = walk_len + 1;
+        const int32_t ch = L <= 96 ? L : 64;                 // 64 x (ch | 1) x 8 bytes of LDS
+        const size_t lds = (size_t)64 * (ch | 1) * 8;
+        const int64_t tiles = (n + 63) / 64;
+        hipLaunchKernelGGL(CwTransposeKernel, dim3((unsigned)(tiles < 65536 ? tiles : 65536)), dim3(block),
+                           lds, st, tr, out_dev, n, L, ch);
+      }
       EG_HIP(hipGetLastError());
       (void)hipFreeAsync(buf, st);
     } else if (fast) {

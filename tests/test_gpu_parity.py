@@ -1606,18 +1606,19 @@ def test_fanout_local_dedup_kernel(EA, O, torch_cuda, big_pair, geom):
 
 def test_random_walk_over_merged_walkers(EA, O, torch_cuda, big_pair):
     """DeepWalk over groups of merged walkers (walk_kernels.hip: CwSampleKernel /
-    CwNumberKernel / CwExpandKernel, tuning key 38): walkers that meet on a node in a step
+    CwNumberKernel / CwChainKernel / CwTransposeKernel, tuning key 38): walkers that meet on a node in a step
     share every later draw (the draw is keyed by node id and step), so the walk is run once
     per distinct node and expanded.  Same paths as the per-walker kernel and the oracle -
     duplicate and unknown start nodes, dangling neighbour ids (never merged: they are
     different ids), rows without the listed type, hashed and identity id maps, one listed
-    type (pivot search) and several (reference loop), walk lengths around the staging size."""
+    type (pivot search) and several (reference loop), walk lengths around the staging size
+    and beyond what the transpose holds in LDS at once (131 steps: three passes)."""
     torch = torch_cuda
     from euler_amd import _lib
     L = _lib.lib()
     G, OG, ids, rng = big_pair
     try:
-        for n, walk_len, et in ((5000, 9, [[0, 1, 2, 3]]), (777, 4, [[2]]), (3000, 17, [[1, 3]]),
+        for n, walk_len, et in ((5000, 9, [[0, 1, 2, 3]]), (777, 4, [[2]]), (3000, 17, [[1, 3]]), (300, 130, [[1]]),
                                 (2500, 8, [[3]])):
             et_w = et * walk_len
             q = np.concatenate([rng.choice(ids, n), rng.choice(ids, 50).repeat(4),
