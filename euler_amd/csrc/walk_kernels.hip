@@ -408,6 +408,8 @@ __global__ __launch_bounds__(256) void TopKNeighborKernel(const TopKArgs a) {
 // key 38: DeepWalk (p = q = 1) of at least this many walkers runs over groups of merged
 // walkers (CwSampleKernel ...); 0 = never
 thread_local int g_walk_collapse = 131072;
+thread_local int g_walk_tail = 12;        // key 43: first step of the merged walk that stops looking for mergers
+                                          // (the rest of the walk is one launch; 0 = never)
 thread_local int g_walk_grid = 1024;      // key 39: workgroups of its per-step launches (0 = one per 256 walkers)
 
 struct WalkArgs {
@@ -516,6 +518,10 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void RandomWalkKernel(const Wal
 //                    them in the table;
 //   CwSampleKernel   (next step, same launch) first reads every group's number back into
 //                    its record;
+//   CwTailKernel     from step `tail` on (tuning key 43, default 12) the groups walk on WITHOUT
+//                    looking for further mergers, all remaining steps in one launch: by then
+//                    a step is ~30 K groups - two launches of ~13 + ~5.5 us that are all
+//                    latency - and the few mergers still to come save less than they cost;
 //   CwChainKernel    walker w follows the records, one 16-byte load per step (four walkers
 //                    per lane: four chains in flight), and leaves its path TRANSPOSED,
 //                    [step][walker] - every store a full run of 512 bytes;
@@ -596,6 +602,48 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void CwSampleKernel(const CwArg
     a.tmp_id[par][gidx] = id;
     a.tmp_slot[par][gidx] = slot;
     a.owner[par][slot] = (uint32_t)gidx;       // benign race: one group naming the row survives
+  }
+}
+
+// The rest of the walk for the groups of level a.step, no more merging: group g of every later
+// level is group g.  (First the numbers step a.step - 1 left in its table, as CwSampleKernel.)
+template <bool FAST>
+__global__ __launch_bounds__(256, kWavesPerSimd) void CwTailKernel(const CwArgs a) {
+  const int32_t s0 = a.step;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n_prev = (int64_t)a.counts[s0 - 1];
+  const int64_t n_cur = (int64_t)a.counts[s0];
+  for (int64_t gidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+       gidx < n_prev || gidx < n_cur; gidx += stride) {
+    if (gidx < n_prev) {
+      const int par = (s0 - 1) & 1;
+      const uint32_t sl = a.tmp_slot[par][gidx];
+      if (sl != (uint32_t)a.g.n_rows)
+        a.rec[(int64_t)(s0 - 1) * a.cap + gidx].next = a.owner[par][sl] & ~kCwFlag;
+    }
+    if (gidx >= n_cur) continue;
+    uint64_t cur = a.rec[(int64_t)s0 * a.cap + gidx].id;
+    a.rec[(int64_t)s0 * a.cap + gidx].next = (uint32_t)gidx;
+    for (int32_t s = s0; s < a.walk_len; ++s) {
+      uint64_t id = 0;
+      float w;
+      int32_t t;
+      const int64_t row = FindRow(a.g, cur);
+      if (FAST) {
+        Segment sg;
+        if (LoadSegment<true>(a.g, row, a.edge_types[s], &sg)) {
+          const Philox4 blk = RngBlock(a.seed, a.call_id + (uint32_t)s, kDomainNeighbor, cur, 0);
+          BlockPivotSample(a.g, sg, UnitFromWords(blk.w[0], blk.w[1]), &id, &w);
+        }
+      } else {
+        RowSampler rs;
+        InitRowSampler(rs, a.g, row, a.edge_types + s * a.k, a.k);
+        if (rs.valid) SampleAt(rs, a.seed, a.call_id + (uint32_t)s, cur, 0, &id, &w, &t);
+      }
+      *reinterpret_cast<uint4*>(&a.rec[(int64_t)(s + 1) * a.cap + gidx]) =
+          make_uint4((uint32_t)id, (uint32_t)(id >> 32), (uint32_t)gidx, 0u);
+      cur = id;
+    }
   }
 }
 
@@ -1123,11 +1171,19 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
       c.step = 0;
       auto sample_kernel = fast ? CwSampleKernel<true> : CwSampleKernel<false>;
       hipLaunchKernelGGL(sample_kernel, dim3(grid), dim3(block), 0, st, c);
-      for (int32_t s2 = 0; s2 < walk_len; ++s2) {
+      // first step of the tail (walk_len: none)
+      const int32_t tail = g_walk_tail > 0 && g_walk_tail < walk_len ? g_walk_tail : walk_len;
+      for (int32_t s2 = 0; s2 < tail; ++s2) {
         c.step = s2;
         hipLaunchKernelGGL(CwNumberKernel, dim3(grid), dim3(block), 0, st, c);
         c.step = s2 + 1;
-        hipLaunchKernelGGL(sample_kernel, dim3(grid), dim3(block), 0, st, c);
+        if (s2 + 1 < tail || tail == walk_len)
+          hipLaunchKernelGGL(sample_kernel, dim3(grid), dim3(block), 0, st, c);
+      }
+      if (tail < walk_len) {
+        c.step = tail;
+        auto tail_kernel = fast ? CwTailKernel<true> : CwTailKernel<false>;
+        hipLaunchKernelGGL(tail_kernel, dim3(grid), dim3(block), 0, st, c);
       }
       {
         int64_t* tr = (int64_t*)(buf + o_tr);

@@ -1609,6 +1609,7 @@ def test_random_walk_over_merged_walkers(EA, O, torch_cuda, big_pair):
     CwNumberKernel / CwChainKernel / CwTransposeKernel, tuning key 38): walkers that meet on a node in a step
     share every later draw (the draw is keyed by node id and step), so the walk is run once
     per distinct node and expanded.  Same paths as the per-walker kernel and the oracle -
+    after `tail` steps (key 43) the groups stop merging and finish the walk in one launch;
     duplicate and unknown start nodes, dangling neighbour ids (never merged: they are
     different ids), rows without the listed type, hashed and identity id maps, one listed
     type (pivot search) and several (reference loop), walk lengths around the staging size
@@ -1626,12 +1627,15 @@ def test_random_walk_over_merged_walkers(EA, O, torch_cuda, big_pair):
             qt = torch.as_tensor(q).cuda()
             G.set_seed(41)
             want = OG.random_walk(41, 500, q, et_w, walk_len, 1.0, 1.0, -9)
-            L.euler_gpu_set_tuning(38, 1)
-            got = G.random_walk(qt, et_w, 1.0, 1.0, -9, call_id=500)
             L.euler_gpu_set_tuning(38, 0)
             ref = G.random_walk(qt, et_w, 1.0, 1.0, -9, call_id=500)
-            assert np.array_equal(t2n(got), want), (n, walk_len, et)
-            assert torch.equal(got, ref)
+            assert np.array_equal(t2n(ref), want), (n, walk_len, et)
+            # merging all the way (0), then from step 1 / 3 / 12 on every group walks alone
+            for tail in (0, 1, 3, 12):
+                L.euler_gpu_set_tuning(38, 1)
+                L.euler_gpu_set_tuning(43, tail)
+                got = G.random_walk(qt, et_w, 1.0, 1.0, -9, call_id=500)
+                assert torch.equal(got, ref), (n, walk_len, et, tail)
         # identity ids, hubs: most walkers merge within a few steps
         p = EA.synth_params(17, 30000, 600000, n_types=1, weighted=True)
         po = O.SynthParams()
@@ -1641,12 +1645,16 @@ def test_random_walk_over_merged_walkers(EA, O, torch_cuda, big_pair):
         q = np.random.default_rng(3).integers(1, 30001, 40000).astype(np.int64)
         G1.set_seed(8)
         L.euler_gpu_set_tuning(38, 1)
-        got = G1.random_walk(torch.as_tensor(q).cuda(), [[0]] * 12, 1.0, 1.0, 30001, call_id=3)
-        assert np.array_equal(t2n(got), OG1.random_walk(8, 3, q, [[0]] * 12, 12, 1.0, 1.0, 30001))
+        want1 = OG1.random_walk(8, 3, q, [[0]] * 12, 12, 1.0, 1.0, 30001)
+        for tail in (0, 5, 11):
+            L.euler_gpu_set_tuning(43, tail)
+            got = G1.random_walk(torch.as_tensor(q).cuda(), [[0]] * 12, 1.0, 1.0, 30001, call_id=3)
+            assert np.array_equal(t2n(got), want1), tail
         frac = len(np.unique(t2n(got)[:, -1])) / len(q)
         assert frac < 0.5, frac          # the premise: walkers do merge on a power-law graph
     finally:
         L.euler_gpu_set_tuning(38, 131072)
+        L.euler_gpu_set_tuning(43, 12)
 
 
 def test_fanout_unique_rows_and_index(EA, O, torch_cuda, big_pair):
