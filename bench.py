@@ -462,8 +462,29 @@ def run_hetero(args, quiet=False):
     # D floats read at random and written in order: 8 E D + 4 E bytes)
     r = roots[n_steps - 1]
     ph = {}
+    host_us = {}
+    from euler_amd import _lib as _lib0
+    L0 = _lib0.lib()
+    o_n = torch.empty((B, CNT), dtype=torch.int64, device="cuda")
+    o_w = torch.empty((B, CNT), dtype=torch.float32, device="cuda")
+    o_t = torch.empty((B, CNT), dtype=torch.int32, device="cuda")
     for c, et in enumerate(type_sets):
-        ph["sample k=%d" % len(et)] = _events(lambda: G.sample_neighbor(r, et, CNT, N + 1, call_id=c), 10)
+        # the launch alone, enqueued back to back from C between two HIP events on its stream
+        # (a Python call of the op costs the host more than the kernel runs: see host_us_per_call)
+        ms_c = C.c_float(0)
+        eta0 = (C.c_int32 * len(et))(*et)
+        _lib0.check(L0.euler_gpu_time_sample_neighbor(
+            G._h, C.c_void_p(torch.cuda.current_stream().cuda_stream), GRAPH_SEED,
+            C.c_void_p(r.data_ptr()), B, eta0, len(et), CNT, _lib0.LAYOUT_TF,
+            C.c_void_p(o_n.data_ptr()), C.c_void_p(o_w.data_ptr()), C.c_void_p(o_t.data_ptr()), 20,
+            C.byref(ms_c)))
+        ph["sample k=%d" % len(et)] = float(ms_c.value)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            G.sample_neighbor(r, et, CNT, N + 1, call_id=c)
+        host_us["sample k=%d" % len(et)] = (time.perf_counter() - t0) / 50 * 1e6     # enqueue only
+        torch.cuda.synchronize()
     nb = G.sample_neighbor(r, [3], CNT, N + 1, call_id=0)[0].reshape(-1).to(torch.int32)
     g_ms = _events(lambda: ops.gather(feat, nb), 10)
     x = ops.gather(feat, nb)
@@ -547,7 +568,11 @@ def run_hetero(args, quiet=False):
                                    else "ops.gather + ops.scatter_mean"),
                    "phases_ms": dict({k_: round(v_, 4) for k_, v_ in ph.items()},
                                      gather=round(g_ms, 4), scatter_mean=round(s_ms, 4),
-                                     gather_scatter_mean=round(f_ms, 4))},
+                                     gather_scatter_mean=round(f_ms, 4)),
+                   "host_us_per_call": {k_: round(v_, 1) for k_, v_ in host_us.items()},
+                   "host_note": "phases_ms of the sampling launches are kernel times (enqueued from C); "
+                                "a step issues 9 Python ops whose enqueue cost (host_us_per_call) is of the "
+                                "same order - the step rate of this leg is a host-bound figure"},
         "roofline": roof,
         "cpu_baseline": None,
     }

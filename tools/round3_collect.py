@@ -6,6 +6,11 @@ tag = sys.argv[1]
 os.makedirs('profiles', exist_ok=True)
 for f in glob.glob('gpurun_out/%s_trace/**/*kernel_stats.csv' % tag, recursive=True):
     shutil.copy(f, 'profiles/%s_kernel_stats.csv' % tag)
+for wl in ('deepwalk', 'hetero'):
+    for f in glob.glob('gpurun_out/%s_%s_trace/**/*kernel_stats.csv' % (tag, wl), recursive=True):
+        # keep the library's kernels and the few torch ones; drop the graph generator's one-off launches
+        rows = [l for l in open(f) if 'Synth' not in l and 'BuildBlocks' not in l and 'BuildPivot' not in l]
+        open('profiles/%s_%s_kernel_stats.csv' % (tag, wl), 'w').writelines(rows)
 p = 'gpurun_out/pmc_%s.json' % tag
 if os.path.exists(p):
     doc = json.load(open(p))

@@ -13,6 +13,11 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$
 echo "trace rc=$?"
 bash tools/pmc_fl.sh ${tag} "" > gpurun_out/${tag}_pmc.log 2>&1
 echo "pmc rc=$?"
+for wl in deepwalk hetero; do
+  timeout 280 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_${wl}_trace -o trace \
+     -- python bench.py --workload ${wl} --steps 3 --warmup 1 > gpurun_out/${tag}_${wl}_trace.log 2>&1
+  echo "${wl} trace rc=$?"
+done
 timeout 600 python bench.py ${BENCH_ARGS} > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 echo "bench rc=$?"
 tail -c 600 gpurun_out/${tag}_bench.json
