@@ -383,7 +383,9 @@ __device__ __forceinline__ float FloorToFloat(double r) {
 }
 
 // Both draws of one Philox block on one row.  lo = first edge, deg > 0, total = the row's
-// last running sum.  m[] = the edge drawn (global index).
+// last running sum.  m[] = the edge drawn (global index).  TWO = false: draw 0 only (the
+// walks take one sample per node and step).
+template <bool TWO = true>
 __device__ __forceinline__ void LeanSamplePair(const GraphView& g, const uint32_t lo,
                                                const int32_t deg, const float total,
                                                const bool live, const double u0, const double u1,
@@ -418,18 +420,18 @@ __device__ __forceinline__ void LeanSamplePair(const GraphView& g, const uint32_
   }
   // cold: Q3 (r rounded up to the row's end) or a row beyond the levels' reach
   const bool cold0 = live && (!((double)total > r0) || K > kPivotLevels);
-  const bool cold1 = live && (!((double)total > r1) || K > kPivotLevels);
+  const bool cold1 = TWO && live && (!((double)total > r1) || K > kPivotLevels);
   if (K > kPivotLevels) K = 0;
   uint32_t x[2] = {l1, l1};
   bool found[2] = {false, false}, onl[2] = {true, true};
-  int32_t ks[2] = {K, K};               // the level a draw's walk starts at
+  int32_t ks[2] = {K, TWO ? K : 0};     // the level a draw's walk starts at
   const bool guess = K > kg && !(ablate & 128);
   if (__ballot(guess) != 0ull) {
     const float* gl = kg == 1 ? g.skip1 : g.bpiv + (kg == 2 ? g.bpiv_off[2] : kg == 3 ? g.bpiv_off[3]
                                                                                    : g.bpiv_off[4]);
     const float inv = __frcp_rn(total) * (float)(hg - lg + 1u);
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < (TWO ? 2 : 1); ++s) {
       if (guess) {
         uint32_t e = lg + (uint32_t)(f[s] * inv);
         // window of entries wq .. wq + 3 (all inside the row: hg - lg >= 5 here),
@@ -471,7 +473,7 @@ __device__ __forceinline__ void LeanSamplePair(const GraphView& g, const uint32_
       uint32_t dl = 0, dh = 0;
       if (k < K) { dl = ldig & 7u; dh = hdig & 7u; ldig >>= 3; hdig >>= 3; }
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+      for (int s = 0; s < (TWO ? 2 : 1); ++s) {
         if (k <= ks[s]) {
           uint32_t c_lo, c_hi;
           if (k == K) { c_lo = lt; c_hi = ht; }
@@ -494,8 +496,9 @@ __device__ __forceinline__ void LeanSamplePair(const GraphView& g, const uint32_
     }
   }
   // leaf: block x[s] holds the answer
+  if (!TWO) { id[1] = 0; w[1] = 0.f; m[1] = lo; }
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
+  for (int s = 0; s < (TWO ? 2 : 1); ++s) {
     const EdgeBlock* bk = g.blk + x[s];
     const uint32_t i_lo = x[s] == l1 ? lo_off : 0u;
     const uint32_t i_hi = found[s] ? (uint32_t)(kEdgesPerBlock - 1) : hi_off;   // inclusive
@@ -549,7 +552,7 @@ __device__ __forceinline__ void LeanSamplePair(const GraphView& g, const uint32_
     // compact_weighted_collection.h:30-52) - right on every row, slow, rare; once in
     // the code for both draws
 #pragma nounroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < (TWO ? 2 : 1); ++s) {
       if (s == 0 ? cold0 : cold1) {
         const float* nw = g.prefix_w + lo;
         const uint32_t mid = (uint32_t)RandomSelect(nw, 0, (uint64_t)(deg - 1), s == 0 ? u0 : u1);

@@ -15,7 +15,7 @@
 #include "fanout_local.h"
 
 extern thread_local int g_feature_vec4;   // mp_kernels.hip
-namespace euler_gpu { extern thread_local int g_walk_collapse, g_walk_grid, g_walk_tail; }   // walk_kernels.hip
+namespace euler_gpu { extern thread_local int g_walk_collapse, g_walk_grid, g_walk_tail, g_walk_lean; }   // walk_kernels.hip
 namespace euler_gpu { extern thread_local int g_root_host_batch, g_adj_scan, g_adj_long_row, g_sum_scalar; }   // layer_kernels.hip
 
 namespace euler_gpu {
@@ -1604,6 +1604,7 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 38 && value >= 0) { g_walk_collapse = value; return EULER_GPU_OK; }
   if (key == 39 && value >= 0) { g_walk_grid = value; return EULER_GPU_OK; }
   if (key == 43 && value >= 0) { g_walk_tail = value; return EULER_GPU_OK; }
+  if (key == 44 && (value == 0 || value == 1)) { g_walk_lean = value; return EULER_GPU_OK; }
   if (key == 35 && (value == 5 || value == 6 || value == 8)) { g_fl_wps = value; return EULER_GPU_OK; }
   return Fail(EULER_GPU_EINVAL, "set_tuning: unknown key");
 }

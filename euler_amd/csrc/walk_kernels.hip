@@ -8,6 +8,7 @@
 
 #include "k1_args.h"
 #include "k1_search.h"
+#include "fanout_local.h"     // LeanSamplePair (the walks over merged walkers)
 #include "wave_sums.h"
 
 namespace euler_gpu {
@@ -408,6 +409,7 @@ __global__ __launch_bounds__(256) void TopKNeighborKernel(const TopKArgs a) {
 // key 38: DeepWalk (p = q = 1) of at least this many walkers runs over groups of merged
 // walkers (CwSampleKernel ...); 0 = never
 thread_local int g_walk_collapse = 131072;
+thread_local int g_walk_lean = 1;         // key 44: plain graphs draw with the lean search of the one-kernel fanout
 thread_local int g_walk_tail = 12;        // key 43: first step of the merged walk that stops looking for mergers
                                           // (the rest of the walk is one launch; 0 = never)
 thread_local int g_walk_grid = 1024;      // key 39: workgroups of its per-step launches (0 = one per 256 walkers)
@@ -560,7 +562,49 @@ __global__ __launch_bounds__(256) void CwInitKernel(const CwArgs a, const int64_
     a.rec[i].id = (uint64_t)starts[i];
 }
 
-template <bool FAST>
+// One step's draw for the node `cur` (draw 0 of its Philox block, call_id + step); 0 = none.
+// MODE 0: the reference loop (several listed types, or running sums that are not
+// monotone); 1: block-pivot search of one listed type; 2: plain graphs (one edge-type
+// group, the row total in its record, identity id map, fewer than 2^31 edges) - the lean
+// search of the one-kernel fanout with its interpolation start: the groups of the later
+// steps stand on hubs, where it skips the upper pivot levels (fanout_local.h).
+template <int MODE>
+__device__ __forceinline__ uint64_t CwDraw(const CwArgs& a, const uint64_t cur, const int32_t s) {
+  uint64_t id = 0;
+  float w;
+  int32_t t;
+  if (MODE == 2) {
+    const GraphView& g = a.g;
+    const int64_t row = LeanFindRow(g, cur);
+    uint32_t lo = 0;
+    int32_t deg = 0;
+    float total = 0.f;
+    if (row >= 0 && a.edge_types[s] == 0) {
+      const uint4 rec = *reinterpret_cast<const uint4*>(g.row_meta + row * 16);
+      lo = rec.x; deg = (int32_t)rec.z; total = __uint_as_float(rec.w);
+    }
+    const bool live = deg > 0;
+    const Philox4 blk = RngBlock(a.seed, a.call_id + (uint32_t)s, kDomainNeighbor, cur, 0);
+    uint64_t id2[2]; float w2[2]; uint32_t m2[2];
+    LeanSamplePair<false>(g, lo, deg, total, live, UnitFromWords(blk.w[0], blk.w[1]), 0.0, id2, w2, m2);
+    return live ? id2[0] : 0;
+  }
+  const int64_t row = FindRow(a.g, cur);
+  if (MODE == 1) {
+    Segment sg;
+    if (LoadSegment<true>(a.g, row, a.edge_types[s], &sg)) {
+      const Philox4 blk = RngBlock(a.seed, a.call_id + (uint32_t)s, kDomainNeighbor, cur, 0);
+      BlockPivotSample(a.g, sg, UnitFromWords(blk.w[0], blk.w[1]), &id, &w);
+    }
+  } else {
+    RowSampler rs;
+    InitRowSampler(rs, a.g, row, a.edge_types + s * a.k, a.k);
+    if (rs.valid) SampleAt(rs, a.seed, a.call_id + (uint32_t)s, cur, 0, &id, &w, &t);
+  }
+  return id;
+}
+
+template <int MODE>
 __global__ __launch_bounds__(256, kWavesPerSimd) void CwSampleKernel(const CwArgs a) {
   const int32_t s = a.step;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -581,21 +625,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void CwSampleKernel(const CwArg
     // (2) this step's draw
     if (gidx >= n_cur) continue;
     const uint64_t cur = a.rec[(int64_t)s * a.cap + gidx].id;
-    uint64_t id = 0;
-    float w;
-    int32_t t;
-    const int64_t row = FindRow(a.g, cur);
-    if (FAST) {
-      Segment sg;
-      if (LoadSegment<true>(a.g, row, a.edge_types[s], &sg)) {
-        const Philox4 blk = RngBlock(a.seed, a.call_id + (uint32_t)s, kDomainNeighbor, cur, 0);
-        BlockPivotSample(a.g, sg, UnitFromWords(blk.w[0], blk.w[1]), &id, &w);
-      }
-    } else {
-      RowSampler rs;
-      InitRowSampler(rs, a.g, row, a.edge_types + s * a.k, a.k);
-      if (rs.valid) SampleAt(rs, a.seed, a.call_id + (uint32_t)s, cur, 0, &id, &w, &t);
-    }
+    const uint64_t id = CwDraw<MODE>(a, cur, s);
     const int par = s & 1;
     const int64_t nrow = FindRow(a.g, id);
     const uint32_t slot = nrow < 0 ? (uint32_t)a.g.n_rows : (uint32_t)nrow;
@@ -607,7 +637,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void CwSampleKernel(const CwArg
 
 // The rest of the walk for the groups of level a.step, no more merging: group g of every later
 // level is group g.  (First the numbers step a.step - 1 left in its table, as CwSampleKernel.)
-template <bool FAST>
+template <int MODE>
 __global__ __launch_bounds__(256, kWavesPerSimd) void CwTailKernel(const CwArgs a) {
   const int32_t s0 = a.step;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -625,21 +655,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void CwTailKernel(const CwArgs 
     uint64_t cur = a.rec[(int64_t)s0 * a.cap + gidx].id;
     a.rec[(int64_t)s0 * a.cap + gidx].next = (uint32_t)gidx;
     for (int32_t s = s0; s < a.walk_len; ++s) {
-      uint64_t id = 0;
-      float w;
-      int32_t t;
-      const int64_t row = FindRow(a.g, cur);
-      if (FAST) {
-        Segment sg;
-        if (LoadSegment<true>(a.g, row, a.edge_types[s], &sg)) {
-          const Philox4 blk = RngBlock(a.seed, a.call_id + (uint32_t)s, kDomainNeighbor, cur, 0);
-          BlockPivotSample(a.g, sg, UnitFromWords(blk.w[0], blk.w[1]), &id, &w);
-        }
-      } else {
-        RowSampler rs;
-        InitRowSampler(rs, a.g, row, a.edge_types + s * a.k, a.k);
-        if (rs.valid) SampleAt(rs, a.seed, a.call_id + (uint32_t)s, cur, 0, &id, &w, &t);
-      }
+      const uint64_t id = CwDraw<MODE>(a, cur, s);
       *reinterpret_cast<uint4*>(&a.rec[(int64_t)(s + 1) * a.cap + gidx]) =
           make_uint4((uint32_t)id, (uint32_t)(id >> 32), (uint32_t)gidx, 0u);
       cur = id;
@@ -1169,7 +1185,11 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
       unsigned grid = (unsigned)((n + block - 1) / block);
       if (g_walk_grid > 0 && grid > (unsigned)g_walk_grid) grid = (unsigned)g_walk_grid;
       c.step = 0;
-      auto sample_kernel = fast ? CwSampleKernel<true> : CwSampleKernel<false>;
+      const GraphView& v = g->view;
+      const int mode = !fast ? 0
+                       : (g_walk_lean != 0 && v.T == 1 && v.total_in_meta != 0 && v.map_mode == 0 &&
+                          v.uniform_w == 0 && v.n_edges < ((int64_t)1 << 31)) ? 2 : 1;
+      auto sample_kernel = mode == 2 ? CwSampleKernel<2> : mode == 1 ? CwSampleKernel<1> : CwSampleKernel<0>;
       hipLaunchKernelGGL(sample_kernel, dim3(grid), dim3(block), 0, st, c);
       // first step of the tail (walk_len: none)
       const int32_t tail = g_walk_tail > 0 && g_walk_tail < walk_len ? g_walk_tail : walk_len;
@@ -1182,7 +1202,7 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
       }
       if (tail < walk_len) {
         c.step = tail;
-        auto tail_kernel = fast ? CwTailKernel<true> : CwTailKernel<false>;
+        auto tail_kernel = mode == 2 ? CwTailKernel<2> : mode == 1 ? CwTailKernel<1> : CwTailKernel<0>;
         hipLaunchKernelGGL(tail_kernel, dim3(grid), dim3(block), 0, st, c);
       }
       {

@@ -1642,19 +1642,40 @@ def test_random_walk_over_merged_walkers(EA, O, torch_cuda, big_pair):
         for f, _ in po._fields_:
             setattr(po, f, getattr(p, f))
         G1, OG1 = EA.Graph.synthetic(p), O.OracleGraph(O.synth_csr(po))
-        q = np.random.default_rng(3).integers(1, 30001, 40000).astype(np.int64)
+        q = np.concatenate([np.random.default_rng(3).integers(1, 30001, 40000),
+                            [0, 30001, 2 ** 40, 1, 1]]).astype(np.int64)
         G1.set_seed(8)
         L.euler_gpu_set_tuning(38, 1)
         want1 = OG1.random_walk(8, 3, q, [[0]] * 12, 12, 1.0, 1.0, 30001)
-        for tail in (0, 5, 11):
+        # a plain graph: the draws come from the lean search (key 44) or the block pivots
+        for lean, tail in ((1, 0), (1, 5), (1, 11), (0, 5)):
+            L.euler_gpu_set_tuning(44, lean)
             L.euler_gpu_set_tuning(43, tail)
             got = G1.random_walk(torch.as_tensor(q).cuda(), [[0]] * 12, 1.0, 1.0, 30001, call_id=3)
-            assert np.array_equal(t2n(got), want1), tail
+            assert np.array_equal(t2n(got), want1), (lean, tail)
+        # a listed type the graph does not have: every walker stops at once
+        L.euler_gpu_set_tuning(44, 1)
+        got = G1.random_walk(torch.as_tensor(q).cuda(), [[0], [0], [2], [0], [0]], 1.0, 1.0, 30001, call_id=9)
+        assert np.array_equal(t2n(got), OG1.random_walk(8, 9, q, [[0], [0], [2], [0], [0]], 5, 1.0, 1.0, 30001))
+        # hubs of thousands of edges (several pivot levels, the interpolation start)
+        ph = EA.synth_params(31, 3000, 900000, n_types=1, weighted=True)
+        po = O.SynthParams()
+        for f, _ in po._fields_:
+            setattr(po, f, getattr(ph, f))
+        G2, OG2 = EA.Graph.synthetic(ph), O.OracleGraph(O.synth_csr(po))
+        q2 = np.random.default_rng(4).integers(1, 3001, 9000).astype(np.int64)
+        G2.set_seed(5)
+        want2 = OG2.random_walk(5, 77, q2, [[0]] * 9, 9, 1.0, 1.0, 3001)
+        for tail in (0, 4):
+            L.euler_gpu_set_tuning(43, tail)
+            got = G2.random_walk(torch.as_tensor(q2).cuda(), [[0]] * 9, 1.0, 1.0, 3001, call_id=77)
+            assert np.array_equal(t2n(got), want2), tail
         frac = len(np.unique(t2n(got)[:, -1])) / len(q)
         assert frac < 0.5, frac          # the premise: walkers do merge on a power-law graph
     finally:
         L.euler_gpu_set_tuning(38, 131072)
         L.euler_gpu_set_tuning(43, 12)
+        L.euler_gpu_set_tuning(44, 1)
 
 
 def test_fanout_unique_rows_and_index(EA, O, torch_cuda, big_pair):
