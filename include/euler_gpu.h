@@ -809,30 +809,26 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
                                 int32_t* split_cnt_host);
 
 /* ---- tuning ---------------------------------------------------------------
- * key 0: sample_neighbor kernel for single-type calls on graphs with
- *        non-decreasing running sums: 5 = pivot levels [default], 4 = wave-staged
- *        LDS search, 3 = blocked index, 2 = flat arrays / several samples per
- *        lane, 1 = flat arrays / one sample per lane, 0 = always the generic
- *        reference-loop kernel.
- * key 1: samples per lane of variant 2 (1, 2, 4 or 8).
+ * (keys 1, 6, 19, 21, 22, 26 belonged to kernels retired in round 3: EINVAL)
+ * key 0: sample_neighbor kernel for single-type calls on graphs with non-decreasing
+ *        running sums: 6 = block pivots over EdgeBlocks [default], 5 = pivot levels over
+ *        the flat arrays, 0 = always the generic reference-loop kernel.
  * key 2: measurement only (ablation mask).
  * key 3: workgroup cap of the sample_neighbor launches: -1 = by concurrency [default]: a
  *        caller that alternates streams between calls (several minibatches in flight)
  *        gets 4096 = 16 waves per CU, so that the kernels of two streams fit on the
  *        chip together, every other call 32 768; 0 = always 32 768; > 0 = that many.
- * key 4: variant 5 draws two adjacent samples per lane when count is even (1).
- * key 6: five adjacent samples per lane for odd counts that are a multiple of 5
- *        (default 0: measured slower on the metric's first hop).
+ * key 4: the pivot kernels draw two adjacent samples per lane when count is even (1).
+ * key 5: duplicate roots: 0 = never look, 1 = look when a call has >= 100 000
+ *        roots [default], 2 = always look.
  * key 7: node2vec kernel: 2 = one wave per walker, runs of children below the
  *        parent cursor resolved by all lanes at once, running sums as integer sums
  *        inside a binade [default]; 3 = the same launched per step, child lists of
  *        key 25 entries or more (default 8192, 0 = none) by a 16-wave workgroup;
  *        1 = one wave per walker, lane 0 walks LDS-staged lists; 0 = one lane per
  *        walker.
- * key 5: duplicate roots: 0 = never look, 1 = look when a call has >= 100 000
- *        roots [default], 2 = always look.
  * key 8: dense-feature kernel: 16-byte loads when the slots allow it (1).
- * key 9: fanout: a hop's kernels enter their ids into the next hop's owner
+ * key 9: fanout, hop by hop: a hop's kernels enter their ids into the next hop's owner
  *        table, 1 [default]; 0 = every hop runs its own mark pass.
  * key 10: expansion of the distinct roots' rows: grid-stride steps in flight per
  *        lane (1, 2 [default], 4).  key 11: rebuild the type column of
@@ -854,18 +850,10 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  *        16384) are cut into segments handled by separate workgroups.
  * key 18: edge weight sums of long rows: 0 = lane-shifting DPP chain [default],
  *        1 = scalar loads and a wave-uniform chain (measured 2x slower).
- * key 19: sample_neighbor calls that do not take the duplicate-root path (first
- *        hop of a fanout, calls below 100 000 roots), single listed type,
- *        4 <= count <= 64: 1 = one lane per ROOT (the row's running sums in
- *        registers, samples staged in LDS and written in output order) for launches
- *        of >= 2^20 samples of a caller that alternates streams [default]; 2 = for
- *        every launch; 0 = one lane per sample
- *        (alone the two designs measure within 10 % of each other on the metric's
- *        first hop; with two minibatches in flight the row kernel wins).
- * key 21: last hop, even count: the lean expansion kernel (1 [default]).
- * key 22: the pass over the distinct roots draws two samples per lane (default 0:
- *        measured 16 % slower).
- * key 23: a 2-hop fanout of single listed types below the duplicate-root threshold
+ * key 20: last hop of a fanout with key 14 = 2: 1 = the expansion reads every
+ *        position's row number from the owner table itself; 0 = a separate resolve
+ *        kernel fills an index array first [default: measured 9 us faster].
+ * key 23: a 2-hop fanout of single listed types below key 33's batch size
  *        (the reference examples' batch of 1 024) runs as ONE launch: a workgroup
  *        draws a root's first-hop samples and, from LDS, their second-hop samples
  *        (1 [default]); 0 = one launch per hop.
@@ -873,13 +861,25 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  *        whatever rows they belong to (1 [default]); 0 = one wave per queried node.
  * key 25: node2vec with key 7 = 3: child lists of this many entries or more go to the
  *        workgroup kernel (default 8192; 0 = none).
- * key 26: single-type graphs created while it is 1 get a 128-byte line per row (record,
- *        running sums and ids of its first 9 edges) and rows of <= 9 edges are sampled
- *        from that one line; 0 [default] = record -> [block pivots ->] EdgeBlock as for
- *        longer rows (measured: no faster on the metric step, +12.8 GB).
- * key 20: last hop of a fanout with key 14 = 2: 1 = the expansion reads every
- *        position's row number from the owner table itself; 0 = a separate resolve
- *        kernel fills an index array first [default: measured 9 us faster].
+ * key 27: the one-kernel fanout (csrc/fanout_local.h: 2 hops, one listed type each,
+ *        >= key 33 roots): 1 = on weighted graphs [default], 2 = on every graph,
+ *        0 = off (hop by hop).  Its geometry: key 28 roots per wave (1..16, default 4),
+ *        key 29 distinct children sampled per pass (0 = 8 per root), key 30 threads
+ *        per workgroup (64 [default], 128, 256), key 31 weights / types as 16-byte
+ *        stores (1), key 32 cap on launched waves (-1 = 16 384 when the caller
+ *        alternates streams, else one tile per wave [default]; 0 = never; > 0 = that
+ *        many), key 33 smallest batch it takes (4096), key 34 plain graphs: 2 = the
+ *        lean build [default], 1 = the general build constant-folded, 0 = general,
+ *        key 35 register budget in waves per SIMD (5 [default: nothing spilled], 6, 8),
+ *        key 36 measurement only (ablation bits, FanoutLocalArgs::ablate).
+ * key 37: calls that draw the edge type (k != 1) on monotone graphs search the
+ *        neighbour with the block pivots (1 [default]); 0 = the reference loop.
+ * key 38: DeepWalk (p = q = 1) of at least this many walkers runs over groups of merged
+ *        walkers (default 131072; 0 = never).  key 39: workgroups of its per-step
+ *        launches (1024; 0 = one per 256 walkers).  key 43: first step from which the
+ *        groups stop looking for mergers and finish the walk in one launch (12; 0 =
+ *        never).  key 44: plain graphs draw with the lean search of the one-kernel
+ *        fanout (1 [default]).
  * All settings produce identical results; the knobs exist for A/B measurements
  * and tests.  They are THREAD-LOCAL: a call changes the launches the calling host
  * thread enqueues afterwards and nobody else's (new threads start from the
