@@ -1129,7 +1129,7 @@ def test_dedup_split_pack_expand(EA, O, torch_cuda):
     assert np.array_equal(t2n(o_t), t2n(r_t)[pos_n])
     assert np.array_equal(t2n(o_m), t2n(r_m)[pos_n])
     # single-type calls: no type column on the wire, types rebuilt from the mask
-    for cnt1 in (6, 5):
+    for cnt1 in (6, 5, 4, 2):          # even counts: the lean expansion; odd: the general kernel
         r_id1 = r_id[:, :cnt1].contiguous(); r_w1 = r_w[:, :cnt1].contiguous()
         packed1 = EA.ops.pack_rows(r_id1, r_w1, r_t[:, :cnt1].contiguous(), r_m, cnt1, single_type=3)
         assert tuple(packed1.shape) == (m, (3 * cnt1 + 3) & ~1)
