@@ -1,8 +1,11 @@
-"""BASELINE.json `configs` as parity cases.  configs[2] (the
-metric: 100M / 1B weighted, fanout [25,10]) is bench.py's workload and is
-property-checked at 2M nodes in test_gpu_parity.py::test_full_size_properties;
-the others are covered here, each against the CPU oracle (and the reference
-sampler build where it is present).
+"""BASELINE.json `configs` as parity cases, each against the CPU oracle
+(and the reference sampler build where it is present).
+
+  config 3  the metric at FULL size (100M nodes / 1B edges, weighted, fanout [25,10],
+            131 072 roots): the one-kernel step == the hop-by-hop kernels on all 36 M
+            samples, == the (distinct rows, index) form, == the oracle on 96 roots fed
+            with the rows exported from HBM; DeepWalk 1M x 40 over merged groups == the
+            per-walker kernel (bench.py repeats the oracle checks on every run)
 
   config 1  Cora-shaped graph, GraphSAGE 2-hop fanout [10,5], batch 32 - the
             whole minibatch construction on the CPU oracle (plumbing, no GPU)
@@ -113,6 +116,76 @@ def test_config2_products_shaped_uniform_fanout(EA, O, torch_cuda):
     assert np.array_equal(on[0], hop1.reshape(-1))
     assert np.array_equal(on[1], t2n(a[0][2]).reshape(4096, 250)[sel].reshape(-1))
     assert np.array_equal(ow[1], t2n(a[1][1]).reshape(4096, 250)[sel].reshape(-1))
+
+
+@pytest.mark.gpu
+def test_config3_metric_step_at_full_size(EA, O, torch_cuda):
+    """configs[2], the headline workload, at its full size: two independent device
+    paths agree bit for bit on every one of the step's 36 044 800 samples (the one-kernel
+    fanout of fanout_local.h against hop-by-hop sampling + global duplicate path +
+    expansion), the (distinct rows, index) form reproduces the dense one, the result is
+    a pure function of (seed, call id, roots), and 96 roots - with every hop-1 child's
+    row exported from HBM - equal the CPU oracle.  Same for DeepWalk of 1M walkers x 40
+    steps: groups of merged walkers == one lane per walker, 16 walkers == the oracle."""
+    torch = torch_cuda
+    from euler_amd import _lib
+    L = _lib.lib()
+    N, B = 100_000_000, 131072
+    G = EA.Graph.synthetic(EA.synth_params(20240521, N, 10 * N, weighted=True))
+    assert G.num_nodes == N and abs(G.num_edges - 10 * N) < 0.01 * 10 * N
+    G.set_seed(20240521)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(77)
+    roots = torch.randint(1, N + 1, (B,), generator=gen, device="cuda", dtype=torch.int64)
+    try:
+        L.euler_gpu_set_tuning(27, 1)
+        a = G.sample_fanout(roots, [[0], [0]], [25, 10], N + 1, call_id=6)
+        a2 = G.sample_fanout(roots, [[0], [0]], [25, 10], N + 1, call_id=6)
+        L.euler_gpu_set_tuning(27, 0)
+        h = G.sample_fanout(roots, [[0], [0]], [25, 10], N + 1, call_id=6)
+    finally:
+        L.euler_gpu_set_tuning(27, 1)
+    assert a[0][2].numel() == B * 250
+    for hop in range(2):
+        assert torch.equal(a[0][hop + 1], h[0][hop + 1]) and torch.equal(a[0][hop + 1], a2[0][hop + 1])
+        assert torch.equal(a[1][hop], h[1][hop]) and torch.equal(a[2][hop], h[2][hop])
+    del h, a2
+    id1, w1, t1, ridx, rid, rw, rt = G.sample_fanout_unique(roots, [[0], [0]], [25, 10], N + 1, call_id=6)
+    assert torch.equal(id1.reshape(-1), a[0][1])
+    assert torch.equal(rid[ridx].reshape(-1), a[0][2]) and torch.equal(rw[ridx].reshape(-1), a[1][1])
+    assert torch.equal(rt[ridx].reshape(-1), a[2][1])
+    del rid, rw, rt
+    # the oracle on 96 roots
+    sel = np.random.default_rng(5).choice(B, 96, replace=False)
+    r_sel = t2n(roots)[sel]
+    hop1 = t2n(a[0][1]).reshape(B, 25)[sel]
+    need = np.unique(np.concatenate([r_sel, hop1.reshape(-1)])).astype(np.uint64)
+    need = need[(need >= 1) & (need <= N)]
+    rp, te, nb, pw, tp = G.export_rows(need)
+    OG = O.OracleGraph(O.CSR(need, rp, te, nb, pw, tp, 1))
+    on, ow, ot = OG.sample_fanout(20240521, 6, r_sel, [[0], [0]], [25, 10], N + 1)
+    assert np.array_equal(on[0], hop1.reshape(-1))
+    assert np.array_equal(ow[0], t2n(a[1][0]).reshape(B, 25)[sel].reshape(-1))
+    assert np.array_equal(on[1], t2n(a[0][2]).reshape(B, 250)[sel].reshape(-1))
+    assert np.array_equal(ow[1], t2n(a[1][1]).reshape(B, 250)[sel].reshape(-1))
+    assert np.array_equal(ot[1], t2n(a[2][1]).reshape(B, 250)[sel].reshape(-1))
+    del a
+    # DeepWalk at configs[3]'s size on the same graph
+    W = 1_000_000
+    starts = torch.randint(1, N + 1, (W,), generator=gen, device="cuda", dtype=torch.int64)
+    et = [[0]] * 40
+    try:
+        L.euler_gpu_set_tuning(38, 131072)
+        m = G.random_walk(starts, et, 1.0, 1.0, N + 1, call_id=50)
+        L.euler_gpu_set_tuning(38, 0)
+        w = G.random_walk(starts, et, 1.0, 1.0, N + 1, call_id=50)
+    finally:
+        L.euler_gpu_set_tuning(38, 131072)
+    assert torch.equal(m, w)
+    walks = t2n(m[:16])
+    rows = np.unique(walks[walks <= N]).astype(np.uint64)
+    rp, te, nb, pw, tp = G.export_rows(rows)
+    OG = O.OracleGraph(O.CSR(rows, rp, te, nb, pw, tp, 1))
+    assert np.array_equal(walks, OG.random_walk(20240521, 50, t2n(starts[:16]), et, 40, 1.0, 1.0, N + 1))
 
 
 @pytest.mark.gpu
