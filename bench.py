@@ -452,6 +452,9 @@ def run_hetero(args, quiet=False):
         return line
     one_stream = None
     if side is not None:                       # the same steps on ONE stream, for the record
+        for i in range(args.warmup, n_steps):  # (untimed first: this stream's allocator pool is empty)
+            step(i)
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.warmup, n_steps):
             step(i)

@@ -12,7 +12,14 @@ from . import _lib
 from ._lib import check, lib
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """The current HIP stream of the current device as a pointer (torch.cuda.current_stream()
+    builds a Stream object for it: 8 us a call, a quarter of a small op's enqueue cost)."""
+    if _RAW_STREAM is not None:
+        return C.c_void_p(_RAW_STREAM(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
