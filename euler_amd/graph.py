@@ -39,6 +39,29 @@ _NULL_CTX = contextlib.nullcontext()
 
 
 _I32_CACHE = {}
+_FANOUT_PLANS = {}
+_WS_BYTES = {}
+
+
+def _fanout_plan(edge_types, counts):
+    """(edge types [layers, k] as int32 array, its pointer, k, counts array, its pointer) of a
+    fanout call; cached for list arguments (a training loop passes the same ones every step)."""
+    key = None
+    try:
+        key = (tuple(tuple(int(t) for t in row) for row in edge_types), tuple(int(c) for c in counts))
+        hit = _FANOUT_PLANS.get(key)
+        if hit is not None:
+            return hit
+    except TypeError:
+        key = None
+    layers = len(counts)
+    et = np.ascontiguousarray(np.asarray(edge_types, dtype=np.int32).reshape(layers, -1)) if layers \
+        else np.zeros((0, 0), np.int32)
+    cnt = np.ascontiguousarray(np.asarray(counts, dtype=np.int32).reshape(-1))
+    res = (et, et.ctypes.data_as(_I32), int(et.size // layers) if layers else 0, cnt, cnt.ctypes.data_as(_I32))
+    if key is not None and len(_FANOUT_PLANS) < 1024:
+        _FANOUT_PLANS[key] = res
+    return res
 
 
 def _i32_array(values):
@@ -345,10 +368,7 @@ class Graph:
         weights_list, types_list) with flattened per-hop tensors."""
         nodes = _as_i64_cuda(nodes, self.device).reshape(-1)
         layers = len(counts)
-        et = np.asarray(edge_types, dtype=np.int32).reshape(layers, -1)
-        et, et_p, _ = _i32_array(et)
-        k = et.size // layers if layers else 0
-        cnt, cnt_p, _ = _i32_array(counts)
+        et, et_p, k, cnt, cnt_p = _fanout_plan(edge_types, counts)
         n = nodes.numel()
         outs_n, outs_w, outs_t = [], [], []
         m = n
@@ -357,9 +377,13 @@ class Graph:
             outs_n.append(torch.empty(m, dtype=torch.int64, device=self.device))
             outs_w.append(torch.empty(m, dtype=torch.float32, device=self.device))
             outs_t.append(torch.empty(m, dtype=torch.int32, device=self.device))
-        ws_bytes = lib().euler_gpu_sample_fanout_workspace(n, cnt_p, layers)
-        ws = torch.empty(max(int(ws_bytes), 16), dtype=torch.uint8,
-                         device=self.device)
+        ws_key = (n,) + tuple(int(c) for c in counts)
+        ws_bytes = _WS_BYTES.get(ws_key)
+        if ws_bytes is None:
+            ws_bytes = int(lib().euler_gpu_sample_fanout_workspace(n, cnt_p, layers))
+            if len(_WS_BYTES) < 4096:
+                _WS_BYTES[ws_key] = ws_bytes
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=self.device)
         pn = (C.c_void_p * layers)(*[t.data_ptr() for t in outs_n])
         pw = (C.c_void_p * layers)(*[t.data_ptr() for t in outs_w])
         pt = (C.c_void_p * layers)(*[t.data_ptr() for t in outs_t])
