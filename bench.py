@@ -574,8 +574,8 @@ def run_hetero(args, quiet=False):
                                      gather_scatter_mean=round(f_ms, 4)),
                    "host_us_per_call": {k_: round(v_, 1) for k_, v_ in host_us.items()},
                    "host_note": "phases_ms of the sampling launches are kernel times (enqueued from C); "
-                                "a step issues 9 Python ops whose enqueue cost (host_us_per_call) is of the "
-                                "same order - the step rate of this leg is a host-bound figure"},
+                                "host_us_per_call = what one Python call of the op costs the host to enqueue "
+                                "(a step issues 9 ops: ~0.16 ms of host time against ~0.32 ms of kernels)"},
         "roofline": roof,
         "cpu_baseline": None,
     }

@@ -3,6 +3,7 @@ message passing (MPGather / MPScatterAdd / MPScatterMax), GenPair, the GQL
 helper ops (ID_UNIQUE / IDX_GATHER / DATA_GATHER) and the shard split/merge
 ops.  All tensors must live on a CUDA (ROCm) device; nothing here has a CPU
 path."""
+import contextlib
 import ctypes as C
 
 import numpy as np
@@ -23,6 +24,16 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_NULL_CTX = contextlib.nullcontext()
+
+
+def _on(device):
+    """Context of `device`; nothing to switch (5 us less per op) when it is the current one."""
+    if device.index is None or torch.cuda.current_device() == device.index:
+        return _NULL_CTX
+    return torch.cuda.device(device)
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -40,7 +51,7 @@ def _gather_raw(params, indices):
     _need_cuda(params, indices)
     e, d = indices.numel(), params.shape[1]
     out = torch.empty((e, d), dtype=torch.float32, device=params.device)
-    with torch.cuda.device(params.device):
+    with _on(params.device):
         check(lib().euler_gpu_gather(_stream(), _ptr(params), _ptr(indices), e, d,
                                      params.shape[0], _ptr(out)))
     return out
@@ -52,7 +63,7 @@ def _scatter_raw(fn, updates, indices, size):
     _need_cuda(updates, indices)
     e, d = updates.shape
     out = torch.empty((int(size), d), dtype=torch.float32, device=updates.device)
-    with torch.cuda.device(updates.device):
+    with _on(updates.device):
         check(fn(_stream(), _ptr(updates), _ptr(indices), e, d, int(size), _ptr(out)))
     return out
 
@@ -167,7 +178,7 @@ def _gather_scatter_raw(mode, params, gather_indices, scatter_indices, size, val
         _check_rows("gather_scatter", gi, params.shape[0])
     e, d = gi.numel(), params.shape[1]
     out = torch.empty((int(size), d), dtype=torch.float32, device=params.device)
-    with torch.cuda.device(params.device):
+    with _on(params.device):
         check(lib().euler_gpu_gather_scatter(_stream(), mode, _ptr(params), _ptr(gi), _ptr(si), e, d,
                                              int(size), _ptr(out)))
     return out
@@ -243,7 +254,7 @@ class _GatherSegmentReduce(torch.autograd.Function):
         if validate:
             _check_rows("gather_segment_reduce", gi, params.shape[0])
         out = torch.empty((int(size), params.shape[1]), dtype=torch.float32, device=params.device)
-        with torch.cuda.device(params.device):
+        with _on(params.device):
             check(lib().euler_gpu_gather_segment_reduce(
                 _stream(), _GS_MODE[op], _ptr(params), _ptr(gi), _ptr(sp) if sp is not None else None,
                 int(count), params.shape[1], int(size), _ptr(out)))
@@ -307,7 +318,7 @@ def gen_pair(paths, left_win_size, right_win_size):
     b, l = paths.shape
     pc = lib().euler_gpu_gen_pair_count(l, left_win_size, right_win_size)
     out = torch.empty((b, pc, 2), dtype=torch.int64, device=paths.device)
-    with torch.cuda.device(paths.device):
+    with _on(paths.device):
         check(lib().euler_gpu_gen_pair(_stream(), _ptr(paths), b, l, left_win_size,
                                        right_win_size, _ptr(out)))
     return out
@@ -333,7 +344,7 @@ def node2vec_step(seed, call_id, c_row, c_idx, c_ids, c_w, p_row, p_idx, p_ids, 
     n = c_row.numel()
     out = torch.empty(n, dtype=torch.int64, device=c_row.device)
     null = C.c_void_p(0)
-    with torch.cuda.device(c_row.device):
+    with _on(c_row.device):
         check(lib().euler_gpu_node2vec_step(
             _stream(), int(seed), int(call_id), n, _ptr(c_row), _ptr(c_idx), _ptr(c_ids), _ptr(c_w),
             _ptr(p_row) if p_row is not None else null,
@@ -351,7 +362,7 @@ def id_unique(ids):
     uq = torch.empty(n, dtype=torch.int64, device=ids.device)
     gi = torch.empty(n, dtype=torch.int32, device=ids.device)
     nu = C.c_int64(0)
-    with torch.cuda.device(ids.device):
+    with _on(ids.device):
         check(lib().euler_gpu_id_unique(_stream(), _ptr(ids), n, _ptr(uq), _ptr(gi),
                                         C.byref(nu)))
     return uq[:nu.value], gi
@@ -365,7 +376,7 @@ def idx_gather(idx, gather_idx):
     n = gi.numel()
     out = torch.empty((n, 2), dtype=torch.int32, device=idx.device)
     total = C.c_int64(0)
-    with torch.cuda.device(idx.device):
+    with _on(idx.device):
         check(lib().euler_gpu_idx_gather(_stream(), _ptr(idx), _ptr(gi), n,
                                          _ptr(out), C.byref(total)))
     return out, int(total.value)
@@ -379,7 +390,7 @@ def data_gather(data, idx, gather_idx):
     _need_cuda(data, idx, gi)
     out_idx, total = idx_gather(idx, gi)
     out = torch.empty(total, dtype=data.dtype, device=data.device)
-    with torch.cuda.device(data.device):
+    with _on(data.device):
         check(lib().euler_gpu_data_gather(_stream(), _ptr(data), data.element_size(),
                                           _ptr(idx), _ptr(gi), _ptr(out_idx),
                                           gi.numel(), _ptr(out)))
@@ -395,7 +406,7 @@ def id_split(ids, partitions, shards):
     off = (C.c_int64 * (shards + 1))()
     sid = torch.empty(n, dtype=torch.int64, device=ids.device)
     mi = torch.empty(n, dtype=torch.int32, device=ids.device)
-    with torch.cuda.device(ids.device):
+    with _on(ids.device):
         check(lib().euler_gpu_id_split(_stream(), _ptr(ids), n, partitions, shards,
                                        off, _ptr(sid), _ptr(mi)))
     return list(off), sid, mi
@@ -422,7 +433,7 @@ def dedup_split(ids, partitions, shards, root_mask=None, root_group=1, dense_tab
     off = (C.c_int64 * (shards + 1))()
     sid = torch.empty(n, dtype=torch.int64, device=ids.device)
     pos = torch.empty(n, dtype=torch.int32, device=ids.device)
-    with torch.cuda.device(ids.device):
+    with _on(ids.device):
         check(lib().euler_gpu_dedup_split(_stream(), _ptr(ids), n, _ptr(root_mask),
                                           int(root_group), partitions, shards,
                                           _ptr(dense_table), limit, off, _ptr(sid),
@@ -450,7 +461,7 @@ class FrontHandle(object):
         limit = dense_table.numel() - 1 if dense_table is not None else 0
         sid = torch.empty(n, dtype=torch.int64, device=ids.device)
         pos = torch.empty(n, dtype=torch.int32, device=ids.device)
-        with torch.cuda.device(ids.device):
+        with _on(ids.device):
             check(lib().euler_gpu_dedup_split_begin(
                 self._h, _stream(), _ptr(ids), n, _ptr(root_mask), int(root_group), partitions,
                 shards, _ptr(dense_table), limit, _ptr(sid), _ptr(pos)))
@@ -488,7 +499,7 @@ def expand_rows(pos, ids, w, t, mask, count):
     o_w = torch.empty((n, count), dtype=torch.float32, device=dev)
     o_t = torch.empty((n, count), dtype=torch.int32, device=dev)
     o_m = torch.empty(n, dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(lib().euler_gpu_expand_rows(_stream(), _ptr(pos), n, int(count), _ptr(ids),
                                           _ptr(w), _ptr(t), _ptr(mask), _ptr(o_id),
                                           _ptr(o_w), _ptr(o_t), _ptr(o_m)))
@@ -510,7 +521,7 @@ def pack_rows(ids, w, t, mask, count, single_type=None):
     m = mask.numel()
     out = torch.empty((m, packed_words(count, single_type)), dtype=torch.int32,
                       device=ids.device)
-    with torch.cuda.device(ids.device):
+    with _on(ids.device):
         check(lib().euler_gpu_pack_rows(_stream(), _ptr(ids), _ptr(w), _ptr(t),
                                         _ptr(mask), m, int(count),
                                         -1 if single_type is None else int(single_type),
@@ -531,7 +542,7 @@ def expand_packed(pos, packed, count, single_type=None):
     o_w = torch.empty((n, count), dtype=torch.float32, device=dev)
     o_t = torch.empty((n, count), dtype=torch.int32, device=dev)
     o_m = torch.empty(n, dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(lib().euler_gpu_expand_packed(_stream(), _ptr(pos), n, int(count),
                                             -1 if single_type is None else int(single_type),
                                             _ptr(packed), _ptr(o_id), _ptr(o_w),
@@ -548,7 +559,7 @@ def merge_rows(rows, merge_idx, n_rows=None):
     out = torch.empty_like(rows) if n_rows is None else torch.empty(
         (n_rows,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
     row_bytes = rows.element_size() * (rows.numel() // max(n, 1)) if n else 4
-    with torch.cuda.device(rows.device):
+    with _on(rows.device):
         check(lib().euler_gpu_merge_rows(_stream(), _ptr(rows), _ptr(mi), n,
                                          row_bytes, _ptr(out)))
     return out
