@@ -291,9 +291,20 @@ def latency_small_batch(G, L, _lib, n_nodes, default_node, batch=1024, iters=300
     torch.cuda.synchronize()
     many = (time.perf_counter() - t0) / (iters * 2)
     e = batch * (FANOUT[0] + FANOUT[0] * FANOUT[1])
+    # the same minibatch through the Python surface (Graph.sample_fanout: allocates its outputs)
+    et_l = [[0]] * layers
+    for i in range(100):
+        G.sample_fanout(roots[i % 64], et_l, FANOUT, default_node, call_id=2 * i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(iters * 2):
+        G.sample_fanout(roots[i % 64], et_l, FANOUT, default_node, call_id=2 * i)
+    torch.cuda.synchronize()
+    py = (time.perf_counter() - t0) / (iters * 2)
     return {"latency_B1024_us": round(one * 1e6, 2), "edges_per_s_one_stream": e / one,
             "us_per_minibatch_%d_streams" % streams: round(many * 1e6, 2),
-            "edges_per_s_%d_streams" % streams: e / many}
+            "edges_per_s_%d_streams" % streams: e / many,
+            "us_per_minibatch_python_surface": round(py * 1e6, 2)}
 
 
 def _events(fn, iters):
