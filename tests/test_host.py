@@ -395,3 +395,30 @@ def test_bench_refuses_more_ranks_than_gpus():
                          capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 2, (out.returncode, out.stderr[-500:])
     assert "--gpus 2 but only" in out.stderr and "{" not in out.stdout
+
+
+def test_python_surface_argument_caches():
+    """Graph methods convert their small list arguments (edge types, counts) once: the same
+    lists come back every minibatch.  Cached entries are value-keyed, ragged / array inputs
+    bypass the cache, and the tuning keys retired in round 3 answer EINVAL."""
+    from euler_amd import graph as g, _lib
+    a = g._i32_array([1, 4, 6])
+    assert a is g._i32_array([1, 4, 6]) and a is g._i32_array((1, 4, 6))
+    assert a[2] == 3 and a[0].dtype == np.int32 and a[0].tolist() == [1, 4, 6]
+    assert g._i32_array([1, 4, 7])[0].tolist() == [1, 4, 7]
+    assert g._i32_array([])[2] == 0
+    arr = np.array([[0, 1], [2, 3]], np.int64)
+    assert g._i32_array(arr)[0].tolist() == [0, 1, 2, 3]          # arrays: converted, not cached
+    assert g._i32_array([True, 2])[0].tolist() == [1, 2]           # (bools are not cache keys)
+    p = g._fanout_plan([[0], [0]], [25, 10])
+    assert p is g._fanout_plan([[0], [0]], [25, 10]) and p is g._fanout_plan(((0,), (0,)), (25, 10))
+    assert p[2] == 1 and p[0].shape == (2, 1) and p[3].tolist() == [25, 10]
+    q = g._fanout_plan([[0, 1], [2, 3]], [3, 4])
+    assert q[2] == 2 and q[0].tolist() == [[0, 1], [2, 3]]
+    f = g._fanout_plan([0, 0], [25, 10])                           # flat list of single types
+    assert f[2] == 1 and f[0].tolist() == [[0], [0]]
+    L = _lib.lib()
+    for key in (1, 6, 19, 21, 22, 26):
+        assert L.euler_gpu_set_tuning(key, 0) != 0
+    for key, v in ((0, 6), (27, 1), (38, 131072), (43, 12), (44, 1)):
+        assert L.euler_gpu_set_tuning(key, v) == 0
