@@ -809,8 +809,12 @@ static int GetWorkspace(const euler_gpu_graph* g, hipStream_t stream, size_t byt
 // Below ~100 K roots the six dependent kernels of the duplicate path (~38 us end to
 // end, whatever the size) lose to sampling the given roots directly, even with 90 %
 // duplicates (tools/ab_dedup_threshold.py on the metric graph: 25 600 roots 26 vs
-// 38 us, 102 400: 42 vs 42, 204 800: 57 vs 48, 819 200: 157 vs 92).
-constexpr int64_t kDedupMinRoots = 100000;
+// 38 us, 102 400: 42 vs 42, 204 800: 57 vs 48, 819 200: 157 vs 92).  A batch of DISTINCT
+// roots loses those ~38 us at any size - 131 072 typed roots x 10: 58-61 us with the
+// detection, ~40 without (profiles/r3_v3_hetero_kernel_stats.csv: mark 6 + number 14 +
+// resolve 5 + two gated exits) - so the automatic policy starts at 200 K roots: a tie at
+// ~60 % duplicates, and past the batch sizes of a first hop.
+constexpr int64_t kDedupMinRoots = 200000;
 
 // Measurement hook (euler_gpu_time_sample_neighbor_phases): when set, the
 // launcher records these 4 events on its stream at the phase boundaries

@@ -819,7 +819,7 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  *        gets 4096 = 16 waves per CU, so that the kernels of two streams fit on the
  *        chip together, every other call 32 768; 0 = always 32 768; > 0 = that many.
  * key 4: the pivot kernels draw two adjacent samples per lane when count is even (1).
- * key 5: duplicate roots: 0 = never look, 1 = look when a call has >= 100 000
+ * key 5: duplicate roots: 0 = never look, 1 = look when a call has >= 200 000
  *        roots [default], 2 = always look.
  * key 7: node2vec kernel: 2 = one wave per walker, runs of children below the
  *        parent cursor resolved by all lanes at once, running sums as integer sums

@@ -626,11 +626,11 @@ def test_duplicate_roots_take_the_unique_path(EA, O, torch_cuda, big_pair, et, c
 
 
 def test_fanout_second_hop_dedup(EA, O, torch_cuda, big_pair):
-    """13 000 roots, fanout [8, 6]: hop 2 has 104 000 roots with many repeats and
-    goes through the duplicate-root path automatically (>= 100 000 roots)."""
+    """26 000 roots, fanout [8, 6]: hop 2 has 208 000 roots with many repeats and
+    goes through the duplicate-root path automatically (>= 200 000 roots)."""
     torch = torch_cuda
     G, OG, ids, rng = big_pair
-    q = np.concatenate([rng.choice(ids, 12998), [0, 777]]).astype(np.int64)
+    q = np.concatenate([rng.choice(ids, 25998), [0, 777]]).astype(np.int64)
     G.set_seed(12)
     gn, gw, gt = G.sample_fanout(torch.as_tensor(q).cuda(), [[0], [1]], [8, 6], -1,
                                  call_id=3)
