@@ -1,5 +1,6 @@
 """tf_euler/python/euler_ops/neighbor_ops.py (hot-path subset)."""
-from . import base, type_ops
+from . import base
+from . import node_ops as type_ops
 
 __all__ = ["sample_neighbor", "sample_fanout", "get_full_neighbor",
            "get_sorted_full_neighbor", "get_top_k_neighbor", "to_sparse",
