@@ -562,7 +562,9 @@ thread_local int g_fl_wide = 1;       // key 31: weights / types as 16-byte stor
 thread_local int g_fl_grid_cap = -1;  // key 32: waves of the launch: 0 = one tile per wave (no loop), -1 = that for a
                                       // caller on one stream and 16 384 looping waves for one that alternates
                                       // streams (two launches share the chip), > 0 = that many
-thread_local int g_fl_min_roots = 4096;   // key 33: smaller batches keep the workgroup-per-root kernel
+thread_local int g_fl_min_roots = 32768;  // key 33: smaller batches keep the workgroup-per-root kernel / the hop-by-hop
+                                          // path (tools/fl_crossover.py: 4 096 roots 51 vs 36 us, 16 384: 76 vs 63, 32 768:
+                                          // 104 vs 102, 65 536: 173 vs 186)
 thread_local int g_fl_plain = 2;      // key 34: plain graphs: 2 = the lean kernel, 1 = the general kernel
                                       // constant-folded, 0 = the general kernel
 thread_local int g_fl_wps = 5;        // key 35: register budget, waves per SIMD (8, 6 or 5; 5: nothing spilled)

@@ -868,7 +868,7 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  *        per workgroup (64 [default], 128, 256), key 31 weights / types as 16-byte
  *        stores (1), key 32 cap on launched waves (-1 = 16 384 when the caller
  *        alternates streams, else one tile per wave [default]; 0 = never; > 0 = that
- *        many), key 33 smallest batch it takes (4096), key 34 plain graphs: 2 = the
+ *        many), key 33 smallest batch it takes (32768), key 34 plain graphs: 2 = the
  *        lean build [default], 1 = the general build constant-folded, 0 = general,
  *        key 35 register budget in waves per SIMD (5 [default: nothing spilled], 6, 8),
  *        key 36 measurement only (ablation bits, FanoutLocalArgs::ablate).

@@ -1516,7 +1516,7 @@ def test_full_neighbor_fill_kernels_agree(EA, O, torch_cuda, big_pair):
         _lib.lib().euler_gpu_set_tuning(24, 1)
 
 
-_FL_DEFAULTS = {27: 1, 28: 4, 29: 0, 30: 64, 31: 1, 32: -1, 33: 4096, 34: 2, 35: 5, 36: 0}
+_FL_DEFAULTS = {27: 1, 28: 4, 29: 0, 30: 64, 31: 1, 32: -1, 33: 32768, 34: 2, 35: 5, 36: 0}
 
 
 @pytest.mark.parametrize("geom", [(4, 0, 256, 1, 8, 2, 0), (1, 1, 64, 0, 5, 0, 0), (2, 3, 128, 1, 8, 0, 0),

@@ -30,7 +30,7 @@ fan = [25, 10]
 gen = torch.Generator(device='cuda'); gen.manual_seed(1234)
 n_sets = 8
 roots = torch.randint(1, N + 1, (n_sets, B), generator=gen, device='cuda')
-DEFAULTS = {27: 1, 28: 4, 29: 0, 30: 64, 31: 1, 32: -1, 33: 4096, 34: 2, 35: 5, 36: 0}
+DEFAULTS = {27: 1, 28: 4, 29: 0, 30: 64, 31: 1, 32: -1, 33: 32768, 34: 2, 35: 5, 36: 0}
 
 
 def apply(cfg):
