@@ -817,6 +817,10 @@ static int GetWorkspace(const euler_gpu_graph* g, hipStream_t stream, size_t byt
 // resolve 5 + two gated exits) - so the automatic policy starts at 200 K roots: a tie at
 // ~60 % duplicates, and past the batch sizes of a first hop.
 constexpr int64_t kDedupMinRoots = 200000;
+// the workgroup-per-root fanout (SampleFanout2Kernel, key 23) against a launch per hop, metric
+// graph, [25, 10]: 1 024 roots 14.7 vs 21.8 us, 2 048: 23.4 vs 26.0, 4 096: 36.6 vs 36.7,
+// 6 144: 47.7 vs 45.4, 7 900: 60.5 vs 53.6
+constexpr int64_t kFanout2MaxRoots = 4096;
 
 // Measurement hook (euler_gpu_time_sample_neighbor_phases): when set, the
 // launcher records these 4 events on its stream at the phase boundaries
@@ -1475,7 +1479,7 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
   // a small 2-hop fanout of single listed types: one launch (SampleFanout2Kernel)
   if (g_fanout_fused != 0 && events == nullptr && layers == 2 && k == 1 && n > 0 &&
       g_k1_variant == 6 && g->view.monotone && g->view.has_zero_nbr == 0 &&
-      counts_host[0] > 0 && counts_host[0] <= 256 && counts_host[1] > 0 &&
+      counts_host[0] > 0 && counts_host[0] <= 256 && counts_host[1] > 0 && n <= kFanout2MaxRoots &&
       !WantsDedup(g, n * counts_host[0], 1) && !WantsDedup(g, n, 1)) {
     if (g->view.blk == nullptr) {
       const int rc0 = EnsureBlockedIndex(g);

@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256) void TopKNeighborKernel(const TopKArgs a) {
 // ------------------------------------------------------------------------
 // key 38: DeepWalk (p = q = 1) of at least this many walkers runs over groups of merged
 // walkers (CwSampleKernel ...); 0 = never
-thread_local int g_walk_collapse = 131072;
+thread_local int g_walk_collapse = 262144;
 thread_local int g_walk_lean = 1;         // key 44: plain graphs draw with the lean search of the one-kernel fanout
 thread_local int g_walk_tail = 12;        // key 43: first step of the merged walk that stops looking for mergers
                                           // (the rest of the walk is one launch; 0 = never)

@@ -174,12 +174,12 @@ def test_config3_metric_step_at_full_size(EA, O, torch_cuda):
     starts = torch.randint(1, N + 1, (W,), generator=gen, device="cuda", dtype=torch.int64)
     et = [[0]] * 40
     try:
-        L.euler_gpu_set_tuning(38, 131072)
+        L.euler_gpu_set_tuning(38, 262144)
         m = G.random_walk(starts, et, 1.0, 1.0, N + 1, call_id=50)
         L.euler_gpu_set_tuning(38, 0)
         w = G.random_walk(starts, et, 1.0, 1.0, N + 1, call_id=50)
     finally:
-        L.euler_gpu_set_tuning(38, 131072)
+        L.euler_gpu_set_tuning(38, 262144)
     assert torch.equal(m, w)
     walks = t2n(m[:16])
     rows = np.unique(walks[walks <= N]).astype(np.uint64)

@@ -1673,7 +1673,7 @@ def test_random_walk_over_merged_walkers(EA, O, torch_cuda, big_pair):
         frac = len(np.unique(t2n(got)[:, -1])) / len(q)
         assert frac < 0.5, frac          # the premise: walkers do merge on a power-law graph
     finally:
-        L.euler_gpu_set_tuning(38, 131072)
+        L.euler_gpu_set_tuning(38, 262144)
         L.euler_gpu_set_tuning(43, 12)
         L.euler_gpu_set_tuning(44, 1)
 

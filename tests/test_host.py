@@ -420,5 +420,5 @@ def test_python_surface_argument_caches():
     L = _lib.lib()
     for key in (1, 6, 19, 21, 22, 26):
         assert L.euler_gpu_set_tuning(key, 0) != 0
-    for key, v in ((0, 6), (27, 1), (38, 131072), (43, 12), (44, 1)):
+    for key, v in ((0, 6), (27, 1), (38, 262144), (43, 12), (44, 1)):
         assert L.euler_gpu_set_tuning(key, v) == 0
