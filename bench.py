@@ -407,10 +407,11 @@ def run_hetero(args, quiet=False):
         aggs = []
         for c, et in enumerate(type_sets):
             nb, _w, _t = sample(roots[i], et, 3 * i + c)
-            src = nb.reshape(-1).to(torch.int32)
-            if fused:      # the rows are reduced as they are read, CNT per root
-                aggs.append(ops.gather_segment_reduce("mean", feat, src, B, count=CNT))
+            if fused:      # the rows are reduced as they are read, CNT per root (the sampler's int64
+                           # ids are the indices: euler_gpu_gather_segment_reduce_ids)
+                aggs.append(ops.gather_segment_reduce("mean", feat, nb.reshape(-1), B, count=CNT))
             else:
+                src = nb.reshape(-1).to(torch.int32)
                 aggs.append(ops.scatter_mean(ops.gather(feat, src), dst, B))
         return aggs
 

@@ -133,11 +133,13 @@ __device__ __forceinline__ void SegBounds(const SegSpec& s, int64_t r, int64_t* 
 // same correctly rounded f32 add and divide give the same bits in one pass.
 // gsrc != nullptr: update p is row gsrc[p] of `upd` (the gather of the message passing
 // step folded into the reduce: the E x d block of gathered rows is never written).
+// gstride = 2: gsrc points at int64 ids (what a sampler returns) and every index is the low
+// word of its id - the int32 a cast would have produced, without the cast's pass.
 template <int MODE>
 __global__ __launch_bounds__(256) void SegmentReduceKernel(
     const float* __restrict__ upd, const SegSpec seg,
     const uint32_t* __restrict__ perm, const int32_t* __restrict__ gsrc, int64_t d,
-    float* __restrict__ out) {
+    float* __restrict__ out, const int32_t gstride) {
   const int lane = threadIdx.x;
   const int32_t size = seg.size;
   for (int64_t r = (int64_t)blockIdx.x * blockDim.y + threadIdx.y; r < size;
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(256) void SegmentReduceKernel(
 #pragma unroll
         for (int x = 0; x < 8; ++x) {
           int64_t src = perm ? (int64_t)perm[p + x] : p + x;
-          if (gsrc) src = gsrc[src];
+          if (gsrc) src = gsrc[src * gstride];
           v[x] = upd[src * d + c];
         }
 #pragma unroll
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256) void SegmentReduceKernel(
       }
       for (; p < en; ++p) {
         int64_t src = perm ? (int64_t)perm[p] : p;
-        if (gsrc) src = gsrc[src];
+        if (gsrc) src = gsrc[src * gstride];
         const float v = upd[src * d + c];
         if (IS_MAX) { if (v > acc) acc = v; }
         else acc = __fadd_rn(acc, v);
@@ -185,7 +187,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void SegmentReduceVec4Kernel(
     const float* __restrict__ upd, const SegSpec seg,
     const uint32_t* __restrict__ perm, const int32_t* __restrict__ gsrc, int32_t d4,
-    float* __restrict__ out) {
+    float* __restrict__ out, const int32_t gstride) {
   constexpr bool IS_MAX = MODE == 1;
   const int32_t size = seg.size;
   const int32_t rows_per_wave = 64 / d4;
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(256) void SegmentReduceVec4Kernel(
       for (int x = 0; x < 8; ++x) src[x] = perm ? (int64_t)perm[p + x] : p + x;
       if (gsrc) {
 #pragma unroll
-        for (int x = 0; x < 8; ++x) src[x] = gsrc[src[x]];
+        for (int x = 0; x < 8; ++x) src[x] = gsrc[src[x] * gstride];
       }
       float4 v[8];
 #pragma unroll
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(256) void SegmentReduceVec4Kernel(
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
         int64_t src = perm ? (int64_t)perm[p + x] : p + x;
-        if (gsrc) src = gsrc[src];
+        if (gsrc) src = gsrc[src * gstride];
         v[x] = u4[src * d4 + cl];
       }
 #pragma unroll
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(256) void SegmentReduceVec4Kernel(
     }
     for (; p < en; ++p) {
       int64_t src = perm ? (int64_t)perm[p] : p;
-      if (gsrc) src = gsrc[src];
+      if (gsrc) src = gsrc[src * gstride];
       const float4 v = u4[src * d4 + cl];
       if (IS_MAX) {
         acc.x = v.x > acc.x ? v.x : acc.x; acc.y = v.y > acc.y ? v.y : acc.y;
@@ -324,12 +326,12 @@ static int ScatterImpl(hipStream_t st, const float* upd, const int32_t* idx,
     int64_t blocks = ((int64_t)size + rows_per_block - 1) / rows_per_block;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(SegmentReduceVec4Kernel<MODE>, dim3((unsigned)blocks), block, 0, st, upd,
-                       SegSpec{keys, nullptr, 0, e, size}, perm, gsrc, (int32_t)d4, out);
+                       SegSpec{keys, nullptr, 0, e, size}, perm, gsrc, (int32_t)d4, out, 1);
   } else {
     int64_t blocks = ((int64_t)size + 3) / 4;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(SegmentReduceKernel<MODE>, dim3((unsigned)blocks), block, 0,
-                       st, upd, SegSpec{keys, nullptr, 0, e, size}, perm, gsrc, d, out);
+                       st, upd, SegSpec{keys, nullptr, 0, e, size}, perm, gsrc, d, out, 1);
   }
   EG_HIP(hipGetLastError());
   return EULER_GPU_OK;
@@ -338,7 +340,7 @@ static int ScatterImpl(hipStream_t st, const float* upd, const int32_t* idx,
 template <int MODE>
 static int SegmentReduceImpl(hipStream_t st, const float* params, const int32_t* gsrc,
                              const int64_t* seg_ptr, int64_t count, int64_t d, int32_t size,
-                             float* out) {
+                             float* out, int32_t gstride = 1) {
   const dim3 block(64, 4);
   const int64_t d4 = d / 4;
   const SegSpec seg{nullptr, seg_ptr, count, 0, size};
@@ -348,12 +350,12 @@ static int SegmentReduceImpl(hipStream_t st, const float* params, const int32_t*
     int64_t blocks = ((int64_t)size + rows_per_block - 1) / rows_per_block;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(SegmentReduceVec4Kernel<MODE>, dim3((unsigned)blocks), block, 0, st, params,
-                       seg, nullptr, gsrc, (int32_t)d4, out);
+                       seg, nullptr, gsrc, (int32_t)d4, out, gstride);
   } else {
     int64_t blocks = ((int64_t)size + 3) / 4;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(SegmentReduceKernel<MODE>, dim3((unsigned)blocks), block, 0, st, params, seg,
-                       nullptr, gsrc, d, out);
+                       nullptr, gsrc, d, out, gstride);
   }
   EG_HIP(hipGetLastError());
   return EULER_GPU_OK;
@@ -788,6 +790,26 @@ int euler_gpu_gather_segment_reduce(void* stream, int32_t mode, const float* par
   if (mode == 1)
     return SegmentReduceImpl<1>(st, params_dev, gather_indices_dev, seg_ptr_dev, count, d, size, out_dev);
   return SegmentReduceImpl<2>(st, params_dev, gather_indices_dev, seg_ptr_dev, count, d, size, out_dev);
+}
+
+int euler_gpu_gather_segment_reduce_ids(void* stream, int32_t mode, const float* params_dev,
+                                        const int64_t* gather_ids_dev,
+                                        const int64_t* seg_ptr_dev, int64_t count, int64_t d,
+                                        int32_t size, float* out_dev) {
+  if (mode < 0 || mode > 2)
+    return Fail(EULER_GPU_EINVAL, "gather_segment_reduce_ids: mode is 0 add, 1 max, 2 mean");
+  if (d < 0 || size < 0 || (!seg_ptr_dev && count < 0))
+    return Fail(EULER_GPU_EINVAL, "gather_segment_reduce_ids: bad shape");
+  if (size == 0 || d == 0) return EULER_GPU_OK;
+  if (!out_dev || !params_dev || !gather_ids_dev)
+    return Fail(EULER_GPU_EINVAL, "gather_segment_reduce_ids: null buffer");
+  if (!seg_ptr_dev && mode == 2 && count >= (1LL << 24))
+    return Fail(EULER_GPU_EINVAL, "gather_segment_reduce_ids: mean needs segments shorter than 2^24");
+  hipStream_t st = (hipStream_t)stream;
+  const int32_t* lo = reinterpret_cast<const int32_t*>(gather_ids_dev);     // little endian: word 0 of every id
+  if (mode == 0) return SegmentReduceImpl<0>(st, params_dev, lo, seg_ptr_dev, count, d, size, out_dev, 2);
+  if (mode == 1) return SegmentReduceImpl<1>(st, params_dev, lo, seg_ptr_dev, count, d, size, out_dev, 2);
+  return SegmentReduceImpl<2>(st, params_dev, lo, seg_ptr_dev, count, d, size, out_dev, 2);
 }
 
 int euler_gpu_gather_scatter(void* stream, int32_t mode, const float* params_dev,

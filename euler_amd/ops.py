@@ -241,7 +241,10 @@ class _GatherSegmentReduce(torch.autograd.Function):
     @staticmethod
     def forward(ctx, params, gather_indices, seg_ptr, count, size, op, validate):
         params = params.contiguous()
-        gi = gather_indices.to(torch.int32).contiguous()
+        # int64 ids (what the samplers return) are read in place: index = low word of the id,
+        # the int32 a cast would give, without the cast's pass (euler_gpu_gather_segment_reduce_ids)
+        as_ids = gather_indices.dtype == torch.int64 and not validate
+        gi = gather_indices.contiguous() if as_ids else gather_indices.to(torch.int32).contiguous()
         _need_cuda(params, gi)
         sp = None
         if seg_ptr is not None:
@@ -254,10 +257,12 @@ class _GatherSegmentReduce(torch.autograd.Function):
         if validate:
             _check_rows("gather_segment_reduce", gi, params.shape[0])
         out = torch.empty((int(size), params.shape[1]), dtype=torch.float32, device=params.device)
+        fn = lib().euler_gpu_gather_segment_reduce_ids if as_ids else lib().euler_gpu_gather_segment_reduce
         with _on(params.device):
-            check(lib().euler_gpu_gather_segment_reduce(
-                _stream(), _GS_MODE[op], _ptr(params), _ptr(gi), _ptr(sp) if sp is not None else None,
-                int(count), params.shape[1], int(size), _ptr(out)))
+            check(fn(_stream(), _GS_MODE[op], _ptr(params), _ptr(gi), _ptr(sp) if sp is not None else None,
+                     int(count), params.shape[1], int(size), _ptr(out)))
+        if as_ids and ctx.needs_input_grad[0]:
+            gi = gi.to(torch.int32)                 # the gradient kernels take int32 indices
         ctx.save_for_backward(params, gi, sp if sp is not None else torch.empty(0), out)
         ctx.has_ptr, ctx.count, ctx.size, ctx.op = sp is not None, int(count), int(size), op
         return out

@@ -656,6 +656,15 @@ int euler_gpu_gather_segment_reduce(void* stream, int32_t mode, const float* par
                                     const int32_t* gather_indices_dev,
                                     const int64_t* seg_ptr_dev, int64_t count, int64_t d,
                                     int32_t size, float* out_dev);
+/* ... with the gather indices given as the int64 ids a sampler returned (SampleNeighbor's
+ * output feeding the aggregation of a block): index p is the low 32 bits of
+ * gather_ids_dev[p] - the int32 MPGather would receive after a cast
+ * (tf_euler/kernels/gather_op.cc:26-59 takes int32 indices) - read in place, without the
+ * cast's pass over the ids. */
+int euler_gpu_gather_segment_reduce_ids(void* stream, int32_t mode, const float* params_dev,
+                                        const int64_t* gather_ids_dev,
+                                        const int64_t* seg_ptr_dev, int64_t count, int64_t d,
+                                        int32_t size, float* out_dev);
 int euler_gpu_gather(void* stream, const float* params_dev,
                      const int32_t* indices_dev, int64_t e, int64_t d,
                      int64_t n_params, float* out_dev);

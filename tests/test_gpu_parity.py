@@ -319,6 +319,14 @@ def test_gather_scatter_fused_equals_composition(EA, O, torch_cuda):
             (ops.gather_segment_reduce(op, p1, gi2t, size, seg_ptr=ptrt) * g).sum().backward()
             (ops.scatter_(op, ops.gather(p2, gi2t), dst2, size) * g).sum().backward()
             assert np.array_equal(t2n(p1.grad), t2n(p2.grad)), (op, d)
+            # the indices as the int64 ids a sampler returns (read in place, low word = index;
+            # euler_gpu_gather_segment_reduce_ids): same bits forward and backward
+            a64 = ops.gather_segment_reduce(op, xt, git.to(torch.int64), size, count=count)
+            b64 = ops.gather_segment_reduce(op, xt, gi2t.to(torch.int64), size, seg_ptr=ptrt)
+            assert torch.equal(a64, a) and torch.equal(b64, b), (op, d)
+            p3 = xt.clone().requires_grad_(True)
+            (ops.gather_segment_reduce(op, p3, gi2t.to(torch.int64), size, seg_ptr=ptrt) * g).sum().backward()
+            assert torch.equal(p3.grad, p1.grad), (op, d)
 
 
 def test_mp_gradients(EA, torch_cuda):
