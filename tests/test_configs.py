@@ -13,7 +13,8 @@
   config 4  DeepWalk: p = q = 1 random walk of length 40 (sharded N > 1 host
             logic: tests/test_distributed_cpu.py with gloo)
   config 5  heterogeneous typed graph: per-type sampling (k = 1, 3-of-8, all)
-            + 128-d features + scatter_mean aggregation
+            + 128-d features + scatter_mean aggregation; and at bench.py's size (20M
+            nodes, 131 072 roots): pivots == reference loop == duplicate path == oracle
 """
 import os
 
@@ -251,6 +252,51 @@ def test_config5_typed_sampling_and_aggregation(EA, O, torch_cuda):
     want = O.scatter_mean(want_x, t2n(dst), len(roots))
     assert np.allclose(t2n(agg), want, rtol=0, atol=1e-5)
     assert np.array_equal(t2n(agg), want)
+
+
+@pytest.mark.gpu
+def test_config5_typed_sampling_at_full_size(EA, O, torch_cuda):
+    """configs[4] at bench.py's size: 20M nodes, 8 edge types, 131 072 roots x 10 samples
+    for one listed type, 3 of 8 and all 8.  Two independent device paths agree on every
+    sample (type draws on the block pivots == the reference loop, tuning key 37), with and
+    without the duplicate-root machinery forced (key 5), the result is a function of
+    (seed, call id, roots), 96 roots equal the oracle fed with their rows exported from
+    HBM, and the one-pass aggregation straight from the int64 ids equals gather +
+    scatter_mean bit for bit."""
+    torch = torch_cuda
+    from euler_amd import _lib
+    L = _lib.lib()
+    N, T, B, CNT, D = 20_000_000, 8, 131072, 10, 128
+    G = EA.Graph.synthetic(EA.synth_params(20240521, N, 20 * N, n_types=T, weighted=True))
+    G.set_seed(20240521)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(9)
+    roots = torch.randint(1, N + 1, (B,), generator=gen, device="cuda", dtype=torch.int64)
+    sel = np.random.default_rng(1).choice(B, 96, replace=False)
+    r_sel = t2n(roots)[sel]
+    rp, te, nb, pw, tp = G.export_rows(np.unique(r_sel).astype(np.uint64))
+    OG = O.OracleGraph(O.CSR(np.unique(r_sel).astype(np.uint64), rp, te, nb, pw, tp, T))
+    feat = torch.randn(N + 2, D, device="cuda", generator=torch.Generator("cuda").manual_seed(7))
+    dst = torch.arange(B, device="cuda", dtype=torch.int32).repeat_interleave(CNT)
+    try:
+        for call, et in enumerate(([3], [1, 4, 6], list(range(T)))):
+            L.euler_gpu_set_tuning(37, 1); L.euler_gpu_set_tuning(5, 1)
+            a = G.sample_neighbor(roots, et, CNT, N + 1, call_id=40 + call)
+            a2 = G.sample_neighbor(roots, et, CNT, N + 1, call_id=40 + call)
+            L.euler_gpu_set_tuning(37, 0)
+            b = G.sample_neighbor(roots, et, CNT, N + 1, call_id=40 + call)
+            L.euler_gpu_set_tuning(37, 1); L.euler_gpu_set_tuning(5, 2)
+            c = G.sample_neighbor(roots, et, CNT, N + 1, call_id=40 + call)
+            for x in range(3):
+                assert torch.equal(a[x], a2[x]) and torch.equal(a[x], b[x]) and torch.equal(a[x], c[x]), (et, x)
+            on, ow, ot = OG.sample_neighbor(20240521, 40 + call, r_sel, et, CNT, N + 1)
+            assert np.array_equal(t2n(a[0])[sel], on.reshape(-1, CNT)), et
+            assert np.array_equal(t2n(a[1])[sel], ow.reshape(-1, CNT))
+            assert np.array_equal(t2n(a[2])[sel], ot.reshape(-1, CNT))
+            agg = EA.ops.gather_segment_reduce("mean", feat, a[0].reshape(-1), B, count=CNT)
+            ref = EA.ops.scatter_mean(EA.ops.gather(feat, a[0].reshape(-1).to(torch.int32)), dst, B)
+            assert torch.equal(agg, ref), et
+    finally:
+        L.euler_gpu_set_tuning(37, 1); L.euler_gpu_set_tuning(5, 1)
 
 
 @pytest.mark.gpu
