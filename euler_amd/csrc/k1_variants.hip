@@ -73,7 +73,10 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborKernel(const
 // launch, 0.060-0.065 ms either way): the row record read into registers in one trip for
 // T <= 8 (select trees over 16 registers cost more VALU than the 3-4 L1 probes they
 // replace: 0.083 ms) and limits taken from the EdgeBlock's own sums when the segment lies
-// inside one block (no change: the leaf read dominates).
+// inside one block (no change: the leaf read dominates).  Two samples of a root per lane
+// (the single-type kernels' pair mode; one record lookup per pair, half the waves) was
+// slower too: 0.041 / 0.044 vs 0.036 / 0.032 ms for 3 of 8 / all types (two Philox blocks,
+// two type draws and two searches in one lane: 64 registers no longer hold it).
 template <bool TF_LAYOUT>
 __global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborTypedPivotKernel(
     const SampleNbArgs a) {
