@@ -118,8 +118,9 @@ def cpu_baseline(args):
     """SURVEY 8(d) protocol.  The reference sampler (oracle/_ref = the reference's
     own sources + RNG seam) and the GPU run the SAME graph (device generator ==
     host generator, tests/test_gpu_parity.py::test_synthetic_graph_matches_host_
-    generator), the SAME roots and the SAME batch sizes (B = 1 024, the batch of
-    every reference example, and B = 131 072, the metric's), and the same DAG:
+    generator), the SAME roots and the SAME batch sizes (B = 1 024, SURVEY 8's latency
+    configuration - the reference's examples default to less still, examples/graphsage/
+    run_graphsage.py:35 batch_size 32 - and B = 131 072, the metric's), and the same DAG:
     per hop ID_UNIQUE -> API_SAMPLE_NB -> DATA_GATHER (parser/compiler.cc:76-90;
     oracle/ref_harness.cc: euler_ref_bench_fanout_dag).  Two named CPU numbers
     per batch size:
@@ -165,7 +166,15 @@ def cpu_baseline(args):
     full = args.cpu_protocol == "full"
     rng = np.random.default_rng(1)
     shipped_threads = min(8, cores)
-    many = min(32, cores)
+    # "best case" = OMP_NUM_THREADS = nproc.  Candidates: 32 threads (where the
+    # sampler's throughput flattened on the hosts measured in rounds 1-3, tools/cpu_scaling.py)
+    # AND every host core; a concurrent query of B = 131072 holds ~1.5 GB of result vectors,
+    # so the concurrent-queries cell is also capped by the RAM left beside the graph.
+    try:
+        import psutil as _ps
+        room = int(_ps.virtual_memory().available * 0.5 / 1.5e9)
+    except Exception:
+        room = 32
     cells = {}
     roots_by_b = {}
     for B in (1024, 131072):
@@ -179,15 +188,19 @@ def cpu_baseline(args):
         cell["as_shipped"] = dict(_stats(secs, e), threads=shipped_threads,
                                   what="%d concurrent single-threaded queries" % shipped_threads)
         cands = []
-        if many > shipped_threads:
+        conc = sorted({min(32, cores), min(cores, max(32, room)) if big else cores})
+        for many in conc:
+            if many <= shipped_threads:
+                continue
             secs, e = R.bench_fanout_dag(GRAPH_SEED, roots, B, FANOUT, many, 0, True,
                                          wu if not big else 1, timed if (not big or full) else 3)
             cands.append(dict(_stats(secs, e), threads=many,
                               what="%d concurrent single-threaded queries" % many))
-        secs, e = R.bench_fanout_dag(GRAPH_SEED, roots, B, FANOUT, many, 1, True,
-                                     wu if not big else max(wu, 2), timed if not big else max(timed, 10))
-        cands.append(dict(_stats(secs, e), threads=many,
-                          what="-DOPENMP batch loop, %d threads, one query at a time" % many))
+        for many in sorted({min(32, cores), cores}):
+            secs, e = R.bench_fanout_dag(GRAPH_SEED, roots, B, FANOUT, many, 1, True,
+                                         wu if not big else max(wu, 2), timed if not big else max(timed, 10))
+            cands.append(dict(_stats(secs, e), threads=many,
+                              what="-DOPENMP batch loop, %d threads, one query at a time" % many))
         cell["best"] = max(cands + [cell["as_shipped"]], key=lambda c: c["edges_per_s"])
         cell["other"] = [c for c in cands if c is not cell["best"]]
         cells[B] = cell
@@ -238,7 +251,7 @@ def cpu_baseline(args):
 
 
 def latency_small_batch(G, L, _lib, n_nodes, default_node, batch=1024, iters=300, streams=8):
-    """B = 1 024 (the batch of every reference example): microseconds per minibatch of
+    """B = 1 024 (SURVEY 8's latency configuration): microseconds per minibatch of
     the 2-hop fanout, euler_gpu_sample_fanout called back to back on ONE stream with
     preallocated outputs (no Python allocation in the loop), and the throughput with
     `streams` minibatches in flight (the reference keeps 8 queries in flight,

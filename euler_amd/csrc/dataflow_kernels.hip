@@ -157,7 +157,8 @@ struct FlowFull {
   uint32_t* lens;             // [cap_n + 1] row lengths (zeros past cnt), then their exclusive scan
   uint32_t* offs;             // [cap_n + 1]
   uint32_t* m_nb;             // out: the hop's neighbour count
-  uint32_t* overflow;         // set to 1 when m_nb > cap_e
+  uint32_t* overflow;         // set to hop + 1 by the first hop whose m_nb > cap_e
+  int32_t hop;
   int64_t cap_n, cap_e;
   uint64_t* nb; int32_t* nb_src; int32_t* nb_t;
 };
@@ -174,6 +175,16 @@ __device__ __forceinline__ uint32_t FlowRowLen(const FlowFull& f, int64_t row) {
   return len;
 }
 
+// The offsets are 32-bit: a hop whose true neighbour total reaches 2^32 must not wrap
+// into a small number that passes the capacity test - the scan saturates instead
+// (saturating addition of unsigned numbers is associative).
+struct SatAdd {
+  __host__ __device__ __forceinline__ uint32_t operator()(uint32_t a, uint32_t b) const {
+    const uint32_t s = a + b;
+    return s < a ? 0xFFFFFFFFu : s;
+  }
+};
+
 __global__ __launch_bounds__(256) void FlowFullCountKernel(const FlowFull f) {
   const int64_t cnt = (int64_t)(*f.cnt);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -183,8 +194,12 @@ __global__ __launch_bounds__(256) void FlowFullCountKernel(const FlowFull f) {
 
 __global__ void FlowFullTotalKernel(const FlowFull f) {
   const uint32_t total = f.offs[f.cap_n];       // exclusive scan over cap_n + 1 entries
-  if ((int64_t)total > f.cap_e) { *f.overflow = 1u; *f.m_nb = 0u; }
-  else *f.m_nb = total;
+  if ((int64_t)total > f.cap_e) {
+    if (*f.overflow == 0u) *f.overflow = (uint32_t)f.hop + 1u;    // hops run in stream order
+    *f.m_nb = 0u;
+  } else {
+    *f.m_nb = total;
+  }
 }
 
 // one lane per output entry: its row is the last i with offs[i] <= e
@@ -343,8 +358,8 @@ size_t euler_gpu_full_blocks_workspace(int64_t n, const int64_t* edge_caps_host,
     size_t scan_bytes = 0, scan2 = 0;
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t*)nullptr,
                                            (uint32_t*)nullptr, (int)(cap_m + 1), nullptr);
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan2, (uint32_t*)nullptr,
-                                           (uint32_t*)nullptr, (int)(cap_n + 1), nullptr);
+    (void)hipcub::DeviceScan::ExclusiveScan(nullptr, scan2, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                            SatAdd(), 0u, (int)(cap_n + 1), nullptr);
     if (scan2 > scan_bytes) scan_bytes = scan2;
     const size_t b = Al(((size_t)cap_n + 1) * 4) * 2 + Al((size_t)cap_e * 8) + Al((size_t)cap_e * 4)
                      + Al((tcap + 1) * 8) + Al((tcap + 1) * 4) * 2 + Al((size_t)cap_m * 4)
@@ -355,7 +370,7 @@ size_t euler_gpu_full_blocks_workspace(int64_t n, const int64_t* edge_caps_host,
 }
 
 // counts_dev: [layers + 1] nodes per layer, then [layers] edges per hop (without the self
-// loops), then one overflow word.  Layer h + 1 holds at most cap_n[h] + edge_caps[h] nodes.
+// loops), then one overflow word: 0, or h + 1 for the first hop h whose edge list did not fit.  Layer h + 1 holds at most cap_n[h] + edge_caps[h] nodes.
 int euler_gpu_full_blocks(const euler_gpu_graph* g, void* stream, const uint64_t* roots_dev,
                           int64_t n, const int32_t* edge_types_host, int32_t k, int32_t layers,
                           int32_t add_self_loops, const int64_t* edge_caps_host,
@@ -398,7 +413,7 @@ int euler_gpu_full_blocks(const euler_gpu_graph* g, void* stream, const uint64_t
     ff.nb_src = (int32_t*)p;            p += Al((size_t)cap_e * 4);
     ff.nb_t = e_type_dev != nullptr ? e_type_dev[h] : nullptr;
     ff.m_nb = counts_dev + layers + 1 + h; ff.overflow = overflow;
-    ff.cap_n = cap_n; ff.cap_e = cap_e;
+    ff.cap_n = cap_n; ff.cap_e = cap_e; ff.hop = h;
     FlowHop f{};
     f.t.keys = (unsigned long long*)p;  p += Al((tcap + 1) * 8);
     f.t.minpos = (uint32_t*)p;          p += Al((tcap + 1) * 4);
@@ -410,10 +425,10 @@ int euler_gpu_full_blocks(const euler_gpu_graph* g, void* stream, const uint64_t
     void* scan_tmp = p;
     size_t scan_bytes = 0, scan2 = 0;
     EG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, f.is_first, f.rank, (int)(cap_m + 1), st));
-    EG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan2, ff.lens, ff.offs, (int)(cap_n + 1), st));
+    EG_HIP(hipcub::DeviceScan::ExclusiveScan(nullptr, scan2, ff.lens, ff.offs, SatAdd(), 0u, (int)(cap_n + 1), st));
     // 1. the rows of the layer's nodes: lengths -> offsets -> the hop's neighbour list
     hipLaunchKernelGGL(FlowFullCountKernel, dim3(GridFor(cap_n + 1, block)), dim3(block), 0, st, ff);
-    EG_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan2, ff.lens, ff.offs, (int)(cap_n + 1), st));
+    EG_HIP(hipcub::DeviceScan::ExclusiveScan(scan_tmp, scan2, ff.lens, ff.offs, SatAdd(), 0u, (int)(cap_n + 1), st));
     hipLaunchKernelGGL(FlowFullTotalKernel, dim3(1), dim3(1), 0, st, ff);
     if (cap_e > 0)
       hipLaunchKernelGGL(FlowFullFillKernel, dim3(GridFor(cap_e, block)), dim3(block), 0, st, ff);

@@ -69,13 +69,29 @@ struct FanoutLocalArgs {
   SmallDiv div_h1, div_h2;  // by the pairs per row, (c1 + 1) / 2 and c2 / 2 (lean kernel)
   uint64_t* id1; float* w1; int32_t* ty1; uint8_t* mask0;
   uint64_t* id2; float* w2; int32_t* ty2; uint8_t* mask1;
-  unsigned long long* dbg;  // measurement only (euler_gpu_set_debug_buffer): [tiles][8] phase stamps
   uint32_t* row_index;      // lean kernel, not null: the (unique rows, index) form - id2 / w2 / ty2
                             // receive each tile's DISTINCT hop-2 rows (row r0 * c1 + slot), row_index
                             // the row of every hop-1 sample; nothing is expanded
-  int32_t ablate;           // measurement only (tuning key 36), lean kernel: 1 = no hop-2 stores,
-                            // 2 = no hop-2 sampling, 4 = no hop-1 stores, 8 = no hop-1 sampling
+#ifdef EULER_GPU_MEASURE
+  // measurement builds only (make MEASURE=1): the shipped kernel carries neither field nor branch
+  unsigned long long* dbg;  // euler_gpu_set_debug_buffer: [tiles][8] phase stamps
+  int32_t ablate;           // tuning key 36, lean kernel: 1 = no hop-2 stores, 2 = no hop-2 sampling,
+                            // 4 = no hop-1 stores, 8 = no hop-1 sampling
+#endif
 };
+
+#ifdef EULER_GPU_MEASURE
+#define EG_FL_ABLATE(a, bits) (((a).ablate & (bits)) != 0)
+#define EG_FL_DBG(a) ((a).dbg != nullptr)
+#else
+#define EG_FL_ABLATE(a, bits) (false)
+#define EG_FL_DBG(a) false
+#endif
+#ifdef EULER_GPU_MEASURE
+#define EG_FL_ABLATE_BITS(a) ((a).ablate)
+#else
+#define EG_FL_ABLATE_BITS(a) 0
+#endif
 
 // LDS of one wave (bytes), and the offsets of its arrays
 struct FanoutLocalLds {
@@ -656,7 +672,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
     if ((uint32_t)lane < gr) s_mask[lane] = 0ull;
     WaveSync();
     unsigned long long t_s[6] = {0, 0, 0, 0, 0, 0};
-    if (a.dbg != nullptr) t_s[0] = __builtin_readcyclecounter();
+    if (EG_FL_DBG(a)) t_s[0] = __builtin_readcyclecounter();
     // ---- P1: hop 1, a lane per pair of samples -----------------------------------
     bool by_edge = true;                  // every root of the tile has <= 64 edges
     const uint32_t t1n = nr * hp1;
@@ -677,7 +693,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
           lo = rec.x; deg = (int32_t)rec.z; total = __uint_as_float(rec.w);
         }
       }
-      const bool live = in && deg > 0 && !(a.ablate & 8);
+      const bool live = in && deg > 0 && !EG_FL_ABLATE(a, 8);
       const Philox4 pb = RngBlock(a.seed, a.call_id, kDomainNeighbor, node, jp);
       uint64_t id[2]; float w[2]; uint32_t m[2];
       if (UNIFORM) LeanSamplePairUniform(g, lo, deg, total, live, UnitFromWords(pb.w[0], pb.w[1]),
@@ -704,7 +720,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
       }
     }
     WaveSync();
-    if (a.dbg != nullptr) t_s[1] = __builtin_readcyclecounter();
+    if (EG_FL_DBG(a)) t_s[1] = __builtin_readcyclecounter();
     // ---- P2: slots of the distinct children -----------------------------------------
     uint32_t n_slots = 0;
     if (by_edge) {
@@ -765,7 +781,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
         if (tk < p1) a.row_index[out1 + tk] = (uint32_t)(out1 + s_slot[tk]);
       }
     }
-    if (a.dbg != nullptr) t_s[2] = __builtin_readcyclecounter();
+    if (EG_FL_DBG(a)) t_s[2] = __builtin_readcyclecounter();
     // ---- P3 / P4 per chunk of `cap` slots -------------------------------------------
     for (uint32_t s0 = 0; s0 < n_slots; s0 += cap) {
       const uint32_t ns = n_slots - s0 < cap ? n_slots - s0 : cap;
@@ -787,13 +803,13 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
             lo = rec.x; deg = (int32_t)rec.z; total = __uint_as_float(rec.w);
           }
         }
-        const bool live = in && deg > 0 && !(a.ablate & 2);
+        const bool live = in && deg > 0 && !EG_FL_ABLATE(a, 2);
         const Philox4 pb = RngBlock(a.seed, a.call_id + 1u, kDomainNeighbor, node, xp);
         uint64_t id[2]; float w[2]; uint32_t m[2];
         if (UNIFORM) LeanSamplePairUniform(g, lo, deg, total, live, UnitFromWords(pb.w[0], pb.w[1]),
                                            UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
         else LeanSamplePair(g, lo, deg, total, live, UnitFromWords(pb.w[0], pb.w[1]),
-                            UnitFromWords(pb.w[2], pb.w[3]), id, w, m, a.ablate);
+                            UnitFromWords(pb.w[2], pb.w[3]), id, w, m, EG_FL_ABLATE_BITS(a));
         if (in) {
           fl_u64x2 iv;
           iv.x = live ? id[0] : (uint64_t)a.default_node;
@@ -805,7 +821,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
         }
       }
       WaveSync();
-      if (a.dbg != nullptr && s0 == 0) t_s[3] = __builtin_readcyclecounter();
+      if (EG_FL_DBG(a) && s0 == 0) t_s[3] = __builtin_readcyclecounter();
       // -- P4, (unique rows, index) form: the chunk's rows as they are, once ------------
       if (a.row_index != nullptr) {
         const int64_t row0 = (out1 + (int64_t)s0) * (int64_t)c2;     // first sample of row r0 * c1 + s0
@@ -820,7 +836,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
         }
       } else
       // -- P4: copy the finished rows to the positions that asked for them ------------
-      if (!(a.ablate & 1)) {
+      if (!EG_FL_ABLATE(a, 1)) {
       for (uint32_t b = 0; b < p2; b += 128) {
         const uint32_t p = b + 2 * lane;
         if (p < p2) {
@@ -829,7 +845,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
           const uint32_t sl = (uint32_t)s_slot[gj] - s0;
           if (sl < ns) {
             const fl_u64x2 iv = *reinterpret_cast<const fl_u64x2*>(s_sid + sl * c2 + x);
-            if (a.ablate & 256) __builtin_nontemporal_store(iv, reinterpret_cast<fl_u64x2*>(a.id2 + out2 + p));
+            if (EG_FL_ABLATE(a, 256)) __builtin_nontemporal_store(iv, reinterpret_cast<fl_u64x2*>(a.id2 + out2 + p));
             else *reinterpret_cast<fl_u64x2*>(a.id2 + out2 + p) = iv;
             if (!WIDE) {
               *reinterpret_cast<float2*>(a.w2 + out2 + p) =
@@ -859,7 +875,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
             if (inb) { wb = *reinterpret_cast<const float2*>(s_sw + slb * c2 + xb); tb = s_st[slb]; }
             float* wp = a.w2 + out2 + p;
             int32_t* tp = a.ty2 + out2 + p;
-            if (ina && inb && (a.ablate & 256)) {
+            if (ina && inb && EG_FL_ABLATE(a, 256)) {
               typedef float fl_f4 __attribute__((ext_vector_type(4)));
               typedef int fl_i4 __attribute__((ext_vector_type(4)));
               const fl_f4 wv4 = {wa.x, wa.y, wb.x, wb.y};
@@ -882,9 +898,9 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
       }
       WaveSync();              // the next chunk rewrites the slot rows
     }
-    if (a.dbg != nullptr) t_s[4] = __builtin_readcyclecounter();
+    if (EG_FL_DBG(a)) t_s[4] = __builtin_readcyclecounter();
     // ---- hop-1 outputs (contiguous over the tile) -----------------------------------
-    for (uint32_t b = 0; b < p1 && !(a.ablate & 4); b += 64) {
+    for (uint32_t b = 0; b < p1 && !EG_FL_ABLATE(a, 4); b += 64) {
       const uint32_t tk = b + lane;
       if (tk < p1) {
         const uint32_t q = a.div_c1(tk);
@@ -895,6 +911,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
       }
     }
     WaveSync();
+#ifdef EULER_GPU_MEASURE
     if (a.dbg != nullptr) {
       __builtin_amdgcn_s_waitcnt(0);          // the stores have left the wave's queue
       t_s[5] = __builtin_readcyclecounter();
@@ -905,6 +922,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
         d[7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
       }
     }
+#endif
   }
 }
 

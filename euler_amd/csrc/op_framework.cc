@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <map>
 #include <memory>
@@ -272,13 +273,20 @@ euler_gpu_graph* OpKernelContext::graph() const {
   return graph_ ? graph_ : euler_gpu_default_graph();
 }
 
+// op_kernel.cc (AsyncOpKernel::Compute): the synchronous entry blocks until the kernel's
+// done callback has run - on this thread for the GPU kernels of this library (they complete
+// inside AsyncCompute), on whichever thread a user-registered asynchronous kernel calls it.
 void AsyncOpKernel::Compute(const NodeDef& node_def, OpKernelContext* ctx) {
   std::mutex mu;
-  std::unique_lock<std::mutex> lk(mu);
+  std::condition_variable cv;
   bool done = false;
-  AsyncCompute(node_def, ctx, [&] { done = true; });
-  (void)lk;
-  (void)done;   // the GPU kernels complete synchronously inside AsyncCompute
+  AsyncCompute(node_def, ctx, [&] {
+    std::lock_guard<std::mutex> lk(mu);
+    done = true;
+    cv.notify_all();
+  });
+  std::unique_lock<std::mutex> lk(mu);
+  cv.wait(lk, [&] { return done; });
 }
 
 OpKernelRegistrar::OpKernelRegistrar(const std::string& name, Factory factory) {

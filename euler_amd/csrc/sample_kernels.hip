@@ -1199,8 +1199,8 @@ static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
 }
 
 // ------------------------------------------------------------------------
-// Small 2-hop fanouts in ONE launch (tuning key 23).  The batch of every reference
-// example is 1 024 roots: hop 1 is 25 600 samples, hop 2 256 000 - too few for
+// Small 2-hop fanouts in ONE launch (tuning key 23).  The latency batch of SURVEY 8 (the reference's
+// examples use less) is 1 024 roots: hop 1 is 25 600 samples, hop 2 256 000 - too few for
 // the duplicate-root path, so the step was two latency-bound launches and a
 // boundary, 26 us.  Hop 2's roots of batch root r are r's own hop-1 samples, so a
 // workgroup that owns root r needs nothing from any other workgroup: it draws
@@ -1423,10 +1423,12 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
           f.cap = lcap; f.wave_lds = (int32_t)ll.bytes;
           f.div_h1.Set((uint32_t)(c1 + 1) / 2); f.div_h2.Set((uint32_t)c2 / 2);
           const size_t llds = (size_t)ll.bytes * wpb;
+#ifdef EULER_GPU_MEASURE
           f.dbg = (unsigned long long*)g_fl_debug;
+          f.ablate = g_fl_ablate;
+#endif
           f.row_index = t_fl_row_index;
           t_fl_took_lean = 1;
-          f.ablate = g_fl_ablate;
           void (*lk)(const FanoutLocalArgs) = nullptr;
           if (v.uniform_w != 0) {
             lk = f.wide ? SampleFanoutLeanKernel<true, 8, true> : SampleFanoutLeanKernel<false, 8, true>;
@@ -1575,11 +1577,19 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
 
 extern "C" {
 
-int euler_gpu_set_debug_buffer(void* dev) { g_fl_debug = dev; return EULER_GPU_OK; }
+int euler_gpu_set_debug_buffer(void* dev) {
+#ifdef EULER_GPU_MEASURE
+  g_fl_debug = dev;
+  return EULER_GPU_OK;
+#else
+  (void)dev;
+  return Fail(EULER_GPU_EINVAL, "set_debug_buffer: this library was built without EULER_GPU_MEASURE "
+                                "(make -C euler_amd/csrc MEASURE=1)");
+#endif
+}
 
 int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 0 && (value == 0 || value == 5 || value == 6)) { g_k1_variant = value; return EULER_GPU_OK; }
-  if (key == 2) { g_k1_ablate = value; return EULER_GPU_OK; }
   if (key == 3) { g_k1_grid_cap = value; return EULER_GPU_OK; }
   if (key == 9) { g_k1_fuse_mark = value != 0; return EULER_GPU_OK; }
   if (key == 10 && (value == 1 || value == 2 || value == 4)) {
@@ -1609,7 +1619,10 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 32 && value >= -1) { g_fl_grid_cap = value; return EULER_GPU_OK; }
   if (key == 33 && value >= 0) { g_fl_min_roots = value; return EULER_GPU_OK; }
   if (key == 34 && value >= 0 && value <= 2) { g_fl_plain = value; return EULER_GPU_OK; }
+#ifdef EULER_GPU_MEASURE
+  if (key == 2) { g_k1_ablate = value; return EULER_GPU_OK; }
   if (key == 36) { g_fl_ablate = value; return EULER_GPU_OK; }
+#endif
   if (key == 37 && value >= 0 && value <= 1) { g_k1_typed_pivot = value; return EULER_GPU_OK; }
   if (key == 38 && value >= 0) { g_walk_collapse = value; return EULER_GPU_OK; }
   if (key == 39 && value >= 0) { g_walk_grid = value; return EULER_GPU_OK; }

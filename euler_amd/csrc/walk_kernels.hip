@@ -440,7 +440,9 @@ struct WalkArgs {
   // rounded w / p); 0 = divide
   float inv_p;
   float inv_q;
-  int32_t ablate;         // measurement only (tuning key 2): 8 = random_walk keeps its path to itself
+#ifdef EULER_GPU_MEASURE
+  int32_t ablate;         // measurement builds only (tuning key 2): 8 = random_walk keeps its path to itself
+#endif
 };
 
 // FAST: one listed edge type per step on a graph with non-decreasing running
@@ -491,7 +493,10 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void RandomWalkKernel(const Wal
       for (int32_t e = threadIdx.x; e < 256 * ns; e += 256) {
         const int32_t wl = e / ns, k = e - wl * ns;
         const int64_t wi = tile * 256 + wl;
-        if (wi < a.n && !(a.ablate & 8))
+#ifdef EULER_GPU_MEASURE
+        if (a.ablate & 8) continue;
+#endif
+        if (wi < a.n)
           a.out[wi * L + s0 + k + 1] = stage[wl * (kWalkStage + 1) + k];
       }
       __syncthreads();
@@ -1145,7 +1150,9 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
   a.g = g->view; a.seed = seed; a.call_id = call_id; a.nodes = nodes_dev;
   a.edge_types = et_dev; a.out = out_dev; a.n = n; a.default_node = default_node;
   a.k = k; a.walk_len = walk_len; a.p = p; a.q = q;
+#ifdef EULER_GPU_MEASURE
   a.ablate = g_k1_ablate;
+#endif
   {
     // w / p by an exact reciprocal when p and q are powers of two (both then are the
     // correctly rounded quotient)
@@ -1160,21 +1167,47 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
   // random_walk_op.cc:281: fabs(p_ - 1.0) <= kEps && fabs(q_ - 1.0) <= kEps
   if (std::fabs((double)p - 1.0) <= kEps && std::fabs((double)q - 1.0) <= kEps) {
     const bool fast = k == 1 && g->view.monotone && g->view.blk != nullptr && g_k1_variant >= 5;
-    if (g_walk_collapse != 0 && walk_len >= 4 && n >= g_walk_collapse && n < ((int64_t)1 << 31) &&
-        g->view.n_rows < ((int64_t)1 << 31) - 2 && k > 0) {
-      // the walk over groups of merged walkers (CwSampleKernel ...)
+    // The walk over groups of merged walkers needs (walk_len + 1) * n * 24 bytes + 8 bytes per
+    // graph row of stream-ordered scratch (1 GB for 1M walkers x 40 steps; tens of GB when
+    // every node of a large graph walks).  It is an optimisation: when the scratch is not
+    // to be had - more than a third of the free HBM, or the allocation fails - the call falls
+    // through to the per-walker kernel, which needs none.
+    bool merged = g_walk_collapse != 0 && walk_len >= 4 && n >= g_walk_collapse && n < ((int64_t)1 << 31) &&
+                  g->view.n_rows < ((int64_t)1 << 31) - 2 && k > 0;
+    uint8_t* buf = nullptr;
+    size_t o_rec = 0, o_tid = 0, o_tsl = 0, o_own = 0, o_tr = 0, total = 0;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    if (merged) {
+      const size_t cap = (size_t)n, rows = (size_t)g->view.n_rows + 1;
+      o_rec = al(((size_t)walk_len + 2) * 4);
+      o_tid = o_rec + al(((size_t)walk_len + 1) * cap * 16); o_tsl = o_tid + al(2 * cap * 8);
+      o_own = o_tsl + al(2 * cap * 4); o_tr = o_own + al(2 * rows * 4);
+      total = o_tr + al(((size_t)walk_len + 1) * cap * 8);
+      if (total > ((size_t)2 << 30)) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total > free_b / 3) merged = false;
+      }
+      if (merged && hipMallocAsync((void**)&buf, total, st) != hipSuccess) {
+        (void)hipGetLastError();          // clear the sticky allocation error
+        buf = nullptr;
+        merged = false;
+      }
+    }
+    if (merged) {
+      // (CwSampleKernel ...; every error return below releases the scratch first)
+      struct Release {
+        uint8_t* p; hipStream_t s;
+        ~Release() { if (p != nullptr) (void)hipFreeAsync(p, s); }
+      } release{buf, st};
+      struct ReleaseEt {
+        int32_t* p; hipStream_t s; bool armed;
+        ~ReleaseEt() { if (armed) (void)hipFreeAsync(p, s); }
+      } release_et{et_dev, st, true};
       CwArgs c{};
       c.g = g->view; c.seed = seed; c.call_id = call_id; c.edge_types = et_dev; c.k = k;
       c.walk_len = walk_len; c.cap = n; c.default_node = default_node; c.fast = fast ? 1 : 0;
       const size_t cap = (size_t)n, rows = (size_t)g->view.n_rows + 1;
-      auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-      const size_t o_counts = 0, o_rec = al(((size_t)walk_len + 2) * 4),
-                   o_tid = o_rec + al(((size_t)walk_len + 1) * cap * 16), o_tsl = o_tid + al(2 * cap * 8),
-                   o_own = o_tsl + al(2 * cap * 4), o_tr = o_own + al(2 * rows * 4),
-                   total = o_tr + al(((size_t)walk_len + 1) * cap * 8);
-      uint8_t* buf = nullptr;
-      EG_HIP(hipMallocAsync((void**)&buf, total, st));
-      c.counts = (uint32_t*)(buf + o_counts);
+      c.counts = (uint32_t*)buf;
       c.rec = (CwArgs::Rec*)(buf + o_rec);
       c.tmp_id[0] = (uint64_t*)(buf + o_tid); c.tmp_id[1] = c.tmp_id[0] + cap;
       c.tmp_slot[0] = (uint32_t*)(buf + o_tsl); c.tmp_slot[1] = c.tmp_slot[0] + cap;
@@ -1217,7 +1250,7 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
                            lds, st, tr, out_dev, n, L, ch);
       }
       EG_HIP(hipGetLastError());
-      (void)hipFreeAsync(buf, st);
+      release_et.armed = false;       // the common exit below frees the edge-type table
     } else if (fast) {
       hipLaunchKernelGGL(RandomWalkKernel<true>, dim3(GridFor(n, block)), dim3(block), 0,
                          st, a);

@@ -189,11 +189,13 @@ class _FullBlocksMixin(object):
             return None
         L = len(self.metapath)
         # edges per node of the layer, as seen: the next estimate (with headroom)
+        over = cnt[2 * L + 1] - 1 if blocks is None else -1     # the overflow word names the hop (h + 1)
         for h in range(L):
-            seen = cnt[L + 1 + h] / max(1, cnt[h])
-            if blocks is None and cnt[L + 1 + h] == 0 and cnt[h] > 0:
-                seen = 4.0 * self._growth[h]           # the hop that overflowed
-            self._growth[h] = max(1.0, 0.5 * self._growth[h], 2.0 * seen)
+            if h == over:
+                self._growth[h] = 4.0 * self._growth[h]           # only the hop that overflowed
+            elif over < 0 or h < over:                            # later hops saw no input
+                seen = cnt[L + 1 + h] / max(1, cnt[h])
+                self._growth[h] = max(1.0, 0.5 * self._growth[h], 2.0 * seen)
         return blocks
 
 

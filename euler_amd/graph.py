@@ -60,6 +60,8 @@ def _fanout_plan(edge_types, counts):
     cnt = np.ascontiguousarray(np.asarray(counts, dtype=np.int32).reshape(-1))
     res = (et, et.ctypes.data_as(_I32), int(et.size // layers) if layers else 0, cnt, cnt.ctypes.data_as(_I32))
     if key is not None and len(_FANOUT_PLANS) < 1024:
+        et.flags.writeable = False      # shared by every later call with these arguments
+        cnt.flags.writeable = False
         _FANOUT_PLANS[key] = res
     return res
 
@@ -76,6 +78,7 @@ def _i32_array(values):
     a = np.ascontiguousarray(np.asarray(values, dtype=np.int32).reshape(-1))
     res = (a, a.ctypes.data_as(_I32), int(a.size))
     if key is not None and len(_I32_CACHE) < 1024:
+        a.flags.writeable = False       # shared by every later call with this list
         _I32_CACHE[key] = res
     return res
 
@@ -417,7 +420,7 @@ class Graph:
         rt = torch.empty((n * c1, c2), dtype=torch.int32, device=dev)
         ws_bytes = lib().euler_gpu_sample_fanout_workspace(n, cnt_p, 2)
         ws = torch.empty(max(int(ws_bytes), 16), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
+        with self._on_device():
             check(lib().euler_gpu_sample_fanout_unique(
                 self._h, _stream(), self.seed, self._take_call_ids(2, call_id), _ptr(nodes), n,
                 et_p, cnt_p, int(default_node), _ptr(id1), _ptr(w1), _ptr(t1), _ptr(idx),
@@ -494,7 +497,7 @@ class Graph:
         ws = torch.empty(max(int(lib().euler_gpu_sage_blocks_workspace(n, fan_p, layers)), 16),
                          dtype=torch.uint8, device=dev)
         arr = lambda ts: (C.c_void_p * layers)(*[t.data_ptr() for t in ts])
-        with torch.cuda.device(dev):
+        with self._on_device():
             check(lib().euler_gpu_sage_blocks(
                 self._h, _stream(), self.seed, self._take_call_ids(layers, call_id), _ptr(nodes), n,
                 et_p, k, fan_p, layers, int(default_node), 1 if add_self_loops else 0, _ptr(ws),
@@ -538,7 +541,7 @@ class Graph:
         ws = torch.empty(max(int(lib().euler_gpu_full_blocks_workspace(n, ecap, layers)), 16),
                          dtype=torch.uint8, device=dev)
         arr = lambda ts: (C.c_void_p * layers)(*[t.data_ptr() for t in ts])
-        with torch.cuda.device(dev):
+        with self._on_device():
             check(lib().euler_gpu_full_blocks(
                 self._h, _stream(), _ptr(nodes), n, et_p, k, layers, 1 if add_self_loops else 0, ecap,
                 _ptr(ws), arr(n_ids), arr(res), arr(esrc), arr(edst),

@@ -880,7 +880,8 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  *        many), key 33 smallest batch it takes (32768), key 34 plain graphs: 2 = the
  *        lean build [default], 1 = the general build constant-folded, 0 = general,
  *        key 35 register budget in waves per SIMD (5 [default: nothing spilled], 6, 8),
- *        key 36 measurement only (ablation bits, FanoutLocalArgs::ablate).
+ *        key 36 ablation bits - exists only in a library built with `make MEASURE=1`
+ *        (-DEULER_GPU_MEASURE); the shipped library answers EINVAL, as for key 2.
  * key 37: calls that draw the edge type (k != 1) on monotone graphs search the
  *        neighbour with the block pivots (1 [default]); 0 = the reference loop.
  * key 38: DeepWalk (p = q = 1) of at least this many walkers runs over groups of merged
@@ -895,8 +896,9 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  * thread enqueues afterwards and nobody else's (new threads start from the
  * defaults), so concurrent query threads cannot disturb one another. */
 int euler_gpu_set_tuning(int32_t key, int32_t value);
-/* Measurement only: a device buffer of 8 x uint64 per wave tile in which the one-kernel
- * fanout (fanout_local.h, lean build) leaves its phase time stamps; NULL = off.
+/* Measurement builds only (`make MEASURE=1`; the shipped library returns EINVAL and its
+ * kernels carry no such code): a device buffer of 8 x uint64 per wave tile in which the
+ * one-kernel fanout (fanout_local.h, lean build) leaves its phase time stamps; NULL = off.
  * Thread-local like the tuning keys. */
 int euler_gpu_set_debug_buffer(void* dev);
 
