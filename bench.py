@@ -79,6 +79,13 @@ def parse():
     ap.add_argument("--unfused-aggregation", action="store_true",
                     help="hetero workload: gather, then scatter_mean (two passes over the E x D block)")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--sustain-steps", type=int, default=4000,
+                    help="metric workload, one GPU: after the K timed steps, this many more steps "
+                         "(>= 1 s of device time) are timed as ONE region and reported as "
+                         "config.sustained - the K-step median is a ~5 ms burst (0 = skip)")
+    ap.add_argument("--large-batch", type=int, default=1048576,
+                    help="roots of the second roofline launch (SURVEY 8(d) config 3: B >= 1M per "
+                         "launch for the HBM-roofline run; 0 = skip)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the short products / hetero / deepwalk (+ node2vec) legs the default "
                          "single-GPU metric run appends under config.secondary")
@@ -304,6 +311,58 @@ def latency_small_batch(G, L, _lib, n_nodes, default_node, batch=1024, iters=300
     torch.cuda.synchronize()
     many = (time.perf_counter() - t0) / (iters * 2)
     e = batch * (FANOUT[0] + FANOUT[0] * FANOUT[1])
+    # M = 64 such minibatches in ONE enqueue (euler_gpu_sample_fanout_multi), one host thread, one
+    # stream: minibatch b draws with call id c0 + 2 b - the results of 64 calls, bit for bit
+    M = 64
+    multi = {}
+    try:
+        cnt_m = (C.c_int32 * layers)(*FANOUT)
+        wsm = int(L.euler_gpu_sample_fanout_workspace(M * batch, cnt_m, layers))
+        mo_n, mo_w, mo_t, m_ = [], [], [], M * batch
+        for c in FANOUT:
+            m_ *= c
+            mo_n.append(torch.empty(m_, dtype=torch.int64, device=dev))
+            mo_w.append(torch.empty(m_, dtype=torch.float32, device=dev))
+            mo_t.append(torch.empty(m_, dtype=torch.int32, device=dev))
+        mws = torch.empty(max(wsm, 16), dtype=torch.uint8, device=dev)
+        mpn = (C.c_void_p * layers)(*[t.data_ptr() for t in mo_n])
+        mpw = (C.c_void_p * layers)(*[t.data_ptr() for t in mo_w])
+        mpt = (C.c_void_p * layers)(*[t.data_ptr() for t in mo_t])
+        mroots = roots[:M].contiguous()
+
+        def call_multi(c0):
+            _lib.check(L.euler_gpu_sample_fanout_multi(
+                G._h, st0, GRAPH_SEED, c0, layers, None, M, C.c_void_p(mroots.data_ptr()), batch, et_a, 1,
+                cnt_m, layers, default_node, mpn, mpw, mpt, C.c_void_p(mws.data_ptr())))
+        for i in range(5):
+            call_multi(0)
+        torch.cuda.synchronize()
+        it_m = 40
+        t0 = time.perf_counter()
+        for i in range(it_m):
+            call_multi(2 * M * i)
+        torch.cuda.synchronize()
+        per_call = (time.perf_counter() - t0) / it_m
+        # == the separate calls (first, a middle and the last minibatch of the last launch)
+        c_last = 2 * M * (it_m - 1)
+        for b_ in (0, 31, M - 1):
+            call(b0, st0, 0)           # placeholder buffers; the call below rewrites them
+            _lib.check(L.euler_gpu_sample_fanout(
+                G._h, st0, GRAPH_SEED, c_last + 2 * b_, C.c_void_p(mroots[b_].data_ptr()), batch, et_a, 1,
+                cnt_a, layers, default_node, b0[4], b0[5], b0[6], C.c_void_p(b0[3].data_ptr())))
+            torch.cuda.synchronize()
+            per = batch
+            for h, c in enumerate(FANOUT):
+                per *= c
+                assert torch.equal(mo_n[h][b_ * per:(b_ + 1) * per], b0[0][h]), "multi != separate calls"
+                assert torch.equal(mo_w[h][b_ * per:(b_ + 1) * per], b0[1][h])
+        multi = {"multi_M": M, "multi_us_per_launch": round(per_call * 1e6, 2),
+                 "multi_us_per_minibatch": round(per_call * 1e6 / M, 3),
+                 "edges_per_s_multi": e * M / per_call,
+                 "multi_checked": "3 of the 64 minibatches == separate euler_gpu_sample_fanout calls"}
+        del mo_n, mo_w, mo_t, mws
+    except Exception as ex:
+        multi = {"multi_error": repr(ex)}
     # the same minibatch through the Python surface (Graph.sample_fanout: allocates its outputs)
     et_l = [[0]] * layers
     for i in range(100):
@@ -317,7 +376,7 @@ def latency_small_batch(G, L, _lib, n_nodes, default_node, batch=1024, iters=300
     return {"latency_B1024_us": round(one * 1e6, 2), "edges_per_s_one_stream": e / one,
             "us_per_minibatch_%d_streams" % streams: round(many * 1e6, 2),
             "edges_per_s_%d_streams" % streams: e / many,
-            "us_per_minibatch_python_surface": round(py * 1e6, 2)}
+            "us_per_minibatch_python_surface": round(py * 1e6, 2), **multi}
 
 
 def _events(fn, iters):
@@ -338,18 +397,64 @@ def _oracle_rows(G, p, need, n_types, spot=64):
     first compared with the HOST generator (oracle/eo_synth.c), so that a device generator
     fault cannot hide behind "oracle fed with exported rows"."""
     from oracle import oracle as O
-    need = np.unique(np.asarray(need, dtype=np.uint64))
+    need = np.unique(np.asarray(need).astype(np.int64).view(np.uint64))
     rp, te, nb, pw, tp = G.export_rows(need)
     po = O.SynthParams()
     for f_, _t in po._fields_:
         setattr(po, f_, getattr(p, f_))
     T = n_types
     for j_ in np.random.default_rng(1).choice(len(need), min(spot, len(need)), replace=False):
-        h_ = O.synth_csr(po, int(need[j_]) - 1, int(need[j_]))
+        x_ = O.synth_internal_id(po, int(need[j_]))       # the id itself unless hashed_ids
         b_, e_ = int(rp[j_]), int(rp[j_ + 1])
+        if not 1 <= x_ <= po.n_nodes:
+            assert b_ == e_, "a row for an id outside the graph"
+            continue
+        h_ = O.synth_csr(po, x_ - 1, x_)
+        assert int(h_.row_id[0]) == int(need[j_])
         assert np.array_equal(h_.nbr, nb[b_:e_]) and np.array_equal(h_.prefix_w, pw[b_:e_]), \
             "device generator differs from the host generator at node %d" % int(need[j_])
     return O.OracleGraph(O.CSR(need, rp, te, nb, pw, tp, T))
+
+
+def _mix64_t(z):
+    """oracle/eo_synth.c's sy_mix64 on an int64 tensor (two's-complement wrap = u64 arithmetic):
+    the external ids of a hashed_ids graph, computed where the roots live."""
+    def lsr(v, sft):
+        return (v >> sft) & ((1 << (64 - sft)) - 1)
+    z = z ^ lsr(z, 30)
+    z = z * (0xbf58476d1ce4e5b9 - (1 << 64))
+    z = z ^ lsr(z, 27)
+    z = z * (0x94d049bb133111eb - (1 << 64))
+    return z ^ lsr(z, 31)
+
+
+def _oracle_sage_blocks(OG, seed, call, roots, metapath, fanouts, default):
+    """SageDataFlow as the reference composes it (dataflow/sage_dataflow.py:35-50 over
+    neighbor_dataflow.py:84-110) on the ORACLE: sample_neighbor of the unique frontier per
+    hop, tf.unique = first-occurrence ID_UNIQUE, res_n_id / edge_index arithmetic."""
+    from oracle import oracle as O
+
+    def uniq(a):
+        uq, gi = O.id_unique(a.astype(np.uint64))
+        return uq.astype(np.int64), gi.astype(np.int64)
+    n_id = roots.copy()
+    nbrs, srcs = [], []
+    for h, (et, c) in enumerate(zip(metapath, fanouts)):
+        nb, _, _ = OG.sample_neighbor(seed, call + h, n_id, et, c, default)
+        nbrs.append(nb.reshape(-1))
+        srcs.append(np.repeat(np.arange(len(n_id)), c))
+        n_id, _ = uniq(np.concatenate([nb.reshape(-1), n_id]))
+    n_id = roots.copy()
+    last_idx = np.arange(len(n_id))
+    want = []
+    for i in range(len(fanouts)):
+        new_n_id, inv = uniq(np.concatenate([nbrs[i], n_id]))
+        res = inv[-len(n_id):]
+        src = np.concatenate([srcs[i], last_idx])
+        last_idx = np.arange(len(new_n_id))
+        want.append((new_n_id, res, np.stack([src, inv])))
+        n_id = new_n_id
+    return want
 
 
 def _rank_ctx():
@@ -383,12 +488,12 @@ def run_hetero(args, quiet=False):
     import euler_amd
     from euler_amd import ops
     rank, world, wire = _rank_ctx()
-    N, T, D, CNT = 20_000_000, 8, 128, 10
-    if args.nodes < 100_000_000:           # functional runs on small graphs (--nodes)
-        N = max(1000, args.nodes // 5)
+    # "same N" as the metric graph - 100M nodes / 1B edges, 8 edge types,
+    # D = 128 (51 GB of features + 36 GB of graph in one GPU's 288 GB)
+    N, E_h, T, D, CNT = args.nodes, args.edges, 8, 128, 10
     B = args.batch
     t0 = time.time()
-    p_h = euler_amd.synth_params(GRAPH_SEED, N, 20 * N, n_types=T, weighted=True)
+    p_h = euler_amd.synth_params(GRAPH_SEED, N, E_h, n_types=T, weighted=True)
     G = euler_amd.Graph.synthetic(p_h, device=torch.cuda.current_device(), partitions=world,
                                   shard_index=rank, shards=world)
     G.set_seed(GRAPH_SEED)
@@ -814,7 +919,93 @@ def run_products_leg(args):
     return res
 
 
-def run_unique_leg(args, G):
+def run_hashed_leg(args):
+    """The metric step on a graph shaped like a converted dataset: the same 100M nodes / 1B
+    weighted edges, but every node known by an arbitrary u64 id (hash id map instead of
+    row = id - 1) and two edge-type groups per node (Cora's train / train_removed,
+    tf_euler/python/dataset/cora.py:36-52); the fanout lists one type per hop, as GraphSAGE
+    does.  This is SampleFanoutLocalKernel (the general build of the one-kernel step), which
+    the headline's plain graph never reaches."""
+    import euler_amd
+    from euler_amd import _lib
+    L = _lib.lib()
+    N, E = args.nodes, args.edges
+    t0 = time.time()
+    p = euler_amd.synth_params(GRAPH_SEED, N, E, n_types=2, weighted=True, hashed_ids=True)
+    G = euler_amd.Graph.synthetic(p)
+    G.set_seed(GRAPH_SEED)
+    torch.cuda.synchronize()
+    build_s = time.time() - t0
+    B = args.batch
+    steps, warm = 10, 3
+    gen = torch.Generator(device="cuda"); gen.manual_seed(2468)
+    roots = _mix64_t(torch.randint(1, N + 1, (steps + warm, B), generator=gen, device="cuda",
+                                   dtype=torch.int64))
+    et = [[0], [0]]
+    default = -1
+    side = [torch.cuda.Stream(), torch.cuda.Stream()]
+
+    def loop(first, last):
+        res = None
+        for i in range(first, last):
+            with torch.cuda.stream(side[i % 2]):
+                res = G.sample_fanout(roots[i], et, FANOUT, default, call_id=2 * i)
+        return res
+    torch.cuda.synchronize()
+    loop(0, warm + 1)
+    torch.cuda.synchronize()
+    reps = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = loop(warm, warm + steps)
+        torch.cuda.synchronize()
+        reps.append(time.perf_counter() - t0)
+    elapsed = float(np.median(reps))
+    last = warm + steps - 1
+    sel = np.random.default_rng(0).choice(B, 64, replace=False)
+    r0 = roots[last].cpu().numpy()[sel]
+    hop1 = out[0][1].reshape(B, FANOUT[0]).cpu().numpy()[sel]
+    hop2 = out[0][2].reshape(B, FANOUT[0], FANOUT[1]).cpu().numpy()[sel]
+    w2 = out[1][1].reshape(B, -1).cpu().numpy()[sel]
+    need = np.concatenate([r0, hop1.reshape(-1)])
+    OG = _oracle_rows(G, p, need[need != default], 2)
+    on, ow, _ot = OG.sample_fanout(GRAPH_SEED, 2 * last, r0, et, FANOUT, default)
+    assert np.array_equal(on[0], hop1.reshape(-1)) and np.array_equal(on[1], hop2.reshape(-1)), \
+        "hashed ids / 2 types: sampled ids differ from the oracle"
+    assert np.array_equal(ow[1], w2.reshape(-1)), "hashed ids / 2 types: weights differ from the oracle"
+    r = roots[last].contiguous()
+    ms_alone = _events(lambda: G.sample_fanout(r, et, FANOUT, default, call_id=5), 10)
+    # SURVEY 8(d) bytes of the step, as for the headline: K1 over the batch + K1 over the
+    # globally distinct hop-2 roots + 12 per hop-2 input id + 16 per expanded edge
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    et1 = (C.c_int32 * 1)(0)
+
+    def algo_bytes(x, cnt):
+        b = C.c_double(0)
+        _lib.check(L.euler_gpu_sample_neighbor_algo_bytes(
+            G._h, st, C.c_void_p(x.data_ptr()), x.numel(), et1, 1, cnt, C.byref(b)))
+        return b.value
+    hop2_roots = out[0][1].reshape(-1)
+    uniq2 = torch.unique(hop2_roots).contiguous()
+    n2 = hop2_roots.numel()
+    algo = algo_bytes(r, FANOUT[0]) + algo_bytes(uniq2, FANOUT[1]) + 12.0 * n2 + 16.0 * n2 * FANOUT[1]
+    edges = B * (FANOUT[0] + FANOUT[0] * FANOUT[1])
+    res = {"value": edges * steps / elapsed, "unit": "sampled edges/s",
+           "ms_per_step": elapsed / steps * 1e3, "one_stream_ms_per_step": round(ms_alone, 4),
+           "roofline_frac": round(algo / (ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "algorithmic_bytes_per_launch": algo, "parity_checked": int(64 * 275),
+           "kernel": "SampleFanoutLocalKernel (general build: hash id map, type groups)",
+           "graph_build_s": round(build_s, 2), "graph_bytes": G.device_bytes,
+           "workload": "the metric step on %d nodes / %d edges with hashed u64 ids and 2 edge-type "
+                       "groups per node, one listed type per hop, %d roots per step, two streams"
+                       % (N, G.num_edges, B)}
+    del G, out
+    torch.cuda.empty_cache()
+    return res
+
+
+def run_unique_leg(args, G, p_g):
     """The metric step in the (unique rows, index) form (euler_gpu_sample_fanout_unique): the
     GQL result before DATA_GATHER - hop 2 as distinct rows + the row of every hop-1 sample;
     the whole result is compared with the dense form on the device."""
@@ -828,16 +1019,31 @@ def run_unique_leg(args, G):
     assert torch.equal(rw[idx].reshape(-1), dw[1]) and torch.equal(rt[idx].reshape(-1), dt[1])
     rows = int(torch.unique(idx).numel())
     del dn, dw, dt
+    # ... and 64 roots of it against the ORACLE (rows exported from HBM, host generator spot check)
+    sel = np.random.default_rng(0).choice(B, 64, replace=False)
+    r0 = r.cpu().numpy()[sel]
+    sel_t = torch.as_tensor(sel).cuda()
+    hop1 = id1.reshape(B, FANOUT[0])[sel_t].cpu().numpy()
+    idx_sel = idx.reshape(B, FANOUT[0])[sel_t].reshape(-1)
+    hop2 = rid[idx_sel].reshape(64, -1).cpu().numpy()
+    w2 = rw[idx_sel].reshape(64, -1).cpu().numpy()
+    need = np.concatenate([r0, hop1.reshape(-1)])
+    OG = _oracle_rows(G, p_g, need[(need >= 1) & (need <= N)], 1)
+    on, ow, _ot = OG.sample_fanout(GRAPH_SEED, 8, r0, et, FANOUT, N + 1)
+    assert np.array_equal(on[0], hop1.reshape(-1)) and np.array_equal(on[1], hop2.reshape(-1)), \
+        "unique rows: ids differ from the oracle"
+    assert np.array_equal(ow[1], w2.reshape(-1)), "unique rows: weights differ from the oracle"
     ms = _events(lambda: G.sample_fanout_unique(r, et, FANOUT, N + 1, call_id=8), 10)
     edges = B * (FANOUT[0] + FANOUT[0] * FANOUT[1])
     return {"value": edges / (ms * 1e-3), "unit": "sampled edges/s (as rows + index)",
             "ms_per_step": round(ms, 4), "roofline_frac": None, "parity_checked": int(edges),
+            "parity_checked_vs_oracle": int(64 * 275),
             "distinct_rows": rows, "positions": int(idx.numel()),
             "workload": "the metric step, hop 2 left as %d distinct rows + a row index per hop-1 sample "
                         "(one stream, output buffers allocated per call)" % rows}
 
 
-def run_sage_leg(args, G):
+def run_sage_leg(args, G, p_g):
     """SageDataFlow block construction (euler_gpu_sage_blocks: sampler + first-occurrence
     unique + res_n_id + edge_index per hop, one enqueue) on the metric graph: blocks/s; the
     blocks are compared with the op-by-op composition of the base class."""
@@ -858,9 +1064,29 @@ def run_sage_leg(args, G):
         assert torch.equal(b1.n_id, b2.n_id) and torch.equal(b1.res_n_id, b2.res_n_id)
         assert torch.equal(b1.edge_index, b2.edge_index)
         n_edges += int(b1.edge_index.shape[1])
+    # ... and against the ORACLE's composition of the reference's flow (sample_neighbor of the
+    # unique frontier, first-occurrence unique, edge_index arithmetic) on this graph for a batch
+    # whose frontier rows can be exported: 128 roots -> ~3 K frontier rows of the 100M-node graph
+    Bo = 128
+    ro = r[:Bo].contiguous()
+    G.set_seed(GRAPH_SEED, 5000)
+    dfo = flow(ro)
+    ro_np = ro.cpu().numpy()
+    G.set_seed(GRAPH_SEED, 5000)
+    nb1 = G.sample_neighbor(ro, [0], FANOUT[0], N + 1, call_id=5000)[0].reshape(-1).cpu().numpy()
+    need = np.concatenate([ro_np, nb1])
+    OG = _oracle_rows(G, p_g, need[(need >= 1) & (need <= N)], 1)
+    want = _oracle_sage_blocks(OG, GRAPH_SEED, 5000, ro_np, [[0], [0]], FANOUT, N + 1)
+    o_edges = 0
+    for blk, (wn, wr, we) in zip(dfo.blocks, want):
+        assert np.array_equal(blk.n_id.cpu().numpy(), wn), "sage blocks: n_id differs from the oracle"
+        assert np.array_equal(blk.res_n_id.cpu().numpy(), wr), "sage blocks: res_n_id differs"
+        assert np.array_equal(blk.edge_index.cpu().numpy(), we), "sage blocks: edge_index differs"
+        o_edges += int(we.shape[1])
+    G.set_seed(GRAPH_SEED)
     ms = _events(lambda: flow(r), 10)
     return {"value": 1e3 / ms, "unit": "minibatches (2 blocks each)/s", "ms_per_step": round(ms, 4),
-            "roofline_frac": None, "parity_checked": n_edges,
+            "roofline_frac": None, "parity_checked": n_edges, "parity_checked_vs_oracle": o_edges,
             "block_edges_per_s": n_edges / (ms * 1e-3),
             "workload": "SageDataFlow, %d roots, fanouts %s, self loops: %d block edges per minibatch; "
                         "one host read (the layer sizes) per minibatch" % (B, FANOUT, n_edges)}
@@ -890,13 +1116,17 @@ def secondary_legs(args, G, p_g):
         sec["deepwalk"] = {"error": repr(e)}
     for name_, fn_ in (("fanout_unique_rows", run_unique_leg), ("sage_blocks", run_sage_leg)):
         try:
-            sec[name_] = fn_(args, G)
+            sec[name_] = fn_(args, G, p_g)
         except Exception as e:
             sec[name_] = {"error": repr(e)}
     try:
         sec["products"] = run_products_leg(args)
     except Exception as e:
         sec["products"] = {"error": repr(e)}
+    try:
+        sec["metric_hashed_T2"] = run_hashed_leg(args)
+    except Exception as e:
+        sec["metric_hashed_T2"] = {"error": repr(e)}
     try:
         a = copy.copy(args)
         a.steps, a.warmup, a.repeats = 10, 3, 3
@@ -1004,6 +1234,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    sustained = None
     if sharded:
         # A sharded hop makes the host wait once (the bucket sizes of its front
         # end).  K minibatches are kept in flight from ONE host thread
@@ -1100,6 +1331,21 @@ def main():
             out = loop(args.warmup, n_steps, side)
             sync()
             rep_secs.append(time.perf_counter() - t0)
+        # the same loop as ONE long region (>= 1 s of device time): what the K-step bursts above
+        # are extrapolated to (roots cycle through the n_steps batches; call ids keep counting)
+        sustained = None
+        if world == 1 and args.sustain_steps > 0 and side is not None:
+            ns_ = args.sustain_steps
+            sync()
+            t0 = time.perf_counter()
+            for i in range(ns_):
+                with torch.cuda.stream(side[i % n_streams]):
+                    G.sample_fanout(roots[i % n_steps], et, FANOUT, default_node, call_id=2 * (n_steps + i))
+            sync()
+            dt_ = time.perf_counter() - t0
+            sustained = {"steps": ns_, "seconds": round(dt_, 4), "ms_per_step": round(dt_ / ns_ * 1e3, 4),
+                         "edges_per_s": B * (FANOUT[0] + FANOUT[0] * FANOUT[1]) * ns_ / dt_,
+                         "streams": n_streams}
         gc.enable()
     exchanged = None
     if world > 1:
@@ -1231,6 +1477,59 @@ def main():
                     "step: K1 of hop 1 over the batch, K1 of hop 2 over the globally distinct hop-2 "
                     "roots, 8 + 4 per hop-2 input id, 16 per expanded output edge",
         }
+        if args.large_batch > 0 and args.large_batch != B:
+            # "B >= 1M per launch for the HBM-roofline run": the same launch
+            # over 1 048 576 roots (8 rounds of the chip instead of 6.4: the tail and the launch
+            # are a smaller share), bytes counted the same way
+            try:
+                BL = args.large_batch
+                gl = torch.Generator(device=dev); gl.manual_seed(555)
+                rl = torch.randint(1, args.nodes + 1, (BL,), generator=gl, device=dev, dtype=torch.int64)
+                ol_n, ol_w, ol_t, m = [], [], [], BL
+                for c in FANOUT:
+                    m *= c
+                    ol_n.append(torch.empty(m, dtype=torch.int64, device=dev))
+                    ol_w.append(torch.empty(m, dtype=torch.float32, device=dev))
+                    ol_t.append(torch.empty(m, dtype=torch.int32, device=dev))
+                wl = torch.empty(max(int(L.euler_gpu_sample_fanout_workspace(BL, cnt_a, layers)), 16),
+                                 dtype=torch.uint8, device=dev)
+                pln = (C.c_void_p * layers)(*[t.data_ptr() for t in ol_n])
+                plw = (C.c_void_p * layers)(*[t.data_ptr() for t in ol_w])
+                plt_ = (C.c_void_p * layers)(*[t.data_ptr() for t in ol_t])
+                msl = C.c_float(0)
+                torch.cuda.synchronize()
+                _lib.check(L.euler_gpu_time_sample_fanout(
+                    G._h, st, GRAPH_SEED, C.c_void_p(rl.data_ptr()), BL, et_a, 1, cnt_a, layers,
+                    default_node, pln, plw, plt_, C.c_void_p(wl.data_ptr()), 5, C.byref(msl)))
+                u2 = torch.unique(ol_n[0]).contiguous()
+                nl2 = ol_n[0].numel()
+                tb = algo_bytes(rl, FANOUT[0]) + algo_bytes(u2, FANOUT[1]) + 12.0 * nl2 + 16.0 * nl2 * FANOUT[1]
+                # the same 64-root oracle check on this launch's output
+                chk = None
+                if not args.no_check:
+                    sel = np.random.default_rng(3).choice(BL, 64, replace=False)
+                    st_t = torch.as_tensor(sel).to(dev)
+                    r0 = rl[st_t].cpu().numpy()
+                    h1 = ol_n[0].reshape(BL, FANOUT[0])[st_t].cpu().numpy()
+                    h2 = ol_n[1].reshape(BL, -1)[st_t].cpu().numpy()
+                    need_l = np.concatenate([r0, h1.reshape(-1)])
+                    OGl = _oracle_rows(G, p, need_l[(need_l >= 1) & (need_l <= args.nodes)], 1)
+                    # euler_gpu_time_sample_fanout draws iteration it with call ids it * layers + h
+                    onl, _, _ = OGl.sample_fanout(GRAPH_SEED, 4 * layers, r0, et, FANOUT, default_node)
+                    assert np.array_equal(onl[0], h1.reshape(-1)) and np.array_equal(onl[1], h2.reshape(-1)), \
+                        "B = 1M launch: sampled ids differ from the oracle"
+                    chk = int(64 * 275)
+                roofline["large_batch"] = {
+                    "roots": BL, "avg_launch_ms": round(msl.value, 4),
+                    "algorithmic_bytes_per_launch": round(tb, 1),
+                    "achieved": round(tb / (msl.value * 1e-3) / 1e9, 2), "unit": "GB/s",
+                    "frac": round(tb / (msl.value * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "edges_per_s": BL * 275 / (msl.value * 1e-3),
+                    "hop2_distinct_roots": int(u2.numel()), "parity_checked_edges": chk}
+                del ol_n, ol_w, ol_t, wl, rl, u2
+                torch.cuda.empty_cache()
+            except Exception as e:          # a side measurement must not fail the bench
+                roofline["large_batch"] = {"error": repr(e)}
     if rank == 0 and not fused:
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         et1 = (C.c_int32 * 1)(0)
@@ -1406,6 +1705,7 @@ def main():
                                 "in flight" % (world, args.pipeline),
                 "parity_checked_edges": checked,
                 "small_batch": small,
+                "sustained": sustained,
                 "secondary": secondary,
                 "latency_B1024_us": (small or {}).get("latency_B1024_us"),
                 "streams": 1 if sharded else max(1, args.streams),

@@ -36,7 +36,7 @@ class SynthParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("n_nodes", C.c_int64),
                 ("n_edges_target", C.c_int64), ("scale", C.c_int32),
                 ("n_types", C.c_int32), ("weighted", C.c_int32),
-                ("pad", C.c_int32), ("deg_table", C.c_double * 64)]
+                ("hashed_ids", C.c_int32), ("deg_table", C.c_double * 64)]
 
 
 # name -> (restype, argtypes); also the list of symbols include/euler_gpu.h declares
@@ -79,6 +79,10 @@ SIGNATURES = {
                                           C.c_int64, i32p, C.c_int32, i32p, C.c_int32,
                                           C.c_int64, C.POINTER(vp), C.POINTER(vp),
                                           C.POINTER(vp), vp]),
+    "euler_gpu_sample_fanout_multi": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, vp,
+                                                C.c_int32, vp, C.c_int64, i32p, C.c_int32, i32p,
+                                                C.c_int32, C.c_int64, C.POINTER(vp), C.POINTER(vp),
+                                                C.POINTER(vp), vp]),
     "euler_gpu_sample_node": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, i32p,
                                         C.c_int32, C.c_int32, vp]),
     "euler_gpu_get_full_neighbor": (C.c_int, [vp, vp, vp, C.c_int64, i32p, C.c_int32,

@@ -69,6 +69,13 @@ struct FanoutLocalArgs {
   SmallDiv div_h1, div_h2;  // by the pairs per row, (c1 + 1) / 2 and c2 / 2 (lean kernel)
   uint64_t* id1; float* w1; int32_t* ty1; uint8_t* mask0;
   uint64_t* id2; float* w2; int32_t* ty2; uint8_t* mask1;
+  // several minibatches in one launch (euler_gpu_sample_fanout_multi): roots [mb_n * M],
+  // minibatch b = root / mb_n draws with call id call_ids[b] (device array) or, when that
+  // is null, call_id + b * call_stride.  mb_n == 0: one minibatch.  A tile never straddles
+  // two minibatches (the launcher requires mb_n % gr == 0).
+  int64_t mb_n;
+  const uint32_t* call_ids;
+  uint32_t call_stride;
   uint32_t* row_index;      // lean kernel, not null: the (unique rows, index) form - id2 / w2 / ty2
                             // receive each tile's DISTINCT hop-2 rows (row r0 * c1 + slot), row_index
                             // the row of every hop-1 sample; nothing is expanded
@@ -92,6 +99,13 @@ struct FanoutLocalArgs {
 #else
 #define EG_FL_ABLATE_BITS(a) 0
 #endif
+
+// call id of the tile that starts at root r0
+__device__ __forceinline__ uint32_t TileCallId(const FanoutLocalArgs& a, int64_t r0) {
+  if (a.mb_n <= 0) return a.call_id;
+  const uint32_t b = (uint32_t)((uint64_t)r0 / (uint64_t)a.mb_n);
+  return a.call_ids != nullptr ? a.call_ids[b] : a.call_id + b * a.call_stride;
+}
 
 // LDS of one wave (bytes), and the offsets of its arrays
 struct FanoutLocalLds {
@@ -160,6 +174,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLocalKernel(
     const uint32_t p2 = nr * c12;              // hop-2 samples (output positions) of the tile
     const int64_t out1 = r0 * (int64_t)c1;     // first hop-1 output position of the tile
     const int64_t out2 = out1 * (int64_t)c2;
+    const uint32_t tile_call = TileCallId(a, r0);
     uint32_t n_slots = 0, s0 = 0;
     // One sampling loop serves both hops (phase 0: the tile's hop-1 samples, phase 1: the
     // hop-2 samples of the slots [s0, s0 + cap)): the search is inlined once.
@@ -171,7 +186,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLocalKernel(
       const uint32_t cx = phase == 0 ? c1 : c2;
       const SmallDiv dv = phase == 0 ? a.div_c1 : a.div_c2;
       const int32_t et = phase == 0 ? a.t1 : a.t2;
-      const uint32_t call = a.call_id + (uint32_t)phase;
+      const uint32_t call = tile_call + (uint32_t)phase;
 #pragma nounroll
       for (uint32_t b = 0; b < tasks; b += 64) {
         const uint32_t tk = b + lane;
@@ -669,6 +684,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
     const uint32_t nr = (uint32_t)(a.n - r0 < (int64_t)gr ? a.n - r0 : (int64_t)gr);
     const uint32_t p1 = nr * c1, p2 = nr * c12;
     const int64_t out1 = r0 * (int64_t)c1, out2 = out1 * (int64_t)c2;
+    const uint32_t tile_call = TileCallId(a, r0);
     if ((uint32_t)lane < gr) s_mask[lane] = 0ull;
     WaveSync();
     unsigned long long t_s[6] = {0, 0, 0, 0, 0, 0};
@@ -694,7 +710,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
         }
       }
       const bool live = in && deg > 0 && !EG_FL_ABLATE(a, 8);
-      const Philox4 pb = RngBlock(a.seed, a.call_id, kDomainNeighbor, node, jp);
+      const Philox4 pb = RngBlock(a.seed, tile_call, kDomainNeighbor, node, jp);
       uint64_t id[2]; float w[2]; uint32_t m[2];
       if (UNIFORM) LeanSamplePairUniform(g, lo, deg, total, live, UnitFromWords(pb.w[0], pb.w[1]),
                                          UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
@@ -804,7 +820,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
           }
         }
         const bool live = in && deg > 0 && !EG_FL_ABLATE(a, 2);
-        const Philox4 pb = RngBlock(a.seed, a.call_id + 1u, kDomainNeighbor, node, xp);
+        const Philox4 pb = RngBlock(a.seed, tile_call + 1u, kDomainNeighbor, node, xp);
         uint64_t id[2]; float w[2]; uint32_t m[2];
         if (UNIFORM) LeanSamplePairUniform(g, lo, deg, total, live, UnitFromWords(pb.w[0], pb.w[1]),
                                            UnitFromWords(pb.w[2], pb.w[3]), id, w, m);

@@ -563,7 +563,7 @@ struct SynthView {
   int32_t scale;
   int32_t n_types;
   int32_t weighted;
-  int32_t pad;
+  int32_t hashed_ids;     // node x carries the external id Mix64(x) (oracle/eo_synth.c: eo_synth_external_id)
   double deg_table[64];
 };
 
@@ -629,8 +629,39 @@ __global__ __launch_bounds__(256) void SynthEdgeKernel(
     }
     const uint64_t id = id_base + (uint64_t)lo * id_stride;
     const int64_t j = e - row_ptr[lo];
-    nbr[e] = SynthNeighbor(p, id, j);
+    const uint64_t nb = SynthNeighbor(p, id, j);
+    nbr[e] = p.hashed_ids ? Mix64(nb) : nb;
     w[e] = SynthWeight(p, id, j);
+  }
+}
+
+// hashed ids: the external id of every row, and the open-addressing id map
+// (device_fns.h: FindRow) filled on the device - keys are distinct and never 0, so a slot
+// is claimed by a CAS on its key word; the row number follows.
+__global__ void SynthRowIdKernel(uint64_t id_base, uint64_t id_stride, int64_t n_rows,
+                                 uint64_t* row_id) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n_rows) row_id[r] = Mix64(id_base + (uint64_t)r * id_stride);
+}
+
+__global__ void HashInitKernel(uint64_t* slots, uint64_t cap) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += stride) {
+    slots[2 * i] = 0; slots[2 * i + 1] = ~0ULL;
+  }
+}
+
+__global__ void HashInsertKernel(const uint64_t* row_id, int64_t n_rows, uint64_t* slots,
+                                 uint64_t mask) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rows) return;
+  const uint64_t key = row_id[r];
+  uint64_t h = Mix64(key) & mask;
+  for (uint64_t probes = 0; probes <= mask; ++probes) {
+    const unsigned long long old =
+        atomicCAS(reinterpret_cast<unsigned long long*>(slots + 2 * h), 0ULL, (unsigned long long)key);
+    if (old == 0ULL) { slots[2 * h + 1] = (uint64_t)r; return; }
+    h = (h + 1) & mask;
   }
 }
 
@@ -702,6 +733,10 @@ int BuildGraphSynthetic(const euler_gpu_synth_params* sp, int device,
   SynthView p{};
   p.seed = sp->seed; p.n_nodes = sp->n_nodes; p.scale = sp->scale;
   p.n_types = sp->n_types; p.weighted = sp->weighted;
+  p.hashed_ids = sp->hashed_ids != 0 ? 1 : 0;
+  if (p.hashed_ids && shards != 1)
+    return Fail(EULER_GPU_EINVAL, "graph_create_synthetic: hashed ids are not sharded (owner(id) "
+                                  "would scatter the rows: build the shard from arrays)");
   std::memcpy(p.deg_table, sp->deg_table, sizeof(p.deg_table));
   const int block = 256;
   // degrees -> row_ptr (temporary, dropped after row_meta is built)
@@ -743,6 +778,23 @@ int BuildGraphSynthetic(const euler_gpu_synth_params* sp, int device,
   EG_HIP(hipDeviceSynchronize());
   EG_HIP(hipFree(row_ptr));
   v.nbr = nbr; v.prefix_w = pw; v.row_meta = meta;
+  if (p.hashed_ids && n_rows > 0) {
+    uint64_t cap = 16;
+    while (cap < (uint64_t)n_rows * 2 + 1) cap <<= 1;
+    uint64_t* rid = b.Alloc<uint64_t>((size_t)n_rows);
+    uint64_t* slots = b.Alloc<uint64_t>((size_t)(2 * cap));
+    if (b.rc != EULER_GPU_OK) { DestroyGraph(b.g.release()); return b.rc; }
+    hipLaunchKernelGGL(SynthRowIdKernel, dim3((n_rows + block - 1) / block), dim3(block), 0, 0,
+                       base, stride, n_rows, rid);
+    hipLaunchKernelGGL(HashInitKernel, dim3(GridFor((int64_t)cap, block)), dim3(block), 0, 0, slots, cap);
+    hipLaunchKernelGGL(HashInsertKernel, dim3((n_rows + block - 1) / block), dim3(block), 0, 0,
+                       rid, n_rows, slots, cap - 1);
+    EG_HIP(hipGetLastError());
+    EG_HIP(hipDeviceSynchronize());
+    v.row_id = rid; v.map_mode = 1; v.hash_slots = slots; v.hash_mask = cap - 1;
+    v.id_base = 0; v.id_stride = 1;
+    b.g->max_id = ~0ULL;          // the ids are spread over the whole u64 range
+  }
   {
     int rc = BuildSearchIndex(&b);
     if (rc != EULER_GPU_OK) { DestroyGraph(b.g.release()); return rc; }

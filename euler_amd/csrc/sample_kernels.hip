@@ -1220,12 +1220,21 @@ struct Fanout2Args {
   int32_t c1, c2, t1, t2;
   uint64_t* id1; float* w1; int32_t* ty1; uint8_t* mask0;
   uint64_t* id2; float* w2; int32_t* ty2; uint8_t* mask1;
+  // several minibatches in one launch (FanoutLocalArgs has the same three fields)
+  int64_t mb_n;
+  const uint32_t* call_ids;
+  uint32_t call_stride;
 };
 
 __global__ __launch_bounds__(256) void SampleFanout2Kernel(const Fanout2Args a) {
   __shared__ uint64_t s_id[256];
   __shared__ int32_t s_valid;
   for (int64_t r = blockIdx.x; r < a.n; r += gridDim.x) {
+    uint32_t call0 = a.call_id;
+    if (a.mb_n > 0) {
+      const uint32_t b = (uint32_t)((uint64_t)r / (uint64_t)a.mb_n);
+      call0 = a.call_ids != nullptr ? a.call_ids[b] : a.call_id + b * a.call_stride;
+    }
     const int32_t j = threadIdx.x;
     if (j < a.c1) {
       const uint64_t node = a.roots[r];
@@ -1234,7 +1243,7 @@ __global__ __launch_bounds__(256) void SampleFanout2Kernel(const Fanout2Args a) 
       uint64_t id = (uint64_t)a.default_node;
       float w = 0.f;
       if (valid) {
-        const Philox4 pb = RngBlock(a.seed, a.call_id, kDomainNeighbor, node, ((uint32_t)j) >> 1);
+        const Philox4 pb = RngBlock(a.seed, call0, kDomainNeighbor, node, ((uint32_t)j) >> 1);
         const double u = (j & 1) ? UnitFromWords(pb.w[2], pb.w[3]) : UnitFromWords(pb.w[0], pb.w[1]);
         BlockPivotSample(a.g, sg, u, &id, &w);
       }
@@ -1256,7 +1265,7 @@ __global__ __launch_bounds__(256) void SampleFanout2Kernel(const Fanout2Args a) 
       uint64_t id = (uint64_t)a.default_node;
       float w = 0.f;
       if (valid) {
-        const Philox4 pb = RngBlock(a.seed, a.call_id + 1u, kDomainNeighbor, node, ((uint32_t)x) >> 1);
+        const Philox4 pb = RngBlock(a.seed, call0 + 1u, kDomainNeighbor, node, ((uint32_t)x) >> 1);
         const double u = (x & 1) ? UnitFromWords(pb.w[2], pb.w[3]) : UnitFromWords(pb.w[0], pb.w[1]);
         BlockPivotSample(a.g, sg, u, &id, &w);
       }
@@ -1340,6 +1349,15 @@ __global__ __launch_bounds__(256) void TfRepackFirstKernel(uint64_t* id, float* 
   }
 }
 
+// M minibatches in one launch (euler_gpu_sample_fanout_multi): `n` of RunFanout is then the
+// total number of roots, minibatch b = root / n_per.
+struct FanoutMulti {
+  int64_t n_per;
+  int32_t m;
+  uint32_t call_stride;
+  const uint32_t* call_ids_dev;
+};
+
 // The hops of a fanout under one lock: hop h's kernels that write the final ids
 // also enter them into hop h+1's owner table (MarkNextHop), so the duplicate
 // detection of hop h+1 starts at its scan.  events: 4 per hop (PhaseMark) or
@@ -1351,7 +1369,7 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
                      const int32_t* counts_host, int32_t layers, int64_t default_node,
                      uint64_t* const* out_id_dev, float* const* out_w_dev,
                      int32_t* const* out_t_dev, void* workspace_dev, hipEvent_t* events,
-                     int64_t* uniq_off) {
+                     int64_t* uniq_off, const FanoutMulti* multi = nullptr) {
   struct FanoutConcurrency {
     bool own;
     FanoutConcurrency(const euler_gpu_graph* g_, hipStream_t st_) : own(t_concurrent < 0) {
@@ -1364,11 +1382,14 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
   // one id load, and the global duplicate detection finds more to share on the small dense
   // graphs of that kind - products-shaped: 135 vs 131 G edges/s)
   if (g_fanout_local != 0 && (g->view.uniform_w == 0 || g_fanout_local == 2) && events == nullptr &&
-      layers == 2 && k == 1 && n >= g_fl_min_roots &&
+      layers == 2 && k == 1 &&
+      n >= (multi != nullptr && g_fl_min_roots > 8192 ? 8192 : g_fl_min_roots) &&
       g_k1_variant == 6 && g->view.monotone && counts_host[0] > 0 && counts_host[1] > 0) {
     const int32_t c1 = counts_host[0], c2 = counts_host[1];
     int32_t gr = g_fl_roots < 1 ? 1 : g_fl_roots > 16 ? 16 : g_fl_roots;
     while (gr > 1 && (int64_t)gr * c1 > 0x7FFF) gr >>= 1;
+    // several minibatches: a tile (gr roots) must not straddle two of them
+    while (multi != nullptr && gr > 1 && multi->n_per % gr != 0) gr >>= 1;
     int32_t cap = g_fl_cap > 0 ? g_fl_cap : 8 * gr;
     if (cap > gr * c1) cap = gr * c1;
     const int block = (g_fl_block == 64 || g_fl_block == 128) ? g_fl_block : 256;
@@ -1392,6 +1413,9 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
       f.c1 = c1; f.c2 = c2;
       f.t1 = edge_types_host[0]; f.t2 = edge_types_host[1];
       f.gr = gr; f.cap = cap; f.wave_lds = (int32_t)lay.bytes;
+      if (multi != nullptr) {
+        f.mb_n = multi->n_per; f.call_ids = multi->call_ids_dev; f.call_stride = multi->call_stride;
+      }
       f.div_c1.Set((uint32_t)c1); f.div_c2.Set((uint32_t)c2);
       uint8_t* wsb = (uint8_t*)workspace_dev;
       f.id1 = out_id_dev[0]; f.w1 = out_w_dev[0]; f.ty1 = out_t_dev[0]; f.mask0 = wsb;
@@ -1458,9 +1482,36 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
     }
   }
   std::lock_guard<std::recursive_mutex> launch_lk(g->launch_mu);
+  const bool fanout2_ok = g_fanout_fused != 0 && events == nullptr && layers == 2 && k == 1 && n > 0 &&
+      g_k1_variant == 6 && g->view.monotone && g->view.has_zero_nbr == 0 &&
+      counts_host[0] > 0 && counts_host[0] <= 256 && counts_host[1] > 0;
+  if (multi != nullptr && !fanout2_ok) {
+    // shapes neither one-launch kernel serves: the minibatches one after the other
+    int64_t per[8];
+    int64_t mrows = multi->n_per;
+    for (int32_t h = 0; h < layers && h < 8; ++h) { mrows *= counts_host[h]; per[h] = mrows; }
+    if (layers > 8) return Fail(EULER_GPU_EINVAL, "sample_fanout_multi: more than 8 layers");
+    if (multi->call_ids_dev != nullptr)
+      return Fail(EULER_GPU_EINVAL, "sample_fanout_multi: device call ids need a 2-hop fanout of "
+                                    "single listed types (pass NULL: call_id + b * stride)");
+    for (int32_t b = 0; b < multi->m; ++b) {
+      uint64_t* oi[8]; float* ow[8]; int32_t* ot[8];
+      for (int32_t h = 0; h < layers; ++h) {
+        oi[h] = out_id_dev[h] + (size_t)b * per[h];
+        ow[h] = out_w_dev[h] + (size_t)b * per[h];
+        ot[h] = out_t_dev[h] + (size_t)b * per[h];
+      }
+      const int rc = RunFanout(g, stream, seed, call_id + (uint32_t)b * multi->call_stride,
+                               roots_dev + (size_t)b * multi->n_per, multi->n_per, edge_types_host, k,
+                               counts_host, layers, default_node, oi, ow, ot, workspace_dev, nullptr,
+                               nullptr, nullptr);
+      if (rc != EULER_GPU_OK) return rc;
+    }
+    return EULER_GPU_OK;
+  }
   // size the stream's scratch for the largest hop up front: the owner table a
   // hop fills for its successor must not move in between
-  {
+  if (multi == nullptr) {
     size_t need = 0;
     int64_t m = n;
     for (int32_t h = 0; h < layers; ++h) {
@@ -1479,10 +1530,8 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
     }
   }
   // a small 2-hop fanout of single listed types: one launch (SampleFanout2Kernel)
-  if (g_fanout_fused != 0 && events == nullptr && layers == 2 && k == 1 && n > 0 &&
-      g_k1_variant == 6 && g->view.monotone && g->view.has_zero_nbr == 0 &&
-      counts_host[0] > 0 && counts_host[0] <= 256 && counts_host[1] > 0 && n <= kFanout2MaxRoots &&
-      !WantsDedup(g, n * counts_host[0], 1) && !WantsDedup(g, n, 1)) {
+  if (fanout2_ok && (multi != nullptr || (n <= kFanout2MaxRoots &&
+      !WantsDedup(g, n * counts_host[0], 1) && !WantsDedup(g, n, 1)))) {
     if (g->view.blk == nullptr) {
       const int rc0 = EnsureBlockedIndex(g);
       if (rc0 != EULER_GPU_OK) return rc0;
@@ -1496,6 +1545,9 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
     f.id1 = out_id_dev[0]; f.w1 = out_w_dev[0]; f.ty1 = out_t_dev[0]; f.mask0 = wsb;
     f.id2 = out_id_dev[1]; f.w2 = out_w_dev[1]; f.ty2 = out_t_dev[1];
     f.mask1 = wsb + (((size_t)n + 15) & ~(size_t)15);
+    if (multi != nullptr) {
+      f.mb_n = multi->n_per; f.call_ids = multi->call_ids_dev; f.call_stride = multi->call_stride;
+    }
     int64_t blocks = n < 256 * 16 ? n : 256 * 16;
     hipLaunchKernelGGL(SampleFanout2Kernel, dim3((unsigned)blocks), dim3(256), 0, stream, f);
     EG_HIP(hipGetLastError());
@@ -1630,6 +1682,32 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 44 && (value == 0 || value == 1)) { g_walk_lean = value; return EULER_GPU_OK; }
   if (key == 35 && (value == 5 || value == 6 || value == 8)) { g_fl_wps = value; return EULER_GPU_OK; }
   return Fail(EULER_GPU_EINVAL, "set_tuning: unknown key");
+}
+
+int euler_gpu_sample_fanout_multi(const euler_gpu_graph* g, void* stream, uint64_t seed,
+                                  uint32_t call_id, uint32_t call_stride,
+                                  const uint32_t* call_ids_dev, int32_t m,
+                                  const uint64_t* roots_dev, int64_t n,
+                                  const int32_t* edge_types_host, int32_t k,
+                                  const int32_t* counts_host, int32_t layers,
+                                  int64_t default_node, uint64_t* const* out_id_dev,
+                                  float* const* out_w_dev, int32_t* const* out_t_dev,
+                                  void* workspace_dev) {
+  if (!g) return Fail(EULER_GPU_ENOGRAPH, "sample_fanout_multi: null graph");
+  if (m < 0 || n < 0 || layers <= 0 || k <= 0 || !counts_host || !edge_types_host)
+    return Fail(EULER_GPU_EINVAL, "sample_fanout_multi: bad arguments");
+  if (m == 0 || n == 0) return EULER_GPU_OK;
+  int64_t total = (int64_t)m * n;
+  for (int32_t h = 0; h < layers; ++h) {
+    if (counts_host[h] <= 0) return Fail(EULER_GPU_EINVAL, "sample_fanout_multi: counts must be > 0");
+    total *= counts_host[h];
+  }
+  if (total >= ((int64_t)1 << 31) || (int64_t)m * n >= ((int64_t)1 << 31))
+    return Fail(EULER_GPU_EINVAL, "sample_fanout_multi: more than 2^31 output positions");
+  FanoutMulti mu{n, m, call_stride, call_ids_dev};
+  return RunFanout(g, (hipStream_t)stream, seed, call_id, roots_dev, (int64_t)m * n, edge_types_host, k,
+                   counts_host, layers, default_node, out_id_dev, out_w_dev, out_t_dev, workspace_dev,
+                   nullptr, nullptr, &mu);
 }
 
 int euler_gpu_sample_neighbor(const euler_gpu_graph* g, void* stream,

@@ -2,7 +2,7 @@
 from . import base
 from . import node_ops as type_ops
 
-__all__ = ["sample_neighbor", "sample_fanout", "get_full_neighbor",
+__all__ = ["sample_neighbor", "sample_fanout", "sample_fanout_multi", "get_full_neighbor",
            "get_sorted_full_neighbor", "get_top_k_neighbor", "to_sparse",
            "sample_fanout_with_feature", "sparse_get_adj",
            "sample_neighbor_layerwise", "sample_fanout_layerwise_each_node",
@@ -25,6 +25,17 @@ def sample_fanout(nodes, edge_types, counts, default_node=-1):
     edge_types = [type_ops.get_edge_type_id(et) for et in edge_types]
     return base.get_default_graph().sample_fanout(nodes, edge_types, counts,
                                                   default_node)
+
+
+def sample_fanout_multi(batches, edge_types, counts, default_node=-1):
+    """sample_fanout of M minibatches ([M, B] roots, or a list of M equally long root
+    tensors) in ONE enqueue: a list of M (neighbors_list, weights_list, types_list), each
+    equal bit for bit to what M consecutive sample_fanout calls return (draws are keyed by
+    (call id, node id)).  Not in the reference: its callers issue one op per minibatch of a
+    few hundred roots (dataflow/sage_dataflow.py:35-50) - this is that loop as one launch."""
+    edge_types = [type_ops.get_edge_type_id(et) for et in edge_types]
+    return base.get_default_graph().sample_fanout_multi(batches, edge_types, counts,
+                                                        default_node)
 
 
 def get_full_neighbor(nodes, edge_types, condition=''):

@@ -95,7 +95,7 @@ def _np(a, dt):
     return np.ascontiguousarray(a, dtype=dt)
 
 
-def synth_params(seed, n_nodes, n_edges, n_types=1, weighted=True, scale=None):
+def synth_params(seed, n_nodes, n_edges, n_types=1, weighted=True, scale=None, hashed_ids=False):
     """Parameters of the deterministic synthetic power-law graph (RMAT
     marginals a,b,c,d = .57,.19,.19,.05, minimum degree 1).
     deg_table[z] = expected extra out-degree of a node whose (id-1) has z one
@@ -123,6 +123,9 @@ def synth_params(seed, n_nodes, n_edges, n_types=1, weighted=True, scale=None):
     p.scale = scale
     p.n_types = n_types
     p.weighted = 1 if weighted else 0
+    # hashed_ids: node x is known outside by mix64(x) (arbitrary u64 ids, hash id map) - what a
+    # dataset converted by euler/tools looks like - instead of x itself (identity id map)
+    p.hashed_ids = 1 if hashed_ids else 0
     wz = [(0.76 ** (scale - z)) * (0.24 ** z) for z in range(scale + 1)]
     norm = sum(c * w for c, w in zip(cnt, wz))
     extra = max(0.0, float(n_edges - n_nodes))
@@ -396,6 +399,52 @@ class Graph:
                 self._take_call_ids(layers, call_id), _ptr(nodes), n, et_p, k,
                 cnt_p, layers, int(default_node), pn, pw, pt, _ptr(ws)))
         return [nodes] + outs_n, outs_w, outs_t
+
+    def sample_fanout_multi(self, batches, edge_types, counts, default_node=-1, call_id=None,
+                            call_ids=None):
+        """M minibatches of sample_fanout in ONE enqueue (euler_gpu_sample_fanout_multi):
+        `batches` is an [M, B] tensor or a list of M equally long root tensors; minibatch b
+        draws with call id call_id + b * len(counts) - what M consecutive sample_fanout calls
+        take from the graph's counter - or call_ids[b] (a device uint32 / int32 tensor).
+        Returns a list of M (neighbors_list, weights_list, types_list), each what
+        sample_fanout returns for that minibatch (views of one allocation per hop), bit for
+        bit."""
+        if isinstance(batches, (list, tuple)):
+            batches = torch.stack([_as_i64_cuda(b, self.device).reshape(-1) for b in batches], 0)
+        roots = _as_i64_cuda(batches, self.device)
+        assert roots.dim() == 2, "batches: [M, B]"
+        roots = roots.contiguous()
+        m, n = int(roots.shape[0]), int(roots.shape[1])
+        layers = len(counts)
+        et, et_p, k, cnt, cnt_p = _fanout_plan(edge_types, counts)
+        outs_n, outs_w, outs_t, rows = [], [], [], n
+        for c in counts:
+            rows *= int(c)
+            outs_n.append(torch.empty((m, rows), dtype=torch.int64, device=self.device))
+            outs_w.append(torch.empty((m, rows), dtype=torch.float32, device=self.device))
+            outs_t.append(torch.empty((m, rows), dtype=torch.int32, device=self.device))
+        ws_key = (m * n,) + tuple(int(c) for c in counts)
+        ws_bytes = _WS_BYTES.get(ws_key)
+        if ws_bytes is None:
+            ws_bytes = int(lib().euler_gpu_sample_fanout_workspace(m * n, cnt_p, layers))
+            if len(_WS_BYTES) < 4096:
+                _WS_BYTES[ws_key] = ws_bytes
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=self.device)
+        pn = (C.c_void_p * layers)(*[t.data_ptr() for t in outs_n])
+        pw = (C.c_void_p * layers)(*[t.data_ptr() for t in outs_w])
+        pt = (C.c_void_p * layers)(*[t.data_ptr() for t in outs_t])
+        ids_p = None
+        if call_ids is not None:
+            call_ids = call_ids.to(device=self.device, dtype=torch.int32).contiguous()
+            assert call_ids.numel() == m
+            ids_p = _ptr(call_ids)
+        with self._on_device():
+            check(lib().euler_gpu_sample_fanout_multi(
+                self._h, _stream(), self.seed, self._take_call_ids(layers * m, call_id), layers,
+                ids_p, m, _ptr(roots), n, et_p, k, cnt_p, layers, int(default_node), pn, pw, pt,
+                _ptr(ws)))
+        return [([roots[b]] + [t[b] for t in outs_n], [t[b] for t in outs_w], [t[b] for t in outs_t])
+                for b in range(m)]
 
     def sample_fanout_unique(self, nodes, edge_types, counts, default_node=-1, call_id=None):
         """The 2-hop fanout in the (unique rows, index) form (euler_gpu_sample_fanout_unique):

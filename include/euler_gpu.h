@@ -98,7 +98,8 @@ typedef struct euler_gpu_synth_params {
   int32_t scale;               /* RMAT scale (bits)                            */
   int32_t n_types;
   int32_t weighted;            /* 0: all weights 1.0f, 1: uniform [0.5, 8)     */
-  int32_t pad;
+  int32_t hashed_ids;          /* 1: node x (1..n_nodes) carries the external id mix64(x), a
+                                * bijection of u64 - arbitrary ids, hash id map - instead of x  */
   double deg_table[64];        /* expected extra degree by popcount(id-1)      */
 } euler_gpu_synth_params;
 
@@ -245,6 +246,26 @@ int euler_gpu_sample_neighbor_packed(const euler_gpu_graph* g, void* stream,
  * workspace_dev must hold euler_gpu_sample_fanout_workspace() bytes. */
 size_t euler_gpu_sample_fanout_workspace(int64_t n, const int32_t* counts_host,
                                          int32_t layers);
+/* M minibatches of one SampleFanout in ONE enqueue - the regime of the reference's callers
+ * (tf_euler/python/dataflow/sage_dataflow.py:35-50 issues one sample_fanout per minibatch of
+ * a few hundred roots; its client keeps 8 such queries in flight, client/query_proxy.cc:
+ * 205-210).  roots_dev holds m * n roots, minibatch b = roots [b n, (b + 1) n) draws with
+ * call id call_ids_dev[b] (a DEVICE array, 2-hop single-type fanouts only) or, when that is
+ * NULL, call_id + b * call_stride (hop h: + h).  out_*_dev[h] has m * n * prod(counts[0..h])
+ * elements, minibatch-major.  Draws are keyed by (call id, node id), so the result equals
+ * m calls of euler_gpu_sample_fanout bit for bit.  A 2-hop fanout of single listed types
+ * is one launch (a workgroup per root below 8 192 roots in all, the wave-per-4-roots kernel
+ * of fanout_local.h above); other shapes enqueue the minibatches one after the other.
+ * workspace_dev: euler_gpu_sample_fanout_workspace(m * n, ...) bytes. */
+int euler_gpu_sample_fanout_multi(const euler_gpu_graph* g, void* stream, uint64_t seed,
+                                  uint32_t call_id, uint32_t call_stride,
+                                  const uint32_t* call_ids_dev, int32_t m,
+                                  const uint64_t* roots_dev, int64_t n,
+                                  const int32_t* edge_types_host, int32_t k,
+                                  const int32_t* counts_host, int32_t layers,
+                                  int64_t default_node, uint64_t* const* out_id_dev,
+                                  float* const* out_w_dev, int32_t* const* out_t_dev,
+                                  void* workspace_dev);
 int euler_gpu_sample_fanout(const euler_gpu_graph* g, void* stream,
                             uint64_t seed, uint32_t call_id,
                             const uint64_t* roots_dev, int64_t n,

@@ -36,6 +36,12 @@ static uint64_t sy_hash(uint64_t seed, uint64_t node, uint64_t j, uint64_t c) {
   return h;
 }
 
+/* hashed_ids: the id a node is known by outside - arbitrary u64 ids, as a .dat dataset has.
+ * mix64 is a bijection of u64 with mix64(0) = 0, so ids are distinct and never the sentinel 0. */
+uint64_t eo_synth_external_id(const eo_synth_params* p, uint64_t node_id) {
+  return p->hashed_ids ? sy_mix64(node_id) : node_id;
+}
+
 void eo_synth_fill_table(eo_synth_params* p) {
   const double p1 = 0.24, p0 = 0.76;
   const int S = p->scale;
@@ -121,7 +127,7 @@ int64_t eo_synth_build(const eo_synth_params* p, int64_t row_begin,
         }
         float w = eo_synth_weight(p, id, j);
         sum += w; tw += w;
-        nbr[off + j] = eo_synth_neighbor(p, id, j);
+        nbr[off + j] = eo_synth_external_id(p, eo_synth_neighbor(p, id, j));
         prefix_w[off + j] = sum;
       }
       while (t < T) {

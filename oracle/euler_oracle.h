@@ -243,9 +243,10 @@ typedef struct eo_synth_params {
   int32_t scale;          /* RMAT scale: ids drawn from [0, 2^scale) */
   int32_t n_types;        /* edge types (edges split by hash) */
   int32_t weighted;       /* 0: all 1.0f; 1: uniform [0.5, 8) */
-  int32_t pad;
+  int32_t hashed_ids;        /* 1: external id of node x = eo_synth_external_id(x) (a bijection of u64) */
   double deg_table[64];   /* expected extra degree by popcount(id-1) */
 } eo_synth_params;
+uint64_t eo_synth_external_id(const eo_synth_params* p, uint64_t node_id);
 void eo_synth_fill_table(eo_synth_params* p);
 int64_t eo_synth_degree(const eo_synth_params* p, uint64_t node_id);
 uint64_t eo_synth_neighbor(const eo_synth_params* p, uint64_t node_id,

@@ -124,6 +124,8 @@ def lib():
                                       C.c_int32, _i32p, C.c_int32, C.c_int32,
                                       _i64p]
         L.eo_synth_fill_table.argtypes = [C.c_void_p]
+        L.eo_synth_external_id.restype = C.c_uint64
+        L.eo_synth_external_id.argtypes = [C.c_void_p, C.c_uint64]
         L.eo_synth_degree.restype = C.c_int64
         L.eo_synth_degree.argtypes = [C.c_void_p, C.c_uint64]
         L.eo_synth_neighbor.restype = C.c_uint64
@@ -953,11 +955,48 @@ class SynthParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("n_nodes", C.c_int64),
                 ("n_edges_target", C.c_int64), ("scale", C.c_int32),
                 ("n_types", C.c_int32), ("weighted", C.c_int32),
-                ("pad", C.c_int32), ("deg_table", C.c_double * 64)]
+                ("hashed_ids", C.c_int32), ("deg_table", C.c_double * 64)]
 
 
-def synth_params(seed, n_nodes, n_edges, n_types=1, weighted=True, scale=None):
+_M64 = (1 << 64) - 1
+
+
+def synth_external_ids(p, x):
+    """External ids of the internal node numbers x (uint64 array): x itself, or - hashed_ids -
+    mix64(x), eo_synth.c's bijection (numpy restatement, checked against the C in the tests)."""
+    x = np.asarray(x, dtype=np.uint64)
+    if not p.hashed_ids:
+        return x.copy()
+    with np.errstate(over="ignore"):
+        z = x.copy()
+        z ^= z >> np.uint64(30); z *= np.uint64(0xbf58476d1ce4e5b9)
+        z ^= z >> np.uint64(27); z *= np.uint64(0x94d049bb133111eb)
+        z ^= z >> np.uint64(31)
+    return z
+
+
+def synth_internal_id(p, ext):
+    """Inverse of synth_external_ids for one id (Python ints)."""
+    z = int(ext) & _M64
+    if not p.hashed_ids:
+        return z
+
+    def unxorshift(v, s):
+        r = v
+        for _ in range(64 // s + 1):
+            r = v ^ (r >> s)
+        return r
+    z = unxorshift(z, 31)
+    z = (z * pow(0x94d049bb133111eb, -1, 1 << 64)) & _M64
+    z = unxorshift(z, 27)
+    z = (z * pow(0xbf58476d1ce4e5b9, -1, 1 << 64)) & _M64
+    z = unxorshift(z, 30)
+    return z
+
+
+def synth_params(seed, n_nodes, n_edges, n_types=1, weighted=True, scale=None, hashed_ids=False):
     p = SynthParams()
+    p.hashed_ids = 1 if hashed_ids else 0
     p.seed = seed
     p.n_nodes = n_nodes
     p.n_edges_target = n_edges
@@ -1006,7 +1045,7 @@ def synth_csr(p, row_begin=0, row_end=None, threads=1):
                 row_ptr[r0:r0 + m] = tmp_ptr[i][:m] + offs[i]
             list(ex.map(fill, range(threads)))
         row_ptr[n] = tot
-        row_id = np.arange(row_begin + 1, row_end + 1, dtype=np.uint64)
+        row_id = synth_external_ids(p, np.arange(row_begin + 1, row_end + 1, dtype=np.uint64))
         return CSR(row_id, row_ptr, type_end, nbr, prefix, tpre, p.n_types)
     tot = lib().eo_synth_build(C.byref(p), row_begin, row_end, None, None, None,
                                None, None)
@@ -1018,7 +1057,7 @@ def synth_csr(p, row_begin=0, row_end=None, threads=1):
     lib().eo_synth_build(C.byref(p), row_begin, row_end, _p(row_ptr, _i64p),
                          _p(type_end, _i32p), _p(nbr, _u64p), _p(prefix, _f32p),
                          _p(tpre, _f32p))
-    row_id = np.arange(row_begin + 1, row_end + 1, dtype=np.uint64)
+    row_id = synth_external_ids(p, np.arange(row_begin + 1, row_end + 1, dtype=np.uint64))
     return CSR(row_id, row_ptr, type_end, nbr, prefix, tpre, p.n_types)
 
 

@@ -434,6 +434,49 @@ def test_synthetic_graph_matches_host_generator(EA, O, torch_cuda, k1_variant):
             assert np.array_equal(t2n(a), ref)
 
 
+def test_synthetic_hashed_ids_two_types(EA, O, torch_cuda):
+    """The synthetic graph with hashed u64 ids (node x known outside as mix64(x): hash id map)
+    and two edge-type groups - what a dataset converted by euler/tools looks like, and what
+    bench.py's metric_hashed_T2 leg runs: device generator == host generator, the id map finds
+    every row and nothing else, and the 2-hop fanout (SampleFanoutLocalKernel: the general
+    build of the one-kernel step) == hop by hop == the oracle."""
+    torch = torch_cuda
+    from euler_amd import _lib
+    L = _lib.lib()
+    p = EA.synth_params(4242, 30000, 300000, n_types=2, weighted=True, hashed_ids=True)
+    po = O.SynthParams()
+    for f, _ in po._fields_:
+        setattr(po, f, getattr(p, f))
+    csr = O.synth_csr(po)
+    G = EA.Graph.synthetic(p)
+    assert G.num_nodes == 30000 and G.num_edges == len(csr.nbr)
+    assert len(np.unique(csr.row_id)) == 30000 and csr.row_id.min() > 0
+    row_ptr, type_end, nbr, pw, tp = G.export_rows(csr.row_id)
+    assert np.array_equal(row_ptr, csr.row_ptr) and np.array_equal(type_end, csr.type_end)
+    assert np.array_equal(nbr, csr.nbr) and np.array_equal(pw, csr.prefix_w)
+    assert np.array_equal(tp, csr.type_prefix)
+    # ids that are not in the graph (the internal numbers themselves) find nothing
+    rp0 = G.export_rows(np.arange(1, 200, dtype=np.uint64))[0]
+    assert rp0[-1] == 0
+    OG = O.OracleGraph(csr)
+    rng = np.random.default_rng(1)
+    q = np.concatenate([rng.choice(csr.row_id, 40000), [0, 5, 2 ** 63 + 9]]).astype(np.uint64).view(np.int64)
+    qt = torch.as_tensor(q).cuda()
+    try:
+        for et, counts in (([[0], [0]], [25, 10]), ([[1], [0]], [5, 4]), ([[0, 1], [1]], [6, 3])):
+            G.set_seed(3)
+            ns, ws, ts = OG.sample_fanout(3, 10, q, et, counts, -1)
+            res = []
+            for key27 in (1, 0):                 # the one-kernel step / hop by hop
+                L.euler_gpu_set_tuning(27, key27)
+                gn, gw, gt = G.sample_fanout(qt, et, counts, -1, call_id=10)
+                for h in range(2):
+                    assert np.array_equal(t2n(gn[h + 1]), ns[h]), (et, counts, key27, h)
+                    assert np.array_equal(t2n(gw[h]), ws[h]) and np.array_equal(t2n(gt[h]), ts[h])
+    finally:
+        L.euler_gpu_set_tuning(27, 1)
+
+
 def test_op_registry_and_dat_loader(EA, O, torch_cuda, fixture_csr, tmp_path):
     """The plugin-API mirror dispatches API_SAMPLE_NB to the GPU; the .dat
     reader loads what euler/tools writes."""
@@ -1610,6 +1653,67 @@ def test_fanout_local_dedup_kernel(EA, O, torch_cuda, big_pair, geom):
     finally:
         for k_, v_ in _FL_DEFAULTS.items():
             L.euler_gpu_set_tuning(k_, v_)
+
+
+def test_sample_fanout_multi_equals_separate_calls(EA, O, torch_cuda, big_pair):
+    """euler_gpu_sample_fanout_multi: M minibatches in one enqueue == M separate
+    sample_fanout calls == the oracle, bit for bit (draws are keyed by (call id, node id)).
+    Covers the workgroup-per-root kernel (few roots in all), the wave-per-4-roots kernels
+    (lean and general build; totals >= 8 192), minibatch sizes that are not a multiple of the
+    tile (the launcher shrinks the tile), shapes that fall back to one enqueue per minibatch
+    (3 hops, several listed types), explicit device call ids, hashed and identity id maps."""
+    torch = torch_cuda
+    from euler_amd import _lib
+    L = _lib.lib()
+
+    def run(G, OG, batches, et, counts, default, seed, call, ids=None, oracle_rows=2):
+        G.set_seed(seed)
+        bt = torch.as_tensor(batches).cuda()
+        layers = len(counts)
+        cid = None if ids is None else torch.as_tensor(np.asarray(ids, np.int32)).cuda()
+        res = G.sample_fanout_multi(bt, et, counts, default, call_id=call, call_ids=cid)
+        assert len(res) == len(batches)
+        for b in range(len(batches)):
+            c = call + b * layers if ids is None else int(ids[b])
+            sn, sw, st = G.sample_fanout(bt[b], et, counts, default, call_id=c)
+            for h in range(layers):
+                assert torch.equal(res[b][0][h + 1], sn[h + 1]), (b, h, counts)
+                assert torch.equal(res[b][1][h], sw[h]) and torch.equal(res[b][2][h], st[h])
+            if b < oracle_rows or b == len(batches) - 1:
+                on, ow, ot = OG.sample_fanout(seed, c, np.asarray(batches[b]), et, counts, default)
+                for h in range(layers):
+                    assert np.array_equal(t2n(res[b][0][h + 1]), on[h]), (b, h, counts)
+                    assert np.array_equal(t2n(res[b][1][h]), ow[h])
+                    assert np.array_equal(t2n(res[b][2][h]), ot[h])
+
+    # hashed ids, 4 edge types: general build / workgroup-per-root kernel / fallbacks
+    G, OG, ids, rng = big_pair
+    for M, B in ((1, 5), (3, 64), (7, 130), (16, 1024), (5, 2050)):
+        q = rng.choice(ids, M * B).astype(np.int64).reshape(M, B)
+        q[0, 0] = 0
+        q[-1, -1] = 2 ** 62
+        run(G, OG, q, [[0], [1]], [25, 10], -5, 23, 1000)
+        run(G, OG, q, [[3], [3]], [5, 4], -5, 23, 7)
+    q = rng.choice(ids, 4 * 96).astype(np.int64).reshape(4, 96)
+    run(G, OG, q, [[0], [1], [2]], [4, 3, 2], -5, 23, 50)           # 3 hops: one enqueue each
+    run(G, OG, q, [[0, 1], [1, 2]], [6, 3], -5, 23, 60)             # type draws: one enqueue each
+    run(G, OG, q, [[0], [1]], [25, 10], -5, 23, 0, ids=[900, 3, 3, 2 ** 31 - 2])
+    # identity ids, one type: lean build (weighted) and its uniform-weight form
+    for weighted in (True, False):
+        p = EA.synth_params(977, 20000, 260000, n_types=1, weighted=weighted)
+        po = O.SynthParams()
+        for f, _ in po._fields_:
+            setattr(po, f, getattr(p, f))
+        G1, OG1 = EA.Graph.synthetic(p), O.OracleGraph(O.synth_csr(po))
+        r1 = np.random.default_rng(5)
+        for M, B in ((64, 1024), (9, 1001), (2, 8192), (33, 256)):
+            q = r1.integers(0, 20002, M * B).astype(np.int64).reshape(M, B)
+            run(G1, OG1, q, [[0], [0]], [25, 10], 20001, 3, 6, oracle_rows=1)
+        q = r1.integers(1, 20001, 12 * 1024).astype(np.int64).reshape(12, 1024)
+        run(G1, OG1, q, [[0], [0]], [25, 10], 20001, 3, 0, ids=list(range(100, 112)), oracle_rows=1)
+        run(G1, OG1, q, [[0], [0]], [3, 4], 20001, 3, 77, oracle_rows=1)
+    # empty
+    assert G1.sample_fanout_multi(torch.zeros((0, 8), dtype=torch.int64).cuda(), [[0], [0]], [2, 2]) == []
 
 
 def test_random_walk_over_merged_walkers(EA, O, torch_cuda, big_pair):
