@@ -199,8 +199,11 @@ def cpu_baseline(args):
         for many in conc:
             if many <= shipped_threads:
                 continue
+            # (a round of `many` concurrent B = 131072 queries takes ~30 s at 256 threads: two rounds)
+            few = big and not full and many > 32
             secs, e = R.bench_fanout_dag(GRAPH_SEED, roots, B, FANOUT, many, 0, True,
-                                         wu if not big else 1, timed if (not big or full) else 3)
+                                         (wu if not big else 1) if not few else 0,
+                                         (timed if (not big or full) else 3) if not few else 2)
             cands.append(dict(_stats(secs, e), threads=many,
                               what="%d concurrent single-threaded queries" % many))
         for many in sorted({min(32, cores), cores}):

@@ -100,6 +100,12 @@ struct GraphView {
   const struct EdgeBlock* blk;
   const float* skip1;           // [n_blk] running sum of the last edge of every EdgeBlock
   int64_t n_blk;
+  // weight-bucket index (wb_index.h; built on first use for plain graphs: one edge-type
+  // group, identity id map, monotone non-uniform weights, < 2^31 edges): a 16-byte record per
+  // row and one 128-byte block per bucket of a row's running-sum range
+  const struct WbRec* wrec;
+  const struct EdgeBlock* wb;
+  int64_t n_wb;
 };
 
 // Edge block of the sampling index: 10 consecutive edges of the flat arrays
@@ -201,6 +207,7 @@ struct euler_gpu_graph {
   // several minibatches in flight, and the launcher then sizes its K1 grids so that the
   // kernels of two streams fit on the chip together (sample_kernels.hip: ConcurrentCall)
   mutable std::atomic<void*> last_stream{nullptr};
+  mutable std::atomic<int> wb_tried{0};     // EnsureWbIndex ran (whatever it decided)
 };
 
 namespace euler_gpu {
@@ -213,6 +220,9 @@ int BuildGraphSynthetic(const euler_gpu_synth_params* p, int device,
                         int32_t partitions, int32_t shard_index, int32_t shards,
                         euler_gpu_graph** out);
 int EnsureBlockedIndex(const euler_gpu_graph* g);   // EdgeBlocks + block pivots, on first use
+// weight-bucket index, on first use; leaves view.wb == nullptr (and returns OK) for graphs it
+// does not serve
+int EnsureWbIndex(const euler_gpu_graph* g);
 // sample_kernels.hip: TF-layout SampleNeighbor over the first *n_dev roots of a list
 // sized for `cap` (dataflow_kernels.hip)
 int LaunchSampleNeighborCounted(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed,

@@ -40,6 +40,7 @@
 #include <hip/hip_runtime.h>
 
 #include "k1_search.h"
+#include "wb_index.h"
 
 namespace euler_gpu {
 
@@ -625,6 +626,57 @@ __device__ __forceinline__ void LeanSamplePairUniform(const GraphView& g, const 
   }
 }
 
+// Both draws of one Philox block on one row through the weight-bucket index (wb_index.h):
+// per draw ONE 128-byte line - the bucket's block - instead of a walk over pivot levels and
+// a leaf.  Same contract as LeanSamplePair: m[] = the flat edge drawn; draws that round up to
+// the row's total (Q3) and draws whose block does not bracket them replay the reference's
+// bisection.  The two blocks' loads are issued before either is examined.
+template <bool TWO = true>
+__device__ __forceinline__ void WbSamplePair(const GraphView& g, const WbRec rec, const bool live,
+                                             const double u0, const double u1, uint64_t id[2],
+                                             float w[2], uint32_t m[2]) {
+  const double r0 = __dmul_rn(u0, (double)rec.total), r1 = __dmul_rn(u1, (double)rec.total);
+  bool cold0 = live && !((double)rec.total > r0);
+  bool cold1 = TWO && live && !((double)rec.total > r1);
+  const float f0 = WbFloorToFloat(r0), f1 = WbFloorToFloat(r1);
+  const uint32_t nbk = WbBuckets(rec.deg);
+  uint32_t j0 = 0u, j1 = 0u;
+  if (nbk > 1u) {
+    const float scale = WbScale(nbk, rec.total);
+    j0 = WbBucketOf(f0, nbk, scale);
+    j1 = WbBucketOf(f1, nbk, scale);
+  }
+  // (a dead lane's record is all zeros: block 0, a valid line nobody uses)
+  const EdgeBlock* b0 = g.wb + rec.wb_lo + j0;
+  const EdgeBlock* b1 = g.wb + rec.wb_lo + (TWO ? j1 : j0);
+  const WbKeys k0 = WbLoadKeys(b0);
+  WbKeys k1 = k0;
+  if (TWO) k1 = WbLoadKeys(b1);
+  id[0] = 0; id[1] = 0; w[0] = 0.f; w[1] = 0.f; m[0] = rec.lo; m[1] = rec.lo;
+  const int32_t i0 = WbPickKeys(k0, f0, &w[0], &m[0]);
+  const int32_t i1 = TWO ? WbPickKeys(k1, f1, &w[1], &m[1]) : 0;
+  const bool hot0 = live && !cold0 && i0 >= 0;
+  const bool hot1 = TWO && live && !cold1 && i1 >= 0;
+  if (hot0) id[0] = b0->nbr[i0];
+  if (hot1) id[1] = b1->nbr[i1];
+  cold0 = live && !hot0;
+  cold1 = TWO && live && !hot1;
+  if (!TWO) { id[1] = 0; w[1] = 0.f; m[1] = rec.lo; }
+  if (__ballot(cold0 || cold1) != 0ull) {
+#pragma nounroll
+    for (int s = 0; s < (TWO ? 2 : 1); ++s) {
+      if (s == 0 ? cold0 : cold1) {
+        const float* nw = g.prefix_w + rec.lo;
+        const uint32_t mid = (uint32_t)RandomSelect(nw, 0, (uint64_t)(rec.deg - 1u), s == 0 ? u0 : u1);
+        const uint64_t ci = g.nbr[rec.lo + mid];
+        const float cw = __fsub_rn(nw[mid], mid == 0u ? 0.f : nw[mid - 1]);
+        if (s == 0) { id[0] = ci; w[0] = cw; m[0] = rec.lo + mid; }
+        else { id[1] = ci; w[1] = cw; m[1] = rec.lo + mid; }
+      }
+    }
+  }
+}
+
 struct FanoutLeanLds {
   uint32_t o_sid, o_c1, o_slotid, o_mask, o_sw, o_w1, o_st, o_slot, o_rvalid, bytes;
 };
@@ -651,7 +703,8 @@ __host__ __device__ inline FanoutLeanLds FanoutLeanLayout(int32_t gr, int32_t c1
 // with ~17 registers spilled - 140 MB of scratch stores and as much again re-read per
 // step, profiles/r3_fl_v2_pmc.json).  a.dbg (measurement only): per tile, s_memtime at
 // the phase boundaries.
-template <bool WIDE, int WPS, bool UNIFORM = false>
+// WB: draws through the weight-bucket index (WbSamplePair) instead of the pivot levels.
+template <bool WIDE, int WPS, bool UNIFORM = false, bool WB = false>
 __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
     const FanoutLocalArgs a) {
   extern __shared__ __align__(16) uint8_t fl_smem[];
@@ -701,18 +754,26 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
       int32_t deg = 0;
       float total = 0.f;
       uint64_t node = 0;
+      WbRec wr{0u, 0u, 0u, 0.f};
       if (in) {
         node = a.roots[r0 + q];
         const int64_t row = LeanFindRow(g, node);
         if (row >= 0) {
-          const uint4 rec = *reinterpret_cast<const uint4*>(g.row_meta + row * 16);
-          lo = rec.x; deg = (int32_t)rec.z; total = __uint_as_float(rec.w);
+          if (WB) {
+            wr = g.wrec[row];
+            lo = wr.lo; deg = (int32_t)wr.deg; total = wr.total;
+          } else {
+            const uint4 rec = *reinterpret_cast<const uint4*>(g.row_meta + row * 16);
+            lo = rec.x; deg = (int32_t)rec.z; total = __uint_as_float(rec.w);
+          }
         }
       }
       const bool live = in && deg > 0 && !EG_FL_ABLATE(a, 8);
       const Philox4 pb = RngBlock(a.seed, tile_call, kDomainNeighbor, node, jp);
       uint64_t id[2]; float w[2]; uint32_t m[2];
-      if (UNIFORM) LeanSamplePairUniform(g, lo, deg, total, live, UnitFromWords(pb.w[0], pb.w[1]),
+      if (WB) WbSamplePair(g, wr, live, UnitFromWords(pb.w[0], pb.w[1]),
+                           UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
+      else if (UNIFORM) LeanSamplePairUniform(g, lo, deg, total, live, UnitFromWords(pb.w[0], pb.w[1]),
                                          UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
       else LeanSamplePair(g, lo, deg, total, live, UnitFromWords(pb.w[0], pb.w[1]),
                           UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
@@ -811,18 +872,26 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
         int32_t deg = 0;
         float total = 0.f;
         uint64_t node = 0;
+        WbRec wr{0u, 0u, 0u, 0.f};
         if (in) {
           node = s_slotid[s0 + sl];
           const int64_t row = LeanFindRow(g, node);
           if (row >= 0) {
-            const uint4 rec = *reinterpret_cast<const uint4*>(g.row_meta + row * 16);
-            lo = rec.x; deg = (int32_t)rec.z; total = __uint_as_float(rec.w);
+            if (WB) {
+              wr = g.wrec[row];
+              lo = wr.lo; deg = (int32_t)wr.deg; total = wr.total;
+            } else {
+              const uint4 rec = *reinterpret_cast<const uint4*>(g.row_meta + row * 16);
+              lo = rec.x; deg = (int32_t)rec.z; total = __uint_as_float(rec.w);
+            }
           }
         }
         const bool live = in && deg > 0 && !EG_FL_ABLATE(a, 2);
         const Philox4 pb = RngBlock(a.seed, tile_call + 1u, kDomainNeighbor, node, xp);
         uint64_t id[2]; float w[2]; uint32_t m[2];
-        if (UNIFORM) LeanSamplePairUniform(g, lo, deg, total, live, UnitFromWords(pb.w[0], pb.w[1]),
+        if (WB) WbSamplePair(g, wr, live, UnitFromWords(pb.w[0], pb.w[1]),
+                             UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
+        else if (UNIFORM) LeanSamplePairUniform(g, lo, deg, total, live, UnitFromWords(pb.w[0], pb.w[1]),
                                            UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
         else LeanSamplePair(g, lo, deg, total, live, UnitFromWords(pb.w[0], pb.w[1]),
                             UnitFromWords(pb.w[2], pb.w[3]), id, w, m, EG_FL_ABLATE_BITS(a));

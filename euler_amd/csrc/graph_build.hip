@@ -13,6 +13,7 @@
 #include <sstream>
 
 #include "device_fns.h"
+#include "wb_index.h"
 
 namespace euler_gpu {
 
@@ -803,6 +804,109 @@ int BuildGraphSynthetic(const euler_gpu_synth_params* sp, int device,
   b.g->n_node_types = 1;
   *out = b.g.release();
   return EULER_GPU_OK;
+}
+
+// ---- weight-bucket index (wb_index.h) ------------------------------------------------
+__global__ void WbCountKernel(GraphView g, uint32_t* nbk) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row > g.n_rows) return;
+  uint32_t n = 0;
+  if (row < g.n_rows) {
+    const uint4 q = *reinterpret_cast<const uint4*>(g.row_meta + row * 16);
+    n = WbBuckets(q.z);
+  }
+  nbk[row] = n;
+}
+
+__global__ void WbRecKernel(GraphView g, const uint32_t* wb_lo, WbRec* rec) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= g.n_rows) return;
+  const uint4 q = *reinterpret_cast<const uint4*>(g.row_meta + row * 16);
+  WbRec r;
+  r.wb_lo = wb_lo[row]; r.deg = q.z; r.lo = q.x; r.total = __uint_as_float(q.w);
+  rec[row] = r;
+}
+
+// one lane per block: its row is the last one with wb_lo[row] <= block (rows without edges
+// have no blocks and share their successor's offset)
+__global__ __launch_bounds__(256) void WbFillKernel(GraphView g, const uint32_t* wb_lo,
+                                                    int64_t n_wb, EdgeBlock* wb) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_wb; b += stride) {
+    int64_t lo = 0, hi = g.n_rows;            // wb_lo[lo] <= b < wb_lo[hi]
+    while (hi - lo > 1) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((int64_t)wb_lo[mid] <= b) lo = mid; else hi = mid;
+    }
+    const uint4 q = *reinterpret_cast<const uint4*>(g.row_meta + lo * 16);
+    EdgeBlock e;
+    WbBuildBlock(g.prefix_w, g.nbr, q.x, q.z, __uint_as_float(q.w), (uint32_t)(b - (int64_t)wb_lo[lo]), &e);
+    wb[b] = e;
+  }
+}
+
+int BuildWbIndex(GraphBuilder* b) {
+  GraphView& v = b->g->view;
+  // what the lean kernels assume of a graph (fanout_local.h), and 32-bit block numbers
+  if (v.T != 1 || v.total_in_meta == 0 || v.map_mode != 0 || v.monotone == 0 || v.uniform_w != 0 ||
+      v.n_edges >= ((int64_t)1 << 31) || v.n_rows <= 0 || v.n_edges <= 0 ||
+      v.n_edges / 4 + v.n_rows >= ((int64_t)1 << 32) - 16)
+    return EULER_GPU_OK;
+  const int block = 256;
+  uint32_t* nbk = nullptr;
+  uint32_t* wb_lo = nullptr;
+  EG_HIP(hipMalloc((void**)&nbk, ((size_t)v.n_rows + 1) * 4 + 16));
+  EG_HIP(hipMalloc((void**)&wb_lo, ((size_t)v.n_rows + 1) * 4 + 16));
+  hipLaunchKernelGGL(WbCountKernel, dim3((v.n_rows + 1 + block - 1) / block), dim3(block), 0, 0, v, nbk);
+  {
+    size_t tmp_bytes = 0;
+    EG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, nbk, wb_lo, v.n_rows + 1));
+    void* tmp = nullptr;
+    EG_HIP(hipMalloc(&tmp, tmp_bytes + 16));
+    EG_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, nbk, wb_lo, v.n_rows + 1));
+    EG_HIP(hipDeviceSynchronize());
+    EG_HIP(hipFree(tmp));
+  }
+  EG_HIP(hipFree(nbk));
+  uint32_t n_wb32 = 0;
+  EG_HIP(hipMemcpy(&n_wb32, wb_lo + v.n_rows, 4, hipMemcpyDeviceToHost));
+  const int64_t n_wb = (int64_t)n_wb32;
+  WbRec* rec = b->Alloc<WbRec>((size_t)v.n_rows);
+  EdgeBlock* wb = b->Alloc<EdgeBlock>((size_t)n_wb);
+  if (b->rc != EULER_GPU_OK) {
+    // no room for the index: the graph keeps the pivot-level search (an optimisation was
+    // declined, nothing failed)
+    (void)hipFree(wb_lo);
+    (void)hipGetLastError();
+    const int rc = b->rc;
+    b->rc = EULER_GPU_OK;
+    return rc == EULER_GPU_ENOMEM ? EULER_GPU_OK : rc;
+  }
+  hipLaunchKernelGGL(WbRecKernel, dim3((v.n_rows + block - 1) / block), dim3(block), 0, 0, v, wb_lo, rec);
+  if (n_wb > 0)
+    hipLaunchKernelGGL(WbFillKernel, dim3(GridFor(n_wb, block)), dim3(block), 0, 0, v, wb_lo, n_wb, wb);
+  EG_HIP(hipGetLastError());
+  EG_HIP(hipDeviceSynchronize());
+  EG_HIP(hipFree(wb_lo));
+  v.wrec = rec; v.wb = wb; v.n_wb = n_wb;
+  return EULER_GPU_OK;
+}
+
+int EnsureWbIndex(const euler_gpu_graph* cg) {
+  euler_gpu_graph* g = const_cast<euler_gpu_graph*>(cg);
+  if (g->wb_tried.load(std::memory_order_acquire) != 0) return EULER_GPU_OK;
+  std::lock_guard<std::mutex> lk(g_blocked_mu);
+  if (g->wb_tried.load(std::memory_order_acquire) != 0) return EULER_GPU_OK;
+  int prev = 0;
+  EG_HIP(hipGetDevice(&prev));
+  EG_HIP(hipSetDevice(g->device));
+  GraphBuilder b;
+  b.g.reset(g);                 // borrow the graph: allocations land in its list
+  const int rc = BuildWbIndex(&b);
+  b.g.release();
+  (void)hipSetDevice(prev);
+  g->wb_tried.store(1, std::memory_order_release);
+  return rc;
 }
 
 int EnsureBlockedIndex(const euler_gpu_graph* cg) {

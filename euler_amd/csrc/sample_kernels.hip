@@ -568,6 +568,8 @@ thread_local int g_fl_min_roots = 32768;  // key 33: smaller batches keep the wo
 thread_local int g_fl_plain = 2;      // key 34: plain graphs: 2 = the lean kernel, 1 = the general kernel
                                       // constant-folded, 0 = the general kernel
 thread_local int g_fl_wps = 5;        // key 35: register budget, waves per SIMD (8, 6 or 5; 5: nothing spilled)
+thread_local int g_fl_wb = 1;         // key 45: the lean kernel draws through the weight-bucket index (wb_index.h:
+                                      // one line per draw); 0 = the pivot-level search of rounds 2-3
 thread_local int g_fl_ablate = 0;     // key 36: measurement only (FanoutLocalArgs::ablate)
 thread_local int g_k1_typed_pivot = 1;   // key 37: calls with type draws search with the block pivots (0 = reference
                                          // loop)
@@ -1454,8 +1456,22 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
           f.row_index = t_fl_row_index;
           t_fl_took_lean = 1;
           void (*lk)(const FanoutLocalArgs) = nullptr;
+          bool use_wb = false;
+          if (v.uniform_w == 0 && g_fl_wb != 0) {
+            const int rcw = EnsureWbIndex(g);
+            if (rcw != EULER_GPU_OK) return rcw;
+            f.g = g->view;                      // the index may have been built just now
+            use_wb = f.g.wb != nullptr;
+          }
           if (v.uniform_w != 0) {
             lk = f.wide ? SampleFanoutLeanKernel<true, 8, true> : SampleFanoutLeanKernel<false, 8, true>;
+          } else if (use_wb) {
+            lk = f.wide ? (g_fl_wps == 8 ? SampleFanoutLeanKernel<true, 8, false, true>
+                                         : g_fl_wps == 5 ? SampleFanoutLeanKernel<true, 5, false, true>
+                                                         : SampleFanoutLeanKernel<true, 6, false, true>)
+                        : (g_fl_wps == 8 ? SampleFanoutLeanKernel<false, 8, false, true>
+                                         : g_fl_wps == 5 ? SampleFanoutLeanKernel<false, 5, false, true>
+                                                         : SampleFanoutLeanKernel<false, 6, false, true>);
           } else {
             lk = f.wide ? (g_fl_wps == 8 ? SampleFanoutLeanKernel<true, 8>
                                          : g_fl_wps == 5 ? SampleFanoutLeanKernel<true, 5>
@@ -1681,6 +1697,7 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 43 && value >= 0) { g_walk_tail = value; return EULER_GPU_OK; }
   if (key == 44 && (value == 0 || value == 1)) { g_walk_lean = value; return EULER_GPU_OK; }
   if (key == 35 && (value == 5 || value == 6 || value == 8)) { g_fl_wps = value; return EULER_GPU_OK; }
+  if (key == 45 && (value == 0 || value == 1)) { g_fl_wb = value; return EULER_GPU_OK; }
   return Fail(EULER_GPU_EINVAL, "set_tuning: unknown key");
 }
 

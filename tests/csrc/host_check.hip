@@ -13,6 +13,7 @@
 
 #include "layer_fns.h"
 #include "local_layer_host.h"
+#include "wb_index.h"
 
 using namespace euler_gpu;
 
@@ -22,6 +23,8 @@ struct HostGraph {
   GraphView v{};
   std::vector<uint8_t> meta;
   std::vector<uint64_t> slots;
+  std::vector<WbRec> wrec;
+  std::vector<EdgeBlock> wb;
 };
 
 }  // namespace
@@ -77,6 +80,55 @@ void* hc_graph_create(int64_t n, int32_t T, const uint64_t* row_id,
 }
 
 void hc_graph_destroy(void* h) { delete static_cast<HostGraph*>(h); }
+
+// The weight-bucket index of a single-type graph, built by the per-block function the
+// device builder runs one block per lane (wb_index.h: WbBuildBlock); returns the block count.
+int64_t hc_wb_build(void* h) {
+  HostGraph* g = static_cast<HostGraph*>(h);
+  const GraphView& v = g->v;
+  if (v.T != 1) return -1;
+  g->wrec.assign((size_t)v.n_rows, WbRec{0, 0, 0, 0.f});
+  uint64_t blocks = 0;
+  for (int64_t r = 0; r < v.n_rows; ++r) {
+    const RowMeta m = LoadRowMeta(v, r);
+    const uint32_t deg = (uint32_t)m.type_end[0];
+    WbRec rec{(uint32_t)blocks, deg, (uint32_t)m.row_ptr, deg ? v.prefix_w[m.row_ptr + deg - 1] : 0.f};
+    g->wrec[(size_t)r] = rec;
+    blocks += WbBuckets(deg);
+  }
+  g->wb.resize((size_t)blocks);
+  for (int64_t r = 0; r < v.n_rows; ++r) {
+    const WbRec& rec = g->wrec[(size_t)r];
+    const uint32_t nbk = WbBuckets(rec.deg);
+    for (uint32_t j = 0; j < nbk; ++j)
+      WbBuildBlock(v.prefix_w, v.nbr, rec.lo, rec.deg, rec.total, j, &g->wb[rec.wb_lo + j]);
+  }
+  return (int64_t)blocks;
+}
+
+// One draw u on row `rows[i]`: the hot path (WbSampleHot) and, when it declines, the
+// reference's search - exactly what the kernels do per lane.  cold_out[i] = 1 for a draw
+// that took the cold way; m_out = row-relative edge, -1 for an empty row.
+void hc_wb_sample(void* h, const int64_t* rows, const double* us, int64_t n, int64_t* m_out,
+                  float* w_out, uint64_t* id_out, int32_t* cold_out) {
+  HostGraph* g = static_cast<HostGraph*>(h);
+  const GraphView& v = g->v;
+  for (int64_t i = 0; i < n; ++i) {
+    const WbRec& rec = g->wrec[(size_t)rows[i]];
+    m_out[i] = -1; w_out[i] = 0.f; id_out[i] = 0; cold_out[i] = 0;
+    if (rec.deg == 0) continue;
+    uint64_t id = 0; float w = 0.f; uint32_t m = 0;
+    if (WbSampleHot(g->wb.data(), rec, us[i], &id, &w, &m)) {
+      m_out[i] = (int64_t)m - (int64_t)rec.lo; w_out[i] = w; id_out[i] = id;
+      continue;
+    }
+    cold_out[i] = 1;
+    const float* nw = v.prefix_w + rec.lo;
+    const uint32_t mid = (uint32_t)RandomSelect(nw, 0, (uint64_t)(rec.deg - 1), us[i]);
+    m_out[i] = mid; id_out[i] = v.nbr[rec.lo + mid];
+    w_out[i] = nw[mid] - (mid == 0u ? 0.f : nw[mid - 1]);   // host pass only (-ffp-contract=off)
+  }
+}
 
 void hc_edge_sum_weight(void* h, const uint64_t* ids, int64_t n, const int32_t* et,
                         int32_t k, float* out) {

@@ -256,7 +256,8 @@ def test_config5_typed_sampling_and_aggregation(EA, O, torch_cuda):
 
 @pytest.mark.gpu
 def test_config5_typed_sampling_at_full_size(EA, O, torch_cuda):
-    """configs[4] at bench.py's size: 20M nodes, 8 edge types, 131 072 roots x 10 samples
+    """configs[4] at the size SURVEY 8(d) states and bench.py runs ("same N" as the metric graph):
+    100M nodes / 1B edges, 8 edge types, D = 128 features (51 GB), 131 072 roots x 10 samples
     for one listed type, 3 of 8 and all 8.  Two independent device paths agree on every
     sample (type draws on the block pivots == the reference loop, tuning key 37), with and
     without the duplicate-root machinery forced (key 5), the result is a function of
@@ -266,8 +267,8 @@ def test_config5_typed_sampling_at_full_size(EA, O, torch_cuda):
     torch = torch_cuda
     from euler_amd import _lib
     L = _lib.lib()
-    N, T, B, CNT, D = 20_000_000, 8, 131072, 10, 128
-    G = EA.Graph.synthetic(EA.synth_params(20240521, N, 20 * N, n_types=T, weighted=True))
+    N, T, B, CNT, D = 100_000_000, 8, 131072, 10, 128
+    G = EA.Graph.synthetic(EA.synth_params(20240521, N, 10 * N, n_types=T, weighted=True))
     G.set_seed(20240521)
     gen = torch.Generator(device="cuda"); gen.manual_seed(9)
     roots = torch.randint(1, N + 1, (B,), generator=gen, device="cuda", dtype=torch.int64)

@@ -463,7 +463,7 @@ def test_synthetic_hashed_ids_two_types(EA, O, torch_cuda):
     q = np.concatenate([rng.choice(csr.row_id, 40000), [0, 5, 2 ** 63 + 9]]).astype(np.uint64).view(np.int64)
     qt = torch.as_tensor(q).cuda()
     try:
-        for et, counts in (([[0], [0]], [25, 10]), ([[1], [0]], [5, 4]), ([[0, 1], [1]], [6, 3])):
+        for et, counts in (([[0], [0]], [25, 10]), ([[1], [0]], [5, 4]), ([[0, 1], [1, 0]], [6, 3])):
             G.set_seed(3)
             ns, ws, ts = OG.sample_fanout(3, 10, q, et, counts, -1)
             res = []

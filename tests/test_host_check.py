@@ -33,7 +33,7 @@ def HC():
     src = os.path.join(HERE, "csrc", "host_check.hip")
     deps = [src] + [os.path.join(ROOT, "euler_amd", "csrc", f)
                     for f in ("layer_fns.h", "device_fns.h", "common.h", "philox.h",
-                              "local_layer_host.h")]
+                              "local_layer_host.h", "wb_index.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so)
                                      for d in deps):
         subprocess.check_call(
@@ -45,6 +45,9 @@ def HC():
     L.hc_graph_create.argtypes = [C.c_int64, C.c_int32, u64p, i64p, i32p, u64p, f32p,
                                   f32p, C.c_int32]
     L.hc_graph_destroy.argtypes = [C.c_void_p]
+    L.hc_wb_build.restype = C.c_int64
+    L.hc_wb_build.argtypes = [C.c_void_p]
+    L.hc_wb_sample.argtypes = [C.c_void_p, i64p, C.POINTER(C.c_double), C.c_int64, i64p, f32p, u64p, i32p]
     L.hc_edge_sum_weight.argtypes = [C.c_void_p, u64p, C.c_int64, i32p, C.c_int32, f32p]
     L.hc_sample_root.argtypes = [C.c_uint64, C.c_uint32, u64p, f32p, C.c_int64,
                                  C.c_int32, C.c_int32, C.c_int64, u64p]
@@ -300,3 +303,75 @@ def test_generic_sampler_logic_host_vs_goldens_and_oracle(HC, O, fixture_csr, ra
             hid, hw, ht = run(H, 99, 5, q, et, count)
             assert np.array_equal(hid, oid) and np.array_equal(ht, ot), et
             assert np.array_equal(hw.view(np.uint32), ow.view(np.uint32)), et
+
+
+def _wb_case(L, O, degs, weight_fn, rng, draws_per_row=64, extra_u=()):
+    """rows of the given degrees with weights from weight_fn(deg) -> f32 array; returns
+    (n draws, n cold draws) after checking every draw against the oracle's RandomSelect."""
+    segs, ws = [0], []
+    for d in degs:
+        w = np.asarray(weight_fn(d), np.float32)
+        assert len(w) == d
+        ws.append(w)
+        segs.append(segs[-1] + d)
+    n = len(degs)
+    w_all = np.concatenate(ws) if ws else np.zeros(0, np.float32)
+    nbr = rng.integers(1, 1 << 40, len(w_all)).astype(np.uint64)
+    csr = O.csr_from_raw(np.arange(1, n + 1, dtype=np.uint64), np.asarray(segs, np.int64), nbr, w_all, 1)
+    H = HostBackend(L, csr)
+    blocks = L.hc_wb_build(H.h)
+    assert blocks == sum((1 if 0 < d <= 10 else (d + 3) // 4) for d in degs if d > 0)
+    rows = np.repeat(np.arange(n, dtype=np.int64), draws_per_row + len(extra_u))
+    us = np.concatenate([np.concatenate([rng.random(draws_per_row), np.asarray(extra_u, np.float64)])
+                         for _ in range(n)]) if n else np.zeros(0)
+    m = np.zeros(len(rows), np.int64); w = np.zeros(len(rows), np.float32)
+    ids = np.zeros(len(rows), np.uint64); cold = np.zeros(len(rows), np.int32)
+    L.hc_wb_sample(H.h, _p(rows, i64p), us.ctypes.data_as(C.POINTER(C.c_double)), len(rows),
+                   _p(m, i64p), _p(w, f32p), _p(ids, u64p), _p(cold, i32p))
+    for i in range(len(rows)):
+        r = int(rows[i]); d = degs[r]
+        if d == 0:
+            assert m[i] == -1
+            continue
+        b = int(csr.row_ptr[r])
+        sw = csr.prefix_w[b:b + d]
+        want = O.random_select(sw, 0, d - 1, float(us[i]))
+        assert m[i] == want, (r, d, us[i], int(m[i]), want, int(cold[i]))
+        assert ids[i] == csr.nbr[b + want]
+        assert w[i] == np.float32(sw[want]) - (np.float32(sw[want - 1]) if want else np.float32(0))
+    return len(rows), int(cold.sum())
+
+
+def test_weight_bucket_index_vs_random_select(HC, O):
+    """wb_index.h (the direct-address search of the one-kernel fanout): for every
+    draw the index, id and weight RandomSelect gives (common/compact_weighted_collection.h:
+    30-52, oracle/euler_oracle.c: eo_random_select) - on smooth rows through ONE block, on
+    rows whose blocks cannot bracket the draw (heavy tails, zero weights, huge dynamic range,
+    denormal totals, draws that round up to the total) through the cold path; and smooth
+    rows must hardly ever go cold (that is the whole point of the layout)."""
+    rng = np.random.default_rng(11)
+    degs = [0, 1, 2, 3, 9, 10, 11, 12, 13, 14, 15, 16, 17, 20, 21, 39, 40, 41, 64, 65, 100, 257, 1000, 4099, 20011]
+    edge_u = (0.0, 1.0 - 2.0 ** -53, 0.5, 2.0 ** -40)
+    # i.i.d. uniform [0.5, 8): the metric graph's weights
+    n, c = _wb_case(HC, O, degs, lambda d: 0.5 + 7.5 * rng.random(d), rng, extra_u=edge_u)
+    assert c <= n * 0.002, (n, c)
+    # all equal (non-unit) weights; unit weights
+    n, c = _wb_case(HC, O, degs, lambda d: np.full(d, 0.37), rng, extra_u=edge_u)
+    assert c <= n * 0.002, (n, c)
+    _wb_case(HC, O, degs, lambda d: np.ones(d), rng, extra_u=edge_u)
+    # heavy tail (Pareto), zeros mixed in, one giant among dust, increasing and decreasing ramps
+    _wb_case(HC, O, degs, lambda d: (rng.pareto(0.7, d) + 1e-3), rng, extra_u=edge_u)
+    _wb_case(HC, O, degs, lambda d: np.where(rng.random(d) < 0.4, 0.0, rng.random(d)), rng, extra_u=edge_u)
+
+    def giant(d):
+        w = np.full(d, 1e-3)
+        if d:
+            w[int(rng.integers(0, d))] = 1e6
+        return w
+    _wb_case(HC, O, degs, giant, rng, extra_u=edge_u)
+    _wb_case(HC, O, degs, lambda d: np.arange(1, d + 1, dtype=np.float64), rng, extra_u=edge_u)
+    _wb_case(HC, O, degs, lambda d: np.arange(d, 0, -1, dtype=np.float64) ** 2, rng, extra_u=edge_u)
+    # all-zero rows (every draw is cold: total = 0), denormal totals, totals near f32 max
+    _wb_case(HC, O, [1, 5, 30, 200], lambda d: np.zeros(d), rng, draws_per_row=8, extra_u=edge_u)
+    _wb_case(HC, O, [1, 5, 30, 200], lambda d: np.full(d, 1e-42), rng, draws_per_row=8, extra_u=edge_u)
+    _wb_case(HC, O, [1, 5, 30, 200], lambda d: np.full(d, 1e36), rng, draws_per_row=8, extra_u=edge_u)
