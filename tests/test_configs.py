@@ -123,8 +123,8 @@ def test_config2_products_shaped_uniform_fanout(EA, O, torch_cuda):
 def test_config3_metric_step_at_full_size(EA, O, torch_cuda):
     """configs[2], the headline workload, at its full size: two independent device
     paths agree bit for bit on every one of the step's 36 044 800 samples (the one-kernel
-    fanout of fanout_local.h against hop-by-hop sampling + global duplicate path +
-    expansion), the (distinct rows, index) form reproduces the dense one, the result is
+    fanout of fanout_local.h - through the weight-bucket index and through the pivot levels -
+    against hop-by-hop sampling + global duplicate path + expansion), the (distinct rows, index) form reproduces the dense one, the result is
     a pure function of (seed, call id, roots), and 96 roots - with every hop-1 child's
     row exported from HBM - equal the CPU oracle.  Same for DeepWalk of 1M walkers x 40
     steps: groups of merged walkers == one lane per walker, 16 walkers == the oracle."""
@@ -143,13 +143,16 @@ def test_config3_metric_step_at_full_size(EA, O, torch_cuda):
         a2 = G.sample_fanout(roots, [[0], [0]], [25, 10], N + 1, call_id=6)
         L.euler_gpu_set_tuning(27, 0)
         h = G.sample_fanout(roots, [[0], [0]], [25, 10], N + 1, call_id=6)
+        L.euler_gpu_set_tuning(27, 1); L.euler_gpu_set_tuning(45, 0)     # pivot levels instead of
+        lv = G.sample_fanout(roots, [[0], [0]], [25, 10], N + 1, call_id=6)   # the weight-bucket index
     finally:
-        L.euler_gpu_set_tuning(27, 1)
+        L.euler_gpu_set_tuning(27, 1); L.euler_gpu_set_tuning(45, 1)
     assert a[0][2].numel() == B * 250
     for hop in range(2):
         assert torch.equal(a[0][hop + 1], h[0][hop + 1]) and torch.equal(a[0][hop + 1], a2[0][hop + 1])
         assert torch.equal(a[1][hop], h[1][hop]) and torch.equal(a[2][hop], h[2][hop])
-    del h, a2
+        assert torch.equal(a[0][hop + 1], lv[0][hop + 1]) and torch.equal(a[1][hop], lv[1][hop])
+    del h, a2, lv
     id1, w1, t1, ridx, rid, rw, rt = G.sample_fanout_unique(roots, [[0], [0]], [25, 10], N + 1, call_id=6)
     assert torch.equal(id1.reshape(-1), a[0][1])
     assert torch.equal(rid[ridx].reshape(-1), a[0][2]) and torch.equal(rw[ridx].reshape(-1), a[1][1])

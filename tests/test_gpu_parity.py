@@ -1567,15 +1567,18 @@ def test_full_neighbor_fill_kernels_agree(EA, O, torch_cuda, big_pair):
         _lib.lib().euler_gpu_set_tuning(24, 1)
 
 
-_FL_DEFAULTS = {27: 1, 28: 4, 29: 0, 30: 64, 31: 1, 32: -1, 33: 32768, 34: 2, 35: 5, 36: 0}
+_FL_DEFAULTS = {27: 1, 28: 4, 29: 0, 30: 64, 31: 1, 32: -1, 33: 32768, 34: 2, 35: 5, 45: 1}
 
 
-@pytest.mark.parametrize("geom", [(4, 0, 256, 1, 8, 2, 0), (1, 1, 64, 0, 5, 0, 0), (2, 3, 128, 1, 8, 0, 0),
-                                  (8, 5, 256, 0, 8, 1, 3), (16, 64, 64, 1, 5, 1, 0), (3, 2, 256, 1, 8, 1, 1),
-                                  (1, 1, 64, 0, 8, 2, 0), (8, 5, 128, 1, 8, 2, 3), (16, 0, 256, 0, 8, 2, 1),
-                                  (5, 2, 256, 1, 8, 2, 0)],
+@pytest.mark.parametrize("geom", [(4, 0, 256, 1, 8, 2, 0, 1), (1, 1, 64, 0, 5, 0, 0, 1), (2, 3, 128, 1, 8, 0, 0, 1),
+                                  (8, 5, 256, 0, 8, 1, 3, 1), (16, 64, 64, 1, 5, 1, 0, 1), (3, 2, 256, 1, 8, 1, 1, 1),
+                                  (1, 1, 64, 0, 8, 2, 0, 1), (8, 5, 128, 1, 8, 2, 3, 1), (16, 0, 256, 0, 8, 2, 1, 1),
+                                  (5, 2, 256, 1, 8, 2, 0, 1), (4, 0, 64, 1, 5, 2, 0, 1), (2, 4, 128, 0, 6, 2, 1, 1),
+                                  (4, 0, 64, 1, 5, 2, 0, 0), (8, 5, 128, 1, 8, 2, 3, 0), (3, 2, 256, 0, 6, 2, 1, 0)],
                          ids=["default", "gr1cap1", "gr2cap3", "gr8cap5grid3", "gr16cap64", "gr3cap2grid1",
-                              "lean_gr1cap1", "lean_gr8cap5grid3", "lean_gr16grid1", "lean_gr5cap2"])
+                              "lean_gr1cap1", "lean_gr8cap5grid3", "lean_gr16grid1", "lean_gr5cap2",
+                              "lean_wb_shipped", "lean_wb_wps6_gr2", "lean_levels_shipped", "lean_levels_gr8",
+                              "lean_levels_wps6"])
 def test_fanout_local_dedup_kernel(EA, O, torch_cuda, big_pair, geom):
     """fanout_local.h: the 2-hop fanout of single listed types as ONE kernel - a wave owns
     `gr` roots, finds the distinct children among its own hop-1 samples and samples each
@@ -1588,8 +1591,8 @@ def test_fanout_local_dedup_kernel(EA, O, torch_cuda, big_pair, geom):
     torch = torch_cuda
     from euler_amd import _lib
     L = _lib.lib()
-    gr, cap, block, wide, wps, plain, grid = geom
-    keys = {27: 2, 28: gr, 29: cap, 30: block, 31: wide, 32: grid, 33: 0, 34: plain, 35: wps}
+    gr, cap, block, wide, wps, plain, grid, wb = geom
+    keys = {27: 2, 28: gr, 29: cap, 30: block, 31: wide, 32: grid, 33: 0, 34: plain, 35: wps, 45: wb}
 
     def check(G, OG, q, et, counts, default, seed, call):
         qt = torch.as_tensor(q).cuda()
