@@ -103,9 +103,15 @@ struct GraphView {
   // weight-bucket index (wb_index.h; built on first use for plain graphs: one edge-type
   // group, identity id map, monotone non-uniform weights, < 2^31 edges): a 16-byte record per
   // row and one 128-byte block per bucket of a row's running-sum range
-  const struct WbRec* wrec;
+  const struct WbRec* wrec;     // plain graphs only (the lean kernels' 16-byte record)
   const struct EdgeBlock* wb;
   int64_t n_wb;
+  // every graph the index serves (monotone non-uniform weights, < 2^32 edges): per row
+  // {uint32 wb_lo; float lim[T]} - the row's first block and the running sum at the end of
+  // every edge-type group (lim[T-1] = the row's total; limit_begin of group t = lim[t-1]) -
+  // so a segment's limits come with the record, not from two more dependent loads
+  const uint8_t* wbg;
+  int32_t wbg_stride;           // 4 + 4 T
 };
 
 // Edge block of the sampling index: 10 consecutive edges of the flat arrays
@@ -223,6 +229,10 @@ int EnsureBlockedIndex(const euler_gpu_graph* g);   // EdgeBlocks + block pivots
 // weight-bucket index, on first use; leaves view.wb == nullptr (and returns OK) for graphs it
 // does not serve
 int EnsureWbIndex(const euler_gpu_graph* g);
+// sample_kernels.hip: the view a sampling launcher hands to its kernels - the search indexes
+// built on first use, the weight-bucket fields nulled when tuning key 45 = 0 (the kernels
+// then walk the pivot levels)
+int SamplingView(const euler_gpu_graph* g, GraphView* out);
 // sample_kernels.hip: TF-layout SampleNeighbor over the first *n_dev roots of a list
 // sized for `cap` (dataflow_kernels.hip)
 int LaunchSampleNeighborCounted(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed,

@@ -812,19 +812,32 @@ __global__ void WbCountKernel(GraphView g, uint32_t* nbk) {
   if (row > g.n_rows) return;
   uint32_t n = 0;
   if (row < g.n_rows) {
-    const uint4 q = *reinterpret_cast<const uint4*>(g.row_meta + row * 16);
-    n = WbBuckets(q.z);
+    const RowMeta m = LoadRowMeta(g, row);
+    n = WbBuckets((uint32_t)m.type_end[g.T - 1]);
   }
   nbk[row] = n;
 }
 
-__global__ void WbRecKernel(GraphView g, const uint32_t* wb_lo, WbRec* rec) {
+// the per-row records: wbg {wb_lo, lim[T]} for every graph, wrec for plain ones
+__global__ void WbRecKernel(GraphView g, const uint32_t* wb_lo, uint8_t* wbg, int32_t wbg_stride,
+                            WbRec* rec) {
   const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= g.n_rows) return;
-  const uint4 q = *reinterpret_cast<const uint4*>(g.row_meta + row * 16);
-  WbRec r;
-  r.wb_lo = wb_lo[row]; r.deg = q.z; r.lo = q.x; r.total = __uint_as_float(q.w);
-  rec[row] = r;
+  const RowMeta m = LoadRowMeta(g, row);
+  uint8_t* out = wbg + row * (int64_t)wbg_stride;
+  *reinterpret_cast<uint32_t*>(out) = wb_lo[row];
+  float* lim = reinterpret_cast<float*>(out + 4);
+  for (int32_t t = 0; t < g.T; ++t) {
+    const int32_t e = m.type_end[t];
+    lim[t] = e > 0 ? g.prefix_w[m.row_ptr + e - 1] : 0.f;
+  }
+  if (rec != nullptr) {
+    WbRec r;
+    const int32_t deg = m.type_end[0];
+    r.wb_lo = wb_lo[row]; r.deg = (uint32_t)deg; r.lo = (uint32_t)m.row_ptr;
+    r.total = deg > 0 ? g.prefix_w[m.row_ptr + deg - 1] : 0.f;
+    rec[row] = r;
+  }
 }
 
 // one lane per block: its row is the last one with wb_lo[row] <= block (rows without edges
@@ -838,25 +851,34 @@ __global__ __launch_bounds__(256) void WbFillKernel(GraphView g, const uint32_t*
       const int64_t mid = (lo + hi) >> 1;
       if ((int64_t)wb_lo[mid] <= b) lo = mid; else hi = mid;
     }
-    const uint4 q = *reinterpret_cast<const uint4*>(g.row_meta + lo * 16);
+    const RowMeta m = LoadRowMeta(g, lo);
+    const uint32_t deg = (uint32_t)m.type_end[g.T - 1];
     EdgeBlock e;
-    WbBuildBlock(g.prefix_w, g.nbr, q.x, q.z, __uint_as_float(q.w), (uint32_t)(b - (int64_t)wb_lo[lo]), &e);
+    WbBuildBlock(g.prefix_w, g.nbr, (uint32_t)m.row_ptr, deg, g.prefix_w[m.row_ptr + deg - 1],
+                 (uint32_t)(b - (int64_t)wb_lo[lo]), &e);
     wb[b] = e;
   }
 }
 
 int BuildWbIndex(GraphBuilder* b) {
   GraphView& v = b->g->view;
-  // what the lean kernels assume of a graph (fanout_local.h), and 32-bit block numbers
-  if (v.T != 1 || v.total_in_meta == 0 || v.map_mode != 0 || v.monotone == 0 || v.uniform_w != 0 ||
-      v.n_edges >= ((int64_t)1 << 31) || v.n_rows <= 0 || v.n_edges <= 0 ||
+  // rows must be non-decreasing (the keys decide by counting) and worth a search at all;
+  // 32-bit edge and block numbers
+  if (v.monotone == 0 || v.uniform_w != 0 || v.n_rows <= 0 || v.n_edges <= 0 ||
+      v.n_edges >= ((int64_t)1 << 32) - 16 ||
       v.n_edges / 4 + v.n_rows >= ((int64_t)1 << 32) - 16)
     return EULER_GPU_OK;
+  const bool plain = v.T == 1 && v.total_in_meta != 0 && v.map_mode == 0 &&
+                     v.n_edges < ((int64_t)1 << 31);
   const int block = 256;
   uint32_t* nbk = nullptr;
   uint32_t* wb_lo = nullptr;
-  EG_HIP(hipMalloc((void**)&nbk, ((size_t)v.n_rows + 1) * 4 + 16));
-  EG_HIP(hipMalloc((void**)&wb_lo, ((size_t)v.n_rows + 1) * 4 + 16));
+  if (hipMalloc((void**)&nbk, ((size_t)v.n_rows + 1) * 4 + 16) != hipSuccess ||
+      hipMalloc((void**)&wb_lo, ((size_t)v.n_rows + 1) * 4 + 16) != hipSuccess) {
+    (void)hipGetLastError();
+    if (nbk) (void)hipFree(nbk);
+    return EULER_GPU_OK;          // no room: the pivot-level search stays
+  }
   hipLaunchKernelGGL(WbCountKernel, dim3((v.n_rows + 1 + block - 1) / block), dim3(block), 0, 0, v, nbk);
   {
     size_t tmp_bytes = 0;
@@ -871,24 +893,28 @@ int BuildWbIndex(GraphBuilder* b) {
   uint32_t n_wb32 = 0;
   EG_HIP(hipMemcpy(&n_wb32, wb_lo + v.n_rows, 4, hipMemcpyDeviceToHost));
   const int64_t n_wb = (int64_t)n_wb32;
-  WbRec* rec = b->Alloc<WbRec>((size_t)v.n_rows);
-  EdgeBlock* wb = b->Alloc<EdgeBlock>((size_t)n_wb);
-  if (b->rc != EULER_GPU_OK) {
-    // no room for the index: the graph keeps the pivot-level search (an optimisation was
-    // declined, nothing failed)
-    (void)hipFree(wb_lo);
-    (void)hipGetLastError();
-    const int rc = b->rc;
-    b->rc = EULER_GPU_OK;
-    return rc == EULER_GPU_ENOMEM ? EULER_GPU_OK : rc;
+  const int32_t stride = 4 + 4 * v.T;
+  // (checked before allocating: an index that does not fit is an optimisation declined)
+  {
+    size_t free_b = 0, total_b = 0;
+    const size_t need = (size_t)n_wb * sizeof(EdgeBlock) + (size_t)v.n_rows * (stride + (plain ? 16 : 0));
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || need + ((size_t)1 << 30) > free_b) {
+      (void)hipFree(wb_lo);
+      return EULER_GPU_OK;
+    }
   }
-  hipLaunchKernelGGL(WbRecKernel, dim3((v.n_rows + block - 1) / block), dim3(block), 0, 0, v, wb_lo, rec);
+  uint8_t* wbg = b->Alloc<uint8_t>((size_t)v.n_rows * stride + 16);
+  WbRec* rec = plain ? b->Alloc<WbRec>((size_t)v.n_rows) : nullptr;
+  EdgeBlock* wb = b->Alloc<EdgeBlock>((size_t)n_wb);
+  if (b->rc != EULER_GPU_OK) { (void)hipFree(wb_lo); return b->rc; }
+  hipLaunchKernelGGL(WbRecKernel, dim3((v.n_rows + block - 1) / block), dim3(block), 0, 0, v, wb_lo,
+                     wbg, stride, rec);
   if (n_wb > 0)
     hipLaunchKernelGGL(WbFillKernel, dim3(GridFor(n_wb, block)), dim3(block), 0, 0, v, wb_lo, n_wb, wb);
   EG_HIP(hipGetLastError());
   EG_HIP(hipDeviceSynchronize());
   EG_HIP(hipFree(wb_lo));
-  v.wrec = rec; v.wb = wb; v.n_wb = n_wb;
+  v.wrec = rec; v.wb = wb; v.n_wb = n_wb; v.wbg = wbg; v.wbg_stride = stride;
   return EULER_GPU_OK;
 }
 

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include "device_fns.h"
+#include "wb_index.h"
 
 namespace euler_gpu {
 
@@ -58,7 +59,24 @@ struct Segment {
   int64_t lo, hi;       // searched edges [lo, hi] (global indices)
   float limit_begin, limit_end;
   int32_t b, e;         // the same segment, row-relative
+  // weight-bucket index (g.wbg != nullptr): the row's first block, its edges, its total
+  uint32_t wb_lo, row_deg;
+  float row_total;
 };
+
+// The row's weight-bucket record: first block, total, and the limits of the edge-type
+// group [b, e] - all out of ONE small record read beside the row record (the pivot path
+// reads the limits from two block lines, a dependent trip).
+__device__ __forceinline__ void LoadWbSegment(const GraphView& g, int64_t row, int32_t t,
+                                              int32_t row_deg, Segment* sg) {
+  const uint8_t* rec = g.wbg + row * (int64_t)g.wbg_stride;
+  const float* lim = reinterpret_cast<const float*>(rec + 4);
+  sg->wb_lo = *reinterpret_cast<const uint32_t*>(rec);
+  sg->row_deg = (uint32_t)row_deg;
+  sg->row_total = lim[g.T - 1];
+  sg->limit_end = lim[t];
+  sg->limit_begin = t == 0 ? 0.f : lim[t - 1];
+}
 
 // One draw u on a segment: the neighbour RandomSelect picks and its weight.
 __device__ __forceinline__ void PivotSample(const GraphView& g, const Segment& sg,
@@ -186,6 +204,24 @@ __device__ __forceinline__ void BlockPivotSample(const GraphView& g, const Segme
     *w = 1.0f;
     return;
   }
+  if (g.wbg != nullptr) {
+    // weight-bucket index (wb_index.h): the bucket of r in the ROW's range names one
+    // 128-byte line; its keys decide.  The first m of the row with nw[m] > r lies in
+    // [lo, hi] because limit_begin <= r < limit_end and the sums do not decrease.
+    const float f = WbFloorToFloat(rr);
+    const uint32_t nbk = WbBuckets(sg.row_deg);
+    const uint32_t j = nbk <= 1u ? 0u : WbBucketOf(f, nbk, WbScale(nbk, sg.row_total));
+    const EdgeBlock* wbk = g.wb + sg.wb_lo + j;
+    uint32_t m = 0;
+    const int32_t i = WbDraw(wbk, f, w, &m);
+    if (i >= 0) { *id = wbk->nbr[i]; return; }
+    // the block does not bracket r (a row whose weights are far from even): the reference
+    const float* nw = g.prefix_w + sg.row_ptr;
+    const int32_t mm = (int32_t)RandomSelect(nw, (uint64_t)sg.b, (uint64_t)sg.e, u);
+    *id = g.nbr[sg.row_ptr + mm];
+    *w = __fsub_rn(nw[mm], mm == 0 ? 0.f : nw[mm - 1]);
+    return;
+  }
   // ranges of the levels, bottom up, only as far as needed: K = first level
   // with <= 4 candidates (most rows stop at level 1 or 2, and a wave whose
   // lanes have all stopped skips the remaining divisions)
@@ -276,6 +312,13 @@ __device__ __forceinline__ bool LoadSegment(const GraphView& g, int64_t row,
     sg->row_ptr = (int64_t)(((uint64_t)q.y << 32) | q.x);
     sg->b = 0;
     sg->e = (int32_t)q.z - 1;
+    if (BLOCKED && g.wbg != nullptr) {
+      // (loaded whether the row has edges or not: the load is issued beside the record's)
+      LoadWbSegment(g, row, 0, (int32_t)q.z, sg);
+      sg->lo = sg->row_ptr;
+      sg->hi = sg->row_ptr + sg->e;
+      return sg->e >= 0;
+    }
     if (g.total_in_meta) {
       // the record's type sum IS the row's last running sum (verified at build):
       // one dependent load less per root
@@ -291,6 +334,12 @@ __device__ __forceinline__ bool LoadSegment(const GraphView& g, int64_t row,
     const int32_t* te = reinterpret_cast<const int32_t*>(rec + 8);
     sg->b = t == 0 ? 0 : te[t - 1];
     sg->e = te[t] - 1;
+    if (BLOCKED && g.wbg != nullptr) {
+      LoadWbSegment(g, row, t, te[g.T - 1], sg);
+      sg->lo = sg->row_ptr + sg->b;
+      sg->hi = sg->row_ptr + sg->e;
+      return sg->e >= sg->b;
+    }
   }
   if (sg->e < sg->b) return false;
   sg->lo = sg->row_ptr + sg->b;

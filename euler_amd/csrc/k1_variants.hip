@@ -125,8 +125,12 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborTypedPivotKe
           Segment sg;
           sg.row_ptr = m.row_ptr; sg.b = b_idx; sg.e = e_idx;
           sg.lo = m.row_ptr + b_idx; sg.hi = m.row_ptr + e_idx;
-          sg.limit_end = BlockedPw(a.g, sg.hi);
-          sg.limit_begin = b_idx == 0 ? 0.f : BlockedPw(a.g, sg.lo - 1);
+          if (a.g.wbg != nullptr) {
+            LoadWbSegment(a.g, row, t, m.type_end[T - 1], &sg);
+          } else {
+            sg.limit_end = BlockedPw(a.g, sg.hi);
+            sg.limit_begin = b_idx == 0 ? 0.f : BlockedPw(a.g, sg.lo - 1);
+          }
           BlockPivotSample(a.g, sg, u_nb, &id, &w);
         }
       }

@@ -555,9 +555,12 @@ thread_local int g_n2v_big = 8192;   // key 25: child lists of this many entries
 // (fanout_local.h).  key 27: 0 = off (hop by hop, global duplicate path), 1 = on for weighted
 // graphs, 2 = on for every graph.
 thread_local int g_fanout_local = 1;
-thread_local int g_fl_roots = 4;      // key 28: roots per wave (1 .. 16)
-thread_local int g_fl_cap = 0;        // key 29: hop-2 slots per pass, 0 = 8 x roots per wave
-thread_local int g_fl_block = 64;     // key 30: threads per workgroup (64, 128, 256)
+thread_local int g_fl_roots = 0;      // key 28: roots per wave (1 .. 16), 0 = the launcher chooses (4, or 8 for a
+                                      // caller that alternates streams on a graph with the weight-bucket index)
+thread_local int g_fl_cap = 0;        // key 29: hop-2 slots per pass, 0 = the launcher chooses (64 with the
+                                      // weight-bucket index, else 8 x roots per wave)
+thread_local int g_fl_block = 0;      // key 30: threads per workgroup (64, 128, 256), 0 = the launcher chooses
+                                      // (128 with the weight-bucket index, else 64)
 thread_local int g_fl_wide = 1;       // key 31: weights / types as 16-byte stores
 thread_local int g_fl_grid_cap = -1;  // key 32: waves of the launch: 0 = one tile per wave (no loop), -1 = that for a
                                       // caller on one stream and 16 384 looping waves for one that alternates
@@ -576,6 +579,21 @@ thread_local int g_k1_typed_pivot = 1;   // key 37: calls with type draws search
 thread_local uint32_t* t_fl_row_index = nullptr;   // set by euler_gpu_sample_fanout_unique around its call
 thread_local int t_fl_took_lean = 0;                // ... and whether the lean kernel served it
 thread_local void* g_fl_debug = nullptr;   // euler_gpu_set_debug_buffer: phase stamps of the lean kernel
+
+int SamplingView(const euler_gpu_graph* g, GraphView* out) {
+  if (g_k1_variant == 6 && g->view.blk == nullptr) {
+    const int rc = EnsureBlockedIndex(g);     // built on first use
+    if (rc != EULER_GPU_OK) return rc;
+  }
+  const bool wb = g_fl_wb != 0 && g_k1_variant == 6;
+  if (wb) {
+    const int rc = EnsureWbIndex(g);
+    if (rc != EULER_GPU_OK) return rc;
+  }
+  *out = g->view;
+  if (!wb) { out->wb = nullptr; out->wbg = nullptr; out->wrec = nullptr; out->n_wb = 0; }
+  return EULER_GPU_OK;
+}
 
 // U = 1: one sample per lane.  U = 2 (even `count`): a lane draws the two
 // adjacent samples (j, j+1) of one root - one root id / row record / limit
@@ -996,12 +1014,11 @@ static int LaunchSampleNeighbor(const euler_gpu_graph* g, hipStream_t stream,
     return Fail(EULER_GPU_EINVAL, "sample_neighbor: null edge_types");
   if (packed_out != nullptr && (dedup > 0 || !K1WritesPacked(g, k, layout)))
     return Fail(EULER_GPU_EINVAL, "sample_neighbor: packed output needs the pivot kernels");
-  if (g_k1_variant == 6 && g->view.blk == nullptr) {
-    const int rc = EnsureBlockedIndex(g);     // built on first use
+  SampleNbArgs a{};
+  {
+    const int rc = SamplingView(g, &a.g);
     if (rc != EULER_GPU_OK) return rc;
   }
-  SampleNbArgs a{};
-  a.g = g->view;
   a.seed = seed; a.call_id = call_id;
   a.roots = roots; a.root_mask = root_mask;
   a.root_group = root_group > 0 ? root_group : 1;
@@ -1298,12 +1315,11 @@ int LaunchSampleNeighborCounted(const euler_gpu_graph* g, hipStream_t stream, ui
   if (cap == 0) return EULER_GPU_OK;
   if (!(g_k1_variant == 5 || g_k1_variant == 6 || g_k1_variant == 0))
     return Fail(EULER_GPU_EINVAL, "sample_neighbor (counted): needs the default kernels");
-  if (g_k1_variant == 6 && g->view.blk == nullptr) {
-    const int rc = EnsureBlockedIndex(g);
+  SampleNbArgs a{};
+  {
+    const int rc = SamplingView(g, &a.g);
     if (rc != EULER_GPU_OK) return rc;
   }
-  SampleNbArgs a{};
-  a.g = g->view;
   a.seed = seed; a.call_id = call_id;
   a.roots = roots; a.root_mask = nullptr; a.root_group = 1;
   a.out_id = out_id; a.out_w = out_w; a.out_t = out_t; a.out_row_mask = nullptr;
@@ -1388,13 +1404,24 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
       n >= (multi != nullptr && g_fl_min_roots > 8192 ? 8192 : g_fl_min_roots) &&
       g_k1_variant == 6 && g->view.monotone && counts_host[0] > 0 && counts_host[1] > 0) {
     const int32_t c1 = counts_host[0], c2 = counts_host[1];
-    int32_t gr = g_fl_roots < 1 ? 1 : g_fl_roots > 16 ? 16 : g_fl_roots;
+    // Geometry.  Keys 28 / 29 / 30 = 0 (the defaults) let the launcher choose: with the
+    // weight-bucket index (plain graphs) a launch that has the chip to itself runs best as
+    // 4 roots per wave, 64 slots per pass, 2 waves per workgroup (0.219-0.221 ms against
+    // 0.218-0.224 as 4 / 32 / 1 and 0.235-0.239 as 8 / 64 / 2); a caller that alternates
+    // streams - two launches share the chip - as 8 roots per wave (0.2055 ms per step against
+    // 0.2175; profiles/r4_ab_wb_geom*.txt).  Everything else keeps round 3's 4 / 32 / 1.
+    const GraphView& gv = g->view;
+    const bool wb_plain = g_fl_wb != 0 && g_fl_plain == 2 && gv.T == 1 && gv.total_in_meta != 0 &&
+                          gv.map_mode == 0 && gv.has_zero_nbr == 0 && gv.uniform_w == 0;
+    int32_t gr = g_fl_roots > 16 ? 16 : g_fl_roots;
+    if (gr < 1) gr = wb_plain && t_concurrent == 1 ? 8 : 4;
     while (gr > 1 && (int64_t)gr * c1 > 0x7FFF) gr >>= 1;
     // several minibatches: a tile (gr roots) must not straddle two of them
     while (multi != nullptr && gr > 1 && multi->n_per % gr != 0) gr >>= 1;
-    int32_t cap = g_fl_cap > 0 ? g_fl_cap : 8 * gr;
+    int32_t cap = g_fl_cap > 0 ? g_fl_cap : wb_plain ? 64 : 8 * gr;
     if (cap > gr * c1) cap = gr * c1;
-    const int block = (g_fl_block == 64 || g_fl_block == 128) ? g_fl_block : 256;
+    const int block = (g_fl_block == 64 || g_fl_block == 128 || g_fl_block == 256) ? g_fl_block
+                      : wb_plain ? 128 : 64;
     FanoutLocalLds lay = FanoutLocalLayout(gr, c1, c2, cap);
     // shrink the pass until a workgroup's LDS fits
     while (cap > 1 && (size_t)lay.bytes * (block / 64) > 64 * 1024) {
@@ -1405,12 +1432,12 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
     const bool fits = (size_t)lay.bytes * (block / 64) <= 64 * 1024 && (int64_t)gr * c1 <= 0x7FFF &&
                       tile_pos * (uint64_t)(c1 > c2 ? c1 : c2) < 0xFFFFFFFFull;
     if (fits) {
-      if (g->view.blk == nullptr) {
-        const int rc0 = EnsureBlockedIndex(g);
+      FanoutLocalArgs f{};
+      {
+        const int rc0 = SamplingView(g, &f.g);
         if (rc0 != EULER_GPU_OK) return rc0;
       }
-      FanoutLocalArgs f{};
-      f.g = g->view; f.seed = seed; f.call_id = call_id; f.roots = roots_dev; f.n = n;
+      f.seed = seed; f.call_id = call_id; f.roots = roots_dev; f.n = n;
       f.default_node = default_node;
       f.c1 = c1; f.c2 = c2;
       f.t1 = edge_types_host[0]; f.t2 = edge_types_host[1];
@@ -1456,13 +1483,7 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
           f.row_index = t_fl_row_index;
           t_fl_took_lean = 1;
           void (*lk)(const FanoutLocalArgs) = nullptr;
-          bool use_wb = false;
-          if (v.uniform_w == 0 && g_fl_wb != 0) {
-            const int rcw = EnsureWbIndex(g);
-            if (rcw != EULER_GPU_OK) return rcw;
-            f.g = g->view;                      // the index may have been built just now
-            use_wb = f.g.wb != nullptr;
-          }
+          const bool use_wb = v.uniform_w == 0 && f.g.wrec != nullptr && f.g.wb != nullptr;
           if (v.uniform_w != 0) {
             lk = f.wide ? SampleFanoutLeanKernel<true, 8, true> : SampleFanoutLeanKernel<false, 8, true>;
           } else if (use_wb) {
@@ -1548,12 +1569,12 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
   // a small 2-hop fanout of single listed types: one launch (SampleFanout2Kernel)
   if (fanout2_ok && (multi != nullptr || (n <= kFanout2MaxRoots &&
       !WantsDedup(g, n * counts_host[0], 1) && !WantsDedup(g, n, 1)))) {
-    if (g->view.blk == nullptr) {
-      const int rc0 = EnsureBlockedIndex(g);
+    Fanout2Args f{};
+    {
+      const int rc0 = SamplingView(g, &f.g);
       if (rc0 != EULER_GPU_OK) return rc0;
     }
-    Fanout2Args f{};
-    f.g = g->view; f.seed = seed; f.call_id = call_id; f.roots = roots_dev; f.n = n;
+    f.seed = seed; f.call_id = call_id; f.roots = roots_dev; f.n = n;
     f.default_node = default_node;
     f.c1 = counts_host[0]; f.c2 = counts_host[1];
     f.t1 = edge_types_host[0]; f.t2 = edge_types_host[1];
@@ -1680,9 +1701,9 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 24) { g_full_nb_balanced = value != 0; return EULER_GPU_OK; }
   if (key == 25 && value >= 0) { g_n2v_big = value; return EULER_GPU_OK; }
   if (key == 27 && value >= 0 && value <= 2) { g_fanout_local = value; return EULER_GPU_OK; }
-  if (key == 28 && value >= 1 && value <= 16) { g_fl_roots = value; return EULER_GPU_OK; }
+  if (key == 28 && value >= 0 && value <= 16) { g_fl_roots = value; return EULER_GPU_OK; }
   if (key == 29 && value >= 0) { g_fl_cap = value; return EULER_GPU_OK; }
-  if (key == 30 && (value == 64 || value == 128 || value == 256)) { g_fl_block = value; return EULER_GPU_OK; }
+  if (key == 30 && (value == 0 || value == 64 || value == 128 || value == 256)) { g_fl_block = value; return EULER_GPU_OK; }
   if (key == 31) { g_fl_wide = value != 0; return EULER_GPU_OK; }
   if (key == 32 && value >= -1) { g_fl_grid_cap = value; return EULER_GPU_OK; }
   if (key == 33 && value >= 0) { g_fl_min_roots = value; return EULER_GPU_OK; }

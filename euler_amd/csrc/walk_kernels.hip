@@ -578,6 +578,17 @@ __device__ __forceinline__ uint64_t CwDraw(const CwArgs& a, const uint64_t cur, 
   uint64_t id = 0;
   float w;
   int32_t t;
+  if (MODE == 3) {            // plain graphs with the weight-bucket index: ONE line per draw
+    const GraphView& g = a.g;
+    const int64_t row = LeanFindRow(g, cur);
+    WbRec wr{0u, 0u, 0u, 0.f};
+    if (row >= 0 && a.edge_types[s] == 0) wr = g.wrec[row];
+    const bool live = wr.deg > 0u;
+    const Philox4 blk = RngBlock(a.seed, a.call_id + (uint32_t)s, kDomainNeighbor, cur, 0);
+    uint64_t id2[2]; float w2[2]; uint32_t m2[2];
+    WbSamplePair<false>(g, wr, live, UnitFromWords(blk.w[0], blk.w[1]), 0.0, id2, w2, m2);
+    return live ? id2[0] : 0;
+  }
   if (MODE == 2) {
     const GraphView& g = a.g;
     const int64_t row = LeanFindRow(g, cur);
@@ -1147,7 +1158,11 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
                           (size_t)walk_len * k * sizeof(int32_t),
                           hipMemcpyHostToDevice, st));
   WalkArgs a{};
-  a.g = g->view; a.seed = seed; a.call_id = call_id; a.nodes = nodes_dev;
+  {
+    const int rcv = SamplingView(g, &a.g);
+    if (rcv != EULER_GPU_OK) { (void)hipFreeAsync(et_dev, st); return rcv; }
+  }
+  a.seed = seed; a.call_id = call_id; a.nodes = nodes_dev;
   a.edge_types = et_dev; a.out = out_dev; a.n = n; a.default_node = default_node;
   a.k = k; a.walk_len = walk_len; a.p = p; a.q = q;
 #ifdef EULER_GPU_MEASURE
@@ -1204,7 +1219,7 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
         ~ReleaseEt() { if (armed) (void)hipFreeAsync(p, s); }
       } release_et{et_dev, st, true};
       CwArgs c{};
-      c.g = g->view; c.seed = seed; c.call_id = call_id; c.edge_types = et_dev; c.k = k;
+      c.g = a.g; c.seed = seed; c.call_id = call_id; c.edge_types = et_dev; c.k = k;
       c.walk_len = walk_len; c.cap = n; c.default_node = default_node; c.fast = fast ? 1 : 0;
       const size_t cap = (size_t)n, rows = (size_t)g->view.n_rows + 1;
       c.counts = (uint32_t*)buf;
@@ -1219,10 +1234,12 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
       if (g_walk_grid > 0 && grid > (unsigned)g_walk_grid) grid = (unsigned)g_walk_grid;
       c.step = 0;
       const GraphView& v = g->view;
-      const int mode = !fast ? 0
-                       : (g_walk_lean != 0 && v.T == 1 && v.total_in_meta != 0 && v.map_mode == 0 &&
-                          v.uniform_w == 0 && v.n_edges < ((int64_t)1 << 31)) ? 2 : 1;
-      auto sample_kernel = mode == 2 ? CwSampleKernel<2> : mode == 1 ? CwSampleKernel<1> : CwSampleKernel<0>;
+      int mode = !fast ? 0
+                 : (g_walk_lean != 0 && v.T == 1 && v.total_in_meta != 0 && v.map_mode == 0 &&
+                    v.uniform_w == 0 && v.n_edges < ((int64_t)1 << 31)) ? 2 : 1;
+      if (mode == 2 && c.g.wrec != nullptr && c.g.wb != nullptr) mode = 3;
+      auto sample_kernel = mode == 3 ? CwSampleKernel<3> : mode == 2 ? CwSampleKernel<2>
+                           : mode == 1 ? CwSampleKernel<1> : CwSampleKernel<0>;
       hipLaunchKernelGGL(sample_kernel, dim3(grid), dim3(block), 0, st, c);
       // first step of the tail (walk_len: none)
       const int32_t tail = g_walk_tail > 0 && g_walk_tail < walk_len ? g_walk_tail : walk_len;
@@ -1235,7 +1252,8 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
       }
       if (tail < walk_len) {
         c.step = tail;
-        auto tail_kernel = mode == 2 ? CwTailKernel<2> : mode == 1 ? CwTailKernel<1> : CwTailKernel<0>;
+        auto tail_kernel = mode == 3 ? CwTailKernel<3> : mode == 2 ? CwTailKernel<2>
+                           : mode == 1 ? CwTailKernel<1> : CwTailKernel<0>;
         hipLaunchKernelGGL(tail_kernel, dim3(grid), dim3(block), 0, st, c);
       }
       {

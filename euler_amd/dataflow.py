@@ -198,6 +198,16 @@ class _FullBlocksMixin(object):
                 self._growth[h] = max(1.0, 0.5 * self._growth[h], 2.0 * seen)
         return blocks
 
+    def _learn_from(self, data_flow, self_loops):
+        """After an overflow the minibatch was redone op by op: its blocks hold the true sizes
+        of every hop - the next minibatch's capacities come from them, not from a guess."""
+        if self._growth is None:
+            return
+        for h, blk in enumerate(data_flow.blocks):
+            n_prev = int(blk.size[0])
+            edges = int(blk.edge_index.shape[1]) - (n_prev if self_loops else 0)
+            self._growth[h] = max(self._growth[h], 1.0, 2.0 * edges / max(1, n_prev))
+
 
 class GCNDataFlow(_FullBlocksMixin, UniqueDataFlow):
     """gcn_dataflow.py:24-47: every hop takes ALL neighbours (of the listed edge
@@ -211,7 +221,9 @@ class GCNDataFlow(_FullBlocksMixin, UniqueDataFlow):
     def produce_subgraph(self, n_id):
         blocks = self._full_blocks(n_id, self.add_self_loops, False)
         if blocks is None:
-            return super(GCNDataFlow, self).produce_subgraph(n_id)
+            data_flow = super(GCNDataFlow, self).produce_subgraph(n_id)
+            self._learn_from(data_flow, self.add_self_loops)
+            return data_flow
         data_flow = DataFlow(n_id.reshape(-1))
         for new_n_id, res_n_id, edge_src, edge_dst, _t in blocks:
             data_flow.append(new_n_id, res_n_id, None, torch.stack([edge_src, edge_dst], 0))
@@ -265,6 +277,7 @@ class RelationDataFlow(_FullBlocksMixin):
             n_id = new_n_id
             edge_index = torch.stack([n_edge_src[i], edge_dst], 0)
             data_flow.append(new_n_id, res_n_id, types[i], edge_index)
+        self._learn_from(data_flow, False)
         return data_flow
 
     def __call__(self, n_id):

@@ -893,9 +893,11 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  *        workgroup kernel (default 8192; 0 = none).
  * key 27: the one-kernel fanout (csrc/fanout_local.h: 2 hops, one listed type each,
  *        >= key 33 roots): 1 = on weighted graphs [default], 2 = on every graph,
- *        0 = off (hop by hop).  Its geometry: key 28 roots per wave (1..16, default 4),
- *        key 29 distinct children sampled per pass (0 = 8 per root), key 30 threads
- *        per workgroup (64 [default], 128, 256), key 31 weights / types as 16-byte
+ *        0 = off (hop by hop).  Its geometry: key 28 roots per wave (1..16; 0 [default] =
+ *        the launcher chooses: 4, or 8 for a caller that alternates streams on a graph with
+ *        the weight-bucket index), key 29 distinct children sampled per pass (0 [default] =
+ *        64 with the weight-bucket index, else 8 per root), key 30 threads per workgroup
+ *        (64, 128, 256; 0 [default] = 128 with the index, else 64), key 31 weights / types as 16-byte
  *        stores (1), key 32 cap on launched waves (-1 = 16 384 when the caller
  *        alternates streams, else one tile per wave [default]; 0 = never; > 0 = that
  *        many), key 33 smallest batch it takes (32768), key 34 plain graphs: 2 = the
@@ -912,6 +914,10 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  *        groups stop looking for mergers and finish the walk in one launch (12; 0 =
  *        never).  key 44: plain graphs draw with the lean search of the one-kernel
  *        fanout (1 [default]).
+ * key 45: 1 [default] = searches go through the weight-bucket index (csrc/wb_index.h: the
+ *        bucket of a draw in its row's running-sum range names ONE 128-byte line; built on
+ *        first use for graphs with non-decreasing, non-uniform running sums and < 2^32
+ *        edges, ~40 bytes per edge of HBM); 0 = the pivot-level search of rounds 2-3.
  * All settings produce identical results; the knobs exist for A/B measurements
  * and tests.  They are THREAD-LOCAL: a call changes the launches the calling host
  * thread enqueues afterwards and nobody else's (new threads start from the

@@ -1567,7 +1567,7 @@ def test_full_neighbor_fill_kernels_agree(EA, O, torch_cuda, big_pair):
         _lib.lib().euler_gpu_set_tuning(24, 1)
 
 
-_FL_DEFAULTS = {27: 1, 28: 4, 29: 0, 30: 64, 31: 1, 32: -1, 33: 32768, 34: 2, 35: 5, 45: 1}
+_FL_DEFAULTS = {27: 1, 28: 0, 29: 0, 30: 0, 31: 1, 32: -1, 33: 32768, 34: 2, 35: 5, 45: 1}
 
 
 @pytest.mark.parametrize("geom", [(4, 0, 256, 1, 8, 2, 0, 1), (1, 1, 64, 0, 5, 0, 0, 1), (2, 3, 128, 1, 8, 0, 0, 1),
@@ -1763,11 +1763,14 @@ def test_random_walk_over_merged_walkers(EA, O, torch_cuda, big_pair):
         L.euler_gpu_set_tuning(38, 1)
         want1 = OG1.random_walk(8, 3, q, [[0]] * 12, 12, 1.0, 1.0, 30001)
         # a plain graph: the draws come from the lean search (key 44) or the block pivots
-        for lean, tail in ((1, 0), (1, 5), (1, 11), (0, 5)):
+        # (with key 45 = 1, the default, the lean draws go through the weight-bucket index)
+        for lean, tail, wb in ((1, 0, 1), (1, 5, 1), (1, 11, 1), (0, 5, 1), (1, 0, 0), (1, 5, 0)):
             L.euler_gpu_set_tuning(44, lean)
             L.euler_gpu_set_tuning(43, tail)
+            L.euler_gpu_set_tuning(45, wb)
             got = G1.random_walk(torch.as_tensor(q).cuda(), [[0]] * 12, 1.0, 1.0, 30001, call_id=3)
-            assert np.array_equal(t2n(got), want1), (lean, tail)
+            assert np.array_equal(t2n(got), want1), (lean, tail, wb)
+        L.euler_gpu_set_tuning(45, 1)
         # a listed type the graph does not have: every walker stops at once
         L.euler_gpu_set_tuning(44, 1)
         got = G1.random_walk(torch.as_tensor(q).cuda(), [[0], [0], [2], [0], [0]], 1.0, 1.0, 30001, call_id=9)
@@ -1791,6 +1794,7 @@ def test_random_walk_over_merged_walkers(EA, O, torch_cuda, big_pair):
         L.euler_gpu_set_tuning(38, 262144)
         L.euler_gpu_set_tuning(43, 12)
         L.euler_gpu_set_tuning(44, 1)
+        L.euler_gpu_set_tuning(45, 1)
 
 
 def test_fanout_unique_rows_and_index(EA, O, torch_cuda, big_pair):
