@@ -78,6 +78,9 @@ def parse():
     ap.add_argument("--n2v", action="store_true", help="deepwalk workload: also time node2vec")
     ap.add_argument("--unfused-aggregation", action="store_true",
                     help="hetero workload: gather, then scatter_mean (two passes over the E x D block)")
+    ap.add_argument("--hetero-separate", action="store_true",
+                    help="hetero workload: one sample_neighbor + one aggregation op per edge-type set "
+                         "(round 3's step) instead of the one-enqueue form")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--sustain-steps", type=int, default=4000,
                     help="metric workload, one GPU: after the K timed steps, this many more steps "
@@ -524,7 +527,14 @@ def run_hetero(args, quiet=False):
 
     fused = not args.unfused_aggregation
 
+    one_enqueue = S is None and not args.unfused_aggregation and not args.hetero_separate
+
     def step(i):
+        if one_enqueue:
+            # the three typed draws of the minibatch as ONE launch and their aggregation as one
+            # pass, enqueued by one C call (euler_gpu_sample_aggregate_sets): the results of the
+            # three sample_neighbor + gather_segment_reduce pairs below, bit for bit
+            return G.sample_neighbor_sets(roots[i], type_sets, CNT, N + 1, call_id=3 * i, feat=feat)[3]
         aggs = []
         for c, et in enumerate(type_sets):
             nb, _w, _t = sample(roots[i], et, 3 * i + c)
@@ -647,6 +657,16 @@ def run_hetero(args, quiet=False):
         a_sel = agg[torch.as_tensor(sel).cuda()].double()
         assert torch.all((a_sel - ref).abs() <= 1e-5 * (1.0 + ref.abs())), "hetero: aggregation off"
         checked += int(got.size)
+    # the one-enqueue step == the three separate ops, on the whole batch
+    sn, sw, st_, sagg = G.sample_neighbor_sets(r, type_sets, CNT, N + 1, call_id=900, feat=feat)
+    for c, et in enumerate(type_sets):
+        nb_b, w_b, t_b = G.sample_neighbor(r, et, CNT, N + 1, call_id=900 + c)
+        assert torch.equal(sn[c], nb_b) and torch.equal(sw[c], w_b) and torch.equal(st_[c], t_b), \
+            "hetero: one launch over the type sets != the separate launches"
+        assert torch.equal(sagg[c], ops.gather_segment_reduce("mean", feat, nb_b.reshape(-1), B, count=CNT))
+    # ... and its launches alone (HIP events around 20 steps enqueued back to back)
+    set_ms = _events(lambda: G.sample_neighbor_sets(r, type_sets, CNT, N + 1, call_id=5), 20)
+    step_ms = _events(lambda: G.sample_neighbor_sets(r, type_sets, CNT, N + 1, call_id=5, feat=feat), 20)
     E = B * CNT
     g_bytes = 8.0 * E * D + 4.0 * E
     s_bytes = 4.0 * E * D + 4.0 * E + 4.0 * B * D
@@ -667,11 +687,15 @@ def run_hetero(args, quiet=False):
                    "GBps": round(b_.value / ms_ / 1e6, 1)})
     k1_bytes = sum(x_["algorithmic_bytes"] for x_ in k1) / len(k1)
     k1_ms = sum(x_["ms"] for x_ in k1) / len(k1)
-    roof = {"kernel": "SampleNeighbor kernels of the three typed hops (one listed type: pivot search; "
-                      "3 of 8 and all 8: type draw + search)",
-            "bound": "hbm", "achieved": round(k1_bytes / k1_ms / 1e6, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(k1_bytes / k1_ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": None,
-            "algorithmic_bytes_per_launch": k1_bytes, "avg_launch_ms": round(k1_ms, 4),
+    sets_bytes = sum(x_["algorithmic_bytes"] for x_ in k1)
+    roof = {"kernel": "SampleNeighborSetsKernel: the three typed draws of a minibatch in one launch (one "
+                      "listed type; 3 of 8 and all 8: type draw + search)",
+            "bound": "hbm", "achieved": round(sets_bytes / set_ms / 1e6, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(sets_bytes / set_ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": None,
+            "algorithmic_bytes_per_launch": sets_bytes, "avg_launch_ms": round(set_ms, 4),
+            "step_kernels_ms": round(step_ms, 4),
+            "separate_launches": {"avg_launch_ms": round(k1_ms, 4), "algorithmic_bytes_per_launch": k1_bytes,
+                                  "frac": round(k1_bytes / k1_ms / 1e6 / HBM_PEAK_GBS, 4)},
             "launches": k1,
             "aggregation": {
                 "one_pass": {"ms": round(f_ms, 4), "algorithmic_bytes": f_bytes,
@@ -702,6 +726,8 @@ def run_hetero(args, quiet=False):
                    "one_stream_ms_per_step": None if one_stream is None else round(one_stream, 4),
                    "aggregation": ("ops.gather_segment_reduce (one pass, %d rows per root)" % CNT if fused
                                    else "ops.gather + ops.scatter_mean"),
+                   "step": ("one enqueue: Graph.sample_neighbor_sets(feat=...) = euler_gpu_sample_aggregate_sets"
+                            if one_enqueue else "3 x (sample_neighbor + aggregation) ops"),
                    "phases_ms": dict({k_: round(v_, 4) for k_, v_ in ph.items()},
                                      gather=round(g_ms, 4), scatter_mean=round(s_ms, 4),
                                      gather_scatter_mean=round(f_ms, 4)),

@@ -83,6 +83,11 @@ SIGNATURES = {
                                                 C.c_int32, vp, C.c_int64, i32p, C.c_int32, i32p,
                                                 C.c_int32, C.c_int64, C.POINTER(vp), C.POINTER(vp),
                                                 C.POINTER(vp), vp]),
+    "euler_gpu_sample_neighbor_sets": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp, C.c_int64, i32p,
+                                                 i32p, C.c_int32, C.c_int32, C.c_int64, vp, vp, vp]),
+    "euler_gpu_sample_aggregate_sets": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp, C.c_int64, i32p,
+                                                  i32p, C.c_int32, C.c_int32, C.c_int64, C.c_int32, vp,
+                                                  C.c_int64, C.c_int64, vp, vp, vp, vp]),
     "euler_gpu_sample_node": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, i32p,
                                         C.c_int32, C.c_int32, vp]),
     "euler_gpu_get_full_neighbor": (C.c_int, [vp, vp, vp, C.c_int64, i32p, C.c_int32,

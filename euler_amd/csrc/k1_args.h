@@ -117,6 +117,14 @@ extern thread_local int g_k1_variant, g_k1_ablate, g_k1_grid_cap, g_k1_pair, g_k
 int LaunchK1Variant(const euler_gpu_graph* g, hipStream_t stream, const SampleNbArgs& a,
                     int grid);
 
+// k1_variants.hip: several edge-type sets over the same roots in one launch; false = not this
+// way (the caller issues the separate calls)
+bool LaunchSampleNeighborSets(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed,
+                              uint32_t call_id, const uint64_t* roots, int64_t n,
+                              const int32_t* edge_types, const int32_t* set_k, int32_t n_sets,
+                              int32_t count, int64_t default_node, uint64_t* out_id, float* out_w,
+                              int32_t* out_t, int* rc_out);
+
 }  // namespace euler_gpu
 
 #endif  // EULER_AMD_CSRC_K1_ARGS_H_

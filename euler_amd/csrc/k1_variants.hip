@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborTypedPivotKe
             sg.limit_end = BlockedPw(a.g, sg.hi);
             sg.limit_begin = b_idx == 0 ? 0.f : BlockedPw(a.g, sg.lo - 1);
           }
-          BlockPivotSample(a.g, sg, u_nb, &id, &w);
+          BlockPivotSample<true>(a.g, sg, u_nb, &id, &w);
         }
       }
     }
@@ -139,6 +139,104 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborTypedPivotKe
     a.out_w[s] = w;
     a.out_t[s] = t;
     if (j == 0 && a.out_row_mask != nullptr) a.out_row_mask[r] = valid ? 0 : 1;
+  }
+}
+
+// ------------------------------------------------------------------------
+// Several edge-type SETS of one batch of roots in ONE launch (euler_gpu_sample_neighbor_sets).
+// A heterogeneous model samples the same roots once per relation set - RGCN-style:
+// sample_neighbor(nodes, [3]), sample_neighbor(nodes, [1, 4, 6]), sample_neighbor(nodes, all) -
+// three launches of ~2.5 rounds of waves each, every one a chain of dependent cold loads
+// (root -> record -> [type draw] -> block).  The calls are independent, so one launch over
+// sets x roots x count samples keeps three times as many of those chains in flight.  Set s
+// draws with call_id + s: the results are those of S euler_gpu_sample_neighbor calls, bit for
+// bit (one listed type: draw j = Philox block j >> 1, half j & 1; otherwise block j, words
+// 0-1 the type, 2-3 the neighbour - node.cc:123-159).  TF layout, monotone graphs without
+// the id-0 sentinel rule.
+// ------------------------------------------------------------------------
+constexpr int kMaxTypeSets = 8;
+struct SampleSetsArgs {
+  GraphView g;
+  uint64_t seed;
+  const uint64_t* roots;
+  uint64_t* out_id; float* out_w; int32_t* out_t;     // [sets][n][count]
+  int64_t n;
+  int64_t default_node;
+  uint32_t call_id;
+  int32_t count;
+  int32_t n_sets;
+  int32_t set_k[kMaxTypeSets];
+  int32_t set_off[kMaxTypeSets];
+  int32_t et[kMaxListedTypes];
+};
+
+__global__ __launch_bounds__(256, 6) void SampleNeighborSetsKernel(const SampleSetsArgs a) {   // 80 VGPRs: nothing spilled
+  const int64_t per_set = a.n * (int64_t)a.count;
+  const int64_t total = per_set * a.n_sets;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int32_t T = a.g.T;
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total; s += stride) {
+    const int32_t set = (int32_t)(s / per_set);
+    const int64_t in_set = s - (int64_t)set * per_set;
+    const int64_t r = in_set / a.count;
+    const int32_t j = (int32_t)(in_set - r * a.count);
+    const int32_t k = a.set_k[set];
+    const int32_t* et = a.et + a.set_off[set];
+    const int32_t mode = TypeModeOf(k, T);
+    const uint32_t call = a.call_id + (uint32_t)set;
+    const uint64_t node = a.roots[r];
+    const int64_t row = FindRow(a.g, node);
+    uint64_t id = (uint64_t)a.default_node;
+    float w = 0.f;
+    int32_t t = -1;
+    if (mode == kTypeSingle) {
+      Segment sg;
+      if (LoadSegment<true>(a.g, row, et[0], &sg)) {
+        const Philox4 b = RngBlock(a.seed, call, kDomainNeighbor, node, ((uint32_t)j) >> 1);
+        const double u = (j & 1) ? UnitFromWords(b.w[2], b.w[3]) : UnitFromWords(b.w[0], b.w[1]);
+        BlockPivotSample<true>(a.g, sg, u, &id, &w);
+        t = et[0];
+      }
+    } else if (row >= 0) {
+      const RowMeta m = LoadRowMeta(a.g, row);
+      bool valid;
+      if (mode == kTypeSub) {
+        valid = true;
+        for (int32_t i = 0; i < k; ++i) valid = valid && et[i] >= 0 && et[i] < T;
+        if (valid) valid = SubTypeSum{m.type_prefix, et}((uint64_t)(k - 1)) != 0.f;
+      } else {
+        valid = m.type_prefix[T - 1] != 0.f;
+      }
+      if (valid) {
+        const Philox4 b = RngBlock(a.seed, call, kDomainNeighbor, node, (uint32_t)j);
+        const double u_type = UnitFromWords(b.w[0], b.w[1]);
+        const double u_nb = UnitFromWords(b.w[2], b.w[3]);
+        if (mode == kTypeSub) {
+          t = et[RandomSelectT(SubTypeSum{m.type_prefix, et}, 0, (uint64_t)(k - 1), u_type)];
+        } else {
+          t = (int32_t)RandomSelect(m.type_prefix, 0, (uint64_t)(T - 1), u_type);
+        }
+        const int32_t b_idx = t == 0 ? 0 : m.type_end[t - 1];
+        const int32_t e_idx = m.type_end[t] - 1;
+        if (e_idx < b_idx) {
+          id = 0; w = 0.f; t = 0;         // as SampleAt (device_fns.h): unreachable for consistent rows
+        } else {
+          Segment sg;
+          sg.row_ptr = m.row_ptr; sg.b = b_idx; sg.e = e_idx;
+          sg.lo = m.row_ptr + b_idx; sg.hi = m.row_ptr + e_idx;
+          if (a.g.wbg != nullptr) {
+            LoadWbSegment(a.g, row, t, m.type_end[T - 1], &sg);
+          } else {
+            sg.limit_end = BlockedPw(a.g, sg.hi);
+            sg.limit_begin = b_idx == 0 ? 0.f : BlockedPw(a.g, sg.lo - 1);
+          }
+          BlockPivotSample<true>(a.g, sg, u_nb, &id, &w);
+        }
+      }
+    }
+    a.out_id[s] = id;
+    a.out_w[s] = w;
+    a.out_t[s] = t;
   }
 }
 
@@ -160,6 +258,39 @@ int LaunchK1Variant(const euler_gpu_graph* g, hipStream_t stream, const SampleNb
   }
   EG_HIP(hipGetLastError());
   return EULER_GPU_OK;
+}
+
+// n_sets edge-type sets over the same roots; false = this graph / tuning takes the separate calls
+bool LaunchSampleNeighborSets(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed,
+                              uint32_t call_id, const uint64_t* roots, int64_t n,
+                              const int32_t* edge_types, const int32_t* set_k, int32_t n_sets,
+                              int32_t count, int64_t default_node, uint64_t* out_id, float* out_w,
+                              int32_t* out_t, int* rc_out) {
+  *rc_out = EULER_GPU_OK;
+  if (g_k1_variant != 6 || g_k1_typed_pivot == 0 || !g->view.monotone || g->view.has_zero_nbr != 0 ||
+      n_sets > kMaxTypeSets)
+    return false;
+  int32_t total_k = 0;
+  for (int32_t s = 0; s < n_sets; ++s) total_k += set_k[s];
+  if (total_k > kMaxListedTypes) return false;
+  SampleSetsArgs a{};
+  *rc_out = SamplingView(g, &a.g);
+  if (*rc_out != EULER_GPU_OK) return true;
+  a.seed = seed; a.call_id = call_id; a.roots = roots; a.n = n; a.count = count;
+  a.default_node = default_node; a.n_sets = n_sets;
+  a.out_id = out_id; a.out_w = out_w; a.out_t = out_t;
+  int32_t off = 0;
+  for (int32_t s = 0; s < n_sets; ++s) {
+    a.set_k[s] = set_k[s]; a.set_off[s] = off;
+    for (int32_t i = 0; i < set_k[s]; ++i) a.et[off + i] = edge_types[off + i];
+    off += set_k[s];
+  }
+  const int64_t total = n * (int64_t)count * n_sets;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > kK1GridCap) blocks = kK1GridCap;
+  hipLaunchKernelGGL(SampleNeighborSetsKernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+  if (hipGetLastError() != hipSuccess) *rc_out = Fail(EULER_GPU_EHIP, "sample_neighbor_sets: launch failed");
+  return true;
 }
 
 }  // namespace euler_gpu

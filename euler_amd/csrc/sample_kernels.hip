@@ -623,7 +623,7 @@ __device__ __forceinline__ void PivotPass(const SampleNbArgs& a, const int64_t n
       if (U == 1) {
         const double u = (j & 1) ? UnitFromWords(blk.w[2], blk.w[3])
                                  : UnitFromWords(blk.w[0], blk.w[1]);
-        if (BLOCKED) BlockPivotSample(a.g, sg, u, &id[0], &w[0]);
+        if (BLOCKED) BlockPivotSample<true>(a.g, sg, u, &id[0], &w[0]);
         else PivotSample(a.g, sg, u, &id[0], &w[0]);
       } else if (BLOCKED) {
         BlockPivotSample(a.g, sg, UnitFromWords(blk.w[0], blk.w[1]), &id[0], &w[0]);
@@ -1264,7 +1264,7 @@ __global__ __launch_bounds__(256) void SampleFanout2Kernel(const Fanout2Args a) 
       if (valid) {
         const Philox4 pb = RngBlock(a.seed, call0, kDomainNeighbor, node, ((uint32_t)j) >> 1);
         const double u = (j & 1) ? UnitFromWords(pb.w[2], pb.w[3]) : UnitFromWords(pb.w[0], pb.w[1]);
-        BlockPivotSample(a.g, sg, u, &id, &w);
+        BlockPivotSample<true>(a.g, sg, u, &id, &w);
       }
       const int64_t d = r * a.c1 + j;
       a.id1[d] = id;
@@ -1286,7 +1286,7 @@ __global__ __launch_bounds__(256) void SampleFanout2Kernel(const Fanout2Args a) 
       if (valid) {
         const Philox4 pb = RngBlock(a.seed, call0 + 1u, kDomainNeighbor, node, ((uint32_t)x) >> 1);
         const double u = (x & 1) ? UnitFromWords(pb.w[2], pb.w[3]) : UnitFromWords(pb.w[0], pb.w[1]);
-        BlockPivotSample(a.g, sg, u, &id, &w);
+        BlockPivotSample<true>(a.g, sg, u, &id, &w);
       }
       const int64_t row = r * a.c1 + q;
       const int64_t d = row * a.c2 + x;
@@ -1746,6 +1746,70 @@ int euler_gpu_sample_fanout_multi(const euler_gpu_graph* g, void* stream, uint64
   return RunFanout(g, (hipStream_t)stream, seed, call_id, roots_dev, (int64_t)m * n, edge_types_host, k,
                    counts_host, layers, default_node, out_id_dev, out_w_dev, out_t_dev, workspace_dev,
                    nullptr, nullptr, &mu);
+}
+
+int euler_gpu_sample_neighbor_sets(const euler_gpu_graph* g, void* stream, uint64_t seed,
+                                   uint32_t call_id, const uint64_t* roots_dev, int64_t n,
+                                   const int32_t* edge_types_host, const int32_t* set_k_host,
+                                   int32_t n_sets, int32_t count, int64_t default_node,
+                                   uint64_t* out_id_dev, float* out_w_dev, int32_t* out_t_dev) {
+  if (!g) return Fail(EULER_GPU_ENOGRAPH, "sample_neighbor_sets: null graph");
+  if (n < 0 || count <= 0 || n_sets < 0 || (n_sets > 0 && !set_k_host))
+    return Fail(EULER_GPU_EINVAL, "sample_neighbor_sets: bad arguments");
+  if (n == 0 || n_sets == 0) return EULER_GPU_OK;
+  if (!roots_dev || !out_id_dev || !out_w_dev || !out_t_dev)
+    return Fail(EULER_GPU_EINVAL, "sample_neighbor_sets: null buffer");
+  int32_t total_k = 0;
+  for (int32_t s = 0; s < n_sets; ++s) {
+    if (set_k_host[s] < 0 || set_k_host[s] > kMaxListedTypes)
+      return Fail(EULER_GPU_EINVAL, "sample_neighbor_sets: bad set size");
+    total_k += set_k_host[s];
+  }
+  if (total_k > 0 && !edge_types_host) return Fail(EULER_GPU_EINVAL, "sample_neighbor_sets: null edge types");
+  if (n * (int64_t)count * n_sets >= ((int64_t)1 << 40))
+    return Fail(EULER_GPU_EINVAL, "sample_neighbor_sets: too many samples");
+  int rc = EULER_GPU_OK;
+  if (LaunchSampleNeighborSets(g, (hipStream_t)stream, seed, call_id, roots_dev, n, edge_types_host,
+                               set_k_host, n_sets, count, default_node, out_id_dev, out_w_dev,
+                               out_t_dev, &rc))
+    return rc;
+  // graphs the one-launch kernel does not serve: the separate calls
+  const int64_t per = n * (int64_t)count;
+  int32_t off = 0;
+  for (int32_t s = 0; s < n_sets && rc == EULER_GPU_OK; ++s) {
+    rc = LaunchSampleNeighbor(g, (hipStream_t)stream, seed, call_id + (uint32_t)s, roots_dev, n, nullptr, 1,
+                              edge_types_host + off, set_k_host[s], count, EULER_GPU_LAYOUT_TF,
+                              default_node, out_id_dev + (size_t)s * per, out_w_dev + (size_t)s * per,
+                              out_t_dev + (size_t)s * per, nullptr);
+    off += set_k_host[s];
+  }
+  return rc;
+}
+
+int euler_gpu_sample_aggregate_sets(const euler_gpu_graph* g, void* stream, uint64_t seed,
+                                    uint32_t call_id, const uint64_t* roots_dev, int64_t n,
+                                    const int32_t* edge_types_host, const int32_t* set_k_host,
+                                    int32_t n_sets, int32_t count, int64_t default_node,
+                                    int32_t mode, const float* feat_dev, int64_t feat_rows, int64_t d,
+                                    uint64_t* out_id_dev, float* out_w_dev, int32_t* out_t_dev,
+                                    float* out_agg_dev) {
+  if (feat_rows < 0 || d < 0 || (d > 0 && (!feat_dev || !out_agg_dev)))
+    return Fail(EULER_GPU_EINVAL, "sample_aggregate_sets: bad feature arguments");
+  // every sampled id (and the default fill) must name a row of the table
+  if (default_node < 0 || default_node >= feat_rows)
+    return Fail(EULER_GPU_EINVAL, "sample_aggregate_sets: default_node is not a row of the feature table");
+  if (g && g->max_id >= (uint64_t)feat_rows)
+    return Fail(EULER_GPU_EINVAL, "sample_aggregate_sets: the feature table has fewer rows than the largest node id");
+  const int rc = euler_gpu_sample_neighbor_sets(g, stream, seed, call_id, roots_dev, n, edge_types_host,
+                                                set_k_host, n_sets, count, default_node, out_id_dev,
+                                                out_w_dev, out_t_dev);
+  if (rc != EULER_GPU_OK || n == 0 || n_sets == 0 || d == 0) return rc;
+  if ((int64_t)n_sets * n >= ((int64_t)1 << 31))
+    return Fail(EULER_GPU_EINVAL, "sample_aggregate_sets: more than 2^31 segments");
+  // [sets][n] segments of `count` sampled ids each: one pass over the feature rows
+  return euler_gpu_gather_segment_reduce_ids(stream, mode, feat_dev,
+                                             reinterpret_cast<const int64_t*>(out_id_dev), nullptr,
+                                             count, d, (int32_t)(n_sets * n), out_agg_dev);
 }
 
 int euler_gpu_sample_neighbor(const euler_gpu_graph* g, void* stream,

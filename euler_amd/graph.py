@@ -349,6 +349,40 @@ class Graph:
         res = (out_n, out_w, out_t)
         return res + (mask,) if return_mask else res
 
+    def sample_neighbor_sets(self, nodes, type_sets, count, default_node=-1, call_id=None,
+                             feat=None, aggr="mean"):
+        """S SampleNeighbor ops over the same nodes - one per edge-type set, as a heterogeneous
+        (RGCN-style) model issues them - in ONE launch (euler_gpu_sample_neighbor_sets): returns
+        (neighbors [S, n, count] int64, weights f32, types int32); set s draws with the call id
+        of the s-th of S consecutive sample_neighbor calls, and the result equals theirs bit
+        for bit.  With `feat` ([rows, d] f32 indexed by node id) the sampled neighbours'
+        rows are aggregated per (set, root) in the same enqueue
+        (euler_gpu_sample_aggregate_sets): a fourth result [S, n, d] = add / max / mean over
+        the `count` rows, the bits of scatter_(aggr, gather(feat, neighbors))."""
+        flat = _as_i64_cuda(nodes, self.device).reshape(-1)
+        n, S = flat.numel(), len(type_sets)
+        ks = [len(ts) for ts in type_sets]
+        ks_a, ks_p, _ = _i32_array(ks)
+        et_a, et_p, _ = _i32_array([int(t) for ts in type_sets for t in ts])
+        out_n = torch.empty((S, n, int(count)), dtype=torch.int64, device=self.device)
+        out_w = torch.empty((S, n, int(count)), dtype=torch.float32, device=self.device)
+        out_t = torch.empty((S, n, int(count)), dtype=torch.int32, device=self.device)
+        cid = self._take_call_ids(S, call_id)
+        with self._on_device():
+            if feat is None:
+                check(lib().euler_gpu_sample_neighbor_sets(
+                    self._h, _stream(), self.seed, cid, _ptr(flat), n, et_p, ks_p, S, int(count),
+                    int(default_node), _ptr(out_n), _ptr(out_w), _ptr(out_t)))
+                return out_n, out_w, out_t
+            assert feat.dtype == torch.float32 and feat.dim() == 2 and feat.is_contiguous()
+            mode = {"add": 0, "max": 1, "mean": 2}[aggr]
+            agg = torch.empty((S, n, feat.shape[1]), dtype=torch.float32, device=self.device)
+            check(lib().euler_gpu_sample_aggregate_sets(
+                self._h, _stream(), self.seed, cid, _ptr(flat), n, et_p, ks_p, S, int(count),
+                int(default_node), mode, _ptr(feat), int(feat.shape[0]), int(feat.shape[1]),
+                _ptr(out_n), _ptr(out_w), _ptr(out_t), _ptr(agg)))
+        return out_n, out_w, out_t, agg
+
     def sample_neighbor_packed(self, nodes, edge_types, count, default_node=-1,
                                call_id=None):
         """The shard side of a multi-GPU hop: TF-layout SampleNeighbor of the

@@ -226,6 +226,33 @@ int euler_gpu_sample_neighbor_distinct(const euler_gpu_graph* g, void* stream,
                                        int64_t default_node, uint64_t* out_id_dev,
                                        float* out_w_dev, int32_t* out_t_dev,
                                        uint8_t* out_row_mask_dev);
+/* Several edge-type SETS of one batch of roots in ONE launch - what a heterogeneous
+ * (RGCN-style) model issues per minibatch as n_sets SampleNeighbor ops over the same nodes
+ * (tf_euler/kernels/sample_neighbor_op.cc:29-132 once per relation set).  Set s lists
+ * set_k_host[s] types, taken in order from edge_types_host, and draws with call_id + s; TF
+ * layout; out_*_dev hold [n_sets][n][count] elements.  The result equals n_sets calls of
+ * euler_gpu_sample_neighbor bit for bit (Node::__SampleNeighbor's type modes,
+ * core/graph/node.cc:98-161: one listed type, a sub-collection in the listed order, all
+ * groups).  Graphs the one-launch kernel does not serve (running sums that decrease, the
+ * id-0 sentinel rule) get the separate calls. */
+int euler_gpu_sample_neighbor_sets(const euler_gpu_graph* g, void* stream, uint64_t seed,
+                                   uint32_t call_id, const uint64_t* roots_dev, int64_t n,
+                                   const int32_t* edge_types_host, const int32_t* set_k_host,
+                                   int32_t n_sets, int32_t count, int64_t default_node,
+                                   uint64_t* out_id_dev, float* out_w_dev, int32_t* out_t_dev);
+/* ... followed, in the same enqueue, by the aggregation of the sampled neighbours' feature
+ * rows per (set, root): out_agg_dev [n_sets][n][d] = add / max / mean (mode 0 / 1 / 2) over
+ * the `count` rows feat_dev[id] of every root, in sample order - the bits of
+ * scatter_(aggr, gather(feat, ids)) (tf_euler/kernels/gather_op.cc, scatter_op.cc;
+ * euler_gpu_gather_segment_reduce_ids).  feat_dev is a [feat_rows, d] f32 table indexed by
+ * node id; default_node must be one of its rows. */
+int euler_gpu_sample_aggregate_sets(const euler_gpu_graph* g, void* stream, uint64_t seed,
+                                    uint32_t call_id, const uint64_t* roots_dev, int64_t n,
+                                    const int32_t* edge_types_host, const int32_t* set_k_host,
+                                    int32_t n_sets, int32_t count, int64_t default_node,
+                                    int32_t mode, const float* feat_dev, int64_t feat_rows, int64_t d,
+                                    uint64_t* out_id_dev, float* out_w_dev, int32_t* out_t_dev,
+                                    float* out_agg_dev);
 /* The shard side of a multi-GPU hop in one call: sample the (distinct) ids this
  * shard received, TF layout, and write the wire rows euler_gpu_expand_packed
  * consumes - euler_gpu_pack_rows' format: 4 * count + 2 int32 words per root

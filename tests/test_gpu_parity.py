@@ -1719,6 +1719,62 @@ def test_sample_fanout_multi_equals_separate_calls(EA, O, torch_cuda, big_pair):
     assert G1.sample_fanout_multi(torch.zeros((0, 8), dtype=torch.int64).cuda(), [[0], [0]], [2, 2]) == []
 
 
+def test_sample_neighbor_sets_one_launch(EA, O, torch_cuda, big_pair):
+    """euler_gpu_sample_neighbor_sets / _sample_aggregate_sets: the SampleNeighbor ops a
+    heterogeneous model issues over one batch of roots - one per edge-type set - as ONE launch.
+    Set s == sample_neighbor(call_id + s) == the oracle for every type mode of
+    Node::__SampleNeighbor (one listed type, a sub-collection in the listed order, all groups,
+    an empty list, a type the graph does not have, more types listed than exist), unknown
+    roots and id 0; with and without the weight-bucket index; and the aggregation of the same
+    enqueue == scatter_(aggr, gather(feat, neighbours)) bit for bit."""
+    torch = torch_cuda
+    from euler_amd import _lib
+    L = _lib.lib()
+    G, OG, ids, rng = big_pair                     # hashed ids, 4 edge types
+    q = np.concatenate([rng.choice(ids, 3000), [0, 4242, 2 ** 62]]).astype(np.int64)
+    qt = torch.as_tensor(q).cuda()
+    sets = [[3], [1, 2], [0, 1, 2, 3], [], [2, 0, 1], [9], [0, 1, 2, 3, 0], [1]]
+    try:
+        for wb in (1, 0):
+            L.euler_gpu_set_tuning(45, wb)
+            for count in (10, 1, 7):
+                G.set_seed(5)
+                gn, gw, gt = G.sample_neighbor_sets(qt, sets, count, -3, call_id=70)
+                assert tuple(gn.shape) == (len(sets), len(q), count)
+                for s_, et in enumerate(sets):
+                    a = G.sample_neighbor(qt, et, count, -3, call_id=70 + s_)
+                    assert torch.equal(gn[s_], a[0]) and torch.equal(gw[s_], a[1]) and torch.equal(gt[s_], a[2]), (wb, et)
+                    on, ow, ot = OG.sample_neighbor(5, 70 + s_, q, et, count, -3)
+                    assert np.array_equal(t2n(gn[s_]).reshape(-1), on.reshape(-1)), (wb, et, count)
+                    assert np.array_equal(t2n(gw[s_]).reshape(-1), ow.reshape(-1))
+                    assert np.array_equal(t2n(gt[s_]).reshape(-1), ot.reshape(-1))
+    finally:
+        L.euler_gpu_set_tuning(45, 1)
+    # identity ids, 8 types, with the aggregation (feature table indexed by node id)
+    N, T, D, CNT = 20000, 8, 32, 10
+    p = EA.synth_params(99, N, 400000, n_types=T, weighted=True)
+    G1 = EA.Graph.synthetic(p)
+    G1.set_seed(4)
+    r = torch.as_tensor(np.random.default_rng(2).integers(1, N + 1, 5000).astype(np.int64)).cuda()
+    feat = torch.randn(N + 2, D, device="cuda", generator=torch.Generator("cuda").manual_seed(1))
+    tsets = [[3], [1, 4, 6], list(range(T))]
+    dst = torch.arange(5000, device="cuda", dtype=torch.int32).repeat_interleave(CNT)
+    for aggr in ("mean", "add", "max"):
+        gn, gw, gt, agg = G1.sample_neighbor_sets(r, tsets, CNT, N + 1, call_id=9, feat=feat, aggr=aggr)
+        for s_, et in enumerate(tsets):
+            a = G1.sample_neighbor(r, et, CNT, N + 1, call_id=9 + s_)
+            assert torch.equal(gn[s_], a[0]) and torch.equal(gw[s_], a[1]) and torch.equal(gt[s_], a[2])
+            x = EA.ops.gather(feat, a[0].reshape(-1).to(torch.int32))
+            ref = {"mean": EA.ops.scatter_mean, "add": EA.ops.scatter_add, "max": EA.ops.scatter_max}[aggr](x, dst, 5000)
+            assert torch.equal(agg[s_], ref), (aggr, et)
+    # a feature table that does not cover the ids is refused
+    with pytest.raises(_lib.EulerGpuError):
+        G1.sample_neighbor_sets(r, tsets, CNT, N + 1, feat=feat[:100].contiguous())
+    # nothing to do
+    e = G1.sample_neighbor_sets(r[:0], tsets, CNT, N + 1)
+    assert tuple(e[0].shape) == (3, 0, CNT)
+
+
 def test_random_walk_over_merged_walkers(EA, O, torch_cuda, big_pair):
     """DeepWalk over groups of merged walkers (walk_kernels.hip: CwSampleKernel /
     CwNumberKernel / CwChainKernel / CwTransposeKernel, tuning key 38): walkers that meet on a node in a step
