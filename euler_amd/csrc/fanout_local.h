@@ -772,7 +772,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
       const Philox4 pb = RngBlock(a.seed, tile_call, kDomainNeighbor, node, jp);
       uint64_t id[2]; float w[2]; uint32_t m[2];
       if (WB) WbSamplePair(g, wr, live, UnitFromWords(pb.w[0], pb.w[1]),
-                           UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
+                                UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
       else if (UNIFORM) LeanSamplePairUniform(g, lo, deg, total, live, UnitFromWords(pb.w[0], pb.w[1]),
                                          UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
       else LeanSamplePair(g, lo, deg, total, live, UnitFromWords(pb.w[0], pb.w[1]),
@@ -890,7 +890,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
         const Philox4 pb = RngBlock(a.seed, tile_call + 1u, kDomainNeighbor, node, xp);
         uint64_t id[2]; float w[2]; uint32_t m[2];
         if (WB) WbSamplePair(g, wr, live, UnitFromWords(pb.w[0], pb.w[1]),
-                             UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
+                                  UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
         else if (UNIFORM) LeanSamplePairUniform(g, lo, deg, total, live, UnitFromWords(pb.w[0], pb.w[1]),
                                            UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
         else LeanSamplePair(g, lo, deg, total, live, UnitFromWords(pb.w[0], pb.w[1]),

@@ -184,9 +184,6 @@ __device__ __forceinline__ void PivotSample(const GraphView& g, const Segment& s
 // them, shared by its samples) and one block line.
 // Same contract as PivotSample: first m in [lo, hi] with nw[m] > r.
 // ------------------------------------------------------------------------
-// FULL (weight-bucket path only): the block's ids are requested with its keys (WbDrawFull) -
-// for kernels that draw once per lane.
-template <bool FULL = false>
 __device__ __forceinline__ void BlockPivotSample(const GraphView& g, const Segment& sg,
                                                  double u, uint64_t* id, float* w) {
   const int64_t lo = sg.lo, hi = sg.hi;
@@ -215,15 +212,12 @@ __device__ __forceinline__ void BlockPivotSample(const GraphView& g, const Segme
     const uint32_t nbk = WbBuckets(sg.row_deg);
     const uint32_t j = nbk <= 1u ? 0u : WbBucketOf(f, nbk, WbScale(nbk, sg.row_total));
     const EdgeBlock* wbk = g.wb + sg.wb_lo + j;
+    // (requesting the line's ids beside its keys - 8 loads instead of 3 + 1 dependent one -
+    // was measured and is SLOWER: the CU's memory pipe is bound by load instructions x
+    // divergent lanes, not by the dependent trip; profiles/r4_ab_wb_full.txt)
     uint32_t m = 0;
-    if (FULL) {
-      uint64_t idf = 0;
-      const int32_t i = WbDrawFull(wbk, f, w, &m, &idf);
-      if (i >= 0) { *id = idf; return; }
-    } else {
-      const int32_t i = WbDraw(wbk, f, w, &m);
-      if (i >= 0) { *id = wbk->nbr[i]; return; }
-    }
+    const int32_t i = WbDraw(wbk, f, w, &m);
+    if (i >= 0) { *id = wbk->nbr[i]; return; }
     // the block does not bracket r (a row whose weights are far from even): the reference
     const float* nw = g.prefix_w + sg.row_ptr;
     const int32_t mm = (int32_t)RandomSelect(nw, (uint64_t)sg.b, (uint64_t)sg.e, u);

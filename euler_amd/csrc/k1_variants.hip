@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborTypedPivotKe
             sg.limit_end = BlockedPw(a.g, sg.hi);
             sg.limit_begin = b_idx == 0 ? 0.f : BlockedPw(a.g, sg.lo - 1);
           }
-          BlockPivotSample<true>(a.g, sg, u_nb, &id, &w);
+          BlockPivotSample(a.g, sg, u_nb, &id, &w);
         }
       }
     }
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256, 6) void SampleNeighborSetsKernel(const SampleS
       if (LoadSegment<true>(a.g, row, et[0], &sg)) {
         const Philox4 b = RngBlock(a.seed, call, kDomainNeighbor, node, ((uint32_t)j) >> 1);
         const double u = (j & 1) ? UnitFromWords(b.w[2], b.w[3]) : UnitFromWords(b.w[0], b.w[1]);
-        BlockPivotSample<true>(a.g, sg, u, &id, &w);
+        BlockPivotSample(a.g, sg, u, &id, &w);
         t = et[0];
       }
     } else if (row >= 0) {
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256, 6) void SampleNeighborSetsKernel(const SampleS
             sg.limit_end = BlockedPw(a.g, sg.hi);
             sg.limit_begin = b_idx == 0 ? 0.f : BlockedPw(a.g, sg.lo - 1);
           }
-          BlockPivotSample<true>(a.g, sg, u_nb, &id, &w);
+          BlockPivotSample(a.g, sg, u_nb, &id, &w);
         }
       }
     }

@@ -623,7 +623,7 @@ __device__ __forceinline__ void PivotPass(const SampleNbArgs& a, const int64_t n
       if (U == 1) {
         const double u = (j & 1) ? UnitFromWords(blk.w[2], blk.w[3])
                                  : UnitFromWords(blk.w[0], blk.w[1]);
-        if (BLOCKED) BlockPivotSample<true>(a.g, sg, u, &id[0], &w[0]);
+        if (BLOCKED) BlockPivotSample(a.g, sg, u, &id[0], &w[0]);
         else PivotSample(a.g, sg, u, &id[0], &w[0]);
       } else if (BLOCKED) {
         BlockPivotSample(a.g, sg, UnitFromWords(blk.w[0], blk.w[1]), &id[0], &w[0]);
@@ -785,7 +785,7 @@ static int LaunchK1(const euler_gpu_graph* g, hipStream_t stream,
         : (pair ? (tf ? SampleNeighborPivotKernel<true, 2>
                       : SampleNeighborPivotKernel<false, 2>)
                 : (tf ? SampleNeighborPivotKernel<true, 1>
-                      : SampleNeighborPivotKernel<false, 1>));
+                      : SampleNeighborPivotKernel<false, true>));
     hipLaunchKernelGGL(kern, dim3(gridp), dim3(block), 0, stream, a, stride_rows,
                        stride_slots);
   } else {
@@ -1264,7 +1264,7 @@ __global__ __launch_bounds__(256) void SampleFanout2Kernel(const Fanout2Args a) 
       if (valid) {
         const Philox4 pb = RngBlock(a.seed, call0, kDomainNeighbor, node, ((uint32_t)j) >> 1);
         const double u = (j & 1) ? UnitFromWords(pb.w[2], pb.w[3]) : UnitFromWords(pb.w[0], pb.w[1]);
-        BlockPivotSample<true>(a.g, sg, u, &id, &w);
+        BlockPivotSample(a.g, sg, u, &id, &w);
       }
       const int64_t d = r * a.c1 + j;
       a.id1[d] = id;
@@ -1286,7 +1286,7 @@ __global__ __launch_bounds__(256) void SampleFanout2Kernel(const Fanout2Args a) 
       if (valid) {
         const Philox4 pb = RngBlock(a.seed, call0 + 1u, kDomainNeighbor, node, ((uint32_t)x) >> 1);
         const double u = (x & 1) ? UnitFromWords(pb.w[2], pb.w[3]) : UnitFromWords(pb.w[0], pb.w[1]);
-        BlockPivotSample<true>(a.g, sg, u, &id, &w);
+        BlockPivotSample(a.g, sg, u, &id, &w);
       }
       const int64_t row = r * a.c1 + q;
       const int64_t d = row * a.c2 + x;

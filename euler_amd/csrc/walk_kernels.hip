@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void RandomWalkKernel(const Wal
             if (LoadSegment<true>(a.g, FindRow(a.g, cur), a.edge_types[s], &sg)) {
               const Philox4 blk = RngBlock(a.seed, a.call_id + (uint32_t)s, kDomainNeighbor,
                                            cur, 0);
-              BlockPivotSample<true>(a.g, sg, UnitFromWords(blk.w[0], blk.w[1]), &id, &w);
+              BlockPivotSample(a.g, sg, UnitFromWords(blk.w[0], blk.w[1]), &id, &w);
             }
           } else {
             RowSampler rs;
@@ -610,7 +610,7 @@ __device__ __forceinline__ uint64_t CwDraw(const CwArgs& a, const uint64_t cur, 
     Segment sg;
     if (LoadSegment<true>(a.g, row, a.edge_types[s], &sg)) {
       const Philox4 blk = RngBlock(a.seed, a.call_id + (uint32_t)s, kDomainNeighbor, cur, 0);
-      BlockPivotSample<true>(a.g, sg, UnitFromWords(blk.w[0], blk.w[1]), &id, &w);
+      BlockPivotSample(a.g, sg, UnitFromWords(blk.w[0], blk.w[1]), &id, &w);
     }
   } else {
     RowSampler rs;

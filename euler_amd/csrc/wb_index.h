@@ -165,25 +165,6 @@ EG_HD int32_t WbDraw(const EdgeBlock* bk, float f, float* w_out, uint32_t* m_out
   return WbPickKeys(WbLoadKeys(bk), f, w_out, m_out);
 }
 
-// The same draw with the WHOLE line requested at once - keys and the ten ids, eight 16-byte
-// loads - and the id picked out of registers: a kernel that draws once per lane has the
-// registers, and the id no longer costs a second, dependent pass through the CU's memory
-// pipe (the line is the same; only the trip is saved).
-EG_HD int32_t WbDrawFull(const EdgeBlock* bk, float f, float* w_out, uint32_t* m_out, uint64_t* id_out) {
-  const WbKeys k = WbLoadKeys(bk);
-  typedef unsigned long long wb_u64x2 __attribute__((ext_vector_type(2)));
-  const wb_u64x2* ip = reinterpret_cast<const wb_u64x2*>(bk->nbr);
-  const wb_u64x2 p0 = ip[0], p1 = ip[1], p2 = ip[2], p3 = ip[3], p4 = ip[4];
-  const int32_t i = WbPickKeys(k, f, w_out, m_out);
-  const uint32_t u = (uint32_t)i;
-  const bool b0 = (u & 1u) != 0, b1 = (u & 2u) != 0, b2 = (u & 4u) != 0, b3 = (u & 8u) != 0;
-  const uint64_t e0 = b0 ? p0.y : p0.x, e1 = b0 ? p1.y : p1.x, e2 = b0 ? p2.y : p2.x,
-                 e3 = b0 ? p3.y : p3.x, e4 = b0 ? p4.y : p4.x;
-  const uint64_t q0 = b1 ? e1 : e0, q1 = b1 ? e3 : e2;
-  *id_out = b3 ? e4 : (b2 ? q1 : q0);
-  return i;
-}
-
 // largest float <= r (r >= 0): for a float v, v > r <=> v > f - one conversion per draw
 // instead of one per key
 EG_HD float WbFloorToFloat(double r) {
