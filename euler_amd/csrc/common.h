@@ -214,6 +214,13 @@ struct euler_gpu_graph {
   // kernels of two streams fit on the chip together (sample_kernels.hip: ConcurrentCall)
   mutable std::atomic<void*> last_stream{nullptr};
   mutable std::atomic<int> wb_tried{0};     // EnsureWbIndex ran (whatever it decided)
+  // Block construction (dataflow_kernels.hip): first-occurrence unique of a hop's node list
+  // through a table indexed by graph ROW, one per stream, kept across calls: 8 bytes per row
+  // {~epoch, smallest position} + 4 bytes {rank}.  Every hop of every call takes a new epoch
+  // and the table is cleared once - an atomicMin with a newer epoch beats whatever an older
+  // one left.  Guarded by ws_mu.
+  struct FlowTableDense { void* p = nullptr; size_t rows = 0; uint32_t next_epoch = 1; };
+  mutable std::map<void*, FlowTableDense> flow_tables;
 };
 
 namespace euler_gpu {

@@ -35,6 +35,7 @@ namespace euler_gpu {
 namespace {
 
 constexpr uint64_t kFlowEmptyKey = ~0ULL;
+constexpr int kFlowChunk = 1024;      // positions of V per workgroup of the flag / emit kernels
 
 struct FlowTable {
   unsigned long long* keys;   // [cap + 1]; slot `cap` is the side slot of the all-ones id
@@ -54,10 +55,18 @@ struct FlowHop {
   int32_t count;
   int32_t self_loops;
   int64_t cap_m;              // cap_n * (count + 1): worst-case length of V
-  FlowTable t;
-  uint32_t* slot_of;          // [cap_m]
-  uint32_t* is_first;         // [cap_m + 1] (entry cap_m stays 0: the scan's total lands there)
-  uint32_t* rank;             // [cap_m + 1]
+  FlowTable t;                // ids without a graph row (unknown ids, the default fill)
+  // ids WITH a row: a table indexed by row (common.h: FlowTableDense) - one atomicMin of
+  // {~epoch, position} claims the row for this hop and keeps the smallest position; no
+  // probing, nothing to clear
+  GraphView g;
+  unsigned long long* dense_min;   // [n_rows] or null (hash table for every id)
+  uint32_t* dense_rank;            // [n_rows]
+  unsigned long long epoch_hi;     // (~epoch) << 32
+  uint32_t* slot_of;          // [cap_m]: the row, or 0x80000000 | hash slot
+  uint32_t* blk_cnt;          // [n_blk + 1] first occurrences per chunk of kFlowChunk positions
+  uint32_t* blk_off;          // [n_blk + 1] their exclusive scan (entry n_blk: the total)
+  int64_t n_blk;              // ceil(cap_m / kFlowChunk)
   uint64_t* new_n_id;         // [cap_m]
   int64_t* inv;               // [cap_m] edge_dst: index of every element of V in new_n_id
   int64_t* edge_src;          // [cap_m]
@@ -72,52 +81,184 @@ __device__ __forceinline__ uint64_t FlowElem(const FlowHop& h, int64_t i, int64_
   return i < m_nb ? h.nb[i] : h.n_id[i - m_nb];
 }
 
-__global__ __launch_bounds__(256) void FlowInsertKernel(const FlowHop h) {
+// The hash table is allocated for the worst case, but a minibatch fills a fraction of it
+// (16 384 roots x [25, 10]: 0.65 M of 4.7 M positions): every kernel sizes the part it uses
+// from the device-side length - a power of two >= 2 m slots - so clearing and probing touch
+// megabytes that stay in the L2 instead of the 200 MB a worst-case table takes
+// (profiles/r4_sage_blocks_kernel_stats.csv: 87 us of fills + an insert that missed the L2).
+__device__ __forceinline__ uint64_t FlowMask(const FlowHop& h, int64_t m) {
+  uint64_t cap = 64;
+  while (cap < (uint64_t)m * 2 && cap <= h.t.mask) cap <<= 1;
+  return (cap > h.t.mask + 1 ? h.t.mask + 1 : cap) - 1;
+}
+
+__global__ __launch_bounds__(256) void FlowClearKernel(const FlowHop h) {
   const int64_t cnt = (int64_t)(*h.cnt);
-  const int64_t m_nb = FlowNbLen(h, cnt), m = m_nb + cnt;
+  const int64_t m = FlowNbLen(h, cnt) + cnt;
+  const int64_t slots = (int64_t)FlowMask(h, m) + 1;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
-    const uint64_t id = FlowElem(h, i, m_nb);
-    uint64_t s;
-    if (id == kFlowEmptyKey) {
-      s = h.t.mask + 1;
-    } else {
-      s = Mix64(id) & h.t.mask;
-      for (;;) {
-        unsigned long long old =
-            __hip_atomic_load(&h.t.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == kFlowEmptyKey)
-          old = atomicCAS(&h.t.keys[s], (unsigned long long)kFlowEmptyKey, (unsigned long long)id);
-        if (old == kFlowEmptyKey || old == id) break;
-        s = (s + 1) & h.t.mask;
-      }
-    }
-    if (__hip_atomic_load(&h.t.minpos[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (uint32_t)i)
-      atomicMin(&h.t.minpos[s], (uint32_t)i);
-    h.slot_of[i] = (uint32_t)s;
+  const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (first == 0) {                    // the side slot of the all-ones id
+    h.t.keys[h.t.mask + 1] = kFlowEmptyKey;
+    h.t.minpos[h.t.mask + 1] = 0xFFFFFFFFu;
+  }
+  for (int64_t i = first; i < slots; i += stride) {
+    h.t.keys[i] = kFlowEmptyKey;
+    h.t.minpos[i] = 0xFFFFFFFFu;
   }
 }
 
-// is_first over the WORST-CASE length (zeros beyond the valid prefix), so that the
-// scan needs no device-side length
+constexpr uint32_t kFlowHashed = 0x80000000u;
+
+// smallest position recorded for the element of slot word `sw`
+__device__ __forceinline__ bool FlowIsFirst(const FlowHop& h, uint32_t sw, int64_t i) {
+  if (sw & kFlowHashed) return h.t.minpos[sw & ~kFlowHashed] == (uint32_t)i;
+  return h.dense_min[sw] == (h.epoch_hi | (unsigned long long)(uint32_t)i);
+}
+
+// Ids with a graph row (all of them, normally) are first reduced INSIDE the workgroup: a chunk
+// of kFlowChunk positions goes through an LDS table {row, smallest position}, and only the
+// table's entries go to the row-indexed table in HBM.  A sampled frontier repeats its hubs
+// thousands of times; without this every wave that starts before the first atomic has landed
+// sends its own, and the memory side works them off one by one (41 us for the 0.43 M
+// positions of the first hop: profiles/r4_sage_blocks_kernel_stats.csv).
+constexpr int kFlowLds = 2 * kFlowChunk;          // LDS slots per workgroup (power of two)
+
+__global__ __launch_bounds__(256) void FlowInsertKernel(const FlowHop h) {
+  __shared__ uint32_t s_row[kFlowLds];
+  __shared__ uint32_t s_pos[kFlowLds];
+  const int64_t cnt = (int64_t)(*h.cnt);
+  const int64_t m_nb = FlowNbLen(h, cnt), m = m_nb + cnt;
+  const uint64_t mask = FlowMask(h, m);
+  for (int64_t base = (int64_t)blockIdx.x * kFlowChunk; base < m; base += (int64_t)gridDim.x * kFlowChunk) {
+    for (int x = threadIdx.x; x < kFlowLds; x += 256) { s_row[x] = 0xFFFFFFFFu; s_pos[x] = 0xFFFFFFFFu; }
+    __syncthreads();
+#pragma unroll
+    for (int x = 0; x < kFlowChunk / 256; ++x) {
+      const int64_t i = base + x * 256 + threadIdx.x;
+      if (i >= m) continue;
+      const uint64_t id = FlowElem(h, i, m_nb);
+      const int64_t row = h.dense_min != nullptr ? FindRow(h.g, id) : -1;
+      if (row >= 0) {
+        h.slot_of[i] = (uint32_t)row;
+        uint32_t s = (uint32_t)(Mix64((uint64_t)row) & (uint64_t)(kFlowLds - 1));
+        for (;;) {                                    // at most kFlowChunk of kFlowLds slots fill up
+          const uint32_t old = atomicCAS(&s_row[s], 0xFFFFFFFFu, (uint32_t)row);
+          if (old == 0xFFFFFFFFu || old == (uint32_t)row) break;
+          s = (s + 1) & (uint32_t)(kFlowLds - 1);
+        }
+        atomicMin(&s_pos[s], (uint32_t)i);
+        continue;
+      }
+      uint64_t s;
+      if (id == kFlowEmptyKey) {
+        s = h.t.mask + 1;
+      } else {
+        s = Mix64(id) & mask;
+        for (;;) {
+          unsigned long long old =
+              __hip_atomic_load(&h.t.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (old == kFlowEmptyKey)
+            old = atomicCAS(&h.t.keys[s], (unsigned long long)kFlowEmptyKey, (unsigned long long)id);
+          if (old == kFlowEmptyKey || old == id) break;
+          s = (s + 1) & mask;
+        }
+      }
+      if (__hip_atomic_load(&h.t.minpos[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (uint32_t)i)
+        atomicMin(&h.t.minpos[s], (uint32_t)i);
+      h.slot_of[i] = kFlowHashed | (uint32_t)s;
+    }
+    __syncthreads();
+    // the chunk's distinct rows, one atomicMin of {~epoch, position} each (a row another
+    // chunk already claimed with a smaller position costs a load)
+    for (int x = threadIdx.x; x < kFlowLds; x += 256) {
+      const uint32_t row = s_row[x];
+      if (row == 0xFFFFFFFFu) continue;
+      const unsigned long long mine = h.epoch_hi | (unsigned long long)s_pos[x];
+      if (__hip_atomic_load(&h.dense_min[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > mine)
+        atomicMin(&h.dense_min[row], mine);
+    }
+    __syncthreads();
+  }
+}
+
+// first occurrences per chunk of kFlowChunk positions (workgroup b = chunk b; chunks past
+// the valid prefix count zero) - the ranks are then a scan over n_blk numbers instead of
+// one over the worst-case length of V
 __global__ __launch_bounds__(256) void FlowFlagKernel(const FlowHop h) {
+  __shared__ uint32_t s_cnt[4];
   const int64_t cnt = (int64_t)(*h.cnt);
   const int64_t m = FlowNbLen(h, cnt) + cnt;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= h.cap_m; i += stride)
-    h.is_first[i] = (i < m && h.t.minpos[h.slot_of[i]] == (uint32_t)i) ? 1u : 0u;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int64_t b = blockIdx.x; b <= h.n_blk; b += gridDim.x) {
+    uint32_t mine = 0;
+    const int64_t base = b * kFlowChunk;
+    if (base < m && b < h.n_blk) {
+#pragma unroll
+      for (int x = 0; x < kFlowChunk / 256; ++x) {
+        const int64_t i = base + x * 256 + threadIdx.x;
+        const bool first = i < m && FlowIsFirst(h, h.slot_of[i], i);
+        mine += (uint32_t)__popcll(__ballot(first));
+      }
+    }
+    if (lane == 0) s_cnt[wv] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) h.blk_cnt[b] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    __syncthreads();
+  }
+}
+
+// exclusive scan of the n_blk + 1 chunk counts by ONE workgroup (a device-wide look-back
+// scan over a few thousand numbers is all latency: 28 us against ~5 here)
+__global__ __launch_bounds__(1024) void FlowScanKernel(const FlowHop h) {
+  __shared__ uint32_t s_sum[1024];
+  const int64_t n = h.n_blk + 1;
+  const int64_t per = (n + 1023) / 1024;
+  const int64_t b = (int64_t)threadIdx.x * per, e = b + per < n ? b + per : n;
+  uint32_t sum = 0;
+  for (int64_t i = b; i < e; ++i) sum += h.blk_cnt[i];
+  s_sum[threadIdx.x] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {          // Hillis-Steele over the 1024 partial sums
+    const uint32_t v = threadIdx.x >= (unsigned)off ? s_sum[threadIdx.x - off] : 0u;
+    __syncthreads();
+    s_sum[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t run = threadIdx.x == 0 ? 0u : s_sum[threadIdx.x - 1];
+  for (int64_t i = b; i < e; ++i) { const uint32_t c = h.blk_cnt[i]; h.blk_off[i] = run; run += c; }
 }
 
 __global__ __launch_bounds__(256) void FlowEmitKernel(const FlowHop h) {
+  __shared__ uint32_t s_cnt[4];
   const int64_t cnt = (int64_t)(*h.cnt);
   const int64_t m_nb = FlowNbLen(h, cnt), m = m_nb + cnt;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (first == 0) *h.cnt_out = h.rank[h.cap_m];          // exclusive scan: the total
-  for (int64_t i = first; i < m; i += stride) {
-    if (h.is_first[i]) {
-      h.new_n_id[h.rank[i]] = FlowElem(h, i, m_nb);
-      h.t.rank[h.slot_of[i]] = (int32_t)h.rank[i];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  if (blockIdx.x == 0 && threadIdx.x == 0) *h.cnt_out = h.blk_off[h.n_blk];   // exclusive scan: the total
+  for (int64_t b = blockIdx.x; b < h.n_blk; b += gridDim.x) {
+    const int64_t base = b * kFlowChunk;
+    if (base >= m) break;                              // block-uniform
+    uint32_t run = h.blk_off[b];
+    for (int x = 0; x < kFlowChunk / 256; ++x) {
+      const int64_t i = base + x * 256 + threadIdx.x;
+      uint32_t slot = 0;
+      bool first = false;
+      if (i < m) { slot = h.slot_of[i]; first = FlowIsFirst(h, slot, i); }
+      const uint64_t bal = __ballot(first);
+      if (lane == 0) s_cnt[wv] = (uint32_t)__popcll(bal);
+      __syncthreads();
+      uint32_t before = 0, all = 0;
+#pragma unroll
+      for (int y = 0; y < 4; ++y) { if (y < wv) before += s_cnt[y]; all += s_cnt[y]; }
+      if (first) {
+        const uint32_t r = run + before + (uint32_t)__popcll(bal & lt);
+        h.new_n_id[r] = FlowElem(h, i, m_nb);
+        if (slot & kFlowHashed) h.t.rank[slot & ~kFlowHashed] = (int32_t)r;
+        else h.dense_rank[slot] = r;
+      }
+      run += all;
+      __syncthreads();
     }
   }
 }
@@ -127,7 +268,8 @@ __global__ __launch_bounds__(256) void FlowIndexKernel(const FlowHop h) {
   const int64_t m_nb = FlowNbLen(h, cnt), m = m_nb + cnt;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
-    const int64_t dst = (int64_t)h.t.rank[h.slot_of[i]];
+    const uint32_t sw = h.slot_of[i];
+    const int64_t dst = (sw & kFlowHashed) ? (int64_t)h.t.rank[sw & ~kFlowHashed] : (int64_t)h.dense_rank[sw];
     if (i < m_nb) {
       h.inv[i] = dst;
       h.edge_src[i] = h.nb_src != nullptr ? (int64_t)h.nb_src[i] : i / h.count;
@@ -233,6 +375,36 @@ __global__ __launch_bounds__(256) void FlowFullFillKernel(const FlowFull f) {
 
 __global__ void FlowInitKernel(uint32_t* counts, uint32_t n) { counts[0] = n; }
 
+// The stream's row-indexed table and the epochs of `hops` hops (common.h: FlowTableDense).
+// No table (allocation failed, more than 2^31 rows): the hash table serves every id.
+int FlowDenseTable(const euler_gpu_graph* g, hipStream_t st, int32_t hops,
+                   unsigned long long** dense_min, uint32_t** dense_rank, uint32_t* epoch0) {
+  *dense_min = nullptr; *dense_rank = nullptr; *epoch0 = 0;
+  const size_t rows = (size_t)g->view.n_rows;
+  if (rows == 0 || rows >= ((size_t)1 << 31)) return EULER_GPU_OK;
+  std::lock_guard<std::mutex> lk(g->ws_mu);
+  auto& ft = g->flow_tables[(void*)st];
+  if (ft.p == nullptr || ft.rows < rows) {
+    if (ft.p != nullptr) { (void)hipStreamSynchronize(st); (void)hipFree(ft.p); ft.p = nullptr; ft.rows = 0; }
+    if (hipMalloc(&ft.p, rows * 12 + 64) != hipSuccess) {
+      (void)hipGetLastError();
+      ft.p = nullptr;
+      return EULER_GPU_OK;
+    }
+    ft.rows = rows; ft.next_epoch = 1;
+    EG_HIP(hipMemsetAsync(ft.p, 0xFF, rows * 8, st));       // {~0, ~0}: older than every epoch
+  }
+  if ((uint64_t)ft.next_epoch + (uint64_t)hops + 2 >= 0xFFFFFFF0ull) {     // the epochs are used up
+    EG_HIP(hipMemsetAsync(ft.p, 0xFF, ft.rows * 8, st));
+    ft.next_epoch = 1;
+  }
+  *dense_min = (unsigned long long*)ft.p;
+  *dense_rank = (uint32_t*)((uint8_t*)ft.p + ft.rows * 8);
+  *epoch0 = ft.next_epoch;
+  ft.next_epoch += (uint32_t)hops;
+  return EULER_GPU_OK;
+}
+
 size_t Al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace
@@ -292,6 +464,13 @@ int euler_gpu_sage_blocks(const euler_gpu_graph* g, void* stream, uint64_t seed,
     return EULER_GPU_OK;
   }
   const uint64_t* n_id = roots_dev;
+  unsigned long long* dense_min = nullptr;
+  uint32_t* dense_rank = nullptr;
+  uint32_t epoch0 = 0;
+  {
+    const int rcd = FlowDenseTable(g, st, layers, &dense_min, &dense_rank, &epoch0);
+    if (rcd != EULER_GPU_OK) return rcd;
+  }
   for (int32_t h = 0; h < layers; ++h) {
     const int32_t count = fanouts_host[h];
     const int64_t cap_n = FlowCap(n, fanouts_host, h);
@@ -303,36 +482,39 @@ int euler_gpu_sage_blocks(const euler_gpu_graph* g, void* stream, uint64_t seed,
     float* nb_w = (float*)p;            p += Al((size_t)cap_n * count * 4);
     int32_t* nb_t = (int32_t*)p;        p += Al((size_t)cap_n * count * 4);
     FlowHop f{};
+    f.g = g->view; f.dense_min = dense_min; f.dense_rank = dense_rank;
+    f.epoch_hi = (unsigned long long)(uint32_t)~(epoch0 + (uint32_t)h) << 32;
     f.t.keys = (unsigned long long*)p;  p += Al((tcap + 1) * 8);
     f.t.minpos = (uint32_t*)p;          p += Al((tcap + 1) * 4);
     f.t.rank = (int32_t*)p;             p += Al((tcap + 1) * 4);
     f.t.mask = tcap - 1;
     f.slot_of = (uint32_t*)p;           p += Al((size_t)cap_m * 4);
-    f.is_first = (uint32_t*)p;          p += Al(((size_t)cap_m + 1) * 4);
-    f.rank = (uint32_t*)p;              p += Al(((size_t)cap_m + 1) * 4);
+    // (the workspace holds two arrays of cap_m + 1 words here: the chunk counts need far less)
+    f.blk_cnt = (uint32_t*)p;           p += Al(((size_t)cap_m + 1) * 4);
+    f.blk_off = (uint32_t*)p;           p += Al(((size_t)cap_m + 1) * 4);
+    f.n_blk = (cap_m + kFlowChunk - 1) / kFlowChunk;
     void* scan_tmp = p;
     size_t scan_bytes = 0;
-    EG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, f.is_first, f.rank,
-                                            (int)(cap_m + 1), st));
+    EG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, f.blk_cnt, f.blk_off,
+                                            (int)(f.n_blk + 1), st));
     // 1. the hop's sampler over the first counts[h] nodes of the layer
     int rc = LaunchSampleNeighborCounted(g, st, seed, call_id + (uint32_t)h, n_id, cap_n,
                                          counts_dev + h, edge_types_host + (size_t)h * k, k, count,
                                          default_node, nb, nb_w, nb_t);
     if (rc != EULER_GPU_OK) return rc;
     // 2. first-occurrence unique of [nb | n_id]
-    EG_HIP(hipMemsetAsync(f.t.keys, 0xFF, (tcap + 1) * 8, st));
-    EG_HIP(hipMemsetAsync(f.t.minpos, 0xFF, (tcap + 1) * 4, st));
     f.nb = nb; f.n_id = n_id; f.cnt = counts_dev + h; f.cnt_out = counts_dev + h + 1;
     f.count = count; f.self_loops = add_self_loops ? 1 : 0; f.cap_m = cap_m;
     f.new_n_id = n_id_dev[h]; f.inv = edge_dst_dev[h]; f.edge_src = edge_src_dev[h];
     f.res_n_id = res_n_id_dev[h];
     const int block = 256;
     const int grid = GridFor(cap_m + 1, block);
-    hipLaunchKernelGGL(FlowInsertKernel, dim3(grid), dim3(block), 0, st, f);
-    hipLaunchKernelGGL(FlowFlagKernel, dim3(grid), dim3(block), 0, st, f);
-    EG_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, f.is_first, f.rank,
-                                            (int)(cap_m + 1), st));
-    hipLaunchKernelGGL(FlowEmitKernel, dim3(grid), dim3(block), 0, st, f);
+    const int grid_b = (int)(f.n_blk + 1 < 65536 ? f.n_blk + 1 : 65536);
+    hipLaunchKernelGGL(FlowClearKernel, dim3(grid), dim3(block), 0, st, f);
+    hipLaunchKernelGGL(FlowInsertKernel, dim3(grid_b), dim3(block), 0, st, f);
+    hipLaunchKernelGGL(FlowFlagKernel, dim3(grid_b), dim3(block), 0, st, f);
+    hipLaunchKernelGGL(FlowScanKernel, dim3(1), dim3(1024), 0, st, f);
+    hipLaunchKernelGGL(FlowEmitKernel, dim3(grid_b), dim3(block), 0, st, f);
     // 3. res_n_id, edge_index
     hipLaunchKernelGGL(FlowIndexKernel, dim3(grid), dim3(block), 0, st, f);
     EG_HIP(hipGetLastError());
@@ -394,6 +576,13 @@ int euler_gpu_full_blocks(const euler_gpu_graph* g, void* stream, const uint64_t
   }
   hipLaunchKernelGGL(FlowInitKernel, dim3(1), dim3(1), 0, st, counts_dev, (uint32_t)n);
   const uint64_t* n_id = roots_dev;
+  unsigned long long* dense_min = nullptr;
+  uint32_t* dense_rank = nullptr;
+  uint32_t epoch0 = 0;
+  {
+    const int rcd = FlowDenseTable(g, st, layers, &dense_min, &dense_rank, &epoch0);
+    if (rcd != EULER_GPU_OK) return rcd;
+  }
   uint32_t* overflow = counts_dev + 2 * layers + 1;
   const int block = 256;
   for (int32_t h = 0; h < layers; ++h) {
@@ -415,16 +604,19 @@ int euler_gpu_full_blocks(const euler_gpu_graph* g, void* stream, const uint64_t
     ff.m_nb = counts_dev + layers + 1 + h; ff.overflow = overflow;
     ff.cap_n = cap_n; ff.cap_e = cap_e; ff.hop = h;
     FlowHop f{};
+    f.g = g->view; f.dense_min = dense_min; f.dense_rank = dense_rank;
+    f.epoch_hi = (unsigned long long)(uint32_t)~(epoch0 + (uint32_t)h) << 32;
     f.t.keys = (unsigned long long*)p;  p += Al((tcap + 1) * 8);
     f.t.minpos = (uint32_t*)p;          p += Al((tcap + 1) * 4);
     f.t.rank = (int32_t*)p;             p += Al((tcap + 1) * 4);
     f.t.mask = tcap - 1;
     f.slot_of = (uint32_t*)p;           p += Al((size_t)cap_m * 4);
-    f.is_first = (uint32_t*)p;          p += Al(((size_t)cap_m + 1) * 4);
-    f.rank = (uint32_t*)p;              p += Al(((size_t)cap_m + 1) * 4);
+    f.blk_cnt = (uint32_t*)p;           p += Al(((size_t)cap_m + 1) * 4);
+    f.blk_off = (uint32_t*)p;           p += Al(((size_t)cap_m + 1) * 4);
+    f.n_blk = (cap_m + kFlowChunk - 1) / kFlowChunk;
     void* scan_tmp = p;
     size_t scan_bytes = 0, scan2 = 0;
-    EG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, f.is_first, f.rank, (int)(cap_m + 1), st));
+    EG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, f.blk_cnt, f.blk_off, (int)(f.n_blk + 1), st));
     EG_HIP(hipcub::DeviceScan::ExclusiveScan(nullptr, scan2, ff.lens, ff.offs, SatAdd(), 0u, (int)(cap_n + 1), st));
     // 1. the rows of the layer's nodes: lengths -> offsets -> the hop's neighbour list
     hipLaunchKernelGGL(FlowFullCountKernel, dim3(GridFor(cap_n + 1, block)), dim3(block), 0, st, ff);
@@ -434,18 +626,18 @@ int euler_gpu_full_blocks(const euler_gpu_graph* g, void* stream, const uint64_t
       hipLaunchKernelGGL(FlowFullFillKernel, dim3(GridFor(cap_e, block)), dim3(block), 0, st, ff);
     // 2. first-occurrence unique of [nb | n_id], 3. res_n_id / edge_index - the kernels of
     // the Sage flow with the list length and the edge sources read from the device
-    EG_HIP(hipMemsetAsync(f.t.keys, 0xFF, (tcap + 1) * 8, st));
-    EG_HIP(hipMemsetAsync(f.t.minpos, 0xFF, (tcap + 1) * 4, st));
     f.nb = ff.nb; f.n_id = n_id; f.cnt = counts_dev + h; f.cnt_out = counts_dev + h + 1;
     f.m_nb_dev = ff.m_nb; f.nb_src = ff.nb_src;
     f.count = 0; f.self_loops = add_self_loops ? 1 : 0; f.cap_m = cap_m;
     f.new_n_id = n_id_dev[h]; f.inv = edge_dst_dev[h]; f.edge_src = edge_src_dev[h];
     f.res_n_id = res_n_id_dev[h];
     const int grid = GridFor(cap_m + 1, block);
-    hipLaunchKernelGGL(FlowInsertKernel, dim3(grid), dim3(block), 0, st, f);
-    hipLaunchKernelGGL(FlowFlagKernel, dim3(grid), dim3(block), 0, st, f);
-    EG_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, f.is_first, f.rank, (int)(cap_m + 1), st));
-    hipLaunchKernelGGL(FlowEmitKernel, dim3(grid), dim3(block), 0, st, f);
+    const int grid_b = (int)(f.n_blk + 1 < 65536 ? f.n_blk + 1 : 65536);
+    hipLaunchKernelGGL(FlowClearKernel, dim3(grid), dim3(block), 0, st, f);
+    hipLaunchKernelGGL(FlowInsertKernel, dim3(grid_b), dim3(block), 0, st, f);
+    hipLaunchKernelGGL(FlowFlagKernel, dim3(grid_b), dim3(block), 0, st, f);
+    hipLaunchKernelGGL(FlowScanKernel, dim3(1), dim3(1024), 0, st, f);
+    hipLaunchKernelGGL(FlowEmitKernel, dim3(grid_b), dim3(block), 0, st, f);
     hipLaunchKernelGGL(FlowIndexKernel, dim3(grid), dim3(block), 0, st, f);
     EG_HIP(hipGetLastError());
     n_id = n_id_dev[h];

@@ -231,6 +231,7 @@ void DestroyGraph(euler_gpu_graph* g) {
   (void)hipSetDevice(g->device);
   for (void* p : g->allocations) (void)hipFree(p);
   for (auto& kv : g->ws) (void)hipFree(kv.second.first);
+  for (auto& kv : g->flow_tables) (void)hipFree(kv.second.p);
   delete g;
 }
 

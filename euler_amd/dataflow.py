@@ -125,8 +125,8 @@ class SageDataFlow(UniqueDataFlow):
                 raise
             return super(SageDataFlow, self).produce_subgraph(n_id)
         data_flow = DataFlow(n_id)
-        for new_n_id, res_n_id, edge_src, edge_dst in blocks:
-            data_flow.append(new_n_id, res_n_id, None, torch.stack([edge_src, edge_dst], 0))
+        for new_n_id, res_n_id, _edge_src, _edge_dst, edge_index in blocks:
+            data_flow.append(new_n_id, res_n_id, None, edge_index)
         return data_flow
 
     def get_neighbors(self, n_id):

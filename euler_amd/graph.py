@@ -558,7 +558,8 @@ class Graph:
         """The whole SageDataFlow (tf_euler/python/dataflow/sage_dataflow.py +
         UniqueDataFlow.produce_subgraph) as ONE enqueue, no host round trip between
         the hops (euler_gpu_sage_blocks).  Returns (blocks, counts): blocks[h] =
-        (n_id, res_n_id, edge_src, edge_dst) and counts = the layer sizes - sliced to
+        (n_id, res_n_id, edge_src, edge_dst, edge_index = the two as rows of one tensor) and
+        counts = the layer sizes - sliced to
         their true sizes after one read of the counts when sync is True, else padded
         to the worst case with `counts` left on the device (uint32 [layers + 1])."""
         nodes = _as_i64_cuda(nodes, self.device).reshape(-1)
@@ -574,8 +575,11 @@ class Graph:
         dev = self.device
         n_ids = [torch.empty(max(caps[h + 1], 1), dtype=torch.int64, device=dev) for h in range(layers)]
         res = [torch.empty(max(caps[h], 1), dtype=torch.int64, device=dev) for h in range(layers)]
-        esrc = [torch.empty(max(caps[h + 1], 1), dtype=torch.int64, device=dev) for h in range(layers)]
-        edst = [torch.empty(max(caps[h + 1], 1), dtype=torch.int64, device=dev) for h in range(layers)]
+        # edge_src / edge_dst of a hop are the two rows of ONE [2, cap] tensor: the block's
+        # edge_index is then a view of it ([:, :e]) instead of a stacked copy
+        eidx = [torch.empty((2, max(caps[h + 1], 1)), dtype=torch.int64, device=dev) for h in range(layers)]
+        esrc = [t[0] for t in eidx]
+        edst = [t[1] for t in eidx]
         counts = torch.zeros(layers + 1, dtype=torch.int32, device=dev)
         ws = torch.empty(max(int(lib().euler_gpu_sage_blocks_workspace(n, fan_p, layers)), 16),
                          dtype=torch.uint8, device=dev)
@@ -586,12 +590,12 @@ class Graph:
                 et_p, k, fan_p, layers, int(default_node), 1 if add_self_loops else 0, _ptr(ws),
                 arr(n_ids), arr(res), arr(esrc), arr(edst), _ptr(counts)))
         if not sync:
-            return list(zip(n_ids, res, esrc, edst)), counts
+            return list(zip(n_ids, res, esrc, edst, eidx)), counts
         cnt = [int(c) for c in counts.cpu().tolist()]          # the one host read
         blocks = []
         for h in range(layers):
             e = cnt[h] * int(fanouts[h]) + (cnt[h] if add_self_loops else 0)
-            blocks.append((n_ids[h][:cnt[h + 1]], res[h][:cnt[h]], esrc[h][:e], edst[h][:e]))
+            blocks.append((n_ids[h][:cnt[h + 1]], res[h][:cnt[h]], esrc[h][:e], edst[h][:e], eidx[h][:, :e]))
         return blocks, cnt
 
     def full_blocks(self, nodes, edge_types, edge_caps, add_self_loops=True, with_types=False):
