@@ -193,7 +193,7 @@ SIGNATURES = {
                                                         C.c_int32, C.c_int32, vp, vp, vp,
                                                         C.c_int32, f32p,
                                                         C.POINTER(C.c_int64)]),
-    "euler_gpu_node2vec_step": (C.c_int, [vp, C.c_uint64, C.c_uint32, C.c_int64, vp, vp, vp, vp,
+    "euler_gpu_node2vec_step": (C.c_int, [vp, C.c_uint64, C.c_uint32, C.c_int64, vp, vp, vp, vp, C.c_int64,
                                           vp, vp, vp, vp, C.c_float, C.c_float, C.c_int64, vp]),
     "euler_gpu_sample_fanout_with_feature": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp, C.c_int64,
                                                        i32p, C.c_int32, i32p, C.c_int32, C.c_int64,

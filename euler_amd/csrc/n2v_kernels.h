@@ -158,6 +158,12 @@ constexpr int kN2vMaxSeg = kMaxListedTypes;
 
 struct N2vList {           // one neighbour list = listed type segments of a row
   int64_t row_ptr;         // row start in nbr / prefix_w
+  // where the list lives: the graph's arrays (ids = nbr + row_ptr, nw = prefix_w + row_ptr:
+  // the weights are differences of the running sums), or a row FETCHED from its owner shard
+  // (euler_gpu_node2vec_step: ids and the weights themselves, w != nullptr)
+  const uint64_t* ids;
+  const float* nw;
+  const float* w;
   int32_t n_seg;
   int32_t total;           // entries
   int32_t seg_b[kN2vMaxSeg];
@@ -177,9 +183,11 @@ struct alignas(16) N2vLds {
 __device__ __forceinline__ void N2vBuildList(N2vList* L, const GraphView& g, int64_t row,
                                              const int32_t* et, int32_t k) {
   L->n_seg = 0; L->total = 0; L->row_ptr = 0;
+  L->ids = g.nbr; L->nw = g.prefix_w; L->w = nullptr;
   if (row < 0) return;
   const RowMeta m = LoadRowMeta(g, row);
   L->row_ptr = m.row_ptr;
+  L->ids = g.nbr + m.row_ptr; L->nw = g.prefix_w + m.row_ptr;
   for (int32_t x = 0; x < k; ++x) {
     const int32_t t = et[x];
     if (t < 0 || t >= g.T) continue;
@@ -193,10 +201,37 @@ __device__ __forceinline__ void N2vBuildList(N2vList* L, const GraphView& g, int
   }
 }
 
+// the running sums of a step never decrease: the graph says so, or - lists fetched from their
+// owners - a pass over the fetched weights found none negative (euler_gpu_node2vec_step)
+__device__ __forceinline__ bool N2vMonotone(const WalkArgs& a) {
+  return a.nonneg_flag != nullptr ? *a.nonneg_flag != 0 : a.g.monotone != 0;
+}
+
+// A fetched row (packed set: row r = entries [idx[2 r], idx[2 r + 1]) of ids / w - the GQL
+// result's (begin, end) pairs); row < 0: empty.
+__device__ __forceinline__ void N2vBuildListFetched(N2vList* L, const int32_t* idx,
+                                                    const uint64_t* ids, const float* w, int32_t row) {
+  L->n_seg = 0; L->total = 0; L->row_ptr = 0;
+  L->ids = ids; L->nw = nullptr; L->w = w;
+  if (row < 0 || idx == nullptr) return;
+  const int32_t b = idx[2 * row], len = idx[2 * row + 1] - b;
+  if (len <= 0) return;
+  L->row_ptr = b;
+  L->ids = ids + b;
+  L->w = w != nullptr ? w + b : nullptr;
+  L->n_seg = 1; L->seg_b[0] = 0; L->seg_len[0] = len; L->total = len;
+}
+
+// weight of the entry at row-relative position ph
+__device__ __forceinline__ float N2vWeightAt(const N2vList& L, int32_t ph) {
+  if (L.w != nullptr) return L.w[ph];
+  return __fsub_rn(L.nw[ph], ph == 0 ? 0.f : L.nw[ph - 1]);
+}
+
 // The child list IS the parent list (the walker took a self loop and the steps list the
 // same types): the two cursors then move in lockstep and every child is common.
 __device__ __forceinline__ bool N2vSameLists(const N2vList& c, const N2vList& p) {
-  if (c.total == 0 || c.total != p.total || c.row_ptr != p.row_ptr || c.n_seg != p.n_seg)
+  if (c.total == 0 || c.total != p.total || c.ids != p.ids || c.n_seg != p.n_seg)
     return false;
   for (int32_t x = 0; x < c.n_seg; ++x)
     if (c.seg_b[x] != p.seg_b[x] || c.seg_len[x] != p.seg_len[x]) return false;
@@ -377,9 +412,22 @@ __device__ __forceinline__ N2vVec N2vLoadVec(const WalkArgs& a, const N2vList& L
                                              int32_t jl) {
   N2vVec v;
   v.live = 0;
-  const float* c_nw = a.g.prefix_w + L.row_ptr;
-  const uint64_t* c_nbr = a.g.nbr + L.row_ptr;
-  if (L.n_seg == 1 && jl + kN2vR <= nc) {
+  const float* c_nw = L.nw;
+  const uint64_t* c_nbr = L.ids;
+  if (L.w != nullptr) {
+    // a fetched row: the weights themselves
+#pragma unroll
+    for (int r = 0; r < kN2vR; ++r) {
+      v.cid[r] = 0;
+      v.w[r] = 0.f;
+      if (jl + r < nc) {
+        const int32_t ph = N2vPhys(L, jl + r);
+        v.cid[r] = (int64_t)c_nbr[ph];
+        v.w[r] = L.w[ph];
+        v.live |= 1u << r;
+      }
+    }
+  } else if (L.n_seg == 1 && jl + kN2vR <= nc) {
     // one listed type (or one non-empty): the entries are adjacent in the row
     const int32_t ph = L.seg_b[0] + jl;
     float prev = ph == 0 ? 0.f : c_nw[ph - 1];
@@ -430,7 +478,7 @@ struct N2vCursor {
 __device__ __forceinline__ uint32_t N2vEventsWave(const WalkArgs& a, const N2vList& P, int lane,
                                                   int32_t np, const N2vVec& e, N2vCursor* c,
                                                   int32_t* events_out) {
-  const uint64_t* p_nbr = a.g.nbr + P.row_ptr;
+  const uint64_t* p_nbr = P.ids;
   int32_t k = c->k;
   uint32_t keep = 0;
   int res_lane = -1, res_r = -1;    // entries up to (res_lane, res_r) are resolved
@@ -538,7 +586,7 @@ __device__ __forceinline__ bool N2vStepParallel(const WalkArgs& a, N2vLds& S, in
   const double r = ScaleDraw(u, 0.f, total);
   WaveSync();
   int32_t first = 0;
-  if (a.g.monotone && a.p > 0.f && a.q > 0.f) {
+  if (N2vMonotone(a) && a.p > 0.f && a.q > 0.f) {
     first = n_slots;
     for (int32_t base = 0; base < n_slots; base += 64) {
       const int32_t idx = base + lane;
@@ -564,7 +612,7 @@ __device__ __forceinline__ bool N2vStepParallel(const WalkArgs& a, N2vLds& S, in
     }
   }
   // no interval holds r (total == 0): RandomSelect's fall-through ends on the last element
-  if (!found) result = (int64_t)(a.g.nbr + S.child.row_ptr)[N2vPhys(S.child, nc - 1)];
+  if (!found) result = (int64_t)S.child.ids[N2vPhys(S.child, nc - 1)];
   WaveSync();          // the checkpoints share LDS with the next step's lists
   *out = result;
   return true;
@@ -576,9 +624,8 @@ __device__ __forceinline__ int64_t N2vStepSequential(const WalkArgs& a, N2vLds& 
                                                      int64_t parent, int64_t walker,
                                                      int32_t step) {
   const int32_t nc = S.child.total, np = S.parent.total;
-  const float* c_nw = a.g.prefix_w + S.child.row_ptr;
-  const uint64_t* c_nbr = a.g.nbr + S.child.row_ptr;
-  const uint64_t* p_nbr = a.g.nbr + S.parent.row_ptr;
+  const uint64_t* c_nbr = S.child.ids;
+  const uint64_t* p_nbr = S.parent.ids;
   float total = 0.f;
   double r = 0.0;
   uint64_t last_id = 0;
@@ -597,7 +644,7 @@ __device__ __forceinline__ int64_t N2vStepSequential(const WalkArgs& a, N2vLds& 
         for (int32_t t = lane; t < c_have; t += 64) {
           const int32_t ph = N2vPhys(S.child, cj0 + t);
           S.c_id[t] = c_nbr[ph];
-          S.c_w[t] = __fsub_rn(c_nw[ph], ph == 0 ? 0.f : c_nw[ph - 1]);
+          S.c_w[t] = N2vWeightAt(S.child, ph);
         }
         need_c = false;
       }
@@ -767,7 +814,7 @@ __device__ __forceinline__ void N2vBigRound(const WalkArgs& a, N2vBigLds& S, int
                                             float (&d)[kN2vR], float* cin_out,
                                             int32_t* events_out) {
   const int tid = wv * 64 + lane;
-  const uint64_t* p_nbr = a.g.nbr + S.seq.parent.row_ptr;
+  const uint64_t* p_nbr = S.seq.parent.ids;
   uint32_t keep = same_lists ? e.live : 0u;
   int res_tid = -1, res_r = -1;
   int32_t events = 0;
@@ -961,7 +1008,7 @@ __global__ __launch_bounds__(64 * kN2vBigWaves) void N2vBigStepKernel(const Walk
       const double r = ScaleDraw(u, 0.f, total);
       __syncthreads();
       int32_t first = 0;
-      if (a.g.monotone && a.p > 0.f && a.q > 0.f) {
+      if (N2vMonotone(a) && a.p > 0.f && a.q > 0.f) {
         first = n_slots;
         for (int32_t base = 0; base < n_slots; base += 64) {
           const int32_t idx = base + lane;
@@ -985,7 +1032,7 @@ __global__ __launch_bounds__(64 * kN2vBigWaves) void N2vBigStepKernel(const Walk
         }
       }
       // no interval holds r (total == 0): RandomSelect's fall-through ends on the last element
-      if (!found) result = (int64_t)(a.g.nbr + S.seq.child.row_ptr)[N2vPhys(S.seq.child, nc - 1)];
+      if (!found) result = (int64_t)S.seq.child.ids[N2vPhys(S.seq.child, nc - 1)];
     }
     if (threadIdx.x == 0) a.out[i * L + s + 1] = result;
   }

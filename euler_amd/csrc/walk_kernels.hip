@@ -440,6 +440,8 @@ struct WalkArgs {
   // rounded w / p); 0 = divide
   float inv_p;
   float inv_q;
+  const int32_t* nonneg_flag;   // not null (node2vec step on fetched lists): device word, 1 = no fetched
+                                // weight is negative or NaN
 #ifdef EULER_GPU_MEASURE
   int32_t ablate;         // measurement builds only (tuning key 2): 8 = random_walk keeps its path to itself
 #endif
@@ -965,6 +967,41 @@ __global__ void WalkAlgoBytesKernel(const WalkBytesArgs a, double* acc) {
   if ((threadIdx.x & 63) == 0 && b != 0.0) atomicAdd(acc, b);
 }
 
+// The same step by the whole wave (n2v_kernels.h: the two-cursor walk with integer running
+// sums), one wave per walker, the lists read from the fetched rows: what the single-GPU
+// walk runs per walker and step, so the sharded walk's step costs what a step costs there
+// (the lane-per-walker loop above: 20 K walkers x 10 steps on hub rows 1.1 s).
+__global__ __launch_bounds__(256) void N2vNonNegKernel(const float* w, int64_t n, int32_t* flag) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  bool bad = false;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) bad = bad || !(w[i] >= 0.f);
+  if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) *flag = 0;
+}
+
+template <bool PAR>
+__global__ __launch_bounds__(256, kWavesPerSimd) void Node2VecListWaveKernel(const WalkArgs a,
+                                                                             const N2vListArgs l) {
+  __shared__ N2vLds lds_all[4];
+  N2vLds& S = lds_all[threadIdx.x >> 6];
+  const int lane = threadIdx.x & 63;
+  const int64_t waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < l.n; i += waves) {
+    const int64_t parent = l.parent_ids[i];
+    WaveSync();
+    if (lane == 0) {
+      N2vBuildListFetched(&S.child, l.c_idx, l.c_ids, l.c_w, l.c_row[i]);
+      N2vBuildListFetched(&S.parent, l.p_idx, l.p_ids, nullptr, l.p_row != nullptr ? l.p_row[i] : -1);
+    }
+    WaveSync();
+    const int32_t nc = S.child.total;
+    int64_t sample_id = l.default_node;
+    bool done = false;
+    if (PAR && nc > 0) done = N2vStepParallel(a, S, lane, parent, i, 0, &sample_id);
+    if (nc > 0 && !done) sample_id = N2vStepSequential(a, S, lane, parent, i, 0);
+    if (lane == 0) l.out[i] = sample_id;
+  }
+}
+
 }  // namespace euler_gpu
 
 using namespace euler_gpu;
@@ -1117,7 +1154,7 @@ int euler_gpu_get_top_k_neighbor(const euler_gpu_graph* g, void* stream,
 // walker index, call_id - the single-GPU kernels' (Node2VecKernel above).
 int euler_gpu_node2vec_step(void* stream, uint64_t seed, uint32_t call_id, int64_t n,
                             const int32_t* c_row_dev, const int32_t* c_idx_dev,
-                            const uint64_t* c_ids_dev, const float* c_w_dev,
+                            const uint64_t* c_ids_dev, const float* c_w_dev, int64_t c_entries,
                             const int32_t* p_row_dev, const int32_t* p_idx_dev,
                             const uint64_t* p_ids_dev, const int64_t* parent_ids_dev,
                             float p, float q, int64_t default_node, int64_t* out_dev) {
@@ -1132,8 +1169,37 @@ int euler_gpu_node2vec_step(void* stream, uint64_t seed, uint32_t call_id, int64
   a.p_row = p_row_dev; a.p_idx = p_idx_dev; a.p_ids = p_ids_dev;
   a.parent_ids = parent_ids_dev; a.p = p; a.q = q; a.default_node = default_node;
   a.out = out_dev;
-  hipLaunchKernelGGL(Node2VecListStepKernel, dim3(GridFor(n, 256)), dim3(256), 0,
-                     (hipStream_t)stream, a);
+  if (c_entries < 0) return Fail(EULER_GPU_EINVAL, "node2vec_step: bad c_entries");
+  if (g_n2v_wave >= 2 && c_w_dev != nullptr && c_ids_dev != nullptr) {
+    // the wave kernels (tuning key 7: 2 or 3 = the whole wave walks, 1 = lane 0 walks LDS-staged
+    // lists, 0 = the lane-per-walker reference loop below)
+    WalkArgs w{};
+    w.seed = seed; w.call_id = call_id; w.n = n; w.default_node = default_node; w.p = p; w.q = q;
+    {
+      int ep = 0, eq = 0;
+      const bool p2 = p > 0.f && std::isfinite(p) && std::frexp(p, &ep) == 0.5f && ep > -100 && ep < 100;
+      const bool q2 = q > 0.f && std::isfinite(q) && std::frexp(q, &eq) == 0.5f && eq > -100 && eq < 100;
+      w.inv_p = p2 && q2 ? 1.0f / p : 0.f;
+      w.inv_q = p2 && q2 ? 1.0f / q : 0.f;
+    }
+    // are the running sums of a step monotone (no negative weight among the fetched ones)?
+    // The whole-wave path then re-runs only the chunks after a checkpoint (n2v_kernels.h).
+    int32_t* flag = nullptr;
+    EG_HIP(hipMallocAsync((void**)&flag, 16, (hipStream_t)stream));
+    EG_HIP(hipMemsetD32Async((hipDeviceptr_t)flag, 1, 1, (hipStream_t)stream));
+    if (c_entries > 0)
+      hipLaunchKernelGGL(N2vNonNegKernel, dim3(GridFor(c_entries, 256)), dim3(256), 0, (hipStream_t)stream,
+                         c_w_dev, c_entries, flag);
+    w.nonneg_flag = flag;
+    hipLaunchKernelGGL(Node2VecListWaveKernel<true>, dim3(GridFor(n * 64, 256)), dim3(256), 0,
+                       (hipStream_t)stream, w, a);
+    EG_HIP(hipGetLastError());
+    EG_HIP(hipFreeAsync(flag, (hipStream_t)stream));
+    return EULER_GPU_OK;
+  } else {
+    hipLaunchKernelGGL(Node2VecListStepKernel, dim3(GridFor(n, 256)), dim3(256), 0,
+                       (hipStream_t)stream, a);
+  }
   EG_HIP(hipGetLastError());
   return EULER_GPU_OK;
 }

@@ -352,6 +352,7 @@ def node2vec_step(seed, call_id, c_row, c_idx, c_ids, c_w, p_row, p_idx, p_ids, 
     with _on(c_row.device):
         check(lib().euler_gpu_node2vec_step(
             _stream(), int(seed), int(call_id), n, _ptr(c_row), _ptr(c_idx), _ptr(c_ids), _ptr(c_w),
+            int(c_w.numel()),
             _ptr(p_row) if p_row is not None else null,
             _ptr(p_idx) if p_row is not None else null,
             _ptr(p_ids) if p_row is not None else null,

@@ -611,14 +611,17 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
  * CompactWeightedCollection::Sample) on the lists the `v(nodes).outV(edge_types)` query
  * returned - no graph: on a sharded graph the requester calls this on fetched rows.
  * Walker i's child list is row c_row[i] of the packed rows (c_idx [rows, 2] int32 offsets,
- * c_ids, c_w), its parent's list row p_row[i] of (p_idx, p_ids) (p_row NULL on the first
+ * c_ids, c_w - c_entries ids / weights in all), its parent's list row p_row[i] of (p_idx,
+ * p_ids) (p_row NULL on the first
  * step: no parent lists yet), parent_ids[i] its previous node (the start node on the first
  * step).  out[i] = the next node, default_node for an empty child list.  RNG: domain WALK,
  * stream = walker index i, draw 0 of call_id (the single-GPU random_walk uses call_id +
- * step). */
+ * step).  One wave per walker runs the single-GPU walk's two-cursor merge with integer
+ * running sums (csrc/n2v_kernels.h) over the fetched rows; tuning key 7 = 0 selects the
+ * lane-per-walker reference loop. */
 int euler_gpu_node2vec_step(void* stream, uint64_t seed, uint32_t call_id, int64_t n,
                             const int32_t* c_row_dev, const int32_t* c_idx_dev,
-                            const uint64_t* c_ids_dev, const float* c_w_dev,
+                            const uint64_t* c_ids_dev, const float* c_w_dev, int64_t c_entries,
                             const int32_t* p_row_dev, const int32_t* p_idx_dev,
                             const uint64_t* p_ids_dev, const int64_t* parent_ids_dev,
                             float p, float q, int64_t default_node, int64_t* out_dev);

@@ -1775,6 +1775,47 @@ def test_sample_neighbor_sets_one_launch(EA, O, torch_cuda, big_pair):
     assert tuple(e[0].shape) == (3, 0, CNT)
 
 
+def test_node2vec_step_on_fetched_lists_wave_and_lane(EA, O, torch_cuda):
+    """euler_gpu_node2vec_step - the step of the SHARDED node2vec walk, on explicit lists
+    (random_walk_op.cc:83-168 on the rows `v(nodes).outV(...)` returned) - run by the wave
+    kernels of the single-GPU walk (tuning key 7 = 2, default) and by the lane-per-walker
+    reference loop (key 7 = 0): both == the single-GPU walk == the oracle, on hub rows of
+    thousands of neighbours (several chunks, checkpoints, parent cursor events), walkers that
+    share rows, unknown nodes and empty lists."""
+    torch = torch_cuda
+    from euler_amd import _lib, ops
+    L = _lib.lib()
+    ph = EA.synth_params(31, 3000, 900000, n_types=1, weighted=True)
+    po = O.SynthParams()
+    for f, _ in po._fields_:
+        setattr(po, f, getattr(ph, f))
+    G, OG = EA.Graph.synthetic(ph), O.OracleGraph(O.synth_csr(po))
+    q = np.concatenate([np.random.default_rng(4).integers(1, 3001, 1500), [0, 3001, 7, 7, 7]]).astype(np.int64)
+    qt = torch.as_tensor(q).cuda()
+    steps = 4
+    try:
+        for p_, q_ in ((0.25, 4.0), (3.0, 0.7)):
+            G.set_seed(5)
+            want = G.random_walk(qt, [[0]] * steps, p_, q_, 3001, call_id=77)
+            assert np.array_equal(t2n(want), OG.random_walk(5, 77, q, [[0]] * steps, steps, p_, q_, 3001))
+            for mode in (2, 0):
+                L.euler_gpu_set_tuning(7, mode)
+                cur = parent = qt
+                p_row = p_idx = p_ids = None
+                cols = [qt]
+                for s_ in range(steps):
+                    # one row per DISTINCT node + the row of every walker, as the sharded sampler fetches
+                    uq, inv = torch.unique(cur, return_inverse=True)
+                    idx, ids, w, _t = G.get_full_neighbor(uq, [0])
+                    nxt = ops.node2vec_step(5, 77 + s_, inv, idx, ids, w, p_row, p_idx, p_ids, parent, p_, q_, 3001)
+                    parent, cur = cur, nxt
+                    p_row, p_idx, p_ids = inv, idx, ids
+                    cols.append(cur)
+                assert torch.equal(torch.stack(cols, 1), want), (p_, q_, mode)
+    finally:
+        L.euler_gpu_set_tuning(7, 2)
+
+
 def test_random_walk_over_merged_walkers(EA, O, torch_cuda, big_pair):
     """DeepWalk over groups of merged walkers (walk_kernels.hip: CwSampleKernel /
     CwNumberKernel / CwChainKernel / CwTransposeKernel, tuning key 38): walkers that meet on a node in a step

@@ -170,6 +170,23 @@ def _worker_body(rank, world, port, partitions):
     assert torch.equal(got, want)
     assert np.array_equal(t2n(got)[:32], OG.random_walk(5, 200, t2n(starts)[:32], etn, 8, 0.25,
                                                        4.0, N + 1))
+
+    # the record DESIGN.md quotes: 20 000 walkers x 10 node2vec steps through the sharded sampler
+    # (world ranks on ONE GPU, host-staged exchange), wave kernels on the fetched rows
+    import time as _time
+    etn10 = [[0]] * 10
+    S.random_walk(starts[:20000], etn10, 0.25, 4.0, default_node=N + 1, call_id=300)
+    torch.cuda.synchronize(); dist.barrier()
+    _t0 = _time.perf_counter()
+    got10 = S.random_walk(starts[:20000], etn10, 0.25, 4.0, default_node=N + 1, call_id=300)
+    torch.cuda.synchronize(); dist.barrier()
+    _ms = (_time.perf_counter() - _t0) * 1e3
+    _same(got10, G_full.random_walk(starts[:20000], etn10, 0.25, 4.0, N + 1, call_id=300), "node2vec 20K x 10")
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "r4_sharded_n2v_world%d_rank%d.txt" % (world, rank)), "w") as fo:
+            fo.write("sharded node2vec (p = 0.25, q = 4), %d ranks on one GPU, 20000 walkers x 10 steps per rank: "
+                     "%.2f ms\n" % (world, _ms))
     # dedup="ops" (ID_UNIQUE / ID_SPLIT / merge_rows / gather as separate kernels)
     S_ops = gpu_sharded_sampler(G_shard, partitions=partitions, dedup="ops")
     got = S_ops.sample_fanout(roots[:5000], et2, [6, 4], N + 1, call_id=13)
