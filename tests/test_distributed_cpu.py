@@ -126,6 +126,8 @@ def _worker(rank, world, port, partitions, out_dir):
         m = ids_.shape[0]
         cols = 3 if len(edge_types) == 1 else 4        # one listed type: no type column
         rows = torch.zeros((m, (cols * count + 3) & ~1), dtype=torch.int32)
+        if m == 0:                # a shard nobody asked anything (world 8, small batches)
+            return rows
         rows[:, :2 * count] = ids_.reshape(m, count).contiguous().view(torch.int32)
         rows[:, 2 * count:3 * count] = w_.reshape(m, count).contiguous().view(torch.int32)
         if cols == 4:
@@ -183,7 +185,9 @@ def _worker(rank, world, port, partitions, out_dir):
     S_two.front_begin_fn = lambda ids_, parts, shards, rm, rg: dedup_split_fn(ids_, parts, shards,
                                                                             rm, rg)
     S_two.front_end_fn = lambda token: token
-    batches = [roots, roots[::2], roots[:0] if rank == 0 else roots[:7], roots[5:90], roots[::3]]
+    # (world 8: ranks 0, 3 and 6 bring an EMPTY batch to the third minibatch - every rank must still
+    # issue the same sequence of collectives)
+    batches = [roots, roots[::2], roots[:0] if rank % 3 == 0 else roots[:7], roots[5:90], roots[::3]]
     et_i, cnt_i = [[0, 1, 2], [0, 1, 2]], [4, 3]
     for in_flight in (2, 3):
         got = run_interleaved(lambda j: S_two.sample_fanout_steps(
@@ -418,7 +422,7 @@ def _worker(rank, world, port, partitions, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,partitions", [(2, 2), (2, 8), (3, 6)])
+@pytest.mark.parametrize("world,partitions", [(2, 2), (2, 8), (3, 6), (8, 8)])
 def test_sharded_fanout_matches_unsharded_gloo(O, tmp_path, world, partitions):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, partitions, str(tmp_path)), nprocs=world,
