@@ -953,8 +953,9 @@ def run_hashed_leg(args):
     weighted edges, but every node known by an arbitrary u64 id (hash id map instead of
     row = id - 1) and two edge-type groups per node (Cora's train / train_removed,
     tf_euler/python/dataset/cora.py:36-52); the fanout lists one type per hop, as GraphSAGE
-    does.  This is SampleFanoutLocalKernel (the general build of the one-kernel step), which
-    the headline's plain graph never reaches."""
+    does.  This is the general form of the one-kernel step (fanout_local.h: WbSamplePairG - hash
+    id map, segment limits out of the row's records), which the headline's plain graph never
+    reaches."""
     import euler_amd
     from euler_amd import _lib
     L = _lib.lib()
@@ -1024,7 +1025,8 @@ def run_hashed_leg(args):
            "ms_per_step": elapsed / steps * 1e3, "one_stream_ms_per_step": round(ms_alone, 4),
            "roofline_frac": round(algo / (ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
            "algorithmic_bytes_per_launch": algo, "parity_checked": int(64 * 275),
-           "kernel": "SampleFanoutLocalKernel (general build: hash id map, type groups)",
+           "kernel": "SampleFanoutLeanKernel<.., WB = 2> (the one-kernel step's general form: hash id map, "
+                     "edge-type groups, weight-bucket index)",
            "graph_build_s": round(build_s, 2), "graph_bytes": G.device_bytes,
            "workload": "the metric step on %d nodes / %d edges with hashed u64 ids and 2 edge-type "
                        "groups per node, one listed type per hop, %d roots per step, two streams"

@@ -677,6 +677,85 @@ __device__ __forceinline__ void WbSamplePair(const GraphView& g, const WbRec rec
   }
 }
 
+// The same pair of draws on ANY graph the weight-bucket index serves - several edge-type
+// groups per node, hashed ids - for one listed type: the segment's limits and the row's first
+// block come out of the row's two small records (row_meta + wbg), read side by side.
+struct WbSeg {
+  uint32_t wb_lo, row_deg;      // the row: first block, edges (the buckets are the ROW's)
+  uint32_t lo, deg;             // the listed type's segment: first flat edge, edges
+  float row_total, lim_b, lim_e;
+  int64_t row;                  // for the cold path (which reloads what it needs)
+};
+
+__device__ __forceinline__ void LoadWbSeg(const GraphView& g, uint64_t node, int32_t t, WbSeg* s) {
+  s->wb_lo = 0; s->row_deg = 0; s->lo = 0; s->deg = 0; s->row_total = 0.f; s->lim_b = 0.f; s->lim_e = 0.f;
+  s->row = FindRow(g, node);
+  if (s->row < 0 || t < 0 || t >= g.T) return;
+  const uint8_t* rec = g.row_meta + s->row * (int64_t)g.meta_stride;
+  const uint8_t* wrec = g.wbg + s->row * (int64_t)g.wbg_stride;
+  const int64_t row_ptr = *reinterpret_cast<const int64_t*>(rec);
+  const int32_t* te = reinterpret_cast<const int32_t*>(rec + 8);
+  const float* lim = reinterpret_cast<const float*>(wrec + 4);
+  const int32_t b = t == 0 ? 0 : te[t - 1], e = te[t];
+  s->wb_lo = *reinterpret_cast<const uint32_t*>(wrec);
+  s->row_deg = (uint32_t)te[g.T - 1];
+  s->row_total = lim[g.T - 1];
+  s->lim_e = lim[t];
+  s->lim_b = t == 0 ? 0.f : lim[t - 1];
+  s->lo = (uint32_t)(row_ptr + b);
+  s->deg = e > b ? (uint32_t)(e - b) : 0u;
+}
+
+template <bool TWO = true>
+__device__ __forceinline__ void WbSamplePairG(const GraphView& g, const WbSeg sg, const int32_t t,
+                                              const bool live, const double u0, const double u1,
+                                              uint64_t id[2], float w[2], uint32_t m[2]) {
+  // r = u * (limit_end - limit_begin) + limit_begin as the reference rounds it (ScaleDraw)
+  const double span = (double)__fsub_rn(sg.lim_e, sg.lim_b);
+  const double r0 = __dadd_rn(__dmul_rn(u0, span), (double)sg.lim_b);
+  const double r1 = __dadd_rn(__dmul_rn(u1, span), (double)sg.lim_b);
+  bool cold0 = live && !((double)sg.lim_e > r0);
+  bool cold1 = TWO && live && !((double)sg.lim_e > r1);
+  const float f0 = WbFloorToFloat(r0), f1 = WbFloorToFloat(r1);
+  const uint32_t nbk = WbBuckets(sg.row_deg);
+  uint32_t j0 = 0u, j1 = 0u;
+  if (nbk > 1u) {
+    const float scale = WbScale(nbk, sg.row_total);
+    j0 = WbBucketOf(f0, nbk, scale);
+    j1 = WbBucketOf(f1, nbk, scale);
+  }
+  const EdgeBlock* b0 = g.wb + sg.wb_lo + j0;
+  const EdgeBlock* b1 = g.wb + sg.wb_lo + (TWO ? j1 : j0);
+  const WbKeys k0 = WbLoadKeys(b0);
+  WbKeys k1 = k0;
+  if (TWO) k1 = WbLoadKeys(b1);
+  id[0] = 0; id[1] = 0; w[0] = 0.f; w[1] = 0.f; m[0] = sg.lo; m[1] = sg.lo;
+  const int32_t i0 = WbPickKeys(k0, f0, &w[0], &m[0]);
+  const int32_t i1 = TWO ? WbPickKeys(k1, f1, &w[1], &m[1]) : 0;
+  const bool hot0 = live && !cold0 && i0 >= 0;
+  const bool hot1 = TWO && live && !cold1 && i1 >= 0;
+  if (hot0) id[0] = b0->nbr[i0];
+  if (hot1) id[1] = b1->nbr[i1];
+  cold0 = live && !hot0;
+  cold1 = TWO && live && !hot1;
+  if (!TWO) { id[1] = 0; w[1] = 0.f; m[1] = sg.lo; }
+  if (__ballot(cold0 || cold1) != 0ull) {
+#pragma nounroll
+    for (int s = 0; s < (TWO ? 2 : 1); ++s) {
+      if (s == 0 ? cold0 : cold1) {
+        const RowMeta rm = LoadRowMeta(g, sg.row);
+        const float* nw = g.prefix_w + rm.row_ptr;
+        const int32_t b = t == 0 ? 0 : rm.type_end[t - 1];
+        const uint32_t mid = (uint32_t)RandomSelect(nw, (uint64_t)b, (uint64_t)(rm.type_end[t] - 1), s == 0 ? u0 : u1);
+        const uint64_t ci = g.nbr[rm.row_ptr + mid];
+        const float cw = __fsub_rn(nw[mid], mid == 0u ? 0.f : nw[mid - 1]);
+        if (s == 0) { id[0] = ci; w[0] = cw; m[0] = (uint32_t)(rm.row_ptr + mid); }
+        else { id[1] = ci; w[1] = cw; m[1] = (uint32_t)(rm.row_ptr + mid); }
+      }
+    }
+  }
+}
+
 struct FanoutLeanLds {
   uint32_t o_sid, o_c1, o_slotid, o_mask, o_sw, o_w1, o_st, o_slot, o_rvalid, bytes;
 };
@@ -703,8 +782,10 @@ __host__ __device__ inline FanoutLeanLds FanoutLeanLayout(int32_t gr, int32_t c1
 // with ~17 registers spilled - 140 MB of scratch stores and as much again re-read per
 // step, profiles/r3_fl_v2_pmc.json).  a.dbg (measurement only): per tile, s_memtime at
 // the phase boundaries.
-// WB: draws through the weight-bucket index (WbSamplePair) instead of the pivot levels.
-template <bool WIDE, int WPS, bool UNIFORM = false, bool WB = false>
+// WB: 1 = draws through the weight-bucket index (WbSamplePair) instead of the pivot levels;
+// 2 = the same on graphs with several edge-type groups / hashed ids (WbSamplePairG: one listed
+// type per hop, no neighbour id 0).
+template <bool WIDE, int WPS, bool UNIFORM = false, int WB = 0>
 __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
     const FanoutLocalArgs a) {
   extern __shared__ __align__(16) uint8_t fl_smem[];
@@ -755,23 +836,32 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
       float total = 0.f;
       uint64_t node = 0;
       WbRec wr{0u, 0u, 0u, 0.f};
+      WbSeg ws;
+      if (WB == 2) { ws.wb_lo = 0; ws.row_deg = 0; ws.lo = 0; ws.deg = 0; ws.row_total = 0.f; ws.lim_b = 0.f; ws.lim_e = 0.f; ws.row = -1; }
       if (in) {
         node = a.roots[r0 + q];
-        const int64_t row = LeanFindRow(g, node);
-        if (row >= 0) {
-          if (WB) {
-            wr = g.wrec[row];
-            lo = wr.lo; deg = (int32_t)wr.deg; total = wr.total;
-          } else {
-            const uint4 rec = *reinterpret_cast<const uint4*>(g.row_meta + row * 16);
-            lo = rec.x; deg = (int32_t)rec.z; total = __uint_as_float(rec.w);
+        if (WB == 2) {
+          LoadWbSeg(g, node, a.t1, &ws);
+          lo = ws.lo; deg = (int32_t)ws.deg;
+        } else {
+          const int64_t row = LeanFindRow(g, node);
+          if (row >= 0) {
+            if (WB) {
+              wr = g.wrec[row];
+              lo = wr.lo; deg = (int32_t)wr.deg; total = wr.total;
+            } else {
+              const uint4 rec = *reinterpret_cast<const uint4*>(g.row_meta + row * 16);
+              lo = rec.x; deg = (int32_t)rec.z; total = __uint_as_float(rec.w);
+            }
           }
         }
       }
       const bool live = in && deg > 0 && !EG_FL_ABLATE(a, 8);
       const Philox4 pb = RngBlock(a.seed, tile_call, kDomainNeighbor, node, jp);
       uint64_t id[2]; float w[2]; uint32_t m[2];
-      if (WB) WbSamplePair(g, wr, live, UnitFromWords(pb.w[0], pb.w[1]),
+      if (WB == 2) WbSamplePairG(g, ws, a.t1, live, UnitFromWords(pb.w[0], pb.w[1]),
+                                 UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
+      else if (WB) WbSamplePair(g, wr, live, UnitFromWords(pb.w[0], pb.w[1]),
                                 UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
       else if (UNIFORM) LeanSamplePairUniform(g, lo, deg, total, live, UnitFromWords(pb.w[0], pb.w[1]),
                                          UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
@@ -873,23 +963,32 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
         float total = 0.f;
         uint64_t node = 0;
         WbRec wr{0u, 0u, 0u, 0.f};
+        WbSeg ws;
+        if (WB == 2) { ws.wb_lo = 0; ws.row_deg = 0; ws.lo = 0; ws.deg = 0; ws.row_total = 0.f; ws.lim_b = 0.f; ws.lim_e = 0.f; ws.row = -1; }
         if (in) {
           node = s_slotid[s0 + sl];
-          const int64_t row = LeanFindRow(g, node);
-          if (row >= 0) {
-            if (WB) {
-              wr = g.wrec[row];
-              lo = wr.lo; deg = (int32_t)wr.deg; total = wr.total;
-            } else {
-              const uint4 rec = *reinterpret_cast<const uint4*>(g.row_meta + row * 16);
-              lo = rec.x; deg = (int32_t)rec.z; total = __uint_as_float(rec.w);
+          if (WB == 2) {
+            LoadWbSeg(g, node, a.t2, &ws);
+            lo = ws.lo; deg = (int32_t)ws.deg;
+          } else {
+            const int64_t row = LeanFindRow(g, node);
+            if (row >= 0) {
+              if (WB) {
+                wr = g.wrec[row];
+                lo = wr.lo; deg = (int32_t)wr.deg; total = wr.total;
+              } else {
+                const uint4 rec = *reinterpret_cast<const uint4*>(g.row_meta + row * 16);
+                lo = rec.x; deg = (int32_t)rec.z; total = __uint_as_float(rec.w);
+              }
             }
           }
         }
         const bool live = in && deg > 0 && !EG_FL_ABLATE(a, 2);
         const Philox4 pb = RngBlock(a.seed, tile_call + 1u, kDomainNeighbor, node, xp);
         uint64_t id[2]; float w[2]; uint32_t m[2];
-        if (WB) WbSamplePair(g, wr, live, UnitFromWords(pb.w[0], pb.w[1]),
+        if (WB == 2) WbSamplePairG(g, ws, a.t2, live, UnitFromWords(pb.w[0], pb.w[1]),
+                                   UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
+        else if (WB) WbSamplePair(g, wr, live, UnitFromWords(pb.w[0], pb.w[1]),
                                   UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
         else if (UNIFORM) LeanSamplePairUniform(g, lo, deg, total, live, UnitFromWords(pb.w[0], pb.w[1]),
                                            UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
@@ -902,7 +1001,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
           *reinterpret_cast<fl_u64x2*>(s_sid + sl * c2 + 2u * xp) = iv;
           *reinterpret_cast<float2*>(s_sw + sl * c2 + 2u * xp) =
               make_float2(live ? w[0] : 0.f, live ? w[1] : 0.f);
-          if (xp == 0) s_st[sl] = live ? 0 : -1;
+          if (xp == 0) s_st[sl] = live ? a.t2 : -1;
         }
       }
       WaveSync();
@@ -992,7 +1091,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
         const bool ok = s_rvalid[q] != 0;
         a.id1[out1 + tk] = ok ? s_c1[tk] : (uint64_t)a.default_node;
         a.w1[out1 + tk] = s_w1[tk];
-        a.ty1[out1 + tk] = ok ? 0 : -1;
+        a.ty1[out1 + tk] = ok ? a.t1 : -1;
       }
     }
     WaveSync();

@@ -785,7 +785,7 @@ static int LaunchK1(const euler_gpu_graph* g, hipStream_t stream,
         : (pair ? (tf ? SampleNeighborPivotKernel<true, 2>
                       : SampleNeighborPivotKernel<false, 2>)
                 : (tf ? SampleNeighborPivotKernel<true, 1>
-                      : SampleNeighborPivotKernel<false, true>));
+                      : SampleNeighborPivotKernel<false, 1>));
     hipLaunchKernelGGL(kern, dim3(gridp), dim3(block), 0, stream, a, stride_rows,
                        stride_slots);
   } else {
@@ -1411,8 +1411,8 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
     // streams - two launches share the chip - as 8 roots per wave (0.2055 ms per step against
     // 0.2175; profiles/r4_ab_wb_geom*.txt).  Everything else keeps round 3's 4 / 32 / 1.
     const GraphView& gv = g->view;
-    const bool wb_plain = g_fl_wb != 0 && g_fl_plain == 2 && gv.T == 1 && gv.total_in_meta != 0 &&
-                          gv.map_mode == 0 && gv.has_zero_nbr == 0 && gv.uniform_w == 0;
+    const bool wb_plain = g_fl_wb != 0 && g_fl_plain == 2 && gv.has_zero_nbr == 0 && gv.uniform_w == 0 &&
+                          gv.monotone != 0;        // (the lean builds over the weight-bucket index)
     int32_t gr = g_fl_roots > 16 ? 16 : g_fl_roots;
     if (gr < 1) gr = wb_plain && t_concurrent == 1 ? 8 : 4;
     while (gr > 1 && (int64_t)gr * c1 > 0x7FFF) gr >>= 1;
@@ -1464,7 +1464,12 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
       const bool plain_u = g_fl_plain != 0 && v.T == 1 && v.total_in_meta != 0 &&
                            v.map_mode == 0 && v.has_zero_nbr == 0 && f.t1 == 0 && f.t2 == 0;
       const bool plain = plain_u && v.uniform_w == 0;
-      if (plain_u && g_fl_plain == 2 && f.vec && v.n_edges < ((int64_t)1 << 31)) {
+      // the lean build's general form: any graph the weight-bucket index serves (several
+      // edge-type groups, hashed ids), valid listed types, no neighbour id 0
+      const bool lean_g = !plain_u && g_fl_plain == 2 && g_fl_wb != 0 && v.wbg != nullptr && v.wb != nullptr &&
+                          v.has_zero_nbr == 0 && v.uniform_w == 0 && f.t1 >= 0 && f.t1 < v.T && f.t2 >= 0 &&
+                          f.t2 < v.T && t_fl_row_index == nullptr;
+      if ((plain_u || lean_g) && g_fl_plain == 2 && f.vec && v.n_edges < ((int64_t)1 << 31)) {
         // the lean build (pairs of samples per lane, f32 compares, duplicates by edge)
         int32_t lcap = cap;
         FanoutLeanLds ll = FanoutLeanLayout(gr, c1, c2, lcap);
@@ -1484,15 +1489,18 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
           t_fl_took_lean = 1;
           void (*lk)(const FanoutLocalArgs) = nullptr;
           const bool use_wb = v.uniform_w == 0 && f.g.wrec != nullptr && f.g.wb != nullptr;
-          if (v.uniform_w != 0) {
+          if (lean_g) {
+            lk = f.wide ? (g_fl_wps == 6 ? SampleFanoutLeanKernel<true, 6, false, 2> : SampleFanoutLeanKernel<true, 5, false, 2>)
+                        : (g_fl_wps == 6 ? SampleFanoutLeanKernel<false, 6, false, 2> : SampleFanoutLeanKernel<false, 5, false, 2>);
+          } else if (v.uniform_w != 0) {
             lk = f.wide ? SampleFanoutLeanKernel<true, 8, true> : SampleFanoutLeanKernel<false, 8, true>;
           } else if (use_wb) {
-            lk = f.wide ? (g_fl_wps == 8 ? SampleFanoutLeanKernel<true, 8, false, true>
-                                         : g_fl_wps == 5 ? SampleFanoutLeanKernel<true, 5, false, true>
-                                                         : SampleFanoutLeanKernel<true, 6, false, true>)
-                        : (g_fl_wps == 8 ? SampleFanoutLeanKernel<false, 8, false, true>
-                                         : g_fl_wps == 5 ? SampleFanoutLeanKernel<false, 5, false, true>
-                                                         : SampleFanoutLeanKernel<false, 6, false, true>);
+            lk = f.wide ? (g_fl_wps == 8 ? SampleFanoutLeanKernel<true, 8, false, 1>
+                                         : g_fl_wps == 5 ? SampleFanoutLeanKernel<true, 5, false, 1>
+                                                         : SampleFanoutLeanKernel<true, 6, false, 1>)
+                        : (g_fl_wps == 8 ? SampleFanoutLeanKernel<false, 8, false, 1>
+                                         : g_fl_wps == 5 ? SampleFanoutLeanKernel<false, 5, false, 1>
+                                                         : SampleFanoutLeanKernel<false, 6, false, 1>);
           } else {
             lk = f.wide ? (g_fl_wps == 8 ? SampleFanoutLeanKernel<true, 8>
                                          : g_fl_wps == 5 ? SampleFanoutLeanKernel<true, 5>
