@@ -110,7 +110,7 @@ constexpr int64_t kK1GridCap = 32768;
 extern thread_local int g_k1_variant, g_k1_ablate, g_k1_grid_cap, g_k1_pair, g_k1_dedup,
     g_k1_fuse_mark, g_k1_dual, g_expand_steps, g_expand_const_type, g_expand_grid_cap,
     g_n2v_wave, g_dedup_block_numbering, g_dedup_resolve_in_expand, g_fanout_fused,
-    g_full_nb_balanced, g_n2v_big, g_k1_typed_pivot, g_fl_wb;
+    g_full_nb_balanced, g_n2v_big, g_k1_typed_pivot, g_fl_wb, g_k1_sets_lds;
 
 // k1_variants.hip: launches the kernel variant `g_k1_variant` selects for calls
 // the pivot kernels do not serve (grid = workgroups for one sample per lane)

@@ -573,6 +573,7 @@ thread_local int g_fl_plain = 2;      // key 34: plain graphs: 2 = the lean kern
 thread_local int g_fl_wps = 5;        // key 35: register budget, waves per SIMD (8, 6 or 5; 5: nothing spilled)
 thread_local int g_fl_wb = 1;         // key 45: the lean kernel draws through the weight-bucket index (wb_index.h:
                                       // one line per draw); 0 = the pivot-level search of rounds 2-3
+thread_local int g_k1_sets_lds = 1;   // key 47: euler_gpu_sample_neighbor_sets stages the roots' records in LDS (1)
 thread_local int g_fl_ablate = 0;     // key 36: measurement only (FanoutLocalArgs::ablate)
 thread_local int g_k1_typed_pivot = 1;   // key 37: calls with type draws search with the block pivots (0 = reference
                                          // loop)
@@ -1727,6 +1728,7 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 44 && (value == 0 || value == 1)) { g_walk_lean = value; return EULER_GPU_OK; }
   if (key == 35 && (value == 5 || value == 6 || value == 8)) { g_fl_wps = value; return EULER_GPU_OK; }
   if (key == 45 && (value == 0 || value == 1)) { g_fl_wb = value; return EULER_GPU_OK; }
+  if (key == 47 && (value == 0 || value == 1)) { g_k1_sets_lds = value; return EULER_GPU_OK; }
   return Fail(EULER_GPU_EINVAL, "set_tuning: unknown key");
 }
 
@@ -2004,6 +2006,12 @@ int euler_gpu_time_sample_neighbor(const euler_gpu_graph* g, void* stream,
   hipEvent_t e0, e1;
   EG_HIP(hipEventCreate(&e0));
   EG_HIP(hipEventCreate(&e1));
+  {
+    // untimed: first-use work of this stream (scratch, indexes built on first use)
+    int rc = LaunchSampleNeighbor(g, st, seed, 0u, roots_dev, n, nullptr, 1, edge_types_host, k, count, layout, -1,
+                                  out_id_dev, out_w_dev, out_t_dev, nullptr);
+    if (rc != EULER_GPU_OK) return rc;
+  }
   EG_HIP(hipEventRecord(e0, st));
   for (int32_t it = 0; it < iters; ++it) {
     int rc = LaunchSampleNeighbor(g, st, seed, (uint32_t)it, roots_dev, n, nullptr,

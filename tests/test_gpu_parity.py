@@ -1735,9 +1735,11 @@ def test_sample_neighbor_sets_one_launch(EA, O, torch_cuda, big_pair):
     qt = torch.as_tensor(q).cuda()
     sets = [[3], [1, 2], [0, 1, 2, 3], [], [2, 0, 1], [9], [0, 1, 2, 3, 0], [1]]
     try:
-        for wb in (1, 0):
+        # (45: weight-bucket index or pivot levels; 47: the roots' records staged in LDS or read per lane)
+        for wb, lds in ((1, 1), (1, 0), (0, 1)):
             L.euler_gpu_set_tuning(45, wb)
-            for count in (10, 1, 7):
+            L.euler_gpu_set_tuning(47, lds)
+            for count in (10, 1, 7, 300):
                 G.set_seed(5)
                 gn, gw, gt = G.sample_neighbor_sets(qt, sets, count, -3, call_id=70)
                 assert tuple(gn.shape) == (len(sets), len(q), count)
@@ -1750,6 +1752,7 @@ def test_sample_neighbor_sets_one_launch(EA, O, torch_cuda, big_pair):
                     assert np.array_equal(t2n(gt[s_]).reshape(-1), ot.reshape(-1))
     finally:
         L.euler_gpu_set_tuning(45, 1)
+        L.euler_gpu_set_tuning(47, 1)
     # identity ids, 8 types, with the aggregation (feature table indexed by node id)
     N, T, D, CNT = 20000, 8, 32, 10
     p = EA.synth_params(99, N, 400000, n_types=T, weighted=True)
