@@ -198,7 +198,12 @@ def cpu_baseline(args):
         cell["as_shipped"] = dict(_stats(secs, e), threads=shipped_threads,
                                   what="%d concurrent single-threaded queries" % shipped_threads)
         cands = []
-        conc = sorted({min(32, cores), min(cores, max(32, room)) if big else cores})
+        # (B = 131072 with EVERY core as a concurrent query - 256 here - is a 9.2 G-edge round of
+        # ~30 s and was measured SLOWER than 32: 301-323 M edges/s in profiles/r4_v1_bench.json and
+        # r4_v9_bench.json; the default run stops at 64 concurrent queries to stay within minutes,
+        # --cpu-protocol full runs every core)
+        conc = sorted({min(32, cores), (min(cores, max(32, room)) if full else min(cores, 64, max(32, room)))
+                       if big else cores})
         for many in conc:
             if many <= shipped_threads:
                 continue
@@ -640,7 +645,7 @@ def run_hetero(args, quiet=False):
     assert torch.equal(ops.gather_scatter("mean", feat, nb, dst, B), ops.scatter_mean(x, dst, B))
     # parity at bench scale: 64 roots of the last step, every type set, against the oracle
     # fed with the rows exported from HBM; their aggregated features against an fp64 mean
-    sel = np.random.default_rng(0).choice(B, 64, replace=False)
+    sel = np.random.default_rng(0).choice(B, 256, replace=False)
     r_sel = r.cpu().numpy()[sel]
     need_ids = r_sel[(r_sel >= 1) & (r_sel <= N)]
     OGh = _oracle_rows(G, p_h, need_ids, T)
@@ -653,7 +658,7 @@ def run_hetero(args, quiet=False):
         assert np.array_equal(w_b.reshape(B, CNT).cpu().numpy()[sel], ow.reshape(-1, CNT))
         assert np.array_equal(t_b.reshape(B, CNT).cpu().numpy()[sel], ot.reshape(-1, CNT))
         agg = ops.gather_segment_reduce("mean", feat, nb_b.reshape(-1).to(torch.int32), B, count=CNT)
-        ref = feat[torch.as_tensor(got.reshape(-1)).cuda()].double().reshape(64, CNT, D).mean(1)
+        ref = feat[torch.as_tensor(got.reshape(-1)).cuda()].double().reshape(len(sel), CNT, D).mean(1)
         a_sel = agg[torch.as_tensor(sel).cuda()].double()
         assert torch.all((a_sel - ref).abs() <= 1e-5 * (1.0 + ref.abs())), "hetero: aggregation off"
         checked += int(got.size)
@@ -854,17 +859,17 @@ def run_deepwalk(args, G=None, p_g=None, quiet=False):
         w2 = G.random_walk(s2, et2, 0.25, 4.0, N + 1, call_id=3)
         ms2 = _events(lambda: G.random_walk(s2, et2, 0.25, 4.0, N + 1, call_id=3), 2)
         b2 = walk_bytes(w2, W2, L2, 0.25, 4.0)
-        # the biased draw is keyed by the walker's INDEX: the first 16 walkers, as walkers 0..15
-        w2_sel = w2.cpu().numpy()[:16]
+        # the biased draw is keyed by the walker's INDEX: the first 64 walkers, as walkers 0..63
+        w2_sel = w2.cpu().numpy()[:64]
         need2 = w2_sel[(w2_sel >= 1) & (w2_sel <= N)]
         OG2 = _oracle_rows(G, p_g, need2, 1)
-        o2 = OG2.random_walk(GRAPH_SEED, 3, s2.cpu().numpy()[:16], et2, L2, 0.25, 4.0, N + 1)
+        o2 = OG2.random_walk(GRAPH_SEED, 3, s2.cpu().numpy()[:64], et2, L2, 0.25, 4.0, N + 1)
         assert np.array_equal(o2, w2_sel), "node2vec: walks differ from the oracle"
         n2v = {"walkers": W2, "walk_len": L2, "p": 0.25, "q": 4.0, "ms": round(ms2, 3),
                "steps_per_s": W2 * L2 / (ms2 * 1e-3), "algorithmic_bytes": b2,
                "GBps": round(b2 / (ms2 * 1e-3) / 1e9, 1),
                "frac": round(b2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-               "parity_checked_steps": int(16 * L2)}
+               "parity_checked_steps": int(64 * L2)}
     line = {
         "metric": "walker steps/sec, DeepWalk random_walk length 40 (p = q = 1) on the 100M-node "
                   "power-law graph (BASELINE configs[3], 1 GPU)",
