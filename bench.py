@@ -55,13 +55,14 @@ def parse():
                          "edges; reduced automatically when the host's RAM does not hold it)")
     ap.add_argument("--cpu-protocol", choices=["quick", "full"], default="quick",
                     help="full = 5 warm-up + 30 timed rounds for every cell (minutes)")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="unsharded path: consecutive minibatches alternate between this many "
                          "HIP streams (each with its own scratch): the latency-bound phases of "
                          "one minibatch (first hop, duplicate detection, sampling of the "
                          "distinct roots) overlap the bandwidth-bound expansion of the other - "
                          "the reference likewise keeps 8 queries in flight "
-                         "(client/query_proxy.cc:205-210)")
+                         "(client/query_proxy.cc:205-210).  Same box, 20 steps x 5: 1 stream 0.229 ms per "
+                         "step, 2: 0.212-0.223, 3: 0.206 (and the steadiest), 4: 0.225")
     ap.add_argument("--workload", choices=["metric", "products", "hetero", "deepwalk"],
                     default="metric",
                     help="metric = BASELINE.json's headline (configs[2]); products = configs[1] "

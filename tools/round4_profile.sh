@@ -8,7 +8,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_2s -o trace \
-   -- python tools/two_stream_trace.py --steps 24 > gpurun_out/${tag}_2s.log 2>&1
+   -- python tools/two_stream_trace.py --steps 24 --streams ${STREAMS:-3} > gpurun_out/${tag}_2s.log 2>&1
 echo "two-stream trace rc=$?"; tail -2 gpurun_out/${tag}_2s.log
 python tools/trace_overlap.py gpurun_out/${tag}_2s gpurun_out/${tag}_two_stream_trace.csv > gpurun_out/${tag}_two_stream_summary.json
 cat gpurun_out/${tag}_two_stream_summary.json

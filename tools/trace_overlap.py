@@ -25,12 +25,13 @@ with open(out, 'w') as fo:
         prev_end = max(prev_end, e) if prev_end is not None else e
 # time with >= 2 dispatches in flight
 ev = sorted([(s, 1) for s, e, *_ in half] + [(e, -1) for s, e, *_ in half])
-depth, last, busy1, busy2 = 0, ev[0][0], 0, 0
+depth, last, busy1, busy2, busy3 = 0, ev[0][0], 0, 0, 0
 for t, d in ev:
     if depth >= 1: busy1 += t - last
     if depth >= 2: busy2 += t - last
+    if depth >= 3: busy3 += t - last
     depth += d; last = t
 span = half[-1][1] - half[0][0]
 print(json.dumps({'dispatches': len(half), 'span_us': span / 1e3, 'us_per_dispatch_by_span': span / 1e3 / len(half),
                   'mean_duration_us': sum(e - s for s, e, *_ in half) / len(half) / 1e3,
-                  'frac_time_two_in_flight': busy2 / max(1, busy1), 'frac_time_busy': busy1 / max(1, span)}))
+                  'frac_time_two_in_flight': busy2 / max(1, busy1), 'frac_time_three_in_flight': busy3 / max(1, busy1), 'frac_time_busy': busy1 / max(1, span)}))

@@ -8,7 +8,7 @@ sys.path.insert(0, '.')
 import torch, euler_amd
 ap = argparse.ArgumentParser()
 ap.add_argument('--steps', type=int, default=24)
-ap.add_argument('--streams', type=int, default=2)
+ap.add_argument('--streams', type=int, default=3)
 ap.add_argument('--nodes', type=int, default=100_000_000)
 ap.add_argument('--edges', type=int, default=1_000_000_000)
 ap.add_argument('--batch', type=int, default=131072)
