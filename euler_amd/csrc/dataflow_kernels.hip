@@ -383,6 +383,12 @@ int FlowDenseTable(const euler_gpu_graph* g, hipStream_t st, int32_t hops,
   const size_t rows = (size_t)g->view.n_rows;
   if (rows == 0 || rows >= ((size_t)1 << 31)) return EULER_GPU_OK;
   std::lock_guard<std::mutex> lk(g->ws_mu);
+  // a table is 12 bytes per graph row and lives as long as the graph: at most kMaxFlowTables
+  // streams get one (a caller that keeps creating streams falls back to the hash table, which
+  // needs no persistent memory)
+  constexpr size_t kMaxFlowTables = 4;
+  if (g->flow_tables.find((void*)st) == g->flow_tables.end() && g->flow_tables.size() >= kMaxFlowTables)
+    return EULER_GPU_OK;
   auto& ft = g->flow_tables[(void*)st];
   if (ft.p == nullptr || ft.rows < rows) {
     if (ft.p != nullptr) { (void)hipStreamSynchronize(st); (void)hipFree(ft.p); ft.p = nullptr; ft.rows = 0; }
