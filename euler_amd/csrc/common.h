@@ -112,6 +112,11 @@ struct GraphView {
   // so a segment's limits come with the record, not from two more dependent loads
   const uint8_t* wbg;
   int32_t wbg_stride;           // 4 + 4 T
+  int32_t wb_lean_ok;           // at most 2 buckets in a thousand overflow their block (counted at
+                                // build): the lean kernels - whose second chance is the reference's
+                                // bisection - draw through the index; otherwise they keep the pivot
+                                // levels, and only the kernels that can fall back to the levels
+                                // (k1_search.h: BlockPivotSample) use it
 };
 
 // Edge block of the sampling index: 10 consecutive edges of the flat arrays

@@ -184,8 +184,12 @@ __device__ __forceinline__ void PivotSample(const GraphView& g, const Segment& s
 // them, shared by its samples) and one block line.
 // Same contract as PivotSample: first m in [lo, hi] with nw[m] > r.
 // ------------------------------------------------------------------------
+// USE_WB = false: the pivot levels whatever the view holds (the lean kernels' second chance for a
+// draw its weight-bucket block did not bracket).  m_out: the flat index of the drawn edge.
+template <bool USE_WB = true>
 __device__ __forceinline__ void BlockPivotSample(const GraphView& g, const Segment& sg,
-                                                 double u, uint64_t* id, float* w) {
+                                                 double u, uint64_t* id, float* w,
+                                                 int64_t* m_out = nullptr) {
   const int64_t lo = sg.lo, hi = sg.hi;
   const double rr = ScaleDraw(u, sg.limit_begin, sg.limit_end);
   if (!((double)sg.limit_end > rr)) {
@@ -194,6 +198,7 @@ __device__ __forceinline__ void BlockPivotSample(const GraphView& g, const Segme
     const int32_t m = (int32_t)RandomSelect(nw, (uint64_t)sg.b, (uint64_t)sg.e, u);
     *id = g.nbr[sg.row_ptr + m];
     *w = __fsub_rn(nw[m], m == 0 ? 0.f : nw[m - 1]);
+    if (m_out != nullptr) *m_out = sg.row_ptr + m;
     return;
   }
   if (g.uniform_w) {
@@ -202,9 +207,10 @@ __device__ __forceinline__ void BlockPivotSample(const GraphView& g, const Segme
     // and the weight nw[m] - nw[m-1] is 1.0f
     *id = g.nbr[sg.row_ptr + (int64_t)rr];
     *w = 1.0f;
+    if (m_out != nullptr) *m_out = sg.row_ptr + (int64_t)rr;
     return;
   }
-  if (g.wbg != nullptr) {
+  if (USE_WB && g.wbg != nullptr) {
     // weight-bucket index (wb_index.h): the bucket of r in the ROW's range names one
     // 128-byte line; its keys decide.  The first m of the row with nw[m] > r lies in
     // [lo, hi] because limit_begin <= r < limit_end and the sums do not decrease.
@@ -217,13 +223,14 @@ __device__ __forceinline__ void BlockPivotSample(const GraphView& g, const Segme
     // divergent lanes, not by the dependent trip; profiles/r4_ab_wb_full.txt)
     uint32_t m = 0;
     const int32_t i = WbDraw(wbk, f, w, &m);
-    if (i >= 0) { *id = wbk->nbr[i]; return; }
-    // the block does not bracket r (a row whose weights are far from even): the reference
-    const float* nw = g.prefix_w + sg.row_ptr;
-    const int32_t mm = (int32_t)RandomSelect(nw, (uint64_t)sg.b, (uint64_t)sg.e, u);
-    *id = g.nbr[sg.row_ptr + mm];
-    *w = __fsub_rn(nw[mm], mm == 0 ? 0.f : nw[mm - 1]);
-    return;
+    if (i >= 0) {
+      *id = wbk->nbr[i];
+      if (m_out != nullptr) *m_out = (int64_t)m;
+      return;
+    }
+    // the block does not bracket r - a row whose weights are far from even (i.i.d. uniform:
+    // 1e-4 of the draws; lognormal sigma 2 or Pareto alpha 0.7: ~5 %): the pivot levels
+    // below find it in ~log5(deg / 10) steps, not the bisection's log2(deg)
   }
   // ranges of the levels, bottom up, only as far as needed: K = first level
   // with <= 4 candidates (most rows stop at level 1 or 2, and a wave whose
@@ -301,6 +308,7 @@ __device__ __forceinline__ void BlockPivotSample(const GraphView& g, const Segme
   if (base + i == sg.row_ptr) prev = 0.f;          // `mid ? nw[mid-1] : 0`, row-relative
   *id = bk->nbr[i];
   *w = __fsub_rn(nw_m, prev);
+  if (m_out != nullptr) *m_out = base + i;
 }
 
 // Row record -> searched segment of the listed type; false = empty / invalid

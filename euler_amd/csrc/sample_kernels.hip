@@ -592,7 +592,7 @@ int SamplingView(const euler_gpu_graph* g, GraphView* out) {
     if (rc != EULER_GPU_OK) return rc;
   }
   *out = g->view;
-  if (!wb) { out->wb = nullptr; out->wbg = nullptr; out->wrec = nullptr; out->n_wb = 0; }
+  if (!wb) { out->wb = nullptr; out->wbg = nullptr; out->wrec = nullptr; out->n_wb = 0; out->wb_lean_ok = 0; }
   return EULER_GPU_OK;
 }
 
@@ -1468,6 +1468,7 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
       // the lean build's general form: any graph the weight-bucket index serves (several
       // edge-type groups, hashed ids), valid listed types, no neighbour id 0
       const bool lean_g = !plain_u && g_fl_plain == 2 && g_fl_wb != 0 && v.wbg != nullptr && v.wb != nullptr &&
+                          v.wb_lean_ok != 0 &&
                           v.has_zero_nbr == 0 && v.uniform_w == 0 && f.t1 >= 0 && f.t1 < v.T && f.t2 >= 0 &&
                           f.t2 < v.T && t_fl_row_index == nullptr;
       if ((plain_u || lean_g) && g_fl_plain == 2 && f.vec && v.n_edges < ((int64_t)1 << 31)) {
@@ -1489,7 +1490,7 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
           f.row_index = t_fl_row_index;
           t_fl_took_lean = 1;
           void (*lk)(const FanoutLocalArgs) = nullptr;
-          const bool use_wb = v.uniform_w == 0 && f.g.wrec != nullptr && f.g.wb != nullptr;
+          const bool use_wb = v.uniform_w == 0 && f.g.wrec != nullptr && f.g.wb != nullptr && v.wb_lean_ok != 0;
           if (lean_g) {
             lk = f.wide ? (g_fl_wps == 6 ? SampleFanoutLeanKernel<true, 6, false, 2> : SampleFanoutLeanKernel<true, 5, false, 2>)
                         : (g_fl_wps == 6 ? SampleFanoutLeanKernel<false, 6, false, 2> : SampleFanoutLeanKernel<false, 5, false, 2>);

@@ -1303,7 +1303,7 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
       int mode = !fast ? 0
                  : (g_walk_lean != 0 && v.T == 1 && v.total_in_meta != 0 && v.map_mode == 0 &&
                     v.uniform_w == 0 && v.n_edges < ((int64_t)1 << 31)) ? 2 : 1;
-      if (mode == 2 && c.g.wrec != nullptr && c.g.wb != nullptr) mode = 3;
+      if (mode == 2 && c.g.wrec != nullptr && c.g.wb != nullptr && c.g.wb_lean_ok != 0) mode = 3;
       auto sample_kernel = mode == 3 ? CwSampleKernel<3> : mode == 2 ? CwSampleKernel<2>
                            : mode == 1 ? CwSampleKernel<1> : CwSampleKernel<0>;
       hipLaunchKernelGGL(sample_kernel, dim3(grid), dim3(block), 0, st, c);

@@ -89,11 +89,27 @@ EG_HD uint32_t WbBlockStart(const SumAt& nw, uint32_t deg, uint32_t nbk, float s
 // up to 10 consecutive edges from the first one that reaches into the bucket; +inf keys and
 // id 0 past the row's end; prev_last = the sum before the block's first edge (0 at the
 // row's start: `mid ? nw[mid-1] : 0` is row-relative); pad = that edge's flat index.
-EG_HD void WbBuildBlock(const float* prefix_w, const uint64_t* nbr, uint32_t lo, uint32_t deg,
+// Returns true when the bucket OVERFLOWS its block: some draw that maps to bucket j has its
+// answer beyond the block's ten edges (more than ten edges' intervals reach into the bucket -
+// dust among giants) and will take the cold path.  The builder counts them: a graph where
+// more than a few buckets in a thousand overflow keeps the pivot levels for its lean kernels.
+EG_HD bool WbBuildBlock(const float* prefix_w, const uint64_t* nbr, uint32_t lo, uint32_t deg,
                         float total, uint32_t j, EdgeBlock* out) {
   const uint32_t nbk = WbBuckets(deg);
   const ArraySum nw{prefix_w + lo};
-  const uint32_t s = WbBlockStart(nw, deg, nbk, WbScale(nbk, total), j);
+  const float scale = WbScale(nbk, total);
+  const uint32_t s = WbBlockStart(nw, deg, nbk, scale, j);
+  bool overflow = false;
+  if (nbk > 1u && s + (uint32_t)kEdgesPerBlock < deg) {
+    // the last edge a draw of this bucket can select: the first one whose sum exceeds the
+    // bucket's upper bound (the row's last edge for the last bucket)
+    if (j + 1u >= nbk) {
+      overflow = true;                       // the row goes on past the block
+    } else {
+      const double U = ((double)(j + 1u) / (double)scale) * (1.0 + 1.0 / 1048576.0);
+      overflow = !((double)nw(s + (uint32_t)kEdgesPerBlock - 1u) > U);
+    }
+  }
   for (int k = 0; k < kEdgesPerBlock; ++k) {
     const uint32_t m = s + (uint32_t)k;
     const bool in = m < deg;
@@ -102,6 +118,7 @@ EG_HD void WbBuildBlock(const float* prefix_w, const uint64_t* nbr, uint32_t lo,
   }
   out->prev_last = s == 0u ? 0.f : prefix_w[lo + s - 1u];
   out->pad = lo + s;
+  return overflow;
 }
 
 // One draw on a block: f = the largest float <= r, r < the row's total.  Returns the

@@ -25,6 +25,7 @@ struct HostGraph {
   std::vector<uint64_t> slots;
   std::vector<WbRec> wrec;
   std::vector<EdgeBlock> wb;
+  int64_t wb_overflows = 0;
 };
 
 }  // namespace
@@ -101,10 +102,14 @@ int64_t hc_wb_build(void* h) {
     const WbRec& rec = g->wrec[(size_t)r];
     const uint32_t nbk = WbBuckets(rec.deg);
     for (uint32_t j = 0; j < nbk; ++j)
-      WbBuildBlock(v.prefix_w, v.nbr, rec.lo, rec.deg, rec.total, j, &g->wb[rec.wb_lo + j]);
+      if (WbBuildBlock(v.prefix_w, v.nbr, rec.lo, rec.deg, rec.total, j, &g->wb[rec.wb_lo + j])) ++g->wb_overflows;
   }
   return (int64_t)blocks;
 }
+
+// buckets whose block cannot hold every answer (what the device builder counts to decide
+// whether the lean kernels may use the index)
+int64_t hc_wb_overflows(void* h) { return static_cast<HostGraph*>(h)->wb_overflows; }
 
 // One draw u on row `rows[i]`: the hot path (WbSampleHot) and, when it declines, the
 // reference's search - exactly what the kernels do per lane.  cold_out[i] = 1 for a draw

@@ -1819,6 +1819,51 @@ def test_node2vec_step_on_fetched_lists_wave_and_lane(EA, O, torch_cuda):
         L.euler_gpu_set_tuning(7, 2)
 
 
+def test_heavy_tailed_weights_take_the_second_chance(EA, O, torch_cuda):
+    """Rows whose weights are far from even - Pareto(0.7): dust among giants - make the weight-bucket
+    index's blocks miss a few draws in a hundred.  The keys decide, so the results do not change:
+    K1 / typed / small-batch kernels fall through to the pivot levels inside BlockPivotSample, the
+    lean kernels are kept off the index by the builder's overflow count (wb_lean_ok) and walk the
+    levels.  SampleNeighbor, the fanout at every size class, type sets and walks == the oracle."""
+    torch = torch_cuda
+    rng = np.random.default_rng(21)
+    n = 4000
+    deg = np.minimum(rng.zipf(1.6, n), 6000).astype(np.int64)
+    seg = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    E = int(seg[-1])
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    nbr = rng.integers(1, n + 1, E).astype(np.uint64)
+    w = (rng.pareto(0.7, E) + 1e-3).astype(np.float32)
+    csr = O.csr_from_raw(ids, seg, nbr, w, 1)
+    G, OG = gpu_graph(EA, csr), O.OracleGraph(csr)
+    hubs = ids[np.argsort(-deg)[:200]].astype(np.int64)
+    q = np.concatenate([rng.integers(1, n + 1, 3000), hubs, hubs, [0, n + 7]]).astype(np.int64)
+    qt = torch.as_tensor(q).cuda()
+    G.set_seed(9)
+    for count in (10, 25, 7):
+        a = G.sample_neighbor(qt, [0], count, -1, call_id=5)
+        on, ow, ot = OG.sample_neighbor(9, 5, q, [0], count, -1)
+        assert np.array_equal(t2n(a[0]).reshape(-1), on.reshape(-1)), count
+        assert np.array_equal(t2n(a[1]).reshape(-1), ow.reshape(-1))
+    for B in (64, 3000, len(q)):                     # workgroup-per-root, hop by hop, one-kernel
+        for counts in ([25, 10], [5, 4]):
+            gn, gw, gt = G.sample_fanout(qt[:B], [[0], [0]], counts, -1, call_id=11)
+            on, ow, ot = OG.sample_fanout(9, 11, q[:B], [[0], [0]], counts, -1)
+            for h in range(2):
+                assert np.array_equal(t2n(gn[h + 1]), on[h]), (B, counts, h)
+                assert np.array_equal(t2n(gw[h]), ow[h])
+    big = torch.as_tensor(np.tile(q, 12)[:40000]).cuda()             # >= 32 768 roots: the lean kernel
+    gn, gw, gt = G.sample_fanout(big, [[0], [0]], [25, 10], -1, call_id=13)
+    on, ow, ot = OG.sample_fanout(9, 13, t2n(big), [[0], [0]], [25, 10], -1)
+    assert np.array_equal(t2n(gn[2]), on[1]) and np.array_equal(t2n(gw[1]), ow[1])
+    sn, sw, st = G.sample_neighbor_sets(qt, [[0], [0, 0], []], 6, -1, call_id=30)
+    for s_, et in enumerate([[0], [0, 0], []]):
+        on, ow, ot = OG.sample_neighbor(9, 30 + s_, q, et, 6, -1)
+        assert np.array_equal(t2n(sn[s_]).reshape(-1), on.reshape(-1)), et
+    walk = G.random_walk(qt, [[0]] * 6, 1.0, 1.0, -1, call_id=40)
+    assert np.array_equal(t2n(walk), OG.random_walk(9, 40, q, [[0]] * 6, 6, 1.0, 1.0, -1))
+
+
 def test_random_walk_over_merged_walkers(EA, O, torch_cuda, big_pair):
     """DeepWalk over groups of merged walkers (walk_kernels.hip: CwSampleKernel /
     CwNumberKernel / CwChainKernel / CwTransposeKernel, tuning key 38): walkers that meet on a node in a step

@@ -47,6 +47,8 @@ def HC():
     L.hc_graph_destroy.argtypes = [C.c_void_p]
     L.hc_wb_build.restype = C.c_int64
     L.hc_wb_build.argtypes = [C.c_void_p]
+    L.hc_wb_overflows.restype = C.c_int64
+    L.hc_wb_overflows.argtypes = [C.c_void_p]
     L.hc_wb_sample.argtypes = [C.c_void_p, i64p, C.POINTER(C.c_double), C.c_int64, i64p, f32p, u64p, i32p]
     L.hc_edge_sum_weight.argtypes = [C.c_void_p, u64p, C.c_int64, i32p, C.c_int32, f32p]
     L.hc_sample_root.argtypes = [C.c_uint64, C.c_uint32, u64p, f32p, C.c_int64,
@@ -321,6 +323,7 @@ def _wb_case(L, O, degs, weight_fn, rng, draws_per_row=64, extra_u=()):
     H = HostBackend(L, csr)
     blocks = L.hc_wb_build(H.h)
     assert blocks == sum((1 if 0 < d <= 10 else (d + 3) // 4) for d in degs if d > 0)
+    _wb_case.last_overflow_frac = L.hc_wb_overflows(H.h) / max(1, blocks)
     rows = np.repeat(np.arange(n, dtype=np.int64), draws_per_row + len(extra_u))
     us = np.concatenate([np.concatenate([rng.random(draws_per_row), np.asarray(extra_u, np.float64)])
                          for _ in range(n)]) if n else np.zeros(0)
@@ -355,12 +358,16 @@ def test_weight_bucket_index_vs_random_select(HC, O):
     # i.i.d. uniform [0.5, 8): the metric graph's weights
     n, c = _wb_case(HC, O, degs, lambda d: 0.5 + 7.5 * rng.random(d), rng, extra_u=edge_u)
     assert c <= n * 0.002, (n, c)
+    # ... and the builder's own statistic says so (<= 2 overflowing buckets in a thousand: the lean
+    # kernels may use the index), while a heavy-tailed graph is told apart (they keep the levels)
+    assert _wb_case.last_overflow_frac <= 0.002, _wb_case.last_overflow_frac
     # all equal (non-unit) weights; unit weights
     n, c = _wb_case(HC, O, degs, lambda d: np.full(d, 0.37), rng, extra_u=edge_u)
     assert c <= n * 0.002, (n, c)
     _wb_case(HC, O, degs, lambda d: np.ones(d), rng, extra_u=edge_u)
     # heavy tail (Pareto), zeros mixed in, one giant among dust, increasing and decreasing ramps
     _wb_case(HC, O, degs, lambda d: (rng.pareto(0.7, d) + 1e-3), rng, extra_u=edge_u)
+    assert _wb_case.last_overflow_frac > 0.002, _wb_case.last_overflow_frac
     _wb_case(HC, O, degs, lambda d: np.where(rng.random(d) < 0.4, 0.0, rng.random(d)), rng, extra_u=edge_u)
 
     def giant(d):
