@@ -947,7 +947,11 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  * key 45: 1 [default] = searches go through the weight-bucket index (csrc/wb_index.h: the
  *        bucket of a draw in its row's running-sum range names ONE 128-byte line; built on
  *        first use for graphs with non-decreasing, non-uniform running sums and < 2^32
- *        edges, ~40 bytes per edge of HBM); 0 = the pivot-level search of rounds 2-3.
+ *        edges, ~40 bytes per edge of HBM); 0 = the pivot-level search of rounds 2-3.  (A graph
+ *        whose weights are so uneven that more than 2 buckets in a thousand overflow their
+ *        block keeps the pivot levels for the one-kernel fanout and the merged walk by itself.)
+ * key 47: euler_gpu_sample_neighbor_sets stages the roots' records in LDS once per workgroup
+ *        (1 [default]); 0 = every sample lane reads them.
  * All settings produce identical results; the knobs exist for A/B measurements
  * and tests.  They are THREAD-LOCAL: a call changes the launches the calling host
  * thread enqueues afterwards and nobody else's (new threads start from the
