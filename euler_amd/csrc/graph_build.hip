@@ -876,25 +876,31 @@ int BuildWbIndex(GraphBuilder* b) {
   const bool plain = v.T == 1 && v.total_in_meta != 0 && v.map_mode == 0 &&
                      v.n_edges < ((int64_t)1 << 31);
   const int block = 256;
-  uint32_t* nbk = nullptr;
-  uint32_t* wb_lo = nullptr;
-  if (hipMalloc((void**)&nbk, ((size_t)v.n_rows + 1) * 4 + 16) != hipSuccess ||
-      hipMalloc((void**)&wb_lo, ((size_t)v.n_rows + 1) * 4 + 16) != hipSuccess) {
+  // temporaries, released on every way out (EG_HIP returns early)
+  struct Temps {
+    uint32_t* nbk = nullptr; uint32_t* wb_lo = nullptr; void* scan = nullptr; unsigned long long* ovf = nullptr;
+    ~Temps() {
+      if (nbk) (void)hipFree(nbk);
+      if (wb_lo) (void)hipFree(wb_lo);
+      if (scan) (void)hipFree(scan);
+      if (ovf) (void)hipFree(ovf);
+    }
+  } tmp;
+  if (hipMalloc((void**)&tmp.nbk, ((size_t)v.n_rows + 1) * 4 + 16) != hipSuccess ||
+      hipMalloc((void**)&tmp.wb_lo, ((size_t)v.n_rows + 1) * 4 + 16) != hipSuccess) {
     (void)hipGetLastError();
-    if (nbk) (void)hipFree(nbk);
     return EULER_GPU_OK;          // no room: the pivot-level search stays
   }
+  uint32_t* nbk = tmp.nbk;
+  uint32_t* wb_lo = tmp.wb_lo;
   hipLaunchKernelGGL(WbCountKernel, dim3((v.n_rows + 1 + block - 1) / block), dim3(block), 0, 0, v, nbk);
   {
     size_t tmp_bytes = 0;
     EG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, nbk, wb_lo, v.n_rows + 1));
-    void* tmp = nullptr;
-    EG_HIP(hipMalloc(&tmp, tmp_bytes + 16));
-    EG_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, nbk, wb_lo, v.n_rows + 1));
+    EG_HIP(hipMalloc(&tmp.scan, tmp_bytes + 16));
+    EG_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.scan, tmp_bytes, nbk, wb_lo, v.n_rows + 1));
     EG_HIP(hipDeviceSynchronize());
-    EG_HIP(hipFree(tmp));
   }
-  EG_HIP(hipFree(nbk));
   uint32_t n_wb32 = 0;
   EG_HIP(hipMemcpy(&n_wb32, wb_lo + v.n_rows, 4, hipMemcpyDeviceToHost));
   const int64_t n_wb = (int64_t)n_wb32;
@@ -903,19 +909,17 @@ int BuildWbIndex(GraphBuilder* b) {
   {
     size_t free_b = 0, total_b = 0;
     const size_t need = (size_t)n_wb * sizeof(EdgeBlock) + (size_t)v.n_rows * (stride + (plain ? 16 : 0));
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || need + ((size_t)1 << 30) > free_b) {
-      (void)hipFree(wb_lo);
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || need + ((size_t)1 << 30) > free_b)
       return EULER_GPU_OK;
-    }
   }
   uint8_t* wbg = b->Alloc<uint8_t>((size_t)v.n_rows * stride + 16);
   WbRec* rec = plain ? b->Alloc<WbRec>((size_t)v.n_rows) : nullptr;
   EdgeBlock* wb = b->Alloc<EdgeBlock>((size_t)n_wb);
-  if (b->rc != EULER_GPU_OK) { (void)hipFree(wb_lo); return b->rc; }
+  if (b->rc != EULER_GPU_OK) return b->rc;
   hipLaunchKernelGGL(WbRecKernel, dim3((v.n_rows + block - 1) / block), dim3(block), 0, 0, v, wb_lo,
                      wbg, stride, rec);
-  unsigned long long* ovf = nullptr;
-  EG_HIP(hipMalloc((void**)&ovf, 16));
+  EG_HIP(hipMalloc((void**)&tmp.ovf, 16));
+  unsigned long long* ovf = tmp.ovf;
   EG_HIP(hipMemset(ovf, 0, 16));
   if (n_wb > 0)
     hipLaunchKernelGGL(WbFillKernel, dim3(GridFor(n_wb, block)), dim3(block), 0, 0, v, wb_lo, n_wb, wb, ovf);
@@ -923,8 +927,6 @@ int BuildWbIndex(GraphBuilder* b) {
   EG_HIP(hipDeviceSynchronize());
   unsigned long long n_ovf = 0;
   EG_HIP(hipMemcpy(&n_ovf, ovf, 8, hipMemcpyDeviceToHost));
-  EG_HIP(hipFree(ovf));
-  EG_HIP(hipFree(wb_lo));
   v.wrec = rec; v.wb = wb; v.n_wb = n_wb; v.wbg = wbg; v.wbg_stride = stride;
   // (i.i.d. uniform weights: 1e-4; lognormal sigma 2, Pareto alpha 0.7: ~5e-2)
   v.wb_lean_ok = (double)n_ovf <= 0.002 * (double)n_wb ? 1 : 0;
