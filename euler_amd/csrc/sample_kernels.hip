@@ -1409,8 +1409,8 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
     // weight-bucket index (plain graphs) a launch that has the chip to itself runs best as
     // 4 roots per wave, 64 slots per pass, 2 waves per workgroup (0.219-0.221 ms against
     // 0.218-0.224 as 4 / 32 / 1 and 0.235-0.239 as 8 / 64 / 2); a caller that alternates
-    // streams - two launches share the chip - as 8 roots per wave (0.2055 ms per step against
-    // 0.2175; profiles/r4_ab_wb_geom*.txt).  Everything else keeps round 3's 4 / 32 / 1.
+    // streams - launches share the chip - as 8 roots per wave, 48 slots per pass, 1 wave per
+    // workgroup (profiles/r4_ab_wb_geom*.txt).  Everything else keeps round 3's 4 / 32 / 1.
     const GraphView& gv = g->view;
     const bool wb_plain = g_fl_wb != 0 && g_fl_plain == 2 && gv.has_zero_nbr == 0 && gv.uniform_w == 0 &&
                           gv.monotone != 0;        // (the lean builds over the weight-bucket index)
@@ -1419,10 +1419,13 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
     while (gr > 1 && (int64_t)gr * c1 > 0x7FFF) gr >>= 1;
     // several minibatches: a tile (gr roots) must not straddle two of them
     while (multi != nullptr && gr > 1 && multi->n_per % gr != 0) gr >>= 1;
-    int32_t cap = g_fl_cap > 0 ? g_fl_cap : wb_plain ? 64 : 8 * gr;
+    const bool wb_conc = wb_plain && t_concurrent == 1;
+    int32_t cap = g_fl_cap > 0 ? g_fl_cap : wb_conc ? 48 : wb_plain ? 64 : 8 * gr;
     if (cap > gr * c1) cap = gr * c1;
+    // (three callers' streams, sustained over 3 000 steps on two boxes: 8 / 48 / 1 wave per
+    // workgroup 0.1975-0.2008 ms per step, 8 / 64 / 2 waves 0.2079-0.2094)
     const int block = (g_fl_block == 64 || g_fl_block == 128 || g_fl_block == 256) ? g_fl_block
-                      : wb_plain ? 128 : 64;
+                      : (wb_plain && !wb_conc) ? 128 : 64;
     FanoutLocalLds lay = FanoutLocalLayout(gr, c1, c2, cap);
     // shrink the pass until a workgroup's LDS fits
     while (cap > 1 && (size_t)lay.bytes * (block / 64) > 64 * 1024) {
