@@ -926,8 +926,9 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  *        0 = off (hop by hop).  Its geometry: key 28 roots per wave (1..16; 0 [default] =
  *        the launcher chooses: 4, or 8 for a caller that alternates streams on a graph with
  *        the weight-bucket index), key 29 distinct children sampled per pass (0 [default] =
- *        64 with the weight-bucket index, else 8 per root), key 30 threads per workgroup
- *        (64, 128, 256; 0 [default] = 128 with the index, else 64), key 31 weights / types as 16-byte
+ *        64 with the weight-bucket index - 48 under alternating streams -, else 8 per root),
+ *        key 30 threads per workgroup (64, 128, 256; 0 [default] = 128 with the index and one
+ *        caller stream, else 64), key 31 weights / types as 16-byte
  *        stores (1), key 32 cap on launched waves (-1 = 16 384 when the caller
  *        alternates streams, else one tile per wave [default]; 0 = never; > 0 = that
  *        many), key 33 smallest batch it takes (32768), key 34 plain graphs: 2 = the
