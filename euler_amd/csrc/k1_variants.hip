@@ -244,10 +244,11 @@ __global__ __launch_bounds__(256, 6) void SampleNeighborSetsKernel(const SampleS
 // of a root's `count` lanes reads the root's row record and weight-bucket record for itself -
 // a dozen small loads per lane, all hits, and yet the launch is bound by exactly that: the CU's
 // memory pipe works off load instructions x lanes, not bytes.  Here a workgroup takes
-// 256 / count (set, root) tasks: their rows are found by one lane each, their records
-// (8 + 8 T bytes of row_meta, 4 + 4 T of {wb_lo, lim[T]}) are copied into LDS by all lanes
-// word by word, and a sample lane then needs global memory only for its block's keys and
-// its id.  Graphs with the weight-bucket index only (the kernel above serves the rest).
+// 256 / count ROOTS: their rows are found by one lane each, their records (8 + 8 T bytes of
+// row_meta, 4 + 4 T of {wb_lo, lim[T]}) are copied into LDS by all lanes word by word - once
+// for all the sets - and a sample lane then needs global memory only for its block's keys and
+// its id, set after set.  Graphs with the weight-bucket index only (the kernel above serves
+// the rest).
 __global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborSetsLdsKernel(const SampleSetsArgs a,
                                                                                  const int32_t rpb) {
   extern __shared__ __align__(16) uint32_t sl_smem[];
@@ -255,17 +256,11 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborSetsLdsKerne
   const int32_t mw = 2 + 2 * T, W = 3 + 3 * T;            // words of row_meta / of both records
   int64_t* s_row = reinterpret_cast<int64_t*>(sl_smem);                  // [rpb]
   uint32_t* s_rec = sl_smem + 2 * rpb;                                    // [rpb][W]
-  const int64_t tasks = a.n * (int64_t)a.n_sets;
   const int32_t q = (int32_t)threadIdx.x / a.count, j = (int32_t)threadIdx.x - q * a.count;
-  for (int64_t t0 = (int64_t)blockIdx.x * rpb; t0 < tasks; t0 += (int64_t)gridDim.x * rpb) {
-    const int32_t nt = (int32_t)(tasks - t0 < (int64_t)rpb ? tasks - t0 : (int64_t)rpb);
-    // (1) rows of the tasks' roots
-    uint64_t my_node = 0;
-    if ((int32_t)threadIdx.x < nt) {
-      const int64_t task = t0 + threadIdx.x;
-      const uint64_t node = a.roots[task % a.n];
-      s_row[threadIdx.x] = FindRow(a.g, node);
-    }
+  for (int64_t r0 = (int64_t)blockIdx.x * rpb; r0 < a.n; r0 += (int64_t)gridDim.x * rpb) {
+    const int32_t nt = (int32_t)(a.n - r0 < (int64_t)rpb ? a.n - r0 : (int64_t)rpb);
+    // (1) rows of the roots
+    if ((int32_t)threadIdx.x < nt) s_row[threadIdx.x] = FindRow(a.g, a.roots[r0 + threadIdx.x]);
     __syncthreads();
     // (2) their records, word by word (consecutive lanes, consecutive words of one root)
     for (int32_t x = (int32_t)threadIdx.x; x < nt * W; x += 256) {
@@ -279,74 +274,74 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborSetsLdsKerne
       s_rec[r * W + k] = v;
     }
     __syncthreads();
-    // (3) the samples
+    // (3) the samples, one set after the other
     if (q < nt) {
-      const int64_t task = t0 + q;
-      const int32_t set = (int32_t)(task / a.n);
-      const int64_t r = task - (int64_t)set * a.n;
-      const int32_t k = a.set_k[set];
-      const int32_t* et = a.et + a.set_off[set];
-      const int32_t mode = TypeModeOf(k, T);
-      const uint32_t call = a.call_id + (uint32_t)set;
+      const int64_t r = r0 + q;
       const int64_t row = s_row[q];
       const uint32_t* rec = s_rec + q * W;
       const int32_t* type_end = reinterpret_cast<const int32_t*>(rec + 2);
       const float* type_prefix = reinterpret_cast<const float*>(rec + 2 + T);
       const float* lim = reinterpret_cast<const float*>(rec + mw + 1);
-      uint64_t id = (uint64_t)a.default_node;
-      float w = 0.f;
-      int32_t t = -1;
-      bool draw = false;
-      double u_nb = 0.0;
-      if (row >= 0) {
-        my_node = a.roots[r];
-        if (mode == kTypeSingle) {
-          const int32_t tt = et[0];
-          if (tt >= 0 && tt < T && type_end[tt] > (tt == 0 ? 0 : type_end[tt - 1])) {
-            const Philox4 b = RngBlock(a.seed, call, kDomainNeighbor, my_node, ((uint32_t)j) >> 1);
-            u_nb = (j & 1) ? UnitFromWords(b.w[2], b.w[3]) : UnitFromWords(b.w[0], b.w[1]);
-            t = tt; draw = true;
-          }
-        } else {
-          bool valid;
-          if (mode == kTypeSub) {
-            valid = true;
-            for (int32_t i = 0; i < k; ++i) valid = valid && et[i] >= 0 && et[i] < T;
-            if (valid) valid = SubTypeSum{type_prefix, et}((uint64_t)(k - 1)) != 0.f;
-          } else {
-            valid = type_prefix[T - 1] != 0.f;
-          }
-          if (valid) {
-            const Philox4 b = RngBlock(a.seed, call, kDomainNeighbor, my_node, (uint32_t)j);
-            const double u_type = UnitFromWords(b.w[0], b.w[1]);
-            u_nb = UnitFromWords(b.w[2], b.w[3]);
-            if (mode == kTypeSub) {
-              t = et[RandomSelectT(SubTypeSum{type_prefix, et}, 0, (uint64_t)(k - 1), u_type)];
-            } else {
-              t = (int32_t)RandomSelect(type_prefix, 0, (uint64_t)(T - 1), u_type);
+      const uint64_t my_node = row >= 0 ? a.roots[r] : 0;
+      for (int32_t set = 0; set < a.n_sets; ++set) {
+        const int32_t k = a.set_k[set];
+        const int32_t* et = a.et + a.set_off[set];
+        const int32_t mode = TypeModeOf(k, T);
+        const uint32_t call = a.call_id + (uint32_t)set;
+        uint64_t id = (uint64_t)a.default_node;
+        float w = 0.f;
+        int32_t t = -1;
+        bool draw = false;
+        double u_nb = 0.0;
+        if (row >= 0) {
+          if (mode == kTypeSingle) {
+            const int32_t tt = et[0];
+            if (tt >= 0 && tt < T && type_end[tt] > (tt == 0 ? 0 : type_end[tt - 1])) {
+              const Philox4 b = RngBlock(a.seed, call, kDomainNeighbor, my_node, ((uint32_t)j) >> 1);
+              u_nb = (j & 1) ? UnitFromWords(b.w[2], b.w[3]) : UnitFromWords(b.w[0], b.w[1]);
+              t = tt; draw = true;
             }
-            if (type_end[t] - 1 < (t == 0 ? 0 : type_end[t - 1])) { id = 0; w = 0.f; t = 0; }   // as SampleAt
-            else draw = true;
+          } else {
+            bool valid;
+            if (mode == kTypeSub) {
+              valid = true;
+              for (int32_t i = 0; i < k; ++i) valid = valid && et[i] >= 0 && et[i] < T;
+              if (valid) valid = SubTypeSum{type_prefix, et}((uint64_t)(k - 1)) != 0.f;
+            } else {
+              valid = type_prefix[T - 1] != 0.f;
+            }
+            if (valid) {
+              const Philox4 b = RngBlock(a.seed, call, kDomainNeighbor, my_node, (uint32_t)j);
+              const double u_type = UnitFromWords(b.w[0], b.w[1]);
+              u_nb = UnitFromWords(b.w[2], b.w[3]);
+              if (mode == kTypeSub) {
+                t = et[RandomSelectT(SubTypeSum{type_prefix, et}, 0, (uint64_t)(k - 1), u_type)];
+              } else {
+                t = (int32_t)RandomSelect(type_prefix, 0, (uint64_t)(T - 1), u_type);
+              }
+              if (type_end[t] - 1 < (t == 0 ? 0 : type_end[t - 1])) { id = 0; w = 0.f; t = 0; }   // as SampleAt
+              else draw = true;
+            }
           }
         }
+        if (draw) {
+          Segment sg;
+          sg.row_ptr = (int64_t)(((uint64_t)rec[1] << 32) | rec[0]);
+          sg.b = t == 0 ? 0 : type_end[t - 1];
+          sg.e = type_end[t] - 1;
+          sg.lo = sg.row_ptr + sg.b; sg.hi = sg.row_ptr + sg.e;
+          sg.wb_lo = rec[mw];
+          sg.row_deg = (uint32_t)type_end[T - 1];
+          sg.row_total = lim[T - 1];
+          sg.limit_end = lim[t];
+          sg.limit_begin = t == 0 ? 0.f : lim[t - 1];
+          BlockPivotSample(a.g, sg, u_nb, &id, &w);
+        }
+        const int64_t s = ((int64_t)set * a.n + r) * a.count + j;
+        a.out_id[s] = id;
+        a.out_w[s] = w;
+        a.out_t[s] = t;
       }
-      if (draw) {
-        Segment sg;
-        sg.row_ptr = (int64_t)(((uint64_t)rec[1] << 32) | rec[0]);
-        sg.b = t == 0 ? 0 : type_end[t - 1];
-        sg.e = type_end[t] - 1;
-        sg.lo = sg.row_ptr + sg.b; sg.hi = sg.row_ptr + sg.e;
-        sg.wb_lo = rec[mw];
-        sg.row_deg = (uint32_t)type_end[T - 1];
-        sg.row_total = lim[T - 1];
-        sg.limit_end = lim[t];
-        sg.limit_begin = t == 0 ? 0.f : lim[t - 1];
-        BlockPivotSample(a.g, sg, u_nb, &id, &w);
-      }
-      const int64_t s = task * a.count + j;
-      a.out_id[s] = id;
-      a.out_w[s] = w;
-      a.out_t[s] = t;
     }
     __syncthreads();            // the records are rewritten by the next round
   }
@@ -401,7 +396,7 @@ bool LaunchSampleNeighborSets(const euler_gpu_graph* g, hipStream_t stream, uint
   const int32_t rpb = count <= 256 ? 256 / count : 0;
   const size_t lds = (size_t)rpb * (8 + 4 * (3 + 3 * (size_t)a.g.T));
   if (a.g.wbg != nullptr && a.g.wb != nullptr && rpb > 0 && lds <= 48 * 1024 && g_k1_sets_lds != 0) {
-    int64_t blocks = (n * (int64_t)n_sets + rpb - 1) / rpb;
+    int64_t blocks = (n + rpb - 1) / rpb;
     if (blocks > kK1GridCap) blocks = kK1GridCap;
     hipLaunchKernelGGL(SampleNeighborSetsLdsKernel, dim3((unsigned)blocks), dim3(256), lds, stream, a, rpb);
     if (hipGetLastError() != hipSuccess) *rc_out = Fail(EULER_GPU_EHIP, "sample_neighbor_sets: launch failed");
