@@ -83,6 +83,13 @@ def _i32_array(values):
     return res
 
 
+def _read_counts(counts):
+    """A few device-side counts as Python ints.  Tensor.cpu() is the cheapest way measured
+    (profiles/r4_ab_count_read.txt: a pinned buffer + stream / event synchronize costs the
+    same or more; what the read costs is the drain of the stream, ~55 us, not the copy)."""
+    return [int(c) for c in counts.cpu().tolist()]
+
+
 def _as_i64_cuda(x, device):
     if not torch.is_tensor(x):
         x = torch.as_tensor(np.asarray(x).astype(np.int64, copy=False))
@@ -591,7 +598,7 @@ class Graph:
                 arr(n_ids), arr(res), arr(esrc), arr(edst), _ptr(counts)))
         if not sync:
             return list(zip(n_ids, res, esrc, edst, eidx)), counts
-        cnt = [int(c) for c in counts.cpu().tolist()]          # the one host read
+        cnt = _read_counts(counts)                             # the one host read
         blocks = []
         for h in range(layers):
             e = cnt[h] * int(fanouts[h]) + (cnt[h] if add_self_loops else 0)
@@ -633,7 +640,7 @@ class Graph:
                 self._h, _stream(), _ptr(nodes), n, et_p, k, layers, 1 if add_self_loops else 0, ecap,
                 _ptr(ws), arr(n_ids), arr(res), arr(esrc), arr(edst),
                 arr(etyp) if with_types else None, _ptr(counts)))
-        cnt = [int(c) for c in counts.cpu().tolist()]          # the one host read
+        cnt = _read_counts(counts)                             # the one host read
         if cnt[2 * layers + 1]:
             return None, cnt
         blocks = []
