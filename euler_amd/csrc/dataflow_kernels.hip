@@ -66,6 +66,7 @@ struct FlowHop {
   uint32_t* slot_of;          // [cap_m]: the row, or 0x80000000 | hash slot
   uint32_t* blk_cnt;          // [n_blk + 1] first occurrences per chunk of kFlowChunk positions
   uint32_t* blk_off;          // [n_blk + 1] their exclusive scan (entry n_blk: the total)
+  unsigned long long* first_bits;   // [cap_m / 64 + 17] is-first-occurrence, one bit per position of V
   int64_t n_blk;              // ceil(cap_m / kFlowChunk)
   uint64_t* new_n_id;         // [cap_m]
   int64_t* inv;               // [cap_m] edge_dst: index of every element of V in new_n_id
@@ -124,18 +125,20 @@ __device__ __forceinline__ bool FlowIsFirst(const FlowHop& h, uint32_t sw, int64
 // positions of the first hop: profiles/r4_sage_blocks_kernel_stats.csv).
 constexpr int kFlowLds = 2 * kFlowChunk;          // LDS slots per workgroup (power of two)
 
-__global__ __launch_bounds__(256) void FlowInsertKernel(const FlowHop h) {
+constexpr int kFlowInsertThreads = 256;    // (1024 - one position per lane - measured slower: 28.8 vs 26.8 us)
+
+__global__ __launch_bounds__(kFlowInsertThreads) void FlowInsertKernel(const FlowHop h) {
   __shared__ uint32_t s_row[kFlowLds];
   __shared__ uint32_t s_pos[kFlowLds];
   const int64_t cnt = (int64_t)(*h.cnt);
   const int64_t m_nb = FlowNbLen(h, cnt), m = m_nb + cnt;
   const uint64_t mask = FlowMask(h, m);
   for (int64_t base = (int64_t)blockIdx.x * kFlowChunk; base < m; base += (int64_t)gridDim.x * kFlowChunk) {
-    for (int x = threadIdx.x; x < kFlowLds; x += 256) { s_row[x] = 0xFFFFFFFFu; s_pos[x] = 0xFFFFFFFFu; }
+    for (int x = threadIdx.x; x < kFlowLds; x += kFlowInsertThreads) { s_row[x] = 0xFFFFFFFFu; s_pos[x] = 0xFFFFFFFFu; }
     __syncthreads();
 #pragma unroll
-    for (int x = 0; x < kFlowChunk / 256; ++x) {
-      const int64_t i = base + x * 256 + threadIdx.x;
+    for (int x = 0; x < kFlowChunk / kFlowInsertThreads; ++x) {
+      const int64_t i = base + x * kFlowInsertThreads + threadIdx.x;
       if (i >= m) continue;
       const uint64_t id = FlowElem(h, i, m_nb);
       const int64_t row = h.dense_min != nullptr ? FindRow(h.g, id) : -1;
@@ -171,12 +174,11 @@ __global__ __launch_bounds__(256) void FlowInsertKernel(const FlowHop h) {
     __syncthreads();
     // the chunk's distinct rows, one atomicMin of {~epoch, position} each (a row another
     // chunk already claimed with a smaller position costs a load)
-    for (int x = threadIdx.x; x < kFlowLds; x += 256) {
+    for (int x = threadIdx.x; x < kFlowLds; x += kFlowInsertThreads) {
       const uint32_t row = s_row[x];
       if (row == 0xFFFFFFFFu) continue;
       const unsigned long long mine = h.epoch_hi | (unsigned long long)s_pos[x];
-      if (__hip_atomic_load(&h.dense_min[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > mine)
-        atomicMin(&h.dense_min[row], mine);
+      atomicMin(&h.dense_min[row], mine);
     }
     __syncthreads();
   }
@@ -198,7 +200,9 @@ __global__ __launch_bounds__(256) void FlowFlagKernel(const FlowHop h) {
       for (int x = 0; x < kFlowChunk / 256; ++x) {
         const int64_t i = base + x * 256 + threadIdx.x;
         const bool first = i < m && FlowIsFirst(h, h.slot_of[i], i);
-        mine += (uint32_t)__popcll(__ballot(first));
+        const unsigned long long bal = __ballot(first);
+        if (lane == 0) h.first_bits[i >> 6] = bal;       // (lane 0: i is a multiple of 64)
+        mine += (uint32_t)__popcll(bal);
       }
     }
     if (lane == 0) s_cnt[wv] = mine;
@@ -242,10 +246,11 @@ __global__ __launch_bounds__(256) void FlowEmitKernel(const FlowHop h) {
     uint32_t run = h.blk_off[b];
     for (int x = 0; x < kFlowChunk / 256; ++x) {
       const int64_t i = base + x * 256 + threadIdx.x;
-      uint32_t slot = 0;
-      bool first = false;
-      if (i < m) { slot = h.slot_of[i]; first = FlowIsFirst(h, slot, i); }
-      const uint64_t bal = __ballot(first);
+      // the flag kernel left its ballots: no second look at the tables
+      const int64_t w0 = base + x * 256 + wv * 64;
+      const uint64_t bal = w0 < m ? h.first_bits[w0 >> 6] : 0ull;
+      const bool first = ((bal >> lane) & 1ull) != 0ull;
+      const uint32_t slot = first ? h.slot_of[i] : 0u;
       if (lane == 0) s_cnt[wv] = (uint32_t)__popcll(bal);
       __syncthreads();
       uint32_t before = 0, all = 0;
@@ -495,10 +500,12 @@ int euler_gpu_sage_blocks(const euler_gpu_graph* g, void* stream, uint64_t seed,
     f.t.rank = (int32_t*)p;             p += Al((tcap + 1) * 4);
     f.t.mask = tcap - 1;
     f.slot_of = (uint32_t*)p;           p += Al((size_t)cap_m * 4);
-    // (the workspace holds two arrays of cap_m + 1 words here: the chunk counts need far less)
+    // (the workspace holds two arrays of cap_m + 1 words here: the chunk counts need far less,
+    // and the first-occurrence bits - cap_m / 64 + 17 double words - follow them in the first)
     f.blk_cnt = (uint32_t*)p;           p += Al(((size_t)cap_m + 1) * 4);
     f.blk_off = (uint32_t*)p;           p += Al(((size_t)cap_m + 1) * 4);
     f.n_blk = (cap_m + kFlowChunk - 1) / kFlowChunk;
+    f.first_bits = (unsigned long long*)(f.blk_cnt + ((f.n_blk + 2) & ~(int64_t)1));   // same region
     void* scan_tmp = p;
     size_t scan_bytes = 0;
     EG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, f.blk_cnt, f.blk_off,
@@ -517,7 +524,7 @@ int euler_gpu_sage_blocks(const euler_gpu_graph* g, void* stream, uint64_t seed,
     const int grid = GridFor(cap_m + 1, block);
     const int grid_b = (int)(f.n_blk + 1 < 65536 ? f.n_blk + 1 : 65536);
     hipLaunchKernelGGL(FlowClearKernel, dim3(grid), dim3(block), 0, st, f);
-    hipLaunchKernelGGL(FlowInsertKernel, dim3(grid_b), dim3(block), 0, st, f);
+    hipLaunchKernelGGL(FlowInsertKernel, dim3(grid_b), dim3(kFlowInsertThreads), 0, st, f);
     hipLaunchKernelGGL(FlowFlagKernel, dim3(grid_b), dim3(block), 0, st, f);
     hipLaunchKernelGGL(FlowScanKernel, dim3(1), dim3(1024), 0, st, f);
     hipLaunchKernelGGL(FlowEmitKernel, dim3(grid_b), dim3(block), 0, st, f);
@@ -620,6 +627,7 @@ int euler_gpu_full_blocks(const euler_gpu_graph* g, void* stream, const uint64_t
     f.blk_cnt = (uint32_t*)p;           p += Al(((size_t)cap_m + 1) * 4);
     f.blk_off = (uint32_t*)p;           p += Al(((size_t)cap_m + 1) * 4);
     f.n_blk = (cap_m + kFlowChunk - 1) / kFlowChunk;
+    f.first_bits = (unsigned long long*)(f.blk_cnt + ((f.n_blk + 2) & ~(int64_t)1));   // same region
     void* scan_tmp = p;
     size_t scan_bytes = 0, scan2 = 0;
     EG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, f.blk_cnt, f.blk_off, (int)(f.n_blk + 1), st));
@@ -640,7 +648,7 @@ int euler_gpu_full_blocks(const euler_gpu_graph* g, void* stream, const uint64_t
     const int grid = GridFor(cap_m + 1, block);
     const int grid_b = (int)(f.n_blk + 1 < 65536 ? f.n_blk + 1 : 65536);
     hipLaunchKernelGGL(FlowClearKernel, dim3(grid), dim3(block), 0, st, f);
-    hipLaunchKernelGGL(FlowInsertKernel, dim3(grid_b), dim3(block), 0, st, f);
+    hipLaunchKernelGGL(FlowInsertKernel, dim3(grid_b), dim3(kFlowInsertThreads), 0, st, f);
     hipLaunchKernelGGL(FlowFlagKernel, dim3(grid_b), dim3(block), 0, st, f);
     hipLaunchKernelGGL(FlowScanKernel, dim3(1), dim3(1024), 0, st, f);
     hipLaunchKernelGGL(FlowEmitKernel, dim3(grid_b), dim3(block), 0, st, f);
