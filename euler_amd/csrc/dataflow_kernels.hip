@@ -65,7 +65,6 @@ struct FlowHop {
   unsigned long long epoch_hi;     // (~epoch) << 32
   uint32_t* slot_of;          // [cap_m]: the row, or 0x80000000 | hash slot
   uint32_t* blk_cnt;          // [n_blk + 1] first occurrences per chunk of kFlowChunk positions
-  uint32_t* blk_off;          // [n_blk + 1] their exclusive scan (entry n_blk: the total)
   unsigned long long* first_bits;   // [cap_m / 64 + 17] is-first-occurrence, one bit per position of V
   int64_t n_blk;              // ceil(cap_m / kFlowChunk)
   uint64_t* new_n_id;         // [cap_m]
@@ -212,25 +211,19 @@ __global__ __launch_bounds__(256) void FlowFlagKernel(const FlowHop h) {
   }
 }
 
-// exclusive scan of the n_blk + 1 chunk counts by ONE workgroup (a device-wide look-back
-// scan over a few thousand numbers is all latency: 28 us against ~5 here)
-__global__ __launch_bounds__(1024) void FlowScanKernel(const FlowHop h) {
-  __shared__ uint32_t s_sum[1024];
-  const int64_t n = h.n_blk + 1;
-  const int64_t per = (n + 1023) / 1024;
-  const int64_t b = (int64_t)threadIdx.x * per, e = b + per < n ? b + per : n;
-  uint32_t sum = 0;
-  for (int64_t i = b; i < e; ++i) sum += h.blk_cnt[i];
-  s_sum[threadIdx.x] = sum;
+// Sum of the first `upto` chunk counts, by the whole workgroup (a few hundred numbers for a
+// minibatch, n_blk at worst): every chunk's workgroup finds its own offset this way, which
+// costs less than the launch of a scan kernel between the flag and the emit kernel did
+// (4.7 us + the gap, twice per minibatch).
+__device__ __forceinline__ uint32_t FlowPrefix(const FlowHop& h, int64_t upto, uint32_t* s_red) {
+  uint32_t v = 0;
+  for (int64_t x = threadIdx.x; x < upto; x += 256) v += h.blk_cnt[x];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  __syncthreads();                                   // s_red may still be read from the last call
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {          // Hillis-Steele over the 1024 partial sums
-    const uint32_t v = threadIdx.x >= (unsigned)off ? s_sum[threadIdx.x - off] : 0u;
-    __syncthreads();
-    s_sum[threadIdx.x] += v;
-    __syncthreads();
-  }
-  uint32_t run = threadIdx.x == 0 ? 0u : s_sum[threadIdx.x - 1];
-  for (int64_t i = b; i < e; ++i) { const uint32_t c = h.blk_cnt[i]; h.blk_off[i] = run; run += c; }
+  return s_red[0] + s_red[1] + s_red[2] + s_red[3];
 }
 
 __global__ __launch_bounds__(256) void FlowEmitKernel(const FlowHop h) {
@@ -239,11 +232,15 @@ __global__ __launch_bounds__(256) void FlowEmitKernel(const FlowHop h) {
   const int64_t m_nb = FlowNbLen(h, cnt), m = m_nb + cnt;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-  if (blockIdx.x == 0 && threadIdx.x == 0) *h.cnt_out = h.blk_off[h.n_blk];   // exclusive scan: the total
+  __shared__ uint32_t s_red[4];
+  if (blockIdx.x == 0) {                               // the new layer's size: all the chunks of V
+    const uint32_t total = FlowPrefix(h, (m + kFlowChunk - 1) / kFlowChunk, s_red);
+    if (threadIdx.x == 0) *h.cnt_out = total;
+  }
   for (int64_t b = blockIdx.x; b < h.n_blk; b += gridDim.x) {
     const int64_t base = b * kFlowChunk;
     if (base >= m) break;                              // block-uniform
-    uint32_t run = h.blk_off[b];
+    uint32_t run = FlowPrefix(h, b, s_red);
     for (int x = 0; x < kFlowChunk / 256; ++x) {
       const int64_t i = base + x * 256 + threadIdx.x;
       // the flag kernel left its ballots: no second look at the tables
@@ -503,13 +500,9 @@ int euler_gpu_sage_blocks(const euler_gpu_graph* g, void* stream, uint64_t seed,
     // (the workspace holds two arrays of cap_m + 1 words here: the chunk counts need far less,
     // and the first-occurrence bits - cap_m / 64 + 17 double words - follow them in the first)
     f.blk_cnt = (uint32_t*)p;           p += Al(((size_t)cap_m + 1) * 4);
-    f.blk_off = (uint32_t*)p;           p += Al(((size_t)cap_m + 1) * 4);
+    p += Al(((size_t)cap_m + 1) * 4);   // (was the counts' scan; the workspace formula keeps it)
     f.n_blk = (cap_m + kFlowChunk - 1) / kFlowChunk;
     f.first_bits = (unsigned long long*)(f.blk_cnt + ((f.n_blk + 2) & ~(int64_t)1));   // same region
-    void* scan_tmp = p;
-    size_t scan_bytes = 0;
-    EG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, f.blk_cnt, f.blk_off,
-                                            (int)(f.n_blk + 1), st));
     // 1. the hop's sampler over the first counts[h] nodes of the layer
     int rc = LaunchSampleNeighborCounted(g, st, seed, call_id + (uint32_t)h, n_id, cap_n,
                                          counts_dev + h, edge_types_host + (size_t)h * k, k, count,
@@ -526,7 +519,6 @@ int euler_gpu_sage_blocks(const euler_gpu_graph* g, void* stream, uint64_t seed,
     hipLaunchKernelGGL(FlowClearKernel, dim3(grid), dim3(block), 0, st, f);
     hipLaunchKernelGGL(FlowInsertKernel, dim3(grid_b), dim3(kFlowInsertThreads), 0, st, f);
     hipLaunchKernelGGL(FlowFlagKernel, dim3(grid_b), dim3(block), 0, st, f);
-    hipLaunchKernelGGL(FlowScanKernel, dim3(1), dim3(1024), 0, st, f);
     hipLaunchKernelGGL(FlowEmitKernel, dim3(grid_b), dim3(block), 0, st, f);
     // 3. res_n_id, edge_index
     hipLaunchKernelGGL(FlowIndexKernel, dim3(grid), dim3(block), 0, st, f);
@@ -625,12 +617,11 @@ int euler_gpu_full_blocks(const euler_gpu_graph* g, void* stream, const uint64_t
     f.t.mask = tcap - 1;
     f.slot_of = (uint32_t*)p;           p += Al((size_t)cap_m * 4);
     f.blk_cnt = (uint32_t*)p;           p += Al(((size_t)cap_m + 1) * 4);
-    f.blk_off = (uint32_t*)p;           p += Al(((size_t)cap_m + 1) * 4);
+    p += Al(((size_t)cap_m + 1) * 4);   // (was the counts' scan; the workspace formula keeps it)
     f.n_blk = (cap_m + kFlowChunk - 1) / kFlowChunk;
     f.first_bits = (unsigned long long*)(f.blk_cnt + ((f.n_blk + 2) & ~(int64_t)1));   // same region
     void* scan_tmp = p;
-    size_t scan_bytes = 0, scan2 = 0;
-    EG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, f.blk_cnt, f.blk_off, (int)(f.n_blk + 1), st));
+    size_t scan2 = 0;
     EG_HIP(hipcub::DeviceScan::ExclusiveScan(nullptr, scan2, ff.lens, ff.offs, SatAdd(), 0u, (int)(cap_n + 1), st));
     // 1. the rows of the layer's nodes: lengths -> offsets -> the hop's neighbour list
     hipLaunchKernelGGL(FlowFullCountKernel, dim3(GridFor(cap_n + 1, block)), dim3(block), 0, st, ff);
@@ -650,7 +641,6 @@ int euler_gpu_full_blocks(const euler_gpu_graph* g, void* stream, const uint64_t
     hipLaunchKernelGGL(FlowClearKernel, dim3(grid), dim3(block), 0, st, f);
     hipLaunchKernelGGL(FlowInsertKernel, dim3(grid_b), dim3(kFlowInsertThreads), 0, st, f);
     hipLaunchKernelGGL(FlowFlagKernel, dim3(grid_b), dim3(block), 0, st, f);
-    hipLaunchKernelGGL(FlowScanKernel, dim3(1), dim3(1024), 0, st, f);
     hipLaunchKernelGGL(FlowEmitKernel, dim3(grid_b), dim3(block), 0, st, f);
     hipLaunchKernelGGL(FlowIndexKernel, dim3(grid), dim3(block), 0, st, f);
     EG_HIP(hipGetLastError());
