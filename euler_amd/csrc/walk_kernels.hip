@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void TopKNeighborKernel(const TopKArgs a) {
 // walkers (CwSampleKernel ...); 0 = never
 thread_local int g_walk_collapse = 262144;
 thread_local int g_walk_lean = 1;         // key 44: plain graphs draw with the lean search of the one-kernel fanout
-thread_local int g_walk_tail = 12;        // key 43: first step of the merged walk that stops looking for mergers
+thread_local int g_walk_tail = 9;         // key 43: first step of the merged walk that stops looking for mergers
                                           // (the rest of the walk is one launch; 0 = never)
 thread_local int g_walk_grid = 1024;      // key 39: workgroups of its per-step launches (0 = one per 256 walkers)
 
@@ -527,15 +527,19 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void RandomWalkKernel(const Wal
 //                    them in the table;
 //   CwSampleKernel   (next step, same launch) first reads every group's number back into
 //                    its record;
-//   CwTailKernel     from step `tail` on (tuning key 43, default 12) the groups walk on WITHOUT
+//   CwTailKernel     from step `tail` on (tuning key 43, default 9) the groups walk on WITHOUT
 //                    looking for further mergers, all remaining steps in one launch: by then
-//                    a step is ~30 K groups - two launches of ~13 + ~5.5 us that are all
-//                    latency - and the few mergers still to come save less than they cost;
-//   CwChainKernel    walker w follows the records, one 16-byte load per step (four walkers
-//                    per lane: four chains in flight), and leaves its path TRANSPOSED,
-//                    [step][walker] - every store a full run of 512 bytes;
-//   CwTransposeKernel  [step][walker] -> the op's [walker][step]: 64 walkers per workgroup
-//                    through LDS, their rows leave as one contiguous run.
+//                    a step is ~100 K groups - two launches of ~20 + ~13 us that are mostly
+//                    latency - and the mergers still to come save less than they cost.  A
+//                    group's tail is left as ONE row of ids (8 bytes per step);
+//   CwPathKernel     a wave takes 64 walkers: lane = walker follows the records of the merging
+//                    levels (`tail` dependent 16-byte loads), then the wave copies the 64 tail
+//                    rows and the heads into the op's [walker][step] layout - every path byte
+//                    written once, in runs of a row (1M x 40: 225 us, sweep of `tail` in
+//                    profiles/r4_walk_tail_sweep.txt);
+//   CwChainKernel + CwTransposeKernel  the same through records for every level and a
+//                    transposed copy (282 + 122 us) - kept for walks whose head tile does not
+//                    fit in LDS (tail >= 127 steps).
 //   (One kernel that staged 8 steps per walker and wrote 64-byte pieces of rows 328 bytes
 //   apart took 0.65 ms for 1 M walkers x 40 steps - a third of the walk - at 0.5 TB/s.)
 // Counts stay on the device; every launch is sized for the walkers and exits past n[s].
@@ -559,6 +563,8 @@ struct CwArgs {
   int32_t walk_len;
   int32_t step;                 // the step this launch samples (walk_len: none)
   int32_t fast;                 // one listed type per step on a monotone graph
+  uint64_t* tail_rows;          // not null: CwTailKernel leaves a group's steps as ONE row of
+                                // walk_len - step ids (CwPathKernel copies it), not as records
 };
 
 constexpr uint32_t kCwFlag = 0x80000000u;
@@ -672,10 +678,14 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void CwTailKernel(const CwArgs 
     if (gidx >= n_cur) continue;
     uint64_t cur = a.rec[(int64_t)s0 * a.cap + gidx].id;
     a.rec[(int64_t)s0 * a.cap + gidx].next = (uint32_t)gidx;
+    const int32_t tl = a.walk_len - s0;
     for (int32_t s = s0; s < a.walk_len; ++s) {
       const uint64_t id = CwDraw<MODE>(a, cur, s);
-      *reinterpret_cast<uint4*>(&a.rec[(int64_t)(s + 1) * a.cap + gidx]) =
-          make_uint4((uint32_t)id, (uint32_t)(id >> 32), (uint32_t)gidx, 0u);
+      if (a.tail_rows != nullptr)
+        a.tail_rows[gidx * tl + (s - s0)] = id;
+      else
+        *reinterpret_cast<uint4*>(&a.rec[(int64_t)(s + 1) * a.cap + gidx]) =
+            make_uint4((uint32_t)id, (uint32_t)(id >> 32), (uint32_t)gidx, 0u);
       cur = id;
     }
   }
@@ -774,6 +784,56 @@ __global__ __launch_bounds__(256) void CwTransposeKernel(const int64_t* tr, int6
       }
       __syncthreads();
     }
+  }
+}
+
+
+// The walkers' paths, written where the op wants them ([walker][step]) by ONE kernel: a wave
+// takes 64 walkers.  (i) Lane = walker follows the records of the levels that still merged -
+// s0 dependent 16-byte loads - and parks those s0 + 1 ids in the wave's LDS tile; it ends on
+// its group of level s0, whose remaining steps CwTailKernel left as one row of ids.  (ii)
+// The wave copies the 64 tail rows, consecutive lanes = consecutive ids of a row: loads and
+// stores that are independent of each other and cover whole runs of a row.  (iii) The heads
+// leave through the LDS tile the same way.  Against CwChainKernel + CwTransposeKernel
+// (1M walkers x 40 steps: 282 + 122 us, a chain of 40 loads per walker and the paths written
+// twice) the chain is s0 = 12 long and every path byte is written once.
+__global__ __launch_bounds__(256) void CwPathKernel(const CwArgs a, const int64_t* starts,
+                                                    const int32_t s0, int64_t* out) {
+  extern __shared__ __align__(16) uint64_t cw_head[];       // per wave: [64][hs] ids, then [64] groups
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, waves = blockDim.x >> 6;
+  const int32_t H = s0 + 1, hs = H | 1, TL = a.walk_len - s0, L = a.walk_len + 1;
+  uint64_t* head = cw_head + (size_t)wv * (64 * hs + 32);
+  uint32_t* s_grp = reinterpret_cast<uint32_t*>(head + 64 * hs);
+  const int64_t tiles = (a.cap + 63) / 64;
+  for (int64_t tile = (int64_t)blockIdx.x * waves + wv; tile < tiles; tile += (int64_t)gridDim.x * waves) {
+    const int64_t w0 = tile * 64, w = w0 + lane;
+    const int32_t nw = (int32_t)(a.cap - w0 < 64 ? a.cap - w0 : 64);
+    const bool live = lane < nw;
+    uint32_t grp = 0;
+    if (live) {
+      head[lane * hs] = (uint64_t)starts[w];
+      grp = a.rec[w].next;                       // level 0 is the walkers themselves
+    }
+    for (int32_t s = 0; s < s0; ++s) {
+      if (live) {
+        const uint4 q = *reinterpret_cast<const uint4*>(&a.rec[(int64_t)(s + 1) * a.cap + grp]);
+        head[lane * hs + s + 1] = ((uint64_t)q.y << 32) | q.x;
+        grp = q.z;                               // (level s0: the group itself, CwTailKernel)
+      }
+    }
+    s_grp[lane] = grp;
+    WaveSync();
+    for (int32_t e = lane; e < nw * TL; e += 64) {
+      const int32_t wl = e / TL, j = e - wl * TL;
+      const uint64_t id = a.tail_rows[(int64_t)s_grp[wl] * TL + j];
+      out[(w0 + wl) * L + H + j] = id == 0 ? a.default_node : (int64_t)id;
+    }
+    for (int32_t e = lane; e < nw * H; e += 64) {
+      const int32_t wl = e / H, x = e - wl * H;
+      const uint64_t id = head[wl * hs + x];
+      out[(w0 + wl) * L + x] = (id == 0 && x != 0) ? a.default_node : (int64_t)id;
+    }
+    WaveSync();                                  // the tile is rewritten by the next round
   }
 }
 
@@ -1248,8 +1308,8 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
   // random_walk_op.cc:281: fabs(p_ - 1.0) <= kEps && fabs(q_ - 1.0) <= kEps
   if (std::fabs((double)p - 1.0) <= kEps && std::fabs((double)q - 1.0) <= kEps) {
     const bool fast = k == 1 && g->view.monotone && g->view.blk != nullptr && g_k1_variant >= 5;
-    // The walk over groups of merged walkers needs (walk_len + 1) * n * 24 bytes + 8 bytes per
-    // graph row of stream-ordered scratch (1 GB for 1M walkers x 40 steps; tens of GB when
+    // The walk over groups of merged walkers needs (walk_len + 1) * n * 16 bytes (24 when the paths go through a transposed copy) + 8 bytes per
+    // graph row of stream-ordered scratch (0.7 GB for 1M walkers x 40 steps; tens of GB when
     // every node of a large graph walks).  It is an optimisation: when the scratch is not
     // to be had - more than a third of the free HBM, or the allocation fails - the call falls
     // through to the per-walker kernel, which needs none.
@@ -1258,12 +1318,18 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
     uint8_t* buf = nullptr;
     size_t o_rec = 0, o_tid = 0, o_tsl = 0, o_own = 0, o_tr = 0, total = 0;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    // first step of the tail (walk_len: none)
+    const int32_t tail = g_walk_tail > 0 && g_walk_tail < walk_len ? g_walk_tail : walk_len;
+    // the paths by CwPathKernel when a wave's tile of head ids fits in LDS (else records for
+    // every level, CwChainKernel + CwTransposeKernel through a transposed copy)
+    const size_t tile_bytes = ((size_t)64 * ((tail + 1) | 1) + 32) * 8;
+    const bool by_path = tile_bytes <= 64 * 1024;
     if (merged) {
       const size_t cap = (size_t)n, rows = (size_t)g->view.n_rows + 1;
       o_rec = al(((size_t)walk_len + 2) * 4);
       o_tid = o_rec + al(((size_t)walk_len + 1) * cap * 16); o_tsl = o_tid + al(2 * cap * 8);
       o_own = o_tsl + al(2 * cap * 4); o_tr = o_own + al(2 * rows * 4);
-      total = o_tr + al(((size_t)walk_len + 1) * cap * 8);
+      total = o_tr + (by_path ? 0 : al(((size_t)walk_len + 1) * cap * 8));
       if (total > ((size_t)2 << 30)) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total > free_b / 3) merged = false;
@@ -1307,8 +1373,6 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
       auto sample_kernel = mode == 3 ? CwSampleKernel<3> : mode == 2 ? CwSampleKernel<2>
                            : mode == 1 ? CwSampleKernel<1> : CwSampleKernel<0>;
       hipLaunchKernelGGL(sample_kernel, dim3(grid), dim3(block), 0, st, c);
-      // first step of the tail (walk_len: none)
-      const int32_t tail = g_walk_tail > 0 && g_walk_tail < walk_len ? g_walk_tail : walk_len;
       for (int32_t s2 = 0; s2 < tail; ++s2) {
         c.step = s2;
         hipLaunchKernelGGL(CwNumberKernel, dim3(grid), dim3(block), 0, st, c);
@@ -1318,11 +1382,19 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
       }
       if (tail < walk_len) {
         c.step = tail;
+        // (the rows take the place of the records of the levels past `tail`: 8 bytes per group
+        // and step where those had 16)
+        if (by_path) c.tail_rows = (uint64_t*)(c.rec + (size_t)(tail + 1) * cap);
         auto tail_kernel = mode == 3 ? CwTailKernel<3> : mode == 2 ? CwTailKernel<2>
                            : mode == 1 ? CwTailKernel<1> : CwTailKernel<0>;
         hipLaunchKernelGGL(tail_kernel, dim3(grid), dim3(block), 0, st, c);
       }
-      {
+      if (by_path) {
+        const int waves = tile_bytes * 4 <= 64 * 1024 ? 4 : tile_bytes * 2 <= 64 * 1024 ? 2 : 1;
+        const int64_t tiles = (n + 63) / 64, wgs = (tiles + waves - 1) / waves;
+        hipLaunchKernelGGL(CwPathKernel, dim3((unsigned)(wgs < 65536 ? wgs : 65536)), dim3(64 * waves),
+                           tile_bytes * waves, st, c, nodes_dev, tail, out_dev);
+      } else {
         int64_t* tr = (int64_t*)(buf + o_tr);
         const int64_t chain_blocks = (n + (int64_t)block * kCwChains - 1) / ((int64_t)block * kCwChains);
         hipLaunchKernelGGL(CwChainKernel, dim3((unsigned)chain_blocks), dim3(block), 0, st, c, nodes_dev, tr);

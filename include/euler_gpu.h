@@ -942,7 +942,7 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  *        walkers (default 262144 - below, one lane per walker is faster: 131 072 walkers x 40 steps
  *        0.45 vs 0.64 ms, 262 144: 0.84 vs 0.77 -; 0 = never).  key 39: workgroups of its per-step
  *        launches (1024; 0 = one per 256 walkers).  key 43: first step from which the
- *        groups stop looking for mergers and finish the walk in one launch (12; 0 =
+ *        groups stop looking for mergers and finish the walk in one launch (9; 0 =
  *        never).  key 44: plain graphs draw with the lean search of the one-kernel
  *        fanout (1 [default]).
  * key 45: 1 [default] = searches go through the weight-bucket index (csrc/wb_index.h: the
