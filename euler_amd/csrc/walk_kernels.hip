@@ -797,14 +797,17 @@ __global__ __launch_bounds__(256) void CwTransposeKernel(const int64_t* tr, int6
 // leave through the LDS tile the same way.  Against CwChainKernel + CwTransposeKernel
 // (1M walkers x 40 steps: 282 + 122 us, a chain of 40 loads per walker and the paths written
 // twice) the chain is s0 = 12 long and every path byte is written once.
-__global__ __launch_bounds__(256) void CwPathKernel(const CwArgs a, const int64_t* starts,
-                                                    const int32_t s0, int64_t* out) {
+__global__ __launch_bounds__(256) void CwPathKernel(const CwArgs a, const int64_t* __restrict__ starts,
+                                                    const int32_t s0, const SmallDiv div_tl,
+                                                    const SmallDiv div_h, int64_t* __restrict__ out) {
   extern __shared__ __align__(16) uint64_t cw_head[];       // per wave: [64][hs] ids, then [64] groups
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, waves = blockDim.x >> 6;
   const int32_t H = s0 + 1, hs = H | 1, TL = a.walk_len - s0, L = a.walk_len + 1;
   uint64_t* head = cw_head + (size_t)wv * (64 * hs + 32);
   uint32_t* s_grp = reinterpret_cast<uint32_t*>(head + 64 * hs);
+  const uint64_t* __restrict__ rows = a.tail_rows;
   const int64_t tiles = (a.cap + 63) / 64;
+  constexpr int kBatch = 8;                      // independent loads in flight per lane
   for (int64_t tile = (int64_t)blockIdx.x * waves + wv; tile < tiles; tile += (int64_t)gridDim.x * waves) {
     const int64_t w0 = tile * 64, w = w0 + lane;
     const int32_t nw = (int32_t)(a.cap - w0 < 64 ? a.cap - w0 : 64);
@@ -823,13 +826,29 @@ __global__ __launch_bounds__(256) void CwPathKernel(const CwArgs a, const int64_
     }
     s_grp[lane] = grp;
     WaveSync();
-    for (int32_t e = lane; e < nw * TL; e += 64) {
-      const int32_t wl = e / TL, j = e - wl * TL;
-      const uint64_t id = a.tail_rows[(int64_t)s_grp[wl] * TL + j];
-      out[(w0 + wl) * L + H + j] = id == 0 ? a.default_node : (int64_t)id;
+    // the tail rows: kBatch loads issued, then their stores (a load-store-load-store loop
+    // would pay a full round trip per element)
+    const int32_t n_tail = nw * TL;
+    for (int32_t e0 = lane; e0 < n_tail; e0 += 64 * kBatch) {
+      uint64_t v[kBatch];
+      int64_t at[kBatch];
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        const int32_t e = e0 + 64 * u;
+        v[u] = 0; at[u] = -1;
+        if (e < n_tail) {
+          const int32_t wl = (int32_t)div_tl((uint32_t)e), j = e - wl * TL;
+          v[u] = rows[(int64_t)s_grp[wl] * TL + j];
+          at[u] = (w0 + wl) * L + H + j;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u)
+        if (at[u] >= 0) out[at[u]] = v[u] == 0 ? a.default_node : (int64_t)v[u];
     }
-    for (int32_t e = lane; e < nw * H; e += 64) {
-      const int32_t wl = e / H, x = e - wl * H;
+    const int32_t n_head = nw * H;
+    for (int32_t e = lane; e < n_head; e += 64) {
+      const int32_t wl = (int32_t)div_h((uint32_t)e), x = e - wl * H;
       const uint64_t id = head[wl * hs + x];
       out[(w0 + wl) * L + x] = (id == 0 && x != 0) ? a.default_node : (int64_t)id;
     }
@@ -1323,7 +1342,7 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
     // the paths by CwPathKernel when a wave's tile of head ids fits in LDS (else records for
     // every level, CwChainKernel + CwTransposeKernel through a transposed copy)
     const size_t tile_bytes = ((size_t)64 * ((tail + 1) | 1) + 32) * 8;
-    const bool by_path = tile_bytes <= 64 * 1024;
+    const bool by_path = tile_bytes <= 64 * 1024 && walk_len - tail < 8192;
     if (merged) {
       const size_t cap = (size_t)n, rows = (size_t)g->view.n_rows + 1;
       o_rec = al(((size_t)walk_len + 2) * 4);
@@ -1392,8 +1411,10 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
       if (by_path) {
         const int waves = tile_bytes * 4 <= 64 * 1024 ? 4 : tile_bytes * 2 <= 64 * 1024 ? 2 : 1;
         const int64_t tiles = (n + 63) / 64, wgs = (tiles + waves - 1) / waves;
+        SmallDiv div_tl, div_h;                   // (exact for e * d < 2^32: e < 64 * d)
+        div_tl.Set((uint32_t)(walk_len - tail)); div_h.Set((uint32_t)(tail + 1));
         hipLaunchKernelGGL(CwPathKernel, dim3((unsigned)(wgs < 65536 ? wgs : 65536)), dim3(64 * waves),
-                           tile_bytes * waves, st, c, nodes_dev, tail, out_dev);
+                           tile_bytes * waves, st, c, nodes_dev, tail, div_tl, div_h, out_dev);
       } else {
         int64_t* tr = (int64_t*)(buf + o_tr);
         const int64_t chain_blocks = (n + (int64_t)block * kCwChains - 1) / ((int64_t)block * kCwChains);
