@@ -679,7 +679,7 @@ __device__ __forceinline__ void WbSamplePair(const GraphView& g, const WbRec rec
 
 // The same pair of draws on ANY graph the weight-bucket index serves - several edge-type
 // groups per node, hashed ids - for one listed type: the segment's limits and the row's first
-// block come out of the row's two small records (row_meta + wbg), read side by side.
+// block come out of the row's weight-bucket record (common.h: GraphView::wbg) alone.
 struct WbSeg {
   uint32_t wb_lo, row_deg;      // the row: first block, edges (the buckets are the ROW's)
   uint32_t lo, deg;             // the listed type's segment: first flat edge, edges
@@ -691,18 +691,17 @@ __device__ __forceinline__ void LoadWbSeg(const GraphView& g, uint64_t node, int
   s->wb_lo = 0; s->row_deg = 0; s->lo = 0; s->deg = 0; s->row_total = 0.f; s->lim_b = 0.f; s->lim_e = 0.f;
   s->row = FindRow(g, node);
   if (s->row < 0 || t < 0 || t >= g.T) return;
-  const uint8_t* rec = g.row_meta + s->row * (int64_t)g.meta_stride;
   const uint8_t* wrec = g.wbg + s->row * (int64_t)g.wbg_stride;
-  const int64_t row_ptr = *reinterpret_cast<const int64_t*>(rec);
-  const int32_t* te = reinterpret_cast<const int32_t*>(rec + 8);
-  const float* lim = reinterpret_cast<const float*>(wrec + 4);
+  const uint32_t* hd = reinterpret_cast<const uint32_t*>(wrec);
+  const int32_t* te = reinterpret_cast<const int32_t*>(wrec + 8);
+  const float* lim = reinterpret_cast<const float*>(wrec + 8 + 4 * g.T);
   const int32_t b = t == 0 ? 0 : te[t - 1], e = te[t];
-  s->wb_lo = *reinterpret_cast<const uint32_t*>(wrec);
+  s->wb_lo = hd[0];
   s->row_deg = (uint32_t)te[g.T - 1];
   s->row_total = lim[g.T - 1];
   s->lim_e = lim[t];
   s->lim_b = t == 0 ? 0.f : lim[t - 1];
-  s->lo = (uint32_t)(row_ptr + b);
+  s->lo = hd[1] + (uint32_t)b;
   s->deg = e > b ? (uint32_t)(e - b) : 0u;
 }
 

@@ -819,17 +819,20 @@ __global__ void WbCountKernel(GraphView g, uint32_t* nbk) {
   nbk[row] = n;
 }
 
-// the per-row records: wbg {wb_lo, lim[T]} for every graph, wrec for plain ones
+// the per-row records: wbg {wb_lo, row_lo, type_end[T], lim[T]} for every graph, wrec for plain ones
 __global__ void WbRecKernel(GraphView g, const uint32_t* wb_lo, uint8_t* wbg, int32_t wbg_stride,
                             WbRec* rec) {
   const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= g.n_rows) return;
   const RowMeta m = LoadRowMeta(g, row);
   uint8_t* out = wbg + row * (int64_t)wbg_stride;
-  *reinterpret_cast<uint32_t*>(out) = wb_lo[row];
-  float* lim = reinterpret_cast<float*>(out + 4);
+  reinterpret_cast<uint32_t*>(out)[0] = wb_lo[row];
+  reinterpret_cast<uint32_t*>(out)[1] = (uint32_t)m.row_ptr;
+  int32_t* te = reinterpret_cast<int32_t*>(out + 8);
+  float* lim = reinterpret_cast<float*>(out + 8 + 4 * g.T);
   for (int32_t t = 0; t < g.T; ++t) {
     const int32_t e = m.type_end[t];
+    te[t] = e;
     lim[t] = e > 0 ? g.prefix_w[m.row_ptr + e - 1] : 0.f;
   }
   if (rec != nullptr) {
@@ -904,7 +907,7 @@ int BuildWbIndex(GraphBuilder* b) {
   uint32_t n_wb32 = 0;
   EG_HIP(hipMemcpy(&n_wb32, wb_lo + v.n_rows, 4, hipMemcpyDeviceToHost));
   const int64_t n_wb = (int64_t)n_wb32;
-  const int32_t stride = 4 + 4 * v.T;
+  const int32_t stride = 8 + 8 * v.T;
   // (checked before allocating: an index that does not fit is an optimisation declined)
   {
     size_t free_b = 0, total_b = 0;

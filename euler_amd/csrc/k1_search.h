@@ -64,18 +64,47 @@ struct Segment {
   float row_total;
 };
 
-// The row's weight-bucket record: first block, total, and the limits of the edge-type
-// group [b, e] - all out of ONE small record read beside the row record (the pivot path
-// reads the limits from two block lines, a dependent trip).
+// The row's weight-bucket record (common.h: GraphView::wbg): first block, total, and the
+// limits of the edge-type group [b, e] - out of ONE small record (the pivot path reads the
+// limits from two block lines, a dependent trip).
 __device__ __forceinline__ void LoadWbSegment(const GraphView& g, int64_t row, int32_t t,
                                               int32_t row_deg, Segment* sg) {
   const uint8_t* rec = g.wbg + row * (int64_t)g.wbg_stride;
-  const float* lim = reinterpret_cast<const float*>(rec + 4);
+  const float* lim = reinterpret_cast<const float*>(rec + 8 + 4 * g.T);
   sg->wb_lo = *reinterpret_cast<const uint32_t*>(rec);
   sg->row_deg = (uint32_t)row_deg;
   sg->row_total = lim[g.T - 1];
   sg->limit_end = lim[t];
   sg->limit_begin = t == 0 ? 0.f : lim[t - 1];
+}
+
+// ... and the whole segment of listed type t from that record alone: the row record is not
+// read at all (false: the row has no edge of the type)
+__device__ __forceinline__ bool LoadWbSegmentOnly(const GraphView& g, int64_t row, int32_t t,
+                                                  Segment* sg) {
+  const uint8_t* rec = g.wbg + row * (int64_t)g.wbg_stride;
+  const int32_t* te = reinterpret_cast<const int32_t*>(rec + 8);
+  const float* lim = reinterpret_cast<const float*>(rec + 8 + 4 * g.T);
+  if (g.T == 1) {                        // one 16-byte load
+    const uint4 q = *reinterpret_cast<const uint4*>(rec);
+    sg->wb_lo = q.x; sg->row_ptr = (int64_t)q.y;
+    sg->b = 0; sg->e = (int32_t)q.z - 1;
+    sg->row_deg = q.z;
+    sg->row_total = __uint_as_float(q.w);
+    sg->limit_begin = 0.f; sg->limit_end = sg->row_total;
+  } else {
+    sg->wb_lo = reinterpret_cast<const uint32_t*>(rec)[0];
+    sg->row_ptr = (int64_t)reinterpret_cast<const uint32_t*>(rec)[1];
+    sg->b = t == 0 ? 0 : te[t - 1];
+    sg->e = te[t] - 1;
+    sg->row_deg = (uint32_t)te[g.T - 1];
+    sg->row_total = lim[g.T - 1];
+    sg->limit_end = lim[t];
+    sg->limit_begin = t == 0 ? 0.f : lim[t - 1];
+  }
+  sg->lo = sg->row_ptr + sg->b;
+  sg->hi = sg->row_ptr + sg->e;
+  return sg->e >= sg->b;
 }
 
 // One draw u on a segment: the neighbour RandomSelect picks and its weight.
@@ -317,19 +346,13 @@ template <bool BLOCKED = false>
 __device__ __forceinline__ bool LoadSegment(const GraphView& g, int64_t row,
                                             int32_t t, Segment* sg) {
   if (row < 0 || t < 0 || t >= g.T) return false;
+  if (BLOCKED && g.wbg != nullptr) return LoadWbSegmentOnly(g, row, t, sg);
   const uint8_t* rec = g.row_meta + row * (int64_t)g.meta_stride;
   if (g.T == 1) {
     const uint4 q = *reinterpret_cast<const uint4*>(rec);
     sg->row_ptr = (int64_t)(((uint64_t)q.y << 32) | q.x);
     sg->b = 0;
     sg->e = (int32_t)q.z - 1;
-    if (BLOCKED && g.wbg != nullptr) {
-      // (loaded whether the row has edges or not: the load is issued beside the record's)
-      LoadWbSegment(g, row, 0, (int32_t)q.z, sg);
-      sg->lo = sg->row_ptr;
-      sg->hi = sg->row_ptr + sg->e;
-      return sg->e >= 0;
-    }
     if (g.total_in_meta) {
       // the record's type sum IS the row's last running sum (verified at build):
       // one dependent load less per root
@@ -345,12 +368,6 @@ __device__ __forceinline__ bool LoadSegment(const GraphView& g, int64_t row,
     const int32_t* te = reinterpret_cast<const int32_t*>(rec + 8);
     sg->b = t == 0 ? 0 : te[t - 1];
     sg->e = te[t] - 1;
-    if (BLOCKED && g.wbg != nullptr) {
-      LoadWbSegment(g, row, t, te[g.T - 1], sg);
-      sg->lo = sg->row_ptr + sg->b;
-      sg->hi = sg->row_ptr + sg->e;
-      return sg->e >= sg->b;
-    }
   }
   if (sg->e < sg->b) return false;
   sg->lo = sg->row_ptr + sg->b;

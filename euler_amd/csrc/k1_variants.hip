@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256, 6) void SampleNeighborSetsKernel(const SampleS
 // a dozen small loads per lane, all hits, and yet the launch is bound by exactly that: the CU's
 // memory pipe works off load instructions x lanes, not bytes.  Here a workgroup takes
 // 256 / count ROOTS: their rows are found by one lane each, their records (8 + 8 T bytes of
-// row_meta, 4 + 4 T of {wb_lo, lim[T]}) are copied into LDS by all lanes word by word - once
+// {wb_lo, row_lo, type_end[T], lim[T]}, 4 T of the row record's type sums) are copied into LDS by all lanes word by word - once
 // for all the sets - and a sample lane then needs global memory only for its block's keys and
 // its id, set after set.  Graphs with the weight-bucket index only (the kernel above serves
 // the rest).
@@ -253,7 +253,9 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborSetsLdsKerne
                                                                                  const int32_t rpb) {
   extern __shared__ __align__(16) uint32_t sl_smem[];
   const int32_t T = a.g.T;
-  const int32_t mw = 2 + 2 * T, W = 3 + 3 * T;            // words of row_meta / of both records
+  // per root: the record of the weight-bucket index (2 + 2 T words: first block, first edge,
+  // group ends, their running sums) and the T type sums of the row record (for the type draws)
+  const int32_t mw = 2 + 2 * T, W = 2 + 3 * T;
   int64_t* s_row = reinterpret_cast<int64_t*>(sl_smem);                  // [rpb]
   uint32_t* s_rec = sl_smem + 2 * rpb;                                    // [rpb][W]
   const int32_t q = (int32_t)threadIdx.x / a.count, j = (int32_t)threadIdx.x - q * a.count;
@@ -268,8 +270,8 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborSetsLdsKerne
       const int64_t row = s_row[r];
       uint32_t v = 0;
       if (row >= 0) {
-        v = k < mw ? reinterpret_cast<const uint32_t*>(a.g.row_meta + row * (int64_t)a.g.meta_stride)[k]
-                   : reinterpret_cast<const uint32_t*>(a.g.wbg + row * (int64_t)a.g.wbg_stride)[k - mw];
+        v = k < mw ? reinterpret_cast<const uint32_t*>(a.g.wbg + row * (int64_t)a.g.wbg_stride)[k]
+                   : reinterpret_cast<const uint32_t*>(a.g.row_meta + row * (int64_t)a.g.meta_stride)[2 + T + (k - mw)];
       }
       s_rec[r * W + k] = v;
     }
@@ -280,8 +282,8 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborSetsLdsKerne
       const int64_t row = s_row[q];
       const uint32_t* rec = s_rec + q * W;
       const int32_t* type_end = reinterpret_cast<const int32_t*>(rec + 2);
-      const float* type_prefix = reinterpret_cast<const float*>(rec + 2 + T);
-      const float* lim = reinterpret_cast<const float*>(rec + mw + 1);
+      const float* lim = reinterpret_cast<const float*>(rec + 2 + T);
+      const float* type_prefix = reinterpret_cast<const float*>(rec + mw);
       const uint64_t my_node = row >= 0 ? a.roots[r] : 0;
       for (int32_t set = 0; set < a.n_sets; ++set) {
         const int32_t k = a.set_k[set];
@@ -326,11 +328,11 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborSetsLdsKerne
         }
         if (draw) {
           Segment sg;
-          sg.row_ptr = (int64_t)(((uint64_t)rec[1] << 32) | rec[0]);
+          sg.row_ptr = (int64_t)rec[1];
           sg.b = t == 0 ? 0 : type_end[t - 1];
           sg.e = type_end[t] - 1;
           sg.lo = sg.row_ptr + sg.b; sg.hi = sg.row_ptr + sg.e;
-          sg.wb_lo = rec[mw];
+          sg.wb_lo = rec[0];
           sg.row_deg = (uint32_t)type_end[T - 1];
           sg.row_total = lim[T - 1];
           sg.limit_end = lim[t];
@@ -394,7 +396,7 @@ bool LaunchSampleNeighborSets(const euler_gpu_graph* g, hipStream_t stream, uint
   }
   const int64_t total = n * (int64_t)count * n_sets;
   const int32_t rpb = count <= 256 ? 256 / count : 0;
-  const size_t lds = (size_t)rpb * (8 + 4 * (3 + 3 * (size_t)a.g.T));
+  const size_t lds = (size_t)rpb * (8 + 4 * (2 + 3 * (size_t)a.g.T));
   if (a.g.wbg != nullptr && a.g.wb != nullptr && rpb > 0 && lds <= 48 * 1024 && g_k1_sets_lds != 0) {
     int64_t blocks = (n + rpb - 1) / rpb;
     if (blocks > kK1GridCap) blocks = kK1GridCap;
