@@ -819,9 +819,8 @@ __global__ void WbCountKernel(GraphView g, uint32_t* nbk) {
   nbk[row] = n;
 }
 
-// the per-row records: wbg {wb_lo, row_lo, type_end[T], lim[T]} for every graph, wrec for plain ones
-__global__ void WbRecKernel(GraphView g, const uint32_t* wb_lo, uint8_t* wbg, int32_t wbg_stride,
-                            WbRec* rec) {
+// the per-row records {wb_lo, row_lo, type_end[T], lim[T]} (plain graphs read them as WbRec)
+__global__ void WbRecKernel(GraphView g, const uint32_t* wb_lo, uint8_t* wbg, int32_t wbg_stride) {
   const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= g.n_rows) return;
   const RowMeta m = LoadRowMeta(g, row);
@@ -834,13 +833,6 @@ __global__ void WbRecKernel(GraphView g, const uint32_t* wb_lo, uint8_t* wbg, in
     const int32_t e = m.type_end[t];
     te[t] = e;
     lim[t] = e > 0 ? g.prefix_w[m.row_ptr + e - 1] : 0.f;
-  }
-  if (rec != nullptr) {
-    WbRec r;
-    const int32_t deg = m.type_end[0];
-    r.wb_lo = wb_lo[row]; r.deg = (uint32_t)deg; r.lo = (uint32_t)m.row_ptr;
-    r.total = deg > 0 ? g.prefix_w[m.row_ptr + deg - 1] : 0.f;
-    rec[row] = r;
   }
 }
 
@@ -911,16 +903,18 @@ int BuildWbIndex(GraphBuilder* b) {
   // (checked before allocating: an index that does not fit is an optimisation declined)
   {
     size_t free_b = 0, total_b = 0;
-    const size_t need = (size_t)n_wb * sizeof(EdgeBlock) + (size_t)v.n_rows * (stride + (plain ? 16 : 0));
+    const size_t need = (size_t)n_wb * sizeof(EdgeBlock) + (size_t)v.n_rows * stride;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || need + ((size_t)1 << 30) > free_b)
       return EULER_GPU_OK;
   }
   uint8_t* wbg = b->Alloc<uint8_t>((size_t)v.n_rows * stride + 16);
-  WbRec* rec = plain ? b->Alloc<WbRec>((size_t)v.n_rows) : nullptr;
+  static_assert(offsetof(WbRec, lo) == 4 && offsetof(WbRec, deg) == 8 && offsetof(WbRec, total) == 12,
+                "WbRec is the general record at T = 1");
+  const WbRec* rec = plain ? reinterpret_cast<const WbRec*>(wbg) : nullptr;
   EdgeBlock* wb = b->Alloc<EdgeBlock>((size_t)n_wb);
   if (b->rc != EULER_GPU_OK) return b->rc;
   hipLaunchKernelGGL(WbRecKernel, dim3((v.n_rows + block - 1) / block), dim3(block), 0, 0, v, wb_lo,
-                     wbg, stride, rec);
+                     wbg, stride);
   EG_HIP(hipMalloc((void**)&tmp.ovf, 16));
   unsigned long long* ovf = tmp.ovf;
   EG_HIP(hipMemset(ovf, 0, 16));

@@ -34,11 +34,13 @@ namespace euler_gpu {
 
 constexpr uint32_t kWbShift = 2;      // a bucket per 4 edges of a large row
 
-// 16-byte row record of the WB path: everything a draw needs before its leaf
+// 16-byte row record of the WB path: everything a draw needs before its leaf.  (The general
+// record of common.h - {wb_lo, row_lo, type_end[T], lim[T]} - at T = 1: plain graphs keep ONE
+// array and read it through either view.)
 struct alignas(16) WbRec {
   uint32_t wb_lo;     // first block of the row in `wb`
-  uint32_t deg;       // edges of the row (single edge-type group)
   uint32_t lo;        // first edge in the flat arrays (cold path, edge numbers)
+  uint32_t deg;       // edges of the row (single edge-type group)
   float total;        // last running sum of the row
 };
 static_assert(sizeof(WbRec) == 16, "WbRec must be 16 bytes");

@@ -93,7 +93,7 @@ int64_t hc_wb_build(void* h) {
   for (int64_t r = 0; r < v.n_rows; ++r) {
     const RowMeta m = LoadRowMeta(v, r);
     const uint32_t deg = (uint32_t)m.type_end[0];
-    WbRec rec{(uint32_t)blocks, deg, (uint32_t)m.row_ptr, deg ? v.prefix_w[m.row_ptr + deg - 1] : 0.f};
+    WbRec rec{(uint32_t)blocks, (uint32_t)m.row_ptr, deg, deg ? v.prefix_w[m.row_ptr + deg - 1] : 0.f};
     g->wrec[(size_t)r] = rec;
     blocks += WbBuckets(deg);
   }
