@@ -280,6 +280,19 @@ def test_cpp_host_example_builds():
     assert "libeuler_gpu.so" in deps and "torch" not in deps and "python" not in deps.lower()
 
 
+def test_makefile_lists_every_kernel_header():
+    """Every header of euler_amd/csrc (and of include/) is a dependency of every object in the
+    library's Makefile: a header left out of HDRS lets objects compiled against two versions of a
+    record struct be linked into one library (WbRec in wb_index.h did exactly that once - a
+    memory fault on the GPU, nothing at build time)."""
+    import glob
+    import re
+    csrc = os.path.join(ROOT, "euler_amd", "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    hdrs = re.search(r"^HDRS :=(.*?)\n\n", mk, re.S | re.M).group(1)
+    for h in glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h")):
+        assert os.path.basename(h) in hdrs, os.path.basename(h)
+
 def test_dat_reader_many_partitions_keeps_file_order(O, tmp_path):
     """The partition files are parsed by several host threads; rows must still
     come out in file order (names sorted), every row intact, and a corrupt file
