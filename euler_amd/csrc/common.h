@@ -107,13 +107,14 @@ struct GraphView {
   const struct EdgeBlock* wb;
   int64_t n_wb;
   // every graph the index serves (monotone non-uniform weights, < 2^32 edges): per row
-  // {uint32 wb_lo; uint32 row_lo; int32 type_end[T]; float lim[T]} - the row's first block,
-  // its first edge, the ends of its edge-type groups and the running sum at the end of each
-  // (lim[T-1] = the row's total; limit_begin of group t = lim[t-1]): everything a draw of ONE
-  // listed type needs, in one record - a cold root costs one line, not the row record's and
+  // {uint32 wb_lo; uint32 row_lo; int32 type_end[T]; float lim[T]; float type_sum[T] (T > 1)} -
+  // the row's first block, its first edge, the ends of its edge-type groups, the running sum
+  // at the end of each (lim[T-1] = the row's total; limit_begin of group t = lim[t-1]) and the
+  // row record's cumulative type sums (what a type draw selects by): everything a draw needs
+  // before its block, in one record - a cold root costs one line, not the row record's and
   // this one's, and a segment's limits are not two more dependent loads
   const uint8_t* wbg;
-  int32_t wbg_stride;           // 8 + 8 T
+  int32_t wbg_stride;           // 16 (T = 1), else 8 + 12 T
   int32_t wb_lean_ok;           // at most 2 buckets in a thousand overflow their block (counted at
                                 // build): the lean kernels - whose second chance is the reference's
                                 // bisection - draw through the index; otherwise they keep the pivot

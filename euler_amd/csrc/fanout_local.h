@@ -77,6 +77,11 @@ struct FanoutLocalArgs {
   int64_t mb_n;
   const uint32_t* call_ids;
   uint32_t call_stride;
+  // WB == 3 (every hop lists k > 1 edge types: a type draw, then the neighbour draw): the
+  // lists of the two hops and how Node::__SampleNeighbor reads a list of that length
+  // (device_fns.h: kTypeSub / kTypeAll)
+  int32_t k, type_mode;
+  int32_t et1[kMaxListedTypes], et2[kMaxListedTypes];
   uint32_t* row_index;      // lean kernel, not null: the (unique rows, index) form - id2 / w2 / ty2
                             // receive each tile's DISTINCT hop-2 rows (row r0 * c1 + slot), row_index
                             // the row of every hop-1 sample; nothing is expanded
@@ -705,44 +710,49 @@ __device__ __forceinline__ void LoadWbSeg(const GraphView& g, uint64_t node, int
   s->deg = e > b ? (uint32_t)(e - b) : 0u;
 }
 
+// Two draws of one row, each on its own segment (sg0 / sg1 of types t0 / t1: the same one when
+// the hop lists one type, the drawn ones when it lists several).
 template <bool TWO = true>
-__device__ __forceinline__ void WbSamplePairG(const GraphView& g, const WbSeg sg, const int32_t t,
-                                              const bool live, const double u0, const double u1,
-                                              uint64_t id[2], float w[2], uint32_t m[2]) {
+__device__ __forceinline__ void WbSamplePairG2(const GraphView& g, const WbSeg sg0, const WbSeg sg1,
+                                               const int32_t t0, const int32_t t1, const bool live0,
+                                               const bool live1, const double u0, const double u1,
+                                               uint64_t id[2], float w[2], uint32_t m[2]) {
   // r = u * (limit_end - limit_begin) + limit_begin as the reference rounds it (ScaleDraw)
-  const double span = (double)__fsub_rn(sg.lim_e, sg.lim_b);
-  const double r0 = __dadd_rn(__dmul_rn(u0, span), (double)sg.lim_b);
-  const double r1 = __dadd_rn(__dmul_rn(u1, span), (double)sg.lim_b);
-  bool cold0 = live && !((double)sg.lim_e > r0);
-  bool cold1 = TWO && live && !((double)sg.lim_e > r1);
+  const double span0 = (double)__fsub_rn(sg0.lim_e, sg0.lim_b);
+  const double span1 = (double)__fsub_rn(sg1.lim_e, sg1.lim_b);
+  const double r0 = __dadd_rn(__dmul_rn(u0, span0), (double)sg0.lim_b);
+  const double r1 = __dadd_rn(__dmul_rn(u1, span1), (double)sg1.lim_b);
+  bool cold0 = live0 && !((double)sg0.lim_e > r0);
+  bool cold1 = TWO && live1 && !((double)sg1.lim_e > r1);
   const float f0 = WbFloorToFloat(r0), f1 = WbFloorToFloat(r1);
-  const uint32_t nbk = WbBuckets(sg.row_deg);
+  const uint32_t nbk = WbBuckets(sg0.row_deg);          // (the buckets are the ROW's)
   uint32_t j0 = 0u, j1 = 0u;
   if (nbk > 1u) {
-    const float scale = WbScale(nbk, sg.row_total);
+    const float scale = WbScale(nbk, sg0.row_total);
     j0 = WbBucketOf(f0, nbk, scale);
     j1 = WbBucketOf(f1, nbk, scale);
   }
-  const EdgeBlock* b0 = g.wb + sg.wb_lo + j0;
-  const EdgeBlock* b1 = g.wb + sg.wb_lo + (TWO ? j1 : j0);
+  const EdgeBlock* b0 = g.wb + sg0.wb_lo + j0;
+  const EdgeBlock* b1 = g.wb + sg0.wb_lo + (TWO ? j1 : j0);
   const WbKeys k0 = WbLoadKeys(b0);
   WbKeys k1 = k0;
   if (TWO) k1 = WbLoadKeys(b1);
-  id[0] = 0; id[1] = 0; w[0] = 0.f; w[1] = 0.f; m[0] = sg.lo; m[1] = sg.lo;
+  id[0] = 0; id[1] = 0; w[0] = 0.f; w[1] = 0.f; m[0] = sg0.lo; m[1] = sg1.lo;
   const int32_t i0 = WbPickKeys(k0, f0, &w[0], &m[0]);
   const int32_t i1 = TWO ? WbPickKeys(k1, f1, &w[1], &m[1]) : 0;
-  const bool hot0 = live && !cold0 && i0 >= 0;
-  const bool hot1 = TWO && live && !cold1 && i1 >= 0;
+  const bool hot0 = live0 && !cold0 && i0 >= 0;
+  const bool hot1 = TWO && live1 && !cold1 && i1 >= 0;
   if (hot0) id[0] = b0->nbr[i0];
   if (hot1) id[1] = b1->nbr[i1];
-  cold0 = live && !hot0;
-  cold1 = TWO && live && !hot1;
-  if (!TWO) { id[1] = 0; w[1] = 0.f; m[1] = sg.lo; }
+  cold0 = live0 && !hot0;
+  cold1 = TWO && live1 && !hot1;
+  if (!TWO) { id[1] = 0; w[1] = 0.f; m[1] = sg1.lo; }
   if (__ballot(cold0 || cold1) != 0ull) {
 #pragma nounroll
     for (int s = 0; s < (TWO ? 2 : 1); ++s) {
       if (s == 0 ? cold0 : cold1) {
-        const RowMeta rm = LoadRowMeta(g, sg.row);
+        const int32_t t = s == 0 ? t0 : t1;
+        const RowMeta rm = LoadRowMeta(g, sg0.row);
         const float* nw = g.prefix_w + rm.row_ptr;
         const int32_t b = t == 0 ? 0 : rm.type_end[t - 1];
         const uint32_t mid = (uint32_t)RandomSelect(nw, (uint64_t)b, (uint64_t)(rm.type_end[t] - 1), s == 0 ? u0 : u1);
@@ -755,11 +765,106 @@ __device__ __forceinline__ void WbSamplePairG(const GraphView& g, const WbSeg sg
   }
 }
 
+template <bool TWO = true>
+__device__ __forceinline__ void WbSamplePairG(const GraphView& g, const WbSeg sg, const int32_t t,
+                                              const bool live, const double u0, const double u1,
+                                              uint64_t id[2], float w[2], uint32_t m[2]) {
+  WbSamplePairG2<TWO>(g, sg, sg, t, t, live, live, u0, u1, id, w, m);
+}
+
+// ---- hops that list SEVERAL edge types (WB == 3) ----------------------------------------
+// Node::__SampleNeighbor (core/graph/node.cc:98-167) then draws the TYPE first - a CDF over the
+// listed types in the listed order, or over all groups when the list is as long as the graph
+// has types (device_fns.h: TypeModeOf) - and the neighbour inside that type's group with the
+// second half of the sample's Philox block (one block per SAMPLE here, not per pair).  Both
+// come out of the row's weight-bucket record, which carries the type sums for that.
+struct WbRowT {
+  const uint32_t* hd;           // {wb_lo, row_lo}
+  const int32_t* te;            // [T] ends of the type groups
+  const float* lim;             // [T] running sums at those ends
+  const float* tsum;            // [T] cumulative type sums
+  int64_t row;
+  uint32_t row_lo, row_deg;
+  bool valid;                   // the listed types have weight: the row yields samples
+};
+
+__device__ __forceinline__ void LoadWbRowT(const GraphView& g, const uint64_t node, const int32_t mode,
+                                           const int32_t* et, const int32_t k, WbRowT* r) {
+  r->hd = nullptr; r->te = nullptr; r->lim = nullptr; r->tsum = nullptr;
+  r->row_lo = 0; r->row_deg = 0; r->valid = false;
+  r->row = FindRow(g, node);
+  if (r->row < 0) return;
+  const uint8_t* rec = g.wbg + r->row * (int64_t)g.wbg_stride;
+  r->hd = reinterpret_cast<const uint32_t*>(rec);
+  r->te = reinterpret_cast<const int32_t*>(rec + 8);
+  r->lim = reinterpret_cast<const float*>(rec + 8 + 4 * g.T);
+  r->tsum = reinterpret_cast<const float*>(rec + 8 + 8 * g.T);
+  r->row_lo = r->hd[1];
+  r->row_deg = (uint32_t)r->te[g.T - 1];
+  if (mode == kTypeSub) {
+    bool ok = true;
+    for (int32_t i = 0; i < k; ++i) ok = ok && et[i] >= 0 && et[i] < g.T;      // node.cc:109-118
+    r->valid = ok && SubTypeSum{r->tsum, et}((uint64_t)(k - 1)) != 0.f;        // node.cc:139-141
+  } else {
+    r->valid = r->tsum[g.T - 1] != 0.f;
+  }
+}
+
+// the type of one sample and that type's segment; false = a group without edges was drawn
+// (only through an inconsistent row: the reference reads out of range there, SampleAt in
+// device_fns.h answers the sentinel {0, 0, type 0})
+__device__ __forceinline__ bool WbTypedSeg(const GraphView& g, const WbRowT& r, const int32_t mode,
+                                           const int32_t* et, const int32_t k, const double u_type,
+                                           int32_t* t_out, WbSeg* s) {
+  const int32_t t = mode == kTypeSub
+      ? et[RandomSelectT(SubTypeSum{r.tsum, et}, 0, (uint64_t)(k - 1), u_type)]
+      : (int32_t)RandomSelect(r.tsum, 0, (uint64_t)(g.T - 1), u_type);
+  const int32_t b = t == 0 ? 0 : r.te[t - 1], e = r.te[t];
+  s->wb_lo = r.hd[0];
+  s->row_deg = r.row_deg;
+  s->row_total = r.lim[g.T - 1];
+  s->lim_e = r.lim[t];
+  s->lim_b = t == 0 ? 0.f : r.lim[t - 1];
+  s->lo = r.row_lo + (uint32_t)b;
+  s->deg = e > b ? (uint32_t)(e - b) : 0u;
+  s->row = r.row;
+  *t_out = t;
+  return e > b;
+}
+
+// The two samples 2 jp and 2 jp + 1 of `node` on a typed hop.  tt[] = their types (-1: the row
+// yields nothing, 0 with id 0 for the sentinel); *sentinel = a sentinel was drawn (the caller
+// must not tell children apart by edge offset then).
+__device__ __forceinline__ void WbSampleTypedPair(const GraphView& g, const WbRowT& r, const int32_t mode,
+                                                  const int32_t* et, const int32_t k, const uint64_t seed,
+                                                  const uint32_t call, const uint64_t node,
+                                                  const uint32_t jp, const bool live, const bool two,
+                                                  uint64_t id[2], float w[2], uint32_t m[2],
+                                                  int32_t tt[2], bool* sentinel) {
+  const Philox4 pa = RngBlock(seed, call, kDomainNeighbor, node, 2u * jp);
+  const Philox4 pb = RngBlock(seed, call, kDomainNeighbor, node, 2u * jp + 1u);
+  WbSeg sg0, sg1;
+  sg0.wb_lo = 0; sg0.row_deg = 0; sg0.lo = 0; sg0.deg = 0; sg0.row_total = 0.f; sg0.lim_b = 0.f; sg0.lim_e = 0.f; sg0.row = -1;
+  sg1 = sg0;
+  tt[0] = -1; tt[1] = -1;
+  bool ok0 = false, ok1 = false;
+  if (live) {
+    ok0 = WbTypedSeg(g, r, mode, et, k, UnitFromWords(pa.w[0], pa.w[1]), &tt[0], &sg0);
+    if (two) ok1 = WbTypedSeg(g, r, mode, et, k, UnitFromWords(pb.w[0], pb.w[1]), &tt[1], &sg1);
+    else sg1 = sg0;
+  }
+  WbSamplePairG2<true>(g, sg0, sg1, tt[0], tt[1], ok0, ok1, UnitFromWords(pa.w[2], pa.w[3]),
+                       UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
+  *sentinel = live && (!ok0 || (two && !ok1));
+  if (live && !ok0) { id[0] = 0; w[0] = 0.f; m[0] = r.row_lo; tt[0] = 0; }
+  if (live && two && !ok1) { id[1] = 0; w[1] = 0.f; m[1] = r.row_lo; tt[1] = 0; }
+}
+
 struct FanoutLeanLds {
-  uint32_t o_sid, o_c1, o_slotid, o_mask, o_sw, o_w1, o_st, o_slot, o_rvalid, bytes;
+  uint32_t o_sid, o_c1, o_slotid, o_mask, o_sw, o_w1, o_st, o_slot, o_rvalid, o_t1, o_t2, bytes;
 };
 __host__ __device__ inline FanoutLeanLds FanoutLeanLayout(int32_t gr, int32_t c1, int32_t c2,
-                                                          int32_t cap) {
+                                                          int32_t cap, bool typed = false) {
   FanoutLeanLds L;
   const uint32_t p = (uint32_t)gr * (uint32_t)c1;
   const uint32_t s = (uint32_t)cap * (uint32_t)c2;
@@ -773,6 +878,11 @@ __host__ __device__ inline FanoutLeanLds FanoutLeanLayout(int32_t gr, int32_t c1
   L.o_st = o; o += (uint32_t)cap * 4;       // i32 [cap]      ... type (or -1)
   L.o_slot = o; o += (p * 2 + 3) & ~3u;     // u16 [gr][c1]   slot of the sample's child
   L.o_rvalid = o; o += ((uint32_t)gr + 3) & ~3u;
+  L.o_t1 = o; L.o_t2 = o;
+  if (typed) {                              // i8: the type of every sample (WB == 3)
+    o += (p + 3) & ~3u;                     //   [gr][c1]
+    L.o_t2 = o; o += (s + 3) & ~3u;         //   [cap][c2]
+  }
   L.bytes = (o + 15) & ~15u;
   return L;
 }
@@ -783,7 +893,8 @@ __host__ __device__ inline FanoutLeanLds FanoutLeanLayout(int32_t gr, int32_t c1
 // the phase boundaries.
 // WB: 1 = draws through the weight-bucket index (WbSamplePair) instead of the pivot levels;
 // 2 = the same on graphs with several edge-type groups / hashed ids (WbSamplePairG: one listed
-// type per hop, no neighbour id 0).
+// type per hop, no neighbour id 0); 3 = ... and hops that list several types (a type draw per
+// sample, WbSampleTypedPair; at most 127 types).
 template <bool WIDE, int WPS, bool UNIFORM = false, int WB = 0>
 __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
     const FanoutLocalArgs a) {
@@ -791,7 +902,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
   const int lane = threadIdx.x & 63;
   const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int waves_per_block = blockDim.x >> 6;
-  const FanoutLeanLds L = FanoutLeanLayout(a.gr, a.c1, a.c2, a.cap);
+  const FanoutLeanLds L = FanoutLeanLayout(a.gr, a.c1, a.c2, a.cap, WB == 3);
   uint8_t* base = fl_smem + (size_t)wave_in_block * a.wave_lds;
   uint64_t* s_sid = reinterpret_cast<uint64_t*>(base + L.o_sid);
   uint64_t* s_c1 = reinterpret_cast<uint64_t*>(base + L.o_c1);
@@ -802,6 +913,8 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
   int32_t* s_st = reinterpret_cast<int32_t*>(base + L.o_st);
   uint16_t* s_slot = reinterpret_cast<uint16_t*>(base + L.o_slot);
   uint8_t* s_rvalid = base + L.o_rvalid;
+  int8_t* s_t1 = reinterpret_cast<int8_t*>(base + L.o_t1);      // (WB == 3)
+  int8_t* s_t2 = reinterpret_cast<int8_t*>(base + L.o_t2);
   // (no local copy of the view: its level offsets are indexed by a runtime level, and a
   // private copy indexed that way lives in scratch memory)
   const GraphView& g = a.g;
@@ -837,9 +950,14 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
       WbRec wr{0u, 0u, 0u, 0.f};
       WbSeg ws;
       if (WB == 2) { ws.wb_lo = 0; ws.row_deg = 0; ws.lo = 0; ws.deg = 0; ws.row_total = 0.f; ws.lim_b = 0.f; ws.lim_e = 0.f; ws.row = -1; }
+      WbRowT wt;
+      if (WB == 3) { wt.hd = nullptr; wt.te = nullptr; wt.lim = nullptr; wt.tsum = nullptr; wt.row = -1; wt.row_lo = 0; wt.row_deg = 0; wt.valid = false; }
       if (in) {
         node = a.roots[r0 + q];
-        if (WB == 2) {
+        if (WB == 3) {
+          LoadWbRowT(g, node, a.type_mode, a.et1, a.k, &wt);
+          lo = wt.row_lo; deg = wt.valid ? (int32_t)wt.row_deg : 0;
+        } else if (WB == 2) {
           LoadWbSeg(g, node, a.t1, &ws);
           lo = ws.lo; deg = (int32_t)ws.deg;
         } else {
@@ -856,9 +974,15 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
         }
       }
       const bool live = in && deg > 0 && !EG_FL_ABLATE(a, 8);
-      const Philox4 pb = RngBlock(a.seed, tile_call, kDomainNeighbor, node, jp);
       uint64_t id[2]; float w[2]; uint32_t m[2];
-      if (WB == 2) WbSamplePairG(g, ws, a.t1, live, UnitFromWords(pb.w[0], pb.w[1]),
+      int32_t tt[2] = {a.t1, a.t1};
+      bool sentinel = false;
+      Philox4 pb;
+      if (WB == 3) WbSampleTypedPair(g, wt, a.type_mode, a.et1, a.k, a.seed, tile_call, node, jp, live,
+                                     2u * jp + 1u < c1, id, w, m, tt, &sentinel);
+      else pb = RngBlock(a.seed, tile_call, kDomainNeighbor, node, jp);
+      if (WB == 3) {}
+      else if (WB == 2) WbSamplePairG(g, ws, a.t1, live, UnitFromWords(pb.w[0], pb.w[1]),
                                  UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
       else if (WB) WbSamplePair(g, wr, live, UnitFromWords(pb.w[0], pb.w[1]),
                                 UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
@@ -866,16 +990,18 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
                                          UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
       else LeanSamplePair(g, lo, deg, total, live, UnitFromWords(pb.w[0], pb.w[1]),
                           UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
-      by_edge = by_edge && __ballot(in && deg > 64) == 0ull;
+      by_edge = by_edge && __ballot(in && (deg > 64 || sentinel)) == 0ull;
       if (in) {
         const uint32_t j0 = 2u * jp;
         const uint32_t e0 = q * c1 + j0;
         s_c1[e0] = live ? id[0] : 0;        // a row without samples hands node id 0 on
         s_w1[e0] = live ? w[0] : 0.f;
+        if (WB == 3) s_t1[e0] = (int8_t)(live ? tt[0] : -1);
         unsigned long long bits = live ? 1ull << ((m[0] - lo) & 63u) : 1ull;
         if (j0 + 1u < c1) {
           s_c1[e0 + 1] = live ? id[1] : 0;
           s_w1[e0 + 1] = live ? w[1] : 0.f;
+          if (WB == 3) s_t1[e0 + 1] = (int8_t)(live ? tt[1] : -1);
           if (live) bits |= 1ull << ((m[1] - lo) & 63u);
           // the slot pass below needs the edge of every sample: park it in s_slot
           s_slot[e0 + 1] = (uint16_t)(live ? (m[1] - lo) & 63u : 0u);
@@ -964,9 +1090,14 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
         WbRec wr{0u, 0u, 0u, 0.f};
         WbSeg ws;
         if (WB == 2) { ws.wb_lo = 0; ws.row_deg = 0; ws.lo = 0; ws.deg = 0; ws.row_total = 0.f; ws.lim_b = 0.f; ws.lim_e = 0.f; ws.row = -1; }
+        WbRowT wt;
+        if (WB == 3) { wt.hd = nullptr; wt.te = nullptr; wt.lim = nullptr; wt.tsum = nullptr; wt.row = -1; wt.row_lo = 0; wt.row_deg = 0; wt.valid = false; }
         if (in) {
           node = s_slotid[s0 + sl];
-          if (WB == 2) {
+          if (WB == 3) {
+            LoadWbRowT(g, node, a.type_mode, a.et2, a.k, &wt);
+            lo = wt.row_lo; deg = wt.valid ? (int32_t)wt.row_deg : 0;
+          } else if (WB == 2) {
             LoadWbSeg(g, node, a.t2, &ws);
             lo = ws.lo; deg = (int32_t)ws.deg;
           } else {
@@ -983,9 +1114,15 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
           }
         }
         const bool live = in && deg > 0 && !EG_FL_ABLATE(a, 2);
-        const Philox4 pb = RngBlock(a.seed, tile_call + 1u, kDomainNeighbor, node, xp);
         uint64_t id[2]; float w[2]; uint32_t m[2];
-        if (WB == 2) WbSamplePairG(g, ws, a.t2, live, UnitFromWords(pb.w[0], pb.w[1]),
+        int32_t tt[2] = {a.t2, a.t2};
+        bool sentinel = false;
+        Philox4 pb;
+        if (WB == 3) WbSampleTypedPair(g, wt, a.type_mode, a.et2, a.k, a.seed, tile_call + 1u, node, xp, live,
+                                       true, id, w, m, tt, &sentinel);
+        else pb = RngBlock(a.seed, tile_call + 1u, kDomainNeighbor, node, xp);
+        if (WB == 3) {}
+        else if (WB == 2) WbSamplePairG(g, ws, a.t2, live, UnitFromWords(pb.w[0], pb.w[1]),
                                    UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
         else if (WB) WbSamplePair(g, wr, live, UnitFromWords(pb.w[0], pb.w[1]),
                                   UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
@@ -1001,6 +1138,10 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
           *reinterpret_cast<float2*>(s_sw + sl * c2 + 2u * xp) =
               make_float2(live ? w[0] : 0.f, live ? w[1] : 0.f);
           if (xp == 0) s_st[sl] = live ? a.t2 : -1;
+          if (WB == 3) {
+            s_t2[sl * c2 + 2u * xp] = (int8_t)(live ? tt[0] : -1);
+            s_t2[sl * c2 + 2u * xp + 1u] = (int8_t)(live ? tt[1] : -1);
+          }
         }
       }
       WaveSync();
@@ -1014,7 +1155,8 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
             *reinterpret_cast<fl_u64x2*>(a.id2 + row0 + e) = *reinterpret_cast<const fl_u64x2*>(s_sid + e);
             *reinterpret_cast<float2*>(a.w2 + row0 + e) = *reinterpret_cast<const float2*>(s_sw + e);
             const int32_t tv = s_st[a.div_c2(e)];
-            *reinterpret_cast<int2*>(a.ty2 + row0 + e) = make_int2(tv, tv);
+            *reinterpret_cast<int2*>(a.ty2 + row0 + e) =
+                WB == 3 ? make_int2((int32_t)s_t2[e], (int32_t)s_t2[e + 1]) : make_int2(tv, tv);
           }
         }
       } else
@@ -1034,7 +1176,8 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
               *reinterpret_cast<float2*>(a.w2 + out2 + p) =
                   *reinterpret_cast<const float2*>(s_sw + sl * c2 + x);
               const int32_t tv = s_st[sl];
-              *reinterpret_cast<int2*>(a.ty2 + out2 + p) = make_int2(tv, tv);
+              *reinterpret_cast<int2*>(a.ty2 + out2 + p) =
+                  WB == 3 ? make_int2((int32_t)s_t2[sl * c2 + x], (int32_t)s_t2[sl * c2 + x + 1]) : make_int2(tv, tv);
             }
           }
         }
@@ -1053,27 +1196,31 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
             const uint32_t slb = hasb ? (uint32_t)s_slot[gjb] - s0 : 0xFFFFFFFFu;
             const bool inb = hasb && slb < ns;
             float2 wa = make_float2(0.f, 0.f), wb = wa;
-            int32_t ta = -1, tb = -1;
-            if (ina) { wa = *reinterpret_cast<const float2*>(s_sw + sla * c2 + xa); ta = s_st[sla]; }
-            if (inb) { wb = *reinterpret_cast<const float2*>(s_sw + slb * c2 + xb); tb = s_st[slb]; }
+            int32_t ta = -1, tb = -1, ta2 = -1, tb2 = -1;
+            if (ina) { wa = *reinterpret_cast<const float2*>(s_sw + sla * c2 + xa); ta = s_st[sla]; ta2 = ta; }
+            if (inb) { wb = *reinterpret_cast<const float2*>(s_sw + slb * c2 + xb); tb = s_st[slb]; tb2 = tb; }
+            if (WB == 3) {
+              if (ina) { ta = (int32_t)s_t2[sla * c2 + xa]; ta2 = (int32_t)s_t2[sla * c2 + xa + 1]; }
+              if (inb) { tb = (int32_t)s_t2[slb * c2 + xb]; tb2 = (int32_t)s_t2[slb * c2 + xb + 1]; }
+            }
             float* wp = a.w2 + out2 + p;
             int32_t* tp = a.ty2 + out2 + p;
             if (ina && inb && EG_FL_ABLATE(a, 256)) {
               typedef float fl_f4 __attribute__((ext_vector_type(4)));
               typedef int fl_i4 __attribute__((ext_vector_type(4)));
               const fl_f4 wv4 = {wa.x, wa.y, wb.x, wb.y};
-              const fl_i4 tv4 = {ta, ta, tb, tb};
+              const fl_i4 tv4 = {ta, ta2, tb, tb2};
               __builtin_nontemporal_store(wv4, reinterpret_cast<fl_f4*>(wp));
               __builtin_nontemporal_store(tv4, reinterpret_cast<fl_i4*>(tp));
             } else if (ina && inb) {
               *reinterpret_cast<float4*>(wp) = make_float4(wa.x, wa.y, wb.x, wb.y);
-              *reinterpret_cast<int4*>(tp) = make_int4(ta, ta, tb, tb);
+              *reinterpret_cast<int4*>(tp) = make_int4(ta, ta2, tb, tb2);
             } else if (ina) {
               *reinterpret_cast<float2*>(wp) = wa;
-              *reinterpret_cast<int2*>(tp) = make_int2(ta, ta);
+              *reinterpret_cast<int2*>(tp) = make_int2(ta, ta2);
             } else if (inb) {
               *reinterpret_cast<float2*>(wp + 2) = wb;
-              *reinterpret_cast<int2*>(tp + 2) = make_int2(tb, tb);
+              *reinterpret_cast<int2*>(tp + 2) = make_int2(tb, tb2);
             }
           }
         }
@@ -1090,7 +1237,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
         const bool ok = s_rvalid[q] != 0;
         a.id1[out1 + tk] = ok ? s_c1[tk] : (uint64_t)a.default_node;
         a.w1[out1 + tk] = s_w1[tk];
-        a.ty1[out1 + tk] = ok ? a.t1 : -1;
+        a.ty1[out1 + tk] = WB == 3 ? (int32_t)s_t1[tk] : ok ? a.t1 : -1;
       }
     }
     WaveSync();

@@ -819,7 +819,7 @@ __global__ void WbCountKernel(GraphView g, uint32_t* nbk) {
   nbk[row] = n;
 }
 
-// the per-row records {wb_lo, row_lo, type_end[T], lim[T]} (plain graphs read them as WbRec)
+// the per-row records {wb_lo, row_lo, type_end[T], lim[T], type_sum[T] (T > 1)} (plain graphs read them as WbRec)
 __global__ void WbRecKernel(GraphView g, const uint32_t* wb_lo, uint8_t* wbg, int32_t wbg_stride) {
   const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= g.n_rows) return;
@@ -829,10 +829,12 @@ __global__ void WbRecKernel(GraphView g, const uint32_t* wb_lo, uint8_t* wbg, in
   reinterpret_cast<uint32_t*>(out)[1] = (uint32_t)m.row_ptr;
   int32_t* te = reinterpret_cast<int32_t*>(out + 8);
   float* lim = reinterpret_cast<float*>(out + 8 + 4 * g.T);
+  float* tsum = lim + g.T;                          // (T > 1 only)
   for (int32_t t = 0; t < g.T; ++t) {
     const int32_t e = m.type_end[t];
     te[t] = e;
     lim[t] = e > 0 ? g.prefix_w[m.row_ptr + e - 1] : 0.f;
+    if (g.T > 1) tsum[t] = m.type_prefix[t];
   }
 }
 
@@ -899,7 +901,7 @@ int BuildWbIndex(GraphBuilder* b) {
   uint32_t n_wb32 = 0;
   EG_HIP(hipMemcpy(&n_wb32, wb_lo + v.n_rows, 4, hipMemcpyDeviceToHost));
   const int64_t n_wb = (int64_t)n_wb32;
-  const int32_t stride = 8 + 8 * v.T;
+  const int32_t stride = v.T == 1 ? 16 : 8 + 12 * v.T;
   // (checked before allocating: an index that does not fit is an optimisation declined)
   {
     size_t free_b = 0, total_b = 0;

@@ -244,8 +244,8 @@ __global__ __launch_bounds__(256, 6) void SampleNeighborSetsKernel(const SampleS
 // of a root's `count` lanes reads the root's row record and weight-bucket record for itself -
 // a dozen small loads per lane, all hits, and yet the launch is bound by exactly that: the CU's
 // memory pipe works off load instructions x lanes, not bytes.  Here a workgroup takes
-// 256 / count ROOTS: their rows are found by one lane each, their records (8 + 8 T bytes of
-// {wb_lo, row_lo, type_end[T], lim[T]}, 4 T of the row record's type sums) are copied into LDS by all lanes word by word - once
+// 256 / count ROOTS: their rows are found by one lane each, their records (8 + 12 T bytes of
+// {wb_lo, row_lo, type_end[T], lim[T], type_sum[T]}) are copied into LDS by all lanes word by word - once
 // for all the sets - and a sample lane then needs global memory only for its block's keys and
 // its id, set after set.  Graphs with the weight-bucket index only (the kernel above serves
 // the rest).
@@ -253,9 +253,9 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborSetsLdsKerne
                                                                                  const int32_t rpb) {
   extern __shared__ __align__(16) uint32_t sl_smem[];
   const int32_t T = a.g.T;
-  // per root: the record of the weight-bucket index (2 + 2 T words: first block, first edge,
-  // group ends, their running sums) and the T type sums of the row record (for the type draws)
-  const int32_t mw = 2 + 2 * T, W = 2 + 3 * T;
+  // per root: the record of the weight-bucket index (first block, first edge, group ends,
+  // their running sums, the type sums: 2 + 3 T words; at T = 1 the total stands for the sum)
+  const int32_t mw = 2 + 2 * T, W = T == 1 ? 4 : 2 + 3 * T;
   int64_t* s_row = reinterpret_cast<int64_t*>(sl_smem);                  // [rpb]
   uint32_t* s_rec = sl_smem + 2 * rpb;                                    // [rpb][W]
   const int32_t q = (int32_t)threadIdx.x / a.count, j = (int32_t)threadIdx.x - q * a.count;
@@ -269,10 +269,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborSetsLdsKerne
       const int32_t r = x / W, k = x - r * W;
       const int64_t row = s_row[r];
       uint32_t v = 0;
-      if (row >= 0) {
-        v = k < mw ? reinterpret_cast<const uint32_t*>(a.g.wbg + row * (int64_t)a.g.wbg_stride)[k]
-                   : reinterpret_cast<const uint32_t*>(a.g.row_meta + row * (int64_t)a.g.meta_stride)[2 + T + (k - mw)];
-      }
+      if (row >= 0) v = reinterpret_cast<const uint32_t*>(a.g.wbg + row * (int64_t)a.g.wbg_stride)[k];
       s_rec[r * W + k] = v;
     }
     __syncthreads();
@@ -283,7 +280,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborSetsLdsKerne
       const uint32_t* rec = s_rec + q * W;
       const int32_t* type_end = reinterpret_cast<const int32_t*>(rec + 2);
       const float* lim = reinterpret_cast<const float*>(rec + 2 + T);
-      const float* type_prefix = reinterpret_cast<const float*>(rec + mw);
+      const float* type_prefix = reinterpret_cast<const float*>(T == 1 ? rec + 3 : rec + mw);
       const uint64_t my_node = row >= 0 ? a.roots[r] : 0;
       for (int32_t set = 0; set < a.n_sets; ++set) {
         const int32_t k = a.set_k[set];

@@ -1400,8 +1400,15 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
   // (a graph of all-1.0 weights keeps the hop-by-hop path unless key 27 = 2: its draws cost
   // one id load, and the global duplicate detection finds more to share on the small dense
   // graphs of that kind - products-shaped: 135 vs 131 G edges/s)
+  // (hops that list several edge types - a type draw per sample - take the same kernel on the
+  // graphs the weight-bucket index serves: fanout_local.h, WB == 3)
+  const bool typed_hops = k > 1 && k <= kMaxListedTypes;
+  const bool typed_ok = typed_hops && g_fl_plain == 2 && g_fl_wb != 0 && g_k1_typed_pivot != 0 &&
+                        g->view.T > 1 && g->view.T <= 127 && g->view.has_zero_nbr == 0 &&
+                        g->view.uniform_w == 0 && g->view.n_edges < ((int64_t)1 << 31) &&
+                        t_fl_row_index == nullptr && counts_host[1] % 2 == 0;
   if (g_fanout_local != 0 && (g->view.uniform_w == 0 || g_fanout_local == 2) && events == nullptr &&
-      layers == 2 && k == 1 &&
+      layers == 2 && (k == 1 || typed_ok) &&
       n >= (multi != nullptr && g_fl_min_roots > 8192 ? 8192 : g_fl_min_roots) &&
       g_k1_variant == 6 && g->view.monotone && counts_host[0] > 0 && counts_host[1] > 0) {
     const int32_t c1 = counts_host[0], c2 = counts_host[1];
@@ -1444,7 +1451,11 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
       f.seed = seed; f.call_id = call_id; f.roots = roots_dev; f.n = n;
       f.default_node = default_node;
       f.c1 = c1; f.c2 = c2;
-      f.t1 = edge_types_host[0]; f.t2 = edge_types_host[1];
+      f.t1 = edge_types_host[0]; f.t2 = edge_types_host[typed_hops ? k : 1];
+      if (typed_hops) {
+        f.k = k; f.type_mode = TypeModeOf(k, g->view.T);
+        for (int32_t i = 0; i < k; ++i) { f.et1[i] = edge_types_host[i]; f.et2[i] = edge_types_host[k + i]; }
+      }
       f.gr = gr; f.cap = cap; f.wave_lds = (int32_t)lay.bytes;
       if (multi != nullptr) {
         f.mb_n = multi->n_per; f.call_ids = multi->call_ids_dev; f.call_stride = multi->call_stride;
@@ -1470,17 +1481,20 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
       const bool plain = plain_u && v.uniform_w == 0;
       // the lean build's general form: any graph the weight-bucket index serves (several
       // edge-type groups, hashed ids), valid listed types, no neighbour id 0
-      const bool lean_g = !plain_u && g_fl_plain == 2 && g_fl_wb != 0 && v.wbg != nullptr && v.wb != nullptr &&
+      const bool lean_t = typed_hops && v.wbg != nullptr && v.wb != nullptr && v.wb_lean_ok != 0;
+      const bool lean_g = !typed_hops &&
+                          !plain_u && g_fl_plain == 2 && g_fl_wb != 0 && v.wbg != nullptr && v.wb != nullptr &&
                           v.wb_lean_ok != 0 &&
                           v.has_zero_nbr == 0 && v.uniform_w == 0 && f.t1 >= 0 && f.t1 < v.T && f.t2 >= 0 &&
                           f.t2 < v.T && t_fl_row_index == nullptr;
-      if ((plain_u || lean_g) && g_fl_plain == 2 && f.vec && v.n_edges < ((int64_t)1 << 31)) {
+      if (((plain_u && !typed_hops) || lean_g || lean_t) && g_fl_plain == 2 && f.vec &&
+          v.n_edges < ((int64_t)1 << 31)) {
         // the lean build (pairs of samples per lane, f32 compares, duplicates by edge)
         int32_t lcap = cap;
-        FanoutLeanLds ll = FanoutLeanLayout(gr, c1, c2, lcap);
+        FanoutLeanLds ll = FanoutLeanLayout(gr, c1, c2, lcap, lean_t);
         while (lcap > 1 && (size_t)ll.bytes * (block / 64) > 64 * 1024) {
           lcap >>= 1;
-          ll = FanoutLeanLayout(gr, c1, c2, lcap);
+          ll = FanoutLeanLayout(gr, c1, c2, lcap, lean_t);
         }
         if ((size_t)ll.bytes * (block / 64) <= 64 * 1024) {
           f.cap = lcap; f.wave_lds = (int32_t)ll.bytes;
@@ -1494,7 +1508,9 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
           t_fl_took_lean = 1;
           void (*lk)(const FanoutLocalArgs) = nullptr;
           const bool use_wb = v.uniform_w == 0 && f.g.wrec != nullptr && f.g.wb != nullptr && v.wb_lean_ok != 0;
-          if (lean_g) {
+          if (lean_t) {
+            lk = f.wide ? SampleFanoutLeanKernel<true, 5, false, 3> : SampleFanoutLeanKernel<false, 5, false, 3>;
+          } else if (lean_g) {
             lk = f.wide ? (g_fl_wps == 6 ? SampleFanoutLeanKernel<true, 6, false, 2> : SampleFanoutLeanKernel<true, 5, false, 2>)
                         : (g_fl_wps == 6 ? SampleFanoutLeanKernel<false, 6, false, 2> : SampleFanoutLeanKernel<false, 5, false, 2>);
           } else if (v.uniform_w != 0) {
@@ -1520,6 +1536,7 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
           return EULER_GPU_OK;
         }
       }
+      if (!typed_hops) {        // (typed hops the lean build does not take go hop by hop, below)
       void (*kern)(const FanoutLocalArgs) = nullptr;
 #define EG_FL(W, P) (g_fl_wps != 8 ? SampleFanoutLocalKernel<W, P, 5> : SampleFanoutLocalKernel<W, P, 8>)
       kern = f.wide ? (plain ? EG_FL(true, true) : EG_FL(true, false))
@@ -1529,6 +1546,7 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
       EG_HIP(hipGetLastError());
       if (uniq_off != nullptr) { uniq_off[0] = -1; uniq_off[1] = -1; }
       return EULER_GPU_OK;
+      }
     }
   }
   std::lock_guard<std::recursive_mutex> launch_lk(g->launch_mu);

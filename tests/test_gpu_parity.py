@@ -1620,7 +1620,13 @@ def test_fanout_local_dedup_kernel(EA, O, torch_cuda, big_pair, geom):
             if B == 1:
                 q = q[:1]
             for et, counts in (([[0], [1]], [25, 10]), ([[3], [3]], [7, 40]), ([[2], [0]], [1, 1]),
-                               ([[1], [9]], [5, 3]), ([[0], [2]], [70, 2]), ([[1], [1]], [10, 5])):
+                               ([[1], [9]], [5, 3]), ([[0], [2]], [70, 2]), ([[1], [1]], [10, 5]),
+                               # hops that list several types: a type draw per sample (a sub-collection
+                               # in the listed order, all groups, a list with a type the graph lacks,
+                               # a type listed twice, an odd second count: hop by hop)
+                               ([[0, 1], [2, 3]], [25, 10]), ([[0, 1, 2, 3], [3, 2, 1, 0]], [7, 4]),
+                               ([[2, 0, 1], [1, 9, 0]], [5, 6]), ([[1, 1], [0, 3]], [10, 2]),
+                               ([[3, 0], [0, 3]], [9, 8]), ([[0, 2], [1, 3]], [4, 3])):
                 check(G, OG, q, et, counts, -5, 23, 91)
         # one edge type, identity ids: weighted (the constant-folded build) and uniform
         for weighted in (True, False):
@@ -1633,6 +1639,25 @@ def test_fanout_local_dedup_kernel(EA, O, torch_cuda, big_pair, geom):
             q = np.concatenate([r1.integers(1, 20001, 3001), [0, 20001, 1, 1, 2]]).astype(np.int64)
             for counts in ([25, 10], [3, 4], [10, 5], [1, 2], [80, 6]):
                 check(G1, OG1, q, [[0], [0]], counts, 20001, 3, 6)
+        # identity ids, 2 and 8 edge-type groups: every hop lists all of them / three of eight
+        for T_, et in ((2, [[0, 1], [0, 1]]), (2, [[1, 0], [1, 0]]), (8, [[3, 1, 6], [0, 7, 2]]),
+                       (8, [list(range(8))] * 2)):
+            p = EA.synth_params(55 + T_, 20000, 400000, n_types=T_, weighted=True)
+            po = O.SynthParams()
+            for f, _ in po._fields_:
+                setattr(po, f, getattr(p, f))
+            Gt, OGt = EA.Graph.synthetic(p), O.OracleGraph(O.synth_csr(po))
+            q = np.concatenate([np.random.default_rng(8).integers(1, 20001, 2500), [0, 20001, 7, 7]]).astype(np.int64)
+            for counts in ([25, 10], [3, 2]):
+                check(Gt, OGt, q, et, counts, 20001, 12, 30)
+        # ... and on hubs (rows of more than 64 edges: duplicates by id; several buckets per row)
+        ph2 = EA.synth_params(37, 3000, 600000, n_types=2, weighted=True)
+        po = O.SynthParams()
+        for f, _ in po._fields_:
+            setattr(po, f, getattr(ph2, f))
+        Gh, OGh = EA.Graph.synthetic(ph2), O.OracleGraph(O.synth_csr(po))
+        q = np.random.default_rng(9).integers(1, 3001, 600).astype(np.int64)
+        check(Gh, OGh, q, [[0, 1], [1, 0]], [25, 10], 3001, 4, 50)
         # hubs: rows of thousands of edges (several pivot levels, > 64 edges: duplicates by id)
         ph = EA.synth_params(31, 3000, 900000, n_types=1, weighted=True)
         po = O.SynthParams()
