@@ -5,6 +5,9 @@ import sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch, euler_amd
 import bench
+if '--lib' in sys.argv:                 # A/B against another build of the library
+    from euler_amd import _lib
+    _lib.LIB_PATH = sys.argv[sys.argv.index('--lib') + 1]
 N = 100_000_000
 p = euler_amd.synth_params(bench.GRAPH_SEED, N, 10 * N, n_types=2, weighted=True, hashed_ids=True)
 G = euler_amd.Graph.synthetic(p)
@@ -13,7 +16,7 @@ gen = torch.Generator(device="cuda"); gen.manual_seed(2468)
 B = 131072
 roots = bench._mix64_t(torch.randint(1, N + 1, (16, B), generator=gen, device="cuda", dtype=torch.int64))
 side = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()]
-ONE = len(sys.argv) > 1 and sys.argv[1] == '--one'       # one stream, the all-types case only (for a kernel trace)
+ONE = '--one' in sys.argv       # one stream, the all-types case only (for a kernel trace)
 for et in ([[0, 1], [0, 1]],) if ONE else ([[0], [0]], [[0, 1], [0, 1]], [[1, 0], [1, 0]]):
     def loop(a, b):
         for i in range(a, b):
