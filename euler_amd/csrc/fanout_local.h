@@ -860,6 +860,117 @@ __device__ __forceinline__ void WbSampleTypedPair(const GraphView& g, const WbRo
   if (live && two && !ok1) { id[1] = 0; w[1] = 0.f; m[1] = r.row_lo; tt[1] = 0; }
 }
 
+// Graphs with at most 4 edge-type groups (every dataset the reference ships has 2 or 3): the
+// row record's three arrays are loaded ONCE into registers, side by side, and the type draw,
+// the group's ends and its limits are register selects - the general form above walks the
+// record with dependent loads (hits, but four round trips in a row per sample).  WB == 4.
+struct WbRowT4 {
+  uint32_t wb_lo, row_lo;
+  int32_t te[4];
+  float lim[4], ts[4];
+  int64_t row;
+  uint32_t row_deg;
+  float row_total;
+  bool valid;
+};
+
+template <typename V>
+__device__ __forceinline__ V At4(const V a[4], const int32_t i) {
+  return i == 0 ? a[0] : i == 1 ? a[1] : i == 2 ? a[2] : a[3];
+}
+
+struct RegSum4 {
+  const float* ts;          // registers (fully unrolled selects)
+  __device__ __forceinline__ float operator()(uint64_t i) const { return At4(ts, (int32_t)i); }
+};
+
+struct SubTypeSum4 {         // SubTypeSum (device_fns.h) over register sums: same sequential f32 adds
+  const float* ts;
+  const int32_t* edge_types;
+  __device__ __forceinline__ float operator()(uint64_t i) const {
+    float s = 0.f;
+    for (uint64_t x = 0; x <= i; ++x) {
+      const int32_t t = edge_types[x];
+      s = EG_FADD(s, EG_FSUB(At4(ts, t), t > 0 ? At4(ts, t - 1) : 0.f));
+    }
+    return s;
+  }
+};
+
+__device__ __forceinline__ void LoadWbRowT4(const GraphView& g, const uint64_t node, const int32_t mode,
+                                            const int32_t* et, const int32_t k, WbRowT4* r) {
+  r->wb_lo = 0; r->row_lo = 0; r->row_deg = 0; r->row_total = 0.f; r->valid = false;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { r->te[i] = 0; r->lim[i] = 0.f; r->ts[i] = 0.f; }
+  r->row = FindRow(g, node);
+  if (r->row < 0) return;
+  const int32_t T = g.T;
+  const uint8_t* rec = g.wbg + r->row * (int64_t)g.wbg_stride;
+  const uint32_t* hd = reinterpret_cast<const uint32_t*>(rec);
+  const int32_t* te = reinterpret_cast<const int32_t*>(rec + 8);
+  const float* lim = reinterpret_cast<const float*>(rec + 8 + 4 * T);
+  const float* ts = reinterpret_cast<const float*>(rec + 8 + 8 * T);
+  r->wb_lo = hd[0]; r->row_lo = hd[1];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {           // entries past T repeat the last one (never selected)
+    const int x = i < T ? i : T - 1;
+    r->te[i] = te[x]; r->lim[i] = lim[x]; r->ts[i] = ts[x];
+  }
+  r->row_deg = (uint32_t)r->te[3];
+  r->row_total = r->lim[3];
+  if (mode == kTypeSub) {
+    bool ok = true;
+    for (int32_t i = 0; i < k; ++i) ok = ok && et[i] >= 0 && et[i] < T;
+    r->valid = ok && SubTypeSum4{r->ts, et}((uint64_t)(k - 1)) != 0.f;
+  } else {
+    r->valid = r->ts[3] != 0.f;
+  }
+}
+
+__device__ __forceinline__ bool WbTypedSeg4(const GraphView& g, const WbRowT4& r, const int32_t mode,
+                                            const int32_t* et, const int32_t k, const double u_type,
+                                            int32_t* t_out, WbSeg* s) {
+  const int32_t t = mode == kTypeSub
+      ? et[RandomSelectT(SubTypeSum4{r.ts, et}, 0, (uint64_t)(k - 1), u_type)]
+      : (int32_t)RandomSelectT(RegSum4{r.ts}, 0, (uint64_t)(g.T - 1), u_type);
+  const int32_t b = t == 0 ? 0 : At4(r.te, t - 1), e = At4(r.te, t);
+  s->wb_lo = r.wb_lo;
+  s->row_deg = r.row_deg;
+  s->row_total = r.row_total;
+  s->lim_e = At4(r.lim, t);
+  s->lim_b = t == 0 ? 0.f : At4(r.lim, t - 1);
+  s->lo = r.row_lo + (uint32_t)b;
+  s->deg = e > b ? (uint32_t)(e - b) : 0u;
+  s->row = r.row;
+  *t_out = t;
+  return e > b;
+}
+
+__device__ __forceinline__ void WbSampleTypedPair4(const GraphView& g, const WbRowT4& r, const int32_t mode,
+                                                   const int32_t* et, const int32_t k, const uint64_t seed,
+                                                   const uint32_t call, const uint64_t node,
+                                                   const uint32_t jp, const bool live, const bool two,
+                                                   uint64_t id[2], float w[2], uint32_t m[2],
+                                                   int32_t tt[2], bool* sentinel) {
+  const Philox4 pa = RngBlock(seed, call, kDomainNeighbor, node, 2u * jp);
+  const Philox4 pb = RngBlock(seed, call, kDomainNeighbor, node, 2u * jp + 1u);
+  WbSeg sg0, sg1;
+  sg0.wb_lo = 0; sg0.row_deg = 0; sg0.lo = 0; sg0.deg = 0; sg0.row_total = 0.f; sg0.lim_b = 0.f; sg0.lim_e = 0.f; sg0.row = -1;
+  sg1 = sg0;
+  tt[0] = -1; tt[1] = -1;
+  bool ok0 = false, ok1 = false;
+  if (live) {
+    ok0 = WbTypedSeg4(g, r, mode, et, k, UnitFromWords(pa.w[0], pa.w[1]), &tt[0], &sg0);
+    if (two) ok1 = WbTypedSeg4(g, r, mode, et, k, UnitFromWords(pb.w[0], pb.w[1]), &tt[1], &sg1);
+    else sg1 = sg0;
+  }
+  WbSamplePairG2<true>(g, sg0, sg1, tt[0], tt[1], ok0, ok1, UnitFromWords(pa.w[2], pa.w[3]),
+                       UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
+  *sentinel = live && (!ok0 || (two && !ok1));
+  if (live && !ok0) { id[0] = 0; w[0] = 0.f; m[0] = r.row_lo; tt[0] = 0; }
+  if (live && two && !ok1) { id[1] = 0; w[1] = 0.f; m[1] = r.row_lo; tt[1] = 0; }
+}
+
 struct FanoutLeanLds {
   uint32_t o_sid, o_c1, o_slotid, o_mask, o_sw, o_w1, o_st, o_slot, o_rvalid, o_t1, o_t2, bytes;
 };
@@ -902,7 +1013,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
   const int lane = threadIdx.x & 63;
   const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int waves_per_block = blockDim.x >> 6;
-  const FanoutLeanLds L = FanoutLeanLayout(a.gr, a.c1, a.c2, a.cap, WB == 3);
+  const FanoutLeanLds L = FanoutLeanLayout(a.gr, a.c1, a.c2, a.cap, WB >= 3);
   uint8_t* base = fl_smem + (size_t)wave_in_block * a.wave_lds;
   uint64_t* s_sid = reinterpret_cast<uint64_t*>(base + L.o_sid);
   uint64_t* s_c1 = reinterpret_cast<uint64_t*>(base + L.o_c1);
@@ -951,10 +1062,16 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
       WbSeg ws;
       if (WB == 2) { ws.wb_lo = 0; ws.row_deg = 0; ws.lo = 0; ws.deg = 0; ws.row_total = 0.f; ws.lim_b = 0.f; ws.lim_e = 0.f; ws.row = -1; }
       WbRowT wt;
+      WbRowT4 w4;
       if (WB == 3) { wt.hd = nullptr; wt.te = nullptr; wt.lim = nullptr; wt.tsum = nullptr; wt.row = -1; wt.row_lo = 0; wt.row_deg = 0; wt.valid = false; }
+      if (WB == 4) { w4.wb_lo = 0; w4.row_lo = 0; w4.row = -1; w4.row_deg = 0; w4.row_total = 0.f; w4.valid = false;
+                     for (int i = 0; i < 4; ++i) { w4.te[i] = 0; w4.lim[i] = 0.f; w4.ts[i] = 0.f; } }
       if (in) {
         node = a.roots[r0 + q];
-        if (WB == 3) {
+        if (WB == 4) {
+          LoadWbRowT4(g, node, a.type_mode, a.et1, a.k, &w4);
+          lo = w4.row_lo; deg = w4.valid ? (int32_t)w4.row_deg : 0;
+        } else if (WB == 3) {
           LoadWbRowT(g, node, a.type_mode, a.et1, a.k, &wt);
           lo = wt.row_lo; deg = wt.valid ? (int32_t)wt.row_deg : 0;
         } else if (WB == 2) {
@@ -978,10 +1095,12 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
       int32_t tt[2] = {a.t1, a.t1};
       bool sentinel = false;
       Philox4 pb;
-      if (WB == 3) WbSampleTypedPair(g, wt, a.type_mode, a.et1, a.k, a.seed, tile_call, node, jp, live,
-                                     2u * jp + 1u < c1, id, w, m, tt, &sentinel);
+      if (WB == 4) WbSampleTypedPair4(g, w4, a.type_mode, a.et1, a.k, a.seed, tile_call, node, jp, live,
+                                      2u * jp + 1u < c1, id, w, m, tt, &sentinel);
+      else if (WB == 3) WbSampleTypedPair(g, wt, a.type_mode, a.et1, a.k, a.seed, tile_call, node, jp, live,
+                                          2u * jp + 1u < c1, id, w, m, tt, &sentinel);
       else pb = RngBlock(a.seed, tile_call, kDomainNeighbor, node, jp);
-      if (WB == 3) {}
+      if (WB >= 3) {}
       else if (WB == 2) WbSamplePairG(g, ws, a.t1, live, UnitFromWords(pb.w[0], pb.w[1]),
                                  UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
       else if (WB) WbSamplePair(g, wr, live, UnitFromWords(pb.w[0], pb.w[1]),
@@ -996,12 +1115,12 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
         const uint32_t e0 = q * c1 + j0;
         s_c1[e0] = live ? id[0] : 0;        // a row without samples hands node id 0 on
         s_w1[e0] = live ? w[0] : 0.f;
-        if (WB == 3) s_t1[e0] = (int8_t)(live ? tt[0] : -1);
+        if (WB >= 3) s_t1[e0] = (int8_t)(live ? tt[0] : -1);
         unsigned long long bits = live ? 1ull << ((m[0] - lo) & 63u) : 1ull;
         if (j0 + 1u < c1) {
           s_c1[e0 + 1] = live ? id[1] : 0;
           s_w1[e0 + 1] = live ? w[1] : 0.f;
-          if (WB == 3) s_t1[e0 + 1] = (int8_t)(live ? tt[1] : -1);
+          if (WB >= 3) s_t1[e0 + 1] = (int8_t)(live ? tt[1] : -1);
           if (live) bits |= 1ull << ((m[1] - lo) & 63u);
           // the slot pass below needs the edge of every sample: park it in s_slot
           s_slot[e0 + 1] = (uint16_t)(live ? (m[1] - lo) & 63u : 0u);
@@ -1091,10 +1210,16 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
         WbSeg ws;
         if (WB == 2) { ws.wb_lo = 0; ws.row_deg = 0; ws.lo = 0; ws.deg = 0; ws.row_total = 0.f; ws.lim_b = 0.f; ws.lim_e = 0.f; ws.row = -1; }
         WbRowT wt;
+        WbRowT4 w4;
         if (WB == 3) { wt.hd = nullptr; wt.te = nullptr; wt.lim = nullptr; wt.tsum = nullptr; wt.row = -1; wt.row_lo = 0; wt.row_deg = 0; wt.valid = false; }
+        if (WB == 4) { w4.wb_lo = 0; w4.row_lo = 0; w4.row = -1; w4.row_deg = 0; w4.row_total = 0.f; w4.valid = false;
+                       for (int i = 0; i < 4; ++i) { w4.te[i] = 0; w4.lim[i] = 0.f; w4.ts[i] = 0.f; } }
         if (in) {
           node = s_slotid[s0 + sl];
-          if (WB == 3) {
+          if (WB == 4) {
+            LoadWbRowT4(g, node, a.type_mode, a.et2, a.k, &w4);
+            lo = w4.row_lo; deg = w4.valid ? (int32_t)w4.row_deg : 0;
+          } else if (WB == 3) {
             LoadWbRowT(g, node, a.type_mode, a.et2, a.k, &wt);
             lo = wt.row_lo; deg = wt.valid ? (int32_t)wt.row_deg : 0;
           } else if (WB == 2) {
@@ -1118,10 +1243,12 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
         int32_t tt[2] = {a.t2, a.t2};
         bool sentinel = false;
         Philox4 pb;
-        if (WB == 3) WbSampleTypedPair(g, wt, a.type_mode, a.et2, a.k, a.seed, tile_call + 1u, node, xp, live,
-                                       true, id, w, m, tt, &sentinel);
+        if (WB == 4) WbSampleTypedPair4(g, w4, a.type_mode, a.et2, a.k, a.seed, tile_call + 1u, node, xp, live,
+                                        true, id, w, m, tt, &sentinel);
+        else if (WB == 3) WbSampleTypedPair(g, wt, a.type_mode, a.et2, a.k, a.seed, tile_call + 1u, node, xp, live,
+                                            true, id, w, m, tt, &sentinel);
         else pb = RngBlock(a.seed, tile_call + 1u, kDomainNeighbor, node, xp);
-        if (WB == 3) {}
+        if (WB >= 3) {}
         else if (WB == 2) WbSamplePairG(g, ws, a.t2, live, UnitFromWords(pb.w[0], pb.w[1]),
                                    UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
         else if (WB) WbSamplePair(g, wr, live, UnitFromWords(pb.w[0], pb.w[1]),
@@ -1138,7 +1265,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
           *reinterpret_cast<float2*>(s_sw + sl * c2 + 2u * xp) =
               make_float2(live ? w[0] : 0.f, live ? w[1] : 0.f);
           if (xp == 0) s_st[sl] = live ? a.t2 : -1;
-          if (WB == 3) {
+          if (WB >= 3) {
             s_t2[sl * c2 + 2u * xp] = (int8_t)(live ? tt[0] : -1);
             s_t2[sl * c2 + 2u * xp + 1u] = (int8_t)(live ? tt[1] : -1);
           }
@@ -1156,7 +1283,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
             *reinterpret_cast<float2*>(a.w2 + row0 + e) = *reinterpret_cast<const float2*>(s_sw + e);
             const int32_t tv = s_st[a.div_c2(e)];
             *reinterpret_cast<int2*>(a.ty2 + row0 + e) =
-                WB == 3 ? make_int2((int32_t)s_t2[e], (int32_t)s_t2[e + 1]) : make_int2(tv, tv);
+                WB >= 3 ? make_int2((int32_t)s_t2[e], (int32_t)s_t2[e + 1]) : make_int2(tv, tv);
           }
         }
       } else
@@ -1177,7 +1304,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
                   *reinterpret_cast<const float2*>(s_sw + sl * c2 + x);
               const int32_t tv = s_st[sl];
               *reinterpret_cast<int2*>(a.ty2 + out2 + p) =
-                  WB == 3 ? make_int2((int32_t)s_t2[sl * c2 + x], (int32_t)s_t2[sl * c2 + x + 1]) : make_int2(tv, tv);
+                  WB >= 3 ? make_int2((int32_t)s_t2[sl * c2 + x], (int32_t)s_t2[sl * c2 + x + 1]) : make_int2(tv, tv);
             }
           }
         }
@@ -1199,7 +1326,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
             int32_t ta = -1, tb = -1, ta2 = -1, tb2 = -1;
             if (ina) { wa = *reinterpret_cast<const float2*>(s_sw + sla * c2 + xa); ta = s_st[sla]; ta2 = ta; }
             if (inb) { wb = *reinterpret_cast<const float2*>(s_sw + slb * c2 + xb); tb = s_st[slb]; tb2 = tb; }
-            if (WB == 3) {
+            if (WB >= 3) {
               if (ina) { ta = (int32_t)s_t2[sla * c2 + xa]; ta2 = (int32_t)s_t2[sla * c2 + xa + 1]; }
               if (inb) { tb = (int32_t)s_t2[slb * c2 + xb]; tb2 = (int32_t)s_t2[slb * c2 + xb + 1]; }
             }
@@ -1237,7 +1364,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
         const bool ok = s_rvalid[q] != 0;
         a.id1[out1 + tk] = ok ? s_c1[tk] : (uint64_t)a.default_node;
         a.w1[out1 + tk] = s_w1[tk];
-        a.ty1[out1 + tk] = WB == 3 ? (int32_t)s_t1[tk] : ok ? a.t1 : -1;
+        a.ty1[out1 + tk] = WB >= 3 ? (int32_t)s_t1[tk] : ok ? a.t1 : -1;
       }
     }
     WaveSync();

@@ -573,6 +573,7 @@ thread_local int g_fl_plain = 2;      // key 34: plain graphs: 2 = the lean kern
 thread_local int g_fl_wps = 5;        // key 35: register budget, waves per SIMD (8, 6 or 5; 5: nothing spilled)
 thread_local int g_fl_wb = 1;         // key 45: the lean kernel draws through the weight-bucket index (wb_index.h:
                                       // one line per draw); 0 = the pivot-level search of rounds 2-3
+thread_local int g_fl_typed_regs = 1;  // key 48: typed hops on graphs of <= 4 edge-type groups keep the row record in registers (1)
 thread_local int g_k1_sets_lds = 1;   // key 47: euler_gpu_sample_neighbor_sets stages the roots' records in LDS (1)
 thread_local int g_fl_ablate = 0;     // key 36: measurement only (FanoutLocalArgs::ablate)
 thread_local int g_k1_typed_pivot = 1;   // key 37: calls with type draws search with the block pivots (0 = reference
@@ -1508,7 +1509,9 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
           t_fl_took_lean = 1;
           void (*lk)(const FanoutLocalArgs) = nullptr;
           const bool use_wb = v.uniform_w == 0 && f.g.wrec != nullptr && f.g.wb != nullptr && v.wb_lean_ok != 0;
-          if (lean_t) {
+          if (lean_t && v.T <= 4 && g_fl_typed_regs != 0) {      // the row record in registers
+            lk = f.wide ? SampleFanoutLeanKernel<true, 5, false, 4> : SampleFanoutLeanKernel<false, 5, false, 4>;
+          } else if (lean_t) {
             lk = f.wide ? SampleFanoutLeanKernel<true, 5, false, 3> : SampleFanoutLeanKernel<false, 5, false, 3>;
           } else if (lean_g) {
             lk = f.wide ? (g_fl_wps == 6 ? SampleFanoutLeanKernel<true, 6, false, 2> : SampleFanoutLeanKernel<true, 5, false, 2>)
@@ -1751,6 +1754,7 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 35 && (value == 5 || value == 6 || value == 8)) { g_fl_wps = value; return EULER_GPU_OK; }
   if (key == 45 && (value == 0 || value == 1)) { g_fl_wb = value; return EULER_GPU_OK; }
   if (key == 47 && (value == 0 || value == 1)) { g_k1_sets_lds = value; return EULER_GPU_OK; }
+  if (key == 48 && (value == 0 || value == 1)) { g_fl_typed_regs = value; return EULER_GPU_OK; }
   return Fail(EULER_GPU_EINVAL, "set_tuning: unknown key");
 }
 

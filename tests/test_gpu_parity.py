@@ -1604,6 +1604,12 @@ def test_fanout_local_dedup_kernel(EA, O, torch_cuda, big_pair, geom):
             assert np.array_equal(t2n(gn[h + 1]), on[h]), (geom, len(q), et, counts, h)
             assert np.array_equal(t2n(gw[h]), ow[h]), (geom, len(q), et, counts, h)
             assert np.array_equal(t2n(gt[h]), ot[h]), (geom, len(q), et, counts, h)
+        if len(et[0]) > 1:                      # typed hops: the row record walked in memory, not held in registers
+            L.euler_gpu_set_tuning(48, 0)
+            mn, mw, mt = G.sample_fanout(qt, et, counts, default, call_id=call)
+            L.euler_gpu_set_tuning(48, 1)
+            for h in range(2):
+                assert torch.equal(gn[h + 1], mn[h + 1]) and torch.equal(gw[h], mw[h]) and torch.equal(gt[h], mt[h])
         L.euler_gpu_set_tuning(27, 0)           # hop by hop
         rn, rw, rt = G.sample_fanout(qt, et, counts, default, call_id=call)
         for h in range(2):
