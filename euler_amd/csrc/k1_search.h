@@ -78,6 +78,19 @@ __device__ __forceinline__ void LoadWbSegment(const GraphView& g, int64_t row, i
   sg->limit_begin = t == 0 ? 0.f : lim[t - 1];
 }
 
+// The row record as the typed kernels read it (first edge, group ends, type sums) - out of the
+// weight-bucket record when the graph has one with type sums (T > 1): the same line the
+// segment's limits come from, instead of the row record's line beside it.
+__device__ __forceinline__ RowMeta LoadRowMetaWb(const GraphView& g, int64_t row) {
+  if (g.wbg == nullptr || g.T == 1) return LoadRowMeta(g, row);
+  const uint8_t* rec = g.wbg + row * (int64_t)g.wbg_stride;
+  RowMeta m;
+  m.row_ptr = (int64_t)reinterpret_cast<const uint32_t*>(rec)[1];
+  m.type_end = reinterpret_cast<const int32_t*>(rec + 8);
+  m.type_prefix = reinterpret_cast<const float*>(rec + 8 + 8 * g.T);
+  return m;
+}
+
 // ... and the whole segment of listed type t from that record alone: the row record is not
 // read at all (false: the row has no edge of the type)
 __device__ __forceinline__ bool LoadWbSegmentOnly(const GraphView& g, int64_t row, int32_t t,

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborTypedPivotKe
     int32_t t = TF_LAYOUT ? -1 : 0;
     bool valid = false;
     if (row >= 0) {
-      const RowMeta m = LoadRowMeta(a.g, row);
+      const RowMeta m = LoadRowMetaWb(a.g, row);
       // node.cc:106-121,137-148: which rows have nothing to draw from
       if (mode == kTypeSub) {
         valid = true;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256, 6) void SampleNeighborSetsKernel(const SampleS
         t = et[0];
       }
     } else if (row >= 0) {
-      const RowMeta m = LoadRowMeta(a.g, row);
+      const RowMeta m = LoadRowMetaWb(a.g, row);
       bool valid;
       if (mode == kTypeSub) {
         valid = true;
@@ -249,8 +249,9 @@ __global__ __launch_bounds__(256, 6) void SampleNeighborSetsKernel(const SampleS
 // for all the sets - and a sample lane then needs global memory only for its block's keys and
 // its id, set after set.  Graphs with the weight-bucket index only (the kernel above serves
 // the rest).
-__global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborSetsLdsKernel(const SampleSetsArgs a,
-                                                                                 const int32_t rpb) {
+template <int WPS>
+__global__ __launch_bounds__(256, WPS) void SampleNeighborSetsLdsKernel(const SampleSetsArgs a,
+                                                                       const int32_t rpb) {
   extern __shared__ __align__(16) uint32_t sl_smem[];
   const int32_t T = a.g.T;
   // per root: the record of the weight-bucket index (first block, first edge, group ends,
@@ -397,7 +398,10 @@ bool LaunchSampleNeighborSets(const euler_gpu_graph* g, hipStream_t stream, uint
   if (a.g.wbg != nullptr && a.g.wb != nullptr && rpb > 0 && lds <= 48 * 1024 && g_k1_sets_lds != 0) {
     int64_t blocks = (n + rpb - 1) / rpb;
     if (blocks > kK1GridCap) blocks = kK1GridCap;
-    hipLaunchKernelGGL(SampleNeighborSetsLdsKernel, dim3((unsigned)blocks), dim3(256), lds, stream, a, rpb);
+    // (key 47 = 2: the build for 6 waves per SIMD - 80 registers, nothing spilled; 1: 8 waves, 72 bytes
+    // of scratch per lane)
+    auto kern = g_k1_sets_lds == 2 ? SampleNeighborSetsLdsKernel<6> : SampleNeighborSetsLdsKernel<8>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, a, rpb);
     if (hipGetLastError() != hipSuccess) *rc_out = Fail(EULER_GPU_EHIP, "sample_neighbor_sets: launch failed");
     return true;
   }

@@ -1753,7 +1753,7 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 44 && (value == 0 || value == 1)) { g_walk_lean = value; return EULER_GPU_OK; }
   if (key == 35 && (value == 5 || value == 6 || value == 8)) { g_fl_wps = value; return EULER_GPU_OK; }
   if (key == 45 && (value == 0 || value == 1)) { g_fl_wb = value; return EULER_GPU_OK; }
-  if (key == 47 && (value == 0 || value == 1)) { g_k1_sets_lds = value; return EULER_GPU_OK; }
+  if (key == 47 && value >= 0 && value <= 2) { g_k1_sets_lds = value; return EULER_GPU_OK; }
   if (key == 48 && (value == 0 || value == 1)) { g_fl_typed_regs = value; return EULER_GPU_OK; }
   return Fail(EULER_GPU_EINVAL, "set_tuning: unknown key");
 }

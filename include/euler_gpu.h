@@ -946,9 +946,6 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  *        groups stop looking for mergers and finish the walk in one launch (9; 0 =
  *        never).  key 44: plain graphs draw with the lean search of the one-kernel
  *        fanout (1 [default]).
- * key 48: typed hops of the one-kernel fanout on graphs with at most 4 edge-type groups keep
- *        the row record in registers (1 [default]); 0 = walk it in memory, as graphs with more
- *        groups do.
  * key 45: 1 [default] = searches go through the weight-bucket index (csrc/wb_index.h: the
  *        bucket of a draw in its row's running-sum range names ONE 128-byte line; built on
  *        first use for graphs with non-decreasing, non-uniform running sums and < 2^32
@@ -956,7 +953,11 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  *        whose weights are so uneven that more than 2 buckets in a thousand overflow their
  *        block keeps the pivot levels for the one-kernel fanout and the merged walk by itself.)
  * key 47: euler_gpu_sample_neighbor_sets stages the roots' records in LDS once per workgroup
- *        (1 [default]); 0 = every sample lane reads them.
+ *        (1 [default]; 2 = the same, built for 6 waves per SIMD instead of 8: no register
+ *        spills, measured equal); 0 = every sample lane reads them.
+ * key 48: typed hops of the one-kernel fanout on graphs with at most 4 edge-type groups keep
+ *        the row record in registers (1 [default]); 0 = walk it in memory, as graphs with more
+ *        groups do.
  * All settings produce identical results; the knobs exist for A/B measurements
  * and tests.  They are THREAD-LOCAL: a call changes the launches the calling host
  * thread enqueues afterwards and nobody else's (new threads start from the
