@@ -1732,6 +1732,11 @@ def test_sample_fanout_multi_equals_separate_calls(EA, O, torch_cuda, big_pair):
     run(G, OG, q, [[0], [1], [2]], [4, 3, 2], -5, 23, 50)           # 3 hops: one enqueue each
     run(G, OG, q, [[0, 1], [1, 2]], [6, 3], -5, 23, 60)             # type draws: one enqueue each
     run(G, OG, q, [[0], [1]], [25, 10], -5, 23, 0, ids=[900, 3, 3, 2 ** 31 - 2])
+    # type draws with enough roots for the one-kernel form: tiles of several minibatches in one
+    # launch, consecutive and explicit call ids
+    q = rng.choice(ids, 16 * 1024).astype(np.int64).reshape(16, 1024)
+    run(G, OG, q, [[0, 1], [2, 3]], [6, 4], -5, 23, 300)
+    run(G, OG, q, [[0, 1, 2, 3], [3, 2, 1, 0]], [5, 2], -5, 23, 0, ids=list(range(40, 56)))
     # identity ids, one type: lean build (weighted) and its uniform-weight form
     for weighted in (True, False):
         p = EA.synth_params(977, 20000, 260000, n_types=1, weighted=weighted)
