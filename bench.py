@@ -954,7 +954,7 @@ def run_products_leg(args):
     return res
 
 
-def run_hashed_leg(args):
+def run_hashed_leg(args, weighted=True):
     """The metric step on a graph shaped like a converted dataset: the same 100M nodes / 1B
     weighted edges, but every node known by an arbitrary u64 id (hash id map instead of
     row = id - 1) and two edge-type groups per node (Cora's train / train_removed,
@@ -967,7 +967,7 @@ def run_hashed_leg(args):
     L = _lib.lib()
     N, E = args.nodes, args.edges
     t0 = time.time()
-    p = euler_amd.synth_params(GRAPH_SEED, N, E, n_types=2, weighted=True, hashed_ids=True)
+    p = euler_amd.synth_params(GRAPH_SEED, N, E, n_types=2, weighted=weighted, hashed_ids=True)
     G = euler_amd.Graph.synthetic(p)
     G.set_seed(GRAPH_SEED)
     torch.cuda.synchronize()
@@ -1032,11 +1032,14 @@ def run_hashed_leg(args):
            "roofline_frac": round(algo / (ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
            "algorithmic_bytes_per_launch": algo, "parity_checked": int(64 * 275),
            "kernel": "SampleFanoutLeanKernel<.., WB = 2> (the one-kernel step's general form: hash id map, "
-                     "edge-type groups, weight-bucket index)",
+                     "edge-type groups, weight-bucket index)" if weighted else
+                     "SampleFanoutLeanKernel<.., WB = 6> (general form on uniform weights: the draw is an index "
+                     "computation, PivotSample's H1)",
            "graph_build_s": round(build_s, 2), "graph_bytes": G.device_bytes,
            "workload": "the metric step on %d nodes / %d edges with hashed u64 ids and 2 edge-type "
-                       "groups per node, one listed type per hop, %d roots per step, two streams"
-                       % (N, G.num_edges, B)}
+                       "groups per node%s, one listed type per hop, %d roots per step, two streams"
+                       % (N, G.num_edges, "" if weighted else ", all weights 1.0 (what the reference's dataset "
+                          "converters write)", B)}
     # the same step listing BOTH type groups per hop - what the reference's evaluation does
     # (metapath = [all_edge_type] * layers, examples/graphsage/run_graphsage.py:57): a type draw
     # per sample, then the neighbour draw (fanout_local.h, WB == 3); checked against the oracle
@@ -1070,7 +1073,8 @@ def run_hashed_leg(args):
     res["all_types_per_hop"] = {"value": edges * steps / el_all, "unit": "sampled edges/s",
                                 "ms_per_step": round(el_all / steps * 1e3, 4), "edge_types": et_all,
                                 "parity_checked": int(64 * 275),
-                                "kernel": "SampleFanoutLeanKernel<.., WB = 3> (a type draw per sample)"}
+                                "kernel": "SampleFanoutLeanKernel<.., WB = %d> (a type draw per sample)"
+                                          % (4 if weighted else 5)}
     del G, out, out_all
     torch.cuda.empty_cache()
     return res
@@ -1202,6 +1206,10 @@ def secondary_legs(args, G, p_g):
         sec["metric_hashed_T2"] = run_hashed_leg(args)
     except Exception as e:
         sec["metric_hashed_T2"] = {"error": repr(e)}
+    try:      # ... with all weights 1.0: the shape of every dataset the reference ships
+        sec["metric_hashed_T2_unweighted"] = run_hashed_leg(args, weighted=False)
+    except Exception as e:
+        sec["metric_hashed_T2_unweighted"] = {"error": repr(e)}
     try:
         a = copy.copy(args)
         a.steps, a.warmup, a.repeats = 10, 3, 3

@@ -115,6 +115,12 @@ struct GraphView {
   // this one's, and a segment's limits are not two more dependent loads
   const uint8_t* wbg;
   int32_t wbg_stride;           // 16 (T = 1), else 8 + 12 T
+  // the same records for the kernels that only need the ROW part (first edge, group ends, their
+  // running sums, type sums) - the typed hops of the one-kernel fanout: = wbg on graphs with
+  // the index; graphs of uniform weights and several edge-type groups (every dataset the
+  // reference ships: weight 1.0, 'train' / 'train_removed') get the records alone (wb_lo = 0)
+  const uint8_t* trec;
+  int32_t trec_stride;
   int32_t wb_lean_ok;           // at most 2 buckets in a thousand overflow their block (counted at
                                 // build): the lean kernels - whose second chance is the reference's
                                 // bisection - draw through the index; otherwise they keep the pivot

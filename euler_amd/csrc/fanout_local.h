@@ -696,7 +696,7 @@ __device__ __forceinline__ void LoadWbSeg(const GraphView& g, uint64_t node, int
   s->wb_lo = 0; s->row_deg = 0; s->lo = 0; s->deg = 0; s->row_total = 0.f; s->lim_b = 0.f; s->lim_e = 0.f;
   s->row = FindRow(g, node);
   if (s->row < 0 || t < 0 || t >= g.T) return;
-  const uint8_t* wrec = g.wbg + s->row * (int64_t)g.wbg_stride;
+  const uint8_t* wrec = g.trec + s->row * (int64_t)g.trec_stride;
   const uint32_t* hd = reinterpret_cast<const uint32_t*>(wrec);
   const int32_t* te = reinterpret_cast<const int32_t*>(wrec + 8);
   const float* lim = reinterpret_cast<const float*>(wrec + 8 + 4 * g.T);
@@ -794,7 +794,7 @@ __device__ __forceinline__ void LoadWbRowT(const GraphView& g, const uint64_t no
   r->row_lo = 0; r->row_deg = 0; r->valid = false;
   r->row = FindRow(g, node);
   if (r->row < 0) return;
-  const uint8_t* rec = g.wbg + r->row * (int64_t)g.wbg_stride;
+  const uint8_t* rec = g.trec + r->row * (int64_t)g.trec_stride;
   r->hd = reinterpret_cast<const uint32_t*>(rec);
   r->te = reinterpret_cast<const int32_t*>(rec + 8);
   r->lim = reinterpret_cast<const float*>(rec + 8 + 4 * g.T);
@@ -905,7 +905,7 @@ __device__ __forceinline__ void LoadWbRowT4(const GraphView& g, const uint64_t n
   r->row = FindRow(g, node);
   if (r->row < 0) return;
   const int32_t T = g.T;
-  const uint8_t* rec = g.wbg + r->row * (int64_t)g.wbg_stride;
+  const uint8_t* rec = g.trec + r->row * (int64_t)g.trec_stride;
   const uint32_t* hd = reinterpret_cast<const uint32_t*>(rec);
   const int32_t* te = reinterpret_cast<const int32_t*>(rec + 8);
   const float* lim = reinterpret_cast<const float*>(rec + 8 + 4 * T);
@@ -946,6 +946,45 @@ __device__ __forceinline__ bool WbTypedSeg4(const GraphView& g, const WbRowT4& r
   return e > b;
 }
 
+// The two neighbour draws on a graph of UNIFORM weights: the running sum after edge m is m + 1
+// exactly, so the first sum above r is edge floor(r) of the row (k1_search.h: PivotSample, H1) -
+// one id load, no search.  r rounded up to the end of the group: the reference's loop replayed.
+__device__ __forceinline__ void UniformSamplePairG2(const GraphView& g, const WbSeg sg0, const WbSeg sg1,
+                                                    const int32_t t0, const int32_t t1, const bool live0,
+                                                    const bool live1, const double u0, const double u1,
+                                                    uint64_t id[2], float w[2], uint32_t m[2]) {
+  const double r0 = __dadd_rn(__dmul_rn(u0, (double)__fsub_rn(sg0.lim_e, sg0.lim_b)), (double)sg0.lim_b);
+  const double r1 = __dadd_rn(__dmul_rn(u1, (double)__fsub_rn(sg1.lim_e, sg1.lim_b)), (double)sg1.lim_b);
+  const bool cold0 = live0 && !((double)sg0.lim_e > r0);
+  const bool cold1 = live1 && !((double)sg1.lim_e > r1);
+  id[0] = 0; id[1] = 0; w[0] = 0.f; w[1] = 0.f; m[0] = sg0.lo; m[1] = sg1.lo;
+  if (live0 && !cold0) {                     // (lim_b = the group's first edge, row-relative, as a float)
+    m[0] = sg0.lo + ((uint32_t)r0 - (uint32_t)sg0.lim_b);
+    id[0] = g.nbr[m[0]]; w[0] = 1.0f;
+  }
+  if (live1 && !cold1) {
+    m[1] = sg1.lo + ((uint32_t)r1 - (uint32_t)sg1.lim_b);
+    id[1] = g.nbr[m[1]]; w[1] = 1.0f;
+  }
+  if (__ballot(cold0 || cold1) != 0ull) {
+#pragma nounroll
+    for (int s = 0; s < 2; ++s) {
+      if (s == 0 ? cold0 : cold1) {
+        const int32_t t = s == 0 ? t0 : t1;
+        const RowMeta rm = LoadRowMeta(g, sg0.row);
+        const float* nw = g.prefix_w + rm.row_ptr;
+        const int32_t b = t == 0 ? 0 : rm.type_end[t - 1];
+        const uint32_t mid = (uint32_t)RandomSelect(nw, (uint64_t)b, (uint64_t)(rm.type_end[t] - 1), s == 0 ? u0 : u1);
+        const uint64_t ci = g.nbr[rm.row_ptr + mid];
+        const float cw = __fsub_rn(nw[mid], mid == 0u ? 0.f : nw[mid - 1]);
+        if (s == 0) { id[0] = ci; w[0] = cw; m[0] = (uint32_t)(rm.row_ptr + mid); }
+        else { id[1] = ci; w[1] = cw; m[1] = (uint32_t)(rm.row_ptr + mid); }
+      }
+    }
+  }
+}
+
+template <bool UNI = false>
 __device__ __forceinline__ void WbSampleTypedPair4(const GraphView& g, const WbRowT4& r, const int32_t mode,
                                                    const int32_t* et, const int32_t k, const uint64_t seed,
                                                    const uint32_t call, const uint64_t node,
@@ -964,8 +1003,10 @@ __device__ __forceinline__ void WbSampleTypedPair4(const GraphView& g, const WbR
     if (two) ok1 = WbTypedSeg4(g, r, mode, et, k, UnitFromWords(pb.w[0], pb.w[1]), &tt[1], &sg1);
     else sg1 = sg0;
   }
-  WbSamplePairG2<true>(g, sg0, sg1, tt[0], tt[1], ok0, ok1, UnitFromWords(pa.w[2], pa.w[3]),
-                       UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
+  if (UNI) UniformSamplePairG2(g, sg0, sg1, tt[0], tt[1], ok0, ok1, UnitFromWords(pa.w[2], pa.w[3]),
+                               UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
+  else WbSamplePairG2<true>(g, sg0, sg1, tt[0], tt[1], ok0, ok1, UnitFromWords(pa.w[2], pa.w[3]),
+                            UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
   *sentinel = live && (!ok0 || (two && !ok1));
   if (live && !ok0) { id[0] = 0; w[0] = 0.f; m[0] = r.row_lo; tt[0] = 0; }
   if (live && two && !ok1) { id[1] = 0; w[1] = 0.f; m[1] = r.row_lo; tt[1] = 0; }
@@ -1005,7 +1046,9 @@ __host__ __device__ inline FanoutLeanLds FanoutLeanLayout(int32_t gr, int32_t c1
 // WB: 1 = draws through the weight-bucket index (WbSamplePair) instead of the pivot levels;
 // 2 = the same on graphs with several edge-type groups / hashed ids (WbSamplePairG: one listed
 // type per hop, no neighbour id 0); 3 = ... and hops that list several types (a type draw per
-// sample, WbSampleTypedPair; at most 127 types).
+// sample, WbSampleTypedPair; at most 127 types); 4 = 3 with the row record in registers (at most 4
+// type groups); 5 = 4 on a graph of uniform weights (the neighbour draw is an index computation);
+// 6 = 2 on a graph of uniform weights.
 template <bool WIDE, int WPS, bool UNIFORM = false, int WB = 0>
 __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
     const FanoutLocalArgs a) {
@@ -1013,7 +1056,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
   const int lane = threadIdx.x & 63;
   const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int waves_per_block = blockDim.x >> 6;
-  const FanoutLeanLds L = FanoutLeanLayout(a.gr, a.c1, a.c2, a.cap, WB >= 3);
+  const FanoutLeanLds L = FanoutLeanLayout(a.gr, a.c1, a.c2, a.cap, WB >= 3 && WB <= 5);
   uint8_t* base = fl_smem + (size_t)wave_in_block * a.wave_lds;
   uint64_t* s_sid = reinterpret_cast<uint64_t*>(base + L.o_sid);
   uint64_t* s_c1 = reinterpret_cast<uint64_t*>(base + L.o_c1);
@@ -1060,21 +1103,21 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
       uint64_t node = 0;
       WbRec wr{0u, 0u, 0u, 0.f};
       WbSeg ws;
-      if (WB == 2) { ws.wb_lo = 0; ws.row_deg = 0; ws.lo = 0; ws.deg = 0; ws.row_total = 0.f; ws.lim_b = 0.f; ws.lim_e = 0.f; ws.row = -1; }
+      if (WB == 2 || WB == 6) { ws.wb_lo = 0; ws.row_deg = 0; ws.lo = 0; ws.deg = 0; ws.row_total = 0.f; ws.lim_b = 0.f; ws.lim_e = 0.f; ws.row = -1; }
       WbRowT wt;
       WbRowT4 w4;
       if (WB == 3) { wt.hd = nullptr; wt.te = nullptr; wt.lim = nullptr; wt.tsum = nullptr; wt.row = -1; wt.row_lo = 0; wt.row_deg = 0; wt.valid = false; }
-      if (WB == 4) { w4.wb_lo = 0; w4.row_lo = 0; w4.row = -1; w4.row_deg = 0; w4.row_total = 0.f; w4.valid = false;
+      if (WB == 4 || WB == 5) { w4.wb_lo = 0; w4.row_lo = 0; w4.row = -1; w4.row_deg = 0; w4.row_total = 0.f; w4.valid = false;
                      for (int i = 0; i < 4; ++i) { w4.te[i] = 0; w4.lim[i] = 0.f; w4.ts[i] = 0.f; } }
       if (in) {
         node = a.roots[r0 + q];
-        if (WB == 4) {
+        if (WB == 4 || WB == 5) {
           LoadWbRowT4(g, node, a.type_mode, a.et1, a.k, &w4);
           lo = w4.row_lo; deg = w4.valid ? (int32_t)w4.row_deg : 0;
         } else if (WB == 3) {
           LoadWbRowT(g, node, a.type_mode, a.et1, a.k, &wt);
           lo = wt.row_lo; deg = wt.valid ? (int32_t)wt.row_deg : 0;
-        } else if (WB == 2) {
+        } else if (WB == 2 || WB == 6) {
           LoadWbSeg(g, node, a.t1, &ws);
           lo = ws.lo; deg = (int32_t)ws.deg;
         } else {
@@ -1095,12 +1138,14 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
       int32_t tt[2] = {a.t1, a.t1};
       bool sentinel = false;
       Philox4 pb;
-      if (WB == 4) WbSampleTypedPair4(g, w4, a.type_mode, a.et1, a.k, a.seed, tile_call, node, jp, live,
+      if (WB == 4 || WB == 5) WbSampleTypedPair4<WB == 5>(g, w4, a.type_mode, a.et1, a.k, a.seed, tile_call, node, jp, live,
                                       2u * jp + 1u < c1, id, w, m, tt, &sentinel);
       else if (WB == 3) WbSampleTypedPair(g, wt, a.type_mode, a.et1, a.k, a.seed, tile_call, node, jp, live,
                                           2u * jp + 1u < c1, id, w, m, tt, &sentinel);
       else pb = RngBlock(a.seed, tile_call, kDomainNeighbor, node, jp);
-      if (WB >= 3) {}
+      if (WB >= 3 && WB <= 5) {}
+      else if (WB == 6) UniformSamplePairG2(g, ws, ws, a.t1, a.t1, live, live && 2u * jp + 1u < c1,
+                                            UnitFromWords(pb.w[0], pb.w[1]), UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
       else if (WB == 2) WbSamplePairG(g, ws, a.t1, live, UnitFromWords(pb.w[0], pb.w[1]),
                                  UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
       else if (WB) WbSamplePair(g, wr, live, UnitFromWords(pb.w[0], pb.w[1]),
@@ -1115,12 +1160,12 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
         const uint32_t e0 = q * c1 + j0;
         s_c1[e0] = live ? id[0] : 0;        // a row without samples hands node id 0 on
         s_w1[e0] = live ? w[0] : 0.f;
-        if (WB >= 3) s_t1[e0] = (int8_t)(live ? tt[0] : -1);
+        if (WB >= 3 && WB <= 5) s_t1[e0] = (int8_t)(live ? tt[0] : -1);
         unsigned long long bits = live ? 1ull << ((m[0] - lo) & 63u) : 1ull;
         if (j0 + 1u < c1) {
           s_c1[e0 + 1] = live ? id[1] : 0;
           s_w1[e0 + 1] = live ? w[1] : 0.f;
-          if (WB >= 3) s_t1[e0 + 1] = (int8_t)(live ? tt[1] : -1);
+          if (WB >= 3 && WB <= 5) s_t1[e0 + 1] = (int8_t)(live ? tt[1] : -1);
           if (live) bits |= 1ull << ((m[1] - lo) & 63u);
           // the slot pass below needs the edge of every sample: park it in s_slot
           s_slot[e0 + 1] = (uint16_t)(live ? (m[1] - lo) & 63u : 0u);
@@ -1208,21 +1253,21 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
         uint64_t node = 0;
         WbRec wr{0u, 0u, 0u, 0.f};
         WbSeg ws;
-        if (WB == 2) { ws.wb_lo = 0; ws.row_deg = 0; ws.lo = 0; ws.deg = 0; ws.row_total = 0.f; ws.lim_b = 0.f; ws.lim_e = 0.f; ws.row = -1; }
+        if (WB == 2 || WB == 6) { ws.wb_lo = 0; ws.row_deg = 0; ws.lo = 0; ws.deg = 0; ws.row_total = 0.f; ws.lim_b = 0.f; ws.lim_e = 0.f; ws.row = -1; }
         WbRowT wt;
         WbRowT4 w4;
         if (WB == 3) { wt.hd = nullptr; wt.te = nullptr; wt.lim = nullptr; wt.tsum = nullptr; wt.row = -1; wt.row_lo = 0; wt.row_deg = 0; wt.valid = false; }
-        if (WB == 4) { w4.wb_lo = 0; w4.row_lo = 0; w4.row = -1; w4.row_deg = 0; w4.row_total = 0.f; w4.valid = false;
+        if (WB == 4 || WB == 5) { w4.wb_lo = 0; w4.row_lo = 0; w4.row = -1; w4.row_deg = 0; w4.row_total = 0.f; w4.valid = false;
                        for (int i = 0; i < 4; ++i) { w4.te[i] = 0; w4.lim[i] = 0.f; w4.ts[i] = 0.f; } }
         if (in) {
           node = s_slotid[s0 + sl];
-          if (WB == 4) {
+          if (WB == 4 || WB == 5) {
             LoadWbRowT4(g, node, a.type_mode, a.et2, a.k, &w4);
             lo = w4.row_lo; deg = w4.valid ? (int32_t)w4.row_deg : 0;
           } else if (WB == 3) {
             LoadWbRowT(g, node, a.type_mode, a.et2, a.k, &wt);
             lo = wt.row_lo; deg = wt.valid ? (int32_t)wt.row_deg : 0;
-          } else if (WB == 2) {
+          } else if (WB == 2 || WB == 6) {
             LoadWbSeg(g, node, a.t2, &ws);
             lo = ws.lo; deg = (int32_t)ws.deg;
           } else {
@@ -1243,12 +1288,14 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
         int32_t tt[2] = {a.t2, a.t2};
         bool sentinel = false;
         Philox4 pb;
-        if (WB == 4) WbSampleTypedPair4(g, w4, a.type_mode, a.et2, a.k, a.seed, tile_call + 1u, node, xp, live,
+        if (WB == 4 || WB == 5) WbSampleTypedPair4<WB == 5>(g, w4, a.type_mode, a.et2, a.k, a.seed, tile_call + 1u, node, xp, live,
                                         true, id, w, m, tt, &sentinel);
         else if (WB == 3) WbSampleTypedPair(g, wt, a.type_mode, a.et2, a.k, a.seed, tile_call + 1u, node, xp, live,
                                             true, id, w, m, tt, &sentinel);
         else pb = RngBlock(a.seed, tile_call + 1u, kDomainNeighbor, node, xp);
-        if (WB >= 3) {}
+        if (WB >= 3 && WB <= 5) {}
+        else if (WB == 6) UniformSamplePairG2(g, ws, ws, a.t2, a.t2, live, live, UnitFromWords(pb.w[0], pb.w[1]),
+                                              UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
         else if (WB == 2) WbSamplePairG(g, ws, a.t2, live, UnitFromWords(pb.w[0], pb.w[1]),
                                    UnitFromWords(pb.w[2], pb.w[3]), id, w, m);
         else if (WB) WbSamplePair(g, wr, live, UnitFromWords(pb.w[0], pb.w[1]),
@@ -1265,7 +1312,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
           *reinterpret_cast<float2*>(s_sw + sl * c2 + 2u * xp) =
               make_float2(live ? w[0] : 0.f, live ? w[1] : 0.f);
           if (xp == 0) s_st[sl] = live ? a.t2 : -1;
-          if (WB >= 3) {
+          if (WB >= 3 && WB <= 5) {
             s_t2[sl * c2 + 2u * xp] = (int8_t)(live ? tt[0] : -1);
             s_t2[sl * c2 + 2u * xp + 1u] = (int8_t)(live ? tt[1] : -1);
           }
@@ -1283,7 +1330,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
             *reinterpret_cast<float2*>(a.w2 + row0 + e) = *reinterpret_cast<const float2*>(s_sw + e);
             const int32_t tv = s_st[a.div_c2(e)];
             *reinterpret_cast<int2*>(a.ty2 + row0 + e) =
-                WB >= 3 ? make_int2((int32_t)s_t2[e], (int32_t)s_t2[e + 1]) : make_int2(tv, tv);
+                (WB >= 3 && WB <= 5) ? make_int2((int32_t)s_t2[e], (int32_t)s_t2[e + 1]) : make_int2(tv, tv);
           }
         }
       } else
@@ -1304,7 +1351,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
                   *reinterpret_cast<const float2*>(s_sw + sl * c2 + x);
               const int32_t tv = s_st[sl];
               *reinterpret_cast<int2*>(a.ty2 + out2 + p) =
-                  WB >= 3 ? make_int2((int32_t)s_t2[sl * c2 + x], (int32_t)s_t2[sl * c2 + x + 1]) : make_int2(tv, tv);
+                  (WB >= 3 && WB <= 5) ? make_int2((int32_t)s_t2[sl * c2 + x], (int32_t)s_t2[sl * c2 + x + 1]) : make_int2(tv, tv);
             }
           }
         }
@@ -1326,7 +1373,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
             int32_t ta = -1, tb = -1, ta2 = -1, tb2 = -1;
             if (ina) { wa = *reinterpret_cast<const float2*>(s_sw + sla * c2 + xa); ta = s_st[sla]; ta2 = ta; }
             if (inb) { wb = *reinterpret_cast<const float2*>(s_sw + slb * c2 + xb); tb = s_st[slb]; tb2 = tb; }
-            if (WB >= 3) {
+            if (WB >= 3 && WB <= 5) {
               if (ina) { ta = (int32_t)s_t2[sla * c2 + xa]; ta2 = (int32_t)s_t2[sla * c2 + xa + 1]; }
               if (inb) { tb = (int32_t)s_t2[slb * c2 + xb]; tb2 = (int32_t)s_t2[slb * c2 + xb + 1]; }
             }
@@ -1364,7 +1411,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
         const bool ok = s_rvalid[q] != 0;
         a.id1[out1 + tk] = ok ? s_c1[tk] : (uint64_t)a.default_node;
         a.w1[out1 + tk] = s_w1[tk];
-        a.ty1[out1 + tk] = WB >= 3 ? (int32_t)s_t1[tk] : ok ? a.t1 : -1;
+        a.ty1[out1 + tk] = (WB >= 3 && WB <= 5) ? (int32_t)s_t1[tk] : ok ? a.t1 : -1;
       }
     }
     WaveSync();

@@ -825,7 +825,7 @@ __global__ void WbRecKernel(GraphView g, const uint32_t* wb_lo, uint8_t* wbg, in
   if (row >= g.n_rows) return;
   const RowMeta m = LoadRowMeta(g, row);
   uint8_t* out = wbg + row * (int64_t)wbg_stride;
-  reinterpret_cast<uint32_t*>(out)[0] = wb_lo[row];
+  reinterpret_cast<uint32_t*>(out)[0] = wb_lo != nullptr ? wb_lo[row] : 0u;
   reinterpret_cast<uint32_t*>(out)[1] = (uint32_t)m.row_ptr;
   int32_t* te = reinterpret_cast<int32_t*>(out + 8);
   float* lim = reinterpret_cast<float*>(out + 8 + 4 * g.T);
@@ -864,6 +864,24 @@ __global__ __launch_bounds__(256) void WbFillKernel(GraphView g, const uint32_t*
 
 int BuildWbIndex(GraphBuilder* b) {
   GraphView& v = b->g->view;
+  // uniform weights, several edge-type groups: the row records alone (a draw there is an index
+  // computation - PivotSample's H1 - and needs no buckets; the typed hops of the one-kernel
+  // fanout read the group ends and the type sums from the record)
+  if (v.monotone != 0 && v.uniform_w != 0 && (v.T > 1 || v.map_mode != 0) && v.n_rows > 0 && v.n_edges > 0 &&
+      v.n_edges < ((int64_t)1 << 31)) {
+    const int32_t stride = v.T == 1 ? 16 : 8 + 12 * v.T;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (size_t)v.n_rows * stride + ((size_t)1 << 30) > free_b)
+      return EULER_GPU_OK;
+    uint8_t* trec = b->Alloc<uint8_t>((size_t)v.n_rows * stride + 16);
+    if (b->rc != EULER_GPU_OK) return b->rc;
+    hipLaunchKernelGGL(WbRecKernel, dim3((v.n_rows + 255) / 256), dim3(256), 0, 0, v, (const uint32_t*)nullptr,
+                       trec, stride);
+    EG_HIP(hipGetLastError());
+    EG_HIP(hipDeviceSynchronize());
+    v.trec = trec; v.trec_stride = stride;
+    return EULER_GPU_OK;
+  }
   // rows must be non-decreasing (the keys decide by counting) and worth a search at all;
   // 32-bit edge and block numbers
   if (v.monotone == 0 || v.uniform_w != 0 || v.n_rows <= 0 || v.n_edges <= 0 ||
@@ -927,6 +945,7 @@ int BuildWbIndex(GraphBuilder* b) {
   unsigned long long n_ovf = 0;
   EG_HIP(hipMemcpy(&n_ovf, ovf, 8, hipMemcpyDeviceToHost));
   v.wrec = rec; v.wb = wb; v.n_wb = n_wb; v.wbg = wbg; v.wbg_stride = stride;
+  v.trec = wbg; v.trec_stride = stride;
   // (i.i.d. uniform weights: 1e-4; lognormal sigma 2, Pareto alpha 0.7: ~5e-2)
   v.wb_lean_ok = (double)n_ovf <= 0.002 * (double)n_wb ? 1 : 0;
   return EULER_GPU_OK;

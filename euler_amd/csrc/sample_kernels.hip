@@ -593,7 +593,8 @@ int SamplingView(const euler_gpu_graph* g, GraphView* out) {
     if (rc != EULER_GPU_OK) return rc;
   }
   *out = g->view;
-  if (!wb) { out->wb = nullptr; out->wbg = nullptr; out->wrec = nullptr; out->n_wb = 0; out->wb_lean_ok = 0; }
+  if (!wb) { out->wb = nullptr; out->wbg = nullptr; out->wrec = nullptr; out->n_wb = 0; out->wb_lean_ok = 0;
+             out->trec = nullptr; out->trec_stride = 0; }
   return EULER_GPU_OK;
 }
 
@@ -1404,11 +1405,21 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
   // (hops that list several edge types - a type draw per sample - take the same kernel on the
   // graphs the weight-bucket index serves: fanout_local.h, WB == 3)
   const bool typed_hops = k > 1 && k <= kMaxListedTypes;
+  // (graphs of uniform weights: the register form only - at most 4 type groups)
   const bool typed_ok = typed_hops && g_fl_plain == 2 && g_fl_wb != 0 && g_k1_typed_pivot != 0 &&
                         g->view.T > 1 && g->view.T <= 127 && g->view.has_zero_nbr == 0 &&
-                        g->view.uniform_w == 0 && g->view.n_edges < ((int64_t)1 << 31) &&
+                        (g->view.uniform_w == 0 || g->view.T <= 4) && g->view.n_edges < ((int64_t)1 << 31) &&
                         t_fl_row_index == nullptr && counts_host[1] % 2 == 0;
-  if (g_fanout_local != 0 && (g->view.uniform_w == 0 || g_fanout_local == 2) && events == nullptr &&
+  // graphs of uniform weights that are not "plain" (several type groups, hashed ids - the shape of
+  // the reference's datasets), one listed type per hop: the lean build with the index
+  // computation as its draw (WB == 6), or hop by hop as before
+  const bool uni_general = k == 1 && g->view.uniform_w != 0 && (g->view.T > 1 || g->view.map_mode != 0) &&
+                           g_fanout_local == 1 && g_fl_plain == 2 && g_fl_wb != 0 && g->view.has_zero_nbr == 0 &&
+                           g->view.n_edges < ((int64_t)1 << 31) && t_fl_row_index == nullptr &&
+                           counts_host[1] % 2 == 0;
+  const bool lean_only = typed_hops || uni_general;       // no general-build fallback inside
+  if (g_fanout_local != 0 && (g->view.uniform_w == 0 || g_fanout_local == 2 || typed_ok || uni_general) &&
+      events == nullptr &&
       layers == 2 && (k == 1 || typed_ok) &&
       n >= (multi != nullptr && g_fl_min_roots > 8192 ? 8192 : g_fl_min_roots) &&
       g_k1_variant == 6 && g->view.monotone && counts_host[0] > 0 && counts_host[1] > 0) {
@@ -1482,13 +1493,18 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
       const bool plain = plain_u && v.uniform_w == 0;
       // the lean build's general form: any graph the weight-bucket index serves (several
       // edge-type groups, hashed ids), valid listed types, no neighbour id 0
-      const bool lean_t = typed_hops && v.wbg != nullptr && v.wb != nullptr && v.wb_lean_ok != 0;
+      const bool lean_tu = typed_hops && v.uniform_w != 0 && v.trec != nullptr && v.T <= 4;
+      const bool lean_t = lean_tu || (typed_hops && v.uniform_w == 0 && v.trec != nullptr && v.wb != nullptr &&
+                                      v.wb_lean_ok != 0);
       const bool lean_g = !typed_hops &&
                           !plain_u && g_fl_plain == 2 && g_fl_wb != 0 && v.wbg != nullptr && v.wb != nullptr &&
                           v.wb_lean_ok != 0 &&
                           v.has_zero_nbr == 0 && v.uniform_w == 0 && f.t1 >= 0 && f.t1 < v.T && f.t2 >= 0 &&
                           f.t2 < v.T && t_fl_row_index == nullptr;
-      if (((plain_u && !typed_hops) || lean_g || lean_t) && g_fl_plain == 2 && f.vec &&
+      const bool lean_gu = !typed_hops && !plain_u && g_fl_plain == 2 && g_fl_wb != 0 && v.trec != nullptr &&
+                           v.uniform_w != 0 && v.has_zero_nbr == 0 && f.t1 >= 0 && f.t1 < v.T && f.t2 >= 0 &&
+                           f.t2 < v.T && t_fl_row_index == nullptr;
+      if (((plain_u && !typed_hops) || lean_g || lean_gu || lean_t) && g_fl_plain == 2 && f.vec &&
           v.n_edges < ((int64_t)1 << 31)) {
         // the lean build (pairs of samples per lane, f32 compares, duplicates by edge)
         int32_t lcap = cap;
@@ -1509,7 +1525,11 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
           t_fl_took_lean = 1;
           void (*lk)(const FanoutLocalArgs) = nullptr;
           const bool use_wb = v.uniform_w == 0 && f.g.wrec != nullptr && f.g.wb != nullptr && v.wb_lean_ok != 0;
-          if (lean_t && v.T <= 4 && g_fl_typed_regs != 0) {      // the row record in registers
+          if (lean_gu) {
+            lk = f.wide ? SampleFanoutLeanKernel<true, 5, false, 6> : SampleFanoutLeanKernel<false, 5, false, 6>;
+          } else if (lean_tu) {                                  // ... and the draw an index computation
+            lk = f.wide ? SampleFanoutLeanKernel<true, 5, false, 5> : SampleFanoutLeanKernel<false, 5, false, 5>;
+          } else if (lean_t && v.T <= 4 && g_fl_typed_regs != 0) {      // the row record in registers
             lk = f.wide ? SampleFanoutLeanKernel<true, 5, false, 4> : SampleFanoutLeanKernel<false, 5, false, 4>;
           } else if (lean_t) {
             lk = f.wide ? SampleFanoutLeanKernel<true, 5, false, 3> : SampleFanoutLeanKernel<false, 5, false, 3>;
@@ -1539,7 +1559,7 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
           return EULER_GPU_OK;
         }
       }
-      if (!typed_hops) {        // (typed hops the lean build does not take go hop by hop, below)
+      if (!lean_only) {         // (typed hops / uniform general graphs the lean build does not take go hop by hop, below)
       void (*kern)(const FanoutLocalArgs) = nullptr;
 #define EG_FL(W, P) (g_fl_wps != 8 ? SampleFanoutLocalKernel<W, P, 5> : SampleFanoutLocalKernel<W, P, 8>)
       kern = f.wide ? (plain ? EG_FL(true, true) : EG_FL(true, false))

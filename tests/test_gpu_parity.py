@@ -1646,16 +1646,30 @@ def test_fanout_local_dedup_kernel(EA, O, torch_cuda, big_pair, geom):
             for counts in ([25, 10], [3, 4], [10, 5], [1, 2], [80, 6]):
                 check(G1, OG1, q, [[0], [0]], counts, 20001, 3, 6)
         # identity ids, 2 and 8 edge-type groups: every hop lists all of them / three of eight
-        for T_, et in ((2, [[0, 1], [0, 1]]), (2, [[1, 0], [1, 0]]), (8, [[3, 1, 6], [0, 7, 2]]),
-                       (8, [list(range(8))] * 2)):
-            p = EA.synth_params(55 + T_, 20000, 400000, n_types=T_, weighted=True)
+        # (weights all 1.0 - what the reference's datasets have: the neighbour draw is an index computation)
+        for T_, et, wgt in ((2, [[0, 1], [0, 1]], True), (2, [[1, 0], [1, 0]], True), (8, [[3, 1, 6], [0, 7, 2]], True),
+                            (8, [list(range(8))] * 2, True), (2, [[0, 1], [0, 1]], False),
+                            (3, [[2, 0], [1, 2]], False), (3, [[0, 1, 2], [2, 1, 0]], False),
+                            (8, [[3, 1, 6], [0, 7, 2]], False),
+                            # ... and one listed type per hop on such a graph (identity and hashed ids)
+                            (2, [[0], [1]], False), (3, [[2], [2]], False), (-2, [[1], [0]], False),
+                            (-2, [[0, 1], [1, 0]], False), (-1, [[0], [0]], False)):
+            if plain != 2 and (not wgt or T_ != 2):
+                continue        # (these take the lean builds, which key 34 = 2 selects: elsewhere one case is enough)
+            hashed = T_ < 0
+            T_ = abs(T_)
+            p = EA.synth_params(55 + T_, 20000, 400000, n_types=T_, weighted=wgt, hashed_ids=hashed)
             po = O.SynthParams()
             for f, _ in po._fields_:
                 setattr(po, f, getattr(p, f))
-            Gt, OGt = EA.Graph.synthetic(p), O.OracleGraph(O.synth_csr(po))
+            csr_t = O.synth_csr(po)
+            Gt, OGt = EA.Graph.synthetic(p), O.OracleGraph(csr_t)
             q = np.concatenate([np.random.default_rng(8).integers(1, 20001, 2500), [0, 20001, 7, 7]]).astype(np.int64)
+            if hashed:          # the graph knows node x by mix64(x)
+                q = np.concatenate([np.random.default_rng(8).choice(csr_t.row_id, 2500),
+                                    np.array([0, 4242, 7], np.uint64)]).astype(np.uint64).view(np.int64)
             for counts in ([25, 10], [3, 2]):
-                check(Gt, OGt, q, et, counts, 20001, 12, 30)
+                check(Gt, OGt, q, et, counts, -7 if hashed else 20001, 12, 30)
         # ... and on hubs (rows of more than 64 edges: duplicates by id; several buckets per row)
         ph2 = EA.synth_params(37, 3000, 600000, n_types=2, weighted=True)
         po = O.SynthParams()

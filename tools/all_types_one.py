@@ -9,7 +9,13 @@ if '--lib' in sys.argv:                 # A/B against another build of the libra
     from euler_amd import _lib
     _lib.LIB_PATH = sys.argv[sys.argv.index('--lib') + 1]
 N = 100_000_000
-p = euler_amd.synth_params(bench.GRAPH_SEED, N, 10 * N, n_types=2, weighted=True, hashed_ids=True)
+WEIGHTED = '--unweighted' not in sys.argv
+if '--tuning' in sys.argv:
+    from euler_amd import _lib as _l
+    for kv in sys.argv[sys.argv.index('--tuning') + 1].split(','):
+        k_, v_ = kv.split('=')
+        _l.check(_l.lib().euler_gpu_set_tuning(int(k_), int(v_)))
+p = euler_amd.synth_params(bench.GRAPH_SEED, N, 10 * N, n_types=2, weighted=WEIGHTED, hashed_ids=True)
 G = euler_amd.Graph.synthetic(p)
 G.set_seed(bench.GRAPH_SEED)
 gen = torch.Generator(device="cuda"); gen.manual_seed(2468)
