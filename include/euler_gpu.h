@@ -922,8 +922,9 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
  * key 25: node2vec with key 7 = 3: child lists of this many entries or more go to the
  *        workgroup kernel (default 8192; 0 = none).
  * key 27: the one-kernel fanout (csrc/fanout_local.h: 2 hops, one listed type each - or,
- *        on graphs with the weight-bucket index and at most 127 edge types, the same number
- *        of several listed types each: a type draw per sample -, >= key 33 roots): 1 = on weighted graphs [default], 2 = on every graph,
+ *        on graphs with the weight-bucket index and at most 127 edge types, or of uniform
+ *        weights and at most 4, the same number of several listed types each: a type draw
+ *        per sample -, >= key 33 roots): 1 = on weighted graphs [default], 2 = on every graph,
  *        0 = off (hop by hop).  Its geometry: key 28 roots per wave (1..16; 0 [default] =
  *        the launcher chooses: 4, or 8 for a caller that alternates streams on a graph with
  *        the weight-bucket index), key 29 distinct children sampled per pass (0 [default] =
