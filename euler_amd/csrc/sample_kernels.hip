@@ -1399,9 +1399,6 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
     ~FanoutConcurrency() { if (own) t_concurrent = -1; }
   } fanout_concurrency(g, stream);
   // a 2-hop fanout of single listed types: ONE kernel, duplicates found inside the wave
-  // (a graph of all-1.0 weights keeps the hop-by-hop path unless key 27 = 2: its draws cost
-  // one id load, and the global duplicate detection finds more to share on the small dense
-  // graphs of that kind - products-shaped: 135 vs 131 G edges/s)
   // (hops that list several edge types - a type draw per sample - take the same kernel on the
   // graphs the weight-bucket index serves: fanout_local.h, WB == 3)
   const bool typed_hops = k > 1 && k <= kMaxListedTypes;
@@ -1418,7 +1415,13 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
                            g->view.n_edges < ((int64_t)1 << 31) && t_fl_row_index == nullptr &&
                            counts_host[1] % 2 == 0;
   const bool lean_only = typed_hops || uni_general;       // no general-build fallback inside
-  if (g_fanout_local != 0 && (g->view.uniform_w == 0 || g_fanout_local == 2 || typed_ok || uni_general) &&
+  // (plain graphs of uniform weights - products-shaped - take the lean build too since it is built
+  // for 5 waves per SIMD: 156 G edges/s against 144 hop by hop and 138 with the spilling 8-wave build)
+  const bool uni_plain = k == 1 && g->view.uniform_w != 0 && g->view.T == 1 && g->view.map_mode == 0 &&
+                         g->view.total_in_meta != 0 && g->view.has_zero_nbr == 0 && g_fl_plain == 2 &&
+                         counts_host[1] % 2 == 0 && g->view.n_edges < ((int64_t)1 << 31);
+  if (g_fanout_local != 0 &&
+      (g->view.uniform_w == 0 || g_fanout_local == 2 || typed_ok || uni_general || uni_plain) &&
       events == nullptr &&
       layers == 2 && (k == 1 || typed_ok) &&
       n >= (multi != nullptr && g_fl_min_roots > 8192 ? 8192 : g_fl_min_roots) &&
@@ -1537,7 +1540,8 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
             lk = f.wide ? (g_fl_wps == 6 ? SampleFanoutLeanKernel<true, 6, false, 2> : SampleFanoutLeanKernel<true, 5, false, 2>)
                         : (g_fl_wps == 6 ? SampleFanoutLeanKernel<false, 6, false, 2> : SampleFanoutLeanKernel<false, 5, false, 2>);
           } else if (v.uniform_w != 0) {
-            lk = f.wide ? SampleFanoutLeanKernel<true, 8, true> : SampleFanoutLeanKernel<false, 8, true>;
+            lk = g_fl_wps == 8 ? (f.wide ? SampleFanoutLeanKernel<true, 8, true> : SampleFanoutLeanKernel<false, 8, true>)
+                               : (f.wide ? SampleFanoutLeanKernel<true, 5, true> : SampleFanoutLeanKernel<false, 5, true>);
           } else if (use_wb) {
             lk = f.wide ? (g_fl_wps == 8 ? SampleFanoutLeanKernel<true, 8, false, 1>
                                          : g_fl_wps == 5 ? SampleFanoutLeanKernel<true, 5, false, 1>
