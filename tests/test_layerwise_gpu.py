@@ -480,20 +480,20 @@ def test_cpp_host_example(EA, O, torch_cuda, fixture_csr):
     assert np.array_equal(bits("w2"), ow[1].reshape(-1).view(np.uint32))
 
 
-def test_python_example_runs(torch_cuda):
+def test_python_example_runs(torch_cuda, capsys, monkeypatch):
     """examples/python/graphsage_minibatch.py: the tf_euler-surface input pipeline (SageDataFlow ->
     get_dense_feature -> mean aggregation per block) on the reference's fixture directory and on a
-    synthetic graph."""
-    import subprocess
+    synthetic graph (run in this process: a fresh interpreter per run costs a torch import)."""
+    import runpy
     import sys
     from conftest import ROOT
     exe = os.path.join(ROOT, "examples", "python", "graphsage_minibatch.py")
     for extra in (["--data", os.path.join(GOLDEN, "fixture_dat"), "--dim", "2", "--batch", "4"],
                   ["--nodes", "100000", "--dim", "16", "--batch", "256"]):
-        out = subprocess.run([sys.executable, exe, "--steps", "2"] + extra, check=True,
-                             capture_output=True, text=True, timeout=300).stdout
+        monkeypatch.setattr(sys, "argv", [exe, "--steps", "2"] + extra)
+        runpy.run_path(exe, run_name="__main__")
+        out = capsys.readouterr().out
         assert "ms per training-step input" in out, out
-
 
 def test_layerwise_weight_func_vs_oracle(EA, O, torch_cuda, lw_pair):
     """sampleLNB with a weight function on a 20 000-node graph: the library (host
