@@ -152,6 +152,7 @@ SIGNATURES = {
                                                        C.c_int32, C.c_int32,
                                                        C.POINTER(C.c_double)]),
     "euler_gpu_set_tuning": (C.c_int, [C.c_int32, C.c_int32]),
+    "euler_gpu_set_index_budget": (C.c_int, [C.c_int64, C.c_double]),
     "euler_gpu_set_debug_buffer": (C.c_int, [vp]),
     "euler_gpu_graph_num_float_features": (C.c_int32, [vp]),
     "euler_gpu_sample_neighbor_distinct": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp,

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/euler_gpu.h"
+#include "../../include/euler_gpu_measure.h"
 #include "philox.h"
 
 namespace euler_gpu {

@@ -463,8 +463,10 @@ int euler_gpu_sage_blocks(const euler_gpu_graph* g, void* stream, uint64_t seed,
     return Fail(EULER_GPU_EINVAL, "sage_blocks: bad arguments");
   for (int32_t h = 0; h < layers; ++h)
     if (fanouts_host[h] <= 0) return Fail(EULER_GPU_EINVAL, "sage_blocks: fanouts must be > 0");
-  if (FlowCap(n, fanouts_host, layers) >= ((int64_t)1 << 31))
-    return Fail(EULER_GPU_EINVAL, "sage_blocks: worst-case layer size >= 2^31");
+  // (slot_of packs "hashed" into bit 31 and the side slot of the all-ones id is slot tcap:
+  // tcap <= 2^30 keeps the two apart, i.e. cap_m <= 2^29)
+  if (FlowCap(n, fanouts_host, layers) > ((int64_t)1 << 29))
+    return Fail(EULER_GPU_EINVAL, "sage_blocks: worst-case layer size > 2^29");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(FlowInitKernel, dim3(1), dim3(1), 0, st, counts_dev, (uint32_t)n);
   if (n == 0) {
@@ -475,6 +477,11 @@ int euler_gpu_sage_blocks(const euler_gpu_graph* g, void* stream, uint64_t seed,
   unsigned long long* dense_min = nullptr;
   uint32_t* dense_rank = nullptr;
   uint32_t epoch0 = 0;
+  // The stream's row-indexed table is shared by every block-construction call on that stream:
+  // a call's hops (epochs e .. e + layers - 1) must be enqueued as one uninterrupted run, or a
+  // second host thread on the same stream would slip its Insert (newer epoch) between this
+  // call's Insert and Flag / Emit.  Same rule as the fanout's scratch (RunFanout).
+  std::lock_guard<std::recursive_mutex> launch_lk(g->launch_mu);
   {
     const int rcd = FlowDenseTable(g, st, layers, &dense_min, &dense_rank, &epoch0);
     if (rcd != EULER_GPU_OK) return rcd;
@@ -576,14 +583,19 @@ int euler_gpu_full_blocks(const euler_gpu_graph* g, void* stream, const uint64_t
   {
     int64_t cap_n, cap_e;
     FullCaps(n, edge_caps_host, layers - 1, &cap_n, &cap_e);
-    if (cap_n + cap_e >= ((int64_t)1 << 31))
-      return Fail(EULER_GPU_EINVAL, "full_blocks: capacities >= 2^31");
+    if (cap_n + cap_e > ((int64_t)1 << 29))       // see sage_blocks: bit 31 of slot_of is a flag
+      return Fail(EULER_GPU_EINVAL, "full_blocks: capacities > 2^29");
   }
   hipLaunchKernelGGL(FlowInitKernel, dim3(1), dim3(1), 0, st, counts_dev, (uint32_t)n);
   const uint64_t* n_id = roots_dev;
   unsigned long long* dense_min = nullptr;
   uint32_t* dense_rank = nullptr;
   uint32_t epoch0 = 0;
+  // The stream's row-indexed table is shared by every block-construction call on that stream:
+  // a call's hops (epochs e .. e + layers - 1) must be enqueued as one uninterrupted run, or a
+  // second host thread on the same stream would slip its Insert (newer epoch) between this
+  // call's Insert and Flag / Emit.  Same rule as the fanout's scratch (RunFanout).
+  std::lock_guard<std::recursive_mutex> launch_lk(g->launch_mu);
   {
     const int rcd = FlowDenseTable(g, st, layers, &dense_min, &dense_rank, &epoch0);
     if (rcd != EULER_GPU_OK) return rcd;

@@ -5,6 +5,8 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -862,6 +864,45 @@ __global__ __launch_bounds__(256) void WbFillKernel(GraphView g, const uint32_t*
   if (mine != 0) atomicAdd(overflows, mine);
 }
 
+// How much HBM the weight-bucket index may take: at most `g_wb_budget_frac` of what
+// is free when it is built (default one half - the rest stays for the caller's features, model
+// and activations, which are usually allocated AFTER the first sampling call) and at most
+// `g_wb_budget_bytes` (default: no absolute cap).  Process-wide, set through
+// euler_gpu_set_index_budget or the environment (EULER_GPU_WB_INDEX=0 turns the index off,
+// EULER_GPU_WB_INDEX_MAX_GB / EULER_GPU_WB_INDEX_MAX_FRACTION bound it).
+std::atomic<int64_t> g_wb_budget_bytes{-2};      // -2 = read the environment first, -1 = no cap
+std::atomic<int64_t> g_wb_budget_ppm{-2};        // fraction of the free HBM, parts per million
+
+void WbBudgetFromEnv() {
+  if (g_wb_budget_bytes.load() != -2) return;
+  int64_t bytes = -1, ppm = 500000;
+  if (const char* e = getenv("EULER_GPU_WB_INDEX")) {
+    if (e[0] == '0') bytes = 0;
+  }
+  if (const char* e = getenv("EULER_GPU_WB_INDEX_MAX_GB")) {
+    const double gb = atof(e);
+    if (gb >= 0 && bytes != 0) bytes = (int64_t)(gb * 1073741824.0);
+  }
+  if (const char* e = getenv("EULER_GPU_WB_INDEX_MAX_FRACTION")) {
+    const double f = atof(e);
+    if (f >= 0 && f <= 1) ppm = (int64_t)(f * 1e6);
+  }
+  g_wb_budget_ppm.store(ppm);
+  g_wb_budget_bytes.store(bytes);
+}
+
+// true when an index of `need` bytes may be built now
+bool WbFits(size_t need) {
+  WbBudgetFromEnv();
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return false; }
+  const int64_t cap = g_wb_budget_bytes.load();
+  if (cap >= 0 && need > (size_t)cap) return false;
+  const double frac = (double)g_wb_budget_ppm.load() * 1e-6;
+  if ((double)need > frac * (double)free_b) return false;
+  return need + ((size_t)1 << 30) <= free_b;
+}
+
 int BuildWbIndex(GraphBuilder* b) {
   GraphView& v = b->g->view;
   // uniform weights, several edge-type groups: the row records alone (a draw there is an index
@@ -870,9 +911,7 @@ int BuildWbIndex(GraphBuilder* b) {
   if (v.monotone != 0 && v.uniform_w != 0 && (v.T > 1 || v.map_mode != 0) && v.n_rows > 0 && v.n_edges > 0 &&
       v.n_edges < ((int64_t)1 << 31)) {
     const int32_t stride = v.T == 1 ? 16 : 8 + 12 * v.T;
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (size_t)v.n_rows * stride + ((size_t)1 << 30) > free_b)
-      return EULER_GPU_OK;
+    if (!WbFits((size_t)v.n_rows * stride)) return EULER_GPU_OK;
     uint8_t* trec = b->Alloc<uint8_t>((size_t)v.n_rows * stride + 16);
     if (b->rc != EULER_GPU_OK) return b->rc;
     hipLaunchKernelGGL(WbRecKernel, dim3((v.n_rows + 255) / 256), dim3(256), 0, 0, v, (const uint32_t*)nullptr,
@@ -921,12 +960,7 @@ int BuildWbIndex(GraphBuilder* b) {
   const int64_t n_wb = (int64_t)n_wb32;
   const int32_t stride = v.T == 1 ? 16 : 8 + 12 * v.T;
   // (checked before allocating: an index that does not fit is an optimisation declined)
-  {
-    size_t free_b = 0, total_b = 0;
-    const size_t need = (size_t)n_wb * sizeof(EdgeBlock) + (size_t)v.n_rows * stride;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || need + ((size_t)1 << 30) > free_b)
-      return EULER_GPU_OK;
-  }
+  if (!WbFits((size_t)n_wb * sizeof(EdgeBlock) + (size_t)v.n_rows * stride)) return EULER_GPU_OK;
   uint8_t* wbg = b->Alloc<uint8_t>((size_t)v.n_rows * stride + 16);
   static_assert(offsetof(WbRec, lo) == 4 && offsetof(WbRec, deg) == 8 && offsetof(WbRec, total) == 12,
                 "WbRec is the general record at T = 1");
@@ -961,11 +995,26 @@ int EnsureWbIndex(const euler_gpu_graph* cg) {
   EG_HIP(hipSetDevice(g->device));
   GraphBuilder b;
   b.g.reset(g);                 // borrow the graph: allocations land in its list
+  const size_t n_alloc = g->allocations.size();
+  const int64_t bytes0 = g->bytes;
   const int rc = BuildWbIndex(&b);
   b.g.release();
+  if (rc != EULER_GPU_OK) {
+    // The index is an optimisation: a failure while building it (no memory for a temporary, a
+    // failed launch) DECLINES it - the view's fields are only set on success, what was
+    // allocated for it is returned, the caller's sampling call goes on over the pivot levels.
+    (void)hipGetLastError();
+    (void)hipDeviceSynchronize();
+    (void)hipGetLastError();
+    while (g->allocations.size() > n_alloc) { (void)hipFree(g->allocations.back()); g->allocations.pop_back(); }
+    g->bytes = bytes0;
+    GraphView& v = g->view;
+    v.wb = nullptr; v.wbg = nullptr; v.wrec = nullptr; v.n_wb = 0; v.wb_lean_ok = 0;
+    v.trec = nullptr; v.trec_stride = 0;
+  }
   (void)hipSetDevice(prev);
   g->wb_tried.store(1, std::memory_order_release);
-  return rc;
+  return EULER_GPU_OK;
 }
 
 int EnsureBlockedIndex(const euler_gpu_graph* cg) {
@@ -1017,6 +1066,14 @@ int euler_gpu_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
+}
+
+int euler_gpu_set_index_budget(int64_t max_bytes, double max_free_fraction) {
+  if (max_free_fraction > 1.0) return Fail(EULER_GPU_EINVAL, "set_index_budget: fraction > 1");
+  WbBudgetFromEnv();
+  if (max_bytes >= 0) g_wb_budget_bytes.store(max_bytes);
+  if (max_free_fraction >= 0.0) g_wb_budget_ppm.store((int64_t)(max_free_fraction * 1e6));
+  return EULER_GPU_OK;
 }
 
 int euler_gpu_graph_create(const euler_gpu_host_csr* csr, int device,

@@ -22,11 +22,17 @@ def L():
 def test_library_exports_every_declared_symbol(L):
     from euler_amd import _lib
     hdr = "".join(open(os.path.join(ROOT, "include", f)).read()
-                  for f in ("euler_gpu.h", "euler_op_framework.h", "euler_query.h"))
+                  for f in ("euler_gpu.h", "euler_gpu_measure.h", "euler_op_framework.h",
+                            "euler_query.h"))
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b((?:euler_(?:gpu|shm|op|query)_\w+)|InitQueryProxy)\s*\(", hdr))
     declared -= {"euler_gpu_graph", "euler_gpu_host_csr", "euler_gpu_synth_params"}
     assert len(declared) >= 55 and "euler_shm_alltoall_i64" in declared
+    # the measurement surface stays out of the product header
+    product = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "euler_gpu.h")).read(), flags=re.S)
+    for name in ("euler_gpu_set_tuning", "euler_gpu_set_debug_buffer", "euler_gpu_time_sample_fanout",
+                 "euler_gpu_sample_neighbor_algo_bytes"):
+        assert name not in product, name + " belongs to include/euler_gpu_measure.h"
     for name in sorted(declared):
         assert hasattr(L, name), "libeuler_gpu.so does not export " + name
         assert name in _lib.SIGNATURES, "python binding lacks " + name
