@@ -107,6 +107,13 @@ def parse():
                          "let the ranks share them (rank r on GPU r %% visible) with a "
                          "gloo host-staged transport (RCCL refuses two ranks per device); "
                          "the line then says so and is not a scaling number")
+    ap.add_argument("--replicas", action="store_true",
+                    help="--gpus N: every rank holds the WHOLE graph (68.6 GB of 288) and runs the "
+                         "unsharded step on its own roots - no exchange (SURVEY H7); the default "
+                         "--gpus N run is hash-sharded and reports this mode beside it "
+                         "(config.replicas)")
+    ap.add_argument("--no-replicas-leg", action="store_true",
+                    help="--gpus N: skip the replicated-graph leg of the sharded run")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU sampler (unique / split / all-to-all / "
                          "merge / gather) even on one rank: measures its overhead")
@@ -171,9 +178,10 @@ def cpu_baseline(args):
     w[starts] = csr.prefix_w[starts]
     n_edges = int(len(csr.nbr))
     R = O.RefGraph.build_raw(csr.row_id, csr.row_ptr, csr.nbr, w, 1, threads=build_threads,
-                             build_sampler=False)
+                             build_sampler=True)        # (the global node sampler too: the K2 cell)
     del csr, w
     build_s = time.time() - t0
+    side_cells = _cpu_node_and_walk_cells(R, n, cores)
     full = args.cpu_protocol == "full"
     rng = np.random.default_rng(1)
     shipped_threads = min(8, cores)
@@ -261,12 +269,148 @@ def cpu_baseline(args):
                         "roots / batch on CPU and GPU; 5 warm-up + 30 timed rounds, median (p10, p90)"
                         + ("" if full else "; B = 131072 cells: 1 + 5 rounds (as shipped) / 2 + 10 "
                            "(OpenMP) - pass --cpu-protocol full for 5 + 30"),
+            "sample_node": side_cells.get("sample_node"), "deepwalk": side_cells.get("deepwalk"),
             "B1024": {"cpu": cells[1024], "gpu_same_graph": same.get(1024, same)},
             "B131072": {"cpu": cells[131072], "gpu_same_graph": same.get(131072, same)},
             "sample": "value = best CPU configuration at B = 131072 (%s); as shipped (8 query "
                       "threads): %.3g edges/s; B = 1024: as shipped %.3g, best %.3g edges/s"
                       % (head["what"], cells[131072]["as_shipped"]["edges_per_s"],
                          cells[1024]["as_shipped"]["edges_per_s"], cells[1024]["best"]["edges_per_s"])}
+
+
+def _threaded_rate(fn, threads, units_per_call, rounds=3):
+    """`threads` host threads each run fn(thread, round) once per round (ctypes releases the
+    GIL inside the reference's code): median units/s over the rounds after one warm-up."""
+    from concurrent.futures import ThreadPoolExecutor
+    secs = []
+    with ThreadPoolExecutor(threads) as ex:
+        for rnd in range(rounds + 1):
+            t0 = time.perf_counter()
+            list(ex.map(lambda t_: fn(t_, rnd), range(threads)))
+            if rnd:
+                secs.append(time.perf_counter() - t0)
+    med = float(np.median(secs))
+    return {"per_s": threads * units_per_call / med, "threads": threads, "rounds": len(secs),
+            "median_ms_per_round": round(med * 1e3, 3), "units_per_round": int(threads * units_per_call)}
+
+
+def _cpu_node_and_walk_cells(R, n, cores):
+    """CPU cells of SampleNode (K2) and DeepWalk on the reference graph `R` (oracle/_ref: the
+    reference's own Graph::SampleNode / Node::SampleNeighbor behind the RNG seam), as the
+    client runs them: 8 concurrent single-threaded queries (client/query_proxy.cc:205-210) and
+    32.  SampleNode: 1M draws per query, type -1 (4 draws per sample, graph.cc:229-236).
+    DeepWalk: 16 384 walkers x 40 steps per query (random_walk_op.cc:207-247)."""
+    out = {}
+    cnt = 1 << 20
+    try:
+        cells = [_threaded_rate(lambda t_, r_: R.sample_node(GRAPH_SEED, 1000 + 64 * r_ + t_, [-1], cnt),
+                                th, cnt) for th in sorted({min(8, cores), min(32, cores)})]
+        best = max(cells, key=lambda c: c["per_s"])
+        out["sample_node"] = {"value": best["per_s"], "unit": "sampled nodes/s", "cores": best["threads"],
+                              "kind": "reference", "as_shipped_8_queries": cells[0]["per_s"],
+                              "cells": cells,
+                              "sample": "Graph::SampleNode(type -1), %d draws per query, alias tables over "
+                                        "%d nodes" % (cnt, n)}
+    except Exception as e:
+        out["sample_node"] = {"error": repr(e)}
+    try:
+        out["deepwalk"] = _walk_cell(R, n, cores)
+    except Exception as e:
+        out["deepwalk"] = {"error": repr(e)}
+    return out
+
+
+def cpu_walk_cell(args):
+    """cpu_baseline of `--workload deepwalk`: the reference's walk (oracle/_ref) on a bounded
+    graph of the metric's family (5M nodes / 50M edges: ~10 s to build with 32 threads)."""
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    if not O.have_ref():
+        return {"value": None, "unit": "walker steps/s", "cores": cores, "kind": "reference",
+                "error": "oracle/_ref/libeuler_ref.so missing"}
+    n = min(5_000_000, args.nodes)
+    R, _ne, build_s = _ref_graph(n, 1, min(32, cores), False)
+    cell = _walk_cell(R, n, cores)
+    del R
+    cell["host_cores"] = cores
+    cell["sample"] += "; %d-edge graph of the metric's family built in %.1f s" % (_ne, build_s)
+    return cell
+
+
+def _walk_cell(R, n, cores):
+    """DeepWalk on the reference graph R: 8 and 32 concurrent queries of 16 384 walkers x 40
+    steps (tf_euler/kernels/random_walk_op.cc:207-247 over the reference's Node::SampleNeighbor)."""
+    W, LEN = 16384, 40
+    rng = np.random.default_rng(5)
+    starts = rng.integers(1, n + 1, (32, W)).astype(np.int64)
+    et = [[0]] * LEN
+    cells = [_threaded_rate(lambda t_, r_: R.random_walk(GRAPH_SEED, 40 * (64 * r_ + t_), starts[t_], et, LEN,
+                                                         1.0, 1.0, n + 1), th, W * LEN)
+             for th in sorted({min(8, cores), min(32, cores)})]
+    best = max(cells, key=lambda c: c["per_s"])
+    return {"value": best["per_s"], "unit": "walker steps/s", "cores": best["threads"], "kind": "reference",
+            "as_shipped_8_queries": cells[0]["per_s"], "cells": cells,
+            "sample": "random_walk p = q = 1 (reference sources behind the RNG seam), %d walkers x %d steps "
+                      "per query, %d-node graph" % (W, LEN, n)}
+
+
+def _ref_graph(n, n_types, threads, build_sampler):
+    """The reference's Graph (oracle/_ref) over the synthetic graph of n nodes / 10 n edges."""
+    from oracle import oracle as O
+    t0 = time.time()
+    po = O.synth_params(GRAPH_SEED, n, 10 * n, n_types=n_types, weighted=True)
+    csr = O.synth_csr(po, threads=threads)
+    w = csr.prefix_w.copy()
+    w[1:] -= csr.prefix_w[:-1]
+    starts = csr.row_ptr[:-1]
+    w[starts] = csr.prefix_w[starts]
+    n_edges = int(len(csr.nbr))
+    if n_types == 1:
+        seg_ptr = csr.row_ptr
+    else:           # build_raw takes one segment per (row, edge type)
+        te = csr.type_end.reshape(n, n_types).astype(np.int64)
+        seg_ptr = np.concatenate([[0], (csr.row_ptr[:-1, None] + te).reshape(-1)]).astype(np.int64)
+    R = O.RefGraph.build_raw(csr.row_id, seg_ptr, csr.nbr, w, n_types, threads=threads,
+                             build_sampler=build_sampler)
+    return R, n_edges, time.time() - t0
+
+
+def cpu_hetero_cell(args, type_sets, cnt, D):
+    """cpu_baseline of the heterogeneous step: typed SampleNeighbor by the reference
+    (oracle/_ref, Node::SampleNeighbor with k = 1 / 3 of 8 / all) + gather + scatter_mean by
+    the oracle's restatement of tf_euler/kernels/{gather,scatter}_op.cc, one query = 8 192
+    roots through the three type sets, 8 and 32 concurrent queries; a bounded graph (2M
+    nodes / 20M edges, 8 edge types)."""
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    if not O.have_ref():
+        return {"value": None, "unit": "sampled edges/s", "cores": cores, "kind": "reference",
+                "error": "oracle/_ref/libeuler_ref.so missing"}
+    n = min(2_000_000, args.nodes)
+    R, n_edges, build_s = _ref_graph(n, 8, min(32, cores), False)
+    B = 8192
+    rng = np.random.default_rng(9)
+    roots = rng.integers(1, n + 1, (32, B)).astype(np.uint64)
+    feat = rng.standard_normal((n + 2, D), dtype=np.float32)
+    dst = np.repeat(np.arange(B, dtype=np.int32), cnt)
+
+    def query(t_, r_):
+        for c, et in enumerate(type_sets):
+            idx_, ids, _w, _t = R.sample_neighbor_core(GRAPH_SEED, 3 * (64 * r_ + t_) + c, roots[t_], et, cnt)
+            # (core layout: a node without such edges has an empty row)
+            lens = (idx_[:, 1] - idx_[:, 0]).astype(np.int64)
+            m_ = int(lens.sum())
+            d_ = dst if m_ == B * cnt else np.repeat(np.arange(B, dtype=np.int32), lens)
+            O.scatter_mean(O.gather(feat, ids[:m_].astype(np.int32)), d_, B)
+    cells = [_threaded_rate(query, th, B * cnt * len(type_sets)) for th in sorted({min(8, cores), min(32, cores)})]
+    best = max(cells, key=lambda c: c["per_s"])
+    del R
+    return {"value": best["per_s"], "unit": "sampled edges/s", "cores": best["threads"], "kind": "reference",
+            "host_cores": cores, "as_shipped_8_queries": cells[0]["per_s"], "cells": cells,
+            "sample": "typed SampleNeighbor (reference sources, k = 1 / 3 of 8 / all, count %d) + gather + "
+                      "scatter_mean (oracle's restatement of gather_op.cc / scatter_op.cc, D = %d), %d roots per "
+                      "query, %d-node / %d-edge graph with 8 edge types (built in %.1f s)"
+                      % (cnt, D, B, n, n_edges, build_s)}
 
 
 def latency_small_batch(G, L, _lib, n_nodes, default_node, batch=1024, iters=300, streams=8):
@@ -579,6 +723,39 @@ def run_hetero(args, quiet=False):
     elapsed = float(np.median(reps))
     if S is not None:
         edges = B * CNT * len(type_sets) * world
+        # the sharded step's own launches: the owners' pass of each typed hop
+        # (euler_gpu_sample_neighbor_packed over the distinct ids asked for), timed alone
+        from euler_amd import _lib as _lb
+        st_s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        x_own = roots[n_steps - 1]
+        if world > 1:
+            x_own = torch.clamp((x_own // world) * world + (rank if rank else world), max=N - world)
+        x_own = torch.unique(x_own).contiguous()
+        k1s = []
+        for c, et in enumerate(type_sets):
+            ms_ = _events(lambda: G.sample_neighbor_packed(x_own, et, CNT, N + 1, call_id=c), 10)
+            b_ = C.c_double(0)
+            eta = (C.c_int32 * len(et))(*et)
+            _lb.check(_lb.lib().euler_gpu_sample_neighbor_algo_bytes(
+                G._h, st_s, C.c_void_p(x_own.data_ptr()), x_own.numel(), eta, len(et), CNT, C.byref(b_)))
+            k1s.append({"listed_types": len(et), "ms": round(ms_, 4), "algorithmic_bytes": b_.value,
+                        "frac": round(b_.value / ms_ / 1e6 / HBM_PEAK_GBS, 4)})
+        tb = sum(x_["algorithmic_bytes"] for x_ in k1s)
+        tm = sum(x_["ms"] for x_ in k1s)
+        roof_s = {"kernel": "SampleNeighborKernel / SampleNeighborTypedPivotKernel (owners' pass of a typed "
+                            "sharded hop, packed wire rows)", "bound": "hbm",
+                  "achieved": round(tb / tm / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "frac": round(tb / tm / 1e6 / HBM_PEAK_GBS, 4), "traffic": None,
+                  "algorithmic_bytes_per_launch": tb / len(k1s), "avg_launch_ms": round(tm / len(k1s), 4),
+                  "launches": k1s,
+                  "note": "rank 0's three typed launches of one step, each timed alone with HIP events over "
+                          "the distinct roots; the aggregation is the unsharded path's (replicas only)"}
+        cpu_s = None
+        if rank == 0 and not args.no_cpu_baseline and not quiet:
+            try:
+                cpu_s = cpu_hetero_cell(args, type_sets, CNT, D)
+            except Exception as e:
+                cpu_s = {"error": repr(e)}
         line = {
             "metric": "sampled + aggregated edges/sec, typed SampleNeighbor (k = 1, 3 of 8, all) + 128-d "
                       "gather + scatter_mean, heterogeneous graph (BASELINE configs[4])",
@@ -593,8 +770,9 @@ def run_hetero(args, quiet=False):
                                    % (N, T, world, B, N + 2, D),
                        "ranks": world, "graph_build_s": round(build_s, 2), "repeats": len(reps),
                        "repeat_ms_per_step": [round(x_ / args.steps * 1e3, 4) for x_ in reps],
-                       "transport": dist.get_backend()},
-            "roofline": None, "cpu_baseline": None,
+                       "transport": "%s, %d ranks in the communicator" % (dist.get_backend(),
+                                                                           dist.get_world_size())},
+            "roofline": roof_s, "cpu_baseline": cpu_s,
         }
         if rank == 0 and not quiet:
             print(json.dumps(line), flush=True)
@@ -744,6 +922,11 @@ def run_hetero(args, quiet=False):
         "roofline": roof,
         "cpu_baseline": None,
     }
+    if not quiet and not args.no_cpu_baseline:
+        try:
+            line["cpu_baseline"] = cpu_hetero_cell(args, type_sets, CNT, D)
+        except Exception as e:
+            line["cpu_baseline"] = {"error": repr(e)}
     if not quiet:
         print(json.dumps(line), flush=True)
     del G, feat
@@ -800,6 +983,47 @@ def run_deepwalk(args, G=None, p_g=None, quiet=False):
     reps = _max_over_ranks(reps, wire)           # slowest rank, per repetition
     elapsed = float(np.median(reps))
     if S is not None:
+        # the call's own figures: host waits / level sizes (C orchestration), SURVEY 8(d)'s bytes
+        # of the walk over the nodes whose rows THIS rank holds (x ranks: every rank's walkers
+        # visit every shard alike), and - one rank - 64 walkers against the oracle
+        walk_stats, roof_s, cpu_s, checked_s = None, None, None, None
+        try:
+            from euler_amd.distributed import c_sharded_random_walk
+            last = n_steps - 1
+            if getattr(S, "c_walk_fn", None) is not None:
+                _w, walk_stats = c_sharded_random_walk(G, S.c_transport, starts[last], et, N + 1, LEN * last,
+                                                       S.partitions, S.walk_cohorts, S.dense_table,
+                                                       return_stats=True)
+            ms_c = elapsed / args.steps * 1e3
+            b_ = C.c_double(0)
+            et_a = (C.c_int32 * LEN)(*([0] * LEN))
+            _lib.check(L.euler_gpu_random_walk_algo_bytes(
+                G._h, C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(walks.data_ptr()),
+                W, et_a, 1, LEN, 1.0, 1.0, C.byref(b_)))
+            wb_ = b_.value * world
+            roof_s = {"kernel": "WalkOwnedKernel + front end + ShWalkPathKernel (the whole "
+                                "euler_gpu_sharded_random_walk call; per-step launches are microseconds)",
+                      "bound": "hbm", "achieved": round(wb_ / world / (ms_c * 1e-3) / 1e9, 1),
+                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": round(wb_ / world / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                      "algorithmic_bytes_per_launch": wb_ / world, "avg_launch_ms": round(ms_c, 4),
+                      "note": "bytes = SURVEY 8(d)'s walk formula (K1 with count 1 per walker step) over the "
+                              "walkers of one rank; time = the call, wall clock (it contains the host waits)"}
+            if world == 1 and not args.no_check:
+                sel = np.random.default_rng(0).choice(W, 64, replace=False)
+                w_sel = walks.cpu().numpy()[sel]
+                need_ids = w_sel[(w_sel >= 1) & (w_sel <= N)]
+                OGw = _oracle_rows(G, p_g, need_ids, 1)
+                ow_ = OGw.random_walk(GRAPH_SEED, LEN * last, starts[last].cpu().numpy()[sel], et, LEN,
+                                      1.0, 1.0, N + 1)
+                assert np.array_equal(ow_, w_sel), "sharded deepwalk: walks differ from the oracle"
+                checked_s = int(64 * LEN)
+            if rank == 0 and not args.no_cpu_baseline and not quiet:
+                cpu_s = cpu_walk_cell(args)
+        except AssertionError:
+            raise
+        except Exception as e:
+            roof_s = {"error": repr(e)}
         n2v = None
         if args.n2v:
             W2, L2 = min(100_000, W), 10
@@ -825,8 +1049,15 @@ def run_deepwalk(args, G=None, p_g=None, quiet=False):
                                    "one exchange per walk step" % (W, LEN, N, args.edges, world),
                        "ranks": world, "graph_build_s": round(build_s, 2), "repeats": len(reps),
                        "repeat_ms_per_step": [round(x_ / args.steps * 1e3, 4) for x_ in reps],
-                       "transport": dist.get_backend(), "node2vec": n2v},
-            "roofline": None, "cpu_baseline": None,
+                       "transport": "%s, %d ranks in the communicator" % (dist.get_backend(),
+                                                                           dist.get_world_size()),
+                       "orchestration": ("euler_gpu_sharded_random_walk (C): levels of merged walkers, "
+                                         "%d cohorts" % getattr(S, "walk_cohorts", 0))
+                                        if getattr(S, "c_walk_fn", None) is not None else
+                                        "ShardedSampler.random_walk (Python): one sample_neighbor per step",
+                       "walk_stats": walk_stats, "parity_checked_steps": checked_s,
+                       "node2vec": n2v},
+            "roofline": roof_s, "cpu_baseline": cpu_s,
         }
         if rank == 0 and not quiet:
             print(json.dumps(line), flush=True)
@@ -890,6 +1121,11 @@ def run_deepwalk(args, G=None, p_g=None, quiet=False):
                      "traffic": None, "algorithmic_bytes_per_launch": wb, "avg_launch_ms": round(ms, 4)},
         "cpu_baseline": None,
     }
+    if not quiet and not args.no_cpu_baseline:
+        try:
+            line["cpu_baseline"] = cpu_walk_cell(args)
+        except Exception as e:
+            line["cpu_baseline"] = {"error": repr(e)}
     if not quiet:
         print(json.dumps(line), flush=True)
     return line
@@ -1070,8 +1306,22 @@ def run_hashed_leg(args, weighted=True):
         "hashed ids / all types: sampled ids differ from the oracle"
     assert np.array_equal(ot[1], t2a.reshape(-1)), "hashed ids / all types: types differ from the oracle"
     el_all = float(np.median(reps_all))
+    ms_all_alone = _events(lambda: G.sample_fanout(r, et_all, FANOUT, default, call_id=5), 10)
+    et2 = (C.c_int32 * 2)(0, 1)
+
+    def algo_bytes2(x, cnt):          # the K1 formula with its type-draw term (both groups listed)
+        b = C.c_double(0)
+        _lib.check(L.euler_gpu_sample_neighbor_algo_bytes(
+            G._h, st, C.c_void_p(x.data_ptr()), x.numel(), et2, 2, cnt, C.byref(b)))
+        return b.value
+    h2a = out_all[0][1].reshape(-1)
+    algo_all = (algo_bytes2(r, FANOUT[0]) + algo_bytes2(torch.unique(h2a).contiguous(), FANOUT[1])
+                + 12.0 * h2a.numel() + 16.0 * h2a.numel() * FANOUT[1])
     res["all_types_per_hop"] = {"value": edges * steps / el_all, "unit": "sampled edges/s",
                                 "ms_per_step": round(el_all / steps * 1e3, 4), "edge_types": et_all,
+                                "one_stream_ms_per_step": round(ms_all_alone, 4),
+                                "roofline_frac": round(algo_all / (ms_all_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                "algorithmic_bytes_per_launch": algo_all,
                                 "parity_checked": int(64 * 275),
                                 "kernel": "SampleFanoutLeanKernel<.., WB = %d> (a type draw per sample)"
                                           % (4 if weighted else 5)}
@@ -1110,8 +1360,25 @@ def run_unique_leg(args, G, p_g):
     assert np.array_equal(ow[1], w2.reshape(-1)), "unique rows: weights differ from the oracle"
     ms = _events(lambda: G.sample_fanout_unique(r, et, FANOUT, N + 1, call_id=8), 10)
     edges = B * (FANOUT[0] + FANOUT[0] * FANOUT[1])
+    # SURVEY 8(d) bytes of this contract: K1 over the batch + K1 over the globally distinct
+    # hop-2 roots (their 16 output bytes per sampled edge are the rows) + 8 + 4 per hop-2 input
+    # id (duplicate detection) + 4 per row-index entry written; no expansion
+    from euler_amd import _lib
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    et1 = (C.c_int32 * 1)(0)
+
+    def algo_bytes(x, cnt):
+        b = C.c_double(0)
+        _lib.check(_lib.lib().euler_gpu_sample_neighbor_algo_bytes(
+            G._h, st, C.c_void_p(x.data_ptr()), x.numel(), et1, 1, cnt, C.byref(b)))
+        return b.value
+    hop2_roots = id1.reshape(-1).contiguous()
+    algo = (algo_bytes(r, FANOUT[0]) + algo_bytes(torch.unique(hop2_roots).contiguous(), FANOUT[1])
+            + 12.0 * hop2_roots.numel() + 4.0 * idx.numel())
     return {"value": edges / (ms * 1e-3), "unit": "sampled edges/s (as rows + index)",
-            "ms_per_step": round(ms, 4), "roofline_frac": None, "parity_checked": int(edges),
+            "ms_per_step": round(ms, 4),
+            "roofline_frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "algorithmic_bytes_per_launch": algo, "parity_checked": int(edges),
             "parity_checked_vs_oracle": int(64 * 275),
             "distinct_rows": rows, "positions": int(idx.numel()),
             "workload": "the metric step, hop 2 left as %d distinct rows + a row index per hop-1 sample "
@@ -1163,12 +1430,168 @@ def run_sage_leg(args, G, p_g):
     # the same enqueue without the host's read of the layer sizes (padded tensors + counts on the
     # device: a consumer that masks never waits)
     ms_nosync = _events(lambda: G.sage_blocks(r, [[0], [0]], FANOUT, default_node=N + 1, sync=False), 10)
+    # SURVEY 8(d) bytes of the flow, hop by hop over the sizes this minibatch really has: K1
+    # over the layer's nodes + 8 + 4 per id that goes through the first-occurrence unique
+    # ([neighbours | nodes]) + 8 per distinct id written (n_id) + 8 per res_n_id entry + 2 x 8
+    # per edge_index column
+    from euler_amd import _lib
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    et1 = (C.c_int32 * 1)(0)
+    algo = 0.0
+    # (df is ordered from the outermost hop inwards: blocks[-1] is hop 0)
+    layer = r
+    for h, blk in enumerate(reversed(list(df))):
+        b_ = C.c_double(0)
+        x = layer.contiguous()
+        _lib.check(_lib.lib().euler_gpu_sample_neighbor_algo_bytes(
+            G._h, st, C.c_void_p(x.data_ptr()), x.numel(), et1, 1, FANOUT[h], C.byref(b_)))
+        m_in = x.numel() * (FANOUT[h] + 1)
+        algo += b_.value + 12.0 * m_in + 8.0 * blk.n_id.numel() + 8.0 * x.numel() \
+            + 16.0 * blk.edge_index.shape[1]
+        layer = blk.n_id
     return {"value": 1e3 / ms, "unit": "minibatches (2 blocks each)/s", "ms_per_step": round(ms, 4),
             "ms_per_step_without_host_read": round(ms_nosync, 4),
-            "roofline_frac": None, "parity_checked": n_edges, "parity_checked_vs_oracle": o_edges,
+            "roofline_frac": round(algo / (ms_nosync * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "roofline_frac_with_host_read": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "algorithmic_bytes_per_minibatch": algo,
+            "parity_checked": n_edges, "parity_checked_vs_oracle": o_edges,
             "block_edges_per_s": n_edges / (ms * 1e-3),
             "workload": "SageDataFlow, %d roots, fanouts %s, self loops: %d block edges per minibatch; "
                         "one host read (the layer sizes) per minibatch" % (B, FANOUT, n_edges)}
+
+
+def run_node_legs(args, G, p_g):
+    """SampleNode (K2: Graph::SampleNode over alias tables, core/graph/graph.cc:221-245,
+    common/alias_method.cc:66-78) on tables of the metric graph's N nodes - 4 node types, f32
+    weights in [0.5, 4.5), the global sampler built by Graph.set_node_sampler - and the
+    DeepWalk minibatch of the reference's example (examples/deepwalk/deepwalk.py:47-63:
+    random_walk -> gen_pair -> sample_node(batch x pairs x num_negs)), both checked against the
+    oracle's restatement on the same arrays.  SURVEY 8(d) bytes of a draw: 8 (id) + 4 (prob) +
+    8 (alias id, only when the coin misses) + 8 out; the legs count 20 per draw, the lower
+    bound."""
+    from oracle import oracle as O
+    from euler_amd import _lib, euler_ops
+    L = _lib.lib()
+    N = args.nodes
+    out = {}
+    t0 = time.time()
+    ids = np.arange(1, N + 1, dtype=np.uint64)
+    types = (((ids * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(61)) & np.uint64(3)).astype(np.int32)
+    weights = (0.5 + 4.0 * np.random.default_rng(11).random(N, dtype=np.float32)).astype(np.float32)
+    G.set_node_sampler(None, types, weights, 4)
+    build_s = time.time() - t0
+    t0 = time.time()
+    osamp = None
+    if not args.no_check:
+        osamp = O.lib().eo_node_sampler_create(N, O._p(ids, O._u64p), O._p(types, O._i32p),
+                                               O._p(weights, O._f32p), 4)
+    oracle_s = time.time() - t0
+
+    def oracle_nodes(call_id, node_type, count):
+        nt = np.asarray([node_type], np.int32)
+        o = np.zeros(count, np.uint64)
+        got = O.lib().eo_sample_node(osamp, GRAPH_SEED, call_id, O._p(nt, O._i32p), 1, count, O._p(o, O._u64p))
+        assert got == count
+        return o
+    count = 32 * 1024 * 1024
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    buf = torch.empty(count, dtype=torch.int64, device="cuda")
+    legs = {}
+    for name_, nt in (("all_types", -1), ("one_type", 1)):
+        nt_a = (C.c_int32 * 1)(nt)
+
+        def call(cid=7):
+            _lib.check(L.euler_gpu_sample_node(G._h, st, GRAPH_SEED, cid, nt_a, 1, count,
+                                               C.c_void_p(buf.data_ptr())))
+        ms = _events(call, 10)
+        chk = 0
+        if osamp is not None:
+            call(7)
+            torch.cuda.synchronize()
+            head = buf[:1 << 18].cpu().numpy().view(np.uint64)
+            assert np.array_equal(head, oracle_nodes(7, nt, 1 << 18)), "sample_node differs from the oracle"
+            chk = 1 << 18
+        # 8 id + 4 prob + 8 out per draw, + 8 for the alias id of the draws that take it
+        # (counted for none of them: the lower bound of SURVEY 8(d)'s 20 .. 28 bytes)
+        algo = 20.0 * count
+        legs[name_] = {"ms": round(ms, 4), "nodes_per_s": count / (ms * 1e-3),
+                       "algorithmic_bytes": algo, "GBps": round(algo / (ms * 1e-3) / 1e9, 1),
+                       "roofline_frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                       "table_lines_per_s": count / (ms * 1e-3), "parity_checked": chk}
+    head_ = legs["all_types"]
+    out["sample_node"] = {
+        "value": head_["nodes_per_s"], "unit": "sampled nodes/s", "ms_per_step": head_["ms"],
+        "roofline_frac": head_["roofline_frac"], "parity_checked": head_["parity_checked"],
+        "count": count, "one_type": legs["one_type"], "all_types": head_,
+        "sampler_build_s": round(build_s, 2), "oracle_build_s": round(oracle_s, 2),
+        "bound": "one random 32-byte table entry per draw: a draw moves one 128-byte line for 20-28 "
+                 "algorithmic bytes, so the line rate of random reads beyond the L2 (54 G lines/s measured, "
+                 "tools/ubench_gather.hip) caps K2 at ~0.19 of the byte roofline; table_lines_per_s against "
+                 "that rate is the figure of merit (profiles/r5_sample_node_pmc.json: read requests per draw)",
+        "workload": "SampleNode count = %d over %d nodes in 4 node types (type -1: type draw + node draw, "
+                    "4 uniforms per sample; one type: 2), weights f32 in [0.5, 4.5)" % (count, N)}
+    del buf
+    # ---- the DeepWalk minibatch (examples/deepwalk/deepwalk.py:47-63)
+    sys.path.insert(0, os.path.join(ROOT, "examples", "python"))
+    import deepwalk_minibatch as dm
+    prev = None
+    try:
+        prev = euler_ops.get_default_graph()
+    except Exception:
+        prev = None
+    euler_ops.set_default_graph(G)
+    try:
+        Bd, WL, NEG = 131072, 3, 5            # run_deepwalk.py's walk_len / windows / num_negs, a big batch
+        gen = torch.Generator(device="cuda"); gen.manual_seed(31)
+        inputs = torch.randint(1, N + 1, (8, Bd), generator=gen, device="cuda", dtype=torch.int64)
+
+        def mb(i, call=None):
+            if call is not None:
+                G.set_seed(GRAPH_SEED, call)
+            return dm.to_sample(inputs[i % 8], 1, [0], N, WL, 1.0, 1.0, 1, 1, NEG)
+        src, pos, negs = mb(0, 600)
+        if osamp is not None:
+            # 64 inputs: their walks (rows exported from HBM), pairs and the call's first negatives
+            sel = np.random.default_rng(2).choice(Bd, 64, replace=False)
+            inp = inputs[0].cpu().numpy()
+            pairs = src.numel() // Bd
+            walk = G.random_walk(inputs[0], [[0]] * WL, 1.0, 1.0, N + 1, call_id=600).cpu().numpy()[sel]
+            OGw = _oracle_rows(G, p_g, walk[(walk >= 1) & (walk <= N)], 1)
+            opath = OGw.random_walk(GRAPH_SEED, 600, inp[sel], [[0]] * WL, WL, 1.0, 1.0, N + 1)
+            opair = O.gen_pair(opath, 1, 1)
+            assert np.array_equal(src.reshape(Bd, pairs).cpu().numpy()[sel], opair[..., 0])
+            assert np.array_equal(pos.reshape(Bd, pairs).cpu().numpy()[sel], opair[..., 1])
+            want = oracle_nodes(600 + WL, 1, 1 << 16)
+            assert np.array_equal(negs.reshape(-1)[:1 << 16].cpu().numpy().view(np.uint64), want), \
+                "deepwalk minibatch: negatives differ from the oracle"
+        G.set_seed(GRAPH_SEED)
+        ms = _events(lambda: mb(1), 10)
+        pairs_n = int(src.shape[0])
+        # bytes: the walk's K1 terms (count 1) + 16 per pair written + 20 per negative
+        wb = C.c_double(0)
+        et_a = (C.c_int32 * WL)(*([0] * WL))
+        walk_all = G.random_walk(inputs[1], [[0]] * WL, 1.0, 1.0, N + 1, call_id=5)
+        _lib.check(L.euler_gpu_random_walk_algo_bytes(G._h, st, C.c_void_p(walk_all.data_ptr()), Bd, et_a, 1,
+                                                      WL, 1.0, 1.0, C.byref(wb)))
+        algo = wb.value + 8.0 * Bd * (WL + 1) + 16.0 * pairs_n + 20.0 * negs.numel()
+        out["deepwalk_minibatch"] = {
+            "value": 1e3 / ms, "unit": "minibatches/s", "ms_per_step": round(ms, 4),
+            "pairs_per_s": pairs_n / (ms * 1e-3), "negatives_per_s": negs.numel() / (ms * 1e-3),
+            "roofline_frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "algorithmic_bytes": algo,
+            "parity_checked": (64 * pairs_n // Bd * 2 + (1 << 16)) if osamp is not None else 0,
+            "workload": "examples/python/deepwalk_minibatch.py to_sample (deepwalk.py:47-63): batch %d, "
+                        "walk_len %d, windows 1 / 1, %d negatives per pair: %d pairs, %d negatives per "
+                        "minibatch, through the euler_ops surface on one stream" % (Bd, WL, NEG, pairs_n,
+                                                                                    negs.numel())}
+    except Exception as e:
+        out["deepwalk_minibatch"] = {"error": repr(e)}
+    finally:
+        if prev is not None:
+            euler_ops.set_default_graph(prev)
+        if osamp is not None:
+            O.lib().eo_node_sampler_destroy(osamp)
+    return out
 
 
 def secondary_legs(args, G, p_g):
@@ -1198,6 +1621,10 @@ def secondary_legs(args, G, p_g):
             sec[name_] = fn_(args, G, p_g)
         except Exception as e:
             sec[name_] = {"error": repr(e)}
+    try:
+        sec.update(run_node_legs(args, G, p_g))
+    except Exception as e:
+        sec["sample_node"] = {"error": repr(e)}
     try:
         sec["products"] = run_products_leg(args)
     except Exception as e:
@@ -1265,9 +1692,10 @@ def main():
     local_rank %= visible
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    sharded = world > 1 or args.force_sharded
+    replicas = bool(args.replicas) and world > 1
+    sharded = (world > 1 and not replicas) or args.force_sharded
     backend = "gloo" if shared_gpus else "nccl"
-    if sharded:
+    if sharded or world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
         if backend == "nccl":
@@ -1283,7 +1711,7 @@ def main():
         _lib.check(L.euler_gpu_set_tuning(int(k_), int(v_)))
     if args.workload in ("hetero", "deepwalk"):
         (run_hetero if args.workload == "hetero" else run_deepwalk)(args)
-        if sharded:
+        if sharded or world > 1:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -1297,8 +1725,9 @@ def main():
 
     t0 = time.time()
     p = euler_amd.synth_params(GRAPH_SEED, args.nodes, args.edges, weighted=weighted)
-    G = euler_amd.Graph.synthetic(p, device=local_rank, partitions=world,
-                                  shard_index=rank, shards=world)
+    g_parts = 1 if replicas else world
+    G = euler_amd.Graph.synthetic(p, device=local_rank, partitions=g_parts,
+                                  shard_index=0 if replicas else rank, shards=g_parts)
     G.set_seed(GRAPH_SEED)
     torch.cuda.synchronize()
     build_s = time.time() - t0
@@ -1313,7 +1742,7 @@ def main():
     default_node = args.nodes + 1
 
     def sync():
-        if sharded:
+        if sharded or world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -1375,9 +1804,11 @@ def main():
             print("trace (step, ms since previous job started, device allocs so far):",
                   [(a[0], round((a[1] - b[1]) * 1e3, 2), a[2]) for a, b in zip(tail[1:], tail[:-1])],
                   file=sys.stderr)
-    else:
+    def unsharded_run(Gx, extras=True):
+        """The K steps on the unsharded graph Gx (this rank's whole graph): --streams callers'
+        streams alternating; returns (rep_secs, one_stream secs, last outputs, sustained)."""
         def step(i):
-            return G.sample_fanout(roots[i], et, FANOUT, default_node, call_id=2 * i)
+            return Gx.sample_fanout(roots[i], et, FANOUT, default_node, call_id=2 * i)
 
         n_streams = max(1, args.streams)
         side = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else None
@@ -1394,51 +1825,79 @@ def main():
             return res
 
         torch.cuda.synchronize()              # roots were produced on the default stream
-        out = loop(0, max(args.warmup, 2 * n_streams), side)
+        out_ = loop(0, max(args.warmup, 2 * n_streams), side)
         sync()
         gc.collect(); gc.freeze(); gc.disable()      # a gen-2 collection costs ~40 ms
-        one_stream = []
-        if side is not None:                  # the same K steps on ONE stream, for the record
+        one_stream_ = []
+        if side is not None and extras:       # the same K steps on ONE stream, for the record
             loop(0, args.warmup, None)
             for _rep in range(3):
                 sync()
                 t0 = time.perf_counter()
                 loop(args.warmup, n_steps, None)
                 sync()
-                one_stream.append(time.perf_counter() - t0)
+                one_stream_.append(time.perf_counter() - t0)
             loop(0, 2 * n_streams, side)
-        rep_secs = []
+        rep_secs_ = []
         for _rep in range(max(1, args.repeats)):
             sync()
             t0 = time.perf_counter()
-            out = loop(args.warmup, n_steps, side)
+            out_ = loop(args.warmup, n_steps, side)
             sync()
-            rep_secs.append(time.perf_counter() - t0)
+            rep_secs_.append(time.perf_counter() - t0)
         # the same loop as ONE long region (>= 1 s of device time): what the K-step bursts above
         # are extrapolated to (roots cycle through the n_steps batches; call ids keep counting)
-        sustained = None
-        if world == 1 and args.sustain_steps > 0 and side is not None:
+        sustained_ = None
+        if world == 1 and extras and args.sustain_steps > 0 and side is not None:
             ns_ = args.sustain_steps
             sync()
             t0 = time.perf_counter()
             for i in range(ns_):
                 with torch.cuda.stream(side[i % n_streams]):
-                    G.sample_fanout(roots[i % n_steps], et, FANOUT, default_node, call_id=2 * (n_steps + i))
+                    Gx.sample_fanout(roots[i % n_steps], et, FANOUT, default_node, call_id=2 * (n_steps + i))
             sync()
             dt_ = time.perf_counter() - t0
-            sustained = {"steps": ns_, "seconds": round(dt_, 4), "ms_per_step": round(dt_ / ns_ * 1e3, 4),
-                         "edges_per_s": B * (FANOUT[0] + FANOUT[0] * FANOUT[1]) * ns_ / dt_,
-                         "streams": n_streams}
+            sustained_ = {"steps": ns_, "seconds": round(dt_, 4), "ms_per_step": round(dt_ / ns_ * 1e3, 4),
+                          "edges_per_s": B * (FANOUT[0] + FANOUT[0] * FANOUT[1]) * ns_ / dt_,
+                          "streams": n_streams}
         gc.enable()
-    exchanged = None
-    if world > 1:
-        wire_dev = dev if backend == "nccl" else "cpu"
-        t = torch.tensor(rep_secs, device=wire_dev, dtype=torch.float64)
+        return rep_secs_, one_stream_, out_, sustained_
+
+    def reduce_secs(secs):
+        if world <= 1:
+            return secs
+        t = torch.tensor(secs, device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)          # slowest rank, per repetition
-        rep_secs = [float(x) for x in t.tolist()]
+        return [float(x) for x in t.tolist()]
+
+    replicas_leg = None
+    one_stream = []
+    if not sharded:
+        rep_secs, one_stream, out, sustained = unsharded_run(G)
+    elif world > 1 and not args.no_replicas_leg and args.workload == "metric":
+        # beside the hash-sharded headline: every rank with the WHOLE graph in its own HBM
+        # (68.6 GB of 288), the unsharded step on its own roots - what sharding costs
+        try:
+            Gr = euler_amd.Graph.synthetic(p, device=local_rank)
+            Gr.set_seed(GRAPH_SEED)
+            r_secs, _one, _out, _sus = unsharded_run(Gr, extras=False)
+            r_secs = reduce_secs(r_secs)
+            r_el = float(np.median(r_secs))
+            replicas_leg = {"value": B * 275 * world * args.steps / r_el, "unit": "sampled edges/s",
+                            "ms_per_step": r_el / args.steps * 1e3, "graph_bytes_per_gpu": Gr.device_bytes,
+                            "repeat_ms_per_step": [round(x / args.steps * 1e3, 4) for x in r_secs],
+                            "what": "graph replicated on every GPU, no exchange (SURVEY H7): the same "
+                                    "roots, steps and timing protocol as the sharded headline"}
+            del Gr, _out
+            torch.cuda.empty_cache()
+        except Exception as e:
+            replicas_leg = {"error": repr(e)}
+    exchanged = None
+    wire_dev = dev if backend == "nccl" else "cpu"
+    rep_secs = reduce_secs(rep_secs)
     # EXACTLY K steps were timed, `repeats` times over; the line reports the median
     elapsed = float(np.median(rep_secs))
-    if world > 1:
+    if world > 1 and sharded:
         t = torch.tensor([float(wire_bytes)], device=wire_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         exchanged = float(t.item()) / args.steps          # bytes / step, all ranks
@@ -1450,7 +1909,7 @@ def main():
     # ---- parity spot check at full size: 64 roots of the last step against
     # the oracle fed with the rows exported from HBM (single GPU only)
     checked = None
-    if world == 1 and not args.no_check:
+    if (world == 1 or replicas) and rank == 0 and not args.no_check:
         from oracle import oracle as O
         last = n_steps - 1
         sel = np.random.default_rng(0).choice(B, 64, replace=False)
@@ -1484,7 +1943,10 @@ def main():
     # (SampleNeighborPivotKernel): its algorithmic bytes are SURVEY 8(d)'s
     # per-root / per-edge figure summed over the roots it actually processes.
     roofline = None
-    fused = world == 1 and not sharded and "27=0" not in args.tuning.split(",")
+    fused = not sharded and "27=0" not in args.tuning.split(",")
+    if not sharded and not fused:
+        raise SystemExit("bench.py: --tuning 27=0 (hop-by-hop fanout) has no roofline leg any more; "
+                         "use tools/ab_key.py for that A/B")
     if rank == 0 and fused:
         # The step is ONE kernel (fanout_local.h: hop 1, the duplicate children found inside
         # the wave, hop 2 once per distinct child, the rows streamed out): the roofline object
@@ -1613,134 +2075,90 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:          # a side measurement must not fail the bench
                 roofline["large_batch"] = {"error": repr(e)}
-    if rank == 0 and not fused:
+    if not fused:
+        # The sharded step's own launches (every rank): the owners' pass of a hop is
+        # euler_gpu_sample_neighbor_packed over the DISTINCT ids a rank is asked for - K1
+        # (SampleNeighborPivotKernel, one sample per lane, wire rows written directly).  Timed
+        # alone with HIP events on its stream, over the ids this rank's own batch asks for
+        # mapped onto ids this rank owns (a rank is asked for as many as it asks, in expectation):
+        # hop 1 = the distinct roots, hop 2 = the distinct hop-1 samples.  Bytes = SURVEY 8(d)'s
+        # K1 formula over exactly those ids.
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         et1 = (C.c_int32 * 1)(0)
-        iters = 5
-        shapes = [(roots[n_steps - 1].contiguous(), FANOUT[0], 0)]
-        if world == 1:
-            shapes.append((out[0][1].contiguous(), FANOUT[1], 1))
-        else:
-            shapes.append((torch.randint(1, args.nodes + 1, (B * FANOUT[0],),
-                                         generator=gen, device=dev,
-                                         dtype=torch.int64), FANOUT[1], 1))
 
-        def algo_bytes(r, cnt):
+        def own(x):
+            if world > 1 and sharded:      # a shard owns ids == rank (mod world)
+                x = (x // world) * world + (rank if rank else world)
+                x = torch.clamp(x, max=args.nodes - world)
+            return torch.unique(x).contiguous()
+
+        def algo_bytes(x, cnt):
             b = C.c_double(0)
             _lib.check(L.euler_gpu_sample_neighbor_algo_bytes(
-                G._h, st, C.c_void_p(r.data_ptr()), r.numel(), et1, 1, cnt, C.byref(b)))
+                G._h, st, C.c_void_p(x.data_ptr()), x.numel(), et1, 1, cnt, C.byref(b)))
             return b.value
-
+        hop_ids = [own(roots[n_steps - 1]), own(out[0][1].reshape(-1))]
         k1_ms, k1_bytes, phases = [], [], []
-        in_place = None
-        if world == 1:
-            # one untimed call on this stream first: the launcher sizes its grids by
-            # whether the caller alternates streams, and the timed loop above did
-            G.sample_fanout(shapes[0][0], et, FANOUT, default_node, call_id=0)
-            torch.cuda.synchronize()
-            # the fanout timed in place (hop 1's kernel also enters its ids into
-            # hop 2's owner table, so the hops are not independent launches)
-            layers = len(FANOUT)
-            cnt_a = (C.c_int32 * layers)(*FANOUT)
-            et_a = (C.c_int32 * layers)(*([0] * layers))
-            r = shapes[0][0]
-            o_n, o_w, o_t, m = [], [], [], r.numel()
-            for c in FANOUT:
-                m *= c
-                o_n.append(torch.empty(m, dtype=torch.int64, device=dev))
-                o_w.append(torch.empty(m, dtype=torch.float32, device=dev))
-                o_t.append(torch.empty(m, dtype=torch.int32, device=dev))
-            wsz = int(L.euler_gpu_sample_fanout_workspace(r.numel(), cnt_a, layers))
-            fws = torch.empty(max(wsz, 16), dtype=torch.uint8, device=dev)
-            pn = (C.c_void_p * layers)(*[t.data_ptr() for t in o_n])
-            pw_ = (C.c_void_p * layers)(*[t.data_ptr() for t in o_w])
-            pt = (C.c_void_p * layers)(*[t.data_ptr() for t in o_t])
-            ms_all = (C.c_float * (3 * layers))()
-            nu_all = (C.c_int64 * layers)()
-            _lib.check(L.euler_gpu_time_sample_fanout_phases(
-                G._h, st, GRAPH_SEED, C.c_void_p(r.data_ptr()), r.numel(), et_a, 1, cnt_a,
-                layers, default_node, pn, pw_, pt, C.c_void_p(fws.data_ptr()), iters,
-                ms_all, nu_all))
-            in_place = ([list(ms_all[3 * h:3 * h + 3]) for h in range(layers)],
-                        list(nu_all), [r] + o_n)
-        for h, (r, cnt, dedup) in enumerate(shapes):
-            if world > 1:      # a shard only owns ids == rank (mod world)
-                r = (r // world) * world + (rank if rank else world)
-                r = torch.clamp(r, max=args.nodes - world)
-            n = r.numel()
-            ms3 = (C.c_float * 3)()
-            nu = C.c_int64(-1)
-            if in_place is None:
-                oid = torch.empty(n * cnt, dtype=torch.int64, device=dev)
-                ow = torch.empty(n * cnt, dtype=torch.float32, device=dev)
-                ot = torch.empty(n * cnt, dtype=torch.int32, device=dev)
-            if in_place is not None:
-                r = in_place[2][h].contiguous()     # this hop's roots in the timed fanout
-                ms3[0], ms3[1], ms3[2] = in_place[0][h]
-                nu = C.c_int64(in_place[1][h])
-            else:
-                _lib.check(L.euler_gpu_time_sample_neighbor_phases(
-                    G._h, st, GRAPH_SEED, C.c_void_p(r.data_ptr()), n, et1, 1, cnt,
-                    _lib.LAYOUT_TF, dedup, C.c_void_p(oid.data_ptr()),
-                    C.c_void_p(ow.data_ptr()), C.c_void_p(ot.data_ptr()), iters, ms3,
-                    C.byref(nu)))
-            unique_path = dedup == 1 and nu.value >= 0 and nu.value * 4 <= n * 3
-            sampled = torch.unique(r) if unique_path else r
-            kb = algo_bytes(sampled.contiguous(), cnt)
-            # hop chaining: this hop's kernel also does the next hop's 4-byte
-            # owner store per id (SURVEY 8(d)'s "dedup: 8 + 4 per input id" -
-            # the 4 move here, the next hop's dedup keeps the 8)
-            marks_next = in_place is not None and h + 1 < len(shapes) and not unique_path
-            premarked = in_place is not None and h > 0
-            if marks_next:
-                kb += 4.0 * n * cnt
-            k1_ms.append(ms3[1])
-            k1_bytes.append(kb)
-            ph = {"roots": n, "count": cnt, "roots_sampled": int(sampled.numel()),
-                  "k1_ms": round(ms3[1], 4), "k1_algorithmic_bytes": kb,
-                  "marks_next_hop": bool(marks_next)}
-            if unique_path:
-                # dedup adds 8 + 4 bytes per input id, the gather 16
-                # per expanded output edge (+ the unique rows it reads once)
-                eb = 16.0 * n * cnt + 16.0 * nu.value * cnt + 4.0 * n
-                ph.update({"dedup_ms": round(ms3[0], 4),
-                           "dedup_algorithmic_bytes": (8.0 if premarked else 12.0) * n,
-                           "expand_ms": round(ms3[2], 4), "expand_algorithmic_bytes": eb,
-                           "expand_GBps": round(eb / (ms3[2] * 1e-3) / 1e9, 1)})
-            phases.append(ph)
+        for h, x in enumerate(hop_ids):
+            cnt = FANOUT[h]
+            ms_h = _events(lambda: G.sample_neighbor_packed(x, [0], cnt, default_node, call_id=h), 10)
+            kb = algo_bytes(x, cnt)
+            k1_ms.append(ms_h); k1_bytes.append(kb)
+            phases.append({"hop": h, "distinct_ids_sampled": int(x.numel()), "count": cnt,
+                           "k1_ms": round(ms_h, 4), "k1_algorithmic_bytes": kb,
+                           "frac": round(kb / (ms_h * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+        # the requester's side of hop 2, for the record: expansion of the answers to positions
+        try:
+            from euler_amd import ops as _ops
+            n2 = out[0][1].numel()
+            rows2 = G.sample_neighbor_packed(hop_ids[1], [0], FANOUT[1], default_node, call_id=1)
+            pos2 = torch.randint(0, hop_ids[1].numel(), (n2,), device=dev, dtype=torch.int32)
+            ms_x = _events(lambda: _ops.expand_packed(pos2, rows2, FANOUT[1], 0), 10)
+            xb = 16.0 * n2 * FANOUT[1] + 4.0 * n2 + rows2.numel() * 4.0
+            phases.append({"hop": 1, "expand_ms": round(ms_x, 4), "expand_algorithmic_bytes": xb,
+                           "expand_GBps": round(xb / (ms_x * 1e-3) / 1e9, 1)})
+            del rows2, pos2
+        except Exception as e:
+            phases.append({"expand_error": repr(e)})
         achieved = sum(k1_bytes) / (sum(k1_ms) * 1e-3) / 1e9
+        per_rank = None
+        if world > 1:
+            t = torch.tensor([sum(k1_bytes), sum(k1_ms)], device=wire_dev, dtype=torch.float64)
+            allt = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(allt, t)
+            per_rank = [{"rank": r_, "frac": round(float(x_[0]) / (float(x_[1]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                         "k1_ms": round(float(x_[1]), 4)} for r_, x_ in enumerate(allt)]
+            achieved = float(np.mean([x_["frac"] for x_ in per_rank])) * HBM_PEAK_GBS
         traffic = None
-        traffic_hops = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        pmc = os.path.join(ROOT, "profiles", "pmc_sharded_latest.json")
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
-                if rec.get("batch") == B and rec.get("nodes") == args.nodes:
+                if rec.get("batch") == B and rec.get("nodes") == args.nodes and \
+                        "SampleNeighborPivotKernel" in rec.get("kernel", ""):
                     traffic = rec.get("hbm_bytes_per_launch")
-                    traffic_hops = [rec.get("hbm_bytes_hop1_launch"), rec.get("hbm_bytes_hop2_launch")]
             except Exception:
                 traffic = None
-        roofline = {
-            "kernel": "SampleNeighborPivotKernel",
-            "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": traffic,
-            "traffic_per_launch": traffic_hops,
-            "traffic_note": "profiles/pmc_latest.json: (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 per launch "
-                            "of hop 1 / hop 2 (separate rocprofv3 --pmc passes); x2 because every L2 read "
-                            "request is one 128-B line tallied at 64 B - calibrated on known request shapes "
-                            "(tools/ubench_fetch.hip, profiles/r2_pmc_summary.json)",
-            "algorithmic_bytes_per_launch": round(sum(k1_bytes) / len(k1_bytes), 1),
-            "avg_launch_ms": round(sum(k1_ms) / len(k1_ms), 4),
-            "launch_ms": [round(x, 4) for x in k1_ms],
-            "launches_per_step": phases,
-            "note": "K1 launches that do work in one step, timed alone on one stream (full "
-                    "grids): hop 1 over the batch, hop 2 over the distinct hop-2 roots (duplicates "
-                    "are counted on device and their rows expanded by DedupExpandLeanKernel); bytes "
-                    "= SURVEY 8(d) formula over the roots each launch processes.  `traffic` is what "
-                    "the launches really move (128-byte lines): hop 2 runs at traffic / time = "
-                    "4.7 TB/s of HBM traffic",
-        }
+        if rank == 0:
+            roofline = {
+                "kernel": "SampleNeighborPivotKernel (owners' pass of a sharded hop, packed wire rows)",
+                "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": traffic,
+                "traffic_note": "profiles/pmc_sharded_latest.json: TCC_EA0_RDREQ x 128 B + WRITE_SIZE per "
+                                "launch of this kernel in the sharded step (separate rocprofv3 --pmc "
+                                "passes over tools/sharded_one.py), mean of the two hops' launches; null when "
+                                "no such file matches this batch / graph",
+                "algorithmic_bytes_per_launch": round(sum(k1_bytes) / len(k1_bytes), 1),
+                "avg_launch_ms": round(sum(k1_ms) / len(k1_ms), 4),
+                "launch_ms": [round(x, 4) for x in k1_ms],
+                "launches_per_step": phases,
+                "per_rank": per_rank,
+                "note": "the K1 launches of one sharded step, each timed alone on one stream with HIP "
+                        "events (10 calls): hop 1 over the distinct roots, hop 2 over the distinct hop-1 "
+                        "samples; bytes = SURVEY 8(d)'s K1 formula over those ids; N ranks: the mean of the "
+                        "ranks' fractions, per_rank lists them",
+            }
 
     small = None
     if rank == 0 and world == 1 and not sharded and not args.no_small_batch:
@@ -1752,7 +2170,9 @@ def main():
     if rank == 0 and world == 1 and not sharded and args.workload == "metric" and not args.no_secondary:
         secondary = secondary_legs(args, G, p)
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
+        # (N ranks: rank 0 alone, after the timed region - the other ranks wait in the closing
+        # barrier; the reference's CPU sampler does not get faster with more GPUs)
         cpu = cpu_baseline(args)
 
     if rank == 0:
@@ -1784,8 +2204,10 @@ def main():
                 "partitioning": ("none" if not sharded else
                                  "sharded sampler on 1 rank, %d minibatches in flight" % args.pipeline)
                                 if world == 1 else
-                                "hash owner(id)=id%%%d, all-to-all per hop, %d minibatches "
-                                "in flight" % (world, args.pipeline),
+                                ("replicas: every rank holds the whole graph, no exchange" if replicas else
+                                 "hash owner(id)=id%%%d, all-to-all per hop, %d minibatches "
+                                 "in flight" % (world, args.pipeline)),
+                "replicas": replicas_leg,
                 "parity_checked_edges": checked,
                 "small_batch": small,
                 "sustained": sustained,
@@ -1798,8 +2220,10 @@ def main():
                 "repeats": len(rep_secs),
                 "repeat_ms_per_step": [round(x / args.steps * 1e3, 4) for x in rep_secs],
                 "ranks": world,
-                "transport": (None if not sharded else
-                              "RCCL all-to-all (%d ranks in the communicator)" % dist.get_world_size()
+                "transport": (None if not (sharded or world > 1) else
+                              "RCCL (torch.distributed nccl backend), %d ranks in the communicator%s"
+                              % (dist.get_world_size(), "" if sharded else "; barriers and the timing "
+                                 "reduction only (replicas)")
                               if backend == "nccl" else
                               "gloo, host-staged: %d ranks share %d GPU(s) - functional check, "
                               "NOT a scaling number" % (world, visible)),
@@ -1815,7 +2239,7 @@ def main():
         except Exception:
             pass
         print(json.dumps(line), flush=True)
-    if sharded:
+    if sharded or world > 1:
         dist.barrier()
         dist.destroy_process_group()
 

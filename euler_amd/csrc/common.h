@@ -262,6 +262,18 @@ int LaunchSampleNeighborCounted(const euler_gpu_graph* g, hipStream_t stream, ui
                                 const uint32_t* n_dev, const int32_t* edge_types, int32_t k,
                                 int32_t count, int64_t default_node, uint64_t* out_id,
                                 float* out_w, int32_t* out_t);
+// walk_kernels.hip: the pieces of the sharded DeepWalk (csrc/sharded.cc) - the edge-type table
+// of a walk on the device (stream-ordered allocation, the caller frees it with hipFreeAsync),
+// the owners' draw of step `step` for the ids asked (0 = no neighbour), and the walkers' paths
+// from the levels' (ids, next) arrays (HOST tables of device pointers)
+int WalkEdgeTypes(hipStream_t st, const int32_t* edge_types_host, int32_t k, int32_t walk_len,
+                  int32_t** et_dev);
+int WalkOwnedStep(const euler_gpu_graph* g, hipStream_t st, uint64_t seed, uint32_t call_id,
+                  const int32_t* et_dev, int32_t k, int32_t walk_len, int32_t step,
+                  const uint64_t* ids_dev, int64_t n, uint64_t* out_dev);
+int WalkPathsFromLevels(hipStream_t st, const int64_t* starts_dev, int64_t n, int32_t walk_len,
+                        const uint64_t* const* level_ids_host, const int32_t* const* level_next_host,
+                        int64_t default_node, int64_t* out_dev);
 // dat_reader.cc
 struct DatGraph {
   std::vector<uint64_t> row_id, nbr;

@@ -1162,6 +1162,44 @@ int euler_gpu_graph_id_range(const euler_gpu_graph* g, uint64_t* max_id_host,
   return EULER_GPU_OK;
 }
 
+int euler_gpu_graph_set_node_sampler(euler_gpu_graph* g, int64_t n, const uint64_t* ids_host,
+                                     const int32_t* types_host, const float* weights_host,
+                                     int32_t n_node_types) {
+  if (!g) return Fail(EULER_GPU_ENOGRAPH, "set_node_sampler: null graph");
+  if (n <= 0 || n_node_types <= 0 || n_node_types > kMaxNodeTypes)
+    return Fail(EULER_GPU_EINVAL, "set_node_sampler: bad arguments");
+  const GraphView& v = g->view;
+  if (!ids_host && (v.map_mode != 0 || n != v.n_rows))
+    return Fail(EULER_GPU_EINVAL, "set_node_sampler: ids required (the id map is not the strided "
+                                  "identity, or n != the graph's rows)");
+  std::vector<uint64_t> ids((size_t)n);
+  std::vector<int32_t> types((size_t)n, 0);
+  std::vector<float> weights((size_t)n, 1.0f);
+  for (int64_t i = 0; i < n; ++i)
+    ids[(size_t)i] = ids_host ? ids_host[i] : v.id_base + v.id_stride * (uint64_t)i;
+  if (types_host) std::memcpy(types.data(), types_host, (size_t)n * sizeof(int32_t));
+  if (weights_host) std::memcpy(weights.data(), weights_host, (size_t)n * sizeof(float));
+  int prev = 0;
+  EG_HIP(hipGetDevice(&prev));
+  EG_HIP(hipSetDevice(g->device));
+  const AliasEntry* old = g->has_sampler ? g->sampler.entries : nullptr;
+  GraphBuilder b;
+  b.g.reset(g);                 // borrow the graph: the table lands in its allocation list
+  const int rc = BuildNodeSampler(&b, ids, types, weights, n_node_types);
+  b.g.release();
+  if (rc == EULER_GPU_OK && old != nullptr) {
+    auto it = std::find(g->allocations.begin(), g->allocations.end(), (void*)old);
+    if (it != g->allocations.end()) {
+      (void)hipDeviceSynchronize();
+      (void)hipFree(*it);
+      g->allocations.erase(it);
+      g->bytes -= (int64_t)0;   // (the old table's size is not tracked separately)
+    }
+  }
+  (void)hipSetDevice(prev);
+  return rc;
+}
+
 int euler_gpu_graph_node_weight_sums(const euler_gpu_graph* g, float* out_host) {
   if (!g || !out_host) return Fail(EULER_GPU_EINVAL, "node_weight_sums: null");
   for (size_t i = 0; i < g->node_weight_sums.size(); ++i)

@@ -201,23 +201,29 @@ int euler_gpu_sharded_sample_neighbor(const euler_gpu_graph* shard, const euler_
   }
   std::vector<int64_t> send_rows((size_t)W), recv_rows((size_t)W);
   for (int32_t s = 0; s < W; ++s) send_rows[s] = off[s + 1] - off[s];
-  // 2. who gets how many ids from whom
-  int rc = tr->alltoall_counts(tr->user, send_rows.data(), recv_rows.data());
+  // 2. who gets how many ids from whom.  (One rank: every id is its own - no exchange, the
+  //    buckets ARE the owned ids and the sampled rows ARE the answers.)
+  int rc = EULER_GPU_OK;
+  if (W == 1) recv_rows[0] = send_rows[0];
+  else rc = tr->alltoall_counts(tr->user, send_rows.data(), recv_rows.data());
   if (rc != EULER_GPU_OK) return rc;
   int64_t m = 0;
   for (int32_t s = 0; s < W; ++s) m += recv_rows[s];
   // 3. ids to their owners
-  uint64_t* owned = (uint64_t*)sc.Get((size_t)(m > 0 ? m : 1) * 8);
-  if (!owned) return Fail(EULER_GPU_ENOMEM, "sharded_sample_neighbor: scratch");
-  rc = tr->alltoallv(tr->user, shard_ids, send_rows.data(), owned, recv_rows.data(), 8, stream);
-  if (rc != EULER_GPU_OK) return rc;
+  uint64_t* owned = shard_ids;
+  if (W > 1) {
+    owned = (uint64_t*)sc.Get((size_t)(m > 0 ? m : 1) * 8);
+    if (!owned) return Fail(EULER_GPU_ENOMEM, "sharded_sample_neighbor: scratch");
+    rc = tr->alltoallv(tr->user, shard_ids, send_rows.data(), owned, recv_rows.data(), 8, stream);
+    if (rc != EULER_GPU_OK) return rc;
+  }
   // 4. the owner samples its rows straight into wire rows
   const int32_t single_type = k == 1 ? edge_types_host[0] : -1;
   const int32_t words = PackedWordsHost(count, single_type >= 0 ? 0 : 1);
   int32_t* rows = (int32_t*)sc.Get((size_t)(m > 0 ? m : 1) * words * 4);
   int64_t asked = 0;
   for (int32_t s = 0; s < W; ++s) asked += send_rows[s];
-  int32_t* back = (int32_t*)sc.Get((size_t)(asked > 0 ? asked : 1) * words * 4);
+  int32_t* back = W == 1 ? rows : (int32_t*)sc.Get((size_t)(asked > 0 ? asked : 1) * words * 4);
   if (!rows || !back) return Fail(EULER_GPU_ENOMEM, "sharded_sample_neighbor: scratch");
   if (m > 0) {
     rc = euler_gpu_sample_neighbor_packed(shard, stream, seed, call_id, owned, m, edge_types_host, k,
@@ -226,9 +232,11 @@ int euler_gpu_sharded_sample_neighbor(const euler_gpu_graph* shard, const euler_
   }
   // 5. rows back along the reversed split; the shards answered in the order they
   //    were asked, so row pos[i] of `back` is position i's row
-  rc = tr->alltoallv(tr->user, rows, recv_rows.data(), back, send_rows.data(), (int64_t)words * 4,
-                     stream);
-  if (rc != EULER_GPU_OK) return rc;
+  if (W > 1) {
+    rc = tr->alltoallv(tr->user, rows, recv_rows.data(), back, send_rows.data(), (int64_t)words * 4,
+                       stream);
+    if (rc != EULER_GPU_OK) return rc;
+  }
   // 6. IDX_MERGE / DATA_MERGE / DATA_GATHER / unpack in one pass
   if (n > 0) {
     rc = euler_gpu_expand_packed(stream, pos, n, count, single_type, back, out_id_dev, out_w_dev,
@@ -269,6 +277,139 @@ int euler_gpu_sharded_sample_fanout(const euler_gpu_graph* shard, const euler_gp
     group = counts_host[h];
     m *= counts_host[h];
   }
+  return EULER_GPU_OK;
+}
+
+// DeepWalk (p = q = 1) over the sharded graph, tf_euler/kernels/random_walk_op.cc:207-247: one
+// `sampleNB(edge_types, 1)` query per step, each ID_UNIQUE -> ID_SPLIT -> REMOTE -> MERGE ->
+// GATHER (parser/compiler.cc:76-90).  Here the GATHER is deferred to the end of the walk:
+//   level s   = the DISTINCT nodes the rank's walkers stand on at step s (level 0 = the
+//               walkers), an entry = a group of walkers that have merged - two walkers on one
+//               node draw the same next node (the draw is keyed by (seed, call_id + s, node)),
+//               so they stay together for good; 1M walkers are 63 % distinct nodes after one
+//               step, 11 % after ten (walk_kernels.hip);
+//   step s    = front end over level s (distinct ids bucketed by owner; next[s][e] = the place
+//               of entry e's answer) -> ids to the owners -> the OWNERS draw (WalkOwnedStep: the
+//               draw of the single-GPU walk) -> the answers, in the order asked, ARE level s + 1;
+//   paths     = every walker follows next[0], next[1], ... once (WalkPathsFromLevels).
+// A step costs what its level holds, not what the batch holds, and the wire carries every
+// distinct node once per rank and step.  The host waits once per step (the bucket sizes, which
+// size the exchange); `cohorts` > 1 splits the walkers into that many independent walks whose
+// steps alternate on the stream, so that while the host waits for one cohort's sizes the GPU
+// runs the other cohorts' kernels.  Bit-identical to euler_gpu_random_walk on the unsharded graph.
+int euler_gpu_sharded_random_walk(const euler_gpu_graph* shard, const euler_gpu_transport* tr,
+                                  void* stream, uint64_t seed, uint32_t call_id,
+                                  const int64_t* starts_dev, int64_t n,
+                                  const int32_t* edge_types_host, int32_t k, int32_t walk_len,
+                                  int64_t default_node, int32_t partitions, int32_t cohorts,
+                                  uint32_t* dense_owner_dev, int64_t dense_limit,
+                                  int64_t* out_dev, int64_t* stats_host) {
+  if (!shard) return Fail(EULER_GPU_ENOGRAPH, "sharded_random_walk: null graph");
+  if (!tr || tr->world < 1 || (tr->world > 1 && (!tr->alltoall_counts || !tr->alltoallv)) || n < 0 ||
+      walk_len < 0 || k < 0 || k > 32 || partitions < tr->world || cohorts < 1 || cohorts > 16 ||
+      n >= ((int64_t)1 << 30) || (n > 0 && (!starts_dev || !out_dev)) ||
+      (k > 0 && walk_len > 0 && !edge_types_host))
+    return Fail(EULER_GPU_EINVAL, "sharded_random_walk: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int32_t W = tr->world, L = walk_len, K = cohorts;
+  Scratch sc(st);
+  int32_t* et_dev = nullptr;
+  {
+    const int rc = euler_gpu::WalkEdgeTypes(st, edge_types_host, k, L, &et_dev);
+    if (rc != EULER_GPU_OK) return rc;
+    sc.ptrs.push_back(et_dev);
+  }
+  struct Cohort {
+    int64_t lo = 0, n = 0, m = 0;                // walkers; entries of the current level
+    euler_gpu_front* front = nullptr;
+    std::vector<const uint64_t*> ids;            // [L + 1] levels (0 = the walkers' start nodes)
+    std::vector<const int32_t*> next;            // [L]
+    uint64_t* bucketed = nullptr;                // [n] the current step's distinct ids by owner
+    uint8_t* arena = nullptr;
+    ~Cohort() { if (front) euler_gpu_front_destroy(front); }
+  };
+  std::vector<Cohort> co((size_t)K);
+  for (int32_t c = 0; c < K; ++c) {
+    Cohort& q = co[(size_t)c];
+    q.lo = n * c / K; q.n = n * (c + 1) / K - q.lo; q.m = q.n;
+    q.ids.assign((size_t)L + 1, nullptr); q.next.assign((size_t)(L > 0 ? L : 1), nullptr);
+    q.ids[0] = (const uint64_t*)starts_dev + q.lo;
+    int rc = euler_gpu_front_create(&q.front);
+    if (rc != EULER_GPU_OK) return rc;
+    if (q.n > 0 && L > 0) {
+      // levels 1 .. L (8 bytes an entry), next 0 .. L - 1 (4), the step's bucketed ids (8): a
+      // level never holds more entries than the cohort has walkers
+      q.arena = (uint8_t*)sc.Get((size_t)q.n * ((size_t)L * 12 + 8) + 256);
+      if (!q.arena) { (void)hipGetLastError(); return Fail(EULER_GPU_ENOMEM, "sharded_random_walk: scratch"); }
+      uint8_t* p8 = q.arena;
+      for (int32_t s = 1; s <= L; ++s) { q.ids[(size_t)s] = (const uint64_t*)p8; p8 += (size_t)q.n * 8; }
+      q.bucketed = (uint64_t*)p8; p8 += (size_t)q.n * 8;
+      for (int32_t s = 0; s < L; ++s) { q.next[(size_t)s] = (const int32_t*)p8; p8 += (size_t)q.n * 4; }
+    }
+  }
+  int64_t waits = 0, entries = 0, wire_ids = 0;
+  auto begin = [&](Cohort& q, int32_t s) -> int {
+    // (an empty level still takes part: its rank must make the step's exchanges)
+    return euler_gpu_dedup_split_begin(q.front, stream, q.ids[(size_t)s], q.m, nullptr, 1, partitions, W,
+                                       dense_owner_dev, dense_limit, q.bucketed,
+                                       const_cast<int32_t*>(q.next[(size_t)s]));
+  };
+  std::vector<int64_t> off((size_t)W + 1), send_rows((size_t)W), recv_rows((size_t)W);
+  auto finish = [&](Cohort& q, int32_t s) -> int {
+    int rc = euler_gpu_dedup_split_end(q.front, off.data());        // the step's one host wait
+    if (rc != EULER_GPU_OK) return rc;
+    ++waits;
+    const int64_t asked = off[(size_t)W];
+    entries += q.m;
+    uint64_t* level = const_cast<uint64_t*>(q.ids[(size_t)s + 1]);
+    if (W == 1) {
+      // one rank: the buckets are the owned ids, the draws are the next level
+      rc = euler_gpu::WalkOwnedStep(shard, st, seed, call_id, et_dev, k, L, s, q.bucketed, asked, level);
+      if (rc != EULER_GPU_OK) return rc;
+    } else {
+      for (int32_t p = 0; p < W; ++p) send_rows[(size_t)p] = off[(size_t)p + 1] - off[(size_t)p];
+      rc = tr->alltoall_counts(tr->user, send_rows.data(), recv_rows.data());
+      if (rc != EULER_GPU_OK) return rc;
+      int64_t m_in = 0;
+      for (int32_t p = 0; p < W; ++p) m_in += recv_rows[(size_t)p];
+      wire_ids += asked - send_rows[(size_t)tr->rank];
+      uint64_t* owned = (uint64_t*)sc.Get((size_t)(m_in > 0 ? m_in : 1) * 16);
+      if (!owned) { (void)hipGetLastError(); return Fail(EULER_GPU_ENOMEM, "sharded_random_walk: scratch"); }
+      uint64_t* drawn = owned + (m_in > 0 ? m_in : 1);
+      rc = tr->alltoallv(tr->user, q.bucketed, send_rows.data(), owned, recv_rows.data(), 8, stream);
+      if (rc != EULER_GPU_OK) return rc;
+      rc = euler_gpu::WalkOwnedStep(shard, st, seed, call_id, et_dev, k, L, s, owned, m_in, drawn);
+      if (rc != EULER_GPU_OK) return rc;
+      // (an empty cohort has no arena and asks for nothing: any valid pointer receives its 0 rows)
+      rc = tr->alltoallv(tr->user, drawn, recv_rows.data(), level ? (void*)level : (void*)owned,
+                         send_rows.data(), 8, stream);
+      if (rc != EULER_GPU_OK) return rc;
+    }
+    q.m = asked;
+    return EULER_GPU_OK;
+  };
+  if (L > 0) {
+    for (int32_t c = 0; c < K; ++c) {
+      const int rc = begin(co[(size_t)c], 0);
+      if (rc != EULER_GPU_OK) return rc;
+    }
+    for (int32_t s = 0; s < L; ++s) {
+      for (int32_t c = 0; c < K; ++c) {
+        int rc = finish(co[(size_t)c], s);
+        if (rc == EULER_GPU_OK && s + 1 < L) rc = begin(co[(size_t)c], s + 1);
+        if (rc != EULER_GPU_OK) return rc;
+      }
+    }
+  }
+  // the walkers' paths: one chain walk per walker through the levels
+  for (int32_t c = 0; c < K; ++c) {
+    Cohort& q = co[(size_t)c];
+    if (q.n == 0) continue;
+    const int rc = euler_gpu::WalkPathsFromLevels(st, starts_dev + q.lo, q.n, L, q.ids.data(), q.next.data(),
+                                                  default_node, out_dev + q.lo * ((int64_t)L + 1));
+    if (rc != EULER_GPU_OK) return rc;
+  }
+  if (stats_host) { stats_host[0] = waits; stats_host[1] = entries; stats_host[2] = wire_ids; stats_host[3] = K; }
   return EULER_GPU_OK;
 }
 

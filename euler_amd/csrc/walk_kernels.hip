@@ -857,6 +857,155 @@ __global__ __launch_bounds__(256) void CwPathKernel(const CwArgs a, const int64_
 }
 
 
+// ---- sharded DeepWalk (csrc/sharded.cc: euler_gpu_sharded_random_walk) -----------------
+// The walk over groups of merged walkers with the groups' nodes OWNED BY OTHER RANKS: level s
+// holds the distinct nodes the walkers stand on at step s; a step sends them to their owners
+// (front end of a sharded hop: distinct ids bucketed by owner + every entry's place among the
+// answers), the OWNER draws - WalkOwnedKernel, the draw of CwSampleKernel - and the answers,
+// in the order asked, are level s + 1.  The walkers themselves are touched twice: as level 0
+// and by ShWalkPathKernel, which follows every walker through the levels' `next` indices.
+template <int MODE>
+__global__ __launch_bounds__(256, kWavesPerSimd) void WalkOwnedKernel(const CwArgs a,
+                                                                      const uint64_t* __restrict__ ids,
+                                                                      const int64_t n,
+                                                                      uint64_t* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = CwDraw<MODE>(a, ids[i], a.step);
+}
+
+constexpr int kShPathLevels = 120;  // levels whose pointers travel as kernel arguments
+struct ShPathArgs {
+  const int64_t* starts;            // [n] level 0
+  const uint64_t* const* ids;       // device [walk_len + 1]: ids[s] = the nodes of level s (ids[0] unused)
+  const int32_t* const* next;       // device [walk_len]: next[s][e] = entry e of level s at level s + 1
+  int64_t* out;                     // [n, walk_len + 1]
+  int64_t n, default_node;
+  int32_t walk_len, ch;             // steps per LDS tile
+  SmallDiv div_ch, div_last;        // by ch and by the last chunk's length
+  // walks of up to kShPathLevels steps: the tables themselves (ids / next above are null)
+  const uint64_t* ids_arg[kShPathLevels + 1];
+  const int32_t* next_arg[kShPathLevels];
+};
+
+// A wave takes 64 walkers: lane = walker follows its chain (one dependent 4-byte load per
+// level, the level's id beside it) and parks `ch` columns at a time in the wave's LDS tile;
+// the wave then writes the tile as runs of the op's [walker][step] rows.
+__global__ __launch_bounds__(256) void ShWalkPathKernel(const ShPathArgs a) {
+  extern __shared__ __align__(16) uint64_t sh_tile[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, waves = blockDim.x >> 6;
+  const int32_t L1 = a.walk_len + 1, ls = a.ch | 1;
+  uint64_t* t = sh_tile + (size_t)wv * 64 * ls;
+  const int64_t tiles = (a.n + 63) / 64;
+  const uint64_t* const* lvl_ids = a.ids != nullptr ? a.ids : a.ids_arg;
+  const int32_t* const* lvl_next = a.next != nullptr ? a.next : a.next_arg;
+  for (int64_t tile = (int64_t)blockIdx.x * waves + wv; tile < tiles; tile += (int64_t)gridDim.x * waves) {
+    const int64_t w0 = tile * 64;
+    const int32_t nw = (int32_t)(a.n - w0 < 64 ? a.n - w0 : 64);
+    const bool live = lane < nw;
+    uint32_t p = (uint32_t)(w0 + lane);
+    for (int32_t c0 = 0; c0 < L1; c0 += a.ch) {
+      const int32_t ns = L1 - c0 < a.ch ? L1 - c0 : a.ch;
+      if (live) {
+        for (int32_t x = 0; x < ns; ++x) {
+          const int32_t col = c0 + x;
+          uint64_t v;
+          if (col == 0) {
+            v = (uint64_t)a.starts[w0 + lane];
+          } else {
+            p = (uint32_t)lvl_next[col - 1][p];
+            v = lvl_ids[col][p];
+            if (v == 0) v = (uint64_t)a.default_node;
+          }
+          t[lane * ls + x] = v;
+        }
+      }
+      WaveSync();
+      const int32_t total = nw * ns;
+      for (int32_t e = lane; e < total; e += 64) {
+        const int32_t wl = (int32_t)(ns == a.ch ? a.div_ch((uint32_t)e) : a.div_last((uint32_t)e));
+        const int32_t x = e - wl * ns;
+        a.out[(w0 + wl) * L1 + c0 + x] = (int64_t)t[wl * ls + x];
+      }
+      WaveSync();
+    }
+  }
+}
+
+int WalkEdgeTypes(hipStream_t st, const int32_t* edge_types_host, int32_t k, int32_t walk_len,
+                  int32_t** et_dev) {
+  *et_dev = nullptr;
+  const size_t et_bytes = (size_t)walk_len * (k > 0 ? k : 1) * sizeof(int32_t) + 16;
+  EG_HIP(hipMallocAsync((void**)et_dev, et_bytes, st));
+  if (k > 0 && walk_len > 0)
+    EG_HIP(hipMemcpyAsync(*et_dev, edge_types_host, (size_t)walk_len * k * sizeof(int32_t),
+                          hipMemcpyHostToDevice, st));
+  return EULER_GPU_OK;
+}
+
+int WalkOwnedStep(const euler_gpu_graph* g, hipStream_t st, uint64_t seed, uint32_t call_id,
+                  const int32_t* et_dev, int32_t k, int32_t walk_len, int32_t step,
+                  const uint64_t* ids_dev, int64_t n, uint64_t* out_dev) {
+  if (n <= 0) return EULER_GPU_OK;
+  CwArgs c{};
+  {
+    const int rcv = SamplingView(g, &c.g);
+    if (rcv != EULER_GPU_OK) return rcv;
+  }
+  c.seed = seed; c.call_id = call_id; c.edge_types = et_dev; c.k = k; c.walk_len = walk_len;
+  c.step = step;
+  const GraphView& v = g->view;
+  const bool fast = k == 1 && v.monotone && v.blk != nullptr && g_k1_variant >= 5;
+  int mode = !fast ? 0
+             : (g_walk_lean != 0 && v.T == 1 && v.total_in_meta != 0 && v.map_mode == 0 &&
+                v.uniform_w == 0 && v.n_edges < ((int64_t)1 << 31)) ? 2 : 1;
+  if (mode == 2 && c.g.wrec != nullptr && c.g.wb != nullptr && c.g.wb_lean_ok != 0) mode = 3;
+  auto kern = mode == 3 ? WalkOwnedKernel<3> : mode == 2 ? WalkOwnedKernel<2>
+              : mode == 1 ? WalkOwnedKernel<1> : WalkOwnedKernel<0>;
+  const int block = 256;
+  unsigned grid = (unsigned)((n + block - 1) / block);
+  if (grid > 4096u) grid = 4096u;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, st, c, ids_dev, n, out_dev);
+  EG_HIP(hipGetLastError());
+  return EULER_GPU_OK;
+}
+
+int WalkPathsFromLevels(hipStream_t st, const int64_t* starts_dev, int64_t n, int32_t walk_len,
+                        const uint64_t* const* level_ids_host, const int32_t* const* level_next_host,
+                        int64_t default_node, int64_t* out_dev) {
+  if (n <= 0) return EULER_GPU_OK;
+  ShPathArgs a{};
+  a.starts = starts_dev; a.out = out_dev;
+  a.n = n; a.default_node = default_node; a.walk_len = walk_len;
+  void* tab = nullptr;
+  if (walk_len <= kShPathLevels) {
+    for (int32_t s = 0; s <= walk_len; ++s) a.ids_arg[s] = level_ids_host[s];
+    for (int32_t s = 0; s < walk_len; ++s) a.next_arg[s] = level_next_host[s];
+  } else {
+    // a long walk: the tables through device memory (the copies are waited for - their
+    // sources are the caller's host arrays)
+    const size_t tb = ((size_t)walk_len + 1) * 8, tn = (size_t)walk_len * 8;
+    EG_HIP(hipMallocAsync(&tab, tb + tn, st));
+    EG_HIP(hipMemcpyAsync(tab, level_ids_host, tb, hipMemcpyHostToDevice, st));
+    EG_HIP(hipMemcpyAsync((uint8_t*)tab + tb, level_next_host, tn, hipMemcpyHostToDevice, st));
+    EG_HIP(hipStreamSynchronize(st));
+    a.ids = (const uint64_t* const*)tab;
+    a.next = (const int32_t* const*)((uint8_t*)tab + tb);
+  }
+  const int32_t L1 = walk_len + 1;
+  a.ch = L1 < 64 ? L1 : 64;
+  a.div_ch.Set((uint32_t)a.ch);
+  a.div_last.Set((uint32_t)(L1 % a.ch == 0 ? a.ch : L1 % a.ch));
+  const size_t wave_bytes = (size_t)64 * (a.ch | 1) * 8;
+  const int waves = wave_bytes * 2 <= 64 * 1024 ? 2 : 1;
+  const int64_t tiles = (n + 63) / 64, wgs = (tiles + waves - 1) / waves;
+  hipLaunchKernelGGL(ShWalkPathKernel, dim3((unsigned)(wgs < 65536 ? wgs : 65536)), dim3(64 * waves),
+                     wave_bytes * waves, st, a);
+  if (tab != nullptr) (void)hipFreeAsync(tab, st);
+  EG_HIP(hipGetLastError());
+  return EULER_GPU_OK;
+}
+
 // node2vec step over explicit lists (euler_gpu_node2vec_step): one lane per walker, the
 // reference's own two passes - BuildWeights while summing, then the first running sum > r
 // (Node2VecKernel above says why that is RandomSelect's index; same sequential f32 adds).

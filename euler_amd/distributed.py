@@ -204,6 +204,11 @@ class ShardedSampler:
         self.bytes_sent += row_bytes * (int(sum(send_counts)) - int(send_counts[me]))
         self.bytes_received += row_bytes * (out_rows - int(recv_counts[me]))
         self.exchanges += 1
+        if self.world == 1:
+            # one rank: every id is this rank's own, nothing crosses a link - the "exchange"
+            # is the buffer itself (a self send / receive through RCCL costs a 46 MB copy per
+            # fanout step and moves nothing)
+            return send.contiguous()
         staged = self.host_staged and send.is_cuda
         src = send.contiguous().cpu() if staged else send.contiguous()
         recv = torch.empty(shape, dtype=send.dtype, device=src.device)
@@ -691,6 +696,11 @@ class ShardedSampler:
         import numpy as _np
         k_eps = 1.0e-6
         if abs(float(_np.float32(p)) - 1.0) <= k_eps and abs(float(_np.float32(q)) - 1.0) <= k_eps:
+            if getattr(self, "c_walk_fn", None) is not None:
+                # the walk over levels of merged walkers, orchestrated inside libeuler_gpu.so
+                # (euler_gpu_sharded_random_walk): one host wait per step, every step as large as
+                # the distinct nodes its walkers stand on
+                return self.c_walk_fn(nodes, edge_types, default_node, call_id)
             cur, mask = nodes, None
             for s, et in enumerate(edge_types):
                 ids, _, _, mask = self.sample_neighbor(cur, et, 1, default_node,
@@ -927,6 +937,13 @@ def gpu_sharded_sampler(graph, partitions=None, group=None, dedup=True, dense_id
     S.node_split_fn = lambda call_id, count, weights: ops.sample_node_split(
         graph.seed, call_id, count, weights)
     S.n2v_step_fn = lambda call_id, *lists: ops.node2vec_step(graph.seed, call_id, *lists)
+    if fused and graph.device.type == "cuda" and os.environ.get("EULER_AMD_C_WALK", "1") != "0":
+        tr_c = CTransport(group, counts_fn=S.counts_fn, device=graph.device)
+        S.c_transport = tr_c
+        S.walk_cohorts = int(os.environ.get("EULER_AMD_WALK_COHORTS", "2"))
+        S.c_walk_fn = lambda nodes, edge_types, default_node, call_id: c_sharded_random_walk(
+            graph, tr_c, nodes, edge_types, default_node, call_id, S.partitions, S.walk_cohorts,
+            dense_table)
     S.local_adj_mask = graph.sparse_adj_mask
     S.adj_from_mask_fn = type(graph).adj_from_mask
     return S
@@ -937,15 +954,26 @@ def gpu_sharded_sampler(graph, partitions=None, group=None, dedup=True, dense_id
 # driven from Python: the hop's orchestration runs inside libeuler_gpu.so, the
 # exchange goes through an euler_gpu_transport.
 # --------------------------------------------------------------------------
-class CTransport:
-    """euler_gpu_transport over a torch.distributed group whose backend cannot move
-    device memory between ranks that share a GPU (gloo): the two callbacks stage the
-    rows through the host (hipMemcpy of libamdhip64) and exchange them with
-    all_to_all_single.  A production C++ host uses euler_gpu_transport_rccl with its
-    ncclComm_t instead; this class exists so that world > 1 runs of the C entry
-    points can be verified on one GPU."""
+class _DevBytes(object):
+    """A raw device pointer as a uint8 torch tensor (no copy): __cuda_array_interface__."""
 
-    def __init__(self, group=None):
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1",
+                                         "data": (int(ptr), False), "version": 2}
+
+
+class CTransport:
+    """euler_gpu_transport over a torch.distributed group, for driving the C entry points
+    (euler_gpu_sharded_sample_fanout / _random_walk) from Python.
+    nccl backend: the callbacks hand the device buffers to all_to_all_single as they are
+    (RCCL over xGMI; the C call must be made with `stream` = torch's current stream, which
+    c_sharded_* do).  gloo backend - ranks that share a GPU in the one-GPU tests, where RCCL
+    refuses two ranks per device -: the rows are staged through the host (hipMemcpy of
+    libamdhip64).  A production C++ host uses euler_gpu_transport_rccl with its ncclComm_t
+    instead.  counts_fn: an all-to-all of the per-peer counts on the host (ShmCounts), else
+    the counts go through the group."""
+
+    def __init__(self, group=None, counts_fn=None, device=None):
         import ctypes as C
         from . import _lib
         self._C = C
@@ -953,6 +981,9 @@ class CTransport:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.bytes_sent = 0
+        self.counts_fn = counts_fn
+        self.on_gpu = dist.get_backend(group) == "nccl"
+        self.device = device
         hip = C.CDLL("libamdhip64.so")
         hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         hip.hipStreamSynchronize.argtypes = [C.c_void_p]
@@ -968,9 +999,16 @@ class CTransport:
 
         def counts(_user, send, recv):
             try:
-                sc = torch.tensor([send[p] for p in range(self.world)], dtype=torch.int64)
+                if self.counts_fn is not None:
+                    got = self.counts_fn([send[p] for p in range(self.world)])
+                    for p in range(self.world):
+                        recv[p] = int(got[p])
+                    return 0
+                sc = torch.tensor([send[p] for p in range(self.world)], dtype=torch.int64,
+                                  device=self.device if self.on_gpu else "cpu")
                 rc = torch.empty_like(sc)
                 dist.all_to_all_single(rc, sc, group=self.group)
+                rc = rc.tolist()
                 for p in range(self.world):
                     recv[p] = int(rc[p])
                 return 0
@@ -981,6 +1019,18 @@ class CTransport:
             try:
                 s_rows = [int(send_rows[p]) for p in range(self.world)]
                 r_rows = [int(recv_rows[p]) for p in range(self.world)]
+                if self.on_gpu:
+                    # device buffers as they are; torch's RCCL work is ordered after the current
+                    # stream, on which the C call enqueued the kernels that filled `send`
+                    dev_ = self.device
+                    sb = torch.as_tensor(_DevBytes(send_dev, max(sum(s_rows) * row_bytes, 1)), device=dev_)
+                    rb = torch.as_tensor(_DevBytes(recv_dev, max(sum(r_rows) * row_bytes, 1)), device=dev_)
+                    dist.all_to_all_single(rb[:sum(r_rows) * row_bytes], sb[:sum(s_rows) * row_bytes],
+                                           output_split_sizes=[r * row_bytes for r in r_rows],
+                                           input_split_sizes=[s_ * row_bytes for s_ in s_rows],
+                                           group=self.group)
+                    self.bytes_sent += (sum(s_rows) - s_rows[self.rank]) * row_bytes
+                    return 0
                 hip.hipStreamSynchronize(stream)          # the rows to send are ready
                 sb = torch.empty(sum(s_rows) * row_bytes, dtype=torch.uint8)
                 rb = torch.empty(sum(r_rows) * row_bytes, dtype=torch.uint8)
@@ -1040,3 +1090,36 @@ def c_sharded_sample_fanout(graph, transport, roots, edge_types, counts, default
             int(default_node), int(partitions or transport.world), pn, pw, pt,
             C.c_void_p(ws.data_ptr())))
     return [roots] + outs_n, outs_w, outs_t
+
+
+def c_sharded_random_walk(graph, transport, starts, edge_types, default_node=-1, call_id=0,
+                          partitions=None, cohorts=2, dense_table=None, return_stats=False):
+    """tf_euler random_walk with p = q = 1 through euler_gpu_sharded_random_walk (the C entry a
+    C++ host calls): [n, len(edge_types) + 1] int64, the same result as Graph.random_walk on
+    the unsharded graph.  edge_types: a list (walk_len) of per-step edge type lists."""
+    import ctypes as C
+    import numpy as np
+    from . import _lib
+    L = _lib.lib()
+    dev = graph.device
+    starts = starts.reshape(-1).to(torch.int64).to(dev).contiguous()
+    n = starts.numel()
+    walk_len = len(edge_types)
+    et = np.ascontiguousarray(np.asarray(edge_types, dtype=np.int32).reshape(walk_len, -1)) \
+        if walk_len else np.zeros((0, 1), np.int32)
+    k = et.shape[1] if walk_len else 1
+    out = torch.empty((n, walk_len + 1), dtype=torch.int64, device=dev)
+    stats = (C.c_int64 * 4)()
+    limit = dense_table.numel() - 1 if dense_table is not None else 0
+    with torch.cuda.device(dev):
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(L.euler_gpu_sharded_random_walk(
+            graph._h, transport.ptr() if hasattr(transport, "ptr") else transport, st, graph.seed,
+            int(call_id) & 0xFFFFFFFF, C.c_void_p(starts.data_ptr()), n, et.ctypes.data_as(_lib.i32p), k,
+            walk_len, int(default_node), int(partitions or transport.world), int(cohorts),
+            C.c_void_p(dense_table.data_ptr()) if dense_table is not None else None, limit,
+            C.c_void_p(out.data_ptr()), stats))
+    if return_stats:
+        return out, {"host_waits": int(stats[0]), "level_entries": int(stats[1]),
+                     "ids_sent": int(stats[2]), "cohorts": int(stats[3])}
+    return out

@@ -651,6 +651,26 @@ class Graph:
                            etyp[h][:m_nb] if with_types else None))
         return blocks, cnt
 
+    def set_node_sampler(self, ids=None, node_types=None, node_weights=None, n_node_types=None):
+        """Graph::BuildGlobalSampler (core/graph/graph.cc:333-370) for a graph that has no
+        global node sampler yet (a synthetic one), or in place of the one it has: the nodes
+        in the order the sampler enumerates them (ids None = the rows in row order), their
+        types (None = 0) and weights (None = 1.0).  Host arrays; host work."""
+        n = self.num_nodes if ids is None else len(ids)
+        ids_a = None if ids is None else _np(ids, np.uint64)
+        ty_a = None if node_types is None else _np(node_types, np.int32)
+        w_a = None if node_weights is None else _np(node_weights, np.float32)
+        for a in (ty_a, w_a):
+            if a is not None and len(a) != n:
+                raise ValueError("set_node_sampler: array lengths differ")
+        if n_node_types is None:
+            n_node_types = int(ty_a.max()) + 1 if ty_a is not None and n else 1
+        check(lib().euler_gpu_graph_set_node_sampler(
+            self._h, int(n),
+            None if ids_a is None else ids_a.ctypes.data_as(_lib.u64p),
+            None if ty_a is None else ty_a.ctypes.data_as(_lib.i32p),
+            None if w_a is None else w_a.ctypes.data_as(_lib.f32p), int(n_node_types)))
+
     def sample_node(self, count, node_type=-1, call_id=None):
         """tf_euler sample_node (tf_euler/kernels/sample_node_op.cc:39-98):
         [count] int64 ids drawn by node weight within the type(s)."""

@@ -6,9 +6,10 @@
 // (ncclSend / ncclRecv groups over xGMI) as the transport.  No Python, no torch.
 //
 //   usage: sharded_fanout [n_gpus (default: all visible)] [nodes] [batch]
-// Every rank samples its own batch with fanout [25, 10]; rank 0's GPU also holds
-// the UNSHARDED graph and the program checks that each rank's result equals the
-// unsharded euler_gpu_sample_fanout of the same roots, bit for bit.
+// Every rank samples its own batch with fanout [25, 10] and walks 40 steps from the same
+// roots (euler_gpu_sharded_random_walk, BASELINE configs[3]); rank 0's GPU also holds the
+// UNSHARDED graph and the program checks that each rank's results equal the unsharded
+// euler_gpu_sample_fanout / euler_gpu_random_walk of the same roots, bit for bit.
 // Build: examples/cpp/Makefile (hipcc, -lrccl, ../../euler_amd/lib/libeuler_gpu.so).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -70,7 +71,7 @@ int main(int argc, char** argv) {
   CHECK(euler_gpu_graph_create_synthetic(&sp, 0, 1, 0, 1, &whole) == EULER_GPU_OK);
 
   std::atomic<int> bad(0);
-  std::atomic<long long> checked(0);
+  std::atomic<long long> checked(0), walked(0);
   auto rank_main = [&](int r) {
     CHECK(hipSetDevice(r) == hipSuccess);
     hipStream_t st;
@@ -99,6 +100,20 @@ int main(int argc, char** argv) {
     std::vector<float> gotw((size_t)n2);
     CHECK(hipMemcpy(got.data(), id2, n2 * 8, hipMemcpyDeviceToHost) == hipSuccess);
     CHECK(hipMemcpy(gotw.data(), w2, n2 * 4, hipMemcpyDeviceToHost) == hipSuccess);
+    // configs[3] from the same host: DeepWalk, random_walk of length 40 (p = q = 1) from the
+    // batch's roots over the sharded graph (tf_euler/kernels/random_walk_op.cc:207-247) - one C
+    // call per rank, two cohorts of walkers whose steps alternate on the stream
+    const int32_t WL = 40;
+    std::vector<int32_t> wet((size_t)WL, 0);
+    int64_t* d_walk = nullptr;
+    int64_t wstats[4] = {0, 0, 0, 0};
+    CHECK(hipMalloc((void**)&d_walk, (size_t)B * (WL + 1) * 8) == hipSuccess);
+    CHECK(euler_gpu_sharded_random_walk(shard, &tr, st, seed, 200, (const int64_t*)d_roots, B, wet.data(), 1,
+                                        WL, default_node, N, 2, nullptr, 0, d_walk, wstats) == EULER_GPU_OK);
+    CHECK(hipStreamSynchronize(st) == hipSuccess);
+    std::vector<int64_t> gotwalk((size_t)B * (WL + 1));
+    CHECK(hipMemcpy(gotwalk.data(), d_walk, gotwalk.size() * 8, hipMemcpyDeviceToHost) == hipSuccess);
+    CHECK(wstats[0] == 2 * WL);                       // one host wait per step and cohort
     // the same roots on the unsharded graph (device 0)
     static std::mutex mu;
     std::lock_guard<std::mutex> lk(mu);
@@ -121,6 +136,16 @@ int main(int argc, char** argv) {
     if (memcmp(got.data(), want.data(), (size_t)n2 * 8) != 0 ||
         memcmp(gotw.data(), wantw.data(), (size_t)n2 * 4) != 0) bad = 1;
     checked += n1 + n2;
+    int64_t* u_walk = nullptr;
+    CHECK(hipMalloc((void**)&u_walk, (size_t)B * (WL + 1) * 8) == hipSuccess);
+    CHECK(euler_gpu_random_walk(whole, nullptr, seed, 200, (const int64_t*)u_roots, B, wet.data(), 1, WL,
+                                1.0f, 1.0f, default_node, u_walk) == EULER_GPU_OK);
+    CHECK(hipDeviceSynchronize() == hipSuccess);
+    std::vector<int64_t> wantwalk((size_t)B * (WL + 1));
+    CHECK(hipMemcpy(wantwalk.data(), u_walk, wantwalk.size() * 8, hipMemcpyDeviceToHost) == hipSuccess);
+    if (memcmp(gotwalk.data(), wantwalk.data(), wantwalk.size() * 8) != 0) bad = 1;
+    walked += B * WL;
+    (void)hipFree(u_walk);
     (void)hipFree(u_roots); (void)hipFree(u1); (void)hipFree(u2); (void)hipFree(uw1);
     (void)hipFree(uw2); (void)hipFree(ut1); (void)hipFree(ut2); (void)hipFree(uws);
     euler_gpu_transport_rccl_release(&tr);
@@ -132,7 +157,7 @@ int main(int argc, char** argv) {
   for (auto& t : pool) t.join();
   for (auto& c : comms) ncclCommDestroy(c);
   if (bad) { printf("sharded_fanout MISMATCH\n"); return 1; }
-  printf("sharded_fanout OK: %d rank(s), %lld sampled edges identical to the unsharded graph\n", N,
-         (long long)checked.load());
+  printf("sharded_fanout OK: %d rank(s), %lld sampled edges and %lld walker steps (random_walk of length 40) "
+         "identical to the unsharded graph\n", N, (long long)checked.load(), (long long)walked.load());
   return 0;
 }

@@ -167,6 +167,16 @@ int32_t euler_gpu_graph_partitions(const euler_gpu_graph* g);
 /* Per node type weight sums (Graph::GetNodeWeightSums, used by
  * SAMPLE_NODE_SPLIT); out_host has n_node_types floats. */
 int euler_gpu_graph_node_weight_sums(const euler_gpu_graph* g, float* out_host);
+/* Graph::BuildGlobalSampler (core/graph/graph.cc:333-370) as a call of its own: the global
+ * node sampler (per node type an alias table over weight / type sum, FastWeightedCollection;
+ * a type table over the type sums) of a graph that has none - a synthetic one - or in place
+ * of the one it has.  The n nodes are taken in the order given, which is the order the
+ * reference enumerates node_map_: ids_host NULL = the graph's rows in row order
+ * (strided-identity id maps only), types_host NULL = all type 0, weights_host NULL = all
+ * 1.0f.  Host work, O(n); not to be called while SampleNode calls are in flight. */
+int euler_gpu_graph_set_node_sampler(euler_gpu_graph* g, int64_t n, const uint64_t* ids_host,
+                                     const int32_t* types_host, const float* weights_host,
+                                     int32_t n_node_types);
 /* Copy rows of the device CSR back to the host for the listed ids, in the
  * euler_gpu_host_csr layout (spot checks at sizes no CPU structure can hold).
  * Call with nbr_host == NULL to obtain row_ptr_host (n+1) first. */
@@ -840,6 +850,28 @@ int euler_gpu_sharded_sample_fanout(const euler_gpu_graph* shard,
                                     int64_t default_node, int32_t partitions,
                                     uint64_t* const* out_id_dev, float* const* out_w_dev,
                                     int32_t* const* out_t_dev, void* workspace_dev);
+
+/* TF RandomWalk with p = q = 1 over the sharded graph
+ * (tf_euler/kernels/random_walk_op.cc:207-247: one sampleNB(edge_types, 1) query per step,
+ * each ID_UNIQUE -> ID_SPLIT -> REMOTE -> MERGE -> GATHER): starts_dev [n] int64 ->
+ * out_dev [n, walk_len + 1] int64 (missing neighbour -> default_node), bit-identical to
+ * euler_gpu_random_walk on the unsharded graph.  The walk runs over LEVELS of distinct nodes
+ * (walkers that meet stay together: the draw is keyed by the node), one front end + id
+ * exchange + owners' draw + answer exchange per step, the walkers' paths written once at
+ * the end; the host waits once per step and cohort (the bucket sizes that size the
+ * exchange).  cohorts (1..16, the same on every rank): the walkers are split into that many
+ * independent walks whose steps alternate on `stream`, so the GPU runs one cohort's kernels
+ * while the host waits for another's sizes.  dense_owner_dev / dense_limit: the id-indexed
+ * table of euler_gpu_dedup_split (NULL / 0 = hashing).  stats_host (optional, int64[4]):
+ * host waits, level entries summed over the steps, ids sent to other ranks, cohorts.  All
+ * ranks must call it together (also with n = 0). */
+int euler_gpu_sharded_random_walk(const euler_gpu_graph* shard, const euler_gpu_transport* tr,
+                                  void* stream, uint64_t seed, uint32_t call_id,
+                                  const int64_t* starts_dev, int64_t n,
+                                  const int32_t* edge_types_host, int32_t k, int32_t walk_len,
+                                  int64_t default_node, int32_t partitions, int32_t cohorts,
+                                  uint32_t* dense_owner_dev, int64_t dense_limit,
+                                  int64_t* out_dev, int64_t* stats_host);
 
 /* SAMPLE_NODE_SPLIT (core/kernels/sample_node_split_op.cc:57-85), host only:
  * shard_weight_host[shards+1] (last = total) -> split_cnt_host[shards]. */

@@ -1050,6 +1050,46 @@ def test_sage_dataflow_blocks(EA, O, torch_cuda, big_pair):
     assert [b.size for b in df] == [w[3] for w in want][::-1]
 
 
+def test_sage_blocks_two_host_threads_one_stream(EA, torch_cuda):
+    """Two host threads building blocks on the SAME stream (the null stream; ctypes releases the
+    GIL inside the C call): the stream's row-indexed first-occurrence table is shared, so a call's
+    hops must be enqueued as one run (g->launch_mu) - every block equals the one a single thread
+    builds (B's Insert with a newer epoch used to slip between A's Insert and Flag)."""
+    import threading
+    torch = torch_cuda
+    N = 200_000
+    G = EA.Graph.synthetic(EA.synth_params(9, N, 12 * N, weighted=True))
+    G.set_seed(3)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+    batches = [torch.randint(1, N + 1, (6000,), generator=gen, device="cuda", dtype=torch.int64) for _ in range(2)]
+    fan, mp_ = [6, 4], [[0], [0]]
+
+    def blocks(t, it):
+        return G.sage_blocks(batches[t], mp_, fan, default_node=N + 1, call_id=1000 + 10 * t + 2 * (it % 3))
+    want = [[blocks(t, it) for it in range(3)] for t in range(2)]
+    torch.cuda.synchronize()
+    errs = []
+
+    def work(t):
+        try:
+            for it in range(60):
+                got = blocks(t, it)
+                for (b1, _c1), (b2, _c2) in ((got, want[t][it % 3]),):
+                    for x, y in zip(b1, b2):
+                        for u, v in zip(x, y):
+                            if u is not None and not torch.equal(u, v):
+                                errs.append((t, it))
+                                return
+        except Exception as e:          # noqa: BLE001
+            errs.append((t, repr(e)))
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs
+
+
 def test_gcn_and_relation_dataflow_blocks(EA, O, torch_cuda, big_pair):
     """GCNDataFlow / RelationDataFlow (RGCN, config 5) on device == the same
     composition on the oracle: full neighbours of the unique frontier per hop

@@ -495,6 +495,51 @@ def test_python_example_runs(torch_cuda, capsys, monkeypatch):
         out = capsys.readouterr().out
         assert "ms per training-step input" in out, out
 
+def test_python_deepwalk_example(EA, O, torch_cuda, capsys, monkeypatch):
+    """examples/python/deepwalk_minibatch.py: BaseNode2Vec.to_sample of the reference
+    (examples/deepwalk/deepwalk.py:47-63) on the tf_euler surface - random_walk -> gen_pair ->
+    sample_node(batch * pairs * num_negs) - runs on the fixture directory and on a synthetic graph,
+    and its three outputs equal the same composition on the oracle."""
+    import runpy
+    import sys
+    import torch
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "examples", "python", "deepwalk_minibatch.py")
+    for extra in (["--data", os.path.join(GOLDEN, "fixture_dat"), "--batch", "4"],
+                  ["--nodes", "100000", "--batch", "256", "--walk-len", "5"]):
+        monkeypatch.setattr(sys, "argv", [exe, "--steps", "2"] + extra)
+        mod = runpy.run_path(exe, run_name="__main__")
+        out = capsys.readouterr().out
+        assert "ms per training-step input" in out, out
+    # the composition against the oracle
+    N = 30000
+    p = EA.synth_params(5, N, 8 * N, weighted=True)
+    G = EA.Graph.synthetic(p)
+    rng = np.random.default_rng(3)
+    w = (0.25 + rng.random(N)).astype(np.float32)
+    ty = rng.integers(0, 3, N).astype(np.int32)
+    G.set_node_sampler(None, ty, w, 3)
+    G.set_seed(77, 10)
+    EA.euler_ops.set_default_graph(G)
+    po = O.SynthParams()
+    for f, _ in po._fields_:
+        setattr(po, f, getattr(p, f))
+    csr = O.synth_csr(po)
+    csr.node_type, csr.node_weight = ty, w
+    OG = O.OracleGraph(csr)
+    OG.build_node_sampler()
+    inputs = rng.integers(1, N + 1, 300).astype(np.int64)
+    for (wl, pp, qq, lw, rw, negs, nt) in ((3, 1.0, 1.0, 1, 1, 5, 1), (6, 0.5, 2.0, 2, 1, 3, -1)):
+        G.set_seed(77, 10)
+        src, pos, ng = mod["to_sample"](torch.as_tensor(inputs).cuda(), nt, [0], N, wl, pp, qq, lw, rw, negs)
+        path = OG.random_walk(77, 10, inputs, [[0]] * wl, wl, pp, qq, N + 1)
+        pair = O.gen_pair(path, lw, rw)
+        want_neg = OG.sample_node(77, 10 + wl, [nt], pair.shape[0] * pair.shape[1] * negs)
+        assert np.array_equal(src.cpu().numpy().reshape(-1), pair[..., 0].reshape(-1))
+        assert np.array_equal(pos.cpu().numpy().reshape(-1), pair[..., 1].reshape(-1))
+        assert np.array_equal(ng.cpu().numpy().reshape(-1).view(np.uint64), want_neg)
+
+
 def test_layerwise_weight_func_vs_oracle(EA, O, torch_cuda, lw_pair):
     """sampleLNB with a weight function on a 20 000-node graph: the library (host
     tables in the real std::unordered_map, draws on the device) == the C oracle

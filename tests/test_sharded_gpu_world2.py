@@ -162,6 +162,24 @@ def _worker_body(rank, world, port, partitions):
     assert torch.equal(got, want)
     assert np.array_equal(t2n(got)[:64], OG.random_walk(5, 100, t2n(starts)[:64], etw, L, 1.0,
                                                        1.0, N + 1))
+    # the C entry a C++ host calls (euler_gpu_sharded_random_walk: levels of merged walkers, the
+    # GATHER deferred to the end of the walk) with 1 and 3 cohorts, a rank without walkers, the
+    # hash front end (no id-indexed table), an empty walk; S.random_walk above already ran it
+    from euler_amd.distributed import c_sharded_random_walk
+    assert getattr(S, "c_walk_fn", None) is not None
+    trw = CTransport()
+    for cohorts, dense in ((1, S.dense_table), (3, None)):
+        gotc, stats = c_sharded_random_walk(G_shard, trw, starts, etw, N + 1, 100, partitions, cohorts,
+                                            dense, return_stats=True)
+        assert torch.equal(gotc, want), ("C walk", cohorts)
+        assert stats["host_waits"] == cohorts * L and stats["ids_sent"] > 0
+        # merged walkers: the levels hold fewer entries than walkers x steps
+        assert stats["level_entries"] < starts.numel() * L
+    mine_w = starts[:900] if rank != 0 else starts[:0]
+    gotc = c_sharded_random_walk(G_shard, trw, mine_w, etw[:7], N + 1, 100, partitions, 2, S.dense_table)
+    assert torch.equal(gotc, G_full.random_walk(mine_w, etw[:7], 1.0, 1.0, N + 1, call_id=100))
+    gotc = c_sharded_random_walk(G_shard, trw, starts[:10], [], N + 1, 100, partitions, 2, None)
+    assert torch.equal(gotc.reshape(-1), starts[:10])
     # ... and its node2vec run (p = 0.25, q = 4): every step fetches the rows of the walkers'
     # nodes from their owners and draws on the requester (random_walk_op.cc:83-168)
     etn = [[0]] * 8
@@ -302,8 +320,9 @@ def test_cpp_multi_gpu_host_over_rccl(torch_cuda):
     """examples/cpp/sharded_fanout: a C++ host (no Python, no torch) with one thread per
     GPU, euler_gpu_transport_rccl (ncclSend / ncclRecv groups, resolved at run time) and
     euler_gpu_sharded_sample_fanout; it compares every rank's result with the unsharded
-    graph itself.  One GPU here, so one rank: the exchanges are self sends through RCCL -
-    the code path an 8-GPU node runs with N = 8."""
+    graph itself - the fanout and a random_walk of length 40 (euler_gpu_sharded_random_walk).
+    One GPU here, so one rank: a rank's own ids never leave it (no exchange), the rest is the
+    code path an 8-GPU node runs with N = 8."""
     import subprocess
     exe = os.path.join(ROOT, "examples", "cpp", "sharded_fanout")
     if not os.path.exists(exe):

@@ -13,7 +13,7 @@ for f in glob.glob(os.path.join(out_dir, prefix + "*", "**", "*kernel_trace.csv"
         dur[short].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
 doc = {}
 for k, cs in sorted(res.items()):
-    if not any(w in k for w in ("Sample", "Dedup", "Expand", "Walk", "N2v", "Node2Vec")):
+    if not any(w in k for w in ("Sample", "Dedup", "Expand", "Walk", "N2v", "Node2Vec", "Flow", "Front", "Segment", "Gather", "Cw")):
         continue
     # skip the first dispatch of every kernel (cold caches, lazy allocations)
     doc[k] = {n: round(sum(v[1:]) / max(1, len(v) - 1), 1) if len(v) > 1 else v[0] for n, v in cs.items()}
