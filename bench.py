@@ -120,6 +120,34 @@ def parse():
     return ap.parse_args()
 
 
+_DEFERRED = None        # a list while a process group is up: the line is printed after its teardown
+
+
+def _emit(line, now=False):
+    """Print the JSON line LAST: RCCL prints its version banner through C stdio (fully buffered
+    when stdout is not a terminal, flushed at exit or at the communicator's teardown): runs with
+    a process group defer the line until the group is gone, and C stdio is flushed first."""
+    if _DEFERRED is not None and not now:
+        _DEFERRED.append(line)
+        return
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(line), flush=True)
+
+
+def _teardown(group_up):
+    """Barrier + destroy the process group, then the deferred line(s)."""
+    global _DEFERRED
+    if group_up:
+        dist.barrier()
+        dist.destroy_process_group()
+    pending, _DEFERRED = _DEFERRED or [], None
+    for line in pending:
+        _emit(line, now=True)
+
+
 def _stats(secs, edges_per_round):
     """median / p10 / p90 of per-round wall times -> edges/s (p10 of the time is
     the p90 of the rate)."""
@@ -775,7 +803,7 @@ def run_hetero(args, quiet=False):
             "roofline": roof_s, "cpu_baseline": cpu_s,
         }
         if rank == 0 and not quiet:
-            print(json.dumps(line), flush=True)
+            _emit(line)
         return line
     one_stream = None
     if side is not None:                       # the same steps on ONE stream, for the record
@@ -928,7 +956,7 @@ def run_hetero(args, quiet=False):
         except Exception as e:
             line["cpu_baseline"] = {"error": repr(e)}
     if not quiet:
-        print(json.dumps(line), flush=True)
+        _emit(line)
     del G, feat
     torch.cuda.empty_cache()
     return line
@@ -1060,7 +1088,7 @@ def run_deepwalk(args, G=None, p_g=None, quiet=False):
             "roofline": roof_s, "cpu_baseline": cpu_s,
         }
         if rank == 0 and not quiet:
-            print(json.dumps(line), flush=True)
+            _emit(line)
         return line
 
     def walk_bytes(walks_, n, L_, p, q):
@@ -1127,7 +1155,7 @@ def run_deepwalk(args, G=None, p_g=None, quiet=False):
         except Exception as e:
             line["cpu_baseline"] = {"error": repr(e)}
     if not quiet:
-        print(json.dumps(line), flush=True)
+        _emit(line)
     return line
 
 
@@ -1696,6 +1724,8 @@ def main():
     sharded = (world > 1 and not replicas) or args.force_sharded
     backend = "gloo" if shared_gpus else "nccl"
     if sharded or world > 1:
+        global _DEFERRED
+        _DEFERRED = []
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
         if backend == "nccl":
@@ -1711,9 +1741,7 @@ def main():
         _lib.check(L.euler_gpu_set_tuning(int(k_), int(v_)))
     if args.workload in ("hetero", "deepwalk"):
         (run_hetero if args.workload == "hetero" else run_deepwalk)(args)
-        if sharded or world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
+        _teardown(sharded or world > 1)
         return
     weighted = args.workload != "products"
     if args.workload == "products":
@@ -1808,7 +1836,7 @@ def main():
         """The K steps on the unsharded graph Gx (this rank's whole graph): --streams callers'
         streams alternating; returns (rep_secs, one_stream secs, last outputs, sustained)."""
         def step(i):
-            return Gx.sample_fanout(roots[i], et, FANOUT, default_node, call_id=2 * i)
+            return Gx.sample_fanout(roots[i % n_steps], et, FANOUT, default_node, call_id=2 * (i % n_steps))
 
         n_streams = max(1, args.streams)
         side = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else None
@@ -2231,17 +2259,8 @@ def main():
             },
             "roofline": roofline, "cpu_baseline": cpu,
         }
-        # RCCL prints its version banner through C stdio (fully buffered when stdout is
-        # not a terminal, i.e. flushed at exit - AFTER this line): flush it first so that
-        # the JSON stays the last line of the output
-        try:
-            C.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        print(json.dumps(line), flush=True)
-    if sharded or world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        _emit(line)
+    _teardown(sharded or world > 1)
 
 
 if __name__ == "__main__":

@@ -122,6 +122,12 @@ struct GraphView {
   // reference ships: weight 1.0, 'train' / 'train_removed') get the records alone (wb_lo = 0)
   const uint8_t* trec;
   int32_t trec_stride;
+  // hash id map + at most two edge-type groups: 64-byte hash slots that carry the row's record
+  // {u64 key | u32 wb_lo, row_lo | i32 te[2], f32 lim[2] | f32 ts[2], i64 row | pad}, slot h =
+  // slot h of hash_slots (same probe sequence); an empty slot has te[1] = -1.  The general
+  // builds of the one-kernel fanout (fanout_local.h: FatFind) find a root's record with ONE
+  // cold line instead of slot -> record.  nullptr: not built (T > 2, identity map, no room).
+  const uint8_t* fat;
   int32_t wb_lean_ok;           // at most 2 buckets in a thousand overflow their block (counted at
                                 // build): the lean kernels - whose second chance is the reference's
                                 // bisection - draw through the index; otherwise they keep the pivot

@@ -689,14 +689,51 @@ struct WbSeg {
   uint32_t wb_lo, row_deg;      // the row: first block, edges (the buckets are the ROW's)
   uint32_t lo, deg;             // the listed type's segment: first flat edge, edges
   float row_total, lim_b, lim_e;
-  int64_t row;                  // for the cold path (which reloads what it needs)
+  uint32_t row_lo;              // the row's first flat edge: the cold path replays RandomSelect over
+                                // prefix_w + row_lo (the sums restart at every row)
 };
+
+// Graphs with a hash id map and at most two edge-type groups (what a converted dataset looks
+// like: arbitrary ids, 'train' / 'train_removed'): the hash slot CARRIES the row's record
+// (common.h: GraphView::fat - 64 bytes: key | wb_lo row_lo | te[2] lim[2] | ts[2] row), so a
+// cold root / child costs one line where the 16-byte slot + the record cost two dependent
+// ones.  Same slot index as the 16-byte table (same probe sequence).  Returns false on a miss.
+__device__ __forceinline__ bool FatFind(const GraphView& g, const uint64_t id, uint4* hd, uint4* tl,
+                                        const uint4** slot) {
+  uint64_t h = Mix64(id) & g.hash_mask;
+  for (uint64_t probes = 0; probes <= g.hash_mask; ++probes) {
+    const uint4* s = reinterpret_cast<const uint4*>(g.fat + h * 64);
+    const uint4 a = s[0], b = s[1];
+    if ((int32_t)b.y == -1) return false;                       // empty slot: no such node
+    if (a.x == (uint32_t)id && a.y == (uint32_t)(id >> 32)) { *hd = a; *tl = b; *slot = s; return true; }
+    h = (h + 1) & g.hash_mask;
+  }
+  return false;
+}
 
 __device__ __forceinline__ void LoadWbSeg(const GraphView& g, uint64_t node, int32_t t, WbSeg* s) {
   s->wb_lo = 0; s->row_deg = 0; s->lo = 0; s->deg = 0; s->row_total = 0.f; s->lim_b = 0.f; s->lim_e = 0.f;
-  s->row = FindRow(g, node);
-  if (s->row < 0 || t < 0 || t >= g.T) return;
-  const uint8_t* wrec = g.trec + s->row * (int64_t)g.trec_stride;
+  s->row_lo = 0;
+  if (g.fat != nullptr) {
+    uint4 hd, tl;
+    const uint4* slot;
+    if (t < 0 || t >= g.T || !FatFind(g, node, &hd, &tl, &slot)) return;
+    const int32_t te0 = (int32_t)tl.x, te1 = (int32_t)tl.y;
+    const float lim0 = __uint_as_float(tl.z), lim1 = __uint_as_float(tl.w);
+    const int32_t b = t == 0 ? 0 : te0, e = t == 0 ? te0 : te1;
+    s->wb_lo = hd.z;
+    s->row_lo = hd.w;
+    s->row_deg = (uint32_t)(g.T == 1 ? te0 : te1);
+    s->row_total = g.T == 1 ? lim0 : lim1;
+    s->lim_e = t == 0 ? lim0 : lim1;
+    s->lim_b = t == 0 ? 0.f : lim0;
+    s->lo = hd.w + (uint32_t)b;
+    s->deg = e > b ? (uint32_t)(e - b) : 0u;
+    return;
+  }
+  const int64_t row = FindRow(g, node);
+  if (row < 0 || t < 0 || t >= g.T) return;
+  const uint8_t* wrec = g.trec + row * (int64_t)g.trec_stride;
   const uint32_t* hd = reinterpret_cast<const uint32_t*>(wrec);
   const int32_t* te = reinterpret_cast<const int32_t*>(wrec + 8);
   const float* lim = reinterpret_cast<const float*>(wrec + 8 + 4 * g.T);
@@ -707,6 +744,7 @@ __device__ __forceinline__ void LoadWbSeg(const GraphView& g, uint64_t node, int
   s->lim_e = lim[t];
   s->lim_b = t == 0 ? 0.f : lim[t - 1];
   s->lo = hd[1] + (uint32_t)b;
+  s->row_lo = hd[1];
   s->deg = e > b ? (uint32_t)(e - b) : 0u;
 }
 
@@ -751,15 +789,16 @@ __device__ __forceinline__ void WbSamplePairG2(const GraphView& g, const WbSeg s
 #pragma nounroll
     for (int s = 0; s < (TWO ? 2 : 1); ++s) {
       if (s == 0 ? cold0 : cold1) {
-        const int32_t t = s == 0 ? t0 : t1;
-        const RowMeta rm = LoadRowMeta(g, sg0.row);
-        const float* nw = g.prefix_w + rm.row_ptr;
-        const int32_t b = t == 0 ? 0 : rm.type_end[t - 1];
-        const uint32_t mid = (uint32_t)RandomSelect(nw, (uint64_t)b, (uint64_t)(rm.type_end[t] - 1), s == 0 ? u0 : u1);
-        const uint64_t ci = g.nbr[rm.row_ptr + mid];
+        // the reference's bisection over the group's running sums (they restart at the row's
+        // first edge: positions are row-relative, b = the group's first)
+        const WbSeg& sg = s == 0 ? sg0 : sg1;
+        const float* nw = g.prefix_w + sg.row_lo;
+        const uint32_t b = sg.lo - sg.row_lo;
+        const uint32_t mid = (uint32_t)RandomSelect(nw, (uint64_t)b, (uint64_t)(b + sg.deg - 1u), s == 0 ? u0 : u1);
+        const uint64_t ci = g.nbr[sg.row_lo + mid];
         const float cw = __fsub_rn(nw[mid], mid == 0u ? 0.f : nw[mid - 1]);
-        if (s == 0) { id[0] = ci; w[0] = cw; m[0] = (uint32_t)(rm.row_ptr + mid); }
-        else { id[1] = ci; w[1] = cw; m[1] = (uint32_t)(rm.row_ptr + mid); }
+        if (s == 0) { id[0] = ci; w[0] = cw; m[0] = sg.row_lo + mid; }
+        else { id[1] = ci; w[1] = cw; m[1] = sg.row_lo + mid; }
       }
     }
   }
@@ -827,7 +866,7 @@ __device__ __forceinline__ bool WbTypedSeg(const GraphView& g, const WbRowT& r, 
   s->lim_b = t == 0 ? 0.f : r.lim[t - 1];
   s->lo = r.row_lo + (uint32_t)b;
   s->deg = e > b ? (uint32_t)(e - b) : 0u;
-  s->row = r.row;
+  s->row_lo = r.row_lo;
   *t_out = t;
   return e > b;
 }
@@ -844,7 +883,7 @@ __device__ __forceinline__ void WbSampleTypedPair(const GraphView& g, const WbRo
   const Philox4 pa = RngBlock(seed, call, kDomainNeighbor, node, 2u * jp);
   const Philox4 pb = RngBlock(seed, call, kDomainNeighbor, node, 2u * jp + 1u);
   WbSeg sg0, sg1;
-  sg0.wb_lo = 0; sg0.row_deg = 0; sg0.lo = 0; sg0.deg = 0; sg0.row_total = 0.f; sg0.lim_b = 0.f; sg0.lim_e = 0.f; sg0.row = -1;
+  sg0.wb_lo = 0; sg0.row_deg = 0; sg0.lo = 0; sg0.deg = 0; sg0.row_total = 0.f; sg0.lim_b = 0.f; sg0.lim_e = 0.f; sg0.row_lo = 0;
   sg1 = sg0;
   tt[0] = -1; tt[1] = -1;
   bool ok0 = false, ok1 = false;
@@ -902,9 +941,23 @@ __device__ __forceinline__ void LoadWbRowT4(const GraphView& g, const uint64_t n
   r->wb_lo = 0; r->row_lo = 0; r->row_deg = 0; r->row_total = 0.f; r->valid = false;
 #pragma unroll
   for (int i = 0; i < 4; ++i) { r->te[i] = 0; r->lim[i] = 0.f; r->ts[i] = 0.f; }
+  const int32_t T = g.T;
+  if (g.fat != nullptr) {              // T <= 2: the record rides in the hash slot
+    uint4 hd, tl;
+    const uint4* slot;
+    if (!FatFind(g, node, &hd, &tl, &slot)) { r->row = -1; return; }
+    const uint4 x = slot[2];
+    r->row = 0;
+    r->wb_lo = hd.z; r->row_lo = hd.w;
+    const int32_t te0 = (int32_t)tl.x, te1 = (int32_t)tl.y;
+    const float lim0 = __uint_as_float(tl.z), lim1 = __uint_as_float(tl.w);
+    const float ts0 = __uint_as_float(x.x), ts1 = __uint_as_float(x.y);
+    r->te[0] = te0; r->lim[0] = lim0; r->ts[0] = ts0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) { r->te[i] = te1; r->lim[i] = lim1; r->ts[i] = ts1; }
+  } else {
   r->row = FindRow(g, node);
   if (r->row < 0) return;
-  const int32_t T = g.T;
   const uint8_t* rec = g.trec + r->row * (int64_t)g.trec_stride;
   const uint32_t* hd = reinterpret_cast<const uint32_t*>(rec);
   const int32_t* te = reinterpret_cast<const int32_t*>(rec + 8);
@@ -915,6 +968,7 @@ __device__ __forceinline__ void LoadWbRowT4(const GraphView& g, const uint64_t n
   for (int i = 0; i < 4; ++i) {           // entries past T repeat the last one (never selected)
     const int x = i < T ? i : T - 1;
     r->te[i] = te[x]; r->lim[i] = lim[x]; r->ts[i] = ts[x];
+  }
   }
   r->row_deg = (uint32_t)r->te[3];
   r->row_total = r->lim[3];
@@ -941,7 +995,7 @@ __device__ __forceinline__ bool WbTypedSeg4(const GraphView& g, const WbRowT4& r
   s->lim_b = t == 0 ? 0.f : At4(r.lim, t - 1);
   s->lo = r.row_lo + (uint32_t)b;
   s->deg = e > b ? (uint32_t)(e - b) : 0u;
-  s->row = r.row;
+  s->row_lo = r.row_lo;
   *t_out = t;
   return e > b;
 }
@@ -970,15 +1024,16 @@ __device__ __forceinline__ void UniformSamplePairG2(const GraphView& g, const Wb
 #pragma nounroll
     for (int s = 0; s < 2; ++s) {
       if (s == 0 ? cold0 : cold1) {
-        const int32_t t = s == 0 ? t0 : t1;
-        const RowMeta rm = LoadRowMeta(g, sg0.row);
-        const float* nw = g.prefix_w + rm.row_ptr;
-        const int32_t b = t == 0 ? 0 : rm.type_end[t - 1];
-        const uint32_t mid = (uint32_t)RandomSelect(nw, (uint64_t)b, (uint64_t)(rm.type_end[t] - 1), s == 0 ? u0 : u1);
-        const uint64_t ci = g.nbr[rm.row_ptr + mid];
+        // the reference's bisection over the group's running sums (they restart at the row's
+        // first edge: positions are row-relative, b = the group's first)
+        const WbSeg& sg = s == 0 ? sg0 : sg1;
+        const float* nw = g.prefix_w + sg.row_lo;
+        const uint32_t b = sg.lo - sg.row_lo;
+        const uint32_t mid = (uint32_t)RandomSelect(nw, (uint64_t)b, (uint64_t)(b + sg.deg - 1u), s == 0 ? u0 : u1);
+        const uint64_t ci = g.nbr[sg.row_lo + mid];
         const float cw = __fsub_rn(nw[mid], mid == 0u ? 0.f : nw[mid - 1]);
-        if (s == 0) { id[0] = ci; w[0] = cw; m[0] = (uint32_t)(rm.row_ptr + mid); }
-        else { id[1] = ci; w[1] = cw; m[1] = (uint32_t)(rm.row_ptr + mid); }
+        if (s == 0) { id[0] = ci; w[0] = cw; m[0] = sg.row_lo + mid; }
+        else { id[1] = ci; w[1] = cw; m[1] = sg.row_lo + mid; }
       }
     }
   }
@@ -994,7 +1049,7 @@ __device__ __forceinline__ void WbSampleTypedPair4(const GraphView& g, const WbR
   const Philox4 pa = RngBlock(seed, call, kDomainNeighbor, node, 2u * jp);
   const Philox4 pb = RngBlock(seed, call, kDomainNeighbor, node, 2u * jp + 1u);
   WbSeg sg0, sg1;
-  sg0.wb_lo = 0; sg0.row_deg = 0; sg0.lo = 0; sg0.deg = 0; sg0.row_total = 0.f; sg0.lim_b = 0.f; sg0.lim_e = 0.f; sg0.row = -1;
+  sg0.wb_lo = 0; sg0.row_deg = 0; sg0.lo = 0; sg0.deg = 0; sg0.row_total = 0.f; sg0.lim_b = 0.f; sg0.lim_e = 0.f; sg0.row_lo = 0;
   sg1 = sg0;
   tt[0] = -1; tt[1] = -1;
   bool ok0 = false, ok1 = false;
@@ -1103,7 +1158,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
       uint64_t node = 0;
       WbRec wr{0u, 0u, 0u, 0.f};
       WbSeg ws;
-      if (WB == 2 || WB == 6) { ws.wb_lo = 0; ws.row_deg = 0; ws.lo = 0; ws.deg = 0; ws.row_total = 0.f; ws.lim_b = 0.f; ws.lim_e = 0.f; ws.row = -1; }
+      if (WB == 2 || WB == 6) { ws.wb_lo = 0; ws.row_deg = 0; ws.lo = 0; ws.deg = 0; ws.row_total = 0.f; ws.lim_b = 0.f; ws.lim_e = 0.f; ws.row_lo = 0; }
       WbRowT wt;
       WbRowT4 w4;
       if (WB == 3) { wt.hd = nullptr; wt.te = nullptr; wt.lim = nullptr; wt.tsum = nullptr; wt.row = -1; wt.row_lo = 0; wt.row_deg = 0; wt.valid = false; }
@@ -1253,7 +1308,7 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutLeanKernel(
         uint64_t node = 0;
         WbRec wr{0u, 0u, 0u, 0.f};
         WbSeg ws;
-        if (WB == 2 || WB == 6) { ws.wb_lo = 0; ws.row_deg = 0; ws.lo = 0; ws.deg = 0; ws.row_total = 0.f; ws.lim_b = 0.f; ws.lim_e = 0.f; ws.row = -1; }
+        if (WB == 2 || WB == 6) { ws.wb_lo = 0; ws.row_deg = 0; ws.lo = 0; ws.deg = 0; ws.row_total = 0.f; ws.lim_b = 0.f; ws.lim_e = 0.f; ws.row_lo = 0; }
         WbRowT wt;
         WbRowT4 w4;
         if (WB == 3) { wt.hd = nullptr; wt.te = nullptr; wt.lim = nullptr; wt.tsum = nullptr; wt.row = -1; wt.row_lo = 0; wt.row_deg = 0; wt.valid = false; }

@@ -864,6 +864,49 @@ __global__ __launch_bounds__(256) void WbFillKernel(GraphView g, const uint32_t*
   if (mine != 0) atomicAdd(overflows, mine);
 }
 
+// 64-byte hash slots carrying the row record (common.h: GraphView::fat)
+__global__ __launch_bounds__(256) void FatFillKernel(GraphView g, const uint8_t* trec, int32_t trec_stride,
+                                                     uint8_t* fat) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h <= g.hash_mask; h += stride) {
+    const uint64_t key = g.hash_slots[2 * h];
+    const int64_t row = (int64_t)g.hash_slots[2 * h + 1];
+    uint4 a = make_uint4(0u, 0u, 0u, 0u), b = make_uint4(0u, 0xFFFFFFFFu, 0u, 0u), c = make_uint4(0u, 0u, 0u, 0u);
+    if (row >= 0) {
+      const uint8_t* rec = trec + row * (int64_t)trec_stride;
+      const uint32_t* hd = reinterpret_cast<const uint32_t*>(rec);
+      const int32_t* te = reinterpret_cast<const int32_t*>(rec + 8);
+      const float* lim = reinterpret_cast<const float*>(rec + 8 + 4 * g.T);
+      const RowMeta m = LoadRowMeta(g, row);
+      const int32_t t1 = g.T - 1;                        // T == 1: both entries are group 0
+      a = make_uint4((uint32_t)key, (uint32_t)(key >> 32), hd[0], hd[1]);
+      b = make_uint4((uint32_t)te[0], (uint32_t)te[t1], __float_as_uint(lim[0]), __float_as_uint(lim[t1]));
+      c = make_uint4(__float_as_uint(m.type_prefix[0]), __float_as_uint(m.type_prefix[t1]),
+                     (uint32_t)(uint64_t)row, (uint32_t)((uint64_t)row >> 32));
+    }
+    uint4* out = reinterpret_cast<uint4*>(fat + h * 64);
+    out[0] = a; out[1] = b; out[2] = c; out[3] = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+
+bool WbFits(size_t need);
+
+// after the row records exist (v.trec): the fat slots of a hashed graph with T <= 2
+int BuildFatSlots(GraphBuilder* b) {
+  GraphView& v = b->g->view;
+  if (v.map_mode != 1 || v.T > 2 || v.trec == nullptr || v.hash_slots == nullptr) return EULER_GPU_OK;
+  const size_t bytes = ((size_t)v.hash_mask + 1) * 64;
+  if (!WbFits(bytes)) return EULER_GPU_OK;
+  uint8_t* fat = b->Alloc<uint8_t>(bytes);
+  if (b->rc != EULER_GPU_OK) return b->rc;
+  hipLaunchKernelGGL(FatFillKernel, dim3(GridFor((int64_t)v.hash_mask + 1, 256)), dim3(256), 0, 0, v, v.trec,
+                     v.trec_stride, fat);
+  EG_HIP(hipGetLastError());
+  EG_HIP(hipDeviceSynchronize());
+  v.fat = fat;
+  return EULER_GPU_OK;
+}
+
 // How much HBM the weight-bucket index may take: at most `g_wb_budget_frac` of what
 // is free when it is built (default one half - the rest stays for the caller's features, model
 // and activations, which are usually allocated AFTER the first sampling call) and at most
@@ -919,7 +962,7 @@ int BuildWbIndex(GraphBuilder* b) {
     EG_HIP(hipGetLastError());
     EG_HIP(hipDeviceSynchronize());
     v.trec = trec; v.trec_stride = stride;
-    return EULER_GPU_OK;
+    return BuildFatSlots(b);
   }
   // rows must be non-decreasing (the keys decide by counting) and worth a search at all;
   // 32-bit edge and block numbers
@@ -982,7 +1025,7 @@ int BuildWbIndex(GraphBuilder* b) {
   v.trec = wbg; v.trec_stride = stride;
   // (i.i.d. uniform weights: 1e-4; lognormal sigma 2, Pareto alpha 0.7: ~5e-2)
   v.wb_lean_ok = (double)n_ovf <= 0.002 * (double)n_wb ? 1 : 0;
-  return EULER_GPU_OK;
+  return BuildFatSlots(b);
 }
 
 int EnsureWbIndex(const euler_gpu_graph* cg) {
@@ -1010,7 +1053,7 @@ int EnsureWbIndex(const euler_gpu_graph* cg) {
     g->bytes = bytes0;
     GraphView& v = g->view;
     v.wb = nullptr; v.wbg = nullptr; v.wrec = nullptr; v.n_wb = 0; v.wb_lean_ok = 0;
-    v.trec = nullptr; v.trec_stride = 0;
+    v.trec = nullptr; v.trec_stride = 0; v.fat = nullptr;
   }
   (void)hipSetDevice(prev);
   g->wb_tried.store(1, std::memory_order_release);

@@ -14,8 +14,10 @@
 #include "device_fns.h"
 
 struct euler_gpu_front {
-  int64_t* stage = nullptr;      // pinned, kMaxShards + 1
+  int64_t* stage = nullptr;      // pinned + mapped: [kMaxShards + 1] bucket starts, then the sequence word
+  int64_t* stage_dev = nullptr;  // the same buffer as the kernels address it
   hipEvent_t done = nullptr;
+  int64_t seq = 0;               // sequence number of the call in flight (the kernel echoes it)
   int32_t shards = 0;
   int32_t pending = 0;           // a begin without its end
 };
@@ -1207,19 +1209,32 @@ __global__ __launch_bounds__(256) void DedupIdsMark2Kernel(const DedupIdsArgs a)
   }
 }
 
-// ---- v2 front end: representatives -> per-(shard, block) counts -> scan ->
-// bucketed index, one host sync.  (The first version numbered the distinct ids
-// with a scan, copied the count to the host, ran ID_SPLIT on them with a second
-// sync and `shards` more 8-byte device-to-host copies at ~40 us each, then
-// inverted and composed two index maps: 0.61 ms for the metric's hop 2 on 8
-// shards, most of it host time.)
+// ---- v3 front end (round 5): representatives -> places, THREE launches, no scan, the bucket
+// sizes written straight into pinned host memory.
+//   mark      owner[slot(id)] = position (plain stores; block 0 also clears the shard totals)
+//   rep/hist  a workgroup takes a chunk of kFrontChunk positions: representative of every
+//             position; a representative takes its rank within (chunk, owner shard) from an
+//             LDS counter; the chunk adds its per-shard counts to the shard totals with ONE
+//             global atomic per shard and keeps what it got back - its base in the bucket
+//   place     bucket start of a shard = the totals before it (<= 64 numbers, summed by every
+//             workgroup itself); place of a representative = start + chunk base + rank;
+//             pos[i] = place of i's representative; block 0 writes the starts into the
+//             caller's pinned buffer and then the call's sequence number - the host polls it.
+// The order inside a bucket is the arrival order of the chunks' atomics: arbitrary, like the
+// choice of representatives (plain-store races) - results never depend on either, the rows
+// come back in the order asked and pos[] is their map.  (v2: per-(shard, block) histogram ->
+// hipcub scan -> scatter -> compose -> 8-byte copy to the host: six launches and a copy; v1:
+// 0.61 ms for the metric's hop 2 on 8 shards, most of it host time.)
+constexpr int kFrontChunk = 2048;
 struct FrontArgs {
   DedupIdsArgs d;            // ids / mask / hash tables (hash mode)
   uint32_t* dense_owner;     // dense mode: [dense_limit + 1], slot = id (or the limit)
   uint64_t dense_limit;
   uint32_t* rep;             // [n] representative of every position
-  int32_t* bidx;             // [n] bucketed index, valid at representatives
-  int64_t* block_hist;       // [shards, n_blocks]
+  uint32_t* place;           // [n] at representatives: owner shard << 16 | rank within (chunk, shard)
+  uint32_t* chunk_base;      // [shards, n_chunks] base of the chunk's representatives in the bucket
+  uint32_t* total;           // [kMaxShards] representatives per shard
+  int64_t n_chunks;
   int32_t partitions, shards;
 };
 
@@ -1231,71 +1246,63 @@ __device__ __forceinline__ uint32_t DenseSlot(const FrontArgs& a, uint64_t id) {
 // DedupMarkKernel); every id >= the limit is "no such node" and shares a slot -
 // whichever owner answers for its representative answers the default row
 __global__ __launch_bounds__(256) void FrontMarkDenseKernel(const FrontArgs a) {
+  if (blockIdx.x == 0 && threadIdx.x < kMaxShards) a.total[threadIdx.x] = 0u;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.d.n; i += stride)
     a.dense_owner[DenseSlot(a, DedupIdAt(a.d, i))] = (uint32_t)i;
 }
 
-// one position per thread: its representative, and the block's count of
-// representatives per owner shard
-__global__ __launch_bounds__(kSplitBlock) void FrontRepHistKernel(const FrontArgs a) {
+__global__ void FrontClearTotalsKernel(uint32_t* total) { total[threadIdx.x] = 0u; }
+
+__global__ __launch_bounds__(256) void FrontRepHistKernel(const FrontArgs a) {
   const bool DENSE = a.dense_owner != nullptr;
-  __shared__ int32_t hist[kMaxShards];
-  if (threadIdx.x < kMaxShards) hist[threadIdx.x] = 0;
+  __shared__ uint32_t hist[kMaxShards];
+  if (threadIdx.x < kMaxShards) hist[threadIdx.x] = 0u;
   __syncthreads();
-  const int64_t i = (int64_t)blockIdx.x * kSplitBlock + threadIdx.x;
-  if (i < a.d.n) {
-    const uint64_t id = DedupIdAt(a.d, i);
-    const uint32_t r = DENSE ? a.dense_owner[DenseSlot(a, id)] : DedupRep(a.d, (uint32_t)i);
-    a.rep[i] = r;
-    if (r == (uint32_t)i) atomicAdd(&hist[OwnerOf(id, a.partitions, a.shards)], 1);
+  const int64_t base = (int64_t)blockIdx.x * kFrontChunk;
+#pragma unroll 2
+  for (int32_t k = 0; k < kFrontChunk / 256; ++k) {
+    const int64_t i = base + (int64_t)k * 256 + threadIdx.x;
+    if (i < a.d.n) {
+      const uint64_t id = DedupIdAt(a.d, i);
+      const uint32_t r = DENSE ? a.dense_owner[DenseSlot(a, id)] : DedupRep(a.d, (uint32_t)i);
+      a.rep[i] = r;
+      if (r == (uint32_t)i) {
+        const uint32_t own = (uint32_t)OwnerOf(id, a.partitions, a.shards);
+        a.place[i] = own << 16 | atomicAdd(&hist[own], 1u);
+      }
+    }
   }
   __syncthreads();
   if ((int)threadIdx.x < a.shards)
-    a.block_hist[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = hist[threadIdx.x];
+    a.chunk_base[(int64_t)threadIdx.x * a.n_chunks + blockIdx.x] =
+        hist[threadIdx.x] != 0u ? atomicAdd(&a.total[threadIdx.x], hist[threadIdx.x]) : 0u;
 }
 
-// representatives take their place in their shard's bucket
-__global__ __launch_bounds__(kSplitBlock) void FrontScatterKernel(
-    const FrontArgs a, const int64_t* block_off, uint64_t* shard_ids) {
-  __shared__ int32_t wave_cnt[kSplitBlock / 64][kMaxShards];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t i = (int64_t)blockIdx.x * kSplitBlock + threadIdx.x;
-  const bool is_rep = i < a.d.n && a.rep[i] == (uint32_t)i;
-  const uint64_t id = is_rep ? DedupIdAt(a.d, i) : 0;
-  const int32_t own = is_rep ? OwnerOf(id, a.partitions, a.shards) : -1;
-  int32_t rank_in_wave = 0;
-  for (int32_t s = 0; s < a.shards; ++s) {
-    const unsigned long long m = __ballot(own == s);
-    if (own == s) rank_in_wave = __popcll(m & ((1ULL << lane) - 1));
-    if (lane == 0) wave_cnt[wave][s] = __popcll(m);
+__global__ __launch_bounds__(256) void FrontPlaceKernel(const FrontArgs a, uint64_t* __restrict__ shard_ids,
+                                                        int32_t* __restrict__ pos_out,
+                                                        volatile int64_t* stage, const int64_t seq) {
+  __shared__ uint32_t bstart[kMaxShards + 1];
+  if (threadIdx.x == 0) {
+    uint32_t acc = 0;
+    for (int32_t s = 0; s < a.shards; ++s) { bstart[s] = acc; acc += a.total[s]; }
+    bstart[a.shards] = acc;
+    if (blockIdx.x == 0) {           // the host waits for exactly this: sizes first, then the echo
+      for (int32_t s = 0; s <= a.shards; ++s) stage[s] = (int64_t)bstart[s];
+      __threadfence_system();
+      stage[kMaxShards + 1] = seq;
+    }
   }
   __syncthreads();
-  if (is_rep) {
-    int32_t before = 0;
-    for (int w = 0; w < wave; ++w) before += wave_cnt[w][own];
-    const int64_t q = block_off[(int64_t)own * gridDim.x + blockIdx.x] + before + rank_in_wave;
-    shard_ids[q] = id;
-    a.bidx[i] = (int32_t)q;
-  }
-}
-
-// pos[i] = bucketed index of position i's id; block 0 also collects the shard
-// starts (and the total) into one contiguous array for a single copy
-__global__ __launch_bounds__(256) void FrontComposeKernel(const FrontArgs a,
-                                                          const int64_t* block_off,
-                                                          int64_t n_blocks, int32_t* pos_out,
-                                                          int64_t* starts /* [shards + 1] */) {
-  if (blockIdx.x == 0 && (int)threadIdx.x <= a.shards) {
-    const int s = threadIdx.x;
-    starts[s] = s < a.shards
-                    ? block_off[(int64_t)s * n_blocks]
-                    : block_off[(int64_t)a.shards * n_blocks - 1] +
-                          a.block_hist[(int64_t)a.shards * n_blocks - 1];
-  }
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.d.n; i += stride)
-    pos_out[i] = a.bidx[a.rep[i]];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.d.n; i += stride) {
+    const uint32_t r = a.rep[i];
+    const uint32_t w = a.place[r];
+    const uint32_t own = w >> 16;
+    const uint32_t q = bstart[own] + a.chunk_base[(int64_t)own * a.n_chunks + r / kFrontChunk] + (w & 0xFFFFu);
+    pos_out[i] = (int32_t)q;
+    if (r == (uint32_t)i) shard_ids[q] = DedupIdAt(a.d, i);
+  }
 }
 
 // Grow-only device scratch per (device, stream) for the front end: it runs
@@ -1346,12 +1353,16 @@ int euler_gpu_front_create(euler_gpu_front** out) {
   if (!out) return Fail(EULER_GPU_EINVAL, "front_create: null");
   euler_gpu_front* f = new (std::nothrow) euler_gpu_front();
   if (!f) return Fail(EULER_GPU_ENOMEM, "front_create: out of memory");
-  if (hipHostMalloc((void**)&f->stage, (kMaxShards + 1) * sizeof(int64_t)) != hipSuccess ||
+  if (hipHostMalloc((void**)&f->stage, (kMaxShards + 2) * sizeof(int64_t),
+                    hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&f->stage_dev, f->stage, 0) != hipSuccess ||
       hipEventCreateWithFlags(&f->done, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
     if (f->stage) (void)hipHostFree(f->stage);
     delete f;
     return Fail(EULER_GPU_ENOMEM, "front_create: pinned buffer / event");
   }
+  f->stage[kMaxShards + 1] = 0;
   *out = f;
   return EULER_GPU_OK;
 }
@@ -1385,19 +1396,13 @@ int euler_gpu_dedup_split_begin(euler_gpu_front* f, void* stream, const uint64_t
   uint64_t cap = 1024;
   while (!dense && cap < (uint64_t)n * 4) cap <<= 1;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  const int64_t n_blocks = (n + kSplitBlock - 1) / kSplitBlock;
-  const int64_t cells = n_blocks * shards;
+  const int64_t n_chunks = (n + kFrontChunk - 1) / kFrontChunk;
   const size_t o_owner = 0, o_owner2 = o_owner + (dense ? 0 : al(cap * 4));
   const size_t o_rep = o_owner2 + (dense ? 0 : al(cap * 4));
-  const size_t o_bidx = o_rep + al((size_t)n * 4);
-  const size_t o_hist = o_bidx + al((size_t)n * 4);
-  const size_t o_off = o_hist + al((size_t)(cells + 1) * 8);
-  const size_t o_starts = o_off + al((size_t)(cells + 1) * 8);
-  size_t scan_bytes = 0;
-  EG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (const int64_t*)nullptr,
-                                          (int64_t*)nullptr, (int)cells, st));
-  const size_t o_scan = o_starts + al((size_t)(shards + 1) * 8);
-  const size_t bytes = o_scan + al(scan_bytes + 16);
+  const size_t o_place = o_rep + al((size_t)n * 4);
+  const size_t o_base = o_place + al((size_t)n * 4);
+  const size_t o_total = o_base + al((size_t)n_chunks * shards * 4);
+  const size_t bytes = o_total + al(kMaxShards * 4);
   StreamScratch* scratch = ScratchEntry(st);
   std::lock_guard<std::mutex> scratch_lk(scratch->mu);
   uint8_t* buf = nullptr;
@@ -1415,38 +1420,28 @@ int euler_gpu_dedup_split_begin(euler_gpu_front* f, void* stream, const uint64_t
   a.dense_owner = dense_owner_dev;
   a.dense_limit = (uint64_t)dense_limit;
   a.rep = (uint32_t*)(buf + o_rep);
-  a.bidx = (int32_t*)(buf + o_bidx);
-  a.block_hist = (int64_t*)(buf + o_hist);
+  a.place = (uint32_t*)(buf + o_place);
+  a.chunk_base = (uint32_t*)(buf + o_base);
+  a.total = (uint32_t*)(buf + o_total);
+  a.n_chunks = n_chunks;
   a.partitions = partitions; a.shards = shards;
-  int64_t* off = (int64_t*)(buf + o_off);
-  int64_t* starts = (int64_t*)(buf + o_starts);
   const int block = 256;
   const int grid = GridFor(n, block);
   int rc = EULER_GPU_OK;
   if (dense) {
     hipLaunchKernelGGL(FrontMarkDenseKernel, dim3(grid), dim3(block), 0, st, a);
-    hipLaunchKernelGGL(FrontRepHistKernel, dim3((unsigned)n_blocks), dim3(kSplitBlock),
-                       0, st, a);
   } else {
+    hipLaunchKernelGGL(FrontClearTotalsKernel, dim3(1), dim3(kMaxShards), 0, st, a.total);
     hipLaunchKernelGGL(DedupIdsMarkKernel, dim3(grid), dim3(block), 0, st, a.d);
     hipLaunchKernelGGL(DedupIdsMark2Kernel, dim3(grid), dim3(block), 0, st, a.d);
-    hipLaunchKernelGGL(FrontRepHistKernel, dim3((unsigned)n_blocks), dim3(kSplitBlock),
-                       0, st, a);
   }
-  if (hipcub::DeviceScan::ExclusiveSum(buf + o_scan, scan_bytes, (const int64_t*)a.block_hist,
-                                       off, (int)cells, st) != hipSuccess)
-    rc = Fail(EULER_GPU_EHIP, "dedup_split: scan failed");
+  hipLaunchKernelGGL(FrontRepHistKernel, dim3((unsigned)n_chunks), dim3(256), 0, st, a);
+  f->seq += 1;
+  hipLaunchKernelGGL(FrontPlaceKernel, dim3(grid), dim3(block), 0, st, a, shard_ids_dev, pos_dev,
+                     (volatile int64_t*)f->stage_dev, f->seq);
+  if (hipGetLastError() != hipSuccess) rc = Fail(EULER_GPU_EHIP, "dedup_split: launch failed");
   if (rc == EULER_GPU_OK) {
-    hipLaunchKernelGGL(FrontScatterKernel, dim3((unsigned)n_blocks), dim3(kSplitBlock), 0, st,
-                       a, off, shard_ids_dev);
-    hipLaunchKernelGGL(FrontComposeKernel, dim3(grid), dim3(block), 0, st, a, off, n_blocks,
-                       pos_dev, starts);
-    if (hipGetLastError() != hipSuccess) rc = Fail(EULER_GPU_EHIP, "dedup_split: launch failed");
-  }
-  if (rc == EULER_GPU_OK) {
-    hipError_t e = hipMemcpyAsync(f->stage, starts, (size_t)(shards + 1) * 8,
-                                  hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipEventRecord(f->done, st);
+    const hipError_t e = hipEventRecord(f->done, st);
     if (e != hipSuccess) rc = Fail(EULER_GPU_EHIP, std::string("dedup_split: ") + hipGetErrorString(e));
     else f->pending = 1;
   }
@@ -1458,12 +1453,31 @@ int euler_gpu_dedup_split_begin(euler_gpu_front* f, void* stream, const uint64_t
 int euler_gpu_dedup_split_end(euler_gpu_front* f, int64_t* shard_off_host) {
   if (!f || !shard_off_host) return Fail(EULER_GPU_EINVAL, "dedup_split_end: null");
   if (f->pending) {
-    const hipError_t e = hipEventSynchronize(f->done);
+    // the place kernel's first workgroup writes the bucket starts into the pinned buffer and
+    // then echoes the call's sequence number: the host polls that word (a few microseconds
+    // after the kernel STARTS, where an event fires after it ends and costs a wake-up); the
+    // event is the fallback for a runtime that would not make the write visible in time
+    volatile int64_t* echo = (volatile int64_t*)f->stage + (kMaxShards + 1);
+    bool seen = false;
+    for (int64_t spin = 0; spin < (int64_t)1 << 22 && !seen; ++spin) {
+      seen = *echo == f->seq;
+      if (!seen && (spin & 63) == 63 && hipEventQuery(f->done) == hipSuccess) { seen = *echo == f->seq; break; }
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+    if (!seen) {
+      const hipError_t e = hipEventSynchronize(f->done);
+      if (e != hipSuccess) {
+        f->pending = 0;
+        return Fail(EULER_GPU_EHIP, std::string("dedup_split_end: ") + hipGetErrorString(e));
+      }
+      if (*echo != f->seq) { f->pending = 0; return Fail(EULER_GPU_EHIP, "dedup_split_end: the bucket sizes did not arrive"); }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
     f->pending = 0;
-    if (e != hipSuccess)
-      return Fail(EULER_GPU_EHIP, std::string("dedup_split_end: ") + hipGetErrorString(e));
   }
-  for (int s = 0; s <= f->shards; ++s) shard_off_host[s] = f->stage[s];
+  for (int s = 0; s <= f->shards; ++s) shard_off_host[s] = ((volatile int64_t*)f->stage)[s];
   return EULER_GPU_OK;
 }
 

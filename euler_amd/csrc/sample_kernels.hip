@@ -575,6 +575,8 @@ thread_local int g_fl_wb = 1;         // key 45: the lean kernel draws through t
                                       // one line per draw); 0 = the pivot-level search of rounds 2-3
 thread_local int g_fl_typed_regs = 1;  // key 48: typed hops on graphs of <= 4 edge-type groups keep the row record in registers (1)
 thread_local int g_k1_sets_lds = 1;   // key 47: euler_gpu_sample_neighbor_sets stages the roots' records in LDS (1)
+thread_local int g_fl_fat = 1;        // key 49: hashed graphs of <= 2 edge-type groups find a root's record in its
+                                      // 64-byte hash slot (1); 0 = 16-byte slot, then the record
 thread_local int g_fl_ablate = 0;     // key 36: measurement only (FanoutLocalArgs::ablate)
 thread_local int g_k1_typed_pivot = 1;   // key 37: calls with type draws search with the block pivots (0 = reference
                                          // loop)
@@ -594,7 +596,8 @@ int SamplingView(const euler_gpu_graph* g, GraphView* out) {
   }
   *out = g->view;
   if (!wb) { out->wb = nullptr; out->wbg = nullptr; out->wrec = nullptr; out->n_wb = 0; out->wb_lean_ok = 0;
-             out->trec = nullptr; out->trec_stride = 0; }
+             out->trec = nullptr; out->trec_stride = 0; out->fat = nullptr; }
+  if (g_fl_fat == 0) out->fat = nullptr;
   return EULER_GPU_OK;
 }
 
@@ -1779,6 +1782,7 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 45 && (value == 0 || value == 1)) { g_fl_wb = value; return EULER_GPU_OK; }
   if (key == 47 && value >= 0 && value <= 2) { g_k1_sets_lds = value; return EULER_GPU_OK; }
   if (key == 48 && (value == 0 || value == 1)) { g_fl_typed_regs = value; return EULER_GPU_OK; }
+  if (key == 49 && (value == 0 || value == 1)) { g_fl_fat = value; return EULER_GPU_OK; }
   return Fail(EULER_GPU_EINVAL, "set_tuning: unknown key");
 }
 

@@ -106,6 +106,9 @@ extern "C" {
  * key 48: typed hops of the one-kernel fanout on graphs with at most 4 edge-type groups keep
  *        the row record in registers (1 [default]); 0 = walk it in memory, as graphs with more
  *        groups do.
+ * key 49: graphs with a hash id map and at most two edge-type groups: the general builds of the
+ *        one-kernel fanout find a root's record in its 64-byte hash slot (1 [default]: one cold
+ *        line per root / child); 0 = the 16-byte slot, then the row's record (two).
  * All settings produce identical results; the knobs exist for A/B measurements
  * and tests.  They are THREAD-LOCAL: a call changes the launches the calling host
  * thread enqueues afterwards and nobody else's (new threads start from the

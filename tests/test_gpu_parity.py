@@ -467,14 +467,40 @@ def test_synthetic_hashed_ids_two_types(EA, O, torch_cuda):
             G.set_seed(3)
             ns, ws, ts = OG.sample_fanout(3, 10, q, et, counts, -1)
             res = []
-            for key27 in (1, 0):                 # the one-kernel step / hop by hop
+            # the one-kernel step with the record in the 64-byte hash slot (key 49 = 1) / through
+            # the 16-byte slot and the row's record / hop by hop
+            for key27, key49 in ((1, 1), (1, 0), (0, 1)):
                 L.euler_gpu_set_tuning(27, key27)
+                L.euler_gpu_set_tuning(49, key49)
                 gn, gw, gt = G.sample_fanout(qt, et, counts, -1, call_id=10)
                 for h in range(2):
-                    assert np.array_equal(t2n(gn[h + 1]), ns[h]), (et, counts, key27, h)
+                    assert np.array_equal(t2n(gn[h + 1]), ns[h]), (et, counts, key27, key49, h)
                     assert np.array_equal(t2n(gw[h]), ws[h]) and np.array_equal(t2n(gt[h]), ts[h])
+        # the other graphs that get fat slots: uniform weights (row records alone, no buckets) and
+        # one edge-type group behind a hash id map
+        for n_types, weighted in ((2, False), (1, True), (1, False)):
+            p2 = EA.synth_params(77, 30000, 300000, n_types=n_types, weighted=weighted, hashed_ids=True)
+            po2 = O.SynthParams()
+            for f, _ in po2._fields_:
+                setattr(po2, f, getattr(p2, f))
+            csr2 = O.synth_csr(po2)
+            G2 = EA.Graph.synthetic(p2)
+            G2.set_seed(3)
+            OG2 = O.OracleGraph(csr2)
+            q2 = np.concatenate([rng.choice(csr2.row_id, 40000), [0, 5]]).astype(np.uint64).view(np.int64)
+            q2t = torch.as_tensor(q2).cuda()
+            ets = [[[0], [0]]] + ([[[1], [0]], [[0, 1], [0, 1]]] if n_types == 2 else [])
+            for et in ets:
+                ns, ws, ts = OG2.sample_fanout(3, 10, q2, et, [25, 10], -1)
+                for key49 in (1, 0):
+                    L.euler_gpu_set_tuning(49, key49)
+                    gn, gw, gt = G2.sample_fanout(q2t, et, [25, 10], -1, call_id=10)
+                    for h in range(2):
+                        assert np.array_equal(t2n(gn[h + 1]), ns[h]), (n_types, weighted, et, key49, h)
+                        assert np.array_equal(t2n(gw[h]), ws[h]) and np.array_equal(t2n(gt[h]), ts[h])
     finally:
         L.euler_gpu_set_tuning(27, 1)
+        L.euler_gpu_set_tuning(49, 1)
 
 
 def test_op_registry_and_dat_loader(EA, O, torch_cuda, fixture_csr, tmp_path):

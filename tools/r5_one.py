@@ -24,6 +24,12 @@ def arg(name, default):
     return type(default)(sys.argv[sys.argv.index(name) + 1]) if name in sys.argv else default
 
 
+from euler_amd import _lib
+for kv in filter(None, arg("--tuning", "").split(",")):
+    k_, v_ = kv.split("=")
+    _lib.check(_lib.lib().euler_gpu_set_tuning(int(k_), int(v_)))
+
+
 if what == "hashed":
     weighted = "--unweighted" not in sys.argv
     p = euler_amd.synth_params(SEED, N, 10 * N, n_types=2, weighted=weighted, hashed_ids=True)
@@ -31,9 +37,16 @@ if what == "hashed":
     gen = torch.Generator(device="cuda"); gen.manual_seed(2468)
     roots = bench._mix64_t(torch.randint(1, N + 1, (4, B), generator=gen, device="cuda", dtype=torch.int64))
     for et in ([[0], [0]], [[0, 1], [0, 1]]):
+        for i in range(3):
+            G.sample_fanout(roots[i % 4], et, [25, 10], -1, call_id=2 * i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         for i in range(it):
             G.sample_fanout(roots[i % 4], et, [25, 10], -1, call_id=2 * i)
         torch.cuda.synchronize()
+        print("RESULT hashed T2 %s %s tuning '%s': %.4f ms per step on one stream, graph %.1f GB"
+              % ("weighted" if weighted else "unweighted", et, arg("--tuning", ""),
+                 (time.perf_counter() - t0) / it * 1e3, G.device_bytes / 1e9), flush=True)
 elif what == "hetero":
     T, D, CNT = 8, 128, 10
     p = euler_amd.synth_params(SEED, N, 10 * N, n_types=T, weighted=True)
@@ -87,7 +100,7 @@ elif what in ("sharded_walk", "sharded_step"):
         torch.cuda.synchronize()
         ms_u = (time.perf_counter() - t0) / it * 1e3
         assert torch.equal(out, ref)
-        print("sharded walk, one rank, %d walkers x %d, %d cohorts: %.3f ms per walk (unsharded %.3f ms) %s"
+        print("RESULT sharded walk, one rank, %d walkers x %d, %d cohorts: %.3f ms per walk (unsharded %.3f ms) %s"
               % (W, L, K, ms, ms_u, stats))
     else:
         roots = torch.randint(1, N + 1, (it, B), generator=gen, device=dev, dtype=torch.int64)
@@ -99,7 +112,7 @@ elif what in ("sharded_walk", "sharded_step"):
         for i in range(it):
             S.sample_fanout(roots[i], [[0], [0]], [25, 10], N + 1, call_id=2 * i)
         torch.cuda.synchronize()
-        print("sharded step, one rank, one minibatch in flight: %.4f ms per step"
+        print("RESULT sharded step, one rank, one minibatch in flight: %.4f ms per step"
               % ((time.perf_counter() - t0) / it * 1e3))
     dist.destroy_process_group()
 elif what == "sage":
