@@ -1245,11 +1245,38 @@ __device__ __forceinline__ uint32_t DenseSlot(const FrontArgs& a, uint64_t id) {
 // dense ids: owner[id] = position by plain stores (see sample_kernels.hip,
 // DedupMarkKernel); every id >= the limit is "no such node" and shares a slot -
 // whichever owner answers for its representative answers the default row
+// The lowest lane of the wave that holds the same id (its LEADER), found among the wave's own
+// 64 positions: one round per distinct id, at most kWaveLeaderRounds of them (the lanes left
+// then lead themselves).  The positions of a fanout's second hop come in runs of `count`
+// samples of one root - 2.8 distinct ids among 25 on the metric graph - so a wave of 64
+// positions holds ~8 distinct ids: only their leaders go to the table (3.28 M random stores
+// and loads become ~0.4 M), the others take the leader's answer through a lane shuffle.
+constexpr int kWaveLeaderRounds = 16;
+__device__ __forceinline__ int WaveLeader(const uint64_t id, const bool active) {
+  const int lane = threadIdx.x & 63;
+  int leader = lane;
+  unsigned long long todo = __ballot(active);
+  for (int round = 0; round < kWaveLeaderRounds && todo != 0ull; ++round) {
+    const int l = __ffsll((long long)todo) - 1;
+    const uint64_t v = ((uint64_t)(uint32_t)__shfl((int)(id >> 32), l) << 32) | (uint32_t)__shfl((int)id, l);
+    const bool same = active && id == v;
+    if (same) leader = l;
+    todo &= ~__ballot(same);
+  }
+  return leader;
+}
+
 __global__ __launch_bounds__(256) void FrontMarkDenseKernel(const FrontArgs a) {
   if (blockIdx.x == 0 && threadIdx.x < kMaxShards) a.total[threadIdx.x] = 0u;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.d.n; i += stride)
-    a.dense_owner[DenseSlot(a, DedupIdAt(a.d, i))] = (uint32_t)i;
+  const int lane = threadIdx.x & 63;
+  // (wave-uniform trip count: the shuffles of WaveLeader need every lane)
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x - lane; i0 < a.d.n; i0 += stride) {
+    const int64_t i = i0 + lane;
+    const bool in = i < a.d.n;
+    const uint64_t id = in ? DedupIdAt(a.d, i) : 0;
+    if (WaveLeader(id, in) == lane && in) a.dense_owner[DenseSlot(a, id)] = (uint32_t)i;
+  }
 }
 
 __global__ void FrontClearTotalsKernel(uint32_t* total) { total[threadIdx.x] = 0u; }
@@ -1260,12 +1287,17 @@ __global__ __launch_bounds__(256) void FrontRepHistKernel(const FrontArgs a) {
   if (threadIdx.x < kMaxShards) hist[threadIdx.x] = 0u;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * kFrontChunk;
-#pragma unroll 2
+  const int lane = threadIdx.x & 63;
   for (int32_t k = 0; k < kFrontChunk / 256; ++k) {
     const int64_t i = base + (int64_t)k * 256 + threadIdx.x;
-    if (i < a.d.n) {
-      const uint64_t id = DedupIdAt(a.d, i);
-      const uint32_t r = DENSE ? a.dense_owner[DenseSlot(a, id)] : DedupRep(a.d, (uint32_t)i);
+    const bool in = i < a.d.n;
+    const uint64_t id = in ? DedupIdAt(a.d, i) : 0;
+    // the table is asked once per distinct id of the wave (WaveLeader), the answer shuffled
+    const int leader = WaveLeader(id, in);
+    uint32_t r = 0;
+    if (in && leader == lane) r = DENSE ? a.dense_owner[DenseSlot(a, id)] : DedupRep(a.d, (uint32_t)i);
+    r = (uint32_t)__shfl((int)r, leader);
+    if (in) {
       a.rep[i] = r;
       if (r == (uint32_t)i) {
         const uint32_t own = (uint32_t)OwnerOf(id, a.partitions, a.shards);

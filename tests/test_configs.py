@@ -193,6 +193,59 @@ def test_config3_metric_step_at_full_size(EA, O, torch_cuda):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("weighted", [True, False], ids=["weighted", "uniform"])
+def test_general_form_step_at_full_size(EA, O, torch_cuda, weighted):
+    """The general builds of the one-kernel step (fanout_local.h, WB = 2 / 4 weighted, 6 / 5
+    uniform) at the metric's size - 100M nodes / 1B edges with hashed u64 ids (a hash map of 268M
+    slots) and two edge-type groups, hub rows of half a million edges in two groups: on all
+    36 044 800 samples of a step the one-kernel form (record in the 64-byte hash slot, and
+    through the 16-byte slot + row record) == the hop-by-hop kernels, for one listed type per
+    hop and for hops that list both (a type draw per sample); 96 roots == the oracle."""
+    torch = torch_cuda
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import bench
+    from euler_amd import _lib
+    L = _lib.lib()
+    N, B = 100_000_000, 131072
+    p = EA.synth_params(20240521, N, 10 * N, n_types=2, weighted=weighted, hashed_ids=True)
+    G = EA.Graph.synthetic(p)
+    assert G.num_nodes == N
+    G.set_seed(20240521)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(78)
+    roots = bench._mix64_t(torch.randint(1, N + 1, (B,), generator=gen, device="cuda", dtype=torch.int64))
+    for et in ([[0], [0]], [[0, 1], [0, 1]]):
+        try:
+            L.euler_gpu_set_tuning(27, 1)
+            a = G.sample_fanout(roots, et, [25, 10], -1, call_id=6)
+            L.euler_gpu_set_tuning(49, 0)
+            s16 = G.sample_fanout(roots, et, [25, 10], -1, call_id=6)
+            L.euler_gpu_set_tuning(49, 1)
+            L.euler_gpu_set_tuning(27, 0)
+            h = G.sample_fanout(roots, et, [25, 10], -1, call_id=6)
+        finally:
+            L.euler_gpu_set_tuning(27, 1); L.euler_gpu_set_tuning(49, 1)
+        assert a[0][2].numel() == B * 250
+        for hop in range(2):
+            for other in (s16, h):
+                assert torch.equal(a[0][hop + 1], other[0][hop + 1]), (et, hop)
+                assert torch.equal(a[1][hop], other[1][hop]) and torch.equal(a[2][hop], other[2][hop])
+        del s16, h
+        sel = np.random.default_rng(5).choice(B, 96, replace=False)
+        r_sel = t2n(roots)[sel]
+        hop1 = t2n(a[0][1]).reshape(B, 25)[sel]
+        need = np.concatenate([r_sel, hop1.reshape(-1)])
+        OG = bench._oracle_rows(G, p, need[need != -1], 2)
+        on, ow, ot = OG.sample_fanout(20240521, 6, r_sel, et, [25, 10], -1)
+        assert np.array_equal(on[0], hop1.reshape(-1))
+        assert np.array_equal(on[1], t2n(a[0][2]).reshape(B, 250)[sel].reshape(-1))
+        assert np.array_equal(ow[1], t2n(a[1][1]).reshape(B, 250)[sel].reshape(-1))
+        assert np.array_equal(ot[1], t2n(a[2][1]).reshape(B, 250)[sel].reshape(-1))
+        del a
+
+
+@pytest.mark.gpu
 def test_config4_deepwalk_walk_length_40(EA, O, torch_cuda):
     """configs[3] on one GPU: 100 000 walkers, p = q = 1, 40 steps on a 1M-node
     power-law graph; 256 walkers bit-exact against the oracle (rows exported
