@@ -717,6 +717,10 @@ def run_hetero(args, quiet=False):
             # three sample_neighbor + gather_segment_reduce pairs below, bit for bit
             return G.sample_neighbor_sets(roots[i], type_sets, CNT, N + 1, call_id=3 * i, feat=feat)[3]
         aggs = []
+        if S is not None and not args.hetero_separate:
+            # sharded: one front end / host wait / id exchange for the three sets over the same roots
+            outs = S.sample_neighbor_sets(roots[i], type_sets, CNT, N + 1, call_id=3 * i)
+            return [ops.gather_segment_reduce("mean", feat, o[0].reshape(-1), B, count=CNT) for o in outs]
         for c, et in enumerate(type_sets):
             nb, _w, _t = sample(roots[i], et, 3 * i + c)
             if fused:      # the rows are reduced as they are read, CNT per root (the sampler's int64

@@ -136,8 +136,8 @@ SIGNATURES = {
     "euler_gpu_gather": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, vp]),
     "euler_gpu_gather_segment_reduce": (C.c_int, [vp, C.c_int32, vp, vp, vp, C.c_int64, C.c_int64,
                                                   C.c_int32, vp]),
-    "euler_gpu_gather_segment_reduce_ids": (C.c_int, [vp, C.c_int32, vp, vp, vp, C.c_int64, C.c_int64,
-                                                  C.c_int32, vp]),
+    "euler_gpu_gather_segment_reduce_ids": (C.c_int, [vp, C.c_int32, vp, C.c_int64, vp, vp, C.c_int64,
+                                                      C.c_int64, C.c_int32, vp]),
     "euler_gpu_gather_scatter": (C.c_int, [vp, C.c_int32, vp, vp, vp, C.c_int64, C.c_int64, C.c_int32,
                                            vp]),
     "euler_gpu_id_split": (C.c_int, [vp, vp, C.c_int64, C.c_int32, C.c_int32, i64p,

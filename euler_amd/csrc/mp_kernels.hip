@@ -141,7 +141,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void SegmentReduceKernel(
     const float* __restrict__ upd, const SegSpec seg,
     const uint32_t* __restrict__ perm, const int32_t* __restrict__ gsrc, int64_t d,
-    float* __restrict__ out, const int32_t gstride) {
+    float* __restrict__ out, const int32_t gstride, const uint32_t row_max) {
   const int lane = threadIdx.x;
   const int32_t size = seg.size;
   for (int64_t r = (int64_t)blockIdx.x * blockDim.y + threadIdx.y; r < size;
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void SegmentReduceKernel(
 #pragma unroll
         for (int x = 0; x < 8; ++x) {
           int64_t src = perm ? (int64_t)perm[p + x] : p + x;
-          if (gsrc) src = gsrc[src * gstride];
+          if (gsrc) src = (int32_t)min((uint32_t)gsrc[src * gstride], row_max);
           v[x] = upd[src * d + c];
         }
 #pragma unroll
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void SegmentReduceKernel(
       }
       for (; p < en; ++p) {
         int64_t src = perm ? (int64_t)perm[p] : p;
-        if (gsrc) src = gsrc[src * gstride];
+        if (gsrc) src = (int32_t)min((uint32_t)gsrc[src * gstride], row_max);
         const float v = upd[src * d + c];
         if (IS_MAX) { if (v > acc) acc = v; }
         else acc = __fadd_rn(acc, v);
@@ -189,7 +189,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void SegmentReduceVec4Kernel(
     const float* __restrict__ upd, const SegSpec seg,
     const uint32_t* __restrict__ perm, const int32_t* __restrict__ gsrc, int32_t d4,
-    float* __restrict__ out, const int32_t gstride) {
+    float* __restrict__ out, const int32_t gstride, const uint32_t row_max) {
   constexpr bool IS_MAX = MODE == 1;
   const int32_t size = seg.size;
   const int32_t rows_per_wave = 64 / d4;
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void SegmentReduceVec4Kernel(
       for (int x = 0; x < 8; ++x) src[x] = perm ? (int64_t)perm[p + x] : p + x;
       if (gsrc) {
 #pragma unroll
-        for (int x = 0; x < 8; ++x) src[x] = gsrc[src[x] * gstride];
+        for (int x = 0; x < 8; ++x) src[x] = (int32_t)min((uint32_t)gsrc[src[x] * gstride], row_max);
       }
       float4 v[8];
 #pragma unroll
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void SegmentReduceVec4Kernel(
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
         int64_t src = perm ? (int64_t)perm[p + x] : p + x;
-        if (gsrc) src = gsrc[src * gstride];
+        if (gsrc) src = (int32_t)min((uint32_t)gsrc[src * gstride], row_max);
         v[x] = u4[src * d4 + cl];
       }
 #pragma unroll
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void SegmentReduceVec4Kernel(
     }
     for (; p < en; ++p) {
       int64_t src = perm ? (int64_t)perm[p] : p;
-      if (gsrc) src = gsrc[src * gstride];
+      if (gsrc) src = (int32_t)min((uint32_t)gsrc[src * gstride], row_max);
       const float4 v = u4[src * d4 + cl];
       if (IS_MAX) {
         acc.x = v.x > acc.x ? v.x : acc.x; acc.y = v.y > acc.y ? v.y : acc.y;
@@ -328,12 +328,12 @@ static int ScatterImpl(hipStream_t st, const float* upd, const int32_t* idx,
     int64_t blocks = ((int64_t)size + rows_per_block - 1) / rows_per_block;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(SegmentReduceVec4Kernel<MODE>, dim3((unsigned)blocks), block, 0, st, upd,
-                       SegSpec{keys, nullptr, 0, e, size}, perm, gsrc, (int32_t)d4, out, 1);
+                       SegSpec{keys, nullptr, 0, e, size}, perm, gsrc, (int32_t)d4, out, 1, 0xFFFFFFFFu);
   } else {
     int64_t blocks = ((int64_t)size + 3) / 4;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(SegmentReduceKernel<MODE>, dim3((unsigned)blocks), block, 0,
-                       st, upd, SegSpec{keys, nullptr, 0, e, size}, perm, gsrc, d, out, 1);
+                       st, upd, SegSpec{keys, nullptr, 0, e, size}, perm, gsrc, d, out, 1, 0xFFFFFFFFu);
   }
   EG_HIP(hipGetLastError());
   return EULER_GPU_OK;
@@ -342,7 +342,7 @@ static int ScatterImpl(hipStream_t st, const float* upd, const int32_t* idx,
 template <int MODE>
 static int SegmentReduceImpl(hipStream_t st, const float* params, const int32_t* gsrc,
                              const int64_t* seg_ptr, int64_t count, int64_t d, int32_t size,
-                             float* out, int32_t gstride = 1) {
+                             float* out, int32_t gstride = 1, uint32_t row_max = 0xFFFFFFFFu) {
   const dim3 block(64, 4);
   const int64_t d4 = d / 4;
   const SegSpec seg{nullptr, seg_ptr, count, 0, size};
@@ -352,12 +352,12 @@ static int SegmentReduceImpl(hipStream_t st, const float* params, const int32_t*
     int64_t blocks = ((int64_t)size + rows_per_block - 1) / rows_per_block;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(SegmentReduceVec4Kernel<MODE>, dim3((unsigned)blocks), block, 0, st, params,
-                       seg, nullptr, gsrc, (int32_t)d4, out, gstride);
+                       seg, nullptr, gsrc, (int32_t)d4, out, gstride, row_max);
   } else {
     int64_t blocks = ((int64_t)size + 3) / 4;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(SegmentReduceKernel<MODE>, dim3((unsigned)blocks), block, 0, st, params, seg,
-                       nullptr, gsrc, d, out, gstride);
+                       nullptr, gsrc, d, out, gstride, row_max);
   }
   EG_HIP(hipGetLastError());
   return EULER_GPU_OK;
@@ -795,7 +795,7 @@ int euler_gpu_gather_segment_reduce(void* stream, int32_t mode, const float* par
 }
 
 int euler_gpu_gather_segment_reduce_ids(void* stream, int32_t mode, const float* params_dev,
-                                        const int64_t* gather_ids_dev,
+                                        int64_t params_rows, const int64_t* gather_ids_dev,
                                         const int64_t* seg_ptr_dev, int64_t count, int64_t d,
                                         int32_t size, float* out_dev) {
   if (mode < 0 || mode > 2)
@@ -807,11 +807,17 @@ int euler_gpu_gather_segment_reduce_ids(void* stream, int32_t mode, const float*
     return Fail(EULER_GPU_EINVAL, "gather_segment_reduce_ids: null buffer");
   if (!seg_ptr_dev && mode == 2 && count >= (1LL << 24))
     return Fail(EULER_GPU_EINVAL, "gather_segment_reduce_ids: mean needs segments shorter than 2^24");
+  // the index is the low 32-bit word of the id: the table must be addressable by it, and an id
+  // past the table (a neighbour that is not a node of this graph, a dangling edge) reads the
+  // LAST row instead of memory outside the table
+  if (params_rows < 0 || params_rows >= ((int64_t)1 << 31))
+    return Fail(EULER_GPU_EINVAL, "gather_segment_reduce_ids: the table must have fewer than 2^31 rows");
+  const uint32_t row_max = params_rows > 0 ? (uint32_t)(params_rows - 1) : 0xFFFFFFFFu;
   hipStream_t st = (hipStream_t)stream;
   const int32_t* lo = reinterpret_cast<const int32_t*>(gather_ids_dev);     // little endian: word 0 of every id
-  if (mode == 0) return SegmentReduceImpl<0>(st, params_dev, lo, seg_ptr_dev, count, d, size, out_dev, 2);
-  if (mode == 1) return SegmentReduceImpl<1>(st, params_dev, lo, seg_ptr_dev, count, d, size, out_dev, 2);
-  return SegmentReduceImpl<2>(st, params_dev, lo, seg_ptr_dev, count, d, size, out_dev, 2);
+  if (mode == 0) return SegmentReduceImpl<0>(st, params_dev, lo, seg_ptr_dev, count, d, size, out_dev, 2, row_max);
+  if (mode == 1) return SegmentReduceImpl<1>(st, params_dev, lo, seg_ptr_dev, count, d, size, out_dev, 2, row_max);
+  return SegmentReduceImpl<2>(st, params_dev, lo, seg_ptr_dev, count, d, size, out_dev, 2, row_max);
 }
 
 int euler_gpu_gather_scatter(void* stream, int32_t mode, const float* params_dev,
@@ -1245,39 +1251,17 @@ __device__ __forceinline__ uint32_t DenseSlot(const FrontArgs& a, uint64_t id) {
 // dense ids: owner[id] = position by plain stores (see sample_kernels.hip,
 // DedupMarkKernel); every id >= the limit is "no such node" and shares a slot -
 // whichever owner answers for its representative answers the default row
-// The lowest lane of the wave that holds the same id (its LEADER), found among the wave's own
-// 64 positions: one round per distinct id, at most kWaveLeaderRounds of them (the lanes left
-// then lead themselves).  The positions of a fanout's second hop come in runs of `count`
-// samples of one root - 2.8 distinct ids among 25 on the metric graph - so a wave of 64
-// positions holds ~8 distinct ids: only their leaders go to the table (3.28 M random stores
-// and loads become ~0.4 M), the others take the leader's answer through a lane shuffle.
-constexpr int kWaveLeaderRounds = 16;
-__device__ __forceinline__ int WaveLeader(const uint64_t id, const bool active) {
-  const int lane = threadIdx.x & 63;
-  int leader = lane;
-  unsigned long long todo = __ballot(active);
-  for (int round = 0; round < kWaveLeaderRounds && todo != 0ull; ++round) {
-    const int l = __ffsll((long long)todo) - 1;
-    const uint64_t v = ((uint64_t)(uint32_t)__shfl((int)(id >> 32), l) << 32) | (uint32_t)__shfl((int)id, l);
-    const bool same = active && id == v;
-    if (same) leader = l;
-    todo &= ~__ballot(same);
-  }
-  return leader;
-}
-
 __global__ __launch_bounds__(256) void FrontMarkDenseKernel(const FrontArgs a) {
   if (blockIdx.x == 0 && threadIdx.x < kMaxShards) a.total[threadIdx.x] = 0u;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const int lane = threadIdx.x & 63;
-  // (wave-uniform trip count: the shuffles of WaveLeader need every lane)
-  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x - lane; i0 < a.d.n; i0 += stride) {
-    const int64_t i = i0 + lane;
-    const bool in = i < a.d.n;
-    const uint64_t id = in ? DedupIdAt(a.d, i) : 0;
-    if (WaveLeader(id, in) == lane && in) a.dense_owner[DenseSlot(a, id)] = (uint32_t)i;
-  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.d.n; i += stride)
+    a.dense_owner[DenseSlot(a, DedupIdAt(a.d, i))] = (uint32_t)i;
 }
+// (Round 5, measured and removed: electing one LEADER lane per distinct id of a wave - a loop of
+// ballots and shuffles - so that only leaders touch the table.  The second hop's positions are
+// ~8 distinct ids per wave, so the table traffic drops 8x; the kernels are latency-bound, not
+// traffic-bound: the sharded step went 0.400 -> 0.413 ms with one minibatch in flight, the
+// sharded walk - whose levels are mostly distinct - 2.55 -> 3.12 ms.)
 
 __global__ void FrontClearTotalsKernel(uint32_t* total) { total[threadIdx.x] = 0u; }
 
@@ -1287,17 +1271,12 @@ __global__ __launch_bounds__(256) void FrontRepHistKernel(const FrontArgs a) {
   if (threadIdx.x < kMaxShards) hist[threadIdx.x] = 0u;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * kFrontChunk;
-  const int lane = threadIdx.x & 63;
+#pragma unroll 2
   for (int32_t k = 0; k < kFrontChunk / 256; ++k) {
     const int64_t i = base + (int64_t)k * 256 + threadIdx.x;
-    const bool in = i < a.d.n;
-    const uint64_t id = in ? DedupIdAt(a.d, i) : 0;
-    // the table is asked once per distinct id of the wave (WaveLeader), the answer shuffled
-    const int leader = WaveLeader(id, in);
-    uint32_t r = 0;
-    if (in && leader == lane) r = DENSE ? a.dense_owner[DenseSlot(a, id)] : DedupRep(a.d, (uint32_t)i);
-    r = (uint32_t)__shfl((int)r, leader);
-    if (in) {
+    if (i < a.d.n) {
+      const uint64_t id = DedupIdAt(a.d, i);
+      const uint32_t r = DENSE ? a.dense_owner[DenseSlot(a, id)] : DedupRep(a.d, (uint32_t)i);
       a.rep[i] = r;
       if (r == (uint32_t)i) {
         const uint32_t own = (uint32_t)OwnerOf(id, a.partitions, a.shards);

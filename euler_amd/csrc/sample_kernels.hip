@@ -1860,8 +1860,11 @@ int euler_gpu_sample_aggregate_sets(const euler_gpu_graph* g, void* stream, uint
   if (feat_rows < 0 || d < 0 || (d > 0 && (!feat_dev || !out_agg_dev)))
     return Fail(EULER_GPU_EINVAL, "sample_aggregate_sets: bad feature arguments");
   // every sampled id (and the default fill) must name a row of the table
+  if (feat_rows >= ((int64_t)1 << 31))
+    return Fail(EULER_GPU_EINVAL, "sample_aggregate_sets: the feature table must have fewer than 2^31 rows");
   if (default_node < 0 || default_node >= feat_rows)
-    return Fail(EULER_GPU_EINVAL, "sample_aggregate_sets: default_node is not a row of the feature table");
+    return Fail(EULER_GPU_EINVAL, "sample_aggregate_sets: default_node is not a row of the feature table "
+                                  "(pass the id of a row kept for the default fill, e.g. max_id + 1)");
   if (g && g->max_id >= (uint64_t)feat_rows)
     return Fail(EULER_GPU_EINVAL, "sample_aggregate_sets: the feature table has fewer rows than the largest node id");
   const int rc = euler_gpu_sample_neighbor_sets(g, stream, seed, call_id, roots_dev, n, edge_types_host,
@@ -1871,7 +1874,7 @@ int euler_gpu_sample_aggregate_sets(const euler_gpu_graph* g, void* stream, uint
   if ((int64_t)n_sets * n >= ((int64_t)1 << 31))
     return Fail(EULER_GPU_EINVAL, "sample_aggregate_sets: more than 2^31 segments");
   // [sets][n] segments of `count` sampled ids each: one pass over the feature rows
-  return euler_gpu_gather_segment_reduce_ids(stream, mode, feat_dev,
+  return euler_gpu_gather_segment_reduce_ids(stream, mode, feat_dev, feat_rows,
                                              reinterpret_cast<const int64_t*>(out_id_dev), nullptr,
                                              count, d, (int32_t)(n_sets * n), out_agg_dev);
 }

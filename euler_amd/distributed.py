@@ -341,6 +341,37 @@ class ShardedSampler:
         ids, w, t, mask = self._unpack(rows, count)
         return ids, w, t, mask
 
+    def sample_neighbor_sets(self, roots, type_sets, count, default_node=-1, call_id=None):
+        """The typed draws of a heterogeneous minibatch: `roots` sampled once per edge-type set
+        of `type_sets` (set s draws with call_id + s - the results of len(type_sets)
+        sample_neighbor calls, bit for bit).  ONE front end, one host wait and one id
+        exchange serve all the sets (the roots are the same); every set is then one owners'
+        pass + one row exchange + one expansion.  Returns a list of (ids, weights, types,
+        row_mask) per set."""
+        type_sets = [list(et) for et in type_sets]
+        call_id = self._take_call_ids(max(len(type_sets), 1), call_id)
+        fused = (self.dedup_split_fn is not None and self.expand_fn is not None and
+                 self.local_sample_packed is not None)
+        if not fused:
+            return [self.sample_neighbor(roots, et, count, default_node, call_id + s)
+                    for s, et in enumerate(type_sets)]
+        roots = roots.reshape(-1).to(torch.int64)
+        if self.front_begin_fn is not None:
+            shard_off, shard_ids, pos = self.front_end_fn(
+                self.front_begin_fn(roots, self.partitions, self.world, None, 1))
+        else:
+            shard_off, shard_ids, pos = self.dedup_split_fn(roots, self.partitions, self.world, None, 1)
+        send_counts = [int(shard_off[s + 1] - shard_off[s]) for s in range(self.world)]
+        recv_counts = self._exchange_counts(send_counts, roots.device)
+        owned = self._exchange(shard_ids, send_counts, recv_counts)
+        outs = []
+        for s, et in enumerate(type_sets):
+            single_type = et[0] if len(et) == 1 else None
+            rows = self.local_sample_packed(owned, et, count, default_node, call_id + s)
+            outs.append(self.expand_fn(pos, self._exchange(rows, recv_counts, send_counts), count,
+                                       single_type))
+        return outs
+
     def sample_fanout(self, roots, edge_types, counts, default_node=-1, call_id=None):
         """Multi-hop fanout (tf_euler sample_fanout): returns (neighbors_list,
         weights_list, types_list) flattened like euler_ops.sample_fanout."""

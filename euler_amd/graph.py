@@ -382,6 +382,10 @@ class Graph:
                     int(default_node), _ptr(out_n), _ptr(out_w), _ptr(out_t)))
                 return out_n, out_w, out_t
             assert feat.dtype == torch.float32 and feat.dim() == 2 and feat.is_contiguous()
+            if not 0 <= int(default_node) < feat.shape[0]:
+                raise ValueError("sample_neighbor_sets(feat=...): default_node must name a row of the "
+                                 "feature table (the row the default fill aggregates, e.g. max_id + 1); "
+                                 "got %d for %d rows" % (int(default_node), feat.shape[0]))
             mode = {"add": 0, "max": 1, "mean": 2}[aggr]
             agg = torch.empty((S, n, feat.shape[1]), dtype=torch.float32, device=self.device)
             check(lib().euler_gpu_sample_aggregate_sets(
@@ -565,7 +569,10 @@ class Graph:
         """The whole SageDataFlow (tf_euler/python/dataflow/sage_dataflow.py +
         UniqueDataFlow.produce_subgraph) as ONE enqueue, no host round trip between
         the hops (euler_gpu_sage_blocks).  Returns (blocks, counts): blocks[h] =
-        (n_id, res_n_id, edge_src, edge_dst, edge_index = the two as rows of one tensor) and
+        (n_id, res_n_id, edge_src, edge_dst, edge_index) - FIVE entries since round 4: edge_index
+        is the [:, :e] view of the [2, cap] tensor whose rows are edge_src / edge_dst (rows
+        contiguous, the tensor as a whole not: .contiguous() before .view(-1) / data_ptr() /
+        torch.save, which would otherwise serialise the cap-sized storage) - and
         counts = the layer sizes - sliced to
         their true sizes after one read of the counts when sync is True, else padded
         to the worst case with `counts` left on the device (uint32 [layers + 1])."""

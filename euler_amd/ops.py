@@ -257,10 +257,15 @@ class _GatherSegmentReduce(torch.autograd.Function):
         if validate:
             _check_rows("gather_segment_reduce", gi, params.shape[0])
         out = torch.empty((int(size), params.shape[1]), dtype=torch.float32, device=params.device)
-        fn = lib().euler_gpu_gather_segment_reduce_ids if as_ids else lib().euler_gpu_gather_segment_reduce
         with _on(params.device):
-            check(fn(_stream(), _GS_MODE[op], _ptr(params), _ptr(gi), _ptr(sp) if sp is not None else None,
-                     int(count), params.shape[1], int(size), _ptr(out)))
+            if as_ids:      # (ids past the table read its last row: euler_gpu.h)
+                check(lib().euler_gpu_gather_segment_reduce_ids(
+                    _stream(), _GS_MODE[op], _ptr(params), int(params.shape[0]), _ptr(gi),
+                    _ptr(sp) if sp is not None else None, int(count), params.shape[1], int(size), _ptr(out)))
+            else:
+                check(lib().euler_gpu_gather_segment_reduce(
+                    _stream(), _GS_MODE[op], _ptr(params), _ptr(gi), _ptr(sp) if sp is not None else None,
+                    int(count), params.shape[1], int(size), _ptr(out)))
         if as_ids and ctx.needs_input_grad[0]:
             gi = gi.to(torch.int32)                 # the gradient kernels take int32 indices
         ctx.save_for_backward(params, gi, sp if sp is not None else torch.empty(0), out)

@@ -700,9 +700,11 @@ int euler_gpu_gather_segment_reduce(void* stream, int32_t mode, const float* par
  * output feeding the aggregation of a block): index p is the low 32 bits of
  * gather_ids_dev[p] - the int32 MPGather would receive after a cast
  * (tf_euler/kernels/gather_op.cc:26-59 takes int32 indices) - read in place, without the
- * cast's pass over the ids. */
+ * cast's pass over the ids.  params_rows = the rows of params_dev (< 2^31): an id at or past
+ * it - a neighbour that is not a node of this graph - reads the LAST row, never memory outside
+ * the table (0 = the caller vouches for the ids). */
 int euler_gpu_gather_segment_reduce_ids(void* stream, int32_t mode, const float* params_dev,
-                                        const int64_t* gather_ids_dev,
+                                        int64_t params_rows, const int64_t* gather_ids_dev,
                                         const int64_t* seg_ptr_dev, int64_t count, int64_t d,
                                         int32_t size, float* out_dev);
 int euler_gpu_gather(void* stream, const float* params_dev,

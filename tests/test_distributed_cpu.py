@@ -173,6 +173,16 @@ def _worker(rank, world, port, partitions, out_dir):
                 assert np.array_equal(ns[h + 1].numpy(), on[h]), (rank, et, h)
                 assert np.array_equal(ws[h].numpy(), ow[h])
                 assert np.array_equal(ts[h].numpy(), ot[h])
+    # the typed draws of a heterogeneous minibatch over one front end / id exchange
+    # (sample_neighbor_sets): == one sample_neighbor per set, fused samplers and the fallback
+    sets = [[1], [0, 2], [0, 1, 2]]
+    for sampler in (S_packed, S_plain):
+        outs = sampler.sample_neighbor_sets(torch.as_tensor(roots), sets, 4, -1, 70)
+        for c, et in enumerate(sets):
+            on, ow, ot = OG_full.sample_neighbor(seed, 70 + c, roots, et, 4, -1)
+            assert np.array_equal(outs[c][0].numpy().reshape(-1), on.reshape(-1)), (rank, et)
+            assert np.array_equal(outs[c][1].numpy().reshape(-1), ow.reshape(-1))
+            assert np.array_equal(outs[c][2].numpy().reshape(-1), ot.reshape(-1))
     # several minibatches in flight from one thread (run_interleaved): a two-phase
     # front end (begin = enqueue, end = wait) lets the hops of different batches
     # alternate; every rank must still issue the same sequence of collectives -

@@ -229,6 +229,11 @@ def _worker_body(rank, world, port, partitions):
         _same(got[:3], want, ("typed", et))
         on, ow, ot = OG5.sample_neighbor(8, call, r5[:500], et, 10, N5 + 1)
         assert np.array_equal(t2n(got[0])[:500], on) and np.array_equal(t2n(got[2])[:500], ot)
+    # the three typed draws of a heterogeneous minibatch behind ONE front end / id exchange
+    sets = [[3], [1, 4, 6], list(range(T))]
+    outs = S5.sample_neighbor_sets(r5t, sets, 10, N5 + 1, call_id=40)
+    for c, et in enumerate(sets):
+        _same(outs[c][:3], G5.sample_neighbor(r5t, et, 10, N5 + 1, call_id=40 + c), ("sets", et))
     # typed fanout + aggregation on the sharded sample (scatter_mean acts on the
     # minibatch-local block: replicas only, no collective)
     gn, gw, gt = S5.sample_fanout(r5t, [[1, 4, 6], [0, 2, 5]], [5, 5], N5 + 1, call_id=20)
