@@ -1888,7 +1888,11 @@ def test_sample_neighbor_sets_one_launch(EA, O, torch_cuda, big_pair):
             ref = {"mean": EA.ops.scatter_mean, "add": EA.ops.scatter_add, "max": EA.ops.scatter_max}[aggr](x, dst, 5000)
             assert torch.equal(agg[s_], ref), (aggr, et)
     # a feature table that does not cover the ids is refused
+    # (a default fill inside the table, so the C entry's own check of the graph's ids is what refuses)
     with pytest.raises(_lib.EulerGpuError):
+        G1.sample_neighbor_sets(r, tsets, CNT, 5, feat=feat[:100].contiguous())
+    # ... and a default fill that names no row of the table is refused before the call
+    with pytest.raises(ValueError):
         G1.sample_neighbor_sets(r, tsets, CNT, N + 1, feat=feat[:100].contiguous())
     # nothing to do
     e = G1.sample_neighbor_sets(r[:0], tsets, CNT, N + 1)
