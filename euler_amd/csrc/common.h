@@ -135,6 +135,12 @@ struct GraphView {
                                 // (k1_search.h: BlockPivotSample) use it
 };
 
+// A sampling view (SamplingView) can serve the block-pivot kernels: through the EdgeBlocks and
+// their pivot levels, or through the weight-bucket index alone - a graph whose index the lean
+// kernels may use (wb_lean_ok) does not get the 13 bytes per edge of EdgeBlocks at all, and the
+// few draws its buckets do not bracket bisect the flat arrays (k1_search.h: BlockPivotSample).
+inline bool HasBlockSearch(const GraphView& v) { return v.blk != nullptr || v.wbg != nullptr; }
+
 // Edge block of the sampling index: 10 consecutive edges of the flat arrays
 // (global edge indices [10 i, 10 i + 10)) with their running sums AND their
 // neighbour ids inside ONE 128-byte line - the fetch unit of the L2 / fabric
@@ -235,6 +241,7 @@ struct euler_gpu_graph {
   // kernels of two streams fit on the chip together (sample_kernels.hip: ConcurrentCall)
   mutable std::atomic<void*> last_stream{nullptr};
   mutable std::atomic<int> wb_tried{0};     // EnsureWbIndex ran (whatever it decided)
+  mutable std::atomic<int> blk_ready{0};    // EnsureBlockedIndex built the EdgeBlocks (view.blk / skip1 / bpiv)
   // Block construction (dataflow_kernels.hip): first-occurrence unique of a hop's node list
   // through a table indexed by graph ROW, one per stream, kept across calls: 8 bytes per row
   // {~epoch, smallest position} + 4 bytes {rank}.  Every hop of every call takes a new epoch

@@ -163,12 +163,14 @@ int VerifyTotals(GraphBuilder* b) {
 
 int BuildBlockedIndex(GraphBuilder* b);
 
-// Pivot levels over the flat arrays (variant 5) and the EdgeBlock copy with its
-// block pivots (variant 6, the default sampler) are both built at creation.
+// At creation: the pivot levels over the flat arrays (1.25 bytes per edge; variant 5 and every
+// search's last resort).  The weight-bucket index and the EdgeBlock copy with its block pivots
+// are built by the first sampling call (sample_kernels.hip: SamplingView) - and the EdgeBlocks
+// (13 bytes per edge) only for graphs the weight-bucket index does not serve.
 int BuildSearchIndex(GraphBuilder* b) {
   int rc = VerifyTotals(b);
   if (rc == EULER_GPU_OK) rc = BuildPivotLevels(b);
-  return rc != EULER_GPU_OK ? rc : BuildBlockedIndex(b);
+  return rc;
 }
 
 int BuildBlockedIndex(GraphBuilder* b) {
@@ -1062,8 +1064,9 @@ int EnsureWbIndex(const euler_gpu_graph* cg) {
 
 int EnsureBlockedIndex(const euler_gpu_graph* cg) {
   euler_gpu_graph* g = const_cast<euler_gpu_graph*>(cg);
+  if (g->blk_ready.load(std::memory_order_acquire) != 0) return EULER_GPU_OK;
   std::lock_guard<std::mutex> lk(g_blocked_mu);
-  if (g->view.blk != nullptr) return EULER_GPU_OK;
+  if (g->blk_ready.load(std::memory_order_acquire) != 0) return EULER_GPU_OK;
   int prev = 0;
   EG_HIP(hipGetDevice(&prev));
   EG_HIP(hipSetDevice(g->device));
@@ -1072,6 +1075,7 @@ int EnsureBlockedIndex(const euler_gpu_graph* cg) {
   const int rc = BuildBlockedIndex(&b);
   b.g.release();
   (void)hipSetDevice(prev);
+  if (rc == EULER_GPU_OK) g->blk_ready.store(1, std::memory_order_release);
   return rc;
 }
 

@@ -274,6 +274,21 @@ __device__ __forceinline__ void BlockPivotSample(const GraphView& g, const Segme
     // 1e-4 of the draws; lognormal sigma 2 or Pareto alpha 0.7: ~5 %): the pivot levels
     // below find it in ~log5(deg / 10) steps, not the bisection's log2(deg)
   }
+  if (g.blk == nullptr) {
+    // a graph served by the weight-bucket index alone (common.h: HasBlockSearch; at most 2
+    // buckets in a thousand overflow): the missed draw bisects the flat running sums - the
+    // first m of [lo, hi] with nw[m] > r, as the levels would find
+    const float* __restrict__ A0 = g.prefix_w;
+    int64_t lo2 = lo, hi2 = hi;
+    while (lo2 < hi2) {
+      const int64_t mid = (lo2 + hi2) >> 1;
+      if ((double)A0[mid] > rr) hi2 = mid; else lo2 = mid + 1;
+    }
+    *id = g.nbr[lo2];
+    *w = __fsub_rn(A0[lo2], lo2 == sg.row_ptr ? 0.f : A0[lo2 - 1]);
+    if (m_out != nullptr) *m_out = lo2;
+    return;
+  }
   // ranges of the levels, bottom up, only as far as needed: K = first level
   // with <= 4 candidates (most rows stop at level 1 or 2, and a wave whose
   // lanes have all stopped skips the remaining divisions)

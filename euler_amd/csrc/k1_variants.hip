@@ -356,7 +356,7 @@ int LaunchK1Variant(const euler_gpu_graph* g, hipStream_t stream, const SampleNb
   const int block = 256;
   const bool tf_zero = layout == EULER_GPU_LAYOUT_TF && g->view.has_zero_nbr != 0;
   if (g_k1_variant == 6 && g_k1_typed_pivot != 0 && k != 1 && g->view.monotone &&
-      !tf_zero && g->view.blk != nullptr) {
+      !tf_zero && HasBlockSearch(a.g)) {
     auto kern = layout == EULER_GPU_LAYOUT_TF ? SampleNeighborTypedPivotKernel<true>
                                               : SampleNeighborTypedPivotKernel<false>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, stream, a);

@@ -585,13 +585,18 @@ thread_local int t_fl_took_lean = 0;                // ... and whether the lean 
 thread_local void* g_fl_debug = nullptr;   // euler_gpu_set_debug_buffer: phase stamps of the lean kernel
 
 int SamplingView(const euler_gpu_graph* g, GraphView* out) {
-  if (g_k1_variant == 6 && g->view.blk == nullptr) {
-    const int rc = EnsureBlockedIndex(g);     // built on first use
-    if (rc != EULER_GPU_OK) return rc;
-  }
   const bool wb = g_fl_wb != 0 && g_k1_variant == 6;
   if (wb) {
     const int rc = EnsureWbIndex(g);
+    if (rc != EULER_GPU_OK) return rc;
+  }
+  // EdgeBlocks + block pivots (13 bytes per edge), built on first use - and only for a caller the
+  // weight-bucket index does not serve: no index (uniform weights, declined, key 45 = 0), or one
+  // with so many overflowing buckets that its misses should walk the levels (wb_lean_ok = 0).
+  // One copy of the adjacency per search structure actually used.
+  const bool wb_serves = wb && g->view.wbg != nullptr && g->view.wb_lean_ok != 0;
+  if (g_k1_variant == 6 && !wb_serves && g->blk_ready.load(std::memory_order_acquire) == 0) {
+    const int rc = EnsureBlockedIndex(g);
     if (rc != EULER_GPU_OK) return rc;
   }
   *out = g->view;
@@ -1510,8 +1515,12 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
       const bool lean_gu = !typed_hops && !plain_u && g_fl_plain == 2 && g_fl_wb != 0 && v.trec != nullptr &&
                            v.uniform_w != 0 && v.has_zero_nbr == 0 && f.t1 >= 0 && f.t1 < v.T && f.t2 >= 0 &&
                            f.t2 < v.T && t_fl_row_index == nullptr;
+      // (the plain build without the index walks the EdgeBlocks' levels: SamplingView builds them
+      // for every graph the index does not serve)
+      const bool lean_search_ok = lean_g || lean_gu || lean_t || v.uniform_w != 0 || f.g.blk != nullptr ||
+                                  (f.g.wrec != nullptr && f.g.wb != nullptr && v.wb_lean_ok != 0);
       if (((plain_u && !typed_hops) || lean_g || lean_gu || lean_t) && g_fl_plain == 2 && f.vec &&
-          v.n_edges < ((int64_t)1 << 31)) {
+          lean_search_ok && v.n_edges < ((int64_t)1 << 31)) {
         // the lean build (pairs of samples per lane, f32 compares, duplicates by edge)
         int32_t lcap = cap;
         FanoutLeanLds ll = FanoutLeanLayout(gr, c1, c2, lcap, lean_t);

@@ -955,11 +955,12 @@ int WalkOwnedStep(const euler_gpu_graph* g, hipStream_t st, uint64_t seed, uint3
   c.seed = seed; c.call_id = call_id; c.edge_types = et_dev; c.k = k; c.walk_len = walk_len;
   c.step = step;
   const GraphView& v = g->view;
-  const bool fast = k == 1 && v.monotone && v.blk != nullptr && g_k1_variant >= 5;
+  const bool fast = k == 1 && v.monotone && HasBlockSearch(c.g) && g_k1_variant >= 5;
   int mode = !fast ? 0
              : (g_walk_lean != 0 && v.T == 1 && v.total_in_meta != 0 && v.map_mode == 0 &&
                 v.uniform_w == 0 && v.n_edges < ((int64_t)1 << 31)) ? 2 : 1;
   if (mode == 2 && c.g.wrec != nullptr && c.g.wb != nullptr && c.g.wb_lean_ok != 0) mode = 3;
+  if (mode == 2 && c.g.blk == nullptr) mode = 1;      // (the lean search of mode 2 walks the EdgeBlocks' levels)
   auto kern = mode == 3 ? WalkOwnedKernel<3> : mode == 2 ? WalkOwnedKernel<2>
               : mode == 1 ? WalkOwnedKernel<1> : WalkOwnedKernel<0>;
   const int block = 256;
@@ -1475,7 +1476,7 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
   const float kEps = 1.0e-6;
   // random_walk_op.cc:281: fabs(p_ - 1.0) <= kEps && fabs(q_ - 1.0) <= kEps
   if (std::fabs((double)p - 1.0) <= kEps && std::fabs((double)q - 1.0) <= kEps) {
-    const bool fast = k == 1 && g->view.monotone && g->view.blk != nullptr && g_k1_variant >= 5;
+    const bool fast = k == 1 && g->view.monotone && HasBlockSearch(a.g) && g_k1_variant >= 5;
     // The walk over groups of merged walkers needs (walk_len + 1) * n * 16 bytes (24 when the paths go through a transposed copy) + 8 bytes per
     // graph row of stream-ordered scratch (0.7 GB for 1M walkers x 40 steps; tens of GB when
     // every node of a large graph walks).  It is an optimisation: when the scratch is not
@@ -1538,6 +1539,7 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
                  : (g_walk_lean != 0 && v.T == 1 && v.total_in_meta != 0 && v.map_mode == 0 &&
                     v.uniform_w == 0 && v.n_edges < ((int64_t)1 << 31)) ? 2 : 1;
       if (mode == 2 && c.g.wrec != nullptr && c.g.wb != nullptr && c.g.wb_lean_ok != 0) mode = 3;
+      if (mode == 2 && c.g.blk == nullptr) mode = 1;    // (the lean search of mode 2 walks the EdgeBlocks' levels)
       auto sample_kernel = mode == 3 ? CwSampleKernel<3> : mode == 2 ? CwSampleKernel<2>
                            : mode == 1 ? CwSampleKernel<1> : CwSampleKernel<0>;
       hipLaunchKernelGGL(sample_kernel, dim3(grid), dim3(block), 0, st, c);
