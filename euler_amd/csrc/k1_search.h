@@ -278,15 +278,15 @@ __device__ __forceinline__ void BlockPivotSample(const GraphView& g, const Segme
     // a graph served by the weight-bucket index alone (common.h: HasBlockSearch; at most 2
     // buckets in a thousand overflow): the missed draw bisects the flat running sums - the
     // first m of [lo, hi] with nw[m] > r, as the levels would find
-    const float* __restrict__ A0 = g.prefix_w;
-    int64_t lo2 = lo, hi2 = hi;
-    while (lo2 < hi2) {
-      const int64_t mid = (lo2 + hi2) >> 1;
-      if ((double)A0[mid] > rr) hi2 = mid; else lo2 = mid + 1;
+    const float* __restrict__ nw = g.prefix_w + sg.row_ptr;      // row-relative, 32-bit positions
+    uint32_t a = (uint32_t)sg.b, b = (uint32_t)sg.e;
+    while (a < b) {
+      const uint32_t mid = (a + b) >> 1;
+      if ((double)nw[mid] > rr) b = mid; else a = mid + 1u;
     }
-    *id = g.nbr[lo2];
-    *w = __fsub_rn(A0[lo2], lo2 == sg.row_ptr ? 0.f : A0[lo2 - 1]);
-    if (m_out != nullptr) *m_out = lo2;
+    *id = g.nbr[sg.row_ptr + a];
+    *w = __fsub_rn(nw[a], a == 0u ? 0.f : nw[a - 1u]);
+    if (m_out != nullptr) *m_out = sg.row_ptr + (int64_t)a;
     return;
   }
   // ranges of the levels, bottom up, only as far as needed: K = first level

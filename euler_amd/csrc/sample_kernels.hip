@@ -577,6 +577,9 @@ thread_local int g_fl_typed_regs = 1;  // key 48: typed hops on graphs of <= 4 e
 thread_local int g_k1_sets_lds = 1;   // key 47: euler_gpu_sample_neighbor_sets stages the roots' records in LDS (1)
 thread_local int g_fl_fat = 1;        // key 49: hashed graphs of <= 2 edge-type groups find a root's record in its
                                       // 64-byte hash slot (1); 0 = 16-byte slot, then the record
+thread_local int g_blk_policy = 0;    // key 51: 1 = a graph with a weight-bucket index is served by it ALONE even when many
+                                      // of its buckets overflow (wb_lean_ok = 0): no EdgeBlocks, every missed draw bisects
+                                      // the flat sums - tests of that fallback; 0 = such graphs get the EdgeBlocks' levels
 thread_local int g_fl_ablate = 0;     // key 36: measurement only (FanoutLocalArgs::ablate)
 thread_local int g_k1_typed_pivot = 1;   // key 37: calls with type draws search with the block pivots (0 = reference
                                          // loop)
@@ -594,7 +597,7 @@ int SamplingView(const euler_gpu_graph* g, GraphView* out) {
   // weight-bucket index does not serve: no index (uniform weights, declined, key 45 = 0), or one
   // with so many overflowing buckets that its misses should walk the levels (wb_lean_ok = 0).
   // One copy of the adjacency per search structure actually used.
-  const bool wb_serves = wb && g->view.wbg != nullptr && g->view.wb_lean_ok != 0;
+  const bool wb_serves = wb && g->view.wbg != nullptr && (g->view.wb_lean_ok != 0 || g_blk_policy == 1);
   if (g_k1_variant == 6 && !wb_serves && g->blk_ready.load(std::memory_order_acquire) == 0) {
     const int rc = EnsureBlockedIndex(g);
     if (rc != EULER_GPU_OK) return rc;
@@ -1792,6 +1795,7 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 47 && value >= 0 && value <= 2) { g_k1_sets_lds = value; return EULER_GPU_OK; }
   if (key == 48 && (value == 0 || value == 1)) { g_fl_typed_regs = value; return EULER_GPU_OK; }
   if (key == 49 && (value == 0 || value == 1)) { g_fl_fat = value; return EULER_GPU_OK; }
+  if (key == 51 && (value == 0 || value == 1)) { g_blk_policy = value; return EULER_GPU_OK; }
   return Fail(EULER_GPU_EINVAL, "set_tuning: unknown key");
 }
 

@@ -109,6 +109,11 @@ extern "C" {
  * key 49: graphs with a hash id map and at most two edge-type groups: the general builds of the
  *        one-kernel fanout find a root's record in its 64-byte hash slot (1 [default]: one cold
  *        line per root / child); 0 = the 16-byte slot, then the row's record (two).
+ * key 51: 1 = a graph that has a weight-bucket index is served by it alone even when more than
+ *        2 of its buckets in a thousand overflow: no EdgeBlocks are built for it and every draw
+ *        its block does not bracket bisects the flat running sums (the fallback of graphs the
+ *        index serves, made frequent for tests); 0 [default] = such graphs get the EdgeBlocks
+ *        and their pivot levels.  Takes effect for graphs whose EdgeBlocks are not built yet.
  * All settings produce identical results; the knobs exist for A/B measurements
  * and tests.  They are THREAD-LOCAL: a call changes the launches the calling host
  * thread enqueues afterwards and nobody else's (new threads start from the

@@ -1940,13 +1940,26 @@ def test_node2vec_step_on_fetched_lists_wave_and_lane(EA, O, torch_cuda):
         L.euler_gpu_set_tuning(7, 2)
 
 
-def test_heavy_tailed_weights_take_the_second_chance(EA, O, torch_cuda):
+@pytest.mark.parametrize("index_alone", [0, 1])
+def test_heavy_tailed_weights_take_the_second_chance(EA, O, torch_cuda, index_alone):
     """Rows whose weights are far from even - Pareto(0.7): dust among giants - make the weight-bucket
     index's blocks miss a few draws in a hundred.  The keys decide, so the results do not change:
     K1 / typed / small-batch kernels fall through to the pivot levels inside BlockPivotSample, the
     lean kernels are kept off the index by the builder's overflow count (wb_lean_ok) and walk the
-    levels.  SampleNeighbor, the fanout at every size class, type sets and walks == the oracle."""
+    levels.  SampleNeighbor, the fanout at every size class, type sets and walks == the oracle.
+    index_alone = 1 (tuning key 51): the graph gets NO EdgeBlocks - the state of every graph the
+    index serves since round 5 - so each of those missed draws takes the fallback such graphs
+    have, the bisection of the flat running sums, in every kernel family."""
     torch = torch_cuda
+    from euler_amd import _lib
+    _lib.check(_lib.lib().euler_gpu_set_tuning(51, index_alone))
+    try:
+        _heavy_tailed_battery(EA, O, torch)
+    finally:
+        _lib.lib().euler_gpu_set_tuning(51, 0)
+
+
+def _heavy_tailed_battery(EA, O, torch):
     rng = np.random.default_rng(21)
     n = 4000
     deg = np.minimum(rng.zipf(1.6, n), 6000).astype(np.int64)
@@ -1983,6 +1996,36 @@ def test_heavy_tailed_weights_take_the_second_chance(EA, O, torch_cuda):
         assert np.array_equal(t2n(sn[s_]).reshape(-1), on.reshape(-1)), et
     walk = G.random_walk(qt, [[0]] * 6, 1.0, 1.0, -1, call_id=40)
     assert np.array_equal(t2n(walk), OG.random_walk(9, 40, q, [[0]] * 6, 6, 1.0, 1.0, -1))
+    # several edge-type groups: the typed kernels (a segment's limits out of the row's record, type
+    # draws, type sets, typed hops of the fanout, a walk on one listed type) on such weights
+    T = 3
+    deg3 = np.minimum(rng.zipf(1.7, n * T), 3000).astype(np.int64)
+    seg3 = np.concatenate([[0], np.cumsum(deg3)]).astype(np.int64)
+    e3 = int(seg3[-1])
+    csr3 = O.csr_from_raw(ids, seg3, rng.integers(1, n + 1, e3).astype(np.uint64),
+                          (rng.pareto(0.7, e3) + 1e-3).astype(np.float32), T)
+    G3, OG3 = gpu_graph(EA, csr3), O.OracleGraph(csr3)
+    G3.set_seed(9)
+    sets3 = [[1], [0, 1, 2], [2, 0], []]
+    for et in sets3:
+        a = G3.sample_neighbor(qt, et, 10, -1, call_id=7)
+        on, ow, ot = OG3.sample_neighbor(9, 7, q, et, 10, -1)
+        assert np.array_equal(t2n(a[0]).reshape(-1), on.reshape(-1)), et
+        assert np.array_equal(t2n(a[1]).reshape(-1), ow.reshape(-1)), et
+        assert np.array_equal(t2n(a[2]).reshape(-1), ot.reshape(-1)), et
+    sn, sw, st = G3.sample_neighbor_sets(qt, sets3, 6, -1, call_id=50)
+    for s_, et in enumerate(sets3):
+        on, ow, ot = OG3.sample_neighbor(9, 50 + s_, q, et, 6, -1)
+        assert np.array_equal(t2n(sn[s_]).reshape(-1), on.reshape(-1)), et
+        assert np.array_equal(t2n(st[s_]).reshape(-1), ot.reshape(-1)), et
+    for etf in ([[0, 1], [1, 2]], [[2], [0]]):
+        gn, gw, gt = G3.sample_fanout(qt, etf, [4, 6], -1, call_id=17)
+        on, ow, ot = OG3.sample_fanout(9, 17, q, etf, [4, 6], -1)
+        for h in range(2):
+            assert np.array_equal(t2n(gn[h + 1]), on[h]), (etf, h)
+            assert np.array_equal(t2n(gw[h]), ow[h]) and np.array_equal(t2n(gt[h]), ot[h])
+    walk = G3.random_walk(qt, [[1]] * 5, 1.0, 1.0, -1, call_id=60)
+    assert np.array_equal(t2n(walk), OG3.random_walk(9, 60, q, [[1]] * 5, 5, 1.0, 1.0, -1))
 
 
 def test_random_walk_over_merged_walkers(EA, O, torch_cuda, big_pair):
