@@ -1484,8 +1484,34 @@ def run_sage_leg(args, G, p_g):
         algo += b_.value + 12.0 * m_in + 8.0 * blk.n_id.numel() + 8.0 * x.numel() \
             + 16.0 * blk.edge_index.shape[1]
         layer = blk.n_id
+    # GraphSAGE callers at small batch: B = 1 024 roots per minibatch, one flow per call against M = 64
+    # minibatches' flows in ONE enqueue (euler_gpu_sage_blocks_multi); sampled edges = the samples the
+    # hops draw (counts[h] x fanout[h]), read once from the counts of a checked run
+    Bs, Ms = 1024, 64
+    rs = torch.randint(1, N + 1, (Ms, Bs), generator=gen, device="cuda", dtype=torch.int64)
+    G.set_seed(GRAPH_SEED, 6000)
+    per_mb = G.sage_blocks_multi(rs, [[0], [0]], FANOUT, default_node=N + 1)
+    multi_checked = 0
+    for b_ in (0, 31, 63):
+        G.set_seed(GRAPH_SEED)
+        one = G.sage_blocks(rs[b_], [[0], [0]], FANOUT, default_node=N + 1, call_id=6000 + 2 * b_)
+        assert list(one[1]) == list(per_mb[b_][1])
+        for x_, y_ in zip(one[0], per_mb[b_][0]):
+            for u_, v_ in zip(x_, y_):
+                assert torch.equal(u_, v_), "sage_blocks_multi differs from the separate call"
+        multi_checked += 1
+    drawn = sum(c_[h_] * FANOUT[h_] for _blk, c_ in per_mb for h_ in range(2))
+    G.set_seed(GRAPH_SEED)
+    ms_multi = _events(lambda: G.sage_blocks_multi(rs, [[0], [0]], FANOUT, default_node=N + 1, sync=False), 10)
+    ms_small = _events(lambda: G.sage_blocks(rs[0], [[0], [0]], FANOUT, default_node=N + 1, sync=False), 20)
+    small = {"B": Bs, "M": Ms, "us_per_minibatch_single_calls": round(ms_small * 1e3, 2),
+             "multi_ms_per_launch": round(ms_multi, 4),
+             "multi_us_per_minibatch": round(ms_multi * 1e3 / Ms, 2),
+             "multi_sampled_edges_per_s": drawn / (ms_multi * 1e-3),
+             "single_sampled_edges_per_s": (drawn / Ms) / (ms_small * 1e-3),
+             "multi_checked": "%d of the %d minibatches == separate euler_gpu_sage_blocks calls" % (multi_checked, Ms)}
     return {"value": 1e3 / ms, "unit": "minibatches (2 blocks each)/s", "ms_per_step": round(ms, 4),
-            "ms_per_step_without_host_read": round(ms_nosync, 4),
+            "ms_per_step_without_host_read": round(ms_nosync, 4), "small_batch": small,
             "roofline_frac": round(algo / (ms_nosync * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "roofline_frac_with_host_read": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "algorithmic_bytes_per_minibatch": algo,

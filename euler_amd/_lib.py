@@ -242,6 +242,10 @@ SIGNATURES = {
     "euler_gpu_sage_blocks": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp, C.c_int64, i32p,
                                         C.c_int32, i32p, C.c_int32, C.c_int64, C.c_int32, vp,
                                         vp, vp, vp, vp, vp]),
+    "euler_gpu_sage_blocks_multi_workspace": (C.c_size_t, [C.c_int32, C.c_int64, i32p, C.c_int32]),
+    "euler_gpu_sage_blocks_multi": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int32, vp,
+                                              C.c_int64, i32p, C.c_int32, i32p, C.c_int32, C.c_int64,
+                                              C.c_int32, vp, vp, vp, vp, vp, vp]),
     "euler_gpu_sharded_random_walk": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint32, vp, C.c_int64,
                                                  i32p, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
                                                  C.c_int32, vp, C.c_int64, vp, i64p]),

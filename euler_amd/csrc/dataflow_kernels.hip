@@ -27,8 +27,11 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <vector>
+
 #include "common.h"
 #include "device_fns.h"
+#include "k1_search.h"
 
 namespace euler_gpu {
 
@@ -67,6 +70,10 @@ struct FlowHop {
   uint32_t* blk_cnt;          // [n_blk + 1] first occurrences per chunk of kFlowChunk positions
   unsigned long long* first_bits;   // [cap_m / 64 + 17] is-first-occurrence, one bit per position of V
   int64_t n_blk;              // ceil(cap_m / kFlowChunk)
+  // several minibatches per launch (euler_gpu_sage_blocks_multi): minibatch b = blockIdx.y has
+  // its own copy of every array, b strides further (FlowOf); 1 = the single flow
+  int32_t n_mb;
+  int64_t mb_nb, mb_nid, mb_cnt, mb_tab, mb_m, mb_blk;
   uint64_t* new_n_id;         // [cap_m]
   int64_t* inv;               // [cap_m] edge_dst: index of every element of V in new_n_id
   int64_t* edge_src;          // [cap_m]
@@ -81,6 +88,22 @@ __device__ __forceinline__ uint64_t FlowElem(const FlowHop& h, int64_t i, int64_
   return i < m_nb ? h.nb[i] : h.n_id[i - m_nb];
 }
 
+// the hop as minibatch b of the launch sees it
+__device__ __forceinline__ FlowHop FlowOf(const FlowHop& h0, uint32_t b) {
+  FlowHop h = h0;
+  if (h0.n_mb > 1) {
+    h.nb += (int64_t)b * h0.mb_nb;        h.n_id += (int64_t)b * h0.mb_nid;
+    h.cnt += (int64_t)b * h0.mb_cnt;      h.cnt_out += (int64_t)b * h0.mb_cnt;
+    h.t.keys += (int64_t)b * h0.mb_tab;   h.t.minpos += (int64_t)b * h0.mb_tab;
+    h.t.rank += (int64_t)b * h0.mb_tab;   h.slot_of += (int64_t)b * h0.mb_m;
+    h.blk_cnt += (int64_t)b * h0.mb_blk;
+    h.first_bits = reinterpret_cast<unsigned long long*>(h.blk_cnt + ((h0.n_blk + 2) & ~(int64_t)1));
+    h.new_n_id += (int64_t)b * h0.mb_m;   h.inv += (int64_t)b * h0.mb_m;
+    h.edge_src += (int64_t)b * h0.mb_m;   h.res_n_id += (int64_t)b * h0.mb_nid;
+  }
+  return h;
+}
+
 // The hash table is allocated for the worst case, but a minibatch fills a fraction of it
 // (16 384 roots x [25, 10]: 0.65 M of 4.7 M positions): every kernel sizes the part it uses
 // from the device-side length - a power of two >= 2 m slots - so clearing and probing touch
@@ -92,7 +115,8 @@ __device__ __forceinline__ uint64_t FlowMask(const FlowHop& h, int64_t m) {
   return (cap > h.t.mask + 1 ? h.t.mask + 1 : cap) - 1;
 }
 
-__global__ __launch_bounds__(256) void FlowClearKernel(const FlowHop h) {
+__global__ __launch_bounds__(256) void FlowClearKernel(const FlowHop h0) {
+  const FlowHop h = FlowOf(h0, blockIdx.y);
   const int64_t cnt = (int64_t)(*h.cnt);
   const int64_t m = FlowNbLen(h, cnt) + cnt;
   const int64_t slots = (int64_t)FlowMask(h, m) + 1;
@@ -126,25 +150,64 @@ constexpr int kFlowLds = 2 * kFlowChunk;          // LDS slots per workgroup (po
 
 constexpr int kFlowInsertThreads = 256;    // (1024 - one position per lane - measured slower: 28.8 vs 26.8 us)
 
-__global__ __launch_bounds__(kFlowInsertThreads) void FlowInsertKernel(const FlowHop h) {
-  __shared__ uint32_t s_row[kFlowLds];
-  __shared__ uint32_t s_pos[kFlowLds];
+// BY_ID = false: the flow has the row-indexed table (h.dense_min): rows reduced in LDS as above, the
+// rare ids without a row straight to the hash table in HBM.  BY_ID = true: a flow WITHOUT that
+// table (the multi-minibatch launch - two minibatches of a launch would fight over a row -, a
+// stream beyond the table budget): every id goes to the hash table, after the same reduction by
+// ID - atomics of many lanes on one slot are worked off one by one by the memory side (round 5,
+// the 64-minibatch launch: hop 1's insert, 6.8 copies of every distinct id, 168 -> 31 us; hop 2's,
+// 1.5 copies, stays at 230 us - the memory side's atomic rate; taking the loads in front of the
+// atomics away instead changed nothing).
+template <bool BY_ID>
+__global__ __launch_bounds__(kFlowInsertThreads) void FlowInsertKernel(const FlowHop h0) {
+  const FlowHop h = FlowOf(h0, blockIdx.y);
+  // BY_ID: u64 ids [kFlowLds] + u32 smallest position, then the global slot [kFlowLds]; else u32 rows + u32 positions
+  __shared__ unsigned long long s_buf[BY_ID ? kFlowLds + kFlowLds / 2 : kFlowLds];
+  __shared__ uint32_t s_side;                         // BY_ID: smallest position of the all-ones id
+  uint32_t* const s_row = reinterpret_cast<uint32_t*>(s_buf);
+  uint32_t* const s_pos = s_row + kFlowLds;
+  unsigned long long* const s_id = s_buf;
+  uint32_t* const s_ipos = reinterpret_cast<uint32_t*>(s_buf + kFlowLds);
   const int64_t cnt = (int64_t)(*h.cnt);
   const int64_t m_nb = FlowNbLen(h, cnt), m = m_nb + cnt;
   const uint64_t mask = FlowMask(h, m);
+  constexpr uint32_t kNone = 0xFFFFFFFFu, kSide = 0xFFFFFFFEu;
   for (int64_t base = (int64_t)blockIdx.x * kFlowChunk; base < m; base += (int64_t)gridDim.x * kFlowChunk) {
-    for (int x = threadIdx.x; x < kFlowLds; x += kFlowInsertThreads) { s_row[x] = 0xFFFFFFFFu; s_pos[x] = 0xFFFFFFFFu; }
+    if (BY_ID) {
+      for (int x = threadIdx.x; x < kFlowLds; x += kFlowInsertThreads) { s_id[x] = kFlowEmptyKey; s_ipos[x] = 0xFFFFFFFFu; }
+      if (threadIdx.x == 0) s_side = 0xFFFFFFFFu;
+    } else {
+      for (int x = threadIdx.x; x < kFlowLds; x += kFlowInsertThreads) { s_row[x] = 0xFFFFFFFFu; s_pos[x] = 0xFFFFFFFFu; }
+    }
     __syncthreads();
+    uint32_t ls[kFlowChunk / kFlowInsertThreads];     // BY_ID: the LDS slot of a position's id (or the side slot)
 #pragma unroll
     for (int x = 0; x < kFlowChunk / kFlowInsertThreads; ++x) {
+      ls[x] = kNone;
       const int64_t i = base + x * kFlowInsertThreads + threadIdx.x;
       if (i >= m) continue;
       const uint64_t id = FlowElem(h, i, m_nb);
-      const int64_t row = h.dense_min != nullptr ? FindRow(h.g, id) : -1;
+      if (BY_ID) {
+        if (id == kFlowEmptyKey) {
+          atomicMin(&s_side, (uint32_t)i);
+          ls[x] = kSide;
+          continue;
+        }
+        uint32_t s = (uint32_t)(Mix64(id) & (uint64_t)(kFlowLds - 1));
+        for (;;) {                                    // at most kFlowChunk of kFlowLds slots fill up
+          const unsigned long long old = atomicCAS(&s_id[s], (unsigned long long)kFlowEmptyKey, (unsigned long long)id);
+          if (old == kFlowEmptyKey || old == id) break;
+          s = (s + 1) & (uint32_t)(kFlowLds - 1);
+        }
+        atomicMin(&s_ipos[s], (uint32_t)i);
+        ls[x] = s;
+        continue;
+      }
+      const int64_t row = FindRow(h.g, id);
       if (row >= 0) {
         h.slot_of[i] = (uint32_t)row;
         uint32_t s = (uint32_t)(Mix64((uint64_t)row) & (uint64_t)(kFlowLds - 1));
-        for (;;) {                                    // at most kFlowChunk of kFlowLds slots fill up
+        for (;;) {
           const uint32_t old = atomicCAS(&s_row[s], 0xFFFFFFFFu, (uint32_t)row);
           if (old == 0xFFFFFFFFu || old == (uint32_t)row) break;
           s = (s + 1) & (uint32_t)(kFlowLds - 1);
@@ -158,26 +221,47 @@ __global__ __launch_bounds__(kFlowInsertThreads) void FlowInsertKernel(const Flo
       } else {
         s = Mix64(id) & mask;
         for (;;) {
-          unsigned long long old =
-              __hip_atomic_load(&h.t.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (old == kFlowEmptyKey)
-            old = atomicCAS(&h.t.keys[s], (unsigned long long)kFlowEmptyKey, (unsigned long long)id);
+          const unsigned long long old =
+              atomicCAS(&h.t.keys[s], (unsigned long long)kFlowEmptyKey, (unsigned long long)id);
           if (old == kFlowEmptyKey || old == id) break;
           s = (s + 1) & mask;
         }
       }
-      if (__hip_atomic_load(&h.t.minpos[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (uint32_t)i)
-        atomicMin(&h.t.minpos[s], (uint32_t)i);
+      atomicMin(&h.t.minpos[s], (uint32_t)i);
       h.slot_of[i] = kFlowHashed | (uint32_t)s;
     }
     __syncthreads();
-    // the chunk's distinct rows, one atomicMin of {~epoch, position} each (a row another
-    // chunk already claimed with a smaller position costs a load)
-    for (int x = threadIdx.x; x < kFlowLds; x += kFlowInsertThreads) {
-      const uint32_t row = s_row[x];
-      if (row == 0xFFFFFFFFu) continue;
-      const unsigned long long mine = h.epoch_hi | (unsigned long long)s_pos[x];
-      atomicMin(&h.dense_min[row], mine);
+    if (BY_ID) {
+      // the chunk's distinct ids: one claim of a hash slot + one minimum each; the slot is left in
+      // LDS for the ids' positions
+      for (int x = threadIdx.x; x < kFlowLds; x += kFlowInsertThreads) {
+        const unsigned long long id = s_id[x];
+        if (id == kFlowEmptyKey) continue;
+        uint64_t s = Mix64(id) & mask;
+        for (;;) {
+          const unsigned long long old = atomicCAS(&h.t.keys[s], (unsigned long long)kFlowEmptyKey, id);
+          if (old == kFlowEmptyKey || old == id) break;
+          s = (s + 1) & mask;
+        }
+        atomicMin(&h.t.minpos[s], s_ipos[x]);
+        s_ipos[x] = (uint32_t)s;
+      }
+      if (threadIdx.x == 0 && s_side != 0xFFFFFFFFu) atomicMin(&h.t.minpos[h.t.mask + 1], s_side);
+      __syncthreads();
+#pragma unroll
+      for (int x = 0; x < kFlowChunk / kFlowInsertThreads; ++x) {
+        if (ls[x] == kNone) continue;
+        const int64_t i = base + x * kFlowInsertThreads + threadIdx.x;
+        h.slot_of[i] = kFlowHashed | (ls[x] == kSide ? (uint32_t)(h.t.mask + 1) : s_ipos[ls[x]]);
+      }
+    } else {
+      // the chunk's distinct rows, one atomicMin of {~epoch, position} each
+      for (int x = threadIdx.x; x < kFlowLds; x += kFlowInsertThreads) {
+        const uint32_t row = s_row[x];
+        if (row == 0xFFFFFFFFu) continue;
+        const unsigned long long mine = h.epoch_hi | (unsigned long long)s_pos[x];
+        atomicMin(&h.dense_min[row], mine);
+      }
     }
     __syncthreads();
   }
@@ -186,7 +270,8 @@ __global__ __launch_bounds__(kFlowInsertThreads) void FlowInsertKernel(const Flo
 // first occurrences per chunk of kFlowChunk positions (workgroup b = chunk b; chunks past
 // the valid prefix count zero) - the ranks are then a scan over n_blk numbers instead of
 // one over the worst-case length of V
-__global__ __launch_bounds__(256) void FlowFlagKernel(const FlowHop h) {
+__global__ __launch_bounds__(256) void FlowFlagKernel(const FlowHop h0) {
+  const FlowHop h = FlowOf(h0, blockIdx.y);
   __shared__ uint32_t s_cnt[4];
   const int64_t cnt = (int64_t)(*h.cnt);
   const int64_t m = FlowNbLen(h, cnt) + cnt;
@@ -226,7 +311,8 @@ __device__ __forceinline__ uint32_t FlowPrefix(const FlowHop& h, int64_t upto, u
   return s_red[0] + s_red[1] + s_red[2] + s_red[3];
 }
 
-__global__ __launch_bounds__(256) void FlowEmitKernel(const FlowHop h) {
+__global__ __launch_bounds__(256) void FlowEmitKernel(const FlowHop h0) {
+  const FlowHop h = FlowOf(h0, blockIdx.y);
   __shared__ uint32_t s_cnt[4];
   const int64_t cnt = (int64_t)(*h.cnt);
   const int64_t m_nb = FlowNbLen(h, cnt), m = m_nb + cnt;
@@ -265,7 +351,8 @@ __global__ __launch_bounds__(256) void FlowEmitKernel(const FlowHop h) {
   }
 }
 
-__global__ __launch_bounds__(256) void FlowIndexKernel(const FlowHop h) {
+__global__ __launch_bounds__(256) void FlowIndexKernel(const FlowHop h0) {
+  const FlowHop h = FlowOf(h0, blockIdx.y);
   const int64_t cnt = (int64_t)(*h.cnt);
   const int64_t m_nb = FlowNbLen(h, cnt), m = m_nb + cnt;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -376,6 +463,52 @@ __global__ __launch_bounds__(256) void FlowFullFillKernel(const FlowFull f) {
 }
 
 __global__ void FlowInitKernel(uint32_t* counts, uint32_t n) { counts[0] = n; }
+
+// counts of minibatch b at counts + b * stride
+__global__ void FlowInitMultiKernel(uint32_t* counts, uint32_t n, int32_t n_mb, int32_t stride) {
+  for (int32_t b = threadIdx.x; b < n_mb; b += blockDim.x) counts[(int64_t)b * stride] = n;
+}
+
+// The hop's sampler for SEVERAL minibatches in one launch (euler_gpu_sage_blocks_multi): lane per
+// sample of the first cnt[b] nodes of minibatch b = blockIdx.y's layer, neighbour ids only (the
+// flow uses nothing else).  One listed edge type on a monotone graph: exactly the draw of
+// SampleNeighborPivotKernel<TF, 1, BLOCKED> (sample_kernels.hip: PivotPass) - sample j of a node
+// is word pair j & 1 of Philox block (seed, call id, node, j >> 1), a node without a row or without
+// edges of the type answers default_node - with minibatch b's own call id, so that the launch
+// equals the separate calls.
+struct FlowSample {
+  GraphView g;
+  uint64_t seed;
+  uint32_t call_id, call_stride;      // minibatch b draws with call_id + b * call_stride
+  const uint64_t* n_id;               // [n_mb][cap_n]
+  const uint32_t* cnt;                // minibatch b: cnt[b * mb_cnt]
+  uint64_t* nb;                       // [n_mb][cap_n * count]
+  int64_t cap_n, mb_cnt, default_node;
+  int32_t count, type;
+};
+
+__global__ __launch_bounds__(256, kWavesPerSimd) void FlowSampleKernel(const FlowSample s) {
+  const uint32_t b = blockIdx.y;
+  const int64_t total = (int64_t)s.cnt[(int64_t)b * s.mb_cnt] * s.count;
+  const uint64_t* n_id = s.n_id + (int64_t)b * s.cap_n;
+  uint64_t* nb = s.nb + (int64_t)b * s.cap_n * s.count;
+  const uint32_t call = s.call_id + b * s.call_stride;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / s.count;
+    const int32_t j = (int32_t)(i - r * s.count);
+    const uint64_t node = n_id[r];
+    uint64_t id = (uint64_t)s.default_node;
+    Segment sg;
+    if (LoadSegment<true>(s.g, FindRow(s.g, node), s.type, &sg)) {
+      const Philox4 blk = RngBlock(s.seed, call, kDomainNeighbor, node, ((uint32_t)j) >> 1);
+      const double u = (j & 1) ? UnitFromWords(blk.w[2], blk.w[3]) : UnitFromWords(blk.w[0], blk.w[1]);
+      float w;
+      BlockPivotSample(s.g, sg, u, &id, &w);
+    }
+    nb[i] = id;
+  }
+}
 
 // The stream's row-indexed table and the epochs of `hops` hops (common.h: FlowTableDense).
 // No table (allocation failed, more than 2^31 rows): the hash table serves every id.
@@ -524,11 +657,150 @@ int euler_gpu_sage_blocks(const euler_gpu_graph* g, void* stream, uint64_t seed,
     const int grid = GridFor(cap_m + 1, block);
     const int grid_b = (int)(f.n_blk + 1 < 65536 ? f.n_blk + 1 : 65536);
     hipLaunchKernelGGL(FlowClearKernel, dim3(grid), dim3(block), 0, st, f);
-    hipLaunchKernelGGL(FlowInsertKernel, dim3(grid_b), dim3(kFlowInsertThreads), 0, st, f);
+    if (f.dense_min != nullptr) hipLaunchKernelGGL(FlowInsertKernel<false>, dim3(grid_b), dim3(kFlowInsertThreads), 0, st, f);
+    else hipLaunchKernelGGL(FlowInsertKernel<true>, dim3(grid_b), dim3(kFlowInsertThreads), 0, st, f);
     hipLaunchKernelGGL(FlowFlagKernel, dim3(grid_b), dim3(block), 0, st, f);
     hipLaunchKernelGGL(FlowEmitKernel, dim3(grid_b), dim3(block), 0, st, f);
     // 3. res_n_id, edge_index
     hipLaunchKernelGGL(FlowIndexKernel, dim3(grid), dim3(block), 0, st, f);
+    EG_HIP(hipGetLastError());
+    n_id = n_id_dev[h];
+  }
+  return EULER_GPU_OK;
+}
+
+// ---- several minibatches per enqueue ------------------------------------------------------
+// The reference's GraphSAGE callers build one flow per minibatch of a few hundred roots
+// (sage_dataflow.py:35-50; run_graphsage.py:35 defaults to 32): a GPU is not filled by 1 024
+// roots, and a flow is a dozen dependent launches of microseconds each.  M minibatches of n roots
+// in ONE enqueue: every kernel of the flow gets a second grid dimension (the minibatch, FlowOf),
+// every array M copies b strides apart, the hops' samplers one launch for all minibatches with
+// minibatch b's own call id - the result of M euler_gpu_sage_blocks calls, bit for bit.  The
+// first-occurrence tables are the hash tables (the row-indexed table is one per stream: two
+// minibatches of a launch would fight over a row).
+static size_t MultiHopBytes(int32_t n_mb, int64_t cap_n, int32_t count, int64_t* r_words) {
+  const int64_t cap_m = cap_n * ((int64_t)count + 1);
+  uint64_t tcap = 64;
+  while (tcap < (uint64_t)cap_m * 2) tcap <<= 1;
+  const int64_t n_blk = (cap_m + kFlowChunk - 1) / kFlowChunk;
+  const int64_t R = ((n_blk + 2) & ~(int64_t)1) + 2 * (cap_m / 64 + 18);
+  if (r_words) *r_words = R;
+  return Al((size_t)n_mb * cap_n * count * 8) + Al((size_t)n_mb * (tcap + 1) * 8) +
+         Al((size_t)n_mb * (tcap + 1) * 4) * 2 + Al((size_t)n_mb * cap_m * 4) + Al((size_t)n_mb * R * 4);
+}
+
+size_t euler_gpu_sage_blocks_multi_workspace(int32_t n_mb, int64_t n, const int32_t* fanouts_host,
+                                             int32_t layers) {
+  size_t best = euler_gpu_sage_blocks_workspace(n, fanouts_host, layers);     // the fallback's
+  for (int32_t h = 0; h < layers; ++h) {
+    const size_t b = MultiHopBytes(n_mb, FlowCap(n, fanouts_host, h), fanouts_host[h], nullptr);
+    if (b > best) best = b;
+  }
+  return best + 256;
+}
+
+int euler_gpu_sage_blocks_multi(const euler_gpu_graph* g, void* stream, uint64_t seed, uint32_t call_id,
+                                uint32_t call_stride, int32_t n_mb, const uint64_t* roots_dev, int64_t n,
+                                const int32_t* edge_types_host, int32_t k, const int32_t* fanouts_host,
+                                int32_t layers, int64_t default_node, int32_t add_self_loops,
+                                void* workspace_dev, uint64_t* const* n_id_dev,
+                                int64_t* const* res_n_id_dev, int64_t* const* edge_src_dev,
+                                int64_t* const* edge_dst_dev, uint32_t* counts_dev) {
+  if (!g) return Fail(EULER_GPU_ENOGRAPH, "sage_blocks_multi: null graph");
+  if (n_mb <= 0 || n_mb > 65535 || n < 0 || layers <= 0 || layers > 8 || k < 0 || !fanouts_host || !n_id_dev ||
+      !res_n_id_dev || !edge_src_dev || !edge_dst_dev || !counts_dev || (n > 0 && (!roots_dev || !workspace_dev)))
+    return Fail(EULER_GPU_EINVAL, "sage_blocks_multi: bad arguments");
+  for (int32_t h = 0; h < layers; ++h)
+    if (fanouts_host[h] <= 0) return Fail(EULER_GPU_EINVAL, "sage_blocks_multi: fanouts must be > 0");
+  if (FlowCap(n, fanouts_host, layers) > ((int64_t)1 << 29))
+    return Fail(EULER_GPU_EINVAL, "sage_blocks_multi: worst-case layer size > 2^29");
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) {
+    EG_HIP(hipMemsetAsync(counts_dev, 0, sizeof(uint32_t) * (size_t)n_mb * (layers + 1), st));
+    return EULER_GPU_OK;
+  }
+  GraphView view;
+  {
+    const int rc = SamplingView(g, &view);
+    if (rc != EULER_GPU_OK) return rc;
+  }
+  bool fast = k == 1 && view.monotone != 0 && view.has_zero_nbr == 0 && HasBlockSearch(view);
+  for (int32_t h = 0; fast && h < layers; ++h) fast = edge_types_host[h] >= 0;
+  if (!fast || n_mb == 1) {
+    // hops with type draws, graphs with the id-0 sentinel rule, non-monotone rows: the separate
+    // calls, one after the other on the stream (same results, the launches of M flows)
+    std::vector<uint64_t*> a_n(layers);
+    std::vector<int64_t*> a_r(layers), a_s(layers), a_d(layers);
+    for (int32_t b = 0; b < n_mb; ++b) {
+      for (int32_t h = 0; h < layers; ++h) {
+        const int64_t cap_n = FlowCap(n, fanouts_host, h), cap_m = cap_n * ((int64_t)fanouts_host[h] + 1);
+        a_n[h] = n_id_dev[h] + (int64_t)b * cap_m;  a_r[h] = res_n_id_dev[h] + (int64_t)b * cap_n;
+        a_s[h] = edge_src_dev[h] + (int64_t)b * cap_m;  a_d[h] = edge_dst_dev[h] + (int64_t)b * cap_m;
+      }
+      const int rc = euler_gpu_sage_blocks(g, stream, seed, call_id + (uint32_t)b * call_stride,
+                                           roots_dev + (int64_t)b * n, n, edge_types_host, k, fanouts_host,
+                                           layers, default_node, add_self_loops, workspace_dev, a_n.data(),
+                                           a_r.data(), a_s.data(), a_d.data(),
+                                           counts_dev + (int64_t)b * (layers + 1));
+      if (rc != EULER_GPU_OK) return rc;
+    }
+    return EULER_GPU_OK;
+  }
+  hipLaunchKernelGGL(FlowInitMultiKernel, dim3(1), dim3(256), 0, st, counts_dev, (uint32_t)n, n_mb, layers + 1);
+  // workgroups per minibatch and kernel: the kernels stride over their work, and the launch as a
+  // whole should be a few thousand workgroups, not n_mb times the worst case
+  const int per_mb = 4096 / n_mb > 0 ? 4096 / n_mb : 1;
+  const uint64_t* n_id = roots_dev;
+  for (int32_t h = 0; h < layers; ++h) {
+    const int32_t count = fanouts_host[h];
+    const int64_t cap_n = FlowCap(n, fanouts_host, h);
+    const int64_t cap_m = cap_n * ((int64_t)count + 1);
+    uint64_t tcap = 64;
+    while (tcap < (uint64_t)cap_m * 2) tcap <<= 1;
+    int64_t R = 0;
+    (void)MultiHopBytes(n_mb, cap_n, count, &R);
+    uint8_t* p = (uint8_t*)workspace_dev;
+    uint64_t* nb = (uint64_t*)p;        p += Al((size_t)n_mb * cap_n * count * 8);
+    FlowHop f{};
+    f.g = view; f.dense_min = nullptr; f.dense_rank = nullptr; f.epoch_hi = 0;
+    f.t.keys = (unsigned long long*)p;  p += Al((size_t)n_mb * (tcap + 1) * 8);
+    f.t.minpos = (uint32_t*)p;          p += Al((size_t)n_mb * (tcap + 1) * 4);
+    f.t.rank = (int32_t*)p;             p += Al((size_t)n_mb * (tcap + 1) * 4);
+    f.t.mask = tcap - 1;
+    f.slot_of = (uint32_t*)p;           p += Al((size_t)n_mb * cap_m * 4);
+    f.blk_cnt = (uint32_t*)p;           p += Al((size_t)n_mb * R * 4);
+    f.n_blk = (cap_m + kFlowChunk - 1) / kFlowChunk;
+    f.first_bits = (unsigned long long*)(f.blk_cnt + ((f.n_blk + 2) & ~(int64_t)1));
+    f.n_mb = n_mb;
+    f.mb_nb = cap_n * count; f.mb_nid = cap_n; f.mb_cnt = layers + 1; f.mb_tab = (int64_t)tcap + 1;
+    f.mb_m = cap_m; f.mb_blk = R;
+    // 1. the hop's sampler, all minibatches
+    FlowSample fs{};
+    fs.g = view; fs.seed = seed; fs.call_id = call_id + (uint32_t)h; fs.call_stride = call_stride;
+    fs.n_id = n_id; fs.cnt = counts_dev + h; fs.nb = nb; fs.cap_n = cap_n; fs.mb_cnt = layers + 1;
+    fs.default_node = default_node; fs.count = count; fs.type = edge_types_host[(size_t)h * k];
+    const int block = 256;
+    {
+      int64_t gx = (cap_n * count + block - 1) / block;
+      if (gx > 2 * per_mb) gx = 2 * per_mb;
+      hipLaunchKernelGGL(FlowSampleKernel, dim3((unsigned)gx, (unsigned)n_mb), dim3(block), 0, st, fs);
+    }
+    // 2. first-occurrence unique of [nb | n_id], 3. res_n_id / edge_index - the kernels of the single
+    // flow, a minibatch per blockIdx.y
+    f.nb = nb; f.n_id = n_id; f.cnt = counts_dev + h; f.cnt_out = counts_dev + h + 1;
+    f.count = count; f.self_loops = add_self_loops ? 1 : 0; f.cap_m = cap_m;
+    f.new_n_id = n_id_dev[h]; f.inv = edge_dst_dev[h]; f.edge_src = edge_src_dev[h];
+    f.res_n_id = res_n_id_dev[h];
+    int64_t gx = (cap_m + 1 + block - 1) / block;
+    if (gx > per_mb) gx = per_mb;
+    int64_t gb = f.n_blk + 1;
+    if (gb > per_mb) gb = per_mb;
+    const dim3 grid((unsigned)gx, (unsigned)n_mb), grid_b((unsigned)gb, (unsigned)n_mb);
+    hipLaunchKernelGGL(FlowClearKernel, grid, dim3(block), 0, st, f);
+    hipLaunchKernelGGL(FlowInsertKernel<true>, grid_b, dim3(kFlowInsertThreads), 0, st, f);
+    hipLaunchKernelGGL(FlowFlagKernel, grid_b, dim3(block), 0, st, f);
+    hipLaunchKernelGGL(FlowEmitKernel, grid_b, dim3(block), 0, st, f);
+    hipLaunchKernelGGL(FlowIndexKernel, grid, dim3(block), 0, st, f);
     EG_HIP(hipGetLastError());
     n_id = n_id_dev[h];
   }
@@ -651,7 +923,8 @@ int euler_gpu_full_blocks(const euler_gpu_graph* g, void* stream, const uint64_t
     const int grid = GridFor(cap_m + 1, block);
     const int grid_b = (int)(f.n_blk + 1 < 65536 ? f.n_blk + 1 : 65536);
     hipLaunchKernelGGL(FlowClearKernel, dim3(grid), dim3(block), 0, st, f);
-    hipLaunchKernelGGL(FlowInsertKernel, dim3(grid_b), dim3(kFlowInsertThreads), 0, st, f);
+    if (f.dense_min != nullptr) hipLaunchKernelGGL(FlowInsertKernel<false>, dim3(grid_b), dim3(kFlowInsertThreads), 0, st, f);
+    else hipLaunchKernelGGL(FlowInsertKernel<true>, dim3(grid_b), dim3(kFlowInsertThreads), 0, st, f);
     hipLaunchKernelGGL(FlowFlagKernel, dim3(grid_b), dim3(block), 0, st, f);
     hipLaunchKernelGGL(FlowEmitKernel, dim3(grid_b), dim3(block), 0, st, f);
     hipLaunchKernelGGL(FlowIndexKernel, dim3(grid), dim3(block), 0, st, f);

@@ -129,6 +129,37 @@ class SageDataFlow(UniqueDataFlow):
             data_flow.append(new_n_id, res_n_id, None, edge_index)
         return data_flow
 
+    def produce_subgraphs(self, n_ids):
+        """The list form: one DataFlow per minibatch of `n_ids` ([M, n] tensor or a list of M
+        equally long id tensors), ALL of them built by one enqueue (Graph.sage_blocks_multi ->
+        euler_gpu_sage_blocks_multi) - what a loop over produce_subgraph returns, bit for
+        bit, for the price of one flow's launches.  Minibatches of different lengths, hops
+        whose edge-type lists differ in length and `fused = False` take that loop."""
+        if not torch.is_tensor(n_ids):
+            n_ids = list(n_ids)
+            same = len({int(x.numel()) for x in n_ids}) == 1
+            if not same or not n_ids:
+                return [self.produce_subgraph(x) for x in n_ids]
+            n_ids = torch.stack([x.reshape(-1) for x in n_ids], 0)
+        lens = {len(m) for m in self.metapath}
+        if not getattr(self, "fused", True) or len(lens) != 1:
+            return [self.produce_subgraph(x) for x in n_ids]
+        try:
+            per_mb = self.graph.sage_blocks_multi(n_ids, self.metapath, self.fanouts,
+                                                  default_node=self.max_id + 1,
+                                                  add_self_loops=self.add_self_loops)
+        except EulerGpuError as e:
+            if e.code != EINVAL:
+                raise
+            return [self.produce_subgraph(x) for x in n_ids]
+        flows = []
+        for b, (blocks, _cnt) in enumerate(per_mb):
+            data_flow = DataFlow(n_ids[b].reshape(-1))
+            for new_n_id, res_n_id, _edge_src, _edge_dst, edge_index in blocks:
+                data_flow.append(new_n_id, res_n_id, None, edge_index)
+            flows.append(data_flow)
+        return flows
+
     def get_neighbors(self, n_id):
         neighbors, neighbor_src = [], []
         for hop_edge_types, count in zip(self.metapath, self.fanouts):

@@ -612,6 +612,54 @@ class Graph:
             blocks.append((n_ids[h][:cnt[h + 1]], res[h][:cnt[h]], esrc[h][:e], edst[h][:e], eidx[h][:, :e]))
         return blocks, cnt
 
+    def sage_blocks_multi(self, nodes, edge_types, fanouts, default_node=-1, add_self_loops=True,
+                          call_id=None, sync=True):
+        """M minibatches' SageDataFlows as ONE enqueue (euler_gpu_sage_blocks_multi): nodes
+        [M, n] int64 -> a list of M (blocks, counts) pairs, each what sage_blocks returns for
+        that minibatch - minibatch b draws with the call ids of the b-th of M consecutive
+        sage_blocks calls, and the result equals theirs bit for bit.  sync=False: (padded
+        tensors per hop - n_id [M, cap], res_n_id [M, cap], edge_src / edge_dst [M, cap] - and the
+        device-side counts [M, layers + 1]), no host read."""
+        nodes = _as_i64_cuda(nodes, self.device)
+        assert nodes.dim() == 2, "sage_blocks_multi: nodes must be [M, n]"
+        M, n = int(nodes.shape[0]), int(nodes.shape[1])
+        nodes = nodes.contiguous()
+        layers = len(fanouts)
+        et = np.asarray(edge_types, dtype=np.int32).reshape(layers, -1)
+        et, et_p, _ = _i32_array(et)
+        k = et.size // layers if layers else 0
+        fan, fan_p, _ = _i32_array(fanouts)
+        caps = [n]
+        for c in fanouts:
+            caps.append(caps[-1] * (int(c) + 1))
+        dev = self.device
+        n_ids = [torch.empty((M, max(caps[h + 1], 1)), dtype=torch.int64, device=dev) for h in range(layers)]
+        res = [torch.empty((M, max(caps[h], 1)), dtype=torch.int64, device=dev) for h in range(layers)]
+        esrc = [torch.empty((M, max(caps[h + 1], 1)), dtype=torch.int64, device=dev) for h in range(layers)]
+        edst = [torch.empty((M, max(caps[h + 1], 1)), dtype=torch.int64, device=dev) for h in range(layers)]
+        counts = torch.zeros((M, layers + 1), dtype=torch.int32, device=dev)
+        ws = torch.empty(max(int(lib().euler_gpu_sage_blocks_multi_workspace(M, n, fan_p, layers)), 16),
+                         dtype=torch.uint8, device=dev)
+        arr = lambda ts: (C.c_void_p * layers)(*[t.data_ptr() for t in ts])
+        with self._on_device():
+            check(lib().euler_gpu_sage_blocks_multi(
+                self._h, _stream(), self.seed, self._take_call_ids(layers * M, call_id), layers, M,
+                _ptr(nodes), n, et_p, k, fan_p, layers, int(default_node), 1 if add_self_loops else 0,
+                _ptr(ws), arr(n_ids), arr(res), arr(esrc), arr(edst), _ptr(counts)))
+        if not sync:
+            return list(zip(n_ids, res, esrc, edst)), counts
+        cnt_all = counts.cpu().numpy().astype(np.int64)          # the one host read
+        out = []
+        for b in range(M):
+            cnt = [int(x) for x in cnt_all[b]]
+            blocks = []
+            for h in range(layers):
+                e = cnt[h] * int(fanouts[h]) + (cnt[h] if add_self_loops else 0)
+                s_, d_ = esrc[h][b, :e], edst[h][b, :e]
+                blocks.append((n_ids[h][b, :cnt[h + 1]], res[h][b, :cnt[h]], s_, d_, torch.stack([s_, d_], 0)))
+            out.append((blocks, cnt))
+        return out
+
     def full_blocks(self, nodes, edge_types, edge_caps, add_self_loops=True, with_types=False):
         """GCNDataFlow / RelationDataFlow block construction as ONE enqueue
         (euler_gpu_full_blocks): every hop = full neighbours of the listed types of the

@@ -581,6 +581,30 @@ int euler_gpu_sage_blocks(const euler_gpu_graph* g, void* stream, uint64_t seed,
                           int64_t* const* edge_src_dev, int64_t* const* edge_dst_dev,
                           uint32_t* counts_dev);
 
+/* n_mb minibatches of n roots each as ONE enqueue - what n_mb consecutive euler_gpu_sage_blocks
+ * calls produce, bit for bit: the reference's GraphSAGE callers build a flow per minibatch of a
+ * few hundred roots (sage_dataflow.py:35-50; examples/graphsage/run_graphsage.py:35 defaults to
+ * 32), which neither fills a GPU nor amortises the dozen launches of a flow.  roots_dev
+ * [n_mb * n], minibatch-major; minibatch b draws hop h with call_id + b * call_stride + h (what
+ * consecutive calls take from a counter with call_stride = layers).  Every output is n_mb copies
+ * of the single call's array, each sized for the worst case and b * cap apart: n_id_dev[h]
+ * [n_mb][cap_{h+1}], res_n_id_dev[h] [n_mb][cap_h], edge_src_dev[h] / edge_dst_dev[h]
+ * [n_mb][cap_{h+1}], counts_dev [n_mb][layers + 1].  Hops that list ONE edge type on a graph
+ * without the id-0 sentinel rule run as one launch per kernel of the flow (a minibatch per
+ * blockIdx.y); other shapes are served by the separate calls, one after the other.
+ * workspace_dev: euler_gpu_sage_blocks_multi_workspace(n_mb, n, fanouts_host, layers) bytes. */
+size_t euler_gpu_sage_blocks_multi_workspace(int32_t n_mb, int64_t n, const int32_t* fanouts_host,
+                                             int32_t layers);
+int euler_gpu_sage_blocks_multi(const euler_gpu_graph* g, void* stream, uint64_t seed,
+                                uint32_t call_id, uint32_t call_stride, int32_t n_mb,
+                                const uint64_t* roots_dev, int64_t n,
+                                const int32_t* edge_types_host, int32_t k,
+                                const int32_t* fanouts_host, int32_t layers, int64_t default_node,
+                                int32_t add_self_loops, void* workspace_dev,
+                                uint64_t* const* n_id_dev, int64_t* const* res_n_id_dev,
+                                int64_t* const* edge_src_dev, int64_t* const* edge_dst_dev,
+                                uint32_t* counts_dev);
+
 /* The full-neighbour dataflows (tf_euler/python/dataflow/gcn_dataflow.py:33-47 GCNDataFlow,
  * relation_dataflow.py:30-72 RelationDataFlow: every hop takes ALL neighbours of the listed
  * edge types of the nodes seen so far, then tf.unique of [neighbours | nodes], res_n_id and

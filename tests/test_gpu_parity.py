@@ -1116,6 +1116,67 @@ def test_sage_blocks_two_host_threads_one_stream(EA, torch_cuda):
     assert not errs, errs
 
 
+def test_sage_blocks_multi_equals_separate_calls(EA, O, torch_cuda, big_pair):
+    """euler_gpu_sage_blocks_multi: M minibatches' SageDataFlows in ONE enqueue (every kernel of the
+    flow with the minibatch as second grid dimension, the hops' samplers one launch with minibatch
+    b's own call id) == M separate sage_blocks calls with the call ids consecutive calls take, bit
+    for bit: identity and hashed id maps, weighted and uniform weights, unknown / duplicate roots,
+    default fills that are no node (-1: the all-ones id's side slot), with and without self loops,
+    three hops, minibatch counts around the launch geometry; hops with type draws go through the
+    separate calls inside the same entry; SageDataFlow.produce_subgraphs == the loop."""
+    torch = torch_cuda
+    N = 200_000
+    gen = torch.Generator(device="cuda"); gen.manual_seed(31)
+
+    def check(G, roots, mp_, fan, dflt, loops):
+        M = roots.shape[0]
+        layers = len(fan)
+        G.set_seed(17)
+        got = G.sage_blocks_multi(roots, mp_, fan, default_node=dflt, add_self_loops=loops, call_id=400)
+        assert len(got) == M
+        for b in range(M):
+            want = G.sage_blocks(roots[b], mp_, fan, default_node=dflt, add_self_loops=loops,
+                                 call_id=400 + b * layers)
+            assert list(got[b][1]) == list(want[1]), (b, got[b][1], want[1])
+            for x, y in zip(got[b][0], want[0]):
+                for u, v in zip(x, y):
+                    assert torch.equal(u, v), b
+        return got
+
+    for weighted in (True, False):
+        G = EA.Graph.synthetic(EA.synth_params(5, N, 8 * N, weighted=weighted))
+        for M, n, fan, dflt, loops in ((64, 300, [5, 4], N + 1, True), (3, 2000, [25, 10], -1, True),
+                                       (130, 17, [3, 2, 2], N + 9, False), (1, 500, [4, 4], N + 1, True)):
+            r = torch.randint(1, N + 1, (M, n), generator=gen, device="cuda", dtype=torch.int64)
+            r[:, ::13] = N + 3                    # ids without a row
+            r[:, 5::29] = 0
+            r[:, 1::7] = r[:, :1]                  # duplicates inside a minibatch
+            if M > 1:
+                r[1] = r[0]                        # ... and two identical minibatches (own call ids: other draws)
+            got = check(G, r, [[0]] * len(fan), fan, dflt, loops)
+            if M > 1 and weighted:
+                assert not torch.equal(got[0][0][0][0], got[1][0][0][0]) or n < 50
+    GH, _OG, ids, rng = big_pair                   # hashed ids, 4 edge types
+    roots = torch.as_tensor(rng.choice(ids, (20, 150)).astype(np.int64)).cuda()
+    roots[:, ::11] = 4242
+    check(GH, roots, [[2], [0]], [4, 3], 10 ** 13 + 1, True)          # one listed type per hop: one enqueue
+    check(GH, roots, [[0, 1], [2, 3]], [4, 3], 10 ** 13 + 1, True)    # type draws: the separate calls
+    # the flow class: the list form == the loop
+    G = EA.Graph.synthetic(EA.synth_params(6, N, 8 * N, weighted=True))
+    r = torch.randint(1, N + 1, (9, 256), generator=gen, device="cuda", dtype=torch.int64)
+    f = EA.dataflow.SageDataFlow(G, [6, 4], [[0], [0]], add_self_loops=True, max_id=N)
+    G.set_seed(3, 70)
+    flows = f.produce_subgraphs(r)
+    G.set_seed(3, 70)
+    loop = [f.produce_subgraph(r[b]) for b in range(9)]
+    for a, b_ in zip(flows, loop):
+        for x, y in zip(a.blocks, b_.blocks):
+            assert torch.equal(x.n_id, y.n_id) and torch.equal(x.res_n_id, y.res_n_id)
+            assert torch.equal(x.edge_index, y.edge_index) and x.size == y.size
+    # minibatches of different lengths take the loop
+    assert len(f.produce_subgraphs([r[0], r[1][:100]])) == 2
+
+
 def test_gcn_and_relation_dataflow_blocks(EA, O, torch_cuda, big_pair):
     """GCNDataFlow / RelationDataFlow (RGCN, config 5) on device == the same
     composition on the oracle: full neighbours of the unique frontier per hop

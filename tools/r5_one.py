@@ -5,6 +5,7 @@
   python tools/r5_one.py sharded_walk [--cohorts K]  euler_gpu_sharded_random_walk, one rank, 1M x 40
   python tools/r5_one.py sharded_step              the sharded fanout step, one rank, ONE minibatch in flight
   python tools/r5_one.py sage                      euler_gpu_sage_blocks, 16 384 roots
+  python tools/r5_one.py sage_multi [--M 64 --B 1024]   euler_gpu_sage_blocks_multi
 Everything on ONE stream, a few iterations, so that kernel durations are not stretched by overlap."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -124,5 +125,17 @@ elif what == "sage":
     for i in range(it):
         G.sage_blocks(r, [[0], [0]], [25, 10], default_node=N + 1, sync=False)
     torch.cuda.synchronize()
+elif what == "sage_multi":
+    # euler_gpu_sage_blocks_multi: M = 64 minibatches of 1 024 roots per enqueue
+    p = euler_amd.synth_params(SEED, N, 10 * N, weighted=True)
+    G = euler_amd.Graph.synthetic(p); G.set_seed(SEED)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(77)
+    M_, B_ = arg("--M", 64), arg("--B", 1024)
+    r = torch.randint(1, N + 1, (M_, B_), generator=gen, device="cuda", dtype=torch.int64)
+    for i in range(3):
+        G.sage_blocks_multi(r, [[0], [0]], [25, 10], default_node=N + 1, sync=False)
+    torch.cuda.synchronize()
+    ms = bench._events(lambda: G.sage_blocks_multi(r, [[0], [0]], [25, 10], default_node=N + 1, sync=False), it)
+    print("RESULT sage_blocks_multi M=%d B=%d: %.4f ms per launch, %.2f us per minibatch" % (M_, B_, ms, ms * 1e3 / M_), flush=True)
 else:
     raise SystemExit("unknown: " + what)
