@@ -908,7 +908,9 @@ int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,
 /* ---- index memory ------------------------------------------------------------
  * The weight-bucket index (csrc/wb_index.h) is built on the first sampling / walk / block call
  * of a graph with non-uniform, non-decreasing running sums: 128 bytes per 4 edges of rows
- * with more than 10 edges + 8 + 8 T bytes per row (44 GB for 100M nodes / 1B edges).  It is an
+ * with more than 10 edges + 8 + 8 T bytes per row (about 40 GB for 100M nodes / 1B edges; a graph
+ * it serves does not get the 13 bytes per edge of EdgeBlocks the pivot-level search needs - those
+ * are built, also on first use, only for graphs without a serving index).  It is an
  * optimisation that is DECLINED - the pivot-level search then serves, same results - when
  * it would take more than `max_free_fraction` of the HBM that is free at that moment
  * (default 0.5) or more than `max_bytes` (default: no absolute cap; 0 = never build it),
