@@ -16,6 +16,7 @@
 
 extern thread_local int g_feature_vec4;   // mp_kernels.hip
 namespace euler_gpu { extern thread_local int g_walk_collapse, g_walk_grid, g_walk_tail, g_walk_lean; }   // walk_kernels.hip
+namespace euler_gpu { extern thread_local int g_sharded_self_exchange; }   // sharded.cc
 namespace euler_gpu { extern thread_local int g_root_host_batch, g_adj_scan, g_adj_long_row, g_sum_scalar; }   // layer_kernels.hip
 
 namespace euler_gpu {
@@ -1796,6 +1797,7 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 48 && (value == 0 || value == 1)) { g_fl_typed_regs = value; return EULER_GPU_OK; }
   if (key == 49 && (value == 0 || value == 1)) { g_fl_fat = value; return EULER_GPU_OK; }
   if (key == 51 && (value == 0 || value == 1)) { g_blk_policy = value; return EULER_GPU_OK; }
+  if (key == 52 && (value == 0 || value == 1)) { g_sharded_self_exchange = value; return EULER_GPU_OK; }
   return Fail(EULER_GPU_EINVAL, "set_tuning: unknown key");
 }
 

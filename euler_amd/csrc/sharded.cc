@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <string>
 #include <vector>
@@ -63,6 +64,23 @@ const Rccl& GetRccl() {
     return x;
   }();
   return r;
+}
+
+}  // namespace (reopened below)
+namespace euler_gpu {
+// One rank's ids never leave it, so its hops make no exchange at all - which would leave the
+// transport (ncclSend / ncclRecv groups) unexecuted on a one-GPU box.  EULER_GPU_SELF_EXCHANGE=1 (or
+// tuning key 52) makes a lone rank send to itself what N ranks send to one another: the
+// coverage switch of the tests, never a production setting.
+thread_local int g_sharded_self_exchange = -1;
+}
+namespace {
+bool SelfExchange() {
+  if (euler_gpu::g_sharded_self_exchange < 0) {
+    const char* e = getenv("EULER_GPU_SELF_EXCHANGE");
+    euler_gpu::g_sharded_self_exchange = (e != nullptr && e[0] == '1') ? 1 : 0;
+  }
+  return euler_gpu::g_sharded_self_exchange != 0;
 }
 
 struct RcclUser {
@@ -204,14 +222,15 @@ int euler_gpu_sharded_sample_neighbor(const euler_gpu_graph* shard, const euler_
   // 2. who gets how many ids from whom.  (One rank: every id is its own - no exchange, the
   //    buckets ARE the owned ids and the sampled rows ARE the answers.)
   int rc = EULER_GPU_OK;
-  if (W == 1) recv_rows[0] = send_rows[0];
+  const bool lone = W == 1 && !SelfExchange();
+  if (lone) recv_rows[0] = send_rows[0];
   else rc = tr->alltoall_counts(tr->user, send_rows.data(), recv_rows.data());
   if (rc != EULER_GPU_OK) return rc;
   int64_t m = 0;
   for (int32_t s = 0; s < W; ++s) m += recv_rows[s];
   // 3. ids to their owners
   uint64_t* owned = shard_ids;
-  if (W > 1) {
+  if (!lone) {
     owned = (uint64_t*)sc.Get((size_t)(m > 0 ? m : 1) * 8);
     if (!owned) return Fail(EULER_GPU_ENOMEM, "sharded_sample_neighbor: scratch");
     rc = tr->alltoallv(tr->user, shard_ids, send_rows.data(), owned, recv_rows.data(), 8, stream);
@@ -223,7 +242,7 @@ int euler_gpu_sharded_sample_neighbor(const euler_gpu_graph* shard, const euler_
   int32_t* rows = (int32_t*)sc.Get((size_t)(m > 0 ? m : 1) * words * 4);
   int64_t asked = 0;
   for (int32_t s = 0; s < W; ++s) asked += send_rows[s];
-  int32_t* back = W == 1 ? rows : (int32_t*)sc.Get((size_t)(asked > 0 ? asked : 1) * words * 4);
+  int32_t* back = lone ? rows : (int32_t*)sc.Get((size_t)(asked > 0 ? asked : 1) * words * 4);
   if (!rows || !back) return Fail(EULER_GPU_ENOMEM, "sharded_sample_neighbor: scratch");
   if (m > 0) {
     rc = euler_gpu_sample_neighbor_packed(shard, stream, seed, call_id, owned, m, edge_types_host, k,
@@ -232,7 +251,7 @@ int euler_gpu_sharded_sample_neighbor(const euler_gpu_graph* shard, const euler_
   }
   // 5. rows back along the reversed split; the shards answered in the order they
   //    were asked, so row pos[i] of `back` is position i's row
-  if (W > 1) {
+  if (!lone) {
     rc = tr->alltoallv(tr->user, rows, recv_rows.data(), back, send_rows.data(), (int64_t)words * 4,
                        stream);
     if (rc != EULER_GPU_OK) return rc;
@@ -312,6 +331,7 @@ int euler_gpu_sharded_random_walk(const euler_gpu_graph* shard, const euler_gpu_
     return Fail(EULER_GPU_EINVAL, "sharded_random_walk: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   const int32_t W = tr->world, L = walk_len, K = cohorts;
+  const bool lone = W == 1 && (!SelfExchange() || !tr->alltoall_counts || !tr->alltoallv);
   Scratch sc(st);
   int32_t* et_dev = nullptr;
   {
@@ -362,7 +382,7 @@ int euler_gpu_sharded_random_walk(const euler_gpu_graph* shard, const euler_gpu_
     const int64_t asked = off[(size_t)W];
     entries += q.m;
     uint64_t* level = const_cast<uint64_t*>(q.ids[(size_t)s + 1]);
-    if (W == 1) {
+    if (lone) {
       // one rank: the buckets are the owned ids, the draws are the next level
       rc = euler_gpu::WalkOwnedStep(shard, st, seed, call_id, et_dev, k, L, s, q.bucketed, asked, level);
       if (rc != EULER_GPU_OK) return rc;

@@ -109,6 +109,10 @@ class ShardedSampler:
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        # a lone rank's ids never leave it, so its hops skip the exchanges; True makes it send to
+        # itself what N ranks send to one another (EULER_GPU_SELF_EXCHANGE=1: the tests' way to
+        # execute the RCCL all-to-all on a one-GPU box - never a production setting)
+        self.force_exchange = os.environ.get("EULER_GPU_SELF_EXCHANGE") == "1"
         self.partitions = partitions or self.world
         self.local_sample = local_sample
         self.split_fn = split_fn
@@ -183,7 +187,7 @@ class ShardedSampler:
         host-side mailbox between the ranks of one node, see ShmCounts) when the
         sampler has one, else an all-to-all of the counts on the GPU followed by
         a device sync."""
-        if self.world == 1:
+        if self.world == 1 and not self.force_exchange:
             return [int(c) for c in send_counts]
         if self.counts_fn is not None:
             return self.counts_fn(send_counts)
@@ -204,7 +208,7 @@ class ShardedSampler:
         self.bytes_sent += row_bytes * (int(sum(send_counts)) - int(send_counts[me]))
         self.bytes_received += row_bytes * (out_rows - int(recv_counts[me]))
         self.exchanges += 1
-        if self.world == 1:
+        if self.world == 1 and not self.force_exchange:
             # one rank: every id is this rank's own, nothing crosses a link - the "exchange"
             # is the buffer itself (a self send / receive through RCCL costs a 46 MB copy per
             # fanout step and moves nothing)

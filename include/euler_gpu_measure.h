@@ -114,6 +114,10 @@ extern "C" {
  *        its block does not bracket bisects the flat running sums (the fallback of graphs the
  *        index serves, made frequent for tests); 0 [default] = such graphs get the EdgeBlocks
  *        and their pivot levels.  Takes effect for graphs whose EdgeBlocks are not built yet.
+ * key 52: 1 = a lone rank of the sharded entry points (euler_gpu_sharded_*) makes the id and row
+ *        exchanges anyway - a send to itself through the transport - instead of skipping them
+ *        (0 [default]; the environment variable EULER_GPU_SELF_EXCHANGE=1 sets the default): the
+ *        tests' way to execute the RCCL transport on a box with one GPU.
  * All settings produce identical results; the knobs exist for A/B measurements
  * and tests.  They are THREAD-LOCAL: a call changes the launches the calling host
  * thread enqueues afterwards and nobody else's (new threads start from the

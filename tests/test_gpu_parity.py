@@ -747,6 +747,33 @@ def test_gpu_sharded_sampler_single_rank(EA, O, torch_cuda, big_pair):
                     assert np.array_equal(t2n(gn[h + 1]), on[h]), (ets, dedup, packed, h)
                     assert np.array_equal(t2n(gw[h]), ow[h])
                     assert np.array_equal(t2n(gt[h]), ot[h])
+        # A lone rank's ids never leave it, so the hops above made no exchange at all.  With the
+        # exchanges MADE - the rank sends itself what N ranks send one another - RCCL's all-to-all
+        # executes on this box: the Python orchestration (dist.all_to_all_single on nccl) and the C
+        # entries over the callback transport (tuning key 52), fanout and walk.
+        from euler_amd.distributed import c_sharded_sample_fanout, c_sharded_random_walk
+        from euler_amd import _lib
+        qt = torch.as_tensor(q).cuda()
+        ets, cnts = [[0], [1]], [6, 5]
+        on, ow, ot = OG.sample_fanout(31, 8, q, ets, cnts, -1)
+        S = gpu_sharded_sampler(G, partitions=1)
+        S.force_exchange = True
+        x0 = S.exchanges
+        gn, gw, gt = S.sample_fanout(qt, ets, cnts, -1, call_id=8)
+        assert S.exchanges > x0
+        for h in range(2):
+            assert np.array_equal(t2n(gn[h + 1]), on[h]) and np.array_equal(t2n(gw[h]), ow[h])
+        walk_ref = G.random_walk(qt, [[0]] * 5, 1.0, 1.0, -1, call_id=90)
+        _lib.check(_lib.lib().euler_gpu_set_tuning(52, 1))
+        try:
+            gn, gw, gt = c_sharded_sample_fanout(G, S.c_transport, qt, ets, cnts, -1, call_id=8, partitions=1)
+            for h in range(2):
+                assert np.array_equal(t2n(gn[h + 1]), on[h]) and np.array_equal(t2n(gw[h]), ow[h])
+                assert np.array_equal(t2n(gt[h]), ot[h])
+            walk = c_sharded_random_walk(G, S.c_transport, qt, [[0]] * 5, -1, 90, 1, 1, S.dense_table)
+            assert torch.equal(walk, walk_ref)
+        finally:
+            _lib.lib().euler_gpu_set_tuning(52, 0)
         S = gpu_sharded_sampler(G, partitions=1)
         # full neighbours through the exchange (variable-length merge)
         qf = torch.as_tensor(q).cuda()

@@ -327,13 +327,21 @@ def test_cpp_multi_gpu_host_over_rccl(torch_cuda):
     euler_gpu_sharded_sample_fanout; it compares every rank's result with the unsharded
     graph itself - the fanout and a random_walk of length 40 (euler_gpu_sharded_random_walk).
     One GPU here, so one rank: a rank's own ids never leave it (no exchange), the rest is the
-    code path an 8-GPU node runs with N = 8."""
+    code path an 8-GPU node runs with N = 8; a second run makes the lone rank's exchanges anyway
+    (EULER_GPU_SELF_EXCHANGE=1), so that the RCCL transport itself executes."""
     import subprocess
     exe = os.path.join(ROOT, "examples", "cpp", "sharded_fanout")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "examples", "cpp")])
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run([exe, "1", "300000", "2048"], capture_output=True, text=True, timeout=600,
+                         env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "sharded_fanout OK: 1 rank(s)" in out.stdout, out.stdout + out.stderr
+    # ... and with the lone rank's exchanges made (it sends itself what N ranks send one another):
+    # the ncclSend / ncclRecv groups of the transport execute on this box
+    env["EULER_GPU_SELF_EXCHANGE"] = "1"
     out = subprocess.run([exe, "1", "300000", "2048"], capture_output=True, text=True, timeout=600,
                          env=env)
     assert out.returncode == 0, out.stdout + out.stderr
