@@ -441,3 +441,20 @@ def test_python_surface_argument_caches():
         assert L.euler_gpu_set_tuning(key, 0) != 0
     for key, v in ((0, 6), (27, 1), (38, 262144), (43, 12), (44, 1)):
         assert L.euler_gpu_set_tuning(key, v) == 0
+
+
+def test_block_construction_workspace_sizes():
+    """euler_gpu_sage_blocks[_multi]_workspace are host arithmetic (no GPU): the multi form's
+    workspace holds the single call's (its fallback - hops with type draws - runs the separate
+    calls in it), grows with the number of minibatches, and is M copies of a hop's arrays."""
+    import ctypes as C
+    from euler_amd import _lib
+    L = _lib.lib()
+    for n, fanouts in ((1024, [25, 10]), (300, [5, 4, 3]), (1, [1])):
+        fan = (C.c_int32 * len(fanouts))(*fanouts)
+        one = L.euler_gpu_sage_blocks_workspace(n, fan, len(fanouts))
+        sizes = [L.euler_gpu_sage_blocks_multi_workspace(m, n, fan, len(fanouts)) for m in (1, 2, 8, 64)]
+        assert one > 0 and sizes[0] >= one
+        assert all(b > a for a, b in zip(sizes, sizes[1:]))
+        assert sizes[3] <= 9 * sizes[2]          # ~linear in M
+
