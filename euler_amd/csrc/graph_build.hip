@@ -270,10 +270,18 @@ void AliasBuild(const std::vector<float>& weights, std::vector<float>* prob,
 int BuildNodeSampler(GraphBuilder* b, const std::vector<uint64_t>& ids,
                      const std::vector<int32_t>& types,
                      const std::vector<float>& weights, int32_t n_types) {
-  if (n_types > kMaxNodeTypes)
-    return Fail(EULER_GPU_EINVAL, "more than 32 node types");
+  if (n_types <= 0 || n_types > kMaxNodeTypes)
+    return Fail(EULER_GPU_EINVAL, "node sampler: 1 .. 32 node types");
   const size_t n = ids.size();
-  NodeSamplerView& s = b->g->sampler;
+  // Everything is validated and built on the side; the graph's sampler is replaced only when the
+  // new table is on the device (a failed rebuild must leave the old sampler intact).
+  for (size_t i = 0; i < n; ++i) {
+    if (types[i] < 0 || types[i] >= n_types)
+      return Fail(EULER_GPU_EINVAL, "node sampler: node type out of range");
+    if (!(weights[i] >= 0.f) || !std::isfinite(weights[i]))
+      return Fail(EULER_GPU_EINVAL, "node sampler: node weights must be finite and >= 0");
+  }
+  NodeSamplerView s;
   std::memset(&s, 0, sizeof(s));
   s.n_types = n_types;
   std::vector<std::vector<uint64_t>> tid(n_types);
@@ -281,18 +289,22 @@ int BuildNodeSampler(GraphBuilder* b, const std::vector<uint64_t>& ids,
   std::vector<float> sums(n_types, 0.f);
   for (size_t i = 0; i < n; ++i) {
     const int32_t t = types[i];
-    if (t < 0 || t >= n_types)
-      return Fail(EULER_GPU_EINVAL, "node type out of range");
     tid[t].push_back(ids[i]);
     tw[t].push_back(weights[i]);
     sums[t] += weights[i];
   }
+  for (int32_t t = 0; t < n_types; ++t)
+    if (!std::isfinite(sums[t]))
+      return Fail(EULER_GPU_EINVAL, "node sampler: a node type's weights sum to infinity");
   std::vector<AliasEntry> entries(n);
   size_t off = 0;
   for (int32_t t = 0; t < n_types; ++t) {
     s.type_off[t] = (int64_t)off;
     std::vector<float>& w = tw[t];
-    for (auto& x : w) x /= sums[t];                  // graph.cc:355-358
+    // a type whose nodes all weigh 0 is never drawn (its type sum is 0: Graph::SampleNode returns
+    // nothing for it, graph.cc:221-245); its table is filled evenly instead of with 0 / 0
+    const bool dead = !w.empty() && !(sums[t] > 0.f);
+    for (auto& x : w) x = dead ? 1.0f / (float)w.size() : x / sums[t];   // graph.cc:355-358
     float sum = 0.f;
     for (auto x : w) sum += x;                       // FWC::Init sum_weight_
     std::vector<float> norm(w);
@@ -308,7 +320,7 @@ int BuildNodeSampler(GraphBuilder* b, const std::vector<uint64_t>& ids,
       entries[off + i] = e;
     }
     s.type_sum[t] = sums[t];
-    s.sampler_sum[t] = w.empty() ? 0.f : sum;
+    s.sampler_sum[t] = (w.empty() || dead) ? 0.f : sum;
     off += w.size();
   }
   s.type_off[n_types] = (int64_t)off;
@@ -317,7 +329,7 @@ int BuildNodeSampler(GraphBuilder* b, const std::vector<uint64_t>& ids,
   for (int32_t t = 0; t < n_types; ++t) tsum += sums[t];
   s.tc_sum = tsum;
   std::vector<float> tnorm(sums);
-  for (auto& x : tnorm) x /= tsum;
+  for (auto& x : tnorm) x = tsum > 0.f ? x / tsum : 1.0f / (float)n_types;
   std::vector<float> tprob;
   std::vector<int64_t> talias;
   AliasBuild(tnorm, &tprob, &talias);
@@ -327,6 +339,7 @@ int BuildNodeSampler(GraphBuilder* b, const std::vector<uint64_t>& ids,
   }
   s.entries = b->Upload(entries.data(), entries.size());
   if (!s.entries) return b->rc;
+  b->g->sampler = s;
   b->g->has_sampler = true;
   b->g->n_node_types = n_types;
   b->g->node_weight_sums = sums;
@@ -1062,6 +1075,15 @@ int EnsureWbIndex(const euler_gpu_graph* cg) {
   return EULER_GPU_OK;
 }
 
+// test hook (euler_gpu_set_tuning key 56): the next N builds of the EdgeBlocks fail as an
+// allocation would (tests/test_gpu_parity.py: test_index_builds_declined)
+std::atomic<int> g_blk_fail_next{0};
+
+// The EdgeBlocks are an optimisation as the weight-bucket index is: when they cannot
+// be built - no memory for 13 bytes per edge after the caller's features / model took the HBM -
+// what the attempt allocated is returned, the decision is remembered (no rebuild per call) and
+// the samplers run WITHOUT them: a view with neither index makes BlockPivotSample bisect the flat
+// running sums and LoadSegment read the limits from them (k1_search.h) - same results, slower.
 int EnsureBlockedIndex(const euler_gpu_graph* cg) {
   euler_gpu_graph* g = const_cast<euler_gpu_graph*>(cg);
   if (g->blk_ready.load(std::memory_order_acquire) != 0) return EULER_GPU_OK;
@@ -1072,11 +1094,30 @@ int EnsureBlockedIndex(const euler_gpu_graph* cg) {
   EG_HIP(hipSetDevice(g->device));
   GraphBuilder b;
   b.g.reset(g);                 // borrow the graph: allocations land in its list
-  const int rc = BuildBlockedIndex(&b);
+  const size_t n_alloc = g->allocations.size();
+  const int64_t bytes0 = g->bytes;
+  int rc;
+  if (g_blk_fail_next.load() > 0) {
+    g_blk_fail_next.fetch_sub(1);
+    (void)b.Alloc<uint8_t>(4096);        // (something to roll back)
+    rc = Fail(EULER_GPU_ENOMEM, "EdgeBlocks: allocation failure injected (tuning key 56)");
+  } else {
+    rc = BuildBlockedIndex(&b);
+  }
   b.g.release();
+  if (rc != EULER_GPU_OK) {
+    (void)hipGetLastError();
+    (void)hipDeviceSynchronize();
+    (void)hipGetLastError();
+    while (g->allocations.size() > n_alloc) { (void)hipFree(g->allocations.back()); g->allocations.pop_back(); }
+    g->bytes = bytes0;
+    GraphView& v = g->view;
+    v.blk = nullptr; v.skip1 = nullptr; v.bpiv = nullptr; v.n_blk = 0;
+  }
   (void)hipSetDevice(prev);
-  if (rc == EULER_GPU_OK) g->blk_ready.store(1, std::memory_order_release);
-  return rc;
+  // 1 = built, 2 = declined: either way this graph is not asked again
+  g->blk_ready.store(rc == EULER_GPU_OK ? 1 : 2, std::memory_order_release);
+  return EULER_GPU_OK;
 }
 
 // rows -> host (spot checks)
@@ -1230,17 +1271,25 @@ int euler_gpu_graph_set_node_sampler(euler_gpu_graph* g, int64_t n, const uint64
   EG_HIP(hipGetDevice(&prev));
   EG_HIP(hipSetDevice(g->device));
   const AliasEntry* old = g->has_sampler ? g->sampler.entries : nullptr;
+  const int64_t old_bytes = g->has_sampler
+      ? (int64_t)std::max<size_t>((size_t)g->sampler.type_off[g->sampler.n_types] * sizeof(AliasEntry), 16) : 0;
+  const size_t n_alloc = g->allocations.size();
+  const int64_t bytes0 = g->bytes;
   GraphBuilder b;
   b.g.reset(g);                 // borrow the graph: the table lands in its allocation list
   const int rc = BuildNodeSampler(&b, ids, types, weights, n_node_types);
   b.g.release();
-  if (rc == EULER_GPU_OK && old != nullptr) {
+  if (rc != EULER_GPU_OK) {
+    // nothing of the graph was touched except, possibly, an allocation whose upload failed
+    while (g->allocations.size() > n_alloc) { (void)hipFree(g->allocations.back()); g->allocations.pop_back(); }
+    g->bytes = bytes0;
+  } else if (old != nullptr) {
     auto it = std::find(g->allocations.begin(), g->allocations.end(), (void*)old);
     if (it != g->allocations.end()) {
-      (void)hipDeviceSynchronize();
+      (void)hipDeviceSynchronize();      // (no launch may still read the old table)
       (void)hipFree(*it);
       g->allocations.erase(it);
-      g->bytes -= (int64_t)0;   // (the old table's size is not tracked separately)
+      g->bytes -= old_bytes;
     }
   }
   (void)hipSetDevice(prev);

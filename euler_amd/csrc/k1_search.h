@@ -14,6 +14,9 @@ namespace euler_gpu {
 
 // running sum of edge m out of its EdgeBlock
 __device__ __forceinline__ float BlockedPw(const GraphView& g, int64_t m) {
+  // (a graph whose EdgeBlocks were declined - graph_build.hip: EnsureBlockedIndex - and that has
+  // no weight-bucket index either: the flat sums hold the same value)
+  if (g.blk == nullptr) return g.prefix_w[m];
   const int64_t bi = m / kEdgesPerBlock;
   return g.blk[bi].pw[(int32_t)(m - bi * kEdgesPerBlock)];
 }

@@ -13,10 +13,12 @@
 #include "k1_args.h"
 #include "k1_search.h"
 #include "fanout_local.h"
+#include "fanout_plain.h"
 
 extern thread_local int g_feature_vec4;   // mp_kernels.hip
 namespace euler_gpu { extern thread_local int g_walk_collapse, g_walk_grid, g_walk_tail, g_walk_lean; }   // walk_kernels.hip
-namespace euler_gpu { extern thread_local int g_sharded_self_exchange; }   // sharded.cc
+namespace euler_gpu { extern std::atomic<int> g_sharded_self_exchange; }   // sharded.cc (process-wide)
+namespace euler_gpu { extern std::atomic<int> g_blk_fail_next; }           // graph_build.hip (test hook)
 namespace euler_gpu { extern thread_local int g_root_host_batch, g_adj_scan, g_adj_long_row, g_sum_scalar; }   // layer_kernels.hip
 
 namespace euler_gpu {
@@ -572,6 +574,11 @@ thread_local int g_fl_min_roots = 32768;  // key 33: smaller batches keep the wo
 thread_local int g_fl_plain = 2;      // key 34: plain graphs: 2 = the lean kernel, 1 = the general kernel
                                       // constant-folded, 0 = the general kernel
 thread_local int g_fl_wps = 5;        // key 35: register budget, waves per SIMD (8, 6 or 5; 5: nothing spilled)
+thread_local int g_fp_on = 1;         // key 53: plain graphs with the weight-bucket index take the kernel of
+                                      // fanout_plain.h (1); 0 = the lean build of fanout_local.h (round 5)
+thread_local int g_fp_coop = 1;       // key 54: ... a block's keys fetched by three lanes as ONE request per line and
+                                      // staged in LDS (1); 0 = three 16-byte loads per lane and line (round 5's pattern)
+thread_local int g_fp_wps = 5;        // key 55: ... its register budget, waves per SIMD (4 .. 8)
 thread_local int g_fl_wb = 1;         // key 45: the lean kernel draws through the weight-bucket index (wb_index.h:
                                       // one line per draw); 0 = the pivot-level search of rounds 2-3
 thread_local int g_fl_typed_regs = 1;  // key 48: typed hops on graphs of <= 4 edge-type groups keep the row record in registers (1)
@@ -1532,6 +1539,45 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
           lcap >>= 1;
           ll = FanoutLeanLayout(gr, c1, c2, lcap, lean_t);
         }
+        // plain graph + weight-bucket index (the metric's shape): the kernel of fanout_plain.h
+        const bool use_wb0 = v.uniform_w == 0 && f.g.wrec != nullptr && f.g.wb != nullptr && v.wb_lean_ok != 0;
+        if (g_fp_on != 0 && plain && !typed_hops && use_wb0 && f.wide) {
+          int32_t pgr = g_fl_roots > 0 ? gr : 4;
+          while (multi != nullptr && pgr > 1 && multi->n_per % pgr != 0) pgr >>= 1;
+          int32_t pcap = g_fl_cap > 0 ? g_fl_cap : (g_fp_coop != 0 ? 64 / (c2 / 2 > 0 ? c2 / 2 : 1) : 32);
+          if (pcap > pgr * c1) pcap = pgr * c1;
+          const int pblock = (g_fl_block == 64 || g_fl_block == 128 || g_fl_block == 256) ? g_fl_block : 128;
+          const bool coop = g_fp_coop != 0;
+          const FanoutPlainLds pl = FanoutPlainLayout(pgr, c1, c2, pcap, coop);
+          const int64_t tp = (int64_t)pgr * c1 * c2;
+          if (pgr * ((c1 + 1) / 2) <= 64 && pgr * c1 <= 255 && pgr * c1 % 4 == 0 && tp % 4 == 0 && c2 <= 64 &&
+              c1 <= 128 && (int64_t)pcap * c2 < 4096 && (size_t)pl.bytes * (pblock / 64) <= 64 * 1024) {
+            FanoutPlainArgs pa{};
+            pa.wrec = f.g.wrec; pa.wb = f.g.wb; pa.prefix_w = f.g.prefix_w; pa.nbr = f.g.nbr;
+            pa.roots = roots_dev;
+            pa.id1 = f.id1; pa.w1 = f.w1; pa.ty1 = f.ty1; pa.id2 = f.id2; pa.w2 = f.w2; pa.ty2 = f.ty2;
+            pa.row_index = t_fl_row_index;
+            pa.call_ids = f.call_ids; pa.seed = seed; pa.id_base = f.g.id_base; pa.id_stride = f.g.id_stride;
+            pa.n = n; pa.n_rows = f.g.n_rows; pa.default_node = default_node; pa.mb_n = f.mb_n;
+            pa.call_id = call_id; pa.call_stride = f.call_stride;
+            pa.c1 = c1; pa.c2 = c2; pa.gr = pgr; pa.cap = pcap; pa.wave_lds = (int32_t)pl.bytes;
+            const int64_t ptiles = (n + pgr - 1) / pgr;
+            const int pwpb = pblock / 64;
+            int64_t pblocks = (ptiles + pwpb - 1) / pwpb;
+            int64_t pwaves = g_fl_grid_cap > 0 ? g_fl_grid_cap : 0;
+            if (pwaves > 0 && pblocks > (pwaves + pwpb - 1) / pwpb) pblocks = (pwaves + pwpb - 1) / pwpb;
+            void (*pk)(const FanoutPlainArgs) = nullptr;
+#define EG_FP(W) (coop ? SampleFanoutPlainKernel<W, true> : SampleFanoutPlainKernel<W, false>)
+            pk = g_fp_wps >= 8 ? EG_FP(8) : g_fp_wps == 7 ? EG_FP(7) : g_fp_wps == 6 ? EG_FP(6)
+                 : g_fp_wps == 5 ? EG_FP(5) : EG_FP(4);
+#undef EG_FP
+            t_fl_took_lean = 1;
+            hipLaunchKernelGGL(pk, dim3((unsigned)pblocks), dim3(pblock), (size_t)pl.bytes * pwpb, stream, pa);
+            EG_HIP(hipGetLastError());
+            if (uniq_off != nullptr) { uniq_off[0] = -1; uniq_off[1] = -1; }
+            return EULER_GPU_OK;
+          }
+        }
         if ((size_t)ll.bytes * (block / 64) <= 64 * 1024) {
           f.cap = lcap; f.wave_lds = (int32_t)ll.bytes;
           f.div_h1.Set((uint32_t)(c1 + 1) / 2); f.div_h2.Set((uint32_t)c2 / 2);
@@ -1797,7 +1843,11 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 48 && (value == 0 || value == 1)) { g_fl_typed_regs = value; return EULER_GPU_OK; }
   if (key == 49 && (value == 0 || value == 1)) { g_fl_fat = value; return EULER_GPU_OK; }
   if (key == 51 && (value == 0 || value == 1)) { g_blk_policy = value; return EULER_GPU_OK; }
-  if (key == 52 && (value == 0 || value == 1)) { g_sharded_self_exchange = value; return EULER_GPU_OK; }
+  if (key == 52 && (value == 0 || value == 1)) { g_sharded_self_exchange.store(value); return EULER_GPU_OK; }
+  if (key == 53 && (value == 0 || value == 1)) { g_fp_on = value; return EULER_GPU_OK; }
+  if (key == 54 && (value == 0 || value == 1)) { g_fp_coop = value; return EULER_GPU_OK; }
+  if (key == 55 && value >= 4 && value <= 8) { g_fp_wps = value; return EULER_GPU_OK; }
+  if (key == 56 && value >= 0) { g_blk_fail_next.store(value); return EULER_GPU_OK; }
   return Fail(EULER_GPU_EINVAL, "set_tuning: unknown key");
 }
 

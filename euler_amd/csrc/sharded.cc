@@ -72,15 +72,22 @@ namespace euler_gpu {
 // transport (ncclSend / ncclRecv groups) unexecuted on a one-GPU box.  EULER_GPU_SELF_EXCHANGE=1 (or
 // tuning key 52) makes a lone rank send to itself what N ranks send to one another: the
 // coverage switch of the tests, never a production setting.
-thread_local int g_sharded_self_exchange = -1;
+// Process-wide: the per-rank threads of a C++ host, a Python dataloader thread and
+// ShardedSampler.force_exchange all read and write this one value (key 52 both ways).
+std::atomic<int> g_sharded_self_exchange{-1};
+std::atomic<long long> g_sharded_exchanges{0};     // exchanges made (euler_gpu_sharded_exchange_count)
 }
 namespace {
 bool SelfExchange() {
-  if (euler_gpu::g_sharded_self_exchange < 0) {
+  int v = euler_gpu::g_sharded_self_exchange.load();
+  if (v < 0) {
     const char* e = getenv("EULER_GPU_SELF_EXCHANGE");
-    euler_gpu::g_sharded_self_exchange = (e != nullptr && e[0] == '1') ? 1 : 0;
+    int want = (e != nullptr && e[0] == '1') ? 1 : 0;
+    int expect = -1;
+    euler_gpu::g_sharded_self_exchange.compare_exchange_strong(expect, want);
+    v = euler_gpu::g_sharded_self_exchange.load();
   }
-  return euler_gpu::g_sharded_self_exchange != 0;
+  return v != 0;
 }
 
 struct RcclUser {

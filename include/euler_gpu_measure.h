@@ -117,7 +117,10 @@ extern "C" {
  * key 52: 1 = a lone rank of the sharded entry points (euler_gpu_sharded_*) makes the id and row
  *        exchanges anyway - a send to itself through the transport - instead of skipping them
  *        (0 [default]; the environment variable EULER_GPU_SELF_EXCHANGE=1 sets the default): the
- *        tests' way to execute the RCCL transport on a box with one GPU.
+ *        tests' way to execute the RCCL transport on a box with one GPU.  PROCESS-WIDE (the
+ *        sharded calls of every host thread see it), unlike the other keys.
+ * key 56: test hook, PROCESS-WIDE: the next `value` builds of the EdgeBlocks fail the way an
+ *        allocation failure would (the graph is then served without them: same results).
  * All settings produce identical results; the knobs exist for A/B measurements
  * and tests.  They are THREAD-LOCAL: a call changes the launches the calling host
  * thread enqueues afterwards and nobody else's (new threads start from the

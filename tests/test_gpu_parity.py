@@ -1721,7 +1721,7 @@ def test_full_neighbor_fill_kernels_agree(EA, O, torch_cuda, big_pair):
         _lib.lib().euler_gpu_set_tuning(24, 1)
 
 
-_FL_DEFAULTS = {27: 1, 28: 0, 29: 0, 30: 0, 31: 1, 32: -1, 33: 32768, 34: 2, 35: 5, 45: 1}
+_FL_DEFAULTS = {27: 1, 28: 0, 29: 0, 30: 0, 31: 1, 32: -1, 33: 32768, 34: 2, 35: 5, 45: 1, 53: 1, 54: 1, 55: 5}
 
 
 @pytest.mark.parametrize("geom", [(4, 0, 256, 1, 8, 2, 0, 1), (1, 1, 64, 0, 5, 0, 0, 1), (2, 3, 128, 1, 8, 0, 0, 1),
@@ -1853,6 +1853,107 @@ def test_fanout_local_dedup_kernel(EA, O, torch_cuda, big_pair, geom):
         for call in range(12):
             check(G0, OG0, q, [[0], [0]], [3, 2], -1, 1, call)
             check(G0, OG0, q, [[0], [0]], [4, 6], -1, 1, 100 + call)
+    finally:
+        for k_, v_ in _FL_DEFAULTS.items():
+            L.euler_gpu_set_tuning(k_, v_)
+
+
+@pytest.mark.parametrize("geom", [(0, 0, 0, 5, 1, -1), (4, 32, 128, 5, 1, -1), (4, 3, 64, 8, 1, -1), (4, 100, 256, 4, 1, 0),
+                                  (2, 7, 128, 7, 1, 5), (4, 12, 128, 6, 1, -1), (4, 2, 64, 5, 0, 3), (1, 1, 64, 6, 1, 1),
+                                  (4, 32, 128, 4, 0, -1), (4, 13, 256, 4, 1, 7)],
+                         ids=["shipped", "cap32", "cap3_wps8", "cap100_wps4", "gr2_grid5", "cap12_wps6", "lane_loads_cap2_grid3",
+                              "gr1_grid1", "lane_loads", "cap13_grid7"])
+def test_fanout_plain_kernel(EA, O, torch_cuda, geom):
+    """fanout_plain.h (round 6): the one-kernel 2-hop fanout rebuilt for plain graphs served by
+    the weight-bucket index.  Every build (register budget; a block's keys fetched by three
+    lanes through LDS-DMA - key 54 = 1, staged over the results when a pass is one step and
+    beside them otherwise - or by the lane that owns the draw) and geometry (roots per wave, slots per pass incl. several
+    passes, block size, grid-stride loop) must write the oracle's ids / weights / types and
+    what round 5's kernel (key 53 = 0) writes: unknown roots, id 0, duplicate roots, ragged
+    last tiles, strided ids, dangling neighbour ids, hub rows (> 64 edges: duplicates by id;
+    several buckets per row), rows without edges, several fanouts, several minibatches per
+    launch and the (unique rows, index) form."""
+    torch = torch_cuda
+    from euler_amd import _lib
+    L = _lib.lib()
+    gr, cap, block, wps, coop, grid = geom
+    keys = {27: 2, 28: gr, 29: cap, 30: block, 32: grid, 33: 0, 55: wps, 54: coop}
+
+    def check(G, OG, q, counts, default, seed, call, took=True):
+        qt = torch.as_tensor(q).cuda()
+        G.set_seed(seed)
+        on, ow, ot = OG.sample_fanout(seed, call, q, [[0], [0]], counts, default)
+        L.euler_gpu_set_tuning(53, 1)
+        gn, gw, gt = G.sample_fanout(qt, [[0], [0]], counts, default, call_id=call)
+        for h in range(2):
+            assert np.array_equal(t2n(gn[h + 1]), on[h]), (geom, len(q), counts, h)
+            assert np.array_equal(t2n(gw[h]), ow[h]), (geom, len(q), counts, h)
+            assert np.array_equal(t2n(gt[h]), ot[h]), (geom, len(q), counts, h)
+        L.euler_gpu_set_tuning(53, 0)           # round 5's kernel
+        rn, rw, rt = G.sample_fanout(qt, [[0], [0]], counts, default, call_id=call)
+        L.euler_gpu_set_tuning(53, 1)
+        for h in range(2):
+            assert torch.equal(gn[h + 1], rn[h + 1]) and torch.equal(gw[h], rw[h]) and torch.equal(gt[h], rt[h])
+        if counts[1] % 2 == 0:
+            id1, w1, t1, idx, rid, rw2, rt2 = G.sample_fanout_unique(qt, [[0], [0]], counts, default, call_id=call)
+            assert np.array_equal(t2n(id1).reshape(-1), on[0]) and np.array_equal(t2n(w1).reshape(-1), ow[0])
+            assert np.array_equal(t2n(rid[idx]).reshape(-1), on[1]), (geom, counts)
+            assert np.array_equal(t2n(rw2[idx]).reshape(-1), ow[1]) and np.array_equal(t2n(rt2[idx]).reshape(-1), ot[1])
+
+    try:
+        for k_, v_ in keys.items():
+            _lib.check(L.euler_gpu_set_tuning(k_, v_))
+        # power-law plain graph: mostly rows of 1 - 2 edges, a few hubs
+        p = EA.synth_params(977, 20000, 260000, n_types=1, weighted=True)
+        po = O.SynthParams()
+        for f, _ in po._fields_:
+            setattr(po, f, getattr(p, f))
+        G1, OG1 = EA.Graph.synthetic(p), O.OracleGraph(O.synth_csr(po))
+        r1 = np.random.default_rng(5)
+        for B in (1, 2, 3, 5, 333, 3001):
+            q = np.concatenate([r1.integers(1, 20001, B), [0, 20001, 1, 1, 2]]).astype(np.int64)
+            if B <= 3:
+                q = q[:B]
+            for counts in ([25, 10], [10, 10], [3, 4], [10, 6], [1, 2], [80, 6], [7, 64], [2, 2]):
+                check(G1, OG1, q, counts, 20001, 3, 6)
+        # hubs only: rows of hundreds / thousands of edges
+        ph = EA.synth_params(31, 3000, 900000, n_types=1, weighted=True)
+        po = O.SynthParams()
+        for f, _ in po._fields_:
+            setattr(po, f, getattr(ph, f))
+        G2, OG2 = EA.Graph.synthetic(ph), O.OracleGraph(O.synth_csr(po))
+        q = np.random.default_rng(6).integers(1, 3001, 701).astype(np.int64)
+        for counts in ([25, 10], [6, 4]):
+            check(G2, OG2, q, counts, 3001, 9, 40)
+        # ids = base + stride * row, rows without edges, dangling neighbour ids, degrees around 64
+        for base, stride in ((1, 1), (7, 3), (0, 2)):
+            rng = np.random.default_rng(99 + stride)
+            n = 6000
+            ids = (base + stride * np.arange(n)).astype(np.uint64)
+            deg = rng.choice([0, 1, 2, 3, 9, 10, 11, 40, 63, 64, 65, 66, 130], n)
+            seg = np.zeros(n + 1, np.int64)
+            seg[1:] = np.cumsum(deg)
+            E = int(seg[-1])
+            nbr = rng.choice(ids[1:] if base == 0 else ids, E).astype(np.uint64)      # (no neighbour id 0)
+            dang = rng.random(E) < 0.03
+            nbr[dang] = nbr[dang] + (1 if stride > 1 else stride * n + 7)
+            w = (rng.random(E) * 7.5 + 0.5).astype(np.float32)
+            csr = O.csr_from_raw(ids, seg, nbr, w, 1, np.zeros(n, np.int32), np.ones(n, np.float32))
+            G3, OG3 = gpu_graph(EA, csr), O.OracleGraph(csr)
+            q = np.concatenate([rng.choice(ids, 2049), [0, base + stride * n + 1, base + 1]]).astype(np.int64)
+            for counts in ([25, 10], [4, 6]):
+                check(G3, OG3, q, counts, -1, 21, 60)
+        # several minibatches per launch: minibatch b draws with its own call id
+        M, Bm = 5, 64
+        r = np.random.default_rng(8).integers(1, 20001, (M, Bm)).astype(np.int64)
+        G1.set_seed(77)
+        res = G1.sample_fanout_multi(torch.as_tensor(r).cuda(), [[0], [0]], [25, 10], 20001, call_id=500)
+        for b in range(M):
+            on, ow, ot = OG1.sample_fanout(77, 500 + 2 * b, r[b], [[0], [0]], [25, 10], 20001)
+            nb, wb, tb = res[b]
+            for h in range(2):
+                assert np.array_equal(t2n(nb[h + 1]).reshape(-1), on[h]), (geom, b, h)
+                assert np.array_equal(t2n(wb[h]).reshape(-1), ow[h]) and np.array_equal(t2n(tb[h]).reshape(-1), ot[h])
     finally:
         for k_, v_ in _FL_DEFAULTS.items():
             L.euler_gpu_set_tuning(k_, v_)

@@ -1,0 +1,135 @@
+// Micro-benchmark (round 6): what does fetching one random 128-byte index block cost on gfx950
+// depending on HOW the lanes of a wave ask for it?  The sampler reads a block's keys as three
+// 16-byte loads per lane plus a dependent 8-byte id load - four requests for one line per lane.
+//   MODE 0: lane-private line, ONE dwordx4 (floor: one request per line)
+//   MODE 1: lane-private line, 3 x dwordx4 + a dependent 8-byte load (what WbSamplePair does)
+//   MODE 2: lane-private line, 3 x dwordx4 only
+//   MODE 3: 8 lanes share a line, each its own 16 bytes (one coalesced request per line,
+//           64 lines per 8 instructions), values exchanged with DPP-style shuffles
+//   MODE 4: 4 lanes share a line: three take the key chunks, the fourth the id chunk the pick
+//           names (dependent), 16 lines per instruction
+// Independent loads per wave-step = UNROLL lines per lane (MODEs 0-2) so that the memory-level
+// parallelism per wave matches the sampler's (a pair of draws per lane).
+//   hipcc --offload-arch=gfx950 -O3 tools/ubench_block.hip -o gpurun_out/ubench_block
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+  printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+__device__ __forceinline__ uint64_t Mix(uint64_t z) {
+  z ^= z >> 30; z *= 0xbf58476d1ce4e5b9ULL;
+  z ^= z >> 27; z *= 0x94d049bb133111ebULL;
+  z ^= z >> 31;
+  return z;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void Fetch(const uint32_t* __restrict__ base, uint64_t n_lines,
+                                             int iters, uint32_t* __restrict__ sink) {
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63;
+  uint32_t acc = 0;
+  uint64_t x = Mix(MODE == 3 ? tid >> 3 : MODE == 4 ? tid >> 2 : tid);
+  for (int i = 0; i < iters; ++i) {
+    if (MODE <= 2) {
+      // two independent lines per lane and step (a pair of draws)
+      const uint64_t l0 = (x >> 8) % n_lines, l1 = (Mix(x) >> 8) % n_lines;
+      const uint4* p0 = reinterpret_cast<const uint4*>(base + l0 * 32);
+      const uint4* p1 = reinterpret_cast<const uint4*>(base + l1 * 32);
+      uint32_t v;
+      if (MODE == 0) {
+        const uint4 a = p0[0], b = p1[0];
+        v = a.x ^ b.y;
+      } else {
+        const uint4 a0 = p0[0], a1 = p0[1], a2 = p0[2];
+        const uint4 b0 = p1[0], b1 = p1[1], b2 = p1[2];
+        v = a0.x ^ a1.y ^ a2.z ^ b0.x ^ b1.y ^ b2.z;
+        if (MODE == 1) {
+          const uint64_t* i0 = reinterpret_cast<const uint64_t*>(p0) + 6 + (v % 10u);
+          const uint64_t* i1 = reinterpret_cast<const uint64_t*>(p1) + 6 + ((v >> 8) % 10u);
+          v ^= (uint32_t)(*i0) ^ (uint32_t)(*i1);
+        }
+      }
+      acc += v;
+      x = Mix(x + v + 0x9E3779B97F4A7C15ULL);
+    } else if (MODE == 3) {
+      // 8 lanes per line; two lines per group and step keep 2 x 8 = 16 lines per wave-step...
+      // the wave makes 4 such steps where MODE 1 makes one (64 lanes x 2 lines = 128 lines)
+      const uint64_t l0 = (x >> 8) % n_lines, l1 = (Mix(x) >> 8) % n_lines;
+      const uint4 a = reinterpret_cast<const uint4*>(base + l0 * 32)[lane & 7];
+      const uint4 b = reinterpret_cast<const uint4*>(base + l1 * 32)[lane & 7];
+      uint32_t v = a.x ^ a.w ^ b.y ^ b.z;
+      // reduce over the group (three xor-shuffles), as a count of keys would be
+      v ^= __shfl_xor(v, 1); v ^= __shfl_xor(v, 2); v ^= __shfl_xor(v, 4);
+      acc += v;
+      x = Mix(x + v + 0x9E3779B97F4A7C15ULL);
+    } else {
+      const uint64_t l0 = (x >> 8) % n_lines, l1 = (Mix(x) >> 8) % n_lines;
+      const uint32_t sub = lane & 3;
+      const uint4* p0 = reinterpret_cast<const uint4*>(base + l0 * 32);
+      const uint4* p1 = reinterpret_cast<const uint4*>(base + l1 * 32);
+      uint4 a = make_uint4(0, 0, 0, 0), b = a;
+      if (sub < 3) { a = p0[sub]; b = p1[sub]; }
+      uint32_t v = a.x ^ a.w ^ b.y ^ b.z;
+      v ^= __shfl_xor(v, 1); v ^= __shfl_xor(v, 2);
+      if (sub == 3) {     // the id chunk the pick names
+        a = p0[3 + (v % 5u)]; b = p1[3 + ((v >> 8) % 5u)];
+        v ^= a.x ^ b.x;
+      }
+      v = __shfl(v, lane | 3);
+      acc += v;
+      x = Mix(x + v + 0x9E3779B97F4A7C15ULL);
+    }
+  }
+  if (acc == 0x12345678u) sink[tid] = acc;
+}
+
+__global__ void Fill(uint32_t* p, uint64_t n) {
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n;
+       i += (uint64_t)gridDim.x * blockDim.x)
+    p[i] = (uint32_t)Mix(i);
+}
+
+template <int MODE>
+static void Run(const uint32_t* buf, uint64_t n_lines, const char* name, uint32_t* sink, int wpc) {
+  // wpc waves per CU resident: 256 CUs x wpc / 4 workgroups of 256 threads
+  const int block = 256, grid = 256 * wpc / 4, iters = MODE == 3 ? 256 : MODE == 4 ? 128 : 32;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(Fetch<MODE>, dim3(grid), dim3(block), 0, 0, buf, n_lines, iters, sink);
+  CK(hipEventRecord(e0, 0));
+  const int reps = 5;
+  for (int r = 0; r < reps; ++r)
+    hipLaunchKernelGGL(Fetch<MODE>, dim3(grid), dim3(block), 0, 0, buf, n_lines, iters, sink);
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= reps;
+  const double lane_steps = (double)grid * block * iters;
+  const double lines = lane_steps * 2.0 / (MODE == 3 ? 8.0 : MODE == 4 ? 4.0 : 1.0);
+  printf("%-44s waves/CU %2d  %8.3f ms  %7.2f G lines/s\n", name, wpc, ms, lines / ms / 1e6);
+}
+
+int main() {
+  const uint64_t bytes = 16ULL << 30;
+  uint32_t* buf; uint32_t* sink;
+  CK(hipMalloc(&buf, bytes));
+  CK(hipMalloc(&sink, 256 * 32 * 64 * 4));
+  hipLaunchKernelGGL(Fill, dim3(4096), dim3(256), 0, 0, buf, bytes / 4);
+  CK(hipDeviceSynchronize());
+  const uint64_t nl = bytes / 128;
+  for (int wpc : {8, 16, 24, 32}) {
+    Run<0>(buf, nl, "private line, 1 x dwordx4", sink, wpc);
+    Run<2>(buf, nl, "private line, 3 x dwordx4", sink, wpc);
+    Run<1>(buf, nl, "private line, 3 x dwordx4 + dependent id", sink, wpc);
+    Run<3>(buf, nl, "8 lanes share a line (coalesced)", sink, wpc);
+    Run<4>(buf, nl, "4 lanes share a line, id chunk dependent", sink, wpc);
+    printf("\n");
+  }
+  return 0;
+}
