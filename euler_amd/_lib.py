@@ -66,6 +66,8 @@ SIGNATURES = {
     "euler_gpu_graph_bytes": (C.c_int64, [vp]),
     "euler_gpu_graph_node_weight_sums": (C.c_int, [vp, f32p]),
     "euler_gpu_graph_set_node_sampler": (C.c_int, [vp, C.c_int64, u64p, i32p, f32p, C.c_int32]),
+    "euler_gpu_last_fanout_kernel": (C.c_char_p, []),
+    "euler_gpu_graph_index_overflow_rows": (C.c_int, [vp, u64p, C.c_int64, i64p]),
     "euler_gpu_graph_export_rows": (C.c_int, [vp, u64p, C.c_int64, i64p, i32p, u64p,
                                               f32p, f32p]),
     "InitQueryProxy": (C.c_bool, [C.c_char_p]),
@@ -249,6 +251,9 @@ SIGNATURES = {
     "euler_gpu_sharded_random_walk": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint32, vp, C.c_int64,
                                                  i32p, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
                                                  C.c_int32, vp, C.c_int64, vp, i64p]),
+    "euler_gpu_sharded_node2vec_walk": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint32, vp, C.c_int64,
+                                                   i32p, C.c_int32, C.c_int32, C.c_float, C.c_float,
+                                                   C.c_int64, C.c_int32, vp, C.c_int64, vp, i64p]),
     "euler_gpu_transport_rccl": (C.c_int, [vp, C.c_int32, C.c_int32, vp, vp]),
     "euler_gpu_transport_rccl_release": (None, [vp]),
     "euler_gpu_sharded_sample_neighbor": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint32, vp,

@@ -241,6 +241,7 @@ struct euler_gpu_graph {
   // kernels of two streams fit on the chip together (sample_kernels.hip: ConcurrentCall)
   mutable std::atomic<void*> last_stream{nullptr};
   mutable std::atomic<int> wb_tried{0};     // EnsureWbIndex ran (whatever it decided)
+  std::vector<uint32_t> wb_overflow_rows;   // rows with a bucket that overflows its block (the first 4 096 found)
   mutable std::atomic<int> blk_ready{0};    // EnsureBlockedIndex built the EdgeBlocks (view.blk / skip1 / bpiv)
   // Block construction (dataflow_kernels.hip): first-occurrence unique of a hop's node list
   // through a table indexed by graph ROW, one per stream, kept across calls: 8 bytes per row
@@ -287,6 +288,12 @@ int WalkOwnedStep(const euler_gpu_graph* g, hipStream_t st, uint64_t seed, uint3
 int WalkPathsFromLevels(hipStream_t st, const int64_t* starts_dev, int64_t n, int32_t walk_len,
                         const uint64_t* const* level_ids_host, const int32_t* const* level_next_host,
                         int64_t default_node, int64_t* out_dev);
+// ... and of the sharded node2vec walk: row lengths <-> FillNeighbor offsets, one column of
+// the [n, walk_len + 1] result, the value offsets at the peers' row bounds
+int N2vRowLens(hipStream_t st, const int32_t* idx_dev, int64_t m, int32_t* lens_dev);
+int N2vIdxFromLens(hipStream_t st, const int32_t* lens_dev, int64_t m, int32_t* tmp_ends_dev, int32_t* idx_dev);
+int N2vStoreColumn(hipStream_t st, const int64_t* src_dev, int64_t n, int64_t stride, int64_t col, int64_t* out_dev);
+int N2vBoundOffsets(hipStream_t st, const int32_t* idx_dev, const int64_t* bounds_dev, int32_t w, int64_t* out_dev);
 // dat_reader.cc
 struct DatGraph {
   std::vector<uint64_t> row_id, nbr;

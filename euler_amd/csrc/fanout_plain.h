@@ -237,6 +237,100 @@ __device__ __forceinline__ void WaveSamplePairs(const FanoutPlainArgs& a, const 
   }
 }
 
+// Hop 2 does not need the drawn edge's number, and most draws do not need the third key chunk:
+// the answer i = #{keys <= f} is known from keys 0 .. 7 unless all eight are <= f, and for
+// 1 <= i <= 7 both nw[i] and nw[i - 1] are among them and key 0 <= f proves the block brackets
+// the draw from below.  So a draw asks for TWO key chunks, then - together with its id -
+// for the third only when i == 0 (prev_last: the weight and the bracket check; the id is
+// nbr[0] either way) or i == 8 (keys 8, 9 and the two candidate ids in the same trip):
+// ~3.3 requests per line instead of 4 on a kernel whose read side is bound by requests
+// (tools/ubench_block.hip).  LITE2 of the sampler below.
+__device__ __forceinline__ float Sel8(const float4 a0, const float4 a1, const uint32_t i) {
+  const bool b0 = (i & 1u) != 0, b1 = (i & 2u) != 0, b2 = (i & 4u) != 0;
+  const float s01 = b0 ? a0.y : a0.x, s23 = b0 ? a0.w : a0.z, s45 = b0 ? a1.y : a1.x, s67 = b0 ? a1.w : a1.z;
+  const float q03 = b1 ? s23 : s01, q47 = b1 ? s67 : s45;
+  return b2 ? q47 : q03;
+}
+
+__device__ __forceinline__ void PlainSamplePairLite(const FanoutPlainArgs& a, const WbRec rec,
+                                                    const bool live0, const bool live1, const double u0,
+                                                    const double u1, uint64_t id[2], float w[2]) {
+  const double r0 = __dmul_rn(u0, (double)rec.total), r1 = __dmul_rn(u1, (double)rec.total);
+  bool cold0 = live0 && !((double)rec.total > r0);
+  bool cold1 = live1 && !((double)rec.total > r1);
+  const float f0 = WbFloorToFloat(r0), f1 = WbFloorToFloat(r1);
+  const uint32_t nbk = WbBuckets(rec.deg);
+  uint32_t j0 = 0u, j1 = 0u;
+  if (nbk > 1u) {
+    const float scale = WbScale(nbk, rec.total);
+    j0 = WbBucketOf(f0, nbk, scale);
+    j1 = WbBucketOf(f1, nbk, scale);
+  }
+  const EdgeBlock* b0 = a.wb + rec.wb_lo + j0;
+  const EdgeBlock* b1 = a.wb + rec.wb_lo + j1;
+  const float4 p0 = *reinterpret_cast<const float4*>(b0->pw), p1 = *reinterpret_cast<const float4*>(b0->pw + 4);
+  const float4 q0 = *reinterpret_cast<const float4*>(b1->pw), q1 = *reinterpret_cast<const float4*>(b1->pw + 4);
+  uint32_t i0 = 0, i1 = 0;
+  i0 += !(p0.x > f0) ? 1u : 0u; i0 += !(p0.y > f0) ? 1u : 0u; i0 += !(p0.z > f0) ? 1u : 0u; i0 += !(p0.w > f0) ? 1u : 0u;
+  i0 += !(p1.x > f0) ? 1u : 0u; i0 += !(p1.y > f0) ? 1u : 0u; i0 += !(p1.z > f0) ? 1u : 0u; i0 += !(p1.w > f0) ? 1u : 0u;
+  i1 += !(q0.x > f1) ? 1u : 0u; i1 += !(q0.y > f1) ? 1u : 0u; i1 += !(q0.z > f1) ? 1u : 0u; i1 += !(q0.w > f1) ? 1u : 0u;
+  i1 += !(q1.x > f1) ? 1u : 0u; i1 += !(q1.y > f1) ? 1u : 0u; i1 += !(q1.z > f1) ? 1u : 0u; i1 += !(q1.w > f1) ? 1u : 0u;
+  const bool t0 = live0 && !cold0, t1 = live1 && !cold1;
+  const bool edge0 = t0 && (i0 == 0u || i0 == 8u), edge1 = t1 && (i1 == 0u || i1 == 8u);
+  // the second trip: the id (nbr[min(i, 8)]: for i == 8 the pair nbr[8], nbr[9]) and, at the
+  // two ends, the third chunk
+  fl_u64x2 n0, n1;
+  n0.x = 0; n0.y = 0; n1 = n0;
+  float4 p2 = make_float4(0.f, 0.f, 0.f, 0.f), q2 = p2;
+  if (t0) {
+    if (i0 == 8u) n0 = *reinterpret_cast<const fl_u64x2*>(b0->nbr + 8);
+    else n0.x = b0->nbr[i0];
+  }
+  if (t1) {
+    if (i1 == 8u) n1 = *reinterpret_cast<const fl_u64x2*>(b1->nbr + 8);
+    else n1.x = b1->nbr[i1];
+  }
+  if (edge0) p2 = *reinterpret_cast<const float4*>(b0->pw + 8);
+  if (edge1) q2 = *reinterpret_cast<const float4*>(b1->pw + 8);
+  id[0] = 0; id[1] = 0; w[0] = 0.f; w[1] = 0.f;
+  bool hot0 = t0, hot1 = t1;
+  if (t0) {
+    if (!edge0) { id[0] = n0.x; w[0] = __fsub_rn(Sel8(p0, p1, i0), Sel8(p0, p1, i0 - 1u)); }
+    else if (i0 == 0u) { hot0 = !(p2.z > f0); id[0] = n0.x; w[0] = __fsub_rn(p0.x, p2.z); }
+    else {              // all of keys 0 .. 7 <= f: the answer is edge 8 or 9 of the block, or beyond it
+      const bool k8 = p2.x > f0, k9 = p2.y > f0;
+      hot0 = k8 || k9;
+      id[0] = k8 ? n0.x : n0.y;
+      w[0] = k8 ? __fsub_rn(p2.x, p1.w) : __fsub_rn(p2.y, p2.x);
+    }
+  }
+  if (t1) {
+    if (!edge1) { id[1] = n1.x; w[1] = __fsub_rn(Sel8(q0, q1, i1), Sel8(q0, q1, i1 - 1u)); }
+    else if (i1 == 0u) { hot1 = !(q2.z > f1); id[1] = n1.x; w[1] = __fsub_rn(q0.x, q2.z); }
+    else {
+      const bool k8 = q2.x > f1, k9 = q2.y > f1;
+      hot1 = k8 || k9;
+      id[1] = k8 ? n1.x : n1.y;
+      w[1] = k8 ? __fsub_rn(q2.x, q1.w) : __fsub_rn(q2.y, q2.x);
+    }
+  }
+  cold0 = live0 && !hot0;
+  cold1 = live1 && !hot1;
+  if (__ballot(cold0 || cold1) != 0ull) {
+#pragma nounroll
+    for (int s = 0; s < 2; ++s) {
+      if (s == 0 ? cold0 : cold1) {
+        const float* nw = a.prefix_w + rec.lo;
+        const uint32_t mid = (uint32_t)RandomSelect(nw, 0, (uint64_t)(rec.deg - 1u), s == 0 ? u0 : u1);
+        const uint64_t ci = a.nbr[rec.lo + mid];
+        const float cw = __fsub_rn(nw[mid], mid == 0u ? 0.f : nw[mid - 1]);
+        if (s == 0) { id[0] = ci; w[0] = cw; }
+        else { id[1] = ci; w[1] = cw; }
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ uint32_t OpaqueLane(uint32_t lane) {
   asm volatile("" : "+v"(lane));
   return lane;
@@ -257,7 +351,7 @@ __device__ __forceinline__ WbRec PlainLoadRec(const FanoutPlainArgs& a, const ui
   return wr;
 }
 
-template <int WPS, bool COOP>
+template <int WPS, bool COOP, bool LITE2 = false>
 __global__ __launch_bounds__(256, WPS) void SampleFanoutPlainKernel(const FanoutPlainArgs a) {
   extern __shared__ __align__(16) uint8_t fp_smem[];
   const uint32_t lane = threadIdx.x & 63u;
@@ -419,6 +513,8 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutPlainKernel(const Fanout
           const uint32_t left = ns - sb < RPI ? ns - sb : RPI;        // slots of this step
           WaveSamplePairs(a, lane, __umul24(left, hp2), s_stage, s_blk, cr, lv, lv, UnitFromWords(pb.w[0], pb.w[1]),
                           UnitFromWords(pb.w[2], pb.w[3]), i2, w2, m2);
+        } else if (LITE2) {
+          PlainSamplePairLite(a, cr, lv, lv, UnitFromWords(pb.w[0], pb.w[1]), UnitFromWords(pb.w[2], pb.w[3]), i2, w2);
         } else {
           PlainSamplePair(a, cr, lv, lv, UnitFromWords(pb.w[0], pb.w[1]), UnitFromWords(pb.w[2], pb.w[3]),
                           i2, w2, m2);

@@ -855,11 +855,16 @@ __global__ void WbRecKernel(GraphView g, const uint32_t* wb_lo, uint8_t* wbg, in
   }
 }
 
+constexpr int kWbOverflowKeep = 4096;
+
 // one lane per block: its row is the last one with wb_lo[row] <= block (rows without edges
 // have no blocks and share their successor's offset)
 __global__ __launch_bounds__(256) void WbFillKernel(GraphView g, const uint32_t* wb_lo,
                                                     int64_t n_wb, EdgeBlock* wb,
                                                     unsigned long long* overflows) {
+  // overflows[0] = buckets that overflow their block, [1] = entries taken in the list of their
+  // rows that follows (kWbOverflowKeep uint32 row numbers: what a test draws roots from)
+  uint32_t* ovf_rows = reinterpret_cast<uint32_t*>(overflows + 2);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   unsigned long long mine = 0;
   for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_wb; b += stride) {
@@ -872,8 +877,11 @@ __global__ __launch_bounds__(256) void WbFillKernel(GraphView g, const uint32_t*
     const uint32_t deg = (uint32_t)m.type_end[g.T - 1];
     EdgeBlock e;
     if (WbBuildBlock(g.prefix_w, g.nbr, (uint32_t)m.row_ptr, deg, g.prefix_w[m.row_ptr + deg - 1],
-                     (uint32_t)(b - (int64_t)wb_lo[lo]), &e))
+                     (uint32_t)(b - (int64_t)wb_lo[lo]), &e)) {
       ++mine;
+      const unsigned long long k = atomicAdd(overflows + 1, 1ull);
+      if (k < (unsigned long long)kWbOverflowKeep) ovf_rows[k] = (uint32_t)lo;
+    }
     wb[b] = e;
   }
   if (mine != 0) atomicAdd(overflows, mine);
@@ -1027,15 +1035,20 @@ int BuildWbIndex(GraphBuilder* b) {
   if (b->rc != EULER_GPU_OK) return b->rc;
   hipLaunchKernelGGL(WbRecKernel, dim3((v.n_rows + block - 1) / block), dim3(block), 0, 0, v, wb_lo,
                      wbg, stride);
-  EG_HIP(hipMalloc((void**)&tmp.ovf, 16));
+  EG_HIP(hipMalloc((void**)&tmp.ovf, 16 + 4 * kWbOverflowKeep));
   unsigned long long* ovf = tmp.ovf;
-  EG_HIP(hipMemset(ovf, 0, 16));
+  EG_HIP(hipMemset(ovf, 0, 16 + 4 * kWbOverflowKeep));
   if (n_wb > 0)
     hipLaunchKernelGGL(WbFillKernel, dim3(GridFor(n_wb, block)), dim3(block), 0, 0, v, wb_lo, n_wb, wb, ovf);
   EG_HIP(hipGetLastError());
   EG_HIP(hipDeviceSynchronize());
   unsigned long long n_ovf = 0;
   EG_HIP(hipMemcpy(&n_ovf, ovf, 8, hipMemcpyDeviceToHost));
+  {
+    const size_t keep = (size_t)std::min<unsigned long long>(n_ovf, (unsigned long long)kWbOverflowKeep);
+    b->g->wb_overflow_rows.resize(keep);
+    if (keep > 0) EG_HIP(hipMemcpy(b->g->wb_overflow_rows.data(), ovf + 2, keep * 4, hipMemcpyDeviceToHost));
+  }
   v.wrec = rec; v.wb = wb; v.n_wb = n_wb; v.wbg = wbg; v.wbg_stride = stride;
   v.trec = wbg; v.trec_stride = stride;
   // (i.i.d. uniform weights: 1e-4; lognormal sigma 2, Pareto alpha 0.7: ~5e-2)
@@ -1294,6 +1307,24 @@ int euler_gpu_graph_set_node_sampler(euler_gpu_graph* g, int64_t n, const uint64
   }
   (void)hipSetDevice(prev);
   return rc;
+}
+
+int euler_gpu_graph_index_overflow_rows(const euler_gpu_graph* g, uint64_t* ids_host, int64_t cap,
+                                        int64_t* n_host) {
+  if (!g || !n_host || cap < 0 || (cap > 0 && !ids_host))
+    return Fail(EULER_GPU_EINVAL, "index_overflow_rows: bad arguments");
+  *n_host = 0;
+  const int rc = EnsureWbIndex(g);
+  if (rc != EULER_GPU_OK) return rc;
+  const GraphView& v = g->view;
+  if (v.map_mode != 0) return EULER_GPU_OK;        // (ids of a hashed graph are not kept per row on the host)
+  int64_t n = 0;
+  for (uint32_t row : g->wb_overflow_rows) {
+    if (n >= cap) break;
+    ids_host[n++] = v.id_base + v.id_stride * (uint64_t)row;
+  }
+  *n_host = n;
+  return EULER_GPU_OK;
 }
 
 int euler_gpu_graph_node_weight_sums(const euler_gpu_graph* g, float* out_host) {

@@ -576,8 +576,10 @@ thread_local int g_fl_plain = 2;      // key 34: plain graphs: 2 = the lean kern
 thread_local int g_fl_wps = 5;        // key 35: register budget, waves per SIMD (8, 6 or 5; 5: nothing spilled)
 thread_local int g_fp_on = 1;         // key 53: plain graphs with the weight-bucket index take the kernel of
                                       // fanout_plain.h (1); 0 = the lean build of fanout_local.h (round 5)
-thread_local int g_fp_coop = 1;       // key 54: ... a block's keys fetched by three lanes as ONE request per line and
+thread_local int g_fp_coop = 0;       // key 54: ... a block's keys fetched by three lanes as ONE request per line and
                                       // staged in LDS (1); 0 = three 16-byte loads per lane and line (round 5's pattern)
+thread_local int g_fp_lite2 = 0;      // key 57: ... hop 2 asks for two key chunks per draw and for the third only at
+                                      // the ends of its block (1); 0 = all three
 thread_local int g_fp_wps = 5;        // key 55: ... its register budget, waves per SIMD (4 .. 8)
 thread_local int g_fl_wb = 1;         // key 45: the lean kernel draws through the weight-bucket index (wb_index.h:
                                       // one line per draw); 0 = the pivot-level search of rounds 2-3
@@ -593,6 +595,7 @@ thread_local int g_k1_typed_pivot = 1;   // key 37: calls with type draws search
                                          // loop)
 thread_local uint32_t* t_fl_row_index = nullptr;   // set by euler_gpu_sample_fanout_unique around its call
 thread_local int t_fl_took_lean = 0;                // ... and whether the lean kernel served it
+thread_local const char* t_fl_last_kernel = "";      // euler_gpu_last_fanout_kernel: what the calling thread's last 2-hop fanout launched
 thread_local void* g_fl_debug = nullptr;   // euler_gpu_set_debug_buffer: phase stamps of the lean kernel
 
 int SamplingView(const euler_gpu_graph* g, GraphView* out) {
@@ -1541,7 +1544,9 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
         }
         // plain graph + weight-bucket index (the metric's shape): the kernel of fanout_plain.h
         const bool use_wb0 = v.uniform_w == 0 && f.g.wrec != nullptr && f.g.wb != nullptr && v.wb_lean_ok != 0;
-        if (g_fp_on != 0 && plain && !typed_hops && use_wb0 && f.wide) {
+        // (a caller that alternates streams keeps round 5's build: its 8-roots-per-wave geometry is the faster one
+        //  when launches share the chip - 0.199 against 0.205-0.212 ms per step, profiles/r6_sweep*.txt)
+        if (g_fp_on != 0 && (t_concurrent != 1 || g_fp_on == 2) && plain && !typed_hops && use_wb0 && f.wide) {
           int32_t pgr = g_fl_roots > 0 ? gr : 4;
           while (multi != nullptr && pgr > 1 && multi->n_per % pgr != 0) pgr >>= 1;
           int32_t pcap = g_fl_cap > 0 ? g_fl_cap : (g_fp_coop != 0 ? 64 / (c2 / 2 > 0 ? c2 / 2 : 1) : 32);
@@ -1567,11 +1572,13 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
             int64_t pwaves = g_fl_grid_cap > 0 ? g_fl_grid_cap : 0;
             if (pwaves > 0 && pblocks > (pwaves + pwpb - 1) / pwpb) pblocks = (pwaves + pwpb - 1) / pwpb;
             void (*pk)(const FanoutPlainArgs) = nullptr;
-#define EG_FP(W) (coop ? SampleFanoutPlainKernel<W, true> : SampleFanoutPlainKernel<W, false>)
+#define EG_FP(W) (coop ? SampleFanoutPlainKernel<W, true, false> : g_fp_lite2 != 0 ? SampleFanoutPlainKernel<W, false, true> \
+                       : SampleFanoutPlainKernel<W, false, false>)
             pk = g_fp_wps >= 8 ? EG_FP(8) : g_fp_wps == 7 ? EG_FP(7) : g_fp_wps == 6 ? EG_FP(6)
                  : g_fp_wps == 5 ? EG_FP(5) : EG_FP(4);
 #undef EG_FP
             t_fl_took_lean = 1;
+            t_fl_last_kernel = "SampleFanoutPlainKernel";
             hipLaunchKernelGGL(pk, dim3((unsigned)pblocks), dim3(pblock), (size_t)pl.bytes * pwpb, stream, pa);
             EG_HIP(hipGetLastError());
             if (uniq_off != nullptr) { uniq_off[0] = -1; uniq_off[1] = -1; }
@@ -1619,6 +1626,7 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
                                          : g_fl_wps == 5 ? SampleFanoutLeanKernel<false, 5>
                                                          : SampleFanoutLeanKernel<false, 6>);
           }
+          t_fl_last_kernel = "SampleFanoutLeanKernel";
           hipLaunchKernelGGL(lk, dim3((unsigned)blocks), dim3(block), llds, stream, f);
           EG_HIP(hipGetLastError());
           if (uniq_off != nullptr) { uniq_off[0] = -1; uniq_off[1] = -1; }
@@ -1631,6 +1639,7 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
       kern = f.wide ? (plain ? EG_FL(true, true) : EG_FL(true, false))
                     : (plain ? EG_FL(false, true) : EG_FL(false, false));
 #undef EG_FL
+      t_fl_last_kernel = "SampleFanoutLocalKernel";
       hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(block), lds, stream, f);
       EG_HIP(hipGetLastError());
       if (uniq_off != nullptr) { uniq_off[0] = -1; uniq_off[1] = -1; }
@@ -1638,6 +1647,7 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
       }
     }
   }
+  t_fl_last_kernel = "hop by hop";
   std::lock_guard<std::recursive_mutex> launch_lk(g->launch_mu);
   const bool fanout2_ok = g_fanout_fused != 0 && events == nullptr && layers == 2 && k == 1 && n > 0 &&
       g_k1_variant == 6 && g->view.monotone && g->view.has_zero_nbr == 0 &&
@@ -1844,12 +1854,15 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 49 && (value == 0 || value == 1)) { g_fl_fat = value; return EULER_GPU_OK; }
   if (key == 51 && (value == 0 || value == 1)) { g_blk_policy = value; return EULER_GPU_OK; }
   if (key == 52 && (value == 0 || value == 1)) { g_sharded_self_exchange.store(value); return EULER_GPU_OK; }
-  if (key == 53 && (value == 0 || value == 1)) { g_fp_on = value; return EULER_GPU_OK; }
+  if (key == 53 && value >= 0 && value <= 2) { g_fp_on = value; return EULER_GPU_OK; }
   if (key == 54 && (value == 0 || value == 1)) { g_fp_coop = value; return EULER_GPU_OK; }
+  if (key == 57 && (value == 0 || value == 1)) { g_fp_lite2 = value; return EULER_GPU_OK; }
   if (key == 55 && value >= 4 && value <= 8) { g_fp_wps = value; return EULER_GPU_OK; }
   if (key == 56 && value >= 0) { g_blk_fail_next.store(value); return EULER_GPU_OK; }
   return Fail(EULER_GPU_EINVAL, "set_tuning: unknown key");
 }
+
+const char* euler_gpu_last_fanout_kernel(void) { return t_fl_last_kernel; }
 
 int euler_gpu_sample_fanout_multi(const euler_gpu_graph* g, void* stream, uint64_t seed,
                                   uint32_t call_id, uint32_t call_stride,

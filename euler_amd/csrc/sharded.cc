@@ -157,6 +157,12 @@ struct Scratch {
     ptrs.push_back(p);
     return p;
   }
+  // stream-ordered free of one block before the call ends (a walk's per-step buffers)
+  void Release(void* p) {
+    if (p == nullptr) return;
+    for (size_t i = 0; i < ptrs.size(); ++i)
+      if (ptrs[i] == p) { ptrs[i] = ptrs.back(); ptrs.pop_back(); (void)hipFreeAsync(p, st); return; }
+  }
 };
 
 int32_t PackedWordsHost(int32_t count, int32_t tcol) { return ((3 + tcol) * count + 2 + 1) & ~1; }
@@ -437,6 +443,166 @@ int euler_gpu_sharded_random_walk(const euler_gpu_graph* shard, const euler_gpu_
     if (rc != EULER_GPU_OK) return rc;
   }
   if (stats_host) { stats_host[0] = waits; stats_host[1] = entries; stats_host[2] = wire_ids; stats_host[3] = K; }
+  return EULER_GPU_OK;
+}
+
+// node2vec (p or q != 1) over the sharded graph, tf_euler/kernels/random_walk_op.cc:83-168: the
+// reference's CLIENT runs the walk - per step one `v(nodes).outV(edge_types)` query for the
+// walkers' current nodes (ID_UNIQUE -> ID_SPLIT -> REMOTE -> MERGE: one row per distinct node),
+// the previous step's rows kept as the parents', BuildWeights + the draw on the client.  Here,
+// per step and rank: front end over the walkers' nodes (distinct ids bucketed by owner + the
+// row of every walker) -> ids to the owners -> the owners' full rows (euler_gpu_get_full_neighbor)
+// -> row lengths, ids and weights back (three all-to-all(v)s, sizes from the lengths) -> the
+// requester's draw on the fetched rows (euler_gpu_node2vec_step, keyed by the walker's index)
+// -> column s + 1 of the result.  Bit-identical to euler_gpu_random_walk on the unsharded graph.
+int euler_gpu_sharded_node2vec_walk(const euler_gpu_graph* shard, const euler_gpu_transport* tr,
+                                    void* stream, uint64_t seed, uint32_t call_id,
+                                    const int64_t* starts_dev, int64_t n,
+                                    const int32_t* edge_types_host, int32_t k, int32_t walk_len,
+                                    float p, float q, int64_t default_node, int32_t partitions,
+                                    uint32_t* dense_owner_dev, int64_t dense_limit,
+                                    int64_t* out_dev, int64_t* stats_host) {
+  if (!shard) return Fail(EULER_GPU_ENOGRAPH, "sharded_node2vec_walk: null graph");
+  if (!tr || tr->world < 1 || (tr->world > 1 && (!tr->alltoall_counts || !tr->alltoallv)) || n < 0 ||
+      walk_len < 0 || k < 0 || k > 32 || partitions < tr->world || n >= ((int64_t)1 << 30) ||
+      (n > 0 && (!starts_dev || !out_dev)) || (k > 0 && walk_len > 0 && !edge_types_host))
+    return Fail(EULER_GPU_EINVAL, "sharded_node2vec_walk: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int32_t W = tr->world, L = walk_len;
+  const bool lone = W == 1 && (!SelfExchange() || !tr->alltoall_counts || !tr->alltoallv);
+  Scratch sc(st);
+  const int64_t n1 = n > 0 ? n : 1;
+  int rc = euler_gpu::N2vStoreColumn(st, starts_dev, n, (int64_t)L + 1, 0, out_dev);
+  if (rc != EULER_GPU_OK) return rc;
+  // per walker: current and previous node, next node; the step's front end
+  int64_t* cur = (int64_t*)sc.Get((size_t)n1 * 8);
+  int64_t* parent = (int64_t*)sc.Get((size_t)n1 * 8);
+  int64_t* nxt = (int64_t*)sc.Get((size_t)n1 * 8);
+  uint64_t* bucketed = (uint64_t*)sc.Get((size_t)n1 * 8);
+  int32_t* c_row = (int32_t*)sc.Get((size_t)n1 * 4);
+  int32_t* p_row = (int32_t*)sc.Get((size_t)n1 * 4);
+  int64_t* bounds_dev = (int64_t*)sc.Get((size_t)(W + 1) * 16);
+  if (!cur || !parent || !nxt || !bucketed || !c_row || !p_row || !bounds_dev) {
+    (void)hipGetLastError();
+    return Fail(EULER_GPU_ENOMEM, "sharded_node2vec_walk: scratch");
+  }
+  int64_t* bound_off_dev = bounds_dev + (W + 1);
+  if (n > 0) {
+    EG_HIP(hipMemcpyAsync(cur, starts_dev, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+    EG_HIP(hipMemcpyAsync(parent, starts_dev, (size_t)n * 8, hipMemcpyDeviceToDevice, st));   // parent_ids_ starts as the start nodes
+  }
+  // the previous step's rows (the parents' neighbour lists)
+  int32_t* p_idx = nullptr; uint64_t* p_ids = nullptr; float* p_w = nullptr;
+  bool have_parent = false;
+  std::vector<int64_t> off((size_t)W + 1), send_rows((size_t)W), recv_rows((size_t)W), val_send((size_t)W),
+      val_recv((size_t)W), bounds((size_t)W + 1), bound_off((size_t)W + 1);
+  int64_t waits = 0, rows_total = 0, entries_total = 0, wire_ids = 0;
+  for (int32_t s = 0; s < L; ++s) {
+    const int32_t* et = edge_types_host + (size_t)s * k;
+    // 1. distinct nodes bucketed by owner; c_row[i] = the row of walker i among the answers
+    for (auto& x : off) x = 0;
+    if (n > 0) {              // (an empty batch still makes the step's exchanges)
+      rc = euler_gpu_dedup_split(stream, (const uint64_t*)cur, n, nullptr, 1, partitions, W, dense_owner_dev,
+                                 dense_limit, off.data(), bucketed, c_row);
+      if (rc != EULER_GPU_OK) return rc;
+      ++waits;
+    }
+    const int64_t asked = off[(size_t)W];
+    for (int32_t r = 0; r < W; ++r) send_rows[(size_t)r] = off[(size_t)r + 1] - off[(size_t)r];
+    rows_total += asked;
+    // 2. ids to their owners
+    int64_t m_in = asked;
+    uint64_t* owned = bucketed;
+    if (lone) recv_rows[0] = send_rows[0];
+    else {
+      rc = tr->alltoall_counts(tr->user, send_rows.data(), recv_rows.data());
+      if (rc != EULER_GPU_OK) return rc;
+      m_in = 0;
+      for (int32_t r = 0; r < W; ++r) m_in += recv_rows[(size_t)r];
+      wire_ids += asked - send_rows[(size_t)tr->rank];
+      owned = (uint64_t*)sc.Get((size_t)(m_in > 0 ? m_in : 1) * 8);
+      if (!owned) { (void)hipGetLastError(); return Fail(EULER_GPU_ENOMEM, "sharded_node2vec_walk: scratch"); }
+      rc = tr->alltoallv(tr->user, bucketed, send_rows.data(), owned, recv_rows.data(), 8, stream);
+      if (rc != EULER_GPU_OK) return rc;
+    }
+    // 3. the owners' rows (offsets first - the one host wait of the owners' side - then the values)
+    const int64_t m1 = m_in > 0 ? m_in : 1;
+    int32_t* o_idx = (int32_t*)sc.Get((size_t)m1 * 8);
+    if (!o_idx) { (void)hipGetLastError(); return Fail(EULER_GPU_ENOMEM, "sharded_node2vec_walk: scratch"); }
+    int64_t o_total = 0;
+    if (m_in > 0) {
+      rc = euler_gpu_get_full_neighbor(shard, stream, owned, m_in, et, k, o_idx, &o_total, nullptr, nullptr, nullptr);
+      if (rc != EULER_GPU_OK) return rc;
+      ++waits;
+    }
+    if (o_total >= ((int64_t)1 << 31))
+      return Fail(EULER_GPU_EINVAL, "sharded_node2vec_walk: a step's rows hold more than 2^31 neighbours");
+    const int64_t t1 = o_total > 0 ? o_total : 1;
+    uint64_t* o_ids = (uint64_t*)sc.Get((size_t)t1 * 8);
+    float* o_w = (float*)sc.Get((size_t)t1 * 4);
+    int32_t* o_t = (int32_t*)sc.Get((size_t)t1 * 4);
+    if (!o_ids || !o_w || !o_t) { (void)hipGetLastError(); return Fail(EULER_GPU_ENOMEM, "sharded_node2vec_walk: scratch"); }
+    if (m_in > 0 && o_total > 0) {
+      rc = euler_gpu_get_full_neighbor(shard, stream, owned, m_in, et, k, o_idx, &o_total, o_ids, o_w, o_t);
+      if (rc != EULER_GPU_OK) return rc;
+    }
+    sc.Release(o_t);                 // (BuildWeights does not read the edge types)
+    // 4. the rows back to whoever asked: lengths, then ids and weights sized from them
+    int32_t* c_idx = o_idx; uint64_t* c_ids = o_ids; float* c_w = o_w;
+    int64_t c_entries = o_total;
+    if (!lone) {
+      int32_t* o_len = (int32_t*)sc.Get((size_t)m1 * 4);
+      int32_t* b_len = (int32_t*)sc.Get((size_t)(asked > 0 ? asked : 1) * 8);     // lengths, then their running ends
+      if (!o_len || !b_len) { (void)hipGetLastError(); return Fail(EULER_GPU_ENOMEM, "sharded_node2vec_walk: scratch"); }
+      rc = euler_gpu::N2vRowLens(st, o_idx, m_in, o_len);
+      if (rc != EULER_GPU_OK) return rc;
+      rc = tr->alltoallv(tr->user, o_len, recv_rows.data(), b_len, send_rows.data(), 4, stream);
+      if (rc != EULER_GPU_OK) return rc;
+      // values per requester = the offsets at the bounds of its rows
+      bounds[0] = 0;
+      for (int32_t r = 0; r < W; ++r) bounds[(size_t)r + 1] = bounds[(size_t)r] + recv_rows[(size_t)r];
+      EG_HIP(hipMemcpyAsync(bounds_dev, bounds.data(), (size_t)(W + 1) * 8, hipMemcpyHostToDevice, st));
+      rc = euler_gpu::N2vBoundOffsets(st, o_idx, bounds_dev, W, bound_off_dev);
+      if (rc != EULER_GPU_OK) return rc;
+      EG_HIP(hipMemcpyAsync(bound_off.data(), bound_off_dev, (size_t)(W + 1) * 8, hipMemcpyDeviceToHost, st));
+      EG_HIP(hipStreamSynchronize(st));
+      ++waits;
+      for (int32_t r = 0; r < W; ++r) val_send[(size_t)r] = bound_off[(size_t)r + 1] - bound_off[(size_t)r];
+      rc = tr->alltoall_counts(tr->user, val_send.data(), val_recv.data());
+      if (rc != EULER_GPU_OK) return rc;
+      c_entries = 0;
+      for (int32_t r = 0; r < W; ++r) c_entries += val_recv[(size_t)r];
+      if (c_entries >= ((int64_t)1 << 31))
+        return Fail(EULER_GPU_EINVAL, "sharded_node2vec_walk: a step's rows hold more than 2^31 neighbours");
+      const int64_t e1 = c_entries > 0 ? c_entries : 1;
+      c_ids = (uint64_t*)sc.Get((size_t)e1 * 8);
+      c_w = (float*)sc.Get((size_t)e1 * 4);
+      c_idx = (int32_t*)sc.Get((size_t)(asked > 0 ? asked : 1) * 8);
+      if (!c_ids || !c_w || !c_idx) { (void)hipGetLastError(); return Fail(EULER_GPU_ENOMEM, "sharded_node2vec_walk: scratch"); }
+      rc = tr->alltoallv(tr->user, o_ids, val_send.data(), c_ids, val_recv.data(), 8, stream);
+      if (rc != EULER_GPU_OK) return rc;
+      rc = tr->alltoallv(tr->user, o_w, val_send.data(), c_w, val_recv.data(), 4, stream);
+      if (rc != EULER_GPU_OK) return rc;
+      rc = euler_gpu::N2vIdxFromLens(st, b_len, asked, b_len + (asked > 0 ? asked : 1), c_idx);
+      if (rc != EULER_GPU_OK) return rc;
+      sc.Release(o_len); sc.Release(b_len); sc.Release(o_idx); sc.Release(o_ids); sc.Release(o_w);
+      sc.Release(owned);
+    }
+    entries_total += c_entries;
+    // 5. the draw, on the requester (RWCallback::operator(), random_walk_op.cc:83-168)
+    rc = euler_gpu_node2vec_step(stream, seed, call_id + (uint32_t)s, n, c_row, c_idx, c_ids, c_w, c_entries,
+                                 have_parent ? p_row : nullptr, p_idx, p_ids, parent, p, q, default_node, nxt);
+    if (rc != EULER_GPU_OK) return rc;
+    rc = euler_gpu::N2vStoreColumn(st, nxt, n, (int64_t)L + 1, (int64_t)s + 1, out_dev);
+    if (rc != EULER_GPU_OK) return rc;
+    // 6. this step's rows are the next step's parents' rows
+    sc.Release(p_idx); sc.Release(p_ids); sc.Release(p_w);
+    p_idx = c_idx; p_ids = c_ids; p_w = c_w;
+    have_parent = true;
+    { int32_t* t = p_row; p_row = c_row; c_row = t; }
+    { int64_t* t = parent; parent = cur; cur = nxt; nxt = t; }
+  }
+  if (stats_host) { stats_host[0] = waits; stats_host[1] = rows_total; stats_host[2] = entries_total; stats_host[3] = wire_ids; }
   return EULER_GPU_OK;
 }
 

@@ -1007,6 +1007,62 @@ int WalkPathsFromLevels(hipStream_t st, const int64_t* starts_dev, int64_t n, in
   return EULER_GPU_OK;
 }
 
+// ---- pieces of the sharded node2vec walk (csrc/sharded.cc: euler_gpu_sharded_node2vec_walk) ----
+__global__ void N2vLensKernel(const int32_t* idx, int64_t m, int32_t* lens) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) lens[i] = idx[2 * i + 1] - idx[2 * i];
+}
+__global__ void N2vIdxKernel(const int32_t* lens, const int32_t* ends, int64_t m, int32_t* idx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) { idx[2 * i] = ends[i] - lens[i]; idx[2 * i + 1] = ends[i]; }
+}
+__global__ void N2vColumnKernel(const int64_t* src, int64_t n, int64_t stride, int64_t col, int64_t* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i * stride + col] = src[i];
+}
+// the (begin, end) offsets of the FillNeighbor layout at rows bounds[0 .. w] (bounds[p] = first
+// row of peer p's ids): bound_off[p] = idx[bounds[p] - 1].end, 0 for row 0
+__global__ void N2vBoundsKernel(const int32_t* idx, const int64_t* bounds, int32_t w, int64_t* bound_off) {
+  const int32_t p = (int32_t)threadIdx.x;
+  if (p <= w) bound_off[p] = bounds[p] <= 0 ? 0 : (int64_t)idx[2 * (bounds[p] - 1) + 1];
+}
+
+// row lengths of an owner's answer (idx [m, 2] as euler_gpu_get_full_neighbor writes it)
+int N2vRowLens(hipStream_t st, const int32_t* idx_dev, int64_t m, int32_t* lens_dev) {
+  if (m <= 0) return EULER_GPU_OK;
+  hipLaunchKernelGGL(N2vLensKernel, dim3(GridFor(m, 256)), dim3(256), 0, st, idx_dev, m, lens_dev);
+  EG_HIP(hipGetLastError());
+  return EULER_GPU_OK;
+}
+
+// ... and back: idx [m, 2] of the concatenated rows from their lengths (tmp_ends: m int32)
+int N2vIdxFromLens(hipStream_t st, const int32_t* lens_dev, int64_t m, int32_t* tmp_ends_dev, int32_t* idx_dev) {
+  if (m <= 0) return EULER_GPU_OK;
+  size_t bytes = 0;
+  EG_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, bytes, lens_dev, tmp_ends_dev, (int)m, st));
+  void* tmp = nullptr;
+  EG_HIP(hipMallocAsync(&tmp, bytes + 16, st));
+  const hipError_t e = hipcub::DeviceScan::InclusiveSum(tmp, bytes, lens_dev, tmp_ends_dev, (int)m, st);
+  (void)hipFreeAsync(tmp, st);
+  EG_HIP(e);
+  hipLaunchKernelGGL(N2vIdxKernel, dim3(GridFor(m, 256)), dim3(256), 0, st, lens_dev, tmp_ends_dev, m, idx_dev);
+  EG_HIP(hipGetLastError());
+  return EULER_GPU_OK;
+}
+
+int N2vStoreColumn(hipStream_t st, const int64_t* src_dev, int64_t n, int64_t stride, int64_t col, int64_t* out_dev) {
+  if (n <= 0) return EULER_GPU_OK;
+  hipLaunchKernelGGL(N2vColumnKernel, dim3(GridFor(n, 256)), dim3(256), 0, st, src_dev, n, stride, col, out_dev);
+  EG_HIP(hipGetLastError());
+  return EULER_GPU_OK;
+}
+
+int N2vBoundOffsets(hipStream_t st, const int32_t* idx_dev, const int64_t* bounds_dev, int32_t w, int64_t* out_dev) {
+  hipLaunchKernelGGL(N2vBoundsKernel, dim3(1), dim3(((w + 1 + 63) / 64) * 64), 0, st, idx_dev, bounds_dev, w, out_dev);
+  EG_HIP(hipGetLastError());
+  return EULER_GPU_OK;
+}
+
 // node2vec step over explicit lists (euler_gpu_node2vec_step): one lane per walker, the
 // reference's own two passes - BuildWeights while summing, then the first running sum > r
 // (Node2VecKernel above says why that is RandomSelect's index; same sequential f32 adds).

@@ -743,6 +743,9 @@ class ShardedSampler:
                 cur = ids.reshape(-1)
                 cols.append(cur)
             return torch.stack(cols, dim=1)
+        if getattr(self, "c_n2v_fn", None) is not None:
+            # the same loop inside libeuler_gpu.so (euler_gpu_sharded_node2vec_walk)
+            return self.c_n2v_fn(nodes, edge_types, p, q, default_node, call_id)
         cur, parent = nodes, nodes            # parent_ids_ starts as the start nodes
         p_row = p_idx = p_ids = None          # parent_neighbors_ starts empty
         for s, et in enumerate(edge_types):
@@ -982,6 +985,9 @@ def gpu_sharded_sampler(graph, partitions=None, group=None, dedup=True, dense_id
         S.c_walk_fn = lambda nodes, edge_types, default_node, call_id: c_sharded_random_walk(
             graph, tr_c, nodes, edge_types, default_node, call_id, S.partitions, S.walk_cohorts,
             dense_table)
+        if os.environ.get("EULER_AMD_C_N2V", "1") != "0":
+            S.c_n2v_fn = lambda nodes, edge_types, p, q, default_node, call_id: c_sharded_node2vec_walk(
+                graph, tr_c, nodes, edge_types, p, q, default_node, call_id, S.partitions, dense_table)
     S.local_adj_mask = graph.sparse_adj_mask
     S.adj_from_mask_fn = type(graph).adj_from_mask
     return S
@@ -1160,4 +1166,38 @@ def c_sharded_random_walk(graph, transport, starts, edge_types, default_node=-1,
     if return_stats:
         return out, {"host_waits": int(stats[0]), "level_entries": int(stats[1]),
                      "ids_sent": int(stats[2]), "cohorts": int(stats[3])}
+    return out
+
+
+def c_sharded_node2vec_walk(graph, transport, starts, edge_types, p, q, default_node=-1, call_id=0,
+                            partitions=None, dense_table=None, return_stats=False):
+    """tf_euler random_walk with p or q != 1 (node2vec) through euler_gpu_sharded_node2vec_walk
+    (the C entry a C++ host calls): [n, len(edge_types) + 1] int64, the same result as
+    Graph.random_walk(p, q) on the unsharded graph.  edge_types: a list (walk_len) of per-step
+    edge type lists."""
+    import ctypes as C
+    import numpy as np
+    from . import _lib
+    L = _lib.lib()
+    dev = graph.device
+    starts = starts.reshape(-1).to(torch.int64).to(dev).contiguous()
+    n = starts.numel()
+    walk_len = len(edge_types)
+    et = np.ascontiguousarray(np.asarray(edge_types, dtype=np.int32).reshape(walk_len, -1)) \
+        if walk_len else np.zeros((0, 1), np.int32)
+    k = et.shape[1] if walk_len else 1
+    out = torch.empty((n, walk_len + 1), dtype=torch.int64, device=dev)
+    stats = (C.c_int64 * 4)()
+    limit = dense_table.numel() - 1 if dense_table is not None else 0
+    with torch.cuda.device(dev):
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(L.euler_gpu_sharded_node2vec_walk(
+            graph._h, transport.ptr() if hasattr(transport, "ptr") else transport, st, graph.seed,
+            int(call_id) & 0xFFFFFFFF, C.c_void_p(starts.data_ptr()), n, et.ctypes.data_as(_lib.i32p), k,
+            walk_len, float(p), float(q), int(default_node), int(partitions or transport.world),
+            C.c_void_p(dense_table.data_ptr()) if dense_table is not None else None, limit,
+            C.c_void_p(out.data_ptr()), stats))
+    if return_stats:
+        return out, {"host_waits": int(stats[0]), "rows_asked": int(stats[1]),
+                     "row_entries": int(stats[2]), "ids_sent": int(stats[3])}
     return out

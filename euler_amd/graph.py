@@ -300,6 +300,16 @@ class Graph:
             tp.ctypes.data_as(_lib.f32p)))
         return row_ptr, type_end, nbr[:tot], pw[:tot], tp
 
+    def index_overflow_rows(self, cap=4096):
+        """Node ids (identity id maps only) of rows in which a bucket of the weight-bucket index
+        overflows its block, as found while the index was built (at most 4 096): draws that land
+        there take the fallback search.  Tests draw roots from them on purpose."""
+        out = np.zeros(max(int(cap), 1), np.uint64)
+        n = C.c_int64(0)
+        check(lib().euler_gpu_graph_index_overflow_rows(self._h, out.ctypes.data_as(_lib.u64p), int(cap),
+                                                        C.byref(n)))
+        return out[:n.value]
+
     # ---------------------------------------------------------------- RNG
 
     def _on_device(self):

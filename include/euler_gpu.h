@@ -899,6 +899,27 @@ int euler_gpu_sharded_random_walk(const euler_gpu_graph* shard, const euler_gpu_
                                   uint32_t* dense_owner_dev, int64_t dense_limit,
                                   int64_t* out_dev, int64_t* stats_host);
 
+/* TF RandomWalk with p or q != 1 (node2vec) over the sharded graph, as the reference's client
+ * runs it (tf_euler/kernels/random_walk_op.cc:83-168: per step one `v(nodes).outV(edge_types)`
+ * query for the walkers' current nodes - ID_UNIQUE -> ID_SPLIT -> REMOTE -> MERGE, one row per
+ * distinct node - the previous step's rows kept as the parents', BuildWeights and the draw on
+ * the client): starts_dev [n] int64 -> out_dev [n, walk_len + 1] int64, bit-identical to
+ * euler_gpu_random_walk(p, q) on the unsharded graph (the draw of step s is keyed by the
+ * walker's index and call_id + s).  Per step and rank: front end (distinct nodes by owner) ->
+ * ids to the owners -> their full rows (euler_gpu_get_full_neighbor) -> row lengths, ids and
+ * weights back (all-to-all(v)s sized from the lengths) -> euler_gpu_node2vec_step on the
+ * fetched rows.  The host waits three times per step (bucket sizes, the owners' row offsets,
+ * the value counts per peer).  stats_host (optional, int64[4]): host waits, rows asked, row
+ * entries received (summed over the steps), ids sent to other ranks.  All ranks call it
+ * together (also with n = 0). */
+int euler_gpu_sharded_node2vec_walk(const euler_gpu_graph* shard, const euler_gpu_transport* tr,
+                                    void* stream, uint64_t seed, uint32_t call_id,
+                                    const int64_t* starts_dev, int64_t n,
+                                    const int32_t* edge_types_host, int32_t k, int32_t walk_len,
+                                    float p, float q, int64_t default_node, int32_t partitions,
+                                    uint32_t* dense_owner_dev, int64_t dense_limit,
+                                    int64_t* out_dev, int64_t* stats_host);
+
 /* SAMPLE_NODE_SPLIT (core/kernels/sample_node_split_op.cc:57-85), host only:
  * shard_weight_host[shards+1] (last = total) -> split_cnt_host[shards]. */
 int euler_gpu_sample_node_split(uint64_t seed, uint32_t call_id, int32_t count,

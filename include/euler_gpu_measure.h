@@ -119,6 +119,14 @@ extern "C" {
  *        (0 [default]; the environment variable EULER_GPU_SELF_EXCHANGE=1 sets the default): the
  *        tests' way to execute the RCCL transport on a box with one GPU.  PROCESS-WIDE (the
  *        sharded calls of every host thread see it), unlike the other keys.
+ * key 53: plain graphs served by the weight-bucket index take the 2-hop fanout kernel of
+ *        csrc/fanout_plain.h when the caller keeps ONE stream (1 [default]; 2 = also when it
+ *        alternates streams); 0 = round 5's lean build (fanout_local.h).
+ * key 54: ... with a block's keys fetched by three lanes through LDS-DMA and staged in LDS (1);
+ *        0 [default] = by the lane that owns the draw.  key 55: its register budget in waves per
+ *        SIMD (4 .. 8, default 5).  key 57: its hop 2 asks for two of a block's three key chunks
+ *        and for the third only when the pick lands on the block's first edge or past its
+ *        eighth (1); 0 [default] = all three at once.
  * key 56: test hook, PROCESS-WIDE: the next `value` builds of the EdgeBlocks fail the way an
  *        allocation failure would (the graph is then served without them: same results).
  * All settings produce identical results; the knobs exist for A/B measurements
@@ -131,6 +139,18 @@ int euler_gpu_set_tuning(int32_t key, int32_t value);
  * one-kernel fanout (fanout_local.h, lean build) leaves its phase time stamps; NULL = off.
  * Thread-local like the tuning keys. */
 int euler_gpu_set_debug_buffer(void* dev);
+
+/* The kernel the calling thread's last euler_gpu_sample_fanout* call of a 2-hop fanout launched
+ * ("SampleFanoutPlainKernel", "SampleFanoutLeanKernel", "SampleFanoutLocalKernel", "hop by hop";
+ * "" before any): what bench.py names in its roofline object. */
+const char* euler_gpu_last_fanout_kernel(void);
+
+/* Rows of the graph (their node ids, identity id maps only) in which some bucket of the
+ * weight-bucket index overflows its block - a draw that lands there takes the fallback search
+ * (csrc/wb_index.h) - as found while the index was built: at most 4 096 of them.  Builds the
+ * index if it is not built yet.  Tests draw roots from these rows on purpose. */
+int euler_gpu_graph_index_overflow_rows(const euler_gpu_graph* g, uint64_t* ids_host, int64_t cap,
+                                        int64_t* n_host);
 
 /* ---- measurement helper -------------------------------------------------------
  * Runs the sample_neighbor kernel `iters` times on `stream` between two HIP

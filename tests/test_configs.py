@@ -125,8 +125,9 @@ def test_config3_metric_step_at_full_size(EA, O, torch_cuda):
     paths agree bit for bit on every one of the step's 36 044 800 samples (the one-kernel
     fanout of fanout_local.h - through the weight-bucket index and through the pivot levels -
     against hop-by-hop sampling + global duplicate path + expansion), the (distinct rows, index) form reproduces the dense one, the result is
-    a pure function of (seed, call id, roots), and 96 roots - with every hop-1 child's
-    row exported from HBM - equal the CPU oracle.  Same for DeepWalk of 1M walkers x 40
+    a pure function of (seed, call id, roots), and the WHOLE step - the 1 000 largest hubs and
+    1 000 rows with overflowing index buckets among its roots - equals the CPU oracle on rows
+    exported from HBM (oracle/step_check.py).  Same for DeepWalk of 1M walkers x 40
     steps: groups of merged walkers == one lane per walker, 16 walkers == the oracle."""
     torch = torch_cuda
     from euler_amd import _lib
@@ -137,16 +138,36 @@ def test_config3_metric_step_at_full_size(EA, O, torch_cuda):
     G.set_seed(20240521)
     gen = torch.Generator(device="cuda"); gen.manual_seed(77)
     roots = torch.randint(1, N + 1, (B,), generator=gen, device="cuda", dtype=torch.int64)
+    # on purpose among the roots: the graph's largest hubs - the 1 000 nodes a
+    # probe step's hop 1 draws most often, rows of 10^4 .. 5 x 10^5 edges past the 2^24 resolution
+    # of an f32 running sum - and up to 1 000 rows in which a bucket of the weight-bucket index
+    # overflows its block (their draws take the fallback search)
+    probe = G.sample_fanout(roots, [[0], [0]], [25, 10], N + 1, call_id=2)[0][1]
+    hub_ids, hub_cnt = torch.unique(probe, return_counts=True)
+    hubs = hub_ids[torch.argsort(hub_cnt, descending=True)[:1000]]
+    hubs = hubs[hubs <= N]
+    ovf = torch.as_tensor(G.index_overflow_rows(1000).astype(np.int64)).cuda()
+    assert ovf.numel() > 0, "the metric graph has buckets that overflow (1e-4 of them)"
+    roots[:hubs.numel()] = hubs
+    roots[hubs.numel():hubs.numel() + ovf.numel()] = ovf
+    del probe, hub_ids, hub_cnt
     try:
         L.euler_gpu_set_tuning(27, 1)
         a = G.sample_fanout(roots, [[0], [0]], [25, 10], N + 1, call_id=6)
         a2 = G.sample_fanout(roots, [[0], [0]], [25, 10], N + 1, call_id=6)
+        L.euler_gpu_set_tuning(53, 0)             # round 5's build of the one-kernel step (fanout_local.h)
+        r5 = G.sample_fanout(roots, [[0], [0]], [25, 10], N + 1, call_id=6)
+        L.euler_gpu_set_tuning(53, 1)
+        for hop in range(2):
+            assert torch.equal(a[0][hop + 1], r5[0][hop + 1]) and torch.equal(a[1][hop], r5[1][hop])
+            assert torch.equal(a[2][hop], r5[2][hop])
+        del r5
         L.euler_gpu_set_tuning(27, 0)
         h = G.sample_fanout(roots, [[0], [0]], [25, 10], N + 1, call_id=6)
         L.euler_gpu_set_tuning(27, 1); L.euler_gpu_set_tuning(45, 0)     # pivot levels instead of
         lv = G.sample_fanout(roots, [[0], [0]], [25, 10], N + 1, call_id=6)   # the weight-bucket index
     finally:
-        L.euler_gpu_set_tuning(27, 1); L.euler_gpu_set_tuning(45, 1)
+        L.euler_gpu_set_tuning(27, 1); L.euler_gpu_set_tuning(45, 1); L.euler_gpu_set_tuning(53, 1)
     assert a[0][2].numel() == B * 250
     for hop in range(2):
         assert torch.equal(a[0][hop + 1], h[0][hop + 1]) and torch.equal(a[0][hop + 1], a2[0][hop + 1])
@@ -158,20 +179,13 @@ def test_config3_metric_step_at_full_size(EA, O, torch_cuda):
     assert torch.equal(rid[ridx].reshape(-1), a[0][2]) and torch.equal(rw[ridx].reshape(-1), a[1][1])
     assert torch.equal(rt[ridx].reshape(-1), a[2][1])
     del rid, rw, rt
-    # the oracle on 96 roots
-    sel = np.random.default_rng(5).choice(B, 96, replace=False)
-    r_sel = t2n(roots)[sel]
-    hop1 = t2n(a[0][1]).reshape(B, 25)[sel]
-    need = np.unique(np.concatenate([r_sel, hop1.reshape(-1)])).astype(np.uint64)
-    need = need[(need >= 1) & (need <= N)]
-    rp, te, nb, pw, tp = G.export_rows(need)
-    OG = O.OracleGraph(O.CSR(need, rp, te, nb, pw, tp, 1))
-    on, ow, ot = OG.sample_fanout(20240521, 6, r_sel, [[0], [0]], [25, 10], N + 1)
-    assert np.array_equal(on[0], hop1.reshape(-1))
-    assert np.array_equal(ow[0], t2n(a[1][0]).reshape(B, 25)[sel].reshape(-1))
-    assert np.array_equal(on[1], t2n(a[0][2]).reshape(B, 250)[sel].reshape(-1))
-    assert np.array_equal(ow[1], t2n(a[1][1]).reshape(B, 250)[sel].reshape(-1))
-    assert np.array_equal(ot[1], t2n(a[2][1]).reshape(B, 250)[sel].reshape(-1))
+    # the WHOLE step against the CPU oracle (oracle/step_check.py): all 131 072 x 25 hop-1
+    # samples on exported rows, every hop-2 position against the first position of its node on the
+    # device, and one row per distinct hop-1 child - ~285 K rows of 10 - against the oracle
+    from oracle.step_check import check_fanout_step
+    edges, distinct = check_fanout_step(G, O.OracleGraph, O.CSR, 20240521, 6, roots, a[0], a[1], a[2], [25, 10],
+                                        N + 1, N)
+    assert edges == B * 275 and distinct > 200_000
     del a
     # DeepWalk at configs[3]'s size on the same graph
     W = 1_000_000

@@ -1721,7 +1721,7 @@ def test_full_neighbor_fill_kernels_agree(EA, O, torch_cuda, big_pair):
         _lib.lib().euler_gpu_set_tuning(24, 1)
 
 
-_FL_DEFAULTS = {27: 1, 28: 0, 29: 0, 30: 0, 31: 1, 32: -1, 33: 32768, 34: 2, 35: 5, 45: 1, 53: 1, 54: 1, 55: 5}
+_FL_DEFAULTS = {27: 1, 28: 0, 29: 0, 30: 0, 31: 1, 32: -1, 33: 32768, 34: 2, 35: 5, 45: 1, 53: 1, 54: 0, 55: 5, 57: 0}
 
 
 @pytest.mark.parametrize("geom", [(4, 0, 256, 1, 8, 2, 0, 1), (1, 1, 64, 0, 5, 0, 0, 1), (2, 3, 128, 1, 8, 0, 0, 1),
@@ -1858,16 +1858,17 @@ def test_fanout_local_dedup_kernel(EA, O, torch_cuda, big_pair, geom):
             L.euler_gpu_set_tuning(k_, v_)
 
 
-@pytest.mark.parametrize("geom", [(0, 0, 0, 5, 1, -1), (4, 32, 128, 5, 1, -1), (4, 3, 64, 8, 1, -1), (4, 100, 256, 4, 1, 0),
-                                  (2, 7, 128, 7, 1, 5), (4, 12, 128, 6, 1, -1), (4, 2, 64, 5, 0, 3), (1, 1, 64, 6, 1, 1),
-                                  (4, 32, 128, 4, 0, -1), (4, 13, 256, 4, 1, 7)],
-                         ids=["shipped", "cap32", "cap3_wps8", "cap100_wps4", "gr2_grid5", "cap12_wps6", "lane_loads_cap2_grid3",
-                              "gr1_grid1", "lane_loads", "cap13_grid7"])
+@pytest.mark.parametrize("geom", [(0, 0, 0, 5, 0, -1, 1), (4, 32, 128, 5, 1, -1, 0), (4, 3, 64, 8, 1, -1, 0), (4, 100, 256, 4, 0, 0, 1),
+                                  (2, 7, 128, 7, 1, 5, 0), (4, 12, 128, 6, 1, -1, 0), (4, 2, 64, 5, 0, 3, 0), (1, 1, 64, 6, 0, 1, 1),
+                                  (4, 32, 128, 4, 0, -1, 0), (4, 13, 256, 4, 1, 7, 0), (4, 5, 64, 6, 0, 2, 1)],
+                         ids=["shipped", "coop_cap32", "coop_cap3_wps8", "cap100_wps4", "coop_gr2_grid5", "coop_cap12_wps6",
+                              "three_chunks_cap2_grid3", "gr1_grid1", "three_chunks", "coop_cap13_grid7", "cap5_wps6_grid2"])
 def test_fanout_plain_kernel(EA, O, torch_cuda, geom):
     """fanout_plain.h (round 6): the one-kernel 2-hop fanout rebuilt for plain graphs served by
     the weight-bucket index.  Every build (register budget; a block's keys fetched by three
     lanes through LDS-DMA - key 54 = 1, staged over the results when a pass is one step and
-    beside them otherwise - or by the lane that owns the draw) and geometry (roots per wave, slots per pass incl. several
+    beside them otherwise - or by the lane that owns the draw, hop 2 with two or all three of a
+    block's key chunks per draw - key 57) and geometry (roots per wave, slots per pass incl. several
     passes, block size, grid-stride loop) must write the oracle's ids / weights / types and
     what round 5's kernel (key 53 = 0) writes: unknown roots, id 0, duplicate roots, ragged
     last tiles, strided ids, dangling neighbour ids, hub rows (> 64 edges: duplicates by id;
@@ -1876,14 +1877,14 @@ def test_fanout_plain_kernel(EA, O, torch_cuda, geom):
     torch = torch_cuda
     from euler_amd import _lib
     L = _lib.lib()
-    gr, cap, block, wps, coop, grid = geom
-    keys = {27: 2, 28: gr, 29: cap, 30: block, 32: grid, 33: 0, 55: wps, 54: coop}
+    gr, cap, block, wps, coop, grid, lite = geom
+    keys = {27: 2, 28: gr, 29: cap, 30: block, 32: grid, 33: 0, 55: wps, 54: coop, 57: lite, 53: 2}
 
     def check(G, OG, q, counts, default, seed, call, took=True):
         qt = torch.as_tensor(q).cuda()
         G.set_seed(seed)
         on, ow, ot = OG.sample_fanout(seed, call, q, [[0], [0]], counts, default)
-        L.euler_gpu_set_tuning(53, 1)
+        L.euler_gpu_set_tuning(53, 2)
         gn, gw, gt = G.sample_fanout(qt, [[0], [0]], counts, default, call_id=call)
         for h in range(2):
             assert np.array_equal(t2n(gn[h + 1]), on[h]), (geom, len(q), counts, h)
@@ -1891,7 +1892,7 @@ def test_fanout_plain_kernel(EA, O, torch_cuda, geom):
             assert np.array_equal(t2n(gt[h]), ot[h]), (geom, len(q), counts, h)
         L.euler_gpu_set_tuning(53, 0)           # round 5's kernel
         rn, rw, rt = G.sample_fanout(qt, [[0], [0]], counts, default, call_id=call)
-        L.euler_gpu_set_tuning(53, 1)
+        L.euler_gpu_set_tuning(53, 2)
         for h in range(2):
             assert torch.equal(gn[h + 1], rn[h + 1]) and torch.equal(gw[h], rw[h]) and torch.equal(gt[h], rt[h])
         if counts[1] % 2 == 0:

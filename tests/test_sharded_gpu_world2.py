@@ -188,6 +188,24 @@ def _worker_body(rank, world, port, partitions):
     assert torch.equal(got, want)
     assert np.array_equal(t2n(got)[:32], OG.random_walk(5, 200, t2n(starts)[:32], etn, 8, 0.25,
                                                        4.0, N + 1))
+    # (S.random_walk just ran the C entry, euler_gpu_sharded_node2vec_walk; the same walk as the
+    # reference's client loop in Python, through the entry itself with the hash front end, from
+    # a rank without walkers and with no steps)
+    from euler_amd.distributed import c_sharded_node2vec_walk
+    assert getattr(S, "c_n2v_fn", None) is not None
+    c_fn, S.c_n2v_fn = S.c_n2v_fn, None
+    got_py = S.random_walk(starts[:1500], etn, 0.25, 4.0, default_node=N + 1, call_id=200)
+    S.c_n2v_fn = c_fn
+    assert torch.equal(got_py, want)
+    gotn, nstats = c_sharded_node2vec_walk(G_shard, trw, starts[:1500], etn, 0.25, 4.0, N + 1, 200, partitions, None,
+                                           return_stats=True)
+    assert torch.equal(gotn, want)
+    assert nstats["rows_asked"] <= 1500 * 8 and nstats["row_entries"] > 0 and nstats["ids_sent"] > 0
+    mine_n = starts[:700] if rank != 0 else starts[:0]
+    gotn = c_sharded_node2vec_walk(G_shard, trw, mine_n, etn[:5], 2.0, 0.5, N + 1, 210, partitions, S.dense_table)
+    assert torch.equal(gotn, G_full.random_walk(mine_n, etn[:5], 2.0, 0.5, N + 1, call_id=210))
+    gotn = c_sharded_node2vec_walk(G_shard, trw, starts[:10], [], 0.25, 4.0, N + 1, 220, partitions, None)
+    assert torch.equal(gotn.reshape(-1), starts[:10])
 
     # the record DESIGN.md quotes: 20 000 walkers x 10 node2vec steps through the sharded sampler
     # (world ranks on ONE GPU, host-staged exchange), wave kernels on the fetched rows
@@ -202,7 +220,7 @@ def _worker_body(rank, world, port, partitions):
     _same(got10, G_full.random_walk(starts[:20000], etn10, 0.25, 4.0, N + 1, call_id=300), "node2vec 20K x 10")
     out_dir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out_dir):
-        with open(os.path.join(out_dir, "r4_sharded_n2v_world%d_rank%d.txt" % (world, rank)), "w") as fo:
+        with open(os.path.join(out_dir, "r6_sharded_n2v_world%d_rank%d.txt" % (world, rank)), "w") as fo:
             fo.write("sharded node2vec (p = 0.25, q = 4), %d ranks on one GPU, 20000 walkers x 10 steps per rank: "
                      "%.2f ms\n" % (world, _ms))
     # dedup="ops" (ID_UNIQUE / ID_SPLIT / merge_rows / gather as separate kernels)

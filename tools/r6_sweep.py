@@ -87,7 +87,7 @@ for cfg in a.configs:
     # back to the defaults the next configuration starts from
     for kv in filter(None, cfg.split(',')):
         k, v = kv.split('=')
-        dflt = {'28': 0, '29': 0, '30': 0, '31': 1, '32': -1, '35': 5, '45': 1, '53': 1, '54': 1, '55': 5}.get(k)
+        dflt = {'28': 0, '29': 0, '30': 0, '31': 1, '32': -1, '35': 5, '45': 1, '53': 1, '54': 0, '55': 5, '57': 0}.get(k)
         if dflt is not None:
             L.euler_gpu_set_tuning(int(k), dflt)
 print(json.dumps({'graph_bytes': G.device_bytes, 'results': out}))
