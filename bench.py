@@ -357,9 +357,28 @@ def _cpu_node_and_walk_cells(R, n, cores):
     return out
 
 
-def cpu_walk_cell(args):
+def _n2v_cell(R, n, cores):
+    """node2vec (p = 0.25, q = 4) on the reference graph R: 8 and 32 concurrent queries of 2 048
+    walkers x 10 steps (tf_euler/kernels/random_walk_op.cc:83-168: the client's loop over
+    GetFullNeighbor + BuildWeights, reference sources behind the RNG seam)."""
+    W, LEN = 2048, 10
+    rng = np.random.default_rng(6)
+    starts = rng.integers(1, n + 1, (32, W)).astype(np.int64)
+    et = [[0]] * LEN
+    cells = [_threaded_rate(lambda t_, r_: R.random_walk(GRAPH_SEED, 10 * (64 * r_ + t_), starts[t_], et, LEN,
+                                                         0.25, 4.0, n + 1), th, W * LEN, rounds=2)
+             for th in sorted({min(8, cores), min(32, cores)})]
+    best = max(cells, key=lambda c: c["per_s"])
+    return {"value": best["per_s"], "unit": "walker steps/s", "cores": best["threads"], "kind": "reference",
+            "as_shipped_8_queries": cells[0]["per_s"], "cells": cells,
+            "sample": "random_walk p = 0.25, q = 4 (reference sources behind the RNG seam), %d walkers x %d "
+                      "steps per query, %d-node graph" % (W, LEN, n)}
+
+
+def cpu_walk_cell(args, n2v=False):
     """cpu_baseline of `--workload deepwalk`: the reference's walk (oracle/_ref) on a bounded
-    graph of the metric's family (5M nodes / 50M edges: ~10 s to build with 32 threads)."""
+    graph of the metric's family (5M nodes / 50M edges: ~10 s to build with 32 threads).
+    n2v: also the node2vec cell (key "node2vec")."""
     from oracle import oracle as O
     cores = os.cpu_count() or 1
     if not O.have_ref():
@@ -368,6 +387,11 @@ def cpu_walk_cell(args):
     n = min(5_000_000, args.nodes)
     R, _ne, build_s = _ref_graph(n, 1, min(32, cores), False)
     cell = _walk_cell(R, n, cores)
+    if n2v:
+        try:
+            cell["node2vec"] = _n2v_cell(R, n, cores)
+        except Exception as e:
+            cell["node2vec"] = {"error": repr(e)}
     del R
     cell["host_cores"] = cores
     cell["sample"] += "; %d-edge graph of the metric's family built in %.1f s" % (_ne, build_s)
@@ -1060,23 +1084,65 @@ def run_deepwalk(args, G=None, p_g=None, quiet=False):
                 assert np.array_equal(ow_, w_sel), "sharded deepwalk: walks differ from the oracle"
                 checked_s = int(64 * LEN)
             if rank == 0 and not args.no_cpu_baseline and not quiet:
-                cpu_s = cpu_walk_cell(args)
+                cpu_s = cpu_walk_cell(args, n2v=args.n2v)
         except AssertionError:
             raise
         except Exception as e:
             roof_s = {"error": repr(e)}
         n2v = None
         if args.n2v:
+            # SURVEY 8(d) config 4's "one node2vec run p = 0.25, q = 4", sharded: the C entry
+            # euler_gpu_sharded_node2vec_walk (per step: rows of the walkers' nodes from their owners,
+            # the draw on the requester), its own roofline / CPU cell / oracle check
             W2, L2 = min(100_000, W), 10
             s2 = starts[0][:W2].contiguous()
-            walk(s2, [[0]] * L2, 0.25, 4.0, 3)
-            _sync_ranks(wire)
-            t0 = time.perf_counter()
-            walk(s2, [[0]] * L2, 0.25, 4.0, 3)
-            _sync_ranks(wire)
-            sec2 = _max_over_ranks([time.perf_counter() - t0], wire)[0]
+            et2 = [[0]] * L2
+            w2 = walk(s2, et2, 0.25, 4.0, 3)
+            secs2 = []
+            for _r in range(3):
+                _sync_ranks(wire)
+                t0 = time.perf_counter()
+                w2 = walk(s2, et2, 0.25, 4.0, 3)
+                _sync_ranks(wire)
+                secs2.append(time.perf_counter() - t0)
+            sec2 = float(np.median(_max_over_ranks(secs2, wire)))
             n2v = {"walkers_per_rank": W2, "walk_len": L2, "p": 0.25, "q": 4.0,
-                   "ms": round(sec2 * 1e3, 3), "steps_per_s": world * W2 * L2 / sec2}
+                   "ms": round(sec2 * 1e3, 3), "steps_per_s": world * W2 * L2 / sec2,
+                   "orchestration": "euler_gpu_sharded_node2vec_walk (C)" if getattr(S, "c_n2v_fn", None) is not None
+                                    else "ShardedSampler.random_walk (Python loop)"}
+            try:
+                from euler_amd.distributed import c_sharded_node2vec_walk
+                if getattr(S, "c_n2v_fn", None) is not None:
+                    _w2, st2 = c_sharded_node2vec_walk(G, S.c_transport, s2, et2, 0.25, 4.0, N + 1, 3, S.partitions,
+                                                       S.dense_table, return_stats=True)
+                    assert torch.equal(_w2, w2)
+                    n2v["walk_stats"] = st2
+                b2_ = C.c_double(0)
+                et_b = (C.c_int32 * L2)(*([0] * L2))
+                if world == 1:
+                    _lib.check(L.euler_gpu_random_walk_algo_bytes(
+                        G._h, C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(w2.data_ptr()),
+                        W2, et_b, 1, L2, 0.25, 4.0, C.byref(b2_)))
+                    n2v["roofline"] = {
+                        "kernel": "Node2VecListWaveKernel + FullNb* + front end (the whole call)", "bound": "hbm",
+                        "achieved": round(b2_.value / sec2 / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(b2_.value / sec2 / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                        "algorithmic_bytes_per_launch": b2_.value, "avg_launch_ms": round(sec2 * 1e3, 3),
+                        "note": "bytes = SURVEY 8(d): (deg(cur) + deg(prev)) x 12 per walker step; time = the "
+                                "call, wall clock (three host waits per step)"}
+                    if not args.no_check:
+                        w2_sel = w2.cpu().numpy()[:64]       # the draw is keyed by the walker's INDEX
+                        need2 = w2_sel[(w2_sel >= 1) & (w2_sel <= N)]
+                        OG2 = _oracle_rows(G, p_g, need2, 1)
+                        o2 = OG2.random_walk(GRAPH_SEED, 3, s2.cpu().numpy()[:64], et2, L2, 0.25, 4.0, N + 1)
+                        assert np.array_equal(o2, w2_sel), "sharded node2vec: walks differ from the oracle"
+                        n2v["parity_checked_steps"] = int(64 * L2)
+                if cpu_s is not None and isinstance(cpu_s.get("node2vec"), dict):
+                    n2v["cpu_baseline"] = cpu_s.pop("node2vec")
+            except AssertionError:
+                raise
+            except Exception as e:
+                n2v["error"] = repr(e)
         line = {
             "metric": "walker steps/sec, DeepWalk random_walk length 40 (p = q = 1) on the power-law "
                       "graph hash-sharded over the ranks (BASELINE configs[3])",

@@ -222,6 +222,12 @@ Tensor::~Tensor() { free(data_); }
 std::string OutputName(const NodeDef& node_def, int i) {
   return node_def.name + ":" + std::to_string(i);
 }
+std::string OutputName(const std::string& name, int i) { return name + ":" + std::to_string(i); }
+
+OpStatus OpKernelContext::RemoveAlias(const std::string& name) {
+  std::lock_guard<std::mutex> lk(mu_);
+  return tensor_map_.erase(name) ? 0 : -1;         // (the tensor stays: op_kernel.cc RemoveAlias)
+}
 
 OpKernelContext::~OpKernelContext() {
   // aliases share a tensor: free every distinct pointer once
@@ -233,14 +239,14 @@ OpKernelContext::~OpKernelContext() {
   }
 }
 
-int OpKernelContext::AddAlias(const std::string& name, Tensor* tensor) {
+OpStatus OpKernelContext::AddAlias(const std::string& name, Tensor* tensor) {
   std::lock_guard<std::mutex> lk(mu_);
   if (tensor_map_.count(name)) return -1;
   tensor_map_[name] = tensor;
   return 0;
 }
 
-int OpKernelContext::Allocate(const std::string& name, const TensorShape& shape,
+OpStatus OpKernelContext::Allocate(const std::string& name, const TensorShape& shape,
                               DataType type, Tensor** tensor) {
   std::lock_guard<std::mutex> lk(mu_);
   if (tensor_map_.count(name)) return -1;        // already exists
@@ -249,7 +255,7 @@ int OpKernelContext::Allocate(const std::string& name, const TensorShape& shape,
   return 0;
 }
 
-int OpKernelContext::tensor(const std::string& name, Tensor** tensor) {
+OpStatus OpKernelContext::tensor(const std::string& name, Tensor** tensor) {
   std::lock_guard<std::mutex> lk(mu_);
   auto it = tensor_map_.find(name);
   if (it == tensor_map_.end()) return -1;
@@ -257,7 +263,7 @@ int OpKernelContext::tensor(const std::string& name, Tensor** tensor) {
   return 0;
 }
 
-int OpKernelContext::Deallocate(const std::string& name) {
+OpStatus OpKernelContext::Deallocate(const std::string& name) {
   std::lock_guard<std::mutex> lk(mu_);
   auto it = tensor_map_.find(name);
   if (it == tensor_map_.end()) return -1;
@@ -301,13 +307,13 @@ OpKernelRegistrar::OpKernelRegistrar(const std::string& name, Factory factory) {
   r->factories[name] = factory;
 }
 
-int LookupOpKernel(const std::string& name) {
+OpStatus LookupOpKernel(const std::string& name) {
   Registry* r = GlobalRegistry();
   std::lock_guard<std::mutex> lk(r->mu);
   return r->factories.count(name) ? 0 : -1;
 }
 
-int CreateOpKernel(const std::string& name, OpKernel** kernel) {
+OpStatus CreateOpKernel(const std::string& name, OpKernel** kernel) {
   Registry* r = GlobalRegistry();
   std::lock_guard<std::mutex> lk(r->mu);
   auto k = r->kernels.find(name);

@@ -77,28 +77,70 @@ class Tensor {
   void* data_;
 };
 
-// The fields of DAGNodeProto the hot-path kernels use.
+// What the reference's Status (euler/common/status.h) is to an op body: `auto s = ctx->tensor(..);
+// if (!s.ok()) ...`.  Converts to and from the int codes this library returns (0 = ok), so both
+// spellings compile: `if (ctx->Allocate(..) != 0)` and `if (!ctx->Allocate(..).ok())`.
+class OpStatus {
+ public:
+  OpStatus(int code = 0) : code_(code) {}          // NOLINT: implicit on purpose
+  bool ok() const { return code_ == 0; }
+  int code() const { return code_; }
+  operator int() const { return code_; }            // NOLINT
+  static OpStatus OK() { return OpStatus(0); }
+ private:
+  int code_;
+};
+
+// The fields of DAGNodeProto the hot-path kernels use, readable BOTH ways: as the protobuf
+// accessors the reference's kernel sources call (`node_def.name()`, `node_def.inputs(0)`,
+// `node_def.inputs_size()`, `node_def.post_process(i)`, `node_def.dnf_size()` - core/kernels/
+// id_unique_op.cc:39, sample_neighbor_op.cc:39-86) and as plain members (`nd.inputs.push_back(..)`,
+// `nd.name = "x"`): a member is a std::string / std::vector<std::string> that can also be called.
+struct NodeStr : std::string {
+  NodeStr() {}
+  NodeStr(const std::string& s) : std::string(s) {}       // NOLINT
+  NodeStr(const char* s) : std::string(s) {}              // NOLINT
+  using std::string::operator=;
+  const std::string& operator()() const { return *this; }
+};
+struct NodeStrList : std::vector<std::string> {
+  using std::vector<std::string>::vector;
+  NodeStrList() {}
+  NodeStrList(const std::vector<std::string>& v) : std::vector<std::string>(v) {}    // NOLINT
+  const std::string& operator()(int i) const { return (*this)[(size_t)i]; }
+};
 struct NodeDef {
-  std::string name;                 // outputs are "<name>:<i>"
-  std::string op;
-  std::vector<std::string> inputs;  // tensor names looked up in the context
+  NodeStr name;                     // outputs are "<name>:<i>"
+  NodeStr op;
+  NodeStrList inputs;               // tensor names looked up in the context
   // DAGNodeProto.post_process of API_GET_NB_NODE: "order_by id|weight [desc]",
   // "limit k" (core/kernels/get_neighbor_op.cc:117-168)
-  std::vector<std::string> post_process;
+  NodeStrList post_process;
+  int inputs_size() const { return (int)inputs.size(); }
+  int post_process_size() const { return (int)post_process.size(); }
+  int dnf_size() const { return 0; }               // conditions (`has` / index lookups): out of scope
+  void set_name(const std::string& v) { name = v; }
+  void set_op(const std::string& v) { op = v; }
+  void add_inputs(const std::string& v) { inputs.push_back(v); }
+  void add_post_process(const std::string& v) { post_process.push_back(v); }
 };
+// The reference's kernels spell the node definition `DAGNodeProto` (core/framework/op_kernel.h:35).
+typedef NodeDef DAGNodeProto;
 std::string OutputName(const NodeDef& node_def, int i);
+std::string OutputName(const std::string& name, int i);
 
 class OpKernelContext {
  public:
   ~OpKernelContext();
-  // 0 on success (the reference returns Status; ok() == (rc == 0)).
-  int Allocate(const std::string& name, const TensorShape& shape, DataType type,
-               Tensor** tensor);
-  int tensor(const std::string& name, Tensor** tensor);
-  int Deallocate(const std::string& name);
+  // 0 / ok() on success (the reference returns Status, op_kernel.h:84-99).
+  OpStatus Allocate(const std::string& name, const TensorShape& shape, DataType type,
+                    Tensor** tensor);
+  OpStatus tensor(const std::string& name, Tensor** tensor);
+  OpStatus Deallocate(const std::string& name);
   // A second name for an existing tensor (op_kernel.cc AddAlias; the context
   // frees every distinct tensor once, op_kernel.cc:80-90).
-  int AddAlias(const std::string& name, Tensor* tensor);
+  OpStatus AddAlias(const std::string& name, Tensor* tensor);
+  OpStatus RemoveAlias(const std::string& name);
   // Sampling randomness (not in the reference, whose RNG is time(0)-seeded and
   // cannot be fixed).  A context the host did not touch - what a DAG executor
   // creates per query - samples with the PROCESS seed (std::random_device once
@@ -148,9 +190,9 @@ class OpKernelRegistrar {
   OpKernelRegistrar(const std::string& name, Factory factory);
 };
 
-// 0 = found / created (cached singleton per op name, op_kernel.cc:217-231).
-int LookupOpKernel(const std::string& name);
-int CreateOpKernel(const std::string& name, OpKernel** kernel);
+// 0 / ok() = found / created (cached singleton per op name, op_kernel.cc:217-231).
+OpStatus LookupOpKernel(const std::string& name);
+OpStatus CreateOpKernel(const std::string& name, OpKernel** kernel);
 
 #define REGISTER_OP_KERNEL(name, cls) \
   REGISTER_OP_KERNEL_UNIQ_HELPER(__COUNTER__, name, cls)
