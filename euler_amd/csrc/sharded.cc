@@ -417,6 +417,9 @@ int euler_gpu_sharded_random_walk(const euler_gpu_graph* shard, const euler_gpu_
       rc = tr->alltoallv(tr->user, drawn, recv_rows.data(), level ? (void*)level : (void*)owned,
                          send_rows.data(), 8, stream);
       if (rc != EULER_GPU_OK) return rc;
+      // (stream-ordered: the block is back in the pool before the next step asks for its own -
+      // the call's footprint is the largest step's, not the sum over the walk's steps)
+      sc.Release(owned);
     }
     q.m = asked;
     return EULER_GPU_OK;

@@ -163,6 +163,9 @@ class ShardedSampler:
         self.bytes_sent = 0
         self.bytes_received = 0
         self.exchanges = 0
+        # not None: every collective this sampler issues is appended as (kind, peers | row bytes) -
+        # all ranks must produce the SAME sequence whatever their batches hold (tests)
+        self.collective_log = None
         # call ids: every sampling call without an explicit call_id takes fresh
         # ones from this counter (by hops for a fanout, by steps for a walk), like
         # Graph._take_call_ids - identically on all ranks, because every rank makes
@@ -189,6 +192,8 @@ class ShardedSampler:
         a device sync."""
         if self.world == 1 and not self.force_exchange:
             return [int(c) for c in send_counts]
+        if self.collective_log is not None:
+            self.collective_log.append(("counts", len(send_counts)))
         if self.counts_fn is not None:
             return self.counts_fn(send_counts)
         sc = torch.tensor(send_counts, dtype=torch.int64,
@@ -213,6 +218,8 @@ class ShardedSampler:
             # is the buffer itself (a self send / receive through RCCL costs a 46 MB copy per
             # fanout step and moves nothing)
             return send.contiguous()
+        if self.collective_log is not None:
+            self.collective_log.append(("alltoallv", row_bytes))
         staged = self.host_staged and send.is_cuda
         src = send.contiguous().cpu() if staged else send.contiguous()
         recv = torch.empty(shape, dtype=send.dtype, device=src.device)
@@ -229,6 +236,8 @@ class ShardedSampler:
         m = ids.shape[0]
         # 4 * count + 2 words: an even width keeps the rows 8-byte aligned
         buf = torch.zeros((m, 4 * count + 2), dtype=torch.int32, device=ids.device)
+        if m == 0:          # a shard nobody asked anything (found by the 8-rank rehearsal: an empty
+            return buf      # tensor's stride cannot be viewed as another width)
         buf[:, :2 * count] = ids.reshape(m, count).contiguous().view(torch.int32)
         buf[:, 2 * count:3 * count] = w.reshape(m, count).contiguous().view(torch.int32)
         buf[:, 3 * count:4 * count] = t.reshape(m, count)
@@ -1025,6 +1034,7 @@ class CTransport:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.bytes_sent = 0
+        self.log = None        # not None: every callback is appended as (kind, peers | row bytes) - tests
         self.counts_fn = counts_fn
         self.on_gpu = dist.get_backend(group) == "nccl"
         self.device = device
@@ -1043,6 +1053,8 @@ class CTransport:
 
         def counts(_user, send, recv):
             try:
+                if self.log is not None:
+                    self.log.append(("counts", self.world))
                 if self.counts_fn is not None:
                     got = self.counts_fn([send[p] for p in range(self.world)])
                     for p in range(self.world):
@@ -1061,6 +1073,8 @@ class CTransport:
 
         def a2av(_user, send_dev, send_rows, recv_dev, recv_rows, row_bytes, stream):
             try:
+                if self.log is not None:
+                    self.log.append(("alltoallv", int(row_bytes)))
                 s_rows = [int(send_rows[p]) for p in range(self.world)]
                 r_rows = [int(recv_rows[p]) for p in range(self.world)]
                 if self.on_gpu:

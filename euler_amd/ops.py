@@ -267,7 +267,13 @@ class _GatherSegmentReduce(torch.autograd.Function):
                     _stream(), _GS_MODE[op], _ptr(params), _ptr(gi), _ptr(sp) if sp is not None else None,
                     int(count), params.shape[1], int(size), _ptr(out)))
         if as_ids and ctx.needs_input_grad[0]:
-            gi = gi.to(torch.int32)                 # the gradient kernels take int32 indices
+            # the gradient kernels take int32 indices.  The forward kernel reads an id past the
+            # table - or a negative one, e.g. default_node = -1: unsigned there - from the table's
+            # LAST row (euler_gpu.h); the gradient must flow to that same row, so the saved
+            # indices get the same clamp (the raw low word would be an out-of-range or
+            # negative scatter key)
+            last = int(params.shape[0]) - 1            # min((uint32) low word, rows - 1), as the kernel
+            gi = torch.clamp(gi & 0xFFFFFFFF, max=last).to(torch.int32)
         ctx.save_for_backward(params, gi, sp if sp is not None else torch.empty(0), out)
         ctx.has_ptr, ctx.count, ctx.size, ctx.op = sp is not None, int(count), int(size), op
         return out
@@ -406,6 +412,44 @@ def data_gather(data, idx, gather_idx):
                                           _ptr(idx), _ptr(gi), _ptr(out_idx),
                                           gi.numel(), _ptr(out)))
     return out
+
+
+def sparse_gather(gather_idx, indices, values, dense_shape):
+    """tf_euler sparse_gather (tf_euler/kernels/sparse_gather_op.cc:32-240, op
+    tf_euler/ops/util_ops.cc:37-55): `gather` on a SparseTensor whose entries are sorted by row.
+    Row g of the result = row gather_idx[g] of the input: its entries in order, first index
+    column rewritten to g, the other columns and the values copied; dense_shape[0] = len(
+    gather_idx).  Returns (out_indices [nnz', cols] int64, out_values, out_dense_shape).  The
+    rows' extents come from a binary search of the first index column (the reference's
+    GatherWithBinarySearch; its GatherWithIndex branch answers the same on inputs where every
+    gathered row has an entry - what get_sparse_feature produces: it inserts a default entry
+    for empty rows), the copies are the DATA_GATHER kernel's.  A row without entries gathers
+    nothing; an index >= dense_shape[0] raises IndexError as the reference's InvalidArgument."""
+    gi = gather_idx.reshape(-1).to(torch.int64)
+    indices = indices.to(torch.int64).contiguous()
+    _need_cuda(indices, values)
+    if indices.dim() != 2 or values.dim() != 1 or values.numel() != indices.shape[0]:
+        raise ValueError("sparse_gather: indices [nnz, cols] and values [nnz]")
+    shape = [int(x) for x in (dense_shape.tolist() if hasattr(dense_shape, "tolist") else dense_shape)]
+    if len(shape) != indices.shape[1]:
+        raise ValueError("sparse_gather: dense_shape and indices shape mismatch")
+    rows = shape[0]
+    if gi.numel() and (int(gi.max()) >= rows or int(gi.min()) < 0):
+        raise IndexError("sparse_gather: gather idx out of range")
+    dev = indices.device
+    col0 = indices[:, 0].contiguous()
+    bounds = torch.searchsorted(col0, torch.arange(rows + 1, device=dev, dtype=torch.int64))
+    idx = torch.stack([bounds[:-1], bounds[1:]], dim=1).to(torch.int32)
+    g32 = gi.to(torch.int32).to(dev)
+    out_values = data_gather(values, idx, g32)
+    lens = (idx[:, 1] - idx[:, 0]).to(torch.int64)[gi.to(dev)]
+    cols = [torch.repeat_interleave(torch.arange(gi.numel(), device=dev, dtype=torch.int64), lens)]
+    for k in range(1, indices.shape[1]):
+        cols.append(data_gather(indices[:, k].contiguous(), idx, g32))
+    out_indices = torch.stack(cols, dim=1) if out_values.numel() else \
+        torch.empty((0, indices.shape[1]), dtype=torch.int64, device=dev)
+    out_shape = torch.tensor([gi.numel()] + shape[1:], dtype=torch.int64)
+    return out_indices, out_values, out_shape
 
 
 def id_split(ids, partitions, shards):

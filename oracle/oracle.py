@@ -864,6 +864,27 @@ def data_gather(data, idx, gather_idx):
     return out
 
 
+def sparse_gather(gather_idx, indices, values, dense_shape):
+    """tf_euler/kernels/sparse_gather_op.cc:136-184 (GatherWithBinarySearch) restated in numpy:
+    rows of a SparseTensor sorted by row, gathered; (out_indices, out_values, out_dense_shape)."""
+    gi = np.asarray(gather_idx, np.int64).reshape(-1)
+    ind = np.asarray(indices, np.int64)
+    val = np.asarray(values)
+    rows = int(dense_shape[0])
+    out_i, out_v = [], []
+    for g, r in enumerate(gi):
+        if r >= rows:
+            raise IndexError("SparseGather: gather idx out of range.")
+        lo = int(np.searchsorted(ind[:, 0], r, side="left"))
+        hi = int(np.searchsorted(ind[:, 0], r + 1, side="left"))
+        for j in range(lo, hi):
+            out_i.append([g] + [int(x) for x in ind[j, 1:]])
+            out_v.append(val[j])
+    oi = np.asarray(out_i, np.int64).reshape(-1, ind.shape[1])
+    ov = np.asarray(out_v, val.dtype)
+    return oi, ov, np.asarray([len(gi)] + [int(x) for x in dense_shape[1:]], np.int64)
+
+
 def alias_init(weights):
     w = _arr(weights, np.float32)
     prob = np.zeros(len(w), np.float32)

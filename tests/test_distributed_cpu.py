@@ -441,6 +441,118 @@ def test_sharded_fanout_matches_unsharded_gloo(O, tmp_path, world, partitions):
         assert os.path.exists(tmp_path / ("ok_%d" % r))
 
 
+def _rehearsal_worker(rank, world, port, partitions, out_dir):
+    """An N-rank dress rehearsal on CPU doubles: 8 ranks, partitions = 1024 (the
+    reference's file partitions: owner = (id % 1024) % 8, core/kernels/id_split_op.cc:46-49,
+    core/graph/graph.cc:90-98), a rank whose shard is EMPTY, a batch whose roots one rank owns
+    alone, ranks with an empty batch - every rank must issue the same sequence of collectives and
+    the results must equal the unsharded graph's."""
+    import json
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from euler_amd.distributed import ShardedSampler
+    csr_all, _ids = _build_csr(O)
+    # the graph without the rows rank `world - 1` would own: that shard is empty, ids that
+    # pointed there are now unknown nodes (their owner answers default rows)
+    keep = O.shard_of(csr_all.row_id, partitions, world) != world - 1
+    rows = np.nonzero(keep)[0]
+    T = csr_all.n_types
+    rp, nbr, pw, te, tp = [0], [], [], [], []
+    for r in rows:
+        b, e = csr_all.row_ptr[r], csr_all.row_ptr[r + 1]
+        nbr.append(csr_all.nbr[b:e]); pw.append(csr_all.prefix_w[b:e])
+        te.append(csr_all.type_end[r * T:(r + 1) * T]); tp.append(csr_all.type_prefix[r * T:(r + 1) * T])
+        rp.append(rp[-1] + (e - b))
+    csr = O.CSR(csr_all.row_id[rows], np.array(rp, np.int64), np.concatenate(te).astype(np.int32),
+                np.concatenate(nbr).astype(np.uint64), np.concatenate(pw).astype(np.float32),
+                np.concatenate(tp).astype(np.float32), T, csr_all.node_type[rows], csr_all.node_weight[rows])
+    shard = _shard_csr(O, csr, partitions, rank, world)
+    assert (len(shard.row_id) == 0) == (rank == world - 1)
+    OG_local, OG_full = O.OracleGraph(shard), O.OracleGraph(csr)
+    seed = 31
+
+    def local_sample(owned, edge_types, count, default_node, call_id):
+        q = owned.numpy().astype(np.int64)
+        assert np.all(O.shard_of(q.astype(np.uint64), partitions, world) == rank)
+        n, w, t = OG_local.sample_neighbor(seed, call_id, q, edge_types, count, default_node)
+        _, cid, _, _ = OG_local.sample_neighbor_core(seed, call_id, q.astype(np.uint64), edge_types, count)
+        mask = (cid.reshape(len(q), count)[:, 0] == 0).astype(np.uint8) if count else np.zeros(len(q), np.uint8)
+        return torch.as_tensor(n), torch.as_tensor(w), torch.as_tensor(t), torch.as_tensor(mask)
+
+    def split_fn(roots, parts, shards):
+        off, sid, mi = O.id_split(roots.numpy().astype(np.uint64), parts, shards)
+        return off.tolist(), torch.as_tensor(sid.astype(np.int64)), torch.as_tensor(mi)
+
+    def merge_fn(rows_, merge_idx):
+        out = torch.empty_like(rows_)
+        out[merge_idx.long()] = rows_
+        return out
+
+    def dedup_split_fn(ids, parts, shards, root_mask=None, root_group=1):
+        if root_mask is not None:
+            m = root_mask.numpy().astype(bool).repeat(root_group)[:ids.numel()]
+            ids = torch.where(torch.as_tensor(m), torch.zeros_like(ids), ids)
+        uq, gi = O.id_unique(ids.numpy().astype(np.uint64))
+        off, sid, mi = O.id_split(uq, parts, shards)
+        inv = np.empty(len(uq), np.int64)
+        inv[mi] = np.arange(len(uq))
+        return off.tolist(), torch.as_tensor(sid.astype(np.int64)), torch.as_tensor(inv[gi])
+
+    def expand_fn(pos, ids, w, t, mask, count):
+        p = pos.long()
+        return ids[p], w[p], t[p], mask[p]
+
+    S = ShardedSampler(local_sample, split_fn, merge_fn, partitions, dedup_split_fn=dedup_split_fn,
+                       expand_fn=expand_fn)
+    S.collective_log = []
+    rng = np.random.default_rng(1000 + rank)
+    all_ids = csr.row_id.astype(np.int64)
+    owner = O.shard_of(csr.row_id, partitions, world)
+    batches = [
+        rng.choice(all_ids, 300 + 37 * rank),                              # ragged sizes
+        rng.choice(all_ids[owner == 5], 256),                              # one rank owns every root
+        rng.choice(all_ids, 200) if rank % 3 else np.zeros(0, np.int64),   # some ranks bring nothing
+        np.concatenate([rng.choice(all_ids, 50), [0, 2 ** 40 + 7]]),       # unknown ids
+    ]
+    for b, roots in enumerate(batches):
+        for et, counts in (([[0], [1]], [5, 3]), ([[0, 1, 2], [2, 0]], [4, 2])):
+            k = max(len(x) for x in et)
+            et_pad = [list(x) + [x[-1]] * (k - len(x)) for x in et] if len({len(x) for x in et}) > 1 else et
+            got = S.sample_fanout(torch.as_tensor(roots), et_pad, counts, -1, call_id=10 * b)
+            want = OG_full.sample_fanout(seed, 10 * b, roots, et_pad, counts, -1)
+            for h in range(2):
+                assert np.array_equal(got[0][h + 1].numpy().reshape(-1), want[0][h]), (rank, b, h)
+                assert np.array_equal(got[1][h].numpy().reshape(-1), want[1][h]), (rank, b, h)
+        walk = S.random_walk(torch.as_tensor(roots), [[0, 1, 2]] * 5, default_node=-1, call_id=500 + 10 * b)
+        assert np.array_equal(walk.numpy(), OG_full.random_walk(seed, 500 + 10 * b, roots, [[0, 1, 2]] * 5, 5,
+                                                                1.0, 1.0, -1)), (rank, b)
+    with open(os.path.join(out_dir, "collectives_rank%d.json" % rank), "w") as f:
+        json.dump(S.collective_log, f)
+    dist.barrier()
+    dist.destroy_process_group()
+    with open(os.path.join(out_dir, "rehearsal_ok_%d" % rank), "w") as f:
+        f.write("ok")
+
+
+def test_eight_rank_rehearsal_partitions_1024(O, tmp_path):
+    import json
+    world = 8
+    port = _free_port()
+    mp.spawn(_rehearsal_worker, args=(world, port, 1024, str(tmp_path)), nprocs=world, join=True)
+    logs = []
+    for r in range(world):
+        assert os.path.exists(os.path.join(str(tmp_path), "rehearsal_ok_%d" % r))
+        logs.append(json.load(open(os.path.join(str(tmp_path), "collectives_rank%d.json" % r))))
+    # the same sequence of collectives on every rank, whatever its batch held: 4 batches x (2
+    # fanouts x 2 hops + 5 walk steps) x (counts, ids out, rows back)
+    assert all(l == logs[0] for l in logs[1:]), "ranks issued different collective sequences"
+    assert len(logs[0]) == 4 * (2 * 2 + 5) * 3
+    assert [k for k, _ in logs[0][:3]] == ["counts", "alltoallv", "alltoallv"]
+
+
 def _mailbox_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"

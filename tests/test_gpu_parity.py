@@ -327,6 +327,96 @@ def test_gather_scatter_fused_equals_composition(EA, O, torch_cuda):
             p3 = xt.clone().requires_grad_(True)
             (ops.gather_segment_reduce(op, p3, gi2t.to(torch.int64), size, seg_ptr=ptrt) * g).sum().backward()
             assert torch.equal(p3.grad, p1.grad), (op, d)
+            # ids that are not rows of the table - a neighbour outside the graph, default_node = -1 -
+            # read the table's LAST row forward, and the gradient flows to that same row
+            bad = gi2t.to(torch.int64).clone()
+            if bad.numel() > 3:
+                bad[0] = -1; bad[1] = n + 12345; bad[2] = n
+                ok = gi2t.clone(); ok[0] = n - 1; ok[1] = n - 1; ok[2] = n - 1
+                p4 = xt.clone().requires_grad_(True)
+                p5 = xt.clone().requires_grad_(True)
+                f4 = ops.gather_segment_reduce(op, p4, bad, size, seg_ptr=ptrt)
+                f5 = ops.gather_segment_reduce(op, p5, ok, size, seg_ptr=ptrt)
+                assert torch.equal(f4, f5), (op, d)
+                (f4 * g).sum().backward(); (f5 * g).sum().backward()
+                assert torch.equal(p4.grad, p5.grad), (op, d)
+
+
+def test_index_builds_declined(EA, O, torch_cuda):
+    """Both search indexes are optimisations: with the weight-bucket index declined
+    (budget 0) AND the EdgeBlocks' build failing the way an allocation failure would (tuning key
+    56), the samplers run on the flat running sums - same results as the oracle for sampling,
+    fanout, walks and block construction; what the failed build allocated is returned
+    (graph_bytes unchanged), and the build is not retried on every call."""
+    torch = torch_cuda
+    from euler_amd import _lib
+    L = _lib.lib()
+    p = EA.synth_params(411, 20000, 300000, n_types=2, weighted=True)
+    po = O.SynthParams()
+    for f, _ in po._fields_:
+        setattr(po, f, getattr(p, f))
+    OG = O.OracleGraph(O.synth_csr(po))
+    q = np.concatenate([np.random.default_rng(3).integers(1, 20001, 3000), [0, 20001, 5, 5]]).astype(np.int64)
+    qt = torch.as_tensor(q).cuda()
+    try:
+        _lib.check(L.euler_gpu_set_index_budget(0, -1.0))      # the weight-bucket index: never
+        _lib.check(L.euler_gpu_set_tuning(56, 1))              # the next EdgeBlocks build fails
+        G = EA.Graph.synthetic(p)
+        G.set_seed(17)
+        bytes0 = G.device_bytes
+        for et, cnt in (([0], 10), ([1], 7), ([0, 1], 6)):
+            gn, gw, gt = G.sample_neighbor(qt, et, cnt, -1, call_id=40)
+            on, ow, ot = OG.sample_neighbor(17, 40, q, et, cnt, -1)
+            assert np.array_equal(t2n(gn), on) and np.array_equal(t2n(gw), ow) and np.array_equal(t2n(gt), ot)
+        assert G.device_bytes == bytes0, "the failed build's allocations were not returned"
+        # (the failure was consumed by the first call and the decision remembered: a second
+        # injected failure is still pending afterwards - nothing tried to build again)
+        _lib.check(L.euler_gpu_set_tuning(56, 1))
+        gn, gw, gt = G.sample_fanout(qt, [[0], [1]], [25, 10], -1, call_id=44)
+        on, ow, ot = OG.sample_fanout(17, 44, q, [[0], [1]], [25, 10], -1)
+        for h in range(2):
+            assert np.array_equal(t2n(gn[h + 1]), on[h]) and np.array_equal(t2n(gw[h]), ow[h])
+        walk = G.random_walk(qt[:1000], [[0, 1]] * 6, 1.0, 1.0, -1, call_id=60)
+        assert np.array_equal(t2n(walk), OG.random_walk(17, 60, q[:1000], [[0, 1]] * 6, 6, 1.0, 1.0, -1))
+        assert G.device_bytes == bytes0
+        G2 = EA.Graph.synthetic(p)          # the pending failure meets this graph's first call
+        G2.set_seed(17)
+        gn, _, _ = G2.sample_neighbor(qt, [0], 4, -1, call_id=41)
+        assert np.array_equal(t2n(gn), OG.sample_neighbor(17, 41, q, [0], 4, -1)[0])
+    finally:
+        L.euler_gpu_set_tuning(56, 0)
+        L.euler_gpu_set_index_budget(-1, 0.5)
+        # (-1 leaves max_bytes unchanged: put "no absolute cap" back through the environment's default)
+        L.euler_gpu_set_index_budget(2 ** 62, 0.5)
+
+
+def test_sparse_gather(EA, O, torch_cuda):
+    """ops.sparse_gather == the restatement of tf_euler/kernels/sparse_gather_op.cc: rows of a
+    row-sorted SparseTensor gathered (repeats, any order), 2 and 3 index columns, float / int64
+    values, rows without entries, an empty gather, the sparse features of a graph's nodes."""
+    torch = torch_cuda
+    ops = EA.ops
+    rng = np.random.default_rng(12)
+    for rows, cols, dt in ((50, 2, np.float32), (7, 3, np.int64), (300, 2, np.int64), (1, 2, np.float32)):
+        lens = rng.integers(0, 6, rows)
+        r = np.repeat(np.arange(rows), lens)
+        ind = np.zeros((len(r), cols), np.int64)
+        ind[:, 0] = r
+        for k in range(1, cols):
+            ind[:, k] = rng.integers(0, 9, len(r))
+        val = rng.integers(0, 1000, len(r)).astype(dt)
+        shape = [rows] + [9] * (cols - 1)
+        for gi in (rng.integers(0, rows, 40), np.arange(rows)[::-1].copy(), np.zeros(0, np.int64), np.array([rows - 1] * 3)):
+            want = O.sparse_gather(gi, ind, val, shape)
+            got = ops.sparse_gather(torch.as_tensor(gi).cuda(), torch.as_tensor(ind).cuda(),
+                                    torch.as_tensor(val).cuda(), shape)
+            assert np.array_equal(t2n(got[0]), want[0]) and np.array_equal(t2n(got[1]), want[1])
+            assert np.array_equal(t2n(got[2]), want[2])
+    with pytest.raises(IndexError):
+        ops.sparse_gather(torch.as_tensor([5]).cuda(), torch.zeros((1, 2), dtype=torch.int64).cuda(),
+                          torch.zeros(1).cuda(), [5, 2])
+    from euler_amd.euler_ops import util_ops
+    assert util_ops.sparse_gather is ops.sparse_gather
 
 
 def test_mp_gradients(EA, torch_cuda):

@@ -315,6 +315,99 @@ def _worker_body(rank, world, port, partitions):
     dist.destroy_process_group()
 
 
+def _worker8(rank, world, port, partitions, err_dir):
+    try:
+        _worker8_body(rank, world, port, partitions, err_dir)
+    except BaseException:
+        with open(os.path.join(err_dir, "rank%d.err" % rank), "w") as f:
+            f.write(traceback.format_exc())
+        raise
+
+
+def _worker8_body(rank, world, port, partitions, out_dir):
+    """8 ranks, partitions = 1024 (owner = (id % 1024) % 8: the reference's file partitions,
+    core/graph/graph.cc:90-98), the C entries only - what a C++ host on an 8-GPU node calls -
+    with a batch one rank owns alone, ranks without a batch, and the sequence of transport
+    callbacks of every rank written out for the parent to compare."""
+    import json
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import euler_amd as EA
+    from euler_amd.distributed import (CTransport, c_sharded_sample_fanout, c_sharded_random_walk,
+                                       c_sharded_node2vec_walk, owner_of)
+    dev = torch.device("cuda", 0)
+    N = 60_000
+    p = EA.synth_params(20240521, N, 10 * N, weighted=True)
+    G_full = EA.Graph.synthetic(p)
+    G_shard = EA.Graph.synthetic(p, partitions=partitions, shard_index=rank, shards=world)
+    G_full.set_seed(9); G_shard.set_seed(9)
+    tr = CTransport()
+    tr.log = []
+    rng = np.random.default_rng(500 + rank)
+    all_ids = torch.arange(1, N + 1, dtype=torch.int64)
+    mine5 = all_ids[owner_of(all_ids, partitions, world) == 5]
+    batches = [
+        torch.as_tensor(rng.integers(1, N + 1, 3000 + 111 * rank).astype(np.int64)),
+        mine5[torch.as_tensor(rng.integers(0, mine5.numel(), 2048))],            # rank 5 owns every root
+        torch.as_tensor(rng.integers(1, N + 1, 1500).astype(np.int64)) if rank % 3 else all_ids[:0],
+    ]
+    for b, roots in enumerate(batches):
+        roots = roots.to(dev)
+        want = G_full.sample_fanout(roots, [[0], [0]], [25, 10], N + 1, call_id=20 * b)
+        got = c_sharded_sample_fanout(G_shard, tr, roots, [[0], [0]], [25, 10], N + 1, call_id=20 * b,
+                                      partitions=partitions)
+        _same(got[0], want[0], "C fanout ids, batch %d" % b)
+        _same(got[1], want[1], "C fanout weights, batch %d" % b)
+        starts = roots[:1000]
+        etw = [[0]] * 12
+        gotw = c_sharded_random_walk(G_shard, tr, starts, etw, N + 1, 300 + 20 * b, partitions, 1, None)
+        assert torch.equal(gotw, G_full.random_walk(starts, etw, 1.0, 1.0, N + 1, call_id=300 + 20 * b)), b
+        gotn = c_sharded_node2vec_walk(G_shard, tr, starts[:400], etw[:4], 0.25, 4.0, N + 1, 600 + 20 * b,
+                                       partitions, None)
+        assert torch.equal(gotn, G_full.random_walk(starts[:400], etw[:4], 0.25, 4.0, N + 1, call_id=600 + 20 * b)), b
+    with open(os.path.join(out_dir, "callbacks_rank%d.json" % rank), "w") as f:
+        json.dump(tr.log, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_partitions_1024_c_entries_on_one_gpu(torch_cuda, tmp_path):
+    """The 8-GPU configuration's C entries (fanout, DeepWalk, node2vec) with 8 ranks sharing this
+    GPU (host-staged gloo transport): results == the unsharded graph, and every rank makes the
+    same sequence of transport callbacks whatever its batch holds."""
+    import json
+    import torch.multiprocessing as mp
+    world, partitions = 8, 1024
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, partitions, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(900)
+    errs = []
+    for r, p in enumerate(procs):
+        if p.is_alive():
+            p.kill()
+            errs.append("rank %d timed out" % r)
+        f = tmp_path / ("rank%d.err" % r)
+        if f.exists():
+            errs.append("rank %d:\n%s" % (r, f.read_text()))
+        elif p.exitcode not in (0, None):
+            errs.append("rank %d exit code %s" % (r, p.exitcode))
+    assert not errs, "\n".join(errs)
+    logs = [json.load(open(str(tmp_path / ("callbacks_rank%d.json" % r)))) for r in range(world)]
+    assert all(l == logs[0] for l in logs[1:]), "ranks made different sequences of transport callbacks"
+    # per batch: fanout 2 hops x (counts, ids, rows) + walk 12 x (counts, ids, answers) + node2vec
+    # 4 x (counts, ids, lengths, counts, ids, weights)
+    assert len(logs[0]) == 3 * (2 * 3 + 12 * 3 + 4 * 6)
+
+
 @pytest.mark.parametrize("world,partitions", [(2, 2), (2, 6), (3, 3)])
 def test_sharded_hip_pieces_world_gt1_on_one_gpu(torch_cuda, tmp_path, world, partitions):
     import torch.multiprocessing as mp
