@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libeuler_gpu.so")
+LIB_PATH = os.environ.get("EULER_GPU_LIB_PATH") or os.path.join(HERE, "lib", "libeuler_gpu.so")   # (the variable: A/B of experimental builds, tools/)
 
 OK, EINVAL, ENOMEM, EHIP, ENOGRAPH, EIO, EEMPTY = 0, -1, -2, -3, -4, -5, -6
 LAYOUT_CORE, LAYOUT_TF = 0, 1
