@@ -1271,18 +1271,53 @@ __global__ __launch_bounds__(256) void FrontRepHistKernel(const FrontArgs a) {
   if (threadIdx.x < kMaxShards) hist[threadIdx.x] = 0u;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * kFrontChunk;
-#pragma unroll 2
-  for (int32_t k = 0; k < kFrontChunk / 256; ++k) {
-    const int64_t i = base + (int64_t)k * 256 + threadIdx.x;
-    if (i < a.d.n) {
-      const uint64_t id = DedupIdAt(a.d, i);
-      const uint32_t r = DENSE ? a.dense_owner[DenseSlot(a, id)] : DedupRep(a.d, (uint32_t)i);
-      a.rep[i] = r;
-      if (r == (uint32_t)i) {
-        const uint32_t own = (uint32_t)OwnerOf(id, a.partitions, a.shards);
-        a.place[i] = own << 16 | atomicAdd(&hist[own], 1u);
-      }
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t lt = lane == 0u ? 0ull : (~0ull >> (64u - lane));
+  constexpr int kPer = kFrontChunk / 256;
+  // dense ids: the chunk's ids, then its table entries - every load of a kind in flight together
+  // (taken position by position the chunk is kPer dependent pairs of round trips long)
+  uint64_t idv[kPer];
+  uint32_t repv[kPer];
+  if (DENSE) {
+#pragma unroll
+    for (int32_t k = 0; k < kPer; ++k) {
+      const int64_t i = base + (int64_t)k * 256 + threadIdx.x;
+      idv[k] = i < a.d.n ? DedupIdAt(a.d, i) : 0ull;
     }
+#pragma unroll
+    for (int32_t k = 0; k < kPer; ++k) {
+      const int64_t i = base + (int64_t)k * 256 + threadIdx.x;
+      repv[k] = i < a.d.n ? a.dense_owner[DenseSlot(a, idv[k])] : 0xFFFFFFFFu;
+    }
+  }
+#pragma unroll
+  for (int32_t k = 0; k < kPer; ++k) {
+    const int64_t i = base + (int64_t)k * 256 + threadIdx.x;
+    bool is_rep = false;
+    uint32_t own = 0xFFFFFFFFu;
+    if (i < a.d.n) {
+      const uint64_t id = DENSE ? idv[k] : DedupIdAt(a.d, i);
+      const uint32_t r = DENSE ? repv[k] : DedupRep(a.d, (uint32_t)i);
+      a.rep[i] = r;
+      is_rep = r == (uint32_t)i;
+      if (is_rep) own = (uint32_t)OwnerOf(id, a.partitions, a.shards);
+    }
+    // ranks within (chunk, owner shard): ONE LDS atomic per shard present in the wave, the lanes'
+    // ranks from the ballot.  (A lane-per-representative atomicAdd is 64 serialized operations on
+    // one LDS address whenever a wave's representatives share an owner - always with one rank,
+    // every eighth with eight: it made this kernel 21 us long whatever the level held.)
+    uint32_t rank = 0;
+    for (uint32_t s = 0; s < (uint32_t)a.shards; ++s) {          // (wave-uniform trip count)
+      const bool mine = is_rep && own == s;
+      const uint64_t same = __ballot(mine);
+      if (same == 0ull) continue;
+      const uint32_t first = (uint32_t)__ffsll((unsigned long long)same) - 1u;
+      uint32_t got = 0;
+      if (lane == first) got = atomicAdd(&hist[s], (uint32_t)__popcll(same));
+      got = (uint32_t)__shfl((int)got, (int)first);
+      if (mine) rank = got + (uint32_t)__popcll(same & lt);
+    }
+    if (is_rep) a.place[i] = own << 16 | rank;
   }
   __syncthreads();
   if ((int)threadIdx.x < a.shards)
