@@ -331,120 +331,6 @@ __device__ __forceinline__ void PlainSamplePairLite(const FanoutPlainArgs& a, co
   }
 }
 
-
-// ---- hop 2 with a block fetched WHOLE by eight lanes (OCT) ---------------------------------------
-// The read side of this kernel is bound by REQUESTS (tools/ubench_block.hip): a lane that asks for
-// its own block with three 16-byte key loads and a dependent id load makes four requests per line,
-// and the chip completes 19.5 G such lines/s; eight lanes that ask for the eight 16-byte chunks of
-// a line with ONE instruction make one request, 36-41 G lines/s.  So hop 2 runs in two phases: a
-// lane per PAIR of draws computes (block number, f) of its draws and parks them where the draws'
-// ids will stand; then eight lanes per draw fetch the block - every load of `kOctBatch` steps in
-// flight before the first is used - count the keys <= f among the three key lanes (a sum over the
-// octet: three DPP adds), and the lane that HOLDS the drawn id / the drawn key writes the id / the
-// weight into the row.  No cross-lane traffic but DPP, no dependent load.  A draw its block does
-// not bracket, and one that rounds up to the row's total, is marked and replayed the reference's
-// way by the pair's lane afterwards (rare).
-constexpr uint32_t kOctBatch = 8;           // steps (of 8 draws) whose loads are issued together
-constexpr uint32_t kColdLine = 0xFFFFFFFEu; // the draw takes the reference's search
-constexpr uint32_t kColdWeight = 0xFFFFFFFFu;   // (a NaN no weight has) the draw is still to be replayed
-
-template <int CTRL>
-__device__ __forceinline__ uint32_t DppU(const uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
-}
-template <int CTRL>
-__device__ __forceinline__ float DppF(const float v) {
-  return __uint_as_float(DppU<CTRL>(__float_as_uint(v)));
-}
-__device__ __forceinline__ float Sel4(const float4 v, const uint32_t i) {
-  const float lo = (i & 1u) ? v.y : v.x, hi = (i & 1u) ? v.w : v.z;
-  return (i & 2u) ? hi : lo;
-}
-
-// phase A of a pair of draws: what PlainSamplePair computes before it touches a block
-__device__ __forceinline__ uint4 OctStagePair(const WbRec rec, const bool lv, const double u0, const double u1) {
-  const double r0 = __dmul_rn(u0, (double)rec.total), r1 = __dmul_rn(u1, (double)rec.total);
-  const bool q0 = !((double)rec.total > r0), q1 = !((double)rec.total > r1);     // Q3: the cold way
-  const float f0 = WbFloorToFloat(r0), f1 = WbFloorToFloat(r1);
-  const uint32_t nbk = WbBuckets(rec.deg);
-  uint32_t j0 = 0u, j1 = 0u;
-  if (nbk > 1u) {
-    const float scale = WbScale(nbk, rec.total);
-    j0 = WbBucketOf(f0, nbk, scale);
-    j1 = WbBucketOf(f1, nbk, scale);
-  }
-  uint4 o;
-  o.x = !lv ? kSkipLine : q0 ? kColdLine : rec.wb_lo + j0;
-  o.y = __float_as_uint(f0);
-  o.z = !lv ? kSkipLine : q1 ? kColdLine : rec.wb_lo + j1;
-  o.w = __float_as_uint(f1);
-  return o;
-}
-
-// phase B: draws [0, nd) of the pass, {block, f} parked in s_sid[d]; results into s_sid / s_sw.
-// Returns (wave-uniform) whether some draw is left for the cold pass.
-__device__ __forceinline__ bool OctDraws(const FanoutPlainArgs& a, const uint32_t lane, const uint32_t nd,
-                                         uint64_t* s_sid, float* s_sw) {
-  const uint32_t o = lane >> 3, c = lane & 7u;
-  const uint8_t* wb = reinterpret_cast<const uint8_t*>(a.wb) + c * 16u;
-  bool any_cold = false;
-  for (uint32_t base = 0; base < nd; base += 8u * kOctBatch) {
-    uint2 key[kOctBatch];
-    float4 v[kOctBatch];
-#pragma unroll
-    for (uint32_t k = 0; k < kOctBatch; ++k) {
-      const uint32_t d = base + 8u * k + o;
-      key[k] = make_uint2(kSkipLine, 0u);
-      v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (base + 8u * k < nd) {                                      // (wave-uniform)
-        if (d < nd) key[k] = *reinterpret_cast<const uint2*>(s_sid + d);
-        if (key[k].x < kColdLine) v[k] = *reinterpret_cast<const float4*>(wb + (size_t)key[k].x * 128u);
-      }
-    }
-#pragma unroll
-    for (uint32_t k = 0; k < kOctBatch; ++k) {
-      if (base + 8u * k < nd) {                                      // (wave-uniform)
-        const uint32_t d = base + 8u * k + o;
-        const uint32_t bi = key[k].x;
-        const float f = __uint_as_float(key[k].y);
-        const float4 x = v[k];
-        // keys <= f in this lane's chunk (chunk 2: keys 8, 9, then prev_last - greater than f
-        // means the block does not bracket the draw: 16 pushes the count past any position)
-        uint32_t cnt = 0;
-        if (c <= 2u) {
-          cnt = (!(x.x > f) ? 1u : 0u) + (!(x.y > f) ? 1u : 0u);
-          if (c < 2u) cnt += (!(x.z > f) ? 1u : 0u) + (!(x.w > f) ? 1u : 0u);
-          else cnt += x.z > f ? 16u : 0u;
-        }
-        cnt += DppU<0xB1>(cnt);            // quad_perm [1, 0, 3, 2]
-        cnt += DppU<0x4E>(cnt);            // quad_perm [2, 3, 0, 1]
-        const uint32_t i = cnt + DppU<0x141>(cnt);     // row_half_mirror: the octet's other quad
-        const float up = DppF<0x111>(x.w);             // row_shr 1: the chunk before this one's last key
-        const float p0 = DppF<0xE6>(x.z);              // quad_perm [2, 1, 2, 3]: prev_last to the octet's lane 0
-        const bool pending = bi < kColdLine && d < nd;
-        const bool hot = pending && i < (uint32_t)kEdgesPerBlock;
-        if (hot && c == (i >> 2)) {
-          const uint32_t q = i & 3u;
-          const float below = q == 0u ? (c == 0u ? p0 : up) : Sel4(x, q - 1u);
-          s_sw[d] = __fsub_rn(Sel4(x, q), below);
-        }
-        if (hot && c == 3u + (i >> 1)) {
-          const uint2 lo = make_uint2(__float_as_uint(x.x), __float_as_uint(x.y));
-          const uint2 hi = make_uint2(__float_as_uint(x.z), __float_as_uint(x.w));
-          *reinterpret_cast<uint2*>(s_sid + d) = (i & 1u) ? hi : lo;
-        }
-        const bool cold = d < nd && c == 0u && (bi == kColdLine || (pending && !hot));
-        if (d < nd && c == 0u) {
-          if (bi == kSkipLine) { s_sid[d] = (uint64_t)a.default_node; s_sw[d] = 0.f; }
-          else if (cold) s_sw[d] = __uint_as_float(kColdWeight);
-        }
-        any_cold = any_cold || __ballot(cold) != 0ull;
-      }
-    }
-  }
-  return any_cold;
-}
-
 __device__ __forceinline__ uint32_t OpaqueLane(uint32_t lane) {
   asm volatile("" : "+v"(lane));
   return lane;
@@ -465,7 +351,7 @@ __device__ __forceinline__ WbRec PlainLoadRec(const FanoutPlainArgs& a, const ui
   return wr;
 }
 
-template <int WPS, bool COOP, bool LITE2 = false, bool OCT = false>
+template <int WPS, bool COOP, bool LITE2 = false>
 __global__ __launch_bounds__(256, WPS) void SampleFanoutPlainKernel(const FanoutPlainArgs a) {
   extern __shared__ __align__(16) uint8_t fp_smem[];
   const uint32_t lane = threadIdx.x & 63u;
@@ -623,15 +509,6 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutPlainKernel(const Fanout
         const bool lv = in && cr.deg > 0u;
         uint64_t i2[2]; float w2[2]; uint32_t m2[2];
         const Philox4 pb = RngBlock(a.seed, call + 1u, kDomainNeighbor, child, x2);
-        if (OCT) {
-          // phase A: the pair's {block, f} x 2 parked in its 16 bytes of the id row
-          if (in) {
-            *reinterpret_cast<uint4*>(s_sid + __umul24(sl, c2) + 2u * x2) =
-                OctStagePair(cr, lv, UnitFromWords(pb.w[0], pb.w[1]), UnitFromWords(pb.w[2], pb.w[3]));
-            if (x2 == 0) s_st[sl] = lv ? 0 : -1;
-          }
-          continue;
-        }
         if (COOP) {
           const uint32_t left = ns - sb < RPI ? ns - sb : RPI;        // slots of this step
           WaveSamplePairs(a, lane, __umul24(left, hp2), s_stage, s_blk, cr, lv, lv, UnitFromWords(pb.w[0], pb.w[1]),
@@ -653,37 +530,6 @@ __global__ __launch_bounds__(256, WPS) void SampleFanoutPlainKernel(const Fanout
         }
       }
       WaveSync();
-      if (OCT) {
-        // phase B: eight lanes per draw; phase C (rare): the draws left over, the reference's way
-        const bool left = OctDraws(a, lane, __umul24(ns, c2), s_sid, s_sw);
-        WaveSync();
-        if (left) {
-          for (uint32_t sb = 0; sb < ns; sb += RPI) {
-            const uint32_t sl = sb + rs;
-            if (act2 && sl < ns) {
-              const uint32_t at = __umul24(sl, c2) + 2u * x2;
-              const bool redo0 = __float_as_uint(s_sw[at]) == kColdWeight;
-              const bool redo1 = __float_as_uint(s_sw[at + 1u]) == kColdWeight;
-              if (redo0 || redo1) {
-                const uint64_t child = s_c1[s_rep[s0 + sl]];
-                const WbRec cr = PlainLoadRec(a, child);
-                const Philox4 pb = RngBlock(a.seed, call + 1u, kDomainNeighbor, child, x2);
-                const float* nw = a.prefix_w + cr.lo;
-#pragma nounroll
-                for (uint32_t s = 0; s < 2u; ++s) {
-                  if (s == 0u ? redo0 : redo1) {
-                    const double u = s == 0u ? UnitFromWords(pb.w[0], pb.w[1]) : UnitFromWords(pb.w[2], pb.w[3]);
-                    const uint32_t mid = (uint32_t)RandomSelect(nw, 0, (uint64_t)(cr.deg - 1u), u);
-                    s_sid[at + s] = a.nbr[cr.lo + mid];
-                    s_sw[at + s] = __fsub_rn(nw[mid], mid == 0u ? 0.f : nw[mid - 1]);
-                  }
-                }
-              }
-            }
-          }
-          WaveSync();
-        }
-      }
       if (a.row_index != nullptr) {
         // the (unique rows, index) form: the chunk's rows as they are, once
         const int64_t row0 = (out1 + (int64_t)s0) * (int64_t)c2;

@@ -580,7 +580,6 @@ thread_local int g_fp_coop = 0;       // key 54: ... a block's keys fetched by t
                                       // staged in LDS (1); 0 = three 16-byte loads per lane and line (round 5's pattern)
 thread_local int g_fp_lite2 = 0;      // key 57: ... hop 2 asks for two key chunks per draw and for the third only at
                                       // the ends of its block (1); 0 = all three
-thread_local int g_fp_oct = 0;        // key 58: ... hop 2 fetches a draw's block WHOLE with eight lanes (one request per line)
 thread_local int g_fp_wps = 5;        // key 55: ... its register budget, waves per SIMD (4 .. 8)
 thread_local int g_fl_wb = 1;         // key 45: the lean kernel draws through the weight-bucket index (wb_index.h:
                                       // one line per draw); 0 = the pivot-level search of rounds 2-3
@@ -1573,8 +1572,7 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
             int64_t pwaves = g_fl_grid_cap > 0 ? g_fl_grid_cap : 0;
             if (pwaves > 0 && pblocks > (pwaves + pwpb - 1) / pwpb) pblocks = (pwaves + pwpb - 1) / pwpb;
             void (*pk)(const FanoutPlainArgs) = nullptr;
-#define EG_FP(W) (coop ? SampleFanoutPlainKernel<W, true, false> : g_fp_oct != 0 ? SampleFanoutPlainKernel<W, false, false, true> \
-                       : g_fp_lite2 != 0 ? SampleFanoutPlainKernel<W, false, true> \
+#define EG_FP(W) (coop ? SampleFanoutPlainKernel<W, true, false> : g_fp_lite2 != 0 ? SampleFanoutPlainKernel<W, false, true> \
                        : SampleFanoutPlainKernel<W, false, false>)
             pk = g_fp_wps >= 8 ? EG_FP(8) : g_fp_wps == 7 ? EG_FP(7) : g_fp_wps == 6 ? EG_FP(6)
                  : g_fp_wps == 5 ? EG_FP(5) : EG_FP(4);
@@ -1859,7 +1857,6 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 53 && value >= 0 && value <= 2) { g_fp_on = value; return EULER_GPU_OK; }
   if (key == 54 && (value == 0 || value == 1)) { g_fp_coop = value; return EULER_GPU_OK; }
   if (key == 57 && (value == 0 || value == 1)) { g_fp_lite2 = value; return EULER_GPU_OK; }
-  if (key == 58 && (value == 0 || value == 1)) { g_fp_oct = value; return EULER_GPU_OK; }
   if (key == 55 && value >= 4 && value <= 8) { g_fp_wps = value; return EULER_GPU_OK; }
   if (key == 56 && value >= 0) { g_blk_fail_next.store(value); return EULER_GPU_OK; }
   return Fail(EULER_GPU_EINVAL, "set_tuning: unknown key");
