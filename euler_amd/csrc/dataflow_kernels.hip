@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <atomic>
 #include <vector>
 
 #include "common.h"
@@ -34,6 +35,8 @@
 #include "k1_search.h"
 
 namespace euler_gpu {
+
+std::atomic<int> g_flow_fused{1};     // tuning key 60: Sage flows: sampler + insert in one kernel, tables cleared by the kernels before (0 = op by op)
 
 namespace {
 
@@ -59,6 +62,8 @@ struct FlowHop {
   int32_t self_loops;
   int64_t cap_m;              // cap_n * (count + 1): worst-case length of V
   FlowTable t;                // ids without a graph row (unknown ids, the default fill)
+  FlowTable t_next;           // not null keys: the NEXT hop's table, cleared by this hop's emit kernel
+  int32_t count_next;         // ... for a layer of cnt_out nodes: cnt_out * (count_next + 1) positions
   // ids WITH a row: a table indexed by row (common.h: FlowTableDense) - one atomicMin of
   // {~epoch, position} claims the row for this hop and keeps the smallest position; no
   // probing, nothing to clear
@@ -69,6 +74,7 @@ struct FlowHop {
   uint32_t* slot_of;          // [cap_m]: the row, or 0x80000000 | hash slot
   uint32_t* blk_cnt;          // [n_blk + 1] first occurrences per chunk of kFlowChunk positions
   unsigned long long* first_bits;   // [cap_m / 64 + 17] is-first-occurrence, one bit per position of V
+  uint32_t* word_pre;         // [cap_m / 64 + 17] first occurrences of the chunk before the word (behind first_bits)
   int64_t n_blk;              // ceil(cap_m / kFlowChunk)
   // several minibatches per launch (euler_gpu_sage_blocks_multi): minibatch b = blockIdx.y has
   // its own copy of every array, b strides further (FlowOf); 1 = the single flow
@@ -98,6 +104,7 @@ __device__ __forceinline__ FlowHop FlowOf(const FlowHop& h0, uint32_t b) {
     h.t.rank += (int64_t)b * h0.mb_tab;   h.slot_of += (int64_t)b * h0.mb_m;
     h.blk_cnt += (int64_t)b * h0.mb_blk;
     h.first_bits = reinterpret_cast<unsigned long long*>(h.blk_cnt + ((h0.n_blk + 2) & ~(int64_t)1));
+    h.word_pre = reinterpret_cast<uint32_t*>(h.first_bits + (h0.cap_m / 64 + 18));
     h.new_n_id += (int64_t)b * h0.mb_m;   h.inv += (int64_t)b * h0.mb_m;
     h.edge_src += (int64_t)b * h0.mb_m;   h.res_n_id += (int64_t)b * h0.mb_nid;
   }
@@ -109,36 +116,37 @@ __device__ __forceinline__ FlowHop FlowOf(const FlowHop& h0, uint32_t b) {
 // from the device-side length - a power of two >= 2 m slots - so clearing and probing touch
 // megabytes that stay in the L2 instead of the 200 MB a worst-case table takes
 // (profiles/r4_sage_blocks_kernel_stats.csv: 87 us of fills + an insert that missed the L2).
-__device__ __forceinline__ uint64_t FlowMask(const FlowHop& h, int64_t m) {
+__device__ __forceinline__ uint64_t FlowMaskOf(uint64_t table_mask, int64_t m) {
   uint64_t cap = 64;
-  while (cap < (uint64_t)m * 2 && cap <= h.t.mask) cap <<= 1;
-  return (cap > h.t.mask + 1 ? h.t.mask + 1 : cap) - 1;
+  while (cap < (uint64_t)m * 2 && cap <= table_mask) cap <<= 1;
+  return (cap > table_mask + 1 ? table_mask + 1 : cap) - 1;
+}
+__device__ __forceinline__ uint64_t FlowMask(const FlowHop& h, int64_t m) { return FlowMaskOf(h.t.mask, m); }
+
+// the part of table t a hop of m positions uses, emptied by the whole grid
+__device__ __forceinline__ void FlowClearTable(const FlowTable& t, int64_t m) {
+  const int64_t slots = (int64_t)FlowMaskOf(t.mask, m) + 1;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (first == 0) {                    // the side slot of the all-ones id
+    t.keys[t.mask + 1] = kFlowEmptyKey;
+    t.minpos[t.mask + 1] = 0xFFFFFFFFu;
+  }
+  for (int64_t i = first; i < slots; i += stride) {
+    t.keys[i] = kFlowEmptyKey;
+    t.minpos[i] = 0xFFFFFFFFu;
+  }
 }
 
 __global__ __launch_bounds__(256) void FlowClearKernel(const FlowHop h0) {
   const FlowHop h = FlowOf(h0, blockIdx.y);
   const int64_t cnt = (int64_t)(*h.cnt);
   const int64_t m = FlowNbLen(h, cnt) + cnt;
-  const int64_t slots = (int64_t)FlowMask(h, m) + 1;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (first == 0) {                    // the side slot of the all-ones id
-    h.t.keys[h.t.mask + 1] = kFlowEmptyKey;
-    h.t.minpos[h.t.mask + 1] = 0xFFFFFFFFu;
-  }
-  for (int64_t i = first; i < slots; i += stride) {
-    h.t.keys[i] = kFlowEmptyKey;
-    h.t.minpos[i] = 0xFFFFFFFFu;
-  }
+  FlowClearTable(h.t, m);
 }
 
 constexpr uint32_t kFlowHashed = 0x80000000u;
 
-// smallest position recorded for the element of slot word `sw`
-__device__ __forceinline__ bool FlowIsFirst(const FlowHop& h, uint32_t sw, int64_t i) {
-  if (sw & kFlowHashed) return h.t.minpos[sw & ~kFlowHashed] == (uint32_t)i;
-  return h.dense_min[sw] == (h.epoch_hi | (unsigned long long)(uint32_t)i);
-}
 
 // Ids with a graph row (all of them, normally) are first reduced INSIDE the workgroup: a chunk
 // of kFlowChunk positions goes through an LDS table {row, smallest position}, and only the
@@ -268,107 +276,188 @@ __global__ __launch_bounds__(kFlowInsertThreads) void FlowInsertKernel(const Flo
 }
 
 // first occurrences per chunk of kFlowChunk positions (workgroup b = chunk b; chunks past
-// the valid prefix count zero) - the ranks are then a scan over n_blk numbers instead of
-// one over the worst-case length of V
+// the valid prefix count zero): one bit per position, per 64-position word the chunk's first
+// occurrences BEFORE the word, per chunk their number - the rank of a first occurrence at
+// position f is then (chunks before f's) + word_pre[f / 64] + (bits of its word below f): three
+// small arrays that stay in the L2, no table of ranks
 __global__ __launch_bounds__(256) void FlowFlagKernel(const FlowHop h0) {
   const FlowHop h = FlowOf(h0, blockIdx.y);
-  __shared__ uint32_t s_cnt[4];
+  __shared__ uint32_t s_pc[kFlowChunk / 64];
   const int64_t cnt = (int64_t)(*h.cnt);
   const int64_t m = FlowNbLen(h, cnt) + cnt;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   for (int64_t b = blockIdx.x; b <= h.n_blk; b += gridDim.x) {
-    uint32_t mine = 0;
     const int64_t base = b * kFlowChunk;
-    if (base < m && b < h.n_blk) {
+    const bool live = base < m && b < h.n_blk;
+    if (live) {
+      // the chunk's 4 positions of this lane: every load of a kind in flight together
+      uint32_t sw[kFlowChunk / 256];
+      bool first[kFlowChunk / 256];
 #pragma unroll
       for (int x = 0; x < kFlowChunk / 256; ++x) {
         const int64_t i = base + x * 256 + threadIdx.x;
-        const bool first = i < m && FlowIsFirst(h, h.slot_of[i], i);
-        const unsigned long long bal = __ballot(first);
-        if (lane == 0) h.first_bits[i >> 6] = bal;       // (lane 0: i is a multiple of 64)
-        mine += (uint32_t)__popcll(bal);
+        sw[x] = i < m ? h.slot_of[i] : 0u;
+      }
+#pragma unroll
+      for (int x = 0; x < kFlowChunk / 256; ++x) {
+        const int64_t i = base + x * 256 + threadIdx.x;
+        first[x] = false;
+        if (i < m) {
+          // the element's first position takes the slot word's place: the emit kernel reads it
+          // in position order instead of going back to the tables
+          const uint32_t f = (sw[x] & kFlowHashed) ? h.t.minpos[sw[x] & ~kFlowHashed] : (uint32_t)h.dense_min[sw[x]];
+          h.slot_of[i] = f;
+          first[x] = f == (uint32_t)i;
+        }
+      }
+#pragma unroll
+      for (int x = 0; x < kFlowChunk / 256; ++x) {
+        const int64_t i = base + x * 256 + threadIdx.x;
+        const unsigned long long bal = __ballot(first[x]);
+        if (lane == 0) {                                  // (lane 0: i is a multiple of 64)
+          h.first_bits[i >> 6] = bal;
+          s_pc[x * 4 + wv] = (uint32_t)__popcll(bal);
+        }
       }
     }
-    if (lane == 0) s_cnt[wv] = mine;
     __syncthreads();
-    if (threadIdx.x == 0) h.blk_cnt[b] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-    __syncthreads();
-  }
-}
-
-// Sum of the first `upto` chunk counts, by the whole workgroup (a few hundred numbers for a
-// minibatch, n_blk at worst): every chunk's workgroup finds its own offset this way, which
-// costs less than the launch of a scan kernel between the flag and the emit kernel did
-// (4.7 us + the gap, twice per minibatch).
-__device__ __forceinline__ uint32_t FlowPrefix(const FlowHop& h, int64_t upto, uint32_t* s_red) {
-  uint32_t v = 0;
-  for (int64_t x = threadIdx.x; x < upto; x += 256) v += h.blk_cnt[x];
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-  __syncthreads();                                   // s_red may still be read from the last call
-  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return s_red[0] + s_red[1] + s_red[2] + s_red[3];
-}
-
-__global__ __launch_bounds__(256) void FlowEmitKernel(const FlowHop h0) {
-  const FlowHop h = FlowOf(h0, blockIdx.y);
-  __shared__ uint32_t s_cnt[4];
-  const int64_t cnt = (int64_t)(*h.cnt);
-  const int64_t m_nb = FlowNbLen(h, cnt), m = m_nb + cnt;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-  __shared__ uint32_t s_red[4];
-  if (blockIdx.x == 0) {                               // the new layer's size: all the chunks of V
-    const uint32_t total = FlowPrefix(h, (m + kFlowChunk - 1) / kFlowChunk, s_red);
-    if (threadIdx.x == 0) *h.cnt_out = total;
-  }
-  for (int64_t b = blockIdx.x; b < h.n_blk; b += gridDim.x) {
-    const int64_t base = b * kFlowChunk;
-    if (base >= m) break;                              // block-uniform
-    uint32_t run = FlowPrefix(h, b, s_red);
-    for (int x = 0; x < kFlowChunk / 256; ++x) {
-      const int64_t i = base + x * 256 + threadIdx.x;
-      // the flag kernel left its ballots: no second look at the tables
-      const int64_t w0 = base + x * 256 + wv * 64;
-      const uint64_t bal = w0 < m ? h.first_bits[w0 >> 6] : 0ull;
-      const bool first = ((bal >> lane) & 1ull) != 0ull;
-      const uint32_t slot = first ? h.slot_of[i] : 0u;
-      if (lane == 0) s_cnt[wv] = (uint32_t)__popcll(bal);
-      __syncthreads();
+    if (threadIdx.x < kFlowChunk / 64) {
       uint32_t before = 0, all = 0;
+      if (live) {
 #pragma unroll
-      for (int y = 0; y < 4; ++y) { if (y < wv) before += s_cnt[y]; all += s_cnt[y]; }
-      if (first) {
-        const uint32_t r = run + before + (uint32_t)__popcll(bal & lt);
-        h.new_n_id[r] = FlowElem(h, i, m_nb);
-        if (slot & kFlowHashed) h.t.rank[slot & ~kFlowHashed] = (int32_t)r;
-        else h.dense_rank[slot] = r;
+        for (int y = 0; y < kFlowChunk / 64; ++y) {
+          const uint32_t v = s_pc[y];
+          if (y < (int)threadIdx.x) before += v;
+          all += v;
+        }
+        h.word_pre[(base >> 6) + threadIdx.x] = before;
       }
-      run += all;
-      __syncthreads();
+      if (threadIdx.x == 0) h.blk_cnt[b] = all;
+    }
+    __syncthreads();
+  }
+}
+
+// Exclusive sums of the valid chunk counts, in place, + the new layer's size - flows whose chunk
+// counts do not fit the emit kernel's LDS (more than kFlowLdsChunks chunks of V).  One workgroup.
+constexpr int kFlowLdsChunks = 8192;
+__global__ __launch_bounds__(1024) void FlowScanKernel(const FlowHop h0) {
+  const FlowHop h = FlowOf(h0, blockIdx.y);
+  __shared__ uint32_t s_part[1024];
+  const int64_t cnt = (int64_t)(*h.cnt);
+  const int64_t m = FlowNbLen(h, cnt) + cnt;
+  const int64_t nc = (m + kFlowChunk - 1) / kFlowChunk;
+  const int64_t per = (nc + 1023) / 1024;
+  const int64_t lo = (int64_t)threadIdx.x * per, hi = lo + per < nc ? lo + per : nc;
+  uint32_t sum = 0;
+  for (int64_t x = lo; x < hi; ++x) sum += h.blk_cnt[x];
+  s_part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t acc = 0;
+    for (int x = 0; x < 1024; ++x) { const uint32_t v = s_part[x]; s_part[x] = acc; acc += v; }
+    *h.cnt_out = acc;
+  }
+  __syncthreads();
+  uint32_t run = s_part[threadIdx.x];
+  for (int64_t x = lo; x < hi; ++x) { const uint32_t v = h.blk_cnt[x]; h.blk_cnt[x] = run; run += v; }
+}
+
+// The new layer and the block's index arrays in one pass over V: position i reads its element's
+// first position f (the table entry the flag kernel has just read), f's rank from the three
+// small arrays, and writes inv / edge_src / res_n_id; i == f also writes new_n_id[rank].
+// SCANNED = false: every workgroup sums the chunk counts into LDS itself (<= kFlowLdsChunks);
+// true: FlowScanKernel has left the exclusive sums in blk_cnt.
+template <bool SCANNED>
+__global__ __launch_bounds__(256) void FlowEmitIndexKernel(const FlowHop h0) {
+  const FlowHop h = FlowOf(h0, blockIdx.y);
+  __shared__ uint32_t s_pre[SCANNED ? 1 : kFlowLdsChunks];
+  __shared__ uint32_t s_part[256];
+  __shared__ uint32_t s_total;
+  const int64_t cnt = (int64_t)(*h.cnt);
+  const int64_t m_nb = FlowNbLen(h, cnt), m = m_nb + cnt;
+  if (!SCANNED) {
+    const int64_t nc = (m + kFlowChunk - 1) / kFlowChunk;       // <= kFlowLdsChunks (the launcher's choice)
+    const int64_t per = (nc + 255) / 256;
+    const int64_t lo = (int64_t)threadIdx.x * per, hi = lo + per < nc ? lo + per : nc;
+    uint32_t sum = 0;
+    for (int64_t x = lo; x < hi; ++x) { const uint32_t v = h.blk_cnt[x]; s_pre[x] = v; sum += v; }
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      // exclusive scan of the 256 partial sums by one wave: 4 per lane
+      uint32_t v0 = s_part[4 * threadIdx.x], v1 = s_part[4 * threadIdx.x + 1], v2 = s_part[4 * threadIdx.x + 2],
+               v3 = s_part[4 * threadIdx.x + 3];
+      uint32_t tot = v0 + v1 + v2 + v3, inc = tot;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(inc, off);
+        if ((int)threadIdx.x >= off) inc += o;
+      }
+      const uint32_t ex = inc - tot;
+      s_part[4 * threadIdx.x] = ex; s_part[4 * threadIdx.x + 1] = ex + v0;
+      s_part[4 * threadIdx.x + 2] = ex + v0 + v1; s_part[4 * threadIdx.x + 3] = ex + v0 + v1 + v2;
+      if (threadIdx.x == 63) { s_total = inc; if (blockIdx.x == 0) *h.cnt_out = inc; }
+    }
+    __syncthreads();
+    uint32_t run = s_part[threadIdx.x];
+    for (int64_t x = lo; x < hi; ++x) { const uint32_t v = s_pre[x]; s_pre[x] = run; run += v; }
+    __syncthreads();
+  }
+  if (h.t_next.keys != nullptr)        // the next hop's table, for the layer this hop has just sized
+    FlowClearTable(h.t_next, (int64_t)(SCANNED ? *h.cnt_out : s_total) * ((int64_t)h.count_next + 1));
+  const uint32_t* pre = SCANNED ? h.blk_cnt : s_pre;
+  constexpr int kU = 4;
+  const int64_t stride = (int64_t)gridDim.x * 256 * kU;
+  for (int64_t i0 = (int64_t)blockIdx.x * 256 * kU + threadIdx.x; i0 < m; i0 += stride) {
+    uint32_t fp[kU], wp[kU];
+    unsigned long long bits[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int64_t i = i0 + (int64_t)u * 256;
+      fp[u] = i < m ? h.slot_of[i] : 0u;           // (the flag kernel left the first position there)
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int64_t i = i0 + (int64_t)u * 256;
+      bits[u] = 0ull; wp[u] = 0u;
+      if (i < m) { bits[u] = h.first_bits[fp[u] >> 6]; wp[u] = h.word_pre[fp[u] >> 6]; }
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int64_t i = i0 + (int64_t)u * 256;
+      if (i >= m) continue;
+      const uint32_t f = fp[u];
+      const uint32_t below = (uint32_t)__popcll(bits[u] & ((1ull << (f & 63u)) - 1ull));
+      const int64_t dst = (int64_t)(pre[f / kFlowChunk] + wp[u] + below);
+      if ((uint32_t)i == f) h.new_n_id[dst] = FlowElem(h, i, m_nb);
+      if (i < m_nb) {
+        h.inv[i] = dst;
+        h.edge_src[i] = h.nb_src != nullptr ? (int64_t)h.nb_src[i] : i / h.count;
+      } else {
+        h.res_n_id[i - m_nb] = dst;
+        if (h.self_loops) {
+          h.inv[i] = dst;
+          h.edge_src[i] = i - m_nb;        // last_idx = arange: node j keeps an edge to itself
+        }
+      }
     }
   }
 }
 
-__global__ __launch_bounds__(256) void FlowIndexKernel(const FlowHop h0) {
-  const FlowHop h = FlowOf(h0, blockIdx.y);
-  const int64_t cnt = (int64_t)(*h.cnt);
-  const int64_t m_nb = FlowNbLen(h, cnt), m = m_nb + cnt;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
-    const uint32_t sw = h.slot_of[i];
-    const int64_t dst = (sw & kFlowHashed) ? (int64_t)h.t.rank[sw & ~kFlowHashed] : (int64_t)h.dense_rank[sw];
-    if (i < m_nb) {
-      h.inv[i] = dst;
-      h.edge_src[i] = h.nb_src != nullptr ? (int64_t)h.nb_src[i] : i / h.count;
-    } else {
-      h.res_n_id[i - m_nb] = dst;
-      if (h.self_loops) {
-        h.inv[i] = dst;
-        h.edge_src[i] = i - m_nb;        // last_idx = arange: node j keeps an edge to itself
-      }
-    }
+// flag -> [scan ->] emit + index for one hop (f.n_blk = chunks of the worst case)
+void LaunchFlowRanks(const FlowHop& f, dim3 grid_b, int64_t work, int per_mb_cap, hipStream_t st) {
+  hipLaunchKernelGGL(FlowFlagKernel, grid_b, dim3(256), 0, st, f);
+  int64_t gx = (work + 256 * 4 - 1) / (256 * 4);
+  const int64_t cap = per_mb_cap > 0 ? per_mb_cap : 1024;       // every workgroup pays the prologue once
+  if (gx > cap) gx = cap;
+  if (gx < 1) gx = 1;
+  const dim3 grid((unsigned)gx, grid_b.y);
+  if (f.n_blk <= kFlowLdsChunks) {
+    hipLaunchKernelGGL(FlowEmitIndexKernel<false>, grid, dim3(256), 0, st, f);
+  } else {
+    hipLaunchKernelGGL(FlowScanKernel, dim3(1, grid_b.y), dim3(1024), 0, st, f);
+    hipLaunchKernelGGL(FlowEmitIndexKernel<true>, grid, dim3(256), 0, st, f);
   }
 }
 
@@ -464,6 +553,12 @@ __global__ __launch_bounds__(256) void FlowFullFillKernel(const FlowFull f) {
 
 __global__ void FlowInitKernel(uint32_t* counts, uint32_t n) { counts[0] = n; }
 
+// ... and the first hop's table emptied (its length is known to the host)
+__global__ __launch_bounds__(256) void FlowInitClearKernel(uint32_t* counts, uint32_t n, const FlowTable t, int64_t m0) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) counts[0] = n;
+  FlowClearTable(t, m0);
+}
+
 // counts of minibatch b at counts + b * stride
 __global__ void FlowInitMultiKernel(uint32_t* counts, uint32_t n, int32_t n_mb, int32_t stride) {
   for (int32_t b = threadIdx.x; b < n_mb; b += blockDim.x) counts[(int64_t)b * stride] = n;
@@ -507,6 +602,88 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void FlowSampleKernel(const Flo
       BlockPivotSample(s.g, sg, u, &id, &w);
     }
     nb[i] = id;
+  }
+}
+
+// The hop's sampler and the insert of what it draws in ONE kernel (single flows with the
+// row-indexed table; one listed edge type on a monotone graph - FlowSampleKernel's draw): a lane
+// draws ONE sample (or takes one node of the previous layer: V = [nb | n_id]), the workgroup's 256
+// ids are reduced by row in LDS, the distinct rows claim {~epoch, smallest position} in the table.
+// The atomics of a workgroup leave while the others still wait for their samples' cold lines: the
+// insert's 42 us (653 K positions, 16 384 roots) hide behind the sampler's 22 instead of following
+// them, and the neighbour list is not read back.
+struct FlowSI {
+  FlowHop h;
+  uint64_t seed;
+  uint32_t call_id;
+  int32_t type;
+  int64_t default_node;
+};
+template <int kThreads>
+__global__ __launch_bounds__(kThreads) void FlowSampleInsertKernel(const FlowSI a) {
+  constexpr int kFlowSiLds = 2 * kThreads;
+  const FlowHop& h = a.h;
+  __shared__ uint32_t s_row[kFlowSiLds];
+  __shared__ uint32_t s_pos[kFlowSiLds];
+  const int64_t cnt = (int64_t)(*h.cnt);
+  const int64_t m_nb = cnt * h.count, m = m_nb + cnt;
+  const uint64_t mask = FlowMask(h, m);
+  for (int64_t base = (int64_t)blockIdx.x * kThreads; base < m; base += (int64_t)gridDim.x * kThreads) {
+    for (int x = threadIdx.x; x < kFlowSiLds; x += kThreads) { s_row[x] = 0xFFFFFFFFu; s_pos[x] = 0xFFFFFFFFu; }
+    __syncthreads();
+    const int64_t i = base + threadIdx.x;
+    if (i < m) {
+      uint64_t id;
+      if (i < m_nb) {
+        const int64_t r = i / h.count;
+        const int32_t j = (int32_t)(i - r * h.count);
+        const uint64_t node = h.n_id[r];
+        id = (uint64_t)a.default_node;
+        Segment sg;
+        if (LoadSegment<true>(h.g, FindRow(h.g, node), a.type, &sg)) {
+          const Philox4 blk = RngBlock(a.seed, a.call_id, kDomainNeighbor, node, ((uint32_t)j) >> 1);
+          const double u = (j & 1) ? UnitFromWords(blk.w[2], blk.w[3]) : UnitFromWords(blk.w[0], blk.w[1]);
+          float w;
+          BlockPivotSample(h.g, sg, u, &id, &w);
+        }
+        const_cast<uint64_t*>(h.nb)[i] = id;
+      } else {
+        id = h.n_id[i - m_nb];
+      }
+      const int64_t row = FindRow(h.g, id);
+      if (row >= 0) {
+        h.slot_of[i] = (uint32_t)row;
+        uint32_t sl = (uint32_t)(Mix64((uint64_t)row) & (uint64_t)(kFlowSiLds - 1));
+        for (;;) {
+          const uint32_t old = atomicCAS(&s_row[sl], 0xFFFFFFFFu, (uint32_t)row);
+          if (old == 0xFFFFFFFFu || old == (uint32_t)row) break;
+          sl = (sl + 1) & (uint32_t)(kFlowSiLds - 1);
+        }
+        atomicMin(&s_pos[sl], (uint32_t)i);
+      } else {
+        uint64_t sl;
+        if (id == kFlowEmptyKey) {
+          sl = h.t.mask + 1;
+        } else {
+          sl = Mix64(id) & mask;
+          for (;;) {
+            const unsigned long long old =
+                atomicCAS(&h.t.keys[sl], (unsigned long long)kFlowEmptyKey, (unsigned long long)id);
+            if (old == kFlowEmptyKey || old == id) break;
+            sl = (sl + 1) & mask;
+          }
+        }
+        atomicMin(&h.t.minpos[sl], (uint32_t)i);
+        h.slot_of[i] = kFlowHashed | (uint32_t)sl;
+      }
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x < kFlowSiLds; x += kThreads) {
+      const uint32_t row = s_row[x];
+      if (row == 0xFFFFFFFFu) continue;
+      atomicMin(&h.dense_min[row], h.epoch_hi | (unsigned long long)s_pos[x]);
+    }
+    __syncthreads();
   }
 }
 
@@ -562,7 +739,15 @@ static int64_t FlowCap(int64_t n, const int32_t* fanouts, int32_t h) {
   return c;
 }
 
-size_t euler_gpu_sage_blocks_workspace(int64_t n, const int32_t* fanouts_host, int32_t layers) {
+// region A: the arrays of one hop (the largest hop's: they are reused hop after hop); behind it
+// one hash table per hop - hop h's emit kernel clears hop h + 1's table while hop h's arrays are
+// still in use, so the tables cannot share region A (round 6)
+static size_t SageTableBytes(int64_t cap_m) {
+  uint64_t tcap = 64;
+  while (tcap < (uint64_t)cap_m * 2) tcap <<= 1;
+  return Al((tcap + 1) * 8) + Al((tcap + 1) * 4);
+}
+static size_t SageRegionA(int64_t n, const int32_t* fanouts_host, int32_t layers) {
   size_t best = 0;
   for (int32_t h = 0; h < layers; ++h) {
     const int64_t cap_n = FlowCap(n, fanouts_host, h);
@@ -574,13 +759,20 @@ size_t euler_gpu_sage_blocks_workspace(int64_t n, const int32_t* fanouts_host, i
                                            (uint32_t*)nullptr, (int)(cap_m + 1), nullptr);
     const size_t b = Al((size_t)cap_n * fanouts_host[h] * 8)      // nb ids
                      + Al((size_t)cap_n * fanouts_host[h] * 4) * 2   // weights, types (unused outputs)
-                     + Al((tcap + 1) * 8) + Al((tcap + 1) * 4) * 2  // table
+                     + Al((tcap + 1) * 8) + Al((tcap + 1) * 4) * 2  // table (the op-by-op path's)
                      + Al((size_t)cap_m * 4)                        // slot_of
-                     + Al(((size_t)cap_m + 1) * 4) * 2              // is_first, rank
+                     + Al(((size_t)cap_m + 1) * 4) * 2              // chunk counts, first-occurrence bits, word sums
                      + Al(scan_bytes) + 256;
     if (b > best) best = b;
   }
-  return best + 256;
+  return Al(best + 256);
+}
+
+size_t euler_gpu_sage_blocks_workspace(int64_t n, const int32_t* fanouts_host, int32_t layers) {
+  size_t total = SageRegionA(n, fanouts_host, layers);
+  for (int32_t h = 0; h < layers; ++h)
+    total += SageTableBytes(FlowCap(n, fanouts_host, h) * ((int64_t)fanouts_host[h] + 1));
+  return total + 256;
 }
 
 int euler_gpu_sage_blocks(const euler_gpu_graph* g, void* stream, uint64_t seed, uint32_t call_id,
@@ -601,7 +793,6 @@ int euler_gpu_sage_blocks(const euler_gpu_graph* g, void* stream, uint64_t seed,
   if (FlowCap(n, fanouts_host, layers) > ((int64_t)1 << 29))
     return Fail(EULER_GPU_EINVAL, "sage_blocks: worst-case layer size > 2^29");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(FlowInitKernel, dim3(1), dim3(1), 0, st, counts_dev, (uint32_t)n);
   if (n == 0) {
     EG_HIP(hipMemsetAsync(counts_dev, 0, sizeof(uint32_t) * (layers + 1), st));
     return EULER_GPU_OK;
@@ -619,6 +810,39 @@ int euler_gpu_sage_blocks(const euler_gpu_graph* g, void* stream, uint64_t seed,
     const int rcd = FlowDenseTable(g, st, layers, &dense_min, &dense_rank, &epoch0);
     if (rcd != EULER_GPU_OK) return rcd;
   }
+  (void)dense_rank;
+  // One listed type per hop on a monotone graph with the row-indexed table: three launches per hop
+  // (sampler + insert, flag, emit + index) and the tables cleared by the kernels before them.
+  GraphView view = g->view;
+  bool fused = k == 1 && dense_min != nullptr && g_flow_fused != 0;
+  if (fused) {
+    if (SamplingView(g, &view) != EULER_GPU_OK) { (void)hipGetLastError(); fused = false; view = g->view; }
+  }
+  fused = fused && view.monotone != 0 && view.has_zero_nbr == 0 && HasBlockSearch(view);
+  for (int32_t h = 0; fused && h < layers; ++h) fused = edge_types_host[h] >= 0;
+  // the per-hop tables behind region A (fused flow)
+  FlowTable tabs[8];
+  {
+    uint8_t* tp = (uint8_t*)workspace_dev + SageRegionA(n, fanouts_host, layers);
+    for (int32_t h = 0; h < layers; ++h) {
+      const int64_t cm = FlowCap(n, fanouts_host, h) * ((int64_t)fanouts_host[h] + 1);
+      uint64_t tcap = 64;
+      while (tcap < (uint64_t)cm * 2) tcap <<= 1;
+      tabs[h].keys = (unsigned long long*)tp;
+      tabs[h].minpos = (uint32_t*)(tp + Al((tcap + 1) * 8));
+      tabs[h].rank = nullptr;
+      tabs[h].mask = tcap - 1;
+      tp += SageTableBytes(cm);
+    }
+  }
+  if (fused) {
+    const int64_t m0 = n * ((int64_t)fanouts_host[0] + 1);
+    int64_t gi = (2 * m0 + 64 + 255) / 256;
+    if (gi > 1024) gi = 1024;
+    hipLaunchKernelGGL(FlowInitClearKernel, dim3((unsigned)gi), dim3(256), 0, st, counts_dev, (uint32_t)n, tabs[0], m0);
+  } else {
+    hipLaunchKernelGGL(FlowInitKernel, dim3(1), dim3(1), 0, st, counts_dev, (uint32_t)n);
+  }
   for (int32_t h = 0; h < layers; ++h) {
     const int32_t count = fanouts_host[h];
     const int64_t cap_n = FlowCap(n, fanouts_host, h);
@@ -630,7 +854,7 @@ int euler_gpu_sage_blocks(const euler_gpu_graph* g, void* stream, uint64_t seed,
     float* nb_w = (float*)p;            p += Al((size_t)cap_n * count * 4);
     int32_t* nb_t = (int32_t*)p;        p += Al((size_t)cap_n * count * 4);
     FlowHop f{};
-    f.g = g->view; f.dense_min = dense_min; f.dense_rank = dense_rank;
+    f.g = view; f.dense_min = dense_min; f.dense_rank = nullptr;
     f.epoch_hi = (unsigned long long)(uint32_t)~(epoch0 + (uint32_t)h) << 32;
     f.t.keys = (unsigned long long*)p;  p += Al((tcap + 1) * 8);
     f.t.minpos = (uint32_t*)p;          p += Al((tcap + 1) * 4);
@@ -638,17 +862,12 @@ int euler_gpu_sage_blocks(const euler_gpu_graph* g, void* stream, uint64_t seed,
     f.t.mask = tcap - 1;
     f.slot_of = (uint32_t*)p;           p += Al((size_t)cap_m * 4);
     // (the workspace holds two arrays of cap_m + 1 words here: the chunk counts need far less,
-    // and the first-occurrence bits - cap_m / 64 + 17 double words - follow them in the first)
+    // and the first-occurrence bits - cap_m / 64 + 18 double words - and the words' sums follow them)
     f.blk_cnt = (uint32_t*)p;           p += Al(((size_t)cap_m + 1) * 4);
-    p += Al(((size_t)cap_m + 1) * 4);   // (was the counts' scan; the workspace formula keeps it)
+    p += Al(((size_t)cap_m + 1) * 4);
     f.n_blk = (cap_m + kFlowChunk - 1) / kFlowChunk;
     f.first_bits = (unsigned long long*)(f.blk_cnt + ((f.n_blk + 2) & ~(int64_t)1));   // same region
-    // 1. the hop's sampler over the first counts[h] nodes of the layer
-    int rc = LaunchSampleNeighborCounted(g, st, seed, call_id + (uint32_t)h, n_id, cap_n,
-                                         counts_dev + h, edge_types_host + (size_t)h * k, k, count,
-                                         default_node, nb, nb_w, nb_t);
-    if (rc != EULER_GPU_OK) return rc;
-    // 2. first-occurrence unique of [nb | n_id]
+    f.word_pre = (uint32_t*)(f.first_bits + (cap_m / 64 + 18));                          // same region
     f.nb = nb; f.n_id = n_id; f.cnt = counts_dev + h; f.cnt_out = counts_dev + h + 1;
     f.count = count; f.self_loops = add_self_loops ? 1 : 0; f.cap_m = cap_m;
     f.new_n_id = n_id_dev[h]; f.inv = edge_dst_dev[h]; f.edge_src = edge_src_dev[h];
@@ -656,13 +875,31 @@ int euler_gpu_sage_blocks(const euler_gpu_graph* g, void* stream, uint64_t seed,
     const int block = 256;
     const int grid = GridFor(cap_m + 1, block);
     const int grid_b = (int)(f.n_blk + 1 < 65536 ? f.n_blk + 1 : 65536);
-    hipLaunchKernelGGL(FlowClearKernel, dim3(grid), dim3(block), 0, st, f);
-    if (f.dense_min != nullptr) hipLaunchKernelGGL(FlowInsertKernel<false>, dim3(grid_b), dim3(kFlowInsertThreads), 0, st, f);
-    else hipLaunchKernelGGL(FlowInsertKernel<true>, dim3(grid_b), dim3(kFlowInsertThreads), 0, st, f);
-    hipLaunchKernelGGL(FlowFlagKernel, dim3(grid_b), dim3(block), 0, st, f);
-    hipLaunchKernelGGL(FlowEmitKernel, dim3(grid_b), dim3(block), 0, st, f);
-    // 3. res_n_id, edge_index
-    hipLaunchKernelGGL(FlowIndexKernel, dim3(grid), dim3(block), 0, st, f);
+    if (fused) {
+      // 1 + 2. the hop's sampler over the first counts[h] nodes of the layer and the insert of
+      // [nb | n_id] in one kernel; the table was cleared by the kernel before it
+      f.t = tabs[h];
+      if (h + 1 < layers) { f.t_next = tabs[h + 1]; f.count_next = fanouts_host[h + 1]; }
+      FlowSI si{};
+      si.h = f; si.seed = seed; si.call_id = call_id + (uint32_t)h; si.type = edge_types_host[(size_t)h * k];
+      si.default_node = default_node;
+      // (a workgroup of 256: 0.120 ms per 16 384-root flow against 0.122 / 0.130 with 512 / 1 024)
+      int64_t gs = (cap_m + 255) / 256;
+      if (gs > 16384) gs = 16384;
+      hipLaunchKernelGGL(FlowSampleInsertKernel<256>, dim3((unsigned)gs), dim3(256), 0, st, si);
+    } else {
+      // 1. the hop's sampler over the first counts[h] nodes of the layer
+      int rc = LaunchSampleNeighborCounted(g, st, seed, call_id + (uint32_t)h, n_id, cap_n,
+                                           counts_dev + h, edge_types_host + (size_t)h * k, k, count,
+                                           default_node, nb, nb_w, nb_t);
+      if (rc != EULER_GPU_OK) return rc;
+      // 2. first-occurrence unique of [nb | n_id]
+      hipLaunchKernelGGL(FlowClearKernel, dim3(grid), dim3(block), 0, st, f);
+      if (f.dense_min != nullptr) hipLaunchKernelGGL(FlowInsertKernel<false>, dim3(grid_b), dim3(kFlowInsertThreads), 0, st, f);
+      else hipLaunchKernelGGL(FlowInsertKernel<true>, dim3(grid_b), dim3(kFlowInsertThreads), 0, st, f);
+    }
+    // 3. ranks, the new layer, res_n_id, edge_index
+    LaunchFlowRanks(f, dim3(grid_b), cap_m, 0, st);
     EG_HIP(hipGetLastError());
     n_id = n_id_dev[h];
   }
@@ -683,7 +920,7 @@ static size_t MultiHopBytes(int32_t n_mb, int64_t cap_n, int32_t count, int64_t*
   uint64_t tcap = 64;
   while (tcap < (uint64_t)cap_m * 2) tcap <<= 1;
   const int64_t n_blk = (cap_m + kFlowChunk - 1) / kFlowChunk;
-  const int64_t R = ((n_blk + 2) & ~(int64_t)1) + 2 * (cap_m / 64 + 18);
+  const int64_t R = ((n_blk + 2) & ~(int64_t)1) + 3 * (cap_m / 64 + 18) + 1;
   if (r_words) *r_words = R;
   return Al((size_t)n_mb * cap_n * count * 8) + Al((size_t)n_mb * (tcap + 1) * 8) +
          Al((size_t)n_mb * (tcap + 1) * 4) * 2 + Al((size_t)n_mb * cap_m * 4) + Al((size_t)n_mb * R * 4);
@@ -771,6 +1008,7 @@ int euler_gpu_sage_blocks_multi(const euler_gpu_graph* g, void* stream, uint64_t
     f.blk_cnt = (uint32_t*)p;           p += Al((size_t)n_mb * R * 4);
     f.n_blk = (cap_m + kFlowChunk - 1) / kFlowChunk;
     f.first_bits = (unsigned long long*)(f.blk_cnt + ((f.n_blk + 2) & ~(int64_t)1));
+    f.word_pre = (uint32_t*)(f.first_bits + (cap_m / 64 + 18));
     f.n_mb = n_mb;
     f.mb_nb = cap_n * count; f.mb_nid = cap_n; f.mb_cnt = layers + 1; f.mb_tab = (int64_t)tcap + 1;
     f.mb_m = cap_m; f.mb_blk = R;
@@ -800,9 +1038,7 @@ int euler_gpu_sage_blocks_multi(const euler_gpu_graph* g, void* stream, uint64_t
     const dim3 grid((unsigned)gx, (unsigned)n_mb), grid_b((unsigned)gb, (unsigned)n_mb);
     hipLaunchKernelGGL(FlowClearKernel, grid, dim3(block), 0, st, f);
     hipLaunchKernelGGL(FlowInsertKernel<true>, grid_b, dim3(kFlowInsertThreads), 0, st, f);
-    hipLaunchKernelGGL(FlowFlagKernel, grid_b, dim3(block), 0, st, f);
-    hipLaunchKernelGGL(FlowEmitKernel, grid_b, dim3(block), 0, st, f);
-    hipLaunchKernelGGL(FlowIndexKernel, grid, dim3(block), 0, st, f);
+    LaunchFlowRanks(f, grid_b, cap_m, 4 * per_mb, st);
     EG_HIP(hipGetLastError());
     n_id = n_id_dev[h];
   }
@@ -906,6 +1142,7 @@ int euler_gpu_full_blocks(const euler_gpu_graph* g, void* stream, const uint64_t
     p += Al(((size_t)cap_m + 1) * 4);   // (was the counts' scan; the workspace formula keeps it)
     f.n_blk = (cap_m + kFlowChunk - 1) / kFlowChunk;
     f.first_bits = (unsigned long long*)(f.blk_cnt + ((f.n_blk + 2) & ~(int64_t)1));   // same region
+    f.word_pre = (uint32_t*)(f.first_bits + (cap_m / 64 + 18));                          // same region
     void* scan_tmp = p;
     size_t scan2 = 0;
     EG_HIP(hipcub::DeviceScan::ExclusiveScan(nullptr, scan2, ff.lens, ff.offs, SatAdd(), 0u, (int)(cap_n + 1), st));
@@ -927,9 +1164,7 @@ int euler_gpu_full_blocks(const euler_gpu_graph* g, void* stream, const uint64_t
     hipLaunchKernelGGL(FlowClearKernel, dim3(grid), dim3(block), 0, st, f);
     if (f.dense_min != nullptr) hipLaunchKernelGGL(FlowInsertKernel<false>, dim3(grid_b), dim3(kFlowInsertThreads), 0, st, f);
     else hipLaunchKernelGGL(FlowInsertKernel<true>, dim3(grid_b), dim3(kFlowInsertThreads), 0, st, f);
-    hipLaunchKernelGGL(FlowFlagKernel, dim3(grid_b), dim3(block), 0, st, f);
-    hipLaunchKernelGGL(FlowEmitKernel, dim3(grid_b), dim3(block), 0, st, f);
-    hipLaunchKernelGGL(FlowIndexKernel, dim3(grid), dim3(block), 0, st, f);
+    LaunchFlowRanks(f, dim3(grid_b), cap_m, 0, st);
     EG_HIP(hipGetLastError());
     n_id = n_id_dev[h];
   }

@@ -129,6 +129,9 @@ extern "C" {
  *        eighth (1); 0 [default] = all three at once.
  * key 56: test hook, PROCESS-WIDE: the next `value` builds of the EdgeBlocks fail the way an
  *        allocation failure would (the graph is then served without them: same results).
+ * key 60: PROCESS-WIDE: a Sage flow whose hops list one edge type runs as three launches per hop -
+ *        sampler + insert in one kernel, flag, emit + index, the hash tables cleared by the kernels
+ *        before them (1 [default]); 0 = sampler, clear, insert as separate launches.
  * All settings produce identical results; the knobs exist for A/B measurements
  * and tests.  They are THREAD-LOCAL: a call changes the launches the calling host
  * thread enqueues afterwards and nobody else's (new threads start from the

@@ -1193,6 +1193,66 @@ def test_sage_dataflow_blocks(EA, O, torch_cuda, big_pair):
     assert [b.size for b in df] == [w[3] for w in want][::-1]
 
 
+def test_sage_blocks_fused_flow(EA, O, torch_cuda, big_pair):
+    """Round 6: a Sage flow whose hops list ONE edge type runs as three launches per hop (sampler +
+    insert in one kernel, flag, emit + index; the hash tables cleared by the kernels before them;
+    tuning key 60) - the blocks must equal the oracle composition and the op-by-op flow's (key 60
+    = 0): hashed ids, unknown roots, duplicate roots, default fills (ids without a row go through
+    the hash table), self loops on and off, a plain graph at a size where chunks and tables span
+    many workgroups."""
+    torch = torch_cuda
+    from euler_amd import _lib
+    L = _lib.lib()
+    G, OG, ids, rng = big_pair
+
+    def uniq(a):
+        uq, gi = O.id_unique(a.astype(np.uint64))
+        return uq.astype(np.int64), gi.astype(np.int64)
+
+    try:
+        roots = np.concatenate([rng.choice(ids, 300), [0, 10 ** 13 + 5], rng.choice(ids, 20)]).astype(np.int64)
+        roots[5] = roots[6]
+        fanouts, metapath, max_id = [5, 4], [[0], [2]], 10 ** 13
+        for fused in (1, 0):
+            _lib.check(L.euler_gpu_set_tuning(60, fused))
+            for loops in (True, False):
+                G.set_seed(79, call_id=700)
+                df = EA.dataflow.SageDataFlow(G, fanouts, metapath, add_self_loops=loops, max_id=max_id)(
+                    torch.as_tensor(roots).cuda())
+                n_id = roots.copy()
+                last_idx = np.arange(len(n_id))
+                want = []
+                for h, (et, c) in enumerate(zip(metapath, fanouts)):
+                    nb, _, _ = OG.sample_neighbor(79, 700 + h, n_id, et, c, max_id + 1)
+                    new_n_id, inv = uniq(np.concatenate([nb.reshape(-1), n_id]))
+                    src = np.repeat(np.arange(len(n_id)), c)
+                    res = inv[-len(n_id):]
+                    e = np.stack([np.concatenate([src, last_idx]), inv]) if loops else np.stack([src, inv[:len(src)]])
+                    last_idx = np.arange(len(new_n_id))
+                    want.append((new_n_id, res, e))
+                    n_id = new_n_id
+                for blk, (wn, wr, we) in zip(df.blocks, want):
+                    assert np.array_equal(t2n(blk.n_id), wn), (fused, loops)
+                    assert np.array_equal(t2n(blk.res_n_id), wr), (fused, loops)
+                    assert np.array_equal(t2n(blk.edge_index), we), (fused, loops)
+        # a plain weighted graph, 20 000 roots x [25, 10]: fused == op by op, every array
+        p = EA.synth_params(4242, 300000, 3000000, n_types=1, weighted=True)
+        Gs = EA.Graph.synthetic(p)
+        r = torch.as_tensor(np.concatenate([np.random.default_rng(4).integers(1, 300001, 20000), [0, 300001, 7, 7]])).cuda()
+        outs = []
+        for fused in (1, 0, 1):
+            _lib.check(L.euler_gpu_set_tuning(60, fused))
+            Gs.set_seed(5, call_id=40)
+            df = EA.dataflow.SageDataFlow(Gs, [25, 10], [[0], [0]], add_self_loops=True, max_id=300000)(r)
+            outs.append([(t2n(b.n_id), t2n(b.res_n_id), t2n(b.edge_index)) for b in df.blocks])
+        for a, b in ((outs[0], outs[1]), (outs[0], outs[2])):
+            for x, y in zip(a, b):
+                assert all(np.array_equal(u, v) for u, v in zip(x, y))
+        assert max(len(x[0]) for x in outs[0]) > 50000
+    finally:
+        L.euler_gpu_set_tuning(60, 1)
+
+
 def test_sage_blocks_two_host_threads_one_stream(EA, torch_cuda):
     """Two host threads building blocks on the SAME stream (the null stream; ctypes releases the
     GIL inside the C call): the stream's row-indexed first-occurrence table is shared, so a call's
@@ -1434,6 +1494,12 @@ def test_dedup_split_pack_expand(EA, O, torch_cuda):
         assert np.array_equal(t2n(s_m), t2n(r_m)[pos_n])
         assert np.array_equal(t2n(s_t), np.where(t2n(r_m)[pos_n][:, None] != 0, -1, 3)
                               * np.ones((1, cnt1), np.int32))
+        # an odd number of positions, a handful of positions
+        for cut in (1, 199_997):
+            po = pos[:len(pos_n) - cut].contiguous()
+            o_id2, o_w2, o_t2, o_m2 = EA.ops.expand_packed(po, packed1, cnt1, single_type=3)
+            assert np.array_equal(t2n(o_id2), t2n(s_id)[:len(pos_n) - cut]) and np.array_equal(t2n(o_w2), t2n(s_w)[:len(pos_n) - cut])
+            assert np.array_equal(t2n(o_t2), t2n(s_t)[:len(pos_n) - cut]) and np.array_equal(t2n(o_m2), t2n(s_m)[:len(pos_n) - cut])
     e_id, e_w, e_t, e_m = EA.ops.expand_rows(pos, r_id, r_w, r_t, r_m, count)
     assert np.array_equal(t2n(e_id), t2n(o_id)) and np.array_equal(t2n(e_m), t2n(o_m))
 
