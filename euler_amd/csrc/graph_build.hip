@@ -993,8 +993,9 @@ int BuildWbIndex(GraphBuilder* b) {
       v.n_edges >= ((int64_t)1 << 32) - 16 ||
       v.n_edges / 4 + v.n_rows >= ((int64_t)1 << 32) - 16)
     return EULER_GPU_OK;
-  const bool plain = v.T == 1 && v.total_in_meta != 0 && v.map_mode == 0 &&
-                     v.n_edges < ((int64_t)1 << 31);
+  // (the 16-byte record of plain graphs: unsigned 32-bit edge and block numbers - the kernel of
+  // fanout_plain.h reads them as such; the lean builds of fanout_local.h stop at 2^31 edges)
+  const bool plain = v.T == 1 && v.total_in_meta != 0 && v.map_mode == 0;
   const int block = 256;
   // temporaries, released on every way out (EG_HIP returns early)
   struct Temps {

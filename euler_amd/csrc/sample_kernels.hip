@@ -1534,8 +1534,11 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
       // for every graph the index does not serve)
       const bool lean_search_ok = lean_g || lean_gu || lean_t || v.uniform_w != 0 || f.g.blk != nullptr ||
                                   (f.g.wrec != nullptr && f.g.wb != nullptr && v.wb_lean_ok != 0);
+      // graphs of 2^31 .. 2^32 edges: the kernel of fanout_plain.h alone (unsigned 32-bit edge
+      // numbers throughout); the lean / local builds of fanout_local.h keep their 2^31
+      const bool big = v.n_edges >= ((int64_t)1 << 31);
       if (((plain_u && !typed_hops) || lean_g || lean_gu || lean_t) && g_fl_plain == 2 && f.vec &&
-          lean_search_ok && v.n_edges < ((int64_t)1 << 31)) {
+          lean_search_ok && (!big || (plain && !typed_hops))) {
         // the lean build (pairs of samples per lane, f32 compares, duplicates by edge)
         int32_t lcap = cap;
         FanoutLeanLds ll = FanoutLeanLayout(gr, c1, c2, lcap, lean_t);
@@ -1547,7 +1550,7 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
         const bool use_wb0 = v.uniform_w == 0 && f.g.wrec != nullptr && f.g.wb != nullptr && v.wb_lean_ok != 0;
         // (a caller that alternates streams keeps round 5's build: its 8-roots-per-wave geometry is the faster one
         //  when launches share the chip - 0.199 against 0.205-0.212 ms per step, profiles/r6_sweep*.txt)
-        if (g_fp_on != 0 && (t_concurrent != 1 || g_fp_on == 2) && plain && !typed_hops && use_wb0 && f.wide) {
+        if (g_fp_on != 0 && (t_concurrent != 1 || g_fp_on == 2 || big) && plain && !typed_hops && use_wb0 && f.wide) {
           int32_t pgr = g_fl_roots > 0 ? gr : 4;
           while (multi != nullptr && pgr > 1 && multi->n_per % pgr != 0) pgr >>= 1;
           int32_t pcap = g_fl_cap > 0 ? g_fl_cap : (g_fp_coop != 0 ? 64 / (c2 / 2 > 0 ? c2 / 2 : 1) : 32);
@@ -1586,7 +1589,7 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
             return EULER_GPU_OK;
           }
         }
-        if ((size_t)ll.bytes * (block / 64) <= 64 * 1024) {
+        if (!big && (size_t)ll.bytes * (block / 64) <= 64 * 1024) {
           f.cap = lcap; f.wave_lds = (int32_t)ll.bytes;
           f.div_h1.Set((uint32_t)(c1 + 1) / 2); f.div_h2.Set((uint32_t)c2 / 2);
           const size_t llds = (size_t)ll.bytes * wpb;
@@ -1634,7 +1637,7 @@ static int RunFanout(const euler_gpu_graph* g, hipStream_t stream, uint64_t seed
           return EULER_GPU_OK;
         }
       }
-      if (!lean_only) {         // (typed hops / uniform general graphs the lean build does not take go hop by hop, below)
+      if (!lean_only && !big) {  // (typed hops / uniform general graphs the lean build does not take go hop by hop, below)
       void (*kern)(const FanoutLocalArgs) = nullptr;
 #define EG_FL(W, P) (g_fl_wps != 8 ? SampleFanoutLocalKernel<W, P, 5> : SampleFanoutLocalKernel<W, P, 8>)
       kern = f.wide ? (plain ? EG_FL(true, true) : EG_FL(true, false))

@@ -120,6 +120,58 @@ def test_config2_products_shaped_uniform_fanout(EA, O, torch_cuda):
 
 
 @pytest.mark.gpu
+def test_plain_graph_between_2_31_and_2_32_edges(EA, O, torch_cuda):
+    """a plain weighted graph of 2.5 billion edges (250M nodes; 2.5x the headline
+    graph, past the signed 32-bit edge numbers the one-kernel builds stopped at) is served by the
+    one-kernel step of fanout_plain.h: every sample of a step == hop-by-hop sampling, and a step
+    whose roots are taken from the rows past edge 2^31 == the CPU oracle on exported rows."""
+    torch = torch_cuda
+    from euler_amd import _lib
+    L = _lib.lib()
+    N, B = 250_000_000, 32768
+    free_b, _ = torch.cuda.mem_get_info()
+    if free_b < 200 * 2 ** 30:
+        pytest.skip("needs ~150 GB of free HBM")
+    G = EA.Graph.synthetic(EA.synth_params(20240522, N, 10 * N, weighted=True))
+    try:
+        assert G.num_edges > 2 ** 31 + 2 ** 28
+        G.set_seed(11)
+        gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+        roots = torch.randint(1, N + 1, (B,), generator=gen, device="cuda", dtype=torch.int64)
+        roots[: B // 2] = torch.randint(int(0.9 * N), N + 1, (B // 2,), generator=gen, device="cuda", dtype=torch.int64)
+        try:
+            L.euler_gpu_set_tuning(27, 1)
+            a = G.sample_fanout(roots, [[0], [0]], [25, 10], N + 1, call_id=3)
+            assert (L.euler_gpu_last_fanout_kernel() or b"").decode() == "SampleFanoutPlainKernel"
+            L.euler_gpu_set_tuning(27, 0)
+            h = G.sample_fanout(roots, [[0], [0]], [25, 10], N + 1, call_id=3)
+            assert (L.euler_gpu_last_fanout_kernel() or b"").decode() == "hop by hop"
+        finally:
+            L.euler_gpu_set_tuning(27, 1)
+        for hop in range(2):
+            assert torch.equal(a[0][hop + 1], h[0][hop + 1]) and torch.equal(a[1][hop], h[1][hop])
+            assert torch.equal(a[2][hop], h[2][hop])
+        del h
+        # the exported rows of the high roots really lie past edge 2^31
+        rp = G.export_rows(np.array([N - 5, N - 4], np.uint64))[0]
+        assert len(rp) == 3
+        from oracle.step_check import check_fanout_step
+        edges, distinct = check_fanout_step(G, O.OracleGraph, O.CSR, 11, 3, roots, a[0], a[1], a[2], [25, 10], N + 1, N)
+        assert edges == B * 275 and distinct > 50_000
+        # a DeepWalk of 100 000 walkers x 10 on the same graph: the walk kernels' own paths == one lane per walker
+        starts = torch.randint(1, N + 1, (100_000,), generator=gen, device="cuda", dtype=torch.int64)
+        w = G.random_walk(starts, [[0]] * 10, 1.0, 1.0, N + 1, call_id=50)
+        walks = t2n(w[:16])          # (16 walkers against the oracle on exported rows)
+        rows = np.unique(walks[walks <= N]).astype(np.uint64)
+        rp, te, nb, pw, tp = G.export_rows(rows)
+        OG = O.OracleGraph(O.CSR(rows, rp, te, nb, pw, tp, 1))
+        assert np.array_equal(walks, OG.random_walk(11, 50, t2n(starts[:16]), [[0]] * 10, 10, 1.0, 1.0, N + 1))
+    finally:
+        del G
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
 def test_config3_metric_step_at_full_size(EA, O, torch_cuda):
     """configs[2], the headline workload, at its full size: two independent device
     paths agree bit for bit on every one of the step's 36 044 800 samples (the one-kernel
