@@ -687,6 +687,87 @@ __global__ __launch_bounds__(kThreads) void FlowSampleInsertKernel(const FlowSI 
   }
 }
 
+// The same fusion for SEVERAL minibatches per launch (euler_gpu_sage_blocks_multi: minibatch
+// blockIdx.y, its own call id, its own hash table - every id goes through it, reduced by ID in LDS
+// first as FlowInsertKernel<true> does): the draw of FlowSampleKernel, then the insert of the
+// workgroup's 256 positions.
+struct FlowSIM {
+  FlowHop h;
+  uint64_t seed;
+  uint32_t call_id, call_stride;
+  int32_t type;
+  int64_t default_node;
+};
+
+__global__ __launch_bounds__(256, kWavesPerSimd) void FlowSampleInsertMultiKernel(const FlowSIM a) {
+  constexpr int kLds = 512;
+  const FlowHop h = FlowOf(a.h, blockIdx.y);
+  __shared__ unsigned long long s_id[kLds];
+  __shared__ uint32_t s_ipos[kLds];
+  __shared__ uint32_t s_side;
+  const int64_t cnt = (int64_t)(*h.cnt);
+  const int64_t m_nb = cnt * h.count, m = m_nb + cnt;
+  const uint64_t mask = FlowMask(h, m);
+  const uint32_t call = a.call_id + blockIdx.y * a.call_stride;
+  constexpr uint32_t kNone = 0xFFFFFFFFu, kSide = 0xFFFFFFFEu;
+  for (int64_t base = (int64_t)blockIdx.x * 256; base < m; base += (int64_t)gridDim.x * 256) {
+    for (int x = threadIdx.x; x < kLds; x += 256) { s_id[x] = kFlowEmptyKey; s_ipos[x] = 0xFFFFFFFFu; }
+    if (threadIdx.x == 0) s_side = 0xFFFFFFFFu;
+    __syncthreads();
+    const int64_t i = base + threadIdx.x;
+    uint32_t ls = kNone;
+    if (i < m) {
+      uint64_t id;
+      if (i < m_nb) {
+        const int64_t r = i / h.count;
+        const int32_t j = (int32_t)(i - r * h.count);
+        const uint64_t node = h.n_id[r];
+        id = (uint64_t)a.default_node;
+        Segment sg;
+        if (LoadSegment<true>(h.g, FindRow(h.g, node), a.type, &sg)) {
+          const Philox4 blk = RngBlock(a.seed, call, kDomainNeighbor, node, ((uint32_t)j) >> 1);
+          const double u = (j & 1) ? UnitFromWords(blk.w[2], blk.w[3]) : UnitFromWords(blk.w[0], blk.w[1]);
+          float w;
+          BlockPivotSample(h.g, sg, u, &id, &w);
+        }
+        const_cast<uint64_t*>(h.nb)[i] = id;
+      } else {
+        id = h.n_id[i - m_nb];
+      }
+      if (id == kFlowEmptyKey) {
+        atomicMin(&s_side, (uint32_t)i);
+        ls = kSide;
+      } else {
+        uint32_t sl = (uint32_t)(Mix64(id) & (uint64_t)(kLds - 1));
+        for (;;) {                                    // at most 256 of the 512 slots fill up
+          const unsigned long long old = atomicCAS(&s_id[sl], (unsigned long long)kFlowEmptyKey, (unsigned long long)id);
+          if (old == kFlowEmptyKey || old == id) break;
+          sl = (sl + 1) & (uint32_t)(kLds - 1);
+        }
+        atomicMin(&s_ipos[sl], (uint32_t)i);
+        ls = sl;
+      }
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x < kLds; x += 256) {
+      const unsigned long long id = s_id[x];
+      if (id == kFlowEmptyKey) continue;
+      uint64_t sl = Mix64(id) & mask;
+      for (;;) {
+        const unsigned long long old = atomicCAS(&h.t.keys[sl], (unsigned long long)kFlowEmptyKey, id);
+        if (old == kFlowEmptyKey || old == id) break;
+        sl = (sl + 1) & mask;
+      }
+      atomicMin(&h.t.minpos[sl], s_ipos[x]);
+      s_ipos[x] = (uint32_t)sl;
+    }
+    if (threadIdx.x == 0 && s_side != 0xFFFFFFFFu) atomicMin(&h.t.minpos[h.t.mask + 1], s_side);
+    __syncthreads();
+    if (ls != kNone) h.slot_of[i] = kFlowHashed | (ls == kSide ? (uint32_t)(h.t.mask + 1) : s_ipos[ls]);
+    __syncthreads();
+  }
+}
+
 // The stream's row-indexed table and the epochs of `hops` hops (common.h: FlowTableDense).
 // No table (allocation failed, more than 2^31 rows): the hash table serves every id.
 int FlowDenseTable(const euler_gpu_graph* g, hipStream_t st, int32_t hops,
@@ -1012,32 +1093,37 @@ int euler_gpu_sage_blocks_multi(const euler_gpu_graph* g, void* stream, uint64_t
     f.n_mb = n_mb;
     f.mb_nb = cap_n * count; f.mb_nid = cap_n; f.mb_cnt = layers + 1; f.mb_tab = (int64_t)tcap + 1;
     f.mb_m = cap_m; f.mb_blk = R;
-    // 1. the hop's sampler, all minibatches
-    FlowSample fs{};
-    fs.g = view; fs.seed = seed; fs.call_id = call_id + (uint32_t)h; fs.call_stride = call_stride;
-    fs.n_id = n_id; fs.cnt = counts_dev + h; fs.nb = nb; fs.cap_n = cap_n; fs.mb_cnt = layers + 1;
-    fs.default_node = default_node; fs.count = count; fs.type = edge_types_host[(size_t)h * k];
-    const int block = 256;
-    {
-      // (a lane should draw ONE sample: a second trip through the dependent chain with a fifth of
-      // the lanes doubles the launch - hop 2 of 64 x 1 024 roots: 142 us with 2 x per_mb workgroups)
-      int64_t gx = (cap_n * count + block - 1) / block;
-      if (gx > 8 * per_mb) gx = 8 * per_mb;
-      hipLaunchKernelGGL(FlowSampleKernel, dim3((unsigned)gx, (unsigned)n_mb), dim3(block), 0, st, fs);
-    }
-    // 2. first-occurrence unique of [nb | n_id], 3. res_n_id / edge_index - the kernels of the single
-    // flow, a minibatch per blockIdx.y
+    // 1 + 2. clear, then the hop's sampler and the insert of [nb | n_id] in one kernel (a minibatch
+    // per blockIdx.y); 3. ranks, the new layer, res_n_id / edge_index - the kernels of the single flow
     f.nb = nb; f.n_id = n_id; f.cnt = counts_dev + h; f.cnt_out = counts_dev + h + 1;
     f.count = count; f.self_loops = add_self_loops ? 1 : 0; f.cap_m = cap_m;
     f.new_n_id = n_id_dev[h]; f.inv = edge_dst_dev[h]; f.edge_src = edge_src_dev[h];
     f.res_n_id = res_n_id_dev[h];
+    const int block = 256;
     int64_t gx = (cap_m + 1 + block - 1) / block;
     if (gx > 4 * per_mb) gx = 4 * per_mb;
     int64_t gb = f.n_blk + 1;
     if (gb > per_mb) gb = per_mb;
     const dim3 grid((unsigned)gx, (unsigned)n_mb), grid_b((unsigned)gb, (unsigned)n_mb);
     hipLaunchKernelGGL(FlowClearKernel, grid, dim3(block), 0, st, f);
-    hipLaunchKernelGGL(FlowInsertKernel<true>, grid_b, dim3(kFlowInsertThreads), 0, st, f);
+    if (g_flow_fused != 0) {
+      FlowSIM sm{};
+      sm.h = f; sm.seed = seed; sm.call_id = call_id + (uint32_t)h; sm.call_stride = call_stride;
+      sm.type = edge_types_host[(size_t)h * k]; sm.default_node = default_node;
+      // (a lane draws ONE sample per trip: as many workgroups as the worst case has positions, up to 8 x per_mb)
+      int64_t gs = (cap_m + block - 1) / block;
+      if (gs > 8 * per_mb) gs = 8 * per_mb;
+      hipLaunchKernelGGL(FlowSampleInsertMultiKernel, dim3((unsigned)gs, (unsigned)n_mb), dim3(block), 0, st, sm);
+    } else {
+      FlowSample fs{};
+      fs.g = view; fs.seed = seed; fs.call_id = call_id + (uint32_t)h; fs.call_stride = call_stride;
+      fs.n_id = n_id; fs.cnt = counts_dev + h; fs.nb = nb; fs.cap_n = cap_n; fs.mb_cnt = layers + 1;
+      fs.default_node = default_node; fs.count = count; fs.type = edge_types_host[(size_t)h * k];
+      int64_t gs = (cap_n * count + block - 1) / block;
+      if (gs > 8 * per_mb) gs = 8 * per_mb;
+      hipLaunchKernelGGL(FlowSampleKernel, dim3((unsigned)gs, (unsigned)n_mb), dim3(block), 0, st, fs);
+      hipLaunchKernelGGL(FlowInsertKernel<true>, grid_b, dim3(kFlowInsertThreads), 0, st, f);
+    }
     LaunchFlowRanks(f, grid_b, cap_m, 4 * per_mb, st);
     EG_HIP(hipGetLastError());
     n_id = n_id_dev[h];

@@ -1318,6 +1318,19 @@ def test_sage_blocks_multi_equals_separate_calls(EA, O, torch_cuda, big_pair):
             for x, y in zip(got[b][0], want[0]):
                 for u, v in zip(x, y):
                     assert torch.equal(u, v), b
+        # ... and the launches of round 5 (sampler, insert as separate kernels: tuning key 60 = 0)
+        from euler_amd import _lib
+        try:
+            _lib.check(_lib.lib().euler_gpu_set_tuning(60, 0))
+            G.set_seed(17)
+            old = G.sage_blocks_multi(roots, mp_, fan, default_node=dflt, add_self_loops=loops, call_id=400)
+        finally:
+            _lib.lib().euler_gpu_set_tuning(60, 1)
+        for b in range(M):
+            assert list(got[b][1]) == list(old[b][1])
+            for x, y in zip(got[b][0], old[b][0]):
+                for u, v in zip(x, y):
+                    assert torch.equal(u, v), b
         return got
 
     for weighted in (True, False):
