@@ -102,7 +102,7 @@ struct GraphView {
   const float* skip1;           // [n_blk] running sum of the last edge of every EdgeBlock
   int64_t n_blk;
   // weight-bucket index (wb_index.h; built on first use for plain graphs: one edge-type
-  // group, identity id map, monotone non-uniform weights, < 2^31 edges): a 16-byte record per
+  // group, identity id map, monotone non-uniform weights, < 2^32 edges): a 16-byte record per
   // row and one 128-byte block per bucket of a row's running-sum range
   const struct WbRec* wrec;     // plain graphs only (the lean kernels' 16-byte record)
   const struct EdgeBlock* wb;
