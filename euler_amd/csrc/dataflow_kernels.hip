@@ -121,11 +121,17 @@ __device__ __forceinline__ uint64_t FlowMaskOf(uint64_t table_mask, int64_t m) {
   while (cap < (uint64_t)m * 2 && cap <= table_mask) cap <<= 1;
   return (cap > table_mask + 1 ? table_mask + 1 : cap) - 1;
 }
-__device__ __forceinline__ uint64_t FlowMask(const FlowHop& h, int64_t m) { return FlowMaskOf(h.t.mask, m); }
+// Flows with the row-indexed table send only the ids WITHOUT a graph row to the hash table (unknown
+// roots, dangling neighbour ids, the default fill - a handful of distinct ids in a real flow):
+// 1.25 slots per position (the worst case - every position a distinct id without a row - probes
+// longer and still fits) instead of 2, half the bytes to clear per hop.  Hash-only flows keep 2.
+__device__ __forceinline__ uint64_t FlowMask(const FlowHop& h, int64_t m) {
+  return FlowMaskOf(h.t.mask, h.dense_min != nullptr ? (m * 5 + 7) / 8 : m);
+}
 
 // the part of table t a hop of m positions uses, emptied by the whole grid
-__device__ __forceinline__ void FlowClearTable(const FlowTable& t, int64_t m) {
-  const int64_t slots = (int64_t)FlowMaskOf(t.mask, m) + 1;
+__device__ __forceinline__ void FlowClearTable(const FlowTable& t, int64_t m, bool dense) {
+  const int64_t slots = (int64_t)FlowMaskOf(t.mask, dense ? (m * 5 + 7) / 8 : m) + 1;      // (FlowMask below)
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (first == 0) {                    // the side slot of the all-ones id
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(256) void FlowClearKernel(const FlowHop h0) {
   const FlowHop h = FlowOf(h0, blockIdx.y);
   const int64_t cnt = (int64_t)(*h.cnt);
   const int64_t m = FlowNbLen(h, cnt) + cnt;
-  FlowClearTable(h.t, m);
+  FlowClearTable(h.t, m, h.dense_min != nullptr);
 }
 
 constexpr uint32_t kFlowHashed = 0x80000000u;
@@ -405,7 +411,7 @@ __global__ __launch_bounds__(256) void FlowEmitIndexKernel(const FlowHop h0) {
     __syncthreads();
   }
   if (h.t_next.keys != nullptr)        // the next hop's table, for the layer this hop has just sized
-    FlowClearTable(h.t_next, (int64_t)(SCANNED ? *h.cnt_out : s_total) * ((int64_t)h.count_next + 1));
+    FlowClearTable(h.t_next, (int64_t)(SCANNED ? *h.cnt_out : s_total) * ((int64_t)h.count_next + 1), true);
   const uint32_t* pre = SCANNED ? h.blk_cnt : s_pre;
   constexpr int kU = 4;
   const int64_t stride = (int64_t)gridDim.x * 256 * kU;
@@ -556,7 +562,7 @@ __global__ void FlowInitKernel(uint32_t* counts, uint32_t n) { counts[0] = n; }
 // ... and the first hop's table emptied (its length is known to the host)
 __global__ __launch_bounds__(256) void FlowInitClearKernel(uint32_t* counts, uint32_t n, const FlowTable t, int64_t m0) {
   if (blockIdx.x == 0 && threadIdx.x == 0) counts[0] = n;
-  FlowClearTable(t, m0);
+  FlowClearTable(t, m0, true);
 }
 
 // counts of minibatch b at counts + b * stride
