@@ -91,7 +91,7 @@ def run_deepwalk(args, G=None, p_g=None, quiet=False):
                       "frac": round(wb_ / world / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
                       "algorithmic_bytes_per_launch": wb_ / world, "avg_launch_ms": round(ms_c, 4),
                       "note": "bytes = SURVEY 8(d)'s walk formula (K1 with count 1 per walker step) over the "
-                              "walkers of one rank; time = the call, wall clock (it contains the host waits)"}
+                              "walkers of one rank; time = the call, wall clock"}
             if world == 1 and not args.no_check:
                 sel = np.random.default_rng(0).choice(W, 64, replace=False)
                 w_sel = walks.cpu().numpy()[sel]
@@ -176,8 +176,10 @@ def run_deepwalk(args, G=None, p_g=None, quiet=False):
                        "repeat_ms_per_step": [round(x_ / args.steps * 1e3, 4) for x_ in reps],
                        "transport": "%s, %d ranks in the communicator" % (dist.get_backend(),
                                                                            dist.get_world_size()),
-                       "orchestration": ("euler_gpu_sharded_random_walk (C): levels of merged walkers, "
-                                         "%d cohorts" % getattr(S, "walk_cohorts", 0))
+                       "orchestration": ("euler_gpu_sharded_random_walk (C): levels of merged walkers in slab "
+                                         "layout, the whole walk enqueued - host waits per call in walk_stats "
+                                         "(tuning key 63 = 0: a wait per step); %d cohorts"
+                                         % getattr(S, "walk_cohorts", 0))
                                         if getattr(S, "c_walk_fn", None) is not None else
                                         "ShardedSampler.random_walk (Python): one sample_neighbor per step",
                        "walk_stats": walk_stats, "parity_checked_steps": checked_s,

@@ -288,6 +288,19 @@ int WalkOwnedStep(const euler_gpu_graph* g, hipStream_t st, uint64_t seed, uint3
 int WalkPathsFromLevels(hipStream_t st, const int64_t* starts_dev, int64_t n, int32_t walk_len,
                         const uint64_t* const* level_ids_host, const int32_t* const* level_next_host,
                         int64_t default_node, int64_t* out_dev);
+// The walk enqueued without host waits: levels and buckets in SLAB layout (a slab per owner:
+// header word = the number of entries, then the entries, then padding), sizes on the device.
+// mp_kernels.hip: the front end over such a level; walk_kernels.hip: the owners' draw over the
+// slabs received (the header of each says how many of its words hold ids; lens_dev not null: that
+// array instead - a lone rank draws on the slabs its own front end filled)
+int FrontSlabs(hipStream_t st, const uint64_t* ids_dev, int64_t n_pos, const uint32_t* in_lens_dev,
+               uint32_t in_stride, int32_t partitions, int32_t shards, uint32_t* dense_owner_dev,
+               int64_t dense_limit, uint64_t* out_slabs_dev, uint32_t out_stride, uint32_t* out_lens_dev,
+               bool write_headers, int32_t* pos_dev);
+int WalkOwnedSlabs(const euler_gpu_graph* g, hipStream_t st, uint64_t seed, uint32_t call_id,
+                   const int32_t* et_dev, int32_t k, int32_t walk_len, int32_t step,
+                   const uint64_t* slabs_dev, const uint32_t* lens_dev, int32_t n_slabs, uint32_t stride,
+                   uint64_t* out_dev);
 // ... and of the sharded node2vec walk: row lengths <-> FillNeighbor offsets, one column of
 // the [n, walk_len + 1] result, the value offsets at the peers' row bounds
 int N2vRowLens(hipStream_t st, const int32_t* idx_dev, int64_t m, int32_t* lens_dev);

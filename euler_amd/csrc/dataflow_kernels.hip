@@ -36,6 +36,12 @@
 
 namespace euler_gpu {
 
+// tuning key 62: fused Sage flows send the ids WITH a graph row through the hop's own {row, smallest
+// position} hash table (a few MB that stay near the chip) instead of the stream's row-indexed table
+// (8 B x n_rows: every claim a cold line).  2 = flows of at most 32 768 roots (16 384 roots x [25, 10]:
+// 0.117 -> 0.111 ms; at 131 072 roots the hop's table is 128 MB itself and the flow 3 % SLOWER:
+// profiles/r6_rowpos_ab.txt), 1 = always, 0 = never
+std::atomic<int> g_flow_rowpos{2};
 std::atomic<int> g_flow_fused{1};     // tuning key 60: Sage flows: sampler + insert in one kernel, tables cleared by the kernels before (0 = op by op)
 
 namespace {
@@ -48,6 +54,9 @@ struct FlowTable {
   uint32_t* minpos;           // [cap + 1]
   int32_t* rank;              // [cap + 1]
   uint64_t mask;              // cap - 1
+  // not null: ids WITH a graph row go through this table instead of the stream's row-indexed one -
+  // one word {row, smallest position} per slot, claimed with one compare-and-swap (tuning key 62)
+  unsigned long long* rowpos; // [cap + 1]
 };
 
 struct FlowHop {
@@ -141,6 +150,10 @@ __device__ __forceinline__ void FlowClearTable(const FlowTable& t, int64_t m, bo
   for (int64_t i = first; i < slots; i += stride) {
     t.keys[i] = kFlowEmptyKey;
     t.minpos[i] = 0xFFFFFFFFu;
+  }
+  if (t.rowpos != nullptr) {          // ids with a row: up to one slot per position, 2 slots per position
+    const int64_t rslots = (int64_t)FlowMaskOf(t.mask, m) + 1;
+    for (int64_t i = first; i < rslots; i += stride) t.rowpos[i] = kFlowEmptyKey;
   }
 }
 
@@ -311,7 +324,8 @@ __global__ __launch_bounds__(256) void FlowFlagKernel(const FlowHop h0) {
         if (i < m) {
           // the element's first position takes the slot word's place: the emit kernel reads it
           // in position order instead of going back to the tables
-          const uint32_t f = (sw[x] & kFlowHashed) ? h.t.minpos[sw[x] & ~kFlowHashed] : (uint32_t)h.dense_min[sw[x]];
+          const uint32_t f = (sw[x] & kFlowHashed) ? h.t.minpos[sw[x] & ~kFlowHashed]
+                             : h.t.rowpos != nullptr ? (uint32_t)h.t.rowpos[sw[x]] : (uint32_t)h.dense_min[sw[x]];
           h.slot_of[i] = f;
           first[x] = f == (uint32_t)i;
         }
@@ -638,6 +652,7 @@ __global__ __launch_bounds__(kThreads) void FlowSampleInsertKernel(const FlowSI 
     for (int x = threadIdx.x; x < kFlowSiLds; x += kThreads) { s_row[x] = 0xFFFFFFFFu; s_pos[x] = 0xFFFFFFFFu; }
     __syncthreads();
     const int64_t i = base + threadIdx.x;
+    uint32_t my_ls = 0xFFFFFFFFu;                      // (rowpos tables) the LDS slot of this position's row
     if (i < m) {
       uint64_t id;
       if (i < m_nb) {
@@ -666,6 +681,7 @@ __global__ __launch_bounds__(kThreads) void FlowSampleInsertKernel(const FlowSI 
           sl = (sl + 1) & (uint32_t)(kFlowSiLds - 1);
         }
         atomicMin(&s_pos[sl], (uint32_t)i);
+        my_ls = sl;
       } else {
         uint64_t sl;
         if (id == kFlowEmptyKey) {
@@ -684,10 +700,32 @@ __global__ __launch_bounds__(kThreads) void FlowSampleInsertKernel(const FlowSI 
       }
     }
     __syncthreads();
-    for (int x = threadIdx.x; x < kFlowSiLds; x += kThreads) {
-      const uint32_t row = s_row[x];
-      if (row == 0xFFFFFFFFu) continue;
-      atomicMin(&h.dense_min[row], h.epoch_hi | (unsigned long long)s_pos[x]);
+    if (h.t.rowpos != nullptr) {
+      // the workgroup's distinct rows claim {row, smallest position} words of the hop's own hash
+      // table (a few MB that stay near the chip, against cold lines of the 8 B x n_rows table):
+      // one compare-and-swap per first claim, + a minimum when another workgroup was first
+      const uint64_t rmask = FlowMaskOf(h.t.mask, m);
+      for (int x = threadIdx.x; x < kFlowSiLds; x += kThreads) {
+        const uint32_t row = s_row[x];
+        if (row == 0xFFFFFFFFu) continue;
+        const unsigned long long mine = (unsigned long long)row << 32 | (unsigned long long)s_pos[x];
+        uint64_t sl = Mix64((uint64_t)row) & rmask;
+        for (;;) {
+          const unsigned long long old = atomicCAS(&h.t.rowpos[sl], (unsigned long long)kFlowEmptyKey, mine);
+          if (old == kFlowEmptyKey) break;
+          if ((uint32_t)(old >> 32) == row) { atomicMin(&h.t.rowpos[sl], mine); break; }
+          sl = (sl + 1) & rmask;
+        }
+        s_pos[x] = (uint32_t)sl;                      // the rows' positions read their slot from here
+      }
+      __syncthreads();
+      if (my_ls != 0xFFFFFFFFu) h.slot_of[base + threadIdx.x] = s_pos[my_ls];
+    } else {
+      for (int x = threadIdx.x; x < kFlowSiLds; x += kThreads) {
+        const uint32_t row = s_row[x];
+        if (row == 0xFFFFFFFFu) continue;
+        atomicMin(&h.dense_min[row], h.epoch_hi | (unsigned long long)s_pos[x]);
+      }
     }
     __syncthreads();
   }
@@ -832,7 +870,7 @@ static int64_t FlowCap(int64_t n, const int32_t* fanouts, int32_t h) {
 static size_t SageTableBytes(int64_t cap_m) {
   uint64_t tcap = 64;
   while (tcap < (uint64_t)cap_m * 2) tcap <<= 1;
-  return Al((tcap + 1) * 8) + Al((tcap + 1) * 4);
+  return Al((tcap + 1) * 8) + Al((tcap + 1) * 4) + Al((tcap + 1) * 8);      // keys, minpos, rowpos
 }
 static size_t SageRegionA(int64_t n, const int32_t* fanouts_host, int32_t layers) {
   size_t best = 0;
@@ -919,6 +957,9 @@ int euler_gpu_sage_blocks(const euler_gpu_graph* g, void* stream, uint64_t seed,
       tabs[h].minpos = (uint32_t*)(tp + Al((tcap + 1) * 8));
       tabs[h].rank = nullptr;
       tabs[h].mask = tcap - 1;
+      const int rp = g_flow_rowpos.load();
+      tabs[h].rowpos = rp == 1 || (rp == 2 && n <= 32768)
+                           ? (unsigned long long*)(tp + Al((tcap + 1) * 8) + Al((tcap + 1) * 4)) : nullptr;
       tp += SageTableBytes(cm);
     }
   }

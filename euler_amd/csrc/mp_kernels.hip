@@ -6,12 +6,15 @@
 // domain kernel is written here.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <atomic>
 #include <map>
 #include <new>
 #include <mutex>
 #include <utility>
 
 #include "device_fns.h"
+
+namespace euler_gpu { std::atomic<int> g_front_claim{0}; }   // tuning key 65 (FrontSlabKernel<1>)
 
 struct euler_gpu_front {
   int64_t* stage = nullptr;      // pinned + mapped: [kMaxShards + 1] bucket starts, then the sequence word
@@ -1177,11 +1180,24 @@ struct DedupIdsArgs {
   uint32_t mask;
   uint32_t* owner;     // [mask + 1]
   uint32_t* owner2;    // [mask + 1] second round (stale entries are checked by id)
+  // a level in SLAB layout (the walk enqueued without host waits, csrc/sharded.cc): `n` positions =
+  // slabs of in_stride words, word 0 of a slab its header, entries 1 .. in_lens[slab] the level's
+  // nodes, the rest padding.  null: every position below n holds an id.
+  const uint32_t* in_lens;
+  uint32_t in_stride;
 };
 
 __device__ __forceinline__ uint64_t DedupIdAt(const DedupIdsArgs& a, int64_t i) {
   if (a.root_mask != nullptr && a.root_mask[i / a.root_group]) return 0;
   return a.ids[i];
+}
+
+// does position i hold an id of the batch?
+__device__ __forceinline__ bool DedupLive(const DedupIdsArgs& a, int64_t i) {
+  if (i >= a.n) return false;
+  if (a.in_lens == nullptr) return true;
+  const uint32_t p = (uint32_t)i / a.in_stride, j = (uint32_t)i - p * a.in_stride;
+  return j != 0u && j <= a.in_lens[p];
 }
 
 __device__ __forceinline__ uint32_t DedupSlot2(uint64_t id, uint32_t mask) {
@@ -1196,19 +1212,21 @@ __device__ __forceinline__ uint32_t DedupRep(const DedupIdsArgs& a, uint32_t i) 
   const uint32_t o = a.owner[(uint32_t)Mix64(id) & a.mask];
   if (DedupIdAt(a, o) == id) return o;
   const uint32_t o2 = a.owner2[DedupSlot2(id, a.mask)];
-  return (o2 < (uint32_t)a.n && DedupIdAt(a, o2) == id) ? o2 : i;
+  // (a stale entry may name a position that holds no id in THIS call - padding of a slab level)
+  return (DedupLive(a, o2) && DedupIdAt(a, o2) == id) ? o2 : i;
 }
 
 __global__ __launch_bounds__(256) void DedupIdsMarkKernel(const DedupIdsArgs a) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride)
-    a.owner[(uint32_t)Mix64(DedupIdAt(a, i)) & a.mask] = (uint32_t)i;
+    if (DedupLive(a, i)) a.owner[(uint32_t)Mix64(DedupIdAt(a, i)) & a.mask] = (uint32_t)i;
 }
 
 // second round: positions whose slot went to a different id try another slot
 __global__ __launch_bounds__(256) void DedupIdsMark2Kernel(const DedupIdsArgs a) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+    if (!DedupLive(a, i)) continue;
     const uint64_t id = DedupIdAt(a, i);
     const uint32_t o = a.owner[(uint32_t)Mix64(id) & a.mask];
     if (DedupIdAt(a, o) != id) a.owner2[DedupSlot2(id, a.mask)] = (uint32_t)i;
@@ -1242,6 +1260,14 @@ struct FrontArgs {
   uint32_t* total;           // [kMaxShards] representatives per shard
   int64_t n_chunks;
   int32_t partitions, shards;
+  // buckets in SLAB layout (FrontSlabKernel): shard s's ids at out_stride * s + 1 .., their number
+  // in word 0 of the slab and in out_lens[s] - fixed-size messages, nothing for the host to wait
+  // for.  0: buckets packed one behind the other, their starts to the host (stage).
+  uint32_t out_stride;
+  uint32_t* out_lens;        // [shards]
+  // FrontSlabKernel: out_lens doubles as the shard totals (zero when the kernel starts); epoch
+  // tags this call's table entries (MODE 1)
+  uint32_t epoch;
 };
 
 __device__ __forceinline__ uint32_t DenseSlot(const FrontArgs& a, uint64_t id) {
@@ -1255,7 +1281,7 @@ __global__ __launch_bounds__(256) void FrontMarkDenseKernel(const FrontArgs a) {
   if (blockIdx.x == 0 && threadIdx.x < kMaxShards) a.total[threadIdx.x] = 0u;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.d.n; i += stride)
-    a.dense_owner[DenseSlot(a, DedupIdAt(a.d, i))] = (uint32_t)i;
+    if (DedupLive(a.d, i)) a.dense_owner[DenseSlot(a, DedupIdAt(a.d, i))] = (uint32_t)i;
 }
 // (Round 5, measured and removed: electing one LEADER lane per distinct id of a wave - a loop of
 // ballots and shuffles - so that only leaders touch the table.  The second hop's positions are
@@ -1278,24 +1304,25 @@ __global__ __launch_bounds__(256) void FrontRepHistKernel(const FrontArgs a) {
   // (taken position by position the chunk is kPer dependent pairs of round trips long)
   uint64_t idv[kPer];
   uint32_t repv[kPer];
+  bool live[kPer];
+#pragma unroll
+  for (int32_t k = 0; k < kPer; ++k) live[k] = DedupLive(a.d, base + (int64_t)k * 256 + threadIdx.x);
   if (DENSE) {
 #pragma unroll
     for (int32_t k = 0; k < kPer; ++k) {
       const int64_t i = base + (int64_t)k * 256 + threadIdx.x;
-      idv[k] = i < a.d.n ? DedupIdAt(a.d, i) : 0ull;
+      idv[k] = live[k] ? DedupIdAt(a.d, i) : 0ull;
     }
 #pragma unroll
-    for (int32_t k = 0; k < kPer; ++k) {
-      const int64_t i = base + (int64_t)k * 256 + threadIdx.x;
-      repv[k] = i < a.d.n ? a.dense_owner[DenseSlot(a, idv[k])] : 0xFFFFFFFFu;
-    }
+    for (int32_t k = 0; k < kPer; ++k)
+      repv[k] = live[k] ? a.dense_owner[DenseSlot(a, idv[k])] : 0xFFFFFFFFu;
   }
 #pragma unroll
   for (int32_t k = 0; k < kPer; ++k) {
     const int64_t i = base + (int64_t)k * 256 + threadIdx.x;
     bool is_rep = false;
     uint32_t own = 0xFFFFFFFFu;
-    if (i < a.d.n) {
+    if (live[k]) {
       const uint64_t id = DENSE ? idv[k] : DedupIdAt(a.d, i);
       const uint32_t r = DENSE ? repv[k] : DedupRep(a.d, (uint32_t)i);
       a.rep[i] = r;
@@ -1342,6 +1369,7 @@ __global__ __launch_bounds__(256) void FrontPlaceKernel(const FrontArgs a, uint6
   __syncthreads();
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.d.n; i += stride) {
+    if (!DedupLive(a.d, i)) continue;
     const uint32_t r = a.rep[i];
     const uint32_t w = a.place[r];
     const uint32_t own = w >> 16;
@@ -1350,6 +1378,120 @@ __global__ __launch_bounds__(256) void FrontPlaceKernel(const FrontArgs a, uint6
     if (r == (uint32_t)i) shard_ids[q] = DedupIdAt(a.d, i);
   }
 }
+
+// ---- the front end as ONE kernel (slab layout; the walk enqueued without host waits) --------
+// With the buckets in slabs a representative's place is known the moment its chunk has taken its
+// base from the shard's total - bucket starts are fixed, no second pass over the totals:
+//   rep     MODE 0 (hashed ids): DedupRep over the tables the two mark kernels wrote;
+//           MODE 2 (id-indexed table): the entry FrontMarkDenseKernel left - the default;
+//           MODE 1 (id-indexed table, tuning key 65): a single pass - read the slot; an entry of this call's
+//           epoch that names a live position holding the same id is the representative (checked
+//           by CONTENT: the 8-bit epoch only spares stale entries the look at ids[]); anything
+//           else is replaced by compare-and-swap, and whoever wins represents the id.  Every
+//           position of an id sees either the winner's entry or loses its swap to it: one
+//           representative per id without a mark pass.  (ids beyond the table represent
+//           themselves: they would take turns at the one slot they share.)  Measured: 1M x 40
+//           walk 4.17 ms against 2.15 with the mark pass - a level repeats its hubs thousands of
+//           times and their swaps queue up at one address; kept for A/B.
+//   place   representatives rank within (chunk, owner) as in FrontRepHistKernel, the chunk adds
+//           its counts to the totals (= out_lens) and places them at slab start + 1 + base + rank;
+//           a position that is NOT its id's representative leaves ~representative in pos[] - the
+//           walk's path kernel follows the one indirection (the representative's chunk may not
+//           have run yet);
+//   sizes   out_lens holds them when the kernel has ended; FrontSlabHeadersKernel copies them into
+//           the slabs' headers when the slabs travel (a "last workgroup writes them" tail - a
+//           fence + one counter every workgroup bumps - cost 30 us a step: 489 atomics on one word).
+__global__ void FrontSlabHeadersKernel(uint64_t* slabs, uint32_t stride, const uint32_t* lens, int32_t shards) {
+  if ((int)threadIdx.x < shards) slabs[(int64_t)threadIdx.x * stride] = (uint64_t)lens[threadIdx.x];
+}
+
+extern "C++" {
+template <int MODE>
+__global__ __launch_bounds__(256) void FrontSlabKernel(const FrontArgs a, uint64_t* __restrict__ shard_ids,
+                                                       int32_t* __restrict__ pos_out) {
+  __shared__ uint32_t hist[kMaxShards];
+  if (threadIdx.x < kMaxShards) hist[threadIdx.x] = 0u;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kFrontChunk;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t lt = lane == 0u ? 0ull : (~0ull >> (64u - lane));
+  constexpr int kPer = kFrontChunk / 256;
+  uint64_t idv[kPer];
+  uint32_t repv[kPer], wv[kPer];
+  bool live[kPer];
+  const bool tagged = a.d.n <= (int64_t)(1 << 24);         // positions fit 24 bits: 8 bits of epoch
+#pragma unroll
+  for (int32_t k = 0; k < kPer; ++k) live[k] = DedupLive(a.d, base + (int64_t)k * 256 + threadIdx.x);
+#pragma unroll
+  for (int32_t k = 0; k < kPer; ++k)
+    idv[k] = live[k] ? DedupIdAt(a.d, base + (int64_t)k * 256 + threadIdx.x) : 0ull;
+  if (MODE == 1) {
+#pragma unroll
+    for (int32_t k = 0; k < kPer; ++k)
+      repv[k] = live[k] && idv[k] < a.dense_limit ? a.dense_owner[(uint32_t)idv[k]] : 0u;
+#pragma unroll
+    for (int32_t k = 0; k < kPer; ++k) {
+      const uint32_t i = (uint32_t)(base + (int64_t)k * 256 + threadIdx.x);
+      if (!live[k] || idv[k] >= a.dense_limit) { repv[k] = i; continue; }
+      const uint32_t mine = tagged ? (a.epoch << 24 | i) : i;
+      uint32_t cur = repv[k];
+      for (;;) {
+        if (!tagged || (cur >> 24) == a.epoch) {
+          const uint32_t c = tagged ? (cur & 0xFFFFFFu) : cur;
+          if (DedupLive(a.d, c) && DedupIdAt(a.d, c) == idv[k]) { repv[k] = c; break; }
+        }
+        const uint32_t old = atomicCAS(&a.dense_owner[(uint32_t)idv[k]], cur, mine);
+        if (old == cur) { repv[k] = i; break; }
+        cur = old;
+      }
+    }
+  } else if (MODE == 2) {
+#pragma unroll
+    for (int32_t k = 0; k < kPer; ++k) repv[k] = live[k] ? a.dense_owner[DenseSlot(a, idv[k])] : 0u;
+  } else {
+#pragma unroll
+    for (int32_t k = 0; k < kPer; ++k)
+      repv[k] = live[k] ? DedupRep(a.d, (uint32_t)(base + (int64_t)k * 256 + threadIdx.x)) : 0u;
+  }
+#pragma unroll
+  for (int32_t k = 0; k < kPer; ++k) {
+    const int64_t i = base + (int64_t)k * 256 + threadIdx.x;
+    const bool is_rep = live[k] && repv[k] == (uint32_t)i;
+    const uint32_t own = is_rep ? (uint32_t)OwnerOf(idv[k], a.partitions, a.shards) : 0xFFFFFFFFu;
+    uint32_t rank = 0;
+    for (uint32_t s = 0; s < (uint32_t)a.shards; ++s) {          // (wave-uniform trip count)
+      const bool mine = is_rep && own == s;
+      const uint64_t same = __ballot(mine);
+      if (same == 0ull) continue;
+      const uint32_t first = (uint32_t)__ffsll((unsigned long long)same) - 1u;
+      uint32_t got = 0;
+      if (lane == first) got = atomicAdd(&hist[s], (uint32_t)__popcll(same));
+      got = (uint32_t)__shfl((int)got, (int)first);
+      if (mine) rank = got + (uint32_t)__popcll(same & lt);
+    }
+    wv[k] = is_rep ? (own << 24 | rank) : 0xFFFFFFFFu;           // (rank < 2 048, own < 64)
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < a.shards) {
+    const uint32_t h = hist[threadIdx.x];
+    hist[threadIdx.x] = h != 0u ? atomicAdd(&a.out_lens[threadIdx.x], h) : 0u;     // the chunk's base
+  }
+  __syncthreads();
+#pragma unroll
+  for (int32_t k = 0; k < kPer; ++k) {
+    if (!live[k]) continue;
+    const int64_t i = base + (int64_t)k * 256 + threadIdx.x;
+    if (wv[k] != 0xFFFFFFFFu) {
+      const uint32_t own = wv[k] >> 24;
+      const uint32_t q = own * a.out_stride + 1u + hist[own] + (wv[k] & 0xFFFFFFu);
+      pos_out[i] = (int32_t)q;
+      shard_ids[q] = idv[k];
+    } else {
+      pos_out[i] = (int32_t)~repv[k];
+    }
+  }
+}
+}  // extern "C++"
 
 // Grow-only device scratch per (device, stream) for the front end: it runs
 // twice per hop with very different sizes, and alternating stream-ordered
@@ -1421,33 +1563,25 @@ void euler_gpu_front_destroy(euler_gpu_front* f) {
   delete f;
 }
 
-int euler_gpu_dedup_split_begin(euler_gpu_front* f, void* stream, const uint64_t* ids_dev,
-                                int64_t n, const uint8_t* root_mask_dev, int32_t root_group,
-                                int32_t partitions, int32_t shards,
-                                uint32_t* dense_owner_dev, int64_t dense_limit,
-                                uint64_t* shard_ids_dev, int32_t* pos_dev) {
-  if (!f || n < 0 || partitions <= 0 || shards <= 0 || shards > kMaxShards)
-    return Fail(EULER_GPU_EINVAL, "dedup_split: bad arguments (shards <= 64)");
-  if (f->pending) return Fail(EULER_GPU_EINVAL, "dedup_split: the handle has a call in flight");
-  f->shards = shards;
-  for (int s = 0; s <= shards; ++s) f->stage[s] = 0;
-  if (n == 0) return EULER_GPU_OK;
-  if (n >= (1LL << 30)) return Fail(EULER_GPU_EINVAL, "dedup_split: n >= 2^30");
-  if (!ids_dev || !shard_ids_dev || !pos_dev)
-    return Fail(EULER_GPU_EINVAL, "dedup_split: null buffer");
+// The front end's three launches (dense ids; five with hashing) on `st`.  in_lens / in_stride: the
+// batch is a level in slab layout (DedupIdsArgs); out_stride / out_lens: the buckets leave in slab
+// layout and their sizes stay on the device (FrontArgs), else their starts go to `stage` + `seq`.
+static int FrontEnqueue(hipStream_t st, const uint64_t* ids_dev, int64_t n, const uint8_t* root_mask_dev,
+                        int32_t root_group, const uint32_t* in_lens_dev, uint32_t in_stride,
+                        int32_t partitions, int32_t shards, uint32_t* dense_owner_dev, int64_t dense_limit,
+                        uint64_t* shard_ids_dev, uint32_t out_stride, uint32_t* out_lens_dev,
+                        bool write_headers, int32_t* pos_dev, volatile int64_t* stage_dev, int64_t seq) {
   const bool dense = dense_owner_dev != nullptr;
-  if (dense && (dense_limit <= 0 || dense_limit >= (1LL << 32) - 1))
-    return Fail(EULER_GPU_EINVAL, "dedup_split: dense_limit out of range");
-  hipStream_t st = (hipStream_t)stream;
   uint64_t cap = 1024;
   while (!dense && cap < (uint64_t)n * 4) cap <<= 1;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const int64_t n_chunks = (n + kFrontChunk - 1) / kFrontChunk;
   const size_t o_owner = 0, o_owner2 = o_owner + (dense ? 0 : al(cap * 4));
+  const bool slabs = out_stride != 0u;      // (FrontSlabKernel keeps representatives and places in registers)
   const size_t o_rep = o_owner2 + (dense ? 0 : al(cap * 4));
-  const size_t o_place = o_rep + al((size_t)n * 4);
-  const size_t o_base = o_place + al((size_t)n * 4);
-  const size_t o_total = o_base + al((size_t)n_chunks * shards * 4);
+  const size_t o_place = o_rep + (slabs ? 0 : al((size_t)n * 4));
+  const size_t o_base = o_place + (slabs ? 0 : al((size_t)n * 4));
+  const size_t o_total = o_base + (slabs ? 0 : al((size_t)n_chunks * shards * 4));
   const size_t bytes = o_total + al(kMaxShards * 4);
   StreamScratch* scratch = ScratchEntry(st);
   std::lock_guard<std::mutex> scratch_lk(scratch->mu);
@@ -1463,6 +1597,7 @@ int euler_gpu_dedup_split_begin(euler_gpu_front* f, void* stream, const uint64_t
   a.d.root_mask = root_mask_dev; a.d.root_group = root_group > 0 ? root_group : 1;
   a.d.owner = (uint32_t*)(buf + o_owner);
   a.d.owner2 = (uint32_t*)(buf + o_owner2);
+  a.d.in_lens = in_lens_dev; a.d.in_stride = in_stride;
   a.dense_owner = dense_owner_dev;
   a.dense_limit = (uint64_t)dense_limit;
   a.rep = (uint32_t*)(buf + o_rep);
@@ -1471,9 +1606,29 @@ int euler_gpu_dedup_split_begin(euler_gpu_front* f, void* stream, const uint64_t
   a.total = (uint32_t*)(buf + o_total);
   a.n_chunks = n_chunks;
   a.partitions = partitions; a.shards = shards;
+  a.out_stride = out_stride; a.out_lens = out_lens_dev;
   const int block = 256;
   const int grid = GridFor(n, block);
-  int rc = EULER_GPU_OK;
+  if (out_stride != 0u) {
+    // slabs: one kernel (two mark kernels before it when the ids are hashed)
+    static std::atomic<uint32_t> epoch{0};
+    a.epoch = epoch.fetch_add(1) & 0xFFu;
+    if (dense && euler_gpu::g_front_claim.load() != 0) {
+      hipLaunchKernelGGL(FrontSlabKernel<1>, dim3((unsigned)n_chunks), dim3(256), 0, st, a, shard_ids_dev, pos_dev);
+    } else if (dense) {
+      hipLaunchKernelGGL(FrontMarkDenseKernel, dim3(grid), dim3(block), 0, st, a);
+      hipLaunchKernelGGL(FrontSlabKernel<2>, dim3((unsigned)n_chunks), dim3(256), 0, st, a, shard_ids_dev, pos_dev);
+    } else {
+      hipLaunchKernelGGL(DedupIdsMarkKernel, dim3(grid), dim3(block), 0, st, a.d);
+      hipLaunchKernelGGL(DedupIdsMark2Kernel, dim3(grid), dim3(block), 0, st, a.d);
+      hipLaunchKernelGGL(FrontSlabKernel<0>, dim3((unsigned)n_chunks), dim3(256), 0, st, a, shard_ids_dev, pos_dev);
+    }
+    if (write_headers)
+      hipLaunchKernelGGL(FrontSlabHeadersKernel, dim3(1), dim3(kMaxShards), 0, st, shard_ids_dev, out_stride,
+                         out_lens_dev, shards);
+    if (hipGetLastError() != hipSuccess) return Fail(EULER_GPU_EHIP, "front_slabs: launch failed");
+    return EULER_GPU_OK;
+  }
   if (dense) {
     hipLaunchKernelGGL(FrontMarkDenseKernel, dim3(grid), dim3(block), 0, st, a);
   } else {
@@ -1482,19 +1637,81 @@ int euler_gpu_dedup_split_begin(euler_gpu_front* f, void* stream, const uint64_t
     hipLaunchKernelGGL(DedupIdsMark2Kernel, dim3(grid), dim3(block), 0, st, a.d);
   }
   hipLaunchKernelGGL(FrontRepHistKernel, dim3((unsigned)n_chunks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(FrontPlaceKernel, dim3(grid), dim3(block), 0, st, a, shard_ids_dev, pos_dev, stage_dev, seq);
+  if (hipGetLastError() != hipSuccess) return Fail(EULER_GPU_EHIP, "dedup_split: launch failed");
+  // the scratch stays in use until the stream has run these kernels; whoever
+  // takes the lock next enqueues on the same stream, i.e. after them
+  return EULER_GPU_OK;
+}
+
+int euler_gpu_dedup_split_begin(euler_gpu_front* f, void* stream, const uint64_t* ids_dev,
+                                int64_t n, const uint8_t* root_mask_dev, int32_t root_group,
+                                int32_t partitions, int32_t shards,
+                                uint32_t* dense_owner_dev, int64_t dense_limit,
+                                uint64_t* shard_ids_dev, int32_t* pos_dev) {
+  if (!f || n < 0 || partitions <= 0 || shards <= 0 || shards > kMaxShards)
+    return Fail(EULER_GPU_EINVAL, "dedup_split: bad arguments (shards <= 64)");
+  if (f->pending) return Fail(EULER_GPU_EINVAL, "dedup_split: the handle has a call in flight");
+  f->shards = shards;
+  for (int s = 0; s <= shards; ++s) f->stage[s] = 0;
+  if (n == 0) return EULER_GPU_OK;
+  if (n >= (1LL << 30)) return Fail(EULER_GPU_EINVAL, "dedup_split: n >= 2^30");
+  if (!ids_dev || !shard_ids_dev || !pos_dev)
+    return Fail(EULER_GPU_EINVAL, "dedup_split: null buffer");
+  if (dense_owner_dev != nullptr && (dense_limit <= 0 || dense_limit >= (1LL << 32) - 1))
+    return Fail(EULER_GPU_EINVAL, "dedup_split: dense_limit out of range");
+  hipStream_t st = (hipStream_t)stream;
   f->seq += 1;
-  hipLaunchKernelGGL(FrontPlaceKernel, dim3(grid), dim3(block), 0, st, a, shard_ids_dev, pos_dev,
-                     (volatile int64_t*)f->stage_dev, f->seq);
-  if (hipGetLastError() != hipSuccess) rc = Fail(EULER_GPU_EHIP, "dedup_split: launch failed");
+  int rc = FrontEnqueue(st, ids_dev, n, root_mask_dev, root_group, nullptr, 0, partitions, shards,
+                        dense_owner_dev, dense_limit, shard_ids_dev, 0, nullptr, false, pos_dev,
+                        (volatile int64_t*)f->stage_dev, f->seq);
   if (rc == EULER_GPU_OK) {
     const hipError_t e = hipEventRecord(f->done, st);
     if (e != hipSuccess) rc = Fail(EULER_GPU_EHIP, std::string("dedup_split: ") + hipGetErrorString(e));
     else f->pending = 1;
   }
-  // the scratch stays in use until the stream has run these kernels; whoever
-  // takes the lock next enqueues on the same stream, i.e. after them
   return rc;
 }
+
+}  // extern "C"
+
+namespace euler_gpu {
+__global__ void FrontSlabsEmptyKernel(uint64_t* slabs, uint32_t stride, uint32_t* lens, int32_t shards) {
+  if ((int)threadIdx.x < shards) { slabs[(int64_t)threadIdx.x * stride] = 0ull; lens[threadIdx.x] = 0u; }
+}
+
+// The front end of a hop whose batch and buckets live in SLAB layout, sizes on the device: no
+// host wait (csrc/sharded.cc, the enqueued walk).  ids_dev: n_pos positions, every one an id
+// (in_lens_dev null: level 0) or slabs of in_stride words with entries 1 .. in_lens_dev[slab].
+// Out: slab s of out_slabs_dev (out_stride words: header = the bucket's size, then its ids),
+// out_lens_dev[s] the same size, pos_dev[i] = the word of position i's id among the slabs, or
+// ~r when position r (>= 0 there) holds the same id.  out_lens_dev [shards] must be ZERO when the
+// kernels start (the caller clears a walk's worth of them at once).  write_headers = false
+// leaves the headers alone: a lone rank's owner pass reads out_lens_dev itself.
+int FrontSlabs(hipStream_t st, const uint64_t* ids_dev, int64_t n_pos, const uint32_t* in_lens_dev,
+               uint32_t in_stride, int32_t partitions, int32_t shards, uint32_t* dense_owner_dev,
+               int64_t dense_limit, uint64_t* out_slabs_dev, uint32_t out_stride, uint32_t* out_lens_dev,
+               bool write_headers, int32_t* pos_dev) {
+  if (n_pos < 0 || n_pos >= (1LL << 30) || partitions <= 0 || shards <= 0 || shards > kMaxShards ||
+      out_stride == 0u || (int64_t)out_stride * shards >= (1LL << 30) || !out_slabs_dev || !out_lens_dev ||
+      (in_lens_dev != nullptr && in_stride == 0u))
+    return Fail(EULER_GPU_EINVAL, "front_slabs: bad arguments");
+  if (n_pos == 0) {
+    hipLaunchKernelGGL(FrontSlabsEmptyKernel, dim3(1), dim3(kMaxShards), 0, st, out_slabs_dev, out_stride,
+                       out_lens_dev, shards);
+    EG_HIP(hipGetLastError());
+    return EULER_GPU_OK;
+  }
+  if (!ids_dev || !pos_dev) return Fail(EULER_GPU_EINVAL, "front_slabs: null buffer");
+  if (dense_owner_dev != nullptr && (dense_limit <= 0 || dense_limit >= (1LL << 32) - 1))
+    return Fail(EULER_GPU_EINVAL, "front_slabs: dense_limit out of range");
+  return FrontEnqueue(st, ids_dev, n_pos, nullptr, 1, in_lens_dev, in_stride, partitions, shards,
+                      dense_owner_dev, dense_limit, out_slabs_dev, out_stride, out_lens_dev, write_headers, pos_dev,
+                      nullptr, 0);
+}
+}  // namespace euler_gpu
+
+extern "C" {
 
 int euler_gpu_dedup_split_end(euler_gpu_front* f, int64_t* shard_off_host) {
   if (!f || !shard_off_host) return Fail(EULER_GPU_EINVAL, "dedup_split_end: null");

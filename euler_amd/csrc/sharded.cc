@@ -76,6 +76,9 @@ namespace euler_gpu {
 // ShardedSampler.force_exchange all read and write this one value (key 52 both ways).
 std::atomic<int> g_sharded_self_exchange{-1};
 std::atomic<long long> g_sharded_exchanges{0};     // exchanges made (euler_gpu_sharded_exchange_count)
+// Tuning key 63: the sharded DeepWalk is ENQUEUED - levels and buckets in slab layout, sizes on the
+// device, fixed-size messages - instead of waiting for every step's bucket sizes on the host (0).
+std::atomic<int> g_sharded_walk_enqueued{1};
 }
 namespace {
 bool SelfExchange() {
@@ -166,6 +169,135 @@ struct Scratch {
 };
 
 int32_t PackedWordsHost(int32_t count, int32_t tcol) { return ((3 + tcol) * count + 2 + 1) & ~1; }
+
+// The sharded DeepWalk WITHOUT a host wait per step.  The polled form sizes every step's exchange
+// from the bucket sizes, which the host has to see first: 40 steps x (front end -> wait ->
+// exchange) made the call host-bound (65 us per step for 33 of kernels on one rank, round 5).
+// Here a level never leaves the device:
+//   slab      stride = the largest walker count of a rank's cohort + 1, rounded up to the front
+//             end's chunk: word 0 = how many entries follow, then the entries, then padding.  A
+//             level holds at most as many distinct nodes as the cohort has walkers, so no bucket
+//             outgrows its slab - whatever the batch looks like (all roots on one owner included);
+//   step s    front end over level s (FrontSlabs, ONE kernel with an id-indexed table: W slabs
+//             out, one per owner, + the sizes as the next level's lens) -> W equal messages -> the
+//             owners draw over the slabs they got (WalkOwnedSlabs reads the headers) -> W equal
+//             messages back INTO level s + 1, whose slabs are the answers in the order asked;
+//             next[s][e] = the word of e's answer (or ~ the entry that holds the same node).
+// One host exchange per CALL (the ranks' walker counts, which fix the stride) instead of one per
+// step; the price is padding on the wire - W x stride words per message round where the polled
+// form sends the level's distinct nodes (1M walkers on 8 ranks: 8 x 1 MB per rank, step and
+// direction ~ 10 us of xGMI, against a host round trip + the counts mailbox).
+int WalkEnqueued(const euler_gpu_graph* shard, const euler_gpu_transport* tr, hipStream_t st,
+                 uint64_t seed, uint32_t call_id, const int64_t* starts_dev, int64_t n,
+                 const int32_t* et_dev, int32_t k, int32_t L, int64_t default_node, int32_t partitions,
+                 int32_t K, uint32_t* dense_owner_dev, int64_t dense_limit, int64_t* out_dev,
+                 int64_t* stats_host, bool lone, Scratch& sc) {
+  const int32_t W = tr->world;
+  int64_t waits = 0;
+  std::vector<int64_t> n_of((size_t)W, n);
+  if (!lone) {
+    std::vector<int64_t> mine((size_t)W, n);
+    const int rc = tr->alltoall_counts(tr->user, mine.data(), n_of.data());
+    if (rc != EULER_GPU_OK) return rc;
+    ++waits;
+  }
+  struct Cohort {
+    int64_t lo = 0, n = 0;
+    uint32_t stride = 0;                         // 0: no rank has a walker in this cohort
+    std::vector<const uint64_t*> ids;            // [L + 1] levels (0 = the walkers' start nodes, plain)
+    std::vector<const int32_t*> next;            // [L]
+    uint64_t* bucketed = nullptr;                // [W, stride] the step's ids by owner
+    uint64_t* owned = nullptr;                   // [W, stride] what the peers ask of this rank
+    uint64_t* drawn = nullptr;                   // [W, stride] its answers
+    uint32_t* lens = nullptr;                    // [L + 1, W] lens[s] = entries of level s's slabs (s >= 1)
+  };
+  std::vector<Cohort> co((size_t)K);
+  for (int32_t c = 0; c < K; ++c) {
+    Cohort& q = co[(size_t)c];
+    q.lo = n * c / K; q.n = n * (c + 1) / K - q.lo;
+    int64_t cap = 0;
+    for (int32_t p = 0; p < W; ++p) {
+      const int64_t np = n_of[(size_t)p] * (c + 1) / K - n_of[(size_t)p] * c / K;
+      if (np > cap) cap = np;
+    }
+    q.ids.assign((size_t)L + 1, nullptr); q.next.assign((size_t)(L > 0 ? L : 1), nullptr);
+    q.ids[0] = (const uint64_t*)starts_dev + q.lo;
+    if (cap == 0 || L == 0) continue;
+    const int64_t stride = (cap + 1 + 2047) & ~(int64_t)2047;
+    if (stride * W >= ((int64_t)1 << 30))
+      return Fail(EULER_GPU_EINVAL, "sharded_random_walk: walkers x ranks >= 2^30 (key 63 = 0 takes the polled form)");
+    q.stride = (uint32_t)stride;
+    const size_t slab = (size_t)stride * W;
+    // levels 1 .. L and the step's buckets (8 bytes a word), next 0 .. L - 1 (4), the lens
+    const size_t bytes = slab * 8 * ((size_t)L + 1 + (lone ? 0 : 2)) + ((size_t)(q.n > 0 ? q.n : 1) + slab * (L - 1)) * 4 +
+                         (size_t)(L + 1) * W * 4 + 1024;
+    uint8_t* p8 = (uint8_t*)sc.Get(bytes);
+    if (!p8) { (void)hipGetLastError(); return Fail(EULER_GPU_ENOMEM, "sharded_random_walk: scratch"); }
+    for (int32_t s = 1; s <= L; ++s) { q.ids[(size_t)s] = (const uint64_t*)p8; p8 += slab * 8; }
+    q.bucketed = (uint64_t*)p8; p8 += slab * 8;
+    if (!lone) { q.owned = (uint64_t*)p8; p8 += slab * 8; q.drawn = (uint64_t*)p8; p8 += slab * 8; }
+    q.next[0] = (const int32_t*)p8; p8 += (size_t)(q.n > 0 ? q.n : 1) * 4;
+    for (int32_t s = 1; s < L; ++s) { q.next[(size_t)s] = (const int32_t*)p8; p8 += slab * 4; }
+    p8 = (uint8_t*)(((uintptr_t)p8 + 255) & ~(uintptr_t)255);
+    q.lens = (uint32_t*)p8;
+    // (the front end adds its buckets' sizes to lens[s + 1]: one clear per call)
+    if (hipMemsetAsync(q.lens, 0, (size_t)(L + 1) * W * 4, st) != hipSuccess)
+      return Fail(EULER_GPU_EHIP, "sharded_random_walk: clearing the level sizes failed");
+  }
+  std::vector<int64_t> rows((size_t)W);
+  for (int32_t s = 0; s < L; ++s) {
+    for (int32_t c = 0; c < K; ++c) {
+      Cohort& q = co[(size_t)c];
+      if (q.stride == 0u) continue;              // (the same on every rank: nobody exchanges)
+      const int64_t slab = (int64_t)q.stride * W;
+      uint64_t* level = const_cast<uint64_t*>(q.ids[(size_t)s + 1]);
+      int rc = euler_gpu::FrontSlabs(st, q.ids[(size_t)s], s == 0 ? q.n : slab, s == 0 ? nullptr : q.lens + (size_t)s * W,
+                                     q.stride, partitions, W, dense_owner_dev, dense_limit, q.bucketed, q.stride,
+                                     q.lens + (size_t)(s + 1) * W, !lone, const_cast<int32_t*>(q.next[(size_t)s]));
+      if (rc != EULER_GPU_OK) return rc;
+      if (lone) {
+        rc = euler_gpu::WalkOwnedSlabs(shard, st, seed, call_id, et_dev, k, L, s, q.bucketed,
+                                       q.lens + (size_t)(s + 1) * W, W, q.stride, level);
+        if (rc != EULER_GPU_OK) return rc;
+        continue;
+      }
+      for (int32_t p = 0; p < W; ++p) rows[(size_t)p] = (int64_t)q.stride;
+      rc = tr->alltoallv(tr->user, q.bucketed, rows.data(), q.owned, rows.data(), 8, st);
+      if (rc != EULER_GPU_OK) return rc;
+      rc = euler_gpu::WalkOwnedSlabs(shard, st, seed, call_id, et_dev, k, L, s, q.owned, nullptr, W, q.stride, q.drawn);
+      if (rc != EULER_GPU_OK) return rc;
+      rc = tr->alltoallv(tr->user, q.drawn, rows.data(), level, rows.data(), 8, st);
+      if (rc != EULER_GPU_OK) return rc;
+    }
+  }
+  for (int32_t c = 0; c < K; ++c) {
+    Cohort& q = co[(size_t)c];
+    if (q.n == 0) continue;
+    const int rc = euler_gpu::WalkPathsFromLevels(st, starts_dev + q.lo, q.n, L, q.ids.data(), q.next.data(),
+                                                  default_node, out_dev + q.lo * ((int64_t)L + 1));
+    if (rc != EULER_GPU_OK) return rc;
+  }
+  if (stats_host) {
+    // (asked for: one wait at the END of the call for the sizes the device kept to itself)
+    int64_t entries = 0, wire_ids = 0;
+    std::vector<uint32_t> lens((size_t)(L + 1) * W);
+    for (int32_t c = 0; c < K; ++c) {
+      const Cohort& q = co[(size_t)c];
+      if (q.stride == 0u) continue;
+      EG_HIP(hipMemcpyAsync(lens.data(), q.lens, lens.size() * 4, hipMemcpyDeviceToHost, st));
+      EG_HIP(hipStreamSynchronize(st));
+      entries += q.n;
+      for (int32_t s = 1; s <= L; ++s)
+        for (int32_t p = 0; p < W; ++p) {
+          const int64_t v = (int64_t)lens[(size_t)s * W + p];
+          if (s < L) entries += v;
+          if (p != tr->rank) wire_ids += v;
+        }
+    }
+    stats_host[0] = waits; stats_host[1] = entries; stats_host[2] = wire_ids; stats_host[3] = K;
+  }
+  return EULER_GPU_OK;
+}
 
 }  // namespace
 
@@ -352,6 +484,9 @@ int euler_gpu_sharded_random_walk(const euler_gpu_graph* shard, const euler_gpu_
     if (rc != EULER_GPU_OK) return rc;
     sc.ptrs.push_back(et_dev);
   }
+  if (euler_gpu::g_sharded_walk_enqueued.load() != 0)
+    return WalkEnqueued(shard, tr, st, seed, call_id, starts_dev, n, et_dev, k, L, default_node, partitions,
+                        K, dense_owner_dev, dense_limit, out_dev, stats_host, lone, sc);
   struct Cohort {
     int64_t lo = 0, n = 0, m = 0;                // walkers; entries of the current level
     euler_gpu_front* front = nullptr;

@@ -1,6 +1,7 @@
 // SampleNode, GetFullNeighbor, RandomWalk / node2vec and gen_pair kernels for
 // gfx950 with their C-ABI entry points.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <hipcub/hipcub.hpp>
 
 #include <cmath>
@@ -412,6 +413,7 @@ thread_local int g_walk_collapse = 262144;
 thread_local int g_walk_lean = 1;         // key 44: plain graphs draw with the lean search of the one-kernel fanout
 thread_local int g_walk_tail = 9;         // key 43: first step of the merged walk that stops looking for mergers
                                           // (the rest of the walk is one launch; 0 = never)
+std::atomic<int> g_walk_path_ch{16};      // key 64: columns the sharded walk's path kernel parks in LDS at a time
 thread_local int g_walk_grid = 1024;      // key 39: workgroups of its per-step launches (0 = one per 256 walkers)
 
 struct WalkArgs {
@@ -874,6 +876,23 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void WalkOwnedKernel(const CwAr
     out[i] = CwDraw<MODE>(a, ids[i], a.step);
 }
 
+// the same draw over SLABS of ids (the walk enqueued without host waits): word 0 of a slab = the
+// number of ids behind it, the rest of the slab is padding nobody reads
+template <int MODE>
+__global__ __launch_bounds__(256, kWavesPerSimd) void WalkOwnedSlabKernel(const CwArgs a,
+                                                                          const uint64_t* __restrict__ ids,
+                                                                          const uint32_t* __restrict__ lens,
+                                                                          const uint32_t stride,
+                                                                          const int64_t n_pos,
+                                                                          uint64_t* __restrict__ out) {
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pos; i += step) {
+    const uint32_t p = (uint32_t)i / stride, j = (uint32_t)i - p * stride;
+    if (j == 0u || (uint64_t)j > (lens != nullptr ? (uint64_t)lens[p] : ids[(int64_t)p * stride])) continue;
+    out[i] = CwDraw<MODE>(a, ids[i], a.step);
+  }
+}
+
 constexpr int kShPathLevels = 120;  // levels whose pointers travel as kernel arguments
 struct ShPathArgs {
   const int64_t* starts;            // [n] level 0
@@ -914,6 +933,7 @@ __global__ __launch_bounds__(256) void ShWalkPathKernel(const ShPathArgs a) {
             v = (uint64_t)a.starts[w0 + lane];
           } else {
             p = (uint32_t)lvl_next[col - 1][p];
+            if ((int32_t)p < 0) p = (uint32_t)lvl_next[col - 1][~p];    // (slab levels: ~representative)
             v = lvl_ids[col][p];
             if (v == 0) v = (uint64_t)a.default_node;
           }
@@ -943,9 +963,10 @@ int WalkEdgeTypes(hipStream_t st, const int32_t* edge_types_host, int32_t k, int
   return EULER_GPU_OK;
 }
 
-int WalkOwnedStep(const euler_gpu_graph* g, hipStream_t st, uint64_t seed, uint32_t call_id,
-                  const int32_t* et_dev, int32_t k, int32_t walk_len, int32_t step,
-                  const uint64_t* ids_dev, int64_t n, uint64_t* out_dev) {
+static int WalkOwnedLaunch(const euler_gpu_graph* g, hipStream_t st, uint64_t seed, uint32_t call_id,
+                           const int32_t* et_dev, int32_t k, int32_t walk_len, int32_t step,
+                           const uint64_t* ids_dev, int64_t n, const uint32_t* slab_lens, uint32_t slab_stride,
+                           uint64_t* out_dev) {
   if (n <= 0) return EULER_GPU_OK;
   CwArgs c{};
   {
@@ -961,14 +982,36 @@ int WalkOwnedStep(const euler_gpu_graph* g, hipStream_t st, uint64_t seed, uint3
                 v.uniform_w == 0 && v.n_edges < ((int64_t)1 << 31)) ? 2 : 1;
   if (mode == 2 && c.g.wrec != nullptr && c.g.wb != nullptr && c.g.wb_lean_ok != 0) mode = 3;
   if (mode == 2 && c.g.blk == nullptr) mode = 1;      // (the lean search of mode 2 walks the EdgeBlocks' levels)
-  auto kern = mode == 3 ? WalkOwnedKernel<3> : mode == 2 ? WalkOwnedKernel<2>
-              : mode == 1 ? WalkOwnedKernel<1> : WalkOwnedKernel<0>;
   const int block = 256;
   unsigned grid = (unsigned)((n + block - 1) / block);
   if (grid > 4096u) grid = 4096u;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, st, c, ids_dev, n, out_dev);
+  if (slab_stride != 0u) {
+    auto kern = mode == 3 ? WalkOwnedSlabKernel<3> : mode == 2 ? WalkOwnedSlabKernel<2>
+                : mode == 1 ? WalkOwnedSlabKernel<1> : WalkOwnedSlabKernel<0>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, st, c, ids_dev, slab_lens, slab_stride, n, out_dev);
+  } else {
+    auto kern = mode == 3 ? WalkOwnedKernel<3> : mode == 2 ? WalkOwnedKernel<2>
+                : mode == 1 ? WalkOwnedKernel<1> : WalkOwnedKernel<0>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, st, c, ids_dev, n, out_dev);
+  }
   EG_HIP(hipGetLastError());
   return EULER_GPU_OK;
+}
+
+int WalkOwnedStep(const euler_gpu_graph* g, hipStream_t st, uint64_t seed, uint32_t call_id,
+                  const int32_t* et_dev, int32_t k, int32_t walk_len, int32_t step,
+                  const uint64_t* ids_dev, int64_t n, uint64_t* out_dev) {
+  return WalkOwnedLaunch(g, st, seed, call_id, et_dev, k, walk_len, step, ids_dev, n, nullptr, 0u, out_dev);
+}
+
+int WalkOwnedSlabs(const euler_gpu_graph* g, hipStream_t st, uint64_t seed, uint32_t call_id,
+                   const int32_t* et_dev, int32_t k, int32_t walk_len, int32_t step,
+                   const uint64_t* slabs_dev, const uint32_t* lens_dev, int32_t n_slabs, uint32_t stride,
+                   uint64_t* out_dev) {
+  if (n_slabs <= 0 || stride == 0u || (int64_t)n_slabs * stride >= ((int64_t)1 << 32))
+    return Fail(EULER_GPU_EINVAL, "walk_owned_slabs: bad arguments");
+  return WalkOwnedLaunch(g, st, seed, call_id, et_dev, k, walk_len, step, slabs_dev,
+                         (int64_t)n_slabs * stride, lens_dev, stride, out_dev);
 }
 
 int WalkPathsFromLevels(hipStream_t st, const int64_t* starts_dev, int64_t n, int32_t walk_len,
@@ -993,12 +1036,16 @@ int WalkPathsFromLevels(hipStream_t st, const int64_t* starts_dev, int64_t n, in
     a.ids = (const uint64_t* const*)tab;
     a.next = (const int32_t* const*)((uint8_t*)tab + tb);
   }
+  // The kernel is a chain of walk_len dependent 4-byte loads per walker: it wants WAVES in flight,
+  // not a wide tile.  16 columns at a time (128-byte runs of a walker's row, 8.7 KB of LDS a wave:
+  // 16+ waves a CU) against the whole row (41 columns = 21 KB: 6 waves a CU, 585 us for 1M x 40).
   const int32_t L1 = walk_len + 1;
-  a.ch = L1 < 64 ? L1 : 64;
+  const int32_t ch_max = g_walk_path_ch.load();
+  a.ch = L1 < ch_max ? L1 : ch_max;
   a.div_ch.Set((uint32_t)a.ch);
   a.div_last.Set((uint32_t)(L1 % a.ch == 0 ? a.ch : L1 % a.ch));
   const size_t wave_bytes = (size_t)64 * (a.ch | 1) * 8;
-  const int waves = wave_bytes * 2 <= 64 * 1024 ? 2 : 1;
+  const int waves = wave_bytes * 4 <= 64 * 1024 ? 4 : wave_bytes * 2 <= 64 * 1024 ? 2 : 1;
   const int64_t tiles = (n + 63) / 64, wgs = (tiles + waves - 1) / waves;
   hipLaunchKernelGGL(ShWalkPathKernel, dim3((unsigned)(wgs < 65536 ? wgs : 65536)), dim3(64 * waves),
                      wave_bytes * waves, st, a);

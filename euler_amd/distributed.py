@@ -1176,7 +1176,7 @@ def c_sharded_random_walk(graph, transport, starts, edge_types, default_node=-1,
             int(call_id) & 0xFFFFFFFF, C.c_void_p(starts.data_ptr()), n, et.ctypes.data_as(_lib.i32p), k,
             walk_len, int(default_node), int(partitions or transport.world), int(cohorts),
             C.c_void_p(dense_table.data_ptr()) if dense_table is not None else None, limit,
-            C.c_void_p(out.data_ptr()), stats))
+            C.c_void_p(out.data_ptr()), stats if return_stats else None))
     if return_stats:
         return out, {"host_waits": int(stats[0]), "level_entries": int(stats[1]),
                      "ids_sent": int(stats[2]), "cohorts": int(stats[3])}

@@ -102,7 +102,7 @@ int main(int argc, char** argv) {
     CHECK(hipMemcpy(gotw.data(), w2, n2 * 4, hipMemcpyDeviceToHost) == hipSuccess);
     // configs[3] from the same host: DeepWalk, random_walk of length 40 (p = q = 1) from the
     // batch's roots over the sharded graph (tf_euler/kernels/random_walk_op.cc:207-247) - one C
-    // call per rank, two cohorts of walkers whose steps alternate on the stream
+    // call per rank (two cohorts of walkers whose steps alternate on the stream)
     const int32_t WL = 40;
     std::vector<int32_t> wet((size_t)WL, 0);
     int64_t* d_walk = nullptr;
@@ -113,7 +113,9 @@ int main(int argc, char** argv) {
     CHECK(hipStreamSynchronize(st) == hipSuccess);
     std::vector<int64_t> gotwalk((size_t)B * (WL + 1));
     CHECK(hipMemcpy(gotwalk.data(), d_walk, gotwalk.size() * 8, hipMemcpyDeviceToHost) == hipSuccess);
-    CHECK(wstats[0] == 2 * WL);                       // one host wait per step and cohort
+    // the walk is ENQUEUED: one host exchange per call (the ranks' walker counts; none when this rank
+    // is alone and skips its exchanges) - euler_gpu_set_tuning(63, 0) waits once per step and cohort
+    CHECK(wstats[0] <= 1 && wstats[1] > 0);
     // the same roots on the unsharded graph (device 0)
     static std::mutex mu;
     std::lock_guard<std::mutex> lk(mu);

@@ -56,5 +56,5 @@ def test_bench_sharded_workloads_on_one_rank(torch_cuda):
     line = _run(small + ["--batch", "8192", "--workload", "hetero"])
     assert line["roofline"]["frac"] > 0 and len(line["roofline"]["launches"]) == 3
     line = _run(small + ["--workload", "deepwalk"])
-    assert line["roofline"]["frac"] > 0 and line["config"]["walk_stats"]["host_waits"] == 40
+    assert line["roofline"]["frac"] > 0 and line["config"]["walk_stats"]["host_waits"] == 0   # (enqueued: key 63)
     assert line["config"]["parity_checked_steps"] == 64 * 40

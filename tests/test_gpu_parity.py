@@ -1213,8 +1213,9 @@ def test_sage_blocks_fused_flow(EA, O, torch_cuda, big_pair):
         roots = np.concatenate([rng.choice(ids, 300), [0, 10 ** 13 + 5], rng.choice(ids, 20)]).astype(np.int64)
         roots[5] = roots[6]
         fanouts, metapath, max_id = [5, 4], [[0], [2]], 10 ** 13
-        for fused in (1, 0):
-            _lib.check(L.euler_gpu_set_tuning(60, fused))
+        for fused in (1, 2, 0):                 # 2: fused, ids with a row through the hop's own table (key 62)
+            _lib.check(L.euler_gpu_set_tuning(60, min(fused, 1)))
+            _lib.check(L.euler_gpu_set_tuning(62, 1 if fused == 2 else 0))
             for loops in (True, False):
                 G.set_seed(79, call_id=700)
                 df = EA.dataflow.SageDataFlow(G, fanouts, metapath, add_self_loops=loops, max_id=max_id)(
@@ -1240,8 +1241,9 @@ def test_sage_blocks_fused_flow(EA, O, torch_cuda, big_pair):
         Gs = EA.Graph.synthetic(p)
         r = torch.as_tensor(np.concatenate([np.random.default_rng(4).integers(1, 300001, 20000), [0, 300001, 7, 7]])).cuda()
         outs = []
-        for fused in (1, 0, 1):
-            _lib.check(L.euler_gpu_set_tuning(60, fused))
+        for fused in (1, 0, 2):
+            _lib.check(L.euler_gpu_set_tuning(60, min(fused, 1)))
+            _lib.check(L.euler_gpu_set_tuning(62, 1 if fused == 2 else 0))
             Gs.set_seed(5, call_id=40)
             df = EA.dataflow.SageDataFlow(Gs, [25, 10], [[0], [0]], add_self_loops=True, max_id=300000)(r)
             outs.append([(t2n(b.n_id), t2n(b.res_n_id), t2n(b.edge_index)) for b in df.blocks])
@@ -1251,6 +1253,7 @@ def test_sage_blocks_fused_flow(EA, O, torch_cuda, big_pair):
         assert max(len(x[0]) for x in outs[0]) > 50000
     finally:
         L.euler_gpu_set_tuning(60, 1)
+        L.euler_gpu_set_tuning(62, 2)
 
 
 def test_sage_blocks_two_host_threads_one_stream(EA, torch_cuda):

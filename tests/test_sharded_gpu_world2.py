@@ -168,13 +168,31 @@ def _worker_body(rank, world, port, partitions):
     from euler_amd.distributed import c_sharded_random_walk
     assert getattr(S, "c_walk_fn", None) is not None
     trw = CTransport()
-    for cohorts, dense in ((1, S.dense_table), (3, None)):
-        gotc, stats = c_sharded_random_walk(G_shard, trw, starts, etw, N + 1, 100, partitions, cohorts,
-                                            dense, return_stats=True)
-        assert torch.equal(gotc, want), ("C walk", cohorts)
-        assert stats["host_waits"] == cohorts * L and stats["ids_sent"] > 0
-        # merged walkers: the levels hold fewer entries than walkers x steps
-        assert stats["level_entries"] < starts.numel() * L
+    # round 6: the walk ENQUEUED (tuning key 63, the default: levels and buckets in slab layout,
+    # fixed-size messages, ONE host exchange per call - the ranks' walker counts) and the polled
+    # form (a wait for every step's bucket sizes): the same walks, the same level sizes
+    from euler_amd import _lib
+    seen = {}
+    for enq in (1, 0):
+        _lib.check(_lib.lib().euler_gpu_set_tuning(63, enq))
+        for cohorts, dense in ((1, S.dense_table), (3, None)):
+            gotc, stats = c_sharded_random_walk(G_shard, trw, starts, etw, N + 1, 100, partitions, cohorts,
+                                                dense, return_stats=True)
+            assert torch.equal(gotc, want), ("C walk", enq, cohorts)
+            assert stats["host_waits"] == (1 if enq else cohorts * L) and stats["ids_sent"] > 0
+            # merged walkers: the levels hold fewer entries than walkers x steps
+            assert stats["level_entries"] < starts.numel() * L
+            # (the dense table merges every duplicate, the hash front end nearly all: compare like with like)
+            seen.setdefault(cohorts, []).append((stats["level_entries"], stats["ids_sent"]))
+        mine_w = starts[:900] if rank != 0 else starts[:0]
+        gotc = c_sharded_random_walk(G_shard, trw, mine_w, etw[:7], N + 1, 100, partitions, 2, S.dense_table)
+        assert torch.equal(gotc, G_full.random_walk(mine_w, etw[:7], 1.0, 1.0, N + 1, call_id=100))
+        # all walkers of the call on one rank, all starting on nodes of ONE owner: a bucket as large as the batch
+        own0 = starts[(starts % partitions) % world == 0][:500] if rank == 1 % world else starts[:0]
+        gotc = c_sharded_random_walk(G_shard, trw, own0, etw[:5], N + 1, 100, partitions, 1, None)
+        assert torch.equal(gotc, G_full.random_walk(own0, etw[:5], 1.0, 1.0, N + 1, call_id=100))
+    assert seen[1][0] == seen[1][1], seen                     # dense table: exact in both forms
+    _lib.check(_lib.lib().euler_gpu_set_tuning(63, 1))
     mine_w = starts[:900] if rank != 0 else starts[:0]
     gotc = c_sharded_random_walk(G_shard, trw, mine_w, etw[:7], N + 1, 100, partitions, 2, S.dense_table)
     assert torch.equal(gotc, G_full.random_walk(mine_w, etw[:7], 1.0, 1.0, N + 1, call_id=100))
@@ -403,9 +421,10 @@ def test_eight_ranks_partitions_1024_c_entries_on_one_gpu(torch_cuda, tmp_path):
     assert not errs, "\n".join(errs)
     logs = [json.load(open(str(tmp_path / ("callbacks_rank%d.json" % r)))) for r in range(world)]
     assert all(l == logs[0] for l in logs[1:]), "ranks made different sequences of transport callbacks"
-    # per batch: fanout 2 hops x (counts, ids, rows) + walk 12 x (counts, ids, answers) + node2vec
-    # 4 x (counts, ids, lengths, counts, ids, weights)
-    assert len(logs[0]) == 3 * (2 * 3 + 12 * 3 + 4 * 6)
+    # per batch: fanout 2 hops x (counts, ids, rows) + the enqueued walk's ONE counts exchange
+    # (the ranks' walker counts) + 12 x (ids, answers) + node2vec 4 x (counts, ids, lengths,
+    # counts, ids, weights)
+    assert len(logs[0]) == 3 * (2 * 3 + 1 + 12 * 2 + 4 * 6)
 
 
 @pytest.mark.parametrize("world,partitions", [(2, 2), (2, 6), (3, 3)])
