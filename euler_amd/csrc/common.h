@@ -296,7 +296,7 @@ int WalkPathsFromLevels(hipStream_t st, const int64_t* starts_dev, int64_t n, in
 int FrontSlabs(hipStream_t st, const uint64_t* ids_dev, int64_t n_pos, const uint32_t* in_lens_dev,
                uint32_t in_stride, int32_t partitions, int32_t shards, uint32_t* dense_owner_dev,
                int64_t dense_limit, uint64_t* out_slabs_dev, uint32_t out_stride, uint32_t* out_lens_dev,
-               bool write_headers, int32_t* pos_dev);
+               bool write_headers, bool dedup, int32_t* pos_dev);
 int WalkOwnedSlabs(const euler_gpu_graph* g, hipStream_t st, uint64_t seed, uint32_t call_id,
                    const int32_t* et_dev, int32_t k, int32_t walk_len, int32_t step,
                    const uint64_t* slabs_dev, const uint32_t* lens_dev, int32_t n_slabs, uint32_t stride,

@@ -1384,6 +1384,8 @@ __global__ __launch_bounds__(256) void FrontPlaceKernel(const FrontArgs a, uint6
 // base from the shard's total - bucket starts are fixed, no second pass over the totals:
 //   rep     MODE 0 (hashed ids): DedupRep over the tables the two mark kernels wrote;
 //           MODE 2 (id-indexed table): the entry FrontMarkDenseKernel left - the default;
+//           MODE 3: every position represents itself (no mark pass, no table: the late levels of
+//           a walk, which hold few new duplicates - the buckets are only split by owner);
 //           MODE 1 (id-indexed table, tuning key 65): a single pass - read the slot; an entry of this call's
 //           epoch that names a live position holding the same id is the representative (checked
 //           by CONTENT: the 8-bit epoch only spares stale entries the look at ids[]); anything
@@ -1448,6 +1450,9 @@ __global__ __launch_bounds__(256) void FrontSlabKernel(const FrontArgs a, uint64
   } else if (MODE == 2) {
 #pragma unroll
     for (int32_t k = 0; k < kPer; ++k) repv[k] = live[k] ? a.dense_owner[DenseSlot(a, idv[k])] : 0u;
+  } else if (MODE == 3) {
+#pragma unroll
+    for (int32_t k = 0; k < kPer; ++k) repv[k] = (uint32_t)(base + (int64_t)k * 256 + threadIdx.x);
   } else {
 #pragma unroll
     for (int32_t k = 0; k < kPer; ++k)
@@ -1570,7 +1575,8 @@ static int FrontEnqueue(hipStream_t st, const uint64_t* ids_dev, int64_t n, cons
                         int32_t root_group, const uint32_t* in_lens_dev, uint32_t in_stride,
                         int32_t partitions, int32_t shards, uint32_t* dense_owner_dev, int64_t dense_limit,
                         uint64_t* shard_ids_dev, uint32_t out_stride, uint32_t* out_lens_dev,
-                        bool write_headers, int32_t* pos_dev, volatile int64_t* stage_dev, int64_t seq) {
+                        bool write_headers, bool dedup, int32_t* pos_dev, volatile int64_t* stage_dev,
+                        int64_t seq) {
   const bool dense = dense_owner_dev != nullptr;
   uint64_t cap = 1024;
   while (!dense && cap < (uint64_t)n * 4) cap <<= 1;
@@ -1613,7 +1619,9 @@ static int FrontEnqueue(hipStream_t st, const uint64_t* ids_dev, int64_t n, cons
     // slabs: one kernel (two mark kernels before it when the ids are hashed)
     static std::atomic<uint32_t> epoch{0};
     a.epoch = epoch.fetch_add(1) & 0xFFu;
-    if (dense && euler_gpu::g_front_claim.load() != 0) {
+    if (!dedup) {
+      hipLaunchKernelGGL(FrontSlabKernel<3>, dim3((unsigned)n_chunks), dim3(256), 0, st, a, shard_ids_dev, pos_dev);
+    } else if (dense && euler_gpu::g_front_claim.load() != 0) {
       hipLaunchKernelGGL(FrontSlabKernel<1>, dim3((unsigned)n_chunks), dim3(256), 0, st, a, shard_ids_dev, pos_dev);
     } else if (dense) {
       hipLaunchKernelGGL(FrontMarkDenseKernel, dim3(grid), dim3(block), 0, st, a);
@@ -1663,7 +1671,7 @@ int euler_gpu_dedup_split_begin(euler_gpu_front* f, void* stream, const uint64_t
   hipStream_t st = (hipStream_t)stream;
   f->seq += 1;
   int rc = FrontEnqueue(st, ids_dev, n, root_mask_dev, root_group, nullptr, 0, partitions, shards,
-                        dense_owner_dev, dense_limit, shard_ids_dev, 0, nullptr, false, pos_dev,
+                        dense_owner_dev, dense_limit, shard_ids_dev, 0, nullptr, false, true, pos_dev,
                         (volatile int64_t*)f->stage_dev, f->seq);
   if (rc == EULER_GPU_OK) {
     const hipError_t e = hipEventRecord(f->done, st);
@@ -1687,11 +1695,12 @@ __global__ void FrontSlabsEmptyKernel(uint64_t* slabs, uint32_t stride, uint32_t
 // out_lens_dev[s] the same size, pos_dev[i] = the word of position i's id among the slabs, or
 // ~r when position r (>= 0 there) holds the same id.  out_lens_dev [shards] must be ZERO when the
 // kernels start (the caller clears a walk's worth of them at once).  write_headers = false
-// leaves the headers alone: a lone rank's owner pass reads out_lens_dev itself.
+// leaves the headers alone: a lone rank's owner pass reads out_lens_dev itself.  dedup = false:
+// every position is sent (equal ids are asked for once each).
 int FrontSlabs(hipStream_t st, const uint64_t* ids_dev, int64_t n_pos, const uint32_t* in_lens_dev,
                uint32_t in_stride, int32_t partitions, int32_t shards, uint32_t* dense_owner_dev,
                int64_t dense_limit, uint64_t* out_slabs_dev, uint32_t out_stride, uint32_t* out_lens_dev,
-               bool write_headers, int32_t* pos_dev) {
+               bool write_headers, bool dedup, int32_t* pos_dev) {
   if (n_pos < 0 || n_pos >= (1LL << 30) || partitions <= 0 || shards <= 0 || shards > kMaxShards ||
       out_stride == 0u || (int64_t)out_stride * shards >= (1LL << 30) || !out_slabs_dev || !out_lens_dev ||
       (in_lens_dev != nullptr && in_stride == 0u))
@@ -1706,7 +1715,8 @@ int FrontSlabs(hipStream_t st, const uint64_t* ids_dev, int64_t n_pos, const uin
   if (dense_owner_dev != nullptr && (dense_limit <= 0 || dense_limit >= (1LL << 32) - 1))
     return Fail(EULER_GPU_EINVAL, "front_slabs: dense_limit out of range");
   return FrontEnqueue(st, ids_dev, n_pos, nullptr, 1, in_lens_dev, in_stride, partitions, shards,
-                      dense_owner_dev, dense_limit, out_slabs_dev, out_stride, out_lens_dev, write_headers, pos_dev,
+                      dense_owner_dev, dense_limit, out_slabs_dev, out_stride, out_lens_dev, write_headers, dedup,
+                      pos_dev,
                       nullptr, 0);
 }
 }  // namespace euler_gpu

@@ -79,6 +79,12 @@ std::atomic<long long> g_sharded_exchanges{0};     // exchanges made (euler_gpu_
 // Tuning key 63: the sharded DeepWalk is ENQUEUED - levels and buckets in slab layout, sizes on the
 // device, fixed-size messages - instead of waiting for every step's bucket sizes on the host (0).
 std::atomic<int> g_sharded_walk_enqueued{1};
+// Tuning key 66: first step of the enqueued walk whose level is sent as it is - no search for
+// nodes that several entries share (the single-GPU walk's key 43 rule: late levels hold few NEW
+// mergers, and a step's mark pass + table look cost more than the duplicate draws they save).
+// 0 = every step deduplicates.  1M x 40 on one rank: 1.86 ms with 0, 1.90 / 1.76 / 1.715 / 1.72 /
+// 1.76 / 1.80 with 9 / 12 / 16 / 20 / 28 / 32 (profiles/r6_walk_tail_ab.txt).
+std::atomic<int> g_sharded_walk_tail{16};
 }
 namespace {
 bool SelfExchange() {
@@ -245,6 +251,7 @@ int WalkEnqueued(const euler_gpu_graph* shard, const euler_gpu_transport* tr, hi
       return Fail(EULER_GPU_EHIP, "sharded_random_walk: clearing the level sizes failed");
   }
   std::vector<int64_t> rows((size_t)W);
+  const int32_t tail = euler_gpu::g_sharded_walk_tail.load();
   for (int32_t s = 0; s < L; ++s) {
     for (int32_t c = 0; c < K; ++c) {
       Cohort& q = co[(size_t)c];
@@ -253,7 +260,8 @@ int WalkEnqueued(const euler_gpu_graph* shard, const euler_gpu_transport* tr, hi
       uint64_t* level = const_cast<uint64_t*>(q.ids[(size_t)s + 1]);
       int rc = euler_gpu::FrontSlabs(st, q.ids[(size_t)s], s == 0 ? q.n : slab, s == 0 ? nullptr : q.lens + (size_t)s * W,
                                      q.stride, partitions, W, dense_owner_dev, dense_limit, q.bucketed, q.stride,
-                                     q.lens + (size_t)(s + 1) * W, !lone, const_cast<int32_t*>(q.next[(size_t)s]));
+                                     q.lens + (size_t)(s + 1) * W, !lone, tail == 0 || s < tail,
+                                     const_cast<int32_t*>(q.next[(size_t)s]));
       if (rc != EULER_GPU_OK) return rc;
       if (lone) {
         rc = euler_gpu::WalkOwnedSlabs(shard, st, seed, call_id, et_dev, k, L, s, q.bucketed,

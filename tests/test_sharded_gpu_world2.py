@@ -173,8 +173,11 @@ def _worker_body(rank, world, port, partitions):
     # form (a wait for every step's bucket sizes): the same walks, the same level sizes
     from euler_amd import _lib
     seen = {}
-    for enq in (1, 0):
+    for enq, tail in ((1, 16), (1, 0), (0, 0)):
+        # (key 66: from step `tail` on the enqueued walk sends its levels as they are - 0: every
+        # step looks for entries that share a node, as the polled form does)
         _lib.check(_lib.lib().euler_gpu_set_tuning(63, enq))
+        _lib.check(_lib.lib().euler_gpu_set_tuning(66, tail))
         for cohorts, dense in ((1, S.dense_table), (3, None)):
             gotc, stats = c_sharded_random_walk(G_shard, trw, starts, etw, N + 1, 100, partitions, cohorts,
                                                 dense, return_stats=True)
@@ -183,7 +186,8 @@ def _worker_body(rank, world, port, partitions):
             # merged walkers: the levels hold fewer entries than walkers x steps
             assert stats["level_entries"] < starts.numel() * L
             # (the dense table merges every duplicate, the hash front end nearly all: compare like with like)
-            seen.setdefault(cohorts, []).append((stats["level_entries"], stats["ids_sent"]))
+            if tail == 0:
+                seen.setdefault(cohorts, []).append((stats["level_entries"], stats["ids_sent"]))
         mine_w = starts[:900] if rank != 0 else starts[:0]
         gotc = c_sharded_random_walk(G_shard, trw, mine_w, etw[:7], N + 1, 100, partitions, 2, S.dense_table)
         assert torch.equal(gotc, G_full.random_walk(mine_w, etw[:7], 1.0, 1.0, N + 1, call_id=100))
@@ -193,6 +197,7 @@ def _worker_body(rank, world, port, partitions):
         assert torch.equal(gotc, G_full.random_walk(own0, etw[:5], 1.0, 1.0, N + 1, call_id=100))
     assert seen[1][0] == seen[1][1], seen                     # dense table: exact in both forms
     _lib.check(_lib.lib().euler_gpu_set_tuning(63, 1))
+    _lib.check(_lib.lib().euler_gpu_set_tuning(66, 16))
     mine_w = starts[:900] if rank != 0 else starts[:0]
     gotc = c_sharded_random_walk(G_shard, trw, mine_w, etw[:7], N + 1, 100, partitions, 2, S.dense_table)
     assert torch.equal(gotc, G_full.random_walk(mine_w, etw[:7], 1.0, 1.0, N + 1, call_id=100))
