@@ -104,12 +104,13 @@ def parse():
     ap.add_argument("--no-small-batch", action="store_true",
                     help="skip the B = 1 024 latency leg (profiling runs: its 1 000 small "
                          "launches would share kernel names with the step's)")
-    ap.add_argument("--pipeline", type=int, default=3,
+    ap.add_argument("--pipeline", type=int, default=4,
                     help="sharded path: minibatches in flight, interleaved hop by hop "
                          "from one host thread (each on its own sampler and HIP "
                          "stream): while the host waits for one batch's bucket sizes "
-                         "the GPU runs the others' kernels and exchanges (one rank: 0.61 ms "
-                         "/ step with 1, 0.47 with 2, 0.46 with 3 or 4)")
+                         "the GPU runs the others' kernels and exchanges (one rank, round 6: "
+                         "0.39-0.40 ms / step with 1, 0.338 with 2, 0.321 with 3, 0.309 with 4, "
+                         "0.323 with 6 or 8)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="functional check only: when fewer GPUs are visible than --gpus, "
                          "let the ranks share them (rank r on GPU r %% visible) with a "

@@ -14,8 +14,6 @@
 
 #include "device_fns.h"
 
-namespace euler_gpu { std::atomic<int> g_front_claim{0}; }   // tuning key 65 (FrontSlabKernel<1>)
-
 struct euler_gpu_front {
   int64_t* stage = nullptr;      // pinned + mapped: [kMaxShards + 1] bucket starts, then the sequence word
   int64_t* stage_dev = nullptr;  // the same buffer as the kernels address it
@@ -1265,9 +1263,7 @@ struct FrontArgs {
   // for.  0: buckets packed one behind the other, their starts to the host (stage).
   uint32_t out_stride;
   uint32_t* out_lens;        // [shards]
-  // FrontSlabKernel: out_lens doubles as the shard totals (zero when the kernel starts); epoch
-  // tags this call's table entries (MODE 1)
-  uint32_t epoch;
+  // (FrontSlabKernel: out_lens doubles as the shard totals - zero when the kernel starts)
 };
 
 __device__ __forceinline__ uint32_t DenseSlot(const FrontArgs& a, uint64_t id) {
@@ -1386,15 +1382,10 @@ __global__ __launch_bounds__(256) void FrontPlaceKernel(const FrontArgs a, uint6
 //           MODE 2 (id-indexed table): the entry FrontMarkDenseKernel left - the default;
 //           MODE 3: every position represents itself (no mark pass, no table: the late levels of
 //           a walk, which hold few new duplicates - the buckets are only split by owner);
-//           MODE 1 (id-indexed table, tuning key 65): a single pass - read the slot; an entry of this call's
-//           epoch that names a live position holding the same id is the representative (checked
-//           by CONTENT: the 8-bit epoch only spares stale entries the look at ids[]); anything
-//           else is replaced by compare-and-swap, and whoever wins represents the id.  Every
-//           position of an id sees either the winner's entry or loses its swap to it: one
-//           representative per id without a mark pass.  (ids beyond the table represent
-//           themselves: they would take turns at the one slot they share.)  Measured: 1M x 40
-//           walk 4.17 ms against 2.15 with the mark pass - a level repeats its hubs thousands of
-//           times and their swaps queue up at one address; kept for A/B.
+//           (measured and removed, round 6: a single pass that claims the table slot by
+//           compare-and-swap, entries tagged with an 8-bit epoch and checked by content - no mark
+//           pass; 1M x 40 walk 1.96-2.30 ms against 1.72-1.83: a level repeats its hubs thousands
+//           of times and their swaps queue up at one address, profiles/r6_walk_enqueued_ab.txt)
 //   place   representatives rank within (chunk, owner) as in FrontRepHistKernel, the chunk adds
 //           its counts to the totals (= out_lens) and places them at slab start + 1 + base + rank;
 //           a position that is NOT its id's representative leaves ~representative in pos[] - the
@@ -1421,33 +1412,12 @@ __global__ __launch_bounds__(256) void FrontSlabKernel(const FrontArgs a, uint64
   uint64_t idv[kPer];
   uint32_t repv[kPer], wv[kPer];
   bool live[kPer];
-  const bool tagged = a.d.n <= (int64_t)(1 << 24);         // positions fit 24 bits: 8 bits of epoch
 #pragma unroll
   for (int32_t k = 0; k < kPer; ++k) live[k] = DedupLive(a.d, base + (int64_t)k * 256 + threadIdx.x);
 #pragma unroll
   for (int32_t k = 0; k < kPer; ++k)
     idv[k] = live[k] ? DedupIdAt(a.d, base + (int64_t)k * 256 + threadIdx.x) : 0ull;
-  if (MODE == 1) {
-#pragma unroll
-    for (int32_t k = 0; k < kPer; ++k)
-      repv[k] = live[k] && idv[k] < a.dense_limit ? a.dense_owner[(uint32_t)idv[k]] : 0u;
-#pragma unroll
-    for (int32_t k = 0; k < kPer; ++k) {
-      const uint32_t i = (uint32_t)(base + (int64_t)k * 256 + threadIdx.x);
-      if (!live[k] || idv[k] >= a.dense_limit) { repv[k] = i; continue; }
-      const uint32_t mine = tagged ? (a.epoch << 24 | i) : i;
-      uint32_t cur = repv[k];
-      for (;;) {
-        if (!tagged || (cur >> 24) == a.epoch) {
-          const uint32_t c = tagged ? (cur & 0xFFFFFFu) : cur;
-          if (DedupLive(a.d, c) && DedupIdAt(a.d, c) == idv[k]) { repv[k] = c; break; }
-        }
-        const uint32_t old = atomicCAS(&a.dense_owner[(uint32_t)idv[k]], cur, mine);
-        if (old == cur) { repv[k] = i; break; }
-        cur = old;
-      }
-    }
-  } else if (MODE == 2) {
+  if (MODE == 2) {
 #pragma unroll
     for (int32_t k = 0; k < kPer; ++k) repv[k] = live[k] ? a.dense_owner[DenseSlot(a, idv[k])] : 0u;
   } else if (MODE == 3) {
@@ -1617,12 +1587,8 @@ static int FrontEnqueue(hipStream_t st, const uint64_t* ids_dev, int64_t n, cons
   const int grid = GridFor(n, block);
   if (out_stride != 0u) {
     // slabs: one kernel (two mark kernels before it when the ids are hashed)
-    static std::atomic<uint32_t> epoch{0};
-    a.epoch = epoch.fetch_add(1) & 0xFFu;
     if (!dedup) {
       hipLaunchKernelGGL(FrontSlabKernel<3>, dim3((unsigned)n_chunks), dim3(256), 0, st, a, shard_ids_dev, pos_dev);
-    } else if (dense && euler_gpu::g_front_claim.load() != 0) {
-      hipLaunchKernelGGL(FrontSlabKernel<1>, dim3((unsigned)n_chunks), dim3(256), 0, st, a, shard_ids_dev, pos_dev);
     } else if (dense) {
       hipLaunchKernelGGL(FrontMarkDenseKernel, dim3(grid), dim3(block), 0, st, a);
       hipLaunchKernelGGL(FrontSlabKernel<2>, dim3((unsigned)n_chunks), dim3(256), 0, st, a, shard_ids_dev, pos_dev);

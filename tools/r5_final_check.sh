@@ -3,7 +3,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 T=${1:-r5_last}
-timeout 900 python -m pytest tests -m gpu --maxfail=5 -q > gpurun_out/${T}_gpu_pytest.txt 2>&1
+timeout 1500 python -m pytest tests -m gpu --maxfail=5 -q > gpurun_out/${T}_gpu_pytest.txt 2>&1
 rc=$?
 echo "pytest rc=$rc"; tail -6 gpurun_out/${T}_gpu_pytest.txt
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
