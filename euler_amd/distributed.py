@@ -361,17 +361,28 @@ class ShardedSampler:
         exchange serve all the sets (the roots are the same); every set is then one owners'
         pass + one row exchange + one expansion.  Returns a list of (ids, weights, types,
         row_mask) per set."""
+        return self._run(self.sample_neighbor_sets_steps(roots, type_sets, count, default_node, call_id))
+
+    def sample_neighbor_sets_steps(self, roots, type_sets, count, default_node=-1, call_id=None):
+        """sample_neighbor_sets as a generator: one yield, where the host has to wait for the
+        front end's bucket sizes (as sample_neighbor_steps; run_interleaved advances the other
+        minibatches there).  A sampler without the fused path yields once per set."""
         type_sets = [list(et) for et in type_sets]
         call_id = self._take_call_ids(max(len(type_sets), 1), call_id)
         fused = (self.dedup_split_fn is not None and self.expand_fn is not None and
                  self.local_sample_packed is not None)
         if not fused:
-            return [self.sample_neighbor(roots, et, count, default_node, call_id + s)
-                    for s, et in enumerate(type_sets)]
+            outs = []
+            for s, et in enumerate(type_sets):
+                outs.append((yield from self.sample_neighbor_steps(roots, et, count, default_node, call_id + s)))
+            return outs
         roots = roots.reshape(-1).to(torch.int64)
+        token = None
         if self.front_begin_fn is not None:
-            shard_off, shard_ids, pos = self.front_end_fn(
-                self.front_begin_fn(roots, self.partitions, self.world, None, 1))
+            token = self.front_begin_fn(roots, self.partitions, self.world, None, 1)
+        yield
+        if token is not None:
+            shard_off, shard_ids, pos = self.front_end_fn(token)
         else:
             shard_off, shard_ids, pos = self.dedup_split_fn(roots, self.partitions, self.world, None, 1)
         send_counts = [int(shard_off[s + 1] - shard_off[s]) for s in range(self.world)]
