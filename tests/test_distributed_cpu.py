@@ -208,6 +208,17 @@ def _worker(rank, world, port, partitions, out_dir):
                 assert np.array_equal(got[j][0][h + 1].numpy(), on[h]), (rank, j, h)
                 assert np.array_equal(got[j][1][h].numpy(), ow[h])
                 assert np.array_equal(got[j][2][h].numpy(), ot[h])
+    # ... and the typed draws of several heterogeneous minibatches in flight
+    # (sample_neighbor_sets_steps: one yield per minibatch, at the front end's wait)
+    for in_flight in (2, 3):
+        got = run_interleaved(lambda j: S_two.sample_neighbor_sets_steps(
+            torch.as_tensor(batches[j]), sets, 4, -1, 300 + 3 * j), len(batches), in_flight)
+        for j, b in enumerate(batches):
+            for c, et in enumerate(sets):
+                on, ow, ot = OG_full.sample_neighbor(seed, 300 + 3 * j + c, b, et, 4, -1)
+                assert np.array_equal(got[j][c][0].numpy().reshape(-1), on.reshape(-1)), (rank, j, et)
+                assert np.array_equal(got[j][c][1].numpy().reshape(-1), ow.reshape(-1))
+                assert np.array_equal(got[j][c][2].numpy().reshape(-1), ot.reshape(-1))
     # calls without an explicit call_id draw fresh ids from the sampler's counter
     # (by hops for a fanout): two consecutive default calls differ, and equal the
     # explicit calls a single-GPU Graph would have made
