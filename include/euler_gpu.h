@@ -884,13 +884,23 @@ int euler_gpu_sharded_sample_fanout(const euler_gpu_graph* shard,
  * euler_gpu_random_walk on the unsharded graph.  The walk runs over LEVELS of distinct nodes
  * (walkers that meet stay together: the draw is keyed by the node), one front end + id
  * exchange + owners' draw + answer exchange per step, the walkers' paths written once at
- * the end; the host waits once per step and cohort (the bucket sizes that size the
- * exchange).  cohorts (1..16, the same on every rank): the walkers are split into that many
- * independent walks whose steps alternate on `stream`, so the GPU runs one cohort's kernels
- * while the host waits for another's sizes.  dense_owner_dev / dense_limit: the id-indexed
+ * the end.  The whole walk is ENQUEUED (round 6): a level and its per-owner buckets live in
+ * slabs of a fixed stride (the largest walker count of a rank + 1, rounded up to 2 048 words:
+ * a header word = the entries behind it, the entries, padding), their sizes stay on the device,
+ * every message has the slab's size - so the host exchanges ONE number per peer per CALL (the
+ * ranks' walker counts, through tr->alltoall_counts) and then only enqueues: per step the
+ * front end (mark + one kernel that ranks and places; from step 16 on the level is sent as it
+ * is), tr->alltoallv of world equal messages, the owners' draw over the slabs received, the
+ * answers back into the next level.  The wire carries world x stride words per exchange
+ * instead of the level's distinct nodes.  euler_gpu_set_tuning(63, 0) (euler_gpu_measure.h)
+ * keeps the polled form: exchanges sized from the bucket sizes, one host wait per step and
+ * cohort.  cohorts (1..16, the same on every rank): the walkers are split into that many
+ * independent walks whose steps alternate on `stream` (the polled form hides its waits with
+ * them; the enqueued form has none to hide).  dense_owner_dev / dense_limit: the id-indexed
  * table of euler_gpu_dedup_split (NULL / 0 = hashing).  stats_host (optional, int64[4]):
- * host waits, level entries summed over the steps, ids sent to other ranks, cohorts.  All
- * ranks must call it together (also with n = 0). */
+ * host waits, level entries summed over the steps, ids sent to other ranks, cohorts - asking
+ * for them makes the enqueued call wait for the stream once at its end (the sizes never
+ * reached the host otherwise).  All ranks must call it together (also with n = 0). */
 int euler_gpu_sharded_random_walk(const euler_gpu_graph* shard, const euler_gpu_transport* tr,
                                   void* stream, uint64_t seed, uint32_t call_id,
                                   const int64_t* starts_dev, int64_t n,

@@ -132,6 +132,15 @@ extern "C" {
  * key 60: PROCESS-WIDE: a Sage flow whose hops list one edge type runs as three launches per hop -
  *        sampler + insert in one kernel, flag, emit + index, the hash tables cleared by the kernels
  *        before them (1 [default]); 0 = sampler, clear, insert as separate launches.
+ * key 62: PROCESS-WIDE: fused Sage flows send the ids WITH a graph row through the hop's own
+ *        {row, smallest position} hash table instead of the stream's row-indexed table: 2 [default] =
+ *        flows of at most 32 768 roots (16 384 roots x [25, 10]: 0.117 -> 0.111 ms; at 131 072 roots
+ *        the hop's table is itself 128 MB and the flow 3 % slower), 1 = always, 0 = never.
+ * key 63: PROCESS-WIDE: euler_gpu_sharded_random_walk ENQUEUED - levels and buckets in slab layout,
+ *        sizes on the device, fixed-size messages, one host exchange per call (1 [default]); 0 = the
+ *        polled form, one host wait per step and cohort.  key 66: first step of the enqueued walk
+ *        whose level is sent as it is, without looking for entries that share a node (16; 0 =
+ *        every step deduplicates).  key 64: columns its path kernel parks in LDS at a time (16).
  * All settings produce identical results; the knobs exist for A/B measurements
  * and tests.  They are THREAD-LOCAL: a call changes the launches the calling host
  * thread enqueues afterwards and nobody else's (new threads start from the
