@@ -301,6 +301,10 @@ int WalkOwnedSlabs(const euler_gpu_graph* g, hipStream_t st, uint64_t seed, uint
                    const int32_t* et_dev, int32_t k, int32_t walk_len, int32_t step,
                    const uint64_t* slabs_dev, const uint32_t* lens_dev, int32_t n_slabs, uint32_t stride,
                    uint64_t* out_dev);
+int WalkPathsFromLevelsTail(hipStream_t st, const int64_t* starts_dev, int64_t n, int32_t walk_len,
+                            const uint64_t* const* level_ids_host, const int32_t* const* level_next_host,
+                            int64_t default_node, int64_t* out_dev, int32_t T, const uint32_t* lens_T_dev,
+                            uint32_t stride, int32_t n_slabs, void* scratch_dev);
 // ... and of the sharded node2vec walk: row lengths <-> FillNeighbor offsets, one column of
 // the [n, walk_len + 1] result, the value offsets at the peers' row bounds
 int N2vRowLens(hipStream_t st, const int32_t* idx_dev, int64_t m, int32_t* lens_dev);

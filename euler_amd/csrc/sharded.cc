@@ -85,6 +85,11 @@ std::atomic<int> g_sharded_walk_enqueued{1};
 // 0 = every step deduplicates.  1M x 40 on one rank: 1.86 ms with 0, 1.90 / 1.76 / 1.715 / 1.72 /
 // 1.76 / 1.80 with 9 / 12 / 16 / 20 / 28 / 32 (profiles/r6_walk_tail_ab.txt).
 std::atomic<int> g_sharded_walk_tail{16};
+// Tuning key 67: level T at which the enqueued walk's path writer splits into two passes
+// (WalkPathsFromLevelsTail; walks of at least T + 8 steps).  0 = one pass.  1M x 40 on one rank:
+// 1.70 ms in one pass, 1.615 / 1.54 / 1.52 / 1.53 / 1.63 / 1.64 with T = 4 / 6 / 10 / 12 / 16 / 24
+// (profiles/r6_walk_split_ab.txt).
+std::atomic<int> g_sharded_walk_split{10};
 }
 namespace {
 bool SelfExchange() {
@@ -278,11 +283,25 @@ int WalkEnqueued(const euler_gpu_graph* shard, const euler_gpu_transport* tr, hi
       if (rc != EULER_GPU_OK) return rc;
     }
   }
+  // the walkers' paths; long walks in two passes: the levels from T on once per ENTRY of level T,
+  // the walkers through the levels before it + the row of the entry they reach (walk_kernels.hip)
+  const int32_t T = euler_gpu::g_sharded_walk_split.load();
   for (int32_t c = 0; c < K; ++c) {
     Cohort& q = co[(size_t)c];
     if (q.n == 0) continue;
-    const int rc = euler_gpu::WalkPathsFromLevels(st, starts_dev + q.lo, q.n, L, q.ids.data(), q.next.data(),
-                                                  default_node, out_dev + q.lo * ((int64_t)L + 1));
+    int rc;
+    void* tail_scratch = nullptr;
+    if (T > 0 && L >= T + 8 && q.stride != 0u && q.n * (int64_t)(L - T + 1) < ((int64_t)1 << 40))
+      tail_scratch = sc.Get((size_t)q.stride * W * (size_t)(L - T + 1) * 8 + (size_t)q.n * 4 + 256);
+    if (tail_scratch != nullptr) {
+      rc = euler_gpu::WalkPathsFromLevelsTail(st, starts_dev + q.lo, q.n, L, q.ids.data(), q.next.data(), default_node,
+                                              out_dev + q.lo * ((int64_t)L + 1), T, q.lens + (size_t)T * W, q.stride,
+                                              W, tail_scratch);
+    } else {
+      (void)hipGetLastError();
+      rc = euler_gpu::WalkPathsFromLevels(st, starts_dev + q.lo, q.n, L, q.ids.data(), q.next.data(),
+                                          default_node, out_dev + q.lo * ((int64_t)L + 1));
+    }
     if (rc != EULER_GPU_OK) return rc;
   }
   if (stats_host) {

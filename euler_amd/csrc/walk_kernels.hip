@@ -902,6 +902,16 @@ struct ShPathArgs {
   int64_t n, default_node;
   int32_t walk_len, ch;             // steps per LDS tile
   SmallDiv div_ch, div_last;        // by ch and by the last chunk's length
+  // The walk in TWO passes (WalkPathsFromLevels): walkers that have merged share the rest of their
+  // path, so the levels from T on are walked once per ENTRY of level T (n = its slab positions,
+  // live_lens / live_stride say which hold an entry, column 0 = the entry's own node: map0) into
+  // rows of `row_stride` words, and the walkers walk levels 0 .. T - 1 into their first columns
+  // and leave the entry they reach in p_out - ShSuffixCopyKernel appends that entry's row.
+  int64_t row_stride;               // words between two rows of `out` (walk_len + 1 when one pass)
+  const uint32_t* live_lens;        // not null: position p = slab * live_stride + j holds a walker iff 1 <= j <= live_lens[slab]
+  uint32_t live_stride;
+  int32_t map0;                     // column 0: 0 -> default_node as in the other columns
+  uint32_t* p_out;                  // not null: [n] the entry of level walk_len + 1 each walker reaches (next_arg[walk_len] valid)
   // walks of up to kShPathLevels steps: the tables themselves (ids / next above are null)
   const uint64_t* ids_arg[kShPathLevels + 1];
   const int32_t* next_arg[kShPathLevels];
@@ -921,7 +931,13 @@ __global__ __launch_bounds__(256) void ShWalkPathKernel(const ShPathArgs a) {
   for (int64_t tile = (int64_t)blockIdx.x * waves + wv; tile < tiles; tile += (int64_t)gridDim.x * waves) {
     const int64_t w0 = tile * 64;
     const int32_t nw = (int32_t)(a.n - w0 < 64 ? a.n - w0 : 64);
-    const bool live = lane < nw;
+    bool live = lane < nw;
+    if (a.live_lens != nullptr) {
+      // (a tile lies inside one slab or straddles two: whole tiles of padding leave at once)
+      const uint32_t pos = (uint32_t)(w0 + lane), sl = pos / a.live_stride, j = pos - sl * a.live_stride;
+      live = live && j != 0u && j <= a.live_lens[sl];
+      if (__ballot(live) == 0ull) continue;
+    }
     uint32_t p = (uint32_t)(w0 + lane);
     for (int32_t c0 = 0; c0 < L1; c0 += a.ch) {
       const int32_t ns = L1 - c0 < a.ch ? L1 - c0 : a.ch;
@@ -931,6 +947,7 @@ __global__ __launch_bounds__(256) void ShWalkPathKernel(const ShPathArgs a) {
           uint64_t v;
           if (col == 0) {
             v = (uint64_t)a.starts[w0 + lane];
+            if (a.map0 != 0 && v == 0) v = (uint64_t)a.default_node;
           } else {
             p = (uint32_t)lvl_next[col - 1][p];
             if ((int32_t)p < 0) p = (uint32_t)lvl_next[col - 1][~p];    // (slab levels: ~representative)
@@ -945,10 +962,30 @@ __global__ __launch_bounds__(256) void ShWalkPathKernel(const ShPathArgs a) {
       for (int32_t e = lane; e < total; e += 64) {
         const int32_t wl = (int32_t)(ns == a.ch ? a.div_ch((uint32_t)e) : a.div_last((uint32_t)e));
         const int32_t x = e - wl * ns;
-        a.out[(w0 + wl) * L1 + c0 + x] = (int64_t)t[wl * ls + x];
+        a.out[(w0 + wl) * a.row_stride + c0 + x] = (int64_t)t[wl * ls + x];
       }
       WaveSync();
     }
+    if (a.p_out != nullptr && live) {
+      p = (uint32_t)lvl_next[L1 - 1][p];
+      if ((int32_t)p < 0) p = (uint32_t)lvl_next[L1 - 1][~p];
+      a.p_out[w0 + lane] = p;
+    }
+  }
+}
+
+// columns first_col .. first_col + cols - 1 of walker w = the row of the level-T entry it reached:
+// 2^shift lanes a walker (consecutive lanes = consecutive columns: runs of a row on both sides)
+__global__ __launch_bounds__(256) void ShSuffixCopyKernel(const uint32_t* __restrict__ p_of,
+                                                          const int64_t* __restrict__ suffix,
+                                                          const int64_t n, const int32_t cols, const int32_t shift,
+                                                          const int64_t out_stride, const int32_t first_col,
+                                                          int64_t* __restrict__ out) {
+  const int32_t per = 256 >> shift;                 // walkers a workgroup takes at a time
+  const int32_t wl = (int32_t)threadIdx.x >> shift, c0 = (int32_t)threadIdx.x & ((1 << shift) - 1);
+  for (int64_t w = (int64_t)blockIdx.x * per + wl; w < n; w += (int64_t)gridDim.x * per) {
+    const int64_t row = (int64_t)p_of[w] * cols;
+    for (int32_t c = c0; c < cols; c += 1 << shift) out[w * out_stride + first_col + c] = suffix[row + c];
   }
 }
 
@@ -1014,21 +1051,25 @@ int WalkOwnedSlabs(const euler_gpu_graph* g, hipStream_t st, uint64_t seed, uint
                          (int64_t)n_slabs * stride, lens_dev, stride, out_dev);
 }
 
-int WalkPathsFromLevels(hipStream_t st, const int64_t* starts_dev, int64_t n, int32_t walk_len,
+// one launch of ShWalkPathKernel: `n` chains from `starts_dev` through levels first .. first + len
+static int LaunchShPath(hipStream_t st, const int64_t* starts_dev, int64_t n, int32_t len,
                         const uint64_t* const* level_ids_host, const int32_t* const* level_next_host,
-                        int64_t default_node, int64_t* out_dev) {
-  if (n <= 0) return EULER_GPU_OK;
+                        int64_t default_node, int64_t* out_dev, int64_t row_stride, const uint32_t* live_lens,
+                        uint32_t live_stride, bool map0, uint32_t* p_out) {
   ShPathArgs a{};
   a.starts = starts_dev; a.out = out_dev;
-  a.n = n; a.default_node = default_node; a.walk_len = walk_len;
+  a.n = n; a.default_node = default_node; a.walk_len = len;
+  a.row_stride = row_stride; a.live_lens = live_lens; a.live_stride = live_stride;
+  a.map0 = map0 ? 1 : 0; a.p_out = p_out;
+  const int32_t n_next = len + (p_out != nullptr ? 1 : 0);      // next tables the kernel reads
   void* tab = nullptr;
-  if (walk_len <= kShPathLevels) {
-    for (int32_t s = 0; s <= walk_len; ++s) a.ids_arg[s] = level_ids_host[s];
-    for (int32_t s = 0; s < walk_len; ++s) a.next_arg[s] = level_next_host[s];
+  if (n_next <= kShPathLevels) {
+    for (int32_t s = 0; s <= len; ++s) a.ids_arg[s] = level_ids_host[s];
+    for (int32_t s = 0; s < n_next; ++s) a.next_arg[s] = level_next_host[s];
   } else {
     // a long walk: the tables through device memory (the copies are waited for - their
     // sources are the caller's host arrays)
-    const size_t tb = ((size_t)walk_len + 1) * 8, tn = (size_t)walk_len * 8;
+    const size_t tb = ((size_t)len + 1) * 8, tn = (size_t)n_next * 8;
     EG_HIP(hipMallocAsync(&tab, tb + tn, st));
     EG_HIP(hipMemcpyAsync(tab, level_ids_host, tb, hipMemcpyHostToDevice, st));
     EG_HIP(hipMemcpyAsync((uint8_t*)tab + tb, level_next_host, tn, hipMemcpyHostToDevice, st));
@@ -1039,7 +1080,7 @@ int WalkPathsFromLevels(hipStream_t st, const int64_t* starts_dev, int64_t n, in
   // The kernel is a chain of walk_len dependent 4-byte loads per walker: it wants WAVES in flight,
   // not a wide tile.  16 columns at a time (128-byte runs of a walker's row, 8.7 KB of LDS a wave:
   // 16+ waves a CU) against the whole row (41 columns = 21 KB: 6 waves a CU, 585 us for 1M x 40).
-  const int32_t L1 = walk_len + 1;
+  const int32_t L1 = len + 1;
   const int32_t ch_max = g_walk_path_ch.load();
   a.ch = L1 < ch_max ? L1 : ch_max;
   a.div_ch.Set((uint32_t)a.ch);
@@ -1050,6 +1091,50 @@ int WalkPathsFromLevels(hipStream_t st, const int64_t* starts_dev, int64_t n, in
   hipLaunchKernelGGL(ShWalkPathKernel, dim3((unsigned)(wgs < 65536 ? wgs : 65536)), dim3(64 * waves),
                      wave_bytes * waves, st, a);
   if (tab != nullptr) (void)hipFreeAsync(tab, st);
+  EG_HIP(hipGetLastError());
+  return EULER_GPU_OK;
+}
+
+int WalkPathsFromLevels(hipStream_t st, const int64_t* starts_dev, int64_t n, int32_t walk_len,
+                        const uint64_t* const* level_ids_host, const int32_t* const* level_next_host,
+                        int64_t default_node, int64_t* out_dev) {
+  if (n <= 0) return EULER_GPU_OK;
+  return LaunchShPath(st, starts_dev, n, walk_len, level_ids_host, level_next_host, default_node, out_dev,
+                      (int64_t)walk_len + 1, nullptr, 0u, false, nullptr);
+}
+
+// The same paths in two passes (slab levels): walkers that have merged share the rest of their
+// path, and by level T a 1M-walker walk stands on ~110 K nodes - so levels T .. walk_len are walked
+// once per ENTRY of level T (rows of walk_len - T + 1 nodes in scratch_dev), the walkers walk
+// levels 0 .. T - 1 and append the row of the entry they reach.  The one-pass kernel makes ~83
+// scattered loads per walker, 65 % of the L2's request rate for 470-490 us (1M x 40); this form
+// ~37 + a 200-byte run.  scratch_dev: slab_positions * (walk_len - T + 1) * 8 + n * 4 bytes.
+int WalkPathsFromLevelsTail(hipStream_t st, const int64_t* starts_dev, int64_t n, int32_t walk_len,
+                            const uint64_t* const* level_ids_host, const int32_t* const* level_next_host,
+                            int64_t default_node, int64_t* out_dev, int32_t T, const uint32_t* lens_T_dev,
+                            uint32_t stride, int32_t n_slabs, void* scratch_dev) {
+  if (n <= 0) return EULER_GPU_OK;
+  if (T < 1 || T >= walk_len || scratch_dev == nullptr)
+    return Fail(EULER_GPU_EINVAL, "walk_paths_tail: bad arguments");
+  const int64_t slab = (int64_t)stride * n_slabs;
+  const int32_t cols = walk_len - T + 1;
+  int64_t* suffix = (int64_t*)scratch_dev;
+  uint32_t* p_of = (uint32_t*)(suffix + slab * cols);
+  // 1. the entries of level T through levels T + 1 .. walk_len (column 0 = the entry's own node)
+  int rc = LaunchShPath(st, (const int64_t*)level_ids_host[T], slab, walk_len - T, level_ids_host + T,
+                        level_next_host + T, default_node, suffix, cols, lens_T_dev, stride, true, nullptr);
+  if (rc != EULER_GPU_OK) return rc;
+  // 2. the walkers through levels 0 .. T - 1, the entry of level T they reach into p_of
+  rc = LaunchShPath(st, starts_dev, n, T - 1, level_ids_host, level_next_host, default_node, out_dev,
+                    (int64_t)walk_len + 1, nullptr, 0u, false, p_of);
+  if (rc != EULER_GPU_OK) return rc;
+  // 3. columns T .. walk_len
+  int32_t shift = 0;
+  while ((1 << shift) < cols && shift < 8) ++shift;
+  const int64_t per = 256 >> shift;
+  const int64_t wgs = (n + per - 1) / per;
+  hipLaunchKernelGGL(ShSuffixCopyKernel, dim3((unsigned)(wgs < 65536 ? wgs : 65536)), dim3(256), 0, st,
+                     (const uint32_t*)p_of, (const int64_t*)suffix, n, cols, shift, (int64_t)walk_len + 1, T, out_dev);
   EG_HIP(hipGetLastError());
   return EULER_GPU_OK;
 }

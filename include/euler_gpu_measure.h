@@ -141,6 +141,9 @@ extern "C" {
  *        polled form, one host wait per step and cohort.  key 66: first step of the enqueued walk
  *        whose level is sent as it is, without looking for entries that share a node (16; 0 =
  *        every step deduplicates).  key 64: columns its path kernel parks in LDS at a time (16).
+ *        key 67: level T at which its path writer splits into two passes - the levels from T on
+ *        are walked once per entry of level T, the walkers walk the levels before it and append
+ *        the row of the entry they reach (10; walks of at least T + 8 steps; 0 = one pass).
  * All settings produce identical results; the knobs exist for A/B measurements
  * and tests.  They are THREAD-LOCAL: a call changes the launches the calling host
  * thread enqueues afterwards and nobody else's (new threads start from the

@@ -173,11 +173,14 @@ def _worker_body(rank, world, port, partitions):
     # form (a wait for every step's bucket sizes): the same walks, the same level sizes
     from euler_amd import _lib
     seen = {}
-    for enq, tail in ((1, 16), (1, 0), (0, 0)):
+    for enq, tail, split in ((1, 16, 10), (1, 0, 25), (1, 16, 0), (0, 0, 0)):
         # (key 66: from step `tail` on the enqueued walk sends its levels as they are - 0: every
-        # step looks for entries that share a node, as the polled form does)
+        # step looks for entries that share a node, as the polled form does; key 67: the level at
+        # which the path writer splits into two passes - the levels behind it are walked once per
+        # entry of that level, not once per walker - 0: one pass)
         _lib.check(_lib.lib().euler_gpu_set_tuning(63, enq))
         _lib.check(_lib.lib().euler_gpu_set_tuning(66, tail))
+        _lib.check(_lib.lib().euler_gpu_set_tuning(67, split))
         for cohorts, dense in ((1, S.dense_table), (3, None)):
             gotc, stats = c_sharded_random_walk(G_shard, trw, starts, etw, N + 1, 100, partitions, cohorts,
                                                 dense, return_stats=True)
@@ -198,6 +201,7 @@ def _worker_body(rank, world, port, partitions):
     assert seen[1][0] == seen[1][1], seen                     # dense table: exact in both forms
     _lib.check(_lib.lib().euler_gpu_set_tuning(63, 1))
     _lib.check(_lib.lib().euler_gpu_set_tuning(66, 16))
+    _lib.check(_lib.lib().euler_gpu_set_tuning(67, 10))
     mine_w = starts[:900] if rank != 0 else starts[:0]
     gotc = c_sharded_random_walk(G_shard, trw, mine_w, etw[:7], N + 1, 100, partitions, 2, S.dense_table)
     assert torch.equal(gotc, G_full.random_walk(mine_w, etw[:7], 1.0, 1.0, N + 1, call_id=100))

@@ -31,14 +31,15 @@ if "walk" in what:
     starts = torch.randint(1, N + 1, (4, W), generator=gen, device=dev, dtype=torch.int64)
     et = [[0]] * L
     from euler_amd import _lib
-    for enq, K, self_x, ch, tail in ((1, 1, 0, 16, 16), (0, 1, 0, 16, 16), (0, 2, 0, 16, 16), (1, 1, 0, 16, 0),
-                                     (1, 1, 0, 64, 16), (1, 1, 1, 16, 16), (0, 1, 1, 16, 16)):
+    for enq, K, self_x, ch, tail, split in ((1, 1, 0, 16, 16, 10), (0, 1, 0, 16, 16, 10), (0, 2, 0, 16, 16, 10), (1, 1, 0, 16, 0, 10),
+                                            (1, 1, 0, 16, 16, 0), (1, 1, 0, 64, 16, 0), (1, 1, 1, 16, 16, 10), (0, 1, 1, 16, 16, 10)):
         # (tuning key 63: the walk enqueued without host waits / a wait per step; key 52: a lone
         # rank makes the exchanges with itself)
         _lib.check(_lib.lib().euler_gpu_set_tuning(63, enq))
         _lib.check(_lib.lib().euler_gpu_set_tuning(52, self_x))
         _lib.check(_lib.lib().euler_gpu_set_tuning(64, ch))      # columns per LDS tile of the path kernel
         _lib.check(_lib.lib().euler_gpu_set_tuning(66, tail))    # first step that sends its level as it is
+        _lib.check(_lib.lib().euler_gpu_set_tuning(67, split))   # level at which the path writer splits into two passes
         for i in range(2):
             out = c_sharded_random_walk(G, S.c_transport, starts[i], et, N + 1, 40 * i, 1, K, S.dense_table)
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -47,5 +48,5 @@ if "walk" in what:
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / 8 * 1e3
         ref = G.random_walk(starts[3], et, 1.0, 1.0, N + 1, call_id=40 * 7)
-        print("RESULT walk 1M x 40, enqueued %d, %d cohorts, self-exchange %d, path tile %d, tail %d: %.3f ms  same as unsharded: %s"
-              % (enq, K, self_x, ch, tail, ms, torch.equal(out, ref)), flush=True)
+        print("RESULT walk 1M x 40, enqueued %d, %d cohorts, self-exchange %d, path tile %d, tail %d, split %d: %.3f ms  same as unsharded: %s"
+              % (enq, K, self_x, ch, tail, split, ms, torch.equal(out, ref)), flush=True)
