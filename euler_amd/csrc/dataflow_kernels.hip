@@ -1012,8 +1012,11 @@ int euler_gpu_sage_blocks(const euler_gpu_graph* g, void* stream, uint64_t seed,
       si.h = f; si.seed = seed; si.call_id = call_id + (uint32_t)h; si.type = edge_types_host[(size_t)h * k];
       si.default_node = default_node;
       // (a workgroup of 256: 0.120 ms per 16 384-root flow against 0.122 / 0.130 with 512 / 1 024)
+      // (the grid is sized for the WORST-case layer, which a sampled flow fills to ~1/7: 4 096
+      // workgroups that stride over what there is - 16 384 roots 0.112 -> 0.107 ms against 16 384
+      // workgroups of which most only read the count and leave)
       int64_t gs = (cap_m + 255) / 256;
-      if (gs > 16384) gs = 16384;
+      if (gs > 4096) gs = 4096;
       hipLaunchKernelGGL(FlowSampleInsertKernel<256>, dim3((unsigned)gs), dim3(256), 0, st, si);
     } else {
       // 1. the hop's sampler over the first counts[h] nodes of the layer
