@@ -917,6 +917,79 @@ __device__ __forceinline__ void N2vBigRound(const WalkArgs& a, N2vBigLds& S, int
   *cin_out = cin;
 }
 
+// One walker's step by the whole workgroup, the lists already in S.seq (N2vBuildList from the
+// graph's rows, or N2vBuildListFetched from rows fetched from their owners): the sample, on
+// every thread.  `s`: the step (the draw's call id is a.call_id + s; explicit lists pass 0).
+__device__ __forceinline__ int64_t N2vBigStepBody(const WalkArgs& a, N2vBigLds& S, int* phase_p, const int wv,
+                                                   const int lane, const int64_t parent, const int64_t i,
+                                                   const int32_t s) {
+  int& phase_ref = *phase_p;
+  const int32_t nc = S.seq.child.total, np = S.seq.parent.total;
+  const int32_t rounds = (nc + kN2vBigRound - 1) / kN2vBigRound;
+  int32_t sh = 0;
+  while ((rounds >> sh) > kN2vBigCk) ++sh;
+  const int32_t n_slots = rounds >> sh;
+  N2vBigState st{{0, -1, 0}, 0.f};
+  const bool same = N2vSameLists(S.seq.child, S.seq.parent);
+  const int32_t jl = threadIdx.x * kN2vR;
+  float d[kN2vR], cin;
+  int32_t events;
+  bool ascending = false;
+  // the next round's entries are requested before this round is worked on
+  N2vVec e = N2vLoadVec(a, S.seq.child, nc, jl), nx = e;
+  for (int32_t ri = 0; ri < rounds; ++ri) {
+    if (ri + 1 < rounds) nx = N2vLoadVec(a, S.seq.child, nc, (ri + 1) * kN2vBigRound + jl);
+    N2vBigRound(a, S, &phase_ref, wv, lane, parent, np, same, e, &st, d, &cin, &events);
+    e = nx;
+    if (ri == 0 && events > 64) { ascending = true; break; }
+    if (((ri + 1) & ((1 << sh) - 1)) == 0 && threadIdx.x == 0) {
+      S.ck_acc[((ri + 1) >> sh) - 1] = st.acc;
+      S.ck_k[((ri + 1) >> sh) - 1] = st.cur.k;
+    }
+  }
+  int64_t result = a.default_node;
+  if (threadIdx.x == 0) {
+    N2vCount(ascending ? 2 : 6, 1);
+    N2vCount(ascending ? 3 : 7, (unsigned long long)nc);
+  }
+  if (ascending) {
+    // every child moves the parent cursor: the lane-0 automaton of one wave does it
+    if (wv == 0) result = N2vStepSequential(a, S.seq, lane, parent, i, s);
+  } else {
+    const float total = st.acc;
+    const double u = RngDraw(a.seed, a.call_id + (uint32_t)s, kDomainWalk, (uint64_t)i, 0);
+    const double r = ScaleDraw(u, 0.f, total);
+    __syncthreads();
+    int32_t first = 0;
+    if (N2vMonotone(a) && a.p > 0.f && a.q > 0.f) {
+      first = n_slots;
+      for (int32_t base = 0; base < n_slots; base += 64) {
+        const int32_t idx = base + lane;
+        const unsigned long long gt = __ballot(idx < n_slots && (double)S.ck_acc[idx] > r);
+        if (gt != 0) { first = base + __ffsll((long long)gt) - 1; break; }
+      }
+    }
+    st.acc = first == 0 ? 0.f : S.ck_acc[first - 1];
+    st.cur.k = first == 0 ? 0 : S.ck_k[first - 1];
+    st.cur.m_k = -1;
+    bool found = false;
+    for (int32_t ri = first << sh; ri < rounds && !found; ++ri) {
+      e = N2vLoadVec(a, S.seq.child, nc, ri * kN2vBigRound + jl);
+      N2vBigRound(a, S, &phase_ref, wv, lane, parent, np, same, e, &st, d, &cin, &events);
+      const uint32_t hm = N2vHits(e, d, cin, r);
+      int64_t hv = 0;
+      if (N2vBigFirst(S, &phase_ref, wv, lane, __ballot(hm != 0),
+                      N2vPick(e, hm != 0 ? __ffs((int)hm) - 1 : 0), &hv) >= 0) {
+        found = true;
+        result = hv;
+      }
+    }
+    // no interval holds r (total == 0): RandomSelect's fall-through ends on the last element
+    if (!found) result = (int64_t)S.seq.child.ids[N2vPhys(S.seq.child, nc - 1)];
+  }
+  return result;
+}
+
 // Lane per walker: queue the walkers whose step `s` has a long child list.
 __global__ __launch_bounds__(256) void N2vClassifyKernel(const WalkArgs a) {
   __shared__ int32_t base;
@@ -971,69 +1044,7 @@ __global__ __launch_bounds__(64 * kN2vBigWaves) void N2vBigStepKernel(const Walk
       N2vBuildList(&S.seq.parent, a.g, s > 0 ? FindRow(a.g, (uint64_t)parent) : -1, pet, a.k);
     }
     __syncthreads();
-    const int32_t nc = S.seq.child.total, np = S.seq.parent.total;
-    const int32_t rounds = (nc + kN2vBigRound - 1) / kN2vBigRound;
-    int32_t sh = 0;
-    while ((rounds >> sh) > kN2vBigCk) ++sh;
-    const int32_t n_slots = rounds >> sh;
-    N2vBigState st{{0, -1, 0}, 0.f};
-    const bool same = N2vSameLists(S.seq.child, S.seq.parent);
-    const int32_t jl = threadIdx.x * kN2vR;
-    float d[kN2vR], cin;
-    int32_t events;
-    bool ascending = false;
-    // the next round's entries are requested before this round is worked on
-    N2vVec e = N2vLoadVec(a, S.seq.child, nc, jl), nx = e;
-    for (int32_t ri = 0; ri < rounds; ++ri) {
-      if (ri + 1 < rounds) nx = N2vLoadVec(a, S.seq.child, nc, (ri + 1) * kN2vBigRound + jl);
-      N2vBigRound(a, S, &phase, wv, lane, parent, np, same, e, &st, d, &cin, &events);
-      e = nx;
-      if (ri == 0 && events > 64) { ascending = true; break; }
-      if (((ri + 1) & ((1 << sh) - 1)) == 0 && threadIdx.x == 0) {
-        S.ck_acc[((ri + 1) >> sh) - 1] = st.acc;
-        S.ck_k[((ri + 1) >> sh) - 1] = st.cur.k;
-      }
-    }
-    int64_t result = a.default_node;
-    if (threadIdx.x == 0) {
-      N2vCount(ascending ? 2 : 6, 1);
-      N2vCount(ascending ? 3 : 7, (unsigned long long)nc);
-    }
-    if (ascending) {
-      // every child moves the parent cursor: the lane-0 automaton of one wave does it
-      if (wv == 0) result = N2vStepSequential(a, S.seq, lane, parent, i, s);
-    } else {
-      const float total = st.acc;
-      const double u = RngDraw(a.seed, a.call_id + (uint32_t)s, kDomainWalk, (uint64_t)i, 0);
-      const double r = ScaleDraw(u, 0.f, total);
-      __syncthreads();
-      int32_t first = 0;
-      if (N2vMonotone(a) && a.p > 0.f && a.q > 0.f) {
-        first = n_slots;
-        for (int32_t base = 0; base < n_slots; base += 64) {
-          const int32_t idx = base + lane;
-          const unsigned long long gt = __ballot(idx < n_slots && (double)S.ck_acc[idx] > r);
-          if (gt != 0) { first = base + __ffsll((long long)gt) - 1; break; }
-        }
-      }
-      st.acc = first == 0 ? 0.f : S.ck_acc[first - 1];
-      st.cur.k = first == 0 ? 0 : S.ck_k[first - 1];
-      st.cur.m_k = -1;
-      bool found = false;
-      for (int32_t ri = first << sh; ri < rounds && !found; ++ri) {
-        e = N2vLoadVec(a, S.seq.child, nc, ri * kN2vBigRound + jl);
-        N2vBigRound(a, S, &phase, wv, lane, parent, np, same, e, &st, d, &cin, &events);
-        const uint32_t hm = N2vHits(e, d, cin, r);
-        int64_t hv = 0;
-        if (N2vBigFirst(S, &phase, wv, lane, __ballot(hm != 0),
-                        N2vPick(e, hm != 0 ? __ffs((int)hm) - 1 : 0), &hv) >= 0) {
-          found = true;
-          result = hv;
-        }
-      }
-      // no interval holds r (total == 0): RandomSelect's fall-through ends on the last element
-      if (!found) result = (int64_t)S.seq.child.ids[N2vPhys(S.seq.child, nc - 1)];
-    }
+    const int64_t result = N2vBigStepBody(a, S, &phase, wv, lane, parent, i, s);
     if (threadIdx.x == 0) a.out[i * L + s + 1] = result;
   }
 }

@@ -14,6 +14,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -159,21 +161,71 @@ int RcclAllToAllV(void* user, const void* send_dev, const int64_t* send_rows, vo
   return EULER_GPU_OK;
 }
 
-// device scratch of one call, stream-ordered
+// Device scratch of one call.  Blocks come from a cache of hipMalloc'd blocks kept per (device,
+// stream) and go back to it when the call releases them: a block is only ever reused by later work
+// of the SAME stream, so stream order makes the reuse safe without a stream-ordered free.
+// Why not hipMallocAsync / hipFreeAsync (rounds 4-5): with the per-step buffers of a node2vec walk
+// (the rows fetched in a step: gigabytes, a different size every step) one hipMallocAsync in a few
+// hundred took 1.5-5 s although the pool kept all its memory (hip-trace of
+// tools/sharded_n2v_ab.py: every third to ninth 0.12 s walk took 1.7-5.0 s; identical calls,
+// constant free memory) - the driver's bench takes medians and never showed it.  Sizes are rounded
+// up to eight classes per octave so that a step finds the blocks of the steps before it.
+struct BlockCache {
+  std::mutex mu;
+  std::map<std::pair<int, void*>, std::multimap<size_t, void*>> free_blocks;
+  size_t cached_bytes = 0;
+};
+BlockCache& Blocks() { static BlockCache* c = new BlockCache(); return *c; }
+constexpr size_t kBlockCacheCap = (size_t)96 << 30;       // beyond this, released blocks go back to the driver
+
 struct Scratch {
   hipStream_t st;
-  std::vector<void*> ptrs;
-  explicit Scratch(hipStream_t s) : st(s) {}
-  ~Scratch() { for (void* p : ptrs) (void)hipFreeAsync(p, st); }
+  int dev = 0;
+  std::vector<void*> ptrs;                            // stream-ordered allocations of others, freed with the call
+  std::vector<std::pair<void*, size_t>> blocks;       // cached blocks in use
+  explicit Scratch(hipStream_t s) : st(s) { (void)hipGetDevice(&dev); }
+  ~Scratch() {
+    for (void* p : ptrs) (void)hipFreeAsync(p, st);
+    while (!blocks.empty()) Release(blocks.back().first);
+  }
+  static size_t SizeClass(size_t bytes) {
+    if (bytes < 256) return 256;
+    int e = 0;
+    while (((size_t)1 << (e + 1)) <= bytes) ++e;            // 2^e <= bytes < 2^(e + 1)
+    const size_t step = (size_t)1 << (e > 11 ? e - 3 : 8);
+    return (bytes + step - 1) & ~(step - 1);
+  }
   void* Get(size_t bytes) {
+    const size_t cls = SizeClass(bytes);
     void* p = nullptr;
-    if (hipMallocAsync(&p, bytes ? bytes : 16, st) != hipSuccess) return nullptr;
-    ptrs.push_back(p);
+    {
+      BlockCache& c = Blocks();
+      std::lock_guard<std::mutex> lk(c.mu);
+      auto& fm = c.free_blocks[std::make_pair(dev, (void*)st)];
+      auto it = fm.find(cls);
+      if (it != fm.end()) { p = it->second; fm.erase(it); c.cached_bytes -= cls; }
+    }
+    if (p == nullptr && hipMalloc(&p, cls) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    blocks.emplace_back(p, cls);
     return p;
   }
-  // stream-ordered free of one block before the call ends (a walk's per-step buffers)
+  // a block the call is done with: back to the cache (later work of this stream may take it)
   void Release(void* p) {
     if (p == nullptr) return;
+    for (size_t i = 0; i < blocks.size(); ++i) {
+      if (blocks[i].first != p) continue;
+      const size_t cls = blocks[i].second;
+      blocks[i] = blocks.back(); blocks.pop_back();
+      BlockCache& c = Blocks();
+      bool keep;
+      {
+        std::lock_guard<std::mutex> lk(c.mu);
+        keep = c.cached_bytes + cls <= kBlockCacheCap;
+        if (keep) { c.free_blocks[std::make_pair(dev, (void*)st)].emplace(cls, p); c.cached_bytes += cls; }
+      }
+      if (!keep) { (void)hipStreamSynchronize(st); (void)hipFree(p); }
+      return;
+    }
     for (size_t i = 0; i < ptrs.size(); ++i)
       if (ptrs[i] == p) { ptrs[i] = ptrs.back(); ptrs.pop_back(); (void)hipFreeAsync(p, st); return; }
   }

@@ -413,6 +413,11 @@ thread_local int g_walk_collapse = 262144;
 thread_local int g_walk_lean = 1;         // key 44: plain graphs draw with the lean search of the one-kernel fanout
 thread_local int g_walk_tail = 9;         // key 43: first step of the merged walk that stops looking for mergers
                                           // (the rest of the walk is one launch; 0 = never)
+// key 69: node2vec steps on fetched rows (the sharded walk): child rows of at least this many entries
+// go to a workgroup each (N2vBigStepListKernel); 0 = none.  100 000 x 10 on the metric graph, one
+// rank: 122 ms without, 123 / 111 / 114 / 99 / 99 / 104 ms with 4 096 / 8 192 / 32 768 / 65 536 /
+// 131 072 / 262 144.
+std::atomic<int> g_n2v_list_big{65536};
 std::atomic<int> g_walk_path_ch{16};      // key 64: columns the sharded walk's path kernel parks in LDS at a time
 thread_local int g_walk_grid = 1024;      // key 39: workgroups of its per-step launches (0 = one per 256 walkers)
 
@@ -1411,11 +1416,60 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void Node2VecListWaveKernel(con
     }
     WaveSync();
     const int32_t nc = S.child.total;
+    if (a.big_threshold > 0 && nc >= a.big_threshold) continue;   // N2vBigStepListKernel's
     int64_t sample_id = l.default_node;
     bool done = false;
     if (PAR && nc > 0) done = N2vStepParallel(a, S, lane, parent, i, 0, &sample_id);
     if (nc > 0 && !done) sample_id = N2vStepSequential(a, S, lane, parent, i, 0);
     if (lane == 0) l.out[i] = sample_id;
+  }
+}
+
+// A step of the sharded walk is ONE launch over fetched rows, so its duration is its slowest
+// wave's - the walker that stands on the 578 088-neighbour hub (9.6 ms a step on the metric
+// graph; the single-GPU walk hides that wave behind the other walkers' remaining steps).  As
+// N2vClassifyKernel / N2vBigStepKernel do for the step-by-step single-GPU walk (key 7 = 3):
+// walkers whose fetched child row has big_threshold entries or more are queued, and a workgroup
+// of 16 waves takes each of them (N2vBigStepBody).
+__global__ __launch_bounds__(256) void N2vListClassifyKernel(const WalkArgs a, const N2vListArgs l) {
+  const int lane = threadIdx.x & 63;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n64 = (l.n + 63) & ~(int64_t)63;          // (whole waves run the loop: ballot, shuffle)
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n64; i += stride) {
+    bool big = false;
+    if (i < l.n) {
+      const int32_t r = l.c_row[i];
+      big = r >= 0 && l.c_idx[2 * (int64_t)r + 1] - l.c_idx[2 * (int64_t)r] >= a.big_threshold;
+    }
+    const unsigned long long m = __ballot(big);
+    if (m == 0ull) continue;
+    int32_t base = 0;
+    if (lane == 0) base = atomicAdd(a.big_count, (int32_t)__popcll(m));
+    base = __shfl(base, 0);
+    if (big) a.big_queue[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)i;
+  }
+}
+
+__global__ __launch_bounds__(64 * kN2vBigWaves) void N2vBigStepListKernel(const WalkArgs a, const N2vListArgs l) {
+  __shared__ N2vBigLds S;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int32_t queued = a.big_count[0];
+  int phase = 0;
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) S.next = atomicAdd(a.big_count + 1, 1);
+    __syncthreads();
+    const int64_t qe = S.next;
+    if (qe >= queued) break;
+    const int64_t i = a.big_queue[qe];
+    const int64_t parent = l.parent_ids[i];
+    if (threadIdx.x == 0) {
+      N2vBuildListFetched(&S.seq.child, l.c_idx, l.c_ids, l.c_w, l.c_row[i]);
+      N2vBuildListFetched(&S.seq.parent, l.p_idx, l.p_ids, nullptr, l.p_row != nullptr ? l.p_row[i] : -1);
+    }
+    __syncthreads();
+    const int64_t result = N2vBigStepBody(a, S, &phase, wv, lane, parent, i, 0);
+    if (threadIdx.x == 0) l.out[i] = result;
   }
 }
 
@@ -1608,10 +1662,28 @@ int euler_gpu_node2vec_step(void* stream, uint64_t seed, uint32_t call_id, int64
       hipLaunchKernelGGL(N2vNonNegKernel, dim3(GridFor(c_entries, 256)), dim3(256), 0, (hipStream_t)stream,
                          c_w_dev, c_entries, flag);
     w.nonneg_flag = flag;
+    // long rows by a workgroup each (key 69: the threshold, 0 = none)
+    int32_t* q = nullptr;
+    const int32_t big_at = g_n2v_list_big.load();
+    const bool big = big_at > 0 && n < (1ll << 31);
+    if (big) {
+      const size_t q_bytes = ((size_t)n * 4 + 15) & ~(size_t)15;
+      EG_HIP(hipMallocAsync((void**)&q, q_bytes + 16, (hipStream_t)stream));
+      w.big_queue = q;
+      w.big_count = (int32_t*)((uint8_t*)q + q_bytes);
+      w.big_threshold = big_at;
+      EG_HIP(hipMemsetAsync(w.big_count, 0, 8, (hipStream_t)stream));
+      hipLaunchKernelGGL(N2vListClassifyKernel, dim3(GridFor(n, 256)), dim3(256), 0, (hipStream_t)stream, w, a);
+    }
     hipLaunchKernelGGL(Node2VecListWaveKernel<true>, dim3(GridFor(n * 64, 256)), dim3(256), 0,
                        (hipStream_t)stream, w, a);
+    // (on a side stream forked from the caller's the long rows' workgroups did not overlap the
+    // other walkers' waves: 512 persistent workgroups of 1 024 threads hold every CU - same 111 ms)
+    if (big)
+      hipLaunchKernelGGL(N2vBigStepListKernel, dim3(512), dim3(64 * kN2vBigWaves), 0, (hipStream_t)stream, w, a);
     EG_HIP(hipGetLastError());
     EG_HIP(hipFreeAsync(flag, (hipStream_t)stream));
+    if (q != nullptr) EG_HIP(hipFreeAsync(q, (hipStream_t)stream));
     return EULER_GPU_OK;
   } else {
     hipLaunchKernelGGL(Node2VecListStepKernel, dim3(GridFor(n, 256)), dim3(256), 0,

@@ -144,6 +144,9 @@ extern "C" {
  *        key 67: level T at which its path writer splits into two passes - the levels from T on
  *        are walked once per entry of level T, the walkers walk the levels before it and append
  *        the row of the entry they reach (10; walks of at least T + 8 steps; 0 = one pass).
+ * key 69: PROCESS-WIDE: euler_gpu_node2vec_step (the sharded node2vec walk's step on fetched rows):
+ *        child rows of at least this many entries are drawn by a workgroup of 16 waves each
+ *        (65536; 0 = every row by one wave).
  * All settings produce identical results; the knobs exist for A/B measurements
  * and tests.  They are THREAD-LOCAL: a call changes the launches the calling host
  * thread enqueues afterwards and nobody else's (new threads start from the

@@ -2284,8 +2284,11 @@ def test_node2vec_step_on_fetched_lists_wave_and_lane(EA, O, torch_cuda):
             G.set_seed(5)
             want = G.random_walk(qt, [[0]] * steps, p_, q_, 3001, call_id=77)
             assert np.array_equal(t2n(want), OG.random_walk(5, 77, q, [[0]] * steps, steps, p_, q_, 3001))
-            for mode in (2, 0):
+            # (mode 2 twice: rows of >= 65 536 / >= 200 entries by a workgroup of 16 waves each -
+            # N2vBigStepListKernel, tuning key 69; this graph's rows average 300 entries, hubs thousands)
+            for mode, big_at in ((2, 65536), (2, 200), (0, 65536)):
                 L.euler_gpu_set_tuning(7, mode)
+                L.euler_gpu_set_tuning(69, big_at)
                 cur = parent = qt
                 p_row = p_idx = p_ids = None
                 cols = [qt]
@@ -2297,9 +2300,10 @@ def test_node2vec_step_on_fetched_lists_wave_and_lane(EA, O, torch_cuda):
                     parent, cur = cur, nxt
                     p_row, p_idx, p_ids = inv, idx, ids
                     cols.append(cur)
-                assert torch.equal(torch.stack(cols, 1), want), (p_, q_, mode)
+                assert torch.equal(torch.stack(cols, 1), want), (p_, q_, mode, big_at)
     finally:
         L.euler_gpu_set_tuning(7, 2)
+        L.euler_gpu_set_tuning(69, 65536)
 
 
 @pytest.mark.parametrize("index_alone", [0, 1])

@@ -228,6 +228,12 @@ def _worker_body(rank, world, port, partitions):
                                            return_stats=True)
     assert torch.equal(gotn, want)
     assert nstats["rows_asked"] <= 1500 * 8 and nstats["row_entries"] > 0 and nstats["ids_sent"] > 0
+    # (the step's long rows by a workgroup each - N2vBigStepListKernel, tuning key 69 - with the bar
+    # low enough for this graph's hubs)
+    _lib.check(_lib.lib().euler_gpu_set_tuning(69, 48))
+    gotn = c_sharded_node2vec_walk(G_shard, trw, starts[:1500], etn, 0.25, 4.0, N + 1, 200, partitions, None)
+    _lib.check(_lib.lib().euler_gpu_set_tuning(69, 65536))
+    assert torch.equal(gotn, want)
     mine_n = starts[:700] if rank != 0 else starts[:0]
     gotn = c_sharded_node2vec_walk(G_shard, trw, mine_n, etn[:5], 2.0, 0.5, N + 1, 210, partitions, S.dense_table)
     assert torch.equal(gotn, G_full.random_walk(mine_n, etn[:5], 2.0, 0.5, N + 1, call_id=210))
