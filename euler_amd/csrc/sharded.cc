@@ -176,7 +176,8 @@ struct BlockCache {
   size_t cached_bytes = 0;
 };
 BlockCache& Blocks() { static BlockCache* c = new BlockCache(); return *c; }
-constexpr size_t kBlockCacheCap = (size_t)96 << 30;       // beyond this, released blocks go back to the driver
+constexpr size_t kBlockCacheCap = (size_t)32 << 30;       // beyond this, released blocks go back to the driver
+                                                          // (a node2vec walk of 100 000 hub walkers holds ~10 GB)
 
 struct Scratch {
   hipStream_t st;
