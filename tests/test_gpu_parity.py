@@ -990,6 +990,35 @@ def test_gpu_sharded_sampler_single_rank(EA, O, torch_cuda, big_pair):
             w2 = S.random_walk(torch.as_tensor(q).cuda(), et, p_, q_, default_node=-1, call_id=30)
             assert np.array_equal(t2n(w2), OG.random_walk(31, 30, q, et, L, p_, q_, -1)), (p_, q_)
             assert torch.equal(w2, G.random_walk(torch.as_tensor(q).cuda(), et, p_, q_, -1, call_id=30))
+        # the ENQUEUED walk (round 6: slab levels, no host wait per step) over shapes: one walker, sizes
+        # around the slab's 2 048-word chunk, walks shorter / longer than the two-pass paths' split and
+        # than the 120 level pointers a launch carries, up to 16 cohorts, the hash front end, levels
+        # sent as they are from step `tail`, the exchanges made with itself; unknown and duplicate starts
+        import itertools
+        Gw = EA.Graph.synthetic(EA.synth_params(77, 200_000, 2_400_000, weighted=True))
+        Gw.set_seed(77)
+        Sw = gpu_sharded_sampler(Gw, partitions=1)
+        try:
+            for n_w, L_w, K_w, dense, tail, split, selfx in itertools.chain(
+                    [(1, 1, 1, True, 16, 10, 0), (2047, 17, 1, True, 16, 10, 0), (2048, 18, 2, False, 16, 10, 0),
+                     (2049, 19, 1, True, 3, 5, 1), (5000, 130, 1, True, 16, 10, 0), (5000, 130, 3, False, 0, 100, 0),
+                     (70000, 40, 16, True, 16, 10, 1), (3, 40, 2, False, 1, 1, 0), (100000, 26, 1, False, 16, 17, 1)],
+                    [(int(rng.integers(1, 30000)), int(rng.integers(0, 60)), int(rng.integers(1, 5)),
+                      bool(rng.integers(0, 2)), int(rng.integers(0, 30)), int(rng.integers(0, 30)),
+                      int(rng.integers(0, 2))) for _ in range(12)]):
+                for key, v in ((63, 1), (66, tail), (67, split), (52, selfx)):
+                    _lib.check(_lib.lib().euler_gpu_set_tuning(key, v))
+                st_w = rng.integers(1, 200_001, n_w).astype(np.int64)
+                if n_w > 4:
+                    st_w[1] = st_w[0]; st_w[2] = 0; st_w[3] = 200_005
+                st_t = torch.as_tensor(st_w).cuda()
+                want_w = Gw.random_walk(st_t, [[0]] * L_w, 1.0, 1.0, 200_001, call_id=11) if L_w else st_t.reshape(-1, 1)
+                got_w = c_sharded_random_walk(Gw, Sw.c_transport, st_t, [[0]] * L_w, 200_001, 11, 1, K_w,
+                                              Sw.dense_table if dense else None)
+                assert torch.equal(got_w.reshape(want_w.shape), want_w), (n_w, L_w, K_w, dense, tail, split, selfx)
+        finally:
+            for key, v in ((66, 16), (67, 10), (52, 0)):
+                _lib.lib().euler_gpu_set_tuning(key, v)
     finally:
         dist.destroy_process_group()
 
