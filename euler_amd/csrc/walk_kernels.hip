@@ -150,9 +150,56 @@ __global__ __launch_bounds__(256) void FullNbFillBalancedKernel(
     float* __restrict__ out_w, int32_t* __restrict__ out_t) {
   const int64_t total = (int64_t)idx[2 * (a.n - 1) + 1];
   const int64_t stride = (int64_t)gridDim.x * blockDim.x * kFullNbPerLane;
-  for (int64_t e0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * kFullNbPerLane; e0 < total;
-       e0 += stride) {
-    int64_t lo = 0, hi = a.n - 1;                 // first row whose end exceeds e0
+  const int lane = threadIdx.x & 63;
+  const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  for (int64_t w0 = ((int64_t)blockIdx.x * blockDim.x + (int64_t)wave_in_block * 64) * kFullNbPerLane; w0 < total;
+       w0 += stride) {
+    // (round 6) The rows of the wave's first and last entry, by the scalar unit.  A wave whose 256
+    // entries lie inside ONE row - a hub's: the rows a node2vec walk fetches are 1 500 entries
+    // long on average - takes them lane by lane, entry w0 + 64 j + lane: every load and store of
+    // the wave one contiguous run, the row's record read once.
+    const int64_t w_n = w0 + 64 * kFullNbPerLane < total ? 64 * kFullNbPerLane : total - w0;
+    int64_t r0, r1;
+    {
+      int64_t lo = 0, hi = a.n - 1;
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)idx[2 * mid + 1] > w0) hi = mid; else lo = mid + 1;
+      }
+      r0 = lo;
+      hi = a.n - 1;
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)idx[2 * mid + 1] > w0 + w_n - 1) hi = mid; else lo = mid + 1;
+      }
+      r1 = lo;
+    }
+    if (r0 == r1) {
+      const int64_t row = FindRow(a.g, a.ids[r0]);
+      const RowMeta m = LoadRowMeta(a.g, row < 0 ? 0 : row);
+      const int64_t begin = idx[2 * r0];
+      const float* nw = a.g.prefix_w + m.row_ptr;
+      const uint64_t* nbr = a.g.nbr + m.row_ptr;
+      for (int64_t e = w0 + lane; e < w0 + w_n; e += 64) {
+        int32_t q = (int32_t)(e - begin);
+        int32_t t = 0, p = 0;
+        for (int32_t x = 0; x < a.k; ++x) {
+          t = a.et[x];
+          if (t < 0 || t >= a.g.T) continue;
+          const int32_t b = t == 0 ? 0 : m.type_end[t - 1];
+          const int32_t len = m.type_end[t] - b;
+          if (q < len) { p = b + q; break; }
+          q -= len;
+        }
+        out_id[e] = nbr[p];
+        out_w[e] = __fsub_rn(nw[p], p == 0 ? 0.f : nw[p - 1]);
+        out_t[e] = t;
+      }
+      continue;
+    }
+    const int64_t e0 = w0 + (int64_t)lane * kFullNbPerLane;
+    if (e0 >= total) continue;
+    int64_t lo = r0, hi = r1;                     // first row whose end exceeds e0
     while (lo < hi) {
       const int64_t mid = (lo + hi) >> 1;
       if ((int64_t)idx[2 * mid + 1] > e0) hi = mid; else lo = mid + 1;
