@@ -841,7 +841,13 @@ int euler_gpu_merge_rows(void* stream, const void* in_dev,
  * euler_gpu_transport_rccl fills it for an ncclComm_t (ncclSend / ncclRecv groups
  * over xGMI; the RCCL the host process already loaded is resolved at run time, this
  * library does not link it); `counts` = an euler_shm mailbox the ranks opened, or
- * NULL = the counts travel through the communicator (a device sync per hop). */
+ * NULL = the counts travel through the communicator (a device sync per hop).
+ *
+ * Memory: the per-call scratch of the euler_gpu_sharded_* entries (bucketed ids, wire rows, a
+ * walk's levels, the rows a node2vec step fetches) comes from blocks the library keeps per
+ * (device, stream) once it has allocated them - at most 32 GB per process, beyond that a
+ * released block goes back to the driver.  (Stream-ordered allocations of gigabyte blocks of
+ * ever different sizes stalled for seconds once in a few hundred calls.) */
 typedef struct euler_gpu_transport {
   int32_t rank, world;
   void* user;
