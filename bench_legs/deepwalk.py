@@ -55,6 +55,8 @@ def run_deepwalk(args, G=None, p_g=None, quiet=False):
     for i in range(args.warmup):
         walk(starts[i], et, 1.0, 1.0, LEN * i)
     _sync_ranks(wire)
+    import gc
+    gc.collect(); gc.freeze(); gc.disable()      # a gen-2 collection costs ~40 ms: one repeat in five at 2 x the others
     reps = []
     for _rep in range(max(1, args.repeats)):
         _sync_ranks(wire)
@@ -63,6 +65,7 @@ def run_deepwalk(args, G=None, p_g=None, quiet=False):
             walks = walk(starts[i], et, 1.0, 1.0, LEN * i)
         _sync_ranks(wire)
         reps.append(time.perf_counter() - t0)
+    gc.enable()
     reps = _max_over_ranks(reps, wire)           # slowest rank, per repetition
     elapsed = float(np.median(reps))
     if S is not None:

@@ -123,6 +123,8 @@ def run_hetero(args, quiet=False):
     _sync_ranks(wire)
     loop(0, max(args.warmup, 2 * n_streams))
     _sync_ranks(wire)
+    import gc
+    gc.collect(); gc.freeze(); gc.disable()      # (a gen-2 collection inside a repeat costs ~40 ms)
     reps = []
     for _rep in range(max(1, args.repeats)):
         _sync_ranks(wire)
@@ -130,6 +132,7 @@ def run_hetero(args, quiet=False):
         loop(args.warmup, n_steps)
         _sync_ranks(wire)
         reps.append(time.perf_counter() - t0)
+    gc.enable()
     reps = _max_over_ranks(reps, wire)           # slowest rank, per repetition
     elapsed = float(np.median(reps))
     if S is not None:
