@@ -238,6 +238,32 @@ __device__ __forceinline__ bool N2vSameLists(const N2vList& c, const N2vList& p)
   return true;
 }
 
+// The same for lists FETCHED from their owners (one segment each, different buffers even when they
+// are one node's row): the cursors move in lockstep exactly when the two id sequences are equal,
+// so the wave compares them - lengths first (almost every pair ends there), then 64 ids a step.
+// Without it a walker that took a self loop on a long row has an event per entry, looks
+// "ascending" and goes to the sequential automaton: 57 650 entries by one lane = 27 ms of a
+// 100 000-walker step that otherwise takes 3-7 (profiles/r6_sharded_n2v_steps.txt).
+__device__ __forceinline__ bool N2vSameFetched(const N2vList& c, const N2vList& p, int lane) {
+  if (c.total == 0 || c.total != p.total || c.n_seg != 1 || p.n_seg != 1) return false;
+  if (c.ids == p.ids) return true;
+  for (int32_t b = 0; b < c.total; b += 64) {
+    const int32_t j = b + lane;
+    const bool ne = j < c.total && c.ids[j] != p.ids[j];
+    if (__ballot(ne) != 0ull) return false;
+  }
+  return true;
+}
+
+// ... by a whole workgroup (every thread calls; the lists' headers in LDS)
+__device__ __forceinline__ bool N2vSameFetchedBlock(const N2vList& c, const N2vList& p) {
+  if (c.total == 0 || c.total != p.total || c.n_seg != 1 || p.n_seg != 1) return false;
+  if (c.ids == p.ids) return true;
+  int ne = 0;
+  for (int32_t j = threadIdx.x; j < c.total && !ne; j += blockDim.x) ne = c.ids[j] != p.ids[j] ? 1 : 0;
+  return __syncthreads_or(ne) == 0;
+}
+
 // row-relative position of logical entry j
 __device__ __forceinline__ int32_t N2vPhys(const N2vList& L, int32_t j) {
   for (int32_t x = 0; x < L.n_seg; ++x) {
@@ -553,13 +579,13 @@ __device__ __forceinline__ uint32_t N2vHits(const N2vVec& e, const float (&d)[kN
 // ascending (the caller then runs the sequential automaton).  *out = sampled id.
 __device__ __forceinline__ bool N2vStepParallel(const WalkArgs& a, N2vLds& S, int lane,
                                                 int64_t parent, int64_t walker, int32_t step,
-                                                int64_t* out) {
+                                                int64_t* out, const int same_in = -1) {
   const int32_t nc = S.child.total, np = S.parent.total;
   const int32_t nchunks = (nc + kN2vChunkR - 1) / kN2vChunkR;
   int32_t sh = 0;
   while ((nchunks >> sh) > kN2vCk) ++sh;
   const int32_t n_slots = nchunks >> sh;
-  const bool same = N2vSameLists(S.child, S.parent);
+  const bool same = same_in >= 0 ? same_in != 0 : N2vSameLists(S.child, S.parent);
   int32_t events = 0;
   float acc = 0.f, cin;
   float d[kN2vR];
@@ -922,7 +948,7 @@ __device__ __forceinline__ void N2vBigRound(const WalkArgs& a, N2vBigLds& S, int
 // every thread.  `s`: the step (the draw's call id is a.call_id + s; explicit lists pass 0).
 __device__ __forceinline__ int64_t N2vBigStepBody(const WalkArgs& a, N2vBigLds& S, int* phase_p, const int wv,
                                                    const int lane, const int64_t parent, const int64_t i,
-                                                   const int32_t s) {
+                                                   const int32_t s, const int same_in = -1) {
   int& phase_ref = *phase_p;
   const int32_t nc = S.seq.child.total, np = S.seq.parent.total;
   const int32_t rounds = (nc + kN2vBigRound - 1) / kN2vBigRound;
@@ -930,7 +956,7 @@ __device__ __forceinline__ int64_t N2vBigStepBody(const WalkArgs& a, N2vBigLds& 
   while ((rounds >> sh) > kN2vBigCk) ++sh;
   const int32_t n_slots = rounds >> sh;
   N2vBigState st{{0, -1, 0}, 0.f};
-  const bool same = N2vSameLists(S.seq.child, S.seq.parent);
+  const bool same = same_in >= 0 ? same_in != 0 : N2vSameLists(S.seq.child, S.seq.parent);
   const int32_t jl = threadIdx.x * kN2vR;
   float d[kN2vR], cin;
   int32_t events;

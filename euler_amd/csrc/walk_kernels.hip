@@ -465,6 +465,10 @@ thread_local int g_walk_tail = 9;         // key 43: first step of the merged wa
 // rank: 122 ms without, 123 / 111 / 114 / 99 / 99 / 104 ms with 4 096 / 8 192 / 32 768 / 65 536 /
 // 131 072 / 262 144.
 std::atomic<int> g_n2v_list_big{65536};
+// key 70: ... and walkers whose child + parent rows hold at least this many entries are handed out first
+// (the wave kernel takes tickets; 0 = index order, the default: 1 024 / 4 096 / 16 384 measured 97.7 / 95.8 /
+// 92.7 ms against 91.9 in index order before the self-loop fix, 75.5 against 71.1 after it)
+std::atomic<int> g_n2v_list_mid{0};
 std::atomic<int> g_walk_path_ch{16};      // key 64: columns the sharded walk's path kernel parks in LDS at a time
 thread_local int g_walk_grid = 1024;      // key 39: workgroups of its per-step launches (0 = one per 256 walkers)
 
@@ -489,7 +493,9 @@ struct WalkArgs {
   int32_t step_end;
   int32_t big_threshold;
   int32_t* big_queue;     // walker indices
-  int32_t* big_count;     // [0] entries queued, [1] next entry to hand out
+  int32_t* big_count;     // [0] entries queued, [1] next entry to hand out; the list step also: [2] walkers
+                          // queued as `mid` (from the queue's END downwards), [3] next ticket of the wave kernel
+  int32_t mid_threshold;  // list step: child + parent entries from which a walker is handed out FIRST (0 = none)
   // p (q) a power of two: w / p == w * inv_p in every bit (both are the correctly
   // rounded w / p); 0 = divide
   float inv_p;
@@ -1447,6 +1453,25 @@ __global__ __launch_bounds__(256) void N2vNonNegKernel(const float* w, int64_t n
   if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) *flag = 0;
 }
 
+// entries of walker i's fetched child row and of its parent's row
+__device__ __forceinline__ void N2vListSizes(const N2vListArgs& l, int64_t i, int32_t* nc, int32_t* np) {
+  const int32_t r = l.c_row[i];
+  *nc = r >= 0 ? l.c_idx[2 * (int64_t)r + 1] - l.c_idx[2 * (int64_t)r] : 0;
+  const int32_t pr = l.p_row != nullptr ? l.p_row[i] : -1;
+  *np = pr >= 0 && l.p_idx != nullptr ? l.p_idx[2 * (int64_t)pr + 1] - l.p_idx[2 * (int64_t)pr] : 0;
+}
+// 0 = an ordinary walker, 1 = mid (handed out first), 2 = big (N2vBigStepListKernel's)
+__device__ __forceinline__ int N2vListClass(const WalkArgs& a, const N2vListArgs& l, int64_t i) {
+  int32_t nc, np;
+  N2vListSizes(l, i, &nc, &np);
+  if (a.big_threshold > 0 && nc >= a.big_threshold) return 2;
+  return a.mid_threshold > 0 && (int64_t)nc + np >= a.mid_threshold ? 1 : 0;
+}
+
+// The walkers are HANDED OUT (a.big_count != NULL): a wave takes a ticket per walker instead of
+// every 16 384th one - first the walkers N2vListClassifyKernel queued as `mid` (long rows: the
+// launch ends when its last wave does, so the long ones start first), then the others in index
+// order.  Which wave draws for a walker does not matter: the draw is keyed by the walker's index.
 template <bool PAR>
 __global__ __launch_bounds__(256, kWavesPerSimd) void Node2VecListWaveKernel(const WalkArgs a,
                                                                              const N2vListArgs l) {
@@ -1454,7 +1479,24 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void Node2VecListWaveKernel(con
   N2vLds& S = lds_all[threadIdx.x >> 6];
   const int lane = threadIdx.x & 63;
   const int64_t waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < l.n; i += waves) {
+  const bool tickets = a.big_count != nullptr;
+  const int64_t n_mid = tickets ? a.big_count[2] : 0;
+  int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  for (;;) {
+    if (tickets) {
+      int32_t t = 0;
+      if (lane == 0) t = atomicAdd(a.big_count + 3, 1);
+      t = __builtin_amdgcn_readfirstlane(t);
+      if (t < n_mid) {
+        i = a.big_queue[l.n - 1 - t];
+      } else {
+        i = (int64_t)t - n_mid;
+        if (i >= l.n) break;
+        if (N2vListClass(a, l, i) != 0) continue;         // queued: a mid ticket / a workgroup takes it
+      }
+    } else if (i >= l.n) {
+      break;
+    }
     const int64_t parent = l.parent_ids[i];
     WaveSync();
     if (lane == 0) {
@@ -1463,12 +1505,16 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void Node2VecListWaveKernel(con
     }
     WaveSync();
     const int32_t nc = S.child.total;
-    if (a.big_threshold > 0 && nc >= a.big_threshold) continue;   // N2vBigStepListKernel's
-    int64_t sample_id = l.default_node;
-    bool done = false;
-    if (PAR && nc > 0) done = N2vStepParallel(a, S, lane, parent, i, 0, &sample_id);
-    if (nc > 0 && !done) sample_id = N2vStepSequential(a, S, lane, parent, i, 0);
-    if (lane == 0) l.out[i] = sample_id;
+    if (!(a.big_threshold > 0 && nc >= a.big_threshold)) {         // (else N2vBigStepListKernel's)
+      int64_t sample_id = l.default_node;
+      bool done = false;
+      if (PAR && nc > 0)
+        done = N2vStepParallel(a, S, lane, parent, i, 0, &sample_id, N2vSameFetched(S.child, S.parent, lane) ? 1 : 0);
+      if (lane == 0 && nc > 0) { N2vCount(done ? 0 : 2, 1); N2vCount(done ? 1 : 3, (unsigned long long)nc); }
+      if (nc > 0 && !done) sample_id = N2vStepSequential(a, S, lane, parent, i, 0);
+      if (lane == 0) l.out[i] = sample_id;
+    }
+    if (!tickets) i += waves;
   }
 }
 
@@ -1483,17 +1529,22 @@ __global__ __launch_bounds__(256) void N2vListClassifyKernel(const WalkArgs a, c
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t n64 = (l.n + 63) & ~(int64_t)63;          // (whole waves run the loop: ballot, shuffle)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n64; i += stride) {
-    bool big = false;
-    if (i < l.n) {
-      const int32_t r = l.c_row[i];
-      big = r >= 0 && l.c_idx[2 * (int64_t)r + 1] - l.c_idx[2 * (int64_t)r] >= a.big_threshold;
+    const int cls = i < l.n ? N2vListClass(a, l, i) : 0;
+    const bool big = cls == 2, mid = cls == 1;
+    const unsigned long long m = __ballot(big), mm = __ballot(mid);
+    if (m != 0ull) {
+      int32_t base = 0;
+      if (lane == 0) base = atomicAdd(a.big_count, (int32_t)__popcll(m));
+      base = __shfl(base, 0);
+      if (big) a.big_queue[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)i;
     }
-    const unsigned long long m = __ballot(big);
-    if (m == 0ull) continue;
-    int32_t base = 0;
-    if (lane == 0) base = atomicAdd(a.big_count, (int32_t)__popcll(m));
-    base = __shfl(base, 0);
-    if (big) a.big_queue[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)i;
+    if (mm != 0ull) {
+      // (the big walkers fill the queue from its start, the mid ones from its end: n slots hold both)
+      int32_t base = 0;
+      if (lane == 0) base = atomicAdd(a.big_count + 2, (int32_t)__popcll(mm));
+      base = __shfl(base, 0);
+      if (mid) a.big_queue[l.n - 1 - (base + __popcll(mm & ((1ull << lane) - 1ull)))] = (int32_t)i;
+    }
   }
 }
 
@@ -1515,7 +1566,8 @@ __global__ __launch_bounds__(64 * kN2vBigWaves) void N2vBigStepListKernel(const 
       N2vBuildListFetched(&S.seq.parent, l.p_idx, l.p_ids, nullptr, l.p_row != nullptr ? l.p_row[i] : -1);
     }
     __syncthreads();
-    const int64_t result = N2vBigStepBody(a, S, &phase, wv, lane, parent, i, 0);
+    const int same = N2vSameFetchedBlock(S.seq.child, S.seq.parent) ? 1 : 0;
+    const int64_t result = N2vBigStepBody(a, S, &phase, wv, lane, parent, i, 0, same);
     if (threadIdx.x == 0) l.out[i] = result;
   }
 }
@@ -1712,20 +1764,22 @@ int euler_gpu_node2vec_step(void* stream, uint64_t seed, uint32_t call_id, int64
     // long rows by a workgroup each (key 69: the threshold, 0 = none)
     int32_t* q = nullptr;
     const int32_t big_at = g_n2v_list_big.load();
-    const bool big = big_at > 0 && n < (1ll << 31);
+    const bool big = big_at > 0 && n <= (1ll << 30);
     if (big) {
       const size_t q_bytes = ((size_t)n * 4 + 15) & ~(size_t)15;
       EG_HIP(hipMallocAsync((void**)&q, q_bytes + 16, (hipStream_t)stream));
       w.big_queue = q;
       w.big_count = (int32_t*)((uint8_t*)q + q_bytes);
       w.big_threshold = big_at;
-      EG_HIP(hipMemsetAsync(w.big_count, 0, 8, (hipStream_t)stream));
+      w.mid_threshold = g_n2v_list_mid.load();
+      EG_HIP(hipMemsetAsync(w.big_count, 0, 16, (hipStream_t)stream));
       hipLaunchKernelGGL(N2vListClassifyKernel, dim3(GridFor(n, 256)), dim3(256), 0, (hipStream_t)stream, w, a);
     }
     hipLaunchKernelGGL(Node2VecListWaveKernel<true>, dim3(GridFor(n * 64, 256)), dim3(256), 0,
                        (hipStream_t)stream, w, a);
-    // (on a side stream forked from the caller's the long rows' workgroups did not overlap the
-    // other walkers' waves: 512 persistent workgroups of 1 024 threads hold every CU - same 111 ms)
+    // (the long rows' workgroups on a side stream, launched before or after the waves: slower at
+    // every size tried - 512 workgroups of 1 024 threads hold every CU, fewer become the step's
+    // tail: 96 / 192 workgroups 78 / 72 ms against 70.5, profiles/r6_sharded_n2v_ab2.txt)
     if (big)
       hipLaunchKernelGGL(N2vBigStepListKernel, dim3(512), dim3(64 * kN2vBigWaves), 0, (hipStream_t)stream, w, a);
     EG_HIP(hipGetLastError());

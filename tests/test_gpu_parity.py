@@ -2335,6 +2335,63 @@ def test_node2vec_step_on_fetched_lists_wave_and_lane(EA, O, torch_cuda):
         L.euler_gpu_set_tuning(69, 65536)
 
 
+def test_node2vec_step_self_loop_rows_in_two_buffers(EA, O, torch_cuda):
+    """A walker that took a self loop stands on its parent: on FETCHED rows the child list and the
+    parent's list are then the same ids in two buffers (this step's rows, last step's rows), every
+    child is a common neighbour and the parent cursor moves on every entry.  The kernels
+    recognise equal id sequences (N2vSameFetched / N2vSameFetchedBlock) instead of handing a
+    long row to the sequential automaton; rows that differ in one entry (first / middle / last),
+    or in length, must not be taken for equal.  Wave kernel, workgroup kernel (key 69 = 2 000), the
+    ticket order with long rows first (key 70) and the lane-per-walker loop == the oracle's
+    restatement of the client loop (random_walk_op.cc:83-168)."""
+    torch = torch_cuda
+    from euler_amd import _lib, ops
+    L = _lib.lib()
+    rng = np.random.default_rng(77)
+    lens = [1, 2, 63, 64, 65, 300, 2500, 5000]
+    c_idx, c_ids, c_w, p_idx, p_ids, c_row, p_row, parent = [], [], [], [], [], [], [], []
+    def add_row(idx, ids, row):
+        idx.append([len(ids), len(ids) + len(row)])
+        ids.extend(int(x) for x in row)
+    for n in lens:
+        row = rng.integers(1, 1 << 40, n)
+        if n > 2:
+            row[n // 3] = 424242                       # the node itself: the self loop's edge
+        variants = [row.copy()]                         # the parent's row: the same ids ...
+        for at in (0, n // 2, n - 1):                   # ... or one entry apart
+            v = row.copy(); v[at] += 1; variants.append(v)
+        variants.append(row[:-1].copy() if n > 1 else np.concatenate([row, row]))   # another length
+        variants.append(np.sort(row))                   # an ascending parent row (events)
+        for v in variants:
+            add_row(c_idx, c_ids, row)
+            c_w.extend(rng.uniform(0.5, 8.0, n).astype(np.float32).tolist())
+            add_row(p_idx, p_ids, v)
+            c_row.append(len(c_idx) - 1); p_row.append(len(p_idx) - 1); parent.append(424242)
+    n_w = len(c_row)
+    # several walkers per row pair (rows are shared between walkers on one node)
+    c_row = np.asarray(c_row * 3, np.int32); p_row = np.asarray(p_row * 3, np.int32)
+    parent = np.asarray(parent * 3, np.int64)
+    c_idx = np.asarray(c_idx, np.int32); p_idx = np.asarray(p_idx, np.int32)
+    c_ids = np.asarray(c_ids, np.uint64); p_ids = np.asarray(p_ids, np.uint64)
+    c_w = np.asarray(c_w, np.float32)
+    cu = lambda a: torch.as_tensor(a.view(np.int64) if a.dtype == np.uint64 else a).cuda()
+    try:
+        for p_, q_ in ((0.25, 4.0), (3.0, 0.7)):
+            want = O.node2vec_step_lists(9, 41, c_row, c_idx, c_ids, c_w, p_row, p_idx, p_ids, parent, p_, q_, -5)
+            for mode, big_at, mid_at in ((2, 65536, 0), (2, 2000, 0), (2, 2000, 1000), (2, 65536, 128), (0, 65536, 0)):
+                L.euler_gpu_set_tuning(7, mode)
+                L.euler_gpu_set_tuning(69, big_at)
+                L.euler_gpu_set_tuning(70, mid_at)
+                got = ops.node2vec_step(9, 41, cu(c_row), cu(c_idx), cu(c_ids), cu(c_w), cu(p_row), cu(p_idx),
+                                        cu(p_ids), cu(parent), p_, q_, -5)
+                assert np.array_equal(t2n(got), want), (p_, q_, mode, big_at, mid_at)
+        assert n_w == len(lens) * 6
+    finally:
+        L.euler_gpu_set_tuning(7, 2)
+        L.euler_gpu_set_tuning(69, 65536)
+        L.euler_gpu_set_tuning(70, 0)
+
+
 @pytest.mark.parametrize("index_alone", [0, 1])
 def test_heavy_tailed_weights_take_the_second_chance(EA, O, torch_cuda, index_alone):
     """Rows whose weights are far from even - Pareto(0.7): dust among giants - make the weight-bucket

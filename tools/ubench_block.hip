@@ -13,6 +13,10 @@
 //   MODE 6: MODE 5 with the key chunks sent straight to LDS (global_load_lds_dwordx4) and read
 //           back from there - the staging of fanout_plain.h's cooperative build
 //   MODE 7: 4 lanes share a line, all four chunks (64 bytes) through LDS-DMA, dependent id private
+//   MODE 8: lane-private line, ONE dwordx4 (a predictor: quantized keys) + a dependent ALIGNED
+//           dwordx4 of the same line
+//   MODE 9: as 8, the dependent dwordx4 at a 4-byte-aligned offset 16 + 12 i (a {sum, id, sum}
+//           window that may straddle a 64-byte boundary)
 // Independent loads per wave-step = UNROLL lines per lane (MODEs 0-2) so that the memory-level
 // parallelism per wave matches the sampler's (a pair of draws per lane).
 //   hipcc --offload-arch=gfx950 -O3 tools/ubench_block.hip -o gpurun_out/ubench_block
@@ -44,7 +48,26 @@ __global__ __launch_bounds__(256) void Fetch(const uint32_t* __restrict__ base, 
   uint64_t x = Mix(MODE == 3 ? tid >> 3 : (MODE == 4 || MODE == 7) ? tid >> 2
                    : (MODE == 5 || MODE == 6) ? (uint64_t)(tid >> 6) * 32 + grp3 : tid);
   for (int i = 0; i < iters; ++i) {
-    if (MODE <= 2) {
+    if (MODE == 8 || MODE == 9) {
+      const uint64_t l0 = (x >> 8) % n_lines, l1 = (Mix(x) >> 8) % n_lines;
+      const uint32_t* p0 = base + l0 * 32;
+      const uint32_t* p1 = base + l1 * 32;
+      const uint4 a = *reinterpret_cast<const uint4*>(p0), b = *reinterpret_cast<const uint4*>(p1);
+      uint32_t v = a.x ^ a.w ^ b.y ^ b.z;
+      uint4 c, d;
+      if (MODE == 8) {
+        c = reinterpret_cast<const uint4*>(p0)[1 + (v % 7u)];
+        d = reinterpret_cast<const uint4*>(p1)[1 + ((v >> 8) % 7u)];
+      } else {
+        const uint32_t* q0 = p0 + 4 + 3 * (v % 9u);
+        const uint32_t* q1 = p1 + 4 + 3 * ((v >> 8) % 9u);
+        c.x = q0[0]; c.y = q0[1]; c.z = q0[2]; c.w = q0[3];
+        d.x = q1[0]; d.y = q1[1]; d.z = q1[2]; d.w = q1[3];
+      }
+      v ^= c.x ^ c.w ^ d.y ^ d.z;
+      acc += v;
+      x = Mix(x + v + 0x9E3779B97F4A7C15ULL);
+    } else if (MODE <= 2) {
       // two independent lines per lane and step (a pair of draws)
       const uint64_t l0 = (x >> 8) % n_lines, l1 = (Mix(x) >> 8) % n_lines;
       const uint4* p0 = reinterpret_cast<const uint4*>(base + l0 * 32);
@@ -146,7 +169,7 @@ __global__ void Fill(uint32_t* p, uint64_t n) {
 template <int MODE>
 static void Run(const uint32_t* buf, uint64_t n_lines, const char* name, uint32_t* sink, int wpc) {
   // wpc waves per CU resident: 256 CUs x wpc / 4 workgroups of 256 threads
-  const int block = 256, grid = 256 * wpc / 4, iters = MODE == 3 ? 256 : (MODE == 4 || MODE == 7) ? 128 : MODE >= 5 ? 96 : 32;
+  const int block = 256, grid = 256 * wpc / 4, iters = MODE == 3 ? 256 : (MODE == 4 || MODE == 7) ? 128 : MODE >= 8 ? 32 : MODE >= 5 ? 96 : 32;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   hipLaunchKernelGGL(Fetch<MODE>, dim3(grid), dim3(block), 8192, 0, buf, n_lines, iters, sink);
@@ -160,12 +183,13 @@ static void Run(const uint32_t* buf, uint64_t n_lines, const char* name, uint32_
   CK(hipEventElapsedTime(&ms, e0, e1));
   ms /= reps;
   const double lane_steps = (double)grid * block * iters;
-  const double lines = lane_steps * 2.0 / (MODE == 3 ? 8.0 : (MODE == 4 || MODE == 7) ? 4.0 : MODE >= 5 ? 64.0 / 21.0 : 1.0);
+  const double lines = lane_steps * 2.0 / (MODE == 3 ? 8.0 : (MODE == 4 || MODE == 7) ? 4.0 : MODE >= 8 ? 1.0 : MODE >= 5 ? 64.0 / 21.0 : 1.0);
   printf("%-44s waves/CU %2d  %8.3f ms  %7.2f G lines/s\n", name, wpc, ms, lines / ms / 1e6);
 }
 
-int main() {
-  const uint64_t bytes = 16ULL << 30;
+int main(int argc, char** argv) {
+  // optional argument: GiB of index to draw the random lines from (default 16)
+  const uint64_t bytes = (uint64_t)(argc > 1 ? atoll(argv[1]) : 16) << 30;
   uint32_t* buf; uint32_t* sink;
   CK(hipMalloc(&buf, bytes));
   CK(hipMalloc(&sink, 256 * 32 * 64 * 4));
@@ -181,6 +205,8 @@ int main() {
     Run<5>(buf, nl, "3 lanes share a line + private id", sink, wpc);
     Run<6>(buf, nl, "3 lanes share a line via LDS-DMA + private id", sink, wpc);
     Run<7>(buf, nl, "4 lanes, 64 B via LDS-DMA + private id", sink, wpc);
+    Run<8>(buf, nl, "private line, 1 x dwordx4 + dependent x4", sink, wpc);
+    Run<9>(buf, nl, "private line, 1 x dwordx4 + dep. x4 at 16+12i", sink, wpc);
     printf("\n");
   }
   return 0;
