@@ -469,6 +469,9 @@ std::atomic<int> g_n2v_list_big{65536};
 // (the wave kernel takes tickets; 0 = index order, the default: 1 024 / 4 096 / 16 384 measured 97.7 / 95.8 /
 // 92.7 ms against 91.9 in index order before the self-loop fix, 75.5 against 71.1 after it)
 std::atomic<int> g_n2v_list_mid{0};
+// key 71: ... and so do walkers whose PARENT's row has at least this many entries: a wave moves the parent cursor
+// 64 entries a (dependent) step - 9 000 steps = 6 ms on the 578 088-entry hub - a workgroup 1 024 (0 = by the child row alone)
+std::atomic<int> g_n2v_list_big_parent{65536};
 std::atomic<int> g_walk_path_ch{16};      // key 64: columns the sharded walk's path kernel parks in LDS at a time
 thread_local int g_walk_grid = 1024;      // key 39: workgroups of its per-step launches (0 = one per 256 walkers)
 
@@ -496,6 +499,7 @@ struct WalkArgs {
   int32_t* big_count;     // [0] entries queued, [1] next entry to hand out; the list step also: [2] walkers
                           // queued as `mid` (from the queue's END downwards), [3] next ticket of the wave kernel
   int32_t mid_threshold;  // list step: child + parent entries from which a walker is handed out FIRST (0 = none)
+  int32_t big_parent;     // list step: parent rows of at least this many entries also go to a workgroup (0 = none)
   // p (q) a power of two: w / p == w * inv_p in every bit (both are the correctly
   // rounded w / p); 0 = divide
   float inv_p;
@@ -1464,7 +1468,7 @@ __device__ __forceinline__ void N2vListSizes(const N2vListArgs& l, int64_t i, in
 __device__ __forceinline__ int N2vListClass(const WalkArgs& a, const N2vListArgs& l, int64_t i) {
   int32_t nc, np;
   N2vListSizes(l, i, &nc, &np);
-  if (a.big_threshold > 0 && nc >= a.big_threshold) return 2;
+  if (a.big_threshold > 0 && (nc >= a.big_threshold || (a.big_parent > 0 && nc > 0 && np >= a.big_parent))) return 2;
   return a.mid_threshold > 0 && (int64_t)nc + np >= a.mid_threshold ? 1 : 0;
 }
 
@@ -1505,7 +1509,9 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void Node2VecListWaveKernel(con
     }
     WaveSync();
     const int32_t nc = S.child.total;
-    if (!(a.big_threshold > 0 && nc >= a.big_threshold)) {         // (else N2vBigStepListKernel's)
+    const bool is_big = a.big_threshold > 0 &&
+                        (nc >= a.big_threshold || (a.big_parent > 0 && nc > 0 && S.parent.total >= a.big_parent));
+    if (!is_big) {                                                 // (else N2vBigStepListKernel's)
       int64_t sample_id = l.default_node;
       bool done = false;
       if (PAR && nc > 0)
@@ -1772,6 +1778,7 @@ int euler_gpu_node2vec_step(void* stream, uint64_t seed, uint32_t call_id, int64
       w.big_count = (int32_t*)((uint8_t*)q + q_bytes);
       w.big_threshold = big_at;
       w.mid_threshold = g_n2v_list_mid.load();
+      w.big_parent = g_n2v_list_big_parent.load();
       EG_HIP(hipMemsetAsync(w.big_count, 0, 16, (hipStream_t)stream));
       hipLaunchKernelGGL(N2vListClassifyKernel, dim3(GridFor(n, 256)), dim3(256), 0, (hipStream_t)stream, w, a);
     }

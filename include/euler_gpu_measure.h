@@ -146,7 +146,11 @@ extern "C" {
  *        the row of the entry they reach (10; walks of at least T + 8 steps; 0 = one pass).
  * key 69: PROCESS-WIDE: euler_gpu_node2vec_step (the sharded node2vec walk's step on fetched rows):
  *        child rows of at least this many entries are drawn by a workgroup of 16 waves each
- *        (65536; 0 = every row by one wave).
+ *        (65536; 0 = every row by one wave).  key 71: ... and so are walkers whose PARENT's row
+ *        has at least this many entries (65536; 0 = by the child row alone: a wave moves the
+ *        parent cursor 64 entries a dependent step).  key 70: its wave kernel hands the walkers
+ *        out by ticket; walkers whose child + parent rows hold at least this many entries first
+ *        (0 = index order, the default).
  * All settings produce identical results; the knobs exist for A/B measurements
  * and tests.  They are THREAD-LOCAL: a call changes the launches the calling host
  * thread enqueues afterwards and nobody else's (new threads start from the
