@@ -145,91 +145,98 @@ __global__ __launch_bounds__(256) void FullNbFillKernel(
 // e is the first i with idx[2i+1] > e (row ends are non-decreasing; rows without
 // neighbours have begin == end and are skipped by the search).
 constexpr int kFullNbPerLane = 4;
+constexpr int kFullNbWindow = 64 * kFullNbPerLane;
+constexpr int kFullNbSuper = 8;      // windows per pair of row searches when the call has many entries
+
+// first row i of [lo, hi] with idx[2 i + 1] > e (hi if none)
+__device__ __forceinline__ int64_t FullNbRowOf(const int32_t* __restrict__ idx, int64_t lo, int64_t hi, int64_t e) {
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)idx[2 * mid + 1] > e) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+
+// entry q of a row's listed segments, in listed order: its position in the row and its type
+__device__ __forceinline__ void FullNbEntry(const FullNbArgs& a, const RowMeta& m, int32_t q, int32_t* p_out,
+                                            int32_t* t_out) {
+  int32_t t = 0, p = 0;
+  for (int32_t x = 0; x < a.k; ++x) {
+    t = a.et[x];
+    if (t < 0 || t >= a.g.T) continue;
+    const int32_t b = t == 0 ? 0 : m.type_end[t - 1];
+    const int32_t len = m.type_end[t] - b;
+    if (q < len) { p = b + q; break; }
+    q -= len;
+  }
+  *p_out = p; *t_out = t;
+}
+
 __global__ __launch_bounds__(256) void FullNbFillBalancedKernel(
     const FullNbArgs a, const int32_t* __restrict__ idx, uint64_t* __restrict__ out_id,
     float* __restrict__ out_w, int32_t* __restrict__ out_t) {
   const int64_t total = (int64_t)idx[2 * (a.n - 1) + 1];
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x * kFullNbPerLane;
   const int lane = threadIdx.x & 63;
   const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  for (int64_t w0 = ((int64_t)blockIdx.x * blockDim.x + (int64_t)wave_in_block * 64) * kFullNbPerLane; w0 < total;
-       w0 += stride) {
-    // (round 6) The rows of the wave's first and last entry, by the scalar unit.  A wave whose 256
-    // entries lie inside ONE row - a hub's: the rows a node2vec walk fetches are 1 500 entries
-    // long on average - takes them lane by lane, entry w0 + 64 j + lane: every load and store of
-    // the wave one contiguous run, the row's record read once.
-    const int64_t w_n = w0 + 64 * kFullNbPerLane < total ? 64 * kFullNbPerLane : total - w0;
-    int64_t r0, r1;
-    {
-      int64_t lo = 0, hi = a.n - 1;
-      while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if ((int64_t)idx[2 * mid + 1] > w0) hi = mid; else lo = mid + 1;
+  // A wave takes SUPER windows of 256 entries at a time and finds the rows of the first and last
+  // entry by the scalar unit - two bisections of ~15 dependent loads each.  Calls with many
+  // entries (a node2vec walk fetches 140 M a step, rows of 1 500 entries on average) take 8
+  // windows per pair of searches: the searches, not the copies, were the kernel's time (1.5 ms a
+  // step at 2.2 TB/s).  Small calls keep one window per wave-step (more waves than CUs).
+  const int super = total >= ((int64_t)32 << 20) ? kFullNbSuper : 1;
+  const int64_t span = (int64_t)kFullNbWindow * super;
+  const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 6) * span;
+  for (int64_t W0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block) * span; W0 < total; W0 += stride) {
+    const int64_t W_n = W0 + span < total ? span : total - W0;
+    const int64_t R0 = FullNbRowOf(idx, 0, a.n - 1, W0);
+    const int64_t R1 = FullNbRowOf(idx, R0, a.n - 1, W0 + W_n - 1);
+    for (int64_t w0 = W0; w0 < W0 + W_n; w0 += kFullNbWindow) {
+      const int64_t w_n = w0 + kFullNbWindow < W0 + W_n ? kFullNbWindow : W0 + W_n - w0;
+      int64_t r0 = R0, r1 = R1;
+      if (R0 != R1 && super > 1) {
+        r0 = FullNbRowOf(idx, R0, R1, w0);
+        r1 = FullNbRowOf(idx, r0, R1, w0 + w_n - 1);
       }
-      r0 = lo;
-      hi = a.n - 1;
-      while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if ((int64_t)idx[2 * mid + 1] > w0 + w_n - 1) hi = mid; else lo = mid + 1;
-      }
-      r1 = lo;
-    }
-    if (r0 == r1) {
-      const int64_t row = FindRow(a.g, a.ids[r0]);
-      const RowMeta m = LoadRowMeta(a.g, row < 0 ? 0 : row);
-      const int64_t begin = idx[2 * r0];
-      const float* nw = a.g.prefix_w + m.row_ptr;
-      const uint64_t* nbr = a.g.nbr + m.row_ptr;
-      for (int64_t e = w0 + lane; e < w0 + w_n; e += 64) {
-        int32_t q = (int32_t)(e - begin);
-        int32_t t = 0, p = 0;
-        for (int32_t x = 0; x < a.k; ++x) {
-          t = a.et[x];
-          if (t < 0 || t >= a.g.T) continue;
-          const int32_t b = t == 0 ? 0 : m.type_end[t - 1];
-          const int32_t len = m.type_end[t] - b;
-          if (q < len) { p = b + q; break; }
-          q -= len;
+      if (r0 == r1) {
+        // (round 6) the window - or the whole super window - lies inside ONE row (a hub's): its
+        // entries lane by lane, entry w0 + 64 j + lane: every load and store of the wave one
+        // contiguous run, the row's record read once
+        const int64_t row = FindRow(a.g, a.ids[r0]);
+        const RowMeta m = LoadRowMeta(a.g, row < 0 ? 0 : row);
+        const int64_t begin = idx[2 * r0];
+        const float* nw = a.g.prefix_w + m.row_ptr;
+        const uint64_t* nbr = a.g.nbr + m.row_ptr;
+        const int64_t e_end = R0 == R1 ? W0 + W_n : w0 + w_n;
+        for (int64_t e = w0 + lane; e < e_end; e += 64) {
+          int32_t p, t;
+          FullNbEntry(a, m, (int32_t)(e - begin), &p, &t);
+          out_id[e] = nbr[p];
+          out_w[e] = __fsub_rn(nw[p], p == 0 ? 0.f : nw[p - 1]);
+          out_t[e] = t;
         }
-        out_id[e] = nbr[p];
+        if (R0 == R1) break;            // the super window is done
+        continue;
+      }
+      const int64_t e0 = w0 + (int64_t)lane * kFullNbPerLane;
+      if (e0 >= w0 + w_n) continue;
+      int64_t i = FullNbRowOf(idx, r0, r1, e0);          // first row whose end exceeds e0
+      int64_t row = FindRow(a.g, a.ids[i]);
+      RowMeta m = LoadRowMeta(a.g, row < 0 ? 0 : row);
+      int64_t begin = idx[2 * i], end = idx[2 * i + 1];
+      const int64_t e1 = e0 + kFullNbPerLane < w0 + w_n ? e0 + kFullNbPerLane : w0 + w_n;
+      for (int64_t e = e0; e < e1; ++e) {
+        while (e >= end) {                           // next row that has entries
+          ++i;
+          begin = idx[2 * i]; end = idx[2 * i + 1];
+          if (end > begin) { row = FindRow(a.g, a.ids[i]); m = LoadRowMeta(a.g, row); }
+        }
+        int32_t p, t;
+        FullNbEntry(a, m, (int32_t)(e - begin), &p, &t);
+        const float* nw = a.g.prefix_w + m.row_ptr;
+        out_id[e] = a.g.nbr[m.row_ptr + p];
         out_w[e] = __fsub_rn(nw[p], p == 0 ? 0.f : nw[p - 1]);
         out_t[e] = t;
       }
-      continue;
-    }
-    const int64_t e0 = w0 + (int64_t)lane * kFullNbPerLane;
-    if (e0 >= total) continue;
-    int64_t lo = r0, hi = r1;                     // first row whose end exceeds e0
-    while (lo < hi) {
-      const int64_t mid = (lo + hi) >> 1;
-      if ((int64_t)idx[2 * mid + 1] > e0) hi = mid; else lo = mid + 1;
-    }
-    int64_t i = lo;
-    int64_t row = FindRow(a.g, a.ids[i]);
-    RowMeta m = LoadRowMeta(a.g, row < 0 ? 0 : row);
-    int64_t begin = idx[2 * i], end = idx[2 * i + 1];
-    const int64_t e1 = e0 + kFullNbPerLane < total ? e0 + kFullNbPerLane : total;
-    for (int64_t e = e0; e < e1; ++e) {
-      while (e >= end) {                           // next row that has entries
-        ++i;
-        begin = idx[2 * i]; end = idx[2 * i + 1];
-        if (end > begin) { row = FindRow(a.g, a.ids[i]); m = LoadRowMeta(a.g, row); }
-      }
-      // entry q of the row's listed segments, in listed order
-      int32_t q = (int32_t)(e - begin);
-      int32_t t = 0, p = 0;
-      for (int32_t x = 0; x < a.k; ++x) {
-        t = a.et[x];
-        if (t < 0 || t >= a.g.T) continue;
-        const int32_t b = t == 0 ? 0 : m.type_end[t - 1];
-        const int32_t len = m.type_end[t] - b;
-        if (q < len) { p = b + q; break; }
-        q -= len;
-      }
-      const float* nw = a.g.prefix_w + m.row_ptr;
-      out_id[e] = a.g.nbr[m.row_ptr + p];
-      out_w[e] = __fsub_rn(nw[p], p == 0 ? 0.f : nw[p - 1]);
-      out_t[e] = t;
     }
   }
 }
@@ -500,6 +507,7 @@ struct WalkArgs {
                           // queued as `mid` (from the queue's END downwards), [3] next ticket of the wave kernel
   int32_t mid_threshold;  // list step: child + parent entries from which a walker is handed out FIRST (0 = none)
   int32_t big_parent;     // list step: parent rows of at least this many entries also go to a workgroup (0 = none)
+  int32_t ticket_batch;   // list step: walkers a wave takes per ticket (1 on long rows, 8 on rows of a few entries)
   // p (q) a power of two: w / p == w * inv_p in every bit (both are the correctly
   // rounded w / p); 0 = divide
   float inv_p;
@@ -1486,11 +1494,20 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void Node2VecListWaveKernel(con
   const bool tickets = a.big_count != nullptr;
   const int64_t n_mid = tickets ? a.big_count[2] : 0;
   int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  // (a.ticket_batch walkers per atomic: 100 000 single tickets on one address made the FIRST step -
+  // rows of ten entries - 1.47 ms long where the static assignment took 0.31, 0.54 with 8 per ticket;
+  // on rows of 1 400 entries 8 per ticket cost 3.0 ms a step against 2.5 with one)
+  const int32_t batch = a.ticket_batch > 0 ? a.ticket_batch : 1;
+  int32_t t_next = 0, t_end = 0;
   for (;;) {
     if (tickets) {
-      int32_t t = 0;
-      if (lane == 0) t = atomicAdd(a.big_count + 3, 1);
-      t = __builtin_amdgcn_readfirstlane(t);
+      if (t_next == t_end) {
+        int32_t t0 = 0;
+        if (lane == 0) t0 = atomicAdd(a.big_count + 3, batch);
+        t_next = __builtin_amdgcn_readfirstlane(t0);
+        t_end = t_next + batch;
+      }
+      const int32_t t = t_next++;
       if (t < n_mid) {
         i = a.big_queue[l.n - 1 - t];
       } else {
@@ -1779,6 +1796,7 @@ int euler_gpu_node2vec_step(void* stream, uint64_t seed, uint32_t call_id, int64
       w.big_threshold = big_at;
       w.mid_threshold = g_n2v_list_mid.load();
       w.big_parent = g_n2v_list_big_parent.load();
+      w.ticket_batch = c_entries < 32 * n ? 8 : c_entries < 256 * n ? 2 : 1;
       EG_HIP(hipMemsetAsync(w.big_count, 0, 16, (hipStream_t)stream));
       hipLaunchKernelGGL(N2vListClassifyKernel, dim3(GridFor(n, 256)), dim3(256), 0, (hipStream_t)stream, w, a);
     }
