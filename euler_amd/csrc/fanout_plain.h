@@ -22,14 +22,18 @@
 //     second id array): 5.3 KB of LDS per wave at 32 slots per pass (9-10 KB before);
 //   * weights / types leave as 16-byte stores over PAIRS of rows (2 c2 floats = c2 / 2 chunks,
 //     the chunk -> (row, column) pattern a per-lane constant).
-// COOP = true (the shipped build): a draw's block is fetched by THREE lanes, 16 bytes each, as
-// one coalesced request per line, staged in LDS and read back by the lane that owns the draw.
-// Why (tools/ubench_block.hip, profiles/r6_ubench_block.txt): a lane that asks for its own line
-// with three 16-byte loads and then a dependent 8-byte one - what every build up to round 5
-// did - makes FOUR requests per line, and the chip completes 19.5 G such lines/s at ANY
-// residency (8 to 32 waves per CU): exactly the 16.6-20 G lines/s the round-5 kernel's read side
-// ran at, however its geometry was tuned.  One request per line: 48 G lines/s; lanes sharing a
-// line + a dependent id request: 34-36 G.  The bound was requests, not lines and not latency.
+// COOP = true (tuning key 54; NOT the shipped build): a draw's block is fetched by THREE lanes, 16 bytes
+// each, as one coalesced request per line, staged in LDS and read back by the lane that owns the
+// draw.  Why it was built (tools/ubench_block.hip, profiles/r6_ubench_block.txt): a lane that asks
+// for its own line with three 16-byte loads and then a dependent 8-byte one - what every build
+// does - makes FOUR requests per line, and the chip completes 19.5 G such lines/s at ANY residency
+// (8 to 32 waves per CU): the rate the kernel's read side runs at however its geometry is tuned.
+// One request per line: 48 G lines/s; lanes sharing a line + a dependent id request: 34-36 G.
+// (What a request costs is its address translation: inside ~2 GiB three loads of a line cost what
+// one costs - profiles/r6_ubench_block_footprint.txt)  In the kernel the staging
+// gives the saving back: 0.237-0.244 ms against 0.222-0.229 (profiles/r6_sweep3_plain_coop.txt).
+// LITE2 = true (key 57): hop 2 asks for two key chunks and the third only at a block's ends -
+// 0.247 against 0.233 ms (profiles/r6_sweep4_plain_lite.txt).  Both stay as parity-tested variants.
 // Bit-identical outputs (tests/test_gpu_parity.py runs every fanout test through both builds).
 #ifndef EULER_AMD_CSRC_FANOUT_PLAIN_H_
 #define EULER_AMD_CSRC_FANOUT_PLAIN_H_
