@@ -479,6 +479,7 @@ std::atomic<int> g_n2v_list_mid{0};
 // key 71: ... and so do walkers whose PARENT's row has at least this many entries: a wave moves the parent cursor
 // 64 entries a (dependent) step - 9 000 steps = 6 ms on the 578 088-entry hub - a workgroup 1 024 (0 = by the child row alone)
 std::atomic<int> g_n2v_list_big_parent{65536};
+std::atomic<int> g_n2v_list_merged{1};     // key 72: both queues in one launch (N2vListMergedKernel); 0 = two launches
 std::atomic<int> g_walk_path_ch{16};      // key 64: columns the sharded walk's path kernel parks in LDS at a time
 thread_local int g_walk_grid = 1024;      // key 39: workgroups of its per-step launches (0 = one per 256 walkers)
 
@@ -1485,10 +1486,7 @@ __device__ __forceinline__ int N2vListClass(const WalkArgs& a, const N2vListArgs
 // launch ends when its last wave does, so the long ones start first), then the others in index
 // order.  Which wave draws for a walker does not matter: the draw is keyed by the walker's index.
 template <bool PAR>
-__global__ __launch_bounds__(256, kWavesPerSimd) void Node2VecListWaveKernel(const WalkArgs a,
-                                                                             const N2vListArgs l) {
-  __shared__ N2vLds lds_all[4];
-  N2vLds& S = lds_all[threadIdx.x >> 6];
+__device__ __forceinline__ void N2vListWaveLoop(const WalkArgs& a, const N2vListArgs& l, N2vLds& S) {
   const int lane = threadIdx.x & 63;
   const int64_t waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const bool tickets = a.big_count != nullptr;
@@ -1539,6 +1537,13 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void Node2VecListWaveKernel(con
     }
     if (!tickets) i += waves;
   }
+}
+
+template <bool PAR>
+__global__ __launch_bounds__(256, kWavesPerSimd) void Node2VecListWaveKernel(const WalkArgs a,
+                                                                             const N2vListArgs l) {
+  __shared__ N2vLds lds_all[4];
+  N2vListWaveLoop<PAR>(a, l, lds_all[threadIdx.x >> 6]);
 }
 
 // A step of the sharded walk is ONE launch over fetched rows, so its duration is its slowest
@@ -1593,6 +1598,40 @@ __global__ __launch_bounds__(64 * kN2vBigWaves) void N2vBigStepListKernel(const 
     const int64_t result = N2vBigStepBody(a, S, &phase, wv, lane, parent, i, 0, same);
     if (threadIdx.x == 0) l.out[i] = result;
   }
+}
+
+// Both queues in ONE launch (key 72, the default): workgroups of 16 waves first take the long rows
+// (the queue N2vListClassifyKernel filled), then their waves go on as 16 single waves over the
+// tickets of the other walkers - the long rows start first, and neither launch waits for the
+// other's last wave (one after the other: waves 2.1-2.4 ms + workgroups 0.95 ms a step).
+__global__ __launch_bounds__(64 * kN2vBigWaves, kWavesPerSimd) void N2vListMergedKernel(const WalkArgs a,
+                                                                                       const N2vListArgs l) {
+  constexpr size_t kWaveBytes = sizeof(N2vLds) * kN2vBigWaves;
+  constexpr size_t kBytes = sizeof(N2vBigLds) > kWaveBytes ? sizeof(N2vBigLds) : kWaveBytes;
+  __shared__ __align__(16) uint8_t smem[kBytes];
+  N2vBigLds& S = *reinterpret_cast<N2vBigLds*>(smem);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int32_t queued = a.big_count[0];
+  int phase = 0;
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) S.next = atomicAdd(a.big_count + 1, 1);
+    __syncthreads();
+    const int64_t qe = S.next;
+    if (qe >= queued) break;
+    const int64_t i = a.big_queue[qe];
+    const int64_t parent = l.parent_ids[i];
+    if (threadIdx.x == 0) {
+      N2vBuildListFetched(&S.seq.child, l.c_idx, l.c_ids, l.c_w, l.c_row[i]);
+      N2vBuildListFetched(&S.seq.parent, l.p_idx, l.p_ids, nullptr, l.p_row != nullptr ? l.p_row[i] : -1);
+    }
+    __syncthreads();
+    const int same = N2vSameFetchedBlock(S.seq.child, S.seq.parent) ? 1 : 0;
+    const int64_t result = N2vBigStepBody(a, S, &phase, wv, lane, parent, i, 0, same);
+    if (threadIdx.x == 0) l.out[i] = result;
+  }
+  __syncthreads();              // (the waves' lists lie over the workgroup's)
+  N2vListWaveLoop<true>(a, l, reinterpret_cast<N2vLds*>(smem)[wv]);
 }
 
 }  // namespace euler_gpu
@@ -1799,6 +1838,16 @@ int euler_gpu_node2vec_step(void* stream, uint64_t seed, uint32_t call_id, int64
       w.ticket_batch = c_entries < 32 * n ? 8 : c_entries < 256 * n ? 2 : 1;
       EG_HIP(hipMemsetAsync(w.big_count, 0, 16, (hipStream_t)stream));
       hipLaunchKernelGGL(N2vListClassifyKernel, dim3(GridFor(n, 256)), dim3(256), 0, (hipStream_t)stream, w, a);
+    }
+    if (big && g_n2v_list_merged.load() != 0) {
+      // 2 workgroups of 1 024 threads a CU; no more workgroups than the walkers need waves
+      int64_t wgs = (n + kN2vBigWaves - 1) / kN2vBigWaves;
+      if (wgs > 512) wgs = 512;
+      hipLaunchKernelGGL(N2vListMergedKernel, dim3((unsigned)wgs), dim3(64 * kN2vBigWaves), 0, (hipStream_t)stream, w, a);
+      EG_HIP(hipGetLastError());
+      EG_HIP(hipFreeAsync(flag, (hipStream_t)stream));
+      EG_HIP(hipFreeAsync(q, (hipStream_t)stream));
+      return EULER_GPU_OK;
     }
     hipLaunchKernelGGL(Node2VecListWaveKernel<true>, dim3(GridFor(n * 64, 256)), dim3(256), 0,
                        (hipStream_t)stream, w, a);

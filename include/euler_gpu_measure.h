@@ -150,7 +150,9 @@ extern "C" {
  *        has at least this many entries (65536; 0 = by the child row alone: a wave moves the
  *        parent cursor 64 entries a dependent step).  key 70: its wave kernel hands the walkers
  *        out by ticket; walkers whose child + parent rows hold at least this many entries first
- *        (0 = index order, the default).
+ *        (0 = index order, the default).  key 72: 1 (default) = the long rows' workgroups and the
+ *        other walkers' waves are ONE launch (a workgroup's 16 waves go on as single waves when the
+ *        long rows are done), 0 = two launches.
  * All settings produce identical results; the knobs exist for A/B measurements
  * and tests.  They are THREAD-LOCAL: a call changes the launches the calling host
  * thread enqueues afterwards and nobody else's (new threads start from the

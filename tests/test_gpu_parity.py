@@ -2316,10 +2316,13 @@ def test_node2vec_step_on_fetched_lists_wave_and_lane(EA, O, torch_cuda):
             # (mode 2 twice: rows of >= 65 536 / >= 200 entries by a workgroup of 16 waves each -
             # N2vBigStepListKernel, tuning key 69; this graph's rows average 300 entries, hubs thousands)
             # (key 71: walkers whose PARENT's row is long go to a workgroup as well)
-            for mode, big_at, par_at in ((2, 65536, 65536), (2, 200, 65536), (2, 4000, 150), (2, 65536, 0), (0, 65536, 65536)):
+            # (key 72: both queues in one launch - the default - or the waves' launch, then the workgroups')
+            for mode, big_at, par_at, merged in ((2, 65536, 65536, 1), (2, 200, 65536, 1), (2, 200, 65536, 0), (2, 4000, 150, 1),
+                                                 (2, 4000, 150, 0), (2, 65536, 0, 1), (0, 65536, 65536, 1)):
                 L.euler_gpu_set_tuning(7, mode)
                 L.euler_gpu_set_tuning(69, big_at)
                 L.euler_gpu_set_tuning(71, par_at)
+                L.euler_gpu_set_tuning(72, merged)
                 cur = parent = qt
                 p_row = p_idx = p_ids = None
                 cols = [qt]
@@ -2331,11 +2334,12 @@ def test_node2vec_step_on_fetched_lists_wave_and_lane(EA, O, torch_cuda):
                     parent, cur = cur, nxt
                     p_row, p_idx, p_ids = inv, idx, ids
                     cols.append(cur)
-                assert torch.equal(torch.stack(cols, 1), want), (p_, q_, mode, big_at, par_at)
+                assert torch.equal(torch.stack(cols, 1), want), (p_, q_, mode, big_at, par_at, merged)
     finally:
         L.euler_gpu_set_tuning(7, 2)
         L.euler_gpu_set_tuning(69, 65536)
         L.euler_gpu_set_tuning(71, 65536)
+        L.euler_gpu_set_tuning(72, 1)
 
 
 def test_node2vec_step_self_loop_rows_in_two_buffers(EA, O, torch_cuda):
@@ -2381,21 +2385,24 @@ def test_node2vec_step_self_loop_rows_in_two_buffers(EA, O, torch_cuda):
     try:
         for p_, q_ in ((0.25, 4.0), (3.0, 0.7)):
             want = O.node2vec_step_lists(9, 41, c_row, c_idx, c_ids, c_w, p_row, p_idx, p_ids, parent, p_, q_, -5)
-            for mode, big_at, mid_at, par_at in ((2, 65536, 0, 65536), (2, 2000, 0, 65536), (2, 2000, 1000, 0), (2, 65536, 128, 0),
-                                                 (2, 65536, 0, 60), (2, 4000, 100, 300), (0, 65536, 0, 65536)):
+            for mode, big_at, mid_at, par_at, merged in ((2, 65536, 0, 65536, 1), (2, 2000, 0, 65536, 1), (2, 2000, 0, 65536, 0),
+                                                         (2, 2000, 1000, 0, 1), (2, 65536, 128, 0, 0), (2, 65536, 0, 60, 1),
+                                                         (2, 4000, 100, 300, 1), (2, 4000, 100, 300, 0), (0, 65536, 0, 65536, 1)):
                 L.euler_gpu_set_tuning(7, mode)
                 L.euler_gpu_set_tuning(69, big_at)
                 L.euler_gpu_set_tuning(70, mid_at)
                 L.euler_gpu_set_tuning(71, par_at)
+                L.euler_gpu_set_tuning(72, merged)
                 got = ops.node2vec_step(9, 41, cu(c_row), cu(c_idx), cu(c_ids), cu(c_w), cu(p_row), cu(p_idx),
                                         cu(p_ids), cu(parent), p_, q_, -5)
-                assert np.array_equal(t2n(got), want), (p_, q_, mode, big_at, mid_at, par_at)
+                assert np.array_equal(t2n(got), want), (p_, q_, mode, big_at, mid_at, par_at, merged)
         assert n_w == len(lens) * 6
     finally:
         L.euler_gpu_set_tuning(7, 2)
         L.euler_gpu_set_tuning(69, 65536)
         L.euler_gpu_set_tuning(70, 0)
         L.euler_gpu_set_tuning(71, 65536)
+        L.euler_gpu_set_tuning(72, 1)
 
 
 @pytest.mark.parametrize("index_alone", [0, 1])
