@@ -758,13 +758,12 @@ int euler_gpu_sharded_node2vec_walk(const euler_gpu_graph* shard, const euler_gp
     const int64_t t1 = o_total > 0 ? o_total : 1;
     uint64_t* o_ids = (uint64_t*)sc.Get((size_t)t1 * 8);
     float* o_w = (float*)sc.Get((size_t)t1 * 4);
-    int32_t* o_t = (int32_t*)sc.Get((size_t)t1 * 4);
-    if (!o_ids || !o_w || !o_t) { (void)hipGetLastError(); return Fail(EULER_GPU_ENOMEM, "sharded_node2vec_walk: scratch"); }
+    if (!o_ids || !o_w) { (void)hipGetLastError(); return Fail(EULER_GPU_ENOMEM, "sharded_node2vec_walk: scratch"); }
     if (m_in > 0 && o_total > 0) {
-      rc = euler_gpu_get_full_neighbor(shard, stream, owned, m_in, et, k, o_idx, &o_total, o_ids, o_w, o_t);
+      // (BuildWeights does not read the edge types: not written - 0.56 GB a step on the metric graph)
+      rc = euler_gpu_get_full_neighbor(shard, stream, owned, m_in, et, k, o_idx, &o_total, o_ids, o_w, nullptr);
       if (rc != EULER_GPU_OK) return rc;
     }
-    sc.Release(o_t);                 // (BuildWeights does not read the edge types)
     // 4. the rows back to whoever asked: lengths, then ids and weights sized from them
     int32_t* c_idx = o_idx; uint64_t* c_ids = o_ids; float* c_w = o_w;
     int64_t c_entries = o_total;

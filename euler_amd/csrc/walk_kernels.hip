@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void FullNbFillKernel(
         const float pre = p == 0 ? 0.f : nw[p - 1];
         out_id[o + (p - b)] = nbr[p];
         out_w[o + (p - b)] = __fsub_rn(nw[p], pre);
-        out_t[o + (p - b)] = t;
+        if (out_t != nullptr) out_t[o + (p - b)] = t;
       }
       o += e - b;
     }
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void FullNbFillBalancedKernel(
           FullNbEntry(a, m, (int32_t)(e - begin), &p, &t);
           out_id[e] = nbr[p];
           out_w[e] = __fsub_rn(nw[p], p == 0 ? 0.f : nw[p - 1]);
-          out_t[e] = t;
+          if (out_t != nullptr) out_t[e] = t;
         }
         if (R0 == R1) break;            // the super window is done
         continue;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void FullNbFillBalancedKernel(
         const float* nw = a.g.prefix_w + m.row_ptr;
         out_id[e] = a.g.nbr[m.row_ptr + p];
         out_w[e] = __fsub_rn(nw[p], p == 0 ? 0.f : nw[p - 1]);
-        out_t[e] = t;
+        if (out_t != nullptr) out_t[e] = t;
       }
     }
   }

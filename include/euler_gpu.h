@@ -342,7 +342,8 @@ int euler_gpu_sample_n_with_types(const euler_gpu_graph* g, void* stream, uint64
  * euler::GetFullNeighbor (core/api/api.cc:208-221) -> Node::GetFullNeighbor
  * (core/graph/node.cc:175-197) in the FillNeighbor layout.  Two calls: first
  * with out_id_dev == NULL fills idx_dev [n,2] (int32 offsets) and *total_host
- * (synchronises the stream); the second call writes the values. */
+ * (synchronises the stream); the second call writes the values (out_t_dev may be
+ * NULL: the edge types are not written - the sharded node2vec walk does not read them). */
 int euler_gpu_get_full_neighbor(const euler_gpu_graph* g, void* stream,
                                 const uint64_t* ids_dev, int64_t n,
                                 const int32_t* edge_types_host, int32_t k,
