@@ -747,8 +747,17 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void Node2VecWaveKernel(const W
   const int64_t waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int64_t L = a.walk_len + 1;
   const int32_t s_end = a.step_end > 0 ? a.step_end : a.walk_len;
-  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < a.n;
-       i += waves) {
+  // a.walk_ticket != NULL: the walkers are handed out by ticket (a walk's cost varies with the rows it
+  // crosses far more than a step's) instead of every `waves`-th walker to a wave
+  int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  for (;; i += waves) {
+    if (a.walk_ticket != nullptr) {
+      unsigned long long t = 0;
+      if (lane == 0) t = atomicAdd(a.walk_ticket, 1ull);
+      i = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(t >> 32)) << 32) |
+                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)t));
+    }
+    if (i >= a.n) break;
     int64_t cur, parent;
     bool have_parent_nb;
     if (a.step_begin == 0) {

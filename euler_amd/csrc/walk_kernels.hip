@@ -479,6 +479,7 @@ std::atomic<int> g_n2v_list_mid{0};
 // key 71: ... and so do walkers whose PARENT's row has at least this many entries: a wave moves the parent cursor
 // 64 entries a (dependent) step - 9 000 steps = 6 ms on the 578 088-entry hub - a workgroup 1 024 (0 = by the child row alone)
 std::atomic<int> g_n2v_list_big_parent{65536};
+std::atomic<int> g_n2v_walk_tickets{1};    // key 73: the single-launch node2vec walk hands its walkers out by ticket
 std::atomic<int> g_n2v_list_merged{1};     // key 72: both queues in one launch (N2vListMergedKernel); 0 = two launches
 std::atomic<int> g_walk_path_ch{16};      // key 64: columns the sharded walk's path kernel parks in LDS at a time
 thread_local int g_walk_grid = 1024;      // key 39: workgroups of its per-step launches (0 = one per 256 walkers)
@@ -508,6 +509,7 @@ struct WalkArgs {
                           // queued as `mid` (from the queue's END downwards), [3] next ticket of the wave kernel
   int32_t mid_threshold;  // list step: child + parent entries from which a walker is handed out FIRST (0 = none)
   int32_t big_parent;     // list step: parent rows of at least this many entries also go to a workgroup (0 = none)
+  unsigned long long* walk_ticket;   // single-launch node2vec: the walkers' ticket counter (NULL = static assignment)
   int32_t ticket_batch;   // list step: walkers a wave takes per ticket (1 on long rows, 8 on rows of a few entries)
   // p (q) a power of two: w / p == w * inv_p in every bit (both are the correctly
   // rounded w / p); 0 = divide
@@ -2046,8 +2048,15 @@ int euler_gpu_random_walk(const euler_gpu_graph* g, void* stream, uint64_t seed,
       EG_HIP(hipGetLastError());
       EG_HIP(hipFreeAsync(q, st));
     } else if (g_n2v_wave >= 2) {
+      unsigned long long* ticket = nullptr;
+      if (g_n2v_walk_tickets.load() != 0 && n > 16384) {      // (fewer walkers than waves: one each)
+        EG_HIP(hipMallocAsync((void**)&ticket, 8, st));
+        EG_HIP(hipMemsetAsync(ticket, 0, 8, st));
+        a.walk_ticket = ticket;
+      }
       hipLaunchKernelGGL(Node2VecWaveKernel<true>, dim3(GridFor(n * 64, block)), dim3(block), 0,
                          st, a);
+      if (ticket != nullptr) EG_HIP(hipFreeAsync(ticket, st));
     } else if (g_n2v_wave != 0) {
       hipLaunchKernelGGL(Node2VecWaveKernel<false>, dim3(GridFor(n * 64, block)), dim3(block), 0,
                          st, a);

@@ -2342,6 +2342,33 @@ def test_node2vec_step_on_fetched_lists_wave_and_lane(EA, O, torch_cuda):
         L.euler_gpu_set_tuning(72, 1)
 
 
+def test_node2vec_walk_hands_walkers_out_by_ticket(EA, O, torch_cuda):
+    """More than 16 384 walkers: the one-launch node2vec walk hands its walkers out by ticket (tuning
+    key 73) instead of giving every 16 384th walker to a wave.  Which wave walks a walker does not
+    matter - the draws are keyed by the walker's index: == the static assignment == the oracle."""
+    torch = torch_cuda
+    from euler_amd import _lib
+    L = _lib.lib()
+    ph = EA.synth_params(91, 5000, 120000, n_types=2, weighted=True)
+    po = O.SynthParams()
+    for f, _ in po._fields_:
+        setattr(po, f, getattr(ph, f))
+    G, OG = EA.Graph.synthetic(ph), O.OracleGraph(O.synth_csr(po))
+    q = np.random.default_rng(5).integers(0, 5002, 40000).astype(np.int64)      # (0 and 5001: unknown nodes)
+    qt = torch.as_tensor(q).cuda()
+    et = [[0, 1], [1, 0], [0, 1], [1, 0]]
+    try:
+        G.set_seed(3)
+        outs = []
+        for tickets in (1, 0):
+            L.euler_gpu_set_tuning(73, tickets)
+            outs.append(G.random_walk(qt, et, 0.25, 4.0, 5001, call_id=11))
+        assert torch.equal(outs[0], outs[1])
+        assert np.array_equal(t2n(outs[0]), OG.random_walk(3, 11, q, et, len(et), 0.25, 4.0, 5001))
+    finally:
+        L.euler_gpu_set_tuning(73, 1)
+
+
 def test_node2vec_step_self_loop_rows_in_two_buffers(EA, O, torch_cuda):
     """A walker that took a self loop stands on its parent: on FETCHED rows the child list and the
     parent's list are then the same ids in two buffers (this step's rows, last step's rows), every

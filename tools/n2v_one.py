@@ -12,6 +12,9 @@ big = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
 W = int(sys.argv[3]) if len(sys.argv) > 3 else 100_000
 _lib.lib().euler_gpu_set_tuning(7, mode)
 _lib.lib().euler_gpu_set_tuning(25, big)
+import os
+for kv in filter(None, os.environ.get('N2V_KEYS', '').split(',')):      # e.g. N2V_KEYS=73=0
+    k, v = kv.split('='); _lib.check(_lib.lib().euler_gpu_set_tuning(int(k), int(v)))
 s = starts[:W].contiguous()
 import ctypes as C
 st = (C.c_uint64 * 8)()
