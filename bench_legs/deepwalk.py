@@ -145,7 +145,7 @@ def run_deepwalk(args, G=None, p_g=None, quiet=False):
                         G._h, C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(w2.data_ptr()),
                         W2, et_b, 1, L2, 0.25, 4.0, C.byref(b2_)))
                     n2v["roofline"] = {
-                        "kernel": "Node2VecListWaveKernel + FullNb* + front end (the whole call)", "bound": "hbm",
+                        "kernel": "N2vListMergedKernel + FullNb* + front end (the whole call)", "bound": "hbm",
                         "achieved": round(b2_.value / sec2 / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(b2_.value / sec2 / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
                         "algorithmic_bytes_per_launch": b2_.value, "avg_launch_ms": round(sec2 * 1e3, 3),
