@@ -135,9 +135,21 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void SampleNeighborTypedPivotKe
         }
       }
     }
-    a.out_id[s] = id;
-    a.out_w[s] = w;
-    a.out_t[s] = t;
+    if (a.packed != nullptr) {
+      // wire row of root r (k1_args.h: PackedWords): ids (2 words each) | weights | types | mask, pad
+      int32_t* prow = a.packed + r * (int64_t)PackedWords(a.count, a.packed_tcol);
+      *reinterpret_cast<uint64_t*>(prow + 2 * j) = id;
+      prow[2 * a.count + j] = __float_as_int(w);
+      if (a.packed_tcol) prow[3 * a.count + j] = t;
+      if (j == 0) {
+        prow[(3 + a.packed_tcol) * a.count] = valid ? 0 : 1;
+        prow[(3 + a.packed_tcol) * a.count + 1] = 0;
+      }
+    } else {
+      a.out_id[s] = id;
+      a.out_w[s] = w;
+      a.out_t[s] = t;
+    }
     if (j == 0 && a.out_row_mask != nullptr) a.out_row_mask[r] = valid ? 0 : 1;
   }
 }

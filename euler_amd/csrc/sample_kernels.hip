@@ -990,11 +990,17 @@ static bool K1CanMark(const euler_gpu_graph* g, int32_t k, int32_t count, int32_
          !tf_zero && layout == EULER_GPU_LAYOUT_TF && g->view.map_mode == 0;
 }
 
-// will LaunchK1 pick a pivot kernel (the only ones that write wire rows)?
+// will LaunchK1 pick a pivot kernel (the only ones that write wire rows)?  Single-type calls: the
+// pivot kernels; calls that draw a type per sample: SampleNeighborTypedPivotKernel (k1_variants.hip:
+// LaunchK1Variant takes it under exactly this condition) - the owners' pass of a typed sharded hop
+// wrote dense arrays and packed them in a second kernel (19 us of a 36-40 us pass) before.
 static bool K1WritesPacked(const euler_gpu_graph* g, int32_t k, int32_t layout) {
-  const bool single = k == 1 && g->view.monotone;
   const bool tf_zero = layout == EULER_GPU_LAYOUT_TF && g->view.has_zero_nbr != 0;
-  return (g_k1_variant == 5 || g_k1_variant == 6) && single && !tf_zero;
+  if (!g->view.monotone || tf_zero) return false;
+  if (k == 1) return g_k1_variant == 5 || g_k1_variant == 6;
+  if (g_k1_variant != 6 || g_k1_typed_pivot == 0) return false;
+  GraphView v;
+  return SamplingView(g, &v) == EULER_GPU_OK && HasBlockSearch(v);
 }
 
 // Hop chaining of a fanout (euler_gpu_sample_fanout holds launch_mu and has
