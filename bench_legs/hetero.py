@@ -155,15 +155,18 @@ def run_hetero(args, quiet=False):
             k1s.append({"listed_types": len(et), "ms": round(ms_, 4), "algorithmic_bytes": b_.value,
                         "frac": round(b_.value / ms_ / 1e6 / HBM_PEAK_GBS, 4)})
         tb = sum(x_["algorithmic_bytes"] for x_ in k1s)
-        tm = sum(x_["ms"] for x_ in k1s)
-        roof_s = {"kernel": "SampleNeighborKernel / SampleNeighborTypedPivotKernel (owners' pass of a typed "
-                            "sharded hop, packed wire rows)", "bound": "hbm",
+        # the step's owners' pass: the three sets as ONE launch writing wire rows
+        # (euler_gpu_sample_neighbor_sets_packed); the separate launches stay beside it
+        tm = _events(lambda: G.sample_neighbor_sets_packed(x_own, type_sets, CNT, N + 1, call_id=0), 10)
+        roof_s = {"kernel": "SampleNeighborSetsLdsKernel (owners' pass of the step's typed sharded hops, the "
+                            "three sets in one launch, packed wire rows)", "bound": "hbm",
                   "achieved": round(tb / tm / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                   "frac": round(tb / tm / 1e6 / HBM_PEAK_GBS, 4), "traffic": None,
-                  "algorithmic_bytes_per_launch": tb / len(k1s), "avg_launch_ms": round(tm / len(k1s), 4),
-                  "launches": k1s,
-                  "note": "rank 0's three typed launches of one step, each timed alone with HIP events over "
-                          "the distinct roots; the aggregation is the unsharded path's (replicas only)"}
+                  "algorithmic_bytes_per_launch": tb, "avg_launch_ms": round(tm, 4),
+                  "separate_launches": k1s,
+                  "note": "rank 0's owners' pass of one step, timed alone with HIP events over the distinct "
+                          "roots (separate_launches: one sample_neighbor_packed call per set, what the step "
+                          "made before); the aggregation is the unsharded path's (replicas only)"}
         cpu_s = None
         if rank == 0 and not args.no_cpu_baseline and not quiet:
             try:

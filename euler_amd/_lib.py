@@ -165,6 +165,8 @@ SIGNATURES = {
     "euler_gpu_sample_neighbor_packed": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp,
                                                    C.c_int64, i32p, C.c_int32, C.c_int32,
                                                    C.c_int64, vp]),
+    "euler_gpu_sample_neighbor_sets_packed": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp, C.c_int64, i32p,
+                                                        i32p, C.c_int32, C.c_int32, C.c_int64, vp]),
     "euler_gpu_dedup_split": (C.c_int, [vp, vp, C.c_int64, vp, C.c_int32, C.c_int32,
                                         C.c_int32, vp, C.c_int64, C.POINTER(C.c_int64),
                                         vp, vp]),

@@ -123,7 +123,7 @@ bool LaunchSampleNeighborSets(const euler_gpu_graph* g, hipStream_t stream, uint
                               uint32_t call_id, const uint64_t* roots, int64_t n,
                               const int32_t* edge_types, const int32_t* set_k, int32_t n_sets,
                               int32_t count, int64_t default_node, uint64_t* out_id, float* out_w,
-                              int32_t* out_t, int* rc_out);
+                              int32_t* out_t, int* rc_out, int32_t* packed = nullptr);
 
 }  // namespace euler_gpu
 

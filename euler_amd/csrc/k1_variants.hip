@@ -180,7 +180,34 @@ struct SampleSetsArgs {
   int32_t set_k[kMaxTypeSets];
   int32_t set_off[kMaxTypeSets];
   int32_t et[kMaxListedTypes];
+  // not null: wire rows (k1_args.h: PackedWords) instead of out_id / out_w / out_t - the owners' pass
+  // of a typed sharded hop; set s's rows begin packed_off[s] words into `packed` (without the type
+  // column when the set lists one type)
+  int32_t* packed;
+  int64_t packed_off[kMaxTypeSets];
 };
+
+// sample j of root r of set `set`: into the three arrays, or into the root's wire row (t < 0 = the row
+// has nothing to draw from: the row mask)
+__device__ __forceinline__ void SetsStore(const SampleSetsArgs& a, int32_t set, int64_t r, int32_t j,
+                                          uint64_t id, float w, int32_t t) {
+  if (a.packed != nullptr) {
+    const int32_t tcol = a.set_k[set] == 1 ? 0 : 1;
+    int32_t* prow = a.packed + a.packed_off[set] + r * (int64_t)PackedWords(a.count, tcol);
+    *reinterpret_cast<uint64_t*>(prow + 2 * j) = id;
+    prow[2 * a.count + j] = __float_as_int(w);
+    if (tcol) prow[3 * a.count + j] = t;
+    if (j == 0) {
+      prow[(3 + tcol) * a.count] = t < 0 ? 1 : 0;
+      prow[(3 + tcol) * a.count + 1] = 0;
+    }
+    return;
+  }
+  const int64_t s = ((int64_t)set * a.n + r) * a.count + j;
+  a.out_id[s] = id;
+  a.out_w[s] = w;
+  a.out_t[s] = t;
+}
 
 __global__ __launch_bounds__(256, 6) void SampleNeighborSetsKernel(const SampleSetsArgs a) {   // 80 VGPRs: nothing spilled
   const int64_t per_set = a.n * (int64_t)a.count;
@@ -246,9 +273,7 @@ __global__ __launch_bounds__(256, 6) void SampleNeighborSetsKernel(const SampleS
         }
       }
     }
-    a.out_id[s] = id;
-    a.out_w[s] = w;
-    a.out_t[s] = t;
+    SetsStore(a, set, r, j, id, w, t);
   }
 }
 
@@ -349,10 +374,7 @@ __global__ __launch_bounds__(256, WPS) void SampleNeighborSetsLdsKernel(const Sa
           sg.limit_begin = t == 0 ? 0.f : lim[t - 1];
           BlockPivotSample(a.g, sg, u_nb, &id, &w);
         }
-        const int64_t s = ((int64_t)set * a.n + r) * a.count + j;
-        a.out_id[s] = id;
-        a.out_w[s] = w;
-        a.out_t[s] = t;
+        SetsStore(a, set, r, j, id, w, t);
       }
     }
     __syncthreads();            // the records are rewritten by the next round
@@ -384,7 +406,7 @@ bool LaunchSampleNeighborSets(const euler_gpu_graph* g, hipStream_t stream, uint
                               uint32_t call_id, const uint64_t* roots, int64_t n,
                               const int32_t* edge_types, const int32_t* set_k, int32_t n_sets,
                               int32_t count, int64_t default_node, uint64_t* out_id, float* out_w,
-                              int32_t* out_t, int* rc_out) {
+                              int32_t* out_t, int* rc_out, int32_t* packed) {
   *rc_out = EULER_GPU_OK;
   if (g_k1_variant != 6 || g_k1_typed_pivot == 0 || !g->view.monotone || g->view.has_zero_nbr != 0 ||
       n_sets > kMaxTypeSets)
@@ -398,8 +420,12 @@ bool LaunchSampleNeighborSets(const euler_gpu_graph* g, hipStream_t stream, uint
   a.seed = seed; a.call_id = call_id; a.roots = roots; a.n = n; a.count = count;
   a.default_node = default_node; a.n_sets = n_sets;
   a.out_id = out_id; a.out_w = out_w; a.out_t = out_t;
+  a.packed = packed;
   int32_t off = 0;
+  int64_t poff = 0;
   for (int32_t s = 0; s < n_sets; ++s) {
+    a.packed_off[s] = poff;
+    poff += n * (int64_t)PackedWords(count, set_k[s] == 1 ? 0 : 1);
     a.set_k[s] = set_k[s]; a.set_off[s] = off;
     for (int32_t i = 0; i < set_k[s]; ++i) a.et[off + i] = edge_types[off + i];
     off += set_k[s];

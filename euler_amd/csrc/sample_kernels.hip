@@ -2046,6 +2046,53 @@ int euler_gpu_sample_neighbor_packed(const euler_gpu_graph* g, void* stream,
   return rc;
 }
 
+int euler_gpu_sample_neighbor_sets_packed(const euler_gpu_graph* g, void* stream, uint64_t seed,
+                                          uint32_t call_id, const uint64_t* roots_dev, int64_t n,
+                                          const int32_t* edge_types_host, const int32_t* set_k_host,
+                                          int32_t n_sets, int32_t count, int64_t default_node,
+                                          int32_t* packed_dev) {
+  if (!g) return Fail(EULER_GPU_ENOGRAPH, "sample_neighbor_sets_packed: null graph");
+  if (n < 0 || count <= 0 || n_sets < 0 || (n_sets > 0 && !set_k_host))
+    return Fail(EULER_GPU_EINVAL, "sample_neighbor_sets_packed: bad arguments");
+  if (n == 0 || n_sets == 0) return EULER_GPU_OK;
+  if (!roots_dev || !packed_dev) return Fail(EULER_GPU_EINVAL, "sample_neighbor_sets_packed: null buffer");
+  int32_t total_k = 0;
+  for (int32_t s = 0; s < n_sets; ++s) {
+    if (set_k_host[s] < 0 || set_k_host[s] > kMaxListedTypes)
+      return Fail(EULER_GPU_EINVAL, "sample_neighbor_sets_packed: bad set size");
+    total_k += set_k_host[s];
+  }
+  if (total_k > 0 && !edge_types_host)
+    return Fail(EULER_GPU_EINVAL, "sample_neighbor_sets_packed: null edge types");
+  if (n * (int64_t)count * n_sets >= ((int64_t)1 << 40))
+    return Fail(EULER_GPU_EINVAL, "sample_neighbor_sets_packed: too many samples");
+  // a set of ONE type must name a valid type (its rows travel without the type column)
+  {
+    int32_t off = 0;
+    for (int32_t s = 0; s < n_sets; ++s) {
+      if (set_k_host[s] == 1 && edge_types_host[off] < 0)
+        return Fail(EULER_GPU_EINVAL, "sample_neighbor_sets_packed: bad edge type");
+      off += set_k_host[s];
+    }
+  }
+  int rc = EULER_GPU_OK;
+  if (LaunchSampleNeighborSets(g, (hipStream_t)stream, seed, call_id, roots_dev, n, edge_types_host,
+                               set_k_host, n_sets, count, default_node, nullptr, nullptr, nullptr, &rc,
+                               packed_dev))
+    return rc;
+  // graphs / settings the one-launch kernel does not serve: the separate calls
+  int32_t off = 0;
+  int64_t poff = 0;
+  for (int32_t s = 0; s < n_sets && rc == EULER_GPU_OK; ++s) {
+    rc = euler_gpu_sample_neighbor_packed(g, stream, seed, call_id + (uint32_t)s, roots_dev, n,
+                                          edge_types_host + off, set_k_host[s], count, default_node,
+                                          packed_dev + poff);
+    off += set_k_host[s];
+    poff += n * (int64_t)PackedWords(count, set_k_host[s] == 1 ? 0 : 1);
+  }
+  return rc;
+}
+
 size_t euler_gpu_sample_fanout_workspace(int64_t n, const int32_t* counts_host,
                                          int32_t layers) {
   // one mask byte per root of every hop (16-byte aligned slices)

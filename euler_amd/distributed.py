@@ -131,6 +131,8 @@ class ShardedSampler:
         # local_sample_packed(owned, edge_types, count, default_node, call_id) ->
         # wire rows (sampling and packing in one kernel)
         self.local_sample_packed = None
+        # local_sample_sets_packed(owned ids, type_sets, count, default_node, call_id) -> wire rows per set
+        self.local_sample_sets_packed = None
         # two-phase front end: front_begin_fn(ids, partitions, shards, root_mask,
         # root_group) enqueues it and returns a token, front_end_fn(token) waits
         # for the bucket sizes -> (shard_off, shard_ids, pos)
@@ -389,9 +391,14 @@ class ShardedSampler:
         recv_counts = self._exchange_counts(send_counts, roots.device)
         owned = self._exchange(shard_ids, send_counts, recv_counts)
         outs = []
+        # (the owners' passes of all the sets as ONE launch where the shard has it)
+        all_rows = None
+        if self.local_sample_sets_packed is not None and len(type_sets) > 1:
+            all_rows = self.local_sample_sets_packed(owned, type_sets, count, default_node, call_id)
         for s, et in enumerate(type_sets):
             single_type = et[0] if len(et) == 1 else None
-            rows = self.local_sample_packed(owned, et, count, default_node, call_id + s)
+            rows = all_rows[s] if all_rows is not None else \
+                self.local_sample_packed(owned, et, count, default_node, call_id + s)
             outs.append(self.expand_fn(pos, self._exchange(rows, recv_counts, send_counts), count,
                                        single_type))
         return outs
@@ -970,6 +977,7 @@ def gpu_sharded_sampler(graph, partitions=None, group=None, dedup=True, dense_id
         S.pack_fn = ops.pack_rows
         if packed:
             S.local_sample_packed = graph.sample_neighbor_packed
+            S.local_sample_sets_packed = graph.sample_neighbor_sets_packed
     S.device = graph.device
     S.local_feature = graph.get_dense_feature
     S.row_gather_fn = lambda rows, pos: ops.gather(rows, pos.to(torch.int32))

@@ -422,6 +422,29 @@ class Graph:
                 _ptr(flat), n, et_p, k, int(count), int(default_node), _ptr(rows)))
         return rows
 
+    def sample_neighbor_sets_packed(self, nodes, type_sets, count, default_node=-1, call_id=None):
+        """sample_neighbor_packed for several edge-type sets over the same (distinct) ids in ONE
+        launch (euler_gpu_sample_neighbor_sets_packed): a list of wire-row tensors, one per set -
+        the rows of len(type_sets) sample_neighbor_packed calls with consecutive call ids (views
+        of one allocation)."""
+        flat = _as_i64_cuda(nodes, self.device).reshape(-1)
+        n, S = flat.numel(), len(type_sets)
+        ks = [len(ts) for ts in type_sets]
+        ks_a, ks_p, _ = _i32_array(ks)
+        et_a, et_p, _ = _i32_array([int(t) for ts in type_sets for t in ts])
+        words = [((3 if k == 1 else 4) * int(count) + 2 + 1) & ~1 for k in ks]
+        buf = torch.empty((n * sum(words),), dtype=torch.int32, device=self.device)
+        cid = self._take_call_ids(S, call_id)
+        with self._on_device():
+            check(lib().euler_gpu_sample_neighbor_sets_packed(
+                self._h, _stream(), self.seed, cid, _ptr(flat), n, et_p, ks_p, S, int(count),
+                int(default_node), _ptr(buf)))
+        out, off = [], 0
+        for w in words:
+            out.append(buf[off:off + n * w].view(n, w))
+            off += n * w
+        return out
+
     def sample_fanout(self, nodes, edge_types, counts, default_node=-1,
                       call_id=None):
         """tf_euler sample_fanout (euler_ops/neighbor_ops.py:122-158 over

@@ -276,6 +276,17 @@ int euler_gpu_sample_neighbor_packed(const euler_gpu_graph* g, void* stream,
                                      const int32_t* edge_types_host, int32_t k,
                                      int32_t count, int64_t default_node,
                                      int32_t* packed_dev);
+/* ... for several edge-type SETS over the same ids in ONE launch (euler_gpu_sample_neighbor_sets'
+ * kernel writing wire rows: the typed hops of a heterogeneous minibatch on a sharded graph).
+ * Set s draws with call_id + s and its n rows begin sum over s' < s of n * words(s') int32 words into
+ * packed_dev, words(s) = 4 * count + 2, or 3 * count + 2 padded to even for a set of ONE type (no
+ * type column) - the rows of n_sets euler_gpu_sample_neighbor_packed calls, bit for bit in every
+ * word euler_gpu_expand_packed reads.  Graphs the one-launch kernel does not serve take those calls. */
+int euler_gpu_sample_neighbor_sets_packed(const euler_gpu_graph* g, void* stream, uint64_t seed,
+                                          uint32_t call_id, const uint64_t* roots_dev, int64_t n,
+                                          const int32_t* edge_types_host, const int32_t* set_k_host,
+                                          int32_t n_sets, int32_t count, int64_t default_node,
+                                          int32_t* packed_dev);
 
 /* TF SampleFanout (tf_euler/kernels/sample_fanout_op.cc:32-148): `layers` hops
  * chained on device; hop h uses call_id + h, edge_types_host[h*k .. h*k+k) and

@@ -54,7 +54,8 @@ def test_bench_sharded_workloads_on_one_rank(torch_cuda):
     line = _run(small + ["--batch", "8192"])
     assert line["roofline"]["kernel"].startswith("SampleNeighborPivotKernel") and line["roofline"]["traffic"] is None
     line = _run(small + ["--batch", "8192", "--workload", "hetero"])
-    assert line["roofline"]["frac"] > 0 and len(line["roofline"]["launches"]) == 3
+    assert line["roofline"]["frac"] > 0 and len(line["roofline"]["separate_launches"]) == 3
+    assert line["roofline"]["kernel"].startswith("SampleNeighborSets")
     line = _run(small + ["--workload", "deepwalk"])
     assert line["roofline"]["frac"] > 0 and line["config"]["walk_stats"]["host_waits"] == 0   # (enqueued: key 63)
     assert line["config"]["parity_checked_steps"] == 64 * 40

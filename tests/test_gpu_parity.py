@@ -2342,6 +2342,48 @@ def test_node2vec_step_on_fetched_lists_wave_and_lane(EA, O, torch_cuda):
         L.euler_gpu_set_tuning(72, 1)
 
 
+def test_sample_neighbor_sets_packed_equals_the_separate_packed_calls(EA, O, torch_cuda):
+    """euler_gpu_sample_neighbor_sets_packed - the owners' passes of a heterogeneous minibatch's typed
+    hops as ONE launch writing wire rows: every word ops.expand_packed reads equals the rows of the
+    separate sample_neighbor_packed calls (one type: no type column; several: type draws), through
+    the kernel that stages the records in LDS, the plain one and the fallback to separate calls
+    (tuning keys 47 / 37), and the expanded rows == the oracle's SampleNeighbor per set."""
+    torch = torch_cuda
+    from euler_amd import _lib, ops
+    L = _lib.lib()
+    ph = EA.synth_params(17, 4000, 90000, n_types=5, weighted=True)
+    po = O.SynthParams()
+    for f, _ in po._fields_:
+        setattr(po, f, getattr(ph, f))
+    G, OG = EA.Graph.synthetic(ph), O.OracleGraph(O.synth_csr(po))
+    G.set_seed(23)
+    ids = np.concatenate([np.random.default_rng(8).permutation(4000)[:1500] + 1, [0, 4001]]).astype(np.int64)
+    it = torch.as_tensor(ids).cuda()
+    sets = [[2], [0, 3, 4], [0, 1, 2, 3, 4], [1]]
+    try:
+        for count in (10, 7):
+            want = [G.sample_neighbor_packed(it, et, count, 4001, call_id=50 + s) for s, et in enumerate(sets)]
+            for lds, typed in ((1, 1), (2, 1), (0, 1), (1, 0)):
+                L.euler_gpu_set_tuning(47, lds)
+                L.euler_gpu_set_tuning(37, typed)
+                got = G.sample_neighbor_sets_packed(it, sets, count, 4001, call_id=50)
+                for s, et in enumerate(sets):
+                    used = (3 if len(et) == 1 else 4) * count + 1          # ids | weights | [types] | mask
+                    assert got[s].shape == want[s].shape
+                    assert torch.equal(got[s][:, :used], want[s][:, :used]), (count, lds, typed, s)
+            L.euler_gpu_set_tuning(47, 1); L.euler_gpu_set_tuning(37, 1)
+            pos = torch.arange(len(ids), dtype=torch.int32, device="cuda")
+            for s, et in enumerate(sets):
+                g_ids, g_w, g_t, g_m = ops.expand_packed(pos, got[s], count, et[0] if len(et) == 1 else None)
+                o_ids, o_w, o_t = OG.sample_neighbor(23, 50 + s, ids, et, count, 4001)
+                assert np.array_equal(t2n(g_ids).reshape(-1), np.asarray(o_ids).reshape(-1)), (count, s)
+                assert np.array_equal(t2n(g_w).reshape(-1), np.asarray(o_w).reshape(-1))
+                assert np.array_equal(t2n(g_t).reshape(-1), np.asarray(o_t).reshape(-1))
+    finally:
+        L.euler_gpu_set_tuning(47, 1)
+        L.euler_gpu_set_tuning(37, 1)
+
+
 def test_node2vec_walk_hands_walkers_out_by_ticket(EA, O, torch_cuda):
     """More than 16 384 walkers: the one-launch node2vec walk hands its walkers out by ticket (tuning
     key 73) instead of giving every 16 384th walker to a wave.  Which wave walks a walker does not
