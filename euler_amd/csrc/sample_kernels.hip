@@ -16,7 +16,7 @@
 #include "fanout_plain.h"
 
 extern thread_local int g_feature_vec4;   // mp_kernels.hip
-namespace euler_gpu { extern thread_local int g_walk_collapse, g_walk_grid, g_walk_tail, g_walk_lean; extern std::atomic<int> g_walk_path_ch, g_n2v_list_big, g_n2v_list_mid, g_n2v_list_big_parent, g_n2v_list_merged, g_n2v_walk_tickets; }   // walk_kernels.hip
+namespace euler_gpu { extern thread_local int g_walk_collapse, g_walk_grid, g_walk_tail, g_walk_lean; extern std::atomic<int> g_walk_path_ch, g_n2v_list_big, g_n2v_list_big_parent, g_n2v_list_merged, g_n2v_walk_tickets; }   // walk_kernels.hip
 namespace euler_gpu { extern std::atomic<int> g_sharded_self_exchange, g_sharded_walk_enqueued, g_sharded_walk_tail, g_sharded_walk_split; }   // sharded.cc (process-wide)
 namespace euler_gpu { extern std::atomic<int> g_flow_fused; extern std::atomic<int> g_flow_rowpos; }              // dataflow_kernels.hip (key 60)
 namespace euler_gpu { extern std::atomic<int> g_blk_fail_next; }           // graph_build.hip (test hook)
@@ -1870,7 +1870,6 @@ int euler_gpu_set_tuning(int32_t key, int32_t value) {
   if (key == 60 && (value == 0 || value == 1)) { g_flow_fused.store(value); return EULER_GPU_OK; }
   if (key == 62 && value >= 0 && value <= 2) { g_flow_rowpos.store(value); return EULER_GPU_OK; }
   if (key == 69 && value >= 0) { g_n2v_list_big.store(value); return EULER_GPU_OK; }
-  if (key == 70 && value >= 0) { g_n2v_list_mid.store(value); return EULER_GPU_OK; }
   if (key == 71 && value >= 0) { g_n2v_list_big_parent.store(value); return EULER_GPU_OK; }
   if (key == 72 && (value == 0 || value == 1)) { g_n2v_list_merged.store(value); return EULER_GPU_OK; }
   if (key == 73 && (value == 0 || value == 1)) { g_n2v_walk_tickets.store(value); return EULER_GPU_OK; }

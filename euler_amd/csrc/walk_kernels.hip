@@ -472,10 +472,6 @@ thread_local int g_walk_tail = 9;         // key 43: first step of the merged wa
 // rank: 122 ms without, 123 / 111 / 114 / 99 / 99 / 104 ms with 4 096 / 8 192 / 32 768 / 65 536 /
 // 131 072 / 262 144.
 std::atomic<int> g_n2v_list_big{65536};
-// key 70: ... and walkers whose child + parent rows hold at least this many entries are handed out first
-// (the wave kernel takes tickets; 0 = index order, the default: 1 024 / 4 096 / 16 384 measured 97.7 / 95.8 /
-// 92.7 ms against 91.9 in index order before the self-loop fix, 75.5 against 71.1 after it)
-std::atomic<int> g_n2v_list_mid{0};
 // key 71: ... and so do walkers whose PARENT's row has at least this many entries: a wave moves the parent cursor
 // 64 entries a (dependent) step - 9 000 steps = 6 ms on the 578 088-entry hub - a workgroup 1 024 (0 = by the child row alone)
 std::atomic<int> g_n2v_list_big_parent{65536};
@@ -505,9 +501,8 @@ struct WalkArgs {
   int32_t step_end;
   int32_t big_threshold;
   int32_t* big_queue;     // walker indices
-  int32_t* big_count;     // [0] entries queued, [1] next entry to hand out; the list step also: [2] walkers
-                          // queued as `mid` (from the queue's END downwards), [3] next ticket of the wave kernel
-  int32_t mid_threshold;  // list step: child + parent entries from which a walker is handed out FIRST (0 = none)
+  int32_t* big_count;     // [0] entries queued, [1] next entry to hand out; the list step also: [3] next ticket of
+                          // the wave kernel
   int32_t big_parent;     // list step: parent rows of at least this many entries also go to a workgroup (0 = none)
   unsigned long long* walk_ticket;   // single-launch node2vec: the walkers' ticket counter (NULL = static assignment)
   int32_t ticket_batch;   // list step: walkers a wave takes per ticket (1 on long rows, 8 on rows of a few entries)
@@ -1475,24 +1470,22 @@ __device__ __forceinline__ void N2vListSizes(const N2vListArgs& l, int64_t i, in
   const int32_t pr = l.p_row != nullptr ? l.p_row[i] : -1;
   *np = pr >= 0 && l.p_idx != nullptr ? l.p_idx[2 * (int64_t)pr + 1] - l.p_idx[2 * (int64_t)pr] : 0;
 }
-// 0 = an ordinary walker, 1 = mid (handed out first), 2 = big (N2vBigStepListKernel's)
-__device__ __forceinline__ int N2vListClass(const WalkArgs& a, const N2vListArgs& l, int64_t i) {
+// does a workgroup take walker i (N2vBigStepListKernel / the first phase of N2vListMergedKernel)?
+__device__ __forceinline__ bool N2vListIsBig(const WalkArgs& a, const N2vListArgs& l, int64_t i) {
   int32_t nc, np;
   N2vListSizes(l, i, &nc, &np);
-  if (a.big_threshold > 0 && (nc >= a.big_threshold || (a.big_parent > 0 && nc > 0 && np >= a.big_parent))) return 2;
-  return a.mid_threshold > 0 && (int64_t)nc + np >= a.mid_threshold ? 1 : 0;
+  return a.big_threshold > 0 && (nc >= a.big_threshold || (a.big_parent > 0 && nc > 0 && np >= a.big_parent));
 }
 
-// The walkers are HANDED OUT (a.big_count != NULL): a wave takes a ticket per walker instead of
-// every 16 384th one - first the walkers N2vListClassifyKernel queued as `mid` (long rows: the
-// launch ends when its last wave does, so the long ones start first), then the others in index
-// order.  Which wave draws for a walker does not matter: the draw is keyed by the walker's index.
+// The walkers are HANDED OUT (a.big_count != NULL): a wave takes a ticket per walker, in index order,
+// instead of every 16 384th walker.  Which wave draws for a walker does not matter: the draw is keyed
+// by the walker's index.  (Long rows first - a second queue in front of the index order - measured
+// slower: 75.5 against 71.1 ms, profiles/r6_sharded_n2v_ab2.txt; removed.)
 template <bool PAR>
 __device__ __forceinline__ void N2vListWaveLoop(const WalkArgs& a, const N2vListArgs& l, N2vLds& S) {
   const int lane = threadIdx.x & 63;
   const int64_t waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const bool tickets = a.big_count != nullptr;
-  const int64_t n_mid = tickets ? a.big_count[2] : 0;
   int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   // (a.ticket_batch walkers per atomic: 100 000 single tickets on one address made the FIRST step -
   // rows of ten entries - 1.47 ms long where the static assignment took 0.31, 0.54 with 8 per ticket;
@@ -1507,14 +1500,9 @@ __device__ __forceinline__ void N2vListWaveLoop(const WalkArgs& a, const N2vList
         t_next = __builtin_amdgcn_readfirstlane(t0);
         t_end = t_next + batch;
       }
-      const int32_t t = t_next++;
-      if (t < n_mid) {
-        i = a.big_queue[l.n - 1 - t];
-      } else {
-        i = (int64_t)t - n_mid;
-        if (i >= l.n) break;
-        if (N2vListClass(a, l, i) != 0) continue;         // queued: a mid ticket / a workgroup takes it
-      }
+      i = t_next++;
+      if (i >= l.n) break;
+      if (N2vListIsBig(a, l, i)) continue;                // queued: a workgroup takes it
     } else if (i >= l.n) {
       break;
     }
@@ -1559,22 +1547,13 @@ __global__ __launch_bounds__(256) void N2vListClassifyKernel(const WalkArgs a, c
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t n64 = (l.n + 63) & ~(int64_t)63;          // (whole waves run the loop: ballot, shuffle)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n64; i += stride) {
-    const int cls = i < l.n ? N2vListClass(a, l, i) : 0;
-    const bool big = cls == 2, mid = cls == 1;
-    const unsigned long long m = __ballot(big), mm = __ballot(mid);
-    if (m != 0ull) {
-      int32_t base = 0;
-      if (lane == 0) base = atomicAdd(a.big_count, (int32_t)__popcll(m));
-      base = __shfl(base, 0);
-      if (big) a.big_queue[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)i;
-    }
-    if (mm != 0ull) {
-      // (the big walkers fill the queue from its start, the mid ones from its end: n slots hold both)
-      int32_t base = 0;
-      if (lane == 0) base = atomicAdd(a.big_count + 2, (int32_t)__popcll(mm));
-      base = __shfl(base, 0);
-      if (mid) a.big_queue[l.n - 1 - (base + __popcll(mm & ((1ull << lane) - 1ull)))] = (int32_t)i;
-    }
+    const bool big = i < l.n && N2vListIsBig(a, l, i);
+    const unsigned long long m = __ballot(big);
+    if (m == 0ull) continue;
+    int32_t base = 0;
+    if (lane == 0) base = atomicAdd(a.big_count, (int32_t)__popcll(m));
+    base = __shfl(base, 0);
+    if (big) a.big_queue[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)i;
   }
 }
 
@@ -1835,7 +1814,6 @@ int euler_gpu_node2vec_step(void* stream, uint64_t seed, uint32_t call_id, int64
       w.big_queue = q;
       w.big_count = (int32_t*)((uint8_t*)q + q_bytes);
       w.big_threshold = big_at;
-      w.mid_threshold = g_n2v_list_mid.load();
       w.big_parent = g_n2v_list_big_parent.load();
       w.ticket_batch = c_entries < 32 * n ? 8 : c_entries < 256 * n ? 2 : 1;
       EG_HIP(hipMemsetAsync(w.big_count, 0, 16, (hipStream_t)stream));

@@ -148,9 +148,7 @@ extern "C" {
  *        child rows of at least this many entries are drawn by a workgroup of 16 waves each
  *        (65536; 0 = every row by one wave).  key 71: ... and so are walkers whose PARENT's row
  *        has at least this many entries (65536; 0 = by the child row alone: a wave moves the
- *        parent cursor 64 entries a dependent step).  key 70: its wave kernel hands the walkers
- *        out by ticket; walkers whose child + parent rows hold at least this many entries first
- *        (0 = index order, the default).  key 72: 1 (default) = the long rows' workgroups and the
+ *        parent cursor 64 entries a dependent step).  Its waves take the walkers by ticket, in index order.  key 72: 1 (default) = the long rows' workgroups and the
  *        other walkers' waves are ONE launch (a workgroup's 16 waves go on as single waves when the
  *        long rows are done), 0 = two launches.  key 73: PROCESS-WIDE: 1 (default) = the node2vec
  *        walk of more than 16 384 walkers (one launch, a wave per walker) hands the walkers out by

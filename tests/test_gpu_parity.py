@@ -2417,8 +2417,8 @@ def test_node2vec_step_self_loop_rows_in_two_buffers(EA, O, torch_cuda):
     child is a common neighbour and the parent cursor moves on every entry.  The kernels
     recognise equal id sequences (N2vSameFetched / N2vSameFetchedBlock) instead of handing a
     long row to the sequential automaton; rows that differ in one entry (first / middle / last),
-    or in length, must not be taken for equal.  Wave kernel, workgroup kernel (key 69 = 2 000), the
-    ticket order with long rows first (key 70) and the lane-per-walker loop == the oracle's
+    or in length, must not be taken for equal.  Wave kernel, workgroup kernel (key 69 = 2 000, long
+    parent rows: key 71), one launch or two (key 72) and the lane-per-walker loop == the oracle's
     restatement of the client loop (random_walk_op.cc:83-168)."""
     torch = torch_cuda
     from euler_amd import _lib, ops
@@ -2454,22 +2454,20 @@ def test_node2vec_step_self_loop_rows_in_two_buffers(EA, O, torch_cuda):
     try:
         for p_, q_ in ((0.25, 4.0), (3.0, 0.7)):
             want = O.node2vec_step_lists(9, 41, c_row, c_idx, c_ids, c_w, p_row, p_idx, p_ids, parent, p_, q_, -5)
-            for mode, big_at, mid_at, par_at, merged in ((2, 65536, 0, 65536, 1), (2, 2000, 0, 65536, 1), (2, 2000, 0, 65536, 0),
-                                                         (2, 2000, 1000, 0, 1), (2, 65536, 128, 0, 0), (2, 65536, 0, 60, 1),
-                                                         (2, 4000, 100, 300, 1), (2, 4000, 100, 300, 0), (0, 65536, 0, 65536, 1)):
+            for mode, big_at, par_at, merged in ((2, 65536, 65536, 1), (2, 2000, 65536, 1), (2, 2000, 65536, 0),
+                                                 (2, 2000, 0, 1), (2, 65536, 0, 0), (2, 65536, 60, 1),
+                                                 (2, 4000, 300, 1), (2, 4000, 300, 0), (0, 65536, 65536, 1)):
                 L.euler_gpu_set_tuning(7, mode)
                 L.euler_gpu_set_tuning(69, big_at)
-                L.euler_gpu_set_tuning(70, mid_at)
                 L.euler_gpu_set_tuning(71, par_at)
                 L.euler_gpu_set_tuning(72, merged)
                 got = ops.node2vec_step(9, 41, cu(c_row), cu(c_idx), cu(c_ids), cu(c_w), cu(p_row), cu(p_idx),
                                         cu(p_ids), cu(parent), p_, q_, -5)
-                assert np.array_equal(t2n(got), want), (p_, q_, mode, big_at, mid_at, par_at, merged)
+                assert np.array_equal(t2n(got), want), (p_, q_, mode, big_at, par_at, merged)
         assert n_w == len(lens) * 6
     finally:
         L.euler_gpu_set_tuning(7, 2)
         L.euler_gpu_set_tuning(69, 65536)
-        L.euler_gpu_set_tuning(70, 0)
         L.euler_gpu_set_tuning(71, 65536)
         L.euler_gpu_set_tuning(72, 1)
 
