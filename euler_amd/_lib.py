@@ -145,6 +145,7 @@ SIGNATURES = {
     "euler_gpu_id_split": (C.c_int, [vp, vp, C.c_int64, C.c_int32, C.c_int32, i64p,
                                      vp, vp]),
     "euler_gpu_merge_rows": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, vp]),
+    "euler_gpu_inflate_idx": (C.c_int, [vp, vp, C.c_int64, vp]),
     "euler_gpu_sample_node_split": (C.c_int, [C.c_uint64, C.c_uint32, C.c_int32, f32p,
                                               C.c_int32, i32p]),
     "euler_gpu_time_sample_neighbor": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_int64,

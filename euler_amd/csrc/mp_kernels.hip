@@ -1157,6 +1157,75 @@ int euler_gpu_id_split(void* stream, const uint64_t* ids_dev, int64_t n,
 }
 
 // ------------------------------------------------------------------------
+// InflateIdx (tf_euler/kernels/inflate_idx_op.cc:34-66; op tf_euler/ops/util_ops.cc): for an
+// index vector whose values are exactly 0 .. U-1, out[i] = (entries with a smaller value) +
+// (entries with the same value before i) - the place of entry i after a STABLE sort by value.
+// The reference counts, prefix-sums and hands the places out in input order on one thread;
+// here: a stable radix sort of (value, position), then position perm[j] gets place j.  The
+// pass that writes the places also counts the value changes of the sorted keys, so the
+// reference's "expect input idx in [0,unique_cnt)" is one comparison on the host afterwards.
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void InflatePlaceKernel(const int32_t* __restrict__ keys,
+                                                          const uint32_t* __restrict__ perm,
+                                                          int64_t n, int32_t* __restrict__ out,
+                                                          int32_t* __restrict__ stat) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool edge = false;
+  if (j < n) {
+    const int32_t k = keys[j];
+    out[perm[j]] = (int32_t)j;
+    edge = j > 0 && keys[j - 1] != k;
+    if (j == 0) stat[1] = k;            // smallest value
+    if (j == n - 1) stat[2] = k;        // largest value
+  }
+  const uint64_t b = __ballot(edge);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(stat, __popcll(b));
+}
+
+int euler_gpu_inflate_idx(void* stream, const int32_t* idx_dev, int64_t n, int32_t* out_dev) {
+  if (n < 0 || (n > 0 && (!idx_dev || !out_dev)))
+    return Fail(EULER_GPU_EINVAL, "inflate_idx: bad arguments");
+  if (n == 0) return EULER_GPU_OK;
+  if (n >= (1LL << 31)) return Fail(EULER_GPU_EINVAL, "inflate_idx: n >= 2^31");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t un = (size_t)n;
+  size_t tmp_bytes = 0;
+  EG_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, idx_dev, (int32_t*)nullptr,
+                                            (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n,
+                                            0, 32, st));
+  const size_t head = (un * 12 + 16 + 255) & ~(size_t)255;     // sorted keys, positions in / out, stat
+  char* buf = nullptr;
+  EG_HIP(hipMallocAsync((void**)&buf, head + tmp_bytes + 16, st));
+  int32_t* keys_out = (int32_t*)buf;
+  uint32_t* vals_in = (uint32_t*)(keys_out + un);
+  uint32_t* vals_out = vals_in + un;
+  int32_t* stat = (int32_t*)(vals_out + un);
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  int rc = EULER_GPU_OK;
+  int32_t h[3] = {0, 0, 0};
+  do {
+    if (hipMemsetAsync(stat, 0, 16, st) != hipSuccess) { rc = EULER_GPU_EHIP; break; }
+    hipLaunchKernelGGL(IotaKernel, dim3(blocks), dim3(256), 0, st, vals_in, n);
+    if (hipcub::DeviceRadixSort::SortPairs(buf + head, tmp_bytes, idx_dev, keys_out, vals_in,
+                                           vals_out, (int)n, 0, 32, st) != hipSuccess) {
+      rc = EULER_GPU_EHIP; break;
+    }
+    hipLaunchKernelGGL(InflatePlaceKernel, dim3(blocks), dim3(256), 0, st, keys_out, vals_out, n,
+                       out_dev, stat);
+    if (hipGetLastError() != hipSuccess ||
+        hipMemcpyAsync(h, stat, 12, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+      rc = EULER_GPU_EHIP;
+  } while (false);
+  (void)hipFreeAsync(buf, st);
+  if (rc != EULER_GPU_OK) return Fail(rc, "inflate_idx: HIP call failed");
+  // h[0] + 1 distinct values, all of them >= h[1] and <= h[2]
+  if (h[1] < 0 || (int64_t)h[2] > (int64_t)h[0])
+    return Fail(EULER_GPU_EINVAL, "inflate_idx: expect input idx in [0,unique_cnt)");
+  return EULER_GPU_OK;
+}
+
+// ------------------------------------------------------------------------
 // Front end of a multi-GPU hop: the distinct ids of a batch, bucketed by owner
 // (ID_UNIQUE then ID_SPLIT, parser/compiler.cc:76-90 + core/kernels/
 // id_split_op.cc), plus for every input position the index of its id in the

@@ -452,6 +452,24 @@ def sparse_gather(gather_idx, indices, values, dense_shape):
     return out_indices, out_values, out_shape
 
 
+def inflate_idx(idx):
+    """tf_euler inflate_idx (tf_euler/kernels/inflate_idx_op.cc:34-66, op tf_euler/ops/util_ops.cc):
+    idx is a 1-D int32 vector whose values are exactly 0 .. U-1; out[i] = the place of entry i
+    after a stable sort by value.  A value outside [0, number of distinct values) raises
+    ValueError (the reference's InvalidArgument), a non-vector too."""
+    if idx.dim() != 1:
+        raise ValueError("InflateIdx expects a 1-D vector.")
+    idx = idx.to(torch.int32).contiguous()
+    _need_cuda(idx)
+    out = torch.empty_like(idx)
+    with _on(idx.device):
+        rc = lib().euler_gpu_inflate_idx(_stream(), _ptr(idx), idx.numel(), _ptr(out))
+    if rc == -1:
+        raise ValueError("InflateIdx: expect input idx in [0,unique_cnt).")
+    check(rc)
+    return out
+
+
 def id_split(ids, partitions, shards):
     """ID_SPLIT: stable bucket by owner(id) = (id % partitions) % shards.
     Returns (shard_off list[shards+1], shard_ids int64 [n], merge_idx int32 [n])."""

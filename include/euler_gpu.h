@@ -757,6 +757,12 @@ int euler_gpu_id_split(void* stream, const uint64_t* ids_dev, int64_t n,
                        int32_t partitions, int32_t shards,
                        int64_t* shard_off_host, uint64_t* shard_ids_dev,
                        int32_t* merge_idx_dev);
+/* InflateIdx (tf_euler/kernels/inflate_idx_op.cc:34-66, op InflateIdx of tf_euler/ops/util_ops.cc):
+ * idx_dev holds n values that are exactly 0 .. U-1 for some U; out_dev[i] = the place of entry
+ * i after a stable sort by value (entries with a smaller value + equal entries before i).
+ * EULER_GPU_EINVAL when a value lies outside [0, number of distinct values) - the reference's
+ * InvalidArgument; out_dev is then unspecified.  Synchronizes the stream (the check). */
+int euler_gpu_inflate_idx(void* stream, const int32_t* idx_dev, int64_t n, int32_t* out_dev);
 /* Split sizes between the ranks of one node without the GPU: an all-to-all of
  * up to 8 int64 per peer through a POSIX shared-memory mailbox.  Replaces what
  * the reference carries inside its per-shard gRPC requests / replies

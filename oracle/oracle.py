@@ -885,6 +885,26 @@ def sparse_gather(gather_idx, indices, values, dense_shape):
     return oi, ov, np.asarray([len(gi)] + [int(x) for x in dense_shape[1:]], np.int64)
 
 
+def inflate_idx(idx):
+    """tf_euler/kernels/inflate_idx_op.cc:34-66 restated: count per value, exclusive prefix sums,
+    places handed out in input order.  ValueError where the reference returns InvalidArgument."""
+    a = [int(x) for x in np.asarray(idx, np.int64).reshape(-1)]
+    unique_cnt = len(set(a))
+    sub_cnt = [0] * unique_cnt
+    for v in a:
+        if not 0 <= v < unique_cnt:
+            raise ValueError("expect input idx in [0,unique_cnt).")
+        sub_cnt[v] += 1
+    off = [0] * unique_cnt
+    for i in range(1, unique_cnt):
+        off[i] = off[i - 1] + sub_cnt[i - 1]
+    out = []
+    for v in a:
+        out.append(off[v])
+        off[v] += 1
+    return np.asarray(out, np.int32)
+
+
 def alias_init(weights):
     w = _arr(weights, np.float32)
     prob = np.zeros(len(w), np.float32)

@@ -419,6 +419,40 @@ def test_sparse_gather(EA, O, torch_cuda):
     assert util_ops.sparse_gather is ops.sparse_gather
 
 
+def test_inflate_idx(EA, O, torch_cuda):
+    """ops.inflate_idx == the restatement of tf_euler/kernels/inflate_idx_op.cc: the two
+    expectations of the reference's util_ops_test.py:44-58, random index vectors (every value
+    0 .. U-1 present, heavy repeats, one value only, 1M entries), an empty vector; values outside
+    [0, unique_cnt) - a hole, a negative - raise as the reference's InvalidArgument."""
+    torch = torch_cuda
+    ops = EA.ops
+    for idx, want in (([0, 2, 1, 3], [0, 2, 1, 3]), ([0, 1, 0, 2, 1], [0, 2, 1, 4, 3])):
+        assert O.inflate_idx(idx).tolist() == want
+        assert t2n(ops.inflate_idx(torch.as_tensor(idx, dtype=torch.int32).cuda())).tolist() == want
+    rng = np.random.default_rng(31)
+    for n, u in ((1, 1), (64, 64), (257, 5), (5000, 1), (70000, 999), (1 << 20, 40000)):
+        idx = np.concatenate([np.arange(u), rng.integers(0, u, n - u)]).astype(np.int32)
+        rng.shuffle(idx)
+        got = t2n(ops.inflate_idx(torch.as_tensor(idx).cuda()))
+        if n <= 70000:
+            assert np.array_equal(got, O.inflate_idx(idx))
+        # the place after a stable sort by value, whatever the size
+        order = np.argsort(idx, kind="stable")
+        want = np.empty(n, np.int32)
+        want[order] = np.arange(n, dtype=np.int32)
+        assert np.array_equal(got, want)
+    assert ops.inflate_idx(torch.zeros(0, dtype=torch.int32).cuda()).numel() == 0
+    for bad in ([0, 2], [1, 2, 3], [0, -1], [0, 1, 1, 5]):
+        with pytest.raises(ValueError):
+            O.inflate_idx(bad)
+        with pytest.raises(ValueError):
+            ops.inflate_idx(torch.as_tensor(bad, dtype=torch.int32).cuda())
+    with pytest.raises(ValueError):
+        ops.inflate_idx(torch.zeros((2, 2), dtype=torch.int32).cuda())
+    from euler_amd.euler_ops import util_ops
+    assert util_ops.inflate_idx is ops.inflate_idx
+
+
 def test_mp_gradients(EA, torch_cuda):
     """mp_ops_test.py:38-94 check compute_gradient_error < 1e-4; here the
     registered gradients are compared with torch's own autograd of the same

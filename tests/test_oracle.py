@@ -73,6 +73,19 @@ def test_unique_gather_reference_goldens(O):
         11, 12, 21, 22, 23, 11, 12, 31, 21, 22, 23]
 
 
+def test_inflate_idx_reference_expectations(O):
+    # tf_euler/python/euler_ops/util_ops_test.py:44-58; inflate_idx_op.cc:53-55 (range check)
+    assert O.inflate_idx([0, 2, 1, 3]).tolist() == [0, 2, 1, 3]
+    assert O.inflate_idx([0, 1, 0, 2, 1]).tolist() == [0, 2, 1, 4, 3]
+    assert O.inflate_idx([]).tolist() == []
+    for bad in ([0, 2], [0, -1]):
+        try:
+            O.inflate_idx(bad)
+        except ValueError:
+            continue
+        assert False, bad
+
+
 def test_full_neighbor_reference_goldens(O, fixture_csr):
     # tf_euler/python/euler_ops/neighbor_ops_test.py:46-75 and
     # GetFullNeighbor({1,2},{0,1}) -> [[2,4,3],[3,5]]
