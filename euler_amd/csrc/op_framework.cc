@@ -214,10 +214,84 @@ size_t SizeOfType(DataType t) {
   }
 }
 
+// ---- host memory of the tensors.  The reference's Tensor is malloc'ed (op_kernel.cc:92-105) and
+// its results travel by gRPC; here they travel by PCIe, and a copy from the device into PAGEABLE
+// memory is staged by the runtime at a few GB/s (the metric step's 577 MB of results: 130-140 ms
+// per query, tools/host_boundary_rate.py) where pinned memory takes the link's 55 GB/s.  Tensors of
+// kPinnedMin bytes or more therefore come from a process-wide cache of pinned blocks (power-of-two
+// size classes; hipHostMalloc itself costs ~0.1 ms per MB, so freed blocks are kept - up to
+// EULER_GPU_PINNED_POOL_MB, default 4096, per process); smaller ones, and every tensor of a process
+// without a GPU or with the pool set to 0, stay malloc'ed.  Ownership is unchanged: the Tensor owns
+// its memory and gives it back in its destructor.
+namespace {
+constexpr size_t kPinnedMin = (size_t)256 << 10;
+struct PinnedPool {
+  std::mutex mu;
+  std::unordered_map<void*, size_t> live;               // pinned blocks handed out -> class bytes
+  std::map<size_t, std::vector<void*>> free_blocks;      // class bytes -> cached blocks
+  size_t cached = 0, cap = 0;
+  bool off = false;
+  PinnedPool() {
+    const char* e = getenv("EULER_GPU_PINNED_POOL_MB");
+    const long mb = e ? atol(e) : 4096;
+    off = mb <= 0;
+    cap = off ? 0 : (size_t)mb << 20;
+  }
+};
+PinnedPool* Pool() {
+  static PinnedPool* p = new PinnedPool();     // leaked: see ThreadArena
+  return p;
+}
+void* HostAlloc(size_t bytes) {
+  PinnedPool* P = Pool();
+  if (bytes >= kPinnedMin && !P->off) {
+    size_t cls = kPinnedMin;
+    while (cls < bytes) cls <<= 1;
+    {
+      std::lock_guard<std::mutex> lk(P->mu);
+      auto it = P->free_blocks.find(cls);
+      if (it != P->free_blocks.end() && !it->second.empty()) {
+        void* p = it->second.back();
+        it->second.pop_back();
+        P->cached -= cls;
+        P->live[p] = cls;
+        return p;
+      }
+    }
+    void* p = nullptr;
+    if (hipHostMalloc(&p, cls, hipHostMallocPortable) == hipSuccess && p != nullptr) {
+      std::lock_guard<std::mutex> lk(P->mu);
+      P->live[p] = cls;
+      return p;
+    }
+    (void)hipGetLastError();                   // no device / no pinned memory left: pageable
+  }
+  return malloc(bytes);
+}
+void HostFree(void* p) {
+  if (p == nullptr) return;
+  PinnedPool* P = Pool();
+  size_t cls = 0;
+  bool keep = false;
+  {
+    std::lock_guard<std::mutex> lk(P->mu);
+    auto it = P->live.find(p);
+    if (it != P->live.end()) {
+      cls = it->second;
+      P->live.erase(it);
+      keep = P->cached + cls <= P->cap;
+      if (keep) { P->free_blocks[cls].push_back(p); P->cached += cls; }
+    }
+  }
+  if (cls == 0) free(p);
+  else if (!keep) (void)hipHostFree(p);
+}
+}  // namespace
+
 Tensor::Tensor(const TensorShape& shape, DataType type)
     : shape_(shape), type_(type),
-      data_(malloc(shape.NumElements() * SizeOfType(type) + 16)) {}
-Tensor::~Tensor() { free(data_); }
+      data_(HostAlloc(shape.NumElements() * SizeOfType(type) + 16)) {}
+Tensor::~Tensor() { HostFree(data_); }
 
 std::string OutputName(const NodeDef& node_def, int i) {
   return node_def.name + ":" + std::to_string(i);

@@ -80,6 +80,19 @@ def test_literal_tf_kernel_queries(EA, O, torch_cuda, pair):
         rc, got = run_query(L, gremlin, inputs, name, dt, len(want))
         assert rc == want.nbytes and np.array_equal(got, want), name
 
+    # ---- a query whose result tensors are large enough for the pinned host blocks (>= 256 KB,
+    # op_framework.cc: HostAlloc): run three times so that blocks come back from the cache
+    big = rng.choice(ids, 20000).astype(np.uint64)
+    binputs = [("nodes", K_UINT64, big), ("edge_types", K_INT32, et), ("nb_count", K_INT32, [count])]
+    _, _rid, _rw, _rt = OG.sample_neighbor_core(91, 0, big, et, count)
+    for _ in range(3):
+        L.euler_query_set_seed(91)
+        rc, got_ids = run_query(L, gremlin, binputs, "nb:1", np.uint64, len(big) * count)
+        assert rc == len(big) * count * 8 and np.array_equal(got_ids, _rid)
+        L.euler_query_set_seed(91)
+        rc, got_w = run_query(L, gremlin, binputs, "nb:2", np.float32, len(big) * count)
+        assert np.array_equal(got_w, _rw)
+
     # ---- tf_euler/kernels/sample_fanout_op.cc:37-42, counts [4, 3]
     counts = [4, 3]
     ss = "v(nodes)"
