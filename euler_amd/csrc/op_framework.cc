@@ -132,6 +132,10 @@ class OpScope {
     dirty_ = true;
     return Check(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, arena_->stream), "copy to host");
   }
+  // whatever the scope's state: nothing of this op is in flight afterwards
+  void Drain() {
+    if (arena_ != nullptr && arena_->stream != nullptr) (void)hipStreamSynchronize(arena_->stream);
+  }
   bool Sync() {
     if (!ok_) return false;
     const bool r = Check(hipStreamSynchronize(arena_->stream), "stream sync");
@@ -446,10 +450,12 @@ class GpuSampleNeighborOp : public OpKernel {
             edge_types.data(), (int32_t)edge_types.size(), count, EULER_GPU_LAYOUT_CORE, 0,
             d_oid, d_ow, d_ot, d_mask)))
       OP_FAIL(sc, "API_SAMPLE_NB");
-    std::vector<int32_t> idx((size_t)n * 2);
-    std::vector<uint8_t> mask((size_t)n, 0);
+    std::vector<int32_t> idx;
+    std::vector<uint8_t> mask;
     int64_t out_total = total;
     if (post && n > 0) {
+      idx.resize((size_t)n * 2);
+      mask.assign((size_t)n, 0);
       // rows with samples: [i * count, (i + 1) * count); rows without: empty, so that
       // order_by / limit leave them alone; the device post-process repacks in place
       if (!sc.Download(mask.data(), d_mask, (size_t)n) || !sc.Sync()) OP_FAIL(sc, "API_SAMPLE_NB");
@@ -536,13 +542,16 @@ class GpuSampleNeighborOp : public OpKernel {
       LogError("Allocate output tensor failed!");
       return;
     }
+    // the copies first, the row offsets while they are in flight
+    const bool queued = sc.Download(oid->Raw<uint64_t>(), d_oid, (size_t)total * 8) &&
+                        sc.Download(ow->Raw<float>(), d_ow, (size_t)total * 4) &&
+                        sc.Download(ot->Raw<int32_t>(), d_ot, (size_t)total * 4);
     for (int64_t i = 0; i < n; ++i) {
       t_idx->Raw<int32_t>()[2 * i] = (int32_t)(i * count);
       t_idx->Raw<int32_t>()[2 * i + 1] = (int32_t)((i + 1) * count);
     }
-    if (!sc.Download(oid->Raw<uint64_t>(), d_oid, (size_t)total * 8) ||
-        !sc.Download(ow->Raw<float>(), d_ow, (size_t)total * 4) ||
-        !sc.Download(ot->Raw<int32_t>(), d_ot, (size_t)total * 4) || !sc.Sync()) {
+    if (!queued || !sc.Sync()) {
+      sc.Drain();            // a copy may still be writing into the tensors
       for (int i = 0; i < 4; ++i) ctx->Deallocate(OutputName(nd, i));
       OP_FAIL(sc, "API_SAMPLE_NB");
     }

@@ -53,10 +53,10 @@ def main():
             rc = L.euler_query_run(gremlin.encode(), 5, c_names, c_dts, c_cnt, c_ptr, b"nb_0:0",
                                    res.ctypes.data_as(C.c_void_p), C.c_int64(res.nbytes))
             assert rc == res.nbytes, rc
-        for _ in range(3):
+        for _ in range(16):           # 8 proxy threads, each with its own stream and staging arena
             q()
         ts = []
-        for _ in range(7):
+        for _ in range(15):
             t0 = time.perf_counter(); q(); ts.append(time.perf_counter() - t0)
         ts.sort()
         out["query_shim_B%d" % B] = {"ms": round(ts[len(ts) // 2] * 1e3, 3), "min_ms": round(ts[0] * 1e3, 3),
