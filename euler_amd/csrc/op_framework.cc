@@ -248,7 +248,9 @@ PinnedPool* Pool() {
 }
 void* HostAlloc(size_t bytes) {
   PinnedPool* P = Pool();
-  if (bytes >= kPinnedMin && !P->off) {
+  bool off;
+  { std::lock_guard<std::mutex> lk(P->mu); off = P->off; }
+  if (bytes >= kPinnedMin && !off) {
     size_t cls = kPinnedMin;
     while (cls < bytes) cls <<= 1;
     {
@@ -269,6 +271,10 @@ void* HostAlloc(size_t bytes) {
       return p;
     }
     (void)hipGetLastError();                   // no device / no pinned memory left: pageable
+    {
+      std::lock_guard<std::mutex> lk(P->mu);
+      if (P->live.empty() && P->cached == 0) P->off = true;   // never worked here: do not ask again
+    }
   }
   return malloc(bytes);
 }
