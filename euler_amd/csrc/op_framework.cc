@@ -222,8 +222,8 @@ size_t SizeOfType(DataType t) {
 // its results travel by gRPC; here they travel by PCIe, and a copy from the device into PAGEABLE
 // memory is staged by the runtime at a few GB/s (the metric step's 577 MB of results: 130-140 ms
 // per query, tools/host_boundary_rate.py) where pinned memory takes the link's 55 GB/s.  Tensors of
-// kPinnedMin bytes or more therefore come from a process-wide cache of pinned blocks (power-of-two
-// size classes; hipHostMalloc itself costs ~0.1 ms per MB, so freed blocks are kept - up to
+// kPinnedMin bytes or more therefore come from a process-wide cache of pinned blocks (four size
+// classes per octave; hipHostMalloc itself costs ~0.1 ms per MB, so freed blocks are kept - up to
 // EULER_GPU_PINNED_POOL_MB, default 4096, per process); smaller ones, and every tensor of a process
 // without a GPU or with the pool set to 0, stay malloc'ed.  Ownership is unchanged: the Tensor owns
 // its memory and gives it back in its destructor.
@@ -251,8 +251,10 @@ void* HostAlloc(size_t bytes) {
   bool off;
   { std::lock_guard<std::mutex> lk(P->mu); off = P->off; }
   if (bytes >= kPinnedMin && !off) {
-    size_t cls = kPinnedMin;
-    while (cls < bytes) cls <<= 1;
+    // size classes: four per octave (at most 25 % of a block unused)
+    size_t q = kPinnedMin >> 2;
+    while ((q << 3) < bytes) q <<= 1;
+    const size_t cls = (bytes + q - 1) / q * q;
     {
       std::lock_guard<std::mutex> lk(P->mu);
       auto it = P->free_blocks.find(cls);
