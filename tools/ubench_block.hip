@@ -191,7 +191,14 @@ int main(int argc, char** argv) {
   // optional argument: GiB of index to draw the random lines from (default 16)
   const uint64_t bytes = (uint64_t)(argc > 1 ? atoll(argv[1]) : 16) << 30;
   uint32_t* buf; uint32_t* sink;
-  CK(hipMalloc(&buf, bytes));
+  // UB_CONTIG=1: physically contiguous device memory (hipDeviceMallocContiguous) - do larger
+  // page-table fragments widen the translation reach?
+  if (getenv("UB_CONTIG") && atoi(getenv("UB_CONTIG"))) {
+    CK(hipExtMallocWithFlags((void**)&buf, bytes, hipDeviceMallocContiguous));
+    printf("# buffer: hipExtMallocWithFlags(hipDeviceMallocContiguous)\n");
+  } else {
+    CK(hipMalloc(&buf, bytes));
+  }
   CK(hipMalloc(&sink, 256 * 32 * 64 * 4));
   hipLaunchKernelGGL(Fill, dim3(4096), dim3(256), 0, 0, buf, bytes / 4);
   CK(hipDeviceSynchronize());
