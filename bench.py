@@ -45,6 +45,7 @@ from bench_legs.deepwalk import *                                         # noqa
 from bench_legs.fanout_legs import *                                      # noqa: E402,F401,F403
 from bench_legs.sage import *                                             # noqa: E402,F401,F403
 from bench_legs.nodes import *                                            # noqa: E402,F401,F403
+from bench_legs.host_boundary import run_host_boundary_leg                # noqa: E402
 
 
 def parse():
@@ -163,6 +164,10 @@ def secondary_legs(args, G, p_g):
         sec.update(run_node_legs(args, G, p_g))
     except Exception as e:
         sec["sample_node"] = {"error": repr(e)}
+    try:
+        sec["host_boundary"] = run_host_boundary_leg(args, G, p_g)
+    except Exception as e:
+        sec["host_boundary"] = {"error": repr(e)}
     try:
         sec["products"] = run_products_leg(args)
     except Exception as e:
