@@ -799,6 +799,11 @@ def main():
                                    "max": round(max(rep_secs) / args.steps * 1e3, 4), "repeats": len(rep_secs)},
             "parity_checked_edges": checked,
         }
+        hb = (secondary or {}).get("host_boundary")
+        if isinstance(hb, dict) and "value" in hb:
+            # PCIe-inclusive (host tensors on both sides of euler::Query): NOT the headline
+            line["host_boundary"] = {"value": hb["value"], "unit": hb["unit"], "ms_per_step": hb["ms_per_step"],
+                                     "link_only_ms_per_step": hb["device_step_plus_copy_to_pinned"]["ms_per_step"]}
         _emit(line)
     _teardown(sharded or world > 1)
 
