@@ -206,3 +206,43 @@ def test_api_sample_nb_post_process(EA, O, torch_cuda, pair):
         assert np.array_equal(oid[:o], np.array(w_id, np.uint64))
         assert np.array_equal(ow[:o], np.array(w_w, np.float32))
         assert np.array_equal(ot[:o], np.array(w_t, np.int32))
+
+
+def test_eight_queries_in_flight(EA, O, torch_cuda, pair):
+    """The reference's client keeps 8 queries in flight (client/query_proxy.cc:205-210): 8 caller threads
+    run `outV` queries (no draws, so the answers do not depend on the order the calls are numbered in)
+    whose result tensors are large enough for the pinned host blocks - concurrent proxy threads, staging
+    arenas and block cache; every answer == the oracle's."""
+    import threading
+    from euler_amd import _lib
+    L = _lib.lib()
+    G, OG, ids, rng = pair
+    L.euler_query_set_graph(G._h)
+    try:
+        et = np.array([0, 1, 2], np.int32)
+        sets = [rng.choice(ids, 30000 + 1000 * k).astype(np.uint64) for k in range(8)]
+        want = [OG.get_full_neighbor(s, [0, 1, 2]) for s in sets]
+        errors = []
+
+        def worker(k):
+            try:
+                for _ in range(6):
+                    inputs = [("nodes", K_UINT64, sets[k]), ("edge_types", K_INT32, et)]
+                    rc, nb_ids = run_query(L, "v(nodes).outV(edge_types).as(nb)", inputs, "nb:1", np.uint64,
+                                           len(want[k][1]) + 8)
+                    if rc != len(want[k][1]) * 8 or not np.array_equal(nb_ids, want[k][1]):
+                        errors.append((k, "ids", rc))
+                    rc, nb_w = run_query(L, "v(nodes).outV(edge_types).as(nb)", inputs, "nb:2", np.float32,
+                                         len(want[k][2]) + 8)
+                    if not np.array_equal(nb_w, want[k][2]):
+                        errors.append((k, "weights", rc))
+            except Exception as e:        # noqa: BLE001
+                errors.append((k, repr(e)))
+        ts = [threading.Thread(target=worker, args=(k,)) for k in range(8)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errors, errors[:3]
+    finally:
+        L.euler_query_set_graph(None)
