@@ -228,7 +228,7 @@ size_t SizeOfType(DataType t) {
 // without a GPU or with the pool set to 0, stay malloc'ed.  Ownership is unchanged: the Tensor owns
 // its memory and gives it back in its destructor.
 namespace {
-constexpr size_t kPinnedMin = (size_t)256 << 10;
+constexpr size_t kPinnedMin = (size_t)16 << 10;
 struct PinnedPool {
   std::mutex mu;
   std::unordered_map<void*, size_t> live;               // pinned blocks handed out -> class bytes

@@ -80,7 +80,7 @@ def test_literal_tf_kernel_queries(EA, O, torch_cuda, pair):
         rc, got = run_query(L, gremlin, inputs, name, dt, len(want))
         assert rc == want.nbytes and np.array_equal(got, want), name
 
-    # ---- a query whose result tensors are large enough for the pinned host blocks (>= 256 KB,
+    # ---- a query whose result tensors are large enough for the pinned host blocks (>= 16 KB,
     # op_framework.cc: HostAlloc): run three times so that blocks come back from the cache
     big = rng.choice(ids, 20000).astype(np.uint64)
     binputs = [("nodes", K_UINT64, big), ("edge_types", K_INT32, et), ("nb_count", K_INT32, [count])]

@@ -61,6 +61,26 @@ def main():
         ts.sort()
         out["query_shim_B%d" % B] = {"ms": round(ts[len(ts) // 2] * 1e3, 3), "min_ms": round(ts[0] * 1e3, 3),
                                      "edges_per_s": edges / ts[len(ts) // 2]}
+        # ---- (1b) eight caller threads keep queries in flight (the reference's client pool,
+        # client/query_proxy.cc:205-210): aggregate rate of the boundary
+        import threading
+        per = 24 if B <= 4096 else 6
+        bufs = [np.zeros(B * 2, np.int32) for _ in range(8)]
+
+        def worker(k):
+            for _ in range(per):
+                rc = L.euler_query_run(gremlin.encode(), 5, c_names, c_dts, c_cnt, c_ptr, b"nb_0:0",
+                                       bufs[k].ctypes.data_as(C.c_void_p), C.c_int64(bufs[k].nbytes))
+                assert rc == bufs[k].nbytes, rc
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(8)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        el = time.perf_counter() - t0
+        out["query_shim_8_in_flight_B%d" % B] = {"queries": 8 * per, "ms_per_query": round(el / (8 * per) * 1e3, 4),
+                                                 "edges_per_s": edges * 8 * per / el}
         # ---- (2) device step + outputs copied to pinned host memory
         dev_roots = torch.as_tensor(roots.astype(np.int64)).cuda()
         host = None
