@@ -246,3 +246,19 @@ def test_eight_queries_in_flight(EA, O, torch_cuda, pair):
         assert not errors, errors[:3]
     finally:
         L.euler_query_set_graph(None)
+
+
+def test_cpp_query_clients_example(torch_cuda):
+    """examples/cpp/query_clients: a C++ client of include/euler_query.h (AllocInput, RunAsyncGremlin,
+    GetResult on the chain sample_fanout_op.cc builds) with four caller threads; every query returns its
+    nb_1:1 tensor (the program exits 2 otherwise)."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "examples", "cpp", "query_clients")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(exe)])
+    out = subprocess.run([exe, "200000", "256", "4", "20"], check=True, capture_output=True, text=True,
+                         timeout=300).stdout
+    lines = [l for l in out.strip().splitlines() if "sampled edges/s" in l]
+    assert len(lines) == 2 and lines[0].startswith("callers 1 ") and lines[1].startswith("callers 4 "), out
