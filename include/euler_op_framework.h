@@ -60,6 +60,10 @@ class TensorShape {
   std::vector<size_t> dims_;
 };
 
+// Host tensor (core/framework/tensor.h).  The memory is the tensor's own, released by its destructor; tensors of
+// 16 KB or more are PINNED host blocks from a process-wide cache (the results of a GPU op arrive by PCIe: pageable
+// memory is staged by the runtime at a tenth of the link's rate).  EULER_GPU_PINNED_POOL_MB (default 4096) caps the
+// blocks the cache keeps; 0 = plain malloc like the reference (op_kernel.cc:92-105).
 class Tensor {
  public:
   Tensor(const TensorShape& shape, DataType type);
